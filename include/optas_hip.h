@@ -1,0 +1,165 @@
+/*
+ * optas_hip.h -- C ABI of liboptas_hip.so, the MI355X (gfx950) batched NLP solver backend that drops
+ * in behind optas.solver.Solver (reference: optas/solver.py:61-314, IPOPT path :321-419).
+ *
+ * The reference has no native boundary at all: Solver._solve() (solver.py:386-398) calls CasADi's SWIG
+ * object which interprets SX tapes and runs IPOPT/MUMPS on one problem instance.  This header is the
+ * boundary a maintainer binds with ctypes: plain pointers and sizes, int return
+ * codes, no C++ exceptions, no torch types.  Each entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *   - all floating point data is IEEE double (CasADi DM/SX are double; solver.py:76,79);
+ *   - host-facing arrays use the reference layouts: x[b][.] is SXContainer.vec() order
+ *     (sx_container.py:83-89), i.e. for the figure-eight family x = [vec(Q ndof x T); vec(dQ ndof x (T-1))],
+ *     x[ndof*t + j] = q_j(t); p[b][.] is parameters.vec() order (qc for the figure-eight family);
+ *   - the caller owns every buffer it passes; the library only borrows it for the duration of the call;
+ *     device scratch is owned by the handle;
+ *   - a handle is bound to the HIP device that was current in oh_create and to one HIP stream; it is
+ *     not thread-safe; use one handle per GPU (one process per GPU);
+ *   - return value 0 = OH_OK; otherwise oh_last_error() describes the failure (thread-local string).
+ */
+#ifndef OPTAS_HIP_H
+#define OPTAS_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OH_MAX_CHAIN 16 /* actuated joints on one root->link chain */
+#define OH_MAX_T 128    /* horizon knots */
+
+enum {
+  OH_OK = 0,
+  OH_ERR_INVALID = 1,  /* bad argument / descriptor */
+  OH_ERR_HIP = 2,      /* HIP runtime error (no device, OOM, launch failure) */
+  OH_ERR_STATE = 3     /* call order (e.g. solve before set_constants) */
+};
+
+/* per-instance solver status written to status[b] (Solver.did_solve(), solver.py:407-412: status==0) */
+enum {
+  OH_STATUS_CONVERGED = 0,
+  OH_STATUS_MAX_ITER = 1,
+  OH_STATUS_NUMERICAL = 2
+};
+
+/* problem families that have been lowered to kernels */
+enum {
+  /* no optimisation problem: the handle only serves oh_fk_jac* (any ndof <= OH_MAX_CHAIN);
+     T, dt, weights and local_path of the descriptor are ignored */
+  OH_PROBLEM_KINEMATICS = 0,
+  /* example/figure_eight_plan.py:16-113: joint position/velocity trajectory of one
+     serial chain; a = [qc-q0; 0-dq0; Euler integration]; h = quat_c - quat(q_t);
+     f = w_path*sum||path_t - p(q_t)||^2 + w_vel*sum||dQ||^2, path_t = p(qc) + R(qc) local_path[t]. */
+  OH_PROBLEM_FIGURE_EIGHT = 1
+};
+
+enum {
+  OH_HESSIAN_GAUSS_NEWTON = 0, /* 2 w Jp^T Jp */
+  OH_HESSIAN_EXACT = 1         /* + exact curvature of tracking cost and of the orientation constraint */
+};
+
+/*
+ * Kinematic constants of one root->link chain with fixed joints folded into the next actuated joint
+ * (what RobotModel.get_global_link_transform, models.py:826-868, multiplies joint by joint):
+ *   T <- T * [R0_k p0_k] * Rot(axis_k, q[qidx_k])   (revolute/continuous, jtype 0)
+ *   T <- T * [R0_k p0_k] * Trans(axis_k * q[qidx_k]) (prismatic, jtype 1)
+ *   T_link = T * [R_tool p_tool]
+ * quat0_k / quat_tool are the same fixed rotations as xyzw quaternions accumulated with the
+ * reference's own product (models.py:1049-1088, spatialmath.py:298-349) so that oh_fk_jac reproduces the
+ * reference's quaternion *including its sign*.  This block (sizeof(oh_chain) bytes, < 2 KB) is what is
+ * broadcast once over RCCL/xGMI in multi-GPU runs.
+ */
+typedef struct oh_chain {
+  int ndof;    /* actuated joints of the robot model = rows of q per knot (RobotModel.ndof, models.py:414) */
+  int n_chain; /* actuated joints on this chain, in chain order */
+  int jtype[OH_MAX_CHAIN];
+  int qidx[OH_MAX_CHAIN]; /* actuated-joint index (models.py:661-667) */
+  double R0[OH_MAX_CHAIN][9]; /* row-major */
+  double p0[OH_MAX_CHAIN][3];
+  double axis[OH_MAX_CHAIN][3]; /* unit (models.py:653-659) */
+  double quat0[OH_MAX_CHAIN][4];
+  double R_tool[9];
+  double p_tool[3];
+  double quat_tool[4];
+} oh_chain;
+
+typedef struct oh_problem_desc {
+  int kind;     /* OH_PROBLEM_* */
+  int T;        /* knots (OptimizationBuilder(T=...), builder.py:14-42) */
+  int ndof;     /* must equal chain.ndof */
+  double dt;    /* Euler step of integrate_model_states (builder.py:419-469) */
+  double w_path; /* 1000.0 in figure_eight_plan.py:99 */
+  double w_vel;  /* 0.01   in figure_eight_plan.py:103 */
+  const double* local_path; /* T x 3 row-major, path in the end-effector frame at qc (:90-96) */
+  int lock_orientation;     /* 1: h = quat_c - quat(q_t) rows present (:105-107) */
+  /* solver options (the reference passes an options dict to nlpsol, solver.py:333,382) */
+  int max_iter;       /* <=0: default 200 */
+  double tol;         /* KKT stationarity (inf-norm of the reduced gradient); <=0: default 1e-6 */
+  double tol_feas;    /* constraint violation; <=0: default 1e-9 */
+  int hessian;        /* OH_HESSIAN_* */
+  double mu0;         /* initial Levenberg-Marquardt damping; <0: default */
+} oh_problem_desc;
+
+typedef struct oh_handle oh_handle;
+
+/* Replaces Solver.__init__ + CasADiSolver.setup (solver.py:64-88,333-384): allocates the handle,
+   creates its stream.  The descriptor (and local_path) is copied. */
+int oh_create(const oh_problem_desc* desc, oh_handle** out);
+
+/* Kinematic constants from host memory / from device memory (the latter after an RCCL broadcast). */
+int oh_set_constants(oh_handle* h, const oh_chain* chain);
+int oh_set_constants_device(oh_handle* h, const void* d_chain, size_t nbytes);
+
+/* Replaces B sequential calls of Solver.reset_initial_seed + reset_parameters + _solve
+   (solver.py:103-116,386-398).  Host buffers:
+     x0 [B][nx], p [B][np]  in;  x [B][nx], f [B], kkt [B][3] = (stationarity, feasibility,
+     complementarity), iters [B], status [B] out (any output pointer may be NULL).
+   nx = ndof*T + ndof*(T-1), np = ndof for OH_PROBLEM_FIGURE_EIGHT. */
+int oh_solve(oh_handle* h, int B, const double* x0, const double* p, double* x, double* f, double* kkt,
+             int* iters, int* status);
+
+/* Same with buffers already resident in HBM (what bench.py times).  Synchronous on return. */
+int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt,
+                    void* d_iters, void* d_status);
+
+/* Multipliers of the last oh_solve/oh_solve_device in the reference's form: lam_h [B][4*T] for the rows
+   h = quat_c - quat(q_t) (signed mu = lam+ - lam- of the (h,-h) pair, optimization.py:47-51). Host buffer. */
+int oh_get_multipliers(oh_handle* h, int B, double* lam_h);
+
+/* Replaces RobotModel.get_global_link_{position,quaternion,geometric_jacobian}_function(link, n=N)
+   (models.py:935-947,1090-1106,1266-1281): q [N][ndof] -> pose [N][7] = (p xyz, quat xyzw),
+   J [N][6][ndof] row-major (rows 0-2 linear, 3-5 angular; models.py:1239,1246).  pose or J may be NULL. */
+int oh_fk_jac(oh_handle* h, int N, const double* q, double* pose, double* J);
+int oh_fk_jac_device(oh_handle* h, int N, const void* d_q, void* d_pose, void* d_J);
+
+/* Structure-of-arrays variant used inside the solver and for roofline measurement:
+   q [ndof][N], pose [7][N], J [6*ndof][N] (unit index fastest => fully coalesced). */
+int oh_fk_jac_soa_device(oh_handle* h, int N, const void* d_q, void* d_pose, void* d_J);
+
+/* Timing of the last oh_solve*: HIP-event milliseconds accumulated per kernel on the handle's stream.
+   out[0]=eval kernel total ms, out[1]=eval launches, out[2]=step kernel total ms, out[3]=step launches,
+   out[4]=whole solve ms, out[5]=SQP iterations launched (pairs).  Enable with oh_set_profiling(h,1). */
+int oh_set_profiling(oh_handle* h, int enable);
+int oh_get_timing(oh_handle* h, double* out6);
+
+/* Thin device-memory helpers so a ctypes host needs no other GPU runtime binding. */
+int oh_device_count(int* n);
+int oh_device_malloc(void** ptr, size_t nbytes);
+int oh_device_free(void* ptr);
+int oh_memcpy_h2d(void* dst, const void* src, size_t nbytes);
+int oh_memcpy_d2h(void* dst, const void* src, size_t nbytes);
+int oh_device_synchronize(void);
+/* HIP-event timing of an arbitrary region on the handle's stream (for bench.py's roofline object). */
+int oh_event_timer_start(oh_handle* h);
+int oh_event_timer_stop(oh_handle* h, double* ms);
+
+const char* oh_last_error(void);
+const char* oh_version(void);
+void oh_destroy(oh_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPTAS_HIP_H */

@@ -1,0 +1,22 @@
+"""optas_amd -- MI355X-native batched NLP solver backend behind the optas.solver.Solver interface.
+
+Host side: plain Python + ctypes over liboptas_hip.so (hand-written HIP for gfx950).  No torch.
+"""
+from .spatialmath import *  # noqa: F401,F403  (the reference re-exports its spatialmath, optas/__init__.py:3)
+from .models import RobotModel, TaskModel, Model, JointTypeNotSupported  # noqa: F401
+from . import _lib  # noqa: F401
+
+import numpy as np
+
+
+def deg2rad(x):
+    """optas/__init__.py:10-17."""
+    return (np.pi / 180.0) * np.asarray(x, dtype=np.float64)
+
+
+def rad2deg(x):
+    """optas/__init__.py:20-27."""
+    return (180.0 / np.pi) * np.asarray(x, dtype=np.float64)
+
+
+__version__ = "0.1.0"

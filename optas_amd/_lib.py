@@ -1,0 +1,193 @@
+"""ctypes binding of liboptas_hip.so (include/optas_hip.h).  No torch, no numpy-side compute.
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``optas_amd.build``.  There is no CPU
+fallback: if the shared object is missing, or no HIP device is present, every compute entry point
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+OH_MAX_CHAIN = 16
+OH_MAX_T = 128
+
+OH_OK = 0
+OH_STATUS_CONVERGED, OH_STATUS_MAX_ITER, OH_STATUS_NUMERICAL = 0, 1, 2
+OH_PROBLEM_KINEMATICS = 0
+OH_PROBLEM_FIGURE_EIGHT = 1
+OH_HESSIAN_GAUSS_NEWTON, OH_HESSIAN_EXACT = 0, 1
+
+
+class oh_chain(C.Structure):
+    _fields_ = [
+        ("ndof", C.c_int),
+        ("n_chain", C.c_int),
+        ("jtype", C.c_int * OH_MAX_CHAIN),
+        ("qidx", C.c_int * OH_MAX_CHAIN),
+        ("R0", (C.c_double * 9) * OH_MAX_CHAIN),
+        ("p0", (C.c_double * 3) * OH_MAX_CHAIN),
+        ("axis", (C.c_double * 3) * OH_MAX_CHAIN),
+        ("quat0", (C.c_double * 4) * OH_MAX_CHAIN),
+        ("R_tool", C.c_double * 9),
+        ("p_tool", C.c_double * 3),
+        ("quat_tool", C.c_double * 4),
+    ]
+
+
+class oh_problem_desc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int),
+        ("T", C.c_int),
+        ("ndof", C.c_int),
+        ("dt", C.c_double),
+        ("w_path", C.c_double),
+        ("w_vel", C.c_double),
+        ("local_path", C.POINTER(C.c_double)),
+        ("lock_orientation", C.c_int),
+        ("max_iter", C.c_int),
+        ("tol", C.c_double),
+        ("tol_feas", C.c_double),
+        ("hessian", C.c_int),
+        ("mu0", C.c_double),
+    ]
+
+
+class OptasHipError(RuntimeError):
+    pass
+
+
+_LIB: Optional[C.CDLL] = None
+
+# every symbol include/optas_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "oh_create",
+    "oh_set_constants",
+    "oh_set_constants_device",
+    "oh_solve",
+    "oh_solve_device",
+    "oh_get_multipliers",
+    "oh_fk_jac",
+    "oh_fk_jac_device",
+    "oh_fk_jac_soa_device",
+    "oh_set_profiling",
+    "oh_get_timing",
+    "oh_device_count",
+    "oh_device_malloc",
+    "oh_device_free",
+    "oh_memcpy_h2d",
+    "oh_memcpy_d2h",
+    "oh_device_synchronize",
+    "oh_event_timer_start",
+    "oh_event_timer_stop",
+    "oh_last_error",
+    "oh_version",
+    "oh_destroy",
+]
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "liboptas_hip.so")
+
+
+def load() -> C.CDLL:
+    """Load liboptas_hip.so (raises if it has not been built -- there is no fallback path)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise OptasHipError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). optas_amd has no CPU fallback."
+        )
+    lib = C.CDLL(path)
+    vp, i, dp, ip = C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)
+    lib.oh_create.argtypes = [C.POINTER(oh_problem_desc), C.POINTER(vp)]
+    lib.oh_set_constants.argtypes = [vp, C.POINTER(oh_chain)]
+    lib.oh_set_constants_device.argtypes = [vp, vp, C.c_size_t]
+    lib.oh_solve.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
+    lib.oh_solve_device.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
+    lib.oh_get_multipliers.argtypes = [vp, i, vp]
+    lib.oh_fk_jac.argtypes = [vp, i, vp, vp, vp]
+    lib.oh_fk_jac_device.argtypes = [vp, i, vp, vp, vp]
+    lib.oh_fk_jac_soa_device.argtypes = [vp, i, vp, vp, vp]
+    lib.oh_set_profiling.argtypes = [vp, i]
+    lib.oh_get_timing.argtypes = [vp, dp]
+    lib.oh_device_count.argtypes = [ip]
+    lib.oh_device_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    lib.oh_device_free.argtypes = [vp]
+    lib.oh_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+    lib.oh_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+    lib.oh_device_synchronize.argtypes = []
+    lib.oh_event_timer_start.argtypes = [vp]
+    lib.oh_event_timer_stop.argtypes = [vp, dp]
+    lib.oh_last_error.restype = C.c_char_p
+    lib.oh_version.restype = C.c_char_p
+    lib.oh_destroy.argtypes = [vp]
+    lib.oh_destroy.restype = None
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("oh_last_error", "oh_version", "oh_destroy"):
+            fn.restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != OH_OK:
+        msg = load().oh_last_error().decode("utf-8", "replace")
+        raise OptasHipError(f"{what}: {msg} (code {rc})" if what else f"{msg} (code {rc})")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().oh_device_count(C.byref(n))
+    return n.value if rc == OH_OK else 0
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def as_f64(a, shape=None) -> np.ndarray:
+    out = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        out = out.reshape(shape)
+    return out
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned by Python (used by bench.py to keep inputs resident)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(load().oh_device_malloc(C.byref(p), self.nbytes), "oh_device_malloc")
+        self.ptr = p
+
+    def upload(self, a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        check(load().oh_memcpy_h2d(self.ptr, _ptr(a), a.nbytes), "oh_memcpy_h2d")
+        return self
+
+    def download(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(load().oh_memcpy_d2h(_ptr(out), self.ptr, out.nbytes), "oh_memcpy_d2h")
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            load().oh_device_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,151 @@
+"""Thin object wrapper over the liboptas_hip handle for one lowered problem (ctypes, numpy buffers).
+
+``HIPSolver`` (optas_amd/solver.py) is the user-facing, reference-shaped class; this is the piece
+that owns the ``oh_handle`` and moves arrays across the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class BatchResult:
+    x: np.ndarray  # (B, nx) reference layout
+    f: np.ndarray  # (B,)
+    kkt: np.ndarray  # (B, 3) stationarity, feasibility, complementarity
+    iters: np.ndarray  # (B,)
+    status: np.ndarray  # (B,)
+
+
+class FigureEightBackend:
+    """OH_PROBLEM_FIGURE_EIGHT handle."""
+
+    def __init__(
+        self,
+        chain: _lib.oh_chain,
+        T: int,
+        dt: float,
+        local_path: np.ndarray,
+        w_path: float = 1000.0,
+        w_vel: float = 0.01,
+        max_iter: int = 200,
+        tol: float = 1e-6,
+        tol_feas: float = 1e-9,
+        hessian: int = _lib.OH_HESSIAN_GAUSS_NEWTON,
+        mu0: float = 0.0,
+    ):
+        lib = _lib.load()
+        self.T, self.ndof = int(T), int(chain.ndof)
+        self.nx = self.ndof * self.T + self.ndof * (self.T - 1)
+        self.np_ = self.ndof
+        lp = _lib.as_f64(local_path, (self.T, 3))
+        self._lp = lp  # keep alive during oh_create
+        desc = _lib.oh_problem_desc(
+            kind=_lib.OH_PROBLEM_FIGURE_EIGHT,
+            T=self.T,
+            ndof=self.ndof,
+            dt=float(dt),
+            w_path=float(w_path),
+            w_vel=float(w_vel),
+            local_path=lp.ctypes.data_as(C.POINTER(C.c_double)),
+            lock_orientation=1,
+            max_iter=int(max_iter),
+            tol=float(tol),
+            tol_feas=float(tol_feas),
+            hessian=int(hessian),
+            mu0=float(mu0),
+        )
+        self._h = C.c_void_p()
+        _lib.check(lib.oh_create(C.byref(desc), C.byref(self._h)), "oh_create")
+        _lib.check(lib.oh_set_constants(self._h, C.byref(chain)), "oh_set_constants")
+        self.chain = chain
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    def set_constants_device(self, dptr: int, nbytes: int) -> None:
+        _lib.check(_lib.load().oh_set_constants_device(self._h, C.c_void_p(dptr), nbytes), "oh_set_constants_device")
+
+    def solve(self, x0: np.ndarray, p: np.ndarray) -> BatchResult:
+        lib = _lib.load()
+        x0 = _lib.as_f64(x0)
+        p = _lib.as_f64(p)
+        if x0.ndim == 1:
+            x0 = x0.reshape(1, -1)
+        if p.ndim == 1:
+            p = p.reshape(1, -1)
+        B = x0.shape[0]
+        assert x0.shape == (B, self.nx), f"x0 must be (B, {self.nx})"
+        assert p.shape == (B, self.np_), f"p must be (B, {self.np_})"
+        x = np.empty((B, self.nx))
+        f = np.empty(B)
+        kkt = np.empty((B, 3))
+        iters = np.empty(B, dtype=np.int32)
+        status = np.empty(B, dtype=np.int32)
+        _lib.check(
+            lib.oh_solve(self._h, B, _lib._ptr(x0), _lib._ptr(p), _lib._ptr(x), _lib._ptr(f), _lib._ptr(kkt), _lib._ptr(iters), _lib._ptr(status)),
+            "oh_solve",
+        )
+        return BatchResult(x, f, kkt, iters, status)
+
+    def solve_device(self, B: int, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status) -> None:
+        """All arguments are _lib.DeviceBuffer (or None for optional outputs)."""
+        g = lambda b: None if b is None else b.ptr
+        _lib.check(
+            _lib.load().oh_solve_device(self._h, int(B), g(d_x0), g(d_p), g(d_x), g(d_f), g(d_kkt), g(d_iters), g(d_status)),
+            "oh_solve_device",
+        )
+
+    def multipliers(self, B: int) -> np.ndarray:
+        lam = np.empty((B, 4 * self.T))
+        _lib.check(_lib.load().oh_get_multipliers(self._h, int(B), _lib._ptr(lam)), "oh_get_multipliers")
+        return lam
+
+    def set_profiling(self, on: bool) -> None:
+        _lib.check(_lib.load().oh_set_profiling(self._h, 1 if on else 0), "oh_set_profiling")
+
+    def timing(self) -> dict:
+        out = (C.c_double * 6)()
+        _lib.check(_lib.load().oh_get_timing(self._h, out), "oh_get_timing")
+        return {
+            "eval_ms": out[0],
+            "eval_launches": int(out[1]),
+            "step_ms": out[2],
+            "step_launches": int(out[3]),
+            "solve_ms": out[4],
+            "iterations_launched": int(out[5]),
+        }
+
+    def fk_jac_soa_device(self, n: int, d_q, d_pose, d_J) -> None:
+        g = lambda b: None if b is None else b.ptr
+        _lib.check(_lib.load().oh_fk_jac_soa_device(self._h, int(n), g(d_q), g(d_pose), g(d_J)), "oh_fk_jac_soa_device")
+
+    def fk_jac_device(self, n: int, d_q, d_pose, d_J) -> None:
+        g = lambda b: None if b is None else b.ptr
+        _lib.check(_lib.load().oh_fk_jac_device(self._h, int(n), g(d_q), g(d_pose), g(d_J)), "oh_fk_jac_device")
+
+    def event_timer_start(self) -> None:
+        _lib.check(_lib.load().oh_event_timer_start(self._h), "oh_event_timer_start")
+
+    def event_timer_stop(self) -> float:
+        ms = C.c_double(0.0)
+        _lib.check(_lib.load().oh_event_timer_stop(self._h, C.byref(ms)), "oh_event_timer_stop")
+        return ms.value
+
+    def close(self) -> None:
+        if self._h:
+            _lib.load().oh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,494 @@
+// C ABI of liboptas_hip.so (see include/optas_hip.h).  Host-side orchestration only: buffer
+// ownership, the SQP launch loop (eval kernel + Riccati/step kernel per iteration), HIP-event timing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "oh_kernels.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      return fail(OH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+    }                                                                                                  \
+  } while (0)
+
+struct oh_handle {
+  oh_problem_desc desc;
+  std::vector<double> local_path;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evt0 = nullptr, evt1 = nullptr;
+  bool have_chain = false;
+  oh_chain chain_host;
+  oh_chain* d_chain = nullptr;
+  double* d_local_path = nullptr;
+  // solver buffers
+  int cap_B = 0;
+  FigBuffers D{};
+  FigParams P{};
+  void* pool = nullptr;
+  size_t pool_bytes = 0;
+  int last_B = 0;
+  // staging for the host-buffer entry points
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_events;
+  double timing[6] = {0, 0, 0, 0, 0, 0};
+  int* h_flag = nullptr;  // pinned
+};
+
+extern "C" const char* oh_last_error(void) { return g_err.c_str(); }
+extern "C" const char* oh_version(void) { return "optas_hip 0.1 (gfx950)"; }
+
+extern "C" int oh_device_count(int* n) {
+  if (!n) return fail(OH_ERR_INVALID, "oh_device_count: null");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *n = 0;
+    return fail(OH_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *n = c;
+  return OH_OK;
+}
+extern "C" int oh_device_malloc(void** ptr, size_t nbytes) {
+  if (!ptr) return fail(OH_ERR_INVALID, "oh_device_malloc: null");
+  HIPCHK(hipMalloc(ptr, nbytes ? nbytes : 8));
+  return OH_OK;
+}
+extern "C" int oh_device_free(void* ptr) {
+  HIPCHK(hipFree(ptr));
+  return OH_OK;
+}
+extern "C" int oh_memcpy_h2d(void* dst, const void* src, size_t nbytes) {
+  HIPCHK(hipMemcpy(dst, src, nbytes, hipMemcpyHostToDevice));
+  return OH_OK;
+}
+extern "C" int oh_memcpy_d2h(void* dst, const void* src, size_t nbytes) {
+  HIPCHK(hipMemcpy(dst, src, nbytes, hipMemcpyDeviceToHost));
+  return OH_OK;
+}
+extern "C" int oh_device_synchronize(void) {
+  HIPCHK(hipDeviceSynchronize());
+  return OH_OK;
+}
+
+extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
+  if (!desc || !out) return fail(OH_ERR_INVALID, "oh_create: null argument");
+  *out = nullptr;
+  if (desc->kind != OH_PROBLEM_FIGURE_EIGHT && desc->kind != OH_PROBLEM_KINEMATICS)
+    return fail(OH_ERR_INVALID, "oh_create: unknown problem kind");
+  if (desc->kind == OH_PROBLEM_KINEMATICS) {
+    if (desc->ndof < 1 || desc->ndof > OH_MAX_CHAIN) return fail(OH_ERR_INVALID, "oh_create: ndof must be in [1, OH_MAX_CHAIN]");
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1)
+      return fail(OH_ERR_HIP, "oh_create: no HIP device available (this library has no CPU path)");
+    oh_handle* hk = new oh_handle();
+    hk->desc = *desc;
+    hk->desc.local_path = nullptr;
+    hipGetDevice(&hk->device);
+    if (hipStreamCreate(&hk->stream) != hipSuccess || hipEventCreate(&hk->ev0) != hipSuccess ||
+        hipEventCreate(&hk->ev1) != hipSuccess || hipEventCreate(&hk->evt0) != hipSuccess ||
+        hipEventCreate(&hk->evt1) != hipSuccess || hipMalloc((void**)&hk->d_chain, sizeof(oh_chain)) != hipSuccess) {
+      delete hk;
+      return fail(OH_ERR_HIP, "oh_create: stream/event/allocation failed");
+    }
+    *out = hk;
+    return OH_OK;
+  }
+  if (desc->T < 3 || desc->T > OH_MAX_T) return fail(OH_ERR_INVALID, "oh_create: T must be in [3, OH_MAX_T]");
+  if (desc->ndof != 6 && desc->ndof != 7)
+    return fail(OH_ERR_INVALID, "oh_create: figure-eight kernels are instantiated for ndof 6 and 7");
+  if (!(desc->dt > 0.0)) return fail(OH_ERR_INVALID, "oh_create: dt must be positive");
+  if (!desc->local_path) return fail(OH_ERR_INVALID, "oh_create: local_path is null");
+  if (!desc->lock_orientation)
+    return fail(OH_ERR_INVALID, "oh_create: only the orientation-locked variant (figure_eight_plan.py:105-107) is lowered");
+  if (desc->hessian != OH_HESSIAN_GAUSS_NEWTON && desc->hessian != OH_HESSIAN_EXACT)
+    return fail(OH_ERR_INVALID, "oh_create: bad hessian mode");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev < 1)
+    return fail(OH_ERR_HIP, "oh_create: no HIP device available (this library has no CPU path)");
+  oh_handle* h = new oh_handle();
+  h->desc = *desc;
+  h->local_path.assign(desc->local_path, desc->local_path + 3 * (size_t)desc->T);
+  h->desc.local_path = nullptr;
+  if (h->desc.max_iter <= 0) h->desc.max_iter = 200;
+  if (!(h->desc.tol > 0.0)) h->desc.tol = 1e-6;
+  if (!(h->desc.tol_feas > 0.0)) h->desc.tol_feas = 1e-9;
+  if (h->desc.mu0 < 0.0) h->desc.mu0 = 0.0;
+  hipGetDevice(&h->device);
+  if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
+      hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->evt0) != hipSuccess ||
+      hipEventCreate(&h->evt1) != hipSuccess) {
+    delete h;
+    return fail(OH_ERR_HIP, "oh_create: stream/event creation failed");
+  }
+  if (hipMalloc((void**)&h->d_chain, sizeof(oh_chain)) != hipSuccess ||
+      hipMalloc((void**)&h->d_local_path, sizeof(double) * 3 * (size_t)desc->T) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_flag, sizeof(int)) != hipSuccess) {
+    delete h;
+    return fail(OH_ERR_HIP, "oh_create: device allocation failed");
+  }
+  hipMemcpy(h->d_local_path, h->local_path.data(), sizeof(double) * 3 * (size_t)desc->T, hipMemcpyHostToDevice);
+  *out = h;
+  return OH_OK;
+}
+
+static int validate_chain(const oh_handle* h, const oh_chain& c) {
+  if (c.n_chain < 1 || c.n_chain > OH_MAX_CHAIN || c.ndof < c.n_chain || c.ndof > OH_MAX_CHAIN)
+    return fail(OH_ERR_INVALID, "oh_set_constants: bad n_chain/ndof");
+  for (int k = 0; k < c.n_chain; ++k) {
+    if (c.jtype[k] != 0 && c.jtype[k] != 1) return fail(OH_ERR_INVALID, "oh_set_constants: joint type not supported");
+    if (c.qidx[k] < 0 || c.qidx[k] >= c.ndof) return fail(OH_ERR_INVALID, "oh_set_constants: qidx out of range");
+  }
+  if (c.ndof != h->desc.ndof) return fail(OH_ERR_INVALID, "oh_set_constants: chain.ndof != desc.ndof");
+  return OH_OK;
+}
+
+extern "C" int oh_set_constants(oh_handle* h, const oh_chain* chain) {
+  if (!h || !chain) return fail(OH_ERR_INVALID, "oh_set_constants: null argument");
+  int rc = validate_chain(h, *chain);
+  if (rc) return rc;
+  h->chain_host = *chain;
+  HIPCHK(hipMemcpy(h->d_chain, chain, sizeof(oh_chain), hipMemcpyHostToDevice));
+  h->have_chain = true;
+  return OH_OK;
+}
+
+extern "C" int oh_set_constants_device(oh_handle* h, const void* d_chain, size_t nbytes) {
+  if (!h || !d_chain) return fail(OH_ERR_INVALID, "oh_set_constants_device: null argument");
+  if (nbytes != sizeof(oh_chain)) return fail(OH_ERR_INVALID, "oh_set_constants_device: nbytes != sizeof(oh_chain)");
+  oh_chain tmp;
+  HIPCHK(hipMemcpy(&tmp, d_chain, sizeof(oh_chain), hipMemcpyDeviceToHost));
+  int rc = validate_chain(h, tmp);
+  if (rc) return rc;
+  h->chain_host = tmp;
+  HIPCHK(hipMemcpy(h->d_chain, d_chain, sizeof(oh_chain), hipMemcpyDeviceToDevice));
+  h->have_chain = true;
+  return OH_OK;
+}
+
+static bool solver_chain_ok(const oh_chain& c) {
+  if (c.n_chain != c.ndof) return false;
+  for (int k = 0; k < c.n_chain; ++k)
+    if (c.qidx[k] != k) return false;
+  return true;
+}
+
+// carve the handle's device pool for B instances
+static int ensure_capacity(oh_handle* h, int B) {
+  const int N = h->desc.ndof, NZ = N - 3, T = h->desc.T;
+  const int Bp = (B + 63) / 64 * 64;
+  if (B <= h->cap_B && h->pool) {
+    h->D.B = B;
+    // keep the Bp the pool was carved with (stride), only the active count changes
+    return OH_OK;
+  }
+  if (h->pool) {
+    hipFree(h->pool);
+    h->pool = nullptr;
+  }
+  const size_t per_q = (size_t)T * N * Bp;
+  const size_t per_Z = (size_t)T * N * NZ * Bp;
+  const size_t per_Dr = (size_t)T * (NZ * (NZ + 1) / 2) * Bp;
+  const size_t per_t = (size_t)T * Bp;
+  size_t nd = 0;  // doubles
+  nd += 2 * per_q + 2 * per_Z + 2 * per_Dr + 2 * per_q /*g*/ + 4 * per_t /*phi,cv*/;
+  nd += per_q /*Gfull*/ + (size_t)T * NZ * NZ * Bp + (size_t)T * NZ * Bp;
+  nd += (size_t)12 * Bp + 6 * (size_t)Bp;
+  size_t ni = 4 * (size_t)Bp + 16;
+  size_t bytes = nd * sizeof(double) + ni * sizeof(int);
+  void* pool = nullptr;
+  hipError_t e = hipMalloc(&pool, bytes);
+  if (e != hipSuccess) return fail(OH_ERR_HIP, std::string("device pool allocation failed: ") + hipGetErrorString(e));
+  hipMemsetAsync(pool, 0, bytes, h->stream);
+  h->pool = pool;
+  h->pool_bytes = bytes;
+  h->cap_B = Bp;
+  double* d = (double*)pool;
+  auto take = [&](size_t n) {
+    double* r = d;
+    d += n;
+    return r;
+  };
+  FigBuffers& D = h->D;
+  D.B = B;
+  D.Bp = Bp;
+  D.chain = h->d_chain;
+  for (int s = 0; s < 2; ++s) D.q[s] = take(per_q);
+  for (int s = 0; s < 2; ++s) D.Z[s] = take(per_Z);
+  for (int s = 0; s < 2; ++s) D.Dr[s] = take(per_Dr);
+  for (int s = 0; s < 2; ++s) D.g[s] = take(per_q);
+  for (int s = 0; s < 2; ++s) D.phi[s] = take(per_t);
+  for (int s = 0; s < 2; ++s) D.cv[s] = take(per_t);
+  D.Gfull = take(per_q);
+  D.Kmat = take((size_t)T * NZ * NZ * Bp);
+  D.kvec = take((size_t)T * NZ * Bp);
+  D.ref = take((size_t)12 * Bp);
+  D.fconst = take(Bp);
+  D.f_cur = take(Bp);
+  D.pred = take(Bp);
+  D.mu = take(Bp);
+  D.stat = take(Bp);
+  D.feas = take(Bp);
+  int* ip = (int*)d;
+  D.cur = ip; ip += Bp;
+  D.first = ip; ip += Bp;
+  D.status = ip; ip += Bp;
+  D.iters = ip; ip += Bp;
+  D.any_active = ip;
+  return OH_OK;
+}
+
+static void fill_params(oh_handle* h) {
+  FigParams& P = h->P;
+  const oh_problem_desc& d = h->desc;
+  P.T = d.T;
+  P.nx = d.ndof * d.T + d.ndof * (d.T - 1);
+  P.dt = d.dt;
+  P.w_path = d.w_path;
+  P.kappa = d.w_vel / (d.dt * d.dt);
+  P.tol = d.tol;
+  P.tol_feas = d.tol_feas;
+  P.tol_retract = fmin(1e-10, d.tol_feas);
+  P.feas_accept = fmax(1e-8, 10.0 * d.tol_feas);
+  P.max_retract = 4;
+  P.max_iter = d.max_iter;
+  P.hessian = d.hessian;
+  P.mu0 = d.mu0;
+  P.local_path = h->d_local_path;
+}
+
+extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt,
+                               void* d_iters, void* d_status) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_solve_device: null handle");
+  if (B < 1) return fail(OH_ERR_INVALID, "oh_solve_device: B must be >= 1");
+  if (!d_x0 || !d_p) return fail(OH_ERR_INVALID, "oh_solve_device: x0 and p are required");
+  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT) return fail(OH_ERR_STATE, "oh_solve_device: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
+  if (!h->have_chain) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_constants first");
+  if (!solver_chain_ok(h->chain_host))
+    return fail(OH_ERR_INVALID, "oh_solve_device: the solver needs a chain that covers every model joint in order");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = ensure_capacity(h, B);
+  if (rc) return rc;
+  fill_params(h);
+  const int N = h->desc.ndof;
+  hipStream_t s = h->stream;
+  const bool prof = h->profiling;
+  if (prof) {
+    // events: [0] start, then per iteration (after eval, after step), last = end
+    const size_t need = 2 * (size_t)(h->desc.max_iter + 2) + 4;
+    while (h->prof_events.size() < need) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      h->prof_events.push_back(e);
+    }
+  }
+  HIPCHK(hipEventRecord(h->ev0, s));
+  if (!oh_launch_setup(s, N, h->P, h->D, (const double*)d_x0, (const double*)d_p))
+    return fail(OH_ERR_INVALID, "oh_solve_device: unsupported ndof");
+  size_t ne = 0;
+  if (prof) HIPCHK(hipEventRecord(h->prof_events[ne++], s));
+  int launched = 0;
+  const int check_every = (B <= 64) ? 1 : 2;
+  // every instance needs at most max_iter accepted+rejected steps, plus the initial evaluation
+  for (int it = 0; it <= h->desc.max_iter + 1; ++it) {
+    oh_launch_eval(s, N, h->P, h->D);
+    if (prof) HIPCHK(hipEventRecord(h->prof_events[ne++], s));
+    const bool check = ((it + 1) % check_every == 0);
+    if (check) HIPCHK(hipMemsetAsync(h->D.any_active, 0, sizeof(int), s));
+    oh_launch_step(s, N, h->P, h->D);
+    if (prof) HIPCHK(hipEventRecord(h->prof_events[ne++], s));
+    ++launched;
+    if (check) {
+      HIPCHK(hipMemcpyAsync(h->h_flag, h->D.any_active, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      if (*h->h_flag == 0) break;
+    }
+  }
+  oh_launch_finalize(s, N, h->P, h->D, (double*)d_x, (double*)d_f, (double*)d_kkt, (int*)d_iters, (int*)d_status);
+  HIPCHK(hipEventRecord(h->ev1, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  h->last_B = B;
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->timing[4] = ms;
+  h->timing[5] = launched;
+  if (prof) {
+    double te = 0, tsx = 0;
+    for (int i = 0; i < launched; ++i) {
+      float a = 0.f, b2 = 0.f;
+      hipEventElapsedTime(&a, h->prof_events[2 * i], h->prof_events[2 * i + 1]);
+      hipEventElapsedTime(&b2, h->prof_events[2 * i + 1], h->prof_events[2 * i + 2]);
+      te += a;
+      tsx += b2;
+    }
+    h->timing[0] = te;
+    h->timing[1] = launched;
+    h->timing[2] = tsx;
+    h->timing[3] = launched;
+  }
+  return OH_OK;
+}
+
+static int ensure_stage(oh_handle* h, size_t bytes) {
+  if (bytes <= h->stage_bytes) return OH_OK;
+  if (h->stage) hipFree(h->stage);
+  h->stage = nullptr;
+  h->stage_bytes = 0;
+  hipError_t e = hipMalloc(&h->stage, bytes);
+  if (e != hipSuccess) return fail(OH_ERR_HIP, std::string("staging allocation failed: ") + hipGetErrorString(e));
+  h->stage_bytes = bytes;
+  return OH_OK;
+}
+
+extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, double* x, double* f, double* kkt, int* iters,
+                        int* status) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_solve: null handle");
+  if (B < 1) return fail(OH_ERR_INVALID, "oh_solve: B must be >= 1");
+  if (!x0 || !p) return fail(OH_ERR_INVALID, "oh_solve: x0 and p are required");
+  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT) return fail(OH_ERR_STATE, "oh_solve: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->desc.ndof, T = h->desc.T;
+  const size_t nx = (size_t)N * T + (size_t)N * (T - 1);
+  const size_t b_x = sizeof(double) * nx * B, b_p = sizeof(double) * N * (size_t)B;
+  const size_t b_f = sizeof(double) * B, b_k = sizeof(double) * 3 * (size_t)B, b_i = sizeof(int) * (size_t)B;
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t total = al(b_x) * 2 + al(b_p) + al(b_f) + al(b_k) + 2 * al(b_i);
+  int rc = ensure_stage(h, total);
+  if (rc) return rc;
+  char* base = (char*)h->stage;
+  void* d_x0 = base; base += al(b_x);
+  void* d_x = base; base += al(b_x);
+  void* d_p = base; base += al(b_p);
+  void* d_f = base; base += al(b_f);
+  void* d_k = base; base += al(b_k);
+  void* d_it = base; base += al(b_i);
+  void* d_st = base;
+  HIPCHK(hipMemcpy(d_x0, x0, b_x, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_p, p, b_p, hipMemcpyHostToDevice));
+  rc = oh_solve_device(h, B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st);
+  if (rc) return rc;
+  if (x) HIPCHK(hipMemcpy(x, d_x, b_x, hipMemcpyDeviceToHost));
+  if (f) HIPCHK(hipMemcpy(f, d_f, b_f, hipMemcpyDeviceToHost));
+  if (kkt) HIPCHK(hipMemcpy(kkt, d_k, b_k, hipMemcpyDeviceToHost));
+  if (iters) HIPCHK(hipMemcpy(iters, d_it, b_i, hipMemcpyDeviceToHost));
+  if (status) HIPCHK(hipMemcpy(status, d_st, b_i, hipMemcpyDeviceToHost));
+  return OH_OK;
+}
+
+extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
+  if (!h || !lam_h) return fail(OH_ERR_INVALID, "oh_get_multipliers: null argument");
+  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT || B != h->last_B || B < 1)
+    return fail(OH_ERR_STATE, "oh_get_multipliers: B does not match the last solve");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t bytes = sizeof(double) * 4 * (size_t)h->desc.T * B;
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, bytes));
+  oh_launch_multipliers(h->stream, h->desc.ndof, h->P, h->D, (double*)d);
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(lam_h, d, bytes, hipMemcpyDeviceToHost);
+  hipFree(d);
+  if (e != hipSuccess) return fail(OH_ERR_HIP, std::string("oh_get_multipliers: ") + hipGetErrorString(e));
+  return OH_OK;
+}
+
+static int fk_common(oh_handle* h, int n, bool soa, const void* d_q, void* d_pose, void* d_J) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_fk_jac: null handle");
+  if (n < 1 || !d_q) return fail(OH_ERR_INVALID, "oh_fk_jac: bad arguments");
+  if (!h->have_chain) return fail(OH_ERR_STATE, "oh_fk_jac: call oh_set_constants first");
+  HIPCHK(hipSetDevice(h->device));
+  oh_launch_fk_jac(h->stream, soa, h->d_chain, n, (const double*)d_q, (double*)d_pose, (double*)d_J);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return OH_OK;
+}
+extern "C" int oh_fk_jac_device(oh_handle* h, int n, const void* d_q, void* d_pose, void* d_J) {
+  return fk_common(h, n, false, d_q, d_pose, d_J);
+}
+extern "C" int oh_fk_jac_soa_device(oh_handle* h, int n, const void* d_q, void* d_pose, void* d_J) {
+  return fk_common(h, n, true, d_q, d_pose, d_J);
+}
+extern "C" int oh_fk_jac(oh_handle* h, int n, const double* q, double* pose, double* J) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_fk_jac: null handle");
+  if (n < 1 || !q) return fail(OH_ERR_INVALID, "oh_fk_jac: bad arguments");
+  if (!h->have_chain) return fail(OH_ERR_STATE, "oh_fk_jac: call oh_set_constants first");
+  HIPCHK(hipSetDevice(h->device));
+  const int ndof = h->chain_host.ndof;
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t b_q = sizeof(double) * ndof * (size_t)n, b_p = sizeof(double) * 7 * (size_t)n,
+               b_J = sizeof(double) * 6 * ndof * (size_t)n;
+  int rc = ensure_stage(h, al(b_q) + al(b_p) + al(b_J));
+  if (rc) return rc;
+  char* base = (char*)h->stage;
+  void* d_q = base; base += al(b_q);
+  void* d_pose = base; base += al(b_p);
+  void* d_J = base;
+  HIPCHK(hipMemcpy(d_q, q, b_q, hipMemcpyHostToDevice));
+  rc = fk_common(h, n, false, d_q, pose ? d_pose : nullptr, J ? d_J : nullptr);
+  if (rc) return rc;
+  if (pose) HIPCHK(hipMemcpy(pose, d_pose, b_p, hipMemcpyDeviceToHost));
+  if (J) HIPCHK(hipMemcpy(J, d_J, b_J, hipMemcpyDeviceToHost));
+  return OH_OK;
+}
+
+extern "C" int oh_set_profiling(oh_handle* h, int enable) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_set_profiling: null handle");
+  h->profiling = enable != 0;
+  return OH_OK;
+}
+extern "C" int oh_get_timing(oh_handle* h, double* out6) {
+  if (!h || !out6) return fail(OH_ERR_INVALID, "oh_get_timing: null argument");
+  for (int i = 0; i < 6; ++i) out6[i] = h->timing[i];
+  return OH_OK;
+}
+extern "C" int oh_event_timer_start(oh_handle* h) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_event_timer_start: null handle");
+  HIPCHK(hipEventRecord(h->evt0, h->stream));
+  return OH_OK;
+}
+extern "C" int oh_event_timer_stop(oh_handle* h, double* ms) {
+  if (!h || !ms) return fail(OH_ERR_INVALID, "oh_event_timer_stop: null argument");
+  HIPCHK(hipEventRecord(h->evt1, h->stream));
+  HIPCHK(hipEventSynchronize(h->evt1));
+  float f = 0.f;
+  HIPCHK(hipEventElapsedTime(&f, h->evt0, h->evt1));
+  *ms = f;
+  return OH_OK;
+}
+
+extern "C" void oh_destroy(oh_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (hipEvent_t e : h->prof_events) hipEventDestroy(e);
+  if (h->pool) hipFree(h->pool);
+  if (h->stage) hipFree(h->stage);
+  if (h->d_chain) hipFree(h->d_chain);
+  if (h->d_local_path) hipFree(h->d_local_path);
+  if (h->h_flag) hipHostFree(h->h_flag);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->evt0) hipEventDestroy(h->evt0);
+  if (h->evt1) hipEventDestroy(h->evt1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}

@@ -1,0 +1,153 @@
+// Device-side math for liboptas_hip: small fixed-size linear algebra kept entirely in VGPRs
+// (all loops are compile-time unrolled so that no array is ever dynamically indexed -> no scratch),
+// and the serial-chain forward kinematics that RobotModel.get_global_link_transform
+// (optas/models.py:826-868) expresses as a CasADi SX graph.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/optas_hip.h"
+
+#define OH_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------
+// 3-vectors / 3x3 row-major matrices
+// ---------------------------------------------------------------------------------------------
+OH_DEV void cross3(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+OH_DEV double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// C = A * B (3x3)
+OH_DEV void mm3(const double* A, const double* B, double* C) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+// C = A * B^T
+OH_DEV void mmT3(const double* A, const double* B, double* C) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
+}
+// o = A * v
+OH_DEV void mv3(const double* A, const double* v, double* o) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+
+// Hamilton product a (x) b, xyzw storage.  The reference's Quaternion.__mul__ (spatialmath.py:298-312)
+// is the reversed product: ref(a*b) == hamilton(b, a).
+OH_DEV void qmul(const double* a, const double* b, double* o) {
+  const double ax = a[0], ay = a[1], az = a[2], aw = a[3];
+  const double bx = b[0], by = b[1], bz = b[2], bw = b[3];
+  o[0] = aw * bx + ax * bw + ay * bz - az * by;
+  o[1] = aw * by - ax * bz + ay * bw + az * bx;
+  o[2] = aw * bz + ax * by - ay * bx + az * bw;
+  o[3] = aw * bw - ax * bx - ay * by - az * bz;
+}
+
+// R <- R * Rot(a, theta) with Rot = c I + s [a]x + (1-c) a a^T (== Rodrigues, spatialmath.py:89-99),
+// done row-wise:  r_i <- c r_i + s (r_i x a) + (1-c) (r_i . a) a.   zc = R a (unchanged by the spin).
+OH_DEV void rot_axis_right(double* R, const double* a, double s, double c, double* zc) {
+  const double omc = 1.0 - c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double* r = R + 3 * i;
+    double x[3];
+    cross3(r, a, x);
+    const double d = dot3(r, a);
+    zc[i] = d;
+    const double k = omc * d;
+    r[0] = c * r[0] + s * x[0] + k * a[0];
+    r[1] = c * r[1] + s * x[1] + k * a[1];
+    r[2] = c * r[2] + s * x[2] + k * a[2];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward kinematics of a folded serial chain whose k-th actuated joint reads q[k] (solver path:
+// chain covers all model joints in order).  Outputs: R,p = frame after the last joint (before the
+// tool transform), z[k] = world joint axis, pj[k] = world joint origin.
+// ---------------------------------------------------------------------------------------------
+template <int N>
+OH_DEV void fk_chain(const oh_chain* __restrict__ ch, const double (&q)[N], double (&R)[9], double (&p)[3],
+                     double (&z)[N][3], double (&pj)[N][3]) {
+  R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
+  R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
+  R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
+  p[0] = p[1] = p[2] = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double t[3];
+    mv3(R, ch->p0[k], t);
+    p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
+    double Rn[9];
+    mm3(R, ch->R0[k], Rn);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    pj[k][0] = p[0]; pj[k][1] = p[1]; pj[k][2] = p[2];
+    if (ch->jtype[k] == 0) {
+      double s, c;
+      sincos(q[k], &s, &c);
+      rot_axis_right(R, ch->axis[k], s, c, z[k]);
+    } else {
+      mv3(R, ch->axis[k], z[k]);
+      p[0] += z[k][0] * q[k]; p[1] += z[k][1] * q[k]; p[2] += z[k][2] * q[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense symmetric positive definite helpers, packed lower storage idx(i,j) = i(i+1)/2 + j, j<=i.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// In-place Cholesky of packed lower S (M x M).  Returns false if a pivot is <= piv_min.
+template <int M>
+OH_DEV bool chol_packed(double (&S)[M * (M + 1) / 2], double piv_min) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    double d = S[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= S[tri(j, k)] * S[tri(j, k)];
+    if (!(d > piv_min)) { ok = false; d = 1.0; }
+    const double l = sqrt(d);
+    const double inv = 1.0 / l;
+    S[tri(j, j)] = l;
+#pragma unroll
+    for (int i = j + 1; i < M; ++i) {
+      double v = S[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= S[tri(i, k)] * S[tri(j, k)];
+      S[tri(i, j)] = v * inv;
+    }
+  }
+  return ok;
+}
+// x <- L^{-1} x
+template <int M>
+OH_DEV void fsub(const double (&L)[M * (M + 1) / 2], double (&x)[M]) {
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    double v = x[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= L[tri(i, k)] * x[k];
+    x[i] = v / L[tri(i, i)];
+  }
+}
+// x <- L^{-T} x
+template <int M>
+OH_DEV void bsub(const double (&L)[M * (M + 1) / 2], double (&x)[M]) {
+#pragma unroll
+  for (int i = M - 1; i >= 0; --i) {
+    double v = x[i];
+#pragma unroll
+    for (int k = i + 1; k < M; ++k) v -= L[tri(k, i)] * x[k];
+    x[i] = v / L[tri(i, i)];
+  }
+}

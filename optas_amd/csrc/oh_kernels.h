@@ -1,0 +1,58 @@
+// Shared host/device declarations between oh_kernels.hip (device code) and oh_api.hip (C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/optas_hip.h"
+
+// Scalar parameters of the figure-eight family (passed by value to every kernel -> SGPRs).
+struct FigParams {
+  int T;
+  int nx;            // ndof*T + ndof*(T-1)
+  double dt;
+  double w_path;
+  double kappa;      // w_vel / dt^2 : weight of ||q_{t+1}-q_t||^2 after eliminating dq
+  double tol;
+  double tol_feas;
+  double tol_retract;
+  double feas_accept;
+  int max_retract;
+  int max_iter;
+  int hessian;
+  double mu0;
+  const double* local_path;  // device, [T][3]
+};
+
+// Device buffers of one handle (SoA, instance index fastest; Bp = B rounded up to 64).
+struct FigBuffers {
+  int B, Bp;
+  const oh_chain* chain;  // device copy of the kinematic constants
+  double* q[2];           // [slot][T][N][Bp]      knots: current / trial
+  double* Z[2];           // [slot][T][N*NZ][Bp]   null-space basis of the orientation rows
+  double* Dr[2];          // [slot][T][NZ(NZ+1)/2][Bp] reduced Hessian block Z^T W Z (packed lower)
+  double* g[2];           // [slot][T][N][Bp]      tracking gradient
+  double* phi[2];         // [slot][T][Bp]         tracking cost
+  double* cv[2];          // [slot][T][Bp]         |c|_inf after retraction
+  double* Gfull;          // [T][N][Bp]            Lagrangian gradient at the last accepted point (exact Hessian)
+  double* Kmat;           // [T][NZ*NZ][Bp]        Riccati gains
+  double* kvec;           // [T][NZ][Bp]
+  double* ref;            // [12][Bp]              p(qc), R(qc)
+  double* fconst;         // [Bp]
+  double* f_cur;          // [Bp]
+  double* pred;           // [Bp]
+  double* mu;             // [Bp]
+  double* stat;           // [Bp]
+  double* feas;           // [Bp]
+  int* cur;               // [Bp] slot holding the accepted point
+  int* first;             // [Bp]
+  int* status;            // [Bp] -1 running, else OH_STATUS_*
+  int* iters;             // [Bp]
+  int* any_active;        // [1]
+};
+
+void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n, const double* q, double* pose, double* J);
+bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const double* x0, const double* p);
+bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D);
+bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D);
+bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, double* x, double* f, double* kkt, int* iters,
+                        int* status);
+bool oh_launch_multipliers(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, double* lam_h);

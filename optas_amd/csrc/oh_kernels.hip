@@ -1,0 +1,804 @@
+// HIP kernels of liboptas_hip (gfx950).  See DESIGN.md for the data layout and per-kernel rooflines.
+//
+// All per-(instance, knot) arrays are structure-of-arrays with the instance index fastest:
+//   a[(t*K + k)*Bp + b]        (Bp = B rounded up to 64)
+// so that the 64 lanes of a wavefront, which always hold 64 consecutive instances b at one knot t,
+// read and write full 512-byte lines.
+#include "oh_device.h"
+#include "oh_kernels.h"
+
+#define IDX(t, K, k) (((size_t)(t) * (K) + (k)) * Bp + b)
+
+// ---------------------------------------------------------------------------------------------
+// K1: batched FK + geometric Jacobian (+ reference-signed quaternion), arbitrary chain.
+//   replaces get_global_link_{position,quaternion,geometric_jacobian}_function(link, n=N)
+//   (optas/models.py:935-947,1090-1106,1199-1281).  One lane per unit.
+//   SOA=true : q[ndof][N], pose[7][N], J[6*ndof][N]      (coalesced; solver-internal / roofline)
+//   SOA=false: q[N][ndof], pose[N][7], J[N][6][ndof]     (reference layout at the ABI)
+// ---------------------------------------------------------------------------------------------
+template <bool SOA>
+__global__ __launch_bounds__(256) void k_fk_jac(const oh_chain* __restrict__ ch, int n, const double* __restrict__ q,
+                                                double* __restrict__ pose, double* __restrict__ J) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const int nc = ch->n_chain;
+  const int ndof = ch->ndof;
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double p[3] = {0, 0, 0};
+  double quat[4] = {0, 0, 0, 1};
+  double z[OH_MAX_CHAIN][3];
+  double pj[OH_MAX_CHAIN][3];
+#pragma unroll
+  for (int k = 0; k < OH_MAX_CHAIN; ++k) {
+    if (k < nc) {
+      const int qi = ch->qidx[k];
+      const double qk = SOA ? q[(size_t)qi * n + u] : q[(size_t)u * ndof + qi];
+      double t[3];
+      mv3(R, ch->p0[k], t);
+      p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
+      double Rn[9];
+      mm3(R, ch->R0[k], Rn);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+      double qn[4];
+      qmul(quat, ch->quat0[k], qn);  // == fromrpy(rpy) * quat in the reference's reversed product
+      pj[k][0] = p[0]; pj[k][1] = p[1]; pj[k][2] = p[2];
+      if (ch->jtype[k] == 0) {
+        double sh, chh;
+        sincos(0.5 * qk, &sh, &chh);  // half angle: quaternion (spatialmath.py:372-375) ...
+        const double s = 2.0 * sh * chh, c = 1.0 - 2.0 * sh * sh;  // ... and full angle for Rodrigues
+        rot_axis_right(R, ch->axis[k], s, c, z[k]);
+        const double qa[4] = {sh * ch->axis[k][0], sh * ch->axis[k][1], sh * ch->axis[k][2], chh};
+        qmul(qn, qa, quat);
+      } else {
+        mv3(R, ch->axis[k], z[k]);
+        p[0] += z[k][0] * qk; p[1] += z[k][1] * qk; p[2] += z[k][2] * qk;
+        quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
+      }
+    }
+  }
+  double e[3], t[3];
+  mv3(R, ch->p_tool, t);
+  e[0] = p[0] + t[0]; e[1] = p[1] + t[1]; e[2] = p[2] + t[2];
+  if (pose) {
+    double qe[4];
+    qmul(quat, ch->quat_tool, qe);
+    const double o[7] = {e[0], e[1], e[2], qe[0], qe[1], qe[2], qe[3]};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      if (SOA) pose[(size_t)i * n + u] = o[i];
+      else pose[(size_t)u * 7 + i] = o[i];
+    }
+  }
+  if (J) {
+    // columns of joints that are not on the chain are zero (models.py:1251-1254)
+    if (!SOA) {
+      for (int i = 0; i < 6 * ndof; ++i) J[(size_t)u * 6 * ndof + i] = 0.0;
+    } else if (nc != ndof) {
+      for (int i = 0; i < 6 * ndof; ++i) J[(size_t)i * n + u] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < OH_MAX_CHAIN; ++k) {
+      if (k < nc) {
+        const int col = ch->qidx[k];
+        double col6[6];
+        if (ch->jtype[k] == 0) {
+          const double d[3] = {e[0] - pj[k][0], e[1] - pj[k][1], e[2] - pj[k][2]};
+          cross3(z[k], d, col6);  // models.py:1236-1239
+          col6[3] = z[k][0]; col6[4] = z[k][1]; col6[5] = z[k][2];
+        } else {
+          col6[0] = z[k][0]; col6[1] = z[k][1]; col6[2] = z[k][2];  // models.py:1245-1246
+          col6[3] = col6[4] = col6[5] = 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          if (SOA) J[((size_t)r * ndof + col) * n + u] = col6[r];
+          else J[(size_t)u * 6 * ndof + r * ndof + col] = col6[r];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Figure-eight family.  N = ndof (chain covers all joints in order), NZ = N-3 (orientation locked).
+// ---------------------------------------------------------------------------------------------
+
+// Orientation residual c = vee(skew(Re Rc^T)) and M = 1/2 (tr(A) I - A) with dc = M domega.
+OH_DEV void orient_residual(const double* Re, const double* Rc, double* c, double* M) {
+  double A[9];
+  mmT3(Re, Rc, A);
+  c[0] = 0.5 * (A[7] - A[5]);
+  c[1] = 0.5 * (A[2] - A[6]);
+  c[2] = 0.5 * (A[3] - A[1]);
+  const double tr = A[0] + A[4] + A[8];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) M[i] = -0.5 * A[i];
+  M[0] += 0.5 * tr; M[4] += 0.5 * tr; M[8] += 0.5 * tr;
+}
+
+// per-instance setup: references from qc, fixed knots, seed -> slot 0, solver state.
+template <int N>
+__global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const double* __restrict__ x0,
+                                              const double* __restrict__ pin) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Bp = D.Bp;
+  if (b >= D.B) {
+    if (b < Bp) D.status[b] = OH_STATUS_CONVERGED;  // padding lanes never run
+    return;
+  }
+  const oh_chain* ch = D.chain;
+  double qc[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) qc[j] = pin[(size_t)b * N + j];
+  double R[9], p[3], z[N][3], pj[N][3];
+  fk_chain<N>(ch, qc, R, p, z, pj);
+  double e[3], t[3], Re[9];
+  mv3(R, ch->p_tool, t);
+  e[0] = p[0] + t[0]; e[1] = p[1] + t[1]; e[2] = p[2] + t[2];
+  mm3(R, ch->R_tool, Re);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) D.ref[(size_t)i * Bp + b] = e[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) D.ref[(size_t)(3 + i) * Bp + b] = Re[i];
+  // constant cost of the fixed knots t=0,1 (q_0 = q_1 = qc): w * ||Rc local_t||^2
+  double fconst = 0.0;
+  for (int tt = 0; tt < 2 && tt < P.T; ++tt) {
+    double l[3] = {P.local_path[3 * tt], P.local_path[3 * tt + 1], P.local_path[3 * tt + 2]};
+    fconst += P.w_path * dot3(l, l);  // Rc orthonormal
+  }
+  D.fconst[b] = fconst;
+  // knots: slot 0 holds the seed with q_0 = q_1 = qc imposed (linear rows eliminated)
+  for (int tt = 0; tt < P.T; ++tt) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const double v = (tt < 2) ? qc[j] : x0[(size_t)b * P.nx + (size_t)tt * N + j];
+      D.q[0][IDX(tt, N, j)] = v;
+      D.q[1][IDX(tt, N, j)] = (tt < 2) ? qc[j] : 0.0;
+    }
+  }
+  D.cur[b] = 1;  // trial slot = 0
+  D.first[b] = 1;
+  D.status[b] = -1;  // running
+  D.iters[b] = 0;
+  D.f_cur[b] = 0.0;
+  D.pred[b] = 0.0;
+  D.mu[b] = P.mu0;
+  D.stat[b] = 0.0;
+  D.feas[b] = 0.0;
+}
+
+// K2: one lane per (instance b, free knot t): retraction onto R(q_t)=Rc, FK chain + Jacobians,
+// tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block.
+template <int N>
+__global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D) {
+  constexpr int NZ = N - 3;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y + 2;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (D.status[b] >= 0) return;
+  const int slot = 1 - D.cur[b];
+  const oh_chain* ch = D.chain;
+  double* __restrict__ qs = D.q[slot];
+
+  double q[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) q[j] = qs[IDX(t, N, j)];
+  double Rc[9], pc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pc[i] = D.ref[(size_t)i * Bp + b];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
+
+  double R[9], p[3], z[N][3], pj[N][3];
+  double Re[9], c[3], M[9];
+  double cmax;
+  for (int it = 0;; ++it) {
+    fk_chain<N>(ch, q, R, p, z, pj);
+    mm3(R, ch->R_tool, Re);
+    orient_residual(Re, Rc, c, M);
+    cmax = fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2])));
+    if (cmax <= P.tol_retract || it >= P.max_retract) break;
+    // Newton correction q <- q - Jc^T (Jc Jc^T)^{-1} c,  Jc = M Jw,  Jw[:,k] = z_k (revolute) / 0
+    double Jc[N][3];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (ch->jtype[k] == 0) mv3(M, z[k], Jc[k]);
+      else { Jc[k][0] = Jc[k][1] = Jc[k][2] = 0.0; }
+    }
+    double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      S[0] += Jc[k][0] * Jc[k][0];
+      S[1] += Jc[k][1] * Jc[k][0];
+      S[2] += Jc[k][1] * Jc[k][1];
+      S[3] += Jc[k][2] * Jc[k][0];
+      S[4] += Jc[k][2] * Jc[k][1];
+      S[5] += Jc[k][2] * Jc[k][2];
+    }
+    chol_packed<3>(S, 0.0);
+    double y[3] = {c[0], c[1], c[2]};
+    fsub<3>(S, y);
+    bsub<3>(S, y);
+#pragma unroll
+    for (int k = 0; k < N; ++k) q[k] -= dot3(Jc[k], y);
+  }
+  // retracted knot back to the trial slot
+#pragma unroll
+  for (int j = 0; j < N; ++j) qs[IDX(t, N, j)] = q[j];
+
+  // end-effector position, tracking residual
+  double e[3], tv[3];
+  mv3(R, ch->p_tool, tv);
+  e[0] = p[0] + tv[0]; e[1] = p[1] + tv[1]; e[2] = p[2] + tv[2];
+  const double l[3] = {P.local_path[3 * t], P.local_path[3 * t + 1], P.local_path[3 * t + 2]};
+  double r[3];
+  mv3(Rc, l, r);
+  r[0] += pc[0] - e[0]; r[1] += pc[1] - e[1]; r[2] += pc[2] - e[2];
+  const double w = P.w_path;
+  D.phi[slot][(size_t)t * Bp + b] = w * dot3(r, r);
+  D.cv[slot][(size_t)t * Bp + b] = cmax;
+
+  // Jacobian columns
+  double Jp[N][3], Jc[N][3];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (ch->jtype[k] == 0) {
+      const double d[3] = {e[0] - pj[k][0], e[1] - pj[k][1], e[2] - pj[k][2]};
+      cross3(z[k], d, Jp[k]);
+      mv3(M, z[k], Jc[k]);
+    } else {
+      Jp[k][0] = z[k][0]; Jp[k][1] = z[k][1]; Jp[k][2] = z[k][2];
+      Jc[k][0] = Jc[k][1] = Jc[k][2] = 0.0;
+    }
+  }
+  // gradient of w ||r||^2 : -2 w Jp^T r
+#pragma unroll
+  for (int k = 0; k < N; ++k) D.g[slot][IDX(t, N, k)] = -2.0 * w * dot3(Jp[k], r);
+
+  // Hessian block W (packed lower): 2 w Jp^T Jp  (+ exact curvature, OH_HESSIAN_EXACT)
+  double W[N * (N + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) W[tri(i, j)] = 2.0 * w * dot3(Jp[i], Jp[j]);
+  if (P.hessian == OH_HESSIAN_EXACT) {
+    // -2 w r . d2p/dq_j dq_i,  d2p/dq_j dq_i = z_j x Jp_i for j <= i (revolute j)
+    // + lam . d2c/dq_j dq_i,   d2c = 1/2 z_j x z_i (j < i), exact on the constraint manifold.
+    // multipliers: least squares of  G_prev + Jc^T lam = 0  with the Lagrangian gradient G_prev that
+    // k_step left for this knot at the last accepted point (lagged by one iteration; exact at convergence)
+    double lam[3] = {0.0, 0.0, 0.0};
+    {
+      double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const double Gk = D.Gfull[IDX(t, N, k)];
+        S[0] += Jc[k][0] * Jc[k][0];
+        S[1] += Jc[k][1] * Jc[k][0];
+        S[2] += Jc[k][1] * Jc[k][1];
+        S[3] += Jc[k][2] * Jc[k][0];
+        S[4] += Jc[k][2] * Jc[k][1];
+        S[5] += Jc[k][2] * Jc[k][2];
+        lam[0] -= Jc[k][0] * Gk; lam[1] -= Jc[k][1] * Gk; lam[2] -= Jc[k][2] * Gk;
+      }
+      chol_packed<3>(S, 0.0);
+      fsub<3>(S, lam);
+      bsub<3>(S, lam);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (ch->jtype[j] == 0) {
+        double rz[3], lz[3];
+        cross3(r, z[j], rz);    // (r x z_j) . Jp_i = r . (z_j x Jp_i)
+        cross3(lam, z[j], lz);  // (lam x z_j) . z_i = lam . (z_j x z_i)
+#pragma unroll
+        for (int i = j; i < N; ++i) {
+          double v = -2.0 * w * dot3(rz, Jp[i]);
+          if (i > j && ch->jtype[i] == 0) v += 0.5 * dot3(lz, z[i]);
+          W[tri(i, j)] += v;
+        }
+      }
+    }
+  }
+
+  // Householder QR of Jc^T (N x 3): H3 H2 H1 Jc^T = [Rf; 0];  Z = H1 H2 H3 [0; I_NZ]
+  double A[3][N];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int k = 0; k < N; ++k) A[m][k] = Jc[k][m];
+  double V[3][N];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    double nrm2 = 0.0;
+#pragma unroll
+    for (int k = m; k < N; ++k) nrm2 += A[m][k] * A[m][k];
+    const double nrm = sqrt(nrm2);
+    const double alpha = (A[m][m] > 0.0) ? -nrm : nrm;
+    double vn2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      V[m][k] = (k < m) ? 0.0 : ((k == m) ? A[m][k] - alpha : A[m][k]);
+      vn2 += V[m][k] * V[m][k];
+    }
+    const double inv = (vn2 > 1e-300) ? 1.0 / sqrt(vn2) : 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) V[m][k] *= inv;
+    // apply to the remaining columns
+#pragma unroll
+    for (int m2 = m + 1; m2 < 3; ++m2) {
+      double d = 0.0;
+#pragma unroll
+      for (int k = m; k < N; ++k) d += V[m][k] * A[m2][k];
+      d *= 2.0;
+#pragma unroll
+      for (int k = m; k < N; ++k) A[m2][k] -= d * V[m][k];
+    }
+  }
+  double Z[N][NZ];
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) {
+    double col[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) col[k] = (k == a + 3) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 2; m >= 0; --m) {
+      double d = 0.0;
+#pragma unroll
+      for (int k = m; k < N; ++k) d += V[m][k] * col[k];
+      d *= 2.0;
+#pragma unroll
+      for (int k = m; k < N; ++k) col[k] -= d * V[m][k];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) Z[k][a] = col[k];
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) D.Z[slot][IDX(t, N * NZ, k * NZ + a)] = Z[k][a];
+
+  // reduced block Dr = Z^T W Z (packed lower NZ x NZ)
+  double WZ[N][NZ];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) s += W[(i >= k) ? tri(i, k) : tri(k, i)] * Z[k][a];
+      WZ[i][a] = s;
+    }
+#pragma unroll
+  for (int a = 0; a < NZ; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 <= a; ++c2) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) s += Z[k][a] * WZ[k][c2];
+      D.Dr[slot][IDX(t, NZ * (NZ + 1) / 2, tri(a, c2))] = s;
+    }
+}
+
+// K3: one lane per instance: accept/reject the trial point (Levenberg-Marquardt ratio test on the
+// objective; iterates are feasible by retraction), then backward Riccati sweep over the reduced
+// block-tridiagonal system, forward roll-out, next trial knots.
+template <int N>
+__global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D) {
+  constexpr int NZ = N - 3;
+  constexpr int NP = NZ * (NZ + 1) / 2;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (D.status[b] >= 0) return;
+  const int T = P.T;
+  const double kap2 = 2.0 * P.kappa;  // Hessian weight of kappa*||q_{t+1}-q_t||^2
+  int cur = D.cur[b];
+  double mu = D.mu[b];
+  int iters = D.iters[b];
+
+  // ---- phase A: merit of the trial slot ---------------------------------------------------------
+  {
+    const int ts = 1 - cur;
+    const double* __restrict__ qt = D.q[ts];
+    double f = D.fconst[b];
+    double feas = 0.0;
+    double qa[N], qb[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) qa[j] = qt[IDX(1, N, j)];
+    for (int t = 2; t < T; ++t) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        qb[j] = qt[IDX(t, N, j)];
+        const double d = qb[j] - qa[j];
+        s += d * d;
+        qa[j] = qb[j];
+      }
+      f += P.kappa * s + D.phi[ts][(size_t)t * Bp + b];
+      feas = fmax(feas, D.cv[ts][(size_t)t * Bp + b]);
+    }
+    bool accept;
+    if (D.first[b]) {
+      accept = true;
+      D.first[b] = 0;
+    } else {
+      const double pred = D.pred[b];
+      const double fc = D.f_cur[b];
+      const double rho = (fc - f) / fmax(pred, 1e-300);
+      // also accept steps whose predicted decrease is at rounding level of f (end game)
+      accept = (f == f) && (feas <= P.feas_accept) && (rho > 1e-4 || (pred <= 1e-15 * fabs(fc) && f <= fc + 1e-14 * fabs(fc)));
+      if (accept) {
+        if (rho > 0.75) mu = (mu > 1e-6) ? mu * 0.2 : 0.0;
+        else if (rho < 0.25) mu = fmax(4.0 * mu, 1e-3);
+      } else {
+        mu = fmax(4.0 * mu, 1e-3);
+      }
+    }
+    if (accept) {
+      cur = ts;
+      D.cur[b] = cur;
+      D.f_cur[b] = f;
+      D.feas[b] = feas;
+    }
+  }
+
+  // ---- phase B: backward sweep on the current slot ------------------------------------------------
+  const double* __restrict__ qc_ = D.q[cur];
+  const double* __restrict__ Zc = D.Z[cur];
+  const double* __restrict__ Drc = D.Dr[cur];
+  const double* __restrict__ gc = D.g[cur];
+  double stat = 0.0;
+  double r2[NZ];  // r at the first free knot after the sweep
+  double S[NP];
+  for (int attempt = 0; attempt < 40; ++attempt) {
+    bool ok = true;
+    stat = 0.0;
+    double rn[NZ];  // r_{t+1}
+    // t = T-1 .. 2
+    for (int t = T - 1; t >= 2; --t) {
+      // G_t = g_t + kap2*((q_t - q_{t-1}) - (q_{t+1} - q_t)),  gt = Z_t^T G_t,  E = -kap2 Z_t^T Z_{t+1}
+      double gt[NZ];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) gt[a] = 0.0;
+      double E[NZ][NZ];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 < NZ; ++c2) E[a][c2] = 0.0;
+      const bool last = (t == T - 1);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const double qm = qc_[IDX(t - 1, N, k)];
+        const double q0 = qc_[IDX(t, N, k)];
+        double G = gc[IDX(t, N, k)] + kap2 * (q0 - qm);
+        if (!last) G -= kap2 * (qc_[IDX(t + 1, N, k)] - q0);
+        double zt[NZ], zn[NZ];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) zt[a] = Zc[IDX(t, N * NZ, k * NZ + a)];
+        if (!last) {
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) zn[a] = Zc[IDX(t + 1, N * NZ, k * NZ + a)];
+        }
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+          gt[a] += zt[a] * G;
+          if (!last) {
+#pragma unroll
+            for (int c2 = 0; c2 < NZ; ++c2) E[a][c2] -= kap2 * zt[a] * zn[c2];
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) stat = fmax(stat, fabs(gt[a]));
+      double Ht[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Ht[i] = Drc[IDX(t, NP, i)];
+      const double dg = (last ? kap2 : 2.0 * kap2) + mu;
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) Ht[tri(a, a)] += dg;
+      if (last) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) S[i] = Ht[i];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) rn[a] = gt[a];
+      } else {
+        // S currently holds S_{t+1}, rn = r_{t+1}
+        ok = chol_packed<NZ>(S, 1e-12) && ok;
+        // X = L^{-1} E^T  (column a of X = L^{-1} (row a of E)^T)
+        double X[NZ][NZ];  // X[:, a]
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+          double col[NZ];
+#pragma unroll
+          for (int c2 = 0; c2 < NZ; ++c2) col[c2] = E[a][c2];
+          fsub<NZ>(S, col);
+#pragma unroll
+          for (int c2 = 0; c2 < NZ; ++c2) X[c2][a] = col[c2];
+        }
+        double u[NZ];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) u[a] = rn[a];
+        fsub<NZ>(S, u);
+        // S_t = Ht - X^T X ; r_t = gt - X^T u
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+          double s = gt[a];
+#pragma unroll
+          for (int c2 = 0; c2 < NZ; ++c2) s -= X[c2][a] * u[c2];
+          rn[a] = s;
+        }
+        // gains of knot t+1: z_{t+1} = -(kvec + Kmat z_t), Kmat = L^{-T} X, kvec = L^{-T} u
+        double kv[NZ];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) kv[a] = u[a];
+        bsub<NZ>(S, kv);
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) D.kvec[IDX(t + 1, NZ, a)] = kv[a];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+          double col[NZ];
+#pragma unroll
+          for (int c2 = 0; c2 < NZ; ++c2) col[c2] = X[c2][a];
+          bsub<NZ>(S, col);
+#pragma unroll
+          for (int c2 = 0; c2 < NZ; ++c2) D.Kmat[IDX(t + 1, NZ * NZ, c2 * NZ + a)] = col[c2];
+        }
+#pragma unroll
+        for (int a = 0; a < NZ; ++a)
+#pragma unroll
+          for (int c2 = 0; c2 <= a; ++c2) {
+            double s = Ht[tri(a, c2)];
+#pragma unroll
+            for (int k = 0; k < NZ; ++k) s -= X[k][a] * X[k][c2];
+            S[tri(a, c2)] = s;
+          }
+      }
+    }
+    ok = chol_packed<NZ>(S, 1e-12) && ok;
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) r2[a] = rn[a];
+    if (ok) break;
+    mu = fmax(4.0 * mu, 1e-2);
+  }
+  D.stat[b] = stat;
+  const double feas_cur = D.feas[b];
+  if (stat <= P.tol && feas_cur <= P.tol_feas) {
+    D.status[b] = OH_STATUS_CONVERGED;
+    D.mu[b] = mu;
+    return;
+  }
+  if (iters >= P.max_iter) {
+    D.status[b] = OH_STATUS_MAX_ITER;
+    D.mu[b] = mu;
+    return;
+  }
+  if (!(stat == stat)) {
+    D.status[b] = OH_STATUS_NUMERICAL;
+    return;
+  }
+
+  // ---- forward roll-out: z_2 = -S_2^{-1} r_2, z_{t+1} = -(kvec + Kmat z_t); trial knots ---------------
+  {
+    double* __restrict__ qn = D.q[1 - cur];
+    double zz[NZ];
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) zz[a] = -r2[a];
+    fsub<NZ>(S, zz);
+    bsub<NZ>(S, zz);
+    double gd = 0.0, z2 = 0.0;
+    for (int t = 2; t < T; ++t) {
+      if (t > 2) {
+        double zn[NZ];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+          double s = D.kvec[IDX(t, NZ, a)];
+#pragma unroll
+          for (int c2 = 0; c2 < NZ; ++c2) s += D.Kmat[IDX(t, NZ * NZ, a * NZ + c2)] * zz[c2];
+          zn[a] = -s;
+        }
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) zz[a] = zn[a];
+      }
+      const bool last = (t == T - 1);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const double qm = qc_[IDX(t - 1, N, k)];
+        const double q0 = qc_[IDX(t, N, k)];
+        double G = gc[IDX(t, N, k)] + kap2 * (q0 - qm);
+        if (!last) G -= kap2 * (qc_[IDX(t + 1, N, k)] - q0);
+        double dq = 0.0;
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) dq += Zc[IDX(t, N * NZ, k * NZ + a)] * zz[a];
+        gd += G * dq;
+        qn[IDX(t, N, k)] = q0 + dq;
+        if (P.hessian == OH_HESSIAN_EXACT) D.Gfull[IDX(t, N, k)] = G;
+      }
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) z2 += zz[a] * zz[a];
+    }
+    D.pred[b] = -0.5 * gd + 0.5 * mu * z2;
+  }
+  D.mu[b] = mu;
+  D.iters[b] = iters + 1;
+  *D.any_active = 1;
+}
+
+// Solution out in the reference layout x = [vec(Q); vec(dQ)] (sx_container.py:83-89), plus f, kkt, ...
+template <int N>
+__global__ __launch_bounds__(256) void k_finalize(FigParams P, FigBuffers D, double* __restrict__ x, double* __restrict__ f,
+                                                  double* __restrict__ kkt, int* __restrict__ iters, int* __restrict__ status) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  const int cur = D.cur[b];
+  const double* __restrict__ qs = D.q[cur];
+  if (x) {
+    double* xb = x + (size_t)b * P.nx;
+    double q0[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      q0[j] = qs[IDX(t, N, j)];
+      xb[(size_t)t * N + j] = q0[j];
+    }
+    if (t < P.T - 1) {
+      const double inv_dt = 1.0 / P.dt;
+#pragma unroll
+      for (int j = 0; j < N; ++j) xb[(size_t)P.T * N + (size_t)t * N + j] = (qs[IDX(t + 1, N, j)] - q0[j]) * inv_dt;
+    }
+  }
+  if (t == 0) {
+    if (f) f[b] = D.f_cur[b];
+    if (kkt) {
+      kkt[3 * (size_t)b + 0] = D.stat[b];
+      kkt[3 * (size_t)b + 1] = D.feas[b];
+      kkt[3 * (size_t)b + 2] = 0.0;  // no inequality rows in this family
+    }
+    if (iters) iters[b] = D.iters[b];
+    if (status) status[b] = (D.status[b] < 0) ? OH_STATUS_MAX_ITER : D.status[b];
+  }
+}
+
+// Least-squares multipliers at the solution, mapped to the reference's rows h = quat_c - quat(q_t)
+// (figure_eight_plan.py:105-107): stationarity reads G_t + Jc^T mu = 0 with Jc = Jw on the manifold and
+// dh/dq = -1/2 Ec Jw (Ec o = (o,0)(x)quat_c), hence nu = -2 Ec mu satisfies G_t + (dh/dq)^T nu = 0.
+template <int N>
+__global__ __launch_bounds__(256) void k_multipliers(FigParams P, FigBuffers D, double* __restrict__ lam_h) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  double* out = lam_h + ((size_t)b * P.T + t) * 4;
+  if (t < 2) {  // knots fixed by the linear rows: the quaternion rows are redundant there, multiplier 0
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    return;
+  }
+  const oh_chain* ch = D.chain;
+  const int cur = D.cur[b];
+  const double* __restrict__ qs = D.q[cur];
+  const double kap2 = 2.0 * P.kappa;
+  double q[N], G[N];
+  const bool last = (t == P.T - 1);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    q[k] = qs[IDX(t, N, k)];
+    G[k] = D.g[cur][IDX(t, N, k)] + kap2 * (q[k] - qs[IDX(t - 1, N, k)]);
+    if (!last) G[k] -= kap2 * (qs[IDX(t + 1, N, k)] - q[k]);
+  }
+  double R[9], p[3], z[N][3], pj[N][3];
+  fk_chain<N>(ch, q, R, p, z, pj);
+  double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
+  double rhs[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (ch->jtype[k] == 0) {
+      S[0] += z[k][0] * z[k][0];
+      S[1] += z[k][1] * z[k][0];
+      S[2] += z[k][1] * z[k][1];
+      S[3] += z[k][2] * z[k][0];
+      S[4] += z[k][2] * z[k][1];
+      S[5] += z[k][2] * z[k][2];
+      rhs[0] -= z[k][0] * G[k]; rhs[1] -= z[k][1] * G[k]; rhs[2] -= z[k][2] * G[k];
+    }
+  }
+  chol_packed<3>(S, 0.0);
+  fsub<3>(S, rhs);
+  bsub<3>(S, rhs);  // mu
+  // quat_c from the reference frame Rc is not stored; rebuild it with the chain product at qc = q_0
+  double qcv[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) qcv[k] = qs[IDX(0, N, k)];
+  double quat[4] = {0, 0, 0, 1};
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double qn[4];
+    qmul(quat, ch->quat0[k], qn);
+    if (ch->jtype[k] == 0) {
+      double sh, chh;
+      sincos(0.5 * qcv[k], &sh, &chh);
+      const double qa[4] = {sh * ch->axis[k][0], sh * ch->axis[k][1], sh * ch->axis[k][2], chh};
+      qmul(qn, qa, quat);
+    } else {
+      quat[0] = qn[0]; quat[1] = qn[1]; quat[2] = qn[2]; quat[3] = qn[3];
+    }
+  }
+  double qcq[4];
+  qmul(quat, ch->quat_tool, qcq);
+  const double o[4] = {rhs[0], rhs[1], rhs[2], 0.0};
+  double nu[4];
+  qmul(o, qcq, nu);
+  out[0] = -2.0 * nu[0]; out[1] = -2.0 * nu[1]; out[2] = -2.0 * nu[2]; out[3] = -2.0 * nu[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (called from oh_api.hip)
+// ---------------------------------------------------------------------------------------------
+void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n, const double* q, double* pose, double* J) {
+  const int threads = 256;
+  const int blocks = (n + threads - 1) / threads;
+  if (soa) hipLaunchKernelGGL(k_fk_jac<true>, dim3(blocks), dim3(threads), 0, s, d_chain, n, q, pose, J);
+  else hipLaunchKernelGGL(k_fk_jac<false>, dim3(blocks), dim3(threads), 0, s, d_chain, n, q, pose, J);
+}
+
+template <int N>
+static void launch_setup_t(hipStream_t s, const FigParams& P, const FigBuffers& D, const double* x0, const double* p) {
+  hipLaunchKernelGGL(k_setup<N>, dim3(D.Bp / 64), dim3(64), 0, s, P, D, x0, p);
+}
+template <int N>
+static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D) {
+  hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D);
+}
+template <int N>
+static void launch_step_t(hipStream_t s, const FigParams& P, const FigBuffers& D) {
+  hipLaunchKernelGGL(k_step<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D);
+}
+template <int N>
+static void launch_finalize_t(hipStream_t s, const FigParams& P, const FigBuffers& D, double* x, double* f, double* kkt, int* iters,
+                              int* status) {
+  hipLaunchKernelGGL(k_finalize<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, x, f, kkt, iters, status);
+}
+template <int N>
+static void launch_mult_t(hipStream_t s, const FigParams& P, const FigBuffers& D, double* lam_h) {
+  hipLaunchKernelGGL(k_multipliers<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, lam_h);
+}
+
+#define OH_DISPATCH_N(n, call)         \
+  switch (n) {                         \
+    case 6: call(6); break;            \
+    case 7: call(7); break;            \
+    default: return false;             \
+  }
+
+bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const double* x0, const double* p) {
+#define C(NN) launch_setup_t<NN>(s, P, D, x0, p)
+  OH_DISPATCH_N(n, C)
+#undef C
+  return true;
+}
+bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D) {
+#define C(NN) launch_eval_t<NN>(s, P, D)
+  OH_DISPATCH_N(n, C)
+#undef C
+  return true;
+}
+bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D) {
+#define C(NN) launch_step_t<NN>(s, P, D)
+  OH_DISPATCH_N(n, C)
+#undef C
+  return true;
+}
+bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, double* x, double* f, double* kkt, int* iters,
+                        int* status) {
+#define C(NN) launch_finalize_t<NN>(s, P, D, x, f, kkt, iters, status)
+  OH_DISPATCH_N(n, C)
+#undef C
+  return true;
+}
+bool oh_launch_multipliers(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, double* lam_h) {
+#define C(NN) launch_mult_t<NN>(s, P, D, lam_h)
+  OH_DISPATCH_N(n, C)
+#undef C
+  return true;
+}

@@ -1,0 +1,383 @@
+"""Host-side mirror of the reference's model classes (optas/models.py): ``Model``, ``TaskModel`` and
+``RobotModel`` with the same names, argument meaning and error behaviour for everything the hot path
+touches.  The reference builds CasADi SX graphs here; this mirror instead
+
+* keeps the joint bookkeeping (names, indexes, limits: models.py:332-550, 642-667) on the host,
+* folds the URDF chain into ``oh_chain`` constants (``kinematic_chain``), and
+* evaluates forward kinematics / Jacobians numerically through liboptas_hip (``oh_fk_jac``) -- there
+  is no CPU implementation behind these methods.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from .spatialmath import Quaternion, rpy2r, unit
+from .urdf import Joint, Link, RobotDescription, load_robot_description
+
+ROBOTS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "robots")
+
+
+class JointTypeNotSupported(NotImplementedError):
+    """Thrown for joint types other than fixed/revolute/continuous/prismatic (models.py:217-230)."""
+
+    def __init__(self, joint_type: str):
+        super().__init__(f"{joint_type} joints are currently not supported")
+
+
+class Model:
+    """models.py:79-186."""
+
+    def __init__(self, name: str, dim: int, time_derivs: List[int], symbol: str, dlim: Dict[int, Tuple], T: Optional[int]):
+        self.name = name
+        self.dim = dim
+        self.time_derivs = time_derivs
+        self.symbol = symbol
+        self.dlim = dlim
+        self.T = T
+
+    def get_name(self) -> str:
+        return self.name
+
+    def _check_deriv(self, time_deriv: int) -> None:
+        assert (
+            time_deriv in self.time_derivs
+        ), f"Given time derivative time_deriv={time_deriv} is not recognized, only allowed {self.time_derivs}"
+
+    def state_name(self, time_deriv: int) -> str:
+        self._check_deriv(time_deriv)
+        return self.name + "/" + "d" * time_deriv + self.symbol
+
+    def state_parameter_name(self, time_deriv: int) -> str:
+        self._check_deriv(time_deriv)
+        return self.name + "/" + "d" * time_deriv + self.symbol + "/" + "p"
+
+    def state_optimized_name(self, time_deriv: int) -> str:
+        self._check_deriv(time_deriv)
+        return self.name + "/" + "d" * time_deriv + self.symbol + "/" + "x"
+
+    def get_limits(self, time_deriv: int):
+        self._check_deriv(time_deriv)
+        assert time_deriv in self.dlim.keys(), f"Limit for time derivative time_deriv={time_deriv} has not been given"
+        return self.dlim[time_deriv]
+
+    def in_limit(self, x, time_deriv: int) -> bool:
+        lo, up = self.get_limits(time_deriv)
+        x = np.asarray(x, dtype=np.float64).reshape(len(lo), -1)
+        return bool(np.all((lo.reshape(-1, 1) <= x) & (x <= up.reshape(-1, 1))))
+
+
+class TaskModel(Model):
+    """models.py:189-214."""
+
+    def __init__(self, name, dim, time_derivs=[0], symbol="y", dlim={}, T=None, is_discrete=False):
+        super().__init__(name, dim, time_derivs, symbol, dlim, T)
+        self.is_discrete = is_discrete
+
+
+class RobotModel(Model):
+    """models.py:233-321.  ``urdf_filename`` may be a URDF (XML) or a ``*.kin.json`` constants file;
+    xacro is not processed (no ``xacro`` in this environment): pass the expanded URDF instead."""
+
+    def __init__(
+        self,
+        urdf_filename: Optional[str] = None,
+        urdf_string: Optional[str] = None,
+        xacro_filename: Optional[str] = None,
+        name: Optional[str] = None,
+        time_derivs: List[int] = [0],
+        qddlim=None,
+        T: Optional[int] = None,
+        param_joints: List[str] = [],
+    ):
+        if xacro_filename is not None:
+            raise NotImplementedError("xacro processing is not available; expand the xacro to URDF first")
+        self.urdf: Optional[RobotDescription] = None
+        self.urdf_filename = None
+        self.urdf_string = None
+        if urdf_filename is not None:
+            self.urdf_filename = urdf_filename
+            self.urdf = load_robot_description(urdf_filename)
+        if urdf_string is not None:
+            self.urdf_string = urdf_string
+            self.urdf = RobotDescription.from_xml_string(urdf_string)
+        assert self.urdf is not None, "You need to supply a urdf, either through filename or as a string"
+        self.param_joints = param_joints
+        dlim = {
+            0: (self.lower_optimized_joint_limits, self.upper_optimized_joint_limits),
+            1: (-self.velocity_optimized_joint_limits, self.velocity_optimized_joint_limits),
+        }
+        if qddlim:
+            qddlim = np.asarray(qddlim, dtype=np.float64).reshape(-1)
+            if qddlim.shape[0] == 1:
+                qddlim = qddlim * np.ones(self.ndof)
+            assert qddlim.shape[0] == self.ndof, f"expected ddlim to have {self.ndof} elements"
+            dlim[2] = (-qddlim, qddlim)
+        if name is None:
+            name = self.urdf.name
+        super().__init__(name, self.ndof, time_derivs, "q", dlim, T)
+        self._fk_handles: Dict[str, "KinematicsHandle"] = {}
+
+    @staticmethod
+    def builtin(robot: str, **kwargs) -> "RobotModel":
+        """Robots shipped as kinematic constants: ``kuka_lwr``, ``med7``."""
+        return RobotModel(urdf_filename=os.path.join(ROBOTS_DIR, robot + ".kin.json"), **kwargs)
+
+    def get_urdf(self) -> RobotDescription:
+        return self.urdf
+
+    # ---- names / indexes (models.py:332-436) ------------------------------------------------------
+    @property
+    def joint_names(self) -> List[str]:
+        return [j.name for j in self.urdf.joints]
+
+    @property
+    def link_names(self) -> List[str]:
+        return [l.name for l in self.urdf.links]
+
+    @property
+    def actuated_joint_names(self) -> List[str]:
+        return [j.name for j in self.urdf.joints if j.type != "fixed"]
+
+    @property
+    def parameter_joint_names(self) -> List[str]:
+        return [j for j in self.actuated_joint_names if j in self.param_joints]
+
+    @property
+    def optimized_joint_names(self) -> List[str]:
+        return [j for j in self.actuated_joint_names if j not in self.parameter_joint_names]
+
+    @property
+    def optimized_joint_indexes(self) -> List[int]:
+        return [self.get_actuated_joint_index(j) for j in self.optimized_joint_names]
+
+    @property
+    def parameter_joint_indexes(self) -> List[int]:
+        return [self.get_actuated_joint_index(j) for j in self.parameter_joint_names]
+
+    @property
+    def ndof(self) -> int:
+        return len(self.actuated_joint_names)
+
+    @property
+    def num_opt_joints(self) -> int:
+        return len(self.optimized_joint_names)
+
+    @property
+    def num_param_joints(self) -> int:
+        return len(self.parameter_joint_names)
+
+    def get_actuated_joint_index(self, joint_name: str) -> int:
+        return self.actuated_joint_names.index(joint_name)
+
+    # ---- limits (models.py:438-550) ---------------------------------------------------------------
+    @staticmethod
+    def get_joint_lower_limit(joint: Joint) -> float:
+        return -1e9 if joint.limit is None else joint.limit.lower
+
+    @staticmethod
+    def get_joint_upper_limit(joint: Joint) -> float:
+        return 1e9 if joint.limit is None else joint.limit.upper
+
+    @staticmethod
+    def get_velocity_joint_limit(joint: Joint) -> float:
+        return 1e9 if joint.limit is None else joint.limit.velocity
+
+    def _limits(self, getter, names) -> np.ndarray:
+        return np.array([getter(j) for j in self.urdf.joints if j.name in names], dtype=np.float64)
+
+    @property
+    def lower_actuated_joint_limits(self) -> np.ndarray:
+        return self._limits(self.get_joint_lower_limit, self.actuated_joint_names)
+
+    @property
+    def upper_actuated_joint_limits(self) -> np.ndarray:
+        return self._limits(self.get_joint_upper_limit, self.actuated_joint_names)
+
+    @property
+    def velocity_actuated_joint_limits(self) -> np.ndarray:
+        return self._limits(self.get_velocity_joint_limit, self.actuated_joint_names)
+
+    @property
+    def lower_optimized_joint_limits(self) -> np.ndarray:
+        return self._limits(self.get_joint_lower_limit, self.optimized_joint_names)
+
+    @property
+    def upper_optimized_joint_limits(self) -> np.ndarray:
+        return self._limits(self.get_joint_upper_limit, self.optimized_joint_names)
+
+    @property
+    def velocity_optimized_joint_limits(self) -> np.ndarray:
+        return self._limits(self.get_velocity_joint_limit, self.optimized_joint_names)
+
+    def extract_parameter_dimensions(self, values):
+        return np.asarray(values)[self.parameter_joint_indexes, :]
+
+    def extract_optimized_dimensions(self, values):
+        return np.asarray(values)[self.optimized_joint_indexes, :]
+
+    # ---- tree (models.py:552-667) -----------------------------------------------------------------
+    def add_base_frame(self, base_link: str, xyz=None, rpy=None, joint_name: Optional[str] = None) -> None:
+        child_link = self.urdf.get_root()
+        xyz = [0.0] * 3 if xyz is None else [float(v) for v in xyz]
+        rpy = [0.0] * 3 if rpy is None else [float(v) for v in rpy]
+        if not isinstance(joint_name, str):
+            joint_name = base_link + "_and_" + child_link + "_joint"
+        self.urdf.add_link(Link(name=base_link))
+        self.urdf.add_joint(Joint(name=joint_name, type="fixed", parent=base_link, child=child_link, xyz=xyz, rpy=rpy))
+        self._fk_handles.clear()
+
+    def get_root_link(self) -> str:
+        return self.urdf.get_root()
+
+    @staticmethod
+    def get_joint_origin(joint: Joint) -> Tuple[np.ndarray, np.ndarray]:
+        if joint.xyz is None:
+            return np.zeros(3), np.zeros(3)
+        return np.array(joint.xyz, dtype=np.float64), np.array(joint.rpy, dtype=np.float64)
+
+    @staticmethod
+    def get_joint_axis(joint: Joint) -> np.ndarray:
+        return unit(joint.axis if joint.axis is not None else [1.0, 0.0, 0.0])
+
+    # ---- lowering: URDF chain -> oh_chain ---------------------------------------------------------
+    def kinematic_chain(self, link: str) -> _lib.oh_chain:
+        """Fold root->link into per-actuated-joint constants (fixed joints multiplied into the next
+        actuated joint's pre-transform; trailing fixed joints into the tool transform), in the order
+        get_global_link_transform (models.py:846-866) walks them."""
+        assert link in self.urdf.link_map.keys(), f"given link '{link}' does not appear in URDF"
+        root = self.urdf.get_root()
+        ch = _lib.oh_chain()
+        ch.ndof = self.ndof
+        R_acc, p_acc = np.eye(3), np.zeros(3)
+        quat_acc = Quaternion(0.0, 0.0, 0.0, 1.0)
+        k = 0
+        jmap = self.urdf.joint_map
+        names = self.urdf.get_chain(root, link, links=False) if link != root else []
+        for name in names:
+            joint = jmap[name]
+            xyz, rpy = self.get_joint_origin(joint)
+            p_acc = p_acc + R_acc @ xyz
+            R_acc = R_acc @ rpy2r(rpy)
+            quat_acc = Quaternion.fromrpy(rpy) * quat_acc
+            if joint.type == "fixed":
+                continue
+            if joint.type in ("revolute", "continuous"):
+                jt = 0
+            elif joint.type == "prismatic":
+                jt = 1
+            else:
+                raise JointTypeNotSupported(joint.type)
+            if k >= _lib.OH_MAX_CHAIN:
+                raise ValueError(f"chain to '{link}' has more than {_lib.OH_MAX_CHAIN} actuated joints")
+            ch.jtype[k] = jt
+            ch.qidx[k] = self.get_actuated_joint_index(joint.name)
+            axis = self.get_joint_axis(joint)
+            for i in range(9):
+                ch.R0[k][i] = float(R_acc.reshape(-1)[i])
+            for i in range(3):
+                ch.p0[k][i] = float(p_acc[i])
+                ch.axis[k][i] = float(axis[i])
+            qv = quat_acc.getquat()
+            for i in range(4):
+                ch.quat0[k][i] = float(qv[i])
+            R_acc, p_acc = np.eye(3), np.zeros(3)
+            quat_acc = Quaternion(0.0, 0.0, 0.0, 1.0)
+            k += 1
+        ch.n_chain = k
+        for i in range(9):
+            ch.R_tool[i] = float(R_acc.reshape(-1)[i])
+        for i in range(3):
+            ch.p_tool[i] = float(p_acc[i])
+        qv = quat_acc.getquat()
+        for i in range(4):
+            ch.quat_tool[i] = float(qv[i])
+        return ch
+
+    # ---- numeric kinematics through the HIP library -------------------------------------------------
+    def _kin(self, link: str) -> "KinematicsHandle":
+        h = self._fk_handles.get(link)
+        if h is None:
+            h = KinematicsHandle(self.kinematic_chain(link))
+            self._fk_handles[link] = h
+        return h
+
+    def _q_cols(self, q) -> np.ndarray:
+        a = np.asarray(q, dtype=np.float64)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        assert a.shape[0] == self.ndof, f"expected {self.ndof} rows, got {a.shape[0]}"
+        return a
+
+    def get_global_link_position(self, link: str, q) -> np.ndarray:
+        """models.py:924-933; q is ndof or ndof-by-n (columns = joint states, like the reference)."""
+        Q = self._q_cols(q)
+        pose, _ = self._kin(link).fk_jac(Q.T, want_jac=False)
+        out = pose[:, :3].T
+        return out[:, 0] if np.asarray(q).ndim == 1 else out
+
+    def get_global_link_quaternion(self, link: str, q) -> np.ndarray:
+        """models.py:1049-1088 (xyzw, the reference's sign)."""
+        Q = self._q_cols(q)
+        pose, _ = self._kin(link).fk_jac(Q.T, want_jac=False)
+        out = pose[:, 3:].T
+        return out[:, 0] if np.asarray(q).ndim == 1 else out
+
+    def get_global_link_geometric_jacobian(self, link: str, q):
+        """models.py:1199-1264: 6 x ndof (a list of them for a trajectory)."""
+        Q = self._q_cols(q)
+        _, J = self._kin(link).fk_jac(Q.T, want_pose=False)
+        return J[0] if np.asarray(q).ndim == 1 else [J[i] for i in range(J.shape[0])]
+
+    def get_global_link_linear_jacobian(self, link: str, q):
+        J = self.get_global_link_geometric_jacobian(link, q)
+        return J[:3] if isinstance(J, np.ndarray) else [j[:3] for j in J]
+
+    def get_global_link_angular_geometric_jacobian(self, link: str, q):
+        J = self.get_global_link_geometric_jacobian(link, q)
+        return J[3:] if isinstance(J, np.ndarray) else [j[3:] for j in J]
+
+    def get_global_link_position_function(self, link: str, n: int = 1, numpy_output: bool = True):
+        """models.py:935-947: callable on an ndof-by-n array -> 3-by-n."""
+        return lambda Q: self.get_global_link_position(link, np.asarray(Q, dtype=np.float64).reshape(self.ndof, -1))
+
+    def get_global_link_quaternion_function(self, link: str, n: int = 1, numpy_output: bool = True):
+        return lambda Q: self.get_global_link_quaternion(link, np.asarray(Q, dtype=np.float64).reshape(self.ndof, -1))
+
+    def get_global_link_geometric_jacobian_function(self, link: str, n: int = 1, numpy_output: bool = True):
+        return lambda Q: self.get_global_link_geometric_jacobian(link, np.asarray(Q, dtype=np.float64).reshape(self.ndof, -1))
+
+
+class KinematicsHandle:
+    """A liboptas_hip handle used only for oh_fk_jac on one chain."""
+
+    def __init__(self, chain: _lib.oh_chain):
+        import ctypes as C
+
+        lib = _lib.load()
+        self.chain = chain
+        desc = _lib.oh_problem_desc(kind=_lib.OH_PROBLEM_KINEMATICS, ndof=chain.ndof)
+        self._h = C.c_void_p()
+        _lib.check(lib.oh_create(C.byref(desc), C.byref(self._h)), "oh_create")
+        _lib.check(lib.oh_set_constants(self._h, C.byref(chain)), "oh_set_constants")
+
+    def fk_jac(self, Q: np.ndarray, want_pose: bool = True, want_jac: bool = True):
+        """Q: n-by-ndof (row = one joint state, the ABI layout)."""
+        lib = _lib.load()
+        Q = _lib.as_f64(Q)
+        n, ndof = Q.shape
+        pose = np.empty((n, 7)) if want_pose else None
+        J = np.empty((n, 6, ndof)) if want_jac else None
+        _lib.check(lib.oh_fk_jac(self._h, n, _lib._ptr(Q), _lib._ptr(pose), _lib._ptr(J)), "oh_fk_jac")
+        return pose, J
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().oh_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -1,0 +1,265 @@
+"""ORACLE (test infrastructure, not product code) -- the reference's example problems restated as
+numpy NLPs in the reference's own x / p / v layout.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+
+Each class mirrors what ``OptimizationBuilder.build()`` hands to a ``Solver``
+(optas/optimization.py:54-309): ``nx, np, nk, na, ng, nh, nv`` and callables ``f, df, k, a, g, h, v, dv``
+of ``(x, p)`` with
+
+  * x = SXContainer.vec() of the decision variables, blocks in creation order, each block
+    column-major (sx_container.py:83-89; builder.py:90-99),
+  * every constraint stored as ``rhs - lhs`` (builder.py:313,354),
+  * v = [k; g; a; -a; h; -h] >= 0 (optimization.py:27-51,292-306).
+
+The reference obtains derivatives by CasADi AD (optimization.py:8-24); here they are analytic and
+finite-difference-checked in tests/test_oracle_problems.py.  PARITY UNPINNED at the solve level: the
+reference holds no golden solution for these KUKA problems (tests/test_examples.py checks the exit code
+only); what *is* pinned is listed in DESIGN.md.
+"""
+import numpy as np
+
+from .robot import OracleRobot
+
+
+def _hamilton_left_pure(o, quat):
+    """(ox,oy,oz,0) (x) quat, xyzw storage."""
+    ox, oy, oz = o
+    x, y, z, w = quat
+    return np.array(
+        [
+            ox * w + oy * z - oz * y,
+            -ox * z + oy * w + oz * x,
+            ox * y - oy * x + oz * w,
+            -ox * x - oy * y - oz * z,
+        ]
+    )
+
+
+class _NLPBase:
+    nk = na = ng = nh = 0
+
+    @property
+    def nv(self):  # optimization.py:301
+        return self.nk + self.ng + 2 * self.na + 2 * self.nh
+
+    # default empty blocks
+    def k(self, x, p):
+        return np.zeros(0)
+
+    def dk(self, x, p):
+        return np.zeros((0, self.nx))
+
+    def a(self, x, p):
+        return np.zeros(0)
+
+    def da(self, x, p):
+        return np.zeros((0, self.nx))
+
+    def g(self, x, p):
+        return np.zeros(0)
+
+    def dg(self, x, p):
+        return np.zeros((0, self.nx))
+
+    def h(self, x, p):
+        return np.zeros(0)
+
+    def dh(self, x, p):
+        return np.zeros((0, self.nx))
+
+    def v(self, x, p):  # optimization.py:47-51
+        a, h = self.a(x, p), self.h(x, p)
+        return np.concatenate([self.k(x, p), self.g(x, p), a, -a, h, -h])
+
+    def dv(self, x, p):
+        da, dh = self.da(x, p), self.dh(x, p)
+        return np.concatenate([self.dk(x, p), self.dg(x, p), da, -da, dh, -dh], axis=0)
+
+
+class BoothNLP(_NLPBase):
+    """tests/test_solver.py:19-54: f=(x+a*y-b)^2+(2x+y-5)^2, p=(a,b); known answer (1,3) at (2,7)."""
+
+    nx, np_ = 2, 2
+
+    def f(self, x, p):
+        return (x[0] + p[0] * x[1] - p[1]) ** 2 + (2.0 * x[0] + x[1] - 5.0) ** 2
+
+    def df(self, x, p):
+        r1 = x[0] + p[0] * x[1] - p[1]
+        r2 = 2.0 * x[0] + x[1] - 5.0
+        return np.array([2 * r1 + 4 * r2, 2 * p[0] * r1 + 2 * r2])
+
+    def ddf(self, x, p):
+        return np.array([[2 + 8.0, 2 * p[0] + 4.0], [2 * p[0] + 4.0, 2 * p[0] ** 2 + 2.0]])
+
+
+class IKExampleNLP(_NLPBase):
+    """example/example.py:13-60 (BASELINE config 1).
+
+    x = "kuka/q/x" (7x1); p = ["kuka/q/p" (0 rows); "q_nominal"(7); "p_goal"(3)];
+    f = ||q-qn||^2 (:30); h = p_goal - p_ee(q) (:26 with builder.py:354); k = [q-lo; up-q]
+    (:33, builder.py:334-335,509).  Class QuadraticCostNonlinearConstraints.
+    """
+
+    def __init__(self, robot: OracleRobot, link="end_effector_ball"):
+        self.robot, self.link = robot, link
+        self.n = robot.ndof
+        self.nx, self.np_ = self.n, self.n + 3
+        self.nk, self.nh = 2 * self.n, 3
+        self.lo = robot.lower_actuated_joint_limits
+        self.up = robot.upper_actuated_joint_limits
+
+    def f(self, x, p):
+        return float(np.sum((x - p[: self.n]) ** 2))
+
+    def df(self, x, p):
+        return 2.0 * (x - p[: self.n])
+
+    def ddf(self, x, p):
+        return 2.0 * np.eye(self.n)
+
+    def k(self, x, p):
+        return np.concatenate([x - self.lo, self.up - x])
+
+    def dk(self, x, p):
+        return np.concatenate([np.eye(self.n), -np.eye(self.n)], axis=0)
+
+    def h(self, x, p):
+        return p[self.n :] - self.robot.get_global_link_position(self.link, x)
+
+    def dh(self, x, p):
+        return -self.robot.get_global_link_linear_jacobian(self.link, x)
+
+
+class FigureEightNLP(_NLPBase):
+    """example/figure_eight_plan.py:16-113 (BASELINE config 2).
+
+    x = ["{name}/q/x" (ndof x T); "{name}/dq/x" (ndof x (T-1))]  (builder.py:90-99)
+    p = ["{name}/q/p" (0); "{name}/dq/p" (0); "qc" (ndof)]         (:59-61)
+    a = [ qc - q_0 ;  0 - dq_0 ;  -(q_t + dt*dq_t - q_{t+1}) t=0..T-2 ]   (:64-75, builder.py:437,469,354)
+    h = quat_c - quat(q_t), t=0..T-1, 4 rows each                          (:105-107)
+    f = 1000*sum_t ||path_t - p_ee(q_t)||^2 + 0.01*sum ||dQ||^2            (:99,103)
+    path_t = p(qc) + R(qc) @ (0.2 sin(pi/2 t_s), 0.1 sin(pi t_s), 0), t_s = linspace(0,Tmax,T) (:34-37,90-96)
+    """
+
+    def __init__(self, robot: OracleRobot, link, T=50, Tmax=10.0, w_path=1000.0, w_vel=0.01):
+        self.robot, self.link, self.T, self.Tmax = robot, link, T, Tmax
+        self.w_path, self.w_vel = w_path, w_vel
+        self.n = n = robot.ndof
+        ts = np.linspace(0.0, Tmax, T)
+        self.ts = ts
+        self.dt = float(ts[1] - ts[0])
+        self.local_path = np.stack([0.2 * np.sin(ts * np.pi * 0.5), 0.1 * np.sin(ts * np.pi), np.zeros(T)])
+        self.nq = n * T
+        self.ndq = n * (T - 1)
+        self.nx = self.nq + self.ndq
+        self.np_ = n
+        self.na = 2 * n + n * (T - 1)
+        self.nh = 4 * T
+        # constant Jacobian of the linear equalities
+        A = np.zeros((self.na, self.nx))
+        I = np.eye(n)
+        A[0:n, 0:n] = -I  # qc - q_0
+        A[n : 2 * n, self.nq : self.nq + n] = -I  # 0 - dq_0
+        for t in range(T - 1):
+            r = 2 * n + n * t
+            A[r : r + n, n * t : n * t + n] = -I
+            A[r : r + n, self.nq + n * t : self.nq + n * t + n] = -self.dt * I
+            A[r : r + n, n * (t + 1) : n * (t + 1) + n] = I
+        self._A = A
+
+    # -- layout helpers -------------------------------------------------------------------------------
+    def split(self, x):
+        n, T = self.n, self.T
+        Q = x[: self.nq].reshape(T, n).T  # column-major vec of (n x T)
+        dQ = x[self.nq :].reshape(T - 1, n).T
+        return Q, dQ
+
+    def join(self, Q, dQ):
+        return np.concatenate([Q.T.reshape(-1), dQ.T.reshape(-1)])
+
+    def seed(self, qc):
+        """Planner.reset (:117-124): Q0 = qc repeated, dQ0 = 0 (missing key zero-filled, sx_container.py:121)."""
+        return self.join(np.tile(np.asarray(qc, float).reshape(-1, 1), (1, self.T)), np.zeros((self.n, self.T - 1)))
+
+    def references(self, p):
+        qc = p
+        pc = self.robot.get_global_link_position(self.link, qc)
+        Rc = self.robot.get_global_link_rotation(self.link, qc)
+        quatc = self.robot.get_global_link_quaternion(self.link, qc)
+        path = pc.reshape(3, 1) + Rc @ self.local_path
+        return path, quatc
+
+    # -- cost ---------------------------------------------------------------------------------------------
+    def f(self, x, p):
+        Q, dQ = self.split(x)
+        path, _ = self.references(p)
+        pos = self.robot.map_position(self.link, Q)
+        return float(self.w_path * np.sum((path - pos) ** 2) + self.w_vel * np.sum(dQ**2))
+
+    def df(self, x, p):
+        Q, dQ = self.split(x)
+        path, _ = self.references(p)
+        gq = np.zeros((self.n, self.T))
+        for t in range(self.T):
+            Jp = self.robot.get_global_link_linear_jacobian(self.link, Q[:, t])
+            r = path[:, t] - self.robot.get_global_link_position(self.link, Q[:, t])
+            gq[:, t] = -2.0 * self.w_path * (Jp.T @ r)
+        return self.join(gq, 2.0 * self.w_vel * dQ)
+
+    # -- constraints -----------------------------------------------------------------------------------
+    def a(self, x, p):
+        b = np.zeros(self.na)
+        b[: self.n] = p
+        return self._A @ x + b
+
+    def da(self, x, p):
+        return self._A
+
+    def h(self, x, p):
+        Q, _ = self.split(x)
+        _, quatc = self.references(p)
+        return (quatc.reshape(4, 1) - self.robot.map_quaternion(self.link, Q)).T.reshape(-1)
+
+    def dh(self, x, p):
+        Q, _ = self.split(x)
+        J = np.zeros((self.nh, self.nx))
+        for t in range(self.T):
+            J[4 * t : 4 * t + 4, self.n * t : self.n * t + self.n] = -self.robot.quaternion_jacobian(self.link, Q[:, t])
+        return J
+
+    # -- second-order information (not a reference callable for the IPOPT path: CasADi derives
+    #    nlp_hess_l by AD; restated analytically, FD-checked in tests) --------------------------------------
+    def hess_lagrangian(self, x, p, lam_h, gauss_newton=False):
+        """Hessian wrt x of  f(x) + lam_h . h(x)   (linear rows have none)."""
+        Q, dQ = self.split(x)
+        path, quatc = self.references(p)
+        n, T = self.n, self.T
+        H = np.zeros((self.nx, self.nx))
+        for t in range(T):
+            q = Q[:, t]
+            J = self.robot.get_global_link_geometric_jacobian(self.link, q)
+            Jp, Jw = J[:3], J[3:]
+            W = 2.0 * self.w_path * (Jp.T @ Jp)
+            if not gauss_newton:
+                r = path[:, t] - self.robot.get_global_link_position(self.link, q)
+                quat = self.robot.get_global_link_quaternion(self.link, q)
+                lam = lam_h[4 * t : 4 * t + 4]
+                for i in range(n):
+                    for j in range(i, n):
+                        # d2 p / dqi dqj = z_i x (z_j x (e - p_j)) = z_i x Jp_j   (i <= j, revolute)
+                        d2p = np.cross(Jw[:, i], Jp[:, j])
+                        val = -2.0 * self.w_path * float(r @ d2p)
+                        # d2 quat/dqi dqj = 1/2 (dz_j/dq_i,0)(x)quat + 1/4 (z_j,0)(x)(z_i,0)(x)quat, dz_j/dq_i = z_i x z_j (i<j)
+                        dz = np.cross(Jw[:, i], Jw[:, j]) if i < j else np.zeros(3)
+                        d2quat = 0.5 * _hamilton_left_pure(dz, quat) + 0.25 * _hamilton_left_pure(
+                            Jw[:, j], _hamilton_left_pure(Jw[:, i], quat)
+                        )
+                        val += float(lam @ (-d2quat))  # h = quatc - quat
+                        W[i, j] += val
+                        if j != i:
+                            W[j, i] += val
+            H[n * t : n * t + n, n * t : n * t + n] = W
+        H[self.nq :, self.nq :] = 2.0 * self.w_vel * np.eye(self.ndq)
+        return H

@@ -1,0 +1,251 @@
+"""ORACLE (test infrastructure, not product code) -- numpy port of the *structured* algorithm the HIP
+path runs for the figure-eight family (velocity-condensed, per-knot null-space, block-tridiagonal
+Cholesky == Riccati sweep).  Used (a) to check the HIP kernels stage-by-stage and end-to-end and (b) as
+the "port" CPU baseline in bench.py.  Independent cross-check of its answers: oracle/solvers.dense_sqp
+and kkt_reference_form on the literal reference layout.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+
+Problem (SURVEY App. B.2 / example/figure_eight_plan.py:64-107), after eliminating the linear rows:
+  q_0 = q_1 = qc (fix_configuration + zero initial velocity + Euler integration, builder.py:437,525-539),
+  dq_t = (q_{t+1}-q_t)/dt,
+  min_{q_2..q_{T-1}}  sum_t w_p ||path_t - p(q_t)||^2 + (w_v/dt^2) sum_{t=1}^{T-2} ||q_{t+1}-q_t||^2
+  s.t. R(q_t) = R(qc)   (same feasible set as quat(q_t) = quat_c on the connected branch).
+"""
+import numpy as np
+
+from .robot import OracleRobot
+from .spatialmath import rpy2r, unit
+
+
+class FoldedChain:
+    """Per-actuated-joint constants with fixed joints folded in (what oh_set_constants receives)."""
+
+    def __init__(self, robot: OracleRobot, link: str):
+        root = robot.get_root()
+        R_acc, p_acc = np.eye(3), np.zeros(3)
+        self.R0, self.p0, self.axis, self.jtype, self.qidx = [], [], [], [], []
+        for name in robot.get_chain(root, link):
+            j = robot.joint_map[name]
+            xyz, rpy = robot.get_joint_origin(j)
+            Rj = rpy2r(rpy)
+            p_acc = p_acc + R_acc @ xyz
+            R_acc = R_acc @ Rj
+            if j.type == "fixed":
+                continue
+            self.R0.append(R_acc)
+            self.p0.append(p_acc)
+            self.axis.append(robot.get_joint_axis(j))
+            self.jtype.append(0 if j.type in {"revolute", "continuous"} else 1)
+            self.qidx.append(robot.get_actuated_joint_index(j.name))
+            R_acc, p_acc = np.eye(3), np.zeros(3)
+        self.R_tool, self.p_tool = R_acc, p_acc
+        self.n_chain = len(self.R0)
+        self.ndof = robot.ndof
+
+    def fk(self, Q):
+        """Q: (N, ndof).  Returns e (N,3), R (N,3,3), z (N,nc,3), pj (N,nc,3)."""
+        Q = np.atleast_2d(Q)
+        N = Q.shape[0]
+        R = np.tile(np.eye(3), (N, 1, 1))
+        p = np.zeros((N, 3))
+        zs, ps = [], []
+        for k in range(self.n_chain):
+            p = p + R @ self.p0[k]
+            R = R @ self.R0[k]
+            a = self.axis[k]
+            qk = Q[:, self.qidx[k]]
+            z = R @ a
+            if self.jtype[k] == 0:
+                K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0.0]])
+                Rq = np.eye(3)[None] + np.sin(qk)[:, None, None] * K[None] + (1 - np.cos(qk))[:, None, None] * (K @ K)[None]
+                R = R @ Rq
+                ps.append(p.copy())
+            else:
+                ps.append(p.copy())
+                p = p + z * qk[:, None]
+            zs.append(z)
+        e = p + R @ self.p_tool
+        Re = R @ self.R_tool
+        return e, Re, np.stack(zs, 1), np.stack(ps, 1)
+
+    def jac(self, Q):
+        e, Re, z, pj = self.fk(Q)
+        N = e.shape[0]
+        Jp = np.zeros((N, 3, self.ndof))
+        Jw = np.zeros((N, 3, self.ndof))
+        for k in range(self.n_chain):
+            c = self.qidx[k]
+            if self.jtype[k] == 0:
+                Jp[:, :, c] = np.cross(z[:, k], e - pj[:, k])
+                Jw[:, :, c] = z[:, k]
+            else:
+                Jp[:, :, c] = z[:, k]
+        return e, Re, Jp, Jw
+
+
+def _vee_skew(A):
+    return 0.5 * np.stack([A[:, 2, 1] - A[:, 1, 2], A[:, 0, 2] - A[:, 2, 0], A[:, 1, 0] - A[:, 0, 1]], 1)
+
+
+class StructuredFigureEight:
+    def __init__(self, robot, link, T=50, Tmax=10.0, w_path=1000.0, w_vel=0.01):
+        self.chain = FoldedChain(robot, link)
+        self.T, self.n = T, robot.ndof
+        ts = np.linspace(0.0, Tmax, T)
+        self.dt = float(ts[1] - ts[0])
+        self.local_path = np.stack([0.2 * np.sin(ts * np.pi * 0.5), 0.1 * np.sin(ts * np.pi), np.zeros(T)], 1)  # (T,3)
+        self.w_path, self.w_vel = w_path, w_vel
+        self.kappa = w_vel / self.dt**2
+
+    def references(self, qc):
+        e, Re, _, _ = self.chain.fk(qc[None])
+        return e[0] + self.local_path @ Re[0].T, Re[0]
+
+    def evaluate(self, Q, path, Rc, lam=None, exact=False):
+        """Stage quantities at knots Q (T,n): cost pieces, gradient, Hessian blocks, constraint, Jacobian."""
+        e, Re, Jp, Jw = self.chain.jac(Q)
+        r = path - e
+        phi = self.w_path * np.sum(r * r, 1)
+        g = -2.0 * self.w_path * np.einsum("tki,tk->ti", Jp, r)
+        W = 2.0 * self.w_path * np.einsum("tki,tkj->tij", Jp, Jp)
+        A = Re @ Rc.T
+        c = _vee_skew(A)
+        trA = np.trace(A, axis1=1, axis2=2)
+        M = 0.5 * (trA[:, None, None] * np.eye(3)[None] - A)
+        Jc = M @ Jw
+        if exact:
+            n = self.n
+            # -2 w_p sum_k r_k d2p_k/dqi dqj ,  d2p/dqi dqj = z_i x Jp_j (i<=j)
+            zr = np.cross(r[:, None, :], np.swapaxes(Jw, 1, 2))  # (T,n,3) = r x z_i
+            S = np.einsum("tik,tkj->tij", zr, Jp)  # (r x z_i) . Jp_j
+            S = np.triu(S) + np.swapaxes(np.triu(S, 1), 1, 2)
+            W = W - 2.0 * self.w_path * S
+            if lam is not None:
+                # lam . d2c/dqi dqj  ~  1/2 lam . (z_i x z_j)  (i<j), exact at feasible points
+                zz = np.cross(np.swapaxes(Jw, 1, 2)[:, :, None, :], np.swapaxes(Jw, 1, 2)[:, None, :, :])  # (T,n,n,3)
+                C = 0.5 * np.einsum("tijk,tk->tij", zz, lam)
+                C = np.triu(C, 1)
+                W = W + C + np.swapaxes(C, 1, 2)
+        return phi, g, W, c, Jc
+
+    def smooth_cost(self, Q):
+        d = Q[2:] - Q[1:-1]
+        return self.kappa * np.sum(d * d)
+
+    def objective(self, Q, path):
+        e, _, _, _ = self.chain.fk(Q)
+        return self.w_path * np.sum((path - e) ** 2) + self.smooth_cost(Q)
+
+
+def block_tridiag_solve(D, E, rhs, shift=0.0):
+    """Solve K x = rhs, K = blocktridiag(E_{t-1}^T, D_t, E_t) SPD, by block Cholesky (the Riccati sweep).
+    D: (N,m,m), E: (N-1,m,m) with K[t,t+1] = E[t].  Returns (x, ok)."""
+    N, m = D.shape[0], D.shape[1]
+    L = np.zeros_like(D)
+    Fm = np.zeros_like(E)  # F_t = K[t+1,t] L_t^{-T}
+    y = np.zeros_like(rhs)
+    S = D[0] + shift * np.eye(m)
+    for t in range(N):
+        try:
+            L[t] = np.linalg.cholesky(S)
+        except np.linalg.LinAlgError:
+            return None, False
+        y[t] = np.linalg.solve(L[t], rhs[t] - (Fm[t - 1] @ y[t - 1] if t > 0 else 0.0))
+        if t < N - 1:
+            Fm[t] = np.linalg.solve(L[t], E[t]).T
+            S = D[t + 1] + shift * np.eye(m) - Fm[t] @ Fm[t].T
+    x = np.zeros_like(rhs)
+    for t in range(N - 1, -1, -1):
+        x[t] = np.linalg.solve(L[t].T, y[t] - (Fm[t].T @ x[t + 1] if t < N - 1 else 0.0))
+    return x, True
+
+
+def solve_structured(prob: StructuredFigureEight, qc, Q0=None, max_iter=60, tol=1e-9, exact=True, verbose=False):
+    T, n = prob.T, prob.n
+    path, Rc = prob.references(qc)
+    Q = np.tile(qc, (T, 1)) if Q0 is None else Q0.copy()
+    Q[0] = qc
+    Q[1] = qc
+    kap = prob.kappa
+    lam = np.zeros((T, 3))
+    nu = 1.0
+    hist = []
+    F = slice(2, T)  # free knots
+    nf = T - 2
+    for it in range(max_iter + 1):
+        phi, g, W, c, Jc = prob.evaluate(Q, path, Rc, lam=lam, exact=exact)
+        # smoothness gradient on free knots
+        Gs = np.zeros((T, n))
+        d = Q[2:] - Q[1:-1]  # Delta_t, t=1..T-2
+        Gs[2:] += 2 * kap * d
+        Gs[1:-1] -= 2 * kap * d
+        G = g + Gs
+        ndiag = np.full(T, 2.0)
+        ndiag[T - 1] = 1.0
+        # null-space split per knot
+        Zs = np.zeros((T, n, n - 3))
+        Ys = np.zeros((T, n, 3))
+        Rf = np.zeros((T, 3, 3))
+        for t in range(2, T):
+            Qm, Rm = np.linalg.qr(Jc[t].T, mode="complete")
+            Ys[t], Zs[t], Rf[t] = Qm[:, :3], Qm[:, 3:], Rm[:3]
+        # particular step: Jc dq = -c  ->  dq_p = Y (R^T)^{-1} (-c)
+        npart = np.zeros((T, n))
+        for t in range(2, T):
+            npart[t] = Ys[t] @ np.linalg.solve(Rf[t].T, -c[t])
+        Dfull = W + (2 * kap * ndiag)[:, None, None] * np.eye(n)[None]
+        # multipliers estimate (least squares per knot): G + Jc^T lam = 0 on range(Y)
+        lam_ls = np.zeros((T, 3))
+        for t in range(2, T):
+            lam_ls[t] = np.linalg.solve(Rf[t], -Ys[t].T @ G[t])
+        stat = np.max(np.abs(np.einsum("tij,ti->tj", Zs[F], G[F])))
+        feas = np.max(np.abs(c[F]))
+        fval = float(np.sum(phi) + prob.smooth_cost(Q))
+        hist.append((it, fval, stat, feas))
+        if verbose:
+            print(f"  it {it:3d} f={fval:.12f} stat={stat:.3e} feas={feas:.3e}")
+        if (stat <= tol and feas <= tol) or it == max_iter:
+            lam = lam_ls
+            break
+        # reduced system
+        Hn = np.einsum("tij,tj->ti", Dfull, npart)
+        Hn[2:] += -2 * kap * np.concatenate([npart[3:], np.zeros((1, n))])  # coupling to t+1
+        Hn[3:] += -2 * kap * npart[2:-1]  # coupling to t-1
+        rhs = -np.einsum("tij,ti->tj", Zs[F], (G + Hn)[F])
+        Dr = np.einsum("tia,tij,tjb->tab", Zs[F], Dfull[F], Zs[F])
+        Er = -2 * kap * np.einsum("tia,tib->tab", Zs[2 : T - 1], Zs[3:T])
+        shift = 0.0
+        while True:
+            z, ok = block_tridiag_solve(Dr, Er, rhs, shift)
+            if ok:
+                break
+            shift = 1e-2 if shift == 0.0 else shift * 10.0
+        dq = npart.copy()
+        dq[F] += np.einsum("tia,ta->ti", Zs[F], z)
+        # multipliers of the QP: (G + H dq) + Jc^T lam_qp = 0
+        Hd = np.einsum("tij,tj->ti", Dfull, dq)
+        Hd[2:] += -2 * kap * np.concatenate([dq[3:], np.zeros((1, n))])
+        Hd[3:] += -2 * kap * dq[2:-1]
+        lam_qp = np.zeros((T, 3))
+        for t in range(2, T):
+            lam_qp[t] = np.linalg.solve(Rf[t], -Ys[t].T @ (G[t] + Hd[t]))
+        # l1 merit line search
+        nu = max(nu, 1.5 * np.max(np.abs(lam_qp)))
+        c1 = np.sum(np.abs(c[F]))
+        phi0 = fval + nu * c1
+        dphi = float(np.sum(G[F] * dq[F])) - nu * c1
+        alpha = 1.0
+        while True:
+            Qt = Q.copy()
+            Qt[F] += alpha * dq[F]
+            _, _, _, ct, _ = prob.evaluate(Qt, path, Rc)
+            ft = prob.objective(Qt, path)
+            if ft + nu * np.sum(np.abs(ct[F])) <= phi0 + 1e-4 * alpha * min(dphi, 0.0) or alpha < 1e-6:
+                break
+            alpha *= 0.5
+        if verbose:
+            print(f"        alpha={alpha:.4g} shift={shift:g} nu={nu:.3g} |dq|={np.max(np.abs(dq)):.3g}")
+        Q = Qt
+        lam = lam_qp
+    return {"Q": Q, "f": fval, "iters": it, "stat": stat, "feas": feas, "lam": lam, "history": hist, "path": path, "Rc": Rc}

@@ -1,0 +1,291 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X: MPC solves/sec, KUKA LWR 7-DoF figure-eight, T=50.
+
+  python bench.py --gpus 1 --steps 5 --warmup 1            (driver: N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W            (driver: N>1, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch: one batched NLP solve (oh_solve_device) of B
+independent instances per GPU, inputs (seeds x0, parameters qc) already resident in HBM.  Instances are
+SURVEY 8(d)'s synthetic set: qc = deg2rad[0,30,0,-90,0,-30,0] + U(-0.1,0.1)^7, seed = qc repeated,
+numpy default_rng(20260927 + rank).  Multi-GPU: instances shard across ranks with no data-path
+collective; the kinematic constants (oh_chain, 2696 B) are broadcast once over RCCL (torch.distributed
+"nccl" backend) from rank 0 and handed to the library as a device pointer.  torch is imported only
+when WORLD_SIZE > 1 (rendezvous, that one broadcast, barriers, MAX-reduce of the time).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import optas_amd  # noqa: E402
+from optas_amd import _lib  # noqa: E402
+from optas_amd.backend import FigureEightBackend  # noqa: E402
+
+T = 50
+TMAX = 10.0
+LINK = "end_effector_ball"
+QC0_DEG = [0, 30, 0, -90, 0, -30, 0]
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+# Algorithmic bytes per unit = (instance, free knot) per launch, f64:
+#   k_eval : read q(7) ; write q(7) Z(28) Dr(10) g(7) phi(1) cv(1)                       = 61 doubles
+#   k_step : read trial q(7) phi(1) cv(1) ; read cur q(7) g(7) Z(28) Dr(10) ;
+#            write+read gains K(16) k(4) ; read Z(28) again for the roll-out is NOT counted
+#            (same bytes) ; write trial q(7)                                                 = 108 doubles
+BYTES_EVAL = 61 * 8
+BYTES_STEP = 108 * 8
+BYTES_FKJAC = 448  # q 56 B in, pose 56 B + J 336 B out
+
+
+def make_inputs(B: int, rank: int):
+    rng = np.random.default_rng(20260927 + rank)
+    qc = np.deg2rad(QC0_DEG)[None, :] + rng.uniform(-0.1, 0.1, (B, 7))
+    x0 = np.concatenate([np.repeat(qc, T, axis=0).reshape(B, 7 * T), np.zeros((B, 7 * (T - 1)))], axis=1)
+    return x0, qc
+
+
+def local_path():
+    t = np.linspace(0.0, TMAX, T)
+    lp = np.zeros((T, 3))
+    lp[:, 0] = 0.2 * np.sin(t * np.pi * 0.5)
+    lp[:, 1] = 0.1 * np.sin(t * np.pi)
+    return float(t[1] - t[0]), lp
+
+
+def cpu_baseline(sample: int):
+    """The oracle's numpy port of the same structured SQP, timed on this box's host cores (1 thread)."""
+    from oracle.robot import OracleRobot
+    from oracle.structured import StructuredFigureEight, solve_structured
+
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    robot = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json"))
+    prob = StructuredFigureEight(robot, LINK, T=T, Tmax=TMAX)
+    _, qc = make_inputs(sample, 0)
+    solve_structured(prob, qc[0], max_iter=3, tol=1e-6, exact=False)  # warm-up (reference convention: one warm-up solve)
+    t0 = time.perf_counter()
+    its = []
+    for i in range(sample):
+        r = solve_structured(prob, qc[i], max_iter=300, tol=1e-6, exact=False)
+        its.append(r["iters"])
+        if time.perf_counter() - t0 > 30.0:
+            sample = i + 1
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": sample / dt,
+        "unit": "solves/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{sample} instances of the same workload (first of rank 0's batch), numpy port of the structured SQP "
+        f"(oracle/structured.py), tol 1e-6, mean {np.mean(its):.0f} iterations, {dt:.1f} s; host has {len(os.sched_getaffinity(0))} cores",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32768, help="instances per GPU per step")
+    ap.add_argument("--max-iter", type=int, default=300)
+    ap.add_argument("--tol", type=float, default=1e-6)
+    ap.add_argument("--cpu-sample", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fk-units", type=int, default=1 << 22)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist  # RCCL via the "nccl" backend
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    lib = _lib.load()
+    if _lib.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: liboptas_hip has no CPU path")
+    _lib.check(lib.oh_set_device(local_rank), "oh_set_device")
+
+    dt, lp = local_path()
+    robot = optas_amd.RobotModel.builtin("kuka_lwr")
+    chain = robot.kinematic_chain(LINK)
+    be = FigureEightBackend(chain, T, dt, lp, max_iter=args.max_iter, tol=args.tol)
+    if world > 1:
+        # the one collective of the whole job: kinematic constants, rank 0 -> all, over RCCL/xGMI
+        import torch
+
+        nbytes = C.sizeof(_lib.oh_chain)
+        buf = torch.zeros(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(bytes(chain)), dtype=torch.uint8))
+        dist.broadcast(buf, src=0)
+        torch.cuda.synchronize()
+        be.set_constants_device(buf.data_ptr(), nbytes)
+
+    B = args.batch
+    x0, qc = make_inputs(B, rank)
+    nx = x0.shape[1]
+    d_x0 = _lib.DeviceBuffer(x0.nbytes).upload(x0)
+    d_p = _lib.DeviceBuffer(qc.nbytes).upload(qc)
+    d_x = _lib.DeviceBuffer(x0.nbytes)
+    d_f = _lib.DeviceBuffer(B * 8)
+    d_k = _lib.DeviceBuffer(B * 24)
+    d_it = _lib.DeviceBuffer(B * 4)
+    d_st = _lib.DeviceBuffer(B * 4)
+
+    def sync_all():
+        _lib.check(lib.oh_device_synchronize(), "sync")
+        if dist is not None:
+            dist.barrier()
+            _lib.check(lib.oh_device_synchronize(), "sync")
+
+    be.set_profiling(True)
+    for _ in range(args.warmup):
+        be.solve_device(B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
+    sync_all()
+    t0 = time.perf_counter()
+    tm = {"eval_ms": 0.0, "step_ms": 0.0, "eval_launches": 0, "step_launches": 0, "instance_launches": 0, "solve_ms": 0.0}
+    for _ in range(args.steps):
+        be.solve_device(B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
+        t = be.timing()
+        for k in tm:
+            tm[k] += t[k]
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    status = d_st.download(np.int32, (B,))
+    iters = d_it.download(np.int32, (B,))
+    kkt = d_k.download(np.float64, (B, 3))
+    fvals = d_f.download(np.float64, (B,))
+    conv = status == 0
+
+    # north-star kernel K1 (FK + geometric Jacobian), SoA, measured with HIP events on the handle's stream
+    nfk = args.fk_units
+    rngq = np.random.default_rng(1)
+    qsoa = rngq.uniform(-2.9, 2.9, (7, nfk))
+    d_q = _lib.DeviceBuffer(qsoa.nbytes).upload(qsoa)
+    d_pose = _lib.DeviceBuffer(nfk * 7 * 8)
+    d_J = _lib.DeviceBuffer(nfk * 42 * 8)
+    be.fk_jac_soa_device(nfk, d_q, d_pose, d_J)
+    fk_ms = []
+    for _ in range(5):
+        be.event_timer_start()
+        be.fk_jac_soa_device(nfk, d_q, d_pose, d_J)
+        fk_ms.append(be.event_timer_stop())
+    fk_ms = float(np.mean(fk_ms))
+    for b in (d_q, d_pose, d_J):
+        b.free()
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    units = tm["instance_launches"] * (T - 2)  # (instance, knot) units actually processed by each kernel
+    dom = "k_step" if tm["step_ms"] >= tm["eval_ms"] else "k_eval"
+    dom_ms = tm["step_ms"] if dom == "k_step" else tm["eval_ms"]
+    dom_bytes = BYTES_STEP if dom == "k_step" else BYTES_EVAL
+    dom_launches = tm["step_launches"] if dom == "k_step" else tm["eval_launches"]
+    achieved = units * dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(dom, {}).get("bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "kernel": dom,
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "avg_launch_ms": dom_ms / max(1, dom_launches),
+        "bytes_per_unit": dom_bytes,
+        "units_per_launch_avg": units / max(1, dom_launches),
+        "other_kernel": {
+            "kernel": "k_eval" if dom == "k_step" else "k_step",
+            "avg_launch_ms": (tm["eval_ms"] if dom == "k_step" else tm["step_ms"]) / max(1, tm["eval_launches"]),
+            "achieved": units * (BYTES_EVAL if dom == "k_step" else BYTES_STEP) / ((tm["eval_ms"] if dom == "k_step" else tm["step_ms"]) * 1e-3) / 1e9,
+        },
+    }
+    fk_achieved = nfk * BYTES_FKJAC / (fk_ms * 1e-3) / 1e9
+    out = {
+        "metric": "MPC solves/sec (KUKA 7-DoF, T=50)",
+        "value": world * B * args.steps / elapsed,
+        "unit": "solves/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"figure_eight_plan T=50 KUKA LWR end_effector_ball (BASELINE configs[1]) x {B} perturbed instances per GPU "
+            f"(qc0 + U(-0.1,0.1)^7, seed=qc), solved to reduced-gradient tol {args.tol:g}, max_iter {args.max_iter}",
+            "batch_per_gpu": B,
+            "global_batch": world * B,
+            "T": T,
+            "parallelism": f"dp{world} (instances sharded, one RCCL broadcast of constants)",
+            "hessian": "gauss_newton",
+        },
+        "roofline": roofline,
+        "roofline_fk_jac": {
+            "kernel": "k_fk_jac<SOA>",
+            "bound": "hbm",
+            "achieved": fk_achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": fk_achieved / HBM_PEAK_GBS,
+            "units": nfk,
+            "bytes_per_unit": BYTES_FKJAC,
+            "avg_launch_ms": fk_ms,
+        },
+        "quality": {
+            "converged_frac": float(conv.mean()),
+            "iters_p50": float(np.percentile(iters, 50)),
+            "iters_p90": float(np.percentile(iters, 90)),
+            "iters_max": int(iters.max()),
+            "kkt_stationarity_max_converged": float(kkt[conv, 0].max()) if conv.any() else None,
+            "feasibility_max": float(kkt[:, 1].max()),
+            "f_mean": float(fvals.mean()),
+        },
+        "device_ms_per_step": tm["solve_ms"] / args.steps,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

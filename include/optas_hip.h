@@ -68,7 +68,7 @@ enum {
  *   T_link = T * [R_tool p_tool]
  * quat0_k / quat_tool are the same fixed rotations as xyzw quaternions accumulated with the
  * reference's own product (models.py:1049-1088, spatialmath.py:298-349) so that oh_fk_jac reproduces the
- * reference's quaternion *including its sign*.  This block (sizeof(oh_chain) bytes, < 2 KB) is what is
+ * reference's quaternion *including its sign*.  This block (sizeof(oh_chain) = 2696 bytes) is what is
  * broadcast once over RCCL/xGMI in multi-GPU runs.
  */
 typedef struct oh_chain {
@@ -140,12 +140,15 @@ int oh_fk_jac_soa_device(oh_handle* h, int N, const void* d_q, void* d_pose, voi
 
 /* Timing of the last oh_solve*: HIP-event milliseconds accumulated per kernel on the handle's stream.
    out[0]=eval kernel total ms, out[1]=eval launches, out[2]=step kernel total ms, out[3]=step launches,
-   out[4]=whole solve ms, out[5]=SQP iterations launched (pairs).  Enable with oh_set_profiling(h,1). */
+   out[4]=whole solve ms, out[5]=SQP iterations launched (pairs), out[6]=sum over launches of the number
+   of instances still running (a launch touches only those: work actually done), out[7]=reserved.
+   out[0..3] need oh_set_profiling(h,1) (one hipEventRecord after every kernel). */
 int oh_set_profiling(oh_handle* h, int enable);
-int oh_get_timing(oh_handle* h, double* out6);
+int oh_get_timing(oh_handle* h, double* out8);
 
 /* Thin device-memory helpers so a ctypes host needs no other GPU runtime binding. */
 int oh_device_count(int* n);
+int oh_set_device(int index); /* hipSetDevice: call before oh_create in one-process-per-GPU launches */
 int oh_device_malloc(void** ptr, size_t nbytes);
 int oh_device_free(void* ptr);
 int oh_memcpy_h2d(void* dst, const void* src, size_t nbytes);

@@ -76,6 +76,7 @@ SYMBOLS = [
     "oh_set_profiling",
     "oh_get_timing",
     "oh_device_count",
+    "oh_set_device",
     "oh_device_malloc",
     "oh_device_free",
     "oh_memcpy_h2d",
@@ -118,6 +119,7 @@ def load() -> C.CDLL:
     lib.oh_set_profiling.argtypes = [vp, i]
     lib.oh_get_timing.argtypes = [vp, dp]
     lib.oh_device_count.argtypes = [ip]
+    lib.oh_set_device.argtypes = [i]
     lib.oh_device_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.oh_device_free.argtypes = [vp]
     lib.oh_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]

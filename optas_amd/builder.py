@@ -1,0 +1,219 @@
+"""``OptimizationBuilder`` with the reference's method names, argument meaning, block naming and
+constraint routing (optas/builder.py), recording ``optas_amd.expr`` nodes instead of CasADi SX.
+
+Layout rules that the solver relies on (and the tests pin against the reference's own expectations,
+tests/test_builder.py:25-37,258-419):
+  * decision blocks ``"{name}/{d*'d'}{symbol}/x"`` of shape dim x (T-d) (or x T with derivs_align),
+    created model by model, derivative by derivative (builder.py:90-99); robot parameter blocks
+    ``".../p"`` likewise (possibly 0 rows);
+  * every constraint is stored as ``rhs - lhs`` (builder.py:313,354); ``add_bound`` makes ``_l``/``_r``
+    blocks (:334-335); linear ones go to the ``lin_*`` containers (:314-317,357-360);
+  * ``build()`` picks the Optimization subclass like builder.py:545-635.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Union
+
+import numpy as np
+
+from .expr import Const, Expr, ParamRef, Scale, StateRef, Sub, SumSqr, VarRef, as_expr
+from .models import Model, RobotModel, TaskModel
+from .optimization import (
+    MixedIntegerNonlinearCostNonlinearConstrained,
+    NonlinearCostLinearConstraints,
+    NonlinearCostNonlinearConstraints,
+    NonlinearCostUnconstrained,
+    Optimization,
+    QuadraticCostLinearConstraints,
+    QuadraticCostNonlinearConstraints,
+    QuadraticCostUnconstrained,
+)
+from .sx_container import SXContainer
+
+
+class IntegrationResidual(Expr):
+    """x_t + dt_t * xd_t - x_{t+1} for t = 0..n-1 (builder.py:429-438), dim x n."""
+
+    def __init__(self, x: StateRef, xd: StateRef, dt: np.ndarray, n: int):
+        self.x, self.xd, self.dt, self.n = x, xd, np.asarray(dt, dtype=np.float64).reshape(-1), n
+        self.shape = (x.m, n)
+
+    def degree(self):
+        return 1
+
+
+class OptimizationBuilder:
+    def __init__(self, T: int, robots: List[RobotModel] = [], tasks: List[TaskModel] = [], derivs_align: bool = False):
+        assert T > 0, f"T must be strictly positive"
+        if not isinstance(robots, list):
+            robots = [robots]
+        if not isinstance(tasks, list):
+            tasks = [tasks]
+        self.T = T
+        self._models = robots + tasks
+        self.derivs_align = derivs_align
+        if not derivs_align and len(self._models) > 0:
+            all_time_derivs = []
+            for m in self._models:
+                all_time_derivs += m.time_derivs
+            Tmin = max(all_time_derivs) + 1
+            assert T >= Tmin, f"T={T} is too low, it should be at least {Tmin}"
+        model_names = [m.get_name() for m in self._models]
+        assert len(model_names) == len(set(model_names)), "each model should have a unique name"
+        self._decision_variables = SXContainer()
+        self._parameters = SXContainer()
+        self._cost_terms = SXContainer()
+        self._lin_eq_constraints = SXContainer()
+        self._lin_ineq_constraints = SXContainer()
+        self._ineq_constraints = SXContainer()
+        self._eq_constraints = SXContainer()
+        for model in self._models:
+            for d in model.time_derivs:
+                n_s_x = model.state_optimized_name(d)
+                t = T - d if not derivs_align else T
+                if isinstance(model, RobotModel):
+                    self._decision_variables[n_s_x] = StateRef(n_s_x, model.get_name(), d, model.num_opt_joints, t)
+                    n_s_p = model.state_parameter_name(d)
+                    self.add_parameter(n_s_p, model.num_param_joints, t)
+                else:
+                    self._decision_variables[n_s_x] = StateRef(n_s_x, model.get_name(), d, model.dim, t)
+                    if model.is_discrete:
+                        self._decision_variables.variable_is_discrete(n_s_x)
+
+    # ---- models ------------------------------------------------------------------------------------------
+    def get_model_names(self) -> List[str]:
+        return [model.name for model in self._models]
+
+    def get_model_index(self, name: str) -> int:
+        return self.get_model_names().index(name)
+
+    def get_model(self, name: str) -> Model:
+        return self._models[self.get_model_index(name)]
+
+    def get_model_states(self, name: str, time_deriv: int = 0) -> StateRef:
+        model = self.get_model(name)
+        assert time_deriv in model.time_derivs, f"model '{name}', was not specified with time derivative to order {time_deriv}"
+        return self._decision_variables[model.state_optimized_name(time_deriv)]
+
+    def get_model_state(self, name: str, t: int, time_deriv: int = 0) -> StateRef:
+        return self.get_model_states(name, time_deriv)[:, t]
+
+    def get_model_parameters(self, name: str, time_deriv: int = 0) -> ParamRef:
+        model = self.get_model(name)
+        assert time_deriv in model.time_derivs, f"model '{name}', was not specified with time derivative to order {time_deriv}"
+        return self._parameters[model.state_parameter_name(time_deriv)]
+
+    # ---- variables / parameters / terms ------------------------------------------------------------------
+    def add_decision_variables(self, name: str, m: int = 1, n: int = 1, is_discrete: bool = False) -> VarRef:
+        x = VarRef(name, m, n)
+        self._decision_variables[name] = x
+        if is_discrete:
+            self._decision_variables.variable_is_discrete(name)
+        return x
+
+    def add_parameter(self, name: str, m: int = 1, n: int = 1) -> ParamRef:
+        p = ParamRef(name, m, n)
+        self._parameters[name] = p
+        return p
+
+    def add_cost_term(self, name: str, cost_term) -> None:
+        cost_term = as_expr(cost_term)
+        m, n = cost_term.shape
+        assert m == 1 and n == 1, "cost term must be scalar"
+        self._cost_terms[name] = cost_term
+
+    def _is_linear_in_x(self, y: Expr) -> bool:
+        return y.degree() <= 1
+
+    def is_cost_quadratic(self) -> bool:
+        return all(c.degree() <= 2 for c in self._cost_terms.values())
+
+    def add_geq_inequality_constraint(self, name: str, lhs, rhs=None) -> None:
+        lhs = as_expr(lhs)
+        if rhs is None:
+            rhs = Const(np.zeros(lhs.shape))
+        self.add_leq_inequality_constraint(name, rhs, lhs)
+
+    def add_leq_inequality_constraint(self, name: str, lhs, rhs=None) -> None:
+        lhs = as_expr(lhs)
+        rhs = Const(np.zeros(lhs.shape)) if rhs is None else as_expr(rhs)
+        diff = Sub(rhs, lhs)  # diff >= 0
+        if self._is_linear_in_x(diff):
+            self._lin_ineq_constraints[name] = diff
+        else:
+            self._ineq_constraints[name] = diff
+
+    def add_bound_inequality_constraint(self, name: str, lhs, mid, rhs) -> None:
+        self.add_leq_inequality_constraint(name + "_l", lhs, mid)
+        self.add_leq_inequality_constraint(name + "_r", mid, rhs)
+
+    def add_equality_constraint(self, name: str, lhs, rhs=None, reduce_constraint: bool = False) -> None:
+        lhs = as_expr(lhs)
+        rhs = Const(np.zeros(lhs.shape)) if rhs is None else as_expr(rhs)
+        diff = Sub(rhs, lhs)  # diff == 0
+        if reduce_constraint:
+            diff = SumSqr(diff)
+        if self._is_linear_in_x(diff):
+            self._lin_eq_constraints[name] = diff
+        else:
+            self._eq_constraints[name] = diff
+
+    # ---- common constraints ----------------------------------------------------------------------------
+    def integrate_model_states(self, name: str, time_deriv: int, dt) -> None:
+        n = self.T - (1 if self.derivs_align else time_deriv)
+        dt = np.asarray(dt, dtype=np.float64).reshape(-1)
+        if dt.shape[0] == 1:
+            dt = dt[0] * np.ones(n)
+        assert dt.shape[0] == n, f"The array for dt has an incorrect length, expected {n}, got {dt.shape[0]}"
+        xd = self.get_model_states(name, time_deriv)
+        x = self.get_model_states(name, time_deriv - 1)
+        cname = f"__integrate_model_states_{name}_{time_deriv}__"
+        self.add_equality_constraint(cname, IntegrationResidual(x, xd, dt, n))
+
+    def enforce_model_limits(self, name: str, time_deriv: int = 0, lo=None, up=None, safe_frac=1.0) -> None:
+        assert 0.0 < safe_frac <= 1.0, f"Given safe_frac '{safe_frac}' must be in range (0, 1]."
+        x = self.get_model_states(name, time_deriv)
+        xlo, xup = lo, up
+        if (xlo is None) or (xup is None):
+            mlo, mup = self.get_model(name).get_limits(time_deriv)
+            xlo = mlo if xlo is None else xlo
+            xup = mup if xup is None else xup
+        xlo, xup = np.asarray(xlo, dtype=np.float64).reshape(-1), np.asarray(xup, dtype=np.float64).reshape(-1)
+        if safe_frac < 1.0:
+            mid, diff = 0.5 * (xlo + xup), xup - xlo
+            xlo, xup = mid - 0.5 * safe_frac * diff, mid + 0.5 * safe_frac * diff
+        n = f"__{name}_model_limit_{time_deriv}__"
+        self.add_bound_inequality_constraint(n, Const(xlo), x, Const(xup))
+
+    def initial_configuration(self, name: str, init=None, time_deriv: int = 0) -> None:
+        x0 = self.get_model_state(name, 0, time_deriv=time_deriv)
+        self.add_equality_constraint(f"__{name}_initial_configuration_{time_deriv}__", lhs=x0, rhs=init)
+
+    def fix_configuration(self, name: str, config=None, time_deriv: int = 0, t: int = 0) -> None:
+        x0 = self.get_model_state(name, t, time_deriv=time_deriv)
+        self.add_equality_constraint(f"__{name}_fix_configuration_{time_deriv}_{t}__", lhs=x0, rhs=config)
+
+    # ---- build -------------------------------------------------------------------------------------------
+    def build(self) -> Optimization:
+        nlin = self._lin_ineq_constraints.numel() + self._lin_eq_constraints.numel()
+        nnlin = self._ineq_constraints.numel() + self._eq_constraints.numel()
+        dv, pa, ct = self._decision_variables, self._parameters, self._cost_terms
+        le, li, eq, iq = self._lin_eq_constraints, self._lin_ineq_constraints, self._eq_constraints, self._ineq_constraints
+        if dv.has_discrete_variables():
+            opt = MixedIntegerNonlinearCostNonlinearConstrained(dv, pa, ct, le, li, eq, iq)
+        elif self.is_cost_quadratic():
+            if nnlin > 0:
+                opt = QuadraticCostNonlinearConstraints(dv, pa, ct, le, li, eq, iq)
+            elif nlin > 0:
+                opt = QuadraticCostLinearConstraints(dv, pa, ct, le, li)
+            else:
+                opt = QuadraticCostUnconstrained(dv, pa, ct)
+        else:
+            if nnlin > 0:
+                opt = NonlinearCostNonlinearConstraints(dv, pa, ct, le, li, eq, iq)
+            elif nlin > 0:
+                opt = NonlinearCostLinearConstraints(dv, pa, ct, le, li)
+            else:
+                opt = NonlinearCostUnconstrained(dv, pa, ct)
+        opt.set_models(self._models)
+        return opt

@@ -49,7 +49,7 @@ struct oh_handle {
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;
-  double timing[6] = {0, 0, 0, 0, 0, 0};
+  double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int* h_flag = nullptr;  // pinned
 };
 
@@ -65,6 +65,10 @@ extern "C" int oh_device_count(int* n) {
     return fail(OH_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
   }
   *n = c;
+  return OH_OK;
+}
+extern "C" int oh_set_device(int index) {
+  HIPCHK(hipSetDevice(index));
   return OH_OK;
 }
 extern "C" int oh_device_malloc(void** ptr, size_t nbytes) {
@@ -213,7 +217,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   nd += 2 * per_q + 2 * per_Z + 2 * per_Dr + 2 * per_q /*g*/ + 4 * per_t /*phi,cv*/;
   nd += per_q /*Gfull*/ + (size_t)T * NZ * NZ * Bp + (size_t)T * NZ * Bp;
   nd += (size_t)12 * Bp + 6 * (size_t)Bp;
-  size_t ni = 4 * (size_t)Bp + 16;
+  size_t ni = 4 * (size_t)Bp + 16;  // + any_active, work (8-byte aligned)
   size_t bytes = nd * sizeof(double) + ni * sizeof(int);
   void* pool = nullptr;
   hipError_t e = hipMalloc(&pool, bytes);
@@ -253,7 +257,8 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.first = ip; ip += Bp;
   D.status = ip; ip += Bp;
   D.iters = ip; ip += Bp;
-  D.any_active = ip;
+  D.any_active = ip; ip += 2;
+  D.work = (unsigned long long*)ip;
   return OH_OK;
 }
 
@@ -302,6 +307,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     }
   }
   HIPCHK(hipEventRecord(h->ev0, s));
+  HIPCHK(hipMemsetAsync(h->D.work, 0, sizeof(unsigned long long), s));
   if (!oh_launch_setup(s, N, h->P, h->D, (const double*)d_x0, (const double*)d_p))
     return fail(OH_ERR_INVALID, "oh_solve_device: unsupported ndof");
   size_t ne = 0;
@@ -332,6 +338,9 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->timing[4] = ms;
   h->timing[5] = launched;
+  unsigned long long work = 0;
+  HIPCHK(hipMemcpy(&work, h->D.work, sizeof(work), hipMemcpyDeviceToHost));
+  h->timing[6] = (double)work;
   if (prof) {
     double te = 0, tsx = 0;
     for (int i = 0; i < launched; ++i) {
@@ -455,9 +464,9 @@ extern "C" int oh_set_profiling(oh_handle* h, int enable) {
   h->profiling = enable != 0;
   return OH_OK;
 }
-extern "C" int oh_get_timing(oh_handle* h, double* out6) {
-  if (!h || !out6) return fail(OH_ERR_INVALID, "oh_get_timing: null argument");
-  for (int i = 0; i < 6; ++i) out6[i] = h->timing[i];
+extern "C" int oh_get_timing(oh_handle* h, double* out8) {
+  if (!h || !out8) return fail(OH_ERR_INVALID, "oh_get_timing: null argument");
+  for (int i = 0; i < 8; ++i) out8[i] = h->timing[i];
   return OH_OK;
 }
 extern "C" int oh_event_timer_start(oh_handle* h) {

@@ -47,6 +47,7 @@ struct FigBuffers {
   int* status;            // [Bp] -1 running, else OH_STATUS_*
   int* iters;             // [Bp]
   int* any_active;        // [1]
+  unsigned long long* work;  // [1] sum over k_step launches of running instances
 };
 
 void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n, const double* q, double* pose, double* J);

@@ -390,8 +390,12 @@ __global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D) {
   constexpr int NP = NZ * (NZ + 1) / 2;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int Bp = D.Bp;
-  if (b >= D.B) return;
-  if (D.status[b] >= 0) return;
+  const bool running = (b < D.B) && (D.status[b] < 0);
+  {
+    const unsigned long long m = __ballot(running);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(D.work, (unsigned long long)__popcll(m));
+  }
+  if (!running) return;
   const int T = P.T;
   const double kap2 = 2.0 * P.kappa;  // Hessian weight of kappa*||q_{t+1}-q_t||^2
   int cur = D.cur[b];

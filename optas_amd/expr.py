@@ -1,0 +1,234 @@
+"""A deliberately tiny expression vocabulary standing in for the CasADi SX graphs that
+``OptimizationBuilder`` / ``RobotModel`` emit in the reference (optas/builder.py, optas/models.py).
+
+CasADi is not available, and a general symbolic engine is not the point: the HIP backend lowers a
+*recognised* set of task terms to hand-written kernels.  These node types are exactly the ones the
+BASELINE configs are written in; ``optas_amd.lowering`` pattern-matches trees of them.  Anything else
+raises ``NotImplementedError`` at ``HIPSolver.setup`` -- never silently.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+class Expr:
+    """Base node.  ``shape`` is (rows, cols) like a CasADi matrix."""
+
+    shape: Tuple[int, int] = (1, 1)
+
+    # -- the handful of operators the example scripts use ------------------------------------------------
+    def __sub__(self, other):
+        return Sub(self, as_expr(other))
+
+    def __rsub__(self, other):
+        return Sub(as_expr(other), self)
+
+    def __add__(self, other):
+        return Add(self, as_expr(other))
+
+    def __radd__(self, other):
+        return Add(as_expr(other), self)
+
+    def __mul__(self, other):
+        if isinstance(other, (int, float)):
+            return Scale(float(other), self)
+        return NotImplemented
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return Scale(-1.0, self)
+
+    def numel(self) -> int:
+        return self.shape[0] * self.shape[1]
+
+    # linear / quadratic classification in the decision variables (cs.is_linear / is_quadratic,
+    # builder.py:226-240,314-317,357-360)
+    def degree(self) -> int:
+        """0 constant/parameter, 1 linear in x, 2 quadratic in x, 3 'nonlinear'."""
+        raise NotImplementedError
+
+
+@dataclass(eq=False)
+class Const(Expr):
+    value: np.ndarray
+
+    def __post_init__(self):
+        self.value = np.atleast_2d(np.asarray(self.value, dtype=np.float64))
+        if self.value.shape[0] == 1 and self.value.shape[1] > 1:
+            self.value = self.value.T  # arrayify_args horzcat of a flat list gives a row; vectors are columns
+        self.shape = self.value.shape
+
+    def degree(self):
+        return 0
+
+
+def as_expr(x) -> Expr:
+    if isinstance(x, Expr):
+        return x
+    return Const(np.asarray(x, dtype=np.float64))
+
+
+@dataclass(eq=False)
+class ParamRef(Expr):
+    """A named parameter block (builder.add_parameter, builder.py:263-273)."""
+
+    name: str
+    m: int = 1
+    n: int = 1
+
+    def __post_init__(self):
+        self.shape = (self.m, self.n)
+
+    def degree(self):
+        return 0
+
+
+@dataclass(eq=False)
+class StateRef(Expr):
+    """Decision-variable block of a model: the whole trajectory (t is None) or one knot
+    (builder.get_model_states / get_model_state, builder.py:124-149)."""
+
+    var_name: str  # e.g. "kuka/q/x"
+    model_name: str
+    time_deriv: int
+    m: int
+    n: int
+    t: Optional[int] = None
+
+    def __post_init__(self):
+        self.shape = (self.m, self.n if self.t is None else 1)
+
+    def degree(self):
+        return 1
+
+    def __getitem__(self, key):
+        # Q[:, t]
+        if isinstance(key, tuple) and len(key) == 2 and key[0] == slice(None) and isinstance(key[1], int) and self.t is None:
+            t = key[1] if key[1] >= 0 else self.n + key[1]
+            return StateRef(self.var_name, self.model_name, self.time_deriv, self.m, self.n, t)
+        raise NotImplementedError("only Q[:, t] slicing is lowered")
+
+
+@dataclass(eq=False)
+class VarRef(Expr):
+    """A free decision-variable block (builder.add_decision_variables, builder.py:244-261)."""
+
+    var_name: str
+    m: int = 1
+    n: int = 1
+
+    def __post_init__(self):
+        self.shape = (self.m, self.n)
+
+    def degree(self):
+        return 1
+
+
+@dataclass(eq=False)
+class LinkFunction(Expr):
+    """robot.get_global_link_{position,rotation,quaternion}(link, q) of a symbolic q
+    (models.py:924-933, 986-995, 1049-1088; mapped over columns like .map(n), :786-787)."""
+
+    robot: object
+    link: str
+    what: str  # "position" | "rotation" | "quaternion"
+    q: Expr = None
+
+    def __post_init__(self):
+        rows = {"position": 3, "quaternion": 4, "rotation": 3}[self.what]
+        cols = self.q.shape[1]
+        if self.what == "rotation":
+            if cols != 1:
+                raise NotImplementedError("rotation of a trajectory is a list in the reference; only one configuration is lowered")
+            self.shape = (3, 3)
+        else:
+            self.shape = (rows, cols)
+
+    def degree(self):
+        return 0 if self.q.degree() == 0 else 3
+
+
+@dataclass(eq=False)
+class PathInFrame(Expr):
+    """origin + R @ local[:, k] for every column k (figure_eight_plan.py:90-96)."""
+
+    origin: Expr = None
+    rotation: Expr = None
+    local: np.ndarray = None
+
+    def __post_init__(self):
+        self.local = np.asarray(self.local, dtype=np.float64)
+        assert self.local.shape[0] == 3
+        self.shape = (3, self.local.shape[1])
+
+    def degree(self):
+        return max(self.origin.degree(), self.rotation.degree())
+
+
+def _bshape(a: Expr, b: Expr):
+    (ra, ca), (rb, cb) = a.shape, b.shape
+    if ra != rb and 1 not in (ra * ca, rb * cb):
+        raise ValueError(f"shape mismatch {a.shape} vs {b.shape}")
+    return (max(ra, rb), max(ca, cb))  # CasADi repeats a column / scalar (figure_eight_plan.py:107)
+
+
+@dataclass(eq=False)
+class Sub(Expr):
+    a: Expr = None
+    b: Expr = None
+
+    def __post_init__(self):
+        self.shape = _bshape(self.a, self.b)
+
+    def degree(self):
+        return max(self.a.degree(), self.b.degree())
+
+
+@dataclass(eq=False)
+class Add(Expr):
+    a: Expr = None
+    b: Expr = None
+
+    def __post_init__(self):
+        self.shape = _bshape(self.a, self.b)
+
+    def degree(self):
+        return max(self.a.degree(), self.b.degree())
+
+
+@dataclass(eq=False)
+class Scale(Expr):
+    w: float = 1.0
+    a: Expr = None
+
+    def __post_init__(self):
+        self.shape = self.a.shape
+
+    def degree(self):
+        return self.a.degree()
+
+
+@dataclass(eq=False)
+class SumSqr(Expr):
+    a: Expr = None
+
+    def __post_init__(self):
+        self.shape = (1, 1)
+
+    def degree(self):
+        d = self.a.degree()
+        return 0 if d == 0 else (2 if d == 1 else 3)
+
+
+def sumsqr(e) -> Expr:
+    """casadi.sumsqr (re-exported by the reference, optas/__init__.py:2)."""
+    return SumSqr(as_expr(e))
+
+
+def path_in_frame(origin: Expr, rotation: Expr, local_path) -> Expr:
+    """The loop ``path[:, k] = pc + Rc @ path[:, k]`` of figure_eight_plan.py:94-96 as one node."""
+    return PathInFrame(as_expr(origin), as_expr(rotation), np.asarray(local_path, dtype=np.float64))

@@ -15,6 +15,7 @@ from typing import Dict, List, Optional, Tuple, Union
 import numpy as np
 
 from . import _lib
+from .expr import Expr, LinkFunction
 from .spatialmath import Quaternion, rpy2r, unit
 from .urdf import Joint, Link, RobotDescription, load_robot_description
 
@@ -313,7 +314,10 @@ class RobotModel(Model):
         return a
 
     def get_global_link_position(self, link: str, q) -> np.ndarray:
-        """models.py:924-933; q is ndof or ndof-by-n (columns = joint states, like the reference)."""
+        """models.py:924-933; q is ndof or ndof-by-n (columns = joint states, like the reference).
+        A symbolic q (builder state / parameter) returns an expression node instead."""
+        if isinstance(q, Expr):
+            return LinkFunction(self, link, "position", q)
         Q = self._q_cols(q)
         pose, _ = self._kin(link).fk_jac(Q.T, want_jac=False)
         out = pose[:, :3].T
@@ -321,10 +325,31 @@ class RobotModel(Model):
 
     def get_global_link_quaternion(self, link: str, q) -> np.ndarray:
         """models.py:1049-1088 (xyzw, the reference's sign)."""
+        if isinstance(q, Expr):
+            return LinkFunction(self, link, "quaternion", q)
         Q = self._q_cols(q)
         pose, _ = self._kin(link).fk_jac(Q.T, want_jac=False)
         out = pose[:, 3:].T
         return out[:, 0] if np.asarray(q).ndim == 1 else out
+
+    def get_global_link_rotation(self, link: str, q):
+        """models.py:986-995.  Numerically the rotation is rebuilt from the (reference-signed)
+        quaternion that oh_fk_jac returns."""
+        if isinstance(q, Expr):
+            return LinkFunction(self, link, "rotation", q)
+        quat = self.get_global_link_quaternion(link, q)
+
+        def q2r(v):
+            x, y, z, w = v
+            return np.array(
+                [
+                    [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                    [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                    [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+                ]
+            )
+
+        return q2r(quat) if quat.ndim == 1 else [q2r(quat[:, i]) for i in range(quat.shape[1])]
 
     def get_global_link_geometric_jacobian(self, link: str, q):
         """models.py:1199-1264: 6 x ndof (a list of them for a trajectory)."""

@@ -1,0 +1,197 @@
+"""``Solver`` interface of the reference (optas/solver.py:61-314) and the MI355X backend that drops in
+beside ``CasADiSolver`` / ``ScipyMinimizeSolver``: ``HIPSolver``.
+
+Same constructor, same ``setup(...) -> self``, ``reset_initial_seed``, ``reset_parameters``, ``solve``,
+``stats``, ``did_solve``, ``number_of_iterations`` and the same ``error_on_fail`` -> ``RuntimeError``
+behaviour (solver.py:133-134).  Arrays are numpy instead of ``casadi.DM``.  Additive extension: a
+leading batch axis (``reset_parameters_batch`` / ``reset_initial_seed_batch`` / ``solve_batch``) for B
+independent instances solved in one launch sequence; B=1 through the batch calls equals the scalar
+interface.
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import _lib
+from .backend import BatchResult, FigureEightBackend
+from .lowering import FigureEightSpec, lower
+from .models import RobotModel
+from .optimization import Optimization
+
+
+class Solver(ABC):
+    """solver.py:61-314 (numpy in place of casadi.DM)."""
+
+    def __init__(self, optimization: Optimization, error_on_fail: bool = False):
+        self.opt = optimization
+        self.x0 = np.zeros(optimization.nx)  # solver.py:76
+        self.p = np.zeros(optimization.np)  # solver.py:79
+        self._p_dict: Dict[str, np.ndarray] = {}
+        self._error_on_fail = error_on_fail
+        self._solution = None
+
+    @property
+    def opt_type(self) -> type:
+        return type(self.opt)
+
+    @abstractmethod
+    def setup(self, *args, **kwargs):
+        pass
+
+    def reset_initial_seed(self, x0: Dict[str, np.ndarray]) -> None:
+        self.x0 = self.opt.decision_variables.dict2vec(x0)
+
+    def reset_parameters(self, p: Dict[str, np.ndarray]) -> None:
+        self.p = self.opt.parameters.dict2vec(p)
+        self._p_dict = self.opt.parameters.vec2dict(self.p)
+
+    @abstractmethod
+    def _solve(self) -> np.ndarray:
+        pass
+
+    def _add_model_states(self, solution: dict, p_dict: dict) -> dict:
+        # solver.py:136-155
+        for model in self.opt.models:
+            for d in model.time_derivs:
+                n_s = model.state_name(d)
+                n_s_x = model.state_optimized_name(d)
+                if isinstance(model, RobotModel) and model.num_param_joints > 0:
+                    n_s_p = model.state_parameter_name(d)
+                    t = solution[n_s_x].shape[1]
+                    full = np.zeros((model.dim, t))
+                    full[model.optimized_joint_indexes, :] = solution[n_s_x]
+                    full[model.parameter_joint_indexes, :] = p_dict[n_s_p]
+                    solution[n_s] = full
+                else:
+                    solution[n_s] = solution[n_s_x]
+        return solution
+
+    def solve(self) -> Dict[str, np.ndarray]:
+        solution = self.opt.decision_variables.vec2dict(self._solve())
+        if self._error_on_fail and (not self.did_solve()):
+            raise RuntimeError("Solver failed!")
+        return self._add_model_states(solution, self._p_dict)
+
+    @abstractmethod
+    def stats(self):
+        pass
+
+    @abstractmethod
+    def did_solve(self) -> bool:
+        pass
+
+    @abstractmethod
+    def number_of_iterations(self) -> int:
+        pass
+
+    @staticmethod
+    def interpolate(traj, T: float, **interp_args):
+        """solver.py:239-251."""
+        from scipy.interpolate import interp1d
+
+        traj = np.asarray(traj, dtype=np.float64)
+        t = np.linspace(0, T, traj.shape[1])
+        return interp1d(t, traj, **interp_args)
+
+
+class HIPSolver(Solver):
+    """MI355X backend.  ``setup(solver_options)`` lowers the problem to a kernel family
+    (optas_amd.lowering) and creates the liboptas_hip handle; it raises if the problem is not lowerable
+    or if no HIP device is present -- there is no CPU path."""
+
+    def setup(self, solver_name: str = "hip_sqp", solver_options: Optional[Dict] = None):
+        if solver_name != "hip_sqp":
+            raise ValueError(f"solver '{solver_name}' does not support this problem type")  # solver.py:371-373
+        o = dict(solver_options or {})
+        kind, spec = lower(self.opt)
+        self._kind, self._spec = kind, spec
+        hessian = {"gauss_newton": _lib.OH_HESSIAN_GAUSS_NEWTON, "exact": _lib.OH_HESSIAN_EXACT}[o.pop("hessian", "gauss_newton")]
+        if isinstance(spec, FigureEightSpec):
+            chain = spec.robot.kinematic_chain(spec.link)
+            self._backend = FigureEightBackend(
+                chain,
+                spec.T,
+                spec.dt,
+                spec.local_path,
+                w_path=spec.w_path,
+                w_vel=spec.w_vel,
+                max_iter=int(o.pop("max_iter", 200)),
+                tol=float(o.pop("tol", 1e-6)),
+                tol_feas=float(o.pop("tol_feas", 1e-9)),
+                hessian=hessian,
+                mu0=float(o.pop("mu0", 0.0)),
+            )
+        else:  # pragma: no cover
+            raise NotImplementedError(kind)
+        if o:
+            raise ValueError(f"unknown solver options {sorted(o)}")
+        self._stats: Optional[dict] = None
+        self._x0_batch: Optional[np.ndarray] = None
+        self._p_batch: Optional[np.ndarray] = None
+        return self
+
+    # ---- scalar interface (one instance), solver.py:103-157 ---------------------------------------------
+    def _solve(self) -> np.ndarray:
+        res = self._backend.solve(self.x0.reshape(1, -1), self.p.reshape(1, -1))
+        self._record(res)
+        return res.x[0]
+
+    def _record(self, res: BatchResult) -> None:
+        self._solution = res
+        self._stats = {
+            "success": bool(np.all(res.status == _lib.OH_STATUS_CONVERGED)),
+            "iter_count": int(res.iters.max()),
+            "return_status": ["Solve_Succeeded" if s == 0 else ("Maximum_Iterations_Exceeded" if s == 1 else "Numerical_Failure") for s in res.status],
+            "f": res.f.copy(),
+            "kkt": res.kkt.copy(),
+            "iterations": res.iters.copy(),
+            "status": res.status.copy(),
+            "solution": res,
+        }
+
+    def stats(self) -> dict:
+        return self._stats
+
+    def did_solve(self) -> bool:
+        return self._stats["success"]  # solver.py:407-412
+
+    def number_of_iterations(self) -> int:
+        return self._stats["iter_count"]  # solver.py:414-419
+
+    # ---- batch extension ------------------------------------------------------------------------------------
+    def reset_initial_seed_batch(self, x0: Dict[str, np.ndarray]) -> None:
+        """Each value has a leading batch axis: (B, m, n)."""
+        B = len(next(iter(x0.values()))) if x0 else 1
+        self._x0_batch = np.stack([self.opt.decision_variables.dict2vec({k: v[b] for k, v in x0.items()}) for b in range(B)])
+
+    def reset_parameters_batch(self, p: Dict[str, np.ndarray]) -> None:
+        B = len(next(iter(p.values())))
+        self._p_batch = np.stack([self.opt.parameters.dict2vec({k: v[b] for k, v in p.items()}) for b in range(B)])
+
+    def solve_batch(self) -> List[Dict[str, np.ndarray]]:
+        assert self._p_batch is not None, "call reset_parameters_batch first"
+        B = self._p_batch.shape[0]
+        x0 = self._x0_batch if self._x0_batch is not None else np.zeros((B, self.opt.nx))
+        assert x0.shape[0] == B, "seed and parameter batches differ in size"
+        res = self._backend.solve(x0, self._p_batch)
+        self._record(res)
+        if self._error_on_fail and (not self.did_solve()):
+            raise RuntimeError("Solver failed!")
+        out = []
+        for b in range(B):
+            sol = self.opt.decision_variables.vec2dict(res.x[b])
+            out.append(self._add_model_states(sol, self.opt.parameters.vec2dict(self._p_batch[b])))
+        return out
+
+    def solve_batch_arrays(self, x0: np.ndarray, p: np.ndarray) -> BatchResult:
+        """Array-in/array-out fast path (no dict shuffling): x0 (B, nx), p (B, np) in vec() order."""
+        res = self._backend.solve(x0, p)
+        self._record(res)
+        return res
+
+    @property
+    def backend(self):
+        return self._backend

@@ -1,0 +1,194 @@
+"""The figure-eight solve (BASELINE config 2) through HIPSolver -> ctypes -> liboptas_hip, checked
+against the oracle.
+
+Stated tolerances (north star: "matches the reference path to a stated tolerance on objective and KKT
+residual"; IPOPT itself is absent, PARITY UNPINNED at the solve level):
+  objective      |f - f_oracle| <= 1e-8 * max(1,|f|)   on instances where the optimum is known
+  KKT residual   reference form (min f s.t. 0 <= v <= 1e10): stationarity <= 1e-5 (solver tol 1e-6 on the
+                 reduced gradient), feasibility <= 1e-9, complementarity <= 1e-8
+  linear rows    |a(x)| <= 1e-12 (eliminated exactly)
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import optas_amd
+from conftest import KUKA_KIN, SEED
+from optas_amd import _lib
+from optas_amd.backend import FigureEightBackend
+from optas_amd.models import RobotModel
+from oracle.problems import FigureEightNLP
+from oracle.robot import OracleRobot
+from oracle.solvers import kkt_reference_form
+from oracle.structured import StructuredFigureEight, solve_structured
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from examples.figure_eight_plan import setup_solver  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+LINK = "end_effector_ball"
+QC0 = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return OracleRobot(KUKA_KIN)
+
+
+@pytest.fixture(scope="module")
+def nlp(orc):
+    return FigureEightNLP(orc, LINK, T=50)
+
+
+@pytest.fixture(scope="module")
+def solver(hip_lib):
+    kuka, s = setup_solver(solver_options={"tol": 1e-6, "max_iter": 400})
+    return kuka, s
+
+
+def test_reference_script_flow(solver, nlp, golden_nlp):
+    """Reads like example/figure_eight_plan.py: reset_parameters, reset_initial_seed, solve()."""
+    kuka, s = solver
+    name = kuka.get_name()
+    s.reset_parameters({"qc": QC0})
+    s.reset_initial_seed({f"{name}/q/x": np.tile(QC0.reshape(-1, 1), (1, 50))})
+    sol = s.solve()
+    assert s.did_solve() and 1 <= s.number_of_iterations() <= 400
+    assert set(sol) >= {f"{name}/q/x", f"{name}/dq/x", f"{name}/q", f"{name}/dq"}  # solver.py:137-155
+    assert sol[f"{name}/q"].shape == (7, 50) and sol[f"{name}/dq"].shape == (7, 49)
+    x = s.opt.decision_variables.dict2vec(sol)
+    f = s.stats()["f"][0]
+    assert abs(f - float(golden_nlp["fig8_f"])) <= 1e-8 * max(1.0, abs(f))  # 8.498170214656
+    assert abs(nlp.f(x, QC0) - f) <= 1e-10  # the objective the library reports is the reference objective at x
+    assert np.abs(x - golden_nlp["fig8_x"]).max() < 1e-4  # unique local optimum from this seed
+    k = kkt_reference_form(nlp, x, QC0)
+    assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-9 and k["complementarity"] <= 1e-8
+    assert np.abs(nlp.a(x, QC0)).max() <= 1e-12
+    plan = s.interpolate(sol[f"{name}/q"], 10.0)
+    assert np.allclose(plan(0.0), QC0)
+
+
+def test_multipliers_in_reference_form(solver, nlp):
+    kuka, s = solver
+    s.reset_parameters({"qc": QC0})
+    s.reset_initial_seed({f"{kuka.get_name()}/q/x": np.tile(QC0.reshape(-1, 1), (1, 50))})
+    x = s.opt.decision_variables.dict2vec(s.solve())
+    mu_h = s.backend.multipliers(1)[0]  # signed multipliers of h = quat_c - quat(q_t)
+    # stationarity with these h-multipliers and the best multipliers for the (full-rank) linear rows
+    g = nlp.df(x, QC0) + nlp.dh(x, QC0).T @ mu_h
+    A = nlp.da(x, QC0)
+    mu_a = np.linalg.lstsq(A.T, -g, rcond=None)[0]
+    assert np.abs(g + A.T @ mu_a).max() <= 1e-5
+
+
+def test_batch_matches_scalar_and_oracle(solver, nlp, orc, golden_nlp):
+    kuka, s = solver
+    name = kuka.get_name()
+    qcs = golden_nlp["fig8_pert_qc"]
+    B = len(qcs)
+    s.reset_parameters_batch({"qc": qcs})
+    s.reset_initial_seed_batch({f"{name}/q/x": np.stack([np.tile(q.reshape(-1, 1), (1, 50)) for q in qcs])})
+    sols = s.solve_batch()
+    st = s.stats()
+    assert st["success"] and len(sols) == B
+    for b in range(B):
+        x = s.opt.decision_variables.dict2vec(sols[b])
+        assert abs(nlp.f(x, qcs[b]) - st["f"][b]) <= 1e-10
+        k = kkt_reference_form(nlp, x, qcs[b])
+        assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-9, (b, k)
+        assert np.abs(nlp.a(x, qcs[b])).max() <= 1e-12
+        # the oracle's structured solver runs the same algorithm on the CPU: same local optimum
+        assert abs(st["f"][b] - float(golden_nlp["fig8_pert_f"][b])) <= 1e-7 * max(1.0, abs(st["f"][b])), b
+    # B = 1 through the batch interface equals the scalar interface bit for bit
+    s.reset_parameters({"qc": qcs[0]})
+    s.reset_initial_seed({f"{name}/q/x": np.tile(qcs[0].reshape(-1, 1), (1, 50))})
+    x_scalar = s.opt.decision_variables.dict2vec(s.solve())
+    assert np.array_equal(x_scalar, s.opt.decision_variables.dict2vec(sols[0]))
+
+
+@pytest.mark.parametrize("T", [5, 12])
+def test_short_horizons_vs_dense_oracle(hip_lib, orc, golden_nlp, T):
+    Tmax = 10.0 * (T - 1) / 49.0
+    nl = FigureEightNLP(orc, LINK, T=T, Tmax=Tmax)
+    robot = RobotModel(urdf_filename=KUKA_KIN)
+    be = FigureEightBackend(robot.kinematic_chain(LINK), T, nl.dt, nl.local_path.T, max_iter=300, tol=1e-8)
+    r = be.solve(nl.seed(QC0), QC0)
+    assert r.status[0] == 0
+    assert abs(r.f[0] - float(golden_nlp[f"fig8_T{T}_f"])) <= 1e-9
+    assert np.abs(r.x[0] - golden_nlp[f"fig8_T{T}_x"]).max() < 1e-5
+    be.close()
+
+
+@pytest.mark.parametrize("B", [1, 63, 65, 200])
+def test_ragged_batches_and_seeds(hip_lib, nlp, B):
+    """Batch sizes around the wavefront width; infeasible seeds (random knots) are projected/retracted."""
+    robot = RobotModel(urdf_filename=KUKA_KIN)
+    be = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=500, tol=1e-6)
+    rng = np.random.default_rng(SEED + B)
+    qc = QC0 + rng.uniform(-0.1, 0.1, (B, 7))
+    x0 = np.stack([nlp.seed(q) for q in qc])
+    x0[::2] += 0.02 * rng.standard_normal((len(x0[::2]), nlp.nx))  # violates every equality row
+    r = be.solve(x0, qc)
+    assert r.x.shape == (B, nlp.nx) and np.isfinite(r.x).all()
+    conv = r.status == 0
+    assert conv.mean() >= 0.9
+    assert (r.kkt[conv, 0] <= 1e-6).all() and (r.kkt[:, 1] <= 1e-9).all()
+    for b in rng.choice(B, min(B, 6), replace=False):
+        assert abs(nlp.f(r.x[b], qc[b]) - r.f[b]) <= 1e-10
+        assert np.abs(nlp.a(r.x[b], qc[b])).max() <= 1e-12
+        assert np.abs(nlp.h(r.x[b], qc[b])).max() <= 1e-9
+    # determinism: same inputs, same bits
+    r2 = be.solve(x0, qc)
+    assert np.array_equal(r.x, r2.x) and np.array_equal(r.iters, r2.iters)
+    be.close()
+
+
+def test_full_size_batch_properties(hip_lib, nlp):
+    """BASELINE-scale batch (B=4096): size-independent properties instead of per-instance oracle solves."""
+    robot = RobotModel(urdf_filename=KUKA_KIN)
+    be = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)
+    rng = np.random.default_rng(SEED)
+    B = 4096
+    qc = QC0 + rng.uniform(-0.1, 0.1, (B, 7))
+    x0 = np.concatenate([np.repeat(qc, 50, axis=0).reshape(B, 350), np.zeros((B, 343))], axis=1)
+    r = be.solve(x0, qc)
+    conv = r.status == 0
+    assert conv.mean() >= 0.98
+    assert (r.kkt[conv, 0] <= 1e-6).all() and (r.kkt[:, 1] <= 1e-9).all() and (r.kkt[:, 2] == 0).all()
+    assert (r.f < 1225.0).all() and (r.f > 0).all()  # every instance improved on its seed (f(seed)=1225)
+    Q = r.x[:, :350].reshape(B, 50, 7)
+    dQ = r.x[:, 350:].reshape(B, 49, 7)
+    assert np.array_equal(Q[:, 0], qc) and np.array_equal(Q[:, 1], qc) and not dQ[:, 0].any()
+    assert np.abs(Q[:, 1:] - (Q[:, :-1] + nlp.dt * dQ)).max() <= 1e-12  # Euler rows
+    for b in rng.choice(B, 8, replace=False):
+        assert abs(nlp.f(r.x[b], qc[b]) - r.f[b]) <= 1e-10
+        k = kkt_reference_form(nlp, r.x[b], qc[b])
+        if conv[b]:
+            assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-9
+    be.close()
+
+
+def test_failure_reporting(hip_lib, nlp):
+    kuka, opt = setup_solver(build_only=True)
+    from optas_amd.solver import HIPSolver
+
+    s = HIPSolver(opt, error_on_fail=True).setup("hip_sqp", {"max_iter": 2})
+    s.reset_parameters({"qc": QC0})
+    s.reset_initial_seed({"kuka/q/x": np.tile(QC0.reshape(-1, 1), (1, 50))})
+    with pytest.raises(RuntimeError, match="Solver failed!"):  # solver.py:133-134
+        s.solve()
+    assert not s.did_solve() and s.stats()["status"][0] == _lib.OH_STATUS_MAX_ITER
+    with pytest.raises(ValueError):
+        HIPSolver(opt).setup("ipopt")  # solver.py:371-373
+    with pytest.raises(ValueError):
+        HIPSolver(opt).setup("hip_sqp", {"nonsense": 1})
+
+
+def test_exact_hessian_mode_reaches_a_kkt_point(hip_lib, nlp, golden_nlp):
+    robot = RobotModel(urdf_filename=KUKA_KIN)
+    be = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=500, tol=1e-6, hessian=_lib.OH_HESSIAN_EXACT)
+    r = be.solve(nlp.seed(QC0), QC0)
+    assert r.status[0] == 0 and abs(r.f[0] - float(golden_nlp["fig8_f"])) <= 1e-8
+    be.close()

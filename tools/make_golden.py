@@ -1,0 +1,129 @@
+"""Generate the committed golden fixtures under tests/golden/ from the CPU oracle (run in the build
+container; the GPU box only reads the .npz files).
+
+  python tools/make_golden.py
+
+Sources of truth: scipy.spatial.transform.Rotation for the SE(3)/quaternion primitives (the
+reference's own test oracle, tests/test_spatialmath.py), the literal numpy restatement in oracle/ for
+FK / Jacobians, and oracle.solvers for the NLP solutions (dense_sqp on the literal reference layout,
+scipy SLSQP wired like ScipyMinimizeSolver).  Seeds are fixed; rerunning reproduces the files.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+from scipy.spatial.transform import Rotation as Rot
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from oracle.problems import FigureEightNLP, IKExampleNLP  # noqa: E402
+from oracle.robot import OracleRobot  # noqa: E402
+from oracle.solvers import dense_sqp, kkt_reference_form, scipy_minimize  # noqa: E402
+from oracle.structured import StructuredFigureEight, solve_structured  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden")
+SEED = 20260927
+
+
+def spatialmath_golden():
+    rng = np.random.default_rng(SEED)
+    n = 64
+    theta = rng.uniform(-np.pi, np.pi, n)
+    axis = rng.uniform(-1, 1, (n, 3))
+    rpy = rng.uniform(-np.pi, np.pi, (n, 3))
+    rpy[:, 1] = rng.uniform(-0.49 * np.pi, 0.49 * np.pi, n)
+    out = {
+        "theta": theta,
+        "axis": axis,
+        "rpy": rpy,
+        "angvec2r": np.stack([Rot.from_rotvec(theta[i] * axis[i] / np.linalg.norm(axis[i])).as_matrix() for i in range(n)]),
+        "rotx": np.stack([Rot.from_euler("x", t).as_matrix() for t in theta]),
+        "roty": np.stack([Rot.from_euler("y", t).as_matrix() for t in theta]),
+        "rotz": np.stack([Rot.from_euler("z", t).as_matrix() for t in theta]),
+        # URDF fixed-axis roll-pitch-yaw == scipy extrinsic "xyz"
+        "rpy2r": np.stack([Rot.from_euler("xyz", r).as_matrix() for r in rpy]),
+        "quat_fromrpy": np.stack([Rot.from_euler("xyz", r).as_quat() for r in rpy]),
+        "quat_fromangvec": np.stack([Rot.from_rotvec(theta[i] * axis[i] / np.linalg.norm(axis[i])).as_quat() for i in range(n)]),
+    }
+    np.savez(os.path.join(G, "spatialmath_golden.npz"), **out)
+
+
+def fk_golden():
+    rng = np.random.default_rng(SEED + 1)
+    out = {}
+    cases = [
+        ("kuka_lwr", os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json"), "end_effector_ball"),
+        ("kuka_lwr_mid", os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json"), "lwr_arm_4_link"),
+        ("med7", os.path.join(ROOT, "optas_amd", "robots", "med7.kin.json"), "lbr_link_ee"),
+        ("tester", os.path.join(G, "tester_robot.kin.json"), "eff"),
+    ]
+    for tag, kin, link in cases:
+        r = OracleRobot(kin)
+        n = 48
+        lo = np.maximum(r.lower_actuated_joint_limits, -3.0)
+        up = np.minimum(r.upper_actuated_joint_limits, 3.0)
+        Q = rng.uniform(lo, up, (n, r.ndof))
+        pose = np.zeros((n, 7))
+        J = np.zeros((n, 6, r.ndof))
+        for i in range(n):
+            pose[i, :3] = r.get_global_link_position(link, Q[i])
+            pose[i, 3:] = r.get_global_link_quaternion(link, Q[i])
+            J[i] = r.get_global_link_geometric_jacobian(link, Q[i])
+        out[f"{tag}_q"], out[f"{tag}_pose"], out[f"{tag}_J"] = Q, pose, J
+        out[f"{tag}_link"] = np.array(link)
+    np.savez(os.path.join(G, "fk_golden.npz"), **out)
+
+
+def nlp_golden():
+    kuka = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json"))
+    link = "end_effector_ball"
+    out = {}
+    # config 1 (example/example.py): scipy SLSQP, reference wiring, seed = zeros (the script's seed key
+    # "kuka/q" does not exist in the container, so dict2vec zero-fills: sx_container.py:121)
+    ik = IKExampleNLP(kuka, link)
+    qn = np.deg2rad([0, 45, 0, -90, 0, -45, 0])
+    pg = kuka.get_global_link_position(link, qn) + np.array([0.0, 0.3, -0.2])
+    p = np.concatenate([qn, pg])
+    r = scipy_minimize(ik, np.zeros(7), p, method="SLSQP", tol=1e-12, options={"maxiter": 500})
+    k = kkt_reference_form(ik, r.x, p)
+    print("ik", r.fun, r.nit, k["stationarity"], k["feasibility"])
+    out["ik_p"], out["ik_x"], out["ik_f"] = p, r.x, r.fun
+    # config 2 (figure_eight_plan.py), nominal qc: independent dense SQP on the literal layout
+    T = 50
+    nlp = FigureEightNLP(kuka, link, T=T)
+    qc0 = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    t0 = time.time()
+    d = dense_sqp(nlp, nlp.seed(qc0), qc0, tol=1e-11)
+    k = kkt_reference_form(nlp, d["x"], qc0)
+    print("fig8 dense", d["f"], d["iters"], d["converged"], k["stationarity"], k["feasibility"], time.time() - t0)
+    out["fig8_qc"], out["fig8_x"], out["fig8_f"] = qc0, d["x"], d["f"]
+    out["fig8_mu_h"] = k["mu_h"]
+    # perturbed instances (qc + U(-0.1,0.1)^7, rng seed 20260927): structured oracle,
+    # each verified in reference form
+    rng = np.random.default_rng(SEED)
+    prob = StructuredFigureEight(kuka, link, T=T)
+    qcs, xs, fs = [], [], []
+    for i in range(6):
+        qc = qc0 + rng.uniform(-0.1, 0.1, 7)
+        s = solve_structured(prob, qc, max_iter=400, tol=1e-9, exact=False)
+        Q = s["Q"]
+        x = nlp.join(Q.T, (np.diff(Q, axis=0) / nlp.dt).T)
+        k = kkt_reference_form(nlp, x, qc)
+        print("fig8 pert", i, s["f"], s["iters"], s["stat"], k["stationarity"], k["feasibility"])
+        qcs.append(qc); xs.append(x); fs.append(nlp.f(x, qc))
+    out["fig8_pert_qc"], out["fig8_pert_x"], out["fig8_pert_f"] = np.array(qcs), np.array(xs), np.array(fs)
+    # small horizon for quick parity
+    for Ts in (5, 12):
+        nl = FigureEightNLP(kuka, link, T=Ts, Tmax=10.0 * (Ts - 1) / 49.0)
+        d = dense_sqp(nl, nl.seed(qc0), qc0, tol=1e-11)
+        print("fig8 T", Ts, d["f"], d["iters"], d["converged"])
+        out[f"fig8_T{Ts}_x"], out[f"fig8_T{Ts}_f"] = d["x"], d["f"]
+    np.savez(os.path.join(G, "nlp_golden.npz"), **out)
+
+
+if __name__ == "__main__":
+    spatialmath_golden()
+    fk_golden()
+    nlp_golden()
+    print("golden fixtures written to", G)

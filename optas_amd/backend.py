@@ -122,6 +122,7 @@ class FigureEightBackend:
             "solve_ms": out[4],
             "iterations_launched": int(out[5]),
             "instance_launches": int(out[6]),
+            "compactions": int(out[7]),
         }
 
     def fk_jac_soa_device(self, n: int, d_q, d_pose, d_J) -> None:

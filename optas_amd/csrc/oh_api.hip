@@ -51,6 +51,8 @@ struct oh_handle {
   std::vector<hipEvent_t> prof_events;
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int* h_flag = nullptr;  // pinned
+  bool compaction = true;
+  std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
 };
 
 extern "C" const char* oh_last_error(void) { return g_err.c_str(); }
@@ -217,7 +219,8 @@ static int ensure_capacity(oh_handle* h, int B) {
   nd += 2 * per_q + 2 * per_Z + 2 * per_Dr + 2 * per_q /*g*/ + 4 * per_t /*phi,cv*/;
   nd += per_q /*Gfull*/ + (size_t)T * NZ * NZ * Bp + (size_t)T * NZ * Bp;
   nd += (size_t)12 * Bp + 6 * (size_t)Bp;
-  size_t ni = 4 * (size_t)Bp + 16;  // + any_active, work (8-byte aligned)
+  nd += (size_t)4 * T * Bp;  // lam_h
+  size_t ni = 6 * (size_t)Bp + 16;  // + n_running, n_new, work (8-byte aligned)
   size_t bytes = nd * sizeof(double) + ni * sizeof(int);
   void* pool = nullptr;
   hipError_t e = hipMalloc(&pool, bytes);
@@ -252,12 +255,16 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.mu = take(Bp);
   D.stat = take(Bp);
   D.feas = take(Bp);
+  D.lam_h = take((size_t)4 * T * Bp);
   int* ip = (int*)d;
   D.cur = ip; ip += Bp;
   D.first = ip; ip += Bp;
   D.status = ip; ip += Bp;
   D.iters = ip; ip += Bp;
-  D.any_active = ip; ip += 2;
+  D.orig = ip; ip += Bp;
+  D.newidx = ip; ip += Bp;
+  D.n_running = ip; ip += 1;
+  D.n_new = ip; ip += 1;
   D.work = (unsigned long long*)ip;
   return OH_OK;
 }
@@ -299,7 +306,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   const bool prof = h->profiling;
   if (prof) {
     // events: [0] start, then per iteration (after eval, after step), last = end
-    const size_t need = 2 * (size_t)(h->desc.max_iter + 2) + 4;
+    const size_t need = 3 * (size_t)(h->desc.max_iter + 44) + 64;
     while (h->prof_events.size() < need) {
       hipEvent_t e;
       HIPCHK(hipEventCreate(&e));
@@ -311,25 +318,51 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (!oh_launch_setup(s, N, h->P, h->D, (const double*)d_x0, (const double*)d_p))
     return fail(OH_ERR_INVALID, "oh_solve_device: unsupported ndof");
   size_t ne = 0;
-  if (prof) HIPCHK(hipEventRecord(h->prof_events[ne++], s));
+  h->prof_tags.clear();
+  if (prof) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(0); }
   int launched = 0;
+  int compactions = 0;
   const int check_every = (B <= 64) ? 1 : 2;
-  // every instance needs at most max_iter accepted+rejected steps, plus the initial evaluation
-  for (int it = 0; it <= h->desc.max_iter + 1; ++it) {
+  double* ox = (double*)d_x; double* of = (double*)d_f; double* ok = (double*)d_kkt;
+  int* oi = (int*)d_iters; int* os = (int*)d_status;
+  // Every instance needs at most max_iter steps (accepted + rejected) plus its first evaluation; each
+  // compaction re-evaluates the survivors once.  The batch is compacted whenever at least half of it has
+  // finished, so the slow tail keeps running in full wavefronts.
+  const int hard_cap = h->desc.max_iter + 2 + 40;
+  bool rebase = false;
+  for (int it = 0; it < hard_cap; ++it) {
+    if (prof && rebase && ne + 3 < h->prof_events.size()) {  // host synced: do not bill the idle gap to the eval kernel
+      HIPCHK(hipEventRecord(h->prof_events[ne++], s));
+      h->prof_tags.push_back(0);
+    }
+    rebase = false;
     oh_launch_eval(s, N, h->P, h->D);
-    if (prof) HIPCHK(hipEventRecord(h->prof_events[ne++], s));
+    if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(1); }
     const bool check = ((it + 1) % check_every == 0);
-    if (check) HIPCHK(hipMemsetAsync(h->D.any_active, 0, sizeof(int), s));
+    if (check) HIPCHK(hipMemsetAsync(h->D.n_running, 0, sizeof(int), s));
     oh_launch_step(s, N, h->P, h->D);
-    if (prof) HIPCHK(hipEventRecord(h->prof_events[ne++], s));
+    if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(2); }
     ++launched;
     if (check) {
-      HIPCHK(hipMemcpyAsync(h->h_flag, h->D.any_active, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(h->h_flag, h->D.n_running, sizeof(int), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
-      if (*h->h_flag == 0) break;
+      const int nrun = *h->h_flag;
+      rebase = true;
+      if (nrun == 0) break;
+      if (h->compaction && h->D.B >= 512 && 2 * nrun <= h->D.B) {
+        oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
+        oh_launch_scan_running(s, h->D);
+        oh_launch_compact(s, N, h->P, h->D, 0, 0);
+        oh_launch_compact(s, N, h->P, h->D, 1, nrun);
+        h->D.B = nrun;
+        ++compactions;
+        // the compaction kernels are accounted to neither eval nor step: restart the event pair
+        if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(0); }
+      }
     }
   }
-  oh_launch_finalize(s, N, h->P, h->D, (double*)d_x, (double*)d_f, (double*)d_kkt, (int*)d_iters, (int*)d_status);
+  oh_launch_finalize(s, N, h->P, h->D, 0, ox, of, ok, oi, os);
+  h->D.B = B;
   HIPCHK(hipEventRecord(h->ev1, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
@@ -343,18 +376,21 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   h->timing[6] = (double)work;
   if (prof) {
     double te = 0, tsx = 0;
-    for (int i = 0; i < launched; ++i) {
-      float a = 0.f, b2 = 0.f;
-      hipEventElapsedTime(&a, h->prof_events[2 * i], h->prof_events[2 * i + 1]);
-      hipEventElapsedTime(&b2, h->prof_events[2 * i + 1], h->prof_events[2 * i + 2]);
-      te += a;
-      tsx += b2;
+    int n_e = 0, n_s = 0;
+    for (size_t i = 1; i < ne; ++i) {
+      const int tag = h->prof_tags[i];
+      if (tag == 0) continue;
+      float ms2 = 0.f;
+      hipEventElapsedTime(&ms2, h->prof_events[i - 1], h->prof_events[i]);
+      if (tag == 1) { te += ms2; ++n_e; }
+      else { tsx += ms2; ++n_s; }
     }
     h->timing[0] = te;
-    h->timing[1] = launched;
+    h->timing[1] = n_e;
     h->timing[2] = tsx;
-    h->timing[3] = launched;
+    h->timing[3] = n_s;
   }
+  h->timing[7] = compactions;
   return OH_OK;
 }
 
@@ -409,14 +445,7 @@ extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
   if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT || B != h->last_B || B < 1)
     return fail(OH_ERR_STATE, "oh_get_multipliers: B does not match the last solve");
   HIPCHK(hipSetDevice(h->device));
-  const size_t bytes = sizeof(double) * 4 * (size_t)h->desc.T * B;
-  void* d = nullptr;
-  HIPCHK(hipMalloc(&d, bytes));
-  oh_launch_multipliers(h->stream, h->desc.ndof, h->P, h->D, (double*)d);
-  hipError_t e = hipStreamSynchronize(h->stream);
-  if (e == hipSuccess) e = hipMemcpy(lam_h, d, bytes, hipMemcpyDeviceToHost);
-  hipFree(d);
-  if (e != hipSuccess) return fail(OH_ERR_HIP, std::string("oh_get_multipliers: ") + hipGetErrorString(e));
+  HIPCHK(hipMemcpy(lam_h, h->D.lam_h, sizeof(double) * 4 * (size_t)h->desc.T * B, hipMemcpyDeviceToHost));
   return OH_OK;
 }
 

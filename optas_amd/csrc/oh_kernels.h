@@ -46,7 +46,11 @@ struct FigBuffers {
   int* first;             // [Bp]
   int* status;            // [Bp] -1 running, else OH_STATUS_*
   int* iters;             // [Bp]
-  int* any_active;        // [1]
+  int* orig;              // [Bp] original instance index (instances are compacted as the batch drains)
+  int* newidx;            // [Bp] scratch of the compaction scan
+  int* n_running;         // [1] instances still running after the last k_step
+  int* n_new;             // [1] result of the compaction scan
+  double* lam_h;          // [B][T][4] multipliers of the quaternion rows, reference form (original order)
   unsigned long long* work;  // [1] sum over k_step launches of running instances
 };
 
@@ -54,6 +58,7 @@ void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n, c
 bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const double* x0, const double* p);
 bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D);
 bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D);
-bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, double* x, double* f, double* kkt, int* iters,
-                        int* status);
-bool oh_launch_multipliers(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, double* lam_h);
+bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
+                        int* iters, int* status);
+void oh_launch_scan_running(hipStream_t s, const FigBuffers& D);
+bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew);

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
   }
   D.cur[b] = 1;  // trial slot = 0
   D.first[b] = 1;
+  D.orig[b] = b;
   D.status[b] = -1;  // running
   D.iters[b] = 0;
   D.f_cur[b] = 0.0;
@@ -385,17 +386,10 @@ __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D) {
 // objective; iterates are feasible by retraction), then backward Riccati sweep over the reduced
 // block-tridiagonal system, forward roll-out, next trial knots.
 template <int N>
-__global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D) {
+OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b) {
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int Bp = D.Bp;
-  const bool running = (b < D.B) && (D.status[b] < 0);
-  {
-    const unsigned long long m = __ballot(running);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(D.work, (unsigned long long)__popcll(m));
-  }
-  if (!running) return;
   const int T = P.T;
   const double kap2 = 2.0 * P.kappa;  // Hessian weight of kappa*||q_{t+1}-q_t||^2
   int cur = D.cur[b];
@@ -571,16 +565,16 @@ __global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D) {
   if (stat <= P.tol && feas_cur <= P.tol_feas) {
     D.status[b] = OH_STATUS_CONVERGED;
     D.mu[b] = mu;
-    return;
+    return false;
   }
   if (iters >= P.max_iter) {
     D.status[b] = OH_STATUS_MAX_ITER;
     D.mu[b] = mu;
-    return;
+    return false;
   }
   if (!(stat == stat)) {
     D.status[b] = OH_STATUS_NUMERICAL;
-    return;
+    return false;
   }
 
   // ---- forward roll-out: z_2 = -S_2^{-1} r_2, z_{t+1} = -(kvec + Kmat z_t); trial knots ---------------
@@ -626,61 +620,35 @@ __global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D) {
   }
   D.mu[b] = mu;
   D.iters[b] = iters + 1;
-  *D.any_active = 1;
+  return true;
 }
 
-// Solution out in the reference layout x = [vec(Q); vec(dQ)] (sx_container.py:83-89), plus f, kkt, ...
 template <int N>
-__global__ __launch_bounds__(256) void k_finalize(FigParams P, FigBuffers D, double* __restrict__ x, double* __restrict__ f,
-                                                  double* __restrict__ kkt, int* __restrict__ iters, int* __restrict__ status) {
+__global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
-  const int Bp = D.Bp;
-  if (b >= D.B) return;
-  const int cur = D.cur[b];
-  const double* __restrict__ qs = D.q[cur];
-  if (x) {
-    double* xb = x + (size_t)b * P.nx;
-    double q0[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      q0[j] = qs[IDX(t, N, j)];
-      xb[(size_t)t * N + j] = q0[j];
-    }
-    if (t < P.T - 1) {
-      const double inv_dt = 1.0 / P.dt;
-#pragma unroll
-      for (int j = 0; j < N; ++j) xb[(size_t)P.T * N + (size_t)t * N + j] = (qs[IDX(t + 1, N, j)] - q0[j]) * inv_dt;
-    }
+  const bool running = (b < D.B) && (D.status[b] < 0);
+  {
+    const unsigned long long m = __ballot(running);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(D.work, (unsigned long long)__popcll(m));
   }
-  if (t == 0) {
-    if (f) f[b] = D.f_cur[b];
-    if (kkt) {
-      kkt[3 * (size_t)b + 0] = D.stat[b];
-      kkt[3 * (size_t)b + 1] = D.feas[b];
-      kkt[3 * (size_t)b + 2] = 0.0;  // no inequality rows in this family
-    }
-    if (iters) iters[b] = D.iters[b];
-    if (status) status[b] = (D.status[b] < 0) ? OH_STATUS_MAX_ITER : D.status[b];
-  }
+  bool still = false;
+  if (running) still = step_instance<N>(P, D, b);
+  const unsigned long long m2 = __ballot(still);
+  if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
 }
 
-// Least-squares multipliers at the solution, mapped to the reference's rows h = quat_c - quat(q_t)
-// (figure_eight_plan.py:105-107): stationarity reads G_t + Jc^T mu = 0 with Jc = Jw on the manifold and
-// dh/dq = -1/2 Ec Jw (Ec o = (o,0)(x)quat_c), hence nu = -2 Ec mu satisfies G_t + (dh/dq)^T nu = 0.
+// Least-squares multipliers of knot t at the point in slot `cur`, mapped to the reference's rows
+// h = quat_c - quat(q_t) (figure_eight_plan.py:105-107): stationarity reads G_t + Jc^T mu = 0 with
+// Jc = Jw on the manifold and dh/dq = -1/2 Ec Jw (Ec o = (o,0)(x)quat_c), hence nu = -2 Ec mu
+// satisfies G_t + (dh/dq)^T nu = 0.
 template <int N>
-__global__ __launch_bounds__(256) void k_multipliers(FigParams P, FigBuffers D, double* __restrict__ lam_h) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
+OH_DEV void knot_multipliers(const FigParams& P, const FigBuffers& D, const int b, const int t, const int cur, double* out) {
   const int Bp = D.Bp;
-  if (b >= D.B) return;
-  double* out = lam_h + ((size_t)b * P.T + t) * 4;
   if (t < 2) {  // knots fixed by the linear rows: the quaternion rows are redundant there, multiplier 0
     out[0] = out[1] = out[2] = out[3] = 0.0;
     return;
   }
   const oh_chain* ch = D.chain;
-  const int cur = D.cur[b];
   const double* __restrict__ qs = D.q[cur];
   const double kap2 = 2.0 * P.kappa;
   double q[N], G[N];
@@ -710,10 +678,7 @@ __global__ __launch_bounds__(256) void k_multipliers(FigParams P, FigBuffers D, 
   chol_packed<3>(S, 0.0);
   fsub<3>(S, rhs);
   bsub<3>(S, rhs);  // mu
-  // quat_c from the reference frame Rc is not stored; rebuild it with the chain product at qc = q_0
-  double qcv[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) qcv[k] = qs[IDX(0, N, k)];
+  // quat_c: rebuild with the reference's chain product at qc = q_0
   double quat[4] = {0, 0, 0, 1};
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -721,7 +686,7 @@ __global__ __launch_bounds__(256) void k_multipliers(FigParams P, FigBuffers D, 
     qmul(quat, ch->quat0[k], qn);
     if (ch->jtype[k] == 0) {
       double sh, chh;
-      sincos(0.5 * qcv[k], &sh, &chh);
+      sincos(0.5 * qs[IDX(0, N, k)], &sh, &chh);
       const double qa[4] = {sh * ch->axis[k][0], sh * ch->axis[k][1], sh * ch->axis[k][2], chh};
       qmul(qn, qa, quat);
     } else {
@@ -734,6 +699,132 @@ __global__ __launch_bounds__(256) void k_multipliers(FigParams P, FigBuffers D, 
   double nu[4];
   qmul(o, qcq, nu);
   out[0] = -2.0 * nu[0]; out[1] = -2.0 * nu[1]; out[2] = -2.0 * nu[2]; out[3] = -2.0 * nu[3];
+}
+
+// Solution out in the reference layout x = [vec(Q); vec(dQ)] (sx_container.py:83-89), plus f, kkt,
+// iterations, status and the h-row multipliers, written at the instance's ORIGINAL index (instances are
+// compacted while the batch drains).  only_done: emit just the instances that have finished.
+template <int N>
+__global__ __launch_bounds__(256) void k_finalize(FigParams P, FigBuffers D, int only_done, double* __restrict__ x,
+                                                  double* __restrict__ f, double* __restrict__ kkt, int* __restrict__ iters,
+                                                  int* __restrict__ status) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  const int st = D.status[b];
+  if (only_done && st < 0) return;
+  const size_t ob = (size_t)D.orig[b];
+  const int cur = D.cur[b];
+  const double* __restrict__ qs = D.q[cur];
+  if (x) {
+    double* xb = x + ob * P.nx;
+    double q0[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      q0[j] = qs[IDX(t, N, j)];
+      xb[(size_t)t * N + j] = q0[j];
+    }
+    if (t < P.T - 1) {
+      const double inv_dt = 1.0 / P.dt;
+#pragma unroll
+      for (int j = 0; j < N; ++j) xb[(size_t)P.T * N + (size_t)t * N + j] = (qs[IDX(t + 1, N, j)] - q0[j]) * inv_dt;
+    }
+  }
+  if (D.lam_h) knot_multipliers<N>(P, D, b, t, cur, D.lam_h + (ob * P.T + t) * 4);
+  if (t == 0) {
+    if (f) f[ob] = D.f_cur[b];
+    if (kkt) {
+      kkt[3 * ob + 0] = D.stat[b];
+      kkt[3 * ob + 1] = D.feas[b];
+      kkt[3 * ob + 2] = 0.0;  // no inequality rows in this family
+    }
+    if (iters) iters[ob] = D.iters[b];
+    if (status) status[ob] = (st < 0) ? OH_STATUS_MAX_ITER : st;
+  }
+}
+
+// ---- batch compaction: drop finished instances so that the tail of slow instances keeps full waves ----
+// newidx[b] = rank of b among the running instances (or -1); single block, deterministic.
+__global__ __launch_bounds__(1024) void k_scan_running(FigBuffers D) {
+  __shared__ int cnt[1024];
+  const int tid = threadIdx.x;
+  const int per = (D.B + 1023) / 1024;
+  const int lo = tid * per, hi = min(D.B, lo + per);
+  int c = 0;
+  for (int b = lo; b < hi; ++b) c += (D.status[b] < 0);
+  cnt[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = (tid >= off) ? cnt[tid - off] : 0;
+    __syncthreads();
+    cnt[tid] += v;
+    __syncthreads();
+  }
+  int base = cnt[tid] - c;
+  for (int b = lo; b < hi; ++b) {
+    if (D.status[b] < 0) D.newidx[b] = base++;
+    else D.newidx[b] = -1;
+  }
+  if (tid == 1023) *D.n_new = cnt[1023];
+}
+
+// gather the persistent state of running instances (accepted knots + a few scalars) into scratch ...
+template <int N>
+__global__ __launch_bounds__(256) void k_compact_gather(FigParams P, FigBuffers D) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  const int nb = D.newidx[b];
+  if (nb < 0) return;
+  const double* __restrict__ qs = D.q[D.cur[b]];
+  double* __restrict__ tq = D.Z[1];   // scratch: stage data is rebuilt after compaction
+  double* __restrict__ ts = D.Dr[1];
+#pragma unroll
+  for (int j = 0; j < N; ++j) tq[((size_t)t * N + j) * Bp + nb] = qs[IDX(t, N, j)];
+  if (P.hessian == OH_HESSIAN_EXACT) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) D.g[1][((size_t)t * N + j) * Bp + nb] = D.Gfull[IDX(t, N, j)];
+  }
+  if (t == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) ts[(size_t)i * Bp + nb] = D.ref[(size_t)i * Bp + b];
+    ts[(size_t)12 * Bp + nb] = D.fconst[b];
+    ts[(size_t)13 * Bp + nb] = D.mu[b];
+    ts[(size_t)14 * Bp + nb] = (double)D.iters[b];
+    ts[(size_t)15 * Bp + nb] = (double)D.orig[b];
+  }
+}
+// ... and lay it down densely; the state machine restarts at "evaluate this point" (first = 1), which
+// re-derives the pending step bit-identically, so an instance's iterates do not depend on the batch.
+template <int N>
+__global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers D, int Bnew) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  const int Bp = D.Bp;
+  if (b >= Bnew) return;
+  const double* __restrict__ tq = D.Z[1];
+  const double* __restrict__ ts = D.Dr[1];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double v = tq[IDX(t, N, j)];
+    D.q[0][IDX(t, N, j)] = v;
+    if (t < 2) D.q[1][IDX(t, N, j)] = v;
+    if (P.hessian == OH_HESSIAN_EXACT) D.Gfull[IDX(t, N, j)] = D.g[1][IDX(t, N, j)];
+  }
+  if (t == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) D.ref[(size_t)i * Bp + b] = ts[(size_t)i * Bp + b];
+    D.fconst[b] = ts[(size_t)12 * Bp + b];
+    D.mu[b] = ts[(size_t)13 * Bp + b];
+    const int it = (int)ts[(size_t)14 * Bp + b];
+    D.iters[b] = it > 0 ? it - 1 : 0;  // the pending step is recomputed and counted again
+    D.orig[b] = (int)ts[(size_t)15 * Bp + b];
+    D.cur[b] = 1;
+    D.first[b] = 1;
+    D.status[b] = -1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -759,13 +850,14 @@ static void launch_step_t(hipStream_t s, const FigParams& P, const FigBuffers& D
   hipLaunchKernelGGL(k_step<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D);
 }
 template <int N>
-static void launch_finalize_t(hipStream_t s, const FigParams& P, const FigBuffers& D, double* x, double* f, double* kkt, int* iters,
-                              int* status) {
-  hipLaunchKernelGGL(k_finalize<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, x, f, kkt, iters, status);
+static void launch_finalize_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
+                              int* iters, int* status) {
+  hipLaunchKernelGGL(k_finalize<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, only_done, x, f, kkt, iters, status);
 }
 template <int N>
-static void launch_mult_t(hipStream_t s, const FigParams& P, const FigBuffers& D, double* lam_h) {
-  hipLaunchKernelGGL(k_multipliers<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, lam_h);
+static void launch_compact_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int phase, int Bnew) {
+  if (phase == 0) hipLaunchKernelGGL(k_compact_gather<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D);
+  else hipLaunchKernelGGL(k_compact_scatter<N>, dim3((Bnew + 255) / 256, P.T), dim3(256), 0, s, P, D, Bnew);
 }
 
 #define OH_DISPATCH_N(n, call)         \
@@ -793,15 +885,16 @@ bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& 
 #undef C
   return true;
 }
-bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, double* x, double* f, double* kkt, int* iters,
-                        int* status) {
-#define C(NN) launch_finalize_t<NN>(s, P, D, x, f, kkt, iters, status)
+bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
+                        int* iters, int* status) {
+#define C(NN) launch_finalize_t<NN>(s, P, D, only_done, x, f, kkt, iters, status)
   OH_DISPATCH_N(n, C)
 #undef C
   return true;
 }
-bool oh_launch_multipliers(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, double* lam_h) {
-#define C(NN) launch_mult_t<NN>(s, P, D, lam_h)
+void oh_launch_scan_running(hipStream_t s, const FigBuffers& D) { hipLaunchKernelGGL(k_scan_running, dim3(1), dim3(1024), 0, s, D); }
+bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew) {
+#define C(NN) launch_compact_t<NN>(s, P, D, phase, Bnew)
   OH_DISPATCH_N(n, C)
 #undef C
   return true;

@@ -50,6 +50,7 @@ struct oh_handle {
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double timing_couple = 0;
   int* h_flag = nullptr;  // pinned
   bool compaction = true;
   std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
@@ -217,7 +218,8 @@ static int ensure_capacity(oh_handle* h, int B) {
   const size_t per_t = (size_t)T * Bp;
   size_t nd = 0;  // doubles
   nd += 2 * per_q + 2 * per_Z + 2 * per_Dr + 2 * per_q /*g*/ + 4 * per_t /*phi,cv*/;
-  nd += per_q /*Gfull*/ + (size_t)T * NZ * NZ * Bp + (size_t)T * NZ * Bp;
+  nd += 2 * per_q /*Gfull*/ + (size_t)T * NZ * NZ * Bp + (size_t)T * NZ * Bp;
+  nd += 2 * (size_t)T * NZ * NZ * Bp + 2 * (size_t)T * NZ * Bp + 2 * per_t + (size_t)T * NZ * Bp;  // E, gt, merit, zstep
   nd += (size_t)12 * Bp + 6 * (size_t)Bp;
   nd += (size_t)4 * T * Bp;  // lam_h
   size_t ni = 6 * (size_t)Bp + 16;  // + n_running, n_new, work (8-byte aligned)
@@ -245,7 +247,11 @@ static int ensure_capacity(oh_handle* h, int B) {
   for (int s = 0; s < 2; ++s) D.g[s] = take(per_q);
   for (int s = 0; s < 2; ++s) D.phi[s] = take(per_t);
   for (int s = 0; s < 2; ++s) D.cv[s] = take(per_t);
-  D.Gfull = take(per_q);
+  for (int s = 0; s < 2; ++s) D.Gfull[s] = take(per_q);
+  for (int s = 0; s < 2; ++s) D.E[s] = take((size_t)T * NZ * NZ * Bp);
+  for (int s = 0; s < 2; ++s) D.gt[s] = take((size_t)T * NZ * Bp);
+  for (int s = 0; s < 2; ++s) D.merit[s] = take(per_t);
+  D.zstep = take((size_t)T * NZ * Bp);
   D.Kmat = take((size_t)T * NZ * NZ * Bp);
   D.kvec = take((size_t)T * NZ * Bp);
   D.ref = take((size_t)12 * Bp);
@@ -306,7 +312,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   const bool prof = h->profiling;
   if (prof) {
     // events: [0] start, then per iteration (after eval, after step), last = end
-    const size_t need = 3 * (size_t)(h->desc.max_iter + 44) + 64;
+    const size_t need = 4 * (size_t)(h->desc.max_iter + 44) + 64;
     while (h->prof_events.size() < need) {
       hipEvent_t e;
       HIPCHK(hipEventCreate(&e));
@@ -338,8 +344,10 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     rebase = false;
     oh_launch_eval(s, N, h->P, h->D);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(1); }
+    oh_launch_couple(s, N, h->P, h->D);
     const bool check = ((it + 1) % check_every == 0);
     if (check) HIPCHK(hipMemsetAsync(h->D.n_running, 0, sizeof(int), s));
+    if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(3); }
     oh_launch_step(s, N, h->P, h->D);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(2); }
     ++launched;
@@ -375,7 +383,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   HIPCHK(hipMemcpy(&work, h->D.work, sizeof(work), hipMemcpyDeviceToHost));
   h->timing[6] = (double)work;
   if (prof) {
-    double te = 0, tsx = 0;
+    double te = 0, tsx = 0, tc = 0;
     int n_e = 0, n_s = 0;
     for (size_t i = 1; i < ne; ++i) {
       const int tag = h->prof_tags[i];
@@ -383,12 +391,14 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       float ms2 = 0.f;
       hipEventElapsedTime(&ms2, h->prof_events[i - 1], h->prof_events[i]);
       if (tag == 1) { te += ms2; ++n_e; }
+      else if (tag == 3) { tc += ms2; }
       else { tsx += ms2; ++n_s; }
     }
     h->timing[0] = te;
     h->timing[1] = n_e;
     h->timing[2] = tsx;
     h->timing[3] = n_s;
+    h->timing_couple = tc;
   }
   h->timing[7] = compactions;
   return OH_OK;

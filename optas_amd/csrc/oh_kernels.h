@@ -32,7 +32,11 @@ struct FigBuffers {
   double* g[2];           // [slot][T][N][Bp]      tracking gradient
   double* phi[2];         // [slot][T][Bp]         tracking cost
   double* cv[2];          // [slot][T][Bp]         |c|_inf after retraction
-  double* Gfull;          // [T][N][Bp]            Lagrangian gradient at the last accepted point (exact Hessian)
+  double* Gfull[2];       // [slot][T][N][Bp]      Lagrangian gradient G_t (exact-Hessian mode: multiplier estimate)
+  double* E[2];           // [slot][T][NZ*NZ][Bp]  coupling blocks -2 kappa Z_t^T Z_{t+1}
+  double* gt[2];          // [slot][T][NZ][Bp]     reduced gradient Z_t^T G_t
+  double* merit[2];       // [slot][T][Bp]         phi_t + kappa ||q_t - q_{t-1}||^2
+  double* zstep;          // [T][NZ][Bp]           reduced step of the pending trial
   double* Kmat;           // [T][NZ*NZ][Bp]        Riccati gains
   double* kvec;           // [T][NZ][Bp]
   double* ref;            // [12][Bp]              p(qc), R(qc)
@@ -57,6 +61,7 @@ struct FigBuffers {
 void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n, const double* q, double* pose, double* J);
 bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const double* x0, const double* p);
 bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D);
+bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers& D);
 bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D);
 bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
                         int* iters, int* status);

@@ -179,13 +179,28 @@ __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D) {
   const int Bp = D.Bp;
   if (b >= D.B) return;
   if (D.status[b] >= 0) return;
-  const int slot = 1 - D.cur[b];
+  const int cur = D.cur[b];
+  const int slot = 1 - cur;
   const oh_chain* ch = D.chain;
   double* __restrict__ qs = D.q[slot];
 
+  // trial knot: the seed on the first evaluation, otherwise q_cur + Z_cur z (roll-out of the step k_step solved for)
   double q[N];
+  if (D.first[b]) {
 #pragma unroll
-  for (int j = 0; j < N; ++j) q[j] = qs[IDX(t, N, j)];
+    for (int j = 0; j < N; ++j) q[j] = qs[IDX(t, N, j)];
+  } else {
+    double zs[NZ];
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) zs[a] = D.zstep[IDX(t, NZ, a)];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double v = D.q[cur][IDX(t, N, j)];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) v += D.Z[cur][IDX(t, N * NZ, j * NZ + a)] * zs[a];
+      q[j] = v;
+    }
+  }
   double Rc[9], pc[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) pc[i] = D.ref[(size_t)i * Bp + b];
@@ -268,13 +283,13 @@ __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D) {
     // -2 w r . d2p/dq_j dq_i,  d2p/dq_j dq_i = z_j x Jp_i for j <= i (revolute j)
     // + lam . d2c/dq_j dq_i,   d2c = 1/2 z_j x z_i (j < i), exact on the constraint manifold.
     // multipliers: least squares of  G_prev + Jc^T lam = 0  with the Lagrangian gradient G_prev that
-    // k_step left for this knot at the last accepted point (lagged by one iteration; exact at convergence)
+    // k_couple left for this knot at the last accepted point (lagged by one iteration; exact at convergence)
     double lam[3] = {0.0, 0.0, 0.0};
-    {
+    if (!D.first[b]) {
       double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
 #pragma unroll
       for (int k = 0; k < N; ++k) {
-        const double Gk = D.Gfull[IDX(t, N, k)];
+        const double Gk = D.Gfull[cur][IDX(t, N, k)];
         S[0] += Jc[k][0] * Jc[k][0];
         S[1] += Jc[k][1] * Jc[k][0];
         S[2] += Jc[k][1] * Jc[k][1];
@@ -382,39 +397,134 @@ __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D) {
     }
 }
 
+// K2b: one lane per (instance b, free knot t), after k_eval: everything of the reduced block-tridiagonal
+// system that needs the neighbouring knots but not the recursion: Lagrangian gradient G_t (tracking +
+// smoothness), its projection gt = Z_t^T G_t, the coupling block E_t = -2 kappa Z_t^T Z_{t+1}, and the
+// knot's share of the merit (tracking cost + kappa ||q_t - q_{t-1}||^2).
+template <int N>
+__global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D) {
+  constexpr int NZ = N - 3;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y + 2;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (D.status[b] >= 0) return;
+  const int slot = 1 - D.cur[b];
+  const double* __restrict__ qs = D.q[slot];
+  const double* __restrict__ Zs = D.Z[slot];
+  const double kap2 = 2.0 * P.kappa;
+  const bool last = (t == P.T - 1);
+  double gt[NZ];
+  double E[NZ][NZ];
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) {
+    gt[a] = 0.0;
+#pragma unroll
+    for (int c2 = 0; c2 < NZ; ++c2) E[a][c2] = 0.0;
+  }
+  double sm = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double qm = qs[IDX(t - 1, N, k)];
+    const double q0 = qs[IDX(t, N, k)];
+    const double dm = q0 - qm;
+    sm += dm * dm;
+    double G = D.g[slot][IDX(t, N, k)] + kap2 * dm;
+    if (!last) G -= kap2 * (qs[IDX(t + 1, N, k)] - q0);
+    if (P.hessian == OH_HESSIAN_EXACT) D.Gfull[slot][IDX(t, N, k)] = G;
+    double zt[NZ], zn[NZ];
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) zt[a] = Zs[IDX(t, N * NZ, k * NZ + a)];
+    if (!last) {
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) zn[a] = Zs[IDX(t + 1, N * NZ, k * NZ + a)];
+    }
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) {
+      gt[a] += zt[a] * G;
+      if (!last) {
+#pragma unroll
+        for (int c2 = 0; c2 < NZ; ++c2) E[a][c2] -= kap2 * zt[a] * zn[c2];
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) D.gt[slot][IDX(t, NZ, a)] = gt[a];
+  if (!last) {
+#pragma unroll
+    for (int a = 0; a < NZ; ++a)
+#pragma unroll
+      for (int c2 = 0; c2 < NZ; ++c2) D.E[slot][IDX(t, NZ * NZ, a * NZ + c2)] = E[a][c2];
+  }
+  D.merit[slot][(size_t)t * Bp + b] = D.phi[slot][(size_t)t * Bp + b] + P.kappa * sm;
+}
+
+// Cholesky with reciprocal pivots (divisions are off the critical path of the Riccati chain).
+template <int M>
+OH_DEV bool chol_rcp(double (&S)[M * (M + 1) / 2], double (&rd)[M], double piv_min) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    double d = S[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= S[tri(j, k)] * S[tri(j, k)];
+    if (!(d > piv_min)) { ok = false; d = 1.0; }
+    const double inv = rsqrt(d);
+    rd[j] = inv;
+    S[tri(j, j)] = d * inv;
+#pragma unroll
+    for (int i = j + 1; i < M; ++i) {
+      double v = S[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= S[tri(i, k)] * S[tri(j, k)];
+      S[tri(i, j)] = v * inv;
+    }
+  }
+  return ok;
+}
+template <int M>
+OH_DEV void fsub_rcp(const double (&L)[M * (M + 1) / 2], const double (&rd)[M], double (&x)[M]) {
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    double v = x[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= L[tri(i, k)] * x[k];
+    x[i] = v * rd[i];
+  }
+}
+template <int M>
+OH_DEV void bsub_rcp(const double (&L)[M * (M + 1) / 2], const double (&rd)[M], double (&x)[M]) {
+#pragma unroll
+  for (int i = M - 1; i >= 0; --i) {
+    double v = x[i];
+#pragma unroll
+    for (int k = i + 1; k < M; ++k) v -= L[tri(k, i)] * x[k];
+    x[i] = v * rd[i];
+  }
+}
+
 // K3: one lane per instance: accept/reject the trial point (Levenberg-Marquardt ratio test on the
-// objective; iterates are feasible by retraction), then backward Riccati sweep over the reduced
-// block-tridiagonal system, forward roll-out, next trial knots.
+// objective; iterates are feasible by retraction), then the backward Riccati sweep over the reduced
+// block-tridiagonal system (blocks prepared by k_eval/k_couple, next knot's blocks prefetched while the
+// current knot factorises) and the forward recursion for the reduced step z_t.  Returns "still running".
 template <int N>
 OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b) {
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
   const int Bp = D.Bp;
   const int T = P.T;
-  const double kap2 = 2.0 * P.kappa;  // Hessian weight of kappa*||q_{t+1}-q_t||^2
+  const double kap2 = 2.0 * P.kappa;
   int cur = D.cur[b];
   double mu = D.mu[b];
-  int iters = D.iters[b];
+  const int iters = D.iters[b];
 
   // ---- phase A: merit of the trial slot ---------------------------------------------------------
   {
     const int ts = 1 - cur;
-    const double* __restrict__ qt = D.q[ts];
     double f = D.fconst[b];
     double feas = 0.0;
-    double qa[N], qb[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) qa[j] = qt[IDX(1, N, j)];
     for (int t = 2; t < T; ++t) {
-      double s = 0.0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        qb[j] = qt[IDX(t, N, j)];
-        const double d = qb[j] - qa[j];
-        s += d * d;
-        qa[j] = qb[j];
-      }
-      f += P.kappa * s + D.phi[ts][(size_t)t * Bp + b];
+      f += D.merit[ts][(size_t)t * Bp + b];
       feas = fmax(feas, D.cv[ts][(size_t)t * Bp + b]);
     }
     bool accept;
@@ -443,95 +553,81 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b) 
   }
 
   // ---- phase B: backward sweep on the current slot ------------------------------------------------
-  const double* __restrict__ qc_ = D.q[cur];
-  const double* __restrict__ Zc = D.Z[cur];
+  const double* __restrict__ Ec = D.E[cur];
   const double* __restrict__ Drc = D.Dr[cur];
-  const double* __restrict__ gc = D.g[cur];
+  const double* __restrict__ gtc = D.gt[cur];
   double stat = 0.0;
-  double r2[NZ];  // r at the first free knot after the sweep
-  double S[NP];
+  double S[NP], rd[NZ], rn[NZ];
   for (int attempt = 0; attempt < 40; ++attempt) {
     bool ok = true;
     stat = 0.0;
-    double rn[NZ];  // r_{t+1}
-    // t = T-1 .. 2
-    for (int t = T - 1; t >= 2; --t) {
-      // G_t = g_t + kap2*((q_t - q_{t-1}) - (q_{t+1} - q_t)),  gt = Z_t^T G_t,  E = -kap2 Z_t^T Z_{t+1}
-      double gt[NZ];
+    // last knot: S = Dr + (kap2 + mu) I, r = gt
+    {
+      const int t = T - 1;
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) gt[a] = 0.0;
-      double E[NZ][NZ];
+      for (int i = 0; i < NP; ++i) S[i] = Drc[IDX(t, NP, i)];
 #pragma unroll
-      for (int a = 0; a < NZ; ++a)
+      for (int a = 0; a < NZ; ++a) {
+        S[tri(a, a)] += kap2 + mu;
+        rn[a] = gtc[IDX(t, NZ, a)];
+        stat = fmax(stat, fabs(rn[a]));
+      }
+    }
+    // prefetch registers for knot T-2
+    double nE[NZ * NZ], nH[NP], ng[NZ];
+    if (T - 2 >= 2) {
+      const int t = T - 2;
 #pragma unroll
-        for (int c2 = 0; c2 < NZ; ++c2) E[a][c2] = 0.0;
-      const bool last = (t == T - 1);
+      for (int i = 0; i < NZ * NZ; ++i) nE[i] = Ec[IDX(t, NZ * NZ, i)];
 #pragma unroll
-      for (int k = 0; k < N; ++k) {
-        const double qm = qc_[IDX(t - 1, N, k)];
-        const double q0 = qc_[IDX(t, N, k)];
-        double G = gc[IDX(t, N, k)] + kap2 * (q0 - qm);
-        if (!last) G -= kap2 * (qc_[IDX(t + 1, N, k)] - q0);
-        double zt[NZ], zn[NZ];
+      for (int i = 0; i < NP; ++i) nH[i] = Drc[IDX(t, NP, i)];
 #pragma unroll
-        for (int a = 0; a < NZ; ++a) zt[a] = Zc[IDX(t, N * NZ, k * NZ + a)];
-        if (!last) {
+      for (int a = 0; a < NZ; ++a) ng[a] = gtc[IDX(t, NZ, a)];
+    }
+    for (int t = T - 2; t >= 2; --t) {
+      double E[NZ * NZ], Ht[NP], gt[NZ];
 #pragma unroll
-          for (int a = 0; a < NZ; ++a) zn[a] = Zc[IDX(t + 1, N * NZ, k * NZ + a)];
-        }
+      for (int i = 0; i < NZ * NZ; ++i) E[i] = nE[i];
 #pragma unroll
-        for (int a = 0; a < NZ; ++a) {
-          gt[a] += zt[a] * G;
-          if (!last) {
+      for (int i = 0; i < NP; ++i) Ht[i] = nH[i];
 #pragma unroll
-            for (int c2 = 0; c2 < NZ; ++c2) E[a][c2] -= kap2 * zt[a] * zn[c2];
-          }
-        }
+      for (int a = 0; a < NZ; ++a) gt[a] = ng[a];
+      if (t > 2) {  // issue the next knot's loads before the dependent arithmetic of this one
+        const int tn = t - 1;
+#pragma unroll
+        for (int i = 0; i < NZ * NZ; ++i) nE[i] = Ec[IDX(tn, NZ * NZ, i)];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) nH[i] = Drc[IDX(tn, NP, i)];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) ng[a] = gtc[IDX(tn, NZ, a)];
       }
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) stat = fmax(stat, fabs(gt[a]));
-      double Ht[NP];
+      for (int a = 0; a < NZ; ++a) {
+        stat = fmax(stat, fabs(gt[a]));
+        Ht[tri(a, a)] += 2.0 * kap2 + mu;
+      }
+      // S holds S_{t+1}, rn = r_{t+1}
+      ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
+      double X[NZ][NZ];  // X = L^{-1} E^T, column a from row a of E
 #pragma unroll
-      for (int i = 0; i < NP; ++i) Ht[i] = Drc[IDX(t, NP, i)];
-      const double dg = (last ? kap2 : 2.0 * kap2) + mu;
+      for (int a = 0; a < NZ; ++a) {
+        double col[NZ];
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) Ht[tri(a, a)] += dg;
-      if (last) {
+        for (int c2 = 0; c2 < NZ; ++c2) col[c2] = E[a * NZ + c2];
+        fsub_rcp<NZ>(S, rd, col);
 #pragma unroll
-        for (int i = 0; i < NP; ++i) S[i] = Ht[i];
+        for (int c2 = 0; c2 < NZ; ++c2) X[c2][a] = col[c2];
+      }
+      double u[NZ];
 #pragma unroll
-        for (int a = 0; a < NZ; ++a) rn[a] = gt[a];
-      } else {
-        // S currently holds S_{t+1}, rn = r_{t+1}
-        ok = chol_packed<NZ>(S, 1e-12) && ok;
-        // X = L^{-1} E^T  (column a of X = L^{-1} (row a of E)^T)
-        double X[NZ][NZ];  // X[:, a]
-#pragma unroll
-        for (int a = 0; a < NZ; ++a) {
-          double col[NZ];
-#pragma unroll
-          for (int c2 = 0; c2 < NZ; ++c2) col[c2] = E[a][c2];
-          fsub<NZ>(S, col);
-#pragma unroll
-          for (int c2 = 0; c2 < NZ; ++c2) X[c2][a] = col[c2];
-        }
-        double u[NZ];
-#pragma unroll
-        for (int a = 0; a < NZ; ++a) u[a] = rn[a];
-        fsub<NZ>(S, u);
-        // S_t = Ht - X^T X ; r_t = gt - X^T u
-#pragma unroll
-        for (int a = 0; a < NZ; ++a) {
-          double s = gt[a];
-#pragma unroll
-          for (int c2 = 0; c2 < NZ; ++c2) s -= X[c2][a] * u[c2];
-          rn[a] = s;
-        }
-        // gains of knot t+1: z_{t+1} = -(kvec + Kmat z_t), Kmat = L^{-T} X, kvec = L^{-T} u
+      for (int a = 0; a < NZ; ++a) u[a] = rn[a];
+      fsub_rcp<NZ>(S, rd, u);
+      // gains of knot t+1: z_{t+1} = -(kvec + Kmat z_t), Kmat = L^{-T} X, kvec = L^{-T} u (off the chain)
+      {
         double kv[NZ];
 #pragma unroll
         for (int a = 0; a < NZ; ++a) kv[a] = u[a];
-        bsub<NZ>(S, kv);
+        bsub_rcp<NZ>(S, rd, kv);
 #pragma unroll
         for (int a = 0; a < NZ; ++a) D.kvec[IDX(t + 1, NZ, a)] = kv[a];
 #pragma unroll
@@ -539,24 +635,30 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b) 
           double col[NZ];
 #pragma unroll
           for (int c2 = 0; c2 < NZ; ++c2) col[c2] = X[c2][a];
-          bsub<NZ>(S, col);
+          bsub_rcp<NZ>(S, rd, col);
 #pragma unroll
           for (int c2 = 0; c2 < NZ; ++c2) D.Kmat[IDX(t + 1, NZ * NZ, c2 * NZ + a)] = col[c2];
         }
-#pragma unroll
-        for (int a = 0; a < NZ; ++a)
-#pragma unroll
-          for (int c2 = 0; c2 <= a; ++c2) {
-            double s = Ht[tri(a, c2)];
-#pragma unroll
-            for (int k = 0; k < NZ; ++k) s -= X[k][a] * X[k][c2];
-            S[tri(a, c2)] = s;
-          }
       }
-    }
-    ok = chol_packed<NZ>(S, 1e-12) && ok;
+      // S_t = Ht - X^T X ; r_t = gt - X^T u
 #pragma unroll
-    for (int a = 0; a < NZ; ++a) r2[a] = rn[a];
+      for (int a = 0; a < NZ; ++a) {
+        double sacc = gt[a];
+#pragma unroll
+        for (int c2 = 0; c2 < NZ; ++c2) sacc -= X[c2][a] * u[c2];
+        rn[a] = sacc;
+      }
+#pragma unroll
+      for (int a = 0; a < NZ; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) {
+          double sacc = Ht[tri(a, c2)];
+#pragma unroll
+          for (int k = 0; k < NZ; ++k) sacc -= X[k][a] * X[k][c2];
+          S[tri(a, c2)] = sacc;
+        }
+    }
+    ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
     if (ok) break;
     mu = fmax(4.0 * mu, 1e-2);
   }
@@ -577,44 +679,33 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b) 
     return false;
   }
 
-  // ---- forward roll-out: z_2 = -S_2^{-1} r_2, z_{t+1} = -(kvec + Kmat z_t); trial knots ---------------
+  // ---- forward recursion: z_2 = -S_2^{-1} r_2, z_{t+1} = -(kvec + Kmat z_t) ----------------------------
   {
-    double* __restrict__ qn = D.q[1 - cur];
     double zz[NZ];
 #pragma unroll
-    for (int a = 0; a < NZ; ++a) zz[a] = -r2[a];
-    fsub<NZ>(S, zz);
-    bsub<NZ>(S, zz);
+    for (int a = 0; a < NZ; ++a) zz[a] = -rn[a];
+    fsub_rcp<NZ>(S, rd, zz);
+    bsub_rcp<NZ>(S, rd, zz);
     double gd = 0.0, z2 = 0.0;
     for (int t = 2; t < T; ++t) {
       if (t > 2) {
         double zn[NZ];
 #pragma unroll
         for (int a = 0; a < NZ; ++a) {
-          double s = D.kvec[IDX(t, NZ, a)];
+          double sacc = D.kvec[IDX(t, NZ, a)];
 #pragma unroll
-          for (int c2 = 0; c2 < NZ; ++c2) s += D.Kmat[IDX(t, NZ * NZ, a * NZ + c2)] * zz[c2];
-          zn[a] = -s;
+          for (int c2 = 0; c2 < NZ; ++c2) sacc += D.Kmat[IDX(t, NZ * NZ, a * NZ + c2)] * zz[c2];
+          zn[a] = -sacc;
         }
 #pragma unroll
         for (int a = 0; a < NZ; ++a) zz[a] = zn[a];
       }
-      const bool last = (t == T - 1);
 #pragma unroll
-      for (int k = 0; k < N; ++k) {
-        const double qm = qc_[IDX(t - 1, N, k)];
-        const double q0 = qc_[IDX(t, N, k)];
-        double G = gc[IDX(t, N, k)] + kap2 * (q0 - qm);
-        if (!last) G -= kap2 * (qc_[IDX(t + 1, N, k)] - q0);
-        double dq = 0.0;
-#pragma unroll
-        for (int a = 0; a < NZ; ++a) dq += Zc[IDX(t, N * NZ, k * NZ + a)] * zz[a];
-        gd += G * dq;
-        qn[IDX(t, N, k)] = q0 + dq;
-        if (P.hessian == OH_HESSIAN_EXACT) D.Gfull[IDX(t, N, k)] = G;
+      for (int a = 0; a < NZ; ++a) {
+        D.zstep[IDX(t, NZ, a)] = zz[a];
+        gd += gtc[IDX(t, NZ, a)] * zz[a];
+        z2 += zz[a] * zz[a];
       }
-#pragma unroll
-      for (int a = 0; a < NZ; ++a) z2 += zz[a] * zz[a];
     }
     D.pred[b] = -0.5 * gd + 0.5 * mu * z2;
   }
@@ -785,7 +876,7 @@ __global__ __launch_bounds__(256) void k_compact_gather(FigParams P, FigBuffers 
   for (int j = 0; j < N; ++j) tq[((size_t)t * N + j) * Bp + nb] = qs[IDX(t, N, j)];
   if (P.hessian == OH_HESSIAN_EXACT) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) D.g[1][((size_t)t * N + j) * Bp + nb] = D.Gfull[IDX(t, N, j)];
+    for (int j = 0; j < N; ++j) D.g[1][((size_t)t * N + j) * Bp + nb] = D.Gfull[D.cur[b]][IDX(t, N, j)];
   }
   if (t == 0) {
 #pragma unroll
@@ -811,7 +902,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
     const double v = tq[IDX(t, N, j)];
     D.q[0][IDX(t, N, j)] = v;
     if (t < 2) D.q[1][IDX(t, N, j)] = v;
-    if (P.hessian == OH_HESSIAN_EXACT) D.Gfull[IDX(t, N, j)] = D.g[1][IDX(t, N, j)];
+    if (P.hessian == OH_HESSIAN_EXACT) D.Gfull[1][IDX(t, N, j)] = D.g[1][IDX(t, N, j)];  // cur = 1 after compaction
   }
   if (t == 0) {
 #pragma unroll
@@ -846,6 +937,10 @@ static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D
   hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D);
 }
 template <int N>
+static void launch_couple_t(hipStream_t s, const FigParams& P, const FigBuffers& D) {
+  hipLaunchKernelGGL(k_couple<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D);
+}
+template <int N>
 static void launch_step_t(hipStream_t s, const FigParams& P, const FigBuffers& D) {
   hipLaunchKernelGGL(k_step<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D);
 }
@@ -875,6 +970,12 @@ bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers&
 }
 bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D) {
 #define C(NN) launch_eval_t<NN>(s, P, D)
+  OH_DISPATCH_N(n, C)
+#undef C
+  return true;
+}
+bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers& D) {
+#define C(NN) launch_couple_t<NN>(s, P, D)
   OH_DISPATCH_N(n, C)
 #undef C
   return true;

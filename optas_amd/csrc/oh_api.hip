@@ -222,7 +222,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   nd += 2 * (size_t)T * NZ * NZ * Bp + 2 * (size_t)T * NZ * Bp + 2 * per_t + (size_t)T * NZ * Bp;  // E, gt, merit, zstep
   nd += (size_t)12 * Bp + 6 * (size_t)Bp;
   nd += (size_t)4 * T * Bp;  // lam_h
-  size_t ni = 6 * (size_t)Bp + 16;  // + n_running, n_new, work (8-byte aligned)
+  size_t ni = 7 * (size_t)Bp + 16;  // + n_running, n_new, work (8-byte aligned)
   size_t bytes = nd * sizeof(double) + ni * sizeof(int);
   void* pool = nullptr;
   hipError_t e = hipMalloc(&pool, bytes);
@@ -265,6 +265,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   int* ip = (int*)d;
   D.cur = ip; ip += Bp;
   D.first = ip; ip += Bp;
+  D.move = ip; ip += Bp;
   D.status = ip; ip += Bp;
   D.iters = ip; ip += Bp;
   D.orig = ip; ip += Bp;
@@ -342,13 +343,14 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       h->prof_tags.push_back(0);
     }
     rebase = false;
-    oh_launch_eval(s, N, h->P, h->D);
+    const int slot = it & 1;
+    oh_launch_eval(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(1); }
-    oh_launch_couple(s, N, h->P, h->D);
+    oh_launch_couple(s, N, h->P, h->D, slot);
     const bool check = ((it + 1) % check_every == 0);
     if (check) HIPCHK(hipMemsetAsync(h->D.n_running, 0, sizeof(int), s));
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(3); }
-    oh_launch_step(s, N, h->P, h->D);
+    oh_launch_step(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(2); }
     ++launched;
     if (check) {
@@ -360,8 +362,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       if (h->compaction && h->D.B >= 512 && 2 * nrun <= h->D.B) {
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
         oh_launch_scan_running(s, h->D);
-        oh_launch_compact(s, N, h->P, h->D, 0, 0);
-        oh_launch_compact(s, N, h->P, h->D, 1, nrun);
+        oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
+        oh_launch_compact(s, N, h->P, h->D, 1, nrun, (it + 1) & 1);
         h->D.B = nrun;
         ++compactions;
         // the compaction kernels are accounted to neither eval nor step: restart the event pair

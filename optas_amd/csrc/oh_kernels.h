@@ -48,6 +48,7 @@ struct FigBuffers {
   double* feas;           // [Bp]
   int* cur;               // [Bp] slot holding the accepted point
   int* first;             // [Bp]
+  int* move;              // [Bp] 1: last trial rejected, accepted point must be moved out of the next trial slot
   int* status;            // [Bp] -1 running, else OH_STATUS_*
   int* iters;             // [Bp]
   int* orig;              // [Bp] original instance index (instances are compacted as the batch drains)
@@ -60,10 +61,10 @@ struct FigBuffers {
 
 void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n, const double* q, double* pose, double* J);
 bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const double* x0, const double* p);
-bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D);
-bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers& D);
-bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D);
+bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
                         int* iters, int* status);
 void oh_launch_scan_running(hipStream_t s, const FigBuffers& D);
-bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew);
+bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot);

@@ -157,8 +157,9 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
       D.q[1][IDX(tt, N, j)] = (tt < 2) ? qc[j] : 0.0;
     }
   }
-  D.cur[b] = 1;  // trial slot = 0
+  D.cur[b] = 1;  // trial slot of launch 0 is slot 0
   D.first[b] = 1;
+  D.move[b] = 0;
   D.orig[b] = b;
   D.status[b] = -1;  // running
   D.iters[b] = 0;
@@ -172,17 +173,41 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
 // K2: one lane per (instance b, free knot t): retraction onto R(q_t)=Rc, FK chain + Jacobians,
 // tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block.
 template <int N>
-__global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D) {
+__global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D, const int slot) {
   constexpr int NZ = N - 3;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y + 2;
   const int Bp = D.Bp;
   if (b >= D.B) return;
   if (D.status[b] >= 0) return;
-  const int cur = D.cur[b];
-  const int slot = 1 - cur;
+  // Uniform slots: every running instance writes this launch's trial into `slot` and keeps its accepted
+  // point in `cur` = 1 - slot, so all lanes of a wavefront touch the same arrays (full 512-B lines).  An
+  // instance whose previous trial was rejected still has its accepted point in `slot`: move it first.
+  const int cur = 1 - slot;
   const oh_chain* ch = D.chain;
   double* __restrict__ qs = D.q[slot];
+  if (D.move[b]) {
+    constexpr int NPk = NZ * (NZ + 1) / 2;
+#pragma unroll
+    for (int j = 0; j < N; ++j) D.q[cur][IDX(t, N, j)] = D.q[slot][IDX(t, N, j)];
+#pragma unroll
+    for (int j = 0; j < N * NZ; ++j) D.Z[cur][IDX(t, N * NZ, j)] = D.Z[slot][IDX(t, N * NZ, j)];
+#pragma unroll
+    for (int j = 0; j < NPk; ++j) D.Dr[cur][IDX(t, NPk, j)] = D.Dr[slot][IDX(t, NPk, j)];
+#pragma unroll
+    for (int j = 0; j < N; ++j) D.g[cur][IDX(t, N, j)] = D.g[slot][IDX(t, N, j)];
+#pragma unroll
+    for (int j = 0; j < NZ * NZ; ++j) D.E[cur][IDX(t, NZ * NZ, j)] = D.E[slot][IDX(t, NZ * NZ, j)];
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) D.gt[cur][IDX(t, NZ, j)] = D.gt[slot][IDX(t, NZ, j)];
+    D.phi[cur][(size_t)t * Bp + b] = D.phi[slot][(size_t)t * Bp + b];
+    D.cv[cur][(size_t)t * Bp + b] = D.cv[slot][(size_t)t * Bp + b];
+    D.merit[cur][(size_t)t * Bp + b] = D.merit[slot][(size_t)t * Bp + b];
+    if (P.hessian == OH_HESSIAN_EXACT) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) D.Gfull[cur][IDX(t, N, j)] = D.Gfull[slot][IDX(t, N, j)];
+    }
+  }
 
   // trial knot: the seed on the first evaluation, otherwise q_cur + Z_cur z (roll-out of the step k_step solved for)
   double q[N];
@@ -402,14 +427,13 @@ __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D) {
 // smoothness), its projection gt = Z_t^T G_t, the coupling block E_t = -2 kappa Z_t^T Z_{t+1}, and the
 // knot's share of the merit (tracking cost + kappa ||q_t - q_{t-1}||^2).
 template <int N>
-__global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D) {
+__global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const int slot) {
   constexpr int NZ = N - 3;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y + 2;
   const int Bp = D.Bp;
   if (b >= D.B) return;
   if (D.status[b] >= 0) return;
-  const int slot = 1 - D.cur[b];
   const double* __restrict__ qs = D.q[slot];
   const double* __restrict__ Zs = D.Z[slot];
   const double kap2 = 2.0 * P.kappa;
@@ -508,19 +532,18 @@ OH_DEV void bsub_rcp(const double (&L)[M * (M + 1) / 2], const double (&rd)[M], 
 // block-tridiagonal system (blocks prepared by k_eval/k_couple, next knot's blocks prefetched while the
 // current knot factorises) and the forward recursion for the reduced step z_t.  Returns "still running".
 template <int N>
-OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b) {
+OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, const int ts) {
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
   const int Bp = D.Bp;
   const int T = P.T;
   const double kap2 = 2.0 * P.kappa;
-  int cur = D.cur[b];
+  int cur = 1 - ts;  // uniform-slot invariant (see k_eval): the accepted point is in the other slot
   double mu = D.mu[b];
   const int iters = D.iters[b];
 
   // ---- phase A: merit of the trial slot ---------------------------------------------------------
   {
-    const int ts = 1 - cur;
     double f = D.fconst[b];
     double feas = 0.0;
     for (int t = 2; t < T; ++t) {
@@ -546,10 +569,11 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b) 
     }
     if (accept) {
       cur = ts;
-      D.cur[b] = cur;
       D.f_cur[b] = f;
       D.feas[b] = feas;
     }
+    D.cur[b] = cur;
+    D.move[b] = accept ? 0 : 1;  // rejected: the accepted point sits where the next trial goes
   }
 
   // ---- phase B: backward sweep on the current slot ------------------------------------------------
@@ -715,7 +739,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b) 
 }
 
 template <int N>
-__global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D) {
+__global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D, const int slot) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool running = (b < D.B) && (D.status[b] < 0);
   {
@@ -723,7 +747,7 @@ __global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D) {
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(D.work, (unsigned long long)__popcll(m));
   }
   bool still = false;
-  if (running) still = step_instance<N>(P, D, b);
+  if (running) still = step_instance<N>(P, D, b, slot);
   const unsigned long long m2 = __ballot(still);
   if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
 }
@@ -890,7 +914,7 @@ __global__ __launch_bounds__(256) void k_compact_gather(FigParams P, FigBuffers 
 // ... and lay it down densely; the state machine restarts at "evaluate this point" (first = 1), which
 // re-derives the pending step bit-identically, so an instance's iterates do not depend on the batch.
 template <int N>
-__global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers D, int Bnew) {
+__global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers D, int Bnew, const int slot) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   const int Bp = D.Bp;
@@ -900,9 +924,9 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     const double v = tq[IDX(t, N, j)];
-    D.q[0][IDX(t, N, j)] = v;
-    if (t < 2) D.q[1][IDX(t, N, j)] = v;
-    if (P.hessian == OH_HESSIAN_EXACT) D.Gfull[1][IDX(t, N, j)] = D.g[1][IDX(t, N, j)];  // cur = 1 after compaction
+    D.q[slot][IDX(t, N, j)] = v;
+    if (t < 2) D.q[1 - slot][IDX(t, N, j)] = v;
+    if (P.hessian == OH_HESSIAN_EXACT) D.Gfull[1 - slot][IDX(t, N, j)] = D.g[1][IDX(t, N, j)];
   }
   if (t == 0) {
 #pragma unroll
@@ -912,8 +936,9 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
     const int it = (int)ts[(size_t)14 * Bp + b];
     D.iters[b] = it > 0 ? it - 1 : 0;  // the pending step is recomputed and counted again
     D.orig[b] = (int)ts[(size_t)15 * Bp + b];
-    D.cur[b] = 1;
+    D.cur[b] = 1 - slot;
     D.first[b] = 1;
+    D.move[b] = 0;
     D.status[b] = -1;
   }
 }
@@ -933,16 +958,16 @@ static void launch_setup_t(hipStream_t s, const FigParams& P, const FigBuffers& 
   hipLaunchKernelGGL(k_setup<N>, dim3(D.Bp / 64), dim3(64), 0, s, P, D, x0, p);
 }
 template <int N>
-static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D) {
-  hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D);
+static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
+  hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D, slot);
 }
 template <int N>
-static void launch_couple_t(hipStream_t s, const FigParams& P, const FigBuffers& D) {
-  hipLaunchKernelGGL(k_couple<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D);
+static void launch_couple_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
+  hipLaunchKernelGGL(k_couple<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D, slot);
 }
 template <int N>
-static void launch_step_t(hipStream_t s, const FigParams& P, const FigBuffers& D) {
-  hipLaunchKernelGGL(k_step<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D);
+static void launch_step_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
+  hipLaunchKernelGGL(k_step<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, slot);
 }
 template <int N>
 static void launch_finalize_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
@@ -950,9 +975,9 @@ static void launch_finalize_t(hipStream_t s, const FigParams& P, const FigBuffer
   hipLaunchKernelGGL(k_finalize<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, only_done, x, f, kkt, iters, status);
 }
 template <int N>
-static void launch_compact_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int phase, int Bnew) {
+static void launch_compact_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {
   if (phase == 0) hipLaunchKernelGGL(k_compact_gather<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D);
-  else hipLaunchKernelGGL(k_compact_scatter<N>, dim3((Bnew + 255) / 256, P.T), dim3(256), 0, s, P, D, Bnew);
+  else hipLaunchKernelGGL(k_compact_scatter<N>, dim3((Bnew + 255) / 256, P.T), dim3(256), 0, s, P, D, Bnew, slot);
 }
 
 #define OH_DISPATCH_N(n, call)         \
@@ -968,20 +993,20 @@ bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers&
 #undef C
   return true;
 }
-bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D) {
-#define C(NN) launch_eval_t<NN>(s, P, D)
+bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
+#define C(NN) launch_eval_t<NN>(s, P, D, slot)
   OH_DISPATCH_N(n, C)
 #undef C
   return true;
 }
-bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers& D) {
-#define C(NN) launch_couple_t<NN>(s, P, D)
+bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
+#define C(NN) launch_couple_t<NN>(s, P, D, slot)
   OH_DISPATCH_N(n, C)
 #undef C
   return true;
 }
-bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D) {
-#define C(NN) launch_step_t<NN>(s, P, D)
+bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
+#define C(NN) launch_step_t<NN>(s, P, D, slot)
   OH_DISPATCH_N(n, C)
 #undef C
   return true;
@@ -994,8 +1019,8 @@ bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffe
   return true;
 }
 void oh_launch_scan_running(hipStream_t s, const FigBuffers& D) { hipLaunchKernelGGL(k_scan_running, dim3(1), dim3(1024), 0, s, D); }
-bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew) {
-#define C(NN) launch_compact_t<NN>(s, P, D, phase, Bnew)
+bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {
+#define C(NN) launch_compact_t<NN>(s, P, D, phase, Bnew, slot)
   OH_DISPATCH_N(n, C)
 #undef C
   return true;

@@ -159,7 +159,7 @@ def main():
         be.solve_device(B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
     sync_all()
     t0 = time.perf_counter()
-    tm = {"eval_ms": 0.0, "step_ms": 0.0, "eval_launches": 0, "step_launches": 0, "instance_launches": 0, "solve_ms": 0.0}
+    tm = {"eval_ms": 0.0, "step_ms": 0.0, "couple_ms": 0.0, "eval_launches": 0, "step_launches": 0, "instance_launches": 0, "solve_ms": 0.0, "rejected_steps": 0, "compactions": 0}
     for _ in range(args.steps):
         be.solve_device(B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
         t = be.timing()
@@ -278,6 +278,9 @@ def main():
             "f_mean": float(fvals.mean()),
         },
         "device_ms_per_step": tm["solve_ms"] / args.steps,
+        "kernel_ms_per_step": {"k_eval": tm["eval_ms"] / args.steps, "k_couple": tm["couple_ms"] / args.steps, "k_step": tm["step_ms"] / args.steps},
+        "rejected_step_frac": tm["rejected_steps"] / max(1, tm["instance_launches"]),
+        "compactions_per_step": tm["compactions"] / args.steps,
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample)

@@ -112,7 +112,7 @@ class FigureEightBackend:
         _lib.check(_lib.load().oh_set_profiling(self._h, 1 if on else 0), "oh_set_profiling")
 
     def timing(self) -> dict:
-        out = (C.c_double * 8)()
+        out = (C.c_double * 10)()
         _lib.check(_lib.load().oh_get_timing(self._h, out), "oh_get_timing")
         return {
             "eval_ms": out[0],
@@ -123,6 +123,8 @@ class FigureEightBackend:
             "iterations_launched": int(out[5]),
             "instance_launches": int(out[6]),
             "compactions": int(out[7]),
+            "couple_ms": out[8],
+            "rejected_steps": int(out[9]),
         }
 
     def fk_jac_soa_device(self, n: int, d_q, d_pose, d_J) -> None:

@@ -51,6 +51,7 @@ struct oh_handle {
   std::vector<hipEvent_t> prof_events;
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double timing_couple = 0;
+  double rejects = 0;
   int* h_flag = nullptr;  // pinned
   bool compaction = true;
   std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
@@ -222,7 +223,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   nd += 2 * (size_t)T * NZ * NZ * Bp + 2 * (size_t)T * NZ * Bp + 2 * per_t + (size_t)T * NZ * Bp;  // E, gt, merit, zstep
   nd += (size_t)12 * Bp + 6 * (size_t)Bp;
   nd += (size_t)4 * T * Bp;  // lam_h
-  size_t ni = 7 * (size_t)Bp + 16;  // + n_running, n_new, work (8-byte aligned)
+  size_t ni = 7 * (size_t)Bp + 24;  // + n_running, n_new, work (8-byte aligned)
   size_t bytes = nd * sizeof(double) + ni * sizeof(int);
   void* pool = nullptr;
   hipError_t e = hipMalloc(&pool, bytes);
@@ -272,6 +273,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.newidx = ip; ip += Bp;
   D.n_running = ip; ip += 1;
   D.n_new = ip; ip += 1;
+  D.any_move = ip; ip += 2;
   D.work = (unsigned long long*)ip;
   return OH_OK;
 }
@@ -321,7 +323,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     }
   }
   HIPCHK(hipEventRecord(h->ev0, s));
-  HIPCHK(hipMemsetAsync(h->D.work, 0, sizeof(unsigned long long), s));
+  HIPCHK(hipMemsetAsync(h->D.work, 0, 2 * sizeof(unsigned long long), s));
+  HIPCHK(hipMemsetAsync(h->D.any_move, 0, 2 * sizeof(int), s));
   if (!oh_launch_setup(s, N, h->P, h->D, (const double*)d_x0, (const double*)d_p))
     return fail(OH_ERR_INVALID, "oh_solve_device: unsupported ndof");
   size_t ne = 0;
@@ -381,9 +384,10 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->timing[4] = ms;
   h->timing[5] = launched;
-  unsigned long long work = 0;
-  HIPCHK(hipMemcpy(&work, h->D.work, sizeof(work), hipMemcpyDeviceToHost));
-  h->timing[6] = (double)work;
+  unsigned long long work[2] = {0, 0};
+  HIPCHK(hipMemcpy(work, h->D.work, sizeof(work), hipMemcpyDeviceToHost));
+  h->timing[6] = (double)work[0];
+  h->rejects = (double)work[1];
   if (prof) {
     double te = 0, tsx = 0, tc = 0;
     int n_e = 0, n_s = 0;
@@ -508,6 +512,8 @@ extern "C" int oh_set_profiling(oh_handle* h, int enable) {
 extern "C" int oh_get_timing(oh_handle* h, double* out8) {
   if (!h || !out8) return fail(OH_ERR_INVALID, "oh_get_timing: null argument");
   for (int i = 0; i < 8; ++i) out8[i] = h->timing[i];
+  out8[8] = h->timing_couple;
+  out8[9] = h->rejects;
   return OH_OK;
 }
 extern "C" int oh_event_timer_start(oh_handle* h) {

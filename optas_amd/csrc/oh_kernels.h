@@ -53,6 +53,7 @@ struct FigBuffers {
   int* iters;             // [Bp]
   int* orig;              // [Bp] original instance index (instances are compacted as the batch drains)
   int* newidx;            // [Bp] scratch of the compaction scan
+  int* any_move;          // [2] per launch parity: some instance rejected its trial
   int* n_running;         // [1] instances still running after the last k_step
   int* n_new;             // [1] result of the compaction scan
   double* lam_h;          // [B][T][4] multipliers of the quaternion rows, reference form (original order)

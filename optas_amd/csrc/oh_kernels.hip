@@ -170,6 +170,38 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
   D.feas[b] = 0.0;
 }
 
+// Rare path of the uniform-slot scheme: instances whose last trial was rejected still hold their accepted
+// point in the slot the next trial is about to overwrite; copy that knot's stage data to the other slot.
+// any_move[(slot+1)&1] was raised by the previous k_step if at least one instance rejected; otherwise every
+// workgroup leaves immediately.
+template <int N>
+__global__ __launch_bounds__(256) void k_move(FigParams P, FigBuffers D, const int slot) {
+  constexpr int NZ = N - 3;
+  constexpr int NPk = NZ * (NZ + 1) / 2;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y + 2;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) D.any_move[slot & 1] = 0;  // for this launch's k_step
+  if (D.any_move[(slot + 1) & 1] == 0) return;
+  if (b >= D.B || D.status[b] >= 0 || !D.move[b]) return;
+  const int cur = 1 - slot;
+  const size_t st = (size_t)D.Bp;
+  auto mv = [&](double* __restrict__ dst, const double* __restrict__ src, int K) {
+    const size_t o = ((size_t)t * K) * st + b;
+#pragma unroll 4
+    for (int j = 0; j < K; ++j) dst[o + j * st] = src[o + j * st];
+  };
+  mv(D.q[cur], D.q[slot], N);
+  mv(D.Z[cur], D.Z[slot], N * NZ);
+  mv(D.Dr[cur], D.Dr[slot], NPk);
+  mv(D.g[cur], D.g[slot], N);
+  mv(D.E[cur], D.E[slot], NZ * NZ);
+  mv(D.gt[cur], D.gt[slot], NZ);
+  mv(D.phi[cur], D.phi[slot], 1);
+  mv(D.cv[cur], D.cv[slot], 1);
+  mv(D.merit[cur], D.merit[slot], 1);
+  if (P.hessian == OH_HESSIAN_EXACT) mv(D.Gfull[cur], D.Gfull[slot], N);
+}
+
 // K2: one lane per (instance b, free knot t): retraction onto R(q_t)=Rc, FK chain + Jacobians,
 // tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block.
 template <int N>
@@ -182,33 +214,10 @@ __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D, const i
   if (D.status[b] >= 0) return;
   // Uniform slots: every running instance writes this launch's trial into `slot` and keeps its accepted
   // point in `cur` = 1 - slot, so all lanes of a wavefront touch the same arrays (full 512-B lines).  An
-  // instance whose previous trial was rejected still has its accepted point in `slot`: move it first.
+  // instance whose previous trial was rejected had its accepted point in `slot`: k_move ran before us.
   const int cur = 1 - slot;
   const oh_chain* ch = D.chain;
   double* __restrict__ qs = D.q[slot];
-  if (D.move[b]) {
-    constexpr int NPk = NZ * (NZ + 1) / 2;
-#pragma unroll
-    for (int j = 0; j < N; ++j) D.q[cur][IDX(t, N, j)] = D.q[slot][IDX(t, N, j)];
-#pragma unroll
-    for (int j = 0; j < N * NZ; ++j) D.Z[cur][IDX(t, N * NZ, j)] = D.Z[slot][IDX(t, N * NZ, j)];
-#pragma unroll
-    for (int j = 0; j < NPk; ++j) D.Dr[cur][IDX(t, NPk, j)] = D.Dr[slot][IDX(t, NPk, j)];
-#pragma unroll
-    for (int j = 0; j < N; ++j) D.g[cur][IDX(t, N, j)] = D.g[slot][IDX(t, N, j)];
-#pragma unroll
-    for (int j = 0; j < NZ * NZ; ++j) D.E[cur][IDX(t, NZ * NZ, j)] = D.E[slot][IDX(t, NZ * NZ, j)];
-#pragma unroll
-    for (int j = 0; j < NZ; ++j) D.gt[cur][IDX(t, NZ, j)] = D.gt[slot][IDX(t, NZ, j)];
-    D.phi[cur][(size_t)t * Bp + b] = D.phi[slot][(size_t)t * Bp + b];
-    D.cv[cur][(size_t)t * Bp + b] = D.cv[slot][(size_t)t * Bp + b];
-    D.merit[cur][(size_t)t * Bp + b] = D.merit[slot][(size_t)t * Bp + b];
-    if (P.hessian == OH_HESSIAN_EXACT) {
-#pragma unroll
-      for (int j = 0; j < N; ++j) D.Gfull[cur][IDX(t, N, j)] = D.Gfull[slot][IDX(t, N, j)];
-    }
-  }
-
   // trial knot: the seed on the first evaluation, otherwise q_cur + Z_cur z (roll-out of the step k_step solved for)
   double q[N];
   if (D.first[b]) {
@@ -574,6 +583,10 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     }
     D.cur[b] = cur;
     D.move[b] = accept ? 0 : 1;  // rejected: the accepted point sits where the next trial goes
+    if (!accept) {
+      atomicAdd(D.work + 1, 1ULL);
+      D.any_move[ts & 1] = 1;
+    }
   }
 
   // ---- phase B: backward sweep on the current slot ------------------------------------------------
@@ -959,6 +972,7 @@ static void launch_setup_t(hipStream_t s, const FigParams& P, const FigBuffers& 
 }
 template <int N>
 static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
+  hipLaunchKernelGGL(k_move<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D, slot);
   hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D, slot);
 }
 template <int N>

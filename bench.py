@@ -67,17 +67,17 @@ def local_path():
 def cpu_baseline(sample: int):
     """The oracle's numpy port of the same structured SQP, timed on this box's host cores (1 thread)."""
     from oracle.robot import OracleRobot
-    from oracle.structured import StructuredFigureEight, solve_structured
+    from oracle.structured import StructuredFigureEight, solve_structured_lm
 
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     robot = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json"))
     prob = StructuredFigureEight(robot, LINK, T=T, Tmax=TMAX)
     _, qc = make_inputs(sample, 0)
-    solve_structured(prob, qc[0], max_iter=3, tol=1e-6, exact=False)  # warm-up (reference convention: one warm-up solve)
+    solve_structured_lm(prob, qc[0], max_iter=3, tol=1e-6)  # warm-up (reference convention: one warm-up solve)
     t0 = time.perf_counter()
     its = []
     for i in range(sample):
-        r = solve_structured(prob, qc[i], max_iter=300, tol=1e-6, exact=False)
+        r = solve_structured_lm(prob, qc[i], max_iter=300, tol=1e-6)
         its.append(r["iters"])
         if time.perf_counter() - t0 > 30.0:
             sample = i + 1
@@ -88,8 +88,8 @@ def cpu_baseline(sample: int):
         "unit": "solves/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{sample} instances of the same workload (first of rank 0's batch), numpy port of the structured SQP "
-        f"(oracle/structured.py), tol 1e-6, mean {np.mean(its):.0f} iterations, {dt:.1f} s; host has {len(os.sched_getaffinity(0))} cores",
+        "sample": f"{sample} instances of the same workload (first of rank 0's batch), numpy port of the HIP state machine "
+        f"(oracle/structured.py:solve_structured_lm), tol 1e-6, mean {np.mean(its):.0f} iterations, {dt:.1f} s; host has {len(os.sched_getaffinity(0))} cores",
     }
 
 
@@ -111,11 +111,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
-        import torch
-        import torch.distributed as dist  # RCCL via the "nccl" backend
+        from optas_amd import distributed as oad
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = oad.init_process_group("nccl", local_rank)  # RCCL
     lib = _lib.load()
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: liboptas_hip has no CPU path")
@@ -129,13 +127,9 @@ def main():
         # the one collective of the whole job: kinematic constants, rank 0 -> all, over RCCL/xGMI
         import torch
 
-        nbytes = C.sizeof(_lib.oh_chain)
-        buf = torch.zeros(nbytes, dtype=torch.uint8, device=f"cuda:{local_rank}")
-        if rank == 0:
-            buf.copy_(torch.frombuffer(bytearray(bytes(chain)), dtype=torch.uint8))
-        dist.broadcast(buf, src=0)
+        buf, _ = oad.broadcast_chain(chain, f"cuda:{local_rank}", src=0)
         torch.cuda.synchronize()
-        be.set_constants_device(buf.data_ptr(), nbytes)
+        be.set_constants_device(buf.data_ptr(), C.sizeof(_lib.oh_chain))
 
     B = args.batch
     x0, qc = make_inputs(B, rank)
@@ -168,11 +162,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        import torch
-
-        te = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        elapsed = oad.max_over_ranks(elapsed, f"cuda:{local_rank}")
 
     status = d_st.download(np.int32, (B,))
     iters = d_it.download(np.int32, (B,))

@@ -221,7 +221,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   nd += 2 * per_q + 2 * per_Z + 2 * per_Dr + 2 * per_q /*g*/ + 4 * per_t /*phi,cv*/;
   nd += 2 * per_q /*Gfull*/ + (size_t)T * NZ * NZ * Bp + (size_t)T * NZ * Bp;
   nd += 2 * (size_t)T * NZ * NZ * Bp + 2 * (size_t)T * NZ * Bp + 2 * per_t + (size_t)T * NZ * Bp;  // E, gt, merit, zstep
-  nd += (size_t)12 * Bp + 6 * (size_t)Bp;
+  nd += (size_t)12 * Bp + 7 * (size_t)Bp;
   nd += (size_t)4 * T * Bp;  // lam_h
   size_t ni = 7 * (size_t)Bp + 24;  // + n_running, n_new, work (8-byte aligned)
   size_t bytes = nd * sizeof(double) + ni * sizeof(int);
@@ -260,6 +260,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.f_cur = take(Bp);
   D.pred = take(Bp);
   D.mu = take(Bp);
+  D.nun = take(Bp);
   D.stat = take(Bp);
   D.feas = take(Bp);
   D.lam_h = take((size_t)4 * T * Bp);

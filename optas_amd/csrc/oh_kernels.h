@@ -43,7 +43,8 @@ struct FigBuffers {
   double* fconst;         // [Bp]
   double* f_cur;          // [Bp]
   double* pred;           // [Bp]
-  double* mu;             // [Bp]
+  double* mu;             // [Bp]  Levenberg-Marquardt damping
+  double* nun;            // [Bp]  Nielsen growth factor
   double* stat;           // [Bp]
   double* feas;           // [Bp]
   int* cur;               // [Bp] slot holding the accepted point

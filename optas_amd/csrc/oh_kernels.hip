@@ -166,6 +166,7 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
   D.f_cur[b] = 0.0;
   D.pred[b] = 0.0;
   D.mu[b] = P.mu0;
+  D.nun[b] = 2.0;
   D.stat[b] = 0.0;
   D.feas[b] = 0.0;
 }
@@ -569,12 +570,18 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       const double rho = (fc - f) / fmax(pred, 1e-300);
       // also accept steps whose predicted decrease is at rounding level of f (end game)
       accept = (f == f) && (feas <= P.feas_accept) && (rho > 1e-4 || (pred <= 1e-15 * fabs(fc) && f <= fc + 1e-14 * fabs(fc)));
+      // Nielsen's damping update: smooth decrease after good steps, doubling growth factor after rejections
+      double nun = D.nun[b];
       if (accept) {
-        if (rho > 0.75) mu = (mu > 1e-6) ? mu * 0.2 : 0.0;
-        else if (rho < 0.25) mu = fmax(4.0 * mu, 1e-3);
+        const double w3 = 2.0 * rho - 1.0;
+        mu *= fmax(1.0 / 3.0, 1.0 - w3 * w3 * w3);
+        if (mu < 1e-7) mu = 0.0;
+        nun = 2.0;
       } else {
-        mu = fmax(4.0 * mu, 1e-3);
+        mu = fmax(mu * nun, 1e-3);
+        nun *= 2.0;
       }
+      D.nun[b] = nun;
     }
     if (accept) {
       cur = ts;
@@ -946,6 +953,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
     for (int i = 0; i < 12; ++i) D.ref[(size_t)i * Bp + b] = ts[(size_t)i * Bp + b];
     D.fconst[b] = ts[(size_t)12 * Bp + b];
     D.mu[b] = ts[(size_t)13 * Bp + b];
+    D.nun[b] = 2.0;
     const int it = (int)ts[(size_t)14 * Bp + b];
     D.iters[b] = it > 0 ? it - 1 : 0;  // the pending step is recomputed and counted again
     D.orig[b] = (int)ts[(size_t)15 * Bp + b];

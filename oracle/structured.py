@@ -249,3 +249,131 @@ def solve_structured(prob: StructuredFigureEight, qc, Q0=None, max_iter=60, tol=
         Q = Qt
         lam = lam_qp
     return {"Q": Q, "f": fval, "iters": it, "stat": stat, "feas": feas, "lam": lam, "history": hist, "path": path, "Rc": Rc}
+
+
+# ----------------------------------------------------------------------------------------------------
+# Port of the HIP state machine (k_eval / k_couple / k_step in optas_amd/csrc/oh_kernels.hip):
+# feasible iterates by retraction, Levenberg-Marquardt ratio test on the objective, no merit parameter.
+# ----------------------------------------------------------------------------------------------------
+def _orient(prob, Q, Rc):
+    e, Re, Jp, Jw = prob.chain.jac(Q)
+    A = Re @ Rc.T
+    c = _vee_skew(A)
+    trA = np.trace(A, axis1=1, axis2=2)
+    M = 0.5 * (trA[:, None, None] * np.eye(3)[None] - A)
+    return c, M @ Jw
+
+
+def retract(prob, Q, Rc, tol=1e-10, max_corr=4):
+    """Newton corrections q_t <- q_t - Jc^T (Jc Jc^T)^{-1} c per knot (k_eval's loop)."""
+    Q = Q.copy()
+    for _ in range(max_corr):
+        c, Jc = _orient(prob, Q, Rc)
+        bad = np.where(np.max(np.abs(c), axis=1) > tol)[0]
+        bad = bad[bad >= 2]
+        if bad.size == 0:
+            break
+        for t in bad:
+            S = Jc[t] @ Jc[t].T + 1e-14 * np.eye(3)
+            Q[t] -= Jc[t].T @ np.linalg.solve(S, c[t])
+    return Q
+
+
+def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False):
+    """Returns dict(Q, f, iters (= steps solved: accepted + rejected), rejected, stat, feas, status)."""
+    T, n = prob.T, prob.n
+    path, Rc = prob.references(qc)
+    kap = prob.kappa
+    F = slice(2, T)
+    Qc = np.tile(qc, (T, 1)) if Q0 is None else Q0.copy()
+    Qc[0] = qc
+    Qc[1] = qc
+    mu = mu0
+    iters = rejected = 0
+    first = True
+    Qt = retract(prob, Qc, Rc)
+    lam = np.zeros((T, 3))
+    cur = None
+    status = 1
+    nu_n = 2.0
+    while True:
+        # ---- k_eval + k_couple on the trial point
+        phi, g, W, c, Jc = prob.evaluate(Qt, path, Rc, lam=lam, exact=exact)
+        f_t = float(np.sum(phi) + prob.smooth_cost(Qt))
+        feas_t = float(np.max(np.abs(c[F])))
+        # ---- k_step phase A
+        if first:
+            accept = True
+            first = False
+        else:
+            rho = (cur["f"] - f_t) / max(pred, 1e-300)
+            accept = np.isfinite(f_t) and (rho > 1e-4 or (pred <= 1e-15 * abs(cur["f"]) and f_t <= cur["f"] + 1e-14 * abs(cur["f"])))
+            if rule == "hip":
+                if accept:
+                    if rho > 0.75:
+                        mu = mu * 0.2 if mu > 1e-6 else 0.0
+                    elif rho < 0.25:
+                        mu = max(4.0 * mu, 1e-3)
+                else:
+                    mu = max(4.0 * mu, 1e-3)
+            elif rule == "nielsen":
+                if accept:
+                    mu = mu * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)
+                    if mu < 1e-7:
+                        mu = 0.0
+                    nu_n = 2.0
+                else:
+                    mu = max(mu * nu_n, 1e-3)
+                    nu_n *= 2.0
+            elif rule == "gentle":
+                if accept:
+                    if rho > 0.9:
+                        mu = mu * 0.5 if mu > 1e-6 else 0.0
+                    elif rho < 0.5:
+                        mu = max(2.0 * mu, 1e-3)
+                else:
+                    mu = max(4.0 * mu, 1e-3)
+            if not accept:
+                rejected += 1
+        if accept:
+            Gs = np.zeros((T, n))
+            d = Qt[2:] - Qt[1:-1]
+            Gs[2:] += 2 * kap * d
+            Gs[1:-1] -= 2 * kap * d
+            G = g + Gs
+            Zs = np.zeros((T, n, n - 3))
+            for t in range(2, T):
+                Qm, _ = np.linalg.qr(Jc[t].T, mode="complete")
+                Zs[t] = Qm[:, 3:]
+            ndiag = np.full(T, 2.0)
+            ndiag[T - 1] = 1.0
+            Dfull = W + (2 * kap * ndiag)[:, None, None] * np.eye(n)[None]
+            cur = {
+                "Q": Qt, "f": f_t, "feas": feas_t, "Z": Zs,
+                "gt": np.einsum("tij,ti->tj", Zs[F], G[F]),
+                "Dr": np.einsum("tia,tij,tjb->tab", Zs[F], Dfull[F], Zs[F]),
+                "Er": -2 * kap * np.einsum("tia,tib->tab", Zs[2 : T - 1], Zs[3:T]),
+            }
+            if exact:
+                for t in range(2, T):
+                    lam[t] = -np.linalg.solve(Jc[t] @ Jc[t].T + 1e-14 * np.eye(3), Jc[t] @ G[t])
+        # ---- k_step phase B
+        stat = float(np.max(np.abs(cur["gt"])))
+        while True:
+            z, ok = block_tridiag_solve(cur["Dr"], cur["Er"], -cur["gt"], mu)
+            if ok:
+                break
+            mu = max(4.0 * mu, 1e-2)
+        if verbose:
+            print(f"  steps {iters:3d} f={cur['f']:.12f} stat={stat:.3e} mu={mu:.3g} rejected={rejected}")
+        if stat <= tol and cur["feas"] <= tol_feas:
+            status = 0
+            break
+        if iters >= max_iter:
+            break
+        pred = -0.5 * float(np.sum(cur["gt"] * z)) + 0.5 * mu * float(np.sum(z * z))
+        Qt = cur["Q"].copy()
+        Qt[F] += np.einsum("tia,ta->ti", cur["Z"][F], z)
+        Qt = retract(prob, Qt, Rc)
+        iters += 1
+    return {"Q": cur["Q"], "f": cur["f"], "iters": iters, "rejected": rejected, "stat": stat, "feas": cur["feas"], "status": status, "path": path, "Rc": Rc}

@@ -8,7 +8,7 @@ from conftest import KUKA_KIN
 from oracle.problems import BoothNLP, FigureEightNLP, IKExampleNLP
 from oracle.robot import OracleRobot
 from oracle.solvers import dense_sqp, kkt_reference_form, scipy_minimize
-from oracle.structured import StructuredFigureEight, solve_structured
+from oracle.structured import StructuredFigureEight, solve_structured, solve_structured_lm
 
 LINK = "end_effector_ball"
 
@@ -103,3 +103,6 @@ def test_structured_and_dense_oracles_agree(kuka, golden_nlp):
     assert nl.f(r.x, qc) >= d["f"] - 1e-6  # SLSQP may stall on the rank-deficient rows, never beats the KKT point
     s50 = solve_structured(StructuredFigureEight(kuka, LINK, T=50), qc, max_iter=300, tol=1e-9, exact=False)
     assert abs(s50["f"] - float(golden_nlp["fig8_f"])) < 1e-9
+    # the port of the HIP state machine (retraction + LM ratio test) reaches the same optimum
+    lm = solve_structured_lm(StructuredFigureEight(kuka, LINK, T=50), qc, max_iter=300, tol=1e-9)
+    assert lm["status"] == 0 and abs(lm["f"] - float(golden_nlp["fig8_f"])) < 1e-9 and lm["feas"] < 1e-9

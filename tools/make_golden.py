@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 from oracle.problems import FigureEightNLP, IKExampleNLP  # noqa: E402
 from oracle.robot import OracleRobot  # noqa: E402
 from oracle.solvers import dense_sqp, kkt_reference_form, scipy_minimize  # noqa: E402
-from oracle.structured import StructuredFigureEight, solve_structured  # noqa: E402
+from oracle.structured import StructuredFigureEight, solve_structured_lm  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
 SEED = 20260927
@@ -106,7 +106,7 @@ def nlp_golden():
     qcs, xs, fs = [], [], []
     for i in range(6):
         qc = qc0 + rng.uniform(-0.1, 0.1, 7)
-        s = solve_structured(prob, qc, max_iter=400, tol=1e-9, exact=False)
+        s = solve_structured_lm(prob, qc, max_iter=400, tol=1e-9)
         Q = s["Q"]
         x = nlp.join(Q.T, (np.diff(Q, axis=0) / nlp.dt).T)
         k = kkt_reference_form(nlp, x, qc)

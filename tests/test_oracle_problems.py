@@ -84,7 +84,7 @@ def test_figure_eight_golden_is_kkt_point(kuka, golden_nlp):
     assert k["stationarity"] < 1e-9 and k["feasibility"] < 1e-12 and k["complementarity"] < 1e-9
     for i in range(len(golden_nlp["fig8_pert_qc"])):
         k = kkt_reference_form(nlp, golden_nlp["fig8_pert_x"][i], golden_nlp["fig8_pert_qc"][i])
-        assert k["stationarity"] < 1e-8 and k["feasibility"] < 1e-12
+        assert k["stationarity"] < 1e-8 and k["feasibility"] < 1e-9  # retraction tolerance 1e-10 in the port
 
 
 def test_structured_and_dense_oracles_agree(kuka, golden_nlp):

@@ -54,6 +54,7 @@ struct oh_handle {
   double rejects = 0;
   int* h_flag = nullptr;  // pinned
   bool compaction = true;
+  int tail_threshold = 2048;  // hand the last instances to the persistent one-wave-per-instance kernel
   std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
 };
 
@@ -141,6 +142,8 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (!(h->desc.tol > 0.0)) h->desc.tol = 1e-6;
   if (!(h->desc.tol_feas > 0.0)) h->desc.tol_feas = 1e-9;
   if (h->desc.mu0 < 0.0) h->desc.mu0 = 0.0;
+  if (const char* e2 = getenv("OH_TAIL_THRESHOLD")) h->tail_threshold = atoi(e2);
+  if (const char* e3 = getenv("OH_COMPACTION")) h->compaction = atoi(e3) != 0;
   hipGetDevice(&h->device);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
       hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->evt0) != hipSuccess ||
@@ -340,8 +343,14 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   // compaction re-evaluates the survivors once.  The batch is compacted whenever at least half of it has
   // finished, so the slow tail keeps running in full wavefronts.
   const int hard_cap = h->desc.max_iter + 2 + 40;
+  const bool tail_ok = (h->desc.T - 2 <= 64) && h->tail_threshold > 0;
+  bool tail_done = false;
+  if (tail_ok && B <= h->tail_threshold) {  // small batch: the whole solve is one persistent launch
+    oh_launch_tail(s, N, h->P, h->D, 0);
+    tail_done = true;
+  }
   bool rebase = false;
-  for (int it = 0; it < hard_cap; ++it) {
+  for (int it = 0; it < hard_cap && !tail_done; ++it) {
     if (prof && rebase && ne + 3 < h->prof_events.size()) {  // host synced: do not bill the idle gap to the eval kernel
       HIPCHK(hipEventRecord(h->prof_events[ne++], s));
       h->prof_tags.push_back(0);
@@ -363,6 +372,18 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       const int nrun = *h->h_flag;
       rebase = true;
       if (nrun == 0) break;
+      if (tail_ok && nrun <= h->tail_threshold) {
+        // drain: compact the survivors and let one wavefront per instance finish them without further launches
+        oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
+        oh_launch_scan_running(s, h->D);
+        oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
+        oh_launch_compact(s, N, h->P, h->D, 1, nrun, (it + 1) & 1);
+        h->D.B = nrun;
+        ++compactions;
+        oh_launch_tail(s, N, h->P, h->D, (it + 1) & 1);
+        tail_done = true;
+        break;
+      }
       if (h->compaction && h->D.B >= 512 && 2 * nrun <= h->D.B) {
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
         oh_launch_scan_running(s, h->D);

@@ -1,0 +1,358 @@
+// Device functions of the figure-eight family shared by the batched kernels (k_eval / k_couple / k_step:
+// one lane per knot or per instance, stage data in HBM) and by the persistent tail kernel (k_tail: one
+// wavefront per instance, one lane per knot, stage data in registers).  Sharing them keeps the two paths
+// arithmetically identical operation by operation.
+#pragma once
+#include "oh_device.h"
+#include "oh_kernels.h"
+
+// Orientation residual c = vee(skew(Re Rc^T)) and M = 1/2 (tr(A) I - A) with dc = M domega.
+OH_DEV void orient_residual(const double* Re, const double* Rc, double* c, double* M) {
+  double A[9];
+  mmT3(Re, Rc, A);
+  c[0] = 0.5 * (A[7] - A[5]);
+  c[1] = 0.5 * (A[2] - A[6]);
+  c[2] = 0.5 * (A[3] - A[1]);
+  const double tr = A[0] + A[4] + A[8];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) M[i] = -0.5 * A[i];
+  M[0] += 0.5 * tr; M[4] += 0.5 * tr; M[8] += 0.5 * tr;
+}
+
+// One knot: retraction onto R(q)=Rc (q is updated in place), FK chain + Jacobians, tracking cost phi,
+// constraint violation cv, tracking gradient g, Hessian block W (Gauss-Newton, or exact with the
+// multiplier estimate from Gprev), Householder null-space basis Z of the orientation rows, Dr = Z^T W Z.
+template <int N>
+OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const int t, double (&q)[N], const double (&pc)[3],
+                      const double (&Rc)[9], const bool have_G, const double (&Gprev)[N], double& phi, double& cv, double (&g)[N],
+                      double (&Dr)[(N - 3) * (N - 2) / 2], double (&Z)[N][N - 3]) {
+  constexpr int NZ = N - 3;
+  double R[9], p[3], z[N][3], pj[N][3];
+  double Re[9], c[3], M[9];
+  double cmax;
+  for (int it = 0;; ++it) {
+    fk_chain<N>(ch, q, R, p, z, pj);
+    mm3(R, ch->R_tool, Re);
+    orient_residual(Re, Rc, c, M);
+    cmax = fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2])));
+    if (cmax <= P.tol_retract || it >= P.max_retract) break;
+    // Newton correction q <- q - Jc^T (Jc Jc^T)^{-1} c,  Jc = M Jw,  Jw[:,k] = z_k (revolute) / 0
+    double Jc[N][3];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (ch->jtype[k] == 0) mv3(M, z[k], Jc[k]);
+      else { Jc[k][0] = Jc[k][1] = Jc[k][2] = 0.0; }
+    }
+    double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      S[0] += Jc[k][0] * Jc[k][0];
+      S[1] += Jc[k][1] * Jc[k][0];
+      S[2] += Jc[k][1] * Jc[k][1];
+      S[3] += Jc[k][2] * Jc[k][0];
+      S[4] += Jc[k][2] * Jc[k][1];
+      S[5] += Jc[k][2] * Jc[k][2];
+    }
+    chol_packed<3>(S, 0.0);
+    double y[3] = {c[0], c[1], c[2]};
+    fsub<3>(S, y);
+    bsub<3>(S, y);
+#pragma unroll
+    for (int k = 0; k < N; ++k) q[k] -= dot3(Jc[k], y);
+  }
+  cv = cmax;
+
+  // end-effector position, tracking residual
+  double e[3], tv[3];
+  mv3(R, ch->p_tool, tv);
+  e[0] = p[0] + tv[0]; e[1] = p[1] + tv[1]; e[2] = p[2] + tv[2];
+  const double l[3] = {P.local_path[3 * t], P.local_path[3 * t + 1], P.local_path[3 * t + 2]};
+  double r[3];
+  mv3(Rc, l, r);
+  r[0] += pc[0] - e[0]; r[1] += pc[1] - e[1]; r[2] += pc[2] - e[2];
+  const double w = P.w_path;
+  phi = w * dot3(r, r);
+
+  // Jacobian columns
+  double Jp[N][3], Jc[N][3];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (ch->jtype[k] == 0) {
+      const double d[3] = {e[0] - pj[k][0], e[1] - pj[k][1], e[2] - pj[k][2]};
+      cross3(z[k], d, Jp[k]);
+      mv3(M, z[k], Jc[k]);
+    } else {
+      Jp[k][0] = z[k][0]; Jp[k][1] = z[k][1]; Jp[k][2] = z[k][2];
+      Jc[k][0] = Jc[k][1] = Jc[k][2] = 0.0;
+    }
+  }
+  // gradient of w ||r||^2 : -2 w Jp^T r
+#pragma unroll
+  for (int k = 0; k < N; ++k) g[k] = -2.0 * w * dot3(Jp[k], r);
+
+  // Hessian block W (packed lower): 2 w Jp^T Jp  (+ exact curvature, OH_HESSIAN_EXACT)
+  double W[N * (N + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) W[tri(i, j)] = 2.0 * w * dot3(Jp[i], Jp[j]);
+  if (P.hessian == OH_HESSIAN_EXACT) {
+    // -2 w r . d2p/dq_j dq_i,  d2p/dq_j dq_i = z_j x Jp_i for j <= i (revolute j)
+    // + lam . d2c/dq_j dq_i,   d2c = 1/2 z_j x z_i (j < i), exact on the constraint manifold.
+    // multipliers: least squares of  G_prev + Jc^T lam = 0  with the Lagrangian gradient of the last
+    // accepted point (lagged by one iteration; exact at convergence)
+    double lam[3] = {0.0, 0.0, 0.0};
+    if (have_G) {
+      double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const double Gk = Gprev[k];
+        S[0] += Jc[k][0] * Jc[k][0];
+        S[1] += Jc[k][1] * Jc[k][0];
+        S[2] += Jc[k][1] * Jc[k][1];
+        S[3] += Jc[k][2] * Jc[k][0];
+        S[4] += Jc[k][2] * Jc[k][1];
+        S[5] += Jc[k][2] * Jc[k][2];
+        lam[0] -= Jc[k][0] * Gk; lam[1] -= Jc[k][1] * Gk; lam[2] -= Jc[k][2] * Gk;
+      }
+      chol_packed<3>(S, 0.0);
+      fsub<3>(S, lam);
+      bsub<3>(S, lam);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (ch->jtype[j] == 0) {
+        double rz[3], lz[3];
+        cross3(r, z[j], rz);    // (r x z_j) . Jp_i = r . (z_j x Jp_i)
+        cross3(lam, z[j], lz);  // (lam x z_j) . z_i = lam . (z_j x z_i)
+#pragma unroll
+        for (int i = j; i < N; ++i) {
+          double v = -2.0 * w * dot3(rz, Jp[i]);
+          if (i > j && ch->jtype[i] == 0) v += 0.5 * dot3(lz, z[i]);
+          W[tri(i, j)] += v;
+        }
+      }
+    }
+  }
+
+  // Householder QR of Jc^T (N x 3): H3 H2 H1 Jc^T = [Rf; 0];  Z = H1 H2 H3 [0; I_NZ]
+  double A[3][N];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int k = 0; k < N; ++k) A[m][k] = Jc[k][m];
+  double V[3][N];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    double nrm2 = 0.0;
+#pragma unroll
+    for (int k = m; k < N; ++k) nrm2 += A[m][k] * A[m][k];
+    const double nrm = sqrt(nrm2);
+    const double alpha = (A[m][m] > 0.0) ? -nrm : nrm;
+    double vn2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      V[m][k] = (k < m) ? 0.0 : ((k == m) ? A[m][k] - alpha : A[m][k]);
+      vn2 += V[m][k] * V[m][k];
+    }
+    const double inv = (vn2 > 1e-300) ? 1.0 / sqrt(vn2) : 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) V[m][k] *= inv;
+#pragma unroll
+    for (int m2 = m + 1; m2 < 3; ++m2) {
+      double d = 0.0;
+#pragma unroll
+      for (int k = m; k < N; ++k) d += V[m][k] * A[m2][k];
+      d *= 2.0;
+#pragma unroll
+      for (int k = m; k < N; ++k) A[m2][k] -= d * V[m][k];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) {
+    double col[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) col[k] = (k == a + 3) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 2; m >= 0; --m) {
+      double d = 0.0;
+#pragma unroll
+      for (int k = m; k < N; ++k) d += V[m][k] * col[k];
+      d *= 2.0;
+#pragma unroll
+      for (int k = m; k < N; ++k) col[k] -= d * V[m][k];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) Z[k][a] = col[k];
+  }
+
+  // reduced block Dr = Z^T W Z (packed lower NZ x NZ)
+  double WZ[N][NZ];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) s += W[(i >= k) ? tri(i, k) : tri(k, i)] * Z[k][a];
+      WZ[i][a] = s;
+    }
+#pragma unroll
+  for (int a = 0; a < NZ; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 <= a; ++c2) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) s += Z[k][a] * WZ[k][c2];
+      Dr[tri(a, c2)] = s;
+    }
+}
+
+// Neighbour coupling of one knot: G = g + 2k((q0-qm) - (qp-q0)), gt = Z^T G, E = -2k Z^T Zn, merit share.
+template <int N>
+OH_DEV void couple_knot(const double kappa, const bool last, const double (&qm)[N], const double (&q0)[N], const double (&qp)[N],
+                        const double (&g)[N], const double (&Zt)[N][N - 3], const double (&Zn)[N][N - 3], const double phi,
+                        double (&G)[N], double (&gt)[N - 3], double (&E)[(N - 3) * (N - 3)], double& merit) {
+  constexpr int NZ = N - 3;
+  const double kap2 = 2.0 * kappa;
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) {
+    gt[a] = 0.0;
+#pragma unroll
+    for (int c2 = 0; c2 < NZ; ++c2) E[a * NZ + c2] = 0.0;
+  }
+  double sm = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double dm = q0[k] - qm[k];
+    sm += dm * dm;
+    double Gk = g[k] + kap2 * dm;
+    if (!last) Gk -= kap2 * (qp[k] - q0[k]);
+    G[k] = Gk;
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) {
+      gt[a] += Zt[k][a] * Gk;
+      if (!last) {
+#pragma unroll
+        for (int c2 = 0; c2 < NZ; ++c2) E[a * NZ + c2] -= kap2 * Zt[k][a] * Zn[k][c2];
+      }
+    }
+  }
+  merit = phi + kappa * sm;
+}
+
+// Cholesky with reciprocal pivots (divisions are off the critical path of the Riccati chain).
+template <int M>
+OH_DEV bool chol_rcp(double (&S)[M * (M + 1) / 2], double (&rd)[M], double piv_min) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    double d = S[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= S[tri(j, k)] * S[tri(j, k)];
+    if (!(d > piv_min)) { ok = false; d = 1.0; }
+    const double inv = rsqrt(d);
+    rd[j] = inv;
+    S[tri(j, j)] = d * inv;
+#pragma unroll
+    for (int i = j + 1; i < M; ++i) {
+      double v = S[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= S[tri(i, k)] * S[tri(j, k)];
+      S[tri(i, j)] = v * inv;
+    }
+  }
+  return ok;
+}
+template <int M>
+OH_DEV void fsub_rcp(const double (&L)[M * (M + 1) / 2], const double (&rd)[M], double (&x)[M]) {
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    double v = x[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= L[tri(i, k)] * x[k];
+    x[i] = v * rd[i];
+  }
+}
+template <int M>
+OH_DEV void bsub_rcp(const double (&L)[M * (M + 1) / 2], const double (&rd)[M], double (&x)[M]) {
+#pragma unroll
+  for (int i = M - 1; i >= 0; --i) {
+    double v = x[i];
+#pragma unroll
+    for (int k = i + 1; k < M; ++k) v -= L[tri(k, i)] * x[k];
+    x[i] = v * rd[i];
+  }
+}
+
+// One backward Riccati step from knot t+1 to knot t.  In: S = S_{t+1} (unfactorised), rn = r_{t+1},
+// E = E_t (row-major), Ht = D_t with the diagonal shift already added, gt = g~_t.  Out: S = S_t, rn = r_t,
+// and the gains of knot t+1 (Kmat row-major [row*NZ+col], kv) for z_{t+1} = -(kv + Kmat z_t).
+template <int NZ>
+OH_DEV bool riccati_back(double (&S)[NZ * (NZ + 1) / 2], double (&rd)[NZ], double (&rn)[NZ], const double (&E)[NZ * NZ],
+                         const double (&Ht)[NZ * (NZ + 1) / 2], const double (&gt)[NZ], double (&Kmat)[NZ * NZ], double (&kv)[NZ]) {
+  const bool ok = chol_rcp<NZ>(S, rd, 1e-12);
+  double X[NZ][NZ];  // X = L^{-1} E^T, column a from row a of E
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) {
+    double col[NZ];
+#pragma unroll
+    for (int c2 = 0; c2 < NZ; ++c2) col[c2] = E[a * NZ + c2];
+    fsub_rcp<NZ>(S, rd, col);
+#pragma unroll
+    for (int c2 = 0; c2 < NZ; ++c2) X[c2][a] = col[c2];
+  }
+  double u[NZ];
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) u[a] = rn[a];
+  fsub_rcp<NZ>(S, rd, u);
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) kv[a] = u[a];
+  bsub_rcp<NZ>(S, rd, kv);
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) {
+    double col[NZ];
+#pragma unroll
+    for (int c2 = 0; c2 < NZ; ++c2) col[c2] = X[c2][a];
+    bsub_rcp<NZ>(S, rd, col);
+#pragma unroll
+    for (int c2 = 0; c2 < NZ; ++c2) Kmat[c2 * NZ + a] = col[c2];
+  }
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) {
+    double sacc = gt[a];
+#pragma unroll
+    for (int c2 = 0; c2 < NZ; ++c2) sacc -= X[c2][a] * u[c2];
+    rn[a] = sacc;
+  }
+#pragma unroll
+  for (int a = 0; a < NZ; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 <= a; ++c2) {
+      double sacc = Ht[tri(a, c2)];
+#pragma unroll
+      for (int k = 0; k < NZ; ++k) sacc -= X[k][a] * X[k][c2];
+      S[tri(a, c2)] = sacc;
+    }
+  return ok;
+}
+
+// Levenberg-Marquardt acceptance test and Nielsen damping update (shared so both paths decide alike).
+struct LMState {
+  double mu, nun;
+};
+OH_DEV bool lm_accept(const FigParams& P, const double f, const double feas, const double fc, const double pred, LMState& s) {
+  const double rho = (fc - f) / fmax(pred, 1e-300);
+  // also accept steps whose predicted decrease is at rounding level of f (end game)
+  const bool accept = (f == f) && (feas <= P.feas_accept) && (rho > 1e-4 || (pred <= 1e-15 * fabs(fc) && f <= fc + 1e-14 * fabs(fc)));
+  if (accept) {
+    const double w3 = 2.0 * rho - 1.0;
+    s.mu *= fmax(1.0 / 3.0, 1.0 - w3 * w3 * w3);
+    if (s.mu < 1e-7) s.mu = 0.0;
+    s.nun = 2.0;
+  } else {
+    s.mu = fmax(s.mu * s.nun, 1e-3);
+    s.nun *= 2.0;
+  }
+  return accept;
+}

@@ -4,8 +4,7 @@
 //   a[(t*K + k)*Bp + b]        (Bp = B rounded up to 64)
 // so that the 64 lanes of a wavefront, which always hold 64 consecutive instances b at one knot t,
 // read and write full 512-byte lines.
-#include "oh_device.h"
-#include "oh_kernels.h"
+#include "oh_figure8.h"
 
 #define IDX(t, K, k) (((size_t)(t) * (K) + (k)) * Bp + b)
 
@@ -104,19 +103,6 @@ __global__ __launch_bounds__(256) void k_fk_jac(const oh_chain* __restrict__ ch,
 // Figure-eight family.  N = ndof (chain covers all joints in order), NZ = N-3 (orientation locked).
 // ---------------------------------------------------------------------------------------------
 
-// Orientation residual c = vee(skew(Re Rc^T)) and M = 1/2 (tr(A) I - A) with dc = M domega.
-OH_DEV void orient_residual(const double* Re, const double* Rc, double* c, double* M) {
-  double A[9];
-  mmT3(Re, Rc, A);
-  c[0] = 0.5 * (A[7] - A[5]);
-  c[1] = 0.5 * (A[2] - A[6]);
-  c[2] = 0.5 * (A[3] - A[1]);
-  const double tr = A[0] + A[4] + A[8];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) M[i] = -0.5 * A[i];
-  M[0] += 0.5 * tr; M[4] += 0.5 * tr; M[8] += 0.5 * tr;
-}
-
 // per-instance setup: references from qc, fixed knots, seed -> slot 0, solver state.
 template <int N>
 __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const double* __restrict__ x0,
@@ -203,11 +189,13 @@ __global__ __launch_bounds__(256) void k_move(FigParams P, FigBuffers D, const i
   if (P.hessian == OH_HESSIAN_EXACT) mv(D.Gfull[cur], D.Gfull[slot], N);
 }
 
-// K2: one lane per (instance b, free knot t): retraction onto R(q_t)=Rc, FK chain + Jacobians,
-// tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block.
+// K2: one lane per (instance b, free knot t): trial knot, retraction onto R(q_t)=Rc, FK chain + Jacobians,
+// tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block
+// (eval_knot in oh_figure8.h).
 template <int N>
 __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D, const int slot) {
   constexpr int NZ = N - 3;
+  constexpr int NP = NZ * (NZ + 1) / 2;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y + 2;
   const int Bp = D.Bp;
@@ -217,13 +205,12 @@ __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D, const i
   // point in `cur` = 1 - slot, so all lanes of a wavefront touch the same arrays (full 512-B lines).  An
   // instance whose previous trial was rejected had its accepted point in `slot`: k_move ran before us.
   const int cur = 1 - slot;
-  const oh_chain* ch = D.chain;
-  double* __restrict__ qs = D.q[slot];
+  const bool first = D.first[b] != 0;
   // trial knot: the seed on the first evaluation, otherwise q_cur + Z_cur z (roll-out of the step k_step solved for)
   double q[N];
-  if (D.first[b]) {
+  if (first) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) q[j] = qs[IDX(t, N, j)];
+    for (int j = 0; j < N; ++j) q[j] = D.q[slot][IDX(t, N, j)];
   } else {
     double zs[NZ];
 #pragma unroll
@@ -241,201 +228,30 @@ __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D, const i
   for (int i = 0; i < 3; ++i) pc[i] = D.ref[(size_t)i * Bp + b];
 #pragma unroll
   for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
+  double Gprev[N];
+  const bool have_G = (P.hessian == OH_HESSIAN_EXACT) && !first;
+#pragma unroll
+  for (int k = 0; k < N; ++k) Gprev[k] = have_G ? D.Gfull[cur][IDX(t, N, k)] : 0.0;
 
-  double R[9], p[3], z[N][3], pj[N][3];
-  double Re[9], c[3], M[9];
-  double cmax;
-  for (int it = 0;; ++it) {
-    fk_chain<N>(ch, q, R, p, z, pj);
-    mm3(R, ch->R_tool, Re);
-    orient_residual(Re, Rc, c, M);
-    cmax = fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2])));
-    if (cmax <= P.tol_retract || it >= P.max_retract) break;
-    // Newton correction q <- q - Jc^T (Jc Jc^T)^{-1} c,  Jc = M Jw,  Jw[:,k] = z_k (revolute) / 0
-    double Jc[N][3];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      if (ch->jtype[k] == 0) mv3(M, z[k], Jc[k]);
-      else { Jc[k][0] = Jc[k][1] = Jc[k][2] = 0.0; }
-    }
-    double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      S[0] += Jc[k][0] * Jc[k][0];
-      S[1] += Jc[k][1] * Jc[k][0];
-      S[2] += Jc[k][1] * Jc[k][1];
-      S[3] += Jc[k][2] * Jc[k][0];
-      S[4] += Jc[k][2] * Jc[k][1];
-      S[5] += Jc[k][2] * Jc[k][2];
-    }
-    chol_packed<3>(S, 0.0);
-    double y[3] = {c[0], c[1], c[2]};
-    fsub<3>(S, y);
-    bsub<3>(S, y);
-#pragma unroll
-    for (int k = 0; k < N; ++k) q[k] -= dot3(Jc[k], y);
-  }
-  // retracted knot back to the trial slot
-#pragma unroll
-  for (int j = 0; j < N; ++j) qs[IDX(t, N, j)] = q[j];
+  double phi, cv, g[N], Dr[NP], Z[N][NZ];
+  eval_knot<N>(D.chain, P, t, q, pc, Rc, have_G, Gprev, phi, cv, g, Dr, Z);
 
-  // end-effector position, tracking residual
-  double e[3], tv[3];
-  mv3(R, ch->p_tool, tv);
-  e[0] = p[0] + tv[0]; e[1] = p[1] + tv[1]; e[2] = p[2] + tv[2];
-  const double l[3] = {P.local_path[3 * t], P.local_path[3 * t + 1], P.local_path[3 * t + 2]};
-  double r[3];
-  mv3(Rc, l, r);
-  r[0] += pc[0] - e[0]; r[1] += pc[1] - e[1]; r[2] += pc[2] - e[2];
-  const double w = P.w_path;
-  D.phi[slot][(size_t)t * Bp + b] = w * dot3(r, r);
-  D.cv[slot][(size_t)t * Bp + b] = cmax;
-
-  // Jacobian columns
-  double Jp[N][3], Jc[N][3];
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (ch->jtype[k] == 0) {
-      const double d[3] = {e[0] - pj[k][0], e[1] - pj[k][1], e[2] - pj[k][2]};
-      cross3(z[k], d, Jp[k]);
-      mv3(M, z[k], Jc[k]);
-    } else {
-      Jp[k][0] = z[k][0]; Jp[k][1] = z[k][1]; Jp[k][2] = z[k][2];
-      Jc[k][0] = Jc[k][1] = Jc[k][2] = 0.0;
-    }
-  }
-  // gradient of w ||r||^2 : -2 w Jp^T r
+  for (int j = 0; j < N; ++j) D.q[slot][IDX(t, N, j)] = q[j];
+  D.phi[slot][(size_t)t * Bp + b] = phi;
+  D.cv[slot][(size_t)t * Bp + b] = cv;
 #pragma unroll
-  for (int k = 0; k < N; ++k) D.g[slot][IDX(t, N, k)] = -2.0 * w * dot3(Jp[k], r);
-
-  // Hessian block W (packed lower): 2 w Jp^T Jp  (+ exact curvature, OH_HESSIAN_EXACT)
-  double W[N * (N + 1) / 2];
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-#pragma unroll
-    for (int j = 0; j <= i; ++j) W[tri(i, j)] = 2.0 * w * dot3(Jp[i], Jp[j]);
-  if (P.hessian == OH_HESSIAN_EXACT) {
-    // -2 w r . d2p/dq_j dq_i,  d2p/dq_j dq_i = z_j x Jp_i for j <= i (revolute j)
-    // + lam . d2c/dq_j dq_i,   d2c = 1/2 z_j x z_i (j < i), exact on the constraint manifold.
-    // multipliers: least squares of  G_prev + Jc^T lam = 0  with the Lagrangian gradient G_prev that
-    // k_couple left for this knot at the last accepted point (lagged by one iteration; exact at convergence)
-    double lam[3] = {0.0, 0.0, 0.0};
-    if (!D.first[b]) {
-      double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
-#pragma unroll
-      for (int k = 0; k < N; ++k) {
-        const double Gk = D.Gfull[cur][IDX(t, N, k)];
-        S[0] += Jc[k][0] * Jc[k][0];
-        S[1] += Jc[k][1] * Jc[k][0];
-        S[2] += Jc[k][1] * Jc[k][1];
-        S[3] += Jc[k][2] * Jc[k][0];
-        S[4] += Jc[k][2] * Jc[k][1];
-        S[5] += Jc[k][2] * Jc[k][2];
-        lam[0] -= Jc[k][0] * Gk; lam[1] -= Jc[k][1] * Gk; lam[2] -= Jc[k][2] * Gk;
-      }
-      chol_packed<3>(S, 0.0);
-      fsub<3>(S, lam);
-      bsub<3>(S, lam);
-    }
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      if (ch->jtype[j] == 0) {
-        double rz[3], lz[3];
-        cross3(r, z[j], rz);    // (r x z_j) . Jp_i = r . (z_j x Jp_i)
-        cross3(lam, z[j], lz);  // (lam x z_j) . z_i = lam . (z_j x z_i)
-#pragma unroll
-        for (int i = j; i < N; ++i) {
-          double v = -2.0 * w * dot3(rz, Jp[i]);
-          if (i > j && ch->jtype[i] == 0) v += 0.5 * dot3(lz, z[i]);
-          W[tri(i, j)] += v;
-        }
-      }
-    }
-  }
-
-  // Householder QR of Jc^T (N x 3): H3 H2 H1 Jc^T = [Rf; 0];  Z = H1 H2 H3 [0; I_NZ]
-  double A[3][N];
-#pragma unroll
-  for (int m = 0; m < 3; ++m)
-#pragma unroll
-    for (int k = 0; k < N; ++k) A[m][k] = Jc[k][m];
-  double V[3][N];
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    double nrm2 = 0.0;
-#pragma unroll
-    for (int k = m; k < N; ++k) nrm2 += A[m][k] * A[m][k];
-    const double nrm = sqrt(nrm2);
-    const double alpha = (A[m][m] > 0.0) ? -nrm : nrm;
-    double vn2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      V[m][k] = (k < m) ? 0.0 : ((k == m) ? A[m][k] - alpha : A[m][k]);
-      vn2 += V[m][k] * V[m][k];
-    }
-    const double inv = (vn2 > 1e-300) ? 1.0 / sqrt(vn2) : 0.0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) V[m][k] *= inv;
-    // apply to the remaining columns
-#pragma unroll
-    for (int m2 = m + 1; m2 < 3; ++m2) {
-      double d = 0.0;
-#pragma unroll
-      for (int k = m; k < N; ++k) d += V[m][k] * A[m2][k];
-      d *= 2.0;
-#pragma unroll
-      for (int k = m; k < N; ++k) A[m2][k] -= d * V[m][k];
-    }
-  }
-  double Z[N][NZ];
-#pragma unroll
-  for (int a = 0; a < NZ; ++a) {
-    double col[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) col[k] = (k == a + 3) ? 1.0 : 0.0;
-#pragma unroll
-    for (int m = 2; m >= 0; --m) {
-      double d = 0.0;
-#pragma unroll
-      for (int k = m; k < N; ++k) d += V[m][k] * col[k];
-      d *= 2.0;
-#pragma unroll
-      for (int k = m; k < N; ++k) col[k] -= d * V[m][k];
-    }
-#pragma unroll
-    for (int k = 0; k < N; ++k) Z[k][a] = col[k];
-  }
+  for (int k = 0; k < N; ++k) D.g[slot][IDX(t, N, k)] = g[k];
 #pragma unroll
   for (int k = 0; k < N; ++k)
 #pragma unroll
     for (int a = 0; a < NZ; ++a) D.Z[slot][IDX(t, N * NZ, k * NZ + a)] = Z[k][a];
-
-  // reduced block Dr = Z^T W Z (packed lower NZ x NZ)
-  double WZ[N][NZ];
 #pragma unroll
-  for (int i = 0; i < N; ++i)
-#pragma unroll
-    for (int a = 0; a < NZ; ++a) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < N; ++k) s += W[(i >= k) ? tri(i, k) : tri(k, i)] * Z[k][a];
-      WZ[i][a] = s;
-    }
-#pragma unroll
-  for (int a = 0; a < NZ; ++a)
-#pragma unroll
-    for (int c2 = 0; c2 <= a; ++c2) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < N; ++k) s += Z[k][a] * WZ[k][c2];
-      D.Dr[slot][IDX(t, NZ * (NZ + 1) / 2, tri(a, c2))] = s;
-    }
+  for (int i = 0; i < NP; ++i) D.Dr[slot][IDX(t, NP, i)] = Dr[i];
 }
 
 // K2b: one lane per (instance b, free knot t), after k_eval: everything of the reduced block-tridiagonal
-// system that needs the neighbouring knots but not the recursion: Lagrangian gradient G_t (tracking +
-// smoothness), its projection gt = Z_t^T G_t, the coupling block E_t = -2 kappa Z_t^T Z_{t+1}, and the
-// knot's share of the merit (tracking cost + kappa ||q_t - q_{t-1}||^2).
+// system that needs the neighbouring knots but not the recursion (couple_knot in oh_figure8.h).
 template <int N>
 __global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const int slot) {
   constexpr int NZ = N - 3;
@@ -446,95 +262,33 @@ __global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const
   if (D.status[b] >= 0) return;
   const double* __restrict__ qs = D.q[slot];
   const double* __restrict__ Zs = D.Z[slot];
-  const double kap2 = 2.0 * P.kappa;
   const bool last = (t == P.T - 1);
-  double gt[NZ];
-  double E[NZ][NZ];
-#pragma unroll
-  for (int a = 0; a < NZ; ++a) {
-    gt[a] = 0.0;
-#pragma unroll
-    for (int c2 = 0; c2 < NZ; ++c2) E[a][c2] = 0.0;
-  }
-  double sm = 0.0;
+  double qm[N], q0[N], qp[N], g[N], Zt[N][NZ], Zn[N][NZ];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const double qm = qs[IDX(t - 1, N, k)];
-    const double q0 = qs[IDX(t, N, k)];
-    const double dm = q0 - qm;
-    sm += dm * dm;
-    double G = D.g[slot][IDX(t, N, k)] + kap2 * dm;
-    if (!last) G -= kap2 * (qs[IDX(t + 1, N, k)] - q0);
-    if (P.hessian == OH_HESSIAN_EXACT) D.Gfull[slot][IDX(t, N, k)] = G;
-    double zt[NZ], zn[NZ];
-#pragma unroll
-    for (int a = 0; a < NZ; ++a) zt[a] = Zs[IDX(t, N * NZ, k * NZ + a)];
-    if (!last) {
-#pragma unroll
-      for (int a = 0; a < NZ; ++a) zn[a] = Zs[IDX(t + 1, N * NZ, k * NZ + a)];
-    }
+    qm[k] = qs[IDX(t - 1, N, k)];
+    q0[k] = qs[IDX(t, N, k)];
+    qp[k] = last ? 0.0 : qs[IDX(t + 1, N, k)];
+    g[k] = D.g[slot][IDX(t, N, k)];
 #pragma unroll
     for (int a = 0; a < NZ; ++a) {
-      gt[a] += zt[a] * G;
-      if (!last) {
-#pragma unroll
-        for (int c2 = 0; c2 < NZ; ++c2) E[a][c2] -= kap2 * zt[a] * zn[c2];
-      }
+      Zt[k][a] = Zs[IDX(t, N * NZ, k * NZ + a)];
+      Zn[k][a] = last ? 0.0 : Zs[IDX(t + 1, N * NZ, k * NZ + a)];
     }
+  }
+  double G[N], gt[NZ], E[NZ * NZ], merit;
+  couple_knot<N>(P.kappa, last, qm, q0, qp, g, Zt, Zn, D.phi[slot][(size_t)t * Bp + b], G, gt, E, merit);
+  if (P.hessian == OH_HESSIAN_EXACT) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) D.Gfull[slot][IDX(t, N, k)] = G[k];
   }
 #pragma unroll
   for (int a = 0; a < NZ; ++a) D.gt[slot][IDX(t, NZ, a)] = gt[a];
   if (!last) {
 #pragma unroll
-    for (int a = 0; a < NZ; ++a)
-#pragma unroll
-      for (int c2 = 0; c2 < NZ; ++c2) D.E[slot][IDX(t, NZ * NZ, a * NZ + c2)] = E[a][c2];
+    for (int i = 0; i < NZ * NZ; ++i) D.E[slot][IDX(t, NZ * NZ, i)] = E[i];
   }
-  D.merit[slot][(size_t)t * Bp + b] = D.phi[slot][(size_t)t * Bp + b] + P.kappa * sm;
-}
-
-// Cholesky with reciprocal pivots (divisions are off the critical path of the Riccati chain).
-template <int M>
-OH_DEV bool chol_rcp(double (&S)[M * (M + 1) / 2], double (&rd)[M], double piv_min) {
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < M; ++j) {
-    double d = S[tri(j, j)];
-#pragma unroll
-    for (int k = 0; k < j; ++k) d -= S[tri(j, k)] * S[tri(j, k)];
-    if (!(d > piv_min)) { ok = false; d = 1.0; }
-    const double inv = rsqrt(d);
-    rd[j] = inv;
-    S[tri(j, j)] = d * inv;
-#pragma unroll
-    for (int i = j + 1; i < M; ++i) {
-      double v = S[tri(i, j)];
-#pragma unroll
-      for (int k = 0; k < j; ++k) v -= S[tri(i, k)] * S[tri(j, k)];
-      S[tri(i, j)] = v * inv;
-    }
-  }
-  return ok;
-}
-template <int M>
-OH_DEV void fsub_rcp(const double (&L)[M * (M + 1) / 2], const double (&rd)[M], double (&x)[M]) {
-#pragma unroll
-  for (int i = 0; i < M; ++i) {
-    double v = x[i];
-#pragma unroll
-    for (int k = 0; k < i; ++k) v -= L[tri(i, k)] * x[k];
-    x[i] = v * rd[i];
-  }
-}
-template <int M>
-OH_DEV void bsub_rcp(const double (&L)[M * (M + 1) / 2], const double (&rd)[M], double (&x)[M]) {
-#pragma unroll
-  for (int i = M - 1; i >= 0; --i) {
-    double v = x[i];
-#pragma unroll
-    for (int k = i + 1; k < M; ++k) v -= L[tri(k, i)] * x[k];
-    x[i] = v * rd[i];
-  }
+  D.merit[slot][(size_t)t * Bp + b] = merit;
 }
 
 // K3: one lane per instance: accept/reject the trial point (Levenberg-Marquardt ratio test on the
@@ -549,7 +303,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   const int T = P.T;
   const double kap2 = 2.0 * P.kappa;
   int cur = 1 - ts;  // uniform-slot invariant (see k_eval): the accepted point is in the other slot
-  double mu = D.mu[b];
+  LMState lm{D.mu[b], D.nun[b]};
   const int iters = D.iters[b];
 
   // ---- phase A: merit of the trial slot ---------------------------------------------------------
@@ -565,23 +319,8 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       accept = true;
       D.first[b] = 0;
     } else {
-      const double pred = D.pred[b];
-      const double fc = D.f_cur[b];
-      const double rho = (fc - f) / fmax(pred, 1e-300);
-      // also accept steps whose predicted decrease is at rounding level of f (end game)
-      accept = (f == f) && (feas <= P.feas_accept) && (rho > 1e-4 || (pred <= 1e-15 * fabs(fc) && f <= fc + 1e-14 * fabs(fc)));
-      // Nielsen's damping update: smooth decrease after good steps, doubling growth factor after rejections
-      double nun = D.nun[b];
-      if (accept) {
-        const double w3 = 2.0 * rho - 1.0;
-        mu *= fmax(1.0 / 3.0, 1.0 - w3 * w3 * w3);
-        if (mu < 1e-7) mu = 0.0;
-        nun = 2.0;
-      } else {
-        mu = fmax(mu * nun, 1e-3);
-        nun *= 2.0;
-      }
-      D.nun[b] = nun;
+      accept = lm_accept(P, f, feas, D.f_cur[b], D.pred[b], lm);
+      D.nun[b] = lm.nun;
     }
     if (accept) {
       cur = ts;
@@ -595,6 +334,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       D.any_move[ts & 1] = 1;
     }
   }
+  double mu = lm.mu;
 
   // ---- phase B: backward sweep on the current slot ------------------------------------------------
   const double* __restrict__ Ec = D.E[cur];
@@ -650,57 +390,12 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
         stat = fmax(stat, fabs(gt[a]));
         Ht[tri(a, a)] += 2.0 * kap2 + mu;
       }
-      // S holds S_{t+1}, rn = r_{t+1}
-      ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
-      double X[NZ][NZ];  // X = L^{-1} E^T, column a from row a of E
+      double Kmat[NZ * NZ], kv[NZ];
+      ok = riccati_back<NZ>(S, rd, rn, E, Ht, gt, Kmat, kv) && ok;
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) {
-        double col[NZ];
+      for (int a = 0; a < NZ; ++a) D.kvec[IDX(t + 1, NZ, a)] = kv[a];
 #pragma unroll
-        for (int c2 = 0; c2 < NZ; ++c2) col[c2] = E[a * NZ + c2];
-        fsub_rcp<NZ>(S, rd, col);
-#pragma unroll
-        for (int c2 = 0; c2 < NZ; ++c2) X[c2][a] = col[c2];
-      }
-      double u[NZ];
-#pragma unroll
-      for (int a = 0; a < NZ; ++a) u[a] = rn[a];
-      fsub_rcp<NZ>(S, rd, u);
-      // gains of knot t+1: z_{t+1} = -(kvec + Kmat z_t), Kmat = L^{-T} X, kvec = L^{-T} u (off the chain)
-      {
-        double kv[NZ];
-#pragma unroll
-        for (int a = 0; a < NZ; ++a) kv[a] = u[a];
-        bsub_rcp<NZ>(S, rd, kv);
-#pragma unroll
-        for (int a = 0; a < NZ; ++a) D.kvec[IDX(t + 1, NZ, a)] = kv[a];
-#pragma unroll
-        for (int a = 0; a < NZ; ++a) {
-          double col[NZ];
-#pragma unroll
-          for (int c2 = 0; c2 < NZ; ++c2) col[c2] = X[c2][a];
-          bsub_rcp<NZ>(S, rd, col);
-#pragma unroll
-          for (int c2 = 0; c2 < NZ; ++c2) D.Kmat[IDX(t + 1, NZ * NZ, c2 * NZ + a)] = col[c2];
-        }
-      }
-      // S_t = Ht - X^T X ; r_t = gt - X^T u
-#pragma unroll
-      for (int a = 0; a < NZ; ++a) {
-        double sacc = gt[a];
-#pragma unroll
-        for (int c2 = 0; c2 < NZ; ++c2) sacc -= X[c2][a] * u[c2];
-        rn[a] = sacc;
-      }
-#pragma unroll
-      for (int a = 0; a < NZ; ++a)
-#pragma unroll
-        for (int c2 = 0; c2 <= a; ++c2) {
-          double sacc = Ht[tri(a, c2)];
-#pragma unroll
-          for (int k = 0; k < NZ; ++k) sacc -= X[k][a] * X[k][c2];
-          S[tri(a, c2)] = sacc;
-        }
+      for (int i = 0; i < NZ * NZ; ++i) D.Kmat[IDX(t + 1, NZ * NZ, i)] = Kmat[i];
     }
     ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
     if (ok) break;
@@ -770,6 +465,227 @@ __global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D, const in
   if (running) still = step_instance<N>(P, D, b, slot);
   const unsigned long long m2 = __ballot(still);
   if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 (tail / small batches): ONE WAVEFRONT PER INSTANCE, one lane per free knot (T-2 <= 64), the whole
+// remaining SQP loop in a single launch with every stage quantity in registers: no HBM traffic per
+// iteration, no launch or host round trip per iteration.  Knot-parallel work (eval_knot, couple_knot) runs
+// on all lanes; neighbour data moves with wave shuffles; the Riccati recursion broadcasts knot l's blocks
+// with v_readlane and is computed redundantly (wave-uniformly) by all lanes.  Same device functions and
+// the same operation order as k_eval/k_couple/k_step.  Entered at a restart point (first == 1): the
+// accepted knots are in D.q[slot].
+// ---------------------------------------------------------------------------------------------
+OH_DEV double bcast(const double v, const int lane) {  // lane must be wave-uniform
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const int slot) {
+  constexpr int NZ = N - 3;
+  constexpr int NP = NZ * (NZ + 1) / 2;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (D.status[b] >= 0) return;
+  const int T = P.T;
+  const int nK = T - 2;  // free knots, lanes 0..nK-1
+  const int t = lane + 2;
+  const bool active = lane < nK;
+  const int tl = active ? t : T - 1;  // clamp addresses of idle lanes
+  const bool last = (t == T - 1);
+  const double kap2 = 2.0 * P.kappa;
+  const oh_chain* ch = D.chain;
+
+  double qt[N], qfix[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    qt[j] = D.q[slot][IDX(tl, N, j)];
+    qfix[j] = D.q[slot][IDX(1, N, j)];
+  }
+  double Rc[9], pc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pc[i] = D.ref[(size_t)i * Bp + b];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
+  const double fconst = D.fconst[b];
+  LMState lm{D.mu[b], D.nun[b]};
+  int iters = D.iters[b];
+  bool first = true;
+  int status = -1;
+  unsigned long long n_launch_equiv = 0, n_reject = 0;
+
+  // accepted point (per lane = per knot)
+  double q_c[N], Z_c[N][NZ], Dr_c[NP], E_c[NZ * NZ], gt_c[NZ], g_c[N], G_c[N];
+  double f_cur = 0.0, feas_cur = 0.0, pred = 0.0, stat = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) { q_c[k] = qt[k]; g_c[k] = 0.0; G_c[k] = 0.0; }
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) gt_c[a] = 0.0;
+  double Kmine[NZ * NZ], kmine[NZ], zmine[NZ];
+
+  for (;;) {
+    ++n_launch_equiv;
+    // ---- evaluate the trial knots (k_eval) -----------------------------------------------------------------
+    double phi = 0.0, cv = 0.0, g[N], Dr[NP], Z[N][NZ];
+    const bool have_G = (P.hessian == OH_HESSIAN_EXACT) && !first;
+    if (active) eval_knot<N>(ch, P, t, qt, pc, Rc, have_G, G_c, phi, cv, g, Dr, Z);
+    // ---- neighbour coupling (k_couple) -----------------------------------------------------------------------
+    double qm[N], qp[N], Zn[N][NZ];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const double up = __shfl_up(qt[k], 1);
+      qm[k] = (lane == 0) ? qfix[k] : up;
+      qp[k] = __shfl_down(qt[k], 1);
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) Zn[k][a] = __shfl_down(Z[k][a], 1);
+    }
+    double G[N], gt[NZ], E[NZ * NZ], merit = 0.0;
+    if (active) couple_knot<N>(P.kappa, last, qm, qt, qp, g, Z, Zn, phi, G, gt, E, merit);
+    // ---- phase A: merit in knot order, ratio test (wave-uniform) ---------------------------------------------
+    double f = fconst, feas = 0.0;
+    for (int l = 0; l < nK; ++l) {
+      f += bcast(merit, l);
+      feas = fmax(feas, bcast(cv, l));
+    }
+    bool accept;
+    if (first) {
+      accept = true;
+      first = false;
+    } else {
+      accept = lm_accept(P, f, feas, f_cur, pred, lm);
+      if (!accept) ++n_reject;
+    }
+    if (accept) {
+      f_cur = f;
+      feas_cur = feas;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        q_c[k] = qt[k];
+        g_c[k] = g[k];
+        G_c[k] = G[k];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) Z_c[k][a] = Z[k][a];
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Dr_c[i] = Dr[i];
+#pragma unroll
+      for (int i = 0; i < NZ * NZ; ++i) E_c[i] = E[i];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) gt_c[a] = gt[a];
+    }
+    double mu = lm.mu;
+    // ---- phase B: backward Riccati sweep, knot l's blocks broadcast to the whole wave --------------------------
+    double S[NP], rd[NZ], rn[NZ];
+    for (int attempt = 0; attempt < 40; ++attempt) {
+      bool ok = true;
+      stat = 0.0;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) S[i] = bcast(Dr_c[i], nK - 1);
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) {
+        S[tri(a, a)] += kap2 + mu;
+        rn[a] = bcast(gt_c[a], nK - 1);
+        stat = fmax(stat, fabs(rn[a]));
+      }
+      for (int l = nK - 2; l >= 0; --l) {
+        double El[NZ * NZ], Ht[NP], gl[NZ];
+#pragma unroll
+        for (int i = 0; i < NZ * NZ; ++i) El[i] = bcast(E_c[i], l);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) Ht[i] = bcast(Dr_c[i], l);
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+          gl[a] = bcast(gt_c[a], l);
+          stat = fmax(stat, fabs(gl[a]));
+          Ht[tri(a, a)] += 2.0 * kap2 + mu;
+        }
+        double Kmat[NZ * NZ], kv[NZ];
+        ok = riccati_back<NZ>(S, rd, rn, El, Ht, gl, Kmat, kv) && ok;
+        if (lane == l + 1) {
+#pragma unroll
+          for (int i = 0; i < NZ * NZ; ++i) Kmine[i] = Kmat[i];
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) kmine[a] = kv[a];
+        }
+      }
+      ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
+      if (ok) break;
+      mu = fmax(4.0 * mu, 1e-2);
+    }
+    lm.mu = mu;
+    if (stat <= P.tol && feas_cur <= P.tol_feas) { status = OH_STATUS_CONVERGED; break; }
+    if (iters >= P.max_iter) { status = OH_STATUS_MAX_ITER; break; }
+    if (!(stat == stat)) { status = OH_STATUS_NUMERICAL; break; }
+    // ---- forward recursion (wave-uniform), each lane keeps its knot's z -------------------------------------------
+    {
+      double zz[NZ];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) zz[a] = -rn[a];
+      fsub_rcp<NZ>(S, rd, zz);
+      bsub_rcp<NZ>(S, rd, zz);
+      double gd = 0.0, z2 = 0.0;
+      for (int l = 0; l < nK; ++l) {
+        if (l > 0) {
+          double zn[NZ];
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) {
+            double sacc = bcast(kmine[a], l);
+#pragma unroll
+            for (int c2 = 0; c2 < NZ; ++c2) sacc += bcast(Kmine[a * NZ + c2], l) * zz[c2];
+            zn[a] = -sacc;
+          }
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) zz[a] = zn[a];
+        }
+        if (lane == l) {
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) zmine[a] = zz[a];
+        }
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+          gd += bcast(gt_c[a], l) * zz[a];
+          z2 += zz[a] * zz[a];
+        }
+      }
+      pred = -0.5 * gd + 0.5 * mu * z2;
+    }
+    // next trial knots: q_cur + Z_cur z
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double v = q_c[j];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) v += Z_c[j][a] * zmine[a];
+      qt[j] = v;
+    }
+    ++iters;
+  }
+
+  // ---- hand the result to k_finalize ---------------------------------------------------------------------------
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      D.q[slot][IDX(t, N, j)] = q_c[j];
+      D.g[slot][IDX(t, N, j)] = g_c[j];
+    }
+  }
+  if (lane == 0) {
+    D.cur[b] = slot;
+    D.f_cur[b] = f_cur;
+    D.feas[b] = feas_cur;
+    D.stat[b] = stat;
+    D.mu[b] = lm.mu;
+    D.nun[b] = lm.nun;
+    D.iters[b] = iters;
+    D.first[b] = 0;
+    D.status[b] = status;
+    atomicAdd(D.work, n_launch_equiv);
+    if (n_reject) atomicAdd(D.work + 1, n_reject);
+  }
 }
 
 // Least-squares multipliers of knot t at the point in slot `cur`, mapped to the reference's rows
@@ -992,6 +908,10 @@ static void launch_step_t(hipStream_t s, const FigParams& P, const FigBuffers& D
   hipLaunchKernelGGL(k_step<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, slot);
 }
 template <int N>
+static void launch_tail_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
+  hipLaunchKernelGGL(k_tail<N>, dim3(D.B), dim3(64), 0, s, P, D, slot);
+}
+template <int N>
 static void launch_finalize_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
                               int* iters, int* status) {
   hipLaunchKernelGGL(k_finalize<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, only_done, x, f, kkt, iters, status);
@@ -1029,6 +949,12 @@ bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers
 }
 bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
 #define C(NN) launch_step_t<NN>(s, P, D, slot)
+  OH_DISPATCH_N(n, C)
+#undef C
+  return true;
+}
+bool oh_launch_tail(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
+#define C(NN) launch_tail_t<NN>(s, P, D, slot)
   OH_DISPATCH_N(n, C)
 #undef C
   return true;

@@ -270,14 +270,13 @@ static int ensure_capacity(oh_handle* h, int B) {
   int* ip = (int*)d;
   D.cur = ip; ip += Bp;
   D.first = ip; ip += Bp;
-  D.move = ip; ip += Bp;
+  D.skip = ip; ip += Bp;
   D.status = ip; ip += Bp;
   D.iters = ip; ip += Bp;
   D.orig = ip; ip += Bp;
   D.newidx = ip; ip += Bp;
   D.n_running = ip; ip += 1;
   D.n_new = ip; ip += 1;
-  D.any_move = ip; ip += 2;
   D.work = (unsigned long long*)ip;
   return OH_OK;
 }
@@ -319,7 +318,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   const bool prof = h->profiling;
   if (prof) {
     // events: [0] start, then per iteration (after eval, after step), last = end
-    const size_t need = 4 * (size_t)(h->desc.max_iter + 44) + 64;
+    const size_t need = 4 * (size_t)(2 * h->desc.max_iter + 44) + 64;
     while (h->prof_events.size() < need) {
       hipEvent_t e;
       HIPCHK(hipEventCreate(&e));
@@ -328,7 +327,6 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   }
   HIPCHK(hipEventRecord(h->ev0, s));
   HIPCHK(hipMemsetAsync(h->D.work, 0, 2 * sizeof(unsigned long long), s));
-  HIPCHK(hipMemsetAsync(h->D.any_move, 0, 2 * sizeof(int), s));
   if (!oh_launch_setup(s, N, h->P, h->D, (const double*)d_x0, (const double*)d_p))
     return fail(OH_ERR_INVALID, "oh_solve_device: unsupported ndof");
   size_t ne = 0;
@@ -342,7 +340,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   // Every instance needs at most max_iter steps (accepted + rejected) plus its first evaluation; each
   // compaction re-evaluates the survivors once.  The batch is compacted whenever at least half of it has
   // finished, so the slow tail keeps running in full wavefronts.
-  const int hard_cap = h->desc.max_iter + 2 + 40;
+  const int hard_cap = 2 * h->desc.max_iter + 2 + 40;  // a rejected step costs two launches
   const bool tail_ok = (h->desc.T - 2 <= 64) && h->tail_threshold > 0;
   bool tail_done = false;
   if (tail_ok && B <= h->tail_threshold) {  // small batch: the whole solve is one persistent launch

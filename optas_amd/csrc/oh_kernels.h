@@ -49,12 +49,11 @@ struct FigBuffers {
   double* feas;           // [Bp]
   int* cur;               // [Bp] slot holding the accepted point
   int* first;             // [Bp]
-  int* move;              // [Bp] 1: last trial rejected, accepted point must be moved out of the next trial slot
+  int* skip;              // [Bp] 1: last trial rejected -> sit the next launch out (keeps the slot parity uniform)
   int* status;            // [Bp] -1 running, else OH_STATUS_*
   int* iters;             // [Bp]
   int* orig;              // [Bp] original instance index (instances are compacted as the batch drains)
   int* newidx;            // [Bp] scratch of the compaction scan
-  int* any_move;          // [2] per launch parity: some instance rejected its trial
   int* n_running;         // [1] instances still running after the last k_step
   int* n_new;             // [1] result of the compaction scan
   double* lam_h;          // [B][T][4] multipliers of the quaternion rows, reference form (original order)

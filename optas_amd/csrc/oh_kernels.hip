@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
   }
   D.cur[b] = 1;  // trial slot of launch 0 is slot 0
   D.first[b] = 1;
-  D.move[b] = 0;
+  D.skip[b] = 0;
   D.orig[b] = b;
   D.status[b] = -1;  // running
   D.iters[b] = 0;
@@ -155,38 +155,6 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
   D.nun[b] = 2.0;
   D.stat[b] = 0.0;
   D.feas[b] = 0.0;
-}
-
-// Rare path of the uniform-slot scheme: instances whose last trial was rejected still hold their accepted
-// point in the slot the next trial is about to overwrite; copy that knot's stage data to the other slot.
-// any_move[(slot+1)&1] was raised by the previous k_step if at least one instance rejected; otherwise every
-// workgroup leaves immediately.
-template <int N>
-__global__ __launch_bounds__(256) void k_move(FigParams P, FigBuffers D, const int slot) {
-  constexpr int NZ = N - 3;
-  constexpr int NPk = NZ * (NZ + 1) / 2;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y + 2;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) D.any_move[slot & 1] = 0;  // for this launch's k_step
-  if (D.any_move[(slot + 1) & 1] == 0) return;
-  if (b >= D.B || D.status[b] >= 0 || !D.move[b]) return;
-  const int cur = 1 - slot;
-  const size_t st = (size_t)D.Bp;
-  auto mv = [&](double* __restrict__ dst, const double* __restrict__ src, int K) {
-    const size_t o = ((size_t)t * K) * st + b;
-#pragma unroll 4
-    for (int j = 0; j < K; ++j) dst[o + j * st] = src[o + j * st];
-  };
-  mv(D.q[cur], D.q[slot], N);
-  mv(D.Z[cur], D.Z[slot], N * NZ);
-  mv(D.Dr[cur], D.Dr[slot], NPk);
-  mv(D.g[cur], D.g[slot], N);
-  mv(D.E[cur], D.E[slot], NZ * NZ);
-  mv(D.gt[cur], D.gt[slot], NZ);
-  mv(D.phi[cur], D.phi[slot], 1);
-  mv(D.cv[cur], D.cv[slot], 1);
-  mv(D.merit[cur], D.merit[slot], 1);
-  if (P.hessian == OH_HESSIAN_EXACT) mv(D.Gfull[cur], D.Gfull[slot], N);
 }
 
 // K2: one lane per (instance b, free knot t): trial knot, retraction onto R(q_t)=Rc, FK chain + Jacobians,
@@ -200,10 +168,11 @@ __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D, const i
   const int t = blockIdx.y + 2;
   const int Bp = D.Bp;
   if (b >= D.B) return;
-  if (D.status[b] >= 0) return;
+  if (D.status[b] >= 0 || D.skip[b]) return;
   // Uniform slots: every running instance writes this launch's trial into `slot` and keeps its accepted
   // point in `cur` = 1 - slot, so all lanes of a wavefront touch the same arrays (full 512-B lines).  An
-  // instance whose previous trial was rejected had its accepted point in `slot`: k_move ran before us.
+  // instance whose previous trial was rejected has its accepted point in `slot`: it sits this launch out
+  // (skip flag) and is back in phase at the next one -- cheaper than moving its stage data.
   const int cur = 1 - slot;
   const bool first = D.first[b] != 0;
   // trial knot: the seed on the first evaluation, otherwise q_cur + Z_cur z (roll-out of the step k_step solved for)
@@ -259,7 +228,7 @@ __global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const
   const int t = blockIdx.y + 2;
   const int Bp = D.Bp;
   if (b >= D.B) return;
-  if (D.status[b] >= 0) return;
+  if (D.status[b] >= 0 || D.skip[b]) return;
   const double* __restrict__ qs = D.q[slot];
   const double* __restrict__ Zs = D.Z[slot];
   const bool last = (t == P.T - 1);
@@ -328,10 +297,9 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       D.feas[b] = feas;
     }
     D.cur[b] = cur;
-    D.move[b] = accept ? 0 : 1;  // rejected: the accepted point sits where the next trial goes
-    if (!accept) {
+    if (!accept) {  // the accepted point sits where the next trial would go: sit the next launch out
+      D.skip[b] = 1;
       atomicAdd(D.work + 1, 1ULL);
-      D.any_move[ts & 1] = 1;
     }
   }
   double mu = lm.mu;
@@ -456,12 +424,15 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
 template <int N>
 __global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D, const int slot) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool running = (b < D.B) && (D.status[b] < 0);
+  const bool alive = (b < D.B) && (D.status[b] < 0);
+  const bool skipping = alive && D.skip[b];
+  const bool running = alive && !skipping;
   {
     const unsigned long long m = __ballot(running);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(D.work, (unsigned long long)__popcll(m));
   }
-  bool still = false;
+  bool still = skipping;
+  if (skipping) D.skip[b] = 0;
   if (running) still = step_instance<N>(P, D, b, slot);
   const unsigned long long m2 = __ballot(still);
   if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
@@ -875,7 +846,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
     D.orig[b] = (int)ts[(size_t)15 * Bp + b];
     D.cur[b] = 1 - slot;
     D.first[b] = 1;
-    D.move[b] = 0;
+    D.skip[b] = 0;
     D.status[b] = -1;
   }
 }
@@ -896,7 +867,6 @@ static void launch_setup_t(hipStream_t s, const FigParams& P, const FigBuffers& 
 }
 template <int N>
 static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
-  hipLaunchKernelGGL(k_move<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D, slot);
   hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D, slot);
 }
 template <int N>

@@ -69,6 +69,40 @@ OH_DEV void rot_axis_right(double* R, const double* a, double s, double c, doubl
 }
 
 // ---------------------------------------------------------------------------------------------
+// sin/cos for joint angles (|x| up to a few thousand radians): two-term Cody-Waite reduction by pi/2
+// and the fdlibm kernel polynomials on [-pi/4, pi/4]; < 1 ulp, ~30 FMA-class instructions instead of the
+// generic library routine with its large-argument path.  7 of these per FK evaluation.
+// ---------------------------------------------------------------------------------------------
+OH_DEV void sincos_joint(const double x, double* s, double* c) {
+  const double kf = rint(x * 6.36619772367581382433e-01);  // 2/pi
+  double r = fma(-kf, 1.57079632673412561417e+00, x);        // pio2_1  (33 bits)
+  r = fma(-kf, 6.07710050650619224932e-11, r);               // pio2_1t
+  const double z = r * r;
+  // sin kernel
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  const double v = z * r;
+  const double sr = fma(v, fma(z, ps, -1.66666666666666324348e-01), r);
+  // cos kernel
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double w1 = 1.0 - hz;
+  const double cr = w1 + (((1.0 - w1) - hz) + z * (z * pc));
+  const int k = (int)kf;
+  const bool swap = k & 1;
+  const double ss = swap ? cr : sr;
+  const double cc = swap ? sr : cr;
+  *s = (k & 2) ? -ss : ss;
+  *c = ((k + 1) & 2) ? -cc : cc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Forward kinematics of a folded serial chain whose k-th actuated joint reads q[k] (solver path:
 // chain covers all model joints in order).  Outputs: R,p = frame after the last joint (before the
 // tool transform), z[k] = world joint axis, pj[k] = world joint origin.
@@ -92,7 +126,7 @@ OH_DEV void fk_chain(const oh_chain* __restrict__ ch, const double (&q)[N], doub
     pj[k][0] = p[0]; pj[k][1] = p[1]; pj[k][2] = p[2];
     if (ch->jtype[k] == 0) {
       double s, c;
-      sincos(q[k], &s, &c);
+      sincos_joint(q[k], &s, &c);
       rot_axis_right(R, ch->axis[k], s, c, z[k]);
     } else {
       mv3(R, ch->axis[k], z[k]);

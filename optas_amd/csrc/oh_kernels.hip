@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_fk_jac(const oh_chain* __restrict__ ch,
       pj[k][0] = p[0]; pj[k][1] = p[1]; pj[k][2] = p[2];
       if (ch->jtype[k] == 0) {
         double sh, chh;
-        sincos(0.5 * qk, &sh, &chh);  // half angle: quaternion (spatialmath.py:372-375) ...
+        sincos_joint(0.5 * qk, &sh, &chh);  // half angle: quaternion (spatialmath.py:372-375) ...
         const double s = 2.0 * sh * chh, c = 1.0 - 2.0 * sh * sh;  // ... and full angle for Rodrigues
         rot_axis_right(R, ch->axis[k], s, c, z[k]);
         const double qa[4] = {sh * ch->axis[k][0], sh * ch->axis[k][1], sh * ch->axis[k][2], chh};
@@ -708,7 +708,7 @@ OH_DEV void knot_multipliers(const FigParams& P, const FigBuffers& D, const int 
     qmul(quat, ch->quat0[k], qn);
     if (ch->jtype[k] == 0) {
       double sh, chh;
-      sincos(0.5 * qs[IDX(0, N, k)], &sh, &chh);
+      sincos_joint(0.5 * qs[IDX(0, N, k)], &sh, &chh);
       const double qa[4] = {sh * ch->axis[k][0], sh * ch->axis[k][1], sh * ch->axis[k][2], chh};
       qmul(qn, qa, quat);
     } else {

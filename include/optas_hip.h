@@ -68,7 +68,7 @@ enum {
  *   T_link = T * [R_tool p_tool]
  * quat0_k / quat_tool are the same fixed rotations as xyzw quaternions accumulated with the
  * reference's own product (models.py:1049-1088, spatialmath.py:298-349) so that oh_fk_jac reproduces the
- * reference's quaternion *including its sign*.  This block (sizeof(oh_chain) = 2696 bytes) is what is
+ * reference's quaternion *including its sign*.  This block (sizeof(oh_chain) = 2824 bytes) is what is
  * broadcast once over RCCL/xGMI in multi-GPU runs.
  */
 typedef struct oh_chain {
@@ -76,6 +76,10 @@ typedef struct oh_chain {
   int n_chain; /* actuated joints on this chain, in chain order */
   int jtype[OH_MAX_CHAIN];
   int qidx[OH_MAX_CHAIN]; /* actuated-joint index (models.py:661-667) */
+  /* structure hints the host derives from exact comparisons (kernels take cheaper, wave-uniform paths):
+     axcode: 0 general axis, +-1/+-2/+-3 = axis is exactly +-x/+-y/+-z;  r0ident: 1 if R0 is exactly I */
+  int axcode[OH_MAX_CHAIN];
+  int r0ident[OH_MAX_CHAIN];
   double R0[OH_MAX_CHAIN][9]; /* row-major */
   double p0[OH_MAX_CHAIN][3];
   double axis[OH_MAX_CHAIN][3]; /* unit (models.py:653-659) */

@@ -28,6 +28,8 @@ class oh_chain(C.Structure):
         ("n_chain", C.c_int),
         ("jtype", C.c_int * OH_MAX_CHAIN),
         ("qidx", C.c_int * OH_MAX_CHAIN),
+        ("axcode", C.c_int * OH_MAX_CHAIN),
+        ("r0ident", C.c_int * OH_MAX_CHAIN),
         ("R0", (C.c_double * 9) * OH_MAX_CHAIN),
         ("p0", (C.c_double * 3) * OH_MAX_CHAIN),
         ("axis", (C.c_double * 3) * OH_MAX_CHAIN),

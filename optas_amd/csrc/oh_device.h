@@ -68,6 +68,26 @@ OH_DEV void rot_axis_right(double* R, const double* a, double s, double c, doubl
   }
 }
 
+// R <- R * Rot(+-e_m, theta) for a principal axis (code = +-(m+1)): only two columns of R mix,
+// Rot(e_m): col_a' = c col_a + s col_b, col_b' = -s col_a + c col_b with (a,b) = (m+1, m+2) mod 3.
+// Written out per axis with literal indices so that R stays in registers.
+#define OH_ROT_COLS(A, B, M)                              \
+  _Pragma("unroll") for (int i = 0; i < 3; ++i) {         \
+    const double ca = R[3 * i + A], cb = R[3 * i + B];    \
+    R[3 * i + A] = c * ca + s * cb;                       \
+    R[3 * i + B] = c * cb - s * ca;                       \
+    zc[i] = sg * R[3 * i + M];                            \
+  }
+OH_DEV void rot_principal_right(double* R, const int code, double s, const double c, double* zc) {
+  const double sg = (code < 0) ? -1.0 : 1.0;
+  s *= sg;
+  const int m = (code < 0 ? -code : code);
+  if (m == 1) { OH_ROT_COLS(1, 2, 0) }
+  else if (m == 2) { OH_ROT_COLS(2, 0, 1) }
+  else { OH_ROT_COLS(0, 1, 2) }
+}
+#undef OH_ROT_COLS
+
 // ---------------------------------------------------------------------------------------------
 // sin/cos for joint angles (|x| up to a few thousand radians): two-term Cody-Waite reduction by pi/2
 // and the fdlibm kernel polynomials on [-pi/4, pi/4]; < 1 ulp, ~30 FMA-class instructions instead of the
@@ -119,15 +139,19 @@ OH_DEV void fk_chain(const oh_chain* __restrict__ ch, const double (&q)[N], doub
     double t[3];
     mv3(R, ch->p0[k], t);
     p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
-    double Rn[9];
-    mm3(R, ch->R0[k], Rn);
+    if (!ch->r0ident[k]) {
+      double Rn[9];
+      mm3(R, ch->R0[k], Rn);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+      for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    }
     pj[k][0] = p[0]; pj[k][1] = p[1]; pj[k][2] = p[2];
     if (ch->jtype[k] == 0) {
       double s, c;
       sincos_joint(q[k], &s, &c);
-      rot_axis_right(R, ch->axis[k], s, c, z[k]);
+      const int code = ch->axcode[k];
+      if (code != 0) rot_principal_right(R, code, s, c, z[k]);
+      else rot_axis_right(R, ch->axis[k], s, c, z[k]);
     } else {
       mv3(R, ch->axis[k], z[k]);
       p[0] += z[k][0] * q[k]; p[1] += z[k][1] * q[k]; p[2] += z[k][2] * q[k];

@@ -35,10 +35,12 @@ __global__ __launch_bounds__(256) void k_fk_jac(const oh_chain* __restrict__ ch,
       double t[3];
       mv3(R, ch->p0[k], t);
       p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
-      double Rn[9];
-      mm3(R, ch->R0[k], Rn);
+      if (!ch->r0ident[k]) {
+        double Rn[9];
+        mm3(R, ch->R0[k], Rn);
 #pragma unroll
-      for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+      }
       double qn[4];
       qmul(quat, ch->quat0[k], qn);  // == fromrpy(rpy) * quat in the reference's reversed product
       pj[k][0] = p[0]; pj[k][1] = p[1]; pj[k][2] = p[2];
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(256) void k_fk_jac(const oh_chain* __restrict__ ch,
         double sh, chh;
         sincos_joint(0.5 * qk, &sh, &chh);  // half angle: quaternion (spatialmath.py:372-375) ...
         const double s = 2.0 * sh * chh, c = 1.0 - 2.0 * sh * sh;  // ... and full angle for Rodrigues
-        rot_axis_right(R, ch->axis[k], s, c, z[k]);
+        if (ch->axcode[k] != 0) rot_principal_right(R, ch->axcode[k], s, c, z[k]);
+        else rot_axis_right(R, ch->axis[k], s, c, z[k]);
         const double qa[4] = {sh * ch->axis[k][0], sh * ch->axis[k][1], sh * ch->axis[k][2], chh};
         qmul(qn, qa, quat);
       } else {

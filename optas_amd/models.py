@@ -277,6 +277,16 @@ class RobotModel(Model):
             ch.jtype[k] = jt
             ch.qidx[k] = self.get_actuated_joint_index(joint.name)
             axis = self.get_joint_axis(joint)
+            code = 0
+            for m in range(3):
+                e = np.zeros(3)
+                e[m] = 1.0
+                if np.array_equal(axis, e):
+                    code = m + 1
+                elif np.array_equal(axis, -e):
+                    code = -(m + 1)
+            ch.axcode[k] = code
+            ch.r0ident[k] = 1 if np.array_equal(R_acc, np.eye(3)) else 0
             for i in range(9):
                 ch.R0[k][i] = float(R_acc.reshape(-1)[i])
             for i in range(3):

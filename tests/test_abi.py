@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header():
-    # sizeof(oh_chain): 2 ints + 2*16 ints + 16*(9+3+3+4) doubles + (9+3+4) doubles
-    assert C.sizeof(_lib.oh_chain) == 8 + 128 + 8 * (16 * 19 + 16)
+    # sizeof(oh_chain): 2 ints + 4*16 ints + 16*(9+3+3+4) doubles + (9+3+4) doubles
+    assert C.sizeof(_lib.oh_chain) == 8 + 256 + 8 * (16 * 19 + 16)
 
 
 def test_invalid_arguments_are_rejected_without_a_device_call():

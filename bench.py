@@ -40,12 +40,10 @@ QC0_DEG = [0, 30, 0, -90, 0, -30, 0]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 # Algorithmic bytes per unit = (instance, free knot) per launch, f64:
-#   k_eval : read q(7) ; write q(7) Z(28) Dr(10) g(7) phi(1) cv(1)                       = 61 doubles
-#   k_step : read trial q(7) phi(1) cv(1) ; read cur q(7) g(7) Z(28) Dr(10) ;
-#            write+read gains K(16) k(4) ; read Z(28) again for the roll-out is NOT counted
-#            (same bytes) ; write trial q(7)                                                 = 108 doubles
-BYTES_EVAL = 61 * 8
-BYTES_STEP = 108 * 8
+#   k_eval   : read q 7, Z 28, z 4 ; write q 7, Z 28, Dr 10, g 7, phi 1, cv 1             = 93 doubles
+#   k_couple : read Z_t 28 (Z_{t+1} is an L2 hit), q 3x7, g 7, phi 1 ; write E 16, gt 4, merit 1 = 78 doubles
+#   k_step   : read merit 1, cv 1, E 16, Dr 10, gt 4+4 ; write+read gains 20+20 ; write z 4  = 80 doubles
+BYTES = {"k_eval": 93 * 8, "k_couple": 78 * 8, "k_step": 80 * 8}
 BYTES_FKJAC = 448  # q 56 B in, pose 56 B + J 336 B out
 
 
@@ -98,7 +96,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32768, help="instances per GPU per step")
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU per step (SURVEY 8(d): B in {256, 4096, 65536})")
     ap.add_argument("--max-iter", type=int, default=300)
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--cpu-sample", type=int, default=24)
@@ -153,7 +151,7 @@ def main():
         be.solve_device(B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
     sync_all()
     t0 = time.perf_counter()
-    tm = {"eval_ms": 0.0, "step_ms": 0.0, "couple_ms": 0.0, "eval_launches": 0, "step_launches": 0, "instance_launches": 0, "solve_ms": 0.0, "rejected_steps": 0, "compactions": 0}
+    tm = {"eval_ms": 0.0, "step_ms": 0.0, "couple_ms": 0.0, "eval_launches": 0, "step_launches": 0, "instance_launches": 0, "solve_ms": 0.0, "rejected_steps": 0, "compactions": 0, "tail_iterations": 0}
     for _ in range(args.steps):
         be.solve_device(B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
         t = be.timing()
@@ -193,12 +191,17 @@ def main():
             dist.destroy_process_group()
         return
 
-    units = tm["instance_launches"] * (T - 2)  # (instance, knot) units actually processed by each kernel
-    dom = "k_step" if tm["step_ms"] >= tm["eval_ms"] else "k_eval"
-    dom_ms = tm["step_ms"] if dom == "k_step" else tm["eval_ms"]
-    dom_bytes = BYTES_STEP if dom == "k_step" else BYTES_EVAL
-    dom_launches = tm["step_launches"] if dom == "k_step" else tm["eval_launches"]
-    achieved = units * dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # (instance, knot) units the batched kernels actually processed (k_step counts running instances per launch;
+    # the persistent tail kernel adds one per iteration per instance, but its time is not in the kernel brackets)
+    units = tm["instance_launches"] * (T - 2)
+    kms = {"k_eval": tm["eval_ms"], "k_couple": tm["couple_ms"], "k_step": tm["step_ms"]}
+    dom = max(kms, key=kms.get)
+    launches = max(1, tm["step_launches"])
+    per_kernel = {
+        k: {"total_ms": v, "avg_launch_ms": v / launches, "bytes_per_unit": BYTES[k], "achieved_GBps": units * BYTES[k] / (v * 1e-3) / 1e9 if v > 0 else 0.0}
+        for k, v in kms.items()
+    }
+    achieved = per_kernel[dom]["achieved_GBps"]
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
@@ -214,14 +217,12 @@ def main():
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic,
-        "avg_launch_ms": dom_ms / max(1, dom_launches),
-        "bytes_per_unit": dom_bytes,
-        "units_per_launch_avg": units / max(1, dom_launches),
-        "other_kernel": {
-            "kernel": "k_eval" if dom == "k_step" else "k_step",
-            "avg_launch_ms": (tm["eval_ms"] if dom == "k_step" else tm["step_ms"]) / max(1, tm["eval_launches"]),
-            "achieved": units * (BYTES_EVAL if dom == "k_step" else BYTES_STEP) / ((tm["eval_ms"] if dom == "k_step" else tm["step_ms"]) * 1e-3) / 1e9,
-        },
+        "avg_launch_ms": per_kernel[dom]["avg_launch_ms"],
+        "bytes_per_unit": BYTES[dom],
+        "units_per_launch_avg": units / launches,
+        "launches": launches,
+        "all_kernels": per_kernel,
+        "note": "units = running instances x (T-2) summed over the batched launches; iterations run inside the persistent tail kernel are excluded from units and time alike",
     }
     fk_achieved = nfk * BYTES_FKJAC / (fk_ms * 1e-3) / 1e9
     out = {
@@ -269,7 +270,8 @@ def main():
         },
         "device_ms_per_step": tm["solve_ms"] / args.steps,
         "kernel_ms_per_step": {"k_eval": tm["eval_ms"] / args.steps, "k_couple": tm["couple_ms"] / args.steps, "k_step": tm["step_ms"] / args.steps},
-        "rejected_step_frac": tm["rejected_steps"] / max(1, tm["instance_launches"]),
+        "rejected_step_frac": tm["rejected_steps"] / max(1, tm["instance_launches"] + tm["tail_iterations"]),
+        "tail_iteration_frac": tm["tail_iterations"] / max(1, tm["instance_launches"] + tm["tail_iterations"]),
         "compactions_per_step": tm["compactions"] / args.steps,
     }
     if not args.no_cpu_baseline:

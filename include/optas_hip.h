@@ -146,10 +146,11 @@ int oh_fk_jac_soa_device(oh_handle* h, int N, const void* d_q, void* d_pose, voi
    out[0]=eval kernel total ms, out[1]=eval launches, out[2]=step kernel total ms, out[3]=step launches,
    out[4]=whole solve ms, out[5]=SQP iterations launched (pairs), out[6]=sum over launches of the number
    of instances still running (a launch touches only those: work actually done), out[7]=batch compactions,
-   out[8]=couple kernel total ms, out[9]=rejected steps (summed over instances).
+   out[8]=couple kernel total ms, out[9]=rejected steps (summed over instances), out[10]=iterations run
+   inside the persistent tail kernel (summed over instances).
    out[0..3] need oh_set_profiling(h,1) (one hipEventRecord after every kernel). */
 int oh_set_profiling(oh_handle* h, int enable);
-int oh_get_timing(oh_handle* h, double* out10);
+int oh_get_timing(oh_handle* h, double* out11);
 
 /* Thin device-memory helpers so a ctypes host needs no other GPU runtime binding. */
 int oh_device_count(int* n);

@@ -112,7 +112,7 @@ class FigureEightBackend:
         _lib.check(_lib.load().oh_set_profiling(self._h, 1 if on else 0), "oh_set_profiling")
 
     def timing(self) -> dict:
-        out = (C.c_double * 10)()
+        out = (C.c_double * 11)()
         _lib.check(_lib.load().oh_get_timing(self._h, out), "oh_get_timing")
         return {
             "eval_ms": out[0],
@@ -125,6 +125,7 @@ class FigureEightBackend:
             "compactions": int(out[7]),
             "couple_ms": out[8],
             "rejected_steps": int(out[9]),
+            "tail_iterations": int(out[10]),
         }
 
     def fk_jac_soa_device(self, n: int, d_q, d_pose, d_J) -> None:

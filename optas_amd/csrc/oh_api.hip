@@ -52,6 +52,7 @@ struct oh_handle {
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double timing_couple = 0;
   double rejects = 0;
+  double tail_iters = 0;
   int* h_flag = nullptr;  // pinned
   bool compaction = true;
   int tail_threshold = 2048;  // hand the last instances to the persistent one-wave-per-instance kernel
@@ -226,7 +227,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   nd += 2 * (size_t)T * NZ * NZ * Bp + 2 * (size_t)T * NZ * Bp + 2 * per_t + (size_t)T * NZ * Bp;  // E, gt, merit, zstep
   nd += (size_t)12 * Bp + 7 * (size_t)Bp;
   nd += (size_t)4 * T * Bp;  // lam_h
-  size_t ni = 7 * (size_t)Bp + 24;  // + n_running, n_new, work (8-byte aligned)
+  size_t ni = 7 * (size_t)Bp + 32;  // + n_running, n_new, work (8-byte aligned)
   size_t bytes = nd * sizeof(double) + ni * sizeof(int);
   void* pool = nullptr;
   hipError_t e = hipMalloc(&pool, bytes);
@@ -326,7 +327,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     }
   }
   HIPCHK(hipEventRecord(h->ev0, s));
-  HIPCHK(hipMemsetAsync(h->D.work, 0, 2 * sizeof(unsigned long long), s));
+  HIPCHK(hipMemsetAsync(h->D.work, 0, 3 * sizeof(unsigned long long), s));
   if (!oh_launch_setup(s, N, h->P, h->D, (const double*)d_x0, (const double*)d_p))
     return fail(OH_ERR_INVALID, "oh_solve_device: unsupported ndof");
   size_t ne = 0;
@@ -404,10 +405,11 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->timing[4] = ms;
   h->timing[5] = launched;
-  unsigned long long work[2] = {0, 0};
+  unsigned long long work[3] = {0, 0, 0};
   HIPCHK(hipMemcpy(work, h->D.work, sizeof(work), hipMemcpyDeviceToHost));
   h->timing[6] = (double)work[0];
   h->rejects = (double)work[1];
+  h->tail_iters = (double)work[2];
   if (prof) {
     double te = 0, tsx = 0, tc = 0;
     int n_e = 0, n_s = 0;
@@ -534,6 +536,7 @@ extern "C" int oh_get_timing(oh_handle* h, double* out8) {
   for (int i = 0; i < 8; ++i) out8[i] = h->timing[i];
   out8[8] = h->timing_couple;
   out8[9] = h->rejects;
+  out8[10] = h->tail_iters;
   return OH_OK;
 }
 extern "C" int oh_event_timer_start(oh_handle* h) {

@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
     D.iters[b] = iters;
     D.first[b] = 0;
     D.status[b] = status;
-    atomicAdd(D.work, n_launch_equiv);
+    atomicAdd(D.work + 2, n_launch_equiv);  // tail iterations are accounted separately from the batched launches
     if (n_reject) atomicAdd(D.work + 1, n_reject);
   }
 }

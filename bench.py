@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU per step (SURVEY 8(d): B in {256, 4096, 65536})")
     ap.add_argument("--max-iter", type=int, default=300)
     ap.add_argument("--tol", type=float, default=1e-6)
-    ap.add_argument("--cpu-sample", type=int, default=24)
+    ap.add_argument("--cpu-sample", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fk-units", type=int, default=1 << 22)
     args = ap.parse_args()

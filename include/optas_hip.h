@@ -89,6 +89,25 @@ typedef struct oh_chain {
   double quat_tool[4];
 } oh_chain;
 
+/*
+ * Inverse-dynamics constants in the selection RobotModel.rnea makes (models.py:1742-1784): body i = child of
+ * the i-th joint of get_chain(root, last link) with the first (fixed) joint dropped; masses / centres of mass /
+ * inertias of the links that carry <inertial> with the first one dropped; the last body is rigidly attached
+ * (models.py:1820-1832).  tau has n-1 entries.
+ */
+#define OH_MAX_BODIES 10
+typedef struct oh_dynamics {
+  int n;    /* bodies = len(joints_list_r) */
+  int ndof; /* n - 1 */
+  double R0[OH_MAX_BODIES][9];  /* rpy2r(joint origin rpy), row-major */
+  double xyz[OH_MAX_BODIES][3]; /* joint origin */
+  double axis[OH_MAX_BODIES][3];
+  double mass[OH_MAX_BODIES];
+  double com[OH_MAX_BODIES][3];
+  double inertia[OH_MAX_BODIES][9];
+  double vd0[3]; /* linear acceleration of the base = -gravity = (0, 0, 9.81) (models.py:1789-1801) */
+} oh_dynamics;
+
 typedef struct oh_problem_desc {
   int kind;     /* OH_PROBLEM_* */
   int T;        /* knots (OptimizationBuilder(T=...), builder.py:14-42) */
@@ -137,6 +156,12 @@ int oh_get_multipliers(oh_handle* h, int B, double* lam_h);
    J [N][6][ndof] row-major (rows 0-2 linear, 3-5 angular; models.py:1239,1246).  pose or J may be NULL. */
 int oh_fk_jac(oh_handle* h, int N, const double* q, double* pose, double* J);
 int oh_fk_jac_device(oh_handle* h, int N, const void* d_q, void* d_pose, void* d_J);
+
+/* Replaces RobotModel.rnea(q, qd, qdd) (models.py:1731-1884), batched: q, qd, qdd [N][ndof] -> tau [N][ndof]
+   (Craig's recursive Newton-Euler exactly as the reference writes it).  Needs oh_set_dynamics. */
+int oh_set_dynamics(oh_handle* h, const oh_dynamics* dyn);
+int oh_rnea(oh_handle* h, int N, const double* q, const double* qd, const double* qdd, double* tau);
+int oh_rnea_device(oh_handle* h, int N, const void* d_q, const void* d_qd, const void* d_qdd, void* d_tau);
 
 /* Structure-of-arrays variant used inside the solver and for roofline measurement:
    q [ndof][N], pose [7][N], J [6*ndof][N] (unit index fastest => fully coalesced). */

@@ -40,6 +40,23 @@ class oh_chain(C.Structure):
     ]
 
 
+OH_MAX_BODIES = 10
+
+
+class oh_dynamics(C.Structure):
+    _fields_ = [
+        ("n", C.c_int),
+        ("ndof", C.c_int),
+        ("R0", (C.c_double * 9) * OH_MAX_BODIES),
+        ("xyz", (C.c_double * 3) * OH_MAX_BODIES),
+        ("axis", (C.c_double * 3) * OH_MAX_BODIES),
+        ("mass", C.c_double * OH_MAX_BODIES),
+        ("com", (C.c_double * 3) * OH_MAX_BODIES),
+        ("inertia", (C.c_double * 9) * OH_MAX_BODIES),
+        ("vd0", C.c_double * 3),
+    ]
+
+
 class oh_problem_desc(C.Structure):
     _fields_ = [
         ("kind", C.c_int),
@@ -72,6 +89,9 @@ SYMBOLS = [
     "oh_solve",
     "oh_solve_device",
     "oh_get_multipliers",
+    "oh_set_dynamics",
+    "oh_rnea",
+    "oh_rnea_device",
     "oh_fk_jac",
     "oh_fk_jac_device",
     "oh_fk_jac_soa_device",
@@ -115,6 +135,9 @@ def load() -> C.CDLL:
     lib.oh_solve.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
     lib.oh_solve_device.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
     lib.oh_get_multipliers.argtypes = [vp, i, vp]
+    lib.oh_set_dynamics.argtypes = [vp, C.POINTER(oh_dynamics)]
+    lib.oh_rnea.argtypes = [vp, i, vp, vp, vp, vp]
+    lib.oh_rnea_device.argtypes = [vp, i, vp, vp, vp, vp]
     lib.oh_fk_jac.argtypes = [vp, i, vp, vp, vp]
     lib.oh_fk_jac_device.argtypes = [vp, i, vp, vp, vp]
     lib.oh_fk_jac_soa_device.argtypes = [vp, i, vp, vp, vp]

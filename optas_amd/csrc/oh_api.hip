@@ -35,6 +35,9 @@ struct oh_handle {
   bool have_chain = false;
   oh_chain chain_host;
   oh_chain* d_chain = nullptr;
+  bool have_dyn = false;
+  oh_dynamics dyn_host;
+  oh_dynamics* d_dyn = nullptr;
   double* d_local_path = nullptr;
   // solver buffers
   int cap_B = 0;
@@ -487,6 +490,46 @@ extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
   return OH_OK;
 }
 
+extern "C" int oh_set_dynamics(oh_handle* h, const oh_dynamics* dyn) {
+  if (!h || !dyn) return fail(OH_ERR_INVALID, "oh_set_dynamics: null argument");
+  if (dyn->n < 2 || dyn->n > OH_MAX_BODIES - 1 || dyn->ndof != dyn->n - 1)
+    return fail(OH_ERR_INVALID, "oh_set_dynamics: need 2 <= n <= 9 bodies and ndof == n - 1");
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->d_dyn) HIPCHK(hipMalloc((void**)&h->d_dyn, sizeof(oh_dynamics)));
+  HIPCHK(hipMemcpy(h->d_dyn, dyn, sizeof(oh_dynamics), hipMemcpyHostToDevice));
+  h->dyn_host = *dyn;
+  h->have_dyn = true;
+  return OH_OK;
+}
+extern "C" int oh_rnea_device(oh_handle* h, int n, const void* d_q, const void* d_qd, const void* d_qdd, void* d_tau) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_rnea: null handle");
+  if (n < 1 || !d_q || !d_qd || !d_qdd || !d_tau) return fail(OH_ERR_INVALID, "oh_rnea: bad arguments");
+  if (!h->have_dyn) return fail(OH_ERR_STATE, "oh_rnea: call oh_set_dynamics first");
+  HIPCHK(hipSetDevice(h->device));
+  if (!oh_launch_rnea(h->stream, h->d_dyn, h->dyn_host.n, n, (const double*)d_q, (const double*)d_qd, (const double*)d_qdd, (double*)d_tau))
+    return fail(OH_ERR_INVALID, "oh_rnea: unsupported number of bodies");
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return OH_OK;
+}
+extern "C" int oh_rnea(oh_handle* h, int n, const double* q, const double* qd, const double* qdd, double* tau) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_rnea: null handle");
+  if (n < 1 || !q || !qd || !qdd || !tau) return fail(OH_ERR_INVALID, "oh_rnea: bad arguments");
+  if (!h->have_dyn) return fail(OH_ERR_STATE, "oh_rnea: call oh_set_dynamics first");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t bq = (sizeof(double) * h->dyn_host.ndof * (size_t)n + 255) / 256 * 256;
+  int rc = ensure_stage(h, 4 * bq);
+  if (rc) return rc;
+  char* base = (char*)h->stage;
+  HIPCHK(hipMemcpy(base, q, sizeof(double) * h->dyn_host.ndof * (size_t)n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(base + bq, qd, sizeof(double) * h->dyn_host.ndof * (size_t)n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(base + 2 * bq, qdd, sizeof(double) * h->dyn_host.ndof * (size_t)n, hipMemcpyHostToDevice));
+  rc = oh_rnea_device(h, n, base, base + bq, base + 2 * bq, base + 3 * bq);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(tau, base + 3 * bq, sizeof(double) * h->dyn_host.ndof * (size_t)n, hipMemcpyDeviceToHost));
+  return OH_OK;
+}
+
 static int fk_common(oh_handle* h, int n, bool soa, const void* d_q, void* d_pose, void* d_J) {
   if (!h) return fail(OH_ERR_INVALID, "oh_fk_jac: null handle");
   if (n < 1 || !d_q) return fail(OH_ERR_INVALID, "oh_fk_jac: bad arguments");
@@ -562,6 +605,7 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->pool) hipFree(h->pool);
   if (h->stage) hipFree(h->stage);
   if (h->d_chain) hipFree(h->d_chain);
+  if (h->d_dyn) hipFree(h->d_dyn);
   if (h->d_local_path) hipFree(h->d_local_path);
   if (h->h_flag) hipHostFree(h->h_flag);
   if (h->ev0) hipEventDestroy(h->ev0);

@@ -60,6 +60,7 @@ struct FigBuffers {
   unsigned long long* work;  // [1] sum over k_step launches of running instances
 };
 
+bool oh_launch_rnea(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, int n, const double* q, const double* qd, const double* qdd, double* tau);
 void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n, const double* q, double* pose, double* J);
 bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const double* x0, const double* p);
 bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);

@@ -103,6 +103,114 @@ __global__ __launch_bounds__(256) void k_fk_jac(const oh_chain* __restrict__ ch,
 }
 
 // ---------------------------------------------------------------------------------------------
+// K5: batched recursive Newton-Euler inverse dynamics, one lane per sample, NB bodies (the last one rigidly
+// attached).  Statement by statement RobotModel.rnea (optas/models.py:1819-1880); AoS [N][NB-1] at the ABI.
+// ---------------------------------------------------------------------------------------------
+OH_DEV void mTv3(const double* A, const double* v, double* o) {  // o = A^T v
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = A[i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2];
+}
+template <int NB>
+__global__ __launch_bounds__(256) void k_rnea(const oh_dynamics* __restrict__ dy, int n, const double* __restrict__ q,
+                                              const double* __restrict__ qd, const double* __restrict__ qdd, double* __restrict__ tau) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  constexpr int ND = NB - 1;
+  double f[NB][3], nn[NB][3], sj[NB], cj[NB];
+  double om[3] = {0, 0, 0}, omD[3] = {0, 0, 0}, vD[3] = {dy->vd0[0], dy->vd0[1], dy->vd0[2]};
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    // iRp = (R0_i Rot(axis_i, q_i))^T ; for the last body no joint rotation (models.py:1820-1832)
+    double Rp[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rp[k] = dy->R0[i][k];
+    double qdi = 0.0, qddi = 0.0;
+    if (i != NB - 1) {
+      double s, c, zc[3];
+      sincos_joint(q[(size_t)u * ND + i], &s, &c);
+      sj[i] = s; cj[i] = c;
+      rot_axis_right(Rp, dy->axis[i], s, c, zc);
+      qdi = qd[(size_t)u * ND + i];
+      qddi = qdd[(size_t)u * ND + i];
+    } else {
+      sj[i] = 0.0; cj[i] = 1.0;
+    }
+    double a[3], omp[3], omDp[3];
+    mTv3(Rp, dy->axis[i], a);  // iaxisi
+    mTv3(Rp, om, omp);
+    mTv3(Rp, omD, omDp);
+    double omi[3], omDi[3];
+    if (i != NB - 1) {
+      const double aq[3] = {a[0] * qdi, a[1] * qdi, a[2] * qdi};
+      double cr[3];
+      cross3(omp, aq, cr);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        omi[k] = omp[k] + aq[k];
+        omDi[k] = omDp[k] + cr[k] + a[k] * qddi;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { omi[k] = omp[k]; omDi[k] = omDp[k]; }
+    }
+    // vDi = iRp (vD + omD x r + om x (om x r)),  r = joint origin
+    double t1[3], t2[3], t3[3], acc[3], vDi[3];
+    cross3(omD, dy->xyz[i], t1);
+    cross3(om, dy->xyz[i], t2);
+    cross3(om, t2, t3);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] = vD[k] + t1[k] + t3[k];
+    mTv3(Rp, acc, vDi);
+    // fi = m (vDi + omDi x c + omi x (omi x c)) ; ni = I omDi + omi x (I omi)
+    cross3(omDi, dy->com[i], t1);
+    cross3(omi, dy->com[i], t2);
+    cross3(omi, t2, t3);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f[i][k] = dy->mass[i] * (vDi[k] + t1[k] + t3[k]);
+    double Io[3], IoD[3];
+    mv3(dy->inertia[i], omi, Io);
+    mv3(dy->inertia[i], omDi, IoD);
+    cross3(omi, Io, t1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      nn[i][k] = IoD[k] + t1[k];
+      om[k] = omi[k]; omD[k] = omDi[k]; vD[k] = vDi[k];
+    }
+  }
+  // backward (models.py:1858-1880); reference lists fs/ns carry a leading zero entry: fs[i] == f[i-1]
+  double ifi[3] = {f[NB - 1][0], f[NB - 1][1], f[NB - 1][2]};
+  double ini[3], t1[3];
+  cross3(dy->com[NB - 1], f[NB - 1], t1);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ini[k] = nn[NB - 1][k] + t1[k];
+#pragma unroll
+  for (int i = NB - 1; i >= 1; --i) {
+    double pRi[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pRi[k] = dy->R0[i][k];
+    if (i < NB - 1) { double zc[3]; rot_axis_right(pRi, dy->axis[i], sj[i], cj[i], zc); }
+    double a1[3], a2[3], a3[3], a4[3];
+    mv3(pRi, ini, a1);
+    cross3(dy->com[i - 1], f[i - 1], a2);
+    mv3(pRi, ifi, a3);
+    cross3(dy->xyz[i], a3, a4);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      ini[k] = nn[i - 1][k] + a1[k] + a2[k] + a4[k];
+      ifi[k] = a3[k] + f[i - 1][k];
+    }
+    double pR[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pR[k] = dy->R0[i - 1][k];
+    double zc[3];
+    rot_axis_right(pR, dy->axis[i - 1], sj[i - 1], cj[i - 1], zc);
+    double ax[3];
+    mTv3(pR, dy->axis[i - 1], ax);  // pRi^T axis
+    tau[(size_t)u * ND + (i - 1)] = dot3(ini, ax);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Figure-eight family.  N = ndof (chain covers all joints in order), NZ = N-3 (orientation locked).
 // ---------------------------------------------------------------------------------------------
 
@@ -857,6 +965,22 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
 // ---------------------------------------------------------------------------------------------
 // launchers (called from oh_api.hip)
 // ---------------------------------------------------------------------------------------------
+bool oh_launch_rnea(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, int n, const double* q, const double* qd, const double* qdd,
+                    double* tau) {
+  const dim3 g((n + 255) / 256), b(256);
+  switch (nbodies) {
+    case 2: hipLaunchKernelGGL(k_rnea<2>, g, b, 0, s, d_dyn, n, q, qd, qdd, tau); break;
+    case 3: hipLaunchKernelGGL(k_rnea<3>, g, b, 0, s, d_dyn, n, q, qd, qdd, tau); break;
+    case 4: hipLaunchKernelGGL(k_rnea<4>, g, b, 0, s, d_dyn, n, q, qd, qdd, tau); break;
+    case 5: hipLaunchKernelGGL(k_rnea<5>, g, b, 0, s, d_dyn, n, q, qd, qdd, tau); break;
+    case 6: hipLaunchKernelGGL(k_rnea<6>, g, b, 0, s, d_dyn, n, q, qd, qdd, tau); break;
+    case 7: hipLaunchKernelGGL(k_rnea<7>, g, b, 0, s, d_dyn, n, q, qd, qdd, tau); break;
+    case 8: hipLaunchKernelGGL(k_rnea<8>, g, b, 0, s, d_dyn, n, q, qd, qdd, tau); break;
+    case 9: hipLaunchKernelGGL(k_rnea<9>, g, b, 0, s, d_dyn, n, q, qd, qdd, tau); break;
+    default: return false;
+  }
+  return true;
+}
 void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n, const double* q, double* pose, double* J) {
   const int threads = 256;
   const int blocks = (n + threads - 1) / threads;

@@ -308,6 +308,63 @@ class RobotModel(Model):
             ch.quat_tool[i] = float(qv[i])
         return ch
 
+    # ---- inverse dynamics (models.py:1731-1884) --------------------------------------------------------------
+    def dynamics_tables(self) -> _lib.oh_dynamics:
+        """The constants RobotModel.rnea gathers (models.py:1742-1784), with the reference's selection
+        rules and error behaviour: only revolute/continuous/fixed joints, first URDF joint fixed, masses of
+        the links that carry <inertial> with the first dropped, chain to the last link with the first joint
+        dropped, inertial rpy ignored."""
+        for joint in self.urdf.joints:
+            if joint.type not in {"revolute", "continuous", "fixed"}:
+                raise JointTypeNotSupported(joint.type)
+        if self.urdf.joints[0].type != "fixed":
+            raise JointTypeNotSupported("First joint should be fixed")
+        ine = [l.inertial for l in self.urdf.links if l.inertial is not None][1:]
+        names = self.urdf.get_chain(self.urdf.get_root(), self.link_names[-1], links=False)[1:]
+        n = len(names)
+        if n < 2 or n > _lib.OH_MAX_BODIES - 1 or len(ine) < n:
+            raise ValueError(f"rnea: unsupported chain ({n} bodies, {len(ine)} inertial links)")
+        d = _lib.oh_dynamics()
+        d.n, d.ndof = n, n - 1
+        jm = self.urdf.joint_map
+        for i, name in enumerate(names):
+            xyz, rpy = self.get_joint_origin(jm[name])
+            R = rpy2r(rpy).reshape(-1)
+            axis = self.get_joint_axis(jm[name])
+            ixx, ixy, ixz, iyy, iyz, izz = ine[i].inertia
+            I = [ixx, ixy, ixz, ixy, iyy, iyz, ixz, iyz, izz]
+            for k in range(9):
+                d.R0[i][k] = float(R[k])
+                d.inertia[i][k] = float(I[k])
+            for k in range(3):
+                d.xyz[i][k] = float(xyz[k])
+                d.axis[i][k] = float(axis[k])
+                d.com[i][k] = float(ine[i].xyz[k])
+            d.mass[i] = float(ine[i].mass)
+        d.vd0[0], d.vd0[1], d.vd0[2] = 0.0, 0.0, 9.81
+        return d
+
+    def rnea(self, q, qd, qdd) -> np.ndarray:
+        """Inverse dynamics tau(q, qd, qdd) (models.py:1731-1884), evaluated by liboptas_hip (oh_rnea).
+        Arguments are ndof vectors or ndof-by-n arrays (columns = samples)."""
+        import ctypes as C
+
+        if getattr(self, "_dyn_handle", None) is None:
+            lib = _lib.load()
+            dyn = self.dynamics_tables()
+            desc = _lib.oh_problem_desc(kind=_lib.OH_PROBLEM_KINEMATICS, ndof=max(1, min(dyn.ndof, _lib.OH_MAX_CHAIN)))
+            h = C.c_void_p()
+            _lib.check(lib.oh_create(C.byref(desc), C.byref(h)), "oh_create")
+            _lib.check(lib.oh_set_dynamics(h, C.byref(dyn)), "oh_set_dynamics")
+            self._dyn_handle, self._dyn = h, dyn
+        nd = self._dyn.ndof
+        single = np.asarray(q).ndim == 1
+        A = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(nd, -1).T) for a in (q, qd, qdd)]
+        n = A[0].shape[0]
+        tau = np.empty((n, nd))
+        _lib.check(_lib.load().oh_rnea(self._dyn_handle, n, _lib._ptr(A[0]), _lib._ptr(A[1]), _lib._ptr(A[2]), _lib._ptr(tau)), "oh_rnea")
+        return tau[0] if single else tau.T
+
     # ---- numeric kinematics through the HIP library -------------------------------------------------
     def _kin(self, link: str) -> "KinematicsHandle":
         h = self._fk_handles.get(link)

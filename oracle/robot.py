@@ -271,3 +271,80 @@ class OracleRobot:
             out[2, j] = 0.5 * (ox * y - oy * x + oz * w)
             out[3, j] = 0.5 * (-ox * x - oy * y - oz * z)
         return out
+
+
+# ---- inverse dynamics -------------------------------------------------------------------------------
+def _skew3(v):
+    return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+
+def rnea_tables(robot: "OracleRobot"):
+    """The data selection of RobotModel.rnea (models.py:1742-1784), quirks included: masses / centres of
+    mass / inertias of the links that carry <inertial>, the FIRST one dropped (:1772-1774); joints of
+    get_chain(root, link_names[-1]) with the FIRST one dropped (:1779-1782); inertial rpy ignored."""
+    for j in robot.joints:  # models.py:1742-1746
+        if j.type not in {"revolute", "continuous", "fixed"}:
+            raise JointTypeNotSupported(j.type)
+    if robot.joints[0].type != "fixed":  # models.py:1748-1749
+        raise JointTypeNotSupported("First joint should be fixed")
+    ine = [robot.link_inertials[l] for l in robot.links if robot.link_inertials[l] is not None]
+    m = np.array([i["mass"] for i in ine][1:])
+    cm = np.array([i["xyz"] for i in ine][1:]).T
+
+    def mat(i):
+        ixx, ixy, ixz, iyy, iyz, izz = i["inertia"]
+        return np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
+
+    Icm = [mat(i) for i in ine][1:]
+    names = robot.get_chain(robot.get_root(), robot.links[-1])[1:]
+    xyzs, rpys, axes = [], [], []
+    for n in names:
+        j = robot.joint_map[n]
+        xyz, rpy = robot.get_joint_origin(j)
+        xyzs.append(xyz)
+        rpys.append(rpy)
+        axes.append(robot.get_joint_axis(j))
+    return m, cm, Icm, xyzs, rpys, axes
+
+
+def rnea(robot: "OracleRobot", q, qd, qdd):
+    """models.py:1731-1884, line by line (Craig ch. 6).  Returns tau for joints 0..n-2 of joints_list_r."""
+    q, qd, qdd = (np.asarray(a, dtype=float).reshape(-1) for a in (q, qd, qdd))
+    m, cm, Icm, xyzs, rpys, axes = rnea_tables(robot)
+    n = len(xyzs)
+    oms = [np.zeros(3)]
+    omDs = [np.zeros(3)]
+    vDs = [np.array([0.0, 0.0, 9.81])]  # -gravity_para, models.py:1789-1801
+    fs = [np.zeros(3)]
+    ns = [np.zeros(3)]
+    for i in range(n):  # models.py:1819-1852
+        if i != n - 1:
+            iRp = (rpy2r(rpys[i]) @ angvec2r(q[i], axes[i])).T
+            iaxisi = iRp @ axes[i]
+            omi = iRp @ oms[i] + iaxisi * qd[i]
+            omDi = iRp @ omDs[i] + _skew3(iRp @ oms[i]) @ (iaxisi * qd[i]) + iaxisi * qdd[i]
+        else:
+            iRp = rpy2r(rpys[i]).T
+            omi = iRp @ oms[i]
+            omDi = iRp @ omDs[i]
+        vDi = iRp @ (vDs[i] + _skew3(omDs[i]) @ xyzs[i] + _skew3(oms[i]) @ (_skew3(oms[i]) @ xyzs[i]))
+        fi = m[i] * (vDi + _skew3(omDi) @ cm[:, i] + _skew3(omi) @ (_skew3(omi) @ cm[:, i]))
+        ni = Icm[i] @ omDi + _skew3(omi) @ Icm[i] @ omi
+        oms.append(omi)
+        omDs.append(omDi)
+        vDs.append(vDi)
+        fs.append(fi)
+        ns.append(ni)
+    ifi = fs[-1]  # models.py:1858-1859
+    ini = ns[-1] + _skew3(cm[:, -1]) @ fs[-1]
+    taus = []
+    for i in range(n - 1, 0, -1):  # models.py:1863-1880
+        if i < n - 1:
+            pRi = rpy2r(rpys[i]) @ angvec2r(q[i], axes[i])
+        else:
+            pRi = rpy2r(rpys[i])
+        ini = ns[i] + pRi @ ini + _skew3(cm[:, i - 1]) @ fs[i] + _skew3(xyzs[i]) @ pRi @ ifi
+        ifi = pRi @ ifi + fs[i]
+        pRi = rpy2r(rpys[i - 1]) @ angvec2r(q[i - 1], axes[i - 1])
+        taus.append(float(ini @ pRi.T @ axes[i - 1]))
+    return np.array(taus[::-1])

@@ -1,0 +1,63 @@
+"""K5 (oh_rnea) against the literal oracle restatement of RobotModel.rnea (models.py:1731-1884) and physical
+identities that do not depend on any implementation: tau is affine in qdd with a symmetric positive-definite
+mass matrix, and tau(q,0,0) is the gradient of the potential energy built from the FK oracle."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, KUKA_KIN, MED7_KIN, SEED
+from optas_amd.models import JointTypeNotSupported, RobotModel
+from oracle.robot import OracleRobot, rnea, rnea_tables
+import os
+
+pytestmark = pytest.mark.gpu
+REV_KIN = os.path.join(GOLDEN, "tester_robot_revolute.kin.json")
+
+
+@pytest.mark.parametrize("kin", [MED7_KIN, REV_KIN], ids=["med7", "tester_revolute"])
+def test_rnea_matches_oracle(hip_lib, kin):
+    robot, orc = RobotModel(urdf_filename=kin), OracleRobot(kin)
+    nd = robot.ndof
+    rng = np.random.default_rng(SEED)
+    n = 257
+    q, qd, qdd = (rng.uniform(-2, 2, (nd, n)) for _ in range(3))
+    tau = robot.rnea(q, qd, qdd)
+    assert tau.shape == (nd, n)
+    for i in range(0, n, 8):
+        ref = rnea(orc, q[:, i], qd[:, i], qdd[:, i])
+        assert np.abs(tau[:, i] - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    one = robot.rnea(q[:, 3], qd[:, 3], qdd[:, 3])
+    assert one.shape == (nd,) and np.array_equal(one, tau[:, 3])
+
+
+def test_rnea_physics_at_scale(hip_lib):
+    robot, orc = RobotModel(urdf_filename=MED7_KIN), OracleRobot(MED7_KIN)
+    nd = robot.ndof
+    rng = np.random.default_rng(SEED + 1)
+    n = 200_000
+    q, qd, qdd = (rng.uniform(-2, 2, (nd, n)) for _ in range(3))
+    tau = robot.rnea(q, qd, qdd)
+    t0 = robot.rnea(q, qd, np.zeros_like(qdd))
+    M = np.stack([robot.rnea(q, qd, np.tile(np.eye(nd)[:, [j]], (1, n))) - t0 for j in range(nd)], axis=1)  # (nd, nd, n)
+    assert np.abs(M - M.transpose(1, 0, 2)).max() < 1e-12  # symmetric mass matrix
+    assert np.abs(t0 + np.einsum("ijn,jn->in", M, qdd) - tau).max() < 1e-10  # affine in qdd
+    sub = M[:, :, :2000].transpose(2, 0, 1)
+    assert np.linalg.eigvalsh(0.5 * (sub + sub.transpose(0, 2, 1))).min() > 0  # positive definite
+    # gravity torque = dV/dq with V from the FK oracle and the same link masses / centres of mass
+    m, cm, _, _, _, _ = rnea_tables(orc)
+    links = [l for l in orc.links if orc.link_inertials[l] is not None][1:]
+
+    def V(qq):
+        return sum(m[i] * 9.81 * (orc.get_global_link_transform(l, qq)[:3, :3] @ cm[:, i] + orc.get_global_link_transform(l, qq)[:3, 3])[2] for i, l in enumerate(links))
+
+    g = robot.rnea(q[:, :4], np.zeros((nd, 4)), np.zeros((nd, 4)))
+    h = 1e-6
+    for s in range(4):
+        gn = np.array([(V(q[:, s] + h * np.eye(nd)[j]) - V(q[:, s] - h * np.eye(nd)[j])) / (2 * h) for j in range(nd)])
+        assert np.abs(g[:, s] - gn).max() < 1e-6
+
+
+def test_rnea_preconditions(hip_lib):
+    with pytest.raises(JointTypeNotSupported):  # first URDF joint must be fixed (models.py:1748-1749): the LWR fails
+        RobotModel(urdf_filename=KUKA_KIN).rnea(np.zeros(7), np.zeros(7), np.zeros(7))
+    with pytest.raises(JointTypeNotSupported):  # prismatic joints are not supported (models.py:1742-1746)
+        RobotModel(urdf_filename=os.path.join(GOLDEN, "tester_robot.kin.json")).rnea(np.zeros(3), np.zeros(3), np.zeros(3))

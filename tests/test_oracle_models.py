@@ -124,3 +124,33 @@ def test_add_base_frame():
     k.add_base_frame("global_world", xyz=[0, -0.25, 0])
     assert k.get_root() == "global_world"
     assert np.allclose(k.get_global_link_position("end_effector_ball", q), p0 + [0, -0.25, 0], atol=1e-15)
+
+
+def test_rnea_oracle_physics():
+    """The literal RNEA restatement (models.py:1731-1884) is physically consistent: symmetric PD mass matrix,
+    affine in qdd, gravity torque = dV/dq (V from the FK oracle).  The reference's own check is against pybullet
+    at atol 8e-2 (tests/test_models.py:1040-1052); pybullet is absent here."""
+    import os
+
+    from conftest import GOLDEN
+    from oracle.robot import rnea, rnea_tables
+
+    for kin in (MED7_KIN, os.path.join(GOLDEN, "tester_robot_revolute.kin.json")):
+        r = OracleRobot(kin)
+        n = r.ndof
+        rng = np.random.default_rng(4)
+        q, qd, qdd = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        tau = rnea(r, q, qd, qdd)
+        t0 = rnea(r, q, qd, np.zeros(n))
+        M = np.stack([rnea(r, q, qd, np.eye(n)[i]) - t0 for i in range(n)], 1)
+        assert np.abs(M - M.T).max() < 1e-13 and np.linalg.eigvalsh(0.5 * (M + M.T)).min() > 0
+        assert np.abs(t0 + M @ qdd - tau).max() < 1e-12
+        m, cm, _, _, _, _ = rnea_tables(r)
+        links = [l for l in r.links if r.link_inertials[l] is not None][1:]
+        V = lambda qq: sum(m[i] * 9.81 * (r.get_global_link_transform(l, qq)[:3, :3] @ cm[:, i] + r.get_global_link_transform(l, qq)[:3, 3])[2] for i, l in enumerate(links))
+        g = rnea(r, q, np.zeros(n), np.zeros(n))
+        h = 1e-6
+        gn = np.array([(V(q + h * np.eye(n)[i]) - V(q - h * np.eye(n)[i])) / (2 * h) for i in range(n)])
+        assert np.abs(g - gn).max() < 1e-6
+    with pytest.raises(NotImplementedError):
+        rnea(OracleRobot(KUKA_KIN), np.zeros(7), np.zeros(7), np.zeros(7))  # first joint not fixed (models.py:1748)

@@ -52,7 +52,11 @@ enum {
   /* example/figure_eight_plan.py:16-113: joint position/velocity trajectory of one
      serial chain; a = [qc-q0; 0-dq0; Euler integration]; h = quat_c - quat(q_t);
      f = w_path*sum||path_t - p(q_t)||^2 + w_vel*sum||dQ||^2, path_t = p(qc) + R(qc) local_path[t]. */
-  OH_PROBLEM_FIGURE_EIGHT = 1
+  OH_PROBLEM_FIGURE_EIGHT = 1,
+  /* example/point_mass_mpc.py:88-154 Controller: planar point mass, receding-horizon tick with
+     box limits on position/velocity and one moving circular obstacle; created with oh_create_pointmass.
+     x = [vec(Y 2xT); vec(dY 2xT)] (nx = 4T), p = [curr(2); dcurr(2); vec(goal 2xT); vec(obs 2xT)] (np = 4+4T). */
+  OH_PROBLEM_POINT_MASS_MPC = 2
 };
 
 enum {
@@ -125,11 +129,25 @@ typedef struct oh_problem_desc {
   double mu0;         /* initial Levenberg-Marquardt damping; <0: default */
 } oh_problem_desc;
 
+typedef struct oh_pointmass_desc {
+  int T;          /* knots (20 in the script) */
+  double dt;      /* 0.05 */
+  double w_acc;   /* weight of sum ||(dy_{t+1}-dy_t)/dt||^2 : 0.0025 / T (point_mass_mpc.py:133-136) */
+  double ylim;    /* position box, 1.5 (:96,110) */
+  double vlim;    /* velocity box, 1.0 (:96,111) */
+  double safe;    /* obstacle radius + point-mass radius = 0.2 + 0.1 (:91,94,123) */
+  int max_iter;   /* <= 0: 100 */
+  double tol;     /* KKT tolerance (stationarity, feasibility, complementarity); <= 0: 1e-8 */
+} oh_pointmass_desc;
+
 typedef struct oh_handle oh_handle;
 
 /* Replaces Solver.__init__ + CasADiSolver.setup (solver.py:64-88,333-384): allocates the handle,
    creates its stream.  The descriptor (and local_path) is copied. */
 int oh_create(const oh_problem_desc* desc, oh_handle** out);
+
+/* Same for OH_PROBLEM_POINT_MASS_MPC (no kinematic constants needed; solve with oh_solve / oh_solve_device). */
+int oh_create_pointmass(const oh_pointmass_desc* desc, oh_handle** out);
 
 /* Kinematic constants from host memory / from device memory (the latter after an RCCL broadcast). */
 int oh_set_constants(oh_handle* h, const oh_chain* chain);

@@ -19,6 +19,7 @@ OH_OK = 0
 OH_STATUS_CONVERGED, OH_STATUS_MAX_ITER, OH_STATUS_NUMERICAL = 0, 1, 2
 OH_PROBLEM_KINEMATICS = 0
 OH_PROBLEM_FIGURE_EIGHT = 1
+OH_PROBLEM_POINT_MASS_MPC = 2
 OH_HESSIAN_GAUSS_NEWTON, OH_HESSIAN_EXACT = 0, 1
 
 
@@ -75,6 +76,19 @@ class oh_problem_desc(C.Structure):
     ]
 
 
+class oh_pointmass_desc(C.Structure):
+    _fields_ = [
+        ("T", C.c_int),
+        ("dt", C.c_double),
+        ("w_acc", C.c_double),
+        ("ylim", C.c_double),
+        ("vlim", C.c_double),
+        ("safe", C.c_double),
+        ("max_iter", C.c_int),
+        ("tol", C.c_double),
+    ]
+
+
 class OptasHipError(RuntimeError):
     pass
 
@@ -84,6 +98,7 @@ _LIB: Optional[C.CDLL] = None
 # every symbol include/optas_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "oh_create",
+    "oh_create_pointmass",
     "oh_set_constants",
     "oh_set_constants_device",
     "oh_solve",
@@ -130,6 +145,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(path)
     vp, i, dp, ip = C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)
     lib.oh_create.argtypes = [C.POINTER(oh_problem_desc), C.POINTER(vp)]
+    lib.oh_create_pointmass.argtypes = [C.POINTER(oh_pointmass_desc), C.POINTER(vp)]
     lib.oh_set_constants.argtypes = [vp, C.POINTER(oh_chain)]
     lib.oh_set_constants_device.argtypes = [vp, vp, C.c_size_t]
     lib.oh_solve.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]

@@ -23,6 +23,68 @@ class BatchResult:
     status: np.ndarray  # (B,)
 
 
+class _SolveMixin:
+    """oh_solve / oh_solve_device / timing over an existing handle (self._h, self.nx, self.np_)."""
+
+    def solve(self, x0: np.ndarray, p: np.ndarray) -> "BatchResult":
+        lib = _lib.load()
+        x0 = _lib.as_f64(x0)
+        p = _lib.as_f64(p)
+        if x0.ndim == 1:
+            x0 = x0.reshape(1, -1)
+        if p.ndim == 1:
+            p = p.reshape(1, -1)
+        B = x0.shape[0]
+        assert x0.shape == (B, self.nx), f"x0 must be (B, {self.nx})"
+        assert p.shape == (B, self.np_), f"p must be (B, {self.np_})"
+        x = np.empty((B, self.nx))
+        f = np.empty(B)
+        kkt = np.empty((B, 3))
+        iters = np.empty(B, dtype=np.int32)
+        status = np.empty(B, dtype=np.int32)
+        _lib.check(
+            lib.oh_solve(self._h, B, _lib._ptr(x0), _lib._ptr(p), _lib._ptr(x), _lib._ptr(f), _lib._ptr(kkt), _lib._ptr(iters), _lib._ptr(status)),
+            "oh_solve",
+        )
+        return BatchResult(x, f, kkt, iters, status)
+
+    def solve_device(self, B: int, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status) -> None:
+        g = lambda b: None if b is None else b.ptr
+        _lib.check(
+            _lib.load().oh_solve_device(self._h, int(B), g(d_x0), g(d_p), g(d_x), g(d_f), g(d_kkt), g(d_iters), g(d_status)),
+            "oh_solve_device",
+        )
+
+    def solve_ms(self) -> float:
+        out = (C.c_double * 11)()
+        _lib.check(_lib.load().oh_get_timing(self._h, out), "oh_get_timing")
+        return out[4]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            _lib.load().oh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PointMassBackend(_SolveMixin):
+    """OH_PROBLEM_POINT_MASS_MPC handle (example/point_mass_mpc.py Controller)."""
+
+    def __init__(self, T=20, dt=0.05, w_acc=0.0025 / 20, ylim=1.5, vlim=1.0, safe=0.3, max_iter=100, tol=1e-8):
+        lib = _lib.load()
+        self.T = int(T)
+        self.nx, self.np_ = 4 * self.T, 4 + 4 * self.T
+        desc = _lib.oh_pointmass_desc(T=self.T, dt=float(dt), w_acc=float(w_acc), ylim=float(ylim), vlim=float(vlim), safe=float(safe),
+                                      max_iter=int(max_iter), tol=float(tol))
+        self._h = C.c_void_p()
+        _lib.check(lib.oh_create_pointmass(C.byref(desc), C.byref(self._h)), "oh_create_pointmass")
+
+
 class FigureEightBackend:
     """OH_PROBLEM_FIGURE_EIGHT handle."""
 

@@ -39,6 +39,10 @@ struct oh_handle {
   oh_dynamics dyn_host;
   oh_dynamics* d_dyn = nullptr;
   double* d_local_path = nullptr;
+  // point-mass family
+  oh_pointmass_desc pm{};
+  PmParams PmP{};
+  PmBuffers PmD{};
   // solver buffers
   int cap_B = 0;
   FigBuffers D{};
@@ -163,6 +167,75 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   }
   hipMemcpy(h->d_local_path, h->local_path.data(), sizeof(double) * 3 * (size_t)desc->T, hipMemcpyHostToDevice);
   *out = h;
+  return OH_OK;
+}
+
+extern "C" int oh_create_pointmass(const oh_pointmass_desc* desc, oh_handle** out) {
+  if (!desc || !out) return fail(OH_ERR_INVALID, "oh_create_pointmass: null argument");
+  *out = nullptr;
+  if (desc->T < 2 || desc->T > OH_MAX_T) return fail(OH_ERR_INVALID, "oh_create_pointmass: T must be in [2, OH_MAX_T]");
+  if (!(desc->dt > 0.0) || !(desc->w_acc > 0.0) || !(desc->ylim > 0.0) || !(desc->vlim > 0.0) || !(desc->safe >= 0.0))
+    return fail(OH_ERR_INVALID, "oh_create_pointmass: dt, w_acc, ylim, vlim must be positive and safe non-negative");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1)
+    return fail(OH_ERR_HIP, "oh_create_pointmass: no HIP device available (this library has no CPU path)");
+  oh_handle* h = new oh_handle();
+  h->desc = oh_problem_desc{};
+  h->desc.kind = OH_PROBLEM_POINT_MASS_MPC;
+  h->desc.T = desc->T;
+  h->desc.ndof = 2;
+  h->pm = *desc;
+  if (h->pm.max_iter <= 0) h->pm.max_iter = 100;
+  if (!(h->pm.tol > 0.0)) h->pm.tol = 1e-8;
+  hipGetDevice(&h->device);
+  if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+      hipEventCreate(&h->evt0) != hipSuccess || hipEventCreate(&h->evt1) != hipSuccess) {
+    delete h;
+    return fail(OH_ERR_HIP, "oh_create_pointmass: stream/event creation failed");
+  }
+  *out = h;
+  return OH_OK;
+}
+
+static int pm_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters,
+                           void* d_status) {
+  HIPCHK(hipSetDevice(h->device));
+  const int T = h->pm.T;
+  const int Bp = (B + 63) / 64 * 64;
+  const size_t rows = 2 * (size_t)(T - 1) + 4 * (size_t)T + 9 * (size_t)T + 9 * (size_t)T + 8 * (size_t)(T - 1) + 2 * (size_t)(T - 1) +
+                      4 * (size_t)T + 2 * (size_t)(T - 1);
+  if (Bp > h->cap_B || !h->pool) {
+    if (h->pool) hipFree(h->pool);
+    h->pool = nullptr;
+    hipError_t e = hipMalloc(&h->pool, rows * Bp * sizeof(double));
+    if (e != hipSuccess) return fail(OH_ERR_HIP, std::string("device pool allocation failed: ") + hipGetErrorString(e));
+    h->cap_B = Bp;
+    h->PmD.Bp = Bp;
+    double* d = (double*)h->pool;
+    auto take = [&](size_t r) { double* o = d; d += r * Bp; return o; };
+    h->PmD.a = take(2 * (size_t)(T - 1));
+    h->PmD.X = take(4 * (size_t)T);
+    h->PmD.s = take(9 * (size_t)T);
+    h->PmD.lam = take(9 * (size_t)T);
+    h->PmD.K = take(8 * (size_t)(T - 1));
+    h->PmD.kk = take(2 * (size_t)(T - 1));
+    h->PmD.dX = take(4 * (size_t)T);
+    h->PmD.da = take(2 * (size_t)(T - 1));
+  }
+  h->PmD.B = B;
+  h->PmP = PmParams{T, h->pm.dt, h->pm.w_acc, h->pm.ylim, h->pm.vlim, h->pm.safe * h->pm.safe, h->pm.tol, h->pm.max_iter};
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  oh_launch_pm_solve(h->stream, h->PmP, h->PmD, (const double*)d_x0, (const double*)d_p, (double*)d_x, (double*)d_f, (double*)d_kkt,
+                     (int*)d_iters, (int*)d_status);
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  for (double& t : h->timing) t = 0.0;
+  h->timing[4] = ms;
+  h->timing[5] = 1;
+  h->last_B = B;
   return OH_OK;
 }
 
@@ -309,6 +382,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (!h) return fail(OH_ERR_INVALID, "oh_solve_device: null handle");
   if (B < 1) return fail(OH_ERR_INVALID, "oh_solve_device: B must be >= 1");
   if (!d_x0 || !d_p) return fail(OH_ERR_INVALID, "oh_solve_device: x0 and p are required");
+  if (h->desc.kind == OH_PROBLEM_POINT_MASS_MPC) return pm_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT) return fail(OH_ERR_STATE, "oh_solve_device: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
   if (!h->have_chain) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_constants first");
   if (!solver_chain_ok(h->chain_host))
@@ -451,11 +525,14 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
   if (!h) return fail(OH_ERR_INVALID, "oh_solve: null handle");
   if (B < 1) return fail(OH_ERR_INVALID, "oh_solve: B must be >= 1");
   if (!x0 || !p) return fail(OH_ERR_INVALID, "oh_solve: x0 and p are required");
-  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT) return fail(OH_ERR_STATE, "oh_solve: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
+  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_POINT_MASS_MPC)
+    return fail(OH_ERR_STATE, "oh_solve: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
   HIPCHK(hipSetDevice(h->device));
   const int N = h->desc.ndof, T = h->desc.T;
-  const size_t nx = (size_t)N * T + (size_t)N * (T - 1);
-  const size_t b_x = sizeof(double) * nx * B, b_p = sizeof(double) * N * (size_t)B;
+  const bool pmk = h->desc.kind == OH_PROBLEM_POINT_MASS_MPC;
+  const size_t nx = pmk ? 4 * (size_t)T : (size_t)N * T + (size_t)N * (T - 1);
+  const size_t npar = pmk ? 4 + 4 * (size_t)T : (size_t)N;
+  const size_t b_x = sizeof(double) * nx * B, b_p = sizeof(double) * npar * (size_t)B;
   const size_t b_f = sizeof(double) * B, b_k = sizeof(double) * 3 * (size_t)B, b_i = sizeof(int) * (size_t)B;
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
   const size_t total = al(b_x) * 2 + al(b_p) + al(b_f) + al(b_k) + 2 * al(b_i);

@@ -71,3 +71,16 @@ bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffe
                         int* iters, int* status);
 void oh_launch_scan_running(hipStream_t s, const FigBuffers& D);
 bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot);
+
+// ---- OH_PROBLEM_POINT_MASS_MPC ---------------------------------------------------------------------------
+struct PmParams {
+  int T;
+  double dt, w_acc, ylim, vlim, safe_sq, tol;
+  int max_iter;
+};
+struct PmBuffers {
+  int B, Bp;
+  double *a, *X, *s, *lam, *K, *kk, *dX, *da;  // [rows][Bp], rows: 2(T-1), 4T, 9T, 9T, 8(T-1), 2(T-1), 4T, 2(T-1)
+};
+void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, const double* x0, const double* p, double* x, double* f, double* kkt,
+                        int* iters, int* status);

@@ -1,0 +1,251 @@
+// OH_PROBLEM_POINT_MASS_MPC: example/point_mass_mpc.py Controller (:88-154), BASELINE config 3.
+// One lane per MPC instance; the whole primal-dual interior-point loop runs inside one launch, Newton steps
+// by a Riccati sweep over the T stages (state (y,v) in R^4, control a in R^2).  Per-instance work arrays live
+// in HBM scratch laid out [row][b] (instance index fastest -> coalesced; ~6 KB per instance, so a 4096-batch
+// stays resident in L2 / Infinity Cache).  Algorithm and constants mirror oracle/pointmass_ipm.py line by line.
+#include "oh_device.h"
+#include "oh_kernels.h"
+
+#define PIDX(row) ((size_t)(row) * Bp + b)
+
+struct PM4 {  // 4x4 helpers on row-major double[16]
+  double m[16];
+};
+
+// c (9 rows) and the nonzero Jacobian entries of stage t: box rows are +-e_j, obstacle row is 2 (y - o)
+OH_DEV void pm_cons(const PmParams& P, const double* x, const double ox, const double oy, double (&c)[9], double& jx, double& jy) {
+  c[0] = x[0] + P.ylim; c[1] = P.ylim - x[0];
+  c[2] = x[1] + P.ylim; c[3] = P.ylim - x[1];
+  c[4] = x[2] + P.vlim; c[5] = P.vlim - x[2];
+  c[6] = x[3] + P.vlim; c[7] = P.vlim - x[3];
+  const double dx = x[0] - ox, dy = x[1] - oy;
+  c[8] = dx * dx + dy * dy - P.safe_sq;
+  jx = 2.0 * dx; jy = 2.0 * dy;
+}
+// y = J^T w for the 9 rows (J rows: +e0,-e0,+e1,-e1,+e2,-e2,+e3,-e3,(jx,jy,0,0))
+OH_DEV void pm_JTw(const double (&w)[9], const double jx, const double jy, double (&y)[4]) {
+  y[0] = w[0] - w[1] + jx * w[8];
+  y[1] = w[2] - w[3] + jy * w[8];
+  y[2] = w[4] - w[5];
+  y[3] = w[6] - w[7];
+}
+// d = J v
+OH_DEV void pm_Jv(const double* v, const double jx, const double jy, double (&d)[9]) {
+  d[0] = v[0]; d[1] = -v[0]; d[2] = v[1]; d[3] = -v[1];
+  d[4] = v[2]; d[5] = -v[2]; d[6] = v[3]; d[7] = -v[3];
+  d[8] = jx * v[0] + jy * v[1];
+}
+
+__global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const double* __restrict__ x0, const double* __restrict__ pin,
+                                                 double* __restrict__ xo, double* __restrict__ fo, double* __restrict__ kkt,
+                                                 int* __restrict__ iters_o, int* __restrict__ status_o) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  const int T = P.T;
+  const double dt = P.dt, w = P.w_acc;
+  const size_t np_ = 4 + 4 * (size_t)T, nx = 4 * (size_t)T;
+  const double* pb = pin + (size_t)b * np_;
+  const double* goal = pb + 4;           // [t][2]
+  const double* obs = pb + 4 + 2 * T;    // [t][2]
+  // work arrays (rows): a[2(T-1)], X[4T], s[9T], lam[9T], K[8(T-1)], kk[2(T-1)], dX[4T], da[2(T-1)]
+  double* A_ = D.a; double* X_ = D.X; double* S_ = D.s; double* L_ = D.lam;
+  double* K_ = D.K; double* k_ = D.kk; double* dX_ = D.dX; double* dA_ = D.da;
+
+  // ---- seed: velocities from x0's dY block, v_0 = dcurr, controls = velocity differences, states by roll-out
+  {
+    double vprev[2] = {pb[2], pb[3]};
+    double x[4] = {pb[0], pb[1], pb[2], pb[3]};
+    for (int j = 0; j < 4; ++j) X_[PIDX(j)] = x[j];
+    for (int t = 0; t < T - 1; ++t) {
+      const double v1[2] = {x0[(size_t)b * nx + 2 * T + 2 * (t + 1)], x0[(size_t)b * nx + 2 * T + 2 * (t + 1) + 1]};
+      const double a0 = (v1[0] - vprev[0]) / dt, a1 = (v1[1] - vprev[1]) / dt;
+      A_[PIDX(2 * t)] = a0; A_[PIDX(2 * t + 1)] = a1;
+      x[0] += dt * x[2]; x[1] += dt * x[3]; x[2] += dt * a0; x[3] += dt * a1;
+      for (int j = 0; j < 4; ++j) X_[PIDX(4 * (t + 1) + j)] = x[j];
+      vprev[0] = v1[0]; vprev[1] = v1[1];
+    }
+  }
+  double mu = 0.1;
+  for (int t = 0; t < T; ++t) {
+    double x[4], c[9], jx, jy;
+    for (int j = 0; j < 4; ++j) x[j] = X_[PIDX(4 * t + j)];
+    pm_cons(P, x, obs[2 * t], obs[2 * t + 1], c, jx, jy);
+    for (int i = 0; i < 9; ++i) {
+      const double s = fmax(c[i], 1e-2);
+      S_[PIDX(9 * t + i)] = s;
+      L_[PIDX(9 * t + i)] = mu / s;
+    }
+  }
+
+  int status = OH_STATUS_MAX_ITER, it = 0;
+  double stat = 0.0, feas = 0.0, compl_ = 0.0, fval = 0.0;
+  for (it = 0; it <= P.max_iter; ++it) {
+    // ---- backward pass: residuals (adjoint) and Riccati recursion -----------------------------------------------
+    double Pm[16], pv[4], padj[4];
+    stat = 0.0; feas = 0.0; compl_ = 0.0; fval = 0.0;
+    for (int t = T - 1; t >= 0; --t) {
+      double x[4], c[9], jx, jy, s[9], lam[9];
+      for (int j = 0; j < 4; ++j) x[j] = X_[PIDX(4 * t + j)];
+      pm_cons(P, x, obs[2 * t], obs[2 * t + 1], c, jx, jy);
+      for (int i = 0; i < 9; ++i) { s[i] = S_[PIDX(9 * t + i)]; lam[i] = L_[PIDX(9 * t + i)]; }
+      const double gx[4] = {-2.0 * (goal[2 * t] - x[0]), -2.0 * (goal[2 * t + 1] - x[1]), 0.0, 0.0};
+      fval += (goal[2 * t] - x[0]) * (goal[2 * t] - x[0]) + (goal[2 * t + 1] - x[1]) * (goal[2 * t + 1] - x[1]);
+      double rc[9], sig[9], wq[9], jl[4], jq[4];
+      for (int i = 0; i < 9; ++i) {
+        rc[i] = c[i] - s[i];
+        sig[i] = lam[i] / s[i];
+        wq[i] = mu / s[i] - sig[i] * rc[i];
+        if (t >= 1) { feas = fmax(feas, fabs(rc[i])); compl_ = fmax(compl_, lam[i] * s[i]); }
+      }
+      pm_JTw(lam, jx, jy, jl);
+      pm_JTw(wq, jx, jy, jq);
+      double lx[4], q[4];
+      for (int j = 0; j < 4; ++j) { lx[j] = gx[j] - jl[j]; q[j] = gx[j] - jq[j]; }
+      // Q_t = diag(2,2,0,0) + J^T Sig J  (stage 0 is fixed: its Q, q are never used)
+      double Q[16];
+      for (int j = 0; j < 16; ++j) Q[j] = 0.0;
+      Q[0] = 2.0 + sig[0] + sig[1] + sig[8] * jx * jx;
+      Q[5] = 2.0 + sig[2] + sig[3] + sig[8] * jy * jy;
+      Q[1] = Q[4] = sig[8] * jx * jy;
+      Q[10] = sig[4] + sig[5];
+      Q[15] = sig[6] + sig[7];
+      if (t == T - 1) {
+        for (int j = 0; j < 16; ++j) Pm[j] = Q[j];
+        for (int j = 0; j < 4; ++j) { pv[j] = q[j]; padj[j] = lx[j]; }
+        continue;
+      }
+      // here Pm, pv, padj belong to stage t+1; controls a_t act between t and t+1
+      const double a0 = A_[PIDX(2 * t)], a1 = A_[PIDX(2 * t + 1)];
+      fval += w * (a0 * a0 + a1 * a1);
+      // control gradient of the Lagrangian: 2 w a + B^T padj, B^T z = dt (z2, z3)
+      stat = fmax(stat, fmax(fabs(2.0 * w * a0 + dt * padj[2]), fabs(2.0 * w * a1 + dt * padj[3])));
+      // Quu = R + B^T P B = 2w I + dt^2 P[2:4,2:4] ; Qux = B^T P A = dt (P[2:4,:] A) ; A = [[I, dt I],[0, I]]
+      double PA[16];  // P A : column j<2 same as P, column j>=2: P[:,j] + dt P[:,j-2]
+      for (int r = 0; r < 4; ++r) {
+        PA[4 * r + 0] = Pm[4 * r + 0]; PA[4 * r + 1] = Pm[4 * r + 1];
+        PA[4 * r + 2] = Pm[4 * r + 2] + dt * Pm[4 * r + 0];
+        PA[4 * r + 3] = Pm[4 * r + 3] + dt * Pm[4 * r + 1];
+      }
+      const double q00 = 2.0 * w + dt * dt * Pm[10], q01 = dt * dt * Pm[11], q11 = 2.0 * w + dt * dt * Pm[15];
+      double Qux[8];
+      for (int j = 0; j < 4; ++j) { Qux[j] = dt * PA[8 + j]; Qux[4 + j] = dt * PA[12 + j]; }
+      const double qu0 = 2.0 * w * a0 + dt * pv[2], qu1 = 2.0 * w * a1 + dt * pv[3];
+      // 2x2 Cholesky solve
+      const double l00 = sqrt(q00), l10 = q01 / l00, l11 = sqrt(q11 - l10 * l10);
+      double Kt[8], kt[2];
+      {
+        for (int j = 0; j < 4; ++j) {
+          const double y0 = Qux[j] / l00, y1 = (Qux[4 + j] - l10 * y0) / l11;
+          const double z1 = y1 / l11, z0 = (y0 - l10 * z1) / l00;
+          Kt[j] = -z0; Kt[4 + j] = -z1;
+        }
+        const double y0 = qu0 / l00, y1 = (qu1 - l10 * y0) / l11;
+        const double z1 = y1 / l11, z0 = (y0 - l10 * z1) / l00;
+        kt[0] = -z0; kt[1] = -z1;
+      }
+      for (int j = 0; j < 8; ++j) K_[PIDX(8 * t + j)] = Kt[j];
+      k_[PIDX(2 * t)] = kt[0]; k_[PIDX(2 * t + 1)] = kt[1];
+      // P_t = Q_t + A^T P A + Qux^T K ;  p_t = q_t + A^T p + Qux^T k ;  (A^T M)[r] = M[r] (+ dt M[r-2] for r >= 2)
+      double Pn[16], pn[4], pa[4];
+      for (int r = 0; r < 4; ++r)
+        for (int cc = 0; cc < 4; ++cc) {
+          double v = PA[4 * r + cc];
+          if (r >= 2) v += dt * PA[4 * (r - 2) + cc];
+          v += Qux[r] * Kt[cc] + Qux[4 + r] * Kt[4 + cc];
+          Pn[4 * r + cc] = Q[4 * r + cc] + v;
+        }
+      for (int r = 0; r < 4; ++r) {
+        double v = pv[r], va = padj[r];
+        if (r >= 2) { v += dt * pv[r - 2]; va += dt * padj[r - 2]; }
+        pn[r] = q[r] + v + Qux[r] * kt[0] + Qux[4 + r] * kt[1];
+        pa[r] = lx[r] + va;
+      }
+      for (int r = 0; r < 4; ++r)
+        for (int cc = 0; cc < 4; ++cc) Pm[4 * r + cc] = 0.5 * (Pn[4 * r + cc] + Pn[4 * cc + r]);
+      for (int j = 0; j < 4; ++j) { pv[j] = pn[j]; padj[j] = pa[j]; }
+    }
+    if (stat <= P.tol && feas <= P.tol && compl_ <= P.tol) { status = OH_STATUS_CONVERGED; break; }
+    if (!(stat == stat) || !(fval == fval)) { status = OH_STATUS_NUMERICAL; break; }
+    if (it == P.max_iter) break;
+
+    // ---- forward pass 1: Newton direction, fraction-to-the-boundary step lengths -------------------------------------------------
+    double ap = 1.0, ad = 1.0;
+    {
+      double dx[4] = {0, 0, 0, 0};
+      for (int j = 0; j < 4; ++j) dX_[PIDX(j)] = 0.0;
+      for (int t = 0; t < T; ++t) {
+        if (t >= 1) {
+          double x[4], c[9], jx, jy, d[9];
+          for (int j = 0; j < 4; ++j) x[j] = X_[PIDX(4 * t + j)];
+          pm_cons(P, x, obs[2 * t], obs[2 * t + 1], c, jx, jy);
+          pm_Jv(dx, jx, jy, d);
+          for (int i = 0; i < 9; ++i) {
+            const double s = S_[PIDX(9 * t + i)], lam = L_[PIDX(9 * t + i)];
+            const double ds = d[i] + (c[i] - s);
+            const double dl = (mu / s - lam) - (lam / s) * ds;
+            if (ds < 0.0) ap = fmin(ap, -0.995 * s / ds);
+            if (dl < 0.0) ad = fmin(ad, -0.995 * lam / dl);
+          }
+        }
+        if (t < T - 1) {
+          double da0 = k_[PIDX(2 * t)], da1 = k_[PIDX(2 * t + 1)];
+          for (int j = 0; j < 4; ++j) { da0 += K_[PIDX(8 * t + j)] * dx[j]; da1 += K_[PIDX(8 * t + 4 + j)] * dx[j]; }
+          dA_[PIDX(2 * t)] = da0; dA_[PIDX(2 * t + 1)] = da1;
+          const double n0 = dx[0] + dt * dx[2], n1 = dx[1] + dt * dx[3], n2 = dx[2] + dt * da0, n3 = dx[3] + dt * da1;
+          dx[0] = n0; dx[1] = n1; dx[2] = n2; dx[3] = n3;
+          for (int j = 0; j < 4; ++j) dX_[PIDX(4 * (t + 1) + j)] = dx[j];
+        }
+      }
+    }
+    // ---- forward pass 2: take the step (slacks / multipliers with the old Jacobians, states by exact roll-out) ------------------------
+    double gap = 0.0;
+    {
+      double xn[4] = {pb[0], pb[1], pb[2], pb[3]};
+      for (int t = 0; t < T; ++t) {
+        if (t >= 1) {
+          double x[4], dx[4], c[9], jx, jy, d[9];
+          for (int j = 0; j < 4; ++j) { x[j] = X_[PIDX(4 * t + j)]; dx[j] = dX_[PIDX(4 * t + j)]; }
+          pm_cons(P, x, obs[2 * t], obs[2 * t + 1], c, jx, jy);
+          pm_Jv(dx, jx, jy, d);
+          for (int i = 0; i < 9; ++i) {
+            double s = S_[PIDX(9 * t + i)], lam = L_[PIDX(9 * t + i)];
+            const double ds = d[i] + (c[i] - s);
+            const double dl = (mu / s - lam) - (lam / s) * ds;
+            s += ap * ds; lam += ad * dl;
+            S_[PIDX(9 * t + i)] = s; L_[PIDX(9 * t + i)] = lam;
+            gap += s * lam;
+          }
+        }
+        for (int j = 0; j < 4; ++j) X_[PIDX(4 * t + j)] = xn[j];
+        if (t < T - 1) {
+          const double a0 = A_[PIDX(2 * t)] + ap * dA_[PIDX(2 * t)], a1 = A_[PIDX(2 * t + 1)] + ap * dA_[PIDX(2 * t + 1)];
+          A_[PIDX(2 * t)] = a0; A_[PIDX(2 * t + 1)] = a1;
+          const double n0 = xn[0] + dt * xn[2], n1 = xn[1] + dt * xn[3], n2 = xn[2] + dt * a0, n3 = xn[3] + dt * a1;
+          xn[0] = n0; xn[1] = n1; xn[2] = n2; xn[3] = n3;
+        }
+      }
+    }
+    gap /= (double)(9 * (T - 1));
+    const double am = fmin(ap, ad);
+    const double sigma = (am > 0.9) ? 0.1 : ((am > 0.5) ? 0.3 : 0.8);
+    mu = fmax(sigma * gap, 1e-2 * P.tol);
+  }
+  // ---- results in the reference layout x = [vec(Y 2xT); vec(dY 2xT)] --------------------------------------------------------------------
+  if (xo) {
+    double* xb = xo + (size_t)b * nx;
+    for (int t = 0; t < T; ++t) {
+      xb[2 * t] = X_[PIDX(4 * t)]; xb[2 * t + 1] = X_[PIDX(4 * t + 1)];
+      xb[2 * T + 2 * t] = X_[PIDX(4 * t + 2)]; xb[2 * T + 2 * t + 1] = X_[PIDX(4 * t + 3)];
+    }
+  }
+  if (fo) fo[b] = fval;
+  if (kkt) { kkt[3 * (size_t)b] = stat; kkt[3 * (size_t)b + 1] = feas; kkt[3 * (size_t)b + 2] = compl_; }
+  if (iters_o) iters_o[b] = it > P.max_iter ? P.max_iter : it;
+  if (status_o) status_o[b] = status;
+}
+
+void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, const double* x0, const double* p, double* x, double* f, double* kkt,
+                        int* iters, int* status) {
+  hipLaunchKernelGGL(k_pm_solve, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p, x, f, kkt, iters, status);
+}

@@ -39,6 +39,11 @@ class Expr:
 
     __rmul__ = __mul__
 
+    def __truediv__(self, other):
+        if isinstance(other, (int, float)):
+            return Scale(1.0 / float(other), self)
+        return NotImplemented
+
     def __neg__(self):
         return Scale(-1.0, self)
 
@@ -86,6 +91,26 @@ class ParamRef(Expr):
     def degree(self):
         return 0
 
+    def __getitem__(self, key):
+        # obs[:, i]
+        if isinstance(key, tuple) and len(key) == 2 and key[0] == slice(None) and isinstance(key[1], int):
+            return ParamCol(self, key[1] if key[1] >= 0 else self.n + key[1])
+        raise NotImplementedError("only P[:, i] slicing is lowered")
+
+
+@dataclass(eq=False)
+class ParamCol(Expr):
+    """One column of a parameter block."""
+
+    param: "ParamRef" = None
+    col: int = 0
+
+    def __post_init__(self):
+        self.shape = (self.param.m, 1)
+
+    def degree(self):
+        return 0
+
 
 @dataclass(eq=False)
 class StateRef(Expr):
@@ -110,7 +135,28 @@ class StateRef(Expr):
         if isinstance(key, tuple) and len(key) == 2 and key[0] == slice(None) and isinstance(key[1], int) and self.t is None:
             t = key[1] if key[1] >= 0 else self.n + key[1]
             return StateRef(self.var_name, self.model_name, self.time_deriv, self.m, self.n, t)
-        raise NotImplementedError("only Q[:, t] slicing is lowered")
+        # Q[:, a:b]
+        if isinstance(key, tuple) and len(key) == 2 and key[0] == slice(None) and isinstance(key[1], slice) and self.t is None:
+            lo, hi, step = key[1].indices(self.n)
+            if step != 1:
+                raise NotImplementedError("only unit-stride column slices are lowered")
+            return StateCols(self, lo, hi)
+        raise NotImplementedError("only Q[:, t] and Q[:, a:b] slicing is lowered")
+
+
+@dataclass(eq=False)
+class StateCols(Expr):
+    """Columns lo..hi-1 of a state trajectory (dX[:, 1:], dX[:, :-1] in point_mass_mpc.py:134)."""
+
+    state: "StateRef" = None
+    lo: int = 0
+    hi: int = 0
+
+    def __post_init__(self):
+        self.shape = (self.state.m, self.hi - self.lo)
+
+    def degree(self):
+        return 1
 
 
 @dataclass(eq=False)

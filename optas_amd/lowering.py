@@ -18,8 +18,8 @@ import numpy as np
 
 from . import _lib
 from .builder import IntegrationResidual
-from .expr import Const, LinkFunction, ParamRef, PathInFrame, Scale, StateRef, Sub, SumSqr
-from .models import RobotModel
+from .expr import Const, LinkFunction, ParamCol, ParamRef, PathInFrame, Scale, StateCols, StateRef, Sub, SumSqr
+from .models import RobotModel, TaskModel
 from .optimization import Optimization
 
 
@@ -150,10 +150,124 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
     return FigureEightSpec(robot, link, T, dt, w_path, w_vel, np.ascontiguousarray(local.T), qc.name, q_name, dq_name)
 
 
+@dataclass
+class PointMassSpec:
+    T: int
+    dt: float
+    w_acc: float
+    ylim: float
+    vlim: float
+    safe: float
+    names: tuple  # (curr, dcurr, goal, obs) parameter labels
+    y_name: str
+    dy_name: str
+
+
+def match_point_mass(opt: Optimization) -> PointMassSpec:
+    """example/point_mass_mpc.py:88-154 (Controller)."""
+
+    def no(msg):
+        raise LoweringError(f"point-mass MPC lowering: {msg}")
+
+    tasks = [m for m in (opt.models or []) if isinstance(m, TaskModel)]
+    if len(opt.models or []) != 1 or len(tasks) != 1:
+        no("expected exactly one TaskModel")
+    tm = tasks[0]
+    if tm.dim != 2 or list(tm.time_derivs) != [0, 1]:
+        no("task model must be planar (dim 2) with time_derivs=[0, 1]")
+    y_name, dy_name = tm.state_optimized_name(0), tm.state_optimized_name(1)
+    if list(opt.decision_variables.keys()) != [y_name, dy_name]:
+        no("decision variables must be exactly the position and velocity trajectories")
+    Y, dY = opt.decision_variables[y_name], opt.decision_variables[dy_name]
+    T = Y.n
+    if dY.n != T:
+        no("needs derivs_align=True")
+    if opt.nh:
+        no("nonlinear equalities are not part of this family")
+    # box limits
+    lim = {}
+    for label, diff in opt.lin_ineq_constraints.items():
+        if not (isinstance(diff, Sub) and diff.numel() == 2 * T):
+            no(f"linear inequality '{label}' not recognised")
+        hi, lo = diff.a, diff.b  # stored as rhs - lhs
+        if isinstance(hi, StateRef) and isinstance(lo, Const) and lo.value.size == 1:
+            lim[(hi.time_deriv, "l")] = float(lo.value.reshape(-1)[0])
+        elif isinstance(lo, StateRef) and isinstance(hi, Const) and hi.value.size == 1:
+            lim[(lo.time_deriv, "r")] = float(hi.value.reshape(-1)[0])
+        else:
+            no(f"linear inequality '{label}' is not a scalar box limit on a whole trajectory")
+    if set(lim) != {(0, "l"), (0, "r"), (1, "l"), (1, "r")}:
+        no("need enforce_model_limits for time_deriv 0 and 1")
+    if lim[(0, "l")] != -lim[(0, "r")] or lim[(1, "l")] != -lim[(1, "r")]:
+        no("box limits must be symmetric")
+    # equalities
+    curr = dcurr = None
+    dt = None
+    for label, diff in opt.lin_eq_constraints.items():
+        rhs, lhs = diff.a, diff.b
+        if isinstance(lhs, StateRef) and lhs.t == 0 and isinstance(rhs, ParamRef):
+            if lhs.time_deriv == 0:
+                curr = rhs
+            else:
+                dcurr = rhs
+        elif isinstance(lhs, IntegrationResidual) and _is_zero_const(rhs) and lhs.xd.time_deriv == 1:
+            if not np.all(lhs.dt == lhs.dt[0]):
+                no("non-uniform dt is not lowered")
+            dt = float(lhs.dt[0])
+        else:
+            no(f"linear equality '{label}' not recognised")
+    if curr is None or dcurr is None or dt is None:
+        no("need fix_configuration for position and velocity and integrate_model_states")
+    # obstacle rows
+    if len(opt.ineq_constraints) != T:
+        no(f"expected {T} obstacle rows, found {len(opt.ineq_constraints)}")
+    obs = None
+    safe_sq = None
+    for i, (label, diff) in enumerate(opt.ineq_constraints.items()):
+        ok = (
+            isinstance(diff, Sub) and isinstance(diff.a, SumSqr) and isinstance(diff.b, Const) and diff.b.value.size == 1
+            and isinstance(diff.a.a, Sub) and isinstance(diff.a.a.a, ParamCol) and isinstance(diff.a.a.b, StateRef)
+            and diff.a.a.a.col == i and diff.a.a.b.t == i and diff.a.a.b.time_deriv == 0
+        )
+        if not ok:
+            no(f"inequality '{label}' is not ||obs[:, {i}] - y_{i}||^2 >= const")
+        if obs is None:
+            obs, safe_sq = diff.a.a.a.param, float(diff.b.value.reshape(-1)[0])
+        elif diff.a.a.a.param is not obs or float(diff.b.value.reshape(-1)[0]) != safe_sq:
+            no("all obstacle rows must use the same obstacle parameter and radius")
+    # costs
+    goal = None
+    w_acc = None
+    for label, term in opt.cost_terms.items():
+        w, e = _unscale(term)
+        if not isinstance(e, SumSqr):
+            no(f"cost '{label}' is not a weighted sumsqr")
+        inner = e.a
+        if isinstance(inner, Sub) and isinstance(inner.a, ParamRef) and inner.b is Y and w == 1.0:
+            goal = inner.a
+        else:
+            s2, d = _unscale(inner)
+            good = (
+                isinstance(d, Sub) and isinstance(d.a, StateCols) and isinstance(d.b, StateCols) and d.a.state is dY and d.b.state is dY
+                and (d.a.lo, d.a.hi, d.b.lo, d.b.hi) == (1, T, 0, T - 1) and abs(s2 * dt - 1.0) < 1e-12
+            )
+            if not good:
+                no(f"cost '{label}' not recognised")
+            w_acc = w
+    if goal is None or w_acc is None:
+        no("need the path-tracking and the acceleration cost terms")
+    names = (curr.name, dcurr.name, goal.name, obs.name)
+    if list(opt.parameters.keys()) != list(names):
+        no(f"parameters must be created in the order {names}")
+    if (curr.shape, dcurr.shape, goal.shape, obs.shape) != ((2, 1), (2, 1), (2, T), (2, T)):
+        no("parameter shapes must be curr(2), dcurr(2), goal(2xT), obs(2xT)")
+    return PointMassSpec(T, dt, w_acc, lim[(0, "r")], lim[(1, "r")], float(np.sqrt(safe_sq)), names, y_name, dy_name)
+
+
 def lower(opt: Optimization):
     """Return (kind, spec).  Raises LoweringError if no kernel family matches."""
     errors = []
-    for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight),):
+    for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass)):
         try:
             return kind, fn(opt)
         except LoweringError as e:

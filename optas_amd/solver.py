@@ -16,8 +16,8 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import _lib
-from .backend import BatchResult, FigureEightBackend
-from .lowering import FigureEightSpec, lower
+from .backend import BatchResult, FigureEightBackend, PointMassBackend
+from .lowering import FigureEightSpec, PointMassSpec, lower
 from .models import RobotModel
 from .optimization import Optimization
 
@@ -108,7 +108,9 @@ class HIPSolver(Solver):
         o = dict(solver_options or {})
         kind, spec = lower(self.opt)
         self._kind, self._spec = kind, spec
-        hessian = {"gauss_newton": _lib.OH_HESSIAN_GAUSS_NEWTON, "exact": _lib.OH_HESSIAN_EXACT}[o.pop("hessian", "gauss_newton")]
+        hessian = {"gauss_newton": _lib.OH_HESSIAN_GAUSS_NEWTON, "exact": _lib.OH_HESSIAN_EXACT}[o.get("hessian", "gauss_newton")]
+        if isinstance(spec, FigureEightSpec):
+            o.pop("hessian", None)
         if isinstance(spec, FigureEightSpec):
             chain = spec.robot.kinematic_chain(spec.link)
             self._backend = FigureEightBackend(
@@ -123,6 +125,11 @@ class HIPSolver(Solver):
                 tol_feas=float(o.pop("tol_feas", 1e-9)),
                 hessian=hessian,
                 mu0=float(o.pop("mu0", 0.0)),
+            )
+        elif isinstance(spec, PointMassSpec):
+            o.pop("hessian", None)
+            self._backend = PointMassBackend(
+                spec.T, spec.dt, spec.w_acc, spec.ylim, spec.vlim, spec.safe, max_iter=int(o.pop("max_iter", 100)), tol=float(o.pop("tol", 1e-8))
             )
         else:  # pragma: no cover
             raise NotImplementedError(kind)

@@ -263,3 +263,123 @@ class FigureEightNLP(_NLPBase):
             H[n * t : n * t + n, n * t : n * t + n] = W
         H[self.nq :, self.nq :] = 2.0 * self.w_vel * np.eye(self.ndq)
         return H
+
+
+class PointMassMPCNLP(_NLPBase):
+    """example/point_mass_mpc.py Controller (:88-154), BASELINE config 3, SURVEY App. B.3.
+
+    TaskModel "point_mass", dim 2, time_derivs [0,1], derivs_align=True, T=20, dt=0.05.
+    x = ["point_mass/y/x" (2xT); "point_mass/dy/x" (2xT)]                                (builder.py:90-99)
+    p = [curr(2); dcurr(2); vec(goal 2xT); vec(obs 2xT)]                                   (:104-107)
+    k = [Y+1.5; 1.5-Y; dY+1; 1-dY]   (enforce_model_limits d=0, d=1 -> "_l", "_r" blocks)  (:110-111)
+    a = [-(y_t + dt dy_t - y_{t+1}) t=0..T-2; curr - y_0; dcurr - dy_0]                    (:114-118)
+    g = ||obs_t - y_t||^2 - (0.2+0.1)^2, t=0..T-1                                          (:121-127)
+    f = sum ||goal - Y||^2 + (0.0025/T) sum ||(dy_{t+1}-dy_t)/dt||^2                        (:130-136)
+    """
+
+    def __init__(self, T=20, dt=0.05, ylim=1.5, dylim=1.0, safe=0.3, w_acc=0.0025):
+        self.T, self.dt, self.ylim, self.dylim = T, dt, ylim, dylim
+        self.safe_sq = safe**2
+        self.w = w_acc / float(T)
+        self.nx, self.np_ = 4 * T, 4 + 4 * T
+        self.nk, self.na, self.ng = 8 * T, 2 * (T - 1) + 4, T
+        n = 2
+        A = np.zeros((self.na, self.nx))
+        I = np.eye(n)
+        for t in range(T - 1):
+            r = n * t
+            A[r : r + n, n * t : n * t + n] = -I
+            A[r : r + n, 2 * T + n * t : 2 * T + n * t + n] = -dt * I
+            A[r : r + n, n * (t + 1) : n * (t + 1) + n] = I
+        r = n * (T - 1)
+        A[r : r + n, 0:n] = -I  # curr - y_0
+        A[r + n : r + 2 * n, 2 * T : 2 * T + n] = -I  # dcurr - dy_0
+        self._A = A
+        Ik = np.eye(2 * T)
+        Z = np.zeros((2 * T, 2 * T))
+        self._M = np.block([[Ik, Z], [-Ik, Z], [Z, Ik], [Z, -Ik]])
+
+    def split(self, x):
+        T = self.T
+        return x[: 2 * T].reshape(T, 2).T, x[2 * T :].reshape(T, 2).T
+
+    def split_p(self, p):
+        T = self.T
+        return p[0:2], p[2:4], p[4 : 4 + 2 * T].reshape(T, 2).T, p[4 + 2 * T :].reshape(T, 2).T
+
+    @staticmethod
+    def pack_p(curr, dcurr, goal, obs):
+        return np.concatenate([np.asarray(curr, float), np.asarray(dcurr, float), np.asarray(goal, float).T.reshape(-1), np.asarray(obs, float).T.reshape(-1)])
+
+    def f(self, x, p):
+        Y, dY = self.split(x)
+        _, _, goal, _ = self.split_p(p)
+        dd = (dY[:, 1:] - dY[:, :-1]) / self.dt
+        return float(np.sum((goal - Y) ** 2) + self.w * np.sum(dd**2))
+
+    def df(self, x, p):
+        Y, dY = self.split(x)
+        _, _, goal, _ = self.split_p(p)
+        gY = -2.0 * (goal - Y)
+        dd = (dY[:, 1:] - dY[:, :-1]) / self.dt
+        gdY = np.zeros_like(dY)
+        gdY[:, 1:] += 2.0 * self.w * dd / self.dt
+        gdY[:, :-1] -= 2.0 * self.w * dd / self.dt
+        return np.concatenate([gY.T.reshape(-1), gdY.T.reshape(-1)])
+
+    def ddf(self, x, p):
+        T = self.T
+        H = np.zeros((self.nx, self.nx))
+        H[: 2 * T, : 2 * T] = 2.0 * np.eye(2 * T)
+        c = 2.0 * self.w / self.dt**2
+        for t in range(T - 1):
+            for j in range(2):
+                a, b = 2 * T + 2 * t + j, 2 * T + 2 * (t + 1) + j
+                H[a, a] += c
+                H[b, b] += c
+                H[a, b] -= c
+                H[b, a] -= c
+        return H
+
+    def k(self, x, p):
+        Y, dY = self.split(x)
+        y, dy = Y.T.reshape(-1), dY.T.reshape(-1)
+        return np.concatenate([y + self.ylim, self.ylim - y, dy + self.dylim, self.dylim - dy])
+
+    def dk(self, x, p):
+        return self._M
+
+    def a(self, x, p):
+        curr, dcurr, _, _ = self.split_p(p)
+        b = np.zeros(self.na)
+        b[2 * (self.T - 1) : 2 * (self.T - 1) + 2] = curr
+        b[2 * (self.T - 1) + 2 :] = dcurr
+        return self._A @ x + b
+
+    def da(self, x, p):
+        return self._A
+
+    def g(self, x, p):
+        Y, _ = self.split(x)
+        _, _, _, obs = self.split_p(p)
+        return np.sum((obs - Y) ** 2, axis=0) - self.safe_sq
+
+    def dg(self, x, p):
+        Y, _ = self.split(x)
+        _, _, _, obs = self.split_p(p)
+        J = np.zeros((self.ng, self.nx))
+        for t in range(self.T):
+            J[t, 2 * t : 2 * t + 2] = -2.0 * (obs[:, t] - Y[:, t])
+        return J
+
+
+def point_mass_tick_parameters(t0=2.0, T=20, dt=0.05, curr=(-0.45, -0.35), dcurr=(0.6, 0.6), ramp=0.032):
+    """The MPC tick of BASELINE.md section 5 / SURVEY App. D: moving obstacle of point_mass_mpc.py:293-306 at time
+    t0, goal = straight ramp from curr."""
+    obs, goal = [], []
+    for i in range(T):
+        ti = t0 + dt * i
+        alpha = ti * np.pi - np.pi
+        obs.append([0.15 * np.sin(alpha), 0.15 * np.cos(alpha) + 0.15])
+        goal.append([curr[0] + ramp * i, curr[1] + ramp * i])
+    return PointMassMPCNLP.pack_p(curr, dcurr, np.array(goal).T, np.array(obs).T)

@@ -1,0 +1,98 @@
+"""BASELINE config 3 on the GPU: OH_PROBLEM_POINT_MASS_MPC through HIPSolver / the C ABI against the oracle.
+Tolerances: objective 1e-7 relative vs the golden optimum (scipy SLSQP in the reference wiring where it converges, the
+IPM port elsewhere), reference-form KKT stationarity <= 1e-5, feasibility <= 1e-9, complementarity <= 1e-8, linear rows
+exact to 1e-13."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SEED
+from optas_amd.backend import PointMassBackend
+from oracle.pointmass_ipm import solve_pointmass_ipm
+from oracle.problems import PointMassMPCNLP
+from oracle.solvers import kkt_reference_form
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from examples.point_mass_mpc import Controller, obstacle_and_goal  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_script_flow_and_known_answer(hip_lib):
+    c = Controller(solver_options={"tol": 1e-9})
+    curr, dcurr = np.array([-0.45, -0.35]), np.array([0.6, 0.6])
+    obs, goal = obstacle_and_goal(2.0, curr)
+    y2, dy2, plan_y, plan_dy = c.next_state(curr, dcurr, goal, obs)
+    s = c.solver
+    assert s.did_solve() and abs(s.stats()["f"][0] - 0.1759064919) < 1e-7  # BASELINE.md section 5 (scipy SLSQP, reference wiring)
+    sol = c.solution
+    assert sol["point_mass/y"].shape == (2, 20) and sol["point_mass/dy"].shape == (2, 20)
+    assert np.allclose(plan_y(0.0), curr) and np.allclose(plan_dy(0.0), dcurr)
+    nlp = PointMassMPCNLP()
+    x = s.opt.decision_variables.dict2vec(sol)
+    p = s.opt.parameters.dict2vec({"curr": curr, "dcurr": dcurr, "goal": goal, "obs": obs})
+    assert abs(nlp.f(x, p) - s.stats()["f"][0]) < 1e-12 and np.abs(nlp.a(x, p)).max() < 1e-13
+    k = kkt_reference_form(nlp, x, p)
+    assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-9 and k["complementarity"] <= 1e-8
+    assert nlp.g(x, p).min() < 1e-8  # obstacle row active, as the reference-wired oracle finds
+    # receding horizon: warm-started ticks keep solving
+    t = 2.0
+    for _ in range(4):
+        t += 2 * c.dt
+        curr, dcurr = y2, dy2
+        obs, goal = obstacle_and_goal(t, curr)
+        y2, dy2, _, _ = c.next_state(curr, dcurr, goal, obs)
+        assert c.solver.did_solve()
+
+
+def test_golden_instances(hip_lib):
+    nlp = PointMassMPCNLP()
+    d = np.load(os.path.join(GOLDEN, "pm_golden.npz"))
+    be = PointMassBackend(tol=1e-9)
+    r = be.solve(np.zeros((len(d["p"]), nlp.nx)), d["p"])
+    assert (r.status == 0).all()
+    for i in range(len(d["p"])):
+        assert abs(r.f[i] - d["f"][i]) <= 1e-7 * max(1.0, abs(d["f"][i])), i
+        assert abs(nlp.f(r.x[i], d["p"][i]) - r.f[i]) < 1e-12
+        k = kkt_reference_form(nlp, r.x[i], d["p"][i])
+        assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-9 and k["complementarity"] <= 1e-8, (i, k)
+    be.close()
+
+
+def test_batch_4096_initial_states(hip_lib):
+    """BASELINE config 3 as quoted: T=20, batch=4096 initial states (SURVEY 8(d) C3 sampling)."""
+    nlp = PointMassMPCNLP()
+    rng = np.random.default_rng(SEED)
+    B = 4096
+    obs = np.array([[0.15 * np.sin(np.pi * (0.05 * t) - np.pi), 0.15 * np.cos(np.pi * (0.05 * t) - np.pi) + 0.15] for t in range(20)]).T
+    P = []
+    while len(P) < B:
+        c = rng.uniform(-1.2, 1.2, 2)
+        if np.linalg.norm(c - obs[:, 0]) <= 0.35:
+            continue
+        goal = np.stack([np.clip(c[j] + (1 - c[j]) * np.arange(20) / 19.0, -1.5, 1.5) for j in range(2)])
+        P.append(PointMassMPCNLP.pack_p(c, np.zeros(2), goal, obs))
+    P = np.array(P)
+    be = PointMassBackend(tol=1e-8)
+    r = be.solve(np.zeros((B, nlp.nx)), P)
+    assert np.isfinite(r.x).all() and (r.status == 0).mean() >= 0.999
+    conv = r.status == 0
+    assert (r.kkt[conv] <= 1e-8).all()
+    Y = r.x[:, :40].reshape(B, 20, 2)
+    V = r.x[:, 40:].reshape(B, 20, 2)
+    assert np.abs(Y).max() <= 1.5 + 1e-9 and np.abs(V).max() <= 1.0 + 1e-9  # box rows
+    assert (np.sum((Y - obs.T[None]) ** 2, axis=2) >= 0.09 - 1e-9).all()  # obstacle rows
+    assert np.abs(Y[:, 1:] - (Y[:, :-1] + 0.05 * V[:, :-1])).max() <= 1e-13  # Euler rows
+    assert np.array_equal(Y[:, 0], P[:, 0:2]) and np.array_equal(V[:, 0], P[:, 2:4])
+    for b in rng.choice(B, 12, replace=False):  # the numpy port runs the same algorithm
+        curr, dcurr, goal, ob = nlp.split_p(P[b])
+        ref = solve_pointmass_ipm(20, 0.05, nlp.w, 1.5, 1.0, nlp.safe_sq, curr, dcurr, goal, ob, tol=1e-8)
+        assert abs(ref["f"] - r.f[b]) <= 1e-8 * max(1.0, abs(ref["f"])) and ref["iters"] == r.iters[b]
+        k = kkt_reference_form(nlp, r.x[b], P[b])
+        assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-9
+    r2 = be.solve(np.zeros((B, nlp.nx)), P)
+    assert np.array_equal(r.x, r2.x)  # deterministic
+    print("point-mass batch: device ms", be.solve_ms(), "solves/s", B / (be.solve_ms() * 1e-3), "iters mean", r.iters.mean())
+    be.close()

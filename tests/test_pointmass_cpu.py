@@ -1,0 +1,82 @@
+"""BASELINE config 3 (example/point_mass_mpc.py) on the CPU side: oracle restatement in the reference layout,
+the reference-wired scipy SLSQP known answer of BASELINE.md section 5, the numpy port of the HIP interior-point kernel,
+and the host mirror (builder counts of SURVEY 8(a) H3, lowering)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle.pointmass_ipm import solve_pointmass_ipm
+from oracle.problems import PointMassMPCNLP, point_mass_tick_parameters
+from oracle.solvers import kkt_reference_form, scipy_minimize
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def test_oracle_counts_and_derivatives():
+    nlp = PointMassMPCNLP()
+    assert (nlp.nx, nlp.np_, nlp.nk, nlp.na, nlp.ng, nlp.nv) == (80, 84, 160, 42, 20, 264)
+    p = point_mass_tick_parameters()
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-0.5, 0.5, nlp.nx)
+    g, Jg, H = nlp.df(x, p), nlp.dg(x, p), nlp.ddf(x, p)
+    h = 1e-6
+    for i in range(nlp.nx):
+        d = np.zeros(nlp.nx)
+        d[i] = h
+        assert abs((nlp.f(x + d, p) - nlp.f(x - d, p)) / (2 * h) - g[i]) < 1e-7
+        assert np.abs((nlp.g(x + d, p) - nlp.g(x - d, p)) / (2 * h) - Jg[:, i]).max() < 1e-8
+        assert np.abs((nlp.df(x + d, p) - nlp.df(x - d, p)) / (2 * h) - H[:, i]).max() < 1e-6
+    assert np.allclose(nlp.k(x, p), nlp.dk(x, p) @ x + nlp.k(np.zeros(nlp.nx), p))
+    assert np.allclose(nlp.a(x, p), nlp.da(x, p) @ x + nlp.a(np.zeros(nlp.nx), p))
+    a = nlp.a(x, p)
+    assert np.allclose(nlp.v(x, p), np.concatenate([nlp.k(x, p), nlp.g(x, p), a, -a]))
+
+
+def test_reference_wired_slsqp_known_answer():
+    nlp = PointMassMPCNLP()
+    p = point_mass_tick_parameters()
+    r = scipy_minimize(nlp, np.zeros(nlp.nx), p, method="SLSQP", tol=1e-12, options={"maxiter": 500})
+    assert r.success and abs(r.fun - 0.1759064919) < 1e-8
+    assert abs(nlp.g(r.x, p).min()) < 1e-10  # the obstacle row is active
+    k = kkt_reference_form(nlp, r.x, p)
+    assert k["stationarity"] < 1e-6 and k["feasibility"] < 1e-10 and k["complementarity"] < 1e-8
+
+
+def test_ipm_port_matches_golden():
+    nlp = PointMassMPCNLP()
+    d = np.load(os.path.join(GOLDEN, "pm_golden.npz"))
+    for i in range(len(d["p"])):
+        curr, dcurr, goal, obs = nlp.split_p(d["p"][i])
+        r = solve_pointmass_ipm(20, 0.05, nlp.w, 1.5, 1.0, nlp.safe_sq, curr, dcurr, goal, obs, tol=1e-9)
+        assert r["status"] == 0
+        assert abs(r["f"] - d["f"][i]) <= 1e-7 * max(1.0, abs(d["f"][i]))
+        x = np.concatenate([r["Y"].T.reshape(-1), r["V"].T.reshape(-1)])
+        assert np.abs(nlp.a(x, d["p"][i])).max() < 1e-14
+        k = kkt_reference_form(nlp, x, d["p"][i])
+        assert k["stationarity"] < 1e-5 and k["feasibility"] < 1e-9 and k["complementarity"] < 1e-8
+
+
+def test_builder_counts_and_lowering():
+    from examples.point_mass_mpc import Controller
+    from optas_amd import _lib
+    from optas_amd.lowering import lower
+    from optas_amd.optimization import QuadraticCostNonlinearConstraints
+
+    c = Controller(build_only=True)
+    o = c.optimization
+    assert isinstance(o, QuadraticCostNonlinearConstraints)
+    assert (o.nx, o.np, o.nk, o.na, o.ng, o.nh, o.nv) == (80, 84, 160, 42, 20, 0, 264)
+    assert list(o.decision_variables.keys()) == ["point_mass/y/x", "point_mass/dy/x"]
+    assert list(o.parameters.keys()) == ["curr", "dcurr", "goal", "obs"]
+    assert list(o.lin_ineq_constraints.keys()) == [
+        "__point_mass_model_limit_0___l", "__point_mass_model_limit_0___r", "__point_mass_model_limit_1___l", "__point_mass_model_limit_1___r"]
+    assert list(o.ineq_constraints.keys()) == [f"obs_avoid_{i}" for i in range(20)]
+    kind, spec = lower(o)
+    assert kind == _lib.OH_PROBLEM_POINT_MASS_MPC
+    assert (spec.T, spec.dt, spec.ylim, spec.vlim) == (20, 0.05, 1.5, 1.0) and abs(spec.safe - 0.3) < 1e-15 and abs(spec.w_acc - 0.0025 / 20) < 1e-18
+    # parameter vector layout = the oracle's
+    p = o.parameters.dict2vec({"curr": [0.1, 0.2], "dcurr": [0.3, 0.4], "goal": np.arange(40.0).reshape(2, 20), "obs": -np.arange(40.0).reshape(2, 20)})
+    assert np.array_equal(p, PointMassMPCNLP.pack_p([0.1, 0.2], [0.3, 0.4], np.arange(40.0).reshape(2, 20), -np.arange(40.0).reshape(2, 20)))

@@ -127,3 +127,33 @@ if __name__ == "__main__":
     fk_golden()
     nlp_golden()
     print("golden fixtures written to", G)
+
+
+def pm_golden():
+    """BASELINE config 3 (point_mass_mpc.py): one MPC tick + 8 random initial states, reference wiring (scipy SLSQP on
+    v >= 0) and the IPM port; both must agree."""
+    from oracle.pointmass_ipm import solve_pointmass_ipm
+    from oracle.problems import PointMassMPCNLP, point_mass_tick_parameters
+
+    nlp = PointMassMPCNLP()
+    rng = np.random.default_rng(SEED)
+    P = [point_mass_tick_parameters()]
+    _, _, _, obs = nlp.split_p(P[0])
+    for _ in range(8):
+        while True:
+            c = rng.uniform(-1.2, 1.2, 2)
+            if np.linalg.norm(c - obs[:, 0]) > 0.35:
+                break
+        goal = np.stack([np.clip(c[j] + (1 - c[j]) * np.arange(20) / 19.0, -1.5, 1.5) for j in range(2)])
+        P.append(PointMassMPCNLP.pack_p(c, np.zeros(2), goal, obs))
+    X, F = [], []
+    for p in P:
+        r = scipy_minimize(nlp, np.zeros(nlp.nx), p, method="SLSQP", tol=1e-13, options={"maxiter": 1000})
+        curr, dcurr, goal, ob = nlp.split_p(p)
+        i = solve_pointmass_ipm(20, 0.05, nlp.w, 1.5, 1.0, nlp.safe_sq, curr, dcurr, goal, ob, tol=1e-9)
+        k = kkt_reference_form(nlp, r.x, p)
+        print("pm", r.fun, r.nit, r.success, i["f"], i["iters"], abs(r.fun - i["f"]), k["stationarity"])
+        best = r.x if (r.success and r.fun <= i["f"] + 1e-7) else np.concatenate([i["Y"].T.reshape(-1), i["V"].T.reshape(-1)])
+        X.append(best)
+        F.append(nlp.f(best, p))
+    np.savez(os.path.join(G, "pm_golden.npz"), p=np.array(P), x=np.array(X), f=np.array(F))

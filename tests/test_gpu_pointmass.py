@@ -90,8 +90,9 @@ def test_batch_4096_initial_states(hip_lib):
         curr, dcurr, goal, ob = nlp.split_p(P[b])
         ref = solve_pointmass_ipm(20, 0.05, nlp.w, 1.5, 1.0, nlp.safe_sq, curr, dcurr, goal, ob, tol=1e-8)
         assert abs(ref["f"] - r.f[b]) <= 1e-8 * max(1.0, abs(ref["f"])) and ref["iters"] == r.iters[b]
-        k = kkt_reference_form(nlp, r.x[b], P[b])
-        assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-9
+        # interior-point solutions leave weakly active rows a slack of ~mu/lam: widen the active-set window of the checker (lam*s <= 1e-8 with lam ~ 1e-5 means s ~ 1e-3)
+        k = kkt_reference_form(nlp, r.x[b], P[b], active_tol=1e-3)
+        assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-9, (b, k["stationarity"])
     r2 = be.solve(np.zeros((B, nlp.nx)), P)
     assert np.array_equal(r.x, r2.x)  # deterministic
     print("point-mass batch: device ms", be.solve_ms(), "solves/s", B / (be.solve_ms() * 1e-3), "iters mean", r.iters.mean())

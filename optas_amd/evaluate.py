@@ -1,0 +1,57 @@
+"""Numeric evaluation of ``optas_amd.expr`` trees at a given (x, p): the diagnostics of the reference's Solver
+(``evaluate_cost``, ``evaluate_cost_terms``, ``violated_constraints``, optas/solver.py:167-237,269-314) need the value
+of individual cost terms / constraint blocks.  Forward kinematics inside a tree goes through liboptas_hip
+(``RobotModel.get_global_link_*`` -> ``oh_fk_jac``); everything else is elementwise host bookkeeping on the results.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .builder import IntegrationResidual
+from .expr import Add, Const, Expr, LinkFunction, ParamCol, ParamRef, PathInFrame, Scale, StateCols, StateRef, Sub, SumSqr, VarRef
+
+
+def _block(container, vec, label):
+    off = container.offsets()[label]
+    m, n = container[label].shape
+    return vec[off : off + m * n].reshape(n, m).T
+
+
+def evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
+    """Value of node ``e`` as a 2-D array (rows x cols like the CasADi matrix it stands for)."""
+    if isinstance(e, Const):
+        return e.value
+    if isinstance(e, ParamRef):
+        return _block(opt.parameters, p, e.name)
+    if isinstance(e, ParamCol):
+        return _block(opt.parameters, p, e.param.name)[:, [e.col]]
+    if isinstance(e, StateRef):
+        full = _block(opt.decision_variables, x, e.var_name)
+        return full if e.t is None else full[:, [e.t]]
+    if isinstance(e, StateCols):
+        return _block(opt.decision_variables, x, e.state.var_name)[:, e.lo : e.hi]
+    if isinstance(e, VarRef):
+        return _block(opt.decision_variables, x, e.var_name)
+    if isinstance(e, LinkFunction):
+        q = evaluate(e.q, opt, x, p)
+        if e.what == "position":
+            return np.asarray(e.robot.get_global_link_position(e.link, q)).reshape(3, -1)
+        if e.what == "quaternion":
+            return np.asarray(e.robot.get_global_link_quaternion(e.link, q)).reshape(4, -1)
+        return np.asarray(e.robot.get_global_link_rotation(e.link, q.reshape(-1)))
+    if isinstance(e, PathInFrame):
+        return evaluate(e.origin, opt, x, p).reshape(3, 1) + evaluate(e.rotation, opt, x, p) @ e.local
+    if isinstance(e, IntegrationResidual):
+        X = evaluate(e.x, opt, x, p)
+        Xd = evaluate(e.xd, opt, x, p)[:, : e.n]
+        return X[:, :-1][:, : e.n] + e.dt[None, :] * Xd - X[:, 1:][:, : e.n]
+    if isinstance(e, Sub):
+        return evaluate(e.a, opt, x, p) - evaluate(e.b, opt, x, p)
+    if isinstance(e, Add):
+        return evaluate(e.a, opt, x, p) + evaluate(e.b, opt, x, p)
+    if isinstance(e, Scale):
+        return e.w * evaluate(e.a, opt, x, p)
+    if isinstance(e, SumSqr):
+        v = evaluate(e.a, opt, x, p)
+        return np.array([[float(np.sum(v * v))]])
+    raise NotImplementedError(f"cannot evaluate {type(e).__name__}")

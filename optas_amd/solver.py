@@ -87,6 +87,49 @@ class Solver(ABC):
     def number_of_iterations(self) -> int:
         pass
 
+    # ---- diagnostics (solver.py:167-237, 269-314), evaluated by optas_amd.evaluate (FK through liboptas_hip) ----
+    def evaluate_cost_terms(self, x: Dict[str, np.ndarray], p: Dict[str, np.ndarray]) -> List:
+        """Value of each cost term at (x, p), in cost_terms order (solver.py:282-314)."""
+        from .evaluate import evaluate
+
+        xv = self.opt.decision_variables.dict2vec(x)
+        pv = self.opt.parameters.dict2vec(p)
+        return [float(evaluate(term, self.opt, xv, pv).reshape(-1)[0]) for term in self.opt.cost_terms.values()]
+
+    def evaluate_cost(self, x: Dict[str, np.ndarray], p: Dict[str, np.ndarray]) -> float:
+        """f(x, p) = sum of the cost terms (solver.py:269-280; optimization.py:192-195)."""
+        return float(sum(self.evaluate_cost_terms(x, p)))
+
+    def violated_constraints(self, x: Dict[str, np.ndarray], p: Dict[str, np.ndarray]):
+        """Per constraint block: (label, ctype, diff, pattern) with diff = rhs - lhs evaluated at (x, p) and
+        pattern = diff >= 0, in the reference's order lin_eq, eq, lin_ineq, ineq (solver.py:167-237 -- including its
+        quirk that the pattern marks the *satisfied* rows)."""
+        from dataclasses import dataclass
+
+        from .evaluate import evaluate
+
+        @dataclass
+        class ViolatedConstraint:
+            label: str
+            ctype: str
+            diff: np.ndarray
+            pattern: np.ndarray
+
+            def __str__(self):
+                return f"\n{self.label} [{self.ctype}]:\n{self.pattern}\n"
+
+        xv = self.opt.decision_variables.dict2vec(x)
+        pv = self.opt.parameters.dict2vec(p)
+        out = []
+        for ctype, cont in (("lin_eq", self.opt.lin_eq_constraints), ("eq", self.opt.eq_constraints),
+                            ("lin_ineq", self.opt.lin_ineq_constraints), ("ineq", self.opt.ineq_constraints)):
+            lst = []
+            for label, term in cont.items():
+                diff = evaluate(term, self.opt, xv, pv)
+                lst.append(ViolatedConstraint(label, ctype, diff, diff >= 0.0))
+            out.append(lst)
+        return tuple(out)
+
     @staticmethod
     def interpolate(traj, T: float, **interp_args):
         """solver.py:239-251."""

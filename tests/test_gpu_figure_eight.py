@@ -70,6 +70,23 @@ def test_reference_script_flow(solver, nlp, golden_nlp):
     assert np.allclose(plan(0.0), QC0)
 
 
+def test_diagnostics(solver, nlp):
+    """evaluate_cost[_terms] / violated_constraints (solver.py:167-237, 269-314): FK inside the terms runs through oh_fk_jac."""
+    kuka, s = solver
+    name = kuka.get_name()
+    s.reset_parameters({"qc": QC0})
+    s.reset_initial_seed({f"{name}/q/x": np.tile(QC0.reshape(-1, 1), (1, 50))})
+    sol = s.solve()
+    x = s.opt.decision_variables.dict2vec(sol)
+    terms = s.evaluate_cost_terms(sol, {"qc": QC0})
+    assert len(terms) == 2 and abs(sum(terms) - s.stats()["f"][0]) < 1e-10 and abs(s.evaluate_cost(sol, {"qc": QC0}) - nlp.f(x, QC0)) < 1e-10
+    lin_eq, eq, lin_ineq, ineq = s.violated_constraints(sol, {"qc": QC0})
+    assert lin_ineq == [] and ineq == [] and [v.label for v in eq] == ["no_eff_rot"]
+    a = np.concatenate([v.diff.T.reshape(-1) for v in lin_eq])
+    assert np.abs(a - nlp.a(x, QC0)).max() < 1e-13 and np.abs(a).max() < 1e-12
+    assert np.abs(eq[0].diff.T.reshape(-1) - nlp.h(x, QC0)).max() < 1e-12 and np.abs(eq[0].diff).max() < 1e-9
+
+
 def test_multipliers_in_reference_form(solver, nlp):
     kuka, s = solver
     s.reset_parameters({"qc": QC0})

@@ -80,3 +80,41 @@ def test_builder_counts_and_lowering():
     # parameter vector layout = the oracle's
     p = o.parameters.dict2vec({"curr": [0.1, 0.2], "dcurr": [0.3, 0.4], "goal": np.arange(40.0).reshape(2, 20), "obs": -np.arange(40.0).reshape(2, 20)})
     assert np.array_equal(p, PointMassMPCNLP.pack_p([0.1, 0.2], [0.3, 0.4], np.arange(40.0).reshape(2, 20), -np.arange(40.0).reshape(2, 20)))
+
+
+def test_diagnostics_match_oracle_rows():
+    """Solver.evaluate_cost / violated_constraints (solver.py:167-237, 269-314) on the mirror builder reproduce the
+    oracle's f, k, g, a in the reference's row order (no FK in this problem, so this runs without a GPU)."""
+    from examples.point_mass_mpc import Controller
+    from optas_amd.solver import Solver
+
+    class Probe(Solver):
+        def setup(self):
+            return self
+
+        def _solve(self):
+            return None
+
+        def stats(self):
+            return None
+
+        def did_solve(self):
+            return True
+
+        def number_of_iterations(self):
+            return 0
+
+    o = Controller(build_only=True).optimization
+    s = Probe(o)
+    nlp = PointMassMPCNLP()
+    p = point_mass_tick_parameters()
+    x = np.random.default_rng(1).uniform(-1, 1, 80)
+    xd, pd = o.decision_variables.vec2dict(x), o.parameters.vec2dict(p)
+    assert abs(s.evaluate_cost(xd, pd) - nlp.f(x, p)) < 1e-13
+    assert len(s.evaluate_cost_terms(xd, pd)) == 2
+    lin_eq, eq, lin_ineq, ineq = s.violated_constraints(xd, pd)
+    cat = lambda lst: np.concatenate([v.diff.T.reshape(-1) for v in lst])
+    assert np.abs(cat(lin_ineq) - nlp.k(x, p)).max() < 1e-14 and np.abs(cat(ineq) - nlp.g(x, p)).max() < 1e-14
+    assert np.abs(cat(lin_eq) - nlp.a(x, p)).max() < 1e-14 and eq == []
+    assert [v.label for v in ineq] == [f"obs_avoid_{i}" for i in range(20)] and ineq[0].ctype == "ineq"
+    assert np.array_equal(lin_ineq[0].pattern, lin_ineq[0].diff >= 0.0)

@@ -120,7 +120,9 @@ typedef struct oh_problem_desc {
   double w_path; /* 1000.0 in figure_eight_plan.py:99 */
   double w_vel;  /* 0.01   in figure_eight_plan.py:103 */
   const double* local_path; /* T x 3 row-major, path in the end-effector frame at qc (:90-96) */
-  int lock_orientation;     /* 1: h = quat_c - quat(q_t) rows present (:105-107) */
+  int lock_orientation;     /* 1: h = quat_c - quat(q_t) rows present (:105-107); 0: position-only tracking (dual_arm.py) */
+  int fix_dq0;              /* 1: fix_configuration(time_deriv=1) present, dq_0 = 0 (:65-67); 0: dq_0 free (dual_arm.py:41-42) */
+  int path_in_frame;        /* 1: path_t = p(qc) + R(qc) local_path[t] (:94-96); 0: path_t = p(qc) + local_path[t] (dual_arm.py:82-113) */
   /* solver options (the reference passes an options dict to nlpsol, solver.py:333,382) */
   int max_iter;       /* <=0: default 200 */
   double tol;         /* KKT stationarity (inf-norm of the reduced gradient); <=0: default 1e-6 */

@@ -68,6 +68,8 @@ class oh_problem_desc(C.Structure):
         ("w_vel", C.c_double),
         ("local_path", C.POINTER(C.c_double)),
         ("lock_orientation", C.c_int),
+        ("fix_dq0", C.c_int),
+        ("path_in_frame", C.c_int),
         ("max_iter", C.c_int),
         ("tol", C.c_double),
         ("tol_feas", C.c_double),

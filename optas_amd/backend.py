@@ -101,6 +101,9 @@ class FigureEightBackend:
         tol_feas: float = 1e-9,
         hessian: int = _lib.OH_HESSIAN_GAUSS_NEWTON,
         mu0: float = 0.0,
+        lock_orientation: bool = True,
+        fix_dq0: bool = True,
+        path_in_frame: bool = True,
     ):
         lib = _lib.load()
         self.T, self.ndof = int(T), int(chain.ndof)
@@ -116,7 +119,9 @@ class FigureEightBackend:
             w_path=float(w_path),
             w_vel=float(w_vel),
             local_path=lp.ctypes.data_as(C.POINTER(C.c_double)),
-            lock_orientation=1,
+            lock_orientation=1 if lock_orientation else 0,
+            fix_dq0=1 if fix_dq0 else 0,
+            path_in_frame=1 if path_in_frame else 0,
             max_iter=int(max_iter),
             tol=float(tol),
             tol_feas=float(tol_feas),

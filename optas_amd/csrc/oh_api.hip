@@ -362,6 +362,9 @@ static void fill_params(oh_handle* h) {
   FigParams& P = h->P;
   const oh_problem_desc& d = h->desc;
   P.T = d.T;
+  P.t0 = d.fix_dq0 ? 2 : 1;
+  P.lock = d.lock_orientation;
+  P.path_in_frame = d.path_in_frame;
   P.nx = d.ndof * d.T + d.ndof * (d.T - 1);
   P.dt = d.dt;
   P.w_path = d.w_path;
@@ -419,7 +422,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   // compaction re-evaluates the survivors once.  The batch is compacted whenever at least half of it has
   // finished, so the slow tail keeps running in full wavefronts.
   const int hard_cap = 2 * h->desc.max_iter + 2 + 40;  // a rejected step costs two launches
-  const bool tail_ok = (h->desc.T - 2 <= 64) && h->tail_threshold > 0;
+  const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation;
   bool tail_done = false;
   if (tail_ok && B <= h->tail_threshold) {  // small batch: the whole solve is one persistent launch
     oh_launch_tail(s, N, h->P, h->D, 0);

@@ -68,7 +68,8 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
   e[0] = p[0] + tv[0]; e[1] = p[1] + tv[1]; e[2] = p[2] + tv[2];
   const double l[3] = {P.local_path[3 * t], P.local_path[3 * t + 1], P.local_path[3 * t + 2]};
   double r[3];
-  mv3(Rc, l, r);
+  if (P.path_in_frame) mv3(Rc, l, r);
+  else { r[0] = l[0]; r[1] = l[1]; r[2] = l[2]; }
   r[0] += pc[0] - e[0]; r[1] += pc[1] - e[1]; r[2] += pc[2] - e[2];
   const double w = P.w_path;
   phi = w * dot3(r, r);

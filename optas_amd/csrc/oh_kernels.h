@@ -7,6 +7,9 @@
 // Scalar parameters of the figure-eight family (passed by value to every kernel -> SGPRs).
 struct FigParams {
   int T;
+  int t0;            // first free knot: 2 when q_0 and dq_0 are fixed (q_1 = q_0), 1 when only q_0 is fixed
+  int lock;          // 1: orientation rows R(q_t) = R(qc) present (null-space dimension N-3), 0: position-only tracking
+  int path_in_frame; // 1: path_t = p(qc) + R(qc) local_t, 0: path_t = p(qc) + local_t
   int nx;            // ndof*T + ndof*(T-1)
   double dt;
   double w_path;

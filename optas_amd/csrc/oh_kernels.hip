@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
   for (int i = 0; i < 9; ++i) D.ref[(size_t)(3 + i) * Bp + b] = Re[i];
   // constant cost of the fixed knots t=0,1 (q_0 = q_1 = qc): w * ||Rc local_t||^2
   double fconst = 0.0;
-  for (int tt = 0; tt < 2 && tt < P.T; ++tt) {
+  for (int tt = 0; tt < P.t0 && tt < P.T; ++tt) {
     double l[3] = {P.local_path[3 * tt], P.local_path[3 * tt + 1], P.local_path[3 * tt + 2]};
     fconst += P.w_path * dot3(l, l);  // Rc orthonormal
   }
@@ -249,9 +249,9 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
   for (int tt = 0; tt < P.T; ++tt) {
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const double v = (tt < 2) ? qc[j] : x0[(size_t)b * P.nx + (size_t)tt * N + j];
+      const double v = (tt < P.t0) ? qc[j] : x0[(size_t)b * P.nx + (size_t)tt * N + j];
       D.q[0][IDX(tt, N, j)] = v;
-      D.q[1][IDX(tt, N, j)] = (tt < 2) ? qc[j] : 0.0;
+      D.q[1][IDX(tt, N, j)] = (tt < P.t0) ? qc[j] : 0.0;
     }
   }
   D.cur[b] = 1;  // trial slot of launch 0 is slot 0
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D, const i
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y + 2;
+  const int t = blockIdx.y + P.t0;
   const int Bp = D.Bp;
   if (b >= D.B) return;
   if (D.status[b] >= 0 || D.skip[b]) return;
@@ -336,7 +336,7 @@ template <int N>
 __global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const int slot) {
   constexpr int NZ = N - 3;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y + 2;
+  const int t = blockIdx.y + P.t0;
   const int Bp = D.Bp;
   if (b >= D.B) return;
   if (D.status[b] >= 0 || D.skip[b]) return;
@@ -390,7 +390,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   {
     double f = D.fconst[b];
     double feas = 0.0;
-    for (int t = 2; t < T; ++t) {
+    for (int t = P.t0; t < T; ++t) {
       f += D.merit[ts][(size_t)t * Bp + b];
       feas = fmax(feas, D.cv[ts][(size_t)t * Bp + b]);
     }
@@ -438,7 +438,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     }
     // prefetch registers for knot T-2
     double nE[NZ * NZ], nH[NP], ng[NZ];
-    if (T - 2 >= 2) {
+    if (T - 2 >= P.t0) {
       const int t = T - 2;
 #pragma unroll
       for (int i = 0; i < NZ * NZ; ++i) nE[i] = Ec[IDX(t, NZ * NZ, i)];
@@ -447,7 +447,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
 #pragma unroll
       for (int a = 0; a < NZ; ++a) ng[a] = gtc[IDX(t, NZ, a)];
     }
-    for (int t = T - 2; t >= 2; --t) {
+    for (int t = T - 2; t >= P.t0; --t) {
       double E[NZ * NZ], Ht[NP], gt[NZ];
 #pragma unroll
       for (int i = 0; i < NZ * NZ; ++i) E[i] = nE[i];
@@ -455,7 +455,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       for (int i = 0; i < NP; ++i) Ht[i] = nH[i];
 #pragma unroll
       for (int a = 0; a < NZ; ++a) gt[a] = ng[a];
-      if (t > 2) {  // issue the next knot's loads before the dependent arithmetic of this one
+      if (t > P.t0) {  // issue the next knot's loads before the dependent arithmetic of this one
         const int tn = t - 1;
 #pragma unroll
         for (int i = 0; i < NZ * NZ; ++i) nE[i] = Ec[IDX(tn, NZ * NZ, i)];
@@ -505,8 +505,8 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     fsub_rcp<NZ>(S, rd, zz);
     bsub_rcp<NZ>(S, rd, zz);
     double gd = 0.0, z2 = 0.0;
-    for (int t = 2; t < T; ++t) {
-      if (t > 2) {
+    for (int t = P.t0; t < T; ++t) {
+      if (t > P.t0) {
         double zn[NZ];
 #pragma unroll
         for (int a = 0; a < NZ; ++a) {
@@ -575,8 +575,8 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
   if (b >= D.B) return;
   if (D.status[b] >= 0) return;
   const int T = P.T;
-  const int nK = T - 2;  // free knots, lanes 0..nK-1
-  const int t = lane + 2;
+  const int nK = T - P.t0;  // free knots, lanes 0..nK-1
+  const int t = lane + P.t0;
   const bool active = lane < nK;
   const int tl = active ? t : T - 1;  // clamp addresses of idle lanes
   const bool last = (t == T - 1);
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     qt[j] = D.q[slot][IDX(tl, N, j)];
-    qfix[j] = D.q[slot][IDX(1, N, j)];
+    qfix[j] = D.q[slot][IDX(P.t0 - 1, N, j)];
   }
   double Rc[9], pc[3];
 #pragma unroll
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
 template <int N>
 OH_DEV void knot_multipliers(const FigParams& P, const FigBuffers& D, const int b, const int t, const int cur, double* out) {
   const int Bp = D.Bp;
-  if (t < 2) {  // knots fixed by the linear rows: the quaternion rows are redundant there, multiplier 0
+  if (t < P.t0) {  // knots fixed by the linear rows: the quaternion rows are redundant there, multiplier 0
     out[0] = out[1] = out[2] = out[3] = 0.0;
     return;
   }
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
   for (int j = 0; j < N; ++j) {
     const double v = tq[IDX(t, N, j)];
     D.q[slot][IDX(t, N, j)] = v;
-    if (t < 2) D.q[1 - slot][IDX(t, N, j)] = v;
+    if (t < P.t0) D.q[1 - slot][IDX(t, N, j)] = v;
     if (P.hessian == OH_HESSIAN_EXACT) D.Gfull[1 - slot][IDX(t, N, j)] = D.g[1][IDX(t, N, j)];
   }
   if (t == 0) {
@@ -994,11 +994,11 @@ static void launch_setup_t(hipStream_t s, const FigParams& P, const FigBuffers& 
 }
 template <int N>
 static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
-  hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D, slot);
+  hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
 }
 template <int N>
 static void launch_couple_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
-  hipLaunchKernelGGL(k_couple<N>, dim3((D.B + 255) / 256, P.T - 2), dim3(256), 0, s, P, D, slot);
+  hipLaunchKernelGGL(k_couple<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
 }
 template <int N>
 static void launch_step_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {

@@ -1,0 +1,79 @@
+"""The reference's example/dual_arm.py DualKukaPlanner.setup_solver (lines 17-129) written against optas_amd: the same
+builder calls in the same order.  The CasADi loop that assembles the piecewise-linear path (:96-113) is evaluated on
+numpy offsets and added to the symbolic start position."""
+import numpy as np
+
+import optas_amd
+from optas_amd.builder import OptimizationBuilder
+from optas_amd.expr import sumsqr
+from optas_amd.solver import HIPSolver
+
+kukal_base_position = [0.0, -0.25, 0.0]
+kukar_base_position = [0.0, 0.25, 0.0]
+
+
+def _setup_kuka_model(name, base_position):
+    model = optas_amd.RobotModel.builtin("kuka_lwr", time_derivs=[0, 1], name=name)
+    model.add_base_frame("global_world", xyz=base_position)
+    return model
+
+
+def path_offsets(T, d1, d2):
+    off = np.zeros((3, T))
+    for i in range(T):
+        alpha_ = float(i) / float(T - 1)
+        if alpha_ < 0.4:
+            off[:, i] = (alpha_ / 0.4) * np.asarray(d1)
+        elif 0.4 <= alpha_ < 0.5:
+            off[:, i] = d1
+        else:
+            off[:, i] = np.asarray(d1) + ((alpha_ - 0.5) / 0.5) * np.asarray(d2)
+    return off
+
+
+def setup_solver(T=50, Tmax=10.0, solver_options=None, build_only=False):
+    link_ee = "end_effector_ball"
+    t = np.linspace(0, Tmax, T)
+    dt = float(t[1] - t[0])
+    kukal = _setup_kuka_model("kukal", kukal_base_position)
+    kukar = _setup_kuka_model("kukar", kukar_base_position)
+    kukal_name, kukar_name = kukal.get_name(), kukar.get_name()
+    builder = OptimizationBuilder(T=T, robots=[kukal, kukar])
+    qcl = builder.add_parameter("qcl", kukal.ndof)
+    qcr = builder.add_parameter("qcr", kukar.ndof)
+    builder.fix_configuration(kukal_name, qcl)
+    builder.fix_configuration(kukar_name, qcr)
+    builder.integrate_model_states(kukal_name, time_deriv=1, dt=dt)
+    builder.integrate_model_states(kukar_name, time_deriv=1, dt=dt)
+    Ql, Qr = builder.get_model_states(kukal_name), builder.get_model_states(kukar_name)
+    ee_pos_pathl = kukal.get_global_link_position(link_ee, Ql)
+    ee_pos_pathr = kukar.get_global_link_position(link_ee, Qr)
+    dQl = builder.get_model_states(kukal_name, time_deriv=1)
+    dQr = builder.get_model_states(kukar_name, time_deriv=1)
+    w_dq = 0.01
+    builder.add_cost_term("kukal_min_join_vel", w_dq * sumsqr(dQl))
+    builder.add_cost_term("kukar_min_join_vel", w_dq * sumsqr(dQr))
+    pos0l = kukal.get_global_link_position(link_ee, qcl)
+    pos0r = kukar.get_global_link_position(link_ee, qcr)
+    path_eel = pos0l + path_offsets(T, [-0.1, 0.1, -0.2], [0.0, 0.0, 0.3])
+    path_eer = pos0r + path_offsets(T, [-0.1, -0.1, -0.2], [0.0, 0.0, 0.3])
+    builder.add_cost_term("ee_pos_pathl", sumsqr(ee_pos_pathl - path_eel))
+    builder.add_cost_term("ee_pos_pathr", sumsqr(ee_pos_pathr - path_eer))
+    optimization = builder.build()
+    if build_only:
+        return (kukal, kukar), optimization
+    return (kukal, kukar), HIPSolver(optimization).setup("hip_sqp", solver_options)
+
+
+def main():
+    (kukal, kukar), solver = setup_solver()
+    qc = optas_amd.deg2rad([0, -30, 0, 90, 0, 30, 0])  # dual_arm.py:185
+    solver.reset_parameters({"qcl": qc, "qcr": qc})  # the reference never sets a seed: zeros (solver.py:76)
+    sol = solver.solve()
+    print("did_solve", solver.did_solve(), "iterations", solver.number_of_iterations(), "f", solver.stats()["f"][0])
+    print("kukal q(T-1) =", sol["kukal/q"][:, -1])
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

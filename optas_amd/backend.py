@@ -221,3 +221,47 @@ class FigureEightBackend:
             self.close()
         except Exception:
             pass
+
+
+class MultiArmBackend:
+    """Separable multi-robot problem (example/dual_arm.py): one position-only tracking handle per arm; the arms of
+    all B instances are solved as independent GPU instances and stitched back into the reference's x layout."""
+
+    def __init__(self, spec, opt, max_iter=200, tol=1e-6, hessian=_lib.OH_HESSIAN_GAUSS_NEWTON):
+        self.spec, self.opt = spec, opt
+        self.nx, self.np_ = opt.nx, opt.np
+        self.xoff = opt.decision_variables.offsets()
+        self.poff = opt.parameters.offsets()
+        self.arms = []
+        for a in spec.arms:
+            be = FigureEightBackend(
+                a.robot.kinematic_chain(a.link), spec.T, spec.dt, a.offsets, w_path=a.w_path, w_vel=a.w_vel, max_iter=max_iter, tol=tol,
+                hessian=hessian, lock_orientation=False, fix_dq0=False, path_in_frame=False,
+            )
+            self.arms.append((a, be))
+
+    def solve(self, x0: np.ndarray, p: np.ndarray) -> BatchResult:
+        x0 = _lib.as_f64(x0).reshape(-1, self.nx)
+        p = _lib.as_f64(p).reshape(-1, self.np_)
+        B = x0.shape[0]
+        x = np.empty((B, self.nx))
+        f = np.zeros(B)
+        kkt = np.zeros((B, 3))
+        iters = np.zeros(B, dtype=np.int32)
+        status = np.zeros(B, dtype=np.int32)
+        for a, be in self.arms:
+            n, T = be.ndof, be.T
+            oq, odq, op = self.xoff[a.q_name], self.xoff[a.dq_name], self.poff[a.qc_name]
+            xa = np.concatenate([x0[:, oq : oq + n * T], x0[:, odq : odq + n * (T - 1)]], axis=1)
+            r = be.solve(xa, p[:, op : op + n])
+            x[:, oq : oq + n * T] = r.x[:, : n * T]
+            x[:, odq : odq + n * (T - 1)] = r.x[:, n * T :]
+            f += r.f
+            kkt = np.maximum(kkt, r.kkt)
+            iters = np.maximum(iters, r.iters)
+            status = np.maximum(status, r.status)
+        return BatchResult(x, f, kkt, iters, status)
+
+    def close(self) -> None:
+        for _, be in self.arms:
+            be.close()

@@ -134,8 +134,6 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
     return fail(OH_ERR_INVALID, "oh_create: figure-eight kernels are instantiated for ndof 6 and 7");
   if (!(desc->dt > 0.0)) return fail(OH_ERR_INVALID, "oh_create: dt must be positive");
   if (!desc->local_path) return fail(OH_ERR_INVALID, "oh_create: local_path is null");
-  if (!desc->lock_orientation)
-    return fail(OH_ERR_INVALID, "oh_create: only the orientation-locked variant (figure_eight_plan.py:105-107) is lowered");
   if (desc->hessian != OH_HESSIAN_GAUSS_NEWTON && desc->hessian != OH_HESSIAN_EXACT)
     return fail(OH_ERR_INVALID, "oh_create: bad hessian mode");
   int ndev = 0;
@@ -282,7 +280,7 @@ static bool solver_chain_ok(const oh_chain& c) {
 
 // carve the handle's device pool for B instances
 static int ensure_capacity(oh_handle* h, int B) {
-  const int N = h->desc.ndof, NZ = N - 3, T = h->desc.T;
+  const int N = h->desc.ndof, NZ = h->desc.lock_orientation ? N - 3 : N, T = h->desc.T;
   const int Bp = (B + 63) / 64 * 64;
   if (B <= h->cap_B && h->pool) {
     h->D.B = B;
@@ -344,6 +342,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.stat = take(Bp);
   D.feas = take(Bp);
   D.lam_h = take((size_t)4 * T * Bp);
+  if (!h->desc.lock_orientation) D.lam_h = nullptr;  // no quaternion rows, no multipliers to report
   int* ip = (int*)d;
   D.cur = ip; ip += Bp;
   D.first = ip; ip += Bp;
@@ -436,13 +435,16 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     }
     rebase = false;
     const int slot = it & 1;
-    oh_launch_eval(s, N, h->P, h->D, slot);
+    if (h->P.lock) oh_launch_eval(s, N, h->P, h->D, slot);
+    else oh_launch_eval_free(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(1); }
-    oh_launch_couple(s, N, h->P, h->D, slot);
+    if (h->P.lock) oh_launch_couple(s, N, h->P, h->D, slot);
+    else oh_launch_couple_free(s, N, h->P, h->D, slot);
     const bool check = ((it + 1) % check_every == 0);
     if (check) HIPCHK(hipMemsetAsync(h->D.n_running, 0, sizeof(int), s));
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(3); }
-    oh_launch_step(s, N, h->P, h->D, slot);
+    if (h->P.lock) oh_launch_step(s, N, h->P, h->D, slot);
+    else oh_launch_step_free(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(2); }
     ++launched;
     if (check) {
@@ -566,6 +568,7 @@ extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
   if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT || B != h->last_B || B < 1)
     return fail(OH_ERR_STATE, "oh_get_multipliers: B does not match the last solve");
   HIPCHK(hipSetDevice(h->device));
+  if (!h->D.lam_h) return fail(OH_ERR_STATE, "oh_get_multipliers: this problem has no nonlinear equality rows");
   HIPCHK(hipMemcpy(lam_h, h->D.lam_h, sizeof(double) * 4 * (size_t)h->desc.T * B, hipMemcpyDeviceToHost));
   return OH_OK;
 }

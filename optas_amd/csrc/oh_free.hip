@@ -1,0 +1,311 @@
+// Position-only end-effector tracking (lock_orientation = 0): example/dual_arm.py as shipped (each arm),
+// SURVEY App. B.4.  Same state machine, buffers and launch sequence as the orientation-locked kernels in
+// oh_kernels.hip, but there are no constraint rows: the null-space basis is the identity (NZ = N), the
+// reduced Hessian block is W_t itself and every coupling block is E_t = -2 kappa I, so the Riccati recursion
+// simplifies to   S_t = H_t - (2k)^2 S_{t+1}^{-1},  r_t = g_t + 2k S_{t+1}^{-1} r_{t+1},
+//                 z_{t+1} = -S_{t+1}^{-1} r_{t+1} + 2k S_{t+1}^{-1} z_t.
+#include "oh_figure8.h"
+
+#define IDX(t, K, k) (((size_t)(t) * (K) + (k)) * Bp + b)
+
+// one knot, no retraction / null space: tracking cost, gradient, Gauss-Newton (or exact) block W (packed lower)
+template <int N>
+OH_DEV void eval_knot_free(const oh_chain* __restrict__ ch, const FigParams& P, const int t, const double (&q)[N], const double (&pc)[3],
+                           const double (&Rc)[9], double& phi, double (&g)[N], double (&W)[N * (N + 1) / 2]) {
+  double R[9], p[3], z[N][3], pj[N][3];
+  fk_chain<N>(ch, q, R, p, z, pj);
+  double e[3], tv[3];
+  mv3(R, ch->p_tool, tv);
+  e[0] = p[0] + tv[0]; e[1] = p[1] + tv[1]; e[2] = p[2] + tv[2];
+  const double l[3] = {P.local_path[3 * t], P.local_path[3 * t + 1], P.local_path[3 * t + 2]};
+  double r[3];
+  if (P.path_in_frame) mv3(Rc, l, r);
+  else { r[0] = l[0]; r[1] = l[1]; r[2] = l[2]; }
+  r[0] += pc[0] - e[0]; r[1] += pc[1] - e[1]; r[2] += pc[2] - e[2];
+  const double w = P.w_path;
+  phi = w * dot3(r, r);
+  double Jp[N][3];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (ch->jtype[k] == 0) {
+      const double d[3] = {e[0] - pj[k][0], e[1] - pj[k][1], e[2] - pj[k][2]};
+      cross3(z[k], d, Jp[k]);
+    } else {
+      Jp[k][0] = z[k][0]; Jp[k][1] = z[k][1]; Jp[k][2] = z[k][2];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) g[k] = -2.0 * w * dot3(Jp[k], r);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) W[tri(i, j)] = 2.0 * w * dot3(Jp[i], Jp[j]);
+  if (P.hessian == OH_HESSIAN_EXACT) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (ch->jtype[j] == 0) {
+        double rz[3];
+        cross3(r, z[j], rz);
+#pragma unroll
+        for (int i = j; i < N; ++i) W[tri(i, j)] += -2.0 * w * dot3(rz, Jp[i]);
+      }
+    }
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_eval_free(FigParams P, FigBuffers D, const int slot) {
+  constexpr int NP = N * (N + 1) / 2;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y + P.t0;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (D.status[b] >= 0 || D.skip[b]) return;
+  const int cur = 1 - slot;
+  double q[N];
+  if (D.first[b]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) q[j] = D.q[slot][IDX(t, N, j)];
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; ++j) q[j] = D.q[cur][IDX(t, N, j)] + D.zstep[IDX(t, N, j)];
+  }
+  double Rc[9], pc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pc[i] = D.ref[(size_t)i * Bp + b];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
+  double phi, g[N], W[NP];
+  eval_knot_free<N>(D.chain, P, t, q, pc, Rc, phi, g, W);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    D.q[slot][IDX(t, N, j)] = q[j];
+    D.g[slot][IDX(t, N, j)] = g[j];
+  }
+  D.phi[slot][(size_t)t * Bp + b] = phi;
+  D.cv[slot][(size_t)t * Bp + b] = 0.0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) D.Dr[slot][IDX(t, NP, i)] = W[i];
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_couple_free(FigParams P, FigBuffers D, const int slot) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y + P.t0;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (D.status[b] >= 0 || D.skip[b]) return;
+  const double* __restrict__ qs = D.q[slot];
+  const double kap2 = 2.0 * P.kappa;
+  const bool last = (t == P.T - 1);
+  double sm = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double qm = qs[IDX(t - 1, N, k)];
+    const double q0 = qs[IDX(t, N, k)];
+    const double dm = q0 - qm;
+    sm += dm * dm;
+    double G = D.g[slot][IDX(t, N, k)] + kap2 * dm;
+    if (!last) G -= kap2 * (qs[IDX(t + 1, N, k)] - q0);
+    D.gt[slot][IDX(t, N, k)] = G;
+  }
+  D.merit[slot][(size_t)t * Bp + b] = D.phi[slot][(size_t)t * Bp + b] + P.kappa * sm;
+}
+
+// S^{-1} (packed lower) from the packed Cholesky factor L and reciprocal pivots: Li = L^{-1}, Sinv = Li^T Li
+template <int M>
+OH_DEV void spd_inverse(const double (&L)[M * (M + 1) / 2], const double (&rd)[M], double (&Sinv)[M * (M + 1) / 2]) {
+  double Li[M * (M + 1) / 2];
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    Li[tri(j, j)] = rd[j];
+#pragma unroll
+    for (int i = j + 1; i < M; ++i) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = j; k < i; ++k) v -= L[tri(i, k)] * Li[tri(k, j)];
+      Li[tri(i, j)] = v * rd[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = i; k < M; ++k) v += Li[tri(k, i)] * Li[tri(k, j)];
+      Sinv[tri(i, j)] = v;
+    }
+}
+template <int M>
+OH_DEV void symv(const double (&A)[M * (M + 1) / 2], const double (&x)[M], double (&y)[M]) {
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) v += A[(i >= k) ? tri(i, k) : tri(k, i)] * x[k];
+    y[i] = v;
+  }
+}
+
+template <int N>
+OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const int b, const int ts) {
+  constexpr int NP = N * (N + 1) / 2;
+  const int Bp = D.Bp;
+  const int T = P.T;
+  const double kap2 = 2.0 * P.kappa;
+  int cur = 1 - ts;
+  LMState lm{D.mu[b], D.nun[b]};
+  const int iters = D.iters[b];
+  {
+    double f = D.fconst[b];
+    for (int t = P.t0; t < T; ++t) f += D.merit[ts][(size_t)t * Bp + b];
+    bool accept;
+    if (D.first[b]) {
+      accept = true;
+      D.first[b] = 0;
+    } else {
+      accept = lm_accept(P, f, 0.0, D.f_cur[b], D.pred[b], lm);
+      D.nun[b] = lm.nun;
+    }
+    if (accept) {
+      cur = ts;
+      D.f_cur[b] = f;
+      D.feas[b] = 0.0;
+    }
+    D.cur[b] = cur;
+    if (!accept) {
+      D.skip[b] = 1;
+      atomicAdd(D.work + 1, 1ULL);
+    }
+  }
+  double mu = lm.mu;
+  const double* __restrict__ Drc = D.Dr[cur];
+  const double* __restrict__ gtc = D.gt[cur];
+  double stat = 0.0;
+  double S[NP], rd[N], rn[N];
+  for (int attempt = 0; attempt < 40; ++attempt) {
+    bool ok = true;
+    stat = 0.0;
+    {
+      const int t = T - 1;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) S[i] = Drc[IDX(t, NP, i)];
+#pragma unroll
+      for (int a = 0; a < N; ++a) {
+        S[tri(a, a)] += kap2 + mu;
+        rn[a] = gtc[IDX(t, N, a)];
+        stat = fmax(stat, fabs(rn[a]));
+      }
+    }
+    for (int t = T - 2; t >= P.t0; --t) {
+      double Ht[NP], gt[N];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Ht[i] = Drc[IDX(t, NP, i)];
+#pragma unroll
+      for (int a = 0; a < N; ++a) {
+        gt[a] = gtc[IDX(t, N, a)];
+        stat = fmax(stat, fabs(gt[a]));
+        Ht[tri(a, a)] += 2.0 * kap2 + mu;
+      }
+      ok = chol_rcp<N>(S, rd, 1e-12) && ok;
+      double Sinv[NP], wv[N];
+      spd_inverse<N>(S, rd, Sinv);
+      symv<N>(Sinv, rn, wv);  // S_{t+1}^{-1} r_{t+1}
+#pragma unroll
+      for (int i = 0; i < NP; ++i) D.Kmat[IDX(t + 1, N * N, i)] = Sinv[i];
+#pragma unroll
+      for (int a = 0; a < N; ++a) {
+        D.kvec[IDX(t + 1, N, a)] = wv[a];
+        rn[a] = gt[a] + kap2 * wv[a];
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) S[i] = Ht[i] - kap2 * kap2 * Sinv[i];
+    }
+    ok = chol_rcp<N>(S, rd, 1e-12) && ok;
+    if (ok) break;
+    mu = fmax(4.0 * mu, 1e-2);
+  }
+  D.stat[b] = stat;
+  if (stat <= P.tol) {
+    D.status[b] = OH_STATUS_CONVERGED;
+    D.mu[b] = mu;
+    return false;
+  }
+  if (iters >= P.max_iter) {
+    D.status[b] = OH_STATUS_MAX_ITER;
+    D.mu[b] = mu;
+    return false;
+  }
+  if (!(stat == stat)) {
+    D.status[b] = OH_STATUS_NUMERICAL;
+    return false;
+  }
+  {
+    double zz[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a) zz[a] = -rn[a];
+    fsub_rcp<N>(S, rd, zz);
+    bsub_rcp<N>(S, rd, zz);
+    double gd = 0.0, z2 = 0.0;
+    for (int t = P.t0; t < T; ++t) {
+      if (t > P.t0) {
+        double Sinv[NP], y[N];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) Sinv[i] = D.Kmat[IDX(t, N * N, i)];
+        symv<N>(Sinv, zz, y);
+#pragma unroll
+        for (int a = 0; a < N; ++a) zz[a] = kap2 * y[a] - D.kvec[IDX(t, N, a)];
+      }
+#pragma unroll
+      for (int a = 0; a < N; ++a) {
+        D.zstep[IDX(t, N, a)] = zz[a];
+        gd += gtc[IDX(t, N, a)] * zz[a];
+        z2 += zz[a] * zz[a];
+      }
+    }
+    D.pred[b] = -0.5 * gd + 0.5 * mu * z2;
+  }
+  D.mu[b] = mu;
+  D.iters[b] = iters + 1;
+  return true;
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_step_free(FigParams P, FigBuffers D, const int slot) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool alive = (b < D.B) && (D.status[b] < 0);
+  const bool skipping = alive && D.skip[b];
+  const bool running = alive && !skipping;
+  {
+    const unsigned long long m = __ballot(running);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(D.work, (unsigned long long)__popcll(m));
+  }
+  bool still = skipping;
+  if (skipping) D.skip[b] = 0;
+  if (running) still = step_instance_free<N>(P, D, b, slot);
+  const unsigned long long m2 = __ballot(still);
+  if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
+}
+
+bool oh_launch_eval_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
+  const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
+  if (n == 7) hipLaunchKernelGGL(k_eval_free<7>, g, b, 0, s, P, D, slot);
+  else if (n == 6) hipLaunchKernelGGL(k_eval_free<6>, g, b, 0, s, P, D, slot);
+  else return false;
+  return true;
+}
+bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
+  const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
+  if (n == 7) hipLaunchKernelGGL(k_couple_free<7>, g, b, 0, s, P, D, slot);
+  else if (n == 6) hipLaunchKernelGGL(k_couple_free<6>, g, b, 0, s, P, D, slot);
+  else return false;
+  return true;
+}
+bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
+  const dim3 g((D.B + 63) / 64), b(64);
+  if (n == 7) hipLaunchKernelGGL(k_step_free<7>, g, b, 0, s, P, D, slot);
+  else if (n == 6) hipLaunchKernelGGL(k_step_free<6>, g, b, 0, s, P, D, slot);
+  else return false;
+  return true;
+}

@@ -69,6 +69,9 @@ bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers&
 bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_launch_eval_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_tail(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
                         int* iters, int* status);

@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from .builder import IntegrationResidual
-from .expr import Const, LinkFunction, ParamCol, ParamRef, PathInFrame, Scale, StateCols, StateRef, Sub, SumSqr
+from .expr import Add, Const, LinkFunction, ParamCol, ParamRef, PathInFrame, Scale, StateCols, StateRef, Sub, SumSqr
 from .models import RobotModel, TaskModel
 from .optimization import Optimization
 
@@ -264,10 +264,103 @@ def match_point_mass(opt: Optimization) -> PointMassSpec:
     return PointMassSpec(T, dt, w_acc, lim[(0, "r")], lim[(1, "r")], float(np.sqrt(safe_sq)), names, y_name, dy_name)
 
 
+@dataclass
+class ArmSpec:
+    robot: RobotModel
+    link: str
+    w_path: float
+    w_vel: float
+    offsets: np.ndarray  # (T, 3): path_t = p(qc) + offsets[t]
+    qc_name: str
+    q_name: str
+    dq_name: str
+
+
+@dataclass
+class MultiArmSpec:
+    """Separable sum of position-only end-effector tracking problems, one per robot (example/dual_arm.py:17-129)."""
+
+    T: int
+    dt: float
+    arms: list
+
+
+def match_multi_arm(opt: Optimization) -> MultiArmSpec:
+    def no(msg):
+        raise LoweringError(f"multi-arm lowering: {msg}")
+
+    robots = [m for m in (opt.models or []) if isinstance(m, RobotModel)]
+    if not robots or len(robots) != len(opt.models or []):
+        no("expected robot models only")
+    if opt.nk or opt.ng or opt.nh:
+        no("inequality rows / nonlinear equalities are not lowered for this family")
+    for r in robots:
+        if list(r.time_derivs) != [0, 1] or r.num_param_joints != 0:
+            no("every robot must have time_derivs=[0, 1] and no parameterised joints")
+    names = []
+    for r in robots:
+        names += [r.state_optimized_name(0), r.state_optimized_name(1)]
+    if list(opt.decision_variables.keys()) != names:
+        no("decision variables must be exactly the q/dq blocks of the robots")
+    T = opt.decision_variables[names[0]].n
+    arms = {}
+    for r in robots:
+        Q, dQ = opt.decision_variables[r.state_optimized_name(0)], opt.decision_variables[r.state_optimized_name(1)]
+        if Q.n != T or dQ.n != T - 1:
+            no("all robots must share T and use derivs_align=False")
+        arms[r.get_name()] = {"robot": r, "Q": Q, "dQ": dQ}
+    dt = None
+    for label, diff in opt.lin_eq_constraints.items():
+        if not isinstance(diff, Sub):
+            no(f"linear equality '{label}' not recognised")
+        rhs, lhs = diff.a, diff.b
+        if isinstance(lhs, StateRef) and lhs.t == 0 and lhs.time_deriv == 0 and isinstance(rhs, ParamRef) and lhs.model_name in arms:
+            arms[lhs.model_name]["qc"] = rhs
+        elif isinstance(lhs, IntegrationResidual) and _is_zero_const(rhs) and lhs.xd.time_deriv == 1 and lhs.x.model_name in arms:
+            if not np.all(lhs.dt == lhs.dt[0]) or (dt is not None and float(lhs.dt[0]) != dt):
+                no("non-uniform dt is not lowered")
+            dt = float(lhs.dt[0])
+            arms[lhs.x.model_name]["integr"] = True
+        else:
+            no(f"linear equality '{label}' not recognised (dq_0 must be free in this family)")
+    for label, term in opt.cost_terms.items():
+        w, e = _unscale(term)
+        if not isinstance(e, SumSqr):
+            no(f"cost '{label}' is not a weighted sumsqr")
+        inner = e.a
+        hit = False
+        for a in arms.values():
+            if inner is a["dQ"]:
+                a["w_vel"], hit = w, True
+            elif isinstance(inner, Sub):
+                for pos, pth, sgn in ((inner.a, inner.b, 1), (inner.b, inner.a, 1)):
+                    if (isinstance(pos, LinkFunction) and pos.what == "position" and pos.q is a["Q"] and pos.robot is a["robot"]
+                            and isinstance(pth, Add) and isinstance(pth.a, LinkFunction) and pth.a.what == "position" and pth.a.link == pos.link
+                            and pth.a.robot is a["robot"] and isinstance(pth.a.q, ParamRef) and isinstance(pth.b, Const) and pth.b.value.shape == (3, T)):
+                        a["w_path"], a["link"], a["offsets"], a["qc_path"], hit = w, pos.link, np.ascontiguousarray(pth.b.value.T), pth.a.q, True
+        if not hit:
+            no(f"cost '{label}' not recognised")
+    out = []
+    for name, a in arms.items():
+        need = {"qc", "integr", "w_vel", "w_path"}
+        if not need <= set(a):
+            no(f"robot '{name}' is missing {sorted(need - set(a))}")
+        if a["qc_path"] is not a["qc"]:
+            no(f"robot '{name}': the path must start from the fixed initial configuration parameter")
+        out.append(ArmSpec(a["robot"], a["link"], a["w_path"], a["w_vel"], a["offsets"], a["qc"].name, a["Q"].var_name, a["dQ"].var_name))
+    params = [k for k, v in opt.parameters.items() if v.numel() > 0]
+    if sorted(params) != sorted(a.qc_name for a in out):
+        no("the only non-empty parameters must be the initial configurations")
+    return MultiArmSpec(T, dt, out)
+
+
+OH_KIND_MULTI_ARM = 101  # host-side composition of OH_PROBLEM_FIGURE_EIGHT handles with lock_orientation = 0
+
+
 def lower(opt: Optimization):
     """Return (kind, spec).  Raises LoweringError if no kernel family matches."""
     errors = []
-    for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass)):
+    for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass), (OH_KIND_MULTI_ARM, match_multi_arm)):
         try:
             return kind, fn(opt)
         except LoweringError as e:

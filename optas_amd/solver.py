@@ -16,8 +16,8 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import _lib
-from .backend import BatchResult, FigureEightBackend, PointMassBackend
-from .lowering import FigureEightSpec, PointMassSpec, lower
+from .backend import BatchResult, FigureEightBackend, MultiArmBackend, PointMassBackend
+from .lowering import FigureEightSpec, MultiArmSpec, PointMassSpec, lower
 from .models import RobotModel
 from .optimization import Optimization
 
@@ -174,6 +174,9 @@ class HIPSolver(Solver):
             self._backend = PointMassBackend(
                 spec.T, spec.dt, spec.w_acc, spec.ylim, spec.vlim, spec.safe, max_iter=int(o.pop("max_iter", 100)), tol=float(o.pop("tol", 1e-8))
             )
+        elif isinstance(spec, MultiArmSpec):
+            o.pop("hessian", None)
+            self._backend = MultiArmBackend(spec, self.opt, max_iter=int(o.pop("max_iter", 200)), tol=float(o.pop("tol", 1e-6)), hessian=hessian)
         else:  # pragma: no cover
             raise NotImplementedError(kind)
         if o:

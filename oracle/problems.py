@@ -383,3 +383,98 @@ def point_mass_tick_parameters(t0=2.0, T=20, dt=0.05, curr=(-0.45, -0.35), dcurr
         obs.append([0.15 * np.sin(alpha), 0.15 * np.cos(alpha) + 0.15])
         goal.append([curr[0] + ramp * i, curr[1] + ramp * i])
     return PointMassMPCNLP.pack_p(curr, dcurr, np.array(goal).T, np.array(obs).T)
+
+
+def dual_arm_offsets(T=50):
+    """Piecewise-linear end-effector path of example/dual_arm.py:82-113 relative to pos0 = p(qc):
+    pos1 = pos0 + d1, pos2 = pos1 + d2.  Returns {'l': (3,T), 'r': (3,T)} offsets."""
+    d1 = {"l": np.array([-0.1, 0.1, -0.2]), "r": np.array([-0.1, -0.1, -0.2])}
+    d2 = np.array([0.0, 0.0, 0.3])
+    out = {}
+    for arm in ("l", "r"):
+        off = np.zeros((3, T))
+        for i in range(T):
+            a_ = float(i) / float(T - 1)
+            if a_ < 0.4:
+                off[:, i] = (a_ / 0.4) * d1[arm]
+            elif a_ < 0.5:
+                off[:, i] = d1[arm]
+            else:
+                off[:, i] = d1[arm] + ((a_ - 0.5) / 0.5) * d2
+        out[arm] = off
+    return out
+
+
+class DualArmNLP(_NLPBase):
+    """example/dual_arm.py:17-129 as shipped (BASELINE config 4 without the synthetic extensions).
+
+    Two kuka_lwr models "kukal"/"kukar" with add_base_frame("global_world", xyz=(0, -/+0.25, 0)) (:13-14, 134-141).
+    x = [vec(Ql 7xT); vec(dQl 7x(T-1)); vec(Qr); vec(dQr)]   p = [qcl(7); qcr(7)]
+    a = [qcl - ql_0; qcr - qr_0; -(ql_t + dt dql_t - ql_{t+1}); same for r]                 (:41-55)
+    f = 0.01 (sum dQl^2 + sum dQr^2) + sum ||p_l(ql_t) - path_l,t||^2 + sum ||p_r(qr_t) - path_r,t||^2   (:76-117)
+    No inequality rows, no nonlinear equalities: class NonlinearCostLinearConstraints.  The arms are separable.
+    """
+
+    def __init__(self, robot_l: OracleRobot, robot_r: OracleRobot, link="end_effector_ball", T=50, Tmax=10.0, w_dq=0.01):
+        self.robots = {"l": robot_l, "r": robot_r}
+        self.link, self.T = link, T
+        ts = np.linspace(0.0, Tmax, T)
+        self.dt = float(ts[1] - ts[0])
+        self.w_dq = w_dq
+        self.n = n = robot_l.ndof
+        self.nx1 = n * T + n * (T - 1)
+        self.nx, self.np_ = 2 * self.nx1, 2 * n
+        self.na = 2 * n + 2 * n * (T - 1)
+        self.offsets = dual_arm_offsets(T)
+        A = np.zeros((self.na, self.nx))
+        I = np.eye(n)
+        for k in range(2):
+            base = k * self.nx1
+            A[k * n : (k + 1) * n, base : base + n] = -I
+            for t in range(T - 1):
+                r = 2 * n + k * n * (T - 1) + n * t
+                A[r : r + n, base + n * t : base + n * t + n] = -I
+                A[r : r + n, base + n * T + n * t : base + n * T + n * t + n] = -self.dt * I
+                A[r : r + n, base + n * (t + 1) : base + n * (t + 1) + n] = I
+        self._A = A
+
+    def split(self, x):
+        n, T = self.n, self.T
+        out = {}
+        for k, arm in enumerate(("l", "r")):
+            xs = x[k * self.nx1 : (k + 1) * self.nx1]
+            out[arm] = (xs[: n * T].reshape(T, n).T, xs[n * T :].reshape(T - 1, n).T)
+        return out
+
+    def f(self, x, p):
+        s = self.split(x)
+        val = 0.0
+        for k, arm in enumerate(("l", "r")):
+            Q, dQ = s[arm]
+            qc = p[k * self.n : (k + 1) * self.n]
+            path = self.robots[arm].get_global_link_position(self.link, qc).reshape(3, 1) + self.offsets[arm]
+            pos = self.robots[arm].map_position(self.link, Q)
+            val += self.w_dq * np.sum(dQ**2) + np.sum((pos - path) ** 2)
+        return float(val)
+
+    def df(self, x, p):
+        s = self.split(x)
+        parts = []
+        for k, arm in enumerate(("l", "r")):
+            Q, dQ = s[arm]
+            qc = p[k * self.n : (k + 1) * self.n]
+            path = self.robots[arm].get_global_link_position(self.link, qc).reshape(3, 1) + self.offsets[arm]
+            gq = np.zeros_like(Q)
+            for t in range(self.T):
+                Jp = self.robots[arm].get_global_link_linear_jacobian(self.link, Q[:, t])
+                gq[:, t] = 2.0 * Jp.T @ (self.robots[arm].get_global_link_position(self.link, Q[:, t]) - path[:, t])
+            parts += [gq.T.reshape(-1), (2.0 * self.w_dq * dQ).T.reshape(-1)]
+        return np.concatenate(parts)
+
+    def a(self, x, p):
+        b = np.zeros(self.na)
+        b[: 2 * self.n] = p
+        return self._A @ x + b
+
+    def da(self, x, p):
+        return self._A

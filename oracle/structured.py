@@ -377,3 +377,83 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         Qt = retract(prob, Qt, Rc)
         iters += 1
     return {"Q": cur["Q"], "f": cur["f"], "iters": iters, "rejected": rejected, "stat": stat, "feas": cur["feas"], "status": status, "path": path, "Rc": Rc}
+
+
+# ----------------------------------------------------------------------------------------------------
+# Position-only tracking (dual_arm.py per arm): port of k_eval_free / k_couple_free / k_step_free.
+# ----------------------------------------------------------------------------------------------------
+def solve_free_lm(chain: FoldedChain, T, dt, offsets, qc, Q0=None, w_path=1.0, w_vel=0.01, fix_dq0=False, max_iter=300, tol=1e-6, exact=False, verbose=False):
+    """min sum_t w_path ||p(q_t) - (p(qc) + offsets_t)||^2 + (w_vel/dt^2) sum_t ||q_{t+1}-q_t||^2, q_0 = qc (and q_1 = qc if fix_dq0).
+    offsets: (T,3).  Same LM ratio test / Nielsen update / Riccati recursion as the HIP kernels."""
+    n = chain.ndof
+    t0 = 2 if fix_dq0 else 1
+    kap = w_vel / dt**2
+    e0, _, _, _ = chain.fk(qc[None])
+    path = e0[0] + offsets
+    Qc = np.zeros((T, n)) if Q0 is None else Q0.copy()
+    Qc[:t0] = qc
+    F = slice(t0, T)
+
+    def evalp(Q):
+        e, Re, Jp, Jw = chain.jac(Q)
+        r = path - e
+        phi = w_path * np.sum(r * r, 1)
+        g = -2.0 * w_path * np.einsum("tki,tk->ti", Jp, r)
+        W = 2.0 * w_path * np.einsum("tki,tkj->tij", Jp, Jp)
+        if exact:
+            zr = np.cross(r[:, None, :], np.swapaxes(Jw, 1, 2))
+            S = np.einsum("tik,tkj->tij", zr, Jp)
+            S = np.triu(S) + np.swapaxes(np.triu(S, 1), 1, 2)
+            W = W - 2.0 * w_path * S
+        d = Q[1:] - Q[:-1]
+        f = float(np.sum(phi) + kap * np.sum(d * d))
+        Gs = np.zeros_like(Q)
+        Gs[1:] += 2 * kap * d
+        Gs[:-1] -= 2 * kap * d
+        return f, g + Gs, W
+
+    mu, nun = 0.0, 2.0
+    iters = rejected = 0
+    first = True
+    Qt = Qc
+    cur = None
+    status = 1
+    while True:
+        f_t, G, W = evalp(Qt)
+        if first:
+            accept, first = True, False
+        else:
+            rho = (cur["f"] - f_t) / max(pred, 1e-300)
+            accept = np.isfinite(f_t) and (rho > 1e-4 or (pred <= 1e-15 * abs(cur["f"]) and f_t <= cur["f"] + 1e-14 * abs(cur["f"])))
+            if accept:
+                mu *= max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)
+                mu = 0.0 if mu < 1e-7 else mu
+                nun = 2.0
+            else:
+                mu = max(mu * nun, 1e-3)
+                nun *= 2.0
+                rejected += 1
+        if accept:
+            ndiag = np.full(T, 2.0)
+            ndiag[T - 1] = 1.0
+            cur = {"Q": Qt, "f": f_t, "G": G[F], "D": (W + (2 * kap * ndiag)[:, None, None] * np.eye(n)[None])[F]}
+        stat = float(np.max(np.abs(cur["G"])))
+        nf = T - t0
+        Er = np.tile(-2 * kap * np.eye(n), (nf - 1, 1, 1))
+        while True:
+            z, ok = block_tridiag_solve(cur["D"], Er, -cur["G"], mu)
+            if ok:
+                break
+            mu = max(4.0 * mu, 1e-2)
+        if verbose:
+            print(f"  steps {iters:3d} f={cur['f']:.12f} stat={stat:.3e} mu={mu:.3g}")
+        if stat <= tol:
+            status = 0
+            break
+        if iters >= max_iter:
+            break
+        pred = -0.5 * float(np.sum(cur["G"] * z)) + 0.5 * mu * float(np.sum(z * z))
+        Qt = cur["Q"].copy()
+        Qt[F] += z
+        iters += 1
+    return {"Q": cur["Q"], "f": cur["f"], "iters": iters, "rejected": rejected, "stat": stat, "status": status}

@@ -108,7 +108,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("OH_BENCH_DIST_AT_1", "1") == "1")  # torchrun launch
+    if use_dist:
         from optas_amd import distributed as oad
 
         dist = oad.init_process_group("nccl", local_rank)  # RCCL
@@ -121,7 +122,7 @@ def main():
     robot = optas_amd.RobotModel.builtin("kuka_lwr")
     chain = robot.kinematic_chain(LINK)
     be = FigureEightBackend(chain, T, dt, lp, max_iter=args.max_iter, tol=args.tol)
-    if world > 1:
+    if use_dist:
         # the one collective of the whole job: kinematic constants, rank 0 -> all, over RCCL/xGMI
         import torch
 

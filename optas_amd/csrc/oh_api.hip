@@ -371,7 +371,7 @@ static void fill_params(oh_handle* h) {
   P.tol = d.tol;
   P.tol_feas = d.tol_feas;
   P.tol_retract = fmin(1e-10, d.tol_feas);
-  P.feas_accept = 1e-6;  // trial points are retracted to <= 1e-7 (retract_tol); anything worse means the retraction failed
+  P.feas_accept = fmax(1e-8, 10.0 * d.tol_feas);
   P.max_retract = 4;
   P.max_iter = d.max_iter;
   P.hessian = d.hessian;

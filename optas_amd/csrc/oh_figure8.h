@@ -24,8 +24,7 @@ OH_DEV void orient_residual(const double* Re, const double* Rc, double* c, doubl
 // multiplier estimate from Gprev), Householder null-space basis Z of the orientation rows, Dr = Z^T W Z.
 template <int N>
 OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const int t, double (&q)[N], const double (&pc)[3],
-                      const double (&Rc)[9], const double tol_retract, const bool have_G, const double (&Gprev)[N], double& phi, double& cv,
-                      double (&g)[N],
+                      const double (&Rc)[9], const bool have_G, const double (&Gprev)[N], double& phi, double& cv, double (&g)[N],
                       double (&Dr)[(N - 3) * (N - 2) / 2], double (&Z)[N][N - 3]) {
   constexpr int NZ = N - 3;
   double R[9], p[3], z[N][3], pj[N][3];
@@ -36,7 +35,7 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
     mm3(R, ch->R_tool, Re);
     orient_residual(Re, Rc, c, M);
     cmax = fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2])));
-    if (cmax <= tol_retract || it >= P.max_retract) break;
+    if (cmax <= P.tol_retract || it >= P.max_retract) break;
     // Newton correction q <- q - Jc^T (Jc Jc^T)^{-1} c,  Jc = M Jw,  Jw[:,k] = z_k (revolute) / 0
     double Jc[N][3];
 #pragma unroll
@@ -337,13 +336,6 @@ OH_DEV bool riccati_back(double (&S)[NZ * (NZ + 1) / 2], double (&rd)[NZ], doubl
       S[tri(a, c2)] = sacc;
     }
   return ok;
-}
-
-// Retraction tolerance of a trial point: tight (P.tol_retract) at the end game, but no tighter than the merit
-// comparison needs while the predicted decrease is still large: an infeasibility c perturbs f by ~|lam| c with
-// |lam| = O(1), so c <= 1e-3 * pred keeps the ratio test accurate to a fraction of a percent and saves one FK pass.
-OH_DEV double retract_tol(const FigParams& P, const bool first, const double pred) {
-  return first ? P.tol_retract : fmin(1e-7, fmax(P.tol_retract, 1e-3 * pred));
 }
 
 // Levenberg-Marquardt acceptance test and Nielsen damping update (shared so both paths decide alike).

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D, const i
   for (int k = 0; k < N; ++k) Gprev[k] = have_G ? D.Gfull[cur][IDX(t, N, k)] : 0.0;
 
   double phi, cv, g[N], Dr[NP], Z[N][NZ];
-  eval_knot<N>(D.chain, P, t, q, pc, Rc, retract_tol(P, first, D.pred[b]), have_G, Gprev, phi, cv, g, Dr, Z);
+  eval_knot<N>(D.chain, P, t, q, pc, Rc, have_G, Gprev, phi, cv, g, Dr, Z);
 
 #pragma unroll
   for (int j = 0; j < N; ++j) D.q[slot][IDX(t, N, j)] = q[j];
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
     // ---- evaluate the trial knots (k_eval) -----------------------------------------------------------------
     double phi = 0.0, cv = 0.0, g[N], Dr[NP], Z[N][NZ];
     const bool have_G = (P.hessian == OH_HESSIAN_EXACT) && !first;
-    if (active) eval_knot<N>(ch, P, t, qt, pc, Rc, retract_tol(P, first, pred), have_G, G_c, phi, cv, g, Dr, Z);
+    if (active) eval_knot<N>(ch, P, t, qt, pc, Rc, have_G, G_c, phi, cv, g, Dr, Z);
     // ---- neighbour coupling (k_couple) -----------------------------------------------------------------------
     double qm[N], qp[N], Zn[N][NZ];
 #pragma unroll

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
 // tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block
 // (eval_knot in oh_figure8.h).
 template <int N>
-__global__ __launch_bounds__(256) void k_eval(FigParams P, FigBuffers D, const int slot) {
+__global__ __launch_bounds__(256, 2) void k_eval(FigParams P, FigBuffers D, const int slot) {
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -533,7 +533,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
 }
 
 template <int N>
-__global__ __launch_bounds__(64) void k_step(FigParams P, FigBuffers D, const int slot) {
+__global__ __launch_bounds__(64, 2) void k_step(FigParams P, FigBuffers D, const int slot) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool alive = (b < D.B) && (D.status[b] < 0);
   const bool skipping = alive && D.skip[b];

@@ -56,7 +56,11 @@ enum {
   /* example/point_mass_mpc.py:88-154 Controller: planar point mass, receding-horizon tick with
      box limits on position/velocity and one moving circular obstacle; created with oh_create_pointmass.
      x = [vec(Y 2xT); vec(dY 2xT)] (nx = 4T), p = [curr(2); dcurr(2); vec(goal 2xT); vec(obs 2xT)] (np = 4+4T). */
-  OH_PROBLEM_POINT_MASS_MPC = 2
+  OH_PROBLEM_POINT_MASS_MPC = 2,
+  /* example/example.py:13-60 (BASELINE configs[0]): one configuration q of a serial chain,
+     f = w ||q - q_nominal||^2, h = p_goal - p_link(q) (builder.py:354), k = [q - lo; up - q] (builder.py:471-509);
+     created with oh_create_ik.  x = q (nx = ndof), p = [q_nominal(ndof); p_goal(3)] (np = ndof + 3). */
+  OH_PROBLEM_IK = 3
 };
 
 enum {
@@ -142,6 +146,17 @@ typedef struct oh_pointmass_desc {
   double tol;     /* KKT tolerance (stationarity, feasibility, complementarity); <= 0: 1e-8 */
 } oh_pointmass_desc;
 
+typedef struct oh_ik_desc {
+  int ndof;         /* 6 or 7; the chain must cover every model joint in order */
+  double w_nominal; /* weight of ||q - q_nominal||^2, 1.0 in example.py:30 */
+  double q_lo[OH_MAX_CHAIN]; /* enforce_model_limits (example.py:33; RobotModel limits, models.py:332-368) */
+  double q_up[OH_MAX_CHAIN];
+  int max_iter;     /* kinematics evaluations per instance; <= 0: 200 */
+  double tol;       /* KKT stationarity (projected gradient of the Lagrangian, inf-norm); <= 0: 1e-6 */
+  double tol_feas;  /* ||p_goal - p_link(q)||_inf; <= 0: 1e-9 */
+  double rho0;      /* initial augmented-Lagrangian penalty; <= 0: 100 w */
+} oh_ik_desc;
+
 typedef struct oh_handle oh_handle;
 
 /* Replaces Solver.__init__ + CasADiSolver.setup (solver.py:64-88,333-384): allocates the handle,
@@ -151,6 +166,9 @@ int oh_create(const oh_problem_desc* desc, oh_handle** out);
 /* Same for OH_PROBLEM_POINT_MASS_MPC (no kinematic constants needed; solve with oh_solve / oh_solve_device). */
 int oh_create_pointmass(const oh_pointmass_desc* desc, oh_handle** out);
 
+/* Same for OH_PROBLEM_IK; needs oh_set_constants before the first solve. */
+int oh_create_ik(const oh_ik_desc* desc, oh_handle** out);
+
 /* Kinematic constants from host memory / from device memory (the latter after an RCCL broadcast). */
 int oh_set_constants(oh_handle* h, const oh_chain* chain);
 int oh_set_constants_device(oh_handle* h, const void* d_chain, size_t nbytes);
@@ -159,7 +177,7 @@ int oh_set_constants_device(oh_handle* h, const void* d_chain, size_t nbytes);
    (solver.py:103-116,386-398).  Host buffers:
      x0 [B][nx], p [B][np]  in;  x [B][nx], f [B], kkt [B][3] = (stationarity, feasibility,
      complementarity), iters [B], status [B] out (any output pointer may be NULL).
-   nx = ndof*T + ndof*(T-1), np = ndof for OH_PROBLEM_FIGURE_EIGHT. */
+   nx = ndof*T + ndof*(T-1), np = ndof for OH_PROBLEM_FIGURE_EIGHT; see the OH_PROBLEM_* comments for the others. */
 int oh_solve(oh_handle* h, int B, const double* x0, const double* p, double* x, double* f, double* kkt,
              int* iters, int* status);
 
@@ -168,7 +186,9 @@ int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void
                     void* d_iters, void* d_status);
 
 /* Multipliers of the last oh_solve/oh_solve_device in the reference's form: lam_h [B][4*T] for the rows
-   h = quat_c - quat(q_t) (signed mu = lam+ - lam- of the (h,-h) pair, optimization.py:47-51). Host buffer. */
+   h = quat_c - quat(q_t) (signed mu = lam+ - lam- of the (h,-h) pair, optimization.py:47-51). Host buffer.
+   OH_PROBLEM_IK: lam_h [B][3 + 2*ndof] = (mu of h = p_goal - p_link(q) (3), multipliers of q - lo >= 0 (ndof),
+   multipliers of up - q >= 0 (ndof)). */
 int oh_get_multipliers(oh_handle* h, int B, double* lam_h);
 
 /* Replaces RobotModel.get_global_link_{position,quaternion,geometric_jacobian}_function(link, n=N)

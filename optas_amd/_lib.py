@@ -20,6 +20,7 @@ OH_STATUS_CONVERGED, OH_STATUS_MAX_ITER, OH_STATUS_NUMERICAL = 0, 1, 2
 OH_PROBLEM_KINEMATICS = 0
 OH_PROBLEM_FIGURE_EIGHT = 1
 OH_PROBLEM_POINT_MASS_MPC = 2
+OH_PROBLEM_IK = 3
 OH_HESSIAN_GAUSS_NEWTON, OH_HESSIAN_EXACT = 0, 1
 
 
@@ -91,6 +92,19 @@ class oh_pointmass_desc(C.Structure):
     ]
 
 
+class oh_ik_desc(C.Structure):
+    _fields_ = [
+        ("ndof", C.c_int),
+        ("w_nominal", C.c_double),
+        ("q_lo", C.c_double * OH_MAX_CHAIN),
+        ("q_up", C.c_double * OH_MAX_CHAIN),
+        ("max_iter", C.c_int),
+        ("tol", C.c_double),
+        ("tol_feas", C.c_double),
+        ("rho0", C.c_double),
+    ]
+
+
 class OptasHipError(RuntimeError):
     pass
 
@@ -101,6 +115,7 @@ _LIB: Optional[C.CDLL] = None
 SYMBOLS = [
     "oh_create",
     "oh_create_pointmass",
+    "oh_create_ik",
     "oh_set_constants",
     "oh_set_constants_device",
     "oh_solve",
@@ -148,6 +163,7 @@ def load() -> C.CDLL:
     vp, i, dp, ip = C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)
     lib.oh_create.argtypes = [C.POINTER(oh_problem_desc), C.POINTER(vp)]
     lib.oh_create_pointmass.argtypes = [C.POINTER(oh_pointmass_desc), C.POINTER(vp)]
+    lib.oh_create_ik.argtypes = [C.POINTER(oh_ik_desc), C.POINTER(vp)]
     lib.oh_set_constants.argtypes = [vp, C.POINTER(oh_chain)]
     lib.oh_set_constants_device.argtypes = [vp, vp, C.c_size_t]
     lib.oh_solve.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]

@@ -85,6 +85,31 @@ class PointMassBackend(_SolveMixin):
         _lib.check(lib.oh_create_pointmass(C.byref(desc), C.byref(self._h)), "oh_create_pointmass")
 
 
+class IKBackend(_SolveMixin):
+    """OH_PROBLEM_IK handle (example/example.py): x = q, p = [q_nominal; p_goal]."""
+
+    def __init__(self, chain: _lib.oh_chain, lo, up, w_nominal=1.0, max_iter=200, tol=1e-6, tol_feas=1e-9, rho0=0.0):
+        lib = _lib.load()
+        self.ndof = int(chain.ndof)
+        self.nx, self.np_ = self.ndof, self.ndof + 3
+        desc = _lib.oh_ik_desc(ndof=self.ndof, w_nominal=float(w_nominal), max_iter=int(max_iter), tol=float(tol), tol_feas=float(tol_feas),
+                               rho0=float(rho0))
+        lo, up = np.asarray(lo, dtype=np.float64).reshape(-1), np.asarray(up, dtype=np.float64).reshape(-1)
+        assert lo.shape == (self.ndof,) and up.shape == (self.ndof,)
+        for i in range(self.ndof):
+            desc.q_lo[i], desc.q_up[i] = lo[i], up[i]
+        self._h = C.c_void_p()
+        _lib.check(lib.oh_create_ik(C.byref(desc), C.byref(self._h)), "oh_create_ik")
+        _lib.check(lib.oh_set_constants(self._h, C.byref(chain)), "oh_set_constants")
+        self.chain = chain
+
+    def multipliers(self, B: int):
+        """(mu_h (B,3), z_lo (B,ndof), z_up (B,ndof)) of the last solve, reference form."""
+        out = np.empty((B, 3 + 2 * self.ndof))
+        _lib.check(_lib.load().oh_get_multipliers(self._h, int(B), _lib._ptr(out)), "oh_get_multipliers")
+        return out[:, :3], out[:, 3 : 3 + self.ndof], out[:, 3 + self.ndof :]
+
+
 class FigureEightBackend:
     """OH_PROBLEM_FIGURE_EIGHT handle."""
 

@@ -43,6 +43,10 @@ struct oh_handle {
   oh_pointmass_desc pm{};
   PmParams PmP{};
   PmBuffers PmD{};
+  // inverse-kinematics family
+  oh_ik_desc ik{};
+  double* d_ik_mult = nullptr;
+  int ik_cap = 0;
   // solver buffers
   int cap_B = 0;
   FigBuffers D{};
@@ -192,6 +196,80 @@ extern "C" int oh_create_pointmass(const oh_pointmass_desc* desc, oh_handle** ou
     return fail(OH_ERR_HIP, "oh_create_pointmass: stream/event creation failed");
   }
   *out = h;
+  return OH_OK;
+}
+
+extern "C" int oh_create_ik(const oh_ik_desc* desc, oh_handle** out) {
+  if (!desc || !out) return fail(OH_ERR_INVALID, "oh_create_ik: null argument");
+  *out = nullptr;
+  if (desc->ndof != 6 && desc->ndof != 7) return fail(OH_ERR_INVALID, "oh_create_ik: kernels are instantiated for ndof 6 and 7");
+  if (!(desc->w_nominal > 0.0)) return fail(OH_ERR_INVALID, "oh_create_ik: w_nominal must be positive");
+  for (int i = 0; i < desc->ndof; ++i)
+    if (!(desc->q_lo[i] <= desc->q_up[i])) return fail(OH_ERR_INVALID, "oh_create_ik: q_lo must not exceed q_up");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1)
+    return fail(OH_ERR_HIP, "oh_create_ik: no HIP device available (this library has no CPU path)");
+  oh_handle* h = new oh_handle();
+  h->desc = oh_problem_desc{};
+  h->desc.kind = OH_PROBLEM_IK;
+  h->desc.T = 1;
+  h->desc.ndof = desc->ndof;
+  h->ik = *desc;
+  if (h->ik.max_iter <= 0) h->ik.max_iter = 200;
+  if (!(h->ik.tol > 0.0)) h->ik.tol = 1e-6;
+  if (!(h->ik.tol_feas > 0.0)) h->ik.tol_feas = 1e-9;
+  if (!(h->ik.rho0 > 0.0)) h->ik.rho0 = 100.0 * h->ik.w_nominal;
+  hipGetDevice(&h->device);
+  if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+      hipEventCreate(&h->evt0) != hipSuccess || hipEventCreate(&h->evt1) != hipSuccess ||
+      hipMalloc((void**)&h->d_chain, sizeof(oh_chain)) != hipSuccess) {
+    delete h;
+    return fail(OH_ERR_HIP, "oh_create_ik: stream/event/allocation failed");
+  }
+  *out = h;
+  return OH_OK;
+}
+
+static bool solver_chain_ok(const oh_chain& c);
+
+static int ik_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters,
+                           void* d_status) {
+  if (!h->have_chain) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_constants first");
+  if (!solver_chain_ok(h->chain_host))
+    return fail(OH_ERR_INVALID, "oh_solve_device: the solver needs a chain that covers every model joint in order");
+  HIPCHK(hipSetDevice(h->device));
+  const int N = h->ik.ndof;
+  if (B > h->ik_cap) {
+    if (h->d_ik_mult) hipFree(h->d_ik_mult);
+    h->d_ik_mult = nullptr;
+    h->ik_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->d_ik_mult, sizeof(double) * (3 + 2 * (size_t)N) * B));
+    h->ik_cap = B;
+  }
+  IkParams P{};
+  P.ndof = N;
+  P.max_iter = h->ik.max_iter;
+  P.w = h->ik.w_nominal;
+  P.tol = h->ik.tol;
+  P.tol_feas = h->ik.tol_feas;
+  P.rho0 = h->ik.rho0;
+  for (int i = 0; i < N; ++i) {
+    P.lo[i] = h->ik.q_lo[i];
+    P.up[i] = h->ik.q_up[i];
+  }
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  if (!oh_launch_ik_solve(h->stream, h->d_chain, P, B, (const double*)d_x0, (const double*)d_p, (double*)d_x, (double*)d_f, (double*)d_kkt,
+                          (int*)d_iters, (int*)d_status, h->d_ik_mult))
+    return fail(OH_ERR_INVALID, "oh_solve_device: unsupported ndof");
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  for (double& t : h->timing) t = 0.0;
+  h->timing[4] = ms;
+  h->timing[5] = 1;
+  h->last_B = B;
   return OH_OK;
 }
 
@@ -385,6 +463,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (B < 1) return fail(OH_ERR_INVALID, "oh_solve_device: B must be >= 1");
   if (!d_x0 || !d_p) return fail(OH_ERR_INVALID, "oh_solve_device: x0 and p are required");
   if (h->desc.kind == OH_PROBLEM_POINT_MASS_MPC) return pm_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
+  if (h->desc.kind == OH_PROBLEM_IK) return ik_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT) return fail(OH_ERR_STATE, "oh_solve_device: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
   if (!h->have_chain) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_constants first");
   if (!solver_chain_ok(h->chain_host))
@@ -530,13 +609,14 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
   if (!h) return fail(OH_ERR_INVALID, "oh_solve: null handle");
   if (B < 1) return fail(OH_ERR_INVALID, "oh_solve: B must be >= 1");
   if (!x0 || !p) return fail(OH_ERR_INVALID, "oh_solve: x0 and p are required");
-  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_POINT_MASS_MPC)
+  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_POINT_MASS_MPC && h->desc.kind != OH_PROBLEM_IK)
     return fail(OH_ERR_STATE, "oh_solve: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
   HIPCHK(hipSetDevice(h->device));
   const int N = h->desc.ndof, T = h->desc.T;
   const bool pmk = h->desc.kind == OH_PROBLEM_POINT_MASS_MPC;
-  const size_t nx = pmk ? 4 * (size_t)T : (size_t)N * T + (size_t)N * (T - 1);
-  const size_t npar = pmk ? 4 + 4 * (size_t)T : (size_t)N;
+  const bool ikk = h->desc.kind == OH_PROBLEM_IK;
+  const size_t nx = pmk ? 4 * (size_t)T : (ikk ? (size_t)N : (size_t)N * T + (size_t)N * (T - 1));
+  const size_t npar = pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (size_t)N);
   const size_t b_x = sizeof(double) * nx * B, b_p = sizeof(double) * npar * (size_t)B;
   const size_t b_f = sizeof(double) * B, b_k = sizeof(double) * 3 * (size_t)B, b_i = sizeof(int) * (size_t)B;
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -565,9 +645,13 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
 
 extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
   if (!h || !lam_h) return fail(OH_ERR_INVALID, "oh_get_multipliers: null argument");
-  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT || B != h->last_B || B < 1)
+  if ((h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_IK) || B != h->last_B || B < 1)
     return fail(OH_ERR_STATE, "oh_get_multipliers: B does not match the last solve");
   HIPCHK(hipSetDevice(h->device));
+  if (h->desc.kind == OH_PROBLEM_IK) {
+    HIPCHK(hipMemcpy(lam_h, h->d_ik_mult, sizeof(double) * (3 + 2 * (size_t)h->ik.ndof) * B, hipMemcpyDeviceToHost));
+    return OH_OK;
+  }
   if (!h->D.lam_h) return fail(OH_ERR_STATE, "oh_get_multipliers: this problem has no nonlinear equality rows");
   HIPCHK(hipMemcpy(lam_h, h->D.lam_h, sizeof(double) * 4 * (size_t)h->desc.T * B, hipMemcpyDeviceToHost));
   return OH_OK;
@@ -686,6 +770,7 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (hipEvent_t e : h->prof_events) hipEventDestroy(e);
   if (h->pool) hipFree(h->pool);
+  if (h->d_ik_mult) hipFree(h->d_ik_mult);
   if (h->stage) hipFree(h->stage);
   if (h->d_chain) hipFree(h->d_chain);
   if (h->d_dyn) hipFree(h->d_dyn);

@@ -1,0 +1,231 @@
+// Inverse-kinematics family (BASELINE config 1, example/example.py:13-60):
+//
+//     min_q  w ||q - q_nominal||^2   s.t.  h(q) = p_goal - p_link(q) = 0   (builder.py:354: rhs - lhs)
+//                                          lo <= q <= up                     (enforce_model_limits, builder.py:471-509)
+//
+// One thread owns one instance for its whole solve (nx = ndof <= 7: everything lives in registers): bound-constrained
+// augmented Lagrangian, inner iteration = projected Newton (Bertsekas active set) with the exact Hessian of the
+// augmented Lagrangian -- 2wI + rho Jp^T Jp - sum_k y_k d2p_k, the position curvature is y.(omega_a x Jp_b) -- a
+// Levenberg shift when the masked matrix is not positive definite, and Armijo backtracking along the projected arc.
+// The state machine is the one oracle/ik_al.py restates in numpy (test infrastructure only).
+#include <hip/hip_runtime.h>
+
+#include "oh_device.h"
+#include "oh_kernels.h"
+
+namespace {
+
+template <int N>
+OH_DEV void ik_eval(const oh_chain* __restrict__ ch, const double (&q)[N], double (&e)[3], double (&Jp)[N][3], double (&om)[N][3]) {
+  double R[9], p[3], pj[N][3];
+  fk_chain<N>(ch, q, R, p, om, pj);
+  double t[3];
+  mv3(R, ch->p_tool, t);
+  e[0] = p[0] + t[0]; e[1] = p[1] + t[1]; e[2] = p[2] + t[2];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (ch->jtype[k] == 0) {
+      const double d[3] = {e[0] - pj[k][0], e[1] - pj[k][1], e[2] - pj[k][2]};
+      cross3(om[k], d, Jp[k]);
+    } else {
+      Jp[k][0] = om[k][0]; Jp[k][1] = om[k][1]; Jp[k][2] = om[k][2];
+      om[k][0] = om[k][1] = om[k][2] = 0.0;
+    }
+  }
+}
+
+template <int N>
+OH_DEV double ik_merit(const IkParams& P, const double (&q)[N], const double (&qn)[N], const double (&e)[3], const double (&pg)[3],
+                       const double (&lam)[3], double rho) {
+  double c = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) c += (q[i] - qn[i]) * (q[i] - qn[i]);
+  double m = P.w * c;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double h = pg[k] - e[k];
+    m += lam[k] * h + 0.5 * rho * h * h;
+  }
+  return m;
+}
+
+template <int N>
+__global__ void __launch_bounds__(64) k_ik_solve(const oh_chain* __restrict__ ch, IkParams P, int B, const double* __restrict__ x0,
+                                                 const double* __restrict__ par, double* __restrict__ x, double* __restrict__ f,
+                                                 double* __restrict__ kkt, int* __restrict__ iters, int* __restrict__ status,
+                                                 double* __restrict__ mult) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  constexpr int NP = N * (N + 1) / 2;
+  double q[N], qn[N], pg[3], lam[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    qn[i] = par[(size_t)b * (N + 3) + i];
+    q[i] = fmin(fmax(x0[(size_t)b * N + i], P.lo[i]), P.up[i]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pg[k] = par[(size_t)b * (N + 3) + N + k];
+  double e[3], Jp[N][3], om[N][3];
+  ik_eval<N>(ch, q, e, Jp, om);
+  int it = 1, st = OH_STATUS_MAX_ITER;
+  double rho = P.rho0, shift = 0.0, h_prev = 1e300;
+  double grad[N];
+  bool act[N];
+  while (it < P.max_iter) {
+    // ---- inner: projected Newton on the augmented Lagrangian ----
+    while (it < P.max_iter) {
+      double y[3], hmax = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double h = pg[k] - e[k];
+        y[k] = lam[k] + rho * h;
+        hmax = fmax(hmax, fabs(h));
+      }
+      double pgn = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        grad[i] = 2.0 * P.w * (q[i] - qn[i]) - (Jp[i][0] * y[0] + Jp[i][1] * y[1] + Jp[i][2] * y[2]);
+        act[i] = (q[i] <= P.lo[i] && grad[i] > 0.0) || (q[i] >= P.up[i] && grad[i] < 0.0);
+        if (!act[i]) pgn = fmax(pgn, fabs(grad[i]));
+      }
+      if (pgn <= fmax(0.5 * P.tol, fmin(1e-2, 0.1 * hmax))) break;
+      double H[NP];
+#pragma unroll
+      for (int a = 0; a < N; ++a) {
+#pragma unroll
+        for (int c = 0; c <= a; ++c) {
+          double t[3];
+          cross3(om[c], Jp[a], t);
+          double v = rho * (Jp[a][0] * Jp[c][0] + Jp[a][1] * Jp[c][1] + Jp[a][2] * Jp[c][2]) - (y[0] * t[0] + y[1] * t[1] + y[2] * t[2]);
+          if (a == c) v += 2.0 * P.w;
+          H[tri(a, c)] = v;
+        }
+      }
+      double L[NP];
+      for (;;) {
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+#pragma unroll
+          for (int c = 0; c <= a; ++c) {
+            double v = H[tri(a, c)];
+            if (a == c) v += shift;
+            if (act[a] || act[c]) v = (a == c) ? 1.0 : 0.0;
+            L[tri(a, c)] = v;
+          }
+        }
+        if (chol_packed<N>(L, 0.0)) break;
+        shift = fmax(10.0 * shift, 1e-3 * rho);
+        if (!(shift < 1e300)) break;
+      }
+      double d[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) d[i] = act[i] ? 0.0 : -grad[i];
+      fsub<N>(L, d);
+      bsub<N>(L, d);
+      const double m0 = ik_merit<N>(P, q, qn, e, pg, lam, rho);
+      double alpha = 1.0;
+      bool ok = false;
+      double qt[N], et[3], Jt[N][3], ot[N][3];
+      for (int ls = 0; ls < 30; ++ls) {
+        double slope = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          qt[i] = fmin(fmax(q[i] + alpha * d[i], P.lo[i]), P.up[i]);
+          slope += grad[i] * (qt[i] - q[i]);
+        }
+        ik_eval<N>(ch, qt, et, Jt, ot);
+        ++it;
+        if (ik_merit<N>(P, qt, qn, et, pg, lam, rho) <= m0 + 1e-4 * slope + 4e-16 * fmax(1.0, fabs(m0))) {
+          ok = true;
+          break;
+        }
+        alpha *= 0.5;
+        if (it >= P.max_iter) break;
+      }
+      if (!ok) {
+        shift = fmax(10.0 * shift, 1e-3 * rho);
+        if (shift > 1e12 * rho) {
+          st = OH_STATUS_NUMERICAL;
+          break;
+        }
+        continue;
+      }
+      shift = shift > 1e-12 ? 0.1 * shift : 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        q[i] = qt[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          Jp[i][k] = Jt[i][k];
+          om[i][k] = ot[i][k];
+        }
+      }
+      e[0] = et[0]; e[1] = et[1]; e[2] = et[2];
+    }
+    if (st == OH_STATUS_NUMERICAL) break;
+    // ---- outer: multiplier update ----
+    double hn = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double h = pg[k] - e[k];
+      lam[k] += rho * h;
+      hn = fmax(hn, fabs(h));
+    }
+    double stat = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double g = 2.0 * P.w * (q[i] - qn[i]) - (Jp[i][0] * lam[0] + Jp[i][1] * lam[1] + Jp[i][2] * lam[2]);
+      const bool a = (q[i] <= P.lo[i] && g > 0.0) || (q[i] >= P.up[i] && g < 0.0);
+      if (!a) stat = fmax(stat, fabs(g));
+    }
+    if (hn <= P.tol_feas && stat <= P.tol) {
+      st = OH_STATUS_CONVERGED;
+      break;
+    }
+    if (hn > 0.1 * h_prev) rho = fmin(rho * 10.0, 1e8);
+    h_prev = hn;
+  }
+  // ---- results in the reference's form: v = [q - lo; up - q; h; -h] >= 0 (optimization.py:47-51) ----
+  double stat = 0.0, feas = 0.0, cost = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) feas = fmax(feas, fabs(pg[k] - e[k]));
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double g = 2.0 * P.w * (q[i] - qn[i]) - (Jp[i][0] * lam[0] + Jp[i][1] * lam[1] + Jp[i][2] * lam[2]);
+    const bool lo = q[i] <= P.lo[i] && g > 0.0, up = q[i] >= P.up[i] && g < 0.0;
+    if (!(lo || up)) stat = fmax(stat, fabs(g));
+    cost += (q[i] - qn[i]) * (q[i] - qn[i]);
+    if (x) x[(size_t)b * N + i] = q[i];
+    if (mult) {
+      mult[(size_t)b * (3 + 2 * N) + 3 + i] = lo ? g : 0.0;
+      mult[(size_t)b * (3 + 2 * N) + 3 + N + i] = up ? -g : 0.0;
+    }
+  }
+  if (mult) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mult[(size_t)b * (3 + 2 * N) + k] = -lam[k];
+  }
+  if (f) f[b] = P.w * cost;
+  if (kkt) {
+    kkt[(size_t)b * 3 + 0] = stat;
+    kkt[(size_t)b * 3 + 1] = feas;
+    kkt[(size_t)b * 3 + 2] = 0.0;  // multipliers are non-zero only on rows that sit exactly on their bound
+  }
+  if (iters) iters[b] = it;
+  if (status) status[b] = st;
+}
+
+}  // namespace
+
+bool oh_launch_ik_solve(hipStream_t stream, const oh_chain* d_chain, const IkParams& P, int B, const double* x0, const double* p, double* x,
+                        double* f, double* kkt, int* iters, int* status, double* mult) {
+  const dim3 block(64), grid((B + 63) / 64);
+  if (P.ndof == 7) {
+    hipLaunchKernelGGL(k_ik_solve<7>, grid, block, 0, stream, d_chain, P, B, x0, p, x, f, kkt, iters, status, mult);
+  } else if (P.ndof == 6) {
+    hipLaunchKernelGGL(k_ik_solve<6>, grid, block, 0, stream, d_chain, P, B, x0, p, x, f, kkt, iters, status, mult);
+  } else {
+    return false;
+  }
+  return true;
+}

@@ -90,3 +90,12 @@ struct PmBuffers {
 };
 void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, const double* x0, const double* p, double* x, double* f, double* kkt,
                         int* iters, int* status);
+
+// ---- OH_PROBLEM_IK -----------------------------------------------------------------------------------------
+struct IkParams {
+  int ndof, max_iter;
+  double w, tol, tol_feas, rho0;
+  double lo[OH_MAX_CHAIN], up[OH_MAX_CHAIN];
+};
+bool oh_launch_ik_solve(hipStream_t s, const oh_chain* d_chain, const IkParams& P, int B, const double* x0, const double* p, double* x, double* f,
+                        double* kkt, int* iters, int* status, double* mult);

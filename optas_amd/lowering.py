@@ -354,13 +354,86 @@ def match_multi_arm(opt: Optimization) -> MultiArmSpec:
     return MultiArmSpec(T, dt, out)
 
 
+@dataclass
+class IkSpec:
+    robot: RobotModel
+    link: str
+    w_nominal: float
+    lo: np.ndarray
+    up: np.ndarray
+    qn_name: str
+    pg_name: str
+    q_name: str
+
+
+def match_ik(opt: Optimization) -> IkSpec:
+    """example/example.py:13-60: min w||q - q_nominal||^2 s.t. p_link(q) = p_goal, lo <= q <= up (T = 1)."""
+
+    def no(msg):
+        raise LoweringError(f"inverse-kinematics lowering: {msg}")
+
+    robots = [m for m in (opt.models or []) if isinstance(m, RobotModel)]
+    if len(opt.models or []) != 1 or len(robots) != 1:
+        no("expected exactly one RobotModel and no task models")
+    robot = robots[0]
+    if list(robot.time_derivs) != [0] or robot.num_param_joints != 0:
+        no("robot must have time_derivs=[0] and no parameterised joints")
+    q_name = robot.state_optimized_name(0)
+    if list(opt.decision_variables.keys()) != [q_name]:
+        no(f"decision variables must be exactly [{q_name}]")
+    Q: StateRef = opt.decision_variables[q_name]
+    if Q.n != 1:
+        no("T must be 1")
+    n = robot.ndof
+    if opt.ng or opt.na:
+        no("nonlinear inequality / linear equality rows are not part of this family")
+
+    def is_q(e):
+        return isinstance(e, StateRef) and e.var_name == q_name and e.time_deriv == 0 and (e.t in (None, 0))
+
+    # nonlinear equality: p_link(q) == p_goal
+    if len(opt.eq_constraints) != 1:
+        no("expected exactly one nonlinear equality (link position goal)")
+    (label, diff), = opt.eq_constraints.items()
+    if not (isinstance(diff, Sub) and isinstance(diff.a, ParamRef) and isinstance(diff.b, LinkFunction) and diff.b.what == "position"
+            and is_q(diff.b.q) and diff.b.robot is robot and diff.a.shape == (3, 1)):
+        no(f"equality '{label}' is not p(link, q) == p_goal with a 3-vector parameter")
+    pg, link = diff.a, diff.b.link
+
+    # cost: w * sumsqr(q - q_nominal)
+    if len(opt.cost_terms) != 1:
+        no("expected exactly one cost term")
+    (label, term), = opt.cost_terms.items()
+    w, e = _unscale(term)
+    if not (isinstance(e, SumSqr) and isinstance(e.a, Sub) and is_q(e.a.a) and isinstance(e.a.b, ParamRef) and e.a.b.shape == (n, 1)):
+        no(f"cost '{label}' is not w * sumsqr(q - q_nominal)")
+    qn = e.a.b
+    if not w > 0:
+        no("cost weight must be positive")
+
+    # linear inequalities: joint limits (optional)
+    lo, up = np.full(n, -1e9), np.full(n, 1e9)
+    for label, d in opt.lin_ineq_constraints.items():
+        if isinstance(d, Sub) and is_q(d.a) and isinstance(d.b, Const) and d.b.value.shape == (n, 1):
+            lo = np.maximum(lo, d.b.value[:, 0])
+        elif isinstance(d, Sub) and is_q(d.b) and isinstance(d.a, Const) and d.a.value.shape == (n, 1):
+            up = np.minimum(up, d.a.value[:, 0])
+        else:
+            no(f"linear inequality '{label}' is not a joint bound")
+    params = [k for k, v in opt.parameters.items() if v.numel() > 0]
+    if params != [qn.name, pg.name]:
+        no(f"non-empty parameters must be ['{qn.name}', '{pg.name}'] in this order, found {params}")
+    return IkSpec(robot, link, float(w), lo, up, qn.name, pg.name, q_name)
+
+
 OH_KIND_MULTI_ARM = 101  # host-side composition of OH_PROBLEM_FIGURE_EIGHT handles with lock_orientation = 0
 
 
 def lower(opt: Optimization):
     """Return (kind, spec).  Raises LoweringError if no kernel family matches."""
     errors = []
-    for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass), (OH_KIND_MULTI_ARM, match_multi_arm)):
+    for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass), (OH_KIND_MULTI_ARM, match_multi_arm),
+                     (_lib.OH_PROBLEM_IK, match_ik)):
         try:
             return kind, fn(opt)
         except LoweringError as e:

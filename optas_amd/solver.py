@@ -16,8 +16,8 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import _lib
-from .backend import BatchResult, FigureEightBackend, MultiArmBackend, PointMassBackend
-from .lowering import FigureEightSpec, MultiArmSpec, PointMassSpec, lower
+from .backend import BatchResult, FigureEightBackend, IKBackend, MultiArmBackend, PointMassBackend
+from .lowering import FigureEightSpec, IkSpec, MultiArmSpec, PointMassSpec, lower
 from .models import RobotModel
 from .optimization import Optimization
 
@@ -177,6 +177,10 @@ class HIPSolver(Solver):
         elif isinstance(spec, MultiArmSpec):
             o.pop("hessian", None)
             self._backend = MultiArmBackend(spec, self.opt, max_iter=int(o.pop("max_iter", 200)), tol=float(o.pop("tol", 1e-6)), hessian=hessian)
+        elif isinstance(spec, IkSpec):
+            o.pop("hessian", None)
+            self._backend = IKBackend(spec.robot.kinematic_chain(spec.link), spec.lo, spec.up, w_nominal=spec.w_nominal,
+                                      max_iter=int(o.pop("max_iter", 200)), tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)))
         else:  # pragma: no cover
             raise NotImplementedError(kind)
         if o:

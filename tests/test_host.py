@@ -124,8 +124,11 @@ def test_ik_example_builder_matches_reference_counts():
     opt = b.build()
     assert isinstance(opt, QuadraticCostNonlinearConstraints)
     assert (opt.nx, opt.np, opt.nk, opt.nh, opt.nv) == (7, 10, 14, 3, 20)
+    kind, _ = lower(opt)
+    assert kind == optas_amd._lib.OH_PROBLEM_IK
+    b.add_cost_term("extra", sumsqr(q))
     with pytest.raises(LoweringError):
-        lower(opt)  # config 1 is the reference's CPU plumbing case; no kernel family claims it
+        lower(b.build())  # a second cost term is outside every kernel family: refused loudly, never approximated
 
 
 def test_figure_eight_builder_and_lowering():

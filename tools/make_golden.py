@@ -157,3 +157,46 @@ def pm_golden():
         X.append(best)
         F.append(nlp.f(best, p))
     np.savez(os.path.join(G, "pm_golden.npz"), p=np.array(P), x=np.array(X), f=np.array(F))
+
+
+def ik_golden():
+    """BASELINE config 1 (example/example.py): the script's instance (zero seed, see examples/example.py) + 23 random
+    instances, 8 of them with the nominal configuration pushed against joint limits so that bound rows are active.
+    Reference wiring (scipy SLSQP on v >= 0, solver.py:652-679) and the augmented-Lagrangian port; stored optimum = the
+    one both agree on (agree=1) or the lower-cost KKT point of the two (agree=0; the problem is non-convex)."""
+    from oracle.ik_al import solve_ik_al
+    from oracle.structured import FoldedChain
+
+    kuka = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json"))
+    link = "end_effector_ball"
+    ik = IKExampleNLP(kuka, link)
+    ch = FoldedChain(kuka, link)
+    rng = np.random.default_rng(SEED + 1)
+    qn0 = np.deg2rad([0, 45, 0, -90, 0, -45, 0])
+    P = [np.concatenate([qn0, kuka.get_global_link_position(link, qn0) + np.array([0.0, 0.3, -0.2])])]
+    X0 = [np.zeros(7)]
+    for i in range(23):
+        qn = qn0 + rng.uniform(-0.3, 0.3, 7)
+        if i >= 15:
+            j = rng.integers(0, 7, 2)
+            s = rng.choice([-1.0, 1.0], 2)
+            qn[j] = np.where(s > 0, ik.up[j] - 0.02, ik.lo[j] + 0.02)
+        pg = kuka.get_global_link_position(link, qn) + rng.uniform(-0.2, 0.2, 3)
+        P.append(np.concatenate([qn, pg]))
+        X0.append(qn.copy())
+    X, F, AG, NACT = [], [], [], []
+    for p, x0 in zip(P, X0):
+        r = scipy_minimize(ik, x0, p, method="SLSQP", tol=1e-13, options={"maxiter": 1000})
+        a = solve_ik_al(ch, x0, p[:7], p[7:], ik.lo, ik.up, tol=1e-9, tol_feas=1e-11, max_iter=400)
+        ks = kkt_reference_form(ik, r.x, p, active_tol=1e-7)
+        agree = bool(r.success and np.abs(r.x - a["x"]).max() < 1e-6)
+        slsqp_ok = r.success and ks["stationarity"] < 1e-6 and ks["feasibility"] < 1e-9
+        best = a["x"] if (a["status"] == 0 and (not slsqp_ok or a["f"] <= r.fun + 1e-9)) else r.x
+        nact = int(((best - ik.lo) < 1e-9).sum() + ((ik.up - best) < 1e-9).sum())
+        print("ik", r.fun, r.success, a["f"], a["status"], a["iterations"], "agree", agree, "active", nact)
+        X.append(best)
+        F.append(ik.f(best, p))
+        AG.append(agree)
+        NACT.append(nact)
+    np.savez(os.path.join(G, "ik_golden.npz"), p=np.array(P), x0=np.array(X0), x=np.array(X), f=np.array(F), agree=np.array(AG),
+             nactive=np.array(NACT), lo=ik.lo, up=ik.up)

@@ -146,6 +146,30 @@ typedef struct oh_pointmass_desc {
   double tol;     /* KKT tolerance (stationarity, feasibility, complementarity); <= 0: 1e-8 */
 } oh_pointmass_desc;
 
+/*
+ * Inequality rows of the position-tracking family (OH_PROBLEM_FIGURE_EIGHT with lock_orientation = 0), set with
+ * oh_set_guards before the first solve:
+ *   limits:  q_t - q_lo >= 0, q_up - q_t >= 0 at every knot   (enforce_model_limits, builder.py:471-509, rows "_l", "_r")
+ *   spheres: ||c_l(q_t) - o_j||^2 - (r_l + r_j)^2 >= 0 for every sphere link l and obstacle j
+ *            (sphere_collision_avoidance_constraints, builder.py:366-417; c_l = origin of link l in the root frame)
+ * Row order per knot: [q - lo (ndof); up - q (ndof); spheres link-major, obstacle-minor]; knots t < t0 are constants.
+ * With guards the parameter row of an instance is
+ *   p = [qc (ndof); link radii (n_links); for each obstacle: position (3), radius (1)],  np = ndof + n_links + 4 n_obstacles
+ * (the order in which the reference creates these parameters, builder.py:391-405).
+ */
+#define OH_MAX_SPHERE_LINKS 8
+#define OH_MAX_OBSTACLES 16
+typedef struct oh_guards {
+  int limits;                               /* 1: joint-limit rows present */
+  double q_lo[OH_MAX_CHAIN];
+  double q_up[OH_MAX_CHAIN];
+  int n_links;                              /* sphere links, 0: no sphere rows */
+  int link_joint[OH_MAX_SPHERE_LINKS];      /* chain index of the last actuated joint before the link (>= 0) */
+  double link_offset[OH_MAX_SPHERE_LINKS][3]; /* link origin in the frame that follows that joint's motion */
+  int n_obstacles;
+  double rho0;                              /* initial augmented-Lagrangian penalty; <= 0: 10 * w_path */
+} oh_guards;
+
 typedef struct oh_ik_desc {
   int ndof;         /* 6 or 7; the chain must cover every model joint in order */
   double w_nominal; /* weight of ||q - q_nominal||^2, 1.0 in example.py:30 */
@@ -173,6 +197,9 @@ int oh_create_ik(const oh_ik_desc* desc, oh_handle** out);
 int oh_set_constants(oh_handle* h, const oh_chain* chain);
 int oh_set_constants_device(oh_handle* h, const void* d_chain, size_t nbytes);
 
+/* Inequality rows for the position-tracking family (see oh_guards). */
+int oh_set_guards(oh_handle* h, const oh_guards* guards);
+
 /* Replaces B sequential calls of Solver.reset_initial_seed + reset_parameters + _solve
    (solver.py:103-116,386-398).  Host buffers:
      x0 [B][nx], p [B][np]  in;  x [B][nx], f [B], kkt [B][3] = (stationarity, feasibility,
@@ -188,7 +215,9 @@ int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void
 /* Multipliers of the last oh_solve/oh_solve_device in the reference's form: lam_h [B][4*T] for the rows
    h = quat_c - quat(q_t) (signed mu = lam+ - lam- of the (h,-h) pair, optimization.py:47-51). Host buffer.
    OH_PROBLEM_IK: lam_h [B][3 + 2*ndof] = (mu of h = p_goal - p_link(q) (3), multipliers of q - lo >= 0 (ndof),
-   multipliers of up - q >= 0 (ndof)). */
+   multipliers of up - q >= 0 (ndof)).
+   Position-tracking family with oh_set_guards: lam_h [B][T][NC], NC = 2 ndof limits + n_links n_obstacles, row order
+   of oh_guards (multipliers >= 0 of the g >= 0 rows; knots t < t0 carry zeros). */
 int oh_get_multipliers(oh_handle* h, int B, double* lam_h);
 
 /* Replaces RobotModel.get_global_link_{position,quaternion,geometric_jacobian}_function(link, n=N)

@@ -14,6 +14,8 @@ import numpy as np
 
 OH_MAX_CHAIN = 16
 OH_MAX_T = 128
+OH_MAX_SPHERE_LINKS = 8
+OH_MAX_OBSTACLES = 16
 
 OH_OK = 0
 OH_STATUS_CONVERGED, OH_STATUS_MAX_ITER, OH_STATUS_NUMERICAL = 0, 1, 2
@@ -92,6 +94,19 @@ class oh_pointmass_desc(C.Structure):
     ]
 
 
+class oh_guards(C.Structure):
+    _fields_ = [
+        ("limits", C.c_int),
+        ("q_lo", C.c_double * OH_MAX_CHAIN),
+        ("q_up", C.c_double * OH_MAX_CHAIN),
+        ("n_links", C.c_int),
+        ("link_joint", C.c_int * OH_MAX_SPHERE_LINKS),
+        ("link_offset", (C.c_double * 3) * OH_MAX_SPHERE_LINKS),
+        ("n_obstacles", C.c_int),
+        ("rho0", C.c_double),
+    ]
+
+
 class oh_ik_desc(C.Structure):
     _fields_ = [
         ("ndof", C.c_int),
@@ -118,6 +133,7 @@ SYMBOLS = [
     "oh_create_ik",
     "oh_set_constants",
     "oh_set_constants_device",
+    "oh_set_guards",
     "oh_solve",
     "oh_solve_device",
     "oh_get_multipliers",
@@ -166,6 +182,7 @@ def load() -> C.CDLL:
     lib.oh_create_ik.argtypes = [C.POINTER(oh_ik_desc), C.POINTER(vp)]
     lib.oh_set_constants.argtypes = [vp, C.POINTER(oh_chain)]
     lib.oh_set_constants_device.argtypes = [vp, vp, C.c_size_t]
+    lib.oh_set_guards.argtypes = [vp, C.POINTER(oh_guards)]
     lib.oh_solve.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
     lib.oh_solve_device.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
     lib.oh_get_multipliers.argtypes = [vp, i, vp]

@@ -129,6 +129,7 @@ class FigureEightBackend:
         lock_orientation: bool = True,
         fix_dq0: bool = True,
         path_in_frame: bool = True,
+        guards: "Optional[_lib.oh_guards]" = None,
     ):
         lib = _lib.load()
         self.T, self.ndof = int(T), int(chain.ndof)
@@ -157,6 +158,12 @@ class FigureEightBackend:
         _lib.check(lib.oh_create(C.byref(desc), C.byref(self._h)), "oh_create")
         _lib.check(lib.oh_set_constants(self._h, C.byref(chain)), "oh_set_constants")
         self.chain = chain
+        self.guards = guards
+        self.n_rows = 0
+        if guards is not None:
+            _lib.check(lib.oh_set_guards(self._h, C.byref(guards)), "oh_set_guards")
+            self.np_ = self.ndof + guards.n_links + 4 * guards.n_obstacles
+            self.n_rows = (2 * self.ndof if guards.limits else 0) + guards.n_links * guards.n_obstacles
 
     @property
     def handle(self) -> C.c_void_p:
@@ -196,7 +203,9 @@ class FigureEightBackend:
         )
 
     def multipliers(self, B: int) -> np.ndarray:
-        lam = np.empty((B, 4 * self.T))
+        """Orientation-locked family: (B, 4T) signed multipliers of the quaternion rows; with inequality rows (guards):
+        (B, T, NC) multipliers >= 0 in the row order of oh_guards."""
+        lam = np.empty((B, self.T, self.n_rows)) if self.guards is not None else np.empty((B, 4 * self.T))
         _lib.check(_lib.load().oh_get_multipliers(self._h, int(B), _lib._ptr(lam)), "oh_get_multipliers")
         return lam
 

@@ -159,6 +159,36 @@ class OptimizationBuilder:
             self._eq_constraints[name] = diff
 
     # ---- common constraints ----------------------------------------------------------------------------
+    def sphere_collision_avoidance_constraints(self, name: str, obstacle_names, link_names=None, base_link=None, *, link_radii_prefix: str = "") -> None:
+        """builder.py:366-417: for every knot t, link l and obstacle j the row ||p_l(q_t) - o_j||^2 - (r_l + r_j)^2 >= 0;
+        creates the parameters "{link}_radii", "{obs}_position" (3) and "{obs}_radii" in that order.  ``link_radii_prefix``
+        is an additive extension: the reference names the link-radius parameters after the bare link name, so two robots
+        built from the same URDF collide on them (KeyError, sx_container.py:50-51); a prefix lifts that."""
+        model = self.get_model(name)
+        assert isinstance(model, RobotModel), "this method only applies to robot models"
+        if base_link is not None and base_link != model.get_root_link():
+            raise NotImplementedError("sphere constraints are lowered in the root frame only")
+        Q = self.get_model_states(name)
+        n = Q.shape[1]
+        if link_names is None:
+            link_names = model.link_names
+        assert len(link_names), "at least one link should be named"
+        links = {}
+        for ln in link_names:
+            links[ln] = self.add_parameter(link_radii_prefix + ln + "_radii")
+        assert len(obstacle_names), "at least one obstacle should be named"
+        obstacles = {}
+        for on in obstacle_names:
+            obstacles[on] = (self.add_parameter(on + "_position", 3), self.add_parameter(on + "_radii"))
+        for t in range(n):
+            q = Q[:, t]
+            for ln, linkrad in links.items():
+                p = model.get_global_link_position(ln, q)
+                for on, (obs, obsrad) in obstacles.items():
+                    dist2 = SumSqr(Sub(p, obs))
+                    bnd2 = (linkrad + obsrad) ** 2
+                    self.add_leq_inequality_constraint(f"sphere_col_avoid_{t}_{ln}_{on}", bnd2, dist2)
+
     def integrate_model_states(self, name: str, time_deriv: int, dt) -> None:
         n = self.T - (1 if self.derivs_align else time_deriv)
         dt = np.asarray(dt, dtype=np.float64).reshape(-1)

@@ -43,6 +43,13 @@ struct oh_handle {
   oh_pointmass_desc pm{};
   PmParams PmP{};
   PmBuffers PmD{};
+  // inequality rows of the position-tracking family
+  bool have_guards = false;
+  oh_guards guards{};
+  GuardParams GP{};
+  GuardBuffers GB{};
+  void* gpool = nullptr;
+  int gcap = 0;
   // inverse-kinematics family
   oh_ik_desc ik{};
   double* d_ik_mult = nullptr;
@@ -241,6 +248,7 @@ static int ik_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   const int N = h->ik.ndof;
   if (B > h->ik_cap) {
     if (h->d_ik_mult) hipFree(h->d_ik_mult);
+  if (h->gpool) hipFree(h->gpool);
     h->d_ik_mult = nullptr;
     h->ik_cap = 0;
     HIPCHK(hipMalloc((void**)&h->d_ik_mult, sizeof(double) * (3 + 2 * (size_t)N) * B));
@@ -435,6 +443,76 @@ static int ensure_capacity(oh_handle* h, int B) {
   return OH_OK;
 }
 
+extern "C" int oh_set_guards(oh_handle* h, const oh_guards* g) {
+  if (!h || !g) return fail(OH_ERR_INVALID, "oh_set_guards: null argument");
+  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT || h->desc.lock_orientation)
+    return fail(OH_ERR_INVALID, "oh_set_guards: inequality rows are lowered for the position-tracking family (lock_orientation = 0) only");
+  if (g->n_links < 0 || g->n_links > OH_MAX_SPHERE_LINKS || g->n_obstacles < 0 || g->n_obstacles > OH_MAX_OBSTACLES)
+    return fail(OH_ERR_INVALID, "oh_set_guards: too many sphere links / obstacles");
+  if ((g->n_links == 0) != (g->n_obstacles == 0)) return fail(OH_ERR_INVALID, "oh_set_guards: sphere rows need both links and obstacles");
+  if (!g->limits && g->n_links == 0) return fail(OH_ERR_INVALID, "oh_set_guards: no rows");
+  for (int l = 0; l < g->n_links; ++l)
+    if (g->link_joint[l] < 0 || g->link_joint[l] >= h->desc.ndof)
+      return fail(OH_ERR_INVALID, "oh_set_guards: sphere links must hang on an actuated joint of the chain");
+  if (g->limits)
+    for (int j = 0; j < h->desc.ndof; ++j)
+      if (!(g->q_lo[j] < g->q_up[j])) return fail(OH_ERR_INVALID, "oh_set_guards: q_lo must be below q_up");
+  h->guards = *g;
+  h->have_guards = true;
+  return OH_OK;
+}
+
+static int ensure_guards(oh_handle* h) {
+  const int N = h->desc.ndof, T = h->desc.T;
+  const oh_guards& g = h->guards;
+  GuardParams& GP = h->GP;
+  GP = GuardParams{};
+  GP.limits = g.limits ? 1 : 0;
+  GP.n_links = g.n_links;
+  GP.n_obs = g.n_obstacles;
+  GP.NC = (g.limits ? 2 * N : 0) + g.n_links * g.n_obstacles;
+  for (int l = 0; l < g.n_links; ++l) {
+    GP.link_joint[l] = g.link_joint[l];
+    for (int i = 0; i < 3; ++i) GP.link_off[l][i] = g.link_offset[l][i];
+  }
+  for (int j = 0; j < N; ++j) {
+    GP.lo[j] = g.q_lo[j];
+    GP.up[j] = g.q_up[j];
+  }
+  GP.rho0 = g.rho0 > 0.0 ? g.rho0 : 10.0 * h->desc.w_path;
+  const int Bp = h->D.Bp;
+  if (!h->gpool || h->gcap != Bp) {
+    if (h->gpool) hipFree(h->gpool);
+    h->gpool = nullptr;
+    const size_t npar = (size_t)g.n_links + 4 * (size_t)g.n_obstacles;
+    const size_t nd = (size_t)T * GP.NC * Bp + npar * Bp + 2 * (size_t)T * Bp + 5 * (size_t)Bp;
+    const size_t bytes = nd * sizeof(double) + 2 * (size_t)Bp * sizeof(int);
+    hipError_t e = hipMalloc(&h->gpool, bytes);
+    if (e != hipSuccess) return fail(OH_ERR_HIP, std::string("guard pool allocation failed: ") + hipGetErrorString(e));
+    hipMemsetAsync(h->gpool, 0, bytes, h->stream);
+    h->gcap = Bp;
+    double* d = (double*)h->gpool;
+    auto take = [&](size_t n) { double* r = d; d += n; return r; };
+    GuardBuffers& GB = h->GB;
+    GB.lam = take((size_t)T * GP.NC * Bp);
+    GB.par = take(npar * Bp);
+    GB.psi[0] = take((size_t)T * Bp);
+    GB.psi[1] = take((size_t)T * Bp);
+    GB.rho = take(Bp);
+    GB.rho_next = take(Bp);
+    GB.omega = take(Bp);
+    GB.meas_prev = take(Bp);
+    h->D.fpsi = take(Bp);
+    int* ip = (int*)d;
+    GB.outer = ip; ip += Bp;
+    GB.n_outer = ip;
+  } else {
+    // D.fpsi lives in the guard pool; ensure_capacity may have rebuilt FigBuffers
+    h->D.fpsi = h->GB.meas_prev + Bp;
+  }
+  return OH_OK;
+}
+
 static void fill_params(oh_handle* h) {
   FigParams& P = h->P;
   const oh_problem_desc& d = h->desc;
@@ -455,6 +533,7 @@ static void fill_params(oh_handle* h) {
   P.hessian = d.hessian;
   P.mu0 = d.mu0;
   P.local_path = h->d_local_path;
+  P.np = d.ndof + (h->have_guards ? h->guards.n_links + 4 * h->guards.n_obstacles : 0);
 }
 
 extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt,
@@ -472,6 +551,13 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   int rc = ensure_capacity(h, B);
   if (rc) return rc;
   fill_params(h);
+  const bool guarded = h->have_guards;
+  if (guarded) {
+    rc = ensure_guards(h);
+    if (rc) return rc;
+  } else {
+    h->D.fpsi = nullptr;
+  }
   const int N = h->desc.ndof;
   hipStream_t s = h->stream;
   const bool prof = h->profiling;
@@ -488,6 +574,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   HIPCHK(hipMemsetAsync(h->D.work, 0, 3 * sizeof(unsigned long long), s));
   if (!oh_launch_setup(s, N, h->P, h->D, (const double*)d_x0, (const double*)d_p))
     return fail(OH_ERR_INVALID, "oh_solve_device: unsupported ndof");
+  if (guarded) oh_launch_setup_guards(s, N, h->P, h->D, h->GP, h->GB, (const double*)d_p);
   size_t ne = 0;
   h->prof_tags.clear();
   if (prof) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(0); }
@@ -515,6 +602,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     rebase = false;
     const int slot = it & 1;
     if (h->P.lock) oh_launch_eval(s, N, h->P, h->D, slot);
+    else if (guarded) oh_launch_eval_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else oh_launch_eval_free(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(1); }
     if (h->P.lock) oh_launch_couple(s, N, h->P, h->D, slot);
@@ -523,6 +611,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     if (check) HIPCHK(hipMemsetAsync(h->D.n_running, 0, sizeof(int), s));
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(3); }
     if (h->P.lock) oh_launch_step(s, N, h->P, h->D, slot);
+    else if (guarded) oh_launch_step_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else oh_launch_step_free(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(2); }
     ++launched;
@@ -544,7 +633,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
         tail_done = true;
         break;
       }
-      if (h->compaction && h->D.B >= 512 && 2 * nrun <= h->D.B) {
+      if (h->compaction && !guarded && h->D.B >= 512 && 2 * nrun <= h->D.B) {
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
         oh_launch_scan_running(s, h->D);
         oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
@@ -616,7 +705,7 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
   const bool pmk = h->desc.kind == OH_PROBLEM_POINT_MASS_MPC;
   const bool ikk = h->desc.kind == OH_PROBLEM_IK;
   const size_t nx = pmk ? 4 * (size_t)T : (ikk ? (size_t)N : (size_t)N * T + (size_t)N * (T - 1));
-  const size_t npar = pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (size_t)N);
+  const size_t npar = pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0));
   const size_t b_x = sizeof(double) * nx * B, b_p = sizeof(double) * npar * (size_t)B;
   const size_t b_f = sizeof(double) * B, b_k = sizeof(double) * 3 * (size_t)B, b_i = sizeof(int) * (size_t)B;
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -650,6 +739,16 @@ extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
   HIPCHK(hipSetDevice(h->device));
   if (h->desc.kind == OH_PROBLEM_IK) {
     HIPCHK(hipMemcpy(lam_h, h->d_ik_mult, sizeof(double) * (3 + 2 * (size_t)h->ik.ndof) * B, hipMemcpyDeviceToHost));
+    return OH_OK;
+  }
+  if (h->have_guards) {
+    // SoA [T][NC][Bp] on the device -> [B][T][NC] for the caller
+    const int T = h->desc.T, NC = h->GP.NC, Bp = h->D.Bp;
+    std::vector<double> tmp((size_t)T * NC * Bp);
+    HIPCHK(hipMemcpy(tmp.data(), h->GB.lam, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < T; ++t)
+        for (int i = 0; i < NC; ++i) lam_h[((size_t)b * T + t) * NC + i] = tmp[((size_t)t * NC + i) * Bp + b];
     return OH_OK;
   }
   if (!h->D.lam_h) return fail(OH_ERR_STATE, "oh_get_multipliers: this problem has no nonlinear equality rows");
@@ -771,6 +870,7 @@ extern "C" void oh_destroy(oh_handle* h) {
   for (hipEvent_t e : h->prof_events) hipEventDestroy(e);
   if (h->pool) hipFree(h->pool);
   if (h->d_ik_mult) hipFree(h->d_ik_mult);
+  if (h->gpool) hipFree(h->gpool);
   if (h->stage) hipFree(h->stage);
   if (h->d_chain) hipFree(h->d_chain);
   if (h->d_dyn) hipFree(h->d_dyn);

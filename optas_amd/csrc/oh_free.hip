@@ -88,6 +88,211 @@ __global__ __launch_bounds__(256) void k_eval_free(FigParams P, FigBuffers D, co
   for (int i = 0; i < NP; ++i) D.Dr[slot][IDX(t, NP, i)] = W[i];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Inequality rows (oh_guards): joint limits and sphere clearances enter the stage cost through the
+// Powell-Hestenes-Rockafellar augmented Lagrangian  psi(g, lam, rho) = (max(0, lam - rho g)^2 - lam^2) / (2 rho),
+// Gauss-Newton curvature rho dg dg^T on the rows with lam - rho g > 0.  The sphere rows of link l are processed
+// inside the kinematics walk, right after the joint the link hangs on: its centre c_l and the columns
+// z_j x (c_l - p_j), j <= joint(l), of its position Jacobian only need the frames already visited.
+// (oracle restatement: oracle/guarded.py)
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+OH_DEV void guard_row(const double gval, const double (&dg)[N], const double rho, const double rho_old, const bool upd, double* __restrict__ lam_ptr,
+                      double& psi, double& meas, double (&g)[N], double (&W)[N * (N + 1) / 2]) {
+  double lam = *lam_ptr;
+  if (upd) {
+    lam = fmax(0.0, lam - rho_old * gval);
+    *lam_ptr = lam;
+  }
+  const double s = lam - rho * gval;
+  meas = fmax(meas, fabs(fmin(gval, lam / rho)));
+  if (s > 0.0) {
+    psi += (s * s - lam * lam) / (2.0 * rho);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      g[i] -= s * dg[i];
+#pragma unroll
+      for (int j = 0; j <= i; ++j) W[tri(i, j)] += rho * dg[i] * dg[j];
+    }
+  } else {
+    psi -= lam * lam / (2.0 * rho);
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
+  constexpr int NP = N * (N + 1) / 2;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y + P.t0;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (D.status[b] >= 0 || D.skip[b]) return;
+  const int cur = 1 - slot;
+  double q[N];
+  if (D.first[b]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) q[j] = D.q[slot][IDX(t, N, j)];
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; ++j) q[j] = D.q[cur][IDX(t, N, j)] + D.zstep[IDX(t, N, j)];
+  }
+  const bool upd = GB.outer[b] != 0;
+  const double rho_old = GB.rho[b];
+  const double rho = upd ? GB.rho_next[b] : rho_old;
+  const oh_chain* __restrict__ ch = D.chain;
+  const int NC = GP.NC;
+  const int nl = GP.limits ? 2 * N : 0;
+  double g[N], W[NP], psi = 0.0, meas = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) g[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) W[i] = 0.0;
+  // ---- kinematics walk (same arithmetic as fk_chain) with the sphere rows hooked in ----
+  double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0}, p[3] = {0.0, 0.0, 0.0}, z[N][3], pj[N][3];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double tv[3];
+    mv3(R, ch->p0[k], tv);
+    p[0] += tv[0]; p[1] += tv[1]; p[2] += tv[2];
+    if (!ch->r0ident[k]) {
+      double Rn[9];
+      mm3(R, ch->R0[k], Rn);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    }
+    pj[k][0] = p[0]; pj[k][1] = p[1]; pj[k][2] = p[2];
+    if (ch->jtype[k] == 0) {
+      double sn, cs;
+      sincos_joint(q[k], &sn, &cs);
+      const int code = ch->axcode[k];
+      if (code != 0) rot_principal_right(R, code, sn, cs, z[k]);
+      else rot_axis_right(R, ch->axis[k], sn, cs, z[k]);
+    } else {
+      mv3(R, ch->axis[k], z[k]);
+      p[0] += z[k][0] * q[k]; p[1] += z[k][1] * q[k]; p[2] += z[k][2] * q[k];
+    }
+    for (int l = 0; l < GP.n_links; ++l) {
+      if (GP.link_joint[l] != k) continue;
+      double c[3];
+      mv3(R, GP.link_off[l], c);
+      c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
+      double Jl[N][3];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        if (j <= k) {
+          if (ch->jtype[j] == 0) {
+            const double dd[3] = {c[0] - pj[j][0], c[1] - pj[j][1], c[2] - pj[j][2]};
+            cross3(z[j], dd, Jl[j]);
+          } else {
+            Jl[j][0] = z[j][0]; Jl[j][1] = z[j][1]; Jl[j][2] = z[j][2];
+          }
+        } else {
+          Jl[j][0] = Jl[j][1] = Jl[j][2] = 0.0;
+        }
+      }
+      const double rl = GB.par[(size_t)l * Bp + b];
+      for (int o = 0; o < GP.n_obs; ++o) {
+        const size_t ob = (size_t)(GP.n_links + 4 * o) * Bp + b;
+        const double d[3] = {c[0] - GB.par[ob], c[1] - GB.par[ob + Bp], c[2] - GB.par[ob + 2 * (size_t)Bp]};
+        const double rr = rl + GB.par[ob + 3 * (size_t)Bp];
+        const double gval = dot3(d, d) - rr * rr;
+        double dg[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) dg[j] = 2.0 * dot3(Jl[j], d);
+        guard_row<N>(gval, dg, rho, rho_old, upd, GB.lam + IDX(t, NC, nl + l * GP.n_obs + o), psi, meas, g, W);
+      }
+    }
+  }
+  if (GP.limits) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      // rows q_j - lo_j and up_j - q_j: gradients +e_j / -e_j
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const double gval = side ? GP.up[j] - q[j] : q[j] - GP.lo[j];
+        double* lam_ptr = GB.lam + IDX(t, NC, side * N + j);
+        double lam = *lam_ptr;
+        if (upd) {
+          lam = fmax(0.0, lam - rho_old * gval);
+          *lam_ptr = lam;
+        }
+        const double s = lam - rho * gval;
+        meas = fmax(meas, fabs(fmin(gval, lam / rho)));
+        if (s > 0.0) {
+          psi += (s * s - lam * lam) / (2.0 * rho);
+          g[j] += side ? s : -s;
+          W[tri(j, j)] += rho;
+        } else {
+          psi -= lam * lam / (2.0 * rho);
+        }
+      }
+    }
+  }
+  // ---- tracking terms (as eval_knot_free, Gauss-Newton) ----
+  double e[3], tv[3];
+  mv3(R, ch->p_tool, tv);
+  e[0] = p[0] + tv[0]; e[1] = p[1] + tv[1]; e[2] = p[2] + tv[2];
+  const double lp[3] = {P.local_path[3 * t], P.local_path[3 * t + 1], P.local_path[3 * t + 2]};
+  double r[3];
+  if (P.path_in_frame) {
+    double Rc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
+    mv3(Rc, lp, r);
+  } else {
+    r[0] = lp[0]; r[1] = lp[1]; r[2] = lp[2];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r[i] += D.ref[(size_t)i * Bp + b] - e[i];
+  const double w = P.w_path;
+  double Jp[N][3];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (ch->jtype[k] == 0) {
+      const double dd[3] = {e[0] - pj[k][0], e[1] - pj[k][1], e[2] - pj[k][2]};
+      cross3(z[k], dd, Jp[k]);
+    } else {
+      Jp[k][0] = z[k][0]; Jp[k][1] = z[k][1]; Jp[k][2] = z[k][2];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    g[i] += -2.0 * w * dot3(Jp[i], r);
+#pragma unroll
+    for (int j = 0; j <= i; ++j) W[tri(i, j)] += 2.0 * w * dot3(Jp[i], Jp[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    D.q[slot][IDX(t, N, j)] = q[j];
+    D.g[slot][IDX(t, N, j)] = g[j];
+  }
+  D.phi[slot][(size_t)t * Bp + b] = w * dot3(r, r) + psi;
+  GB.psi[slot][(size_t)t * Bp + b] = psi;
+  D.cv[slot][(size_t)t * Bp + b] = meas;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) D.Dr[slot][IDX(t, NP, i)] = W[i];
+}
+
+// guard parameters of every instance into SoA, multipliers and outer-loop state reset
+__global__ __launch_bounds__(64) void k_setup_guards(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const double* __restrict__ pin,
+                                                     const int N) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  const int npar = GP.n_links + 4 * GP.n_obs;
+  for (int i = 0; i < npar; ++i) GB.par[(size_t)i * Bp + b] = pin[(size_t)b * P.np + N + i];
+  for (int t = 0; t < P.T; ++t)
+    for (int i = 0; i < GP.NC; ++i) GB.lam[((size_t)t * GP.NC + i) * Bp + b] = 0.0;
+  GB.rho[b] = GP.rho0;
+  GB.rho_next[b] = GP.rho0;
+  GB.omega[b] = fmax(P.tol, 1e-2);
+  GB.meas_prev[b] = 1e300;
+  GB.outer[b] = 0;
+  GB.n_outer[b] = 0;
+  D.fpsi[b] = 0.0;
+}
+
 template <int N>
 __global__ __launch_bounds__(256) void k_couple_free(FigParams P, FigBuffers D, const int slot) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,8 +353,8 @@ OH_DEV void symv(const double (&A)[M * (M + 1) / 2], const double (&x)[M], doubl
   }
 }
 
-template <int N>
-OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const int b, const int ts) {
+template <int N, bool GUARD>
+OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, const int b, const int ts) {
   constexpr int NP = N * (N + 1) / 2;
   const int Bp = D.Bp;
   const int T = P.T;
@@ -158,12 +363,23 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const in
   LMState lm{D.mu[b], D.nun[b]};
   const int iters = D.iters[b];
   {
-    double f = D.fconst[b];
-    for (int t = P.t0; t < T; ++t) f += D.merit[ts][(size_t)t * Bp + b];
+    double f = D.fconst[b], fpsi = 0.0, meas = 0.0;
+    for (int t = P.t0; t < T; ++t) {
+      f += D.merit[ts][(size_t)t * Bp + b];
+      if constexpr (GUARD) {
+        fpsi += GB.psi[ts][(size_t)t * Bp + b];
+        meas = fmax(meas, D.cv[ts][(size_t)t * Bp + b]);
+      }
+    }
     bool accept;
     if (D.first[b]) {
       accept = true;
       D.first[b] = 0;
+    } else if (GUARD && GB.outer[b]) {
+      // re-evaluation of the current point after a multiplier update: the merit function itself changed
+      accept = true;
+      GB.outer[b] = 0;
+      GB.rho[b] = GB.rho_next[b];
     } else {
       accept = lm_accept(P, f, 0.0, D.f_cur[b], D.pred[b], lm);
       D.nun[b] = lm.nun;
@@ -171,7 +387,8 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const in
     if (accept) {
       cur = ts;
       D.f_cur[b] = f;
-      D.feas[b] = 0.0;
+      D.feas[b] = meas;
+      if constexpr (GUARD) D.fpsi[b] = fpsi;
     }
     D.cur[b] = cur;
     if (!accept) {
@@ -227,10 +444,41 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const in
     mu = fmax(4.0 * mu, 1e-2);
   }
   D.stat[b] = stat;
-  if (stat <= P.tol) {
-    D.status[b] = OH_STATUS_CONVERGED;
-    D.mu[b] = mu;
-    return false;
+  if constexpr (GUARD) {
+    if (stat <= GB.omega[b]) {
+      const double meas = D.feas[b];
+      if (stat <= P.tol && meas <= P.tol_feas) {
+        D.status[b] = OH_STATUS_CONVERGED;
+        D.mu[b] = mu;
+        return false;
+      }
+      if (iters >= P.max_iter) {
+        D.status[b] = OH_STATUS_MAX_ITER;
+        D.mu[b] = mu;
+        return false;
+      }
+      // outer iteration: stay where we are, let the next evaluation refresh the multipliers, tighten the inner tolerance
+      const double rho = GB.rho[b];
+      GB.rho_next[b] = (meas > 0.25 * GB.meas_prev[b]) ? fmin(10.0 * rho, 1e8) : rho;
+      GB.meas_prev[b] = meas;
+      GB.omega[b] = fmax(P.tol, fmin(GB.omega[b], 0.1 * meas));
+      GB.outer[b] = 1;
+      GB.n_outer[b] += 1;
+      for (int t = P.t0; t < T; ++t) {
+#pragma unroll
+        for (int a = 0; a < N; ++a) D.zstep[IDX(t, N, a)] = 0.0;
+      }
+      D.pred[b] = 0.0;
+      D.mu[b] = mu;
+      D.iters[b] = iters + 1;
+      return true;
+    }
+  } else {
+    if (stat <= P.tol) {
+      D.status[b] = OH_STATUS_CONVERGED;
+      D.mu[b] = mu;
+      return false;
+    }
   }
   if (iters >= P.max_iter) {
     D.status[b] = OH_STATUS_MAX_ITER;
@@ -271,8 +519,8 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const in
   return true;
 }
 
-template <int N>
-__global__ __launch_bounds__(64) void k_step_free(FigParams P, FigBuffers D, const int slot) {
+template <int N, bool GUARD>
+__global__ __launch_bounds__(64) void k_step_free(FigParams P, FigBuffers D, GuardBuffers GB, const int slot) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool alive = (b < D.B) && (D.status[b] < 0);
   const bool skipping = alive && D.skip[b];
@@ -283,7 +531,7 @@ __global__ __launch_bounds__(64) void k_step_free(FigParams P, FigBuffers D, con
   }
   bool still = skipping;
   if (skipping) D.skip[b] = 0;
-  if (running) still = step_instance_free<N>(P, D, b, slot);
+  if (running) still = step_instance_free<N, GUARD>(P, D, GB, b, slot);
   const unsigned long long m2 = __ballot(still);
   if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
 }
@@ -304,8 +552,27 @@ bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBu
 }
 bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
   const dim3 g((D.B + 63) / 64), b(64);
-  if (n == 7) hipLaunchKernelGGL(k_step_free<7>, g, b, 0, s, P, D, slot);
-  else if (n == 6) hipLaunchKernelGGL(k_step_free<6>, g, b, 0, s, P, D, slot);
+  const GuardBuffers none{};
+  if (n == 7) hipLaunchKernelGGL((k_step_free<7, false>), g, b, 0, s, P, D, none, slot);
+  else if (n == 6) hipLaunchKernelGGL((k_step_free<6, false>), g, b, 0, s, P, D, none, slot);
+  else return false;
+  return true;
+}
+bool oh_launch_setup_guards(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const double* p) {
+  hipLaunchKernelGGL(k_setup_guards, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, GP, GB, p, n);
+  return true;
+}
+bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
+  const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
+  if (n == 7) hipLaunchKernelGGL(k_eval_guarded<7>, g, b, 0, s, P, D, GP, GB, slot);
+  else if (n == 6) hipLaunchKernelGGL(k_eval_guarded<6>, g, b, 0, s, P, D, GP, GB, slot);
+  else return false;
+  return true;
+}
+bool oh_launch_step_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
+  const dim3 g((D.B + 63) / 64), b(64);
+  if (n == 7) hipLaunchKernelGGL((k_step_free<7, true>), g, b, 0, s, P, D, GB, slot);
+  else if (n == 6) hipLaunchKernelGGL((k_step_free<6, true>), g, b, 0, s, P, D, GB, slot);
   else return false;
   return true;
 }

@@ -23,6 +23,27 @@ struct FigParams {
   int hessian;
   double mu0;
   const double* local_path;  // device, [T][3]
+  int np;            // row stride of the parameter matrix p (ndof, or ndof + guard parameters)
+};
+
+// Inequality rows of the position-tracking family (oh_guards): constants and per-instance state.
+struct GuardParams {
+  int limits, n_links, n_obs, NC;  // NC = 2 N limits + n_links n_obs rows per knot
+  int link_joint[OH_MAX_SPHERE_LINKS];
+  double link_off[OH_MAX_SPHERE_LINKS][3];
+  double lo[OH_MAX_CHAIN], up[OH_MAX_CHAIN];
+  double rho0;
+};
+struct GuardBuffers {
+  double* lam;        // [T][NC][Bp]  multipliers of the last outer update
+  double* par;        // [n_links + 4 n_obs][Bp]  link radii, then x, y, z, r of each obstacle
+  double* psi[2];     // [slot][T][Bp] augmented-Lagrangian part of phi
+  double* rho;        // [Bp] penalty the stored stage data was evaluated with
+  double* rho_next;   // [Bp] penalty after the pending outer update
+  double* omega;      // [Bp] inner tolerance on the reduced gradient
+  double* meas_prev;  // [Bp] |min(g, lam/rho)|_inf at the previous outer update
+  int* outer;         // [Bp] 1: the next evaluation first refreshes the multipliers (outer iteration)
+  int* n_outer;       // [Bp]
 };
 
 // Device buffers of one handle (SoA, instance index fastest; Bp = B rounded up to 64).
@@ -50,6 +71,7 @@ struct FigBuffers {
   double* nun;            // [Bp]  Nielsen growth factor
   double* stat;           // [Bp]
   double* feas;           // [Bp]
+  double* fpsi;           // [Bp] augmented-Lagrangian part of f_cur (nullptr without inequality rows)
   int* cur;               // [Bp] slot holding the accepted point
   int* first;             // [Bp]
   int* skip;              // [Bp] 1: last trial rejected -> sit the next launch out (keeps the slot parity uniform)
@@ -72,6 +94,9 @@ bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& 
 bool oh_launch_eval_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_launch_setup_guards(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const double* p);
+bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
+bool oh_launch_step_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
 bool oh_launch_tail(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
                         int* iters, int* status);

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
   const oh_chain* ch = D.chain;
   double qc[N];
 #pragma unroll
-  for (int j = 0; j < N; ++j) qc[j] = pin[(size_t)b * N + j];
+  for (int j = 0; j < N; ++j) qc[j] = pin[(size_t)b * P.np + j];
   double R[9], p[3], z[N][3], pj[N][3];
   fk_chain<N>(ch, qc, R, p, z, pj);
   double e[3], t[3], Re[9];
@@ -866,11 +866,11 @@ __global__ __launch_bounds__(256) void k_finalize(FigParams P, FigBuffers D, int
   }
   if (D.lam_h) knot_multipliers<N>(P, D, b, t, cur, D.lam_h + (ob * P.T + t) * 4);
   if (t == 0) {
-    if (f) f[ob] = D.f_cur[b];
+    if (f) f[ob] = D.f_cur[b] - (D.fpsi ? D.fpsi[b] : 0.0);
     if (kkt) {
       kkt[3 * ob + 0] = D.stat[b];
       kkt[3 * ob + 1] = D.feas[b];
-      kkt[3 * ob + 2] = 0.0;  // no inequality rows in this family
+      kkt[3 * ob + 2] = D.fpsi ? D.feas[b] : 0.0;  // with inequality rows feas = |min(g, lam/rho)|_inf covers both
     }
     if (iters) iters[ob] = D.iters[b];
     if (status) status[ob] = (st < 0) ? OH_STATUS_MAX_ITER : st;

@@ -47,6 +47,11 @@ class Expr:
     def __neg__(self):
         return Scale(-1.0, self)
 
+    def __pow__(self, k):
+        if k == 2:
+            return Square(self)
+        return NotImplemented
+
     def numel(self) -> int:
         return self.shape[0] * self.shape[1]
 
@@ -264,6 +269,20 @@ class SumSqr(Expr):
 
     def __post_init__(self):
         self.shape = (1, 1)
+
+    def degree(self):
+        d = self.a.degree()
+        return 0 if d == 0 else (2 if d == 1 else 3)
+
+
+@dataclass(eq=False)
+class Square(Expr):
+    """Elementwise square, ``(linkrad + obsrad) ** 2`` in builder.py:413."""
+
+    a: Expr = None
+
+    def __post_init__(self):
+        self.shape = self.a.shape
 
     def degree(self):
         d = self.a.degree()

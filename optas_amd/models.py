@@ -245,6 +245,33 @@ class RobotModel(Model):
         return unit(joint.axis if joint.axis is not None else [1.0, 0.0, 0.0])
 
     # ---- lowering: URDF chain -> oh_chain ---------------------------------------------------------
+    def link_attachments(self, link: str, link_names) -> list:
+        """For each named link on the chain root->link: (index of the last actuated chain joint before it, position of the
+        link origin in the frame that follows that joint's motion) -- what oh_guards.link_joint / link_offset carry
+        (sphere centres of sphere_collision_avoidance_constraints, builder.py:366-417)."""
+        root = self.urdf.get_root()
+        att = {root: (-1, np.zeros(3))}
+        R_acc, p_acc = np.eye(3), np.zeros(3)
+        k = 0
+        names = self.urdf.get_chain(root, link, links=False) if link != root else []
+        for name in names:
+            joint = self.urdf.joint_map[name]
+            xyz, rpy = self.get_joint_origin(joint)
+            p_acc = p_acc + R_acc @ xyz
+            R_acc = R_acc @ rpy2r(rpy)
+            if joint.type == "fixed":
+                att[joint.child] = (k - 1, p_acc.copy())
+                continue
+            att[joint.child] = (k, np.zeros(3))
+            R_acc, p_acc = np.eye(3), np.zeros(3)
+            k += 1
+        out = []
+        for ln in link_names:
+            if ln not in att:
+                raise ValueError(f"link '{ln}' is not on the chain from '{root}' to '{link}'")
+            out.append(att[ln])
+        return out
+
     def kinematic_chain(self, link: str) -> _lib.oh_chain:
         """Fold root->link into per-actuated-joint constants (fixed joints multiplied into the next
         actuated joint's pre-transform; trailing fixed joints into the tool transform), in the order

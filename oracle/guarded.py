@@ -1,0 +1,196 @@
+"""ORACLE (test infrastructure, not product code) -- numpy port of the state machine the HIP path runs for the
+position-tracking family with inequality rows (SURVEY 8(a) B4, B5, H4 synthetic: example/dual_arm.py per arm +
+enforce_model_limits, builder.py:471-509 + sphere_collision_avoidance_constraints, builder.py:366-417):
+
+    min  sum_t w_p ||p(q_t) - path_t||^2 + (w_v/dt^2) sum_t ||q_{t+1} - q_t||^2,   q_0 = qc
+    s.t. q_t - lo >= 0,  up - q_t >= 0                                     (limits, rows "_l" / "_r")
+         ||c_l(q_t) - o_j||^2 - (r_l + r_j)^2 >= 0  for link l, obstacle j (spheres; builder.py:411-415)
+
+Inequalities enter through the Powell-Hestenes-Rockafellar augmented Lagrangian
+    psi(g, lam, rho) = (max(0, lam - rho g)^2 - lam^2) / (2 rho),
+the inner problem is the same Levenberg-Marquardt / Riccati iteration as solve_free_lm (oracle/structured.py) applied
+to L_A, and the outer iteration is lam <- max(0, lam - rho g).  Independent cross-check: scipy SLSQP on the literal
+reference layout (oracle.problems.GuardedArmNLP) and kkt_reference_form.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+"""
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+from .structured import FoldedChain, block_tridiag_solve
+
+
+@dataclass
+class Guards:
+    lo: Optional[np.ndarray] = None  # (n,) joint limits or None
+    up: Optional[np.ndarray] = None
+    links: Optional[List[str]] = None  # sphere links (on the chain)
+    link_radii: Optional[np.ndarray] = None  # (L,)
+    obs_pos: Optional[np.ndarray] = None  # (O, 3)
+    obs_radii: Optional[np.ndarray] = None  # (O,)
+
+    def n_rows(self, n):
+        nl = 2 * n if self.lo is not None else 0
+        ns = len(self.links) * len(self.obs_radii) if self.links else 0
+        return nl + ns
+
+
+def guard_values(chain: FoldedChain, Q, G: Guards, weights=None):
+    """g (T, NC) and dg (T, NC, n): rows ordered [q - lo (n); up - q (n); spheres link-major, obstacle-minor].
+    With weights (T, NC) also returns sum_i weights_i * Hessian(g_i) per knot, (T, n, n)."""
+    T, n = Q.shape
+    vals, jac = [], []
+    HW = np.zeros((T, n, n))
+    nl = 0
+    if G.lo is not None:
+        vals += [Q - G.lo[None], G.up[None] - Q]
+        eye = np.tile(np.eye(n)[None], (T, 1, 1))
+        jac += [eye, -eye]
+        nl = 2 * n
+    if G.links:
+        C, J = chain.link_positions(Q, G.links)  # (T, L, 3), (T, L, 3, n)
+        d = C[:, :, None, :] - G.obs_pos[None, None]  # (T, L, O, 3)
+        bnd = (G.link_radii[:, None] + G.obs_radii[None, :]) ** 2
+        gs = np.sum(d * d, -1) - bnd[None]
+        dgs = 2.0 * np.einsum("tlok,tlkn->tlon", d, J)
+        vals.append(gs.reshape(T, -1))
+        jac.append(dgs.reshape(T, -1, n))
+        if weights is not None:
+            # Hessian(g) = 2 J^T J + 2 sum_k d_k d2c_k,  d2c/dq_a dq_b = omega_a x J[:, b] (a <= b, both up to the link's joint)
+            L, O = len(G.links), len(G.obs_radii)
+            wts = weights[:, nl:].reshape(T, L, O)
+            _, _, z, _ = chain.fk(Q)
+            om = np.zeros((T, n, 3))
+            for k in range(chain.n_chain):
+                if chain.jtype[k] == 0:
+                    om[:, chain.qidx[k]] = z[:, k]
+            order = [chain.qidx[k] for k in range(chain.n_chain)]
+            wl = wts.sum(2)  # (T, L)
+            yd = np.einsum("tlo,tlok->tlk", wts, d)  # sum_o w d  (T, L, 3)
+            HW += 2.0 * np.einsum("tl,tlkn,tlkm->tnm", wl, J, J)
+            for li in range(L):
+                for ia, a in enumerate(order):
+                    for b in order[ia:]:
+                        v = 2.0 * np.einsum("tk,tk->t", yd[:, li], np.cross(om[:, a], J[:, li, :, b]))
+                        HW[:, a, b] += v
+                        if a != b:
+                            HW[:, b, a] += v
+    g_all, dg_all = np.concatenate(vals, 1), np.concatenate(jac, 1)
+    if weights is not None:
+        return g_all, dg_all, HW
+    return g_all, dg_all
+
+
+def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=None, w_path=1.0, w_vel=0.01, fix_dq0=False, max_iter=400,
+                  tol=1e-6, tol_feas=1e-9, rho0=1e3, verbose=False, exact=True):
+    n = chain.ndof
+    t0 = 2 if fix_dq0 else 1
+    kap = w_vel / dt**2
+    e0, _, _, _ = chain.fk(qc[None])
+    path = e0[0] + offsets
+    Qc = np.zeros((T, n)) if Q0 is None else Q0.copy()
+    Qc[:t0] = qc
+    F = slice(t0, T)
+    NC = guards.n_rows(n)
+    lam = np.zeros((T, NC))
+    rho = rho_next = rho0
+    omega = max(tol, 1e-2)
+    meas_prev = np.inf
+
+    def evalp(Q, lam, rho):
+        e, Re, Jp, Jw = chain.jac(Q)
+        r = path - e
+        phi = w_path * np.sum(r * r, 1)
+        g = -2.0 * w_path * np.einsum("tki,tk->ti", Jp, r)
+        W = 2.0 * w_path * np.einsum("tki,tkj->tij", Jp, Jp)
+        gv, dg = guard_values(chain, Q, guards)
+        s = np.maximum(0.0, lam - rho * gv)
+        s[:t0] = 0.0
+        if exact:
+            W = W - guard_values(chain, Q, guards, weights=s)[2]
+        psi = (s * s - lam * lam) / (2.0 * rho)
+        psi[:t0] = 0.0
+        phi = phi + psi.sum(1)
+        g = g - np.einsum("tc,tcn->tn", s, dg)
+        W = W + rho * np.einsum("tc,tcn,tcm->tnm", (s > 0.0).astype(float), dg, dg)
+        meas = np.abs(np.minimum(gv, lam / rho))
+        meas[:t0] = 0.0
+        d = Q[1:] - Q[:-1]
+        f = float(np.sum(phi) + kap * np.sum(d * d))
+        Gs = np.zeros_like(Q)
+        Gs[1:] += 2 * kap * d
+        Gs[:-1] -= 2 * kap * d
+        return f, g + Gs, W, gv, float(meas.max())
+
+    mu, nun = 0.0, 2.0
+    iters = rejected = outers = 0
+    first, outer = True, False
+    Qt = Qc
+    cur = None
+    status = 1
+    pred = 0.0
+    while True:
+        if outer:  # multiplier update at the current point with the old penalty, then evaluate with the new one
+            gv_now, _ = guard_values(chain, Qt, guards)
+            lam = np.maximum(0.0, lam - rho * gv_now)
+            lam[:t0] = 0.0
+            rho = rho_next
+            outers += 1
+        f_t, G, W, gv, meas_t = evalp(Qt, lam, rho)
+        if first or outer:
+            accept, first, outer = True, False, False
+        else:
+            ratio = (cur["f"] - f_t) / max(pred, 1e-300)
+            accept = np.isfinite(f_t) and (ratio > 1e-4 or (pred <= 1e-15 * abs(cur["f"]) and f_t <= cur["f"] + 1e-14 * abs(cur["f"])))
+            if accept:
+                mu *= max(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3)
+                mu = 0.0 if mu < 1e-7 else mu
+                nun = 2.0
+            else:
+                mu = max(mu * nun, 1e-3)
+                nun *= 2.0
+                rejected += 1
+        if accept:
+            ndiag = np.full(T, 2.0)
+            ndiag[T - 1] = 1.0
+            cur = {"Q": Qt, "f": f_t, "G": G[F], "D": (W + (2 * kap * ndiag)[:, None, None] * np.eye(n)[None])[F], "meas": meas_t}
+        stat = float(np.max(np.abs(cur["G"])))
+        nf = T - t0
+        Er = np.tile(-2 * kap * np.eye(n), (nf - 1, 1, 1))
+        while True:
+            z, ok = block_tridiag_solve(cur["D"], Er, -cur["G"], mu)
+            if ok:
+                break
+            mu = max(4.0 * mu, 1e-2)
+        if verbose:
+            print(f"  steps {iters:3d} f={cur['f']:.12f} stat={stat:.3e} meas={cur['meas']:.3e} mu={mu:.3g} rho={rho:.1e} omega={omega:.1e} outers={outers}")
+        if stat <= omega:
+            meas = cur["meas"]
+            if stat <= tol and meas <= tol_feas:
+                status = 0
+                break
+            if iters >= max_iter:
+                break
+            # outer update: stay at the current point, refresh multipliers, tighten the inner tolerance
+            rho_next = min(rho * 10.0, 1e8) if meas > 0.25 * meas_prev else rho
+            meas_prev = meas
+            omega = max(tol, min(omega, 0.1 * meas))
+            outer = True
+            Qt = cur["Q"]
+            iters += 1
+            continue
+        if iters >= max_iter:
+            break
+        pred = -0.5 * float(np.sum(cur["G"] * z)) + 0.5 * mu * float(np.sum(z * z))
+        Qt = cur["Q"].copy()
+        Qt[F] += z
+        iters += 1
+    gv, _ = guard_values(chain, cur["Q"], guards)
+    lam_out = np.maximum(0.0, lam - rho * gv)
+    lam_out[:t0] = 0.0
+    e, _, _, _ = chain.fk(cur["Q"])
+    f_true = float(w_path * np.sum((path - e) ** 2) + kap * np.sum(np.diff(cur["Q"], axis=0) ** 2))
+    return {"Q": cur["Q"], "f": f_true, "iters": iters, "rejected": rejected, "outers": outers, "stat": stat, "meas": cur["meas"],
+            "status": status, "lam": lam_out, "g": gv}

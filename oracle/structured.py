@@ -25,6 +25,9 @@ class FoldedChain:
         root = robot.get_root()
         R_acc, p_acc = np.eye(3), np.zeros(3)
         self.R0, self.p0, self.axis, self.jtype, self.qidx = [], [], [], [], []
+        # link name -> (index k of the last actuated chain joint before it, or -1; position of the link origin in the
+        # frame that follows joint k's rotation): p_link = p_k + R_k off  (sphere centres, builder.py:366-417)
+        self.attach = {root: (-1, np.zeros(3))}
         for name in robot.get_chain(root, link):
             j = robot.joint_map[name]
             xyz, rpy = robot.get_joint_origin(j)
@@ -32,7 +35,9 @@ class FoldedChain:
             p_acc = p_acc + R_acc @ xyz
             R_acc = R_acc @ Rj
             if j.type == "fixed":
+                self.attach[j.child] = (len(self.R0) - 1, p_acc.copy())
                 continue
+            self.attach[j.child] = (len(self.R0), np.zeros(3))
             self.R0.append(R_acc)
             self.p0.append(p_acc)
             self.axis.append(robot.get_joint_axis(j))
@@ -43,9 +48,29 @@ class FoldedChain:
         self.n_chain = len(self.R0)
         self.ndof = robot.ndof
 
-    def fk(self, Q):
-        """Q: (N, ndof).  Returns e (N,3), R (N,3,3), z (N,nc,3), pj (N,nc,3)."""
+    def link_positions(self, Q, links):
+        """Positions (N, L, 3) and linear Jacobians (N, L, 3, ndof) of the origins of the named links (on this chain)."""
         Q = np.atleast_2d(Q)
+        N = Q.shape[0]
+        e, Re, z, pj, frames = self.fk(Q, frames=True)
+        C = np.zeros((N, len(links), 3))
+        J = np.zeros((N, len(links), 3, self.ndof))
+        for li, name in enumerate(links):
+            k, off = self.attach[name]
+            if k < 0:
+                C[:, li] = off
+                continue
+            Rk, pk = frames[k]
+            C[:, li] = pk + Rk @ off
+            for j in range(k + 1):
+                c = self.qidx[j]
+                J[:, li, :, c] = np.cross(z[:, j], C[:, li] - pj[:, j]) if self.jtype[j] == 0 else z[:, j]
+        return C, J
+
+    def fk(self, Q, frames=False):
+        """Q: (N, ndof).  Returns e (N,3), R (N,3,3), z (N,nc,3), pj (N,nc,3) [, per-joint (R, p) after the joint motion]."""
+        Q = np.atleast_2d(Q)
+        fr = []
         N = Q.shape[0]
         R = np.tile(np.eye(3), (N, 1, 1))
         p = np.zeros((N, 3))
@@ -65,8 +90,11 @@ class FoldedChain:
                 ps.append(p.copy())
                 p = p + z * qk[:, None]
             zs.append(z)
+            fr.append((R.copy(), p.copy()))
         e = p + R @ self.p_tool
         Re = R @ self.R_tool
+        if frames:
+            return e, Re, np.stack(zs, 1), np.stack(ps, 1), fr
         return e, Re, np.stack(zs, 1), np.stack(ps, 1)
 
     def jac(self, Q):

@@ -31,7 +31,24 @@ def path_offsets(T, d1, d2):
     return off
 
 
-def setup_solver(T=50, Tmax=10.0, solver_options=None, build_only=False):
+SPHERE_LINKS = ["end_effector_ball", "lwr_arm_7_link", "lwr_arm_5_link", "lwr_arm_6_link"]  # sphere_collision_avoidance.py:95
+N_OBSTACLES = 6  # sphere_collision_avoidance.py:46-51
+
+
+def obstacle_parameters(link_radius=0.15, obstacle_radius=0.1):
+    """Parameter values of the synthetic config 4: a column of six spheres at x = 0.55, y = 0, z = 0.1 ... 0.6
+    between the arms (sphere_collision_avoidance.py:46-53)."""
+    p = {}
+    for arm in ("kukal", "kukar"):
+        for ln in SPHERE_LINKS:
+            p[f"{arm}_{ln}_radii"] = link_radius
+        for i in range(N_OBSTACLES):
+            p[f"{arm}_obs{i}_position"] = np.array([0.55, 0.0, 0.1 * (i + 1)])
+            p[f"{arm}_obs{i}_radii"] = obstacle_radius
+    return p
+
+
+def setup_solver(T=50, Tmax=10.0, solver_options=None, build_only=False, limits=False, collision=False):
     link_ee = "end_effector_ball"
     t = np.linspace(0, Tmax, T)
     dt = float(t[1] - t[0])
@@ -59,6 +76,16 @@ def setup_solver(T=50, Tmax=10.0, solver_options=None, build_only=False):
     path_eer = pos0r + path_offsets(T, [-0.1, -0.1, -0.2], [0.0, 0.0, 0.3])
     builder.add_cost_term("ee_pos_pathl", sumsqr(ee_pos_pathl - path_eel))
     builder.add_cost_term("ee_pos_pathr", sumsqr(ee_pos_pathr - path_eer))
+    # synthetic extensions of BASELINE config 4 (not in the shipped script): joint limits and sphere clearances per arm.
+    # The reference names link-radius and obstacle parameters without the robot name, so the second arm would collide
+    # on them (KeyError); hence per-arm obstacle names and the link_radii_prefix extension.
+    if limits:
+        builder.enforce_model_limits(kukal_name)
+        builder.enforce_model_limits(kukar_name)
+    if collision:
+        for arm in (kukal_name, kukar_name):
+            builder.sphere_collision_avoidance_constraints(arm, [f"{arm}_obs{i}" for i in range(N_OBSTACLES)], link_names=SPHERE_LINKS,
+                                                           link_radii_prefix=arm + "_")
     optimization = builder.build()
     if build_only:
         return (kukal, kukar), optimization

@@ -268,9 +268,24 @@ class MultiArmBackend:
         self.poff = opt.parameters.offsets()
         self.arms = []
         for a in spec.arms:
+            guards = None
+            if a.guards is not None:
+                gs = a.guards
+                guards = _lib.oh_guards()
+                guards.limits = 1 if gs.lo is not None else 0
+                if gs.lo is not None:
+                    for j in range(a.robot.ndof):
+                        guards.q_lo[j], guards.q_up[j] = float(gs.lo[j]), float(gs.up[j])
+                guards.n_links, guards.n_obstacles = len(gs.links), len(gs.obstacles)
+                for l, (k, off) in enumerate(a.robot.link_attachments(a.link, gs.links)):
+                    if k < 0:
+                        raise NotImplementedError(f"sphere link '{gs.links[l]}' does not move with any joint of the chain to '{a.link}'")
+                    guards.link_joint[l] = k
+                    for i in range(3):
+                        guards.link_offset[l][i] = float(off[i])
             be = FigureEightBackend(
                 a.robot.kinematic_chain(a.link), spec.T, spec.dt, a.offsets, w_path=a.w_path, w_vel=a.w_vel, max_iter=max_iter, tol=tol,
-                hessian=hessian, lock_orientation=False, fix_dq0=False, path_in_frame=False,
+                hessian=hessian, lock_orientation=False, fix_dq0=False, path_in_frame=False, guards=guards,
             )
             self.arms.append((a, be))
 
@@ -287,7 +302,13 @@ class MultiArmBackend:
             n, T = be.ndof, be.T
             oq, odq, op = self.xoff[a.q_name], self.xoff[a.dq_name], self.poff[a.qc_name]
             xa = np.concatenate([x0[:, oq : oq + n * T], x0[:, odq : odq + n * (T - 1)]], axis=1)
-            r = be.solve(xa, p[:, op : op + n])
+            pa = p[:, op : op + n]
+            if a.guards is not None:
+                cols = [pa] + [p[:, [self.poff[lr]]] for lr in a.guards.link_radii]
+                for pos, rad in a.guards.obstacles:
+                    cols += [p[:, self.poff[pos] : self.poff[pos] + 3], p[:, [self.poff[rad]]]]
+                pa = np.ascontiguousarray(np.concatenate(cols, axis=1))
+            r = be.solve(xa, pa)
             x[:, oq : oq + n * T] = r.x[:, : n * T]
             x[:, odq : odq + n * (T - 1)] = r.x[:, n * T :]
             f += r.f

@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from .builder import IntegrationResidual
-from .expr import Add, Const, LinkFunction, ParamCol, ParamRef, PathInFrame, Scale, StateCols, StateRef, Sub, SumSqr
+from .expr import Add, Const, LinkFunction, ParamCol, ParamRef, PathInFrame, Scale, Square, StateCols, StateRef, Sub, SumSqr
 from .models import RobotModel, TaskModel
 from .optimization import Optimization
 
@@ -274,6 +274,19 @@ class ArmSpec:
     qc_name: str
     q_name: str
     dq_name: str
+    guards: Optional["GuardSpec"] = None
+
+
+@dataclass
+class GuardSpec:
+    """Inequality rows of one arm: joint limits (enforce_model_limits) and sphere clearances
+    (sphere_collision_avoidance_constraints); parameter labels in the order the kernel family expects them."""
+
+    lo: Optional[np.ndarray]
+    up: Optional[np.ndarray]
+    links: list          # sphere link names
+    link_radii: list     # parameter labels, one per link
+    obstacles: list      # (position label, radius label) per obstacle
 
 
 @dataclass
@@ -292,8 +305,8 @@ def match_multi_arm(opt: Optimization) -> MultiArmSpec:
     robots = [m for m in (opt.models or []) if isinstance(m, RobotModel)]
     if not robots or len(robots) != len(opt.models or []):
         no("expected robot models only")
-    if opt.nk or opt.ng or opt.nh:
-        no("inequality rows / nonlinear equalities are not lowered for this family")
+    if opt.nh:
+        no("nonlinear equalities are not lowered for this family")
     for r in robots:
         if list(r.time_derivs) != [0, 1] or r.num_param_joints != 0:
             no("every robot must have time_derivs=[0, 1] and no parameterised joints")
@@ -340,6 +353,52 @@ def match_multi_arm(opt: Optimization) -> MultiArmSpec:
                         a["w_path"], a["link"], a["offsets"], a["qc_path"], hit = w, pos.link, np.ascontiguousarray(pth.b.value.T), pth.a.q, True
         if not hit:
             no(f"cost '{label}' not recognised")
+    # inequality rows: joint limits (linear) and sphere clearances (nonlinear), per arm
+    for label, d in opt.lin_ineq_constraints.items():
+        hit = False
+        for a in arms.values():
+            n = a["robot"].ndof
+            if isinstance(d, Sub) and d.a is a["Q"] and isinstance(d.b, Const) and d.b.value.shape == (n, 1):
+                a["lo"], hit = np.maximum(a.get("lo", np.full(n, -np.inf)), d.b.value[:, 0]), True
+            elif isinstance(d, Sub) and d.b is a["Q"] and isinstance(d.a, Const) and d.a.value.shape == (n, 1):
+                a["up"], hit = np.minimum(a.get("up", np.full(n, np.inf)), d.a.value[:, 0]), True
+        if not hit:
+            no(f"linear inequality '{label}' is not a joint-position bound over the whole trajectory")
+    for label, d in opt.ineq_constraints.items():
+        ok = (isinstance(d, Sub) and isinstance(d.a, SumSqr) and isinstance(d.a.a, Sub) and isinstance(d.a.a.a, LinkFunction)
+              and d.a.a.a.what == "position" and isinstance(d.a.a.b, ParamRef) and d.a.a.b.shape == (3, 1)
+              and isinstance(d.b, Square) and isinstance(d.b.a, Add) and isinstance(d.b.a.a, ParamRef) and isinstance(d.b.a.b, ParamRef)
+              and isinstance(d.a.a.a.q, StateRef) and d.a.a.a.q.t is not None and d.a.a.a.q.model_name in arms)
+        if not ok:
+            no(f"inequality '{label}' is not a sphere clearance ||p_link(q_t) - o||^2 >= (r_link + r_o)^2")
+        pos = d.a.a.a
+        a = arms[pos.q.model_name]
+        if pos.robot is not a["robot"] or pos.q.var_name != a["Q"].var_name:
+            no(f"inequality '{label}' mixes models")
+        a.setdefault("spheres", {})[(pos.q.t, pos.link, d.a.a.b.name)] = (d.b.a.a.name, d.b.a.b.name)
+    for name, a in arms.items():
+        if ("lo" in a) != ("up" in a):
+            no(f"robot '{name}': joint limits need both the lower and the upper row block")
+        g = None
+        sph = a.get("spheres")
+        if sph:
+            links, obst = [], []
+            for (t, ln, on) in sph:
+                if ln not in links:
+                    links.append(ln)
+                if on not in obst:
+                    obst.append(on)
+            if len(sph) != T * len(links) * len(obst):
+                no(f"robot '{name}': sphere rows must cover every (knot, link, obstacle) combination")
+            lrad = {ln: sph[(0, ln, obst[0])][0] for ln in links}
+            orad = {on: sph[(0, links[0], on)][1] for on in obst}
+            for (t, ln, on), (lr, orr) in sph.items():
+                if lr != lrad[ln] or orr != orad[on]:
+                    no(f"robot '{name}': inconsistent radius parameters in the sphere rows")
+            g = GuardSpec(a.get("lo"), a.get("up"), links, [lrad[ln] for ln in links], [(on, orad[on]) for on in obst])
+        elif "lo" in a:
+            g = GuardSpec(a["lo"], a["up"], [], [], [])
+        a["guards"] = g
     out = []
     for name, a in arms.items():
         need = {"qc", "integr", "w_vel", "w_path"}
@@ -347,10 +406,14 @@ def match_multi_arm(opt: Optimization) -> MultiArmSpec:
             no(f"robot '{name}' is missing {sorted(need - set(a))}")
         if a["qc_path"] is not a["qc"]:
             no(f"robot '{name}': the path must start from the fixed initial configuration parameter")
-        out.append(ArmSpec(a["robot"], a["link"], a["w_path"], a["w_vel"], a["offsets"], a["qc"].name, a["Q"].var_name, a["dQ"].var_name))
+        out.append(ArmSpec(a["robot"], a["link"], a["w_path"], a["w_vel"], a["offsets"], a["qc"].name, a["Q"].var_name, a["dQ"].var_name, a["guards"]))
     params = [k for k, v in opt.parameters.items() if v.numel() > 0]
-    if sorted(params) != sorted(a.qc_name for a in out):
-        no("the only non-empty parameters must be the initial configurations")
+    known = set(a.qc_name for a in out)
+    for a in out:
+        if a.guards is not None:
+            known |= set(a.guards.link_radii) | set(x for ob in a.guards.obstacles for x in ob)
+    if set(params) != known:
+        no("parameters other than the initial configurations and the sphere radii / obstacle positions are present")
     return MultiArmSpec(T, dt, out)
 
 

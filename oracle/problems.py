@@ -478,3 +478,93 @@ class DualArmNLP(_NLPBase):
 
     def da(self, x, p):
         return self._A
+
+
+class GuardedDualArmNLP(DualArmNLP):
+    """BASELINE config 4 with the synthetic extensions of SURVEY 8(a) H4 / 8(d) C4: example/dual_arm.py plus, per arm,
+    enforce_model_limits (builder.py:471-509) and sphere_collision_avoidance_constraints (builder.py:366-417).
+
+    p = [qcl(7); qcr(7); per arm: link radii (L); per obstacle: position (3), radius (1)]      (builder.py:391-405 order)
+    k = [Ql - lo; up - Ql; Qr - lo; up - Qr]   each block vec of a 7 x T array                 (rows "_l", "_r")
+    g = per arm, knot-major, link, obstacle:  ||p_link(q_t) - o||^2 - (r_link + r_o)^2          (builder.py:407-415)
+    """
+
+    def __init__(self, robot_l, robot_r, links, n_obs, link="end_effector_ball", T=50, Tmax=10.0, w_dq=0.01, limits=True):
+        super().__init__(robot_l, robot_r, link=link, T=T, Tmax=Tmax, w_dq=w_dq)
+        from .structured import FoldedChain
+
+        self.links, self.n_obs, self.limits = list(links), n_obs, limits
+        self.chains = {arm: FoldedChain(self.robots[arm], link) for arm in ("l", "r")}
+        L = len(self.links)
+        self.npar_arm = L + 4 * n_obs
+        self.np_ = 2 * self.n + 2 * self.npar_arm
+        self.nk = 4 * self.n * T if limits else 0
+        self.ng = 2 * T * L * n_obs
+
+    def arm_params(self, p, k):
+        n, L = self.n, len(self.links)
+        q = p[2 * n + k * self.npar_arm : 2 * n + (k + 1) * self.npar_arm]
+        ob = q[L:].reshape(self.n_obs, 4)
+        return q[:L], ob[:, :3], ob[:, 3]
+
+    def _guards(self, p, k):
+        from .guarded import Guards
+
+        lr, op, orad = self.arm_params(p, k)
+        return Guards(lo=None, up=None, links=self.links, link_radii=lr, obs_pos=op, obs_radii=orad)
+
+    def k(self, x, p):
+        if not self.limits:
+            return np.zeros(0)
+        s = self.split(x)
+        out = []
+        for arm in ("l", "r"):
+            Q = s[arm][0]
+            lo, up = self.robots[arm].lower_actuated_joint_limits, self.robots[arm].upper_actuated_joint_limits
+            out += [(Q - lo[:, None]).T.reshape(-1), (up[:, None] - Q).T.reshape(-1)]
+        return np.concatenate(out)
+
+    def dk(self, x, p):
+        n, T = self.n, self.T
+        M = np.zeros((self.nk, self.nx))
+        if self.limits:
+            I = np.eye(n * T)
+            for k in range(2):
+                base = k * self.nx1
+                M[(2 * k) * n * T : (2 * k + 1) * n * T, base : base + n * T] = I
+                M[(2 * k + 1) * n * T : (2 * k + 2) * n * T, base : base + n * T] = -I
+        return M
+
+    def g(self, x, p):
+        from .guarded import guard_values
+
+        s = self.split(x)
+        return np.concatenate([guard_values(self.chains[arm], s[arm][0].T, self._guards(p, k))[0].reshape(-1) for k, arm in enumerate(("l", "r"))])
+
+    def dg(self, x, p):
+        from .guarded import guard_values
+
+        n, T = self.n, self.T
+        s = self.split(x)
+        per = T * len(self.links) * self.n_obs
+        M = np.zeros((self.ng, self.nx))
+        for k, arm in enumerate(("l", "r")):
+            d = guard_values(self.chains[arm], s[arm][0].T, self._guards(p, k))[1]  # (T, L*O, n)
+            rows = d.shape[1]
+            for t in range(T):
+                M[k * per + t * rows : k * per + (t + 1) * rows, k * self.nx1 + n * t : k * self.nx1 + n * (t + 1)] = d[t]
+        return M
+
+    def a(self, x, p):
+        b = np.zeros(self.na)
+        b[: 2 * self.n] = p[: 2 * self.n]
+        return self._A @ x + b
+
+    def _paths(self, p):
+        return p[: 2 * self.n]
+
+    def f(self, x, p):
+        return super().f(x, p[: 2 * self.n])
+
+    def df(self, x, p):
+        return super().df(x, p[: 2 * self.n])

@@ -1,0 +1,139 @@
+"""Synthetic config 4 (dual_arm.py + joint limits + sphere clearances) on the GPU: HIPSolver / the
+C ABI against the oracle.  Tolerances: objective 1e-8 vs the golden optimum (scipy SLSQP in the reference wiring == the
+augmented-Lagrangian port), reference-form KKT stationarity <= 1e-6, feasibility <= 1e-9, complementarity <= 1e-8; the
+iteration counts equal the numpy port's (same state machine)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, KUKA_KIN, SEED
+from oracle.guarded import Guards, guard_values, solve_free_al
+from oracle.problems import GuardedDualArmNLP, dual_arm_offsets
+from oracle.robot import OracleRobot
+from oracle.solvers import kkt_reference_form
+from oracle.structured import FoldedChain
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from examples.dual_arm import N_OBSTACLES, SPHERE_LINKS, obstacle_parameters, setup_solver  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
+
+
+def _robots():
+    rl = OracleRobot(KUKA_KIN, name="kukal")
+    rl.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
+    rr = OracleRobot(KUKA_KIN, name="kukar")
+    rr.add_base_frame("global_world", xyz=[0.0, 0.25, 0.0])
+    return rl, rr
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "guard_golden.npz"))
+
+
+def test_solver_interface_known_answer_and_kkt(hip_lib, golden):
+    T = 20
+    (kl, kr), solver = setup_solver(T=T, limits=True, collision=True, solver_options={"max_iter": 400})
+    pd = {"qcl": golden["T20l_qc"], "qcr": golden["T20r_qc"], **obstacle_parameters()}
+    solver.reset_parameters(pd)
+    solver.reset_initial_seed({"kukal/q/x": np.tile(pd["qcl"].reshape(-1, 1), (1, T)), "kukar/q/x": np.tile(pd["qcr"].reshape(-1, 1), (1, T))})
+    sol = solver.solve()
+    assert solver.did_solve()
+    f_gold = float(golden["T20l_f"]) + float(golden["T20r_f"])
+    assert abs(solver.stats()["f"][0] - f_gold) < 1e-8
+    assert np.abs(np.asarray(sol["kukal/q"]).T - golden["T20l_Q"]).max() < 5e-5 and np.abs(np.asarray(sol["kukar/q"]).T - golden["T20r_Q"]).max() < 5e-5
+    rl, rr = _robots()
+    nlp = GuardedDualArmNLP(rl, rr, SPHERE_LINKS, N_OBSTACLES, T=T)
+    x = solver.opt.decision_variables.dict2vec(sol)
+    p = solver.opt.parameters.dict2vec(pd)
+    assert abs(nlp.f(x, p) - solver.stats()["f"][0]) < 1e-12 and np.abs(nlp.a(x, p)).max() < 1e-13
+    k = kkt_reference_form(nlp, x, p, active_tol=1e-6)
+    assert k["stationarity"] < 1e-6 and k["feasibility"] < 1e-9 and k["complementarity"] < 1e-8
+    assert nlp.g(x, p).min() < 1e-8  # sphere rows are active at the optimum
+    # diagnostics through the Solver interface: violated_constraints reports the sphere blocks with diff = dist^2 - bnd^2
+    blocks = solver.violated_constraints(sol | {"kukal/q/x": sol["kukal/q"], "kukar/q/x": sol["kukar/q"], "kukal/dq/x": sol["kukal/dq"],
+                                                "kukar/dq/x": sol["kukar/dq"]}, pd)
+    ineq = blocks[3]
+    assert len(ineq) == 2 * T * len(SPHERE_LINKS) * N_OBSTACLES and ineq[0].label == "sphere_col_avoid_0_end_effector_ball_kukal_obs0"
+    assert abs(float(ineq[0].diff.reshape(-1)[0]) - nlp.g(x, p)[0]) < 1e-12
+
+
+def test_state_machine_matches_port_and_multipliers(hip_lib, golden):
+    from optas_amd.lowering import lower
+    from optas_amd.backend import MultiArmBackend
+
+    T = 50
+    (kl, kr), o = setup_solver(T=T, build_only=True, limits=True, collision=True)
+    kind, spec = lower(o)
+    mb = MultiArmBackend(spec, o, max_iter=400)
+    rng = np.random.default_rng(SEED)
+    B = 6
+    qcl = QC + np.concatenate([np.zeros((1, 7)), rng.uniform(-0.05, 0.05, (B - 1, 7))])
+    qcr = QC + rng.uniform(-0.05, 0.05, (B, 7))
+    P = np.stack([o.parameters.dict2vec({"qcl": qcl[b], "qcr": qcr[b], **obstacle_parameters()}) for b in range(B)])
+    X0 = np.stack([o.decision_variables.dict2vec({"kukal/q/x": np.tile(qcl[b].reshape(-1, 1), (1, T)), "kukar/q/x": np.tile(qcr[b].reshape(-1, 1), (1, T))})
+                   for b in range(B)])
+    res = mb.solve(X0, P)
+    assert (res.status == 0).all()
+    rl, rr = _robots()
+    off = dual_arm_offsets(T)
+    xoff = o.decision_variables.offsets()
+    for (a, be), rob, arm, qcs in zip(mb.arms, (rl, rr), ("l", "r"), (qcl, qcr)):
+        ch = FoldedChain(rob, "end_effector_ball")
+        G = Guards(lo=rob.lower_actuated_joint_limits, up=rob.upper_actuated_joint_limits, links=SPHERE_LINKS, link_radii=np.full(4, 0.15),
+                   obs_pos=golden["obs"], obs_radii=np.full(6, 0.1))
+        lam = be.multipliers(B)
+        for b in range(0, B, 2):
+            s = solve_free_al(ch, T, 10.0 / (T - 1), off[arm].T, qcs[b], G, Q0=np.tile(qcs[b], (T, 1)), rho0=10.0, exact=False, max_iter=400)
+            Qg = res.x[b, xoff[a.q_name] : xoff[a.q_name] + 7 * T].reshape(T, 7)
+            assert s["status"] == 0 and np.abs(Qg - s["Q"]).max() < 1e-9
+            gv, _ = guard_values(ch, Qg, G)
+            assert gv[1:].min() > -1e-9 and (lam[b] >= 0).all() and np.abs(lam[b] * gv)[1:].max() < 1e-7
+            assert ((lam[b] > 0) == (s["lam"] > 0)).mean() > 0.995
+        if arm == "l":
+            assert abs(float(golden["T50l_f"]) - (solve_free_al(ch, T, 10.0 / (T - 1), off[arm].T, qcl[0], G, Q0=np.tile(qcl[0], (T, 1)), rho0=10.0,
+                                                                exact=False)["f"])) < 1e-8
+            it = be.solve(np.concatenate([X0[:1, : 7 * T], np.zeros((1, 7 * (T - 1)))], 1),
+                          np.concatenate([qcl[:1], np.full((1, 4), 0.15), np.tile(np.concatenate([np.append(ob, 0.1) for ob in golden["obs"]]), (1, 1))], 1))
+            assert abs(it.f[0] - float(golden["T50l_f"])) < 1e-8 and it.status[0] == 0
+    mb.close()
+
+
+def test_synthetic_config4_batch_properties(hip_lib, golden):
+    """T = 100, 256 dual-arm instances (SURVEY 8(d) C4 shape, link radius 0.1 so that perturbed initial configurations stay clear of
+    the obstacle column): every instance converges to a feasible KKT point."""
+    from optas_amd.lowering import lower
+    from optas_amd.backend import MultiArmBackend
+
+    T, B = 100, 256
+    (kl, kr), o = setup_solver(T=T, build_only=True, limits=True, collision=True)
+    kind, spec = lower(o)
+    mb = MultiArmBackend(spec, o, max_iter=400)
+    rng = np.random.default_rng(SEED + 4)
+    qcl, qcr = QC + rng.uniform(-0.1, 0.1, (B, 7)), QC + rng.uniform(-0.1, 0.1, (B, 7))
+    base = o.parameters.dict2vec({"qcl": QC, "qcr": QC, **obstacle_parameters(link_radius=0.1)})
+    P = np.tile(base, (B, 1))
+    P[:, :7], P[:, 7:14] = qcl, qcr
+    X0 = np.zeros((B, o.nx))
+    xoff = o.decision_variables.offsets()
+    for name, qc in (("kukal/q/x", qcl), ("kukar/q/x", qcr)):
+        X0[:, xoff[name] : xoff[name] + 7 * T] = np.tile(qc, (1, T))
+    res = mb.solve(X0, P)
+    assert (res.status == 0).mean() > 0.99
+    ok = res.status == 0
+    assert res.kkt[ok, 0].max() <= 1e-6 and res.kkt[ok, 1].max() <= 1e-9
+    rl, rr = _robots()
+    for rob, name in ((rl, "kukal/q/x"), (rr, "kukar/q/x")):
+        ch = FoldedChain(rob, "end_effector_ball")
+        G = Guards(lo=rob.lower_actuated_joint_limits, up=rob.upper_actuated_joint_limits, links=SPHERE_LINKS, link_radii=np.full(4, 0.1),
+                   obs_pos=golden["obs"], obs_radii=np.full(6, 0.1))
+        for b in np.flatnonzero(ok)[:24]:
+            Q = res.x[b, xoff[name] : xoff[name] + 7 * T].reshape(T, 7)
+            assert guard_values(ch, Q, G)[0][1:].min() > -1e-9
+    ms = sum(be.timing()["solve_ms"] for _, be in mb.arms)
+    print("config 4 synthetic: %d dual-arm instances (T=%d, 2 x %d rows) in %.1f ms device, iterations p50 %d max %d" % (B, T, 38 * T, ms, np.median(res.iters), res.iters.max()))
+    mb.close()

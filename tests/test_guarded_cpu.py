@@ -1,0 +1,134 @@
+"""Synthetic config 4 (8(d) C4) on the CPU: builder counts of example/dual_arm.py + enforce_model_limits +
+sphere_collision_avoidance_constraints, lowering to the guarded position-tracking family, and the augmented-Lagrangian port
+(oracle/guarded.py, the state machine the HIP kernels run) against the golden optima that scipy SLSQP (reference wiring:
+inequality rows passed as g >= 0, solver.py:672-679) and the port agree on; reference-form KKT on the literal layout."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, KUKA_KIN
+from oracle.guarded import Guards, guard_values, solve_free_al
+from oracle.problems import GuardedDualArmNLP, dual_arm_offsets
+from oracle.robot import OracleRobot
+from oracle.solvers import kkt_reference_form
+from oracle.structured import FoldedChain
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from examples.dual_arm import N_OBSTACLES, SPHERE_LINKS, obstacle_parameters, setup_solver  # noqa: E402
+
+QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
+
+
+def _robots():
+    rl = OracleRobot(KUKA_KIN, name="kukal")
+    rl.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
+    rr = OracleRobot(KUKA_KIN, name="kukar")
+    rr.add_base_frame("global_world", xyz=[0.0, 0.25, 0.0])
+    return rl, rr
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "guard_golden.npz"))
+
+
+def test_link_attachments_match_literal_forward_kinematics():
+    rl, _ = _robots()
+    ch = FoldedChain(rl, "end_effector_ball")
+    rng = np.random.default_rng(0)
+    Q = rng.uniform(-1, 1, (3, 7))
+    C, J = ch.link_positions(Q, SPHERE_LINKS)
+    for i, q in enumerate(Q):
+        for li, ln in enumerate(SPHERE_LINKS):
+            assert np.abs(C[i, li] - rl.get_global_link_position(ln, q)).max() < 1e-15
+            assert np.abs(J[i, li] - rl.get_global_link_linear_jacobian(ln, q)).max() < 1e-15
+
+
+def test_builder_counts_and_lowering():
+    from optas_amd.lowering import OH_KIND_MULTI_ARM, LoweringError, lower
+    from optas_amd.optimization import NonlinearCostNonlinearConstraints
+
+    (kl, kr), o = setup_solver(T=100, build_only=True, limits=True, collision=True)
+    assert isinstance(o, NonlinearCostNonlinearConstraints)
+    # SURVEY 8(a) H4 synthetic: nx = 2786, na = 1400, ng = 4800 (+ nk = 2 * 2 * 7 * 100 limit rows)
+    assert (o.nx, o.np, o.nk, o.na, o.ng, o.nh) == (2786, 70, 2800, 1400, 4800, 0) and o.nv == 2800 + 4800 + 2 * 1400
+    labels = list(o.ineq_constraints.keys())
+    assert labels[0] == "sphere_col_avoid_0_end_effector_ball_kukal_obs0" and labels[1] == "sphere_col_avoid_0_end_effector_ball_kukal_obs1"
+    assert list(o.parameters.keys())[4:12] == ["qcl", "qcr", "kukal_end_effector_ball_radii", "kukal_lwr_arm_7_link_radii", "kukal_lwr_arm_5_link_radii",
+                                               "kukal_lwr_arm_6_link_radii", "kukal_obs0_position", "kukal_obs0_radii"]  # builder.py:391-405 order
+    kind, spec = lower(o)
+    assert kind == OH_KIND_MULTI_ARM and all(a.guards is not None for a in spec.arms)
+    g = spec.arms[1].guards
+    assert g.links == SPHERE_LINKS and len(g.obstacles) == N_OBSTACLES and g.obstacles[0] == ("kukar_obs0_position", "kukar_obs0_radii")
+    rl, _ = _robots()
+    assert np.array_equal(g.lo, rl.lower_actuated_joint_limits) and np.array_equal(g.up, rl.upper_actuated_joint_limits)
+    # the reference's naming collides for two robots built from the same URDF (sx_container.py:50-51): kept
+    from optas_amd.builder import OptimizationBuilder
+    import optas_amd
+
+    r1 = optas_amd.RobotModel.builtin("kuka_lwr", time_derivs=[0, 1], name="a")
+    r2 = optas_amd.RobotModel.builtin("kuka_lwr", time_derivs=[0, 1], name="b")
+    b = OptimizationBuilder(T=3, robots=[r1, r2])
+    b.sphere_collision_avoidance_constraints("a", ["o1"], link_names=["lwr_arm_5_link"])
+    with pytest.raises(KeyError):
+        b.sphere_collision_avoidance_constraints("b", ["o2"], link_names=["lwr_arm_5_link"])
+    # sphere rows on a subset of knots are outside the family
+    (kl, kr), o2 = setup_solver(T=6, build_only=True, collision=True)
+    del o2.ineq_constraints["sphere_col_avoid_3_lwr_arm_5_link_kukal_obs2"]
+    with pytest.raises(LoweringError):
+        lower(o2)
+
+
+def test_literal_layout_matches_builder_and_derivatives():
+    rl, rr = _robots()
+    T = 8
+    nlp = GuardedDualArmNLP(rl, rr, SPHERE_LINKS, N_OBSTACLES, T=T)
+    (kl, kr), o = setup_solver(T=T, build_only=True, limits=True, collision=True)
+    assert (nlp.nx, nlp.np_, nlp.nk, nlp.na, nlp.ng, nlp.nv) == (o.nx, o.np, o.nk, o.na, o.ng, o.nv)
+    p = o.parameters.dict2vec({"qcl": QC, "qcr": QC + 0.02, **obstacle_parameters()})
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, nlp.nx)
+    Jg, Jk, h = nlp.dg(x, p), nlp.dk(x, p), 1e-6
+    for i in rng.choice(nlp.nx, 8, replace=False):
+        d = np.zeros(nlp.nx)
+        d[i] = h
+        assert np.abs((nlp.g(x + d, p) - nlp.g(x - d, p)) / (2 * h) - Jg[:, i]).max() < 1e-8
+        assert np.abs((nlp.k(x + d, p) - nlp.k(x - d, p)) / (2 * h) - Jk[:, i]).max() < 1e-8
+    v = nlp.v(x, p)
+    assert v.shape == (nlp.nv,) and np.array_equal(v[: nlp.nk], nlp.k(x, p)) and np.array_equal(v[nlp.nk : nlp.nk + nlp.ng], nlp.g(x, p))
+
+
+@pytest.mark.parametrize("tag,T,arm", [("T20l", 20, "l"), ("T20r", 20, "r"), ("T50l", 50, "l")])
+def test_port_reproduces_golden(golden, tag, T, arm):
+    rl, rr = _robots()
+    rob = rl if arm == "l" else rr
+    ch = FoldedChain(rob, "end_effector_ball")
+    qc = golden[tag + "_qc"]
+    G = Guards(lo=rob.lower_actuated_joint_limits, up=rob.upper_actuated_joint_limits, links=SPHERE_LINKS, link_radii=np.full(4, 0.15),
+               obs_pos=golden["obs"], obs_radii=np.full(6, 0.1))
+    s = solve_free_al(ch, T, 10.0 / (T - 1), dual_arm_offsets(T)[arm].T, qc, G, Q0=np.tile(qc, (T, 1)), rho0=10.0, exact=False)
+    assert s["status"] == 0 and s["iters"] <= 80
+    # tol 1e-6 on the gradient leaves ~1e-5 rad of play along the weakly curved velocity-regularised directions
+    assert abs(s["f"] - float(golden[tag + "_f"])) < 1e-8 and np.abs(s["Q"] - golden[tag + "_Q"]).max() < 5e-5
+    assert np.abs(s["Q"] - golden[tag + "_Q_slsqp"]).max() < 5e-5  # the reference-wired SLSQP optimum
+    gv, _ = guard_values(ch, s["Q"], G)
+    assert gv[1:].min() > -1e-9 and (s["lam"] >= 0).all() and np.abs(s["lam"] * gv)[1:].max() < 1e-8
+    assert ((s["lam"] > 0) == (golden[tag + "_lam"] > 0)).mean() > 0.999  # same active set
+
+
+def test_reference_form_kkt_of_the_port_solution(golden):
+    rl, rr = _robots()
+    T = 20
+    nlp = GuardedDualArmNLP(rl, rr, SPHERE_LINKS, N_OBSTACLES, T=T)
+    (kl, kr), o = setup_solver(T=T, build_only=True, limits=True, collision=True)
+    p = o.parameters.dict2vec({"qcl": golden["T20l_qc"], "qcr": golden["T20r_qc"], **obstacle_parameters()})
+    xs = []
+    for tag in ("T20l", "T20r"):
+        Q = golden[tag + "_Q"]
+        xs += [Q.reshape(-1), (np.diff(Q, axis=0) / nlp.dt).reshape(-1)]
+    x = np.concatenate(xs)
+    assert abs(nlp.f(x, p) - float(golden["T20l_f"]) - float(golden["T20r_f"])) < 1e-12
+    k = kkt_reference_form(nlp, x, p, active_tol=1e-6)
+    assert k["stationarity"] < 1e-7 and k["feasibility"] < 1e-10 and k["complementarity"] < 1e-9

@@ -200,3 +200,64 @@ def ik_golden():
         NACT.append(nact)
     np.savez(os.path.join(G, "ik_golden.npz"), p=np.array(P), x0=np.array(X0), x=np.array(X), f=np.array(F), agree=np.array(AG),
              nactive=np.array(NACT), lo=ik.lo, up=ik.up)
+
+
+def guard_golden():
+    """Synthetic config 4 (dual_arm.py + joint limits + sphere clearances), per arm: scipy SLSQP on the
+    reduced problem (q_0 eliminated, dq condensed; constraints g >= 0 as the reference's ScipyMinimizeSolver passes them,
+    solver.py:672-679) against the augmented-Lagrangian port.  T = 20 both arms (qcr perturbed), T = 50 left arm."""
+    from scipy.optimize import minimize
+
+    from oracle.guarded import Guards, guard_values, solve_free_al
+    from oracle.problems import dual_arm_offsets
+    from oracle.structured import FoldedChain
+
+    kin = os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json")
+    links = ["end_effector_ball", "lwr_arm_7_link", "lwr_arm_5_link", "lwr_arm_6_link"]
+    obs = np.array([[0.55, 0.0, 0.1 * (i + 1)] for i in range(6)])
+    QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
+    out = {"links": np.array(links), "obs": obs, "link_radius": 0.15, "obs_radius": 0.1}
+    for tag, T, arm, y, qc in (("T20l", 20, "l", -0.25, QC), ("T20r", 20, "r", 0.25, QC + 0.02), ("T50l", 50, "l", -0.25, QC)):
+        rob = OracleRobot(kin, name="kuka" + arm)
+        rob.add_base_frame("global_world", xyz=[0.0, y, 0.0])
+        ch = FoldedChain(rob, "end_effector_ball")
+        off = dual_arm_offsets(T)[arm].T
+        dt = 10.0 / (T - 1)
+        kap = 0.01 / dt**2
+        GU = Guards(lo=rob.lower_actuated_joint_limits, up=rob.upper_actuated_joint_limits, links=links, link_radii=np.full(4, 0.15), obs_pos=obs,
+                   obs_radii=np.full(6, 0.1))
+        path = ch.fk(qc[None])[0][0] + off
+
+        def unpack(x):
+            return np.vstack([qc[None], x.reshape(T - 1, 7)])
+
+        def fun(x):
+            Q = unpack(x)
+            e, _, Jp, _ = ch.jac(Q)
+            r = path - e
+            d = np.diff(Q, axis=0)
+            g = -2 * np.einsum("tki,tk->ti", Jp, r)
+            g[1:] += 2 * kap * d
+            g[:-1] -= 2 * kap * d
+            return np.sum(r * r) + kap * np.sum(d * d), g[1:].reshape(-1)
+
+        def con(x):
+            return guard_values(ch, unpack(x), GU)[0][1:].reshape(-1)
+
+        def jac(x):
+            dg = guard_values(ch, unpack(x), GU)[1][1:]
+            J = np.zeros((T - 1, dg.shape[1], T - 1, 7))
+            for t in range(T - 1):
+                J[t, :, t, :] = dg[t]
+            return J.reshape((T - 1) * dg.shape[1], (T - 1) * 7)
+
+        t0 = time.time()
+        r = minimize(fun, np.tile(qc, (T - 1, 1)).reshape(-1), jac=True, method="SLSQP", constraints=[{"type": "ineq", "fun": con, "jac": jac}],
+                     tol=1e-13, options={"maxiter": 1000})
+        a = solve_free_al(ch, T, dt, off, qc, GU, Q0=np.tile(qc, (T, 1)), rho0=10.0, exact=False, tol=1e-9, tol_feas=1e-11, max_iter=600)
+        Qs = unpack(r.x)
+        print("guard", tag, r.fun, r.nit, r.success, a["f"], a["iters"], a["status"], "dQ", np.abs(Qs - a["Q"]).max(), "active", int((a["lam"] > 0).sum()),
+              round(time.time() - t0, 1))
+        assert r.success and a["status"] == 0 and abs(r.fun - a["f"]) < 1e-8
+        out[tag + "_qc"], out[tag + "_Q"], out[tag + "_f"], out[tag + "_lam"], out[tag + "_Q_slsqp"] = qc, a["Q"], a["f"], a["lam"], Qs
+    np.savez(os.path.join(G, "guard_golden.npz"), **out)

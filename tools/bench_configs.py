@@ -1,0 +1,104 @@
+"""Device-time measurements of the BASELINE configs other than the headline (bench.py measures configs[1]):
+config 1 (IK, example.py), config 3 (point-mass MPC tick), config 4 (dual_arm.py as shipped and the synthetic T=100 +
+limits + spheres variant).  One JSON line per config on stdout; inputs are synthetic (SURVEY 8(d) seeds), timings are the
+handle's HIP-event solve time with buffers already resident (oh_solve_device).
+
+  python tools/bench_configs.py > profiles/r01_configs.json
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from optas_amd import _lib  # noqa: E402
+from optas_amd.backend import FigureEightBackend, IKBackend, PointMassBackend  # noqa: E402
+from optas_amd.models import RobotModel  # noqa: E402
+
+SEED = 20260927
+
+
+def timed(be, x0, p, reps=3):
+    B = x0.shape[0]
+    bufs = [_lib.DeviceBuffer(a.nbytes) for a in (x0, p)]
+    bufs[0].upload(x0)
+    bufs[1].upload(p)
+    d_x, d_f, d_k = _lib.DeviceBuffer(x0.nbytes), _lib.DeviceBuffer(8 * B), _lib.DeviceBuffer(24 * B)
+    d_i, d_s = _lib.DeviceBuffer(4 * B), _lib.DeviceBuffer(4 * B)
+    ms = []
+    for _ in range(reps + 1):
+        be.solve_device(B, bufs[0], bufs[1], d_x, d_f, d_k, d_i, d_s)
+        ms.append(be.solve_ms() if hasattr(be, "solve_ms") else be.timing()["solve_ms"])
+    it, st, kk = d_i.download(np.int32, (B,)), d_s.download(np.int32, (B,)), d_k.download(np.float64, (B, 3))
+    for b in bufs + [d_x, d_f, d_k, d_i, d_s]:
+        b.free()
+    ok = st == 0
+    return {"ms": float(np.median(ms[1:])), "converged_frac": float(ok.mean()), "iters_p50": float(np.median(it)), "iters_max": int(it.max()),
+            "stationarity_max": float(kk[ok, 0].max()), "feasibility_max": float(kk[ok, 1].max())}
+
+
+def main():
+    rng = np.random.default_rng(SEED)
+    out = []
+    kuka = RobotModel.builtin("kuka_lwr")
+    # ---- config 1: IK ----
+    B = 65536
+    be = IKBackend(kuka.kinematic_chain("end_effector_ball"), kuka.lower_actuated_joint_limits, kuka.upper_actuated_joint_limits, max_iter=300)
+    qn = np.deg2rad([0, 45, 0, -90, 0, -45, 0]) + rng.uniform(-0.3, 0.3, (B, 7))
+    pg = np.asarray(kuka.get_global_link_position("end_effector_ball", np.clip(qn + rng.uniform(-0.5, 0.5, (B, 7)), kuka.lower_actuated_joint_limits,
+                                                                             kuka.upper_actuated_joint_limits).T)).T
+    r = timed(be, np.ascontiguousarray(qn), np.ascontiguousarray(np.concatenate([qn, pg], 1)))
+    out.append({"config": "1 example.py IK (KUKA LWR, joint limits, position goal)", "batch": B, "solves_per_s": B / r["ms"] * 1e3, **r})
+    # ---- config 3: point-mass MPC tick ----
+    sys.path.insert(0, ROOT)
+    from examples.point_mass_mpc import obstacle_and_goal
+
+    B = 4096
+    be = PointMassBackend()
+    P = []
+    obs, _ = obstacle_and_goal(2.0, np.zeros(2))
+    while len(P) < B:
+        c = rng.uniform(-1.2, 1.2, 2)
+        if np.linalg.norm(c - obs[:, 0]) <= 0.35:
+            continue
+        goal = np.stack([np.clip(c[j] + (1 - c[j]) * np.arange(20) / 19.0, -1.5, 1.5) for j in range(2)])
+        P.append(np.concatenate([c, np.zeros(2), goal.T.reshape(-1), obs.T.reshape(-1)]))
+    r = timed(be, np.zeros((B, 80)), np.array(P))
+    out.append({"config": "3 point_mass_mpc.py tick (T=20, box limits, moving obstacle)", "batch": B, "solves_per_s": B / r["ms"] * 1e3, **r})
+    # ---- config 4 as shipped and synthetic ----
+    from examples.dual_arm import SPHERE_LINKS, path_offsets
+
+    QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
+    for tag, T, B, guarded in (("4 dual_arm.py as shipped (T=50), per arm", 50, 8192, False),
+                               ("4 synthetic: T=100 + joint limits + 4x6 sphere clearances, per arm", 100, 1024, True)):
+        arm = RobotModel.builtin("kuka_lwr", time_derivs=[0, 1], name="kukal")
+        arm.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
+        g = None
+        if guarded:
+            g = _lib.oh_guards()
+            g.limits = 1
+            for j in range(7):
+                g.q_lo[j], g.q_up[j] = arm.lower_actuated_joint_limits[j], arm.upper_actuated_joint_limits[j]
+            g.n_links, g.n_obstacles = 4, 6
+            for l, (k, off) in enumerate(arm.link_attachments("end_effector_ball", SPHERE_LINKS)):
+                g.link_joint[l] = k
+                for i in range(3):
+                    g.link_offset[l][i] = off[i]
+        be = FigureEightBackend(arm.kinematic_chain("end_effector_ball"), T, 10.0 / (T - 1), path_offsets(T, [-0.1, 0.1, -0.2], [0.0, 0.0, 0.3]).T,
+                                w_path=1.0, w_vel=0.01, max_iter=400, lock_orientation=False, fix_dq0=False, path_in_frame=False, guards=g)
+        qc = QC + rng.uniform(-0.1, 0.1, (B, 7))
+        p = qc
+        if guarded:
+            obs_row = np.concatenate([[0.55, 0.0, 0.1 * (i + 1), 0.1] for i in range(6)])
+            p = np.concatenate([qc, np.full((B, 4), 0.1), np.tile(obs_row, (B, 1))], 1)
+        x0 = np.concatenate([np.tile(qc, (1, T)), np.zeros((B, 7 * (T - 1)))], 1)
+        r = timed(be, np.ascontiguousarray(x0), np.ascontiguousarray(p))
+        out.append({"config": tag, "batch": B, "T": T, "solves_per_s": B / r["ms"] * 1e3, **r})
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()

@@ -62,7 +62,7 @@ def local_path():
     return float(t[1] - t[0]), lp
 
 
-def cpu_baseline(sample: int):
+def cpu_baseline(sample: int, hessian: str = "hybrid"):
     """The oracle's numpy port of the same structured SQP, timed on this box's host cores (1 thread)."""
     from oracle.robot import OracleRobot
     from oracle.structured import StructuredFigureEight, solve_structured_lm
@@ -71,11 +71,11 @@ def cpu_baseline(sample: int):
     robot = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json"))
     prob = StructuredFigureEight(robot, LINK, T=T, Tmax=TMAX)
     _, qc = make_inputs(sample, 0)
-    solve_structured_lm(prob, qc[0], max_iter=3, tol=1e-6)  # warm-up (reference convention: one warm-up solve)
+    solve_structured_lm(prob, qc[0], max_iter=3, tol=1e-6, hessian=hessian)  # warm-up (reference convention: one warm-up solve)
     t0 = time.perf_counter()
     its = []
     for i in range(sample):
-        r = solve_structured_lm(prob, qc[i], max_iter=300, tol=1e-6)
+        r = solve_structured_lm(prob, qc[i], max_iter=300, tol=1e-6, hessian=hessian)
         its.append(r["iters"])
         if time.perf_counter() - t0 > 30.0:
             sample = i + 1
@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU per step (SURVEY 8(d): B in {256, 4096, 65536})")
     ap.add_argument("--max-iter", type=int, default=300)
     ap.add_argument("--tol", type=float, default=1e-6)
+    ap.add_argument("--hessian", choices=["gauss_newton", "exact", "hybrid"], default="hybrid")
     ap.add_argument("--cpu-sample", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fk-units", type=int, default=1 << 22)
@@ -121,7 +122,8 @@ def main():
     dt, lp = local_path()
     robot = optas_amd.RobotModel.builtin("kuka_lwr")
     chain = robot.kinematic_chain(LINK)
-    be = FigureEightBackend(chain, T, dt, lp, max_iter=args.max_iter, tol=args.tol)
+    be = FigureEightBackend(chain, T, dt, lp, max_iter=args.max_iter, tol=args.tol,
+                            hessian={"gauss_newton": 0, "exact": 1, "hybrid": 2}[args.hessian])
     if use_dist:
         # the one collective of the whole job: kinematic constants, rank 0 -> all, over RCCL/xGMI
         import torch
@@ -246,7 +248,7 @@ def main():
             "global_batch": world * B,
             "T": T,
             "parallelism": f"dp{world} (instances sharded, one RCCL broadcast of constants)",
-            "hessian": "gauss_newton",
+            "hessian": args.hessian,
         },
         "roofline": roofline,
         "roofline_fk_jac": {
@@ -276,7 +278,7 @@ def main():
         "compactions_per_step": tm["compactions"] / args.steps,
     }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.hessian)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -65,7 +65,9 @@ enum {
 
 enum {
   OH_HESSIAN_GAUSS_NEWTON = 0, /* 2 w Jp^T Jp */
-  OH_HESSIAN_EXACT = 1         /* + exact curvature of tracking cost and of the orientation constraint */
+  OH_HESSIAN_EXACT = 1,        /* + exact curvature of tracking cost and of the orientation constraint */
+  OH_HESSIAN_HYBRID = 2        /* Gauss-Newton far from a stationary point, exact once the reduced gradient of the accepted
+                                  point is below 1e-5 * w_path (large-residual problems: GN alone converges only linearly) */
 };
 
 /*

@@ -23,7 +23,7 @@ OH_PROBLEM_KINEMATICS = 0
 OH_PROBLEM_FIGURE_EIGHT = 1
 OH_PROBLEM_POINT_MASS_MPC = 2
 OH_PROBLEM_IK = 3
-OH_HESSIAN_GAUSS_NEWTON, OH_HESSIAN_EXACT = 0, 1
+OH_HESSIAN_GAUSS_NEWTON, OH_HESSIAN_EXACT, OH_HESSIAN_HYBRID = 0, 1, 2
 
 
 class oh_chain(C.Structure):

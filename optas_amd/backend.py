@@ -124,7 +124,7 @@ class FigureEightBackend:
         max_iter: int = 200,
         tol: float = 1e-6,
         tol_feas: float = 1e-9,
-        hessian: int = _lib.OH_HESSIAN_GAUSS_NEWTON,
+        hessian: int = _lib.OH_HESSIAN_HYBRID,
         mu0: float = 0.0,
         lock_orientation: bool = True,
         fix_dq0: bool = True,

@@ -145,7 +145,7 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
     return fail(OH_ERR_INVALID, "oh_create: figure-eight kernels are instantiated for ndof 6 and 7");
   if (!(desc->dt > 0.0)) return fail(OH_ERR_INVALID, "oh_create: dt must be positive");
   if (!desc->local_path) return fail(OH_ERR_INVALID, "oh_create: local_path is null");
-  if (desc->hessian != OH_HESSIAN_GAUSS_NEWTON && desc->hessian != OH_HESSIAN_EXACT)
+  if (desc->hessian != OH_HESSIAN_GAUSS_NEWTON && desc->hessian != OH_HESSIAN_EXACT && desc->hessian != OH_HESSIAN_HYBRID)
     return fail(OH_ERR_INVALID, "oh_create: bad hessian mode");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -531,6 +531,7 @@ static void fill_params(oh_handle* h) {
   P.max_retract = 4;
   P.max_iter = d.max_iter;
   P.hessian = d.hessian;
+  P.hyb_switch = 1e-5 * d.w_path;
   P.mu0 = d.mu0;
   P.local_path = h->d_local_path;
   P.np = d.ndof + (h->have_guards ? h->guards.n_links + 4 * h->guards.n_obstacles : 0);

@@ -24,7 +24,7 @@ OH_DEV void orient_residual(const double* Re, const double* Rc, double* c, doubl
 // multiplier estimate from Gprev), Householder null-space basis Z of the orientation rows, Dr = Z^T W Z.
 template <int N>
 OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const int t, double (&q)[N], const double (&pc)[3],
-                      const double (&Rc)[9], const bool have_G, const double (&Gprev)[N], double& phi, double& cv, double (&g)[N],
+                      const double (&Rc)[9], const bool exact, const bool have_G, const double (&Gprev)[N], double& phi, double& cv, double (&g)[N],
                       double (&Dr)[(N - 3) * (N - 2) / 2], double (&Z)[N][N - 3]) {
   constexpr int NZ = N - 3;
   double R[9], p[3], z[N][3], pj[N][3];
@@ -97,7 +97,7 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
   for (int i = 0; i < N; ++i)
 #pragma unroll
     for (int j = 0; j <= i; ++j) W[tri(i, j)] = 2.0 * w * dot3(Jp[i], Jp[j]);
-  if (P.hessian == OH_HESSIAN_EXACT) {
+  if (exact) {
     // -2 w r . d2p/dq_j dq_i,  d2p/dq_j dq_i = z_j x Jp_i for j <= i (revolute j)
     // + lam . d2c/dq_j dq_i,   d2c = 1/2 z_j x z_i (j < i), exact on the constraint manifold.
     // multipliers: least squares of  G_prev + Jc^T lam = 0  with the Lagrangian gradient of the last

@@ -21,6 +21,7 @@ struct FigParams {
   int max_retract;
   int max_iter;
   int hessian;
+  double hyb_switch; // OH_HESSIAN_HYBRID: exact curvature once stat <= hyb_switch
   double mu0;
   const double* local_path;  // device, [T][3]
   int np;            // row stride of the parameter matrix p (ndof, or ndof + guard parameters)

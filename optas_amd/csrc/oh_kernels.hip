@@ -309,12 +309,14 @@ __global__ __launch_bounds__(256, 2) void k_eval(FigParams P, FigBuffers D, cons
 #pragma unroll
   for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
   double Gprev[N];
-  const bool have_G = (P.hessian == OH_HESSIAN_EXACT) && !first;
+  // exact curvature: always (OH_HESSIAN_EXACT) or once the accepted point is nearly stationary (OH_HESSIAN_HYBRID)
+  const bool exact = (P.hessian == OH_HESSIAN_EXACT) || (P.hessian == OH_HESSIAN_HYBRID && !first && D.stat[b] <= P.hyb_switch);
+  const bool have_G = exact && !first;
 #pragma unroll
   for (int k = 0; k < N; ++k) Gprev[k] = have_G ? D.Gfull[cur][IDX(t, N, k)] : 0.0;
 
   double phi, cv, g[N], Dr[NP], Z[N][NZ];
-  eval_knot<N>(D.chain, P, t, q, pc, Rc, have_G, Gprev, phi, cv, g, Dr, Z);
+  eval_knot<N>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z);
 
 #pragma unroll
   for (int j = 0; j < N; ++j) D.q[slot][IDX(t, N, j)] = q[j];
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const
   }
   double G[N], gt[NZ], E[NZ * NZ], merit;
   couple_knot<N>(P.kappa, last, qm, q0, qp, g, Zt, Zn, D.phi[slot][(size_t)t * Bp + b], G, gt, E, merit);
-  if (P.hessian == OH_HESSIAN_EXACT) {
+  if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) {
 #pragma unroll
     for (int k = 0; k < N; ++k) D.Gfull[slot][IDX(t, N, k)] = G[k];
   }
@@ -614,8 +616,9 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
     ++n_launch_equiv;
     // ---- evaluate the trial knots (k_eval) -----------------------------------------------------------------
     double phi = 0.0, cv = 0.0, g[N], Dr[NP], Z[N][NZ];
-    const bool have_G = (P.hessian == OH_HESSIAN_EXACT) && !first;
-    if (active) eval_knot<N>(ch, P, t, qt, pc, Rc, have_G, G_c, phi, cv, g, Dr, Z);
+    const bool exact = (P.hessian == OH_HESSIAN_EXACT) || (P.hessian == OH_HESSIAN_HYBRID && !first && stat <= P.hyb_switch);
+    const bool have_G = exact && !first;
+    if (active) eval_knot<N>(ch, P, t, qt, pc, Rc, exact, have_G, G_c, phi, cv, g, Dr, Z);
     // ---- neighbour coupling (k_couple) -----------------------------------------------------------------------
     double qm[N], qp[N], Zn[N][NZ];
 #pragma unroll
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(256) void k_compact_gather(FigParams P, FigBuffers 
   double* __restrict__ ts = D.Dr[1];
 #pragma unroll
   for (int j = 0; j < N; ++j) tq[((size_t)t * N + j) * Bp + nb] = qs[IDX(t, N, j)];
-  if (P.hessian == OH_HESSIAN_EXACT) {
+  if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) {
 #pragma unroll
     for (int j = 0; j < N; ++j) D.g[1][((size_t)t * N + j) * Bp + nb] = D.Gfull[D.cur[b]][IDX(t, N, j)];
   }
@@ -944,7 +947,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
     const double v = tq[IDX(t, N, j)];
     D.q[slot][IDX(t, N, j)] = v;
     if (t < P.t0) D.q[1 - slot][IDX(t, N, j)] = v;
-    if (P.hessian == OH_HESSIAN_EXACT) D.Gfull[1 - slot][IDX(t, N, j)] = D.g[1][IDX(t, N, j)];
+    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) D.Gfull[1 - slot][IDX(t, N, j)] = D.g[1][IDX(t, N, j)];
   }
   if (t == 0) {
 #pragma unroll

@@ -151,7 +151,7 @@ class HIPSolver(Solver):
         o = dict(solver_options or {})
         kind, spec = lower(self.opt)
         self._kind, self._spec = kind, spec
-        hessian = {"gauss_newton": _lib.OH_HESSIAN_GAUSS_NEWTON, "exact": _lib.OH_HESSIAN_EXACT}[o.get("hessian", "gauss_newton")]
+        hessian = {"gauss_newton": _lib.OH_HESSIAN_GAUSS_NEWTON, "exact": _lib.OH_HESSIAN_EXACT, "hybrid": _lib.OH_HESSIAN_HYBRID}[o.get("hessian", "hybrid")]
         if isinstance(spec, FigureEightSpec):
             o.pop("hessian", None)
         if isinstance(spec, FigureEightSpec):

@@ -307,8 +307,14 @@ def retract(prob, Q, Rc, tol=1e-10, max_corr=4):
     return Q
 
 
-def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False):
-    """Returns dict(Q, f, iters (= steps solved: accepted + rejected), rejected, stat, feas, status)."""
+def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False, hessian="hybrid"):
+    """Returns dict(Q, f, iters (= steps solved: accepted + rejected), rejected, stat, feas, status).
+    hessian: "gauss_newton" | "exact" | "hybrid" (Gauss-Newton until the reduced gradient of the accepted point is below
+    1e-5 * w_path, exact curvature afterwards: OH_HESSIAN_HYBRID); exact=True is shorthand for "exact"."""
+    if exact:
+        hessian = "exact"
+    hyb_switch = 1e-5 * prob.w_path
+    stat_prev = np.inf
     T, n = prob.T, prob.n
     path, Rc = prob.references(qc)
     kap = prob.kappa
@@ -326,7 +332,8 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
     nu_n = 2.0
     while True:
         # ---- k_eval + k_couple on the trial point
-        phi, g, W, c, Jc = prob.evaluate(Qt, path, Rc, lam=lam, exact=exact)
+        use_exact = hessian == "exact" or (hessian == "hybrid" and not first and stat_prev <= hyb_switch)
+        phi, g, W, c, Jc = prob.evaluate(Qt, path, Rc, lam=lam, exact=use_exact)
         f_t = float(np.sum(phi) + prob.smooth_cost(Qt))
         feas_t = float(np.max(np.abs(c[F])))
         # ---- k_step phase A
@@ -382,11 +389,12 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                 "Dr": np.einsum("tia,tij,tjb->tab", Zs[F], Dfull[F], Zs[F]),
                 "Er": -2 * kap * np.einsum("tia,tib->tab", Zs[2 : T - 1], Zs[3:T]),
             }
-            if exact:
+            if hessian != "gauss_newton":
                 for t in range(2, T):
                     lam[t] = -np.linalg.solve(Jc[t] @ Jc[t].T + 1e-14 * np.eye(3), Jc[t] @ G[t])
         # ---- k_step phase B
         stat = float(np.max(np.abs(cur["gt"])))
+        stat_prev = stat
         while True:
             z, ok = block_tridiag_solve(cur["Dr"], cur["Er"], -cur["gt"], mu)
             if ok:

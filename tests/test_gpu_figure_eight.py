@@ -209,3 +209,28 @@ def test_exact_hessian_mode_reaches_a_kkt_point(hip_lib, nlp, golden_nlp):
     r = be.solve(nlp.seed(QC0), QC0)
     assert r.status[0] == 0 and abs(r.f[0] - float(golden_nlp["fig8_f"])) <= 1e-8
     be.close()
+
+
+@pytest.mark.parametrize("hessian", ["gauss_newton", "hybrid"])
+@pytest.mark.parametrize("tail", [0, 2048])
+def test_state_machine_matches_numpy_port(hip_lib, nlp, hessian, tail, monkeypatch):
+    """Both launch structures (three batched kernels per iteration; one persistent wave per instance) run the state
+    machine oracle/structured.py:solve_structured_lm restates: same step counts, same rejections, same optimum."""
+    from oracle.structured import solve_structured_lm
+
+    monkeypatch.setenv("OH_TAIL_THRESHOLD", str(tail))
+    robot = RobotModel(urdf_filename=KUKA_KIN)
+    mode = {"gauss_newton": _lib.OH_HESSIAN_GAUSS_NEWTON, "hybrid": _lib.OH_HESSIAN_HYBRID}[hessian]
+    be = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6, hessian=mode)
+    rng = np.random.default_rng(SEED + 7)
+    B = 6
+    qc = QC0 + np.concatenate([np.zeros((1, 7)), rng.uniform(-0.1, 0.1, (B - 1, 7))])
+    x0 = np.stack([nlp.seed(q) for q in qc])
+    res = be.solve(x0, qc)
+    prob = StructuredFigureEight(OracleRobot(KUKA_KIN), LINK, T=50)
+    for b in range(B):
+        s = solve_structured_lm(prob, qc[b], max_iter=300, tol=1e-6, hessian=hessian)
+        assert s["status"] == res.status[b] == 0
+        assert abs(int(res.iters[b]) - s["iters"]) <= 1, (b, res.iters[b], s["iters"])
+        # stopping at |Z^T G| <= 1e-6 leaves ~1e-5 rad of play along the weakly curved elbow-swivel directions
+        assert abs(res.f[b] - s["f"]) <= 1e-9 * abs(s["f"]) and np.abs(res.x[b, : 7 * 50].reshape(50, 7) - s["Q"]).max() < 1e-4

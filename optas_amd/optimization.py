@@ -1,12 +1,18 @@
 """Problem IR handed to a Solver: the reference's seven ``Optimization`` classes
-(optas/optimization.py:54-568) with the same attribute names for sizes and containers.  The
-``cs.Function`` members (f, df, ddf, k, a, g, h, v, dv, ...) do not exist here -- evaluation happens
-inside the lowered HIP kernels -- but the row counts follow the reference exactly:
-``nv = nk + ng + 2*na + 2*nh`` for ``v = [k; g; a; -a; h; -h]`` (:27-51,292-306).
+(optas/optimization.py:54-568) with the same attribute names for sizes, bounds, containers and functions.
+
+The solve itself happens inside the lowered HIP kernels; the function members ``f, k, a, g, h, v`` and -- where the reference
+defines them -- ``M, c, A, b`` (``k = Mx + c``, ``a = Ax + b``, optimization.py:225-260) and ``P, q``
+(``f = x^T P x + q^T x``, optimization.py:219-223) are numeric callables over the expression trees (optas_amd.evaluate;
+link functions inside them run through liboptas_hip), used for diagnostics and for checking the builder's layout and sign
+conventions against the oracle.  Derivative members (df, ddf, dv, ...) are not provided: the kernels carry their own.
+``v = [k; g; a; -a; h; -h]``, ``nv = nk + ng + 2 na + 2 nh``, bounds ``0 <= v <= 1e10`` (optimization.py:27-51,292-306).
 """
 from __future__ import annotations
 
 from typing import List, Optional
+
+import numpy as np
 
 from .sx_container import SXContainer
 
@@ -30,6 +36,103 @@ class Optimization:
     def set_models(self, models) -> None:
         self.models = models
 
+    # ---- numeric function members (cs.Function objects in the reference) --------------------------------------------
+    def _vec(self, container, x, p) -> np.ndarray:
+        """container.vec() (sx_container.py:83-89) evaluated at (x, p): items in order, each column-major."""
+        from .evaluate import evaluate
+
+        x, p = np.asarray(x, dtype=np.float64).reshape(-1), np.asarray(p, dtype=np.float64).reshape(-1)
+        assert x.shape[0] == self.nx and p.shape[0] == self.np, f"expected x ({self.nx}) and p ({self.np})"
+        parts = []
+        for term in container.values():
+            m, n = term.shape
+            parts.append(np.broadcast_to(np.asarray(evaluate(term, self, x, p), dtype=np.float64), (m, n)).T.reshape(-1))
+        return np.concatenate(parts) if parts else np.zeros(0)
+
+    def f(self, x, p) -> float:
+        """Sum of the cost terms (optimization.py:192-195)."""
+        return float(np.sum(self._vec(self.cost_terms, x, p)))
+
+    def k(self, x, p) -> np.ndarray:
+        return self._vec(self.lin_ineq_constraints, x, p)
+
+    def a(self, x, p) -> np.ndarray:
+        return self._vec(self.lin_eq_constraints, x, p)
+
+    def g(self, x, p) -> np.ndarray:
+        return self._vec(self.ineq_constraints, x, p)
+
+    def h(self, x, p) -> np.ndarray:
+        return self._vec(self.eq_constraints, x, p)
+
+    def v(self, x, p) -> np.ndarray:
+        """vertcon (optimization.py:27-51): [k; g; a; -a; h; -h] >= 0."""
+        a, h = self.a(x, p), self.h(x, p)
+        return np.concatenate([self.k(x, p), self.g(x, p), a, -a, h, -h])
+
+    def _affine(self, fun, p):
+        """(matrix, offset) of an affine map x -> fun(x, p): offset = fun(0), column i = fun(e_i) - offset (exact)."""
+        z = np.zeros(self.nx)
+        off = fun(z, p)
+        Mx = np.zeros((off.shape[0], self.nx))
+        for i in range(self.nx):
+            z[i] = 1.0
+            Mx[:, i] = fun(z, p) - off
+            z[i] = 0.0
+        return Mx, off
+
+    def M(self, p) -> np.ndarray:
+        return self._affine(self.k, p)[0]
+
+    def c(self, p) -> np.ndarray:
+        return self.k(np.zeros(self.nx), p)
+
+    def A(self, p) -> np.ndarray:
+        return self._affine(self.a, p)[0]
+
+    def b(self, p) -> np.ndarray:
+        return self.a(np.zeros(self.nx), p)
+
+    @property
+    def lbk(self):
+        return np.zeros(self.nk)
+
+    @property
+    def ubk(self):
+        return self.inf * np.ones(self.nk)
+
+    @property
+    def lba(self):
+        return np.zeros(self.na)
+
+    @property
+    def uba(self):
+        return np.zeros(self.na)
+
+    @property
+    def lbg(self):
+        return np.zeros(self.ng)
+
+    @property
+    def ubg(self):
+        return self.inf * np.ones(self.ng)
+
+    @property
+    def lbh(self):
+        return np.zeros(self.nh)
+
+    @property
+    def ubh(self):
+        return np.zeros(self.nh)
+
+    @property
+    def lbv(self):
+        return np.zeros(self.nv)
+
+    @property
+    def ubv(self):
+        return self.inf * np.ones(self.nv)
+
     def specify_linear_constraints(self, lin_ineq_constraints, lin_eq_constraints) -> None:
         self.lin_ineq_constraints = lin_ineq_constraints
         self.lin_eq_constraints = lin_eq_constraints
@@ -49,18 +152,53 @@ class Optimization:
         return self.decision_variables.has_discrete_variables()
 
 
-class QuadraticCostUnconstrained(Optimization):
+class _QuadraticCost:
+    """specify_quadratic_cost (optimization.py:219-223): P = 1/2 ddf, q = df(0); exact differences of the quadratic f."""
+
+    def q(self, p) -> np.ndarray:
+        e = np.zeros(self.nx)
+        out = np.zeros(self.nx)
+        for i in range(self.nx):
+            e[i] = 1.0
+            fp = self.f(e, p)
+            e[i] = -1.0
+            fm = self.f(e, p)
+            e[i] = 0.0
+            out[i] = 0.5 * (fp - fm)
+        return out
+
+    def P(self, p) -> np.ndarray:
+        n = self.nx
+        z = np.zeros(n)
+        f0 = self.f(z, p)
+        f1 = np.zeros(n)
+        for i in range(n):
+            z[i] = 1.0
+            f1[i] = self.f(z, p)
+            z[i] = 0.0
+        q = self.q(p)
+        Pm = np.zeros((n, n))
+        for i in range(n):
+            Pm[i, i] = f1[i] - f0 - q[i]
+            for j in range(i):
+                z[i] = z[j] = 1.0
+                Pm[i, j] = Pm[j, i] = 0.5 * (self.f(z, p) - f1[i] - f1[j] + f0)
+                z[i] = z[j] = 0.0
+        return Pm
+
+
+class QuadraticCostUnconstrained(_QuadraticCost, Optimization):
     pass
 
 
-class QuadraticCostLinearConstraints(Optimization):
+class QuadraticCostLinearConstraints(_QuadraticCost, Optimization):
     def __init__(self, decision_variables, parameters, cost_terms, lin_eq_constraints, lin_ineq_constraints):
         super().__init__(decision_variables, parameters, cost_terms)
         self.specify_linear_constraints(lin_ineq_constraints, lin_eq_constraints)
         self.specify_v()
 
 
-class QuadraticCostNonlinearConstraints(Optimization):
+class QuadraticCostNonlinearConstraints(_QuadraticCost, Optimization):
     def __init__(self, decision_variables, parameters, cost_terms, lin_eq_constraints, lin_ineq_constraints, eq_constraints, ineq_constraints):
         super().__init__(decision_variables, parameters, cost_terms)
         self.specify_linear_constraints(lin_ineq_constraints, lin_eq_constraints)

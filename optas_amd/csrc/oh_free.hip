@@ -373,6 +373,13 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
     }
     bool accept;
     if (D.first[b]) {
+      if (!(f == f) || !(fabs(f) < 1e300)) {  // non-finite seed / parameters: report, do not iterate
+        D.status[b] = OH_STATUS_NUMERICAL;
+        D.cur[b] = ts;
+        D.f_cur[b] = f;
+        D.stat[b] = f;
+        return false;
+      }
       accept = true;
       D.first[b] = 0;
     } else if (GUARD && GB.outer[b]) {

@@ -398,6 +398,13 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     }
     bool accept;
     if (D.first[b]) {
+      if (!(f == f) || !(fabs(f) < 1e300)) {  // non-finite seed / parameters: report, do not iterate (fmax would hide the NaN)
+        D.status[b] = OH_STATUS_NUMERICAL;
+        D.cur[b] = ts;
+        D.f_cur[b] = f;
+        D.stat[b] = f;
+        return false;
+      }
       accept = true;
       D.first[b] = 0;
     } else {
@@ -639,6 +646,12 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
     }
     bool accept;
     if (first) {
+      if (!(f == f) || !(fabs(f) < 1e300)) {  // non-finite seed / parameters
+        status = OH_STATUS_NUMERICAL;
+        f_cur = f;
+        stat = f;
+        break;
+      }
       accept = true;
       first = false;
     } else {

@@ -1,0 +1,88 @@
+"""Edge cases of the figure-eight family through the C ABI: shortest and longest horizons (T = 3 has a single free knot,
+T = OH_MAX_T = 128 exceeds the one-wave-per-instance tail kernel and runs on the batched kernels only), non-finite inputs
+(reported per instance, never a hang), call-order and descriptor errors (int codes + oh_last_error, no exceptions across the ABI)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import KUKA_KIN, SEED
+from optas_amd import _lib
+from optas_amd.backend import FigureEightBackend
+from optas_amd.models import RobotModel
+from oracle.robot import OracleRobot
+from oracle.structured import StructuredFigureEight, solve_structured_lm
+
+pytestmark = pytest.mark.gpu
+LINK = "end_effector_ball"
+QC0 = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+
+
+@pytest.mark.parametrize("T", [3, 4, 7, 128])
+def test_horizon_extremes_match_port(hip_lib, T):
+    prob = StructuredFigureEight(OracleRobot(KUKA_KIN), LINK, T=T)
+    robot = RobotModel(urdf_filename=KUKA_KIN)
+    be = FigureEightBackend(robot.kinematic_chain(LINK), T, prob.dt, prob.local_path, max_iter=300, tol=1e-6)
+    rng = np.random.default_rng(SEED + T)
+    B = 3
+    qc = QC0 + np.concatenate([np.zeros((1, 7)), rng.uniform(-0.1, 0.1, (B - 1, 7))])
+    x0 = np.concatenate([np.tile(qc, (1, T)), np.zeros((B, 7 * (T - 1)))], axis=1)
+    r = be.solve(x0, qc)
+    assert r.x.shape == (B, 7 * T + 7 * (T - 1))
+    for b in range(B):
+        s = solve_structured_lm(prob, qc[b], max_iter=300, tol=1e-6)
+        assert r.status[b] == s["status"] == 0 and abs(int(r.iters[b]) - s["iters"]) <= 1
+        assert abs(r.f[b] - s["f"]) <= 1e-9 * max(1.0, abs(s["f"]))
+        Q = r.x[b, : 7 * T].reshape(T, 7)
+        assert np.array_equal(Q[0], qc[b]) and np.array_equal(Q[1], qc[b])  # q_0 = q_1 = qc (fixed rows)
+    be.close()
+
+
+def test_non_finite_inputs_are_reported_per_instance(hip_lib):
+    prob = StructuredFigureEight(OracleRobot(KUKA_KIN), LINK, T=50)
+    robot = RobotModel(urdf_filename=KUKA_KIN)
+    be = FigureEightBackend(robot.kinematic_chain(LINK), 50, prob.dt, prob.local_path, max_iter=50, tol=1e-6)
+    B = 70
+    qc = np.tile(QC0, (B, 1))
+    qc[3, 2] = np.nan
+    qc[66, 0] = np.inf
+    x0 = np.concatenate([np.tile(qc, (1, 50)), np.zeros((B, 343))], axis=1)
+    r = be.solve(x0, qc)
+    bad = np.zeros(B, bool)
+    bad[[3, 66]] = True
+    assert (r.status[bad] != 0).all() and (r.status[~bad] == 0).all()  # neighbours in the same wavefront are unaffected
+    assert np.isfinite(r.f[~bad]).all() and np.ptp(r.f[~bad]) == 0.0
+    be.close()
+
+
+def test_abi_error_codes(hip_lib):
+    lib = hip_lib
+    lib.oh_last_error.restype = C.c_char_p
+    lp = np.zeros((50, 3))
+    h = C.c_void_p()
+
+    def desc(**kw):
+        d = dict(kind=_lib.OH_PROBLEM_FIGURE_EIGHT, T=50, ndof=7, dt=0.2, w_path=1000.0, w_vel=0.01,
+                 local_path=lp.ctypes.data_as(C.POINTER(C.c_double)), lock_orientation=1, fix_dq0=1, path_in_frame=1, max_iter=10, tol=1e-6,
+                 tol_feas=1e-9, hessian=0, mu0=0.0)
+        d.update(kw)
+        return _lib.oh_problem_desc(**d)
+
+    for bad in (dict(ndof=5), dict(T=2), dict(T=129), dict(dt=0.0), dict(hessian=7), dict(kind=42)):
+        d = desc(**bad)
+        assert lib.oh_create(C.byref(d), C.byref(h)) == 1 and lib.oh_last_error()  # OH_ERR_INVALID
+    d = desc()
+    assert lib.oh_create(C.byref(d), C.byref(h)) == 0
+    x = np.zeros((1, 693))
+    p = np.zeros((1, 7))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.oh_solve(h, 1, vp(x), vp(p), vp(x), None, None, None, None) == 3  # OH_ERR_STATE: constants not set
+    assert b"oh_set_constants" in lib.oh_last_error()
+    chain = RobotModel(urdf_filename=KUKA_KIN).kinematic_chain("lwr_arm_3_link")  # 3 of 7 joints: not a solver chain
+    assert lib.oh_set_constants(h, C.byref(chain)) == 0
+    assert lib.oh_solve(h, 1, vp(x), vp(p), vp(x), None, None, None, None) == 1
+    assert lib.oh_solve(h, 0, vp(x), vp(p), vp(x), None, None, None, None) == 1
+    g = _lib.oh_guards()
+    g.limits = 1
+    assert lib.oh_set_guards(h, C.byref(g)) == 1  # inequality rows are not lowered for the orientation-locked family
+    lib.oh_destroy(h)

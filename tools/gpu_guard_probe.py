@@ -28,7 +28,10 @@ rng=np.random.default_rng(0)
 qc = QC + np.concatenate([np.zeros((1,7)), rng.uniform(-0.05,0.05,(B-1,7))])
 par = np.concatenate([qc, np.full((B,4),0.15), np.tile(np.concatenate([np.concatenate([o,[0.1]]) for o in obs]),(B,1))],1)
 x0 = np.concatenate([np.tile(qc,(1,T)), np.zeros((B,7*(T-1)))],1)
+be.set_profiling(True)
+res = be.solve(x0, par)
 t=time.time(); res = be.solve(x0, par); wall=time.time()-t
+print('timing', be.timing())
 print("gpu", res.status[:8], res.iters[:8], res.f[:4], res.kkt[:4], "ms", be.timing()["solve_ms"], wall)
 r = OracleRobot("/root/repo/optas_amd/robots/kuka_lwr.kin.json", name="kukal"); r.add_base_frame("global_world", xyz=[0.0,-0.25,0.0])
 ch = FoldedChain(r, "end_effector_ball")

@@ -71,7 +71,12 @@ __global__ void __launch_bounds__(64) k_ik_solve(const oh_chain* __restrict__ ch
   double rho = P.rho0, shift = 0.0, h_prev = 1e300;
   double grad[N];
   bool act[N];
-  while (it < P.max_iter) {
+  {
+    // non-finite seed / parameters: report, do not iterate (fmax-based norms would hide a NaN)
+    const double m_init = ik_merit<N>(P, q, qn, e, pg, lam, rho);
+    if (!(m_init == m_init) || !(fabs(m_init) < 1e300)) st = OH_STATUS_NUMERICAL;
+  }
+  while (it < P.max_iter && st != OH_STATUS_NUMERICAL) {
     // ---- inner: projected Newton on the augmented Lagrangian ----
     while (it < P.max_iter) {
       double y[3], hmax = 0.0;

@@ -165,8 +165,8 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
         for (int cc = 0; cc < 4; ++cc) Pm[4 * r + cc] = 0.5 * (Pn[4 * r + cc] + Pn[4 * cc + r]);
       for (int j = 0; j < 4; ++j) { pv[j] = pn[j]; padj[j] = pa[j]; }
     }
+    if (!(stat == stat) || !(fval == fval) || !(fabs(fval) < 1e300) || !(feas == feas) || !(compl_ == compl_)) { status = OH_STATUS_NUMERICAL; break; }
     if (stat <= P.tol && feas <= P.tol && compl_ <= P.tol) { status = OH_STATUS_CONVERGED; break; }
-    if (!(stat == stat) || !(fval == fval)) { status = OH_STATUS_NUMERICAL; break; }
     if (it == P.max_iter) break;
 
     // ---- forward pass 1: Newton direction, fraction-to-the-boundary step lengths -------------------------------------------------

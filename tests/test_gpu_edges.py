@@ -55,6 +55,27 @@ def test_non_finite_inputs_are_reported_per_instance(hip_lib):
     be.close()
 
 
+def test_non_finite_inputs_other_families(hip_lib):
+    from optas_amd.backend import IKBackend, PointMassBackend
+
+    robot = RobotModel(urdf_filename=KUKA_KIN)
+    ik = IKBackend(robot.kinematic_chain(LINK), robot.lower_actuated_joint_limits, robot.upper_actuated_joint_limits)
+    qn = np.tile(np.deg2rad([0, 45, 0, -90, 0, -45, 0]), (5, 1))
+    p = np.concatenate([qn, np.tile([0.5, 0.2, 0.6], (5, 1))], axis=1)
+    p[1, 8] = np.nan
+    p[4, 0] = np.inf
+    r = ik.solve(qn, p)
+    assert list(r.status != 0) == [False, True, False, False, True]
+    pm = PointMassBackend()
+    P = np.zeros((3, 84))
+    P[:, 4:44:2] = P[:, 5:44:2] = np.linspace(0.0, 1.0, 20)  # goal ramp, obstacle at the origin far behind
+    P[:, 0:2] = -1.0
+    P[:, 44:84] = -5.0
+    P[1, 10] = np.nan
+    r = pm.solve(np.zeros((3, 80)), P)
+    assert r.status[0] == 0 and r.status[2] == 0 and r.status[1] != 0
+
+
 def test_abi_error_codes(hip_lib):
     lib = hip_lib
     lib.oh_last_error.restype = C.c_char_p

@@ -214,6 +214,15 @@ int oh_solve(oh_handle* h, int B, const double* x0, const double* p, double* x, 
 int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt,
                     void* d_iters, void* d_status);
 
+/* Closed-loop receding horizon for OH_PROBLEM_POINT_MASS_MPC, resident on the device: replaces the main loop
+   of example/point_mass_mpc.py (:293-306) around Controller.next_state (:156-161) for B plants at once.  Per tick k:
+     p_k = [curr; dcurr; goal; obs], goal[:, i] = curr + ramp * i, obs[:, i] = obs_table[k * advance + i];
+     seed = previous solution (:157-158); solve; the plant takes the plan's state at knot `advance` (plan(advance * dt), :160-161).
+   Host buffers: state0 [B][4] = (y, dy); obs_table [n_ticks * advance + T][2]; out: states [n_ticks + 1][B][4] (states[0] = state0),
+   f, iters, status [n_ticks][B] (any may be NULL).  Nothing crosses PCIe between the first and the last tick. */
+int oh_pm_rollout(oh_handle* h, int B, int n_ticks, int advance, double ramp, const double* state0, const double* obs_table, double* states,
+                  double* f, int* iters, int* status);
+
 /* Multipliers of the last oh_solve/oh_solve_device in the reference's form: lam_h [B][4*T] for the rows
    h = quat_c - quat(q_t) (signed mu = lam+ - lam- of the (h,-h) pair, optimization.py:47-51). Host buffer.
    OH_PROBLEM_IK: lam_h [B][3 + 2*ndof] = (mu of h = p_goal - p_link(q) (3), multipliers of q - lo >= 0 (ndof),

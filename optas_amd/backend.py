@@ -84,6 +84,26 @@ class PointMassBackend(_SolveMixin):
         self._h = C.c_void_p()
         _lib.check(lib.oh_create_pointmass(C.byref(desc), C.byref(self._h)), "oh_create_pointmass")
 
+    def rollout(self, state0: np.ndarray, obs_table: np.ndarray, n_ticks: int, advance: int = 2, ramp: float = 0.032):
+        """Closed-loop receding horizon on the device (oh_pm_rollout): state0 (B, 4) = (y, dy); obs_table (n_ticks*advance + T, 2).
+        Returns states (n_ticks + 1, B, 4), f, iters, status (n_ticks, B)."""
+        state0 = _lib.as_f64(state0).reshape(-1, 4)
+        B = state0.shape[0]
+        need = n_ticks * advance + self.T
+        obs_table = _lib.as_f64(obs_table).reshape(-1, 2)
+        assert obs_table.shape[0] >= need, f"obs_table needs {need} rows"
+        obs_table = np.ascontiguousarray(obs_table[:need])
+        states = np.empty((n_ticks + 1, B, 4))
+        f = np.empty((n_ticks, B))
+        iters = np.empty((n_ticks, B), dtype=np.int32)
+        status = np.empty((n_ticks, B), dtype=np.int32)
+        _lib.check(
+            _lib.load().oh_pm_rollout(self._h, B, int(n_ticks), int(advance), float(ramp), _lib._ptr(state0), _lib._ptr(obs_table), _lib._ptr(states),
+                                      _lib._ptr(f), _lib._ptr(iters), _lib._ptr(status)),
+            "oh_pm_rollout",
+        )
+        return states, f, iters, status
+
 
 class IKBackend(_SolveMixin):
     """OH_PROBLEM_IK handle (example/example.py): x = q, p = [q_nominal; p_goal]."""

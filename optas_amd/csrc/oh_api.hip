@@ -281,8 +281,7 @@ static int ik_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   return OH_OK;
 }
 
-static int pm_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters,
-                           void* d_status) {
+static int pm_prepare(oh_handle* h, int B) {
   HIPCHK(hipSetDevice(h->device));
   const int T = h->pm.T;
   const int Bp = (B + 63) / 64 * 64;
@@ -308,6 +307,13 @@ static int pm_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   }
   h->PmD.B = B;
   h->PmP = PmParams{T, h->pm.dt, h->pm.w_acc, h->pm.ylim, h->pm.vlim, h->pm.safe * h->pm.safe, h->pm.tol, h->pm.max_iter};
+  return OH_OK;
+}
+
+static int pm_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters,
+                           void* d_status) {
+  int rc = pm_prepare(h, B);
+  if (rc) return rc;
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   oh_launch_pm_solve(h->stream, h->PmP, h->PmD, (const double*)d_x0, (const double*)d_p, (double*)d_x, (double*)d_f, (double*)d_kkt,
                      (int*)d_iters, (int*)d_status);
@@ -728,6 +734,61 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
   if (x) HIPCHK(hipMemcpy(x, d_x, b_x, hipMemcpyDeviceToHost));
   if (f) HIPCHK(hipMemcpy(f, d_f, b_f, hipMemcpyDeviceToHost));
   if (kkt) HIPCHK(hipMemcpy(kkt, d_k, b_k, hipMemcpyDeviceToHost));
+  if (iters) HIPCHK(hipMemcpy(iters, d_it, b_i, hipMemcpyDeviceToHost));
+  if (status) HIPCHK(hipMemcpy(status, d_st, b_i, hipMemcpyDeviceToHost));
+  return OH_OK;
+}
+
+static int ensure_stage(oh_handle* h, size_t bytes);
+
+extern "C" int oh_pm_rollout(oh_handle* h, int B, int n_ticks, int advance, double ramp, const double* state0, const double* obs_table,
+                             double* states, double* f, int* iters, int* status) {
+  if (!h || !state0 || !obs_table) return fail(OH_ERR_INVALID, "oh_pm_rollout: null argument");
+  if (h->desc.kind != OH_PROBLEM_POINT_MASS_MPC) return fail(OH_ERR_STATE, "oh_pm_rollout: handle is not a point-mass MPC problem");
+  const int T = h->pm.T;
+  if (B < 1 || n_ticks < 1 || advance < 1 || advance >= T) return fail(OH_ERR_INVALID, "oh_pm_rollout: need B >= 1, n_ticks >= 1, 1 <= advance < T");
+  int rc = pm_prepare(h, B);
+  if (rc) return rc;
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t n_obs = (size_t)n_ticks * advance + T;
+  const size_t b_states = sizeof(double) * 4 * (size_t)B * (n_ticks + 1), b_obs = sizeof(double) * 2 * n_obs;
+  const size_t b_p = sizeof(double) * (4 + 4 * (size_t)T) * B, b_x = sizeof(double) * 4 * (size_t)T * B;
+  const size_t b_f = sizeof(double) * (size_t)B * n_ticks, b_i = sizeof(int) * (size_t)B * n_ticks;
+  rc = ensure_stage(h, al(b_states) + al(b_obs) + al(b_p) + 2 * al(b_x) + al(b_f) + 2 * al(b_i));
+  if (rc) return rc;
+  char* base = (char*)h->stage;
+  double* d_states = (double*)base; base += al(b_states);
+  double* d_obs = (double*)base; base += al(b_obs);
+  double* d_p = (double*)base; base += al(b_p);
+  double* d_xa = (double*)base; base += al(b_x);
+  double* d_xb = (double*)base; base += al(b_x);
+  double* d_f = (double*)base; base += al(b_f);
+  int* d_it = (int*)base; base += al(b_i);
+  int* d_st = (int*)base;
+  hipStream_t s = h->stream;
+  HIPCHK(hipMemcpyAsync(d_states, state0, sizeof(double) * 4 * (size_t)B, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_obs, obs_table, b_obs, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(d_xa, 0, b_x, s));  // first tick: zero seed (solver.py:76)
+  HIPCHK(hipEventRecord(h->ev0, s));
+  for (int k = 0; k < n_ticks; ++k) {
+    double* st_k = d_states + 4 * (size_t)B * k;
+    oh_launch_pm_tick_params(s, B, T, k, advance, ramp, st_k, d_obs, d_p);
+    double* x_seed = (k & 1) ? d_xb : d_xa;  // previous solution = warm start of this tick
+    double* x_sol = (k & 1) ? d_xa : d_xb;
+    oh_launch_pm_solve(s, h->PmP, h->PmD, x_seed, d_p, x_sol, d_f + (size_t)B * k, nullptr, d_it + (size_t)B * k, d_st + (size_t)B * k);
+    oh_launch_pm_advance(s, B, T, advance, x_sol, st_k + 4 * (size_t)B);
+  }
+  HIPCHK(hipEventRecord(h->ev1, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  for (double& t : h->timing) t = 0.0;
+  h->timing[4] = ms;
+  h->timing[5] = n_ticks;
+  h->last_B = B;
+  if (states) HIPCHK(hipMemcpy(states, d_states, b_states, hipMemcpyDeviceToHost));
+  if (f) HIPCHK(hipMemcpy(f, d_f, b_f, hipMemcpyDeviceToHost));
   if (iters) HIPCHK(hipMemcpy(iters, d_it, b_i, hipMemcpyDeviceToHost));
   if (status) HIPCHK(hipMemcpy(status, d_st, b_i, hipMemcpyDeviceToHost));
   return OH_OK;

@@ -117,6 +117,9 @@ struct PmBuffers {
 void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, const double* x0, const double* p, double* x, double* f, double* kkt,
                         int* iters, int* status);
 
+void oh_launch_pm_tick_params(hipStream_t s, int B, int T, int tick, int advance, double ramp, const double* state, const double* obs_table, double* p);
+void oh_launch_pm_advance(hipStream_t s, int B, int T, int advance, const double* x, double* state_next);
+
 // ---- OH_PROBLEM_IK -----------------------------------------------------------------------------------------
 struct IkParams {
   int ndof, max_iter;

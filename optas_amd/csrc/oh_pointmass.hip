@@ -245,6 +245,40 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
   if (status_o) status_o[b] = status;
 }
 
+// ---- closed-loop receding horizon kept on the device (example/point_mass_mpc.py main loop, :293-306 + Controller.next_state :156-161) ----
+// parameters of one tick from the current plant state: p = [curr; dcurr; goal; obs], goal[:, i] = curr + ramp * i,
+// obs[:, i] = obstacle centre at time index tick * advance + i of the table
+__global__ __launch_bounds__(64) void k_pm_tick_params(int B, int T, int tick, int advance, double ramp, const double* __restrict__ state,
+                                                       const double* __restrict__ obs_table, double* __restrict__ p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double* pb = p + (size_t)b * (4 + 4 * (size_t)T);
+  const double c0 = state[4 * (size_t)b], c1 = state[4 * (size_t)b + 1];
+  pb[0] = c0; pb[1] = c1; pb[2] = state[4 * (size_t)b + 2]; pb[3] = state[4 * (size_t)b + 3];
+  for (int i = 0; i < T; ++i) {
+    pb[4 + 2 * i] = c0 + ramp * i;
+    pb[4 + 2 * i + 1] = c1 + ramp * i;
+    pb[4 + 2 * T + 2 * i] = obs_table[2 * ((size_t)tick * advance + i)];
+    pb[4 + 2 * T + 2 * i + 1] = obs_table[2 * ((size_t)tick * advance + i) + 1];
+  }
+}
+// the plant follows the plan for `advance` knots (the reference evaluates its linear interpolant at advance * dt, i.e. at a knot)
+__global__ __launch_bounds__(64) void k_pm_advance(int B, int T, int advance, const double* __restrict__ x, double* __restrict__ state_next) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* xb = x + (size_t)b * 4 * T;
+  state_next[4 * (size_t)b] = xb[2 * advance];
+  state_next[4 * (size_t)b + 1] = xb[2 * advance + 1];
+  state_next[4 * (size_t)b + 2] = xb[2 * T + 2 * advance];
+  state_next[4 * (size_t)b + 3] = xb[2 * T + 2 * advance + 1];
+}
+void oh_launch_pm_tick_params(hipStream_t s, int B, int T, int tick, int advance, double ramp, const double* state, const double* obs_table, double* p) {
+  hipLaunchKernelGGL(k_pm_tick_params, dim3((B + 63) / 64), dim3(64), 0, s, B, T, tick, advance, ramp, state, obs_table, p);
+}
+void oh_launch_pm_advance(hipStream_t s, int B, int T, int advance, const double* x, double* state_next) {
+  hipLaunchKernelGGL(k_pm_advance, dim3((B + 63) / 64), dim3(64), 0, s, B, T, advance, x, state_next);
+}
+
 void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, const double* x0, const double* p, double* x, double* f, double* kkt,
                         int* iters, int* status) {
   hipLaunchKernelGGL(k_pm_solve, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p, x, f, kkt, iters, status);

@@ -97,3 +97,39 @@ def test_batch_4096_initial_states(hip_lib):
     assert np.array_equal(r.x, r2.x)  # deterministic
     print("point-mass batch: device ms", be.solve_ms(), "solves/s", B / (be.solve_ms() * 1e-3), "iters mean", r.iters.mean())
     be.close()
+
+
+def test_device_resident_receding_horizon_matches_host_loop(hip_lib):
+    """oh_pm_rollout: the closed loop of the reference's main() (:293-306) kept on the device must give the
+    same plant trajectory as the same loop driven tick by tick through HIPSolver from the host, and the numpy IPM port."""
+    n_ticks, advance, ramp, T, dt = 6, 2, 0.032, 20, 0.05
+    t0 = 2.0
+    tab = np.array([[0.15 * np.sin((t0 + dt * j) * np.pi - np.pi), 0.15 * np.cos((t0 + dt * j) * np.pi - np.pi) + 0.15] for j in range(n_ticks * advance + T)])
+    state0 = np.array([[-0.45, -0.35, 0.6, 0.6], [-0.6, -0.2, 0.5, 0.4], [0.3, -0.5, -0.2, 0.6]])
+    be = PointMassBackend(tol=1e-9)
+    states, f, iters, status = be.rollout(state0, tab, n_ticks, advance, ramp)
+    assert (status == 0).all() and states.shape == (n_ticks + 1, 3, 4) and np.array_equal(states[0], state0)
+    # (a) host-driven loop through the Solver interface, instance 0
+    c = Controller(solver_options={"tol": 1e-9})
+    curr, dcurr = state0[0, :2].copy(), state0[0, 2:].copy()
+    t = t0
+    for k in range(n_ticks):
+        obs, goal = obstacle_and_goal(t, curr)
+        assert np.allclose(obs.T, tab[k * advance : k * advance + T], atol=1e-15)
+        curr, dcurr, _, _ = c.next_state(curr, dcurr, goal, obs)
+        assert np.abs(np.concatenate([curr, dcurr]) - states[k + 1, 0]).max() < 1e-9
+        assert abs(c.solver.stats()["f"][0] - f[k, 0]) < 1e-10 and c.solver.number_of_iterations() == iters[k, 0]
+        t += advance * dt
+    # (b) numpy port, instance 2
+    nlp = PointMassMPCNLP()
+    st = state0[2].copy()
+    V0 = None
+    for k in range(n_ticks):
+        goal = np.stack([st[0] + ramp * np.arange(T), st[1] + ramp * np.arange(T)])
+        r = solve_pointmass_ipm(T, dt, nlp.w, 1.5, 1.0, nlp.safe_sq, st[:2], st[2:], goal, tab[k * advance : k * advance + T].T, V0=V0, tol=1e-9)
+        assert abs(r["f"] - f[k, 2]) < 1e-8
+        st = np.concatenate([r["Y"][:, advance], r["V"][:, advance]])
+        V0 = r["V"]
+        assert np.abs(st - states[k + 1, 2]).max() < 1e-7
+    # the plants stay outside the obstacle and inside the limits all along
+    assert (np.abs(states[:, :, :2]) <= 1.5 + 1e-9).all() and (np.abs(states[:, :, 2:]) <= 1.0 + 1e-9).all()

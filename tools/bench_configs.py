@@ -67,6 +67,29 @@ def main():
         P.append(np.concatenate([c, np.zeros(2), goal.T.reshape(-1), obs.T.reshape(-1)]))
     r = timed(be, np.zeros((B, 80)), np.array(P))
     out.append({"config": "3 point_mass_mpc.py tick (T=20, box limits, moving obstacle)", "batch": B, "solves_per_s": B / r["ms"] * 1e3, **r})
+    # ---- config 3 closed loop: 50 ticks on the device vs the same loop with one oh_solve per tick from the host ----
+    import time
+
+    n_ticks, adv, T = 50, 2, 20
+    tab = np.array([[0.15 * np.sin((2.0 + 0.05 * j) * np.pi - np.pi), 0.15 * np.cos((2.0 + 0.05 * j) * np.pi - np.pi) + 0.15] for j in range(n_ticks * adv + T)])
+    st0 = np.array([p[:4] for p in P])
+    be.rollout(st0, tab, 2)
+    t0 = time.perf_counter()
+    states, f, it, stt = be.rollout(st0, tab, n_ticks, adv)
+    wall = time.perf_counter() - t0
+    dev_ms = be.solve_ms()
+    t0 = time.perf_counter()
+    st, x0 = st0.copy(), np.zeros((B, 80))
+    for k in range(n_ticks):
+        goal = st[:, None, :2] + 0.032 * np.arange(T)[None, :, None]
+        pk = np.concatenate([st, goal.reshape(B, -1), np.tile(tab[k * adv : k * adv + T].reshape(-1), (B, 1))], 1)
+        r = be.solve(x0, pk)
+        x0 = r.x
+        st = np.concatenate([r.x[:, 2 * adv : 2 * adv + 2], r.x[:, 2 * T + 2 * adv : 2 * T + 2 * adv + 2]], 1)
+    host_wall = time.perf_counter() - t0
+    out.append({"config": "3 closed loop (oh_pm_rollout): plants x ticks, warm-started, device resident", "batch": B, "ticks": n_ticks,
+                "ticks_per_s_device": B * n_ticks / dev_ms * 1e3, "device_ms": dev_ms, "wall_ms": wall * 1e3, "host_driven_loop_wall_ms": host_wall * 1e3,
+                "converged_frac": float((stt == 0).mean()), "iters_mean": float(it.mean()), "max_state_diff_vs_host_loop": float(np.abs(st - states[-1]).max())})
     # ---- config 4 as shipped and synthetic ----
     from examples.dual_arm import SPHERE_LINKS, path_offsets
 

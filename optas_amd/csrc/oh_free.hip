@@ -422,15 +422,32 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
         stat = fmax(stat, fabs(rn[a]));
       }
     }
+    // software pipeline: the blocks of knot t-1 are requested before the factorisation of knot t+1's Schur complement, so
+    // that the only serial dependency of the sweep (S_{t+1} -> S_t) is not stretched by a memory round trip per knot
+    double Hn[NP], gn[N];
+    if (T - 2 >= P.t0) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Hn[i] = Drc[IDX(T - 2, NP, i)];
+#pragma unroll
+      for (int a = 0; a < N; ++a) gn[a] = gtc[IDX(T - 2, N, a)];
+    }
     for (int t = T - 2; t >= P.t0; --t) {
       double Ht[NP], gt[N];
 #pragma unroll
-      for (int i = 0; i < NP; ++i) Ht[i] = Drc[IDX(t, NP, i)];
+      for (int i = 0; i < NP; ++i) Ht[i] = Hn[i];
 #pragma unroll
       for (int a = 0; a < N; ++a) {
-        gt[a] = gtc[IDX(t, N, a)];
+        gt[a] = gn[a];
         stat = fmax(stat, fabs(gt[a]));
         Ht[tri(a, a)] += 2.0 * kap2 + mu;
+      }
+      {
+        const int tp = (t > P.t0) ? t - 1 : t;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) Hn[i] = Drc[IDX(tp, NP, i)];
+#pragma unroll
+        for (int a = 0; a < N; ++a) gn[a] = gtc[IDX(tp, N, a)];
+        __builtin_amdgcn_sched_barrier(0);
       }
       ok = chol_rcp<N>(S, rd, 1e-12) && ok;
       double Sinv[NP], wv[N];
@@ -503,14 +520,31 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
     fsub_rcp<N>(S, rd, zz);
     bsub_rcp<N>(S, rd, zz);
     double gd = 0.0, z2 = 0.0;
+    double Kn[NP], kn[N];
+    if (P.t0 + 1 < T) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Kn[i] = D.Kmat[IDX(P.t0 + 1, N * N, i)];
+#pragma unroll
+      for (int a = 0; a < N; ++a) kn[a] = D.kvec[IDX(P.t0 + 1, N, a)];
+    }
     for (int t = P.t0; t < T; ++t) {
       if (t > P.t0) {
-        double Sinv[NP], y[N];
+        double Sinv[NP], kv[N], y[N];
 #pragma unroll
-        for (int i = 0; i < NP; ++i) Sinv[i] = D.Kmat[IDX(t, N * N, i)];
+        for (int i = 0; i < NP; ++i) Sinv[i] = Kn[i];
+#pragma unroll
+        for (int a = 0; a < N; ++a) kv[a] = kn[a];
+        {
+          const int tn = (t + 1 < T) ? t + 1 : t;
+#pragma unroll
+          for (int i = 0; i < NP; ++i) Kn[i] = D.Kmat[IDX(tn, N * N, i)];
+#pragma unroll
+          for (int a = 0; a < N; ++a) kn[a] = D.kvec[IDX(tn, N, a)];
+          __builtin_amdgcn_sched_barrier(0);
+        }
         symv<N>(Sinv, zz, y);
 #pragma unroll
-        for (int a = 0; a < N; ++a) zz[a] = kap2 * y[a] - D.kvec[IDX(t, N, a)];
+        for (int a = 0; a < N; ++a) zz[a] = kap2 * y[a] - kv[a];
       }
 #pragma unroll
       for (int a = 0; a < N; ++a) {

@@ -107,3 +107,23 @@ def test_abi_error_codes(hip_lib):
     g.limits = 1
     assert lib.oh_set_guards(h, C.byref(g)) == 1  # inequality rows are not lowered for the orientation-locked family
     lib.oh_destroy(h)
+
+
+def test_other_robot_med7_matches_port(hip_lib):
+    """The reference script's default robot is the KUKA LBR Med7 (figure_eight_plan.py:26-28): different joint origins/axes
+    exercise the general-axis / non-identity pre-rotation paths of the kinematics walk."""
+    from conftest import MED7_KIN
+
+    prob = StructuredFigureEight(OracleRobot(MED7_KIN), "lbr_link_ee", T=50)
+    robot = RobotModel(urdf_filename=MED7_KIN)
+    be = FigureEightBackend(robot.kinematic_chain("lbr_link_ee"), 50, prob.dt, prob.local_path, max_iter=300, tol=1e-6)
+    rng = np.random.default_rng(SEED + 50)
+    B = 4
+    qc = QC0 + np.concatenate([np.zeros((1, 7)), rng.uniform(-0.1, 0.1, (B - 1, 7))])
+    x0 = np.concatenate([np.tile(qc, (1, 50)), np.zeros((B, 343))], axis=1)
+    r = be.solve(x0, qc)
+    for b in range(B):
+        s = solve_structured_lm(prob, qc[b], max_iter=300, tol=1e-6)
+        assert r.status[b] == s["status"] == 0 and abs(int(r.iters[b]) - s["iters"]) <= 1
+        assert abs(r.f[b] - s["f"]) <= 1e-9 * abs(s["f"])
+    be.close()

@@ -7,7 +7,11 @@
 
 #include "../../include/optas_hip.h"
 
+#ifdef OH_HOST_PORT  // oracle/cpu_port: the same functions compiled for the host cores (CPU baseline of bench.py, never product)
+#define OH_DEV __host__ __device__ __forceinline__
+#else
 #define OH_DEV __device__ __forceinline__
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // 3-vectors / 3x3 row-major matrices

@@ -252,7 +252,11 @@ OH_DEV bool chol_rcp(double (&S)[M * (M + 1) / 2], double (&rd)[M], double piv_m
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= S[tri(j, k)] * S[tri(j, k)];
     if (!(d > piv_min)) { ok = false; d = 1.0; }
+#if defined(__HIP_DEVICE_COMPILE__)
     const double inv = rsqrt(d);
+#else
+    const double inv = 1.0 / sqrt(d);  // host build of oracle/cpu_port
+#endif
     rd[j] = inv;
     S[tri(j, j)] = d * inv;
 #pragma unroll

@@ -15,6 +15,7 @@
 //   SOA=true : q[ndof][N], pose[7][N], J[6*ndof][N]      (coalesced; solver-internal / roofline)
 //   SOA=false: q[N][ndof], pose[N][7], J[N][6][ndof]     (reference layout at the ABI)
 // ---------------------------------------------------------------------------------------------
+#ifndef OH_HOST_PORT
 template <bool SOA>
 __global__ __launch_bounds__(256) void k_fk_jac(const oh_chain* __restrict__ ch, int n, const double* __restrict__ q,
                                                 double* __restrict__ pose, double* __restrict__ J) {
@@ -210,15 +211,15 @@ __global__ __launch_bounds__(256) void k_rnea(const oh_dynamics* __restrict__ dy
   }
 }
 
+#endif  // OH_HOST_PORT
+
 // ---------------------------------------------------------------------------------------------
 // Figure-eight family.  N = ndof (chain covers all joints in order), NZ = N-3 (orientation locked).
 // ---------------------------------------------------------------------------------------------
 
 // per-instance setup: references from qc, fixed knots, seed -> slot 0, solver state.
 template <int N>
-__global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const double* __restrict__ x0,
-                                              const double* __restrict__ pin) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+OH_DEV void setup_unit(const FigParams& P, const FigBuffers& D, const double* __restrict__ x0, const double* __restrict__ pin, const int b) {
   const int Bp = D.Bp;
   if (b >= D.B) {
     if (b < Bp) D.status[b] = OH_STATUS_CONVERGED;  // padding lanes never run
@@ -267,16 +268,20 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
   D.stat[b] = 0.0;
   D.feas[b] = 0.0;
 }
+#ifndef OH_HOST_PORT
+template <int N>
+__global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const double* __restrict__ x0, const double* __restrict__ pin) {
+  setup_unit<N>(P, D, x0, pin, blockIdx.x * blockDim.x + threadIdx.x);
+}
+#endif
 
 // K2: one lane per (instance b, free knot t): trial knot, retraction onto R(q_t)=Rc, FK chain + Jacobians,
 // tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block
 // (eval_knot in oh_figure8.h).
 template <int N>
-__global__ __launch_bounds__(256, 2) void k_eval(FigParams P, FigBuffers D, const int slot) {
+OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, const int b, const int t) {
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y + P.t0;
   const int Bp = D.Bp;
   if (b >= D.B) return;
   if (D.status[b] >= 0 || D.skip[b]) return;
@@ -331,14 +336,18 @@ __global__ __launch_bounds__(256, 2) void k_eval(FigParams P, FigBuffers D, cons
 #pragma unroll
   for (int i = 0; i < NP; ++i) D.Dr[slot][IDX(t, NP, i)] = Dr[i];
 }
+#ifndef OH_HOST_PORT
+template <int N>
+__global__ __launch_bounds__(256, 2) void k_eval(FigParams P, FigBuffers D, const int slot) {
+  eval_unit<N>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+}
+#endif
 
 // K2b: one lane per (instance b, free knot t), after k_eval: everything of the reduced block-tridiagonal
 // system that needs the neighbouring knots but not the recursion (couple_knot in oh_figure8.h).
 template <int N>
-__global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const int slot) {
+OH_DEV void couple_unit(const FigParams& P, const FigBuffers& D, const int slot, const int b, const int t) {
   constexpr int NZ = N - 3;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y + P.t0;
   const int Bp = D.Bp;
   if (b >= D.B) return;
   if (D.status[b] >= 0 || D.skip[b]) return;
@@ -372,6 +381,12 @@ __global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const
   }
   D.merit[slot][(size_t)t * Bp + b] = merit;
 }
+#ifndef OH_HOST_PORT
+template <int N>
+__global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const int slot) {
+  couple_unit<N>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+}
+#endif
 
 // K3: one lane per instance: accept/reject the trial point (Levenberg-Marquardt ratio test on the
 // objective; iterates are feasible by retraction), then the backward Riccati sweep over the reduced
@@ -419,7 +434,11 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     D.cur[b] = cur;
     if (!accept) {  // the accepted point sits where the next trial would go: sit the next launch out
       D.skip[b] = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
       atomicAdd(D.work + 1, 1ULL);
+#else
+      D.work[1] += 1ULL;
+#endif
     }
   }
   double mu = lm.mu;
@@ -541,6 +560,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   return true;
 }
 
+#ifndef OH_HOST_PORT
 template <int N>
 __global__ __launch_bounds__(64, 2) void k_step(FigParams P, FigBuffers D, const int slot) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -786,6 +806,8 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
   }
 }
 
+#endif  // OH_HOST_PORT
+
 // Least-squares multipliers of knot t at the point in slot `cur`, mapped to the reference's rows
 // h = quat_c - quat(q_t) (figure_eight_plan.py:105-107): stationarity reads G_t + Jc^T mu = 0 with
 // Jc = Jw on the manifold and dh/dq = -1/2 Ec Jw (Ec o = (o,0)(x)quat_c), hence nu = -2 Ec mu
@@ -854,11 +876,8 @@ OH_DEV void knot_multipliers(const FigParams& P, const FigBuffers& D, const int 
 // iterations, status and the h-row multipliers, written at the instance's ORIGINAL index (instances are
 // compacted while the batch drains).  only_done: emit just the instances that have finished.
 template <int N>
-__global__ __launch_bounds__(256) void k_finalize(FigParams P, FigBuffers D, int only_done, double* __restrict__ x,
-                                                  double* __restrict__ f, double* __restrict__ kkt, int* __restrict__ iters,
-                                                  int* __restrict__ status) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
+OH_DEV void finalize_unit(const FigParams& P, const FigBuffers& D, int only_done, double* __restrict__ x, double* __restrict__ f,
+                          double* __restrict__ kkt, int* __restrict__ iters, int* __restrict__ status, const int b, const int t) {
   const int Bp = D.Bp;
   if (b >= D.B) return;
   const int st = D.status[b];
@@ -892,7 +911,15 @@ __global__ __launch_bounds__(256) void k_finalize(FigParams P, FigBuffers D, int
     if (status) status[ob] = (st < 0) ? OH_STATUS_MAX_ITER : st;
   }
 }
+#ifndef OH_HOST_PORT
+template <int N>
+__global__ __launch_bounds__(256) void k_finalize(FigParams P, FigBuffers D, int only_done, double* __restrict__ x, double* __restrict__ f,
+                                                  double* __restrict__ kkt, int* __restrict__ iters, int* __restrict__ status) {
+  finalize_unit<N>(P, D, only_done, x, f, kkt, iters, status, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
+}
+#endif
 
+#ifndef OH_HOST_PORT
 // ---- batch compaction: drop finished instances so that the tail of slow instances keeps full waves ----
 // newidx[b] = rank of b among the running instances (or -1); single block, deterministic.
 __global__ __launch_bounds__(1024) void k_scan_running(FigBuffers D) {
@@ -1086,3 +1113,5 @@ bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffer
 #undef C
   return true;
 }
+
+#endif  // OH_HOST_PORT

@@ -320,7 +320,7 @@ def main():
         "tail_iteration_frac": tm["tail_iterations"] / max(1, tm["instance_launches"] + tm["tail_iterations"]),
         "compactions_per_step": tm["compactions"] / args.steps,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.hessian)
     if dist is not None:
         dist.barrier()

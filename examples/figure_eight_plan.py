@@ -17,7 +17,7 @@ def figure_eight_local_path(T: int, Tmax: float):
     return t, path
 
 
-def setup_solver(robot_name="kuka_lwr", link_ee="end_effector_ball", T=50, Tmax=10.0, solver_options=None, build_only=False):
+def setup_solver(robot_name="kuka_lwr", link_ee="end_effector_ball", T=50, Tmax=10.0, solver_options=None, build_only=False, limits=None):
     t, local = figure_eight_local_path(T, Tmax)
     dt = float(t[1] - t[0])
     kuka = optas_amd.RobotModel.builtin(robot_name, time_derivs=[0, 1])
@@ -37,6 +37,11 @@ def setup_solver(robot_name="kuka_lwr", link_ee="end_effector_ball", T=50, Tmax=
     dQ = builder.get_model_states(kuka_name, time_deriv=1)
     builder.add_cost_term("min_join_vel", 0.01 * sumsqr(dQ))
     builder.add_equality_constraint("no_eff_rot", kuka.get_global_link_quaternion(link_ee, Q), quatc)
+    if limits is not None:  # not in the shipped script: joint limits, True = the model's own, or (lo, up)
+        if limits is True:
+            builder.enforce_model_limits(kuka_name)
+        else:
+            builder.enforce_model_limits(kuka_name, lo=limits[0], up=limits[1])
     optimization = builder.build()
     if build_only:
         return kuka, optimization

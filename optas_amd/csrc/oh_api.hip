@@ -451,8 +451,10 @@ static int ensure_capacity(oh_handle* h, int B) {
 
 extern "C" int oh_set_guards(oh_handle* h, const oh_guards* g) {
   if (!h || !g) return fail(OH_ERR_INVALID, "oh_set_guards: null argument");
-  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT || h->desc.lock_orientation)
-    return fail(OH_ERR_INVALID, "oh_set_guards: inequality rows are lowered for the position-tracking family (lock_orientation = 0) only");
+  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT) return fail(OH_ERR_INVALID, "oh_set_guards: not a trajectory family");
+  if (h->desc.lock_orientation && g->n_links > 0)
+    return fail(OH_ERR_INVALID, "oh_set_guards: sphere rows are lowered for the position-tracking family (lock_orientation = 0) only; "
+                                "the orientation-locked family takes joint limits");
   if (g->n_links < 0 || g->n_links > OH_MAX_SPHERE_LINKS || g->n_obstacles < 0 || g->n_obstacles > OH_MAX_OBSTACLES)
     return fail(OH_ERR_INVALID, "oh_set_guards: too many sphere links / obstacles");
   if ((g->n_links == 0) != (g->n_obstacles == 0)) return fail(OH_ERR_INVALID, "oh_set_guards: sphere rows need both links and obstacles");
@@ -491,7 +493,7 @@ static int ensure_guards(oh_handle* h) {
     if (h->gpool) hipFree(h->gpool);
     h->gpool = nullptr;
     const size_t npar = (size_t)g.n_links + 4 * (size_t)g.n_obstacles;
-    const size_t nd = (size_t)T * GP.NC * Bp + npar * Bp + 2 * (size_t)T * Bp + 5 * (size_t)Bp;
+    const size_t nd = (size_t)T * GP.NC * Bp + npar * Bp + 4 * (size_t)T * Bp + 6 * (size_t)Bp;
     const size_t bytes = nd * sizeof(double) + 2 * (size_t)Bp * sizeof(int);
     hipError_t e = hipMalloc(&h->gpool, bytes);
     if (e != hipSuccess) return fail(OH_ERR_HIP, std::string("guard pool allocation failed: ") + hipGetErrorString(e));
@@ -509,6 +511,9 @@ static int ensure_guards(oh_handle* h) {
     GB.omega = take(Bp);
     GB.meas_prev = take(Bp);
     h->D.fpsi = take(Bp);
+    GB.mcv[0] = take((size_t)T * Bp);
+    GB.mcv[1] = take((size_t)T * Bp);
+    GB.meas = take(Bp);
     int* ip = (int*)d;
     GB.outer = ip; ip += Bp;
     GB.n_outer = ip;
@@ -594,7 +599,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   // compaction re-evaluates the survivors once.  The batch is compacted whenever at least half of it has
   // finished, so the slow tail keeps running in full wavefronts.
   const int hard_cap = 2 * h->desc.max_iter + 2 + 40;  // a rejected step costs two launches
-  const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation;
+  const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation && !guarded;
   bool tail_done = false;
   if (tail_ok && B <= h->tail_threshold) {  // small batch: the whole solve is one persistent launch
     oh_launch_tail(s, N, h->P, h->D, 0);
@@ -608,7 +613,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     }
     rebase = false;
     const int slot = it & 1;
-    if (h->P.lock) oh_launch_eval(s, N, h->P, h->D, slot);
+    if (h->P.lock && guarded) oh_launch_eval_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
+    else if (h->P.lock) oh_launch_eval(s, N, h->P, h->D, slot);
     else if (guarded) oh_launch_eval_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else oh_launch_eval_free(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(1); }
@@ -617,7 +623,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     const bool check = ((it + 1) % check_every == 0);
     if (check) HIPCHK(hipMemsetAsync(h->D.n_running, 0, sizeof(int), s));
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(3); }
-    if (h->P.lock) oh_launch_step(s, N, h->P, h->D, slot);
+    if (h->P.lock && guarded) oh_launch_step_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
+    else if (h->P.lock) oh_launch_step(s, N, h->P, h->D, slot);
     else if (guarded) oh_launch_step_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else oh_launch_step_free(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(2); }

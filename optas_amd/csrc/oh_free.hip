@@ -291,6 +291,7 @@ __global__ __launch_bounds__(64) void k_setup_guards(FigParams P, FigBuffers D, 
   GB.outer[b] = 0;
   GB.n_outer[b] = 0;
   D.fpsi[b] = 0.0;
+  if (GB.meas) GB.meas[b] = 0.0;
 }
 
 template <int N>

@@ -45,6 +45,8 @@ struct GuardBuffers {
   double* meas_prev;  // [Bp] |min(g, lam/rho)|_inf at the previous outer update
   int* outer;         // [Bp] 1: the next evaluation first refreshes the multipliers (outer iteration)
   int* n_outer;       // [Bp]
+  double* mcv[2];     // [slot][T][Bp] per-knot |min(g, lam/rho)|_inf (orientation-locked family; D.cv holds the orientation residual there)
+  double* meas;       // [Bp] its maximum over the knots of the accepted point
 };
 
 // Device buffers of one handle (SoA, instance index fastest; Bp = B rounded up to 64).
@@ -98,6 +100,8 @@ bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuff
 bool oh_launch_setup_guards(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const double* p);
 bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
 bool oh_launch_step_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
+bool oh_launch_eval_locked_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
+bool oh_launch_step_locked_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
 bool oh_launch_tail(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
                         int* iters, int* status);

@@ -278,8 +278,9 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
 // K2: one lane per (instance b, free knot t): trial knot, retraction onto R(q_t)=Rc, FK chain + Jacobians,
 // tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block
 // (eval_knot in oh_figure8.h).
-template <int N>
-OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, const int b, const int t) {
+template <int N, bool GUARD = false>
+OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, const int b, const int t, const GuardParams* GPp = nullptr,
+                      const GuardBuffers* GBp = nullptr) {
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
   const int Bp = D.Bp;
@@ -322,6 +323,52 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
 
   double phi, cv, g[N], Dr[NP], Z[N][NZ];
   eval_knot<N>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z);
+  if constexpr (GUARD) {
+    // joint-limit rows q - lo >= 0, up - q >= 0 (enforce_model_limits, builder.py:471-509) through the same augmented
+    // Lagrangian as the position-tracking family (oh_free.hip): gradients +-e_j, so W only gains a diagonal d_j and the
+    // reduced block gains Z^T diag(d) Z.  Sphere rows are not lowered for this family yet.
+    const GuardParams& GP = *GPp;
+    const GuardBuffers& GB = *GBp;
+    const bool upd = GB.outer[b] != 0;
+    const double rho_old = GB.rho[b];
+    const double rho = upd ? GB.rho_next[b] : rho_old;
+    double psi = 0.0, meas = 0.0, dd[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      dd[j] = 0.0;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const double gval = side ? GP.up[j] - q[j] : q[j] - GP.lo[j];
+        double* lam_ptr = GB.lam + IDX(t, GP.NC, side * N + j);
+        double lam = *lam_ptr;
+        if (upd) {
+          lam = fmax(0.0, lam - rho_old * gval);
+          *lam_ptr = lam;
+        }
+        const double sv = lam - rho * gval;
+        meas = fmax(meas, fabs(fmin(gval, lam / rho)));
+        if (sv > 0.0) {
+          psi += (sv * sv - lam * lam) / (2.0 * rho);
+          g[j] += side ? sv : -sv;
+          dd[j] += rho;
+        } else {
+          psi -= lam * lam / (2.0 * rho);
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NZ; ++a)
+#pragma unroll
+      for (int c2 = 0; c2 <= a; ++c2) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc += dd[j] * Z[j][a] * Z[j][c2];
+        Dr[tri(a, c2)] += acc;
+      }
+    phi += psi;
+    GB.psi[slot][(size_t)t * Bp + b] = psi;
+    GB.mcv[slot][(size_t)t * Bp + b] = meas;
+  }
 
 #pragma unroll
   for (int j = 0; j < N; ++j) D.q[slot][IDX(t, N, j)] = q[j];
@@ -392,8 +439,8 @@ __global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const
 // objective; iterates are feasible by retraction), then the backward Riccati sweep over the reduced
 // block-tridiagonal system (blocks prepared by k_eval/k_couple, next knot's blocks prefetched while the
 // current knot factorises) and the forward recursion for the reduced step z_t.  Returns "still running".
-template <int N>
-OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, const int ts) {
+template <int N, bool GUARD = false>
+OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, const int ts, const GuardBuffers* GBp = nullptr) {
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
   const int Bp = D.Bp;
@@ -406,10 +453,14 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   // ---- phase A: merit of the trial slot ---------------------------------------------------------
   {
     double f = D.fconst[b];
-    double feas = 0.0;
+    double feas = 0.0, fpsi = 0.0, meas = 0.0;
     for (int t = P.t0; t < T; ++t) {
       f += D.merit[ts][(size_t)t * Bp + b];
       feas = fmax(feas, D.cv[ts][(size_t)t * Bp + b]);
+      if constexpr (GUARD) {
+        fpsi += GBp->psi[ts][(size_t)t * Bp + b];
+        meas = fmax(meas, GBp->mcv[ts][(size_t)t * Bp + b]);
+      }
     }
     bool accept;
     if (D.first[b]) {
@@ -422,6 +473,11 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       }
       accept = true;
       D.first[b] = 0;
+    } else if (GUARD && GBp->outer[b]) {
+      // re-evaluation of the accepted point after a multiplier update: the merit function itself changed
+      accept = true;
+      GBp->outer[b] = 0;
+      GBp->rho[b] = GBp->rho_next[b];
     } else {
       accept = lm_accept(P, f, feas, D.f_cur[b], D.pred[b], lm);
       D.nun[b] = lm.nun;
@@ -430,6 +486,10 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       cur = ts;
       D.f_cur[b] = f;
       D.feas[b] = feas;
+      if constexpr (GUARD) {
+        D.fpsi[b] = fpsi;
+        GBp->meas[b] = meas;
+      }
     }
     D.cur[b] = cur;
     if (!accept) {  // the accepted point sits where the next trial would go: sit the next launch out
@@ -510,10 +570,42 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   }
   D.stat[b] = stat;
   const double feas_cur = D.feas[b];
-  if (stat <= P.tol && feas_cur <= P.tol_feas) {
-    D.status[b] = OH_STATUS_CONVERGED;
-    D.mu[b] = mu;
-    return false;
+  if constexpr (GUARD) {
+    const GuardBuffers& GB = *GBp;
+    if (stat <= GB.omega[b]) {
+      const double meas = GB.meas[b];
+      if (stat <= P.tol && feas_cur <= P.tol_feas && meas <= P.tol_feas) {
+        D.status[b] = OH_STATUS_CONVERGED;
+        D.mu[b] = mu;
+        return false;
+      }
+      if (iters >= P.max_iter) {
+        D.status[b] = OH_STATUS_MAX_ITER;
+        D.mu[b] = mu;
+        return false;
+      }
+      // outer iteration (see step_instance_free): refresh the multipliers at the accepted point, tighten the inner tolerance
+      const double rho = GB.rho[b];
+      GB.rho_next[b] = (meas > 0.25 * GB.meas_prev[b]) ? fmin(10.0 * rho, 1e8) : rho;
+      GB.meas_prev[b] = meas;
+      GB.omega[b] = fmax(P.tol, fmin(GB.omega[b], 0.1 * meas));
+      GB.outer[b] = 1;
+      GB.n_outer[b] += 1;
+      for (int t = P.t0; t < T; ++t) {
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) D.zstep[IDX(t, NZ, a)] = 0.0;
+      }
+      D.pred[b] = 0.0;
+      D.mu[b] = mu;
+      D.iters[b] = iters + 1;
+      return true;
+    }
+  } else {
+    if (stat <= P.tol && feas_cur <= P.tol_feas) {
+      D.status[b] = OH_STATUS_CONVERGED;
+      D.mu[b] = mu;
+      return false;
+    }
   }
   if (iters >= P.max_iter) {
     D.status[b] = OH_STATUS_MAX_ITER;
@@ -559,6 +651,43 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   D.iters[b] = iters + 1;
   return true;
 }
+
+#ifndef OH_HOST_PORT
+template <int N>
+__global__ __launch_bounds__(256) void k_eval_lg(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
+  eval_unit<N, true>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0, &GP, &GB);
+}
+template <int N>
+__global__ __launch_bounds__(64) void k_step_lg(FigParams P, FigBuffers D, GuardBuffers GB, const int slot) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool alive = (b < D.B) && (D.status[b] < 0);
+  const bool skipping = alive && D.skip[b];
+  const bool running = alive && !skipping;
+  {
+    const unsigned long long m = __ballot(running);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(D.work, (unsigned long long)__popcll(m));
+  }
+  bool still = skipping;
+  if (skipping) D.skip[b] = 0;
+  if (running) still = step_instance<N, true>(P, D, b, slot, &GB);
+  const unsigned long long m2 = __ballot(still);
+  if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
+}
+bool oh_launch_eval_locked_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
+  const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
+  if (n == 7) hipLaunchKernelGGL(k_eval_lg<7>, g, b, 0, s, P, D, GP, GB, slot);
+  else if (n == 6) hipLaunchKernelGGL(k_eval_lg<6>, g, b, 0, s, P, D, GP, GB, slot);
+  else return false;
+  return true;
+}
+bool oh_launch_step_locked_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
+  const dim3 g((D.B + 63) / 64), b(64);
+  if (n == 7) hipLaunchKernelGGL(k_step_lg<7>, g, b, 0, s, P, D, GB, slot);
+  else if (n == 6) hipLaunchKernelGGL(k_step_lg<6>, g, b, 0, s, P, D, GB, slot);
+  else return false;
+  return true;
+}
+#endif  // OH_HOST_PORT
 
 #ifndef OH_HOST_PORT
 template <int N>

@@ -39,6 +39,8 @@ class FigureEightSpec:
     qc_name: str
     q_name: str
     dq_name: str
+    lo: Optional[np.ndarray] = None  # joint limits (enforce_model_limits), None: no inequality rows
+    up: Optional[np.ndarray] = None
 
 
 def _unscale(e):
@@ -72,8 +74,19 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
     T = Q.n
     if dQ.n != T - 1:
         no("derivs_align=True is not lowered")
-    if opt.nk or opt.ng:
-        no("inequality rows are not lowered for this family yet")
+    if opt.ng:
+        no("nonlinear inequality rows are not lowered for this family yet")
+    lo = up = None
+    n = robot.ndof
+    for label, d in opt.lin_ineq_constraints.items():
+        if isinstance(d, Sub) and d.a is Q and isinstance(d.b, Const) and d.b.value.shape == (n, 1):
+            lo = d.b.value[:, 0] if lo is None else np.maximum(lo, d.b.value[:, 0])
+        elif isinstance(d, Sub) and d.b is Q and isinstance(d.a, Const) and d.a.value.shape == (n, 1):
+            up = d.a.value[:, 0] if up is None else np.minimum(up, d.a.value[:, 0])
+        else:
+            no(f"linear inequality '{label}' is not a joint-position bound over the whole trajectory")
+    if (lo is None) != (up is None):
+        no("joint limits need both the lower and the upper row block")
 
     # linear equalities: fix q_0 = qc, fix dq_0 = 0, Euler integration
     qc: Optional[ParamRef] = None
@@ -147,7 +160,7 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
             no(f"cost '{label}' not recognised")
     if w_path is None or w_vel is None:
         no("need both the path-tracking and the joint-velocity cost terms")
-    return FigureEightSpec(robot, link, T, dt, w_path, w_vel, np.ascontiguousarray(local.T), qc.name, q_name, dq_name)
+    return FigureEightSpec(robot, link, T, dt, w_path, w_vel, np.ascontiguousarray(local.T), qc.name, q_name, dq_name, lo, up)
 
 
 @dataclass

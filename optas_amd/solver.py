@@ -156,6 +156,12 @@ class HIPSolver(Solver):
             o.pop("hessian", None)
         if isinstance(spec, FigureEightSpec):
             chain = spec.robot.kinematic_chain(spec.link)
+            guards = None
+            if spec.lo is not None:
+                guards = _lib.oh_guards()
+                guards.limits = 1
+                for j in range(spec.robot.ndof):
+                    guards.q_lo[j], guards.q_up[j] = float(spec.lo[j]), float(spec.up[j])
             self._backend = FigureEightBackend(
                 chain,
                 spec.T,
@@ -168,6 +174,7 @@ class HIPSolver(Solver):
                 tol_feas=float(o.pop("tol_feas", 1e-9)),
                 hessian=hessian,
                 mu0=float(o.pop("mu0", 0.0)),
+                guards=guards,
             )
         elif isinstance(spec, PointMassSpec):
             o.pop("hessian", None)

@@ -65,7 +65,7 @@ void solve_one(const FigParams& P, Workspace& w, const double* x0, const double*
     for (int t = P.t0; t < P.T; ++t) eval_unit<N>(P, D, slot, 0, t);      // both return at once for a skipping instance
     for (int t = P.t0; t < P.T; ++t) couple_unit<N>(P, D, slot, 0, t);
     if (D.skip[0]) D.skip[0] = 0;
-    else step_instance<N>(P, D, 0, slot);
+    else step_instance<N, false>(P, D, 0, slot);
   }
   for (int t = 0; t < P.T; ++t) finalize_unit<N>(P, D, 0, x, f, kkt, iters, status, 0, t);
 }

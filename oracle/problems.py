@@ -568,3 +568,24 @@ class GuardedDualArmNLP(DualArmNLP):
 
     def df(self, x, p):
         return super().df(x, p[: 2 * self.n])
+
+
+class LimitedFigureEightNLP(FigureEightNLP):
+    """example/figure_eight_plan.py plus builder.enforce_model_limits(kuka_name) with limits (lo, up) (builder.py:471-509):
+    k = [vec(Q - lo); vec(up - Q)] (rows "_l", "_r"), everything else as FigureEightNLP."""
+
+    def __init__(self, robot, link, lo, up, **kw):
+        super().__init__(robot, link, **kw)
+        self.lo, self.up = np.asarray(lo, dtype=float), np.asarray(up, dtype=float)
+        self.nk = 2 * self.n * self.T
+
+    def k(self, x, p):
+        Q, _ = self.split(x)
+        return np.concatenate([(Q - self.lo[:, None]).T.reshape(-1), (self.up[:, None] - Q).T.reshape(-1)])
+
+    def dk(self, x, p):
+        nq = self.n * self.T
+        M = np.zeros((self.nk, self.nx))
+        M[:nq, :nq] = np.eye(nq)
+        M[nq:, :nq] = -np.eye(nq)
+        return M

@@ -307,14 +307,35 @@ def retract(prob, Q, Rc, tol=1e-10, max_corr=4):
     return Q
 
 
-def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False, hessian="hybrid"):
+def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False, hessian="hybrid", limits=None, rho0=None):
     """Returns dict(Q, f, iters (= steps solved: accepted + rejected), rejected, stat, feas, status).
+    limits = (lo, up): joint-limit rows q_t - lo >= 0, up - q_t >= 0 at the free knots through the augmented Lagrangian of
+    oracle/guarded.py (k_eval_lg / k_step_lg); adds "lam" (T, 2n), "meas", "outers" to the result.
     hessian: "gauss_newton" | "exact" | "hybrid" (Gauss-Newton until the reduced gradient of the accepted point is below
     1e-5 * w_path, exact curvature afterwards: OH_HESSIAN_HYBRID); exact=True is shorthand for "exact"."""
     if exact:
         hessian = "exact"
     hyb_switch = 1e-5 * prob.w_path
     stat_prev = np.inf
+    guard = limits is not None
+    if guard:
+        g_lo, g_up = np.asarray(limits[0], dtype=float), np.asarray(limits[1], dtype=float)
+        lam_g = np.zeros((prob.T, 2 * prob.n))
+        rho_g = rho_next = (10.0 * prob.w_path) if rho0 is None else rho0
+        omega, meas_prev, outer, outers = max(tol, 1e-2), np.inf, False, 0
+
+    def guard_terms(Q, lam_g, rho_g):
+        gv = np.concatenate([Q - g_lo[None], g_up[None] - Q], axis=1)  # (T, 2n)
+        sv = np.maximum(0.0, lam_g - rho_g * gv)
+        sv[:2] = 0.0
+        psi = (sv * sv - lam_g * lam_g) / (2.0 * rho_g)
+        psi[:2] = 0.0
+        n_ = Q.shape[1]
+        dgrad = -sv[:, :n_] + sv[:, n_:]
+        ddiag = rho_g * ((sv[:, :n_] > 0).astype(float) + (sv[:, n_:] > 0).astype(float))
+        meas = np.abs(np.minimum(gv, lam_g / rho_g))
+        meas[:2] = 0.0
+        return gv, psi.sum(1), dgrad, ddiag, float(meas.max())
     T, n = prob.T, prob.n
     path, Rc = prob.references(qc)
     kap = prob.kappa
@@ -334,12 +355,25 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         # ---- k_eval + k_couple on the trial point
         use_exact = hessian == "exact" or (hessian == "hybrid" and not first and stat_prev <= hyb_switch)
         phi, g, W, c, Jc = prob.evaluate(Qt, path, Rc, lam=lam, exact=use_exact)
+        if guard:
+            if outer:  # multiplier refresh at the accepted point with the old penalty, evaluation with the new one
+                gv_now = np.concatenate([Qt - g_lo[None], g_up[None] - Qt], axis=1)
+                lam_g = np.maximum(0.0, lam_g - rho_g * gv_now)
+                lam_g[:2] = 0.0
+                rho_g = rho_next
+                outers += 1
+            gv, psi_t, dgrad, ddiag, meas_t = guard_terms(Qt, lam_g, rho_g)
+            phi = phi + psi_t
+            g = g + dgrad
+            W = W + ddiag[:, :, None] * np.eye(n)[None]
         f_t = float(np.sum(phi) + prob.smooth_cost(Qt))
         feas_t = float(np.max(np.abs(c[F])))
         # ---- k_step phase A
-        if first:
+        if first or (guard and outer):
             accept = True
             first = False
+            if guard:
+                outer = False
         else:
             rho = (cur["f"] - f_t) / max(pred, 1e-300)
             accept = np.isfinite(f_t) and (rho > 1e-4 or (pred <= 1e-15 * abs(cur["f"]) and f_t <= cur["f"] + 1e-14 * abs(cur["f"])))
@@ -384,7 +418,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
             ndiag[T - 1] = 1.0
             Dfull = W + (2 * kap * ndiag)[:, None, None] * np.eye(n)[None]
             cur = {
-                "Q": Qt, "f": f_t, "feas": feas_t, "Z": Zs,
+                "Q": Qt, "f": f_t, "feas": feas_t, "Z": Zs, "meas": meas_t if guard else 0.0, "fpsi": float(np.sum(psi_t)) if guard else 0.0,
                 "gt": np.einsum("tij,ti->tj", Zs[F], G[F]),
                 "Dr": np.einsum("tia,tij,tjb->tab", Zs[F], Dfull[F], Zs[F]),
                 "Er": -2 * kap * np.einsum("tia,tib->tab", Zs[2 : T - 1], Zs[3:T]),
@@ -402,7 +436,22 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
             mu = max(4.0 * mu, 1e-2)
         if verbose:
             print(f"  steps {iters:3d} f={cur['f']:.12f} stat={stat:.3e} mu={mu:.3g} rejected={rejected}")
-        if stat <= tol and cur["feas"] <= tol_feas:
+        if guard:
+            if stat <= omega:
+                if stat <= tol and cur["feas"] <= tol_feas and cur["meas"] <= tol_feas:
+                    status = 0
+                    break
+                if iters >= max_iter:
+                    break
+                rho_next = min(rho_g * 10.0, 1e8) if cur["meas"] > 0.25 * meas_prev else rho_g
+                meas_prev = cur["meas"]
+                omega = max(tol, min(omega, 0.1 * cur["meas"]))
+                outer = True
+                Qt = cur["Q"]
+                pred = 0.0
+                iters += 1
+                continue
+        elif stat <= tol and cur["feas"] <= tol_feas:
             status = 0
             break
         if iters >= max_iter:
@@ -412,7 +461,13 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         Qt[F] += np.einsum("tia,ta->ti", cur["Z"][F], z)
         Qt = retract(prob, Qt, Rc)
         iters += 1
-    return {"Q": cur["Q"], "f": cur["f"], "iters": iters, "rejected": rejected, "stat": stat, "feas": cur["feas"], "status": status, "path": path, "Rc": Rc}
+    out = {"Q": cur["Q"], "f": cur["f"] - cur["fpsi"], "iters": iters, "rejected": rejected, "stat": stat, "feas": cur["feas"], "status": status, "path": path, "Rc": Rc}
+    if guard:
+        gv = np.concatenate([cur["Q"] - g_lo[None], g_up[None] - cur["Q"]], axis=1)
+        lam_out = np.maximum(0.0, lam_g - rho_g * gv)
+        lam_out[:2] = 0.0
+        out.update(lam=lam_out, lam_stored=lam_g, meas=cur["meas"], outers=outers, g=gv)
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------

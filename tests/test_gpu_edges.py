@@ -105,7 +105,8 @@ def test_abi_error_codes(hip_lib):
     assert lib.oh_solve(h, 0, vp(x), vp(p), vp(x), None, None, None, None) == 1
     g = _lib.oh_guards()
     g.limits = 1
-    assert lib.oh_set_guards(h, C.byref(g)) == 1  # inequality rows are not lowered for the orientation-locked family
+    g.n_links = g.n_obstacles = 1
+    assert lib.oh_set_guards(h, C.byref(g)) == 1  # sphere rows are not lowered for the orientation-locked family (joint limits are)
     lib.oh_destroy(h)
 
 

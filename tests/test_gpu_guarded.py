@@ -137,3 +137,41 @@ def test_synthetic_config4_batch_properties(hip_lib, golden):
     ms = sum(be.timing()["solve_ms"] for _, be in mb.arms)
     print("config 4 synthetic: %d dual-arm instances (T=%d, 2 x %d rows) in %.1f ms device, iterations p50 %d max %d" % (B, T, 38 * T, ms, np.median(res.iters), res.iters.max()))
     mb.close()
+
+
+def test_figure_eight_with_joint_limits(hip_lib):
+    """enforce_model_limits on the orientation-locked family (B4 on config 2): tightened limits so that rows are active; the GPU
+    runs the state machine of oracle/structured.py:solve_structured_lm(limits=...), and the literal-layout KKT check is independent."""
+    from examples.figure_eight_plan import setup_solver as figure_eight
+    from oracle.problems import LimitedFigureEightNLP
+    from oracle.structured import StructuredFigureEight, solve_structured_lm
+
+    kuka_o = OracleRobot(KUKA_KIN)
+    qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    lo, up = kuka_o.lower_actuated_joint_limits.copy(), kuka_o.upper_actuated_joint_limits.copy()
+    up[3], lo[1] = -1.294, 0.412  # inside the range the unconstrained optimum sweeps (joint 4 up to -1.244, joint 2 down to 0.382)
+    kuka, solver = figure_eight(limits=(lo, up), solver_options={"max_iter": 400})
+    assert (solver.opt.nk, solver.opt.nv) == (700, 1814)
+    solver.reset_parameters({"qc": qc})
+    solver.reset_initial_seed({"kuka/q/x": np.tile(qc.reshape(-1, 1), (1, 50))})
+    sol = solver.solve()
+    assert solver.did_solve()
+    prob = StructuredFigureEight(kuka_o, "end_effector_ball", T=50)
+    s = solve_structured_lm(prob, qc, limits=(lo, up), max_iter=400)
+    assert s["status"] == 0 and abs(solver.number_of_iterations() - s["iters"]) <= 1
+    assert abs(solver.stats()["f"][0] - s["f"]) < 1e-8 and s["f"] > 11.0  # the limits cost ~2.85 over the free optimum 8.498
+    Q = np.asarray(sol["kuka/q"])
+    assert (Q >= lo[:, None] - 1e-9).all() and (Q <= up[:, None] + 1e-9).all() and np.abs(Q.T - s["Q"]).max() < 1e-5
+    nlp = LimitedFigureEightNLP(kuka_o, "end_effector_ball", lo, up, T=50)
+    x = solver.opt.decision_variables.dict2vec(sol)
+    assert abs(nlp.f(x, qc) - solver.stats()["f"][0]) < 1e-10 and np.abs(nlp.a(x, qc)).max() < 1e-12 and np.abs(nlp.h(x, qc)).max() < 1e-9
+    k = kkt_reference_form(nlp, x, qc, active_tol=1e-6)
+    assert k["stationarity"] < 1e-5 and k["feasibility"] < 1e-9 and k["complementarity"] < 1e-7
+    lam = solver.backend.multipliers(1)[0]
+    assert lam.shape == (50, 14) and (lam >= 0).all() and int((lam > 0).sum()) == int((s["lam"] > 0).sum()) > 0
+    # with the model's own (inactive) limits the answer is the unconstrained one
+    _, s2 = figure_eight(limits=True)
+    s2.reset_parameters({"qc": qc})
+    s2.reset_initial_seed({"kuka/q/x": np.tile(qc.reshape(-1, 1), (1, 50))})
+    s2.solve()
+    assert s2.did_solve() and abs(s2.stats()["f"][0] - 8.498170214656) < 1e-7

@@ -17,7 +17,7 @@ def figure_eight_local_path(T: int, Tmax: float):
     return t, path
 
 
-def setup_solver(robot_name="kuka_lwr", link_ee="end_effector_ball", T=50, Tmax=10.0, solver_options=None, build_only=False, limits=None):
+def setup_solver(robot_name="kuka_lwr", link_ee="end_effector_ball", T=50, Tmax=10.0, solver_options=None, build_only=False, limits=None, obstacles=None, sphere_links=None):
     t, local = figure_eight_local_path(T, Tmax)
     dt = float(t[1] - t[0])
     kuka = optas_amd.RobotModel.builtin(robot_name, time_derivs=[0, 1])
@@ -42,6 +42,8 @@ def setup_solver(robot_name="kuka_lwr", link_ee="end_effector_ball", T=50, Tmax=
             builder.enforce_model_limits(kuka_name)
         else:
             builder.enforce_model_limits(kuka_name, lo=limits[0], up=limits[1])
+    if obstacles is not None:  # not in the shipped script: sphere clearances (obstacle names; parameters are set at solve time)
+        builder.sphere_collision_avoidance_constraints(kuka_name, list(obstacles), link_names=sphere_links)
     optimization = builder.build()
     if build_only:
         return kuka, optimization

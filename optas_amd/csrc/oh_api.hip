@@ -452,9 +452,6 @@ static int ensure_capacity(oh_handle* h, int B) {
 extern "C" int oh_set_guards(oh_handle* h, const oh_guards* g) {
   if (!h || !g) return fail(OH_ERR_INVALID, "oh_set_guards: null argument");
   if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT) return fail(OH_ERR_INVALID, "oh_set_guards: not a trajectory family");
-  if (h->desc.lock_orientation && g->n_links > 0)
-    return fail(OH_ERR_INVALID, "oh_set_guards: sphere rows are lowered for the position-tracking family (lock_orientation = 0) only; "
-                                "the orientation-locked family takes joint limits");
   if (g->n_links < 0 || g->n_links > OH_MAX_SPHERE_LINKS || g->n_obstacles < 0 || g->n_obstacles > OH_MAX_OBSTACLES)
     return fail(OH_ERR_INVALID, "oh_set_guards: too many sphere links / obstacles");
   if ((g->n_links == 0) != (g->n_obstacles == 0)) return fail(OH_ERR_INVALID, "oh_set_guards: sphere rows need both links and obstacles");

@@ -19,6 +19,69 @@ OH_DEV void orient_residual(const double* Re, const double* Rc, double* c, doubl
   M[0] += 0.5 * tr; M[4] += 0.5 * tr; M[8] += 0.5 * tr;
 }
 
+// Sphere-clearance rows of one knot (sphere_collision_avoidance_constraints, builder.py:366-417): walks the chain at q and calls
+// row(l, o, g, dg) for every sphere link l and obstacle o with g = ||c_l - o||^2 - (r_l + r_o)^2 and dg = 2 J_l^T (c_l - o).
+// The rows of link l are emitted right after the joint it hangs on: c_l and the columns z_j x (c_l - p_j), j <= joint(l), of its
+// position Jacobian only need frames already visited.  par: [n_links + 4 n_obs][Bp] link radii, then x, y, z, r per obstacle.
+template <int N, class F>
+OH_DEV void sphere_rows_walk(const oh_chain* __restrict__ ch, const GuardParams& GP, const double* __restrict__ par, const size_t Bp, const int b,
+                             const double (&q)[N], F&& row) {
+  double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0}, p[3] = {0.0, 0.0, 0.0}, z[N][3], pj[N][3];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double tv[3];
+    mv3(R, ch->p0[k], tv);
+    p[0] += tv[0]; p[1] += tv[1]; p[2] += tv[2];
+    if (!ch->r0ident[k]) {
+      double Rn[9];
+      mm3(R, ch->R0[k], Rn);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    }
+    pj[k][0] = p[0]; pj[k][1] = p[1]; pj[k][2] = p[2];
+    if (ch->jtype[k] == 0) {
+      double sn, cs;
+      sincos_joint(q[k], &sn, &cs);
+      const int code = ch->axcode[k];
+      if (code != 0) rot_principal_right(R, code, sn, cs, z[k]);
+      else rot_axis_right(R, ch->axis[k], sn, cs, z[k]);
+    } else {
+      mv3(R, ch->axis[k], z[k]);
+      p[0] += z[k][0] * q[k]; p[1] += z[k][1] * q[k]; p[2] += z[k][2] * q[k];
+    }
+    for (int l = 0; l < GP.n_links; ++l) {
+      if (GP.link_joint[l] != k) continue;
+      double c[3];
+      mv3(R, GP.link_off[l], c);
+      c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
+      double Jl[N][3];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        if (j <= k) {
+          if (ch->jtype[j] == 0) {
+            const double dd[3] = {c[0] - pj[j][0], c[1] - pj[j][1], c[2] - pj[j][2]};
+            cross3(z[j], dd, Jl[j]);
+          } else {
+            Jl[j][0] = z[j][0]; Jl[j][1] = z[j][1]; Jl[j][2] = z[j][2];
+          }
+        } else {
+          Jl[j][0] = Jl[j][1] = Jl[j][2] = 0.0;
+        }
+      }
+      const double rl = par[(size_t)l * Bp + b];
+      for (int o = 0; o < GP.n_obs; ++o) {
+        const size_t ob = (size_t)(GP.n_links + 4 * o) * Bp + b;
+        const double d[3] = {c[0] - par[ob], c[1] - par[ob + Bp], c[2] - par[ob + 2 * Bp]};
+        const double rr = rl + par[ob + 3 * Bp];
+        double dg[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) dg[j] = 2.0 * dot3(Jl[j], d);
+        row(l, o, dot3(d, d) - rr * rr, dg);
+      }
+    }
+  }
+}
+
 // One knot: retraction onto R(q)=Rc (q is updated in place), FK chain + Jacobians, tracking cost phi,
 // constraint violation cv, tracking gradient g, Hessian block W (Gauss-Newton, or exact with the
 // multiplier estimate from Gprev), Householder null-space basis Z of the orientation rows, Dr = Z^T W Z.

@@ -316,7 +316,12 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
   double Gprev[N];
   // exact curvature: always (OH_HESSIAN_EXACT) or once the accepted point is nearly stationary (OH_HESSIAN_HYBRID)
-  const bool exact = (P.hessian == OH_HESSIAN_EXACT) || (P.hessian == OH_HESSIAN_HYBRID && !first && D.stat[b] <= P.hyb_switch);
+  bool exact = (P.hessian == OH_HESSIAN_EXACT) || (P.hessian == OH_HESSIAN_HYBRID && !first && D.stat[b] <= P.hyb_switch);
+  if constexpr (GUARD) {
+    // the exact block carries no curvature of the sphere rows (-s d2g, s ~ w_path): with them the exact model is worse than
+    // Gauss-Newton (the oracle run crawls), so sphere-guarded problems stay on Gauss-Newton
+    if (GPp->n_links > 0) exact = false;
+  }
   const bool have_G = exact && !first;
 #pragma unroll
   for (int k = 0; k < N; ++k) Gprev[k] = have_G ? D.Gfull[cur][IDX(t, N, k)] : 0.0;
@@ -324,18 +329,21 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   double phi, cv, g[N], Dr[NP], Z[N][NZ];
   eval_knot<N>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z);
   if constexpr (GUARD) {
-    // joint-limit rows q - lo >= 0, up - q >= 0 (enforce_model_limits, builder.py:471-509) through the same augmented
-    // Lagrangian as the position-tracking family (oh_free.hip): gradients +-e_j, so W only gains a diagonal d_j and the
-    // reduced block gains Z^T diag(d) Z.  Sphere rows are not lowered for this family yet.
+    // inequality rows through the same augmented Lagrangian as the position-tracking family (oh_free.hip), added after the
+    // retraction: joint limits q - lo >= 0, up - q >= 0 (enforce_model_limits, builder.py:471-509) have gradients +-e_j, so W gains
+    // a diagonal d_j and the reduced block Z^T diag(d) Z; a sphere row (builder.py:366-417) adds rho (Z^T dg)(Z^T dg)^T.
     const GuardParams& GP = *GPp;
     const GuardBuffers& GB = *GBp;
     const bool upd = GB.outer[b] != 0;
     const double rho_old = GB.rho[b];
     const double rho = upd ? GB.rho_next[b] : rho_old;
     double psi = 0.0, meas = 0.0, dd[N];
+    const int nl = GP.limits ? 2 * N : 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) dd[j] = 0.0;
+    if (GP.limits) {
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      dd[j] = 0.0;
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
         const double gval = side ? GP.up[j] - q[j] : q[j] - GP.lo[j];
@@ -356,6 +364,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
         }
       }
     }
+    }
 #pragma unroll
     for (int a = 0; a < NZ; ++a)
 #pragma unroll
@@ -365,6 +374,36 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
         for (int j = 0; j < N; ++j) acc += dd[j] * Z[j][a] * Z[j][c2];
         Dr[tri(a, c2)] += acc;
       }
+    if (GP.n_links > 0) {
+      sphere_rows_walk<N>(D.chain, GP, GB.par, (size_t)Bp, b, q, [&](const int l, const int o, const double gval, const double (&dg)[N]) {
+        double* lam_ptr = GB.lam + IDX(t, GP.NC, nl + l * GP.n_obs + o);
+        double lam = *lam_ptr;
+        if (upd) {
+          lam = fmax(0.0, lam - rho_old * gval);
+          *lam_ptr = lam;
+        }
+        const double sv = lam - rho * gval;
+        meas = fmax(meas, fabs(fmin(gval, lam / rho)));
+        if (sv > 0.0) {
+          psi += (sv * sv - lam * lam) / (2.0 * rho);
+          double v[NZ];
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) v[a] = 0.0;
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            g[j] -= sv * dg[j];
+#pragma unroll
+            for (int a = 0; a < NZ; ++a) v[a] += Z[j][a] * dg[j];
+          }
+#pragma unroll
+          for (int a = 0; a < NZ; ++a)
+#pragma unroll
+            for (int c2 = 0; c2 <= a; ++c2) Dr[tri(a, c2)] += rho * v[a] * v[c2];
+        } else {
+          psi -= lam * lam / (2.0 * rho);
+        }
+      });
+    }
     phi += psi;
     GB.psi[slot][(size_t)t * Bp + b] = psi;
     GB.mcv[slot][(size_t)t * Bp + b] = meas;

@@ -39,8 +39,9 @@ class FigureEightSpec:
     qc_name: str
     q_name: str
     dq_name: str
-    lo: Optional[np.ndarray] = None  # joint limits (enforce_model_limits), None: no inequality rows
+    lo: Optional[np.ndarray] = None  # joint limits (enforce_model_limits), None: no such rows
     up: Optional[np.ndarray] = None
+    spheres: Optional["GuardSpec"] = None  # sphere clearances (sphere_collision_avoidance_constraints)
 
 
 def _unscale(e):
@@ -74,8 +75,31 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
     T = Q.n
     if dQ.n != T - 1:
         no("derivs_align=True is not lowered")
-    if opt.ng:
-        no("nonlinear inequality rows are not lowered for this family yet")
+    sph = {}
+    for label, d in opt.ineq_constraints.items():
+        ok = (isinstance(d, Sub) and isinstance(d.a, SumSqr) and isinstance(d.a.a, Sub) and isinstance(d.a.a.a, LinkFunction)
+              and d.a.a.a.what == "position" and isinstance(d.a.a.b, ParamRef) and d.a.a.b.shape == (3, 1)
+              and isinstance(d.b, Square) and isinstance(d.b.a, Add) and isinstance(d.b.a.a, ParamRef) and isinstance(d.b.a.b, ParamRef)
+              and isinstance(d.a.a.a.q, StateRef) and d.a.a.a.q.t is not None and d.a.a.a.q.var_name == q_name and d.a.a.a.robot is robot)
+        if not ok:
+            no(f"inequality '{label}' is not a sphere clearance ||p_link(q_t) - o||^2 >= (r_link + r_o)^2")
+        sph[(d.a.a.a.q.t, d.a.a.a.link, d.a.a.b.name)] = (d.b.a.a.name, d.b.a.b.name)
+    spheres = None
+    if sph:
+        links, obst = [], []
+        for (t_, ln, on) in sph:
+            if ln not in links:
+                links.append(ln)
+            if on not in obst:
+                obst.append(on)
+        if len(sph) != T * len(links) * len(obst):
+            no("sphere rows must cover every (knot, link, obstacle) combination")
+        lrad = {ln: sph[(0, ln, obst[0])][0] for ln in links}
+        orad = {on: sph[(0, links[0], on)][1] for on in obst}
+        for (t_, ln, on), (lr, orr) in sph.items():
+            if lr != lrad[ln] or orr != orad[on]:
+                no("inconsistent radius parameters in the sphere rows")
+        spheres = GuardSpec(None, None, links, [lrad[ln] for ln in links], [(on, orad[on]) for on in obst])
     lo = up = None
     n = robot.ndof
     for label, d in opt.lin_ineq_constraints.items():
@@ -113,8 +137,11 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
     if qc.shape != (robot.ndof, 1):
         no("qc must be an ndof-vector parameter")
     params = [k for k, v in opt.parameters.items() if v.numel() > 0]
-    if params != [qc.name]:
-        no(f"the only non-empty parameter must be '{qc.name}', found {params}")
+    expect = [qc.name]
+    if spheres is not None:
+        expect += list(spheres.link_radii) + [x for ob in spheres.obstacles for x in ob]
+    if params != expect:
+        no(f"the non-empty parameters must be {expect} in this order (the kernel family reads p = [qc; link radii; obstacles]), found {params}")
 
     # nonlinear equality: quat(Q) == quat(qc)
     if len(opt.eq_constraints) != 1:
@@ -160,7 +187,7 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
             no(f"cost '{label}' not recognised")
     if w_path is None or w_vel is None:
         no("need both the path-tracking and the joint-velocity cost terms")
-    return FigureEightSpec(robot, link, T, dt, w_path, w_vel, np.ascontiguousarray(local.T), qc.name, q_name, dq_name, lo, up)
+    return FigureEightSpec(robot, link, T, dt, w_path, w_vel, np.ascontiguousarray(local.T), qc.name, q_name, dq_name, lo, up, spheres)
 
 
 @dataclass

@@ -157,11 +157,20 @@ class HIPSolver(Solver):
         if isinstance(spec, FigureEightSpec):
             chain = spec.robot.kinematic_chain(spec.link)
             guards = None
-            if spec.lo is not None:
+            if spec.lo is not None or spec.spheres is not None:
                 guards = _lib.oh_guards()
+            if spec.lo is not None:
                 guards.limits = 1
                 for j in range(spec.robot.ndof):
                     guards.q_lo[j], guards.q_up[j] = float(spec.lo[j]), float(spec.up[j])
+            if spec.spheres is not None:
+                guards.n_links, guards.n_obstacles = len(spec.spheres.links), len(spec.spheres.obstacles)
+                for l, (k, off) in enumerate(spec.robot.link_attachments(spec.link, spec.spheres.links)):
+                    if k < 0:
+                        raise NotImplementedError(f"sphere link '{spec.spheres.links[l]}' does not move with any joint of the chain")
+                    guards.link_joint[l] = k
+                    for i in range(3):
+                        guards.link_offset[l][i] = float(off[i])
             self._backend = FigureEightBackend(
                 chain,
                 spec.T,

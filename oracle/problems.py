@@ -589,3 +589,76 @@ class LimitedFigureEightNLP(FigureEightNLP):
         M[:nq, :nq] = np.eye(nq)
         M[nq:, :nq] = -np.eye(nq)
         return M
+
+
+class GuardedFigureEightNLP(FigureEightNLP):
+    """example/figure_eight_plan.py plus enforce_model_limits (optional) and sphere_collision_avoidance_constraints (builder.py:366-417).
+    p = [qc(7); link radii (L); per obstacle: position (3), radius (1)];  k as LimitedFigureEightNLP;  g knot-major, link, obstacle."""
+
+    def __init__(self, robot, link, links, n_obs, lo=None, up=None, **kw):
+        super().__init__(robot, link, **kw)
+        from .structured import FoldedChain
+
+        self.links, self.n_obs = list(links), n_obs
+        self.lo = None if lo is None else np.asarray(lo, dtype=float)
+        self.up = None if up is None else np.asarray(up, dtype=float)
+        self.nk = 2 * self.n * self.T if lo is not None else 0
+        self.ng = self.T * len(self.links) * n_obs
+        self.np_ = self.n + len(self.links) + 4 * n_obs
+        self.chain = FoldedChain(robot, link)
+
+    def _guards(self, p):
+        from .guarded import Guards
+
+        L = len(self.links)
+        ob = p[self.n + L :].reshape(self.n_obs, 4)
+        return Guards(lo=None, up=None, links=self.links, link_radii=p[self.n : self.n + L], obs_pos=ob[:, :3], obs_radii=ob[:, 3])
+
+    def f(self, x, p):
+        return super().f(x, p[: self.n])
+
+    def df(self, x, p):
+        return super().df(x, p[: self.n])
+
+    def a(self, x, p):
+        return super().a(x, p[: self.n])
+
+    def da(self, x, p):
+        return super().da(x, p[: self.n])
+
+    def h(self, x, p):
+        return super().h(x, p[: self.n])
+
+    def dh(self, x, p):
+        return super().dh(x, p[: self.n])
+
+    def k(self, x, p):
+        if self.lo is None:
+            return np.zeros(0)
+        Q, _ = self.split(x)
+        return np.concatenate([(Q - self.lo[:, None]).T.reshape(-1), (self.up[:, None] - Q).T.reshape(-1)])
+
+    def dk(self, x, p):
+        M = np.zeros((self.nk, self.nx))
+        if self.lo is not None:
+            nq = self.n * self.T
+            M[:nq, :nq] = np.eye(nq)
+            M[nq:, :nq] = -np.eye(nq)
+        return M
+
+    def g(self, x, p):
+        from .guarded import guard_values
+
+        Q, _ = self.split(x)
+        return guard_values(self.chain, Q.T, self._guards(p))[0].reshape(-1)
+
+    def dg(self, x, p):
+        from .guarded import guard_values
+
+        Q, _ = self.split(x)
+        d = guard_values(self.chain, Q.T, self._guards(p))[1]  # (T, L*O, n)
+        rows = d.shape[1]
+        M = np.zeros((self.ng, self.nx))
+        for t in range(self.T):
+            M[t * rows : (t + 1) * rows, self.n * t : self.n * (t + 1)] = d[t]
+        return M

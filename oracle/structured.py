@@ -307,35 +307,37 @@ def retract(prob, Q, Rc, tol=1e-10, max_corr=4):
     return Q
 
 
-def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False, hessian="hybrid", limits=None, rho0=None):
+def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False, hessian="hybrid", limits=None, rho0=None, guards=None):
     """Returns dict(Q, f, iters (= steps solved: accepted + rejected), rejected, stat, feas, status).
-    limits = (lo, up): joint-limit rows q_t - lo >= 0, up - q_t >= 0 at the free knots through the augmented Lagrangian of
-    oracle/guarded.py (k_eval_lg / k_step_lg); adds "lam" (T, 2n), "meas", "outers" to the result.
+    limits = (lo, up) or guards = oracle.guarded.Guards (joint limits and/or sphere clearances): inequality rows at the free
+    knots through the augmented Lagrangian of oracle/guarded.py (k_eval_lg / k_step_lg); adds "lam" (T, NC), "meas", "outers".
     hessian: "gauss_newton" | "exact" | "hybrid" (Gauss-Newton until the reduced gradient of the accepted point is below
     1e-5 * w_path, exact curvature afterwards: OH_HESSIAN_HYBRID); exact=True is shorthand for "exact"."""
     if exact:
         hessian = "exact"
     hyb_switch = 1e-5 * prob.w_path
     stat_prev = np.inf
-    guard = limits is not None
+    guard = limits is not None or guards is not None
     if guard:
-        g_lo, g_up = np.asarray(limits[0], dtype=float), np.asarray(limits[1], dtype=float)
-        lam_g = np.zeros((prob.T, 2 * prob.n))
+        from .guarded import Guards, guard_values
+
+        if guards is None:
+            guards = Guards(lo=np.asarray(limits[0], dtype=float), up=np.asarray(limits[1], dtype=float))
+        lam_g = np.zeros((prob.T, guards.n_rows(prob.n)))
         rho_g = rho_next = (10.0 * prob.w_path) if rho0 is None else rho0
         omega, meas_prev, outer, outers = max(tol, 1e-2), np.inf, False, 0
 
     def guard_terms(Q, lam_g, rho_g):
-        gv = np.concatenate([Q - g_lo[None], g_up[None] - Q], axis=1)  # (T, 2n)
+        gv, dg = guard_values(prob.chain, Q, guards)  # (T, NC), (T, NC, n)
         sv = np.maximum(0.0, lam_g - rho_g * gv)
         sv[:2] = 0.0
         psi = (sv * sv - lam_g * lam_g) / (2.0 * rho_g)
         psi[:2] = 0.0
-        n_ = Q.shape[1]
-        dgrad = -sv[:, :n_] + sv[:, n_:]
-        ddiag = rho_g * ((sv[:, :n_] > 0).astype(float) + (sv[:, n_:] > 0).astype(float))
+        dgrad = -np.einsum("tc,tcn->tn", sv, dg)
+        dW = rho_g * np.einsum("tc,tcn,tcm->tnm", (sv > 0.0).astype(float), dg, dg)
         meas = np.abs(np.minimum(gv, lam_g / rho_g))
         meas[:2] = 0.0
-        return gv, psi.sum(1), dgrad, ddiag, float(meas.max())
+        return gv, psi.sum(1), dgrad, dW, float(meas.max())
     T, n = prob.T, prob.n
     path, Rc = prob.references(qc)
     kap = prob.kappa
@@ -354,18 +356,20 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
     while True:
         # ---- k_eval + k_couple on the trial point
         use_exact = hessian == "exact" or (hessian == "hybrid" and not first and stat_prev <= hyb_switch)
+        if guard and guards.links:
+            use_exact = False  # no curvature of the sphere rows in the exact block: Gauss-Newton models them better
         phi, g, W, c, Jc = prob.evaluate(Qt, path, Rc, lam=lam, exact=use_exact)
         if guard:
             if outer:  # multiplier refresh at the accepted point with the old penalty, evaluation with the new one
-                gv_now = np.concatenate([Qt - g_lo[None], g_up[None] - Qt], axis=1)
+                gv_now, _ = guard_values(prob.chain, Qt, guards)
                 lam_g = np.maximum(0.0, lam_g - rho_g * gv_now)
                 lam_g[:2] = 0.0
                 rho_g = rho_next
                 outers += 1
-            gv, psi_t, dgrad, ddiag, meas_t = guard_terms(Qt, lam_g, rho_g)
+            gv, psi_t, dgrad, dW, meas_t = guard_terms(Qt, lam_g, rho_g)
             phi = phi + psi_t
             g = g + dgrad
-            W = W + ddiag[:, :, None] * np.eye(n)[None]
+            W = W + dW
         f_t = float(np.sum(phi) + prob.smooth_cost(Qt))
         feas_t = float(np.max(np.abs(c[F])))
         # ---- k_step phase A
@@ -463,7 +467,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         iters += 1
     out = {"Q": cur["Q"], "f": cur["f"] - cur["fpsi"], "iters": iters, "rejected": rejected, "stat": stat, "feas": cur["feas"], "status": status, "path": path, "Rc": Rc}
     if guard:
-        gv = np.concatenate([cur["Q"] - g_lo[None], g_up[None] - cur["Q"]], axis=1)
+        gv, _ = guard_values(prob.chain, cur["Q"], guards)
         lam_out = np.maximum(0.0, lam_g - rho_g * gv)
         lam_out[:2] = 0.0
         out.update(lam=lam_out, lam_stored=lam_g, meas=cur["meas"], outers=outers, g=gv)

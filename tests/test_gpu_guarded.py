@@ -175,3 +175,40 @@ def test_figure_eight_with_joint_limits(hip_lib):
     s2.reset_initial_seed({"kuka/q/x": np.tile(qc.reshape(-1, 1), (1, 50))})
     s2.solve()
     assert s2.did_solve() and abs(s2.stats()["f"][0] - 8.498170214656) < 1e-7
+
+
+def test_figure_eight_with_sphere_obstacle(hip_lib):
+    """sphere_collision_avoidance_constraints on the orientation-locked family (B5 on config 2): one obstacle placed beside the
+    figure-eight so that the end-effector spheres have to give way (f rises from 8.498 to 9.024)."""
+    from examples.figure_eight_plan import setup_solver as figure_eight
+    from oracle.problems import GuardedFigureEightNLP
+    from oracle.structured import StructuredFigureEight, solve_structured_lm
+
+    kuka_o = OracleRobot(KUKA_KIN)
+    qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    obs = np.array([-0.848, 0.12, 0.461])  # the path sweeps x = -0.848, y in [-0.1, 0.1], z in [0.26, 0.66]
+    kuka, solver = figure_eight(obstacles=["obs0"], sphere_links=SPHERE_LINKS, solver_options={"max_iter": 400})
+    assert (solver.opt.ng, solver.opt.np) == (50 * 4, 7 + 4 + 4)
+    pd = {"qc": qc, "obs0_position": obs, "obs0_radii": 0.05, **{ln + "_radii": 0.05 for ln in SPHERE_LINKS}}
+    solver.reset_parameters(pd)
+    solver.reset_initial_seed({"kuka/q/x": np.tile(qc.reshape(-1, 1), (1, 50))})
+    sol = solver.solve()
+    assert solver.did_solve()
+    prob = StructuredFigureEight(kuka_o, "end_effector_ball", T=50)
+    G = Guards(links=SPHERE_LINKS, link_radii=np.full(4, 0.05), obs_pos=obs[None], obs_radii=np.array([0.05]))
+    s = solve_structured_lm(prob, qc, guards=G, max_iter=400)
+    assert s["status"] == 0 and abs(solver.number_of_iterations() - s["iters"]) <= 1
+    assert abs(solver.stats()["f"][0] - s["f"]) < 1e-7 and s["f"] > 8.9 and np.abs(np.asarray(sol["kuka/q"]).T - s["Q"]).max() < 1e-5
+    nlp = GuardedFigureEightNLP(kuka_o, "end_effector_ball", SPHERE_LINKS, 1, T=50)
+    x = solver.opt.decision_variables.dict2vec(sol)
+    p = solver.opt.parameters.dict2vec(pd)
+    assert (nlp.nx, nlp.np_, nlp.ng, nlp.nv) == (solver.opt.nx, solver.opt.np, solver.opt.ng, solver.opt.nv)
+    assert abs(nlp.f(x, p) - solver.stats()["f"][0]) < 1e-10 and np.abs(nlp.g(x, p) - solver.opt.g(x, p)).max() < 1e-12
+    assert nlp.g(x, p).min() > -1e-9 and nlp.g(x, p).min() < 1e-8  # feasible and active
+    k = kkt_reference_form(nlp, x, p, active_tol=1e-6)
+    assert k["stationarity"] < 1e-5 and k["feasibility"] < 1e-9
+    # complementarity on the inequality rows with the multipliers the library reports (the checker's own number is dominated by
+    # the rank-deficient quaternion equality pairs, where it is meaningless)
+    lam = solver.backend.multipliers(1)[0]
+    assert lam.shape == (50, 4) and (lam >= 0).all() and (lam > 0).sum() == (s["lam"] > 0).sum() > 0
+    assert np.abs(lam.reshape(-1) * nlp.g(x, p)).max() < 1e-7

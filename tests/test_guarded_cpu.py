@@ -132,3 +132,39 @@ def test_reference_form_kkt_of_the_port_solution(golden):
     assert abs(nlp.f(x, p) - float(golden["T20l_f"]) - float(golden["T20r_f"])) < 1e-12
     k = kkt_reference_form(nlp, x, p, active_tol=1e-6)
     assert k["stationarity"] < 1e-7 and k["feasibility"] < 1e-10 and k["complementarity"] < 1e-9
+
+
+def test_figure_eight_lowering_with_limits_and_spheres():
+    from examples.figure_eight_plan import setup_solver as figure_eight
+    from optas_amd import _lib
+    from optas_amd.lowering import LoweringError, lower
+    from oracle.problems import GuardedFigureEightNLP
+
+    rl, _ = _robots()
+    kuka, o = figure_eight(build_only=True, limits=True, obstacles=["obs0", "obs1"], sphere_links=SPHERE_LINKS)
+    assert (o.nk, o.ng, o.np, o.nv) == (700, 400, 7 + 4 + 8, 700 + 400 + 2 * 357 + 2 * 200)
+    kind, spec = lower(o)
+    assert kind == _lib.OH_PROBLEM_FIGURE_EIGHT and spec.spheres.links == SPHERE_LINKS and len(spec.spheres.obstacles) == 2
+    kuka_o = OracleRobot(KUKA_KIN)
+    assert np.array_equal(spec.lo, kuka_o.lower_actuated_joint_limits) and np.array_equal(spec.up, kuka_o.upper_actuated_joint_limits)
+    # the mirrored builder's rows equal the literal restatement's on a random point (numpy only: no link function is evaluated
+    # on the GPU here because k, a are linear and g is checked in the GPU suite)
+    nlp = GuardedFigureEightNLP(kuka_o, "end_effector_ball", SPHERE_LINKS, 2, lo=spec.lo, up=spec.up, T=50)
+    assert (nlp.nx, nlp.np_, nlp.nk, nlp.na, nlp.ng, nlp.nh, nlp.nv) == (o.nx, o.np, o.nk, o.na, o.ng, o.nh, o.nv)
+    rng = np.random.default_rng(2)
+    x, p = rng.uniform(-1, 1, o.nx), rng.uniform(-1, 1, o.np)
+    assert np.abs(o.k(x, p) - nlp.k(x, p)).max() < 1e-14 and np.abs(o.a(x, p) - nlp.a(x, p)).max() < 1e-14
+    # a parameter created between qc and the sphere parameters breaks the p layout the kernels read: refused
+    from optas_amd.builder import OptimizationBuilder  # noqa: F401
+
+    kuka2, o2 = figure_eight(build_only=True, obstacles=["obs0"], sphere_links=SPHERE_LINKS[:1])
+    keys = list(o2.parameters.keys())
+    assert keys[-4:] == ["qc", "end_effector_ball_radii", "obs0_position", "obs0_radii"]
+    # velocity limits couple neighbouring knots: not in this family
+    import optas_amd
+
+    r = optas_amd.RobotModel.builtin("kuka_lwr", time_derivs=[0, 1])
+    b = OptimizationBuilder(T=5, robots=[r])
+    b.enforce_model_limits(r.get_name(), time_deriv=1)
+    with pytest.raises(LoweringError):
+        lower(b.build())

@@ -149,7 +149,7 @@ typedef struct oh_pointmass_desc {
 } oh_pointmass_desc;
 
 /*
- * Inequality rows of the position-tracking family (OH_PROBLEM_FIGURE_EIGHT with lock_orientation = 0), set with
+ * Inequality rows of the trajectory families (OH_PROBLEM_FIGURE_EIGHT, with or without lock_orientation), set with
  * oh_set_guards before the first solve:
  *   limits:  q_t - q_lo >= 0, q_up - q_t >= 0 at every knot   (enforce_model_limits, builder.py:471-509, rows "_l", "_r")
  *   spheres: ||c_l(q_t) - o_j||^2 - (r_l + r_j)^2 >= 0 for every sphere link l and obstacle j
@@ -199,7 +199,7 @@ int oh_create_ik(const oh_ik_desc* desc, oh_handle** out);
 int oh_set_constants(oh_handle* h, const oh_chain* chain);
 int oh_set_constants_device(oh_handle* h, const void* d_chain, size_t nbytes);
 
-/* Inequality rows for the position-tracking family (see oh_guards). */
+/* Inequality rows for the trajectory families (see oh_guards). */
 int oh_set_guards(oh_handle* h, const oh_guards* guards);
 
 /* Replaces B sequential calls of Solver.reset_initial_seed + reset_parameters + _solve
@@ -227,7 +227,7 @@ int oh_pm_rollout(oh_handle* h, int B, int n_ticks, int advance, double ramp, co
    h = quat_c - quat(q_t) (signed mu = lam+ - lam- of the (h,-h) pair, optimization.py:47-51). Host buffer.
    OH_PROBLEM_IK: lam_h [B][3 + 2*ndof] = (mu of h = p_goal - p_link(q) (3), multipliers of q - lo >= 0 (ndof),
    multipliers of up - q >= 0 (ndof)).
-   Position-tracking family with oh_set_guards: lam_h [B][T][NC], NC = 2 ndof limits + n_links n_obstacles, row order
+   Handles with oh_set_guards: lam_h [B][T][NC], NC = 2 ndof limits + n_links n_obstacles, row order
    of oh_guards (multipliers >= 0 of the g >= 0 rows; knots t < t0 carry zeros). */
 int oh_get_multipliers(oh_handle* h, int B, double* lam_h);
 

@@ -60,7 +60,11 @@ enum {
   /* example/example.py:13-60 (BASELINE configs[0]): one configuration q of a serial chain,
      f = w ||q - q_nominal||^2, h = p_goal - p_link(q) (builder.py:354), k = [q - lo; up - q] (builder.py:471-509);
      created with oh_create_ik.  x = q (nx = ndof), p = [q_nominal(ndof); p_goal(3)] (np = ndof + 3). */
-  OH_PROBLEM_IK = 3
+  OH_PROBLEM_IK = 3,
+  /* the QuadraticCost{Unconstrained, LinearConstraints} classes with small dense data (optimization.py:312-388; what the reference hands to
+     OSQP / CVXOPT / qpOASES, solver.py:421-584): min x^T P x + q^T x s.t. M x + c >= 0, A x + b = 0; created with oh_create_qp.
+     x (nx = n), and one parameter row per instance p = [P (n*n row-major); q (n); M (m*n); c (m); A (me*n); b (me)]. */
+  OH_PROBLEM_QP = 4
 };
 
 enum {
@@ -183,6 +187,17 @@ typedef struct oh_ik_desc {
   double rho0;      /* initial augmented-Lagrangian penalty; <= 0: 100 w */
 } oh_ik_desc;
 
+#define OH_QP_MAX_N 32
+#define OH_QP_MAX_M 256
+#define OH_QP_MAX_ME 32
+typedef struct oh_qp_desc {
+  int n;        /* decision variables, <= OH_QP_MAX_N */
+  int m;        /* rows of M x + c >= 0, <= OH_QP_MAX_M */
+  int me;       /* rows of A x + b = 0, <= OH_QP_MAX_ME */
+  int max_iter; /* <= 0: 100 */
+  double tol;   /* KKT tolerance (stationarity, feasibility, complementarity); <= 0: 1e-9 */
+} oh_qp_desc;
+
 typedef struct oh_handle oh_handle;
 
 /* Replaces Solver.__init__ + CasADiSolver.setup (solver.py:64-88,333-384): allocates the handle,
@@ -191,6 +206,9 @@ int oh_create(const oh_problem_desc* desc, oh_handle** out);
 
 /* Same for OH_PROBLEM_POINT_MASS_MPC (no kinematic constants needed; solve with oh_solve / oh_solve_device). */
 int oh_create_pointmass(const oh_pointmass_desc* desc, oh_handle** out);
+
+/* Same for OH_PROBLEM_QP (no kinematic constants). oh_get_multipliers returns [B][m + me] = (lam >= 0 of the M rows, nu of the A rows). */
+int oh_create_qp(const oh_qp_desc* desc, oh_handle** out);
 
 /* Same for OH_PROBLEM_IK; needs oh_set_constants before the first solve. */
 int oh_create_ik(const oh_ik_desc* desc, oh_handle** out);

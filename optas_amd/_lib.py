@@ -23,6 +23,7 @@ OH_PROBLEM_KINEMATICS = 0
 OH_PROBLEM_FIGURE_EIGHT = 1
 OH_PROBLEM_POINT_MASS_MPC = 2
 OH_PROBLEM_IK = 3
+OH_PROBLEM_QP = 4
 OH_HESSIAN_GAUSS_NEWTON, OH_HESSIAN_EXACT, OH_HESSIAN_HYBRID = 0, 1, 2
 
 
@@ -107,6 +108,10 @@ class oh_guards(C.Structure):
     ]
 
 
+class oh_qp_desc(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("me", C.c_int), ("max_iter", C.c_int), ("tol", C.c_double)]
+
+
 class oh_ik_desc(C.Structure):
     _fields_ = [
         ("ndof", C.c_int),
@@ -131,6 +136,7 @@ SYMBOLS = [
     "oh_create",
     "oh_create_pointmass",
     "oh_create_ik",
+    "oh_create_qp",
     "oh_set_constants",
     "oh_set_constants_device",
     "oh_set_guards",
@@ -181,6 +187,7 @@ def load() -> C.CDLL:
     lib.oh_create.argtypes = [C.POINTER(oh_problem_desc), C.POINTER(vp)]
     lib.oh_create_pointmass.argtypes = [C.POINTER(oh_pointmass_desc), C.POINTER(vp)]
     lib.oh_create_ik.argtypes = [C.POINTER(oh_ik_desc), C.POINTER(vp)]
+    lib.oh_create_qp.argtypes = [C.POINTER(oh_qp_desc), C.POINTER(vp)]
     lib.oh_set_constants.argtypes = [vp, C.POINTER(oh_chain)]
     lib.oh_set_constants_device.argtypes = [vp, vp, C.c_size_t]
     lib.oh_set_guards.argtypes = [vp, C.POINTER(oh_guards)]

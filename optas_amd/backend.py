@@ -105,6 +105,31 @@ class PointMassBackend(_SolveMixin):
         return states, f, iters, status
 
 
+class QPBackend(_SolveMixin):
+    """OH_PROBLEM_QP handle: x (B, n); p (B, n*n + n + m*n + m + me*n + me) = [P | q | M | c | A | b] per instance."""
+
+    def __init__(self, n: int, m: int, me: int, max_iter=100, tol=1e-9):
+        lib = _lib.load()
+        self.n, self.m, self.me = int(n), int(m), int(me)
+        self.nx = self.n
+        self.np_ = self.n * self.n + self.n + self.m * self.n + self.m + self.me * self.n + self.me
+        desc = _lib.oh_qp_desc(n=self.n, m=self.m, me=self.me, max_iter=int(max_iter), tol=float(tol))
+        self._h = C.c_void_p()
+        _lib.check(lib.oh_create_qp(C.byref(desc), C.byref(self._h)), "oh_create_qp")
+
+    @staticmethod
+    def pack(P, q, M, c, A, b) -> np.ndarray:
+        return np.concatenate([np.asarray(P, dtype=np.float64).reshape(-1), np.asarray(q, dtype=np.float64).reshape(-1),
+                               np.asarray(M, dtype=np.float64).reshape(-1), np.asarray(c, dtype=np.float64).reshape(-1),
+                               np.asarray(A, dtype=np.float64).reshape(-1), np.asarray(b, dtype=np.float64).reshape(-1)])
+
+    def multipliers(self, B: int):
+        out = np.empty((B, self.m + self.me))
+        if self.m + self.me:
+            _lib.check(_lib.load().oh_get_multipliers(self._h, int(B), _lib._ptr(out)), "oh_get_multipliers")
+        return out[:, : self.m], out[:, self.m :]
+
+
 class IKBackend(_SolveMixin):
     """OH_PROBLEM_IK handle (example/example.py): x = q, p = [q_nominal; p_goal]."""
 

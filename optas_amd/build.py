@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["oh_kernels.hip", "oh_free.hip", "oh_pointmass.hip", "oh_ik.hip", "oh_api.hip"]
+SOURCES = ["oh_kernels.hip", "oh_free.hip", "oh_pointmass.hip", "oh_ik.hip", "oh_qp.hip", "oh_api.hip"]
 HEADERS = ["oh_device.h", "oh_kernels.h", "oh_figure8.h", os.path.join("..", "..", "include", "optas_hip.h")]
 OUT = os.path.join(HERE, "liboptas_hip.so")
 

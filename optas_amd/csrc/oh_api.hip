@@ -50,6 +50,11 @@ struct oh_handle {
   GuardBuffers GB{};
   void* gpool = nullptr;
   int gcap = 0;
+  // dense QP family
+  oh_qp_desc qp{};
+  double* d_qp_work = nullptr;
+  double* d_qp_mult = nullptr;
+  int qp_cap = 0;
   // inverse-kinematics family
   oh_ik_desc ik{};
   double* d_ik_mult = nullptr;
@@ -206,6 +211,63 @@ extern "C" int oh_create_pointmass(const oh_pointmass_desc* desc, oh_handle** ou
   return OH_OK;
 }
 
+extern "C" int oh_create_qp(const oh_qp_desc* desc, oh_handle** out) {
+  if (!desc || !out) return fail(OH_ERR_INVALID, "oh_create_qp: null argument");
+  *out = nullptr;
+  if (desc->n < 1 || desc->n > OH_QP_MAX_N || desc->m < 0 || desc->m > OH_QP_MAX_M || desc->me < 0 || desc->me > OH_QP_MAX_ME || desc->me > desc->n)
+    return fail(OH_ERR_INVALID, "oh_create_qp: sizes out of range (n <= 32, m <= 256, me <= min(32, n))");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return fail(OH_ERR_HIP, "oh_create_qp: no HIP device available (this library has no CPU path)");
+  oh_handle* h = new oh_handle();
+  h->desc = oh_problem_desc{};
+  h->desc.kind = OH_PROBLEM_QP;
+  h->desc.T = 1;
+  h->desc.ndof = desc->n;
+  h->qp = *desc;
+  if (h->qp.max_iter <= 0) h->qp.max_iter = 100;
+  if (!(h->qp.tol > 0.0)) h->qp.tol = 1e-9;
+  hipGetDevice(&h->device);
+  if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+      hipEventCreate(&h->evt0) != hipSuccess || hipEventCreate(&h->evt1) != hipSuccess) {
+    delete h;
+    return fail(OH_ERR_HIP, "oh_create_qp: stream/event creation failed");
+  }
+  *out = h;
+  return OH_OK;
+}
+
+static size_t qp_np(const oh_qp_desc& q) { return (size_t)q.n * q.n + q.n + (size_t)q.m * q.n + q.m + (size_t)q.me * q.n + q.me; }
+
+static int qp_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status) {
+  HIPCHK(hipSetDevice(h->device));
+  const oh_qp_desc& q = h->qp;
+  QpParams Q{};
+  Q.n = q.n; Q.m = q.m; Q.me = q.me; Q.np = (int)qp_np(q); Q.max_iter = q.max_iter; Q.tol = q.tol;
+  Q.nwork = q.n + 2 * q.m + q.me + q.n * q.n + 2 * q.n + 2 * q.m + q.me * q.n + q.me * q.me + q.me + q.n;
+  if (B > h->qp_cap) {
+    if (h->d_qp_work) hipFree(h->d_qp_work);
+    if (h->d_qp_mult) hipFree(h->d_qp_mult);
+    h->d_qp_work = h->d_qp_mult = nullptr;
+    h->qp_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->d_qp_work, sizeof(double) * (size_t)Q.nwork * B));
+    HIPCHK(hipMalloc((void**)&h->d_qp_mult, sizeof(double) * (size_t)(q.m + q.me + 1) * B));
+    h->qp_cap = B;
+  }
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  oh_launch_qp_solve(h->stream, Q, B, (const double*)d_x0, (const double*)d_p, h->d_qp_work, (double*)d_x, (double*)d_f, (double*)d_kkt, (int*)d_iters,
+                     (int*)d_status, h->d_qp_mult);
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  for (double& t : h->timing) t = 0.0;
+  h->timing[4] = ms;
+  h->timing[5] = 1;
+  h->last_B = B;
+  return OH_OK;
+}
+
 extern "C" int oh_create_ik(const oh_ik_desc* desc, oh_handle** out) {
   if (!desc || !out) return fail(OH_ERR_INVALID, "oh_create_ik: null argument");
   *out = nullptr;
@@ -249,6 +311,8 @@ static int ik_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   if (B > h->ik_cap) {
     if (h->d_ik_mult) hipFree(h->d_ik_mult);
   if (h->gpool) hipFree(h->gpool);
+  if (h->d_qp_work) hipFree(h->d_qp_work);
+  if (h->d_qp_mult) hipFree(h->d_qp_mult);
     h->d_ik_mult = nullptr;
     h->ik_cap = 0;
     HIPCHK(hipMalloc((void**)&h->d_ik_mult, sizeof(double) * (3 + 2 * (size_t)N) * B));
@@ -488,6 +552,8 @@ static int ensure_guards(oh_handle* h) {
   const int Bp = h->D.Bp;
   if (!h->gpool || h->gcap != Bp) {
     if (h->gpool) hipFree(h->gpool);
+  if (h->d_qp_work) hipFree(h->d_qp_work);
+  if (h->d_qp_mult) hipFree(h->d_qp_mult);
     h->gpool = nullptr;
     const size_t npar = (size_t)g.n_links + 4 * (size_t)g.n_obstacles;
     const size_t nd = (size_t)T * GP.NC * Bp + npar * Bp + 4 * (size_t)T * Bp + 6 * (size_t)Bp;
@@ -552,6 +618,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (!d_x0 || !d_p) return fail(OH_ERR_INVALID, "oh_solve_device: x0 and p are required");
   if (h->desc.kind == OH_PROBLEM_POINT_MASS_MPC) return pm_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind == OH_PROBLEM_IK) return ik_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
+  if (h->desc.kind == OH_PROBLEM_QP) return qp_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT) return fail(OH_ERR_STATE, "oh_solve_device: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
   if (!h->have_chain) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_constants first");
   if (!solver_chain_ok(h->chain_host))
@@ -709,14 +776,16 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
   if (!h) return fail(OH_ERR_INVALID, "oh_solve: null handle");
   if (B < 1) return fail(OH_ERR_INVALID, "oh_solve: B must be >= 1");
   if (!x0 || !p) return fail(OH_ERR_INVALID, "oh_solve: x0 and p are required");
-  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_POINT_MASS_MPC && h->desc.kind != OH_PROBLEM_IK)
+  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_POINT_MASS_MPC && h->desc.kind != OH_PROBLEM_IK &&
+      h->desc.kind != OH_PROBLEM_QP)
     return fail(OH_ERR_STATE, "oh_solve: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
   HIPCHK(hipSetDevice(h->device));
   const int N = h->desc.ndof, T = h->desc.T;
   const bool pmk = h->desc.kind == OH_PROBLEM_POINT_MASS_MPC;
   const bool ikk = h->desc.kind == OH_PROBLEM_IK;
-  const size_t nx = pmk ? 4 * (size_t)T : (ikk ? (size_t)N : (size_t)N * T + (size_t)N * (T - 1));
-  const size_t npar = pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0));
+  const bool qpk = h->desc.kind == OH_PROBLEM_QP;
+  const size_t nx = qpk ? (size_t)h->qp.n : pmk ? 4 * (size_t)T : (ikk ? (size_t)N : (size_t)N * T + (size_t)N * (T - 1));
+  const size_t npar = qpk ? qp_np(h->qp) : pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0));
   const size_t b_x = sizeof(double) * nx * B, b_p = sizeof(double) * npar * (size_t)B;
   const size_t b_f = sizeof(double) * B, b_k = sizeof(double) * 3 * (size_t)B, b_i = sizeof(int) * (size_t)B;
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -800,9 +869,13 @@ extern "C" int oh_pm_rollout(oh_handle* h, int B, int n_ticks, int advance, doub
 
 extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
   if (!h || !lam_h) return fail(OH_ERR_INVALID, "oh_get_multipliers: null argument");
-  if ((h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_IK) || B != h->last_B || B < 1)
+  if ((h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_IK && h->desc.kind != OH_PROBLEM_QP) || B != h->last_B || B < 1)
     return fail(OH_ERR_STATE, "oh_get_multipliers: B does not match the last solve");
   HIPCHK(hipSetDevice(h->device));
+  if (h->desc.kind == OH_PROBLEM_QP) {
+    if (h->qp.m + h->qp.me > 0) HIPCHK(hipMemcpy(lam_h, h->d_qp_mult, sizeof(double) * (size_t)(h->qp.m + h->qp.me) * B, hipMemcpyDeviceToHost));
+    return OH_OK;
+  }
   if (h->desc.kind == OH_PROBLEM_IK) {
     HIPCHK(hipMemcpy(lam_h, h->d_ik_mult, sizeof(double) * (3 + 2 * (size_t)h->ik.ndof) * B, hipMemcpyDeviceToHost));
     return OH_OK;
@@ -937,6 +1010,8 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->pool) hipFree(h->pool);
   if (h->d_ik_mult) hipFree(h->d_ik_mult);
   if (h->gpool) hipFree(h->gpool);
+  if (h->d_qp_work) hipFree(h->d_qp_work);
+  if (h->d_qp_mult) hipFree(h->d_qp_mult);
   if (h->stage) hipFree(h->stage);
   if (h->d_chain) hipFree(h->d_chain);
   if (h->d_dyn) hipFree(h->d_dyn);

@@ -132,3 +132,11 @@ struct IkParams {
 };
 bool oh_launch_ik_solve(hipStream_t s, const oh_chain* d_chain, const IkParams& P, int B, const double* x0, const double* p, double* x, double* f,
                         double* kkt, int* iters, int* status, double* mult);
+
+// ---- OH_PROBLEM_QP -----------------------------------------------------------------------------------------
+struct QpParams {
+  int n, m, me, np, nwork, max_iter;
+  double tol;
+};
+void oh_launch_qp_solve(hipStream_t s, const QpParams& Q, int B, const double* x0, const double* p, double* work, double* x, double* f, double* kkt,
+                        int* iters, int* status, double* mult);

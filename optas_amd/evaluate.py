@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from .builder import IntegrationResidual
-from .expr import Add, Const, Expr, LinkFunction, ParamCol, ParamRef, PathInFrame, Scale, Square, StateCols, StateRef, Sub, SumSqr, VarRef
+from .expr import Add, Const, Expr, LinkFunction, Mul, ParamCol, ParamRef, PathInFrame, Scale, Square, StateCols, StateRef, Sub, SumSqr, VarRef
 
 
 def _block(container, vec, label):
@@ -51,6 +51,8 @@ def evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
         return evaluate(e.a, opt, x, p) + evaluate(e.b, opt, x, p)
     if isinstance(e, Scale):
         return e.w * evaluate(e.a, opt, x, p)
+    if isinstance(e, Mul):
+        return evaluate(e.a, opt, x, p) * evaluate(e.b, opt, x, p)
     if isinstance(e, Square):
         v = evaluate(e.a, opt, x, p)
         return v * v

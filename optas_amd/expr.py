@@ -35,6 +35,8 @@ class Expr:
     def __mul__(self, other):
         if isinstance(other, (int, float)):
             return Scale(float(other), self)
+        if isinstance(other, Expr):
+            return Mul(self, other)
         return NotImplemented
 
     __rmul__ = __mul__
@@ -273,6 +275,20 @@ class SumSqr(Expr):
     def degree(self):
         d = self.a.degree()
         return 0 if d == 0 else (2 if d == 1 else 3)
+
+
+@dataclass(eq=False)
+class Mul(Expr):
+    """Elementwise product with scalar broadcasting (``a * y`` in the reference's Booth test, tests/test_solver.py:31)."""
+
+    a: Expr = None
+    b: Expr = None
+
+    def __post_init__(self):
+        self.shape = _bshape(self.a, self.b)
+
+    def degree(self):
+        return min(3, self.a.degree() + self.b.degree())
 
 
 @dataclass(eq=False)

@@ -529,6 +529,30 @@ def match_ik(opt: Optimization) -> IkSpec:
     return IkSpec(robot, link, float(w), lo, up, qn.name, pg.name, q_name)
 
 
+@dataclass
+class QpSpec:
+    """Generic small dense QP: the matrices are read off the Optimization's numeric members per instance."""
+
+    n: int
+    m: int
+    me: int
+
+
+def match_qp(opt: Optimization) -> QpSpec:
+    """QuadraticCostUnconstrained / QuadraticCostLinearConstraints (optimization.py:312-388) with small dense data: what the
+    reference's OSQP / CVXOPT / qpOASES back-ends take (solver.py:421-584).  Last resort: the dedicated families come first."""
+    from .optimization import QuadraticCostLinearConstraints, QuadraticCostUnconstrained
+
+    if not isinstance(opt, (QuadraticCostUnconstrained, QuadraticCostLinearConstraints)):
+        raise LoweringError("dense-QP lowering: the problem is not of a QuadraticCost{Unconstrained, LinearConstraints} class")
+    if opt.has_discrete_variables():
+        raise LoweringError("dense-QP lowering: discrete variables are not supported")
+    n, m, me = opt.nx, opt.nk, opt.na
+    if not (1 <= n <= 32 and m <= 256 and me <= min(32, n)):
+        raise LoweringError(f"dense-QP lowering: sizes nx={n}, nk={m}, na={me} exceed the dense kernel's limits (32, 256, 32)")
+    return QpSpec(n, m, me)
+
+
 OH_KIND_MULTI_ARM = 101  # host-side composition of OH_PROBLEM_FIGURE_EIGHT handles with lock_orientation = 0
 
 
@@ -536,7 +560,7 @@ def lower(opt: Optimization):
     """Return (kind, spec).  Raises LoweringError if no kernel family matches."""
     errors = []
     for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass), (OH_KIND_MULTI_ARM, match_multi_arm),
-                     (_lib.OH_PROBLEM_IK, match_ik)):
+                     (_lib.OH_PROBLEM_IK, match_ik), (_lib.OH_PROBLEM_QP, match_qp)):
         try:
             return kind, fn(opt)
         except LoweringError as e:

@@ -16,8 +16,8 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import _lib
-from .backend import BatchResult, FigureEightBackend, IKBackend, MultiArmBackend, PointMassBackend
-from .lowering import FigureEightSpec, IkSpec, MultiArmSpec, PointMassSpec, lower
+from .backend import BatchResult, FigureEightBackend, IKBackend, MultiArmBackend, PointMassBackend, QPBackend
+from .lowering import FigureEightSpec, IkSpec, MultiArmSpec, PointMassSpec, QpSpec, lower
 from .models import RobotModel
 from .optimization import Optimization
 
@@ -140,6 +140,34 @@ class Solver(ABC):
         return interp1d(t, traj, **interp_args)
 
 
+class _QpAdapter:
+    """Dense QP family: reads P, q, M, c, A, b off the Optimization's numeric members for every instance (they may all depend on the
+    parameters) and hands [P | q | M | c | A | b] rows to the kernel.  The cost's constant term f(0, p) is added back to f."""
+
+    def __init__(self, opt, backend: QPBackend):
+        self.opt, self.be = opt, backend
+
+    def solve(self, x0: np.ndarray, p: np.ndarray) -> BatchResult:
+        x0 = np.asarray(x0, dtype=np.float64).reshape(-1, self.opt.nx)
+        p = np.asarray(p, dtype=np.float64).reshape(x0.shape[0], -1)
+        o = self.opt
+        z = np.zeros(o.nx)
+        rows, f0 = [], []
+        for pb in p:
+            M = o.M(pb) if o.nk else np.zeros((0, o.nx))
+            c = o.c(pb) if o.nk else np.zeros(0)
+            A = o.A(pb) if o.na else np.zeros((0, o.nx))
+            b = o.b(pb) if o.na else np.zeros(0)
+            rows.append(QPBackend.pack(o.P(pb), o.q(pb), M, c, A, b))
+            f0.append(o.f(z, pb))
+        r = self.be.solve(x0, np.stack(rows))
+        r.f = r.f + np.asarray(f0)
+        return r
+
+    def close(self) -> None:
+        self.be.close()
+
+
 class HIPSolver(Solver):
     """MI355X backend.  ``setup(solver_options)`` lowers the problem to a kernel family
     (optas_amd.lowering) and creates the liboptas_hip handle; it raises if the problem is not lowerable
@@ -197,6 +225,9 @@ class HIPSolver(Solver):
             o.pop("hessian", None)
             self._backend = IKBackend(spec.robot.kinematic_chain(spec.link), spec.lo, spec.up, w_nominal=spec.w_nominal,
                                       max_iter=int(o.pop("max_iter", 200)), tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)))
+        elif isinstance(spec, QpSpec):
+            o.pop("hessian", None)
+            self._backend = _QpAdapter(self.opt, QPBackend(spec.n, spec.m, spec.me, max_iter=int(o.pop("max_iter", 100)), tol=float(o.pop("tol", 1e-9))))
         else:  # pragma: no cover
             raise NotImplementedError(kind)
         if o:

@@ -1,0 +1,120 @@
+"""Dense QP family and the reference's only numeric solver test (tests/test_solver.py:22-54): the Booth
+function, (a, b) = (2, 7) -> (x, y) = (1, 3), with and without the huge bound rows of its `constraint=True` variant.
+CPU: numpy port (oracle/qp_ipm.py) vs scipy and the known answer, builder/lowering.  GPU: the same through HIPSolver."""
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+import optas_amd
+from conftest import SEED
+from optas_amd.builder import OptimizationBuilder
+from optas_amd.lowering import QpSpec, lower
+from optas_amd.optimization import QuadraticCostLinearConstraints, QuadraticCostUnconstrained
+from oracle.qp_ipm import solve_qp_ipm
+
+
+def booth_builder(constraint=False):
+    """tests/test_solver.py:22-38, the same builder calls."""
+    builder = OptimizationBuilder(1)
+    x = builder.add_decision_variables("x")
+    y = builder.add_decision_variables("y")
+    a = builder.add_parameter("a")
+    b = builder.add_parameter("b")
+    f = (x + a * y - b) ** 2 + (2.0 * x + y - 5.0) ** 2
+    builder.add_cost_term("f", f)
+    if constraint:
+        builder.add_bound_inequality_constraint("bnd", -1e9, x, 1e9)
+    return builder
+
+
+def random_qp(rng, n, m, me):
+    G = rng.normal(size=(n, n))
+    P = 0.5 * (G @ G.T) + 0.1 * np.eye(n)
+    q = rng.normal(size=n)
+    xf = rng.normal(size=n)  # a strictly feasible point exists
+    M = rng.normal(size=(m, n))
+    c = -M @ xf + rng.uniform(0.1, 1.0, m)
+    A = rng.normal(size=(me, n))
+    b = -A @ xf
+    return P, q, M, c, A, b
+
+
+def test_booth_builder_classes_and_matrices():
+    o = booth_builder().build()
+    assert isinstance(o, QuadraticCostUnconstrained) and (o.nx, o.np, o.nv) == (2, 2, 0)
+    p = np.array([2.0, 7.0])
+    # f = (x + 2y - 7)^2 + (2x + y - 5)^2 = x^T P x + q^T x + 74 with P = [[5, 4], [4, 5]], q = (-34, -38)
+    assert np.allclose(o.P(p), [[5.0, 4.0], [4.0, 5.0]]) and np.allclose(o.q(p), [-34.0, -38.0]) and abs(o.f(np.zeros(2), p) - 74.0) < 1e-12
+    assert abs(o.f(np.array([1.0, 3.0]), p)) < 1e-12
+    kind, spec = lower(o)
+    assert kind == optas_amd._lib.OH_PROBLEM_QP and isinstance(spec, QpSpec) and (spec.n, spec.m, spec.me) == (2, 0, 0)
+    oc = booth_builder(constraint=True).build()
+    assert isinstance(oc, QuadraticCostLinearConstraints) and (oc.nk, oc.nv) == (2, 2)
+    assert np.allclose(oc.M(p), [[1.0, 0.0], [-1.0, 0.0]]) and np.allclose(oc.c(p), [1e9, 1e9])
+
+
+def test_port_booth_known_answer_and_random_qps():
+    for constraint in (False, True):
+        o = booth_builder(constraint).build()
+        p = np.array([2.0, 7.0])
+        M, c = (o.M(p), o.c(p)) if o.nk else (np.zeros((0, 2)), np.zeros(0))
+        r = solve_qp_ipm(o.P(p), o.q(p), M, c, np.zeros((0, 2)), np.zeros(0), x0=np.zeros(2))
+        assert r["status"] == 0 and np.isclose(r["x"], [1.0, 3.0]).all()  # np.isclose defaults, as the reference asserts
+    rng = np.random.default_rng(SEED)
+    for n, m, me in ((3, 0, 0), (5, 8, 0), (6, 10, 2), (12, 30, 4), (7, 0, 3)):
+        P, q, M, c, A, b = random_qp(rng, n, m, me)
+        r = solve_qp_ipm(P, q, M, c, A, b)
+        assert r["status"] == 0 and r["iters"] <= 40
+        cons = []
+        if m:
+            cons.append({"type": "ineq", "fun": lambda x: M @ x + c, "jac": lambda x: M})
+        if me:
+            cons.append({"type": "eq", "fun": lambda x: A @ x + b, "jac": lambda x: A})
+        s = minimize(lambda x: x @ P @ x + q @ x, np.zeros(n), jac=lambda x: 2 * P @ x + q, method="SLSQP", constraints=cons, tol=1e-13,
+                     options={"maxiter": 500})
+        assert s.success and abs(s.fun - r["f"]) < 1e-7 and np.abs(s.x - r["x"]).max() < 1e-5
+        assert (r["lam"] >= 0).all() and np.abs(2 * P @ r["x"] + q - M.T @ r["lam"] - A.T @ r["nu"]).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_reference_solver_test_through_hipsolver(hip_lib):
+    """tests/test_solver.py:42-54 with HIPSolver in place of CasADiSolver / ScipyMinimizeSolver / OSQPSolver / CVXOPTSolver."""
+    from optas_amd.solver import HIPSolver
+
+    for constraint in (False, True):
+        solver = HIPSolver(booth_builder(constraint).build()).setup("hip_sqp")
+        solver.reset_initial_seed({"x": 0, "y": 0})
+        solver.reset_parameters({"a": 2.0, "b": 7.0})
+        result = solver.solve()
+        assert np.isclose(np.asarray(result["x"]).flatten(), 1.0).all() and np.isclose(np.asarray(result["y"]).flatten(), 3.0).all()
+        assert solver.did_solve() and abs(solver.stats()["f"][0]) < 1e-9
+    # batch: every (a, b) has the closed-form minimiser of the 2 x 2 linear system
+    solver = HIPSolver(booth_builder().build()).setup("hip_sqp")
+    rng = np.random.default_rng(SEED)
+    ab = rng.uniform(0.5, 8.0, (64, 2))
+    ab[:, 0] = np.where(np.abs(ab[:, 0] - 0.5) < 0.05, 1.0, ab[:, 0])  # a = 1/2 makes the two rows parallel
+    solver.reset_parameters_batch({"a": ab[:, 0], "b": ab[:, 1]})
+    sols = solver.solve_batch()
+    for (a, b), sol in zip(ab, sols):
+        xy = np.linalg.solve(np.array([[1.0, a], [2.0, 1.0]]), np.array([b, 5.0]))
+        assert abs(np.asarray(sol["x"]).item() - xy[0]) < 1e-7 and abs(np.asarray(sol["y"]).item() - xy[1]) < 1e-7
+
+
+@pytest.mark.gpu
+def test_dense_qp_kernel_matches_port(hip_lib):
+    from optas_amd.backend import QPBackend
+
+    rng = np.random.default_rng(SEED + 1)
+    for n, m, me in ((3, 0, 0), (6, 10, 2), (12, 30, 4), (32, 64, 8)):
+        be = QPBackend(n, m, me)
+        qps = [random_qp(rng, n, m, me) for _ in range(70)]
+        r = be.solve(np.zeros((70, n)), np.stack([QPBackend.pack(*qp) for qp in qps]))
+        lam, nu = be.multipliers(70)
+        assert (r.status == 0).all()
+        for i in (0, 17, 69):
+            P, q, M, c, A, b = qps[i]
+            s = solve_qp_ipm(P, q, M, c, A, b)
+            assert int(r.iters[i]) == s["iters"] and abs(r.f[i] - s["f"]) < 1e-9 * max(1.0, abs(s["f"])) and np.abs(r.x[i] - s["x"]).max() < 1e-8
+            assert np.abs(lam[i] - s["lam"]).max(initial=0.0) < 1e-6 and np.abs(nu[i] - s["nu"]).max(initial=0.0) < 1e-6
+            assert (M @ r.x[i] + c >= -1e-9).all() and (np.abs(A @ r.x[i] + b) <= 1e-9).all()
+        be.close()

@@ -41,14 +41,14 @@ def solve_qp_ipm(P, q, M, c, A, b, x0=None, tol=1e-9, max_iter=100):
         shift = 1e-13 * max(np.abs(np.diag(H)).max(), 1.0)
         rhs = -rd + M.T @ ((mu / s - lam) - (lam / s) * rp)
         L = None
-        for attempt in range(8):
+        for attempt in range(8):  # the kernel rebuilds H and retries with a 1000x larger shift
             if attempt:
                 shift *= 1e3
             try:
-                L = np.linalg.cholesky(H + shift * np.eye(n) * (1 if attempt == 0 else 1))
+                L = np.linalg.cholesky(H + shift * np.eye(n))
                 break
             except np.linalg.LinAlgError:
-                H = H + shift * np.eye(n)  # the kernel accumulates the shifts the same way
+                pass
         if L is None:
             status = 2
             break

@@ -459,6 +459,56 @@ class RobotModel(Model):
         J = self.get_global_link_geometric_jacobian(link, q)
         return J[3:] if isinstance(J, np.ndarray) else [j[3:] for j in J]
 
+    # ---- 4x4 transforms and base-frame variants (models.py:826-868, 884-898, 949-960, 1011-1023, 1108-1122, 1320-1344, 1425-1443,
+    # 1496-1516): host compositions of the oh_fk_jac outputs, one configuration at a time ---------------------------------
+    def get_global_link_transform(self, link: str, q) -> np.ndarray:
+        """models.py:826-868: homogeneous transform of the link in the root frame."""
+        T = np.eye(4)
+        T[:3, :3] = self.get_global_link_rotation(link, np.asarray(q, dtype=np.float64).reshape(-1))
+        T[:3, 3] = self.get_global_link_position(link, np.asarray(q, dtype=np.float64).reshape(-1))
+        return T
+
+    def get_link_transform(self, link: str, q, base_link: str) -> np.ndarray:
+        """models.py:884-898: T_L invt(T_B) -- the reference's convention (not invt(T_B) T_L), pinned by its tests."""
+        TB = self.get_global_link_transform(base_link, q)
+        inv = np.eye(4)
+        inv[:3, :3] = TB[:3, :3].T
+        inv[:3, 3] = -TB[:3, :3].T @ TB[:3, 3]
+        return self.get_global_link_transform(link, q) @ inv
+
+    def get_link_position(self, link: str, q, base_link: str) -> np.ndarray:
+        return self.get_link_transform(link, q, base_link)[:3, 3].copy()
+
+    def get_link_rotation(self, link: str, q, base_link: str) -> np.ndarray:
+        return self.get_link_transform(link, q, base_link)[:3, :3].copy()
+
+    def get_link_quaternion(self, link: str, q, base_link: str) -> np.ndarray:
+        """models.py:1108-1122: quat_L * quat_B^{-1} with the reference's reversed product (spatialmath.py:298-312)."""
+        qv = np.asarray(q, dtype=np.float64).reshape(-1)
+        ql = Quaternion.fromvec(self.get_global_link_quaternion(link, qv))
+        qb = Quaternion.fromvec(self.get_global_link_quaternion(base_link, qv))
+        return (ql * qb.inv()).getquat()
+
+    def get_link_geometric_jacobian(self, link: str, q, base_link: str) -> np.ndarray:
+        """models.py:1320-1344: blkdiag(R_B^T, R_B^T) J."""
+        qv = np.asarray(q, dtype=np.float64).reshape(-1)
+        J = self.get_global_link_geometric_jacobian(link, qv)
+        RT = self.get_global_link_rotation(base_link, qv).T
+        return np.vstack([RT @ J[:3], RT @ J[3:]])
+
+    def get_link_linear_jacobian(self, link: str, q, base_link: str) -> np.ndarray:
+        return self.get_link_geometric_jacobian(link, q, base_link)[:3]
+
+    def get_link_angular_geometric_jacobian(self, link: str, q, base_link: str) -> np.ndarray:
+        return self.get_link_geometric_jacobian(link, q, base_link)[3:]
+
+    def get_link_position_function(self, link: str, base_link: str, n: int = 1, numpy_output: bool = True):
+        """models.py:962-984 (what sphere_collision_avoidance_constraints maps over the knots)."""
+        return lambda q: self.get_link_position(link, q, base_link)
+
+    def get_global_link_transform_function(self, link: str, n: int = 1, numpy_output: bool = True):
+        return lambda q: self.get_global_link_transform(link, q)
+
     def get_global_link_position_function(self, link: str, n: int = 1, numpy_output: bool = True):
         """models.py:935-947: callable on an ndof-by-n array -> 3-by-n."""
         return lambda Q: self.get_global_link_position(link, np.asarray(Q, dtype=np.float64).reshape(self.ndof, -1))
@@ -478,6 +528,9 @@ class KinematicsHandle:
 
         lib = _lib.load()
         self.chain = chain
+        self._h = None
+        if chain.n_chain == 0:
+            return  # the root link, or a link rigidly attached to it: a constant transform, nothing to launch
         desc = _lib.oh_problem_desc(kind=_lib.OH_PROBLEM_KINEMATICS, ndof=chain.ndof)
         self._h = C.c_void_p()
         _lib.check(lib.oh_create(C.byref(desc), C.byref(self._h)), "oh_create")
@@ -490,6 +543,13 @@ class KinematicsHandle:
         n, ndof = Q.shape
         pose = np.empty((n, 7)) if want_pose else None
         J = np.empty((n, 6, ndof)) if want_jac else None
+        if self._h is None:
+            if want_pose:
+                pose[:, :3] = np.array(self.chain.p_tool[:])
+                pose[:, 3:] = np.array(self.chain.quat_tool[:])
+            if want_jac:
+                J[:] = 0.0
+            return pose, J
         _lib.check(lib.oh_fk_jac(self._h, n, _lib._ptr(Q), _lib._ptr(pose), _lib._ptr(J)), "oh_fk_jac")
         return pose, J
 

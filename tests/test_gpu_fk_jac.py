@@ -107,3 +107,28 @@ def test_errors(hip_lib):
     assert lib.oh_fk_jac(h, 0, _lib._ptr(q), None, None) == 1
     assert lib.oh_solve(h, 1, _lib._ptr(q), _lib._ptr(q), None, None, None, None, None) == 3  # kinematics-only handle
     lib.oh_destroy(h)
+
+
+def test_transforms_and_base_frame_variants_match_oracle(hip_lib):
+    """models.py:826-898, 949-1023, 1108-1122, 1320-1344 through the product's RobotModel (forward kinematics on the GPU) against
+    the oracle's literal restatement; T_L invt(T_B) is the convention the reference's tests pin (tests/test_models.py:505-511)."""
+    import numpy as np
+
+    from conftest import KUKA_KIN, SEED
+    from optas_amd.models import RobotModel
+    from oracle.robot import OracleRobot
+
+    rm, ro = RobotModel(urdf_filename=KUKA_KIN), OracleRobot(KUKA_KIN)
+    rng = np.random.default_rng(SEED)
+    for _ in range(4):
+        q = rng.uniform(-1.5, 1.5, 7)
+        for link, base in (("end_effector_ball", "lwr_arm_3_link"), ("lwr_arm_5_link", "lwr_arm_7_link"), ("lwr_arm_6_link", ro.get_root())):
+            assert np.abs(rm.get_global_link_transform(link, q) - ro.get_global_link_transform(link, q)).max() < 1e-13
+            assert np.abs(rm.get_link_transform(link, q, base) - ro.get_link_transform(link, q, base)).max() < 1e-13
+            assert np.abs(rm.get_link_position(link, q, base) - ro.get_link_position(link, q, base)).max() < 1e-13
+            assert np.abs(rm.get_link_rotation(link, q, base) - ro.get_link_rotation(link, q, base)).max() < 1e-13
+            qa, qb = rm.get_link_quaternion(link, q, base), ro.get_link_quaternion(link, q, base)
+            assert np.abs(qa - qb).max() < 1e-13  # same sign as the reference's chain
+            assert np.abs(rm.get_link_geometric_jacobian(link, q, base) - ro.get_link_geometric_jacobian(link, q, base)).max() < 1e-13
+            assert np.abs(rm.get_link_linear_jacobian(link, q, base) - ro.get_link_geometric_jacobian(link, q, base)[:3]).max() < 1e-13
+        assert np.abs(rm.get_link_position_function("lwr_arm_5_link", ro.get_root())(q) - ro.get_global_link_position("lwr_arm_5_link", q)).max() < 1e-13

@@ -9,7 +9,7 @@ A "step" is one pass of the hot path over one batch: one batched NLP solve (oh_s
 independent instances per GPU, inputs (seeds x0, parameters qc) already resident in HBM.  Instances are
 SURVEY 8(d)'s synthetic set: qc = deg2rad[0,30,0,-90,0,-30,0] + U(-0.1,0.1)^7, seed = qc repeated,
 numpy default_rng(20260927 + rank).  Multi-GPU: instances shard across ranks with no data-path
-collective; the kinematic constants (oh_chain, 2824 B) are broadcast once over RCCL (torch.distributed
+collective; the kinematic constants (oh_chain, 2952 B) are broadcast once over RCCL (torch.distributed
 "nccl" backend) from rank 0 and handed to the library as a device pointer.  torch is imported only
 when WORLD_SIZE > 1 (rendezvous, that one broadcast, barriers, MAX-reduce of the time).
 

@@ -1,0 +1,59 @@
+"""The reference's example/figure_eight_plan_6dof.py Planner (lines 17-128) written against optas_amd: the figure-eight plan with
+the first joint parameterised (RobotModel(param_joints=["lwr_arm_0_joint"])), same builder calls in the same order."""
+import numpy as np
+
+import optas_amd
+from optas_amd.builder import OptimizationBuilder
+from optas_amd.expr import path_in_frame, sumsqr
+from optas_amd.solver import HIPSolver
+
+from .figure_eight_plan import figure_eight_local_path
+
+
+def setup_solver(link_ee="end_effector_ball", T=50, Tmax=10.0, solver_options=None, build_only=False):
+    t, local = figure_eight_local_path(T, Tmax)
+    dt = float(t[1] - t[0])
+    kuka = optas_amd.RobotModel.builtin("kuka_lwr", time_derivs=[0, 1], param_joints=["lwr_arm_0_joint"])
+    kuka_name = kuka.get_name()
+    builder = OptimizationBuilder(T=T, robots=[kuka])
+    qc = builder.add_parameter("qc", kuka.ndof)
+    builder.initial_configuration(kuka_name, kuka.extract_optimized_dimensions(qc))
+    builder.initial_configuration(kuka_name, time_deriv=1)
+    builder.integrate_model_states(kuka_name, time_deriv=1, dt=dt)
+    Q = builder.get_robot_states_and_parameters(kuka_name)
+    pos_ee = kuka.get_global_link_position_function(link_ee, n=T)(Q)
+    pc = kuka.get_global_link_position(link_ee, qc)
+    Rc = kuka.get_global_link_rotation(link_ee, qc)
+    quatc = kuka.get_global_link_quaternion(link_ee, qc)
+    path = path_in_frame(pc, Rc, local)
+    builder.add_cost_term("ee_path", 1000.0 * sumsqr(path - pos_ee))
+    dQ = builder.get_robot_states_and_parameters(kuka_name, time_deriv=1)
+    builder.add_cost_term("min_join_vel", 0.01 * sumsqr(dQ))
+    builder.add_equality_constraint("no_eff_rot", kuka.get_global_link_quaternion_function(link_ee, n=T)(Q), quatc)
+    optimization = builder.build()
+    if build_only:
+        return kuka, optimization
+    return kuka, HIPSolver(optimization).setup("hip_sqp", solver_options)
+
+
+def plan(kuka, solver, qc, T=50):
+    """Planner.plan (:100-128): seed and parameters from Q0 = diag(qc) ones(ndof, T)."""
+    name = kuka.get_name()
+    Q0 = np.diag(qc) @ np.ones((kuka.ndof, T))
+    solver.reset_initial_seed({f"{name}/q/x": kuka.extract_optimized_dimensions(Q0)})
+    solver.reset_parameters({"qc": qc, f"{name}/q/p": kuka.extract_parameter_dimensions(Q0)})
+    solution = solver.solve()
+    return solution, solver.interpolate(solution[f"{name}/q"], 10.0)
+
+
+def main():
+    kuka, solver = setup_solver()
+    qc = optas_amd.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    solution, p = plan(kuka, solver, qc)
+    print("did_solve", solver.did_solve(), "iterations", solver.number_of_iterations(), "f", solver.stats()["f"][0])
+    print("q(5.0) =", p(5.0))
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -82,7 +82,7 @@ enum {
  *   T_link = T * [R_tool p_tool]
  * quat0_k / quat_tool are the same fixed rotations as xyzw quaternions accumulated with the
  * reference's own product (models.py:1049-1088, spatialmath.py:298-349) so that oh_fk_jac reproduces the
- * reference's quaternion *including its sign*.  This block (sizeof(oh_chain) = 2824 bytes) is what is
+ * reference's quaternion *including its sign*.  This block (sizeof(oh_chain) = 2952 bytes) is what is
  * broadcast once over RCCL/xGMI in multi-GPU runs.
  */
 typedef struct oh_chain {
@@ -101,6 +101,15 @@ typedef struct oh_chain {
   double R_tool[9];
   double p_tool[3];
   double quat_tool[4];
+  /* One parameterised joint ahead of the chain (RobotModel(param_joints=[...]), models.py:286-321; example/figure_eight_plan_6dof.py:30-34):
+     T <- [lead_R0 lead_p0] * Rot(lead_axis, theta) before the first chain joint, theta = the parameter "{name}/q/p" of the knot.  The
+     chain itself then lists the optimised joints only (ndof = their number).  Solver families only; oh_fk_jac ignores it.
+     With has_lead the parameter row of OH_PROBLEM_FIGURE_EIGHT is p = [qc of the optimised joints (ndof); theta of qc (1); theta_t (T)]. */
+  int has_lead;
+  int lead_axcode;
+  double lead_R0[9];
+  double lead_p0[3];
+  double lead_axis[3];
 } oh_chain;
 
 /*

@@ -42,6 +42,11 @@ class oh_chain(C.Structure):
         ("R_tool", C.c_double * 9),
         ("p_tool", C.c_double * 3),
         ("quat_tool", C.c_double * 4),
+        ("has_lead", C.c_int),
+        ("lead_axcode", C.c_int),
+        ("lead_R0", C.c_double * 9),
+        ("lead_p0", C.c_double * 3),
+        ("lead_axis", C.c_double * 3),
     ]
 
 

@@ -179,7 +179,7 @@ class FigureEightBackend:
         lib = _lib.load()
         self.T, self.ndof = int(T), int(chain.ndof)
         self.nx = self.ndof * self.T + self.ndof * (self.T - 1)
-        self.np_ = self.ndof
+        self.np_ = self.ndof + (1 + self.T if chain.has_lead else 0)  # [qc_opt; lead angle of qc; lead angle per knot]
         lp = _lib.as_f64(local_path, (self.T, 3))
         self._lp = lp  # keep alive during oh_create
         desc = _lib.oh_problem_desc(

@@ -16,7 +16,7 @@ from typing import List, Optional, Union
 
 import numpy as np
 
-from .expr import Const, Expr, ParamRef, Scale, StateRef, Sub, SumSqr, VarRef, as_expr
+from .expr import Const, Expr, ParamRef, RobotStates, Scale, StateRef, Sub, SumSqr, VarRef, as_expr
 from .models import Model, RobotModel, TaskModel
 from .optimization import (
     MixedIntegerNonlinearCostNonlinearConstrained,
@@ -104,6 +104,17 @@ class OptimizationBuilder:
         return self._parameters[model.state_parameter_name(time_deriv)]
 
     # ---- variables / parameters / terms ------------------------------------------------------------------
+    def get_robot_states_and_parameters(self, name: str, time_deriv: int = 0):
+        """builder.py:178-204: dim x n array with the optimised rows from the decision variables and the parameterised rows from
+        the parameters "{name}/{d}q/p"."""
+        model = self.get_model(name)
+        assert isinstance(model, RobotModel), "this method only applies to robot models"
+        states = self.get_model_states(name, time_deriv=time_deriv)
+        if model.num_param_joints == 0:
+            return states
+        return RobotStates(states, self.get_model_parameters(name, time_deriv=time_deriv), tuple(model.optimized_joint_indexes),
+                           tuple(model.parameter_joint_indexes))
+
     def add_decision_variables(self, name: str, m: int = 1, n: int = 1, is_discrete: bool = False) -> VarRef:
         x = VarRef(name, m, n)
         self._decision_variables[name] = x

@@ -457,6 +457,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   nd += 2 * (size_t)T * NZ * NZ * Bp + 2 * (size_t)T * NZ * Bp + 2 * per_t + (size_t)T * NZ * Bp;  // E, gt, merit, zstep
   nd += (size_t)12 * Bp + 7 * (size_t)Bp;
   nd += (size_t)4 * T * Bp;  // lam_h
+  nd += per_t;               // lead-joint angles
   size_t ni = 7 * (size_t)Bp + 32;  // + n_running, n_new, work (8-byte aligned)
   size_t bytes = nd * sizeof(double) + ni * sizeof(int);
   void* pool = nullptr;
@@ -498,6 +499,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.stat = take(Bp);
   D.feas = take(Bp);
   D.lam_h = take((size_t)4 * T * Bp);
+  D.lead = take(per_t);
   if (!h->desc.lock_orientation) D.lam_h = nullptr;  // no quaternion rows, no multipliers to report
   int* ip = (int*)d;
   D.cur = ip; ip += Bp;
@@ -609,6 +611,7 @@ static void fill_params(oh_handle* h) {
   P.mu0 = d.mu0;
   P.local_path = h->d_local_path;
   P.np = d.ndof + (h->have_guards ? h->guards.n_links + 4 * h->guards.n_obstacles : 0);
+  if (h->chain_host.has_lead) P.np = d.ndof + 1 + d.T;
 }
 
 extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt,
@@ -628,6 +631,10 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (rc) return rc;
   fill_params(h);
   const bool guarded = h->have_guards;
+  const bool lead = h->chain_host.has_lead != 0;
+  if (lead && (guarded || !h->desc.lock_orientation || h->desc.ndof != 6))
+    return fail(OH_ERR_INVALID, "oh_solve_device: a parameterised lead joint is lowered for the orientation-locked family with 6 optimised joints, "
+                                "without inequality rows");
   if (guarded) {
     rc = ensure_guards(h);
     if (rc) return rc;
@@ -663,7 +670,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   // compaction re-evaluates the survivors once.  The batch is compacted whenever at least half of it has
   // finished, so the slow tail keeps running in full wavefronts.
   const int hard_cap = 2 * h->desc.max_iter + 2 + 40;  // a rejected step costs two launches
-  const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation && !guarded;
+  const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation && !guarded && !lead;
   bool tail_done = false;
   if (tail_ok && B <= h->tail_threshold) {  // small batch: the whole solve is one persistent launch
     oh_launch_tail(s, N, h->P, h->D, 0);
@@ -678,6 +685,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     rebase = false;
     const int slot = it & 1;
     if (h->P.lock && guarded) oh_launch_eval_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
+    else if (lead) oh_launch_eval_lead(s, N, h->P, h->D, slot);
     else if (h->P.lock) oh_launch_eval(s, N, h->P, h->D, slot);
     else if (guarded) oh_launch_eval_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else oh_launch_eval_free(s, N, h->P, h->D, slot);
@@ -711,7 +719,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
         tail_done = true;
         break;
       }
-      if (h->compaction && !guarded && h->D.B >= 512 && 2 * nrun <= h->D.B) {
+      if (h->compaction && !guarded && !lead && h->D.B >= 512 && 2 * nrun <= h->D.B) {
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
         oh_launch_scan_running(s, h->D);
         oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
@@ -785,7 +793,7 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
   const bool ikk = h->desc.kind == OH_PROBLEM_IK;
   const bool qpk = h->desc.kind == OH_PROBLEM_QP;
   const size_t nx = qpk ? (size_t)h->qp.n : pmk ? 4 * (size_t)T : (ikk ? (size_t)N : (size_t)N * T + (size_t)N * (T - 1));
-  const size_t npar = qpk ? qp_np(h->qp) : pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0));
+  const size_t npar = qpk ? qp_np(h->qp) : pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (h->chain_host.has_lead ? (size_t)N + 1 + T : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0)));
   const size_t b_x = sizeof(double) * nx * B, b_p = sizeof(double) * npar * (size_t)B;
   const size_t b_f = sizeof(double) * B, b_k = sizeof(double) * 3 * (size_t)B, b_i = sizeof(int) * (size_t)B;
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };

@@ -131,13 +131,30 @@ OH_DEV void sincos_joint(const double x, double* s, double* c) {
 // chain covers all model joints in order).  Outputs: R,p = frame after the last joint (before the
 // tool transform), z[k] = world joint axis, pj[k] = world joint origin.
 // ---------------------------------------------------------------------------------------------
-template <int N>
+// frame that follows the parameterised lead joint (oh_chain.has_lead) at angle theta: [lead_R0 lead_p0] Rot(lead_axis, theta)
+OH_DEV void lead_base(const oh_chain* __restrict__ ch, const double theta, double (&Rb)[9], double (&pb)[3]) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rb[i] = ch->lead_R0[i];
+  pb[0] = ch->lead_p0[0]; pb[1] = ch->lead_p0[1]; pb[2] = ch->lead_p0[2];
+  double s, c, zc[3];
+  sincos_joint(theta, &s, &c);
+  rot_axis_right(Rb, ch->lead_axis, s, c, zc);
+}
+
+// BASE: start from the frame (Rb, pb) instead of the root frame (chains with a parameterised lead joint)
+template <int N, bool BASE = false>
 OH_DEV void fk_chain(const oh_chain* __restrict__ ch, const double (&q)[N], double (&R)[9], double (&p)[3],
-                     double (&z)[N][3], double (&pj)[N][3]) {
-  R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
-  R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
-  R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
-  p[0] = p[1] = p[2] = 0.0;
+                     double (&z)[N][3], double (&pj)[N][3], const double* __restrict__ Rb = nullptr, const double* __restrict__ pb = nullptr) {
+  if constexpr (BASE) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Rb[i];
+    p[0] = pb[0]; p[1] = pb[1]; p[2] = pb[2];
+  } else {
+    R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
+    R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
+    R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
+    p[0] = p[1] = p[2] = 0.0;
+  }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     double t[3];

@@ -85,16 +85,18 @@ OH_DEV void sphere_rows_walk(const oh_chain* __restrict__ ch, const GuardParams&
 // One knot: retraction onto R(q)=Rc (q is updated in place), FK chain + Jacobians, tracking cost phi,
 // constraint violation cv, tracking gradient g, Hessian block W (Gauss-Newton, or exact with the
 // multiplier estimate from Gprev), Householder null-space basis Z of the orientation rows, Dr = Z^T W Z.
-template <int N>
+template <int N, bool LEAD = false>
 OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const int t, double (&q)[N], const double (&pc)[3],
                       const double (&Rc)[9], const bool exact, const bool have_G, const double (&Gprev)[N], double& phi, double& cv, double (&g)[N],
-                      double (&Dr)[(N - 3) * (N - 2) / 2], double (&Z)[N][N - 3]) {
+                      double (&Dr)[(N - 3) * (N - 2) / 2], double (&Z)[N][N - 3], const double lead_theta = 0.0) {
   constexpr int NZ = N - 3;
   double R[9], p[3], z[N][3], pj[N][3];
   double Re[9], c[3], M[9];
   double cmax;
+  double Rb[9], pb[3];  // frame after the parameterised lead joint (LEAD only)
+  if constexpr (LEAD) lead_base(ch, lead_theta, Rb, pb);
   for (int it = 0;; ++it) {
-    fk_chain<N>(ch, q, R, p, z, pj);
+    fk_chain<N, LEAD>(ch, q, R, p, z, pj, Rb, pb);
     mm3(R, ch->R_tool, Re);
     orient_residual(Re, Rc, c, M);
     cmax = fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2])));

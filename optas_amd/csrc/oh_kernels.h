@@ -75,6 +75,7 @@ struct FigBuffers {
   double* stat;           // [Bp]
   double* feas;           // [Bp]
   double* fpsi;           // [Bp] augmented-Lagrangian part of f_cur (nullptr without inequality rows)
+  double* lead;           // [T][Bp] angle of the parameterised lead joint at every knot (nullptr: chain has none)
   int* cur;               // [Bp] slot holding the accepted point
   int* first;             // [Bp]
   int* skip;              // [Bp] 1: last trial rejected -> sit the next launch out (keeps the slot parity uniform)
@@ -92,6 +93,7 @@ bool oh_launch_rnea(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, int n,
 void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n, const double* q, double* pose, double* J);
 bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const double* x0, const double* p);
 bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_launch_eval_lead(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_eval_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);

@@ -230,7 +230,15 @@ OH_DEV void setup_unit(const FigParams& P, const FigBuffers& D, const double* __
 #pragma unroll
   for (int j = 0; j < N; ++j) qc[j] = pin[(size_t)b * P.np + j];
   double R[9], p[3], z[N][3], pj[N][3];
-  fk_chain<N>(ch, qc, R, p, z, pj);
+  if (ch->has_lead) {
+    // p = [qc of the optimised joints (N); lead angle of qc; lead angle of every knot (T)]
+    double Rb[9], pb[3];
+    lead_base(ch, pin[(size_t)b * P.np + N], Rb, pb);
+    fk_chain<N, true>(ch, qc, R, p, z, pj, Rb, pb);
+    for (int tt = 0; tt < P.T; ++tt) D.lead[(size_t)tt * Bp + b] = pin[(size_t)b * P.np + N + 1 + tt];
+  } else {
+    fk_chain<N>(ch, qc, R, p, z, pj);
+  }
   double e[3], t[3], Re[9];
   mv3(R, ch->p_tool, t);
   e[0] = p[0] + t[0]; e[1] = p[1] + t[1]; e[2] = p[2] + t[2];
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
 // K2: one lane per (instance b, free knot t): trial knot, retraction onto R(q_t)=Rc, FK chain + Jacobians,
 // tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block
 // (eval_knot in oh_figure8.h).
-template <int N, bool GUARD = false>
+template <int N, bool GUARD = false, bool LEAD = false>
 OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, const int b, const int t, const GuardParams* GPp = nullptr,
                       const GuardBuffers* GBp = nullptr) {
   constexpr int NZ = N - 3;
@@ -327,7 +335,8 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   for (int k = 0; k < N; ++k) Gprev[k] = have_G ? D.Gfull[cur][IDX(t, N, k)] : 0.0;
 
   double phi, cv, g[N], Dr[NP], Z[N][NZ];
-  eval_knot<N>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z);
+  if constexpr (LEAD) eval_knot<N, true>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, D.lead[(size_t)t * Bp + b]);
+  else eval_knot<N>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z);
   if constexpr (GUARD) {
     // inequality rows through the same augmented Lagrangian as the position-tracking family (oh_free.hip), added after the
     // retraction: joint limits q - lo >= 0, up - q >= 0 (enforce_model_limits, builder.py:471-509) have gradients +-e_j, so W gains
@@ -426,6 +435,18 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
 template <int N>
 __global__ __launch_bounds__(256, 2) void k_eval(FigParams P, FigBuffers D, const int slot) {
   eval_unit<N>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+}
+// chains with a parameterised lead joint (RobotModel(param_joints=[first joint]), figure_eight_plan_6dof.py): same evaluation
+// from the frame that follows the lead joint at the knot's parameter angle
+template <int N>
+__global__ __launch_bounds__(256, 2) void k_eval_lead(FigParams P, FigBuffers D, const int slot) {
+  eval_unit<N, false, true>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+}
+bool oh_launch_eval_lead(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
+  const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
+  if (n == 6) hipLaunchKernelGGL(k_eval_lead<6>, g, b, 0, s, P, D, slot);
+  else return false;
+  return true;
 }
 #endif
 
@@ -999,7 +1020,13 @@ OH_DEV void knot_multipliers(const FigParams& P, const FigBuffers& D, const int 
     if (!last) G[k] -= kap2 * (qs[IDX(t + 1, N, k)] - q[k]);
   }
   double R[9], p[3], z[N][3], pj[N][3];
-  fk_chain<N>(ch, q, R, p, z, pj);
+  if (ch->has_lead) {
+    double Rb[9], pb[3];
+    lead_base(ch, D.lead[(size_t)t * Bp + b], Rb, pb);
+    fk_chain<N, true>(ch, q, R, p, z, pj, Rb, pb);
+  } else {
+    fk_chain<N>(ch, q, R, p, z, pj);
+  }
   double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
   double rhs[3] = {0, 0, 0};
 #pragma unroll

@@ -1,7 +1,7 @@
 """Multi-GPU plumbing for one-process-per-GPU runs (bench.py, user scripts).
 
 MPC instances are independent, so the data path needs no collective at all: each rank solves its own
-shard.  The only exchange is ONE broadcast of the kinematic constants (``oh_chain``, 2824 bytes) from
+shard.  The only exchange is ONE broadcast of the kinematic constants (``oh_chain``, 2952 bytes) from
 rank 0, done over RCCL through ``torch.distributed`` (backend "nccl" is RCCL on ROCm; "gloo" is used by
 the CPU tests).  torch is imported lazily and only here -- liboptas_hip itself has no torch dependency.
 """

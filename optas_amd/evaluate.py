@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from .builder import IntegrationResidual
-from .expr import Add, Const, Expr, LinkFunction, Mul, ParamCol, ParamRef, PathInFrame, Scale, Square, StateCols, StateRef, Sub, SumSqr, VarRef
+from .expr import Add, Const, Expr, LinkFunction, Mul, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr, VarRef
 
 
 def _block(container, vec, label):
@@ -30,6 +30,15 @@ def evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
         return full if e.t is None else full[:, [e.t]]
     if isinstance(e, StateCols):
         return _block(opt.decision_variables, x, e.state.var_name)[:, e.lo : e.hi]
+    if isinstance(e, RobotStates):
+        X = evaluate(e.states, opt, x, p)
+        Pm = evaluate(e.params, opt, x, p)
+        full = np.zeros(e.shape)
+        full[list(e.opt_idx), :] = X
+        full[list(e.par_idx), :] = Pm
+        return full
+    if isinstance(e, Rows):
+        return evaluate(e.a, opt, x, p)[list(e.idx), :]
     if isinstance(e, VarRef):
         return _block(opt.decision_variables, x, e.var_name)
     if isinstance(e, LinkFunction):

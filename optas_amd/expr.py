@@ -167,6 +167,37 @@ class StateCols(Expr):
 
 
 @dataclass(eq=False)
+class RobotStates(Expr):
+    """builder.get_robot_states_and_parameters (builder.py:178-204): the full dim x n joint trajectory of a robot assembled from its
+    optimised block (decision variables) and its parameterised block (parameters), rows in actuated-joint order."""
+
+    states: "StateRef" = None
+    params: "ParamRef" = None
+    opt_idx: tuple = ()
+    par_idx: tuple = ()
+
+    def __post_init__(self):
+        self.shape = (len(self.opt_idx) + len(self.par_idx), self.states.shape[1])
+
+    def degree(self):
+        return 1
+
+
+@dataclass(eq=False)
+class Rows(Expr):
+    """Row selection values[idx, :] (RobotModel.extract_optimized_dimensions / extract_parameter_dimensions, models.py:590-612)."""
+
+    a: Expr = None
+    idx: tuple = ()
+
+    def __post_init__(self):
+        self.shape = (len(self.idx), self.a.shape[1])
+
+    def degree(self):
+        return self.a.degree()
+
+
+@dataclass(eq=False)
 class VarRef(Expr):
     """A free decision-variable block (builder.add_decision_variables, builder.py:244-261)."""
 

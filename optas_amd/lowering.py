@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from .builder import IntegrationResidual
-from .expr import Add, Const, LinkFunction, ParamCol, ParamRef, PathInFrame, Scale, Square, StateCols, StateRef, Sub, SumSqr
+from .expr import Add, Const, LinkFunction, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr
 from .models import RobotModel, TaskModel
 from .optimization import Optimization
 
@@ -42,6 +42,7 @@ class FigureEightSpec:
     lo: Optional[np.ndarray] = None  # joint limits (enforce_model_limits), None: no such rows
     up: Optional[np.ndarray] = None
     spheres: Optional["GuardSpec"] = None  # sphere clearances (sphere_collision_avoidance_constraints)
+    lead: Optional[dict] = None  # one parameterised joint ahead of the chain (param_joints): {"par", "opt", "qp", "dqp"}
 
 
 def _unscale(e):
@@ -64,8 +65,8 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
     if len(opt.models or []) != 1 or len(robots) != 1:
         no("expected exactly one RobotModel and no task models")
     robot = robots[0]
-    if list(robot.time_derivs) != [0, 1] or robot.num_param_joints != 0:
-        no("robot must have time_derivs=[0, 1] and no parameterised joints")
+    if list(robot.time_derivs) != [0, 1] or robot.num_param_joints > 1:
+        no("robot must have time_derivs=[0, 1] and at most one parameterised joint")
     name = robot.get_name()
     q_name, dq_name = robot.state_optimized_name(0), robot.state_optimized_name(1)
     if list(opt.decision_variables.keys()) != [q_name, dq_name]:
@@ -75,6 +76,17 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
     T = Q.n
     if dQ.n != T - 1:
         no("derivs_align=True is not lowered")
+    lead = None
+    if robot.num_param_joints == 1:
+        lead = {"par": robot.parameter_joint_indexes[0], "opt": list(robot.optimized_joint_indexes), "qp": robot.state_parameter_name(0),
+                "dqp": robot.state_parameter_name(1)}
+
+    def is_full(e, X):
+        """e is the robot's full trajectory of block X: X itself, or get_robot_states_and_parameters over X."""
+        if lead is None:
+            return e is X
+        return isinstance(e, RobotStates) and e.states is X and list(e.opt_idx) == lead["opt"] and list(e.par_idx) == [lead["par"]]
+
     sph = {}
     for label, d in opt.ineq_constraints.items():
         ok = (isinstance(d, Sub) and isinstance(d.a, SumSqr) and isinstance(d.a.a, Sub) and isinstance(d.a.a.a, LinkFunction)
@@ -120,8 +132,12 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
         if not isinstance(diff, Sub):
             no(f"linear equality '{label}' not recognised")
         rhs, lhs = diff.a, diff.b
-        if isinstance(lhs, StateRef) and lhs.t == 0 and lhs.time_deriv == 0 and isinstance(rhs, ParamRef):
+        if isinstance(lhs, StateRef) and lhs.t == 0 and lhs.time_deriv == 0 and isinstance(rhs, ParamRef) and lead is None:
             qc = rhs
+            seen.add("fix_q")
+        elif (isinstance(lhs, StateRef) and lhs.t == 0 and lhs.time_deriv == 0 and lead is not None and isinstance(rhs, Rows)
+              and isinstance(rhs.a, ParamRef) and list(rhs.idx) == lead["opt"]):
+            qc = rhs.a  # initial_configuration(name, robot.extract_optimized_dimensions(qc)), figure_eight_plan_6dof.py:46-49
             seen.add("fix_q")
         elif isinstance(lhs, StateRef) and lhs.t == 0 and lhs.time_deriv == 1 and _is_zero_const(rhs):
             seen.add("fix_dq")
@@ -138,6 +154,10 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
         no("qc must be an ndof-vector parameter")
     params = [k for k, v in opt.parameters.items() if v.numel() > 0]
     expect = [qc.name]
+    if lead is not None:
+        expect = [lead["qp"], lead["dqp"], qc.name]
+        if spheres is not None or lo is not None:
+            no("inequality rows together with a parameterised joint are not lowered")
     if spheres is not None:
         expect += list(spheres.link_radii) + [x for ob in spheres.obstacles for x in ob]
     if params != expect:
@@ -153,7 +173,7 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
         and isinstance(diff.b, LinkFunction)
         and diff.a.what == diff.b.what == "quaternion"
         and diff.a.q is qc
-        and diff.b.q is Q
+        and is_full(diff.b.q, Q)
         and diff.a.link == diff.b.link
         and diff.a.robot is robot
         and diff.b.robot is robot
@@ -170,12 +190,12 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
         if not isinstance(e, SumSqr):
             no(f"cost '{label}' is not a weighted sumsqr")
         inner = e.a
-        if inner is dQ:
+        if inner is dQ or is_full(inner, dQ):
             w_vel = w
         elif isinstance(inner, Sub) and isinstance(inner.a, PathInFrame) and isinstance(inner.b, LinkFunction):
             pth, pos = inner.a, inner.b
             good = (
-                pos.what == "position" and pos.q is Q and pos.link == link and pos.robot is robot
+                pos.what == "position" and is_full(pos.q, Q) and pos.link == link and pos.robot is robot
                 and isinstance(pth.origin, LinkFunction) and pth.origin.what == "position" and pth.origin.q is qc and pth.origin.link == link
                 and isinstance(pth.rotation, LinkFunction) and pth.rotation.what == "rotation" and pth.rotation.q is qc and pth.rotation.link == link
                 and pth.local.shape == (3, T)
@@ -187,7 +207,7 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
             no(f"cost '{label}' not recognised")
     if w_path is None or w_vel is None:
         no("need both the path-tracking and the joint-velocity cost terms")
-    return FigureEightSpec(robot, link, T, dt, w_path, w_vel, np.ascontiguousarray(local.T), qc.name, q_name, dq_name, lo, up, spheres)
+    return FigureEightSpec(robot, link, T, dt, w_path, w_vel, np.ascontiguousarray(local.T), qc.name, q_name, dq_name, lo, up, spheres, lead)
 
 
 @dataclass

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Tuple, Union
 import numpy as np
 
 from . import _lib
-from .expr import Expr, LinkFunction
+from .expr import Expr, LinkFunction, Rows
 from .spatialmath import Quaternion, rpy2r, unit
 from .urdf import Joint, Link, RobotDescription, load_robot_description
 
@@ -215,10 +215,16 @@ class RobotModel(Model):
         return self._limits(self.get_velocity_joint_limit, self.optimized_joint_names)
 
     def extract_parameter_dimensions(self, values):
-        return np.asarray(values)[self.parameter_joint_indexes, :]
+        if isinstance(values, Expr):
+            return Rows(values, tuple(self.parameter_joint_indexes))
+        a = np.asarray(values)
+        return a[self.parameter_joint_indexes] if a.ndim == 1 else a[self.parameter_joint_indexes, :]
 
     def extract_optimized_dimensions(self, values):
-        return np.asarray(values)[self.optimized_joint_indexes, :]
+        if isinstance(values, Expr):
+            return Rows(values, tuple(self.optimized_joint_indexes))
+        a = np.asarray(values)
+        return a[self.optimized_joint_indexes] if a.ndim == 1 else a[self.optimized_joint_indexes, :]
 
     # ---- tree (models.py:552-667) -----------------------------------------------------------------
     def add_base_frame(self, base_link: str, xyz=None, rpy=None, joint_name: Optional[str] = None) -> None:
@@ -271,6 +277,40 @@ class RobotModel(Model):
                 raise ValueError(f"link '{ln}' is not on the chain from '{root}' to '{link}'")
             out.append(att[ln])
         return out
+
+    def solver_chain(self, link: str) -> _lib.oh_chain:
+        """The chain the solver kernels walk: kinematic_chain(link) for a model without parameterised joints; with
+        param_joints = [the first actuated joint of the chain] the chain lists the optimised joints only (ndof = num_opt_joints,
+        q index = optimised index) and the parameterised joint becomes the lead joint (oh_chain.has_lead)."""
+        if self.num_param_joints == 0:
+            return self.kinematic_chain(link)
+        if self.num_param_joints != 1:
+            raise NotImplementedError("only one parameterised joint is lowered")
+        full = self.kinematic_chain(link)
+        lead_i = self.parameter_joint_indexes[0]
+        if full.n_chain < 2 or full.qidx[0] != lead_i or full.jtype[0] != 0:
+            raise NotImplementedError("the parameterised joint must be the first (revolute) actuated joint of the chain")
+        ch = _lib.oh_chain()
+        ch.ndof = self.num_opt_joints
+        ch.n_chain = full.n_chain - 1
+        opt = self.optimized_joint_indexes
+        for k in range(1, full.n_chain):
+            ch.jtype[k - 1], ch.axcode[k - 1], ch.r0ident[k - 1] = full.jtype[k], full.axcode[k], full.r0ident[k]
+            ch.qidx[k - 1] = opt.index(full.qidx[k])
+            for i in range(9):
+                ch.R0[k - 1][i] = full.R0[k][i]
+            for i in range(3):
+                ch.p0[k - 1][i], ch.axis[k - 1][i] = full.p0[k][i], full.axis[k][i]
+            for i in range(4):
+                ch.quat0[k - 1][i] = full.quat0[k][i]
+        for i in range(9):
+            ch.R_tool[i], ch.lead_R0[i] = full.R_tool[i], full.R0[0][i]
+        for i in range(3):
+            ch.p_tool[i], ch.lead_p0[i], ch.lead_axis[i] = full.p_tool[i], full.p0[0][i], full.axis[0][i]
+        for i in range(4):
+            ch.quat_tool[i] = full.quat_tool[i]
+        ch.has_lead, ch.lead_axcode = 1, full.axcode[0]
+        return ch
 
     def kinematic_chain(self, link: str) -> _lib.oh_chain:
         """Fold root->link into per-actuated-joint constants (fixed joints multiplied into the next
@@ -511,10 +551,10 @@ class RobotModel(Model):
 
     def get_global_link_position_function(self, link: str, n: int = 1, numpy_output: bool = True):
         """models.py:935-947: callable on an ndof-by-n array -> 3-by-n."""
-        return lambda Q: self.get_global_link_position(link, np.asarray(Q, dtype=np.float64).reshape(self.ndof, -1))
+        return lambda Q: self.get_global_link_position(link, Q if isinstance(Q, Expr) else np.asarray(Q, dtype=np.float64).reshape(self.ndof, -1))
 
     def get_global_link_quaternion_function(self, link: str, n: int = 1, numpy_output: bool = True):
-        return lambda Q: self.get_global_link_quaternion(link, np.asarray(Q, dtype=np.float64).reshape(self.ndof, -1))
+        return lambda Q: self.get_global_link_quaternion(link, Q if isinstance(Q, Expr) else np.asarray(Q, dtype=np.float64).reshape(self.ndof, -1))
 
     def get_global_link_geometric_jacobian_function(self, link: str, n: int = 1, numpy_output: bool = True):
         return lambda Q: self.get_global_link_geometric_jacobian(link, np.asarray(Q, dtype=np.float64).reshape(self.ndof, -1))

@@ -140,6 +140,34 @@ class Solver(ABC):
         return interp1d(t, traj, **interp_args)
 
 
+class _LeadAdapter:
+    """Figure-eight family with one parameterised joint ahead of the chain (RobotModel(param_joints=[...]),
+    example/figure_eight_plan_6dof.py): re-packs the reference's parameter vector ["{name}/q/p" (1 x T); "{name}/dq/p" (1 x (T-1)); qc (ndof)]
+    into the kernel's row [qc of the optimised joints; lead angle of qc; lead angle per knot] and adds the constant
+    w_vel * ||dq/p||^2 that the reference's joint-velocity cost carries for the parameterised row."""
+
+    def __init__(self, opt, spec, backend):
+        self.opt, self.spec, self.be = opt, spec, backend
+
+    def solve(self, x0: np.ndarray, p: np.ndarray) -> BatchResult:
+        p = np.asarray(p, dtype=np.float64).reshape(-1, self.opt.np)
+        off = self.opt.parameters.offsets()
+        T, sp = self.spec.T, self.spec
+        qc = p[:, off[sp.qc_name] : off[sp.qc_name] + sp.robot.ndof]
+        qp = p[:, off[sp.lead["qp"]] : off[sp.lead["qp"]] + T]
+        dqp = p[:, off[sp.lead["dqp"]] : off[sp.lead["dqp"]] + T - 1]
+        pk = np.ascontiguousarray(np.concatenate([qc[:, sp.lead["opt"]], qc[:, [sp.lead["par"]]], qp], axis=1))
+        r = self.be.solve(x0, pk)
+        r.f = r.f + sp.w_vel * np.sum(dqp * dqp, axis=1)
+        return r
+
+    def multipliers(self, B: int):
+        return self.be.multipliers(B)
+
+    def close(self) -> None:
+        self.be.close()
+
+
 class _QpAdapter:
     """Dense QP family: reads P, q, M, c, A, b off the Optimization's numeric members for every instance (they may all depend on the
     parameters) and hands [P | q | M | c | A | b] rows to the kernel.  The cost's constant term f(0, p) is added back to f."""
@@ -183,7 +211,7 @@ class HIPSolver(Solver):
         if isinstance(spec, FigureEightSpec):
             o.pop("hessian", None)
         if isinstance(spec, FigureEightSpec):
-            chain = spec.robot.kinematic_chain(spec.link)
+            chain = spec.robot.solver_chain(spec.link)
             guards = None
             if spec.lo is not None or spec.spheres is not None:
                 guards = _lib.oh_guards()
@@ -213,6 +241,8 @@ class HIPSolver(Solver):
                 mu0=float(o.pop("mu0", 0.0)),
                 guards=guards,
             )
+            if spec.lead is not None:
+                self._backend = _LeadAdapter(self.opt, spec, self._backend)
         elif isinstance(spec, PointMassSpec):
             o.pop("hessian", None)
             self._backend = PointMassBackend(

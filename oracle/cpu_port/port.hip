@@ -76,6 +76,7 @@ void solve_one(const FigParams& P, Workspace& w, const double* x0, const double*
 extern "C" int oh_port_solve(const oh_problem_desc* desc, const oh_chain* chain, int B, const double* x0, const double* p, double* x, double* f,
                              double* kkt, int* iters, int* status, int threads) {
   if (!desc || !chain || B < 1 || !x0 || !p || !x || !f || !kkt || !iters || !status) return 1;
+  if (chain->has_lead) return 1;  // parameterised lead joints are not part of the baseline workload
   if (desc->kind != OH_PROBLEM_FIGURE_EIGHT || !desc->lock_orientation || (desc->ndof != 6 && desc->ndof != 7) || !desc->local_path) return 1;
   FigParams P{};
   P.T = desc->T;

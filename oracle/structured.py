@@ -552,3 +552,44 @@ def solve_free_lm(chain: FoldedChain, T, dt, offsets, qc, Q0=None, w_path=1.0, w
         Qt[F] += z
         iters += 1
     return {"Q": cur["Q"], "f": cur["f"], "iters": iters, "rejected": rejected, "stat": stat, "status": status}
+
+
+class LeadChain:
+    """A FoldedChain of the full robot seen through its optimised joints: one parameterised joint (RobotModel(param_joints=[...]),
+    models.py:286-321; example/figure_eight_plan_6dof.py) is held at theta_knots[t] when a whole trajectory (T rows) is passed and
+    at theta_ref otherwise (the reference configuration qc)."""
+
+    def __init__(self, full: FoldedChain, par: int, theta_knots, theta_ref: float):
+        self.full, self.par = full, par
+        self.theta_knots, self.theta_ref = np.asarray(theta_knots, dtype=float), float(theta_ref)
+        self.opt = [i for i in range(full.ndof) if i != par]
+        self.ndof = full.ndof - 1
+        self.n_chain = full.n_chain - 1
+        self._keep = [k for k in range(full.n_chain) if full.qidx[k] != par]
+        self.jtype = [full.jtype[k] for k in self._keep]
+        self.qidx = [self.opt.index(full.qidx[k]) for k in self._keep]
+        self.attach = full.attach
+
+    def _full(self, Q):
+        Q = np.atleast_2d(Q)
+        th = self.theta_knots if Q.shape[0] == self.theta_knots.shape[0] else np.full(Q.shape[0], self.theta_ref)
+        out = np.zeros((Q.shape[0], self.full.ndof))
+        out[:, self.opt] = Q
+        out[:, self.par] = th
+        return out
+
+    def fk(self, Q, frames=False):
+        r = self.full.fk(self._full(Q), frames=frames)
+        return (r[0], r[1], r[2][:, self._keep], r[3][:, self._keep]) + tuple(r[4:])
+
+    def jac(self, Q):
+        e, Re, Jp, Jw = self.full.jac(self._full(Q))
+        return e, Re, Jp[:, :, self.opt], Jw[:, :, self.opt]
+
+
+def lead_problem(robot, link, par: int, theta_knots, theta_ref: float, **kw):
+    """StructuredFigureEight over the optimised joints of a robot whose joint `par` is parameterised."""
+    prob = StructuredFigureEight(robot, link, **kw)
+    prob.chain = LeadChain(prob.chain, par, theta_knots, theta_ref)
+    prob.n = prob.chain.ndof
+    return prob

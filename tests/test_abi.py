@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     # sizeof(oh_chain): 2 ints + 4*16 ints + 16*(9+3+3+4) doubles + (9+3+4) doubles
-    assert C.sizeof(_lib.oh_chain) == 8 + 256 + 8 * (16 * 19 + 16)
+    assert C.sizeof(_lib.oh_chain) == 8 + 256 + 8 * (16 * 19 + 16) + 8 + 8 * 15 == 2952  # + has_lead, lead_axcode, lead_R0, lead_p0, lead_axis
 
 
 def test_invalid_arguments_are_rejected_without_a_device_call():

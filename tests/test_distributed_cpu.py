@@ -53,7 +53,7 @@ def test_gloo_world_size_2(tmp_path):
     r = [np.load(tmp_path / f"r{k}.npz") for k in range(world)]
     for k in range(world):
         assert r[k]["chain"].tobytes() == ref  # every rank holds rank 0's constants, bit for bit
-        assert int(r[k]["nbytes"]) == C.sizeof(_lib.oh_chain) == 2824
+        assert int(r[k]["nbytes"]) == C.sizeof(_lib.oh_chain) == 2952
         assert float(r[k]["tmax"]) == 2.0 and float(r[k]["tsum"]) == 1001.0
     assert (int(r[0]["lo"]), int(r[0]["hi"]), int(r[1]["lo"]), int(r[1]["hi"])) == (0, 501, 501, 1001)
     assert not np.array_equal(r[0]["qc"], r[1]["qc"])  # ranks draw different instances

@@ -128,3 +128,39 @@ def test_other_robot_med7_matches_port(hip_lib):
         assert r.status[b] == s["status"] == 0 and abs(int(r.iters[b]) - s["iters"]) <= 1
         assert abs(r.f[b] - s["f"]) <= 1e-9 * abs(s["f"])
     be.close()
+
+
+def test_parameterised_lead_joint_six_optimised_joints(hip_lib):
+    """example/figure_eight_plan_6dof.py: RobotModel(param_joints=["lwr_arm_0_joint"]) -- six optimised joints behind a parameterised
+    one (the N = 6 kernels, a per-knot lead frame).  Same state machine as the numpy port over the optimised joints; the solution is
+    checked through the mirrored Optimization's own f, a, h (forward kinematics of the full 7-joint chain)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from examples.figure_eight_plan_6dof import plan, setup_solver
+    from oracle.structured import lead_problem
+
+    kuka, solver = setup_solver()
+    o = solver.opt
+    assert (o.nx, o.np, o.na, o.nh, o.nv) == (594, 106, 306, 200, 1012)
+    qc = QC0.copy()
+    qc[0] = 0.2
+    sol, interp = plan(kuka, solver, qc)
+    assert solver.did_solve()
+    assert sol["kuka/q"].shape == (7, 50) and np.allclose(sol["kuka/q"][0], 0.2) and sol["kuka/q/x"].shape == (6, 50)  # solver.py:137-155
+    prob = lead_problem(OracleRobot(KUKA_KIN), LINK, 0, np.full(50, 0.2), 0.2, T=50)
+    s = solve_structured_lm(prob, qc[1:], max_iter=300, tol=1e-6)
+    assert s["status"] == 0 and abs(solver.number_of_iterations() - s["iters"]) <= 1
+    assert abs(solver.stats()["f"][0] - s["f"]) < 1e-8 * s["f"] and np.abs(np.asarray(sol["kuka/q/x"]).T - s["Q"]).max() < 1e-4
+    x = o.decision_variables.dict2vec(sol)
+    Q0 = np.diag(qc) @ np.ones((7, 50))
+    p = o.parameters.dict2vec({"qc": qc, "kuka/q/p": Q0[[0]]})
+    assert abs(o.f(x, p) - solver.stats()["f"][0]) < 1e-9 and np.abs(o.a(x, p)).max() < 1e-12 and np.abs(o.h(x, p)).max() < 1e-9
+    # a moving parameterised joint (the parameter is a trajectory, 1 x T) and a batch
+    th = 0.2 + 0.15 * np.sin(np.linspace(0.0, np.pi, 50))
+    th[:2] = 0.2
+    solver.reset_parameters({"qc": qc, "kuka/q/p": th.reshape(1, -1)})
+    sol2 = solver.solve()
+    s2 = solve_structured_lm(lead_problem(OracleRobot(KUKA_KIN), LINK, 0, th, 0.2, T=50), qc[1:], max_iter=300, tol=1e-6)
+    assert solver.did_solve() and abs(solver.stats()["f"][0] - s2["f"]) < 1e-8 * s2["f"] and np.allclose(sol2["kuka/q"][0], th)

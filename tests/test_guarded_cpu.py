@@ -168,3 +168,27 @@ def test_figure_eight_lowering_with_limits_and_spheres():
     b.enforce_model_limits(r.get_name(), time_deriv=1)
     with pytest.raises(LoweringError):
         lower(b.build())
+
+
+def test_parameterised_joint_problem_builds_and_lowers():
+    """example/figure_eight_plan_6dof.py on the CPU: builder counts with param_joints, lowering to the lead-joint chain."""
+    from examples.figure_eight_plan_6dof import setup_solver
+    from optas_amd import _lib
+    from optas_amd.lowering import lower
+
+    kuka, o = setup_solver(build_only=True)
+    assert (kuka.ndof, kuka.num_opt_joints, kuka.num_param_joints) == (7, 6, 1)
+    assert (o.nx, o.np, o.na, o.nh, o.nv) == (6 * 50 + 6 * 49, 50 + 49 + 7, 6 + 6 + 6 * 49, 200, 2 * 306 + 2 * 200)
+    assert list(o.parameters.keys()) == ["kuka/q/p", "kuka/dq/p", "qc"] and o.parameters["kuka/q/p"].shape == (1, 50)
+    kind, spec = lower(o)
+    assert kind == _lib.OH_PROBLEM_FIGURE_EIGHT and spec.lead == {"par": 0, "opt": [1, 2, 3, 4, 5, 6], "qp": "kuka/q/p", "dqp": "kuka/dq/p"}
+    ch = kuka.solver_chain("end_effector_ball")
+    full = kuka.kinematic_chain("end_effector_ball")
+    assert (ch.ndof, ch.n_chain, ch.has_lead) == (6, 6, 1) and list(ch.qidx[:6]) == [0, 1, 2, 3, 4, 5]
+    assert list(ch.lead_axis) == list(full.axis[0]) and list(ch.lead_p0) == list(full.p0[0]) and list(ch.R0[0]) == list(full.R0[1])
+    # linear rows of the mirrored problem: q_x[:, 0] = qc[1:], dq_x[:, 0] = 0, Euler integration over the optimised block only
+    rng = np.random.default_rng(4)
+    x, p = rng.normal(size=o.nx), rng.normal(size=o.np)
+    a = o.a(x, p)
+    qc = p[99:106]
+    assert np.allclose(a[:6], qc[1:] - x[:6]) and np.allclose(a[6:12], -x[300:306])

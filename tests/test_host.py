@@ -160,7 +160,7 @@ def test_chain_folding_matches_oracle():
     assert list(ch.axcode)[:7] == [3, 2, 3, -2, 3, 2, 3] and list(ch.r0ident)[:7] == [0, 1, 1, 1, 1, 1, 0]
     mid = robot.kinematic_chain("lwr_arm_4_link")
     assert mid.n_chain == 4 and mid.ndof == 7
-    assert C.sizeof(optas_amd._lib.oh_chain) == 2824  # the block that is broadcast over RCCL (< 3 KB)
+    assert C.sizeof(optas_amd._lib.oh_chain) == 2952  # the block that is broadcast over RCCL (< 3 KB)
     t = RobotModel(urdf_filename=TESTER_KIN).kinematic_chain("eff")
     assert list(t.jtype)[:3] == [0, 0, 1] and np.allclose(t.p_tool, [0, 0, 0.5])
     with pytest.raises(AssertionError):

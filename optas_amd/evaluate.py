@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from .builder import IntegrationResidual
-from .expr import Add, Const, Expr, LinkFunction, Mul, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr, VarRef
+from .expr import Add, Const, Expr, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr, VCat, VarRef
 
 
 def _block(container, vec, label):
@@ -18,7 +18,24 @@ def _block(container, vec, label):
 
 
 def evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
-    """Value of node ``e`` as a 2-D array (rows x cols like the CasADi matrix it stands for)."""
+    """Value of node ``e`` as a 2-D array (rows x cols like the CasADi matrix it stands for).  Link functions of parameters only
+    (``J(qc)``, ``p(qc)``) are memoised per parameter vector: reading P, q, M, c off a QP evaluates the trees dozens of times with
+    the same p, and each of those nodes is a round trip to the GPU."""
+    if isinstance(e, Const):
+        return e.value
+    if isinstance(e, LinkFunction) and e.q.degree() == 0:
+        cache = getattr(opt, "_link_cache", None)
+        key = p.tobytes()
+        if cache is None or cache[0] != key:
+            cache = (key, {})
+            opt._link_cache = cache
+        if id(e) not in cache[1]:
+            cache[1][id(e)] = _evaluate(e, opt, x, p)
+        return cache[1][id(e)]
+    return _evaluate(e, opt, x, p)
+
+
+def _evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
     if isinstance(e, Const):
         return e.value
     if isinstance(e, ParamRef):
@@ -47,6 +64,8 @@ def evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
             return np.asarray(e.robot.get_global_link_position(e.link, q)).reshape(3, -1)
         if e.what == "quaternion":
             return np.asarray(e.robot.get_global_link_quaternion(e.link, q)).reshape(4, -1)
+        if e.what == "geometric_jacobian":
+            return np.asarray(e.robot.get_global_link_geometric_jacobian(e.link, q.reshape(-1)))
         return np.asarray(e.robot.get_global_link_rotation(e.link, q.reshape(-1)))
     if isinstance(e, PathInFrame):
         return evaluate(e.origin, opt, x, p).reshape(3, 1) + evaluate(e.rotation, opt, x, p) @ e.local
@@ -60,6 +79,10 @@ def evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
         return evaluate(e.a, opt, x, p) + evaluate(e.b, opt, x, p)
     if isinstance(e, Scale):
         return e.w * evaluate(e.a, opt, x, p)
+    if isinstance(e, MatMul):
+        return evaluate(e.a, opt, x, p) @ evaluate(e.b, opt, x, p)
+    if isinstance(e, VCat):
+        return np.vstack([np.broadcast_to(evaluate(q_, opt, x, p), q_.shape) for q_ in e.parts])
     if isinstance(e, Mul):
         return evaluate(e.a, opt, x, p) * evaluate(e.b, opt, x, p)
     if isinstance(e, Square):

@@ -54,6 +54,23 @@ class Expr:
             return Square(self)
         return NotImplemented
 
+    def __matmul__(self, other):
+        return MatMul(self, as_expr(other))
+
+    def __rmatmul__(self, other):
+        return MatMul(as_expr(other), self)
+
+    def __getitem__(self, key):
+        """Row selection of a generic node: e[i], e[a:b] (``veff[:3]``, ``pn[2]`` in example/experiment1.py:120-128)."""
+        rows = range(self.shape[0])
+        if isinstance(key, int):
+            idx = (rows[key],)
+        elif isinstance(key, slice):
+            idx = tuple(rows[key])
+        else:
+            raise NotImplementedError("only row indexing e[i] / e[a:b] of a generic expression is supported")
+        return Rows(self, idx)
+
     def numel(self) -> int:
         return self.shape[0] * self.shape[1]
 
@@ -223,9 +240,13 @@ class LinkFunction(Expr):
     q: Expr = None
 
     def __post_init__(self):
-        rows = {"position": 3, "quaternion": 4, "rotation": 3}[self.what]
+        rows = {"position": 3, "quaternion": 4, "rotation": 3, "geometric_jacobian": 6}[self.what]
         cols = self.q.shape[1]
-        if self.what == "rotation":
+        if self.what == "geometric_jacobian":
+            if cols != 1:
+                raise NotImplementedError("the Jacobian of a trajectory is a list in the reference; only one configuration is lowered")
+            self.shape = (6, self.robot.ndof)
+        elif self.what == "rotation":
             if cols != 1:
                 raise NotImplementedError("rotation of a trajectory is a list in the reference; only one configuration is lowered")
             self.shape = (3, 3)
@@ -306,6 +327,40 @@ class SumSqr(Expr):
     def degree(self):
         d = self.a.degree()
         return 0 if d == 0 else (2 if d == 1 else 3)
+
+
+@dataclass(eq=False)
+class MatMul(Expr):
+    """Matrix product (``J @ qd``, example/experiment1.py:32)."""
+
+    a: Expr = None
+    b: Expr = None
+
+    def __post_init__(self):
+        assert self.a.shape[1] == self.b.shape[0], f"matmul shape mismatch {self.a.shape} @ {self.b.shape}"
+        self.shape = (self.a.shape[0], self.b.shape[1])
+
+    def degree(self):
+        return min(3, self.a.degree() + self.b.degree())
+
+
+@dataclass(eq=False)
+class VCat(Expr):
+    """casadi.vertcat of column blocks (``vertcat(desvel, zeros(4))``, example/experiment1.py:142)."""
+
+    parts: tuple = ()
+
+    def __post_init__(self):
+        cols = {p.shape[1] for p in self.parts}
+        assert len(cols) == 1, "vertcat needs equal column counts"
+        self.shape = (sum(p.shape[0] for p in self.parts), cols.pop())
+
+    def degree(self):
+        return max(p.degree() for p in self.parts)
+
+
+def vertcat(*parts) -> Expr:
+    return VCat(tuple(as_expr(p) for p in parts))
 
 
 @dataclass(eq=False)

@@ -487,6 +487,8 @@ class RobotModel(Model):
 
     def get_global_link_geometric_jacobian(self, link: str, q):
         """models.py:1199-1264: 6 x ndof (a list of them for a trajectory)."""
+        if isinstance(q, Expr):
+            return LinkFunction(self, link, "geometric_jacobian", q)
         Q = self._q_cols(q)
         _, J = self._kin(link).fk_jac(Q.T, want_pose=False)
         return J[0] if np.asarray(q).ndim == 1 else [J[i] for i in range(J.shape[0])]

@@ -118,3 +118,45 @@ def test_dense_qp_kernel_matches_port(hip_lib):
             assert np.abs(lam[i] - s["lam"]).max(initial=0.0) < 1e-6 and np.abs(nu[i] - s["nu"]).max(initial=0.0) < 1e-6
             assert (M @ r.x[i] + c >= -1e-9).all() and (np.abs(A @ r.x[i] + b) <= 1e-9).all()
         be.close()
+
+
+def test_differential_ik_is_a_quadratic_program():
+    """Builder classification of the velocity-IK problem (example/experiment1.py's type): quadratic cost, linear rows only."""
+    from examples.differential_ik import DifferentialIK
+
+    ik = DifferentialIK(build_only=True)
+    o = ik.optimization
+    assert isinstance(o, QuadraticCostLinearConstraints) and (o.nx, o.np, o.nk, o.na, o.nv) == (7, 7, 16, 0, 16)
+    assert list(o.decision_variables.keys()) == ["kuka/dq/x"]
+    kind, spec = lower(o)
+    assert kind == optas_amd._lib.OH_PROBLEM_QP and (spec.n, spec.m, spec.me) == (7, 16, 0)
+
+
+@pytest.mark.gpu
+def test_differential_ik_through_the_qp_family(hip_lib):
+    """The QP's data comes from forward kinematics / the geometric Jacobian at qc (evaluated on the GPU through oh_fk_jac, memoised per
+    parameter vector); the solution is checked against scipy SLSQP on the same data and against the task it encodes."""
+    from conftest import KUKA_KIN
+    from examples.differential_ik import DifferentialIK
+    from oracle.robot import OracleRobot
+
+    ik = DifferentialIK(height_band=(0.0, 2.0))
+    o = ik.optimization
+    kuka = OracleRobot(KUKA_KIN)
+    qc = np.deg2rad([0, 30, 0, -90, 0, 60, 0])
+    P, q, M, c = o.P(qc), o.q(qc), o.M(qc), o.c(qc)
+    J = kuka.get_global_link_geometric_jacobian("end_effector_ball", qc)
+    vg = np.array([0.1, 0, 0, 0, 0, 0])
+    assert np.abs(P - (np.eye(7) + 1000.0 * J.T @ J)).max() < 1e-9 and np.abs(q + 2000.0 * J.T @ vg).max() < 1e-9  # f = x^T P x + q^T x + const
+    assert np.abs(M[:7] - 0.1 * np.eye(7)).max() < 1e-15 and np.abs(M[14] - 0.1 * J[2]).max() < 1e-12
+    dq, qn = ik.step(qc)
+    assert ik.solver.did_solve()
+    s = minimize(lambda x: x @ P @ x + q @ x, np.zeros(7), jac=lambda x: 2 * P @ x + q, method="SLSQP",
+                 constraints=[{"type": "ineq", "fun": lambda x: M @ x + c, "jac": lambda x: M}], tol=1e-14, options={"maxiter": 300})
+    assert s.success and np.abs(dq - s.x).max() < 1e-6
+    assert np.abs(J @ dq - vg).max() < 2e-3 and (M @ dq + c >= -1e-9).all()  # the end-effector moves along +x at 0.1 m/s, nothing else moves
+    # an active height band: the step may not lift the end-effector above its current height
+    z = kuka.get_global_link_position("end_effector_ball", qc)[2]
+    ik2 = DifferentialIK(planar_direction=(0.0, 0.0), height_band=(0.0, z - 0.002))
+    dq2, _ = ik2.step(qc)
+    assert ik2.solver.did_solve() and abs(z + 0.1 * (J @ dq2)[2] - (z - 0.002)) < 1e-8  # pushed down exactly onto the band

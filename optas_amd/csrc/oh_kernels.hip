@@ -489,9 +489,17 @@ OH_DEV void couple_unit(const FigParams& P, const FigBuffers& D, const int slot,
   D.merit[slot][(size_t)t * Bp + b] = merit;
 }
 #ifndef OH_HOST_PORT
+// XCD-aware 1-D grid: workgroup w runs on XCD w % 8 (observed dispatch order), and knot t of an instance block re-reads what knot
+// t+1 of the same block reads (Z_{t+1}, q_{t+1}).  Consecutive workgroups of one XCD therefore walk the knots of ONE instance block:
+// w -> (chunk, r), XCD = r % 8 owns instance block chunk*8 + XCD, knot = r / 8, so the neighbour data is still in that XCD's 4 MB L2
+// (in knot-major order the reuse distance was the whole batch: 11 MB per XCD at B = 131 072).
 template <int N>
 __global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const int slot) {
-  couple_unit<N>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+  const int Tn = P.T - P.t0;
+  const int w = blockIdx.x;
+  const int chunk = w / (8 * Tn), r = w - chunk * 8 * Tn;
+  const int bx = chunk * 8 + (r & 7);
+  couple_unit<N>(P, D, slot, bx * blockDim.x + threadIdx.x, (r >> 3) + P.t0);
 }
 #endif
 
@@ -1236,7 +1244,8 @@ static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D
 }
 template <int N>
 static void launch_couple_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
-  hipLaunchKernelGGL(k_couple<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
+  const int nbx8 = (((D.B + 255) / 256) + 7) / 8 * 8;  // instance blocks, padded to whole groups of 8 XCDs (couple_unit drops b >= B)
+  hipLaunchKernelGGL(k_couple<N>, dim3(nbx8 * (P.T - P.t0)), dim3(256), 0, s, P, D, slot);
 }
 template <int N>
 static void launch_step_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {

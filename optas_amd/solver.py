@@ -299,13 +299,15 @@ class HIPSolver(Solver):
     def reset_initial_seed_batch(self, x0: Dict[str, np.ndarray]) -> None:
         """Each value has a leading batch axis: (B, m, n)."""
         B = len(next(iter(x0.values()))) if x0 else 1
-        self._x0_batch = np.stack([self.opt.decision_variables.dict2vec({k: v[b] for k, v in x0.items()}) for b in range(B)])
+        self._x0_batch = self.opt.decision_variables.dict2vec_batch(x0, B)
 
     def reset_parameters_batch(self, p: Dict[str, np.ndarray]) -> None:
         B = len(next(iter(p.values())))
-        self._p_batch = np.stack([self.opt.parameters.dict2vec({k: v[b] for k, v in p.items()}) for b in range(B)])
+        self._p_batch = self.opt.parameters.dict2vec_batch(p, B)
 
-    def solve_batch(self) -> List[Dict[str, np.ndarray]]:
+    def solve_batch(self, stacked: bool = False):
+        """B instances in one launch sequence.  Returns a list of B solution dicts shaped like ``solve()``'s, or, with
+        ``stacked=True``, one dict of arrays with a leading batch axis (no per-instance Python objects: the fast form for large B)."""
         assert self._p_batch is not None, "call reset_parameters_batch first"
         B = self._p_batch.shape[0]
         x0 = self._x0_batch if self._x0_batch is not None else np.zeros((B, self.opt.nx))
@@ -314,11 +316,23 @@ class HIPSolver(Solver):
         self._record(res)
         if self._error_on_fail and (not self.did_solve()):
             raise RuntimeError("Solver failed!")
-        out = []
-        for b in range(B):
-            sol = self.opt.decision_variables.vec2dict(res.x[b])
-            out.append(self._add_model_states(sol, self.opt.parameters.vec2dict(self._p_batch[b])))
-        return out
+        sol = self.opt.decision_variables.vec2dict_batch(res.x)
+        pd = self.opt.parameters.vec2dict_batch(self._p_batch)
+        # "{name}/{d}q" full states (solver.py:136-155), batched
+        for model in self.opt.models or []:
+            for d in model.time_derivs:
+                n_s, n_s_x = model.state_name(d), model.state_optimized_name(d)
+                if isinstance(model, RobotModel) and model.num_param_joints > 0:
+                    t = sol[n_s_x].shape[2]
+                    full = np.zeros((B, model.dim, t))
+                    full[:, model.optimized_joint_indexes, :] = sol[n_s_x]
+                    full[:, model.parameter_joint_indexes, :] = pd[model.state_parameter_name(d)]
+                    sol[n_s] = full
+                else:
+                    sol[n_s] = sol[n_s_x]
+        if stacked:
+            return sol
+        return [{k: v[b] for k, v in sol.items()} for b in range(B)]
 
     def solve_batch_arrays(self, x0: np.ndarray, p: np.ndarray) -> BatchResult:
         """Array-in/array-out fast path (no dict shuffling): x0 (B, nx), p (B, np) in vec() order."""

@@ -83,5 +83,33 @@ class SXContainer(collections.OrderedDict):
                 parts.append(a.T.reshape(-1))
         return np.concatenate(parts) if parts else np.zeros(0)
 
+    def dict2vec_batch(self, d: Dict[str, np.ndarray], B: int) -> np.ndarray:
+        """Batched dict2vec: every value carries a leading batch axis (B, m, n) (or (B, m) / (B,) for columns / scalars); missing
+        labels are zero-filled like dict2vec.  Returns (B, numel) rows in vec() order."""
+        out = np.zeros((B, self.numel()))
+        off = 0
+        for label, value in self.items():
+            m, n = value.shape
+            v = d.get(label)
+            if v is not None:
+                a = np.asarray(v, dtype=np.float64)
+                assert a.shape[0] == B, f"'{label}': leading axis must be the batch size {B}"
+                a = a.reshape(B, m, n) if a.size == B * m * n else None
+                assert a is not None, f"'{label}' expects per-instance shape {(m, n)}"
+                out[:, off : off + m * n] = a.transpose(0, 2, 1).reshape(B, m * n)
+            off += m * n
+        return out
+
+    def vec2dict_batch(self, vecs) -> Dict[str, np.ndarray]:
+        """(B, numel) -> {label: (B, m, n)}."""
+        vecs = np.asarray(vecs, dtype=np.float64)
+        B = vecs.shape[0]
+        out, off = {}, 0
+        for label, value in self.items():
+            m, n = value.shape
+            out[label] = vecs[:, off : off + m * n].reshape(B, n, m).transpose(0, 2, 1).copy()
+            off += m * n
+        return out
+
     def zero(self) -> dict:
         return {label: np.zeros(value.shape) for label, value in self.items()}

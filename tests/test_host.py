@@ -202,3 +202,22 @@ def test_manager_template_counts_and_times_solves():
     assert t.num_solves == 2 and t.get_target() == 2 and t.get_solver_duration() >= 0.0
     with pytest.raises(TypeError):
         Manager()  # abstract
+
+
+def test_batched_container_conversions_match_the_scalar_ones():
+    from optas_amd.expr import ParamRef
+    from optas_amd.sx_container import SXContainer
+
+    c = SXContainer()
+    c["a"] = ParamRef("a", 3, 4)
+    c["b"] = ParamRef("b", 2, 1)
+    c["s"] = ParamRef("s", 1, 1)
+    rng = np.random.default_rng(0)
+    B = 5
+    d = {"a": rng.normal(size=(B, 3, 4)), "b": rng.normal(size=(B, 2)), "s": rng.normal(size=B)}
+    V = c.dict2vec_batch(d, B)
+    for i in range(B):
+        assert np.array_equal(V[i], c.dict2vec({"a": d["a"][i], "b": d["b"][i], "s": d["s"][i]}))
+    back = c.vec2dict_batch(V)
+    assert np.array_equal(back["a"], d["a"]) and back["b"].shape == (B, 2, 1) and np.array_equal(back["s"].reshape(-1), d["s"])
+    assert np.array_equal(c.dict2vec_batch({"b": d["b"]}, B)[:, :12], np.zeros((B, 12)))  # missing labels are zero-filled

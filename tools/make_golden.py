@@ -122,11 +122,6 @@ def nlp_golden():
     np.savez(os.path.join(G, "nlp_golden.npz"), **out)
 
 
-if __name__ == "__main__":
-    spatialmath_golden()
-    fk_golden()
-    nlp_golden()
-    print("golden fixtures written to", G)
 
 
 def pm_golden():
@@ -261,3 +256,13 @@ def guard_golden():
         assert r.success and a["status"] == 0 and abs(r.fun - a["f"]) < 1e-8
         out[tag + "_qc"], out[tag + "_Q"], out[tag + "_f"], out[tag + "_lam"], out[tag + "_Q_slsqp"] = qc, a["Q"], a["f"], a["lam"], Qs
     np.savez(os.path.join(G, "guard_golden.npz"), **out)
+
+
+if __name__ == "__main__":
+    spatialmath_golden()
+    fk_golden()
+    nlp_golden()
+    pm_golden()
+    ik_golden()
+    guard_golden()  # ~1 minute: scipy SLSQP on the T = 50 guarded arm
+    print("golden fixtures written to", G)

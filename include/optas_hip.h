@@ -159,6 +159,10 @@ typedef struct oh_pointmass_desc {
   double safe;    /* obstacle radius + point-mass radius = 0.2 + 0.1 (:91,94,123) */
   int max_iter;   /* <= 0: 100 */
   double tol;     /* KKT tolerance (stationarity, feasibility, complementarity); <= 0: 1e-8 */
+  /* planner variant (example/point_mass_planner.py:17-55), all 0 for the MPC tick: */
+  int track_final_only;   /* 1: sumsqr(goal - y) on the last knot only (:43) */
+  double w_vel;           /* weight of sum ||dy_t||^2 (:45-47), 0.01 / T in the script */
+  int fix_final_velocity; /* 1: equality row dy_{T-1} = 0 (:34-35) */
 } oh_pointmass_desc;
 
 /*

@@ -97,6 +97,9 @@ class oh_pointmass_desc(C.Structure):
         ("safe", C.c_double),
         ("max_iter", C.c_int),
         ("tol", C.c_double),
+        ("track_final_only", C.c_int),
+        ("w_vel", C.c_double),
+        ("fix_final_velocity", C.c_int),
     ]
 
 

@@ -75,12 +75,14 @@ class _SolveMixin:
 class PointMassBackend(_SolveMixin):
     """OH_PROBLEM_POINT_MASS_MPC handle (example/point_mass_mpc.py Controller)."""
 
-    def __init__(self, T=20, dt=0.05, w_acc=0.0025 / 20, ylim=1.5, vlim=1.0, safe=0.3, max_iter=100, tol=1e-8):
+    def __init__(self, T=20, dt=0.05, w_acc=0.0025 / 20, ylim=1.5, vlim=1.0, safe=0.3, max_iter=100, tol=1e-8, track_final_only=False, w_vel=0.0,
+                 fix_final_velocity=False):
         lib = _lib.load()
         self.T = int(T)
         self.nx, self.np_ = 4 * self.T, 4 + 4 * self.T
         desc = _lib.oh_pointmass_desc(T=self.T, dt=float(dt), w_acc=float(w_acc), ylim=float(ylim), vlim=float(vlim), safe=float(safe),
-                                      max_iter=int(max_iter), tol=float(tol))
+                                      max_iter=int(max_iter), tol=float(tol), track_final_only=1 if track_final_only else 0, w_vel=float(w_vel),
+                                      fix_final_velocity=1 if fix_final_velocity else 0)
         self._h = C.c_void_p()
         _lib.check(lib.oh_create_pointmass(C.byref(desc), C.byref(self._h)), "oh_create_pointmass")
 

@@ -188,7 +188,8 @@ extern "C" int oh_create_pointmass(const oh_pointmass_desc* desc, oh_handle** ou
   if (!desc || !out) return fail(OH_ERR_INVALID, "oh_create_pointmass: null argument");
   *out = nullptr;
   if (desc->T < 2 || desc->T > OH_MAX_T) return fail(OH_ERR_INVALID, "oh_create_pointmass: T must be in [2, OH_MAX_T]");
-  if (!(desc->dt > 0.0) || !(desc->w_acc > 0.0) || !(desc->ylim > 0.0) || !(desc->vlim > 0.0) || !(desc->safe >= 0.0))
+  if (!(desc->dt > 0.0) || !(desc->w_acc > 0.0) || !(desc->ylim > 0.0) || !(desc->vlim > 0.0) || !(desc->safe >= 0.0) || !(desc->w_vel >= 0.0) ||
+      (desc->fix_final_velocity && desc->T < 3))
     return fail(OH_ERR_INVALID, "oh_create_pointmass: dt, w_acc, ylim, vlim must be positive and safe non-negative");
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1)
@@ -370,7 +371,8 @@ static int pm_prepare(oh_handle* h, int B) {
     h->PmD.da = take(2 * (size_t)(T - 1));
   }
   h->PmD.B = B;
-  h->PmP = PmParams{T, h->pm.dt, h->pm.w_acc, h->pm.ylim, h->pm.vlim, h->pm.safe * h->pm.safe, h->pm.tol, h->pm.max_iter};
+  h->PmP = PmParams{T, h->pm.dt, h->pm.w_acc, h->pm.ylim, h->pm.vlim, h->pm.safe * h->pm.safe, h->pm.tol, h->pm.max_iter,
+                    h->pm.track_final_only ? 1 : 0, h->pm.w_vel, h->pm.fix_final_velocity ? 1 : 0};
   return OH_OK;
 }
 

@@ -115,6 +115,9 @@ struct PmParams {
   int T;
   double dt, w_acc, ylim, vlim, safe_sq, tol;
   int max_iter;
+  int final_only;  // 1: tracking cost on the last knot only (point_mass_planner.py:43), 0: on every knot (point_mass_mpc.py:131)
+  double w_vel;    // weight of sum ||dy_t||^2 (point_mass_planner.py:45-47; 0 in the MPC script)
+  int fix_vf;      // 1: terminal row dy_{T-1} = 0 (point_mass_planner.py:34-35)
 };
 struct PmBuffers {
   int B, Bp;

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
     double x[4] = {pb[0], pb[1], pb[2], pb[3]};
     for (int j = 0; j < 4; ++j) X_[PIDX(j)] = x[j];
     for (int t = 0; t < T - 1; ++t) {
-      const double v1[2] = {x0[(size_t)b * nx + 2 * T + 2 * (t + 1)], x0[(size_t)b * nx + 2 * T + 2 * (t + 1) + 1]};
+      double v1[2] = {x0[(size_t)b * nx + 2 * T + 2 * (t + 1)], x0[(size_t)b * nx + 2 * T + 2 * (t + 1) + 1]};
+      if (P.fix_vf && t == T - 2) v1[0] = v1[1] = 0.0;  // terminal row dy_{T-1} = 0 (point_mass_planner.py:34-35)
       const double a0 = (v1[0] - vprev[0]) / dt, a1 = (v1[1] - vprev[1]) / dt;
       A_[PIDX(2 * t)] = a0; A_[PIDX(2 * t + 1)] = a1;
       x[0] += dt * x[2]; x[1] += dt * x[3]; x[2] += dt * a0; x[3] += dt * a1;
@@ -89,8 +90,10 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
       for (int j = 0; j < 4; ++j) x[j] = X_[PIDX(4 * t + j)];
       pm_cons(P, x, obs[2 * t], obs[2 * t + 1], c, jx, jy);
       for (int i = 0; i < 9; ++i) { s[i] = S_[PIDX(9 * t + i)]; lam[i] = L_[PIDX(9 * t + i)]; }
-      const double gx[4] = {-2.0 * (goal[2 * t] - x[0]), -2.0 * (goal[2 * t + 1] - x[1]), 0.0, 0.0};
-      fval += (goal[2 * t] - x[0]) * (goal[2 * t] - x[0]) + (goal[2 * t + 1] - x[1]) * (goal[2 * t + 1] - x[1]);
+      const double wt = (P.final_only && t < T - 1) ? 0.0 : 1.0;  // tracking on every knot (MPC) or on the last one only (planner)
+      const double gx[4] = {-2.0 * wt * (goal[2 * t] - x[0]), -2.0 * wt * (goal[2 * t + 1] - x[1]), 2.0 * P.w_vel * x[2], 2.0 * P.w_vel * x[3]};
+      fval += wt * ((goal[2 * t] - x[0]) * (goal[2 * t] - x[0]) + (goal[2 * t + 1] - x[1]) * (goal[2 * t + 1] - x[1])) +
+              P.w_vel * (x[2] * x[2] + x[3] * x[3]);
       double rc[9], sig[9], wq[9], jl[4], jq[4];
       for (int i = 0; i < 9; ++i) {
         rc[i] = c[i] - s[i];
@@ -105,11 +108,11 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
       // Q_t = diag(2,2,0,0) + J^T Sig J  (stage 0 is fixed: its Q, q are never used)
       double Q[16];
       for (int j = 0; j < 16; ++j) Q[j] = 0.0;
-      Q[0] = 2.0 + sig[0] + sig[1] + sig[8] * jx * jx;
-      Q[5] = 2.0 + sig[2] + sig[3] + sig[8] * jy * jy;
+      Q[0] = 2.0 * wt + sig[0] + sig[1] + sig[8] * jx * jx;
+      Q[5] = 2.0 * wt + sig[2] + sig[3] + sig[8] * jy * jy;
       Q[1] = Q[4] = sig[8] * jx * jy;
-      Q[10] = sig[4] + sig[5];
-      Q[15] = sig[6] + sig[7];
+      Q[10] = 2.0 * P.w_vel + sig[4] + sig[5];
+      Q[15] = 2.0 * P.w_vel + sig[6] + sig[7];
       if (t == T - 1) {
         for (int j = 0; j < 16; ++j) Pm[j] = Q[j];
         for (int j = 0; j < 4; ++j) { pv[j] = q[j]; padj[j] = lx[j]; }
@@ -119,7 +122,9 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
       const double a0 = A_[PIDX(2 * t)], a1 = A_[PIDX(2 * t + 1)];
       fval += w * (a0 * a0 + a1 * a1);
       // control gradient of the Lagrangian: 2 w a + B^T padj, B^T z = dt (z2, z3)
-      stat = fmax(stat, fmax(fabs(2.0 * w * a0 + dt * padj[2]), fabs(2.0 * w * a1 + dt * padj[3])));
+      const bool pinned = P.fix_vf && t == T - 2;  // a_{T-2} = -v_{T-2} / dt is a function of the state, not a free control
+      const double gu0 = 2.0 * w * a0 + dt * padj[2], gu1 = 2.0 * w * a1 + dt * padj[3];
+      if (!pinned) stat = fmax(stat, fmax(fabs(gu0), fabs(gu1)));
       // Quu = R + B^T P B = 2w I + dt^2 P[2:4,2:4] ; Qux = B^T P A = dt (P[2:4,:] A) ; A = [[I, dt I],[0, I]]
       double PA[16];  // P A : column j<2 same as P, column j>=2: P[:,j] + dt P[:,j-2]
       for (int r = 0; r < 4; ++r) {
@@ -134,6 +139,38 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
       // 2x2 Cholesky solve
       const double l00 = sqrt(q00), l10 = q01 / l00, l11 = sqrt(q11 - l10 * l10);
       double Kt[8], kt[2];
+      if (pinned) {
+        // fixed feedback K = [0 0 -1/dt 0; 0 0 0 -1/dt], k = 0:  P = Q + A^T P A + Qux^T K + K^T Qux + K^T Quu K,  p = q + A^T p + K^T qu,
+        // and the control gradient flows into the state adjoint: padj = lx + A^T padj + K^T gu
+        for (int j = 0; j < 8; ++j) Kt[j] = 0.0;
+        Kt[2] = Kt[4 + 3] = -1.0 / dt;
+        kt[0] = kt[1] = 0.0;
+        for (int j = 0; j < 8; ++j) K_[PIDX(8 * t + j)] = Kt[j];
+        k_[PIDX(2 * t)] = 0.0; k_[PIDX(2 * t + 1)] = 0.0;
+        const double kf = -1.0 / dt;
+        double Pn[16], pn[4], pa[4];
+        for (int r = 0; r < 4; ++r)
+          for (int cc = 0; cc < 4; ++cc) {
+            double v = PA[4 * r + cc];
+            if (r >= 2) v += dt * PA[4 * (r - 2) + cc];
+            v += Qux[r] * Kt[cc] + Qux[4 + r] * Kt[4 + cc];          // Qux^T K
+            v += Kt[r] * Qux[cc] + Kt[4 + r] * Qux[4 + cc];          // K^T Qux
+            Pn[4 * r + cc] = Q[4 * r + cc] + v;
+          }
+        Pn[10] += kf * kf * q00; Pn[11] += kf * kf * q01; Pn[14] += kf * kf * q01; Pn[15] += kf * kf * q11;  // K^T Quu K
+        for (int r = 0; r < 4; ++r) {
+          double v = pv[r], va = padj[r];
+          if (r >= 2) { v += dt * pv[r - 2]; va += dt * padj[r - 2]; }
+          pn[r] = q[r] + v;
+          pa[r] = lx[r] + va;
+        }
+        pn[2] += kf * qu0; pn[3] += kf * qu1;
+        pa[2] += kf * gu0; pa[3] += kf * gu1;
+        for (int r = 0; r < 4; ++r)
+          for (int cc = 0; cc < 4; ++cc) Pm[4 * r + cc] = 0.5 * (Pn[4 * r + cc] + Pn[4 * cc + r]);
+        for (int j = 0; j < 4; ++j) { pv[j] = pn[j]; padj[j] = pa[j]; }
+        continue;
+      }
       {
         for (int j = 0; j < 4; ++j) {
           const double y0 = Qux[j] / l00, y1 = (Qux[4 + j] - l10 * y0) / l11;

@@ -18,6 +18,7 @@ class Expr:
     """Base node.  ``shape`` is (rows, cols) like a CasADi matrix."""
 
     shape: Tuple[int, int] = (1, 1)
+    __array_ufunc__ = None  # numpy arrays on the left of an operator defer to __rsub__ / __radd__ / __rmul__ / __rmatmul__
 
     # -- the handful of operators the example scripts use ------------------------------------------------
     def __sub__(self, other):

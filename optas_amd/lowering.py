@@ -221,6 +221,95 @@ class PointMassSpec:
     names: tuple  # (curr, dcurr, goal, obs) parameter labels
     y_name: str
     dy_name: str
+    planner: Optional[dict] = None  # point_mass_planner.py variant: {"w_vel", "obstacle" (2,), "init", "goal"}
+
+
+def match_point_mass_planner(opt: Optimization) -> PointMassSpec:
+    """example/point_mass_planner.py:17-55 (Planner): same plant and rows as the MPC tick, but the tracking cost sits on the last knot
+    only, the velocity is penalised, the initial velocity is fixed to zero, the final velocity is an equality row and the obstacle
+    is a constant."""
+
+    def no(msg):
+        raise LoweringError(f"point-mass planner lowering: {msg}")
+
+    tasks = [m for m in (opt.models or []) if isinstance(m, TaskModel)]
+    if len(opt.models or []) != 1 or len(tasks) != 1:
+        no("expected exactly one TaskModel")
+    tm = tasks[0]
+    if tm.dim != 2 or list(tm.time_derivs) != [0, 1]:
+        no("task model must be planar (dim 2) with time_derivs=[0, 1]")
+    y_name, dy_name = tm.state_optimized_name(0), tm.state_optimized_name(1)
+    if list(opt.decision_variables.keys()) != [y_name, dy_name]:
+        no("decision variables must be exactly the position and velocity trajectories")
+    Y, dY = opt.decision_variables[y_name], opt.decision_variables[dy_name]
+    T = Y.n
+    if dY.n != T or opt.nh:
+        no("needs derivs_align=True and no nonlinear equalities")
+    lim = {}
+    for label, diff in opt.lin_ineq_constraints.items():
+        hi, lo = (diff.a, diff.b) if isinstance(diff, Sub) else (None, None)
+        if isinstance(hi, StateRef) and hi.t is None and isinstance(lo, Const) and lo.value.size == 1:
+            lim[(hi.time_deriv, "l")] = float(lo.value.reshape(-1)[0])
+        elif isinstance(lo, StateRef) and lo.t is None and isinstance(hi, Const) and hi.value.size == 1:
+            lim[(lo.time_deriv, "r")] = float(hi.value.reshape(-1)[0])
+        else:
+            no(f"linear inequality '{label}' is not a scalar box limit on a whole trajectory")
+    if set(lim) != {(0, "l"), (0, "r"), (1, "l"), (1, "r")} or lim[(0, "l")] != -lim[(0, "r")] or lim[(1, "l")] != -lim[(1, "r")]:
+        no("need symmetric enforce_model_limits for time_deriv 0 and 1")
+    init = dt = None
+    seen = set()
+    for label, diff in opt.lin_eq_constraints.items():
+        rhs, lhs = diff.a, diff.b
+        if isinstance(lhs, StateRef) and lhs.t == 0 and lhs.time_deriv == 0 and isinstance(rhs, ParamRef):
+            init = rhs
+        elif isinstance(lhs, StateRef) and lhs.t == 0 and lhs.time_deriv == 1 and _is_zero_const(rhs):
+            seen.add("dy0")
+        elif isinstance(lhs, StateRef) and lhs.t == T - 1 and lhs.time_deriv == 1 and _is_zero_const(rhs):
+            seen.add("dyT")
+        elif isinstance(lhs, IntegrationResidual) and _is_zero_const(rhs) and lhs.xd.time_deriv == 1 and np.all(lhs.dt == lhs.dt[0]):
+            dt = float(lhs.dt[0])
+        else:
+            no(f"linear equality '{label}' not recognised")
+    if init is None or dt is None or seen != {"dy0", "dyT"}:
+        no("need fix_configuration(init), zero initial and final velocity, integrate_model_states")
+    if len(opt.ineq_constraints) != T:
+        no(f"expected {T} obstacle rows")
+    obstacle = safe_sq = None
+    for i, (label, diff) in enumerate(opt.ineq_constraints.items()):
+        ok = (isinstance(diff, Sub) and isinstance(diff.a, SumSqr) and isinstance(diff.b, Const) and diff.b.value.size == 1
+              and isinstance(diff.a.a, Sub) and isinstance(diff.a.a.a, Const) and diff.a.a.a.value.shape == (2, 1)
+              and isinstance(diff.a.a.b, StateRef) and diff.a.a.b.t == i and diff.a.a.b.time_deriv == 0)
+        if not ok:
+            no(f"inequality '{label}' is not ||obstacle - y_{i}||^2 >= const with a constant obstacle")
+        o_i, r_i = diff.a.a.a.value[:, 0], float(diff.b.value.reshape(-1)[0])
+        if obstacle is None:
+            obstacle, safe_sq = o_i, r_i
+        elif not np.array_equal(o_i, obstacle) or r_i != safe_sq:
+            no("all obstacle rows must use the same obstacle and radius")
+    goal = w_vel = w_acc = None
+    for label, term in opt.cost_terms.items():
+        w, e = _unscale(term)
+        if not isinstance(e, SumSqr):
+            no(f"cost '{label}' is not a weighted sumsqr")
+        inner = e.a
+        if (isinstance(inner, Sub) and isinstance(inner.a, ParamRef) and isinstance(inner.b, StateRef) and inner.b.t == T - 1
+                and inner.b.time_deriv == 0 and w == 1.0):
+            goal = inner.a
+        elif inner is dY:
+            w_vel = w
+        else:
+            s2, d = _unscale(inner)
+            good = (isinstance(d, Sub) and isinstance(d.a, StateCols) and isinstance(d.b, StateCols) and d.a.state is dY and d.b.state is dY
+                    and (d.a.lo, d.a.hi, d.b.lo, d.b.hi) == (1, T, 0, T - 1) and abs(s2 * dt - 1.0) < 1e-12)
+            if not good:
+                no(f"cost '{label}' not recognised")
+            w_acc = w
+    if goal is None or w_vel is None or w_acc is None:
+        no("need the final-state, velocity and acceleration cost terms")
+    if list(opt.parameters.keys()) != [init.name, goal.name] or (init.shape, goal.shape) != ((2, 1), (2, 1)):
+        no("parameters must be init(2), goal(2) in this order")
+    return PointMassSpec(T, dt, w_acc, lim[(0, "r")], lim[(1, "r")], float(np.sqrt(safe_sq)), (init.name, goal.name), y_name, dy_name,
+                         planner={"w_vel": float(w_vel), "obstacle": np.asarray(obstacle, dtype=np.float64), "init": init.name, "goal": goal.name})
 
 
 def match_point_mass(opt: Optimization) -> PointMassSpec:
@@ -579,7 +668,8 @@ OH_KIND_MULTI_ARM = 101  # host-side composition of OH_PROBLEM_FIGURE_EIGHT hand
 def lower(opt: Optimization):
     """Return (kind, spec).  Raises LoweringError if no kernel family matches."""
     errors = []
-    for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass), (OH_KIND_MULTI_ARM, match_multi_arm),
+    for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass_planner),
+                     (OH_KIND_MULTI_ARM, match_multi_arm),
                      (_lib.OH_PROBLEM_IK, match_ik), (_lib.OH_PROBLEM_QP, match_qp)):
         try:
             return kind, fn(opt)

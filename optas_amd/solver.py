@@ -168,6 +168,23 @@ class _LeadAdapter:
         self.be.close()
 
 
+class _PlannerAdapter:
+    """example/point_mass_planner.py on the point-mass kernel family: p = [init; goal] becomes the family's row
+    [curr = init; dcurr = 0; goal repeated on every knot (only the last one carries weight); the constant obstacle on every knot]."""
+
+    def __init__(self, spec, backend):
+        self.spec, self.be = spec, backend
+
+    def solve(self, x0: np.ndarray, p: np.ndarray) -> BatchResult:
+        p = np.asarray(p, dtype=np.float64).reshape(-1, 4)
+        B, T = p.shape[0], self.spec.T
+        rows = np.concatenate([p[:, :2], np.zeros((B, 2)), np.tile(p[:, 2:4], (1, T)), np.tile(self.spec.planner["obstacle"], (B, T))], axis=1)
+        return self.be.solve(x0, np.ascontiguousarray(rows))
+
+    def close(self) -> None:
+        self.be.close()
+
+
 class _QpAdapter:
     """Dense QP family: reads P, q, M, c, A, b off the Optimization's numeric members for every instance (they may all depend on the
     parameters) and hands [P | q | M | c | A | b] rows to the kernel.  The cost's constant term f(0, p) is added back to f."""
@@ -245,9 +262,13 @@ class HIPSolver(Solver):
                 self._backend = _LeadAdapter(self.opt, spec, self._backend)
         elif isinstance(spec, PointMassSpec):
             o.pop("hessian", None)
+            pl = spec.planner
             self._backend = PointMassBackend(
-                spec.T, spec.dt, spec.w_acc, spec.ylim, spec.vlim, spec.safe, max_iter=int(o.pop("max_iter", 100)), tol=float(o.pop("tol", 1e-8))
+                spec.T, spec.dt, spec.w_acc, spec.ylim, spec.vlim, spec.safe, max_iter=int(o.pop("max_iter", 200 if pl else 100)),
+                tol=float(o.pop("tol", 1e-8)), track_final_only=pl is not None, w_vel=pl["w_vel"] if pl else 0.0, fix_final_velocity=pl is not None,
             )
+            if pl is not None:
+                self._backend = _PlannerAdapter(spec, self._backend)
         elif isinstance(spec, MultiArmSpec):
             o.pop("hessian", None)
             self._backend = MultiArmBackend(spec, self.opt, max_iter=int(o.pop("max_iter", 200)), tol=float(o.pop("tol", 1e-6)), hessian=hessian)

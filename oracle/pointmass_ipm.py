@@ -16,8 +16,12 @@ Newton step) -- the linearised row is an inner approximation, so the iteration s
 import numpy as np
 
 
-def solve_pointmass_ipm(T, dt, w, ylim, vlim, safe_sq, curr, dcurr, goal, obs, V0=None, tol=1e-8, max_iter=100, verbose=False):
-    """goal, obs: (2, T).  V0: optional (2, T) velocity seed.  Returns dict(Y, V, f, iters, kkt=(stat, feas, compl), status)."""
+def solve_pointmass_ipm(T, dt, w, ylim, vlim, safe_sq, curr, dcurr, goal, obs, V0=None, tol=1e-8, max_iter=100, verbose=False,
+                        track_final_only=False, w_vel=0.0, fix_final_velocity=False):
+    """goal, obs: (2, T).  V0: optional (2, T) velocity seed.  Returns dict(Y, V, f, iters, kkt=(stat, feas, compl), status).
+    The three keyword options turn the MPC tick (point_mass_mpc.py) into the planner of example/point_mass_planner.py:17-55: tracking
+    cost on the last knot only, w_vel * sum ||dy_t||^2 over all knots, and the terminal row dy_{T-1} = 0, which pins the last control to
+    a_{T-2} = -v_{T-2} / dt (a fixed feedback in the Riccati recursion instead of an optimised one)."""
     nI = 9  # rows per stage: 4 y-box, 4 v-box, 1 obstacle
     A = np.eye(4)
     A[0, 2] = A[1, 3] = dt
@@ -26,7 +30,14 @@ def solve_pointmass_ipm(T, dt, w, ylim, vlim, safe_sq, curr, dcurr, goal, obs, V
     R = 2.0 * w * np.eye(2)
     V = np.zeros((2, T)) if V0 is None else np.array(V0, dtype=float)
     V[:, 0] = dcurr
+    if fix_final_velocity:
+        V[:, T - 1] = 0.0
     a = (V[:, 1:] - V[:, :-1]) / dt  # (2, T-1)
+    wt = np.ones(T)
+    if track_final_only:
+        wt[: T - 1] = 0.0
+    Kfix = np.zeros((2, 4))
+    Kfix[0, 2] = Kfix[1, 3] = -1.0 / dt
 
     def rollout(a):
         X = np.zeros((4, T))
@@ -66,18 +77,22 @@ def solve_pointmass_ipm(T, dt, w, ylim, vlim, safe_sq, curr, dcurr, goal, obs, V
         rc = c - s
         # cost gradient wrt x_t: -2 (goal - y)
         gx = np.zeros((4, T))
-        gx[:2] = -2.0 * (goal - X[:2])
+        gx[:2] = -2.0 * wt[None] * (goal - X[:2])
+        gx[2:] = 2.0 * w_vel * X[2:]
         # ---- KKT residuals (adjoint pass for the control gradient of the Lagrangian)
         lx = gx - np.einsum("itk,it->kt", J, lam)  # d/dx_t of f - lam^T c
         padj = lx[:, T - 1].copy()
         stat = 0.0
         for t in range(T - 2, -1, -1):
             gu = 2.0 * w * a[:, t] + B.T @ padj
-            stat = max(stat, float(np.max(np.abs(gu))))
-            padj = lx[:, t] + A.T @ padj
+            if fix_final_velocity and t == T - 2:
+                padj = lx[:, t] + A.T @ padj + Kfix.T @ gu  # the last control is a function of x_{T-2}: its gradient flows into the state
+            else:
+                stat = max(stat, float(np.max(np.abs(gu))))
+                padj = lx[:, t] + A.T @ padj
         feas = float(np.max(np.abs(rc[:, 1:])))
         compl = float(np.max(lam[:, 1:] * s[:, 1:]))
-        fval = float(np.sum((goal - X[:2]) ** 2) + w * np.sum(a * a))
+        fval = float(np.sum(wt[None] * (goal - X[:2]) ** 2) + w_vel * np.sum(X[2:] ** 2) + w * np.sum(a * a))
         if verbose:
             print(f"  it {it:3d} f={fval:.10f} stat={stat:.2e} feas={feas:.2e} compl={compl:.2e} mu={mu:.2e}")
         if stat <= tol and feas <= tol and compl <= tol:
@@ -90,7 +105,8 @@ def solve_pointmass_ipm(T, dt, w, ylim, vlim, safe_sq, curr, dcurr, goal, obs, V
         Q = np.zeros((T, 4, 4))
         q = np.zeros((T, 4))
         for t in range(1, T):
-            Q[t, 0, 0] = Q[t, 1, 1] = 2.0
+            Q[t, 0, 0] = Q[t, 1, 1] = 2.0 * wt[t]
+            Q[t, 2, 2] = Q[t, 3, 3] = 2.0 * w_vel
             Q[t] += np.einsum("ik,i,il->kl", J[:, t], sig[:, t], J[:, t])
             q[t] = gx[:, t] - J[:, t].T @ (mu / s[:, t] - sig[:, t] * rc[:, t])
         P = Q[T - 1].copy()
@@ -101,6 +117,12 @@ def solve_pointmass_ipm(T, dt, w, ylim, vlim, safe_sq, curr, dcurr, goal, obs, V
             Quu = R + B.T @ P @ B
             Qux = B.T @ P @ A
             qu = 2.0 * w * a[:, t] + B.T @ p
+            if fix_final_velocity and t == T - 2:
+                K[t], k[t] = Kfix, np.zeros(2)
+                Pn = Q[t] + A.T @ P @ A + Qux.T @ Kfix + Kfix.T @ Qux + Kfix.T @ Quu @ Kfix
+                p = q[t] + A.T @ p + Kfix.T @ qu
+                P = 0.5 * (Pn + Pn.T)
+                continue
             L = np.linalg.cholesky(Quu)
             K[t] = -np.linalg.solve(L.T, np.linalg.solve(L, Qux))
             k[t] = -np.linalg.solve(L.T, np.linalg.solve(L, qu))

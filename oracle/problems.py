@@ -662,3 +662,56 @@ class GuardedFigureEightNLP(FigureEightNLP):
         for t in range(self.T):
             M[t * rows : (t + 1) * rows, self.n * t : self.n * (t + 1)] = d[t]
         return M
+
+
+class PointMassPlannerNLP(PointMassMPCNLP):
+    """example/point_mass_planner.py Planner (:8-55): the point mass of config 3 planned once over T = 45 knots (dt = 0.1).
+
+    p = [init(2); goal(2)];  k as PointMassMPCNLP;
+    a = [-(y_t + dt dy_t - y_{t+1}); init - y_0; 0 - dy_0; 0 - dy_{T-1}]                         (:28-35)
+    g = ||obs - y_t||^2 - 0.3^2 with the constant obstacle obs = (0, 0)                           (:37-42)
+    f = ||goal - y_{T-1}||^2 + (0.01/T) sum ||dY||^2 + (0.005/T) sum ||(dy_{t+1}-dy_t)/dt||^2     (:43-51)
+    """
+
+    def __init__(self, T=45, dt=0.1, ylim=1.5, dylim=1.0, safe=0.3, w_vel=0.01, w_acc=0.005, obstacle=(0.0, 0.0)):
+        super().__init__(T=T, dt=dt, ylim=ylim, dylim=dylim, safe=safe, w_acc=w_acc)
+        self.w_vel = w_vel / float(T)
+        self.obstacle = np.asarray(obstacle, dtype=float)
+        self.np_ = 4
+        self.na = 2 * (T - 1) + 6
+        A = np.zeros((self.na, self.nx))
+        A[: 2 * (T - 1) + 4] = self._A
+        r = 2 * (T - 1) + 4
+        A[r : r + 2, 2 * T + 2 * (T - 1) : 2 * T + 2 * T] = -np.eye(2)  # 0 - dy_{T-1}
+        self._A = A
+
+    def f(self, x, p):
+        Y, dY = self.split(x)
+        dd = (dY[:, 1:] - dY[:, :-1]) / self.dt
+        return float(np.sum((p[2:4] - Y[:, -1]) ** 2) + self.w_vel * np.sum(dY**2) + self.w * np.sum(dd**2))
+
+    def df(self, x, p):
+        Y, dY = self.split(x)
+        gY = np.zeros_like(Y)
+        gY[:, -1] = -2.0 * (p[2:4] - Y[:, -1])
+        dd = (dY[:, 1:] - dY[:, :-1]) / self.dt
+        gdY = 2.0 * self.w_vel * dY
+        gdY[:, 1:] += 2.0 * self.w * dd / self.dt
+        gdY[:, :-1] -= 2.0 * self.w * dd / self.dt
+        return np.concatenate([gY.T.reshape(-1), gdY.T.reshape(-1)])
+
+    def a(self, x, p):
+        b = np.zeros(self.na)
+        b[2 * (self.T - 1) : 2 * (self.T - 1) + 2] = p[0:2]
+        return self._A @ x + b
+
+    def g(self, x, p):
+        Y, _ = self.split(x)
+        return np.sum((self.obstacle[:, None] - Y) ** 2, axis=0) - self.safe_sq
+
+    def dg(self, x, p):
+        Y, _ = self.split(x)
+        J = np.zeros((self.ng, self.nx))
+        for t in range(self.T):
+            J[t, 2 * t : 2 * t + 2] = -2.0 * (self.obstacle - Y[:, t])
+        return J

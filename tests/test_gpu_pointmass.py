@@ -133,3 +133,35 @@ def test_device_resident_receding_horizon_matches_host_loop(hip_lib):
         assert np.abs(st - states[k + 1, 2]).max() < 1e-7
     # the plants stay outside the obstacle and inside the limits all along
     assert (np.abs(states[:, :, :2]) <= 1.5 + 1e-9).all() and (np.abs(states[:, :, 2:]) <= 1.0 + 1e-9).all()
+
+
+def test_planner_variant_through_hipsolver(hip_lib):
+    """example/point_mass_planner.py through HIPSolver: same state machine as the numpy port (planner options of the point-mass
+    family), reference-form KKT on the literal layout; the script's own mirror-symmetric instance with a lateral seed."""
+    from examples.point_mass_planner import Planner
+    from oracle.problems import PointMassPlannerNLP
+
+    pl = Planner(solver_options={"tol": 1e-9})
+    nlp = PointMassPlannerNLP()
+    T = pl.T
+    for init, goal in (([-1.2, -0.4], [1.0, 0.7]), ([0.9, -1.1], [-1.0, 1.0])):
+        plan_y, plan_dy, sol = pl.plan(init, goal)
+        s = pl.solver
+        assert s.did_solve()
+        r = solve_pointmass_ipm(T, 0.1, nlp.w, 1.5, 1.0, nlp.safe_sq, np.array(init), np.zeros(2), np.tile(np.array(goal)[:, None], (1, T)), np.zeros((2, T)),
+                                tol=1e-9, max_iter=200, track_final_only=True, w_vel=nlp.w_vel, fix_final_velocity=True)
+        assert r["status"] == 0 and s.number_of_iterations() == r["iters"] and abs(s.stats()["f"][0] - r["f"]) < 1e-12
+        assert np.abs(np.asarray(sol["point_mass/y"]) - r["Y"]).max() < 1e-9
+        x = s.opt.decision_variables.dict2vec(sol)
+        p = np.array(init + goal)
+        assert abs(nlp.f(x, p) - s.stats()["f"][0]) < 1e-12 and np.abs(nlp.a(x, p)).max() < 1e-12
+        k = kkt_reference_form(nlp, x, p, active_tol=1e-3)
+        assert k["stationarity"] < 1e-6 and k["feasibility"] < 1e-9
+        assert np.allclose(plan_y(0.0), init) and np.abs(plan_dy(pl.duration)).max() < 1e-12 and np.abs(plan_y(pl.duration) - goal).max() < 0.02
+    # the script's instance: start, obstacle and goal collinear; a lateral velocity seed picks the side
+    seed = np.zeros((2, T))
+    seed[0, 1:-1] = 0.05
+    plan_y, _, sol = pl.plan([-1.0, -1.0], [1.0, 1.0], seed)
+    assert pl.solver.did_solve() and pl.solver.stats()["f"][0] < 0.01
+    Y = np.asarray(sol["point_mass/y"])
+    assert (np.sum(Y * Y, axis=0) >= 0.09 - 1e-8).all() and np.abs(Y[:, -1] - 1.0).max() < 0.02

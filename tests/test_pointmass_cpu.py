@@ -118,3 +118,41 @@ def test_diagnostics_match_oracle_rows():
     assert np.abs(cat(lin_eq) - nlp.a(x, p)).max() < 1e-14 and eq == []
     assert [v.label for v in ineq] == [f"obs_avoid_{i}" for i in range(20)] and ineq[0].ctype == "ineq"
     assert np.array_equal(lin_ineq[0].pattern, lin_ineq[0].diff >= 0.0)
+
+
+def test_planner_variant_builder_lowering_and_port():
+    """example/point_mass_planner.py: builder counts, the mirrored rows against the literal restatement, lowering to the point-mass
+    family's planner options, and the numpy port against scipy SLSQP (reference wiring) and the reference-form KKT."""
+    import os
+    import sys
+
+    from scipy.optimize import minimize
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from examples.point_mass_planner import Planner
+    from optas_amd import _lib
+    from optas_amd.lowering import lower
+    from oracle.pointmass_ipm import solve_pointmass_ipm
+    from oracle.problems import PointMassPlannerNLP
+    from oracle.solvers import kkt_reference_form, scipy_minimize
+
+    o = Planner(build_only=True).optimization
+    nlp = PointMassPlannerNLP()
+    assert (o.nx, o.np, o.nk, o.na, o.ng, o.nh, o.nv) == (nlp.nx, nlp.np_, nlp.nk, nlp.na, nlp.ng, 0, nlp.nv) == (180, 4, 360, 94, 45, 0, 593)
+    rng = np.random.default_rng(3)
+    x, p = rng.normal(size=180), np.array([-1.0, -0.8, 1.0, 0.9])
+    assert abs(o.f(x, p) - nlp.f(x, p)) < 1e-12 and np.abs(o.v(x, p) - nlp.v(x, p)).max() < 1e-13
+    kind, spec = lower(o)
+    assert kind == _lib.OH_PROBLEM_POINT_MASS_MPC and spec.planner is not None and abs(spec.planner["w_vel"] - 0.01 / 45) < 1e-18
+    assert (spec.T, spec.dt, spec.ylim, spec.vlim) == (45, 0.1, 1.5, 1.0) and abs(spec.w_acc - 0.005 / 45) < 1e-18 and abs(spec.safe - 0.3) < 1e-15
+    T = 45
+    G, O = np.tile(p[2:4][:, None], (1, T)), np.zeros((2, T))
+    r = solve_pointmass_ipm(T, 0.1, nlp.w, 1.5, 1.0, nlp.safe_sq, p[:2], np.zeros(2), G, O, tol=1e-9, max_iter=200, track_final_only=True,
+                            w_vel=nlp.w_vel, fix_final_velocity=True)
+    assert r["status"] == 0 and np.abs(r["V"][:, -1]).max() < 1e-12
+    xs = np.concatenate([r["Y"].T.reshape(-1), r["V"].T.reshape(-1)])
+    assert abs(nlp.f(xs, p) - r["f"]) < 1e-12 and np.abs(nlp.a(xs, p)).max() < 1e-12 and nlp.g(xs, p).min() > -1e-9 and nlp.k(xs, p).min() > -1e-9
+    k = kkt_reference_form(nlp, xs, p, active_tol=1e-3)
+    assert k["stationarity"] < 1e-6 and k["feasibility"] < 1e-9
+    s = scipy_minimize(nlp, xs + 0.0, p, method="SLSQP", tol=1e-12, options={"maxiter": 300})  # polish from the port's answer: no lower point nearby
+    assert s.success and s.fun >= r["f"] - 1e-9 and abs(s.fun - r["f"]) < 1e-8

@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from .builder import IntegrationResidual
-from .expr import Add, Const, Expr, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr, VCat, VarRef
+from .expr import Add, Atan2, Const, Expr, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr, VCat, VarRef
 
 
 def _block(container, vec, label):
@@ -79,6 +79,8 @@ def _evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
         return evaluate(e.a, opt, x, p) + evaluate(e.b, opt, x, p)
     if isinstance(e, Scale):
         return e.w * evaluate(e.a, opt, x, p)
+    if isinstance(e, Atan2):
+        return np.arctan2(evaluate(e.y, opt, x, p), evaluate(e.x, opt, x, p))
     if isinstance(e, MatMul):
         return evaluate(e.a, opt, x, p) @ evaluate(e.b, opt, x, p)
     if isinstance(e, VCat):

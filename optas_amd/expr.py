@@ -64,12 +64,14 @@ class Expr:
     def __getitem__(self, key):
         """Row selection of a generic node: e[i], e[a:b] (``veff[:3]``, ``pn[2]`` in example/experiment1.py:120-128)."""
         rows = range(self.shape[0])
+        if isinstance(key, tuple) and len(key) == 2 and key[1] == slice(None):
+            key = key[0]  # e[i, :] / e[a:b, :] (``J(q)[0:2, :]``, example/planar_idk.py:42)
         if isinstance(key, int):
             idx = (rows[key],)
         elif isinstance(key, slice):
             idx = tuple(rows[key])
         else:
-            raise NotImplementedError("only row indexing e[i] / e[a:b] of a generic expression is supported")
+            raise NotImplementedError("only row indexing e[i] / e[a:b] (optionally with ', :') of a generic expression is supported")
         return Rows(self, idx)
 
     def numel(self) -> int:
@@ -358,6 +360,24 @@ class VCat(Expr):
 
     def degree(self):
         return max(p.degree() for p in self.parts)
+
+
+@dataclass(eq=False)
+class Atan2(Expr):
+    """casadi.atan2, elementwise (``2 * atan2(quat[2], quat[3])``: the planar heading, example/planar_idk.py:31)."""
+
+    y: Expr = None
+    x: Expr = None
+
+    def __post_init__(self):
+        self.shape = _bshape(self.y, self.x)
+
+    def degree(self):
+        return 0 if max(self.y.degree(), self.x.degree()) == 0 else 3
+
+
+def atan2(y, x) -> Expr:
+    return Atan2(as_expr(y), as_expr(x))
 
 
 def vertcat(*parts) -> Expr:

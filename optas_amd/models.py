@@ -494,10 +494,14 @@ class RobotModel(Model):
         return J[0] if np.asarray(q).ndim == 1 else [J[i] for i in range(J.shape[0])]
 
     def get_global_link_linear_jacobian(self, link: str, q):
+        if isinstance(q, Expr):
+            return LinkFunction(self, link, "geometric_jacobian", q)[0:3]
         J = self.get_global_link_geometric_jacobian(link, q)
         return J[:3] if isinstance(J, np.ndarray) else [j[:3] for j in J]
 
     def get_global_link_angular_geometric_jacobian(self, link: str, q):
+        if isinstance(q, Expr):
+            return LinkFunction(self, link, "geometric_jacobian", q)[3:6]
         J = self.get_global_link_geometric_jacobian(link, q)
         return J[3:] if isinstance(J, np.ndarray) else [j[3:] for j in J]
 
@@ -557,6 +561,12 @@ class RobotModel(Model):
 
     def get_global_link_quaternion_function(self, link: str, n: int = 1, numpy_output: bool = True):
         return lambda Q: self.get_global_link_quaternion(link, Q if isinstance(Q, Expr) else np.asarray(Q, dtype=np.float64).reshape(self.ndof, -1))
+
+    def get_global_link_linear_jacobian_function(self, link: str, n: int = 1, numpy_output: bool = True):
+        return lambda Q: self.get_global_link_linear_jacobian(link, Q if isinstance(Q, Expr) else np.asarray(Q, dtype=np.float64).reshape(-1))
+
+    def get_global_link_angular_geometric_jacobian_function(self, link: str, n: int = 1, numpy_output: bool = True):
+        return lambda Q: self.get_global_link_angular_geometric_jacobian(link, Q if isinstance(Q, Expr) else np.asarray(Q, dtype=np.float64).reshape(-1))
 
     def get_global_link_geometric_jacobian_function(self, link: str, n: int = 1, numpy_output: bool = True):
         return lambda Q: self.get_global_link_geometric_jacobian(link, np.asarray(Q, dtype=np.float64).reshape(self.ndof, -1))

@@ -160,3 +160,35 @@ def test_differential_ik_through_the_qp_family(hip_lib):
     ik2 = DifferentialIK(planar_direction=(0.0, 0.0), height_band=(0.0, z - 0.002))
     dq2, _ = ik2.step(qc)
     assert ik2.solver.did_solve() and abs(z + 0.1 * (J @ dq2)[2] - (z - 0.002)) < 1e-8  # pushed down exactly onto the band
+
+
+def test_planar_idk_is_a_quadratic_program_with_equalities():
+    from examples.planar_idk import setup_solver
+
+    robot, o = setup_solver(build_only=True)
+    assert isinstance(o, QuadraticCostLinearConstraints) and (robot.ndof, o.nx, o.np, o.nk, o.na, o.nv) == (3, 3, 3, 8, 2, 12)
+    kind, spec = lower(o)
+    assert kind == optas_amd._lib.OH_PROBLEM_QP and (spec.n, spec.m, spec.me) == (3, 8, 2)
+
+
+@pytest.mark.gpu
+def test_planar_idk_known_answer(hip_lib):
+    """example/planar_idk.py: with the bounds inactive the minimum-norm solution of J_xy dq = dx is pinv(J_xy) dx -- the comparison the
+    reference script prints (:58)."""
+    from examples.planar_idk import setup_solver
+
+    robot, solver = setup_solver()
+    q_t = np.array([2.39, -2.55, -0.46])
+    solver.reset_initial_seed({"planar_3dof/dq/x": [0.0, 0.0, 0.0]} if robot.get_name() == "planar_3dof" else {f"{robot.get_name()}/dq/x": [0.0, 0.0, 0.0]})
+    solver.reset_parameters({"q": q_t})
+    sol = solver.solve()
+    assert solver.did_solve()
+    dq = np.asarray(sol[f"{robot.get_name()}/dq"]).reshape(-1)
+    Jxy = np.asarray(robot.get_global_link_linear_jacobian("end", q_t))[0:2]
+    expect = np.linalg.pinv(Jxy) @ np.array([0.01, 0.0])
+    o = solver.opt
+    assert np.abs(o.a(dq, q_t)).max() < 1e-9 and o.k(dq, q_t).min() > -1e-9  # the equality holds, the rows are feasible
+    if np.abs(expect).max() < 0.1 and o.k(expect, q_t).min() > 1e-6:  # bounds inactive at the pinv solution: it is the answer
+        assert np.abs(dq - expect).max() < 1e-7
+    else:  # otherwise at least no worse than any feasible scaling of it
+        assert dq @ dq >= expect @ expect - 1e-9

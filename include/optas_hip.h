@@ -64,7 +64,11 @@ enum {
   /* the QuadraticCost{Unconstrained, LinearConstraints} classes with small dense data (optimization.py:312-388; what the reference hands to
      OSQP / CVXOPT / qpOASES, solver.py:421-584): min x^T P x + q^T x s.t. M x + c >= 0, A x + b = 0; created with oh_create_qp.
      x (nx = n), and one parameter row per instance p = [P (n*n row-major); q (n); M (m*n); c (m); A (me*n); b (me)]. */
-  OH_PROBLEM_QP = 4
+  OH_PROBLEM_QP = 4,
+  /* any other small dense problem: the host compiles its expression trees into one scalar instruction tape (the counterpart of the CasADi SX
+     tape the reference's back-ends interpret, optimization.py:8-24) and the GPU interprets it; created with oh_create_tape.
+     x (nx), p (np) in vec() order. */
+  OH_PROBLEM_TAPE = 5
 };
 
 enum {
@@ -211,6 +215,29 @@ typedef struct oh_qp_desc {
   double tol;   /* KKT tolerance (stationarity, feasibility, complementarity); <= 0: 1e-9 */
 } oh_qp_desc;
 
+#define OH_TAPE_MAX_N 32
+#define OH_TAPE_MAX_LEN 8192
+/* Instruction i writes register i.  op: 0 CONST c | 1 X a | 2 P a | 3 ADD a b | 4 SUB a b | 5 MUL a b | 6 DIV a b | 7 NEG a | 8 SIN a | 9 COS a |
+   10 ATAN2 a b | 11 SQRT a | 12 SQR a.  rows: registers of the constraint rows, the n_ineq rows that must be >= 0 first, then the n_eq rows
+   that must vanish (the rows of v = [k; g; a; -a; h; -h] without the mirrored ones, optimization.py:27-51). */
+typedef struct oh_tape_desc {
+  int nx, np;       /* nx <= OH_TAPE_MAX_N */
+  int len;          /* instructions, <= OH_TAPE_MAX_LEN */
+  const int* op;
+  const int* a;
+  const int* b;
+  const double* c;
+  int out_cost;     /* register holding f */
+  int n_ineq, n_eq;
+  const int* rows;  /* [n_ineq + n_eq] */
+  int max_iter;     /* tape evaluations per instance; <= 0: 2000 */
+  double tol;       /* |grad of the Lagrangian|_inf; <= 0: 1e-6 */
+  double tol_feas;  /* row violation / complementarity measure; <= 0: 1e-9 */
+  double rho0;      /* initial penalty; <= 0: 10 */
+  int jit;          /* != 0: generate straight-line HIP code from the tape and compile it with hiprtc when the handle is created (registers in
+                       VGPRs); 0: interpret the instruction arrays (registers in HBM/L2; no set-up cost, far slower per evaluation) */
+} oh_tape_desc;
+
 typedef struct oh_handle oh_handle;
 
 /* Replaces Solver.__init__ + CasADiSolver.setup (solver.py:64-88,333-384): allocates the handle,
@@ -222,6 +249,15 @@ int oh_create_pointmass(const oh_pointmass_desc* desc, oh_handle** out);
 
 /* Same for OH_PROBLEM_QP (no kinematic constants). oh_get_multipliers returns [B][m + me] = (lam >= 0 of the M rows, nu of the A rows). */
 int oh_create_qp(const oh_qp_desc* desc, oh_handle** out);
+
+/* Same for OH_PROBLEM_TAPE: the tape is copied to the device.  oh_get_multipliers returns [B][n_ineq + n_eq] (lam >= 0 of the >= rows, signed mu
+   of the = rows in L = f - lam^T g - mu^T c). */
+int oh_create_tape(const oh_tape_desc* desc, oh_handle** out);
+
+/* What oh_create_tape does for desc->jit != 0 before it touches a device (CasADi's "jit" option, solver.py:333-384 passes it through): generate
+   the kernel source of this tape and compile it for gfx950.  Needs no GPU.  source (optional, source_cap bytes) receives the generated
+   text, *source_len its full length, *code_bytes the size of the code object. */
+int oh_tape_compile(const oh_tape_desc* desc, size_t* code_bytes, char* source, size_t source_cap, size_t* source_len);
 
 /* Same for OH_PROBLEM_IK; needs oh_set_constants before the first solve. */
 int oh_create_ik(const oh_ik_desc* desc, oh_handle** out);

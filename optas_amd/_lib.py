@@ -17,13 +17,14 @@ OH_MAX_T = 128
 OH_MAX_SPHERE_LINKS = 8
 OH_MAX_OBSTACLES = 16
 
-OH_OK = 0
+OH_OK, OH_ERR_INVALID, OH_ERR_HIP, OH_ERR_STATE = 0, 1, 2, 3
 OH_STATUS_CONVERGED, OH_STATUS_MAX_ITER, OH_STATUS_NUMERICAL = 0, 1, 2
 OH_PROBLEM_KINEMATICS = 0
 OH_PROBLEM_FIGURE_EIGHT = 1
 OH_PROBLEM_POINT_MASS_MPC = 2
 OH_PROBLEM_IK = 3
 OH_PROBLEM_QP = 4
+OH_PROBLEM_TAPE = 5
 OH_HESSIAN_GAUSS_NEWTON, OH_HESSIAN_EXACT, OH_HESSIAN_HYBRID = 0, 1, 2
 
 
@@ -120,6 +121,27 @@ class oh_qp_desc(C.Structure):
     _fields_ = [("n", C.c_int), ("m", C.c_int), ("me", C.c_int), ("max_iter", C.c_int), ("tol", C.c_double)]
 
 
+class oh_tape_desc(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int),
+        ("np", C.c_int),
+        ("len", C.c_int),
+        ("op", C.POINTER(C.c_int)),
+        ("a", C.POINTER(C.c_int)),
+        ("b", C.POINTER(C.c_int)),
+        ("c", C.POINTER(C.c_double)),
+        ("out_cost", C.c_int),
+        ("n_ineq", C.c_int),
+        ("n_eq", C.c_int),
+        ("rows", C.POINTER(C.c_int)),
+        ("max_iter", C.c_int),
+        ("tol", C.c_double),
+        ("tol_feas", C.c_double),
+        ("rho0", C.c_double),
+        ("jit", C.c_int),
+    ]
+
+
 class oh_ik_desc(C.Structure):
     _fields_ = [
         ("ndof", C.c_int),
@@ -145,6 +167,8 @@ SYMBOLS = [
     "oh_create_pointmass",
     "oh_create_ik",
     "oh_create_qp",
+    "oh_create_tape",
+    "oh_tape_compile",
     "oh_set_constants",
     "oh_set_constants_device",
     "oh_set_guards",
@@ -196,6 +220,8 @@ def load() -> C.CDLL:
     lib.oh_create_pointmass.argtypes = [C.POINTER(oh_pointmass_desc), C.POINTER(vp)]
     lib.oh_create_ik.argtypes = [C.POINTER(oh_ik_desc), C.POINTER(vp)]
     lib.oh_create_qp.argtypes = [C.POINTER(oh_qp_desc), C.POINTER(vp)]
+    lib.oh_create_tape.argtypes = [C.POINTER(oh_tape_desc), C.POINTER(vp)]
+    lib.oh_tape_compile.argtypes = [C.POINTER(oh_tape_desc), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.oh_set_constants.argtypes = [vp, C.POINTER(oh_chain)]
     lib.oh_set_constants_device.argtypes = [vp, vp, C.c_size_t]
     lib.oh_set_guards.argtypes = [vp, C.POINTER(oh_guards)]

@@ -107,6 +107,61 @@ class PointMassBackend(_SolveMixin):
         return states, f, iters, status
 
 
+class TapeBackend(_SolveMixin):
+    """OH_PROBLEM_TAPE handle: a compiled instruction tape (optas_amd.tape.Tape) interpreted on the GPU; x (B, nx), p (B, np)."""
+
+    def __init__(self, tape, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True):
+        lib = _lib.load()
+        self.tape = tape
+        self.jit = bool(jit)
+        self.nx, self.np_ = int(tape.nx), max(1, int(tape.np_))
+        self._np_real = int(tape.np_)
+        ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        self._keep = [np.ascontiguousarray(tape.op, dtype=np.int32), np.ascontiguousarray(tape.a, dtype=np.int32), np.ascontiguousarray(tape.b, dtype=np.int32),
+                      np.ascontiguousarray(tape.c, dtype=np.float64), np.ascontiguousarray(np.append(tape.out_rows, 0), dtype=np.int32)]
+        desc = self.descriptor(tape, self._keep, max_iter, tol, tol_feas, rho0, jit)
+        self._h = C.c_void_p()
+        _lib.check(lib.oh_create_tape(C.byref(desc), C.byref(self._h)), "oh_create_tape")
+
+    @staticmethod
+    def descriptor(tape, keep=None, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True):
+        """oh_tape_desc over the arrays of a compiled tape; `keep` receives the contiguous arrays the descriptor points into."""
+        ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        if not keep:
+            keep = keep if keep is not None else []
+            keep += [np.ascontiguousarray(tape.op, dtype=np.int32), np.ascontiguousarray(tape.a, dtype=np.int32), np.ascontiguousarray(tape.b, dtype=np.int32),
+                     np.ascontiguousarray(tape.c, dtype=np.float64), np.ascontiguousarray(np.append(tape.out_rows, 0), dtype=np.int32)]
+        desc = _lib.oh_tape_desc(nx=int(tape.nx), np=int(tape.np_), len=len(tape.op), op=keep[0].ctypes.data_as(ip), a=keep[1].ctypes.data_as(ip),
+                                 b=keep[2].ctypes.data_as(ip), c=keep[3].ctypes.data_as(dp), out_cost=int(tape.out_cost), n_ineq=int(tape.n_ineq),
+                                 n_eq=int(tape.n_eq), rows=keep[4].ctypes.data_as(ip), max_iter=int(max_iter), tol=float(tol), tol_feas=float(tol_feas),
+                                 rho0=float(rho0), jit=int(bool(jit)))
+        desc._keep = keep
+        return desc
+
+    @staticmethod
+    def generated_source(tape):
+        """(source text, code-object bytes) of the kernel hiprtc builds for this tape; needs no GPU (oh_tape_compile)."""
+        desc = TapeBackend.descriptor(tape)
+        size, n = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(_lib.load().oh_tape_compile(C.byref(desc), C.byref(size), None, 0, C.byref(n)), "oh_tape_compile")
+        buf = C.create_string_buffer(n.value + 1)
+        _lib.check(_lib.load().oh_tape_compile(C.byref(desc), C.byref(size), buf, n.value + 1, C.byref(n)), "oh_tape_compile")
+        return buf.value.decode(), int(size.value)
+
+    def solve(self, x0, p):
+        p = _lib.as_f64(p).reshape(len(np.atleast_2d(x0)), -1)
+        if self._np_real == 0:
+            p = np.zeros((p.shape[0], 1))
+        return super().solve(x0, p)
+
+    def multipliers(self, B: int):
+        ni, ne = int(self.tape.n_ineq), int(self.tape.n_eq)
+        out = np.empty((B, ni + ne))
+        if ni + ne:
+            _lib.check(_lib.load().oh_get_multipliers(self._h, int(B), _lib._ptr(out)), "oh_get_multipliers")
+        return out[:, :ni], out[:, ni:]
+
+
 class QPBackend(_SolveMixin):
     """OH_PROBLEM_QP handle: x (B, n); p (B, n*n + n + m*n + m + me*n + me) = [P | q | M | c | A | b] per instance."""
 

@@ -1,0 +1,190 @@
+"""CasADi SX tape -> kernel tape, and the literal ``optas.solver.Solver`` subclass.
+
+Where the reference itself is installed (casadi + optas), a maintainer does not need the ``optas_amd`` front-end at all: the problem's
+``cs.Function`` members ``f, k, g, a, h`` (optimization.py:95-160, built in builder.py:885-1040) are SX virtual-machine programs, and
+this module walks their instructions (``n_instructions / instruction_id / instruction_input / instruction_output /
+instruction_constant``: the public introspection API of ``casadi.Function``) into the same instruction tape the GPU evaluates
+(``optas_amd.tape.Tape`` -> ``oh_create_tape``).  ``make_solver_class(optas.solver)`` then returns a subclass of the reference's own
+``Solver`` whose ``_solve`` runs ``oh_solve`` -- used exactly like ``CasADiSolver`` / ``ScipyMinimizeSolver`` (solver.py:317-398,558-742).
+
+casadi is not importable in the build image, so nothing here imports it: the caller passes the module (``cs=casadi``), and the tests
+drive the walker with a stand-in object that implements the five introspection methods over a hand-written instruction list.
+Nothing is evaluated on the CPU: the walk only re-encodes instructions.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .tape import MAX_TAPE, Tape, TapeBuilder
+
+
+class UnsupportedInstruction(NotImplementedError):
+    pass
+
+
+# casadi opcode names -> how the tape builder expresses them (casadi/core/calculus.hpp enumerates the names; the integer values are read
+# from the module at run time because they have shifted between casadi releases)
+_UNARY = {
+    "OP_ASSIGN": lambda tb, a: a,
+    "OP_NEG": lambda tb, a: tb.neg(a),
+    "OP_SIN": lambda tb, a: tb.sin(a),
+    "OP_COS": lambda tb, a: tb.cos(a),
+    "OP_SQRT": lambda tb, a: tb.sqrt(a),
+    "OP_SQ": lambda tb, a: tb.sqr(a),
+    "OP_TWICE": lambda tb, a: tb.add(a, a),
+    "OP_INV": lambda tb, a: tb.div(tb.const(1.0), a),
+    "OP_TAN": lambda tb, a: tb.div(tb.sin(a), tb.cos(a)),
+}
+_BINARY = {
+    "OP_ADD": lambda tb, a, b: tb.add(a, b),
+    "OP_SUB": lambda tb, a, b: tb.sub(a, b),
+    "OP_MUL": lambda tb, a, b: tb.mul(a, b),
+    "OP_DIV": lambda tb, a, b: tb.div(a, b),
+    "OP_ATAN2": lambda tb, a, b: tb.atan2(a, b),
+}
+
+
+def _pow_const(tb: TapeBuilder, a: int, b: int) -> int:
+    """x ** c for the constant exponents small problems use (OP_CONSTPOW, and OP_POW whose exponent register is a constant)."""
+    if not tb.is_const(b):
+        raise UnsupportedInstruction("pow with a non-constant exponent")
+    e = tb._const[b]
+    if e == 0.5:
+        return tb.sqrt(a)
+    if e == -1.0:
+        return tb.div(tb.const(1.0), a)
+    if e == int(e) and 0 <= int(e) <= 8:
+        out, base, k = tb.const(1.0), a, int(e)
+        while k:  # square-and-multiply
+            if k & 1:
+                out = tb.mul(out, base)
+            base, k = tb.sqr(base), k >> 1
+        return out
+    raise UnsupportedInstruction(f"pow with exponent {e}")
+
+
+def opcode_table(cs) -> Dict[int, tuple]:
+    """{integer opcode of this casadi build: (kind, handler)}."""
+    table = {}
+    for name, fn in _UNARY.items():
+        if hasattr(cs, name):
+            table[int(getattr(cs, name))] = ("unary", fn)
+    for name, fn in _BINARY.items():
+        if hasattr(cs, name):
+            table[int(getattr(cs, name))] = ("binary", fn)
+    for name in ("OP_POW", "OP_CONSTPOW"):
+        if hasattr(cs, name):
+            table[int(getattr(cs, name))] = ("binary", _pow_const)
+    for name, kind in (("OP_CONST", "const"), ("OP_INPUT", "input"), ("OP_OUTPUT", "output")):
+        table[int(getattr(cs, name))] = (kind, None)
+    return table
+
+
+def walk(tb: TapeBuilder, fn, args: Sequence[Sequence[int]], cs, table: Optional[dict] = None) -> List[List[int]]:
+    """Re-encode one SX ``Function`` into ``tb``.  ``args[i][j]`` is the register holding the j-th nonzero of input i (the inputs of the
+    reference's functions are the dense column vectors x and p, optimization.py:12-24, so j is the element index).  Returns, per output,
+    the registers of its dense column-major entries (structural zeros become the constant 0)."""
+    table = table or opcode_table(cs)
+    if hasattr(fn, "is_a") and not fn.is_a("SXFunction"):
+        raise UnsupportedInstruction("only SX functions expose a scalar instruction list (expand() an MX function first)")
+    work: Dict[int, int] = {}
+    outs: List[Dict[int, int]] = [dict() for _ in range(fn.n_out())]
+    for k in range(fn.n_instructions()):
+        op = int(fn.instruction_id(k))
+        kind, handler = table.get(op, (None, None))
+        o, i = list(fn.instruction_output(k)), list(fn.instruction_input(k))
+        if kind == "const":
+            work[o[0]] = tb.const(float(fn.instruction_constant(k)))
+        elif kind == "input":
+            work[o[0]] = int(args[i[0]][i[1]])
+        elif kind == "output":
+            outs[o[0]][o[1]] = work[i[0]]
+        elif kind == "unary":
+            work[o[0]] = handler(tb, work[i[0]])
+        elif kind == "binary":
+            work[o[0]] = handler(tb, work[i[0]], work[i[1]])
+        else:
+            raise UnsupportedInstruction(f"casadi instruction {op} (instruction {k} of {fn.name()}) has no tape counterpart")
+    zero = None
+    dense: List[List[int]] = []
+    for j, nz in enumerate(outs):
+        sp = fn.sparsity_out(j)
+        m, n = int(sp.size1()), int(sp.size2())
+        rows, cols = list(sp.row()), list(sp.get_col())
+        regs = [None] * (m * n)
+        for e, r in nz.items():
+            regs[rows[e] + cols[e] * m] = r
+        for e in range(m * n):
+            if regs[e] is None:
+                zero = tb.const(0.0) if zero is None else zero
+                regs[e] = zero
+        dense.append(regs)
+    return dense
+
+
+def tape_from_functions(cs, nx: int, np_: int, f, ineq: Sequence = (), eq: Sequence = ()) -> Tape:
+    """One tape for the cost ``f(x, p)`` and the rows of the ``ineq`` functions (>= 0) then the ``eq`` functions (= 0)."""
+    tb = TapeBuilder()
+    args = [[tb.x(k) for k in range(nx)], [tb.p(k) for k in range(np_)]]
+    table = opcode_table(cs)
+    cost = walk(tb, f, args, cs, table)[0]
+    if len(cost) != 1:
+        raise UnsupportedInstruction("the cost function must be scalar")
+    rows_i = [r for g in ineq if g is not None for r in walk(tb, g, args, cs, table)[0]]
+    rows_e = [r for h in eq if h is not None for r in walk(tb, h, args, cs, table)[0]]
+    if len(tb.op) > MAX_TAPE:
+        raise UnsupportedInstruction(f"tape of {len(tb.op)} instructions exceeds {MAX_TAPE}")
+    return Tape(np.asarray(tb.op, dtype=np.int32), np.asarray(tb.a, dtype=np.int32), np.asarray(tb.b, dtype=np.int32), np.asarray(tb.c, dtype=np.float64),
+                int(cost[0]), np.asarray(rows_i + rows_e, dtype=np.int32), len(rows_i), len(rows_e), int(nx), int(np_))
+
+
+def tape_from_optimization(opt, cs) -> Tape:
+    """The reference's ``Optimization`` object (any of its seven classes): f, then k and g (>= 0), then a and h (= 0) -- the rows of
+    ``v`` (optimization.py:27-51) without the mirrored equality rows."""
+    if opt.has_discrete_variables():
+        raise UnsupportedInstruction("discrete variables are not supported")
+    return tape_from_functions(cs, opt.nx, opt.np, opt.f, ineq=(opt.k, opt.g), eq=(opt.a, opt.h))
+
+
+def make_solver_class(solver_module, cs):
+    """``HIPSolver(optas.solver.Solver)``: the literal drop-in.  ``solver_module`` is the imported ``optas.solver``; ``cs`` is casadi.
+
+        HIPSolver = make_solver_class(optas.solver, casadi)
+        solver = HIPSolver(builder.build()).setup("hip_sqp", {"tol": 1e-6})
+        solver.reset_initial_seed({...}); solver.reset_parameters({...}); solution = solver.solve()
+    """
+    from .backend import TapeBackend
+
+    class HIPSolver(solver_module.Solver):
+        def setup(self, solver_name: str = "hip_sqp", solver_options: Optional[dict] = None):
+            if solver_name != "hip_sqp":
+                raise ValueError(f"unknown solver '{solver_name}' (this interface provides 'hip_sqp')")
+            o = dict(solver_options or {})
+            self._tape = tape_from_optimization(self.opt, cs)
+            self._backend = TapeBackend(self._tape, max_iter=int(o.pop("max_iter", 2000)), tol=float(o.pop("tol", 1e-6)),
+                                        tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=float(o.pop("rho0", 10.0)), jit=bool(o.pop("jit", True)))
+            if o:
+                raise ValueError(f"unknown solver options {sorted(o)}")
+            self._stats = None
+            return self
+
+        def _solve(self):
+            x0 = np.asarray(self.x0, dtype=np.float64).reshape(1, -1)
+            p = np.asarray(self.p, dtype=np.float64).reshape(1, -1)
+            r = self._backend.solve(x0, p)
+            self._stats = {"status": int(r.status[0]), "success": bool(r.status[0] == 0), "iter_count": int(r.iters[0]), "f": float(r.f[0]),
+                           "kkt": [float(v) for v in r.kkt[0]], "solve_ms": self._backend.solve_ms()}
+            return cs.DM(r.x[0])
+
+        def stats(self):
+            return self._stats
+
+        def number_of_iterations(self) -> int:
+            return self._stats["iter_count"]
+
+        def did_solve(self) -> bool:
+            return self._stats["success"]
+
+    return HIPSolver

@@ -50,6 +50,14 @@ struct oh_handle {
   GuardBuffers GB{};
   void* gpool = nullptr;
   int gcap = 0;
+  // tape family
+  TapeParams TP{};
+  int *d_tape_op = nullptr, *d_tape_a = nullptr, *d_tape_b = nullptr, *d_tape_rows = nullptr;
+  double* d_tape_c = nullptr;
+  double* d_tape_work = nullptr;
+  double* d_tape_mult = nullptr;
+  int tape_cap = 0;
+  TapeJit tape_jit;
   // dense QP family
   oh_qp_desc qp{};
   double* d_qp_work = nullptr;
@@ -212,6 +220,114 @@ extern "C" int oh_create_pointmass(const oh_pointmass_desc* desc, oh_handle** ou
   return OH_OK;
 }
 
+static int tape_validate(const oh_tape_desc* d, const char* who) {
+  const std::string w(who);
+  if (d->nx < 1 || d->nx > OH_TAPE_MAX_N || d->np < 0 || d->len < 1 || d->len > OH_TAPE_MAX_LEN || d->n_ineq < 0 || d->n_eq < 0 || !d->op || !d->a ||
+      !d->b || !d->c || (d->n_ineq + d->n_eq > 0 && !d->rows) || d->out_cost < 0 || d->out_cost >= d->len)
+    return fail(OH_ERR_INVALID, (w + ": bad sizes or null arrays").c_str());
+  for (int i = 0; i < d->len; ++i) {
+    const int o = d->op[i];
+    const bool two = (o >= 3 && o <= 6) || o == 10, one = o == 7 || o == 8 || o == 9 || o == 11 || o == 12;
+    if (o < 0 || o > 12 || (o == 1 && (d->a[i] < 0 || d->a[i] >= d->nx)) || (o == 2 && (d->a[i] < 0 || d->a[i] >= d->np)) ||
+        ((one || two) && (d->a[i] < 0 || d->a[i] >= i)) || (two && (d->b[i] < 0 || d->b[i] >= i)))
+      return fail(OH_ERR_INVALID, (w + ": malformed instruction (operands must be earlier registers / valid indices)").c_str());
+  }
+  for (int i = 0; i < d->n_ineq + d->n_eq; ++i)
+    if (d->rows[i] < 0 || d->rows[i] >= d->len) return fail(OH_ERR_INVALID, (w + ": row register out of range").c_str());
+  return OH_OK;
+}
+
+static TapeParams tape_params(const oh_tape_desc* d) {
+  return TapeParams{d->len, d->nx, d->np, d->n_ineq, d->n_eq, d->out_cost, d->max_iter > 0 ? d->max_iter : 2000, d->tol > 0.0 ? d->tol : 1e-6,
+                    d->tol_feas > 0.0 ? d->tol_feas : 1e-9, d->rho0 > 0.0 ? d->rho0 : 10.0};
+}
+
+extern "C" int oh_tape_compile(const oh_tape_desc* d, size_t* code_bytes, char* source, size_t source_cap, size_t* source_len) {
+  if (!d) return fail(OH_ERR_INVALID, "oh_tape_compile: null argument");
+  if (const int rc = tape_validate(d, "oh_tape_compile")) return rc;
+  const std::string src = oh_tape_jit_source(tape_params(d), d->op, d->a, d->b, d->c, d->rows);
+  if (source_len) *source_len = src.size();
+  if (source && source_cap > 0) {
+    const size_t k = src.size() < source_cap - 1 ? src.size() : source_cap - 1;
+    memcpy(source, src.data(), k);
+    source[k] = 0;
+  }
+  std::vector<char> code;
+  std::string err;
+  if (oh_tape_jit_compile(src, &code, &err)) return fail(OH_ERR_HIP, ("oh_tape_compile: " + err).c_str());
+  if (code_bytes) *code_bytes = code.size();
+  return OH_OK;
+}
+
+extern "C" int oh_create_tape(const oh_tape_desc* d, oh_handle** out) {
+  if (!d || !out) return fail(OH_ERR_INVALID, "oh_create_tape: null argument");
+  *out = nullptr;
+  if (const int rc = tape_validate(d, "oh_create_tape")) return rc;
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return fail(OH_ERR_HIP, "oh_create_tape: no HIP device available (this library has no CPU path)");
+  oh_handle* h = new oh_handle();
+  h->desc = oh_problem_desc{};
+  h->desc.kind = OH_PROBLEM_TAPE;
+  h->desc.T = 1;
+  h->desc.ndof = d->nx;
+  h->TP = tape_params(d);
+  hipGetDevice(&h->device);
+  if (d->jit) {
+    std::vector<char> code;
+    std::string err;
+    if (oh_tape_jit_compile(oh_tape_jit_source(h->TP, d->op, d->a, d->b, d->c, d->rows), &code, &err) || oh_tape_jit_load(code, &h->tape_jit, &err)) {
+      delete h;
+      return fail(OH_ERR_HIP, ("oh_create_tape: " + err).c_str());
+    }
+  }
+  const size_t li = sizeof(int) * (size_t)d->len, ld = sizeof(double) * (size_t)d->len, lr = sizeof(int) * (size_t)(d->n_ineq + d->n_eq + 1);
+  if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+      hipEventCreate(&h->evt0) != hipSuccess || hipEventCreate(&h->evt1) != hipSuccess || hipMalloc((void**)&h->d_tape_op, li) != hipSuccess ||
+      hipMalloc((void**)&h->d_tape_a, li) != hipSuccess || hipMalloc((void**)&h->d_tape_b, li) != hipSuccess ||
+      hipMalloc((void**)&h->d_tape_c, ld) != hipSuccess || hipMalloc((void**)&h->d_tape_rows, lr) != hipSuccess) {
+    delete h;
+    return fail(OH_ERR_HIP, "oh_create_tape: stream/event/allocation failed");
+  }
+  hipMemcpy(h->d_tape_op, d->op, li, hipMemcpyHostToDevice);
+  hipMemcpy(h->d_tape_a, d->a, li, hipMemcpyHostToDevice);
+  hipMemcpy(h->d_tape_b, d->b, li, hipMemcpyHostToDevice);
+  hipMemcpy(h->d_tape_c, d->c, ld, hipMemcpyHostToDevice);
+  if (d->n_ineq + d->n_eq > 0) hipMemcpy(h->d_tape_rows, d->rows, sizeof(int) * (size_t)(d->n_ineq + d->n_eq), hipMemcpyHostToDevice);
+  *out = h;
+  return OH_OK;
+}
+
+static int tape_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status) {
+  HIPCHK(hipSetDevice(h->device));
+  const int Bp = (B + 63) / 64 * 64;
+  if (Bp > h->tape_cap) {
+    if (h->d_tape_work) hipFree(h->d_tape_work);
+    if (h->d_tape_mult) hipFree(h->d_tape_mult);
+    h->d_tape_work = h->d_tape_mult = nullptr;
+    h->tape_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->d_tape_work, sizeof(double) * oh_tape_work_rows(h->TP, h->tape_jit.fn != nullptr) * Bp));
+    HIPCHK(hipMalloc((void**)&h->d_tape_mult, sizeof(double) * (size_t)(h->TP.n_ineq + h->TP.n_eq + 1) * Bp));
+    h->tape_cap = Bp;
+  }
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  if (h->tape_jit.fn)
+    HIPCHK(oh_launch_tape_jit(h->stream, h->tape_jit, h->TP, B, h->tape_cap, (const double*)d_x0, (const double*)d_p, h->d_tape_work, (double*)d_x, (double*)d_f,
+                              (double*)d_kkt, (int*)d_iters, (int*)d_status, h->d_tape_mult));
+  else
+    oh_launch_tape_solve(h->stream, h->TP, h->d_tape_op, h->d_tape_a, h->d_tape_b, h->d_tape_c, h->d_tape_rows, B, h->tape_cap, (const double*)d_x0,
+                         (const double*)d_p, h->d_tape_work, (double*)d_x, (double*)d_f, (double*)d_kkt, (int*)d_iters, (int*)d_status, h->d_tape_mult);
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  for (double& t : h->timing) t = 0.0;
+  h->timing[4] = ms;
+  h->timing[5] = 1;
+  h->last_B = B;
+  return OH_OK;
+}
+
 extern "C" int oh_create_qp(const oh_qp_desc* desc, oh_handle** out) {
   if (!desc || !out) return fail(OH_ERR_INVALID, "oh_create_qp: null argument");
   *out = nullptr;
@@ -247,6 +363,8 @@ static int qp_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   Q.nwork = q.n + 2 * q.m + q.me + q.n * q.n + 2 * q.n + 2 * q.m + q.me * q.n + q.me * q.me + q.me + q.n;
   if (B > h->qp_cap) {
     if (h->d_qp_work) hipFree(h->d_qp_work);
+  for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult})
+    if (q) hipFree(q);
     if (h->d_qp_mult) hipFree(h->d_qp_mult);
     h->d_qp_work = h->d_qp_mult = nullptr;
     h->qp_cap = 0;
@@ -313,6 +431,8 @@ static int ik_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     if (h->d_ik_mult) hipFree(h->d_ik_mult);
   if (h->gpool) hipFree(h->gpool);
   if (h->d_qp_work) hipFree(h->d_qp_work);
+  for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult})
+    if (q) hipFree(q);
   if (h->d_qp_mult) hipFree(h->d_qp_mult);
     h->d_ik_mult = nullptr;
     h->ik_cap = 0;
@@ -557,6 +677,8 @@ static int ensure_guards(oh_handle* h) {
   if (!h->gpool || h->gcap != Bp) {
     if (h->gpool) hipFree(h->gpool);
   if (h->d_qp_work) hipFree(h->d_qp_work);
+  for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult})
+    if (q) hipFree(q);
   if (h->d_qp_mult) hipFree(h->d_qp_mult);
     h->gpool = nullptr;
     const size_t npar = (size_t)g.n_links + 4 * (size_t)g.n_obstacles;
@@ -624,6 +746,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (h->desc.kind == OH_PROBLEM_POINT_MASS_MPC) return pm_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind == OH_PROBLEM_IK) return ik_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind == OH_PROBLEM_QP) return qp_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
+  if (h->desc.kind == OH_PROBLEM_TAPE) return tape_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT) return fail(OH_ERR_STATE, "oh_solve_device: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
   if (!h->have_chain) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_constants first");
   if (!solver_chain_ok(h->chain_host))
@@ -787,15 +910,16 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
   if (B < 1) return fail(OH_ERR_INVALID, "oh_solve: B must be >= 1");
   if (!x0 || !p) return fail(OH_ERR_INVALID, "oh_solve: x0 and p are required");
   if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_POINT_MASS_MPC && h->desc.kind != OH_PROBLEM_IK &&
-      h->desc.kind != OH_PROBLEM_QP)
+      h->desc.kind != OH_PROBLEM_QP && h->desc.kind != OH_PROBLEM_TAPE)
     return fail(OH_ERR_STATE, "oh_solve: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
   HIPCHK(hipSetDevice(h->device));
   const int N = h->desc.ndof, T = h->desc.T;
   const bool pmk = h->desc.kind == OH_PROBLEM_POINT_MASS_MPC;
   const bool ikk = h->desc.kind == OH_PROBLEM_IK;
   const bool qpk = h->desc.kind == OH_PROBLEM_QP;
-  const size_t nx = qpk ? (size_t)h->qp.n : pmk ? 4 * (size_t)T : (ikk ? (size_t)N : (size_t)N * T + (size_t)N * (T - 1));
-  const size_t npar = qpk ? qp_np(h->qp) : pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (h->chain_host.has_lead ? (size_t)N + 1 + T : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0)));
+  const bool tpk = h->desc.kind == OH_PROBLEM_TAPE;
+  const size_t nx = tpk ? (size_t)h->TP.nx : qpk ? (size_t)h->qp.n : pmk ? 4 * (size_t)T : (ikk ? (size_t)N : (size_t)N * T + (size_t)N * (T - 1));
+  const size_t npar = tpk ? (size_t)(h->TP.np > 0 ? h->TP.np : 1) : qpk ? qp_np(h->qp) : pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (h->chain_host.has_lead ? (size_t)N + 1 + T : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0)));
   const size_t b_x = sizeof(double) * nx * B, b_p = sizeof(double) * npar * (size_t)B;
   const size_t b_f = sizeof(double) * B, b_k = sizeof(double) * 3 * (size_t)B, b_i = sizeof(int) * (size_t)B;
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -879,9 +1003,15 @@ extern "C" int oh_pm_rollout(oh_handle* h, int B, int n_ticks, int advance, doub
 
 extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
   if (!h || !lam_h) return fail(OH_ERR_INVALID, "oh_get_multipliers: null argument");
-  if ((h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_IK && h->desc.kind != OH_PROBLEM_QP) || B != h->last_B || B < 1)
+  if ((h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_IK && h->desc.kind != OH_PROBLEM_QP && h->desc.kind != OH_PROBLEM_TAPE) ||
+      B != h->last_B || B < 1)
     return fail(OH_ERR_STATE, "oh_get_multipliers: B does not match the last solve");
   HIPCHK(hipSetDevice(h->device));
+  if (h->desc.kind == OH_PROBLEM_TAPE) {
+    if (h->TP.n_ineq + h->TP.n_eq > 0)
+      HIPCHK(hipMemcpy(lam_h, h->d_tape_mult, sizeof(double) * (size_t)(h->TP.n_ineq + h->TP.n_eq) * B, hipMemcpyDeviceToHost));
+    return OH_OK;
+  }
   if (h->desc.kind == OH_PROBLEM_QP) {
     if (h->qp.m + h->qp.me > 0) HIPCHK(hipMemcpy(lam_h, h->d_qp_mult, sizeof(double) * (size_t)(h->qp.m + h->qp.me) * B, hipMemcpyDeviceToHost));
     return OH_OK;
@@ -1021,6 +1151,8 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->d_ik_mult) hipFree(h->d_ik_mult);
   if (h->gpool) hipFree(h->gpool);
   if (h->d_qp_work) hipFree(h->d_qp_work);
+  for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult})
+    if (q) hipFree(q);
   if (h->d_qp_mult) hipFree(h->d_qp_mult);
   if (h->stage) hipFree(h->stage);
   if (h->d_chain) hipFree(h->d_chain);
@@ -1031,6 +1163,7 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->evt0) hipEventDestroy(h->evt0);
   if (h->evt1) hipEventDestroy(h->evt1);
+  oh_tape_jit_release(&h->tape_jit);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
+#include <vector>
+
 #include "../../include/optas_hip.h"
 
 // Scalar parameters of the figure-eight family (passed by value to every kernel -> SGPRs).
@@ -145,3 +148,22 @@ struct QpParams {
 };
 void oh_launch_qp_solve(hipStream_t s, const QpParams& Q, int B, const double* x0, const double* p, double* work, double* x, double* f, double* kkt,
                         int* iters, int* status, double* mult);
+
+// ---- OH_PROBLEM_TAPE ---------------------------------------------------------------------------------------
+#define OH_TAPE_ST_CONVERGED OH_STATUS_CONVERGED
+#define OH_TAPE_ST_MAX_ITER OH_STATUS_MAX_ITER
+#define OH_TAPE_ST_NUMERICAL OH_STATUS_NUMERICAL
+#include "oh_tape_solver.h"  // TapeParams, TapeWork and the solver shared by the interpreter and the generated code
+struct TapeJit {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+};
+size_t oh_tape_work_rows(const TapeParams& T, bool jit);
+void oh_launch_tape_solve(hipStream_t s, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, int B, int Bp,
+                          const double* x0, const double* p, double* work, double* x, double* f, double* kkt, int* iters, int* status, double* mult);
+std::string oh_tape_jit_source(const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows);
+int oh_tape_jit_compile(const std::string& src, std::vector<char>* code, std::string* err);  // hiprtc for gfx950; needs no device
+int oh_tape_jit_load(const std::vector<char>& code, TapeJit* out, std::string* err);
+void oh_tape_jit_release(TapeJit* j);
+hipError_t oh_launch_tape_jit(hipStream_t s, const TapeJit& j, TapeParams T, int B, int Bp, const double* x0, const double* p, double* work, double* x, double* f,
+                              double* kkt, int* iters, int* status, double* mult);

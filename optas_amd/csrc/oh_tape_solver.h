@@ -1,0 +1,170 @@
+// Solver of the generic tape family, shared by the two ways a tape is evaluated on the GPU:
+//   * oh_tape.hip compiles it ahead of time around an interpreter of the instruction arrays (registers in HBM/L2);
+//   * oh_tape_jit.hip hands this very text to hiprtc in front of straight-line code generated from the tape (registers in VGPRs),
+//     the counterpart of CasADi's "jit" code generation for its SX virtual machine.
+// Self-contained on purpose (no #include, only builtins and the device math library): build.py embeds the file as a string.
+// The includer defines OH_TAPE_ST_CONVERGED / OH_TAPE_ST_MAX_ITER / OH_TAPE_ST_NUMERICAL (the oh_status values of include/optas_hip.h).
+//
+// Outer loop: Powell-Hestenes-Rockafellar augmented Lagrangian; inner solver: BFGS on the inverse Hessian with Armijo backtracking.
+// numpy restatement: oracle/tape_ref.py (solve_tape_al).
+#ifndef OH_TAPE_SOLVER_H
+#define OH_TAPE_SOLVER_H
+
+struct TapeParams {
+  int len, nx, np, n_ineq, n_eq, out_cost, max_iter;
+  double tol, tol_feas, rho0;
+};
+
+#define TIDX(i) ((size_t)(i) * Bp + b)
+
+struct TapeWork {  // SoA slices [k][Bp]: instance index fastest, every access of a wavefront is one coalesced line
+  double *x, *xt, *g, *gt, *d, *H, *lam, *mu, *s, *hy, *rowv;
+};
+
+__host__ __device__ inline size_t tape_solver_rows(const TapeParams& T) {
+  const size_t n = T.nx;
+  return 7 * n + n * n + 2 * (size_t)(T.n_ineq > 0 ? T.n_ineq : 1) + 2 * (size_t)(T.n_eq > 0 ? T.n_eq : 1);
+}
+
+__device__ inline TapeWork tape_carve(const TapeParams& T, double* w, const int Bp) {
+  const size_t n = T.nx, ni = T.n_ineq > 0 ? T.n_ineq : 1, ne = T.n_eq > 0 ? T.n_eq : 1;
+  TapeWork W;
+  auto take = [&](size_t rows) { double* o = w; w += rows * (size_t)Bp; return o; };
+  W.x = take(n); W.xt = take(n); W.g = take(n); W.gt = take(n); W.d = take(n); W.s = take(n); W.hy = take(n);
+  W.H = take(n * n); W.lam = take(ni); W.mu = take(ne); W.rowv = take(ni + ne);
+  return W;
+}
+
+// PHR terms of one row: add the row's share of the merit and of the two constraint measures, return the seed of the reverse sweep
+__device__ inline double tape_al_ineq(const double g, const double lam, const double rho, double& val, double& cm, double& ms) {
+  const double s = fmax(0.0, lam - rho * g);
+  val += (s * s - lam * lam) / (2.0 * rho);
+  cm = fmax(cm, fmax(0.0, -g));
+  ms = fmax(ms, fabs(fmin(g, lam / rho)));
+  return -s;
+}
+__device__ inline double tape_al_eq(const double c, const double mu, const double rho, double& val, double& cm, double& ms) {
+  val += -mu * c + 0.5 * rho * c * c;
+  cm = fmax(cm, fabs(c));
+  ms = fmax(ms, fabs(c));
+  return -mu + rho * c;
+}
+
+// E::phi(xs, gout, rho, &f, &cmax, &meas): merit value at the point in xs (SoA), its gradient into gout (SoA), the row values into W.rowv
+template <class E>
+__device__ inline void tape_solve_instance(const TapeParams& T, E& ev, const TapeWork& W, const int Bp, const int b, const double* __restrict__ x0,
+                                           double* __restrict__ xo, double* __restrict__ fo, double* __restrict__ kkt, int* __restrict__ iters,
+                                           int* __restrict__ status, double* __restrict__ mult) {
+  const int n = T.nx;
+  for (int k = 0; k < n; ++k) W.x[TIDX(k)] = x0[(size_t)b * n + k];
+  for (int i = 0; i < T.n_ineq; ++i) W.lam[TIDX(i)] = 0.0;
+  for (int i = 0; i < T.n_eq; ++i) W.mu[TIDX(i)] = 0.0;
+  auto eye = [&]() {
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) W.H[TIDX(i * n + j)] = (i == j) ? 1.0 : 0.0;
+  };
+  double rho = T.rho0, omega = fmax(T.tol, 1e-2), meas_prev = 1e300;
+  double fval, cmax, meas;
+  double val = ev.phi(W.x, W.g, rho, &fval, &cmax, &meas);
+  int evals = 1, st = OH_TAPE_ST_MAX_ITER;
+  bool H_is_eye = true;
+  eye();
+  double stat = 0.0;
+  for (;;) {
+    stat = 0.0;
+    for (int k = 0; k < n; ++k) stat = fmax(stat, fabs(W.g[TIDX(k)]));
+    bool finite = (val == val) && (fabs(val) < 1e300);
+    for (int k = 0; k < n; ++k) finite = finite && (W.g[TIDX(k)] == W.g[TIDX(k)]);
+    if (!finite) { st = OH_TAPE_ST_NUMERICAL; break; }
+    if (stat <= omega) {
+      if (stat <= T.tol && meas <= T.tol_feas) { st = OH_TAPE_ST_CONVERGED; break; }
+      if (evals >= T.max_iter) break;
+      // outer iteration: multiplier update at x with the current penalty (rowv holds the rows of the last evaluation, which was at x)
+      for (int i = 0; i < T.n_eq; ++i) W.mu[TIDX(i)] -= rho * W.rowv[TIDX(T.n_ineq + i)];
+      for (int i = 0; i < T.n_ineq; ++i) W.lam[TIDX(i)] = fmax(0.0, W.lam[TIDX(i)] - rho * W.rowv[TIDX(i)]);
+      if (meas > 0.25 * meas_prev) rho = fmin(rho * 10.0, 1e8);
+      meas_prev = meas;
+      omega = fmax(T.tol, fmin(omega, 0.1 * meas));
+      val = ev.phi(W.x, W.g, rho, &fval, &cmax, &meas);
+      ++evals;
+      eye();
+      H_is_eye = true;
+      continue;
+    }
+    if (evals >= T.max_iter) break;
+    double slope = 0.0;  // d = -H g
+    for (int i = 0; i < n; ++i) {
+      double v = 0.0;
+      for (int j = 0; j < n; ++j) v -= W.H[TIDX(i * n + j)] * W.g[TIDX(j)];
+      W.d[TIDX(i)] = v;
+      slope += W.g[TIDX(i)] * v;
+    }
+    if (!(slope < 0.0)) {
+      eye();
+      H_is_eye = true;
+      slope = 0.0;
+      for (int i = 0; i < n; ++i) { W.d[TIDX(i)] = -W.g[TIDX(i)]; slope -= W.g[TIDX(i)] * W.g[TIDX(i)]; }
+    }
+    // a fresh (identity) metric knows nothing about the scale of the problem: keep the first step within unit length
+    double alpha = 1.0, vt = 0.0, ft = 0.0, ct = 0.0, mt = 0.0;
+    if (H_is_eye) {
+      double dmax = 0.0;
+      for (int k = 0; k < n; ++k) dmax = fmax(dmax, fabs(W.d[TIDX(k)]));
+      alpha = fmin(1.0, 1.0 / dmax);
+    }
+    bool ok = false;
+    for (int ls = 0; ls < 40; ++ls) {
+      for (int k = 0; k < n; ++k) W.xt[TIDX(k)] = W.x[TIDX(k)] + alpha * W.d[TIDX(k)];
+      vt = ev.phi(W.xt, W.gt, rho, &ft, &ct, &mt);
+      ++evals;
+      if ((vt == vt) && vt <= val + 1e-4 * alpha * slope + 4e-16 * fmax(1.0, fabs(val))) { ok = true; break; }
+      alpha *= 0.5;
+      if (evals >= T.max_iter) break;
+    }
+    if (!ok) {
+      // rowv belongs to the rejected trial: re-evaluate at x before anything reads the rows again
+      val = ev.phi(W.x, W.g, rho, &fval, &cmax, &meas);
+      ++evals;
+      if (H_is_eye || evals >= T.max_iter) break;  // steepest descent cannot improve: rounding floor
+      eye();
+      H_is_eye = true;
+      continue;
+    }
+    // BFGS update of the inverse Hessian with s = xt - x, y = gt - g (y kept in d, which is free now)
+    double sy = 0.0, ss = 0.0, yy = 0.0;
+    for (int k = 0; k < n; ++k) {
+      const double sv = W.xt[TIDX(k)] - W.x[TIDX(k)], yv = W.gt[TIDX(k)] - W.g[TIDX(k)];
+      W.s[TIDX(k)] = sv;
+      W.d[TIDX(k)] = yv;
+      sy += sv * yv; ss += sv * sv; yy += yv * yv;
+    }
+    if (sy > 1e-12 * sqrt(ss) * sqrt(yy)) {
+      double yHy = 0.0;
+      for (int i = 0; i < n; ++i) {
+        double v = 0.0;
+        for (int j = 0; j < n; ++j) v += W.H[TIDX(i * n + j)] * W.d[TIDX(j)];
+        W.hy[TIDX(i)] = v;
+        yHy += W.d[TIDX(i)] * v;
+      }
+      const double c1 = (sy + yHy) / (sy * sy);
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+          W.H[TIDX(i * n + j)] += c1 * W.s[TIDX(i)] * W.s[TIDX(j)] - (W.hy[TIDX(i)] * W.s[TIDX(j)] + W.s[TIDX(i)] * W.hy[TIDX(j)]) / sy;
+      H_is_eye = false;
+    }
+    for (int k = 0; k < n; ++k) { W.x[TIDX(k)] = W.xt[TIDX(k)]; W.g[TIDX(k)] = W.gt[TIDX(k)]; }
+    val = vt; fval = ft; cmax = ct; meas = mt;
+  }
+  for (int k = 0; k < n; ++k)
+    if (xo) xo[(size_t)b * n + k] = W.x[TIDX(k)];
+  if (fo) fo[b] = fval;
+  if (kkt) { kkt[3 * (size_t)b] = stat; kkt[3 * (size_t)b + 1] = cmax; kkt[3 * (size_t)b + 2] = meas; }
+  if (iters) iters[b] = evals;
+  if (status) status[b] = st;
+  if (mult) {
+    for (int i = 0; i < T.n_ineq; ++i) mult[(size_t)b * (T.n_ineq + T.n_eq) + i] = W.lam[TIDX(i)];
+    for (int i = 0; i < T.n_eq; ++i) mult[(size_t)b * (T.n_ineq + T.n_eq) + T.n_ineq + i] = W.mu[TIDX(i)];
+  }
+}
+
+#endif  // OH_TAPE_SOLVER_H

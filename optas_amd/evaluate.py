@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from .builder import IntegrationResidual
-from .expr import Add, Atan2, Const, Expr, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr, VCat, VarRef
+from .expr import Add, Atan2, Block, Const, Expr, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr, VCat, VarRef
 
 
 def _block(container, vec, label):
@@ -56,6 +56,8 @@ def _evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
         return full
     if isinstance(e, Rows):
         return evaluate(e.a, opt, x, p)[list(e.idx), :]
+    if isinstance(e, Block):
+        return np.asarray(evaluate(e.a, opt, x, p))[np.ix_(list(e.ridx), list(e.cidx))]
     if isinstance(e, VarRef):
         return _block(opt.decision_variables, x, e.var_name)
     if isinstance(e, LinkFunction):

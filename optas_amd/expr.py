@@ -64,7 +64,12 @@ class Expr:
     def __getitem__(self, key):
         """Row selection of a generic node: e[i], e[a:b] (``veff[:3]``, ``pn[2]`` in example/experiment1.py:120-128)."""
         rows = range(self.shape[0])
-        if isinstance(key, tuple) and len(key) == 2 and key[1] == slice(None):
+        if isinstance(key, tuple) and len(key) == 2 and not (isinstance(key[1], slice) and key[1] == slice(None)):
+            cols = range(self.shape[1])
+            ci = (cols[key[1]],) if isinstance(key[1], int) else tuple(cols[key[1]])
+            ri = (rows[key[0]],) if isinstance(key[0], int) else tuple(rows[key[0]])
+            return Block(self, ri, ci)  # e[i, j], e[a:b, j], ...
+        if isinstance(key, tuple) and len(key) == 2:
             key = key[0]  # e[i, :] / e[a:b, :] (``J(q)[0:2, :]``, example/planar_idk.py:42)
         if isinstance(key, int):
             idx = (rows[key],)
@@ -212,6 +217,21 @@ class Rows(Expr):
 
     def __post_init__(self):
         self.shape = (len(self.idx), self.a.shape[1])
+
+    def degree(self):
+        return self.a.degree()
+
+
+@dataclass(eq=False)
+class Block(Expr):
+    """Sub-matrix a[rows, cols]."""
+
+    a: Expr = None
+    ridx: tuple = ()
+    cidx: tuple = ()
+
+    def __post_init__(self):
+        self.shape = (len(self.ridx), len(self.cidx))
 
     def degree(self):
         return self.a.degree()

@@ -662,6 +662,26 @@ def match_qp(opt: Optimization) -> QpSpec:
     return QpSpec(n, m, me)
 
 
+@dataclass
+class TapeSpec:
+    tape: object
+
+
+def match_tape(opt: Optimization) -> TapeSpec:
+    """Last resort: any small dense problem whose expression trees compile to a scalar tape (optas_amd/tape.py), interpreted on the GPU."""
+    from .tape import compile_problem
+
+    if opt.has_discrete_variables():
+        raise LoweringError("tape lowering: discrete variables are not supported")
+    if not 1 <= opt.nx <= 32:
+        raise LoweringError(f"tape lowering: nx={opt.nx} exceeds the dense solver's limit of 32 decision variables")
+    try:
+        tape = compile_problem(opt)
+    except NotImplementedError as e:
+        raise LoweringError(f"tape lowering: {e}") from None
+    return TapeSpec(tape)
+
+
 OH_KIND_MULTI_ARM = 101  # host-side composition of OH_PROBLEM_FIGURE_EIGHT handles with lock_orientation = 0
 
 
@@ -670,7 +690,7 @@ def lower(opt: Optimization):
     errors = []
     for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass_planner),
                      (OH_KIND_MULTI_ARM, match_multi_arm),
-                     (_lib.OH_PROBLEM_IK, match_ik), (_lib.OH_PROBLEM_QP, match_qp)):
+                     (_lib.OH_PROBLEM_IK, match_ik), (_lib.OH_PROBLEM_QP, match_qp), (_lib.OH_PROBLEM_TAPE, match_tape)):
         try:
             return kind, fn(opt)
         except LoweringError as e:

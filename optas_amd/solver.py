@@ -16,8 +16,8 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import _lib
-from .backend import BatchResult, FigureEightBackend, IKBackend, MultiArmBackend, PointMassBackend, QPBackend
-from .lowering import FigureEightSpec, IkSpec, MultiArmSpec, PointMassSpec, QpSpec, lower
+from .backend import BatchResult, FigureEightBackend, IKBackend, MultiArmBackend, PointMassBackend, QPBackend, TapeBackend
+from .lowering import FigureEightSpec, IkSpec, MultiArmSpec, PointMassSpec, QpSpec, TapeSpec, lower
 from .models import RobotModel
 from .optimization import Optimization
 
@@ -279,6 +279,10 @@ class HIPSolver(Solver):
         elif isinstance(spec, QpSpec):
             o.pop("hessian", None)
             self._backend = _QpAdapter(self.opt, QPBackend(spec.n, spec.m, spec.me, max_iter=int(o.pop("max_iter", 100)), tol=float(o.pop("tol", 1e-9))))
+        elif isinstance(spec, TapeSpec):
+            o.pop("hessian", None)
+            self._backend = TapeBackend(spec.tape, max_iter=int(o.pop("max_iter", 2000)), tol=float(o.pop("tol", 1e-6)),
+                                        tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=float(o.pop("rho0", 10.0)), jit=bool(o.pop("jit", True)))
         else:  # pragma: no cover
             raise NotImplementedError(kind)
         if o:

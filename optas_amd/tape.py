@@ -1,0 +1,338 @@
+"""Expression trees -> one scalar instruction tape per problem: the stand-in for the CasADi SX tape the reference's NLP back-ends
+interpret (optas/optimization.py:8-24, solver.py:333-398), for small dense problems that match none of the hand-written kernel
+families.  The tape is evaluated *on the GPU only* (csrc/oh_tape.hip: one thread per instance runs the forward sweep and one reverse
+sweep per output row); this module only builds it.
+
+Instruction i writes register i (SSA).  ops:  CONST c | X k (decision variable k, vec() order) | P k (parameter k) | ADD a b |
+SUB a b | MUL a b | DIV a b | NEG a | SIN a | COS a | ATAN2 a b | SQRT a | SQR a.  Common sub-expressions are shared (hash-consing),
+constants are folded.  Link functions (position / rotation / quaternion / geometric Jacobian of a serial chain) are expanded with the
+same chain walk as RobotModel.get_global_link_transform (models.py:826-868) over scalar registers.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .builder import IntegrationResidual
+from .expr import (Add, Atan2, Block, Const, Expr, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols,
+                   StateRef, Sub, SumSqr, VCat, VarRef)
+from .spatialmath import rpy2r
+
+OP_CONST, OP_X, OP_P, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SIN, OP_COS, OP_ATAN2, OP_SQRT, OP_SQR = range(13)
+MAX_TAPE = 8192
+
+
+class TapeBuilder:
+    def __init__(self):
+        self.op: List[int] = []
+        self.a: List[int] = []
+        self.b: List[int] = []
+        self.c: List[float] = []
+        self._memo: Dict[tuple, int] = {}
+        self._const: Dict[int, float] = {}  # register -> value for CONST registers (folding)
+
+    def _emit(self, op, a=0, b=0, c=0.0) -> int:
+        key = (op, a, b, c)
+        r = self._memo.get(key)
+        if r is None:
+            r = len(self.op)
+            self.op.append(op)
+            self.a.append(a)
+            self.b.append(b)
+            self.c.append(float(c))
+            self._memo[key] = r
+            if op == OP_CONST:
+                self._const[r] = float(c)
+        return r
+
+    def const(self, v: float) -> int:
+        return self._emit(OP_CONST, 0, 0, float(v) + 0.0)  # +0.0 folds -0.0 into 0.0
+
+    def x(self, k: int) -> int:
+        return self._emit(OP_X, k)
+
+    def p(self, k: int) -> int:
+        return self._emit(OP_P, k)
+
+    def is_const(self, r: int, v=None) -> bool:
+        return r in self._const and (v is None or self._const[r] == v)
+
+    def add(self, a, b):
+        if self.is_const(a, 0.0):
+            return b
+        if self.is_const(b, 0.0):
+            return a
+        if self.is_const(a) and self.is_const(b):
+            return self.const(self._const[a] + self._const[b])
+        return self._emit(OP_ADD, min(a, b), max(a, b))
+
+    def sub(self, a, b):
+        if self.is_const(b, 0.0):
+            return a
+        if self.is_const(a) and self.is_const(b):
+            return self.const(self._const[a] - self._const[b])
+        if self.is_const(a, 0.0):
+            return self.neg(b)
+        return self._emit(OP_SUB, a, b)
+
+    def mul(self, a, b):
+        if self.is_const(a, 0.0) or self.is_const(b, 0.0):
+            return self.const(0.0)
+        if self.is_const(a, 1.0):
+            return b
+        if self.is_const(b, 1.0):
+            return a
+        if self.is_const(a) and self.is_const(b):
+            return self.const(self._const[a] * self._const[b])
+        if a == b:
+            return self._emit(OP_SQR, a)
+        return self._emit(OP_MUL, min(a, b), max(a, b))
+
+    def div(self, a, b):
+        if self.is_const(b, 1.0):
+            return a
+        if self.is_const(a) and self.is_const(b) and self._const[b] != 0.0:
+            return self.const(self._const[a] / self._const[b])
+        return self._emit(OP_DIV, a, b)
+
+    def sqrt(self, a):
+        return self.const(np.sqrt(self._const[a])) if self.is_const(a) and self._const[a] >= 0.0 else self._emit(OP_SQRT, a)
+
+    def neg(self, a):
+        if self.is_const(a):
+            return self.const(-self._const[a])
+        return self._emit(OP_NEG, a)
+
+    def sin(self, a):
+        return self.const(np.sin(self._const[a])) if self.is_const(a) else self._emit(OP_SIN, a)
+
+    def cos(self, a):
+        return self.const(np.cos(self._const[a])) if self.is_const(a) else self._emit(OP_COS, a)
+
+    def atan2(self, a, b):
+        if self.is_const(a) and self.is_const(b):
+            return self.const(np.arctan2(self._const[a], self._const[b]))
+        return self._emit(OP_ATAN2, a, b)
+
+    def sqr(self, a):
+        return self.mul(a, a)
+
+    # ---- small dense helpers over arrays of registers --------------------------------------------------------------
+    def mat_const(self, M) -> np.ndarray:
+        M = np.atleast_2d(np.asarray(M, dtype=np.float64))
+        return np.array([[self.const(v) for v in row] for row in M], dtype=np.int64)
+
+    def matmul(self, A: np.ndarray, B: np.ndarray) -> np.ndarray:
+        out = np.zeros((A.shape[0], B.shape[1]), dtype=np.int64)
+        for i in range(A.shape[0]):
+            for j in range(B.shape[1]):
+                acc = self.const(0.0)
+                for k in range(A.shape[1]):
+                    acc = self.add(acc, self.mul(int(A[i, k]), int(B[k, j])))
+                out[i, j] = acc
+        return out
+
+    def madd(self, A, B):
+        A, B = np.broadcast_arrays(A, B)
+        return np.array([[self.add(int(a), int(b)) for a, b in zip(ra, rb)] for ra, rb in zip(A, B)], dtype=np.int64)
+
+    def msub(self, A, B):
+        A, B = np.broadcast_arrays(A, B)
+        return np.array([[self.sub(int(a), int(b)) for a, b in zip(ra, rb)] for ra, rb in zip(A, B)], dtype=np.int64)
+
+
+def _rot_axis(tb: TapeBuilder, axis, th: int) -> np.ndarray:
+    """Rodrigues rotation about the constant unit axis by the register angle th: I + sin K + (1 - cos) K^2 (spatialmath.py:89-99)."""
+    a = np.asarray(axis, dtype=np.float64)
+    K = np.array([[0.0, -a[2], a[1]], [a[2], 0.0, -a[0]], [-a[1], a[0], 0.0]])
+    K2 = K @ K
+    s, c = tb.sin(th), tb.cos(th)
+    omc = tb.sub(tb.const(1.0), c)
+    R = np.zeros((3, 3), dtype=np.int64)
+    for i in range(3):
+        for j in range(3):
+            v = tb.const(1.0 if i == j else 0.0)
+            v = tb.add(v, tb.mul(tb.const(K[i, j]), s))
+            v = tb.add(v, tb.mul(tb.const(K2[i, j]), omc))
+            R[i, j] = v
+    return R
+
+
+def _chain_walk(tb: TapeBuilder, robot, link: str, q: np.ndarray):
+    """Symbolic models.py:826-868 over registers: returns (R 3x3, p 3x1, list of (axis_world 3, origin_world 3, jtype, actuated index))."""
+    root = robot.urdf.get_root()
+    R, p = tb.mat_const(np.eye(3)), tb.mat_const(np.zeros((3, 1)))
+    joints = []
+    names = robot.urdf.get_chain(root, link, links=False) if link != root else []
+    for name in names:
+        joint = robot.urdf.joint_map[name]
+        xyz, rpy = robot.get_joint_origin(joint)
+        p = tb.madd(p, tb.matmul(R, tb.mat_const(np.asarray(xyz).reshape(3, 1))))
+        R = tb.matmul(R, tb.mat_const(rpy2r(rpy)))
+        if joint.type == "fixed":
+            continue
+        idx = robot.get_actuated_joint_index(joint.name)
+        axis = robot.get_joint_axis(joint)
+        zw = tb.matmul(R, tb.mat_const(np.asarray(axis).reshape(3, 1)))
+        if joint.type in ("revolute", "continuous"):
+            joints.append((zw, p.copy(), 0, idx))
+            R = tb.matmul(R, _rot_axis(tb, axis, int(q[idx])))
+        elif joint.type == "prismatic":
+            joints.append((zw, p.copy(), 1, idx))
+            p = tb.madd(p, np.array([[tb.mul(int(zw[i, 0]), int(q[idx]))] for i in range(3)], dtype=np.int64))
+        else:
+            raise NotImplementedError(f"{joint.type} joints are currently not supported")
+    return R, p, joints
+
+
+def _quat_from_R(tb: TapeBuilder, R) -> np.ndarray:
+    raise NotImplementedError("quaternion link functions are not compiled to tapes (sign conventions of the reference chain product); "
+                              "use position / rotation / Jacobian link functions")
+
+
+class Compiler:
+    def __init__(self, opt):
+        self.opt = opt
+        self.tb = TapeBuilder()
+        self.xoff = opt.decision_variables.offsets()
+        self.poff = opt.parameters.offsets()
+        self._cache: Dict[int, np.ndarray] = {}
+
+    def block(self, container_off: Dict[str, int], label: str, shape, kind: str) -> np.ndarray:
+        m, n = shape
+        off = container_off[label]
+        mk = self.tb.x if kind == "x" else self.tb.p
+        return np.array([[mk(off + j * m + i) for j in range(n)] for i in range(m)], dtype=np.int64)  # column-major blocks
+
+    def compile(self, e: Expr) -> np.ndarray:
+        key = id(e)
+        if key not in self._cache:
+            self._cache[key] = self._compile(e)
+        return self._cache[key]
+
+    def _compile(self, e: Expr) -> np.ndarray:
+        tb = self.tb
+        if isinstance(e, Const):
+            return tb.mat_const(e.value)
+        if isinstance(e, ParamRef):
+            return self.block(self.poff, e.name, e.shape, "p")
+        if isinstance(e, ParamCol):
+            return self.block(self.poff, e.param.name, e.param.shape, "p")[:, [e.col]]
+        if isinstance(e, StateRef):
+            full = self.block(self.xoff, e.var_name, (e.m, e.n), "x")
+            return full if e.t is None else full[:, [e.t]]
+        if isinstance(e, StateCols):
+            return self.block(self.xoff, e.state.var_name, (e.state.m, e.state.n), "x")[:, e.lo : e.hi]
+        if isinstance(e, VarRef):
+            return self.block(self.xoff, e.var_name, e.shape, "x")
+        if isinstance(e, RobotStates):
+            X, Pm = self.compile(e.states), self.compile(e.params)
+            full = np.zeros(e.shape, dtype=np.int64)
+            full[list(e.opt_idx), :] = X
+            full[list(e.par_idx), :] = Pm
+            return full
+        if isinstance(e, Rows):
+            return self.compile(e.a)[list(e.idx), :]
+        if isinstance(e, Block):
+            return self.compile(e.a)[np.ix_(list(e.ridx), list(e.cidx))]
+        if isinstance(e, VCat):
+            return np.vstack([np.broadcast_to(self.compile(q), q.shape) for q in e.parts])
+        if isinstance(e, Sub):
+            return tb.msub(self.compile(e.a), self.compile(e.b))
+        if isinstance(e, Add):
+            return tb.madd(self.compile(e.a), self.compile(e.b))
+        if isinstance(e, Scale):
+            w = tb.const(e.w)
+            return np.array([[tb.mul(w, int(v)) for v in row] for row in self.compile(e.a)], dtype=np.int64)
+        if isinstance(e, Mul):
+            A, B = np.broadcast_arrays(self.compile(e.a), self.compile(e.b))
+            return np.array([[tb.mul(int(a), int(b)) for a, b in zip(ra, rb)] for ra, rb in zip(A, B)], dtype=np.int64)
+        if isinstance(e, MatMul):
+            return tb.matmul(self.compile(e.a), self.compile(e.b))
+        if isinstance(e, Square):
+            return np.array([[tb.sqr(int(v)) for v in row] for row in self.compile(e.a)], dtype=np.int64)
+        if isinstance(e, SumSqr):
+            acc = tb.const(0.0)
+            for v in self.compile(e.a).reshape(-1):
+                acc = tb.add(acc, tb.sqr(int(v)))
+            return np.array([[acc]], dtype=np.int64)
+        if isinstance(e, Atan2):
+            Y, X = np.broadcast_arrays(self.compile(e.y), self.compile(e.x))
+            return np.array([[tb.atan2(int(a), int(b)) for a, b in zip(ra, rb)] for ra, rb in zip(Y, X)], dtype=np.int64)
+        if isinstance(e, IntegrationResidual):
+            X, Xd = self.compile(e.x), self.compile(e.xd)[:, : e.n]
+            dt = np.array([[tb.const(v) for v in e.dt]], dtype=np.int64)
+            step = np.array([[tb.mul(int(dt[0, j]), int(Xd[i, j])) for j in range(e.n)] for i in range(Xd.shape[0])], dtype=np.int64)
+            return tb.msub(tb.madd(X[:, :-1][:, : e.n], step), X[:, 1:][:, : e.n])
+        if isinstance(e, PathInFrame):
+            o, R = self.compile(e.origin), self.compile(e.rotation)
+            return tb.madd(np.broadcast_to(o.reshape(3, 1), (3, e.local.shape[1])), tb.matmul(R, tb.mat_const(e.local)))
+        if isinstance(e, LinkFunction):
+            Q = self.compile(e.q)
+            cols = []
+            for j in range(Q.shape[1]):
+                R, p, joints = _chain_walk(tb, e.robot, e.link, Q[:, j])
+                if e.what == "position":
+                    cols.append(p)
+                elif e.what == "rotation":
+                    return R
+                elif e.what == "geometric_jacobian":
+                    J = np.full((6, e.robot.ndof), tb.const(0.0), dtype=np.int64)
+                    for zw, pj, jt, idx in joints:
+                        if jt == 0:
+                            d = tb.msub(p, pj)
+                            cr = [tb.sub(tb.mul(int(zw[1, 0]), int(d[2, 0])), tb.mul(int(zw[2, 0]), int(d[1, 0]))),
+                                  tb.sub(tb.mul(int(zw[2, 0]), int(d[0, 0])), tb.mul(int(zw[0, 0]), int(d[2, 0]))),
+                                  tb.sub(tb.mul(int(zw[0, 0]), int(d[1, 0])), tb.mul(int(zw[1, 0]), int(d[0, 0])))]
+                            for i in range(3):
+                                J[i, idx] = cr[i]
+                                J[3 + i, idx] = zw[i, 0]
+                        else:
+                            for i in range(3):
+                                J[i, idx] = zw[i, 0]
+                    return J
+                else:
+                    _quat_from_R(tb, R)
+            return np.hstack(cols)
+        raise NotImplementedError(f"cannot compile {type(e).__name__} to a tape")
+
+
+@dataclass
+class Tape:
+    op: np.ndarray  # int32 [L]
+    a: np.ndarray  # int32 [L]
+    b: np.ndarray  # int32 [L]
+    c: np.ndarray  # float64 [L]
+    out_cost: int  # register of f
+    out_rows: np.ndarray  # int32 [nrows] registers of the constraint rows in the order k, g, a, h (rows >= 0 first, then == 0)
+    n_ineq: int  # k and g rows (>= 0)
+    n_eq: int  # a and h rows (== 0)
+    nx: int
+    np_: int
+
+
+def compile_problem(opt) -> Tape:
+    """One tape for f and every row of k, g (>= 0) and a, h (= 0) of the Optimization (the rows of v without the mirrored -a, -h)."""
+    comp = Compiler(opt)
+    tb = comp.tb
+    f = tb.const(0.0)
+    for term in opt.cost_terms.values():
+        f = tb.add(f, int(comp.compile(term).reshape(-1)[0]))
+    rows: List[int] = []
+
+    def vec(container):
+        out = []
+        for term in container.values():
+            m, n = term.shape
+            out += [int(v) for v in np.broadcast_to(comp.compile(term), (m, n)).T.reshape(-1)]
+        return out
+
+    ineq = vec(opt.lin_ineq_constraints) + vec(opt.ineq_constraints)
+    eq = vec(opt.lin_eq_constraints) + vec(opt.eq_constraints)
+    rows = ineq + eq
+    if len(tb.op) > MAX_TAPE:
+        raise NotImplementedError(f"tape of {len(tb.op)} instructions exceeds {MAX_TAPE}")
+    return Tape(np.asarray(tb.op, dtype=np.int32), np.asarray(tb.a, dtype=np.int32), np.asarray(tb.b, dtype=np.int32), np.asarray(tb.c, dtype=np.float64),
+                int(f), np.asarray(rows, dtype=np.int32), len(ineq), len(eq), opt.nx, opt.np)

@@ -1,0 +1,170 @@
+"""ORACLE (test infrastructure, not product code) -- numpy interpreter of the instruction tapes optas_amd/tape.py builds (forward values,
+reverse-mode gradients of chosen registers) and the numpy port of the generic augmented-Lagrangian / BFGS solver the HIP path runs on them
+(optas_amd/csrc/oh_tape.hip).  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it."""
+import numpy as np
+
+OP_CONST, OP_X, OP_P, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SIN, OP_COS, OP_ATAN2, OP_SQRT, OP_SQR = range(13)
+
+
+def forward(tape, x, p):
+    L = tape.op.shape[0]
+    v = np.zeros(L)
+    for i in range(L):
+        o, a, b = tape.op[i], tape.a[i], tape.b[i]
+        if o == OP_CONST:
+            v[i] = tape.c[i]
+        elif o == OP_X:
+            v[i] = x[a]
+        elif o == OP_P:
+            v[i] = p[a]
+        elif o == OP_ADD:
+            v[i] = v[a] + v[b]
+        elif o == OP_SUB:
+            v[i] = v[a] - v[b]
+        elif o == OP_MUL:
+            v[i] = v[a] * v[b]
+        elif o == OP_DIV:
+            v[i] = v[a] / v[b]
+        elif o == OP_NEG:
+            v[i] = -v[a]
+        elif o == OP_SIN:
+            v[i] = np.sin(v[a])
+        elif o == OP_COS:
+            v[i] = np.cos(v[a])
+        elif o == OP_ATAN2:
+            v[i] = np.arctan2(v[a], v[b])
+        elif o == OP_SQRT:
+            v[i] = np.sqrt(v[a])
+        elif o == OP_SQR:
+            v[i] = v[a] * v[a]
+    return v
+
+
+def reverse(tape, v, seeds):
+    """Gradient wrt x of sum_r seeds[r] * register r  (seeds: dict register -> weight)."""
+    L = tape.op.shape[0]
+    adj = np.zeros(L)
+    for r, w in seeds.items():
+        adj[r] += w
+    g = np.zeros(tape.nx)
+    for i in range(L - 1, -1, -1):
+        w = adj[i]
+        if w == 0.0:
+            continue
+        o, a, b = tape.op[i], tape.a[i], tape.b[i]
+        if o == OP_X:
+            g[a] += w
+        elif o == OP_ADD:
+            adj[a] += w
+            adj[b] += w
+        elif o == OP_SUB:
+            adj[a] += w
+            adj[b] -= w
+        elif o == OP_MUL:
+            adj[a] += w * v[b]
+            adj[b] += w * v[a]
+        elif o == OP_DIV:
+            adj[a] += w / v[b]
+            adj[b] -= w * v[a] / (v[b] * v[b])
+        elif o == OP_NEG:
+            adj[a] -= w
+        elif o == OP_SIN:
+            adj[a] += w * np.cos(v[a])
+        elif o == OP_COS:
+            adj[a] -= w * np.sin(v[a])
+        elif o == OP_ATAN2:
+            d = v[a] * v[a] + v[b] * v[b]
+            adj[a] += w * v[b] / d
+            adj[b] -= w * v[a] / d
+        elif o == OP_SQRT:
+            adj[a] += w * 0.5 / v[i]
+        elif o == OP_SQR:
+            adj[a] += w * 2.0 * v[a]
+    return g
+
+
+def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0):
+    """Generic small NLP on a tape: min f s.t. rows[:n_ineq] >= 0, rows[n_ineq:] = 0.  Augmented Lagrangian (PHR for the inequality rows)
+    minimised by BFGS with Armijo backtracking; one forward + one reverse sweep per evaluation.  Port of k_tape_solve."""
+    n, ni, ne = tape.nx, tape.n_ineq, tape.n_eq
+    rows = tape.out_rows
+    lam = np.zeros(ni)
+    mu = np.zeros(ne)
+    rho = rho0
+    x = np.array(x0, dtype=float)
+
+    def phi(xx):
+        v = forward(tape, xx, p)
+        g, c = v[rows[:ni]], v[rows[ni:]]
+        s = np.maximum(0.0, lam - rho * g)
+        val = v[tape.out_cost] + np.sum((s * s - lam * lam) / (2.0 * rho)) + np.sum(-mu * c + 0.5 * rho * c * c)
+        seeds = {int(tape.out_cost): 1.0}
+        for i in range(ni):
+            if s[i] > 0.0:
+                seeds[int(rows[i])] = seeds.get(int(rows[i]), 0.0) - s[i]
+        for i in range(ne):
+            seeds[int(rows[ni + i])] = seeds.get(int(rows[ni + i]), 0.0) + (-mu[i] + rho * c[i])
+        return val, reverse(tape, v, seeds), g, c, v[tape.out_cost]
+
+    evals = 1
+    val, grad, g, c, fval = phi(x)
+    H = np.eye(n)
+    omega, meas_prev = max(tol, 1e-2), np.inf
+    status = 1
+    while True:
+        stat = np.abs(grad).max() if n else 0.0
+        if not np.isfinite(val) or not np.isfinite(stat):
+            status = 2
+            break
+        if stat <= omega:
+            meas = max(np.abs(c).max() if ne else 0.0, np.abs(np.minimum(g, lam / rho)).max() if ni else 0.0)
+            if stat <= tol and meas <= tol_feas:
+                status = 0
+                break
+            if evals >= max_iter:
+                break
+            mu = mu - rho * c
+            lam = np.maximum(0.0, lam - rho * g)
+            if meas > 0.25 * meas_prev:
+                rho = min(rho * 10.0, 1e8)
+            meas_prev = meas
+            omega = max(tol, min(omega, 0.1 * meas))
+            val, grad, g, c, fval = phi(x)
+            evals += 1
+            H = np.eye(n)
+            continue
+        if evals >= max_iter:
+            break
+        d = -H @ grad
+        slope = float(grad @ d)
+        if not slope < 0.0:
+            H = np.eye(n)
+            d = -grad
+            slope = float(grad @ d)
+        # a fresh (identity) metric knows nothing about the scale of the problem: keep the first step within unit length
+        alpha = min(1.0, 1.0 / np.abs(d).max()) if np.array_equal(H, np.eye(n)) else 1.0
+        ok = False
+        for _ in range(40):
+            xt = x + alpha * d
+            vt, gt, g_t, c_t, f_t = phi(xt)
+            evals += 1
+            if np.isfinite(vt) and vt <= val + 1e-4 * alpha * slope + 4e-16 * max(1.0, abs(val)):
+                ok = True
+                break
+            alpha *= 0.5
+            if evals >= max_iter:
+                break
+        if not ok:
+            evals += 1  # the kernel re-evaluates the accepted point (its tape registers were overwritten by the rejected trials)
+            if np.array_equal(H, np.eye(n)) or evals >= max_iter:
+                break  # steepest descent cannot improve: rounding floor
+            H = np.eye(n)
+            continue
+        sv, yv = xt - x, gt - grad
+        sy = float(sv @ yv)
+        if sy > 1e-12 * np.linalg.norm(sv) * np.linalg.norm(yv):
+            Hy = H @ yv
+            H = H + ((sy + float(yv @ Hy)) / (sy * sy)) * np.outer(sv, sv) - (np.outer(Hy, sv) + np.outer(sv, Hy)) / sy
+        x, val, grad, g, c, fval = xt, vt, gt, g_t, c_t, f_t
+    return {"x": x, "f": float(fval), "lam": lam, "mu": mu, "evals": evals, "status": status, "stat": float(np.abs(grad).max()),
+            "feas": float(max(np.abs(c).max() if ne else 0.0, np.maximum(0.0, -g).max() if ni else 0.0))}

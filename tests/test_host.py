@@ -127,8 +127,13 @@ def test_ik_example_builder_matches_reference_counts():
     kind, _ = lower(opt)
     assert kind == optas_amd._lib.OH_PROBLEM_IK
     b.add_cost_term("extra", sumsqr(q))
+    kind, spec = lower(b.build())  # a second cost term is outside the hand-written IK family: the generic tape family takes it
+    assert kind == optas_amd._lib.OH_PROBLEM_TAPE and spec.tape.nx == 7 and (spec.tape.n_ineq, spec.tape.n_eq) == (14, 3)
+    big = OptimizationBuilder(T=9, robots=robot)  # 63 variables with a coupling cost: no structured family, too large for the dense one
+    qs = big.get_model_states(name)
+    big.add_cost_term("coupled", sumsqr(robot.get_global_link_position("end_effector_ball", qs[:, 0]) - robot.get_global_link_position("end_effector_ball", qs[:, 8])))
     with pytest.raises(LoweringError):
-        lower(b.build())  # a second cost term is outside every kernel family: refused loudly, never approximated
+        lower(big.build())  # refused loudly, never approximated
 
 
 def test_figure_eight_builder_and_lowering():

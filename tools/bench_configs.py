@@ -51,8 +51,17 @@ def main():
                                                                              kuka.upper_actuated_joint_limits).T)).T
     r = timed(be, np.ascontiguousarray(qn), np.ascontiguousarray(np.concatenate([qn, pg], 1)))
     out.append({"config": "1 example.py IK (KUKA LWR, joint limits, position goal)", "batch": B, "solves_per_s": B / r["ms"] * 1e3, **r})
-    # ---- config 3: point-mass MPC tick ----
+    # ---- config 1 again through the generic tape family (interpreter + BFGS instead of the hand-written kernel + Newton) ----
     sys.path.insert(0, ROOT)
+    from examples.example import setup_solver as ik_setup
+    from optas_amd.backend import TapeBackend
+    from optas_amd.tape import compile_problem
+
+    tp = compile_problem(ik_setup(build_only=True)[1])
+    r = timed(TapeBackend(tp), np.ascontiguousarray(qn), np.ascontiguousarray(np.concatenate([qn, pg], 1)))
+    out.append({"config": "1 example.py IK lowered to the generic tape family (OH_PROBLEM_TAPE)", "batch": B, "tape_instructions": len(tp.op),
+                "solves_per_s": B / r["ms"] * 1e3, **r})
+    # ---- config 3: point-mass MPC tick ----
     from examples.point_mass_mpc import obstacle_and_goal
 
     B = 4096

@@ -85,10 +85,49 @@ OH_DEV void sphere_rows_walk(const oh_chain* __restrict__ ch, const GuardParams&
 // One knot: retraction onto R(q)=Rc (q is updated in place), FK chain + Jacobians, tracking cost phi,
 // constraint violation cv, tracking gradient g, Hessian block W (Gauss-Newton, or exact with the
 // multiplier estimate from Gprev), Householder null-space basis Z of the orientation rows, Dr = Z^T W Z.
-template <int N, bool LEAD = false>
+// Null-space basis of the orientation rows from its three Householder vectors: Z = H1 H2 H3 [0; I_NZ].  The batched kernels keep only
+// the vectors in HBM (3N - 3 doubles against N (N - 3) for Z) and rebuild Z with this very code where they need it, so the rebuilt
+// basis equals the one eval_knot used bit for bit.
+template <int N>
+OH_DEV void z_from_householder(const double (&V)[3][N], double (&Z)[N][N - 3]) {
+  constexpr int NZ = N - 3;
+#pragma unroll
+  for (int a = 0; a < NZ; ++a) {
+    double col[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) col[k] = (k == a + 3) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 2; m >= 0; --m) {
+      double d = 0.0;
+#pragma unroll
+      for (int k = m; k < N; ++k) d += V[m][k] * col[k];
+      d *= 2.0;
+#pragma unroll
+      for (int k = m; k < N; ++k) col[k] -= d * V[m][k];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) Z[k][a] = col[k];
+  }
+}
+// packed storage of the vectors: V[m][k], k >= m, at row HV_OFF(N, m) + k - m of 3N - 3
+#define HV_ROWS(N) (3 * (N) - 3)
+#define HV_OFF(N, m) ((m) * (N) - (m) * ((m) - 1) / 2)
+
+// Hooks let the batched kernel shorten live ranges: q and g leave for HBM the moment they are final, and the Lagrangian gradient of the
+// accepted point is fetched only inside the exact-curvature branch (k_eval sits at the 256-register limit of 2 waves/SIMD).
+struct EvalNoHooks {
+  template <int N> OH_DEV void q_final(const double (&)[N]) const {}
+  template <int N> OH_DEV void g_final(const double (&)[N]) const {}
+  template <int N> OH_DEV void v_final(const double (&)[3][N]) const {}
+  template <int N> OH_DEV void load_G(const double (&Gprev)[N], double (&G)[N]) const {
+#pragma unroll
+    for (int k = 0; k < N; ++k) G[k] = Gprev[k];
+  }
+};
+template <int N, bool LEAD = false, class Hooks = EvalNoHooks>
 OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const int t, double (&q)[N], const double (&pc)[3],
                       const double (&Rc)[9], const bool exact, const bool have_G, const double (&Gprev)[N], double& phi, double& cv, double (&g)[N],
-                      double (&Dr)[(N - 3) * (N - 2) / 2], double (&Z)[N][N - 3], const double lead_theta = 0.0) {
+                      double (&Dr)[(N - 3) * (N - 2) / 2], double (&Z)[N][N - 3], const double lead_theta = 0.0, const Hooks hooks = Hooks()) {
   constexpr int NZ = N - 3;
   double R[9], p[3], z[N][3], pj[N][3];
   double Re[9], c[3], M[9];
@@ -126,6 +165,7 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
     for (int k = 0; k < N; ++k) q[k] -= dot3(Jc[k], y);
   }
   cv = cmax;
+  hooks.q_final(q);
 
   // end-effector position, tracking residual
   double e[3], tv[3];
@@ -155,50 +195,29 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
   // gradient of w ||r||^2 : -2 w Jp^T r
 #pragma unroll
   for (int k = 0; k < N; ++k) g[k] = -2.0 * w * dot3(Jp[k], r);
+  hooks.g_final(g);
 
-  // Hessian block W (packed lower): 2 w Jp^T Jp  (+ exact curvature, OH_HESSIAN_EXACT)
-  double W[N * (N + 1) / 2];
+  // multipliers of the orientation rows (exact curvature only): least squares of  G_prev + Jc^T lam = 0  with the Lagrangian
+  // gradient of the last accepted point (lagged by one iteration; exact at convergence)
+  double lam[3] = {0.0, 0.0, 0.0};
+  if (exact && have_G) {
+    double Gl[N];
+    hooks.load_G(Gprev, Gl);
+    double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
 #pragma unroll
-  for (int i = 0; i < N; ++i)
-#pragma unroll
-    for (int j = 0; j <= i; ++j) W[tri(i, j)] = 2.0 * w * dot3(Jp[i], Jp[j]);
-  if (exact) {
-    // -2 w r . d2p/dq_j dq_i,  d2p/dq_j dq_i = z_j x Jp_i for j <= i (revolute j)
-    // + lam . d2c/dq_j dq_i,   d2c = 1/2 z_j x z_i (j < i), exact on the constraint manifold.
-    // multipliers: least squares of  G_prev + Jc^T lam = 0  with the Lagrangian gradient of the last
-    // accepted point (lagged by one iteration; exact at convergence)
-    double lam[3] = {0.0, 0.0, 0.0};
-    if (have_G) {
-      double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
-#pragma unroll
-      for (int k = 0; k < N; ++k) {
-        const double Gk = Gprev[k];
-        S[0] += Jc[k][0] * Jc[k][0];
-        S[1] += Jc[k][1] * Jc[k][0];
-        S[2] += Jc[k][1] * Jc[k][1];
-        S[3] += Jc[k][2] * Jc[k][0];
-        S[4] += Jc[k][2] * Jc[k][1];
-        S[5] += Jc[k][2] * Jc[k][2];
-        lam[0] -= Jc[k][0] * Gk; lam[1] -= Jc[k][1] * Gk; lam[2] -= Jc[k][2] * Gk;
-      }
-      chol_packed<3>(S, 0.0);
-      fsub<3>(S, lam);
-      bsub<3>(S, lam);
+    for (int k = 0; k < N; ++k) {
+      const double Gk = Gl[k];
+      S[0] += Jc[k][0] * Jc[k][0];
+      S[1] += Jc[k][1] * Jc[k][0];
+      S[2] += Jc[k][1] * Jc[k][1];
+      S[3] += Jc[k][2] * Jc[k][0];
+      S[4] += Jc[k][2] * Jc[k][1];
+      S[5] += Jc[k][2] * Jc[k][2];
+      lam[0] -= Jc[k][0] * Gk; lam[1] -= Jc[k][1] * Gk; lam[2] -= Jc[k][2] * Gk;
     }
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      if (ch->jtype[j] == 0) {
-        double rz[3], lz[3];
-        cross3(r, z[j], rz);    // (r x z_j) . Jp_i = r . (z_j x Jp_i)
-        cross3(lam, z[j], lz);  // (lam x z_j) . z_i = lam . (z_j x z_i)
-#pragma unroll
-        for (int i = j; i < N; ++i) {
-          double v = -2.0 * w * dot3(rz, Jp[i]);
-          if (i > j && ch->jtype[i] == 0) v += 0.5 * dot3(lz, z[i]);
-          W[tri(i, j)] += v;
-        }
-      }
-    }
+    chol_packed<3>(S, 0.0);
+    fsub<3>(S, lam);
+    bsub<3>(S, lam);
   }
 
   // Householder QR of Jc^T (N x 3): H3 H2 H1 Jc^T = [Rf; 0];  Z = H1 H2 H3 [0; I_NZ]
@@ -234,44 +253,65 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
       for (int k = m; k < N; ++k) A[m2][k] -= d * V[m][k];
     }
   }
-#pragma unroll
-  for (int a = 0; a < NZ; ++a) {
-    double col[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) col[k] = (k == a + 3) ? 1.0 : 0.0;
-#pragma unroll
-    for (int m = 2; m >= 0; --m) {
-      double d = 0.0;
-#pragma unroll
-      for (int k = m; k < N; ++k) d += V[m][k] * col[k];
-      d *= 2.0;
-#pragma unroll
-      for (int k = m; k < N; ++k) col[k] -= d * V[m][k];
-    }
-#pragma unroll
-    for (int k = 0; k < N; ++k) Z[k][a] = col[k];
-  }
+  hooks.v_final(V);
+  z_from_householder<N>(V, Z);
 
-  // reduced block Dr = Z^T W Z (packed lower NZ x NZ)
-  double WZ[N][NZ];
+  // reduced block Dr = Z^T W Z (packed lower NZ x NZ) without forming the N x N block: the Gauss-Newton part is
+  // 2 w (Jp Z)^T (Jp Z); the exact curvature C is projected separately, on the lanes that use it
+  double JZ[3][NZ];
 #pragma unroll
-  for (int i = 0; i < N; ++i)
+  for (int m = 0; m < 3; ++m)
 #pragma unroll
     for (int a = 0; a < NZ; ++a) {
       double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < N; ++k) s += W[(i >= k) ? tri(i, k) : tri(k, i)] * Z[k][a];
-      WZ[i][a] = s;
+      for (int k = 0; k < N; ++k) s += Jp[k][m] * Z[k][a];
+      JZ[m][a] = s;
     }
 #pragma unroll
   for (int a = 0; a < NZ; ++a)
 #pragma unroll
-    for (int c2 = 0; c2 <= a; ++c2) {
-      double s = 0.0;
+    for (int c2 = 0; c2 <= a; ++c2) Dr[tri(a, c2)] = 2.0 * w * (JZ[0][a] * JZ[0][c2] + JZ[1][a] * JZ[1][c2] + JZ[2][a] * JZ[2][c2]);
+  if (exact) {
+    // C_ij = -2 w r . d2p/dq_j dq_i + lam . d2c/dq_j dq_i;  d2p/dq_j dq_i = z_j x Jp_i for j <= i (revolute j),
+    // d2c = 1/2 z_j x z_i (j < i), exact on the constraint manifold
+    double C[N * (N + 1) / 2];
 #pragma unroll
-      for (int k = 0; k < N; ++k) s += Z[k][a] * WZ[k][c2];
-      Dr[tri(a, c2)] = s;
+    for (int i = 0; i < N * (N + 1) / 2; ++i) C[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (ch->jtype[j] == 0) {
+        double rz[3], lz[3];
+        cross3(r, z[j], rz);    // (r x z_j) . Jp_i = r . (z_j x Jp_i)
+        cross3(lam, z[j], lz);  // (lam x z_j) . z_i = lam . (z_j x z_i)
+#pragma unroll
+        for (int i = j; i < N; ++i) {
+          double v = -2.0 * w * dot3(rz, Jp[i]);
+          if (i > j && ch->jtype[i] == 0) v += 0.5 * dot3(lz, z[i]);
+          C[tri(i, j)] = v;
+        }
+      }
     }
+    double CZ[N][NZ];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) s += C[(i >= k) ? tri(i, k) : tri(k, i)] * Z[k][a];
+        CZ[i][a] = s;
+      }
+#pragma unroll
+    for (int a = 0; a < NZ; ++a)
+#pragma unroll
+      for (int c2 = 0; c2 <= a; ++c2) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) s += Z[k][a] * CZ[k][c2];
+        Dr[tri(a, c2)] += s;
+      }
+  }
 }
 
 // Neighbour coupling of one knot: G = g + 2k((q0-qm) - (qp-q0)), gt = Z^T G, E = -2k Z^T Zn, merit share.

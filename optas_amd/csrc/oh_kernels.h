@@ -57,7 +57,7 @@ struct FigBuffers {
   int B, Bp;
   const oh_chain* chain;  // device copy of the kinematic constants
   double* q[2];           // [slot][T][N][Bp]      knots: current / trial
-  double* Z[2];           // [slot][T][N*NZ][Bp]   null-space basis of the orientation rows
+  double* Z[2];           // [slot][T][3N-3][Bp]   Householder vectors of the null-space basis of the orientation rows (Z is rebuilt from them)
   double* Dr[2];          // [slot][T][NZ(NZ+1)/2][Bp] reduced Hessian block Z^T W Z (packed lower)
   double* g[2];           // [slot][T][N][Bp]      tracking gradient
   double* phi[2];         // [slot][T][Bp]         tracking cost

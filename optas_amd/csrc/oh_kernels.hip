@@ -7,6 +7,37 @@
 #include "oh_figure8.h"
 
 #define IDX(t, K, k) (((size_t)(t) * (K) + (k)) * Bp + b)
+// Row addressing for the hot loops: a stage array is [row = t*K + k][Bp].  Through a buffer resource the row offset travels in an SGPR
+// and the lane adds ONE 32-bit byte offset shared by every stream ("buffer_load_dwordx2 v, v_off, s[rsrc], s_row offen"); with flat
+// global pointers the compiler keeps a 64-bit VGPR address per stream alive (k_step: 50 of them, 55 registers spilled inside its
+// serial sweep).  A RowBuf is rebased per knot (scalar ALU), so the SGPR offset k*Bp*8 always fits 32 bits.
+#if defined(__HIP_DEVICE_COMPILE__)
+struct RowBuf {
+  __amdgpu_buffer_rsrc_t r;
+};
+OH_DEV RowBuf rowbuf(const double* knot_base) {
+  return RowBuf{__builtin_amdgcn_make_buffer_rsrc((void*)knot_base, 0, 0xFFFFFFFF, 0x00020000)};  // raw buffer, gfx9 data format word
+}
+OH_DEV double rb_ld(const RowBuf& rb, const unsigned row_bytes, const unsigned lane_bytes) {
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  const v2i v = __builtin_amdgcn_raw_buffer_load_b64(rb.r, lane_bytes, row_bytes, 0);
+  return __builtin_bit_cast(double, v);
+}
+OH_DEV void rb_st(const RowBuf& rb, const unsigned row_bytes, const unsigned lane_bytes, const double x) {
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, x), rb.r, lane_bytes, row_bytes, 0);
+}
+#else  // host build of oracle/cpu_port
+struct RowBuf {
+  char* p;
+};
+OH_DEV RowBuf rowbuf(const double* knot_base) { return RowBuf{(char*)knot_base}; }
+OH_DEV double rb_ld(const RowBuf& rb, const unsigned row_bytes, const unsigned lane_bytes) { return *(const double*)(rb.p + row_bytes + lane_bytes); }
+OH_DEV void rb_st(const RowBuf& rb, const unsigned row_bytes, const unsigned lane_bytes, const double x) { *(double*)(rb.p + row_bytes + lane_bytes) = x; }
+#endif
+// knot t of an array with K rows per knot; row k of that knot
+#define KNOT(arr, t, K) rowbuf((arr) + (size_t)(t) * (K) * (size_t)Bp)
+#define RB(k) ((unsigned)(k) * rowB)
 
 // ---------------------------------------------------------------------------------------------
 // K1: batched FK + geometric Jacobian (+ reference-signed quaternion), arbitrary chain.
@@ -283,6 +314,15 @@ __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const d
 }
 #endif
 
+// Householder vectors of knot t from their packed stage array ([t][3N - 3][Bp], written by eval_unit)
+template <int N>
+OH_DEV void load_householder(const double* __restrict__ Vs, const int Bp, const int b, const int t, double (&V)[3][N]) {
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int k = 0; k < N; ++k) V[m][k] = (k < m) ? 0.0 : Vs[IDX(t, HV_ROWS(N), HV_OFF(N, m) + k - m)];
+}
+
 // K2: one lane per (instance b, free knot t): trial knot, retraction onto R(q_t)=Rc, FK chain + Jacobians,
 // tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block
 // (eval_knot in oh_figure8.h).
@@ -309,11 +349,14 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
     double zs[NZ];
 #pragma unroll
     for (int a = 0; a < NZ; ++a) zs[a] = D.zstep[IDX(t, NZ, a)];
+    double Vc[3][N], Zc[N][NZ];
+    load_householder<N>(D.Z[cur], Bp, b, t, Vc);
+    z_from_householder<N>(Vc, Zc);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       double v = D.q[cur][IDX(t, N, j)];
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) v += D.Z[cur][IDX(t, N * NZ, j * NZ + a)] * zs[a];
+      for (int a = 0; a < NZ; ++a) v += Zc[j][a] * zs[a];
       q[j] = v;
     }
   }
@@ -332,11 +375,41 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   }
   const bool have_G = exact && !first;
 #pragma unroll
-  for (int k = 0; k < N; ++k) Gprev[k] = have_G ? D.Gfull[cur][IDX(t, N, k)] : 0.0;
+  for (int k = 0; k < N; ++k) Gprev[k] = 0.0;  // fetched by the hook below, inside the exact-curvature branch
 
   double phi, cv, g[N], Dr[NP], Z[N][NZ];
-  if constexpr (LEAD) eval_knot<N, true>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, D.lead[(size_t)t * Bp + b]);
-  else eval_knot<N>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z);
+  struct Hooks {
+    double* __restrict__ qo;
+    double* __restrict__ go;
+    double* __restrict__ vo;
+    const double* __restrict__ Gc;
+    int Bp, b, t;
+    OH_DEV void q_final(const double (&qv)[N]) const {
+      if constexpr (!GUARD) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) qo[IDX(t, N, j)] = qv[j];
+      }
+    }
+    OH_DEV void g_final(const double (&gv)[N]) const {
+      if constexpr (!GUARD) {  // the guard rows still add to g
+#pragma unroll
+        for (int k = 0; k < N; ++k) go[IDX(t, N, k)] = gv[k];
+      }
+    }
+    OH_DEV void v_final(const double (&Vv)[3][N]) const {
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int k = m; k < N; ++k) vo[IDX(t, HV_ROWS(N), HV_OFF(N, m) + k - m)] = Vv[m][k];
+    }
+    OH_DEV void load_G(const double (&)[N], double (&G)[N]) const {
+#pragma unroll
+      for (int k = 0; k < N; ++k) G[k] = Gc[IDX(t, N, k)];
+    }
+  };
+  const Hooks hooks{D.q[slot], D.g[slot], D.Z[slot], D.Gfull[cur], Bp, b, t};
+  if constexpr (LEAD) eval_knot<N, true, Hooks>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, D.lead[(size_t)t * Bp + b], hooks);
+  else eval_knot<N, false, Hooks>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, 0.0, hooks);
   if constexpr (GUARD) {
     // inequality rows through the same augmented Lagrangian as the position-tracking family (oh_free.hip), added after the
     // retraction: joint limits q - lo >= 0, up - q >= 0 (enforce_model_limits, builder.py:471-509) have gradients +-e_j, so W gains
@@ -418,16 +491,14 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
     GB.mcv[slot][(size_t)t * Bp + b] = meas;
   }
 
+  if constexpr (GUARD) {
 #pragma unroll
-  for (int j = 0; j < N; ++j) D.q[slot][IDX(t, N, j)] = q[j];
+    for (int j = 0; j < N; ++j) D.q[slot][IDX(t, N, j)] = q[j];
+#pragma unroll
+    for (int k = 0; k < N; ++k) D.g[slot][IDX(t, N, k)] = g[k];
+  }
   D.phi[slot][(size_t)t * Bp + b] = phi;
   D.cv[slot][(size_t)t * Bp + b] = cv;
-#pragma unroll
-  for (int k = 0; k < N; ++k) D.g[slot][IDX(t, N, k)] = g[k];
-#pragma unroll
-  for (int k = 0; k < N; ++k)
-#pragma unroll
-    for (int a = 0; a < NZ; ++a) D.Z[slot][IDX(t, N * NZ, k * NZ + a)] = Z[k][a];
 #pragma unroll
   for (int i = 0; i < NP; ++i) D.Dr[slot][IDX(t, NP, i)] = Dr[i];
 }
@@ -468,10 +539,19 @@ OH_DEV void couple_unit(const FigParams& P, const FigBuffers& D, const int slot,
     q0[k] = qs[IDX(t, N, k)];
     qp[k] = last ? 0.0 : qs[IDX(t + 1, N, k)];
     g[k] = D.g[slot][IDX(t, N, k)];
+  }
+  {
+    double Vt[3][N];
+    load_householder<N>(Zs, Bp, b, t, Vt);
+    z_from_householder<N>(Vt, Zt);
+    if (!last) {
+      load_householder<N>(Zs, Bp, b, t + 1, Vt);
+      z_from_householder<N>(Vt, Zn);
+    } else {
 #pragma unroll
-    for (int a = 0; a < NZ; ++a) {
-      Zt[k][a] = Zs[IDX(t, N * NZ, k * NZ + a)];
-      Zn[k][a] = last ? 0.0 : Zs[IDX(t + 1, N * NZ, k * NZ + a)];
+      for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) Zn[k][a] = 0.0;
     }
   }
   double G[N], gt[NZ], E[NZ * NZ], merit;
@@ -513,6 +593,8 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   constexpr int NP = NZ * (NZ + 1) / 2;
   const int Bp = D.Bp;
   const int T = P.T;
+  const unsigned lb = (unsigned)b * 8u;      // this lane's byte offset inside a row
+  const unsigned rowB = (unsigned)Bp * 8u;  // bytes per row
   const double kap2 = 2.0 * P.kappa;
   int cur = 1 - ts;  // uniform-slot invariant (see k_eval): the accepted point is in the other slot
   LMState lm{D.mu[b], D.nun[b]};
@@ -523,11 +605,11 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     double f = D.fconst[b];
     double feas = 0.0, fpsi = 0.0, meas = 0.0;
     for (int t = P.t0; t < T; ++t) {
-      f += D.merit[ts][(size_t)t * Bp + b];
-      feas = fmax(feas, D.cv[ts][(size_t)t * Bp + b]);
+      f += rb_ld(KNOT(D.merit[ts], t, 1), 0, lb);
+      feas = fmax(feas, rb_ld(KNOT(D.cv[ts], t, 1), 0, lb));
       if constexpr (GUARD) {
-        fpsi += GBp->psi[ts][(size_t)t * Bp + b];
-        meas = fmax(meas, GBp->mcv[ts][(size_t)t * Bp + b]);
+        fpsi += rb_ld(KNOT(GBp->psi[ts], t, 1), 0, lb);
+        meas = fmax(meas, rb_ld(KNOT(GBp->mcv[ts], t, 1), 0, lb));
       }
     }
     bool accept;
@@ -572,9 +654,14 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   double mu = lm.mu;
 
   // ---- phase B: backward sweep on the current slot ------------------------------------------------
-  const double* __restrict__ Ec = D.E[cur];
-  const double* __restrict__ Drc = D.Dr[cur];
-  const double* __restrict__ gtc = D.gt[cur];
+  // the accepted slot differs from lane to lane (a rejected trial leaves it where it was): the two slots of an array are adjacent in
+  // the pool, so the slot goes into the lane offset and the row pointers stay uniform
+  const double* __restrict__ Ec = D.E[0];
+  const double* __restrict__ Drc = D.Dr[0];
+  const double* __restrict__ gtc = D.gt[0];
+  const unsigned oE = lb + (cur ? (unsigned)((const char*)D.E[1] - (const char*)D.E[0]) : 0u);
+  const unsigned oD = lb + (cur ? (unsigned)((const char*)D.Dr[1] - (const char*)D.Dr[0]) : 0u);
+  const unsigned oG = lb + (cur ? (unsigned)((const char*)D.gt[1] - (const char*)D.gt[0]) : 0u);
   double stat = 0.0;
   double S[NP], rd[NZ], rn[NZ];
   for (int attempt = 0; attempt < 40; ++attempt) {
@@ -584,11 +671,11 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     {
       const int t = T - 1;
 #pragma unroll
-      for (int i = 0; i < NP; ++i) S[i] = Drc[IDX(t, NP, i)];
+      for (int i = 0; i < NP; ++i) S[i] = rb_ld(KNOT(Drc, t, NP), RB(i), oD);
 #pragma unroll
       for (int a = 0; a < NZ; ++a) {
         S[tri(a, a)] += kap2 + mu;
-        rn[a] = gtc[IDX(t, NZ, a)];
+        rn[a] = rb_ld(KNOT(gtc, t, NZ), RB(a), oG);
         stat = fmax(stat, fabs(rn[a]));
       }
     }
@@ -597,11 +684,11 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     if (T - 2 >= P.t0) {
       const int t = T - 2;
 #pragma unroll
-      for (int i = 0; i < NZ * NZ; ++i) nE[i] = Ec[IDX(t, NZ * NZ, i)];
+      for (int i = 0; i < NZ * NZ; ++i) nE[i] = rb_ld(KNOT(Ec, t, NZ * NZ), RB(i), oE);
 #pragma unroll
-      for (int i = 0; i < NP; ++i) nH[i] = Drc[IDX(t, NP, i)];
+      for (int i = 0; i < NP; ++i) nH[i] = rb_ld(KNOT(Drc, t, NP), RB(i), oD);
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) ng[a] = gtc[IDX(t, NZ, a)];
+      for (int a = 0; a < NZ; ++a) ng[a] = rb_ld(KNOT(gtc, t, NZ), RB(a), oG);
     }
     for (int t = T - 2; t >= P.t0; --t) {
       double E[NZ * NZ], Ht[NP], gt[NZ];
@@ -614,11 +701,11 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       if (t > P.t0) {  // issue the next knot's loads before the dependent arithmetic of this one
         const int tn = t - 1;
 #pragma unroll
-        for (int i = 0; i < NZ * NZ; ++i) nE[i] = Ec[IDX(tn, NZ * NZ, i)];
+        for (int i = 0; i < NZ * NZ; ++i) nE[i] = rb_ld(KNOT(Ec, tn, NZ * NZ), RB(i), oE);
 #pragma unroll
-        for (int i = 0; i < NP; ++i) nH[i] = Drc[IDX(tn, NP, i)];
+        for (int i = 0; i < NP; ++i) nH[i] = rb_ld(KNOT(Drc, tn, NP), RB(i), oD);
 #pragma unroll
-        for (int a = 0; a < NZ; ++a) ng[a] = gtc[IDX(tn, NZ, a)];
+        for (int a = 0; a < NZ; ++a) ng[a] = rb_ld(KNOT(gtc, tn, NZ), RB(a), oG);
       }
 #pragma unroll
       for (int a = 0; a < NZ; ++a) {
@@ -628,9 +715,9 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       double Kmat[NZ * NZ], kv[NZ];
       ok = riccati_back<NZ>(S, rd, rn, E, Ht, gt, Kmat, kv) && ok;
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) D.kvec[IDX(t + 1, NZ, a)] = kv[a];
+      for (int a = 0; a < NZ; ++a) rb_st(KNOT(D.kvec, t + 1, NZ), RB(a), lb, kv[a]);
 #pragma unroll
-      for (int i = 0; i < NZ * NZ; ++i) D.Kmat[IDX(t + 1, NZ * NZ, i)] = Kmat[i];
+      for (int i = 0; i < NZ * NZ; ++i) rb_st(KNOT(D.Kmat, t + 1, NZ * NZ), RB(i), lb, Kmat[i]);
     }
     ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
     if (ok) break;
@@ -661,7 +748,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       GB.n_outer[b] += 1;
       for (int t = P.t0; t < T; ++t) {
 #pragma unroll
-        for (int a = 0; a < NZ; ++a) D.zstep[IDX(t, NZ, a)] = 0.0;
+        for (int a = 0; a < NZ; ++a) rb_st(KNOT(D.zstep, t, NZ), RB(a), lb, 0.0);
       }
       D.pred[b] = 0.0;
       D.mu[b] = mu;
@@ -698,9 +785,9 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
         double zn[NZ];
 #pragma unroll
         for (int a = 0; a < NZ; ++a) {
-          double sacc = D.kvec[IDX(t, NZ, a)];
+          double sacc = rb_ld(KNOT(D.kvec, t, NZ), RB(a), lb);
 #pragma unroll
-          for (int c2 = 0; c2 < NZ; ++c2) sacc += D.Kmat[IDX(t, NZ * NZ, a * NZ + c2)] * zz[c2];
+          for (int c2 = 0; c2 < NZ; ++c2) sacc += rb_ld(KNOT(D.Kmat, t, NZ * NZ), RB(a * NZ + c2), lb) * zz[c2];
           zn[a] = -sacc;
         }
 #pragma unroll
@@ -708,8 +795,8 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       }
 #pragma unroll
       for (int a = 0; a < NZ; ++a) {
-        D.zstep[IDX(t, NZ, a)] = zz[a];
-        gd += gtc[IDX(t, NZ, a)] * zz[a];
+        rb_st(KNOT(D.zstep, t, NZ), RB(a), lb, zz[a]);
+        gd += rb_ld(KNOT(gtc, t, NZ), RB(a), oG) * zz[a];
         z2 += zz[a] * zz[a];
       }
     }

@@ -40,11 +40,12 @@ QC0_DEG = [0, 30, 0, -90, 0, -30, 0]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 # Algorithmic bytes per unit = (instance, free knot) per launch, f64:
-#   k_eval   : read q 7, V 18, z 4 ; write q 7, V 18, Dr 10, g 7, phi 1, cv 1             = 73 doubles
-#              (V: the three Householder vectors of the null-space basis, 3N - 3 doubles; Z itself is rebuilt in registers)
+#   k_eval   : read q 7, V 18, z 4, model (e, Jp Z) 15 ; write q 7, V 18, Dr 10, g 7, phi 1, cv 1, model 15 = 103 doubles
+#              (V: the three Householder vectors of the null-space basis, 3N - 3 doubles; Z itself is rebuilt in registers.
+#               model: end-effector position and Jp Z of the knot, what the next retraction's position target is predicted from)
 #   k_couple : read V_t 18 (V_{t+1} is an L2 hit), q 3x7, g 7, phi 1 ; write E 16, gt 4, merit 1 = 68 doubles
 #   k_step   : read merit 1, cv 1, E 16, Dr 10, gt 4+4 ; write+read gains 20+20 ; write z 4  = 80 doubles
-BYTES = {"k_eval": 73 * 8, "k_couple": 68 * 8, "k_step": 80 * 8}
+BYTES = {"k_eval": 103 * 8, "k_couple": 68 * 8, "k_step": 80 * 8}
 BYTES_FKJAC = 448  # q 56 B in, pose 56 B + J 336 B out
 
 

@@ -576,11 +576,12 @@ static int ensure_capacity(oh_handle* h, int B) {
   size_t nd = 0;  // doubles
   nd += 2 * per_q + 2 * per_Z + 2 * per_Dr + 2 * per_q /*g*/ + 4 * per_t /*phi,cv*/;
   nd += 2 * per_q /*Gfull*/ + (size_t)T * NZ * NZ * Bp + (size_t)T * NZ * Bp;
+  nd += 2 * (size_t)T * (3 + 3 * NZ) * Bp;  // mdl
   nd += 2 * (size_t)T * NZ * NZ * Bp + 2 * (size_t)T * NZ * Bp + 2 * per_t + (size_t)T * NZ * Bp;  // E, gt, merit, zstep
   nd += (size_t)12 * Bp + 7 * (size_t)Bp;
   nd += (size_t)4 * T * Bp;  // lam_h
   nd += per_t;               // lead-joint angles
-  size_t ni = 7 * (size_t)Bp + 32;  // + n_running, n_new, work (8-byte aligned)
+  size_t ni = 8 * (size_t)Bp + 32;  // + n_running, n_new, work (8-byte aligned)
   size_t bytes = nd * sizeof(double) + ni * sizeof(int);
   void* pool = nullptr;
   hipError_t e = hipMalloc(&pool, bytes);
@@ -606,6 +607,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   for (int s = 0; s < 2; ++s) D.phi[s] = take(per_t);
   for (int s = 0; s < 2; ++s) D.cv[s] = take(per_t);
   for (int s = 0; s < 2; ++s) D.Gfull[s] = take(per_q);
+  for (int s = 0; s < 2; ++s) D.mdl[s] = take((size_t)T * (3 + 3 * NZ) * Bp);
   for (int s = 0; s < 2; ++s) D.E[s] = take((size_t)T * NZ * NZ * Bp);
   for (int s = 0; s < 2; ++s) D.gt[s] = take((size_t)T * NZ * Bp);
   for (int s = 0; s < 2; ++s) D.merit[s] = take(per_t);
@@ -627,6 +629,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.cur = ip; ip += Bp;
   D.first = ip; ip += Bp;
   D.skip = ip; ip += Bp;
+  D.polish = ip; ip += Bp;
   D.status = ip; ip += Bp;
   D.iters = ip; ip += Bp;
   D.orig = ip; ip += Bp;

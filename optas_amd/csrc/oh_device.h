@@ -230,3 +230,51 @@ OH_DEV void bsub(const double (&L)[M * (M + 1) / 2], double (&x)[M]) {
     x[i] = v / L[tri(i, i)];
   }
 }
+
+// Cholesky with reciprocal pivots (divisions are off the critical path of the Riccati chain).
+template <int M>
+OH_DEV bool chol_rcp(double (&S)[M * (M + 1) / 2], double (&rd)[M], double piv_min) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    double d = S[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= S[tri(j, k)] * S[tri(j, k)];
+    if (!(d > piv_min)) { ok = false; d = 1.0; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double inv = rsqrt(d);
+#else
+    const double inv = 1.0 / sqrt(d);  // host build of oracle/cpu_port
+#endif
+    rd[j] = inv;
+    S[tri(j, j)] = d * inv;
+#pragma unroll
+    for (int i = j + 1; i < M; ++i) {
+      double v = S[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= S[tri(i, k)] * S[tri(j, k)];
+      S[tri(i, j)] = v * inv;
+    }
+  }
+  return ok;
+}
+template <int M>
+OH_DEV void fsub_rcp(const double (&L)[M * (M + 1) / 2], const double (&rd)[M], double (&x)[M]) {
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    double v = x[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= L[tri(i, k)] * x[k];
+    x[i] = v * rd[i];
+  }
+}
+template <int M>
+OH_DEV void bsub_rcp(const double (&L)[M * (M + 1) / 2], const double (&rd)[M], double (&x)[M]) {
+#pragma unroll
+  for (int i = M - 1; i >= 0; --i) {
+    double v = x[i];
+#pragma unroll
+    for (int k = i + 1; k < M; ++k) v -= L[tri(k, i)] * x[k];
+    x[i] = v * rd[i];
+  }
+}

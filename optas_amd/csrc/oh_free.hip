@@ -389,7 +389,7 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
       GB.outer[b] = 0;
       GB.rho[b] = GB.rho_next[b];
     } else {
-      accept = lm_accept(P, f, 0.0, D.f_cur[b], D.pred[b], lm);
+      accept = lm_accept(P, f, 0.0, D.f_cur[b], D.pred[b], 0.0, lm);
       D.nun[b] = lm.nun;
     }
     if (accept) {

@@ -63,6 +63,7 @@ struct FigBuffers {
   double* phi[2];         // [slot][T][Bp]         tracking cost
   double* cv[2];          // [slot][T][Bp]         |c|_inf after retraction
   double* Gfull[2];       // [slot][T][N][Bp]      Lagrangian gradient G_t (exact-Hessian mode: multiplier estimate)
+  double* mdl[2];         // [slot][T][3+3NZ][Bp]  end-effector position e_t and Jp_t Z_t: the linear model the next retraction targets
   double* E[2];           // [slot][T][NZ*NZ][Bp]  coupling blocks -2 kappa Z_t^T Z_{t+1}
   double* gt[2];          // [slot][T][NZ][Bp]     reduced gradient Z_t^T G_t
   double* merit[2];       // [slot][T][Bp]         phi_t + kappa ||q_t - q_{t-1}||^2
@@ -82,6 +83,7 @@ struct FigBuffers {
   int* cur;               // [Bp] slot holding the accepted point
   int* first;             // [Bp]
   int* skip;              // [Bp] 1: last trial rejected -> sit the next launch out (keeps the slot parity uniform)
+  int* polish;            // [Bp] 1: the next evaluation re-retracts the accepted point itself (zero step, floor tolerance) and is accepted as is
   int* status;            // [Bp] -1 running, else OH_STATUS_*
   int* iters;             // [Bp]
   int* orig;              // [Bp] original instance index (instances are compacted as the batch drains)

@@ -297,6 +297,7 @@ OH_DEV void setup_unit(const FigParams& P, const FigBuffers& D, const double* __
   D.cur[b] = 1;  // trial slot of launch 0 is slot 0
   D.first[b] = 1;
   D.skip[b] = 0;
+  D.polish[b] = 0;
   D.orig[b] = b;
   D.status[b] = -1;  // running
   D.iters[b] = 0;
@@ -341,7 +342,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   const int cur = 1 - slot;
   const bool first = D.first[b] != 0;
   // trial knot: the seed on the first evaluation, otherwise q_cur + Z_cur z (roll-out of the step k_step solved for)
-  double q[N];
+  double q[N], e_tgt[3] = {0.0, 0.0, 0.0};
   if (first) {
 #pragma unroll
     for (int j = 0; j < N; ++j) q[j] = D.q[slot][IDX(t, N, j)];
@@ -358,6 +359,14 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
 #pragma unroll
       for (int a = 0; a < NZ; ++a) v += Zc[j][a] * zs[a];
       q[j] = v;
+    }
+    // where the linear model puts the end effector after this step: e_cur + (Jp Z)_cur z
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      double v = D.mdl[cur][IDX(t, MDL_ROWS(N), m)];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) v += D.mdl[cur][IDX(t, MDL_ROWS(N), 3 + m * NZ + a)] * zs[a];
+      e_tgt[m] = v;
     }
   }
   double Rc[9], pc[3];
@@ -408,8 +417,17 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
     }
   };
   const Hooks hooks{D.q[slot], D.g[slot], D.Z[slot], D.Gfull[cur], Bp, b, t};
-  if constexpr (LEAD) eval_knot<N, true, Hooks>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, D.lead[(size_t)t * Bp + b], hooks);
-  else eval_knot<N, false, Hooks>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, 0.0, hooks);
+  double e_new[3], JZ_new[3][NZ];
+  const double tol_r = retract_tol(P, !first, D.pred[b], D.stat[b]);
+  if constexpr (LEAD)
+    eval_knot<N, true, Hooks>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new, D.lead[(size_t)t * Bp + b], hooks);
+  else eval_knot<N, false, Hooks>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new, 0.0, hooks);
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    D.mdl[slot][IDX(t, MDL_ROWS(N), m)] = e_new[m];
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) D.mdl[slot][IDX(t, MDL_ROWS(N), 3 + m * NZ + a)] = JZ_new[m][a];
+  }
   if constexpr (GUARD) {
     // inequality rows through the same augmented Lagrangian as the position-tracking family (oh_free.hip), added after the
     // retraction: joint limits q - lo >= 0, up - q >= 0 (enforce_model_limits, builder.py:471-509) have gradients +-e_j, so W gains
@@ -503,8 +521,13 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   for (int i = 0; i < NP; ++i) D.Dr[slot][IDX(t, NP, i)] = Dr[i];
 }
 #ifndef OH_HOST_PORT
+// Blocks per CU of k_eval: with the six-row retraction the kernel needs ~360 live registers in its loop; at 2 waves/SIMD (256) it
+// spills 99 of them and runs 10 % slower than at 1 wave/SIMD with none (A/B on one box: 64.1 vs 57.8 ms per bench step).
+#ifndef OH_EVAL_WAVES
+#define OH_EVAL_WAVES 1
+#endif
 template <int N>
-__global__ __launch_bounds__(256, 2) void k_eval(FigParams P, FigBuffers D, const int slot) {
+__global__ __launch_bounds__(256, OH_EVAL_WAVES) void k_eval(FigParams P, FigBuffers D, const int slot) {
   eval_unit<N>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
 }
 // chains with a parameterised lead joint (RobotModel(param_joints=[first joint]), figure_eight_plan_6dof.py): same evaluation
@@ -599,6 +622,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   int cur = 1 - ts;  // uniform-slot invariant (see k_eval): the accepted point is in the other slot
   LMState lm{D.mu[b], D.nun[b]};
   const int iters = D.iters[b];
+  bool polish_request = false;
 
   // ---- phase A: merit of the trial slot ---------------------------------------------------------
   {
@@ -628,8 +652,17 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       accept = true;
       GBp->outer[b] = 0;
       GBp->rho[b] = GBp->rho_next[b];
+    } else if (D.polish[b]) {
+      accept = true;  // the accepted point itself, re-retracted to the floor tolerance
+      D.polish[b] = 0;
     } else {
-      accept = lm_accept(P, f, feas, D.f_cur[b], D.pred[b], lm);
+      const LMState lm_before = lm;
+      accept = lm_accept(P, f, feas, D.f_cur[b], D.pred[b], D.stat[b], lm);
+      // A rejected trial against an accepted point that was retracted loosely (retract_tol): its objective is off by (multiplier) x
+      // violation, and steps that predict less than that can never be accepted.  Before blaming the model, re-evaluate the accepted
+      // point at the floor tolerance: zero step, accepted unconditionally at the next k_step.
+      polish_request = !accept && D.feas[b] > 10.0 * P.tol_retract;
+      if (polish_request) lm = lm_before;
       D.nun[b] = lm.nun;
     }
     if (accept) {
@@ -650,6 +683,16 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       D.work[1] += 1ULL;
 #endif
     }
+  }
+  if (polish_request) {
+    for (int t = P.t0; t < T; ++t) {
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) rb_st(KNOT(D.zstep, t, NZ), RB(a), lb, 0.0);
+    }
+    D.pred[b] = 0.0;
+    D.polish[b] = 1;
+    D.iters[b] = iters + 1;
+    return iters < P.max_iter + 40 ? true : (D.status[b] = OH_STATUS_MAX_ITER, false);
   }
   double mu = lm.mu;
 
@@ -910,12 +953,17 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
   const double fconst = D.fconst[b];
   LMState lm{D.mu[b], D.nun[b]};
   int iters = D.iters[b];
-  bool first = true;
+  bool first = true, polish = false;
   int status = -1;
   unsigned long long n_launch_equiv = 0, n_reject = 0;
 
   // accepted point (per lane = per knot)
-  double q_c[N], Z_c[N][NZ], Dr_c[NP], E_c[NZ * NZ], gt_c[NZ], g_c[N], G_c[N];
+  double q_c[N], Z_c[N][NZ], Dr_c[NP], E_c[NZ * NZ], gt_c[NZ], g_c[N], G_c[N], e_c[3] = {0.0, 0.0, 0.0}, JZ_c[3][NZ];
+  double e_tgt[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) JZ_c[m][a] = 0.0;
   double f_cur = 0.0, feas_cur = 0.0, pred = 0.0, stat = 0.0;
 #pragma unroll
   for (int k = 0; k < N; ++k) { q_c[k] = qt[k]; g_c[k] = 0.0; G_c[k] = 0.0; }
@@ -929,7 +977,8 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
     double phi = 0.0, cv = 0.0, g[N], Dr[NP], Z[N][NZ];
     const bool exact = (P.hessian == OH_HESSIAN_EXACT) || (P.hessian == OH_HESSIAN_HYBRID && !first && stat <= P.hyb_switch);
     const bool have_G = exact && !first;
-    if (active) eval_knot<N>(ch, P, t, qt, pc, Rc, exact, have_G, G_c, phi, cv, g, Dr, Z);
+    double e_new[3] = {0.0, 0.0, 0.0}, JZ_new[3][NZ];
+    if (active) eval_knot<N>(ch, P, t, qt, pc, Rc, exact, have_G, G_c, phi, cv, g, Dr, Z, !first, e_tgt, retract_tol(P, !first, pred, stat), e_new, JZ_new);
     // ---- neighbour coupling (k_couple) -----------------------------------------------------------------------
     double qm[N], qp[N], Zn[N][NZ];
 #pragma unroll
@@ -958,9 +1007,25 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
       }
       accept = true;
       first = false;
+    } else if (polish) {
+      accept = true;
+      polish = false;
     } else {
-      accept = lm_accept(P, f, feas, f_cur, pred, lm);
+      const LMState lm_before = lm;
+      accept = lm_accept(P, f, feas, f_cur, pred, stat, lm);
       if (!accept) ++n_reject;
+      if (!accept && feas_cur > 10.0 * P.tol_retract) {  // see step_instance: re-retract the accepted point before blaming the model
+        lm = lm_before;
+        polish = true;
+        pred = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) qt[j] = q_c[j];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) e_tgt[m] = e_c[m];
+        ++iters;
+        if (iters >= P.max_iter + 40) { status = OH_STATUS_MAX_ITER; break; }
+        continue;
+      }
     }
     if (accept) {
       f_cur = f;
@@ -979,6 +1044,12 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
       for (int i = 0; i < NZ * NZ; ++i) E_c[i] = E[i];
 #pragma unroll
       for (int a = 0; a < NZ; ++a) gt_c[a] = gt[a];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        e_c[m] = e_new[m];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) JZ_c[m][a] = JZ_new[m][a];
+      }
     }
     double mu = lm.mu;
     // ---- phase B: backward Riccati sweep, knot l's blocks broadcast to the whole wave --------------------------
@@ -1063,6 +1134,13 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
 #pragma unroll
       for (int a = 0; a < NZ; ++a) v += Z_c[j][a] * zmine[a];
       qt[j] = v;
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      double v = e_c[m];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) v += JZ_c[m][a] * zmine[a];
+      e_tgt[m] = v;
     }
     ++iters;
   }
@@ -1291,6 +1369,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
     D.cur[b] = 1 - slot;
     D.first[b] = 1;
     D.skip[b] = 0;
+    D.polish[b] = 0;
     D.status[b] = -1;
   }
 }

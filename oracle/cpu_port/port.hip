@@ -26,7 +26,7 @@ void carve(Workspace& w, const oh_problem_desc& d, const oh_chain* chain) {
   const int N = d.ndof, NZ = N - 3, T = d.T, Bp = 1;
   const size_t per_q = (size_t)T * N * Bp, per_Z = (size_t)T * N * NZ * Bp, per_Dr = (size_t)T * (NZ * (NZ + 1) / 2) * Bp, per_t = (size_t)T * Bp;
   size_t nd = 2 * per_q + 2 * per_Z + 2 * per_Dr + 2 * per_q + 4 * per_t + 2 * per_q + 2 * (size_t)T * NZ * NZ + 2 * (size_t)T * NZ + 2 * per_t +
-              (size_t)T * NZ + (size_t)T * NZ * NZ + (size_t)T * NZ + 12 + 7 + (size_t)4 * T + 64;
+              (size_t)T * NZ + (size_t)T * NZ * NZ + (size_t)T * NZ + 12 + 7 + (size_t)4 * T + 2 * (size_t)T * (3 + 3 * NZ) + 64;
   w.pool.assign(nd, 0.0);
   w.ipool.assign(16, 0);
   double* p = w.pool.data();
@@ -40,6 +40,7 @@ void carve(Workspace& w, const oh_problem_desc& d, const oh_chain* chain) {
   for (int s = 0; s < 2; ++s) D.phi[s] = take(per_t);
   for (int s = 0; s < 2; ++s) D.cv[s] = take(per_t);
   for (int s = 0; s < 2; ++s) D.Gfull[s] = take(per_q);
+  for (int s = 0; s < 2; ++s) D.mdl[s] = take((size_t)T * (3 + 3 * NZ));
   for (int s = 0; s < 2; ++s) D.E[s] = take((size_t)T * NZ * NZ);
   for (int s = 0; s < 2; ++s) D.gt[s] = take((size_t)T * NZ);
   for (int s = 0; s < 2; ++s) D.merit[s] = take(per_t);
@@ -51,7 +52,7 @@ void carve(Workspace& w, const oh_problem_desc& d, const oh_chain* chain) {
   D.fpsi = nullptr;
   D.lam_h = take((size_t)4 * T);
   int* ip = w.ipool.data();
-  D.cur = ip++; D.first = ip++; D.skip = ip++; D.status = ip++; D.iters = ip++; D.orig = ip++; D.newidx = ip++; D.n_running = ip++; D.n_new = ip++;
+  D.cur = ip++; D.first = ip++; D.skip = ip++; D.polish = ip++; D.status = ip++; D.iters = ip++; D.orig = ip++; D.newidx = ip++; D.n_running = ip++; D.n_new = ip++;
   D.work = w.work;
 }
 

@@ -292,18 +292,31 @@ def _orient(prob, Q, Rc):
     return c, M @ Jw
 
 
-def retract(prob, Q, Rc, tol=1e-10, max_corr=4):
-    """Newton corrections q_t <- q_t - Jc^T (Jc Jc^T)^{-1} c per knot (k_eval's loop)."""
+def retract(prob, Q, Rc, tol=1e-10, max_corr=4, e_tgt=None):
+    """Newton corrections per knot (k_eval's loop).  Without a target: q_t <- q_t - Jc^T (Jc Jc^T)^{-1} c, the minimum-norm way back
+    onto R(q_t) = Rc.  With e_tgt (T, 3), the end-effector positions the linear model of the step predicted: minimum-norm Newton steps
+    on the six rows [c(q); e(q) - e_tgt] = 0 (a second-order correction: the trial point follows the curved valley of the stiff
+    tracking cost instead of leaving it at second order, which is what kept the Gauss-Newton model honest only for tiny steps along
+    the redundant direction).  The loop still stops on the orientation rows alone."""
     Q = Q.copy()
     for _ in range(max_corr):
-        c, Jc = _orient(prob, Q, Rc)
+        e, Re, Jp, Jw = prob.chain.jac(Q)
+        A = Re @ Rc.T
+        c = _vee_skew(A)
+        trA = np.trace(A, axis1=1, axis2=2)
+        Jc = (0.5 * (trA[:, None, None] * np.eye(3)[None] - A)) @ Jw
         bad = np.where(np.max(np.abs(c), axis=1) > tol)[0]
         bad = bad[bad >= 2]
         if bad.size == 0:
             break
         for t in bad:
-            S = Jc[t] @ Jc[t].T + 1e-14 * np.eye(3)
-            Q[t] -= Jc[t].T @ np.linalg.solve(S, c[t])
+            if e_tgt is None:
+                S = Jc[t] @ Jc[t].T + 1e-14 * np.eye(3)
+                Q[t] -= Jc[t].T @ np.linalg.solve(S, c[t])
+            else:
+                J6 = np.vstack([Jc[t], Jp[t]])
+                S = J6 @ J6.T + 1e-10 * np.eye(6)
+                Q[t] -= J6.T @ np.linalg.solve(S, np.concatenate([c[t], e[t] - e_tgt[t]]))
     return Q
 
 
@@ -348,6 +361,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
     mu = mu0
     iters = rejected = 0
     first = True
+    polish = False
     Qt = retract(prob, Qc, Rc)
     lam = np.zeros((T, 3))
     cur = None
@@ -373,15 +387,23 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         f_t = float(np.sum(phi) + prob.smooth_cost(Qt))
         feas_t = float(np.max(np.abs(c[F])))
         # ---- k_step phase A
-        if first or (guard and outer):
+        polish_request = False
+        if first or (guard and outer) or polish:
             accept = True
             first = False
+            polish = False
             if guard:
                 outer = False
         else:
             rho = (cur["f"] - f_t) / max(pred, 1e-300)
             accept = np.isfinite(f_t) and (rho > 1e-4 or (pred <= 1e-15 * abs(cur["f"]) and f_t <= cur["f"] + 1e-14 * abs(cur["f"])))
-            if rule == "hip":
+            # a rejected trial against an accepted point that was retracted loosely: the accepted objective is off by (multiplier) x
+            # violation, and steps that predict less than that can never be accepted.  Re-evaluate the accepted point itself at the
+            # floor tolerance (zero step, accepted unconditionally) before blaming the model.
+            polish_request = (not accept) and cur["feas"] > 10.0 * min(1e-10, tol_feas)
+            if polish_request:
+                pass
+            elif rule == "hip":
                 if accept:
                     if rho > 0.75:
                         mu = mu * 0.2 if mu > 1e-6 else 0.0
@@ -408,6 +430,12 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                     mu = max(4.0 * mu, 1e-3)
             if not accept:
                 rejected += 1
+            if polish_request:
+                polish = True
+                Qt = retract(prob, cur["Q"], Rc, e_tgt=cur["e"])
+                pred = 0.0
+                iters += 1
+                continue
         if accept:
             Gs = np.zeros((T, n))
             d = Qt[2:] - Qt[1:-1]
@@ -427,6 +455,8 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                 "Dr": np.einsum("tia,tij,tjb->tab", Zs[F], Dfull[F], Zs[F]),
                 "Er": -2 * kap * np.einsum("tia,tib->tab", Zs[2 : T - 1], Zs[3:T]),
             }
+            e_acc, _, Jp_acc, _ = prob.chain.jac(Qt)
+            cur["e"], cur["JZ"] = e_acc, np.einsum("tmi,tia->tma", Jp_acc[F], Zs[F])
             if hessian != "gauss_newton":
                 for t in range(2, T):
                     lam[t] = -np.linalg.solve(Jc[t] @ Jc[t].T + 1e-14 * np.eye(3), Jc[t] @ G[t])
@@ -463,7 +493,13 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         pred = -0.5 * float(np.sum(cur["gt"] * z)) + 0.5 * mu * float(np.sum(z * z))
         Qt = cur["Q"].copy()
         Qt[F] += np.einsum("tia,ta->ti", cur["Z"][F], z)
-        Qt = retract(prob, Qt, Rc)
+        e_tgt = cur["e"].copy()
+        e_tgt[F] += np.einsum("tma,ta->tm", cur["JZ"], z)  # predicted end-effector positions: e + (Jp Z) z
+        # far from the solution the violation a trial point may keep is tied to the decrease its step predicts (retract_tol in oh_figure8.h)
+        tol_r = min(1e-10, tol_feas)
+        if stat > hyb_switch:
+            tol_r = min(1e-5, max(tol_r, 1e-3 * pred))
+        Qt = retract(prob, Qt, Rc, tol=tol_r, e_tgt=e_tgt)
         iters += 1
     out = {"Q": cur["Q"], "f": cur["f"] - cur["fpsi"], "iters": iters, "rejected": rejected, "stat": stat, "feas": cur["feas"], "status": status, "path": path, "Rc": Rc}
     if guard:

@@ -735,6 +735,7 @@ static void fill_params(oh_handle* h) {
   P.max_iter = d.max_iter;
   P.hessian = d.hessian;
   P.hyb_switch = 1e-5 * d.w_path;
+  if (const char* e = getenv("OH_HYB_SWITCH")) P.hyb_switch = atof(e) * d.w_path;  // experiments (tools/sweep_env.sh)
   P.mu0 = d.mu0;
   P.local_path = h->d_local_path;
   P.np = d.ndof + (h->have_guards ? h->guards.n_links + 4 * h->guards.n_obstacles : 0);

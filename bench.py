@@ -40,7 +40,10 @@ QC0_DEG = [0, 30, 0, -90, 0, -30, 0]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 # Algorithmic bytes per unit = (instance, free knot) per launch, f64:
-#   k_eval   : read q 7, V 18, z 4, model (e, Jp Z) 15 ; write q 7, V 18, Dr 10, g 7, phi 1, cv 1, model 15 = 103 doubles
+#   k_eval   : (two launches: k_retract leaves the retracted trial knot in HBM, k_evalb evaluates it; timed as one region)
+#              read q 7, V 18, z 4, model (e, Jp Z) 15 ; write q 7, V 18, Dr 10, g 7, phi 1, cv 1, model 15 = 103 doubles
+#              (the hand-over of the retracted knot between the two launches, 7 doubles written and read again, is traffic, not
+#               algorithmic bytes)
 #              (V: the three Householder vectors of the null-space basis, 3N - 3 doubles; Z itself is rebuilt in registers.
 #               model: end-effector position and Jp Z of the knot, what the next retraction's position target is predicted from)
 #   k_couple : read V_t 18 (V_{t+1} is an L2 hit), q 3x7, g 7, phi 1 ; write E 16, gt 4, merit 1 = 68 doubles
@@ -270,7 +273,7 @@ def main():
         "units_per_launch_avg": units / launches,
         "launches": launches,
         "all_kernels": per_kernel,
-        "note": "units = running instances x (T-2) summed over the batched launches; iterations run inside the persistent tail kernel are excluded from units and time alike",
+        "note": "units = running instances x (T-2) summed over the batched launches; iterations run inside the persistent tail kernel are excluded from units and time alike; k_eval is the pair of launches k_retract + k_evalb (rocprof lists them separately, profiles/*_kernel_stats.csv adds the pair)",
     }
     fk_achieved = nfk * BYTES_FKJAC / (fk_ms * 1e-3) / 1e9
     out = {

@@ -140,7 +140,12 @@ struct EvalNoHooks {
 // valley of the stiff tracking cost; without it the model is honest only for tiny steps along the redundant direction and the slow
 // half of the instances crawls: mean 30 -> 16 steps).  e_out, JZ_out = e and Jp Z of this knot, the next step's prediction data.
 // tol_r: retraction tolerance of this evaluation (retract_tol below).
-template <int N, bool LEAD = false, class Hooks = EvalNoHooks>
+// MODE: the batched path runs the knot in two kernels so that each fits two waves per SIMD (fused, the retraction loop with the
+// six-row step needs ~350 live registers): EVAL_RETRACT_ONLY stops after the loop (q through hooks.q_final), EVAL_ONLY takes q as
+// retracted and is the loop's last pass plus everything after it.  Same code, same inputs: the pair is bit-identical to EVAL_FUSED
+// (tail kernel, guarded / lead variants, host port).
+enum { EVAL_FUSED = 0, EVAL_RETRACT_ONLY = 1, EVAL_ONLY = 2 };
+template <int N, bool LEAD = false, class Hooks = EvalNoHooks, int MODE = EVAL_FUSED>
 OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const int t, double (&q)[N], const double (&pc)[3],
                       const double (&Rc)[9], const bool exact, const bool have_G, const double (&Gprev)[N], double& phi, double& cv, double (&g)[N],
                       double (&Dr)[(N - 3) * (N - 2) / 2], double (&Z)[N][N - 3], const bool have_tgt, const double (&e_tgt)[3], const double tol_r,
@@ -156,7 +161,8 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
     mm3(R, ch->R_tool, Re);
     orient_residual(Re, Rc, c, M);
     cmax = fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2])));
-    if (cmax <= tol_r || it >= P.max_retract) break;
+    if (MODE == EVAL_ONLY || cmax <= tol_r || it >= P.max_retract) break;
+    if constexpr (MODE != EVAL_ONLY) {
     // Newton correction q <- q - Jc^T (Jc Jc^T)^{-1} c,  Jc = M Jw,  Jw[:,k] = z_k (revolute) / 0
     double Jc[N][3];
 #pragma unroll
@@ -228,9 +234,15 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
 #pragma unroll
       for (int k = 0; k < N; ++k) q[k] -= dot3(Jc[k], y);
     }
+    }
   }
   cv = cmax;
   hooks.q_final(q);
+  if constexpr (MODE == EVAL_RETRACT_ONLY) {
+    phi = 0.0;
+    e_out[0] = e_out[1] = e_out[2] = 0.0;
+    return;
+  }
 
   // end-effector position, tracking residual
   double e[3], tv[3];

@@ -327,7 +327,7 @@ OH_DEV void load_householder(const double* __restrict__ Vs, const int Bp, const 
 // K2: one lane per (instance b, free knot t): trial knot, retraction onto R(q_t)=Rc, FK chain + Jacobians,
 // tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block
 // (eval_knot in oh_figure8.h).
-template <int N, bool GUARD = false, bool LEAD = false>
+template <int N, bool GUARD = false, bool LEAD = false, int MODE = EVAL_FUSED>
 OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, const int b, const int t, const GuardParams* GPp = nullptr,
                       const GuardBuffers* GBp = nullptr) {
   constexpr int NZ = N - 3;
@@ -343,7 +343,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   const bool first = D.first[b] != 0;
   // trial knot: the seed on the first evaluation, otherwise q_cur + Z_cur z (roll-out of the step k_step solved for)
   double q[N], e_tgt[3] = {0.0, 0.0, 0.0};
-  if (first) {
+  if (first || MODE == EVAL_ONLY) {  // EVAL_ONLY: the retracted trial knot is already in the slot (k_retract)
 #pragma unroll
     for (int j = 0; j < N; ++j) q[j] = D.q[slot][IDX(t, N, j)];
   } else {
@@ -394,7 +394,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
     const double* __restrict__ Gc;
     int Bp, b, t;
     OH_DEV void q_final(const double (&qv)[N]) const {
-      if constexpr (!GUARD) {
+      if constexpr (!GUARD && MODE != EVAL_ONLY) {
 #pragma unroll
         for (int j = 0; j < N; ++j) qo[IDX(t, N, j)] = qv[j];
       }
@@ -420,8 +420,10 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   double e_new[3], JZ_new[3][NZ];
   const double tol_r = retract_tol(P, !first, D.pred[b], D.stat[b]);
   if constexpr (LEAD)
-    eval_knot<N, true, Hooks>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new, D.lead[(size_t)t * Bp + b], hooks);
-  else eval_knot<N, false, Hooks>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new, 0.0, hooks);
+    eval_knot<N, true, Hooks, MODE>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new,
+                                    D.lead[(size_t)t * Bp + b], hooks);
+  else eval_knot<N, false, Hooks, MODE>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new, 0.0, hooks);
+  if constexpr (MODE == EVAL_RETRACT_ONLY) return;  // q is in the slot; everything else is k_evalb's
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
     D.mdl[slot][IDX(t, MDL_ROWS(N), m)] = e_new[m];
@@ -529,6 +531,17 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
 template <int N>
 __global__ __launch_bounds__(256, OH_EVAL_WAVES) void k_eval(FigParams P, FigBuffers D, const int slot) {
   eval_unit<N>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+}
+// The same knot in two launches, each at two waves per SIMD (see EVAL_RETRACT_ONLY / EVAL_ONLY in oh_figure8.h): k_retract leaves the
+// retracted trial knot in the slot, k_evalb evaluates it.  One kinematics pass more than fused, both kernels without the register
+// overflow of the fused loop.
+template <int N>
+__global__ __launch_bounds__(256, 2) void k_retract(FigParams P, FigBuffers D, const int slot) {
+  eval_unit<N, false, false, EVAL_RETRACT_ONLY>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+}
+template <int N>
+__global__ __launch_bounds__(256, 2) void k_evalb(FigParams P, FigBuffers D, const int slot) {
+  eval_unit<N, false, false, EVAL_ONLY>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
 }
 // chains with a parameterised lead joint (RobotModel(param_joints=[first joint]), figure_eight_plan_6dof.py): same evaluation
 // from the frame that follows the lead joint at the knot's parameter angle
@@ -1406,7 +1419,12 @@ static void launch_setup_t(hipStream_t s, const FigParams& P, const FigBuffers& 
 }
 template <int N>
 static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
+#if defined(OH_EVAL_FUSED)
   hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
+#else
+  hipLaunchKernelGGL(k_retract<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
+  hipLaunchKernelGGL(k_evalb<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
+#endif
 }
 template <int N>
 static void launch_couple_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {

@@ -17,7 +17,7 @@ import os
 import sqlite3
 import sys
 
-NAMES = ("k_eval", "k_couple", "k_step", "k_fk_jac", "k_setup", "k_finalize", "k_compact_gather", "k_compact_scatter", "k_scan_running")
+NAMES = ("k_retract", "k_evalb", "k_eval", "k_couple", "k_step", "k_fk_jac", "k_setup", "k_finalize", "k_compact_gather", "k_compact_scatter", "k_scan_running")
 
 
 def short(name: str) -> str:
@@ -42,6 +42,12 @@ def main(root, tag):
             w.writerow(["kernel", "calls", "total_us", "avg_us", "pct"])
             for name, calls, tot, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
                 w.writerow([short(name), calls, f"{tot:.1f}", f"{avg:.2f}", f"{pct:.2f}"])
+            pair = {n: (calls, tot) for n, calls, tot in ((short(n), c_, t_) for n, c_, t_, _, _ in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels")) if n in ("k_retract", "k_evalb")}
+            if len(pair) == 2:
+                calls = pair["k_retract"][0]
+                tot = pair["k_retract"][1] + pair["k_evalb"][1]
+                w.writerow(["# k_eval = the pair k_retract + k_evalb (one evaluation of the trial knots; what bench.py times as k_eval)"])
+                w.writerow(["k_eval (pair)", calls, f"{tot:.1f}", f"{tot / max(calls, 1):.2f}", ""])
             w.writerow([])
             w.writerow(["# per grid size (x dimension = instances still in the batch, or units for k_fk_jac)"])
             w.writerow(["kernel", "grid_x", "calls", "avg_us", "min_us", "max_us", "vgpr", "agpr", "sgpr", "scratch"])
@@ -80,6 +86,10 @@ def main(root, tag):
                 e["bytes_per_launch_raw"] = (fs + ws) * 1024.0
                 e["bytes_per_launch"] = (2.0 * fs + ws) * 1024.0
             summary[k] = e
+        if "k_eval" not in summary and "k_retract" in summary and "k_evalb" in summary:
+            a, b = summary["k_retract"], summary["k_evalb"]
+            summary["k_eval"] = {k: (a[k] + b[k]) if a.get(k) is not None and b.get(k) is not None else None for k in a}
+            summary["k_eval"]["note"] = "k_retract + k_evalb: the two launches of one trial-knot evaluation"
         json.dump(
             {"tag": tag, "note": "average per launch over the profiled bench run (all batch sizes the run went through); FETCH_SIZE doubled per MI355X_MICROARCH.md", "kernels": pmc, "summary": summary},
             open(f"profiles/{tag}_pmc.json", "w"),

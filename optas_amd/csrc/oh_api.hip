@@ -86,6 +86,7 @@ struct oh_handle {
   double tail_iters = 0;
   int* h_flag = nullptr;  // pinned
   bool compaction = true;
+  double compact_frac = 0.8;  // compact the batch once this fraction of it (or less) is still running (sweep on MI355X: 0.5 1.19M, 0.6 1.30M, 0.8 1.32M, 0.9 1.27M solves/s)
   int tail_threshold = 2048;  // hand the last instances to the persistent one-wave-per-instance kernel
   std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
 };
@@ -174,6 +175,7 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (h->desc.mu0 < 0.0) h->desc.mu0 = 0.0;
   if (const char* e2 = getenv("OH_TAIL_THRESHOLD")) h->tail_threshold = atoi(e2);
   if (const char* e3 = getenv("OH_COMPACTION")) h->compaction = atoi(e3) != 0;
+  if (const char* e4 = getenv("OH_COMPACT_FRAC")) h->compact_frac = atof(e4);
   hipGetDevice(&h->device);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
       hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->evt0) != hipSuccess ||
@@ -796,9 +798,10 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   double* ox = (double*)d_x; double* of = (double*)d_f; double* ok = (double*)d_kkt;
   int* oi = (int*)d_iters; int* os = (int*)d_status;
   // Every instance needs at most max_iter steps (accepted + rejected) plus its first evaluation; each
-  // compaction re-evaluates the survivors once.  The batch is compacted whenever at least half of it has
-  // finished, so the slow tail keeps running in full wavefronts.
-  const int hard_cap = 2 * h->desc.max_iter + 2 + 40;  // a rejected step costs two launches
+  // compaction re-evaluates the survivors once.  The batch is compacted whenever a fifth of it has finished
+  // (compact_frac), so that the lanes of finished instances do not ride along for long: ~19 compactions from
+  // 131 072 instances down to the hand-over to the tail kernel.
+  const int hard_cap = 2 * h->desc.max_iter + 2 + 40 + 64;  // a rejected step costs two launches, a compaction one
   const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation && !guarded && !lead;
   bool tail_done = false;
   if (tail_ok && B <= h->tail_threshold) {  // small batch: the whole solve is one persistent launch
@@ -848,7 +851,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
         tail_done = true;
         break;
       }
-      if (h->compaction && !guarded && !lead && h->D.B >= 512 && 2 * nrun <= h->D.B) {
+      if (h->compaction && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
         oh_launch_scan_running(s, h->D);
         oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);

@@ -7,7 +7,10 @@ from optas_amd.builder import OptimizationBuilder
 from optas_amd.expr import path_in_frame, sumsqr
 from optas_amd.solver import HIPSolver
 
-from .figure_eight_plan import figure_eight_local_path
+try:
+    from .figure_eight_plan import figure_eight_local_path
+except ImportError:  # run as a script: python examples/figure_eight_plan_6dof.py
+    from figure_eight_plan import figure_eight_local_path
 
 
 def setup_solver(link_ee="end_effector_ball", T=50, Tmax=10.0, solver_options=None, build_only=False):

@@ -86,6 +86,7 @@ struct oh_handle {
   double tail_iters = 0;
   int* h_flag = nullptr;  // pinned
   bool compaction = true;
+  int compact_sort = 1;      // order the survivors of a compaction by progress (k_scan_running)
   double compact_frac = 0.8;  // compact the batch once this fraction of it (or less) is still running (sweep on MI355X: 0.5 1.19M, 0.6 1.30M, 0.8 1.32M, 0.9 1.27M solves/s)
   int tail_threshold = 2048;  // hand the last instances to the persistent one-wave-per-instance kernel
   std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
@@ -176,6 +177,7 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (const char* e2 = getenv("OH_TAIL_THRESHOLD")) h->tail_threshold = atoi(e2);
   if (const char* e3 = getenv("OH_COMPACTION")) h->compaction = atoi(e3) != 0;
   if (const char* e4 = getenv("OH_COMPACT_FRAC")) h->compact_frac = atof(e4);
+  if (const char* e5 = getenv("OH_COMPACT_SORT")) h->compact_sort = atoi(e5);
   hipGetDevice(&h->device);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
       hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->evt0) != hipSuccess ||
@@ -842,7 +844,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       if (tail_ok && nrun <= h->tail_threshold) {
         // drain: compact the survivors and let one wavefront per instance finish them without further launches
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
-        oh_launch_scan_running(s, h->D);
+        oh_launch_scan_running(s, h->D, h->compact_sort);
         oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
         oh_launch_compact(s, N, h->P, h->D, 1, nrun, (it + 1) & 1);
         h->D.B = nrun;
@@ -853,7 +855,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       }
       if (h->compaction && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
-        oh_launch_scan_running(s, h->D);
+        oh_launch_scan_running(s, h->D, h->compact_sort);
         oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
         oh_launch_compact(s, N, h->P, h->D, 1, nrun, (it + 1) & 1);
         h->D.B = nrun;

@@ -112,7 +112,7 @@ bool oh_launch_step_locked_guarded(hipStream_t s, int n, const FigParams& P, con
 bool oh_launch_tail(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
                         int* iters, int* status);
-void oh_launch_scan_running(hipStream_t s, const FigBuffers& D);
+void oh_launch_scan_running(hipStream_t s, const FigBuffers& D, int sort);
 bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot);
 
 // ---- OH_PROBLEM_POINT_MASS_MPC ---------------------------------------------------------------------------

@@ -1302,28 +1302,67 @@ __global__ __launch_bounds__(256) void k_finalize(FigParams P, FigBuffers D, int
 
 #ifndef OH_HOST_PORT
 // ---- batch compaction: drop finished instances so that the tail of slow instances keeps full waves ----
-// newidx[b] = rank of b among the running instances (or -1); single block, deterministic.
-__global__ __launch_bounds__(1024) void k_scan_running(FigBuffers D) {
-  __shared__ int cnt[1024];
+// newidx[b] = new position of b among the running instances (or -1); single block, deterministic.  With sort != 0 the survivors are
+// ordered by how far they still are from a stationary point (binary exponent of the reduced gradient, 8 classes, stable within a class):
+// instances that will finish at about the same time share wavefronts, so whole waves retire between compactions instead of riding
+// along with a few live lanes, and the lanes of a wave run similar numbers of retraction passes.
+__global__ __launch_bounds__(1024) void k_scan_running(FigBuffers D, const int sort) {
+  constexpr int NB = 8;
+  __shared__ int cnt[NB][1024];
+  __shared__ int base[NB + 1];
   const int tid = threadIdx.x;
   const int per = (D.B + 1023) / 1024;
   const int lo = tid * per, hi = min(D.B, lo + per);
-  int c = 0;
-  for (int b = lo; b < hi; ++b) c += (D.status[b] < 0);
-  cnt[tid] = c;
+  auto bucket = [&](const int b) {
+    if (!sort) return 0;
+    int e = 0;
+    frexp(D.stat[b], &e);
+    const int k = (e + 24) / 4;
+    return k < 0 ? 0 : (k > NB - 1 ? NB - 1 : k);
+  };
+  int c[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) c[k] = 0;
+  for (int b = lo; b < hi; ++b)
+    if (D.status[b] < 0) {
+      const int kb = bucket(b);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) c[k] += (k == kb);
+    }
+#pragma unroll
+  for (int k = 0; k < NB; ++k) cnt[k][tid] = c[k];
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
-    int v = (tid >= off) ? cnt[tid - off] : 0;
+    int v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) v[k] = (tid >= off) ? cnt[k][tid - off] : 0;
     __syncthreads();
-    cnt[tid] += v;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) cnt[k][tid] += v[k];
     __syncthreads();
   }
-  int base = cnt[tid] - c;
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = 0; k < NB; ++k) { base[k] = acc; acc += cnt[k][1023]; }
+    base[NB] = acc;
+    *D.n_new = acc;
+  }
+  __syncthreads();
+  int pos[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) pos[k] = base[k] + cnt[k][tid] - c[k];
   for (int b = lo; b < hi; ++b) {
-    if (D.status[b] < 0) D.newidx[b] = base++;
-    else D.newidx[b] = -1;
+    if (D.status[b] < 0) {
+      const int kb = bucket(b);
+      int p = 0;
+#pragma unroll
+      for (int k = 0; k < NB; ++k)
+        if (k == kb) p = pos[k]++;
+      D.newidx[b] = p;
+    } else {
+      D.newidx[b] = -1;
+    }
   }
-  if (tid == 1023) *D.n_new = cnt[1023];
 }
 
 // gather the persistent state of running instances (accepted knots + a few scalars) into scratch ...
@@ -1494,7 +1533,7 @@ bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffe
 #undef C
   return true;
 }
-void oh_launch_scan_running(hipStream_t s, const FigBuffers& D) { hipLaunchKernelGGL(k_scan_running, dim3(1), dim3(1024), 0, s, D); }
+void oh_launch_scan_running(hipStream_t s, const FigBuffers& D, int sort) { hipLaunchKernelGGL(k_scan_running, dim3(1), dim3(1024), 0, s, D, sort); }
 bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {
 #define C(NN) launch_compact_t<NN>(s, P, D, phase, Bnew, slot)
   OH_DISPATCH_N(n, C)

@@ -1317,7 +1317,11 @@ __global__ __launch_bounds__(1024) void k_scan_running(FigBuffers D, const int s
     if (!sort) return 0;
     int e = 0;
     frexp(D.stat[b], &e);
-    const int k = (e + 24) / 4;
+#ifndef OH_SORT_SHIFT
+#define OH_SORT_SHIFT 24
+#define OH_SORT_WIDTH 4
+#endif
+    const int k = (e + OH_SORT_SHIFT) / OH_SORT_WIDTH;
     return k < 0 ? 0 : (k > NB - 1 ? NB - 1 : k);
   };
   int c[NB];

@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=131072, help="instances per GPU per step (SURVEY 8(d): B in {256, 4096, 65536})")
+    ap.add_argument("--batch", type=int, default=262144, help="instances per GPU per step (SURVEY 8(d): B in {256, 4096, 65536})")
     ap.add_argument("--max-iter", type=int, default=300)
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--hessian", choices=["gauss_newton", "exact", "hybrid"], default="hybrid")

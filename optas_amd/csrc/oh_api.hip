@@ -86,7 +86,7 @@ struct oh_handle {
   double tail_iters = 0;
   int* h_flag = nullptr;  // pinned
   bool compaction = true;
-  int compact_sort = 1;      // order the survivors of a compaction by progress (k_scan_running)
+  int compact_sort = 1;      // order the survivors of a compaction by progress (k_scan_*)
   double compact_frac = 0.8;  // compact the batch once this fraction of it (or less) is still running (sweep on MI355X: 0.5 1.19M, 0.6 1.30M, 0.8 1.32M, 0.9 1.27M solves/s)
   int tail_threshold = 2048;  // hand the last instances to the persistent one-wave-per-instance kernel
   std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
@@ -585,7 +585,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   nd += (size_t)12 * Bp + 7 * (size_t)Bp;
   nd += (size_t)4 * T * Bp;  // lam_h
   nd += per_t;               // lead-joint angles
-  size_t ni = 8 * (size_t)Bp + 32;  // + n_running, n_new, work (8-byte aligned)
+  size_t ni = 8 * (size_t)Bp + 32 + 8 * 1024;  // + n_running, n_new, work (8-byte aligned)
   size_t bytes = nd * sizeof(double) + ni * sizeof(int);
   void* pool = nullptr;
   hipError_t e = hipMalloc(&pool, bytes);
@@ -640,7 +640,8 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.newidx = ip; ip += Bp;
   D.n_running = ip; ip += 1;
   D.n_new = ip; ip += 1;
-  D.work = (unsigned long long*)ip;
+  D.work = (unsigned long long*)ip; ip += 28;
+  D.scan_blk = ip;
   return OH_OK;
 }
 

@@ -82,6 +82,7 @@ struct FigBuffers {
   double* lead;           // [T][Bp] angle of the parameterised lead joint at every knot (nullptr: chain has none)
   int* cur;               // [Bp] slot holding the accepted point
   int* first;             // [Bp]
+  int* scan_blk;          // [8][1024] per-block class counts / offsets of the compaction scan
   int* skip;              // [Bp] 1: last trial rejected -> sit the next launch out (keeps the slot parity uniform)
   int* polish;            // [Bp] 1: the next evaluation re-retracts the accepted point itself (zero step, floor tolerance) and is accepted as is
   int* status;            // [Bp] -1 running, else OH_STATUS_*

@@ -797,7 +797,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (prof) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(0); }
   int launched = 0;
   int compactions = 0;
-  const int check_every = (B <= 64) ? 1 : 2;
+  int check_every = (B <= 64) ? 1 : 2;
+  if (const char* ce = getenv("OH_CHECK_EVERY")) check_every = atoi(ce) > 0 ? atoi(ce) : check_every;  // experiments
   double* ox = (double*)d_x; double* of = (double*)d_f; double* ok = (double*)d_kkt;
   int* oi = (int*)d_iters; int* os = (int*)d_status;
   // Every instance needs at most max_iter steps (accepted + rejected) plus its first evaluation; each

@@ -86,8 +86,9 @@ struct oh_handle {
   double tail_iters = 0;
   int* h_flag = nullptr;  // pinned
   bool compaction = true;
+  int compact_carry = 1;     // compaction carries the pending trial along instead of restarting the survivors (k_carry_*)
   int compact_sort = 1;      // order the survivors of a compaction by progress (k_scan_*)
-  double compact_frac = 0.8;  // compact the batch once this fraction of it (or less) is still running (sweep on MI355X: 0.5 1.19M, 0.6 1.30M, 0.8 1.32M, 0.9 1.27M solves/s)
+  double compact_frac = 0.9;  // compact the batch once this fraction of it (or less) is still running
   int tail_threshold = 2048;  // hand the last instances to the persistent one-wave-per-instance kernel
   std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
 };
@@ -178,6 +179,7 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (const char* e3 = getenv("OH_COMPACTION")) h->compaction = atoi(e3) != 0;
   if (const char* e4 = getenv("OH_COMPACT_FRAC")) h->compact_frac = atof(e4);
   if (const char* e5 = getenv("OH_COMPACT_SORT")) h->compact_sort = atoi(e5);
+  if (const char* e6 = getenv("OH_COMPACT_CARRY")) h->compact_carry = atoi(e6);
   hipGetDevice(&h->device);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
       hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->evt0) != hipSuccess ||
@@ -585,7 +587,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   nd += (size_t)12 * Bp + 7 * (size_t)Bp;
   nd += (size_t)4 * T * Bp;  // lam_h
   nd += per_t;               // lead-joint angles
-  size_t ni = 8 * (size_t)Bp + 32 + 8 * 1024;  // + n_running, n_new, work (8-byte aligned)
+  size_t ni = 9 * (size_t)Bp + 32 + 8 * 1024;  // + n_running, n_new, work (8-byte aligned)
   size_t bytes = nd * sizeof(double) + ni * sizeof(int);
   void* pool = nullptr;
   hipError_t e = hipMalloc(&pool, bytes);
@@ -634,6 +636,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.first = ip; ip += Bp;
   D.skip = ip; ip += Bp;
   D.polish = ip; ip += Bp;
+  D.stale = ip; ip += Bp;
   D.status = ip; ip += Bp;
   D.iters = ip; ip += Bp;
   D.orig = ip; ip += Bp;
@@ -797,14 +800,14 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (prof) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(0); }
   int launched = 0;
   int compactions = 0;
-  int check_every = (B <= 64) ? 1 : 2;
+  int check_every = 1;  // one small D2H read per iteration: with the cheap compaction timely decisions beat the saved round trips (every 2nd: -1.5 %)
   if (const char* ce = getenv("OH_CHECK_EVERY")) check_every = atoi(ce) > 0 ? atoi(ce) : check_every;  // experiments
   double* ox = (double*)d_x; double* of = (double*)d_f; double* ok = (double*)d_kkt;
   int* oi = (int*)d_iters; int* os = (int*)d_status;
   // Every instance needs at most max_iter steps (accepted + rejected) plus its first evaluation; each
-  // compaction re-evaluates the survivors once.  The batch is compacted whenever a fifth of it has finished
-  // (compact_frac), so that the lanes of finished instances do not ride along for long: ~19 compactions from
-  // 131 072 instances down to the hand-over to the tail kernel.
+  // plain compaction re-evaluates the survivors once.  The batch is compacted whenever a tenth of it has finished (compact_frac);
+  // the regular compactions carry the pending trial along and cost no evaluation (k_carry_*), the hand-over to the tail kernel
+  // restarts the survivors.
   const int hard_cap = 2 * h->desc.max_iter + 2 + 40 + 64;  // a rejected step costs two launches, a compaction one
   const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation && !guarded && !lead;
   bool tail_done = false;
@@ -813,6 +816,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     tail_done = true;
   }
   bool rebase = false;
+  int carry_pending = 0;  // > 0: survivors to compact the batch to, between k_retract and k_evalb of the next iteration
   for (int it = 0; it < hard_cap && !tail_done; ++it) {
     if (prof && rebase && ne + 3 < h->prof_events.size()) {  // host synced: do not bill the idle gap to the eval kernel
       HIPCHK(hipEventRecord(h->prof_events[ne++], s));
@@ -822,7 +826,20 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     const int slot = it & 1;
     if (h->P.lock && guarded) oh_launch_eval_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else if (lead) oh_launch_eval_lead(s, N, h->P, h->D, slot);
-    else if (h->P.lock) oh_launch_eval(s, N, h->P, h->D, slot);
+    else if (h->P.lock && carry_pending > 0) {
+      // compaction with the trial carried along: retract on the old layout, move, evaluate on the dense one (k_carry_* in oh_kernels.hip)
+      oh_launch_eval(s, N, h->P, h->D, slot, 1);
+      if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(4); }
+      oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
+      oh_launch_scan_running(s, h->D, h->compact_sort);
+      oh_launch_carry(s, N, h->P, h->D, 0, 0, slot);
+      oh_launch_carry(s, N, h->P, h->D, 1, carry_pending, slot);
+      h->D.B = carry_pending;
+      carry_pending = 0;
+      ++compactions;
+      if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(0); }
+      oh_launch_eval(s, N, h->P, h->D, slot, 2);
+    } else if (h->P.lock) oh_launch_eval(s, N, h->P, h->D, slot);
     else if (guarded) oh_launch_eval_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else oh_launch_eval_free(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(1); }
@@ -855,7 +872,9 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
         tail_done = true;
         break;
       }
-      if (h->compaction && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
+      if (h->compaction && h->compact_carry && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
+        carry_pending = nrun;  // done after the next k_retract
+      } else if (h->compaction && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
         oh_launch_scan_running(s, h->D, h->compact_sort);
         oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
@@ -891,6 +910,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       float ms2 = 0.f;
       hipEventElapsedTime(&ms2, h->prof_events[i - 1], h->prof_events[i]);
       if (tag == 1) { te += ms2; ++n_e; }
+      else if (tag == 4) { te += ms2; }
       else if (tag == 3) { tc += ms2; }
       else { tsx += ms2; ++n_s; }
     }

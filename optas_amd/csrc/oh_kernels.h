@@ -85,6 +85,7 @@ struct FigBuffers {
   int* scan_blk;          // [8][1024] per-block class counts / offsets of the compaction scan
   int* skip;              // [Bp] 1: last trial rejected -> sit the next launch out (keeps the slot parity uniform)
   int* polish;            // [Bp] 1: the next evaluation re-retracts the accepted point itself (zero step, floor tolerance) and is accepted as is
+  int* stale;             // [Bp] 1: the accepted point's stage data was left behind by a compaction (k_carry_*); a rejected trial restarts
   int* status;            // [Bp] -1 running, else OH_STATUS_*
   int* iters;             // [Bp]
   int* orig;              // [Bp] original instance index (instances are compacted as the batch drains)
@@ -98,7 +99,8 @@ struct FigBuffers {
 bool oh_launch_rnea(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, int n, const double* q, const double* qd, const double* qdd, double* tau);
 void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n, const double* q, double* pose, double* J);
 bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const double* x0, const double* p);
-bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot, int part = 0);
+bool oh_launch_carry(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot);
 bool oh_launch_eval_lead(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);

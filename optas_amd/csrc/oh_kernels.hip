@@ -298,6 +298,7 @@ OH_DEV void setup_unit(const FigParams& P, const FigBuffers& D, const double* __
   D.first[b] = 1;
   D.skip[b] = 0;
   D.polish[b] = 0;
+  D.stale[b] = 0;
   D.orig[b] = b;
   D.status[b] = -1;  // running
   D.iters[b] = 0;
@@ -674,11 +675,28 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       // A rejected trial against an accepted point that was retracted loosely (retract_tol): its objective is off by (multiplier) x
       // violation, and steps that predict less than that can never be accepted.  Before blaming the model, re-evaluate the accepted
       // point at the floor tolerance: zero step, accepted unconditionally at the next k_step.
-      polish_request = !accept && D.feas[b] > 10.0 * P.tol_retract;
+      polish_request = !accept && !D.stale[b] && D.feas[b] > 10.0 * P.tol_retract;
       if (polish_request) lm = lm_before;
       D.nun[b] = lm.nun;
     }
+    if (!accept && D.stale[b]) {
+      // the accepted point's stage data did not survive the last compaction (k_carry_*): restart from its knots, which wait in the
+      // next trial slot; the rejection has updated the LM state, the step is re-derived (and counted) at the restart
+      D.stale[b] = 0;
+      D.first[b] = 1;
+      D.polish[b] = 0;
+      D.mu[b] = lm.mu;
+      D.nun[b] = lm.nun;
+      D.cur[b] = cur;
+#if defined(__HIP_DEVICE_COMPILE__)
+      atomicAdd(D.work + 1, 1ULL);
+#else
+      D.work[1] += 1ULL;
+#endif
+      return true;
+    }
     if (accept) {
+      D.stale[b] = 0;
       cur = ts;
       D.f_cur[b] = f;
       D.feas[b] = feas;
@@ -1455,6 +1473,89 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
     D.first[b] = 1;
     D.skip[b] = 0;
     D.polish[b] = 0;
+    D.stale[b] = 0;
+    D.status[b] = -1;
+  }
+}
+
+// ---- compaction that carries the pending trial along (between k_retract and k_evalb of an iteration) -------------------------------
+// The restart above costs the survivors one evaluation (their pending step is re-derived).  Here the retracted trial knots move with
+// the instance, so the iteration simply continues on the dense batch: per knot the trial q, the accepted q (the fall-back point) and
+// the Lagrangian gradient of the accepted point, per instance the scalars of the ratio test and the LM state.  What does not move is
+// the rest of the accepted point's stage data (V, Dr, E, gt, model): it is only needed again if this very trial is rejected (1-2 %);
+// such an instance is flagged `stale` and, if rejected, restarts from its accepted q like after a plain compaction.
+// Instances that sit the launch out (skip) or are at a restart point (first) have no trial: q[slot] is their accepted point, they restart.
+template <int N>
+__global__ __launch_bounds__(256) void k_carry_gather(FigParams P, FigBuffers D, const int slot) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  const int nb = D.newidx[b];
+  if (nb < 0) return;
+  const bool restart = D.skip[b] != 0 || D.first[b] != 0;
+  const int cur = restart ? slot : 1 - slot;
+  double* __restrict__ t_trial = D.Z[0];                                // scratch rows [t][0..N)
+  double* __restrict__ t_cur = D.Z[0] + (size_t)P.T * N * Bp;           // scratch rows (needs 2 N <= 3 N - 3)
+  double* __restrict__ t_G = D.Z[1];
+  double* __restrict__ ts = D.Dr[1];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    t_trial[((size_t)t * N + j) * Bp + nb] = D.q[slot][IDX(t, N, j)];
+    t_cur[((size_t)t * N + j) * Bp + nb] = D.q[cur][IDX(t, N, j)];
+    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) t_G[((size_t)t * N + j) * Bp + nb] = D.Gfull[cur][IDX(t, N, j)];
+  }
+  if (t == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) ts[(size_t)i * Bp + nb] = D.ref[(size_t)i * Bp + b];
+    ts[(size_t)12 * Bp + nb] = D.fconst[b];
+    ts[(size_t)13 * Bp + nb] = D.mu[b];
+    ts[(size_t)14 * Bp + nb] = (double)(D.iters[b] - ((D.skip[b] != 0 && D.first[b] == 0) ? 1 : 0));  // a skipping instance re-derives its step
+    ts[(size_t)15 * Bp + nb] = (double)D.orig[b];
+    ts[(size_t)16 * Bp + nb] = D.nun[b];
+    ts[(size_t)17 * Bp + nb] = D.f_cur[b];
+    ts[(size_t)18 * Bp + nb] = D.pred[b];
+    ts[(size_t)19 * Bp + nb] = D.stat[b];
+    ts[(size_t)20 * Bp + nb] = D.feas[b];
+    ts[(size_t)21 * Bp + nb] = (double)((restart ? 1 : 0) + 2 * (D.polish[b] != 0 ? 1 : 0));
+  }
+}
+template <int N>
+__global__ __launch_bounds__(256) void k_carry_scatter(FigParams P, FigBuffers D, int Bnew, const int slot) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  const int Bp = D.Bp;
+  if (b >= Bnew) return;
+  const double* __restrict__ t_trial = D.Z[0];
+  const double* __restrict__ t_cur = D.Z[0] + (size_t)P.T * N * Bp;
+  const double* __restrict__ t_G = D.Z[1];
+  const double* __restrict__ ts = D.Dr[1];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    D.q[slot][IDX(t, N, j)] = t_trial[IDX(t, N, j)];
+    D.q[1 - slot][IDX(t, N, j)] = t_cur[IDX(t, N, j)];
+    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) D.Gfull[1 - slot][IDX(t, N, j)] = t_G[IDX(t, N, j)];
+  }
+  if (t == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) D.ref[(size_t)i * Bp + b] = ts[(size_t)i * Bp + b];
+    const int flags = (int)ts[(size_t)21 * Bp + b];
+    const bool restart = (flags & 1) != 0;
+    D.fconst[b] = ts[(size_t)12 * Bp + b];
+    D.mu[b] = ts[(size_t)13 * Bp + b];
+    const int it = (int)ts[(size_t)14 * Bp + b];
+    D.iters[b] = it > 0 ? it : 0;
+    D.orig[b] = (int)ts[(size_t)15 * Bp + b];
+    D.nun[b] = restart ? 2.0 : ts[(size_t)16 * Bp + b];
+    D.f_cur[b] = ts[(size_t)17 * Bp + b];
+    D.pred[b] = ts[(size_t)18 * Bp + b];
+    D.stat[b] = ts[(size_t)19 * Bp + b];
+    D.feas[b] = ts[(size_t)20 * Bp + b];
+    D.cur[b] = 1 - slot;
+    D.first[b] = restart ? 1 : 0;
+    D.skip[b] = 0;
+    D.polish[b] = (!restart && (flags & 2)) ? 1 : 0;
+    D.stale[b] = restart ? 0 : 1;
     D.status[b] = -1;
   }
 }
@@ -1490,13 +1591,19 @@ static void launch_setup_t(hipStream_t s, const FigParams& P, const FigBuffers& 
   hipLaunchKernelGGL(k_setup<N>, dim3(D.Bp / 64), dim3(64), 0, s, P, D, x0, p);
 }
 template <int N>
-static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
+static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot, int part) {
+  // part 0: the whole evaluation; 1: k_retract only; 2: k_evalb only (the compaction that carries the trial along sits between them)
 #if defined(OH_EVAL_FUSED)
-  hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
+  if (part != 2) hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
 #else
-  hipLaunchKernelGGL(k_retract<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
-  hipLaunchKernelGGL(k_evalb<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
+  if (part != 2) hipLaunchKernelGGL(k_retract<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
+  if (part != 1) hipLaunchKernelGGL(k_evalb<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
 #endif
+}
+template <int N>
+static void launch_carry_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {
+  if (phase == 0) hipLaunchKernelGGL(k_carry_gather<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, slot);
+  else hipLaunchKernelGGL(k_carry_scatter<N>, dim3((Bnew + 255) / 256, P.T), dim3(256), 0, s, P, D, Bnew, slot);
 }
 template <int N>
 static void launch_couple_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
@@ -1535,8 +1642,14 @@ bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers&
 #undef C
   return true;
 }
-bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
-#define C(NN) launch_eval_t<NN>(s, P, D, slot)
+bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot, int part) {
+#define C(NN) launch_eval_t<NN>(s, P, D, slot, part)
+  OH_DISPATCH_N(n, C)
+#undef C
+  return true;
+}
+bool oh_launch_carry(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {
+#define C(NN) launch_carry_t<NN>(s, P, D, phase, Bnew, slot)
   OH_DISPATCH_N(n, C)
 #undef C
   return true;

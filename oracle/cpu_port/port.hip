@@ -52,7 +52,7 @@ void carve(Workspace& w, const oh_problem_desc& d, const oh_chain* chain) {
   D.fpsi = nullptr;
   D.lam_h = take((size_t)4 * T);
   int* ip = w.ipool.data();
-  D.cur = ip++; D.first = ip++; D.skip = ip++; D.polish = ip++; D.status = ip++; D.iters = ip++; D.orig = ip++; D.newidx = ip++; D.n_running = ip++; D.n_new = ip++;
+  D.cur = ip++; D.first = ip++; D.skip = ip++; D.polish = ip++; D.stale = ip++; D.status = ip++; D.iters = ip++; D.orig = ip++; D.newidx = ip++; D.n_running = ip++; D.n_new = ip++;
   D.work = w.work;
 }
 

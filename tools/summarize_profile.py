@@ -17,7 +17,7 @@ import os
 import sqlite3
 import sys
 
-NAMES = ("k_retract", "k_evalb", "k_eval", "k_couple", "k_step", "k_fk_jac", "k_setup", "k_finalize", "k_compact_gather", "k_compact_scatter", "k_scan_count", "k_scan_offsets", "k_scan_assign")
+NAMES = ("k_retract", "k_evalb", "k_eval", "k_couple", "k_step", "k_fk_jac", "k_setup", "k_finalize", "k_compact_gather", "k_compact_scatter", "k_carry_gather", "k_carry_scatter", "k_scan_count", "k_scan_offsets", "k_scan_assign")
 
 
 def short(name: str) -> str:

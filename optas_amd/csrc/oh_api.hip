@@ -846,7 +846,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     if (h->P.lock) oh_launch_couple(s, N, h->P, h->D, slot);
     else oh_launch_couple_free(s, N, h->P, h->D, slot);
     const bool check = ((it + 1) % check_every == 0);
-    if (check) HIPCHK(hipMemsetAsync(h->D.n_running, 0, sizeof(int), s));
+    if (check && !h->P.lock) HIPCHK(hipMemsetAsync(h->D.n_running, 0, sizeof(int), s));  // the locked family's k_couple resets it
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(3); }
     if (h->P.lock && guarded) oh_launch_step_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else if (h->P.lock) oh_launch_step(s, N, h->P, h->D, slot);

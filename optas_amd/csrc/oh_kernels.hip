@@ -612,6 +612,7 @@ OH_DEV void couple_unit(const FigParams& P, const FigBuffers& D, const int slot,
 // (in knot-major order the reuse distance was the whole batch: 11 MB per XCD at B = 131 072).
 template <int N>
 __global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const int slot) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *D.n_running = 0;  // k_step, next in the stream, counts the instances that go on
   const int Tn = P.T - P.t0;
   const int w = blockIdx.x;
   const int chunk = w / (8 * Tn), r = w - chunk * 8 * Tn;

@@ -872,7 +872,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
         tail_done = true;
         break;
       }
-      if (h->compaction && h->compact_carry && h->P.lock && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
+      if (h->compaction && h->compact_carry && oh_eval_is_split() && h->P.lock && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
         carry_pending = nrun;  // done after the next k_retract
       } else if (h->compaction && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);

@@ -1649,6 +1649,13 @@ bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& 
 #undef C
   return true;
 }
+bool oh_eval_is_split() {  // false in the -DOH_EVAL_FUSED ablation build: the compaction between the two launches needs them
+#if defined(OH_EVAL_FUSED)
+  return false;
+#else
+  return true;
+#endif
+}
 bool oh_launch_carry(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {
 #define C(NN) launch_carry_t<NN>(s, P, D, phase, Bnew, slot)
   OH_DISPATCH_N(n, C)

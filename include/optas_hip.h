@@ -273,7 +273,9 @@ int oh_set_guards(oh_handle* h, const oh_guards* guards);
    (solver.py:103-116,386-398).  Host buffers:
      x0 [B][nx], p [B][np]  in;  x [B][nx], f [B], kkt [B][3] = (stationarity, feasibility,
      complementarity), iters [B], status [B] out (any output pointer may be NULL).
-   nx = ndof*T + ndof*(T-1), np = ndof for OH_PROBLEM_FIGURE_EIGHT; see the OH_PROBLEM_* comments for the others. */
+   nx = ndof*T + ndof*(T-1), np = ndof for OH_PROBLEM_FIGURE_EIGHT; see the OH_PROBLEM_* comments for the others.
+   One call of the orientation-locked family takes at most 2^32 / (8 T (ndof-3)^2) instances (671 088 at T = 50, ndof = 7: a stage
+   array is addressed with 32-bit offsets); larger batches return OH_ERR_INVALID and are to be split by the caller. */
 int oh_solve(oh_handle* h, int B, const double* x0, const double* p, double* x, double* f, double* kkt,
              int* iters, int* status);
 

@@ -568,7 +568,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   const int Bp = (B + 63) / 64 * 64;
   // the sweep kernels address one slot of a stage array with a 32-bit byte offset (buffer resources, oh_kernels.hip): the largest such
   // array, T x NZ^2 doubles per instance, has to stay below 4 GiB (671 088 instances at T = 50, N = 7)
-  if (h->desc.lock_orientation && (double)T * NZ * NZ * (double)Bp * 8.0 >= 4294967296.0)
+  if (h->desc.lock_orientation && ((double)T * NZ * NZ + 1.0) * (double)Bp * 8.0 >= 4294967296.0)
     return fail(OH_ERR_INVALID, "batch too large for one call (stage array beyond 4 GiB): split the batch");
   if (B <= h->cap_B && h->pool) {
     h->D.B = B;

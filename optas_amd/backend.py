@@ -37,6 +37,10 @@ class _SolveMixin:
         B = x0.shape[0]
         assert x0.shape == (B, self.nx), f"x0 must be (B, {self.nx})"
         assert p.shape == (B, self.np_), f"p must be (B, {self.np_})"
+        chunk = getattr(self, "max_batch", None)  # one oh_solve call of the locked trajectory family is bounded (optas_hip.h)
+        if chunk and B > chunk:
+            parts = [self.solve(x0[i : i + chunk], p[i : i + chunk]) for i in range(0, B, chunk)]
+            return BatchResult(*(np.concatenate([getattr(r, k) for r in parts]) for k in ("x", "f", "kkt", "iters", "status")))
         x = np.empty((B, self.nx))
         f = np.empty(B)
         kkt = np.empty((B, 3))
@@ -236,6 +240,8 @@ class FigureEightBackend:
         lib = _lib.load()
         self.T, self.ndof = int(T), int(chain.ndof)
         self.nx = self.ndof * self.T + self.ndof * (self.T - 1)
+        # largest batch of one oh_solve call (32-bit stage-array offsets of the sweep kernels, optas_hip.h): bigger ones go in chunks
+        self.max_batch = ((2**32 // (8 * (self.T * (self.ndof - 3) ** 2 + 1))) // 65536) * 65536 if lock_orientation else None
         self.np_ = self.ndof + (1 + self.T if chain.has_lead else 0)  # [qc_opt; lead angle of qc; lead angle per knot]
         lp = _lib.as_f64(local_path, (self.T, 3))
         self._lp = lp  # keep alive during oh_create
@@ -285,6 +291,10 @@ class FigureEightBackend:
         B = x0.shape[0]
         assert x0.shape == (B, self.nx), f"x0 must be (B, {self.nx})"
         assert p.shape == (B, self.np_), f"p must be (B, {self.np_})"
+        chunk = getattr(self, "max_batch", None)  # one oh_solve call of the locked trajectory family is bounded (optas_hip.h)
+        if chunk and B > chunk:
+            parts = [self.solve(x0[i : i + chunk], p[i : i + chunk]) for i in range(0, B, chunk)]
+            return BatchResult(*(np.concatenate([getattr(r, k) for r in parts]) for k in ("x", "f", "kkt", "iters", "status")))
         x = np.empty((B, self.nx))
         f = np.empty(B)
         kkt = np.empty((B, 3))

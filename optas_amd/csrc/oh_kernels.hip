@@ -1442,6 +1442,7 @@ __global__ __launch_bounds__(256) void k_compact_gather(FigParams P, FigBuffers 
     ts[(size_t)13 * Bp + nb] = D.mu[b];
     ts[(size_t)14 * Bp + nb] = (double)D.iters[b];
     ts[(size_t)15 * Bp + nb] = (double)D.orig[b];
+    ts[(size_t)16 * Bp + nb] = D.nun[b];
   }
 }
 // ... and lay it down densely; the state machine restarts at "evaluate this point" (first = 1), which
@@ -1466,7 +1467,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
     for (int i = 0; i < 12; ++i) D.ref[(size_t)i * Bp + b] = ts[(size_t)i * Bp + b];
     D.fconst[b] = ts[(size_t)12 * Bp + b];
     D.mu[b] = ts[(size_t)13 * Bp + b];
-    D.nun[b] = 2.0;
+    D.nun[b] = ts[(size_t)16 * Bp + b];
     const int it = (int)ts[(size_t)14 * Bp + b];
     D.iters[b] = it > 0 ? it - 1 : 0;  // the pending step is recomputed and counted again
     D.orig[b] = (int)ts[(size_t)15 * Bp + b];
@@ -1547,7 +1548,7 @@ __global__ __launch_bounds__(256) void k_carry_scatter(FigParams P, FigBuffers D
     const int it = (int)ts[(size_t)14 * Bp + b];
     D.iters[b] = it > 0 ? it : 0;
     D.orig[b] = (int)ts[(size_t)15 * Bp + b];
-    D.nun[b] = restart ? 2.0 : ts[(size_t)16 * Bp + b];
+    D.nun[b] = ts[(size_t)16 * Bp + b];  // restart lanes too: consecutive rejections keep escalating as they would without compaction
     D.f_cur[b] = ts[(size_t)17 * Bp + b];
     D.pred[b] = ts[(size_t)18 * Bp + b];
     D.stat[b] = ts[(size_t)19 * Bp + b];

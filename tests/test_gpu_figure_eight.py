@@ -294,6 +294,6 @@ def test_compaction_schedule_does_not_change_the_answers(hip_lib, nlp, monkeypat
         assert (r.status == ref.status).all()
         ok = ref.status == 0
         same = np.abs(r.f - ref.f) <= 1e-9 * np.abs(ref.f)
-        assert same[ok].mean() > 0.995  # the rest sit at a fork between two local minima (see the port comparison above)
+        assert same[ok].mean() > 0.999  # same kernels, same arithmetic: the schedule must not matter (LM state travels with the instance)
         assert np.abs(r.x[ok & same] - ref.x[ok & same]).max() < 1e-3
         assert np.median(np.abs(r.iters - ref.iters)[ok & same]) <= 1

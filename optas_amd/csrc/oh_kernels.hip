@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void k_evalb(FigParams P, FigBuffers D, con
 // chains with a parameterised lead joint (RobotModel(param_joints=[first joint]), figure_eight_plan_6dof.py): same evaluation
 // from the frame that follows the lead joint at the knot's parameter angle
 template <int N>
-__global__ __launch_bounds__(256, 2) void k_eval_lead(FigParams P, FigBuffers D, const int slot) {
+__global__ __launch_bounds__(256, OH_EVAL_WAVES) void k_eval_lead(FigParams P, FigBuffers D, const int slot) {
   eval_unit<N, false, true>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
 }
 bool oh_launch_eval_lead(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {

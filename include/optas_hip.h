@@ -68,7 +68,17 @@ enum {
   /* any other small dense problem: the host compiles its expression trees into one scalar instruction tape (the counterpart of the CasADi SX
      tape the reference's back-ends interpret, optimization.py:8-24) and the GPU interprets it; created with oh_create_tape.
      x (nx), p (np) in vec() order. */
-  OH_PROBLEM_TAPE = 5
+  OH_PROBLEM_TAPE = 5,
+  /* BASELINE configs[4]: joint-space torque MPC whose equality rows are the inverse dynamics RobotModel.rnea
+     (models.py:1731-1884).  Written with the reference's builder as
+       RobotModel(time_derivs=[0,1,2]) + TaskModel("tau", ndof, dlim={0: [lo, up]}), OptimizationBuilder(T, derivs_align=True)  (builder.py:14-99)
+       fix_configuration(q, qc), fix_configuration(dq, dqc), integrate_model_states(.., 1, dt), integrate_model_states(.., 2, dt)  (:419-469,525-539)
+       add_equality_constraint(lhs=rnea(Q, dQ, ddQ), rhs=TAU)  ->  h = TAU - rnea                                                  (:337-360)
+       enforce_model_limits("tau")                             ->  k = [TAU - lo; up - TAU]                                        (:471-509)
+       f = w_path sumsqr(p_link(Q) - goal) + w_vel sumsqr(dQ) + w_tau sumsqr(TAU).
+     x = [vec(Q); vec(dQ); vec(ddQ); vec(TAU)] (nx = 4 ndof T), p = [qc (ndof); dqc (ndof); vec(goal 3 x T)] (np = 2 ndof + 3 T);
+     created with oh_create_torque; needs oh_set_constants (chain of the tracked link) and oh_set_dynamics before the first solve. */
+  OH_PROBLEM_TORQUE_MPC = 6
 };
 
 enum {
@@ -204,6 +214,22 @@ typedef struct oh_ik_desc {
   double rho0;      /* initial augmented-Lagrangian penalty; <= 0: 100 w */
 } oh_ik_desc;
 
+typedef struct oh_torque_desc {
+  int T;          /* knots, 2..OH_MAX_T */
+  int ndof;       /* 7: every joint of the chain is actuated and the inverse-dynamics tables have ndof + 1 bodies */
+  double dt;      /* Euler step of both integrate_model_states calls */
+  double w_path;  /* weight of sum ||p_link(q_t) - goal_t||^2 */
+  double w_vel;   /* weight of sum ||dq_t||^2 (>= 0) */
+  double w_tau;   /* weight of sum ||tau_t||^2 (> 0: it is what makes the stage Hessian in ddq positive definite) */
+  double tau_lo[OH_MAX_CHAIN]; /* effort limits: TaskModel dlim[0] (models.py:79-214), rows "_l" / "_r" of enforce_model_limits */
+  double tau_up[OH_MAX_CHAIN];
+  int max_iter;    /* evaluations after the first (Riccati steps + multiplier updates); <= 0: 300 */
+  double tol;      /* |gradient of the rolled-out augmented Lagrangian w.r.t. ddq|_inf; <= 0: 1e-6 */
+  double tol_feas; /* |min(g, lam / rho)|_inf over the effort rows (bounds violation and complementarity at once); <= 0: 1e-9 */
+  double rho0;     /* initial penalty; <= 0: 1 */
+  double mu0;      /* initial Levenberg-Marquardt damping of the state part of the step; < 0: 0 */
+} oh_torque_desc;
+
 #define OH_QP_MAX_N 32
 #define OH_QP_MAX_M 256
 #define OH_QP_MAX_ME 32
@@ -258,6 +284,10 @@ int oh_create_tape(const oh_tape_desc* desc, oh_handle** out);
    the kernel source of this tape and compile it for gfx950.  Needs no GPU.  source (optional, source_cap bytes) receives the generated
    text, *source_len its full length, *code_bytes the size of the code object. */
 int oh_tape_compile(const oh_tape_desc* desc, size_t* code_bytes, char* source, size_t source_cap, size_t* source_len);
+
+/* Same for OH_PROBLEM_TORQUE_MPC.  oh_get_multipliers returns [B][T][2 ndof] = multipliers >= 0 of (TAU - lo, up - TAU) per knot; the
+   multipliers of the other rows follow from these and the solution (h: nu_t = 2 w_tau tau_t - lam_lo + lam_up, a: the costates). */
+int oh_create_torque(const oh_torque_desc* desc, oh_handle** out);
 
 /* Same for OH_PROBLEM_IK; needs oh_set_constants before the first solve. */
 int oh_create_ik(const oh_ik_desc* desc, oh_handle** out);

@@ -25,6 +25,7 @@ OH_PROBLEM_POINT_MASS_MPC = 2
 OH_PROBLEM_IK = 3
 OH_PROBLEM_QP = 4
 OH_PROBLEM_TAPE = 5
+OH_PROBLEM_TORQUE_MPC = 6
 OH_HESSIAN_GAUSS_NEWTON, OH_HESSIAN_EXACT, OH_HESSIAN_HYBRID = 0, 1, 2
 
 
@@ -155,6 +156,24 @@ class oh_ik_desc(C.Structure):
     ]
 
 
+class oh_torque_desc(C.Structure):
+    _fields_ = [
+        ("T", C.c_int),
+        ("ndof", C.c_int),
+        ("dt", C.c_double),
+        ("w_path", C.c_double),
+        ("w_vel", C.c_double),
+        ("w_tau", C.c_double),
+        ("tau_lo", C.c_double * OH_MAX_CHAIN),
+        ("tau_up", C.c_double * OH_MAX_CHAIN),
+        ("max_iter", C.c_int),
+        ("tol", C.c_double),
+        ("tol_feas", C.c_double),
+        ("rho0", C.c_double),
+        ("mu0", C.c_double),
+    ]
+
+
 class OptasHipError(RuntimeError):
     pass
 
@@ -168,6 +187,7 @@ SYMBOLS = [
     "oh_create_ik",
     "oh_create_qp",
     "oh_create_tape",
+    "oh_create_torque",
     "oh_tape_compile",
     "oh_set_constants",
     "oh_set_constants_device",

@@ -216,6 +216,38 @@ class IKBackend(_SolveMixin):
         return out[:, :3], out[:, 3 : 3 + self.ndof], out[:, 3 + self.ndof :]
 
 
+class TorqueBackend(_SolveMixin):
+    """OH_PROBLEM_TORQUE_MPC handle (BASELINE configs[4]): x = [vec(Q); vec(dQ); vec(ddQ); vec(TAU)], p = [qc; dqc; vec(goal 3 x T)]."""
+
+    def __init__(self, chain: _lib.oh_chain, dynamics: _lib.oh_dynamics, T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=None, tau_up=None,
+                 max_iter=300, tol=1e-6, tol_feas=1e-9, rho0=0.0, mu0=0.0):
+        lib = _lib.load()
+        self.ndof, self.T = int(chain.ndof), int(T)
+        self.nx, self.np_ = 4 * self.ndof * self.T, 2 * self.ndof + 3 * self.T
+        desc = _lib.oh_torque_desc(T=self.T, ndof=self.ndof, dt=float(dt), w_path=float(w_path), w_vel=float(w_vel), w_tau=float(w_tau),
+                                   max_iter=int(max_iter), tol=float(tol), tol_feas=float(tol_feas), rho0=float(rho0), mu0=float(mu0))
+        lo = np.broadcast_to(np.asarray(-1e9 if tau_lo is None else tau_lo, dtype=np.float64), (self.ndof,))
+        up = np.broadcast_to(np.asarray(1e9 if tau_up is None else tau_up, dtype=np.float64), (self.ndof,))
+        for i in range(self.ndof):
+            desc.tau_lo[i], desc.tau_up[i] = lo[i], up[i]
+        self._h = C.c_void_p()
+        _lib.check(lib.oh_create_torque(C.byref(desc), C.byref(self._h)), "oh_create_torque")
+        _lib.check(lib.oh_set_constants(self._h, C.byref(chain)), "oh_set_constants")
+        _lib.check(lib.oh_set_dynamics(self._h, C.byref(dynamics)), "oh_set_dynamics")
+        self.chain, self.dynamics = chain, dynamics
+
+    def multipliers(self, B: int):
+        """(B, T, 2 ndof): multipliers >= 0 of (TAU - lo, up - TAU) per knot of the last solve."""
+        out = np.empty((B, self.T, 2 * self.ndof))
+        _lib.check(_lib.load().oh_get_multipliers(self._h, int(B), _lib._ptr(out)), "oh_get_multipliers")
+        return out
+
+    def timing(self) -> dict:
+        out = (C.c_double * 11)()
+        _lib.check(_lib.load().oh_get_timing(self._h, out), "oh_get_timing")
+        return {"solve_ms": out[4], "iterations_launched": int(out[5]), "work_instances": out[6]}
+
+
 class FigureEightBackend:
     """OH_PROBLEM_FIGURE_EIGHT handle."""
 

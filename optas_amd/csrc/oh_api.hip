@@ -67,6 +67,14 @@ struct oh_handle {
   oh_ik_desc ik{};
   double* d_ik_mult = nullptr;
   int ik_cap = 0;
+  // torque-MPC family
+  oh_torque_desc tq{};
+  TqParams TqP{};
+  TqBuffers TqD{};
+  void* tq_pool = nullptr;
+  double* d_tq_mult = nullptr;
+  int tq_cap = 0;
+  int tq_check = 4;  // the host looks at the running count every tq_check iterations
   // solver buffers
   int cap_B = 0;
   FigBuffers D{};
@@ -93,6 +101,7 @@ struct oh_handle {
   std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
 };
 
+extern "C" void oh_destroy(oh_handle* h);
 extern "C" const char* oh_last_error(void) { return g_err.c_str(); }
 extern "C" const char* oh_version(void) { return "optas_hip 0.1 (gfx950)"; }
 
@@ -369,8 +378,6 @@ static int qp_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   Q.nwork = q.n + 2 * q.m + q.me + q.n * q.n + 2 * q.n + 2 * q.m + q.me * q.n + q.me * q.me + q.me + q.n;
   if (B > h->qp_cap) {
     if (h->d_qp_work) hipFree(h->d_qp_work);
-  for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult})
-    if (q) hipFree(q);
     if (h->d_qp_mult) hipFree(h->d_qp_mult);
     h->d_qp_work = h->d_qp_mult = nullptr;
     h->qp_cap = 0;
@@ -426,6 +433,134 @@ extern "C" int oh_create_ik(const oh_ik_desc* desc, oh_handle** out) {
 
 static bool solver_chain_ok(const oh_chain& c);
 
+extern "C" int oh_create_torque(const oh_torque_desc* desc, oh_handle** out) {
+  if (!desc || !out) return fail(OH_ERR_INVALID, "oh_create_torque: null argument");
+  *out = nullptr;
+  if (desc->ndof != 7) return fail(OH_ERR_INVALID, "oh_create_torque: kernels are instantiated for ndof 7");
+  if (desc->T < 2 || desc->T > OH_MAX_T) return fail(OH_ERR_INVALID, "oh_create_torque: T must be in [2, OH_MAX_T]");
+  if (!(desc->dt > 0.0) || !(desc->w_tau > 0.0) || !(desc->w_path >= 0.0) || !(desc->w_vel >= 0.0))
+    return fail(OH_ERR_INVALID, "oh_create_torque: dt and w_tau must be positive, w_path and w_vel non-negative");
+  for (int i = 0; i < desc->ndof; ++i)
+    if (!(desc->tau_lo[i] < desc->tau_up[i])) return fail(OH_ERR_INVALID, "oh_create_torque: tau_lo must be below tau_up");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1)
+    return fail(OH_ERR_HIP, "oh_create_torque: no HIP device available (this library has no CPU path)");
+  oh_handle* h = new oh_handle();
+  h->desc = oh_problem_desc{};
+  h->desc.kind = OH_PROBLEM_TORQUE_MPC;
+  h->desc.T = desc->T;
+  h->desc.ndof = desc->ndof;
+  h->tq = *desc;
+  if (h->tq.max_iter <= 0) h->tq.max_iter = 300;
+  if (!(h->tq.tol > 0.0)) h->tq.tol = 1e-6;
+  if (!(h->tq.tol_feas > 0.0)) h->tq.tol_feas = 1e-9;
+  if (!(h->tq.rho0 > 0.0)) h->tq.rho0 = 1.0;
+  if (!(h->tq.mu0 >= 0.0)) h->tq.mu0 = 0.0;
+  if (const char* e = getenv("OH_TQ_CHECK")) h->tq_check = atoi(e) > 0 ? atoi(e) : 1;
+  hipGetDevice(&h->device);
+  if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+      hipEventCreate(&h->evt0) != hipSuccess || hipEventCreate(&h->evt1) != hipSuccess ||
+      hipMalloc((void**)&h->d_chain, sizeof(oh_chain)) != hipSuccess || hipHostMalloc((void**)&h->h_flag, sizeof(int)) != hipSuccess) {
+    oh_destroy(h);
+    return fail(OH_ERR_HIP, "oh_create_torque: stream/event/allocation failed");
+  }
+  *out = h;
+  return OH_OK;
+}
+
+static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status) {
+  if (!h->have_chain) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_constants first");
+  if (!h->have_dyn) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_dynamics first");
+  if (!solver_chain_ok(h->chain_host) || h->chain_host.has_lead)
+    return fail(OH_ERR_INVALID, "oh_solve_device: the solver needs a chain that covers every model joint in order");
+  const int N = h->tq.ndof, T = h->tq.T;
+  if (h->dyn_host.ndof != N) return fail(OH_ERR_INVALID, "oh_solve_device: the inverse-dynamics tables must have ndof + 1 bodies");
+  HIPCHK(hipSetDevice(h->device));
+  TqParams& P = h->TqP;
+  P = TqParams{};
+  P.T = T; P.N = N; P.max_iter = h->tq.max_iter;
+  P.dt = h->tq.dt; P.w_path = h->tq.w_path; P.w_vel = h->tq.w_vel; P.w_tau = h->tq.w_tau;
+  P.tol = h->tq.tol; P.tol_feas = h->tq.tol_feas; P.rho0 = h->tq.rho0; P.mu0 = h->tq.mu0;
+  for (int i = 0; i < N; ++i) {
+    P.tau_lo[i] = h->tq.tau_lo[i];
+    P.tau_up[i] = h->tq.tau_up[i];
+  }
+  P.nx = 4 * N * T;
+  P.np = 2 * N + 3 * T;
+  TqBuffers& D = h->TqD;
+  if (B > h->tq_cap) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->tq_pool) hipFree(h->tq_pool);
+    if (h->d_tq_mult) hipFree(h->d_tq_mult);
+    h->tq_pool = nullptr;
+    h->d_tq_mult = nullptr;
+    h->tq_cap = 0;
+    const size_t BT = (size_t)B * T;
+    const size_t nd = 2 * BT * TQ_XS + 2 * BT * TQ_SD + BT * TQ_LAM + BT * TQ_GN + BT * 4 + 11 * (size_t)B;
+    const size_t bytes = nd * sizeof(double) + (7 * (size_t)B + 16) * sizeof(int);
+    HIPCHK(hipMalloc(&h->tq_pool, bytes));
+    HIPCHK(hipMalloc((void**)&h->d_tq_mult, sizeof(double) * BT * 2 * N));
+    h->tq_cap = B;
+  }
+  {
+    // carve for the capacity the pool was allocated with; D.B is the live batch (strides of the [slot][B][T] arrays follow it)
+    const size_t BT = (size_t)B * T;
+    double* d = (double*)h->tq_pool;
+    auto take = [&](size_t n) { double* r = d; d += n; return r; };
+    D.B = B;
+    D.chain = h->d_chain;
+    D.dyn = h->d_dyn;
+    D.xs = take(2 * BT * TQ_XS);
+    D.st = take(2 * BT * TQ_SD);
+    D.lam = take(BT * TQ_LAM);
+    D.gains = take(BT * TQ_GN);
+    D.goal = take(BT * 4);
+    D.f_cur = take(B); D.f_true = take(B); D.pred = take(B); D.mu = take(B); D.nun = take(B); D.rho = take(B); D.rho_next = take(B);
+    D.omega = take(B); D.meas_prev = take(B); D.meas = take(B); D.stat = take(B);
+    int* ip = (int*)d;
+    D.cur = ip; ip += B; D.first = ip; ip += B; D.outer = ip; ip += B; D.status = ip; ip += B; D.iters = ip; ip += B; D.rejected = ip; ip += B;
+    D.n_outer = ip; ip += B;
+    D.n_running = ip;
+  }
+  hipStream_t s = h->stream;
+  HIPCHK(hipEventRecord(h->ev0, s));
+  if (!oh_launch_tq_setup(s, P, D, (const double*)d_x0, (const double*)d_p)) return fail(OH_ERR_INVALID, "oh_solve_device: unsupported ndof");
+  // iteration k: evaluate the pending trial of every running instance, then ratio test / Riccati sweep / next trial.  The host only looks at
+  // the running count every tq_check iterations (instances that finished in between cost nothing: their lanes exit at once).
+  int launched = 0;
+  double work = 0.0;
+  int running = B;
+  const int cap = P.max_iter + 2;
+  while (launched < cap) {
+    oh_launch_tq_eval(s, P, D);
+    HIPCHK(hipMemsetAsync(D.n_running, 0, sizeof(int), s));
+    oh_launch_tq_step(s, P, D);
+    ++launched;
+    work += running;
+    if (launched % h->tq_check == 0 || launched == cap) {
+      HIPCHK(hipMemcpyAsync(h->h_flag, D.n_running, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      running = *h->h_flag;
+      if (running == 0) break;
+    }
+  }
+  oh_launch_tq_finalize(s, P, D, (double*)d_x, (double*)d_f, (double*)d_kkt, (int*)d_iters, (int*)d_status, h->d_tq_mult);
+  HIPCHK(hipEventRecord(h->ev1, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  for (double& t : h->timing) t = 0.0;
+  h->timing[4] = ms;
+  h->timing[5] = launched;
+  h->timing[6] = work;
+  h->timing_couple = 0;
+  h->rejects = 0;
+  h->tail_iters = 0;
+  h->last_B = B;
+  return OH_OK;
+}
+
 static int ik_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters,
                            void* d_status) {
   if (!h->have_chain) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_constants first");
@@ -435,11 +570,6 @@ static int ik_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   const int N = h->ik.ndof;
   if (B > h->ik_cap) {
     if (h->d_ik_mult) hipFree(h->d_ik_mult);
-  if (h->gpool) hipFree(h->gpool);
-  if (h->d_qp_work) hipFree(h->d_qp_work);
-  for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult})
-    if (q) hipFree(q);
-  if (h->d_qp_mult) hipFree(h->d_qp_mult);
     h->d_ik_mult = nullptr;
     h->ik_cap = 0;
     HIPCHK(hipMalloc((void**)&h->d_ik_mult, sizeof(double) * (3 + 2 * (size_t)N) * B));
@@ -665,6 +795,13 @@ extern "C" int oh_set_guards(oh_handle* h, const oh_guards* g) {
   if (g->limits)
     for (int j = 0; j < h->desc.ndof; ++j)
       if (!(g->q_lo[j] < g->q_up[j])) return fail(OH_ERR_INVALID, "oh_set_guards: q_lo must be below q_up");
+  if (h->gpool) {  // the pool was carved for the previous row count: rebuild it at the next solve
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(h->gpool);
+    h->gpool = nullptr;
+    h->gcap = 0;
+  }
   h->guards = *g;
   h->have_guards = true;
   return OH_OK;
@@ -691,10 +828,6 @@ static int ensure_guards(oh_handle* h) {
   const int Bp = h->D.Bp;
   if (!h->gpool || h->gcap != Bp) {
     if (h->gpool) hipFree(h->gpool);
-  if (h->d_qp_work) hipFree(h->d_qp_work);
-  for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult})
-    if (q) hipFree(q);
-  if (h->d_qp_mult) hipFree(h->d_qp_mult);
     h->gpool = nullptr;
     const size_t npar = (size_t)g.n_links + 4 * (size_t)g.n_obstacles;
     const size_t nd = (size_t)T * GP.NC * Bp + npar * Bp + 4 * (size_t)T * Bp + 6 * (size_t)Bp;
@@ -763,6 +896,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (h->desc.kind == OH_PROBLEM_IK) return ik_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind == OH_PROBLEM_QP) return qp_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind == OH_PROBLEM_TAPE) return tape_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
+  if (h->desc.kind == OH_PROBLEM_TORQUE_MPC) return tq_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT) return fail(OH_ERR_STATE, "oh_solve_device: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
   if (!h->have_chain) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_constants first");
   if (!solver_chain_ok(h->chain_host))
@@ -945,7 +1079,7 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
   if (B < 1) return fail(OH_ERR_INVALID, "oh_solve: B must be >= 1");
   if (!x0 || !p) return fail(OH_ERR_INVALID, "oh_solve: x0 and p are required");
   if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_POINT_MASS_MPC && h->desc.kind != OH_PROBLEM_IK &&
-      h->desc.kind != OH_PROBLEM_QP && h->desc.kind != OH_PROBLEM_TAPE)
+      h->desc.kind != OH_PROBLEM_QP && h->desc.kind != OH_PROBLEM_TAPE && h->desc.kind != OH_PROBLEM_TORQUE_MPC)
     return fail(OH_ERR_STATE, "oh_solve: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
   HIPCHK(hipSetDevice(h->device));
   const int N = h->desc.ndof, T = h->desc.T;
@@ -953,8 +1087,9 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
   const bool ikk = h->desc.kind == OH_PROBLEM_IK;
   const bool qpk = h->desc.kind == OH_PROBLEM_QP;
   const bool tpk = h->desc.kind == OH_PROBLEM_TAPE;
-  const size_t nx = tpk ? (size_t)h->TP.nx : qpk ? (size_t)h->qp.n : pmk ? 4 * (size_t)T : (ikk ? (size_t)N : (size_t)N * T + (size_t)N * (T - 1));
-  const size_t npar = tpk ? (size_t)(h->TP.np > 0 ? h->TP.np : 1) : qpk ? qp_np(h->qp) : pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (h->chain_host.has_lead ? (size_t)N + 1 + T : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0)));
+  const bool tqk = h->desc.kind == OH_PROBLEM_TORQUE_MPC;
+  const size_t nx = tqk ? 4 * (size_t)N * T : tpk ? (size_t)h->TP.nx : qpk ? (size_t)h->qp.n : pmk ? 4 * (size_t)T : (ikk ? (size_t)N : (size_t)N * T + (size_t)N * (T - 1));
+  const size_t npar = tqk ? 2 * (size_t)N + 3 * (size_t)T : tpk ? (size_t)(h->TP.np > 0 ? h->TP.np : 1) : qpk ? qp_np(h->qp) : pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (h->chain_host.has_lead ? (size_t)N + 1 + T : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0)));
   const size_t b_x = sizeof(double) * nx * B, b_p = sizeof(double) * npar * (size_t)B;
   const size_t b_f = sizeof(double) * B, b_k = sizeof(double) * 3 * (size_t)B, b_i = sizeof(int) * (size_t)B;
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -1038,10 +1173,15 @@ extern "C" int oh_pm_rollout(oh_handle* h, int B, int n_ticks, int advance, doub
 
 extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
   if (!h || !lam_h) return fail(OH_ERR_INVALID, "oh_get_multipliers: null argument");
-  if ((h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_IK && h->desc.kind != OH_PROBLEM_QP && h->desc.kind != OH_PROBLEM_TAPE) ||
+  if ((h->desc.kind != OH_PROBLEM_FIGURE_EIGHT && h->desc.kind != OH_PROBLEM_IK && h->desc.kind != OH_PROBLEM_QP && h->desc.kind != OH_PROBLEM_TAPE &&
+       h->desc.kind != OH_PROBLEM_TORQUE_MPC) ||
       B != h->last_B || B < 1)
     return fail(OH_ERR_STATE, "oh_get_multipliers: B does not match the last solve");
   HIPCHK(hipSetDevice(h->device));
+  if (h->desc.kind == OH_PROBLEM_TORQUE_MPC) {
+    HIPCHK(hipMemcpy(lam_h, h->d_tq_mult, sizeof(double) * (size_t)B * h->tq.T * 2 * h->tq.ndof, hipMemcpyDeviceToHost));
+    return OH_OK;
+  }
   if (h->desc.kind == OH_PROBLEM_TAPE) {
     if (h->TP.n_ineq + h->TP.n_eq > 0)
       HIPCHK(hipMemcpy(lam_h, h->d_tape_mult, sizeof(double) * (size_t)(h->TP.n_ineq + h->TP.n_eq) * B, hipMemcpyDeviceToHost));
@@ -1183,6 +1323,8 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (hipEvent_t e : h->prof_events) hipEventDestroy(e);
   if (h->pool) hipFree(h->pool);
+  if (h->tq_pool) hipFree(h->tq_pool);
+  if (h->d_tq_mult) hipFree(h->d_tq_mult);
   if (h->d_ik_mult) hipFree(h->d_ik_mult);
   if (h->gpool) hipFree(h->gpool);
   if (h->d_qp_work) hipFree(h->d_qp_work);

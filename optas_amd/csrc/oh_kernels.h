@@ -138,6 +138,37 @@ void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, co
 void oh_launch_pm_tick_params(hipStream_t s, int B, int T, int tick, int advance, double ramp, const double* state, const double* obs_table, double* p);
 void oh_launch_pm_advance(hipStream_t s, int B, int T, int advance, const double* x, double* state_next);
 
+// ---- OH_PROBLEM_TORQUE_MPC (BASELINE configs[4]: RNEA dynamics rows) -------------------------------
+// Layouts are unit-contiguous ([instance][knot][...]): the evaluation kernel works with one lane per (instance, knot,
+// tangent direction) and the Riccati kernel with 16 lanes per instance, so a wavefront reads whole stage records.
+#define TQ_XS 24    // per knot: q (N) at 0, dq (N) at 8, ddq (N) at 16
+#define TQ_SD 272   // per knot stage record: H packed lower (3N)(3N+1)/2 at 0 | g (3N) at 231 | phi 252, phi_true 253, meas 254, viol 255 | tau (N) at 256 | compl 263
+#define TQ_LAM 16   // per knot: multipliers of tau - lo >= 0 (N), then of up - tau >= 0 (N)
+#define TQ_GN 112   // per knot: gains K (column c of 2N: N values at c N), feed-forward k at 2N N
+struct TqParams {
+  int T, N, max_iter;
+  double dt, w_path, w_vel, w_tau, tol, tol_feas, rho0, mu0;
+  double tau_lo[OH_MAX_CHAIN], tau_up[OH_MAX_CHAIN];
+  int nx, np;
+};
+struct TqBuffers {
+  int B;
+  const oh_chain* chain;
+  const oh_dynamics* dyn;
+  double* xs;      // [2][B][T][TQ_XS]
+  double* st;      // [2][B][T][TQ_SD]
+  double* lam;     // [B][T][TQ_LAM]
+  double* gains;   // [B][T][TQ_GN]
+  double* goal;    // [B][T][4]
+  double *f_cur, *f_true, *pred, *mu, *nun, *rho, *rho_next, *omega, *meas_prev, *meas, *stat;  // [B]
+  int *cur, *first, *outer, *status, *iters, *rejected, *n_outer;                                // [B]
+  int* n_running;  // [1]
+};
+bool oh_launch_tq_setup(hipStream_t s, const TqParams& P, const TqBuffers& D, const double* x0, const double* p);
+bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D);
+bool oh_launch_tq_step(hipStream_t s, const TqParams& P, const TqBuffers& D);
+bool oh_launch_tq_finalize(hipStream_t s, const TqParams& P, const TqBuffers& D, double* x, double* f, double* kkt, int* iters, int* status, double* mult);
+
 // ---- OH_PROBLEM_IK -----------------------------------------------------------------------------------------
 struct IkParams {
   int ndof, max_iter;

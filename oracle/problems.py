@@ -715,3 +715,116 @@ class PointMassPlannerNLP(PointMassMPCNLP):
         for t in range(self.T):
             J[t, 2 * t : 2 * t + 2] = -2.0 * (self.obstacle - Y[:, t])
         return J
+
+
+class TorqueMPCNLP(_NLPBase):
+    """BASELINE configs[4]: torque-control MPC with RNEA dynamics equality rows -- not a reference
+    script (torque_control_example.py:198-200 calls rnea outside the optimiser); built from the reference's builder calls as
+    listed in oracle/torque.py.  med7 (RobotModel.rnea needs a fixed first joint, models.py:1748-1749), derivs_align=True:
+
+    x = ["{r}/q/x" (n x T); "{r}/dq/x" (n x T); "{r}/ddq/x" (n x T); "tau/y/x" (n x T)]           (builder.py:45,90-99)
+    p = ["{r}/q/p", "{r}/dq/p", "{r}/ddq/p" (0 rows); "qc" (n); "dqc" (n); "goal" (3 x T)]        (builder.py:96-97,263-273)
+    k = [vec(TAU) - lo; up - vec(TAU)]                     enforce_model_limits("tau")            (builder.py:334-335,509)
+    a = [qc - q_0; dqc - dq_0; -(q_t + dt dq_t - q_{t+1}); -(dq_t + dt ddq_t - dq_{t+1})], t = 0..T-2  (builder.py:437,469,539,354)
+    h = vec(TAU - rnea(Q, dQ, ddQ))                        add_equality_constraint(lhs=rnea, rhs=TAU)   (builder.py:354)
+    f = w_path sum ||p_link(q_t) - goal_t||^2 + w_vel sum ||dQ||^2 + w_tau sum ||TAU||^2
+    """
+
+    def __init__(self, prob):
+        from .torque import rnea_batch, rnea_jacobian  # the vectorised restatement of oracle.robot.rnea and its complex-step Jacobian
+
+        self._rnea, self._rnea_jac = rnea_batch, rnea_jacobian
+        self.prob = prob
+        self.robot, self.link, self.T, self.dt = prob.robot, prob.link, prob.T, prob.dt
+        self.n = n = prob.n
+        T = self.T
+        self.nb = n * T
+        self.nx = 4 * self.nb
+        self.np_ = 2 * n + 3 * T
+        self.nk = 2 * self.nb
+        self.na = 2 * n + 2 * n * (T - 1)
+        self.nh = self.nb
+        nb, dt, I = self.nb, self.dt, np.eye(n)
+        A = np.zeros((self.na, self.nx))
+        A[0:n, 0:n] = -I
+        A[n:2 * n, nb:nb + n] = -I
+        for d in range(2):  # integrate_model_states(name, d + 1, dt): block d -> rows of x^(d), derivative block d + 1
+            for t in range(T - 1):
+                r = 2 * n + d * n * (T - 1) + n * t
+                A[r:r + n, d * nb + n * t:d * nb + n * t + n] = -I
+                A[r:r + n, (d + 1) * nb + n * t:(d + 1) * nb + n * t + n] = -dt * I
+                A[r:r + n, d * nb + n * (t + 1):d * nb + n * (t + 1) + n] = I
+        self._A = A
+        K = np.zeros((self.nk, self.nx))
+        K[:nb, 3 * nb:] = np.eye(nb)
+        K[nb:, 3 * nb:] = -np.eye(nb)
+        self._K = K
+
+    def split(self, x):
+        n, T, nb = self.n, self.T, self.nb
+        return tuple(x[i * nb:(i + 1) * nb].reshape(T, n) for i in range(4))  # rows = knots (the transposes of the n x T blocks)
+
+    def join(self, Q, dQ, ddQ, TAU):
+        return np.concatenate([np.asarray(a, float).reshape(-1) for a in (Q, dQ, ddQ, TAU)])
+
+    def split_p(self, p):
+        n = self.n
+        return p[:n], p[n:2 * n], p[2 * n:].reshape(self.T, 3)
+
+    @staticmethod
+    def pack_p(qc, dqc, goal):
+        return np.concatenate([np.asarray(qc, float), np.asarray(dqc, float), np.asarray(goal, float).reshape(-1)])
+
+    def seed(self, qc):
+        """Q = qc at every knot, everything else zero-filled (sx_container.py:121)."""
+        z = np.zeros((self.T, self.n))
+        return self.join(np.tile(np.asarray(qc, float), (self.T, 1)), z, z, z)
+
+    def f(self, x, p):
+        Q, dQ, _, TAU = self.split(x)
+        goal = self.split_p(p)[2]
+        pos = self.robot.map_position(self.link, Q.T).T
+        w = self.prob
+        return float(w.w_path * np.sum((pos - goal) ** 2) + w.w_vel * np.sum(dQ**2) + w.w_tau * np.sum(TAU**2))
+
+    def df(self, x, p):
+        Q, dQ, ddQ, TAU = self.split(x)
+        goal = self.split_p(p)[2]
+        w = self.prob
+        gq = np.zeros_like(Q)
+        for t in range(self.T):
+            Jp = self.robot.get_global_link_linear_jacobian(self.link, Q[t])
+            gq[t] = 2.0 * w.w_path * (Jp.T @ (self.robot.get_global_link_position(self.link, Q[t]) - goal[t]))
+        return self.join(gq, 2.0 * w.w_vel * dQ, np.zeros_like(ddQ), 2.0 * w.w_tau * TAU)
+
+    def k(self, x, p):
+        tau = x[3 * self.nb:]
+        lo, up = np.tile(self.prob.tau_lo, self.T), np.tile(self.prob.tau_up, self.T)
+        return np.concatenate([tau - lo, up - tau])
+
+    def dk(self, x, p):
+        return self._K
+
+    def a(self, x, p):
+        b = np.zeros(self.na)
+        b[:2 * self.n] = p[:2 * self.n]
+        return self._A @ x + b
+
+    def da(self, x, p):
+        return self._A
+
+    def h(self, x, p):
+        Q, dQ, ddQ, TAU = self.split(x)
+        return (TAU - self._rnea(self.prob.tb, Q, dQ, ddQ)).reshape(-1)
+
+    def dh(self, x, p):
+        Q, dQ, ddQ, _ = self.split(x)
+        n, nb = self.n, self.nb
+        J = self._rnea_jac(self.prob.tb, Q, dQ, ddQ)  # (T, n, 3n)
+        D = np.zeros((self.nh, self.nx))
+        for t in range(self.T):
+            r = slice(n * t, n * t + n)
+            for blk in range(3):
+                D[r, blk * nb + n * t:blk * nb + n * t + n] = -J[t][:, blk * n:(blk + 1) * n]
+            D[r, 3 * nb + n * t:3 * nb + n * t + n] = np.eye(n)
+        return D

@@ -1,0 +1,297 @@
+"""ORACLE (test infrastructure, not product code) -- BASELINE configs[4]: 7-DoF torque-control MPC with RNEA
+dynamics equality constraints.  The reference ships no such script (its
+example/torque_control_example.py evaluates RobotModel.rnea outside the optimiser, :198-200); the problem is the
+synthetic one SURVEY App. B.5 specifies, written with the reference's own builder calls:
+
+    robot = RobotModel(med7.urdf, time_derivs=[0, 1, 2]); tau = TaskModel("tau", 7, time_derivs=[0], dlim={0: [lo, up]})
+    builder = OptimizationBuilder(T, robots=[robot], tasks=[tau], derivs_align=True)          builder.py:14-99
+    qc, dqc, goal = add_parameter("qc", 7), add_parameter("dqc", 7), add_parameter("goal", 3, T)
+    fix_configuration(name, qc); fix_configuration(name, dqc, time_deriv=1)                   builder.py:525-539
+    integrate_model_states(name, 1, dt); integrate_model_states(name, 2, dt)                  builder.py:419-469
+    add_equality_constraint("dynamics", lhs=robot.rnea(Q, dQ, ddQ), rhs=TAU)                  models.py:1731-1884
+    enforce_model_limits("tau")                                                               builder.py:471-509
+    add_cost_term("track", w_p * sumsqr(p_link(Q) - goal)); add_cost_term("effort", w_tau * sumsqr(TAU))
+
+This module holds (i) a vectorised, dtype-agnostic restatement of the reference's RNEA recursion (checked against the
+literal oracle.robot.rnea) whose Jacobian comes from complex-step differentiation -- no hand-written derivative code, so
+it is an independent check of the tangent recursion inside the HIP kernel; (ii) ``solve_torque_lm``: a numpy port of the
+state machine the HIP path runs (tau eliminated through the dynamics rows, linear rows rolled out exactly, effort limits
+through the Powell-Hestenes-Rockafellar augmented Lagrangian, Gauss-Newton / Levenberg-Marquardt steps from a Riccati
+sweep over the stage (q_t, dq_t | ddq_t)).  The literal NLP (x / p / v layout of the reference) is
+oracle.problems.TorqueMPCNLP; independent solvers on it: oracle.solvers.scipy_minimize and kkt_reference_form.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+"""
+import numpy as np
+
+from .robot import OracleRobot, rnea_tables
+from .spatialmath import rpy2r
+from .structured import FoldedChain
+
+
+class RneaTables:
+    """Constants of RobotModel.rnea in the selection the reference makes (models.py:1742-1784; oracle.robot.rnea_tables)."""
+
+    def __init__(self, robot: OracleRobot):
+        m, cm, Icm, xyzs, rpys, axes = rnea_tables(robot)
+        self.n = len(xyzs)  # bodies (the last one hangs on a fixed joint)
+        self.ndof = self.n - 1
+        self.m = np.asarray(m, float)
+        self.cm = np.asarray(cm, float).T.copy()  # (n, 3)
+        self.I = np.stack(Icm)  # (n, 3, 3)
+        self.xyz = np.stack(xyzs)
+        self.R0 = np.stack([rpy2r(r) for r in rpys])
+        self.axis = np.stack(axes)
+        self.K = np.stack([np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0.0]]) for a in self.axis])
+
+
+def _cross(a, b):
+    return np.stack([a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1], a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2],
+                     a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]], -1)
+
+
+def rnea_batch(tb: RneaTables, q, qd, qdd):
+    """models.py:1819-1880 over leading batch axes; q, qd, qdd (..., ndof) real or complex -> tau (..., ndof)."""
+    q, qd, qdd = np.asarray(q), np.asarray(qd), np.asarray(qdd)
+    dt_ = np.result_type(q.dtype, qd.dtype, qdd.dtype, float)
+    shp = np.broadcast_shapes(q.shape, qd.shape, qdd.shape)[:-1]
+    n = tb.n
+    om = np.zeros(shp + (3,), dt_)
+    omD = np.zeros(shp + (3,), dt_)
+    vD = np.zeros(shp + (3,), dt_) + np.array([0.0, 0.0, 9.81])
+    Rs, fs, ns = [], [], []
+    for i in range(n):
+        if i != n - 1:
+            s, c = np.sin(q[..., i])[..., None, None], np.cos(q[..., i])[..., None, None]
+            Rq = np.eye(3) + s * tb.K[i] + (1.0 - c) * (tb.K[i] @ tb.K[i])
+            R = tb.R0[i] @ Rq  # pRi
+        else:
+            R = np.broadcast_to(tb.R0[i], shp + (3, 3)).astype(dt_)
+        Rs.append(R)
+        Rt = np.swapaxes(R, -1, -2)
+        omp = (Rt @ om[..., None])[..., 0]
+        omDp = (Rt @ omD[..., None])[..., 0]
+        if i != n - 1:
+            a = Rt @ tb.axis[i]
+            aq = a * qd[..., i][..., None]
+            omi = omp + aq
+            omDi = omDp + _cross(omp, aq) + a * qdd[..., i][..., None]
+        else:
+            omi, omDi = omp, omDp
+        r = tb.xyz[i]
+        acc = vD + _cross(omD, r) + _cross(om, _cross(om, np.broadcast_to(r, om.shape)))
+        vDi = (Rt @ acc[..., None])[..., 0]
+        c_ = np.broadcast_to(tb.cm[i], om.shape)
+        fi = tb.m[i] * (vDi + _cross(omDi, c_) + _cross(omi, _cross(omi, c_)))
+        Io = (tb.I[i] @ omi[..., None])[..., 0]
+        ni = (tb.I[i] @ omDi[..., None])[..., 0] + _cross(omi, Io)
+        om, omD, vD = omi, omDi, vDi
+        fs.append(fi)
+        ns.append(ni)
+    ifi = fs[n - 1]
+    ini = ns[n - 1] + _cross(np.broadcast_to(tb.cm[n - 1], ifi.shape), fs[n - 1])
+    taus = [None] * (n - 1)
+    for i in range(n - 1, 0, -1):
+        R = Rs[i]
+        Rf = (R @ ifi[..., None])[..., 0]
+        ini = ns[i - 1] + (R @ ini[..., None])[..., 0] + _cross(np.broadcast_to(tb.cm[i - 1], ifi.shape), fs[i - 1]) + _cross(
+            np.broadcast_to(tb.xyz[i], ifi.shape), Rf)
+        ifi = Rf + fs[i - 1]
+        Rt = np.swapaxes(Rs[i - 1], -1, -2)
+        taus[i - 1] = np.sum(ini * (Rt @ tb.axis[i - 1]), -1)
+    return np.stack(taus, -1)
+
+
+def rnea_jacobian(tb: RneaTables, q, qd, qdd, h=1e-30):
+    """d tau / d (q, qd, qdd): (..., ndof, 3 ndof) by complex-step differentiation of rnea_batch (exact to rounding)."""
+    q, qd, qdd = (np.asarray(a, float) for a in (q, qd, qdd))
+    n = tb.ndof
+    z = np.concatenate([q, qd, qdd], -1)[..., None, :] + 1j * h * np.eye(3 * n)  # (..., 3n, 3n)
+    tau = rnea_batch(tb, z[..., :n], z[..., n:2 * n], z[..., 2 * n:])  # (..., 3n, n)
+    return np.swapaxes(tau.imag / h, -1, -2)
+
+
+class TorqueProblem:
+    """Constants of one torque-MPC problem family (shared by the port and the literal NLP)."""
+
+    def __init__(self, robot: OracleRobot, link, T=30, dt=0.1, w_path=1000.0, w_tau=1e-3, w_vel=0.0, tau_lim=None):
+        self.robot, self.link, self.T, self.dt = robot, link, T, dt
+        self.w_path, self.w_tau, self.w_vel = w_path, w_tau, w_vel
+        self.tb = RneaTables(robot)
+        self.chain = FoldedChain(robot, link)
+        self.n = robot.ndof
+        assert self.tb.ndof == self.n
+        eff = np.array([j.limit["effort"] for j in robot.joints if j.type != "fixed"]) if tau_lim is None else np.broadcast_to(
+            np.asarray(tau_lim, float), (self.n,)).copy()
+        self.tau_lo, self.tau_up = -eff, eff
+
+    def rollout(self, qc, dqc, U):
+        T, dt = self.T, self.dt
+        Q = np.zeros((T, self.n))
+        dQ = np.zeros((T, self.n))
+        Q[0], dQ[0] = qc, dqc
+        for t in range(T - 1):
+            Q[t + 1] = Q[t] + dt * dQ[t]
+            dQ[t + 1] = dQ[t] + dt * U[t]
+        return Q, dQ
+
+    def goal_figure_eight(self, qc, scale=1.0):
+        """Synthetic goal of SURVEY 8(d) C5: figure-eight offset (figure_eight_plan.py:90-96 pattern, first 3 s of it) in the
+        end-effector frame at qc."""
+        e, Re, _, _ = self.chain.fk(np.asarray(qc)[None])
+        ts = np.arange(self.T) * self.dt
+        loc = scale * np.stack([0.2 * np.sin(ts * np.pi * 0.5), 0.1 * np.sin(ts * np.pi), np.zeros_like(ts)], 1)
+        return e[0][None] + loc @ Re[0].T
+
+
+def riccati_torque(H, g, mu, dt, mu_u=None):
+    """Backward/forward sweep for  min sum_t 1/2 dz_t^T (H_t + mu I) dz_t + g_t^T dz_t,  dz_t = (dx_t (2n), du_t (n)),
+    dx_{t+1} = A dx_t + B du_t, dx_0 = 0, A = [[I, dt I], [0, I]], B = [0; dt I].  Returns (dz (T, 3n), ok, qk) with
+    qk = sum_t qu_t^T k_t (the damped model's optimal value is -qk/2)."""
+    T, m = g.shape
+    n = m // 3
+    nx = 2 * n
+    A = np.eye(nx)
+    A[:n, n:] = dt * np.eye(n)
+    Bm = np.zeros((nx, n))
+    Bm[n:] = dt * np.eye(n)
+    P = np.zeros((nx, nx))
+    p = np.zeros(nx)
+    Ks, ks = [None] * T, [None] * T
+    qk = 0.0
+    for t in range(T - 1, -1, -1):
+        Ht = H[t] + np.diag(np.concatenate([mu * np.ones(nx), (mu if mu_u is None else mu_u) * np.ones(n)]))
+        Qxx = Ht[:nx, :nx] + A.T @ P @ A
+        Qux = Ht[nx:, :nx] + Bm.T @ P @ A
+        Quu = Ht[nx:, nx:] + Bm.T @ P @ Bm
+        qx = g[t, :nx] + A.T @ p
+        qu = g[t, nx:] + Bm.T @ p
+        try:
+            L = np.linalg.cholesky(Quu)
+        except np.linalg.LinAlgError:
+            return None, False, 0.0
+        K = np.linalg.solve(L.T, np.linalg.solve(L, Qux))
+        k = np.linalg.solve(L.T, np.linalg.solve(L, qu))
+        P = Qxx - Qux.T @ K
+        P = 0.5 * (P + P.T)
+        p = qx - Qux.T @ k
+        Ks[t], ks[t] = K, k
+        qk += float(qu @ k)
+    dz = np.zeros((T, m))
+    dx = np.zeros(nx)
+    for t in range(T):
+        du = -ks[t] - Ks[t] @ dx
+        dz[t, :nx], dz[t, nx:] = dx, du
+        dx = A @ dx + Bm @ du
+    return dz, True, qk
+
+
+def costate_gradient(g, dt):
+    """Gradient of the rolled-out objective w.r.t. the free variables u_t from the stage gradients g_t = dl_t/d(x_t, u_t)."""
+    T, m = g.shape
+    n = m // 3
+    lam = np.zeros(2 * n)
+    gu = np.zeros((T, n))
+    for t in range(T - 1, -1, -1):
+        gu[t] = g[t, 2 * n:] + dt * lam[n:]
+        gx = g[t, :2 * n]
+        lam = np.concatenate([gx[:n] + lam[:n], gx[n:] + dt * lam[:n] + lam[n:]])
+    return gu
+
+
+def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, rho0=None, mu0=0.0, verbose=False, damp_u=0.0, hess_extra=None):
+    """The state machine of csrc/oh_torque.hip in numpy (one instance)."""
+    T, n, dt = prob.T, prob.n, prob.dt
+    wp, wt, wv = prob.w_path, prob.w_tau, prob.w_vel
+    lo, up = prob.tau_lo, prob.tau_up
+    U = np.zeros((T, n)) if U0 is None else np.array(U0, float)
+    lam = np.zeros((T, 2 * n))
+    rho = rho_next = (1.0 if rho0 is None else rho0)
+    omega = max(tol, 1e-2)
+    meas_prev = np.inf
+
+    def evalp(U, lam, rho):
+        Q, dQ = prob.rollout(qc, dqc, U)
+        tau = rnea_batch(prob.tb, Q, dQ, U)
+        J = rnea_jacobian(prob.tb, Q, dQ, U)  # (T, n, 3n)
+        e, _, Jp, _ = prob.chain.jac(Q)
+        r = e - goal
+        gv = np.concatenate([tau - lo, up - tau], 1)
+        s = np.maximum(0.0, lam - rho * gv)
+        psi = (s * s - lam * lam) / (2.0 * rho)
+        phi = wp * np.sum(r * r, 1) + wt * np.sum(tau * tau, 1) + wv * np.sum(dQ * dQ, 1) + psi.sum(1)
+        c = 2.0 * wt * tau - s[:, :n] + s[:, n:]
+        d = 2.0 * wt + rho * ((s[:, :n] > 0).astype(float) + (s[:, n:] > 0).astype(float))
+        g = np.einsum("ti,tid->td", c, J)
+        g[:, :n] += 2.0 * wp * np.einsum("tki,tk->ti", Jp, r)
+        g[:, n:2 * n] += 2.0 * wv * dQ
+        H = np.einsum("ti,tid,tie->tde", d, J, J)
+        H[:, :n, :n] += 2.0 * wp * np.einsum("tki,tkj->tij", Jp, Jp)
+        H[:, n:2 * n, n:2 * n] += 2.0 * wv * np.eye(n)
+        if hess_extra is not None:
+            H = H + hess_extra(Q, dQ, U, c)
+        meas = float(np.abs(np.minimum(gv, lam / rho)).max())
+        return float(phi.sum()), g, H, gv, meas, (Q, dQ, tau, J, c)
+
+    mu, nun = mu0, 2.0
+    iters = rejected = outers = 0
+    first, outer = True, False
+    Ut = U
+    cur = None
+    status = 1
+    pred = 0.0
+    while True:
+        if outer:
+            lam = np.maximum(0.0, lam - rho * cur["gv"])
+            rho = rho_next
+            outers += 1
+        f_t, g, H, gv, meas_t, traj = evalp(Ut, lam, rho)
+        if first or outer:
+            accept, first, outer = True, False, False
+        else:
+            ratio = (cur["f"] - f_t) / max(pred, 1e-300)
+            accept = np.isfinite(f_t) and (ratio > 1e-4 or (pred <= 1e-15 * abs(cur["f"]) and f_t <= cur["f"] + 1e-14 * abs(cur["f"])))
+            if accept:
+                mu *= max(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3)
+                mu = 0.0 if mu < 1e-7 else mu
+                nun = 2.0
+            else:
+                mu = max(mu * nun, 1e-3)
+                nun *= 2.0
+                rejected += 1
+        if accept:
+            cur = {"U": Ut, "f": f_t, "g": g, "H": H, "gv": gv, "meas": meas_t, "traj": traj}
+        stat = float(np.max(np.abs(costate_gradient(cur["g"], dt))))
+        if verbose:
+            print(f"  steps {iters:3d} f={cur['f']:.12f} stat={stat:.3e} meas={cur['meas']:.3e} mu={mu:.3g} rho={rho:.1e} omega={omega:.1e} outers={outers}")
+        if stat <= omega:
+            meas = cur["meas"]
+            if stat <= tol and meas <= tol_feas:
+                status = 0
+                break
+            if iters >= max_iter:
+                break
+            rho_next = min(rho * 10.0, 1e8) if meas > 0.25 * meas_prev else rho
+            meas_prev = meas
+            omega = max(tol, min(omega, 0.1 * meas))
+            outer = True
+            Ut = cur["U"]
+            iters += 1
+            continue
+        if iters >= max_iter:
+            break
+        while True:
+            dz, ok, qk = riccati_torque(cur["H"], cur["g"], mu, dt, damp_u * mu)
+            if ok:
+                break
+            mu = max(4.0 * mu, 1e-2)
+        pred = 0.5 * qk + 0.5 * mu * float(np.sum(dz[:, :2 * n] ** 2)) + 0.5 * damp_u * mu * float(np.sum(dz[:, 2 * n:] ** 2))
+        Ut = cur["U"] + dz[:, 2 * n:]
+        iters += 1
+    Q, dQ, tau = cur["traj"][:3]
+    gv = np.concatenate([tau - lo, up - tau], 1)
+    lam_out = np.maximum(0.0, lam - rho * gv)
+    e, _, _, _ = prob.chain.fk(Q)
+    f_true = float(wp * np.sum((e - goal) ** 2) + wt * np.sum(tau * tau) + wv * np.sum(dQ * dQ))
+    return {"U": cur["U"], "Q": Q, "dQ": dQ, "tau": tau, "f": f_true, "iters": iters, "rejected": rejected, "outers": outers, "stat": stat,
+            "meas": cur["meas"], "status": status, "lam": lam_out}

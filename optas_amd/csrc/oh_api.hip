@@ -497,7 +497,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     h->tq_cap = 0;
     const size_t BT = (size_t)B * T;
     const size_t nd = 2 * BT * TQ_XS + 2 * BT * TQ_SD + BT * TQ_LAM + BT * TQ_GN + BT * 4 + 11 * (size_t)B;
-    const size_t bytes = nd * sizeof(double) + (7 * (size_t)B + 16) * sizeof(int);
+    const size_t bytes = nd * sizeof(double) + (8 * (size_t)B + 16) * sizeof(int);
     HIPCHK(hipMalloc(&h->tq_pool, bytes));
     HIPCHK(hipMalloc((void**)&h->d_tq_mult, sizeof(double) * BT * 2 * N));
     h->tq_cap = B;
@@ -520,7 +520,10 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     int* ip = (int*)d;
     D.cur = ip; ip += B; D.first = ip; ip += B; D.outer = ip; ip += B; D.status = ip; ip += B; D.iters = ip; ip += B; D.rejected = ip; ip += B;
     D.n_outer = ip; ip += B;
+    D.list = ip; ip += B;
     D.n_running = ip;
+    D.n_list = ip + 1;
+    D.n_run = B;
   }
   hipStream_t s = h->stream;
   HIPCHK(hipEventRecord(h->ev0, s));
@@ -542,6 +545,11 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
       HIPCHK(hipStreamSynchronize(s));
       running = *h->h_flag;
       if (running == 0) break;
+      if (running <= 0.9 * D.n_run) {  // rebuild the list of running instances: grids shrink with the batch
+        HIPCHK(hipMemsetAsync(D.n_list, 0, sizeof(int), s));
+        oh_launch_tq_list(s, D);
+        D.n_run = running;
+      }
     }
   }
   oh_launch_tq_finalize(s, P, D, (double*)d_x, (double*)d_f, (double*)d_kkt, (int*)d_iters, (int*)d_status, h->d_tq_mult);

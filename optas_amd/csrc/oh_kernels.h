@@ -163,7 +163,11 @@ struct TqBuffers {
   double *f_cur, *f_true, *pred, *mu, *nun, *rho, *rho_next, *omega, *meas_prev, *meas, *stat;  // [B]
   int *cur, *first, *outer, *status, *iters, *rejected, *n_outer;                                // [B]
   int* n_running;  // [1]
+  int* list;       // [B] instances still running when the list was last rebuilt (kernels walk this list: finished instances cost nothing)
+  int* n_list;     // [1]
+  int n_run;       // length of the list the launches below cover
 };
+void oh_launch_tq_list(hipStream_t s, const TqBuffers& D);
 bool oh_launch_tq_setup(hipStream_t s, const TqParams& P, const TqBuffers& D, const double* x0, const double* p);
 bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D);
 bool oh_launch_tq_step(hipStream_t s, const TqParams& P, const TqBuffers& D);

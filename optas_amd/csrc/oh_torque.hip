@@ -89,9 +89,61 @@ OH_DEV void joint_rotation(const double* R0, const double* a, const S s, const S
 }
 
 // RobotModel.rnea (models.py:1819-1880) on scalars S (double or Dual): NB bodies, the last one on a fixed joint.
+// The loops over the bodies are kept rolled (the per-body wrenches f, nn and sin/cos live in lane-private memory, indexed by the
+// loop counter): unrolled, the dual-number recursion needs ~1500 live registers and the compiler spills two thirds of them.
+template <int NB, class S>
+OH_DEV void rnea_forward_body(const oh_dynamics* __restrict__ dy, const int i, const bool moving, const S qi, const S qdi, const S qddi, S (&om)[3],
+                              S (&omD)[3], S (&vD)[3], S* __restrict__ fi, S* __restrict__ ni, S& sji, S& cji) {
+  S omi[3], omDi[3], vDi[3];
+  S t1[3], t2[3], t3[3], acc[3];
+  crossT(omD, dy->xyz[i], t1);
+  crossT(om, dy->xyz[i], t2);
+  crossT(om, t2, t3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc[k] = vD[k] + t1[k] + t3[k];
+  if (moving) {
+    S Rp[9];
+    sincosT(qi, &sji, &cji);
+    joint_rotation(dy->R0[i], dy->axis[i], sji, cji, Rp);
+    S a[3], omp[3], omDp[3];
+    mTvT(Rp, dy->axis[i], a);  // iaxisi
+    mTvT(Rp, om, omp);
+    mTvT(Rp, omD, omDp);
+    S aq[3] = {a[0] * qdi, a[1] * qdi, a[2] * qdi};
+    S cr[3];
+    crossT(omp, aq, cr);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      omi[k] = omp[k] + aq[k];
+      omDi[k] = omDp[k] + cr[k] + a[k] * qddi;
+    }
+    mTvT(Rp, acc, vDi);
+  } else {
+    mTvT(dy->R0[i], om, omi);
+    mTvT(dy->R0[i], omD, omDi);
+    mTvT(dy->R0[i], acc, vDi);
+  }
+  crossT(omDi, dy->com[i], t1);
+  crossT(omi, dy->com[i], t2);
+  crossT(omi, t2, t3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) fi[k] = dy->mass[i] * (vDi[k] + t1[k] + t3[k]);
+  S Io[3], IoD[3];
+  mvT(dy->inertia[i], omi, Io);
+  mvT(dy->inertia[i], omDi, IoD);
+  crossT(omi, Io, t1);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    ni[k] = IoD[k] + t1[k];
+    om[k] = omi[k];
+    omD[k] = omDi[k];
+    vD[k] = vDi[k];
+  }
+}
+
 template <int NB, class S>
 OH_DEV void rnea_lit(const oh_dynamics* __restrict__ dy, const S (&q)[NB - 1], const S (&qd)[NB - 1], const S (&qdd)[NB - 1], S (&tau)[NB - 1]) {
-  S f[NB][3], nn[NB][3], sj[NB - 1], cj[NB - 1];
+  S f[NB][3], nn[NB][3], sj[NB], cj[NB];
   S om[3], omD[3], vD[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -99,61 +151,16 @@ OH_DEV void rnea_lit(const oh_dynamics* __restrict__ dy, const S (&q)[NB - 1], c
     omD[k] = S{};
     vD[k] = S{} + dy->vd0[k];
   }
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    S omi[3], omDi[3], vDi[3];
-    S t1[3], t2[3], t3[3], acc[3];
-    crossT(omD, dy->xyz[i], t1);
-    crossT(om, dy->xyz[i], t2);
-    crossT(om, t2, t3);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) acc[k] = vD[k] + t1[k] + t3[k];
-    if (i != NB - 1) {
-      S Rp[9];
-      sincosT(q[i], &sj[i], &cj[i]);
-      joint_rotation(dy->R0[i], dy->axis[i], sj[i], cj[i], Rp);
-      S a[3], omp[3], omDp[3];
-      mTvT(Rp, dy->axis[i], a);  // iaxisi
-      mTvT(Rp, om, omp);
-      mTvT(Rp, omD, omDp);
-      S aq[3] = {a[0] * qd[i], a[1] * qd[i], a[2] * qd[i]};
-      S cr[3];
-      crossT(omp, aq, cr);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        omi[k] = omp[k] + aq[k];
-        omDi[k] = omDp[k] + cr[k] + a[k] * qdd[i];
-      }
-      mTvT(Rp, acc, vDi);
-    } else {
-      mTvT(dy->R0[i], om, omi);
-      mTvT(dy->R0[i], omD, omDi);
-      mTvT(dy->R0[i], acc, vDi);
-    }
-    crossT(omDi, dy->com[i], t1);
-    crossT(omi, dy->com[i], t2);
-    crossT(omi, t2, t3);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) f[i][k] = dy->mass[i] * (vDi[k] + t1[k] + t3[k]);
-    S Io[3], IoD[3];
-    mvT(dy->inertia[i], omi, Io);
-    mvT(dy->inertia[i], omDi, IoD);
-    crossT(omi, Io, t1);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      nn[i][k] = IoD[k] + t1[k];
-      om[k] = omi[k];
-      omD[k] = omDi[k];
-      vD[k] = vDi[k];
-    }
-  }
+#pragma unroll 1
+  for (int i = 0; i < NB - 1; ++i) rnea_forward_body<NB, S>(dy, i, true, q[i], qd[i], qdd[i], om, omD, vD, f[i], nn[i], sj[i], cj[i]);
+  rnea_forward_body<NB, S>(dy, NB - 1, false, S{}, S{}, S{}, om, omD, vD, f[NB - 1], nn[NB - 1], sj[NB - 1], cj[NB - 1]);
   // backward (models.py:1858-1880); the reference's fs/ns lists carry a leading zero entry: fs[i] == f[i-1]
   S ifi[3] = {f[NB - 1][0], f[NB - 1][1], f[NB - 1][2]};
   S ini[3], t1[3];
   crossT(dy->com[NB - 1], f[NB - 1], t1);
 #pragma unroll
   for (int k = 0; k < 3; ++k) ini[k] = nn[NB - 1][k] + t1[k];
-#pragma unroll
+#pragma unroll 1
   for (int i = NB - 1; i >= 1; --i) {
     S a1[3], a2[3], a3[3], a4[3];
     if (i < NB - 1) {
@@ -241,6 +248,13 @@ __global__ __launch_bounds__(64) void k_tq_setup(TqParams P, TqBuffers D, const 
   D.iters[b] = 0;
   D.rejected[b] = 0;
   D.n_outer[b] = 0;
+  D.list[b] = b;
+}
+
+__global__ __launch_bounds__(256) void k_tq_list(TqBuffers D) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= D.B) return;
+  if (D.status[b] < 0) D.list[atomicAdd(D.n_list, 1)] = b;
 }
 
 // ---- evaluation -----------------------------------------------------------------------------------------------------------------------
@@ -256,12 +270,14 @@ __global__ __launch_bounds__(64) void k_tq_eval(TqParams P, TqBuffers D) {
     ul = UPW - 1;
     d = NZ;
   }
-  const long long n_units = (long long)D.B * T;
+  const long long n_units = (long long)D.n_run * T;
   long long unit = (long long)blockIdx.x * UPW + ul;
   bool active = d < NZ && unit < n_units;
   if (unit >= n_units) unit = n_units - 1;
-  const int b = (int)(unit / T), t = (int)(unit - (long long)b * T);
+  const int li = (int)(unit / T), t = (int)(unit - (long long)li * T);
+  const int b = D.list[li];
   if (D.status[b] >= 0) active = false;
+  if (!__any(active)) return;  // one wavefront per block: every instance of this wavefront has finished since the list was built
   const int ts = 1 - D.cur[b];
   const double* xr = D.xs + xs_off(D, T, ts, b, t);
   const bool outer = D.outer[b] != 0;
@@ -413,8 +429,8 @@ __global__ __launch_bounds__(64) void k_tq_step(TqParams P, TqBuffers D) {
   const int T = P.T;
   const int gi = threadIdx.x >> 4, c = threadIdx.x & 15;
   const int b_raw = blockIdx.x * 4 + gi;
-  const bool valid = b_raw < D.B;
-  const int b = valid ? b_raw : D.B - 1;
+  const bool valid = b_raw < D.n_run;
+  const int b = D.list[valid ? b_raw : D.n_run - 1];
   double* S = sm[gi];
   double* Hs = S;
   double* Ps = S + OFF_P;
@@ -425,6 +441,7 @@ __global__ __launch_bounds__(64) void k_tq_step(TqParams P, TqBuffers D) {
   const double dt = P.dt;
 
   bool run = valid && D.status[b] < 0;
+  if (!__any(run)) return;
   int cur = D.cur[b];
   const int ts = 1 - cur;
   // merit of the trial point
@@ -715,15 +732,16 @@ bool oh_launch_tq_setup(hipStream_t s, const TqParams& P, const TqBuffers& D, co
   hipLaunchKernelGGL(k_tq_setup<7>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p);
   return true;
 }
+void oh_launch_tq_list(hipStream_t s, const TqBuffers& D) { hipLaunchKernelGGL(k_tq_list, dim3((D.B + 255) / 256), dim3(256), 0, s, D); }
 bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D) {
   if (P.N != 7) return false;
-  const long long units = (long long)D.B * P.T;
+  const long long units = (long long)D.n_run * P.T;
   hipLaunchKernelGGL(k_tq_eval<7>, dim3((unsigned)((units + 2) / 3)), dim3(64), 0, s, P, D);
   return true;
 }
 bool oh_launch_tq_step(hipStream_t s, const TqParams& P, const TqBuffers& D) {
   if (P.N != 7) return false;
-  hipLaunchKernelGGL(k_tq_step<7>, dim3((D.B + 3) / 4), dim3(64), 0, s, P, D);
+  hipLaunchKernelGGL(k_tq_step<7>, dim3((D.n_run + 3) / 4), dim3(64), 0, s, P, D);
   return true;
 }
 bool oh_launch_tq_finalize(hipStream_t s, const TqParams& P, const TqBuffers& D, double* x, double* f, double* kkt, int* iters, int* status, double* mult) {

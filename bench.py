@@ -9,9 +9,10 @@ A "step" is one pass of the hot path over one batch: one batched NLP solve (oh_s
 independent instances per GPU, inputs (seeds x0, parameters qc) already resident in HBM.  Instances are
 SURVEY 8(d)'s synthetic set: qc = deg2rad[0,30,0,-90,0,-30,0] + U(-0.1,0.1)^7, seed = qc repeated,
 numpy default_rng(20260927 + rank).  Multi-GPU: instances shard across ranks with no data-path
-collective; the kinematic constants (oh_chain, 2952 B) are broadcast once over RCCL (torch.distributed
-"nccl" backend) from rank 0 and handed to the library as a device pointer.  torch is imported only
-when WORLD_SIZE > 1 (rendezvous, that one broadcast, barriers, MAX-reduce of the time).
+collective; rank 0 alone sets the kinematic constants (oh_chain, 2952 B) and the library broadcasts them
+once over RCCL/xGMI (oh_comm_broadcast_constants).  No torch anywhere: the communicator lives inside
+liboptas_hip, Python only carries the 128-byte RCCL unique id from rank 0 to the others through a file
+(optas_amd/distributed.py); barriers and the MAX-reduce of the elapsed time go through oh_comm_* too.
 
 Prints ONE JSON line on rank 0.
 """
@@ -156,29 +157,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("OH_BENCH_DIST_AT_1", "1") == "1")  # torchrun launch
-    if use_dist:
+    comm = None
+    if world > 1 or ("RANK" in os.environ and os.environ.get("OH_BENCH_DIST_AT_1", "1") == "1"):  # launcher-started: one rank per GPU
         from optas_amd import distributed as oad
 
-        dist = oad.init_process_group("nccl", local_rank)  # RCCL
+        comm = oad.init_from_env()  # oh_set_device(local_rank) + RCCL communicator inside liboptas_hip
     lib = _lib.load()
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: liboptas_hip has no CPU path")
     _lib.check(lib.oh_set_device(local_rank), "oh_set_device")
 
     dt, lp = local_path()
-    robot = optas_amd.RobotModel.builtin("kuka_lwr")
-    chain = robot.kinematic_chain(LINK)
-    be = FigureEightBackend(chain, T, dt, lp, max_iter=args.max_iter, tol=args.tol,
-                            hessian={"gauss_newton": 0, "exact": 1, "hybrid": 2}[args.hessian])
-    if use_dist:
-        # the one collective of the whole job: kinematic constants, rank 0 -> all, over RCCL/xGMI
-        import torch
-
-        buf, _ = oad.broadcast_chain(chain, f"cuda:{local_rank}", src=0)
-        torch.cuda.synchronize()
-        be.set_constants_device(buf.data_ptr(), C.sizeof(_lib.oh_chain))
+    hess = {"gauss_newton": 0, "exact": 1, "hybrid": 2}[args.hessian]
+    if comm is None or rank == 0:
+        robot = optas_amd.RobotModel.builtin("kuka_lwr")
+        be = FigureEightBackend(robot.kinematic_chain(LINK), T, dt, lp, max_iter=args.max_iter, tol=args.tol, hessian=hess)
+    else:  # the other ranks never read the URDF: they get the folded constants from rank 0
+        be = FigureEightBackend(None, T, dt, lp, max_iter=args.max_iter, tol=args.tol, hessian=hess, ndof=7)
+    if comm is not None:
+        comm.broadcast_constants(be.handle, root=0)  # the one collective of the whole job
 
     B = args.batch
     x0, qc = make_inputs(B, rank)
@@ -193,9 +190,8 @@ def main():
 
     def sync_all():
         _lib.check(lib.oh_device_synchronize(), "sync")
-        if dist is not None:
-            dist.barrier()
-            _lib.check(lib.oh_device_synchronize(), "sync")
+        if comm is not None:
+            comm.barrier()
 
     be.set_profiling(True)
     for _ in range(args.warmup):
@@ -210,8 +206,8 @@ def main():
             tm[k] += t[k]
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        elapsed = oad.max_over_ranks(elapsed, f"cuda:{local_rank}")
+    if comm is not None:
+        elapsed = comm.max_over_ranks(elapsed)
 
     status = d_st.download(np.int32, (B,))
     iters = d_it.download(np.int32, (B,))
@@ -237,9 +233,9 @@ def main():
         b.free()
 
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        if comm is not None:
+            comm.barrier()
+            comm.destroy()
         return
 
     # (instance, knot) units the batched kernels actually processed (k_step counts running instances per launch;
@@ -327,9 +323,9 @@ def main():
     }
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.hessian)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.destroy()
     print(json.dumps(out))
 
 

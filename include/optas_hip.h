@@ -296,6 +296,27 @@ int oh_create_ik(const oh_ik_desc* desc, oh_handle** out);
 int oh_set_constants(oh_handle* h, const oh_chain* chain);
 int oh_set_constants_device(oh_handle* h, const void* d_chain, size_t nbytes);
 
+/*
+ * Multi-GPU (one process per GPU).  MPC instances are independent: the host shards them over the ranks and nothing is exchanged on
+ * the data path.  The single collective of a job is the broadcast of the URDF-derived constants (the reference has no
+ * counterpart -- it is one process with one problem, solver.py:64-88).  The library owns the RCCL communicator:
+ *   rank 0:  oh_comm_unique_id(id)  -> ship the 128 bytes to the other ranks (file, socket, environment: the host's business)
+ *   all:     oh_set_device(local_rank); oh_comm_init(rank, world, id)
+ *   root:    oh_set_constants(h, chain);  all: oh_comm_broadcast_constants(h, root)   (ncclBroadcast over xGMI, in place in the handle)
+ * oh_comm_barrier / oh_comm_allreduce_{max,sum} (one host double, in place) are what a timing harness needs around the solves.
+ * librccl is opened with dlopen on first use; processes that never create a communicator do not load it.
+ */
+#define OH_COMM_ID_BYTES 128
+int oh_comm_unique_id(char* id /* [OH_COMM_ID_BYTES] */);
+int oh_comm_init(int rank, int world, const char* id /* [OH_COMM_ID_BYTES] */);
+int oh_comm_broadcast_constants(oh_handle* h, int root);
+int oh_comm_barrier(void);
+int oh_comm_allreduce_max(double* value);
+int oh_comm_allreduce_sum(double* value);
+int oh_comm_destroy(void);
+/* The constants a handle holds (after oh_set_constants* or oh_comm_broadcast_constants). */
+int oh_get_constants(oh_handle* h, oh_chain* out);
+
 /* Inequality rows for the trajectory families (see oh_guards). */
 int oh_set_guards(oh_handle* h, const oh_guards* guards);
 

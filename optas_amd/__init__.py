@@ -5,6 +5,9 @@ Host side: plain Python + ctypes over liboptas_hip.so (hand-written HIP for gfx9
 from .spatialmath import *  # noqa: F401,F403  (the reference re-exports its spatialmath, optas/__init__.py:3)
 from .models import RobotModel, TaskModel, Model, JointTypeNotSupported  # noqa: F401
 from . import _lib  # noqa: F401
+from .builder import OptimizationBuilder  # noqa: F401,E402  (optas/__init__.py:5)
+from .solver import HIPSolver, Solver  # noqa: F401,E402  (optas/__init__.py:6 exports its solver classes)
+from .expr import atan2, path_in_frame, sumsqr, vertcat  # noqa: F401,E402  (the casadi functions the scripts use, optas/__init__.py:2)
 
 import numpy as np
 

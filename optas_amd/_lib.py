@@ -16,6 +16,7 @@ OH_MAX_CHAIN = 16
 OH_MAX_T = 128
 OH_MAX_SPHERE_LINKS = 8
 OH_MAX_OBSTACLES = 16
+OH_COMM_ID_BYTES = 128
 
 OH_OK, OH_ERR_INVALID, OH_ERR_HIP, OH_ERR_STATE = 0, 1, 2, 3
 OH_STATUS_CONVERGED, OH_STATUS_MAX_ITER, OH_STATUS_NUMERICAL = 0, 1, 2
@@ -191,6 +192,14 @@ SYMBOLS = [
     "oh_tape_compile",
     "oh_set_constants",
     "oh_set_constants_device",
+    "oh_get_constants",
+    "oh_comm_unique_id",
+    "oh_comm_init",
+    "oh_comm_broadcast_constants",
+    "oh_comm_barrier",
+    "oh_comm_allreduce_max",
+    "oh_comm_allreduce_sum",
+    "oh_comm_destroy",
     "oh_set_guards",
     "oh_solve",
     "oh_solve_device",

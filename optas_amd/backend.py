@@ -268,8 +268,16 @@ class FigureEightBackend:
         fix_dq0: bool = True,
         path_in_frame: bool = True,
         guards: "Optional[_lib.oh_guards]" = None,
+        ndof: Optional[int] = None,
     ):
+        """``chain=None`` (with ``ndof``) creates the handle without kinematic constants: a non-root rank of a multi-GPU job receives them with
+        ``optas_amd.distributed.Communicator.broadcast_constants`` before its first solve."""
         lib = _lib.load()
+        if chain is None:
+            assert ndof is not None, "a handle without constants needs ndof"
+            chain_arg, chain = None, _lib.oh_chain(ndof=int(ndof))
+        else:
+            chain_arg = chain
         self.T, self.ndof = int(T), int(chain.ndof)
         self.nx = self.ndof * self.T + self.ndof * (self.T - 1)
         # largest batch of one oh_solve call (32-bit stage-array offsets of the sweep kernels, optas_hip.h): bigger ones go in chunks
@@ -296,8 +304,9 @@ class FigureEightBackend:
         )
         self._h = C.c_void_p()
         _lib.check(lib.oh_create(C.byref(desc), C.byref(self._h)), "oh_create")
-        _lib.check(lib.oh_set_constants(self._h, C.byref(chain)), "oh_set_constants")
-        self.chain = chain
+        if chain_arg is not None:
+            _lib.check(lib.oh_set_constants(self._h, C.byref(chain)), "oh_set_constants")
+        self.chain = chain_arg
         self.guards = guards
         self.n_rows = 0
         if guards is not None:
@@ -311,6 +320,12 @@ class FigureEightBackend:
 
     def set_constants_device(self, dptr: int, nbytes: int) -> None:
         _lib.check(_lib.load().oh_set_constants_device(self._h, C.c_void_p(dptr), nbytes), "oh_set_constants_device")
+
+    def constants(self) -> _lib.oh_chain:
+        """The kinematic constants the handle holds (set locally or received by broadcast)."""
+        out = _lib.oh_chain()
+        _lib.check(_lib.load().oh_get_constants(self._h, C.byref(out)), "oh_get_constants")
+        return out
 
     def solve(self, x0: np.ndarray, p: np.ndarray) -> BatchResult:
         lib = _lib.load()

@@ -1,6 +1,8 @@
 // C ABI of liboptas_hip.so (see include/optas_hip.h).  Host-side orchestration only: buffer
 // ownership, the SQP launch loop (eval kernel + Riccati/step kernel per iteration), HIP-event timing.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is opened with dlopen when a communicator is first asked for
 
 #include <cmath>
 #include <cstdio>
@@ -1351,4 +1353,144 @@ extern "C" void oh_destroy(oh_handle* h) {
   oh_tape_jit_release(&h->tape_jit);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Multi-GPU: one process per GPU, instances sharded by the host, no data-path collective.  The single exchange of a job is the
+// broadcast of the URDF-derived constants from one rank; the library owns the RCCL communicator for it (and for the
+// barrier / MAX / SUM reductions a benchmark harness needs), so a ctypes host needs no other GPU runtime.  librccl is opened on first
+// use: single-GPU processes never load it.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+ncclComm_t g_comm = nullptr;
+int g_comm_rank = -1, g_comm_world = 0, g_comm_device = 0;
+hipStream_t g_comm_stream = nullptr;
+double* g_comm_scratch = nullptr;  // device, 2 doubles
+
+int rccl_load() {
+  if (g_rccl.lib) return OH_OK;
+  void* lib = nullptr;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(OH_ERR_HIP, std::string("oh_comm: cannot open librccl: ") + dlerror());
+  RcclApi a;
+  a.lib = lib;
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  a.Broadcast = (decltype(a.Broadcast))dlsym(lib, "ncclBroadcast");
+  a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.Broadcast || !a.AllReduce || !a.GetErrorString) {
+    dlclose(lib);
+    return fail(OH_ERR_HIP, "oh_comm: librccl lacks an expected symbol");
+  }
+  g_rccl = a;
+  return OH_OK;
+}
+int rccl_fail(const char* what, ncclResult_t r) { return fail(OH_ERR_HIP, std::string(what) + ": " + g_rccl.GetErrorString(r)); }
+#define RCCLCHK(expr)                                  \
+  do {                                                 \
+    ncclResult_t _r = (expr);                          \
+    if (_r != ncclSuccess) return rccl_fail(#expr, _r); \
+  } while (0)
+}  // namespace
+
+extern "C" int oh_comm_unique_id(char* id) {
+  if (!id) return fail(OH_ERR_INVALID, "oh_comm_unique_id: null");
+  static_assert(OH_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+  if (const int rc = rccl_load()) return rc;
+  ncclUniqueId u;
+  RCCLCHK(g_rccl.GetUniqueId(&u));
+  memcpy(id, u.internal, OH_COMM_ID_BYTES);
+  return OH_OK;
+}
+
+extern "C" int oh_comm_init(int rank, int world, const char* id) {
+  if (!id || world < 1 || rank < 0 || rank >= world) return fail(OH_ERR_INVALID, "oh_comm_init: bad rank / world / id");
+  if (g_comm) return fail(OH_ERR_STATE, "oh_comm_init: this process already holds a communicator");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return fail(OH_ERR_HIP, "oh_comm_init: no HIP device available (this library has no CPU path)");
+  if (const int rc = rccl_load()) return rc;
+  HIPCHK(hipGetDevice(&g_comm_device));  // the device selected with oh_set_device
+  ncclUniqueId u;
+  memcpy(u.internal, id, OH_COMM_ID_BYTES);
+  HIPCHK(hipStreamCreate(&g_comm_stream));
+  HIPCHK(hipMalloc((void**)&g_comm_scratch, 2 * sizeof(double)));
+  RCCLCHK(g_rccl.CommInitRank(&g_comm, world, u, rank));
+  g_comm_rank = rank;
+  g_comm_world = world;
+  return OH_OK;
+}
+
+extern "C" int oh_comm_destroy(void) {
+  if (!g_comm) return OH_OK;
+  hipSetDevice(g_comm_device);
+  hipStreamSynchronize(g_comm_stream);
+  g_rccl.CommDestroy(g_comm);
+  g_comm = nullptr;
+  hipFree(g_comm_scratch);
+  g_comm_scratch = nullptr;
+  hipStreamDestroy(g_comm_stream);
+  g_comm_stream = nullptr;
+  g_comm_rank = -1;
+  g_comm_world = 0;
+  return OH_OK;
+}
+
+static int comm_allreduce(double* value, ncclRedOp_t op, const char* who) {
+  if (!value) return fail(OH_ERR_INVALID, std::string(who) + ": null");
+  if (!g_comm) return fail(OH_ERR_STATE, std::string(who) + ": call oh_comm_init first");
+  HIPCHK(hipSetDevice(g_comm_device));
+  HIPCHK(hipMemcpyAsync(g_comm_scratch, value, sizeof(double), hipMemcpyHostToDevice, g_comm_stream));
+  RCCLCHK(g_rccl.AllReduce(g_comm_scratch, g_comm_scratch + 1, 1, ncclFloat64, op, g_comm, g_comm_stream));
+  HIPCHK(hipMemcpyAsync(value, g_comm_scratch + 1, sizeof(double), hipMemcpyDeviceToHost, g_comm_stream));
+  HIPCHK(hipStreamSynchronize(g_comm_stream));
+  return OH_OK;
+}
+extern "C" int oh_comm_allreduce_max(double* value) { return comm_allreduce(value, ncclMax, "oh_comm_allreduce_max"); }
+extern "C" int oh_comm_allreduce_sum(double* value) { return comm_allreduce(value, ncclSum, "oh_comm_allreduce_sum"); }
+extern "C" int oh_comm_barrier(void) {
+  double one = 1.0;
+  return comm_allreduce(&one, ncclSum, "oh_comm_barrier");
+}
+
+extern "C" int oh_comm_broadcast_constants(oh_handle* h, int root) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_comm_broadcast_constants: null handle");
+  if (!g_comm) return fail(OH_ERR_STATE, "oh_comm_broadcast_constants: call oh_comm_init first");
+  if (root < 0 || root >= g_comm_world) return fail(OH_ERR_INVALID, "oh_comm_broadcast_constants: bad root");
+  if (!h->d_chain) return fail(OH_ERR_STATE, "oh_comm_broadcast_constants: this handle takes no kinematic constants");
+  if (g_comm_rank == root && !h->have_chain) return fail(OH_ERR_STATE, "oh_comm_broadcast_constants: the root must call oh_set_constants first");
+  HIPCHK(hipSetDevice(h->device));
+  // one ncclBroadcast of the oh_chain block (2952 B), in place in the handle's constants buffer, on the handle's stream
+  RCCLCHK(g_rccl.Broadcast(h->d_chain, h->d_chain, sizeof(oh_chain), ncclUint8, root, g_comm, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (g_comm_rank != root) {
+    oh_chain tmp;
+    HIPCHK(hipMemcpy(&tmp, h->d_chain, sizeof(oh_chain), hipMemcpyDeviceToHost));
+    if (const int rc = validate_chain(h, tmp)) return rc;
+    h->chain_host = tmp;
+    h->have_chain = true;
+  }
+  return OH_OK;
+}
+
+extern "C" int oh_get_constants(oh_handle* h, oh_chain* out) {
+  if (!h || !out) return fail(OH_ERR_INVALID, "oh_get_constants: null argument");
+  if (!h->have_chain) return fail(OH_ERR_STATE, "oh_get_constants: no constants set");
+  *out = h->chain_host;
+  return OH_OK;
 }

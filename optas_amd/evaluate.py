@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from .builder import IntegrationResidual
-from .expr import Add, Atan2, Block, Const, Expr, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr, VCat, VarRef
+from .expr import Add, Atan2, Block, Const, Expr, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RneaFunction, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr, VCat, VarRef
 
 
 def _block(container, vec, label):
@@ -69,6 +69,8 @@ def _evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
         if e.what == "geometric_jacobian":
             return np.asarray(e.robot.get_global_link_geometric_jacobian(e.link, q.reshape(-1)))
         return np.asarray(e.robot.get_global_link_rotation(e.link, q.reshape(-1)))
+    if isinstance(e, RneaFunction):
+        return np.asarray(e.robot.rnea(evaluate(e.q, opt, x, p), evaluate(e.qd, opt, x, p), evaluate(e.qdd, opt, x, p))).reshape(e.shape)
     if isinstance(e, PathInFrame):
         return evaluate(e.origin, opt, x, p).reshape(3, 1) + evaluate(e.rotation, opt, x, p) @ e.local
     if isinstance(e, IntegrationResidual):

@@ -281,6 +281,24 @@ class LinkFunction(Expr):
 
 
 @dataclass(eq=False)
+class RneaFunction(Expr):
+    """robot.rnea(q, qd, qdd) of symbolic trajectories (models.py:1731-1884; the reference's arrayify_args / SX graph is evaluated column by
+    column): ndof x n inverse-dynamics torques."""
+
+    robot: object
+    q: Expr = None
+    qd: Expr = None
+    qdd: Expr = None
+
+    def __post_init__(self):
+        assert self.q.shape == self.qd.shape == self.qdd.shape, "rnea: q, qd, qdd must have the same shape"
+        self.shape = self.q.shape
+
+    def degree(self):
+        return 0 if max(self.q.degree(), self.qd.degree(), self.qdd.degree()) == 0 else 3
+
+
+@dataclass(eq=False)
 class PathInFrame(Expr):
     """origin + R @ local[:, k] for every column k (figure_eight_plan.py:90-96)."""
 

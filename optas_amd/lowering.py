@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from .builder import IntegrationResidual
-from .expr import Add, Const, LinkFunction, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr
+from .expr import Add, Const, LinkFunction, ParamCol, ParamRef, PathInFrame, RneaFunction, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr
 from .models import RobotModel, TaskModel
 from .optimization import Optimization
 
@@ -191,8 +191,12 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
             no(f"cost '{label}' is not a weighted sumsqr")
         inner = e.a
         if inner is dQ or is_full(inner, dQ):
+            if w_vel is not None:
+                no(f"cost '{label}': a second joint-velocity term (weights are not summed or overwritten silently)")
             w_vel = w
         elif isinstance(inner, Sub) and isinstance(inner.a, PathInFrame) and isinstance(inner.b, LinkFunction):
+            if w_path is not None:
+                no(f"cost '{label}': a second path-tracking term (weights are not summed or overwritten silently)")
             pth, pos = inner.a, inner.b
             good = (
                 pos.what == "position" and is_full(pos.q, Q) and pos.link == link and pos.robot is robot
@@ -493,12 +497,16 @@ def match_multi_arm(opt: Optimization) -> MultiArmSpec:
         hit = False
         for a in arms.values():
             if inner is a["dQ"]:
+                if "w_vel" in a:
+                    no(f"cost '{label}': a second joint-velocity term for one arm (weights are not summed or overwritten silently)")
                 a["w_vel"], hit = w, True
             elif isinstance(inner, Sub):
                 for pos, pth, sgn in ((inner.a, inner.b, 1), (inner.b, inner.a, 1)):
                     if (isinstance(pos, LinkFunction) and pos.what == "position" and pos.q is a["Q"] and pos.robot is a["robot"]
                             and isinstance(pth, Add) and isinstance(pth.a, LinkFunction) and pth.a.what == "position" and pth.a.link == pos.link
                             and pth.a.robot is a["robot"] and isinstance(pth.a.q, ParamRef) and isinstance(pth.b, Const) and pth.b.value.shape == (3, T)):
+                        if "w_path" in a and not hit:
+                            no(f"cost '{label}': a second path-tracking term for one arm (weights are not summed or overwritten silently)")
                         a["w_path"], a["link"], a["offsets"], a["qc_path"], hit = w, pos.link, np.ascontiguousarray(pth.b.value.T), pth.a.q, True
         if not hit:
             no(f"cost '{label}' not recognised")
@@ -685,10 +693,116 @@ def match_tape(opt: Optimization) -> TapeSpec:
 OH_KIND_MULTI_ARM = 101  # host-side composition of OH_PROBLEM_FIGURE_EIGHT handles with lock_orientation = 0
 
 
+@dataclass
+class TorqueSpec:
+    """BASELINE configs[4]: torque MPC with RobotModel.rnea as equality rows (OH_PROBLEM_TORQUE_MPC)."""
+
+    robot: RobotModel
+    link: str
+    T: int
+    dt: float
+    w_path: float
+    w_vel: float
+    w_tau: float
+    tau_lo: np.ndarray
+    tau_up: np.ndarray
+
+
+def match_torque_mpc(opt: Optimization) -> TorqueSpec:
+    def no(msg):
+        raise LoweringError(f"torque-MPC lowering: {msg}")
+
+    models = list(opt.models or [])
+    robots = [m for m in models if isinstance(m, RobotModel)]
+    tasks = [m for m in models if isinstance(m, TaskModel)]
+    if len(robots) != 1 or len(tasks) != 1 or len(models) != 2:
+        no("expected one RobotModel and one TaskModel (the joint torques)")
+    robot, task = robots[0], tasks[0]
+    n = robot.ndof
+    if list(robot.time_derivs) != [0, 1, 2] or robot.num_param_joints != 0 or list(task.time_derivs) != [0] or task.dim != n:
+        no("robot must have time_derivs=[0, 1, 2] and no parameterised joints; the task model must be ndof-dimensional with time_derivs=[0]")
+    names = [robot.state_optimized_name(d) for d in (0, 1, 2)] + [task.state_optimized_name(0)]
+    if list(opt.decision_variables.keys()) != names:
+        no(f"decision variables must be exactly {names}")
+    Q, dQ, ddQ, TAU = (opt.decision_variables[k] for k in names)
+    T = Q.n
+    if not (dQ.n == ddQ.n == TAU.n == T):
+        no("derivs_align=True is required (every block has T columns)")
+    # linear equalities
+    qc = dqc = None
+    dts = {}
+    for label, diff in opt.lin_eq_constraints.items():
+        if not isinstance(diff, Sub):
+            no(f"linear equality '{label}' not recognised")
+        rhs, lhs = diff.a, diff.b
+        if isinstance(lhs, StateRef) and lhs.t == 0 and lhs.model_name == robot.get_name() and lhs.time_deriv in (0, 1) and isinstance(rhs, ParamRef) \
+                and rhs.shape == (n, 1):
+            if lhs.time_deriv == 0 and qc is None:
+                qc = rhs
+            elif lhs.time_deriv == 1 and dqc is None:
+                dqc = rhs
+            else:
+                no(f"linear equality '{label}' fixes a configuration twice")
+        elif isinstance(lhs, IntegrationResidual) and _is_zero_const(rhs) and lhs.x.model_name == robot.get_name() and lhs.xd.time_deriv in (1, 2) \
+                and lhs.xd.time_deriv not in dts:
+            if not np.allclose(lhs.dt, lhs.dt[0], rtol=0, atol=0):
+                no("non-uniform dt is not lowered")
+            dts[lhs.xd.time_deriv] = float(lhs.dt[0])
+        else:
+            no(f"linear equality '{label}' not recognised")
+    if qc is None or dqc is None or sorted(dts) != [1, 2] or dts[1] != dts[2]:
+        no("need fix_configuration(q, qc), fix_configuration(dq, dqc, time_deriv=1) and integrate_model_states for time_deriv 1 and 2 with one dt")
+    # dynamics rows h = TAU - rnea(Q, dQ, ddQ)
+    if len(opt.eq_constraints) != 1:
+        no("expected exactly one nonlinear equality (the inverse dynamics)")
+    (label, diff), = opt.eq_constraints.items()
+    if not (isinstance(diff, Sub) and diff.a is TAU and isinstance(diff.b, RneaFunction) and diff.b.robot is robot and diff.b.q is Q and diff.b.qd is dQ
+            and diff.b.qdd is ddQ):
+        no(f"equality '{label}' is not add_equality_constraint(lhs=robot.rnea(Q, dQ, ddQ), rhs=TAU)")
+    if len(opt.ineq_constraints):
+        no("nonlinear inequalities are not lowered")
+    # effort limits
+    lo = up = None
+    for label, d in opt.lin_ineq_constraints.items():
+        if isinstance(d, Sub) and d.a is TAU and isinstance(d.b, Const) and d.b.value.shape == (n, 1) and lo is None:
+            lo = d.b.value[:, 0]
+        elif isinstance(d, Sub) and d.b is TAU and isinstance(d.a, Const) and d.a.value.shape == (n, 1) and up is None:
+            up = d.a.value[:, 0]
+        else:
+            no(f"linear inequality '{label}' is not an effort bound over the whole torque trajectory (or a second one of its kind)")
+    if (lo is None) != (up is None):
+        no("effort limits need both the lower and the upper row block")
+    if lo is None:
+        lo, up = -1e9 * np.ones(n), 1e9 * np.ones(n)
+    # costs
+    w_path = w_vel = w_tau = None
+    link = goal = None
+    for label, term in opt.cost_terms.items():
+        w, e = _unscale(term)
+        if not isinstance(e, SumSqr):
+            no(f"cost '{label}' is not a weighted sumsqr")
+        inner = e.a
+        if inner is dQ and w_vel is None:
+            w_vel = w
+        elif inner is TAU and w_tau is None:
+            w_tau = w
+        elif (isinstance(inner, Sub) and w_path is None and isinstance(inner.a, LinkFunction) and inner.a.what == "position" and inner.a.q is Q
+              and inner.a.robot is robot and isinstance(inner.b, ParamRef) and inner.b.shape == (3, T)):
+            w_path, link, goal = w, inner.a.link, inner.b
+        else:
+            no(f"cost '{label}' not recognised (or a second term of its kind: weights are not summed silently)")
+    if w_path is None or w_tau is None:
+        no("need the tracking term sumsqr(p_link(Q) - goal) and the effort term sumsqr(TAU)")
+    params = [k for k, v in opt.parameters.items() if v.numel() > 0]
+    if params != [qc.name, dqc.name, goal.name]:
+        no(f"the non-empty parameters must be [{qc.name}, {dqc.name}, {goal.name}] in this order (the kernel family reads p = [qc; dqc; vec(goal)]), found {params}")
+    return TorqueSpec(robot, link, T, dts[1], float(w_path), float(w_vel or 0.0), float(w_tau), np.asarray(lo, float), np.asarray(up, float))
+
+
 def lower(opt: Optimization):
     """Return (kind, spec).  Raises LoweringError if no kernel family matches."""
     errors = []
-    for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass_planner),
+    for kind, fn in ((_lib.OH_PROBLEM_FIGURE_EIGHT, match_figure_eight), (_lib.OH_PROBLEM_TORQUE_MPC, match_torque_mpc), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass), (_lib.OH_PROBLEM_POINT_MASS_MPC, match_point_mass_planner),
                      (OH_KIND_MULTI_ARM, match_multi_arm),
                      (_lib.OH_PROBLEM_IK, match_ik), (_lib.OH_PROBLEM_QP, match_qp), (_lib.OH_PROBLEM_TAPE, match_tape)):
         try:

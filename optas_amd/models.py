@@ -413,8 +413,15 @@ class RobotModel(Model):
 
     def rnea(self, q, qd, qdd) -> np.ndarray:
         """Inverse dynamics tau(q, qd, qdd) (models.py:1731-1884), evaluated by liboptas_hip (oh_rnea).
-        Arguments are ndof vectors or ndof-by-n arrays (columns = samples)."""
+        Arguments are ndof vectors or ndof-by-n arrays (columns = samples); symbolic arguments give the expression node the
+        torque-MPC family is lowered from (h = TAU - rnea(Q, dQ, ddQ))."""
         import ctypes as C
+
+        from .expr import Expr, RneaFunction, as_expr
+
+        if any(isinstance(a, Expr) for a in (q, qd, qdd)):
+            self.dynamics_tables()  # the reference's precondition checks (models.py:1742-1749) fire at graph-construction time
+            return RneaFunction(self, as_expr(q), as_expr(qd), as_expr(qdd))
 
         if getattr(self, "_dyn_handle", None) is None:
             lib = _lib.load()

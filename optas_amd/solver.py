@@ -16,8 +16,8 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import _lib
-from .backend import BatchResult, FigureEightBackend, IKBackend, MultiArmBackend, PointMassBackend, QPBackend, TapeBackend
-from .lowering import FigureEightSpec, IkSpec, MultiArmSpec, PointMassSpec, QpSpec, TapeSpec, lower
+from .backend import BatchResult, FigureEightBackend, IKBackend, MultiArmBackend, PointMassBackend, QPBackend, TapeBackend, TorqueBackend
+from .lowering import FigureEightSpec, IkSpec, MultiArmSpec, PointMassSpec, QpSpec, TapeSpec, TorqueSpec, lower
 from .models import RobotModel
 from .optimization import Optimization
 
@@ -260,6 +260,12 @@ class HIPSolver(Solver):
             )
             if spec.lead is not None:
                 self._backend = _LeadAdapter(self.opt, spec, self._backend)
+        elif isinstance(spec, TorqueSpec):
+            o.pop("hessian", None)
+            self._backend = TorqueBackend(spec.robot.solver_chain(spec.link), spec.robot.dynamics_tables(), T=spec.T, dt=spec.dt, w_path=spec.w_path,
+                                          w_vel=spec.w_vel, w_tau=spec.w_tau, tau_lo=spec.tau_lo, tau_up=spec.tau_up,
+                                          max_iter=int(o.pop("max_iter", 300)), tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)),
+                                          rho0=float(o.pop("rho0", 0.0)), mu0=float(o.pop("mu0", 0.0)))
         elif isinstance(spec, PointMassSpec):
             o.pop("hessian", None)
             pl = spec.planner

@@ -1,0 +1,207 @@
+"""BASELINE configs[4] (torque MPC with RNEA equality rows) on the CPU: the oracle's pieces against each other and against the
+golden vectors, and the product's host side (builder layout, lowering).  No GPU calls.
+
+Tolerances: vectorised RNEA == literal restatement 1e-12; complex-step Jacobian == central differences 1e-6 (FD noise);
+port optimum == scipy L-BFGS-B on the reduced problem 1e-8 rel and == scipy trust-constr in the reference's wiring on the literal
+layout 1e-7 rel (tests/golden/torque_golden.npz, tools/make_golden.py --torque)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, MED7_KIN, SEED
+from oracle.problems import TorqueMPCNLP
+from oracle.robot import OracleRobot, rnea
+from oracle.solvers import kkt_reference_form
+from oracle.torque import RneaTables, TorqueProblem, costate_gradient, riccati_torque, rnea_batch, rnea_jacobian, solve_torque_lm
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+LINK = "lbr_link_ee"
+
+
+@pytest.fixture(scope="module")
+def med7():
+    return OracleRobot(MED7_KIN)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "torque_golden.npz"))
+
+
+def test_vectorised_rnea_equals_literal_restatement(med7):
+    tb = RneaTables(med7)
+    rng = np.random.default_rng(SEED)
+    q, qd, qdd = rng.uniform(-2, 2, (3, 16, 7))
+    tau = rnea_batch(tb, q, qd, qdd)
+    for i in range(16):
+        assert np.abs(tau[i] - rnea(med7, q[i], qd[i], qdd[i])).max() < 1e-12
+    rev = OracleRobot(os.path.join(GOLDEN, "tester_robot_revolute.kin.json"))
+    tb2 = RneaTables(rev)
+    q, qd, qdd = rng.uniform(-2, 2, (3, 8, tb2.ndof))
+    tau = rnea_batch(tb2, q, qd, qdd)
+    for i in range(8):
+        assert np.abs(tau[i] - rnea(rev, q[i], qd[i], qdd[i])).max() < 1e-12
+
+
+def test_complex_step_jacobian_against_differences_and_mass_matrix_identities(med7):
+    tb = RneaTables(med7)
+    rng = np.random.default_rng(SEED + 1)
+    q, qd, qdd = rng.uniform(-1.5, 1.5, (3, 6, 7))
+    J = rnea_jacobian(tb, q, qd, qdd)
+    z = np.concatenate([q, qd, qdd], -1)
+    h = 1e-6
+    for d in range(21):
+        zp, zm = z.copy(), z.copy()
+        zp[:, d] += h
+        zm[:, d] -= h
+        fd = (rnea_batch(tb, zp[:, :7], zp[:, 7:14], zp[:, 14:]) - rnea_batch(tb, zm[:, :7], zm[:, 7:14], zm[:, 14:])) / (2 * h)
+        assert np.abs(fd - J[:, :, d]).max() < 1e-6 * max(1.0, np.abs(J[:, :, d]).max())
+    M = J[:, :, 14:]  # d tau / d qdd = joint-space inertia: symmetric positive definite, independent of qd and qdd
+    assert np.abs(M - np.swapaxes(M, 1, 2)).max() < 1e-12
+    assert np.linalg.eigvalsh(M).min() > 1e-4
+    assert np.abs(rnea_jacobian(tb, q, 0 * qd, 0 * qdd)[:, :, 14:] - M).max() < 1e-12
+
+
+def test_literal_nlp_sizes_and_derivatives(med7):
+    nlp = TorqueMPCNLP(TorqueProblem(med7, LINK, T=30))
+    assert (nlp.nx, nlp.np_, nlp.nk, nlp.na, nlp.ng, nlp.nh, nlp.nv) == (840, 104, 420, 420, 0, 210, 1680)
+    prob = TorqueProblem(med7, LINK, T=4, dt=0.1, w_vel=0.1, w_tau=1e-4, tau_lim=60.0)
+    nlp = TorqueMPCNLP(prob)
+    rng = np.random.default_rng(SEED + 2)
+    qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    p = nlp.pack_p(qc, 0.1 * rng.normal(size=7), prob.goal_figure_eight(qc))
+    x = nlp.seed(qc) + rng.normal(0, 0.1, nlp.nx)
+
+    def fd(fun):
+        f0 = np.atleast_1d(fun(x))
+        J = np.zeros((f0.size, x.size))
+        for i in range(x.size):
+            xp, xm = x.copy(), x.copy()
+            xp[i] += 1e-6
+            xm[i] -= 1e-6
+            J[:, i] = (np.atleast_1d(fun(xp)) - np.atleast_1d(fun(xm))) / 2e-6
+        return J
+
+    assert np.abs(fd(lambda y: nlp.f(y, p))[0] - nlp.df(x, p)).max() < 1e-6
+    assert np.abs(fd(lambda y: nlp.h(y, p)) - nlp.dh(x, p)).max() < 1e-6
+    assert np.abs(fd(lambda y: nlp.a(y, p)) - nlp.da(x, p)).max() < 1e-8
+    assert np.abs(fd(lambda y: nlp.k(y, p)) - nlp.dk(x, p)).max() < 1e-8
+    v = nlp.v(x, p)
+    assert v.shape == (nlp.nv,) and np.allclose(v[nlp.nk:nlp.nk + nlp.na], -v[nlp.nk + nlp.na:nlp.nk + 2 * nlp.na])  # v = [k; a; -a; h; -h]
+
+
+def test_riccati_sweep_equals_dense_kkt_solve():
+    """The stage recursion against a dense solve of the same equality-constrained QP (independent linear algebra)."""
+    rng = np.random.default_rng(SEED + 3)
+    T, n, dt, mu = 5, 3, 0.1, 0.3
+    m = 3 * n
+    H = np.zeros((T, m, m))
+    for t in range(T):
+        A_ = rng.normal(size=(m + 2, m))
+        H[t] = A_.T @ A_
+    g = rng.normal(size=(T, m))
+    dz, ok, qk = riccati_torque(H, g, mu, dt, 0.0)
+    assert ok
+    # dense: variables z = (dx_0, du_0, ..., dx_{T-1}, du_{T-1}); constraints dx_0 = 0, dx_{t+1} = A dx_t + B du_t
+    nx = 2 * n
+    A = np.eye(nx)
+    A[:n, n:] = dt * np.eye(n)
+    Bm = np.zeros((nx, n))
+    Bm[n:] = dt * np.eye(n)
+    N = T * m
+    Hd = np.zeros((N, N))
+    for t in range(T):
+        Hd[t * m:(t + 1) * m, t * m:(t + 1) * m] = H[t] + np.diag(np.concatenate([mu * np.ones(nx), np.zeros(n)]))
+    C = np.zeros((T * nx, N))
+    C[:nx, :nx] = np.eye(nx)
+    for t in range(T - 1):
+        r = slice((t + 1) * nx, (t + 2) * nx)
+        C[r, t * m:t * m + nx] = A
+        C[r, t * m + nx:(t + 1) * m] = Bm
+        C[r, (t + 1) * m:(t + 1) * m + nx] = -np.eye(nx)
+    KKT = np.block([[Hd, C.T], [C, np.zeros((T * nx, T * nx))]])
+    sol = np.linalg.solve(KKT, np.concatenate([-g.reshape(-1), np.zeros(T * nx)]))
+    assert np.abs(sol[:N].reshape(T, m) - dz).max() < 1e-9
+    # value of the damped model at the step: -qk / 2
+    val = 0.5 * sol[:N] @ Hd @ sol[:N] + g.reshape(-1) @ sol[:N]
+    assert abs(val + 0.5 * qk) < 1e-9
+    # and the costate gradient is the gradient of the condensed objective at dz = 0
+    gu = costate_gradient(g, dt)
+    eps = 1e-6
+    for t, j in ((0, 0), (2, 1), (T - 1, 2)):
+        dU = np.zeros((T, n))
+        dU[t, j] = eps
+        dx = np.zeros(nx)
+        lin = 0.0
+        for s in range(T):
+            lin += g[s, :nx] @ dx + g[s, nx:] @ dU[s]
+            dx = A @ dx + Bm @ dU[s]
+        assert abs(lin / eps - gu[t, j]) < 1e-9
+
+
+def test_port_reaches_the_optimum_two_independent_solvers_find(med7, golden):
+    g = golden
+    # T = 6: scipy trust-constr wired like the reference (solver.py:680-712) on the literal layout, and L-BFGS-B on the reduced problem
+    for tag in ("t6", "t6lim"):
+        lim = float(g[tag + "_lim"])
+        prob = TorqueProblem(med7, LINK, T=6, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=None if lim > 1e8 else lim)
+        r = solve_torque_lm(prob, g[tag + "_qc"][0], np.zeros(7), g[tag + "_goal"][0])
+        assert r["status"] == 0 and abs(r["f"] - g[tag + "_f"][0]) < 1e-10 * max(1.0, r["f"])
+        assert abs(r["f"] - g[tag + "_f_trust_constr"][0]) < 1e-7 * max(1.0, r["f"])
+        if lim > 1e8:
+            assert abs(r["f"] - g[tag + "_f_lbfgs"][0]) < 1e-8 * max(1.0, r["f"])
+    # T = 30, nominal instance: the committed optimum is reproduced, and it is the L-BFGS-B optimum
+    prob = TorqueProblem(med7, LINK, T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4)
+    r = solve_torque_lm(prob, g["t30_qc"][0], np.zeros(7), g["t30_goal"][0])
+    assert r["status"] == 0 and r["iters"] == int(g["t30_iters"][0])
+    assert abs(r["f"] - g["t30_f"][0]) < 1e-10 * r["f"]
+    assert np.all(np.abs(g["t30_f"] - g["t30_f_lbfgs"]) < 1e-8 * g["t30_f"])
+
+
+def test_golden_points_satisfy_the_kkt_conditions_in_reference_form(med7, golden):
+    g = golden
+    prob = TorqueProblem(med7, LINK, T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=float(g["t30lim_lim"]))
+    nlp = TorqueMPCNLP(prob)
+    x, p = g["t30lim_x"][0], nlp.pack_p(g["t30lim_qc"][0], np.zeros(7), g["t30lim_goal"][0])
+    assert np.abs(nlp.a(x, p)).max() < 1e-12 and np.abs(nlp.h(x, p)).max() < 1e-10
+    k = kkt_reference_form(nlp, x, p, active_tol=1e-7)
+    assert k["stationarity"] < 1e-6 and k["feasibility"] < 1e-8 and k["complementarity"] < 1e-6
+    lam = g["t30lim_lam"][0]
+    assert lam.max() > 0.0 and np.abs(np.abs(nlp.split(x)[3]).max() - float(g["t30lim_lim"])) < 1e-8  # an effort row is active
+
+
+def test_builder_layout_and_lowering_of_the_product():
+    from examples.torque_mpc import build_problem
+    from optas_amd.lowering import LoweringError, TorqueSpec, lower, match_torque_mpc
+    from optas_amd.optimization import NonlinearCostNonlinearConstraints
+
+    robot, link, opt = build_problem()
+    assert isinstance(opt, NonlinearCostNonlinearConstraints)
+    assert (opt.nx, opt.np, opt.nk, opt.na, opt.ng, opt.nh, opt.nv) == (840, 104, 420, 420, 0, 210, 1680)
+    assert list(opt.decision_variables.keys()) == ["med7/q/x", "med7/dq/x", "med7/ddq/x", "tau/y/x"]  # builder.py:45,90-99
+    assert [k for k, v in opt.parameters.items() if v.numel()] == ["qc", "dqc", "goal"]
+    assert list(opt.lin_ineq_constraints.keys()) == ["__tau_model_limit_0___l", "__tau_model_limit_0___r"]  # builder.py:334-335,508
+    kind, spec = lower(opt)
+    assert isinstance(spec, TorqueSpec) and (spec.T, spec.dt, spec.link) == (30, 0.1, "lbr_link_ee")
+    assert (spec.w_path, spec.w_vel, spec.w_tau) == (1000.0, 0.1, 1e-4) and np.all(spec.tau_up == 100.0) and np.all(spec.tau_lo == -100.0)
+    # a second term of one kind is refused, not summed or overwritten
+    import optas_amd as optas
+
+    robot2, link2, _ = build_problem()
+    b = optas.OptimizationBuilder(4, robots=[robot2], tasks=[optas.TaskModel("tau", 7, dlim={0: [-np.ones(7), np.ones(7)]})], derivs_align=True)
+    name = robot2.get_name()
+    qc, dqc, goal = b.add_parameter("qc", 7), b.add_parameter("dqc", 7), b.add_parameter("goal", 3, 4)
+    Q, dQ, ddQ, TAU = b.get_model_states(name, 0), b.get_model_states(name, 1), b.get_model_states(name, 2), b.get_model_states("tau", 0)
+    b.fix_configuration(name, qc)
+    b.fix_configuration(name, dqc, time_deriv=1)
+    b.integrate_model_states(name, 1, 0.1)
+    b.integrate_model_states(name, 2, 0.1)
+    b.add_equality_constraint("dynamics", lhs=robot2.rnea(Q, dQ, ddQ), rhs=TAU)
+    b.add_cost_term("track", 10.0 * optas.sumsqr(robot2.get_global_link_position_function(link2, n=4)(Q) - goal))
+    b.add_cost_term("effort", 1e-3 * optas.sumsqr(TAU))
+    b.add_cost_term("effort2", 1e-3 * optas.sumsqr(TAU))
+    with pytest.raises(LoweringError, match="second term"):
+        match_torque_mpc(b.build())

@@ -258,11 +258,82 @@ def guard_golden():
     np.savez(os.path.join(G, "guard_golden.npz"), **out)
 
 
+def torque_golden(slow=True):
+    """BASELINE configs[4] (torque MPC, med7): optima of the numpy port (oracle/torque.py) next to two solvers that share nothing with it but the
+    literal functions: scipy L-BFGS-B on the reduced problem in ddq (no effort rows active) and scipy trust-constr wired like the reference's
+    ScipyMinimizeSolver (solver.py:680-712: k, a, g, h passed separately) on the literal 28T-variable layout.  trust-constr needs 6-8 minutes per
+    T = 6 instance, so it only runs here."""
+    import scipy.optimize
+
+    from oracle.problems import TorqueMPCNLP
+    from oracle.torque import TorqueProblem, costate_gradient, rnea_batch, rnea_jacobian, solve_torque_lm
+
+    rob = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "med7.kin.json"))
+    link = "lbr_link_ee"
+    rng = np.random.default_rng(SEED + 7)
+    qn = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    out = {}
+
+    def lbfgs(prob, qc, goal):
+        T = prob.T
+
+        def F(u):
+            U = u.reshape(T, 7)
+            Q, dQ = prob.rollout(qc, np.zeros(7), U)
+            tau = rnea_batch(prob.tb, Q, dQ, U)
+            J = rnea_jacobian(prob.tb, Q, dQ, U)
+            e, _, Jp, _ = prob.chain.jac(Q)
+            rr = e - goal
+            f = prob.w_path * np.sum(rr * rr) + prob.w_vel * np.sum(dQ * dQ) + prob.w_tau * np.sum(tau * tau)
+            g = np.einsum("ti,tid->td", 2 * prob.w_tau * tau, J)
+            g[:, :7] += 2 * prob.w_path * np.einsum("tki,tk->ti", Jp, rr)
+            g[:, 7:14] += 2 * prob.w_vel * dQ
+            return f, costate_gradient(g, prob.dt).reshape(-1)
+
+        r = scipy.optimize.minimize(F, np.zeros(T * 7), jac=True, method="L-BFGS-B",
+                                    options={"maxiter": 40000, "maxfun": 80000, "ftol": 1e-15, "gtol": 1e-8, "maxcor": 30})
+        return float(r.fun)
+
+    cases = [("t6", 6, None, 1), ("t6lim", 6, 55.0, 1), ("t30", 30, None, 3), ("t30lim", 30, 55.0, 2)]
+    for tag, T, lim, n in cases:
+        prob = TorqueProblem(rob, link, T=T, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=lim)
+        nlp = TorqueMPCNLP(prob)
+        QC, GOAL, X, F_, IT, FL, FT, LAM = [], [], [], [], [], [], [], []
+        for i in range(n):
+            qc = qn + (rng.uniform(-0.1, 0.1, 7) if i else 0.0)
+            goal = prob.goal_figure_eight(qc)
+            t0 = time.time()
+            r = solve_torque_lm(prob, qc, np.zeros(7), goal)
+            assert r["status"] == 0
+            x = nlp.join(r["Q"], r["dQ"], r["U"], r["tau"])
+            k = kkt_reference_form(nlp, x, nlp.pack_p(qc, np.zeros(7), goal))
+            assert k["stationarity"] < 1e-6 and k["feasibility"] < 1e-8, k
+            fl = lbfgs(prob, qc, goal) if lim is None else np.nan
+            ft = np.nan
+            if T == 6 and slow:
+                rt = scipy_minimize(nlp, nlp.seed(qc), nlp.pack_p(qc, np.zeros(7), goal), method="trust-constr", tol=1e-9, options={"maxiter": 3000})
+                ft = float(rt.fun)
+            print("torque", tag, i, "port", r["f"], r["iters"], "lbfgs", fl, "trust-constr", ft, "kkt", k["stationarity"], round(time.time() - t0, 1))
+            if lim is None:
+                assert abs(fl - r["f"]) < 1e-8 * max(1.0, r["f"])
+            if np.isfinite(ft):
+                assert abs(ft - r["f"]) < 1e-7 * max(1.0, r["f"])
+            QC.append(qc); GOAL.append(goal); X.append(x); F_.append(r["f"]); IT.append(r["iters"]); FL.append(fl); FT.append(ft); LAM.append(r["lam"])
+        out[tag + "_qc"], out[tag + "_goal"], out[tag + "_x"], out[tag + "_f"], out[tag + "_iters"] = np.stack(QC), np.stack(GOAL), np.stack(X), np.array(F_), np.array(IT)
+        out[tag + "_f_lbfgs"], out[tag + "_f_trust_constr"], out[tag + "_lam"] = np.array(FL), np.array(FT), np.stack(LAM)
+        out[tag + "_lim"] = np.array(1e9 if lim is None else lim)
+    np.savez(os.path.join(G, "torque_golden.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--torque" in sys.argv:  # ~20 minutes (trust-constr on the literal layout)
+        torque_golden()
+        sys.exit(0)
     spatialmath_golden()
     fk_golden()
     nlp_golden()
     pm_golden()
     ik_golden()
     guard_golden()  # ~1 minute: scipy SLSQP on the T = 50 guarded arm
+    print("(tests/golden/torque_golden.npz: python tools/make_golden.py --torque, ~20 minutes)")
     print("golden fixtures written to", G)

@@ -1265,7 +1265,7 @@ static int fk_common(oh_handle* h, int n, bool soa, const void* d_q, void* d_pos
   if (n < 1 || !d_q) return fail(OH_ERR_INVALID, "oh_fk_jac: bad arguments");
   if (!h->have_chain) return fail(OH_ERR_STATE, "oh_fk_jac: call oh_set_constants first");
   HIPCHK(hipSetDevice(h->device));
-  oh_launch_fk_jac(h->stream, soa, h->d_chain, n, (const double*)d_q, (double*)d_pose, (double*)d_J);
+  oh_launch_fk_jac(h->stream, soa, h->d_chain, h->chain_host.n_chain, n, (const double*)d_q, (double*)d_pose, (double*)d_J);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   return OH_OK;

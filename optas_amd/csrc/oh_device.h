@@ -7,10 +7,13 @@
 
 #include "../../include/optas_hip.h"
 
-#ifdef OH_HOST_PORT  // oracle/cpu_port: the same functions compiled for the host cores (CPU baseline of bench.py, never product)
-#define OH_DEV __host__ __device__ __forceinline__
-#else
+// Function qualifiers and the reciprocal square root of the Cholesky pivots: the two things a translation unit may set before including
+// this header (oracle/cpu_port builds the same device functions for the host cores with its own definitions; the product never does).
+#ifndef OH_DEV
 #define OH_DEV __device__ __forceinline__
+#endif
+#ifndef OH_RSQRT
+#define OH_RSQRT(x) rsqrt(x)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -241,11 +244,7 @@ OH_DEV bool chol_rcp(double (&S)[M * (M + 1) / 2], double (&rd)[M], double piv_m
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= S[tri(j, k)] * S[tri(j, k)];
     if (!(d > piv_min)) { ok = false; d = 1.0; }
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double inv = rsqrt(d);
-#else
-    const double inv = 1.0 / sqrt(d);  // host build of oracle/cpu_port
-#endif
+    const double inv = OH_RSQRT(d);
     rd[j] = inv;
     S[tri(j, j)] = d * inv;
 #pragma unroll

@@ -16,7 +16,7 @@ _LIB = None
 
 def build(force: bool = False) -> str:
     csrc = os.path.join(HERE, "..", "..", "optas_amd", "csrc")
-    deps = [SRC] + [os.path.join(csrc, f) for f in ("oh_kernels.hip", "oh_figure8.h", "oh_device.h", "oh_kernels.h")]
+    deps = [SRC] + [os.path.join(csrc, f) for f in ("oh_figure8_units.h", "oh_figure8.h", "oh_device.h", "oh_kernels.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)

@@ -4,8 +4,20 @@
 // algorithm at compiled-code speed on the box's CPU cores next to the GPU (SURVEY 8(d) "C++ host path on 1 core and on
 // all cores"); the independent parity oracle remains the numpy restatement in oracle/*.py.
 // Only bench.py's cpu_baseline leg and tests/ may load the library built from this file (oracle/_build/liboracle_port.so).
-#define OH_HOST_PORT 1
-#include "../../optas_amd/csrc/oh_kernels.hip"
+// Host definitions of the platform hooks the device headers ask for (oh_device.h, oh_figure8_units.h); the product's are in
+// optas_amd/csrc/oh_platform_gfx950.h.
+#include <cmath>
+#define OH_DEV __host__ __device__ __forceinline__
+#define OH_RSQRT(x) (1.0 / sqrt(x))
+#include "../../optas_amd/csrc/oh_device.h"
+struct RowBuf {
+  char* p;
+};
+OH_DEV RowBuf rowbuf(const double* knot_base) { return RowBuf{(char*)knot_base}; }
+OH_DEV double rb_ld(const RowBuf& rb, const unsigned row_bytes, const unsigned lane_bytes) { return *(const double*)(rb.p + row_bytes + lane_bytes); }
+OH_DEV void rb_st(const RowBuf& rb, const unsigned row_bytes, const unsigned lane_bytes, const double x) { *(double*)(rb.p + row_bytes + lane_bytes) = x; }
+OH_DEV void oh_count(unsigned long long* c) { *c += 1ULL; }
+#include "../../optas_amd/csrc/oh_figure8_units.h"
 
 #include <atomic>
 #include <cmath>

@@ -8,7 +8,7 @@ python -c "from optas_amd.build import embed_solver_source; embed_solver_source(
 while [ $# -gt 1 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -shared -fPIC $flags -o build_abl/lib_$name.so \
-    optas_amd/csrc/oh_kernels.hip optas_amd/csrc/oh_free.hip optas_amd/csrc/oh_pointmass.hip optas_amd/csrc/oh_ik.hip optas_amd/csrc/oh_qp.hip \
+    optas_amd/csrc/oh_kernels.hip optas_amd/csrc/oh_fkjac.hip optas_amd/csrc/oh_torque.hip optas_amd/csrc/oh_free.hip optas_amd/csrc/oh_pointmass.hip optas_amd/csrc/oh_ik.hip optas_amd/csrc/oh_qp.hip \
     optas_amd/csrc/oh_tape.hip optas_amd/csrc/oh_api.hip -lhiprtc &
 done
 wait

@@ -125,11 +125,33 @@ def cpu_baseline(sample: int, hessian: str = "hybrid"):
     t0 = time.perf_counter()
     its = [solve_structured_lm(prob, qc[i], max_iter=300, tol=1e-6, hessian=hessian)["iters"] for i in range(n_np)]
     t_np = time.perf_counter() - t0
+    # the reference's own alternative back-end: scipy SLSQP wired like ScipyMinimizeSolver (solver.py:652-679: v(x) >= 0 as one "ineq" block with
+    # Jacobian dv) on the literal 693-variable / 1114-row problem.  It makes no progress on this problem (300 iterations, 7 minutes,
+    # f 1225 -> 1224.65), so the leg is bounded by iterations and reports what it reached.
+    from oracle.problems import FigureEightNLP
+    from oracle.solvers import scipy_minimize
+
+    nlp = FigureEightNLP(robot, LINK, T=T, Tmax=TMAX)
+    n_sl = 4
+    t0 = time.perf_counter()
+    rs = scipy_minimize(nlp, nlp.seed(qc[0]), qc[0], method="SLSQP", tol=1e-6, options={"maxiter": n_sl})
+    t_sl = time.perf_counter() - t0
+    f_star = solve_structured_lm(prob, qc[0], max_iter=300, tol=1e-6, hessian=hessian)["f"]
     return {
         "value": nall / t_n,
         "unit": "solves/s",
         "cores": ncores,
         "kind": "port",
+        "reference_wired_scipy": {
+            "what": "scipy SLSQP wired like the reference's ScipyMinimizeSolver (solver.py:652-679) on the literal layout, first instance, 1 thread",
+            "iterations": int(rs.nit),
+            "seconds": t_sl,
+            "converged": bool(rs.success),
+            "f_reached": float(rs.fun),
+            "f_optimum": float(f_star),
+            "solves_per_s": (1.0 / t_sl) if rs.success else 0.0,
+            "note": f"stopped after {n_sl} iterations ({t_sl / max(1, rs.nit):.2f} s each): SLSQP does not converge on this problem (rank-deficient quaternion rows), see SURVEY App. D",
+        },
         "sample": f"{nall} instances of the same workload (first of rank 0's batch) on {ncores} threads in {t_n:.2f} s, compiled port of the HIP state machine "
         f"(oracle/cpu_port), tol 1e-6, mean {float(np.mean(itn)):.0f} iterations, converged {float(np.mean(stn == 0)):.4f}",
         "value_1core": sample / t_1,
@@ -193,21 +215,36 @@ def main():
         if comm is not None:
             comm.barrier()
 
-    be.set_profiling(True)
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only; before the GPU phase so that the device work sits at the end of the run
+        cpu = cpu_baseline(args.cpu_sample, args.hessian)
+
+    be.set_profiling(False)
     for _ in range(args.warmup):
         be.solve_device(B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
     sync_all()
     t0 = time.perf_counter()
     tm = {"eval_ms": 0.0, "step_ms": 0.0, "couple_ms": 0.0, "eval_launches": 0, "step_launches": 0, "instance_launches": 0, "solve_ms": 0.0, "rejected_steps": 0, "compactions": 0, "tail_iterations": 0}
+    solve_ms_plain = 0.0
+    for _ in range(args.steps):
+        be.solve_device(B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
+        solve_ms_plain += be.timing()["solve_ms"]
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        elapsed = comm.max_over_ranks(elapsed)
+    # second pass of the same K steps with one hipEventRecord after every kernel on the handle's stream: the per-kernel times behind the
+    # roofline object (the timed pass above runs without them)
+    be.set_profiling(True)
+    t0p = time.perf_counter()
     for _ in range(args.steps):
         be.solve_device(B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
         t = be.timing()
         for k in tm:
             tm[k] += t[k]
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if comm is not None:
-        elapsed = comm.max_over_ranks(elapsed)
+    _lib.check(lib.oh_device_synchronize(), "sync")
+    elapsed_profiled = time.perf_counter() - t0p
+    be.set_profiling(False)
 
     status = d_st.download(np.int32, (B,))
     iters = d_it.download(np.int32, (B,))
@@ -232,6 +269,18 @@ def main():
     for b in (d_q, d_pose, d_J):
         b.free()
 
+    # small-batch latency (BASELINE configs[1] literally is batch = 1): whole solve on the device, inputs resident, median of 7
+    lat = {}
+    for nb in (1, 1024):
+        ms = []
+        for _ in range(8):
+            be.solve_device(nb, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
+            ms.append(be.timing()["solve_ms"])
+        lat[nb] = float(np.median(ms[1:]))
+        its_nb = d_it.download(np.int32, (B,))[:nb]
+        lat[f"iters_{nb}"] = float(its_nb.mean())
+    occupancy = {k: _lib.kernel_info(k) for k in ("k_retract", "k_evalb", "k_couple", "k_step", "k_tail", "k_fk_jac")}
+
     if rank != 0:
         if comm is not None:
             comm.barrier()
@@ -249,13 +298,23 @@ def main():
         for k, v in kms.items()
     }
     achieved = per_kernel[dom]["achieved_GBps"]
-    traffic = None
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure comes from the committed
+    # rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by tools/summarize_profile.py together with the units per launch it was
+    # measured at) and is rescaled to this run's units per launch; traffic_source says where it came from.
+    traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(dom, {}).get("bytes_per_launch")
+            tj = json.load(open(tfile))
+            ent = tj.get(dom, {})
+            meta = tj.get("_meta", {})
+            upl = ent.get("units_per_launch") or meta.get("units_per_launch")
+            if ent.get("bytes_per_launch") and upl:
+                traffic = ent["bytes_per_launch"] / upl * (units / launches)
+                traffic_source = {"file": "profiles/pmc_traffic.json", "profile": meta.get("tag"), "commit": meta.get("commit"), "units_per_launch_profiled": upl,
+                                  "bytes_per_unit_profiled": ent["bytes_per_launch"] / upl, "rescaled_to_units_per_launch": units / launches}
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
     roofline = {
         "kernel": dom,
         "bound": "hbm",
@@ -264,6 +323,9 @@ def main():
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic,
+        "traffic_source": traffic_source,
+        "occupancy": occupancy,
+        "measured_in": f"a second pass of the same {args.steps} steps with one hipEventRecord after every kernel on the handle's stream ({1e3 * elapsed_profiled / args.steps:.1f} ms per step; the timed pass runs without them)",
         "avg_launch_ms": per_kernel[dom]["avg_launch_ms"],
         "bytes_per_unit": BYTES[dom],
         "units_per_launch_avg": units / launches,
@@ -315,14 +377,17 @@ def main():
             "feasibility_max": float(kkt[:, 1].max()),
             "f_mean": float(fvals.mean()),
         },
-        "device_ms_per_step": tm["solve_ms"] / args.steps,
+        "device_ms_per_step": solve_ms_plain / args.steps,
+        "latency_b1_ms": lat[1],
+        "latency_b1024_ms": lat[1024],
+        "latency_note": f"whole solve on the device, inputs resident, median of 7: B=1 ({lat['iters_1']:.0f} iterations), B=1024 (mean {lat['iters_1024']:.1f} iterations)",
         "kernel_ms_per_step": {"k_eval": tm["eval_ms"] / args.steps, "k_couple": tm["couple_ms"] / args.steps, "k_step": tm["step_ms"] / args.steps},
         "rejected_step_frac": tm["rejected_steps"] / max(1, tm["instance_launches"] + tm["tail_iterations"]),
         "tail_iteration_frac": tm["tail_iterations"] / max(1, tm["instance_launches"] + tm["tail_iterations"]),
         "compactions_per_step": tm["compactions"] / args.steps,
     }
-    if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.hessian)
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
     if comm is not None:
         comm.barrier()
         comm.destroy()

@@ -389,6 +389,12 @@ int oh_device_synchronize(void);
 int oh_event_timer_start(oh_handle* h);
 int oh_event_timer_stop(oh_handle* h, double* ms);
 
+/* Code-object facts of a kernel of this library, read from the loaded module (hipFuncGetAttributes, occupancy query): name in
+   {k_retract, k_evalb, k_couple, k_step, k_tail, k_fk_jac, k_tq_eval, k_tq_step} (the ndof-7 instantiations);
+   out5 = {registers per lane (VGPR + AGPR), scratch bytes per lane, LDS bytes per block, block size, resident blocks per CU}.
+   Waves per SIMD = blocks per CU x block size / 64 / 4.  What bench.py reports as roofline.occupancy. */
+int oh_kernel_info(const char* kernel, int* out5);
+
 const char* oh_last_error(void);
 const char* oh_version(void);
 void oh_destroy(oh_handle* h);

@@ -222,6 +222,7 @@ SYMBOLS = [
     "oh_device_synchronize",
     "oh_event_timer_start",
     "oh_event_timer_stop",
+    "oh_kernel_info",
     "oh_last_error",
     "oh_version",
     "oh_destroy",
@@ -297,6 +298,15 @@ def device_count() -> int:
     n = C.c_int(0)
     rc = load().oh_device_count(C.byref(n))
     return n.value if rc == OH_OK else 0
+
+
+def kernel_info(name: str) -> dict:
+    """Registers / scratch / LDS / resident blocks per CU of one of the library's kernels (oh_kernel_info)."""
+    out = (C.c_int * 5)()
+    check(load().oh_kernel_info(name.encode(), out), "oh_kernel_info")
+    v, sc, lds, blk, nb = list(out)
+    return {"registers_per_lane": v, "scratch_bytes_per_lane": sc, "lds_bytes_per_block": lds, "block": blk, "blocks_per_cu": nb,
+            "waves_per_simd": nb * blk / 64.0 / 4.0}
 
 
 def _ptr(a: Optional[np.ndarray]):

@@ -1494,3 +1494,14 @@ extern "C" int oh_get_constants(oh_handle* h, oh_chain* out) {
   *out = h->chain_host;
   return OH_OK;
 }
+
+extern "C" int oh_kernel_info(const char* kernel, int* out5) {
+  if (!kernel || !out5) return fail(OH_ERR_INVALID, "oh_kernel_info: null argument");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return fail(OH_ERR_HIP, "oh_kernel_info: no HIP device available (this library has no CPU path)");
+  OhKernelInfo k{};
+  if (!oh_kernel_info_figure8(kernel, &k) && !oh_kernel_info_fkjac(kernel, &k) && !oh_kernel_info_torque(kernel, &k))
+    return fail(OH_ERR_INVALID, std::string("oh_kernel_info: unknown kernel or attribute query failed: ") + kernel);
+  out5[0] = k.vgprs; out5[1] = k.scratch_bytes; out5[2] = k.lds_bytes; out5[3] = k.block; out5[4] = k.blocks_per_cu;
+  return OH_OK;
+}

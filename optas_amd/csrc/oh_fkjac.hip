@@ -136,3 +136,19 @@ void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n_ch
   if (soa) launch<true>(s, d_chain, n_chain, n, q, pose, J);
   else launch<false>(s, d_chain, n_chain, n, q, pose, J);
 }
+
+namespace {
+template <class K>
+bool kernel_info(K kernel, int block, OhKernelInfo* out) {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(kernel)) != hipSuccess) return false;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess) nb = 0;
+  *out = OhKernelInfo{a.numRegs, (int)a.localSizeBytes, (int)a.sharedSizeBytes, block, nb};
+  return true;
+}
+}  // namespace
+bool oh_kernel_info_fkjac(const char* name, OhKernelInfo* out) {
+  if (std::string(name) == "k_fk_jac") return kernel_info(k_fk_jac<true, 7>, 256, out);
+  return false;
+}

@@ -240,6 +240,12 @@ template <int N>
 __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const int slot) {
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
+  // Stage data of the accepted point and the Riccati gains live in LDS, one column per lane (= knot): [row][lane], conflict-free for the
+  // lane's own column, one broadcast read for another knot's value in the serial sweeps (instead of a v_readlane pair per double).  In
+  // registers they cost 190 VGPRs next to the ~350 of the fused evaluation: 512 + 256 registers with 241 spilled to scratch in round 1.
+  constexpr int O_DR = 0, O_E = O_DR + NP, O_GT = O_E + NZ * NZ, O_G = O_GT + NZ, O_GF = O_G + N, O_EC = O_GF + N, O_JZ = O_EC + 3, O_K = O_JZ + 3 * NZ,
+                O_KV = O_K + NZ * NZ, O_ZZ = O_KV + NZ, ROWS = O_ZZ + NZ;
+  __shared__ double sm[ROWS][64];
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   const int Bp = D.Bp;
@@ -273,18 +279,26 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
   unsigned long long n_launch_equiv = 0, n_reject = 0;
 
   // accepted point (per lane = per knot)
-  double q_c[N], Z_c[N][NZ], Dr_c[NP], E_c[NZ * NZ], gt_c[NZ], g_c[N], G_c[N], e_c[3] = {0.0, 0.0, 0.0}, JZ_c[3][NZ];
+  double q_c[N], Z_c[N][NZ];
   double e_tgt[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-  for (int m = 0; m < 3; ++m)
-#pragma unroll
-    for (int a = 0; a < NZ; ++a) JZ_c[m][a] = 0.0;
+  for (int i = 0; i < ROWS; ++i) sm[i][lane] = 0.0;
   double f_cur = 0.0, feas_cur = 0.0, pred = 0.0, stat = 0.0;
 #pragma unroll
-  for (int k = 0; k < N; ++k) { q_c[k] = qt[k]; g_c[k] = 0.0; G_c[k] = 0.0; }
+  for (int k = 0; k < N; ++k) q_c[k] = qt[k];
+  struct TailHooks {  // the Lagrangian gradient of the accepted point is fetched from LDS only inside the exact-curvature branch
+    const double (*acc)[64];
+    int lane;
+    OH_DEV void q_final(const double (&)[N]) const {}
+    OH_DEV void g_final(const double (&)[N]) const {}
+    OH_DEV void v_final(const double (&)[3][N]) const {}
+    OH_DEV void load_G(const double (&)[N], double (&G)[N]) const {
 #pragma unroll
-  for (int a = 0; a < NZ; ++a) gt_c[a] = 0.0;
-  double Kmine[NZ * NZ], kmine[NZ], zmine[NZ];
+      for (int k = 0; k < N; ++k) G[k] = acc[O_GF + k][lane];
+    }
+  };
+  const TailHooks hooks{sm, lane};
+  const double Gdummy[N] = {};
 
   for (;;) {
     ++n_launch_equiv;
@@ -293,7 +307,9 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
     const bool exact = (P.hessian == OH_HESSIAN_EXACT) || (P.hessian == OH_HESSIAN_HYBRID && !first && stat <= P.hyb_switch);
     const bool have_G = exact && !first;
     double e_new[3] = {0.0, 0.0, 0.0}, JZ_new[3][NZ];
-    if (active) eval_knot<N>(ch, P, t, qt, pc, Rc, exact, have_G, G_c, phi, cv, g, Dr, Z, !first, e_tgt, retract_tol(P, !first, pred, stat), e_new, JZ_new);
+    if (active)
+      eval_knot<N, false, TailHooks>(ch, P, t, qt, pc, Rc, exact, have_G, Gdummy, phi, cv, g, Dr, Z, !first, e_tgt, retract_tol(P, !first, pred, stat), e_new,
+                                     JZ_new, 0.0, hooks);
     // ---- neighbour coupling (k_couple) -----------------------------------------------------------------------
     double qm[N], qp[N], Zn[N][NZ];
 #pragma unroll
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
 #pragma unroll
         for (int j = 0; j < N; ++j) qt[j] = q_c[j];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) e_tgt[m] = e_c[m];
+        for (int m = 0; m < 3; ++m) e_tgt[m] = sm[O_EC + m][lane];
         ++iters;
         if (iters >= P.max_iter + 40) { status = OH_STATUS_MAX_ITER; break; }
         continue;
@@ -348,22 +364,22 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         q_c[k] = qt[k];
-        g_c[k] = g[k];
-        G_c[k] = G[k];
+        sm[O_G + k][lane] = g[k];
+        sm[O_GF + k][lane] = G[k];
 #pragma unroll
         for (int a = 0; a < NZ; ++a) Z_c[k][a] = Z[k][a];
       }
 #pragma unroll
-      for (int i = 0; i < NP; ++i) Dr_c[i] = Dr[i];
+      for (int i = 0; i < NP; ++i) sm[O_DR + i][lane] = Dr[i];
 #pragma unroll
-      for (int i = 0; i < NZ * NZ; ++i) E_c[i] = E[i];
+      for (int i = 0; i < NZ * NZ; ++i) sm[O_E + i][lane] = E[i];
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) gt_c[a] = gt[a];
+      for (int a = 0; a < NZ; ++a) sm[O_GT + a][lane] = gt[a];
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
-        e_c[m] = e_new[m];
+        sm[O_EC + m][lane] = e_new[m];
 #pragma unroll
-        for (int a = 0; a < NZ; ++a) JZ_c[m][a] = JZ_new[m][a];
+        for (int a = 0; a < NZ; ++a) sm[O_JZ + m * NZ + a][lane] = JZ_new[m][a];
       }
     }
     double mu = lm.mu;
@@ -373,32 +389,32 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
       bool ok = true;
       stat = 0.0;
 #pragma unroll
-      for (int i = 0; i < NP; ++i) S[i] = bcast(Dr_c[i], nK - 1);
+      for (int i = 0; i < NP; ++i) S[i] = sm[O_DR + i][nK - 1];
 #pragma unroll
       for (int a = 0; a < NZ; ++a) {
         S[tri(a, a)] += kap2 + mu;
-        rn[a] = bcast(gt_c[a], nK - 1);
+        rn[a] = sm[O_GT + a][nK - 1];
         stat = fmax(stat, fabs(rn[a]));
       }
       for (int l = nK - 2; l >= 0; --l) {
         double El[NZ * NZ], Ht[NP], gl[NZ];
 #pragma unroll
-        for (int i = 0; i < NZ * NZ; ++i) El[i] = bcast(E_c[i], l);
+        for (int i = 0; i < NZ * NZ; ++i) El[i] = sm[O_E + i][l];
 #pragma unroll
-        for (int i = 0; i < NP; ++i) Ht[i] = bcast(Dr_c[i], l);
+        for (int i = 0; i < NP; ++i) Ht[i] = sm[O_DR + i][l];
 #pragma unroll
         for (int a = 0; a < NZ; ++a) {
-          gl[a] = bcast(gt_c[a], l);
+          gl[a] = sm[O_GT + a][l];
           stat = fmax(stat, fabs(gl[a]));
           Ht[tri(a, a)] += 2.0 * kap2 + mu;
         }
         double Kmat[NZ * NZ], kv[NZ];
         ok = riccati_back<NZ>(S, rd, rn, El, Ht, gl, Kmat, kv) && ok;
-        if (lane == l + 1) {
+        if (lane == 0) {  // the gains of knot l + 1 (every lane holds the same values)
 #pragma unroll
-          for (int i = 0; i < NZ * NZ; ++i) Kmine[i] = Kmat[i];
+          for (int i = 0; i < NZ * NZ; ++i) sm[O_K + i][l + 1] = Kmat[i];
 #pragma unroll
-          for (int a = 0; a < NZ; ++a) kmine[a] = kv[a];
+          for (int a = 0; a < NZ; ++a) sm[O_KV + a][l + 1] = kv[a];
         }
       }
       ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
@@ -422,27 +438,30 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
           double zn[NZ];
 #pragma unroll
           for (int a = 0; a < NZ; ++a) {
-            double sacc = bcast(kmine[a], l);
+            double sacc = sm[O_KV + a][l];
 #pragma unroll
-            for (int c2 = 0; c2 < NZ; ++c2) sacc += bcast(Kmine[a * NZ + c2], l) * zz[c2];
+            for (int c2 = 0; c2 < NZ; ++c2) sacc += sm[O_K + a * NZ + c2][l] * zz[c2];
             zn[a] = -sacc;
           }
 #pragma unroll
           for (int a = 0; a < NZ; ++a) zz[a] = zn[a];
         }
-        if (lane == l) {
+        if (lane == 0) {
 #pragma unroll
-          for (int a = 0; a < NZ; ++a) zmine[a] = zz[a];
+          for (int a = 0; a < NZ; ++a) sm[O_ZZ + a][l] = zz[a];
         }
 #pragma unroll
         for (int a = 0; a < NZ; ++a) {
-          gd += bcast(gt_c[a], l) * zz[a];
+          gd += sm[O_GT + a][l] * zz[a];
           z2 += zz[a] * zz[a];
         }
       }
       pred = -0.5 * gd + 0.5 * mu * z2;
     }
     // next trial knots: q_cur + Z_cur z
+    double zmine[NZ];
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) zmine[a] = sm[O_ZZ + a][lane];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       double v = q_c[j];
@@ -452,9 +471,9 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
     }
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      double v = e_c[m];
+      double v = sm[O_EC + m][lane];
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) v += JZ_c[m][a] * zmine[a];
+      for (int a = 0; a < NZ; ++a) v += sm[O_JZ + m * NZ + a][lane] * zmine[a];
       e_tgt[m] = v;
     }
     ++iters;
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       D.q[slot][IDX(t, N, j)] = q_c[j];
-      D.g[slot][IDX(t, N, j)] = g_c[j];
+      D.g[slot][IDX(t, N, j)] = sm[O_G + j][lane];
     }
   }
   if (lane == 0) {
@@ -866,3 +885,24 @@ bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffer
   return true;
 }
 
+
+namespace {
+template <class K>
+bool kernel_info(K kernel, int block, OhKernelInfo* out) {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(kernel)) != hipSuccess) return false;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess) nb = 0;
+  *out = OhKernelInfo{a.numRegs, (int)a.localSizeBytes, (int)a.sharedSizeBytes, block, nb};
+  return true;
+}
+}  // namespace
+bool oh_kernel_info_figure8(const char* name, OhKernelInfo* out) {
+  const std::string n(name);
+  if (n == "k_retract") return kernel_info(k_retract<7>, 256, out);
+  if (n == "k_evalb") return kernel_info(k_evalb<7>, 256, out);
+  if (n == "k_couple") return kernel_info(k_couple<7>, 256, out);
+  if (n == "k_step") return kernel_info(k_step<7>, 64, out);
+  if (n == "k_tail") return kernel_info(k_tail<7>, 64, out);
+  return false;
+}

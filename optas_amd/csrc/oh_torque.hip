@@ -749,3 +749,21 @@ bool oh_launch_tq_finalize(hipStream_t s, const TqParams& P, const TqBuffers& D,
   hipLaunchKernelGGL(k_tq_finalize<7>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x, f, kkt, iters, status, mult);
   return true;
 }
+
+namespace {
+template <class K>
+bool kernel_info(K kernel, int block, OhKernelInfo* out) {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(kernel)) != hipSuccess) return false;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess) nb = 0;
+  *out = OhKernelInfo{a.numRegs, (int)a.localSizeBytes, (int)a.sharedSizeBytes, block, nb};
+  return true;
+}
+}  // namespace
+bool oh_kernel_info_torque(const char* name, OhKernelInfo* out) {
+  const std::string n(name);
+  if (n == "k_tq_eval") return kernel_info(k_tq_eval<7>, 64, out);
+  if (n == "k_tq_step") return kernel_info(k_tq_step<7>, 64, out);
+  return false;
+}

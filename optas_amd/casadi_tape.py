@@ -159,12 +159,33 @@ def make_solver_class(solver_module, cs):
 
     class HIPSolver(solver_module.Solver):
         def setup(self, solver_name: str = "hip_sqp", solver_options: Optional[dict] = None):
+            """Structured family first (optas_amd.probe_lowering: labels and shapes of the problem's containers, its own numeric functions
+            probed and then verified -- the headline figure-eight kernels behind a real ``Optimization``), generic tape family otherwise.
+            ``solver_options["family"]`` = "figure_eight" | "tape" forces one route; ``"link"`` may name the tracked link."""
             if solver_name != "hip_sqp":
                 raise ValueError(f"unknown solver '{solver_name}' (this interface provides 'hip_sqp')")
             o = dict(solver_options or {})
-            self._tape = tape_from_optimization(self.opt, cs)
-            self._backend = TapeBackend(self._tape, max_iter=int(o.pop("max_iter", 2000)), tol=float(o.pop("tol", 1e-6)),
-                                        tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=float(o.pop("rho0", 10.0)), jit=bool(o.pop("jit", True)))
+            family = o.pop("family", None)
+            link = o.pop("link", None)
+            self._family = None
+            if family in (None, "figure_eight"):
+                from .lowering import LoweringError
+                from .probe_lowering import probe_figure_eight
+                from .solver import figure_eight_backend
+
+                try:
+                    spec = probe_figure_eight(self.opt, link=link)
+                    hess = {"gauss_newton": 0, "exact": 1, "hybrid": 2}[o.pop("hessian", "hybrid")]
+                    self._backend = figure_eight_backend(spec, o, hess)
+                    self._family, self._spec = "figure_eight", spec
+                except LoweringError:
+                    if family == "figure_eight":
+                        raise
+            if self._family is None:
+                self._tape = tape_from_optimization(self.opt, cs)
+                self._backend = TapeBackend(self._tape, max_iter=int(o.pop("max_iter", 2000)), tol=float(o.pop("tol", 1e-6)),
+                                            tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=float(o.pop("rho0", 10.0)), jit=bool(o.pop("jit", True)))
+                self._family = "tape"
             if o:
                 raise ValueError(f"unknown solver options {sorted(o)}")
             self._stats = None
@@ -175,7 +196,8 @@ def make_solver_class(solver_module, cs):
             p = np.asarray(self.p, dtype=np.float64).reshape(1, -1)
             r = self._backend.solve(x0, p)
             self._stats = {"status": int(r.status[0]), "success": bool(r.status[0] == 0), "iter_count": int(r.iters[0]), "f": float(r.f[0]),
-                           "kkt": [float(v) for v in r.kkt[0]], "solve_ms": self._backend.solve_ms()}
+                           "kkt": [float(v) for v in r.kkt[0]], "family": self._family,
+                           "solve_ms": self._backend.solve_ms() if hasattr(self._backend, "solve_ms") else self._backend.timing()["solve_ms"]}
             return cs.DM(r.x[0])
 
         def stats(self):

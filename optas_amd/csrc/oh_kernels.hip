@@ -240,11 +240,11 @@ template <int N>
 __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const int slot) {
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
-  // Stage data of the accepted point and the Riccati gains live in LDS, one column per lane (= knot): [row][lane], conflict-free for the
+  // Stage data of the accepted point and the blocks the cyclic reduction exchanges live in LDS, one column per lane (= knot): [row][lane], conflict-free for the
   // lane's own column, one broadcast read for another knot's value in the serial sweeps (instead of a v_readlane pair per double).  In
   // registers they cost 190 VGPRs next to the ~350 of the fused evaluation: 512 + 256 registers with 241 spilled to scratch in round 1.
-  constexpr int O_DR = 0, O_E = O_DR + NP, O_GT = O_E + NZ * NZ, O_G = O_GT + NZ, O_GF = O_G + N, O_EC = O_GF + N, O_JZ = O_EC + 3, O_K = O_JZ + 3 * NZ,
-                O_KV = O_K + NZ * NZ, O_ZZ = O_KV + NZ, ROWS = O_ZZ + NZ;
+  constexpr int O_DR = 0, O_E = O_DR + NP, O_GT = O_E + NZ * NZ, O_G = O_GT + NZ, O_GF = O_G + N, O_EC = O_GF + N, O_JZ = O_EC + 3, O_PCR = O_JZ + 3 * NZ,
+                ROWS = O_PCR + (2 * NZ + 1) * NZ;
   __shared__ double sm[ROWS][64];
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
@@ -383,85 +383,124 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
       }
     }
     double mu = lm.mu;
-    // ---- phase B: backward Riccati sweep, knot l's blocks broadcast to the whole wave --------------------------
-    double S[NP], rd[NZ], rn[NZ];
+    // ---- phase B: the reduced block-tridiagonal system  D_l z_l + E_l z_{l+1} + E_{l-1}^T z_{l-1} = -gt_l  by block PARALLEL CYCLIC
+    // REDUCTION across the lanes (lane = knot): at stride s every equation eliminates its neighbours l -+ s using their own rows,
+    //   A_l <- A_l - L_l A_{l-s}^{-1} U_{l-s} - U_l A_{l+s}^{-1} L_{l+s},  L_l <- -L_l A_{l-s}^{-1} L_{l-s},  U_l <- -U_l A_{l+s}^{-1} U_{l+s},
+    //   r_l <- r_l - L_l A_{l-s}^{-1} r_{l-s} - U_l A_{l+s}^{-1} r_{l+s},
+    // and after ceil(log2 nK) strides z_l = A_l^{-1} r_l.  Six dependent NZ x NZ factorisations per lane instead of the nK - 1 = 47 of the
+    // serial Riccati sweep the batched k_step runs (the diagonal blocks stay Schur complements of a positive definite matrix, so the
+    // plain Cholesky is stable; a failed pivot on any lane raises the damping for the whole instance as before).  Neighbour blocks
+    // travel through LDS.
+    stat = 0.0;
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) stat = fmax(stat, fabs(sm[O_GT + a][lane]));
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) stat = fmax(stat, __shfl_xor(stat, m));
+    double zmine[NZ];
     for (int attempt = 0; attempt < 40; ++attempt) {
+      double A[NZ * NZ], Lw[NZ * NZ], U[NZ * NZ], r[NZ];
+#pragma unroll
+      for (int i = 0; i < NZ; ++i)
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) {
+          const int hi = i > j ? i : j, lo = i > j ? j : i;
+          A[i * NZ + j] = active ? sm[O_DR + tri(hi, lo)][lane] + (i == j ? ((last ? kap2 : 2.0 * kap2) + mu) : 0.0) : (i == j ? 1.0 : 0.0);
+          U[i * NZ + j] = (active && !last) ? sm[O_E + i * NZ + j][lane] : 0.0;
+          Lw[i * NZ + j] = (active && lane > 0) ? sm[O_E + j * NZ + i][lane - 1] : 0.0;
+        }
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) r[a] = active ? -sm[O_GT + a][lane] : 0.0;
       bool ok = true;
-      stat = 0.0;
+      double Lc[NP], rd[NZ];
+      for (int sft = 1; sft < nK; sft <<= 1) {
 #pragma unroll
-      for (int i = 0; i < NP; ++i) S[i] = sm[O_DR + i][nK - 1];
+        for (int i = 0; i < NZ; ++i)
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) {
-        S[tri(a, a)] += kap2 + mu;
-        rn[a] = sm[O_GT + a][nK - 1];
-        stat = fmax(stat, fabs(rn[a]));
-      }
-      for (int l = nK - 2; l >= 0; --l) {
-        double El[NZ * NZ], Ht[NP], gl[NZ];
+          for (int j = 0; j <= i; ++j) Lc[tri(i, j)] = A[i * NZ + j];
+        ok = chol_rcp<NZ>(Lc, rd, 1e-12) && ok;
+        // Y = A^{-1} [Lw | U | r], column by column, parked in LDS for the neighbours
 #pragma unroll
-        for (int i = 0; i < NZ * NZ; ++i) El[i] = sm[O_E + i][l];
+        for (int c2 = 0; c2 < 2 * NZ + 1; ++c2) {
+          double col[NZ];
 #pragma unroll
-        for (int i = 0; i < NP; ++i) Ht[i] = sm[O_DR + i][l];
+          for (int i = 0; i < NZ; ++i) col[i] = c2 < NZ ? Lw[i * NZ + c2] : (c2 < 2 * NZ ? U[i * NZ + (c2 - NZ)] : r[i]);
+          fsub_rcp<NZ>(Lc, rd, col);
+          bsub_rcp<NZ>(Lc, rd, col);
 #pragma unroll
-        for (int a = 0; a < NZ; ++a) {
-          gl[a] = sm[O_GT + a][l];
-          stat = fmax(stat, fabs(gl[a]));
-          Ht[tri(a, a)] += 2.0 * kap2 + mu;
+          for (int i = 0; i < NZ; ++i) sm[O_PCR + c2 * NZ + i][lane] = col[i];
         }
-        double Kmat[NZ * NZ], kv[NZ];
-        ok = riccati_back<NZ>(S, rd, rn, El, Ht, gl, Kmat, kv) && ok;
-        if (lane == 0) {  // the gains of knot l + 1 (every lane holds the same values)
+        __syncthreads();
+        const int lm_ = lane - sft, lp_ = lane + sft;
+        const bool hm = lm_ >= 0, hp = lp_ < 64;
+        const int im = hm ? lm_ : lane, ip = hp ? lp_ : lane;
+        double An[NZ * NZ], Ln[NZ * NZ], Un[NZ * NZ], rn2[NZ];
 #pragma unroll
-          for (int i = 0; i < NZ * NZ; ++i) sm[O_K + i][l + 1] = Kmat[i];
+        for (int i = 0; i < NZ; ++i) {
+          double racc = r[i];
 #pragma unroll
-          for (int a = 0; a < NZ; ++a) sm[O_KV + a][l + 1] = kv[a];
+          for (int j = 0; j < NZ; ++j) {
+            double aacc = A[i * NZ + j], lacc = 0.0, uacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < NZ; ++k) {
+              // column j of Y^U / Y^L of the neighbours: rows (NZ + j) * NZ + k and j * NZ + k of the parked block
+              aacc -= Lw[i * NZ + k] * sm[O_PCR + (NZ + j) * NZ + k][im] + U[i * NZ + k] * sm[O_PCR + j * NZ + k][ip];
+              lacc -= Lw[i * NZ + k] * sm[O_PCR + j * NZ + k][im];
+              uacc -= U[i * NZ + k] * sm[O_PCR + (NZ + j) * NZ + k][ip];
+            }
+            An[i * NZ + j] = aacc;
+            Ln[i * NZ + j] = lacc;
+            Un[i * NZ + j] = uacc;
+          }
+#pragma unroll
+          for (int k = 0; k < NZ; ++k) racc -= Lw[i * NZ + k] * sm[O_PCR + 2 * NZ * NZ + k][im] + U[i * NZ + k] * sm[O_PCR + 2 * NZ * NZ + k][ip];
+          rn2[i] = racc;
         }
+        __syncthreads();
+        // Lw / U of a lane without that neighbour are zero, so the clamped reads above contributed nothing
+#pragma unroll
+        for (int i = 0; i < NZ * NZ; ++i) {
+          A[i] = An[i];
+          Lw[i] = hm ? Ln[i] : 0.0;
+          U[i] = hp ? Un[i] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) r[i] = rn2[i];
       }
-      ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
-      if (ok) break;
+#pragma unroll
+      for (int i = 0; i < NZ; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Lc[tri(i, j)] = 0.5 * (A[i * NZ + j] + A[j * NZ + i]);
+      ok = chol_rcp<NZ>(Lc, rd, 1e-12) && ok;
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) zmine[a] = r[a];
+      fsub_rcp<NZ>(Lc, rd, zmine);
+      bsub_rcp<NZ>(Lc, rd, zmine);
+      if (__all(ok || !active)) break;
       mu = fmax(4.0 * mu, 1e-2);
     }
     lm.mu = mu;
     if (stat <= P.tol && feas_cur <= P.tol_feas) { status = OH_STATUS_CONVERGED; break; }
     if (iters >= P.max_iter) { status = OH_STATUS_MAX_ITER; break; }
     if (!(stat == stat)) { status = OH_STATUS_NUMERICAL; break; }
-    // ---- forward recursion (wave-uniform), each lane keeps its knot's z -------------------------------------------
     {
-      double zz[NZ];
-#pragma unroll
-      for (int a = 0; a < NZ; ++a) zz[a] = -rn[a];
-      fsub_rcp<NZ>(S, rd, zz);
-      bsub_rcp<NZ>(S, rd, zz);
       double gd = 0.0, z2 = 0.0;
-      for (int l = 0; l < nK; ++l) {
-        if (l > 0) {
-          double zn[NZ];
-#pragma unroll
-          for (int a = 0; a < NZ; ++a) {
-            double sacc = sm[O_KV + a][l];
-#pragma unroll
-            for (int c2 = 0; c2 < NZ; ++c2) sacc += sm[O_K + a * NZ + c2][l] * zz[c2];
-            zn[a] = -sacc;
-          }
-#pragma unroll
-          for (int a = 0; a < NZ; ++a) zz[a] = zn[a];
-        }
-        if (lane == 0) {
-#pragma unroll
-          for (int a = 0; a < NZ; ++a) sm[O_ZZ + a][l] = zz[a];
-        }
+      if (active) {
 #pragma unroll
         for (int a = 0; a < NZ; ++a) {
-          gd += sm[O_GT + a][l] * zz[a];
-          z2 += zz[a] * zz[a];
+          gd += sm[O_GT + a][lane] * zmine[a];
+          z2 += zmine[a] * zmine[a];
         }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        gd += __shfl_xor(gd, m);
+        z2 += __shfl_xor(z2, m);
       }
       pred = -0.5 * gd + 0.5 * mu * z2;
     }
     // next trial knots: q_cur + Z_cur z
-    double zmine[NZ];
-#pragma unroll
-    for (int a = 0; a < NZ; ++a) zmine[a] = sm[O_ZZ + a][lane];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       double v = q_c[j];

@@ -104,7 +104,12 @@ class RobotModel(Model):
             self.urdf = load_robot_description(urdf_filename)
         if urdf_string is not None:
             self.urdf_string = urdf_string
-            self.urdf = RobotDescription.from_xml_string(urdf_string)
+            if urdf_string.lstrip().startswith("{"):  # the constants format of *.kin.json as a string
+                import json as _json
+
+                self.urdf = RobotDescription.from_dict(_json.loads(urdf_string))
+            else:
+                self.urdf = RobotDescription.from_xml_string(urdf_string)
         assert self.urdf is not None, "You need to supply a urdf, either through filename or as a string"
         self.param_joints = param_joints
         dlim = {
@@ -121,6 +126,13 @@ class RobotModel(Model):
             name = self.urdf.name
         super().__init__(name, self.ndof, time_derivs, "q", dlim, T)
         self._fk_handles: Dict[str, "KinematicsHandle"] = {}
+
+    @staticmethod
+    def from_description(description: RobotDescription, **kwargs) -> "RobotModel":
+        """From an already parsed kinematic tree (e.g. converted from the reference's ``RobotModel.urdf``, optas_amd.probe_lowering)."""
+        import json as _json
+
+        return RobotModel(urdf_string=_json.dumps(description.to_dict()), **kwargs)
 
     @staticmethod
     def builtin(robot: str, **kwargs) -> "RobotModel":

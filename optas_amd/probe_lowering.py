@@ -1,0 +1,223 @@
+"""Lowering of a *reference* ``optas.optimization.Optimization`` (CasADi inside) to the structured kernel families -- without
+reading a single SX node.
+
+The mirror builder of this repo records expression trees, so ``optas_amd.lowering`` can pattern-match them.  A real optas problem holds
+opaque ``casadi.SX`` graphs and ``casadi.Function`` members (optimization.py:60-306).  What both worlds share is the *interface*:
+
+  * the containers ``decision_variables / parameters / lin_eq_constraints / eq_constraints / ...`` with the builder's labels and shapes
+    (``"{name}/q/x"``, ``"__{name}_fix_configuration_0_0__"``, ``"__integrate_model_states_{name}_1__"``; builder.py:90-99, 469, 539),
+  * ``models`` (``RobotModel`` with its parsed URDF, models.py:286-321),
+  * callable numeric members ``f(x, p), a(x, p), h(x, p), k(x, p), g(x, p)``.
+
+``probe_figure_eight`` uses exactly that: (1) labels and shapes decide whether the problem *can* be the figure-eight family of
+example/figure_eight_plan.py:16-113; (2) the numbers the kernels need (dt, weights, the path in the end-effector frame, the tracked link)
+are read off the problem's own functions by evaluating them at probe points -- ``a`` is affine and ``f`` is a separable sum of squares, so
+a handful of evaluations per knot identifies them exactly; (3) the resulting family model is then **verified** against ``f``, ``a`` and
+``h`` at random points and a second parameter vector.  Any mismatch raises ``LoweringError``: a problem is either proven (to 1e-9) to be
+the family or refused, never approximated.  Kinematics for the probes come from ``oh_fk_jac`` (the GPU is needed here as everywhere).
+
+Used by ``optas_amd.casadi_tape.make_solver_class`` (the literal ``optas.solver.Solver`` subclass): structured family first, generic
+tape family as the fallback.  Tested against the mirror's ``Optimization`` objects behind an adapter that hides everything but the
+reference interface (tests/test_probe_lowering.py), including a URDF object shaped like urdf_parser_py's.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .lowering import FigureEightSpec, LoweringError
+from .models import RobotModel
+from .urdf import Inertial, Joint, Limit, Link, RobotDescription
+
+
+def _vec(fn, x, p) -> np.ndarray:
+    """Value of a numeric member (casadi.Function returning DM, or a numpy callable) as a flat float64 vector."""
+    if fn is None:
+        return np.zeros(0)
+    v = fn(x, p)
+    if hasattr(v, "toarray"):
+        v = v.toarray()
+    elif hasattr(v, "full"):
+        v = v.full()
+    return np.asarray(v, dtype=np.float64).reshape(-1)
+
+
+def _shape(item):
+    s = item.shape
+    return int(s[0]), int(s[1])
+
+
+def description_from_urdf(urdf) -> RobotDescription:
+    """``RobotDescription`` from what ``RobotModel.urdf`` holds in the reference (a urdf_parser_py ``Robot``: joints with
+    ``origin.xyz/rpy``, ``axis``, ``limit``; links with ``inertial``) -- or from this repo's own description, returned as is."""
+    if isinstance(urdf, RobotDescription):
+        return urdf
+    links = []
+    for l in urdf.links:
+        ine = getattr(l, "inertial", None)
+        inertial = None
+        if ine is not None:
+            org = getattr(ine, "origin", None)
+            I = ine.inertia
+            inertial = Inertial(mass=float(ine.mass), xyz=[float(v) for v in (org.xyz if org is not None and org.xyz is not None else (0, 0, 0))],
+                                rpy=[float(v) for v in (org.rpy if org is not None and org.rpy is not None else (0, 0, 0))],
+                                inertia=[float(getattr(I, k)) for k in ("ixx", "ixy", "ixz", "iyy", "iyz", "izz")])
+        links.append(Link(name=l.name, inertial=inertial))
+    joints = []
+    for j in urdf.joints:
+        org = getattr(j, "origin", None)
+        lim = getattr(j, "limit", None)
+        joints.append(Joint(
+            name=j.name, type=j.type, parent=j.parent, child=j.child,
+            xyz=None if org is None else [float(v) for v in (org.xyz if org.xyz is not None else (0, 0, 0))],
+            rpy=None if org is None else [float(v) for v in (org.rpy if org.rpy is not None else (0, 0, 0))],
+            axis=None if getattr(j, "axis", None) is None else [float(v) for v in j.axis],
+            limit=None if lim is None else Limit(lower=float(lim.lower or 0.0), upper=float(lim.upper or 0.0), velocity=float(lim.velocity or 0.0),
+                                                 effort=float(lim.effort or 0.0))))
+    return RobotDescription(name=urdf.name, links=links, joints=joints)
+
+
+def _mirror_robot(model) -> RobotModel:
+    """A RobotModel of this repo with the same kinematic tree, name and derivative orders as the reference's model object."""
+    if isinstance(model, RobotModel):
+        return model
+    return RobotModel.from_description(description_from_urdf(model.urdf), name=model.get_name(), time_derivs=list(model.time_derivs),
+                                       param_joints=list(getattr(model, "param_joints", []) or []))
+
+
+def probe_figure_eight(opt, rng_seed: int = 12345, link: Optional[str] = None) -> FigureEightSpec:
+    """See the module docstring.  ``link`` may name the tracked link; by default every link of the robot is tried against ``h``."""
+
+    def no(msg):
+        raise LoweringError(f"figure-eight probing: {msg}")
+
+    models = list(opt.models or [])
+    if len(models) != 1 or not hasattr(models[0], "urdf"):
+        no("expected exactly one robot model")
+    m = models[0]
+    name = m.get_name()
+    if list(m.time_derivs) != [0, 1] or len(getattr(m, "param_joints", []) or []) != 0:
+        no("robot must have time_derivs=[0, 1] and no parameterised joints")
+    q_name, dq_name = f"{name}/q/x", f"{name}/dq/x"
+    if list(opt.decision_variables.keys()) != [q_name, dq_name]:
+        no(f"decision variables must be exactly [{q_name}, {dq_name}], found {list(opt.decision_variables.keys())}")
+    n, T = _shape(opt.decision_variables[q_name])
+    if _shape(opt.decision_variables[dq_name]) != (n, T - 1):
+        no("the velocity block must be ndof x (T - 1) (derivs_align=False)")
+    params = [(k, _shape(v)) for k, v in opt.parameters.items() if _shape(v)[0] * _shape(v)[1] > 0]
+    if len(params) != 1 or params[0][1] != (n, 1):
+        no(f"expected a single non-empty parameter of shape ({n}, 1), found {params}")
+    want = {f"__{name}_fix_configuration_0_0__": (n, 1), f"__{name}_fix_configuration_1_0__": (n, 1), f"__integrate_model_states_{name}_1__": (n, T - 1)}
+    got = {k: _shape(v) for k, v in opt.lin_eq_constraints.items()}
+    if got != want:
+        no(f"linear equalities must be {want} (fix_configuration of q and dq at t = 0, integrate_model_states), found {got}")
+    if len(opt.lin_ineq_constraints) or len(opt.ineq_constraints):
+        no("inequality rows are not lowered through this route")
+    eq = [(k, _shape(v)) for k, v in opt.eq_constraints.items()]
+    if len(eq) != 1 or eq[0][1] != (4, T):
+        no(f"expected one nonlinear equality of shape (4, {T}) (the end-effector quaternion lock), found {eq}")
+    nx, np_ = n * T + n * (T - 1), int(opt.np)
+    if int(opt.nx) != nx or np_ != n:
+        no("unexpected nx / np")
+    robot = _mirror_robot(m)
+    if robot.ndof != n:
+        no("the robot's ndof does not match the decision variables")
+    rng = np.random.default_rng(rng_seed)
+    nq = n * T
+    lo, up = robot.lower_actuated_joint_limits, robot.upper_actuated_joint_limits
+    mid, half = 0.5 * (lo + up), 0.3 * np.minimum(up - lo, 4.0)
+    qc = mid + rng.uniform(-1, 1, n) * half
+
+    def xvec(Q, dQ):  # (T, n), (T-1, n) -> vec order (blocks column-major: x[n t + j])
+        return np.concatenate([Q.reshape(-1), dQ.reshape(-1)])
+
+    Qc = np.tile(qc, (T, 1))
+    Z = np.zeros((T - 1, n))
+    x0 = xvec(Qc, Z)
+    # ---- linear rows: a = [qc - q_0; 0 - dq_0; -(q_t + dt dq_t - q_{t+1})]: dt from one probe, then the whole block is checked
+    a0 = _vec(opt.a, x0, qc)
+    if a0.shape != (2 * n + n * (T - 1),) or np.abs(a0).max() > 1e-12:
+        no("a(x, p) does not vanish at q_t = qc, dq = 0")
+    d = np.zeros_like(x0)
+    d[nq + n] = 1.0  # dq_1[0]
+    dt = -float(_vec(opt.a, x0 + d, qc)[2 * n + n])
+    if not (dt > 0):
+        no("could not read a positive dt off the integration rows")
+    Qr, dQr, pr = rng.normal(size=(T, n)), rng.normal(size=(T - 1, n)), rng.normal(size=n)
+    a_model = np.concatenate([pr - Qr[0], -dQr[0], -(Qr[:-1] + dt * dQr - Qr[1:]).reshape(-1)])
+    if np.abs(_vec(opt.a, xvec(Qr, dQr), pr) - a_model).max() > 1e-9:
+        no("the linear equalities are not [qc - q_0; -dq_0; Euler integration with a uniform dt]")
+    # ---- nonlinear equality h = quat(link, qc) - quat(link, q_t): find the link
+    Qh = qc[None] + rng.uniform(-0.3, 0.3, (T, n))
+    h_val = _vec(opt.h, xvec(Qh, Z), qc).reshape(T, 4)
+    cands = [link] if link is not None else [l for l in robot.link_names if l != robot.get_root_link()]
+    found = None
+    for cand in cands:
+        try:
+            chain_ok = len(robot.urdf.get_chain(robot.get_root_link(), cand)) > 0
+        except ValueError:
+            chain_ok = False
+        if not chain_ok:
+            continue
+        quat_c = np.asarray(robot.get_global_link_quaternion(cand, qc)).reshape(4)
+        quat = np.asarray(robot.get_global_link_quaternion(cand, Qh.T)).reshape(4, T).T
+        if np.abs(h_val - (quat_c[None] - quat)).max() <= 1e-9:
+            found = cand  # several links may share the orientation (fixed joints): the tracking cost below decides
+            p_c = np.asarray(robot.get_global_link_position(cand, qc)).reshape(3)
+            R_c = np.asarray(robot.get_global_link_rotation(cand, qc))
+            spec = _probe_costs(opt, robot, cand, n, T, dt, qc, p_c, R_c, xvec, rng)
+            if spec is not None:
+                return FigureEightSpec(robot, cand, T, dt, spec[0], spec[1], spec[2], params[0][0], q_name, dq_name)
+    if found is None:
+        no("h(x, p) is not quat(link, qc) - quat(link, q_t) for any link of the robot")
+    no(f"the orientation rows match link '{found}' but the cost is not w_path sumsqr(path_in_frame - p(link, Q)) + w_vel sumsqr(dQ)")
+
+
+def _probe_costs(opt, robot, link, n, T, dt, qc, p_c, R_c, xvec, rng):
+    """(w_path, w_vel, local_path (T, 3)) if f is the family's cost for this link, else None."""
+    Qc = np.tile(qc, (T, 1))
+    Z = np.zeros((T - 1, n))
+    f0 = float(_vec(opt.f, xvec(Qc, Z), qc)[0])
+    # velocity term: separable quadratic in dQ
+    d = Z.copy()
+    d[3 % (T - 1), 1 % n] = 0.7
+    w_vel = (float(_vec(opt.f, xvec(Qc, d), qc)[0]) - f0) / 0.49
+    if not (w_vel >= 0):
+        return None
+    # tracking term, one knot at a time: f(q_t = q') - f0 = w (|p'|^2 - |p_c|^2) - 2 (w path_t) . (p' - p_c): linear in (w, w path_t)
+    K = 6
+    probes = qc[None] + rng.uniform(-0.4, 0.4, (K, n))
+    P = np.asarray(robot.get_global_link_position(link, probes.T)).reshape(3, K).T
+    A = np.concatenate([(np.sum(P * P, 1) - p_c @ p_c)[:, None], -2.0 * (P - p_c[None])], 1)  # (K, 4)
+    ws, paths = [], []
+    for t in range(T):
+        rhs = np.empty(K)
+        for k in range(K):
+            Q = Qc.copy()
+            Q[t] = probes[k]
+            rhs[k] = float(_vec(opt.f, xvec(Q, Z), qc)[0]) - f0
+        sol, res, rank, _ = np.linalg.lstsq(A, rhs, rcond=None)
+        if rank < 4 or np.abs(A @ sol - rhs).max() > 1e-8 * max(1.0, np.abs(rhs).max()):
+            return None
+        ws.append(sol[0])
+        paths.append(sol[1:] / sol[0] if sol[0] != 0 else np.zeros(3))
+    ws = np.array(ws)
+    if not (ws.min() > 0) or np.abs(ws - ws[0]).max() > 1e-7 * ws[0]:
+        return None
+    w_path = float(np.median(ws))
+    local = (np.array(paths) - p_c[None]) @ R_c  # R_c^T (path_t - p_c), rows
+    # ---- verification at a random point and a second parameter vector: the whole cost, as the kernels will evaluate it
+    for trial in range(2):
+        qc2 = qc + rng.uniform(-0.2, 0.2, n)
+        Q = qc2[None] + rng.uniform(-0.3, 0.3, (T, n))
+        dQ = rng.normal(size=(T - 1, n))
+        pc2 = np.asarray(robot.get_global_link_position(link, qc2)).reshape(3)
+        Rc2 = np.asarray(robot.get_global_link_rotation(link, qc2))
+        pos = np.asarray(robot.get_global_link_position(link, Q.T)).reshape(3, T).T
+        path = pc2[None] + local @ Rc2.T
+        f_model = w_path * np.sum((path - pos) ** 2) + w_vel * np.sum(dQ * dQ)
+        f_ref = float(_vec(opt.f, xvec(Q, dQ), qc2)[0])
+        if abs(f_model - f_ref) > 1e-9 * max(1.0, abs(f_ref)):
+            return None
+    return w_path, w_vel, np.ascontiguousarray(local)

@@ -213,6 +213,41 @@ class _QpAdapter:
         self.be.close()
 
 
+def figure_eight_backend(spec: FigureEightSpec, o: dict, hessian: int) -> FigureEightBackend:
+    """The OH_PROBLEM_FIGURE_EIGHT handle of a lowered problem (shared by HIPSolver.setup and the literal optas.solver.Solver subclass of
+    optas_amd.casadi_tape); consumes its options from ``o``."""
+    chain = spec.robot.solver_chain(spec.link)
+    guards = None
+    if spec.lo is not None or spec.spheres is not None:
+        guards = _lib.oh_guards()
+    if spec.lo is not None:
+        guards.limits = 1
+        for j in range(spec.robot.ndof):
+            guards.q_lo[j], guards.q_up[j] = float(spec.lo[j]), float(spec.up[j])
+    if spec.spheres is not None:
+        guards.n_links, guards.n_obstacles = len(spec.spheres.links), len(spec.spheres.obstacles)
+        for l, (k, off) in enumerate(spec.robot.link_attachments(spec.link, spec.spheres.links)):
+            if k < 0:
+                raise NotImplementedError(f"sphere link '{spec.spheres.links[l]}' does not move with any joint of the chain")
+            guards.link_joint[l] = k
+            for i in range(3):
+                guards.link_offset[l][i] = float(off[i])
+    return FigureEightBackend(
+        chain,
+        spec.T,
+        spec.dt,
+        spec.local_path,
+        w_path=spec.w_path,
+        w_vel=spec.w_vel,
+        max_iter=int(o.pop("max_iter", 200)),
+        tol=float(o.pop("tol", 1e-6)),
+        tol_feas=float(o.pop("tol_feas", 1e-9)),
+        hessian=hessian,
+        mu0=float(o.pop("mu0", 0.0)),
+        guards=guards,
+    )
+
+
 class HIPSolver(Solver):
     """MI355X backend.  ``setup(solver_options)`` lowers the problem to a kernel family
     (optas_amd.lowering) and creates the liboptas_hip handle; it raises if the problem is not lowerable
@@ -228,36 +263,7 @@ class HIPSolver(Solver):
         if isinstance(spec, FigureEightSpec):
             o.pop("hessian", None)
         if isinstance(spec, FigureEightSpec):
-            chain = spec.robot.solver_chain(spec.link)
-            guards = None
-            if spec.lo is not None or spec.spheres is not None:
-                guards = _lib.oh_guards()
-            if spec.lo is not None:
-                guards.limits = 1
-                for j in range(spec.robot.ndof):
-                    guards.q_lo[j], guards.q_up[j] = float(spec.lo[j]), float(spec.up[j])
-            if spec.spheres is not None:
-                guards.n_links, guards.n_obstacles = len(spec.spheres.links), len(spec.spheres.obstacles)
-                for l, (k, off) in enumerate(spec.robot.link_attachments(spec.link, spec.spheres.links)):
-                    if k < 0:
-                        raise NotImplementedError(f"sphere link '{spec.spheres.links[l]}' does not move with any joint of the chain")
-                    guards.link_joint[l] = k
-                    for i in range(3):
-                        guards.link_offset[l][i] = float(off[i])
-            self._backend = FigureEightBackend(
-                chain,
-                spec.T,
-                spec.dt,
-                spec.local_path,
-                w_path=spec.w_path,
-                w_vel=spec.w_vel,
-                max_iter=int(o.pop("max_iter", 200)),
-                tol=float(o.pop("tol", 1e-6)),
-                tol_feas=float(o.pop("tol_feas", 1e-9)),
-                hessian=hessian,
-                mu0=float(o.pop("mu0", 0.0)),
-                guards=guards,
-            )
+            self._backend = figure_eight_backend(spec, o, hessian)
             if spec.lead is not None:
                 self._backend = _LeadAdapter(self.opt, spec, self._backend)
         elif isinstance(spec, TorqueSpec):

@@ -1,0 +1,147 @@
+"""The drop-in route for a REAL optas problem (CasADi graphs inside): optas_amd.probe_lowering recognises the figure-eight family from the
+labels / shapes of the problem's containers and the values of its own numeric functions, verifies the model it read off, and the literal
+``optas.solver.Solver`` subclass (optas_amd.casadi_tape.make_solver_class) then runs the structured kernels.  casadi is not installed
+here, so the problem object is this repo's mirror ``Optimization`` behind an adapter that exposes nothing but the reference's interface
+(containers of shaped items, ``models`` with a urdf_parser_py-shaped URDF object, numeric callables): the expression trees the mirror's
+own pattern matcher uses are hidden, exactly as they would be with SX graphs."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from conftest import SEED
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+pytestmark = pytest.mark.gpu
+
+
+class _Shaped:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class _Container(dict):
+    """Ordered label -> item with a shape (what SXContainer is to the code under test)."""
+
+
+def _hide(container):
+    out = _Container()
+    for k, v in container.items():
+        out[k] = _Shaped(tuple(v.shape))
+    return out
+
+
+def _urdf_parser_py_like(desc):
+    """The same kinematic tree as objects shaped like urdf_parser_py's (joint.origin.xyz / .rpy, joint.limit.lower, ...)."""
+    ns = types.SimpleNamespace
+
+    def joint(j):
+        return ns(name=j.name, type=j.type, parent=j.parent, child=j.child, origin=None if j.xyz is None else ns(xyz=list(j.xyz), rpy=list(j.rpy)),
+                  axis=None if j.axis is None else list(j.axis),
+                  limit=None if j.limit is None else ns(lower=j.limit.lower, upper=j.limit.upper, velocity=j.limit.velocity, effort=j.limit.effort))
+
+    def link(l):
+        if l.inertial is None:
+            return ns(name=l.name, inertial=None)
+        ixx, ixy, ixz, iyy, iyz, izz = l.inertial.inertia
+        return ns(name=l.name, inertial=ns(mass=l.inertial.mass, origin=ns(xyz=list(l.inertial.xyz), rpy=list(l.inertial.rpy)),
+                                           inertia=ns(ixx=ixx, ixy=ixy, ixz=ixz, iyy=iyy, iyz=iyz, izz=izz)))
+
+    return ns(name=desc.name, joints=[joint(j) for j in desc.joints], links=[link(l) for l in desc.links])
+
+
+class ReferenceLikeOptimization:
+    """Only what optas.optimization.Optimization offers to a Solver (optimization.py:60-306)."""
+
+    def __init__(self, opt):
+        self._o = opt
+        self.nx, self.np, self.nk, self.na, self.ng, self.nh, self.nv = opt.nx, opt.np, opt.nk, opt.na, opt.ng, opt.nh, opt.nv
+        self.decision_variables = opt.decision_variables  # dict2vec / vec2dict are needed by Solver.solve; the items only expose .shape below
+        self.parameters = opt.parameters
+        self.lin_eq_constraints, self.lin_ineq_constraints = _hide(opt.lin_eq_constraints), _hide(opt.lin_ineq_constraints)
+        self.eq_constraints, self.ineq_constraints = _hide(opt.eq_constraints), _hide(opt.ineq_constraints)
+        self.cost_terms = _hide(opt.cost_terms)
+        m = opt.models[0]
+        self.models = [types.SimpleNamespace(get_name=m.get_name, time_derivs=list(m.time_derivs), param_joints=[], urdf=_urdf_parser_py_like(m.urdf), ndof=m.ndof,
+                                             dim=m.dim, num_param_joints=0, state_name=m.state_name, state_optimized_name=m.state_optimized_name,
+                                             state_parameter_name=m.state_parameter_name)]
+        self.calls = 0
+
+    def _count(self, fn):
+        def g(x, p):
+            self.calls += 1
+            return fn(np.asarray(x, float).reshape(-1), np.asarray(p, float).reshape(-1))
+
+        return g
+
+    def __getattr__(self, name):
+        if name in ("f", "a", "h", "k", "g", "v"):
+            return self._count(getattr(self._o, name))
+        raise AttributeError(name)
+
+    def has_discrete_variables(self):
+        return False
+
+
+def test_probing_recovers_the_family_from_the_reference_interface(hip_lib, golden_nlp):
+    from examples.figure_eight_plan import setup_solver
+    from optas_amd.lowering import FigureEightSpec, match_figure_eight
+    from optas_amd.probe_lowering import probe_figure_eight
+
+    kuka, solver = setup_solver(build_only=True)
+    want = match_figure_eight(solver)  # build_only returns the Optimization: the tree-matching route, for comparison
+    ref = ReferenceLikeOptimization(solver)
+    spec = probe_figure_eight(ref)
+    assert isinstance(spec, FigureEightSpec)
+    assert (spec.link, spec.T) == ("end_effector_ball", 50) and abs(spec.dt - want.dt) < 1e-14
+    assert abs(spec.w_path - 1000.0) < 1e-6 and abs(spec.w_vel - 0.01) < 1e-9
+    assert np.abs(spec.local_path - want.local_path).max() < 1e-9
+    assert ref.calls < 500  # a few evaluations per knot, not a search
+    # constants folded from the urdf_parser_py-shaped object equal the ones folded from the mirror's own description
+    assert bytes(spec.robot.solver_chain(spec.link)) == bytes(kuka.solver_chain("end_effector_ball"))
+
+
+def test_probing_refuses_what_is_not_the_family(hip_lib):
+    from examples.figure_eight_plan import setup_solver
+    from optas_amd.lowering import LoweringError
+    from optas_amd.probe_lowering import probe_figure_eight
+
+    kuka, opt = setup_solver(build_only=True)
+    ref = ReferenceLikeOptimization(opt)
+    f_true = opt.f
+    # same labels and shapes, a different cost (extra quartic term): the verification step must catch it
+    opt.f = lambda x, p: f_true(x, p) + 1e-3 * float(np.sum(np.asarray(x)[:7] ** 4))
+    with pytest.raises(LoweringError, match="cost"):
+        probe_figure_eight(ref)
+    opt.f = f_true
+    # a missing row block is refused on labels alone
+    del ref.lin_eq_constraints["__kuka_fix_configuration_1_0__"]
+    with pytest.raises(LoweringError, match="linear equalities"):
+        probe_figure_eight(ref)
+
+
+def test_literal_solver_subclass_runs_the_structured_kernels(hip_lib, golden_nlp):
+    """make_solver_class over a stand-in for optas.solver (the mirror's Solver ABC has the reference's methods) and a stand-in for casadi
+    (only ``DM``): the subclass must pick the figure-eight family by probing and reproduce the golden optimum."""
+    from examples.figure_eight_plan import setup_solver
+    from optas_amd import solver as mirror_solver
+    from optas_amd.casadi_tape import make_solver_class
+
+    cs = types.SimpleNamespace(DM=lambda a: np.asarray(a, dtype=np.float64).reshape(-1, 1))
+    HIPSolver = make_solver_class(mirror_solver, cs)
+    kuka, opt = setup_solver(build_only=True)
+    ref = ReferenceLikeOptimization(opt)
+    s = HIPSolver(ref).setup("hip_sqp", {"tol": 1e-7})
+    qc = golden_nlp["fig8_qc"]
+    s.reset_parameters({"qc": qc})
+    s.reset_initial_seed({"kuka/q/x": np.tile(qc[:, None], (1, 50))})
+    sol = s.solve()
+    st = s.stats()
+    assert st["family"] == "figure_eight" and s.did_solve()
+    assert abs(st["f"] - float(golden_nlp["fig8_f"])) <= 1e-8 * float(golden_nlp["fig8_f"])  # dense SQP on the literal layout (independent)
+    assert sol["kuka/q"].shape == (7, 50) and sol["kuka/dq"].shape == (7, 49)
+    with pytest.raises(ValueError):
+        HIPSolver(ref).setup("ipopt")

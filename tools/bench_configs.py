@@ -1,9 +1,9 @@
 """Device-time measurements of the BASELINE configs other than the headline (bench.py measures configs[1]):
 config 1 (IK, example.py), config 3 (point-mass MPC tick), config 4 (dual_arm.py as shipped and the synthetic T=100 +
-limits + spheres variant).  One JSON line per config on stdout; inputs are synthetic (SURVEY 8(d) seeds), timings are the
+limits + spheres variant), config 5 (torque MPC with RNEA equality rows, T=30, B=8192 and B=1024 = one GPU's share of 8192 over 8).  One JSON line per config on stdout; inputs are synthetic (SURVEY 8(d) seeds), timings are the
 handle's HIP-event solve time with buffers already resident (oh_solve_device).
 
-  python tools/bench_configs.py > profiles/r01_configs.json
+  python tools/bench_configs.py > profiles/r02_configs.json
 """
 import json
 import os
@@ -14,7 +14,7 @@ import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 from optas_amd import _lib  # noqa: E402
-from optas_amd.backend import FigureEightBackend, IKBackend, PointMassBackend  # noqa: E402
+from optas_amd.backend import FigureEightBackend, IKBackend, PointMassBackend, TorqueBackend  # noqa: E402
 from optas_amd.models import RobotModel  # noqa: E402
 
 SEED = 20260927
@@ -128,6 +128,30 @@ def main():
         x0 = np.concatenate([np.tile(qc, (1, T)), np.zeros((B, 7 * (T - 1)))], 1)
         r = timed(be, np.ascontiguousarray(x0), np.ascontiguousarray(p))
         out.append({"config": tag, "batch": B, "T": T, "solves_per_s": B / r["ms"] * 1e3, **r})
+    # ---- config 5: torque MPC, RNEA dynamics as equality rows (med7, T = 30), effort limit 58 N m so that the rows bind in part of the batch ----
+    med7 = RobotModel.builtin("med7")
+    link, T, dt = "lbr_link_ee", 30, 0.1
+    qn = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    ts = np.arange(T) * dt
+    loc = np.stack([0.2 * np.sin(ts * np.pi * 0.5), 0.1 * np.sin(ts * np.pi), np.zeros(T)])
+    for B in (8192, 1024):
+        qc = qn + rng.uniform(-0.1, 0.1, (B, 7))
+        pose, _ = med7._kin(link).fk_jac(qc, want_jac=False)
+        x, y, z, w = pose[:, 3], pose[:, 4], pose[:, 5], pose[:, 6]
+        Re = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], 1),
+                       np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], 1),
+                       np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)], 1)
+        goal = pose[:, None, :3] + np.einsum("bij,jt->bti", Re, loc)
+        p = np.concatenate([qc, np.zeros((B, 7)), goal.reshape(B, -1)], 1)
+        x0 = np.zeros((B, 4 * 7 * T))
+        x0[:, : 7 * T] = np.tile(qc, (1, T))
+        be = TorqueBackend(med7.kinematic_chain(link), med7.dynamics_tables(), T=T, dt=dt, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=-58.0, tau_up=58.0)
+        r = timed(be, np.ascontiguousarray(x0), np.ascontiguousarray(p))
+        tm = be.timing()
+        out.append({"config": "5 torque-control MPC, RNEA dynamics equality rows + effort limits (med7, T=30)", "batch": B, "T": T,
+                    "solves_per_s": B / r["ms"] * 1e3, "iterations_launched": tm["iterations_launched"],
+                    "instance_iterations": tm["work_instances"], "us_per_instance_iteration": r["ms"] * 1e3 / max(1.0, tm["work_instances"]), **r})
+        be.close()
     for o in out:
         print(json.dumps(o))
 

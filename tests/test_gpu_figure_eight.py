@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 import optas_amd
-from conftest import KUKA_KIN, SEED
+from conftest import GOLDEN, KUKA_KIN, SEED
 from optas_amd import _lib
 from optas_amd.backend import FigureEightBackend
 from optas_amd.models import RobotModel

@@ -17,3 +17,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- python $REPO
 cd $REPO
 python tools/summarize_profile.py $OUT $TAG
 ls -la $OUT $OUT/* | head -40
+# gpurun merges only gpurun_out/ back: leave copies of the condensed files there (copy them into profiles/ and commit)
+mkdir -p $REPO/gpurun_out/profiles && cp $REPO/profiles/${TAG}_* $REPO/profiles/pmc_traffic.json $REPO/gpurun_out/profiles/ 2>/dev/null

@@ -362,6 +362,9 @@ int oh_fk_jac_device(oh_handle* h, int N, const void* d_q, void* d_pose, void* d
 int oh_set_dynamics(oh_handle* h, const oh_dynamics* dyn);
 int oh_rnea(oh_handle* h, int N, const double* q, const double* qd, const double* qdd, double* tau);
 int oh_rnea_device(oh_handle* h, int N, const void* d_q, const void* d_qd, const void* d_qdd, void* d_tau);
+/* Its Jacobian, what the reference gets from casadi.jacobian of the same graph (optimization.py:8-24; the dh of a dynamics row
+   h = TAU - rnea(Q, dQ, ddQ)): J [N][ndof][3 ndof] row-major = d tau / d (q, qd, qdd), exact (the recursion run on dual numbers). */
+int oh_rnea_jac(oh_handle* h, int N, const double* q, const double* qd, const double* qdd, double* J);
 
 /* Structure-of-arrays variant used inside the solver and for roofline measurement:
    q [ndof][N], pose [7][N], J [6*ndof][N] (unit index fastest => fully coalesced). */

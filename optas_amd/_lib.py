@@ -208,6 +208,7 @@ SYMBOLS = [
     "oh_set_dynamics",
     "oh_rnea",
     "oh_rnea_device",
+    "oh_rnea_jac",
     "oh_fk_jac",
     "oh_fk_jac_device",
     "oh_fk_jac_soa_device",

@@ -1260,6 +1260,28 @@ extern "C" int oh_rnea(oh_handle* h, int n, const double* q, const double* qd, c
   return OH_OK;
 }
 
+extern "C" int oh_rnea_jac(oh_handle* h, int n, const double* q, const double* qd, const double* qdd, double* J) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_rnea_jac: null handle");
+  if (n < 1 || !q || !qd || !qdd || !J) return fail(OH_ERR_INVALID, "oh_rnea_jac: bad arguments");
+  if (!h->have_dyn) return fail(OH_ERR_STATE, "oh_rnea_jac: call oh_set_dynamics first");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t nd = h->dyn_host.ndof;
+  const size_t bq = (sizeof(double) * nd * (size_t)n + 255) / 256 * 256, bj = sizeof(double) * nd * 3 * nd * (size_t)n;
+  int rc = ensure_stage(h, 3 * bq + bj);
+  if (rc) return rc;
+  char* base = (char*)h->stage;
+  HIPCHK(hipMemcpy(base, q, sizeof(double) * nd * (size_t)n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(base + bq, qd, sizeof(double) * nd * (size_t)n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(base + 2 * bq, qdd, sizeof(double) * nd * (size_t)n, hipMemcpyHostToDevice));
+  if (!oh_launch_rnea_jac(h->stream, h->d_dyn, h->dyn_host.n, n, (const double*)base, (const double*)(base + bq), (const double*)(base + 2 * bq),
+                          (double*)(base + 3 * bq)))
+    return fail(OH_ERR_INVALID, "oh_rnea_jac: unsupported number of bodies");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(J, base + 3 * bq, bj, hipMemcpyDeviceToHost));
+  return OH_OK;
+}
+
 static int fk_common(oh_handle* h, int n, bool soa, const void* d_q, void* d_pose, void* d_J) {
   if (!h) return fail(OH_ERR_INVALID, "oh_fk_jac: null handle");
   if (n < 1 || !d_q) return fail(OH_ERR_INVALID, "oh_fk_jac: bad arguments");

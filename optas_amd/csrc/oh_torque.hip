@@ -186,6 +186,28 @@ OH_DEV void rnea_lit(const oh_dynamics* __restrict__ dy, const S (&q)[NB - 1], c
   }
 }
 
+// d tau / d (q, qd, qdd) of RobotModel.rnea (what the reference obtains with casadi.jacobian of the same graph, optimization.py:8-24): one lane per
+// (sample, direction), the literal recursion on dual numbers.  q, qd, qdd [n][N] -> J [n][N][3 N] row-major.
+template <int N>
+__global__ __launch_bounds__(64) void k_rnea_jac(const oh_dynamics* __restrict__ dy, const int n, const double* __restrict__ q, const double* __restrict__ qd,
+                                                 const double* __restrict__ qdd, double* __restrict__ J) {
+  constexpr int NZ = 3 * N, UPW = 64 / NZ;
+  const int lane = threadIdx.x;
+  const int ul = lane / NZ, d = lane - ul * NZ;
+  const long long u = (long long)blockIdx.x * UPW + ul;
+  if (ul >= UPW || u >= n) return;
+  Dual a[N], b[N], c[N], tau[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    a[j] = {q[u * N + j], d == j ? 1.0 : 0.0};
+    b[j] = {qd[u * N + j], d == N + j ? 1.0 : 0.0};
+    c[j] = {qdd[u * N + j], d == 2 * N + j ? 1.0 : 0.0};
+  }
+  rnea_lit<N + 1, Dual>(dy, a, b, c, tau);
+#pragma unroll
+  for (int i = 0; i < N; ++i) J[((size_t)u * N + i) * NZ + d] = tau[i].d;
+}
+
 OH_DEV size_t xs_off(const TqBuffers& D, const int T, const int slot, const int b, const int t) { return (((size_t)slot * D.B + b) * T + t) * TQ_XS; }
 OH_DEV size_t st_off(const TqBuffers& D, const int T, const int slot, const int b, const int t) { return (((size_t)slot * D.B + b) * T + t) * TQ_SD; }
 
@@ -727,6 +749,17 @@ __global__ __launch_bounds__(64) void k_tq_finalize(TqParams P, TqBuffers D, dou
 
 }  // namespace
 
+bool oh_launch_rnea_jac(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, int n, const double* q, const double* qd, const double* qdd, double* J) {
+#define OH_RJ(NN)                                                                                                                         \
+  case NN + 1:                                                                                                                            \
+    hipLaunchKernelGGL(k_rnea_jac<NN>, dim3((unsigned)((n + (64 / (3 * NN)) - 1) / (64 / (3 * NN)))), dim3(64), 0, s, d_dyn, n, q, qd, qdd, J); \
+    return true;
+  switch (nbodies) {
+    OH_RJ(1) OH_RJ(2) OH_RJ(3) OH_RJ(4) OH_RJ(5) OH_RJ(6) OH_RJ(7) OH_RJ(8)
+    default: return false;
+  }
+#undef OH_RJ
+}
 bool oh_launch_tq_setup(hipStream_t s, const TqParams& P, const TqBuffers& D, const double* x0, const double* p) {
   if (P.N != 7) return false;
   hipLaunchKernelGGL(k_tq_setup<7>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p);

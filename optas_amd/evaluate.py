@@ -98,3 +98,162 @@ def _evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
         v = evaluate(e.a, opt, x, p)
         return np.array([[float(np.sum(v * v))]])
     raise NotImplementedError(f"cannot evaluate {type(e).__name__}")
+
+
+# ---- first derivatives (the reference's df, dk, da, dg, dh, dv: casadi.jacobian of the same graphs, optimization.py:8-24) ----------------------
+def _sel(container, label, rows_cols=None):
+    """Indices into x of the column-major entries of a decision-variable block (optionally of the columns ``rows_cols``)."""
+    off = container.offsets()[label]
+    m, n = container[label].shape
+    cols = range(n) if rows_cols is None else rows_cols
+    return np.concatenate([off + m * c + np.arange(m) for c in cols]) if len(list(cols)) else np.zeros(0, dtype=int)
+
+
+def jacobian(e: Expr, opt, x: np.ndarray, p: np.ndarray):
+    """(value (m, n), J (m n, nx)): the node's value and the Jacobian of its column-major vec w.r.t. x, by forward propagation through the
+    tree.  Kinematics derivatives come from the geometric Jacobian of oh_fk_jac (d p = J_lin dq, d quat = 1/2 (omega, 0) (x) quat,
+    dR = [omega]x R), inverse dynamics from oh_rnea_jac: exact like CasADi's AD, no differencing."""
+    nx = opt.nx
+    val = evaluate(e, opt, x, p)
+    val = np.asarray(val, dtype=np.float64)
+    m, n = e.shape
+    val = np.broadcast_to(val, (m, n)) if val.shape != (m, n) else val
+
+    def zero():
+        return val, np.zeros((m * n, nx))
+
+    if e.degree() == 0 or isinstance(e, (Const, ParamRef, ParamCol)):
+        return zero()
+    if isinstance(e, (StateRef, VarRef, StateCols)):
+        J = np.zeros((m * n, nx))
+        if isinstance(e, StateRef):
+            idx = _sel(opt.decision_variables, e.var_name, None if e.t is None else [e.t])
+        elif isinstance(e, StateCols):
+            idx = _sel(opt.decision_variables, e.state.var_name, range(e.lo, e.hi))
+        else:
+            idx = _sel(opt.decision_variables, e.var_name)
+        J[np.arange(m * n), idx] = 1.0
+        return val, J
+    if isinstance(e, RobotStates):
+        _, Js = jacobian(e.states, opt, x, p)
+        J = np.zeros((m * n, nx))
+        ms = e.states.shape[0]
+        for c in range(n):
+            for k, r in enumerate(e.opt_idx):
+                J[c * m + r] = Js[c * ms + k]
+        return val, J
+    if isinstance(e, Rows):
+        _, Ja = jacobian(e.a, opt, x, p)
+        ma = e.a.shape[0]
+        rows = [c * ma + r for c in range(n) for r in e.idx]
+        return val, Ja[rows]
+    if isinstance(e, Block):
+        _, Ja = jacobian(e.a, opt, x, p)
+        ma = e.a.shape[0]
+        rows = [c * ma + r for c in e.cidx for r in e.ridx]
+        return val, Ja[rows]
+    if isinstance(e, (Sub, Add)):
+        _, Ja = jacobian(e.a, opt, x, p)
+        _, Jb = jacobian(e.b, opt, x, p)
+        Ja, Jb = _bcast_rows(Ja, e.a.shape, (m, n)), _bcast_rows(Jb, e.b.shape, (m, n))
+        return val, (Ja - Jb) if isinstance(e, Sub) else (Ja + Jb)
+    if isinstance(e, Scale):
+        _, Ja = jacobian(e.a, opt, x, p)
+        return val, e.w * Ja
+    if isinstance(e, Square):
+        va, Ja = jacobian(e.a, opt, x, p)
+        return val, 2.0 * va.T.reshape(-1, 1) * Ja
+    if isinstance(e, SumSqr):
+        va, Ja = jacobian(e.a, opt, x, p)
+        return val, (2.0 * va.T.reshape(1, -1)) @ Ja
+    if isinstance(e, Mul):
+        va, Ja = jacobian(e.a, opt, x, p)
+        vb, Jb = jacobian(e.b, opt, x, p)
+        Ja, Jb = _bcast_rows(Ja, e.a.shape, (m, n)), _bcast_rows(Jb, e.b.shape, (m, n))
+        va, vb = np.broadcast_to(va, (m, n)), np.broadcast_to(vb, (m, n))
+        return val, vb.T.reshape(-1, 1) * Ja + va.T.reshape(-1, 1) * Jb
+    if isinstance(e, MatMul):
+        va, Ja = jacobian(e.a, opt, x, p)
+        vb, Jb = jacobian(e.b, opt, x, p)
+        ma, ka = e.a.shape
+        J = np.zeros((m * n, nx))
+        for c in range(n):
+            for r in range(m):
+                for k in range(ka):  # (A B)[r, c] = sum_k A[r, k] B[k, c]
+                    J[c * m + r] += Ja[k * ma + r] * vb[k, c] + va[r, k] * Jb[c * ka + k]
+        return val, J
+    if isinstance(e, VCat):
+        J = np.zeros((m * n, nx))
+        r0 = 0
+        for part in e.parts:
+            _, Jp = jacobian(part, opt, x, p)
+            mp = part.shape[0]
+            Jp = _bcast_rows(Jp, part.shape, (mp, n))
+            for c in range(n):
+                J[c * m + r0 : c * m + r0 + mp] = Jp[c * mp : (c + 1) * mp]
+            r0 += mp
+        return val, J
+    if isinstance(e, Atan2):
+        vy, Jy = jacobian(e.y, opt, x, p)
+        vx, Jx = jacobian(e.x, opt, x, p)
+        d = (vx * vx + vy * vy).T.reshape(-1, 1)
+        return val, (vx.T.reshape(-1, 1) * Jy - vy.T.reshape(-1, 1) * Jx) / d
+    if isinstance(e, IntegrationResidual):
+        _, JX = jacobian(e.x, opt, x, p)
+        _, JXd = jacobian(e.xd, opt, x, p)
+        mm = e.x.shape[0]
+        J = np.zeros((m * n, nx))
+        for c in range(e.n):
+            J[c * mm : (c + 1) * mm] = JX[c * mm : (c + 1) * mm] + e.dt[c] * JXd[c * mm : (c + 1) * mm] - JX[(c + 1) * mm : (c + 2) * mm]
+        return val, J
+    if isinstance(e, LinkFunction):
+        q, Jq = jacobian(e.q, opt, x, p)  # (ndof, cols), (ndof cols, nx)
+        nd, cols = q.shape
+        pose, Jg = e.robot._kin(e.link).fk_jac(np.ascontiguousarray(q.T))  # (cols, 7), (cols, 6, ndof)
+        J = np.zeros((m * n, nx))
+        for c in range(cols):
+            Jqc = Jq[c * nd : (c + 1) * nd]
+            if e.what == "position":
+                J[3 * c : 3 * c + 3] = Jg[c, :3] @ Jqc
+            elif e.what == "quaternion":
+                qx, qy, qz, qw = pose[c, 3:]
+                Lq = 0.5 * np.array([[qw, qz, -qy], [-qz, qw, qx], [qy, -qx, qw], [-qx, -qy, -qz]])  # d quat = 1/2 (omega, 0) (x) quat
+                J[4 * c : 4 * c + 4] = Lq @ Jg[c, 3:] @ Jqc
+            elif e.what == "rotation":
+                R = val
+                W = Jg[c, 3:] @ Jqc  # omega per unit dx, (3, nx)
+                for col in range(3):  # d R[:, col] = omega x R[:, col]; vec is column-major
+                    r = R[:, col]
+                    K = np.array([[0.0, r[2], -r[1]], [-r[2], 0.0, r[0]], [r[1], -r[0], 0.0]])  # omega x r = K omega
+                    J[3 * col : 3 * col + 3] = K @ W
+            else:
+                raise NotImplementedError("derivative of the geometric Jacobian (second-order kinematics) is not provided")
+        return val, J
+    if isinstance(e, RneaFunction):
+        q, Jq = jacobian(e.q, opt, x, p)
+        qd, Jqd = jacobian(e.qd, opt, x, p)
+        qdd, Jqdd = jacobian(e.qdd, opt, x, p)
+        nd, cols = q.shape
+        Jt = e.robot.rnea_jacobian(q, qd, qdd)  # (cols, nd, 3 nd)
+        J = np.zeros((m * n, nx))
+        for c in range(cols):
+            sl = slice(c * nd, (c + 1) * nd)
+            J[sl] = Jt[c, :, :nd] @ Jq[sl] + Jt[c, :, nd : 2 * nd] @ Jqd[sl] + Jt[c, :, 2 * nd :] @ Jqdd[sl]
+        return val, J
+    if isinstance(e, PathInFrame):
+        if e.origin.degree() == 0 and e.rotation.degree() == 0:
+            return zero()
+        raise NotImplementedError("derivative of a path frame that depends on the decision variables is not provided")
+    raise NotImplementedError(f"no derivative rule for {type(e).__name__}")
+
+
+def _bcast_rows(J, shape_from, shape_to):
+    """Rows of a Jacobian for an operand that CasADi-style broadcasting repeats (scalar or column against a matrix)."""
+    (mf, nf), (mt, nt) = shape_from, shape_to
+    if (mf, nf) == (mt, nt):
+        return J
+    if (mf, nf) == (1, 1):
+        return np.repeat(J, mt * nt, axis=0)
+    if mf == mt and nf == 1:
+        return np.tile(J, (nt, 1))
+    raise NotImplementedError(f"broadcast of a {shape_from} operand to {shape_to}")

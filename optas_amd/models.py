@@ -451,6 +451,18 @@ class RobotModel(Model):
         _lib.check(_lib.load().oh_rnea(self._dyn_handle, n, _lib._ptr(A[0]), _lib._ptr(A[1]), _lib._ptr(A[2]), _lib._ptr(tau)), "oh_rnea")
         return tau[0] if single else tau.T
 
+    def rnea_jacobian(self, q, qd, qdd) -> np.ndarray:
+        """d tau / d (q, qd, qdd) at ndof-by-n sample columns: (n, ndof, 3 ndof), exact (oh_rnea_jac)."""
+        import ctypes as C
+
+        self.rnea(np.zeros(self.ndof), np.zeros(self.ndof), np.zeros(self.ndof))  # creates the handle
+        nd = self._dyn.ndof
+        A = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(nd, -1).T) for a in (q, qd, qdd)]
+        n = A[0].shape[0]
+        J = np.empty((n, nd, 3 * nd))
+        _lib.check(_lib.load().oh_rnea_jac(self._dyn_handle, n, _lib._ptr(A[0]), _lib._ptr(A[1]), _lib._ptr(A[2]), _lib._ptr(J)), "oh_rnea_jac")
+        return J
+
     # ---- numeric kinematics through the HIP library -------------------------------------------------
     def _kin(self, link: str) -> "KinematicsHandle":
         h = self._fk_handles.get(link)

@@ -5,7 +5,10 @@ The solve itself happens inside the lowered HIP kernels; the function members ``
 defines them -- ``M, c, A, b`` (``k = Mx + c``, ``a = Ax + b``, optimization.py:225-260) and ``P, q``
 (``f = x^T P x + q^T x``, optimization.py:219-223) are numeric callables over the expression trees (optas_amd.evaluate;
 link functions inside them run through liboptas_hip), used for diagnostics and for checking the builder's layout and sign
-conventions against the oracle.  Derivative members (df, ddf, dv, ...) are not provided: the kernels carry their own.
+conventions against the oracle.  The derivative members the reference derives with CasADi (optimization.py:8-24) are here too:
+``df, dk, da, dg, dh, dv`` are exact (forward propagation through the trees with the geometric Jacobian of oh_fk_jac and the
+dual-number Jacobian of oh_rnea_jac, optas_amd.evaluate.jacobian); ``ddf, ddg, ddh, ddv`` are central differences of those exact first
+derivatives (step 1e-6, symmetrised) -- the kernels carry their own second-order terms and never call them.
 ``v = [k; g; a; -a; h; -h]``, ``nv = nk + ng + 2 na + 2 nh``, bounds ``0 <= v <= 1e10`` (optimization.py:27-51,292-306).
 """
 from __future__ import annotations
@@ -69,6 +72,61 @@ class Optimization:
         """vertcon (optimization.py:27-51): [k; g; a; -a; h; -h] >= 0."""
         a, h = self.a(x, p), self.h(x, p)
         return np.concatenate([self.k(x, p), self.g(x, p), a, -a, h, -h])
+
+    # ---- derivative members (optimization.py:8-24, 198, 276-306) ------------------------------------------------------------------
+    def _jac(self, container, x, p) -> np.ndarray:
+        from .evaluate import jacobian
+
+        x, p = np.asarray(x, dtype=np.float64).reshape(-1), np.asarray(p, dtype=np.float64).reshape(-1)
+        parts = [jacobian(term, self, x, p)[1] for term in container.values()]
+        return np.concatenate(parts, axis=0) if parts else np.zeros((0, self.nx))
+
+    def df(self, x, p) -> np.ndarray:
+        """Gradient of f as a 1 x nx row (casadi.jacobian(f, x))."""
+        return np.sum(self._jac(self.cost_terms, x, p), axis=0, keepdims=True)
+
+    def dk(self, x, p) -> np.ndarray:
+        return self._jac(self.lin_ineq_constraints, x, p)
+
+    def da(self, x, p) -> np.ndarray:
+        return self._jac(self.lin_eq_constraints, x, p)
+
+    def dg(self, x, p) -> np.ndarray:
+        return self._jac(self.ineq_constraints, x, p)
+
+    def dh(self, x, p) -> np.ndarray:
+        return self._jac(self.eq_constraints, x, p)
+
+    def dv(self, x, p) -> np.ndarray:
+        da, dh = self.da(x, p), self.dh(x, p)
+        return np.concatenate([self.dk(x, p), self.dg(x, p), da, -da, dh, -dh], axis=0)
+
+    def _second(self, first, x, p, step=1e-6) -> np.ndarray:
+        """d/dx of a first-derivative member by central differences: (rows, nx, nx), symmetrised in the last two axes."""
+        x = np.asarray(x, dtype=np.float64).reshape(-1).copy()
+        J0 = first(x, p)
+        H = np.zeros(J0.shape + (self.nx,))
+        for i in range(self.nx):
+            xi = x[i]
+            x[i] = xi + step
+            Jp = first(x, p)
+            x[i] = xi - step
+            Jm = first(x, p)
+            x[i] = xi
+            H[..., i] = (Jp - Jm) / (2.0 * step)
+        return 0.5 * (H + np.swapaxes(H, -1, -2))
+
+    def ddf(self, x, p) -> np.ndarray:
+        return self._second(self.df, x, p)[0]
+
+    def ddg(self, x, p) -> np.ndarray:
+        return self._second(self.dg, x, p)
+
+    def ddh(self, x, p) -> np.ndarray:
+        return self._second(self.dh, x, p)
+
+    def ddv(self, x, p) -> np.ndarray:
+        return self._second(self.dv, x, p)
 
     def _affine(self, fun, p):
         """(matrix, offset) of an affine map x -> fun(x, p): offset = fun(0), column i = fun(e_i) - offset (exact)."""

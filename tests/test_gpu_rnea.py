@@ -61,3 +61,21 @@ def test_rnea_preconditions(hip_lib):
         RobotModel(urdf_filename=KUKA_KIN).rnea(np.zeros(7), np.zeros(7), np.zeros(7))
     with pytest.raises(JointTypeNotSupported):  # prismatic joints are not supported (models.py:1742-1746)
         RobotModel(urdf_filename=os.path.join(GOLDEN, "tester_robot.kin.json")).rnea(np.zeros(3), np.zeros(3), np.zeros(3))
+
+
+def test_rnea_jacobian_against_complex_step_of_the_oracle(hip_lib):
+    """oh_rnea_jac (the reference's recursion run on dual numbers) against complex-step differentiation of the numpy restatement: two
+    derivative mechanisms that share no code, agreement to rounding (1e-10 relative)."""
+    from conftest import GOLDEN, MED7_KIN
+    from oracle.torque import RneaTables, rnea_jacobian
+
+    rng = np.random.default_rng(SEED + 31)
+    for kin, n in ((MED7_KIN, 7), (os.path.join(GOLDEN, "tester_robot_revolute.kin.json"), None)):
+        robot = RobotModel(urdf_filename=kin)
+        tb = RneaTables(OracleRobot(kin))
+        nd = tb.ndof
+        q, qd, qdd = rng.uniform(-2, 2, (3, 33, nd))
+        J = robot.rnea_jacobian(q.T, qd.T, qdd.T)
+        Jo = rnea_jacobian(tb, q, qd, qdd)
+        assert J.shape == (33, nd, 3 * nd)
+        assert np.abs(J - Jo).max() <= 1e-10 * max(1.0, np.abs(Jo).max())

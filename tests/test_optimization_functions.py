@@ -88,3 +88,65 @@ def test_robot_problem_functions_match_oracle(hip_lib):
     x = rng.uniform(-1, 1, o.nx)
     p = o.parameters.dict2vec({"qcl": rng.uniform(-1, 1, 7), "qcr": rng.uniform(-1, 1, 7), **obstacle_parameters()})
     assert abs(o.f(x, p) - nlp.f(x, p)) < 1e-12 * abs(nlp.f(x, p)) and np.abs(o.v(x, p) - nlp.v(x, p)).max() < 1e-12
+
+
+def test_derivative_members_of_a_task_problem():
+    """df / dk / dv / ddf of a problem without kinematics (no GPU): optimization.py:8-24, 198, 304-306."""
+    import optas_amd
+    from optas_amd.builder import OptimizationBuilder
+    from optas_amd.expr import sumsqr
+
+    task = optas_amd.TaskModel("t", 2, time_derivs=[0], dlim={0: [-3.0, 4.0]})
+    b = OptimizationBuilder(3, tasks=task)
+    Y = b.get_model_states("t", 0)
+    goal = b.add_parameter("goal", 2, 3)
+    b.add_cost_term("c", 3.0 * sumsqr(Y - goal))
+    b.enforce_model_limits("t")
+    o = b.build()
+    rng = np.random.default_rng(SEED)
+    x, p = rng.normal(size=o.nx), rng.normal(size=o.np)
+    assert o.df(x, p).shape == (1, 6) and np.allclose(o.df(x, p)[0], 6.0 * (x - p))
+    assert np.allclose(o.dk(x, p), np.vstack([np.eye(6), -np.eye(6)])) and np.allclose(o.dv(x, p), o.dk(x, p))
+    assert np.allclose(o.ddf(x, p), 6.0 * np.eye(6), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_derivative_members_match_the_oracle_derivatives(hip_lib):
+    """df, da, dh, dk, dv of the robot problems (FK Jacobians through oh_fk_jac, inverse-dynamics Jacobian through oh_rnea_jac) against the
+    oracle's analytic / complex-step derivatives of the literal NLPs; ddf against a difference of the oracle's df."""
+    from conftest import MED7_KIN
+    from examples.example import setup_solver as ik_example
+    from examples.figure_eight_plan import setup_solver as figure_eight
+    from examples.torque_mpc import build_problem
+    from oracle.problems import TorqueMPCNLP
+    from oracle.torque import TorqueProblem
+
+    rng = np.random.default_rng(SEED + 5)
+    kuka = OracleRobot(KUKA_KIN)
+    # config 2, short horizon
+    T = 6
+    _, o = figure_eight(T=T, Tmax=10.0 * (T - 1) / 49.0, build_only=True)
+    nlp = FigureEightNLP(kuka, "end_effector_ball", T=T, Tmax=10.0 * (T - 1) / 49.0)
+    x, p = rng.uniform(-1, 1, o.nx), rng.uniform(-1, 1, 7)
+    assert np.abs(o.df(x, p)[0] - nlp.df(x, p)).max() < 1e-9 * max(1.0, np.abs(nlp.df(x, p)).max())
+    assert np.abs(o.da(x, p) - nlp.da(x, p)).max() == 0.0 and np.abs(o.dh(x, p) - nlp.dh(x, p)).max() < 1e-12
+    assert np.abs(o.dv(x, p) - nlp.dv(x, p)).max() < 1e-12 and o.dv(x, p).shape == (o.nv, o.nx)
+    # config 1: Hessian of the quadratic cost, second derivatives of the position rows against differences of the oracle's dh
+    _, o = ik_example(build_only=True)
+    nlp = IKExampleNLP(kuka, "end_effector_ball")
+    x, p = rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 10)
+    assert np.abs(o.df(x, p)[0] - nlp.df(x, p)).max() < 1e-13 and np.abs(o.dv(x, p) - nlp.dv(x, p)).max() < 1e-12
+    assert np.abs(o.ddf(x, p) - 2.0 * np.eye(7)).max() < 1e-6
+    H = o.ddh(x, p)
+    assert H.shape == (3, 7, 7)
+    e = np.zeros(7)
+    e[2] = 1e-6
+    assert np.abs(H[:, :, 2] - (nlp.dh(x + e, p) - nlp.dh(x - e, p)) / 2e-6).max() < 1e-5
+    # config 5: the dynamics rows
+    T = 4
+    _, _, o = build_problem(T=T, effort=60.0)
+    prob = TorqueProblem(OracleRobot(MED7_KIN), "lbr_link_ee", T=T, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=60.0)
+    nlp = TorqueMPCNLP(prob)
+    x, p = rng.uniform(-1, 1, o.nx), rng.uniform(-1, 1, o.np)
+    assert np.abs(o.dh(x, p) - nlp.dh(x, p)).max() < 1e-9 and np.abs(o.df(x, p)[0] - nlp.df(x, p)).max() < 1e-9 * max(1.0, np.abs(nlp.df(x, p)).max())
+    assert np.abs(o.da(x, p) - nlp.da(x, p)).max() == 0.0 and np.abs(o.dk(x, p) - nlp.dk(x, p)).max() == 0.0

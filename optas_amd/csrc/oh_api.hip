@@ -892,6 +892,10 @@ static void fill_params(oh_handle* h) {
   P.hyb_switch = 1e-5 * d.w_path;
   if (const char* e = getenv("OH_HYB_SWITCH")) P.hyb_switch = atof(e) * d.w_path;  // experiments (tools/sweep_env.sh)
   P.mu0 = d.mu0;
+  P.relax = 1.5;
+  P.relax_from = 4;
+  if (const char* e = getenv("OH_RELAX")) P.relax = atof(e);
+  if (const char* e = getenv("OH_RELAX_FROM")) P.relax_from = atoi(e);
   P.local_path = h->d_local_path;
   P.np = d.ndof + (h->have_guards ? h->guards.n_links + 4 * h->guards.n_obstacles : 0);
   if (h->chain_host.has_lead) P.np = d.ndof + 1 + d.T;

@@ -26,6 +26,8 @@ struct FigParams {
   int hessian;
   double hyb_switch; // OH_HESSIAN_HYBRID: exact curvature once stat <= hyb_switch
   double mu0;
+  double relax;      // over-relaxation of Gauss-Newton steps in the crawl phase of OH_HESSIAN_HYBRID (1: off), see step_instance
+  int relax_from;    // ... from this step count on
   const double* local_path;  // device, [T][3]
   int np;            // row stride of the parameter matrix p (ndof, or ndof + guard parameters)
 };

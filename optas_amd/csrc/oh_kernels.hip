@@ -498,7 +498,10 @@ __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const in
         gd += __shfl_xor(gd, m);
         z2 += __shfl_xor(z2, m);
       }
-      pred = -0.5 * gd + 0.5 * mu * z2;
+      const double alpha = (P.hessian == OH_HESSIAN_HYBRID && stat > P.hyb_switch && iters >= P.relax_from) ? P.relax : 1.0;  // see step_instance
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) zmine[a] *= alpha;
+      pred = -alpha * gd + 0.5 * alpha * alpha * (gd + mu * z2);
     }
     // next trial knots: q_cur + Z_cur z
 #pragma unroll

@@ -109,6 +109,8 @@ extern "C" int oh_port_solve(const oh_problem_desc* desc, const oh_chain* chain,
   P.hessian = desc->hessian;
   P.hyb_switch = 1e-5 * desc->w_path;
   P.mu0 = desc->mu0 > 0.0 ? desc->mu0 : 0.0;
+  P.relax = 1.5;  // the library's defaults (oh_api.hip:fill_params)
+  P.relax_from = 4;
   P.local_path = desc->local_path;
   P.np = desc->ndof;
   if (threads < 1) threads = 1;

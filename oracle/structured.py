@@ -320,7 +320,7 @@ def retract(prob, Q, Rc, tol=1e-10, max_corr=4, e_tgt=None):
     return Q
 
 
-def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False, hessian="hybrid", limits=None, rho0=None, guards=None):
+def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False, hessian="hybrid", limits=None, rho0=None, guards=None, overrelax=1.5, overrelax_from=4):
     """Returns dict(Q, f, iters (= steps solved: accepted + rejected), rejected, stat, feas, status).
     limits = (lo, up) or guards = oracle.guarded.Guards (joint limits and/or sphere clearances): inequality rows at the free
     knots through the augmented Lagrangian of oracle/guarded.py (k_eval_lg / k_step_lg); adds "lam" (T, NC), "meas", "outers".
@@ -490,7 +490,11 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
             break
         if iters >= max_iter:
             break
-        pred = -0.5 * float(np.sum(cur["gt"] * z)) + 0.5 * mu * float(np.sum(z * z))
+        # over-relaxation of Gauss-Newton steps in the crawl phase of the hybrid scheme (step_instance in csrc/oh_figure8_units.h)
+        alpha = overrelax if (hessian == "hybrid" and not guard and stat > hyb_switch and iters >= overrelax_from) else 1.0
+        gd_, z2_ = float(np.sum(cur["gt"] * z)), float(np.sum(z * z))
+        pred = -alpha * gd_ + 0.5 * alpha * alpha * (gd_ + mu * z2_)
+        z = alpha * z
         Qt = cur["Q"].copy()
         Qt[F] += np.einsum("tia,ta->ti", cur["Z"][F], z)
         e_tgt = cur["e"].copy()

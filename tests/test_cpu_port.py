@@ -22,7 +22,9 @@ def test_compiled_port_matches_numpy_restatement():
         prob = StructuredFigureEight(OracleRobot(KUKA_KIN), "end_effector_ball", T=50)
         for b in range(0, B, 3):
             s = solve_structured_lm(prob, qc[b], max_iter=300, tol=1e-6, hessian=hessian)
-            assert abs(int(it[b]) - s["iters"]) <= 1 and abs(f[b] - s["f"]) <= 1e-9 * abs(s["f"])
+            # same optimum; the step at which the reduced gradient first dips under the hybrid switch (1e-2, approached as 1.2e-2, 7.4e-3 ...)
+            # and the fate of a borderline over-relaxed step depend on rounding, which differs between libm and the kernels' own sincos
+            assert abs(int(it[b]) - s["iters"]) <= 3 and abs(f[b] - s["f"]) <= 1e-9 * abs(s["f"])
             assert np.abs(x[b, :350].reshape(50, 7) - s["Q"]).max() < 1e-4
     x1, f1, _, it1, _ = cpu_port.solve(chain, 50, dt, lp, x0, qc, hessian=2, threads=1)
     x3, f3, _, it3, _ = cpu_port.solve(chain, 50, dt, lp, x0, qc, hessian=2, threads=3)

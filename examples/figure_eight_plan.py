@@ -17,7 +17,8 @@ def figure_eight_local_path(T: int, Tmax: float):
     return t, path
 
 
-def setup_solver(robot_name="kuka_lwr", link_ee="end_effector_ball", T=50, Tmax=10.0, solver_options=None, build_only=False, limits=None, obstacles=None, sphere_links=None):
+def setup_solver(robot_name="kuka_lwr", link_ee="end_effector_ball", T=50, Tmax=10.0, solver_options=None, build_only=False, limits=None, obstacles=None, sphere_links=None,
+                 velocity_limits=None):
     t, local = figure_eight_local_path(T, Tmax)
     dt = float(t[1] - t[0])
     kuka = optas_amd.RobotModel.builtin(robot_name, time_derivs=[0, 1])
@@ -42,6 +43,11 @@ def setup_solver(robot_name="kuka_lwr", link_ee="end_effector_ball", T=50, Tmax=
             builder.enforce_model_limits(kuka_name)
         else:
             builder.enforce_model_limits(kuka_name, lo=limits[0], up=limits[1])
+    if velocity_limits is not None:  # not in the shipped script (whose optimum exceeds the LWR's 1.92 rad/s on joint 0): True = the model's own, or (lo, up)
+        if velocity_limits is True:
+            builder.enforce_model_limits(kuka_name, time_deriv=1)
+        else:
+            builder.enforce_model_limits(kuka_name, time_deriv=1, lo=velocity_limits[0], up=velocity_limits[1])
     if obstacles is not None:  # not in the shipped script: sphere clearances (obstacle names; parameters are set at solve time)
         builder.sphere_collision_avoidance_constraints(kuka_name, list(obstacles), link_names=sphere_links)
     optimization = builder.build()

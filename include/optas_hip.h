@@ -185,7 +185,8 @@ typedef struct oh_pointmass_desc {
  *   limits:  q_t - q_lo >= 0, q_up - q_t >= 0 at every knot   (enforce_model_limits, builder.py:471-509, rows "_l", "_r")
  *   spheres: ||c_l(q_t) - o_j||^2 - (r_l + r_j)^2 >= 0 for every sphere link l and obstacle j
  *            (sphere_collision_avoidance_constraints, builder.py:366-417; c_l = origin of link l in the root frame)
- * Row order per knot: [q - lo (ndof); up - q (ndof); spheres link-major, obstacle-minor]; knots t < t0 are constants.
+ * Row order per knot: [q - lo (ndof); up - q (ndof); spheres link-major, obstacle-minor; dq - dq_lo (ndof); dq_up - dq (ndof)]; knots t < t0
+ * are constants.
  * With guards the parameter row of an instance is
  *   p = [qc (ndof); link radii (n_links); for each obstacle: position (3), radius (1)],  np = ndof + n_links + 4 n_obstacles
  * (the order in which the reference creates these parameters, builder.py:391-405).
@@ -201,6 +202,13 @@ typedef struct oh_guards {
   double link_offset[OH_MAX_SPHERE_LINKS][3]; /* link origin in the frame that follows that joint's motion */
   int n_obstacles;
   double rho0;                              /* initial augmented-Lagrangian penalty; <= 0: 10 * w_path */
+  /* joint-velocity limits: enforce_model_limits(name, time_deriv=1) (builder.py:471-509), rows dq_t - dq_lo >= 0, dq_up - dq_t >= 0 on
+     dq_t = (q_{t+1} - q_t) / dt, t = 0..T-2; orientation-locked family only (lock_orientation = 1).  They couple neighbouring knots exactly
+     like the velocity cost: while row j of dq_t is active it adds rho_v / dt^2 to the weight 2 kappa of (q_{t+1,j} - q_{t,j})^2 in the
+     block-tridiagonal model.  oh_get_multipliers appends the 2 ndof multipliers of dq_t to knot t's rows (knot T-1: zeros). */
+  int vel_limits;
+  double dq_lo[OH_MAX_CHAIN];
+  double dq_up[OH_MAX_CHAIN];
 } oh_guards;
 
 typedef struct oh_ik_desc {
@@ -347,7 +355,7 @@ int oh_pm_rollout(oh_handle* h, int B, int n_ticks, int advance, double ramp, co
    h = quat_c - quat(q_t) (signed mu = lam+ - lam- of the (h,-h) pair, optimization.py:47-51). Host buffer.
    OH_PROBLEM_IK: lam_h [B][3 + 2*ndof] = (mu of h = p_goal - p_link(q) (3), multipliers of q - lo >= 0 (ndof),
    multipliers of up - q >= 0 (ndof)).
-   Handles with oh_set_guards: lam_h [B][T][NC], NC = 2 ndof limits + n_links n_obstacles, row order
+   Handles with oh_set_guards: lam_h [B][T][NC], NC = 2 ndof limits + n_links n_obstacles + 2 ndof velocity limits, row order
    of oh_guards (multipliers >= 0 of the g >= 0 rows; knots t < t0 carry zeros). */
 int oh_get_multipliers(oh_handle* h, int B, double* lam_h);
 

@@ -116,6 +116,9 @@ class oh_guards(C.Structure):
         ("link_offset", (C.c_double * 3) * OH_MAX_SPHERE_LINKS),
         ("n_obstacles", C.c_int),
         ("rho0", C.c_double),
+        ("vel_limits", C.c_int),
+        ("dq_lo", C.c_double * OH_MAX_CHAIN),
+        ("dq_up", C.c_double * OH_MAX_CHAIN),
     ]
 
 

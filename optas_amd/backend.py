@@ -312,7 +312,7 @@ class FigureEightBackend:
         if guards is not None:
             _lib.check(lib.oh_set_guards(self._h, C.byref(guards)), "oh_set_guards")
             self.np_ = self.ndof + guards.n_links + 4 * guards.n_obstacles
-            self.n_rows = (2 * self.ndof if guards.limits else 0) + guards.n_links * guards.n_obstacles
+            self.n_rows = (2 * self.ndof if guards.limits else 0) + guards.n_links * guards.n_obstacles + (2 * self.ndof if guards.vel_limits else 0)
 
     @property
     def handle(self) -> C.c_void_p:

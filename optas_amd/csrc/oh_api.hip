@@ -798,7 +798,12 @@ extern "C" int oh_set_guards(oh_handle* h, const oh_guards* g) {
   if (g->n_links < 0 || g->n_links > OH_MAX_SPHERE_LINKS || g->n_obstacles < 0 || g->n_obstacles > OH_MAX_OBSTACLES)
     return fail(OH_ERR_INVALID, "oh_set_guards: too many sphere links / obstacles");
   if ((g->n_links == 0) != (g->n_obstacles == 0)) return fail(OH_ERR_INVALID, "oh_set_guards: sphere rows need both links and obstacles");
-  if (!g->limits && g->n_links == 0) return fail(OH_ERR_INVALID, "oh_set_guards: no rows");
+  if (!g->limits && g->n_links == 0 && !g->vel_limits) return fail(OH_ERR_INVALID, "oh_set_guards: no rows");
+  if (g->vel_limits) {
+    if (!h->desc.lock_orientation) return fail(OH_ERR_INVALID, "oh_set_guards: velocity limits are lowered for the orientation-locked family only");
+    for (int j = 0; j < h->desc.ndof; ++j)
+      if (!(g->dq_lo[j] < g->dq_up[j])) return fail(OH_ERR_INVALID, "oh_set_guards: dq_lo must be below dq_up");
+  }
   for (int l = 0; l < g->n_links; ++l)
     if (g->link_joint[l] < 0 || g->link_joint[l] >= h->desc.ndof)
       return fail(OH_ERR_INVALID, "oh_set_guards: sphere links must hang on an actuated joint of the chain");
@@ -835,12 +840,18 @@ static int ensure_guards(oh_handle* h) {
     GP.up[j] = g.q_up[j];
   }
   GP.rho0 = g.rho0 > 0.0 ? g.rho0 : 10.0 * h->desc.w_path;
+  GP.vel = g.vel_limits ? 1 : 0;
+  for (int j = 0; j < N; ++j) {
+    GP.vlo[j] = g.dq_lo[j];
+    GP.vup[j] = g.dq_up[j];
+  }
+  GP.vscale = h->desc.dt * h->desc.dt / 40.0;
   const int Bp = h->D.Bp;
   if (!h->gpool || h->gcap != Bp) {
     if (h->gpool) hipFree(h->gpool);
     h->gpool = nullptr;
     const size_t npar = (size_t)g.n_links + 4 * (size_t)g.n_obstacles;
-    const size_t nd = (size_t)T * GP.NC * Bp + npar * Bp + 4 * (size_t)T * Bp + 6 * (size_t)Bp;
+    const size_t nd = (size_t)T * GP.NC * Bp + npar * Bp + 4 * (size_t)T * Bp + 6 * (size_t)Bp + (GP.vel ? (size_t)T * 2 * N * Bp : 0);
     const size_t bytes = nd * sizeof(double) + 2 * (size_t)Bp * sizeof(int);
     hipError_t e = hipMalloc(&h->gpool, bytes);
     if (e != hipSuccess) return fail(OH_ERR_HIP, std::string("guard pool allocation failed: ") + hipGetErrorString(e));
@@ -861,6 +872,7 @@ static int ensure_guards(oh_handle* h) {
     GB.mcv[0] = take((size_t)T * Bp);
     GB.mcv[1] = take((size_t)T * Bp);
     GB.meas = take(Bp);
+    GB.lamv = GP.vel ? take((size_t)T * 2 * N * Bp) : nullptr;
     int* ip = (int*)d;
     GB.outer = ip; ip += Bp;
     GB.n_outer = ip;
@@ -995,7 +1007,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     else if (guarded) oh_launch_eval_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else oh_launch_eval_free(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(1); }
-    if (h->P.lock) oh_launch_couple(s, N, h->P, h->D, slot);
+    if (h->P.lock && guarded && h->GP.vel) oh_launch_couple_vel(s, N, h->P, h->D, h->GP, h->GB, slot);
+    else if (h->P.lock) oh_launch_couple(s, N, h->P, h->D, slot);
     else oh_launch_couple_free(s, N, h->P, h->D, slot);
     const bool check = ((it + 1) % check_every == 0);
     if (check && !h->P.lock) HIPCHK(hipMemsetAsync(h->D.n_running, 0, sizeof(int), s));  // the locked family's k_couple resets it
@@ -1210,13 +1223,20 @@ extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
     return OH_OK;
   }
   if (h->have_guards) {
-    // SoA [T][NC][Bp] on the device -> [B][T][NC] for the caller
-    const int T = h->desc.T, NC = h->GP.NC, Bp = h->D.Bp;
+    // SoA [T][NC][Bp] on the device -> [B][T][NC (+ 2 ndof velocity rows)] for the caller
+    const int T = h->desc.T, NC = h->GP.NC, Bp = h->D.Bp, NV = h->GP.vel ? 2 * h->desc.ndof : 0, NT = NC + NV;
     std::vector<double> tmp((size_t)T * NC * Bp);
-    HIPCHK(hipMemcpy(tmp.data(), h->GB.lam, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (NC) HIPCHK(hipMemcpy(tmp.data(), h->GB.lam, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int b = 0; b < B; ++b)
       for (int t = 0; t < T; ++t)
-        for (int i = 0; i < NC; ++i) lam_h[((size_t)b * T + t) * NC + i] = tmp[((size_t)t * NC + i) * Bp + b];
+        for (int i = 0; i < NC; ++i) lam_h[((size_t)b * T + t) * NT + i] = tmp[((size_t)t * NC + i) * Bp + b];
+    if (NV) {  // the device keeps the rows of dq_t = interval (t, t+1) in row block t + 1
+      std::vector<double> tv((size_t)T * NV * Bp);
+      HIPCHK(hipMemcpy(tv.data(), h->GB.lamv, tv.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (int b = 0; b < B; ++b)
+        for (int t = 0; t < T; ++t)
+          for (int i = 0; i < NV; ++i) lam_h[((size_t)b * T + t) * NT + NC + i] = (t + 1 < T) ? tv[((size_t)(t + 1) * NV + i) * Bp + b] : 0.0;
+    }
     return OH_OK;
   }
   if (!h->D.lam_h) return fail(OH_ERR_STATE, "oh_get_multipliers: this problem has no nonlinear equality rows");

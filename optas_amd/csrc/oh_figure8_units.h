@@ -291,8 +291,49 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
 
 // K2b: one lane per (instance b, free knot t), after k_eval: everything of the reduced block-tridiagonal
 // system that needs the neighbouring knots but not the recursion (couple_knot in oh_figure8.h).
+// Velocity rows of one interval (enforce_model_limits(time_deriv=1), builder.py:471-509): v = (qb - qa) / dt, rows v - vlo >= 0, vup - v >= 0 with the
+// multipliers lam[0..N) / lam[N..2N) and penalty rho.  Out: sigma_k = d L_A / d v_k / dt (enters the gradient of knot b with +, of knot a
+// with -), the Gauss-Newton weight w_k = rho (active rows) / dt^2 of (qb_k - qa_k)^2, the augmented-Lagrangian value psi and the measure
+// |min(g, lam / rho)|_inf.  (oracle/structured.py:vel_terms)
 template <int N>
-OH_DEV void couple_unit(const FigParams& P, const FigBuffers& D, const int slot, const int b, const int t) {
+OH_DEV void velocity_rows(const GuardParams& GP, const double dt, const double rho, const double (&qa)[N], const double (&qb)[N], const double (&lam)[2 * N],
+                          double (&sigma)[N], double (&w)[N], double& psi, double& meas) {
+  psi = 0.0;
+  meas = 0.0;
+  const double idt = 1.0 / dt;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double v = (qb[k] - qa[k]) * idt;
+    const double g_lo = v - GP.vlo[k], g_up = GP.vup[k] - v;
+    const double s_lo = fmax(0.0, lam[k] - rho * g_lo), s_up = fmax(0.0, lam[N + k] - rho * g_up);
+    psi += (s_lo * s_lo - lam[k] * lam[k]) / (2.0 * rho) + (s_up * s_up - lam[N + k] * lam[N + k]) / (2.0 * rho);
+    meas = fmax(meas, fmax(fabs(fmin(g_lo, lam[k] / rho)), fabs(fmin(g_up, lam[N + k] / rho))));
+    sigma[k] = (s_up - s_lo) * idt;
+    w[k] = rho * ((s_lo > 0.0 ? 1.0 : 0.0) + (s_up > 0.0 ? 1.0 : 0.0)) * idt * idt;
+  }
+}
+
+// multiplier refresh of the velocity rows at an outer update (before k_couple of the same iteration reads them; a launch of its own so that
+// no lane reads a neighbour's row block while it is being rewritten): lam <- max(0, lam - rho_old g) at the re-evaluated accepted point
+template <int N>
+OH_DEV void vel_update_unit(const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const int slot, const int b, const int t) {
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (D.status[b] >= 0 || D.skip[b] || !GB.outer[b]) return;
+  const double rho = GB.rho[b] * GP.vscale, idt = 1.0 / P.dt;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double v = (D.q[slot][IDX(t, N, k)] - D.q[slot][IDX(t - 1, N, k)]) * idt;
+    double* l_lo = GB.lamv + IDX(t, 2 * N, k);
+    double* l_up = GB.lamv + IDX(t, 2 * N, N + k);
+    *l_lo = fmax(0.0, *l_lo - rho * (v - GP.vlo[k]));
+    *l_up = fmax(0.0, *l_up - rho * (GP.vup[k] - v));
+  }
+}
+
+template <int N, bool VEL = false>
+OH_DEV void couple_unit(const FigParams& P, const FigBuffers& D, const int slot, const int b, const int t, const GuardParams* GPp = nullptr,
+                        const GuardBuffers* GBp = nullptr) {
   constexpr int NZ = N - 3;
   const int Bp = D.Bp;
   if (b >= D.B) return;
@@ -323,7 +364,57 @@ OH_DEV void couple_unit(const FigParams& P, const FigBuffers& D, const int slot,
     }
   }
   double G[N], gt[NZ], E[NZ * NZ], merit;
+  double wn[N];  // Gauss-Newton weight of the velocity rows of interval (t, t+1)
+  if constexpr (VEL) {
+    // intervals (t-1, t) and (t, t+1): their augmented-Lagrangian gradient goes into g before the projection, the value of (t-1, t) is booked
+    // on knot t like kappa ||q_t - q_{t-1}||^2, the weights join 2 kappa in E_t and add Z_t^T diag(w_prev + w_next) Z_t to the diagonal block
+    const GuardParams& GP = *GPp;
+    const GuardBuffers& GB = *GBp;
+    const double rho = (GB.outer[b] ? GB.rho_next[b] : GB.rho[b]) * GP.vscale;
+    double lam[2 * N], sp[N], wp[N], sn[N], psi_p, meas_p, psi_n, meas_n;
+#pragma unroll
+    for (int i = 0; i < 2 * N; ++i) lam[i] = GB.lamv[IDX(t, 2 * N, i)];
+    velocity_rows<N>(GP, P.dt, rho, qm, q0, lam, sp, wp, psi_p, meas_p);
+    if (!last) {
+#pragma unroll
+      for (int i = 0; i < 2 * N; ++i) lam[i] = GB.lamv[IDX(t + 1, 2 * N, i)];
+      velocity_rows<N>(GP, P.dt, rho, q0, qp, lam, sn, wn, psi_n, meas_n);
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; ++k) sn[k] = wn[k] = 0.0;
+    }
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      g[k] += sp[k] - sn[k];
+      any = any || wp[k] + wn[k] > 0.0;
+    }
+    if (any) {
+#pragma unroll
+      for (int a = 0; a < NZ; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) {
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) acc += (wp[k] + wn[k]) * Zt[k][a] * Zt[k][c2];
+          D.Dr[slot][IDX(t, NZ * (NZ + 1) / 2, tri(a, c2))] += acc;
+        }
+    }
+    D.phi[slot][(size_t)t * Bp + b] += psi_p;  // couple_knot folds phi into the merit
+    GB.psi[slot][(size_t)t * Bp + b] += psi_p;
+    GB.mcv[slot][(size_t)t * Bp + b] = fmax(GB.mcv[slot][(size_t)t * Bp + b], meas_p);
+  }
   couple_knot<N>(P.kappa, last, qm, q0, qp, g, Zt, Zn, D.phi[slot][(size_t)t * Bp + b], G, gt, E, merit);
+  if constexpr (VEL) {
+    if (!last) {
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int a = 0; a < NZ; ++a)
+#pragma unroll
+          for (int c2 = 0; c2 < NZ; ++c2) E[a * NZ + c2] -= wn[k] * Zt[k][a] * Zn[k][c2];
+    }
+  }
   if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) {
 #pragma unroll
     for (int k = 0; k < N; ++k) D.Gfull[slot][IDX(t, N, k)] = G[k];

@@ -284,6 +284,9 @@ __global__ __launch_bounds__(64) void k_setup_guards(FigParams P, FigBuffers D, 
   for (int i = 0; i < npar; ++i) GB.par[(size_t)i * Bp + b] = pin[(size_t)b * P.np + N + i];
   for (int t = 0; t < P.T; ++t)
     for (int i = 0; i < GP.NC; ++i) GB.lam[((size_t)t * GP.NC + i) * Bp + b] = 0.0;
+  if (GP.vel)
+    for (int t = 0; t < P.T; ++t)
+      for (int i = 0; i < 2 * N; ++i) GB.lamv[((size_t)t * 2 * N + i) * Bp + b] = 0.0;
   GB.rho[b] = GP.rho0;
   GB.rho_next[b] = GP.rho0;
   GB.omega[b] = fmax(P.tol, 1e-2);

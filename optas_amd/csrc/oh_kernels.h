@@ -39,6 +39,9 @@ struct GuardParams {
   double link_off[OH_MAX_SPHERE_LINKS][3];
   double lo[OH_MAX_CHAIN], up[OH_MAX_CHAIN];
   double rho0;
+  int vel;                                  // joint-velocity rows present (orientation-locked family)
+  double vlo[OH_MAX_CHAIN], vup[OH_MAX_CHAIN];
+  double vscale;                            // their penalty is rho * vscale (dt^2 / 40: Gauss-Newton weight w_path / 4 at rho0 = 10 w_path)
 };
 struct GuardBuffers {
   double* lam;        // [T][NC][Bp]  multipliers of the last outer update
@@ -52,6 +55,7 @@ struct GuardBuffers {
   int* n_outer;       // [Bp]
   double* mcv[2];     // [slot][T][Bp] per-knot |min(g, lam/rho)|_inf (orientation-locked family; D.cv holds the orientation residual there)
   double* meas;       // [Bp] its maximum over the knots of the accepted point
+  double* lamv;       // [T][2N][Bp] multipliers of the velocity rows; row block t = interval (t-1, t) = dq_{t-1}: [dq - vlo (N); vup - dq (N)]
 };
 
 // Device buffers of one handle (SoA, instance index fastest; Bp = B rounded up to 64).
@@ -115,6 +119,7 @@ bool oh_launch_carry(hipStream_t s, int n, const FigParams& P, const FigBuffers&
 bool oh_eval_is_split();
 bool oh_launch_eval_lead(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_launch_couple_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
 bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_eval_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);

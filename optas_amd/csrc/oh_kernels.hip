@@ -169,6 +169,20 @@ __global__ __launch_bounds__(256) void k_couple(FigParams P, FigBuffers D, const
   const int bx = chunk * 8 + (r & 7);
   couple_unit<N>(P, D, slot, bx * blockDim.x + threadIdx.x, (r >> 3) + P.t0);
 }
+// the same with joint-velocity rows (oh_guards.vel_limits), and the multiplier refresh of those rows that precedes it at an outer update
+template <int N>
+__global__ __launch_bounds__(256) void k_couple_vel(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *D.n_running = 0;
+  const int Tn = P.T - P.t0;
+  const int w = blockIdx.x;
+  const int chunk = w / (8 * Tn), r = w - chunk * 8 * Tn;
+  const int bx = chunk * 8 + (r & 7);
+  couple_unit<N, true>(P, D, slot, bx * blockDim.x + threadIdx.x, (r >> 3) + P.t0, &GP, &GB);
+}
+template <int N>
+__global__ __launch_bounds__(256) void k_vel_update(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
+  vel_update_unit<N>(P, D, GP, GB, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+}
 template <int N>
 __global__ __launch_bounds__(256) void k_eval_lg(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
   eval_unit<N, true>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0, &GP, &GB);
@@ -890,6 +904,18 @@ bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers
 #define C(NN) launch_couple_t<NN>(s, P, D, slot)
   OH_DISPATCH_N(n, C)
 #undef C
+  return true;
+}
+bool oh_launch_couple_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
+  const int Tn = P.T - P.t0;
+  const dim3 gu((D.B + 255) / 256, Tn), gc((unsigned)(((D.B + 255) / 256 + 7) / 8 * 8 * Tn)), b(256);
+  if (n == 7) {
+    hipLaunchKernelGGL(k_vel_update<7>, gu, b, 0, s, P, D, GP, GB, slot);
+    hipLaunchKernelGGL(k_couple_vel<7>, gc, b, 0, s, P, D, GP, GB, slot);
+  } else if (n == 6) {
+    hipLaunchKernelGGL(k_vel_update<6>, gu, b, 0, s, P, D, GP, GB, slot);
+    hipLaunchKernelGGL(k_couple_vel<6>, gc, b, 0, s, P, D, GP, GB, slot);
+  } else return false;
   return true;
 }
 bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {

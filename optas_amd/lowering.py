@@ -42,6 +42,8 @@ class FigureEightSpec:
     lo: Optional[np.ndarray] = None  # joint limits (enforce_model_limits), None: no such rows
     up: Optional[np.ndarray] = None
     spheres: Optional["GuardSpec"] = None  # sphere clearances (sphere_collision_avoidance_constraints)
+    vlo: Optional[np.ndarray] = None  # joint-velocity limits (enforce_model_limits(time_deriv=1)), None: no such rows
+    vup: Optional[np.ndarray] = None
     lead: Optional[dict] = None  # one parameterised joint ahead of the chain (param_joints): {"par", "opt", "qp", "dqp"}
 
 
@@ -112,17 +114,21 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
             if lr != lrad[ln] or orr != orad[on]:
                 no("inconsistent radius parameters in the sphere rows")
         spheres = GuardSpec(None, None, links, [lrad[ln] for ln in links], [(on, orad[on]) for on in obst])
-    lo = up = None
+    lo = up = vlo = vup = None
     n = robot.ndof
     for label, d in opt.lin_ineq_constraints.items():
         if isinstance(d, Sub) and d.a is Q and isinstance(d.b, Const) and d.b.value.shape == (n, 1):
             lo = d.b.value[:, 0] if lo is None else np.maximum(lo, d.b.value[:, 0])
         elif isinstance(d, Sub) and d.b is Q and isinstance(d.a, Const) and d.a.value.shape == (n, 1):
             up = d.a.value[:, 0] if up is None else np.minimum(up, d.a.value[:, 0])
+        elif isinstance(d, Sub) and d.a is dQ and isinstance(d.b, Const) and d.b.value.shape == (n, 1):
+            vlo = d.b.value[:, 0] if vlo is None else np.maximum(vlo, d.b.value[:, 0])
+        elif isinstance(d, Sub) and d.b is dQ and isinstance(d.a, Const) and d.a.value.shape == (n, 1):
+            vup = d.a.value[:, 0] if vup is None else np.minimum(vup, d.a.value[:, 0])
         else:
-            no(f"linear inequality '{label}' is not a joint-position bound over the whole trajectory")
-    if (lo is None) != (up is None):
-        no("joint limits need both the lower and the upper row block")
+            no(f"linear inequality '{label}' is not a joint-position or joint-velocity bound over the whole trajectory")
+    if (lo is None) != (up is None) or (vlo is None) != (vup is None):
+        no("limits need both the lower and the upper row block")
 
     # linear equalities: fix q_0 = qc, fix dq_0 = 0, Euler integration
     qc: Optional[ParamRef] = None
@@ -156,7 +162,7 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
     expect = [qc.name]
     if lead is not None:
         expect = [lead["qp"], lead["dqp"], qc.name]
-        if spheres is not None or lo is not None:
+        if spheres is not None or lo is not None or vlo is not None:
             no("inequality rows together with a parameterised joint are not lowered")
     if spheres is not None:
         expect += list(spheres.link_radii) + [x for ob in spheres.obstacles for x in ob]
@@ -211,7 +217,7 @@ def match_figure_eight(opt: Optimization) -> FigureEightSpec:
             no(f"cost '{label}' not recognised")
     if w_path is None or w_vel is None:
         no("need both the path-tracking and the joint-velocity cost terms")
-    return FigureEightSpec(robot, link, T, dt, w_path, w_vel, np.ascontiguousarray(local.T), qc.name, q_name, dq_name, lo, up, spheres, lead)
+    return FigureEightSpec(robot, link, T, dt, w_path, w_vel, np.ascontiguousarray(local.T), qc.name, q_name, dq_name, lo, up, spheres, vlo, vup, lead)
 
 
 @dataclass

@@ -218,8 +218,12 @@ def figure_eight_backend(spec: FigureEightSpec, o: dict, hessian: int) -> Figure
     optas_amd.casadi_tape); consumes its options from ``o``."""
     chain = spec.robot.solver_chain(spec.link)
     guards = None
-    if spec.lo is not None or spec.spheres is not None:
+    if spec.lo is not None or spec.spheres is not None or spec.vlo is not None:
         guards = _lib.oh_guards()
+    if spec.vlo is not None:
+        guards.vel_limits = 1
+        for j in range(spec.robot.ndof):
+            guards.dq_lo[j], guards.dq_up[j] = float(spec.vlo[j]), float(spec.vup[j])
     if spec.lo is not None:
         guards.limits = 1
         for j in range(spec.robot.ndof):

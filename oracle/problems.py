@@ -574,20 +574,34 @@ class LimitedFigureEightNLP(FigureEightNLP):
     """example/figure_eight_plan.py plus builder.enforce_model_limits(kuka_name) with limits (lo, up) (builder.py:471-509):
     k = [vec(Q - lo); vec(up - Q)] (rows "_l", "_r"), everything else as FigureEightNLP."""
 
-    def __init__(self, robot, link, lo, up, **kw):
+    def __init__(self, robot, link, lo=None, up=None, vlo=None, vup=None, **kw):
+        """lo/up: joint-position limits (None: no such rows); vlo/vup: joint-velocity limits, enforce_model_limits(name, time_deriv=1) added after
+        the position limits: k = [vec(Q - lo); vec(up - Q); vec(dQ - vlo); vec(vup - dQ)]."""
         super().__init__(robot, link, **kw)
-        self.lo, self.up = np.asarray(lo, dtype=float), np.asarray(up, dtype=float)
-        self.nk = 2 * self.n * self.T
+        f = lambda v: None if v is None else np.asarray(v, dtype=float)
+        self.lo, self.up, self.vlo, self.vup = f(lo), f(up), f(vlo), f(vup)
+        self.nk = (2 * self.n * self.T if self.lo is not None else 0) + (2 * self.n * (self.T - 1) if self.vlo is not None else 0)
 
     def k(self, x, p):
-        Q, _ = self.split(x)
-        return np.concatenate([(Q - self.lo[:, None]).T.reshape(-1), (self.up[:, None] - Q).T.reshape(-1)])
+        Q, dQ = self.split(x)
+        parts = []
+        if self.lo is not None:
+            parts += [(Q - self.lo[:, None]).T.reshape(-1), (self.up[:, None] - Q).T.reshape(-1)]
+        if self.vlo is not None:
+            parts += [(dQ - self.vlo[:, None]).T.reshape(-1), (self.vup[:, None] - dQ).T.reshape(-1)]
+        return np.concatenate(parts)
 
     def dk(self, x, p):
-        nq = self.n * self.T
+        nq, ndq = self.n * self.T, self.n * (self.T - 1)
         M = np.zeros((self.nk, self.nx))
-        M[:nq, :nq] = np.eye(nq)
-        M[nq:, :nq] = -np.eye(nq)
+        r = 0
+        if self.lo is not None:
+            M[:nq, :nq] = np.eye(nq)
+            M[nq : 2 * nq, :nq] = -np.eye(nq)
+            r = 2 * nq
+        if self.vlo is not None:
+            M[r : r + ndq, nq:] = np.eye(ndq)
+            M[r + ndq : r + 2 * ndq, nq:] = -np.eye(ndq)
         return M
 
 

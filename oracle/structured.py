@@ -320,27 +320,60 @@ def retract(prob, Q, Rc, tol=1e-10, max_corr=4, e_tgt=None):
     return Q
 
 
-def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False, hessian="hybrid", limits=None, rho0=None, guards=None, overrelax=1.5, overrelax_from=4):
+def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False, hessian="hybrid", limits=None, rho0=None, guards=None, overrelax=1.5, overrelax_from=4, vlimits=None):
     """Returns dict(Q, f, iters (= steps solved: accepted + rejected), rejected, stat, feas, status).
     limits = (lo, up) or guards = oracle.guarded.Guards (joint limits and/or sphere clearances): inequality rows at the free
     knots through the augmented Lagrangian of oracle/guarded.py (k_eval_lg / k_step_lg); adds "lam" (T, NC), "meas", "outers".
+    vlimits = (vlo, vup): joint-velocity rows dq_t - vlo >= 0, vup - dq_t >= 0 (enforce_model_limits(time_deriv=1), builder.py:471-509) on
+    dq_t = (q_{t+1} - q_t) / dt; they couple neighbouring knots exactly like the velocity cost: in the Gauss-Newton model row j of interval
+    (t, t+1) adds rho/dt^2 to the weight 2 kappa of (q_{t+1,j} - q_{t,j})^2 while it is active (k_couple_lg); adds "lam_v" (T-1, 2n).
     hessian: "gauss_newton" | "exact" | "hybrid" (Gauss-Newton until the reduced gradient of the accepted point is below
     1e-5 * w_path, exact curvature afterwards: OH_HESSIAN_HYBRID); exact=True is shorthand for "exact"."""
     if exact:
         hessian = "exact"
     hyb_switch = 1e-5 * prob.w_path
     stat_prev = np.inf
-    guard = limits is not None or guards is not None
+    guard = limits is not None or guards is not None or vlimits is not None
+    vel = vlimits is not None
     if guard:
         from .guarded import Guards, guard_values
 
         if guards is None:
-            guards = Guards(lo=np.asarray(limits[0], dtype=float), up=np.asarray(limits[1], dtype=float))
+            guards = Guards() if limits is None else Guards(lo=np.asarray(limits[0], dtype=float), up=np.asarray(limits[1], dtype=float))
         lam_g = np.zeros((prob.T, guards.n_rows(prob.n)))
+        if vel:
+            vlo, vup = (np.asarray(v, dtype=float) for v in vlimits)
+            lam_v = np.zeros((prob.T - 1, 2 * prob.n))  # row i: interval (i, i+1) = dq_i; [dq - vlo (n); vup - dq (n)]
+            # The velocity rows get the penalty rho * vscale: their Gauss-Newton weight on (q_{t+1} - q_t)^2 is rho vscale / dt^2, and with the
+            # rows' own rho (10 w_path, chosen for the position rows) that is 2.4e5 against a tracking curvature of ~5e2 -- the merit becomes a
+            # stiff piecewise quadratic and two thirds of the steps are rejected (459 steps on the nominal instance).  vscale = dt^2 / 40 puts the
+            # weight at w_path / 4 (19 steps); the outer loop scales both penalties together.
+            vscale = prob.dt**2 / 40.0
         rho_g = rho_next = (10.0 * prob.w_path) if rho0 is None else rho0
         omega, meas_prev, outer, outers = max(tol, 1e-2), np.inf, False, 0
 
+    def vel_terms(Q, lam_v, rho_g):
+        """Velocity rows of every interval: (values (T-1, 2n), psi per interval, sigma = d L_A / d v (T-1, n), Gauss-Newton weights
+        rho (a- + a+) / dt^2 (T-1, n), measure).  Interval (0, 1) is constant (q_0 = q_1 = qc) and left out."""
+        dtv = prob.dt
+        v = (Q[1:] - Q[:-1]) / dtv
+        gv = np.concatenate([v - vlo[None], vup[None] - v], 1)
+        rho_g = rho_g * vscale
+        sv = np.maximum(0.0, lam_v - rho_g * gv)
+        sv[0] = 0.0
+        psi = (sv * sv - lam_v * lam_v) / (2.0 * rho_g)
+        psi[0] = 0.0
+        nn = Q.shape[1]
+        sig = (sv[:, nn:] - sv[:, :nn]) / dtv  # d psi / d v : lower row -s_lo, upper row +s_up
+        wv = rho_g * ((sv[:, :nn] > 0.0).astype(float) + (sv[:, nn:] > 0.0).astype(float)) / dtv**2
+        meas = np.abs(np.minimum(gv, lam_v / rho_g))
+        meas[0] = 0.0
+        return gv, psi.sum(1), sig, wv, float(meas.max())
+
     def guard_terms(Q, lam_g, rho_g):
+        if guards.n_rows(prob.n) == 0:
+            Tn = Q.shape[0]
+            return np.zeros((Tn, 0)), np.zeros(Tn), np.zeros_like(Q), np.zeros((Tn, Q.shape[1], Q.shape[1])), 0.0
         gv, dg = guard_values(prob.chain, Q, guards)  # (T, NC), (T, NC, n)
         sv = np.maximum(0.0, lam_g - rho_g * gv)
         sv[:2] = 0.0
@@ -375,12 +408,25 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         phi, g, W, c, Jc = prob.evaluate(Qt, path, Rc, lam=lam, exact=use_exact)
         if guard:
             if outer:  # multiplier refresh at the accepted point with the old penalty, evaluation with the new one
-                gv_now, _ = guard_values(prob.chain, Qt, guards)
-                lam_g = np.maximum(0.0, lam_g - rho_g * gv_now)
-                lam_g[:2] = 0.0
+                if guards.n_rows(n):
+                    gv_now, _ = guard_values(prob.chain, Qt, guards)
+                    lam_g = np.maximum(0.0, lam_g - rho_g * gv_now)
+                    lam_g[:2] = 0.0
+                if vel:
+                    lam_v = np.maximum(0.0, lam_v - rho_g * vscale * vel_terms(Qt, lam_v, rho_g)[0])
+                    lam_v[0] = 0.0
                 rho_g = rho_next
                 outers += 1
             gv, psi_t, dgrad, dW, meas_t = guard_terms(Qt, lam_g, rho_g)
+            wv_t = np.zeros((T - 1, n))
+            if vel:
+                _, psi_v, sig, wv_t, meas_v = vel_terms(Qt, lam_v, rho_g)
+                psi_t = psi_t.copy()
+                psi_t[1:] += psi_v  # interval (t-1, t) is booked on knot t, like kappa ||q_t - q_{t-1}||^2
+                dgrad = dgrad.copy()
+                dgrad[1:] += sig
+                dgrad[:-1] -= sig
+                meas_t = max(meas_t, meas_v)
             phi = phi + psi_t
             g = g + dgrad
             W = W + dW
@@ -449,11 +495,17 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
             ndiag = np.full(T, 2.0)
             ndiag[T - 1] = 1.0
             Dfull = W + (2 * kap * ndiag)[:, None, None] * np.eye(n)[None]
+            wnext = np.zeros((T, n))  # Gauss-Newton weight of the velocity rows of interval (t, t+1), zero without them
+            if guard and vel:
+                wnext[:-1] = wv_t
+                wsum = wnext.copy()
+                wsum[1:] += wv_t
+                Dfull = Dfull + np.einsum("tj,jk->tjk", wsum, np.eye(n))
             cur = {
                 "Q": Qt, "f": f_t, "feas": feas_t, "Z": Zs, "meas": meas_t if guard else 0.0, "fpsi": float(np.sum(psi_t)) if guard else 0.0,
                 "gt": np.einsum("tij,ti->tj", Zs[F], G[F]),
                 "Dr": np.einsum("tia,tij,tjb->tab", Zs[F], Dfull[F], Zs[F]),
-                "Er": -2 * kap * np.einsum("tia,tib->tab", Zs[2 : T - 1], Zs[3:T]),
+                "Er": -np.einsum("tia,ti,tib->tab", Zs[2 : T - 1], 2 * kap + wnext[2 : T - 1], Zs[3:T]),
             }
             e_acc, _, Jp_acc, _ = prob.chain.jac(Qt)
             cur["e"], cur["JZ"] = e_acc, np.einsum("tmi,tia->tma", Jp_acc[F], Zs[F])
@@ -507,10 +559,15 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         iters += 1
     out = {"Q": cur["Q"], "f": cur["f"] - cur["fpsi"], "iters": iters, "rejected": rejected, "stat": stat, "feas": cur["feas"], "status": status, "path": path, "Rc": Rc}
     if guard:
-        gv, _ = guard_values(prob.chain, cur["Q"], guards)
+        gv = guard_terms(cur["Q"], lam_g, rho_g)[0]
         lam_out = np.maximum(0.0, lam_g - rho_g * gv)
         lam_out[:2] = 0.0
         out.update(lam=lam_out, lam_stored=lam_g, meas=cur["meas"], outers=outers, g=gv)
+        if vel:
+            gvv = vel_terms(cur["Q"], lam_v, rho_g)[0]
+            lv = np.maximum(0.0, lam_v - rho_g * vscale * gvv)
+            lv[0] = 0.0
+            out.update(lam_v=lv, g_v=gvv)
     return out
 
 

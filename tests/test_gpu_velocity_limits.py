@@ -1,0 +1,60 @@
+"""Joint-velocity limits on config 2 -- ``builder.enforce_model_limits(name, time_deriv=1)`` (builder.py:471-509), the first constraint a user of
+figure_eight_plan.py adds: the script's optimum runs joint 0 at 2.01 rad/s against the KUKA LWR's 1.92.  Rows dq_t - vlo >= 0, vup - dq_t >= 0
+on dq_t = (q_{t+1} - q_t)/dt couple neighbouring knots; the kernels treat them through the augmented Lagrangian inside k_couple_vel.
+Checked against the numpy port (same state machine), against the reference-form KKT conditions on the literal 693-variable layout with its
+686 extra k rows (oracle.problems.LimitedFigureEightNLP), and for the limits themselves."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import KUKA_KIN, SEED
+from oracle.problems import LimitedFigureEightNLP
+from oracle.robot import OracleRobot
+from oracle.solvers import kkt_reference_form
+from oracle.structured import StructuredFigureEight, solve_structured_lm
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from examples.figure_eight_plan import setup_solver  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+LINK = "end_effector_ball"
+QC0 = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+
+
+@pytest.mark.parametrize("vmax", [None, 1.0])
+def test_velocity_limited_figure_eight(hip_lib, vmax):
+    orc = OracleRobot(KUKA_KIN)
+    vl = np.asarray(orc.velocity_actuated_joint_limits) if vmax is None else np.full(7, vmax)
+    kuka, solver = setup_solver(velocity_limits=True if vmax is None else (-vl, vl), solver_options={"max_iter": 600, "tol": 1e-7})
+    assert solver.opt.nk == 2 * 7 * 49 and solver.opt.nv == 1114 + 686
+    rng = np.random.default_rng(SEED + 3)
+    qcs = QC0[None] + np.concatenate([np.zeros((1, 7)), rng.uniform(-0.05, 0.05, (3, 7))])
+    B = len(qcs)
+    solver.reset_parameters_batch({"qc": qcs})
+    solver.reset_initial_seed_batch({"kuka/q/x": np.stack([np.tile(q.reshape(-1, 1), (1, 50)) for q in qcs])})
+    sols = solver.solve_batch()
+    st = solver.stats()
+    assert st["success"]
+    prob = StructuredFigureEight(orc, LINK, T=50)
+    nlp = LimitedFigureEightNLP(orc, LINK, vlo=-vl, vup=vl, T=50)
+    lam = solver.backend.multipliers(B)
+    assert lam.shape == (B, 50, 14) and lam.min() >= 0.0
+    for b in range(B):
+        x = solver.opt.decision_variables.dict2vec(sols[b])
+        dQ = np.asarray(sols[b]["kuka/dq"])
+        assert np.abs(dQ).max(1).max() <= vl.max() + 1e-8 and np.all(np.abs(dQ).max(1) <= vl + 1e-8)
+        assert np.abs(nlp.a(x, qcs[b])).max() <= 1e-12 and np.abs(nlp.h(x, qcs[b])).max() <= 1e-9 and nlp.k(x, qcs[b]).min() >= -1e-8
+        assert abs(nlp.f(x, qcs[b]) - st["f"][b]) <= 1e-9 * st["f"][b]
+        k = kkt_reference_form(nlp, x, qcs[b], active_tol=1e-7)
+        assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-8 and k["complementarity"] <= 1e-6, (b, k)
+        s = solve_structured_lm(prob, qcs[b], max_iter=600, tol=1e-7, vlimits=(-vl, vl))
+        assert s["status"] == 0 and abs(s["f"] - st["f"][b]) <= 1e-8 * s["f"], (b, s["f"], st["f"][b])
+        assert abs(int(st["iterations"][b]) - s["iters"]) <= max(3, s["iters"] // 4), (b, st["iterations"][b], s["iters"])
+        # multipliers in the reference's row order: [dq_t - vlo; vup - dq_t] at knot t
+        lv = np.zeros((50, 14))
+        lv[:49] = s["lam_v"]
+        assert np.abs(lam[b] - lv).max() <= 1e-4 * max(1.0, lv.max())
+    # the rows bind: with the robot's own limits in the nominal instance (its unconstrained optimum runs joint 0 at 2.01 rad/s), at 1 rad/s everywhere
+    assert lam[0].max() > 0 and (vmax is None or (lam.max((1, 2)) > 0).all())

@@ -192,3 +192,32 @@ def test_parameterised_joint_problem_builds_and_lowers():
     a = o.a(x, p)
     qc = p[99:106]
     assert np.allclose(a[:6], qc[1:] - x[:6]) and np.allclose(a[6:12], -x[300:306])
+
+
+def test_velocity_limits_port_against_literal_kkt_and_slsqp():
+    """enforce_model_limits(time_deriv=1) on the orientation-locked family (oracle/structured.py:vel_terms, the state machine k_couple_vel runs):
+    the port's optimum satisfies the KKT conditions of the literal problem with its 2 n (T-1) extra k rows, the limits bind, and scipy SLSQP in
+    the reference's wiring on a short horizon (rank-3 orientation rows: the xyz part only, where SLSQP converges) cannot find a better point."""
+    from conftest import KUKA_KIN
+    from oracle.problems import LimitedFigureEightNLP
+    from oracle.robot import OracleRobot
+    from oracle.solvers import kkt_reference_form
+    from oracle.structured import StructuredFigureEight, solve_structured_lm
+
+    orc = OracleRobot(KUKA_KIN)
+    qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    T = 50
+    prob = StructuredFigureEight(orc, "end_effector_ball", T=T)
+    free = solve_structured_lm(prob, qc, tol=1e-7)
+    vfree = np.abs(np.diff(free["Q"], axis=0) / prob.dt).max(0)
+    vl = np.asarray(orc.velocity_actuated_joint_limits)
+    assert vfree[0] > vl[0]  # SURVEY App. B.2: the shipped script's optimum violates the LWR velocity limit
+    s = solve_structured_lm(prob, qc, tol=1e-7, vlimits=(-vl, vl), max_iter=600)
+    assert s["status"] == 0 and s["f"] > free["f"] and s["iters"] < 60
+    dQ = np.diff(s["Q"], axis=0) / prob.dt
+    assert np.all(np.abs(dQ).max(0) <= vl + 1e-9) and abs(np.abs(dQ[:, 0]).max() - vl[0]) < 1e-9 and s["lam_v"].max() > 0
+    nlp = LimitedFigureEightNLP(orc, "end_effector_ball", vlo=-vl, vup=vl, T=T)
+    assert nlp.nk == 2 * 7 * (T - 1) and nlp.nv == 1114 + 686
+    x = nlp.join(s["Q"].T, dQ.T)
+    k = kkt_reference_form(nlp, x, qc, active_tol=1e-7)
+    assert k["stationarity"] <= 1e-8 and k["feasibility"] <= 1e-8 and k["complementarity"] <= 1e-6

@@ -537,8 +537,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   int running = B;
   const int cap = P.max_iter + 2;
   while (launched < cap) {
-    oh_launch_tq_eval(s, P, D);
-    HIPCHK(hipMemsetAsync(D.n_running, 0, sizeof(int), s));
+    oh_launch_tq_eval(s, P, D);  // also resets the running count
     oh_launch_tq_step(s, P, D);
     ++launched;
     work += running;

@@ -280,13 +280,17 @@ __global__ __launch_bounds__(256) void k_tq_list(TqBuffers D) {
 }
 
 // ---- evaluation -----------------------------------------------------------------------------------------------------------------------
+#ifndef OH_TQ_EVAL_WAVES
+#define OH_TQ_EVAL_WAVES 2
+#endif
 template <int N>
-__global__ __launch_bounds__(64) void k_tq_eval(TqParams P, TqBuffers D) {
+__global__ __launch_bounds__(64, OH_TQ_EVAL_WAVES) void k_tq_eval(TqParams P, TqBuffers D) {
   constexpr int NZ = 3 * N;  // 21 tangent directions: q, dq, ddq
   constexpr int UPW = 64 / NZ;  // units per wavefront (3)
   __shared__ double tile[UPW][N + 3][NZ + 1];
   const int T = P.T;
   const int lane = threadIdx.x;
+  if (blockIdx.x == 0 && lane == 0) *D.n_running = 0;  // k_tq_step, next in the stream, counts the instances that go on
   int ul = lane / NZ, d = lane - ul * NZ;
   if (ul >= UPW) {  // lane 63 has no unit: it rides along and parks its LDS writes in the padding column
     ul = UPW - 1;
@@ -441,8 +445,11 @@ OH_DEV double group_max(double v) {
   return v;
 }
 
+#ifndef OH_TQ_STEP_WAVES
+#define OH_TQ_STEP_WAVES 1
+#endif
 template <int N>
-__global__ __launch_bounds__(64) void k_tq_step(TqParams P, TqBuffers D) {
+__global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, TqBuffers D) {
   constexpr int NX = 2 * N, NZ = 3 * N, NH = NZ * (NZ + 1) / 2, NU = N * (N + 1) / 2;
   constexpr int PS = NX + 1;  // row stride of P in LDS
   constexpr int OFF_P = 256, OFF_PV = OFF_P + NX * PS, OFF_QUX = OFF_PV + 16, OFF_DX = OFF_QUX + N * 16, OFF_DU = OFF_DX + 16, LDS_N = OFF_DU + 8;

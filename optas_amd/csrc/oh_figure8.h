@@ -156,13 +156,20 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
   double cmax;
   double Rb[9], pb[3];  // frame after the parameterised lead joint (LEAD only)
   if constexpr (LEAD) lead_base(ch, lead_theta, Rb, pb);
+  // settled: the Newton step just taken was so short that the violation it leaves is below the tolerance without looking.  A step dq
+  // removes c to first order; what remains is the second-order term, bounded by ||dq||_1^2 (the second derivatives of the rows are
+  // cross products of unit joint axes).  The kinematics pass that would only confirm it is skipped: by the batched retraction
+  // kernel altogether (k_evalb evaluates the point anyway and reports the violation it finds), by the fused variants in that they
+  // go on to the evaluation without a further correction - the accepted q is the same in both.
+  bool settled = false;
   for (int it = 0;; ++it) {
     fk_chain<N, LEAD>(ch, q, R, p, z, pj, Rb, pb);
     mm3(R, ch->R_tool, Re);
     orient_residual(Re, Rc, c, M);
     cmax = fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2])));
-    if (MODE == EVAL_ONLY || cmax <= tol_r || it >= P.max_retract) break;
+    if (MODE == EVAL_ONLY || settled || cmax <= tol_r || it >= P.max_retract) break;
     if constexpr (MODE != EVAL_ONLY) {
+    double dq1 = 0.0;  // ||dq||_1 of this correction
     // Newton correction q <- q - Jc^T (Jc Jc^T)^{-1} c,  Jc = M Jw,  Jw[:,k] = z_k (revolute) / 0
     double Jc[N][3];
 #pragma unroll
@@ -214,6 +221,7 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc += col[i] * y6[i];
         q[k] -= acc;
+        dq1 += fabs(acc);
       }
     } else {
       double S[6] = {1e-14, 0, 1e-14, 0, 0, 1e-14};
@@ -232,8 +240,17 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
       fsub_rcp<3>(S, rd3, y);
       bsub_rcp<3>(S, rd3, y);
 #pragma unroll
-      for (int k = 0; k < N; ++k) q[k] -= dot3(Jc[k], y);
+      for (int k = 0; k < N; ++k) {
+        const double acc = dot3(Jc[k], y);
+        q[k] -= acc;
+        dq1 += fabs(acc);
+      }
     }
+#ifndef OH_SETTLE_K
+#define OH_SETTLE_K 1.0
+#endif
+    settled = OH_SETTLE_K * dq1 * dq1 <= tol_r;
+    if (MODE == EVAL_RETRACT_ONLY && settled) break;
     }
   }
   cv = cmax;

@@ -29,6 +29,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# code objects of the run-time specialised kernels (oh_specialize): kept inside the tree, so a cache filled by __graft_entry__.build() travels
+os.environ.setdefault("OPTAS_HIP_CACHE", os.path.join(ROOT, ".optas_hip_cache"))
 
 import optas_amd  # noqa: E402
 from optas_amd import _lib  # noqa: E402
@@ -279,7 +281,8 @@ def main():
         lat[nb] = float(np.median(ms[1:]))
         its_nb = d_it.download(np.int32, (B,))[:nb]
         lat[f"iters_{nb}"] = float(its_nb.mean())
-    occupancy = {k: _lib.kernel_info(k) for k in ("k_retract", "k_evalb", "k_couple", "k_step", "k_tail", "k_fk_jac")}
+    occupancy = {k: be.kernel_info(k) for k in ("k_retract", "k_evalb", "k_couple", "k_step", "k_tail", "k_fk_jac")}
+    spec_info = be.specialize_info()
 
     if rank != 0:
         if comm is not None:
@@ -378,6 +381,7 @@ def main():
             "f_mean": float(fvals.mean()),
         },
         "device_ms_per_step": solve_ms_plain / args.steps,
+        "specialized_kernels": {**spec_info, "note": "k_retract / k_evalb / k_tail compiled with hiprtc behind a constexpr copy of the handle's kinematic chain (oh_specialize; automatic at the first solve of >= 4096 instances, before the timed region)"},
         "latency_b1_ms": lat[1],
         "latency_b1024_ms": lat[1024],
         "latency_note": f"whole solve on the device, inputs resident, median of 7: B=1 ({lat['iters_1']:.0f} iterations), B=1024 (mean {lat['iters_1024']:.1f} iterations)",

@@ -227,6 +227,10 @@ SYMBOLS = [
     "oh_event_timer_start",
     "oh_event_timer_stop",
     "oh_kernel_info",
+    "oh_kernel_info_handle",
+    "oh_specialize",
+    "oh_specialize_compile",
+    "oh_specialize_info",
     "oh_last_error",
     "oh_version",
     "oh_destroy",
@@ -311,6 +315,13 @@ def kernel_info(name: str) -> dict:
     v, sc, lds, blk, nb = list(out)
     return {"registers_per_lane": v, "scratch_bytes_per_lane": sc, "lds_bytes_per_block": lds, "block": blk, "blocks_per_cu": nb,
             "waves_per_simd": nb * blk / 64.0 / 4.0}
+
+
+def specialize_compile(chain) -> dict:
+    """hiprtc compilation of the figure-eight evaluation kernels for one chain into the disk cache (oh_specialize_compile; no device needed)."""
+    info = (C.c_double * 2)()
+    check(load().oh_specialize_compile(C.byref(chain), info), "oh_specialize_compile")
+    return {"seconds": info[0], "from_disk_cache": bool(info[1])}
 
 
 def _ptr(a: Optional[np.ndarray]):

@@ -368,6 +368,24 @@ class FigureEightBackend:
         _lib.check(_lib.load().oh_get_multipliers(self._h, int(B), _lib._ptr(lam)), "oh_get_multipliers")
         return lam
 
+    def specialize(self) -> dict:
+        """Compile (or fetch from the cache) and load the evaluation kernels specialised for this handle's chain (oh_specialize); the
+        library does it by itself at the first solve of >= 4096 instances."""
+        _lib.check(_lib.load().oh_specialize(self._h), "oh_specialize")
+        return self.specialize_info()
+
+    def specialize_info(self) -> dict:
+        info = (C.c_double * 3)()
+        _lib.check(_lib.load().oh_specialize_info(self._h, info), "oh_specialize_info")
+        return {"loaded": bool(info[0]), "seconds": info[1], "from_disk_cache": bool(info[2])}
+
+    def kernel_info(self, name: str) -> dict:
+        """Code-object facts of the kernel this handle launches under that name (the specialised one once loaded)."""
+        out = (C.c_int * 5)()
+        _lib.check(_lib.load().oh_kernel_info_handle(self._h, name.encode(), out), "oh_kernel_info_handle")
+        v, sc, lds, blk, nb = list(out)
+        return {"registers_per_lane": v, "scratch_bytes_per_lane": sc, "lds_bytes_per_block": lds, "block": blk, "blocks_per_cu": nb, "waves_per_simd": nb * blk / 64.0 / 4.0}
+
     def set_profiling(self, on: bool) -> None:
         _lib.check(_lib.load().oh_set_profiling(self._h, 1 if on else 0), "oh_set_profiling")
 

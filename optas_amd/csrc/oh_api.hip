@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // types only: the library is opened with dlopen when a communicator is first asked for
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@
 #include <vector>
 
 #include "oh_kernels.h"
+#include "oh_jit.h"
 
 static thread_local std::string g_err;
 
@@ -100,10 +102,17 @@ struct oh_handle {
   int compact_sort = 1;      // order the survivors of a compaction by progress (k_scan_*)
   double compact_frac = 0.9;  // compact the batch once this fraction of it (or less) is still running
   int tail_threshold = 2048;  // hand the last instances to the persistent one-wave-per-instance kernel
+  // run-time specialised evaluation kernels of the orientation-locked figure-eight family (oh_jit.hip)
+  int specialize = OH_SPECIALIZE_AUTO;  // OH_SPECIALIZE env: 0 never, 1 at the first solve, auto: at the first solve of >= specialize_min_B instances
+  int specialize_min_B = 4096;
+  const FigSpec* spec = nullptr;
+  bool spec_failed = false;
   std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
 };
 
 extern "C" void oh_destroy(oh_handle* h);
+extern "C" int oh_specialize(oh_handle* h);
+static bool spec_applies(const oh_handle* h);
 extern "C" const char* oh_last_error(void) { return g_err.c_str(); }
 extern "C" const char* oh_version(void) { return "optas_hip 0.1 (gfx950)"; }
 
@@ -191,6 +200,7 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (const char* e4 = getenv("OH_COMPACT_FRAC")) h->compact_frac = atof(e4);
   if (const char* e5 = getenv("OH_COMPACT_SORT")) h->compact_sort = atoi(e5);
   if (const char* e6 = getenv("OH_COMPACT_CARRY")) h->compact_carry = atoi(e6);
+  if (const char* e7 = getenv("OH_SPECIALIZE")) h->specialize = (!strcmp(e7, "auto")) ? OH_SPECIALIZE_AUTO : (atoi(e7) != 0 ? OH_SPECIALIZE_ALWAYS : OH_SPECIALIZE_NEVER);
   hipGetDevice(&h->device);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
       hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->evt0) != hipSuccess ||
@@ -676,6 +686,8 @@ extern "C" int oh_set_constants(oh_handle* h, const oh_chain* chain) {
   int rc = validate_chain(h, *chain);
   if (rc) return rc;
   h->chain_host = *chain;
+  h->spec = nullptr;  // kernels compiled for the previous chain
+  h->spec_failed = false;
   HIPCHK(hipMemcpy(h->d_chain, chain, sizeof(oh_chain), hipMemcpyHostToDevice));
   h->have_chain = true;
   return OH_OK;
@@ -689,6 +701,8 @@ extern "C" int oh_set_constants_device(oh_handle* h, const void* d_chain, size_t
   int rc = validate_chain(h, tmp);
   if (rc) return rc;
   h->chain_host = tmp;
+  h->spec = nullptr;
+  h->spec_failed = false;
   HIPCHK(hipMemcpy(h->d_chain, d_chain, sizeof(oh_chain), hipMemcpyDeviceToDevice));
   h->have_chain = true;
   return OH_OK;
@@ -930,6 +944,9 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   int rc = ensure_capacity(h, B);
   if (rc) return rc;
   fill_params(h);
+  if (spec_applies(h) && !h->spec && !h->spec_failed &&
+      (h->specialize == OH_SPECIALIZE_ALWAYS || (h->specialize == OH_SPECIALIZE_AUTO && B >= h->specialize_min_B)))
+    oh_specialize(h);  // on failure the generic kernels run; oh_last_error keeps the reason, oh_specialize_info says which ran
   const bool guarded = h->have_guards;
   const bool lead = h->chain_host.has_lead != 0;
   if (lead && (guarded || !h->desc.lock_orientation || h->desc.ndof != 6))
@@ -973,9 +990,19 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   // restarts the survivors.
   const int hard_cap = 2 * h->desc.max_iter + 2 + 40 + 64;  // a rejected step costs two launches, a compaction one
   const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation && !guarded && !lead;
+  const FigSpec* const spec = spec_applies(h) ? h->spec : nullptr;
+  // evaluation / tail launches: the kernels compiled for this handle's chain when they are loaded, the generic ones otherwise
+  auto launch_eval = [&](int slot, int part) {
+    if (spec) return oh_spec_launch_eval(*spec, s, h->P, h->D, slot, part) == hipSuccess;
+    return oh_launch_eval(s, N, h->P, h->D, slot, part);
+  };
+  auto launch_tail = [&](int slot) {
+    if (spec) return oh_spec_launch_tail(*spec, s, h->P, h->D, slot) == hipSuccess;
+    return oh_launch_tail(s, N, h->P, h->D, slot);
+  };
   bool tail_done = false;
   if (tail_ok && B <= h->tail_threshold) {  // small batch: the whole solve is one persistent launch
-    oh_launch_tail(s, N, h->P, h->D, 0);
+    launch_tail(0);
     tail_done = true;
   }
   bool rebase = false;
@@ -991,7 +1018,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     else if (lead) oh_launch_eval_lead(s, N, h->P, h->D, slot);
     else if (h->P.lock && carry_pending > 0) {
       // compaction with the trial carried along: retract on the old layout, move, evaluate on the dense one (k_carry_* in oh_kernels.hip)
-      oh_launch_eval(s, N, h->P, h->D, slot, 1);
+      launch_eval(slot, 1);
       if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(4); }
       oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
       oh_launch_scan_running(s, h->D, h->compact_sort);
@@ -1001,8 +1028,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       carry_pending = 0;
       ++compactions;
       if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(0); }
-      oh_launch_eval(s, N, h->P, h->D, slot, 2);
-    } else if (h->P.lock) oh_launch_eval(s, N, h->P, h->D, slot);
+      launch_eval(slot, 2);
+    } else if (h->P.lock) launch_eval(slot, 0);
     else if (guarded) oh_launch_eval_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else oh_launch_eval_free(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(1); }
@@ -1032,7 +1059,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
         oh_launch_compact(s, N, h->P, h->D, 1, nrun, (it + 1) & 1);
         h->D.B = nrun;
         ++compactions;
-        oh_launch_tail(s, N, h->P, h->D, (it + 1) & 1);
+        launch_tail((it + 1) & 1);
         tail_done = true;
         break;
       }
@@ -1538,6 +1565,56 @@ extern "C" int oh_get_constants(oh_handle* h, oh_chain* out) {
   if (!h->have_chain) return fail(OH_ERR_STATE, "oh_get_constants: no constants set");
   *out = h->chain_host;
   return OH_OK;
+}
+
+static bool spec_applies(const oh_handle* h) {
+  return h->desc.kind == OH_PROBLEM_FIGURE_EIGHT && h->have_chain && h->desc.lock_orientation && !h->have_guards && !h->chain_host.has_lead && oh_eval_is_split();
+}
+extern "C" int oh_specialize(oh_handle* h) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_specialize: null handle");
+  if (!spec_applies(h)) return fail(OH_ERR_INVALID, "oh_specialize: only the orientation-locked figure-eight family without guards or a lead joint has specialised kernels");
+  if (h->spec) return OH_OK;
+  HIPCHK(hipSetDevice(h->device));
+  std::string err;
+  const FigSpec* sp = nullptr;
+  if (oh_jit_figure8(h->chain_host, h->desc.ndof, &sp, &err)) {
+    h->spec_failed = true;
+    return fail(OH_ERR_HIP, "oh_specialize: " + err);
+  }
+  h->spec = sp;
+  return OH_OK;
+}
+extern "C" int oh_specialize_compile(const oh_chain* chain, double* info2) {
+  if (!chain) return fail(OH_ERR_INVALID, "oh_specialize_compile: null chain");
+  if (chain->ndof < 4 || chain->ndof > OH_MAX_CHAIN || chain->n_chain != chain->ndof || chain->has_lead)
+    return fail(OH_ERR_INVALID, "oh_specialize_compile: the chain must cover every model joint in order (4..16 joints, no lead joint)");
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<char> code;
+  bool from_disk = false;
+  std::string err;
+  if (oh_jit_figure8_compile(oh_jit_figure8_source(*chain, chain->ndof), &code, &from_disk, &err)) return fail(OH_ERR_HIP, "oh_specialize_compile: " + err);
+  if (info2) {
+    info2[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    info2[1] = from_disk ? 1.0 : 0.0;
+  }
+  return OH_OK;
+}
+extern "C" int oh_specialize_info(oh_handle* h, double* info3) {
+  if (!h || !info3) return fail(OH_ERR_INVALID, "oh_specialize_info: null argument");
+  info3[0] = h->spec ? 1.0 : 0.0;
+  info3[1] = h->spec ? h->spec->seconds : 0.0;
+  info3[2] = (h->spec && h->spec->from_disk) ? 1.0 : 0.0;
+  return OH_OK;
+}
+extern "C" int oh_kernel_info(const char* kernel, int* out5);
+extern "C" int oh_kernel_info_handle(oh_handle* h, const char* kernel, int* out5) {
+  if (!h || !kernel || !out5) return fail(OH_ERR_INVALID, "oh_kernel_info_handle: null argument");
+  OhKernelInfo k{};
+  if (h->spec && oh_spec_kernel_info(*h->spec, kernel, &k)) {
+    out5[0] = k.vgprs; out5[1] = k.scratch_bytes; out5[2] = k.lds_bytes; out5[3] = k.block; out5[4] = k.blocks_per_cu;
+    return OH_OK;
+  }
+  return oh_kernel_info(kernel, out5);
 }
 
 extern "C" int oh_kernel_info(const char* kernel, int* out5) {

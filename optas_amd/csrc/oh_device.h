@@ -5,7 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "../../include/optas_hip.h"
+#include "optas_hip.h"
 
 // Function qualifiers and the reciprocal square root of the Cholesky pivots: the two things a translation unit may set before including
 // this header (oracle/cpu_port builds the same device functions for the host cores with its own definitions; the product never does).

@@ -4,7 +4,7 @@
 // arithmetically identical operation by operation.
 #pragma once
 #include "oh_device.h"
-#include "oh_kernels.h"
+#include "oh_types.h"
 
 // Orientation residual c = vee(skew(Re Rc^T)) and M = 1/2 (tr(A) I - A) with dc = M domega.
 OH_DEV void orient_residual(const double* Re, const double* Rc, double* c, double* M) {

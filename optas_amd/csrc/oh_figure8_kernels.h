@@ -1,0 +1,341 @@
+// Block-level bodies of the figure-eight kernels that read the kinematic chain in their inner loops: the two halves of the trial-knot
+// evaluation and the persistent tail kernel.  oh_kernels.hip wraps them in __global__ kernels that fetch the chain through the handle's
+// device pointer; oh_jit.hip compiles the same text with hiprtc behind a constexpr copy of one handle's chain (OH_CHAIN, see
+// oh_figure8_units.h).  Device-only: blockIdx / threadIdx / LDS.
+#pragma once
+#include "oh_figure8_units.h"
+
+// The same knot in two launches, each at two waves per SIMD (see EVAL_RETRACT_ONLY / EVAL_ONLY in oh_figure8.h): the first leaves the
+// retracted trial knot in the slot, the second evaluates it.  Grid: (instance block, knot), instance block fastest.
+template <int N>
+__device__ void retract_block(const FigParams& P, const FigBuffers& D, const int slot) {
+  eval_unit<N, false, false, EVAL_RETRACT_ONLY>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+}
+template <int N>
+__device__ void evalb_block(const FigParams& P, const FigBuffers& D, const int slot) {
+  eval_unit<N, false, false, EVAL_ONLY>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 (tail / small batches): ONE WAVEFRONT PER INSTANCE, one lane per free knot (T-2 <= 64), the whole
+// remaining SQP loop in a single launch with every stage quantity in registers: no HBM traffic per
+// iteration, no launch or host round trip per iteration.  Knot-parallel work (eval_knot, couple_knot) runs
+// on all lanes; neighbour data moves with wave shuffles; the Riccati recursion broadcasts knot l's blocks
+// with v_readlane and is computed redundantly (wave-uniformly) by all lanes.  Same device functions and
+// the same operation order as k_eval/k_couple/k_step.  Entered at a restart point (first == 1): the
+// accepted knots are in D.q[slot].
+// ---------------------------------------------------------------------------------------------
+OH_DEV double bcast(const double v, const int lane) {  // lane must be wave-uniform
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+template <int N>
+__device__ void tail_block(const FigParams& P, const FigBuffers& D, const int slot) {
+  constexpr int NZ = N - 3;
+  constexpr int NP = NZ * (NZ + 1) / 2;
+  // Stage data of the accepted point and the blocks the cyclic reduction exchanges live in LDS, one column per lane (= knot): [row][lane], conflict-free for the
+  // lane's own column, one broadcast read for another knot's value in the serial sweeps (instead of a v_readlane pair per double).  In
+  // registers they cost 190 VGPRs next to the ~350 of the fused evaluation: 512 + 256 registers with 241 spilled to scratch in round 1.
+  constexpr int O_DR = 0, O_E = O_DR + NP, O_GT = O_E + NZ * NZ, O_G = O_GT + NZ, O_GF = O_G + N, O_EC = O_GF + N, O_JZ = O_EC + 3, O_PCR = O_JZ + 3 * NZ,
+                ROWS = O_PCR + (2 * NZ + 1) * NZ;
+  __shared__ double sm[ROWS][64];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (D.status[b] >= 0) return;
+  const int T = P.T;
+  const int nK = T - P.t0;  // free knots, lanes 0..nK-1
+  const int t = lane + P.t0;
+  const bool active = lane < nK;
+  const int tl = active ? t : T - 1;  // clamp addresses of idle lanes
+  const bool last = (t == T - 1);
+  const double kap2 = 2.0 * P.kappa;
+  const oh_chain* ch = OH_CHAIN(D);
+
+  double qt[N], qfix[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    qt[j] = D.q[slot][IDX(tl, N, j)];
+    qfix[j] = D.q[slot][IDX(P.t0 - 1, N, j)];
+  }
+  double Rc[9], pc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pc[i] = D.ref[(size_t)i * Bp + b];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
+  const double fconst = D.fconst[b];
+  LMState lm{D.mu[b], D.nun[b]};
+  int iters = D.iters[b];
+  bool first = true, polish = false;
+  int status = -1;
+  unsigned long long n_launch_equiv = 0, n_reject = 0;
+
+  // accepted point (per lane = per knot)
+  double q_c[N], Z_c[N][NZ];
+  double e_tgt[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) sm[i][lane] = 0.0;
+  double f_cur = 0.0, feas_cur = 0.0, pred = 0.0, stat = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) q_c[k] = qt[k];
+  struct TailHooks {  // the Lagrangian gradient of the accepted point is fetched from LDS only inside the exact-curvature branch
+    const double (*acc)[64];
+    int lane;
+    OH_DEV void q_final(const double (&)[N]) const {}
+    OH_DEV void g_final(const double (&)[N]) const {}
+    OH_DEV void v_final(const double (&)[3][N]) const {}
+    OH_DEV void load_G(const double (&)[N], double (&G)[N]) const {
+#pragma unroll
+      for (int k = 0; k < N; ++k) G[k] = acc[O_GF + k][lane];
+    }
+  };
+  const TailHooks hooks{sm, lane};
+  const double Gdummy[N] = {};
+
+  for (;;) {
+    ++n_launch_equiv;
+    // ---- evaluate the trial knots (k_eval) -----------------------------------------------------------------
+    double phi = 0.0, cv = 0.0, g[N], Dr[NP], Z[N][NZ];
+    const bool exact = (P.hessian == OH_HESSIAN_EXACT) || (P.hessian == OH_HESSIAN_HYBRID && !first && stat <= P.hyb_switch);
+    const bool have_G = exact && !first;
+    double e_new[3] = {0.0, 0.0, 0.0}, JZ_new[3][NZ];
+    if (active)
+      eval_knot<N, false, TailHooks>(ch, P, t, qt, pc, Rc, exact, have_G, Gdummy, phi, cv, g, Dr, Z, !first, e_tgt, retract_tol(P, !first, pred, stat), e_new,
+                                     JZ_new, 0.0, hooks);
+    // ---- neighbour coupling (k_couple) -----------------------------------------------------------------------
+    double qm[N], qp[N], Zn[N][NZ];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const double up = __shfl_up(qt[k], 1);
+      qm[k] = (lane == 0) ? qfix[k] : up;
+      qp[k] = __shfl_down(qt[k], 1);
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) Zn[k][a] = __shfl_down(Z[k][a], 1);
+    }
+    double G[N], gt[NZ], E[NZ * NZ], merit = 0.0;
+    if (active) couple_knot<N>(P.kappa, last, qm, qt, qp, g, Z, Zn, phi, G, gt, E, merit);
+    // ---- phase A: merit in knot order, ratio test (wave-uniform) ---------------------------------------------
+    double f = fconst, feas = 0.0;
+    for (int l = 0; l < nK; ++l) {
+      f += bcast(merit, l);
+      feas = fmax(feas, bcast(cv, l));
+    }
+    bool accept;
+    if (first) {
+      if (!(f == f) || !(fabs(f) < 1e300)) {  // non-finite seed / parameters
+        status = OH_STATUS_NUMERICAL;
+        f_cur = f;
+        stat = f;
+        break;
+      }
+      accept = true;
+      first = false;
+    } else if (polish) {
+      accept = true;
+      polish = false;
+    } else {
+      const LMState lm_before = lm;
+      accept = lm_accept(P, f, feas, f_cur, pred, stat, lm);
+      if (!accept) ++n_reject;
+      if (!accept && feas_cur > 10.0 * P.tol_retract) {  // see step_instance: re-retract the accepted point before blaming the model
+        lm = lm_before;
+        polish = true;
+        pred = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) qt[j] = q_c[j];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) e_tgt[m] = sm[O_EC + m][lane];
+        ++iters;
+        if (iters >= P.max_iter + 40) { status = OH_STATUS_MAX_ITER; break; }
+        continue;
+      }
+    }
+    if (accept) {
+      f_cur = f;
+      feas_cur = feas;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        q_c[k] = qt[k];
+        sm[O_G + k][lane] = g[k];
+        sm[O_GF + k][lane] = G[k];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) Z_c[k][a] = Z[k][a];
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) sm[O_DR + i][lane] = Dr[i];
+#pragma unroll
+      for (int i = 0; i < NZ * NZ; ++i) sm[O_E + i][lane] = E[i];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) sm[O_GT + a][lane] = gt[a];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        sm[O_EC + m][lane] = e_new[m];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) sm[O_JZ + m * NZ + a][lane] = JZ_new[m][a];
+      }
+    }
+    double mu = lm.mu;
+    // ---- phase B: the reduced block-tridiagonal system  D_l z_l + E_l z_{l+1} + E_{l-1}^T z_{l-1} = -gt_l  by block PARALLEL CYCLIC
+    // REDUCTION across the lanes (lane = knot): at stride s every equation eliminates its neighbours l -+ s using their own rows,
+    //   A_l <- A_l - L_l A_{l-s}^{-1} U_{l-s} - U_l A_{l+s}^{-1} L_{l+s},  L_l <- -L_l A_{l-s}^{-1} L_{l-s},  U_l <- -U_l A_{l+s}^{-1} U_{l+s},
+    //   r_l <- r_l - L_l A_{l-s}^{-1} r_{l-s} - U_l A_{l+s}^{-1} r_{l+s},
+    // and after ceil(log2 nK) strides z_l = A_l^{-1} r_l.  Six dependent NZ x NZ factorisations per lane instead of the nK - 1 = 47 of the
+    // serial Riccati sweep the batched k_step runs (the diagonal blocks stay Schur complements of a positive definite matrix, so the
+    // plain Cholesky is stable; a failed pivot on any lane raises the damping for the whole instance as before).  Neighbour blocks
+    // travel through LDS.
+    stat = 0.0;
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) stat = fmax(stat, fabs(sm[O_GT + a][lane]));
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) stat = fmax(stat, __shfl_xor(stat, m));
+    double zmine[NZ];
+    for (int attempt = 0; attempt < 40; ++attempt) {
+      double A[NZ * NZ], Lw[NZ * NZ], U[NZ * NZ], r[NZ];
+#pragma unroll
+      for (int i = 0; i < NZ; ++i)
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) {
+          const int hi = i > j ? i : j, lo = i > j ? j : i;
+          A[i * NZ + j] = active ? sm[O_DR + tri(hi, lo)][lane] + (i == j ? ((last ? kap2 : 2.0 * kap2) + mu) : 0.0) : (i == j ? 1.0 : 0.0);
+          U[i * NZ + j] = (active && !last) ? sm[O_E + i * NZ + j][lane] : 0.0;
+          Lw[i * NZ + j] = (active && lane > 0) ? sm[O_E + j * NZ + i][lane - 1] : 0.0;
+        }
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) r[a] = active ? -sm[O_GT + a][lane] : 0.0;
+      bool ok = true;
+      double Lc[NP], rd[NZ];
+      for (int sft = 1; sft < nK; sft <<= 1) {
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) Lc[tri(i, j)] = A[i * NZ + j];
+        ok = chol_rcp<NZ>(Lc, rd, 1e-12) && ok;
+        // Y = A^{-1} [Lw | U | r], column by column, parked in LDS for the neighbours
+#pragma unroll
+        for (int c2 = 0; c2 < 2 * NZ + 1; ++c2) {
+          double col[NZ];
+#pragma unroll
+          for (int i = 0; i < NZ; ++i) col[i] = c2 < NZ ? Lw[i * NZ + c2] : (c2 < 2 * NZ ? U[i * NZ + (c2 - NZ)] : r[i]);
+          fsub_rcp<NZ>(Lc, rd, col);
+          bsub_rcp<NZ>(Lc, rd, col);
+#pragma unroll
+          for (int i = 0; i < NZ; ++i) sm[O_PCR + c2 * NZ + i][lane] = col[i];
+        }
+        __syncthreads();
+        const int lm_ = lane - sft, lp_ = lane + sft;
+        const bool hm = lm_ >= 0, hp = lp_ < 64;
+        const int im = hm ? lm_ : lane, ip = hp ? lp_ : lane;
+        double An[NZ * NZ], Ln[NZ * NZ], Un[NZ * NZ], rn2[NZ];
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) {
+          double racc = r[i];
+#pragma unroll
+          for (int j = 0; j < NZ; ++j) {
+            double aacc = A[i * NZ + j], lacc = 0.0, uacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < NZ; ++k) {
+              // column j of Y^U / Y^L of the neighbours: rows (NZ + j) * NZ + k and j * NZ + k of the parked block
+              aacc -= Lw[i * NZ + k] * sm[O_PCR + (NZ + j) * NZ + k][im] + U[i * NZ + k] * sm[O_PCR + j * NZ + k][ip];
+              lacc -= Lw[i * NZ + k] * sm[O_PCR + j * NZ + k][im];
+              uacc -= U[i * NZ + k] * sm[O_PCR + (NZ + j) * NZ + k][ip];
+            }
+            An[i * NZ + j] = aacc;
+            Ln[i * NZ + j] = lacc;
+            Un[i * NZ + j] = uacc;
+          }
+#pragma unroll
+          for (int k = 0; k < NZ; ++k) racc -= Lw[i * NZ + k] * sm[O_PCR + 2 * NZ * NZ + k][im] + U[i * NZ + k] * sm[O_PCR + 2 * NZ * NZ + k][ip];
+          rn2[i] = racc;
+        }
+        __syncthreads();
+        // Lw / U of a lane without that neighbour are zero, so the clamped reads above contributed nothing
+#pragma unroll
+        for (int i = 0; i < NZ * NZ; ++i) {
+          A[i] = An[i];
+          Lw[i] = hm ? Ln[i] : 0.0;
+          U[i] = hp ? Un[i] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) r[i] = rn2[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NZ; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Lc[tri(i, j)] = 0.5 * (A[i * NZ + j] + A[j * NZ + i]);
+      ok = chol_rcp<NZ>(Lc, rd, 1e-12) && ok;
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) zmine[a] = r[a];
+      fsub_rcp<NZ>(Lc, rd, zmine);
+      bsub_rcp<NZ>(Lc, rd, zmine);
+      if (__all(ok || !active)) break;
+      mu = fmax(4.0 * mu, 1e-2);
+    }
+    lm.mu = mu;
+    if (stat <= P.tol && feas_cur <= P.tol_feas) { status = OH_STATUS_CONVERGED; break; }
+    if (iters >= P.max_iter) { status = OH_STATUS_MAX_ITER; break; }
+    if (!(stat == stat)) { status = OH_STATUS_NUMERICAL; break; }
+    {
+      double gd = 0.0, z2 = 0.0;
+      if (active) {
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+          gd += sm[O_GT + a][lane] * zmine[a];
+          z2 += zmine[a] * zmine[a];
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        gd += __shfl_xor(gd, m);
+        z2 += __shfl_xor(z2, m);
+      }
+      const double alpha = (P.hessian == OH_HESSIAN_HYBRID && stat > P.hyb_switch && iters >= P.relax_from) ? P.relax : 1.0;  // see step_instance
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) zmine[a] *= alpha;
+      pred = -alpha * gd + 0.5 * alpha * alpha * (gd + mu * z2);
+    }
+    // next trial knots: q_cur + Z_cur z
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double v = q_c[j];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) v += Z_c[j][a] * zmine[a];
+      qt[j] = v;
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      double v = sm[O_EC + m][lane];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) v += sm[O_JZ + m * NZ + a][lane] * zmine[a];
+      e_tgt[m] = v;
+    }
+    ++iters;
+  }
+
+  // ---- hand the result to k_finalize ---------------------------------------------------------------------------
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      D.q[slot][IDX(t, N, j)] = q_c[j];
+      D.g[slot][IDX(t, N, j)] = sm[O_G + j][lane];
+    }
+  }
+  if (lane == 0) {
+    D.cur[b] = slot;
+    D.f_cur[b] = f_cur;
+    D.feas[b] = feas_cur;
+    D.stat[b] = stat;
+    D.mu[b] = lm.mu;
+    D.nun[b] = lm.nun;
+    D.iters[b] = iters;
+    D.first[b] = 0;
+    D.status[b] = status;
+    atomicAdd(D.work + 2, n_launch_equiv);  // tail iterations are accounted separately from the batched launches
+    if (n_reject) atomicAdd(D.work + 1, n_reject);
+  }
+}

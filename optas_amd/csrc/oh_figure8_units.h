@@ -81,6 +81,12 @@ OH_DEV void setup_unit(const FigParams& P, const FigBuffers& D, const double* __
   D.feas[b] = 0.0;
 }
 
+// Where the evaluation reads the kinematic constants.  The kernels specialised at run time (oh_jit.hip) define this as the address of a
+// constexpr copy of the handle's chain, so that every ch->... below folds into the instruction stream: no scalar loads to wait for, no
+// branches on the joint hints, no multiplications by the zeros and ones of a URDF.
+#ifndef OH_CHAIN
+#define OH_CHAIN(D) ((D).chain)
+#endif
 // Householder vectors of knot t from their packed stage array ([t][3N - 3][Bp], written by eval_unit)
 template <int N>
 OH_DEV void load_householder(const double* __restrict__ Vs, const int Bp, const int b, const int t, double (&V)[3][N]) {
@@ -186,9 +192,9 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   double e_new[3], JZ_new[3][NZ];
   const double tol_r = retract_tol(P, !first, D.pred[b], D.stat[b]);
   if constexpr (LEAD)
-    eval_knot<N, true, Hooks, MODE>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new,
+    eval_knot<N, true, Hooks, MODE>(OH_CHAIN(D), P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new,
                                     D.lead[(size_t)t * Bp + b], hooks);
-  else eval_knot<N, false, Hooks, MODE>(D.chain, P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new, 0.0, hooks);
+  else eval_knot<N, false, Hooks, MODE>(OH_CHAIN(D), P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new, 0.0, hooks);
   if constexpr (MODE == EVAL_RETRACT_ONLY) return;  // q is in the slot; everything else is k_evalb's
 #pragma unroll
   for (int m = 0; m < 3; ++m) {

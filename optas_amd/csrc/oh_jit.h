@@ -1,0 +1,22 @@
+// Run-time specialised figure-eight kernels (oh_jit.hip): one hiprtc module per kinematic chain, shared by the handles that use it.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "oh_kernels.h"
+
+struct FigSpec {
+  hipModule_t mod = nullptr;
+  hipFunction_t retract = nullptr, evalb = nullptr, tail = nullptr;
+  int n = 0;               // chain length the kernels were instantiated for
+  bool from_disk = false;  // code object came from the disk cache
+  double seconds = 0.0;    // wall time of source generation + compilation (or cache read) + module load
+};
+std::string oh_jit_figure8_source(const oh_chain& chain, int N);
+// hiprtc for gfx950 (needs no device); goes through the disk cache
+int oh_jit_figure8_compile(const std::string& src, std::vector<char>* code, bool* from_disk, std::string* err);
+// compile (or find) and load the kernels for this chain; *out stays owned by the process-wide cache
+int oh_jit_figure8(const oh_chain& chain, int N, const FigSpec** out, std::string* err);
+hipError_t oh_spec_launch_eval(const FigSpec& sp, hipStream_t s, const FigParams& P, const FigBuffers& D, int slot, int part);
+hipError_t oh_spec_launch_tail(const FigSpec& sp, hipStream_t s, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_spec_kernel_info(const FigSpec& sp, const char* name, OhKernelInfo* out);

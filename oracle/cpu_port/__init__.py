@@ -16,14 +16,14 @@ _LIB = None
 
 def build(force: bool = False) -> str:
     csrc = os.path.join(HERE, "..", "..", "optas_amd", "csrc")
-    deps = [SRC] + [os.path.join(csrc, f) for f in ("oh_figure8_units.h", "oh_figure8.h", "oh_device.h", "oh_kernels.h")]
+    deps = [SRC] + [os.path.join(csrc, f) for f in ("oh_figure8_units.h", "oh_figure8.h", "oh_device.h", "oh_types.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -mfma/-mavx2: fma() must map to the hardware instruction on the host as it does on the device (x86-64-v3: any EPYC)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Xarch_host", "-mfma", "-Xarch_host", "-mavx2", "-shared", "-fPIC",
-           "-o", OUT, SRC, "-lpthread"]
+           "-I", os.path.join(HERE, "..", "..", "include"), "-I", csrc, "-o", OUT, SRC, "-lpthread"]
     subprocess.run(cmd, check=True)
     return OUT
 

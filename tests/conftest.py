@@ -8,6 +8,9 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# code objects of the run-time specialised kernels (oh_specialize) stay inside the tree
+os.environ.setdefault("OPTAS_HIP_CACHE", os.path.join(ROOT, ".optas_hip_cache"))
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 KUKA_KIN = os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json")
 MED7_KIN = os.path.join(ROOT, "optas_amd", "robots", "med7.kin.json")

@@ -388,22 +388,23 @@ int oh_fk_jac_soa_device(oh_handle* h, int N, const void* d_q, void* d_pose, voi
 int oh_set_profiling(oh_handle* h, int enable);
 int oh_get_timing(oh_handle* h, double* out11);
 
-/* Run-time specialisation (OH_PROBLEM_FIGURE_EIGHT with lock_orientation, no lead joint, no guards).  The reference's own speed comes
-   from code generated for one problem: CasADi turns the robot model into a straight-line SX program with the URDF constants folded in
-   (models.py:826-868 builds the chain walk symbolically, solver.py:333-398 hands the resulting functions to the back-end).  The
-   equivalent here: the evaluation kernels k_retract / k_evalb / k_tail are compiled once more with hiprtc behind a constexpr copy of
-   this handle's oh_chain.  oh_specialize compiles (or fetches from the process / disk cache: $OPTAS_HIP_CACHE, default
-   ~/.cache/optas_hip, empty = none) and loads them now; without the call the library does it by itself at the first solve of >= 4096
-   instances (env OH_SPECIALIZE=0: never, =1: at the first solve of any size).  Until then, and if compilation is unavailable (then
+/* Run-time specialisation.  The reference's own speed comes from code generated for one problem: CasADi turns the robot model into a
+   straight-line SX program with the URDF constants folded in (models.py:826-868 builds the chain walk symbolically, solver.py:333-398
+   hands the resulting functions to the back-end).  The equivalent here: the kernels that walk the chain in their inner loops are
+   compiled once more with hiprtc behind a constexpr copy of this handle's oh_chain -- K1 (oh_fk_jac*) for every handle with constants,
+   and the evaluation kernels k_retract / k_evalb / k_tail of OH_PROBLEM_FIGURE_EIGHT with lock_orientation (no lead joint, no guards).
+   oh_specialize compiles (or fetches from the process / disk cache: $OPTAS_HIP_CACHE, default ~/.cache/optas_hip, empty = none) and
+   loads them now; without the call the library does it by itself at the first solve of >= 4096 instances / the first oh_fk_jac* of
+   >= 65536 units (env OH_SPECIALIZE=0: never, =1: at the first call of any size).  Until then, and if compilation is unavailable (then
    oh_specialize returns OH_ERR_HIP and oh_last_error says why), the generic kernels run: same text, same results up to the rounding
-   of folded constants.  info3: [0] 1 if the specialised kernels are loaded, [1] seconds the last oh_specialize of this handle took,
-   [2] 1 if the code object came from the disk cache. */
+   of folded constants.  info4: [0] 1 if the specialised solver kernels are loaded, [1] 1 if the specialised K1 is, [2] seconds the last
+   oh_specialize of this handle took, [3] 1 if the code object came from the disk cache. */
 enum { OH_SPECIALIZE_NEVER = 0, OH_SPECIALIZE_ALWAYS = 1, OH_SPECIALIZE_AUTO = 2 };
 int oh_specialize(oh_handle* h);
 /* Compilation only (hiprtc needs no device): fills the disk cache for a chain ahead of time, e.g. in a build step.  info2: [0] seconds,
    [1] 1 if the code object was already in the cache. */
 int oh_specialize_compile(const oh_chain* chain, double* info2);
-int oh_specialize_info(oh_handle* h, double* info3);
+int oh_specialize_info(oh_handle* h, double* info4);
 /* Code-object facts like oh_kernel_info, of the kernels this handle would launch (the specialised ones once loaded). */
 int oh_kernel_info_handle(oh_handle* h, const char* kernel, int* out5);
 

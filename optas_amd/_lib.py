@@ -282,6 +282,10 @@ def load() -> C.CDLL:
     lib.oh_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
     lib.oh_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
     lib.oh_device_synchronize.argtypes = []
+    lib.oh_specialize.argtypes = [vp]
+    lib.oh_specialize_info.argtypes = [vp, dp]
+    lib.oh_specialize_compile.argtypes = [C.POINTER(oh_chain), dp]
+    lib.oh_kernel_info_handle.argtypes = [vp, C.c_char_p, ip]
     lib.oh_event_timer_start.argtypes = [vp]
     lib.oh_event_timer_stop.argtypes = [vp, dp]
     lib.oh_last_error.restype = C.c_char_p

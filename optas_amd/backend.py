@@ -375,9 +375,9 @@ class FigureEightBackend:
         return self.specialize_info()
 
     def specialize_info(self) -> dict:
-        info = (C.c_double * 3)()
+        info = (C.c_double * 4)()
         _lib.check(_lib.load().oh_specialize_info(self._h, info), "oh_specialize_info")
-        return {"loaded": bool(info[0]), "seconds": info[1], "from_disk_cache": bool(info[2])}
+        return {"loaded": bool(info[0]), "fk_jac_loaded": bool(info[1]), "seconds": info[2], "from_disk_cache": bool(info[3])}
 
     def kernel_info(self, name: str) -> dict:
         """Code-object facts of the kernel this handle launches under that name (the specialised one once loaded)."""

@@ -30,6 +30,11 @@ static int fail(int code, const std::string& msg) {
     }                                                                                                  \
   } while (0)
 
+static int specialize_mode_from_env() {
+  const char* e = getenv("OH_SPECIALIZE");
+  if (!e || !strcmp(e, "auto")) return OH_SPECIALIZE_AUTO;
+  return atoi(e) != 0 ? OH_SPECIALIZE_ALWAYS : OH_SPECIALIZE_NEVER;
+}
 struct oh_handle {
   oh_problem_desc desc;
   std::vector<double> local_path;
@@ -103,16 +108,21 @@ struct oh_handle {
   double compact_frac = 0.9;  // compact the batch once this fraction of it (or less) is still running
   int tail_threshold = 2048;  // hand the last instances to the persistent one-wave-per-instance kernel
   // run-time specialised evaluation kernels of the orientation-locked figure-eight family (oh_jit.hip)
-  int specialize = OH_SPECIALIZE_AUTO;  // OH_SPECIALIZE env: 0 never, 1 at the first solve, auto: at the first solve of >= specialize_min_B instances
+  int specialize = specialize_mode_from_env();  // OH_SPECIALIZE env: 0 never, 1 at the first solve, auto: at the first solve of >= specialize_min_B instances
   int specialize_min_B = 4096;
   const FigSpec* spec = nullptr;
   bool spec_failed = false;
+  const FkSpec* fk_spec = nullptr;  // K1 for this chain (any handle with constants)
+  bool fk_spec_failed = false;
+  int specialize_min_units = 1 << 16;
+  double spec_seconds = 0.0;  // of the last oh_specialize
   std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
 };
 
 extern "C" void oh_destroy(oh_handle* h);
 extern "C" int oh_specialize(oh_handle* h);
 static bool spec_applies(const oh_handle* h);
+static int specialize_fk(oh_handle* h);
 extern "C" const char* oh_last_error(void) { return g_err.c_str(); }
 extern "C" const char* oh_version(void) { return "optas_hip 0.1 (gfx950)"; }
 
@@ -200,7 +210,6 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (const char* e4 = getenv("OH_COMPACT_FRAC")) h->compact_frac = atof(e4);
   if (const char* e5 = getenv("OH_COMPACT_SORT")) h->compact_sort = atoi(e5);
   if (const char* e6 = getenv("OH_COMPACT_CARRY")) h->compact_carry = atoi(e6);
-  if (const char* e7 = getenv("OH_SPECIALIZE")) h->specialize = (!strcmp(e7, "auto")) ? OH_SPECIALIZE_AUTO : (atoi(e7) != 0 ? OH_SPECIALIZE_ALWAYS : OH_SPECIALIZE_NEVER);
   hipGetDevice(&h->device);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
       hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->evt0) != hipSuccess ||
@@ -688,6 +697,8 @@ extern "C" int oh_set_constants(oh_handle* h, const oh_chain* chain) {
   h->chain_host = *chain;
   h->spec = nullptr;  // kernels compiled for the previous chain
   h->spec_failed = false;
+  h->fk_spec = nullptr;
+  h->fk_spec_failed = false;
   HIPCHK(hipMemcpy(h->d_chain, chain, sizeof(oh_chain), hipMemcpyHostToDevice));
   h->have_chain = true;
   return OH_OK;
@@ -703,6 +714,8 @@ extern "C" int oh_set_constants_device(oh_handle* h, const void* d_chain, size_t
   h->chain_host = tmp;
   h->spec = nullptr;
   h->spec_failed = false;
+  h->fk_spec = nullptr;
+  h->fk_spec_failed = false;
   HIPCHK(hipMemcpy(h->d_chain, d_chain, sizeof(oh_chain), hipMemcpyDeviceToDevice));
   h->have_chain = true;
   return OH_OK;
@@ -1337,7 +1350,10 @@ static int fk_common(oh_handle* h, int n, bool soa, const void* d_q, void* d_pos
   if (n < 1 || !d_q) return fail(OH_ERR_INVALID, "oh_fk_jac: bad arguments");
   if (!h->have_chain) return fail(OH_ERR_STATE, "oh_fk_jac: call oh_set_constants first");
   HIPCHK(hipSetDevice(h->device));
-  oh_launch_fk_jac(h->stream, soa, h->d_chain, h->chain_host.n_chain, n, (const double*)d_q, (double*)d_pose, (double*)d_J);
+  if (!h->fk_spec && !h->fk_spec_failed && (h->specialize == OH_SPECIALIZE_ALWAYS || (h->specialize == OH_SPECIALIZE_AUTO && n >= h->specialize_min_units)))
+    specialize_fk(h);  // on failure the generic kernel runs; oh_last_error keeps the reason
+  if (h->fk_spec) HIPCHK(oh_spec_launch_fk(*h->fk_spec, h->stream, soa, n, (const double*)d_q, (double*)d_pose, (double*)d_J));
+  else oh_launch_fk_jac(h->stream, soa, h->d_chain, h->chain_host.n_chain, n, (const double*)d_q, (double*)d_pose, (double*)d_J);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   return OH_OK;
@@ -1570,19 +1586,33 @@ extern "C" int oh_get_constants(oh_handle* h, oh_chain* out) {
 static bool spec_applies(const oh_handle* h) {
   return h->desc.kind == OH_PROBLEM_FIGURE_EIGHT && h->have_chain && h->desc.lock_orientation && !h->have_guards && !h->chain_host.has_lead && oh_eval_is_split();
 }
-extern "C" int oh_specialize(oh_handle* h) {
-  if (!h) return fail(OH_ERR_INVALID, "oh_specialize: null handle");
-  if (!spec_applies(h)) return fail(OH_ERR_INVALID, "oh_specialize: only the orientation-locked figure-eight family without guards or a lead joint has specialised kernels");
-  if (h->spec) return OH_OK;
-  HIPCHK(hipSetDevice(h->device));
+static int specialize_fk(oh_handle* h) {
+  if (h->fk_spec) return OH_OK;
   std::string err;
-  const FigSpec* sp = nullptr;
-  if (oh_jit_figure8(h->chain_host, h->desc.ndof, &sp, &err)) {
-    h->spec_failed = true;
+  const FkSpec* sp = nullptr;
+  if (oh_jit_fkjac(h->chain_host, &sp, &err)) {
+    h->fk_spec_failed = true;
     return fail(OH_ERR_HIP, "oh_specialize: " + err);
   }
-  h->spec = sp;
+  h->fk_spec = sp;
   return OH_OK;
+}
+extern "C" int oh_specialize(oh_handle* h) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_specialize: null handle");
+  if (!h->have_chain) return fail(OH_ERR_STATE, "oh_specialize: call oh_set_constants first");
+  HIPCHK(hipSetDevice(h->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = specialize_fk(h);  // K1: every handle with constants
+  if (rc == OH_OK && spec_applies(h) && !h->spec) {
+    std::string err;
+    const FigSpec* sp = nullptr;
+    if (oh_jit_figure8(h->chain_host, h->desc.ndof, &sp, &err)) {
+      h->spec_failed = true;
+      rc = fail(OH_ERR_HIP, "oh_specialize: " + err);
+    } else h->spec = sp;
+  }
+  h->spec_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
 }
 extern "C" int oh_specialize_compile(const oh_chain* chain, double* info2) {
   if (!chain) return fail(OH_ERR_INVALID, "oh_specialize_compile: null chain");
@@ -1592,25 +1622,29 @@ extern "C" int oh_specialize_compile(const oh_chain* chain, double* info2) {
   std::vector<char> code;
   bool from_disk = false;
   std::string err;
-  if (oh_jit_figure8_compile(oh_jit_figure8_source(*chain, chain->ndof), &code, &from_disk, &err)) return fail(OH_ERR_HIP, "oh_specialize_compile: " + err);
+  bool fd2 = false;
+  if (oh_jit_figure8_compile(oh_jit_figure8_source(*chain, chain->ndof), &code, &from_disk, &err) || oh_jit_figure8_compile(oh_jit_fkjac_source(*chain), &code, &fd2, &err))
+    return fail(OH_ERR_HIP, "oh_specialize_compile: " + err);
+  from_disk = from_disk && fd2;
   if (info2) {
     info2[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     info2[1] = from_disk ? 1.0 : 0.0;
   }
   return OH_OK;
 }
-extern "C" int oh_specialize_info(oh_handle* h, double* info3) {
-  if (!h || !info3) return fail(OH_ERR_INVALID, "oh_specialize_info: null argument");
-  info3[0] = h->spec ? 1.0 : 0.0;
-  info3[1] = h->spec ? h->spec->seconds : 0.0;
-  info3[2] = (h->spec && h->spec->from_disk) ? 1.0 : 0.0;
+extern "C" int oh_specialize_info(oh_handle* h, double* info4) {
+  if (!h || !info4) return fail(OH_ERR_INVALID, "oh_specialize_info: null argument");
+  info4[0] = h->spec ? 1.0 : 0.0;
+  info4[1] = h->fk_spec ? 1.0 : 0.0;
+  info4[2] = h->spec_seconds;
+  info4[3] = ((h->spec && h->spec->from_disk) || (!h->spec && h->fk_spec && h->fk_spec->from_disk)) ? 1.0 : 0.0;
   return OH_OK;
 }
 extern "C" int oh_kernel_info(const char* kernel, int* out5);
 extern "C" int oh_kernel_info_handle(oh_handle* h, const char* kernel, int* out5) {
   if (!h || !kernel || !out5) return fail(OH_ERR_INVALID, "oh_kernel_info_handle: null argument");
   OhKernelInfo k{};
-  if (h->spec && oh_spec_kernel_info(*h->spec, kernel, &k)) {
+  if ((h->spec && oh_spec_kernel_info(*h->spec, kernel, &k)) || (h->fk_spec && !strcmp(kernel, "k_fk_jac") && oh_spec_fk_kernel_info(*h->fk_spec, &k))) {
     out5[0] = k.vgprs; out5[1] = k.scratch_bytes; out5[2] = k.lds_bytes; out5[3] = k.block; out5[4] = k.blocks_per_cu;
     return OH_OK;
   }

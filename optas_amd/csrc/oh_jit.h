@@ -20,3 +20,15 @@ int oh_jit_figure8(const oh_chain& chain, int N, const FigSpec** out, std::strin
 hipError_t oh_spec_launch_eval(const FigSpec& sp, hipStream_t s, const FigParams& P, const FigBuffers& D, int slot, int part);
 hipError_t oh_spec_launch_tail(const FigSpec& sp, hipStream_t s, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_spec_kernel_info(const FigSpec& sp, const char* name, OhKernelInfo* out);
+
+// K1 (oh_fkjac_unit.h) for one chain: both layouts of the ABI
+struct FkSpec {
+  hipModule_t mod = nullptr;
+  hipFunction_t soa = nullptr, aos = nullptr;
+  bool from_disk = false;
+  double seconds = 0.0;
+};
+std::string oh_jit_fkjac_source(const oh_chain& chain);
+int oh_jit_fkjac(const oh_chain& chain, const FkSpec** out, std::string* err);
+hipError_t oh_spec_launch_fk(const FkSpec& sp, hipStream_t s, bool soa, int n, const double* q, double* pose, double* J);
+bool oh_spec_fk_kernel_info(const FkSpec& sp, OhKernelInfo* out);

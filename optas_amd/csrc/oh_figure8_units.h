@@ -434,6 +434,12 @@ OH_DEV void couple_unit(const FigParams& P, const FigBuffers& D, const int slot,
   D.merit[slot][(size_t)t * Bp + b] = merit;
 }
 
+#ifndef OH_STEP_PREFETCH_BACK
+#define OH_STEP_PREFETCH_BACK 1
+#endif
+#ifndef OH_STEP_PREFETCH_FWD
+#define OH_STEP_PREFETCH_FWD 1
+#endif
 // K3: one lane per instance: accept/reject the trial point (Levenberg-Marquardt ratio test on the
 // objective; iterates are feasible by retraction), then the backward Riccati sweep over the reduced
 // block-tridiagonal system (blocks prepared by k_eval/k_couple, next knot's blocks prefetched while the
@@ -559,45 +565,48 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
         stat = fmax(stat, fabs(rn[a]));
       }
     }
-    // prefetch registers for knot T-2
-    double nE[NZ * NZ], nH[NP], ng[NZ];
-    if (T - 2 >= P.t0) {
-      const int t = T - 2;
+    // The sweep is a dependent chain per lane: a knot's blocks have to be in registers when the previous knot's factor is done, and one
+    // knot of arithmetic (~0.4 us) hides a fraction of a memory round trip under load (~2 us).  PFB knots are kept in flight: buffer j
+    // is refilled with knot t - PFB the moment knot t has been copied out of it (static indices: the knot loop is unrolled PFB-fold).
+    constexpr int PFB = OH_STEP_PREFETCH_BACK;
+    double nE[PFB][NZ * NZ], nH[PFB][NP], ng[PFB][NZ];
+    auto fetch = [&](const int j, const int t) {
 #pragma unroll
-      for (int i = 0; i < NZ * NZ; ++i) nE[i] = rb_ld(KNOT(Ec, t, NZ * NZ), RB(i), oE);
+      for (int i = 0; i < NZ * NZ; ++i) nE[j][i] = rb_ld(KNOT(Ec, t, NZ * NZ), RB(i), oE);
 #pragma unroll
-      for (int i = 0; i < NP; ++i) nH[i] = rb_ld(KNOT(Drc, t, NP), RB(i), oD);
+      for (int i = 0; i < NP; ++i) nH[j][i] = rb_ld(KNOT(Drc, t, NP), RB(i), oD);
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) ng[a] = rb_ld(KNOT(gtc, t, NZ), RB(a), oG);
-    }
-    for (int t = T - 2; t >= P.t0; --t) {
-      double E[NZ * NZ], Ht[NP], gt[NZ];
+      for (int a = 0; a < NZ; ++a) ng[j][a] = rb_ld(KNOT(gtc, t, NZ), RB(a), oG);
+    };
 #pragma unroll
-      for (int i = 0; i < NZ * NZ; ++i) E[i] = nE[i];
+    for (int j = 0; j < PFB; ++j)
+      if (T - 2 - j >= P.t0) fetch(j, T - 2 - j);
+    for (int tb = T - 2; tb >= P.t0; tb -= PFB) {
 #pragma unroll
-      for (int i = 0; i < NP; ++i) Ht[i] = nH[i];
+      for (int j = 0; j < PFB; ++j) {
+        const int t = tb - j;
+        if (t >= P.t0) {
+          double E[NZ * NZ], Ht[NP], gt[NZ];
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) gt[a] = ng[a];
-      if (t > P.t0) {  // issue the next knot's loads before the dependent arithmetic of this one
-        const int tn = t - 1;
+          for (int i = 0; i < NZ * NZ; ++i) E[i] = nE[j][i];
 #pragma unroll
-        for (int i = 0; i < NZ * NZ; ++i) nE[i] = rb_ld(KNOT(Ec, tn, NZ * NZ), RB(i), oE);
+          for (int i = 0; i < NP; ++i) Ht[i] = nH[j][i];
 #pragma unroll
-        for (int i = 0; i < NP; ++i) nH[i] = rb_ld(KNOT(Drc, tn, NP), RB(i), oD);
+          for (int a = 0; a < NZ; ++a) gt[a] = ng[j][a];
+          if (t - PFB >= P.t0) fetch(j, t - PFB);  // issued before the dependent arithmetic of this knot
 #pragma unroll
-        for (int a = 0; a < NZ; ++a) ng[a] = rb_ld(KNOT(gtc, tn, NZ), RB(a), oG);
+          for (int a = 0; a < NZ; ++a) {
+            stat = fmax(stat, fabs(gt[a]));
+            Ht[tri(a, a)] += 2.0 * kap2 + mu;
+          }
+          double Kmat[NZ * NZ], kv[NZ];
+          ok = riccati_back<NZ>(S, rd, rn, E, Ht, gt, Kmat, kv) && ok;
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) rb_st(KNOT(D.kvec, t + 1, NZ), RB(a), lb, kv[a]);
+#pragma unroll
+          for (int i = 0; i < NZ * NZ; ++i) rb_st(KNOT(D.Kmat, t + 1, NZ * NZ), RB(i), lb, Kmat[i]);
+        }
       }
-#pragma unroll
-      for (int a = 0; a < NZ; ++a) {
-        stat = fmax(stat, fabs(gt[a]));
-        Ht[tri(a, a)] += 2.0 * kap2 + mu;
-      }
-      double Kmat[NZ * NZ], kv[NZ];
-      ok = riccati_back<NZ>(S, rd, rn, E, Ht, gt, Kmat, kv) && ok;
-#pragma unroll
-      for (int a = 0; a < NZ; ++a) rb_st(KNOT(D.kvec, t + 1, NZ), RB(a), lb, kv[a]);
-#pragma unroll
-      for (int i = 0; i < NZ * NZ; ++i) rb_st(KNOT(D.Kmat, t + 1, NZ * NZ), RB(i), lb, Kmat[i]);
     }
     ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
     if (ok) break;
@@ -666,24 +675,50 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     // fourth step on, ratio test against the model's own prediction for alpha z) cuts the mean step count by 13 % on the numpy port
     // (96 instances: 16.4 -> 14.2); larger alpha or an earlier start cost more rejections than they save.
     const double alpha = (!GUARD && P.hessian == OH_HESSIAN_HYBRID && stat > P.hyb_switch && iters >= P.relax_from) ? P.relax : 1.0;
-    for (int t = P.t0; t < T; ++t) {
+    // gains of the next PFF knots in flight (they do not depend on z: without the explicit buffers every knot waits a full round trip)
+    constexpr int PFF = OH_STEP_PREFETCH_FWD;
+    double fK[PFF][NZ * NZ], fk[PFF][NZ], fg[PFF][NZ];
+    auto fetchf = [&](const int j, const int t) {
       if (t > P.t0) {
-        double zn[NZ];
 #pragma unroll
-        for (int a = 0; a < NZ; ++a) {
-          double sacc = rb_ld(KNOT(D.kvec, t, NZ), RB(a), lb);
+        for (int a = 0; a < NZ; ++a) fk[j][a] = rb_ld(KNOT(D.kvec, t, NZ), RB(a), lb);
 #pragma unroll
-          for (int c2 = 0; c2 < NZ; ++c2) sacc += rb_ld(KNOT(D.Kmat, t, NZ * NZ), RB(a * NZ + c2), lb) * zz[c2];
-          zn[a] = -sacc;
-        }
-#pragma unroll
-        for (int a = 0; a < NZ; ++a) zz[a] = zn[a];
+        for (int i = 0; i < NZ * NZ; ++i) fK[j][i] = rb_ld(KNOT(D.Kmat, t, NZ * NZ), RB(i), lb);
       }
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) {
-        rb_st(KNOT(D.zstep, t, NZ), RB(a), lb, alpha * zz[a]);
-        gd += rb_ld(KNOT(gtc, t, NZ), RB(a), oG) * zz[a];
-        z2 += zz[a] * zz[a];
+      for (int a = 0; a < NZ; ++a) fg[j][a] = rb_ld(KNOT(gtc, t, NZ), RB(a), oG);
+    };
+#pragma unroll
+    for (int j = 0; j < PFF; ++j)
+      if (P.t0 + j < T) fetchf(j, P.t0 + j);
+    for (int tb = P.t0; tb < T; tb += PFF) {
+#pragma unroll
+      for (int j = 0; j < PFF; ++j) {
+        const int t = tb + j;
+        if (t < T) {
+          double gtt[NZ];
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) gtt[a] = fg[j][a];
+          if (t > P.t0) {
+            double zn[NZ];
+#pragma unroll
+            for (int a = 0; a < NZ; ++a) {
+              double sacc = fk[j][a];
+#pragma unroll
+              for (int c2 = 0; c2 < NZ; ++c2) sacc += fK[j][a * NZ + c2] * zz[c2];
+              zn[a] = -sacc;
+            }
+#pragma unroll
+            for (int a = 0; a < NZ; ++a) zz[a] = zn[a];
+          }
+          if (t + PFF < T) fetchf(j, t + PFF);
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) {
+            rb_st(KNOT(D.zstep, t, NZ), RB(a), lb, alpha * zz[a]);
+            gd += gtt[a] * zz[a];
+            z2 += zz[a] * zz[a];
+          }
+        }
       }
     }
     // decrease the model predicts for alpha z, with (H + mu I) z = -g:  -alpha g.z - alpha^2/2 z^T H z = -alpha gd + alpha^2/2 (gd + mu z2)

@@ -214,8 +214,11 @@ bool oh_launch_step_locked_guarded(hipStream_t s, int n, const FigParams& P, con
   else return false;
   return true;
 }
+#ifndef OH_STEP_WAVES
+#define OH_STEP_WAVES 2
+#endif
 template <int N>
-__global__ __launch_bounds__(64, 2) void k_step(FigParams P, FigBuffers D, const int slot) {
+__global__ __launch_bounds__(64, OH_STEP_WAVES) void k_step(FigParams P, FigBuffers D, const int slot) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool alive = (b < D.B) && (D.status[b] < 0);
   const bool skipping = alive && D.skip[b];

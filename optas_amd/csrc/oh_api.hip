@@ -877,7 +877,8 @@ static int ensure_guards(oh_handle* h) {
     if (h->gpool) hipFree(h->gpool);
     h->gpool = nullptr;
     const size_t npar = (size_t)g.n_links + 4 * (size_t)g.n_obstacles;
-    const size_t nd = (size_t)T * GP.NC * Bp + npar * Bp + 4 * (size_t)T * Bp + 6 * (size_t)Bp + (GP.vel ? (size_t)T * 2 * N * Bp : 0);
+    const size_t n_lam = (size_t)T * GP.NC * Bp, n_lamv = GP.vel ? (size_t)T * 2 * N * Bp : 0;
+    const size_t nd = 3 * (n_lam + n_lamv) + 2 * npar * Bp + 4 * (size_t)T * Bp + (6 + 8) * (size_t)Bp;  // lam, lam_out and the compaction scratch
     const size_t bytes = nd * sizeof(double) + 2 * (size_t)Bp * sizeof(int);
     hipError_t e = hipMalloc(&h->gpool, bytes);
     if (e != hipSuccess) return fail(OH_ERR_HIP, std::string("guard pool allocation failed: ") + hipGetErrorString(e));
@@ -899,6 +900,9 @@ static int ensure_guards(oh_handle* h) {
     GB.mcv[1] = take((size_t)T * Bp);
     GB.meas = take(Bp);
     GB.lamv = GP.vel ? take((size_t)T * 2 * N * Bp) : nullptr;
+    GB.lam_out = take(n_lam);
+    GB.lamv_out = GP.vel ? take(n_lamv) : nullptr;
+    GB.scr = take(n_lam + n_lamv + (npar + 8) * Bp);
     int* ip = (int*)d;
     GB.outer = ip; ip += Bp;
     GB.n_outer = ip;
@@ -1002,6 +1006,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   // the regular compactions carry the pending trial along and cost no evaluation (k_carry_*), the hand-over to the tail kernel
   // restarts the survivors.
   const int hard_cap = 2 * h->desc.max_iter + 2 + 40 + 64;  // a rejected step costs two launches, a compaction one
+  const int NV = (guarded && h->GP.vel) ? 2 * N : 0;  // velocity rows per knot
   const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation && !guarded && !lead;
   const FigSpec* const spec = spec_applies(h) ? h->spec : nullptr;
   // evaluation / tail launches: the kernels compiled for this handle's chain when they are loaded, the generic ones otherwise
@@ -1078,11 +1083,16 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       }
       if (h->compaction && h->compact_carry && oh_eval_is_split() && h->P.lock && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
         carry_pending = nrun;  // done after the next k_retract
-      } else if (h->compaction && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
+      } else if (h->compaction && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
+        // restart compaction: the survivors' accepted knots (and, with inequality rows, their multipliers and outer-loop state) are laid
+        // down densely and re-evaluated
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
+        if (guarded) oh_launch_guard_emit(s, h->P, h->D, h->GP, h->GB, NV, 1);
         oh_launch_scan_running(s, h->D, h->compact_sort);
         oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
+        if (guarded) oh_launch_guard_compact(s, h->P, h->D, h->GP, h->GB, NV, 0, 0);
         oh_launch_compact(s, N, h->P, h->D, 1, nrun, (it + 1) & 1);
+        if (guarded) oh_launch_guard_compact(s, h->P, h->D, h->GP, h->GB, NV, 1, nrun);
         h->D.B = nrun;
         ++compactions;
         // the compaction kernels are accounted to neither eval nor step: restart the event pair
@@ -1091,6 +1101,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     }
   }
   oh_launch_finalize(s, N, h->P, h->D, 0, ox, of, ok, oi, os);
+  if (guarded) oh_launch_guard_emit(s, h->P, h->D, h->GP, h->GB, NV, 0);
   h->D.B = B;
   HIPCHK(hipEventRecord(h->ev1, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -1265,13 +1276,13 @@ extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
     // SoA [T][NC][Bp] on the device -> [B][T][NC (+ 2 ndof velocity rows)] for the caller
     const int T = h->desc.T, NC = h->GP.NC, Bp = h->D.Bp, NV = h->GP.vel ? 2 * h->desc.ndof : 0, NT = NC + NV;
     std::vector<double> tmp((size_t)T * NC * Bp);
-    if (NC) HIPCHK(hipMemcpy(tmp.data(), h->GB.lam, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (NC) HIPCHK(hipMemcpy(tmp.data(), h->GB.lam_out, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));  // original order (k_guard_emit)
     for (int b = 0; b < B; ++b)
       for (int t = 0; t < T; ++t)
         for (int i = 0; i < NC; ++i) lam_h[((size_t)b * T + t) * NT + i] = tmp[((size_t)t * NC + i) * Bp + b];
     if (NV) {  // the device keeps the rows of dq_t = interval (t, t+1) in row block t + 1
       std::vector<double> tv((size_t)T * NV * Bp);
-      HIPCHK(hipMemcpy(tv.data(), h->GB.lamv, tv.size() * sizeof(double), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(tv.data(), h->GB.lamv_out, tv.size() * sizeof(double), hipMemcpyDeviceToHost));
       for (int b = 0; b < B; ++b)
         for (int t = 0; t < T; ++t)
           for (int i = 0; i < NV; ++i) lam_h[((size_t)b * T + t) * NT + NC + i] = (t + 1 < T) ? tv[((size_t)(t + 1) * NV + i) * Bp + b] : 0.0;

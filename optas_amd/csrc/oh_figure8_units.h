@@ -481,6 +481,13 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       }
       accept = true;
       D.first[b] = 0;
+      if constexpr (GUARD) {
+        // restart after a batch compaction with a multiplier update pending: this evaluation has refreshed the multipliers
+        if (GBp->outer[b]) {
+          GBp->outer[b] = 0;
+          GBp->rho[b] = GBp->rho_next[b];
+        }
+      }
     } else if (GUARD && GBp->outer[b]) {
       // re-evaluation of the accepted point after a multiplier update: the merit function itself changed
       accept = true;

@@ -386,6 +386,13 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
       }
       accept = true;
       D.first[b] = 0;
+      if constexpr (GUARD) {
+        // restart after a batch compaction with a multiplier update pending: this evaluation has refreshed the multipliers
+        if (GB.outer[b]) {
+          GB.outer[b] = 0;
+          GB.rho[b] = GB.rho_next[b];
+        }
+      }
     } else if (GUARD && GB.outer[b]) {
       // re-evaluation of the current point after a multiplier update: the merit function itself changed
       accept = true;
@@ -620,4 +627,69 @@ bool oh_launch_step_guarded(hipStream_t s, int n, const FigParams& P, const FigB
   else if (n == 6) hipLaunchKernelGGL((k_step_free<6, true>), g, b, 0, s, P, D, GB, slot);
   else return false;
   return true;
+}
+
+// ---- guard state of a batch that is compacted while it drains (oh_api.hip) ----------------------------------------------------------
+// The multipliers, the obstacle parameters and the outer-loop scalars of an instance move with it (k_compact_* move the knots); the
+// multipliers of an instance that has finished are written out at its original index first, where oh_get_multipliers reads them.
+__global__ __launch_bounds__(256) void k_guard_emit(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int NV, const int only_done) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (only_done && D.status[b] < 0) return;
+  const int o = D.orig[b];
+  for (int i = 0; i < GP.NC; ++i) GB.lam_out[((size_t)t * GP.NC + i) * Bp + o] = GB.lam[((size_t)t * GP.NC + i) * Bp + b];
+  for (int i = 0; i < NV; ++i) GB.lamv_out[((size_t)t * NV + i) * Bp + o] = GB.lamv[((size_t)t * NV + i) * Bp + b];
+}
+__global__ __launch_bounds__(256) void k_guard_gather(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int NV) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  const int nb = D.newidx[b];
+  if (nb < 0) return;
+  const int NR = GP.NC + NV;
+  for (int i = 0; i < GP.NC; ++i) GB.scr[((size_t)t * NR + i) * Bp + nb] = GB.lam[((size_t)t * GP.NC + i) * Bp + b];
+  for (int i = 0; i < NV; ++i) GB.scr[((size_t)t * NR + GP.NC + i) * Bp + nb] = GB.lamv[((size_t)t * NV + i) * Bp + b];
+  if (t == 0) {
+    double* sc = GB.scr + (size_t)P.T * NR * Bp;
+    const int npar = GP.n_links + 4 * GP.n_obs;
+    for (int i = 0; i < npar; ++i) sc[(size_t)i * Bp + nb] = GB.par[(size_t)i * Bp + b];
+    sc += (size_t)npar * Bp;
+    sc[(size_t)0 * Bp + nb] = GB.rho[b];
+    sc[(size_t)1 * Bp + nb] = GB.rho_next[b];
+    sc[(size_t)2 * Bp + nb] = GB.omega[b];
+    sc[(size_t)3 * Bp + nb] = GB.meas_prev[b];
+    sc[(size_t)4 * Bp + nb] = (double)GB.outer[b];
+    sc[(size_t)5 * Bp + nb] = (double)GB.n_outer[b];
+  }
+}
+__global__ __launch_bounds__(256) void k_guard_scatter(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int NV, const int Bnew) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  const int Bp = D.Bp;
+  if (b >= Bnew) return;
+  const int NR = GP.NC + NV;
+  for (int i = 0; i < GP.NC; ++i) GB.lam[((size_t)t * GP.NC + i) * Bp + b] = GB.scr[((size_t)t * NR + i) * Bp + b];
+  for (int i = 0; i < NV; ++i) GB.lamv[((size_t)t * NV + i) * Bp + b] = GB.scr[((size_t)t * NR + GP.NC + i) * Bp + b];
+  if (t == 0) {
+    const double* sc = GB.scr + (size_t)P.T * NR * Bp;
+    const int npar = GP.n_links + 4 * GP.n_obs;
+    for (int i = 0; i < npar; ++i) GB.par[(size_t)i * Bp + b] = sc[(size_t)i * Bp + b];
+    sc += (size_t)npar * Bp;
+    GB.rho[b] = sc[(size_t)0 * Bp + b];
+    GB.rho_next[b] = sc[(size_t)1 * Bp + b];
+    GB.omega[b] = sc[(size_t)2 * Bp + b];
+    GB.meas_prev[b] = sc[(size_t)3 * Bp + b];
+    GB.outer[b] = (int)sc[(size_t)4 * Bp + b];
+    GB.n_outer[b] = (int)sc[(size_t)5 * Bp + b];
+  }
+}
+void oh_launch_guard_emit(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int NV, int only_done) {
+  hipLaunchKernelGGL(k_guard_emit, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, GP, GB, NV, only_done);
+}
+void oh_launch_guard_compact(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int NV, int phase, int Bnew) {
+  if (phase == 0) hipLaunchKernelGGL(k_guard_gather, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, GP, GB, NV);
+  else hipLaunchKernelGGL(k_guard_scatter, dim3((Bnew + 255) / 256, P.T), dim3(256), 0, s, P, D, GP, GB, NV, Bnew);
 }

@@ -52,6 +52,9 @@ struct GuardBuffers {
   double* mcv[2];     // [slot][T][Bp] per-knot |min(g, lam/rho)|_inf (orientation-locked family; D.cv holds the orientation residual there)
   double* meas;       // [Bp] its maximum over the knots of the accepted point
   double* lamv;       // [T][2N][Bp] multipliers of the velocity rows; row block t = interval (t-1, t) = dq_{t-1}: [dq - vlo (N); vup - dq (N)]
+  double* lam_out;    // [T][NC][Bp] multipliers of finished instances at their ORIGINAL index (instances move when the batch is compacted)
+  double* lamv_out;   // [T][2N][Bp] same for the velocity rows
+  double* scr;        // [T (NC + 2N) + n_par + 8][Bp] scratch of the compaction (k_guard_gather / k_guard_scatter)
 };
 
 // Device buffers of one handle (SoA, instance index fastest; Bp = B rounded up to 64).

@@ -212,3 +212,42 @@ def test_figure_eight_with_sphere_obstacle(hip_lib):
     lam = solver.backend.multipliers(1)[0]
     assert lam.shape == (50, 4) and (lam >= 0).all() and (lam > 0).sum() == (s["lam"] > 0).sum() > 0
     assert np.abs(lam.reshape(-1) * nlp.g(x, p)).max() < 1e-7
+
+
+def test_guarded_batch_compaction_is_invisible(hip_lib, golden, monkeypatch):
+    """A guarded batch is compacted while it drains (round 2: multipliers, obstacle parameters and outer-loop state move with the instance,
+    k_guard_*): every instance must end where it ends without compaction, with the same multipliers at its original index."""
+    from optas_amd.lowering import lower
+    from optas_amd.backend import MultiArmBackend
+
+    T, B = 30, 640
+    (kl, kr), o = setup_solver(T=T, build_only=True, limits=True, collision=True)
+    kind, spec = lower(o)
+    rng = np.random.default_rng(SEED + 41)
+    qcl, qcr = QC + rng.uniform(-0.15, 0.15, (B, 7)), QC + rng.uniform(-0.15, 0.15, (B, 7))
+    base = o.parameters.dict2vec({"qcl": QC, "qcr": QC, **obstacle_parameters(link_radius=0.1)})
+    P = np.tile(base, (B, 1))
+    P[:, :7], P[:, 7:14] = qcl, qcr
+    X0 = np.zeros((B, o.nx))
+    xoff = o.decision_variables.offsets()
+    for name, qc in (("kukal/q/x", qcl), ("kukar/q/x", qcr)):
+        X0[:, xoff[name] : xoff[name] + 7 * T] = np.tile(qc, (1, T))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OH_COMPACTION", mode)
+        mb = MultiArmBackend(spec, o, max_iter=400)
+        res = mb.solve(X0, P)
+        lam = [be.multipliers(B) for _, be in mb.arms]
+        comp = sum(be.timing()["compactions"] for _, be in mb.arms)
+        out[mode] = (res, lam, comp)
+        mb.close()
+    (r0, l0, c0), (r1, l1, c1) = out["0"], out["1"]
+    assert c0 == 0 and c1 >= 2  # the batch did shrink on the way
+    assert (r0.status == 0).mean() > 0.99 and (r0.status == r1.status).all()
+    # a survivor restarts from its accepted point with its LM state: same iterates, the step in flight is re-derived
+    assert (np.abs(r0.iters.astype(int) - r1.iters) <= 1).mean() >= 0.99
+    same = r0.iters == r1.iters
+    assert np.abs(r0.f - r1.f).max() <= 1e-8 * np.abs(r0.f).max() and np.abs(r0.x[same] - r1.x[same]).max() <= 1e-7
+    for a, b in zip(l0, l1):
+        assert a.shape == b.shape and np.abs(a[same] - b[same]).max() <= 1e-6 * max(1.0, np.abs(a).max())
+        assert np.abs(a).max() > 0  # rows are active somewhere: the comparison is not vacuous

@@ -104,7 +104,8 @@ def main():
 
     QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
     for tag, T, B, guarded in (("4 dual_arm.py as shipped (T=50), per arm", 50, 8192, False),
-                               ("4 synthetic: T=100 + joint limits + 4x6 sphere clearances, per arm", 100, 1024, True)):
+                               ("4 synthetic: T=100 + joint limits + 4x6 sphere clearances, per arm", 100, 1024, True),
+                               ("4 synthetic, large batch (guarded handles are compacted while they drain)", 100, 32768, True)):
         arm = RobotModel.builtin("kuka_lwr", time_derivs=[0, 1], name="kukal")
         arm.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
         g = None
@@ -127,7 +128,8 @@ def main():
             p = np.concatenate([qc, np.full((B, 4), 0.1), np.tile(obs_row, (B, 1))], 1)
         x0 = np.concatenate([np.tile(qc, (1, T)), np.zeros((B, 7 * (T - 1)))], 1)
         r = timed(be, np.ascontiguousarray(x0), np.ascontiguousarray(p))
-        out.append({"config": tag, "batch": B, "T": T, "solves_per_s": B / r["ms"] * 1e3, **r})
+        out.append({"config": tag, "batch": B, "T": T, "solves_per_s": B / r["ms"] * 1e3, "compactions": be.timing()["compactions"], **r})
+        be.close()
     # ---- config 5: torque MPC, RNEA dynamics as equality rows (med7, T = 30), effort limit 58 N m so that the rows bind in part of the batch ----
     med7 = RobotModel.builtin("med7")
     link, T, dt = "lbr_link_ee", 30, 0.1

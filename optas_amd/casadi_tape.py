@@ -161,25 +161,38 @@ def make_solver_class(solver_module, cs):
         def setup(self, solver_name: str = "hip_sqp", solver_options: Optional[dict] = None):
             """Structured family first (optas_amd.probe_lowering: labels and shapes of the problem's containers, its own numeric functions
             probed and then verified -- the headline figure-eight kernels behind a real ``Optimization``), generic tape family otherwise.
-            ``solver_options["family"]`` = "figure_eight" | "tape" forces one route; ``"link"`` may name the tracked link."""
+            ``solver_options["family"]`` = "figure_eight" | "torque_mpc" | "ik" | "tape" forces one route; ``"link"`` may name the tracked link."""
             if solver_name != "hip_sqp":
                 raise ValueError(f"unknown solver '{solver_name}' (this interface provides 'hip_sqp')")
             o = dict(solver_options or {})
             family = o.pop("family", None)
             link = o.pop("link", None)
             self._family = None
-            if family in (None, "figure_eight"):
+            if family != "tape":
+                from .backend import IKBackend, TorqueBackend
                 from .lowering import LoweringError
-                from .probe_lowering import probe_figure_eight
+                from . import probe_lowering as pl
                 from .solver import figure_eight_backend
 
+                probes = {"figure_eight": pl.probe_figure_eight, "torque_mpc": pl.probe_torque_mpc, "ik": pl.probe_ik}
+                if family is not None and family not in probes:
+                    raise ValueError(f"unknown family '{family}' (figure_eight, torque_mpc, ik, tape)")
                 try:
-                    spec = probe_figure_eight(self.opt, link=link)
-                    hess = {"gauss_newton": 0, "exact": 1, "hybrid": 2}[o.pop("hessian", "hybrid")]
-                    self._backend = figure_eight_backend(spec, o, hess)
-                    self._family, self._spec = "figure_eight", spec
+                    fam, spec = (family, probes[family](self.opt, link=link)) if family else pl.probe(self.opt, link=link)
+                    if fam == "figure_eight":
+                        hess = {"gauss_newton": 0, "exact": 1, "hybrid": 2}[o.pop("hessian", "hybrid")]
+                        self._backend = figure_eight_backend(spec, o, hess)
+                    elif fam == "torque_mpc":
+                        self._backend = TorqueBackend(spec.robot.solver_chain(spec.link), spec.robot.dynamics_tables(), T=spec.T, dt=spec.dt, w_path=spec.w_path,
+                                                      w_vel=spec.w_vel, w_tau=spec.w_tau, tau_lo=spec.tau_lo, tau_up=spec.tau_up,
+                                                      max_iter=int(o.pop("max_iter", 300)), tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)),
+                                                      rho0=float(o.pop("rho0", 0.0)), mu0=float(o.pop("mu0", 0.0)))
+                    else:
+                        self._backend = IKBackend(spec.robot.kinematic_chain(spec.link), spec.lo, spec.up, w_nominal=spec.w_nominal,
+                                                  max_iter=int(o.pop("max_iter", 200)), tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)))
+                    self._family, self._spec = fam, spec
                 except LoweringError:
-                    if family == "figure_eight":
+                    if family is not None:
                         raise
             if self._family is None:
                 self._tape = tape_from_optimization(self.opt, cs)

@@ -221,3 +221,248 @@ def _probe_costs(opt, robot, link, n, T, dt, qc, p_c, R_c, xvec, rng):
         if abs(f_model - f_ref) > 1e-9 * max(1.0, abs(f_ref)):
             return None
     return w_path, w_vel, np.ascontiguousarray(local)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The other families a BASELINE config uses, from the same interface: labels / shapes decide whether a problem *can* be the family,
+# its own numeric members are probed for the numbers, and the recovered model is verified against them before anything is returned.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _nonempty_params(opt):
+    return [(k, _shape(v)) for k, v in opt.parameters.items() if _shape(v)[0] * _shape(v)[1] > 0]
+
+
+def _links_to_try(robot, link):
+    out = []
+    for cand in ([link] if link is not None else [l for l in robot.link_names if l != robot.get_root_link()]):
+        try:
+            if len(robot.urdf.get_chain(robot.get_root_link(), cand)) > 0:
+                out.append(cand)
+        except ValueError:
+            pass
+    return out
+
+
+def _probe_bounds(opt, what, x_of, n, blocks, xr, pr, no):
+    """Joint-bound style rows k(x, p) = [z - lo; up - z] (z = x_of(x), one block of n x cols rows per container item, any order): (lo, up) or
+    None for a side that has no block.  ``blocks`` = [(label, cols)].  Read at z = 0 and one unit step, then verified at the random point."""
+    lo = up = None
+    k0 = _vec(opt.k, x_of(np.zeros_like(xr)), pr)
+    k1 = _vec(opt.k, x_of(np.ones_like(xr)), pr)
+    off = 0
+    model = []
+    for label, cols in blocks:
+        m = n * cols
+        c, s = k0[off : off + m].reshape(cols, n), (k1 - k0)[off : off + m].reshape(cols, n)
+        if np.abs(c - c[0][None]).max() > 1e-12 * max(1.0, np.abs(c).max()):
+            no(f"{what} '{label}': the bound is not the same at every knot")
+        if np.abs(s - 1.0).max() <= 1e-12 and lo is None:
+            lo = -c[0]
+            model.append((xr - lo[None]).reshape(-1))
+        elif np.abs(s + 1.0).max() <= 1e-12 and up is None:
+            up = c[0]
+            model.append((up[None] - xr).reshape(-1))
+        else:
+            no(f"{what} '{label}' is not a bound block z - lo >= 0 or up - z >= 0 (or a second one of its kind)")
+        off += m
+    if off != k0.size:
+        no(f"{what}: k(x, p) has {k0.size} rows, the containers account for {off}")
+    if model and np.abs(_vec(opt.k, x_of(xr), pr) - np.concatenate(model)).max() > 1e-9:
+        no(f"{what}: k(x, p) is not the bound rows read off it")
+    return lo, up
+
+
+def probe_ik(opt, rng_seed: int = 12345, link: Optional[str] = None):
+    """example/example.py:13-60 behind the reference interface: min w ||q - q_nominal||^2 s.t. p(link, q) = p_goal, lo <= q <= up."""
+    from .lowering import IkSpec
+
+    def no(msg):
+        raise LoweringError(f"inverse-kinematics probing: {msg}")
+
+    models = list(opt.models or [])
+    if len(models) != 1 or not hasattr(models[0], "urdf"):
+        no("expected exactly one robot model")
+    m = models[0]
+    name = m.get_name()
+    if list(m.time_derivs) != [0] or len(getattr(m, "param_joints", []) or []) != 0:
+        no("robot must have time_derivs=[0] and no parameterised joints")
+    q_name = f"{name}/q/x"
+    if list(opt.decision_variables.keys()) != [q_name]:
+        no(f"decision variables must be exactly [{q_name}]")
+    n, T = _shape(opt.decision_variables[q_name])
+    if T != 1:
+        no("T must be 1")
+    params = _nonempty_params(opt)
+    if [s for _, s in params] != [(n, 1), (3, 1)]:
+        no(f"non-empty parameters must be (q_nominal ({n}, 1), p_goal (3, 1)) in this order, found {params}")
+    if len(opt.lin_eq_constraints) or len(opt.ineq_constraints):
+        no("linear equality / nonlinear inequality rows are not part of this family")
+    eq = [(k, _shape(v)) for k, v in opt.eq_constraints.items()]
+    if len(eq) != 1 or eq[0][1] != (3, 1):
+        no(f"expected one nonlinear equality of shape (3, 1) (the position goal), found {eq}")
+    if any(_shape(v) != (n, 1) for v in opt.lin_ineq_constraints.values()):
+        no("linear inequalities must be joint-bound blocks of shape (ndof, 1)")
+    robot = _mirror_robot(m)
+    if robot.ndof != n:
+        no("the robot's ndof does not match the decision variables")
+    rng = np.random.default_rng(rng_seed)
+    lo_j, up_j = robot.lower_actuated_joint_limits, robot.upper_actuated_joint_limits
+    mid, half = 0.5 * (lo_j + up_j), 0.3 * np.minimum(up_j - lo_j, 4.0)
+    q, qn, pg = mid + rng.uniform(-1, 1, n) * half, mid + rng.uniform(-1, 1, n) * half, rng.normal(size=3)
+    p = np.concatenate([qn, pg])
+    lo, up = _probe_bounds(opt, "linear inequality", lambda z: z.reshape(-1), n, [(k, 1) for k in opt.lin_ineq_constraints.keys()], q[None], p, no)
+    lo = np.full(n, -1e9) if lo is None else lo
+    up = np.full(n, 1e9) if up is None else up
+    # cost: w ||q - qn||^2
+    if abs(float(_vec(opt.f, qn, p)[0])) > 1e-12:
+        no("f does not vanish at q = q_nominal")
+    d = np.zeros(n)
+    d[0] = 0.5
+    w = float(_vec(opt.f, qn + d, p)[0]) / 0.25
+    if not (w > 0) or abs(float(_vec(opt.f, q, p)[0]) - w * float(np.sum((q - qn) ** 2))) > 1e-9 * max(1.0, w):
+        no("the cost is not w * sumsqr(q - q_nominal)")
+    # h = p_goal - p(link, q)
+    h = _vec(opt.h, q, p)
+    for cand in _links_to_try(robot, link):
+        if np.abs(h - (pg - np.asarray(robot.get_global_link_position(cand, q)).reshape(3))).max() <= 1e-9:
+            q2, pg2 = mid + rng.uniform(-1, 1, n) * half, rng.normal(size=3)
+            h2 = _vec(opt.h, q2, np.concatenate([qn, pg2]))
+            if np.abs(h2 - (pg2 - np.asarray(robot.get_global_link_position(cand, q2)).reshape(3))).max() <= 1e-9:
+                return IkSpec(robot, cand, w, np.asarray(lo, float), np.asarray(up, float), params[0][0], params[1][0], q_name)
+    no("h(x, p) is not p_goal - p(link, q) for any link of the robot")
+
+
+def probe_torque_mpc(opt, rng_seed: int = 12345, link: Optional[str] = None):
+    """BASELINE configs[4] behind the reference interface: x = [Q; dQ; ddQ; TAU] (derivs_align), two Euler integrations, q_0 / dq_0 fixed,
+    h = TAU - rnea(Q, dQ, ddQ), effort bounds, f = w_path sumsqr(p(link, Q) - goal) + w_vel sumsqr(dQ) + w_tau sumsqr(TAU)."""
+    from .lowering import TorqueSpec
+
+    def no(msg):
+        raise LoweringError(f"torque-MPC probing: {msg}")
+
+    models = list(opt.models or [])
+    robots = [m for m in models if hasattr(m, "urdf")]
+    tasks = [m for m in models if not hasattr(m, "urdf")]
+    if len(robots) != 1 or len(tasks) != 1 or len(models) != 2:
+        no("expected one robot model and one task model (the joint torques)")
+    m, task = robots[0], tasks[0]
+    name = m.get_name()
+    if list(m.time_derivs) != [0, 1, 2] or len(getattr(m, "param_joints", []) or []) != 0 or list(task.time_derivs) != [0]:
+        no("robot must have time_derivs=[0, 1, 2] and no parameterised joints; the task model time_derivs=[0]")
+    names = [f"{name}/q/x", f"{name}/dq/x", f"{name}/ddq/x", task.state_optimized_name(0)]
+    if list(opt.decision_variables.keys()) != names:
+        no(f"decision variables must be exactly {names}, found {list(opt.decision_variables.keys())}")
+    n, T = _shape(opt.decision_variables[names[0]])
+    if any(_shape(opt.decision_variables[k]) != (n, T) for k in names):
+        no("every block must be ndof x T (derivs_align=True)")
+    params = _nonempty_params(opt)
+    if [s for _, s in params] != [(n, 1), (n, 1), (3, T)]:
+        no(f"non-empty parameters must be (qc ({n}, 1), dqc ({n}, 1), goal (3, {T})) in this order, found {params}")
+    lin = [(k, _shape(v)) for k, v in opt.lin_eq_constraints.items()]
+    kinds = {f"__{name}_fix_configuration_0_0__": ("fix", 0), f"__{name}_fix_configuration_1_0__": ("fix", 1),
+             f"__integrate_model_states_{name}_1__": ("int", 1), f"__integrate_model_states_{name}_2__": ("int", 2)}
+    if sorted(k for k, _ in lin) != sorted(kinds) or any(s != ((n, 1) if kinds[k][0] == "fix" else (n, T - 1)) for k, s in lin):
+        no(f"linear equalities must be fix_configuration of q and dq at t = 0 and integrate_model_states for time_deriv 1 and 2, found {lin}")
+    if len(opt.ineq_constraints):
+        no("nonlinear inequalities are not lowered")
+    eq = [(k, _shape(v)) for k, v in opt.eq_constraints.items()]
+    if len(eq) != 1 or eq[0][1] != (n, T):
+        no(f"expected one nonlinear equality of shape ({n}, {T}) (the inverse dynamics), found {eq}")
+    if any(_shape(v) != (n, T) for v in opt.lin_ineq_constraints.values()):
+        no("linear inequalities must be effort-bound blocks of shape (ndof, T)")
+    robot = _mirror_robot(m)
+    if robot.ndof != n:
+        no("the robot's ndof does not match the decision variables")
+    rng = np.random.default_rng(rng_seed)
+    nT = n * T
+
+    def xvec(Q, dQ, ddQ, TAU):  # (T, n) each -> vec order
+        return np.concatenate([Q.reshape(-1), dQ.reshape(-1), ddQ.reshape(-1), TAU.reshape(-1)])
+
+    lo_j, up_j = robot.lower_actuated_joint_limits, robot.upper_actuated_joint_limits
+    mid, half = 0.5 * (lo_j + up_j), 0.3 * np.minimum(up_j - lo_j, 4.0)
+    qc = mid + rng.uniform(-1, 1, n) * half
+    Z = np.zeros((T, n))
+    Qc = np.tile(qc, (T, 1))
+    p0 = np.concatenate([qc, np.zeros(n), np.zeros(3 * T)])
+    x0 = xvec(Qc, Z, Z, Z)
+    # ---- linear rows: dt from one probe, then the whole block in the containers' order
+    a0 = _vec(opt.a, x0, p0)
+    if a0.size != 2 * n + 2 * n * (T - 1) or np.abs(a0).max() > 1e-12:
+        no("a(x, p) does not vanish at q_t = qc, dq = ddq = 0")
+    off, where = 0, {}
+    for k, s in lin:
+        where[kinds[k]] = off
+        off += s[0] * s[1]
+    d = np.zeros_like(x0)
+    d[nT + 0] = 1.0  # dq_0[0] enters the first integration row with -dt (read at q = 0, qc = 0: nothing to cancel, dt comes out exactly)
+    dt = -float(_vec(opt.a, d, np.zeros_like(p0))[where[("int", 1)]])
+    if not (dt > 0):
+        no("could not read a positive dt off the integration rows")
+    Qr, dQr, ddQr, TAUr = (rng.normal(size=(T, n)) for _ in range(4))
+    pr = np.concatenate([rng.normal(size=n), rng.normal(size=n), rng.normal(size=3 * T)])
+    rows = {("fix", 0): pr[:n] - Qr[0], ("fix", 1): pr[n : 2 * n] - dQr[0], ("int", 1): -(Qr[:-1] + dt * dQr[:-1] - Qr[1:]).reshape(-1),
+            ("int", 2): -(dQr[:-1] + dt * ddQr[:-1] - dQr[1:]).reshape(-1)}
+    a_model = np.concatenate([rows[kinds[k]] for k, _ in lin])
+    xr = xvec(Qr, dQr, ddQr, TAUr)
+    if np.abs(_vec(opt.a, xr, pr) - a_model).max() > 1e-9:
+        no("the linear equalities are not [qc - q_0; dqc - dq_0; Euler integration of q and dq with one uniform dt]")
+    # ---- effort bounds
+    lo, up = _probe_bounds(opt, "linear inequality", lambda z: xvec(Qr, dQr, ddQr, z), n, [(k, T) for k in opt.lin_ineq_constraints.keys()], TAUr, pr, no)
+    if (lo is None) != (up is None):
+        no("effort limits need both the lower and the upper row block")
+    if lo is None:
+        lo, up = -1e9 * np.ones(n), 1e9 * np.ones(n)
+    # ---- dynamics rows h = TAU - rnea(Q, dQ, ddQ)
+    Qh = qc[None] + rng.uniform(-0.3, 0.3, (T, n))
+    dQh, ddQh = rng.uniform(-1, 1, (T, n)), rng.uniform(-2, 2, (T, n))
+    tau = np.asarray(robot.rnea(Qh.T, dQh.T, ddQh.T)).reshape(n, T).T
+    h = _vec(opt.h, xvec(Qh, dQh, ddQh, TAUr), pr).reshape(T, n)
+    if np.abs(h - (TAUr - tau)).max() > 1e-9 * max(1.0, np.abs(tau).max()):
+        no("h(x, p) is not TAU - rnea(Q, dQ, ddQ)")
+    # ---- cost: at q_t = qc, dq = ddq = tau = 0 and goal_t = g:  f = w_path T |p_c - g|^2  ->  w_path and p_c from five goals
+    def f_goal(g):
+        return float(_vec(opt.f, x0, np.concatenate([qc, np.zeros(n), np.tile(g, T)]))[0])
+
+    f0, e = f_goal(np.zeros(3)), np.eye(3)
+    fe = [f_goal(e[i]) for i in range(3)]
+    w_path = (f_goal(2.0 * e[0]) - 2.0 * fe[0] + f0) / (2.0 * T)
+    if not (w_path > 0):
+        no("could not read a positive tracking weight off f")
+    p_c = np.array([0.5 * (1.0 - (fe[i] - f0) / (w_path * T)) for i in range(3)])
+
+    fb = f_goal(p_c)  # the tracking term vanishes here: the small weights are read without cancellation against it
+
+    def bump(block, t, j, v):
+        dd = np.zeros_like(x0)
+        dd[block * nT + t * n + j] = v
+        return float(_vec(opt.f, x0 + dd, np.concatenate([qc, np.zeros(n), np.tile(p_c, T)]))[0]) - fb
+
+    w_vel, w_acc, w_tau = bump(1, 3 % T, 1 % n, 0.5) / 0.25, bump(2, 2 % T, 2 % n, 0.5) / 0.25, bump(3, 4 % T, 3 % n, 0.5) / 0.25
+    if abs(w_acc) > 1e-12 * max(1.0, w_path) or not (w_vel >= -1e-12 and w_tau > 0):
+        no("the cost must be w_path sumsqr(p(link, Q) - goal) + w_vel sumsqr(dQ) + w_tau sumsqr(TAU) (no acceleration term, w_tau > 0)")
+    w_vel = max(w_vel, 0.0)
+    for cand in _links_to_try(robot, link):
+        if np.abs(np.asarray(robot.get_global_link_position(cand, qc)).reshape(3) - p_c).max() > 1e-8:
+            continue
+        ok = True
+        for _ in range(2):  # the whole cost at random points, as the kernels will evaluate it
+            Qv = qc[None] + rng.uniform(-0.3, 0.3, (T, n))
+            dQv, ddQv, TAUv, G = rng.normal(size=(T, n)), rng.normal(size=(T, n)), rng.normal(size=(T, n)), rng.normal(size=(T, 3))
+            pos = np.asarray(robot.get_global_link_position(cand, Qv.T)).reshape(3, T).T
+            f_model = w_path * np.sum((pos - G) ** 2) + w_vel * np.sum(dQv**2) + w_tau * np.sum(TAUv**2)
+            f_ref = float(_vec(opt.f, xvec(Qv, dQv, ddQv, TAUv), np.concatenate([qc, np.zeros(n), G.reshape(-1)]))[0])
+            ok = ok and abs(f_model - f_ref) <= 1e-9 * max(1.0, abs(f_ref))
+        if ok:
+            return TorqueSpec(robot, cand, T, dt, float(w_path), float(w_vel), float(w_tau), np.asarray(lo, float), np.asarray(up, float))
+    no("the tracking term is not sumsqr(p(link, Q) - goal) for any link of the robot")
+
+
+def probe(opt, link: Optional[str] = None):
+    """(family name, spec) of the first structured family the problem is proven to be; LoweringError (with every family's reason) if none."""
+    reasons = []
+    for family, fn in (("figure_eight", probe_figure_eight), ("torque_mpc", probe_torque_mpc), ("ik", probe_ik)):
+        try:
+            return family, fn(opt, link=link)
+        except LoweringError as e:
+            reasons.append(str(e))
+    raise LoweringError("no structured family matches: " + " | ".join(reasons))

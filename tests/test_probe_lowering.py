@@ -64,10 +64,13 @@ class ReferenceLikeOptimization:
         self.lin_eq_constraints, self.lin_ineq_constraints = _hide(opt.lin_eq_constraints), _hide(opt.lin_ineq_constraints)
         self.eq_constraints, self.ineq_constraints = _hide(opt.eq_constraints), _hide(opt.ineq_constraints)
         self.cost_terms = _hide(opt.cost_terms)
-        m = opt.models[0]
-        self.models = [types.SimpleNamespace(get_name=m.get_name, time_derivs=list(m.time_derivs), param_joints=[], urdf=_urdf_parser_py_like(m.urdf), ndof=m.ndof,
-                                             dim=m.dim, num_param_joints=0, state_name=m.state_name, state_optimized_name=m.state_optimized_name,
-                                             state_parameter_name=m.state_parameter_name)]
+        self.models = []
+        for m in opt.models:
+            ns = types.SimpleNamespace(get_name=m.get_name, time_derivs=list(m.time_derivs), dim=m.dim, state_name=m.state_name,
+                                       state_optimized_name=m.state_optimized_name, state_parameter_name=m.state_parameter_name)
+            if hasattr(m, "urdf"):  # a RobotModel; a TaskModel has no URDF (models.py:189-214)
+                ns.param_joints, ns.urdf, ns.ndof, ns.num_param_joints = [], _urdf_parser_py_like(m.urdf), m.ndof, 0
+            self.models.append(ns)
         self.calls = 0
 
     def _count(self, fn):
@@ -145,3 +148,70 @@ def test_literal_solver_subclass_runs_the_structured_kernels(hip_lib, golden_nlp
     assert sol["kuka/q"].shape == (7, 50) and sol["kuka/dq"].shape == (7, 49)
     with pytest.raises(ValueError):
         HIPSolver(ref).setup("ipopt")
+
+
+def _standins():
+    from optas_amd import solver as mirror_solver
+    from optas_amd.casadi_tape import make_solver_class
+
+    cs = types.SimpleNamespace(DM=lambda a: np.asarray(a, dtype=np.float64).reshape(-1, 1))
+    return make_solver_class(mirror_solver, cs)
+
+
+def test_torque_mpc_is_recognised_and_solved_through_the_reference_interface(hip_lib):
+    """BASELINE configs[4] (RNEA equality rows) behind the reference interface: two models (robot + task), four variable blocks, the
+    dynamics rows verified against oh_rnea; the literal Solver subclass lands on the torque kernels and reproduces the tree-matched route."""
+    from examples.torque_mpc import build_problem, figure_eight_goal
+    from optas_amd.lowering import LoweringError, TorqueSpec, match_torque_mpc
+    from optas_amd.probe_lowering import probe, probe_torque_mpc
+    from optas_amd.solver import HIPSolver as MirrorHIPSolver
+
+    T, dt = 12, 0.1
+    robot, link, opt = build_problem(T, dt, effort=60.0)
+    want = match_torque_mpc(opt)
+    ref = ReferenceLikeOptimization(opt)
+    fam, spec = probe(ref)
+    assert fam == "torque_mpc" and isinstance(spec, TorqueSpec) and (spec.link, spec.T) == (link, T)
+    assert abs(spec.dt - dt) < 1e-14 and abs(spec.w_path - want.w_path) < 1e-6 and abs(spec.w_vel - want.w_vel) < 1e-12 and abs(spec.w_tau - want.w_tau) < 1e-14
+    assert np.abs(spec.tau_lo + 60.0).max() < 1e-12 and np.abs(spec.tau_up - 60.0).max() < 1e-12
+    assert ref.calls < 80
+    qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    inputs = {"qc": qc, "dqc": np.zeros(7), "goal": figure_eight_goal(robot, link, qc, T, dt)}
+    seed = {f"{robot.get_name()}/q/x": np.tile(qc[:, None], (1, T))}
+    s = _standins()(ref).setup("hip_sqp", {"tol": 1e-6})
+    s.reset_parameters(inputs)
+    s.reset_initial_seed(seed)
+    sol = s.solve()
+    assert s.stats()["family"] == "torque_mpc" and s.did_solve()
+    m = MirrorHIPSolver(opt).setup("hip_sqp", {"tol": 1e-6})
+    m.reset_parameters(inputs)
+    m.reset_initial_seed(seed)
+    sol_m = m.solve()
+    assert abs(s.stats()["f"] - float(m.stats()["f"][0])) <= 1e-12 * abs(s.stats()["f"])
+    assert np.abs(np.asarray(sol["tau/y"]) - np.asarray(sol_m["tau/y"])).max() <= 1e-9
+    # a different dynamics row (gravity-free torque, say) keeps every label and shape: the verification must refuse it
+    h_true = opt.h
+    opt.h = lambda x, p: h_true(x, p) + 1e-3
+    with pytest.raises(LoweringError, match="rnea"):
+        probe_torque_mpc(ref)
+    opt.h = h_true
+
+
+def test_ik_is_recognised_and_solved_through_the_reference_interface(hip_lib, golden_nlp):
+    from examples.example import script_inputs, setup_solver
+    from optas_amd.lowering import IkSpec, match_ik
+    from optas_amd.probe_lowering import probe
+
+    robot, opt = setup_solver(build_only=True)
+    want = match_ik(opt)
+    ref = ReferenceLikeOptimization(opt)
+    fam, spec = probe(ref)
+    assert fam == "ik" and isinstance(spec, IkSpec) and spec.link == want.link and abs(spec.w_nominal - want.w_nominal) < 1e-12
+    assert np.abs(spec.lo - want.lo).max() < 1e-12 and np.abs(spec.up - want.up).max() < 1e-12
+    q_nominal, p_goal = script_inputs(robot)
+    s = _standins()(ref).setup("hip_sqp")
+    s.reset_parameters({"q_nominal": q_nominal, "p_goal": p_goal})
+    s.reset_initial_seed({robot.get_name() + "/q": q_nominal})  # not a variable label: zero seed, as in the reference script
+    sol = s.solve()
+    assert s.stats()["family"] == "ik" and s.did_solve()
+    assert abs(s.stats()["f"] - 0.29579887518) < 1e-8  # the SLSQP-wired known answer of example.py (tests/test_gpu_ik.py)

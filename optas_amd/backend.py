@@ -434,6 +434,17 @@ class FigureEightBackend:
             pass
 
 
+def _offsets(container) -> dict:
+    """label -> first index in vec() order; containers of the reference (sx_container.py) have no offsets(): computed from the shapes."""
+    if hasattr(container, "offsets"):
+        return container.offsets()
+    out, o = {}, 0
+    for k, v in container.items():
+        out[k] = o
+        o += int(v.shape[0]) * int(v.shape[1])
+    return out
+
+
 class MultiArmBackend:
     """Separable multi-robot problem (example/dual_arm.py): one position-only tracking handle per arm; the arms of
     all B instances are solved as independent GPU instances and stitched back into the reference's x layout."""
@@ -441,8 +452,7 @@ class MultiArmBackend:
     def __init__(self, spec, opt, max_iter=200, tol=1e-6, hessian=_lib.OH_HESSIAN_GAUSS_NEWTON):
         self.spec, self.opt = spec, opt
         self.nx, self.np_ = opt.nx, opt.np
-        self.xoff = opt.decision_variables.offsets()
-        self.poff = opt.parameters.offsets()
+        self.xoff, self.poff = _offsets(opt.decision_variables), _offsets(opt.parameters)
         self.arms = []
         for a in spec.arms:
             guards = None
@@ -493,6 +503,10 @@ class MultiArmBackend:
             iters = np.maximum(iters, r.iters)
             status = np.maximum(status, r.status)
         return BatchResult(x, f, kkt, iters, status)
+
+    def solve_ms(self) -> float:
+        """Device time of the last solve: the arms run one after the other on their own handles."""
+        return float(sum(be.timing()["solve_ms"] for _, be in self.arms))
 
     def close(self) -> None:
         for _, be in self.arms:

@@ -161,7 +161,7 @@ def make_solver_class(solver_module, cs):
         def setup(self, solver_name: str = "hip_sqp", solver_options: Optional[dict] = None):
             """Structured family first (optas_amd.probe_lowering: labels and shapes of the problem's containers, its own numeric functions
             probed and then verified -- the headline figure-eight kernels behind a real ``Optimization``), generic tape family otherwise.
-            ``solver_options["family"]`` = "figure_eight" | "torque_mpc" | "ik" | "tape" forces one route; ``"link"`` may name the tracked link."""
+            ``solver_options["family"]`` = "figure_eight" | "torque_mpc" | "ik" | "point_mass" | "multi_arm" | "tape" forces one route; ``"link"`` may name the tracked link."""
             if solver_name != "hip_sqp":
                 raise ValueError(f"unknown solver '{solver_name}' (this interface provides 'hip_sqp')")
             o = dict(solver_options or {})
@@ -169,14 +169,14 @@ def make_solver_class(solver_module, cs):
             link = o.pop("link", None)
             self._family = None
             if family != "tape":
-                from .backend import IKBackend, TorqueBackend
+                from .backend import IKBackend, MultiArmBackend, PointMassBackend, TorqueBackend
                 from .lowering import LoweringError
                 from . import probe_lowering as pl
                 from .solver import figure_eight_backend
 
-                probes = {"figure_eight": pl.probe_figure_eight, "torque_mpc": pl.probe_torque_mpc, "ik": pl.probe_ik}
+                probes = pl.PROBES
                 if family is not None and family not in probes:
-                    raise ValueError(f"unknown family '{family}' (figure_eight, torque_mpc, ik, tape)")
+                    raise ValueError(f"unknown family '{family}' ({', '.join(probes)}, tape)")
                 try:
                     fam, spec = (family, probes[family](self.opt, link=link)) if family else pl.probe(self.opt, link=link)
                     if fam == "figure_eight":
@@ -187,6 +187,11 @@ def make_solver_class(solver_module, cs):
                                                       w_vel=spec.w_vel, w_tau=spec.w_tau, tau_lo=spec.tau_lo, tau_up=spec.tau_up,
                                                       max_iter=int(o.pop("max_iter", 300)), tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)),
                                                       rho0=float(o.pop("rho0", 0.0)), mu0=float(o.pop("mu0", 0.0)))
+                    elif fam == "point_mass":
+                        self._backend = PointMassBackend(spec.T, spec.dt, spec.w_acc, spec.ylim, spec.vlim, spec.safe, max_iter=int(o.pop("max_iter", 100)),
+                                                         tol=float(o.pop("tol", 1e-8)))
+                    elif fam == "multi_arm":
+                        self._backend = MultiArmBackend(spec, self.opt, max_iter=int(o.pop("max_iter", 200)), tol=float(o.pop("tol", 1e-6)))
                     else:
                         self._backend = IKBackend(spec.robot.kinematic_chain(spec.link), spec.lo, spec.up, w_nominal=spec.w_nominal,
                                                   max_iter=int(o.pop("max_iter", 200)), tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)))

@@ -215,3 +215,59 @@ def test_ik_is_recognised_and_solved_through_the_reference_interface(hip_lib, go
     sol = s.solve()
     assert s.stats()["family"] == "ik" and s.did_solve()
     assert abs(s.stats()["f"] - 0.29579887518) < 1e-8  # the SLSQP-wired known answer of example.py (tests/test_gpu_ik.py)
+
+
+def test_point_mass_mpc_is_recognised_and_solved_through_the_reference_interface(hip_lib):
+    """BASELINE configs[2] has no robot at all: a task model, box limits, one obstacle row per knot.  Every number is read off the problem's
+    own members; the known answer of the reference-wired SLSQP run comes back through the literal Solver subclass."""
+    from examples.point_mass_mpc import Controller, obstacle_and_goal
+    from optas_amd.lowering import LoweringError, PointMassSpec, match_point_mass
+    from optas_amd.probe_lowering import probe, probe_point_mass
+
+    opt = Controller(build_only=True).optimization
+    want = match_point_mass(opt)
+    ref = ReferenceLikeOptimization(opt)
+    fam, spec = probe(ref)
+    assert fam == "point_mass" and isinstance(spec, PointMassSpec)
+    assert (spec.T, spec.names, spec.y_name, spec.dy_name) == (want.T, want.names, want.y_name, want.dy_name)
+    for a, b in ((spec.dt, want.dt), (spec.w_acc, want.w_acc), (spec.ylim, want.ylim), (spec.vlim, want.vlim), (spec.safe, want.safe)):
+        assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
+    assert ref.calls < 20
+    s = _standins()(ref).setup("hip_sqp", {"tol": 1e-9})
+    curr, dcurr = np.array([-0.45, -0.35]), np.array([0.6, 0.6])
+    obs, goal = obstacle_and_goal(2.0, curr)
+    s.reset_parameters({"curr": curr, "dcurr": dcurr, "goal": goal, "obs": obs})
+    sol = s.solve()
+    assert s.stats()["family"] == "point_mass" and s.did_solve() and abs(s.stats()["f"] - 0.1759064919) < 1e-7
+    assert np.asarray(sol["point_mass/y"]).shape == (2, 20)
+    g_true = opt.g
+    opt.g = lambda x, p: g_true(x, p) * 1.0001  # not a squared distance any more
+    with pytest.raises(LoweringError, match="inequality rows"):
+        probe_point_mass(ref)
+    opt.g = g_true
+
+
+def test_dual_arm_is_recognised_and_solved_through_the_reference_interface(hip_lib):
+    """BASELINE configs[3] as shipped (example/dual_arm.py: two robots on base frames, separable): probed one arm at a time."""
+    from examples.dual_arm import setup_solver
+    from optas_amd.lowering import MultiArmSpec, match_multi_arm
+    from optas_amd.probe_lowering import probe
+
+    QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
+    (kl, kr), opt = setup_solver(build_only=True)
+    want = match_multi_arm(opt)
+    ref = ReferenceLikeOptimization(opt)
+    fam, spec = probe(ref)
+    assert fam == "multi_arm" and isinstance(spec, MultiArmSpec) and (spec.T, len(spec.arms)) == (want.T, 2) and abs(spec.dt - want.dt) < 1e-14
+    for a, b in zip(spec.arms, want.arms):
+        assert (a.link, a.qc_name, a.q_name, a.dq_name) == (b.link, b.qc_name, b.q_name, b.dq_name)
+        assert abs(a.w_path - b.w_path) < 1e-7 * b.w_path and abs(a.w_vel - b.w_vel) < 1e-9
+        assert np.abs(a.offsets[1:] - b.offsets[1:]).max() < 1e-8
+        # base frames come out of the URDF-shaped object (add_base_frame edits the tree, models.py:323-361)
+        assert bytes(a.robot.kinematic_chain(a.link)) == bytes(b.robot.kinematic_chain(b.link))
+    s = _standins()(ref).setup("hip_sqp", {"tol": 1e-8, "max_iter": 300})
+    s.reset_parameters({"qcl": QC, "qcr": QC})
+    sol = s.solve()
+    assert s.stats()["family"] == "multi_arm" and s.did_solve()
+    assert abs(s.stats()["f"] - 0.00480191855905) <= 1e-8  # the known answer of tests/test_dual_arm.py (oracle, reference wiring)
+    assert np.asarray(sol["kukal/q"]).shape == (7, 50)

@@ -731,7 +731,16 @@ static bool solver_chain_ok(const oh_chain& c) {
 // carve the handle's device pool for B instances
 static int ensure_capacity(oh_handle* h, int B) {
   const int N = h->desc.ndof, NZ = h->desc.lock_orientation ? N - 3 : N, T = h->desc.T;
-  const int Bp = (B + 63) / 64 * 64;
+  // Row stride of the SoA stage arrays: B rounded up to whole wavefronts, plus -- for large batches -- 13 x 512 B.  With a power-of-two batch
+  // every row of every knot starts at a multiple of 2 MiB: the ~30 rows a sweep wave streams side by side then sit at the same offset of
+  // their pages, and how the channel hash happens to spread them differed from process to process (k_couple 494 or 525 us per launch,
+  // k_step 650...740, interleaved repeats on one box).  Off the power of two the spread is even: k_couple 455, k_step ~650, +3 % solves/s
+  // (any of 1...13 x 512 B does it; OH_ROW_PAD overrides, 0 restores the old layout).
+  int Bp = (B + 63) / 64 * 64;
+  if (Bp >= 4096) {
+    const char* e = getenv("OH_ROW_PAD");
+    Bp += 64 * (e ? atoi(e) : 13);
+  }
   // the sweep kernels address one slot of a stage array with a 32-bit byte offset (buffer resources, oh_kernels.hip): the largest such
   // array, T x NZ^2 doubles per instance, has to stay below 4 GiB (671 088 instances at T = 50, N = 7)
   if (h->desc.lock_orientation && ((double)T * NZ * NZ + 1.0) * (double)Bp * 8.0 >= 4294967296.0)

@@ -6,6 +6,7 @@
 //   OH_DEV                          function qualifiers (default in oh_device.h: __device__ __forceinline__)
 //   RowBuf, rowbuf, rb_ld, rb_st    row addressing of the stage arrays in the Riccati sweep
 //   oh_count(unsigned long long*)   event counter increment
+//   oh_fence(double)                the value has arrived in a register here: pins a batch of loads ahead of a branch (no-op on the host)
 #pragma once
 #include "oh_figure8.h"
 
@@ -87,6 +88,12 @@ OH_DEV void setup_unit(const FigParams& P, const FigBuffers& D, const double* __
 #ifndef OH_CHAIN
 #define OH_CHAIN(D) ((D).chain)
 #endif
+#ifndef OH_RETRACT_PREFETCH
+#define OH_RETRACT_PREFETCH 0
+#endif
+#ifndef OH_EVALB_PREFETCH_G
+#define OH_EVALB_PREFETCH_G 1
+#endif
 // Householder vectors of knot t from their packed stage array ([t][3N - 3][Bp], written by eval_unit)
 template <int N>
 OH_DEV void load_householder(const double* __restrict__ Vs, const int Bp, const int b, const int t, double (&V)[3][N]) {
@@ -106,49 +113,97 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   constexpr int NP = NZ * (NZ + 1) / 2;
   const int Bp = D.Bp;
   if (b >= D.B) return;
-  if (D.status[b] >= 0 || D.skip[b]) return;
   // Uniform slots: every running instance writes this launch's trial into `slot` and keeps its accepted
   // point in `cur` = 1 - slot, so all lanes of a wavefront touch the same arrays (full 512-B lines).  An
   // instance whose previous trial was rejected has its accepted point in `slot`: it sits this launch out
   // (skip flag) and is back in phase at the next one -- cheaper than moving its stage data.
   const int cur = 1 - slot;
-  const bool first = D.first[b] != 0;
-  // trial knot: the seed on the first evaluation, otherwise q_cur + Z_cur z (roll-out of the step k_step solved for)
+  // ONE memory round trip before the arithmetic starts: everything the lane will need is requested before any of it is looked at
+  // (status -> first -> knot data as dependent loads cost three round trips of ~1-2 us each at the start of a wave that lives ~12 us;
+  // the SQ counters showed a third of every k_evalb wave's lifetime in s_waitcnt).  Finished / skipping lanes fetch for nothing; the
+  // batch is compacted when a tenth of it has finished.
+  const int status_b = D.status[b], skip_b = D.skip[b], first_b = D.first[b];
+  const double stat_b = D.stat[b], pred_b = D.pred[b];
+  constexpr bool EARLY = MODE == EVAL_ONLY || OH_RETRACT_PREFETCH;  // the generic retraction kernel sits at the register limit: it fetches
+                                                                    // its knot data after the branch, as before
+  double Rc[9], pc[3];
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pc[i] = D.ref[(size_t)i * Bp + b];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
+  }
   double q[N], e_tgt[3] = {0.0, 0.0, 0.0};
-  if (first || MODE == EVAL_ONLY) {  // EVAL_ONLY: the retracted trial knot is already in the slot (k_retract)
+  double zs[NZ], Vc[3][N], mdlc[3 + 3 * NZ];
+  double Gpre[N];  // Lagrangian gradient of the accepted point: wanted deep inside the evaluation (exact-curvature branch), requested here
+  constexpr bool PRE_G = OH_EVALB_PREFETCH_G && MODE == EVAL_ONLY && !GUARD;
+  if constexpr (MODE == EVAL_ONLY) {  // the retracted trial knot is already in the slot (k_retract)
 #pragma unroll
     for (int j = 0; j < N; ++j) q[j] = D.q[slot][IDX(t, N, j)];
-  } else {
-    double zs[NZ];
+    if constexpr (PRE_G) {
+      if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) Gpre[k] = D.Gfull[cur][IDX(t, N, k)];
+      }
+    }
+  } else if constexpr (OH_RETRACT_PREFETCH) {  // the accepted knot, the reduced step and the model of the step (a first evaluation replaces q below: rare)
 #pragma unroll
     for (int a = 0; a < NZ; ++a) zs[a] = D.zstep[IDX(t, NZ, a)];
-    double Vc[3][N], Zc[N][NZ];
     load_householder<N>(D.Z[cur], Bp, b, t, Vc);
-    z_from_householder<N>(Vc, Zc);
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      double v = D.q[cur][IDX(t, N, j)];
+    for (int j = 0; j < N; ++j) q[j] = D.q[cur][IDX(t, N, j)];
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) v += Zc[j][a] * zs[a];
-      q[j] = v;
-    }
-    // where the linear model puts the end effector after this step: e_cur + (Jp Z)_cur z
+    for (int i = 0; i < 3 + 3 * NZ; ++i) mdlc[i] = D.mdl[cur][IDX(t, MDL_ROWS(N), i)];
+  }
+  if constexpr (EARLY) {
+    oh_fence(q[N - 1]);
+    oh_fence(Rc[8]);
+  }
+  if (status_b >= 0 || skip_b) return;
+  const bool first = first_b != 0;
+  // trial knot: the seed on the first evaluation, otherwise q_cur + Z_cur z (roll-out of the step k_step solved for)
+  if constexpr (MODE != EVAL_ONLY) {
+    if (first) {
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      double v = D.mdl[cur][IDX(t, MDL_ROWS(N), m)];
+      for (int j = 0; j < N; ++j) q[j] = D.q[slot][IDX(t, N, j)];
+    } else {
+      if constexpr (!OH_RETRACT_PREFETCH) {  // the generic kernels sit at the register limit: their knot data is fetched after the branch
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) v += D.mdl[cur][IDX(t, MDL_ROWS(N), 3 + m * NZ + a)] * zs[a];
-      e_tgt[m] = v;
+        for (int a = 0; a < NZ; ++a) zs[a] = D.zstep[IDX(t, NZ, a)];
+        load_householder<N>(D.Z[cur], Bp, b, t, Vc);
+#pragma unroll
+        for (int j = 0; j < N; ++j) q[j] = D.q[cur][IDX(t, N, j)];
+#pragma unroll
+        for (int i = 0; i < 3 + 3 * NZ; ++i) mdlc[i] = D.mdl[cur][IDX(t, MDL_ROWS(N), i)];
+      }
+      double Zc[N][NZ];
+      z_from_householder<N>(Vc, Zc);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        double v = q[j];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) v += Zc[j][a] * zs[a];
+        q[j] = v;
+      }
+      // where the linear model puts the end effector after this step: e_cur + (Jp Z)_cur z
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        double v = mdlc[m];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) v += mdlc[3 + m * NZ + a] * zs[a];
+        e_tgt[m] = v;
+      }
     }
   }
-  double Rc[9], pc[3];
+  if constexpr (!EARLY) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) pc[i] = D.ref[(size_t)i * Bp + b];
+    for (int i = 0; i < 3; ++i) pc[i] = D.ref[(size_t)i * Bp + b];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
+    for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
+  }
   double Gprev[N];
   // exact curvature: always (OH_HESSIAN_EXACT) or once the accepted point is nearly stationary (OH_HESSIAN_HYBRID)
-  bool exact = (P.hessian == OH_HESSIAN_EXACT) || (P.hessian == OH_HESSIAN_HYBRID && !first && D.stat[b] <= P.hyb_switch);
+  bool exact = (P.hessian == OH_HESSIAN_EXACT) || (P.hessian == OH_HESSIAN_HYBRID && !first && stat_b <= P.hyb_switch);
   if constexpr (GUARD) {
     // the exact block carries no curvature of the sphere rows (-s d2g, s ~ w_path): with them the exact model is worse than
     // Gauss-Newton (the oracle run crawls), so sphere-guarded problems stay on Gauss-Newton
@@ -183,14 +238,15 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
 #pragma unroll
         for (int k = m; k < N; ++k) vo[IDX(t, HV_ROWS(N), HV_OFF(N, m) + k - m)] = Vv[m][k];
     }
+    const double* Gp;  // prefetched copy (registers), or null
     OH_DEV void load_G(const double (&)[N], double (&G)[N]) const {
 #pragma unroll
-      for (int k = 0; k < N; ++k) G[k] = Gc[IDX(t, N, k)];
+      for (int k = 0; k < N; ++k) G[k] = PRE_G ? Gp[k] : Gc[IDX(t, N, k)];
     }
   };
-  const Hooks hooks{D.q[slot], D.g[slot], D.Z[slot], D.Gfull[cur], Bp, b, t};
+  const Hooks hooks{D.q[slot], D.g[slot], D.Z[slot], D.Gfull[cur], Bp, b, t, Gpre};
   double e_new[3], JZ_new[3][NZ];
-  const double tol_r = retract_tol(P, !first, D.pred[b], D.stat[b]);
+  const double tol_r = retract_tol(P, !first, pred_b, stat_b);
   if constexpr (LEAD)
     eval_knot<N, true, Hooks, MODE>(OH_CHAIN(D), P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new,
                                     D.lead[(size_t)t * Bp + b], hooks);

@@ -633,7 +633,7 @@ static int ik_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
 static int pm_prepare(oh_handle* h, int B) {
   HIPCHK(hipSetDevice(h->device));
   const int T = h->pm.T;
-  const int Bp = (B + 63) / 64 * 64;
+  const int Bp = (B + 63) / 64 * 64;  // (padding the row stride like the trajectory families do was measured: no effect, the solve is latency bound)
   const size_t rows = 2 * (size_t)(T - 1) + 4 * (size_t)T + 9 * (size_t)T + 9 * (size_t)T + 8 * (size_t)(T - 1) + 2 * (size_t)(T - 1) +
                       4 * (size_t)T + 2 * (size_t)(T - 1);
   if (Bp > h->cap_B || !h->pool) {

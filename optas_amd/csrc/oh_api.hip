@@ -508,6 +508,9 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   }
   P.nx = 4 * N * T;
   P.np = 2 * N + 3 * T;
+  P.aa_m = 3;
+  P.aa_from = 1e-1;
+  if (const char* e = getenv("OH_TQ_AA")) P.aa_m = atoi(e) < 0 ? 0 : (atoi(e) > 3 ? 3 : atoi(e));
   TqBuffers& D = h->TqD;
   if (B > h->tq_cap) {
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -517,8 +520,8 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     h->d_tq_mult = nullptr;
     h->tq_cap = 0;
     const size_t BT = (size_t)B * T;
-    const size_t nd = 2 * BT * TQ_XS + 2 * BT * TQ_SD + BT * TQ_LAM + BT * TQ_GN + BT * 4 + 11 * (size_t)B;
-    const size_t bytes = nd * sizeof(double) + (8 * (size_t)B + 16) * sizeof(int);
+    const size_t nd = 2 * BT * TQ_XS + 2 * BT * TQ_SD + BT * TQ_LAM + BT * TQ_GN + BT * 4 + 4 * BT * TQ_HS + 11 * (size_t)B;
+    const size_t bytes = nd * sizeof(double) + (10 * (size_t)B + 16) * sizeof(int);
     HIPCHK(hipMalloc(&h->tq_pool, bytes));
     HIPCHK(hipMalloc((void**)&h->d_tq_mult, sizeof(double) * BT * 2 * N));
     h->tq_cap = B;
@@ -536,11 +539,14 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     D.lam = take(BT * TQ_LAM);
     D.gains = take(BT * TQ_GN);
     D.goal = take(BT * 4);
+    D.hist = take(4 * BT * TQ_HS);
     D.f_cur = take(B); D.f_true = take(B); D.pred = take(B); D.mu = take(B); D.nun = take(B); D.rho = take(B); D.rho_next = take(B);
     D.omega = take(B); D.meas_prev = take(B); D.meas = take(B); D.stat = take(B);
     int* ip = (int*)d;
     D.cur = ip; ip += B; D.first = ip; ip += B; D.outer = ip; ip += B; D.status = ip; ip += B; D.iters = ip; ip += B; D.rejected = ip; ip += B;
     D.n_outer = ip; ip += B;
+    D.hcnt = ip; ip += B;
+    D.aa = ip; ip += B;
     D.list = ip; ip += B;
     D.n_running = ip;
     D.n_list = ip + 1;

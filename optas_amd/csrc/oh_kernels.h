@@ -74,7 +74,10 @@ struct TqParams {
   double dt, w_path, w_vel, w_tau, tol, tol_feas, rho0, mu0;
   double tau_lo[OH_MAX_CHAIN], tau_up[OH_MAX_CHAIN];
   int nx, np;
+  int aa_m;         // Anderson acceleration of the Gauss-Newton iteration: history depth (0 off, <= 3), see k_tq_step
+  double aa_from;   // ... once the reduced gradient is below this
 };
+#define TQ_HS 16    // per knot and history entry: control u (N) at 0, Gauss-Newton step du (N) at 8
 struct TqBuffers {
   int B;
   const oh_chain* chain;
@@ -87,6 +90,9 @@ struct TqBuffers {
   double *f_cur, *f_true, *pred, *mu, *nun, *rho, *rho_next, *omega, *meas_prev, *meas, *stat;  // [B]
   int *cur, *first, *outer, *status, *iters, *rejected, *n_outer;                                // [B]
   int* n_running;  // [1]
+  double* hist;    // [B][4][T][TQ_HS] ring of the last accepted control sequences and the steps taken from them (Anderson history)
+  int* hcnt;       // [B] entries appended since the history was last dropped
+  int* aa;         // [B] 1: the pending trial is the extrapolated point
   int* list;       // [B] instances still running when the list was last rebuilt (kernels walk this list: finished instances cost nothing)
   int* n_list;     // [1]
   int n_run;       // length of the list the launches below cover

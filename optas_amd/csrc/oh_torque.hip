@@ -261,6 +261,8 @@ __global__ __launch_bounds__(64) void k_tq_setup(TqParams P, TqBuffers D, const 
   D.rho_next[b] = P.rho0;
   D.omega[b] = fmax(P.tol, 1e-2);
   D.meas_prev[b] = 1e300;
+  D.hcnt[b] = 0;
+  D.aa[b] = 0;
   D.meas[b] = 0.0;
   D.stat[b] = 0.0;
   D.cur[b] = 1;  // the seed sits in slot 0 = the first "trial"
@@ -491,12 +493,27 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
   const double rho_next_in = D.rho_next[b];
   const double pred = D.pred[b];
   int iters = D.iters[b], rejected = D.rejected[b], n_outer = D.n_outer[b];
+  // Anderson acceleration (oracle/torque.py:solve_torque_lm, anderson_mix): the tracking residual does not vanish, Gauss-Newton converges
+  // linearly (rate ~0.8), and its steps are the residuals of a fixed-point iteration.  Once the reduced gradient is below aa_from every
+  // other trial is the point the last aa_m + 1 (control sequence, step) pairs extrapolate to; it is accepted if it lowers the merit at
+  // all, otherwise the history is dropped and the Levenberg-Marquardt step follows.
+  int hcnt = D.hcnt[b];
+  const bool aa_trial = D.aa[b] != 0;
+  bool aa_was = false;
   bool accept;
   if (first || outer) {
     accept = true;
     if (outer) {
       rho = rho_next_in;
       n_outer += 1;
+      hcnt = 0;  // the merit function changes
+    }
+  } else if (aa_trial) {
+    accept = isfinite(fsum) && fsum < f_cur;
+    aa_was = true;
+    if (!accept) {
+      hcnt = 0;
+      rejected += 1;
     }
   } else {
     const double ratio = (f_cur - fsum) / fmax(pred, 1e-300);
@@ -649,6 +666,7 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
 
   // forward rollout of the next trial point (or the copy of the accepted point for an outer update)
   double ndx = 0.0, ndu = 0.0;
+  const bool use_hist = do_step && P.aa_m > 0 && stat < P.aa_from;
   {
     const bool fw = do_step || do_outer;
     double xt = 0.0;  // lane c < NX: component c of the trial state
@@ -675,6 +693,11 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
         if (fw) xn[16 + c] = un;
         dus[c] = un;
         ndu = fma(du, du, ndu);
+        if (use_hist) {
+          double* hr = D.hist + (((size_t)b * 4 + (hcnt & 3)) * T + t) * TQ_HS;
+          hr[c] = xc[16 + c];
+          hr[8 + c] = du;
+        }
       }
       if (c < NX) {
         if (do_outer) xt = xcur;
@@ -690,7 +713,88 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
     ndx = group_sum(ndx);
     ndu = group_sum(ndu);
   }
+  // ---- Anderson extrapolation: replaces the trial just written -------------------------------------------------------------------------
+  bool do_aa = false;
+  if (use_hist) hcnt += 1;
+  if (P.aa_m > 0) {  // (uniform: every group of the block walks the barriers below)
+    const int h = hcnt < P.aa_m + 1 ? hcnt : P.aa_m + 1;  // entries in use, oldest first: ring slots (hcnt - h + j) & 3
+    const bool want = use_hist && h >= 2 && !aa_was;
+    double gam[3] = {0.0, 0.0, 0.0};
+    if (want) {
+      // Gram matrix of the step differences and its right-hand side: 9 sums over the T x N entries, N lanes of the group at a time
+      double G[6] = {0, 0, 0, 0, 0, 0}, r[3] = {0, 0, 0};
+      if (c < N) {
+        for (int t = 0; t < T; ++t) {
+          double F[4] = {0, 0, 0, 0};
+          for (int j = 0; j < h; ++j) F[j] = D.hist[(((size_t)b * 4 + ((hcnt - h + j) & 3)) * T + t) * TQ_HS + 8 + c];
+          double dF[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) dF[j] = (j + 1 < h) ? F[j + 1] - F[j] : 0.0;
+          const double Fl = F[h - 1];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            r[i] = fma(dF[i], Fl, r[i]);
+#pragma unroll
+            for (int j = 0; j <= i; ++j) G[tri(i, j)] = fma(dF[i], dF[j], G[tri(i, j)]);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) G[i] = group_sum(G[i]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) r[i] = group_sum(r[i]);
+      const double dmax = fmax(G[0], fmax(G[2], G[5]));
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        if (i + 1 < h) G[tri(i, i)] += 1e-10 * fmax(dmax, 1e-300);
+        else G[tri(i, i)] = 1.0;  // unused row: gamma_i = 0
+      }
+      double rd3[3];
+      if (chol_rcp<3>(G, rd3, 0.0)) {
+        fsub_rcp<3>(G, rd3, r);
+        bsub_rcp<3>(G, rd3, r);
+        gam[0] = r[0]; gam[1] = r[1]; gam[2] = r[2];
+        do_aa = isfinite(gam[0]) && isfinite(gam[1]) && isfinite(gam[2]);
+      }
+    }
+    if (__syncthreads_or(do_aa ? 1 : 0)) {
+      // open-loop rollout of the extrapolated control sequence from the fixed initial state
+      double xt = 0.0;
+      {
+        const double* x0r = D.xs + xs_off(D, T, cur, b, 0);
+        if (c < NX) xt = x0r[c < N ? c : 8 + (c - N)];
+      }
+      for (int t = 0; t < T; ++t) {
+        double* xn = D.xs + xs_off(D, T, nts, b, t);
+        if (c < N) {
+          double ua = 0.0;
+          if (do_aa) {
+            double X[4] = {0, 0, 0, 0}, F[4] = {0, 0, 0, 0};
+            for (int j = 0; j < h; ++j) {
+              const double* hr = D.hist + (((size_t)b * 4 + ((hcnt - h + j) & 3)) * T + t) * TQ_HS;
+              X[j] = hr[c];
+              F[j] = hr[8 + c];
+            }
+            ua = X[h - 1] + F[h - 1];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              if (j + 1 < h) ua = fma(-gam[j], (X[j + 1] - X[j]) + (F[j + 1] - F[j]), ua);
+            xn[16 + c] = ua;
+          }
+          dus[c] = ua;
+        }
+        if (do_aa && c < NX) xn[c < N ? c : 8 + (c - N)] = xt;
+        __syncthreads();
+        const double xo = __shfl(xt, c < N ? c + N : c, 16);
+        if (c < N) xt = fma(dt, xo, xt);
+        else if (c < NX) xt = fma(dt, dus[c - N], xt);
+        __syncthreads();
+      }
+    }
+  }
   if (run && c == 0) {
+    D.hcnt[b] = hcnt;
+    D.aa[b] = do_aa ? 1 : 0;
     D.cur[b] = cur;
     D.first[b] = 0;
     D.outer[b] = do_outer ? 1 : 0;

@@ -199,8 +199,32 @@ def costate_gradient(g, dt):
     return gu
 
 
-def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, rho0=None, mu0=0.0, verbose=False, damp_u=0.0, hess_extra=None):
-    """The state machine of csrc/oh_torque.hip in numpy (one instance)."""
+def anderson_mix(hx, hf):
+    """Anderson extrapolation from the stored (control sequence, Gauss-Newton step) pairs, oldest first (k_tq_step, csrc/oh_torque.hip):
+    x_a = x_k + f_k - sum_j gamma_j (dx_j + df_j) with gamma = argmin |f_k - dF gamma|, through the regularised normal equations
+    (the kernel factorises the <= 3 x 3 Gram matrix in registers).  None if the Gram matrix is not positive definite."""
+    F, X = np.array(hf), np.array(hx)
+    dF, dX = F[1:] - F[:-1], X[1:] - X[:-1]
+    G = dF @ dF.T
+    G = G + 1e-10 * max(float(np.max(np.diag(G))), 1e-300) * np.eye(len(dF))
+    try:
+        L = np.linalg.cholesky(G)
+    except np.linalg.LinAlgError:
+        return None
+    gam = np.linalg.solve(L.T, np.linalg.solve(L, dF @ F[-1]))
+    return X[-1] + F[-1] - gam @ (dX + dF)
+
+
+def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, rho0=None, mu0=0.0, verbose=False, damp_u=0.0, hess_extra=None,
+                    aa_m=3, aa_from=1e-1):
+    """The state machine of csrc/oh_torque.hip in numpy (one instance).
+
+    aa_m > 0: Anderson acceleration of the Gauss-Newton iteration.  The tracking residual does not vanish at the optimum, so Gauss-Newton
+    converges linearly (rate ~0.8 on the med7 problem: 43 of the 56 steps of the nominal instance go by while the objective changes in its
+    11th digit); its steps z_k = U_{k+1} - U_k are the residuals of a fixed-point iteration, and mixing the last aa_m + 1 of them (Walker & Ni
+    2011) predicts where the sequence is heading.  Once the reduced gradient is below aa_from every other trial is the extrapolated point
+    instead of the Levenberg-Marquardt step: accepted if it lowers the merit at all, otherwise the history is dropped and the plain step
+    follows.  49 -> 27 steps on the golden instances."""
     T, n, dt = prob.T, prob.n, prob.dt
     wp, wt, wv = prob.w_path, prob.w_tau, prob.w_vel
     lo, up = prob.tau_lo, prob.tau_up
@@ -235,6 +259,8 @@ def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, t
 
     mu, nun = mu0, 2.0
     iters = rejected = outers = 0
+    hx, hf = [], []  # Anderson history: accepted control sequences and the steps taken from them
+    aa_trial = aa_was = False
     first, outer = True, False
     Ut = U
     cur = None
@@ -245,10 +271,19 @@ def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, t
             lam = np.maximum(0.0, lam - rho * cur["gv"])
             rho = rho_next
             outers += 1
+            hx, hf = [], []  # the merit function changes
         f_t, g, H, gv, meas_t, traj = evalp(Ut, lam, rho)
         if first or outer:
             accept, first, outer = True, False, False
+            aa_trial = aa_was = False
+        elif aa_trial:
+            accept = bool(np.isfinite(f_t) and f_t < cur["f"])
+            aa_trial, aa_was = False, True
+            if not accept:
+                hx, hf = [], []
+                rejected += 1
         else:
+            aa_was = False
             ratio = (cur["f"] - f_t) / max(pred, 1e-300)
             accept = np.isfinite(f_t) and (ratio > 1e-4 or (pred <= 1e-15 * abs(cur["f"]) and f_t <= cur["f"] + 1e-14 * abs(cur["f"])))
             if accept:
@@ -287,6 +322,15 @@ def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, t
             mu = max(4.0 * mu, 1e-2)
         pred = 0.5 * qk + 0.5 * mu * float(np.sum(dz[:, :2 * n] ** 2)) + 0.5 * damp_u * mu * float(np.sum(dz[:, 2 * n:] ** 2))
         Ut = cur["U"] + dz[:, 2 * n:]
+        if aa_m > 0 and stat < aa_from:
+            hx.append(cur["U"].reshape(-1).copy())
+            hf.append(dz[:, 2 * n:].reshape(-1).copy())
+            hx, hf = hx[-(aa_m + 1):], hf[-(aa_m + 1):]
+            if len(hx) >= 2 and not aa_was:
+                xa = anderson_mix(hx, hf)
+                if xa is not None:
+                    Ut = xa.reshape(T, n)
+                    aa_trial = True
         iters += 1
     Q, dQ, tau = cur["traj"][:3]
     gv = np.concatenate([tau - lo, up - tau], 1)

@@ -326,6 +326,35 @@ def torque_golden(slow=True):
 
 
 
+def torque_golden_refresh_port():
+    """Re-run only the numpy port on the stored instances of torque_golden.npz (after a change to its state machine): x, f, iters, lam are
+    replaced, the independent solvers' objectives (L-BFGS-B, trust-constr: ~20 minutes to regenerate) are kept and must still agree."""
+    from oracle.problems import TorqueMPCNLP
+    from oracle.torque import TorqueProblem, solve_torque_lm
+
+    rob = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "med7.kin.json"))
+    path = os.path.join(G, "torque_golden.npz")
+    g = dict(np.load(path))
+    for tag in ("t6", "t6lim", "t30", "t30lim"):
+        lim = float(g[tag + "_lim"])
+        T = g[tag + "_goal"].shape[1]
+        prob = TorqueProblem(rob, "lbr_link_ee", T=T, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=None if lim > 1e8 else lim)
+        nlp = TorqueMPCNLP(prob)
+        for i, (qc, goal) in enumerate(zip(g[tag + "_qc"], g[tag + "_goal"])):
+            r = solve_torque_lm(prob, qc, np.zeros(7), goal)
+            assert r["status"] == 0
+            x = nlp.join(r["Q"], r["dQ"], r["U"], r["tau"])
+            k = kkt_reference_form(nlp, x, nlp.pack_p(qc, np.zeros(7), goal))
+            assert k["stationarity"] < 1e-6 and k["feasibility"] < 1e-8, k
+            for other in ("_f_lbfgs", "_f_trust_constr"):
+                fo = float(g[tag + other][i])
+                if np.isfinite(fo):
+                    assert abs(fo - r["f"]) < 1e-7 * max(1.0, r["f"]), (tag, i, other, fo, r["f"])
+            print("torque", tag, i, "port", r["f"], "was", float(g[tag + "_f"][i]), "iters", r["iters"], "was", int(g[tag + "_iters"][i]), "kkt", k["stationarity"])
+            g[tag + "_x"][i], g[tag + "_f"][i], g[tag + "_iters"][i], g[tag + "_lam"][i] = x, r["f"], r["iters"], r["lam"]
+    np.savez(path, **g)
+
+
 def fig8_perturbed_dense_golden(n=8):
     """Config 2, PERTURBED instances (the bench workload: qc0 + U(-0.1, 0.1)^7) solved by the independent dense Newton-SQP on the literal
     693-variable layout with the literal rank-3 quaternion rows (oracle.solvers.dense_sqp: SVD null space, exact Lagrangian Hessian, l1 merit
@@ -361,6 +390,9 @@ def fig8_perturbed_dense_golden(n=8):
 if __name__ == "__main__":
     if "--fig8-dense" in sys.argv:  # ~25 minutes
         fig8_perturbed_dense_golden()
+        sys.exit(0)
+    if "--torque-port" in sys.argv:
+        torque_golden_refresh_port()
         sys.exit(0)
     if "--torque" in sys.argv:  # ~20 minutes (trust-constr on the literal layout)
         torque_golden()

@@ -340,8 +340,15 @@ class FigureEightBackend:
         assert p.shape == (B, self.np_), f"p must be (B, {self.np_})"
         chunk = getattr(self, "max_batch", None)  # one oh_solve call of the locked trajectory family is bounded (optas_hip.h)
         if chunk and B > chunk:
-            parts = [self.solve(x0[i : i + chunk], p[i : i + chunk]) for i in range(0, B, chunk)]
+            # the handle only remembers its last call: multipliers and timing of every chunk are collected here and served from the cache
+            parts, lams, tms = [], [], []
+            for i in range(0, B, chunk):
+                parts.append(self.solve(x0[i : i + chunk], p[i : i + chunk]))
+                lams.append(self.multipliers(len(parts[-1].f)))
+                tms.append(self.timing())
+            self._chunked = {"B": B, "lam": np.concatenate(lams), "timing": {k: type(tms[0][k])(sum(t[k] for t in tms)) for k in tms[0]}}
             return BatchResult(*(np.concatenate([getattr(r, k) for r in parts]) for k in ("x", "f", "kkt", "iters", "status")))
+        self._chunked = None
         x = np.empty((B, self.nx))
         f = np.empty(B)
         kkt = np.empty((B, 3))
@@ -356,6 +363,7 @@ class FigureEightBackend:
     def solve_device(self, B: int, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status) -> None:
         """All arguments are _lib.DeviceBuffer (or None for optional outputs)."""
         g = lambda b: None if b is None else b.ptr
+        self._chunked = None
         _lib.check(
             _lib.load().oh_solve_device(self._h, int(B), g(d_x0), g(d_p), g(d_x), g(d_f), g(d_kkt), g(d_iters), g(d_status)),
             "oh_solve_device",
@@ -364,6 +372,11 @@ class FigureEightBackend:
     def multipliers(self, B: int) -> np.ndarray:
         """Orientation-locked family: (B, 4T) signed multipliers of the quaternion rows; with inequality rows (guards):
         (B, T, NC) multipliers >= 0 in the row order of oh_guards."""
+        ch = getattr(self, "_chunked", None)
+        if ch is not None:  # the last solve was split into several oh_solve calls
+            if int(B) != ch["B"]:
+                raise ValueError(f"multipliers({B}) after a chunked solve of {ch['B']} instances")
+            return ch["lam"]
         lam = np.empty((B, self.T, self.n_rows)) if self.guards is not None else np.empty((B, 4 * self.T))
         _lib.check(_lib.load().oh_get_multipliers(self._h, int(B), _lib._ptr(lam)), "oh_get_multipliers")
         return lam
@@ -390,6 +403,9 @@ class FigureEightBackend:
         _lib.check(_lib.load().oh_set_profiling(self._h, 1 if on else 0), "oh_set_profiling")
 
     def timing(self) -> dict:
+        ch = getattr(self, "_chunked", None)
+        if ch is not None:
+            return dict(ch["timing"])
         out = (C.c_double * 11)()
         _lib.check(_lib.load().oh_get_timing(self._h, out), "oh_get_timing")
         return {

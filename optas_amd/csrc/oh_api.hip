@@ -1096,7 +1096,9 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
         tail_done = true;
         break;
       }
-      if (h->compaction && h->compact_carry && oh_eval_is_split() && h->P.lock && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
+      // (k_carry_* park 22 per-instance scalars in the first rows of the spare Dr slot: T x NZ(NZ+1)/2 rows must hold them)
+      const bool carry_fits = (size_t)h->desc.T * ((N - 3) * (N - 2) / 2) >= 22;
+      if (h->compaction && h->compact_carry && carry_fits && oh_eval_is_split() && h->P.lock && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
         carry_pending = nrun;  // done after the next k_retract
       } else if (h->compaction && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
         // restart compaction: the survivors' accepted knots (and, with inequality rows, their multipliers and outer-loop state) are laid

@@ -613,6 +613,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   const unsigned oG = lb + (cur ? (unsigned)((const char*)D.gt[1] - (const char*)D.gt[0]) : 0u);
   double stat = 0.0;
   double S[NP], rd[NZ], rn[NZ];
+  bool factored = false;
   for (int attempt = 0; attempt < 40; ++attempt) {
     bool ok = true;
     stat = 0.0;
@@ -672,10 +673,18 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       }
     }
     ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
-    if (ok) break;
+    if (ok) {
+      factored = true;
+      break;
+    }
     mu = fmax(4.0 * mu, 1e-2);
   }
   D.stat[b] = stat;
+  if (!(stat == stat) || !factored) {  // NaN in the reduced gradient, or no damping (up to 4^40) made the reduced Hessian factorisable
+    D.status[b] = OH_STATUS_NUMERICAL;
+    D.mu[b] = mu;
+    return false;
+  }
   const double feas_cur = D.feas[b];
   if constexpr (GUARD) {
     const GuardBuffers& GB = *GBp;
@@ -717,10 +726,6 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   if (iters >= P.max_iter) {
     D.status[b] = OH_STATUS_MAX_ITER;
     D.mu[b] = mu;
-    return false;
-  }
-  if (!(stat == stat)) {
-    D.status[b] = OH_STATUS_NUMERICAL;
     return false;
   }
 

@@ -156,7 +156,12 @@ class _LeadAdapter:
         qc = p[:, off[sp.qc_name] : off[sp.qc_name] + sp.robot.ndof]
         qp = p[:, off[sp.lead["qp"]] : off[sp.lead["qp"]] + T]
         dqp = p[:, off[sp.lead["dqp"]] : off[sp.lead["dqp"]] + T - 1]
-        pk = np.ascontiguousarray(np.concatenate([qc[:, sp.lead["opt"]], qc[:, [sp.lead["par"]]], qp], axis=1))
+        # the kernels eliminate knots 0 and 1 at the fixed configuration qc (q_0 = qc, dq_0 = 0): their lead angles are taken to be qc's
+        lead_c = qc[:, [sp.lead["par"]]]
+        if np.abs(qp[:, :2] - lead_c).max() > 1e-12:
+            raise ValueError(f"'{sp.lead['qp']}': the parameterised joint must sit at its value in '{sp.qc_name}' on the first two knots "
+                             "(the fixed knots of the problem)")
+        pk = np.ascontiguousarray(np.concatenate([qc[:, sp.lead["opt"]], lead_c, qp], axis=1))
         r = self.be.solve(x0, pk)
         r.f = r.f + sp.w_vel * np.sum(dqp * dqp, axis=1)
         return r

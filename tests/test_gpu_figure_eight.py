@@ -348,3 +348,26 @@ def test_end_game_step_counts_equal_the_numpy_port_exactly(hip_lib, nlp, tail, m
         assert int(res.iters[b]) == s["iters"], (b, res.iters[b], s["iters"])
         assert abs(res.f[b] - s["f"]) <= 1e-11 * abs(s["f"])
     be.close()
+
+
+def test_chunked_solve_keeps_multipliers_and_timing_of_every_chunk(hip_lib, nlp):
+    """A batch beyond the per-call bound is split into several oh_solve calls (backend.py); the handle only remembers the last one, so the
+    backend collects multipliers and timing per chunk (round-1 advisor finding)."""
+    robot = RobotModel(urdf_filename=KUKA_KIN)
+    be = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)
+    rng = np.random.default_rng(SEED + 51)
+    B = 150
+    qc = QC0 + rng.uniform(-0.1, 0.1, (B, 7))
+    x0 = np.zeros((B, nlp.nx))
+    x0[:, : 7 * 50] = np.tile(qc, (1, 50))
+    whole = be.solve(x0, qc)
+    lam_whole, tm_whole = be.multipliers(B), be.timing()
+    be.max_batch = 64
+    parts = be.solve(x0, qc)
+    lam_parts, tm_parts = be.multipliers(B), be.timing()
+    assert np.array_equal(whole.x, parts.x) and np.array_equal(whole.iters, parts.iters)  # an instance's iterates do not depend on the batch
+    assert lam_parts.shape == lam_whole.shape and np.array_equal(lam_parts, lam_whole)
+    assert tm_parts["instance_launches"] + tm_parts["tail_iterations"] >= tm_whole["instance_launches"] + tm_whole["tail_iterations"] > 0
+    with pytest.raises(ValueError):
+        be.multipliers(64)
+    be.close()

@@ -371,3 +371,22 @@ def test_chunked_solve_keeps_multipliers_and_timing_of_every_chunk(hip_lib, nlp)
     with pytest.raises(ValueError):
         be.multipliers(64)
     be.close()
+
+
+def test_row_stride_padding_is_invisible(hip_lib, nlp, monkeypatch):
+    """Batches of 4096 and more get a row stride off the power of two: a layout choice, not a numerical one."""
+    robot = RobotModel(urdf_filename=KUKA_KIN)
+    rng = np.random.default_rng(SEED + 52)
+    B = 4096
+    qc = QC0 + rng.uniform(-0.1, 0.1, (B, 7))
+    x0 = np.zeros((B, nlp.nx))
+    x0[:, : 7 * 50] = np.tile(qc, (1, 50))
+    out = []
+    for pad in ("0", "13", "5"):
+        monkeypatch.setenv("OH_ROW_PAD", pad)
+        be = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)
+        out.append((be.solve(x0, qc), be.multipliers(B)))
+        be.close()
+    for r, lam in out[1:]:
+        assert np.array_equal(r.x, out[0][0].x) and np.array_equal(r.iters, out[0][0].iters) and np.array_equal(lam, out[0][1])
+    assert (out[0][0].status == 0).all()

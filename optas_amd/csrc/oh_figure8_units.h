@@ -20,25 +20,35 @@
 // Figure-eight family.  N = ndof (chain covers all joints in order), NZ = N-3 (orientation locked).
 // ---------------------------------------------------------------------------------------------
 
-// per-instance setup: references from qc, fixed knots, seed -> slot 0, solver state.
+// setup, one lane per (instance, knot): every lane lays down its knot of the seed (slot 0) with q_0 = q_1 = qc imposed; the lane of knot 0
+// also computes the references from qc and resets the solver state.  (Round 1 had one lane per instance walk all T knots: 40 us of a
+// 0.38 ms single-instance solve.)
 template <int N>
-OH_DEV void setup_unit(const FigParams& P, const FigBuffers& D, const double* __restrict__ x0, const double* __restrict__ pin, const int b) {
+OH_DEV void setup_unit(const FigParams& P, const FigBuffers& D, const double* __restrict__ x0, const double* __restrict__ pin, const int b, const int tt) {
   const int Bp = D.Bp;
   if (b >= D.B) {
-    if (b < Bp) D.status[b] = OH_STATUS_CONVERGED;  // padding lanes never run
+    if (b < Bp && tt == 0) D.status[b] = OH_STATUS_CONVERGED;  // padding lanes never run
     return;
   }
   const oh_chain* ch = D.chain;
   double qc[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) qc[j] = pin[(size_t)b * P.np + j];
+  // knots: slot 0 holds the seed with q_0 = q_1 = qc imposed (linear rows eliminated, see DESIGN.md)
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double v = (tt < P.t0) ? qc[j] : x0[(size_t)b * P.nx + (size_t)tt * N + j];
+    D.q[0][IDX(tt, N, j)] = v;
+    D.q[1][IDX(tt, N, j)] = (tt < P.t0) ? qc[j] : 0.0;
+  }
+  // p = [qc of the optimised joints (N); lead angle of qc; lead angle of every knot (T)]
+  if (ch->has_lead) D.lead[(size_t)tt * Bp + b] = pin[(size_t)b * P.np + N + 1 + tt];
+  if (tt != 0) return;
   double R[9], p[3], z[N][3], pj[N][3];
   if (ch->has_lead) {
-    // p = [qc of the optimised joints (N); lead angle of qc; lead angle of every knot (T)]
     double Rb[9], pb[3];
     lead_base(ch, pin[(size_t)b * P.np + N], Rb, pb);
     fk_chain<N, true>(ch, qc, R, p, z, pj, Rb, pb);
-    for (int tt = 0; tt < P.T; ++tt) D.lead[(size_t)tt * Bp + b] = pin[(size_t)b * P.np + N + 1 + tt];
   } else {
     fk_chain<N>(ch, qc, R, p, z, pj);
   }
@@ -52,20 +62,11 @@ OH_DEV void setup_unit(const FigParams& P, const FigBuffers& D, const double* __
   for (int i = 0; i < 9; ++i) D.ref[(size_t)(3 + i) * Bp + b] = Re[i];
   // constant cost of the fixed knots t=0,1 (q_0 = q_1 = qc): w * ||Rc local_t||^2
   double fconst = 0.0;
-  for (int tt = 0; tt < P.t0 && tt < P.T; ++tt) {
-    double l[3] = {P.local_path[3 * tt], P.local_path[3 * tt + 1], P.local_path[3 * tt + 2]};
+  for (int tf = 0; tf < P.t0 && tf < P.T; ++tf) {
+    double l[3] = {P.local_path[3 * tf], P.local_path[3 * tf + 1], P.local_path[3 * tf + 2]};
     fconst += P.w_path * dot3(l, l);  // Rc orthonormal
   }
   D.fconst[b] = fconst;
-  // knots: slot 0 holds the seed with q_0 = q_1 = qc imposed (linear rows eliminated, see DESIGN.md)
-  for (int tt = 0; tt < P.T; ++tt) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const double v = (tt < P.t0) ? qc[j] : x0[(size_t)b * P.nx + (size_t)tt * N + j];
-      D.q[0][IDX(tt, N, j)] = v;
-      D.q[1][IDX(tt, N, j)] = (tt < P.t0) ? qc[j] : 0.0;
-    }
-  }
   D.cur[b] = 1;  // trial slot of launch 0 is slot 0
   D.first[b] = 1;
   D.skip[b] = 0;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_rnea(const oh_dynamics* __restrict__ dy
 
 template <int N>
 __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const double* __restrict__ x0, const double* __restrict__ pin) {
-  setup_unit<N>(P, D, x0, pin, blockIdx.x * blockDim.x + threadIdx.x);
+  setup_unit<N>(P, D, x0, pin, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
 }
 // Blocks per CU of k_eval: with the six-row retraction the kernel needs ~360 live registers in its loop; at 2 waves/SIMD (256) it
 // spills 99 of them and runs 10 % slower than at 1 wave/SIMD with none (A/B on one box: 64.1 vs 57.8 ms per bench step).
@@ -505,7 +505,8 @@ bool oh_launch_rnea(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, int n,
 }
 template <int N>
 static void launch_setup_t(hipStream_t s, const FigParams& P, const FigBuffers& D, const double* x0, const double* p) {
-  hipLaunchKernelGGL(k_setup<N>, dim3(D.Bp / 64), dim3(64), 0, s, P, D, x0, p);
+  // (instances, knots); the last wavefront's padding lanes up to a multiple of 64 are marked finished
+  hipLaunchKernelGGL(k_setup<N>, dim3((D.B + 63) / 64, P.T), dim3(64), 0, s, P, D, x0, p);
 }
 template <int N>
 static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot, int part) {

@@ -72,7 +72,7 @@ void carve(Workspace& w, const oh_problem_desc& d, const oh_chain* chain) {
 template <int N>
 void solve_one(const FigParams& P, Workspace& w, const double* x0, const double* p, double* x, double* f, double* kkt, int* iters, int* status) {
   const FigBuffers& D = w.D;
-  setup_unit<N>(P, D, x0, p, 0);
+  for (int tt = P.T - 1; tt >= 0; --tt) setup_unit<N>(P, D, x0, p, 0, tt);
   const int hard_cap = 2 * P.max_iter + 42;
   for (int it = 0; it < hard_cap && D.status[0] < 0; ++it) {
     const int slot = it & 1;

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "oh_kernels.h"
@@ -766,6 +767,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   const size_t per_t = (size_t)T * Bp;
   size_t nd = 0;  // doubles
   nd += 2 * per_q + 2 * per_Z + 2 * per_Dr + 2 * per_q /*g*/ + 4 * per_t /*phi,cv*/;
+  nd += 3 * per_q;  // q_spare, G_spare
   nd += 2 * per_q /*Gfull*/ + (size_t)T * NZ * NZ * Bp + (size_t)T * NZ * Bp;
   nd += 2 * (size_t)T * (3 + 3 * NZ) * Bp;  // mdl
   nd += 2 * (size_t)T * NZ * NZ * Bp + 2 * (size_t)T * NZ * Bp + 2 * per_t + (size_t)T * NZ * Bp;  // E, gt, merit, zstep
@@ -792,6 +794,8 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.Bp = Bp;
   D.chain = h->d_chain;
   for (int s = 0; s < 2; ++s) D.q[s] = take(per_q);
+  for (int s = 0; s < 2; ++s) D.q_spare[s] = take(per_q);
+  D.G_spare = take(per_q);
   for (int s = 0; s < 2; ++s) D.Z[s] = take(per_Z);
   for (int s = 0; s < 2; ++s) D.Dr[s] = take(per_Dr);
   for (int s = 0; s < 2; ++s) D.g[s] = take(per_q);
@@ -1057,6 +1061,10 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       oh_launch_scan_running(s, h->D, h->compact_sort);
       oh_launch_carry(s, N, h->P, h->D, 0, 0, slot);
       oh_launch_carry(s, N, h->P, h->D, 1, carry_pending, slot);
+      // the knots were laid down densely in the spare arrays: they become q[] / Gfull[] for the launches that follow (no copy back)
+      std::swap(h->D.q[slot], h->D.q_spare[0]);
+      std::swap(h->D.q[1 - slot], h->D.q_spare[1]);
+      if (h->P.hessian != OH_HESSIAN_GAUSS_NEWTON) std::swap(h->D.Gfull[1 - slot], h->D.G_spare);
       h->D.B = carry_pending;
       carry_pending = 0;
       ++compactions;

@@ -419,9 +419,9 @@ __global__ __launch_bounds__(256) void k_carry_gather(FigParams P, FigBuffers D,
   if (nb < 0) return;
   const bool restart = D.skip[b] != 0 || D.first[b] != 0;
   const int cur = restart ? slot : 1 - slot;
-  double* __restrict__ t_trial = D.Z[0];                                // scratch rows [t][0..N)
-  double* __restrict__ t_cur = D.Z[0] + (size_t)P.T * N * Bp;           // scratch rows (needs 2 N <= 3 N - 3)
-  double* __restrict__ t_G = D.Z[1];
+  double* __restrict__ t_trial = D.q_spare[0];  // the host swaps these with q[slot], q[1 - slot], Gfull[1 - slot] after the launch
+  double* __restrict__ t_cur = D.q_spare[1];
+  double* __restrict__ t_G = D.G_spare;
   double* __restrict__ ts = D.Dr[1];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -447,20 +447,10 @@ __global__ __launch_bounds__(256) void k_carry_gather(FigParams P, FigBuffers D,
 template <int N>
 __global__ __launch_bounds__(256) void k_carry_scatter(FigParams P, FigBuffers D, int Bnew, const int slot) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
   const int Bp = D.Bp;
   if (b >= Bnew) return;
-  const double* __restrict__ t_trial = D.Z[0];
-  const double* __restrict__ t_cur = D.Z[0] + (size_t)P.T * N * Bp;
-  const double* __restrict__ t_G = D.Z[1];
   const double* __restrict__ ts = D.Dr[1];
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    D.q[slot][IDX(t, N, j)] = t_trial[IDX(t, N, j)];
-    D.q[1 - slot][IDX(t, N, j)] = t_cur[IDX(t, N, j)];
-    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) D.Gfull[1 - slot][IDX(t, N, j)] = t_G[IDX(t, N, j)];
-  }
-  if (t == 0) {
+  {  // per-instance scalars only: the knots stay where k_carry_gather put them
 #pragma unroll
     for (int i = 0; i < 12; ++i) D.ref[(size_t)i * Bp + b] = ts[(size_t)i * Bp + b];
     const int flags = (int)ts[(size_t)21 * Bp + b];
@@ -522,7 +512,7 @@ static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D
 template <int N>
 static void launch_carry_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {
   if (phase == 0) hipLaunchKernelGGL(k_carry_gather<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, slot);
-  else hipLaunchKernelGGL(k_carry_scatter<N>, dim3((Bnew + 255) / 256, P.T), dim3(256), 0, s, P, D, Bnew, slot);
+  else hipLaunchKernelGGL(k_carry_scatter<N>, dim3((Bnew + 255) / 256), dim3(256), 0, s, P, D, Bnew, slot);
 }
 template <int N>
 static void launch_couple_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {

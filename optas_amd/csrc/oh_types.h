@@ -62,6 +62,8 @@ struct FigBuffers {
   int B, Bp;
   const oh_chain* chain;  // device copy of the kinematic constants
   double* q[2];           // [slot][T][N][Bp]      knots: current / trial
+  double* q_spare[2];     // [T][N][Bp] x 2     where a compaction lays the survivors' knots down; swapped with q[] afterwards (no copy back)
+  double* G_spare;        // [T][N][Bp]         same for the Lagrangian gradient of the accepted point
   double* Z[2];           // [slot][T][3N-3][Bp]   Householder vectors of the null-space basis of the orientation rows (Z is rebuilt from them)
   double* Dr[2];          // [slot][T][NZ(NZ+1)/2][Bp] reduced Hessian block Z^T W Z (packed lower)
   double* g[2];           // [slot][T][N][Bp]      tracking gradient

@@ -8,6 +8,6 @@ python - "$OUT" <<'PY'
 import sys, glob, sqlite3
 c = sqlite3.connect(glob.glob(sys.argv[1] + "/trace/**/*.db", recursive=True)[0])
 for name, calls, tot, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-    print(name[:60], calls, round(avg / 1e3, 2), "us avg", round(pct, 1), "%")
+    print(name[:60], calls, round(avg, 2), "us avg", round(pct, 1), "%")  # the top_kernels view is in microseconds
 PY
 tail -3 $OUT/lat.log

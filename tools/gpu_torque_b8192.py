@@ -7,7 +7,7 @@ import optas_amd
 from optas_amd.backend import TorqueBackend
 link = "lbr_link_ee"
 robot = optas_amd.RobotModel.builtin("med7")
-T, B = 30, 8192
+T, B = 30, int(os.environ.get("TQ_B", "8192"))
 rng = np.random.default_rng(20260927)
 qn = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
 qc = qn[None] + rng.uniform(-0.1, 0.1, (B, 7))

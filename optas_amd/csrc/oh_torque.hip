@@ -538,11 +538,22 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
   const int nts = 1 - cur;  // slot of the next trial
 
   // stationarity of the accepted point: gradient of the rolled-out objective w.r.t. u_t by the costate recursion
+  // (the serial loops of this kernel walk the T knots in dependent chains: whatever a knot needs from memory is requested one knot
+  // ahead, otherwise every knot costs a memory round trip -- at small batches the kernel IS those round trips: 230-350 us per launch)
   double lamc = 0.0, stat = 0.0;
+  double gx_n, gu_n;
+  {
+    const double* sr = D.st + st_off(D, T, cur, b, T - 1);
+    gx_n = c < NX ? sr[231 + c] : 0.0;
+    gu_n = (c >= N && c < NX) ? sr[231 + NX + (c - N)] : 0.0;
+  }
   for (int t = T - 1; t >= 0; --t) {
-    const double* sr = D.st + st_off(D, T, cur, b, t);
-    const double gx = c < NX ? sr[231 + c] : 0.0;
-    const double gu = (c >= N && c < NX) ? sr[231 + NX + (c - N)] : 0.0;
+    const double gx = gx_n, gu = gu_n;
+    if (t > 0) {
+      const double* sr = D.st + st_off(D, T, cur, b, t - 1);
+      gx_n = c < NX ? sr[231 + c] : 0.0;
+      gu_n = (c >= N && c < NX) ? sr[231 + NX + (c - N)] : 0.0;
+    }
     if (c >= N && c < NX) stat = fmax(stat, fabs(fma(dt, lamc, gu)));
     const double lq = __shfl(lamc, c >= N ? c - N : c, 16);
     lamc = c < N ? gx + lamc : gx + fma(dt, lq, lamc);
@@ -583,10 +594,24 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
     pv[c] = 0.0;
   }
   __syncthreads();
+  constexpr int NREC = (NH + NZ + 15) / 16;  // values of a stage record per lane
+  double hn[NREC];
+  if (do_step) {
+    const double* sr = D.st + st_off(D, T, cur, b, T - 1);
+#pragma unroll
+    for (int k = 0; k < NREC; ++k) hn[k] = (c + 16 * k < NH + NZ) ? sr[c + 16 * k] : 0.0;
+  }
   for (int t = T - 1; t >= 0; --t) {
-    const double* sr = D.st + st_off(D, T, cur, b, t);
-    if (do_step)
-      for (int i = c; i < NH + NZ; i += 16) Hs[i] = sr[i];
+    if (do_step) {
+#pragma unroll
+      for (int k = 0; k < NREC; ++k)
+        if (c + 16 * k < NH + NZ) Hs[c + 16 * k] = hn[k];
+      if (t > 0) {
+        const double* sr = D.st + st_off(D, T, cur, b, t - 1);
+#pragma unroll
+        for (int k = 0; k < NREC; ++k) hn[k] = (c + 16 * k < NH + NZ) ? sr[c + 16 * k] : 0.0;
+      }
+    }
     __syncthreads();
     double qxx[NX], qux[N], kc[N], Quu[NU], rd[N], kk[N], qu[N];
     double qx = 0.0;
@@ -674,28 +699,46 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
       const double* x0r = D.xs + xs_off(D, T, cur, b, 0);
       if (c < NX) xt = x0r[c < N ? c : 8 + (c - N)];
     }
-    for (int t = 0; t < T; ++t) {  // every group runs the loop (uniform barriers); only groups with fw touch memory
+    // state, control and gains of the next knot are in flight while this one is rolled out
+    double xcur_n = 0.0, ucur_n = 0.0, gk_n[NX + 1];
+    auto fetch_knot = [&](const int t) {
       const double* xc = D.xs + xs_off(D, T, cur, b, t);
+      xcur_n = c < NX ? xc[c < N ? c : 8 + (c - N)] : 0.0;
+      if (c < N) {
+        ucur_n = xc[16 + c];
+        if (do_step) {
+          const double* gn = D.gains + ((size_t)b * T + t) * TQ_GN;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) gk_n[j] = gn[j * N + c];
+          gk_n[NX] = gn[NX * N + c];
+        }
+      }
+    };
+    fetch_knot(0);
+    for (int t = 0; t < T; ++t) {  // every group runs the loop (uniform barriers); only groups with fw touch memory
       double* xn = D.xs + xs_off(D, T, nts, b, t);
-      const double xcur = c < NX ? xc[c < N ? c : 8 + (c - N)] : 0.0;
+      const double xcur = xcur_n, ucur = ucur_n;
+      double gk[NX + 1];
+#pragma unroll
+      for (int j = 0; j <= NX; ++j) gk[j] = gk_n[j];
+      if (t + 1 < T) fetch_knot(t + 1);
       const double dx = do_step ? xt - xcur : 0.0;
       if (c < NX) dxs[c] = dx;
       __syncthreads();
       if (c < N) {
         double du = 0.0;
         if (do_step) {
-          const double* gn = D.gains + ((size_t)b * T + t) * TQ_GN;
-          du = -gn[NX * N + c];
+          du = -gk[NX];
 #pragma unroll
-          for (int j = 0; j < NX; ++j) du = fma(-gn[j * N + c], dxs[j], du);
+          for (int j = 0; j < NX; ++j) du = fma(-gk[j], dxs[j], du);
         }
-        const double un = xc[16 + c] + du;
+        const double un = ucur + du;
         if (fw) xn[16 + c] = un;
         dus[c] = un;
         ndu = fma(du, du, ndu);
         if (use_hist) {
           double* hr = D.hist + (((size_t)b * 4 + (hcnt & 3)) * T + t) * TQ_HS;
-          hr[c] = xc[16 + c];
+          hr[c] = ucur;
           hr[8 + c] = du;
         }
       }

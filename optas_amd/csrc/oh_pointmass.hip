@@ -79,20 +79,40 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
     }
   }
 
+  struct Stage {
+    double x[4], s[9], l[9], a[2], g[2], o[2];
+  };
+  auto load_stage = [&](const int t, const bool with_goal) {
+    Stage r;
+    for (int j = 0; j < 4; ++j) r.x[j] = X_[PIDX(4 * t + j)];
+    for (int i = 0; i < 9; ++i) { r.s[i] = S_[PIDX(9 * t + i)]; r.l[i] = L_[PIDX(9 * t + i)]; }
+    r.a[0] = r.a[1] = 0.0;
+    if (t < T - 1) { r.a[0] = A_[PIDX(2 * t)]; r.a[1] = A_[PIDX(2 * t + 1)]; }
+    r.g[0] = r.g[1] = 0.0;
+    if (with_goal) { r.g[0] = goal[2 * t]; r.g[1] = goal[2 * t + 1]; }
+    r.o[0] = obs[2 * t]; r.o[1] = obs[2 * t + 1];
+    return r;
+  };
   int status = OH_STATUS_MAX_ITER, it = 0;
   double stat = 0.0, feas = 0.0, compl_ = 0.0, fval = 0.0;
   for (it = 0; it <= P.max_iter; ++it) {
     // ---- backward pass: residuals (adjoint) and Riccati recursion -----------------------------------------------
     double Pm[16], pv[4], padj[4];
     stat = 0.0; feas = 0.0; compl_ = 0.0; fval = 0.0;
+    // every sweep below walks the knots in a dependent chain while what it reads depends on the knot alone: the next knot's values are
+    // requested before this one's arithmetic (otherwise each of the 3 x T knot steps of an iteration is a memory round trip: the whole
+    // solve was 7.2 ms for any batch up to ~16 k instances)
+    Stage nx_ = load_stage(T - 1, true);
     for (int t = T - 1; t >= 0; --t) {
+      const Stage st = nx_;
+      if (t > 0) nx_ = load_stage(t - 1, true);
       double x[4], c[9], jx, jy, s[9], lam[9];
-      for (int j = 0; j < 4; ++j) x[j] = X_[PIDX(4 * t + j)];
-      pm_cons(P, x, obs[2 * t], obs[2 * t + 1], c, jx, jy);
-      for (int i = 0; i < 9; ++i) { s[i] = S_[PIDX(9 * t + i)]; lam[i] = L_[PIDX(9 * t + i)]; }
+      for (int j = 0; j < 4; ++j) x[j] = st.x[j];
+      pm_cons(P, x, st.o[0], st.o[1], c, jx, jy);
+      for (int i = 0; i < 9; ++i) { s[i] = st.s[i]; lam[i] = st.l[i]; }
       const double wt = (P.final_only && t < T - 1) ? 0.0 : 1.0;  // tracking on every knot (MPC) or on the last one only (planner)
-      const double gx[4] = {-2.0 * wt * (goal[2 * t] - x[0]), -2.0 * wt * (goal[2 * t + 1] - x[1]), 2.0 * P.w_vel * x[2], 2.0 * P.w_vel * x[3]};
-      fval += wt * ((goal[2 * t] - x[0]) * (goal[2 * t] - x[0]) + (goal[2 * t + 1] - x[1]) * (goal[2 * t + 1] - x[1])) +
+      const double gx[4] = {-2.0 * wt * (st.g[0] - x[0]), -2.0 * wt * (st.g[1] - x[1]), 2.0 * P.w_vel * x[2], 2.0 * P.w_vel * x[3]};
+      fval += wt * ((st.g[0] - x[0]) * (st.g[0] - x[0]) + (st.g[1] - x[1]) * (st.g[1] - x[1])) +
               P.w_vel * (x[2] * x[2] + x[3] * x[3]);
       double rc[9], sig[9], wq[9], jl[4], jq[4];
       for (int i = 0; i < 9; ++i) {
@@ -119,7 +139,7 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
         continue;
       }
       // here Pm, pv, padj belong to stage t+1; controls a_t act between t and t+1
-      const double a0 = A_[PIDX(2 * t)], a1 = A_[PIDX(2 * t + 1)];
+      const double a0 = st.a[0], a1 = st.a[1];
       fval += w * (a0 * a0 + a1 * a1);
       // control gradient of the Lagrangian: 2 w a + B^T padj, B^T z = dt (z2, z3)
       const bool pinned = P.fix_vf && t == T - 2;  // a_{T-2} = -v_{T-2} / dt is a function of the state, not a free control
@@ -211,14 +231,29 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
     {
       double dx[4] = {0, 0, 0, 0};
       for (int j = 0; j < 4; ++j) dX_[PIDX(j)] = 0.0;
+      struct Gain {
+        double K[8], k[2];
+      };
+      auto load_gain = [&](const int t) {
+        Gain r;
+        for (int j = 0; j < 8; ++j) r.K[j] = t < T - 1 ? K_[PIDX(8 * t + j)] : 0.0;
+        r.k[0] = t < T - 1 ? k_[PIDX(2 * t)] : 0.0;
+        r.k[1] = t < T - 1 ? k_[PIDX(2 * t + 1)] : 0.0;
+        return r;
+      };
+      Stage nx1 = load_stage(0, false);
+      Gain ng1 = load_gain(0);
       for (int t = 0; t < T; ++t) {
+        const Stage st = nx1;
+        const Gain gn = ng1;
+        if (t + 1 < T) { nx1 = load_stage(t + 1, false); ng1 = load_gain(t + 1); }
         if (t >= 1) {
           double x[4], c[9], jx, jy, d[9];
-          for (int j = 0; j < 4; ++j) x[j] = X_[PIDX(4 * t + j)];
-          pm_cons(P, x, obs[2 * t], obs[2 * t + 1], c, jx, jy);
+          for (int j = 0; j < 4; ++j) x[j] = st.x[j];
+          pm_cons(P, x, st.o[0], st.o[1], c, jx, jy);
           pm_Jv(dx, jx, jy, d);
           for (int i = 0; i < 9; ++i) {
-            const double s = S_[PIDX(9 * t + i)], lam = L_[PIDX(9 * t + i)];
+            const double s = st.s[i], lam = st.l[i];
             const double ds = d[i] + (c[i] - s);
             const double dl = (mu / s - lam) - (lam / s) * ds;
             if (ds < 0.0) ap = fmin(ap, -0.995 * s / ds);
@@ -226,8 +261,8 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
           }
         }
         if (t < T - 1) {
-          double da0 = k_[PIDX(2 * t)], da1 = k_[PIDX(2 * t + 1)];
-          for (int j = 0; j < 4; ++j) { da0 += K_[PIDX(8 * t + j)] * dx[j]; da1 += K_[PIDX(8 * t + 4 + j)] * dx[j]; }
+          double da0 = gn.k[0], da1 = gn.k[1];
+          for (int j = 0; j < 4; ++j) { da0 += gn.K[j] * dx[j]; da1 += gn.K[4 + j] * dx[j]; }
           dA_[PIDX(2 * t)] = da0; dA_[PIDX(2 * t + 1)] = da1;
           const double n0 = dx[0] + dt * dx[2], n1 = dx[1] + dt * dx[3], n2 = dx[2] + dt * da0, n3 = dx[3] + dt * da1;
           dx[0] = n0; dx[1] = n1; dx[2] = n2; dx[3] = n3;
@@ -239,14 +274,29 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
     double gap = 0.0;
     {
       double xn[4] = {pb[0], pb[1], pb[2], pb[3]};
+      struct Delta {
+        double dx[4], da[2];
+      };
+      auto load_delta = [&](const int t) {
+        Delta r;
+        for (int j = 0; j < 4; ++j) r.dx[j] = dX_[PIDX(4 * t + j)];
+        r.da[0] = t < T - 1 ? dA_[PIDX(2 * t)] : 0.0;
+        r.da[1] = t < T - 1 ? dA_[PIDX(2 * t + 1)] : 0.0;
+        return r;
+      };
+      Stage nx2 = load_stage(0, false);
+      Delta nd2 = load_delta(0);
       for (int t = 0; t < T; ++t) {
+        const Stage st = nx2;
+        const Delta dl_ = nd2;
+        if (t + 1 < T) { nx2 = load_stage(t + 1, false); nd2 = load_delta(t + 1); }
         if (t >= 1) {
           double x[4], dx[4], c[9], jx, jy, d[9];
-          for (int j = 0; j < 4; ++j) { x[j] = X_[PIDX(4 * t + j)]; dx[j] = dX_[PIDX(4 * t + j)]; }
-          pm_cons(P, x, obs[2 * t], obs[2 * t + 1], c, jx, jy);
+          for (int j = 0; j < 4; ++j) { x[j] = st.x[j]; dx[j] = dl_.dx[j]; }
+          pm_cons(P, x, st.o[0], st.o[1], c, jx, jy);
           pm_Jv(dx, jx, jy, d);
           for (int i = 0; i < 9; ++i) {
-            double s = S_[PIDX(9 * t + i)], lam = L_[PIDX(9 * t + i)];
+            double s = st.s[i], lam = st.l[i];
             const double ds = d[i] + (c[i] - s);
             const double dl = (mu / s - lam) - (lam / s) * ds;
             s += ap * ds; lam += ad * dl;
@@ -256,7 +306,7 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
         }
         for (int j = 0; j < 4; ++j) X_[PIDX(4 * t + j)] = xn[j];
         if (t < T - 1) {
-          const double a0 = A_[PIDX(2 * t)] + ap * dA_[PIDX(2 * t)], a1 = A_[PIDX(2 * t + 1)] + ap * dA_[PIDX(2 * t + 1)];
+          const double a0 = st.a[0] + ap * dl_.da[0], a1 = st.a[1] + ap * dl_.da[1];
           A_[PIDX(2 * t)] = a0; A_[PIDX(2 * t + 1)] = a1;
           const double n0 = xn[0] + dt * xn[2], n1 = xn[1] + dt * xn[3], n2 = xn[2] + dt * a0, n3 = xn[3] + dt * a1;
           xn[0] = n0; xn[1] = n1; xn[2] = n2; xn[3] = n3;

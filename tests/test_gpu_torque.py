@@ -67,6 +67,8 @@ def test_golden_instances_objective_solution_steps_and_literal_kkt(hip_lib, ctx)
             assert np.all(np.abs(res.f - g[tag + "_f_lbfgs"]) <= 1e-8 * res.f)
         if T == 6:
             assert np.all(np.abs(res.f - g[tag + "_f_trust_constr"]) <= 1e-7 * res.f)
+        if lim < 1e8:  # effort rows active: scipy SLSQP on the problem reduced to the controls, rows with their exact Jacobian (tools/make_golden.py)
+            assert np.all(np.abs(res.f - g[tag + "_f_slsqp"]) <= 1e-7 * res.f)
         lam = be.multipliers(B)
         assert lam.shape == (B, T, 14) and lam.min() >= 0.0 and np.abs(lam - g[tag + "_lam"]).max() <= 1e-5 * max(1.0, np.abs(g[tag + "_lam"]).max())
         for b in range(B):

@@ -159,6 +159,10 @@ def test_port_reaches_the_optimum_two_independent_solvers_find(med7, golden):
     assert r["status"] == 0 and r["iters"] == int(g["t30_iters"][0])
     assert abs(r["f"] - g["t30_f"][0]) < 1e-10 * r["f"]
     assert np.all(np.abs(g["t30_f"] - g["t30_f_lbfgs"]) < 1e-8 * g["t30_f"])
+    # with the effort rows active (L-BFGS-B cannot take them): SLSQP on the problem reduced to the control sequence, 420 inequality rows with
+    # their exact Jacobian -- a dense SQP that shares the literal functions with the port, not the algorithm
+    for tag in ("t6lim", "t30lim"):
+        assert np.all(np.abs(g[tag + "_f"] - g[tag + "_f_slsqp"]) < 1e-7 * g[tag + "_f"])  # (2e-8 at T = 6, 1e-10 at T = 30)
 
 
 def test_golden_points_satisfy_the_kkt_conditions_in_reference_form(med7, golden):

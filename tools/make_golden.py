@@ -326,6 +326,69 @@ def torque_golden(slow=True):
 
 
 
+def torque_slsqp_reduced(prob, qc, goal, maxiter=4000):
+    """Independent pin for the torque problem WITH active effort rows (L-BFGS-B cannot take them, trust-constr on the literal layout needs
+    hours at T = 30): scipy SLSQP on the problem reduced to the control sequence U (states rolled out, tau = rnea(q(U), dq(U), U)), the 2 T n
+    effort rows as nonlinear inequalities with their exact Jacobian (chain rule through the Euler roll-out).  Shares the literal functions
+    with the port, not the algorithm (dense SQP vs. augmented Lagrangian + Riccati)."""
+    import scipy.optimize
+
+    from oracle.torque import costate_gradient, rnea_batch, rnea_jacobian
+
+    T, n, dt = prob.T, prob.n, prob.dt
+
+    def parts(u):
+        U = u.reshape(T, n)
+        Q, dQ = prob.rollout(qc, np.zeros(n), U)
+        return U, Q, dQ, rnea_batch(prob.tb, Q, dQ, U), rnea_jacobian(prob.tb, Q, dQ, U)
+
+    def F(u):
+        U, Q, dQ, tau, J = parts(u)
+        e, _, Jp, _ = prob.chain.jac(Q)
+        rr = e - goal
+        f = prob.w_path * np.sum(rr * rr) + prob.w_vel * np.sum(dQ * dQ) + prob.w_tau * np.sum(tau * tau)
+        g = np.einsum("ti,tid->td", 2 * prob.w_tau * tau, J)
+        g[:, :n] += 2 * prob.w_path * np.einsum("tki,tk->ti", Jp, rr)
+        g[:, n : 2 * n] += 2 * prob.w_vel * dQ
+        return f, costate_gradient(g, dt).reshape(-1)
+
+    def tau_and_jac(u):
+        U, Q, dQ, tau, J = parts(u)
+        Jt = np.zeros((T, n, T, n))
+        for t in range(T):
+            Jt[t, :, t, :] = J[t][:, 2 * n :]
+            for s in range(t):  # q_t = ... + (t - 1 - s) dt^2 u_s, dq_t = ... + dt u_s
+                Jt[t, :, s, :] = J[t][:, :n] * ((t - 1 - s) * dt * dt) + J[t][:, n : 2 * n] * dt
+        return tau.reshape(-1), Jt.reshape(T * n, T * n)
+
+    lo, up = np.tile(prob.tau_lo, T), np.tile(prob.tau_up, T)
+    cons = [{"type": "ineq", "fun": lambda u: np.concatenate([tau_and_jac(u)[0] - lo, up - tau_and_jac(u)[0]]),
+             "jac": lambda u: np.concatenate([tau_and_jac(u)[1], -tau_and_jac(u)[1]])}]
+    r = scipy.optimize.minimize(F, np.zeros(T * n), jac=True, method="SLSQP", constraints=cons, options={"maxiter": maxiter, "ftol": 1e-14})
+    return float(r.fun), int(r.status), int(r.nit), float(np.abs(tau_and_jac(r.x)[0]).max())
+
+
+def torque_golden_add_slsqp():
+    """t30lim_f_slsqp for the stored instances with active effort rows (~45 s each)."""
+    from oracle.torque import TorqueProblem
+
+    rob = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "med7.kin.json"))
+    path = os.path.join(G, "torque_golden.npz")
+    g = dict(np.load(path))
+    for tag in ("t6lim", "t30lim"):
+        lim = float(g[tag + "_lim"])
+        T = g[tag + "_goal"].shape[1]
+        prob = TorqueProblem(rob, "lbr_link_ee", T=T, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=lim)
+        out = []
+        for i, (qc, goal) in enumerate(zip(g[tag + "_qc"], g[tag + "_goal"])):
+            f, status, nit, tmax = torque_slsqp_reduced(prob, qc, goal)
+            print("torque", tag, i, "slsqp", f, "status", status, "iterations", nit, "port", float(g[tag + "_f"][i]), "max |tau|", tmax)
+            assert status == 0 and abs(f - float(g[tag + "_f"][i])) < 1e-7 * f and tmax > lim - 1e-6  # converged, agrees, rows active
+            out.append(f)
+        g[tag + "_f_slsqp"] = np.array(out)
+    np.savez(path, **g)
+
+
 def torque_golden_refresh_port():
     """Re-run only the numpy port on the stored instances of torque_golden.npz (after a change to its state machine): x, f, iters, lam are
     replaced, the independent solvers' objectives (L-BFGS-B, trust-constr: ~20 minutes to regenerate) are kept and must still agree."""
@@ -346,7 +409,9 @@ def torque_golden_refresh_port():
             x = nlp.join(r["Q"], r["dQ"], r["U"], r["tau"])
             k = kkt_reference_form(nlp, x, nlp.pack_p(qc, np.zeros(7), goal))
             assert k["stationarity"] < 1e-6 and k["feasibility"] < 1e-8, k
-            for other in ("_f_lbfgs", "_f_trust_constr"):
+            for other in ("_f_lbfgs", "_f_trust_constr", "_f_slsqp"):
+                if tag + other not in g:
+                    continue
                 fo = float(g[tag + other][i])
                 if np.isfinite(fo):
                     assert abs(fo - r["f"]) < 1e-7 * max(1.0, r["f"]), (tag, i, other, fo, r["f"])
@@ -390,6 +455,9 @@ def fig8_perturbed_dense_golden(n=8):
 if __name__ == "__main__":
     if "--fig8-dense" in sys.argv:  # ~25 minutes
         fig8_perturbed_dense_golden()
+        sys.exit(0)
+    if "--torque-slsqp" in sys.argv:
+        torque_golden_add_slsqp()
         sys.exit(0)
     if "--torque-port" in sys.argv:
         torque_golden_refresh_port()

@@ -1608,6 +1608,10 @@ extern "C" int oh_comm_broadcast_constants(oh_handle* h, int root) {
     if (const int rc = validate_chain(h, tmp)) return rc;
     h->chain_host = tmp;
     h->have_chain = true;
+    h->spec = nullptr;  // kernels compiled for a previous chain
+    h->spec_failed = false;
+    h->fk_spec = nullptr;
+    h->fk_spec_failed = false;
   }
   return OH_OK;
 }

@@ -80,7 +80,7 @@ def test_velocity_limited_batch_is_compacted_invisibly(hip_lib, monkeypatch):
         be.close()
     (f0, i0, s0, x0, l0, c0), (f1, i1, s1, x1, l1, c1) = out["0"], out["1"]
     assert c0 == 0 and c1 >= 1
-    assert (s0 == 0).mean() > 0.9 and (s0 == s1).mean() > 0.99  # (a few per cent of the perturbed instances do not finish their outer loop in 600 steps)
+    assert (s0 == 0).all() and (s1 == 0).all()
     # a survivor restarts from its accepted point, which the restart re-retracts to the floor tolerance (far from the solution accepted points
     # keep up to 1e-5 of orientation violation): the paths part by rounding-size amounts and a long run may end some steps apart -- the optima
     # and their multipliers must not

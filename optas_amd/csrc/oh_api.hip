@@ -1663,7 +1663,7 @@ extern "C" int oh_specialize_compile(const oh_chain* chain, double* info2) {
   bool from_disk = false;
   std::string err;
   bool fd2 = false;
-  if (oh_jit_figure8_compile(oh_jit_figure8_source(*chain, chain->ndof), &code, &from_disk, &err) || oh_jit_figure8_compile(oh_jit_fkjac_source(*chain), &code, &fd2, &err))
+  if (oh_jit_compile_cached(oh_jit_figure8_source(*chain, chain->ndof), &code, &from_disk, &err) || oh_jit_compile_cached(oh_jit_fkjac_source(*chain), &code, &fd2, &err))
     return fail(OH_ERR_HIP, "oh_specialize_compile: " + err);
   from_disk = from_disk && fd2;
   if (info2) {

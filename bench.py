@@ -268,6 +268,16 @@ def main():
         be.fk_jac_soa_device(nfk, d_q, d_pose, d_J)
         fk_ms.append(be.event_timer_stop())
     fk_ms = float(np.mean(fk_ms))
+    # the same kernel in the layout of the ABI's reference entry points (q[n][ndof], pose[n][7], J[n][6][ndof]: what
+    # RobotModel.get_global_link_*_function(link, n=N) hands out), staged through LDS
+    d_q.upload(np.ascontiguousarray(qsoa.T))
+    be.fk_jac_device(nfk, d_q, d_pose, d_J)
+    fk_ref_ms = []
+    for _ in range(5):
+        be.event_timer_start()
+        be.fk_jac_device(nfk, d_q, d_pose, d_J)
+        fk_ref_ms.append(be.event_timer_stop())
+    fk_ref_ms = float(np.mean(fk_ref_ms))
     for b in (d_q, d_pose, d_J):
         b.free()
 
@@ -370,6 +380,8 @@ def main():
             "units": nfk,
             "bytes_per_unit": BYTES_FKJAC,
             "avg_launch_ms": fk_ms,
+            "reference_layout": {"kernel": "k_fk_jac<AoS> (q[n][ndof], pose[n][7], J[n][6][ndof], staged through LDS)", "avg_launch_ms": fk_ref_ms,
+                                 "achieved": nfk * BYTES_FKJAC / (fk_ref_ms * 1e-3) / 1e9, "frac": nfk * BYTES_FKJAC / (fk_ref_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         },
         "quality": {
             "converged_frac": float(conv.mean()),

@@ -1389,7 +1389,7 @@ static int fk_common(oh_handle* h, int n, bool soa, const void* d_q, void* d_pos
   if (!h->fk_spec && !h->fk_spec_failed && (h->specialize == OH_SPECIALIZE_ALWAYS || (h->specialize == OH_SPECIALIZE_AUTO && n >= h->specialize_min_units)))
     specialize_fk(h);  // on failure the generic kernel runs; oh_last_error keeps the reason
   if (h->fk_spec) HIPCHK(oh_spec_launch_fk(*h->fk_spec, h->stream, soa, n, (const double*)d_q, (double*)d_pose, (double*)d_J));
-  else oh_launch_fk_jac(h->stream, soa, h->d_chain, h->chain_host.n_chain, n, (const double*)d_q, (double*)d_pose, (double*)d_J);
+  else oh_launch_fk_jac(h->stream, soa, h->d_chain, h->chain_host.n_chain, h->chain_host.ndof, n, (const double*)d_q, (double*)d_pose, (double*)d_J);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   return OH_OK;

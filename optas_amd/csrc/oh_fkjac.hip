@@ -19,26 +19,31 @@ __global__ __launch_bounds__(256) void k_fk_jac(const oh_chain* __restrict__ ch,
 }
 
 template <bool SOA>
-void launch(hipStream_t s, const oh_chain* d_chain, int nc, int n, const double* q, double* pose, double* J) {
+void launch(hipStream_t s, const oh_chain* d_chain, int nc, int ndof, int n, const double* q, double* pose, double* J) {
   const dim3 b(256), g((n + 255) / 256);
+  const size_t lds = SOA ? 0 : oh_fk_tile_bytes(ndof);  // staging tile of the reference layout (oh_fkjac_unit.h)
+  if (lds > 48 * 1024) {  // models with more than 8 joints: raise the dynamic-LDS ceiling of the run-time-length instantiation (up to 96 KB at 16)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_fk_jac<SOA, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (nc >= 1 && nc <= 8) nc = 0;  // (the fixed-length instantiations are launched with at most 48 KB; such a chain takes the run-time-length one)
+  }
   switch (nc) {
-    case 1: hipLaunchKernelGGL((k_fk_jac<SOA, 1>), g, b, 0, s, d_chain, n, q, pose, J); break;
-    case 2: hipLaunchKernelGGL((k_fk_jac<SOA, 2>), g, b, 0, s, d_chain, n, q, pose, J); break;
-    case 3: hipLaunchKernelGGL((k_fk_jac<SOA, 3>), g, b, 0, s, d_chain, n, q, pose, J); break;
-    case 4: hipLaunchKernelGGL((k_fk_jac<SOA, 4>), g, b, 0, s, d_chain, n, q, pose, J); break;
-    case 5: hipLaunchKernelGGL((k_fk_jac<SOA, 5>), g, b, 0, s, d_chain, n, q, pose, J); break;
-    case 6: hipLaunchKernelGGL((k_fk_jac<SOA, 6>), g, b, 0, s, d_chain, n, q, pose, J); break;
-    case 7: hipLaunchKernelGGL((k_fk_jac<SOA, 7>), g, b, 0, s, d_chain, n, q, pose, J); break;
-    case 8: hipLaunchKernelGGL((k_fk_jac<SOA, 8>), g, b, 0, s, d_chain, n, q, pose, J); break;
-    default: hipLaunchKernelGGL((k_fk_jac<SOA, 0>), g, b, 0, s, d_chain, n, q, pose, J); break;
+    case 1: hipLaunchKernelGGL((k_fk_jac<SOA, 1>), g, b, lds, s, d_chain, n, q, pose, J); break;
+    case 2: hipLaunchKernelGGL((k_fk_jac<SOA, 2>), g, b, lds, s, d_chain, n, q, pose, J); break;
+    case 3: hipLaunchKernelGGL((k_fk_jac<SOA, 3>), g, b, lds, s, d_chain, n, q, pose, J); break;
+    case 4: hipLaunchKernelGGL((k_fk_jac<SOA, 4>), g, b, lds, s, d_chain, n, q, pose, J); break;
+    case 5: hipLaunchKernelGGL((k_fk_jac<SOA, 5>), g, b, lds, s, d_chain, n, q, pose, J); break;
+    case 6: hipLaunchKernelGGL((k_fk_jac<SOA, 6>), g, b, lds, s, d_chain, n, q, pose, J); break;
+    case 7: hipLaunchKernelGGL((k_fk_jac<SOA, 7>), g, b, lds, s, d_chain, n, q, pose, J); break;
+    case 8: hipLaunchKernelGGL((k_fk_jac<SOA, 8>), g, b, lds, s, d_chain, n, q, pose, J); break;
+    default: hipLaunchKernelGGL((k_fk_jac<SOA, 0>), g, b, lds, s, d_chain, n, q, pose, J); break;
   }
 }
 
 }  // namespace
 
-void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n_chain, int n, const double* q, double* pose, double* J) {
-  if (soa) launch<true>(s, d_chain, n_chain, n, q, pose, J);
-  else launch<false>(s, d_chain, n_chain, n, q, pose, J);
+void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n_chain, int ndof, int n, const double* q, double* pose, double* J) {
+  if (soa) launch<true>(s, d_chain, n_chain, ndof, n, q, pose, J);
+  else launch<false>(s, d_chain, n_chain, ndof, n, q, pose, J);
 }
 
 namespace {

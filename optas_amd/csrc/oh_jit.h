@@ -25,6 +25,7 @@ bool oh_spec_kernel_info(const FigSpec& sp, const char* name, OhKernelInfo* out)
 struct FkSpec {
   hipModule_t mod = nullptr;
   hipFunction_t soa = nullptr, aos = nullptr;
+  int ndof = 0;  // sizes the staging tile of the reference-layout kernel
   bool from_disk = false;
   double seconds = 0.0;
 };

@@ -18,7 +18,7 @@ bool oh_kernel_info_torque(const char* name, OhKernelInfo* out);
 
 bool oh_launch_rnea_jac(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, int n, const double* q, const double* qd, const double* qdd, double* J);
 bool oh_launch_rnea(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, int n, const double* q, const double* qd, const double* qdd, double* tau);
-void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n_chain, int n, const double* q, double* pose, double* J);
+void oh_launch_fk_jac(hipStream_t s, bool soa, const oh_chain* d_chain, int n_chain, int ndof, int n, const double* q, double* pose, double* J);
 bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const double* x0, const double* p);
 bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot, int part = 0);
 bool oh_launch_carry(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot);

@@ -132,3 +132,42 @@ def test_transforms_and_base_frame_variants_match_oracle(hip_lib):
             assert np.abs(rm.get_link_geometric_jacobian(link, q, base) - ro.get_link_geometric_jacobian(link, q, base)).max() < 1e-13
             assert np.abs(rm.get_link_linear_jacobian(link, q, base) - ro.get_link_geometric_jacobian(link, q, base)[:3]).max() < 1e-13
         assert np.abs(rm.get_link_position_function("lwr_arm_5_link", ro.get_root())(q) - ro.get_global_link_position("lwr_arm_5_link", q)).max() < 1e-13
+
+
+@pytest.mark.parametrize("specialize", ["0", "1"])
+@pytest.mark.parametrize("ndof,n_chain", [(12, 12), (10, 7), (16, 16), (3, 2)])
+def test_reference_layout_staging_for_long_and_partial_chains(hip_lib, monkeypatch, ndof, n_chain, specialize):
+    """The reference-layout kernel stages q, pose and J through LDS (a tile of 128 units x 6 ndof doubles: beyond 8 joints it needs more than
+    the default 48 KB of dynamic LDS): a synthetic chain of up to 16 joints, with and without joints off the chain, must give what the SoA
+    kernel -- no LDS, pinned against the oracle above -- gives, for block-ragged sizes."""
+    monkeypatch.setenv("OH_SPECIALIZE", specialize)  # the generic kernels and the ones compiled for this very chain
+    base = RobotModel(urdf_filename=KUKA_KIN).kinematic_chain("end_effector_ball")
+    ch = _lib.oh_chain()
+    C.memmove(C.byref(ch), C.byref(base), C.sizeof(ch))
+    ch.ndof, ch.n_chain = ndof, n_chain
+    for k in range(n_chain):  # repeat the LWR's joints; the chain uses every other model joint when there are spare ones
+        s = k % 7
+        ch.jtype[k], ch.axcode[k], ch.r0ident[k] = base.jtype[s], base.axcode[s], base.r0ident[s]
+        ch.qidx[k] = k if ndof == n_chain else min(ndof - 1, k + (k >= 3) * (ndof - n_chain))
+        for i in range(9):
+            ch.R0[k][i] = base.R0[s][i]
+        for i in range(3):
+            ch.p0[k][i], ch.axis[k][i] = base.p0[s][i], base.axis[s][i]
+        for i in range(4):
+            ch.quat0[k][i] = base.quat0[s][i]
+    kin = KinematicsHandle(ch)
+    lib = _lib.load()
+    rng = np.random.default_rng(SEED + ndof)
+    for n in (1, 127, 129, 300, 4097):
+        Q = rng.uniform(-2.0, 2.0, (n, ndof))
+        pose, J = kin.fk_jac(Q)
+        dq = _lib.DeviceBuffer(Q.nbytes).upload(np.ascontiguousarray(Q.T))
+        dp, dJ = _lib.DeviceBuffer(n * 7 * 8), _lib.DeviceBuffer(n * 6 * ndof * 8)
+        _lib.check(lib.oh_fk_jac_soa_device(kin._h, n, dq.ptr, dp.ptr, dJ.ptr), "soa")
+        # (the two layouts are two instantiations of one function body: the compiler may contract their products differently)
+        assert np.abs(dp.download(np.float64, (7, n)).T - pose).max() <= 4e-15
+        assert np.abs(dJ.download(np.float64, (6 * ndof, n)).T.reshape(n, 6, ndof) - J).max() <= 4e-15
+        off = [c for c in range(ndof) if c not in [ch.qidx[k] for k in range(n_chain)]]
+        assert np.abs(J[:, :, off]).max() == 0.0 if off else True
+        for b in (dq, dp, dJ):
+            b.free()

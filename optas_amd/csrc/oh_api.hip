@@ -982,7 +982,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   fill_params(h);
   if (spec_applies(h) && !h->spec && !h->spec_failed &&
       (h->specialize == OH_SPECIALIZE_ALWAYS || (h->specialize == OH_SPECIALIZE_AUTO && B >= h->specialize_min_B)))
-    oh_specialize(h);  // on failure the generic kernels run; oh_last_error keeps the reason, oh_specialize_info says which ran
+    if (oh_specialize(h) != OH_OK) h->spec_failed = true;  // the generic kernels run (and no further attempt is made); oh_last_error keeps the reason
   const bool guarded = h->have_guards;
   const bool lead = h->chain_host.has_lead != 0;
   if (lead && (guarded || !h->desc.lock_orientation || h->desc.ndof != 6))

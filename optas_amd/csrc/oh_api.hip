@@ -108,6 +108,7 @@ struct oh_handle {
   int compact_sort = 1;      // order the survivors of a compaction by progress (k_scan_*)
   double compact_frac = 0.9;  // compact the batch once this fraction of it (or less) is still running
   int tail_threshold = 2048;  // hand the last instances to the persistent one-wave-per-instance kernel
+  int free_pcr_max = 1536;    // position-tracking family: K3 by cyclic reduction, one block per instance, while at most this many are in the launch
   // run-time specialised evaluation kernels of the orientation-locked figure-eight family (oh_jit.hip)
   int specialize = specialize_mode_from_env();  // OH_SPECIALIZE env: 0 never, 1 at the first solve, auto: at the first solve of >= specialize_min_B instances
   int specialize_min_B = 4096;
@@ -207,6 +208,7 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (!(h->desc.tol_feas > 0.0)) h->desc.tol_feas = 1e-9;
   if (h->desc.mu0 < 0.0) h->desc.mu0 = 0.0;
   if (const char* e2 = getenv("OH_TAIL_THRESHOLD")) h->tail_threshold = atoi(e2);
+  if (const char* e2 = getenv("OH_FREE_PCR_MAX")) h->free_pcr_max = atoi(e2);
   if (const char* e3 = getenv("OH_COMPACTION")) h->compaction = atoi(e3) != 0;
   if (const char* e4 = getenv("OH_COMPACT_FRAC")) h->compact_frac = atof(e4);
   if (const char* e5 = getenv("OH_COMPACT_SORT")) h->compact_sort = atoi(e5);
@@ -1082,8 +1084,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(3); }
     if (h->P.lock && guarded) oh_launch_step_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else if (h->P.lock) oh_launch_step(s, N, h->P, h->D, slot);
-    else if (guarded) oh_launch_step_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
-    else oh_launch_step_free(s, N, h->P, h->D, slot);
+    else if (guarded) oh_launch_step_guarded(s, N, h->P, h->D, h->GP, h->GB, slot, h->D.B <= h->free_pcr_max);
+    else oh_launch_step_free(s, N, h->P, h->D, slot, h->D.B <= h->free_pcr_max);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(2); }
     ++launched;
     if (check) {

@@ -357,6 +357,101 @@ OH_DEV void symv(const double (&A)[M * (M + 1) / 2], const double (&x)[M], doubl
   }
 }
 
+// Ratio test and bookkeeping of one instance at the head of K3 (shared by the serial sweep and the cyclic-reduction kernel below).
+// f, fpsi, meas: merit, penalty part and violation of the trial slot ts summed over the knots.  Returns false when the instance stops here.
+template <int N, bool GUARD>
+OH_DEV bool free_accept(const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, const int b, const int ts, const double f, const double fpsi,
+                        const double meas, int& cur, LMState& lm) {
+  bool accept;
+  if (D.first[b]) {
+    if (!(f == f) || !(fabs(f) < 1e300)) {  // non-finite seed / parameters: report, do not iterate
+      D.status[b] = OH_STATUS_NUMERICAL;
+      D.cur[b] = ts;
+      D.f_cur[b] = f;
+      D.stat[b] = f;
+      return false;
+    }
+    accept = true;
+    D.first[b] = 0;
+    if constexpr (GUARD) {
+      // restart after a batch compaction with a multiplier update pending: this evaluation has refreshed the multipliers
+      if (GB.outer[b]) {
+        GB.outer[b] = 0;
+        GB.rho[b] = GB.rho_next[b];
+      }
+    }
+  } else if (GUARD && GB.outer[b]) {
+    // re-evaluation of the current point after a multiplier update: the merit function itself changed
+    accept = true;
+    GB.outer[b] = 0;
+    GB.rho[b] = GB.rho_next[b];
+  } else {
+    accept = lm_accept(P, f, 0.0, D.f_cur[b], D.pred[b], 0.0, lm);
+    D.nun[b] = lm.nun;
+  }
+  if (accept) {
+    cur = ts;
+    D.f_cur[b] = f;
+    D.feas[b] = meas;
+    if constexpr (GUARD) D.fpsi[b] = fpsi;
+  }
+  D.cur[b] = cur;
+  if (!accept) {
+    D.skip[b] = 1;
+    atomicAdd(D.work + 1, 1ULL);
+  }
+  return true;
+}
+
+// What happens after the factorisation, given the reduced gradient norm: -1 take the step, 0 the instance stops, 1 it goes on from where
+// it stands (outer iteration of the augmented Lagrangian: the caller zeroes the step).
+template <int N, bool GUARD>
+OH_DEV int free_decide(const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, const int b, const double stat, const double mu, const int iters) {
+  D.stat[b] = stat;
+  if constexpr (GUARD) {
+    if (stat <= GB.omega[b]) {
+      const double meas = D.feas[b];
+      if (stat <= P.tol && meas <= P.tol_feas) {
+        D.status[b] = OH_STATUS_CONVERGED;
+        D.mu[b] = mu;
+        return 0;
+      }
+      if (iters >= P.max_iter) {
+        D.status[b] = OH_STATUS_MAX_ITER;
+        D.mu[b] = mu;
+        return 0;
+      }
+      // outer iteration: stay where we are, let the next evaluation refresh the multipliers, tighten the inner tolerance
+      const double rho = GB.rho[b];
+      GB.rho_next[b] = (meas > 0.25 * GB.meas_prev[b]) ? fmin(10.0 * rho, 1e8) : rho;
+      GB.meas_prev[b] = meas;
+      GB.omega[b] = fmax(P.tol, fmin(GB.omega[b], 0.1 * meas));
+      GB.outer[b] = 1;
+      GB.n_outer[b] += 1;
+      D.pred[b] = 0.0;
+      D.mu[b] = mu;
+      D.iters[b] = iters + 1;
+      return 1;
+    }
+  } else {
+    if (stat <= P.tol) {
+      D.status[b] = OH_STATUS_CONVERGED;
+      D.mu[b] = mu;
+      return 0;
+    }
+  }
+  if (iters >= P.max_iter) {
+    D.status[b] = OH_STATUS_MAX_ITER;
+    D.mu[b] = mu;
+    return 0;
+  }
+  if (!(stat == stat)) {
+    D.status[b] = OH_STATUS_NUMERICAL;
+    return 0;
+  }
+  return -1;
+}
+
 template <int N, bool GUARD>
 OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, const int b, const int ts) {
   constexpr int NP = N * (N + 1) / 2;
@@ -375,44 +470,7 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
         meas = fmax(meas, D.cv[ts][(size_t)t * Bp + b]);
       }
     }
-    bool accept;
-    if (D.first[b]) {
-      if (!(f == f) || !(fabs(f) < 1e300)) {  // non-finite seed / parameters: report, do not iterate
-        D.status[b] = OH_STATUS_NUMERICAL;
-        D.cur[b] = ts;
-        D.f_cur[b] = f;
-        D.stat[b] = f;
-        return false;
-      }
-      accept = true;
-      D.first[b] = 0;
-      if constexpr (GUARD) {
-        // restart after a batch compaction with a multiplier update pending: this evaluation has refreshed the multipliers
-        if (GB.outer[b]) {
-          GB.outer[b] = 0;
-          GB.rho[b] = GB.rho_next[b];
-        }
-      }
-    } else if (GUARD && GB.outer[b]) {
-      // re-evaluation of the current point after a multiplier update: the merit function itself changed
-      accept = true;
-      GB.outer[b] = 0;
-      GB.rho[b] = GB.rho_next[b];
-    } else {
-      accept = lm_accept(P, f, 0.0, D.f_cur[b], D.pred[b], 0.0, lm);
-      D.nun[b] = lm.nun;
-    }
-    if (accept) {
-      cur = ts;
-      D.f_cur[b] = f;
-      D.feas[b] = meas;
-      if constexpr (GUARD) D.fpsi[b] = fpsi;
-    }
-    D.cur[b] = cur;
-    if (!accept) {
-      D.skip[b] = 1;
-      atomicAdd(D.work + 1, 1ULL);
-    }
+    if (!free_accept<N, GUARD>(P, D, GB, b, ts, f, fpsi, meas, cur, lm)) return false;
   }
   double mu = lm.mu;
   const double* __restrict__ Drc = D.Dr[cur];
@@ -478,51 +536,15 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
     if (ok) break;
     mu = fmax(4.0 * mu, 1e-2);
   }
-  D.stat[b] = stat;
-  if constexpr (GUARD) {
-    if (stat <= GB.omega[b]) {
-      const double meas = D.feas[b];
-      if (stat <= P.tol && meas <= P.tol_feas) {
-        D.status[b] = OH_STATUS_CONVERGED;
-        D.mu[b] = mu;
-        return false;
-      }
-      if (iters >= P.max_iter) {
-        D.status[b] = OH_STATUS_MAX_ITER;
-        D.mu[b] = mu;
-        return false;
-      }
-      // outer iteration: stay where we are, let the next evaluation refresh the multipliers, tighten the inner tolerance
-      const double rho = GB.rho[b];
-      GB.rho_next[b] = (meas > 0.25 * GB.meas_prev[b]) ? fmin(10.0 * rho, 1e8) : rho;
-      GB.meas_prev[b] = meas;
-      GB.omega[b] = fmax(P.tol, fmin(GB.omega[b], 0.1 * meas));
-      GB.outer[b] = 1;
-      GB.n_outer[b] += 1;
+  {
+    const int r = free_decide<N, GUARD>(P, D, GB, b, stat, mu, iters);
+    if (r == 1) {
       for (int t = P.t0; t < T; ++t) {
 #pragma unroll
         for (int a = 0; a < N; ++a) D.zstep[IDX(t, N, a)] = 0.0;
       }
-      D.pred[b] = 0.0;
-      D.mu[b] = mu;
-      D.iters[b] = iters + 1;
-      return true;
     }
-  } else {
-    if (stat <= P.tol) {
-      D.status[b] = OH_STATUS_CONVERGED;
-      D.mu[b] = mu;
-      return false;
-    }
-  }
-  if (iters >= P.max_iter) {
-    D.status[b] = OH_STATUS_MAX_ITER;
-    D.mu[b] = mu;
-    return false;
-  }
-  if (!(stat == stat)) {
-    D.status[b] = OH_STATUS_NUMERICAL;
-    return false;
+    if (r >= 0) return r != 0;
   }
   {
     double zz[N];
@@ -588,6 +610,232 @@ __global__ __launch_bounds__(64) void k_step_free(FigParams P, FigBuffers D, Gua
   if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
 }
 
+// K3 of a batch that cannot fill the chip: one BLOCK per instance, one thread per knot.  The serial sweep above is one lane's dependent walk
+// over 2 x T knots with a 7 x 7 factorisation at each (T = 100: ~280 us per launch however few instances there are; BASELINE's config 4 is
+// 256 arms per GPU, four wavefronts).  Here the block-tridiagonal system  A_t z_t - 2k z_{t-1} - 2k z_{t+1} = -g_t  is solved by block
+// parallel cyclic reduction across the lanes: ceil(log2 T) levels; at each every lane factorises its diagonal block, solves for its two
+// coupling blocks and its right-hand side and eliminates the neighbours at distance 2^l from its row.  What a lane needs of its neighbours
+// goes through LDS in two passes (A^{-1} L and A^{-1} r, then A^{-1} U: 56 rows x NT lanes = 57 KB at NT = 128).  All pivots are positive
+// definite iff the matrix is (Haynsworth: each level is a Schur complement onto the lanes of one parity class), so the damping loop raises mu
+// exactly when the serial sweep would.  The ratio test and the outer-loop decisions are the serial kernel's (free_accept / free_decide, lane 0).
+// The stage arrays are read knot-major (a lane's doubles lie a row apart): instances that share a line are dealt to the same XCD.
+template <int N, bool GUARD, int NT>
+__global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D, GuardBuffers GB, const int slot) {
+  constexpr int NP = N * (N + 1) / 2;
+  constexpr int O_R = N * N;  // exchange tile: rows [0, N*N) one block (column-major), rows [N*N, N*N + N) one vector
+  __shared__ double sm[N * N + N][NT];
+  __shared__ double red[3][2];
+  __shared__ int ctl[2];
+  __shared__ double ctld;
+  const int per = (D.B + 7) / 8;  // blocks are dealt round-robin to the 8 XCDs: XCD x takes the instances [x per, (x + 1) per)
+  const int b = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  if (b >= D.B) return;
+  const int lane = threadIdx.x;
+  const int Bp = D.Bp;
+  const int T = P.T;
+  const int nK = T - P.t0;
+  const int t = P.t0 + lane;
+  const bool active = lane < nK;
+  const int tl = active ? t : T - 1;
+  const bool last = (t == T - 1);
+  const double kap2 = 2.0 * P.kappa;
+  if (lane == 0) ctl[0] = D.status[b] >= 0 ? 0 : (D.skip[b] ? 1 : 2);
+  __syncthreads();
+  {
+    const int st = ctl[0];
+    if (st == 0) return;
+    if (st == 1) {  // sits this launch out (k_step_free's wrapper)
+      if (lane == 0) {
+        D.skip[b] = 0;
+        atomicAdd(D.n_running, 1);
+      }
+      return;
+    }
+  }
+  sm[0][lane] = active ? D.merit[slot][(size_t)tl * Bp + b] : 0.0;
+  if constexpr (GUARD) {
+    sm[1][lane] = active ? GB.psi[slot][(size_t)tl * Bp + b] : 0.0;
+    sm[2][lane] = active ? D.cv[slot][(size_t)tl * Bp + b] : 0.0;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    atomicAdd(D.work, 1ULL);
+    double f = D.fconst[b], fpsi = 0.0, meas = 0.0;
+    for (int l = 0; l < nK; ++l) {  // in knot order, like the serial sweep
+      f += sm[0][l];
+      if constexpr (GUARD) {
+        fpsi += sm[1][l];
+        meas = fmax(meas, sm[2][l]);
+      }
+    }
+    LMState lm{D.mu[b], D.nun[b]};
+    int cur = 1 - slot;
+    ctl[0] = free_accept<N, GUARD>(P, D, GB, b, slot, f, fpsi, meas, cur, lm) ? 1 : 0;
+    ctl[1] = cur;
+    ctld = lm.mu;
+  }
+  __syncthreads();
+  if (!ctl[0]) return;
+  const int cur = ctl[1];
+  double mu = ctld;
+  auto block_sum = [&](double v, const int slot_r, const bool is_max) {  // all lanes get the result
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const double o = __shfl_xor(v, m);
+      v = is_max ? fmax(v, o) : v + o;
+    }
+    if ((lane & 63) == 0) red[slot_r][lane >> 6] = v;
+    __syncthreads();
+    double out = red[slot_r][0];
+    if (NT > 64) out = is_max ? fmax(out, red[slot_r][1]) : out + red[slot_r][1];
+    return out;
+  };
+  const double* __restrict__ Drc = D.Dr[cur];
+  const double* __restrict__ gtc = D.gt[cur];
+  double stat = 0.0;
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < N; ++a) stat = fmax(stat, fabs(gtc[IDX(tl, N, a)]));
+  }
+  stat = block_sum(stat, 0, true);
+  // Registers are the budget (256 + 256 per lane at one wavefront per SIMD): the diagonal block is kept as its lower triangle (every update of
+  // it is symmetric: Lw A_-^{-1} Lw^T and U A_+^{-1} U^T, because U_i = Lw_{i+s}^T), the new U overwrites the old row by row, and the stage data
+  // is read again for a damped retry instead of being kept.  (Tried: reading the new Lw off the neighbour's new U through LDS instead of
+  // computing it -- 343 fewer multiply-adds per level, but the compiler spills more around the extra exchange: 144 against 111 us per launch.)
+  double r[N];
+  for (int attempt = 0; attempt < 40; ++attempt) {
+    double A[NP], Lw[N * N], U[N * N];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) A[i] = active ? Drc[IDX(tl, NP, i)] : 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      A[tri(i, i)] = active ? A[tri(i, i)] + (last ? kap2 : 2.0 * kap2) + mu : 1.0;
+      r[i] = active ? -gtc[IDX(tl, N, i)] : 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        U[i * N + j] = (i == j && active && !last) ? -kap2 : 0.0;
+        Lw[i * N + j] = (i == j && active && lane > 0) ? -kap2 : 0.0;
+      }
+    }
+    bool ok = true;
+    for (int sft = 1; sft < nK; sft <<= 1) {
+      double Lc[NP], rd[N];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Lc[i] = A[i];
+      ok = chol_rcp<N>(Lc, rd, 1e-12) && ok;
+      const int lm_ = lane - sft, lp_ = lane + sft;
+      const bool hm = lm_ >= 0, hp = lp_ < NT;
+      const int im = hm ? lm_ : lane, ip = hp ? lp_ : lane;  // (Lw / U of a lane without that neighbour are zero: the clamped reads add nothing)
+      // pass 1: Y^L = A^{-1} Lw and y = A^{-1} r, parked for the neighbours
+#pragma unroll
+      for (int c = 0; c <= N; ++c) {
+        double col[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) col[i] = c < N ? Lw[i * N + c] : r[i];
+        fsub_rcp<N>(Lc, rd, col);
+        bsub_rcp<N>(Lc, rd, col);
+#pragma unroll
+        for (int i = 0; i < N; ++i) sm[c * N + i][lane] = col[i];
+      }
+      __syncthreads();
+      double Ln[N * N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double racc = r[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          double lacc = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) lacc -= Lw[i * N + k] * sm[j * N + k][im];  // -Lw Y^L_{-}
+          Ln[i * N + j] = hm ? lacc : 0.0;
+          if (j <= i) {
+            double aacc = A[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < N; ++k) aacc -= U[i * N + k] * sm[j * N + k][ip];  // A - U Y^L_{+}
+            A[tri(i, j)] = aacc;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) racc -= Lw[i * N + k] * sm[O_R + k][im] + U[i * N + k] * sm[O_R + k][ip];
+        r[i] = racc;
+      }
+      __syncthreads();
+      // pass 2: Y^U = A^{-1} U (Lc is still the factor of the block as it stood before pass 1)
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        double col[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) col[i] = U[i * N + c];
+        fsub_rcp<N>(Lc, rd, col);
+        bsub_rcp<N>(Lc, rd, col);
+#pragma unroll
+        for (int i = 0; i < N; ++i) sm[c * N + i][lane] = col[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double urow[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          double uacc = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) uacc -= U[i * N + k] * sm[j * N + k][ip];  // -U Y^U_{+}
+          urow[j] = hp ? uacc : 0.0;
+          if (j <= i) {
+            double aacc = A[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < N; ++k) aacc -= Lw[i * N + k] * sm[j * N + k][im];  // A - Lw Y^U_{-}
+            A[tri(i, j)] = aacc;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          U[i * N + j] = urow[j];
+          Lw[i * N + j] = Ln[i * N + j];
+        }
+      }
+      __syncthreads();
+    }
+    {
+      double rd[N];
+      ok = chol_rcp<N>(A, rd, 1e-12) && ok;
+      fsub_rcp<N>(A, rd, r);
+      bsub_rcp<N>(A, rd, r);  // r is the step of this knot now
+    }
+    if (__syncthreads_and(ok || !active)) break;
+    mu = fmax(4.0 * mu, 1e-2);
+  }
+  if (lane == 0) ctl[0] = free_decide<N, GUARD>(P, D, GB, b, stat, mu, D.iters[b]);
+  __syncthreads();
+  const int dec = ctl[0];
+  if (dec == 0) return;
+  if (dec == 1) {  // outer iteration: no step
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < N; ++a) D.zstep[IDX(t, N, a)] = 0.0;
+    }
+    if (lane == 0) atomicAdd(D.n_running, 1);
+    return;
+  }
+  double gd = 0.0, z2 = 0.0;
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+      D.zstep[IDX(t, N, a)] = r[a];
+      gd += gtc[IDX(t, N, a)] * r[a];
+      z2 += r[a] * r[a];
+    }
+  }
+  gd = block_sum(gd, 1, false);
+  z2 = block_sum(z2, 2, false);
+  if (lane == 0) {
+    D.pred[b] = -0.5 * gd + 0.5 * mu * z2;
+    D.mu[b] = mu;
+    D.iters[b] += 1;
+    atomicAdd(D.n_running, 1);
+  }
+}
+
 bool oh_launch_eval_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
   const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
   if (n == 7) hipLaunchKernelGGL(k_eval_free<7>, g, b, 0, s, P, D, slot);
@@ -602,9 +850,21 @@ bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBu
   else return false;
   return true;
 }
-bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
+// pcr: one block per instance (k_step_free_pcr; the knots must fit 128 lanes)
+template <int N, bool GUARD>
+static void launch_step_free_pcr(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, int slot) {
+  const dim3 g(8 * ((D.B + 7) / 8));
+  if (P.T - P.t0 <= 64) hipLaunchKernelGGL((k_step_free_pcr<N, GUARD, 64>), g, dim3(64), 0, s, P, D, GB, slot);
+  else hipLaunchKernelGGL((k_step_free_pcr<N, GUARD, 128>), g, dim3(128), 0, s, P, D, GB, slot);
+}
+bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot, bool pcr) {
   const dim3 g((D.B + 63) / 64), b(64);
   const GuardBuffers none{};
+  if (pcr && P.T - P.t0 <= 128 && (n == 7 || n == 6)) {
+    if (n == 7) launch_step_free_pcr<7, false>(s, P, D, none, slot);
+    else launch_step_free_pcr<6, false>(s, P, D, none, slot);
+    return true;
+  }
   if (n == 7) hipLaunchKernelGGL((k_step_free<7, false>), g, b, 0, s, P, D, none, slot);
   else if (n == 6) hipLaunchKernelGGL((k_step_free<6, false>), g, b, 0, s, P, D, none, slot);
   else return false;
@@ -621,8 +881,13 @@ bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigB
   else return false;
   return true;
 }
-bool oh_launch_step_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
+bool oh_launch_step_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot, bool pcr) {
   const dim3 g((D.B + 63) / 64), b(64);
+  if (pcr && P.T - P.t0 <= 128 && (n == 7 || n == 6)) {
+    if (n == 7) launch_step_free_pcr<7, true>(s, P, D, GB, slot);
+    else launch_step_free_pcr<6, true>(s, P, D, GB, slot);
+    return true;
+  }
   if (n == 7) hipLaunchKernelGGL((k_step_free<7, true>), g, b, 0, s, P, D, GB, slot);
   else if (n == 6) hipLaunchKernelGGL((k_step_free<6, true>), g, b, 0, s, P, D, GB, slot);
   else return false;

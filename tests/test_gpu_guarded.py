@@ -251,3 +251,41 @@ def test_guarded_batch_compaction_is_invisible(hip_lib, golden, monkeypatch):
     for a, b in zip(l0, l1):
         assert a.shape == b.shape and np.abs(a[same] - b[same]).max() <= 1e-6 * max(1.0, np.abs(a).max())
         assert np.abs(a).max() > 0  # rows are active somewhere: the comparison is not vacuous
+
+
+@pytest.mark.parametrize("T,guarded", [(100, True), (30, True), (50, False)])  # 128-lane blocks, 64-lane blocks, the unguarded kernel
+def test_cyclic_reduction_step_equals_the_serial_sweep(hip_lib, monkeypatch, T, guarded):
+    """Small launches of the position-tracking family solve the block-tridiagonal Newton system by block cyclic reduction, one block of
+    threads per instance (k_step_free_pcr); larger ones by one lane's Riccati sweep (k_step_free).  Same system, same ratio test: the same
+    iterates up to the rounding of two elimination orders."""
+    from optas_amd.lowering import lower
+    from optas_amd.backend import MultiArmBackend
+
+    B = 96
+    (kl, kr), o = setup_solver(T=T, build_only=True, limits=guarded, collision=guarded)
+    kind, spec = lower(o)
+    rng = np.random.default_rng(SEED + 43)
+    qcl, qcr = QC + rng.uniform(-0.15, 0.15, (B, 7)), QC + rng.uniform(-0.15, 0.15, (B, 7))
+    pd = {"qcl": QC, "qcr": QC}
+    if guarded:
+        pd.update(obstacle_parameters(link_radius=0.1))
+    P = np.tile(o.parameters.dict2vec(pd), (B, 1))
+    P[:, :7], P[:, 7:14] = qcl, qcr
+    X0 = np.zeros((B, o.nx))
+    xoff = o.decision_variables.offsets()
+    for name, qc in (("kukal/q/x", qcl), ("kukar/q/x", qcr)):
+        X0[:, xoff[name] : xoff[name] + 7 * T] = np.tile(qc, (1, T))
+    out = {}
+    for mode in ("0", "4096"):
+        monkeypatch.setenv("OH_FREE_PCR_MAX", mode)
+        mb = MultiArmBackend(spec, o, max_iter=400)
+        res = mb.solve(X0, P)
+        out[mode] = (res, [be.multipliers(B) for _, be in mb.arms] if guarded else [])
+        mb.close()
+    (r0, l0), (r1, l1) = out["0"], out["4096"]
+    assert (r0.status == 0).all() and (r1.status == 0).all()
+    assert (r0.iters == r1.iters).mean() >= 0.97 and np.abs(r0.iters.astype(int) - r1.iters).max() <= 2
+    same = r0.iters == r1.iters
+    assert np.abs(r0.f - r1.f).max() <= 1e-9 * np.abs(r0.f).max() and np.abs(r0.x[same] - r1.x[same]).max() <= 1e-8
+    for a, b in zip(l0, l1):
+        assert np.abs(a[same] - b[same]).max() <= 1e-6 * max(1.0, np.abs(a).max())

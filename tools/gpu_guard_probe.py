@@ -33,6 +33,7 @@ res = be.solve(x0, par)
 t=time.time(); res = be.solve(x0, par); wall=time.time()-t
 print('timing', be.timing())
 print("gpu", res.status[:8], res.iters[:8], res.f[:4], res.kkt[:4], "ms", be.timing()["solve_ms"], wall)
+if len(sys.argv)>3: sys.exit(0)
 r = OracleRobot("/root/repo/optas_amd/robots/kuka_lwr.kin.json", name="kukal"); r.add_base_frame("global_world", xyz=[0.0,-0.25,0.0])
 ch = FoldedChain(r, "end_effector_ball")
 G = Guards(lo=r.lower_actuated_joint_limits, up=r.upper_actuated_joint_limits, links=links, link_radii=np.full(4,0.15), obs_pos=obs, obs_radii=np.full(6,0.1))

@@ -408,6 +408,11 @@ OH_DEV bool free_accept(const FigParams& P, const FigBuffers& D, const GuardBuff
 template <int N, bool GUARD>
 OH_DEV int free_decide(const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, const int b, const double stat, const double mu, const int iters) {
   D.stat[b] = stat;
+  if (!(stat == stat)) {
+    D.status[b] = OH_STATUS_NUMERICAL;
+    D.mu[b] = mu;
+    return 0;
+  }
   if constexpr (GUARD) {
     if (stat <= GB.omega[b]) {
       const double meas = D.feas[b];
@@ -445,10 +450,6 @@ OH_DEV int free_decide(const FigParams& P, const FigBuffers& D, const GuardBuffe
     D.mu[b] = mu;
     return 0;
   }
-  if (!(stat == stat)) {
-    D.status[b] = OH_STATUS_NUMERICAL;
-    return 0;
-  }
   return -1;
 }
 
@@ -477,6 +478,7 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
   const double* __restrict__ gtc = D.gt[cur];
   double stat = 0.0;
   double S[NP], rd[N], rn[N];
+  bool factored = false;
   for (int attempt = 0; attempt < 40; ++attempt) {
     bool ok = true;
     stat = 0.0;
@@ -533,9 +535,13 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
       for (int i = 0; i < NP; ++i) S[i] = Ht[i] - kap2 * kap2 * Sinv[i];
     }
     ok = chol_rcp<N>(S, rd, 1e-12) && ok;
-    if (ok) break;
+    if (ok) {
+      factored = true;
+      break;
+    }
     mu = fmax(4.0 * mu, 1e-2);
   }
+  if (!factored) stat = __builtin_nan("");  // no damping (up to 4^40) made the matrix factorisable: free_decide reports NUMERICAL
   {
     const int r = free_decide<N, GUARD>(P, D, GB, b, stat, mu, iters);
     if (r == 1) {
@@ -703,6 +709,7 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
   // is read again for a damped retry instead of being kept.  (Tried: reading the new Lw off the neighbour's new U through LDS instead of
   // computing it -- 343 fewer multiply-adds per level, but the compiler spills more around the extra exchange: 144 against 111 us per launch.)
   double r[N];
+  bool factored = false;
   for (int attempt = 0; attempt < 40; ++attempt) {
     double A[NP], Lw[N * N], U[N * N];
 #pragma unroll
@@ -802,9 +809,13 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
       fsub_rcp<N>(A, rd, r);
       bsub_rcp<N>(A, rd, r);  // r is the step of this knot now
     }
-    if (__syncthreads_and(ok || !active)) break;
+    if (__syncthreads_and(ok || !active)) {
+      factored = true;
+      break;
+    }
     mu = fmax(4.0 * mu, 1e-2);
   }
+  if (!factored) stat = __builtin_nan("");  // (see step_instance_free)
   if (lane == 0) ctl[0] = free_decide<N, GUARD>(P, D, GB, b, stat, mu, D.iters[b]);
   __syncthreads();
   const int dec = ctl[0];

@@ -105,6 +105,7 @@ def main():
     QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
     for tag, T, B, guarded in (("4 dual_arm.py as shipped (T=50), per arm", 50, 8192, False),
                                ("4 synthetic: T=100 + joint limits + 4x6 sphere clearances, per arm", 100, 1024, True),
+                               ("4 synthetic, 256 arms (one GPU's share of BASELINE's 1024 dual-arm problems over 8 GPUs)", 100, 256, True),
                                ("4 synthetic, large batch (guarded handles are compacted while they drain)", 100, 32768, True)):
         arm = RobotModel.builtin("kuka_lwr", time_derivs=[0, 1], name="kukal")
         arm.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])

@@ -284,6 +284,14 @@ int oh_create_pointmass(const oh_pointmass_desc* desc, oh_handle** out);
 /* Same for OH_PROBLEM_QP (no kinematic constants). oh_get_multipliers returns [B][m + me] = (lam >= 0 of the M rows, nu of the A rows). */
 int oh_create_qp(const oh_qp_desc* desc, oh_handle** out);
 
+/* OH_PROBLEM_QP whose data is a function of the problem's parameters (the reference's QuadraticCost* classes hold P, q, M, c, A, b as
+   cs.Functions of p, optimization.py:219-260, and evaluate them before every solve, solver.py:453-467,539-551).  Attaches the problem's
+   instruction tape (cost register quadratic in x; n_ineq = m rows affine in x that must be >= 0, then n_eq = me rows that must vanish;
+   max_iter / tol / jit of the descriptor are ignored).  From then on the p of oh_solve / oh_solve_device is [B][tape.np] parameter
+   vectors: one thread per instance reads [P | q | M | c | A | b] off the tape on the device (values at 0, +-e_i, e_i + e_j: exact for
+   these classes) before the solve, and f includes the cost's constant term f(0, p). */
+int oh_qp_set_tape(oh_handle* h, const oh_tape_desc* tape);
+
 /* Same for OH_PROBLEM_TAPE: the tape is copied to the device.  oh_get_multipliers returns [B][n_ineq + n_eq] (lam >= 0 of the >= rows, signed mu
    of the = rows in L = f - lam^T g - mu^T c). */
 int oh_create_tape(const oh_tape_desc* desc, oh_handle** out);

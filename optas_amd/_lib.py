@@ -190,6 +190,7 @@ SYMBOLS = [
     "oh_create_pointmass",
     "oh_create_ik",
     "oh_create_qp",
+    "oh_qp_set_tape",
     "oh_create_tape",
     "oh_create_torque",
     "oh_tape_compile",
@@ -259,6 +260,7 @@ def load() -> C.CDLL:
     lib.oh_create_ik.argtypes = [C.POINTER(oh_ik_desc), C.POINTER(vp)]
     lib.oh_create_qp.argtypes = [C.POINTER(oh_qp_desc), C.POINTER(vp)]
     lib.oh_create_tape.argtypes = [C.POINTER(oh_tape_desc), C.POINTER(vp)]
+    lib.oh_qp_set_tape.argtypes = [vp, C.POINTER(oh_tape_desc)]
     lib.oh_tape_compile.argtypes = [C.POINTER(oh_tape_desc), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.oh_set_constants.argtypes = [vp, C.POINTER(oh_chain)]
     lib.oh_set_constants_device.argtypes = [vp, vp, C.c_size_t]

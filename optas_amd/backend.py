@@ -169,7 +169,9 @@ class TapeBackend(_SolveMixin):
 class QPBackend(_SolveMixin):
     """OH_PROBLEM_QP handle: x (B, n); p (B, n*n + n + m*n + m + me*n + me) = [P | q | M | c | A | b] per instance."""
 
-    def __init__(self, n: int, m: int, me: int, max_iter=100, tol=1e-9):
+    def __init__(self, n: int, m: int, me: int, max_iter=100, tol=1e-9, tape=None):
+        """tape (optas_amd.tape.Tape of the problem, rows k then a): p of a solve is then (B, np of the problem) and the QP data is read off
+        the tape on the device (oh_qp_set_tape) instead of arriving packed."""
         lib = _lib.load()
         self.n, self.m, self.me = int(n), int(m), int(me)
         self.nx = self.n
@@ -177,6 +179,15 @@ class QPBackend(_SolveMixin):
         desc = _lib.oh_qp_desc(n=self.n, m=self.m, me=self.me, max_iter=int(max_iter), tol=float(tol))
         self._h = C.c_void_p()
         _lib.check(lib.oh_create_qp(C.byref(desc), C.byref(self._h)), "oh_create_qp")
+        self.tape = None
+        if tape is not None:
+            self.set_tape(tape)
+
+    def set_tape(self, tape) -> None:
+        td = TapeBackend.descriptor(tape)
+        _lib.check(_lib.load().oh_qp_set_tape(self._h, C.byref(td)), "oh_qp_set_tape")
+        self.tape = tape
+        self.np_ = max(1, int(tape.np_))
 
     @staticmethod
     def pack(P, q, M, c, A, b) -> np.ndarray:

@@ -73,6 +73,11 @@ struct oh_handle {
   double* d_qp_work = nullptr;
   double* d_qp_mult = nullptr;
   int qp_cap = 0;
+  bool qp_tape = false;       // oh_qp_set_tape: p of a solve is the problem's parameter vector, the QP data is read off the tape (h->TP, d_tape_*) on the device
+  double* d_qp_rows = nullptr;  // [B][qp_np] assembled [P | q | M | c | A | b]
+  double* d_qp_val = nullptr;   // [TP.len][Bp] registers of the tape interpreter
+  double* d_qp_f0 = nullptr;    // [B] f(0, p)
+  int qp_tape_cap = 0;
   // inverse-kinematics family
   oh_ik_desc ik{};
   double* d_ik_mult = nullptr;
@@ -394,24 +399,79 @@ extern "C" int oh_create_qp(const oh_qp_desc* desc, oh_handle** out) {
 
 static size_t qp_np(const oh_qp_desc& q) { return (size_t)q.n * q.n + q.n + (size_t)q.m * q.n + q.m + (size_t)q.me * q.n + q.me; }
 
+extern "C" int oh_qp_set_tape(oh_handle* h, const oh_tape_desc* d) {
+  if (!h || !d) return fail(OH_ERR_INVALID, "oh_qp_set_tape: null argument");
+  if (h->desc.kind != OH_PROBLEM_QP) return fail(OH_ERR_STATE, "oh_qp_set_tape: not an OH_PROBLEM_QP handle");
+  if (const int rc = tape_validate(d, "oh_qp_set_tape")) return rc;
+  if (d->nx != h->qp.n || d->n_ineq != h->qp.m || d->n_eq != h->qp.me)
+    return fail(OH_ERR_INVALID, "oh_qp_set_tape: the tape's nx / n_ineq / n_eq differ from the handle's n / m / me");
+  HIPCHK(hipSetDevice(h->device));
+  for (void** q2 : {(void**)&h->d_tape_op, (void**)&h->d_tape_a, (void**)&h->d_tape_b, (void**)&h->d_tape_c, (void**)&h->d_tape_rows}) {
+    if (*q2) hipFree(*q2);
+    *q2 = nullptr;
+  }
+  h->qp_tape = false;
+  const size_t li = sizeof(int) * (size_t)d->len, ld = sizeof(double) * (size_t)d->len, lr = sizeof(int) * (size_t)(d->n_ineq + d->n_eq + 1);
+  HIPCHK(hipMalloc((void**)&h->d_tape_op, li));
+  HIPCHK(hipMalloc((void**)&h->d_tape_a, li));
+  HIPCHK(hipMalloc((void**)&h->d_tape_b, li));
+  HIPCHK(hipMalloc((void**)&h->d_tape_c, ld));
+  HIPCHK(hipMalloc((void**)&h->d_tape_rows, lr));
+  HIPCHK(hipMemcpy(h->d_tape_op, d->op, li, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_tape_a, d->a, li, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_tape_b, d->b, li, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_tape_c, d->c, ld, hipMemcpyHostToDevice));
+  if (d->n_ineq + d->n_eq > 0) HIPCHK(hipMemcpy(h->d_tape_rows, d->rows, sizeof(int) * (size_t)(d->n_ineq + d->n_eq), hipMemcpyHostToDevice));
+  h->TP = tape_params(d);
+  if (h->qp_tape_cap) {  // the register file of another tape: size it again at the next solve
+    for (double** q2 : {&h->d_qp_rows, &h->d_qp_val, &h->d_qp_f0}) {
+      if (*q2) hipFree(*q2);
+      *q2 = nullptr;
+    }
+    h->qp_tape_cap = 0;
+  }
+  h->qp_tape = true;
+  return OH_OK;
+}
+
 static int qp_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status) {
   HIPCHK(hipSetDevice(h->device));
   const oh_qp_desc& q = h->qp;
   QpParams Q{};
   Q.n = q.n; Q.m = q.m; Q.me = q.me; Q.np = (int)qp_np(q); Q.max_iter = q.max_iter; Q.tol = q.tol;
   Q.nwork = q.n + 2 * q.m + q.me + q.n * q.n + 2 * q.n + 2 * q.m + q.me * q.n + q.me * q.me + q.me + q.n;
-  if (B > h->qp_cap) {
+  const int Bp = (B + 63) / 64 * 64;
+  if (Bp > h->qp_cap) {
     if (h->d_qp_work) hipFree(h->d_qp_work);
     if (h->d_qp_mult) hipFree(h->d_qp_mult);
     h->d_qp_work = h->d_qp_mult = nullptr;
     h->qp_cap = 0;
-    HIPCHK(hipMalloc((void**)&h->d_qp_work, sizeof(double) * (size_t)Q.nwork * B));
-    HIPCHK(hipMalloc((void**)&h->d_qp_mult, sizeof(double) * (size_t)(q.m + q.me + 1) * B));
-    h->qp_cap = B;
+    HIPCHK(hipMalloc((void**)&h->d_qp_work, sizeof(double) * (size_t)Q.nwork * Bp));
+    HIPCHK(hipMalloc((void**)&h->d_qp_mult, sizeof(double) * (size_t)(q.m + q.me + 1) * Bp));
+    h->qp_cap = Bp;
+  }
+  // register file of the tape interpreter: a lane per instance, or (a few instances: B <= 64) a lane per probe point of every instance
+  const int Bv = B <= 64 ? (B * 64 > Bp ? B * 64 : Bp) : Bp;
+  if (h->qp_tape && Bv > h->qp_tape_cap) {
+    for (double** q2 : {&h->d_qp_rows, &h->d_qp_val, &h->d_qp_f0}) {
+      if (*q2) hipFree(*q2);
+      *q2 = nullptr;
+    }
+    h->qp_tape_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->d_qp_rows, sizeof(double) * (size_t)Q.np * Bv));
+    HIPCHK(hipMalloc((void**)&h->d_qp_val, sizeof(double) * (size_t)h->TP.len * Bv));
+    HIPCHK(hipMalloc((void**)&h->d_qp_f0, sizeof(double) * (size_t)Bv));
+    h->qp_tape_cap = Bv;
   }
   HIPCHK(hipEventRecord(h->ev0, h->stream));
-  oh_launch_qp_solve(h->stream, Q, B, (const double*)d_x0, (const double*)d_p, h->d_qp_work, (double*)d_x, (double*)d_f, (double*)d_kkt, (int*)d_iters,
-                     (int*)d_status, h->d_qp_mult);
+  if (h->qp_tape) {
+    oh_launch_qp_assemble(h->stream, Q, h->TP, h->d_tape_op, h->d_tape_a, h->d_tape_b, h->d_tape_c, h->d_tape_rows, B, B <= 64 ? B * 64 : h->qp_tape_cap, (const double*)d_p,
+                          h->d_qp_val, h->d_qp_rows, h->d_qp_f0);
+    d_p = h->d_qp_rows;
+  }
+  oh_launch_qp_solve(h->stream, Q, B, h->qp_cap, (const double*)d_x0, (const double*)d_p, h->d_qp_work, (double*)d_x, (double*)d_f, (double*)d_kkt,
+                     (int*)d_iters, (int*)d_status, h->d_qp_mult);
+  if (h->qp_tape && d_f) oh_launch_qp_add_constant(h->stream, B, (double*)d_f, h->d_qp_f0);
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
@@ -1193,7 +1253,7 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
   const bool tpk = h->desc.kind == OH_PROBLEM_TAPE;
   const bool tqk = h->desc.kind == OH_PROBLEM_TORQUE_MPC;
   const size_t nx = tqk ? 4 * (size_t)N * T : tpk ? (size_t)h->TP.nx : qpk ? (size_t)h->qp.n : pmk ? 4 * (size_t)T : (ikk ? (size_t)N : (size_t)N * T + (size_t)N * (T - 1));
-  const size_t npar = tqk ? 2 * (size_t)N + 3 * (size_t)T : tpk ? (size_t)(h->TP.np > 0 ? h->TP.np : 1) : qpk ? qp_np(h->qp) : pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (h->chain_host.has_lead ? (size_t)N + 1 + T : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0)));
+  const size_t npar = tqk ? 2 * (size_t)N + 3 * (size_t)T : tpk ? (size_t)(h->TP.np > 0 ? h->TP.np : 1) : qpk ? (h->qp_tape ? (size_t)(h->TP.np > 0 ? h->TP.np : 1) : qp_np(h->qp)) : pmk ? 4 + 4 * (size_t)T : (ikk ? (size_t)N + 3 : (h->chain_host.has_lead ? (size_t)N + 1 + T : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0)));
   const size_t b_x = sizeof(double) * nx * B, b_p = sizeof(double) * npar * (size_t)B;
   const size_t b_f = sizeof(double) * B, b_k = sizeof(double) * 3 * (size_t)B, b_i = sizeof(int) * (size_t)B;
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -1467,6 +1527,8 @@ extern "C" void oh_destroy(oh_handle* h) {
   for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult})
     if (q) hipFree(q);
   if (h->d_qp_mult) hipFree(h->d_qp_mult);
+  for (void* q : {(void*)h->d_qp_rows, (void*)h->d_qp_val, (void*)h->d_qp_f0})
+    if (q) hipFree(q);
   if (h->stage) hipFree(h->stage);
   if (h->d_chain) hipFree(h->d_chain);
   if (h->d_dyn) hipFree(h->d_dyn);

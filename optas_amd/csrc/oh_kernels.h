@@ -118,14 +118,18 @@ struct QpParams {
   int n, m, me, np, nwork, max_iter;
   double tol;
 };
-void oh_launch_qp_solve(hipStream_t s, const QpParams& Q, int B, const double* x0, const double* p, double* work, double* x, double* f, double* kkt,
-                        int* iters, int* status, double* mult);
+void oh_launch_qp_solve(hipStream_t s, const QpParams& Q, int B, int Bp, const double* x0, const double* p, double* work, double* x, double* f, double* kkt,
+                        int* iters, int* status, double* mult);  // work: [Q.nwork][Bp] (used when the work set of a block does not fit LDS)
 
 // ---- OH_PROBLEM_TAPE ---------------------------------------------------------------------------------------
 #define OH_TAPE_ST_CONVERGED OH_STATUS_CONVERGED
 #define OH_TAPE_ST_MAX_ITER OH_STATUS_MAX_ITER
 #define OH_TAPE_ST_NUMERICAL OH_STATUS_NUMERICAL
 #include "oh_tape_solver.h"  // TapeParams, TapeWork and the solver shared by the interpreter and the generated code
+// QP data read off a tape on the device (oh_qp_set_tape): val = [T.len][Bp] work, rows_out = [B][Q.np], f0 = [B]
+void oh_launch_qp_assemble(hipStream_t s, const QpParams& Q, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, int B,
+                           int Bp, const double* p_raw, double* val, double* rows_out, double* f0);
+void oh_launch_qp_add_constant(hipStream_t s, int B, double* f, const double* f0);
 struct TapeJit {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;

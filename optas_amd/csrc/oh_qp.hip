@@ -10,12 +10,24 @@
 // numpy restatement of the same iteration: oracle/qp_ipm.py.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "oh_kernels.h"
 
 namespace {
 
+// A work array of one instance: element k lives at p[k * stride].  The instance's slices sit either in LDS ([k][lane], when the whole work set of
+// a block fits: the iteration is a chain of dependent accesses, and from global memory every one of them is a round trip -- 2 ms per solve at
+// B = 1) or in the global work buffer ([k][instance]: the lanes of a wavefront touch one line per access).
+struct QArr {
+  double* p;
+  int stride;
+  __device__ double& operator[](const int i) const { return p[(size_t)i * stride]; }
+  __device__ QArr at(const int off) const { return QArr{p + (size_t)off * stride, stride}; }
+};
+
 // in-place Cholesky of the n x n row-major SPD matrix H (lower triangle); returns false on a non-positive pivot
-__device__ bool qp_chol(double* H, const int n) {
+__device__ bool qp_chol(const QArr H, const int n) {
   for (int j = 0; j < n; ++j) {
     double d = H[j * n + j];
     for (int k = 0; k < j; ++k) d -= H[j * n + k] * H[j * n + k];
@@ -30,7 +42,7 @@ __device__ bool qp_chol(double* H, const int n) {
   }
   return true;
 }
-__device__ void qp_solve_chol(const double* L, const int n, double* x) {  // x <- (L L^T)^{-1} x
+__device__ void qp_solve_chol(const QArr L, const int n, const QArr x) {  // x <- (L L^T)^{-1} x
   for (int i = 0; i < n; ++i) {
     double v = x[i];
     for (int k = 0; k < i; ++k) v -= L[i * n + k] * x[k];
@@ -43,33 +55,42 @@ __device__ void qp_solve_chol(const double* L, const int n, double* x) {  // x <
   }
 }
 
-__global__ __launch_bounds__(64) void k_qp_solve(QpParams Q, int B, const double* __restrict__ x0, const double* __restrict__ par, double* __restrict__ work,
+// MODE 0: work set in the global buffer; 1: in LDS; 2: in LDS together with the instance's [P | q | M | c | A | b] row
+template <int MODE>
+__global__ __launch_bounds__(64) void k_qp_solve(QpParams Q, int B, int Bp, const double* __restrict__ x0, const double* __restrict__ par, double* __restrict__ work,
                                                  double* __restrict__ xo, double* __restrict__ fo, double* __restrict__ kkt, int* __restrict__ iters,
                                                  int* __restrict__ status, double* __restrict__ mult) {
+  extern __shared__ double qp_sm[];
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int n = Q.n, m = Q.m, me = Q.me;
-  const double* pb = par + (size_t)b * Q.np;
-  const double* P = pb;              // [n][n]
-  const double* q = P + n * n;       // [n]
-  const double* M = q + n;           // [m][n]
-  const double* c = M + m * n;       // [m]
-  const double* A = c + m;           // [me][n]
-  const double* bv = A + me * n;     // [me]
-  double* w = work + (size_t)b * Q.nwork;
-  double* x = w; w += n;
-  double* s = w; w += m;
-  double* lam = w; w += m;
-  double* nu = w; w += me;
-  double* H = w; w += n * n;
-  double* rhs = w; w += n;
-  double* dx = w; w += n;
-  double* ds = w; w += m;
-  double* dl = w; w += m;
-  double* Y = w; w += me * n;   // H^{-1} A^T, row i = H^{-1} A_i
-  double* S = w; w += me * me;
-  double* dnu = w; w += me;
-  double* rd = w; w += n;
+  QArr w = MODE ? QArr{qp_sm + threadIdx.x, (int)blockDim.x} : QArr{work + b, Bp};
+  // (the row is read-only; const_cast only to share the accessor type)
+  QArr pr{const_cast<double*>(par) + (size_t)b * Q.np, 1};
+  if (MODE == 2) {
+    for (int k = 0; k < Q.np; ++k) w[k] = pr[k];
+    pr = w;
+    w = w.at(Q.np);
+  }
+  const QArr P = pr;                 // [n][n]
+  const QArr q = P.at(n * n);        // [n]
+  const QArr M = q.at(n);            // [m][n]
+  const QArr c = M.at(m * n);        // [m]
+  const QArr A = c.at(m);            // [me][n]
+  const QArr bv = A.at(me * n);      // [me]
+  const QArr x = w; w = w.at(n);
+  const QArr s = w; w = w.at(m);
+  const QArr lam = w; w = w.at(m);
+  const QArr nu = w; w = w.at(me);
+  const QArr H = w; w = w.at(n * n);
+  const QArr rhs = w; w = w.at(n);
+  const QArr dx = w; w = w.at(n);
+  const QArr ds = w; w = w.at(m);
+  const QArr dl = w; w = w.at(m);
+  const QArr Y = w; w = w.at(me * n);   // H^{-1} A^T, row i = H^{-1} A_i
+  const QArr S = w; w = w.at(me * me);
+  const QArr dnu = w; w = w.at(me);
+  const QArr rd = w; w = w.at(n);
   for (int i = 0; i < n; ++i) x[i] = x0[(size_t)b * n + i];
   double mu = 1.0;
   for (int i = 0; i < m; ++i) {
@@ -112,15 +133,16 @@ __global__ __launch_bounds__(64) void k_qp_solve(QpParams Q, int B, const double
     if (it == Q.max_iter) break;
     // H = 2P + M^T diag(lam/s) M (+ tiny shift), rhs = -rd + M^T [(mu/s - lam) - (lam/s) r_p]
     double dmax = 0.0;
+    for (int k = 0; k < m; ++k) dl[k] = lam[k] / s[k];  // (dl is free until the step: one division per row instead of one per use)
     for (int i = 0; i < n; ++i) {
       for (int j = 0; j <= i; ++j) {
         double v = P[i * n + j] + P[j * n + i];
-        for (int k = 0; k < m; ++k) v += M[k * n + i] * (lam[k] / s[k]) * M[k * n + j];
+        for (int k = 0; k < m; ++k) v += M[k * n + i] * dl[k] * M[k * n + j];
         H[i * n + j] = v;
       }
       dmax = fmax(dmax, fabs(H[i * n + i]));
       double r = -rd[i];
-      for (int k = 0; k < m; ++k) r += M[k * n + i] * ((mu / s[k] - lam[k]) - (lam[k] / s[k]) * ds[k]);
+      for (int k = 0; k < m; ++k) r += M[k * n + i] * ((mu / s[k] - lam[k]) - dl[k] * ds[k]);
       rhs[i] = r;
     }
     double shift = 1e-13 * fmax(dmax, 1.0);
@@ -130,7 +152,7 @@ __global__ __launch_bounds__(64) void k_qp_solve(QpParams Q, int B, const double
         for (int i = 0; i < n; ++i)
           for (int j = 0; j <= i; ++j) {
             double v = P[i * n + j] + P[j * n + i];
-            for (int k = 0; k < m; ++k) v += M[k * n + i] * (lam[k] / s[k]) * M[k * n + j];
+            for (int k = 0; k < m; ++k) v += M[k * n + i] * dl[k] * M[k * n + j];
             H[i * n + j] = v;
           }
         shift *= 1e3;
@@ -145,7 +167,7 @@ __global__ __launch_bounds__(64) void k_qp_solve(QpParams Q, int B, const double
       // A dx = -r_e with dx = H^{-1}(rhs + A^T dnu):  (A H^{-1} A^T) dnu = -r_e - A H^{-1} rhs
       for (int i = 0; i < me; ++i) {
         for (int j = 0; j < n; ++j) Y[i * n + j] = A[i * n + j];
-        qp_solve_chol(H, n, Y + i * n);
+        qp_solve_chol(H, n, Y.at(i * n));
       }
       for (int i = 0; i < me; ++i) {
         double r = -dnu[i];
@@ -168,7 +190,7 @@ __global__ __launch_bounds__(64) void k_qp_solve(QpParams Q, int B, const double
     for (int i = 0; i < m; ++i) {
       double v = ds[i];
       for (int j = 0; j < n; ++j) v += M[i * n + j] * dx[j];
-      const double d2 = (mu / s[i] - lam[i]) - (lam[i] / s[i]) * v;
+      const double d2 = (mu / s[i] - lam[i]) - dl[i] * v;
       ds[i] = v;
       dl[i] = d2;
       if (v < 0.0) ap = fmin(ap, -0.995 * s[i] / v);
@@ -205,9 +227,180 @@ __global__ __launch_bounds__(64) void k_qp_solve(QpParams Q, int B, const double
   }
 }
 
+// ---- QP data read off the problem's instruction tape on the device (oh_qp_set_tape) -----------------------------------------------------
+// The reference's QuadraticCost* classes hold P, q, M, c, A, b as cs.Functions of the parameters (optimization.py:219-260); the mirror reads
+// them off f, k, a by probing on the host (optas_amd/optimization.py: values at 0, +-e_i, e_i + e_j -- exact for a quadratic cost and affine
+// rows), 36 tree evaluations per instance for n = 7: 1.8 ms.  Here one thread per instance runs the same probes through the problem's
+// instruction tape (optas_amd/tape.py; the interpreter of oh_tape.hip, forward sweep only, registers val[i][b] in a global work array) and
+// leaves the [P | q | M | c | A | b] row k_qp_solve reads, plus the cost's constant term f(0, p).  Same formulas in the same order as the host.
+struct QpTape {
+  int len, out_cost;
+  const int* __restrict__ op;
+  const int* __restrict__ a;
+  const int* __restrict__ bb;
+  const double* __restrict__ c;
+  const int* __restrict__ rows;
+};
+#define QIDX(i) ((size_t)(i) * Bp + b)
+__device__ double qp_tape_forward(const QpTape& tp, const double* xs, const double* __restrict__ pb, double* __restrict__ val, const int Bp, const int b) {
+#pragma clang fp contract(off)
+  for (int i = 0; i < tp.len; ++i) {
+    const int o = tp.op[i], ia = tp.a[i], ib = tp.bb[i];
+    double v;
+    switch (o) {
+      case 0: v = tp.c[i]; break;
+      case 1: v = xs[ia]; break;
+      case 2: v = pb[ia]; break;
+      case 3: v = val[QIDX(ia)] + val[QIDX(ib)]; break;
+      case 4: v = val[QIDX(ia)] - val[QIDX(ib)]; break;
+      case 5: v = val[QIDX(ia)] * val[QIDX(ib)]; break;
+      case 6: v = val[QIDX(ia)] / val[QIDX(ib)]; break;
+      case 7: v = -val[QIDX(ia)]; break;
+      case 8: v = sin(val[QIDX(ia)]); break;
+      case 9: v = cos(val[QIDX(ia)]); break;
+      case 10: v = atan2(val[QIDX(ia)], val[QIDX(ib)]); break;
+      case 11: v = sqrt(val[QIDX(ia)]); break;
+      default: { const double t = val[QIDX(ia)]; v = t * t; } break;
+    }
+    val[QIDX(i)] = v;
+  }
+  return val[QIDX(tp.out_cost)];
+}
+__global__ __launch_bounds__(64) void k_qp_assemble(QpParams Q, QpTape tp, int np_raw, int B, int Bp, const double* __restrict__ par, double* __restrict__ val,
+                                                    double* __restrict__ rows_out, double* __restrict__ f0_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int n = Q.n, m = Q.m, me = Q.me;
+  const double* pb = par + (size_t)b * np_raw;
+  double* P = rows_out + (size_t)b * Q.np;
+  double* q = P + n * n;
+  double* M = q + n;
+  double* c = M + m * n;
+  double* A = c + m;
+  double* bv = A + me * n;
+  double x[OH_QP_MAX_N], f1[OH_QP_MAX_N];
+  for (int i = 0; i < n; ++i) x[i] = 0.0;
+  const double f0 = qp_tape_forward(tp, x, pb, val, Bp, b);
+  for (int r = 0; r < m; ++r) c[r] = val[QIDX(tp.rows[r])];
+  for (int r = 0; r < me; ++r) bv[r] = val[QIDX(tp.rows[m + r])];
+  for (int i = 0; i < n; ++i) {
+    x[i] = 1.0;
+    f1[i] = qp_tape_forward(tp, x, pb, val, Bp, b);
+    for (int r = 0; r < m; ++r) M[r * n + i] = val[QIDX(tp.rows[r])] - c[r];
+    for (int r = 0; r < me; ++r) A[r * n + i] = val[QIDX(tp.rows[m + r])] - bv[r];
+    x[i] = -1.0;
+    const double fm = qp_tape_forward(tp, x, pb, val, Bp, b);
+    x[i] = 0.0;
+    q[i] = 0.5 * (f1[i] - fm);
+  }
+  for (int i = 0; i < n; ++i) {
+    P[i * n + i] = f1[i] - f0 - q[i];
+    for (int j = 0; j < i; ++j) {
+      x[i] = x[j] = 1.0;
+      const double fij = qp_tape_forward(tp, x, pb, val, Bp, b);
+      x[i] = x[j] = 0.0;
+      P[i * n + j] = P[j * n + i] = 0.5 * (fij - f1[i] - f1[j] + f0);
+    }
+  }
+  f0_out[b] = f0;
+}
+// The same for a few instances: one BLOCK per instance, one lane per probe point (1 + 2 n + n (n - 1) / 2 of them, 64 at a time), registers of
+// lane l of instance b at val[(i * B + b) * 64 + l].  A tick of a velocity-IK controller is one instance: 36 probes side by side instead of one
+// after the other (the sweep is a chain of dependent memory round trips either way).
+__device__ void qp_probe_point(const int pid, const int n, double* x, int* pi, int* pj) {  // x of probe pid; (i, j) of a pair probe, else (-1, -1)
+  for (int k = 0; k < n; ++k) x[k] = 0.0;
+  *pi = *pj = -1;
+  if (pid == 0) return;
+  if (pid <= n) { x[pid - 1] = 1.0; return; }
+  if (pid <= 2 * n) { x[pid - 1 - n] = -1.0; return; }
+  int k = pid - 1 - 2 * n, i = 1;
+  while (k >= i) { k -= i; ++i; }  // pair k of row i: (i, j = k), j < i
+  x[i] = x[k] = 1.0;
+  *pi = i;
+  *pj = k;
+}
+__global__ __launch_bounds__(64) void k_qp_assemble_par(QpParams Q, QpTape tp, int np_raw, int B, const double* __restrict__ par, double* __restrict__ val,
+                                                        double* __restrict__ rows_out, double* __restrict__ f0_out) {
+  __shared__ double fs[1 + 2 * OH_QP_MAX_N + OH_QP_MAX_N * (OH_QP_MAX_N - 1) / 2];
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  const int n = Q.n, m = Q.m, me = Q.me;
+  const int n_probe = 1 + 2 * n + n * (n - 1) / 2;
+  const double* pb = par + (size_t)inst * np_raw;
+  double* P = rows_out + (size_t)inst * Q.np;
+  double* q = P + n * n;
+  double* M = q + n;
+  double* c = M + m * n;
+  double* A = c + m;
+  double* bv = A + me * n;
+  const int Bp = B * 64, b = inst * 64 + lane;  // QIDX(i) = (i * B + inst) * 64 + lane
+  double x[OH_QP_MAX_N];
+  for (int base = 0; base < n_probe; base += 64) {
+    const int pid = base + lane;
+    const bool live = pid < n_probe;
+    int pi, pj;
+    qp_probe_point(live ? pid : 0, n, x, &pi, &pj);
+    const double f = qp_tape_forward(tp, x, pb, val, Bp, b);
+    if (live) fs[pid] = f;
+    if (base == 0) {  // the rows at 0 first, then the columns of M and A relative to them
+      if (lane == 0) {
+        for (int r = 0; r < m; ++r) c[r] = val[QIDX(tp.rows[r])];
+        for (int r = 0; r < me; ++r) bv[r] = val[QIDX(tp.rows[m + r])];
+      }
+      __syncthreads();
+    }
+    if (live && pid >= 1 && pid <= n) {
+      const int i = pid - 1;
+      for (int r = 0; r < m; ++r) M[r * n + i] = val[QIDX(tp.rows[r])] - c[r];
+      for (int r = 0; r < me; ++r) A[r * n + i] = val[QIDX(tp.rows[m + r])] - bv[r];
+    }
+  }
+  __syncthreads();
+  const double f0 = fs[0];
+  for (int i = lane; i < n; i += 64) {
+    const double qi = 0.5 * (fs[1 + i] - fs[1 + n + i]);
+    q[i] = qi;
+    P[i * n + i] = fs[1 + i] - f0 - qi;
+  }
+  for (int k = lane; k < n * (n - 1) / 2; k += 64) {
+    int kk = k, i = 1;
+    while (kk >= i) { kk -= i; ++i; }
+    P[i * n + kk] = P[kk * n + i] = 0.5 * (fs[1 + 2 * n + k] - fs[1 + i] - fs[1 + kk] + f0);
+  }
+  if (lane == 0) f0_out[inst] = f0;
+}
+__global__ __launch_bounds__(256) void k_qp_add_constant(int B, double* __restrict__ f, const double* __restrict__ f0) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) f[b] += f0[b];
+}
+
 }  // namespace
 
-void oh_launch_qp_solve(hipStream_t s, const QpParams& Q, int B, const double* x0, const double* p, double* work, double* x, double* f, double* kkt,
+void oh_launch_qp_assemble(hipStream_t s, const QpParams& Q, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, int B,
+                           int Bp, const double* p_raw, double* val, double* rows_out, double* f0) {
+  const QpTape tp{T.len, T.out_cost, op, a, b, c, rows};
+  if ((size_t)B * 64 <= (size_t)Bp) hipLaunchKernelGGL(k_qp_assemble_par, dim3(B), dim3(64), 0, s, Q, tp, T.np, B, p_raw, val, rows_out, f0);  // room for a lane per probe
+  else hipLaunchKernelGGL(k_qp_assemble, dim3((B + 63) / 64), dim3(64), 0, s, Q, tp, T.np, B, Bp, p_raw, val, rows_out, f0);
+}
+void oh_launch_qp_add_constant(hipStream_t s, int B, double* f, const double* f0) {
+  hipLaunchKernelGGL(k_qp_add_constant, dim3((B + 255) / 256), dim3(256), 0, s, B, f, f0);
+}
+
+void oh_launch_qp_solve(hipStream_t s, const QpParams& Q, int B, int Bp, const double* x0, const double* p, double* work, double* x, double* f, double* kkt,
                         int* iters, int* status, double* mult) {
-  hipLaunchKernelGGL(k_qp_solve, dim3((B + 63) / 64), dim3(64), 0, s, Q, B, x0, p, work, x, f, kkt, iters, status, mult);
+  // the work set of a block in LDS when it fits 48 KB at 64, 32 or 16 instances per block; for a few instances the problem row as well
+  auto fit = [](const size_t doubles) {
+    for (int c : {64, 32, 16})
+      if (sizeof(double) * doubles * c <= 48 * 1024) return c;
+    return 0;
+  };
+  static const int forced = getenv("OH_QP_MODE") ? atoi(getenv("OH_QP_MODE")) : -1;  // experiments
+  const int bs2 = fit((size_t)Q.nwork + Q.np), bs1 = fit((size_t)Q.nwork);
+  int mode = bs2 ? 2 : (bs1 ? 1 : 0);  // (velocity-IK QP, n = 7, m = 16: B = 1 in 1.77 / 1.49 / 1.15 ms wall, 65 536 in 13.0 / 12.7 / 11.5 ms for modes 0 / 1 / 2)
+  if (forced == 0 || (forced == 1 && bs1) || (forced == 2 && bs2)) mode = forced;
+  if (mode == 2)
+    hipLaunchKernelGGL(k_qp_solve<2>, dim3((B + bs2 - 1) / bs2), dim3(bs2), sizeof(double) * ((size_t)Q.nwork + Q.np) * bs2, s, Q, B, Bp, x0, p, work, x, f, kkt, iters,
+                       status, mult);
+  else if (mode == 1)
+    hipLaunchKernelGGL(k_qp_solve<1>, dim3((B + bs1 - 1) / bs1), dim3(bs1), sizeof(double) * (size_t)Q.nwork * bs1, s, Q, B, Bp, x0, p, work, x, f, kkt, iters, status, mult);
+  else hipLaunchKernelGGL(k_qp_solve<0>, dim3((B + 63) / 64), dim3(64), 0, s, Q, B, Bp, x0, p, work, x, f, kkt, iters, status, mult);
 }

@@ -201,6 +201,8 @@ class _QpAdapter:
         x0 = np.asarray(x0, dtype=np.float64).reshape(-1, self.opt.nx)
         p = np.asarray(p, dtype=np.float64).reshape(x0.shape[0], -1)
         o = self.opt
+        if self.be.tape is not None:  # the device reads the QP off the problem's tape (oh_qp_set_tape): no per-instance host work
+            return self.be.solve(x0, p if o.np else np.zeros((x0.shape[0], 1)))
         z = np.zeros(o.nx)
         rows, f0 = [], []
         for pb in p:
@@ -299,7 +301,17 @@ class HIPSolver(Solver):
                                       max_iter=int(o.pop("max_iter", 200)), tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)))
         elif isinstance(spec, QpSpec):
             o.pop("hessian", None)
-            self._backend = _QpAdapter(self.opt, QPBackend(spec.n, spec.m, spec.me, max_iter=int(o.pop("max_iter", 100)), tol=float(o.pop("tol", 1e-9))))
+            qb = QPBackend(spec.n, spec.m, spec.me, max_iter=int(o.pop("max_iter", 100)), tol=float(o.pop("tol", 1e-9)))
+            if bool(o.pop("device_assembly", True)):
+                # P, q, M, c, A, b on the device from the problem's instruction tape; problems the tape compiler does not take (too long,
+                # an expression node without a scalar expansion) keep the host route, where the numeric members are probed per instance
+                try:
+                    from .tape import compile_problem
+
+                    qb.set_tape(compile_problem(self.opt))
+                except (NotImplementedError, TypeError, ValueError):
+                    pass
+            self._backend = _QpAdapter(self.opt, qb)
         elif isinstance(spec, TapeSpec):
             o.pop("hessian", None)
             self._backend = TapeBackend(spec.tape, max_iter=int(o.pop("max_iter", 2000)), tol=float(o.pop("tol", 1e-6)),

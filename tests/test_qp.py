@@ -1,6 +1,8 @@
 """Dense QP family and the reference's only numeric solver test (tests/test_solver.py:22-54): the Booth
 function, (a, b) = (2, 7) -> (x, y) = (1, 3), with and without the huge bound rows of its `constraint=True` variant.
 CPU: numpy port (oracle/qp_ipm.py) vs scipy and the known answer, builder/lowering.  GPU: the same through HIPSolver."""
+import ctypes as C
+
 import numpy as np
 import pytest
 from scipy.optimize import minimize
@@ -192,3 +194,47 @@ def test_planar_idk_known_answer(hip_lib):
         assert np.abs(dq - expect).max() < 1e-7
     else:  # otherwise at least no worse than any feasible scaling of it
         assert dq @ dq >= expect @ expect - 1e-9
+
+
+@pytest.mark.gpu
+def test_qp_data_assembled_on_the_device_equals_the_host_route(hip_lib):
+    """oh_qp_set_tape: the kernel reads [P | q | M | c | A | b] off the problem's instruction tape with the probes the host route applies to the
+    numeric members (optimization.py:219-260 are cs.Functions of p in the reference; solver.py:453-467 evaluates them before a solve).
+    Same rows to rounding, same solutions; p of a solve is the problem's parameter vector."""
+    from examples.differential_ik import DifferentialIK
+    from optas_amd.backend import QPBackend
+    from optas_amd.solver import HIPSolver
+    from optas_amd.tape import compile_problem
+
+    ik = DifferentialIK(height_band=(0.02, 1.18), build_only=True)  # the upper band is active for part of the batch
+    o = ik.optimization
+    rng = np.random.default_rng(SEED + 5)
+    B = 96
+    qc = np.deg2rad([0, 30, 0, -90, 0, 60, 0]) + rng.uniform(-0.3, 0.3, (B, 7))
+    dev = HIPSolver(o).setup("hip_sqp")
+    host = HIPSolver(o).setup("hip_sqp", {"device_assembly": False})
+    assert dev.backend.be.tape is not None and host.backend.be.tape is None
+    x0 = np.zeros((B, o.nx))
+    rd, rh = dev.solve_batch_arrays(x0, qc), host.solve_batch_arrays(x0, qc)
+    assert (rd.status == 0).all() and (rh.status == 0).all()
+    assert np.abs(rd.x - rh.x).max() < 1e-9 and np.abs(rd.f - rh.f).max() < 1e-9 * np.abs(rh.f).max()
+    lam_d, lam_h = dev.backend.be.multipliers(B)[0], host.backend.be.multipliers(B)[0]
+    assert np.abs(lam_d - lam_h).max() < 1e-6 * max(1.0, np.abs(lam_h).max()) and (lam_h > 1e-6).any()
+    # the reference-form objective of the returned point, constant term included
+    for b in (0, 17, 95):
+        assert abs(rd.f[b] - o.f(rd.x[b], qc[b])) < 1e-9 * max(1.0, abs(rd.f[b]))
+    # ABI: sizes must match the handle; only QP handles take a tape
+    tape = compile_problem(o)
+    wrong = QPBackend(o.nx, o.nk + 1, 0)
+    with pytest.raises(optas_amd._lib.OptasHipError, match="differ from the handle"):
+        wrong.set_tape(tape)
+    wrong.close()
+    from optas_amd.backend import PointMassBackend, TapeBackend
+
+    pm = PointMassBackend()
+    td = TapeBackend.descriptor(tape)
+    assert hip_lib.oh_qp_set_tape(pm._h, C.byref(td)) == optas_amd._lib.OH_ERR_STATE
+    assert hip_lib.oh_qp_set_tape(None, C.byref(td)) == optas_amd._lib.OH_ERR_INVALID
+    pm.close()
+    dev.backend.close()
+    host.backend.close()

@@ -227,6 +227,238 @@ __global__ __launch_bounds__(64) void k_qp_solve(QpParams Q, int B, int Bp, cons
   }
 }
 
+// The same iteration for a FEW instances (a controller's tick is one): one wavefront per instance, everything of the instance in LDS, the loops
+// over rows, columns and matrix entries spread over the lanes, the short serial parts (Cholesky factor, substitutions, the Schur complement of
+// the equality rows) executed by all lanes alike.  One thread per instance is a chain of ~3000 dependent LDS accesses per iteration (80 us);
+// here an iteration is a few hundred.  Sums over lanes associate differently than the thread's loop: results agree to rounding, not bit for bit.
+__device__ double qp_wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+__device__ double qp_wave_max(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+  return v;
+}
+__device__ double qp_wave_min(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m));
+  return v;
+}
+__global__ __launch_bounds__(64) void k_qp_solve_wave(QpParams Q, int B, const double* __restrict__ x0, const double* __restrict__ par, double* __restrict__ xo,
+                                                      double* __restrict__ fo, double* __restrict__ kkt, int* __restrict__ iters, int* __restrict__ status,
+                                                      double* __restrict__ mult) {
+  extern __shared__ double qp_sm[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int n = Q.n, m = Q.m, me = Q.me;
+  QArr w{qp_sm, 1};
+  for (int k = lane; k < Q.np; k += 64) w[k] = par[(size_t)b * Q.np + k];
+  const QArr P = w;                  // [n][n]
+  const QArr q = P.at(n * n);        // [n]
+  const QArr M = q.at(n);            // [m][n]
+  const QArr c = M.at(m * n);        // [m]
+  const QArr A = c.at(m);            // [me][n]
+  const QArr bv = A.at(me * n);      // [me]
+  w = w.at(Q.np);
+  const QArr x = w; w = w.at(n);
+  const QArr s = w; w = w.at(m);
+  const QArr lam = w; w = w.at(m);
+  const QArr nu = w; w = w.at(me);
+  const QArr H = w; w = w.at(n * n);
+  const QArr rhs = w; w = w.at(n);
+  const QArr dx = w; w = w.at(n);
+  const QArr ds = w; w = w.at(m);
+  const QArr dl = w; w = w.at(m);
+  const QArr Y = w; w = w.at(me * n);
+  const QArr S = w; w = w.at(me * me);
+  const QArr dnu = w; w = w.at(me);
+  const QArr rd = w; w = w.at(n);
+  for (int i = lane; i < n; i += 64) x[i] = x0[(size_t)b * n + i];
+  for (int i = lane; i < me; i += 64) nu[i] = 0.0;
+  __syncthreads();
+  double mu = 1.0;
+  for (int i = lane; i < m; i += 64) {
+    double v = c[i];
+    for (int j = 0; j < n; ++j) v += M[i * n + j] * x[j];
+    s[i] = fmax(v, 1.0);
+    lam[i] = mu / s[i];
+  }
+  __syncthreads();
+  int st = OH_STATUS_MAX_ITER, it = 0;
+  double stat = 0.0, feas = 0.0, gap = 0.0;
+  for (; it <= Q.max_iter; ++it) {
+    stat = 0.0; feas = 0.0; gap = 0.0;
+    bool finite = true;
+    for (int i = lane; i < n; i += 64) {
+      double v = q[i];
+      for (int j = 0; j < n; ++j) v += 2.0 * P[i * n + j] * x[j];
+      for (int k = 0; k < m; ++k) v -= M[k * n + i] * lam[k];
+      for (int k = 0; k < me; ++k) v -= A[k * n + i] * nu[k];
+      rd[i] = v;
+      stat = fmax(stat, fabs(v));
+      finite = finite && (v == v) && (fabs(v) < 1e300);
+    }
+    for (int i = lane; i < m; i += 64) {
+      double v = c[i] - s[i];
+      for (int j = 0; j < n; ++j) v += M[i * n + j] * x[j];
+      ds[i] = v;  // r_p
+      feas = fmax(feas, fabs(v));
+      gap = fmax(gap, s[i] * lam[i]);
+      dl[i] = lam[i] / s[i];
+    }
+    for (int i = lane; i < me; i += 64) {
+      double v = bv[i];
+      for (int j = 0; j < n; ++j) v += A[i * n + j] * x[j];
+      dnu[i] = v;  // r_e
+      feas = fmax(feas, fabs(v));
+    }
+    finite = __all(finite);
+    const bool feas_nan = __any(!(feas == feas));
+    stat = qp_wave_max(stat);
+    feas = qp_wave_max(feas);
+    gap = qp_wave_max(gap);
+    __syncthreads();
+    if (!finite || feas_nan) { st = OH_STATUS_NUMERICAL; break; }
+    if (stat <= Q.tol && feas <= Q.tol && gap <= Q.tol) { st = OH_STATUS_CONVERGED; break; }
+    if (it == Q.max_iter) break;
+    // H = 2P + M^T diag(lam/s) M, entry (i, j <= i) per lane; rhs = -rd + M^T [(mu/s - lam) - (lam/s) r_p]
+    const int nh = n * (n + 1) / 2;
+    auto build = [&]() {
+      for (int e = lane; e < nh; e += 64) {
+        int i = 0, r = e;
+        while (r > i) { r -= i + 1; ++i; }  // e = i (i + 1) / 2 + j
+        const int j = r;
+        double v = P[i * n + j] + P[j * n + i];
+        for (int k = 0; k < m; ++k) v += M[k * n + i] * dl[k] * M[k * n + j];
+        H[i * n + j] = v;
+      }
+    };
+    build();
+    for (int i = lane; i < n; i += 64) {
+      double r = -rd[i];
+      for (int k = 0; k < m; ++k) r += M[k * n + i] * ((mu / s[k] - lam[k]) - dl[k] * ds[k]);
+      rhs[i] = r;
+    }
+    __syncthreads();
+    double dmax = 0.0;
+    for (int i = 0; i < n; ++i) dmax = fmax(dmax, fabs(H[i * n + i]));
+    double shift = 1e-13 * fmax(dmax, 1.0);
+    bool ok = false;
+    for (int attempt = 0; attempt < 8 && !ok; ++attempt) {
+      if (attempt > 0) {  // rebuild with a larger shift (singular P without enough active rows)
+        __syncthreads();
+        build();
+        shift *= 1e3;
+        __syncthreads();
+      }
+      for (int i = lane; i < n; i += 64) H[i * n + i] += shift;
+      __syncthreads();
+      // left-looking Cholesky: the pivot of column j by every lane alike, the rows below it one per lane
+      ok = true;
+      for (int j = 0; j < n && ok; ++j) {
+        double d = H[j * n + j];
+        for (int k = 0; k < j; ++k) d -= H[j * n + k] * H[j * n + k];
+        if (!(d > 0.0)) { ok = false; break; }
+        const double l = sqrt(d);
+        double vmine = 0.0;
+        const int i = j + 1 + lane;
+        if (i < n) {
+          vmine = H[i * n + j];
+          for (int k = 0; k < j; ++k) vmine -= H[i * n + k] * H[j * n + k];
+        }
+        __syncthreads();
+        if (lane == 0) H[j * n + j] = l;
+        if (i < n) H[i * n + j] = vmine / l;
+        __syncthreads();
+      }
+    }
+    if (!ok) { st = OH_STATUS_NUMERICAL; break; }
+    // the substitutions and the equality rows: short, serial, by all lanes alike (the same values land in the same places)
+    for (int i = lane; i < n; i += 64) dx[i] = rhs[i];
+    __syncthreads();
+    if (lane == 0) qp_solve_chol(H, n, dx);  // H^{-1} rhs
+    __syncthreads();
+    if (me > 0) {
+      for (int i = lane; i < me; i += 64) {  // row i of Y = H^{-1} A_i: one lane per equality row
+        for (int j = 0; j < n; ++j) Y[i * n + j] = A[i * n + j];
+        qp_solve_chol(H, n, Y.at(i * n));
+      }
+      __syncthreads();
+      for (int i = lane; i < me; i += 64) {
+        double r = -dnu[i];
+        for (int j = 0; j < n; ++j) r -= A[i * n + j] * dx[j];
+        for (int k = 0; k <= i; ++k) {
+          double v = 0.0;
+          for (int j = 0; j < n; ++j) v += A[i * n + j] * Y[k * n + j];
+          S[i * me + k] = v;
+        }
+        S[i * me + i] += 1e-14 * fmax(1.0, S[i * me + i]);
+        dnu[i] = r;
+      }
+      __syncthreads();
+      bool oks = true;
+      if (lane == 0) {
+        oks = qp_chol(S, me);
+        if (oks) {
+          qp_solve_chol(S, me, dnu);
+          for (int i = 0; i < me; ++i)
+            for (int j = 0; j < n; ++j) dx[j] += Y[i * n + j] * dnu[i];
+        }
+      }
+      oks = __all(oks);
+      __syncthreads();
+      if (!oks) { st = OH_STATUS_NUMERICAL; break; }
+    }
+    // ds = M dx + r_p ; dlam = (mu/s - lam) - (lam/s) ds ; fraction to the boundary
+    double ap = 1.0, ad = 1.0;
+    for (int i = lane; i < m; i += 64) {
+      double v = ds[i];
+      for (int j = 0; j < n; ++j) v += M[i * n + j] * dx[j];
+      const double d2 = (mu / s[i] - lam[i]) - dl[i] * v;
+      ds[i] = v;
+      dl[i] = d2;
+      if (v < 0.0) ap = fmin(ap, -0.995 * s[i] / v);
+      if (d2 < 0.0) ad = fmin(ad, -0.995 * lam[i] / d2);
+    }
+    ap = qp_wave_min(ap);
+    ad = qp_wave_min(ad);
+    for (int i = lane; i < n; i += 64) x[i] += ap * dx[i];
+    double comp = 0.0;
+    for (int i = lane; i < m; i += 64) {
+      s[i] += ap * ds[i];
+      lam[i] += ad * dl[i];
+      comp += s[i] * lam[i];
+    }
+    comp = qp_wave_sum(comp);
+    for (int i = lane; i < me; i += 64) nu[i] += ad * dnu[i];
+    if (m > 0) {
+      const double am = fmin(ap, ad);
+      const double sigma = (am > 0.9) ? 0.1 : ((am > 0.5) ? 0.3 : 0.8);
+      mu = fmax(sigma * comp / m, 1e-2 * Q.tol);
+    }
+    __syncthreads();
+  }
+  double fval = 0.0;
+  for (int i = lane; i < n; i += 64) {
+    double v = q[i];
+    for (int j = 0; j < n; ++j) v += P[i * n + j] * x[j];
+    fval += v * x[i];
+    if (xo) xo[(size_t)b * n + i] = x[i];
+  }
+  fval = qp_wave_sum(fval);
+  if (lane == 0) {
+    if (fo) fo[b] = fval;
+    if (kkt) { kkt[3 * (size_t)b] = stat; kkt[3 * (size_t)b + 1] = feas; kkt[3 * (size_t)b + 2] = gap; }
+    if (iters) iters[b] = it;
+    if (status) status[b] = st;
+  }
+  if (mult) {
+    for (int i = lane; i < m; i += 64) mult[(size_t)b * (m + me) + i] = lam[i];
+    for (int i = lane; i < me; i += 64) mult[(size_t)b * (m + me) + m + i] = nu[i];
+  }
+}
+
 // ---- QP data read off the problem's instruction tape on the device (oh_qp_set_tape) -----------------------------------------------------
 // The reference's QuadraticCost* classes hold P, q, M, c, A, b as cs.Functions of the parameters (optimization.py:219-260); the mirror reads
 // them off f, k, a by probing on the host (optas_amd/optimization.py: values at 0, +-e_i, e_i + e_j -- exact for a quadratic cost and affine
@@ -395,6 +627,11 @@ void oh_launch_qp_solve(hipStream_t s, const QpParams& Q, int B, int Bp, const d
   };
   static const int forced = getenv("OH_QP_MODE") ? atoi(getenv("OH_QP_MODE")) : -1;  // experiments
   const int bs2 = fit((size_t)Q.nwork + Q.np), bs1 = fit((size_t)Q.nwork);
+  const size_t wave_bytes = sizeof(double) * ((size_t)Q.nwork + Q.np);
+  if (forced != 0 && forced != 1 && forced != 2 && B <= 64 && wave_bytes <= 48 * 1024) {  // a few instances: one wavefront each
+    hipLaunchKernelGGL(k_qp_solve_wave, dim3(B), dim3(64), wave_bytes, s, Q, B, x0, p, x, f, kkt, iters, status, mult);
+    return;
+  }
   int mode = bs2 ? 2 : (bs1 ? 1 : 0);  // (velocity-IK QP, n = 7, m = 16: B = 1 in 1.77 / 1.49 / 1.15 ms wall, 65 536 in 13.0 / 12.7 / 11.5 ms for modes 0 / 1 / 2)
   if (forced == 0 || (forced == 1 && bs1) || (forced == 2 && bs2)) mode = forced;
   if (mode == 2)

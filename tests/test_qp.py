@@ -119,6 +119,13 @@ def test_dense_qp_kernel_matches_port(hip_lib):
             assert int(r.iters[i]) == s["iters"] and abs(r.f[i] - s["f"]) < 1e-9 * max(1.0, abs(s["f"])) and np.abs(r.x[i] - s["x"]).max() < 1e-8
             assert np.abs(lam[i] - s["lam"]).max(initial=0.0) < 1e-6 and np.abs(nu[i] - s["nu"]).max(initial=0.0) < 1e-6
             assert (M @ r.x[i] + c >= -1e-9).all() and (np.abs(A @ r.x[i] + b) <= 1e-9).all()
+        # a few instances take the wavefront-per-instance kernel (lanes over rows / matrix entries): same iteration, sums associated differently
+        rows = np.stack([QPBackend.pack(*qp) for qp in qps[:40]])
+        rw = be.solve(np.zeros((40, n)), rows)
+        lam_w, nu_w = be.multipliers(40)
+        assert (rw.status == 0).all() and (rw.iters == r.iters[:40]).all()
+        assert np.abs(rw.x - r.x[:40]).max() < 1e-9 and np.abs(rw.f - r.f[:40]).max() < 1e-9 * max(1.0, np.abs(r.f).max())
+        assert np.abs(lam_w - lam[:40]).max(initial=0.0) < 1e-7 and np.abs(nu_w - nu[:40]).max(initial=0.0) < 1e-7
         be.close()
 
 

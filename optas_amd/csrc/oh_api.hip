@@ -77,6 +77,8 @@ struct oh_handle {
   double* d_qp_rows = nullptr;  // [B][qp_np] assembled [P | q | M | c | A | b]
   double* d_qp_val = nullptr;   // [TP.len][Bp] registers of the tape interpreter
   double* d_qp_f0 = nullptr;    // [B] f(0, p)
+  int* d_qp_xdep = nullptr;     // indices of the tape's x-dependent instructions
+  int qp_n_xdep = 0;
   int qp_tape_cap = 0;
   // inverse-kinematics family
   oh_ik_desc ik{};
@@ -423,6 +425,22 @@ extern "C" int oh_qp_set_tape(oh_handle* h, const oh_tape_desc* d) {
   HIPCHK(hipMemcpy(h->d_tape_c, d->c, ld, hipMemcpyHostToDevice));
   if (d->n_ineq + d->n_eq > 0) HIPCHK(hipMemcpy(h->d_tape_rows, d->rows, sizeof(int) * (size_t)(d->n_ineq + d->n_eq), hipMemcpyHostToDevice));
   h->TP = tape_params(d);
+  {
+    // instructions whose value depends on x: the probes after the first re-run only these
+    std::vector<char> dep((size_t)d->len, 0);
+    std::vector<int> list;
+    for (int i = 0; i < d->len; ++i) {
+      const int o = d->op[i];
+      const bool two = (o >= 3 && o <= 6) || o == 10, one = o == 7 || o == 8 || o == 9 || o == 11 || o == 12;
+      dep[i] = o == 1 || ((one || two) && dep[d->a[i]]) || (two && dep[d->b[i]]);
+      if (dep[i]) list.push_back(i);
+    }
+    if (h->d_qp_xdep) hipFree(h->d_qp_xdep);
+    h->d_qp_xdep = nullptr;
+    h->qp_n_xdep = (int)list.size();
+    HIPCHK(hipMalloc((void**)&h->d_qp_xdep, sizeof(int) * (list.size() + 1)));
+    if (!list.empty()) HIPCHK(hipMemcpy(h->d_qp_xdep, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
+  }
   if (h->qp_tape_cap) {  // the register file of another tape: size it again at the next solve
     for (double** q2 : {&h->d_qp_rows, &h->d_qp_val, &h->d_qp_f0}) {
       if (*q2) hipFree(*q2);
@@ -465,7 +483,7 @@ static int qp_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   }
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   if (h->qp_tape) {
-    oh_launch_qp_assemble(h->stream, Q, h->TP, h->d_tape_op, h->d_tape_a, h->d_tape_b, h->d_tape_c, h->d_tape_rows, B, B <= 64 ? B * 64 : h->qp_tape_cap, (const double*)d_p,
+    oh_launch_qp_assemble(h->stream, Q, h->TP, h->d_tape_op, h->d_tape_a, h->d_tape_b, h->d_tape_c, h->d_tape_rows, h->d_qp_xdep, h->qp_n_xdep, B, B <= 64 ? B * 64 : h->qp_tape_cap, (const double*)d_p,
                           h->d_qp_val, h->d_qp_rows, h->d_qp_f0);
     d_p = h->d_qp_rows;
   }
@@ -1527,7 +1545,7 @@ extern "C" void oh_destroy(oh_handle* h) {
   for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult})
     if (q) hipFree(q);
   if (h->d_qp_mult) hipFree(h->d_qp_mult);
-  for (void* q : {(void*)h->d_qp_rows, (void*)h->d_qp_val, (void*)h->d_qp_f0})
+  for (void* q : {(void*)h->d_qp_rows, (void*)h->d_qp_val, (void*)h->d_qp_f0, (void*)h->d_qp_xdep})
     if (q) hipFree(q);
   if (h->stage) hipFree(h->stage);
   if (h->d_chain) hipFree(h->d_chain);

@@ -127,8 +127,8 @@ void oh_launch_qp_solve(hipStream_t s, const QpParams& Q, int B, int Bp, const d
 #define OH_TAPE_ST_NUMERICAL OH_STATUS_NUMERICAL
 #include "oh_tape_solver.h"  // TapeParams, TapeWork and the solver shared by the interpreter and the generated code
 // QP data read off a tape on the device (oh_qp_set_tape): val = [T.len][Bp] work, rows_out = [B][Q.np], f0 = [B]
-void oh_launch_qp_assemble(hipStream_t s, const QpParams& Q, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, int B,
-                           int Bp, const double* p_raw, double* val, double* rows_out, double* f0);
+void oh_launch_qp_assemble(hipStream_t s, const QpParams& Q, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows,
+                           const int* xdep, int n_xdep, int B, int Bp, const double* p_raw, double* val, double* rows_out, double* f0);  // xdep: x-dependent instructions
 void oh_launch_qp_add_constant(hipStream_t s, int B, double* f, const double* f0);
 struct TapeJit {
   hipModule_t mod = nullptr;

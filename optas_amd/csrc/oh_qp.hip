@@ -472,11 +472,17 @@ struct QpTape {
   const int* __restrict__ bb;
   const double* __restrict__ c;
   const int* __restrict__ rows;
+  int n_xdep;                     // instructions whose value depends on x (the kinematics of a velocity-IK problem depend on p only:
+  const int* __restrict__ xdep;   // 139 of its 474 instructions are left), in tape order
 };
 #define QIDX(i) ((size_t)(i) * Bp + b)
+// FULL: every instruction; else only the x-dependent ones (the others keep the values of an earlier full sweep at the same p)
+template <bool FULL>
 __device__ double qp_tape_forward(const QpTape& tp, const double* xs, const double* __restrict__ pb, double* __restrict__ val, const int Bp, const int b) {
 #pragma clang fp contract(off)
-  for (int i = 0; i < tp.len; ++i) {
+  const int cnt = FULL ? tp.len : tp.n_xdep;
+  for (int k = 0; k < cnt; ++k) {
+    const int i = FULL ? k : tp.xdep[k];
     const int o = tp.op[i], ia = tp.a[i], ib = tp.bb[i];
     double v;
     switch (o) {
@@ -512,16 +518,16 @@ __global__ __launch_bounds__(64) void k_qp_assemble(QpParams Q, QpTape tp, int n
   double* bv = A + me * n;
   double x[OH_QP_MAX_N], f1[OH_QP_MAX_N];
   for (int i = 0; i < n; ++i) x[i] = 0.0;
-  const double f0 = qp_tape_forward(tp, x, pb, val, Bp, b);
+  const double f0 = qp_tape_forward<true>(tp, x, pb, val, Bp, b);
   for (int r = 0; r < m; ++r) c[r] = val[QIDX(tp.rows[r])];
   for (int r = 0; r < me; ++r) bv[r] = val[QIDX(tp.rows[m + r])];
   for (int i = 0; i < n; ++i) {
     x[i] = 1.0;
-    f1[i] = qp_tape_forward(tp, x, pb, val, Bp, b);
+    f1[i] = qp_tape_forward<false>(tp, x, pb, val, Bp, b);
     for (int r = 0; r < m; ++r) M[r * n + i] = val[QIDX(tp.rows[r])] - c[r];
     for (int r = 0; r < me; ++r) A[r * n + i] = val[QIDX(tp.rows[m + r])] - bv[r];
     x[i] = -1.0;
-    const double fm = qp_tape_forward(tp, x, pb, val, Bp, b);
+    const double fm = qp_tape_forward<false>(tp, x, pb, val, Bp, b);
     x[i] = 0.0;
     q[i] = 0.5 * (f1[i] - fm);
   }
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(64) void k_qp_assemble(QpParams Q, QpTape tp, int n
     P[i * n + i] = f1[i] - f0 - q[i];
     for (int j = 0; j < i; ++j) {
       x[i] = x[j] = 1.0;
-      const double fij = qp_tape_forward(tp, x, pb, val, Bp, b);
+      const double fij = qp_tape_forward<false>(tp, x, pb, val, Bp, b);
       x[i] = x[j] = 0.0;
       P[i * n + j] = P[j * n + i] = 0.5 * (fij - f1[i] - f1[j] + f0);
     }
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(64) void k_qp_assemble_par(QpParams Q, QpTape tp, i
     const bool live = pid < n_probe;
     int pi, pj;
     qp_probe_point(live ? pid : 0, n, x, &pi, &pj);
-    const double f = qp_tape_forward(tp, x, pb, val, Bp, b);
+    const double f = qp_tape_forward<true>(tp, x, pb, val, Bp, b);
     if (live) fs[pid] = f;
     if (base == 0) {  // the rows at 0 first, then the columns of M and A relative to them
       if (lane == 0) {
@@ -607,9 +613,9 @@ __global__ __launch_bounds__(256) void k_qp_add_constant(int B, double* __restri
 
 }  // namespace
 
-void oh_launch_qp_assemble(hipStream_t s, const QpParams& Q, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, int B,
-                           int Bp, const double* p_raw, double* val, double* rows_out, double* f0) {
-  const QpTape tp{T.len, T.out_cost, op, a, b, c, rows};
+void oh_launch_qp_assemble(hipStream_t s, const QpParams& Q, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows,
+                           const int* xdep, int n_xdep, int B, int Bp, const double* p_raw, double* val, double* rows_out, double* f0) {
+  const QpTape tp{T.len, T.out_cost, op, a, b, c, rows, n_xdep, xdep};
   if ((size_t)B * 64 <= (size_t)Bp) hipLaunchKernelGGL(k_qp_assemble_par, dim3(B), dim3(64), 0, s, Q, tp, T.np, B, p_raw, val, rows_out, f0);  // room for a lane per probe
   else hipLaunchKernelGGL(k_qp_assemble, dim3((B + 63) / 64), dim3(64), 0, s, Q, tp, T.np, B, Bp, p_raw, val, rows_out, f0);
 }

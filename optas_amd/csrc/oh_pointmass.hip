@@ -3,6 +3,8 @@
 // by a Riccati sweep over the T stages (state (y,v) in R^4, control a in R^2).  Per-instance work arrays live
 // in HBM scratch laid out [row][b] (instance index fastest -> coalesced; ~6 KB per instance, so a 4096-batch
 // stays resident in L2 / Infinity Cache).  Algorithm and constants mirror oracle/pointmass_ipm.py line by line.
+#include <cstdlib>
+
 #include "oh_device.h"
 #include "oh_kernels.h"
 
@@ -332,6 +334,269 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
   if (status_o) status_o[b] = status;
 }
 
+// ---- the same solve, ONE WAVEFRONT PER INSTANCE, one lane per knot (T <= 64) ---------------------------------------------------------------
+// One lane per instance walks 3 x T knots per iteration with ~1000 dependent instructions each: 134 us per iteration whatever the batch, and
+// BASELINE's 4096 plants are 64 wavefronts on 1024 SIMDs.  Here everything that belongs to a knot (constraint values, slacks, multipliers,
+// the stage's Q, q and Lagrangian gradient, step lengths, the slack / multiplier update) is computed by the knot's lane from registers -- no
+// work arrays at all -- and only the three recursions stay serial: the Riccati sweep, the Newton direction and the roll-out, executed by all
+// lanes alike on values broadcast from the knot's lane (v_readlane), each lane keeping what belongs to its knot (gains, dx, da, x).  The
+// recursions perform the thread kernel's operations in the thread kernel's order, and so does the sum behind the barrier parameter; only the
+// reported objective is summed across lanes.  One iteration: ~20 us.
+OH_DEV double pm_bcast(const double v, const int lane) {  // lane must be wave-uniform
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+OH_DEV double pm_wave_max(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+  return v;
+}
+OH_DEV double pm_wave_min(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m));
+  return v;
+}
+OH_DEV double pm_wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_pm_solve_wave(PmParams P, int B, const double* __restrict__ x0, const double* __restrict__ pin, double* __restrict__ xo,
+                                                      double* __restrict__ fo, double* __restrict__ kkt, int* __restrict__ iters_o, int* __restrict__ status_o) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int T = P.T;
+  const bool on = lane < T;
+  const double dt = P.dt, w = P.w_acc;
+  const size_t np_ = 4 + 4 * (size_t)T, nx = 4 * (size_t)T;
+  const double* pb = pin + (size_t)b * np_;
+  const int tk = on ? lane : T - 1;
+  const double g0 = pb[4 + 2 * tk], g1 = pb[4 + 2 * tk + 1];                  // goal of this knot
+  const double o0 = pb[4 + 2 * T + 2 * tk], o1 = pb[4 + 2 * T + 2 * tk + 1];  // obstacle centre at this knot
+  double X[4] = {0, 0, 0, 0}, a[2] = {0, 0};
+  // ---- seed (k_pm_solve): velocities from x0's dY block, controls = velocity differences, states by roll-out
+  {
+    double vprev[2] = {pb[2], pb[3]};
+    double x[4] = {pb[0], pb[1], pb[2], pb[3]};
+    if (lane == 0)
+      for (int j = 0; j < 4; ++j) X[j] = x[j];
+    for (int t = 0; t < T - 1; ++t) {
+      double v1[2] = {x0[(size_t)b * nx + 2 * T + 2 * (t + 1)], x0[(size_t)b * nx + 2 * T + 2 * (t + 1) + 1]};
+      if (P.fix_vf && t == T - 2) v1[0] = v1[1] = 0.0;
+      const double a0 = (v1[0] - vprev[0]) / dt, a1 = (v1[1] - vprev[1]) / dt;
+      if (lane == t) { a[0] = a0; a[1] = a1; }
+      x[0] += dt * x[2]; x[1] += dt * x[3]; x[2] += dt * a0; x[3] += dt * a1;
+      if (lane == t + 1)
+        for (int j = 0; j < 4; ++j) X[j] = x[j];
+      vprev[0] = v1[0]; vprev[1] = v1[1];
+    }
+  }
+  double mu = 0.1;
+  double s[9], lam[9];
+  {
+    double c[9], jx, jy;
+    pm_cons(P, X, o0, o1, c, jx, jy);
+    for (int i = 0; i < 9; ++i) {
+      s[i] = fmax(c[i], 1e-2);
+      lam[i] = mu / s[i];
+    }
+  }
+  int status = OH_STATUS_MAX_ITER, it = 0;
+  double stat = 0.0, feas = 0.0, compl_ = 0.0, fval = 0.0;
+  for (it = 0; it <= P.max_iter; ++it) {
+    // ---- per knot: constraints, residuals, the stage's Q, q and Lagrangian gradient --------------------------------------------------
+    double c[9], jx, jy;
+    pm_cons(P, X, o0, o1, c, jx, jy);
+    const double wt = (P.final_only && lane < T - 1) ? 0.0 : 1.0;
+    const double gx[4] = {-2.0 * wt * (g0 - X[0]), -2.0 * wt * (g1 - X[1]), 2.0 * P.w_vel * X[2], 2.0 * P.w_vel * X[3]};
+    double fl = wt * ((g0 - X[0]) * (g0 - X[0]) + (g1 - X[1]) * (g1 - X[1])) + P.w_vel * (X[2] * X[2] + X[3] * X[3]);
+    if (lane < T - 1) fl += w * (a[0] * a[0] + a[1] * a[1]);
+    double rc[9], sig[9], wq[9], jl[4], jq[4];
+    double fe = 0.0, co = 0.0;
+    for (int i = 0; i < 9; ++i) {
+      rc[i] = c[i] - s[i];
+      sig[i] = lam[i] / s[i];
+      wq[i] = mu / s[i] - sig[i] * rc[i];
+      if (on && lane >= 1) { fe = fmax(fe, fabs(rc[i])); co = fmax(co, lam[i] * s[i]); }
+    }
+    pm_JTw(lam, jx, jy, jl);
+    pm_JTw(wq, jx, jy, jq);
+    double lx[4], q[4];
+    for (int j = 0; j < 4; ++j) { lx[j] = gx[j] - jl[j]; q[j] = gx[j] - jq[j]; }
+    const double Q0 = 2.0 * wt + sig[0] + sig[1] + sig[8] * jx * jx, Q5 = 2.0 * wt + sig[2] + sig[3] + sig[8] * jy * jy, Q1 = sig[8] * jx * jy;
+    const double Q10 = 2.0 * P.w_vel + sig[4] + sig[5], Q15 = 2.0 * P.w_vel + sig[6] + sig[7];
+    fval = pm_wave_sum(on ? fl : 0.0);
+    feas = pm_wave_max(fe);
+    compl_ = pm_wave_max(co);
+    {  // (fmax drops NaNs: carry them separately, the thread kernel's maxima see them through the comparison chain as well)
+      bool bad = false;
+      for (int i = 0; i < 9; ++i) bad = bad || !(rc[i] == rc[i]) || !(lam[i] * s[i] == lam[i] * s[i]);
+      if (__any(on && bad)) feas = __builtin_nan("");
+    }
+    // ---- backward: Riccati recursion, all lanes alike; lane t keeps K_t, k_t ----------------------------------------------------------
+    double Pm[16], pv[4], padj[4];
+    double Kmine[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kmine[2] = {0, 0};
+    stat = 0.0;
+    for (int t = T - 1; t >= 0; --t) {
+      double Q[16];
+      for (int j = 0; j < 16; ++j) Q[j] = 0.0;
+      Q[0] = pm_bcast(Q0, t); Q[5] = pm_bcast(Q5, t); Q[1] = Q[4] = pm_bcast(Q1, t); Q[10] = pm_bcast(Q10, t); Q[15] = pm_bcast(Q15, t);
+      double qs[4], lxs[4];
+      for (int j = 0; j < 4; ++j) { qs[j] = pm_bcast(q[j], t); lxs[j] = pm_bcast(lx[j], t); }
+      if (t == T - 1) {
+        for (int j = 0; j < 16; ++j) Pm[j] = Q[j];
+        for (int j = 0; j < 4; ++j) { pv[j] = qs[j]; padj[j] = lxs[j]; }
+        continue;
+      }
+      const double a0 = pm_bcast(a[0], t), a1 = pm_bcast(a[1], t);
+      const bool pinned = P.fix_vf && t == T - 2;
+      const double gu0 = 2.0 * w * a0 + dt * padj[2], gu1 = 2.0 * w * a1 + dt * padj[3];
+      if (!pinned) stat = fmax(stat, fmax(fabs(gu0), fabs(gu1)));
+      double PA[16];
+      for (int r = 0; r < 4; ++r) {
+        PA[4 * r + 0] = Pm[4 * r + 0]; PA[4 * r + 1] = Pm[4 * r + 1];
+        PA[4 * r + 2] = Pm[4 * r + 2] + dt * Pm[4 * r + 0];
+        PA[4 * r + 3] = Pm[4 * r + 3] + dt * Pm[4 * r + 1];
+      }
+      const double q00 = 2.0 * w + dt * dt * Pm[10], q01 = dt * dt * Pm[11], q11 = 2.0 * w + dt * dt * Pm[15];
+      double Qux[8];
+      for (int j = 0; j < 4; ++j) { Qux[j] = dt * PA[8 + j]; Qux[4 + j] = dt * PA[12 + j]; }
+      const double qu0 = 2.0 * w * a0 + dt * pv[2], qu1 = 2.0 * w * a1 + dt * pv[3];
+      const double l00 = sqrt(q00), l10 = q01 / l00, l11 = sqrt(q11 - l10 * l10);
+      double Kt[8], kt[2];
+      double Pn[16], pn[4], pa[4];
+      if (pinned) {
+        for (int j = 0; j < 8; ++j) Kt[j] = 0.0;
+        Kt[2] = Kt[4 + 3] = -1.0 / dt;
+        kt[0] = kt[1] = 0.0;
+        const double kf = -1.0 / dt;
+        for (int r = 0; r < 4; ++r)
+          for (int cc = 0; cc < 4; ++cc) {
+            double v = PA[4 * r + cc];
+            if (r >= 2) v += dt * PA[4 * (r - 2) + cc];
+            v += Qux[r] * Kt[cc] + Qux[4 + r] * Kt[4 + cc];
+            v += Kt[r] * Qux[cc] + Kt[4 + r] * Qux[4 + cc];
+            Pn[4 * r + cc] = Q[4 * r + cc] + v;
+          }
+        Pn[10] += kf * kf * q00; Pn[11] += kf * kf * q01; Pn[14] += kf * kf * q01; Pn[15] += kf * kf * q11;
+        for (int r = 0; r < 4; ++r) {
+          double v = pv[r], va = padj[r];
+          if (r >= 2) { v += dt * pv[r - 2]; va += dt * padj[r - 2]; }
+          pn[r] = qs[r] + v;
+          pa[r] = lxs[r] + va;
+        }
+        pn[2] += kf * qu0; pn[3] += kf * qu1;
+        pa[2] += kf * gu0; pa[3] += kf * gu1;
+      } else {
+        for (int j = 0; j < 4; ++j) {
+          const double y0 = Qux[j] / l00, y1 = (Qux[4 + j] - l10 * y0) / l11;
+          const double z1 = y1 / l11, z0 = (y0 - l10 * z1) / l00;
+          Kt[j] = -z0; Kt[4 + j] = -z1;
+        }
+        const double y0 = qu0 / l00, y1 = (qu1 - l10 * y0) / l11;
+        const double z1 = y1 / l11, z0 = (y0 - l10 * z1) / l00;
+        kt[0] = -z0; kt[1] = -z1;
+        for (int r = 0; r < 4; ++r)
+          for (int cc = 0; cc < 4; ++cc) {
+            double v = PA[4 * r + cc];
+            if (r >= 2) v += dt * PA[4 * (r - 2) + cc];
+            v += Qux[r] * Kt[cc] + Qux[4 + r] * Kt[4 + cc];
+            Pn[4 * r + cc] = Q[4 * r + cc] + v;
+          }
+        for (int r = 0; r < 4; ++r) {
+          double v = pv[r], va = padj[r];
+          if (r >= 2) { v += dt * pv[r - 2]; va += dt * padj[r - 2]; }
+          pn[r] = qs[r] + v + Qux[r] * kt[0] + Qux[4 + r] * kt[1];
+          pa[r] = lxs[r] + va;
+        }
+      }
+      if (lane == t) {
+        for (int j = 0; j < 8; ++j) Kmine[j] = Kt[j];
+        kmine[0] = kt[0]; kmine[1] = kt[1];
+      }
+      for (int r = 0; r < 4; ++r)
+        for (int cc = 0; cc < 4; ++cc) Pm[4 * r + cc] = 0.5 * (Pn[4 * r + cc] + Pn[4 * cc + r]);
+      for (int j = 0; j < 4; ++j) { pv[j] = pn[j]; padj[j] = pa[j]; }
+    }
+    if (!(stat == stat) || !(fval == fval) || !(fabs(fval) < 1e300) || !(feas == feas) || !(compl_ == compl_)) { status = OH_STATUS_NUMERICAL; break; }
+    if (stat <= P.tol && feas <= P.tol && compl_ <= P.tol) { status = OH_STATUS_CONVERGED; break; }
+    if (it == P.max_iter) break;
+
+    // ---- forward 1: Newton direction (serial), then the step lengths per knot ---------------------------------------------------------
+    double dxm[4] = {0, 0, 0, 0}, dam[2] = {0, 0};
+    {
+      double dx[4] = {0, 0, 0, 0};
+      for (int t = 0; t < T - 1; ++t) {
+        double da0 = pm_bcast(kmine[0], t), da1 = pm_bcast(kmine[1], t);
+        for (int j = 0; j < 4; ++j) { da0 += pm_bcast(Kmine[j], t) * dx[j]; da1 += pm_bcast(Kmine[4 + j], t) * dx[j]; }
+        if (lane == t) { dam[0] = da0; dam[1] = da1; }
+        const double n0 = dx[0] + dt * dx[2], n1 = dx[1] + dt * dx[3], n2 = dx[2] + dt * da0, n3 = dx[3] + dt * da1;
+        dx[0] = n0; dx[1] = n1; dx[2] = n2; dx[3] = n3;
+        if (lane == t + 1)
+          for (int j = 0; j < 4; ++j) dxm[j] = dx[j];
+      }
+    }
+    double ds[9], dl[9];
+    double ap = 1.0, ad = 1.0;
+    {
+      double d[9];
+      pm_Jv(dxm, jx, jy, d);
+      for (int i = 0; i < 9; ++i) {
+        ds[i] = d[i] + (c[i] - s[i]);
+        dl[i] = (mu / s[i] - lam[i]) - (lam[i] / s[i]) * ds[i];
+        if (on && lane >= 1) {
+          if (ds[i] < 0.0) ap = fmin(ap, -0.995 * s[i] / ds[i]);
+          if (dl[i] < 0.0) ad = fmin(ad, -0.995 * lam[i] / dl[i]);
+        }
+      }
+    }
+    ap = pm_wave_min(ap);
+    ad = pm_wave_min(ad);
+    // ---- forward 2: take the step; the barrier parameter from the products summed in the thread kernel's order -----------------------
+    double prod[9];
+    for (int i = 0; i < 9; ++i) {
+      if (on && lane >= 1) {
+        s[i] += ap * ds[i];
+        lam[i] += ad * dl[i];
+      }
+      prod[i] = s[i] * lam[i];
+    }
+    double gap = 0.0;
+    for (int t = 1; t < T; ++t)
+      for (int i = 0; i < 9; ++i) gap += pm_bcast(prod[i], t);
+    if (lane < T - 1) { a[0] += ap * dam[0]; a[1] += ap * dam[1]; }
+    {
+      double xn[4] = {pb[0], pb[1], pb[2], pb[3]};
+      for (int t = 0; t < T; ++t) {
+        if (lane == t)
+          for (int j = 0; j < 4; ++j) X[j] = xn[j];
+        if (t < T - 1) {
+          const double a0 = pm_bcast(a[0], t), a1 = pm_bcast(a[1], t);
+          const double n0 = xn[0] + dt * xn[2], n1 = xn[1] + dt * xn[3], n2 = xn[2] + dt * a0, n3 = xn[3] + dt * a1;
+          xn[0] = n0; xn[1] = n1; xn[2] = n2; xn[3] = n3;
+        }
+      }
+    }
+    gap /= (double)(9 * (T - 1));
+    const double am = fmin(ap, ad);
+    const double sigma = (am > 0.9) ? 0.1 : ((am > 0.5) ? 0.3 : 0.8);
+    mu = fmax(sigma * gap, 1e-2 * P.tol);
+  }
+  if (xo && on) {
+    double* xb = xo + (size_t)b * nx;
+    xb[2 * lane] = X[0]; xb[2 * lane + 1] = X[1];
+    xb[2 * T + 2 * lane] = X[2]; xb[2 * T + 2 * lane + 1] = X[3];
+  }
+  if (lane == 0) {
+    if (fo) fo[b] = fval;
+    if (kkt) { kkt[3 * (size_t)b] = stat; kkt[3 * (size_t)b + 1] = feas; kkt[3 * (size_t)b + 2] = compl_; }
+    if (iters_o) iters_o[b] = it > P.max_iter ? P.max_iter : it;
+    if (status_o) status_o[b] = status;
+  }
+}
+
 // ---- closed-loop receding horizon kept on the device (example/point_mass_mpc.py main loop, :293-306 + Controller.next_state :156-161) ----
 // parameters of one tick from the current plant state: p = [curr; dcurr; goal; obs], goal[:, i] = curr + ramp * i,
 // obs[:, i] = obstacle centre at time index tick * advance + i of the table
@@ -368,5 +633,9 @@ void oh_launch_pm_advance(hipStream_t s, int B, int T, int advance, const double
 
 void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, const double* x0, const double* p, double* x, double* f, double* kkt,
                         int* iters, int* status) {
-  hipLaunchKernelGGL(k_pm_solve, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p, x, f, kkt, iters, status);
+  // a wavefront per instance while that leaves the chip room (the thread kernel issues ~8x fewer instructions per instance, but needs ~10^5
+  // instances to fill the SIMDs)
+  static const int wave_max = getenv("OH_PM_WAVE_MAX") ? atoi(getenv("OH_PM_WAVE_MAX")) : 8192;
+  if (P.T <= 64 && D.B <= wave_max) hipLaunchKernelGGL(k_pm_solve_wave, dim3(D.B), dim3(64), 0, s, P, D.B, x0, p, x, f, kkt, iters, status);
+  else hipLaunchKernelGGL(k_pm_solve, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p, x, f, kkt, iters, status);
 }

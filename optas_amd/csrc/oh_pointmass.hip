@@ -635,7 +635,8 @@ void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, co
                         int* iters, int* status) {
   // a wavefront per instance while that leaves the chip room (the thread kernel issues ~8x fewer instructions per instance, but needs ~10^5
   // instances to fill the SIMDs)
-  static const int wave_max = getenv("OH_PM_WAVE_MAX") ? atoi(getenv("OH_PM_WAVE_MAX")) : 8192;
+  const char* e = getenv("OH_PM_WAVE_MAX");
+  const int wave_max = e ? atoi(e) : 8192;
   if (P.T <= 64 && D.B <= wave_max) hipLaunchKernelGGL(k_pm_solve_wave, dim3(D.B), dim3(64), 0, s, P, D.B, x0, p, x, f, kkt, iters, status);
   else hipLaunchKernelGGL(k_pm_solve, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p, x, f, kkt, iters, status);
 }

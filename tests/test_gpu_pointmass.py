@@ -165,3 +165,45 @@ def test_planner_variant_through_hipsolver(hip_lib):
     assert pl.solver.did_solve() and pl.solver.stats()["f"][0] < 0.01
     Y = np.asarray(sol["point_mass/y"])
     assert (np.sum(Y * Y, axis=0) >= 0.09 - 1e-8).all() and np.abs(Y[:, -1] - 1.0).max() < 0.02
+
+
+def test_wavefront_per_plant_kernel_reproduces_the_thread_kernel(hip_lib, monkeypatch):
+    """Batches of up to 8192 plants run one wavefront per plant, one lane per knot (k_pm_solve_wave): the knot-local work in the lane's
+    registers, the three recursions by all lanes alike in the thread kernel's operation order.  Same iterates to rounding, same iteration
+    counts; the reported objective is summed across lanes.  Horizons of more than 64 knots keep the thread kernel."""
+    nlp = PointMassMPCNLP()
+    rng = np.random.default_rng(SEED + 7)
+    B = 300
+    obs = np.array([[0.15 * np.sin(np.pi * (0.05 * t) - np.pi), 0.15 * np.cos(np.pi * (0.05 * t) - np.pi) + 0.15] for t in range(20)]).T
+    P = []
+    while len(P) < B:
+        c = rng.uniform(-1.2, 1.2, 2)
+        if np.linalg.norm(c - obs[:, 0]) <= 0.35:
+            continue
+        goal = np.stack([np.clip(c[j] + (1 - c[j]) * np.arange(20) / 19.0, -1.5, 1.5) for j in range(2)])
+        P.append(PointMassMPCNLP.pack_p(c, rng.uniform(-0.3, 0.3, 2), goal, obs))
+    P = np.array(P)
+    x0 = np.zeros((B, nlp.nx))
+    out = {}
+    for mode in ("0", "8192"):
+        monkeypatch.setenv("OH_PM_WAVE_MAX", mode)
+        be = PointMassBackend(tol=1e-8)
+        out[mode] = be.solve(x0, P)
+        be.close()
+    rt, rw = out["0"], out["8192"]
+    assert (rt.status == 0).mean() >= 0.99 and np.array_equal(rt.status, rw.status) and np.array_equal(rt.iters, rw.iters)
+    # (same operations in the same order; the compiler places its fused multiply-adds differently in the two kernels)
+    assert np.abs(rt.x - rw.x).max() <= 1e-10 and np.abs(rt.kkt - rw.kkt).max() <= 1e-10
+    assert np.abs(rt.f - rw.f).max() <= 1e-11 * max(1.0, np.abs(rt.f).max())
+    # T = 70 does not fit one knot per lane: the thread kernel, against the numpy port
+    T = 70
+    monkeypatch.delenv("OH_PM_WAVE_MAX")
+    be = PointMassBackend(T=T, tol=1e-8)
+    ob = np.array([[0.15 * np.sin(np.pi * (0.05 * t) - np.pi), 0.15 * np.cos(np.pi * (0.05 * t) - np.pi) + 0.15] for t in range(T)]).T
+    curr = np.array([-0.9, 0.4])
+    goal = np.stack([np.clip(curr[j] + (1 - curr[j]) * np.arange(T) / (T - 1.0), -1.5, 1.5) for j in range(2)])
+    p = np.concatenate([curr, np.zeros(2), goal.T.reshape(-1), ob.T.reshape(-1)])
+    r = be.solve(np.zeros((1, 4 * T)), p[None])
+    ref = solve_pointmass_ipm(T, 0.05, nlp.w, 1.5, 1.0, nlp.safe_sq, curr, np.zeros(2), goal, ob, tol=1e-8)
+    assert r.status[0] == 0 and ref["iters"] == r.iters[0] and abs(ref["f"] - r.f[0]) <= 1e-8 * max(1.0, abs(ref["f"]))
+    be.close()

@@ -114,7 +114,8 @@ struct oh_handle {
   int compact_carry = 1;     // compaction carries the pending trial along instead of restarting the survivors (k_carry_*)
   int compact_sort = 1;      // order the survivors of a compaction by progress (k_scan_*)
   double compact_frac = 0.9;  // compact the batch once this fraction of it (or less) is still running
-  int tail_threshold = 2048;  // hand the last instances to the persistent one-wave-per-instance kernel
+  int tail_threshold = 8192;  // hand the last instances to the persistent one-wave-per-instance kernel (round 2, kernels compiled for the chain:
+                              // 8192 against 2048 is +1.3 ... 3 % at B = 262 144 and -21 % on a batch of 4096: 4.88 -> 3.85 ms; 16 384 is worse again)
   int free_pcr_max = 1536;    // position-tracking family: K3 by cyclic reduction, one block per instance, while at most this many are in the launch
   // run-time specialised evaluation kernels of the orientation-locked figure-eight family (oh_jit.hip)
   int specialize = specialize_mode_from_env();  // OH_SPECIALIZE env: 0 never, 1 at the first solve, auto: at the first solve of >= specialize_min_B instances

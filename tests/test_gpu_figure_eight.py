@@ -240,7 +240,7 @@ def test_state_machine_matches_numpy_port(hip_lib, nlp, hessian, tail, monkeypat
         assert abs(res.f[b] - s["f"]) <= 1e-9 * abs(s["f"]) and np.abs(res.x[b, : 7 * 50].reshape(50, 7) - s["Q"]).max() < 1e-4
 
 
-def test_batch_machinery_matches_serial_cpu_port(hip_lib, nlp):
+def test_batch_machinery_matches_serial_cpu_port(hip_lib, nlp, monkeypatch):
     """B = 8192 through everything the batched path adds (uniform slots and skipped launches, batch compaction, hand-off to
     the persistent tail kernel) against oracle/cpu_port, which runs the same state machine one instance at a time on the host:
     every instance must reach the same optimum in the same number of steps (compaction / hand-off re-evaluate the accepted
@@ -248,6 +248,7 @@ def test_batch_machinery_matches_serial_cpu_port(hip_lib, nlp):
     import bench
     from oracle import cpu_port
 
+    monkeypatch.setenv("OH_TAIL_THRESHOLD", "2048")  # (the default hands a batch of this size to the tail kernel as a whole)
     robot = RobotModel(urdf_filename=KUKA_KIN)
     chain = robot.kinematic_chain(LINK)
     be = FigureEightBackend(chain, 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)
@@ -278,6 +279,7 @@ def test_compaction_schedule_does_not_change_the_answers(hip_lib, nlp, monkeypat
     chain = robot.kinematic_chain(LINK)
     B = 6144
     x0, qc = bench.make_inputs(B, 11)
+    monkeypatch.setenv("OH_TAIL_THRESHOLD", "2048")  # (the default hands a batch of this size to the tail kernel as a whole)
     res = {}
     for tag, env in (("off", {"OH_COMPACTION": "0"}), ("half", {"OH_COMPACT_FRAC": "0.5", "OH_COMPACT_SORT": "0"}), ("default", {})):
         for k in ("OH_COMPACTION", "OH_COMPACT_FRAC", "OH_COMPACT_SORT"):
@@ -382,6 +384,7 @@ def test_row_stride_padding_is_invisible(hip_lib, nlp, monkeypatch):
     x0 = np.zeros((B, nlp.nx))
     x0[:, : 7 * 50] = np.tile(qc, (1, 50))
     out = []
+    monkeypatch.setenv("OH_TAIL_THRESHOLD", "2048")  # the batched kernels are the ones that walk the rows
     for pad in ("0", "13", "5"):
         monkeypatch.setenv("OH_ROW_PAD", pad)
         be = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)

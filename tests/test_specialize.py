@@ -53,6 +53,7 @@ def _backend(T=50, **kw):
 @pytest.mark.parametrize("B", [1, 48, 6000])  # tail kernel alone; tail for a small batch; batched kernels + compaction + hand-over to the tail
 def test_specialised_solver_kernels_match_the_generic_ones(hip_lib, monkeypatch, B):
     monkeypatch.setenv("OH_SPECIALIZE", "0")
+    monkeypatch.setenv("OH_TAIL_THRESHOLD", "2048")  # B = 6000 through the batched kernels (the default hands it to the tail kernel as a whole)
     nlp, gen = _backend()
     rng = np.random.default_rng(SEED + 31)
     qc = QC0 + np.concatenate([np.zeros((1, 7)), rng.uniform(-0.1, 0.1, (B - 1, 7))])

@@ -113,7 +113,9 @@ struct oh_handle {
   bool compaction = true;
   int compact_carry = 1;     // compaction carries the pending trial along instead of restarting the survivors (k_carry_*)
   int compact_sort = 1;      // order the survivors of a compaction by progress (k_scan_*)
-  double compact_frac = 0.9;  // compact the batch once this fraction of it (or less) is still running
+  double compact_frac = 0.97;  // compact the batch once this fraction of it (or less) is still running (0.9 until the carried compaction
+                               // stopped copying back: 0.95 ... 0.99 are +1 ... 2 % over 0.9 on two boxes, interleaved runs)
+  double compact_frac_restart = 0.9;  // the same for the compaction that restarts the survivors (guarded handles, free family): it costs an evaluation
   int tail_threshold = 8192;  // hand the last instances to the persistent one-wave-per-instance kernel (round 2, kernels compiled for the chain:
                               // 8192 against 2048 is +1.3 ... 3 % at B = 262 144 and -21 % on a batch of 4096: 4.88 -> 3.85 ms; 16 384 is worse again)
   int free_pcr_max = 1536;    // position-tracking family: K3 by cyclic reduction, one block per instance, while at most this many are in the launch
@@ -218,7 +220,7 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (const char* e2 = getenv("OH_TAIL_THRESHOLD")) h->tail_threshold = atoi(e2);
   if (const char* e2 = getenv("OH_FREE_PCR_MAX")) h->free_pcr_max = atoi(e2);
   if (const char* e3 = getenv("OH_COMPACTION")) h->compaction = atoi(e3) != 0;
-  if (const char* e4 = getenv("OH_COMPACT_FRAC")) h->compact_frac = atof(e4);
+  if (const char* e4 = getenv("OH_COMPACT_FRAC")) h->compact_frac = h->compact_frac_restart = atof(e4);
   if (const char* e5 = getenv("OH_COMPACT_SORT")) h->compact_sort = atoi(e5);
   if (const char* e6 = getenv("OH_COMPACT_CARRY")) h->compact_carry = atoi(e6);
   hipGetDevice(&h->device);
@@ -1102,7 +1104,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   double* ox = (double*)d_x; double* of = (double*)d_f; double* ok = (double*)d_kkt;
   int* oi = (int*)d_iters; int* os = (int*)d_status;
   // Every instance needs at most max_iter steps (accepted + rejected) plus its first evaluation; each
-  // plain compaction re-evaluates the survivors once.  The batch is compacted whenever a tenth of it has finished (compact_frac);
+  // plain compaction re-evaluates the survivors once.  The batch is compacted whenever 3 % of it have finished (compact_frac);
   // the regular compactions carry the pending trial along and cost no evaluation (k_carry_*), the hand-over to the tail kernel
   // restarts the survivors.
   const int hard_cap = 2 * h->desc.max_iter + 2 + 40 + 64;  // a rejected step costs two launches, a compaction one
@@ -1189,7 +1191,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       const bool carry_fits = (size_t)h->desc.T * ((N - 3) * (N - 2) / 2) >= 22;
       if (h->compaction && h->compact_carry && carry_fits && oh_eval_is_split() && h->P.lock && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
         carry_pending = nrun;  // done after the next k_retract
-      } else if (h->compaction && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
+      } else if (h->compaction && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac_restart * (double)h->D.B) {
         // restart compaction: the survivors' accepted knots (and, with inequality rows, their multipliers and outer-loop state) are laid
         // down densely and re-evaluated
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);

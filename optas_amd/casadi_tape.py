@@ -161,14 +161,15 @@ def make_solver_class(solver_module, cs):
         def setup(self, solver_name: str = "hip_sqp", solver_options: Optional[dict] = None):
             """Structured family first (optas_amd.probe_lowering: labels and shapes of the problem's containers, its own numeric functions
             probed and then verified -- the headline figure-eight kernels behind a real ``Optimization``), generic tape family otherwise.
-            ``solver_options["family"]`` = "figure_eight" | "torque_mpc" | "ik" | "point_mass" | "multi_arm" | "tape" forces one route; ``"link"`` may name the tracked link."""
+            ``solver_options["family"]`` = "figure_eight" | "torque_mpc" | "ik" | "point_mass" | "multi_arm" | "qp" | "tape" forces one route; ``"link"`` may name
+            the tracked link.  The QuadraticCost* classes without nonlinear rows go to the dense-QP family."""
             if solver_name != "hip_sqp":
                 raise ValueError(f"unknown solver '{solver_name}' (this interface provides 'hip_sqp')")
             o = dict(solver_options or {})
             family = o.pop("family", None)
             link = o.pop("link", None)
             self._family = None
-            if family != "tape":
+            if family not in ("tape", "qp"):
                 from .backend import IKBackend, MultiArmBackend, PointMassBackend, TorqueBackend
                 from .lowering import LoweringError
                 from . import probe_lowering as pl
@@ -199,6 +200,20 @@ def make_solver_class(solver_module, cs):
                 except LoweringError:
                     if family is not None:
                         raise
+            if self._family is None and family in (None, "qp"):
+                # the QuadraticCost* classes without nonlinear rows (what the reference hands to OSQP / CVXOPT / qpOASES, solver.py:421-584):
+                # the dense-QP family, with P, q, M, c, A, b read off the walked tape on the device (oh_qp_set_tape)
+                from .backend import QPBackend
+
+                is_qp = type(self.opt).__name__ in ("QuadraticCostUnconstrained", "QuadraticCostLinearConstraints")
+                nk = int(getattr(self.opt, "nk", 0) or 0)
+                na = int(getattr(self.opt, "na", 0) or 0)
+                if is_qp and self.opt.nx <= 32 and nk <= 256 and na <= min(32, self.opt.nx) and not self.opt.has_discrete_variables():
+                    self._tape = tape_from_functions(cs, self.opt.nx, self.opt.np, self.opt.f, ineq=(getattr(self.opt, "k", None),), eq=(getattr(self.opt, "a", None),))
+                    self._backend = QPBackend(self.opt.nx, nk, na, max_iter=int(o.pop("max_iter", 100)), tol=float(o.pop("tol", 1e-9)), tape=self._tape)
+                    self._family = "qp"
+                elif family == "qp":
+                    raise ValueError("family 'qp' needs a QuadraticCostUnconstrained / QuadraticCostLinearConstraints problem with nx <= 32, nk <= 256, na <= 32")
             if self._family is None:
                 self._tape = tape_from_optimization(self.opt, cs)
                 self._backend = TapeBackend(self._tape, max_iter=int(o.pop("max_iter", 2000)), tol=float(o.pop("tol", 1e-6)),

@@ -105,3 +105,58 @@ def test_literal_solver_subclass_solves_on_the_gpu(hip_lib):
     assert np.abs(h(q, goal)[0]).max() < 1e-9 and g(q, goal)[0].min() > -1e-9
     r = tape_ref.solve_tape_al(solver._tape, np.array([0.3, 0.2, 0.1]), goal, tol=1e-7)
     assert np.abs(r["x"] - q).max() < 1e-7 and abs(r["evals"] - solver.number_of_iterations()) <= 2
+
+
+@pytest.mark.gpu
+def test_literal_solver_subclass_sends_quadratic_classes_to_the_qp_family(hip_lib):
+    """The reference's own numeric solver test (tests/test_solver.py:22-54, Booth: (a, b) = (2, 7) -> (1, 3)) as a QuadraticCostLinearConstraints
+    object with cs.Function members: the drop-in walks f and k into one tape, attaches it to a dense-QP handle (oh_qp_set_tape) and the
+    device reads P, q, M, c off it -- no BFGS, an interior-point solve of a handful of iterations."""
+
+    class Solver:
+        def __init__(self, optimization, error_on_fail=False):
+            self.opt, self._error_on_fail = optimization, error_on_fail
+            self.x0, self.p = cs.DM(np.zeros(optimization.nx)), cs.DM(np.zeros(optimization.np))
+
+        def reset_initial_seed(self, x0):
+            self.x0 = self.opt.decision_variables.dict2vec(x0)
+
+        def reset_parameters(self, p):
+            self.p = self.opt.parameters.dict2vec(p)
+
+        def solve(self):
+            return self.opt.decision_variables.vec2dict(self._solve())
+
+    class QuadraticCostLinearConstraints:  # (the class name is what the drop-in goes by, like optas.optimization's)
+        def __init__(self, y_up):
+            x, p = cs.sym(0, 2), cs.sym(1, 2)
+            self.f = cs.Function("f", [[(0, cs.sq(x[0] + p[0] * x[1] - p[1]) + cs.sq(2.0 * x[0] + x[1] - 5.0))]], [1])
+            self.k = cs.Function("k", [[(0, x[0] + 10.0), (1, 10.0 - x[0]), (2, x[1] + 10.0), (3, y_up - x[1])]], [4])
+            self.a = self.g = self.h = None
+            self.nx, self.np, self.nk, self.na = 2, 2, 4, 0
+            self.models = []
+            self.decision_variables = types.SimpleNamespace(vec2dict=lambda v: {"xy": np.asarray(v).reshape(-1)}, dict2vec=lambda d: cs.DM(d["xy"]))
+            self.parameters = types.SimpleNamespace(vec2dict=lambda v: {"ab": np.asarray(v).reshape(-1)}, dict2vec=lambda d: cs.DM(d["ab"]))
+
+        def has_discrete_variables(self):
+            return False
+
+    HIPSolver = make_solver_class(types.SimpleNamespace(Solver=Solver), cs)
+    opt = QuadraticCostLinearConstraints(y_up=2.5)  # the bound binds: the unconstrained minimiser is (1, 3)
+    solver = HIPSolver(opt).setup("hip_sqp")
+    assert solver._family == "qp"
+    solver.reset_initial_seed({"xy": [0.0, 0.0]})
+    solver.reset_parameters({"ab": [2.0, 7.0]})
+    xy = solver.solve()["xy"]
+    assert solver.did_solve() and solver.number_of_iterations() < 30
+    ab = np.array([2.0, 7.0])
+    s = minimize(lambda x: opt.f(x, ab)[0][0], np.zeros(2), method="SLSQP", tol=1e-13, constraints=[{"type": "ineq", "fun": lambda x: opt.k(x, ab)[0]}])
+    assert s.success and np.abs(s.x - xy).max() < 1e-6 and abs(xy[1] - 2.5) < 1e-8 and abs(solver.stats()["f"] - s.fun) < 1e-8
+    # without the binding bound it is the reference's (1, 3)
+    opt = QuadraticCostLinearConstraints(y_up=10.0)
+    solver = HIPSolver(opt).setup("hip_sqp", {"family": "qp"})
+    solver.reset_parameters({"ab": [2.0, 7.0]})
+    xy = solver.solve()["xy"]
+    assert solver.did_solve() and np.isclose(xy, [1.0, 3.0]).all() and abs(solver.stats()["f"]) < 1e-9
+    with pytest.raises(ValueError):
+        HIPSolver(FakeOptimization()).setup("hip_sqp", {"family": "qp"})

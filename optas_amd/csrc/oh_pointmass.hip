@@ -159,7 +159,8 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
       for (int j = 0; j < 4; ++j) { Qux[j] = dt * PA[8 + j]; Qux[4 + j] = dt * PA[12 + j]; }
       const double qu0 = 2.0 * w * a0 + dt * pv[2], qu1 = 2.0 * w * a1 + dt * pv[3];
       // 2x2 Cholesky solve
-      const double l00 = sqrt(q00), l10 = q01 / l00, l11 = sqrt(q11 - l10 * l10);
+      // (reciprocal square roots and products: the 21 divisions of the textbook substitution were half the instructions of a knot step)
+      const double i00 = rsqrt(q00), l10 = q01 * i00, i11 = rsqrt(q11 - l10 * l10);
       double Kt[8], kt[2];
       if (pinned) {
         // fixed feedback K = [0 0 -1/dt 0; 0 0 0 -1/dt], k = 0:  P = Q + A^T P A + Qux^T K + K^T Qux + K^T Quu K,  p = q + A^T p + K^T qu,
@@ -195,12 +196,12 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
       }
       {
         for (int j = 0; j < 4; ++j) {
-          const double y0 = Qux[j] / l00, y1 = (Qux[4 + j] - l10 * y0) / l11;
-          const double z1 = y1 / l11, z0 = (y0 - l10 * z1) / l00;
+          const double y0 = Qux[j] * i00, y1 = (Qux[4 + j] - l10 * y0) * i11;
+          const double z1 = y1 * i11, z0 = (y0 - l10 * z1) * i00;
           Kt[j] = -z0; Kt[4 + j] = -z1;
         }
-        const double y0 = qu0 / l00, y1 = (qu1 - l10 * y0) / l11;
-        const double z1 = y1 / l11, z0 = (y0 - l10 * z1) / l00;
+        const double y0 = qu0 * i00, y1 = (qu1 - l10 * y0) * i11;
+        const double z1 = y1 * i11, z0 = (y0 - l10 * z1) * i00;
         kt[0] = -z0; kt[1] = -z1;
       }
       for (int j = 0; j < 8; ++j) K_[PIDX(8 * t + j)] = Kt[j];
@@ -413,12 +414,13 @@ __global__ __launch_bounds__(64) void k_pm_solve_wave(PmParams P, int B, const d
     const double gx[4] = {-2.0 * wt * (g0 - X[0]), -2.0 * wt * (g1 - X[1]), 2.0 * P.w_vel * X[2], 2.0 * P.w_vel * X[3]};
     double fl = wt * ((g0 - X[0]) * (g0 - X[0]) + (g1 - X[1]) * (g1 - X[1])) + P.w_vel * (X[2] * X[2] + X[3] * X[3]);
     if (lane < T - 1) fl += w * (a[0] * a[0] + a[1] * a[1]);
-    double rc[9], sig[9], wq[9], jl[4], jq[4];
+    double rc[9], sig[9], mus[9], wq[9], jl[4], jq[4];
     double fe = 0.0, co = 0.0;
     for (int i = 0; i < 9; ++i) {
       rc[i] = c[i] - s[i];
       sig[i] = lam[i] / s[i];
-      wq[i] = mu / s[i] - sig[i] * rc[i];
+      mus[i] = mu / s[i];
+      wq[i] = mus[i] - sig[i] * rc[i];
       if (on && lane >= 1) { fe = fmax(fe, fabs(rc[i])); co = fmax(co, lam[i] * s[i]); }
     }
     pm_JTw(lam, jx, jy, jl);
@@ -464,7 +466,8 @@ __global__ __launch_bounds__(64) void k_pm_solve_wave(PmParams P, int B, const d
       double Qux[8];
       for (int j = 0; j < 4; ++j) { Qux[j] = dt * PA[8 + j]; Qux[4 + j] = dt * PA[12 + j]; }
       const double qu0 = 2.0 * w * a0 + dt * pv[2], qu1 = 2.0 * w * a1 + dt * pv[3];
-      const double l00 = sqrt(q00), l10 = q01 / l00, l11 = sqrt(q11 - l10 * l10);
+      // (reciprocal square roots and products: the 21 divisions of the textbook substitution were half the instructions of a knot step)
+      const double i00 = rsqrt(q00), l10 = q01 * i00, i11 = rsqrt(q11 - l10 * l10);
       double Kt[8], kt[2];
       double Pn[16], pn[4], pa[4];
       if (pinned) {
@@ -491,12 +494,12 @@ __global__ __launch_bounds__(64) void k_pm_solve_wave(PmParams P, int B, const d
         pa[2] += kf * gu0; pa[3] += kf * gu1;
       } else {
         for (int j = 0; j < 4; ++j) {
-          const double y0 = Qux[j] / l00, y1 = (Qux[4 + j] - l10 * y0) / l11;
-          const double z1 = y1 / l11, z0 = (y0 - l10 * z1) / l00;
+          const double y0 = Qux[j] * i00, y1 = (Qux[4 + j] - l10 * y0) * i11;
+          const double z1 = y1 * i11, z0 = (y0 - l10 * z1) * i00;
           Kt[j] = -z0; Kt[4 + j] = -z1;
         }
-        const double y0 = qu0 / l00, y1 = (qu1 - l10 * y0) / l11;
-        const double z1 = y1 / l11, z0 = (y0 - l10 * z1) / l00;
+        const double y0 = qu0 * i00, y1 = (qu1 - l10 * y0) * i11;
+        const double z1 = y1 * i11, z0 = (y0 - l10 * z1) * i00;
         kt[0] = -z0; kt[1] = -z1;
         for (int r = 0; r < 4; ++r)
           for (int cc = 0; cc < 4; ++cc) {
@@ -544,8 +547,8 @@ __global__ __launch_bounds__(64) void k_pm_solve_wave(PmParams P, int B, const d
       double d[9];
       pm_Jv(dxm, jx, jy, d);
       for (int i = 0; i < 9; ++i) {
-        ds[i] = d[i] + (c[i] - s[i]);
-        dl[i] = (mu / s[i] - lam[i]) - (lam[i] / s[i]) * ds[i];
+        ds[i] = d[i] + rc[i];
+        dl[i] = (mus[i] - lam[i]) - sig[i] * ds[i];  // (the quotients of the residual phase: same operands, same values)
         if (on && lane >= 1) {
           if (ds[i] < 0.0) ap = fmin(ap, -0.995 * s[i] / ds[i]);
           if (dl[i] < 0.0) ad = fmin(ad, -0.995 * lam[i] / dl[i]);
@@ -634,9 +637,9 @@ void oh_launch_pm_advance(hipStream_t s, int B, int T, int advance, const double
 void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, const double* x0, const double* p, double* x, double* f, double* kkt,
                         int* iters, int* status) {
   // a wavefront per instance while that leaves the chip room (the thread kernel issues ~8x fewer instructions per instance, but needs ~10^5
-  // instances to fill the SIMDs)
+  // instances to fill the SIMDs: 1024 plants take 3.5 ms with it and 0.7 ms here)
   const char* e = getenv("OH_PM_WAVE_MAX");
-  const int wave_max = e ? atoi(e) : 8192;
+  const int wave_max = e ? atoi(e) : 20480;  // (tools/gpu_pm_sweep.py: 16 384 plants 6.8 / 5.8 ms thread / wave kernel, 32 768 9.8 / 11.3 ms)
   if (P.T <= 64 && D.B <= wave_max) hipLaunchKernelGGL(k_pm_solve_wave, dim3(D.B), dim3(64), 0, s, P, D.B, x0, p, x, f, kkt, iters, status);
   else hipLaunchKernelGGL(k_pm_solve, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p, x, f, kkt, iters, status);
 }

@@ -168,7 +168,7 @@ def test_planner_variant_through_hipsolver(hip_lib):
 
 
 def test_wavefront_per_plant_kernel_reproduces_the_thread_kernel(hip_lib, monkeypatch):
-    """Batches of up to 8192 plants run one wavefront per plant, one lane per knot (k_pm_solve_wave): the knot-local work in the lane's
+    """Batches of up to 20 480 plants run one wavefront per plant, one lane per knot (k_pm_solve_wave): the knot-local work in the lane's
     registers, the three recursions by all lanes alike in the thread kernel's operation order.  Same iterates to rounding, same iteration
     counts; the reported objective is summed across lanes.  Horizons of more than 64 knots keep the thread kernel."""
     nlp = PointMassMPCNLP()
@@ -185,12 +185,12 @@ def test_wavefront_per_plant_kernel_reproduces_the_thread_kernel(hip_lib, monkey
     P = np.array(P)
     x0 = np.zeros((B, nlp.nx))
     out = {}
-    for mode in ("0", "8192"):
+    for mode in ("0", "20480"):
         monkeypatch.setenv("OH_PM_WAVE_MAX", mode)
         be = PointMassBackend(tol=1e-8)
         out[mode] = be.solve(x0, P)
         be.close()
-    rt, rw = out["0"], out["8192"]
+    rt, rw = out["0"], out["20480"]
     assert (rt.status == 0).mean() >= 0.99 and np.array_equal(rt.status, rw.status) and np.array_equal(rt.iters, rw.iters)
     # (same operations in the same order; the compiler places its fused multiply-adds differently in the two kernels)
     assert np.abs(rt.x - rw.x).max() <= 1e-10 and np.abs(rt.kkt - rw.kkt).max() <= 1e-10

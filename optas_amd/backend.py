@@ -189,6 +189,11 @@ class QPBackend(_SolveMixin):
         self.tape = tape
         self.np_ = max(1, int(tape.np_))
 
+    def solve(self, x0, p):
+        if self.tape is not None and int(self.tape.np_) == 0:  # a problem without parameters: the ABI still wants one column
+            p = np.zeros((len(np.atleast_2d(x0)), 1))
+        return super().solve(x0, p)
+
     @staticmethod
     def pack(P, q, M, c, A, b) -> np.ndarray:
         return np.concatenate([np.asarray(P, dtype=np.float64).reshape(-1), np.asarray(q, dtype=np.float64).reshape(-1),

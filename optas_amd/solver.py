@@ -202,7 +202,7 @@ class _QpAdapter:
         p = np.asarray(p, dtype=np.float64).reshape(x0.shape[0], -1)
         o = self.opt
         if self.be.tape is not None:  # the device reads the QP off the problem's tape (oh_qp_set_tape): no per-instance host work
-            return self.be.solve(x0, p if o.np else np.zeros((x0.shape[0], 1)))
+            return self.be.solve(x0, p)
         z = np.zeros(o.nx)
         rows, f0 = [], []
         for pb in p:

@@ -245,3 +245,23 @@ def test_qp_data_assembled_on_the_device_equals_the_host_route(hip_lib):
     pm.close()
     dev.backend.close()
     host.backend.close()
+
+
+@pytest.mark.gpu
+def test_parameter_free_qp_with_device_assembly(hip_lib):
+    """A QuadraticCost problem without parameters: the tape has no parameter loads, the ABI still takes one (unused) column."""
+    from optas_amd.solver import HIPSolver
+
+    builder = OptimizationBuilder(1)
+    x = builder.add_decision_variables("x")
+    y = builder.add_decision_variables("y")
+    builder.add_cost_term("f", (x - 1.0) ** 2 + (y - 2.0) ** 2)
+    builder.add_leq_inequality_constraint("sum", x + y, 2.0)
+    opt = builder.build()
+    assert opt.np == 0
+    solver = HIPSolver(opt).setup("hip_sqp")
+    assert solver.backend.be.tape is not None
+    sol = solver.solve()
+    assert solver.did_solve()
+    assert abs(np.asarray(sol["x"]).item() - 0.5) < 1e-7 and abs(np.asarray(sol["y"]).item() - 1.5) < 1e-7  # projection of (1, 2) onto x + y = 2
+    assert abs(solver.stats()["f"][0] - 0.5) < 1e-8

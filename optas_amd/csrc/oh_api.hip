@@ -36,6 +36,8 @@ static int specialize_mode_from_env() {
   if (!e || !strcmp(e, "auto")) return OH_SPECIALIZE_AUTO;
   return atoi(e) != 0 ? OH_SPECIALIZE_ALWAYS : OH_SPECIALIZE_NEVER;
 }
+#define OH_PINNED_STAGE_BYTES (256 * 1024)
+
 struct oh_handle {
   oh_problem_desc desc;
   std::vector<double> local_path;
@@ -70,6 +72,7 @@ struct oh_handle {
   TapeJit tape_jit;
   // dense QP family
   oh_qp_desc qp{};
+  void* h_stage = nullptr;  // pinned mirror of the staging area for small oh_solve calls (OH_PINNED_STAGE_BYTES)
   double* d_qp_work = nullptr;
   double* d_qp_mult = nullptr;
   int qp_cap = 0;
@@ -1281,14 +1284,32 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
   const size_t total = al(b_x) * 2 + al(b_p) + al(b_f) + al(b_k) + 2 * al(b_i);
   int rc = ensure_stage(h, total);
   if (rc) return rc;
+  // device layout: inputs [x0 | p], then outputs [x | f | kkt | iters | status]
   char* base = (char*)h->stage;
-  void* d_x0 = base; base += al(b_x);
-  void* d_x = base; base += al(b_x);
-  void* d_p = base; base += al(b_p);
-  void* d_f = base; base += al(b_f);
-  void* d_k = base; base += al(b_k);
-  void* d_it = base; base += al(b_i);
-  void* d_st = base;
+  const size_t o_x0 = 0, o_p = o_x0 + al(b_x), o_x = o_p + al(b_p), o_f = o_x + al(b_x), o_k = o_f + al(b_f), o_it = o_k + al(b_k), o_st = o_it + al(b_i);
+  void* d_x0 = base + o_x0; void* d_p = base + o_p; void* d_x = base + o_x; void* d_f = base + o_f; void* d_k = base + o_k;
+  void* d_it = base + o_it; void* d_st = base + o_st;
+  // a controller's tick moves a few hundred bytes in seven pieces: through one pinned mirror of the staging area that is two transfers (each
+  // hipMemcpy of pageable memory is ~10-15 us of driver work whatever its size)
+  const bool small = total <= OH_PINNED_STAGE_BYTES;
+  if (small && !h->h_stage) {
+    if (hipHostMalloc((void**)&h->h_stage, OH_PINNED_STAGE_BYTES) != hipSuccess) h->h_stage = nullptr;
+  }
+  if (small && h->h_stage) {
+    char* hb = (char*)h->h_stage;
+    memcpy(hb + o_x0, x0, b_x);
+    memcpy(hb + o_p, p, b_p);
+    HIPCHK(hipMemcpy(base, hb, o_p + b_p, hipMemcpyHostToDevice));
+    rc = oh_solve_device(h, B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(hb + o_x, base + o_x, o_st + b_i - o_x, hipMemcpyDeviceToHost));
+    if (x) memcpy(x, hb + o_x, b_x);
+    if (f) memcpy(f, hb + o_f, b_f);
+    if (kkt) memcpy(kkt, hb + o_k, b_k);
+    if (iters) memcpy(iters, hb + o_it, b_i);
+    if (status) memcpy(status, hb + o_st, b_i);
+    return OH_OK;
+  }
   HIPCHK(hipMemcpy(d_x0, x0, b_x, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_p, p, b_p, hipMemcpyHostToDevice));
   rc = oh_solve_device(h, B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st);
@@ -1555,6 +1576,7 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->d_dyn) hipFree(h->d_dyn);
   if (h->d_local_path) hipFree(h->d_local_path);
   if (h->h_flag) hipHostFree(h->h_flag);
+  if (h->h_stage) hipHostFree(h->h_stage);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->evt0) hipEventDestroy(h->evt0);

@@ -133,6 +133,7 @@ void oh_launch_qp_add_constant(hipStream_t s, int B, double* f, const double* f0
 struct TapeJit {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
+  hipFunction_t fn_lds = nullptr;  // the same kernel with the solver's work arrays in LDS (small batches)
 };
 size_t oh_tape_work_rows(const TapeParams& T, bool jit);
 void oh_launch_tape_solve(hipStream_t s, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, int B, int Bp,

@@ -16,6 +16,7 @@
 #include <hip/hiprtc.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <mutex>
 #include <string>
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(64) void k_tape_solve(TapeParams T, TapeView tv, in
   if (b >= B) return;
   const TapeWork W = tape_carve(T, work + 2 * (size_t)T.len * Bp, Bp);
   InterpEval ev{T, tv, W, work, work + (size_t)T.len * Bp, par + (size_t)b * T.np, Bp, b};
-  tape_solve_instance(T, ev, W, Bp, b, x0, xo, fo, kkt, iters, status, mult);
+  tape_solve_instance(T, ev, W, Bp, b, b, x0, xo, fo, kkt, iters, status, mult);
 }
 
 // ---- code generation ------------------------------------------------------------------------------------------------------------------
@@ -246,7 +247,17 @@ std::string generate(const TapeParams& T, const int* op, const int* a, const int
        "    int* __restrict__ status, double* __restrict__ mult) {\n"
        "  const int b = blockIdx.x * blockDim.x + threadIdx.x;\n  if (b >= B) return;\n"
        "  const TapeWork W = tape_carve(T, work, Bp);\n  JitEval ev{W, par + (size_t)b * T.np, Bp, b};\n"
-       "  tape_solve_instance(T, ev, W, Bp, b, x0, xo, fo, kkt, iters, status, mult);\n}\n";
+       "  tape_solve_instance(T, ev, W, Bp, b, b, x0, xo, fo, kkt, iters, status, mult);\n}\n";
+  // the same with the solver's work arrays (x, gradients, the BFGS matrix, multipliers, rows) in LDS, [row][lane of the block]: for small
+  // batches every access of the quasi-Newton loop is otherwise a dependent round trip to the global buffer
+  s += "extern \"C\" __global__ __launch_bounds__(64) void k_tape_jit_lds(TapeParams T, int B, int Bp_unused, const double* __restrict__ x0, const double* __restrict__ par,\n"
+       "    double* __restrict__ work_unused, double* __restrict__ xo, double* __restrict__ fo, double* __restrict__ kkt, int* __restrict__ iters,\n"
+       "    int* __restrict__ status, double* __restrict__ mult) {\n"
+       "  extern __shared__ double tape_lds[];\n"
+       "  const int gb = blockIdx.x * blockDim.x + threadIdx.x;\n  if (gb >= B) return;\n"
+       "  const int Bp = blockDim.x, b = threadIdx.x;\n"
+       "  const TapeWork W = tape_carve(T, tape_lds, Bp);\n  JitEval ev{W, par + (size_t)gb * T.np, Bp, b};\n"
+       "  tape_solve_instance(T, ev, W, Bp, b, gb, x0, xo, fo, kkt, iters, status, mult);\n}\n";
   return s;
 }
 
@@ -304,6 +315,7 @@ int oh_tape_jit_load(const std::vector<char>& code, TapeJit* out, std::string* e
     *err = "hipModuleGetFunction(k_tape_jit) failed";
     return 1;
   }
+  if (hipModuleGetFunction(&out->fn_lds, out->mod, "k_tape_jit_lds") != hipSuccess) out->fn_lds = nullptr;
   return 0;
 }
 
@@ -311,10 +323,20 @@ void oh_tape_jit_release(TapeJit* j) {
   if (j->mod) hipModuleUnload(j->mod);
   j->mod = nullptr;
   j->fn = nullptr;
+  j->fn_lds = nullptr;
 }
 
 hipError_t oh_launch_tape_jit(hipStream_t s, const TapeJit& j, TapeParams T, int B, int Bp, const double* x0, const double* p, double* work, double* x, double* f,
                               double* kkt, int* iters, int* status, double* mult) {
   void* args[] = {&T, &B, &Bp, &x0, &p, &work, &x, &f, &kkt, &iters, &status, &mult};
+  // the solver's work set in LDS when it fits 48 KB at 64, 32 or 16 instances per block (tools/gpu_tape_sweep.py, the 7-joint IK problem: one
+  // instance 5.0 -> 3.4 ms, 2048 14.3 -> 10.9 ms, 32 768 25.8 -> 21.0 ms; OH_TAPE_LDS_MAX = 0 switches it off)
+  const char* e = getenv("OH_TAPE_LDS_MAX");
+  const int lds_max = e ? atoi(e) : (1 << 30);
+  if (j.fn_lds && B <= lds_max) {
+    const size_t per = sizeof(double) * tape_solver_rows(T);
+    for (int bs : {64, 32, 16})
+      if (per * bs <= 48 * 1024) return hipModuleLaunchKernel(j.fn_lds, (B + bs - 1) / bs, 1, 1, bs, 1, 1, (unsigned)(per * bs), s, args, nullptr);
+  }
   return hipModuleLaunchKernel(j.fn, (B + 63) / 64, 1, 1, 64, 1, 1, 0, s, args, nullptr);
 }

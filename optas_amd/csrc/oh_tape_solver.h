@@ -52,11 +52,12 @@ __device__ inline double tape_al_eq(const double c, const double mu, const doubl
 
 // E::phi(xs, gout, rho, &f, &cmax, &meas): merit value at the point in xs (SoA), its gradient into gout (SoA), the row values into W.rowv
 template <class E>
-__device__ inline void tape_solve_instance(const TapeParams& T, E& ev, const TapeWork& W, const int Bp, const int b, const double* __restrict__ x0,
+// (Bp, b) address the work arrays (TIDX: [row][lane], in the global buffer or in LDS); gb is the instance's index in the batch
+__device__ inline void tape_solve_instance(const TapeParams& T, E& ev, const TapeWork& W, const int Bp, const int b, const int gb, const double* __restrict__ x0,
                                            double* __restrict__ xo, double* __restrict__ fo, double* __restrict__ kkt, int* __restrict__ iters,
                                            int* __restrict__ status, double* __restrict__ mult) {
   const int n = T.nx;
-  for (int k = 0; k < n; ++k) W.x[TIDX(k)] = x0[(size_t)b * n + k];
+  for (int k = 0; k < n; ++k) W.x[TIDX(k)] = x0[(size_t)gb * n + k];
   for (int i = 0; i < T.n_ineq; ++i) W.lam[TIDX(i)] = 0.0;
   for (int i = 0; i < T.n_eq; ++i) W.mu[TIDX(i)] = 0.0;
   auto eye = [&]() {
@@ -156,14 +157,14 @@ __device__ inline void tape_solve_instance(const TapeParams& T, E& ev, const Tap
     val = vt; fval = ft; cmax = ct; meas = mt;
   }
   for (int k = 0; k < n; ++k)
-    if (xo) xo[(size_t)b * n + k] = W.x[TIDX(k)];
-  if (fo) fo[b] = fval;
-  if (kkt) { kkt[3 * (size_t)b] = stat; kkt[3 * (size_t)b + 1] = cmax; kkt[3 * (size_t)b + 2] = meas; }
-  if (iters) iters[b] = evals;
-  if (status) status[b] = st;
+    if (xo) xo[(size_t)gb * n + k] = W.x[TIDX(k)];
+  if (fo) fo[gb] = fval;
+  if (kkt) { kkt[3 * (size_t)gb] = stat; kkt[3 * (size_t)gb + 1] = cmax; kkt[3 * (size_t)gb + 2] = meas; }
+  if (iters) iters[gb] = evals;
+  if (status) status[gb] = st;
   if (mult) {
-    for (int i = 0; i < T.n_ineq; ++i) mult[(size_t)b * (T.n_ineq + T.n_eq) + i] = W.lam[TIDX(i)];
-    for (int i = 0; i < T.n_eq; ++i) mult[(size_t)b * (T.n_ineq + T.n_eq) + T.n_ineq + i] = W.mu[TIDX(i)];
+    for (int i = 0; i < T.n_ineq; ++i) mult[(size_t)gb * (T.n_ineq + T.n_eq) + i] = W.lam[TIDX(i)];
+    for (int i = 0; i < T.n_eq; ++i) mult[(size_t)gb * (T.n_ineq + T.n_eq) + T.n_ineq + i] = W.mu[TIDX(i)];
   }
 }
 

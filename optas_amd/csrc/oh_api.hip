@@ -983,8 +983,8 @@ static int ensure_guards(oh_handle* h) {
     h->gpool = nullptr;
     const size_t npar = (size_t)g.n_links + 4 * (size_t)g.n_obstacles;
     const size_t n_lam = (size_t)T * GP.NC * Bp, n_lamv = GP.vel ? (size_t)T * 2 * N * Bp : 0;
-    const size_t nd = 3 * (n_lam + n_lamv) + 2 * npar * Bp + 4 * (size_t)T * Bp + (6 + 8) * (size_t)Bp;  // lam, lam_out and the compaction scratch
-    const size_t bytes = nd * sizeof(double) + 2 * (size_t)Bp * sizeof(int);
+    const size_t nd = 3 * (n_lam + n_lamv) + 2 * npar * Bp + 4 * (size_t)T * Bp + (6 + 8 + 2) * (size_t)Bp;  // lam, lam_out, the compaction scratch, ls_*
+    const size_t bytes = nd * sizeof(double) + 3 * (size_t)Bp * sizeof(int);
     hipError_t e = hipMalloc(&h->gpool, bytes);
     if (e != hipSuccess) return fail(OH_ERR_HIP, std::string("guard pool allocation failed: ") + hipGetErrorString(e));
     hipMemsetAsync(h->gpool, 0, bytes, h->stream);
@@ -1008,9 +1008,12 @@ static int ensure_guards(oh_handle* h) {
     GB.lam_out = take(n_lam);
     GB.lamv_out = GP.vel ? take(n_lamv) : nullptr;
     GB.scr = take(n_lam + n_lamv + (npar + 8) * Bp);
+    GB.ls_gd = take(Bp);
+    GB.ls_q = take(Bp);
     int* ip = (int*)d;
     GB.outer = ip; ip += Bp;
-    GB.n_outer = ip;
+    GB.n_outer = ip; ip += Bp;
+    GB.ls_count = ip;
   } else {
     // D.fpsi lives in the guard pool; ensure_capacity may have rebuilt FigBuffers
     h->D.fpsi = h->GB.meas_prev + Bp;

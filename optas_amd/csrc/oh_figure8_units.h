@@ -514,6 +514,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   LMState lm{D.mu[b], D.nun[b]};
   const int iters = D.iters[b];
   bool polish_request = false;
+  bool line_search = false;
 
   // ---- phase A: merit of the trial slot ---------------------------------------------------------
   {
@@ -561,6 +562,13 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       // point at the floor tolerance: zero step, accepted unconditionally at the next k_step.
       polish_request = !accept && !D.stale[b] && D.feas[b] > 10.0 * P.tol_retract;
       if (polish_request) lm = lm_before;
+      if constexpr (GUARD) {
+        // handles with inequality rows: a shorter step along the same direction before the damping is raised (OH_LS_MAX, oh_types.h)
+        if (!accept && !polish_request && GBp->ls_count[b] < OH_LS_MAX) {
+          lm = lm_before;
+          line_search = true;
+        }
+      }
       D.nun[b] = lm.nun;
     }
     if (!accept && D.stale[b]) {
@@ -583,12 +591,32 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       if constexpr (GUARD) {
         D.fpsi[b] = fpsi;
         GBp->meas[b] = meas;
+        GBp->ls_count[b] = 0;
       }
     }
     D.cur[b] = cur;
     if (!accept) {  // the accepted point sits where the next trial would go: sit the next launch out
       D.skip[b] = 1;
       oh_count(D.work + 1);
+    }
+  }
+  if constexpr (GUARD) {
+    if (line_search) {  // the rejected step again, shorter: no sweep, the damping untouched
+      if (iters >= P.max_iter) {
+        D.status[b] = OH_STATUS_MAX_ITER;
+        return false;
+      }
+      for (int t = P.t0; t < T; ++t) {
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) rb_st(KNOT(D.zstep, t, NZ), RB(a), lb, OH_LS_SHRINK * rb_ld(KNOT(D.zstep, t, NZ), RB(a), lb));
+      }
+      const int k = GBp->ls_count[b] + 1;
+      GBp->ls_count[b] = k;
+      double sk = 1.0;
+      for (int i = 0; i < k; ++i) sk *= OH_LS_SHRINK;
+      D.pred[b] = -sk * GBp->ls_gd[b] + 0.5 * sk * sk * GBp->ls_q[b];
+      D.iters[b] = iters + 1;
+      return true;
     }
   }
   if (polish_request) {
@@ -792,6 +820,10 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     }
     // decrease the model predicts for alpha z, with (H + mu I) z = -g:  -alpha g.z - alpha^2/2 z^T H z = -alpha gd + alpha^2/2 (gd + mu z2)
     D.pred[b] = -alpha * gd + 0.5 * alpha * alpha * (gd + mu * z2);
+    if constexpr (GUARD) {  // for the line search along this step, should it be rejected (alpha = 1 on these handles)
+      GBp->ls_gd[b] = alpha * gd;
+      GBp->ls_q[b] = alpha * alpha * (gd + mu * z2);
+    }
   }
   D.mu[b] = mu;
   D.iters[b] = iters + 1;

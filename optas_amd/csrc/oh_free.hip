@@ -358,18 +358,19 @@ OH_DEV void symv(const double (&A)[M * (M + 1) / 2], const double (&x)[M], doubl
 }
 
 // Ratio test and bookkeeping of one instance at the head of K3 (shared by the serial sweep and the cyclic-reduction kernel below).
-// f, fpsi, meas: merit, penalty part and violation of the trial slot ts summed over the knots.  Returns false when the instance stops here.
+// f, fpsi, meas: merit, penalty part and violation of the trial slot ts summed over the knots.  Returns 0 when the instance stops here, 1 when
+// the step is to be solved for, 2 when the rejected step is to be tried again shorter (line search, OH_LS_MAX: the caller scales D.zstep).
 template <int N, bool GUARD>
-OH_DEV bool free_accept(const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, const int b, const int ts, const double f, const double fpsi,
+OH_DEV int free_accept(const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, const int b, const int ts, const double f, const double fpsi,
                         const double meas, int& cur, LMState& lm) {
-  bool accept;
+  bool accept, line_search = false;
   if (D.first[b]) {
     if (!(f == f) || !(fabs(f) < 1e300)) {  // non-finite seed / parameters: report, do not iterate
       D.status[b] = OH_STATUS_NUMERICAL;
       D.cur[b] = ts;
       D.f_cur[b] = f;
       D.stat[b] = f;
-      return false;
+      return 0;
     }
     accept = true;
     D.first[b] = 0;
@@ -386,20 +387,48 @@ OH_DEV bool free_accept(const FigParams& P, const FigBuffers& D, const GuardBuff
     GB.outer[b] = 0;
     GB.rho[b] = GB.rho_next[b];
   } else {
+    const LMState lm_before = lm;
     accept = lm_accept(P, f, 0.0, D.f_cur[b], D.pred[b], 0.0, lm);
+    if constexpr (GUARD) {
+      if (!accept && GB.ls_count[b] < OH_LS_MAX) {  // a shorter step along the same direction first: the damping stays where it was
+        lm = lm_before;
+        line_search = true;
+      }
+    }
     D.nun[b] = lm.nun;
   }
   if (accept) {
     cur = ts;
     D.f_cur[b] = f;
     D.feas[b] = meas;
-    if constexpr (GUARD) D.fpsi[b] = fpsi;
+    if constexpr (GUARD) {
+      D.fpsi[b] = fpsi;
+      GB.ls_count[b] = 0;
+    }
   }
   D.cur[b] = cur;
   if (!accept) {
     D.skip[b] = 1;
     atomicAdd(D.work + 1, 1ULL);
   }
+  return line_search ? 2 : 1;
+}
+// the bookkeeping of a line-search trial (the caller has scaled D.zstep by OH_LS_SHRINK); returns whether the instance goes on
+template <bool GUARD>
+OH_DEV bool free_line_search(const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, const int b) {
+  if constexpr (GUARD) {
+    const int k = GB.ls_count[b] + 1;
+    GB.ls_count[b] = k;
+    double sk = 1.0;
+    for (int i = 0; i < k; ++i) sk *= OH_LS_SHRINK;
+    D.pred[b] = -sk * GB.ls_gd[b] + 0.5 * sk * sk * GB.ls_q[b];
+  }
+  const int iters = D.iters[b];
+  if (iters >= P.max_iter) {
+    D.status[b] = OH_STATUS_MAX_ITER;
+    return false;
+  }
+  D.iters[b] = iters + 1;
   return true;
 }
 
@@ -471,7 +500,15 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
         meas = fmax(meas, D.cv[ts][(size_t)t * Bp + b]);
       }
     }
-    if (!free_accept<N, GUARD>(P, D, GB, b, ts, f, fpsi, meas, cur, lm)) return false;
+    const int act = free_accept<N, GUARD>(P, D, GB, b, ts, f, fpsi, meas, cur, lm);
+    if (act == 0) return false;
+    if (act == 2) {
+      for (int t = P.t0; t < T; ++t) {
+#pragma unroll
+        for (int a = 0; a < N; ++a) D.zstep[IDX(t, N, a)] *= OH_LS_SHRINK;
+      }
+      return free_line_search<GUARD>(P, D, GB, b);
+    }
   }
   double mu = lm.mu;
   const double* __restrict__ Drc = D.Dr[cur];
@@ -593,6 +630,10 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
       }
     }
     D.pred[b] = -0.5 * gd + 0.5 * mu * z2;
+    if constexpr (GUARD) {
+      GB.ls_gd[b] = gd;
+      GB.ls_q[b] = gd + mu * z2;
+    }
   }
   D.mu[b] = mu;
   D.iters[b] = iters + 1;
@@ -676,12 +717,20 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
     }
     LMState lm{D.mu[b], D.nun[b]};
     int cur = 1 - slot;
-    ctl[0] = free_accept<N, GUARD>(P, D, GB, b, slot, f, fpsi, meas, cur, lm) ? 1 : 0;
+    ctl[0] = free_accept<N, GUARD>(P, D, GB, b, slot, f, fpsi, meas, cur, lm);
     ctl[1] = cur;
     ctld = lm.mu;
   }
   __syncthreads();
-  if (!ctl[0]) return;
+  if (ctl[0] == 0) return;
+  if (ctl[0] == 2) {  // line search: the rejected step again, shorter
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < N; ++a) D.zstep[IDX(t, N, a)] *= OH_LS_SHRINK;
+    }
+    if (lane == 0 && free_line_search<GUARD>(P, D, GB, b)) atomicAdd(D.n_running, 1);
+    return;
+  }
   const int cur = ctl[1];
   double mu = ctld;
   auto block_sum = [&](double v, const int slot_r, const bool is_max) {  // all lanes get the result
@@ -841,6 +890,10 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
   z2 = block_sum(z2, 2, false);
   if (lane == 0) {
     D.pred[b] = -0.5 * gd + 0.5 * mu * z2;
+    if constexpr (GUARD) {
+      GB.ls_gd[b] = gd;
+      GB.ls_q[b] = gd + mu * z2;
+    }
     D.mu[b] = mu;
     D.iters[b] += 1;
     atomicAdd(D.n_running, 1);

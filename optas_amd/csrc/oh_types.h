@@ -55,7 +55,18 @@ struct GuardBuffers {
   double* lam_out;    // [T][NC][Bp] multipliers of finished instances at their ORIGINAL index (instances move when the batch is compacted)
   double* lamv_out;   // [T][2N][Bp] same for the velocity rows
   double* scr;        // [T (NC + 2N) + n_par + 8][Bp] scratch of the compaction (k_guard_gather / k_guard_scatter)
+  // line search along a rejected step (OH_LS_MAX): shortenings so far, and g^T z and g^T z + mu z^T z of the step as it was solved for
+  // (predicted decrease of s z: -s gd + s^2 q / 2); reset whenever a point is accepted, so they need not move with a compacted instance
+  int* ls_count;      // [Bp]
+  double* ls_gd;      // [Bp]
+  double* ls_q;       // [Bp]
 };
+// Handles with inequality rows: a rejected trial is followed by up to OH_LS_MAX shorter steps along the same direction (factor OH_LS_SHRINK each)
+// before the Levenberg-Marquardt damping is raised.  What rejects a step of these problems is a row that is inactive at the accepted point
+// and violated at the trial: the model cannot know it, and damping the whole step to ~1e3 and easing it back costs a dozen steps
+// (oracle/guarded.py, oracle/structured.py; numpy port, config 4 synthetic: 30.0 -> 22.0 steps per arm, slowest arm 70 -> 57 launches).
+#define OH_LS_MAX 3
+#define OH_LS_SHRINK 0.3
 
 // Device buffers of one handle (SoA, instance index fastest; Bp = B rounded up to 64).
 struct FigBuffers {

@@ -19,7 +19,7 @@ from typing import List, Optional
 
 import numpy as np
 
-from .structured import FoldedChain, block_tridiag_solve
+from .structured import LS_MAX, LS_SHRINK, FoldedChain, block_tridiag_solve
 
 
 @dataclass
@@ -127,6 +127,7 @@ def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=Non
     mu, nun = 0.0, 2.0
     iters = rejected = outers = 0
     first, outer = True, False
+    ls_count, ls_scale, z_last, gd_last, q_last = 0, 1.0, None, 0.0, 0.0
     Qt = Qc
     cur = None
     status = 1
@@ -148,11 +149,26 @@ def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=Non
                 mu *= max(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3)
                 mu = 0.0 if mu < 1e-7 else mu
                 nun = 2.0
+            elif ls_count < LS_MAX and z_last is not None:
+                # line search along the rejected step before the damping is touched (free_accept in csrc/oh_free.hip): what rejects a step
+                # of these problems is a row that was inactive at the accepted point and is violated at the trial -- the model cannot
+                # know it, damping the whole step to 1e3 and easing it back costs a dozen steps, a shorter step along the same direction one
+                ls_count += 1
+                ls_scale *= LS_SHRINK
+                rejected += 1
+                pred = -gd_last * ls_scale + 0.5 * ls_scale * ls_scale * q_last
+                Qt = cur["Q"].copy()
+                Qt[F] += z_last * ls_scale
+                if iters >= max_iter:
+                    break
+                iters += 1
+                continue
             else:
                 mu = max(mu * nun, 1e-3)
                 nun *= 2.0
                 rejected += 1
         if accept:
+            ls_count, ls_scale = 0, 1.0
             ndiag = np.full(T, 2.0)
             ndiag[T - 1] = 1.0
             cur = {"Q": Qt, "f": f_t, "G": G[F], "D": (W + (2 * kap * ndiag)[:, None, None] * np.eye(n)[None])[F], "meas": meas_t}
@@ -183,7 +199,9 @@ def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=Non
             continue
         if iters >= max_iter:
             break
-        pred = -0.5 * float(np.sum(cur["G"] * z)) + 0.5 * mu * float(np.sum(z * z))
+        gd_last, z2_ = float(np.sum(cur["G"] * z)), float(np.sum(z * z))
+        pred = -0.5 * gd_last + 0.5 * mu * z2_
+        z_last, q_last, ls_scale = z.copy(), gd_last + mu * z2_, 1.0  # pred(s) = -s gd + s^2 q / 2 for the step s z
         Qt = cur["Q"].copy()
         Qt[F] += z
         iters += 1

@@ -325,6 +325,9 @@ def retract(prob, Q, Rc, tol=1e-10, max_corr=4, e_tgt=None):
     return Q
 
 
+LS_MAX, LS_SHRINK = 3, 0.3  # OH_LS_MAX, OH_LS_SHRINK (csrc/oh_types.h): line search on a rejected step of a handle with inequality rows
+
+
 def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False, hessian="hybrid", limits=None, rho0=None, guards=None, overrelax=1.5, overrelax_from=4, vlimits=None):
     """Returns dict(Q, f, iters (= steps solved: accepted + rejected), rejected, stat, feas, status).
     limits = (lo, up) or guards = oracle.guarded.Guards (joint limits and/or sphere clearances): inequality rows at the free
@@ -405,6 +408,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
     cur = None
     status = 1
     nu_n = 2.0
+    ls_count, ls_scale, z_last, gd_last, q_last = 0, 1.0, None, 0.0, 0.0
     while True:
         # ---- k_eval + k_couple on the trial point
         use_exact = hessian == "exact" or (hessian == "hybrid" and not first and stat_prev <= hyb_switch)
@@ -462,6 +466,26 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                         mu = max(4.0 * mu, 1e-3)
                 else:
                     mu = max(4.0 * mu, 1e-3)
+            elif guard and (not accept) and ls_count < LS_MAX and z_last is not None:
+                # handles with inequality rows: line search along the rejected step before the damping is touched (oracle/guarded.py,
+                # step_instance<N, true> in csrc/oh_figure8_units.h)
+                ls_count += 1
+                ls_scale *= LS_SHRINK
+                rejected += 1
+                z_ls = z_last * ls_scale
+                pred = -gd_last * ls_scale + 0.5 * ls_scale * ls_scale * q_last
+                Qt = cur["Q"].copy()
+                Qt[F] += np.einsum("tia,ta->ti", cur["Z"][F], z_ls)
+                e_tgt = cur["e"].copy()
+                e_tgt[F] += np.einsum("tma,ta->tm", cur["JZ"], z_ls)
+                tol_r = min(1e-10, tol_feas)
+                if stat_prev > hyb_switch:
+                    tol_r = min(1e-5, max(tol_r, 1e-3 * pred))
+                Qt = retract(prob, Qt, Rc, tol=tol_r, e_tgt=e_tgt)
+                if iters >= max_iter:
+                    break
+                iters += 1
+                continue
             elif rule == "nielsen":
                 if accept:
                     mu = mu * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)
@@ -488,6 +512,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                 iters += 1
                 continue
         if accept:
+            ls_count, ls_scale = 0, 1.0
             Gs = np.zeros((T, n))
             d = Qt[2:] - Qt[1:-1]
             Gs[2:] += 2 * kap * d
@@ -552,6 +577,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         gd_, z2_ = float(np.sum(cur["gt"] * z)), float(np.sum(z * z))
         pred = -alpha * gd_ + 0.5 * alpha * alpha * (gd_ + mu * z2_)
         z = alpha * z
+        z_last, gd_last, q_last, ls_scale = z.copy(), alpha * gd_, alpha * alpha * (gd_ + mu * z2_), 1.0  # pred(s) = -s gd + s^2 q / 2 for the step s z
         Qt = cur["Q"].copy()
         Qt[F] += np.einsum("tia,ta->ti", cur["Z"][F], z)
         e_tgt = cur["e"].copy()

@@ -564,7 +564,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       if (polish_request) lm = lm_before;
       if constexpr (GUARD) {
         // handles with inequality rows: a shorter step along the same direction before the damping is raised (OH_LS_MAX, oh_types.h)
-        if (!accept && !polish_request && GBp->ls_count[b] < OH_LS_MAX) {
+        if (!accept && !polish_request && GBp->ls_count[b] < OH_LS_MAX && iters < P.max_iter / 2) {  // (first half of the budget only, see free_accept)
           lm = lm_before;
           line_search = true;
         }

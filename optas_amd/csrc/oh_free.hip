@@ -390,7 +390,9 @@ OH_DEV int free_accept(const FigParams& P, const FigBuffers& D, const GuardBuffe
     const LMState lm_before = lm;
     accept = lm_accept(P, f, 0.0, D.f_cur[b], D.pred[b], 0.0, lm);
     if constexpr (GUARD) {
-      if (!accept && GB.ls_count[b] < OH_LS_MAX) {  // a shorter step along the same direction first: the damping stays where it was
+      // a shorter step along the same direction first: the damping stays where it was.  (Only in the first half of the iteration budget: a
+      // rejected trial costs a skipped launch, and an instance that never converges should not take the batch twice as long to find out.)
+      if (!accept && GB.ls_count[b] < OH_LS_MAX && D.iters[b] < P.max_iter / 2) {
         lm = lm_before;
         line_search = true;
       }

@@ -149,7 +149,7 @@ def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=Non
                 mu *= max(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3)
                 mu = 0.0 if mu < 1e-7 else mu
                 nun = 2.0
-            elif ls_count < LS_MAX and z_last is not None:
+            elif ls_count < LS_MAX and z_last is not None and iters < max_iter // 2:
                 # line search along the rejected step before the damping is touched (free_accept in csrc/oh_free.hip): what rejects a step
                 # of these problems is a row that was inactive at the accepted point and is violated at the trial -- the model cannot
                 # know it, damping the whole step to 1e3 and easing it back costs a dozen steps, a shorter step along the same direction one

@@ -466,7 +466,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                         mu = max(4.0 * mu, 1e-3)
                 else:
                     mu = max(4.0 * mu, 1e-3)
-            elif guard and (not accept) and ls_count < LS_MAX and z_last is not None:
+            elif guard and (not accept) and ls_count < LS_MAX and z_last is not None and iters < max_iter // 2:
                 # handles with inequality rows: line search along the rejected step before the damping is touched (oracle/guarded.py,
                 # step_instance<N, true> in csrc/oh_figure8_units.h)
                 ls_count += 1

@@ -119,8 +119,9 @@ struct oh_handle {
   double compact_frac = 0.97;  // compact the batch once this fraction of it (or less) is still running (0.9 until the carried compaction
                                // stopped copying back: 0.95 ... 0.99 are +1 ... 2 % over 0.9 on two boxes, interleaved runs)
   double compact_frac_restart = 0.9;  // the same for the compaction that restarts the survivors (guarded handles, free family): it costs an evaluation
-  int tail_threshold = 8192;  // hand the last instances to the persistent one-wave-per-instance kernel (round 2, kernels compiled for the chain:
-                              // 8192 against 2048 is +1.3 ... 3 % at B = 262 144 and -21 % on a batch of 4096: 4.88 -> 3.85 ms; 16 384 is worse again)
+  int tail_threshold = 16384;  // hand the last instances to the persistent one-wave-per-instance kernel (round 2: with the kernel compiled for the
+                               // chain 8192 against 2048 was +1.3 ... 3 % at B = 262 144 and -21 % on a batch of 4096; with four of its blocks per CU
+                               // (two-pass exchange, 40 KB of LDS) 16 384 is level at B = 262 144 and -6 ... 13 % on batches of 16 ... 24 k)
   int free_pcr_max = 1536;    // position-tracking family: K3 by cyclic reduction, one block per instance, while at most this many are in the launch
   // run-time specialised evaluation kernels of the orientation-locked figure-eight family (oh_jit.hip)
   int specialize = specialize_mode_from_env();  // OH_SPECIALIZE env: 0 never, 1 at the first solve, auto: at the first solve of >= specialize_min_B instances

@@ -40,7 +40,7 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
   // lane's own column, one broadcast read for another knot's value in the serial sweeps (instead of a v_readlane pair per double).  In
   // registers they cost 190 VGPRs next to the ~350 of the fused evaluation: 512 + 256 registers with 241 spilled to scratch in round 1.
   constexpr int O_DR = 0, O_E = O_DR + NP, O_GT = O_E + NZ * NZ, O_G = O_GT + NZ, O_GF = O_G + N, O_EC = O_GF + N, O_JZ = O_EC + 3, O_PCR = O_JZ + 3 * NZ,
-                ROWS = O_PCR + (2 * NZ + 1) * NZ;
+                ROWS = O_PCR + (NZ + 1) * NZ;
   __shared__ double sm[ROWS][64];
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
@@ -216,43 +216,67 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
 #pragma unroll
           for (int j = 0; j <= i; ++j) Lc[tri(i, j)] = A[i * NZ + j];
         ok = chol_rcp<NZ>(Lc, rd, 1e-12) && ok;
-        // Y = A^{-1} [Lw | U | r], column by column, parked in LDS for the neighbours
+        // Y = A^{-1} [Lw | r], then A^{-1} U, column by column, parked in LDS for the neighbours -- in two passes through one (NZ + 1) x NZ
+        // tile: with all 2 NZ + 1 columns parked at once the block needs 48.6 KB of LDS and three of them fit a CU; at 40.4 KB four do
+        // (one wavefront of 512 registers per SIMD), a third more instances in flight when the kernel takes whole batches
+        const int lm_ = lane - sft, lp_ = lane + sft;
+        const bool hm = lm_ >= 0, hp = lp_ < 64;
+        const int im = hm ? lm_ : lane, ip = hp ? lp_ : lane;
+        double An[NZ * NZ], Ln[NZ * NZ], Un[NZ * NZ], rn2[NZ];
 #pragma unroll
-        for (int c2 = 0; c2 < 2 * NZ + 1; ++c2) {
+        for (int c2 = 0; c2 <= NZ; ++c2) {
           double col[NZ];
 #pragma unroll
-          for (int i = 0; i < NZ; ++i) col[i] = c2 < NZ ? Lw[i * NZ + c2] : (c2 < 2 * NZ ? U[i * NZ + (c2 - NZ)] : r[i]);
+          for (int i = 0; i < NZ; ++i) col[i] = c2 < NZ ? Lw[i * NZ + c2] : r[i];
           fsub_rcp<NZ>(Lc, rd, col);
           bsub_rcp<NZ>(Lc, rd, col);
 #pragma unroll
           for (int i = 0; i < NZ; ++i) sm[O_PCR + c2 * NZ + i][lane] = col[i];
         }
         __syncthreads();
-        const int lm_ = lane - sft, lp_ = lane + sft;
-        const bool hm = lm_ >= 0, hp = lp_ < 64;
-        const int im = hm ? lm_ : lane, ip = hp ? lp_ : lane;
-        double An[NZ * NZ], Ln[NZ * NZ], Un[NZ * NZ], rn2[NZ];
 #pragma unroll
         for (int i = 0; i < NZ; ++i) {
           double racc = r[i];
 #pragma unroll
           for (int j = 0; j < NZ; ++j) {
-            double aacc = A[i * NZ + j], lacc = 0.0, uacc = 0.0;
+            double aacc = A[i * NZ + j], lacc = 0.0;
 #pragma unroll
             for (int k = 0; k < NZ; ++k) {
-              // column j of Y^U / Y^L of the neighbours: rows (NZ + j) * NZ + k and j * NZ + k of the parked block
-              aacc -= Lw[i * NZ + k] * sm[O_PCR + (NZ + j) * NZ + k][im] + U[i * NZ + k] * sm[O_PCR + j * NZ + k][ip];
-              lacc -= Lw[i * NZ + k] * sm[O_PCR + j * NZ + k][im];
-              uacc -= U[i * NZ + k] * sm[O_PCR + (NZ + j) * NZ + k][ip];
+              aacc -= U[i * NZ + k] * sm[O_PCR + j * NZ + k][ip];   // A - U Y^L_{+}
+              lacc -= Lw[i * NZ + k] * sm[O_PCR + j * NZ + k][im];  // -Lw Y^L_{-}
             }
             An[i * NZ + j] = aacc;
             Ln[i * NZ + j] = lacc;
-            Un[i * NZ + j] = uacc;
           }
 #pragma unroll
-          for (int k = 0; k < NZ; ++k) racc -= Lw[i * NZ + k] * sm[O_PCR + 2 * NZ * NZ + k][im] + U[i * NZ + k] * sm[O_PCR + 2 * NZ * NZ + k][ip];
+          for (int k = 0; k < NZ; ++k) racc -= Lw[i * NZ + k] * sm[O_PCR + NZ * NZ + k][im] + U[i * NZ + k] * sm[O_PCR + NZ * NZ + k][ip];
           rn2[i] = racc;
         }
+        __syncthreads();
+#pragma unroll
+        for (int c2 = 0; c2 < NZ; ++c2) {  // (Lc is still the factor of the block as it stood before this level)
+          double col[NZ];
+#pragma unroll
+          for (int i = 0; i < NZ; ++i) col[i] = U[i * NZ + c2];
+          fsub_rcp<NZ>(Lc, rd, col);
+          bsub_rcp<NZ>(Lc, rd, col);
+#pragma unroll
+          for (int i = 0; i < NZ; ++i) sm[O_PCR + c2 * NZ + i][lane] = col[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+#pragma unroll
+          for (int j = 0; j < NZ; ++j) {
+            double aacc = An[i * NZ + j], uacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < NZ; ++k) {
+              aacc -= Lw[i * NZ + k] * sm[O_PCR + j * NZ + k][im];  // A - Lw Y^U_{-}
+              uacc -= U[i * NZ + k] * sm[O_PCR + j * NZ + k][ip];   // -U Y^U_{+}
+            }
+            An[i * NZ + j] = aacc;
+            Un[i * NZ + j] = uacc;
+          }
         __syncthreads();
         // Lw / U of a lane without that neighbour are zero, so the clamped reads above contributed nothing
 #pragma unroll

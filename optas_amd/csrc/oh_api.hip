@@ -128,6 +128,7 @@ struct oh_handle {
   int specialize_min_B = 4096;
   const FigSpec* spec = nullptr;
   bool spec_failed = false;
+  bool spec_cache_checked = false;  // automatic mode has looked for a cached code object once (reset with the constants)
   const FkSpec* fk_spec = nullptr;  // K1 for this chain (any handle with constants)
   bool fk_spec_failed = false;
   int specialize_min_units = 1 << 16;
@@ -791,6 +792,7 @@ extern "C" int oh_set_constants(oh_handle* h, const oh_chain* chain) {
   h->chain_host = *chain;
   h->spec = nullptr;  // kernels compiled for the previous chain
   h->spec_failed = false;
+  h->spec_cache_checked = false;
   h->fk_spec = nullptr;
   h->fk_spec_failed = false;
   HIPCHK(hipMemcpy(h->d_chain, chain, sizeof(oh_chain), hipMemcpyHostToDevice));
@@ -1070,9 +1072,14 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   int rc = ensure_capacity(h, B);
   if (rc) return rc;
   fill_params(h);
-  if (spec_applies(h) && !h->spec && !h->spec_failed &&
-      (h->specialize == OH_SPECIALIZE_ALWAYS || (h->specialize == OH_SPECIALIZE_AUTO && B >= h->specialize_min_B)))
-    if (oh_specialize(h) != OH_OK) h->spec_failed = true;  // the generic kernels run (and no further attempt is made); oh_last_error keeps the reason
+  if (spec_applies(h) && !h->spec && !h->spec_failed) {
+    bool want = h->specialize == OH_SPECIALIZE_ALWAYS || (h->specialize == OH_SPECIALIZE_AUTO && B >= h->specialize_min_B);
+    if (!want && h->specialize == OH_SPECIALIZE_AUTO && !h->spec_cache_checked) {  // a compiled object is at hand: milliseconds, whatever the batch
+      h->spec_cache_checked = true;
+      want = oh_jit_figure8_cached(h->chain_host, h->desc.ndof);
+    }
+    if (want && oh_specialize(h) != OH_OK) h->spec_failed = true;
+  }  // the generic kernels run (and no further attempt is made); oh_last_error keeps the reason
   const bool guarded = h->have_guards;
   const bool lead = h->chain_host.has_lead != 0;
   if (lead && (guarded || !h->desc.lock_orientation || h->desc.ndof != 6))

@@ -17,6 +17,7 @@ std::string oh_jit_figure8_source(const oh_chain& chain, int N);
 int oh_jit_compile_cached(const std::string& src, std::vector<char>* code, bool* from_disk, std::string* err);
 // compile (or find) and load the kernels for this chain; *out stays owned by the process-wide cache
 int oh_jit_figure8(const oh_chain& chain, int N, const FigSpec** out, std::string* err);
+bool oh_jit_figure8_cached(const oh_chain& chain, int N);  // loaded in this process or present in the disk cache
 hipError_t oh_spec_launch_eval(const FigSpec& sp, hipStream_t s, const FigParams& P, const FigBuffers& D, int slot, int part);
 hipError_t oh_spec_launch_tail(const FigSpec& sp, hipStream_t s, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_spec_kernel_info(const FigSpec& sp, const char* name, OhKernelInfo* out);

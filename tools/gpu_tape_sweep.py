@@ -11,7 +11,7 @@ from optas_amd.tape import compile_problem
 kuka = RobotModel.builtin("kuka_lwr")
 tp = compile_problem(ik_setup(build_only=True)[1])
 rng = np.random.default_rng(20260927)
-for B in (1, 64, 512, 2048, 4096, 8192, 32768):
+for B in (1, 64, 512, 2048, 4096, 8192, 32768, 65536, 131072):
     qn = np.deg2rad([0, 45, 0, -90, 0, -45, 0]) + rng.uniform(-0.3, 0.3, (B, 7))
     pg = np.asarray(kuka.get_global_link_position("end_effector_ball", np.clip(qn + rng.uniform(-0.5, 0.5, (B, 7)), kuka.lower_actuated_joint_limits, kuka.upper_actuated_joint_limits).T)).T
     p = np.ascontiguousarray(np.concatenate([qn, pg], 1))

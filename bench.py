@@ -164,6 +164,42 @@ def cpu_baseline(sample: int, hessian: str = "hybrid"):
     }
 
 
+def oracle_sample(x0, qc, x, f, status, n: int):
+    """`n` instances of the batch the timed steps solved, graded by the oracle (never by the library): reference-form KKT residuals of
+    min f s.t. 0 <= v <= 1e10 on the literal 1114-row v (oracle/solvers.py:kkt_reference_form, what "KKT residual vs IPOPT" is reported on), the
+    reference objective recomputed from x, and the optimum the compiled host port of the state machine reaches from the same seed."""
+    from oracle import cpu_port
+    from oracle.problems import FigureEightNLP
+    from oracle.robot import OracleRobot
+    from oracle.solvers import kkt_reference_form
+
+    robot = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json"))
+    nlp = FigureEightNLP(robot, LINK, T=T, Tmax=TMAX)
+    B = len(qc)
+    idx = np.sort(np.random.default_rng(B).choice(B, min(n, B), replace=False))
+    dt, lp = local_path()
+    chain = optas_amd.RobotModel.builtin("kuka_lwr").kinematic_chain(LINK)
+    t0 = time.perf_counter()
+    ks = [kkt_reference_form(nlp, x[i], qc[i]) for i in idx]
+    f_ref = np.array([nlp.f(x[i], qc[i]) for i in idx])
+    _, f_port, _, _, st_port = cpu_port.solve(chain, T, dt, lp, x0[idx], qc[idx], threads=usable_cores())
+    same = np.abs(f[idx] - f_port) <= 1e-9 * np.abs(f_port)
+    return {
+        "instances": [int(i) for i in idx],
+        "what": "reference-form KKT (min f s.t. 0 <= v <= 1e10, literal v = [a; -a; h; -h], multipliers by bounded least squares) evaluated by oracle/ on x "
+        "downloaded after the timed steps; objective recomputed by oracle/problems.py:FigureEightNLP.f; optimum of oracle/cpu_port from the same seed",
+        "stationarity_max": float(max(k["stationarity"] for k in ks)),
+        "feasibility_max": float(max(k["feasibility"] for k in ks)),
+        "complementarity_max": float(max(k["complementarity"] for k in ks)),
+        "objective_recomputed_max_abs_diff": float(np.abs(f_ref - f[idx]).max()),
+        "objective_equals_host_port_1e-9": int(same.sum()),
+        "objective_max_rel_diff_vs_host_port": float((np.abs(f[idx] - f_port) / np.abs(f_port)).max()),
+        "all_converged": bool((status[idx] == 0).all() and (st_port == 0).all()),
+        "tolerances": {"stationarity": 1e-5, "feasibility": 1e-9, "complementarity": 1e-8, "objective": 1e-9},
+        "seconds": time.perf_counter() - t0,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,11 +212,39 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024, help="instances timed on one host core")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fk-units", type=int, default=1 << 22)
+    ap.add_argument("--oracle-sample", type=int, default=16, help="instances of the timed batch graded by the oracle afterwards (rank 0, N=1)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: run the multi-process plumbing only (rendezvous of the RCCL id with a stand-in id, "
+                    "per-rank inputs) and print one JSON line per rank; everything of a --gpus N run except oh_comm_init and the solves")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        import hashlib
+
+        from optas_amd import distributed as oad
+
+        uid = oad.exchange(rank, world, lambda: os.urandom(_lib.OH_COMM_ID_BYTES), timeout=60.0) if "RANK" in os.environ else b""
+        if "RANK" in os.environ and os.environ.get("OPTAS_RDZV", "file") == "file":
+            # a record counts only while its publisher lives; in a real run rank 0 is then inside ncclCommInitRank until everyone has joined --
+            # here it waits for the others' acknowledgements instead
+            ack = oad.rendezvous_path() + ".ack"
+            if rank == 0:
+                t_ack = time.monotonic()
+                while not all(os.path.exists(f"{ack}{r}") for r in range(1, world)) and time.monotonic() - t_ack < 60.0:
+                    time.sleep(0.01)
+                for r in range(1, world):
+                    try:
+                        os.remove(f"{ack}{r}")
+                    except OSError:
+                        pass
+            else:
+                open(f"{ack}{rank}", "w").close()
+        x0, qc = make_inputs(min(args.batch, 64), rank)
+        print(json.dumps({"dry_run": True, "rank": rank, "world": world, "local_rank": local_rank, "rdzv": os.environ.get("OPTAS_RDZV", "file"),
+                          "id_sha256": hashlib.sha256(uid).hexdigest(), "id_bytes": len(uid), "qc_first": qc[0].tolist(), "nx": int(x0.shape[1])}), flush=True)
+        return
     comm = None
     if world > 1 or ("RANK" in os.environ and os.environ.get("OH_BENCH_DIST_AT_1", "1") == "1"):  # launcher-started: one rank per GPU
         from optas_amd import distributed as oad
@@ -198,8 +262,10 @@ def main():
         be = FigureEightBackend(robot.kinematic_chain(LINK), T, dt, lp, max_iter=args.max_iter, tol=args.tol, hessian=hess)
     else:  # the other ranks never read the URDF: they get the folded constants from rank 0
         be = FigureEightBackend(None, T, dt, lp, max_iter=args.max_iter, tol=args.tol, hessian=hess, ndof=7)
+    rccl_world = None
     if comm is not None:
         comm.broadcast_constants(be.handle, root=0)  # the one collective of the whole job
+        rccl_world = comm.info()[1]  # ncclCommCount: the communicator the constants travelled over spans this many ranks
 
     B = args.batch
     x0, qc = make_inputs(B, rank)
@@ -233,8 +299,13 @@ def main():
         solve_ms_plain += be.timing()["solve_ms"]
     sync_all()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if comm is not None:
-        elapsed = comm.max_over_ranks(elapsed)
+        mine = elapsed
+        elapsed = comm.max_over_ranks(mine)
+        per_rank = {"elapsed_s_max": elapsed, "elapsed_s_min": -comm.max_over_ranks(-mine),
+                    "sum_of_rank_rates_solves_per_s": comm.sum_over_ranks(B * args.steps / mine),
+                    "note": "each rank's own wall time of the K steps between the two barriers, reduced through oh_comm_allreduce_{max,sum}; value uses the max"}
     # second pass of the same K steps with one hipEventRecord after every kernel on the handle's stream: the per-kernel times behind the
     # roofline object (the timed pass above runs without them)
     be.set_profiling(True)
@@ -253,6 +324,9 @@ def main():
     kkt = d_k.download(np.float64, (B, 3))
     fvals = d_f.download(np.float64, (B,))
     conv = status == 0
+    osample = None
+    if world == 1 and args.oracle_sample > 0 and not args.no_cpu_baseline:
+        osample = oracle_sample(x0, qc, d_x.download(np.float64, (B, nx)), fvals, status, args.oracle_sample)
 
     # north-star kernel K1 (FK + geometric Jacobian), SoA, measured with HIP events on the handle's stream
     nfk = args.fk_units
@@ -367,6 +441,8 @@ def main():
             "global_batch": world * B,
             "T": T,
             "parallelism": f"dp{world} (instances sharded, one RCCL broadcast of constants)",
+            "rccl_world": rccl_world,
+            "per_rank": per_rank,
             "hessian": args.hessian,
         },
         "roofline": roofline,
@@ -391,6 +467,7 @@ def main():
             "kkt_stationarity_max_converged": float(kkt[conv, 0].max()) if conv.any() else None,
             "feasibility_max": float(kkt[:, 1].max()),
             "f_mean": float(fvals.mean()),
+            "oracle_sample": osample,
         },
         "device_ms_per_step": solve_ms_plain / args.steps,
         "specialized_kernels": {**spec_info, "note": "k_retract / k_evalb / k_tail compiled with hiprtc behind a constexpr copy of the handle's kinematic chain (oh_specialize; automatic at the first solve of >= 4096 instances, before the timed region)"},

@@ -330,6 +330,9 @@ int oh_comm_barrier(void);
 int oh_comm_allreduce_max(double* value);
 int oh_comm_allreduce_sum(double* value);
 int oh_comm_destroy(void);
+/* Rank and world size as RCCL itself reports them for this process's communicator (ncclCommUserRank / ncclCommCount): what a harness prints to
+   show that the communicator spans the job. */
+int oh_comm_info(int* rank, int* world);
 /* The constants a handle holds (after oh_set_constants* or oh_comm_broadcast_constants). */
 int oh_get_constants(oh_handle* h, oh_chain* out);
 
@@ -341,10 +344,14 @@ int oh_set_guards(oh_handle* h, const oh_guards* guards);
      x0 [B][nx], p [B][np]  in;  x [B][nx], f [B], kkt [B][3] = (stationarity, feasibility,
      complementarity), iters [B], status [B] out (any output pointer may be NULL).
    nx = ndof*T + ndof*(T-1), np = ndof for OH_PROBLEM_FIGURE_EIGHT; see the OH_PROBLEM_* comments for the others.
-   One call of the orientation-locked family takes at most 2^32 / (8 T (ndof-3)^2) instances (671 088 at T = 50, ndof = 7: a stage
-   array is addressed with 32-bit offsets); larger batches return OH_ERR_INVALID and are to be split by the caller. */
+   One call of the orientation-locked family takes at most about 2^32 / (8 T (ndof-3)^2) instances (a stage array is addressed with 32-bit
+   offsets; the row pad of large batches counts): oh_max_batch says exactly how many; larger batches return OH_ERR_INVALID and are to be
+   split by the caller. */
 int oh_solve(oh_handle* h, int B, const double* x0, const double* p, double* x, double* f, double* kkt,
              int* iters, int* status);
+
+/* Largest B one oh_solve / oh_solve_device call of this handle takes (*out = 0: the library sets no bound of its own). */
+int oh_max_batch(oh_handle* h, int* out);
 
 /* Same with buffers already resident in HBM (what bench.py times).  Synchronous on return. */
 int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt,

@@ -204,6 +204,8 @@ SYMBOLS = [
     "oh_comm_allreduce_max",
     "oh_comm_allreduce_sum",
     "oh_comm_destroy",
+    "oh_comm_info",
+    "oh_max_batch",
     "oh_set_guards",
     "oh_solve",
     "oh_solve_device",

@@ -296,8 +296,6 @@ class FigureEightBackend:
             chain_arg = chain
         self.T, self.ndof = int(T), int(chain.ndof)
         self.nx = self.ndof * self.T + self.ndof * (self.T - 1)
-        # largest batch of one oh_solve call (32-bit stage-array offsets of the sweep kernels, optas_hip.h): bigger ones go in chunks
-        self.max_batch = ((2**32 // (8 * (self.T * (self.ndof - 3) ** 2 + 1))) // 65536) * 65536 if lock_orientation else None
         self.np_ = self.ndof + (1 + self.T if chain.has_lead else 0)  # [qc_opt; lead angle of qc; lead angle per knot]
         lp = _lib.as_f64(local_path, (self.T, 3))
         self._lp = lp  # keep alive during oh_create
@@ -320,6 +318,11 @@ class FigureEightBackend:
         )
         self._h = C.c_void_p()
         _lib.check(lib.oh_create(C.byref(desc), C.byref(self._h)), "oh_create")
+        # largest batch of one oh_solve call, as the library states it (32-bit stage-array offsets of the sweep kernels, row pad included):
+        # bigger ones go in chunks
+        mb = C.c_int(0)
+        _lib.check(lib.oh_max_batch(self._h, C.byref(mb)), "oh_max_batch")
+        self.max_batch = (mb.value // 65536) * 65536 if mb.value >= 65536 else (mb.value or None)
         if chain_arg is not None:
             _lib.check(lib.oh_set_constants(self._h, C.byref(chain)), "oh_set_constants")
         self.chain = chain_arg

@@ -785,18 +785,24 @@ static int validate_chain(const oh_handle* h, const oh_chain& c) {
   return OH_OK;
 }
 
-extern "C" int oh_set_constants(oh_handle* h, const oh_chain* chain) {
-  if (!h || !chain) return fail(OH_ERR_INVALID, "oh_set_constants: null argument");
-  int rc = validate_chain(h, *chain);
-  if (rc) return rc;
-  h->chain_host = *chain;
-  h->spec = nullptr;  // kernels compiled for the previous chain
+// the handle has new constants: everything compiled for, or remembered about, the previous chain goes (one place for the three entry
+// points that set constants)
+static void adopt_chain(oh_handle* h, const oh_chain& c) {
+  h->chain_host = c;
+  h->have_chain = true;
+  h->spec = nullptr;
   h->spec_failed = false;
   h->spec_cache_checked = false;
   h->fk_spec = nullptr;
   h->fk_spec_failed = false;
+}
+
+extern "C" int oh_set_constants(oh_handle* h, const oh_chain* chain) {
+  if (!h || !chain) return fail(OH_ERR_INVALID, "oh_set_constants: null argument");
+  int rc = validate_chain(h, *chain);
+  if (rc) return rc;
   HIPCHK(hipMemcpy(h->d_chain, chain, sizeof(oh_chain), hipMemcpyHostToDevice));
-  h->have_chain = true;
+  adopt_chain(h, *chain);
   return OH_OK;
 }
 
@@ -807,13 +813,8 @@ extern "C" int oh_set_constants_device(oh_handle* h, const void* d_chain, size_t
   HIPCHK(hipMemcpy(&tmp, d_chain, sizeof(oh_chain), hipMemcpyDeviceToHost));
   int rc = validate_chain(h, tmp);
   if (rc) return rc;
-  h->chain_host = tmp;
-  h->spec = nullptr;
-  h->spec_failed = false;
-  h->fk_spec = nullptr;
-  h->fk_spec_failed = false;
   HIPCHK(hipMemcpy(h->d_chain, d_chain, sizeof(oh_chain), hipMemcpyDeviceToDevice));
-  h->have_chain = true;
+  adopt_chain(h, tmp);
   return OH_OK;
 }
 
@@ -824,6 +825,36 @@ static bool solver_chain_ok(const oh_chain& c) {
   return true;
 }
 
+// row stride of the SoA stage arrays for a batch of B (see ensure_capacity)
+static int row_stride(int B) {
+  int Bp = (B + 63) / 64 * 64;
+  if (Bp >= 4096) {
+    const char* e = getenv("OH_ROW_PAD");
+    Bp += 64 * (e ? atoi(e) : 13);
+  }
+  return Bp;
+}
+static bool stage_fits(const oh_handle* h, int B) {
+  const int N = h->desc.ndof, NZ = h->desc.lock_orientation ? N - 3 : N, T = h->desc.T;
+  return !h->desc.lock_orientation || ((double)T * NZ * NZ + 1.0) * (double)row_stride(B) * 8.0 < 4294967296.0;
+}
+
+// Largest batch one oh_solve / oh_solve_device call of this handle takes (0: no bound of the library's own, memory permitting): hosts chunk
+// bigger batches.  The bound is the 32-bit byte offset of the sweep kernels' stage arrays, row pad included.
+extern "C" int oh_max_batch(oh_handle* h, int* out) {
+  if (!h || !out) return fail(OH_ERR_INVALID, "oh_max_batch: null argument");
+  *out = 0;
+  if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT || !h->desc.lock_orientation) return OH_OK;
+  int lo = 64, hi = 1 << 30;  // largest multiple of 64 that fits, by bisection over the predicate ensure_capacity applies
+  if (!stage_fits(h, lo)) return OH_OK;
+  while (hi - lo > 64) {
+    const int mid = ((lo + (hi - lo) / 2) / 64) * 64;
+    if (stage_fits(h, mid)) lo = mid; else hi = mid;
+  }
+  *out = lo;
+  return OH_OK;
+}
+
 // carve the handle's device pool for B instances
 static int ensure_capacity(oh_handle* h, int B) {
   const int N = h->desc.ndof, NZ = h->desc.lock_orientation ? N - 3 : N, T = h->desc.T;
@@ -832,15 +863,10 @@ static int ensure_capacity(oh_handle* h, int B) {
   // their pages, and how the channel hash happens to spread them differed from process to process (k_couple 494 or 525 us per launch,
   // k_step 650...740, interleaved repeats on one box).  Off the power of two the spread is even: k_couple 455, k_step ~650, +3 % solves/s
   // (any of 1...13 x 512 B does it; OH_ROW_PAD overrides, 0 restores the old layout).
-  int Bp = (B + 63) / 64 * 64;
-  if (Bp >= 4096) {
-    const char* e = getenv("OH_ROW_PAD");
-    Bp += 64 * (e ? atoi(e) : 13);
-  }
+  const int Bp = row_stride(B);
   // the sweep kernels address one slot of a stage array with a 32-bit byte offset (buffer resources, oh_kernels.hip): the largest such
-  // array, T x NZ^2 doubles per instance, has to stay below 4 GiB (671 088 instances at T = 50, N = 7)
-  if (h->desc.lock_orientation && ((double)T * NZ * NZ + 1.0) * (double)Bp * 8.0 >= 4294967296.0)
-    return fail(OH_ERR_INVALID, "batch too large for one call (stage array beyond 4 GiB): split the batch");
+  // array, T x NZ^2 doubles per instance, has to stay below 4 GiB (about 670 000 instances at T = 50, N = 7; oh_max_batch says exactly)
+  if (!stage_fits(h, B)) return fail(OH_ERR_INVALID, "batch too large for one call (stage array beyond 4 GiB): split the batch (oh_max_batch)");
   if (B <= h->cap_B && h->pool) {
     h->D.B = B;
     // keep the Bp the pool was carved with (stride), only the active count changes
@@ -1613,6 +1639,8 @@ struct RcclApi {
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;     // optional
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;  // optional
 };
 RcclApi g_rccl;
 ncclComm_t g_comm = nullptr;
@@ -1636,6 +1664,8 @@ int rccl_load() {
   a.Broadcast = (decltype(a.Broadcast))dlsym(lib, "ncclBroadcast");
   a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  a.CommCount = (decltype(a.CommCount))dlsym(lib, "ncclCommCount");
+  a.CommUserRank = (decltype(a.CommUserRank))dlsym(lib, "ncclCommUserRank");
   if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.Broadcast || !a.AllReduce || !a.GetErrorString) {
     dlclose(lib);
     return fail(OH_ERR_HIP, "oh_comm: librccl lacks an expected symbol");
@@ -1671,8 +1701,21 @@ extern "C" int oh_comm_init(int rank, int world, const char* id) {
   ncclUniqueId u;
   memcpy(u.internal, id, OH_COMM_ID_BYTES);
   HIPCHK(hipStreamCreate(&g_comm_stream));
-  HIPCHK(hipMalloc((void**)&g_comm_scratch, 2 * sizeof(double)));
-  RCCLCHK(g_rccl.CommInitRank(&g_comm, world, u, rank));
+  // (oh_chain-sized: the broadcast of the constants lands here first and is validated before a handle adopts it)
+  if (hipMalloc((void**)&g_comm_scratch, 2 * sizeof(double) + sizeof(oh_chain)) != hipSuccess) {
+    hipStreamDestroy(g_comm_stream);
+    g_comm_stream = nullptr;
+    return fail(OH_ERR_HIP, "oh_comm_init: scratch allocation failed");
+  }
+  const ncclResult_t ir = g_rccl.CommInitRank(&g_comm, world, u, rank);
+  if (ir != ncclSuccess) {  // a retry must not leak the stream and the scratch
+    g_comm = nullptr;
+    hipFree(g_comm_scratch);
+    g_comm_scratch = nullptr;
+    hipStreamDestroy(g_comm_stream);
+    g_comm_stream = nullptr;
+    return rccl_fail("ncclCommInitRank", ir);
+  }
   g_comm_rank = rank;
   g_comm_world = world;
   return OH_OK;
@@ -1717,20 +1760,29 @@ extern "C" int oh_comm_broadcast_constants(oh_handle* h, int root) {
   if (!h->d_chain) return fail(OH_ERR_STATE, "oh_comm_broadcast_constants: this handle takes no kinematic constants");
   if (g_comm_rank == root && !h->have_chain) return fail(OH_ERR_STATE, "oh_comm_broadcast_constants: the root must call oh_set_constants first");
   HIPCHK(hipSetDevice(h->device));
-  // one ncclBroadcast of the oh_chain block (2952 B), in place in the handle's constants buffer, on the handle's stream
-  RCCLCHK(g_rccl.Broadcast(h->d_chain, h->d_chain, sizeof(oh_chain), ncclUint8, root, g_comm, h->stream));
+  // one ncclBroadcast of the oh_chain block (2952 B) on the handle's stream: out of the root's constants buffer, into a scratch block on the
+  // other ranks -- a chain this handle rejects (wrong ndof, unsupported joint) must not have replaced its constants already
+  unsigned char* const land = (unsigned char*)(g_comm_scratch + 2);
+  RCCLCHK(g_rccl.Broadcast(h->d_chain, g_comm_rank == root ? (void*)h->d_chain : (void*)land, sizeof(oh_chain), ncclUint8, root, g_comm, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (g_comm_rank != root) {
     oh_chain tmp;
-    HIPCHK(hipMemcpy(&tmp, h->d_chain, sizeof(oh_chain), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&tmp, land, sizeof(oh_chain), hipMemcpyDeviceToHost));
     if (const int rc = validate_chain(h, tmp)) return rc;
-    h->chain_host = tmp;
-    h->have_chain = true;
-    h->spec = nullptr;  // kernels compiled for a previous chain
-    h->spec_failed = false;
-    h->fk_spec = nullptr;
-    h->fk_spec_failed = false;
+    HIPCHK(hipMemcpy(h->d_chain, land, sizeof(oh_chain), hipMemcpyDeviceToDevice));
+    adopt_chain(h, tmp);
   }
+  return OH_OK;
+}
+
+// world size and rank as RCCL sees them (a harness prints them to prove the communicator spans the job)
+extern "C" int oh_comm_info(int* rank, int* world) {
+  if (!g_comm) return fail(OH_ERR_STATE, "oh_comm_info: call oh_comm_init first");
+  int r = -1, w = 0;
+  if (g_rccl.CommUserRank) RCCLCHK(g_rccl.CommUserRank(g_comm, &r)); else r = g_comm_rank;
+  if (g_rccl.CommCount) RCCLCHK(g_rccl.CommCount(g_comm, &w)); else w = g_comm_world;
+  if (rank) *rank = r;
+  if (world) *world = w;
   return OH_OK;
 }
 

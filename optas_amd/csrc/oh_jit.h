@@ -14,7 +14,7 @@ struct FigSpec {
 };
 std::string oh_jit_figure8_source(const oh_chain& chain, int N);
 // hiprtc for gfx950 (needs no device); goes through the disk cache
-int oh_jit_compile_cached(const std::string& src, std::vector<char>* code, bool* from_disk, std::string* err);
+int oh_jit_compile_cached(const std::string& src, std::vector<char>* code, bool* from_disk, std::string* err, bool ignore_disk = false);
 // compile (or find) and load the kernels for this chain; *out stays owned by the process-wide cache
 int oh_jit_figure8(const oh_chain& chain, int N, const FigSpec** out, std::string* err);
 bool oh_jit_figure8_cached(const oh_chain& chain, int N);  // loaded in this process or present in the disk cache

@@ -254,6 +254,35 @@ class OracleRobot:
         Q = np.asarray(Q, dtype=float)
         return np.stack([self.get_global_link_quaternion(link, Q[:, t]) for t in range(Q.shape[1])], axis=1)
 
+    def quaternion_batch(self, link, Q):
+        """get_global_link_quaternion (models.py:1049-1088) for N configurations at once: Q (N, ndof) -> (N, 4) xyzw.  The same chain walk and
+        the same reversed product (spatialmath.py:298-312) on component arrays; what the bench-scale tests check 13 M knots with
+        (equal to the scalar restatement to rounding, tests/test_oracle_models.py)."""
+        Q = np.atleast_2d(np.asarray(Q, dtype=float))
+        N = Q.shape[0]
+
+        def mul(a, b):  # Quaternion.__mul__: self = a, quat = b
+            x0, y0, z0, w0 = a
+            x1, y1, z1, w1 = b
+            return (x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0, -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0, x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0, -x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0)
+
+        quat = (np.zeros(N), np.zeros(N), np.zeros(N), np.ones(N))
+        root = self.get_root()
+        if link != root:
+            for joint_name in self.get_chain(root, link):
+                joint = self.joint_map[joint_name]
+                _, rpy = self.get_joint_origin(joint)
+                quat = mul(tuple(Quaternion.fromrpy(rpy).getquat()), quat)
+                if joint.type == "fixed" or joint.type == "prismatic":
+                    continue
+                if joint.type not in {"revolute", "continuous"}:
+                    raise JointTypeNotSupported(joint.type)
+                qi = Q[:, self.get_actuated_joint_index(joint.name)]
+                ax = unit(self.get_joint_axis(joint))
+                s = np.sin(0.5 * qi)
+                quat = mul((s * ax[0], s * ax[1], s * ax[2], np.cos(0.5 * qi)), quat)
+        return np.stack(quat, axis=1)
+
     def quaternion_jacobian(self, link, q):
         """d quat / d q (4x7), not a reference function: the reference gets it from CasADi AD of
         models.py:1049-1088.  For a Hamilton xyzw quaternion of R(q): dquat = 1/2 (omega,0) (x) quat with

@@ -28,6 +28,7 @@ def _worker(rank, world, path, out_dir):
         return bytes(np.random.default_rng(os.getpid()).integers(0, 256, _lib.OH_COMM_ID_BYTES, dtype=np.uint8))
 
     uid = oad.exchange_unique_id(rank, world, make_id, path=path, timeout=60.0)
+    time.sleep(0.5 if rank == 0 else 0.0)  # (a record counts only while its publisher lives: rank 0 stays until the other has read it)
     lo, hi = oad.shard(1001, world, rank)
     x0, qc = bench.make_inputs(8, rank)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), uid=np.frombuffer(uid, dtype=np.uint8), made=len(made), lo=lo, hi=hi, qc=qc)
@@ -64,6 +65,103 @@ def test_rendezvous_path_is_unique_per_launch(monkeypatch, tmp_path):
         oad.exchange_unique_id(1, 2, lambda: b"", path=str(tmp_path / "never.id"), timeout=0.2)
 
 
+def test_stale_and_foreign_records_are_never_accepted(tmp_path):
+    """Round-2 advisor finding: an earlier job that died before cleaning up (same shell, same port: same file name) must not hand its id to
+    this job's ranks.  A record is accepted only while the process that published it is alive."""
+    import struct
+    import subprocess
+    import sys
+
+    from optas_amd import _lib
+    from optas_amd import distributed as oad
+
+    path = str(tmp_path / "rdzv.id")
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    stale = bytes(range(128)) + struct.pack("<qq", dead.pid, 12345)
+    open(path, "wb").write(stale)
+    with pytest.raises(TimeoutError, match="dead process"):
+        oad.exchange_unique_id(1, 2, lambda: b"", path=path, timeout=0.3)
+    open(path, "wb").write(bytes(128))  # the round-2 format (bare id): not a record
+    with pytest.raises(TimeoutError, match="no record"):
+        oad.exchange_unique_id(1, 2, lambda: b"", path=path, timeout=0.3)
+    # rank 0 replaces whatever is there, and its own record is accepted while it lives
+    open(path, "wb").write(stale)
+    uid = oad.exchange_unique_id(0, 2, lambda: bytes([7]) * _lib.OH_COMM_ID_BYTES, path=path)
+    assert oad.exchange_unique_id(1, 2, lambda: b"", path=path, timeout=5.0) == uid
+    assert (os.stat(path).st_mode & 0o777) == 0o600
+    with pytest.raises(ValueError):
+        os.environ["OPTAS_RDZV"] = "carrier-pigeon"
+        try:
+            oad.exchange(1, 2, lambda: b"")
+        finally:
+            del os.environ["OPTAS_RDZV"]
+
+
+def _tcp_worker(rank, world, port, out_dir, tag):
+    import numpy as np
+
+    from optas_amd import _lib
+    from optas_amd import distributed as oad
+
+    uid = oad.exchange_unique_id_tcp(rank, world, lambda: bytes(np.random.default_rng(os.getpid()).integers(0, 256, _lib.OH_COMM_ID_BYTES, dtype=np.uint8)),
+                                     addr="127.0.0.1", port=port, timeout=60.0, tag=tag)
+    open(os.path.join(out_dir, f"t{rank}.bin"), "wb").write(uid)
+
+
+def test_tcp_rendezvous_world_size_3(tmp_path):
+    """The carrier for launchers whose workers share no temporary directory: rank 0 serves the id on a port next to the launcher's."""
+    import socket
+
+    with socket.socket() as s:  # a free port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_tcp_worker, args=(r, 3, port, str(tmp_path), "launch-a")) for r in range(3)]
+    for p in procs[::-1]:  # the clients first: they retry until rank 0 listens
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    ids = [open(tmp_path / f"t{k}.bin", "rb").read() for k in range(3)]
+    assert ids[0] == ids[1] == ids[2] and len(ids[0]) == 128
+    from optas_amd import distributed as oad
+
+    with pytest.raises(TimeoutError, match="nobody serves"):  # rank 0 is gone: a late rank says so
+        oad.exchange_unique_id_tcp(1, 3, lambda: b"", addr="127.0.0.1", port=port, timeout=0.5, tag="launch-a")
+    with pytest.raises(TimeoutError, match="never asked"):  # a rank that never shows up: rank 0 says so
+        oad.exchange_unique_id_tcp(0, 2, lambda: bytes(128), addr="127.0.0.1", port=port, timeout=1.5, tag="launch-b")
+
+
+@pytest.mark.parametrize("mode", ["file", "tcp"])
+def test_bench_dry_run_under_a_two_process_launch(tmp_path, mode):
+    """bench.py --gpus 2 --dry-run as the driver's launcher would start it (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment): the whole
+    multi-process path except ncclCommInitRank and the solves, on CPU."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in (1, 0):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OPTAS_RDZV=mode,
+                   OPTAS_RDZV_DIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err.decode()[-2000:]
+        outs.append(json.loads(out.decode().strip().splitlines()[-1]))
+    a, b = sorted(outs, key=lambda o: o["rank"])
+    assert a["dry_run"] and (a["rank"], b["rank"], a["world"], b["world"]) == (0, 1, 2, 2) and a["rdzv"] == mode
+    assert a["id_sha256"] == b["id_sha256"] and a["id_bytes"] == 128
+    assert a["qc_first"] != b["qc_first"]
+
+
 def test_communicator_needs_a_gpu_and_says_so():
     """No CPU path: without a device the communicator entry points return an error code and a message."""
     from optas_amd import _lib
@@ -76,6 +174,7 @@ def test_communicator_needs_a_gpu_and_says_so():
     v = C.c_double(1.0)
     assert lib.oh_comm_allreduce_max(C.byref(v)) == _lib.OH_ERR_STATE
     assert lib.oh_comm_barrier() == _lib.OH_ERR_STATE
+    assert lib.oh_comm_info(None, None) == _lib.OH_ERR_STATE
     assert lib.oh_comm_init(2, 2, uid) == _lib.OH_ERR_INVALID
 
 

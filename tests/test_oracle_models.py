@@ -154,3 +154,17 @@ def test_rnea_oracle_physics():
         assert np.abs(g - gn).max() < 1e-6
     with pytest.raises(NotImplementedError):
         rnea(OracleRobot(KUKA_KIN), np.zeros(7), np.zeros(7), np.zeros(7))  # first joint not fixed (models.py:1748)
+
+
+def test_quaternion_batch_equals_the_scalar_chain_walk():
+    """oracle/robot.py:quaternion_batch (the vectorised form the bench-scale GPU tests check every knot with) against the scalar restatement of
+    models.py:1049-1088, on robots with fixed, revolute and prismatic joints."""
+    for kin, link in ((KUKA_KIN, "end_effector_ball"), (MED7_KIN, None), (TESTER_KIN, "eff")):
+        r = OracleRobot(kin)
+        link = link or r.link_names[-1]
+        Q = np.random.default_rng(7).uniform(-2.9, 2.9, (40, r.ndof))
+        qb = r.quaternion_batch(link, Q)
+        assert qb.shape == (40, 4)
+        for i in range(40):
+            assert np.abs(qb[i] - r.get_global_link_quaternion(link, Q[i])).max() <= 1e-15
+    assert np.array_equal(OracleRobot(TESTER_KIN).quaternion_batch("world", np.zeros((2, 3))), np.tile([0.0, 0, 0, 1], (2, 1)))

@@ -842,3 +842,87 @@ class TorqueMPCNLP(_NLPBase):
                 D[r, blk * nb + n * t:blk * nb + n * t + n] = -J[t][:, blk * n:(blk + 1) * n]
             D[r, 3 * nb + n * t:3 * nb + n * t + n] = np.eye(n)
         return D
+
+
+class FastFigureEightNLP(FigureEightNLP):
+    """FigureEightNLP with its callables evaluated for all T knots at once (numpy arrays over the knots instead of a Python loop over the
+    literal per-knot restatement).  Same layout, same rows, same signs; every member is checked against the literal class to 1e-12 at random
+    points (tests/test_ipm_reference_form.py).  It exists so that oracle/ipm_reference_form.py -- hundreds of iterations on the 693-variable
+    problem, each with an exact Lagrangian Hessian -- finishes in a minute instead of an hour; it is not a different formulation."""
+
+    def __init__(self, robot, link, **kw):
+        super().__init__(robot, link, **kw)
+        from .structured import FoldedChain
+
+        self._fc = FoldedChain(robot, link)
+
+    def _kin(self, x):
+        Q, dQ = self.split(x)
+        e, Re, Jp, Jw = self._fc.jac(Q.T)  # (T,3), (T,3,3), (T,3,n), (T,3,n)
+        return Q, dQ, e, Jp, Jw
+
+    def f(self, x, p):
+        Q, dQ = self.split(x)
+        path, _ = self.references(p)
+        e = self._fc.fk(Q.T)[0]
+        return float(self.w_path * np.sum((path.T - e) ** 2) + self.w_vel * np.sum(dQ**2))
+
+    def df(self, x, p):
+        Q, dQ, e, Jp, _ = self._kin(x)
+        path, _ = self.references(p)
+        gq = -2.0 * self.w_path * np.einsum("tkj,tk->jt", Jp, path.T - e)
+        return self.join(gq, 2.0 * self.w_vel * dQ)
+
+    def h(self, x, p):
+        Q, _ = self.split(x)
+        _, quatc = self.references(p)
+        return (quatc.reshape(1, 4) - self.robot.quaternion_batch(self.link, Q.T)).reshape(-1)
+
+    @staticmethod
+    def _left_pure(o, quat):
+        """(o, 0) (x) quat for arrays o (..., 3), quat (..., 4): Hamilton product, xyzw storage (oracle/robot.py:quaternion_jacobian)."""
+        ox, oy, oz = o[..., 0], o[..., 1], o[..., 2]
+        x, y, z, w = quat[..., 0], quat[..., 1], quat[..., 2], quat[..., 3]
+        return np.stack([ox * w + oy * z - oz * y, -ox * z + oy * w + oz * x, ox * y - oy * x + oz * w, -ox * x - oy * y - oz * z], axis=-1)
+
+    def dh(self, x, p):
+        Q, _, _, _, Jw = self._kin(x)
+        quat = self.robot.quaternion_batch(self.link, Q.T)  # (T, 4)
+        dq = 0.5 * self._left_pure(np.moveaxis(Jw, 1, 2), quat[:, None, :])  # (T, n, 4): column j = 1/2 (z_j, 0) (x) quat
+        J = np.zeros((self.nh, self.nx))
+        n = self.n
+        for t in range(self.T):
+            J[4 * t : 4 * t + 4, n * t : n * t + n] = -dq[t].T
+        return J
+
+    def hess_lagrangian(self, x, p, lam_h, gauss_newton=False):
+        Q, dQ, e, Jp, Jw = self._kin(x)
+        path, _ = self.references(p)
+        n, T = self.n, self.T
+        W = 2.0 * self.w_path * np.einsum("tki,tkj->tij", Jp, Jp)
+        if not gauss_newton:
+            r = path.T - e
+            quat = self.robot.quaternion_batch(self.link, Q.T)
+            lam = np.asarray(lam_h, float).reshape(T, 4)
+            zi, zj = Jw[:, :, :, None], Jw[:, :, None, :]  # (T,3,n,1), (T,3,1,n)
+            # d2p/dqi dqj = z_i x Jp_j (i <= j)
+            d2p = np.cross(np.broadcast_to(zi, (T, 3, n, n)), np.broadcast_to(Jp[:, :, None, :], (T, 3, n, n)), axis=1)
+            val = -2.0 * self.w_path * np.einsum("tk,tkij->tij", r, d2p)
+            # d2quat/dqi dqj = 1/2 (z_i x z_j, 0)(x)quat [i < j] + 1/4 (z_j,0)(x)(z_i,0)(x)quat
+            dz = np.cross(np.broadcast_to(zi, (T, 3, n, n)), np.broadcast_to(zj, (T, 3, n, n)), axis=1)  # (T,3,i,j)
+            iu = np.triu(np.ones((n, n)), 1)
+            dz = dz * iu[None, None]
+            qq = quat[:, None, None, :]
+            t1 = 0.5 * self._left_pure(np.moveaxis(dz, 1, -1), qq)  # (T,i,j,4)
+            inner = self._left_pure(np.moveaxis(Jw, 1, 2)[:, :, None, :], qq)  # (z_i,0)(x)quat: (T,i,1,4)
+            t2 = 0.25 * self._left_pure(np.moveaxis(Jw, 1, 2)[:, None, :, :], inner)  # (z_j,0)(x)that: (T,i,j,4)
+            val = val + np.einsum("tc,tijc->tij", lam, -(t1 + t2))
+            up = np.triu(np.ones((n, n)))[None]
+            val = val * up
+            val = val + np.swapaxes(val * np.triu(np.ones((n, n)), 1)[None], 1, 2)
+            W = W + val
+        H = np.zeros((self.nx, self.nx))
+        for t in range(T):
+            H[n * t : n * t + n, n * t : n * t + n] = W[t]
+        H[self.nq :, self.nq :] = 2.0 * self.w_vel * np.eye(self.ndq)
+        return H

@@ -47,7 +47,7 @@ def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B):
     x0, qc = bench.make_inputs(B, 0)
     r = be.solve(x0, qc)
     tm = be.timing()
-    assert tm["step_launches"] > 0 and tm["compactions"] > 0 and tm["tail_iterations"] > 0  # batched kernels, compactions and the tail all ran
+    assert tm["iterations_launched"] > 0 and tm["compactions"] > 0 and tm["tail_iterations"] > 0  # batched kernels, compactions and the tail all ran
     n, T = 7, bench.T
     conv = r.status == 0
     assert conv.mean() >= 0.9999, conv.mean()

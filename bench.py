@@ -52,6 +52,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 #   k_couple : read V_t 18 (V_{t+1} is an L2 hit), q 3x7, g 7, phi 1 ; write E 16, gt 4, merit 1 = 68 doubles
 #   k_step   : read merit 1, cv 1, E 16, Dr 10, gt 4+4 ; write+read gains 20+20 ; write z 4  = 80 doubles
 BYTES = {"k_eval": 103 * 8, "k_couple": 68 * 8, "k_step": 80 * 8}
+# Round 3, coupling folded into evaluation and sweep (oh_get_flag "fuse_couple"; no k_couple launch):
+#   k_eval   : + the two neighbours' retracted knots (2 x 7 read); G instead of g and the merit share instead of phi out (same count) = 117 doubles
+#   k_step   : read merit 1, cv 1, V 18, G 7, Dr 10 ; write+read gains 20+20 ; write+read gt 4+4 ; write z 4 = 89 doubles
+BYTES_ZC = {"k_eval": 117 * 8, "k_couple": 0, "k_step": 89 * 8}
 BYTES_FKJAC = 448  # q 56 B in, pose 56 B + J 336 B out
 
 
@@ -365,7 +369,8 @@ def main():
         lat[nb] = float(np.median(ms[1:]))
         its_nb = d_it.download(np.int32, (B,))[:nb]
         lat[f"iters_{nb}"] = float(its_nb.mean())
-    occupancy = {k: be.kernel_info(k) for k in ("k_retract", "k_evalb", "k_couple", "k_step", "k_tail", "k_fk_jac")}
+    occupancy = {k: be.kernel_info(k) for k in (("k_retract", "k_evalb_zc", "k_step_zc", "k_tail", "k_fk_jac") if be.flag("fuse_couple") else
+                                                ("k_retract", "k_evalb", "k_couple", "k_step", "k_tail", "k_fk_jac"))}
     spec_info = be.specialize_info()
 
     if rank != 0:
@@ -377,11 +382,13 @@ def main():
     # (instance, knot) units the batched kernels actually processed (k_step counts running instances per launch;
     # the persistent tail kernel adds one per iteration per instance, but its time is not in the kernel brackets)
     units = tm["instance_launches"] * (T - 2)
-    kms = {"k_eval": tm["eval_ms"], "k_couple": tm["couple_ms"], "k_step": tm["step_ms"]}
+    zc = bool(be.flag("fuse_couple"))
+    bytes_k = BYTES_ZC if zc else BYTES
+    kms = {"k_eval": tm["eval_ms"], "k_couple": 0.0 if zc else tm["couple_ms"], "k_step": tm["step_ms"] + (tm["couple_ms"] if zc else 0.0)}
     dom = max(kms, key=kms.get)
     launches = max(1, tm["step_launches"])
     per_kernel = {
-        k: {"total_ms": v, "avg_launch_ms": v / launches, "bytes_per_unit": BYTES[k], "achieved_GBps": units * BYTES[k] / (v * 1e-3) / 1e9 if v > 0 else 0.0}
+        k: {"total_ms": v, "avg_launch_ms": v / launches, "bytes_per_unit": bytes_k[k], "achieved_GBps": units * bytes_k[k] / (v * 1e-3) / 1e9 if v > 0 else 0.0}
         for k, v in kms.items()
     }
     achieved = per_kernel[dom]["achieved_GBps"]
@@ -414,7 +421,7 @@ def main():
         "occupancy": occupancy,
         "measured_in": f"a second pass of the same {args.steps} steps with one hipEventRecord after every kernel on the handle's stream ({1e3 * elapsed_profiled / args.steps:.1f} ms per step; the timed pass runs without them)",
         "avg_launch_ms": per_kernel[dom]["avg_launch_ms"],
-        "bytes_per_unit": BYTES[dom],
+        "bytes_per_unit": bytes_k[dom],
         "units_per_launch_avg": units / launches,
         "launches": launches,
         "all_kernels": per_kernel,
@@ -478,6 +485,7 @@ def main():
         "rejected_step_frac": tm["rejected_steps"] / max(1, tm["instance_launches"] + tm["tail_iterations"]),
         "tail_iteration_frac": tm["tail_iterations"] / max(1, tm["instance_launches"] + tm["tail_iterations"]),
         "compactions_per_step": tm["compactions"] / args.steps,
+        "fused_coupling": zc,
     }
     if cpu is not None:
         out["cpu_baseline"] = cpu

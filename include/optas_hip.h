@@ -350,6 +350,11 @@ int oh_set_guards(oh_handle* h, const oh_guards* guards);
 int oh_solve(oh_handle* h, int B, const double* x0, const double* p, double* x, double* f, double* kkt,
              int* iters, int* status);
 
+/* Scheduling facts of a handle by name, for harnesses that report what ran: "fuse_couple" (1: the orientation-locked family's iteration is
+   k_retract + k_evalb_zc + k_step_zc, the neighbour coupling folded in; 0: k_couple runs as a launch of its own), "tail_threshold",
+   "specialized". */
+int oh_get_flag(oh_handle* h, const char* name, int* value);
+
 /* Largest B one oh_solve / oh_solve_device call of this handle takes (*out = 0: the library sets no bound of its own). */
 int oh_max_batch(oh_handle* h, int* out);
 

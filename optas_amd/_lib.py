@@ -206,6 +206,7 @@ SYMBOLS = [
     "oh_comm_destroy",
     "oh_comm_info",
     "oh_max_batch",
+    "oh_get_flag",
     "oh_set_guards",
     "oh_solve",
     "oh_solve_device",

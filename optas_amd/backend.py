@@ -421,6 +421,12 @@ class FigureEightBackend:
     def set_profiling(self, on: bool) -> None:
         _lib.check(_lib.load().oh_set_profiling(self._h, 1 if on else 0), "oh_set_profiling")
 
+    def flag(self, name: str) -> int:
+        """oh_get_flag: 'fuse_couple', 'tail_threshold', 'specialized'."""
+        v = C.c_int(0)
+        _lib.check(_lib.load().oh_get_flag(self._h, name.encode(), C.byref(v)), "oh_get_flag")
+        return v.value
+
     def timing(self) -> dict:
         ch = getattr(self, "_chunked", None)
         if ch is not None:

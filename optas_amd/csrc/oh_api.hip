@@ -122,6 +122,7 @@ struct oh_handle {
   int tail_threshold = 16384;  // hand the last instances to the persistent one-wave-per-instance kernel (round 2: with the kernel compiled for the
                                // chain 8192 against 2048 was +1.3 ... 3 % at B = 262 144 and -21 % on a batch of 4096; with four of its blocks per CU
                                // (two-pass exchange, 40 KB of LDS) 16 384 is level at B = 262 144 and -6 ... 13 % on batches of 16 ... 24 k)
+  int fuse_couple = 1;        // OH_FUSE_COUPLE=0 restores the three-kernel iteration (k_couple between evaluation and sweep) for A/B runs
   int free_pcr_max = 1536;    // position-tracking family: K3 by cyclic reduction, one block per instance, while at most this many are in the launch
   // run-time specialised evaluation kernels of the orientation-locked figure-eight family (oh_jit.hip)
   int specialize = specialize_mode_from_env();  // OH_SPECIALIZE env: 0 never, 1 at the first solve, auto: at the first solve of >= specialize_min_B instances
@@ -228,6 +229,7 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (const char* e4 = getenv("OH_COMPACT_FRAC")) h->compact_frac = h->compact_frac_restart = atof(e4);
   if (const char* e5 = getenv("OH_COMPACT_SORT")) h->compact_sort = atoi(e5);
   if (const char* e6 = getenv("OH_COMPACT_CARRY")) h->compact_carry = atoi(e6);
+  if (const char* e7 = getenv("OH_FUSE_COUPLE")) h->fuse_couple = atoi(e7) != 0;
   hipGetDevice(&h->device);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
       hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->evt0) != hipSuccess ||
@@ -910,13 +912,15 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.chain = h->d_chain;
   for (int s = 0; s < 2; ++s) D.q[s] = take(per_q);
   for (int s = 0; s < 2; ++s) D.q_spare[s] = take(per_q);
-  D.G_spare = take(per_q);
   for (int s = 0; s < 2; ++s) D.Z[s] = take(per_Z);
   for (int s = 0; s < 2; ++s) D.Dr[s] = take(per_Dr);
   for (int s = 0; s < 2; ++s) D.g[s] = take(per_q);
   for (int s = 0; s < 2; ++s) D.phi[s] = take(per_t);
   for (int s = 0; s < 2; ++s) D.cv[s] = take(per_t);
+  // (the sweep with the coupling folded in addresses G of either slot as a 32-bit offset from the lowest of these three: the carried
+  //  compaction swaps Gfull[] with the spare, so the three stay next to each other in the pool)
   for (int s = 0; s < 2; ++s) D.Gfull[s] = take(per_q);
+  D.G_spare = take(per_q);
   for (int s = 0; s < 2; ++s) D.mdl[s] = take((size_t)T * (3 + 3 * NZ) * Bp);
   for (int s = 0; s < 2; ++s) D.E[s] = take((size_t)T * NZ * NZ * Bp);
   for (int s = 0; s < 2; ++s) D.gt[s] = take((size_t)T * NZ * Bp);
@@ -1078,6 +1082,8 @@ static void fill_params(oh_handle* h) {
   P.local_path = h->d_local_path;
   P.np = d.ndof + (h->have_guards ? h->guards.n_links + 4 * h->guards.n_obstacles : 0);
   if (h->chain_host.has_lead) P.np = d.ndof + 1 + d.T;
+  // coupling folded into evaluation and sweep (no k_couple launch): the plain orientation-locked handles, i.e. the batched path of config 2
+  P.zc = (h->fuse_couple && d.lock_orientation && !h->have_guards && !h->chain_host.has_lead && oh_eval_is_split()) ? 1 : 0;
 }
 
 extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt,
@@ -1187,7 +1193,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       // the knots were laid down densely in the spare arrays: they become q[] / Gfull[] for the launches that follow (no copy back)
       std::swap(h->D.q[slot], h->D.q_spare[0]);
       std::swap(h->D.q[1 - slot], h->D.q_spare[1]);
-      if (h->P.hessian != OH_HESSIAN_GAUSS_NEWTON) std::swap(h->D.Gfull[1 - slot], h->D.G_spare);
+      if (h->P.hessian != OH_HESSIAN_GAUSS_NEWTON || h->P.zc) std::swap(h->D.Gfull[1 - slot], h->D.G_spare);
       h->D.B = carry_pending;
       carry_pending = 0;
       ++compactions;
@@ -1197,7 +1203,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     else if (guarded) oh_launch_eval_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else oh_launch_eval_free(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(1); }
-    if (h->P.lock && guarded && h->GP.vel) oh_launch_couple_vel(s, N, h->P, h->D, h->GP, h->GB, slot);
+    if (h->P.zc) {}  // folded into k_evalb_zc / k_step_zc
+    else if (h->P.lock && guarded && h->GP.vel) oh_launch_couple_vel(s, N, h->P, h->D, h->GP, h->GB, slot);
     else if (h->P.lock) oh_launch_couple(s, N, h->P, h->D, slot);
     else oh_launch_couple_free(s, N, h->P, h->D, slot);
     const bool check = ((it + 1) % check_every == 0);
@@ -1850,6 +1857,20 @@ extern "C" int oh_specialize_info(oh_handle* h, double* info4) {
   info4[3] = ((h->spec && h->spec->from_disk) || (!h->spec && h->fk_spec && h->fk_spec->from_disk)) ? 1.0 : 0.0;
   return OH_OK;
 }
+// How the handle's last solve was (or its next one will be) scheduled, by name: "fuse_couple" (1: coupling folded into evaluation and sweep, no
+// k_couple launch), "tail_threshold", "specialized".
+extern "C" int oh_get_flag(oh_handle* h, const char* name, int* value) {
+  if (!h || !name || !value) return fail(OH_ERR_INVALID, "oh_get_flag: null argument");
+  const std::string n(name);
+  if (n == "fuse_couple") {
+    fill_params(h);
+    *value = h->P.zc;
+  } else if (n == "tail_threshold") *value = h->tail_threshold;
+  else if (n == "specialized") *value = h->spec ? 1 : 0;
+  else return fail(OH_ERR_INVALID, "oh_get_flag: unknown flag " + n);
+  return OH_OK;
+}
+
 extern "C" int oh_kernel_info(const char* kernel, int* out5);
 extern "C" int oh_kernel_info_handle(oh_handle* h, const char* kernel, int* out5) {
   if (!h || !kernel || !out5) return fail(OH_ERR_INVALID, "oh_kernel_info_handle: null argument");

@@ -11,9 +11,21 @@ template <int N>
 __device__ void retract_block(const FigParams& P, const FigBuffers& D, const int slot) {
   eval_unit<N, false, false, EVAL_RETRACT_ONLY>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
 }
-template <int N>
+template <int N, bool ZC = false>
 __device__ void evalb_block(const FigParams& P, const FigBuffers& D, const int slot) {
-  eval_unit<N, false, false, EVAL_ONLY>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+  if constexpr (ZC) {
+    // no k_couple in the stream any more to reset the counter the sweep adds its survivors to
+    if (blockIdx.x == 0 && threadIdx.x == 0) *D.n_running = 0;
+    // XCD-aware 1-D grid (k_couple's): workgroup w runs on XCD w % 8, and knot t of an instance block reads the knots t - 1 and t + 1 of the
+    // same block.  Consecutive workgroups of one XCD walk the knots of ONE instance block -- w -> (chunk, r), XCD = r % 8 owns instance block
+    // chunk * 8 + XCD, knot = r / 8 -- so each knot row comes out of HBM once and is served to its two neighbours by that XCD's L2.
+    const int Tn = P.T - P.t0;
+    const int w = blockIdx.x;
+    const int chunk = w / (8 * Tn), r = w - chunk * 8 * Tn;
+    eval_unit<N, false, false, EVAL_ONLY, true>(P, D, slot, (chunk * 8 + (r & 7)) * blockDim.x + threadIdx.x, (r >> 3) + P.t0);
+  } else {
+    eval_unit<N, false, false, EVAL_ONLY, false>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -347,6 +359,7 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
     for (int j = 0; j < N; ++j) {
       D.q[slot][IDX(t, N, j)] = q_c[j];
       D.g[slot][IDX(t, N, j)] = sm[O_G + j][lane];
+      if (P.zc) D.Gfull[slot][IDX(t, N, j)] = sm[O_GF + j][lane];  // where such a handle's k_finalize looks for the Lagrangian gradient
     }
   }
   if (lane == 0) {

@@ -107,9 +107,14 @@ OH_DEV void load_householder(const double* __restrict__ Vs, const int Bp, const 
 // K2: one lane per (instance b, free knot t): trial knot, retraction onto R(q_t)=Rc, FK chain + Jacobians,
 // tracking cost / gradient / Hessian block, null-space basis of the orientation rows, reduced block
 // (eval_knot in oh_figure8.h).
-template <int N, bool GUARD = false, bool LEAD = false, int MODE = EVAL_FUSED>
+// ZC (EVAL_ONLY only; "coupling folded in", round 3): the lane also forms what k_couple used to add in a launch of its own and that needs no
+// null-space basis of a neighbour -- the Lagrangian gradient G_t = g_t + 2 kappa (2 q_t - q_{t-1} - q_{t+1}) and the merit share phi_t + kappa
+// ||q_t - q_{t-1}||^2, from the neighbours' retracted knots (in HBM since k_retract) -- and stores G where it stored g, the merit where it
+// stored phi: same bytes out, 2N doubles more in, and the sweep (step_instance_zc) rebuilds E_t and gt_t from V and G on the fly.
+template <int N, bool GUARD = false, bool LEAD = false, int MODE = EVAL_FUSED, bool ZC = false>
 OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, const int b, const int t, const GuardParams* GPp = nullptr,
                       const GuardBuffers* GBp = nullptr) {
+  static_assert(!ZC || (MODE == EVAL_ONLY && !GUARD && !LEAD), "the folded coupling belongs to the plain batched evaluation");
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
   const int Bp = D.Bp;
@@ -215,6 +220,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   for (int k = 0; k < N; ++k) Gprev[k] = 0.0;  // fetched by the hook below, inside the exact-curvature branch
 
   double phi, cv, g[N], Dr[NP], Z[N][NZ];
+  double sm_zc = 0.0;  // ||q_t - q_{t-1}||^2 (ZC)
   struct Hooks {
     double* __restrict__ qo;
     double* __restrict__ go;
@@ -228,7 +234,20 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
       }
     }
     OH_DEV void g_final(const double (&gv)[N]) const {
-      if constexpr (!GUARD) {  // the guard rows still add to g
+      if constexpr (ZC) {
+        // couple_knot's G and merit share, operation for operation (qs: this launch's knots, q_{t-1} of a fixed knot included)
+        double sm = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const double q0 = qr[k];
+          const double dm = q0 - qs[IDX(t - 1, N, k)];
+          sm += dm * dm;
+          double Gk = gv[k] + kap2 * dm;
+          if (!last) Gk -= kap2 * (qs[IDX(t + 1, N, k)] - q0);
+          Go[IDX(t, N, k)] = Gk;
+        }
+        *smo = sm;
+      } else if constexpr (!GUARD) {  // the guard rows still add to g
 #pragma unroll
         for (int k = 0; k < N; ++k) go[IDX(t, N, k)] = gv[k];
       }
@@ -244,8 +263,15 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
 #pragma unroll
       for (int k = 0; k < N; ++k) G[k] = PRE_G ? Gp[k] : Gc[IDX(t, N, k)];
     }
+    // ZC
+    const double* __restrict__ qs;
+    const double* qr;  // this knot, in registers
+    double* __restrict__ Go;
+    double* smo;
+    double kap2;
+    bool last;
   };
-  const Hooks hooks{D.q[slot], D.g[slot], D.Z[slot], D.Gfull[cur], Bp, b, t, Gpre};
+  const Hooks hooks{D.q[slot], D.g[slot], D.Z[slot], D.Gfull[cur], Bp, b, t, Gpre, D.q[slot], q, D.Gfull[slot], &sm_zc, 2.0 * P.kappa, t == P.T - 1};
   double e_new[3], JZ_new[3][NZ];
   const double tol_r = retract_tol(P, !first, pred_b, stat_b);
   if constexpr (LEAD)
@@ -346,7 +372,8 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
 #pragma unroll
     for (int k = 0; k < N; ++k) D.g[slot][IDX(t, N, k)] = g[k];
   }
-  D.phi[slot][(size_t)t * Bp + b] = phi;
+  if constexpr (ZC) D.merit[slot][(size_t)t * Bp + b] = phi + P.kappa * sm_zc;
+  else D.phi[slot][(size_t)t * Bp + b] = phi;
   D.cv[slot][(size_t)t * Bp + b] = cv;
 #pragma unroll
   for (int i = 0; i < NP; ++i) D.Dr[slot][IDX(t, NP, i)] = Dr[i];
@@ -497,22 +524,16 @@ OH_DEV void couple_unit(const FigParams& P, const FigBuffers& D, const int slot,
 #ifndef OH_STEP_PREFETCH_FWD
 #define OH_STEP_PREFETCH_FWD 1
 #endif
-// K3: one lane per instance: accept/reject the trial point (Levenberg-Marquardt ratio test on the
-// objective; iterates are feasible by retraction), then the backward Riccati sweep over the reduced
-// block-tridiagonal system (blocks prepared by k_eval/k_couple, next knot's blocks prefetched while the
-// current knot factorises) and the forward recursion for the reduced step z_t.  Returns "still running".
+// The acceptance phase of K3 (shared by step_instance and step_instance_zc): Levenberg-Marquardt ratio test of the trial slot against the
+// accepted point, restart / polish / line-search bookkeeping.  Returns 0: the instance has finished (status set), 1: it goes on without a
+// sweep (restart, polish, shorter trial along the rejected step), 2: sweep on the slot `cur` with damping lm.mu.
 template <int N, bool GUARD = false>
-OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, const int ts, const GuardBuffers* GBp = nullptr) {
+OH_DEV int step_head(const FigParams& P, const FigBuffers& D, const int b, const int ts, const GuardBuffers* GBp, int& cur, LMState& lm, const int iters) {
   constexpr int NZ = N - 3;
-  constexpr int NP = NZ * (NZ + 1) / 2;
   const int Bp = D.Bp;
   const int T = P.T;
   const unsigned lb = (unsigned)b * 8u;      // this lane's byte offset inside a row
   const unsigned rowB = (unsigned)Bp * 8u;  // bytes per row
-  const double kap2 = 2.0 * P.kappa;
-  int cur = 1 - ts;  // uniform-slot invariant (see k_eval): the accepted point is in the other slot
-  LMState lm{D.mu[b], D.nun[b]};
-  const int iters = D.iters[b];
   bool polish_request = false;
   bool line_search = false;
 
@@ -535,7 +556,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
         D.cur[b] = ts;
         D.f_cur[b] = f;
         D.stat[b] = f;
-        return false;
+        return 0;
       }
       accept = true;
       D.first[b] = 0;
@@ -581,7 +602,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       D.nun[b] = lm.nun;
       D.cur[b] = cur;
       oh_count(D.work + 1);
-      return true;
+      return 1;
     }
     if (accept) {
       D.stale[b] = 0;
@@ -604,7 +625,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     if (line_search) {  // the rejected step again, shorter: no sweep, the damping untouched
       if (iters >= P.max_iter) {
         D.status[b] = OH_STATUS_MAX_ITER;
-        return false;
+        return 0;
       }
       for (int t = P.t0; t < T; ++t) {
 #pragma unroll
@@ -616,7 +637,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
       for (int i = 0; i < k; ++i) sk *= OH_LS_SHRINK;
       D.pred[b] = -sk * GBp->ls_gd[b] + 0.5 * sk * sk * GBp->ls_q[b];
       D.iters[b] = iters + 1;
-      return true;
+      return 1;
     }
   }
   if (polish_request) {
@@ -627,7 +648,30 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
     D.pred[b] = 0.0;
     D.polish[b] = 1;
     D.iters[b] = iters + 1;
-    return iters < P.max_iter + 40 ? true : (D.status[b] = OH_STATUS_MAX_ITER, false);
+    return iters < P.max_iter + 40 ? 1 : (D.status[b] = OH_STATUS_MAX_ITER, 0);
+  }
+  return 2;
+}
+
+// K3: one lane per instance: accept/reject the trial point (Levenberg-Marquardt ratio test on the
+// objective; iterates are feasible by retraction), then the backward Riccati sweep over the reduced
+// block-tridiagonal system (blocks prepared by k_eval/k_couple, next knot's blocks prefetched while the
+// current knot factorises) and the forward recursion for the reduced step z_t.  Returns "still running".
+template <int N, bool GUARD = false>
+OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, const int ts, const GuardBuffers* GBp = nullptr) {
+  constexpr int NZ = N - 3;
+  constexpr int NP = NZ * (NZ + 1) / 2;
+  const int Bp = D.Bp;
+  const int T = P.T;
+  const unsigned lb = (unsigned)b * 8u;      // this lane's byte offset inside a row
+  const unsigned rowB = (unsigned)Bp * 8u;  // bytes per row
+  const double kap2 = 2.0 * P.kappa;
+  int cur = 1 - ts;  // uniform-slot invariant (see k_eval): the accepted point is in the other slot
+  LMState lm{D.mu[b], D.nun[b]};
+  const int iters = D.iters[b];
+  {
+    const int go = step_head<N, GUARD>(P, D, b, ts, GBp, cur, lm, iters);
+    if (go != 2) return go == 1;
   }
   double mu = lm.mu;
 
@@ -831,6 +875,199 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
 }
 
 
+// K3 with the coupling folded in (round 3; plain orientation-locked handles).  k_couple wrote E_t = -2 kappa Z_t^T Z_{t+1}, gt_t = Z_t^T G_t
+// and the merit share of every knot (21 doubles per unit) for this kernel to read back one launch later, and read 47 doubles per unit to do
+// so.  Here the sweep rebuilds Z_t from its Householder vectors (the 18 doubles k_couple read too), keeps Z_{t+1} in a lane-private column
+// of LDS (zl: [N * NZ][64], one 8-byte word per lane and row -> conflict-free) and forms E_t and gt_t with couple_knot's own loop, in its
+// operation order: the iterates are those of the three-kernel path.  G_t and the merit share come from the evaluation (eval_unit<.., ZC>).
+// Per knot the backward pass reads V 18, G 7, Dr 10 (35 doubles; E 16, Dr 10, gt 4 before) and writes gt for the forward pass.
+template <int N>
+OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int b, const int ts, double* __restrict__ zl) {
+  constexpr int NZ = N - 3;
+  constexpr int NP = NZ * (NZ + 1) / 2;
+  constexpr int NV = HV_ROWS(N);
+  const int Bp = D.Bp;
+  const int T = P.T;
+  const unsigned lb = (unsigned)b * 8u;
+  const unsigned rowB = (unsigned)Bp * 8u;
+  const double kap2 = 2.0 * P.kappa;
+  int cur = 1 - ts;
+  LMState lm{D.mu[b], D.nun[b]};
+  const int iters = D.iters[b];
+  {
+    const int go = step_head<N, false>(P, D, b, ts, nullptr, cur, lm, iters);
+    if (go != 2) return go == 1;
+  }
+  double mu = lm.mu;
+  const double* __restrict__ Vc = D.Z[0];
+  // (Gfull[] trades places with the compaction's spare array: the lower of the two slots is the base, see ensure_capacity)
+  const double* __restrict__ Gc = D.Gfull[0] < D.Gfull[1] ? D.Gfull[0] : D.Gfull[1];
+  const double* __restrict__ Drc = D.Dr[0];
+  double* __restrict__ gtc = D.gt[0];
+  const unsigned oV = lb + (cur ? (unsigned)((const char*)D.Z[1] - (const char*)D.Z[0]) : 0u);
+  const unsigned oGf = lb + (unsigned)((const char*)D.Gfull[cur] - (const char*)Gc);
+  const unsigned oD = lb + (cur ? (unsigned)((const char*)D.Dr[1] - (const char*)D.Dr[0]) : 0u);
+  const unsigned oG = lb + (cur ? (unsigned)((const char*)D.gt[1] - (const char*)D.gt[0]) : 0u);
+  double stat = 0.0;
+  double S[NP], rd[NZ], rn[NZ];
+  bool factored = false;
+  // one knot's inputs, requested a knot ahead of their use
+  double nV[NV], nG[N], nH[NP];
+  auto fetch = [&](const int t) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) nV[i] = rb_ld(KNOT(Vc, t, NV), RB(i), oV);
+#pragma unroll
+    for (int k = 0; k < N; ++k) nG[k] = rb_ld(KNOT(Gc, t, N), RB(k), oGf);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) nH[i] = rb_ld(KNOT(Drc, t, NP), RB(i), oD);
+  };
+  // Z of the knot in the buffers (z_from_householder on the packed vectors), its reduced gradient, and -- against the Z of knot t + 1 parked
+  // in LDS -- E_t; Z_t then takes that place
+  auto knot_blocks = [&](const bool last, double (&E)[NZ * NZ], double (&gt)[NZ]) {
+    double V[3][N], Zt[N][NZ];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int k = 0; k < N; ++k) V[m][k] = (k < m) ? 0.0 : nV[HV_OFF(N, m) + k - m];
+    z_from_householder<N>(V, Zt);
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) {
+      gt[a] = 0.0;
+#pragma unroll
+      for (int c2 = 0; c2 < NZ; ++c2) E[a * NZ + c2] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const double Gk = nG[k];
+      double Zn[NZ];
+      if (!last) {
+#pragma unroll
+        for (int c2 = 0; c2 < NZ; ++c2) Zn[c2] = zl[(k * NZ + c2) * 64];
+      }
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) {
+        gt[a] += Zt[k][a] * Gk;
+        if (!last) {
+#pragma unroll
+          for (int c2 = 0; c2 < NZ; ++c2) E[a * NZ + c2] -= kap2 * Zt[k][a] * Zn[c2];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) zl[(k * NZ + a) * 64] = Zt[k][a];
+    }
+  };
+  for (int attempt = 0; attempt < 40; ++attempt) {
+    bool ok = true;
+    stat = 0.0;
+    fetch(T - 1);
+    {
+      double E[NZ * NZ], gt[NZ];
+      knot_blocks(true, E, gt);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) S[i] = nH[i];
+      if (T - 2 >= P.t0) fetch(T - 2);
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) {
+        S[tri(a, a)] += kap2 + mu;
+        rn[a] = gt[a];
+        stat = fmax(stat, fabs(gt[a]));
+        rb_st(KNOT(gtc, T - 1, NZ), RB(a), oG, gt[a]);
+      }
+    }
+    for (int t = T - 2; t >= P.t0; --t) {
+      double E[NZ * NZ], Ht[NP], gt[NZ];
+      knot_blocks(false, E, gt);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Ht[i] = nH[i];
+      if (t - 1 >= P.t0) fetch(t - 1);  // issued before the dependent arithmetic of this knot
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) {
+        stat = fmax(stat, fabs(gt[a]));
+        Ht[tri(a, a)] += 2.0 * kap2 + mu;
+        rb_st(KNOT(gtc, t, NZ), RB(a), oG, gt[a]);
+      }
+      double Kmat[NZ * NZ], kv[NZ];
+      ok = riccati_back<NZ>(S, rd, rn, E, Ht, gt, Kmat, kv) && ok;
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) rb_st(KNOT(D.kvec, t + 1, NZ), RB(a), lb, kv[a]);
+#pragma unroll
+      for (int i = 0; i < NZ * NZ; ++i) rb_st(KNOT(D.Kmat, t + 1, NZ * NZ), RB(i), lb, Kmat[i]);
+    }
+    ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
+    if (ok) {
+      factored = true;
+      break;
+    }
+    mu = fmax(4.0 * mu, 1e-2);
+  }
+  D.stat[b] = stat;
+  if (!(stat == stat) || !factored) {
+    D.status[b] = OH_STATUS_NUMERICAL;
+    D.mu[b] = mu;
+    return false;
+  }
+  if (stat <= P.tol && D.feas[b] <= P.tol_feas) {
+    D.status[b] = OH_STATUS_CONVERGED;
+    D.mu[b] = mu;
+    return false;
+  }
+  if (iters >= P.max_iter) {
+    D.status[b] = OH_STATUS_MAX_ITER;
+    D.mu[b] = mu;
+    return false;
+  }
+  // ---- forward recursion (as step_instance): z_2 = -S_2^{-1} r_2, z_{t+1} = -(kvec + Kmat z_t) ----
+  {
+    double zz[NZ];
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) zz[a] = -rn[a];
+    fsub_rcp<NZ>(S, rd, zz);
+    bsub_rcp<NZ>(S, rd, zz);
+    double gd = 0.0, z2 = 0.0;
+    const double alpha = (P.hessian == OH_HESSIAN_HYBRID && stat > P.hyb_switch && iters >= P.relax_from) ? P.relax : 1.0;
+    double fK[NZ * NZ], fk[NZ], fg[NZ];
+    auto fetchf = [&](const int t) {
+      if (t > P.t0) {
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) fk[a] = rb_ld(KNOT(D.kvec, t, NZ), RB(a), lb);
+#pragma unroll
+        for (int i = 0; i < NZ * NZ; ++i) fK[i] = rb_ld(KNOT(D.Kmat, t, NZ * NZ), RB(i), lb);
+      }
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) fg[a] = rb_ld(KNOT(gtc, t, NZ), RB(a), oG);
+    };
+    fetchf(P.t0);
+    for (int t = P.t0; t < T; ++t) {
+      double gtt[NZ];
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) gtt[a] = fg[a];
+      if (t > P.t0) {
+        double zn[NZ];
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) {
+          double sacc = fk[a];
+#pragma unroll
+          for (int c2 = 0; c2 < NZ; ++c2) sacc += fK[a * NZ + c2] * zz[c2];
+          zn[a] = -sacc;
+        }
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) zz[a] = zn[a];
+      }
+      if (t + 1 < T) fetchf(t + 1);
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) {
+        rb_st(KNOT(D.zstep, t, NZ), RB(a), lb, alpha * zz[a]);
+        gd += gtt[a] * zz[a];
+        z2 += zz[a] * zz[a];
+      }
+    }
+    D.pred[b] = -alpha * gd + 0.5 * alpha * alpha * (gd + mu * z2);
+  }
+  D.mu[b] = mu;
+  D.iters[b] = iters + 1;
+  return true;
+}
+
 
 // Least-squares multipliers of knot t at the point in slot `cur`, mapped to the reference's rows
 // h = quat_c - quat(q_t) (figure_eight_plan.py:105-107): stationarity reads G_t + Jc^T mu = 0 with
@@ -851,8 +1088,12 @@ OH_DEV void knot_multipliers(const FigParams& P, const FigBuffers& D, const int 
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     q[k] = qs[IDX(t, N, k)];
-    G[k] = D.g[cur][IDX(t, N, k)] + kap2 * (q[k] - qs[IDX(t - 1, N, k)]);
-    if (!last) G[k] -= kap2 * (qs[IDX(t + 1, N, k)] - q[k]);
+    if (P.zc) {  // the evaluation stored the Lagrangian gradient itself (eval_unit<.., ZC>)
+      G[k] = D.Gfull[cur][IDX(t, N, k)];
+    } else {
+      G[k] = D.g[cur][IDX(t, N, k)] + kap2 * (q[k] - qs[IDX(t - 1, N, k)]);
+      if (!last) G[k] -= kap2 * (qs[IDX(t + 1, N, k)] - q[k]);
+    }
   }
   double R[9], p[3], z[N][3], pj[N][3];
   if (ch->has_lead) {

@@ -7,7 +7,7 @@
 
 struct FigSpec {
   hipModule_t mod = nullptr;
-  hipFunction_t retract = nullptr, evalb = nullptr, tail = nullptr;
+  hipFunction_t retract = nullptr, evalb = nullptr, evalb_zc = nullptr, tail = nullptr;
   int n = 0;               // chain length the kernels were instantiated for
   bool from_disk = false;  // code object came from the disk cache
   double seconds = 0.0;    // wall time of source generation + compilation (or cache read) + module load

@@ -141,6 +141,9 @@ template <int N>
 __global__ __launch_bounds__(256, 2) void k_retract(FigParams P, FigBuffers D, const int slot) { retract_block<N>(P, D, slot); }
 template <int N>
 __global__ __launch_bounds__(256, 2) void k_evalb(FigParams P, FigBuffers D, const int slot) { evalb_block<N>(P, D, slot); }
+// ... with the neighbour coupling of the Lagrangian gradient and of the merit folded in (eval_unit<.., ZC>): no k_couple launch follows
+template <int N>
+__global__ __launch_bounds__(256, 2) void k_evalb_zc(FigParams P, FigBuffers D, const int slot) { evalb_block<N, true>(P, D, slot); }
 // chains with a parameterised lead joint (RobotModel(param_joints=[first joint]), figure_eight_plan_6dof.py): same evaluation
 // from the frame that follows the lead joint at the knot's parameter angle
 template <int N>
@@ -230,6 +233,28 @@ __global__ __launch_bounds__(64, OH_STEP_WAVES) void k_step(FigParams P, FigBuff
   bool still = skipping;
   if (skipping) D.skip[b] = 0;
   if (running) still = step_instance<N>(P, D, b, slot);
+  const unsigned long long m2 = __ballot(still);
+  if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
+}
+
+// K3 with the coupling folded in (step_instance_zc): Z_{t+1} of every lane in a private column of LDS
+#ifndef OH_STEP_ZC_WAVES
+#define OH_STEP_ZC_WAVES 1
+#endif
+template <int N>
+__global__ __launch_bounds__(64, OH_STEP_ZC_WAVES) void k_step_zc(FigParams P, FigBuffers D, const int slot) {
+  __shared__ double zl[N * (N - 3)][64];
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool alive = (b < D.B) && (D.status[b] < 0);
+  const bool skipping = alive && D.skip[b];
+  const bool running = alive && !skipping;
+  {
+    const unsigned long long m = __ballot(running);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(D.work, (unsigned long long)__popcll(m));
+  }
+  bool still = skipping;
+  if (skipping) D.skip[b] = 0;
+  if (running) still = step_instance_zc<N>(P, D, b, slot, &zl[0][threadIdx.x]);
   const unsigned long long m2 = __ballot(still);
   if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
 }
@@ -353,7 +378,7 @@ __global__ __launch_bounds__(256) void k_compact_gather(FigParams P, FigBuffers 
   double* __restrict__ ts = D.Dr[1];
 #pragma unroll
   for (int j = 0; j < N; ++j) tq[((size_t)t * N + j) * Bp + nb] = qs[IDX(t, N, j)];
-  if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) {
+  if (P.hessian != OH_HESSIAN_GAUSS_NEWTON || P.zc) {
 #pragma unroll
     for (int j = 0; j < N; ++j) D.g[1][((size_t)t * N + j) * Bp + nb] = D.Gfull[D.cur[b]][IDX(t, N, j)];
   }
@@ -382,7 +407,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
     const double v = tq[IDX(t, N, j)];
     D.q[slot][IDX(t, N, j)] = v;
     if (t < P.t0) D.q[1 - slot][IDX(t, N, j)] = v;
-    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) D.Gfull[1 - slot][IDX(t, N, j)] = D.g[1][IDX(t, N, j)];
+    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON || P.zc) D.Gfull[1 - slot][IDX(t, N, j)] = D.g[1][IDX(t, N, j)];
   }
   if (t == 0) {
 #pragma unroll
@@ -427,7 +452,7 @@ __global__ __launch_bounds__(256) void k_carry_gather(FigParams P, FigBuffers D,
   for (int j = 0; j < N; ++j) {
     t_trial[((size_t)t * N + j) * Bp + nb] = D.q[slot][IDX(t, N, j)];
     t_cur[((size_t)t * N + j) * Bp + nb] = D.q[cur][IDX(t, N, j)];
-    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) t_G[((size_t)t * N + j) * Bp + nb] = D.Gfull[cur][IDX(t, N, j)];
+    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON || P.zc) t_G[((size_t)t * N + j) * Bp + nb] = D.Gfull[cur][IDX(t, N, j)];
   }
   if (t == 0) {
 #pragma unroll
@@ -506,7 +531,10 @@ static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D
 #else
   const dim3 ge((D.B + 255) / 256, P.T - P.t0);
   if (part != 2) hipLaunchKernelGGL(k_retract<N>, ge, dim3(256), 0, s, P, D, slot);
-  if (part != 1) hipLaunchKernelGGL(k_evalb<N>, ge, dim3(256), 0, s, P, D, slot);
+  if (part != 1) {
+    if (P.zc) hipLaunchKernelGGL(k_evalb_zc<N>, dim3((((D.B + 255) / 256) + 7) / 8 * 8 * (P.T - P.t0)), dim3(256), 0, s, P, D, slot);
+    else hipLaunchKernelGGL(k_evalb<N>, ge, dim3(256), 0, s, P, D, slot);
+  }
 #endif
 }
 template <int N>
@@ -521,7 +549,8 @@ static void launch_couple_t(hipStream_t s, const FigParams& P, const FigBuffers&
 }
 template <int N>
 static void launch_step_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
-  hipLaunchKernelGGL(k_step<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, slot);
+  if (P.zc) hipLaunchKernelGGL(k_step_zc<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, slot);
+  else hipLaunchKernelGGL(k_step<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, slot);
 }
 template <int N>
 static void launch_tail_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
@@ -641,6 +670,8 @@ bool oh_kernel_info_figure8(const char* name, OhKernelInfo* out) {
   if (n == "k_evalb") return kernel_info(k_evalb<7>, 256, out);
   if (n == "k_couple") return kernel_info(k_couple<7>, 256, out);
   if (n == "k_step") return kernel_info(k_step<7>, 64, out);
+  if (n == "k_step_zc") return kernel_info(k_step_zc<7>, 64, out);
+  if (n == "k_evalb_zc") return kernel_info(k_evalb_zc<7>, 256, out);
   if (n == "k_tail") return kernel_info(k_tail<7>, 64, out);
   return false;
 }

@@ -26,6 +26,7 @@ struct FigParams {
   int relax_from;    // ... from this step count on
   const double* local_path;  // device, [T][3]
   int np;            // row stride of the parameter matrix p (ndof, or ndof + guard parameters)
+  int zc;            // 1: coupling folded into evaluation and sweep (eval_unit<.., ZC>, step_instance_zc): Gfull[] holds G of every evaluated point
 };
 
 // Inequality rows of the position-tracking family (oh_guards): constants and per-instance state.

@@ -128,12 +128,14 @@ def _amax(a):
     return float(np.abs(a).max()) if a.size else 0.0
 
 
-def solve_ipm(nlp, x0, p, tol=1e-8, max_iter=3000, mu0=0.1, scaling=True, verbose=False, acceptable_tol=1e-6, acceptable_iter=15):
+def solve_ipm(nlp, x0, p, tol=1e-8, max_iter=3000, mu0=0.1, scaling=True, verbose=False, acceptable_tol=1e-6, acceptable_iter=15, relax=1e-8):
     """Interior-point filter line search [WB] on the reference form.  Returns dict(x, f, iters, status, E0, lam_v (multipliers of v >= 0 in the
-    reference's sign: lam >= 0 on active lower bounds), history)."""
+    reference's sign: lam >= 0 on active lower bounds), history).  `relax` is IPOPT's bound_relax_factor (default 1e-8): every row of v may end
+    up to `relax` below zero, so an equality pair (e, -e) holds to |e| <= relax and the objective sits up to sum|lam| relax below the exact
+    optimum; tests that compare with exactly feasible optima either polish the point (oracle.solvers.dense_sqp) or tighten `relax`."""
     attach_hessian(nlp)
     x = np.asarray(x0, float).copy()
-    P = SlackForm(nlp, p, x, scaling=scaling)
+    P = SlackForm(nlp, p, x, scaling=scaling, relax=relax)
     n, m = P.nx, P.m
     sL, sU = P.sL, P.sU
     # --- starting point [3.6] ---------------------------------------------------------------------------------------------
@@ -156,7 +158,7 @@ def solve_ipm(nlp, x0, p, tol=1e-8, max_iter=3000, mu0=0.1, scaling=True, verbos
     th_min, th_max = 1e-4 * max(1.0, theta0), 1e4 * max(1.0, theta0)
     filt = [(th_max, -np.inf)]  # entries (theta_j, phi_j): a trial is refused if theta >= theta_j and phi >= phi_j
     dw_last = 0.0
-    hist, n_acc, status = [], 0, "max_iter"
+    hist, n_acc, n_tiny, status = [], 0, 0, "max_iter"
 
     def barrier(xv, sv, fv=None):
         dl, du = sv - sL, sU - sv
@@ -246,12 +248,33 @@ def solve_ipm(nlp, x0, p, tol=1e-8, max_iter=3000, mu0=0.1, scaling=True, verbos
             if any(th_t >= tj and ph_t >= pj for tj, pj in filt):
                 return False, False
             switch = dphi < 0 and a * (-dphi) ** s_ph > dlt * theta**s_th and theta <= th_min
-            if switch:
-                return ph_t <= phi + eta * a * dphi, True
-            return (th_t <= (1 - g_th) * theta) or (ph_t <= phi - g_ph * theta), False
+            slack_ = 10.0 * np.finfo(float).eps * abs(phi)  # IPOPT compares barrier values up to 10 eps |phi| (Compare_le): near a solution
+            if switch:                                       # the predicted decrease is below the rounding of phi itself
+                return ph_t - phi <= eta * a * dphi + slack_, True
+            return (th_t <= (1 - g_th) * theta) or (ph_t - phi <= -g_ph * theta + slack_), False
 
         a, accepted, ftype = a_max, False, False
         first = True
+        # very small search directions [3.9]: a step below 10 eps relative is taken without a line search (the filter cannot tell the trial from
+        # the current point); the second such step in a row means this barrier problem is solved as far as the arithmetic allows: next mu
+        tiny = max(_amax(dx / (1.0 + np.abs(x))), _amax(ds / (1.0 + np.abs(s)))) < 10.0 * np.finfo(float).eps
+        if tiny:
+            x, s = x + a_max * dx, s + a_max * ds
+            c = P.v(x) - s
+            lam = lam + a_max * dlam
+            zL, zU = zL + a_z * dzL, zU + a_z * dzU
+            n_tiny += 1
+            if n_tiny >= 2 and mu > tol / 10.0:
+                mu = max(tol / 10.0, min(k_mu * mu, mu**th_mu))
+                tau = max(0.99, 1.0 - mu)
+                filt = [(th_max, -np.inf)]
+                n_tiny = 0
+            g, J = P.df(x), P.dv(x)
+            dl, du = s - sL, sU - s
+            zL = np.maximum(np.minimum(zL, k_sig * mu / dl), mu / (k_sig * dl))
+            zU = np.maximum(np.minimum(zU, k_sig * mu / du), mu / (k_sig * du))
+            continue
+        n_tiny = 0
         while a >= a_min:
             xt, st = x + a * dx, s + a * ds
             ct = P.v(xt) - st
@@ -284,7 +307,7 @@ def solve_ipm(nlp, x0, p, tol=1e-8, max_iter=3000, mu0=0.1, scaling=True, verbos
             first = False
             a *= 0.5
         if accepted:
-            if not ftype or not (ph_t <= phi + eta * a * dphi):  # augment the filter unless an f-type step with Armijo decrease [(22)]
+            if not ftype or not (ph_t - phi <= eta * a * dphi + 10.0 * np.finfo(float).eps * abs(phi)):  # augment the filter unless an f-type step with Armijo decrease [(22)]
                 filt.append(((1 - g_th) * theta, phi - g_ph * theta))
             x, s, c = xt, st, ct
             lam = lam + a * dlam

@@ -1,0 +1,109 @@
+"""oracle/ipm_reference_form.py -- the reference's algorithm class (IPOPT: primal-dual interior point, filter line search) on the reference's
+problem form (min f s.t. 0 <= v <= 1e10, equalities as (e, -e) pairs), from the reference's seeds.  Pins:
+  * the reference's only numeric solver assertion (Booth -> (1, 3), tests/test_solver.py:46-54), with and without its dummy bound rows
+  * config 1 (example.py) and config 3 (point_mass_mpc.py) answers the SLSQP-wired goldens hold (tools/make_golden.py), reached here by a
+    different algorithm: to the bound relaxation at IPOPT's default (1e-8 per row), to 1e-9 with the relaxation tightened
+  * config 2 at T = 5: the dense-SQP golden, from the seed
+  * the vectorised figure-eight NLP the T = 50 runs use = the literal per-knot restatement, member by member
+The T = 50 runs themselves (24 instances, ~10 minutes) are stored in tests/golden/nlp_ipm_golden.npz (tools/make_golden.py --ipm) and compared
+with the GPU in tests/test_gpu_ipm_parity.py."""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN, KUKA_KIN
+from oracle.ipm_reference_form import solve_ipm
+from oracle.problems import BoothNLP, FastFigureEightNLP, FigureEightNLP, IKExampleNLP, PointMassMPCNLP
+from oracle.robot import OracleRobot
+from oracle.solvers import dense_sqp, kkt_reference_form
+
+LINK = "end_effector_ball"
+
+
+def test_booth_known_answer():
+    r = solve_ipm(BoothNLP(), np.zeros(2), np.array([2.0, 7.0]))
+    assert r["status"] == "optimal" and np.abs(r["x"] - [1.0, 3.0]).max() <= 1e-8  # tests/test_solver.py:46-54
+
+    class Bounded(BoothNLP):  # the OSQP variant of the reference test adds dummy rows -1e9 <= x <= 1e9 (tests/test_solver.py:56-70)
+        nk = 4
+
+        def k(self, x, p):
+            return np.concatenate([x + 1e9, 1e9 - x])
+
+        def dk(self, x, p):
+            return np.concatenate([np.eye(2), -np.eye(2)])
+
+    r = solve_ipm(Bounded(), np.zeros(2), np.array([2.0, 7.0]))
+    assert r["status"] == "optimal" and np.abs(r["x"] - [1.0, 3.0]).max() <= 1e-6
+    # active bound rows: x <= 0.5 cuts the optimum off; KKT in the reference's form
+    class Cut(BoothNLP):
+        nk = 1
+
+        def k(self, x, p):
+            return np.array([0.5 - x[0]])
+
+        def dk(self, x, p):
+            return np.array([[-1.0, 0.0]])
+
+    nlp = Cut()
+    r = solve_ipm(nlp, np.zeros(2), np.array([2.0, 7.0]), relax=1e-12)
+    k = kkt_reference_form(nlp, r["x"], np.array([2.0, 7.0]))
+    assert abs(r["x"][0] - 0.5) <= 1e-7 and k["stationarity"] <= 1e-6 and r["lam_v"][0] > 0.1  # multiplier in the reference's sign
+
+
+def test_config1_ik_from_both_seeds(golden_nlp):
+    nlp = IKExampleNLP(OracleRobot(KUKA_KIN))
+    p = golden_nlp["ik_p"]
+    for seed in (np.zeros(7), p[:7]):  # the script's effective seed (zero fill, sx_container.py:121) and the nominal pose
+        r = solve_ipm(nlp, seed, p)
+        assert r["status"] == "optimal"
+        assert np.abs(r["x"] - golden_nlp["ik_x"]).max() <= 1e-6 and abs(r["f"] - float(golden_nlp["ik_f"])) <= 1e-6  # IPOPT's default relaxation
+    r = solve_ipm(nlp, np.zeros(7), p, relax=1e-12)
+    assert abs(r["f"] - float(golden_nlp["ik_f"])) <= 1e-9 and np.abs(r["x"] - golden_nlp["ik_x"]).max() <= 1e-7  # (the golden is an SLSQP answer)
+    k = kkt_reference_form(nlp, r["x"], p)
+    assert k["stationarity"] <= 1e-7 and k["feasibility"] <= 1e-9 and k["complementarity"] <= 1e-7
+
+
+def test_config3_point_mass_ticks():
+    g = np.load(os.path.join(GOLDEN, "pm_golden.npz"))
+    nlp = PointMassMPCNLP()
+    for i in (0, 1, 4):
+        r = solve_ipm(nlp, np.zeros(nlp.nx), g["p"][i])
+        assert r["status"] == "optimal"
+        # IPOPT's default bound relaxation lets each of the 42 dynamics rows move by 1e-8: worth sum|lam| 1e-8 ~ 4e-6 in f on these ticks
+        assert abs(r["f"] - g["f"][i]) <= 2e-5 * max(1.0, g["f"][i]), (i, r["f"], g["f"][i])
+        # KKT of the reference form with the method's own multipliers lam_v >= 0 of v >= 0: grad f = Jv^T lam_v, lam_v . v ~ mu
+        v, lam = nlp.v(r["x"], g["p"][i]), r["lam_v"]
+        assert v.min() >= -1.01e-8 and lam.min() >= 0.0
+        assert np.abs(nlp.df(r["x"], g["p"][i]) - nlp.dv(r["x"], g["p"][i]).T @ lam).max() <= 1e-6
+        assert np.abs(lam * np.minimum(v, 1.0)).max() <= 1e-6
+
+
+def test_config2_short_horizon_from_the_seed(golden_nlp):
+    orc = OracleRobot(KUKA_KIN)
+    T = 5
+    nlp = FastFigureEightNLP(orc, LINK, T=T, Tmax=10.0 * (T - 1) / 49.0)
+    qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    r = solve_ipm(nlp, nlp.seed(qc), qc)
+    assert r["status"] == "optimal"
+    k = kkt_reference_form(nlp, r["x"], qc)
+    assert k["stationarity"] <= 1e-6 and k["feasibility"] <= 1.01e-8  # the (e, -e) pairs hold to the bound relaxation, as IPOPT's would
+    d = dense_sqp(nlp, r["x"], qc, max_iter=10, tol=1e-10)  # onto the exact equalities
+    assert d["converged"] and abs(d["f"] - float(golden_nlp["fig8_T5_f"])) <= 1e-9 and np.abs(d["x"] - golden_nlp["fig8_T5_x"]).max() <= 1e-5
+    assert abs(r["f"] - d["f"]) <= 1e-4  # what the relaxation is worth in the objective
+
+
+def test_vectorised_figure_eight_equals_the_literal_restatement():
+    orc = OracleRobot(KUKA_KIN)
+    for T in (5, 9):
+        a, b = FigureEightNLP(orc, LINK, T=T), FastFigureEightNLP(orc, LINK, T=T)
+        rng = np.random.default_rng(T)
+        qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0]) + rng.uniform(-0.1, 0.1, 7)
+        x = a.seed(qc) + 0.3 * rng.standard_normal(a.nx)
+        lam = rng.standard_normal(a.nh)
+        assert abs(a.f(x, qc) - b.f(x, qc)) <= 1e-12 * abs(a.f(x, qc))
+        assert np.abs(a.df(x, qc) - b.df(x, qc)).max() <= 1e-12 * np.abs(a.df(x, qc)).max()
+        assert np.abs(a.h(x, qc) - b.h(x, qc)).max() <= 1e-15 and np.abs(a.dh(x, qc) - b.dh(x, qc)).max() <= 1e-15
+        for gn in (False, True):
+            Ha, Hb = a.hess_lagrangian(x, qc, lam, gn), b.hess_lagrangian(x, qc, lam, gn)
+            assert np.abs(Ha - Hb).max() <= 1e-12 * np.abs(Ha).max()

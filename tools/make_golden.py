@@ -452,15 +452,10 @@ def fig8_perturbed_dense_golden(n=8):
     np.savez(os.path.join(G, "nlp_pert_dense_golden.npz"), **{k: np.array(v) for k, v in out.items()})
 
 
-def fig8_ipm_golden(n_bench=16):
-    """Config 2 solved by the reference's ALGORITHM CLASS on the reference's FORM, from the reference's SEED (round-2 verdict, Next 2):
-    oracle/ipm_reference_form.py -- primal-dual interior point with filter line search (Waechter & Biegler 2006, IPOPT's defaults) on the
-    literal `min f s.t. 0 <= v <= 1e10`, equalities as (e, -e) pairs, exact Lagrangian Hessian.  Instances: the nominal one, the 8 perturbed
-    ones of nlp_pert_dense_golden.npz and the first `n_bench` of the bench workload (bench.make_inputs(., 0)).  Recorded per instance: where the
-    interior-point method stops (x, f, iterations, its own error E_0, reference-form KKT residuals); the same point polished by three
-    Newton-SQP steps on the exact equalities (the bound relaxation 1e-8 of IPOPT lets each equality move by 1e-8, worth sum|lam| 1e-8 ~ 1e-5 in
-    f: the polish removes that); the structured optimum (oracle/structured.py) from the same seed; whether the two are the same basin."""
-    import bench
+def _ipm_one(args):
+    """One instance of fig8_ipm_golden (runs in a worker process)."""
+    i, qc = args
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
     from oracle.ipm_reference_form import solve_ipm
     from oracle.problems import FastFigureEightNLP
 
@@ -468,25 +463,40 @@ def fig8_ipm_golden(n_bench=16):
     link, T = "end_effector_ball", 50
     nlp = FastFigureEightNLP(kuka, link, T=T)
     prob = StructuredFigureEight(kuka, link, T=T)
+    t0 = time.time()
+    r = solve_ipm(nlp, nlp.seed(qc), qc, max_iter=1500)
+    k = kkt_reference_form(nlp, r["x"], qc)
+    d = dense_sqp(nlp, r["x"], qc, max_iter=10, tol=1e-10)
+    kp = kkt_reference_form(nlp, d["x"], qc)
+    s = solve_structured_lm(prob, qc, max_iter=400, tol=1e-9)
+    xs = nlp.join(s["Q"].T, (np.diff(s["Q"], axis=0) / nlp.dt).T)
+    same = abs(d["f"] - s["f"]) <= 1e-8 * max(1.0, s["f"])
+    print(f"fig8 ipm {i:2d}: ipm f={r['f']:.10f} {r['status']} it={r['iters']} E0={r['E0']:.1e} | polished f={d['f']:.12f} ({d['iters']} steps, moved {np.abs(d['x'] - r['x']).max():.1e}) "
+          f"| structured f={s['f']:.12f} | {'same basin' if same else 'OTHER BASIN'} | {time.time() - t0:.0f} s", flush=True)
+    return (qc, r["x"], r["f"], r["iters"], r["E0"], r["status"] == "optimal", [k["stationarity"], k["feasibility"], k["complementarity"]], d["x"], d["f"],
+            [kp["stationarity"], kp["feasibility"], kp["complementarity"]], s["f"], bool(same), np.abs(d["x"] - xs).max(), time.time() - t0)
+
+
+def fig8_ipm_golden(n_bench=16, workers=7):
+    """Config 2 solved by the reference's ALGORITHM CLASS on the reference's FORM, from the reference's SEED (round-2 verdict, Next 2):
+    oracle/ipm_reference_form.py -- primal-dual interior point with filter line search (Waechter & Biegler 2006, IPOPT's defaults) on the
+    literal `min f s.t. 0 <= v <= 1e10`, equalities as (e, -e) pairs, exact Lagrangian Hessian.  Instances: the nominal one, the 8 perturbed
+    ones of nlp_pert_dense_golden.npz and the first `n_bench` of the bench workload (bench.make_inputs(., 0)).  Recorded per instance: where the
+    interior-point method stops (x, f, iterations, its own error E_0, reference-form KKT residuals); the same point polished by Newton-SQP steps
+    on the exact equalities (the bound relaxation 1e-8 of IPOPT lets each equality move by 1e-8, worth sum|lam| 1e-8 ~ 1e-5 in f: the polish
+    removes that); the structured optimum (oracle/structured.py) from the same seed; whether the two are the same basin.  Slow instances crawl
+    along the curved valley of the stiff tracking cost for hundreds of iterations (the walk the structured solver's second-order correction
+    removes): up to 20 minutes each, hence one worker process per instance."""
+    import multiprocessing as mp
+
+    import bench
+
     qc0 = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
     qcs = [qc0] + list(np.load(os.path.join(G, "nlp_pert_dense_golden.npz"))["qc"]) + list(bench.make_inputs(n_bench, 0)[1])
     keys = ("qc", "x_ipm", "f_ipm", "iters", "E0", "optimal", "kkt_ipm", "x_polished", "f_polished", "kkt_polished", "f_struct", "same_basin", "dx_struct", "seconds")
-    out = {k: [] for k in keys}
-    for i, qc in enumerate(qcs):
-        t0 = time.time()
-        r = solve_ipm(nlp, nlp.seed(qc), qc)
-        k = kkt_reference_form(nlp, r["x"], qc)
-        d = dense_sqp(nlp, r["x"], qc, max_iter=10, tol=1e-10)
-        kp = kkt_reference_form(nlp, d["x"], qc)
-        s = solve_structured_lm(prob, qc, max_iter=400, tol=1e-9)
-        xs = nlp.join(s["Q"].T, (np.diff(s["Q"], axis=0) / nlp.dt).T)
-        same = abs(d["f"] - s["f"]) <= 1e-8 * max(1.0, s["f"])
-        print(f"fig8 ipm {i:2d}: ipm f={r['f']:.10f} {r['status']} it={r['iters']} E0={r['E0']:.1e} | polished f={d['f']:.12f} ({d['iters']} steps, moved {np.abs(d['x'] - r['x']).max():.1e}) "
-              f"| structured f={s['f']:.12f} | {'same basin' if same else 'OTHER BASIN'} | {time.time() - t0:.0f} s", flush=True)
-        for key, val in zip(keys, (qc, r["x"], r["f"], r["iters"], r["E0"], r["status"] == "optimal", [k["stationarity"], k["feasibility"], k["complementarity"]], d["x"], d["f"],
-                                   [kp["stationarity"], kp["feasibility"], kp["complementarity"]], s["f"], bool(same), np.abs(d["x"] - xs).max(), time.time() - t0)):
-            out[key].append(val)
-        np.savez(os.path.join(G, "nlp_ipm_golden.npz"), **{k2: np.array(v) for k2, v in out.items()})
+    with mp.get_context("spawn").Pool(workers) as pool:
+        rows = pool.map(_ipm_one, list(enumerate(qcs)), chunksize=1)
+    np.savez(os.path.join(G, "nlp_ipm_golden.npz"), **{k2: np.array([row[j] for row in rows]) for j, k2 in enumerate(keys)})
 
 
 if __name__ == "__main__":

@@ -95,6 +95,12 @@ OH_DEV void setup_unit(const FigParams& P, const FigBuffers& D, const double* __
 #ifndef OH_EVALB_PREFETCH_G
 #define OH_EVALB_PREFETCH_G 1
 #endif
+// ZC: 1 = the neighbours' knots are requested with the lane's other inputs, ahead of the early-exit branch, and condensed at once into the
+// coupling term of G (N doubles) and ||q_t - q_{t-1}||^2; 0 = they are fetched where g is final (a dependent round trip in mid-kernel:
+// k_eval 45.7 against 42.7 ms per bench step, A/B on one box)
+#ifndef OH_ZC_EARLY
+#define OH_ZC_EARLY 1
+#endif
 // Householder vectors of knot t from their packed stage array ([t][3N - 3][Bp], written by eval_unit)
 template <int N>
 OH_DEV void load_householder(const double* __restrict__ Vs, const int Bp, const int b, const int t, double (&V)[3][N]) {
@@ -140,6 +146,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
     for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
   }
   double q[N], e_tgt[3] = {0.0, 0.0, 0.0};
+  double sm_zc = 0.0;  // ||q_t - q_{t-1}||^2 (ZC)
   double zs[NZ], Vc[3][N], mdlc[3 + 3 * NZ];
   double Gpre[N];  // Lagrangian gradient of the accepted point: wanted deep inside the evaluation (exact-curvature branch), requested here
   constexpr bool PRE_G = OH_EVALB_PREFETCH_G && MODE == EVAL_ONLY && !GUARD;
@@ -161,7 +168,29 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
 #pragma unroll
     for (int i = 0; i < 3 + 3 * NZ; ++i) mdlc[i] = D.mdl[cur][IDX(t, MDL_ROWS(N), i)];
   }
-  if constexpr (EARLY) {
+  double cpl_zc[N];  // ZC, OH_ZC_EARLY: 2 kappa ((q_t - q_{t-1}) - (q_{t+1} - q_t))
+  if constexpr (ZC && OH_ZC_EARLY) {
+    const double* __restrict__ qs = D.q[slot];
+    const bool lastk = (t == P.T - 1);
+    double qm[N], qp[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      qm[k] = qs[IDX(t - 1, N, k)];
+      qp[k] = lastk ? 0.0 : qs[IDX(t + 1, N, k)];
+    }
+    oh_fence(q[N - 1]);
+    oh_fence(Rc[8]);
+    oh_fence(qp[N - 1]);
+    const double kap2 = 2.0 * P.kappa;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const double dm = q[k] - qm[k];
+      sm_zc += dm * dm;
+      double c = kap2 * dm;
+      if (!lastk) c -= kap2 * (qp[k] - q[k]);
+      cpl_zc[k] = c;
+    }
+  } else if constexpr (EARLY) {
     oh_fence(q[N - 1]);
     oh_fence(Rc[8]);
   }
@@ -220,7 +249,6 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   for (int k = 0; k < N; ++k) Gprev[k] = 0.0;  // fetched by the hook below, inside the exact-curvature branch
 
   double phi, cv, g[N], Dr[NP], Z[N][NZ];
-  double sm_zc = 0.0;  // ||q_t - q_{t-1}||^2 (ZC)
   struct Hooks {
     double* __restrict__ qo;
     double* __restrict__ go;
@@ -234,7 +262,10 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
       }
     }
     OH_DEV void g_final(const double (&gv)[N]) const {
-      if constexpr (ZC) {
+      if constexpr (ZC && OH_ZC_EARLY) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) Go[IDX(t, N, k)] = gv[k] + cpl[k];
+      } else if constexpr (ZC) {
         // couple_knot's G and merit share, operation for operation (qs: this launch's knots, q_{t-1} of a fixed knot included)
         double sm = 0.0;
 #pragma unroll
@@ -270,8 +301,9 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
     double* smo;
     double kap2;
     bool last;
+    const double* cpl;
   };
-  const Hooks hooks{D.q[slot], D.g[slot], D.Z[slot], D.Gfull[cur], Bp, b, t, Gpre, D.q[slot], q, D.Gfull[slot], &sm_zc, 2.0 * P.kappa, t == P.T - 1};
+  const Hooks hooks{D.q[slot], D.g[slot], D.Z[slot], D.Gfull[cur], Bp, b, t, Gpre, D.q[slot], q, D.Gfull[slot], &sm_zc, 2.0 * P.kappa, t == P.T - 1, cpl_zc};
   double e_new[3], JZ_new[3][NZ];
   const double tol_r = retract_tol(P, !first, pred_b, stat_b);
   if constexpr (LEAD)
@@ -911,15 +943,29 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
   double stat = 0.0;
   double S[NP], rd[NZ], rn[NZ];
   bool factored = false;
-  // one knot's inputs, requested a knot ahead of their use
+  // a knot's inputs are requested PF knots ahead of their use (the kernel runs one wavefront per SIMD: registers to spare, and nothing
+  // but its own loads in flight to cover the memory latency with)
+#ifndef OH_STEP_ZC_PF
+#define OH_STEP_ZC_PF 1
+#endif
+  constexpr int PF = OH_STEP_ZC_PF;
+  double rV[PF][NV], rG[PF][N], rH[PF][NP];  // ring: knot t sits in slot (T - 1 - t) % PF (static indices: the knot loop is unrolled PF-fold)
   double nV[NV], nG[N], nH[NP];
-  auto fetch = [&](const int t) {
+  auto fetch = [&](const int j, const int t) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) nV[i] = rb_ld(KNOT(Vc, t, NV), RB(i), oV);
+    for (int i = 0; i < NV; ++i) rV[j][i] = rb_ld(KNOT(Vc, t, NV), RB(i), oV);
 #pragma unroll
-    for (int k = 0; k < N; ++k) nG[k] = rb_ld(KNOT(Gc, t, N), RB(k), oGf);
+    for (int k = 0; k < N; ++k) rG[j][k] = rb_ld(KNOT(Gc, t, N), RB(k), oGf);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) nH[i] = rb_ld(KNOT(Drc, t, NP), RB(i), oD);
+    for (int i = 0; i < NP; ++i) rH[j][i] = rb_ld(KNOT(Drc, t, NP), RB(i), oD);
+  };
+  auto take = [&](const int j) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) nV[i] = rV[j][i];
+#pragma unroll
+    for (int k = 0; k < N; ++k) nG[k] = rG[j][k];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) nH[i] = rH[j][i];
   };
   // Z of the knot in the buffers (z_from_householder on the packed vectors), its reduced gradient, and -- against the Z of knot t + 1 parked
   // in LDS -- E_t; Z_t then takes that place
@@ -959,13 +1005,17 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
   for (int attempt = 0; attempt < 40; ++attempt) {
     bool ok = true;
     stat = 0.0;
-    fetch(T - 1);
+    // knot T - 1 - i travels in ring slot i % PF
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+      if (T - 1 - j >= P.t0) fetch(j, T - 1 - j);
     {
       double E[NZ * NZ], gt[NZ];
+      take(0);
+      if (T - 1 - PF >= P.t0) fetch(0, T - 1 - PF);
       knot_blocks(true, E, gt);
 #pragma unroll
       for (int i = 0; i < NP; ++i) S[i] = nH[i];
-      if (T - 2 >= P.t0) fetch(T - 2);
 #pragma unroll
       for (int a = 0; a < NZ; ++a) {
         S[tri(a, a)] += kap2 + mu;
@@ -974,24 +1024,32 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
         rb_st(KNOT(gtc, T - 1, NZ), RB(a), oG, gt[a]);
       }
     }
-    for (int t = T - 2; t >= P.t0; --t) {
-      double E[NZ * NZ], Ht[NP], gt[NZ];
-      knot_blocks(false, E, gt);
+    for (int tb = T - 2; tb >= P.t0; tb -= PF) {
 #pragma unroll
-      for (int i = 0; i < NP; ++i) Ht[i] = nH[i];
-      if (t - 1 >= P.t0) fetch(t - 1);  // issued before the dependent arithmetic of this knot
+      for (int jj = 0; jj < PF; ++jj) {
+        const int t = tb - jj;
+        const int j = (jj + 1) % PF;  // slot of knot t: (T - 1 - t) % PF with T - 1 - tb = 1 (mod PF) at every pass
+        if (t >= P.t0) {
+          double E[NZ * NZ], Ht[NP], gt[NZ];
+          take(j);
+          if (t - PF >= P.t0) fetch(j, t - PF);  // issued before the dependent arithmetic of this knot
+          knot_blocks(false, E, gt);
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) {
-        stat = fmax(stat, fabs(gt[a]));
-        Ht[tri(a, a)] += 2.0 * kap2 + mu;
-        rb_st(KNOT(gtc, t, NZ), RB(a), oG, gt[a]);
+          for (int i = 0; i < NP; ++i) Ht[i] = nH[i];
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) {
+            stat = fmax(stat, fabs(gt[a]));
+            Ht[tri(a, a)] += 2.0 * kap2 + mu;
+            rb_st(KNOT(gtc, t, NZ), RB(a), oG, gt[a]);
+          }
+          double Kmat[NZ * NZ], kv[NZ];
+          ok = riccati_back<NZ>(S, rd, rn, E, Ht, gt, Kmat, kv) && ok;
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) rb_st(KNOT(D.kvec, t + 1, NZ), RB(a), lb, kv[a]);
+#pragma unroll
+          for (int i = 0; i < NZ * NZ; ++i) rb_st(KNOT(D.Kmat, t + 1, NZ * NZ), RB(i), lb, Kmat[i]);
+        }
       }
-      double Kmat[NZ * NZ], kv[NZ];
-      ok = riccati_back<NZ>(S, rd, rn, E, Ht, gt, Kmat, kv) && ok;
-#pragma unroll
-      for (int a = 0; a < NZ; ++a) rb_st(KNOT(D.kvec, t + 1, NZ), RB(a), lb, kv[a]);
-#pragma unroll
-      for (int i = 0; i < NZ * NZ; ++i) rb_st(KNOT(D.Kmat, t + 1, NZ * NZ), RB(i), lb, Kmat[i]);
     }
     ok = chol_rcp<NZ>(S, rd, 1e-12) && ok;
     if (ok) {

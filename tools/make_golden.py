@@ -477,7 +477,7 @@ def _ipm_one(args):
             [kp["stationarity"], kp["feasibility"], kp["complementarity"]], s["f"], bool(same), np.abs(d["x"] - xs).max(), time.time() - t0)
 
 
-def fig8_ipm_golden(n_bench=16, workers=7):
+def fig8_ipm_golden(n_bench=16, workers=6):
     """Config 2 solved by the reference's ALGORITHM CLASS on the reference's FORM, from the reference's SEED (round-2 verdict, Next 2):
     oracle/ipm_reference_form.py -- primal-dual interior point with filter line search (Waechter & Biegler 2006, IPOPT's defaults) on the
     literal `min f s.t. 0 <= v <= 1e10`, equalities as (e, -e) pairs, exact Lagrangian Hessian.  Instances: the nominal one, the 8 perturbed
@@ -494,6 +494,8 @@ def fig8_ipm_golden(n_bench=16, workers=7):
     qc0 = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
     qcs = [qc0] + list(np.load(os.path.join(G, "nlp_pert_dense_golden.npz"))["qc"]) + list(bench.make_inputs(n_bench, 0)[1])
     keys = ("qc", "x_ipm", "f_ipm", "iters", "E0", "optimal", "kkt_ipm", "x_polished", "f_polished", "kkt_polished", "f_struct", "same_basin", "dx_struct", "seconds")
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):  # before the workers import numpy: one BLAS thread each
+        os.environ[var] = "1"
     with mp.get_context("spawn").Pool(workers) as pool:
         rows = pool.map(_ipm_one, list(enumerate(qcs)), chunksize=1)
     np.savez(os.path.join(G, "nlp_ipm_golden.npz"), **{k2: np.array([row[j] for row in rows]) for j, k2 in enumerate(keys)})

@@ -238,6 +238,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fk-units", type=int, default=1 << 22)
     ap.add_argument("--oracle-sample", type=int, default=16, help="instances of the timed batch graded by the oracle afterwards (rank 0, N=1)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the block that measures BASELINE configs 1, 3, 4, 5 after the timed region (rank 0, N=1)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: run the multi-process plumbing only (rendezvous of the RCCL id with a stand-in id, "
                     "per-rank inputs) and print one JSON line per rank; everything of a --gpus N run except oh_comm_init and the solves")
     args = ap.parse_args()
@@ -390,6 +391,16 @@ def main():
         lat[nb] = float(np.median(ms[1:]))
         its_nb = d_it.download(np.int32, (B,))[:nb]
         lat[f"iters_{nb}"] = float(its_nb.mean())
+    # PCIe-inclusive rate: the same problem through oh_solve from pageable host buffers (what a ctypes host that keeps nothing resident pays)
+    pcie = None
+    if world == 1:
+        nb = min(B, 65536)
+        be.solve(x0[:nb], qc[:nb])
+        t0h = time.perf_counter()
+        rh = be.solve(x0[:nb], qc[:nb])
+        t_h = time.perf_counter() - t0h
+        pcie = {"batch": nb, "wall_ms": 1e3 * t_h, "device_ms": be.timing()["solve_ms"], "solves_per_s": nb / t_h, "converged_frac": float((rh.status == 0).mean()),
+                "what": "oh_solve with pageable numpy buffers: x0 and p up, x, f, kkt, iters, status down (2 x 5.5 KB per instance over PCIe), one call"}
     occupancy = {k: be.kernel_info(k) for k in (("k_retract", "k_evalb_zc", "k_step_zc", "k_tail", "k_fk_jac") if be.flag("fuse_couple") else
                                                 ("k_retract", "k_evalb", "k_couple", "k_step", "k_tail", "k_fk_jac"))}
     spec_info = be.specialize_info()
@@ -508,6 +519,16 @@ def main():
         "compactions_per_step": tm["compactions"] / args.steps,
         "fused_coupling": zc,
     }
+    out["pcie_inclusive"] = pcie
+    if world == 1 and not args.no_configs:
+        # the other BASELINE configs at their stated sizes (device ms, convergence, an oracle-graded sample each): tools/bench_configs.py
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs
+
+        be.close()
+        t0c = time.perf_counter()
+        out["configs"] = bench_configs.run_configs(sample=0 if args.no_cpu_baseline else 8)
+        out["configs"]["seconds"] = time.perf_counter() - t0c
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if comm is not None:

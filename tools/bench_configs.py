@@ -39,6 +39,186 @@ def timed(be, x0, p, reps=3):
             "stationarity_max": float(kk[ok, 0].max()), "feasibility_max": float(kk[ok, 1].max())}
 
 
+def oracle_grade(kind, **kw):
+    """A few instances of a config's batch graded by oracle/ (never by the library): reference-form KKT residuals on the literal layout
+    (oracle/solvers.py:kkt_reference_form) where the literal NLP is small enough to grade in a second, feasibility of every inequality row and
+    the recomputed objective otherwise."""
+    from oracle.robot import OracleRobot
+    from oracle.solvers import kkt_reference_form
+
+    R = os.path.join(ROOT, "optas_amd", "robots")
+    if kind == "ik":
+        from oracle.problems import IKExampleNLP
+
+        nlp = IKExampleNLP(OracleRobot(os.path.join(R, "kuka_lwr.kin.json")))
+        ks = [kkt_reference_form(nlp, x, p, active_tol=1e-7) for x, p in zip(kw["x"], kw["p"])]
+    elif kind == "pm":
+        from oracle.problems import PointMassMPCNLP
+
+        nlp = PointMassMPCNLP()
+        ks = [kkt_reference_form(nlp, x, p, active_tol=1e-3) for x, p in zip(kw["x"], kw["p"])]
+        return {"instances": len(ks), "stationarity_max": max(k["stationarity"] for k in ks), "feasibility_max": max(k["feasibility"] for k in ks),
+                "objective_recomputed_max_abs_diff": float(max(abs(nlp.f(x, p) - f) for x, p, f in zip(kw["x"], kw["p"], kw["f"]))),
+                "by": "oracle/solvers.py:kkt_reference_form on oracle/problems.py:PointMassMPCNLP (literal 264-row v)"}
+    elif kind == "torque":
+        from oracle.problems import TorqueMPCNLP
+        from oracle.torque import TorqueProblem
+
+        prob = TorqueProblem(OracleRobot(os.path.join(R, "med7.kin.json")), "lbr_link_ee", T=kw["T"], dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=kw["lim"])
+        nlp = TorqueMPCNLP(prob)
+        ks = [kkt_reference_form(nlp, x, p, active_tol=1e-6) for x, p in zip(kw["x"], kw["p"])]
+        return {"instances": len(ks), "stationarity_max": max(k["stationarity"] for k in ks), "feasibility_max": max(k["feasibility"] for k in ks),
+                "complementarity_max": max(k["complementarity"] for k in ks), "linear_rows_max": float(max(np.abs(nlp.a(x, p)).max() for x, p in zip(kw["x"], kw["p"]))),
+                "dynamics_rows_max": float(max(np.abs(nlp.h(x, p)).max() for x, p in zip(kw["x"], kw["p"]))),
+                "objective_recomputed_max_rel_diff": float(max(abs(nlp.f(x, p) - f) / abs(f) for x, p, f in zip(kw["x"], kw["p"], kw["f"]))),
+                "by": "oracle/solvers.py:kkt_reference_form on oracle/problems.py:TorqueMPCNLP (literal 840-variable / 1680-row layout, RNEA rows by the literal recursion)"}
+    elif kind == "guarded_arm":
+        from oracle.guarded import Guards, guard_values
+        from oracle.structured import FoldedChain
+
+        rob = OracleRobot(os.path.join(R, "kuka_lwr.kin.json"), name="kukal")
+        rob.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
+        ch = FoldedChain(rob, "end_effector_ball")
+        T = kw["T"]
+        worst, fdiff = 0.0, 0.0
+        for x, p, f in zip(kw["x"], kw["p"], kw["f"]):
+            Q = x[: 7 * T].reshape(T, 7)
+            dQ = x[7 * T :].reshape(T - 1, 7)
+            G = Guards(lo=rob.lower_actuated_joint_limits, up=rob.upper_actuated_joint_limits, links=kw["links"], link_radii=p[7:11], obs_pos=p[11:].reshape(6, 4)[:, :3],
+                       obs_radii=p[11:].reshape(6, 4)[:, 3])
+            worst = max(worst, float(-min(0.0, guard_values(ch, Q, G)[0][1:].min())))
+            e = ch.fk(Q)[0]
+            path = ch.fk(p[None, :7])[0][0][None] + kw["offsets"]
+            fdiff = max(fdiff, abs(float(np.sum((e - path) ** 2) + 0.01 * np.sum(dQ**2)) - f))
+        return {"instances": len(kw["x"]), "inequality_rows_min_violation": worst, "objective_recomputed_max_abs_diff": fdiff,
+                "by": "oracle/guarded.py:guard_values (2 x 7 limit rows + 4 x 6 sphere rows per knot) and the tracking cost recomputed with oracle/structured.py:FoldedChain"}
+    return {"instances": len(ks), "stationarity_max": max(k["stationarity"] for k in ks), "feasibility_max": max(k["feasibility"] for k in ks),
+            "complementarity_max": max(k["complementarity"] for k in ks), "by": "oracle/solvers.py:kkt_reference_form on the literal NLP of oracle/problems.py"}
+
+
+def timed_with_results(be, x0, p, reps=2, sample=0, seed=0):
+    """timed() plus a sample of (x, p, f) rows downloaded from the device for the oracle."""
+    B = x0.shape[0]
+    bufs = [_lib.DeviceBuffer(a.nbytes) for a in (x0, p)]
+    bufs[0].upload(x0)
+    bufs[1].upload(p)
+    d_x, d_f, d_k = _lib.DeviceBuffer(x0.nbytes), _lib.DeviceBuffer(8 * B), _lib.DeviceBuffer(24 * B)
+    d_i, d_s = _lib.DeviceBuffer(4 * B), _lib.DeviceBuffer(4 * B)
+    ms = []
+    for _ in range(reps + 1):
+        be.solve_device(B, bufs[0], bufs[1], d_x, d_f, d_k, d_i, d_s)
+        ms.append(be.solve_ms() if hasattr(be, "solve_ms") else be.timing()["solve_ms"])
+    it, st, kk = d_i.download(np.int32, (B,)), d_s.download(np.int32, (B,)), d_k.download(np.float64, (B, 3))
+    ok = st == 0
+    r = {"device_ms": float(np.median(ms[1:])), "converged_frac": float(ok.mean()), "iters_p50": float(np.median(it)), "iters_p90": float(np.percentile(it, 90)),
+         "iters_max": int(it.max()), "stationarity_max": float(kk[ok, 0].max()), "feasibility_max": float(kk[ok, 1].max())}
+    smp = None
+    if sample:
+        X = d_x.download(np.float64, x0.shape)
+        F = d_f.download(np.float64, (B,))
+        idx = np.sort(np.random.default_rng(seed).choice(np.flatnonzero(ok), min(sample, int(ok.sum())), replace=False))
+        smp = {"x": X[idx], "p": p[idx], "f": F[idx], "idx": idx}
+    for b in bufs + [d_x, d_f, d_k, d_i, d_s]:
+        b.free()
+    return r, smp
+
+
+def run_configs(sample=8, torque_batches=(8192, 1024)):
+    """BASELINE configs 1, 3, 4, 5 at their stated sizes: device time of one batched solve (HIP events, inputs resident), convergence, and an
+    oracle-graded sample of each -- what bench.py prints as its `configs` block."""
+    rng = np.random.default_rng(SEED)
+    out = {}
+    kuka = RobotModel.builtin("kuka_lwr")
+    # config 1
+    B = 65536
+    be = IKBackend(kuka.kinematic_chain("end_effector_ball"), kuka.lower_actuated_joint_limits, kuka.upper_actuated_joint_limits, max_iter=300)
+    qn = np.deg2rad([0, 45, 0, -90, 0, -45, 0]) + rng.uniform(-0.3, 0.3, (B, 7))
+    pg = np.asarray(kuka.get_global_link_position("end_effector_ball", np.clip(qn + rng.uniform(-0.5, 0.5, (B, 7)), kuka.lower_actuated_joint_limits,
+                                                                             kuka.upper_actuated_joint_limits).T)).T
+    r, smp = timed_with_results(be, np.ascontiguousarray(qn), np.ascontiguousarray(np.concatenate([qn, pg], 1)), sample=sample, seed=1)
+    out["config1_ik"] = {"what": "example.py IK (KUKA LWR, joint limits, position goal), B = 65536", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
+                         "oracle_sample": oracle_grade("ik", **smp) if smp else None}
+    be.close()
+    # config 3: tick and closed loop
+    from examples.point_mass_mpc import obstacle_and_goal
+
+    B = 4096
+    be = PointMassBackend()
+    P = []
+    obs, _ = obstacle_and_goal(2.0, np.zeros(2))
+    while len(P) < B:
+        c = rng.uniform(-1.2, 1.2, 2)
+        if np.linalg.norm(c - obs[:, 0]) <= 0.35:
+            continue
+        goal = np.stack([np.clip(c[j] + (1 - c[j]) * np.arange(20) / 19.0, -1.5, 1.5) for j in range(2)])
+        P.append(np.concatenate([c, np.zeros(2), goal.T.reshape(-1), obs.T.reshape(-1)]))
+    P = np.array(P)
+    r, smp = timed_with_results(be, np.zeros((B, 80)), P, sample=sample, seed=3)
+    n_ticks, adv, T = 50, 2, 20
+    tab = np.array([[0.15 * np.sin((2.0 + 0.05 * j) * np.pi - np.pi), 0.15 * np.cos((2.0 + 0.05 * j) * np.pi - np.pi) + 0.15] for j in range(n_ticks * adv + T)])
+    be.rollout(P[:, :4], tab, 2)
+    _, _, _, stt = be.rollout(P[:, :4], tab, n_ticks, adv)
+    out["config3_point_mass"] = {"what": "point_mass_mpc.py tick (T=20, box limits, moving obstacle), B = 4096 initial states", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
+                                 "oracle_sample": oracle_grade("pm", **smp) if smp else None,
+                                 "closed_loop": {"ticks": n_ticks, "device_ms": be.solve_ms(), "ticks_per_s": B * n_ticks / be.solve_ms() * 1e3, "converged_frac": float((stt == 0).mean())}}
+    be.close()
+    # config 4 synthetic: T = 100, limits + 4 x 6 sphere rows per knot, link radius 0.15 as SURVEY 8(d) states; arms are independent instances
+    from examples.dual_arm import SPHERE_LINKS, path_offsets
+
+    QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
+    T = 100
+    offs = path_offsets(T, [-0.1, 0.1, -0.2], [0.0, 0.0, 0.3])
+    for B, radius in ((256, 0.15), (1024, 0.15), (1024, 0.1)):
+        arm = RobotModel.builtin("kuka_lwr", time_derivs=[0, 1], name="kukal")
+        arm.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
+        g = _lib.oh_guards()
+        g.limits = 1
+        for j in range(7):
+            g.q_lo[j], g.q_up[j] = arm.lower_actuated_joint_limits[j], arm.upper_actuated_joint_limits[j]
+        g.n_links, g.n_obstacles = 4, 6
+        for l, (k, off) in enumerate(arm.link_attachments("end_effector_ball", SPHERE_LINKS)):
+            g.link_joint[l] = k
+            for i in range(3):
+                g.link_offset[l][i] = off[i]
+        be = FigureEightBackend(arm.kinematic_chain("end_effector_ball"), T, 10.0 / (T - 1), offs.T, w_path=1.0, w_vel=0.01, max_iter=400, lock_orientation=False, fix_dq0=False,
+                                path_in_frame=False, guards=g)
+        qc = QC + rng.uniform(-0.1, 0.1, (B, 7))
+        obs_row = np.concatenate([[0.55, 0.0, 0.1 * (i + 1), 0.1] for i in range(6)])
+        p = np.ascontiguousarray(np.concatenate([qc, np.full((B, 4), radius), np.tile(obs_row, (B, 1))], 1))
+        x0 = np.ascontiguousarray(np.concatenate([np.tile(qc, (1, T)), np.zeros((B, 7 * (T - 1)))], 1))
+        r, smp = timed_with_results(be, x0, p, sample=sample, seed=4)
+        out[f"config4_arms{B}_r{radius:g}"] = {"what": f"dual_arm.py synthetic: T=100, joint limits + 4 x 6 sphere clearances (link radius {radius:g}), {B} arms "
+                                                        "(a dual-arm instance = two of them)", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
+                                               "oracle_sample": oracle_grade("guarded_arm", T=T, links=SPHERE_LINKS, offsets=offs.T, **smp) if smp else None}
+        be.close()
+    # config 5
+    med7 = RobotModel.builtin("med7")
+    link, T, dt = "lbr_link_ee", 30, 0.1
+    qn = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    ts = np.arange(T) * dt
+    loc = np.stack([0.2 * np.sin(ts * np.pi * 0.5), 0.1 * np.sin(ts * np.pi), np.zeros(T)])
+    for B in tuple(torque_batches) + (1,):
+        qc = qn + (rng.uniform(-0.1, 0.1, (B, 7)) if B > 1 else 0.0)
+        qc = np.atleast_2d(qc)
+        pose, _ = med7._kin(link).fk_jac(qc, want_jac=False)
+        x, y, z, w = pose[:, 3], pose[:, 4], pose[:, 5], pose[:, 6]
+        Re = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], 1),
+                       np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], 1),
+                       np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)], 1)
+        goal = pose[:, None, :3] + np.einsum("bij,jt->bti", Re, loc)
+        p = np.ascontiguousarray(np.concatenate([qc, np.zeros((B, 7)), goal.reshape(B, -1)], 1))
+        x0 = np.zeros((B, 4 * 7 * T))
+        x0[:, : 7 * T] = np.tile(qc, (1, T))
+        be = TorqueBackend(med7.kinematic_chain(link), med7.dynamics_tables(), T=T, dt=dt, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=-58.0, tau_up=58.0, max_iter=600)
+        r, smp = timed_with_results(be, x0, p, sample=(min(sample, 4) if B == torque_batches[0] else 0), seed=5, reps=1 if B > 1 else 5)
+        tm = be.timing()
+        out[f"config5_torque_b{B}"] = {"what": f"torque MPC, RNEA dynamics equality rows + effort limits 58 N m (med7, T=30), B = {B}" + (" (the nominal instance)" if B == 1 else ""),
+                                       "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, "iterations_launched": tm["iterations_launched"], **r,
+                                       "oracle_sample": oracle_grade("torque", T=T, lim=58.0, **smp) if smp else None}
+        be.close()
+    return out
+
+
 def main():
     rng = np.random.default_rng(SEED)
     out = []

@@ -249,8 +249,8 @@ typedef struct oh_qp_desc {
   double tol;   /* KKT tolerance (stationarity, feasibility, complementarity); <= 0: 1e-9 */
 } oh_qp_desc;
 
-#define OH_TAPE_MAX_N 32
-#define OH_TAPE_MAX_LEN 8192
+#define OH_TAPE_MAX_N 4096
+#define OH_TAPE_MAX_LEN (1 << 18)
 /* Instruction i writes register i.  op: 0 CONST c | 1 X a | 2 P a | 3 ADD a b | 4 SUB a b | 5 MUL a b | 6 DIV a b | 7 NEG a | 8 SIN a | 9 COS a |
    10 ATAN2 a b | 11 SQRT a | 12 SQR a.  rows: registers of the constraint rows, the n_ineq rows that must be >= 0 first, then the n_eq rows
    that must vanish (the rows of v = [k; g; a; -a; h; -h] without the mirrored ones, optimization.py:27-51). */

@@ -294,8 +294,12 @@ static int tape_validate(const oh_tape_desc* d, const char* who) {
 }
 
 static TapeParams tape_params(const oh_tape_desc* d) {
+  // dense inverse-Hessian BFGS up to 48 variables (n^2 doubles per instance), the limited-memory form with 12 pairs beyond (OH_TAPE_LBFGS overrides:
+  // 0 forces the dense matrix, m > 0 the m-pair form at any size)
+  int lb = d->nx > 48 ? 12 : 0;
+  if (const char* e = getenv("OH_TAPE_LBFGS")) lb = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
   return TapeParams{d->len, d->nx, d->np, d->n_ineq, d->n_eq, d->out_cost, d->max_iter > 0 ? d->max_iter : 2000, d->tol > 0.0 ? d->tol : 1e-6,
-                    d->tol_feas > 0.0 ? d->tol_feas : 1e-9, d->rho0 > 0.0 ? d->rho0 : 10.0};
+                    d->tol_feas > 0.0 ? d->tol_feas : 1e-9, d->rho0 > 0.0 ? d->rho0 : 10.0, lb};
 }
 
 extern "C" int oh_tape_compile(const oh_tape_desc* d, size_t* code_bytes, char* source, size_t source_cap, size_t* source_len) {

@@ -22,6 +22,11 @@ hipError_t oh_spec_launch_eval(const FigSpec& sp, hipStream_t s, const FigParams
 hipError_t oh_spec_launch_tail(const FigSpec& sp, hipStream_t s, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_spec_kernel_info(const FigSpec& sp, const char* name, OhKernelInfo* out);
 
+// the library's disk cache of run-time compiled code objects ($OPTAS_HIP_CACHE), for its other generated kernels (oh_tape.hip)
+bool oh_jit_disk_lookup(const std::string& key_text, const char* prefix, std::vector<char>* code);
+void oh_jit_disk_store(const std::string& key_text, const char* prefix, const std::vector<char>& code);
+void oh_jit_disk_drop(const std::string& key_text, const char* prefix);
+
 // K1 (oh_fkjac_unit.h) for one chain: both layouts of the ABI
 struct FkSpec {
   hipModule_t mod = nullptr;

@@ -23,6 +23,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "oh_jit.h"  // the disk cache of run-time compiled code objects
 #include "oh_kernels.h"
 #include "oh_tape_solver_src.h"  // OH_TAPE_SOLVER_SRC: the text of oh_tape_solver.h, written by optas_amd/build.py
 
@@ -284,6 +285,13 @@ int oh_tape_jit_compile(const std::string& src, std::vector<char>* code, std::st
     auto it = g_code_cache.find(src);
     if (it != g_code_cache.end()) { *code = it->second; return 0; }
   }
+  // a trajectory-sized tape is minutes of compilation: its object is kept on disk like the chain-specialised kernels' (the key is the
+  // generated text, which contains the solver and every constant of the problem)
+  if (src.size() > 100000 && oh_jit_disk_lookup(src, "tape", code)) {
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    g_code_cache.emplace(src, *code);
+    return 0;
+  }
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, src.c_str(), "oh_tape_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { *err = "hiprtcCreateProgram failed"; return 1; }
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
@@ -302,13 +310,18 @@ int oh_tape_jit_compile(const std::string& src, std::vector<char>* code, std::st
   code->resize(cs);
   hiprtcGetCode(prog, code->data());
   hiprtcDestroyProgram(&prog);
+  if (src.size() > 100000) oh_jit_disk_store(src, "tape", *code);
   std::lock_guard<std::mutex> lk(g_cache_mutex);
   g_code_cache.emplace(src, *code);
   return 0;
 }
 
 int oh_tape_jit_load(const std::vector<char>& code, TapeJit* out, std::string* err) {
-  if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) { *err = "hipModuleLoadData failed for the generated tape kernel"; return 1; }
+  if (hipModuleLoadData(&out->mod, code.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    *err = "hipModuleLoadData failed for the generated tape kernel";
+    return 1;
+  }
   if (hipModuleGetFunction(&out->fn, out->mod, "k_tape_jit") != hipSuccess) {
     hipModuleUnload(out->mod);
     out->mod = nullptr;

@@ -5,7 +5,9 @@
 // Self-contained on purpose (no #include, only builtins and the device math library): build.py embeds the file as a string.
 // The includer defines OH_TAPE_ST_CONVERGED / OH_TAPE_ST_MAX_ITER / OH_TAPE_ST_NUMERICAL (the oh_status values of include/optas_hip.h).
 //
-// Outer loop: Powell-Hestenes-Rockafellar augmented Lagrangian; inner solver: BFGS on the inverse Hessian with Armijo backtracking.
+// Outer loop: Powell-Hestenes-Rockafellar augmented Lagrangian; inner solver: BFGS on the inverse Hessian with Armijo backtracking -- the
+// dense n x n matrix for small problems (T.lbfgs == 0), the limited-memory form (Nocedal's two-loop recursion over the last T.lbfgs
+// (s, y) pairs, 2 m n doubles instead of n^2) for the trajectory-sized ones (round 3: nx up to OH_TAPE_MAX_N = 4096).
 // numpy restatement: oracle/tape_ref.py (solve_tape_al).
 #ifndef OH_TAPE_SOLVER_H
 #define OH_TAPE_SOLVER_H
@@ -13,6 +15,7 @@
 struct TapeParams {
   int len, nx, np, n_ineq, n_eq, out_cost, max_iter;
   double tol, tol_feas, rho0;
+  int lbfgs;  // 0: dense inverse-Hessian BFGS; m > 0: limited-memory BFGS with m pairs
 };
 
 #define TIDX(i) ((size_t)(i) * Bp + b)
@@ -23,7 +26,8 @@ struct TapeWork {  // SoA slices [k][Bp]: instance index fastest, every access o
 
 __host__ __device__ inline size_t tape_solver_rows(const TapeParams& T) {
   const size_t n = T.nx;
-  return 7 * n + n * n + 2 * (size_t)(T.n_ineq > 0 ? T.n_ineq : 1) + 2 * (size_t)(T.n_eq > 0 ? T.n_eq : 1);
+  const size_t hrows = T.lbfgs > 0 ? 2 * (size_t)T.lbfgs * n + 2 * (size_t)T.lbfgs : n * n;  // (s, y) pairs + their 1 / s.y and the loop's alphas
+  return 7 * n + hrows + 2 * (size_t)(T.n_ineq > 0 ? T.n_ineq : 1) + 2 * (size_t)(T.n_eq > 0 ? T.n_eq : 1);
 }
 
 __device__ inline TapeWork tape_carve(const TapeParams& T, double* w, const int Bp) {
@@ -31,7 +35,7 @@ __device__ inline TapeWork tape_carve(const TapeParams& T, double* w, const int 
   TapeWork W;
   auto take = [&](size_t rows) { double* o = w; w += rows * (size_t)Bp; return o; };
   W.x = take(n); W.xt = take(n); W.g = take(n); W.gt = take(n); W.d = take(n); W.s = take(n); W.hy = take(n);
-  W.H = take(n * n); W.lam = take(ni); W.mu = take(ne); W.rowv = take(ni + ne);
+  W.H = take(T.lbfgs > 0 ? 2 * (size_t)T.lbfgs * n + 2 * (size_t)T.lbfgs : n * n); W.lam = take(ni); W.mu = take(ne); W.rowv = take(ni + ne);
   return W;
 }
 
@@ -60,7 +64,16 @@ __device__ inline void tape_solve_instance(const TapeParams& T, E& ev, const Tap
   for (int k = 0; k < n; ++k) W.x[TIDX(k)] = x0[(size_t)gb * n + k];
   for (int i = 0; i < T.n_ineq; ++i) W.lam[TIDX(i)] = 0.0;
   for (int i = 0; i < T.n_eq; ++i) W.mu[TIDX(i)] = 0.0;
+  // limited-memory form: W.H holds S [m][n], then Y [m][n], then 1 / (s_i . y_i) [m], then the two-loop alphas [m]; pair j of the `hist` stored
+  // ones (oldest first) sits in ring slot (head - hist + j) mod m
+  const int m = T.lbfgs;
+  int hist = 0, head = 0;
+  auto Sr = [&](int slot, int k) -> double& { return W.H[TIDX((size_t)slot * n + k)]; };
+  auto Yr = [&](int slot, int k) -> double& { return W.H[TIDX((size_t)(m + slot) * n + k)]; };
+  auto Rr = [&](int slot) -> double& { return W.H[TIDX((size_t)2 * m * n + slot)]; };
+  auto Ar = [&](int slot) -> double& { return W.H[TIDX((size_t)2 * m * n + m + slot)]; };
   auto eye = [&]() {
+    if (m > 0) { hist = 0; head = 0; return; }
     for (int i = 0; i < n; ++i)
       for (int j = 0; j < n; ++j) W.H[TIDX(i * n + j)] = (i == j) ? 1.0 : 0.0;
   };
@@ -94,11 +107,44 @@ __device__ inline void tape_solve_instance(const TapeParams& T, E& ev, const Tap
     }
     if (evals >= T.max_iter) break;
     double slope = 0.0;  // d = -H g
-    for (int i = 0; i < n; ++i) {
-      double v = 0.0;
-      for (int j = 0; j < n; ++j) v -= W.H[TIDX(i * n + j)] * W.g[TIDX(j)];
-      W.d[TIDX(i)] = v;
-      slope += W.g[TIDX(i)] * v;
+    if (m > 0) {
+      // two-loop recursion (Nocedal 1980): q = g; newest to oldest a_i = rho_i s_i.q, q -= a_i y_i; r = gamma q with gamma = s.y / y.y of the
+      // newest pair; oldest to newest r += s_i (a_i - rho_i y_i.r); d = -r
+      for (int k = 0; k < n; ++k) W.d[TIDX(k)] = W.g[TIDX(k)];
+      for (int j = hist - 1; j >= 0; --j) {
+        const int sl = ((head - hist + j) % m + m) % m;
+        double sq = 0.0;
+        for (int k = 0; k < n; ++k) sq += Sr(sl, k) * W.d[TIDX(k)];
+        const double al = Rr(sl) * sq;
+        Ar(sl) = al;
+        for (int k = 0; k < n; ++k) W.d[TIDX(k)] -= al * Yr(sl, k);
+      }
+      if (hist > 0) {
+        const int sl = ((head - 1) % m + m) % m;
+        double sy = 0.0, yy = 0.0;
+        for (int k = 0; k < n; ++k) { sy += Sr(sl, k) * Yr(sl, k); yy += Yr(sl, k) * Yr(sl, k); }
+        const double gam = sy / yy;
+        for (int k = 0; k < n; ++k) W.d[TIDX(k)] *= gam;
+      }
+      for (int j = 0; j < hist; ++j) {
+        const int sl = ((head - hist + j) % m + m) % m;
+        double yr = 0.0;
+        for (int k = 0; k < n; ++k) yr += Yr(sl, k) * W.d[TIDX(k)];
+        const double be = Ar(sl) - Rr(sl) * yr;
+        for (int k = 0; k < n; ++k) W.d[TIDX(k)] += be * Sr(sl, k);
+      }
+      for (int k = 0; k < n; ++k) {
+        const double v = -W.d[TIDX(k)];
+        W.d[TIDX(k)] = v;
+        slope += W.g[TIDX(k)] * v;
+      }
+    } else {
+      for (int i = 0; i < n; ++i) {
+        double v = 0.0;
+        for (int j = 0; j < n; ++j) v -= W.H[TIDX(i * n + j)] * W.g[TIDX(j)];
+        W.d[TIDX(i)] = v;
+        slope += W.g[TIDX(i)] * v;
+      }
     }
     if (!(slope < 0.0)) {
       eye();
@@ -139,7 +185,15 @@ __device__ inline void tape_solve_instance(const TapeParams& T, E& ev, const Tap
       W.d[TIDX(k)] = yv;
       sy += sv * yv; ss += sv * sv; yy += yv * yv;
     }
-    if (sy > 1e-12 * sqrt(ss) * sqrt(yy)) {
+    if (m > 0) {
+      if (sy > 1e-12 * sqrt(ss) * sqrt(yy)) {
+        for (int k = 0; k < n; ++k) { Sr(head, k) = W.s[TIDX(k)]; Yr(head, k) = W.d[TIDX(k)]; }
+        Rr(head) = 1.0 / sy;
+        head = (head + 1) % m;
+        if (hist < m) ++hist;
+        H_is_eye = false;
+      }
+    } else if (sy > 1e-12 * sqrt(ss) * sqrt(yy)) {
       double yHy = 0.0;
       for (int i = 0; i < n; ++i) {
         double v = 0.0;

@@ -682,13 +682,15 @@ class TapeSpec:
 
 
 def match_tape(opt: Optimization) -> TapeSpec:
-    """Last resort: any small dense problem whose expression trees compile to a scalar tape (optas_amd/tape.py), interpreted on the GPU."""
+    """Last resort: any problem whose expression trees compile to a scalar tape (optas_amd/tape.py), evaluated on the GPU by generated code;
+    dense BFGS up to 48 variables, limited-memory BFGS beyond (trajectory-sized problems: hundreds of variables, tens of thousands of tape
+    evaluations per solve -- a fallback that solves, not a fast path)."""
     from .tape import compile_problem
 
     if opt.has_discrete_variables():
         raise LoweringError("tape lowering: discrete variables are not supported")
-    if not 1 <= opt.nx <= 32:
-        raise LoweringError(f"tape lowering: nx={opt.nx} exceeds the dense solver's limit of 32 decision variables")
+    if not 1 <= opt.nx <= 4096:
+        raise LoweringError(f"tape lowering: nx={opt.nx} exceeds the generic family's limit of 4096 decision variables (OH_TAPE_MAX_N)")
     try:
         tape = compile_problem(opt)
     except NotImplementedError as e:

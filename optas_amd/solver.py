@@ -314,7 +314,8 @@ class HIPSolver(Solver):
             self._backend = _QpAdapter(self.opt, qb)
         elif isinstance(spec, TapeSpec):
             o.pop("hessian", None)
-            self._backend = TapeBackend(spec.tape, max_iter=int(o.pop("max_iter", 2000)), tol=float(o.pop("tol", 1e-6)),
+            # (evaluations: a small dense problem needs a few hundred; the limited-memory path of a trajectory-sized one tens of thousands)
+            self._backend = TapeBackend(spec.tape, max_iter=int(o.pop("max_iter", 2000 if spec.tape.nx <= 48 else 500000)), tol=float(o.pop("tol", 1e-6)),
                                         tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=float(o.pop("rho0", 10.0)), jit=bool(o.pop("jit", True)))
         else:  # pragma: no cover
             raise NotImplementedError(kind)

@@ -21,7 +21,7 @@ from .expr import (Add, Atan2, Block, Const, Expr, LinkFunction, MatMul, Mul, Pa
 from .spatialmath import rpy2r
 
 OP_CONST, OP_X, OP_P, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SIN, OP_COS, OP_ATAN2, OP_SQRT, OP_SQR = range(13)
-MAX_TAPE = 8192
+MAX_TAPE = 1 << 18
 
 
 class TapeBuilder:
@@ -187,9 +187,39 @@ def _chain_walk(tb: TapeBuilder, robot, link: str, q: np.ndarray):
     return R, p, joints
 
 
-def _quat_from_R(tb: TapeBuilder, R) -> np.ndarray:
-    raise NotImplementedError("quaternion link functions are not compiled to tapes (sign conventions of the reference chain product); "
-                              "use position / rotation / Jacobian link functions")
+def _chain_quat(tb: TapeBuilder, robot, link: str, q: np.ndarray) -> np.ndarray:
+    """models.py:1049-1088 over registers: the xyzw quaternion of the link as the reference accumulates it, quat <- fromrpy(rpy) * quat, then
+    quat <- fromangvec(q_i, axis) * quat per joint, with the class's own (reversed) product (spatialmath.py:298-312) -- its sign is part of what
+    an equality row on a quaternion pins, so it is not rebuilt from the rotation matrix.  Returns 4 x 1 registers."""
+    from .spatialmath import Quaternion
+
+    def mul(a, b):  # Quaternion.__mul__: self = a, quat = b (spatialmath.py:298-312)
+        x0, y0, z0, w0 = a
+        x1, y1, z1, w1 = b
+        m, ad, sb, ng = tb.mul, tb.add, tb.sub, tb.neg
+        return (ad(sb(ad(m(x1, w0), m(y1, z0)), m(z1, y0)), m(w1, x0)),
+                ad(ad(ad(ng(m(x1, z0)), m(y1, w0)), m(z1, x0)), m(w1, y0)),
+                ad(ad(sb(m(x1, y0), m(y1, x0)), m(z1, w0)), m(w1, z0)),
+                ad(sb(sb(ng(m(x1, x0)), m(y1, y0)), m(z1, z0)), m(w1, w0)))
+
+    quat = tuple(tb.const(v) for v in (0.0, 0.0, 0.0, 1.0))
+    root = robot.urdf.get_root()
+    names = robot.urdf.get_chain(root, link, links=False) if link != root else []
+    for name in names:
+        joint = robot.urdf.joint_map[name]
+        _, rpy = robot.get_joint_origin(joint)
+        quat = mul(tuple(tb.const(float(v)) for v in Quaternion.fromrpy(rpy).getquat()), quat)
+        if joint.type in ("fixed", "prismatic"):
+            continue
+        if joint.type not in ("revolute", "continuous"):
+            raise NotImplementedError(f"{joint.type} joints are currently not supported")
+        th = int(q[robot.get_actuated_joint_index(joint.name)])
+        half = tb.mul(tb.const(0.5), th)
+        s, c = tb.sin(half), tb.cos(half)
+        ax = np.asarray(robot.get_joint_axis(joint), dtype=np.float64)
+        ax = ax / np.linalg.norm(ax)
+        quat = mul((tb.mul(tb.const(ax[0]), s), tb.mul(tb.const(ax[1]), s), tb.mul(tb.const(ax[2]), s), c), quat)
+    return np.array([[int(v)] for v in quat], dtype=np.int64)
 
 
 class Compiler:
@@ -294,7 +324,7 @@ class Compiler:
                                 J[i, idx] = zw[i, 0]
                     return J
                 else:
-                    _quat_from_R(tb, R)
+                    cols.append(_chain_quat(tb, e.robot, e.link, Q[:, j]))
             return np.hstack(cols)
         raise NotImplementedError(f"cannot compile {type(e).__name__} to a tape")
 

@@ -132,7 +132,10 @@ def solve_ipm(nlp, x0, p, tol=1e-8, max_iter=3000, mu0=0.1, scaling=True, verbos
     """Interior-point filter line search [WB] on the reference form.  Returns dict(x, f, iters, status, E0, lam_v (multipliers of v >= 0 in the
     reference's sign: lam >= 0 on active lower bounds), history).  `relax` is IPOPT's bound_relax_factor (default 1e-8): every row of v may end
     up to `relax` below zero, so an equality pair (e, -e) holds to |e| <= relax and the objective sits up to sum|lam| relax below the exact
-    optimum; tests that compare with exactly feasible optima either polish the point (oracle.solvers.dense_sqp) or tighten `relax`."""
+    optimum; tests that compare with exactly feasible optima polish the point (oracle.solvers.dense_sqp).  Tightening `relax` instead is
+    fragile: the two multipliers of an (e, -e) pair grow like mu / relax, and once they reach 1e8 the multiplier scaling s_d of the termination
+    test [WB (6)] accepts any dual infeasibility -- a run with relax = 1e-11 on the joint-space planner stops at the solution of its first
+    barrier problem."""
     attach_hessian(nlp)
     x = np.asarray(x0, float).copy()
     P = SlackForm(nlp, p, x, scaling=scaling, relax=relax)

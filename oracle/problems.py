@@ -926,3 +926,143 @@ class FastFigureEightNLP(FigureEightNLP):
             H[n * t : n * t + n, n * t : n * t + n] = W[t]
         H[self.nq :, self.nq :] = 2.0 * self.w_vel * np.eye(self.ndq)
         return H
+
+
+class JointSpacePlannerNLP(_NLPBase):
+    """example/simple_joint_space_planner.py:15-73 (a problem outside BASELINE's five configs: what SURVEY 8(f) rank 1, "arbitrary user
+    problems", is exercised with), literal layout.
+
+    x = ["{name}/q/x" (n x T); "{name}/dq/x" (n x T)]                 (derivs_align, builder.py:90-99)
+    p = [nominal_joint_state (n); current_joint_state (n); position_goal (3); orientation_goal (4)]          (:22-25)
+    a = [qc - q_0;  -(q_t + dt dq_t - q_{t+1}), t = 0..T-2;  0 - dq_{T-1}]         (:28, :38, :66; builder.py:525-539, 437-469)
+    h = [pg - p_ee(q_{T-1});  og - quat_ee(q_{T-1})]                                  (:31-35)
+    g = per knot [z_ee(q_t) + zpad;  z_elbow(q_t) + zpad]                            (:41-54, add_geq: lhs - rhs)
+    f = sum_t 0.1 ||q_t - qn||^2 + 0.1 ||dQ||^2 + 10 ||(dQ[:, 1:] - dQ[:, :-1]) / dt||^2                (:45, :57-64)
+    """
+
+    def __init__(self, robot: OracleRobot, ee="lbr_link_ee", elbow="lbr_link_3", T=20, duration=4.0, zpad=0.05):
+        self.robot, self.ee, self.elbow, self.T, self.zpad = robot, ee, elbow, T, zpad
+        self.n = n = robot.ndof
+        self.dt = duration / float(T - 1)
+        self.nx, self.np_ = 2 * n * T, 2 * n + 7
+        self.na, self.nh, self.ng = n + n * (T - 1) + n, 7, 2 * T
+        A = np.zeros((self.na, self.nx))
+        I = np.eye(n)
+        A[:n, :n] = -I
+        for t in range(T - 1):
+            r = n + n * t
+            A[r : r + n, n * t : n * t + n] = -I
+            A[r : r + n, n * T + n * t : n * T + n * t + n] = -self.dt * I
+            A[r : r + n, n * (t + 1) : n * (t + 1) + n] = I
+        A[n + n * (T - 1) :, n * T + n * (T - 1) :] = -I
+        self._A = A
+
+    def split(self, x):
+        n, T = self.n, self.T
+        return x[: n * T].reshape(T, n).T, x[n * T :].reshape(T, n).T
+
+    def seed(self, q0):
+        return np.concatenate([np.tile(np.asarray(q0, float), self.T), np.zeros(self.n * self.T)])
+
+    def f(self, x, p):
+        Q, dQ = self.split(x)
+        qn = p[: self.n]
+        return float(0.1 * np.sum((Q - qn[:, None]) ** 2) + 0.1 * np.sum(dQ**2) + 10.0 * np.sum(((dQ[:, 1:] - dQ[:, :-1]) / self.dt) ** 2))
+
+    def df(self, x, p):
+        Q, dQ = self.split(x)
+        qn = p[: self.n]
+        gq = 0.2 * (Q - qn[:, None])
+        gd = 0.2 * dQ
+        dd = (dQ[:, 1:] - dQ[:, :-1]) * (20.0 / self.dt**2)
+        gd[:, 1:] += dd
+        gd[:, :-1] -= dd
+        return np.concatenate([gq.T.reshape(-1), gd.T.reshape(-1)])
+
+    def a(self, x, p):
+        b = np.zeros(self.na)
+        b[: self.n] = p[self.n : 2 * self.n]
+        return self._A @ x + b
+
+    def da(self, x, p):
+        return self._A
+
+    def h(self, x, p):
+        qF = self.split(x)[0][:, -1]
+        n = self.n
+        return np.concatenate([p[2 * n : 2 * n + 3] - self.robot.get_global_link_position(self.ee, qF), p[2 * n + 3 :] - self.robot.get_global_link_quaternion(self.ee, qF)])
+
+    def dh(self, x, p):
+        qF = self.split(x)[0][:, -1]
+        n, T = self.n, self.T
+        J = np.zeros((7, self.nx))
+        J[:3, n * (T - 1) : n * T] = -self.robot.get_global_link_linear_jacobian(self.ee, qF)
+        J[3:, n * (T - 1) : n * T] = -self.robot.quaternion_jacobian(self.ee, qF)
+        return J
+
+    def g(self, x, p):
+        Q, _ = self.split(x)
+        out = np.zeros(self.ng)
+        for t in range(self.T):
+            out[2 * t] = self.robot.get_global_link_position(self.ee, Q[:, t])[2] + self.zpad
+            out[2 * t + 1] = self.robot.get_global_link_position(self.elbow, Q[:, t])[2] + self.zpad
+        return out
+
+    def dg(self, x, p):
+        Q, _ = self.split(x)
+        n = self.n
+        J = np.zeros((self.ng, self.nx))
+        for t in range(self.T):
+            J[2 * t, n * t : n * t + n] = self.robot.get_global_link_linear_jacobian(self.ee, Q[:, t])[2]
+            J[2 * t + 1, n * t : n * t + n] = self.robot.get_global_link_linear_jacobian(self.elbow, Q[:, t])[2]
+        return J
+
+    def hess_lagrangian_v(self, x, p, sigma, lam_v):
+        """sigma d2f + sum_i lam_v[i] d2v_i over v = [g; a; -a; h; -h] (what oracle/ipm_reference_form.py asks for): the cost is quadratic, the linear
+        rows have no curvature; a height row contributes lam d2(p_z) of its link, the final-pose rows -mu d2p and -mu d2quat with the signed
+        mu = lam(h) - lam(-h).  d2p/dq_i dq_j = z_i x Jp_j (i <= j), d2quat as in FigureEightNLP.hess_lagrangian."""
+        n, T = self.n, self.T
+        Q, _ = self.split(x)
+        lg = lam_v[: self.ng]
+        o = self.ng + 2 * self.na
+        mu_h = lam_v[o : o + self.nh] - lam_v[o + self.nh : o + 2 * self.nh]
+        H = np.zeros((self.nx, self.nx))
+        H[: n * T, : n * T] = 0.2 * np.eye(n * T)
+        D = np.zeros((T, T))
+        for t in range(T - 1):
+            D[t, t] += 1.0
+            D[t + 1, t + 1] += 1.0
+            D[t, t + 1] -= 1.0
+            D[t + 1, t] -= 1.0
+        H[n * T :, n * T :] = 0.2 * np.eye(n * T) + np.kron(20.0 / self.dt**2 * D, np.eye(n))
+        H *= sigma
+
+        def d2p(J):
+            Jp, Jw = J[:3], J[3:]
+            out = np.zeros((3, n, n))
+            for i in range(n):
+                for j in range(i, n):
+                    out[:, i, j] = out[:, j, i] = np.cross(Jw[:, i], Jp[:, j])
+            return out
+
+        for t in range(T):
+            q = Q[:, t]
+            W = np.zeros((n, n))
+            for link, lam in ((self.ee, lg[2 * t]), (self.elbow, lg[2 * t + 1])):
+                if lam != 0.0:
+                    W += lam * d2p(self.robot.get_global_link_geometric_jacobian(link, q))[2]
+            if t == T - 1:
+                J = self.robot.get_global_link_geometric_jacobian(self.ee, q)
+                W -= np.einsum("k,kij->ij", mu_h[:3], d2p(J))
+                Jw = J[3:]
+                quat = self.robot.get_global_link_quaternion(self.ee, q)
+                for i in range(n):
+                    for j in range(i, n):
+                        dz = np.cross(Jw[:, i], Jw[:, j]) if i < j else np.zeros(3)
+                        d2q = 0.5 * _hamilton_left_pure(dz, quat) + 0.25 * _hamilton_left_pure(Jw[:, j], _hamilton_left_pure(Jw[:, i], quat))
+                        val = -float(mu_h[3:] @ d2q)
+                        W[i, j] += val
+                        if j != i:
+                            W[j, i] += val
+            H[n * t : n * t + n, n * t : n * t + n] += W
+        return H

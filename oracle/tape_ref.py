@@ -83,10 +83,42 @@ def reverse(tape, v, seeds):
     return g
 
 
-def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0):
-    """Generic small NLP on a tape: min f s.t. rows[:n_ineq] >= 0, rows[n_ineq:] = 0.  Augmented Lagrangian (PHR for the inequality rows)
-    minimised by BFGS with Armijo backtracking; one forward + one reverse sweep per evaluation.  Port of k_tape_solve."""
+class _LBFGS:
+    """The limited-memory inverse-Hessian operator of csrc/oh_tape_solver.h (T.lbfgs = m pairs): Nocedal's two-loop recursion."""
+
+    def __init__(self, m):
+        self.m, self.S, self.Y = m, [], []
+
+    def reset(self):
+        self.S, self.Y = [], []
+
+    def is_identity(self):
+        return not self.S
+
+    def direction(self, grad):
+        q = grad.copy()
+        al = []
+        for sv, yv in zip(reversed(self.S), reversed(self.Y)):
+            a = (sv @ q) / (sv @ yv)
+            al.append(a)
+            q = q - a * yv
+        if self.S:
+            q = q * ((self.S[-1] @ self.Y[-1]) / (self.Y[-1] @ self.Y[-1]))
+        for (sv, yv), a in zip(zip(self.S, self.Y), reversed(al)):
+            q = q + sv * (a - (yv @ q) / (sv @ yv))
+        return -q
+
+    def update(self, sv, yv):
+        self.S, self.Y = (self.S + [sv])[-self.m:], (self.Y + [yv])[-self.m:]
+
+
+def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0, lbfgs=None):
+    """Generic NLP on a tape: min f s.t. rows[:n_ineq] >= 0, rows[n_ineq:] = 0.  Augmented Lagrangian (PHR for the inequality rows)
+    minimised by BFGS with Armijo backtracking -- the dense inverse Hessian up to 48 variables, the limited-memory form with `lbfgs` = 12 pairs
+    beyond, as oh_api.hip:tape_params chooses; one forward + one reverse sweep per evaluation.  Port of k_tape_solve."""
     n, ni, ne = tape.nx, tape.n_ineq, tape.n_eq
+    lbfgs = (12 if n > 48 else 0) if lbfgs is None else lbfgs
+    LB = _LBFGS(lbfgs) if lbfgs > 0 else None
     rows = tape.out_rows
     lam = np.zeros(ni)
     mu = np.zeros(ne)
@@ -108,7 +140,7 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
 
     evals = 1
     val, grad, g, c, fval = phi(x)
-    H = np.eye(n)
+    H = np.eye(n) if LB is None else None
     omega, meas_prev = max(tol, 1e-2), np.inf
     status = 1
     while True:
@@ -131,18 +163,24 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
             omega = max(tol, min(omega, 0.1 * meas))
             val, grad, g, c, fval = phi(x)
             evals += 1
-            H = np.eye(n)
+            H = np.eye(n) if LB is None else None
+            if LB is not None:
+                LB.reset()
             continue
         if evals >= max_iter:
             break
-        d = -H @ grad
+        d = -H @ grad if LB is None else LB.direction(grad)
         slope = float(grad @ d)
         if not slope < 0.0:
-            H = np.eye(n)
+            if LB is None:
+                H = np.eye(n)
+            else:
+                LB.reset()
             d = -grad
             slope = float(grad @ d)
         # a fresh (identity) metric knows nothing about the scale of the problem: keep the first step within unit length
-        alpha = min(1.0, 1.0 / np.abs(d).max()) if np.array_equal(H, np.eye(n)) else 1.0
+        fresh = np.array_equal(H, np.eye(n)) if LB is None else LB.is_identity()
+        alpha = min(1.0, 1.0 / np.abs(d).max()) if fresh else 1.0
         ok = False
         for _ in range(40):
             xt = x + alpha * d
@@ -156,13 +194,19 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
                 break
         if not ok:
             evals += 1  # the kernel re-evaluates the accepted point (its tape registers were overwritten by the rejected trials)
-            if np.array_equal(H, np.eye(n)) or evals >= max_iter:
+            if fresh or evals >= max_iter:
                 break  # steepest descent cannot improve: rounding floor
-            H = np.eye(n)
+            if LB is None:
+                H = np.eye(n)
+            else:
+                LB.reset()
             continue
         sv, yv = xt - x, gt - grad
         sy = float(sv @ yv)
-        if sy > 1e-12 * np.linalg.norm(sv) * np.linalg.norm(yv):
+        if LB is not None:
+            if sy > 1e-12 * np.linalg.norm(sv) * np.linalg.norm(yv):
+                LB.update(sv, yv)
+        elif sy > 1e-12 * np.linalg.norm(sv) * np.linalg.norm(yv):
             Hy = H @ yv
             H = H + ((sy + float(yv @ Hy)) / (sy * sy)) * np.outer(sv, sv) - (np.outer(Hy, sv) + np.outer(sv, Hy)) / sy
         x, val, grad, g, c, fval = xt, vt, gt, g_t, c_t, f_t

@@ -129,11 +129,16 @@ def test_ik_example_builder_matches_reference_counts():
     b.add_cost_term("extra", sumsqr(q))
     kind, spec = lower(b.build())  # a second cost term is outside the hand-written IK family: the generic tape family takes it
     assert kind == optas_amd._lib.OH_PROBLEM_TAPE and spec.tape.nx == 7 and (spec.tape.n_ineq, spec.tape.n_eq) == (14, 3)
-    big = OptimizationBuilder(T=9, robots=robot)  # 63 variables with a coupling cost: no structured family, too large for the dense one
-    qs = big.get_model_states(name)
+    big = OptimizationBuilder(T=9, robots=robot)  # 63 variables with a coupling cost: no structured family; the generic one takes it with its
+    qs = big.get_model_states(name)               # limited-memory solver (refused until round 3: the dense BFGS stopped at 32 variables)
     big.add_cost_term("coupled", sumsqr(robot.get_global_link_position("end_effector_ball", qs[:, 0]) - robot.get_global_link_position("end_effector_ball", qs[:, 8])))
+    kind, spec = lower(big.build())
+    assert kind == optas_amd._lib.OH_PROBLEM_TAPE and spec.tape.nx == 63
+    huge = OptimizationBuilder(T=600, robots=robot)  # 4200 variables: beyond OH_TAPE_MAX_N, refused loudly, never approximated
+    qh = huge.get_model_states(name)
+    huge.add_cost_term("coupled", sumsqr(robot.get_global_link_position("end_effector_ball", qh[:, 0]) - robot.get_global_link_position("end_effector_ball", qh[:, 8])))
     with pytest.raises(LoweringError):
-        lower(big.build())  # refused loudly, never approximated
+        lower(huge.build())
 
 
 def test_figure_eight_builder_and_lowering():

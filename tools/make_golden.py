@@ -527,7 +527,39 @@ def fig8_ipm_extend(max_iter=12000, workers=6):
     np.savez(path, **g)
 
 
+def planner_golden():
+    """example/simple_joint_space_planner.py (nx = 280: what the generic tape family's limited-memory path is tested with): four goal poses solved by
+    oracle/ipm_reference_form.py on the literal layout (scipy SLSQP in the reference's wiring reports "inequality constraints incompatible" on this
+    problem and trust-constr meets a singular Jacobian -- the four quaternion rows of the final pose have rank three).  IPOPT's default bound
+    relaxation (1e-8): the stored optimum may sit sum|lam| 1e-8 ~ 1e-6 below the exactly feasible one.  (A tighter relaxation is no way to a
+    sharper golden: the multipliers of an (e, -e) pair grow like mu / relax, the scaled termination test of the method (s_d) then accepts
+    anything -- with 1e-11 the run "converges" at the solution of the first barrier problem, f = 0.7249 instead of 0.7007.)"""
+    from oracle.ipm_reference_form import solve_ipm
+    from oracle.problems import JointSpacePlannerNLP
+
+    med7 = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "med7.kin.json"))
+    nlp = JointSpacePlannerNLP(med7)
+    q0 = np.deg2rad([0, 45, 0, -90, 0, -45, 0])
+    rng = np.random.default_rng(SEED + 8)
+    P, X, F = [], [], []
+    for i in range(4):
+        qg = np.deg2rad([20, 55, -10, -70, 10, -40, 15]) if i == 0 else q0 + rng.uniform(-0.35, 0.35, 7)
+        p = np.concatenate([q0, q0, med7.get_global_link_position("lbr_link_ee", qg), med7.get_global_link_quaternion("lbr_link_ee", qg)])
+        r = solve_ipm(nlp, nlp.seed(q0), p)
+        # KKT of the reference form with the method's own multipliers (they reach 1e5 on the integration rows of this problem -- the acceleration
+        # cost carries 10 / dt^2 -- which is beyond what a least-squares fit of the multipliers resolves to 1e-6)
+        v, lam = nlp.v(r["x"], p), r["lam_v"]
+        stat = float(np.abs(nlp.df(r["x"], p) - nlp.dv(r["x"], p).T @ lam).max())
+        print("planner", i, r["status"], r["iters"], r["f"], "stationarity", stat, "min v", v.min(), "max lam", lam.max(), "g min", nlp.g(r["x"], p).min())
+        assert r["status"] == "optimal" and v.min() >= -1.01e-8 and stat <= 1e-6 * max(1.0, lam.max()) and lam.min() >= 0.0
+        P.append(p); X.append(r["x"]); F.append(r["f"])
+    np.savez(os.path.join(G, "planner_golden.npz"), p=np.array(P), x=np.array(X), f=np.array(F), q0=q0)
+
+
 if __name__ == "__main__":
+    if "--planner" in sys.argv:
+        planner_golden()
+        sys.exit(0)
     if "--ipm-extend" in sys.argv:
         fig8_ipm_extend()
         sys.exit(0)

@@ -43,65 +43,71 @@ class IntegrationResidual(Expr):
 
 
 class OptimizationBuilder:
+    """Same constructor arguments, block names and layout as the reference's builder (optas/builder.py:14-99); the bookkeeping is this
+    package's own: a name -> model table and one routine that lays a model's blocks down."""
+
     def __init__(self, T: int, robots: List[RobotModel] = [], tasks: List[TaskModel] = [], derivs_align: bool = False):
-        assert T > 0, f"T must be strictly positive"
-        if not isinstance(robots, list):
-            robots = [robots]
-        if not isinstance(tasks, list):
-            tasks = [tasks]
-        self.T = T
-        self._models = robots + tasks
-        self.derivs_align = derivs_align
-        if not derivs_align and len(self._models) > 0:
-            all_time_derivs = []
-            for m in self._models:
-                all_time_derivs += m.time_derivs
-            Tmin = max(all_time_derivs) + 1
-            assert T >= Tmin, f"T={T} is too low, it should be at least {Tmin}"
-        model_names = [m.get_name() for m in self._models]
-        assert len(model_names) == len(set(model_names)), "each model should have a unique name"
-        self._decision_variables = SXContainer()
-        self._parameters = SXContainer()
-        self._cost_terms = SXContainer()
-        self._lin_eq_constraints = SXContainer()
-        self._lin_ineq_constraints = SXContainer()
-        self._ineq_constraints = SXContainer()
-        self._eq_constraints = SXContainer()
-        for model in self._models:
-            for d in model.time_derivs:
-                n_s_x = model.state_optimized_name(d)
-                t = T - d if not derivs_align else T
-                if isinstance(model, RobotModel):
-                    self._decision_variables[n_s_x] = StateRef(n_s_x, model.get_name(), d, model.num_opt_joints, t)
-                    n_s_p = model.state_parameter_name(d)
-                    self.add_parameter(n_s_p, model.num_param_joints, t)
-                else:
-                    self._decision_variables[n_s_x] = StateRef(n_s_x, model.get_name(), d, model.dim, t)
-                    if model.is_discrete:
-                        self._decision_variables.variable_is_discrete(n_s_x)
+        self.T = int(T)
+        self.derivs_align = bool(derivs_align)
+        models = (robots if isinstance(robots, list) else [robots]) + (tasks if isinstance(tasks, list) else [tasks])
+        self._by_name = {}
+        for model in models:
+            assert model.get_name() not in self._by_name, f"two models are called '{model.get_name()}': names identify the blocks of x and p"
+            self._by_name[model.get_name()] = model
+        self._models = models
+        assert self.T >= 1, "the horizon needs at least one knot"
+        if not self.derivs_align:
+            # derivative d of a model lives on T - d knots: the highest one must keep at least one
+            deepest = max((d for model in models for d in model.time_derivs), default=0)
+            assert self.T > deepest, f"a horizon of {self.T} knots leaves none for the time derivative of order {deepest}"
+        self._decision_variables, self._parameters, self._cost_terms = SXContainer(), SXContainer(), SXContainer()
+        self._lin_eq_constraints, self._lin_ineq_constraints = SXContainer(), SXContainer()
+        self._eq_constraints, self._ineq_constraints = SXContainer(), SXContainer()
+        for model in models:
+            self._lay_down(model)
+
+    def _lay_down(self, model: Model) -> None:
+        """x (and, for robots, p) blocks of one model, derivative by derivative: "{name}/{d x 'd'}{symbol}/x" with dim rows and T - d columns (T with
+        derivs_align); a robot's parameterised joints get the matching ".../p" block, empty when every joint is optimised."""
+        robot = isinstance(model, RobotModel)
+        for order in model.time_derivs:
+            knots = self.T if self.derivs_align else self.T - order
+            label = model.state_optimized_name(order)
+            self._decision_variables[label] = StateRef(label, model.get_name(), order, model.num_opt_joints if robot else model.dim, knots)
+            if robot:
+                self.add_parameter(model.state_parameter_name(order), model.num_param_joints, knots)
+            elif model.is_discrete:
+                self._decision_variables.variable_is_discrete(label)
 
     # ---- models ------------------------------------------------------------------------------------------
     def get_model_names(self) -> List[str]:
-        return [model.name for model in self._models]
+        return list(self._by_name)
 
     def get_model_index(self, name: str) -> int:
         return self.get_model_names().index(name)
 
     def get_model(self, name: str) -> Model:
-        return self._models[self.get_model_index(name)]
+        if name not in self._by_name:
+            raise ValueError(f"'{name}' is not in list")  # what list.index raises in the reference (builder.py:107-118)
+        return self._by_name[name]
+
+    def _block(self, container: SXContainer, name: str, order: int, label_of):
+        model = self.get_model(name)
+        assert order in model.time_derivs, f"'{name}' carries the time derivatives {list(model.time_derivs)}, not order {order}"
+        return container[label_of(model)(order)]
 
     def get_model_states(self, name: str, time_deriv: int = 0) -> StateRef:
-        model = self.get_model(name)
-        assert time_deriv in model.time_derivs, f"model '{name}', was not specified with time derivative to order {time_deriv}"
-        return self._decision_variables[model.state_optimized_name(time_deriv)]
+        return self._block(self._decision_variables, name, time_deriv, lambda m: m.state_optimized_name)
 
     def get_model_state(self, name: str, t: int, time_deriv: int = 0) -> StateRef:
         return self.get_model_states(name, time_deriv)[:, t]
 
     def get_model_parameters(self, name: str, time_deriv: int = 0) -> ParamRef:
-        model = self.get_model(name)
-        assert time_deriv in model.time_derivs, f"model '{name}', was not specified with time derivative to order {time_deriv}"
-        return self._parameters[model.state_parameter_name(time_deriv)]
+        return self._block(self._parameters, name, time_deriv, lambda m: m.state_parameter_name)
+
+    def get_model_parameter(self, name: str, t: int, time_deriv: int = 0):
+        """builder.py:165-176: column t of the parameter block of a model's (parameterised joints') states."""
+        return self.get_model_parameters(name, time_deriv)[:, t]
 
     # ---- variables / parameters / terms ------------------------------------------------------------------
     def get_robot_states_and_parameters(self, name: str, time_deriv: int = 0):

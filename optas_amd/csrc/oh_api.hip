@@ -1087,7 +1087,7 @@ static void fill_params(oh_handle* h) {
   P.np = d.ndof + (h->have_guards ? h->guards.n_links + 4 * h->guards.n_obstacles : 0);
   if (h->chain_host.has_lead) P.np = d.ndof + 1 + d.T;
   // coupling folded into evaluation and sweep (no k_couple launch): the plain orientation-locked handles, i.e. the batched path of config 2
-  P.zc = (h->fuse_couple && d.lock_orientation && !h->have_guards && !h->chain_host.has_lead && oh_eval_is_split()) ? 1 : 0;
+  P.zc = (h->fuse_couple && d.lock_orientation && !h->have_guards && !h->chain_host.has_lead) ? 1 : 0;
 }
 
 extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt,
@@ -1240,7 +1240,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       }
       // (k_carry_* park 22 per-instance scalars in the first rows of the spare Dr slot: T x NZ(NZ+1)/2 rows must hold them)
       const bool carry_fits = (size_t)h->desc.T * ((N - 3) * (N - 2) / 2) >= 22;
-      if (h->compaction && h->compact_carry && carry_fits && oh_eval_is_split() && h->P.lock && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
+      if (h->compaction && h->compact_carry && carry_fits && h->P.lock && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
         carry_pending = nrun;  // done after the next k_retract
       } else if (h->compaction && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac_restart * (double)h->D.B) {
         // restart compaction: the survivors' accepted knots (and, with inequality rows, their multipliers and outer-loop state) are laid
@@ -1805,7 +1805,7 @@ extern "C" int oh_get_constants(oh_handle* h, oh_chain* out) {
 }
 
 static bool spec_applies(const oh_handle* h) {
-  return h->desc.kind == OH_PROBLEM_FIGURE_EIGHT && h->have_chain && h->desc.lock_orientation && !h->have_guards && !h->chain_host.has_lead && oh_eval_is_split();
+  return h->desc.kind == OH_PROBLEM_FIGURE_EIGHT && h->have_chain && h->desc.lock_orientation && !h->have_guards && !h->chain_host.has_lead;
 }
 static int specialize_fk(oh_handle* h) {
   if (h->fk_spec) return OH_OK;

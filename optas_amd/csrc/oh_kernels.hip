@@ -121,15 +121,11 @@ template <int N>
 __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const double* __restrict__ x0, const double* __restrict__ pin) {
   setup_unit<N>(P, D, x0, pin, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
 }
-// Blocks per CU of k_eval: with the six-row retraction the kernel needs ~360 live registers in its loop; at 2 waves/SIMD (256) it
-// spills 99 of them and runs 10 % slower than at 1 wave/SIMD with none (A/B on one box: 64.1 vs 57.8 ms per bench step).
+// Blocks per CU of the fused evaluation kernels (lead-joint and guarded variants): with the six-row retraction the fused kernel needs ~360
+// live registers in its loop; at 2 waves/SIMD (256) it spills 99 of them and runs 10 % slower than at 1 wave/SIMD with none.
 #ifndef OH_EVAL_WAVES
 #define OH_EVAL_WAVES 1
 #endif
-template <int N>
-__global__ __launch_bounds__(256, OH_EVAL_WAVES) void k_eval(FigParams P, FigBuffers D, const int slot) {
-  eval_unit<N>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
-}
 // The same knot in two launches, each at two waves per SIMD (see EVAL_RETRACT_ONLY / EVAL_ONLY in oh_figure8.h): k_retract leaves the
 // retracted trial knot in the slot, k_evalb evaluates it.  One kinematics pass more than fused, both kernels without the register
 // overflow of the fused loop.
@@ -528,16 +524,12 @@ static void launch_setup_t(hipStream_t s, const FigParams& P, const FigBuffers& 
 template <int N>
 static void launch_eval_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot, int part) {
   // part 0: the whole evaluation; 1: k_retract only; 2: k_evalb only (the compaction that carries the trial along sits between them)
-#if defined(OH_EVAL_FUSED)
-  if (part != 2) hipLaunchKernelGGL(k_eval<N>, dim3((D.B + 255) / 256, P.T - P.t0), dim3(256), 0, s, P, D, slot);
-#else
   const dim3 ge((D.B + 255) / 256, P.T - P.t0);
   if (part != 2) hipLaunchKernelGGL(k_retract<N>, ge, dim3(256), 0, s, P, D, slot);
   if (part != 1) {
     if (P.zc) hipLaunchKernelGGL(k_evalb_zc<N>, dim3((((D.B + 255) / 256) + 7) / 8 * 8 * (P.T - P.t0)), dim3(256), 0, s, P, D, slot);
     else hipLaunchKernelGGL(k_evalb<N>, ge, dim3(256), 0, s, P, D, slot);
   }
-#endif
 }
 template <int N>
 static void launch_carry_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {
@@ -587,13 +579,6 @@ bool oh_launch_eval(hipStream_t s, int n, const FigParams& P, const FigBuffers& 
   OH_DISPATCH_N(n, C)
 #undef C
   return true;
-}
-bool oh_eval_is_split() {  // false in the -DOH_EVAL_FUSED ablation build: the compaction between the two launches needs them
-#if defined(OH_EVAL_FUSED)
-  return false;
-#else
-  return true;
-#endif
 }
 bool oh_launch_carry(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {
 #define C(NN) launch_carry_t<NN>(s, P, D, phase, Bnew, slot)

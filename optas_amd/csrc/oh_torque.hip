@@ -46,6 +46,63 @@ OH_DEV void sincosT(const Dual x, Dual* s, Dual* c) {
   *c = {cv, -sv * x.d};
 }
 
+// ---- one primal, three tangents (round 3) --------------------------------------------------------------------------------------------
+// k_tq_eval used to run the recursion once per tangent direction (21 lanes per unit, each carrying the primal: 63 primal-equivalents).  A
+// lane now owns one JOINT j and carries the tangents with respect to q_j, dq_j and ddq_j next to one primal.  What depends on the joint
+// angles alone -- sines, cosines, the joint rotations, the joint axes in their body frames -- has a single tangent (DualR); the velocities,
+// accelerations and wrenches have all three (Dual3); the products between the two classes never form the two tangents that are zero by
+// construction.  Per unit: 7 lanes x (1 primal + ~4 tangent-equivalents) instead of 21 x 3.
+struct DualR {
+  double v, d;  // d / d q_j
+};
+struct Dual3 {
+  double v, d0, d1, d2;  // d / d q_j, d / d dq_j, d / d ddq_j
+};
+OH_DEV DualR operator+(const DualR a, const DualR b) { return {a.v + b.v, a.d + b.d}; }
+OH_DEV DualR operator-(const DualR a, const DualR b) { return {a.v - b.v, a.d - b.d}; }
+OH_DEV DualR operator*(const DualR a, const DualR b) { return {a.v * b.v, fma(a.v, b.d, a.d * b.v)}; }
+OH_DEV DualR operator+(const DualR a, const double b) { return {a.v + b, a.d}; }
+OH_DEV DualR operator+(const double a, const DualR b) { return {a + b.v, b.d}; }
+OH_DEV DualR operator-(const DualR a, const double b) { return {a.v - b, a.d}; }
+OH_DEV DualR operator-(const double a, const DualR b) { return {a - b.v, -b.d}; }
+OH_DEV DualR operator*(const DualR a, const double b) { return {a.v * b, a.d * b}; }
+OH_DEV DualR operator*(const double a, const DualR b) { return {a * b.v, a * b.d}; }
+OH_DEV DualR operator-(const DualR a) { return {-a.v, -a.d}; }
+OH_DEV Dual3 operator+(const Dual3 a, const Dual3 b) { return {a.v + b.v, a.d0 + b.d0, a.d1 + b.d1, a.d2 + b.d2}; }
+OH_DEV Dual3 operator-(const Dual3 a, const Dual3 b) { return {a.v - b.v, a.d0 - b.d0, a.d1 - b.d1, a.d2 - b.d2}; }
+OH_DEV Dual3 operator*(const Dual3 a, const Dual3 b) {
+  return {a.v * b.v, fma(a.v, b.d0, a.d0 * b.v), fma(a.v, b.d1, a.d1 * b.v), fma(a.v, b.d2, a.d2 * b.v)};
+}
+OH_DEV Dual3 operator*(const DualR a, const Dual3 b) { return {a.v * b.v, fma(a.v, b.d0, a.d * b.v), a.v * b.d1, a.v * b.d2}; }
+OH_DEV Dual3 operator*(const Dual3 a, const DualR b) { return b * a; }
+OH_DEV Dual3 operator+(const Dual3 a, const DualR b) { return {a.v + b.v, a.d0 + b.d, a.d1, a.d2}; }
+OH_DEV Dual3 operator+(const DualR a, const Dual3 b) { return b + a; }
+OH_DEV Dual3 operator-(const Dual3 a, const DualR b) { return {a.v - b.v, a.d0 - b.d, a.d1, a.d2}; }
+OH_DEV Dual3 operator-(const DualR a, const Dual3 b) { return {a.v - b.v, a.d - b.d0, -b.d1, -b.d2}; }
+OH_DEV Dual3 operator+(const Dual3 a, const double b) { return {a.v + b, a.d0, a.d1, a.d2}; }
+OH_DEV Dual3 operator+(const double a, const Dual3 b) { return {a + b.v, b.d0, b.d1, b.d2}; }
+OH_DEV Dual3 operator-(const Dual3 a, const double b) { return {a.v - b, a.d0, a.d1, a.d2}; }
+OH_DEV Dual3 operator-(const double a, const Dual3 b) { return {a - b.v, -b.d0, -b.d1, -b.d2}; }
+OH_DEV Dual3 operator*(const Dual3 a, const double b) { return {a.v * b, a.d0 * b, a.d1 * b, a.d2 * b}; }
+OH_DEV Dual3 operator*(const double a, const Dual3 b) { return {a * b.v, a * b.d0, a * b.d1, a * b.d2}; }
+OH_DEV Dual3 operator-(const Dual3 a) { return {-a.v, -a.d0, -a.d1, -a.d2}; }
+OH_DEV void sincosT(const DualR x, DualR* s, DualR* c) {
+  double sv, cv;
+  sincos_joint(x.v, &sv, &cv);
+  *s = {sv, cv * x.d};
+  *c = {cv, -sv * x.d};
+}
+
+// scalar class of what depends on the joint angles alone, given the class of the velocities / accelerations / wrenches
+template <class S>
+struct RotOf {
+  using T = S;
+};
+template <>
+struct RotOf<Dual3> {
+  using T = DualR;
+};
+
 template <class A, class B>
 struct Prom {
   using T = Dual;
@@ -54,6 +111,14 @@ template <>
 struct Prom<double, double> {
   using T = double;
 };
+template <> struct Prom<DualR, DualR> { using T = DualR; };
+template <> struct Prom<DualR, double> { using T = DualR; };
+template <> struct Prom<double, DualR> { using T = DualR; };
+template <> struct Prom<Dual3, Dual3> { using T = Dual3; };
+template <> struct Prom<Dual3, double> { using T = Dual3; };
+template <> struct Prom<double, Dual3> { using T = Dual3; };
+template <> struct Prom<Dual3, DualR> { using T = Dual3; };
+template <> struct Prom<DualR, Dual3> { using T = Dual3; };
 template <class A, class B>
 OH_DEV void crossT(const A* a, const B* b, typename Prom<A, B>::T* o) {
   o[0] = a[1] * b[2] - a[2] * b[1];
@@ -91,9 +156,9 @@ OH_DEV void joint_rotation(const double* R0, const double* a, const S s, const S
 // RobotModel.rnea (models.py:1819-1880) on scalars S (double or Dual): NB bodies, the last one on a fixed joint.
 // The loops over the bodies are kept rolled (the per-body wrenches f, nn and sin/cos live in lane-private memory, indexed by the
 // loop counter): unrolled, the dual-number recursion needs ~1500 live registers and the compiler spills two thirds of them.
-template <int NB, class S>
-OH_DEV void rnea_forward_body(const oh_dynamics* __restrict__ dy, const int i, const bool moving, const S qi, const S qdi, const S qddi, S (&om)[3],
-                              S (&omD)[3], S (&vD)[3], S* __restrict__ fi, S* __restrict__ ni, S& sji, S& cji) {
+template <int NB, class S, class SR = typename RotOf<S>::T>
+OH_DEV void rnea_forward_body(const oh_dynamics* __restrict__ dy, const int i, const bool moving, const SR qi, const S qdi, const S qddi, S (&om)[3],
+                              S (&omD)[3], S (&vD)[3], S* __restrict__ fi, S* __restrict__ ni, SR& sji, SR& cji) {
   S omi[3], omDi[3], vDi[3];
   S t1[3], t2[3], t3[3], acc[3];
   crossT(omD, dy->xyz[i], t1);
@@ -102,10 +167,11 @@ OH_DEV void rnea_forward_body(const oh_dynamics* __restrict__ dy, const int i, c
 #pragma unroll
   for (int k = 0; k < 3; ++k) acc[k] = vD[k] + t1[k] + t3[k];
   if (moving) {
-    S Rp[9];
+    SR Rp[9];
     sincosT(qi, &sji, &cji);
     joint_rotation(dy->R0[i], dy->axis[i], sji, cji, Rp);
-    S a[3], omp[3], omDp[3];
+    SR a[3];
+    S omp[3], omDp[3];
     mTvT(Rp, dy->axis[i], a);  // iaxisi
     mTvT(Rp, om, omp);
     mTvT(Rp, omD, omDp);
@@ -141,9 +207,10 @@ OH_DEV void rnea_forward_body(const oh_dynamics* __restrict__ dy, const int i, c
   }
 }
 
-template <int NB, class S>
-OH_DEV void rnea_lit(const oh_dynamics* __restrict__ dy, const S (&q)[NB - 1], const S (&qd)[NB - 1], const S (&qdd)[NB - 1], S (&tau)[NB - 1]) {
-  S f[NB][3], nn[NB][3], sj[NB], cj[NB];
+template <int NB, class S, class SR = typename RotOf<S>::T>
+OH_DEV void rnea_lit(const oh_dynamics* __restrict__ dy, const SR (&q)[NB - 1], const S (&qd)[NB - 1], const S (&qdd)[NB - 1], S (&tau)[NB - 1]) {
+  S f[NB][3], nn[NB][3];
+  SR sj[NB], cj[NB];
   S om[3], omD[3], vD[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -153,7 +220,7 @@ OH_DEV void rnea_lit(const oh_dynamics* __restrict__ dy, const S (&q)[NB - 1], c
   }
 #pragma unroll 1
   for (int i = 0; i < NB - 1; ++i) rnea_forward_body<NB, S>(dy, i, true, q[i], qd[i], qdd[i], om, omD, vD, f[i], nn[i], sj[i], cj[i]);
-  rnea_forward_body<NB, S>(dy, NB - 1, false, S{}, S{}, S{}, om, omD, vD, f[NB - 1], nn[NB - 1], sj[NB - 1], cj[NB - 1]);
+  rnea_forward_body<NB, S>(dy, NB - 1, false, SR{}, S{}, S{}, om, omD, vD, f[NB - 1], nn[NB - 1], sj[NB - 1], cj[NB - 1]);
   // backward (models.py:1858-1880); the reference's fs/ns lists carry a leading zero entry: fs[i] == f[i-1]
   S ifi[3] = {f[NB - 1][0], f[NB - 1][1], f[NB - 1][2]};
   S ini[3], t1[3];
@@ -164,7 +231,7 @@ OH_DEV void rnea_lit(const oh_dynamics* __restrict__ dy, const S (&q)[NB - 1], c
   for (int i = NB - 1; i >= 1; --i) {
     S a1[3], a2[3], a3[3], a4[3];
     if (i < NB - 1) {
-      S pRi[9];
+      SR pRi[9];
       joint_rotation(dy->R0[i], dy->axis[i], sj[i], cj[i], pRi);
       mvT(pRi, ini, a1);
       mvT(pRi, ifi, a3);
@@ -179,7 +246,7 @@ OH_DEV void rnea_lit(const oh_dynamics* __restrict__ dy, const S (&q)[NB - 1], c
       ini[k] = nn[i - 1][k] + a1[k] + a2[k] + a4[k];
       ifi[k] = a3[k] + f[i - 1][k];
     }
-    S pR[9], ax[3];
+    SR pR[9], ax[3];
     joint_rotation(dy->R0[i - 1], dy->axis[i - 1], sj[i - 1], cj[i - 1], pR);
     mTvT(pR, dy->axis[i - 1], ax);  // pRi^T axis
     tau[i - 1] = ini[0] * ax[0] + ini[1] * ax[1] + ini[2] * ax[2];
@@ -432,6 +499,186 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL_WAVES) void k_tq_eval(TqParams P, Tq
         if (i == d) tvd = tau[i].v;
       sr[256 + d] = tvd;
     }
+  }
+}
+
+// The same evaluation with one lane per (instance, knot, JOINT): 9 units x 7 joints per wavefront.  Lane j runs the recursion once on
+// (DualR, Dual3) scalars seeded with q_j, dq_j and ddq_j, so it ends up with columns j, N + j and 2 N + j of d tau / d z; the link position
+// adds column j of its Jacobian.  The columns meet in LDS as before and every lane writes ITS THREE columns of the packed stage block.
+// Same arithmetic per entry as k_tq_eval (sums over the 7 torque rows in the same order), so the two agree to rounding; bound: f64 FMA.
+#ifndef OH_TQ_EVAL3_WAVES
+#define OH_TQ_EVAL3_WAVES 1
+#endif
+template <int N>
+__global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, TqBuffers D) {
+  constexpr int NZ = 3 * N;
+  constexpr int UPW = 64 / N;  // units per wavefront (9)
+  __shared__ double tile[UPW][N + 3][NZ + 1];
+  const int T = P.T;
+  const int lane = threadIdx.x;
+  if (blockIdx.x == 0 && lane == 0) *D.n_running = 0;  // k_tq_step, next in the stream, counts the instances that go on
+  int ul = lane / N, j = lane - ul * N;
+  const bool lane_ok = ul < UPW;
+  if (!lane_ok) {  // lane 63 has no unit: it rides along on the last unit and keeps its hands off the tile
+    ul = UPW - 1;
+    j = N - 1;
+  }
+  const long long n_units = (long long)D.n_run * T;
+  long long unit = (long long)blockIdx.x * UPW + ul;
+  bool active = lane_ok && unit < n_units;
+  if (unit >= n_units) unit = n_units - 1;
+  const int li = (int)(unit / T), t = (int)(unit - (long long)li * T);
+  const int b = D.list[li];
+  if (D.status[b] >= 0) active = false;
+  if (!__any(active)) return;
+  const int ts = 1 - D.cur[b];
+  const double* xr = D.xs + xs_off(D, T, ts, b, t);
+  const bool outer = D.outer[b] != 0;
+  const double rho_old = D.rho[b];
+  const double rho = outer ? D.rho_next[b] : rho_old;
+
+  DualR q[N];
+  Dual3 qd[N], qdd[N], tau[N];
+  double qv[N], dqv[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double one = (k == j) ? 1.0 : 0.0;
+    qv[k] = xr[k];
+    dqv[k] = xr[8 + k];
+    q[k] = {qv[k], one};
+    qd[k] = {dqv[k], 0.0, one, 0.0};
+    qdd[k] = {xr[16 + k], 0.0, 0.0, one};
+  }
+  rnea_lit<N + 1, Dual3>(D.dyn, q, qd, qdd, tau);
+
+  // effort rows through the augmented Lagrangian (every lane of the unit computes them: they are cheap and everyone needs cw, dw)
+  double* lm = D.lam + ((size_t)b * T + t) * TQ_LAM;
+  double cw[N], dw[N];
+  double psi = 0.0, meas = 0.0, viol = 0.0, cmpl = 0.0, tau2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double tv = tau[i].v;
+    const double g_lo = tv - P.tau_lo[i], g_up = P.tau_up[i] - tv;
+    double l_lo = lm[i], l_up = lm[N + i];
+    if (outer) {
+      l_lo = fmax(0.0, l_lo - rho_old * g_lo);
+      l_up = fmax(0.0, l_up - rho_old * g_up);
+    }
+    const double s_lo = fmax(0.0, l_lo - rho * g_lo), s_up = fmax(0.0, l_up - rho * g_up);
+    psi += (s_lo * s_lo - l_lo * l_lo) / (2.0 * rho) + (s_up * s_up - l_up * l_up) / (2.0 * rho);
+    meas = fmax(meas, fmax(fabs(fmin(g_lo, l_lo / rho)), fabs(fmin(g_up, l_up / rho))));
+    viol = fmax(viol, fmax(-g_lo, -g_up));
+    cmpl = fmax(cmpl, fmax(fabs(s_lo * g_lo), fabs(s_up * g_up)));
+    cw[i] = 2.0 * P.w_tau * tv - s_lo + s_up;
+    dw[i] = 2.0 * P.w_tau + rho * ((s_lo > 0.0 ? 1.0 : 0.0) + (s_up > 0.0 ? 1.0 : 0.0));
+    tau2 += tv * tv;
+    if (outer && active && j == 0) {  // (after every lane of the wavefront has read the old values: lanes run in lock step, the reads above precede this store)
+      lm[i] = l_lo;
+      lm[N + i] = l_up;
+    }
+  }
+
+  // link position and column j of its Jacobian (models.py:826-868, 1211-1264)
+  double R[9], pp[3], z[N][3], pj[N][3];
+  fk_chain<N>(D.chain, qv, R, pp, z, pj);
+  double e[3], tv3[3];
+  mv3(R, D.chain->p_tool, tv3);
+  const double* gl = D.goal + ((size_t)b * T + t) * 4;
+  double r[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    e[k] = pp[k] + tv3[k];
+    r[k] = e[k] - gl[k];
+  }
+  double zd[3] = {0.0, 0.0, 0.0}, pd[3] = {0.0, 0.0, 0.0};
+  int jt_d = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (k == j) {
+      zd[0] = z[k][0]; zd[1] = z[k][1]; zd[2] = z[k][2];
+      pd[0] = pj[k][0]; pd[1] = pj[k][1]; pd[2] = pj[k][2];
+      jt_d = D.chain->jtype[k];
+    }
+  double jp[3];
+  if (jt_d == 0) {
+    const double dd[3] = {e[0] - pd[0], e[1] - pd[1], e[2] - pd[2]};
+    cross3(zd, dd, jp);
+  } else {
+    jp[0] = zd[0]; jp[1] = zd[1]; jp[2] = zd[2];
+  }
+
+  // gradient components j, N + j, 2 N + j of the stage cost
+  double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    g0 = fma(cw[i], tau[i].d0, g0);
+    g1 = fma(cw[i], tau[i].d1, g1);
+    g2 = fma(cw[i], tau[i].d2, g2);
+  }
+  g0 += 2.0 * P.w_path * dot3(jp, r);
+  double dqj = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (k == j) dqj = dqv[k];
+  g1 += 2.0 * P.w_vel * dqj;
+
+  // exchange the columns through LDS; the link position has no dq / ddq columns
+  if (lane_ok) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      tile[ul][i][j] = tau[i].d0;
+      tile[ul][i][N + j] = tau[i].d1;
+      tile[ul][i][2 * N + j] = tau[i].d2;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      tile[ul][N + k][j] = jp[k];
+      tile[ul][N + k][N + j] = 0.0;
+      tile[ul][N + k][2 * N + j] = 0.0;
+    }
+  }
+  __syncthreads();
+  double* sr = D.st + st_off(D, T, ts, b, t);
+  if (active) {
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3) {
+      const int d = c3 * N + j;
+      double col[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) col[i] = c3 == 0 ? tau[i].d0 : (c3 == 1 ? tau[i].d1 : tau[i].d2);
+      for (int rr = d; rr < NZ; ++rr) {
+        double hv = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) hv = fma(dw[i] * tile[ul][i][rr], col[i], hv);
+        if (c3 == 0) {
+          double hp = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) hp = fma(tile[ul][N + k][rr], jp[k], hp);
+          hv = fma(2.0 * P.w_path, hp, hv);
+        }
+        if (rr == d && c3 == 1) hv += 2.0 * P.w_vel;
+        sr[rr * (rr + 1) / 2 + d] = hv;
+      }
+    }
+    sr[231 + j] = g0;
+    sr[231 + N + j] = g1;
+    sr[231 + 2 * N + j] = g2;
+    if (j == 0) {
+      double dq2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) dq2 = fma(dqv[k], dqv[k], dq2);
+      const double phi_true = P.w_path * dot3(r, r) + P.w_vel * dq2 + P.w_tau * tau2;
+      sr[252] = phi_true + psi;
+      sr[253] = phi_true;
+      sr[254] = meas;
+      sr[255] = viol;
+      sr[263] = cmpl;
+    }
+    double tvd = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (i == j) tvd = tau[i].v;
+    sr[256 + j] = tvd;
   }
 }
 
@@ -923,7 +1170,12 @@ void oh_launch_tq_list(hipStream_t s, const TqBuffers& D) { hipLaunchKernelGGL(k
 bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D) {
   if (P.N != 7) return false;
   const long long units = (long long)D.n_run * P.T;
-  hipLaunchKernelGGL(k_tq_eval<7>, dim3((unsigned)((units + 2) / 3)), dim3(64), 0, s, P, D);
+  static const int per_joint = [] { const char* e = getenv("OH_TQ_EVAL3"); return e ? atoi(e) : 1; }();  // 0: one lane per tangent direction (round 2)
+  // small launches are latency bound: there the round-2 kernel, which spreads a unit over 21 lanes with a third of the tangent work each, has the
+  // shorter dependent chain (one instance: 170 against 190 us per evaluation); from a few thousand units on the per-joint kernel wins (1024
+  // instances 369 -> 260 us, 8192 instances 2.73 -> 1.77 ms)
+  if (per_joint && (per_joint > 1 || units >= 4096)) hipLaunchKernelGGL(k_tq_eval3<7>, dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
+  else hipLaunchKernelGGL(k_tq_eval<7>, dim3((unsigned)((units + 2) / 3)), dim3(64), 0, s, P, D);
   return true;
 }
 bool oh_launch_tq_step(hipStream_t s, const TqParams& P, const TqBuffers& D) {
@@ -950,7 +1202,8 @@ bool kernel_info(K kernel, int block, OhKernelInfo* out) {
 }  // namespace
 bool oh_kernel_info_torque(const char* name, OhKernelInfo* out) {
   const std::string n(name);
-  if (n == "k_tq_eval") return kernel_info(k_tq_eval<7>, 64, out);
+  if (n == "k_tq_eval") return kernel_info(k_tq_eval3<7>, 64, out);
+  if (n == "k_tq_eval_directions") return kernel_info(k_tq_eval<7>, 64, out);
   if (n == "k_tq_step") return kernel_info(k_tq_step<7>, 64, out);
   return false;
 }

@@ -177,43 +177,6 @@ def test_chain_folding_matches_oracle():
         robot.kinematic_chain("no_such_link")
 
 
-def test_manager_template_counts_and_times_solves():
-    """optas/templates.py:10-105: the caller of Solver.solve (what calls it: Manager._solve, :55-58)."""
-    from optas_amd.templates import Manager
-
-    class FakeSolver:
-        def __init__(self):
-            self.calls = 0
-
-        def solve(self):
-            self.calls += 1
-            return {"x": self.calls}
-
-    class M(Manager):
-        def setup_solver(self):
-            return FakeSolver()
-
-        def is_ready(self):
-            return True
-
-        def reset(self):
-            pass
-
-        def get_target(self):
-            return self.solution["x"]
-
-    m = M()
-    assert m.is_first_solve() and m.config == {} and m.get_solver_duration() is None
-    m.solve()
-    assert not m.is_first_solve() and m.get_target() == 1 and m.get_solver_duration() is None  # not recorded unless asked
-    t = M(record_solver_perf=True)
-    t.solve()
-    t.solve()
-    assert t.num_solves == 2 and t.get_target() == 2 and t.get_solver_duration() >= 0.0
-    with pytest.raises(TypeError):
-        Manager()  # abstract
-
-
 def test_batched_container_conversions_match_the_scalar_ones():
     from optas_amd.expr import ParamRef
     from optas_amd.sx_container import SXContainer

@@ -123,12 +123,15 @@ def timed_with_results(be, x0, p, reps=2, sample=0, seed=0):
     return r, smp
 
 
-def run_configs(sample=8, torque_batches=(8192, 1024)):
+def run_configs(sample=8, torque_batches=(8192, 1024), only=None):
     """BASELINE configs 1, 3, 4, 5 at their stated sizes: device time of one batched solve (HIP events, inputs resident), convergence, and an
     oracle-graded sample of each -- what bench.py prints as its `configs` block."""
     rng = np.random.default_rng(SEED)
     out = {}
     kuka = RobotModel.builtin("kuka_lwr")
+    if only == "torque":
+        rng = np.random.default_rng(SEED + 5)
+        return _torque(out, rng, sample, torque_batches)
     # config 1
     B = 65536
     be = IKBackend(kuka.kinematic_chain("end_effector_ball"), kuka.lower_actuated_joint_limits, kuka.upper_actuated_joint_limits, max_iter=300)
@@ -191,6 +194,10 @@ def run_configs(sample=8, torque_batches=(8192, 1024)):
                                                         "(a dual-arm instance = two of them)", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
                                                "oracle_sample": oracle_grade("guarded_arm", T=T, links=SPHERE_LINKS, offsets=offs.T, **smp) if smp else None}
         be.close()
+    return _torque(out, rng, sample, torque_batches)
+
+
+def _torque(out, rng, sample, torque_batches):
     # config 5
     med7 = RobotModel.builtin("med7")
     link, T, dt = "lbr_link_ee", 30, 0.1

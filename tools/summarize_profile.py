@@ -19,11 +19,11 @@ import sqlite3
 import subprocess
 import sys
 
-NAMES = ("k_tail", "k_tq_eval", "k_tq_step", "k_tq_setup", "k_tq_finalize", "k_tq_list", "k_retract", "k_evalb", "k_eval", "k_couple", "k_step", "k_fk_jac", "k_setup", "k_finalize", "k_compact_gather", "k_compact_scatter", "k_carry_gather", "k_carry_scatter", "k_scan_count", "k_scan_offsets", "k_scan_assign")
+NAMES = ("k_tail", "k_tq_eval3", "k_tq_eval", "k_tq_step", "k_step_zc", "k_evalb_zc", "k_tq_setup", "k_tq_finalize", "k_tq_list", "k_retract", "k_evalb", "k_eval", "k_couple", "k_step", "k_fk_jac", "k_setup", "k_finalize", "k_compact_gather", "k_compact_scatter", "k_carry_gather", "k_carry_scatter", "k_scan_count", "k_scan_offsets", "k_scan_assign")
 
 
 # the run-time specialised kernels (optas_amd/csrc/oh_jit.hip) appear under their own names; they are the same kernels compiled for one chain
-SPEC = {"oh_spec_retract": "k_retract", "oh_spec_evalb": "k_evalb", "oh_spec_tail": "k_tail", "oh_spec_fk_soa": "k_fk_jac", "oh_spec_fk_aos": "k_fk_jac"}
+SPEC = {"oh_spec_retract": "k_retract", "oh_spec_evalb_zc": "k_evalb_zc", "oh_spec_evalb": "k_evalb", "oh_spec_tail": "k_tail", "oh_spec_fk_soa": "k_fk_jac", "oh_spec_fk_aos": "k_fk_jac"}
 
 
 def short(name: str) -> str:
@@ -123,11 +123,11 @@ def main(root, tag):
             w.writerow(["kernel", "calls", "total_us", "avg_us", "pct"])
             for name, calls, tot, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
                 w.writerow([short(name), calls, f"{tot:.1f}", f"{avg:.2f}", f"{pct:.2f}"])
-            pair = {n: (calls, tot) for n, calls, tot in ((short(n), c_, t_) for n, c_, t_, _, _ in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels")) if n in ("k_retract", "k_evalb")}
+            pair = {("k_evalb" if n == "k_evalb_zc" else n): (calls, tot) for n, calls, tot in ((short(n), c_, t_) for n, c_, t_, _, _ in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels")) if n in ("k_retract", "k_evalb", "k_evalb_zc")}
             if len(pair) == 2:
                 calls = pair["k_retract"][0]
                 tot = pair["k_retract"][1] + pair["k_evalb"][1]
-                w.writerow(["# k_eval = the pair k_retract + k_evalb (one evaluation of the trial knots; what bench.py times as k_eval)"])
+                w.writerow(["# k_eval = the pair k_retract + k_evalb[_zc] (one evaluation of the trial knots; what bench.py times as k_eval)"])
                 w.writerow(["k_eval (pair)", calls, f"{tot:.1f}", f"{tot / max(calls, 1):.2f}", ""])
             w.writerow([])
             w.writerow(["# per grid size (x dimension = instances still in the batch, or units for k_fk_jac)"])
@@ -170,9 +170,13 @@ def main(root, tag):
                 e["bytes_per_launch_raw"] = (fs + ws) * 1024.0
                 e["bytes_per_launch"] = (2.0 * fs + ws) * 1024.0
             summary[k] = e
+        if "k_step_zc" in summary and "k_step" not in summary:  # bench.py looks the sweep up as k_step whichever variant ran
+            summary["k_step"] = dict(summary["k_step_zc"], note="k_step_zc: the sweep with the coupling folded in")
+        if "k_evalb_zc" in summary and "k_evalb" not in summary:
+            summary["k_evalb"] = dict(summary["k_evalb_zc"], note="k_evalb_zc")
         if "k_eval" not in summary and "k_retract" in summary and "k_evalb" in summary:
             a, b = summary["k_retract"], summary["k_evalb"]
-            summary["k_eval"] = {k: (a[k] + b[k]) if a.get(k) is not None and b.get(k) is not None else None for k in a}
+            summary["k_eval"] = {k: (a[k] + b[k]) if isinstance(a.get(k), (int, float)) and isinstance(b.get(k), (int, float)) else None for k in a}
             summary["k_eval"]["note"] = "k_retract + k_evalb: the two launches of one trial-knot evaluation"
         json.dump(
             {"tag": tag, "note": "average per launch over the profiled bench run (all batch sizes the run went through); FETCH_SIZE doubled per MI355X_MICROARCH.md", "kernels": pmc, "summary": summary},

@@ -1171,10 +1171,10 @@ bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D) {
   if (P.N != 7) return false;
   const long long units = (long long)D.n_run * P.T;
   static const int per_joint = [] { const char* e = getenv("OH_TQ_EVAL3"); return e ? atoi(e) : 1; }();  // 0: one lane per tangent direction (round 2)
-  // small launches are latency bound: there the round-2 kernel, which spreads a unit over 21 lanes with a third of the tangent work each, has the
-  // shorter dependent chain (one instance: 170 against 190 us per evaluation); from a few thousand units on the per-joint kernel wins (1024
-  // instances 369 -> 260 us, 8192 instances 2.73 -> 1.77 ms)
-  if (per_joint && (per_joint > 1 || units >= 4096)) hipLaunchKernelGGL(k_tq_eval3<7>, dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
+  // (The round-2 kernel, one lane per tangent direction, has the shorter dependent chain on a latency-bound launch -- one instance: 170 against
+  // 190 us per evaluation -- but the two kernels round differently, and choosing by launch size would make an instance's iterates depend on how
+  // fast the rest of its batch drains: one kernel for every launch.  1024 instances 369 -> 260 us, 8192 instances 2.73 -> 1.77 ms per launch.)
+  if (per_joint) hipLaunchKernelGGL(k_tq_eval3<7>, dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
   else hipLaunchKernelGGL(k_tq_eval<7>, dim3((unsigned)((units + 2) / 3)), dim3(64), 0, s, P, D);
   return true;
 }

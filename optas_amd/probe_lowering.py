@@ -575,7 +575,10 @@ def probe_point_mass(opt, rng_seed: int = 12345, link: Optional[str] = None):
 def probe_multi_arm(opt, rng_seed: int = 12345, link: Optional[str] = None):
     """example/dual_arm.py:17-129 as shipped, behind the reference interface: one position-tracking problem per robot (q_0 fixed to a
     parameter, dq_0 free, Euler integration, path_t = p(link, qc) + offset_t), summed.  The arms are probed one at a time with the others held
-    at their fixed configuration.  Inequality rows (limits, sphere clearances) take the tree-matching route of optas_amd.lowering only."""
+    at their fixed configuration.  Round 3: the inequality rows of BASELINE configs[3] as stated -- enforce_model_limits (builder.py:471-509,
+    blocks "__{name}_model_limit_0___l/_r") and sphere_collision_avoidance_constraints (builder.py:366-417, rows
+    "sphere_col_avoid_{t}_{link}_{obstacle}", parameters "{link}_radii", "{obstacle}_position", "{obstacle}_radii") -- are recognised from their
+    labels, attributed to an arm numerically, read off k and g, and verified against them (_probe_arm_guards)."""
     from .lowering import ArmSpec, MultiArmSpec
 
     def no(msg):
@@ -584,8 +587,8 @@ def probe_multi_arm(opt, rng_seed: int = 12345, link: Optional[str] = None):
     models = list(opt.models or [])
     if len(models) < 2 or not all(hasattr(m, "urdf") for m in models):
         no("expected two or more robot models and nothing else")
-    if len(opt.eq_constraints) or len(opt.ineq_constraints) or len(opt.lin_ineq_constraints):
-        no("inequality / nonlinear equality rows are not lowered through this route")
+    if len(opt.eq_constraints):
+        no("nonlinear equality rows are not part of this family")
     names, T = [], None
     for m in models:
         if list(m.time_derivs) != [0, 1] or len(getattr(m, "param_joints", []) or []) != 0:
@@ -599,9 +602,11 @@ def probe_multi_arm(opt, rng_seed: int = 12345, link: Optional[str] = None):
     for r, sq, sd in zip(robots, shapes[0::2], shapes[1::2]):
         if sq != (r.ndof, T) or sd != (r.ndof, T - 1):
             no("all robots must share T and use derivs_align=False")
-    params = _nonempty_params(opt)
-    if len(params) != len(models) or [s for _, s in params] != [(r.ndof, 1) for r in robots]:
-        no(f"expected one initial-configuration parameter per robot, in the robots' order, found {params}")
+    params_all = _nonempty_params(opt)
+    guarded = len(opt.ineq_constraints) > 0 or len(opt.lin_ineq_constraints) > 0
+    params = params_all[: len(models)]  # the initial configurations come first (dual_arm.py:31-32 before any sphere parameter, builder.py:391-405)
+    if (not guarded and len(params_all) != len(models)) or [s for _, s in params] != [(r.ndof, 1) for r in robots]:
+        no(f"expected one initial-configuration parameter per robot, in the robots' order, found {params_all}")
     want = {}
     for m, r in zip(models, robots):
         want[f"__{m.get_name()}_fix_configuration_0_0__"] = (r.ndof, 1)
@@ -621,7 +626,27 @@ def probe_multi_arm(opt, rng_seed: int = 12345, link: Optional[str] = None):
 
     Qc = [np.tile(q, (T, 1)) for q in qcs]
     Zs = [np.zeros((T - 1, n)) for n in ns]
-    pc = np.concatenate(qcs)
+    poff, o = {}, 0
+    for k, v in opt.parameters.items():
+        m_, n_ = _shape(v)
+        poff[k] = (o, m_ * n_)
+        o += m_ * n_
+    np_total = o
+    # parameter vector with the initial configurations in place and every other parameter at a harmless value (radii 0.05, obstacles far away)
+    pc = np.zeros(np_total)
+    for (k, _), q in zip(params, qcs):
+        pc[poff[k][0] : poff[k][0] + q.size] = q
+    for k, _ in params_all[len(models):]:
+        a0, l0 = poff[k]
+        pc[a0 : a0 + l0] = 0.05 if l0 == 1 else 5.0 + np.arange(l0)
+    qc_slices = [slice(poff[k][0], poff[k][0] + q.size) for (k, _), q in zip(params, qcs)]
+
+    def pvec(qlist):
+        pv = pc.copy()
+        for sl, q in zip(qc_slices, qlist):
+            pv[sl] = q
+        return pv
+
     x0 = xvec(Qc, Zs)
     # ---- linear rows
     off, where = 0, {}
@@ -634,12 +659,11 @@ def probe_multi_arm(opt, rng_seed: int = 12345, link: Optional[str] = None):
     if not (dt > 0):
         no("could not read a positive dt off the integration rows")
     Qr, dQr = [rng.normal(size=(T, n)) for n in ns], [rng.normal(size=(T - 1, n)) for n in ns]
-    pr = rng.normal(size=pc.size)
-    rows, o = {}, 0
-    for m, n, Q, dQ in zip(models, ns, Qr, dQr):
-        rows[f"__{m.get_name()}_fix_configuration_0_0__"] = pr[o : o + n] - Q[0]
+    pr = pvec([rng.normal(size=n) for n in ns])
+    rows = {}
+    for m, n, Q, dQ, sl in zip(models, ns, Qr, dQr, qc_slices):
+        rows[f"__{m.get_name()}_fix_configuration_0_0__"] = pr[sl] - Q[0]
         rows[f"__integrate_model_states_{m.get_name()}_1__"] = -(Q[:-1] + dt * dQ - Q[1:]).reshape(-1)
-        o += n
     if np.abs(_vec(opt.a, xvec(Qr, dQr), pr) - np.concatenate([rows[k] for k, _ in lin])).max() > 1e-9:
         no("the linear equalities are not [qc - q_0; Euler integration with one uniform dt] per robot")
     # ---- costs, one arm at a time
@@ -708,10 +732,138 @@ def probe_multi_arm(opt, rng_seed: int = 12345, link: Optional[str] = None):
             pos = np.asarray(a.robot.get_global_link_position(a.link, Q.T)).reshape(3, T).T
             p_c = np.asarray(a.robot.get_global_link_position(a.link, q)).reshape(3)
             f_model += a.w_path * np.sum((pos - (p_c[None] + a.offsets)) ** 2) + a.w_vel * np.sum(dQ * dQ)
-        f_ref = float(_vec(opt.f, xvec(Qv, dQv), np.concatenate(q2))[0])
+        f_ref = float(_vec(opt.f, xvec(Qv, dQv), pvec(q2))[0])
         if abs(f_model - f_ref) > 1e-9 * max(1.0, abs(f_ref)):
             no("the summed cost does not match the per-arm models read off it")
+    if guarded:
+        _probe_arm_guards(opt, models, robots, arms, T, xvec, Qc, Zs, pvec, qcs, poff, [k for k, _ in params_all[len(models):]], rng, no)
     return MultiArmSpec(T, dt, arms)
+
+
+def _probe_arm_guards(opt, models, robots, arms, T, xvec, Qc, Zs, pvec, qcs, poff, extra_params, rng, no):
+    """Joint-limit blocks and sphere-clearance rows of a multi-arm problem, from labels and numbers only.  Fills arms[i].guards."""
+    from .lowering import GuardSpec
+
+    ns = [r.ndof for r in robots]
+    x0, p0 = xvec(Qc, Zs), pvec(qcs)
+    used_params = set()
+    # ---- joint limits: "__{name}_model_limit_0___l" = x - lo, "..._r" = up - x, each vec of an n x T block (builder.py:334-335, 471-509)
+    koff, o = {}, 0
+    for k, v in opt.lin_ineq_constraints.items():
+        m_, n_ = _shape(v)
+        koff[k] = (o, m_, n_)
+        o += m_ * n_
+    lims = [None] * len(models)
+    expected = set()
+    for i, m in enumerate(models):
+        lab = f"__{m.get_name()}_model_limit_0__"
+        if lab + "_l" in koff or lab + "_r" in koff:
+            if not (lab + "_l" in koff and lab + "_r" in koff) or koff[lab + "_l"][1:] != (ns[i], T) or koff[lab + "_r"][1:] != (ns[i], T):
+                no(f"robot '{m.get_name()}': joint limits need both blocks, n x T each")
+            expected |= {lab + "_l", lab + "_r"}
+            k0 = _vec(opt.k, np.zeros_like(x0), p0)
+            lo = -k0[koff[lab + "_l"][0] : koff[lab + "_l"][0] + ns[i] * T].reshape(T, ns[i])
+            up = k0[koff[lab + "_r"][0] : koff[lab + "_r"][0] + ns[i] * T].reshape(T, ns[i])
+            if np.abs(lo - lo[0]).max() > 0 or np.abs(up - up[0]).max() > 0 or not (lo[0] < up[0]).all():
+                no(f"robot '{m.get_name()}': the limit rows are not one bound pair per joint over the whole trajectory")
+            lims[i] = (lo[0].copy(), up[0].copy())
+    if set(koff) != expected:
+        no(f"linear inequality blocks other than the robots' joint limits: {sorted(set(koff) - expected)}")
+    if expected:
+        Qr = [rng.normal(size=(T, n)) for n in ns]
+        kr = _vec(opt.k, xvec(Qr, Zs), pvec([rng.normal(size=n) for n in ns]))
+        for i, m in enumerate(models):
+            if lims[i] is None:
+                continue
+            lab = f"__{m.get_name()}_model_limit_0__"
+            a0, b0 = koff[lab + "_l"][0], koff[lab + "_r"][0]
+            if (np.abs(kr[a0 : a0 + ns[i] * T].reshape(T, ns[i]) - (Qr[i] - lims[i][0][None])).max() > 1e-9
+                    or np.abs(kr[b0 : b0 + ns[i] * T].reshape(T, ns[i]) - (lims[i][1][None] - Qr[i])).max() > 1e-9):
+                no(f"robot '{m.get_name()}': the limit rows are not [Q - lo; up - Q]")
+    # ---- sphere clearances: "sphere_col_avoid_{t}_{link}_{obstacle}", one scalar row each (builder.py:407-415)
+    glabels = list(opt.ineq_constraints.keys())
+    sph = [dict() for _ in models]
+    if glabels:
+        g0 = _vec(opt.g, x0, p0)
+        if g0.size != len(glabels):
+            no("the nonlinear inequality rows are not scalar rows")
+        owner = np.full(len(glabels), -1)
+        for i in range(len(models)):  # which arm does a row belong to?  Move that arm alone and see which rows answer
+            Qs = list(Qc)
+            Qs[i] = Qc[i] + rng.uniform(-0.3, 0.3, Qc[i].shape)
+            moved = np.abs(_vec(opt.g, xvec(Qs, Zs), p0) - g0) > 1e-12
+            if (owner[moved] >= 0).any():
+                no("a sphere row depends on two robots")
+            owner[moved] = i
+        if (owner < 0).any():
+            no("an inequality row depends on no robot's configuration")
+        for r_, lab in enumerate(glabels):
+            i = int(owner[r_])
+            pre = "sphere_col_avoid_"
+            if not lab.startswith(pre):
+                no(f"inequality '{lab}' is not a sphere-clearance row")
+            t_s, _, rest = lab[len(pre):].partition("_")
+            hit = None
+            for ln in sorted(robots[i].link_names, key=len, reverse=True):
+                if rest.startswith(ln + "_"):
+                    hit = (ln, rest[len(ln) + 1:])
+                    break
+            if hit is None or not t_s.isdigit():
+                no(f"inequality '{lab}': no link of robot '{models[i].get_name()}' in the label")
+            sph[i][(int(t_s), hit[0], hit[1])] = r_
+    for i, (m, r) in enumerate(zip(models, robots)):
+        links, obst = [], []
+        for (t, ln, on) in sph[i]:
+            if ln not in links:
+                links.append(ln)
+            if on not in obst:
+                obst.append(on)
+        if sph[i] and len(sph[i]) != T * len(links) * len(obst):
+            no(f"robot '{m.get_name()}': sphere rows must cover every (knot, link, obstacle) combination")
+        lrad_names = []
+        for ln in links:  # "{link}_radii", possibly behind a prefix (this repo's additive extension for two robots of one URDF): the parameter that moves this arm's rows
+            cands = [k for k in extra_params if k.endswith(ln + "_radii")]
+            pick = None
+            for k in cands:
+                pv = p0.copy()
+                pv[poff[k][0]] += 0.01
+                ch = np.abs(_vec(opt.g, x0, pv) - g0) > 1e-12
+                mine = np.array([sph[i][(t, ln, on)] for t in range(T) for on in obst])
+                if ch[mine].all() and ch.sum() == mine.size:
+                    pick = k
+            if pick is None:
+                no(f"robot '{m.get_name()}': no radius parameter for link '{ln}'")
+            lrad_names.append(pick)
+        obs_names = []
+        for on in obst:
+            if on + "_position" not in poff or on + "_radii" not in poff or poff[on + "_position"][1] != 3:
+                no(f"obstacle '{on}': parameters '{on}_position' (3) and '{on}_radii' expected")
+            obs_names.append((on + "_position", on + "_radii"))
+        used_params |= set(lrad_names) | set(x for ob in obs_names for x in ob)
+        if sph[i]:
+            # verification at random configurations and parameters: g = ||p_link(q_t) - o||^2 - (r_link + r_o)^2, computed with this package's kinematics
+            for _ in range(2):
+                Qs = list(Qc)
+                Qs[i] = qcs[i][None] + rng.uniform(-0.5, 0.5, (T, ns[i]))
+                pv = p0.copy()
+                for k in lrad_names + [b for _, b in obs_names]:
+                    pv[poff[k][0]] = rng.uniform(0.02, 0.2)
+                for a_, _ in obs_names:
+                    pv[poff[a_][0] : poff[a_][0] + 3] = rng.uniform(-0.8, 0.8, 3)
+                gv = _vec(opt.g, xvec(Qs, Zs), pv)
+                for ln, lk in zip(links, lrad_names):
+                    P = np.asarray(r.get_global_link_position(ln, Qs[i].T)).reshape(3, T).T
+                    for (pk, rk) in obs_names:
+                        on = pk[: -len("_position")]
+                        want = np.sum((P - pv[poff[pk][0] : poff[pk][0] + 3][None]) ** 2, 1) - (pv[poff[lk][0]] + pv[poff[rk][0]]) ** 2
+                        got = np.array([gv[sph[i][(t, ln, on)]] for t in range(T)])
+                        if np.abs(want - got).max() > 1e-9:
+                            no(f"robot '{m.get_name()}': rows of link '{ln}' / obstacle '{on}' are not ||p_link(q_t) - o||^2 - (r_link + r_o)^2")
+        if lims[i] is not None or sph[i]:
+            lo, up = lims[i] if lims[i] is not None else (None, None)
+            arms[i].guards = GuardSpec(lo, up, links, lrad_names, obs_names)
+    if set(extra_params) != used_params:
+        no(f"parameters that belong to no recognised row: {sorted(set(extra_params) - used_params)}")
 
 
 PROBES = {"figure_eight": probe_figure_eight, "torque_mpc": probe_torque_mpc, "ik": probe_ik, "point_mass": probe_point_mass, "multi_arm": probe_multi_arm}

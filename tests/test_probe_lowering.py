@@ -271,3 +271,45 @@ def test_dual_arm_is_recognised_and_solved_through_the_reference_interface(hip_l
     assert s.stats()["family"] == "multi_arm" and s.did_solve()
     assert abs(s.stats()["f"] - 0.00480191855905) <= 1e-8  # the known answer of tests/test_dual_arm.py (oracle, reference wiring)
     assert np.asarray(sol["kukal/q"]).shape == (7, 50)
+
+
+def test_guarded_dual_arm_is_recognised_and_solved_through_the_reference_interface(hip_lib):
+    """BASELINE configs[3] AS STATED (dual-arm + joint limits + sphere-collision inequalities) behind the reference interface (round-2 verdict,
+    Missing 2): limit blocks and sphere rows are recognised from their labels, attributed to an arm and read off k and g numerically, verified,
+    and the guarded kernels run.  Known answer: the SLSQP-wired optimum of tests/golden/guard_golden.npz (reference wiring, T = 20)."""
+    from conftest import GOLDEN
+    from examples.dual_arm import N_OBSTACLES, SPHERE_LINKS, obstacle_parameters, setup_solver
+    from optas_amd.lowering import LoweringError, MultiArmSpec, match_multi_arm
+    from optas_amd.probe_lowering import probe, probe_multi_arm
+
+    golden = np.load(os.path.join(GOLDEN, "guard_golden.npz"))
+    T = 20
+    (kl, kr), opt = setup_solver(T=T, build_only=True, limits=True, collision=True)
+    want = match_multi_arm(opt)  # the tree matcher of the mirror builder: what the probing route has to reproduce without seeing a tree
+    ref = ReferenceLikeOptimization(opt)
+    fam, spec = probe(ref)
+    assert fam == "multi_arm" and isinstance(spec, MultiArmSpec) and len(spec.arms) == 2
+    for a, b in zip(spec.arms, want.arms):
+        assert a.guards is not None and b.guards is not None
+        assert a.guards.links == b.guards.links == SPHERE_LINKS and a.guards.link_radii == b.guards.link_radii and a.guards.obstacles == b.guards.obstacles
+        assert len(a.guards.obstacles) == N_OBSTACLES and np.array_equal(a.guards.lo, b.guards.lo) and np.array_equal(a.guards.up, b.guards.up)
+        assert abs(a.w_path - b.w_path) < 1e-7 * b.w_path and np.abs(a.offsets[1:] - b.offsets[1:]).max() < 1e-8
+    s = _standins()(ref).setup("hip_sqp", {"max_iter": 400})
+    pd = {"qcl": golden["T20l_qc"], "qcr": golden["T20r_qc"], **obstacle_parameters()}
+    s.reset_parameters(pd)
+    s.reset_initial_seed({"kukal/q/x": np.tile(pd["qcl"].reshape(-1, 1), (1, T)), "kukar/q/x": np.tile(pd["qcr"].reshape(-1, 1), (1, T))})
+    sol = s.solve()
+    assert s.stats()["family"] == "multi_arm" and s.did_solve()
+    assert abs(s.stats()["f"] - (float(golden["T20l_f"]) + float(golden["T20r_f"]))) < 1e-8  # scipy SLSQP in the reference's wiring (tools/make_golden.py)
+    assert np.abs(np.asarray(sol["kukal/q"]).T - golden["T20l_Q"]).max() < 5e-5 and np.abs(np.asarray(sol["kukar/q"]).T - golden["T20r_Q"]).max() < 5e-5
+    # a problem whose rows only look like sphere rows is refused, not approximated
+    g_true = opt.g
+    opt.g = lambda x, p: g_true(x, p) + 1e-4 * np.sin(np.asarray(x)[3])
+    with pytest.raises(LoweringError):
+        probe_multi_arm(ref)
+    opt.g = g_true
+    k_true = opt.k
+    opt.k = lambda x, p: k_true(x, p) * 1.001
+    with pytest.raises(LoweringError, match="limit"):
+        probe_multi_arm(ref)
+    opt.k = k_true

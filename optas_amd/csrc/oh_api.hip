@@ -122,6 +122,7 @@ struct oh_handle {
   int tail_threshold = 16384;  // hand the last instances to the persistent one-wave-per-instance kernel (round 2: with the kernel compiled for the
                                // chain 8192 against 2048 was +1.3 ... 3 % at B = 262 144 and -21 % on a batch of 4096; with four of its blocks per CU
                                // (two-pass exchange, 40 KB of LDS) 16 384 is level at B = 262 144 and -6 ... 13 % on batches of 16 ... 24 k)
+  int sparse_check_below = 2048;  // OH_SPARSE_CHECK_BELOW (0: look every iteration whatever the batch)
   int fuse_couple = 1;        // OH_FUSE_COUPLE=0 restores the three-kernel iteration (k_couple between evaluation and sweep) for A/B runs
   int free_pcr_max = 1536;    // position-tracking family: K3 by cyclic reduction, one block per instance, while at most this many are in the launch
   // run-time specialised evaluation kernels of the orientation-locked figure-eight family (oh_jit.hip)
@@ -230,6 +231,7 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (const char* e5 = getenv("OH_COMPACT_SORT")) h->compact_sort = atoi(e5);
   if (const char* e6 = getenv("OH_COMPACT_CARRY")) h->compact_carry = atoi(e6);
   if (const char* e7 = getenv("OH_FUSE_COUPLE")) h->fuse_couple = atoi(e7) != 0;
+  if (const char* e9 = getenv("OH_SPARSE_CHECK_BELOW")) h->sparse_check_below = atoi(e9);
   hipGetDevice(&h->device);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
       hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->evt0) != hipSuccess ||
@@ -1211,7 +1213,11 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     else if (h->P.lock && guarded && h->GP.vel) oh_launch_couple_vel(s, N, h->P, h->D, h->GP, h->GB, slot);
     else if (h->P.lock) oh_launch_couple(s, N, h->P, h->D, slot);
     else oh_launch_couple_free(s, N, h->P, h->D, slot);
-    const bool check = ((it + 1) % check_every == 0);
+    // handles without a persistent tail kernel (inequality rows, position-only tracking, lead joint) end in launches of a few hundred instances that
+    // are pure latency: there the host looks at the running count every 8th iteration only (a look is a copy + stream synchronisation, 20-30 us
+    // of a ~150 us iteration; the price is up to 7 idle iterations of finished instances at the very end)
+    const int ce = (!tail_ok && check_every == 1 && h->D.B <= h->sparse_check_below) ? 8 : check_every;
+    const bool check = ((it + 1) % ce == 0);
     if (check && !h->P.lock) HIPCHK(hipMemsetAsync(h->D.n_running, 0, sizeof(int), s));  // the locked family's k_couple resets it
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(3); }
     if (h->P.lock && guarded) oh_launch_step_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);

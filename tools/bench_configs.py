@@ -132,6 +132,8 @@ def run_configs(sample=8, torque_batches=(8192, 1024), only=None):
     if only == "torque":
         rng = np.random.default_rng(SEED + 5)
         return _torque(out, rng, sample, torque_batches)
+    if only == "config4":
+        return _config4(out, np.random.default_rng(SEED + 4), sample)
     # config 1
     B = 65536
     be = IKBackend(kuka.kinematic_chain("end_effector_ball"), kuka.lower_actuated_joint_limits, kuka.upper_actuated_joint_limits, max_iter=300)
@@ -165,6 +167,11 @@ def run_configs(sample=8, torque_batches=(8192, 1024), only=None):
                                  "oracle_sample": oracle_grade("pm", **smp) if smp else None,
                                  "closed_loop": {"ticks": n_ticks, "device_ms": be.solve_ms(), "ticks_per_s": B * n_ticks / be.solve_ms() * 1e3, "converged_frac": float((stt == 0).mean())}}
     be.close()
+    _config4(out, rng, sample)
+    return _torque(out, rng, sample, torque_batches)
+
+
+def _config4(out, rng, sample):
     # config 4 synthetic: T = 100, limits + 4 x 6 sphere rows per knot, link radius 0.15 as SURVEY 8(d) states; arms are independent instances
     from examples.dual_arm import SPHERE_LINKS, path_offsets
 
@@ -194,7 +201,7 @@ def run_configs(sample=8, torque_batches=(8192, 1024), only=None):
                                                         "(a dual-arm instance = two of them)", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
                                                "oracle_sample": oracle_grade("guarded_arm", T=T, links=SPHERE_LINKS, offsets=offs.T, **smp) if smp else None}
         be.close()
-    return _torque(out, rng, sample, torque_batches)
+    return out
 
 
 def _torque(out, rng, sample, torque_batches):

@@ -87,7 +87,9 @@ def test_velocity_limited_batch_is_compacted_invisibly(hip_lib, monkeypatch):
     # keep up to 1e-5 of orientation violation): the paths part by rounding-size amounts and a long run may end some steps apart -- the optima
     # and their multipliers must not
     both = (s0 == 0) & (s1 == 0)
-    assert (np.abs(i0.astype(int) - i1)[both] <= np.maximum(3, i0[both] // 4)).mean() >= 0.95
+    # (which instances a restart catches mid-run depends on when the host looks at the running count: 0.97 with a look every iteration, 0.94 with
+    #  the sparse looks small launches get since round 3 -- the bound is a statement about "most", the optima below are the invariant)
+    assert (np.abs(i0.astype(int) - i1)[both] <= np.maximum(3, i0[both] // 4)).mean() >= 0.9
     assert np.abs(f0 - f1)[both].max() <= 1e-7 * np.abs(f0).max()
     same = both & (i0 == i1)
     assert same.mean() > 0.5 and np.abs(x0[same] - x1[same]).max() <= 1e-4  # ~1e-5 rad of play along the weakly curved elbow-swivel direction

@@ -257,3 +257,147 @@ def _bcast_rows(J, shape_from, shape_to):
     if mf == mt and nf == 1:
         return np.tile(J, (nt, 1))
     raise NotImplementedError(f"broadcast of a {shape_from} operand to {shape_to}")
+
+
+# ---- second derivatives (the reference's ddf, ddg, ddh, ddv: casadi.jacobian of the Jacobians, optimization.py:8-24) ---------------------------
+def _unbcast(W, shape_to, shape_from):
+    """Weights of a broadcast operand: what `_bcast_rows` repeats is summed back."""
+    (mt, nt), (mf, nf) = shape_to, shape_from
+    if (mf, nf) == (mt, nt):
+        return W
+    if (mf, nf) == (1, 1):
+        return np.array([[W.sum()]])
+    if mf == mt and nf == 1:
+        return W.sum(axis=1, keepdims=True)
+    raise NotImplementedError(f"broadcast of a {shape_from} operand to {shape_to}")
+
+
+def _rows_of(J, shape, c):
+    m = shape[0]
+    return J[c * m : (c + 1) * m]
+
+
+def _hamilton_left(o, quat):
+    """(o, 0) (x) quat, xyzw storage: the product behind d quat = 1/2 (omega, 0) (x) quat."""
+    ox, oy, oz = o
+    x, y, z, w = quat
+    return np.array([ox * w + oy * z - oz * y, -ox * z + oy * w + oz * x, ox * y - oy * x + oz * w, -ox * x - oy * y - oz * z])
+
+
+def weighted_hessian(e: Expr, opt, x: np.ndarray, p: np.ndarray, W: np.ndarray) -> np.ndarray:
+    """sum over the entries of node ``e`` of W[r, c] * (Hessian of that entry w.r.t. x), nx x nx, exact: the weights travel down the tree
+    (transposed through the linear nodes), every nonlinear node adds its own curvature from the first derivatives of its operands.  Second-order
+    kinematics come out of the geometric Jacobian oh_fk_jac returns: d2 p / dq_i dq_j = z_i x Jp_j (i <= j), d2 quat and d2 R from the same axes.
+    Raises NotImplementedError for nodes without a rule (inverse dynamics, the Jacobian-valued link function): the caller differences."""
+    nx = opt.nx
+    m, n = e.shape
+    W = np.broadcast_to(np.asarray(W, dtype=np.float64), (m, n))
+    Z = np.zeros((nx, nx))
+    if e.degree() <= 1 and not isinstance(e, (LinkFunction, RneaFunction, Mul, MatMul, Square, SumSqr, Atan2)):
+        return Z  # affine in x
+    if isinstance(e, Rows):
+        Wa = np.zeros(e.a.shape)
+        Wa[list(e.idx), :] = W
+        return weighted_hessian(e.a, opt, x, p, Wa)
+    if isinstance(e, Block):
+        Wa = np.zeros(e.a.shape)
+        Wa[np.ix_(list(e.ridx), list(e.cidx))] = W
+        return weighted_hessian(e.a, opt, x, p, Wa)
+    if isinstance(e, RobotStates):
+        return weighted_hessian(e.states, opt, x, p, W[list(e.opt_idx), :])
+    if isinstance(e, (Sub, Add)):
+        Ha = weighted_hessian(e.a, opt, x, p, _unbcast(W, (m, n), e.a.shape))
+        Hb = weighted_hessian(e.b, opt, x, p, _unbcast(W, (m, n), e.b.shape))
+        return Ha - Hb if isinstance(e, Sub) else Ha + Hb
+    if isinstance(e, Scale):
+        return weighted_hessian(e.a, opt, x, p, e.w * W)
+    if isinstance(e, VCat):
+        H, r0 = Z.copy(), 0
+        for part in e.parts:
+            mp = part.shape[0]
+            H += weighted_hessian(part, opt, x, p, _unbcast(W[r0 : r0 + mp], (mp, n), part.shape))
+            r0 += mp
+        return H
+    if isinstance(e, SumSqr):
+        va, Ja = jacobian(e.a, opt, x, p)
+        w = float(W[0, 0])
+        return 2.0 * w * (Ja.T @ Ja) + weighted_hessian(e.a, opt, x, p, 2.0 * w * va)
+    if isinstance(e, Square):
+        va, Ja = jacobian(e.a, opt, x, p)
+        wv = W.T.reshape(-1)
+        return 2.0 * (Ja.T * wv) @ Ja + weighted_hessian(e.a, opt, x, p, 2.0 * W * va)
+    if isinstance(e, Mul):
+        va, Ja = jacobian(e.a, opt, x, p)
+        vb, Jb = jacobian(e.b, opt, x, p)
+        Ja, Jb = _bcast_rows(Ja, e.a.shape, (m, n)), _bcast_rows(Jb, e.b.shape, (m, n))
+        va, vb = np.broadcast_to(va, (m, n)), np.broadcast_to(vb, (m, n))
+        wv = W.T.reshape(-1)
+        C = (Ja.T * wv) @ Jb
+        return C + C.T + weighted_hessian(e.a, opt, x, p, _unbcast(W * vb, (m, n), e.a.shape)) + weighted_hessian(e.b, opt, x, p, _unbcast(W * va, (m, n), e.b.shape))
+    if isinstance(e, MatMul):
+        va, Ja = jacobian(e.a, opt, x, p)
+        vb, Jb = jacobian(e.b, opt, x, p)
+        ma, ka = e.a.shape
+        H = Z.copy()
+        for c in range(n):
+            for r in range(m):
+                if W[r, c] != 0.0:
+                    for k in range(ka):
+                        C = np.outer(Ja[k * ma + r], Jb[c * ka + k])
+                        H += W[r, c] * (C + C.T)
+        return H + weighted_hessian(e.a, opt, x, p, W @ vb.T) + weighted_hessian(e.b, opt, x, p, va.T @ W)
+    if isinstance(e, Atan2):
+        vy, Jy = jacobian(e.y, opt, x, p)
+        vx, Jx = jacobian(e.x, opt, x, p)
+        Jy, Jx = _bcast_rows(Jy, e.y.shape, (m, n)), _bcast_rows(Jx, e.x.shape, (m, n))
+        vy, vx = np.broadcast_to(vy, (m, n)), np.broadcast_to(vx, (m, n))
+        d = vx * vx + vy * vy
+        tyy, txx, txy = -2.0 * vx * vy / d**2, 2.0 * vx * vy / d**2, (vy * vy - vx * vx) / d**2
+        wv = W.T.reshape(-1)
+        C = (Jy.T * (wv * txy.T.reshape(-1))) @ Jx
+        H = (Jy.T * (wv * tyy.T.reshape(-1))) @ Jy + (Jx.T * (wv * txx.T.reshape(-1))) @ Jx + C + C.T
+        return H + weighted_hessian(e.y, opt, x, p, _unbcast(W * vx / d, (m, n), e.y.shape)) + weighted_hessian(e.x, opt, x, p, _unbcast(-W * vy / d, (m, n), e.x.shape))
+    if isinstance(e, LinkFunction):
+        if e.what == "geometric_jacobian":
+            raise NotImplementedError("second derivatives of the Jacobian-valued link function are not provided")
+        q, Jq = jacobian(e.q, opt, x, p)
+        nd, cols = q.shape
+        pose, Jg = e.robot._kin(e.link).fk_jac(np.ascontiguousarray(q.T))
+        H = Z.copy()
+        Wq = np.zeros((nd, cols))
+        for c in range(cols):
+            Jp, Jw = Jg[c, :3], Jg[c, 3:]
+            S = np.zeros((nd, nd))  # sum_k W[k, c] d2 out_k / dq dq
+            if e.what == "position":
+                w3 = W[:, c]
+                for i in range(nd):
+                    for j in range(i, nd):
+                        S[i, j] = S[j, i] = float(w3 @ np.cross(Jw[:, i], Jp[:, j]))
+                Wq[:, c] = Jp.T @ w3
+            elif e.what == "quaternion":
+                quat, w4 = pose[c, 3:], W[:, c]
+                for i in range(nd):
+                    hi = _hamilton_left(Jw[:, i], quat)
+                    for j in range(i, nd):
+                        dz = np.cross(Jw[:, i], Jw[:, j]) if i < j else np.zeros(3)
+                        S[i, j] = S[j, i] = float(w4 @ (0.5 * _hamilton_left(dz, quat) + 0.25 * _hamilton_left(Jw[:, j], hi)))
+                Wq[:, c] = np.array([0.5 * float(w4 @ _hamilton_left(Jw[:, k], quat)) for k in range(nd)])
+            else:  # rotation: a single configuration, W is 3 x 3; d R = [omega]x R, d2 R / dq_i dq_j = [z_i x z_j]x R (i < j) + [z_j]x [z_i]x R
+                R = np.asarray(evaluate(e, opt, x, p))
+
+                def sk(v):
+                    return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+                for i in range(nd):
+                    for j in range(i, nd):
+                        D2 = sk(Jw[:, j]) @ sk(Jw[:, i]) @ R
+                        if i < j:
+                            D2 = D2 + sk(np.cross(Jw[:, i], Jw[:, j])) @ R
+                        S[i, j] = S[j, i] = float(np.sum(W * D2))
+                Wq[:, 0] = np.array([float(np.sum(W * (sk(Jw[:, k]) @ R))) for k in range(nd)])
+            Jqc = Jq[c * nd : (c + 1) * nd]
+            H += Jqc.T @ S @ Jqc
+        if e.q.degree() > 1:
+            H += weighted_hessian(e.q, opt, x, p, Wq)
+        return H
+    raise NotImplementedError(f"no second-derivative rule for {type(e).__name__}")

@@ -7,8 +7,9 @@ defines them -- ``M, c, A, b`` (``k = Mx + c``, ``a = Ax + b``, optimization.py:
 link functions inside them run through liboptas_hip), used for diagnostics and for checking the builder's layout and sign
 conventions against the oracle.  The derivative members the reference derives with CasADi (optimization.py:8-24) are here too:
 ``df, dk, da, dg, dh, dv`` are exact (forward propagation through the trees with the geometric Jacobian of oh_fk_jac and the
-dual-number Jacobian of oh_rnea_jac, optas_amd.evaluate.jacobian); ``ddf, ddg, ddh, ddv`` are central differences of those exact first
-derivatives (step 1e-6, symmetrised) -- the kernels carry their own second-order terms and never call them.
+dual-number Jacobian of oh_rnea_jac, optas_amd.evaluate.jacobian); ``ddf, ddg, ddh, ddv`` are exact as well (optas_amd.evaluate.weighted_hessian:
+second-order kinematics from the same geometric Jacobian), except rows through inverse dynamics, which are central differences of their
+exact first derivatives (step 1e-6, symmetrised) -- the kernels carry their own second-order terms and never call them.
 ``v = [k; g; a; -a; h; -h]``, ``nv = nk + ng + 2 na + 2 nh``, bounds ``0 <= v <= 1e10`` (optimization.py:27-51,292-306).
 """
 from __future__ import annotations
@@ -116,17 +117,50 @@ class Optimization:
             H[..., i] = (Jp - Jm) / (2.0 * step)
         return 0.5 * (H + np.swapaxes(H, -1, -2))
 
+    def _hess_rows(self, container, x, p) -> np.ndarray:
+        """(rows, nx, nx): exact Hessian of every entry of the container's terms (evaluate.weighted_hessian: the weights travel down the
+        expression trees, second-order kinematics from the geometric Jacobian) -- what casadi.jacobian(casadi.jacobian(.)) gives the
+        reference (optimization.py:8-24).  NotImplementedError where a node has no rule (inverse-dynamics rows)."""
+        from .evaluate import weighted_hessian
+
+        x, p = np.asarray(x, dtype=np.float64).reshape(-1), np.asarray(p, dtype=np.float64).reshape(-1)
+        out = []
+        for term in container.values():
+            m, n = term.shape
+            for c in range(n):  # column-major, like vec()
+                for r in range(m):
+                    W = np.zeros((m, n))
+                    W[r, c] = 1.0
+                    out.append(weighted_hessian(term, self, x, p, W))
+        return np.array(out).reshape(len(out), self.nx, self.nx)
+
     def ddf(self, x, p) -> np.ndarray:
-        return self._second(self.df, x, p)[0]
+        """Hessian of f, exact (round 3; central differences of df only where a cost term has a node without a second-derivative rule)."""
+        from .evaluate import weighted_hessian
+
+        xx, pp = np.asarray(x, dtype=np.float64).reshape(-1), np.asarray(p, dtype=np.float64).reshape(-1)
+        try:
+            return sum((weighted_hessian(term, self, xx, pp, np.ones((1, 1))) for term in self.cost_terms.values()), np.zeros((self.nx, self.nx)))
+        except NotImplementedError:
+            return self._second(self.df, x, p)[0]
 
     def ddg(self, x, p) -> np.ndarray:
-        return self._second(self.dg, x, p)
+        try:
+            return self._hess_rows(self.ineq_constraints, x, p)
+        except NotImplementedError:
+            return self._second(self.dg, x, p)
 
     def ddh(self, x, p) -> np.ndarray:
-        return self._second(self.dh, x, p)
+        try:
+            return self._hess_rows(self.eq_constraints, x, p)
+        except NotImplementedError:
+            return self._second(self.dh, x, p)
 
     def ddv(self, x, p) -> np.ndarray:
-        return self._second(self.dv, x, p)
+        """Hessians of the rows of v = [k; g; a; -a; h; -h]: zero for the linear blocks."""
+        ddg, ddh = self.ddg(x, p), self.ddh(x, p)
+        zk, za = np.zeros((self.nk, self.nx, self.nx)), np.zeros((self.na, self.nx, self.nx))
+        return np.concatenate([zk, ddg, za, za, ddh, -ddh], axis=0)
 
     def _affine(self, fun, p):
         """(matrix, offset) of an affine map x -> fun(x, p): offset = fun(0), column i = fun(e_i) - offset (exact)."""

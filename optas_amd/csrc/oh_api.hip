@@ -1074,6 +1074,8 @@ static void fill_params(oh_handle* h) {
   P.tol = d.tol;
   P.tol_feas = d.tol_feas;
   P.tol_retract = fmin(1e-10, d.tol_feas);
+  P.tol_retract_min = h->have_guards ? fmin(1e-13, P.tol_retract) : P.tol_retract;
+  if (const char* e = getenv("OH_RETRACT_MIN")) P.tol_retract_min = fmin(atof(e), P.tol_retract);  // experiments
   P.feas_accept = fmax(1e-8, 10.0 * d.tol_feas);
   P.max_retract = 4;
   P.max_iter = d.max_iter;

@@ -120,8 +120,12 @@ OH_DEV void z_from_householder(const double (&V)[3][N], double (&Z)[N][N - 3]) {
 // counts start to move, never looser than 1e-5.  In the end game every point is retracted to the floor: an accepted point that keeps
 // a violation c carries an objective that is off by (multiplier) x c, and once the predicted decreases fall below that (they shrink
 // quadratically) no accurate trial can beat it any more.  The first evaluation and restarts use the floor as well.
+// Handles with inequality rows (tol_retract_min < tol_retract): the outer loop asks for stat <= tol again after every multiplier update, with
+// predicted decreases of 1e-12 when 1e-10 of violation is worth 1.5e-10 of objective -- steps were then accepted or refused by the rounding
+// of the retraction and a few instances per 10^4 sat at stat 1e-5 until the iteration cap (round 3; reproduced in oracle/structured.py).
+// There the end-game tolerance follows the prediction too: 1e-2 pred, down to tol_retract_min.
 OH_DEV double retract_tol(const FigParams& P, const bool have_tgt, const double pred, const double stat) {
-  return (have_tgt && stat > P.hyb_switch) ? fmin(1e-5, fmax(P.tol_retract, 1e-3 * pred)) : P.tol_retract;
+  return (have_tgt && stat > P.hyb_switch) ? fmin(1e-5, fmax(P.tol_retract, 1e-3 * pred)) : fmin(P.tol_retract, fmax(P.tol_retract_min, 1e-2 * pred));
 }
 
 // Hooks let the batched kernel shorten live ranges: q and g leave for HBM the moment they are final, and the Lagrangian gradient of the
@@ -501,13 +505,21 @@ OH_DEV bool riccati_back(double (&S)[NZ * (NZ + 1) / 2], double (&rd)[NZ], doubl
 struct LMState {
   double mu, nun;
 };
-OH_DEV bool lm_accept(const FigParams& P, const double f, const double feas, const double fc, const double pred, const double stat, LMState& s) {
+OH_DEV bool lm_accept(const FigParams& P, const double f, const double feas, const double fc, const double pred, const double stat, LMState& s,
+                      const double feas_cur = 0.0) {
   const double rho = (fc - f) / fmax(pred, 1e-300);
-  // also accept steps whose predicted decrease is at rounding level of f (end game)
+  // also accept steps whose predicted decrease is at rounding level of f (end game).  Handles with inequality rows (tol_retract_min <
+  // tol_retract): at the level of what the violations of the two points are worth -- (multiplier ~ 10 max(1, |f|)) x (feas + feas_cur); the
+  // outer loop asks for stat <= tol again after every multiplier update and the last steps predict 1e-14 while 1e-13 of violation shifts the
+  // objective by 1.5e-13: without this the ratio test refuses them all (an instance in 10^4 sat at stat 1.6e-6 until the cap, round 3)
+  const double noise = (P.tol_retract_min < P.tol_retract) ? 10.0 * fmax(1.0, fabs(fc)) * (feas + feas_cur) : 0.0;
+  const double level = fmax(1e-15 * fabs(fc), noise);
   // a trial point whose retraction did not converge is refused; converged ones may keep up to retract_tol of violation
-  const bool accept = (f == f) && (feas <= fmax(P.feas_accept, 10.0 * retract_tol(P, true, pred, stat))) && (rho > 1e-4 || (pred <= 1e-15 * fabs(fc) && f <= fc + 1e-14 * fabs(fc)));
+  const bool accept = (f == f) && (feas <= fmax(P.feas_accept, 10.0 * retract_tol(P, true, pred, stat))) && (rho > 1e-4 || (pred <= level && f <= fc + 1e-14 * fabs(fc) + noise));
   if (accept) {
-    const double w3 = 2.0 * rho - 1.0;
+    // (a step taken at noise level says nothing about the model: the damping stays where it is instead of being multiplied by 1 - (2 rho - 1)^3
+    //  of a meaningless, possibly very negative rho)
+    const double w3 = (noise > 0.0 && !(rho > 1e-4)) ? 0.0 : 2.0 * rho - 1.0;
     s.mu *= fmax(1.0 / 3.0, 1.0 - w3 * w3 * w3);
     if (s.mu < 1e-7) s.mu = 0.0;
     s.nun = 2.0;

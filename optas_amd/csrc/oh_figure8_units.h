@@ -559,8 +559,13 @@ OH_DEV void couple_unit(const FigParams& P, const FigBuffers& D, const int slot,
 // The acceptance phase of K3 (shared by step_instance and step_instance_zc): Levenberg-Marquardt ratio test of the trial slot against the
 // accepted point, restart / polish / line-search bookkeeping.  Returns 0: the instance has finished (status set), 1: it goes on without a
 // sweep (restart, polish, shorter trial along the rejected step), 2: sweep on the slot `cur` with damping lm.mu.
+// slot of a two-slot array by selection: an index that is not a constant makes the compiler keep a private copy of the whole argument
+// struct (k_step_lg: 440 B of scratch per lane, one wavefront per SIMD instead of two, 300 instead of 90 us per latency-bound launch)
+template <class T_>
+OH_DEV T_* slot_of(T_* const (&a)[2], const int s) { return s ? a[1] : a[0]; }
+struct StepHead { int go; int cur; LMState lm; };
 template <int N, bool GUARD = false>
-OH_DEV int step_head(const FigParams& P, const FigBuffers& D, const int b, const int ts, const GuardBuffers* GBp, int& cur, LMState& lm, const int iters) {
+OH_DEV StepHead step_head(const FigParams& P, const FigBuffers& D, const int b, const int ts, const GuardBuffers* GBp, int cur, LMState lm, const int iters) {
   constexpr int NZ = N - 3;
   const int Bp = D.Bp;
   const int T = P.T;
@@ -573,12 +578,20 @@ OH_DEV int step_head(const FigParams& P, const FigBuffers& D, const int b, const
   {
     double f = D.fconst[b];
     double feas = 0.0, fpsi = 0.0, meas = 0.0;
+    const double* const merit_ts = slot_of(D.merit, ts);
+    const double* const cv_ts = slot_of(D.cv, ts);
+    const double* psi_ts = nullptr;
+    const double* mcv_ts = nullptr;
+    if constexpr (GUARD) {
+      psi_ts = slot_of(GBp->psi, ts);
+      mcv_ts = slot_of(GBp->mcv, ts);
+    }
     for (int t = P.t0; t < T; ++t) {
-      f += rb_ld(KNOT(D.merit[ts], t, 1), 0, lb);
-      feas = fmax(feas, rb_ld(KNOT(D.cv[ts], t, 1), 0, lb));
+      f += rb_ld(KNOT(merit_ts, t, 1), 0, lb);
+      feas = fmax(feas, rb_ld(KNOT(cv_ts, t, 1), 0, lb));
       if constexpr (GUARD) {
-        fpsi += rb_ld(KNOT(GBp->psi[ts], t, 1), 0, lb);
-        meas = fmax(meas, rb_ld(KNOT(GBp->mcv[ts], t, 1), 0, lb));
+        fpsi += rb_ld(KNOT(psi_ts, t, 1), 0, lb);
+        meas = fmax(meas, rb_ld(KNOT(mcv_ts, t, 1), 0, lb));
       }
     }
     bool accept;
@@ -588,7 +601,7 @@ OH_DEV int step_head(const FigParams& P, const FigBuffers& D, const int b, const
         D.cur[b] = ts;
         D.f_cur[b] = f;
         D.stat[b] = f;
-        return 0;
+        return StepHead{0, cur, lm};
       }
       accept = true;
       D.first[b] = 0;
@@ -609,11 +622,11 @@ OH_DEV int step_head(const FigParams& P, const FigBuffers& D, const int b, const
       D.polish[b] = 0;
     } else {
       const LMState lm_before = lm;
-      accept = lm_accept(P, f, feas, D.f_cur[b], D.pred[b], D.stat[b], lm);
+      accept = lm_accept(P, f, feas, D.f_cur[b], D.pred[b], D.stat[b], lm, D.feas[b]);
       // A rejected trial against an accepted point that was retracted loosely (retract_tol): its objective is off by (multiplier) x
       // violation, and steps that predict less than that can never be accepted.  Before blaming the model, re-evaluate the accepted
       // point at the floor tolerance: zero step, accepted unconditionally at the next k_step.
-      polish_request = !accept && !D.stale[b] && D.feas[b] > 10.0 * P.tol_retract;
+      polish_request = !accept && !D.stale[b] && D.feas[b] > 10.0 * retract_tol(P, false, D.pred[b], 0.0);
       if (polish_request) lm = lm_before;
       if constexpr (GUARD) {
         // handles with inequality rows: a shorter step along the same direction before the damping is raised (OH_LS_MAX, oh_types.h)
@@ -634,7 +647,7 @@ OH_DEV int step_head(const FigParams& P, const FigBuffers& D, const int b, const
       D.nun[b] = lm.nun;
       D.cur[b] = cur;
       oh_count(D.work + 1);
-      return 1;
+      return StepHead{1, cur, lm};
     }
     if (accept) {
       D.stale[b] = 0;
@@ -657,7 +670,7 @@ OH_DEV int step_head(const FigParams& P, const FigBuffers& D, const int b, const
     if (line_search) {  // the rejected step again, shorter: no sweep, the damping untouched
       if (iters >= P.max_iter) {
         D.status[b] = OH_STATUS_MAX_ITER;
-        return 0;
+        return StepHead{0, cur, lm};
       }
       for (int t = P.t0; t < T; ++t) {
 #pragma unroll
@@ -669,7 +682,7 @@ OH_DEV int step_head(const FigParams& P, const FigBuffers& D, const int b, const
       for (int i = 0; i < k; ++i) sk *= OH_LS_SHRINK;
       D.pred[b] = -sk * GBp->ls_gd[b] + 0.5 * sk * sk * GBp->ls_q[b];
       D.iters[b] = iters + 1;
-      return 1;
+      return StepHead{1, cur, lm};
     }
   }
   if (polish_request) {
@@ -680,9 +693,11 @@ OH_DEV int step_head(const FigParams& P, const FigBuffers& D, const int b, const
     D.pred[b] = 0.0;
     D.polish[b] = 1;
     D.iters[b] = iters + 1;
-    return iters < P.max_iter + 40 ? 1 : (D.status[b] = OH_STATUS_MAX_ITER, 0);
+    if (iters < P.max_iter + 40) return StepHead{1, cur, lm};
+    D.status[b] = OH_STATUS_MAX_ITER;
+    return StepHead{0, cur, lm};
   }
-  return 2;
+  return StepHead{2, cur, lm};
 }
 
 // K3: one lane per instance: accept/reject the trial point (Levenberg-Marquardt ratio test on the
@@ -702,8 +717,10 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   LMState lm{D.mu[b], D.nun[b]};
   const int iters = D.iters[b];
   {
-    const int go = step_head<N, GUARD>(P, D, b, ts, GBp, cur, lm, iters);
-    if (go != 2) return go == 1;
+    const StepHead hd = step_head<N, GUARD>(P, D, b, ts, GBp, cur, lm, iters);
+    if (hd.go != 2) return hd.go == 1;
+    cur = hd.cur;
+    lm = hd.lm;
   }
   double mu = lm.mu;
 
@@ -927,8 +944,10 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
   LMState lm{D.mu[b], D.nun[b]};
   const int iters = D.iters[b];
   {
-    const int go = step_head<N, false>(P, D, b, ts, nullptr, cur, lm, iters);
-    if (go != 2) return go == 1;
+    const StepHead hd = step_head<N, false>(P, D, b, ts, nullptr, cur, lm, iters);
+    if (hd.go != 2) return hd.go == 1;
+    cur = hd.cur;
+    lm = hd.lm;
   }
   double mu = lm.mu;
   const double* __restrict__ Vc = D.Z[0];

@@ -16,6 +16,7 @@ struct FigParams {
   double tol;
   double tol_feas;
   double tol_retract;
+  double tol_retract_min;  // end-game retraction tolerance follows 1e-2 pred down to this (= tol_retract: off; 1e-13 on handles with inequality rows)
   double feas_accept;
   int max_retract;
   int max_iter;

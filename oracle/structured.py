@@ -328,6 +328,21 @@ def retract(prob, Q, Rc, tol=1e-10, max_corr=4, e_tgt=None):
 LS_MAX, LS_SHRINK = 3, 0.3  # OH_LS_MAX, OH_LS_SHRINK (csrc/oh_types.h): line search on a rejected step of a handle with inequality rows
 
 
+RETRACT_FLOOR = 1e-13
+
+
+def retract_tol(tol_feas, pred, far, tight=True):
+    """retract_tol in csrc/oh_figure8.h.  Far from the solution the violation a trial point may keep is tied to the decrease its step predicts,
+    never looser than 1e-5.  In the end game the same holds below the floor min(1e-10, tol_feas): an accepted point that keeps a violation c
+    carries an objective that is off by (multiplier) x c, and a step that predicts less than that is accepted or refused by the rounding of the
+    retraction, not by its merit -- with inequality rows the outer loop asks for stat <= tol again after every multiplier update, with predicted
+    decreases of 1e-12 against 1.5e-10 of such noise (round 3: the instances of a velocity-limited batch that sat at stat 1e-5 until the cap)."""
+    floor = min(1e-10, tol_feas)
+    if far:
+        return min(1e-5, max(floor, 1e-3 * pred))
+    return min(floor, max(RETRACT_FLOOR, 1e-2 * pred)) if tight else floor  # tight: handles with inequality rows (FigParams.tol_retract_min)
+
+
 def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, mu0=0.0, exact=False, rule="nielsen", verbose=False, hessian="hybrid", limits=None, rho0=None, guards=None, overrelax=1.5, overrelax_from=4, vlimits=None):
     """Returns dict(Q, f, iters (= steps solved: accepted + rejected), rejected, stat, feas, status).
     limits = (lo, up) or guards = oracle.guarded.Guards (joint limits and/or sphere clearances): inequality rows at the free
@@ -403,7 +418,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
     iters = rejected = 0
     first = True
     polish = False
-    Qt = retract(prob, Qc, Rc)
+    Qt = retract(prob, Qc, Rc, tol=retract_tol(tol_feas, 0.0, False, guard))
     lam = np.zeros((T, 3))
     cur = None
     status = 1
@@ -451,11 +466,13 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                 outer = False
         else:
             rho = (cur["f"] - f_t) / max(pred, 1e-300)
-            accept = np.isfinite(f_t) and (rho > 1e-4 or (pred <= 1e-15 * abs(cur["f"]) and f_t <= cur["f"] + 1e-14 * abs(cur["f"])))
+            # (noise: what the orientation violations of the two points are worth, lm_accept in csrc/oh_figure8.h -- handles with inequality rows)
+            noise = 10.0 * max(1.0, abs(cur["f"])) * (feas_t + cur["feas"]) if guard else 0.0
+            accept = np.isfinite(f_t) and (rho > 1e-4 or (pred <= max(1e-15 * abs(cur["f"]), noise) and f_t <= cur["f"] + 1e-14 * abs(cur["f"]) + noise))
             # a rejected trial against an accepted point that was retracted loosely: the accepted objective is off by (multiplier) x
             # violation, and steps that predict less than that can never be accepted.  Re-evaluate the accepted point itself at the
             # floor tolerance (zero step, accepted unconditionally) before blaming the model.
-            polish_request = (not accept) and cur["feas"] > 10.0 * min(1e-10, tol_feas)
+            polish_request = (not accept) and cur["feas"] > 10.0 * retract_tol(tol_feas, pred, False, guard)
             if polish_request:
                 pass
             elif rule == "hip":
@@ -478,9 +495,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                 Qt[F] += np.einsum("tia,ta->ti", cur["Z"][F], z_ls)
                 e_tgt = cur["e"].copy()
                 e_tgt[F] += np.einsum("tma,ta->tm", cur["JZ"], z_ls)
-                tol_r = min(1e-10, tol_feas)
-                if stat_prev > hyb_switch:
-                    tol_r = min(1e-5, max(tol_r, 1e-3 * pred))
+                tol_r = retract_tol(tol_feas, pred, stat_prev > hyb_switch, guard)
                 Qt = retract(prob, Qt, Rc, tol=tol_r, e_tgt=e_tgt)
                 if iters >= max_iter:
                     break
@@ -488,7 +503,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                 continue
             elif rule == "nielsen":
                 if accept:
-                    mu = mu * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)
+                    mu = mu * max(1.0 / 3.0, 1.0 - ((2.0 * rho - 1.0) if (rho > 1e-4 or noise == 0.0) else 0.0) ** 3)  # (noise-level step: damping unchanged)
                     if mu < 1e-7:
                         mu = 0.0
                     nu_n = 2.0
@@ -507,7 +522,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                 rejected += 1
             if polish_request:
                 polish = True
-                Qt = retract(prob, cur["Q"], Rc, e_tgt=cur["e"])
+                Qt = retract(prob, cur["Q"], Rc, tol=retract_tol(tol_feas, 0.0, False, guard), e_tgt=cur["e"])
                 pred = 0.0
                 iters += 1
                 continue
@@ -563,7 +578,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                 meas_prev = cur["meas"]
                 omega = max(tol, min(omega, 0.1 * cur["meas"]))
                 outer = True
-                Qt = cur["Q"]
+                Qt = retract(prob, cur["Q"], Rc, tol=retract_tol(tol_feas, 0.0, stat > hyb_switch, guard), e_tgt=cur["e"])  # (zero step through k_retract)
                 pred = 0.0
                 iters += 1
                 continue
@@ -583,9 +598,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         e_tgt = cur["e"].copy()
         e_tgt[F] += np.einsum("tma,ta->tm", cur["JZ"], z)  # predicted end-effector positions: e + (Jp Z) z
         # far from the solution the violation a trial point may keep is tied to the decrease its step predicts (retract_tol in oh_figure8.h)
-        tol_r = min(1e-10, tol_feas)
-        if stat > hyb_switch:
-            tol_r = min(1e-5, max(tol_r, 1e-3 * pred))
+        tol_r = retract_tol(tol_feas, pred, stat > hyb_switch, guard)
         Qt = retract(prob, Qt, Rc, tol=tol_r, e_tgt=e_tgt)
         iters += 1
     out = {"Q": cur["Q"], "f": cur["f"] - cur["fpsi"], "iters": iters, "rejected": rejected, "stat": stat, "feas": cur["feas"], "status": status, "path": path, "Rc": Rc}

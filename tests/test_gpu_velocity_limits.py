@@ -95,3 +95,55 @@ def test_velocity_limited_batch_is_compacted_invisibly(hip_lib, monkeypatch):
     assert same.mean() > 0.5 and np.abs(x0[same] - x1[same]).max() <= 1e-4  # ~1e-5 rad of play along the weakly curved elbow-swivel direction
     assert l0.shape == l1.shape and np.abs(l0[same] - l1[same]).max() <= 1e-3 * max(1.0, np.abs(l0).max())
     assert np.abs(l0[..., -14:]).max() > 0  # velocity rows are active somewhere (the LWR's limit of joint 0 binds on the nominal path)
+
+
+def test_batch_of_16384_has_no_stalled_instance_and_matches_its_instances_solved_alone(hip_lib, monkeypatch):
+    """Round-2 verdict, Weak 4 / Next 5: in a 16 384-instance velocity-limited batch (seed 5, the reproducer of DESIGN 7.4) one instance sat at a
+    reduced gradient of 1e-5 until the cap of 600 while the same input alone converged in 64 steps; with compaction off three others did.
+    Cause (reproduced in the numpy port, oracle/structured.py:retract_tol): in the end game of the outer loop the steps predict decreases of
+    1e-12 while 1e-10 of orientation violation -- the retraction tolerance -- is worth 1.5e-10 of objective: steps were accepted or refused by
+    the rounding of the retraction.  With the tolerance tied to the prediction no instance stalls, with compaction on or off, and every instance
+    reaches the optimum it reaches alone."""
+    B = 16384
+    rng = np.random.default_rng(5)
+    qcs = QC0[None] + rng.uniform(-0.1, 0.1, (B, 7))
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OH_COMPACTION", mode)
+        kuka, solver = setup_solver(velocity_limits=True, solver_options={"max_iter": 600, "tol": 1e-6})
+        x0 = np.zeros((B, solver.opt.nx))
+        x0[:, :350] = np.repeat(qcs, 50, axis=0).reshape(B, 350)
+        r = solver.solve_batch_arrays(x0, qcs)
+        assert (r.status == 0).all(), (mode, np.flatnonzero(r.status != 0)[:8], r.kkt[r.status != 0][:8])
+        assert r.iters.max() <= 300, (mode, r.iters.max())  # the slowest instance: 158 steps
+        assert (r.kkt[:, 0] <= 1e-6).all() and (r.kkt[:, 1] <= 1e-9).all()
+        res[mode] = (r, solver)
+    (r1, solver), (r0, s0) = res["1"], res["0"]
+    assert solver.backend.timing()["compactions"] >= 5 and s0.backend.timing()["compactions"] == 0
+    # compaction is invisible in the result: same optimum (a restart may send an instance that sits on a fork between two local minima down the
+    # other branch -- both are KKT points of the reference form, checked below for the sample; at most a handful in 16 384)
+    same = np.abs(r1.f - r0.f) <= 1e-8 * np.abs(r0.f)
+    assert same.mean() >= 0.9995, (same.mean(), np.flatnonzero(~same)[:10], r1.f[~same][:10], r0.f[~same][:10])
+    # without compaction an instance's iterates do not depend on the batch at all: bit-identical to the instance solved alone
+    idx = np.concatenate([[14952, 1725, 2953, 3292], rng.choice(B, 60, replace=False)])  # the four former cap hitters among them
+    for b in idx:
+        a = s0.solve_batch_arrays(x0[b : b + 1], qcs[b : b + 1])
+        assert a.status[0] == 0 and a.iters[0] == r0.iters[b] and a.f[0] == r0.f[b] and np.array_equal(a.x[0], r0.x[b]), b
+        assert abs(a.f[0] - r1.f[b]) <= 1e-8 * abs(a.f[0]) or not same[b], b  # ... and the compacted batch reaches the same optimum
+    # the literal rows of the reference layout on a sample (k = velocity rows, a = linear rows, h = quaternion rows), reference-form KKT,
+    # and the numpy port on the four former cap hitters
+    orc = OracleRobot(KUKA_KIN)
+    vl = np.asarray(orc.velocity_actuated_joint_limits)
+    nlp = LimitedFigureEightNLP(orc, LINK, vlo=-vl, vup=vl, T=50)
+    prob = StructuredFigureEight(orc, LINK, T=50)
+    for n_b, b in enumerate(idx[:12]):
+        x = r1.x[b]
+        assert np.abs(nlp.a(x, qcs[b])).max() <= 1e-12 and np.abs(nlp.h(x, qcs[b])).max() <= 1e-9 and nlp.k(x, qcs[b]).min() >= -1e-8
+        assert abs(nlp.f(x, qcs[b]) - r1.f[b]) <= 1e-9 * r1.f[b]
+        k = kkt_reference_form(nlp, x, qcs[b], active_tol=1e-7)
+        assert k["stationarity"] <= 1e-4 and k["feasibility"] <= 1e-8 and k["complementarity"] <= 1e-5, (b, k)
+        if n_b < 4:
+            s = solve_structured_lm(prob, qcs[b], max_iter=600, tol=1e-6, vlimits=(-vl, vl))
+            assert s["status"] == 0 and abs(s["f"] - r1.f[b]) <= 1e-8 * s["f"], (b, s["status"], s["iters"], s["f"], r1.f[b])
+    solver.backend.close()
+    s0.backend.close()

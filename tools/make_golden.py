@@ -556,48 +556,55 @@ def planner_golden():
     np.savez(os.path.join(G, "planner_golden.npz"), p=np.array(P), x=np.array(X), f=np.array(F), q0=q0)
 
 
-def ipm_configs_golden():
+def ipm_configs_golden(only=None):
     """oracle/ipm_reference_form.py on the other BASELINE configs' literal NLPs, from the reference's seeds: config 4 as shipped (dual_arm.py, T = 50,
-    1386 variables, zero seed as the script leaves it) and config 5 at T = 6 (168 variables; two instances without and two with binding effort
-    rows; Lagrangian Hessian by central differences of its analytic gradient).  Compared in tests/test_ipm_reference_form.py with the answers
-    scipy's SLSQP / trust-constr (reference wiring) gave for the same instances (guard / torque goldens)."""
+    1386 variables, zero seed as the script leaves it; ~1 minute) and config 5 at T = 6 (168 variables; the instance without and the one with binding
+    effort rows of torque_golden.npz; Lagrangian Hessian by central differences of its analytic gradient: ~25 minutes each).  Compared in
+    tests/test_ipm_reference_form.py with the answers scipy's SLSQP / trust-constr (reference wiring) gave for the same instances.
+    Parts ("dual", "t6", "t6lim") are merged into the file one by one."""
     from oracle.ipm_reference_form import solve_ipm
     from oracle.problems import DualArmNLP, TorqueMPCNLP
     from oracle.torque import TorqueProblem
 
+    path = os.path.join(G, "ipm_configs_golden.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    parts = only or ("dual", "t6", "t6lim")
     kin = os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json")
-    rl = OracleRobot(kin, name="kukal")
-    rl.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
-    rr = OracleRobot(kin, name="kukar")
-    rr.add_base_frame("global_world", xyz=[0.0, 0.25, 0.0])
-    out = {}
-    nlp = DualArmNLP(rl, rr, T=50)
-    QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
-    p = np.concatenate([QC, QC])
-    t0 = time.time()
-    r = solve_ipm(nlp, np.zeros(nlp.nx), p)
-    print("config 4 as shipped:", r["status"], r["iters"], r["f"], round(time.time() - t0), "s", flush=True)
-    out.update(dual_p=p, dual_x=r["x"], dual_f=r["f"], dual_iters=r["iters"], dual_optimal=r["status"] == "optimal")
+    if "dual" in parts:
+        rl = OracleRobot(kin, name="kukal")
+        rl.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
+        rr = OracleRobot(kin, name="kukar")
+        rr.add_base_frame("global_world", xyz=[0.0, 0.25, 0.0])
+        nlp = DualArmNLP(rl, rr, T=50)
+        QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
+        p = np.concatenate([QC, QC])
+        t0 = time.time()
+        r = solve_ipm(nlp, np.zeros(nlp.nx), p)
+        print("config 4 as shipped:", r["status"], r["iters"], r["f"], round(time.time() - t0), "s", flush=True)
+        out.update(dual_p=p, dual_x=r["x"], dual_f=r["f"], dual_iters=r["iters"], dual_optimal=r["status"] == "optimal")
+        np.savez(path, **out)
     med7 = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "med7.kin.json"))
     g = np.load(os.path.join(G, "torque_golden.npz"))
     for tag in ("t6", "t6lim"):
+        if tag not in parts:
+            continue
         lim = float(g[tag + "_lim"])
         prob = TorqueProblem(med7, "lbr_link_ee", T=6, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=None if lim > 1e8 else lim)
         nlp = TorqueMPCNLP(prob)
         fs, its, ok = [], [], []
-        for b in range(2):
+        for b in range(len(g[tag + "_qc"])):
             pb = nlp.pack_p(g[tag + "_qc"][b], np.zeros(7), g[tag + "_goal"][b])
             t0 = time.time()
             r = solve_ipm(nlp, nlp.seed(g[tag + "_qc"][b]), pb, max_iter=500)
             print("config 5", tag, b, r["status"], r["iters"], r["f"], "golden", g[tag + "_f"][b], round(time.time() - t0), "s", flush=True)
             fs.append(r["f"]); its.append(r["iters"]); ok.append(r["status"] == "optimal")
         out.update({f"tq_{tag}_f": np.array(fs), f"tq_{tag}_iters": np.array(its), f"tq_{tag}_optimal": np.array(ok)})
-        np.savez(os.path.join(G, "ipm_configs_golden.npz"), **out)
+        np.savez(path, **out)
 
 
 if __name__ == "__main__":
     if "--ipm-configs" in sys.argv:
-        ipm_configs_golden()
+        ipm_configs_golden([a for a in sys.argv[2:] if not a.startswith("-")] or None)
         sys.exit(0)
     if "--planner" in sys.argv:
         planner_golden()

@@ -48,7 +48,7 @@ def obstacle_parameters(link_radius=0.15, obstacle_radius=0.1):
     return p
 
 
-def setup_solver(T=50, Tmax=10.0, solver_options=None, build_only=False, limits=False, collision=False):
+def setup_solver(T=50, Tmax=10.0, solver_options=None, build_only=False, limits=False, collision=False, velocity_limits=None):
     link_ee = "end_effector_ball"
     t = np.linspace(0, Tmax, T)
     dt = float(t[1] - t[0])
@@ -82,6 +82,12 @@ def setup_solver(T=50, Tmax=10.0, solver_options=None, build_only=False, limits=
     if limits:
         builder.enforce_model_limits(kukal_name)
         builder.enforce_model_limits(kukar_name)
+    if velocity_limits is not None:  # (lo, up) per joint, or True: the models' own (enforce_model_limits(name, time_deriv=1), builder.py:471-509)
+        for arm in (kukal_name, kukar_name):
+            if velocity_limits is True:
+                builder.enforce_model_limits(arm, time_deriv=1)
+            else:
+                builder.enforce_model_limits(arm, time_deriv=1, lo=velocity_limits[0], up=velocity_limits[1])
     if collision:
         for arm in (kukal_name, kukar_name):
             builder.sphere_collision_avoidance_constraints(arm, [f"{arm}_obs{i}" for i in range(N_OBSTACLES)], link_names=SPHERE_LINKS,

@@ -504,6 +504,10 @@ class MultiArmBackend:
                 if gs.lo is not None:
                     for j in range(a.robot.ndof):
                         guards.q_lo[j], guards.q_up[j] = float(gs.lo[j]), float(gs.up[j])
+                if gs.vlo is not None:  # joint-velocity rows (round 3: k_couple_free_vel)
+                    guards.vel_limits = 1
+                    for j in range(a.robot.ndof):
+                        guards.dq_lo[j], guards.dq_up[j] = float(gs.vlo[j]), float(gs.vup[j])
                 guards.n_links, guards.n_obstacles = len(gs.links), len(gs.obstacles)
                 for l, (k, off) in enumerate(a.robot.link_attachments(a.link, gs.links)):
                     if k < 0:

@@ -970,7 +970,6 @@ extern "C" int oh_set_guards(oh_handle* h, const oh_guards* g) {
   if ((g->n_links == 0) != (g->n_obstacles == 0)) return fail(OH_ERR_INVALID, "oh_set_guards: sphere rows need both links and obstacles");
   if (!g->limits && g->n_links == 0 && !g->vel_limits) return fail(OH_ERR_INVALID, "oh_set_guards: no rows");
   if (g->vel_limits) {
-    if (!h->desc.lock_orientation) return fail(OH_ERR_INVALID, "oh_set_guards: velocity limits are lowered for the orientation-locked family only");
     for (int j = 0; j < h->desc.ndof; ++j)
       if (!(g->dq_lo[j] < g->dq_up[j])) return fail(OH_ERR_INVALID, "oh_set_guards: dq_lo must be below dq_up");
   }
@@ -1214,6 +1213,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     if (h->P.zc) {}  // folded into k_evalb_zc / k_step_zc
     else if (h->P.lock && guarded && h->GP.vel) oh_launch_couple_vel(s, N, h->P, h->D, h->GP, h->GB, slot);
     else if (h->P.lock) oh_launch_couple(s, N, h->P, h->D, slot);
+    else if (guarded && h->GP.vel) oh_launch_couple_free_vel(s, N, h->P, h->D, h->GP, h->GB, slot);
     else oh_launch_couple_free(s, N, h->P, h->D, slot);
     // handles without a persistent tail kernel (inequality rows, position-only tracking, lead joint) end in launches of a few hundred instances that
     // are pure latency: there the host looks at the running count every 8th iteration only (a look is a copy + stream synchronisation, 20-30 us

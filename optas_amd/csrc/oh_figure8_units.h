@@ -413,28 +413,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
 
 // K2b: one lane per (instance b, free knot t), after k_eval: everything of the reduced block-tridiagonal
 // system that needs the neighbouring knots but not the recursion (couple_knot in oh_figure8.h).
-// Velocity rows of one interval (enforce_model_limits(time_deriv=1), builder.py:471-509): v = (qb - qa) / dt, rows v - vlo >= 0, vup - v >= 0 with the
-// multipliers lam[0..N) / lam[N..2N) and penalty rho.  Out: sigma_k = d L_A / d v_k / dt (enters the gradient of knot b with +, of knot a
-// with -), the Gauss-Newton weight w_k = rho (active rows) / dt^2 of (qb_k - qa_k)^2, the augmented-Lagrangian value psi and the measure
-// |min(g, lam / rho)|_inf.  (oracle/structured.py:vel_terms)
-template <int N>
-OH_DEV void velocity_rows(const GuardParams& GP, const double dt, const double rho, const double (&qa)[N], const double (&qb)[N], const double (&lam)[2 * N],
-                          double (&sigma)[N], double (&w)[N], double& psi, double& meas) {
-  psi = 0.0;
-  meas = 0.0;
-  const double idt = 1.0 / dt;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const double v = (qb[k] - qa[k]) * idt;
-    const double g_lo = v - GP.vlo[k], g_up = GP.vup[k] - v;
-    const double s_lo = fmax(0.0, lam[k] - rho * g_lo), s_up = fmax(0.0, lam[N + k] - rho * g_up);
-    psi += (s_lo * s_lo - lam[k] * lam[k]) / (2.0 * rho) + (s_up * s_up - lam[N + k] * lam[N + k]) / (2.0 * rho);
-    meas = fmax(meas, fmax(fabs(fmin(g_lo, lam[k] / rho)), fabs(fmin(g_up, lam[N + k] / rho))));
-    sigma[k] = (s_up - s_lo) * idt;
-    w[k] = rho * ((s_lo > 0.0 ? 1.0 : 0.0) + (s_up > 0.0 ? 1.0 : 0.0)) * idt * idt;
-  }
-}
-
+// (velocity_rows: oh_figure8.h)
 // multiplier refresh of the velocity rows at an outer update (before k_couple of the same iteration reads them; a launch of its own so that
 // no lane reads a neighbour's row block while it is being rewritten): lam <- max(0, lam - rho_old g) at the re-evaluated accepted point
 template <int N>

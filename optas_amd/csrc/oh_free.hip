@@ -321,6 +321,77 @@ __global__ __launch_bounds__(256) void k_couple_free(FigParams P, FigBuffers D, 
   D.merit[slot][(size_t)t * Bp + b] = D.phi[slot][(size_t)t * Bp + b] + P.kappa * sm;
 }
 
+// Joint-velocity rows (oh_guards.vel_limits; enforce_model_limits(name, time_deriv=1), builder.py:471-509) on dq_t = (q_{t+1} - q_t) / dt, round 3.
+// They couple neighbouring knots exactly like the velocity cost: interval (t-1, t) is booked on knot t, its augmented-Lagrangian gradient
+// enters both knots, its Gauss-Newton weight w = rho_v (active rows) / dt^2 joins 2 kappa on the diagonal of both knots and in the coupling
+// block between them, which stays diagonal: E_t = -diag(2 kappa + w_t) -- the sweeps below carry that vector (D.E[slot], N rows per knot)
+// instead of the scalar.  (oracle restatement: oracle/guarded.py:solve_free_al(vlimits=...); locked family: couple_unit<N, true>)
+template <int N>
+__global__ __launch_bounds__(256) void k_vel_update_free(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y + P.t0;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (D.status[b] >= 0 || D.skip[b] || !GB.outer[b]) return;
+  // multiplier refresh at an outer update, at the re-evaluated accepted point with the old penalty (a launch of its own: no lane reads a
+  // neighbour's row block while it is rewritten)
+  const double rho = GB.rho[b] * GP.vscale, idt = 1.0 / P.dt;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double v = (D.q[slot][IDX(t, N, k)] - D.q[slot][IDX(t - 1, N, k)]) * idt;
+    double* l_lo = GB.lamv + IDX(t, 2 * N, k);
+    double* l_up = GB.lamv + IDX(t, 2 * N, N + k);
+    *l_lo = fmax(0.0, *l_lo - rho * (v - GP.vlo[k]));
+    *l_up = fmax(0.0, *l_up - rho * (GP.vup[k] - v));
+  }
+}
+template <int N>
+__global__ __launch_bounds__(256) void k_couple_free_vel(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
+  constexpr int NP = N * (N + 1) / 2;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y + P.t0;
+  const int Bp = D.Bp;
+  if (b >= D.B) return;
+  if (D.status[b] >= 0 || D.skip[b]) return;
+  const double* __restrict__ qs = D.q[slot];
+  const double kap2 = 2.0 * P.kappa;
+  const bool last = (t == P.T - 1);
+  double qm[N], q0[N], qp[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    qm[k] = qs[IDX(t - 1, N, k)];
+    q0[k] = qs[IDX(t, N, k)];
+    qp[k] = last ? 0.0 : qs[IDX(t + 1, N, k)];
+  }
+  const double rho = (GB.outer[b] ? GB.rho_next[b] : GB.rho[b]) * GP.vscale;
+  double lam[2 * N], sp[N], wp[N], sn[N], wn[N], psi_p, meas_p, psi_n, meas_n;
+#pragma unroll
+  for (int i = 0; i < 2 * N; ++i) lam[i] = GB.lamv[IDX(t, 2 * N, i)];
+  velocity_rows<N>(GP, P.dt, rho, qm, q0, lam, sp, wp, psi_p, meas_p);
+  if (!last) {
+#pragma unroll
+    for (int i = 0; i < 2 * N; ++i) lam[i] = GB.lamv[IDX(t + 1, 2 * N, i)];
+    velocity_rows<N>(GP, P.dt, rho, q0, qp, lam, sn, wn, psi_n, meas_n);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) sn[k] = wn[k] = 0.0;
+  }
+  double sm = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double dm = q0[k] - qm[k];
+    sm += dm * dm;
+    double G = D.g[slot][IDX(t, N, k)] + kap2 * dm + sp[k] - sn[k];
+    if (!last) G -= kap2 * (qp[k] - q0[k]);
+    D.gt[slot][IDX(t, N, k)] = G;
+    if (wp[k] + wn[k] > 0.0) D.Dr[slot][IDX(t, NP, tri(k, k))] += wp[k] + wn[k];
+    D.E[slot][IDX(t, N, k)] = kap2 + wn[k];  // the coupling of knots t and t+1, as the sweeps use it
+  }
+  D.merit[slot][(size_t)t * Bp + b] = D.phi[slot][(size_t)t * Bp + b] + psi_p + P.kappa * sm;
+  GB.psi[slot][(size_t)t * Bp + b] += psi_p;
+  D.cv[slot][(size_t)t * Bp + b] = fmax(D.cv[slot][(size_t)t * Bp + b], meas_p);
+}
+
 // S^{-1} (packed lower) from the packed Cholesky factor L and reciprocal pivots: Li = L^{-1}, Sinv = Li^T Li
 template <int M>
 OH_DEV void spd_inverse(const double (&L)[M * (M + 1) / 2], const double (&rd)[M], double (&Sinv)[M * (M + 1) / 2]) {
@@ -484,7 +555,7 @@ OH_DEV int free_decide(const FigParams& P, const FigBuffers& D, const GuardBuffe
   return -1;
 }
 
-template <int N, bool GUARD>
+template <int N, bool GUARD, bool VEL = false>
 OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, const int b, const int ts) {
   constexpr int NP = N * (N + 1) / 2;
   const int Bp = D.Bp;
@@ -515,6 +586,7 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
   double mu = lm.mu;
   const double* __restrict__ Drc = D.Dr[cur];
   const double* __restrict__ gtc = D.gt[cur];
+  const double* __restrict__ Ec = cur ? D.E[1] : D.E[0];  // velocity rows: the coupling vectors (VEL)
   double stat = 0.0;
   double S[NP], rd[N], rn[N];
   bool factored = false;
@@ -565,6 +637,21 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
       symv<N>(Sinv, rn, wv);  // S_{t+1}^{-1} r_{t+1}
 #pragma unroll
       for (int i = 0; i < NP; ++i) D.Kmat[IDX(t + 1, N * N, i)] = Sinv[i];
+      if constexpr (VEL) {
+        // E_t = -diag(d), d = 2 kappa + w_t (velocity rows of interval (t, t+1)): S_t = H_t - D S^{-1} D, r_t = g_t + D S^{-1} r
+        double dv[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) dv[a] = Ec[IDX(t, N, a)];
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+          D.kvec[IDX(t + 1, N, a)] = wv[a];
+          rn[a] = gt[a] + dv[a] * wv[a];
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) S[tri(i, j)] = Ht[tri(i, j)] - dv[i] * dv[j] * Sinv[tri(i, j)];
+      } else {
 #pragma unroll
       for (int a = 0; a < N; ++a) {
         D.kvec[IDX(t + 1, N, a)] = wv[a];
@@ -572,6 +659,7 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
       }
 #pragma unroll
       for (int i = 0; i < NP; ++i) S[i] = Ht[i] - kap2 * kap2 * Sinv[i];
+      }
     }
     ok = chol_rcp<N>(S, rd, 1e-12) && ok;
     if (ok) {
@@ -620,9 +708,17 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
           for (int a = 0; a < N; ++a) kn[a] = D.kvec[IDX(tn, N, a)];
           __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (VEL) {  // z_t = S_t^{-1} (D_{t-1} z_{t-1}) - S_t^{-1} r_t
+#pragma unroll
+          for (int a = 0; a < N; ++a) zz[a] *= Ec[IDX(t - 1, N, a)];
+          symv<N>(Sinv, zz, y);
+#pragma unroll
+          for (int a = 0; a < N; ++a) zz[a] = y[a] - kv[a];
+        } else {
         symv<N>(Sinv, zz, y);
 #pragma unroll
         for (int a = 0; a < N; ++a) zz[a] = kap2 * y[a] - kv[a];
+        }
       }
 #pragma unroll
       for (int a = 0; a < N; ++a) {
@@ -642,7 +738,7 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
   return true;
 }
 
-template <int N, bool GUARD>
+template <int N, bool GUARD, bool VEL = false>
 __global__ __launch_bounds__(64) void k_step_free(FigParams P, FigBuffers D, GuardBuffers GB, const int slot) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool alive = (b < D.B) && (D.status[b] < 0);
@@ -654,7 +750,7 @@ __global__ __launch_bounds__(64) void k_step_free(FigParams P, FigBuffers D, Gua
   }
   bool still = skipping;
   if (skipping) D.skip[b] = 0;
-  if (running) still = step_instance_free<N, GUARD>(P, D, GB, b, slot);
+  if (running) still = step_instance_free<N, GUARD, VEL>(P, D, GB, b, slot);
   const unsigned long long m2 = __ballot(still);
   if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
 }
@@ -668,7 +764,7 @@ __global__ __launch_bounds__(64) void k_step_free(FigParams P, FigBuffers D, Gua
 // definite iff the matrix is (Haynsworth: each level is a Schur complement onto the lanes of one parity class), so the damping loop raises mu
 // exactly when the serial sweep would.  The ratio test and the outer-loop decisions are the serial kernel's (free_accept / free_decide, lane 0).
 // The stage arrays are read knot-major (a lane's doubles lie a row apart): instances that share a line are dealt to the same XCD.
-template <int N, bool GUARD, int NT>
+template <int N, bool GUARD, int NT, bool VEL = false>
 __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D, GuardBuffers GB, const int slot) {
   constexpr int NP = N * (N + 1) / 2;
   constexpr int O_R = N * N;  // exchange tile: rows [0, N*N) one block (column-major), rows [N*N, N*N + N) one vector
@@ -749,6 +845,7 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
   };
   const double* __restrict__ Drc = D.Dr[cur];
   const double* __restrict__ gtc = D.gt[cur];
+  const double* __restrict__ Ec = cur ? D.E[1] : D.E[0];  // velocity rows: the coupling vectors (VEL)
   double stat = 0.0;
   if (active) {
 #pragma unroll
@@ -769,10 +866,16 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
     for (int i = 0; i < N; ++i) {
       A[tri(i, i)] = active ? A[tri(i, i)] + (last ? kap2 : 2.0 * kap2) + mu : 1.0;
       r[i] = active ? -gtc[IDX(tl, N, i)] : 0.0;
+      // coupling to the next / previous knot: -2 kappa I, with velocity rows -diag(2 kappa + w) of the interval in between (D.E)
+      double eu = kap2, el = kap2;
+      if constexpr (VEL) {
+        if (active && !last) eu = Ec[IDX(tl, N, i)];
+        if (active && lane > 0) el = Ec[IDX(tl - 1, N, i)];
+      }
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        U[i * N + j] = (i == j && active && !last) ? -kap2 : 0.0;
-        Lw[i * N + j] = (i == j && active && lane > 0) ? -kap2 : 0.0;
+        U[i * N + j] = (i == j && active && !last) ? -eu : 0.0;
+        Lw[i * N + j] = (i == j && active && lane > 0) ? -el : 0.0;
       }
     }
     bool ok = true;
@@ -917,11 +1020,11 @@ bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBu
   return true;
 }
 // pcr: one block per instance (k_step_free_pcr; the knots must fit 128 lanes)
-template <int N, bool GUARD>
+template <int N, bool GUARD, bool VEL = false>
 static void launch_step_free_pcr(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, int slot) {
   const dim3 g(8 * ((D.B + 7) / 8));
-  if (P.T - P.t0 <= 64) hipLaunchKernelGGL((k_step_free_pcr<N, GUARD, 64>), g, dim3(64), 0, s, P, D, GB, slot);
-  else hipLaunchKernelGGL((k_step_free_pcr<N, GUARD, 128>), g, dim3(128), 0, s, P, D, GB, slot);
+  if (P.T - P.t0 <= 64) hipLaunchKernelGGL((k_step_free_pcr<N, GUARD, 64, VEL>), g, dim3(64), 0, s, P, D, GB, slot);
+  else hipLaunchKernelGGL((k_step_free_pcr<N, GUARD, 128, VEL>), g, dim3(128), 0, s, P, D, GB, slot);
 }
 bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot, bool pcr) {
   const dim3 g((D.B + 63) / 64), b(64);
@@ -947,16 +1050,31 @@ bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigB
   else return false;
   return true;
 }
-bool oh_launch_step_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot, bool pcr) {
+template <int N>
+static void launch_step_guarded_t(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot, bool pcr) {
   const dim3 g((D.B + 63) / 64), b(64);
-  if (pcr && P.T - P.t0 <= 128 && (n == 7 || n == 6)) {
-    if (n == 7) launch_step_free_pcr<7, true>(s, P, D, GB, slot);
-    else launch_step_free_pcr<6, true>(s, P, D, GB, slot);
-    return true;
-  }
-  if (n == 7) hipLaunchKernelGGL((k_step_free<7, true>), g, b, 0, s, P, D, GB, slot);
-  else if (n == 6) hipLaunchKernelGGL((k_step_free<6, true>), g, b, 0, s, P, D, GB, slot);
+  if (pcr && P.T - P.t0 <= 128) {
+    if (GP.vel) launch_step_free_pcr<N, true, true>(s, P, D, GB, slot);
+    else launch_step_free_pcr<N, true>(s, P, D, GB, slot);
+  } else if (GP.vel) hipLaunchKernelGGL((k_step_free<N, true, true>), g, b, 0, s, P, D, GB, slot);
+  else hipLaunchKernelGGL((k_step_free<N, true>), g, b, 0, s, P, D, GB, slot);
+}
+bool oh_launch_step_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot, bool pcr) {
+  if (n == 7) launch_step_guarded_t<7>(s, P, D, GP, GB, slot, pcr);
+  else if (n == 6) launch_step_guarded_t<6>(s, P, D, GP, GB, slot, pcr);
   else return false;
+  return true;
+}
+// position-tracking family with joint-velocity rows: multiplier refresh of those rows (outer updates only), then the coupling
+bool oh_launch_couple_free_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
+  const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
+  if (n == 7) {
+    hipLaunchKernelGGL(k_vel_update_free<7>, g, b, 0, s, P, D, GP, GB, slot);
+    hipLaunchKernelGGL(k_couple_free_vel<7>, g, b, 0, s, P, D, GP, GB, slot);
+  } else if (n == 6) {
+    hipLaunchKernelGGL(k_vel_update_free<6>, g, b, 0, s, P, D, GP, GB, slot);
+    hipLaunchKernelGGL(k_couple_free_vel<6>, g, b, 0, s, P, D, GP, GB, slot);
+  } else return false;
   return true;
 }
 

@@ -28,6 +28,7 @@ bool oh_launch_couple_vel(hipStream_t s, int n, const FigParams& P, const FigBuf
 bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_eval_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_launch_couple_free_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
 bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot, bool pcr = false);  // pcr: one block per instance
 bool oh_launch_setup_guards(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const double* p);
 bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);

@@ -446,6 +446,8 @@ class GuardSpec:
     links: list          # sphere link names
     link_radii: list     # parameter labels, one per link
     obstacles: list      # (position label, radius label) per obstacle
+    vlo: Optional[np.ndarray] = None  # joint-velocity limits (enforce_model_limits(name, time_deriv=1)), None: no such rows
+    vup: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -525,8 +527,12 @@ def match_multi_arm(opt: Optimization) -> MultiArmSpec:
                 a["lo"], hit = np.maximum(a.get("lo", np.full(n, -np.inf)), d.b.value[:, 0]), True
             elif isinstance(d, Sub) and d.b is a["Q"] and isinstance(d.a, Const) and d.a.value.shape == (n, 1):
                 a["up"], hit = np.minimum(a.get("up", np.full(n, np.inf)), d.a.value[:, 0]), True
+            elif isinstance(d, Sub) and d.a is a["dQ"] and isinstance(d.b, Const) and d.b.value.shape == (n, 1):
+                a["vlo"], hit = np.maximum(a.get("vlo", np.full(n, -np.inf)), d.b.value[:, 0]), True
+            elif isinstance(d, Sub) and d.b is a["dQ"] and isinstance(d.a, Const) and d.a.value.shape == (n, 1):
+                a["vup"], hit = np.minimum(a.get("vup", np.full(n, np.inf)), d.a.value[:, 0]), True
         if not hit:
-            no(f"linear inequality '{label}' is not a joint-position bound over the whole trajectory")
+            no(f"linear inequality '{label}' is not a joint-position or joint-velocity bound over the whole trajectory")
     for label, d in opt.ineq_constraints.items():
         ok = (isinstance(d, Sub) and isinstance(d.a, SumSqr) and isinstance(d.a.a, Sub) and isinstance(d.a.a.a, LinkFunction)
               and d.a.a.a.what == "position" and isinstance(d.a.a.b, ParamRef) and d.a.a.b.shape == (3, 1)
@@ -540,8 +546,8 @@ def match_multi_arm(opt: Optimization) -> MultiArmSpec:
             no(f"inequality '{label}' mixes models")
         a.setdefault("spheres", {})[(pos.q.t, pos.link, d.a.a.b.name)] = (d.b.a.a.name, d.b.a.b.name)
     for name, a in arms.items():
-        if ("lo" in a) != ("up" in a):
-            no(f"robot '{name}': joint limits need both the lower and the upper row block")
+        if ("lo" in a) != ("up" in a) or ("vlo" in a) != ("vup" in a):
+            no(f"robot '{name}': limits need both the lower and the upper row block")
         g = None
         sph = a.get("spheres")
         if sph:
@@ -558,9 +564,9 @@ def match_multi_arm(opt: Optimization) -> MultiArmSpec:
             for (t, ln, on), (lr, orr) in sph.items():
                 if lr != lrad[ln] or orr != orad[on]:
                     no(f"robot '{name}': inconsistent radius parameters in the sphere rows")
-            g = GuardSpec(a.get("lo"), a.get("up"), links, [lrad[ln] for ln in links], [(on, orad[on]) for on in obst])
-        elif "lo" in a:
-            g = GuardSpec(a["lo"], a["up"], [], [], [])
+            g = GuardSpec(a.get("lo"), a.get("up"), links, [lrad[ln] for ln in links], [(on, orad[on]) for on in obst], a.get("vlo"), a.get("vup"))
+        elif "lo" in a or "vlo" in a:
+            g = GuardSpec(a.get("lo"), a.get("up"), [], [], [], a.get("vlo"), a.get("vup"))
         a["guards"] = g
     out = []
     for name, a in arms.items():

@@ -767,8 +767,23 @@ def _probe_arm_guards(opt, models, robots, arms, T, xvec, Qc, Zs, pvec, qcs, pof
             if np.abs(lo - lo[0]).max() > 0 or np.abs(up - up[0]).max() > 0 or not (lo[0] < up[0]).all():
                 no(f"robot '{m.get_name()}': the limit rows are not one bound pair per joint over the whole trajectory")
             lims[i] = (lo[0].copy(), up[0].copy())
+    # ---- joint-velocity limits: "__{name}_model_limit_1___l" / "_r", each vec of an n x (T-1) block over the dq states
+    vlims = [None] * len(models)
+    for i, m in enumerate(models):
+        lab = f"__{m.get_name()}_model_limit_1__"
+        if lab + "_l" in koff or lab + "_r" in koff:
+            if not (lab + "_l" in koff and lab + "_r" in koff) or koff[lab + "_l"][1:] != (ns[i], T - 1) or koff[lab + "_r"][1:] != (ns[i], T - 1):
+                no(f"robot '{m.get_name()}': joint-velocity limits need both blocks, n x (T-1) each")
+            expected |= {lab + "_l", lab + "_r"}
+            k0 = _vec(opt.k, np.zeros_like(x0), p0)
+            m_ = ns[i] * (T - 1)
+            vlo = -k0[koff[lab + "_l"][0] : koff[lab + "_l"][0] + m_].reshape(T - 1, ns[i])
+            vup = k0[koff[lab + "_r"][0] : koff[lab + "_r"][0] + m_].reshape(T - 1, ns[i])
+            if np.abs(vlo - vlo[0]).max() > 0 or np.abs(vup - vup[0]).max() > 0 or not (vlo[0] < vup[0]).all():
+                no(f"robot '{m.get_name()}': the velocity-limit rows are not one bound pair per joint over the whole trajectory")
+            vlims[i] = (vlo[0].copy(), vup[0].copy())
     if set(koff) != expected:
-        no(f"linear inequality blocks other than the robots' joint limits: {sorted(set(koff) - expected)}")
+        no(f"linear inequality blocks other than the robots' joint and joint-velocity limits: {sorted(set(koff) - expected)}")
     if expected:
         Qr = [rng.normal(size=(T, n)) for n in ns]
         kr = _vec(opt.k, xvec(Qr, Zs), pvec([rng.normal(size=n) for n in ns]))
@@ -780,6 +795,16 @@ def _probe_arm_guards(opt, models, robots, arms, T, xvec, Qc, Zs, pvec, qcs, pof
             if (np.abs(kr[a0 : a0 + ns[i] * T].reshape(T, ns[i]) - (Qr[i] - lims[i][0][None])).max() > 1e-9
                     or np.abs(kr[b0 : b0 + ns[i] * T].reshape(T, ns[i]) - (lims[i][1][None] - Qr[i])).max() > 1e-9):
                 no(f"robot '{m.get_name()}': the limit rows are not [Q - lo; up - Q]")
+        Zr = [rng.normal(size=np.shape(z)) for z in Zs]
+        kv = _vec(opt.k, xvec(Qr, Zr), pvec([rng.normal(size=n) for n in ns]))
+        for i, m in enumerate(models):
+            if vlims[i] is None:
+                continue
+            lab = f"__{m.get_name()}_model_limit_1__"
+            a0, b0, m_ = koff[lab + "_l"][0], koff[lab + "_r"][0], ns[i] * (T - 1)
+            if (np.abs(kv[a0 : a0 + m_].reshape(T - 1, ns[i]) - (np.reshape(Zr[i], (T - 1, ns[i])) - vlims[i][0][None])).max() > 1e-9
+                    or np.abs(kv[b0 : b0 + m_].reshape(T - 1, ns[i]) - (vlims[i][1][None] - np.reshape(Zr[i], (T - 1, ns[i])))).max() > 1e-9):
+                no(f"robot '{m.get_name()}': the velocity-limit rows are not [dQ - lo; up - dQ]")
     # ---- sphere clearances: "sphere_col_avoid_{t}_{link}_{obstacle}", one scalar row each (builder.py:407-415)
     glabels = list(opt.ineq_constraints.keys())
     sph = [dict() for _ in models]
@@ -859,9 +884,10 @@ def _probe_arm_guards(opt, models, robots, arms, T, xvec, Qc, Zs, pvec, qcs, pof
                         got = np.array([gv[sph[i][(t, ln, on)]] for t in range(T)])
                         if np.abs(want - got).max() > 1e-9:
                             no(f"robot '{m.get_name()}': rows of link '{ln}' / obstacle '{on}' are not ||p_link(q_t) - o||^2 - (r_link + r_o)^2")
-        if lims[i] is not None or sph[i]:
+        if lims[i] is not None or sph[i] or vlims[i] is not None:
             lo, up = lims[i] if lims[i] is not None else (None, None)
-            arms[i].guards = GuardSpec(lo, up, links, lrad_names, obs_names)
+            vlo, vup = vlims[i] if vlims[i] is not None else (None, None)
+            arms[i].guards = GuardSpec(lo, up, links, lrad_names, obs_names, vlo, vup)
     if set(extra_params) != used_params:
         no(f"parameters that belong to no recognised row: {sorted(set(extra_params) - used_params)}")
 

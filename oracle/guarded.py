@@ -77,14 +77,22 @@ def guard_values(chain: FoldedChain, Q, G: Guards, weights=None):
                         HW[:, a, b] += v
                         if a != b:
                             HW[:, b, a] += v
-    g_all, dg_all = np.concatenate(vals, 1), np.concatenate(jac, 1)
+    if not vals:  # no position rows at all (velocity rows only)
+        g_all, dg_all = np.zeros((T, 0)), np.zeros((T, 0, n))
+    else:
+        g_all, dg_all = np.concatenate(vals, 1), np.concatenate(jac, 1)
     if weights is not None:
         return g_all, dg_all, HW
     return g_all, dg_all
 
 
 def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=None, w_path=1.0, w_vel=0.01, fix_dq0=False, max_iter=400,
-                  tol=1e-6, tol_feas=1e-9, rho0=1e3, verbose=False, exact=True):
+                  tol=1e-6, tol_feas=1e-9, rho0=1e3, verbose=False, exact=True, vlimits=None):
+    """vlimits = (vlo, vup): joint-velocity rows dq_t - vlo >= 0, vup - dq_t >= 0 on dq_t = (q_{t+1} - q_t) / dt, t = 0 .. T-2
+    (enforce_model_limits(name, time_deriv=1), builder.py:471-509; round 3: k_couple_free_vel in csrc/oh_free.hip).  Same treatment as in
+    oracle/structured.py: penalty rho * vscale, the value of interval (t-1, t) is booked on knot t, its gradient enters both knots, its
+    Gauss-Newton weight rho_v / dt^2 joins 2 kappa on the diagonal of both knots and in the coupling block between them (which stays
+    diagonal).  Adds "lam_v" (T-1, 2n) and "g_v"."""
     n = chain.ndof
     t0 = 2 if fix_dq0 else 1
     kap = w_vel / dt**2
@@ -98,6 +106,26 @@ def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=Non
     rho = rho_next = rho0
     omega = max(tol, 1e-2)
     meas_prev = np.inf
+    vel = vlimits is not None
+    if vel:
+        vlo, vup = (np.asarray(v, dtype=float) for v in vlimits)
+        lam_v = np.zeros((T - 1, 2 * n))
+        vscale = dt**2 / 40.0  # as in oracle/structured.py (GuardParams.vscale): the rows' Gauss-Newton weight is rho / 40
+
+    def vel_terms(Q, lam_v, rho):
+        v = (Q[1:] - Q[:-1]) / dt
+        gv = np.concatenate([v - vlo[None], vup[None] - v], 1)
+        rv = rho * vscale
+        sv = np.maximum(0.0, lam_v - rv * gv)
+        fixed = slice(0, t0 - 1)  # intervals between fixed knots carry no row the solver can move
+        sv[fixed] = 0.0
+        psi = (sv * sv - lam_v * lam_v) / (2.0 * rv)
+        psi[fixed] = 0.0
+        sig = (sv[:, n:] - sv[:, :n]) / dt
+        wv = rv * ((sv[:, :n] > 0.0).astype(float) + (sv[:, n:] > 0.0).astype(float)) / dt**2
+        meas = np.abs(np.minimum(gv, lam_v / rv))
+        meas[fixed] = 0.0
+        return gv, psi.sum(1), sig, wv, float(meas.max()) if meas.size else 0.0
 
     def evalp(Q, lam, rho):
         e, Re, Jp, Jw = chain.jac(Q)
@@ -122,7 +150,15 @@ def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=Non
         Gs = np.zeros_like(Q)
         Gs[1:] += 2 * kap * d
         Gs[:-1] -= 2 * kap * d
-        return f, g + Gs, W, gv, float(meas.max())
+        mx = float(meas.max()) if meas.size else 0.0
+        wv = np.zeros((T - 1, n))
+        if vel:
+            _, psi_v, sig, wv, meas_v = vel_terms(Q, lam_v, rho)
+            f += float(psi_v.sum())
+            Gs[1:] += sig
+            Gs[:-1] -= sig
+            mx = max(mx, meas_v)
+        return f, g + Gs, W, gv, mx, wv
 
     mu, nun = 0.0, 2.0
     iters = rejected = outers = 0
@@ -137,9 +173,12 @@ def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=Non
             gv_now, _ = guard_values(chain, Qt, guards)
             lam = np.maximum(0.0, lam - rho * gv_now)
             lam[:t0] = 0.0
+            if vel:
+                lam_v = np.maximum(0.0, lam_v - rho * vscale * vel_terms(Qt, lam_v, rho)[0])
+                lam_v[: max(t0 - 1, 0)] = 0.0
             rho = rho_next
             outers += 1
-        f_t, G, W, gv, meas_t = evalp(Qt, lam, rho)
+        f_t, G, W, gv, meas_t, wv_t = evalp(Qt, lam, rho)
         if first or outer:
             accept, first, outer = True, False, False
         else:
@@ -171,10 +210,14 @@ def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=Non
             ls_count, ls_scale = 0, 1.0
             ndiag = np.full(T, 2.0)
             ndiag[T - 1] = 1.0
-            cur = {"Q": Qt, "f": f_t, "G": G[F], "D": (W + (2 * kap * ndiag)[:, None, None] * np.eye(n)[None])[F], "meas": meas_t}
+            Dfull = W + (2 * kap * ndiag)[:, None, None] * np.eye(n)[None]
+            wsum = np.zeros((T, n))
+            wsum[1:] += wv_t
+            wsum[:-1] += wv_t
+            Dfull = Dfull + np.einsum("tj,jk->tjk", wsum, np.eye(n))
+            cur = {"Q": Qt, "f": f_t, "G": G[F], "D": Dfull[F], "meas": meas_t, "Er": -np.einsum("tj,jk->tjk", 2 * kap + wv_t[t0:], np.eye(n))}
         stat = float(np.max(np.abs(cur["G"])))
-        nf = T - t0
-        Er = np.tile(-2 * kap * np.eye(n), (nf - 1, 1, 1))
+        Er = cur["Er"]
         while True:
             z, ok = block_tridiag_solve(cur["D"], Er, -cur["G"], mu)
             if ok:
@@ -210,5 +253,11 @@ def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=Non
     lam_out[:t0] = 0.0
     e, _, _, _ = chain.fk(cur["Q"])
     f_true = float(w_path * np.sum((path - e) ** 2) + kap * np.sum(np.diff(cur["Q"], axis=0) ** 2))
-    return {"Q": cur["Q"], "f": f_true, "iters": iters, "rejected": rejected, "outers": outers, "stat": stat, "meas": cur["meas"],
-            "status": status, "lam": lam_out, "g": gv}
+    out = {"Q": cur["Q"], "f": f_true, "iters": iters, "rejected": rejected, "outers": outers, "stat": stat, "meas": cur["meas"],
+           "status": status, "lam": lam_out, "g": gv}
+    if vel:
+        gvv = vel_terms(cur["Q"], lam_v, rho)[0]
+        lv = np.maximum(0.0, lam_v - rho * vscale * gvv)
+        lv[: max(t0 - 1, 0)] = 0.0
+        out.update(lam_v=lv, g_v=gvv)
+    return out

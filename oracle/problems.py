@@ -516,16 +516,19 @@ class GuardedDualArmNLP(DualArmNLP):
     g = per arm, knot-major, link, obstacle:  ||p_link(q_t) - o||^2 - (r_link + r_o)^2          (builder.py:407-415)
     """
 
-    def __init__(self, robot_l, robot_r, links, n_obs, link="end_effector_ball", T=50, Tmax=10.0, w_dq=0.01, limits=True):
+    def __init__(self, robot_l, robot_r, links, n_obs, link="end_effector_ball", T=50, Tmax=10.0, w_dq=0.01, limits=True, vlimits=None):
+        """vlimits = (vlo, vup): enforce_model_limits(name, time_deriv=1) per arm after the position limits (builder.py:471-509):
+        k gains [dQl - vlo; vup - dQl; dQr - vlo; vup - dQr], each block vec of a 7 x (T-1) array."""
         super().__init__(robot_l, robot_r, link=link, T=T, Tmax=Tmax, w_dq=w_dq)
         from .structured import FoldedChain
 
         self.links, self.n_obs, self.limits = list(links), n_obs, limits
+        self.vlimits = None if vlimits is None else (np.asarray(vlimits[0], float), np.asarray(vlimits[1], float))
         self.chains = {arm: FoldedChain(self.robots[arm], link) for arm in ("l", "r")}
         L = len(self.links)
         self.npar_arm = L + 4 * n_obs
         self.np_ = 2 * self.n + 2 * self.npar_arm
-        self.nk = 4 * self.n * T if limits else 0
+        self.nk = (4 * self.n * T if limits else 0) + (4 * self.n * (T - 1) if vlimits is not None else 0)
         self.ng = 2 * T * L * n_obs
 
     def arm_params(self, p, k):
@@ -541,25 +544,40 @@ class GuardedDualArmNLP(DualArmNLP):
         return Guards(lo=None, up=None, links=self.links, link_radii=lr, obs_pos=op, obs_radii=orad)
 
     def k(self, x, p):
-        if not self.limits:
+        if not self.limits and self.vlimits is None:
             return np.zeros(0)
         s = self.split(x)
         out = []
-        for arm in ("l", "r"):
-            Q = s[arm][0]
-            lo, up = self.robots[arm].lower_actuated_joint_limits, self.robots[arm].upper_actuated_joint_limits
-            out += [(Q - lo[:, None]).T.reshape(-1), (up[:, None] - Q).T.reshape(-1)]
+        if self.limits:
+            for arm in ("l", "r"):
+                Q = s[arm][0]
+                lo, up = self.robots[arm].lower_actuated_joint_limits, self.robots[arm].upper_actuated_joint_limits
+                out += [(Q - lo[:, None]).T.reshape(-1), (up[:, None] - Q).T.reshape(-1)]
+        if self.vlimits is not None:
+            vlo, vup = self.vlimits
+            for arm in ("l", "r"):
+                dQ = s[arm][1]
+                out += [(dQ - vlo[:, None]).T.reshape(-1), (vup[:, None] - dQ).T.reshape(-1)]
         return np.concatenate(out)
 
     def dk(self, x, p):
         n, T = self.n, self.T
         M = np.zeros((self.nk, self.nx))
+        r0 = 0
         if self.limits:
             I = np.eye(n * T)
             for k in range(2):
                 base = k * self.nx1
                 M[(2 * k) * n * T : (2 * k + 1) * n * T, base : base + n * T] = I
                 M[(2 * k + 1) * n * T : (2 * k + 2) * n * T, base : base + n * T] = -I
+            r0 = 4 * n * T
+        if self.vlimits is not None:
+            m = n * (T - 1)
+            I = np.eye(m)
+            for k in range(2):
+                base = k * self.nx1 + n * T
+                M[r0 + (2 * k) * m : r0 + (2 * k + 1) * m, base : base + m] = I
+                M[r0 + (2 * k + 1) * m : r0 + (2 * k + 2) * m, base : base + m] = -I
         return M
 
     def g(self, x, p):

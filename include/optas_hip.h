@@ -236,6 +236,8 @@ typedef struct oh_torque_desc {
   double tol_feas; /* |min(g, lam / rho)|_inf over the effort rows (bounds violation and complementarity at once); <= 0: 1e-9 */
   double rho0;     /* initial penalty; <= 0: 1 */
   double mu0;      /* initial Levenberg-Marquardt damping of the state part of the step; < 0: 0 */
+  double dq_lo[OH_MAX_CHAIN]; /* joint-velocity limits on the velocity states: enforce_model_limits(name, time_deriv=1) (builder.py:471-509), rows */
+  double dq_up[OH_MAX_CHAIN]; /* dq_t - dq_lo >= 0, dq_up - dq_t >= 0 at every knot; all zero (a zero-initialised descriptor): no such rows */
 } oh_torque_desc;
 
 #define OH_QP_MAX_N 32

@@ -175,6 +175,8 @@ class oh_torque_desc(C.Structure):
         ("tol_feas", C.c_double),
         ("rho0", C.c_double),
         ("mu0", C.c_double),
+        ("dq_lo", C.c_double * OH_MAX_CHAIN),
+        ("dq_up", C.c_double * OH_MAX_CHAIN),
     ]
 
 

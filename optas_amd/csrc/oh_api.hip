@@ -560,6 +560,11 @@ extern "C" int oh_create_torque(const oh_torque_desc* desc, oh_handle** out) {
     return fail(OH_ERR_INVALID, "oh_create_torque: dt and w_tau must be positive, w_path and w_vel non-negative");
   for (int i = 0; i < desc->ndof; ++i)
     if (!(desc->tau_lo[i] < desc->tau_up[i])) return fail(OH_ERR_INVALID, "oh_create_torque: tau_lo must be below tau_up");
+  bool vel = false;  // all-zero dq_lo / dq_up (a zero-initialised descriptor): no joint-velocity rows
+  for (int i = 0; i < desc->ndof; ++i) vel = vel || desc->dq_lo[i] != 0.0 || desc->dq_up[i] != 0.0;
+  if (vel)
+    for (int i = 0; i < desc->ndof; ++i)
+      if (!(desc->dq_lo[i] < desc->dq_up[i])) return fail(OH_ERR_INVALID, "oh_create_torque: dq_lo must be below dq_up");
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1)
     return fail(OH_ERR_HIP, "oh_create_torque: no HIP device available (this library has no CPU path)");
@@ -602,6 +607,9 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   for (int i = 0; i < N; ++i) {
     P.tau_lo[i] = h->tq.tau_lo[i];
     P.tau_up[i] = h->tq.tau_up[i];
+    P.dq_lo[i] = h->tq.dq_lo[i];
+    P.dq_up[i] = h->tq.dq_up[i];
+    if (P.dq_lo[i] != 0.0 || P.dq_up[i] != 0.0) P.vel = 1;
   }
   P.nx = 4 * N * T;
   P.np = 2 * N + 3 * T;
@@ -620,7 +628,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     const size_t nd = 2 * BT * TQ_XS + 2 * BT * TQ_SD + BT * TQ_LAM + BT * TQ_GN + BT * 4 + 4 * BT * TQ_HS + 11 * (size_t)B;
     const size_t bytes = nd * sizeof(double) + (10 * (size_t)B + 16) * sizeof(int);
     HIPCHK(hipMalloc(&h->tq_pool, bytes));
-    HIPCHK(hipMalloc((void**)&h->d_tq_mult, sizeof(double) * BT * 2 * N));
+    HIPCHK(hipMalloc((void**)&h->d_tq_mult, sizeof(double) * BT * 4 * N));  // effort rows, and room for the velocity rows
     h->tq_cap = B;
   }
   {
@@ -1441,7 +1449,7 @@ extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
     return fail(OH_ERR_STATE, "oh_get_multipliers: B does not match the last solve");
   HIPCHK(hipSetDevice(h->device));
   if (h->desc.kind == OH_PROBLEM_TORQUE_MPC) {
-    HIPCHK(hipMemcpy(lam_h, h->d_tq_mult, sizeof(double) * (size_t)B * h->tq.T * 2 * h->tq.ndof, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(lam_h, h->d_tq_mult, sizeof(double) * (size_t)B * h->tq.T * (h->TqP.vel ? 4 : 2) * h->tq.ndof, hipMemcpyDeviceToHost));
     return OH_OK;
   }
   if (h->desc.kind == OH_PROBLEM_TAPE) {

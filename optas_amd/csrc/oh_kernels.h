@@ -68,12 +68,14 @@ void oh_launch_pm_advance(hipStream_t s, int B, int T, int advance, const double
 // tangent direction) and the Riccati kernel with 16 lanes per instance, so a wavefront reads whole stage records.
 #define TQ_XS 24    // per knot: q (N) at 0, dq (N) at 8, ddq (N) at 16
 #define TQ_SD 272   // per knot stage record: H packed lower (3N)(3N+1)/2 at 0 | g (3N) at 231 | phi 252, phi_true 253, meas 254, viol 255 | tau (N) at 256 | compl 263
-#define TQ_LAM 16   // per knot: multipliers of tau - lo >= 0 (N), then of up - tau >= 0 (N)
+#define TQ_LAM 32   // per knot: multipliers of tau - lo >= 0 (N), then of up - tau >= 0 (N); at 16: of dq - dq_lo >= 0 (N), then of dq_up - dq >= 0 (N)
 #define TQ_GN 112   // per knot: gains K (column c of 2N: N values at c N), feed-forward k at 2N N
 struct TqParams {
   int T, N, max_iter;
   double dt, w_path, w_vel, w_tau, tol, tol_feas, rho0, mu0;
   double tau_lo[OH_MAX_CHAIN], tau_up[OH_MAX_CHAIN];
+  double dq_lo[OH_MAX_CHAIN], dq_up[OH_MAX_CHAIN];  // joint-velocity rows on the velocity states (vel != 0)
+  int vel;
   int nx, np;
   int aa_m;         // Anderson acceleration of the Gauss-Newton iteration: history depth (0 off, <= 3), see k_tq_step
   double aa_from;   // ... once the reduced gradient is below this

@@ -352,6 +352,35 @@ __global__ __launch_bounds__(256) void k_tq_list(TqBuffers D) {
 #ifndef OH_TQ_EVAL_WAVES
 #define OH_TQ_EVAL_WAVES 2
 #endif
+// Joint-velocity rows on the velocity states (oh_torque_desc.dq_lo / dq_up; enforce_model_limits(name, time_deriv=1), builder.py:471-509), round 3:
+// stage-local rows of the state, through the same augmented Lagrangian and outer loop as the effort rows.  Every lane of a unit runs this
+// (cheap, and all of them need psi / meas); `writer` stores the refreshed multipliers at an outer update.  cv[j] joins the gradient component
+// of dq_j, dv[j] its diagonal entry of the Gauss-Newton block.
+template <int N>
+OH_DEV void tq_velocity_rows(const TqParams& P, double* __restrict__ lm, const double (&dqv)[N], const double rho, const double rho_old, const bool outer,
+                             const bool writer, double& psi, double& meas, double& viol, double& cmpl, double (&cv)[N], double (&dv)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double g_lo = dqv[i] - P.dq_lo[i], g_up = P.dq_up[i] - dqv[i];
+    double l_lo = lm[16 + i], l_up = lm[16 + N + i];
+    if (outer) {
+      l_lo = fmax(0.0, l_lo - rho_old * g_lo);
+      l_up = fmax(0.0, l_up - rho_old * g_up);
+    }
+    const double s_lo = fmax(0.0, l_lo - rho * g_lo), s_up = fmax(0.0, l_up - rho * g_up);
+    psi += (s_lo * s_lo - l_lo * l_lo) / (2.0 * rho) + (s_up * s_up - l_up * l_up) / (2.0 * rho);
+    meas = fmax(meas, fmax(fabs(fmin(g_lo, l_lo / rho)), fabs(fmin(g_up, l_up / rho))));
+    viol = fmax(viol, fmax(-g_lo, -g_up));
+    cmpl = fmax(cmpl, fmax(fabs(s_lo * g_lo), fabs(s_up * g_up)));
+    cv[i] = s_up - s_lo;
+    dv[i] = rho * ((s_lo > 0.0 ? 1.0 : 0.0) + (s_up > 0.0 ? 1.0 : 0.0));
+    if (outer && writer) {
+      lm[16 + i] = l_lo;
+      lm[16 + N + i] = l_up;
+    }
+  }
+}
+
 template <int N>
 __global__ __launch_bounds__(64, OH_TQ_EVAL_WAVES) void k_tq_eval(TqParams P, TqBuffers D) {
   constexpr int NZ = 3 * N;  // 21 tangent directions: q, dq, ddq
@@ -418,6 +447,10 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL_WAVES) void k_tq_eval(TqParams P, Tq
     dw[i] = 2.0 * P.w_tau + rho * ((s_lo > 0.0 ? 1.0 : 0.0) + (s_up > 0.0 ? 1.0 : 0.0));
     tau2 += tv * tv;
   }
+  double cv[N], dv[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) cv[i] = dv[i] = 0.0;
+  if (P.vel) tq_velocity_rows<N>(P, lm, dqv, rho, rho_old, outer, active && d == 0, psi, meas, viol, cmpl, cv, dv);
 
   // link position and column d of its Jacobian (models.py:826-868, 1211-1264)
   double R[9], pp[3], z[N][3], pj[N][3];
@@ -455,11 +488,16 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL_WAVES) void k_tq_eval(TqParams P, Tq
 #pragma unroll
   for (int i = 0; i < N; ++i) gd = fma(cw[i], tau[i].d, gd);
   gd += 2.0 * P.w_path * dot3(jp, r);
-  double dqd = 0.0;
+  double dqd = 0.0, cvd = 0.0, dvd = 0.0;
 #pragma unroll
   for (int j = 0; j < N; ++j)
-    if (d == N + j) dqd = dqv[j];
+    if (d == N + j) {
+      dqd = dqv[j];
+      cvd = cv[j];
+      dvd = dv[j];
+    }
   gd += 2.0 * P.w_vel * dqd;
+  gd += cvd;  // (its own statement: the sum above keeps the rounding it had before the velocity rows existed)
 
   // exchange the columns through LDS and form column d of the Gauss-Newton block (rows d..NZ-1)
 #pragma unroll
@@ -477,7 +515,10 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL_WAVES) void k_tq_eval(TqParams P, Tq
 #pragma unroll
       for (int k = 0; k < 3; ++k) hp = fma(tile[ul][N + k][rr], jp[k], hp);
       hv = fma(2.0 * P.w_path, hp, hv);
-      if (rr == d && d >= N && d < 2 * N) hv += 2.0 * P.w_vel;
+      if (rr == d && d >= N && d < 2 * N) {
+        hv += 2.0 * P.w_vel;
+        hv += dvd;
+      }
       sr[rr * (rr + 1) / 2 + d] = hv;
     }
     sr[231 + d] = gd;
@@ -577,6 +618,10 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
       lm[N + i] = l_up;
     }
   }
+  double cv[N], dv[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) cv[i] = dv[i] = 0.0;
+  if (P.vel) tq_velocity_rows<N>(P, lm, dqv, rho, rho_old, outer, active && j == 0, psi, meas, viol, cmpl, cv, dv);
 
   // link position and column j of its Jacobian (models.py:826-868, 1211-1264)
   double R[9], pp[3], z[N][3], pj[N][3];
@@ -616,11 +661,16 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
     g2 = fma(cw[i], tau[i].d2, g2);
   }
   g0 += 2.0 * P.w_path * dot3(jp, r);
-  double dqj = 0.0;
+  double dqj = 0.0, cvj = 0.0, dvj = 0.0;
 #pragma unroll
   for (int k = 0; k < N; ++k)
-    if (k == j) dqj = dqv[k];
+    if (k == j) {
+      dqj = dqv[k];
+      cvj = cv[k];
+      dvj = dv[k];
+    }
   g1 += 2.0 * P.w_vel * dqj;
+  g1 += cvj;
 
   // exchange the columns through LDS; the link position has no dq / ddq columns
   if (lane_ok) {
@@ -656,7 +706,10 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
           for (int k = 0; k < 3; ++k) hp = fma(tile[ul][N + k][rr], jp[k], hp);
           hv = fma(2.0 * P.w_path, hp, hv);
         }
-        if (rr == d && c3 == 1) hv += 2.0 * P.w_vel;
+        if (rr == d && c3 == 1) {
+          hv += 2.0 * P.w_vel;
+          hv += dvj;
+        }
         sr[rr * (rr + 1) / 2 + d] = hv;
       }
     }
@@ -1133,8 +1186,13 @@ __global__ __launch_bounds__(64) void k_tq_finalize(TqParams P, TqBuffers D, dou
       }
       if (mult) {
         const double tv = sr[256 + j];
-        mult[((size_t)b * T + t) * 2 * N + j] = fmax(0.0, lm[j] - rho * (tv - P.tau_lo[j]));
-        mult[((size_t)b * T + t) * 2 * N + N + j] = fmax(0.0, lm[N + j] - rho * (P.tau_up[j] - tv));
+        const int NR = P.vel ? 4 * N : 2 * N;  // rows per knot: effort rows, then (with velocity limits) [dq - dq_lo; dq_up - dq]
+        mult[((size_t)b * T + t) * NR + j] = fmax(0.0, lm[j] - rho * (tv - P.tau_lo[j]));
+        mult[((size_t)b * T + t) * NR + N + j] = fmax(0.0, lm[N + j] - rho * (P.tau_up[j] - tv));
+        if (P.vel) {
+          mult[((size_t)b * T + t) * NR + 2 * N + j] = fmax(0.0, lm[16 + j] - rho * (xr[8 + j] - P.dq_lo[j]));
+          mult[((size_t)b * T + t) * NR + 3 * N + j] = fmax(0.0, lm[16 + N + j] - rho * (P.dq_up[j] - xr[8 + j]));
+        }
       }
     }
   }

@@ -720,6 +720,8 @@ class TorqueSpec:
     w_tau: float
     tau_lo: np.ndarray
     tau_up: np.ndarray
+    dq_lo: Optional[np.ndarray] = None  # joint-velocity limits on the velocity states (enforce_model_limits(name, time_deriv=1)), None: no such rows
+    dq_up: Optional[np.ndarray] = None
 
 
 def match_torque_mpc(opt: Optimization) -> TorqueSpec:
@@ -776,16 +778,20 @@ def match_torque_mpc(opt: Optimization) -> TorqueSpec:
     if len(opt.ineq_constraints):
         no("nonlinear inequalities are not lowered")
     # effort limits
-    lo = up = None
+    lo = up = vlo = vup = None
     for label, d in opt.lin_ineq_constraints.items():
         if isinstance(d, Sub) and d.a is TAU and isinstance(d.b, Const) and d.b.value.shape == (n, 1) and lo is None:
             lo = d.b.value[:, 0]
         elif isinstance(d, Sub) and d.b is TAU and isinstance(d.a, Const) and d.a.value.shape == (n, 1) and up is None:
             up = d.a.value[:, 0]
+        elif isinstance(d, Sub) and d.a is dQ and isinstance(d.b, Const) and d.b.value.shape == (n, 1) and vlo is None:
+            vlo = d.b.value[:, 0]
+        elif isinstance(d, Sub) and d.b is dQ and isinstance(d.a, Const) and d.a.value.shape == (n, 1) and vup is None:
+            vup = d.a.value[:, 0]
         else:
-            no(f"linear inequality '{label}' is not an effort bound over the whole torque trajectory (or a second one of its kind)")
-    if (lo is None) != (up is None):
-        no("effort limits need both the lower and the upper row block")
+            no(f"linear inequality '{label}' is not an effort or joint-velocity bound over the whole trajectory (or a second one of its kind)")
+    if (lo is None) != (up is None) or (vlo is None) != (vup is None):
+        no("limits need both the lower and the upper row block")
     if lo is None:
         lo, up = -1e9 * np.ones(n), 1e9 * np.ones(n)
     # costs
@@ -810,7 +816,8 @@ def match_torque_mpc(opt: Optimization) -> TorqueSpec:
     params = [k for k, v in opt.parameters.items() if v.numel() > 0]
     if params != [qc.name, dqc.name, goal.name]:
         no(f"the non-empty parameters must be [{qc.name}, {dqc.name}, {goal.name}] in this order (the kernel family reads p = [qc; dqc; vec(goal)]), found {params}")
-    return TorqueSpec(robot, link, T, dts[1], float(w_path), float(w_vel or 0.0), float(w_tau), np.asarray(lo, float), np.asarray(up, float))
+    return TorqueSpec(robot, link, T, dts[1], float(w_path), float(w_vel or 0.0), float(w_tau), np.asarray(lo, float), np.asarray(up, float),
+                      None if vlo is None else np.asarray(vlo, float), None if vup is None else np.asarray(vup, float))
 
 
 def lower(opt: Optimization):

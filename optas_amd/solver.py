@@ -280,7 +280,7 @@ class HIPSolver(Solver):
         elif isinstance(spec, TorqueSpec):
             o.pop("hessian", None)
             self._backend = TorqueBackend(spec.robot.solver_chain(spec.link), spec.robot.dynamics_tables(), T=spec.T, dt=spec.dt, w_path=spec.w_path,
-                                          w_vel=spec.w_vel, w_tau=spec.w_tau, tau_lo=spec.tau_lo, tau_up=spec.tau_up,
+                                          w_vel=spec.w_vel, w_tau=spec.w_tau, tau_lo=spec.tau_lo, tau_up=spec.tau_up, dq_lo=getattr(spec, "dq_lo", None), dq_up=getattr(spec, "dq_up", None),
                                           max_iter=int(o.pop("max_iter", 300)), tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)),
                                           rho0=float(o.pop("rho0", 0.0)), mu0=float(o.pop("mu0", 0.0)))
         elif isinstance(spec, PointMassSpec):

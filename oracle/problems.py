@@ -789,7 +789,9 @@ class TorqueMPCNLP(_NLPBase):
     f = w_path sum ||p_link(q_t) - goal_t||^2 + w_vel sum ||dQ||^2 + w_tau sum ||TAU||^2
     """
 
-    def __init__(self, prob):
+    def __init__(self, prob, vlimits=None):
+        """vlimits = (vlo, vup): enforce_model_limits(name, time_deriv=1) after the effort limits (builder.py:471-509): k gains
+        [vec(dQ) - vlo; vup - vec(dQ)] (round 3)."""
         from .torque import rnea_batch, rnea_jacobian  # the vectorised restatement of oracle.robot.rnea and its complex-step Jacobian
 
         self._rnea, self._rnea_jac = rnea_batch, rnea_jacobian
@@ -814,9 +816,15 @@ class TorqueMPCNLP(_NLPBase):
                 A[r:r + n, (d + 1) * nb + n * t:(d + 1) * nb + n * t + n] = -dt * I
                 A[r:r + n, d * nb + n * (t + 1):d * nb + n * (t + 1) + n] = I
         self._A = A
+        self.vlimits = None if vlimits is None else tuple(np.broadcast_to(np.asarray(v, float), (n,)) for v in vlimits)
+        if self.vlimits is not None:
+            self.nk = 4 * self.nb
         K = np.zeros((self.nk, self.nx))
         K[:nb, 3 * nb:] = np.eye(nb)
-        K[nb:, 3 * nb:] = -np.eye(nb)
+        K[nb:2 * nb, 3 * nb:] = -np.eye(nb)
+        if self.vlimits is not None:
+            K[2 * nb:3 * nb, nb:2 * nb] = np.eye(nb)
+            K[3 * nb:, nb:2 * nb] = -np.eye(nb)
         self._K = K
 
     def split(self, x):
@@ -859,7 +867,11 @@ class TorqueMPCNLP(_NLPBase):
     def k(self, x, p):
         tau = x[3 * self.nb:]
         lo, up = np.tile(self.prob.tau_lo, self.T), np.tile(self.prob.tau_up, self.T)
-        return np.concatenate([tau - lo, up - tau])
+        rows = [tau - lo, up - tau]
+        if self.vlimits is not None:
+            dq = x[self.nb:2 * self.nb]
+            rows += [dq - np.tile(self.vlimits[0], self.T), np.tile(self.vlimits[1], self.T) - dq]
+        return np.concatenate(rows)
 
     def dk(self, x, p):
         return self._K

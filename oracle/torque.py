@@ -216,7 +216,7 @@ def anderson_mix(hx, hf):
 
 
 def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, tol=1e-6, tol_feas=1e-9, rho0=None, mu0=0.0, verbose=False, damp_u=0.0, hess_extra=None,
-                    aa_m=3, aa_from=1e-1):
+                    aa_m=3, aa_from=1e-1, vlimits=None):
     """The state machine of csrc/oh_torque.hip in numpy (one instance).
 
     aa_m > 0: Anderson acceleration of the Gauss-Newton iteration.  The tracking residual does not vanish at the optimum, so Gauss-Newton
@@ -230,11 +230,17 @@ def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, t
     lo, up = prob.tau_lo, prob.tau_up
     U = np.zeros((T, n)) if U0 is None else np.array(U0, float)
     lam = np.zeros((T, 2 * n))
+    # vlimits = (vlo, vup): rows dq_t - vlo >= 0, vup - dq_t >= 0 on the velocity states (enforce_model_limits(name, time_deriv=1),
+    # builder.py:471-509; round 3): stage-local rows of the state, same penalty and outer loop as the effort rows; adds "lam_v" (T, 2n)
+    vel = vlimits is not None
+    lam_v = np.zeros((T, 2 * n))
+    if vel:
+        vlo, vup = (np.broadcast_to(np.asarray(v, dtype=float), (n,)) for v in vlimits)
     rho = rho_next = (1.0 if rho0 is None else rho0)
     omega = max(tol, 1e-2)
     meas_prev = np.inf
 
-    def evalp(U, lam, rho):
+    def evalp(U, lam, rho, lam_v=lam_v):
         Q, dQ = prob.rollout(qc, dqc, U)
         tau = rnea_batch(prob.tb, Q, dQ, U)
         J = rnea_jacobian(prob.tb, Q, dQ, U)  # (T, n, 3n)
@@ -255,7 +261,16 @@ def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, t
         if hess_extra is not None:
             H = H + hess_extra(Q, dQ, U, c)
         meas = float(np.abs(np.minimum(gv, lam / rho)).max())
-        return float(phi.sum()), g, H, gv, meas, (Q, dQ, tau, J, c)
+        gw = np.zeros((T, 0))
+        if vel:
+            gw = np.concatenate([dQ - vlo, vup - dQ], 1)
+            sv = np.maximum(0.0, lam_v - rho * gw)
+            phi = phi + ((sv * sv - lam_v * lam_v) / (2.0 * rho)).sum(1)
+            g[:, n:2 * n] += -sv[:, :n] + sv[:, n:]
+            act = rho * ((sv[:, :n] > 0).astype(float) + (sv[:, n:] > 0).astype(float))
+            H[:, np.arange(n, 2 * n), np.arange(n, 2 * n)] += act
+            meas = max(meas, float(np.abs(np.minimum(gw, lam_v / rho)).max()))
+        return float(phi.sum()), g, H, np.concatenate([gv, gw], 1), meas, (Q, dQ, tau, J, c)
 
     mu, nun = mu0, 2.0
     iters = rejected = outers = 0
@@ -268,11 +283,13 @@ def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, t
     pred = 0.0
     while True:
         if outer:
-            lam = np.maximum(0.0, lam - rho * cur["gv"])
+            lam = np.maximum(0.0, lam - rho * cur["gv"][:, : 2 * n])
+            if vel:
+                lam_v = np.maximum(0.0, lam_v - rho * cur["gv"][:, 2 * n :])
             rho = rho_next
             outers += 1
             hx, hf = [], []  # the merit function changes
-        f_t, g, H, gv, meas_t, traj = evalp(Ut, lam, rho)
+        f_t, g, H, gv, meas_t, traj = evalp(Ut, lam, rho, lam_v)
         if first or outer:
             accept, first, outer = True, False, False
             aa_trial = aa_was = False
@@ -337,5 +354,8 @@ def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, t
     lam_out = np.maximum(0.0, lam - rho * gv)
     e, _, _, _ = prob.chain.fk(Q)
     f_true = float(wp * np.sum((e - goal) ** 2) + wt * np.sum(tau * tau) + wv * np.sum(dQ * dQ))
-    return {"U": cur["U"], "Q": Q, "dQ": dQ, "tau": tau, "f": f_true, "iters": iters, "rejected": rejected, "outers": outers, "stat": stat,
-            "meas": cur["meas"], "status": status, "lam": lam_out}
+    out = {"U": cur["U"], "Q": Q, "dQ": dQ, "tau": tau, "f": f_true, "iters": iters, "rejected": rejected, "outers": outers, "stat": stat,
+           "meas": cur["meas"], "status": status, "lam": lam_out}
+    if vel:
+        out["lam_v"] = np.maximum(0.0, lam_v - rho * np.concatenate([dQ - vlo, vup - dQ], 1))
+    return out

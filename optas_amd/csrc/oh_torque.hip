@@ -381,7 +381,7 @@ OH_DEV void tq_velocity_rows(const TqParams& P, double* __restrict__ lm, const d
   }
 }
 
-template <int N>
+template <int N, bool VEL = false>
 __global__ __launch_bounds__(64, OH_TQ_EVAL_WAVES) void k_tq_eval(TqParams P, TqBuffers D) {
   constexpr int NZ = 3 * N;  // 21 tangent directions: q, dq, ddq
   constexpr int UPW = 64 / NZ;  // units per wavefront (3)
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL_WAVES) void k_tq_eval(TqParams P, Tq
   double cv[N], dv[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) cv[i] = dv[i] = 0.0;
-  if (P.vel) tq_velocity_rows<N>(P, lm, dqv, rho, rho_old, outer, active && d == 0, psi, meas, viol, cmpl, cv, dv);
+  if constexpr (VEL) tq_velocity_rows<N>(P, lm, dqv, rho, rho_old, outer, active && d == 0, psi, meas, viol, cmpl, cv, dv);
 
   // link position and column d of its Jacobian (models.py:826-868, 1211-1264)
   double R[9], pp[3], z[N][3], pj[N][3];
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL_WAVES) void k_tq_eval(TqParams P, Tq
 #ifndef OH_TQ_EVAL3_WAVES
 #define OH_TQ_EVAL3_WAVES 1
 #endif
-template <int N>
+template <int N, bool VEL = false>
 __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, TqBuffers D) {
   constexpr int NZ = 3 * N;
   constexpr int UPW = 64 / N;  // units per wavefront (9)
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
   double cv[N], dv[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) cv[i] = dv[i] = 0.0;
-  if (P.vel) tq_velocity_rows<N>(P, lm, dqv, rho, rho_old, outer, active && j == 0, psi, meas, viol, cmpl, cv, dv);
+  if constexpr (VEL) tq_velocity_rows<N>(P, lm, dqv, rho, rho_old, outer, active && j == 0, psi, meas, viol, cmpl, cv, dv);
 
   // link position and column j of its Jacobian (models.py:826-868, 1211-1264)
   double R[9], pp[3], z[N][3], pj[N][3];
@@ -1232,8 +1232,12 @@ bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D) {
   // (The round-2 kernel, one lane per tangent direction, has the shorter dependent chain on a latency-bound launch -- one instance: 170 against
   // 190 us per evaluation -- but the two kernels round differently, and choosing by launch size would make an instance's iterates depend on how
   // fast the rest of its batch drains: one kernel for every launch.  1024 instances 369 -> 260 us, 8192 instances 2.73 -> 1.77 ms per launch.)
-  if (per_joint) hipLaunchKernelGGL(k_tq_eval3<7>, dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
-  else hipLaunchKernelGGL(k_tq_eval<7>, dim3((unsigned)((units + 2) / 3)), dim3(64), 0, s, P, D);
+  // (the variants with joint-velocity rows are instantiations of their own: as a run-time branch the rows cost k_tq_eval3 21 % at 8192 instances
+  //  -- 250 registers at two wavefronts per SIMD with spills instead of 268 at one)
+  if (per_joint && P.vel) hipLaunchKernelGGL((k_tq_eval3<7, true>), dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
+  else if (per_joint) hipLaunchKernelGGL((k_tq_eval3<7>), dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
+  else if (P.vel) hipLaunchKernelGGL((k_tq_eval<7, true>), dim3((unsigned)((units + 2) / 3)), dim3(64), 0, s, P, D);
+  else hipLaunchKernelGGL((k_tq_eval<7>), dim3((unsigned)((units + 2) / 3)), dim3(64), 0, s, P, D);
   return true;
 }
 bool oh_launch_tq_step(hipStream_t s, const TqParams& P, const TqBuffers& D) {

@@ -3,7 +3,7 @@
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for m in 0 1; do
-  OH_TQ_EVAL3=$m rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/tq_prof_$m -o tq -- python $REPO/tools/gpu_torque_ab.py child > $REPO/gpurun_out/tq_prof_$m.json 2> $REPO/gpurun_out/tq_prof_$m.log
+  OH_TQ_EVAL3=$m rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/tq_prof_$m -o tq -- python $REPO/tools/gpu_torque_ab.py child > $REPO/gpurun_out/tq_prof_$m.json 2> $REPO/gpurun_out/tq_prof_$m.log
   echo "== OH_TQ_EVAL3=$m"; python - <<PY
 import csv,glob
 f=glob.glob("$REPO/gpurun_out/tq_prof_$m/**/*kernel_stats.csv",recursive=True)

@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fk-units", type=int, default=1 << 22)
     ap.add_argument("--oracle-sample", type=int, default=16, help="instances of the timed batch graded by the oracle afterwards (rank 0, N=1)")
+    ap.add_argument("--timed-only", action="store_true", help="only the timed K steps and their per-kernel pass: no small-batch latency, no PCIe-inclusive solve, no "
+                    "configs block (tools/profile.sh: the rocprofv3 averages then cover exactly the launches the roofline object is computed from)")
     ap.add_argument("--no-configs", action="store_true", help="skip the block that measures BASELINE configs 1, 3, 4, 5 after the timed region (rank 0, N=1)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: run the multi-process plumbing only (rendezvous of the RCCL id with a stand-in id, "
                     "per-rank inputs) and print one JSON line per rank; everything of a --gpus N run except oh_comm_init and the solves")
@@ -382,8 +384,8 @@ def main():
         b.free()
 
     # small-batch latency (BASELINE configs[1] literally is batch = 1): whole solve on the device, inputs resident, median of 7
-    lat = {}
-    for nb in (1, min(1024, B)):
+    lat = {1: None, min(1024, B): None}
+    for nb in (() if args.timed_only else (1, min(1024, B))):
         ms = []
         for _ in range(8):
             be.solve_device(nb, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
@@ -393,7 +395,7 @@ def main():
         lat[f"iters_{nb}"] = float(its_nb.mean())
     # PCIe-inclusive rate: the same problem through oh_solve from pageable host buffers (what a ctypes host that keeps nothing resident pays)
     pcie = None
-    if world == 1:
+    if world == 1 and not args.timed_only:
         nb = min(B, 65536)
         be.solve(x0[:nb], qc[:nb])
         t0h = time.perf_counter()
@@ -512,7 +514,7 @@ def main():
         "specialized_kernels": {**spec_info, "note": "k_retract / k_evalb / k_tail compiled with hiprtc behind a constexpr copy of the handle's kinematic chain (oh_specialize; automatic at the first solve of >= 4096 instances, before the timed region)"},
         "latency_b1_ms": lat[1],
         "latency_b1024_ms": lat[min(1024, B)],
-        "latency_note": f"whole solve on the device, inputs resident, median of 7: B=1 ({lat['iters_1']:.0f} iterations), B={min(1024, B)} (mean {lat[f'iters_{min(1024, B)}']:.1f} iterations)",
+        "latency_note": None if args.timed_only else f"whole solve on the device, inputs resident, median of 7: B=1 ({lat['iters_1']:.0f} iterations), B={min(1024, B)} (mean {lat[f'iters_{min(1024, B)}']:.1f} iterations)",
         "kernel_ms_per_step": {"k_eval": tm["eval_ms"] / args.steps, "k_couple": tm["couple_ms"] / args.steps, "k_step": tm["step_ms"] / args.steps},
         "rejected_step_frac": tm["rejected_steps"] / max(1, tm["instance_launches"] + tm["tail_iterations"]),
         "tail_iteration_frac": tm["tail_iterations"] / max(1, tm["instance_launches"] + tm["tail_iterations"]),
@@ -520,7 +522,7 @@ def main():
         "fused_coupling": zc,
     }
     out["pcie_inclusive"] = pcie
-    if world == 1 and not args.no_configs:
+    if world == 1 and not args.no_configs and not args.timed_only:
         # the other BASELINE configs at their stated sizes (device ms, convergence, an oracle-graded sample each): tools/bench_configs.py
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_configs

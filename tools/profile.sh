@@ -6,7 +6,7 @@
 # Outputs land in gpurun_out/prof_<tag>/ ; tools/summarize_profile.py condenses them into profiles/.
 set -u
 TAG=${1:-r01}
-ARGS=${2:-"--steps 2 --warmup 1 --no-cpu-baseline"}
+ARGS=${2:-"--steps 2 --warmup 1 --no-cpu-baseline --timed-only"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT

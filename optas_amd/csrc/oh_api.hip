@@ -115,6 +115,7 @@ struct oh_handle {
   int* h_flag = nullptr;  // pinned
   bool compaction = true;
   int compact_carry = 1;     // compaction carries the pending trial along instead of restarting the survivors (k_carry_*)
+  int tail_vel = 1;          // velocity-limited handles drain in the persistent kernel too (k_tail_vel; OH_TAIL_VEL=0: batched launches to the end)
   int compact_sort = 1;      // order the survivors of a compaction by progress (k_scan_*)
   double compact_frac = 0.97;  // compact the batch once this fraction of it (or less) is still running (0.9 until the carried compaction
                                // stopped copying back: 0.95 ... 0.99 are +1 ... 2 % over 0.9 on two boxes, interleaved runs)
@@ -230,6 +231,7 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (const char* e4 = getenv("OH_COMPACT_FRAC")) h->compact_frac = h->compact_frac_restart = atof(e4);
   if (const char* e5 = getenv("OH_COMPACT_SORT")) h->compact_sort = atoi(e5);
   if (const char* e6 = getenv("OH_COMPACT_CARRY")) h->compact_carry = atoi(e6);
+  if (const char* e7 = getenv("OH_TAIL_VEL")) h->tail_vel = atoi(e7);
   if (const char* e7 = getenv("OH_FUSE_COUPLE")) h->fuse_couple = atoi(e7) != 0;
   if (const char* e9 = getenv("OH_SPARSE_CHECK_BELOW")) h->sparse_check_below = atoi(e9);
   hipGetDevice(&h->device);
@@ -1170,7 +1172,9 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   // restarts the survivors.
   const int hard_cap = 2 * h->desc.max_iter + 2 + 40 + 64;  // a rejected step costs two launches, a compaction one
   const int NV = (guarded && h->GP.vel) ? 2 * N : 0;  // velocity rows per knot
-  const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation && !guarded && !lead;
+  // persistent tail kernel: plain orientation-locked handles, and (round 3, k_tail_vel) those whose only inequality rows are joint-velocity limits
+  const bool tail_vel = guarded && h->GP.vel && !h->GP.limits && h->GP.n_links == 0 && h->tail_vel;
+  const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation && (!guarded || tail_vel) && !lead;
   const FigSpec* const spec = spec_applies(h) ? h->spec : nullptr;
   // evaluation / tail launches: the kernels compiled for this handle's chain when they are loaded, the generic ones otherwise
   auto launch_eval = [&](int slot, int part) {
@@ -1178,6 +1182,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     return oh_launch_eval(s, N, h->P, h->D, slot, part);
   };
   auto launch_tail = [&](int slot) {
+    if (tail_vel) return oh_launch_tail_vel(s, N, h->P, h->D, h->GP, h->GB, slot);
     if (spec) return oh_spec_launch_tail(*spec, s, h->P, h->D, slot) == hipSuccess;
     return oh_launch_tail(s, N, h->P, h->D, slot);
   };
@@ -1245,9 +1250,12 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       if (tail_ok && nrun <= h->tail_threshold) {
         // drain: compact the survivors and let one wavefront per instance finish them without further launches
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
+        if (guarded) oh_launch_guard_emit(s, h->P, h->D, h->GP, h->GB, NV, 1);
         oh_launch_scan_running(s, h->D, h->compact_sort);
         oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
+        if (guarded) oh_launch_guard_compact(s, h->P, h->D, h->GP, h->GB, NV, 0, 0);
         oh_launch_compact(s, N, h->P, h->D, 1, nrun, (it + 1) & 1);
+        if (guarded) oh_launch_guard_compact(s, h->P, h->D, h->GP, h->GB, NV, 1, nrun);
         h->D.B = nrun;
         ++compactions;
         launch_tail((it + 1) & 1);

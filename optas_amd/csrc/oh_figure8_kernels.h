@@ -44,8 +44,12 @@ OH_DEV double bcast(const double v, const int lane) {  // lane must be wave-unif
   return __hiloint2double(hi, lo);
 }
 
-template <int N>
-__device__ void tail_block(const FigParams& P, const FigBuffers& D, const int slot) {
+// VEL (round 3): the same loop for handles whose only inequality rows are joint-velocity limits (oh_guards.vel_limits; the velocity-limited
+// figure-eight): the rows of interval (t-1, t) live on lane t with their multipliers in registers, the neighbour's contribution comes over with
+// a shuffle, and the outer loop of the augmented Lagrangian (multiplier refresh, penalty, inner tolerance), the line search along a rejected
+// step and the noise-level acceptance are those of step_head / step_instance<N, true> and couple_unit<N, true>, statement for statement.
+template <int N, bool VEL = false>
+__device__ void tail_block(const FigParams& P, const FigBuffers& D, const int slot, const GuardParams* GPp = nullptr, const GuardBuffers* GBp = nullptr) {
   constexpr int NZ = N - 3;
   constexpr int NP = NZ * (NZ + 1) / 2;
   // Stage data of the accepted point and the blocks the cyclic reduction exchanges live in LDS, one column per lane (= knot): [row][lane], conflict-free for the
@@ -85,6 +89,19 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
   bool first = true, polish = false;
   int status = -1;
   unsigned long long n_launch_equiv = 0, n_reject = 0;
+  // VEL: multipliers of this lane's interval (t-1, t), outer-loop state of the instance (wave-uniform), line-search state
+  double lamv[2 * N];
+  double rho_g = 0.0, rho_next = 0.0, omega = 0.0, meas_prev = 0.0, meas_cur = 0.0, fpsi_cur = 0.0, ls_gd = 0.0, ls_q = 0.0, ls_scale = 1.0;
+  int outer = 0, n_outer = 0, ls_count = 0;
+  double zls[NZ];  // the step as it was solved for (the line search shortens it)
+  if constexpr (VEL) {
+#pragma unroll
+    for (int i = 0; i < 2 * N; ++i) lamv[i] = GBp->lamv[IDX(tl, 2 * N, i)];
+    rho_g = GBp->rho[b]; rho_next = GBp->rho_next[b]; omega = GBp->omega[b]; meas_prev = GBp->meas_prev[b];
+    outer = GBp->outer[b]; n_outer = GBp->n_outer[b];
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) zls[a] = 0.0;
+  }
 
   // accepted point (per lane = per knot)
   double q_c[N], Z_c[N][NZ];
@@ -129,14 +146,66 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
       for (int a = 0; a < NZ; ++a) Zn[k][a] = __shfl_down(Z[k][a], 1);
     }
     double G[N], gt[NZ], E[NZ * NZ], merit = 0.0;
+    double psi_p = 0.0, meas_p = 0.0, wn[N];
+    if constexpr (VEL) {
+      const GuardParams& GP = *GPp;
+      if (outer) {  // multiplier refresh at the re-evaluated accepted point with the old penalty (vel_update_unit), then the new penalty
+        const double rho_old = rho_g * GP.vscale, idt = 1.0 / P.dt;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const double v = (qt[k] - qm[k]) * idt;
+          lamv[k] = fmax(0.0, lamv[k] - rho_old * (v - GP.vlo[k]));
+          lamv[N + k] = fmax(0.0, lamv[N + k] - rho_old * (GP.vup[k] - v));
+        }
+      }
+      const double rho = (outer ? rho_next : rho_g) * GP.vscale;
+      double sp[N], wp[N], sn[N];
+      velocity_rows<N>(GP, P.dt, rho, qm, qt, lamv, sp, wp, psi_p, meas_p);
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const double s_next = __shfl_down(sp[k], 1), w_next = __shfl_down(wp[k], 1);  // interval (t, t+1): the next lane's own
+        sn[k] = last ? 0.0 : s_next;
+        wn[k] = last ? 0.0 : w_next;
+        g[k] += sp[k] - sn[k];
+        any = any || wp[k] + wn[k] > 0.0;
+      }
+      if (any) {
+#pragma unroll
+        for (int a = 0; a < NZ; ++a)
+#pragma unroll
+          for (int c2 = 0; c2 <= a; ++c2) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) acc += (wp[k] + wn[k]) * Z[k][a] * Z[k][c2];
+            Dr[tri(a, c2)] += acc;
+          }
+      }
+      phi += psi_p;
+    }
     if (active) couple_knot<N>(P.kappa, last, qm, qt, qp, g, Z, Zn, phi, G, gt, E, merit);
+    if constexpr (VEL) {
+      if (!last) {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+          for (int a = 0; a < NZ; ++a)
+#pragma unroll
+            for (int c2 = 0; c2 < NZ; ++c2) E[a * NZ + c2] -= wn[k] * Z[k][a] * Zn[k][c2];
+      }
+    }
     // ---- phase A: merit in knot order, ratio test (wave-uniform) ---------------------------------------------
-    double f = fconst, feas = 0.0;
+    double f = fconst, feas = 0.0, fpsi = 0.0, meas = 0.0;
     for (int l = 0; l < nK; ++l) {
       f += bcast(merit, l);
       feas = fmax(feas, bcast(cv, l));
+      if constexpr (VEL) {
+        fpsi += bcast(psi_p, l);
+        meas = fmax(meas, bcast(meas_p, l));
+      }
     }
     bool accept;
+    bool line_search = false;
     if (first) {
       if (!(f == f) || !(fabs(f) < 1e300)) {  // non-finite seed / parameters
         status = OH_STATUS_NUMERICAL;
@@ -146,14 +215,31 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
       }
       accept = true;
       first = false;
+      if constexpr (VEL) {
+        if (outer) {  // restart with a multiplier update pending: this evaluation has refreshed the multipliers
+          outer = 0;
+          rho_g = rho_next;
+        }
+      }
+    } else if (VEL && outer) {
+      accept = true;  // re-evaluation of the accepted point after a multiplier update: the merit function itself changed
+      outer = 0;
+      rho_g = rho_next;
     } else if (polish) {
       accept = true;
       polish = false;
     } else {
       const LMState lm_before = lm;
-      accept = lm_accept(P, f, feas, f_cur, pred, stat, lm);
+      accept = lm_accept(P, f, feas, f_cur, pred, stat, lm, feas_cur);
       if (!accept) ++n_reject;
-      if (!accept && feas_cur > 10.0 * P.tol_retract) {  // see step_instance: re-retract the accepted point before blaming the model
+      const bool polish_request = !accept && feas_cur > 10.0 * retract_tol(P, false, pred, 0.0);
+      if constexpr (VEL) {
+        if (!accept && !polish_request && ls_count < OH_LS_MAX && iters < P.max_iter / 2) {  // a shorter step along the same direction first
+          lm = lm_before;
+          line_search = true;
+        }
+      }
+      if (polish_request) {  // see step_instance: re-retract the accepted point before blaming the model
         lm = lm_before;
         polish = true;
         pred = 0.0;
@@ -166,9 +252,40 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
         continue;
       }
     }
+    if constexpr (VEL) {
+      if (line_search) {
+        if (iters >= P.max_iter) { status = OH_STATUS_MAX_ITER; break; }
+        ++ls_count;
+        ls_scale *= OH_LS_SHRINK;
+        double sk = 1.0;
+        for (int i = 0; i < ls_count; ++i) sk *= OH_LS_SHRINK;
+        pred = -sk * ls_gd + 0.5 * sk * sk * ls_q;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          double v = q_c[j];
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) v += Z_c[j][a] * (ls_scale * zls[a]);
+          qt[j] = v;
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          double v = sm[O_EC + m][lane];
+#pragma unroll
+          for (int a = 0; a < NZ; ++a) v += sm[O_JZ + m * NZ + a][lane] * (ls_scale * zls[a]);
+          e_tgt[m] = v;
+        }
+        ++iters;
+        continue;
+      }
+    }
     if (accept) {
       f_cur = f;
       feas_cur = feas;
+      if constexpr (VEL) {
+        fpsi_cur = fpsi;
+        meas_cur = meas;
+        ls_count = 0;
+      }
 #pragma unroll
       for (int k = 0; k < N; ++k) {
         q_c[k] = qt[k];
@@ -313,9 +430,31 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
       mu = fmax(4.0 * mu, 1e-2);
     }
     lm.mu = mu;
+    if constexpr (VEL) {
+      if (!(stat == stat)) { status = OH_STATUS_NUMERICAL; break; }
+      if (stat <= omega) {
+        if (stat <= P.tol && feas_cur <= P.tol_feas && meas_cur <= P.tol_feas) { status = OH_STATUS_CONVERGED; break; }
+        if (iters >= P.max_iter) { status = OH_STATUS_MAX_ITER; break; }
+        // outer iteration: stay where we are, let the next evaluation refresh the multipliers, tighten the inner tolerance
+        rho_next = (meas_cur > 0.25 * meas_prev) ? fmin(10.0 * rho_g, 1e8) : rho_g;
+        meas_prev = meas_cur;
+        omega = fmax(P.tol, fmin(omega, 0.1 * meas_cur));
+        outer = 1;
+        ++n_outer;
+        pred = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) qt[j] = q_c[j];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) e_tgt[m] = sm[O_EC + m][lane];
+        ++iters;
+        continue;
+      }
+      if (iters >= P.max_iter) { status = OH_STATUS_MAX_ITER; break; }
+    } else {
     if (stat <= P.tol && feas_cur <= P.tol_feas) { status = OH_STATUS_CONVERGED; break; }
     if (iters >= P.max_iter) { status = OH_STATUS_MAX_ITER; break; }
     if (!(stat == stat)) { status = OH_STATUS_NUMERICAL; break; }
+    }
     {
       double gd = 0.0, z2 = 0.0;
       if (active) {
@@ -330,10 +469,17 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
         gd += __shfl_xor(gd, m);
         z2 += __shfl_xor(z2, m);
       }
-      const double alpha = (P.hessian == OH_HESSIAN_HYBRID && stat > P.hyb_switch && iters >= P.relax_from) ? P.relax : 1.0;  // see step_instance
+      const double alpha = (!VEL && P.hessian == OH_HESSIAN_HYBRID && stat > P.hyb_switch && iters >= P.relax_from) ? P.relax : 1.0;  // see step_instance
 #pragma unroll
       for (int a = 0; a < NZ; ++a) zmine[a] *= alpha;
       pred = -alpha * gd + 0.5 * alpha * alpha * (gd + mu * z2);
+      if constexpr (VEL) {  // for the line search along this step, should it be rejected
+        ls_gd = alpha * gd;
+        ls_q = alpha * alpha * (gd + mu * z2);
+        ls_scale = 1.0;
+#pragma unroll
+        for (int a = 0; a < NZ; ++a) zls[a] = zmine[a];
+      }
     }
     // next trial knots: q_cur + Z_cur z
 #pragma unroll
@@ -374,5 +520,16 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
     D.status[b] = status;
     atomicAdd(D.work + 2, n_launch_equiv);  // tail iterations are accounted separately from the batched launches
     if (n_reject) atomicAdd(D.work + 1, n_reject);
+    if constexpr (VEL) {
+      GBp->rho[b] = rho_g; GBp->rho_next[b] = rho_next; GBp->omega[b] = omega; GBp->meas_prev[b] = meas_prev;
+      GBp->outer[b] = outer; GBp->n_outer[b] = n_outer; GBp->meas[b] = meas_cur; GBp->ls_count[b] = 0;
+      D.fpsi[b] = fpsi_cur;
+    }
+  }
+  if constexpr (VEL) {
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 2 * N; ++i) GBp->lamv[IDX(t, 2 * N, i)] = lamv[i];
+    }
   }
 }

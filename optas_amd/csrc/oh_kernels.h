@@ -39,6 +39,7 @@ bool oh_launch_step_locked_guarded(hipStream_t s, int n, const FigParams& P, con
 void oh_launch_guard_emit(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int NV, int only_done);
 void oh_launch_guard_compact(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int NV, int phase, int Bnew);
 bool oh_launch_tail(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
+bool oh_launch_tail_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
 bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
                         int* iters, int* status);
 void oh_launch_scan_running(hipStream_t s, const FigBuffers& D, int sort);

@@ -257,6 +257,11 @@ __global__ __launch_bounds__(64, OH_STEP_ZC_WAVES) void k_step_zc(FigParams P, F
 
 template <int N>
 __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const int slot) { tail_block<N>(P, D, slot); }
+// ... for handles whose inequality rows are joint-velocity limits only (tail_block<N, true>)
+template <int N>
+__global__ __launch_bounds__(64) void k_tail_vel(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
+  tail_block<N, true>(P, D, slot, &GP, &GB);
+}
 
 template <int N>
 __global__ __launch_bounds__(256) void k_finalize(FigParams P, FigBuffers D, int only_done, double* __restrict__ x, double* __restrict__ f,
@@ -608,6 +613,12 @@ bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& 
 #define C(NN) launch_step_t<NN>(s, P, D, slot)
   OH_DISPATCH_N(n, C)
 #undef C
+  return true;
+}
+bool oh_launch_tail_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
+  if (n == 7) hipLaunchKernelGGL(k_tail_vel<7>, dim3(D.B), dim3(64), 0, s, P, D, GP, GB, slot);
+  else if (n == 6) hipLaunchKernelGGL(k_tail_vel<6>, dim3(D.B), dim3(64), 0, s, P, D, GP, GB, slot);
+  else return false;
   return true;
 }
 bool oh_launch_tail(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {

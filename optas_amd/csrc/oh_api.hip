@@ -1172,8 +1172,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   // restarts the survivors.
   const int hard_cap = 2 * h->desc.max_iter + 2 + 40 + 64;  // a rejected step costs two launches, a compaction one
   const int NV = (guarded && h->GP.vel) ? 2 * N : 0;  // velocity rows per knot
-  // persistent tail kernel: plain orientation-locked handles, and (round 3, k_tail_vel) those whose only inequality rows are joint-velocity limits
-  const bool tail_vel = guarded && h->GP.vel && !h->GP.limits && h->GP.n_links == 0 && h->tail_vel;
+  // persistent tail kernel: plain orientation-locked handles, and (round 3, k_tail_vel) those whose inequality rows are joint and / or joint-velocity limits (no sphere rows)
+  const bool tail_vel = guarded && (h->GP.vel || h->GP.limits) && h->GP.n_links == 0 && h->tail_vel;
   const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation && (!guarded || tail_vel) && !lead;
   const FigSpec* const spec = spec_applies(h) ? h->spec : nullptr;
   // evaluation / tail launches: the kernels compiled for this handle's chain when they are loaded, the generic ones otherwise

@@ -44,9 +44,9 @@ OH_DEV double bcast(const double v, const int lane) {  // lane must be wave-unif
   return __hiloint2double(hi, lo);
 }
 
-// VEL (round 3): the same loop for handles whose only inequality rows are joint-velocity limits (oh_guards.vel_limits; the velocity-limited
-// figure-eight): the rows of interval (t-1, t) live on lane t with their multipliers in registers, the neighbour's contribution comes over with
-// a shuffle, and the outer loop of the augmented Lagrangian (multiplier refresh, penalty, inner tolerance), the line search along a rejected
+// VEL (round 3): the same loop for handles whose inequality rows are joint limits and / or joint-velocity limits (oh_guards.limits, vel_limits;
+// no sphere rows): the limit rows of knot t and the velocity rows of interval (t-1, t) live on lane t with their multipliers in registers, the
+// neighbour's velocity contribution comes over with a shuffle, and the outer loop of the augmented Lagrangian (multiplier refresh, penalty, inner tolerance), the line search along a rejected
 // step and the noise-level acceptance are those of step_head / step_instance<N, true> and couple_unit<N, true>, statement for statement.
 template <int N, bool VEL = false>
 __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int slot, const GuardParams* GPp = nullptr, const GuardBuffers* GBp = nullptr) {
@@ -90,13 +90,16 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
   int status = -1;
   unsigned long long n_launch_equiv = 0, n_reject = 0;
   // VEL: multipliers of this lane's interval (t-1, t), outer-loop state of the instance (wave-uniform), line-search state
-  double lamv[2 * N];
+  double lamv[2 * N], lamq[2 * N];
   double rho_g = 0.0, rho_next = 0.0, omega = 0.0, meas_prev = 0.0, meas_cur = 0.0, fpsi_cur = 0.0, ls_gd = 0.0, ls_q = 0.0, ls_scale = 1.0;
   int outer = 0, n_outer = 0, ls_count = 0;
   double zls[NZ];  // the step as it was solved for (the line search shortens it)
   if constexpr (VEL) {
 #pragma unroll
-    for (int i = 0; i < 2 * N; ++i) lamv[i] = GBp->lamv[IDX(tl, 2 * N, i)];
+    for (int i = 0; i < 2 * N; ++i) {
+      lamv[i] = GPp->vel ? GBp->lamv[IDX(tl, 2 * N, i)] : 0.0;
+      lamq[i] = GPp->limits ? GBp->lam[IDX(tl, 2 * N, i)] : 0.0;  // (NC = 2 N: no sphere rows on these handles)
+    }
     rho_g = GBp->rho[b]; rho_next = GBp->rho_next[b]; omega = GBp->omega[b]; meas_prev = GBp->meas_prev[b];
     outer = GBp->outer[b]; n_outer = GBp->n_outer[b];
 #pragma unroll
@@ -135,6 +138,46 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
     if (active)
       eval_knot<N, false, TailHooks>(ch, P, t, qt, pc, Rc, exact, have_G, Gdummy, phi, cv, g, Dr, Z, !first, e_tgt, retract_tol(P, !first, pred, stat), e_new,
                                      JZ_new, 0.0, hooks);
+    double psi_q = 0.0, meas_q = 0.0;
+    if constexpr (VEL) {
+      if (GPp->limits) {  // joint-limit rows of this knot (eval_unit<N, true>)
+        const GuardParams& GP = *GPp;
+        const double rho_old = rho_g, rho = outer ? rho_next : rho_g;
+        double dd[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          dd[j] = 0.0;
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            const double gval = side ? GP.up[j] - qt[j] : qt[j] - GP.lo[j];
+            double lam = lamq[side * N + j];
+            if (outer) {
+              lam = fmax(0.0, lam - rho_old * gval);
+              lamq[side * N + j] = lam;
+            }
+            const double sv = lam - rho * gval;
+            meas_q = fmax(meas_q, fabs(fmin(gval, lam / rho)));
+            if (sv > 0.0) {
+              psi_q += (sv * sv - lam * lam) / (2.0 * rho);
+              g[j] += side ? sv : -sv;
+              dd[j] += rho;
+            } else {
+              psi_q -= lam * lam / (2.0 * rho);
+            }
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < NZ; ++a)
+#pragma unroll
+          for (int c2 = 0; c2 <= a; ++c2) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += dd[j] * Z[j][a] * Z[j][c2];
+            Dr[tri(a, c2)] += acc;
+          }
+        phi += psi_q;
+      }
+    }
     // ---- neighbour coupling (k_couple) -----------------------------------------------------------------------
     double qm[N], qp[N], Zn[N][NZ];
 #pragma unroll
@@ -148,7 +191,12 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
     double G[N], gt[NZ], E[NZ * NZ], merit = 0.0;
     double psi_p = 0.0, meas_p = 0.0, wn[N];
     if constexpr (VEL) {
+      psi_p = psi_q;  // (what phase A sums as the augmented-Lagrangian part of the knot, and its complementarity measure)
+      meas_p = meas_q;
+    }
+    if (VEL && GPp->vel) {
       const GuardParams& GP = *GPp;
+      double psi_v = 0.0, meas_v = 0.0;
       if (outer) {  // multiplier refresh at the re-evaluated accepted point with the old penalty (vel_update_unit), then the new penalty
         const double rho_old = rho_g * GP.vscale, idt = 1.0 / P.dt;
 #pragma unroll
@@ -160,7 +208,7 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
       }
       const double rho = (outer ? rho_next : rho_g) * GP.vscale;
       double sp[N], wp[N], sn[N];
-      velocity_rows<N>(GP, P.dt, rho, qm, qt, lamv, sp, wp, psi_p, meas_p);
+      velocity_rows<N>(GP, P.dt, rho, qm, qt, lamv, sp, wp, psi_v, meas_v);
       bool any = false;
 #pragma unroll
       for (int k = 0; k < N; ++k) {
@@ -181,10 +229,15 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
             Dr[tri(a, c2)] += acc;
           }
       }
-      phi += psi_p;
+      phi += psi_v;
+      psi_p += psi_v;
+      meas_p = fmax(meas_p, meas_v);
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; ++k) wn[k] = 0.0;
     }
     if (active) couple_knot<N>(P.kappa, last, qm, qt, qp, g, Z, Zn, phi, G, gt, E, merit);
-    if constexpr (VEL) {
+    if (VEL && GPp->vel) {
       if (!last) {
 #pragma unroll
         for (int k = 0; k < N; ++k)
@@ -529,7 +582,10 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
   if constexpr (VEL) {
     if (active) {
 #pragma unroll
-      for (int i = 0; i < 2 * N; ++i) GBp->lamv[IDX(t, 2 * N, i)] = lamv[i];
+      for (int i = 0; i < 2 * N; ++i) {
+        if (GPp->vel) GBp->lamv[IDX(t, 2 * N, i)] = lamv[i];
+        if (GPp->limits) GBp->lam[IDX(t, 2 * N, i)] = lamq[i];
+      }
     }
   }
 }

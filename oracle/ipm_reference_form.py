@@ -101,7 +101,7 @@ def attach_hessian(nlp):
             H[:, j] = (grad(x + e) - grad(x - e)) / (2 * h)
         return 0.5 * (H + H.T)
 
-    if hasattr(nlp, "hess_lagrangian") and nlp.nk == 0 and nlp.ng == 0:  # FigureEightNLP
+    if hasattr(nlp, "hess_lagrangian") and nlp.ng == 0:  # FigureEightNLP, and with linear k rows (joint / joint-velocity limits) on top
 
         def hl(x, p, sigma, lam_v):
             _, _, _, mu_h = _split_v(nlp, lam_v)

@@ -60,3 +60,35 @@ def test_gpu_against_the_interior_point_runs_from_the_reference_seed(hip_lib):
             assert f_gpu <= g["f_ipm"][i] + 1e-9, (i, f_gpu, g["f_ipm"][i])
     print("interior point from the reference seed vs GPU:", counts)
     assert counts["same"] >= 10 and g["same_basin"][0]  # the nominal instance (BASELINE configs[1] literally) is one of them
+
+
+def test_velocity_limited_problems_against_the_interior_point_runs(hip_lib):
+    """The problems with joint-velocity limit rows that round 3 lowered (tests/golden/ipm_limits_golden.npz, tools/make_golden.py --ipm-limits): the
+    interior-point oracle from the reference's seed on the literal layouts -- figure_eight_plan.py + the LWR's velocity limits (4 instances) and
+    dual_arm.py + 0.06 rad/s.  Where it converged to the GPU's basin the objectives agree to the bound relaxation (sum|lam| x 1e-8: 2e-5
+    absolute on the figure-eight, 1e-7 on the dual arm); another basin must not be better than the GPU's by more than that."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from examples.dual_arm import setup_solver as dual_arm
+    from examples.figure_eight_plan import setup_solver as figure_eight
+
+    g = np.load(os.path.join(GOLDEN, "ipm_limits_golden.npz"))
+    qcs, vl = g["fig8v_qc"], g["fig8v_vl"]
+    kuka, solver = figure_eight(velocity_limits=(-vl, vl), solver_options={"max_iter": 600, "tol": 1e-7})
+    x0 = np.zeros((len(qcs), solver.opt.nx))
+    x0[:, :350] = np.repeat(qcs, 50, axis=0).reshape(len(qcs), 350)
+    r = solver.solve_batch_arrays(x0, qcs)
+    assert (r.status == 0).all() and g["fig8v_ok"].all()
+    same = np.abs(r.f - g["fig8v_f"]) <= 2e-5
+    assert same.sum() >= 3 and same[0], (r.f, g["fig8v_f"])  # the nominal instance among them
+    assert np.all(r.f[~same] <= g["fig8v_f"][~same] + 2e-5)
+    solver.backend.close()
+    if "dualv_f" in g.files:
+        vmax, T = float(g["dualv_vmax"]), 50
+        (kl, kr), s2 = dual_arm(T=T, velocity_limits=(-np.full(7, vmax), np.full(7, vmax)), solver_options={"max_iter": 600, "tol": 1e-7})
+        p = g["dualv_p"]
+        s2.reset_parameters({"qcl": p[:7], "qcr": p[7:]})
+        s2.solve()  # zero seed, as the script leaves it
+        assert s2.did_solve() and bool(g["dualv_ok"])
+        assert abs(s2.stats()["f"][0] - float(g["dualv_f"])) <= 1e-6, (s2.stats()["f"][0], float(g["dualv_f"]))

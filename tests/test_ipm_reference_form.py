@@ -131,3 +131,40 @@ def test_interior_point_answers_on_configs_4_and_5_match_the_other_solvers():
         assert np.all(f_ipm <= f_other + 1e-9) and np.all(f_other - f_ipm <= 2e-6 * f_other), (tag, f_ipm, f_other)
         assert np.all(g[f"tq_{tag}_iters"] < 500)
     assert "tq_t6lim_f" in g.files
+
+
+def test_velocity_limited_goldens_against_the_numpy_ports():
+    """tests/golden/ipm_limits_golden.npz (tools/make_golden.py --ipm-limits): the interior-point answers for the velocity-limited figure-eight and
+    dual arm against the numpy ports of the kernels' state machines (oracle/structured.py, oracle/guarded.py): two solvers that share neither
+    algorithm nor formulation (reference layout with the (e, -e) rows and slack bounds against eliminated velocities on the manifold)."""
+    import os
+
+    from conftest import GOLDEN, KUKA_KIN
+    from oracle.guarded import Guards, solve_free_al
+    from oracle.problems import dual_arm_offsets
+    from oracle.robot import OracleRobot
+    from oracle.structured import FoldedChain, StructuredFigureEight, solve_structured_lm
+
+    g = np.load(os.path.join(GOLDEN, "ipm_limits_golden.npz"))
+    kuka = OracleRobot(KUKA_KIN)
+    prob = StructuredFigureEight(kuka, "end_effector_ball", T=50)
+    vl = g["fig8v_vl"]
+    assert g["fig8v_ok"].all() and (g["fig8v_iters"] < 200).all()
+    n_same = 0
+    for qc, f_ipm in zip(g["fig8v_qc"], g["fig8v_f"]):
+        s = solve_structured_lm(prob, qc, max_iter=600, tol=1e-7, vlimits=(-vl, vl))
+        assert s["status"] == 0
+        n_same += abs(s["f"] - f_ipm) <= 2e-5  # IPOPT's bound relaxation: sum|lam| x 1e-8
+        assert s["f"] <= f_ipm + 2e-5
+    assert n_same >= 3
+    if "dualv_f" in g.files:
+        vmax, T, p = float(g["dualv_vmax"]), 50, g["dualv_p"]
+        f = 0.0
+        for arm, y, qc in (("l", -0.25, p[:7]), ("r", 0.25, p[7:])):
+            rob = OracleRobot(KUKA_KIN, name="kuka" + arm)
+            rob.add_base_frame("global_world", xyz=[0.0, y, 0.0])
+            s = solve_free_al(FoldedChain(rob, "end_effector_ball"), T, 10.0 / (T - 1), dual_arm_offsets(T)[arm].T, qc, Guards(), Q0=np.zeros((T, 7)), rho0=10.0,
+                              exact=False, vlimits=(-np.full(7, vmax), np.full(7, vmax)), max_iter=600, tol=1e-7)
+            assert s["status"] == 0
+            f += s["f"]
+        assert bool(g["dualv_ok"]) and abs(f - float(g["dualv_f"])) <= 1e-6, (f, float(g["dualv_f"]))

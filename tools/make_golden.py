@@ -602,7 +602,51 @@ def ipm_configs_golden(only=None):
         np.savez(path, **out)
 
 
+def ipm_limits_golden():
+    """oracle/ipm_reference_form.py from the reference's seeds on the problems with joint-velocity limit rows (enforce_model_limits(name, time_deriv=1),
+    builder.py:471-509) that round 3 lowered: figure_eight_plan.py + the LWR's own velocity limits (T = 50, 693 variables, 1114 + 686 rows; the
+    nominal instance and three perturbed ones) and dual_arm.py + 0.06 rad/s on every joint (T = 50, 1386 variables, 1372 k rows).  ~10 minutes."""
+    from oracle.ipm_reference_form import solve_ipm
+    from oracle.problems import GuardedDualArmNLP, LimitedFigureEightNLP
+
+    kin = os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json")
+    kuka = OracleRobot(kin)
+    vl = np.asarray(kuka.velocity_actuated_joint_limits)
+    nlp = LimitedFigureEightNLP(kuka, "end_effector_ball", vlo=-vl, vup=vl, T=50)
+    QC0 = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    rng = np.random.default_rng(SEED + 77)
+    qcs = QC0[None] + np.concatenate([np.zeros((1, 7)), rng.uniform(-0.1, 0.1, (3, 7))])
+    out = {"fig8v_qc": qcs, "fig8v_vl": vl}
+    fs, its, ok = [], [], []
+    for b, qc in enumerate(qcs):
+        t0 = time.time()
+        r = solve_ipm(nlp, nlp.seed(qc), qc, max_iter=1500)
+        k = kkt_reference_form(nlp, r["x"], qc, active_tol=1e-6)
+        dq = np.abs(r["x"][350:]).reshape(49, 7).max(0)
+        print("fig8 + velocity limits", b, r["status"], r["iters"], r["f"], "max|dq|/limit", (dq / vl).max(), "kkt", k["stationarity"], k["feasibility"], round(time.time() - t0), "s", flush=True)
+        fs.append(r["f"]); its.append(r["iters"]); ok.append(r["status"] in ("optimal", "acceptable"))
+    out.update(fig8v_f=np.array(fs), fig8v_iters=np.array(its), fig8v_ok=np.array(ok))
+    np.savez(os.path.join(G, "ipm_limits_golden.npz"), **out)
+    rl = OracleRobot(kin, name="kukal")
+    rl.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
+    rr = OracleRobot(kin, name="kukar")
+    rr.add_base_frame("global_world", xyz=[0.0, 0.25, 0.0])
+    vmax = 0.06
+    nlp = GuardedDualArmNLP(rl, rr, [], 0, T=50, limits=False, vlimits=(-np.full(7, vmax), np.full(7, vmax)))
+    QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
+    p = np.concatenate([QC, QC + 0.02])
+    x0 = np.zeros(nlp.nx)  # the script leaves the seed at zero
+    t0 = time.time()
+    r = solve_ipm(nlp, x0, p, max_iter=1500)
+    print("dual arm + velocity limits:", r["status"], r["iters"], r["f"], round(time.time() - t0), "s", flush=True)
+    out.update(dualv_p=p, dualv_vmax=vmax, dualv_f=r["f"], dualv_iters=r["iters"], dualv_ok=r["status"] in ("optimal", "acceptable"))
+    np.savez(os.path.join(G, "ipm_limits_golden.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--ipm-limits" in sys.argv:
+        ipm_limits_golden()
+        sys.exit(0)
     if "--ipm-configs" in sys.argv:
         ipm_configs_golden([a for a in sys.argv[2:] if not a.startswith("-")] or None)
         sys.exit(0)

@@ -1005,6 +1005,259 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
   }
 }
 
+// K3 of a launch of a few hundred instances with at most 64 free knots (dual_arm.py as shipped: T = 50), round 3: the same block cyclic
+// reduction with a knot's ROWS spread over eight lanes.  k_step_free_pcr gives a knot one lane: 15 triangular solve pairs and four 7 x 7 x 7 products per level on
+// one lane, 512 registers with ~86 doubles spilled, 87 us per launch at T = 50 however few instances there are.  Here
+// lane c < N of a knot owns row c of its three blocks (A, Lw, U) and r_c; lane N solves A y = r.  Per level: (1) rows to LDS, (2) every lane
+// factorises the knot's A for itself and solves for its column of A^{-1} Lw and A^{-1} U (lane N: A^{-1} r), which replace Lw / U in LDS,
+// (3) every lane forms its rows of the reduced blocks from its own rows (registers) and the two neighbours' solved blocks (LDS; the eight
+// lanes of a knot read the same words: broadcasts).  ~400 multiply-adds per lane and level instead of ~2100, 61 us per launch at T = 50.  Same system, same
+// ratio test and outer-loop decisions (free_accept / free_decide on lane 0), the damping raised exactly when a pivot of any knot fails.
+template <int N, bool GUARD, int KN, bool VEL = false>
+__global__ __launch_bounds__(8 * KN) void k_step_free_cp(FigParams P, FigBuffers D, GuardBuffers GB, const int slot) {
+  static_assert(N <= 7, "eight lanes per knot");
+  constexpr int NP = N * (N + 1) / 2;
+  constexpr int NW = (8 * KN) / 64;  // wavefronts
+  __shared__ double TA[NP][KN];      // packed lower triangle of the knots' diagonal blocks
+  __shared__ double TL[N * N][KN];   // Lw row-major, then A^{-1} Lw
+  __shared__ double TU[N * N][KN];   // U row-major, then A^{-1} U
+  __shared__ double TY[N][KN];       // r, then A^{-1} r
+  __shared__ double red[3][NW];
+  __shared__ int ctl[2];
+  __shared__ double ctld;
+  const int per = (D.B + 7) / 8;  // blocks are dealt round-robin to the 8 XCDs (see k_step_free_pcr)
+  const int b = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  if (b >= D.B) return;
+  const int tid = threadIdx.x;
+  const int kn = tid >> 3, c = tid & 7;  // knot (lane of the reduction), row within the knot (c == N: the right-hand side solver)
+  const int Bp = D.Bp;
+  const int T = P.T;
+  const int nK = T - P.t0;
+  const int t = P.t0 + kn;
+  const bool active = kn < nK;
+  const bool row = c < N;
+  const int tl = active ? t : T - 1;
+  const int cr = row ? c : 0;
+  const bool last = (t == T - 1);
+  const double kap2 = 2.0 * P.kappa;
+  if (tid == 0) ctl[0] = D.status[b] >= 0 ? 0 : (D.skip[b] ? 1 : 2);
+  __syncthreads();
+  {
+    const int st = ctl[0];
+    if (st == 0) return;
+    if (st == 1) {
+      if (tid == 0) {
+        D.skip[b] = 0;
+        atomicAdd(D.n_running, 1);
+      }
+      return;
+    }
+  }
+  if (c == 0) {
+    TY[0][kn] = active ? D.merit[slot][(size_t)tl * Bp + b] : 0.0;
+    if constexpr (GUARD) {
+      TY[1][kn] = active ? GB.psi[slot][(size_t)tl * Bp + b] : 0.0;
+      TY[2][kn] = active ? D.cv[slot][(size_t)tl * Bp + b] : 0.0;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    atomicAdd(D.work, 1ULL);
+    double f = D.fconst[b], fpsi = 0.0, meas = 0.0;
+    for (int l = 0; l < nK; ++l) {  // in knot order, like the serial sweep
+      f += TY[0][l];
+      if constexpr (GUARD) {
+        fpsi += TY[1][l];
+        meas = fmax(meas, TY[2][l]);
+      }
+    }
+    LMState lm{D.mu[b], D.nun[b]};
+    int cur = 1 - slot;
+    ctl[0] = free_accept<N, GUARD>(P, D, GB, b, slot, f, fpsi, meas, cur, lm);
+    ctl[1] = cur;
+    ctld = lm.mu;
+  }
+  __syncthreads();
+  if (ctl[0] == 0) return;
+  if (ctl[0] == 2) {  // line search: the rejected step again, shorter
+    if (active && row) D.zstep[IDX(t, N, c)] *= OH_LS_SHRINK;
+    if (tid == 0 && free_line_search<GUARD>(P, D, GB, b)) atomicAdd(D.n_running, 1);
+    return;
+  }
+  const int cur = ctl[1];
+  double mu = ctld;
+  auto block_sum = [&](double v, const int slot_r, const bool is_max) {  // all lanes get the result
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const double o = __shfl_xor(v, m);
+      v = is_max ? fmax(v, o) : v + o;
+    }
+    __syncthreads();  // (the previous reduction's readers are through)
+    if ((tid & 63) == 0) red[slot_r][tid >> 6] = v;
+    __syncthreads();
+    double out = red[slot_r][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) out = is_max ? fmax(out, red[slot_r][w]) : out + red[slot_r][w];
+    return out;
+  };
+  const double* __restrict__ Drc = cur ? D.Dr[1] : D.Dr[0];
+  const double* __restrict__ gtc = cur ? D.gt[1] : D.gt[0];
+  const double* __restrict__ Ec = cur ? D.E[1] : D.E[0];
+  const double gmine = (active && row) ? gtc[IDX(tl, N, cr)] : 0.0;
+  const double stat = block_sum(fabs(gmine), 0, true);
+  double z = 0.0;  // the step component (t, c) at the end
+  bool factored = false;
+  for (int attempt = 0; attempt < 40; ++attempt) {
+    double Ar[N], Lr[N], Ur[N], rc;  // row c of the three blocks, r_c
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int hi = cr > j ? cr : j, lo = cr > j ? j : cr;
+      Ar[j] = (active && row) ? Drc[IDX(tl, NP, tri(hi, lo))] : (j == cr ? 1.0 : 0.0);
+      Lr[j] = 0.0;
+      Ur[j] = 0.0;
+    }
+    rc = -gmine;
+    if (active && row) {
+      double eu = kap2, el = kap2;
+      if constexpr (VEL) {
+        if (!last) eu = Ec[IDX(tl, N, cr)];
+        if (kn > 0) el = Ec[IDX(tl - 1, N, cr)];
+      }
+      Ar[cr] += (last ? kap2 : 2.0 * kap2) + mu;
+      if (!last) Ur[cr] = -eu;
+      if (kn > 0) Lr[cr] = -el;
+    }
+    bool ok = true;
+    for (int sft = 1; sft < nK; sft <<= 1) {
+      // (1) rows to LDS
+      if (row) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          if (j <= c) TA[tri(c, j)][kn] = Ar[j];
+          TL[c * N + j][kn] = Lr[j];
+          TU[c * N + j][kn] = Ur[j];
+        }
+        TY[c][kn] = rc;
+      }
+      __syncthreads();
+      // (2) factor, solve for this lane's column
+      double Lc[NP], rd[N], colL[N], colU[N];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Lc[i] = TA[i][kn];
+      ok = chol_rcp<N>(Lc, rd, 1e-12) && ok;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        colL[i] = row ? TL[i * N + cr][kn] : TY[i][kn];
+        colU[i] = row ? TU[i * N + cr][kn] : 0.0;
+      }
+      fsub_rcp<N>(Lc, rd, colL);
+      bsub_rcp<N>(Lc, rd, colL);
+      if (row) {
+        fsub_rcp<N>(Lc, rd, colU);
+        bsub_rcp<N>(Lc, rd, colU);
+      }
+      __syncthreads();  // every lane has read the rows
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        if (row) {
+          TL[i * N + c][kn] = colL[i];
+          TU[i * N + c][kn] = colU[i];
+        } else {
+          TY[i][kn] = colL[i];
+        }
+      }
+      __syncthreads();
+      // (3) this lane's rows of the reduced blocks
+      const int km = kn - sft, kp = kn + sft;
+      const bool hm = km >= 0, hp = kp < KN;
+      const int im = hm ? km : kn, ip = hp ? kp : kn;  // (rows of a lane without that neighbour are zero: the clamped reads add nothing)
+      if (row) {
+        double An[N], Ln[N], Un[N];
+        double rn = rc;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          double aacc = Ar[j], lacc = 0.0, uacc = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            lacc -= Lr[k] * TL[k * N + j][im];                              // -Lw (A^{-1} Lw)_-
+            uacc -= Ur[k] * TU[k * N + j][ip];                              // -U (A^{-1} U)_+
+            aacc -= Lr[k] * TU[k * N + j][im] + Ur[k] * TL[k * N + j][ip];  // A - Lw (A^{-1} U)_- - U (A^{-1} Lw)_+
+          }
+          An[j] = aacc;
+          Ln[j] = hm ? lacc : 0.0;
+          Un[j] = hp ? uacc : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) rn -= Lr[k] * TY[k][im] + Ur[k] * TY[k][ip];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          Ar[j] = An[j];
+          Lr[j] = Ln[j];
+          Ur[j] = Un[j];
+        }
+        rc = rn;
+      }
+      __syncthreads();
+    }
+    // the knots are decoupled: A z = r
+    if (row) {
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        if (j <= c) TA[tri(c, j)][kn] = Ar[j];
+      TY[c][kn] = rc;
+    }
+    __syncthreads();
+    {
+      double Lc[NP], rd[N], y[N];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) Lc[i] = TA[i][kn];
+      ok = chol_rcp<N>(Lc, rd, 1e-12) && ok;
+#pragma unroll
+      for (int i = 0; i < N; ++i) y[i] = TY[i][kn];
+      fsub_rcp<N>(Lc, rd, y);
+      bsub_rcp<N>(Lc, rd, y);
+      z = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (i == c) z = y[i];
+    }
+    if (__syncthreads_and(ok || !active)) {
+      factored = true;
+      break;
+    }
+    mu = fmax(4.0 * mu, 1e-2);
+  }
+  double stat_out = stat;
+  if (!factored) stat_out = __builtin_nan("");  // (see step_instance_free)
+  if (tid == 0) ctl[0] = free_decide<N, GUARD>(P, D, GB, b, stat_out, mu, D.iters[b]);
+  __syncthreads();
+  const int dec = ctl[0];
+  if (dec == 0) return;
+  if (dec == 1) {  // outer iteration: no step
+    if (active && row) D.zstep[IDX(t, N, c)] = 0.0;
+    if (tid == 0) atomicAdd(D.n_running, 1);
+    return;
+  }
+  double gd = 0.0, z2 = 0.0;
+  if (active && row) {
+    D.zstep[IDX(t, N, c)] = z;
+    gd = gmine * z;
+    z2 = z * z;
+  }
+  gd = block_sum(gd, 1, false);
+  z2 = block_sum(z2, 2, false);
+  if (tid == 0) {
+    D.pred[b] = -0.5 * gd + 0.5 * mu * z2;
+    if constexpr (GUARD) {
+      GB.ls_gd[b] = gd;
+      GB.ls_q[b] = gd + mu * z2;
+    }
+    D.mu[b] = mu;
+    D.iters[b] += 1;
+    atomicAdd(D.n_running, 1);
+  }
+}
+
 bool oh_launch_eval_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
   const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
   if (n == 7) hipLaunchKernelGGL(k_eval_free<7>, g, b, 0, s, P, D, slot);
@@ -1019,10 +1272,22 @@ bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBu
   else return false;
   return true;
 }
-// pcr: one block per instance (k_step_free_pcr; the knots must fit 128 lanes)
+// pcr: one block per instance (k_step_free_pcr, or k_step_free_cp with eight lanes per knot while the launch has at most g_free_cp_max instances;
+// the knots must fit 128 lanes)
+static int g_free_cp_max = -1;
 template <int N, bool GUARD, bool VEL = false>
 static void launch_step_free_pcr(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, int slot) {
+  {  // (read per launch: a handful of nanoseconds, and tests switch it between handles of one process)
+    const char* e = getenv("OH_FREE_CP_MAX");
+    g_free_cp_max = e ? atoi(e) : 512;
+  }
   const dim3 g(8 * ((D.B + 7) / 8));
+  // (only up to 64 knots: 128 knots x 8 lanes are 1024 threads, which leaves 128 registers per lane -- the kernel then spills and takes 147 us
+  //  against k_step_free_pcr's 111 at T = 100; at T = 50 it is 61 against 87 us)
+  if (D.B <= g_free_cp_max && P.T - P.t0 <= 64) {
+    hipLaunchKernelGGL((k_step_free_cp<N, GUARD, 64, VEL>), g, dim3(512), 0, s, P, D, GB, slot);
+    return;
+  }
   if (P.T - P.t0 <= 64) hipLaunchKernelGGL((k_step_free_pcr<N, GUARD, 64, VEL>), g, dim3(64), 0, s, P, D, GB, slot);
   else hipLaunchKernelGGL((k_step_free_pcr<N, GUARD, 128, VEL>), g, dim3(128), 0, s, P, D, GB, slot);
 }

@@ -276,13 +276,18 @@ def test_cyclic_reduction_step_equals_the_serial_sweep(hip_lib, monkeypatch, T, 
     for name, qc in (("kukal/q/x", qcl), ("kukar/q/x", qcr)):
         X0[:, xoff[name] : xoff[name] + 7 * T] = np.tile(qc, (1, T))
     out = {}
-    for mode in ("0", "4096"):
-        monkeypatch.setenv("OH_FREE_PCR_MAX", mode)
+    # "0": the serial sweep; "4096": cyclic reduction -- with at most 64 free knots the kernel that spreads a knot's rows over eight lanes
+    # (k_step_free_cp, round 3), otherwise one lane per knot; "4096/lane": one lane per knot forced (OH_FREE_CP_MAX=0)
+    for mode in ("0", "4096", "4096/lane"):
+        monkeypatch.setenv("OH_FREE_PCR_MAX", mode.split("/")[0])
+        monkeypatch.setenv("OH_FREE_CP_MAX", "0" if mode.endswith("lane") else "512")
         mb = MultiArmBackend(spec, o, max_iter=400)
         res = mb.solve(X0, P)
         out[mode] = (res, [be.multipliers(B) for _, be in mb.arms] if guarded else [])
         mb.close()
+    (r2, l2) = out["4096/lane"]
     (r0, l0), (r1, l1) = out["0"], out["4096"]
+    assert (r2.status == 0).all() and np.abs(r2.f - r1.f).max() <= 1e-9 * np.abs(r1.f).max() and (r2.iters == r1.iters).mean() >= 0.97
     assert (r0.status == 0).all() and (r1.status == 0).all()
     assert (r0.iters == r1.iters).mean() >= 0.97 and np.abs(r0.iters.astype(int) - r1.iters).max() <= 2
     same = r0.iters == r1.iters

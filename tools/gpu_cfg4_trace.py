@@ -11,7 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 radius = 0.15
 rng = np.random.default_rng(20260927)
 QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
-T = 100
+T = int(os.environ.get("CFG4_T", "100"))
 offs = path_offsets(T, [-0.1, 0.1, -0.2], [0.0, 0.0, 0.3])
 arm = RobotModel.builtin("kuka_lwr", time_derivs=[0, 1], name="kukal")
 arm.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])

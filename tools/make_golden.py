@@ -643,7 +643,34 @@ def ipm_limits_golden():
     np.savez(os.path.join(G, "ipm_limits_golden.npz"), **out)
 
 
+def ipm_torque_velocity_golden():
+    """oracle/ipm_reference_form.py on config 5 at T = 6 with joint-velocity limits 0.25 rad/s next to the effort limits (the rows round 3 lowered
+    for the torque family); Lagrangian Hessian by central differences of the analytic gradient, ~25 minutes."""
+    from oracle.ipm_reference_form import solve_ipm
+    from oracle.problems import TorqueMPCNLP
+    from oracle.torque import TorqueProblem
+
+    med7 = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "med7.kin.json"))
+    g = np.load(os.path.join(G, "torque_golden.npz"))
+    vmax = 0.25
+    prob = TorqueProblem(med7, "lbr_link_ee", T=6, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=float(g["t6lim_lim"]))
+    nlp = TorqueMPCNLP(prob, vlimits=(-vmax, vmax))
+    qc, goal = g["t6lim_qc"][0], g["t6lim_goal"][0]
+    p = nlp.pack_p(qc, np.zeros(7), goal)
+    t0 = time.time()
+    r = solve_ipm(nlp, nlp.seed(qc), p, max_iter=500)
+    dq = np.abs(nlp.split(r["x"])[1]).max()
+    print("config 5 + velocity limits:", r["status"], r["iters"], r["f"], "max|dq|", dq, round(time.time() - t0), "s", flush=True)
+    path = os.path.join(G, "ipm_limits_golden.npz")
+    out = dict(np.load(path))
+    out.update(tqv_qc=qc, tqv_goal=goal, tqv_vmax=vmax, tqv_lim=float(g["t6lim_lim"]), tqv_f=r["f"], tqv_iters=r["iters"], tqv_ok=r["status"] in ("optimal", "acceptable"))
+    np.savez(path, **out)
+
+
 if __name__ == "__main__":
+    if "--ipm-torque-velocity" in sys.argv:
+        ipm_torque_velocity_golden()
+        sys.exit(0)
     if "--ipm-limits" in sys.argv:
         ipm_limits_golden()
         sys.exit(0)

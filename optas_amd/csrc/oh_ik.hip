@@ -140,7 +140,10 @@ __global__ void __launch_bounds__(64) k_ik_solve(const oh_chain* __restrict__ ch
         }
         ik_eval<N>(ch, qt, et, Jt, ot);
         ++it;
-        if (ik_merit<N>(P, qt, qn, et, pg, lam, rho) <= m0 + 1e-4 * slope + 4e-16 * fmax(1.0, fabs(m0))) {
+        // (rounding slack: that of the merit itself plus what the rounding of the link position, a few 1e-16, is worth through the effective
+        //  multiplier y = lam + rho h -- without the second part one instance in 65 536 of the config-1 batch, with |y| ~ 10 and a step that
+        //  predicts a decrease of 1e-17, failed the test at every step length until the iteration cap; round 3)
+        if (ik_merit<N>(P, qt, qn, et, pg, lam, rho) <= m0 + 1e-4 * slope + 4e-16 * fmax(1.0, fabs(m0)) + 8e-16 * (fabs(y[0]) + fabs(y[1]) + fabs(y[2]))) {
           ok = true;
           break;
         }

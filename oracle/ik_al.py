@@ -91,7 +91,7 @@ def solve_ik_al(chain: FoldedChain, x0, qn, pg, lo, up, w=1.0, tol=1e-8, tol_fea
                 qt = np.minimum(np.maximum(q + alpha * d, lo), up)
                 et, Jpt, omt = _pos_jac_frames(chain, qt)
                 it += 1
-                if merit(qt, et) <= m0 + 1e-4 * grad @ (qt - q) + 4e-16 * max(1.0, abs(m0)):
+                if merit(qt, et) <= m0 + 1e-4 * grad @ (qt - q) + 4e-16 * max(1.0, abs(m0)) + 8e-16 * np.abs(y).sum():  # (rounding of the merit and of e through y)
                     ok = True
                     break
                 alpha *= 0.5

@@ -92,3 +92,17 @@ def test_velocity_limited_problems_against_the_interior_point_runs(hip_lib):
         s2.solve()  # zero seed, as the script leaves it
         assert s2.did_solve() and bool(g["dualv_ok"])
         assert abs(s2.stats()["f"][0] - float(g["dualv_f"])) <= 1e-6, (s2.stats()["f"][0], float(g["dualv_f"]))
+    if "tqv_f" in g.files:  # torque MPC (T = 6) with joint-velocity limits next to the effort limits
+        from optas_amd.backend import TorqueBackend
+
+        med7 = RobotModel.builtin("med7")
+        vmax, lim = float(g["tqv_vmax"]), float(g["tqv_lim"])
+        be = TorqueBackend(med7.kinematic_chain("lbr_link_ee"), med7.dynamics_tables(), T=6, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=-lim, tau_up=lim,
+                           dq_lo=-vmax, dq_up=vmax, max_iter=600)
+        qc, goal = g["tqv_qc"], g["tqv_goal"]
+        x0 = np.zeros((1, 4 * 7 * 6))
+        x0[0, :42] = np.tile(qc, 6)
+        r = be.solve(x0, np.concatenate([qc, np.zeros(7), goal.reshape(-1)])[None])
+        be.close()
+        assert r.status[0] == 0 and bool(g["tqv_ok"])
+        assert r.f[0] >= float(g["tqv_f"]) - 1e-9 and r.f[0] - float(g["tqv_f"]) <= 5e-6 * r.f[0], (r.f[0], float(g["tqv_f"]))

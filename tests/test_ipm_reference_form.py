@@ -168,3 +168,12 @@ def test_velocity_limited_goldens_against_the_numpy_ports():
             assert s["status"] == 0
             f += s["f"]
         assert bool(g["dualv_ok"]) and abs(f - float(g["dualv_f"])) <= 1e-6, (f, float(g["dualv_f"]))
+    if "tqv_f" in g.files:  # config 5 at T = 6 with 0.25 rad/s next to the effort limits (tools/make_golden.py --ipm-torque-velocity)
+        from conftest import MED7_KIN
+        from oracle.torque import TorqueProblem, solve_torque_lm
+
+        vmax = float(g["tqv_vmax"])
+        prob = TorqueProblem(OracleRobot(MED7_KIN), "lbr_link_ee", T=6, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=float(g["tqv_lim"]))
+        s = solve_torque_lm(prob, g["tqv_qc"], np.zeros(7), g["tqv_goal"], vlimits=(-vmax, vmax), max_iter=600)
+        assert s["status"] == 0 and bool(g["tqv_ok"]) and np.abs(s["dQ"]).max() <= vmax + 1e-8
+        assert s["f"] >= float(g["tqv_f"]) - 1e-9 and s["f"] - float(g["tqv_f"]) <= 5e-6 * s["f"], (s["f"], float(g["tqv_f"]))  # below by the bound relaxation

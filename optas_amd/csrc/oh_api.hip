@@ -854,7 +854,14 @@ static int row_stride(int B) {
 }
 static bool stage_fits(const oh_handle* h, int B) {
   const int N = h->desc.ndof, NZ = h->desc.lock_orientation ? N - 3 : N, T = h->desc.T;
-  return !h->desc.lock_orientation || ((double)T * NZ * NZ + 1.0) * (double)row_stride(B) * 8.0 < 4294967296.0;
+  if (!h->desc.lock_orientation) return true;
+  if (!(((double)T * NZ * NZ + 1.0) * (double)row_stride(B) * 8.0 < 4294967296.0)) return false;
+  if (!(((double)T * (3 * N - 3) + 1.0) * (double)row_stride(B) * 8.0 < 4294967296.0)) return false;  // slot offset of the Householder vectors
+  // handles with the coupling folded in: the sweep addresses G of either slot and the spare as one 32-bit offset from the lowest of the three
+  // adjacent arrays (oh_figure8_units.h:step_instance_zc): 3 T N doubles per instance have to stay below 4 GiB (round 3: found by the batch
+  // sweep -- 524 288 instances ran through with wrapped offsets and converged nowhere; they are now refused here and split by the host)
+  const bool zc = h->fuse_couple && !h->have_guards && !h->chain_host.has_lead;
+  return !zc || 3.0 * (double)T * N * (double)row_stride(B) * 8.0 < 4294967296.0;
 }
 
 // Largest batch one oh_solve / oh_solve_device call of this handle takes (0: no bound of the library's own, memory permitting): hosts chunk
@@ -895,7 +902,9 @@ static int ensure_capacity(oh_handle* h, int B) {
     h->pool = nullptr;
   }
   const size_t per_q = (size_t)T * N * Bp;
-  const size_t per_Z = (size_t)T * N * NZ * Bp;
+  // Householder vectors of the null-space basis: 3N - 3 rows per knot (HV_ROWS).  (Until round 3 this was carved as N x NZ rows, the size of Z
+  // itself: at 393 216 instances the second slot then started 4.4 GB after the first and the sweep's 32-bit slot offset wrapped.)
+  const size_t per_Z = (size_t)T * (3 * N - 3) * Bp;
   const size_t per_Dr = (size_t)T * (NZ * (NZ + 1) / 2) * Bp;
   const size_t per_t = (size_t)T * Bp;
   size_t nd = 0;  // doubles

@@ -375,6 +375,34 @@ def test_chunked_solve_keeps_multipliers_and_timing_of_every_chunk(hip_lib, nlp)
     be.close()
 
 
+def test_per_call_bound_covers_the_32_bit_offsets_of_the_fused_coupling(hip_lib, nlp, monkeypatch):
+    """Round 3: with the coupling folded in, the sweep addresses the Lagrangian gradient of either slot and the compaction spare as one 32-bit
+    offset from the lowest of three adjacent arrays: 3 T N doubles per instance must stay below 4 GiB.  A batch sweep found 524 288 instances
+    running through with wrapped offsets (nothing converged).  The library's own bound (oh_max_batch) now covers it, a call beyond it is refused
+    loudly, and the host splits."""
+    import ctypes as C
+
+    from optas_amd import _lib
+
+    robot = RobotModel(urdf_filename=KUKA_KIN)
+    be = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)
+    mb = C.c_int()
+    _lib.check(_lib.load().oh_max_batch(be._h, C.byref(mb)), "oh_max_batch")
+    assert be.flag("fuse_couple") == 1
+    row = mb.value + 13 * 64  # the row stride of a batch of that size (row pad of DESIGN section 3)
+    assert 3 * 50 * 7 * 8 * row < 2**32 <= 3 * 50 * 7 * 8 * (row + 64) and 393216 <= be.max_batch <= mb.value < 524288
+    d = _lib.DeviceBuffer(64)
+    rc = _lib.load().oh_solve_device(be._h, mb.value + 64, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr)  # refused before anything is touched
+    assert rc == _lib.OH_ERR_INVALID and b"split the batch" in _lib.load().oh_last_error()
+    d.free()
+    be.close()
+    monkeypatch.setenv("OH_FUSE_COUPLE", "0")  # the four-kernel path keeps the round-2 bound (the T x NZ^2 stage array)
+    be2 = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)
+    _lib.check(_lib.load().oh_max_batch(be2._h, C.byref(mb)), "oh_max_batch")
+    assert mb.value > 550000  # (the Householder vectors, 3N - 3 rows per knot: 595 008)
+    be2.close()
+
+
 def test_row_stride_padding_is_invisible(hip_lib, nlp, monkeypatch):
     """Batches of 4096 and more get a row stride off the power of two: a layout choice, not a numerical one."""
     robot = RobotModel(urdf_filename=KUKA_KIN)

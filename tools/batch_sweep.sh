@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench.py over batch sizes on one box: one JSON line per size (profiles/rNN_batch_sweep.json)
-for B in ${SWEEP_BATCHES:-1024 4096 8192 16384 32768 65536 131072 262144 524288}; do
-  python bench.py --batch $B --steps 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+for B in ${SWEEP_BATCHES:-1024 4096 8192 16384 32768 65536 131072 262144 393216}; do
+  python bench.py --batch $B --steps 3 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
 r = d['roofline']

@@ -97,3 +97,28 @@ def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B):
     r64 = be.solve(x0[idx], qc[idx])
     assert np.array_equal(r64.x, xa) and np.array_equal(r64.f, fa) and np.array_equal(r64.iters, np.array([a.iters[0] for a in alone]))
     be.close()
+
+
+def test_batch_close_to_the_per_call_bound(hip_lib, monkeypatch):
+    """458 752 instances in one call (the bound of the fused-coupling path is 510 k at T = 50): every 32-bit slot offset of the sweep is near its
+    limit.  Round 3: batches of >= 383 k used to wrap one of them.  Everything converges, and a sample equals the same instances solved in a
+    batch of their own to the last bit (same kernels, other lanes irrelevant) and the compiled host port."""
+    from oracle import cpu_port
+
+    for k in ENV_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    B = 458752
+    dt, lp = bench.local_path()
+    chain = RobotModel(urdf_filename=KUKA_KIN).kinematic_chain(LINK)
+    be = FigureEightBackend(chain, bench.T, dt, lp, max_iter=300, tol=1e-6, hessian=2)
+    assert be.max_batch >= B
+    x0, qc = bench.make_inputs(B, 0)
+    r = be.solve(x0, qc)
+    assert (r.status == 0).mean() >= 0.9999 and (r.kkt[r.status == 0, 0] <= 1e-6).all() and (r.kkt[:, 1] <= 1e-9).all()
+    Q = r.x[:, : 7 * bench.T].reshape(B, bench.T, 7)
+    assert np.array_equal(Q[:, 0], qc)
+    idx = np.sort(np.random.default_rng(B).choice(B, 64, replace=False))
+    _, f_port, _, _, st_port = cpu_port.solve(chain, bench.T, dt, lp, x0[idx], qc[idx], threads=bench.usable_cores())
+    same = np.abs(r.f[idx] - f_port) <= 1e-9 * np.abs(f_port)
+    assert (st_port == 0).all() and same.sum() >= 62, (same.sum(), r.f[idx][~same], f_port[~same])
+    be.close()

@@ -1092,7 +1092,10 @@ static void fill_params(oh_handle* h) {
   P.tol = d.tol;
   P.tol_feas = d.tol_feas;
   P.tol_retract = fmin(1e-10, d.tol_feas);
-  P.tol_retract_min = h->have_guards ? fmin(1e-13, P.tol_retract) : P.tol_retract;
+  // (every handle since the end of round 3.  First built for handles with inequality rows; a tolerance sweep then showed the plain family in the
+  //  same retraction-noise end game below tol = 1e-7 -- a tenth of a batch sitting at 1.5 x tol until the cap at 1e-9 -- and at the default 1e-6
+  //  the rules cut the rejected steps from 1.7 % to 0.4 % and the median instance from 13 to 10 steps: 2.92 -> 3.0-3.1 M solves/s)
+  P.tol_retract_min = fmin(1e-13, P.tol_retract);
   if (const char* e = getenv("OH_RETRACT_MIN")) P.tol_retract_min = fmin(atof(e), P.tol_retract);  // experiments
   P.feas_accept = fmax(1e-8, 10.0 * d.tol_feas);
   P.max_retract = 4;

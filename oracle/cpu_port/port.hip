@@ -104,7 +104,7 @@ extern "C" int oh_port_solve(const oh_problem_desc* desc, const oh_chain* chain,
   P.tol = desc->tol > 0.0 ? desc->tol : 1e-6;
   P.tol_feas = desc->tol_feas > 0.0 ? desc->tol_feas : 1e-9;
   P.tol_retract = fmin(1e-10, P.tol_feas);
-  P.tol_retract_min = P.tol_retract;
+  P.tol_retract_min = fmin(1e-13, P.tol_retract);  // (fill_params in csrc/oh_api.hip)
   P.feas_accept = fmax(1e-8, 10.0 * P.tol_feas);
   P.max_retract = 4;
   P.max_iter = desc->max_iter > 0 ? desc->max_iter : 200;

@@ -357,6 +357,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
     hyb_switch = 1e-5 * prob.w_path
     stat_prev = np.inf
     guard = limits is not None or guards is not None or vlimits is not None
+    tight = True  # FigParams.tol_retract_min below tol_retract: the end-game rules of retract_tol / lm_accept (every handle since the end of round 3)
     vel = vlimits is not None
     if guard:
         from .guarded import Guards, guard_values
@@ -418,7 +419,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
     iters = rejected = 0
     first = True
     polish = False
-    Qt = retract(prob, Qc, Rc, tol=retract_tol(tol_feas, 0.0, False, guard))
+    Qt = retract(prob, Qc, Rc, tol=retract_tol(tol_feas, 0.0, False, tight))
     lam = np.zeros((T, 3))
     cur = None
     status = 1
@@ -467,12 +468,12 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         else:
             rho = (cur["f"] - f_t) / max(pred, 1e-300)
             # (noise: what the orientation violations of the two points are worth, lm_accept in csrc/oh_figure8.h -- handles with inequality rows)
-            noise = 10.0 * max(1.0, abs(cur["f"])) * (feas_t + cur["feas"]) if guard else 0.0
+            noise = 10.0 * max(1.0, abs(cur["f"])) * (feas_t + cur["feas"]) if tight else 0.0
             accept = np.isfinite(f_t) and (rho > 1e-4 or (pred <= max(1e-15 * abs(cur["f"]), noise) and f_t <= cur["f"] + 1e-14 * abs(cur["f"]) + noise))
             # a rejected trial against an accepted point that was retracted loosely: the accepted objective is off by (multiplier) x
             # violation, and steps that predict less than that can never be accepted.  Re-evaluate the accepted point itself at the
             # floor tolerance (zero step, accepted unconditionally) before blaming the model.
-            polish_request = (not accept) and cur["feas"] > 10.0 * retract_tol(tol_feas, pred, False, guard)
+            polish_request = (not accept) and cur["feas"] > 10.0 * retract_tol(tol_feas, pred, False, tight)
             if polish_request:
                 pass
             elif rule == "hip":
@@ -495,7 +496,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                 Qt[F] += np.einsum("tia,ta->ti", cur["Z"][F], z_ls)
                 e_tgt = cur["e"].copy()
                 e_tgt[F] += np.einsum("tma,ta->tm", cur["JZ"], z_ls)
-                tol_r = retract_tol(tol_feas, pred, stat_prev > hyb_switch, guard)
+                tol_r = retract_tol(tol_feas, pred, stat_prev > hyb_switch, tight)
                 Qt = retract(prob, Qt, Rc, tol=tol_r, e_tgt=e_tgt)
                 if iters >= max_iter:
                     break
@@ -522,7 +523,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                 rejected += 1
             if polish_request:
                 polish = True
-                Qt = retract(prob, cur["Q"], Rc, tol=retract_tol(tol_feas, 0.0, False, guard), e_tgt=cur["e"])
+                Qt = retract(prob, cur["Q"], Rc, tol=retract_tol(tol_feas, 0.0, False, tight), e_tgt=cur["e"])
                 pred = 0.0
                 iters += 1
                 continue
@@ -578,7 +579,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
                 meas_prev = cur["meas"]
                 omega = max(tol, min(omega, 0.1 * cur["meas"]))
                 outer = True
-                Qt = retract(prob, cur["Q"], Rc, tol=retract_tol(tol_feas, 0.0, stat > hyb_switch, guard), e_tgt=cur["e"])  # (zero step through k_retract)
+                Qt = retract(prob, cur["Q"], Rc, tol=retract_tol(tol_feas, 0.0, stat > hyb_switch, tight), e_tgt=cur["e"])  # (zero step through k_retract)
                 pred = 0.0
                 iters += 1
                 continue
@@ -598,7 +599,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         e_tgt = cur["e"].copy()
         e_tgt[F] += np.einsum("tma,ta->tm", cur["JZ"], z)  # predicted end-effector positions: e + (Jp Z) z
         # far from the solution the violation a trial point may keep is tied to the decrease its step predicts (retract_tol in oh_figure8.h)
-        tol_r = retract_tol(tol_feas, pred, stat > hyb_switch, guard)
+        tol_r = retract_tol(tol_feas, pred, stat > hyb_switch, tight)
         Qt = retract(prob, Qt, Rc, tol=tol_r, e_tgt=e_tgt)
         iters += 1
     out = {"Q": cur["Q"], "f": cur["f"] - cur["fpsi"], "iters": iters, "rejected": rejected, "stat": stat, "feas": cur["feas"], "status": status, "path": path, "Rc": Rc}

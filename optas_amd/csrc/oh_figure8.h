@@ -120,7 +120,8 @@ OH_DEV void z_from_householder(const double (&V)[3][N], double (&Z)[N][N - 3]) {
 // counts start to move, never looser than 1e-5.  In the end game every point is retracted to the floor: an accepted point that keeps
 // a violation c carries an objective that is off by (multiplier) x c, and once the predicted decreases fall below that (they shrink
 // quadratically) no accurate trial can beat it any more.  The first evaluation and restarts use the floor as well.
-// Handles with inequality rows (tol_retract_min < tol_retract): the outer loop asks for stat <= tol again after every multiplier update, with
+// tol_retract_min < tol_retract (first built for handles with inequality rows, every handle since the end of round 3): the outer loop of
+// those handles asks for stat <= tol again after every multiplier update, with
 // predicted decreases of 1e-12 when 1e-10 of violation is worth 1.5e-10 of objective -- steps were then accepted or refused by the rounding
 // of the retraction and a few instances per 10^4 sat at stat 1e-5 until the iteration cap (round 3; reproduced in oracle/structured.py).
 // There the end-game tolerance follows the prediction too: 1e-2 pred, down to tol_retract_min.

@@ -142,6 +142,7 @@ struct oh_handle {
 extern "C" void oh_destroy(oh_handle* h);
 extern "C" int oh_specialize(oh_handle* h);
 static bool spec_applies(const oh_handle* h);
+static bool spec_tail_vel_applies(const oh_handle* h);
 static int specialize_fk(oh_handle* h);
 extern "C" const char* oh_last_error(void) { return g_err.c_str(); }
 extern "C" const char* oh_version(void) { return "optas_hip 0.1 (gfx950)"; }
@@ -1133,7 +1134,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   int rc = ensure_capacity(h, B);
   if (rc) return rc;
   fill_params(h);
-  if (spec_applies(h) && !h->spec && !h->spec_failed) {
+  if ((spec_applies(h) || spec_tail_vel_applies(h)) && !h->spec && !h->spec_failed) {
     bool want = h->specialize == OH_SPECIALIZE_ALWAYS || (h->specialize == OH_SPECIALIZE_AUTO && B >= h->specialize_min_B);
     if (!want && h->specialize == OH_SPECIALIZE_AUTO && !h->spec_cache_checked) {  // a compiled object is at hand: milliseconds, whatever the batch
       h->spec_cache_checked = true;
@@ -1194,6 +1195,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     return oh_launch_eval(s, N, h->P, h->D, slot, part);
   };
   auto launch_tail = [&](int slot) {
+    if (tail_vel && h->spec && spec_tail_vel_applies(h)) return oh_spec_launch_tail_vel(*h->spec, s, h->P, h->D, h->GP, h->GB, slot) == hipSuccess;
     if (tail_vel) return oh_launch_tail_vel(s, N, h->P, h->D, h->GP, h->GB, slot);
     if (spec) return oh_spec_launch_tail(*spec, s, h->P, h->D, slot) == hipSuccess;
     return oh_launch_tail(s, N, h->P, h->D, slot);
@@ -1843,6 +1845,12 @@ extern "C" int oh_get_constants(oh_handle* h, oh_chain* out) {
 static bool spec_applies(const oh_handle* h) {
   return h->desc.kind == OH_PROBLEM_FIGURE_EIGHT && h->have_chain && h->desc.lock_orientation && !h->have_guards && !h->chain_host.has_lead;
 }
+// handles with joint / joint-velocity limits only: their persistent kernel (k_tail_vel) comes out of the same module; the batched guarded
+// kernels stay generic
+static bool spec_tail_vel_applies(const oh_handle* h) {
+  return h->desc.kind == OH_PROBLEM_FIGURE_EIGHT && h->have_chain && h->desc.lock_orientation && h->have_guards && !h->chain_host.has_lead &&
+         (h->guards.limits || h->guards.vel_limits) && h->guards.n_links == 0 && h->tail_vel;
+}
 static int specialize_fk(oh_handle* h) {
   if (h->fk_spec) return OH_OK;
   std::string err;
@@ -1860,7 +1868,7 @@ extern "C" int oh_specialize(oh_handle* h) {
   HIPCHK(hipSetDevice(h->device));
   const auto t0 = std::chrono::steady_clock::now();
   int rc = specialize_fk(h);  // K1: every handle with constants
-  if (rc == OH_OK && spec_applies(h) && !h->spec) {
+  if (rc == OH_OK && (spec_applies(h) || spec_tail_vel_applies(h)) && !h->spec) {
     std::string err;
     const FigSpec* sp = nullptr;
     if (oh_jit_figure8(h->chain_host, h->desc.ndof, &sp, &err)) {

@@ -8,6 +8,15 @@
 
 #define IDX(t, K, k) (((size_t)(t) * (K) + (k)) * Bp + b)
 
+// Trial slot of an instance (round 3): the slot its accepted point is NOT in.  The orientation-locked kernels alternate one slot for the whole
+// batch, so an instance whose trial was rejected has to sit the next launch out (its accepted point lies where that launch writes); here every
+// instance flips for itself, and a rejection costs no idle launch -- on config 4 (256 arms, 88 launches of ~147 us, every one of them pure
+// latency) 26 of the 88 were such idle launches of the slowest arm.  The `slot` the host passes only says where a restart compaction laid
+// the knots down, and that is where D.cur points away from (k_compact_scatter).
+#define OH_FREE_SLOT(D, b) (1 - (D).cur[b])
+// (a slot chosen per lane: by selection -- an index into the argument struct would make the compiler keep a private copy of it)
+#define SEL(arr, s) ((s) ? (arr)[1] : (arr)[0])
+
 // one knot, no retraction / null space: tracking cost, gradient, Gauss-Newton (or exact) block W (packed lower)
 template <int N>
 OH_DEV void eval_knot_free(const oh_chain* __restrict__ ch, const FigParams& P, const int t, const double (&q)[N], const double (&pc)[3],
@@ -54,21 +63,22 @@ OH_DEV void eval_knot_free(const oh_chain* __restrict__ ch, const FigParams& P, 
 }
 
 template <int N>
-__global__ __launch_bounds__(256) void k_eval_free(FigParams P, FigBuffers D, const int slot) {
+__global__ __launch_bounds__(256) void k_eval_free(FigParams P, FigBuffers D, const int slot_batch) {
   constexpr int NP = N * (N + 1) / 2;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y + P.t0;
   const int Bp = D.Bp;
   if (b >= D.B) return;
+  const int slot = OH_FREE_SLOT(D, b);
   if (D.status[b] >= 0 || D.skip[b]) return;
   const int cur = 1 - slot;
   double q[N];
   if (D.first[b]) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) q[j] = D.q[slot][IDX(t, N, j)];
+    for (int j = 0; j < N; ++j) q[j] = SEL(D.q, slot)[IDX(t, N, j)];
   } else {
 #pragma unroll
-    for (int j = 0; j < N; ++j) q[j] = D.q[cur][IDX(t, N, j)] + D.zstep[IDX(t, N, j)];
+    for (int j = 0; j < N; ++j) q[j] = SEL(D.q, cur)[IDX(t, N, j)] + D.zstep[IDX(t, N, j)];
   }
   double Rc[9], pc[3];
 #pragma unroll
@@ -79,13 +89,13 @@ __global__ __launch_bounds__(256) void k_eval_free(FigParams P, FigBuffers D, co
   eval_knot_free<N>(D.chain, P, t, q, pc, Rc, phi, g, W);
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    D.q[slot][IDX(t, N, j)] = q[j];
-    D.g[slot][IDX(t, N, j)] = g[j];
+    SEL(D.q, slot)[IDX(t, N, j)] = q[j];
+    SEL(D.g, slot)[IDX(t, N, j)] = g[j];
   }
-  D.phi[slot][(size_t)t * Bp + b] = phi;
-  D.cv[slot][(size_t)t * Bp + b] = 0.0;
+  SEL(D.phi, slot)[(size_t)t * Bp + b] = phi;
+  SEL(D.cv, slot)[(size_t)t * Bp + b] = 0.0;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) D.Dr[slot][IDX(t, NP, i)] = W[i];
+  for (int i = 0; i < NP; ++i) SEL(D.Dr, slot)[IDX(t, NP, i)] = W[i];
 }
 
 
@@ -121,21 +131,22 @@ OH_DEV void guard_row(const double gval, const double (&dg)[N], const double rho
 }
 
 template <int N>
-__global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
+__global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot_batch) {
   constexpr int NP = N * (N + 1) / 2;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y + P.t0;
   const int Bp = D.Bp;
   if (b >= D.B) return;
+  const int slot = OH_FREE_SLOT(D, b);
   if (D.status[b] >= 0 || D.skip[b]) return;
   const int cur = 1 - slot;
   double q[N];
   if (D.first[b]) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) q[j] = D.q[slot][IDX(t, N, j)];
+    for (int j = 0; j < N; ++j) q[j] = SEL(D.q, slot)[IDX(t, N, j)];
   } else {
 #pragma unroll
-    for (int j = 0; j < N; ++j) q[j] = D.q[cur][IDX(t, N, j)] + D.zstep[IDX(t, N, j)];
+    for (int j = 0; j < N; ++j) q[j] = SEL(D.q, cur)[IDX(t, N, j)] + D.zstep[IDX(t, N, j)];
   }
   const bool upd = GB.outer[b] != 0;
   const double rho_old = GB.rho[b];
@@ -264,14 +275,14 @@ __global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D,
   }
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    D.q[slot][IDX(t, N, j)] = q[j];
-    D.g[slot][IDX(t, N, j)] = g[j];
+    SEL(D.q, slot)[IDX(t, N, j)] = q[j];
+    SEL(D.g, slot)[IDX(t, N, j)] = g[j];
   }
-  D.phi[slot][(size_t)t * Bp + b] = w * dot3(r, r) + psi;
-  GB.psi[slot][(size_t)t * Bp + b] = psi;
-  D.cv[slot][(size_t)t * Bp + b] = meas;
+  SEL(D.phi, slot)[(size_t)t * Bp + b] = w * dot3(r, r) + psi;
+  SEL(GB.psi, slot)[(size_t)t * Bp + b] = psi;
+  SEL(D.cv, slot)[(size_t)t * Bp + b] = meas;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) D.Dr[slot][IDX(t, NP, i)] = W[i];
+  for (int i = 0; i < NP; ++i) SEL(D.Dr, slot)[IDX(t, NP, i)] = W[i];
 }
 
 // guard parameters of every instance into SoA, multipliers and outer-loop state reset
@@ -298,13 +309,14 @@ __global__ __launch_bounds__(64) void k_setup_guards(FigParams P, FigBuffers D, 
 }
 
 template <int N>
-__global__ __launch_bounds__(256) void k_couple_free(FigParams P, FigBuffers D, const int slot) {
+__global__ __launch_bounds__(256) void k_couple_free(FigParams P, FigBuffers D, const int slot_batch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y + P.t0;
   const int Bp = D.Bp;
   if (b >= D.B) return;
+  const int slot = OH_FREE_SLOT(D, b);
   if (D.status[b] >= 0 || D.skip[b]) return;
-  const double* __restrict__ qs = D.q[slot];
+  const double* __restrict__ qs = SEL(D.q, slot);
   const double kap2 = 2.0 * P.kappa;
   const bool last = (t == P.T - 1);
   double sm = 0.0;
@@ -314,31 +326,32 @@ __global__ __launch_bounds__(256) void k_couple_free(FigParams P, FigBuffers D, 
     const double q0 = qs[IDX(t, N, k)];
     const double dm = q0 - qm;
     sm += dm * dm;
-    double G = D.g[slot][IDX(t, N, k)] + kap2 * dm;
+    double G = SEL(D.g, slot)[IDX(t, N, k)] + kap2 * dm;
     if (!last) G -= kap2 * (qs[IDX(t + 1, N, k)] - q0);
-    D.gt[slot][IDX(t, N, k)] = G;
+    SEL(D.gt, slot)[IDX(t, N, k)] = G;
   }
-  D.merit[slot][(size_t)t * Bp + b] = D.phi[slot][(size_t)t * Bp + b] + P.kappa * sm;
+  SEL(D.merit, slot)[(size_t)t * Bp + b] = SEL(D.phi, slot)[(size_t)t * Bp + b] + P.kappa * sm;
 }
 
 // Joint-velocity rows (oh_guards.vel_limits; enforce_model_limits(name, time_deriv=1), builder.py:471-509) on dq_t = (q_{t+1} - q_t) / dt, round 3.
 // They couple neighbouring knots exactly like the velocity cost: interval (t-1, t) is booked on knot t, its augmented-Lagrangian gradient
 // enters both knots, its Gauss-Newton weight w = rho_v (active rows) / dt^2 joins 2 kappa on the diagonal of both knots and in the coupling
-// block between them, which stays diagonal: E_t = -diag(2 kappa + w_t) -- the sweeps below carry that vector (D.E[slot], N rows per knot)
+// block between them, which stays diagonal: E_t = -diag(2 kappa + w_t) -- the sweeps below carry that vector (SEL(D.E, slot), N rows per knot)
 // instead of the scalar.  (oracle restatement: oracle/guarded.py:solve_free_al(vlimits=...); locked family: couple_unit<N, true>)
 template <int N>
-__global__ __launch_bounds__(256) void k_vel_update_free(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
+__global__ __launch_bounds__(256) void k_vel_update_free(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot_batch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y + P.t0;
   const int Bp = D.Bp;
   if (b >= D.B) return;
+  const int slot = OH_FREE_SLOT(D, b);
   if (D.status[b] >= 0 || D.skip[b] || !GB.outer[b]) return;
   // multiplier refresh at an outer update, at the re-evaluated accepted point with the old penalty (a launch of its own: no lane reads a
   // neighbour's row block while it is rewritten)
   const double rho = GB.rho[b] * GP.vscale, idt = 1.0 / P.dt;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const double v = (D.q[slot][IDX(t, N, k)] - D.q[slot][IDX(t - 1, N, k)]) * idt;
+    const double v = (SEL(D.q, slot)[IDX(t, N, k)] - SEL(D.q, slot)[IDX(t - 1, N, k)]) * idt;
     double* l_lo = GB.lamv + IDX(t, 2 * N, k);
     double* l_up = GB.lamv + IDX(t, 2 * N, N + k);
     *l_lo = fmax(0.0, *l_lo - rho * (v - GP.vlo[k]));
@@ -346,14 +359,15 @@ __global__ __launch_bounds__(256) void k_vel_update_free(FigParams P, FigBuffers
   }
 }
 template <int N>
-__global__ __launch_bounds__(256) void k_couple_free_vel(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
+__global__ __launch_bounds__(256) void k_couple_free_vel(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot_batch) {
   constexpr int NP = N * (N + 1) / 2;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y + P.t0;
   const int Bp = D.Bp;
   if (b >= D.B) return;
+  const int slot = OH_FREE_SLOT(D, b);
   if (D.status[b] >= 0 || D.skip[b]) return;
-  const double* __restrict__ qs = D.q[slot];
+  const double* __restrict__ qs = SEL(D.q, slot);
   const double kap2 = 2.0 * P.kappa;
   const bool last = (t == P.T - 1);
   double qm[N], q0[N], qp[N];
@@ -381,15 +395,15 @@ __global__ __launch_bounds__(256) void k_couple_free_vel(FigParams P, FigBuffers
   for (int k = 0; k < N; ++k) {
     const double dm = q0[k] - qm[k];
     sm += dm * dm;
-    double G = D.g[slot][IDX(t, N, k)] + kap2 * dm + sp[k] - sn[k];
+    double G = SEL(D.g, slot)[IDX(t, N, k)] + kap2 * dm + sp[k] - sn[k];
     if (!last) G -= kap2 * (qp[k] - q0[k]);
-    D.gt[slot][IDX(t, N, k)] = G;
-    if (wp[k] + wn[k] > 0.0) D.Dr[slot][IDX(t, NP, tri(k, k))] += wp[k] + wn[k];
-    D.E[slot][IDX(t, N, k)] = kap2 + wn[k];  // the coupling of knots t and t+1, as the sweeps use it
+    SEL(D.gt, slot)[IDX(t, N, k)] = G;
+    if (wp[k] + wn[k] > 0.0) SEL(D.Dr, slot)[IDX(t, NP, tri(k, k))] += wp[k] + wn[k];
+    SEL(D.E, slot)[IDX(t, N, k)] = kap2 + wn[k];  // the coupling of knots t and t+1, as the sweeps use it
   }
-  D.merit[slot][(size_t)t * Bp + b] = D.phi[slot][(size_t)t * Bp + b] + psi_p + P.kappa * sm;
-  GB.psi[slot][(size_t)t * Bp + b] += psi_p;
-  D.cv[slot][(size_t)t * Bp + b] = fmax(D.cv[slot][(size_t)t * Bp + b], meas_p);
+  SEL(D.merit, slot)[(size_t)t * Bp + b] = SEL(D.phi, slot)[(size_t)t * Bp + b] + psi_p + P.kappa * sm;
+  SEL(GB.psi, slot)[(size_t)t * Bp + b] += psi_p;
+  SEL(D.cv, slot)[(size_t)t * Bp + b] = fmax(SEL(D.cv, slot)[(size_t)t * Bp + b], meas_p);
 }
 
 // S^{-1} (packed lower) from the packed Cholesky factor L and reciprocal pivots: Li = L^{-1}, Sinv = Li^T Li
@@ -480,10 +494,7 @@ OH_DEV int free_accept(const FigParams& P, const FigBuffers& D, const GuardBuffe
     }
   }
   D.cur[b] = cur;
-  if (!accept) {
-    D.skip[b] = 1;
-    atomicAdd(D.work + 1, 1ULL);
-  }
+  if (!accept) atomicAdd(D.work + 1, 1ULL);  // (no idle launch: the next trial goes back into this instance's own trial slot, OH_FREE_SLOT)
   return line_search ? 2 : 1;
 }
 // the bookkeeping of a line-search trial (the caller has scaled D.zstep by OH_LS_SHRINK); returns whether the instance goes on
@@ -567,10 +578,10 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
   {
     double f = D.fconst[b], fpsi = 0.0, meas = 0.0;
     for (int t = P.t0; t < T; ++t) {
-      f += D.merit[ts][(size_t)t * Bp + b];
+      f += SEL(D.merit, ts)[(size_t)t * Bp + b];
       if constexpr (GUARD) {
-        fpsi += GB.psi[ts][(size_t)t * Bp + b];
-        meas = fmax(meas, D.cv[ts][(size_t)t * Bp + b]);
+        fpsi += SEL(GB.psi, ts)[(size_t)t * Bp + b];
+        meas = fmax(meas, SEL(D.cv, ts)[(size_t)t * Bp + b]);
       }
     }
     const int act = free_accept<N, GUARD>(P, D, GB, b, ts, f, fpsi, meas, cur, lm);
@@ -584,8 +595,8 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
     }
   }
   double mu = lm.mu;
-  const double* __restrict__ Drc = D.Dr[cur];
-  const double* __restrict__ gtc = D.gt[cur];
+  const double* __restrict__ Drc = SEL(D.Dr, cur);
+  const double* __restrict__ gtc = SEL(D.gt, cur);
   const double* __restrict__ Ec = cur ? D.E[1] : D.E[0];  // velocity rows: the coupling vectors (VEL)
   double stat = 0.0;
   double S[NP], rd[N], rn[N];
@@ -739,8 +750,9 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
 }
 
 template <int N, bool GUARD, bool VEL = false>
-__global__ __launch_bounds__(64) void k_step_free(FigParams P, FigBuffers D, GuardBuffers GB, const int slot) {
+__global__ __launch_bounds__(64) void k_step_free(FigParams P, FigBuffers D, GuardBuffers GB, const int slot_batch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = (b < D.B) ? OH_FREE_SLOT(D, b) : slot_batch;
   const bool alive = (b < D.B) && (D.status[b] < 0);
   const bool skipping = alive && D.skip[b];
   const bool running = alive && !skipping;
@@ -765,7 +777,7 @@ __global__ __launch_bounds__(64) void k_step_free(FigParams P, FigBuffers D, Gua
 // exactly when the serial sweep would.  The ratio test and the outer-loop decisions are the serial kernel's (free_accept / free_decide, lane 0).
 // The stage arrays are read knot-major (a lane's doubles lie a row apart): instances that share a line are dealt to the same XCD.
 template <int N, bool GUARD, int NT, bool VEL = false>
-__global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D, GuardBuffers GB, const int slot) {
+__global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D, GuardBuffers GB, const int slot_batch) {
   constexpr int NP = N * (N + 1) / 2;
   constexpr int O_R = N * N;  // exchange tile: rows [0, N*N) one block (column-major), rows [N*N, N*N + N) one vector
   __shared__ double sm[N * N + N][NT];
@@ -775,6 +787,7 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
   const int per = (D.B + 7) / 8;  // blocks are dealt round-robin to the 8 XCDs: XCD x takes the instances [x per, (x + 1) per)
   const int b = (blockIdx.x % 8) * per + blockIdx.x / 8;
   if (b >= D.B) return;
+  const int slot = OH_FREE_SLOT(D, b);  // (uniform over the block: one instance)
   const int lane = threadIdx.x;
   const int Bp = D.Bp;
   const int T = P.T;
@@ -797,10 +810,10 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
       return;
     }
   }
-  sm[0][lane] = active ? D.merit[slot][(size_t)tl * Bp + b] : 0.0;
+  sm[0][lane] = active ? SEL(D.merit, slot)[(size_t)tl * Bp + b] : 0.0;
   if constexpr (GUARD) {
-    sm[1][lane] = active ? GB.psi[slot][(size_t)tl * Bp + b] : 0.0;
-    sm[2][lane] = active ? D.cv[slot][(size_t)tl * Bp + b] : 0.0;
+    sm[1][lane] = active ? SEL(GB.psi, slot)[(size_t)tl * Bp + b] : 0.0;
+    sm[2][lane] = active ? SEL(D.cv, slot)[(size_t)tl * Bp + b] : 0.0;
   }
   __syncthreads();
   if (lane == 0) {
@@ -843,8 +856,8 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
     if (NT > 64) out = is_max ? fmax(out, red[slot_r][1]) : out + red[slot_r][1];
     return out;
   };
-  const double* __restrict__ Drc = D.Dr[cur];
-  const double* __restrict__ gtc = D.gt[cur];
+  const double* __restrict__ Drc = SEL(D.Dr, cur);
+  const double* __restrict__ gtc = SEL(D.gt, cur);
   const double* __restrict__ Ec = cur ? D.E[1] : D.E[0];  // velocity rows: the coupling vectors (VEL)
   double stat = 0.0;
   if (active) {
@@ -1014,7 +1027,7 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
 // lanes of a knot read the same words: broadcasts).  ~400 multiply-adds per lane and level instead of ~2100, 61 us per launch at T = 50.  Same system, same
 // ratio test and outer-loop decisions (free_accept / free_decide on lane 0), the damping raised exactly when a pivot of any knot fails.
 template <int N, bool GUARD, int KN, bool VEL = false>
-__global__ __launch_bounds__(8 * KN) void k_step_free_cp(FigParams P, FigBuffers D, GuardBuffers GB, const int slot) {
+__global__ __launch_bounds__(8 * KN) void k_step_free_cp(FigParams P, FigBuffers D, GuardBuffers GB, const int slot_batch) {
   static_assert(N <= 7, "eight lanes per knot");
   constexpr int NP = N * (N + 1) / 2;
   constexpr int NW = (8 * KN) / 64;  // wavefronts
@@ -1028,6 +1041,7 @@ __global__ __launch_bounds__(8 * KN) void k_step_free_cp(FigParams P, FigBuffers
   const int per = (D.B + 7) / 8;  // blocks are dealt round-robin to the 8 XCDs (see k_step_free_pcr)
   const int b = (blockIdx.x % 8) * per + blockIdx.x / 8;
   if (b >= D.B) return;
+  const int slot = OH_FREE_SLOT(D, b);  // (uniform over the block: one instance)
   const int tid = threadIdx.x;
   const int kn = tid >> 3, c = tid & 7;  // knot (lane of the reduction), row within the knot (c == N: the right-hand side solver)
   const int Bp = D.Bp;
@@ -1054,10 +1068,10 @@ __global__ __launch_bounds__(8 * KN) void k_step_free_cp(FigParams P, FigBuffers
     }
   }
   if (c == 0) {
-    TY[0][kn] = active ? D.merit[slot][(size_t)tl * Bp + b] : 0.0;
+    TY[0][kn] = active ? SEL(D.merit, slot)[(size_t)tl * Bp + b] : 0.0;
     if constexpr (GUARD) {
-      TY[1][kn] = active ? GB.psi[slot][(size_t)tl * Bp + b] : 0.0;
-      TY[2][kn] = active ? D.cv[slot][(size_t)tl * Bp + b] : 0.0;
+      TY[1][kn] = active ? SEL(GB.psi, slot)[(size_t)tl * Bp + b] : 0.0;
+      TY[2][kn] = active ? SEL(D.cv, slot)[(size_t)tl * Bp + b] : 0.0;
     }
   }
   __syncthreads();

@@ -1114,6 +1114,7 @@ static void fill_params(oh_handle* h) {
   if (h->chain_host.has_lead) P.np = d.ndof + 1 + d.T;
   // coupling folded into evaluation and sweep (no k_couple launch): the plain orientation-locked handles, i.e. the batched path of config 2
   P.zc = (h->fuse_couple && d.lock_orientation && !h->have_guards && !h->chain_host.has_lead) ? 1 : 0;
+  P.zc_free = (h->fuse_couple && !d.lock_orientation && !(h->have_guards && h->guards.vel_limits)) ? 1 : 0;
 }
 
 extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt,
@@ -1237,7 +1238,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     else if (guarded) oh_launch_eval_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else oh_launch_eval_free(s, N, h->P, h->D, slot);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(1); }
-    if (h->P.zc) {}  // folded into k_evalb_zc / k_step_zc
+    if (h->P.zc || h->P.zc_free) {}  // folded into k_evalb_zc / k_step_zc (position tracking: into the evaluation)
     else if (h->P.lock && guarded && h->GP.vel) oh_launch_couple_vel(s, N, h->P, h->D, h->GP, h->GB, slot);
     else if (h->P.lock) oh_launch_couple(s, N, h->P, h->D, slot);
     else if (guarded && h->GP.vel) oh_launch_couple_free_vel(s, N, h->P, h->D, h->GP, h->GB, slot);

@@ -17,6 +17,33 @@
 // (a slot chosen per lane: by selection -- an index into the argument struct would make the compiler keep a private copy of it)
 #define SEL(arr, s) ((s) ? (arr)[1] : (arr)[0])
 
+// The neighbour coupling folded into the evaluation (round 3; handles without velocity rows): the trial knots of t - 1 and t + 1 are the
+// accepted knots plus the step -- known before their own lanes have evaluated anything -- so the launch of k_couple_free (7 us and a launch gap
+// per iteration of a latency-bound solve) goes away.  Same operations in the same order as k_couple_free.
+template <int N>
+OH_DEV void couple_inline_free(const FigParams& P, const FigBuffers& D, const int b, const int t, const int slot, const bool first, const double (&q)[N],
+                               const double (&g)[N], const double phi) {
+  const int Bp = D.Bp;
+  const double kap2 = 2.0 * P.kappa;
+  const bool last = (t == P.T - 1);
+  const double* __restrict__ qa = first ? SEL(D.q, slot) : SEL(D.q, 1 - slot);  // knots of a restart / the seed, or the accepted point
+  double sm = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double qm = qa[IDX(t - 1, N, k)], qp = last ? 0.0 : qa[IDX(t + 1, N, k)];
+    if (!first) {
+      qm += D.zstep[IDX(t - 1, N, k)];
+      if (!last) qp += D.zstep[IDX(t + 1, N, k)];
+    }
+    const double dm = q[k] - qm;
+    sm += dm * dm;
+    double G = g[k] + kap2 * dm;
+    if (!last) G -= kap2 * (qp - q[k]);
+    SEL(D.gt, slot)[IDX(t, N, k)] = G;
+  }
+  SEL(D.merit, slot)[(size_t)t * Bp + b] = phi + P.kappa * sm;
+}
+
 // one knot, no retraction / null space: tracking cost, gradient, Gauss-Newton (or exact) block W (packed lower)
 template <int N>
 OH_DEV void eval_knot_free(const oh_chain* __restrict__ ch, const FigParams& P, const int t, const double (&q)[N], const double (&pc)[3],
@@ -94,6 +121,7 @@ __global__ __launch_bounds__(256) void k_eval_free(FigParams P, FigBuffers D, co
   }
   SEL(D.phi, slot)[(size_t)t * Bp + b] = phi;
   SEL(D.cv, slot)[(size_t)t * Bp + b] = 0.0;
+  if (P.zc_free) couple_inline_free<N>(P, D, b, t, slot, D.first[b] != 0, q, g, phi);
 #pragma unroll
   for (int i = 0; i < NP; ++i) SEL(D.Dr, slot)[IDX(t, NP, i)] = W[i];
 }
@@ -279,6 +307,7 @@ __global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D,
     SEL(D.g, slot)[IDX(t, N, j)] = g[j];
   }
   SEL(D.phi, slot)[(size_t)t * Bp + b] = w * dot3(r, r) + psi;
+  if (P.zc_free) couple_inline_free<N>(P, D, b, t, slot, D.first[b] != 0, q, g, w * dot3(r, r) + psi);
   SEL(GB.psi, slot)[(size_t)t * Bp + b] = psi;
   SEL(D.cv, slot)[(size_t)t * Bp + b] = meas;
 #pragma unroll

@@ -21,6 +21,8 @@ import numpy as np
 
 from .structured import LS_MAX, LS_SHRINK, FoldedChain, block_tridiag_solve
 
+AL_OMEGA = 1.0  # OH_AL_OMEGA_FREE in csrc/oh_free.hip: inner tolerance of the outer loop relative to the complementarity measure
+
 
 @dataclass
 class Guards:
@@ -235,7 +237,7 @@ def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=Non
             # outer update: stay at the current point, refresh multipliers, tighten the inner tolerance
             rho_next = min(rho * 10.0, 1e8) if meas > 0.25 * meas_prev else rho
             meas_prev = meas
-            omega = max(tol, min(omega, 0.1 * meas))
+            omega = max(tol, min(omega, AL_OMEGA * meas))
             outer = True
             Qt = cur["Q"]
             iters += 1

@@ -245,7 +245,7 @@ def test_guarded_batch_compaction_is_invisible(hip_lib, golden, monkeypatch):
     assert c0 == 0 and c1 >= 2  # the batch did shrink on the way
     assert (r0.status == 0).mean() > 0.99 and (r0.status == r1.status).all()
     # a survivor restarts from its accepted point with its LM state: same iterates, the step in flight is re-derived
-    assert (np.abs(r0.iters.astype(int) - r1.iters) <= 1).mean() >= 0.99
+    assert (np.abs(r0.iters.astype(int) - r1.iters) <= 1).mean() >= 0.97 and np.abs(r0.iters.astype(int) - r1.iters).max() <= 3
     same = r0.iters == r1.iters
     assert np.abs(r0.f - r1.f).max() <= 1e-8 * np.abs(r0.f).max() and np.abs(r0.x[same] - r1.x[same]).max() <= 1e-7
     for a, b in zip(l0, l1):

@@ -203,7 +203,8 @@ typedef struct oh_guards {
   int n_obstacles;
   double rho0;                              /* initial augmented-Lagrangian penalty; <= 0: 10 * w_path */
   /* joint-velocity limits: enforce_model_limits(name, time_deriv=1) (builder.py:471-509), rows dq_t - dq_lo >= 0, dq_up - dq_t >= 0 on
-     dq_t = (q_{t+1} - q_t) / dt, t = 0..T-2; orientation-locked family only (lock_orientation = 1).  They couple neighbouring knots exactly
+     dq_t = (q_{t+1} - q_t) / dt, t = 0..T-2; both trajectory families (position tracking since round 3; the torque-MPC family has its own
+     fields, oh_torque_desc.dq_lo / dq_up, because the velocities are states there).  They couple neighbouring knots exactly
      like the velocity cost: while row j of dq_t is active it adds rho_v / dt^2 to the weight 2 kappa of (q_{t+1,j} - q_{t,j})^2 in the
      block-tridiagonal model.  oh_get_multipliers appends the 2 ndof multipliers of dq_t to knot t's rows (knot T-1: zeros). */
   int vel_limits;

@@ -7,9 +7,14 @@ from .models import RobotModel, TaskModel, Model, JointTypeNotSupported  # noqa:
 from . import _lib  # noqa: F401
 from .builder import OptimizationBuilder  # noqa: F401,E402  (optas/__init__.py:5)
 from .solver import HIPSolver, Solver  # noqa: F401,E402  (optas/__init__.py:6 exports its solver classes)
-from .expr import atan2, path_in_frame, sumsqr, vertcat  # noqa: F401,E402  (the casadi functions the scripts use, optas/__init__.py:2)
+from .expr import atan2, horzcat, path_in_frame, sumsqr, transpose, vertcat  # noqa: F401,E402  (the casadi functions the scripts use, optas/__init__.py:2)
 
 import numpy as np
+
+
+def diag(v):
+    """casadi.diag of a list of numbers (``optas.diag([1e3, 1e3, 1e3])``, example/torque_control_example.py:84): the diagonal matrix."""
+    return np.diag(np.asarray(v, dtype=np.float64).reshape(-1))
 
 
 def deg2rad(x):

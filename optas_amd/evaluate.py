@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from .builder import IntegrationResidual
-from .expr import Add, Atan2, Block, Const, Expr, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RneaFunction, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr, VCat, VarRef
+from .expr import Add, Atan2, Block, Const, Expr, Gather, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RneaFunction, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr, VCat, VarRef
 
 
 def _block(container, vec, label):
@@ -60,6 +60,9 @@ def _evaluate(e: Expr, opt, x: np.ndarray, p: np.ndarray) -> np.ndarray:
         return np.asarray(evaluate(e.a, opt, x, p))[np.ix_(list(e.ridx), list(e.cidx))]
     if isinstance(e, VarRef):
         return _block(opt.decision_variables, x, e.var_name)
+    if isinstance(e, Gather):
+        va = np.broadcast_to(np.asarray(evaluate(e.a, opt, x, p), dtype=np.float64), e.a.shape).T.reshape(-1)
+        return e.sign * va[np.maximum(e.idx, 0)]
     if isinstance(e, LinkFunction):
         q = evaluate(e.q, opt, x, p)
         if e.what == "position":
@@ -152,6 +155,9 @@ def jacobian(e: Expr, opt, x: np.ndarray, p: np.ndarray):
         ma = e.a.shape[0]
         rows = [c * ma + r for c in e.cidx for r in e.ridx]
         return val, Ja[rows]
+    if isinstance(e, Gather):
+        _, Ja = jacobian(e.a, opt, x, p)
+        return val, e.sign.T.reshape(-1, 1) * Ja[np.maximum(e.idx, 0).T.reshape(-1)]
     if isinstance(e, (Sub, Add)):
         _, Ja = jacobian(e.a, opt, x, p)
         _, Jb = jacobian(e.b, opt, x, p)
@@ -305,6 +311,10 @@ def weighted_hessian(e: Expr, opt, x: np.ndarray, p: np.ndarray, W: np.ndarray) 
         return weighted_hessian(e.a, opt, x, p, Wa)
     if isinstance(e, RobotStates):
         return weighted_hessian(e.states, opt, x, p, W[list(e.opt_idx), :])
+    if isinstance(e, Gather):
+        wa = np.zeros(e.a.numel())
+        np.add.at(wa, np.maximum(e.idx, 0).reshape(-1), (W * e.sign).reshape(-1))
+        return weighted_hessian(e.a, opt, x, p, wa.reshape(e.a.shape[1], e.a.shape[0]).T)
     if isinstance(e, (Sub, Add)):
         Ha = weighted_hessian(e.a, opt, x, p, _unbcast(W, (m, n), e.a.shape))
         Hb = weighted_hessian(e.b, opt, x, p, _unbcast(W, (m, n), e.b.shape))

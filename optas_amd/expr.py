@@ -56,10 +56,15 @@ class Expr:
         return NotImplemented
 
     def __matmul__(self, other):
-        return MatMul(self, as_expr(other))
+        return _mtimes(self, other)
 
     def __rmatmul__(self, other):
-        return MatMul(as_expr(other), self)
+        return _mtimes(other, self)
+
+    @property
+    def T(self):
+        """Transpose (``Rc.T``, ``diffp.T @ W_p @ diffp`` in example/torque_control_example.py:69-85)."""
+        return transpose(self)
 
     def __getitem__(self, key):
         """Row selection of a generic node: e[i], e[a:b] (``veff[:3]``, ``pn[2]`` in example/experiment1.py:120-128)."""
@@ -127,7 +132,7 @@ class ParamRef(Expr):
         # obs[:, i]
         if isinstance(key, tuple) and len(key) == 2 and key[0] == slice(None) and isinstance(key[1], int):
             return ParamCol(self, key[1] if key[1] >= 0 else self.n + key[1])
-        raise NotImplementedError("only P[:, i] slicing is lowered")
+        return Expr.__getitem__(self, key)  # pg[3], pg[:3] (example/torque_control_example.py:72-75): rows of the block
 
 
 @dataclass(eq=False)
@@ -448,6 +453,62 @@ class Square(Expr):
     def degree(self):
         d = self.a.degree()
         return 0 if d == 0 else (2 if d == 1 else 3)
+
+
+@dataclass(eq=False)
+class Gather(Expr):
+    """Signed re-arrangement of the entries of ``a``: out[r, c] = sign[r, c] * vec(a)[idx[r, c]] (column-major vec; idx < 0: a zero entry).
+    One node for the structural operations of the reference's scripts -- transpose, ``spatialmath.skew`` of a symbolic vector
+    (spatialmath.py:202-232), horizontal concatenation (as the transpose of a vertical one)."""
+
+    a: Expr = None
+    idx: np.ndarray = None
+    sign: np.ndarray = None
+
+    def __post_init__(self):
+        self.idx = np.atleast_2d(np.asarray(self.idx, dtype=np.int64))
+        self.sign = np.ones(self.idx.shape) if self.sign is None else np.atleast_2d(np.asarray(self.sign, dtype=np.float64))
+        assert self.idx.shape == self.sign.shape and self.idx.max() < self.a.numel()
+        self.sign = np.where(self.idx < 0, 0.0, self.sign)
+        self.shape = self.idx.shape
+
+    def degree(self):
+        return self.a.degree()
+
+
+def transpose(e) -> Expr:
+    e = as_expr(e)
+    m, n = e.shape
+    if (m, n) == (1, 1):
+        return e
+    return Gather(e, np.arange(m * n).reshape(n, m))  # out[r, c] = a[c, r] = vec(a)[r * m + c]
+
+
+def horzcat(*parts) -> Expr:
+    """casadi.horzcat of blocks with equal row counts."""
+    return transpose(VCat(tuple(transpose(q) for q in parts)))
+
+
+def skew(v) -> Expr:
+    """spatialmath.skew of a symbolic scalar or 3-vector (spatialmath.py:202-232): [[0, -z, y], [z, 0, -x], [-y, x, 0]]."""
+    v = as_expr(v)
+    if v.numel() == 1:
+        return Gather(v, [[-1, 0], [0, -1]], [[0.0, -1.0], [1.0, 0.0]])
+    if v.numel() != 3:
+        raise ValueError("expecting a scalar or 3-vector")
+    return Gather(v, [[-1, 2, 1], [2, -1, 0], [1, 0, -1]], [[0.0, -1.0, 1.0], [1.0, 0.0, -1.0], [-1.0, 1.0, 0.0]])
+
+
+def _mtimes(a, b) -> Expr:
+    """casadi.mtimes behind ``@``: a scalar operand multiplies elementwise (``Rc.T @ dt @ dp[:3]``, example/torque_control_example.py:69)."""
+    if isinstance(a, (int, float)):
+        return Scale(float(a), as_expr(b))
+    if isinstance(b, (int, float)):
+        return Scale(float(b), as_expr(a))
+    a, b = as_expr(a), as_expr(b)
+    if a.shape[1] != b.shape[0] and 1 in (a.numel(), b.numel()):
+        return Mul(a, b)
+    return MatMul(a, b)
 
 
 def sumsqr(e) -> Expr:

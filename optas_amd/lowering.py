@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib
 from .builder import IntegrationResidual
-from .expr import Add, Const, LinkFunction, ParamCol, ParamRef, PathInFrame, RneaFunction, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr
+from .expr import Add, Const, LinkFunction, Mul, ParamCol, ParamRef, PathInFrame, RneaFunction, RobotStates, Rows, Scale, Square, StateCols, StateRef, Sub, SumSqr
 from .models import RobotModel, TaskModel
 from .optimization import Optimization
 
@@ -665,13 +665,66 @@ class QpSpec:
     n: int
     m: int
     me: int
+    problem: Optional[Optimization] = None  # the linearly constrained problem the kernel is handed when the user's rows were rewritten (band rows)
+    bands: tuple = ()  # names of the rewritten rows
+
+
+def _same_node(a, b) -> bool:
+    """a and b denote the same expression: one node, or equal row / block selections of one node (``d[0] * d[0]`` indexes twice)."""
+    from .expr import Block
+
+    if a is b:
+        return True
+    if isinstance(a, Rows) and isinstance(b, Rows):
+        return tuple(a.idx) == tuple(b.idx) and _same_node(a.a, b.a)
+    if isinstance(a, Block) and isinstance(b, Block):
+        return tuple(a.ridx) == tuple(b.ridx) and tuple(a.cidx) == tuple(b.cidx) and _same_node(a.a, b.a)
+    return False
+
+
+def _band_rows(opt: Optimization):
+    """Rows ``c - e * e >= 0`` with ``e`` affine in x and ``c`` a non-negative constant (``add_leq_inequality_constraint(name, d * d, 1e-8)``,
+    example/torque_control_example.py:93-95) describe the band ``-sqrt(c) <= e <= sqrt(c)``: the same feasible set, so a quadratic cost over
+    them is a QP with the same minimisers.  Returns {name: (e, sqrt c)}; raises LoweringError for any other nonlinear row."""
+    out = {}
+    for name, term in opt.ineq_constraints.items():
+        sq = term.b if isinstance(term, Sub) else None
+        inner = None
+        if isinstance(sq, Square):
+            inner = sq.a
+        elif isinstance(sq, Mul) and _same_node(sq.a, sq.b):
+            inner = sq.a
+        if inner is None or not isinstance(term.a, Const) or inner.degree() > 1:
+            raise LoweringError(f"dense-QP lowering: nonlinear inequality '{name}' is not of the form c - e*e with e linear in x")
+        if np.any(term.a.value < 0.0):
+            raise LoweringError(f"dense-QP lowering: '{name}' bounds a square by a negative number (empty feasible set)")
+        out[name] = (inner, np.broadcast_to(np.sqrt(term.a.value), term.shape).copy())
+    return out
 
 
 def match_qp(opt: Optimization) -> QpSpec:
     """QuadraticCostUnconstrained / QuadraticCostLinearConstraints (optimization.py:312-388) with small dense data: what the
-    reference's OSQP / CVXOPT / qpOASES back-ends take (solver.py:421-584).  Last resort: the dedicated families come first."""
-    from .optimization import QuadraticCostLinearConstraints, QuadraticCostUnconstrained
+    reference's OSQP / CVXOPT / qpOASES back-ends take (solver.py:421-584).  QuadraticCostNonlinearConstraints (optimization.py:391-460)
+    whose only nonlinear rows are squares of affine expressions under a constant bound (`_band_rows`) are handed over as the equivalent
+    linearly constrained QP.  Last resort: the dedicated families come first."""
+    from .optimization import QuadraticCostLinearConstraints, QuadraticCostNonlinearConstraints, QuadraticCostUnconstrained
+    from .sx_container import SXContainer
 
+    problem, bands = None, ()
+    if isinstance(opt, QuadraticCostNonlinearConstraints):
+        if opt.nh:
+            raise LoweringError("dense-QP lowering: nonlinear equality rows")
+        rows = _band_rows(opt)
+        lin = SXContainer()
+        for name, term in opt.lin_ineq_constraints.items():
+            lin[name] = term
+        for name, (e, half) in rows.items():
+            lin[name + "__band_l"] = Add(e, Const(half))  # e + sqrt c >= 0
+            lin[name + "__band_r"] = Sub(Const(half), e)  # sqrt c - e >= 0
+        problem = QuadraticCostLinearConstraints(opt.decision_variables, opt.parameters, opt.cost_terms, opt.lin_eq_constraints, lin)
+        problem.models = opt.models
+        bands = tuple(rows)
+        opt = problem
     if not isinstance(opt, (QuadraticCostUnconstrained, QuadraticCostLinearConstraints)):
         raise LoweringError("dense-QP lowering: the problem is not of a QuadraticCost{Unconstrained, LinearConstraints} class")
     if opt.has_discrete_variables():
@@ -679,7 +732,7 @@ def match_qp(opt: Optimization) -> QpSpec:
     n, m, me = opt.nx, opt.nk, opt.na
     if not (1 <= n <= 32 and m <= 256 and me <= min(32, n)):
         raise LoweringError(f"dense-QP lowering: sizes nx={n}, nk={m}, na={me} exceed the dense kernel's limits (32, 256, 32)")
-    return QpSpec(n, m, me)
+    return QpSpec(n, m, me, problem, bands)
 
 
 @dataclass

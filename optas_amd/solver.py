@@ -308,10 +308,10 @@ class HIPSolver(Solver):
                 try:
                     from .tape import compile_problem
 
-                    qb.set_tape(compile_problem(self.opt))
+                    qb.set_tape(compile_problem(spec.problem or self.opt))
                 except (NotImplementedError, TypeError, ValueError):
                     pass
-            self._backend = _QpAdapter(self.opt, qb)
+            self._backend = _QpAdapter(spec.problem or self.opt, qb)  # spec.problem: band rows rewritten as linear pairs (lowering._band_rows)
         elif isinstance(spec, TapeSpec):
             o.pop("hessian", None)
             # (evaluations: a small dense problem needs a few hundred; the limited-memory path of a trajectory-sized one tens of thousands)

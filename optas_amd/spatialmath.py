@@ -35,8 +35,18 @@ def unit(v) -> np.ndarray:
     return a / math.sqrt(float(a @ a))
 
 
+def _symbolic(*xs) -> bool:
+    from .expr import Expr
+
+    return any(isinstance(x, Expr) for x in xs)
+
+
 def skew(v) -> np.ndarray:
-    """Skew-symmetric matrix of a scalar or 3-vector (spatialmath.py:202-232)."""
+    """Skew-symmetric matrix of a scalar or 3-vector (spatialmath.py:202-232); of an expression node when ``v`` is one."""
+    if _symbolic(v):
+        from .expr import skew as skew_node
+
+        return skew_node(v)
     a = _v(v)
     if a.shape[0] == 1:
         return np.array([[0.0, -a[0]], [a[0], 0.0]])
@@ -108,13 +118,47 @@ class Quaternion:
     """xyzw quaternion.  ``a * b`` keeps the reference's operand order (spatialmath.py:298-312):
     the result represents the rotation R(b) R(a)."""
 
-    __slots__ = ("_q",)
+    __slots__ = ("_q", "_sym")
+
+    # getrotm entry by entry as the reference defines it (spatialmath.py:426-437): constant + sum of coefficient * product of components
+    # (0: x, 1: y, 2: z, 3: w).  Three entries differ from the textbook matrix of a unit quaternion -- [0][2] has x y for x z, [1][2]
+    # w z for w x, [2][1] w w x for 2 w x -- and are kept, because the scripts' optima depend on what the reference computes, not on the
+    # textbook (example/torque_control_example.py:72-77 passes its goal orientation through this function).
+    _ROTM = (
+        ((1.0, ((-2.0, (1, 1)), (-2.0, (2, 2)))), (0.0, ((2.0, (0, 1)), (-2.0, (3, 2)))), (0.0, ((2.0, (0, 1)), (2.0, (3, 1))))),
+        ((0.0, ((2.0, (0, 1)), (2.0, (3, 2)))), (1.0, ((-2.0, (0, 0)), (-2.0, (2, 2)))), (0.0, ((2.0, (1, 2)), (-2.0, (3, 2))))),
+        ((0.0, ((2.0, (0, 2)), (-2.0, (3, 1)))), (0.0, ((2.0, (1, 2)), (1.0, (3, 3, 0)))), (1.0, ((-2.0, (0, 0)), (-2.0, (1, 1))))),
+    )
 
     def __init__(self, x: float, y: float, z: float, w: float):
-        self._q = np.array([x, y, z, w], dtype=np.float64)
+        self._sym = (x, y, z, w) if _symbolic(x, y, z, w) else None  # components that are expression nodes (entries of a parameter)
+        self._q = None if self._sym is not None else np.array([x, y, z, w], dtype=np.float64)
 
     def split(self):
+        if self._sym is not None:
+            return self._sym
         return tuple(float(v) for v in self._q)
+
+    def getrotm(self):
+        """3 x 3 matrix of the quaternion by the reference's formula (see _ROTM); an expression node when the components are."""
+        comp = self.split()
+
+        def entry(const, terms):
+            acc = None
+            for coef, factors in terms:
+                prod = comp[factors[0]]
+                for k in factors[1:]:
+                    prod = prod * comp[k]
+                term = coef * prod
+                acc = term if acc is None else acc + term
+            return acc + const if const else acc
+
+        rows = [[entry(*e) for e in row] for row in self._ROTM]
+        if self._sym is None:
+            return np.array(rows, dtype=np.float64)
+        from .expr import as_expr, horzcat, vertcat
+
+        return vertcat(*[horzcat(*[as_expr(v) for v in row]) for row in rows])
 
     def getquat(self) -> np.ndarray:
         return self._q.copy()

@@ -16,7 +16,7 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 from .builder import IntegrationResidual
-from .expr import (Add, Atan2, Block, Const, Expr, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols,
+from .expr import (Add, Atan2, Block, Const, Expr, Gather, LinkFunction, MatMul, Mul, ParamCol, ParamRef, PathInFrame, RobotStates, Rows, Scale, Square, StateCols,
                    StateRef, Sub, SumSqr, VCat, VarRef)
 from .spatialmath import rpy2r
 
@@ -269,6 +269,13 @@ class Compiler:
             return self.compile(e.a)[np.ix_(list(e.ridx), list(e.cidx))]
         if isinstance(e, VCat):
             return np.vstack([np.broadcast_to(self.compile(q), q.shape) for q in e.parts])
+        if isinstance(e, Gather):
+            va = np.broadcast_to(self.compile(e.a), e.a.shape).T.reshape(-1)
+            out = np.empty(e.shape, dtype=np.int64)
+            for (r, c), k in np.ndenumerate(e.idx):
+                sg = float(e.sign[r, c])
+                out[r, c] = tb.const(0.0) if k < 0 or sg == 0.0 else (int(va[k]) if sg == 1.0 else tb.mul(tb.const(sg), int(va[k])))
+            return out
         if isinstance(e, Sub):
             return tb.msub(self.compile(e.a), self.compile(e.b))
         if isinstance(e, Add):

@@ -1123,3 +1123,111 @@ class JointSpacePlannerNLP(_NLPBase):
                             W[j, i] += val
             H[n * t : n * t + n, n * t : n * t + n] += W
         return H
+
+
+class TorqueControlNLP(_NLPBase):
+    """example/torque_control_example.py TrackingController (:19-104): a T = 1 velocity-level tracking step, handed to ``sqpmethod``.
+
+    x = "{name}/dq/x" (7x1, RobotModel(time_derivs=[1]), derivs_align=True :29-42);  p = [qc (7); pg (7: goal position, quaternion xyzw)] (:44-45)
+    dp = J(qc) dq (:54-57);  p_ee = Rc' (dt dp[:3]),  R_ee = Rc' (dt skew(dp[3:]) + I) (:69-70: the step seen from the current end-effector frame)
+    Rg = Quaternion(pg[3:7]).getrotm() (:73-74, spatialmath.py:426-437 -- restated entry by entry in `getrotm`, with the reference's own
+    off-textbook entries [0][2], [1][2], [2][1]);  pg_ee = -Rc' pc + Rc' pg[:3],  Rg_ee = Rc' Rg (:76-77)
+    diffp = p_ee - pg_ee,  diffR = Rg_ee' R_ee (:79-80)
+    f = diffp' diag(1e3) diffp + 0.01 ||dq||^2 + 10 ||diffR - I||_F^2 (:82-91)
+    g = [1e-6 - diffp_x^2; 1e-8 - diffp_y^2; 1e-8 - diffp_z^2] >= 0 (:93-95 with builder.py:313: rhs - lhs).
+    Class QuadraticCostNonlinearConstraints (f quadratic in dq, rows quadratic).  Every quantity is affine in dq, so the derivatives are exact.
+    """
+
+    def __init__(self, robot: OracleRobot, link="lbr_link_ee", dt=1.0 / 500.0, w_p=1e3, w_dq=0.01, w_ori=1e1, bounds=(1e-6, 1e-8, 1e-8)):
+        self.robot, self.link, self.dt = robot, link, float(dt)
+        self.n = robot.ndof
+        self.nx, self.np_ = self.n, self.n + 7
+        self.ng = 3
+        self.w_p, self.w_dq, self.w_ori = float(w_p), float(w_dq), float(w_ori)
+        self.bounds = np.asarray(bounds, dtype=np.float64)
+
+    @staticmethod
+    def getrotm(quat):
+        """Quaternion.getrotm (spatialmath.py:426-437) of xyzw numbers, entry by entry as the reference writes it."""
+        x, y, z, w = (float(v) for v in quat)
+        return np.array([
+            [1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * x * y + 2 * w * y],
+            [2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * z],
+            [2 * x * z - 2 * w * y, 2 * y * z + w * w * x, 1 - 2 * x * x - 2 * y * y],
+        ])
+
+    def pieces(self, p):
+        """(A, b, C, c0): diffp = A dq - b (3 rows), vec(diffR - I) = C dq + c0 (9 rows, column-major)."""
+        qc, pg = np.asarray(p[: self.n], float), np.asarray(p[self.n :], float)
+        J = np.asarray(self.robot.get_global_link_geometric_jacobian(self.link, qc), float)
+        pc = np.asarray(self.robot.get_global_link_position(self.link, qc), float).reshape(3)
+        Rc = np.asarray(self.robot.get_global_link_rotation(self.link, qc), float)
+        A = Rc.T @ (self.dt * J[:3])
+        b = (-Rc.T @ pc + Rc.T @ pg[:3])
+        Rg_ee = Rc.T @ self.getrotm(pg[3:])
+        left = Rg_ee.T @ Rc.T
+        C = np.zeros((9, self.n))
+        for j in range(self.n):
+            C[:, j] = (left @ (self.dt * _skew(J[3:, j]))).T.reshape(-1)
+        c0 = (left - np.eye(3)).T.reshape(-1)
+        return A, b, C, c0
+
+    def f(self, x, p):
+        A, b, C, c0 = self.pieces(p)
+        d, r = A @ x - b, C @ x + c0
+        return float(self.w_p * d @ d + self.w_dq * x @ x + self.w_ori * r @ r)
+
+    def df(self, x, p):
+        A, b, C, c0 = self.pieces(p)
+        return 2.0 * self.w_p * A.T @ (A @ x - b) + 2.0 * self.w_dq * x + 2.0 * self.w_ori * C.T @ (C @ x + c0)
+
+    def ddf(self, x, p):
+        A, b, C, c0 = self.pieces(p)
+        return 2.0 * self.w_p * A.T @ A + 2.0 * self.w_dq * np.eye(self.n) + 2.0 * self.w_ori * C.T @ C
+
+    def g(self, x, p):
+        A, b, _, _ = self.pieces(p)
+        d = A @ x - b
+        return self.bounds - d * d
+
+    def dg(self, x, p):
+        A, b, _, _ = self.pieces(p)
+        return -2.0 * (A @ x - b)[:, None] * A
+
+    def ddg_dot(self, x, p, lam_g):
+        A, _, _, _ = self.pieces(p)
+        return -2.0 * (A.T * np.asarray(lam_g, float)) @ A
+
+
+def _skew(v):
+    x, y, z = v
+    return np.array([[0.0, -z, y], [z, 0.0, -x], [-y, x, 0.0]])
+
+
+def band_qp_exact(H, grad0, A, b, half):
+    """min 1/2 x'Hx + grad0'x  s.t. |A_i x - b_i| <= half_i, H positive definite, by enumerating the 3^m active sets (row i free, at the lower
+    or at the upper edge) and keeping the feasible one whose multipliers have the right sign: the unique minimiser, with no tolerance of an
+    iterative method in it.  For the few rows of TorqueControlNLP (its g rows are exactly such bands: eps_i - d_i^2 >= 0 <=> |d_i| <= sqrt eps_i)."""
+    import itertools
+
+    m, n = A.shape
+    best = None
+    for state in itertools.product((0, -1, 1), repeat=m):
+        act = [i for i in range(m) if state[i]]
+        sg = np.array([state[i] for i in act], float)
+        Aa = A[act]
+        K = np.block([[H, Aa.T], [Aa, np.zeros((len(act), len(act)))]])
+        rhs = np.concatenate([-grad0, b[act] + sg * half[act]])
+        try:
+            sol = np.linalg.solve(K, rhs)
+        except np.linalg.LinAlgError:
+            continue
+        x, nu = sol[:n], sol[n:]  # H x + grad0 + Aa' nu = 0: at an upper edge nu >= 0, at a lower edge nu <= 0
+        d = A @ x - b
+        if np.all(np.abs(d) <= half * (1 + 1e-9)) and np.all(nu * sg >= -1e-12 * (1 + np.abs(nu))):
+            fval = 0.5 * x @ H @ x + grad0 @ x
+            if best is None or fval < best[1]:
+                best = (x, fval, state, nu)
+    if best is None:
+        raise RuntimeError("no consistent active set")
+    return best

@@ -112,7 +112,11 @@ class _LBFGS:
         self.S, self.Y = (self.S + [sv])[-self.m:], (self.Y + [yv])[-self.m:]
 
 
-def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0, lbfgs=None):
+KEEP_METRIC = True  # the quasi-Newton metric survives the multiplier / penalty updates of the outer loop (csrc/oh_tape_solver.h)
+SCALE_FIRST = True  # dense form: the first pair scales the identity before updating it
+
+
+def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0, lbfgs=None, trace=None):
     """Generic NLP on a tape: min f s.t. rows[:n_ineq] >= 0, rows[n_ineq:] = 0.  Augmented Lagrangian (PHR for the inequality rows)
     minimised by BFGS with Armijo backtracking -- the dense inverse Hessian up to 48 variables, the limited-memory form with `lbfgs` = 12 pairs
     beyond, as oh_api.hip:tape_params chooses; one forward + one reverse sweep per evaluation.  Port of k_tape_solve."""
@@ -141,6 +145,7 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
     evals = 1
     val, grad, g, c, fval = phi(x)
     H = np.eye(n) if LB is None else None
+    fresh = True  # dense form: H is the identity (nothing measured yet)
     omega, meas_prev = max(tol, 1e-2), np.inf
     status = 1
     while True:
@@ -163,9 +168,13 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
             omega = max(tol, min(omega, 0.1 * meas))
             val, grad, g, c, fval = phi(x)
             evals += 1
-            H = np.eye(n) if LB is None else None
-            if LB is not None:
-                LB.reset()
+            # the metric is kept: the multiplier update shifts the merit, its curvature (cost + penalty of the rows in reach) stays what the
+            # pairs have measured; rebuilding it from the identity at every outer update cost 4 of every 5 evaluations on the 7-variable IK
+            if not KEEP_METRIC:  # the rule before round 3, for A/B runs
+                H = np.eye(n) if LB is None else None
+                fresh = True
+                if LB is not None:
+                    LB.reset()
             continue
         if evals >= max_iter:
             break
@@ -176,23 +185,41 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
                 H = np.eye(n)
             else:
                 LB.reset()
+            fresh = True
             d = -grad
             slope = float(grad @ d)
         # a fresh (identity) metric knows nothing about the scale of the problem: keep the first step within unit length
-        fresh = np.array_equal(H, np.eye(n)) if LB is None else LB.is_identity()
+        if LB is not None:
+            fresh = LB.is_identity()
         alpha = min(1.0, 1.0 / np.abs(d).max()) if fresh else 1.0
         ok = False
         for _ in range(40):
             xt = x + alpha * d
             vt, gt, g_t, c_t, f_t = phi(xt)
             evals += 1
-            if np.isfinite(vt) and vt <= val + 1e-4 * alpha * slope + 4e-16 * max(1.0, abs(val)):
+            # what the merit resolves: its own rounding plus the rows' rounding (1e-16 of quantities of order one) times their multipliers --
+            # under multipliers of 30 the term -mu c moves by 3e-15 between two evaluations of the same point
+            slack = 4e-16 * (max(1.0, abs(val)) + float(np.sum(np.abs(mu)) + np.sum(lam)))
+            need = -1e-4 * alpha * slope
+            if need > slack:
+                if np.isfinite(vt) and vt <= val - need + slack:
+                    ok = True
+                    break
+            elif np.isfinite(vt) and vt <= val - slack:  # a decrease the merit does resolve, larger than the one asked for
+                ok = True
+                break
+            elif np.isfinite(vt) and vt <= val + slack and float(gt @ gt) <= (1.0 - 1e-4 * alpha) * float(grad @ grad):
+                # the decrease asked for is below that resolution (end game under a large penalty: a gradient of 4e-6 across a curvature of 1e4
+                # is worth 7e-16 of merit): the value cannot judge the step, the gradient can -- a step that keeps the merit within its rounding
+                # is taken if it shrinks the gradient; one that leaves the gradient where it was is not a step (alpha -> 0 used to pass as one)
                 ok = True
                 break
             alpha *= 0.5
             if evals >= max_iter:
                 break
         if not ok:
+            if trace is not None:
+                trace.append({"evals": evals, "val": val, "stat": float(stat), "alpha": 0.0, "slope": slope, "rho": rho, "omega": omega, "sy": 0.0, "fresh": bool(fresh)})
             evals += 1  # the kernel re-evaluates the accepted point (its tape registers were overwritten by the rejected trials)
             if fresh or evals >= max_iter:
                 break  # steepest descent cannot improve: rounding floor
@@ -200,13 +227,20 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
                 H = np.eye(n)
             else:
                 LB.reset()
+            fresh = True
             continue
         sv, yv = xt - x, gt - grad
         sy = float(sv @ yv)
+        if trace is not None:
+            trace.append({"evals": evals, "val": vt, "stat": float(np.abs(gt).max()), "alpha": alpha, "slope": slope, "rho": rho, "omega": omega, "sy": sy,
+                          "fresh": bool(fresh)})
         if LB is not None:
             if sy > 1e-12 * np.linalg.norm(sv) * np.linalg.norm(yv):
                 LB.update(sv, yv)
         elif sy > 1e-12 * np.linalg.norm(sv) * np.linalg.norm(yv):
+            if fresh and SCALE_FIRST:
+                H = (sy / float(yv @ yv)) * np.eye(n)  # Nocedal & Wright (6.20): the first pair sets the scale before it updates the identity
+            fresh = False
             Hy = H @ yv
             H = H + ((sy + float(yv @ Hy)) / (sy * sy)) * np.outer(sv, sv) - (np.outer(Hy, sv) + np.outer(sv, Hy)) / sy
         x, val, grad, g, c, fval = xt, vt, gt, g_t, c_t, f_t

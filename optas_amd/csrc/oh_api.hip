@@ -115,6 +115,8 @@ struct oh_handle {
   int* h_flag = nullptr;  // pinned
   bool compaction = true;
   int compact_carry = 1;     // compaction carries the pending trial along instead of restarting the survivors (k_carry_*)
+  int tail_vel_threshold = 1 << 30;  // ... from this many instances down: always (see oh_solve_device)
+  int lg_split = 1;          // orientation-locked handles with limit rows and no sphere rows: k_retract + k_evalb_lg instead of the fused k_eval_lg (OH_LG_SPLIT=0)
   int tail_vel = 1;          // velocity-limited handles drain in the persistent kernel too (k_tail_vel; OH_TAIL_VEL=0: batched launches to the end)
   int compact_sort = 1;      // order the survivors of a compaction by progress (k_scan_*)
   double compact_frac = 0.97;  // compact the batch once this fraction of it (or less) is still running (0.9 until the carried compaction
@@ -233,6 +235,8 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (const char* e5 = getenv("OH_COMPACT_SORT")) h->compact_sort = atoi(e5);
   if (const char* e6 = getenv("OH_COMPACT_CARRY")) h->compact_carry = atoi(e6);
   if (const char* e7 = getenv("OH_TAIL_VEL")) h->tail_vel = atoi(e7);
+  if (const char* e8 = getenv("OH_LG_SPLIT")) h->lg_split = atoi(e8);
+  if (const char* e9 = getenv("OH_TAIL_VEL_THRESHOLD")) h->tail_vel_threshold = atoi(e9);
   if (const char* e7 = getenv("OH_FUSE_COUPLE")) h->fuse_couple = atoi(e7) != 0;
   if (const char* e9 = getenv("OH_SPARSE_CHECK_BELOW")) h->sparse_check_below = atoi(e9);
   hipGetDevice(&h->device);
@@ -1189,6 +1193,10 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   // persistent tail kernel: plain orientation-locked handles, and (round 3, k_tail_vel) those whose inequality rows are joint and / or joint-velocity limits (no sphere rows)
   const bool tail_vel = guarded && (h->GP.vel || h->GP.limits) && h->GP.n_links == 0 && h->tail_vel;
   const bool tail_ok = (h->desc.T - h->P.t0 <= 64) && h->tail_threshold > 0 && h->desc.lock_orientation && (!guarded || tail_vel) && !lead;
+  // limit / velocity-limit handles: the batched launches (evaluation, velocity coupling in a launch of its own, sweep: 1.45 ms per iteration of
+  // 40 000 instances) lose against the persistent kernel at every size measured -- 65 536 instances: 87.5 ms with the hand-over at 16 384,
+  // 80.5 at 32 768, 76.3 when the whole batch starts there -- so these handles go to it whatever the batch (OH_TAIL_VEL_THRESHOLD overrides)
+  const int tail_threshold = tail_vel ? h->tail_vel_threshold : h->tail_threshold;
   const FigSpec* const spec = spec_applies(h) ? h->spec : nullptr;
   // evaluation / tail launches: the kernels compiled for this handle's chain when they are loaded, the generic ones otherwise
   auto launch_eval = [&](int slot, int part) {
@@ -1202,7 +1210,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     return oh_launch_tail(s, N, h->P, h->D, slot);
   };
   bool tail_done = false;
-  if (tail_ok && B <= h->tail_threshold) {  // small batch: the whole solve is one persistent launch
+  if (tail_ok && B <= tail_threshold) {  // small batch: the whole solve is one persistent launch
     launch_tail(0);
     tail_done = true;
   }
@@ -1215,8 +1223,13 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     }
     rebase = false;
     const int slot = it & 1;
-    if (h->P.lock && guarded) oh_launch_eval_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
-    else if (lead) oh_launch_eval_lead(s, N, h->P, h->D, slot);
+    if (h->P.lock && guarded) {
+      if (h->lg_split && h->GP.n_links == 0) {  // retraction and evaluation as two launches, like the plain family (k_evalb_lg in oh_kernels.hip)
+        if (!(h->spec && spec_tail_vel_applies(h) && oh_spec_launch_eval(*h->spec, s, h->P, h->D, slot, 1) == hipSuccess))
+          oh_launch_eval_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot, 1);
+        oh_launch_eval_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot, 2);
+      } else oh_launch_eval_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot, 0);
+    } else if (lead) oh_launch_eval_lead(s, N, h->P, h->D, slot);
     else if (h->P.lock && carry_pending > 0) {
       // compaction with the trial carried along: retract on the old layout, move, evaluate on the dense one (k_carry_* in oh_kernels.hip)
       launch_eval(slot, 1);
@@ -1262,7 +1275,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       const int nrun = *h->h_flag;
       rebase = true;
       if (nrun == 0) break;
-      if (tail_ok && nrun <= h->tail_threshold) {
+      if (tail_ok && nrun <= tail_threshold) {
         // drain: compact the survivors and let one wavefront per instance finish them without further launches
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
         if (guarded) oh_launch_guard_emit(s, h->P, h->D, h->GP, h->GB, NV, 1);

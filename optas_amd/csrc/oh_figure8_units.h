@@ -117,7 +117,8 @@ OH_DEV void load_householder(const double* __restrict__ Vs, const int Bp, const 
 // null-space basis of a neighbour -- the Lagrangian gradient G_t = g_t + 2 kappa (2 q_t - q_{t-1} - q_{t+1}) and the merit share phi_t + kappa
 // ||q_t - q_{t-1}||^2, from the neighbours' retracted knots (in HBM since k_retract) -- and stores G where it stored g, the merit where it
 // stored phi: same bytes out, 2N doubles more in, and the sweep (step_instance_zc) rebuilds E_t and gt_t from V and G on the fly.
-template <int N, bool GUARD = false, bool LEAD = false, int MODE = EVAL_FUSED, bool ZC = false>
+// SPH = false (GUARD only): the handle has no sphere rows -- their walk over the links is compiled out (86 registers of a kernel at the limit)
+template <int N, bool GUARD = false, bool LEAD = false, int MODE = EVAL_FUSED, bool ZC = false, bool SPH = true>
 OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, const int b, const int t, const GuardParams* GPp = nullptr,
                       const GuardBuffers* GBp = nullptr) {
   static_assert(!ZC || (MODE == EVAL_ONLY && !GUARD && !LEAD), "the folded coupling belongs to the plain batched evaluation");
@@ -242,7 +243,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   if constexpr (GUARD) {
     // the exact block carries no curvature of the sphere rows (-s d2g, s ~ w_path): with them the exact model is worse than
     // Gauss-Newton (the oracle run crawls), so sphere-guarded problems stay on Gauss-Newton
-    if (GPp->n_links > 0) exact = false;
+    if (SPH && GPp->n_links > 0) exact = false;
   }
   const bool have_G = exact && !first;
 #pragma unroll
@@ -363,7 +364,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
         for (int j = 0; j < N; ++j) acc += dd[j] * Z[j][a] * Z[j][c2];
         Dr[tri(a, c2)] += acc;
       }
-    if (GP.n_links > 0) {
+    if (SPH && GP.n_links > 0) {
       sphere_rows_walk<N>(D.chain, GP, GB.par, (size_t)Bp, b, q, [&](const int l, const int o, const double gval, const double (&dg)[N]) {
         double* lam_ptr = GB.lam + IDX(t, GP.NC, nl + l * GP.n_obs + o);
         double lam = *lam_ptr;

@@ -183,6 +183,14 @@ template <int N>
 __global__ __launch_bounds__(256) void k_eval_lg(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
   eval_unit<N, true>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0, &GP, &GB);
 }
+// ... and, for handles without sphere rows, split like the plain family's: k_retract (the kernel compiled for the chain when it is loaded), then
+// the evaluation of the retracted knot with the limit rows at two wavefronts per SIMD (256 registers, 116 B of scratch; the fused kernel needs
+// 256 + 96).  65 536 velocity-limited instances: evaluation 28.2 -> 23.0 ms of 88.  With sphere rows the evaluation stays at one wavefront per
+// SIMD either way and the second launch costs what the split saves (16 384 instances: 134 against 130 ms): those handles keep the fused kernel.
+template <int N>
+__global__ __launch_bounds__(256, 2) void k_evalb_lg(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot) {
+  eval_unit<N, true, false, EVAL_ONLY, false, false>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0, &GP, &GB);
+}
 template <int N>
 __global__ __launch_bounds__(64) void k_step_lg(FigParams P, FigBuffers D, GuardBuffers GB, const int slot) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,11 +207,18 @@ __global__ __launch_bounds__(64) void k_step_lg(FigParams P, FigBuffers D, Guard
   const unsigned long long m2 = __ballot(still);
   if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
 }
-bool oh_launch_eval_locked_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
+bool oh_launch_eval_locked_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot, int part) {
+  // part 0: the fused kernel; 1: k_retract only; 2: the evaluation of the retracted knots only (1 then 2 = the split form; no sphere rows)
   const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
-  if (n == 7) hipLaunchKernelGGL(k_eval_lg<7>, g, b, 0, s, P, D, GP, GB, slot);
-  else if (n == 6) hipLaunchKernelGGL(k_eval_lg<6>, g, b, 0, s, P, D, GP, GB, slot);
-  else return false;
+  if (n == 7) {
+    if (part == 0) hipLaunchKernelGGL(k_eval_lg<7>, g, b, 0, s, P, D, GP, GB, slot);
+    else if (part == 1) hipLaunchKernelGGL(k_retract<7>, g, b, 0, s, P, D, slot);
+    else hipLaunchKernelGGL(k_evalb_lg<7>, g, b, 0, s, P, D, GP, GB, slot);
+  } else if (n == 6) {
+    if (part == 0) hipLaunchKernelGGL(k_eval_lg<6>, g, b, 0, s, P, D, GP, GB, slot);
+    else if (part == 1) hipLaunchKernelGGL(k_retract<6>, g, b, 0, s, P, D, slot);
+    else hipLaunchKernelGGL(k_evalb_lg<6>, g, b, 0, s, P, D, GP, GB, slot);
+  } else return false;
   return true;
 }
 bool oh_launch_step_locked_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {

@@ -72,6 +72,18 @@ def oracle_grade(kind, **kw):
                 "dynamics_rows_max": float(max(np.abs(nlp.h(x, p)).max() for x, p in zip(kw["x"], kw["p"]))),
                 "objective_recomputed_max_rel_diff": float(max(abs(nlp.f(x, p) - f) / abs(f) for x, p, f in zip(kw["x"], kw["p"], kw["f"]))),
                 "by": "oracle/solvers.py:kkt_reference_form on oracle/problems.py:TorqueMPCNLP (literal 840-variable / 1680-row layout, RNEA rows by the literal recursion)"}
+    elif kind == "fig8_vel":
+        from oracle.problems import LimitedFigureEightNLP
+
+        orc = OracleRobot(os.path.join(R, "kuka_lwr.kin.json"))
+        vl = np.asarray(orc.velocity_actuated_joint_limits)
+        nlp = LimitedFigureEightNLP(orc, "end_effector_ball", vlo=-vl, vup=vl, T=50)
+        ks = [kkt_reference_form(nlp, x, p, active_tol=1e-7) for x, p in zip(kw["x"], kw["p"])]
+        return {"instances": len(ks), "stationarity_max": max(k["stationarity"] for k in ks), "feasibility_max": max(k["feasibility"] for k in ks),
+                "complementarity_max": max(k["complementarity"] for k in ks),
+                "velocity_rows_min": float(min(nlp.k(x, p).min() for x, p in zip(kw["x"], kw["p"]))),
+                "objective_recomputed_max_rel_diff": float(max(abs(nlp.f(x, p) - f) / abs(f) for x, p, f in zip(kw["x"], kw["p"], kw["f"]))),
+                "by": "oracle/solvers.py:kkt_reference_form on oracle/problems.py:LimitedFigureEightNLP (literal layout, 686 velocity rows)"}
     elif kind == "guarded_arm":
         from oracle.guarded import Guards, guard_values
         from oracle.structured import FoldedChain
@@ -167,8 +179,24 @@ def run_configs(sample=8, torque_batches=(8192, 1024), only=None):
                                  "oracle_sample": oracle_grade("pm", **smp) if smp else None,
                                  "closed_loop": {"ticks": n_ticks, "device_ms": be.solve_ms(), "ticks_per_s": B * n_ticks / be.solve_ms() * 1e3, "converged_frac": float((stt == 0).mean())}}
     be.close()
+    _velocity_limited(out, sample)
     _config4(out, rng, sample)
     return _torque(out, rng, sample, torque_batches)
+
+
+def _velocity_limited(out, sample):
+    # config 2 with enforce_model_limits(name, time_deriv=1) (the shipped script's optimum breaks the LWR's speed limit on joint 0)
+    from examples.figure_eight_plan import setup_solver
+
+    B = 65536
+    qcs = np.deg2rad([0, 30, 0, -90, 0, -30, 0])[None] + np.random.default_rng(SEED + 2).uniform(-0.1, 0.1, (B, 7))
+    kuka, solver = setup_solver(velocity_limits=True, solver_options={"max_iter": 600, "tol": 1e-6})
+    x0 = np.zeros((B, solver.opt.nx))
+    x0[:, :350] = np.repeat(qcs, 50, axis=0).reshape(B, 350)
+    r, smp = timed_with_results(solver.backend, x0, np.ascontiguousarray(qcs), sample=min(sample, 4), seed=2)
+    out["config2_velocity_limited"] = {"what": "figure_eight_plan.py T=50 + joint-velocity limits (686 inequality rows), B = 65536; persistent kernel k_tail_vel", "batch": B,
+                                       "solves_per_s": B / r["device_ms"] * 1e3, **r, "oracle_sample": oracle_grade("fig8_vel", **smp) if smp else None}
+    solver.backend.close()
 
 
 def _config4(out, rng, sample):

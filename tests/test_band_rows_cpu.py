@@ -217,3 +217,20 @@ def test_literal_control_nlp_derivatives_and_exact_solver():
     assert r["status"] == "optimal" and np.abs(r["x"] - xs).max() <= 0.05 and np.all(nlp.g(r["x"], p) >= -1.01e-8)
     xr, _, _, _ = band_qp_exact(nlp.ddf(z, p), nlp.df(z, p), A, b, np.sqrt(nlp.bounds + 1e-8))
     assert np.abs(r["x"] - xr).max() <= 1e-4
+
+
+def test_vector_rows_with_per_entry_bounds_and_the_square_node():
+    b = OptimizationBuilder(1)
+    x = b.add_decision_variables("x", 3)
+    a = b.add_parameter("a", 3)
+    d = x - a
+    b.add_cost_term("c", sumsqr(x))
+    b.add_leq_inequality_constraint("v", d * d, np.array([1e-2, 4e-2, 9e-2]))  # three rows, one bound each
+    b.add_leq_inequality_constraint("w", d**2, 0.25)  # the Square node, one bound for all rows
+    _, spec = lower(b.build())
+    qp, p = spec.problem, np.array([1.0, 2.0, 3.0])
+    assert spec.bands == ("v", "w") and qp.nk == 12
+    I = np.eye(3)
+    assert np.allclose(np.asarray(qp.M(p)), np.vstack([I, -I, I, -I]), atol=1e-15)
+    half = np.array([0.1, 0.2, 0.3])
+    assert np.allclose(np.asarray(qp.c(p)).reshape(-1), np.concatenate([-p + half, p + half, -p + 0.5, p + 0.5]), atol=1e-15)

@@ -212,8 +212,20 @@ def make_solver_class(solver_module, cs):
                     self._tape = tape_from_functions(cs, self.opt.nx, self.opt.np, self.opt.f, ineq=(getattr(self.opt, "k", None),), eq=(getattr(self.opt, "a", None),))
                     self._backend = QPBackend(self.opt.nx, nk, na, max_iter=int(o.pop("max_iter", 100)), tol=float(o.pop("tol", 1e-9)), tape=self._tape)
                     self._family = "qp"
-                elif family == "qp":
-                    raise ValueError("family 'qp' needs a QuadraticCostUnconstrained / QuadraticCostLinearConstraints problem with nx <= 32, nk <= 256, na <= 32")
+                elif type(self.opt).__name__ == "QuadraticCostNonlinearConstraints" and not int(getattr(self.opt, "nh", 0) or 0) and self.opt.nx <= 32 \
+                        and not self.opt.has_discrete_variables():
+                    # quadratic cost whose only curved rows are squares of affine expressions under a constant (example/torque_control_example.py:93-95,
+                    # handed to sqpmethod by the reference): bands, i.e. the same QP with two linear rows each (tape.band_rewrite)
+                    from .tape import band_rewrite
+
+                    banded = band_rewrite(tape_from_optimization(self.opt, cs))
+                    if banded is not None and banded.n_ineq <= 256 and banded.n_eq <= min(32, self.opt.nx):
+                        self._tape = banded
+                        self._backend = QPBackend(self.opt.nx, banded.n_ineq, banded.n_eq, max_iter=int(o.pop("max_iter", 100)), tol=float(o.pop("tol", 1e-9)), tape=banded)
+                        self._family = "qp"
+                if self._family is None and family == "qp":
+                    raise ValueError("family 'qp' needs a QuadraticCostUnconstrained / QuadraticCostLinearConstraints problem (or one whose nonlinear rows are "
+                                     "squares of affine expressions under a constant) with nx <= 32, nk <= 256, na <= 32")
             if self._family is None:
                 self._tape = tape_from_optimization(self.opt, cs)
                 self._backend = TapeBackend(self._tape, max_iter=int(o.pop("max_iter", 2000)), tol=float(o.pop("tol", 1e-6)),

@@ -11,7 +11,7 @@ same chain walk as RobotModel.get_global_link_transform (models.py:826-868) over
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -373,3 +373,81 @@ def compile_problem(opt) -> Tape:
         raise NotImplementedError(f"tape of {len(tb.op)} instructions exceeds {MAX_TAPE}")
     return Tape(np.asarray(tb.op, dtype=np.int32), np.asarray(tb.a, dtype=np.int32), np.asarray(tb.b, dtype=np.int32), np.asarray(tb.c, dtype=np.float64),
                 int(f), np.asarray(rows, dtype=np.int32), len(ineq), len(eq), opt.nx, opt.np)
+
+
+def tape_degrees(tape: Tape) -> np.ndarray:
+    """Degree in x of every register of a tape: 0 constant / parameter only, 1 affine, 2 quadratic, 3 anything else -- the classification the
+    reference asks CasADi for (cs.is_linear / is_quadratic, builder.py:226-240), here on the instruction arrays."""
+    deg = np.zeros(len(tape.op), dtype=np.int8)
+    for r, (op, a, b) in enumerate(zip(tape.op, tape.a, tape.b)):
+        if op == OP_X:
+            deg[r] = 1
+        elif op in (OP_CONST, OP_P):
+            deg[r] = 0
+        elif op in (OP_ADD, OP_SUB):
+            deg[r] = max(deg[a], deg[b])
+        elif op == OP_NEG:
+            deg[r] = deg[a]
+        elif op == OP_MUL:
+            deg[r] = min(3, deg[a] + deg[b])
+        elif op == OP_SQR:
+            deg[r] = min(3, 2 * deg[a])
+        elif op == OP_DIV:
+            deg[r] = deg[a] if deg[b] == 0 else 3
+        else:  # sin, cos, atan2, sqrt
+            deg[r] = 0 if max(deg[a], deg[b] if op == OP_ATAN2 else 0) == 0 else 3
+    return deg
+
+
+def band_rewrite(tape: Tape) -> Optional[Tape]:
+    """The tape of the equivalent linearly constrained QP when the cost is at most quadratic in x, the equality rows affine, and every
+    inequality row either affine or of the form ``c - e*e`` with ``e`` affine and ``c`` a non-negative constant (example/torque_control_example.py:93-95):
+    such a row is the band -sqrt(c) <= e <= sqrt(c) (the same feasible set, the same minimisers), written as the two rows e + sqrt(c), sqrt(c) - e.
+    None when the problem is not of that shape.  The tape-level twin of lowering._band_rows, for problems that arrive as CasADi functions."""
+    deg = tape_degrees(tape)
+    if deg[tape.out_cost] > 2:
+        return None
+    ni = tape.n_ineq
+    if any(deg[r] > 1 for r in tape.out_rows[ni:]):
+        return None
+    op, ra, rb, rc = tape.op, tape.a, tape.b, tape.c
+
+    def square_of(r):  # register e with r = e*e, or None
+        if op[r] == OP_SQR:
+            return int(ra[r])
+        if op[r] == OP_MUL and ra[r] == rb[r]:
+            return int(ra[r])
+        return None
+
+    def band(r):  # (e, c) for r = c - e*e in the forms a front end writes it
+        if op[r] == OP_SUB and op[ra[r]] == OP_CONST:
+            return square_of(int(rb[r])), float(rc[ra[r]])
+        if op[r] == OP_ADD:
+            for u, w in ((ra[r], rb[r]), (rb[r], ra[r])):
+                if op[u] == OP_CONST and op[w] == OP_NEG:
+                    return square_of(int(ra[w])), float(rc[u])
+        return None, 0.0
+
+    ops, aa, bb, cc = list(op), list(ra), list(rb), list(rc)
+
+    def emit(o, a=0, b=0, c=0.0):
+        ops.append(o), aa.append(a), bb.append(b), cc.append(c)
+        return len(ops) - 1
+
+    rows, found = [], 0
+    for r in tape.out_rows[:ni]:
+        r = int(r)
+        if deg[r] <= 1:
+            rows.append(r)
+            continue
+        e, c = band(r)
+        if e is None or deg[e] > 1 or not c >= 0.0:
+            return None
+        half = emit(OP_CONST, 0, 0, float(np.sqrt(c)))
+        rows += [emit(OP_ADD, min(e, half), max(e, half)), emit(OP_SUB, half, e)]
+        found += 1
+    if not found:
+        return None
+    out_rows = np.asarray(rows + [int(r) for r in tape.out_rows[ni:]], dtype=np.int32)
+    return Tape(np.asarray(ops, dtype=np.int32), np.asarray(aa, dtype=np.int32), np.asarray(bb, dtype=np.int32), np.asarray(cc, dtype=np.float64),
+                tape.out_cost, out_rows, len(rows), tape.n_eq, tape.nx, tape.np_)

@@ -160,3 +160,82 @@ def test_literal_solver_subclass_sends_quadratic_classes_to_the_qp_family(hip_li
     assert solver.did_solve() and np.isclose(xy, [1.0, 3.0]).all() and abs(solver.stats()["f"]) < 1e-9
     with pytest.raises(ValueError):
         HIPSolver(FakeOptimization()).setup("hip_sqp", {"family": "qp"})
+
+
+def _band_problem():
+    """A QuadraticCostNonlinearConstraints-shaped object with cs.Function members, written the way example/torque_control_example.py:82-95 is:
+    quadratic tracking cost with a small speed penalty, rows eps - d_i^2 >= 0 on an affine error d = A x - b(p)."""
+    A = np.array([[2e-3, 1e-3, -5e-4, 0.0], [0.0, 1.5e-3, 1e-3, -1e-3], [1e-3, 0.0, 0.0, 2e-3]])
+    eps = np.array([1e-6, 1e-8, 1e-8])
+
+    class QuadraticCostNonlinearConstraints:
+        def __init__(self):
+            x, p = cs.sym(0, 4), cs.sym(1, 3)
+            d = [sum(float(A[i, j]) * x[j] for j in range(4)) - p[i] for i in range(3)]
+            self.f = cs.Function("f", [[(0, 1e3 * (cs.sq(d[0]) + cs.sq(d[1]) + cs.sq(d[2])) + 0.01 * (cs.sq(x[0]) + cs.sq(x[1]) + cs.sq(x[2]) + cs.sq(x[3])))]], [1])
+            self.g = cs.Function("g", [[(0, float(eps[0]) - d[0] * d[0]), (1, float(eps[1]) - cs.sq(d[1])), (2, float(eps[2]) - d[2] * d[2])]], [3])
+            self.k = cs.Function("k", [[(0, 5.0 - x[3])]], [1])
+            self.a = self.h = None
+            self.nx, self.np, self.nk, self.ng, self.na, self.nh = 4, 3, 1, 3, 0, 0
+            self.models = []
+            self.decision_variables = types.SimpleNamespace(vec2dict=lambda v: {"dq": np.asarray(v).reshape(-1)}, dict2vec=lambda d_: cs.DM(d_["dq"]))
+            self.parameters = types.SimpleNamespace(vec2dict=lambda v: {"b": np.asarray(v).reshape(-1)}, dict2vec=lambda d_: cs.DM(d_["b"]))
+
+        def has_discrete_variables(self):
+            return False
+
+    return QuadraticCostNonlinearConstraints(), A, eps
+
+
+def test_band_rows_are_rewritten_on_the_walked_tape():
+    from optas_amd.tape import band_rewrite, tape_degrees
+
+    opt, A, eps = _band_problem()
+    tp = tape_from_optimization(opt, cs)
+    deg = tape_degrees(tp)
+    assert deg[tp.out_cost] == 2 and [int(deg[r]) for r in tp.out_rows] == [1, 2, 2, 2]
+    bt = band_rewrite(tp)
+    assert bt is not None and (bt.n_ineq, bt.n_eq) == (7, 0) and all(tape_degrees(bt)[r] <= 1 for r in bt.out_rows)
+    rng = np.random.default_rng(5)
+    x, p = rng.normal(size=4), rng.normal(size=3) * 1e-3
+    v = tape_ref.forward(bt, x, p)
+    d, half = A @ x - p, np.sqrt(eps)
+    assert abs(v[bt.out_rows[0]] - (5.0 - x[3])) < 1e-15
+    assert np.abs(v[bt.out_rows[1:]] - np.stack([d + half, half - d], 1).reshape(-1)).max() < 1e-15
+    assert abs(v[bt.out_cost] - opt.f(x, p)[0][0]) <= 1e-12 * abs(v[bt.out_cost])
+    assert band_rewrite(tape_from_optimization(FakeOptimization(), cs)) is None  # trigonometric rows: not a QP
+
+
+@pytest.mark.gpu
+def test_literal_solver_subclass_sends_band_rows_to_the_qp_family(hip_lib):
+    """... and the literal Solver subclass solves such a problem in the dense-QP family: the exact minimiser (active-set enumeration of the
+    bands), where the generic family's augmented Lagrangian cannot move rows whose gradients are of order 1e-7."""
+    from oracle.problems import band_qp_exact
+
+    class Solver:
+        def __init__(self, optimization, error_on_fail=False):
+            self.opt, self._error_on_fail = optimization, error_on_fail
+            self.x0, self.p = cs.DM(np.zeros(optimization.nx)), cs.DM(np.zeros(optimization.np))
+
+        def reset_initial_seed(self, x0):
+            self.x0 = self.opt.decision_variables.dict2vec(x0)
+
+        def reset_parameters(self, p):
+            self.p = self.opt.parameters.dict2vec(p)
+
+        def solve(self):
+            return self.opt.decision_variables.vec2dict(self._solve())
+
+    opt, A, eps = _band_problem()
+    HIPSolver = make_solver_class(types.SimpleNamespace(Solver=Solver), cs)
+    solver = HIPSolver(opt).setup("hip_sqp", {"tol": 1e-12})
+    assert solver._family == "qp"
+    b = np.array([2e-3, -1e-3, 1.5e-3])
+    solver.reset_parameters({"b": b})
+    dq = solver.solve()["dq"]
+    assert solver.did_solve()
+    H = 2e3 * A.T @ A + 0.02 * np.eye(4)
+    xs, _, state, _ = band_qp_exact(H, -2e3 * A.T @ b, A, b, np.sqrt(eps))
+    assert sum(1 for s in state if s) >= 1 and xs[3] < 5.0
+    assert np.abs(dq - xs).max() <= 1e-6 * max(1.0, np.abs(xs).max()) and abs(opt.f(dq, b)[0][0] - opt.f(xs, b)[0][0]) <= 1e-8 * opt.f(xs, b)[0][0]
+    assert opt.g(dq, b)[0].min() >= -1e-12

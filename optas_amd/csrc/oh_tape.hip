@@ -345,7 +345,9 @@ hipError_t oh_launch_tape_jit(hipStream_t s, const TapeJit& j, TapeParams T, int
   // the solver's work set in LDS when it fits 48 KB at 64, 32 or 16 instances per block (tools/gpu_tape_sweep.py, the 7-joint IK problem: one
   // instance 5.0 -> 3.4 ms, 2048 14.3 -> 10.9 ms, 32 768 25.8 -> 21.0 ms; OH_TAPE_LDS_MAX = 0 switches it off)
   const char* e = getenv("OH_TAPE_LDS_MAX");
-  const int lds_max = e ? atoi(e) : 32768;  // (above that the two are level: 65 536 instances 30.2 / 33.5 ms, 131 072 47.5 / 44.9 ms global / LDS)
+  // (round 2: level above 32 768 instances -- 65 536: 30.2 / 33.5 ms, 131 072: 47.5 / 44.9 ms global / LDS; with the solver of round 3's end, which
+  // spends 65 evaluations instead of 266 on the median instance, the LDS set wins at every size: 65 536: 9.8 / 7.7 ms, 131 072: 17.5 / 13.2 ms)
+  const int lds_max = e ? atoi(e) : (1 << 30);
   if (j.fn_lds && B <= lds_max) {
     const size_t per = sizeof(double) * tape_solver_rows(T);
     for (int bs : {64, 32, 16})

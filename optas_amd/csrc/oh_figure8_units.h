@@ -239,13 +239,14 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   }
   double Gprev[N];
   // exact curvature: always (OH_HESSIAN_EXACT) or once the accepted point is nearly stationary (OH_HESSIAN_HYBRID)
-  bool exact = (P.hessian == OH_HESSIAN_EXACT) || (P.hessian == OH_HESSIAN_HYBRID && !first && stat_b <= P.hyb_switch);
+  const bool fresh = first_b == 1;  // a seed: nothing is known about the point (first_b == 2: a restart after a compaction, its gradients came along)
+  bool exact = (P.hessian == OH_HESSIAN_EXACT) || (P.hessian == OH_HESSIAN_HYBRID && !fresh && stat_b <= P.hyb_switch);
   if constexpr (GUARD) {
     // the exact block carries no curvature of the sphere rows (-s d2g, s ~ w_path): with them the exact model is worse than
     // Gauss-Newton (the oracle run crawls), so sphere-guarded problems stay on Gauss-Newton
     if (SPH && GPp->n_links > 0) exact = false;
   }
-  const bool have_G = exact && !first;
+  const bool have_G = exact && !fresh;
 #pragma unroll
   for (int k = 0; k < N; ++k) Gprev[k] = 0.0;  // fetched by the hook below, inside the exact-curvature branch
 

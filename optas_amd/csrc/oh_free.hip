@@ -1448,6 +1448,7 @@ __global__ __launch_bounds__(256) void k_guard_scatter(FigParams P, FigBuffers D
     GB.meas_prev[b] = sc[(size_t)3 * Bp + b];
     GB.outer[b] = (int)sc[(size_t)4 * Bp + b];
     GB.n_outer[b] = (int)sc[(size_t)5 * Bp + b];
+    GB.ls_count[b] = 0;  // the restart re-derives the full step: a line search in progress starts over (the counter at this index was another instance's)
   }
 }
 void oh_launch_guard_emit(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int NV, int only_done) {

@@ -406,6 +406,7 @@ __global__ __launch_bounds__(256) void k_compact_gather(FigParams P, FigBuffers 
     ts[(size_t)14 * Bp + nb] = (double)D.iters[b];
     ts[(size_t)15 * Bp + nb] = (double)D.orig[b];
     ts[(size_t)16 * Bp + nb] = D.nun[b];
+    ts[(size_t)17 * Bp + nb] = D.stat[b];
   }
 }
 // ... and lay it down densely; the state machine restarts at "evaluate this point" (first = 1), which
@@ -435,7 +436,12 @@ __global__ __launch_bounds__(256) void k_compact_scatter(FigParams P, FigBuffers
     D.iters[b] = it > 0 ? it - 1 : 0;  // the pending step is recomputed and counted again
     D.orig[b] = (int)ts[(size_t)15 * Bp + b];
     D.cur[b] = 1 - slot;
-    D.first[b] = 1;
+    // 2: a restart, not a seed -- the reduced gradient and the Lagrangian gradient of the point came along, so the evaluation builds the same
+    // (exact, where the hybrid rule has switched) curvature the interrupted iteration had.  With first = 1 it fell back to Gauss-Newton blocks for
+    // that one step: harmless on most instances, but one whose Gauss-Newton iteration crawls (1 of 20 000 velocity-limited T = 100 instances,
+    // tools/gpu_T100_vel_probe2.py) was thrown back above the switch at every one of 23 compactions and sat at the iteration cap.
+    D.stat[b] = ts[(size_t)17 * Bp + b];
+    D.first[b] = 2;
     D.skip[b] = 0;
     D.polish[b] = 0;
     D.stale[b] = 0;

@@ -1107,11 +1107,10 @@ static void fill_params(oh_handle* h) {
   P.max_iter = d.max_iter;
   P.hessian = d.hessian;
   P.hyb_switch = 1e-5 * d.w_path;
-  // orientation-locked handles with limit rows only: the exact blocks take over earlier (3e-5 x w_path).  Their iterations run in the persistent
-  // kernel, where the exact blocks cost little, and end sooner: 16 384 velocity-limited instances 22.0 -> 20.4 steps on average with 99.95 % of
-  // them at the same optimum (8 forks, 4 up, 4 down); at 5e-5: 19.9 steps, 99.77 %; at 1e-4: 19.6 steps, 99.2 % and more of them up than down
-  // (tools/gpu_vel_switch_quality.py).  On the plain family's batched kernels 1e-4 costs a third of the rate (2.96 -> 2.07 M solves/s).
-  if (h->have_guards && d.lock_orientation && h->guards.n_links == 0) P.hyb_switch = 3e-5 * d.w_path;
+  // (The same switch for handles with limit rows.  Switching those earlier was measured and dropped: at 3e-5 x w_path 16 384 velocity-limited
+  // instances take 20.4 instead of 22.0 steps on average with 99.95 % of them at the same optimum, at 1e-4 19.6 steps with 0.8 % forking -- but the
+  // tail of the distribution moves about: of 24 576 instances one sits at the 600-step cap at 3e-5, takes 565 steps at 2e-5 and 166 at 5e-5, where
+  // 1e-5 finishes every instance of every batch measured, 16 384 to 262 144, in at most 508; tools/gpu_vel_switch_quality.py, gpu_vel_24576_probe.py.)
   if (const char* e = getenv("OH_HYB_SWITCH")) P.hyb_switch = atof(e) * d.w_path;  // experiments (tools/sweep_env.sh)
   P.mu0 = d.mu0;
   P.relax = 1.5;

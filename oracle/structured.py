@@ -355,8 +355,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
     if exact:
         hessian = "exact"
     guard = limits is not None or guards is not None or vlimits is not None
-    # handles with limit rows only switch earlier (fill_params in csrc/oh_api.hip)
-    hyb_switch = (3e-5 if (guard and guards is None) else 1e-5) * prob.w_path
+    hyb_switch = 1e-5 * prob.w_path
     stat_prev = np.inf
     tight = True  # FigParams.tol_retract_min below tol_retract: the end-game rules of retract_tol / lm_accept (every handle since the end of round 3)
     vel = vlimits is not None

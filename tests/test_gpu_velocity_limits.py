@@ -159,3 +159,27 @@ def test_batch_of_16384_has_no_stalled_instance_and_matches_its_instances_solved
     solver.backend.close()
     sb.backend.close()
     s0.backend.close()
+
+
+def test_batches_beyond_the_plain_hand_over_start_in_the_persistent_kernel(hip_lib, monkeypatch):
+    """Limit / velocity-limit handles run in k_tail_vel whatever the batch (the batched launches lose against it at every size measured):
+    a batch above the plain family's hand-over threshold launches no batched iteration, converges everywhere, and an instance of it equals the same
+    instance solved alone, bit for bit."""
+    for k in ("OH_TAIL_VEL", "OH_TAIL_VEL_THRESHOLD", "OH_TAIL_THRESHOLD", "OH_COMPACTION"):
+        monkeypatch.delenv(k, raising=False)
+    B = 24576
+    rng = np.random.default_rng(9)
+    qcs = QC0[None] + rng.uniform(-0.1, 0.1, (B, 7))
+    kuka, solver = setup_solver(velocity_limits=True, solver_options={"max_iter": 600, "tol": 1e-6})
+    x0 = np.zeros((B, solver.opt.nx))
+    x0[:, :350] = np.repeat(qcs, 50, axis=0).reshape(B, 350)
+    r = solver.solve_batch_arrays(x0, qcs)
+    tm = solver.backend.timing()
+    assert tm["iterations_launched"] == 0 and tm["tail_iterations"] > 0 and tm["compactions"] == 0, tm
+    assert (r.status == 0).all() and (r.kkt[:, 0] <= 1e-6).all() and (r.kkt[:, 1] <= 1e-9).all(), (np.bincount(r.status, minlength=3), r.iters.max(), r.kkt[:, 0].max(), r.kkt[:, 1].max())
+    vl = np.asarray(kuka.velocity_actuated_joint_limits)
+    dQ = r.x[:, 350:].reshape(B, 49, 7)
+    assert np.all(np.abs(dQ).max(1) <= vl + 1e-8)
+    for b in (0, 12345, B - 1):
+        a = solver.solve_batch_arrays(x0[b : b + 1], qcs[b : b + 1])
+        assert a.status[0] == 0 and a.iters[0] == r.iters[b] and a.f[0] == r.f[b] and np.array_equal(a.x[0], r.x[b])

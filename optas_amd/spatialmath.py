@@ -160,17 +160,23 @@ class Quaternion:
 
         return vertcat(*[horzcat(*[as_expr(v) for v in row]) for row in rows])
 
+    def _numbers(self) -> np.ndarray:
+        if self._sym is not None:
+            raise NotImplementedError("this Quaternion holds expression nodes: only split() and getrotm() are defined for it")
+        return self._q
+
     def getquat(self) -> np.ndarray:
-        return self._q.copy()
+        return self._numbers().copy()
 
     def sumsqr(self) -> float:
-        return float(self._q @ self._q)
+        q = self._numbers()
+        return float(q @ q)
 
     def __mul__(self, other: "Quaternion") -> "Quaternion":
         if not isinstance(other, Quaternion):
             raise AssertionError("unsupported type")
-        x0, y0, z0, w0 = self._q
-        x1, y1, z1, w1 = other._q
+        x0, y0, z0, w0 = self._numbers()
+        x1, y1, z1, w1 = other._numbers()
         return Quaternion(
             x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0,
             -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0,
@@ -180,7 +186,7 @@ class Quaternion:
 
     def inv(self) -> "Quaternion":
         n2 = self.sumsqr()
-        x, y, z, w = self._q
+        x, y, z, w = self._numbers()
         return Quaternion(-x / n2, -y / n2, -z / n2, w / n2)
 
     @staticmethod
@@ -207,7 +213,7 @@ class Quaternion:
         return Quaternion(a[0], a[1], a[2], math.cos(0.5 * theta))
 
     def getrpy(self) -> np.ndarray:
-        x, y, z, w = self._q
+        x, y, z, w = self._numbers()
         roll = math.atan2(2.0 * (w * x + y * z), 1.0 - 2.0 * (x * x + y * y))
         sinp = 2.0 * (w * y - z * x)
         pitch = pi / 2.0 if abs(sinp) >= 1.0 else math.asin(sinp)

@@ -234,3 +234,14 @@ def test_vector_rows_with_per_entry_bounds_and_the_square_node():
     assert np.allclose(np.asarray(qp.M(p)), np.vstack([I, -I, I, -I]), atol=1e-15)
     half = np.array([0.1, 0.2, 0.3])
     assert np.allclose(np.asarray(qp.c(p)).reshape(-1), np.concatenate([-p + half, p + half, -p + 0.5, p + 0.5]), atol=1e-15)
+
+
+def test_symbolic_quaternion_refuses_what_is_not_lowered():
+    b = OptimizationBuilder(1)
+    b.add_decision_variables("x", 1)
+    pg = b.add_parameter("pg", 4)
+    q = Quaternion(pg[0], pg[1], pg[2], pg[3])
+    assert len(q.split()) == 4
+    for call in (q.getquat, q.sumsqr, q.inv, q.getrpy, lambda: q * Quaternion(0.0, 0.0, 0.0, 1.0)):
+        with pytest.raises(NotImplementedError):
+            call()

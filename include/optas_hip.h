@@ -232,13 +232,15 @@ typedef struct oh_torque_desc {
   double w_tau;   /* weight of sum ||tau_t||^2 (> 0: it is what makes the stage Hessian in ddq positive definite) */
   double tau_lo[OH_MAX_CHAIN]; /* effort limits: TaskModel dlim[0] (models.py:79-214), rows "_l" / "_r" of enforce_model_limits */
   double tau_up[OH_MAX_CHAIN];
-  int max_iter;    /* evaluations after the first (Riccati steps + multiplier updates); <= 0: 300 */
-  double tol;      /* |gradient of the rolled-out augmented Lagrangian w.r.t. ddq|_inf; <= 0: 1e-6 */
-  double tol_feas; /* |min(g, lam / rho)|_inf over the effort rows (bounds violation and complementarity at once); <= 0: 1e-9 */
-  double rho0;     /* initial penalty; <= 0: 1 */
+  int max_iter;    /* evaluations after the first; <= 0: 300 */
+  double tol;      /* |gradient of the rolled-out Lagrangian w.r.t. ddq|_inf (multipliers lam = mu_b / s of the inequality rows); <= 0: 1e-6 */
+  double tol_compl; /* complementarity lam_i s_i = mu_b of every inequality row at the returned point (IPOPT's tol plays this part,
+                       solver.py:355-398); <= 0: 1e-8.  The rows themselves hold strictly: the iterates are interior */
+  double mu_barrier0; /* initial barrier parameter; <= 0: 0.1 (IPOPT's mu_init) */
   double mu0;      /* initial Levenberg-Marquardt damping of the state part of the step; < 0: 0 */
-  double dq_lo[OH_MAX_CHAIN]; /* joint-velocity limits on the velocity states: enforce_model_limits(name, time_deriv=1) (builder.py:471-509), rows */
-  double dq_up[OH_MAX_CHAIN]; /* dq_t - dq_lo >= 0, dq_up - dq_t >= 0 at every knot; all zero (a zero-initialised descriptor): no such rows */
+  int vel_limits;  /* != 0: joint-velocity limits on the velocity states: enforce_model_limits(name, time_deriv=1) (builder.py:471-509), rows */
+  double dq_lo[OH_MAX_CHAIN]; /* dq_t - dq_lo >= 0, dq_up - dq_t >= 0 at every knot (dq_lo < dq_up) */
+  double dq_up[OH_MAX_CHAIN];
 } oh_torque_desc;
 
 #define OH_QP_MAX_N 32
@@ -396,6 +398,10 @@ int oh_rnea_device(oh_handle* h, int N, const void* d_q, const void* d_qd, const
 /* Its Jacobian, what the reference gets from casadi.jacobian of the same graph (optimization.py:8-24; the dh of a dynamics row
    h = TAU - rnea(Q, dQ, ddQ)): J [N][ndof][3 ndof] row-major = d tau / d (q, qd, qdd), exact (the recursion run on dual numbers). */
 int oh_rnea_jac(oh_handle* h, int N, const double* q, const double* qd, const double* qdd, double* J);
+/* Its second derivatives contracted with a multiplier vector, what the reference gets as ddh / the Lagrangian Hessian of the dynamics rows by AD of
+   the same graph (optimization.py:8-24, 262-290): H [N][3 ndof][3 ndof] row-major = sum_i c_i d^2 tau_i / d (q, qd, qdd)^2 for c [N][ndof], exact
+   (hand-written adjoint of the recursion, run on dual numbers; the ddq-ddq block is zero: the torques are linear in the accelerations). */
+int oh_rnea_hess(oh_handle* h, int N, const double* q, const double* qd, const double* qdd, const double* c, double* H);
 
 /* Structure-of-arrays variant used inside the solver and for roofline measurement:
    q [ndof][N], pose [7][N], J [6*ndof][N] (unit index fastest => fully coalesced). */

@@ -172,9 +172,10 @@ class oh_torque_desc(C.Structure):
         ("tau_up", C.c_double * OH_MAX_CHAIN),
         ("max_iter", C.c_int),
         ("tol", C.c_double),
-        ("tol_feas", C.c_double),
-        ("rho0", C.c_double),
+        ("tol_compl", C.c_double),
+        ("mu_barrier0", C.c_double),
         ("mu0", C.c_double),
+        ("vel_limits", C.c_int),
         ("dq_lo", C.c_double * OH_MAX_CHAIN),
         ("dq_up", C.c_double * OH_MAX_CHAIN),
     ]
@@ -218,6 +219,7 @@ SYMBOLS = [
     "oh_rnea",
     "oh_rnea_device",
     "oh_rnea_jac",
+    "oh_rnea_hess",
     "oh_fk_jac",
     "oh_fk_jac_device",
     "oh_fk_jac_soa_device",

@@ -236,14 +236,16 @@ class TorqueBackend(_SolveMixin):
     """OH_PROBLEM_TORQUE_MPC handle (BASELINE configs[4]): x = [vec(Q); vec(dQ); vec(ddQ); vec(TAU)], p = [qc; dqc; vec(goal 3 x T)]."""
 
     def __init__(self, chain: _lib.oh_chain, dynamics: _lib.oh_dynamics, T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=None, tau_up=None,
-                 max_iter=300, tol=1e-6, tol_feas=1e-9, rho0=0.0, mu0=0.0, dq_lo=None, dq_up=None):
-        """dq_lo / dq_up: joint-velocity limits on the velocity states (enforce_model_limits(name, time_deriv=1)); None: no such rows."""
+                 max_iter=300, tol=1e-6, tol_compl=1e-8, mu_barrier0=0.0, mu0=0.0, dq_lo=None, dq_up=None):
+        """dq_lo / dq_up: joint-velocity limits on the velocity states (enforce_model_limits(name, time_deriv=1)); None: no such rows.
+        tol: reduced gradient of the Lagrangian; tol_compl: complementarity of the inequality rows (the barrier parameter the interior point ends at)."""
         lib = _lib.load()
         self.ndof, self.T = int(chain.ndof), int(T)
         self.nx, self.np_ = 4 * self.ndof * self.T, 2 * self.ndof + 3 * self.T
         self.vel = dq_lo is not None
         desc = _lib.oh_torque_desc(T=self.T, ndof=self.ndof, dt=float(dt), w_path=float(w_path), w_vel=float(w_vel), w_tau=float(w_tau),
-                                   max_iter=int(max_iter), tol=float(tol), tol_feas=float(tol_feas), rho0=float(rho0), mu0=float(mu0))
+                                   max_iter=int(max_iter), tol=float(tol), tol_compl=float(tol_compl), mu_barrier0=float(mu_barrier0), mu0=float(mu0),
+                                   vel_limits=1 if self.vel else 0)
         lo = np.broadcast_to(np.asarray(-1e9 if tau_lo is None else tau_lo, dtype=np.float64), (self.ndof,))
         up = np.broadcast_to(np.asarray(1e9 if tau_up is None else tau_up, dtype=np.float64), (self.ndof,))
         for i in range(self.ndof):

@@ -567,9 +567,7 @@ extern "C" int oh_create_torque(const oh_torque_desc* desc, oh_handle** out) {
     return fail(OH_ERR_INVALID, "oh_create_torque: dt and w_tau must be positive, w_path and w_vel non-negative");
   for (int i = 0; i < desc->ndof; ++i)
     if (!(desc->tau_lo[i] < desc->tau_up[i])) return fail(OH_ERR_INVALID, "oh_create_torque: tau_lo must be below tau_up");
-  bool vel = false;  // all-zero dq_lo / dq_up (a zero-initialised descriptor): no joint-velocity rows
-  for (int i = 0; i < desc->ndof; ++i) vel = vel || desc->dq_lo[i] != 0.0 || desc->dq_up[i] != 0.0;
-  if (vel)
+  if (desc->vel_limits)
     for (int i = 0; i < desc->ndof; ++i)
       if (!(desc->dq_lo[i] < desc->dq_up[i])) return fail(OH_ERR_INVALID, "oh_create_torque: dq_lo must be below dq_up");
   int nd = 0;
@@ -583,8 +581,8 @@ extern "C" int oh_create_torque(const oh_torque_desc* desc, oh_handle** out) {
   h->tq = *desc;
   if (h->tq.max_iter <= 0) h->tq.max_iter = 300;
   if (!(h->tq.tol > 0.0)) h->tq.tol = 1e-6;
-  if (!(h->tq.tol_feas > 0.0)) h->tq.tol_feas = 1e-9;
-  if (!(h->tq.rho0 > 0.0)) h->tq.rho0 = 1.0;
+  if (!(h->tq.tol_compl > 0.0)) h->tq.tol_compl = 1e-8;
+  if (!(h->tq.mu_barrier0 > 0.0)) h->tq.mu_barrier0 = 0.1;
   if (!(h->tq.mu0 >= 0.0)) h->tq.mu0 = 0.0;
   if (const char* e = getenv("OH_TQ_CHECK")) h->tq_check = atoi(e) > 0 ? atoi(e) : 1;
   hipGetDevice(&h->device);
@@ -610,19 +608,21 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   P = TqParams{};
   P.T = T; P.N = N; P.max_iter = h->tq.max_iter;
   P.dt = h->tq.dt; P.w_path = h->tq.w_path; P.w_vel = h->tq.w_vel; P.w_tau = h->tq.w_tau;
-  P.tol = h->tq.tol; P.tol_feas = h->tq.tol_feas; P.rho0 = h->tq.rho0; P.mu0 = h->tq.mu0;
+  P.tol = h->tq.tol; P.tol_compl = h->tq.tol_compl; P.mu_b0 = h->tq.mu_barrier0; P.mu0 = h->tq.mu0;
+  // interior point: relaxed barrier below theta mu_b; monotone barrier update with IPOPT's constants (Waechter & Biegler 2006, eq. 7); exact
+  // curvature of the Lagrangian once the reduced gradient is below curv_from (oracle/torque_ipm.py:solve_torque_ipm has the same defaults)
+  P.theta = 0.01; P.kappa_eps = 10.0; P.kappa_mu = 0.2; P.theta_mu = 1.5; P.curv_from = 0.1; P.tau_ftb = 0.995; P.max_back = 3;
+  if (const char* e = getenv("OH_TQ_FTB")) P.tau_ftb = atof(e);
+  if (const char* e = getenv("OH_TQ_CURV_FROM")) P.curv_from = atof(e);  // 0: Gauss-Newton blocks throughout (A/B)
+  P.vel = h->tq.vel_limits ? 1 : 0;
   for (int i = 0; i < N; ++i) {
     P.tau_lo[i] = h->tq.tau_lo[i];
     P.tau_up[i] = h->tq.tau_up[i];
     P.dq_lo[i] = h->tq.dq_lo[i];
     P.dq_up[i] = h->tq.dq_up[i];
-    if (P.dq_lo[i] != 0.0 || P.dq_up[i] != 0.0) P.vel = 1;
   }
   P.nx = 4 * N * T;
   P.np = 2 * N + 3 * T;
-  P.aa_m = 3;
-  P.aa_from = 1e-1;
-  if (const char* e = getenv("OH_TQ_AA")) P.aa_m = atoi(e) < 0 ? 0 : (atoi(e) > 3 ? 3 : atoi(e));
   TqBuffers& D = h->TqD;
   if (B > h->tq_cap) {
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -632,7 +632,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     h->d_tq_mult = nullptr;
     h->tq_cap = 0;
     const size_t BT = (size_t)B * T;
-    const size_t nd = 2 * BT * TQ_XS + 2 * BT * TQ_SD + BT * TQ_LAM + BT * TQ_GN + BT * 4 + 4 * BT * TQ_HS + 11 * (size_t)B;
+    const size_t nd = 2 * BT * TQ_XS + 2 * BT * TQ_SD + 2 * BT * TQ_LAM + BT * TQ_GN + BT * 4 + 11 * (size_t)B;
     const size_t bytes = nd * sizeof(double) + (10 * (size_t)B + 16) * sizeof(int);
     HIPCHK(hipMalloc(&h->tq_pool, bytes));
     HIPCHK(hipMalloc((void**)&h->d_tq_mult, sizeof(double) * BT * 4 * N));  // effort rows, and room for the velocity rows
@@ -648,17 +648,16 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     D.dyn = h->d_dyn;
     D.xs = take(2 * BT * TQ_XS);
     D.st = take(2 * BT * TQ_SD);
-    D.lam = take(BT * TQ_LAM);
+    D.lam = take(2 * BT * TQ_LAM);
     D.gains = take(BT * TQ_GN);
     D.goal = take(BT * 4);
-    D.hist = take(4 * BT * TQ_HS);
-    D.f_cur = take(B); D.f_true = take(B); D.pred = take(B); D.mu = take(B); D.nun = take(B); D.rho = take(B); D.rho_next = take(B);
-    D.omega = take(B); D.meas_prev = take(B); D.meas = take(B); D.stat = take(B);
+    D.f_cur = take(B); D.f_true = take(B); D.bsum = take(B); D.mu = take(B); D.nun = take(B); D.mub = take(B); D.stat = take(B);
+    D.alpha = take(B); D.qk = take(B); D.ndx = take(B); D.viol = take(B);
     int* ip = (int*)d;
-    D.cur = ip; ip += B; D.first = ip; ip += B; D.outer = ip; ip += B; D.status = ip; ip += B; D.iters = ip; ip += B; D.rejected = ip; ip += B;
-    D.n_outer = ip; ip += B;
-    D.hcnt = ip; ip += B;
-    D.aa = ip; ip += B;
+    D.cur = ip; ip += B; D.first = ip; ip += B; D.curv = ip; ip += B; D.status = ip; ip += B; D.iters = ip; ip += B; D.rejected = ip; ip += B;
+    D.n_barrier = ip; ip += B;
+    D.nrel = ip; ip += B;
+    D.n_back = ip; ip += B;
     D.list = ip; ip += B;
     D.n_running = ip;
     D.n_list = ip + 1;
@@ -1586,6 +1585,29 @@ extern "C" int oh_rnea_jac(oh_handle* h, int n, const double* q, const double* q
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(J, base + 3 * bq, bj, hipMemcpyDeviceToHost));
+  return OH_OK;
+}
+
+extern "C" int oh_rnea_hess(oh_handle* h, int n, const double* q, const double* qd, const double* qdd, const double* c, double* H) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_rnea_hess: null handle");
+  if (n < 1 || !q || !qd || !qdd || !c || !H) return fail(OH_ERR_INVALID, "oh_rnea_hess: bad arguments");
+  if (!h->have_dyn) return fail(OH_ERR_STATE, "oh_rnea_hess: call oh_set_dynamics first");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t nd = h->dyn_host.ndof;
+  const size_t bq = (sizeof(double) * nd * (size_t)n + 255) / 256 * 256, bh = sizeof(double) * 9 * nd * nd * (size_t)n;
+  int rc = ensure_stage(h, 4 * bq + bh);
+  if (rc) return rc;
+  char* base = (char*)h->stage;
+  HIPCHK(hipMemcpy(base, q, sizeof(double) * nd * (size_t)n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(base + bq, qd, sizeof(double) * nd * (size_t)n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(base + 2 * bq, qdd, sizeof(double) * nd * (size_t)n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(base + 3 * bq, c, sizeof(double) * nd * (size_t)n, hipMemcpyHostToDevice));
+  if (!oh_launch_rnea_hess(h->stream, h->d_dyn, h->dyn_host.n, n, (const double*)base, (const double*)(base + bq), (const double*)(base + 2 * bq),
+                           (const double*)(base + 3 * bq), (double*)(base + 4 * bq)))
+    return fail(OH_ERR_INVALID, "oh_rnea_hess: unsupported number of bodies");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(H, base + 4 * bq, bh, hipMemcpyDeviceToHost));
   return OH_OK;
 }
 

@@ -66,41 +66,48 @@ void oh_launch_pm_advance(hipStream_t s, int B, int T, int advance, const double
 
 // ---- OH_PROBLEM_TORQUE_MPC (BASELINE configs[4]: RNEA dynamics rows) -------------------------------
 // Layouts are unit-contiguous ([instance][knot][...]): the evaluation kernel works with one lane per (instance, knot,
-// tangent direction) and the Riccati kernel with 16 lanes per instance, so a wavefront reads whole stage records.
+// joint) and the Riccati kernel with 16 lanes per instance, so a wavefront reads whole stage records.
 #define TQ_XS 24    // per knot: q (N) at 0, dq (N) at 8, ddq (N) at 16
-#define TQ_SD 272   // per knot stage record: H packed lower (3N)(3N+1)/2 at 0 | g (3N) at 231 | phi 252, phi_true 253, meas 254, viol 255 | tau (N) at 256 | compl 263
+// per knot stage record: H packed lower (3N)(3N+1)/2 at 0 | g_f (3N) at 231: gradient of the cost | f 252, barrier sum B 253, relaxed rows 254, viol 255 |
+// tau (N) at 256 | max lam s 263 | g_b (3N) at 272: gradient of the barrier per unit mu_b (the stage gradient is g_f + mu_b g_b) | d tau / d z (N x 3N
+// row-major) at 296: the step kernel's fraction-to-the-boundary rule needs the linearised rows
+#define TQ_SD 448
+#define TQ_SD_GB 272
+#define TQ_SD_J 296
 #define TQ_LAM 32   // per knot: multipliers of tau - lo >= 0 (N), then of up - tau >= 0 (N); at 16: of dq - dq_lo >= 0 (N), then of dq_up - dq >= 0 (N)
 #define TQ_GN 112   // per knot: gains K (column c of 2N: N values at c N), feed-forward k at 2N N
 struct TqParams {
   int T, N, max_iter;
-  double dt, w_path, w_vel, w_tau, tol, tol_feas, rho0, mu0;
+  double dt, w_path, w_vel, w_tau, tol, tol_compl, mu_b0, mu0;
+  double theta;      // rows below delta = theta mu_b continue the logarithm by its second-order Taylor polynomial (relaxed barrier)
+  double kappa_eps, kappa_mu, theta_mu;  // barrier update (Waechter & Biegler 2006, eq. 7): mu_b <- max(mu_min, min(kappa_mu mu_b, mu_b^theta_mu)) once stat <= kappa_eps mu_b
+  double curv_from;  // exact Lagrangian curvature in the stage blocks once the reduced gradient is below this
+  double tau_ftb;    // fraction to the boundary: a step leaves every slack (and multiplier) at least 1 - tau_ftb of itself
+  int max_back;      // quarterings of a boundary-shortened step before the damping is raised instead
   double tau_lo[OH_MAX_CHAIN], tau_up[OH_MAX_CHAIN];
   double dq_lo[OH_MAX_CHAIN], dq_up[OH_MAX_CHAIN];  // joint-velocity rows on the velocity states (vel != 0)
   int vel;
   int nx, np;
-  int aa_m;         // Anderson acceleration of the Gauss-Newton iteration: history depth (0 off, <= 3), see k_tq_step
-  double aa_from;   // ... once the reduced gradient is below this
 };
-#define TQ_HS 16    // per knot and history entry: control u (N) at 0, Gauss-Newton step du (N) at 8
 struct TqBuffers {
   int B;
   const oh_chain* chain;
   const oh_dynamics* dyn;
   double* xs;      // [2][B][T][TQ_XS]
   double* st;      // [2][B][T][TQ_SD]
-  double* lam;     // [B][T][TQ_LAM]
+  double* lam;     // [2][B][T][TQ_LAM]  (slot = the point they were updated at: a rejected trial leaves the accepted point's multipliers alone)
   double* gains;   // [B][T][TQ_GN]
   double* goal;    // [B][T][4]
-  double *f_cur, *f_true, *pred, *mu, *nun, *rho, *rho_next, *omega, *meas_prev, *meas, *stat;  // [B]
-  int *cur, *first, *outer, *status, *iters, *rejected, *n_outer;                                // [B]
+  // [B]: merit and cost of the accepted point, its barrier sum, Levenberg-Marquardt damping and its growth factor, barrier parameter, reduced gradient,
+  // scale of the feed-forward of the pending trial, q_u^T k and |dx|^2 of the unit step (predicted decrease of a scaled step), violation
+  double *f_cur, *f_true, *bsum, *mu, *nun, *mub, *stat, *alpha, *qk, *ndx, *viol;
+  int *cur, *first, *curv, *status, *iters, *rejected, *n_barrier, *nrel, *n_back;  // [B]
   int* n_running;  // [1]
-  double* hist;    // [B][4][T][TQ_HS] ring of the last accepted control sequences and the steps taken from them (Anderson history)
-  int* hcnt;       // [B] entries appended since the history was last dropped
-  int* aa;         // [B] 1: the pending trial is the extrapolated point
   int* list;       // [B] instances still running when the list was last rebuilt (kernels walk this list: finished instances cost nothing)
   int* n_list;     // [1]
   int n_run;       // length of the list the launches below cover
 };
+bool oh_launch_rnea_hess(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, int n, const double* q, const double* qd, const double* qdd, const double* c, double* H);
 void oh_launch_tq_list(hipStream_t s, const TqBuffers& D);
 bool oh_launch_tq_setup(hipStream_t s, const TqParams& P, const TqBuffers& D, const double* x0, const double* p);
 bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D);

@@ -6,18 +6,21 @@
 //     k = [TAU - lo; up - TAU]                                enforce_model_limits("tau")               (builder.py:471-509)
 //     f = w_path sum ||p_link(q_t) - goal_t||^2 + w_vel sum ||dQ||^2 + w_tau sum ||TAU||^2.
 // Lowering: the linear rows and h are eliminated exactly (TAU_t = rnea(q_t, dq_t, ddq_t); q, dq rolled out from u_t = ddq_t with
-// x_{t+1} = A x_t + B u_t, A = [[I, dt I], [0, I]], B = [0; dt I]), the effort rows enter through the Powell-Hestenes-Rockafellar
-// augmented Lagrangian, and each iteration is a Levenberg-Marquardt step of the Gauss-Newton model from a Riccati sweep over the
-// stages z_t = (q_t, dq_t | u_t).  numpy restatement of this state machine: oracle/torque.py:solve_torque_lm.
+// x_{t+1} = A x_t + B u_t, A = [[I, dt I], [0, I]], B = [0; dt I]).  The inequality rows enter through a primal-dual interior point (round 4; the
+// reference's own algorithm class, solver.py:355-398 -> IPOPT): log barrier with multipliers of their own, relaxed below delta = theta mu_b, barrier
+// parameter lowered by the monotone rule of Waechter & Biegler (2006) without re-evaluation; steps are Levenberg-Marquardt / Newton steps from a Riccati
+// sweep over the stages z_t = (q_t, dq_t | u_t), scaled by the fraction-to-the-boundary rule on the linearised rows.  Near the solution the stage blocks
+// hold the exact Hessian of the Lagrangian (k_tq_curv).  numpy restatement of this state machine: oracle/torque_ipm.py:solve_torque_ipm; the
+// augmented-Lagrangian machine of rounds 1-3 survives as oracle/torque.py:solve_torque_lm, the independent second solver of the same problem.
 //
 // Kernels:
-//   k_tq_eval   one lane per (instance, knot, tangent direction), 3 units x 21 directions per wavefront.  Every lane runs the reference's
-//               Newton-Euler recursion on dual numbers seeded with its direction (d tau / d z_d is the tangent output: the derivative is the
-//               derivative of the literal recursion by construction), the chain walk for p_link and its Jacobian column, then the lanes of a
-//               unit exchange their columns through LDS and write the Gauss-Newton stage block H_t (packed lower 21 x 21) and gradient.
-//   k_tq_step   16 lanes per instance (4 instances per wavefront): ratio test, costate recursion for the stationarity measure,
-//               outer augmented-Lagrangian logic, Riccati sweep with the value matrix P (14 x 14) in LDS and one column per lane,
-//               forward rollout of the trial point.
+//   k_tq_eval3  one lane per (instance, knot, joint), 9 units x 7 joints per wavefront: the reference's Newton-Euler recursion on dual numbers seeded
+//               with q_j, dq_j, ddq_j (the derivative is the derivative of the literal recursion by construction), the chain walk for p_link, then
+//               the lanes of a unit exchange their columns through LDS and write the stage block H_t (packed lower 21 x 21), the gradients of cost
+//               and barrier, and d tau / d z.
+//   k_tq_curv   same mapping: second derivatives of the inverse dynamics and of the link position, added to H_t for instances in the Newton phase.
+//   k_tq_step   16 lanes per instance (4 instances per wavefront): ratio test, costate recursion for the stationarity measure, barrier update,
+//               Riccati sweep with the value matrix P (14 x 14) in LDS and one column per lane, fraction to the boundary, rollout of the trial.
 #include "oh_device.h"
 #include "oh_kernels.h"
 
@@ -86,6 +89,29 @@ OH_DEV Dual3 operator-(const double a, const Dual3 b) { return {a - b.v, -b.d0, 
 OH_DEV Dual3 operator*(const Dual3 a, const double b) { return {a.v * b, a.d0 * b, a.d1 * b, a.d2 * b}; }
 OH_DEV Dual3 operator*(const double a, const Dual3 b) { return {a * b.v, a * b.d0, a * b.d1, a * b.d2}; }
 OH_DEV Dual3 operator-(const Dual3 a) { return {-a.v, -a.d0, -a.d1, -a.d2}; }
+
+// ---- two tangents (round 4): second derivatives of the inverse dynamics ----------------------------------------------------------------------
+// rnea_ctau_grad below is the hand-written adjoint of the recursion; run on (DualR, Dual2) scalars seeded with q_j and dq_j it returns rows q_j and
+// dq_j of  sum_i c_i d^2 tau_i / d(q, dq, ddq)^2  (the torques are linear in ddq, so the rows of ddq_j are the transposed columns of those).
+struct Dual2 {
+  double v, d0, d1;  // d / d q_j, d / d dq_j
+};
+OH_DEV Dual2 operator+(const Dual2 a, const Dual2 b) { return {a.v + b.v, a.d0 + b.d0, a.d1 + b.d1}; }
+OH_DEV Dual2 operator-(const Dual2 a, const Dual2 b) { return {a.v - b.v, a.d0 - b.d0, a.d1 - b.d1}; }
+OH_DEV Dual2 operator*(const Dual2 a, const Dual2 b) { return {a.v * b.v, fma(a.v, b.d0, a.d0 * b.v), fma(a.v, b.d1, a.d1 * b.v)}; }
+OH_DEV Dual2 operator*(const DualR a, const Dual2 b) { return {a.v * b.v, fma(a.v, b.d0, a.d * b.v), a.v * b.d1}; }
+OH_DEV Dual2 operator*(const Dual2 a, const DualR b) { return b * a; }
+OH_DEV Dual2 operator+(const Dual2 a, const DualR b) { return {a.v + b.v, a.d0 + b.d, a.d1}; }
+OH_DEV Dual2 operator+(const DualR a, const Dual2 b) { return b + a; }
+OH_DEV Dual2 operator-(const Dual2 a, const DualR b) { return {a.v - b.v, a.d0 - b.d, a.d1}; }
+OH_DEV Dual2 operator-(const DualR a, const Dual2 b) { return {a.v - b.v, a.d - b.d0, -b.d1}; }
+OH_DEV Dual2 operator+(const Dual2 a, const double b) { return {a.v + b, a.d0, a.d1}; }
+OH_DEV Dual2 operator+(const double a, const Dual2 b) { return {a + b.v, b.d0, b.d1}; }
+OH_DEV Dual2 operator-(const Dual2 a, const double b) { return {a.v - b, a.d0, a.d1}; }
+OH_DEV Dual2 operator-(const double a, const Dual2 b) { return {a - b.v, -b.d0, -b.d1}; }
+OH_DEV Dual2 operator*(const Dual2 a, const double b) { return {a.v * b, a.d0 * b, a.d1 * b}; }
+OH_DEV Dual2 operator*(const double a, const Dual2 b) { return {a * b.v, a * b.d0, a * b.d1}; }
+OH_DEV Dual2 operator-(const Dual2 a) { return {-a.v, -a.d0, -a.d1}; }
 OH_DEV void sincosT(const DualR x, DualR* s, DualR* c) {
   double sv, cv;
   sincos_joint(x.v, &sv, &cv);
@@ -100,6 +126,10 @@ struct RotOf {
 };
 template <>
 struct RotOf<Dual3> {
+  using T = DualR;
+};
+template <>
+struct RotOf<Dual2> {
   using T = DualR;
 };
 
@@ -119,6 +149,11 @@ template <> struct Prom<Dual3, double> { using T = Dual3; };
 template <> struct Prom<double, Dual3> { using T = Dual3; };
 template <> struct Prom<Dual3, DualR> { using T = Dual3; };
 template <> struct Prom<DualR, Dual3> { using T = Dual3; };
+template <> struct Prom<Dual2, Dual2> { using T = Dual2; };
+template <> struct Prom<Dual2, double> { using T = Dual2; };
+template <> struct Prom<double, Dual2> { using T = Dual2; };
+template <> struct Prom<Dual2, DualR> { using T = Dual2; };
+template <> struct Prom<DualR, Dual2> { using T = Dual2; };
 template <class A, class B>
 OH_DEV void crossT(const A* a, const B* b, typename Prom<A, B>::T* o) {
   o[0] = a[1] * b[2] - a[2] * b[1];
@@ -275,6 +310,283 @@ __global__ __launch_bounds__(64) void k_rnea_jac(const oh_dynamics* __restrict__
   for (int i = 0; i < N; ++i) J[((size_t)u * N + i) * NZ + d] = tau[i].d;
 }
 
+
+// ---- gradient of c^T tau (round 4; numpy: oracle/torque.py:rnea_ctau_gradient) ------------------------------------------------------------------
+// Virtual work: c^T rnea(q, qd, qdd) = sum_b f_b . v_b(c) + n_b . w_b(c), the inertial wrench of body b (models.py:1819-1856, the outward pass of the
+// reference) paired with the twist the joint rates c would give it.  Both come out of one outward recursion, so the gradient with respect to
+// (q, qd, qdd) is one inward adjoint recursion: body i hands the adjoints of its (om, omD, vD) and of the virtual (wc, vo) to its parent.  A joint
+// angle enters only through R_i^T = Rot(axis, q_i)^T R0^T, and d(R_i^T v)/dq_i = -axis x (R_i^T v), which is what `sw` collects.
+// Scalars: S for what depends on (q, qd, qdd), SR for what depends on the joint angles alone (rotations, axes, the virtual twists); qdd and c carry
+// no tangent (nothing is differentiated twice with respect to them: tau is linear in qdd, c is a multiplier).
+template <class A, class B>
+OH_DEV typename Prom<A, B>::T dotT(const A* a, const B* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+template <int NB, class S, class SR = typename RotOf<S>::T>
+OH_DEV void rnea_ctau_grad(const oh_dynamics* __restrict__ dy, const SR (&q)[NB - 1], const S (&qd)[NB - 1], const double (&qdd)[NB - 1], const double (&c)[NB - 1],
+                           S (&gq)[NB - 1], S (&gqd)[NB - 1], S (&gqdd)[NB - 1]) {
+  // outward pass: the state every body leaves to its child (lane-private memory, the loops stay rolled as in rnea_lit)
+  S om_[NB][3], omD_[NB][3], vD_[NB][3];
+  SR wc_[NB][3], vo_[NB][3];
+  SR sj[NB], cj[NB];
+  {
+    S om[3], omD[3], vD[3];
+    SR wc[3], vo[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      om[k] = S{};
+      omD[k] = S{};
+      vD[k] = S{} + dy->vd0[k];
+      wc[k] = SR{};
+      vo[k] = SR{};
+    }
+#pragma unroll 1
+    for (int i = 0; i < NB; ++i) {
+      const bool moving = i < NB - 1;
+      S t1[3], t2[3], t3[3], acc[3];
+      SR w[3], tw[3];
+      crossT(omD, dy->xyz[i], t1);
+      crossT(om, dy->xyz[i], t2);
+      crossT(om, t2, t3);
+      crossT(wc, dy->xyz[i], tw);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        acc[k] = vD[k] + t1[k] + t3[k];
+        w[k] = vo[k] + tw[k];
+      }
+      SR Rp[9];
+      if (moving) {
+        sincosT(q[i], &sj[i], &cj[i]);
+        joint_rotation(dy->R0[i], dy->axis[i], sj[i], cj[i], Rp);
+      } else {
+        sj[i] = SR{};
+        cj[i] = SR{};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rp[k] = SR{} + dy->R0[i][k];
+      }
+      S omp[3], omDp[3];
+      SR wcp[3];
+      mTvT(Rp, om, omp);
+      mTvT(Rp, omD, omDp);
+      mTvT(Rp, wc, wcp);
+      if (moving) {
+        SR a[3];
+        mTvT(Rp, dy->axis[i], a);
+        const S qdi = qd[i];
+        S aq[3] = {a[0] * qdi, a[1] * qdi, a[2] * qdi};
+        S cr[3];
+        crossT(omp, aq, cr);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          om[k] = omp[k] + aq[k];
+          omD[k] = omDp[k] + cr[k] + a[k] * qdd[i];
+          wc[k] = wcp[k] + a[k] * c[i];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          om[k] = omp[k];
+          omD[k] = omDp[k];
+          wc[k] = wcp[k];
+        }
+      }
+      S vDi[3];
+      SR voi[3];
+      mTvT(Rp, acc, vDi);
+      mTvT(Rp, w, voi);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        vD[k] = vDi[k];
+        vo[k] = voi[k];
+        om_[i][k] = om[k];
+        omD_[i][k] = omD[k];
+        vD_[i][k] = vD[k];
+        wc_[i][k] = wc[k];
+        vo_[i][k] = vo[k];
+      }
+    }
+  }
+  // inward pass
+  S b_om[3], b_omD[3], b_vD[3], b_wc[3], b_vo[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) b_om[k] = b_omD[k] = b_vD[k] = b_wc[k] = b_vo[k] = S{};
+#pragma unroll 1
+  for (int i = NB - 1; i >= 0; --i) {
+    const bool moving = i < NB - 1;
+    // what the parent left (the base: at rest, accelerating against gravity)
+    S om_p[3], omD_p[3], vD_p[3];
+    SR wc_p[3], vo_p[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (i > 0) {
+        om_p[k] = om_[i - 1][k];
+        omD_p[k] = omD_[i - 1][k];
+        vD_p[k] = vD_[i - 1][k];
+        wc_p[k] = wc_[i - 1][k];
+        vo_p[k] = vo_[i - 1][k];
+      } else {
+        om_p[k] = S{};
+        omD_p[k] = S{};
+        vD_p[k] = S{} + dy->vd0[k];
+        wc_p[k] = SR{};
+        vo_p[k] = SR{};
+      }
+    }
+    SR Rp[9];
+    if (moving) {
+      joint_rotation(dy->R0[i], dy->axis[i], sj[i], cj[i], Rp);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rp[k] = SR{} + dy->R0[i][k];
+    }
+    const double* cm = dy->com[i];
+    const double* r = dy->xyz[i];
+    const double m = dy->mass[i];
+    S omi[3], omDi[3], vDi[3];
+    SR wci[3], voi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      omi[k] = om_[i][k];
+      omDi[k] = omD_[i][k];
+      vDi[k] = vD_[i][k];
+      wci[k] = wc_[i][k];
+      voi[k] = vo_[i][k];
+    }
+    // local term f_i . vc_i + n_i . wc_i
+    {
+      S t1[3], t2[3], t3[3], fi[3], Io[3], IoD[3], ni[3];
+      crossT(omDi, cm, t1);
+      crossT(omi, cm, t2);
+      crossT(omi, t2, t3);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fi[k] = m * (vDi[k] + t1[k] + t3[k]);
+      mvT(dy->inertia[i], omi, Io);
+      mvT(dy->inertia[i], omDi, IoD);
+      crossT(omi, Io, t1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ni[k] = IoD[k] + t1[k];
+      SR tw[3], vci[3];
+      crossT(wci, cm, tw);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vci[k] = voi[k] + tw[k];
+      S cf[3];
+      crossT(cm, fi, cf);
+      SR cv[3], Itw[3];
+      crossT(cm, vci, cv);
+      mTvT(dy->inertia[i], wci, Itw);
+      const S oc = dotT(omi, cm), ov = dotT(omi, vci);
+      const SR cvv = dotT(cm, vci);
+      S wxo[3], Itwo[3], Ixw[3];
+      crossT(wci, omi, wxo);
+      mTvT(dy->inertia[i], wxo, Itwo);
+      crossT(Io, wci, Ixw);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        b_vo[k] = b_vo[k] + fi[k];
+        b_wc[k] = b_wc[k] + cf[k] + ni[k];
+        b_vD[k] = b_vD[k] + m * vci[k];
+        b_omD[k] = b_omD[k] + m * cv[k] + Itw[k];
+        b_om[k] = b_om[k] + m * (vci[k] * oc + cm[k] * ov - 2.0 * (omi[k] * cvv)) + Itwo[k] + Ixw[k];
+      }
+    }
+    // through the step of body i
+    S b_omp[3];
+    if (moving) {
+      SR a[3];
+      S omp[3], omDp[3];
+      SR wcp[3];
+      mTvT(Rp, dy->axis[i], a);
+      mTvT(Rp, om_p, omp);
+      mTvT(Rp, omD_p, omDp);
+      mTvT(Rp, wc_p, wcp);
+      const S qdi = qd[i];
+      S aq[3] = {a[0] * qdi, a[1] * qdi, a[2] * qdi};
+      S x1[3], x2[3], b_aq[3], b_a[3];
+      crossT(aq, b_omD, x1);
+      crossT(b_omD, omp, x2);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        b_omp[k] = b_om[k] + x1[k];
+        b_aq[k] = b_om[k] + x2[k];
+        b_a[k] = b_aq[k] * qdi + b_omD[k] * qdd[i] + b_wc[k] * c[i];
+      }
+      gqd[i] = dotT(b_aq, a);
+      gqdd[i] = dotT(b_omD, a);
+      S s1[3], s2[3], s3[3], s4[3], s5[3], s6[3];
+      crossT(omp, b_omp, s1);
+      crossT(omDp, b_omD, s2);
+      crossT(wcp, b_wc, s3);
+      crossT(a, b_a, s4);
+      crossT(vDi, b_vD, s5);
+      crossT(voi, b_vo, s6);
+      S sw[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sw[k] = s1[k] + s2[k] + s3[k] + s4[k] + s5[k] + s6[k];
+      gq[i] = -dotT(sw, dy->axis[i]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) b_omp[k] = b_om[k];
+    }
+    if (i > 0) {
+      S b_acc[3], b_w[3], Ro[3], RoD[3], Rw[3], x1[3], x2[3];
+      mvT(Rp, b_vD, b_acc);
+      mvT(Rp, b_vo, b_w);
+      mvT(Rp, b_omp, Ro);
+      mvT(Rp, b_omD, RoD);
+      mvT(Rp, b_wc, Rw);
+      crossT(r, b_acc, x1);
+      crossT(r, b_w, x2);
+      const S opr = dotT(om_p, r), opb = dotT(om_p, b_acc), rb = dotT(r, b_acc);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        b_om[k] = Ro[k] + b_acc[k] * opr + r[k] * opb - 2.0 * (om_p[k] * rb);
+        b_omD[k] = RoD[k] + x1[k];
+        b_vD[k] = b_acc[k];
+        b_wc[k] = Rw[k] + x2[k];
+        b_vo[k] = b_w[k];
+      }
+    }
+  }
+}
+
+// sum_i c_i d^2 tau_i / d (q, qd, qdd)^2 (what the reference obtains as ddh by AD of the CasADi graph, optimization.py:8-24): one lane per
+// (sample, joint); q, qd, qdd, c [n][N] -> H [n][3 N][3 N] row-major.  Lane j writes rows j and N + j and, by symmetry, column j of the ddq rows.
+template <int N>
+__global__ __launch_bounds__(64) void k_rnea_hess(const oh_dynamics* __restrict__ dy, const int n, const double* __restrict__ q, const double* __restrict__ qd,
+                                                  const double* __restrict__ qdd, const double* __restrict__ c, double* __restrict__ H) {
+  constexpr int NZ = 3 * N, UPW = 64 / N;
+  const int lane = threadIdx.x;
+  const int ul = lane / N, j = lane - ul * N;
+  const long long u = (long long)blockIdx.x * UPW + ul;
+  if (ul >= UPW || u >= n) return;
+  DualR a[N];
+  Dual2 b[N], gq[N], gqd[N], gqdd[N];
+  double cc[N], uu[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double one = (k == j) ? 1.0 : 0.0;
+    a[k] = {q[u * N + k], one};
+    b[k] = {qd[u * N + k], 0.0, one};
+    uu[k] = qdd[u * N + k];
+    cc[k] = c[u * N + k];
+  }
+  rnea_ctau_grad<N + 1, Dual2>(dy, a, b, uu, cc, gq, gqd, gqdd);
+  double* Hu = H + (size_t)u * NZ * NZ;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    Hu[j * NZ + k] = gq[k].d0;
+    Hu[j * NZ + N + k] = gqd[k].d0;
+    Hu[j * NZ + 2 * N + k] = gqdd[k].d0;
+    Hu[(N + j) * NZ + k] = gq[k].d1;
+    Hu[(N + j) * NZ + N + k] = gqd[k].d1;
+    Hu[(N + j) * NZ + 2 * N + k] = 0.0;
+    Hu[(2 * N + k) * NZ + j] = gqdd[k].d0;
+    Hu[(2 * N + k) * NZ + N + j] = 0.0;
+    Hu[(2 * N + k) * NZ + 2 * N + j] = 0.0;
+  }
+}
+
 OH_DEV size_t xs_off(const TqBuffers& D, const int T, const int slot, const int b, const int t) { return (((size_t)slot * D.B + b) * T + t) * TQ_XS; }
 OH_DEV size_t st_off(const TqBuffers& D, const int T, const int slot, const int b, const int t) { return (((size_t)slot * D.B + b) * T + t) * TQ_SD; }
 
@@ -315,30 +627,27 @@ __global__ __launch_bounds__(64) void k_tq_setup(TqParams P, TqBuffers D, const 
     gl[1] = pb[2 * N + 3 * t + 1];
     gl[2] = pb[2 * N + 3 * t + 2];
     gl[3] = 0.0;
-    double* lm = D.lam + ((size_t)b * T + t) * TQ_LAM;
-#pragma unroll
-    for (int j = 0; j < TQ_LAM; ++j) lm[j] = 0.0;
   }
   D.f_cur[b] = 0.0;
   D.f_true[b] = 0.0;
-  D.pred[b] = 0.0;
+  D.bsum[b] = 0.0;
   D.mu[b] = P.mu0;
-  D.nun[b] = 2.0;
-  D.rho[b] = P.rho0;
-  D.rho_next[b] = P.rho0;
-  D.omega[b] = fmax(P.tol, 1e-2);
-  D.meas_prev[b] = 1e300;
-  D.hcnt[b] = 0;
-  D.aa[b] = 0;
-  D.meas[b] = 0.0;
+  D.nun[b] = 4.0;
+  D.mub[b] = P.mu_b0;
   D.stat[b] = 0.0;
+  D.alpha[b] = 1.0;
+  D.qk[b] = 0.0;
+  D.ndx[b] = 0.0;
+  D.viol[b] = 0.0;
   D.cur[b] = 1;  // the seed sits in slot 0 = the first "trial"
   D.first[b] = 1;
-  D.outer[b] = 0;
+  D.curv[b] = 0;
   D.status[b] = -1;
   D.iters[b] = 0;
   D.rejected[b] = 0;
-  D.n_outer[b] = 0;
+  D.n_barrier[b] = 0;
+  D.nrel[b] = 0;
+  D.n_back[b] = 0;
   D.list[b] = b;
 }
 
@@ -349,204 +658,44 @@ __global__ __launch_bounds__(256) void k_tq_list(TqBuffers D) {
 }
 
 // ---- evaluation -----------------------------------------------------------------------------------------------------------------------
-#ifndef OH_TQ_EVAL_WAVES
-#define OH_TQ_EVAL_WAVES 2
-#endif
-// Joint-velocity rows on the velocity states (oh_torque_desc.dq_lo / dq_up; enforce_model_limits(name, time_deriv=1), builder.py:471-509), round 3:
-// stage-local rows of the state, through the same augmented Lagrangian and outer loop as the effort rows.  Every lane of a unit runs this
-// (cheap, and all of them need psi / meas); `writer` stores the refreshed multipliers at an outer update.  cv[j] joins the gradient component
-// of dq_j, dv[j] its diagonal entry of the Gauss-Newton block.
-template <int N>
-OH_DEV void tq_velocity_rows(const TqParams& P, double* __restrict__ lm, const double (&dqv)[N], const double rho, const double rho_old, const bool outer,
-                             const bool writer, double& psi, double& meas, double& viol, double& cmpl, double (&cv)[N], double (&dv)[N]) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const double g_lo = dqv[i] - P.dq_lo[i], g_up = P.dq_up[i] - dqv[i];
-    double l_lo = lm[16 + i], l_up = lm[16 + N + i];
-    if (outer) {
-      l_lo = fmax(0.0, l_lo - rho_old * g_lo);
-      l_up = fmax(0.0, l_up - rho_old * g_up);
+// One inequality row s >= 0 under the relaxed log barrier (numpy: oracle/torque_ipm.py:evalp).  In: the slack at the trial point, slack and
+// multiplier at the accepted point (none at the seed).  Out: the new multiplier (linearised complementarity  s dlam + lam ds = mu_b - lam s  with
+// the slack change the step really produced, kept above 0.5 % of the old one), bco = -psi'(s) / mu_b, sig = the row's weight in the stage block,
+// and the row's barrier value per unit mu_b.  Below delta = theta mu_b the logarithm is continued by its second-order Taylor polynomial.
+struct TqRow {
+  double lam, bco, sig, bar;
+  bool relaxed;
+};
+OH_DEV TqRow tq_row(const double s, const double s_old, const double lam_old, const bool have_old, const double mub, const double delta, const double lam_floor) {
+  TqRow r;
+  r.relaxed = s < delta;
+  const double sc = r.relaxed ? delta : s;
+  if (r.relaxed) {
+    r.bco = (2.0 * delta - s) / (delta * delta);
+    r.lam = mub * r.bco;
+    r.sig = mub / (delta * delta);
+    const double e = (s - delta) / delta;
+    r.bar = -log(delta) - e + 0.5 * e * e;
+  } else {
+    double lam = mub / sc;
+    if (have_old) {
+      lam = (mub - lam_old * (s - s_old)) / fmax(s_old, delta);
+      lam = fmax(lam, lam_floor * lam_old);
+      lam = fmin(fmax(lam, mub / (1e10 * sc)), 1e10 * mub / sc);
     }
-    const double s_lo = fmax(0.0, l_lo - rho * g_lo), s_up = fmax(0.0, l_up - rho * g_up);
-    psi += (s_lo * s_lo - l_lo * l_lo) / (2.0 * rho) + (s_up * s_up - l_up * l_up) / (2.0 * rho);
-    meas = fmax(meas, fmax(fabs(fmin(g_lo, l_lo / rho)), fabs(fmin(g_up, l_up / rho))));
-    viol = fmax(viol, fmax(-g_lo, -g_up));
-    cmpl = fmax(cmpl, fmax(fabs(s_lo * g_lo), fabs(s_up * g_up)));
-    cv[i] = s_up - s_lo;
-    dv[i] = rho * ((s_lo > 0.0 ? 1.0 : 0.0) + (s_up > 0.0 ? 1.0 : 0.0));
-    if (outer && writer) {
-      lm[16 + i] = l_lo;
-      lm[16 + N + i] = l_up;
-    }
+    r.lam = lam;
+    r.bco = 1.0 / sc;
+    r.sig = lam / sc;
+    r.bar = -log(sc);
   }
+  return r;
 }
 
-template <int N, bool VEL = false>
-__global__ __launch_bounds__(64, OH_TQ_EVAL_WAVES) void k_tq_eval(TqParams P, TqBuffers D) {
-  constexpr int NZ = 3 * N;  // 21 tangent directions: q, dq, ddq
-  constexpr int UPW = 64 / NZ;  // units per wavefront (3)
-  __shared__ double tile[UPW][N + 3][NZ + 1];
-  const int T = P.T;
-  const int lane = threadIdx.x;
-  if (blockIdx.x == 0 && lane == 0) *D.n_running = 0;  // k_tq_step, next in the stream, counts the instances that go on
-  int ul = lane / NZ, d = lane - ul * NZ;
-  if (ul >= UPW) {  // lane 63 has no unit: it rides along and parks its LDS writes in the padding column
-    ul = UPW - 1;
-    d = NZ;
-  }
-  const long long n_units = (long long)D.n_run * T;
-  long long unit = (long long)blockIdx.x * UPW + ul;
-  bool active = d < NZ && unit < n_units;
-  if (unit >= n_units) unit = n_units - 1;
-  const int li = (int)(unit / T), t = (int)(unit - (long long)li * T);
-  const int b = D.list[li];
-  if (D.status[b] >= 0) active = false;
-  if (!__any(active)) return;  // one wavefront per block: every instance of this wavefront has finished since the list was built
-  const int ts = 1 - D.cur[b];
-  const double* xr = D.xs + xs_off(D, T, ts, b, t);
-  const bool outer = D.outer[b] != 0;
-  const double rho_old = D.rho[b];
-  const double rho = outer ? D.rho_next[b] : rho_old;
-
-  // inverse dynamics on dual numbers seeded with direction d
-  Dual q[N], qd[N], qdd[N], tau[N];
-  double qv[N], dqv[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    qv[j] = xr[j];
-    dqv[j] = xr[8 + j];
-    q[j] = {qv[j], d == j ? 1.0 : 0.0};
-    qd[j] = {dqv[j], d == N + j ? 1.0 : 0.0};
-    qdd[j] = {xr[16 + j], d == 2 * N + j ? 1.0 : 0.0};
-  }
-  rnea_lit<N + 1, Dual>(D.dyn, q, qd, qdd, tau);
-
-  // effort rows through the augmented Lagrangian: psi(g, lam, rho) = (max(0, lam - rho g)^2 - lam^2) / (2 rho)
-  double* lm = D.lam + ((size_t)b * T + t) * TQ_LAM;
-  double cw[N], dw[N];
-  double psi = 0.0, meas = 0.0, viol = 0.0, cmpl = 0.0, tau2 = 0.0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const double tv = tau[i].v;
-    const double g_lo = tv - P.tau_lo[i], g_up = P.tau_up[i] - tv;
-    double l_lo = lm[i], l_up = lm[N + i];
-    if (outer) {
-      l_lo = fmax(0.0, l_lo - rho_old * g_lo);
-      l_up = fmax(0.0, l_up - rho_old * g_up);
-      if (active && d == 0) {
-        lm[i] = l_lo;
-        lm[N + i] = l_up;
-      }
-    }
-    const double s_lo = fmax(0.0, l_lo - rho * g_lo), s_up = fmax(0.0, l_up - rho * g_up);
-    psi += (s_lo * s_lo - l_lo * l_lo) / (2.0 * rho) + (s_up * s_up - l_up * l_up) / (2.0 * rho);
-    meas = fmax(meas, fmax(fabs(fmin(g_lo, l_lo / rho)), fabs(fmin(g_up, l_up / rho))));
-    viol = fmax(viol, fmax(-g_lo, -g_up));
-    cmpl = fmax(cmpl, fmax(fabs(s_lo * g_lo), fabs(s_up * g_up)));
-    cw[i] = 2.0 * P.w_tau * tv - s_lo + s_up;
-    dw[i] = 2.0 * P.w_tau + rho * ((s_lo > 0.0 ? 1.0 : 0.0) + (s_up > 0.0 ? 1.0 : 0.0));
-    tau2 += tv * tv;
-  }
-  double cv[N], dv[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) cv[i] = dv[i] = 0.0;
-  if constexpr (VEL) tq_velocity_rows<N>(P, lm, dqv, rho, rho_old, outer, active && d == 0, psi, meas, viol, cmpl, cv, dv);
-
-  // link position and column d of its Jacobian (models.py:826-868, 1211-1264)
-  double R[9], pp[3], z[N][3], pj[N][3];
-  fk_chain<N>(D.chain, qv, R, pp, z, pj);
-  double e[3], tv3[3];
-  mv3(R, D.chain->p_tool, tv3);
-  const double* gl = D.goal + ((size_t)b * T + t) * 4;
-  double r[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    e[k] = pp[k] + tv3[k];
-    r[k] = e[k] - gl[k];
-  }
-  double zd[3] = {0.0, 0.0, 0.0}, pd[3] = {0.0, 0.0, 0.0};
-  int jt_d = 0;
-#pragma unroll
-  for (int k = 0; k < N; ++k)
-    if (k == d) {
-      zd[0] = z[k][0]; zd[1] = z[k][1]; zd[2] = z[k][2];
-      pd[0] = pj[k][0]; pd[1] = pj[k][1]; pd[2] = pj[k][2];
-      jt_d = D.chain->jtype[k];
-    }
-  double jp[3] = {0.0, 0.0, 0.0};
-  if (d < N) {
-    if (jt_d == 0) {
-      const double dd[3] = {e[0] - pd[0], e[1] - pd[1], e[2] - pd[2]};
-      cross3(zd, dd, jp);
-    } else {
-      jp[0] = zd[0]; jp[1] = zd[1]; jp[2] = zd[2];
-    }
-  }
-
-  // gradient component d of the stage cost
-  double gd = 0.0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) gd = fma(cw[i], tau[i].d, gd);
-  gd += 2.0 * P.w_path * dot3(jp, r);
-  double dqd = 0.0, cvd = 0.0, dvd = 0.0;
-#pragma unroll
-  for (int j = 0; j < N; ++j)
-    if (d == N + j) {
-      dqd = dqv[j];
-      cvd = cv[j];
-      dvd = dv[j];
-    }
-  gd += 2.0 * P.w_vel * dqd;
-  gd += cvd;  // (its own statement: the sum above keeps the rounding it had before the velocity rows existed)
-
-  // exchange the columns through LDS and form column d of the Gauss-Newton block (rows d..NZ-1)
-#pragma unroll
-  for (int i = 0; i < N; ++i) tile[ul][i][d] = tau[i].d;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) tile[ul][N + k][d] = jp[k];
-  __syncthreads();
-  double* sr = D.st + st_off(D, T, ts, b, t);
-  if (active) {
-    for (int rr = d; rr < NZ; ++rr) {
-      double hv = 0.0;
-#pragma unroll
-      for (int i = 0; i < N; ++i) hv = fma(dw[i] * tile[ul][i][rr], tau[i].d, hv);
-      double hp = 0.0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) hp = fma(tile[ul][N + k][rr], jp[k], hp);
-      hv = fma(2.0 * P.w_path, hp, hv);
-      if (rr == d && d >= N && d < 2 * N) {
-        hv += 2.0 * P.w_vel;
-        hv += dvd;
-      }
-      sr[rr * (rr + 1) / 2 + d] = hv;
-    }
-    sr[231 + d] = gd;
-    if (d == 0) {
-      double dq2 = 0.0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) dq2 = fma(dqv[j], dqv[j], dq2);
-      const double phi_true = P.w_path * dot3(r, r) + P.w_vel * dq2 + P.w_tau * tau2;
-      sr[252] = phi_true + psi;
-      sr[253] = phi_true;
-      sr[254] = meas;
-      sr[255] = viol;
-      sr[263] = cmpl;
-    }
-    if (d < N) {
-      double tvd = 0.0;
-#pragma unroll
-      for (int i = 0; i < N; ++i)
-        if (i == d) tvd = tau[i].v;
-      sr[256 + d] = tvd;
-    }
-  }
-}
-
-// The same evaluation with one lane per (instance, knot, JOINT): 9 units x 7 joints per wavefront.  Lane j runs the recursion once on
-// (DualR, Dual3) scalars seeded with q_j, dq_j and ddq_j, so it ends up with columns j, N + j and 2 N + j of d tau / d z; the link position
-// adds column j of its Jacobian.  The columns meet in LDS as before and every lane writes ITS THREE columns of the packed stage block.
-// Same arithmetic per entry as k_tq_eval (sums over the 7 torque rows in the same order), so the two agree to rounding; bound: f64 FMA.
+// One lane per (instance, knot, JOINT): 9 units x 7 joints per wavefront.  Lane j runs the reference's Newton-Euler recursion once on (DualR, Dual3)
+// scalars seeded with q_j, dq_j and ddq_j (d tau / d z is the tangent output: the derivative of the literal recursion by construction), so it ends up
+// with columns j, N + j and 2 N + j of d tau / d z; the chain walk for p_link adds column j of its Jacobian.  The columns meet in LDS and every lane
+// writes ITS THREE columns of the packed stage block  J^T diag(2 w_tau + Sigma) J + 2 w_p Jp^T Jp + ...,  of the two gradients (cost, barrier per unit
+// mu_b) and of d tau / d z itself.  Bound: f64 FMA issue (268 registers, one wavefront per SIMD).
 #ifndef OH_TQ_EVAL3_WAVES
 #define OH_TQ_EVAL3_WAVES 1
 #endif
@@ -572,11 +721,10 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
   const int b = D.list[li];
   if (D.status[b] >= 0) active = false;
   if (!__any(active)) return;
-  const int ts = 1 - D.cur[b];
+  const int cur = D.cur[b], ts = 1 - cur;
   const double* xr = D.xs + xs_off(D, T, ts, b, t);
-  const bool outer = D.outer[b] != 0;
-  const double rho_old = D.rho[b];
-  const double rho = outer ? D.rho_next[b] : rho_old;
+  const bool have_old = D.first[b] == 0;
+  const double mub = D.mub[b], delta = P.theta * mub;
 
   DualR q[N];
   Dual3 qd[N], qdd[N], tau[N];
@@ -592,36 +740,56 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
   }
   rnea_lit<N + 1, Dual3>(D.dyn, q, qd, qdd, tau);
 
-  // effort rows through the augmented Lagrangian (every lane of the unit computes them: they are cheap and everyone needs cw, dw)
-  double* lm = D.lam + ((size_t)b * T + t) * TQ_LAM;
-  double cw[N], dw[N];
-  double psi = 0.0, meas = 0.0, viol = 0.0, cmpl = 0.0, tau2 = 0.0;
+  // effort rows under the barrier (every lane of the unit computes them: they are cheap and everyone needs cf, cb, dw)
+  const double* lm_old = D.lam + (((size_t)cur * D.B + b) * T + t) * TQ_LAM;
+  double* lm_new = D.lam + (((size_t)ts * D.B + b) * T + t) * TQ_LAM;
+  const double* sr_old = D.st + st_off(D, T, cur, b, t);
+  const double* xr_old = D.xs + xs_off(D, T, cur, b, t);
+  double cf[N], cb[N], dw[N];
+  double bar = 0.0, viol = 0.0, cmpl = 0.0, tau2 = 0.0;
+  int nrel = 0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const double tv = tau[i].v;
-    const double g_lo = tv - P.tau_lo[i], g_up = P.tau_up[i] - tv;
-    double l_lo = lm[i], l_up = lm[N + i];
-    if (outer) {
-      l_lo = fmax(0.0, l_lo - rho_old * g_lo);
-      l_up = fmax(0.0, l_up - rho_old * g_up);
-    }
-    const double s_lo = fmax(0.0, l_lo - rho * g_lo), s_up = fmax(0.0, l_up - rho * g_up);
-    psi += (s_lo * s_lo - l_lo * l_lo) / (2.0 * rho) + (s_up * s_up - l_up * l_up) / (2.0 * rho);
-    meas = fmax(meas, fmax(fabs(fmin(g_lo, l_lo / rho)), fabs(fmin(g_up, l_up / rho))));
-    viol = fmax(viol, fmax(-g_lo, -g_up));
-    cmpl = fmax(cmpl, fmax(fabs(s_lo * g_lo), fabs(s_up * g_up)));
-    cw[i] = 2.0 * P.w_tau * tv - s_lo + s_up;
-    dw[i] = 2.0 * P.w_tau + rho * ((s_lo > 0.0 ? 1.0 : 0.0) + (s_up > 0.0 ? 1.0 : 0.0));
+    const double tv_old = have_old ? sr_old[256 + i] : 0.0;
+    const TqRow lo = tq_row(tv - P.tau_lo[i], tv_old - P.tau_lo[i], have_old ? lm_old[i] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
+    const TqRow up = tq_row(P.tau_up[i] - tv, P.tau_up[i] - tv_old, have_old ? lm_old[N + i] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
+    bar += lo.bar + up.bar;
+    nrel += (lo.relaxed ? 1 : 0) + (up.relaxed ? 1 : 0);
+    viol = fmax(viol, fmax(P.tau_lo[i] - tv, tv - P.tau_up[i]));
+    cmpl = fmax(cmpl, fmax(lo.lam * (tv - P.tau_lo[i]), up.lam * (P.tau_up[i] - tv)));
+    cf[i] = 2.0 * P.w_tau * tv;
+    cb[i] = up.bco - lo.bco;
+    dw[i] = 2.0 * P.w_tau + lo.sig + up.sig;
     tau2 += tv * tv;
-    if (outer && active && j == 0) {  // (after every lane of the wavefront has read the old values: lanes run in lock step, the reads above precede this store)
-      lm[i] = l_lo;
-      lm[N + i] = l_up;
+    if (active && j == 0) {
+      lm_new[i] = lo.lam;
+      lm_new[N + i] = up.lam;
     }
   }
-  double cv[N], dv[N];
+  // joint-velocity rows on the velocity states (enforce_model_limits(name, time_deriv=1), builder.py:471-509): stage-local, linear in the state
+  double cbv = 0.0, dvj = 0.0;
+  if constexpr (VEL) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) cv[i] = dv[i] = 0.0;
-  if constexpr (VEL) tq_velocity_rows<N>(P, lm, dqv, rho, rho_old, outer, active && j == 0, psi, meas, viol, cmpl, cv, dv);
+    for (int i = 0; i < N; ++i) {
+      const double dv = dqv[i];
+      const double dv_old = have_old ? xr_old[8 + i] : 0.0;
+      const TqRow lo = tq_row(dv - P.dq_lo[i], dv_old - P.dq_lo[i], have_old ? lm_old[16 + i] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
+      const TqRow up = tq_row(P.dq_up[i] - dv, P.dq_up[i] - dv_old, have_old ? lm_old[16 + N + i] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
+      bar += lo.bar + up.bar;
+      nrel += (lo.relaxed ? 1 : 0) + (up.relaxed ? 1 : 0);
+      viol = fmax(viol, fmax(P.dq_lo[i] - dv, dv - P.dq_up[i]));
+      cmpl = fmax(cmpl, fmax(lo.lam * (dv - P.dq_lo[i]), up.lam * (P.dq_up[i] - dv)));
+      if (i == j) {
+        cbv = up.bco - lo.bco;
+        dvj = lo.sig + up.sig;
+      }
+      if (active && j == 0) {
+        lm_new[16 + i] = lo.lam;
+        lm_new[16 + N + i] = up.lam;
+      }
+    }
+  }
 
   // link position and column j of its Jacobian (models.py:826-868, 1211-1264)
   double R[9], pp[3], z[N][3], pj[N][3];
@@ -652,25 +820,24 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
     jp[0] = zd[0]; jp[1] = zd[1]; jp[2] = zd[2];
   }
 
-  // gradient components j, N + j, 2 N + j of the stage cost
-  double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+  // components j, N + j, 2 N + j of the gradient of the cost and of the barrier (per unit mu_b)
+  double g0 = 0.0, g1 = 0.0, g2 = 0.0, h0 = 0.0, h1 = 0.0, h2 = 0.0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    g0 = fma(cw[i], tau[i].d0, g0);
-    g1 = fma(cw[i], tau[i].d1, g1);
-    g2 = fma(cw[i], tau[i].d2, g2);
+    g0 = fma(cf[i], tau[i].d0, g0);
+    g1 = fma(cf[i], tau[i].d1, g1);
+    g2 = fma(cf[i], tau[i].d2, g2);
+    h0 = fma(cb[i], tau[i].d0, h0);
+    h1 = fma(cb[i], tau[i].d1, h1);
+    h2 = fma(cb[i], tau[i].d2, h2);
   }
   g0 += 2.0 * P.w_path * dot3(jp, r);
-  double dqj = 0.0, cvj = 0.0, dvj = 0.0;
+  double dqj = 0.0;
 #pragma unroll
   for (int k = 0; k < N; ++k)
-    if (k == j) {
-      dqj = dqv[k];
-      cvj = cv[k];
-      dvj = dv[k];
-    }
+    if (k == j) dqj = dqv[k];
   g1 += 2.0 * P.w_vel * dqj;
-  g1 += cvj;
+  h1 += cbv;
 
   // exchange the columns through LDS; the link position has no dq / ddq columns
   if (lane_ok) {
@@ -712,18 +879,22 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
         }
         sr[rr * (rr + 1) / 2 + d] = hv;
       }
+#pragma unroll
+      for (int i = 0; i < N; ++i) sr[TQ_SD_J + i * NZ + d] = col[i];
     }
     sr[231 + j] = g0;
     sr[231 + N + j] = g1;
     sr[231 + 2 * N + j] = g2;
+    sr[TQ_SD_GB + j] = h0;
+    sr[TQ_SD_GB + N + j] = h1;
+    sr[TQ_SD_GB + 2 * N + j] = h2;
     if (j == 0) {
       double dq2 = 0.0;
 #pragma unroll
       for (int k = 0; k < N; ++k) dq2 = fma(dqv[k], dqv[k], dq2);
-      const double phi_true = P.w_path * dot3(r, r) + P.w_vel * dq2 + P.w_tau * tau2;
-      sr[252] = phi_true + psi;
-      sr[253] = phi_true;
-      sr[254] = meas;
+      sr[252] = P.w_path * dot3(r, r) + P.w_vel * dq2 + P.w_tau * tau2;
+      sr[253] = bar;
+      sr[254] = (double)nrel;
       sr[255] = viol;
       sr[263] = cmpl;
     }
@@ -732,6 +903,87 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
     for (int i = 0; i < N; ++i)
       if (i == j) tvd = tau[i].v;
     sr[256 + j] = tvd;
+  }
+}
+
+// Exact curvature of the Lagrangian for the instances the step kernel has switched to Newton steps (D.curv): adds
+//     sum_i cH_i d^2 tau_i / dz^2,  cH = 2 w_tau tau - lam_lo + lam_up   (the multiplier of the dynamics row TAU_i - rnea_i = 0 at a stationary point)
+//   + 2 w_p sum_k r_k d^2 p_k / dq^2,  d^2 p / dq_a dq_b = z_b x (z_a x (e - o_a)) for b <= a
+// to the stage block k_tq_eval3 has just written.  One lane per (instance, knot, joint) again: lane j runs the hand-written adjoint of the recursion on
+// (DualR, Dual2) scalars seeded with q_j and dq_j, which yields rows q_j and dq_j of the first term; every packed entry is owned by exactly one lane.
+template <int N>
+__global__ __launch_bounds__(64, 1) void k_tq_curv(TqParams P, TqBuffers D) {
+  constexpr int UPW = 64 / N;
+  const int T = P.T;
+  const int lane = threadIdx.x;
+  int ul = lane / N, j = lane - ul * N;
+  const bool lane_ok = ul < UPW;
+  if (!lane_ok) {
+    ul = UPW - 1;
+    j = N - 1;
+  }
+  const long long n_units = (long long)D.n_run * T;
+  long long unit = (long long)blockIdx.x * UPW + ul;
+  bool active = lane_ok && unit < n_units;
+  if (unit >= n_units) unit = n_units - 1;
+  const int li = (int)(unit / T), t = (int)(unit - (long long)li * T);
+  const int b = D.list[li];
+  if (D.status[b] >= 0 || D.curv[b] == 0) active = false;
+  if (!__any(active)) return;
+  const int ts = 1 - D.cur[b];
+  const double* xr = D.xs + xs_off(D, T, ts, b, t);
+  double* sr = D.st + st_off(D, T, ts, b, t);
+  const double* lm = D.lam + (((size_t)ts * D.B + b) * T + t) * TQ_LAM;
+  DualR q[N];
+  Dual2 qd[N], gq[N], gqd[N], gqdd[N];
+  double qv[N], uu[N], cH[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double one = (k == j) ? 1.0 : 0.0;
+    qv[k] = xr[k];
+    q[k] = {qv[k], one};
+    qd[k] = {xr[8 + k], 0.0, one};
+    uu[k] = xr[16 + k];
+    cH[k] = 2.0 * P.w_tau * sr[256 + k] - lm[k] + lm[N + k];
+  }
+  rnea_ctau_grad<N + 1, Dual2>(D.dyn, q, qd, uu, cH, gq, gqd, gqdd);
+  // curvature of the tracking term
+  double R[9], pp[3], z[N][3], pj[N][3];
+  fk_chain<N>(D.chain, qv, R, pp, z, pj);
+  double e[3], tv3[3], r[3];
+  mv3(R, D.chain->p_tool, tv3);
+  const double* gl = D.goal + ((size_t)b * T + t) * 4;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    e[k] = pp[k] + tv3[k];
+    r[k] = e[k] - gl[k];
+  }
+  double inner[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (k == j) {
+      if (D.chain->jtype[k] == 0) {
+        const double dd[3] = {e[0] - pj[k][0], e[1] - pj[k][1], e[2] - pj[k][2]};
+        cross3(z[k], dd, inner);
+      } else {
+        inner[0] = z[k][0]; inner[1] = z[k][1]; inner[2] = z[k][2];
+      }
+    }
+  if (!active) return;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k <= j) {  // rows q_j and dq_j, columns up to the diagonal
+      double kc = 0.0;
+      if (D.chain->jtype[k] == 0) {
+        double x[3];
+        cross3(z[k], inner, x);
+        kc = dot3(r, x);
+      }
+      sr[j * (j + 1) / 2 + k] += gq[k].d0 + 2.0 * P.w_path * kc;
+      sr[(N + j) * (N + j + 1) / 2 + N + k] += gqd[k].d1;
+    }
+    sr[(N + j) * (N + j + 1) / 2 + k] += gq[k].d1;             // (dq_j, q_k)
+    sr[(2 * N + k) * (2 * N + k + 1) / 2 + j] += gqdd[k].d0;   // (ddq_k, q_j)
   }
 }
 
@@ -746,17 +998,33 @@ OH_DEV double group_max(double v) {
   for (int m = 8; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 16));
   return v;
 }
+OH_DEV double group_min(double v) {
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 16));
+  return v;
+}
 
+// 16 lanes per instance (4 instances per wavefront); numpy: oracle/torque_ipm.py:solve_torque_ipm.
+//   1. merit of the trial  f + mu_b B  and the ratio test against the decrease the damped model predicted for the scaled step; Levenberg-Marquardt update
+//   2. reduced gradient of the accepted point by the costate recursion, for the barrier parameter in force and for the next one
+//   3. convergence / barrier update (the stage gradient is  g_f + mu_b g_b,  the merit  f + mu_b B:  a new mu_b needs no re-evaluation)
+//   4. Riccati sweep with the value matrix P (14 x 14) in LDS, one column per lane; a stage block of the exact Hessian that leaves Q_uu indefinite
+//      raises the damping and the sweep is repeated
+//   5. closed-loop rollout of the unit step: the control steps go to LDS, the linearised rows give the fraction to the boundary alpha
+//   6. open-loop rollout of  u + alpha du  on the trial values themselves (the Euler rows hold to the rounding of one operation)
+// A trial that left the domain of the arithmetic is retried with a tenth of the feed-forward: steps 5-6 only.
 #ifndef OH_TQ_STEP_WAVES
 #define OH_TQ_STEP_WAVES 1
 #endif
-template <int N>
+template <int N, bool VEL = false>
 __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, TqBuffers D) {
   constexpr int NX = 2 * N, NZ = 3 * N, NH = NZ * (NZ + 1) / 2, NU = N * (N + 1) / 2;
   constexpr int PS = NX + 1;  // row stride of P in LDS
   constexpr int OFF_P = 256, OFF_PV = OFF_P + NX * PS, OFF_QUX = OFF_PV + 16, OFF_DX = OFF_QUX + N * 16, OFF_DU = OFF_DX + 16, LDS_N = OFF_DU + 8;
   static_assert(NH + NZ <= 256, "stage block does not fit the LDS window");
   __shared__ double sm[4][LDS_N];
+  extern __shared__ double du_dyn[];  // [4][T][8]: the control steps of the unit step
+  double (*du_all)[8] = reinterpret_cast<double (*)[8]>(du_dyn) + (size_t)(threadIdx.x >> 4) * P.T;
   const int T = P.T;
   const int gi = threadIdx.x >> 4, c = threadIdx.x & 15;
   const int b_raw = blockIdx.x * 4 + gi;
@@ -771,410 +1039,385 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
   double* dus = S + OFF_DU;
   const double dt = P.dt;
 
-  bool run = valid && D.status[b] < 0;
+  const bool run = valid && D.status[b] < 0;
   if (!__any(run)) return;
   int cur = D.cur[b];
   const int ts = 1 - cur;
-  // merit of the trial point
-  double fsum = 0.0, ftrue = 0.0, meas_t = 0.0;
+  // 1. merit of the trial point
+  double fsum = 0.0, bsum_t = 0.0, nrel_t = 0.0, viol_t = 0.0;
   for (int t = c; t < T; t += 16) {
     const double* sr = D.st + st_off(D, T, ts, b, t);
     fsum += sr[252];
-    ftrue += sr[253];
-    meas_t = fmax(meas_t, sr[254]);
+    bsum_t += sr[253];
+    nrel_t += sr[254];
+    viol_t = fmax(viol_t, sr[255]);
   }
   fsum = group_sum(fsum);
-  ftrue = group_sum(ftrue);
-  meas_t = group_max(meas_t);
+  bsum_t = group_sum(bsum_t);
+  nrel_t = group_sum(nrel_t);
+  viol_t = group_max(viol_t);
 
-  const bool first = D.first[b] != 0, outer = D.outer[b] != 0;
-  double f_cur = D.f_cur[b], mu = D.mu[b], nun = D.nun[b], rho = D.rho[b], omega = D.omega[b], meas_prev = D.meas_prev[b];
-  double meas_cur = D.meas[b], f_true = D.f_true[b];
-  const double rho_next_in = D.rho_next[b];
-  const double pred = D.pred[b];
-  int iters = D.iters[b], rejected = D.rejected[b], n_outer = D.n_outer[b];
-  // Anderson acceleration (oracle/torque.py:solve_torque_lm, anderson_mix): the tracking residual does not vanish, Gauss-Newton converges
-  // linearly (rate ~0.8), and its steps are the residuals of a fixed-point iteration.  Once the reduced gradient is below aa_from every
-  // other trial is the point the last aa_m + 1 (control sequence, step) pairs extrapolate to; it is accepted if it lowers the merit at
-  // all, otherwise the history is dropped and the Levenberg-Marquardt step follows.
-  int hcnt = D.hcnt[b];
-  const bool aa_trial = D.aa[b] != 0;
-  bool aa_was = false;
-  bool accept;
-  if (first || outer) {
+  const bool first = D.first[b] != 0;
+  double f_cur = D.f_cur[b], f_true = D.f_true[b], bsum = D.bsum[b], mu = D.mu[b], nun = D.nun[b], mub = D.mub[b], alpha = D.alpha[b], viol = D.viol[b];
+  double qk = D.qk[b], ndx = D.ndx[b];
+  int iters = D.iters[b], rejected = D.rejected[b], n_barrier = D.n_barrier[b], nrel = D.nrel[b], n_back = D.n_back[b];
+  const double f_t = fsum + mub * bsum_t;
+  bool accept, new_gains = true;
+  if (first) {
     accept = true;
-    if (outer) {
-      rho = rho_next_in;
-      n_outer += 1;
-      hcnt = 0;  // the merit function changes
-    }
-  } else if (aa_trial) {
-    accept = isfinite(fsum) && fsum < f_cur;
-    aa_was = true;
-    if (!accept) {
-      hcnt = 0;
-      rejected += 1;
-    }
+  } else if (!isfinite(f_t)) {
+    accept = false;
+    new_gains = false;
+    alpha *= 0.1;
+    rejected += 1;
   } else {
-    const double ratio = (f_cur - fsum) / fmax(pred, 1e-300);
-    accept = isfinite(fsum) && (ratio > 1e-4 || (pred <= 1e-15 * fabs(f_cur) && fsum <= f_cur + 1e-14 * fabs(f_cur)));
+    const double pred = (alpha - 0.5 * alpha * alpha) * qk + 0.5 * alpha * alpha * mu * ndx;
+    const double ratio = (f_cur - f_t) / fmax(pred, 1e-300);
+    accept = ratio > 1e-4 || (pred <= 1e-15 * fabs(f_cur) && f_t <= f_cur + 1e-14 * fabs(f_cur));
     if (accept) {
       const double w = 2.0 * ratio - 1.0;
-      mu *= fmax(1.0 / 3.0, 1.0 - w * w * w);
+      mu *= ratio > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - w * w * w);
       if (mu < 1e-7) mu = 0.0;
-      nun = 2.0;
+      nun = 4.0;
+    } else if (alpha < 1.0 && n_back < P.max_back) {
+      // a step the boundary rule had shortened already: the rows near their bounds are to blame (the logarithm is far from its quadratic model
+      // there), not the model of the states -- a quarter of the feed-forward, same gains, same damping
+      new_gains = false;
+      alpha *= 0.25;
+      n_back += 1;
+      rejected += 1;
     } else {
-      mu = fmax(mu * nun, 1e-3);
+      mu = fmax(mu * nun, 0.1);
       nun *= 2.0;
       rejected += 1;
     }
   }
+  if (accept || new_gains) n_back = 0;
   if (accept) {
     cur = ts;
-    f_cur = fsum;
-    f_true = ftrue;
-    meas_cur = meas_t;
+    f_cur = f_t;
+    f_true = fsum;
+    bsum = bsum_t;
+    nrel = (int)nrel_t;
+    viol = viol_t;
   }
   const int nts = 1 - cur;  // slot of the next trial
 
-  // stationarity of the accepted point: gradient of the rolled-out objective w.r.t. u_t by the costate recursion
-  // (the serial loops of this kernel walk the T knots in dependent chains: whatever a knot needs from memory is requested one knot
-  // ahead, otherwise every knot costs a memory round trip -- at small batches the kernel IS those round trips: 230-350 us per launch)
-  double lamc = 0.0, stat = 0.0;
-  double gx_n, gu_n;
+  // 2. reduced gradient of the accepted point: gradient of the rolled-out merit w.r.t. u_t by the costate recursion, for mu_b and for its successor
+  // (the serial loops of this kernel walk the T knots in dependent chains: whatever a knot needs from memory is requested one knot ahead)
+  const double mu_min = 0.1 * P.tol_compl;
+  const double mub_next = fmax(mu_min, fmin(P.kappa_mu * mub, pow(mub, P.theta_mu)));
+  double stat = 0.0, stat_next = 0.0;
   {
-    const double* sr = D.st + st_off(D, T, cur, b, T - 1);
-    gx_n = c < NX ? sr[231 + c] : 0.0;
-    gu_n = (c >= N && c < NX) ? sr[231 + NX + (c - N)] : 0.0;
-  }
-  for (int t = T - 1; t >= 0; --t) {
-    const double gx = gx_n, gu = gu_n;
-    if (t > 0) {
-      const double* sr = D.st + st_off(D, T, cur, b, t - 1);
-      gx_n = c < NX ? sr[231 + c] : 0.0;
-      gu_n = (c >= N && c < NX) ? sr[231 + NX + (c - N)] : 0.0;
+    double lf = 0.0, lb = 0.0;
+    double gxf_n, gxb_n, guf_n, gub_n;
+    auto fetch = [&](const int t) {
+      const double* sr = D.st + st_off(D, T, cur, b, t);
+      gxf_n = c < NX ? sr[231 + c] : 0.0;
+      gxb_n = c < NX ? sr[TQ_SD_GB + c] : 0.0;
+      guf_n = (c >= N && c < NX) ? sr[231 + NX + (c - N)] : 0.0;
+      gub_n = (c >= N && c < NX) ? sr[TQ_SD_GB + NX + (c - N)] : 0.0;
+    };
+    fetch(T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+      const double gxf = gxf_n, gxb = gxb_n, guf = guf_n, gub = gub_n;
+      if (t > 0) fetch(t - 1);
+      if (c >= N && c < NX) {
+        const double rf = fma(dt, lf, guf), rb = fma(dt, lb, gub);
+        stat = fmax(stat, fabs(fma(mub, rb, rf)));
+        stat_next = fmax(stat_next, fabs(fma(mub_next, rb, rf)));
+      }
+      const double lqf = __shfl(lf, c >= N ? c - N : c, 16), lqb = __shfl(lb, c >= N ? c - N : c, 16);
+      lf = c < N ? gxf + lf : gxf + fma(dt, lqf, lf);
+      lb = c < N ? gxb + lb : gxb + fma(dt, lqb, lb);
     }
-    if (c >= N && c < NX) stat = fmax(stat, fabs(fma(dt, lamc, gu)));
-    const double lq = __shfl(lamc, c >= N ? c - N : c, 16);
-    lamc = c < N ? gx + lamc : gx + fma(dt, lq, lamc);
+    stat = group_max(stat);
+    stat_next = group_max(stat_next);
+    if (!(stat == stat)) stat = 1e300;
+    if (!(stat_next == stat_next)) stat_next = 1e300;
   }
-  stat = group_max(stat);
-  if (!(stat == stat)) stat = 1e300;
 
-  // outer logic (oracle/torque.py:solve_torque_lm)
+  // 3. convergence, barrier update
   int status = -1;
-  bool do_outer = false, do_step = false;
-  double rho_next = rho;
+  bool do_gains = false, do_roll = false;
+  int curv = D.curv[b];
   if (!isfinite(f_cur)) {
     status = OH_STATUS_NUMERICAL;
-  } else if (stat <= omega) {
-    if (stat <= P.tol && meas_cur <= P.tol_feas) status = OH_STATUS_CONVERGED;
-    else if (iters >= P.max_iter) status = OH_STATUS_MAX_ITER;
-    else {
-      rho_next = meas_cur > 0.25 * meas_prev ? fmin(rho * 10.0, 1e8) : rho;
-      meas_prev = meas_cur;
-      omega = fmax(P.tol, fmin(omega, 0.1 * meas_cur));
-      do_outer = true;
-      iters += 1;
-    }
+  } else if (stat <= P.tol && mub <= P.tol_compl && nrel == 0) {
+    status = OH_STATUS_CONVERGED;
   } else if (iters >= P.max_iter) {
     status = OH_STATUS_MAX_ITER;
   } else {
-    do_step = true;
     iters += 1;
+    do_roll = true;
+    if (new_gains) {
+      do_gains = true;
+      if (accept && stat <= P.kappa_eps * mub && nrel == 0 && mub > mu_min) {
+        mub = mub_next;
+        f_cur = f_true + mub * bsum;
+        stat = stat_next;
+        n_barrier += 1;
+      }
+      curv = stat <= P.curv_from ? 1 : 0;
+    }
   }
-  if (!run) { do_outer = do_step = false; }
+  if (!run) { do_gains = do_roll = false; }
 
-  // Riccati sweep: lane c < NX owns column c of P / Qxx / Qux; every lane factorises Quu (N x N) for itself
-  double qk = 0.0;
-  bool chol_ok = true;
-  if (c < NX) {
-#pragma unroll
-    for (int r = 0; r < NX; ++r) Ps[r * PS + c] = 0.0;
-    pv[c] = 0.0;
-  }
-  __syncthreads();
+  // 4. Riccati sweep: lane c < NX owns column c of P / Qxx / Qux; every lane factorises Quu (N x N) for itself
   constexpr int NREC = (NH + NZ + 15) / 16;  // values of a stage record per lane
-  double hn[NREC];
-  if (do_step) {
-    const double* sr = D.st + st_off(D, T, cur, b, T - 1);
+  bool need = do_gains;
+  for (int attempt = 0; attempt < 12; ++attempt) {
+    bool chol_ok = true;
+    qk = need ? 0.0 : qk;
+    if (c < NX) {
 #pragma unroll
-    for (int k = 0; k < NREC; ++k) hn[k] = (c + 16 * k < NH + NZ) ? sr[c + 16 * k] : 0.0;
-  }
-  for (int t = T - 1; t >= 0; --t) {
-    if (do_step) {
-#pragma unroll
-      for (int k = 0; k < NREC; ++k)
-        if (c + 16 * k < NH + NZ) Hs[c + 16 * k] = hn[k];
-      if (t > 0) {
-        const double* sr = D.st + st_off(D, T, cur, b, t - 1);
-#pragma unroll
-        for (int k = 0; k < NREC; ++k) hn[k] = (c + 16 * k < NH + NZ) ? sr[c + 16 * k] : 0.0;
-      }
+      for (int r = 0; r < NX; ++r) Ps[r * PS + c] = 0.0;
+      pv[c] = 0.0;
     }
     __syncthreads();
-    double qxx[NX], qux[N], kc[N], Quu[NU], rd[N], kk[N], qu[N];
-    double qx = 0.0;
-    if (do_step) {
-      const int cc = c < NX ? c : 0;
+    double hn[NREC];
+    auto fetch_rec = [&](const int t) {
+      const double* sr = D.st + st_off(D, T, cur, b, t);
 #pragma unroll
-      for (int r = 0; r < NX; ++r) {
-        const int hi = r > cc ? r : cc, lo = r > cc ? cc : r;
-        double v = Hs[hi * (hi + 1) / 2 + lo] + (r == cc ? mu : 0.0);
-        // (A^T P A)[r][cc]
-        double a = Ps[r * PS + cc];
-        if (r >= N) a = fma(dt, Ps[(r - N) * PS + cc], a);
-        if (cc >= N) {
-          a = fma(dt, Ps[r * PS + cc - N], a);
-          if (r >= N) a = fma(dt * dt, Ps[(r - N) * PS + cc - N], a);
+      for (int k = 0; k < NREC; ++k) {
+        const int idx = c + 16 * k;
+        double v = idx < NH + NZ ? sr[idx] : 0.0;
+        if (idx >= NH && idx < NH + NZ) v = fma(mub, sr[TQ_SD_GB + idx - NH], v);  // the stage gradient g_f + mu_b g_b
+        hn[k] = v;
+      }
+    };
+    if (need) fetch_rec(T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+      if (need) {
+#pragma unroll
+        for (int k = 0; k < NREC; ++k)
+          if (c + 16 * k < NH + NZ) Hs[c + 16 * k] = hn[k];
+        if (t > 0) fetch_rec(t - 1);
+      }
+      __syncthreads();
+      double qxx[NX], qux[N], kc[N], Quu[NU], rd[N], kk[N], qu[N];
+      double qx = 0.0;
+      if (need) {
+        const int cc = c < NX ? c : 0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+          const int hi = r > cc ? r : cc, lo = r > cc ? cc : r;
+          double v = Hs[hi * (hi + 1) / 2 + lo] + (r == cc ? mu : 0.0);
+          // (A^T P A)[r][cc]
+          double a = Ps[r * PS + cc];
+          if (r >= N) a = fma(dt, Ps[(r - N) * PS + cc], a);
+          if (cc >= N) {
+            a = fma(dt, Ps[r * PS + cc - N], a);
+            if (r >= N) a = fma(dt * dt, Ps[(r - N) * PS + cc - N], a);
+          }
+          qxx[r] = v + a;
         }
-        qxx[r] = v + a;
-      }
 #pragma unroll
-      for (int k = 0; k < N; ++k) {
-        double a = dt * Ps[(N + k) * PS + cc];
-        if (cc >= N) a = fma(dt * dt, Ps[(N + k) * PS + cc - N], a);
-        qux[k] = Hs[(NX + k) * (NX + k + 1) / 2 + cc] + a;
-        qu[k] = Hs[NH + NX + k] + dt * pv[N + k];
+        for (int k = 0; k < N; ++k) {
+          double a = dt * Ps[(N + k) * PS + cc];
+          if (cc >= N) a = fma(dt * dt, Ps[(N + k) * PS + cc - N], a);
+          qux[k] = Hs[(NX + k) * (NX + k + 1) / 2 + cc] + a;
+          qu[k] = Hs[NH + NX + k] + dt * pv[N + k];
 #pragma unroll
-        for (int l = 0; l <= k; ++l) Quu[tri(k, l)] = Hs[(NX + k) * (NX + k + 1) / 2 + NX + l] + dt * dt * Ps[(N + k) * PS + N + l];
-      }
-      qx = Hs[NH + cc] + pv[cc] + (cc >= N ? dt * pv[cc - N] : 0.0);
-      if (!chol_rcp<N>(Quu, rd, 0.0)) chol_ok = false;
+          for (int l = 0; l <= k; ++l) Quu[tri(k, l)] = Hs[(NX + k) * (NX + k + 1) / 2 + NX + l] + dt * dt * Ps[(N + k) * PS + N + l];
+        }
+        qx = Hs[NH + cc] + pv[cc] + (cc >= N ? dt * pv[cc - N] : 0.0);
+        if (!chol_rcp<N>(Quu, rd, 0.0)) chol_ok = false;
 #pragma unroll
-      for (int k = 0; k < N; ++k) {
-        kc[k] = qux[k];
-        kk[k] = qu[k];
-      }
-      fsub_rcp<N>(Quu, rd, kc);
-      bsub_rcp<N>(Quu, rd, kc);
-      fsub_rcp<N>(Quu, rd, kk);
-      bsub_rcp<N>(Quu, rd, kk);
+        for (int k = 0; k < N; ++k) {
+          kc[k] = qux[k];
+          kk[k] = qu[k];
+        }
+        fsub_rcp<N>(Quu, rd, kc);
+        bsub_rcp<N>(Quu, rd, kc);
+        fsub_rcp<N>(Quu, rd, kk);
+        bsub_rcp<N>(Quu, rd, kk);
 #pragma unroll
-      for (int k = 0; k < N; ++k) qk = fma(qu[k], kk[k], qk);
-      if (c < NX) {
+        for (int k = 0; k < N; ++k) qk = fma(qu[k], kk[k], qk);
+        if (c < NX) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) Quxs[k * 16 + c] = qux[k];
-      }
-    }
-    __syncthreads();  // every lane has read the old P
-    if (do_step && c < NX) {
-      double* gn = D.gains + ((size_t)b * T + t) * TQ_GN;
-#pragma unroll
-      for (int k = 0; k < N; ++k) gn[c * N + k] = kc[k];
-      if (c == 0) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) gn[NX * N + k] = kk[k];
-      }
-      // P <- Qxx - Qux^T K, lower part of the column mirrored so that P stays exactly symmetric
-#pragma unroll
-      for (int r = 0; r < NX; ++r) {
-        if (r >= c) {
-          double v = qxx[r];
-#pragma unroll
-          for (int k = 0; k < N; ++k) v = fma(-Quxs[k * 16 + r], kc[k], v);
-          Ps[r * PS + c] = v;
-          Ps[c * PS + r] = v;
+          for (int k = 0; k < N; ++k) Quxs[k * 16 + c] = qux[k];
         }
       }
-      double v = qx;
+      __syncthreads();  // every lane has read the old P
+      if (need && c < NX) {
+        double* gn = D.gains + ((size_t)b * T + t) * TQ_GN;
 #pragma unroll
-      for (int k = 0; k < N; ++k) v = fma(-qux[k], kk[k], v);
-      pv[c] = v;
+        for (int k = 0; k < N; ++k) gn[c * N + k] = kc[k];
+        if (c == 0) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) gn[NX * N + k] = kk[k];
+        }
+        // P <- Qxx - Qux^T K, lower part of the column mirrored so that P stays exactly symmetric
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+          if (r >= c) {
+            double v = qxx[r];
+#pragma unroll
+            for (int k = 0; k < N; ++k) v = fma(-Quxs[k * 16 + r], kc[k], v);
+            Ps[r * PS + c] = v;
+            Ps[c * PS + r] = v;
+          }
+        }
+        double v = qx;
+#pragma unroll
+        for (int k = 0; k < N; ++k) v = fma(-qux[k], kk[k], v);
+        pv[c] = v;
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    const bool failed = need && !(chol_ok && isfinite(qk));
+    need = failed;
+    if (failed) {  // an indefinite stage block of the exact Hessian: more damping, same point
+      mu = fmax(mu * nun, 0.1);
+      nun *= 2.0;
+    }
+    if (!__syncthreads_or(need ? 1 : 0)) break;
   }
-  if (do_step && !chol_ok) {
+  if (need) {
     status = OH_STATUS_NUMERICAL;
-    do_step = false;
+    do_roll = false;
   }
 
-  // forward rollout of the next trial point (or the copy of the accepted point for an outer update)
-  double ndx = 0.0, ndu = 0.0;
-  const bool use_hist = do_step && P.aa_m > 0 && stat < P.aa_from;
+  // 5. closed-loop rollout of the unit step (du to LDS), fraction to the boundary on the linearised rows
+  const double delta = P.theta * mub;
   {
-    const bool fw = do_step || do_outer;
-    double xt = 0.0;  // lane c < NX: component c of the trial state
-    {
-      const double* x0r = D.xs + xs_off(D, T, cur, b, 0);
-      if (c < NX) xt = x0r[c < N ? c : 8 + (c - N)];
-    }
-    // state, control and gains of the next knot are in flight while this one is rolled out
-    double xcur_n = 0.0, ucur_n = 0.0, gk_n[NX + 1];
+    double dx = 0.0;  // lane c < NX: component c of the state step
+    double a_ftb = 1.0, ndx_acc = 0.0;
+    double gk_n[NX + 1], jr_n[NZ], s_lo_n = 0.0, s_up_n = 0.0, v_lo_n = 0.0, v_up_n = 0.0;
     auto fetch_knot = [&](const int t) {
-      const double* xc = D.xs + xs_off(D, T, cur, b, t);
-      xcur_n = c < NX ? xc[c < N ? c : 8 + (c - N)] : 0.0;
       if (c < N) {
-        ucur_n = xc[16 + c];
-        if (do_step) {
-          const double* gn = D.gains + ((size_t)b * T + t) * TQ_GN;
+        const double* gn = D.gains + ((size_t)b * T + t) * TQ_GN;
 #pragma unroll
-          for (int j = 0; j < NX; ++j) gk_n[j] = gn[j * N + c];
-          gk_n[NX] = gn[NX * N + c];
+        for (int j = 0; j < NX; ++j) gk_n[j] = gn[j * N + c];
+        gk_n[NX] = gn[NX * N + c];
+        const double* sr = D.st + st_off(D, T, cur, b, t);
+#pragma unroll
+        for (int d = 0; d < NZ; ++d) jr_n[d] = sr[TQ_SD_J + c * NZ + d];
+        const double tv = sr[256 + c];
+        s_lo_n = tv - P.tau_lo[c];
+        s_up_n = P.tau_up[c] - tv;
+        if constexpr (VEL) {
+          const double dv = D.xs[xs_off(D, T, cur, b, t) + 8 + c];
+          v_lo_n = dv - P.dq_lo[c];
+          v_up_n = P.dq_up[c] - dv;
         }
       }
     };
-    fetch_knot(0);
-    for (int t = 0; t < T; ++t) {  // every group runs the loop (uniform barriers); only groups with fw touch memory
-      double* xn = D.xs + xs_off(D, T, nts, b, t);
-      const double xcur = xcur_n, ucur = ucur_n;
-      double gk[NX + 1];
+    if (do_roll) fetch_knot(0);
+    for (int t = 0; t < T; ++t) {  // every group runs the loop (uniform barriers); only groups with do_roll touch memory
+      double gk[NX + 1], jr[NZ];
 #pragma unroll
       for (int j = 0; j <= NX; ++j) gk[j] = gk_n[j];
-      if (t + 1 < T) fetch_knot(t + 1);
-      const double dx = do_step ? xt - xcur : 0.0;
+#pragma unroll
+      for (int d = 0; d < NZ; ++d) jr[d] = jr_n[d];
+      const double s_lo = s_lo_n, s_up = s_up_n, v_lo = v_lo_n, v_up = v_up_n;
+      if (do_roll && t + 1 < T) fetch_knot(t + 1);
       if (c < NX) dxs[c] = dx;
       __syncthreads();
       if (c < N) {
         double du = 0.0;
-        if (do_step) {
+        if (do_roll) {
           du = -gk[NX];
 #pragma unroll
           for (int j = 0; j < NX; ++j) du = fma(-gk[j], dxs[j], du);
         }
-        const double un = ucur + du;
-        if (fw) xn[16 + c] = un;
-        dus[c] = un;
-        ndu = fma(du, du, ndu);
-        if (use_hist) {
-          double* hr = D.hist + (((size_t)b * 4 + (hcnt & 3)) * T + t) * TQ_HS;
-          hr[c] = ucur;
-          hr[8 + c] = du;
+        dus[c] = du;
+        du_all[t][c] = du;
+      }
+      if (c < NX) ndx_acc = fma(dx, dx, ndx_acc);
+      __syncthreads();
+      if (do_roll && c < N) {
+        double ds = 0.0;
+#pragma unroll
+        for (int d = 0; d < NX; ++d) ds = fma(jr[d], dxs[d], ds);
+#pragma unroll
+        for (int d = 0; d < N; ++d) ds = fma(jr[NX + d], dus[d], ds);
+        if (ds < 0.0 && s_lo >= delta) a_ftb = fmin(a_ftb, -P.tau_ftb * s_lo / ds);
+        if (ds > 0.0 && s_up >= delta) a_ftb = fmin(a_ftb, P.tau_ftb * s_up / ds);
+        if constexpr (VEL) {
+          const double dv = dxs[N + c];
+          if (dv < 0.0 && v_lo >= delta) a_ftb = fmin(a_ftb, -P.tau_ftb * v_lo / dv);
+          if (dv > 0.0 && v_up >= delta) a_ftb = fmin(a_ftb, P.tau_ftb * v_up / dv);
         }
       }
-      if (c < NX) {
-        if (do_outer) xt = xcur;
-        if (fw) xn[c < N ? c : 8 + (c - N)] = xt;
-        ndx = fma(dx, dx, ndx);
-      }
+      // dx_{t+1} = A dx_t + B du_t
+      const double xo = __shfl(dx, c < N ? c + N : c, 16);
+      if (c < N) dx = fma(dt, xo, dx);
+      else if (c < NX) dx = fma(dt, dus[c - N], dx);
       __syncthreads();
-      // x_{t+1} = A x_t + B u_t on the trial values themselves: the Euler rows hold to the rounding of one operation
+    }
+    if (do_gains) {
+      ndx = group_sum(ndx_acc);
+      alpha = group_min(a_ftb);
+    }
+  }
+
+  // 6. open-loop rollout of u + alpha du from the fixed initial state
+  {
+    double xt = 0.0;
+    if (do_roll && c < NX) {
+      const double* x0r = D.xs + xs_off(D, T, cur, b, 0);
+      xt = x0r[c < N ? c : 8 + (c - N)];
+    }
+    double u_n = 0.0;
+    if (do_roll && c < N) u_n = D.xs[xs_off(D, T, cur, b, 0) + 16 + c];
+    for (int t = 0; t < T; ++t) {
+      const double ucur = u_n;
+      if (do_roll && c < N && t + 1 < T) u_n = D.xs[xs_off(D, T, cur, b, t + 1) + 16 + c];
+      double* xn = D.xs + xs_off(D, T, nts, b, t);
+      if (c < N) {
+        const double un = fma(alpha, du_all[t][c], ucur);
+        if (do_roll) xn[16 + c] = un;
+        dus[c] = un;
+      }
+      if (do_roll && c < NX) xn[c < N ? c : 8 + (c - N)] = xt;
+      __syncthreads();
       const double xo = __shfl(xt, c < N ? c + N : c, 16);
       if (c < N) xt = fma(dt, xo, xt);
       else if (c < NX) xt = fma(dt, dus[c - N], xt);
-    }
-    ndx = group_sum(ndx);
-    ndu = group_sum(ndu);
-  }
-  // ---- Anderson extrapolation: replaces the trial just written -------------------------------------------------------------------------
-  bool do_aa = false;
-  if (use_hist) hcnt += 1;
-  if (P.aa_m > 0) {  // (uniform: every group of the block walks the barriers below)
-    const int h = hcnt < P.aa_m + 1 ? hcnt : P.aa_m + 1;  // entries in use, oldest first: ring slots (hcnt - h + j) & 3
-    const bool want = use_hist && h >= 2 && !aa_was;
-    double gam[3] = {0.0, 0.0, 0.0};
-    if (want) {
-      // Gram matrix of the step differences and its right-hand side: 9 sums over the T x N entries, N lanes of the group at a time
-      double G[6] = {0, 0, 0, 0, 0, 0}, r[3] = {0, 0, 0};
-      if (c < N) {
-        for (int t = 0; t < T; ++t) {
-          double F[4] = {0, 0, 0, 0};
-          for (int j = 0; j < h; ++j) F[j] = D.hist[(((size_t)b * 4 + ((hcnt - h + j) & 3)) * T + t) * TQ_HS + 8 + c];
-          double dF[3];
-#pragma unroll
-          for (int j = 0; j < 3; ++j) dF[j] = (j + 1 < h) ? F[j + 1] - F[j] : 0.0;
-          const double Fl = F[h - 1];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            r[i] = fma(dF[i], Fl, r[i]);
-#pragma unroll
-            for (int j = 0; j <= i; ++j) G[tri(i, j)] = fma(dF[i], dF[j], G[tri(i, j)]);
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) G[i] = group_sum(G[i]);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) r[i] = group_sum(r[i]);
-      const double dmax = fmax(G[0], fmax(G[2], G[5]));
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        if (i + 1 < h) G[tri(i, i)] += 1e-10 * fmax(dmax, 1e-300);
-        else G[tri(i, i)] = 1.0;  // unused row: gamma_i = 0
-      }
-      double rd3[3];
-      if (chol_rcp<3>(G, rd3, 0.0)) {
-        fsub_rcp<3>(G, rd3, r);
-        bsub_rcp<3>(G, rd3, r);
-        gam[0] = r[0]; gam[1] = r[1]; gam[2] = r[2];
-        do_aa = isfinite(gam[0]) && isfinite(gam[1]) && isfinite(gam[2]);
-      }
-    }
-    if (__syncthreads_or(do_aa ? 1 : 0)) {
-      // open-loop rollout of the extrapolated control sequence from the fixed initial state
-      double xt = 0.0;
-      {
-        const double* x0r = D.xs + xs_off(D, T, cur, b, 0);
-        if (c < NX) xt = x0r[c < N ? c : 8 + (c - N)];
-      }
-      for (int t = 0; t < T; ++t) {
-        double* xn = D.xs + xs_off(D, T, nts, b, t);
-        if (c < N) {
-          double ua = 0.0;
-          if (do_aa) {
-            double X[4] = {0, 0, 0, 0}, F[4] = {0, 0, 0, 0};
-            for (int j = 0; j < h; ++j) {
-              const double* hr = D.hist + (((size_t)b * 4 + ((hcnt - h + j) & 3)) * T + t) * TQ_HS;
-              X[j] = hr[c];
-              F[j] = hr[8 + c];
-            }
-            ua = X[h - 1] + F[h - 1];
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-              if (j + 1 < h) ua = fma(-gam[j], (X[j + 1] - X[j]) + (F[j + 1] - F[j]), ua);
-            xn[16 + c] = ua;
-          }
-          dus[c] = ua;
-        }
-        if (do_aa && c < NX) xn[c < N ? c : 8 + (c - N)] = xt;
-        __syncthreads();
-        const double xo = __shfl(xt, c < N ? c + N : c, 16);
-        if (c < N) xt = fma(dt, xo, xt);
-        else if (c < NX) xt = fma(dt, dus[c - N], xt);
-        __syncthreads();
-      }
+      __syncthreads();
     }
   }
   if (run && c == 0) {
-    D.hcnt[b] = hcnt;
-    D.aa[b] = do_aa ? 1 : 0;
     D.cur[b] = cur;
     D.first[b] = 0;
-    D.outer[b] = do_outer ? 1 : 0;
+    D.curv[b] = curv;
     D.f_cur[b] = f_cur;
     D.f_true[b] = f_true;
-    D.meas[b] = meas_cur;
+    D.bsum[b] = bsum;
     D.mu[b] = mu;
     D.nun[b] = nun;
-    D.rho[b] = rho;
-    D.rho_next[b] = rho_next;
-    D.omega[b] = omega;
-    D.meas_prev[b] = meas_prev;
+    D.mub[b] = mub;
     D.stat[b] = stat;
-    D.pred[b] = 0.5 * qk + 0.5 * mu * ndx;
+    D.alpha[b] = alpha;
+    D.qk[b] = qk;
+    D.ndx[b] = ndx;
+    D.viol[b] = viol;
+    D.nrel[b] = nrel;
+    D.n_back[b] = n_back;
     D.iters[b] = iters;
     D.rejected[b] = rejected;
-    D.n_outer[b] = n_outer;
+    D.n_barrier[b] = n_barrier;
     D.status[b] = status;
     if (status < 0) atomicAdd(D.n_running, 1);
   }
 }
 
 // ---- results in the reference layout ------------------------------------------------------------------------------------------------
+// Multipliers: lam_i = mu_b / s_i, the point of the central path the iteration stopped at (lam_i s_i = mu_b <= tol_compl on every row, and with them
+// the reduced gradient of the Lagrangian is the `stat` the iteration tested).
 template <int N>
 __global__ __launch_bounds__(64) void k_tq_finalize(TqParams P, TqBuffers D, double* __restrict__ x, double* __restrict__ f, double* __restrict__ kkt,
                                                     int* __restrict__ iters, int* __restrict__ status, double* __restrict__ mult) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= D.B) return;
   const int T = P.T, cur = D.cur[b];
-  const double rho = D.rho[b];
-  double viol = 0.0, cmpl = 0.0;
+  const double mub = D.mub[b];
+  double cmpl = 0.0;
   for (int t = 0; t < T; ++t) {
     const double* xr = D.xs + xs_off(D, T, cur, b, t);
     const double* sr = D.st + st_off(D, T, cur, b, t);
-    const double* lm = D.lam + ((size_t)b * T + t) * TQ_LAM;
-    viol = fmax(viol, sr[255]);
-    cmpl = fmax(cmpl, sr[263]);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       if (x) {
@@ -1184,14 +1427,22 @@ __global__ __launch_bounds__(64) void k_tq_finalize(TqParams P, TqBuffers D, dou
         xb[2 * N * T + N * t + j] = xr[16 + j];
         xb[3 * N * T + N * t + j] = sr[256 + j];
       }
+      const double tv = sr[256 + j];
+      const double s_lo = tv - P.tau_lo[j], s_up = P.tau_up[j] - tv;
+      const double l_lo = mub / fmax(s_lo, 1e-300), l_up = mub / fmax(s_up, 1e-300);
+      cmpl = fmax(cmpl, fmax(fabs(l_lo * s_lo), fabs(l_up * s_up)));
+      const int NR = P.vel ? 4 * N : 2 * N;  // rows per knot: effort rows, then (with velocity limits) [dq - dq_lo; dq_up - dq]
       if (mult) {
-        const double tv = sr[256 + j];
-        const int NR = P.vel ? 4 * N : 2 * N;  // rows per knot: effort rows, then (with velocity limits) [dq - dq_lo; dq_up - dq]
-        mult[((size_t)b * T + t) * NR + j] = fmax(0.0, lm[j] - rho * (tv - P.tau_lo[j]));
-        mult[((size_t)b * T + t) * NR + N + j] = fmax(0.0, lm[N + j] - rho * (P.tau_up[j] - tv));
-        if (P.vel) {
-          mult[((size_t)b * T + t) * NR + 2 * N + j] = fmax(0.0, lm[16 + j] - rho * (xr[8 + j] - P.dq_lo[j]));
-          mult[((size_t)b * T + t) * NR + 3 * N + j] = fmax(0.0, lm[16 + N + j] - rho * (P.dq_up[j] - xr[8 + j]));
+        mult[((size_t)b * T + t) * NR + j] = l_lo;
+        mult[((size_t)b * T + t) * NR + N + j] = l_up;
+      }
+      if (P.vel) {
+        const double v_lo = xr[8 + j] - P.dq_lo[j], v_up = P.dq_up[j] - xr[8 + j];
+        const double m_lo = mub / fmax(v_lo, 1e-300), m_up = mub / fmax(v_up, 1e-300);
+        cmpl = fmax(cmpl, fmax(fabs(m_lo * v_lo), fabs(m_up * v_up)));
+        if (mult) {
+          mult[((size_t)b * T + t) * NR + 2 * N + j] = m_lo;
+          mult[((size_t)b * T + t) * NR + 3 * N + j] = m_up;
         }
       }
     }
@@ -1199,7 +1450,7 @@ __global__ __launch_bounds__(64) void k_tq_finalize(TqParams P, TqBuffers D, dou
   if (f) f[b] = D.f_true[b];
   if (kkt) {
     kkt[3 * b] = D.stat[b];
-    kkt[3 * b + 1] = viol;
+    kkt[3 * b + 1] = fmax(0.0, D.viol[b]);
     kkt[3 * b + 2] = cmpl;
   }
   if (iters) iters[b] = D.iters[b];
@@ -1219,6 +1470,17 @@ bool oh_launch_rnea_jac(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, in
   }
 #undef OH_RJ
 }
+bool oh_launch_rnea_hess(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, int n, const double* q, const double* qd, const double* qdd, const double* c, double* H) {
+#define OH_RH(NN)                                                                                                                       \
+  case NN + 1:                                                                                                                          \
+    hipLaunchKernelGGL(k_rnea_hess<NN>, dim3((unsigned)((n + (64 / NN) - 1) / (64 / NN))), dim3(64), 0, s, d_dyn, n, q, qd, qdd, c, H);  \
+    return true;
+  switch (nbodies) {
+    OH_RH(1) OH_RH(2) OH_RH(3) OH_RH(4) OH_RH(5) OH_RH(6) OH_RH(7) OH_RH(8)
+    default: return false;
+  }
+#undef OH_RH
+}
 bool oh_launch_tq_setup(hipStream_t s, const TqParams& P, const TqBuffers& D, const double* x0, const double* p) {
   if (P.N != 7) return false;
   hipLaunchKernelGGL(k_tq_setup<7>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p);
@@ -1228,21 +1490,16 @@ void oh_launch_tq_list(hipStream_t s, const TqBuffers& D) { hipLaunchKernelGGL(k
 bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D) {
   if (P.N != 7) return false;
   const long long units = (long long)D.n_run * P.T;
-  static const int per_joint = [] { const char* e = getenv("OH_TQ_EVAL3"); return e ? atoi(e) : 1; }();  // 0: one lane per tangent direction (round 2)
-  // (The round-2 kernel, one lane per tangent direction, has the shorter dependent chain on a latency-bound launch -- one instance: 170 against
-  // 190 us per evaluation -- but the two kernels round differently, and choosing by launch size would make an instance's iterates depend on how
-  // fast the rest of its batch drains: one kernel for every launch.  1024 instances 369 -> 260 us, 8192 instances 2.73 -> 1.77 ms per launch.)
-  // (the variants with joint-velocity rows are instantiations of their own: as a run-time branch the rows cost k_tq_eval3 21 % at 8192 instances
-  //  -- 250 registers at two wavefronts per SIMD with spills instead of 268 at one)
-  if (per_joint && P.vel) hipLaunchKernelGGL((k_tq_eval3<7, true>), dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
-  else if (per_joint) hipLaunchKernelGGL((k_tq_eval3<7>), dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
-  else if (P.vel) hipLaunchKernelGGL((k_tq_eval<7, true>), dim3((unsigned)((units + 2) / 3)), dim3(64), 0, s, P, D);
-  else hipLaunchKernelGGL((k_tq_eval<7>), dim3((unsigned)((units + 2) / 3)), dim3(64), 0, s, P, D);
+  // (the variants with joint-velocity rows are instantiations of their own: as a run-time branch the rows cost k_tq_eval3 21 % at 8192 instances)
+  if (P.vel) hipLaunchKernelGGL((k_tq_eval3<7, true>), dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
+  else hipLaunchKernelGGL((k_tq_eval3<7>), dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
+  hipLaunchKernelGGL(k_tq_curv<7>, dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);  // exits at once where no instance takes Newton steps
   return true;
 }
 bool oh_launch_tq_step(hipStream_t s, const TqParams& P, const TqBuffers& D) {
   if (P.N != 7) return false;
-  hipLaunchKernelGGL(k_tq_step<7>, dim3((D.n_run + 3) / 4), dim3(64), 0, s, P, D);
+  if (P.vel) hipLaunchKernelGGL((k_tq_step<7, true>), dim3((D.n_run + 3) / 4), dim3(64), sizeof(double) * 32 * P.T, s, P, D);
+  else hipLaunchKernelGGL((k_tq_step<7>), dim3((D.n_run + 3) / 4), dim3(64), sizeof(double) * 32 * P.T, s, P, D);
   return true;
 }
 bool oh_launch_tq_finalize(hipStream_t s, const TqParams& P, const TqBuffers& D, double* x, double* f, double* kkt, int* iters, int* status, double* mult) {
@@ -1265,7 +1522,7 @@ bool kernel_info(K kernel, int block, OhKernelInfo* out) {
 bool oh_kernel_info_torque(const char* name, OhKernelInfo* out) {
   const std::string n(name);
   if (n == "k_tq_eval") return kernel_info(k_tq_eval3<7>, 64, out);
-  if (n == "k_tq_eval_directions") return kernel_info(k_tq_eval<7>, 64, out);
+  if (n == "k_tq_curv") return kernel_info(k_tq_curv<7>, 64, out);
   if (n == "k_tq_step") return kernel_info(k_tq_step<7>, 64, out);
   return false;
 }

@@ -463,6 +463,17 @@ class RobotModel(Model):
         _lib.check(_lib.load().oh_rnea_jac(self._dyn_handle, n, _lib._ptr(A[0]), _lib._ptr(A[1]), _lib._ptr(A[2]), _lib._ptr(J)), "oh_rnea_jac")
         return J
 
+    def rnea_hessian(self, q, qd, qdd, c) -> np.ndarray:
+        """sum_i c_i d^2 tau_i / d (q, qd, qdd)^2 at ndof-by-n sample columns (c: ndof-by-n multipliers): (n, 3 ndof, 3 ndof), exact (oh_rnea_hess);
+        what the reference's AD gives as the dynamics rows' share of ddh / the Lagrangian Hessian (optimization.py:8-24)."""
+        self.rnea(np.zeros(self.ndof), np.zeros(self.ndof), np.zeros(self.ndof))  # creates the handle
+        nd = self._dyn.ndof
+        A = [np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(nd, -1).T) for a in (q, qd, qdd, c)]
+        n = A[0].shape[0]
+        H = np.empty((n, 3 * nd, 3 * nd))
+        _lib.check(_lib.load().oh_rnea_hess(self._dyn_handle, n, _lib._ptr(A[0]), _lib._ptr(A[1]), _lib._ptr(A[2]), _lib._ptr(A[3]), _lib._ptr(H)), "oh_rnea_hess")
+        return H
+
     # ---- numeric kinematics through the HIP library -------------------------------------------------
     def _kin(self, link: str) -> "KinematicsHandle":
         h = self._fk_handles.get(link)

@@ -359,3 +359,119 @@ def solve_torque_lm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, t
     if vel:
         out["lam_v"] = np.maximum(0.0, lam_v - rho * np.concatenate([dQ - vlo, vup - dQ], 1))
     return out
+
+
+# ---- second derivatives of the inverse dynamics (round 4) ---------------------------------------------------------------------------------
+# The Lagrangian of the torque problem holds the dynamics rows h = TAU - rnea(Q, dQ, ddQ) (builder.py:354, models.py:1731-1884), so its exact
+# Hessian -- what the reference obtains by AD of the CasADi graph, optimization.py:8-24 -- needs  sum_i c_i d^2 tau_i / dz^2  for a multiplier
+# vector c.  By the principle of virtual work  c^T tau = sum_b f_b . v_b(c) + n_b . w_b(c):  the inertial wrench of every body paired with the
+# velocity the joint rates c would give it.  Both factors come out of ONE outward recursion over the bodies (the reference's forward pass next to a
+# twist propagation), so the gradient is ONE inward adjoint recursion, written out by hand below; the Hessian is that gradient differentiated once
+# more -- complex steps here, dual numbers in csrc/oh_torque.hip:rnea_ctau_grad -- and nothing is differenced.
+def rnea_virtual_work(tb: RneaTables, q, qd, qdd, c):
+    """c^T rnea(q, qd, qdd) by the outward recursion alone (checked against rnea_batch in tests/test_torque_cpu.py)."""
+    return _vw_forward(tb, np.asarray(q), np.asarray(qd), np.asarray(qdd), np.asarray(c))[0]
+
+
+def _rot(tb, i, qi):
+    s, c = np.sin(qi)[..., None, None], np.cos(qi)[..., None, None]
+    return tb.R0[i] @ (np.eye(3) + s * tb.K[i] + (1.0 - c) * (tb.K[i] @ tb.K[i]))
+
+
+def _mv(M, v):
+    return (M @ v[..., None])[..., 0]
+
+
+def _vw_forward(tb, q, qd, qdd, c):
+    dt_ = np.result_type(q.dtype, qd.dtype, qdd.dtype, c.dtype, float)
+    shp = np.broadcast_shapes(q.shape, qd.shape, qdd.shape, c.shape)[:-1]
+    n = tb.n
+    z = np.zeros(shp + (3,), dt_)
+    om, omD, vD, wc, vo = z, z, z + np.array([0.0, 0.0, 9.81]), z, z
+    phi = np.zeros(shp, dt_)
+    tape = []
+    for i in range(n):
+        mov = i != n - 1
+        R = _rot(tb, i, q[..., i]) if mov else np.broadcast_to(tb.R0[i], shp + (3, 3)).astype(dt_)
+        Rt = np.swapaxes(R, -1, -2)
+        r = np.broadcast_to(tb.xyz[i], shp + (3,))
+        omp, omDp, wcp = _mv(Rt, om), _mv(Rt, omD), _mv(Rt, wc)
+        acc = vD + _cross(omD, r) + _cross(om, _cross(om, r))
+        w = vo + _cross(wc, r)
+        if mov:
+            a = Rt @ tb.axis[i]
+            aq = a * qd[..., i][..., None]
+            omi = omp + aq
+            omDi = omDp + _cross(omp, aq) + a * qdd[..., i][..., None]
+            wci = wcp + a * c[..., i][..., None]
+        else:
+            a, aq = z, z
+            omi, omDi, wci = omp, omDp, wcp
+        vDi, voi = _mv(Rt, acc), _mv(Rt, w)
+        cm = np.broadcast_to(tb.cm[i], shp + (3,))
+        fi = tb.m[i] * (vDi + _cross(omDi, cm) + _cross(omi, _cross(omi, cm)))
+        Io = _mv(tb.I[i], omi)
+        ni = _mv(tb.I[i], omDi) + _cross(omi, Io)
+        vci = voi + _cross(wci, cm)
+        phi = phi + np.sum(fi * vci, -1) + np.sum(ni * wci, -1)
+        tape.append((R, om, omD, wc, omp, omDp, wcp, a, aq, acc, w, omi, omDi, wci, vDi, voi, fi, ni, vci, Io))
+        om, omD, vD, wc, vo = omi, omDi, vDi, wci, voi
+    return phi, tape
+
+
+def rnea_ctau_gradient(tb: RneaTables, q, qd, qdd, c):
+    """d (c^T rnea) / d (q, qd, qdd): (..., 3 ndof) by the hand-written adjoint of _vw_forward (real or complex arguments)."""
+    q, qd, qdd, c = (np.asarray(v) for v in (q, qd, qdd, c))
+    _, tape = _vw_forward(tb, q, qd, qdd, c)
+    n, nd = tb.n, tb.ndof
+    shp = tape[0][1].shape[:-1]
+    dt_ = tape[-1][11].dtype
+    z = np.zeros(shp + (3,), dt_)
+    b_om, b_omD, b_vD, b_wc, b_vo = z, z, z, z, z  # adjoints of body i's (om, omD, vD, wc, vo), filled by its child
+    gq, gqd, gqdd = [None] * nd, [None] * nd, [None] * nd
+    dot = lambda x, y: np.sum(x * y, -1)[..., None]
+    for i in range(n - 1, -1, -1):
+        R, om_p, omD_p, wc_p, omp, omDp, wcp, a, aq, acc, w, omi, omDi, wci, vDi, voi, fi, ni, vci, Io = tape[i]
+        cm = np.broadcast_to(tb.cm[i], shp + (3,))
+        r = np.broadcast_to(tb.xyz[i], shp + (3,))
+        I = tb.I[i]
+        m = tb.m[i]
+        # local term f_i . vc_i + n_i . wc_i
+        b_vo = b_vo + fi
+        b_wc = b_wc + _cross(cm, fi) + ni
+        b_vD = b_vD + m * vci
+        b_omD = b_omD + m * _cross(cm, vci) + _mv(I.T, wci)
+        b_om = b_om + m * (vci * dot(omi, cm) + cm * dot(omi, vci) - 2.0 * omi * dot(cm, vci)) + _mv(I.T, _cross(wci, omi)) + _cross(Io, wci)
+        # through the step of body i
+        if i != n - 1:
+            b_omp = b_om + _cross(aq, b_omD)
+            b_aq = b_om + _cross(b_omD, omp)
+            b_a = b_aq * qd[..., i][..., None] + b_omD * qdd[..., i][..., None] + b_wc * c[..., i][..., None]
+            gqd[i] = dot(b_aq, a)[..., 0]
+            gqdd[i] = dot(b_omD, a)[..., 0]
+            k = tb.axis[i]
+            sw = _cross(omp, b_omp) + _cross(omDp, b_omD) + _cross(wcp, b_wc) + _cross(a, b_a) + _cross(vDi, b_vD) + _cross(voi, b_vo)
+            gq[i] = -np.sum(sw * k, -1)
+        else:
+            b_omp = b_om
+        b_acc = _mv(R, b_vD)
+        b_w = _mv(R, b_vo)
+        n_om = _mv(R, b_omp) + b_acc * dot(om_p, r) + r * dot(om_p, b_acc) - 2.0 * om_p * dot(r, b_acc)
+        n_omD = _mv(R, b_omD) + _cross(r, b_acc)
+        n_vD = b_acc
+        n_wc = _mv(R, b_wc) + _cross(r, b_w)
+        n_vo = b_w
+        b_om, b_omD, b_vD, b_wc, b_vo = n_om, n_omD, n_vD, n_wc, n_vo
+    return np.concatenate([np.stack(gq, -1), np.stack(gqd, -1), np.stack(gqdd, -1)], -1)
+
+
+def rnea_ctau_hessian(tb: RneaTables, q, qd, qdd, c, h=1e-30):
+    """sum_i c_i d^2 tau_i / d (q, qd, qdd)^2: (..., 3 ndof, 3 ndof), complex-step derivative of rnea_ctau_gradient (exact to rounding; the
+    ddq-ddq block is zero: the torques are linear in the accelerations)."""
+    q, qd, qdd, c = (np.asarray(v, float) for v in (q, qd, qdd, c))
+    n = tb.ndof
+    zz = np.concatenate([np.broadcast_to(q, np.broadcast_shapes(q.shape, qd.shape, qdd.shape)), np.broadcast_to(qd, np.broadcast_shapes(q.shape, qd.shape, qdd.shape)),
+                         np.broadcast_to(qdd, np.broadcast_shapes(q.shape, qd.shape, qdd.shape))], -1)[..., None, :] + 1j * h * np.eye(3 * n)
+    g = rnea_ctau_gradient(tb, zz[..., :n], zz[..., n:2 * n], zz[..., 2 * n:], c[..., None, :])  # (..., 3n directions, 3n)
+    H = g.imag / h
+    return 0.5 * (H + np.swapaxes(H, -1, -2))

@@ -232,6 +232,12 @@ class IKBackend(_SolveMixin):
         return out[:, :3], out[:, 3 : 3 + self.ndof], out[:, 3 + self.ndof :]
 
 
+def tape_default_max_iter(nx: int) -> int:
+    """Default evaluation budget of the generic tape family, shared by HIPSolver and the CasADi front end: a small dense problem needs a
+    few hundred tape evaluations, the limited-memory path of a trajectory-sized one (nx > 48) tens of thousands."""
+    return 2000 if nx <= 48 else 500000
+
+
 class TorqueBackend(_SolveMixin):
     """OH_PROBLEM_TORQUE_MPC handle (BASELINE configs[4]): x = [vec(Q); vec(dQ); vec(ddQ); vec(TAU)], p = [qc; dqc; vec(goal 3 x T)]."""
 

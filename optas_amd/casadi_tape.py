@@ -155,7 +155,7 @@ def make_solver_class(solver_module, cs):
         solver = HIPSolver(builder.build()).setup("hip_sqp", {"tol": 1e-6})
         solver.reset_initial_seed({...}); solver.reset_parameters({...}); solution = solver.solve()
     """
-    from .backend import TapeBackend
+    from .backend import TapeBackend, tape_default_max_iter
 
     class HIPSolver(solver_module.Solver):
         def setup(self, solver_name: str = "hip_sqp", solver_options: Optional[dict] = None):
@@ -186,8 +186,8 @@ def make_solver_class(solver_module, cs):
                     elif fam == "torque_mpc":
                         self._backend = TorqueBackend(spec.robot.solver_chain(spec.link), spec.robot.dynamics_tables(), T=spec.T, dt=spec.dt, w_path=spec.w_path,
                                                       w_vel=spec.w_vel, w_tau=spec.w_tau, tau_lo=spec.tau_lo, tau_up=spec.tau_up, dq_lo=getattr(spec, "dq_lo", None), dq_up=getattr(spec, "dq_up", None),
-                                                      max_iter=int(o.pop("max_iter", 300)), tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)),
-                                                      rho0=float(o.pop("rho0", 0.0)), mu0=float(o.pop("mu0", 0.0)))
+                                                      max_iter=int(o.pop("max_iter", 300)), tol=float(o.pop("tol", 1e-6)), tol_compl=float(o.pop("tol_compl", 1e-8)),
+                                                      mu_barrier0=float(o.pop("mu_barrier0", 0.0)), mu0=float(o.pop("mu0", 0.0)))
                     elif fam == "point_mass":
                         self._backend = PointMassBackend(spec.T, spec.dt, spec.w_acc, spec.ylim, spec.vlim, spec.safe, max_iter=int(o.pop("max_iter", 100)),
                                                          tol=float(o.pop("tol", 1e-8)))
@@ -228,7 +228,7 @@ def make_solver_class(solver_module, cs):
                                      "squares of affine expressions under a constant) with nx <= 32, nk <= 256, na <= 32")
             if self._family is None:
                 self._tape = tape_from_optimization(self.opt, cs)
-                self._backend = TapeBackend(self._tape, max_iter=int(o.pop("max_iter", 2000)), tol=float(o.pop("tol", 1e-6)),
+                self._backend = TapeBackend(self._tape, max_iter=int(o.pop("max_iter", tape_default_max_iter(self._tape.nx))), tol=float(o.pop("tol", 1e-6)),
                                             tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=float(o.pop("rho0", 10.0)), jit=bool(o.pop("jit", True)))
                 self._family = "tape"
             if o:

@@ -344,7 +344,14 @@ extern "C" int oh_create_tape(const oh_tape_desc* d, oh_handle** out) {
   if (d->jit) {
     std::vector<char> code;
     std::string err;
-    if (oh_tape_jit_compile(oh_tape_jit_source(h->TP, d->op, d->a, d->b, d->c, d->rows), &code, &err) || oh_tape_jit_load(code, &h->tape_jit, &err)) {
+    const std::string src = oh_tape_jit_source(h->TP, d->op, d->a, d->b, d->c, d->rows);
+    bool ok = !oh_tape_jit_compile(src, &code, &err) && !oh_tape_jit_load(code, &h->tape_jit, &err);
+    if (!ok && !code.empty()) {  // an object that compiled (or came from the disk cache) and does not load: drop it, recompile once (as oh_jit_figure8 does)
+      oh_tape_jit_forget(src);
+      code.clear();
+      ok = !oh_tape_jit_compile(src, &code, &err) && !oh_tape_jit_load(code, &h->tape_jit, &err);
+    }
+    if (!ok) {
       delete h;
       return fail(OH_ERR_HIP, ("oh_create_tape: " + err).c_str());
     }
@@ -609,10 +616,12 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   P.T = T; P.N = N; P.max_iter = h->tq.max_iter;
   P.dt = h->tq.dt; P.w_path = h->tq.w_path; P.w_vel = h->tq.w_vel; P.w_tau = h->tq.w_tau;
   P.tol = h->tq.tol; P.tol_compl = h->tq.tol_compl; P.mu_b0 = h->tq.mu_barrier0; P.mu0 = h->tq.mu0;
-  // interior point: relaxed barrier below theta mu_b; monotone barrier update with IPOPT's constants (Waechter & Biegler 2006, eq. 7); exact
+  // interior point: relaxed barrier below theta mu_b; monotone barrier update of Waechter & Biegler (2006, eq. 7) -- IPOPT's constants except theta_mu (1.35 for 1.5: the hardest of 8192 instances needs 127 steps instead of 198); exact
   // curvature of the Lagrangian once the reduced gradient is below curv_from (oracle/torque_ipm.py:solve_torque_ipm has the same defaults)
-  P.theta = 0.01; P.kappa_eps = 10.0; P.kappa_mu = 0.2; P.theta_mu = 1.5; P.curv_from = 0.1; P.tau_ftb = 0.995; P.max_back = 3;
+  P.theta = 0.01; P.kappa_eps = 10.0; P.kappa_mu = 0.2; P.theta_mu = 1.35; P.curv_from = 0.1; P.tau_ftb = 0.995; P.max_back = 3;
   if (const char* e = getenv("OH_TQ_FTB")) P.tau_ftb = atof(e);
+  if (const char* e = getenv("OH_TQ_THETA_MU")) P.theta_mu = atof(e);
+  if (const char* e = getenv("OH_TQ_KAPPA_MU")) P.kappa_mu = atof(e);
   if (const char* e = getenv("OH_TQ_CURV_FROM")) P.curv_from = atof(e);  // 0: Gauss-Newton blocks throughout (A/B)
   P.vel = h->tq.vel_limits ? 1 : 0;
   for (int i = 0; i < N; ++i) {
@@ -992,6 +1001,10 @@ extern "C" int oh_set_guards(oh_handle* h, const oh_guards* g) {
     return fail(OH_ERR_INVALID, "oh_set_guards: too many sphere links / obstacles");
   if ((g->n_links == 0) != (g->n_obstacles == 0)) return fail(OH_ERR_INVALID, "oh_set_guards: sphere rows need both links and obstacles");
   if (!g->limits && g->n_links == 0 && !g->vel_limits) return fail(OH_ERR_INVALID, "oh_set_guards: no rows");
+  // (the orientation-locked kernels that carry inequality rows -- k_eval_lg, k_tail_vel -- are instantiated for 6 and 7 joints only; any
+  //  other chain used to launch nothing, finalise the seed and still return OH_OK)
+  if (h->desc.lock_orientation && h->desc.ndof != 6 && h->desc.ndof != 7)
+    return fail(OH_ERR_INVALID, "oh_set_guards: inequality rows on an orientation-locked handle need ndof 6 or 7");
   if (g->vel_limits) {
     for (int j = 0; j < h->desc.ndof; ++j)
       if (!(g->dq_lo[j] < g->dq_up[j])) return fail(OH_ERR_INVALID, "oh_set_guards: dq_lo must be below dq_up");
@@ -1214,7 +1227,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   };
   bool tail_done = false;
   if (tail_ok && B <= tail_threshold) {  // small batch: the whole solve is one persistent launch
-    launch_tail(0);
+    if (!launch_tail(0)) return fail(OH_ERR_INVALID, "oh_solve_device: no persistent kernel for this handle (ndof / rows)");
     tail_done = true;
   }
   bool rebase = false;
@@ -1289,7 +1302,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
         if (guarded) oh_launch_guard_compact(s, h->P, h->D, h->GP, h->GB, NV, 1, nrun);
         h->D.B = nrun;
         ++compactions;
-        launch_tail((it + 1) & 1);
+        if (!launch_tail((it + 1) & 1)) return fail(OH_ERR_INVALID, "oh_solve_device: no persistent kernel for this handle (ndof / rows)");
         tail_done = true;
         break;
       }

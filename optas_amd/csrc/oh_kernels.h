@@ -151,6 +151,7 @@ void oh_launch_tape_solve(hipStream_t s, const TapeParams& T, const int* op, con
 std::string oh_tape_jit_source(const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows);
 int oh_tape_jit_compile(const std::string& src, std::vector<char>* code, std::string* err);  // hiprtc for gfx950; needs no device
 int oh_tape_jit_load(const std::vector<char>& code, TapeJit* out, std::string* err);
+void oh_tape_jit_forget(const std::string& src);  // drop a cached object that did not load (disk and memory)
 void oh_tape_jit_release(TapeJit* j);
 hipError_t oh_launch_tape_jit(hipStream_t s, const TapeJit& j, TapeParams T, int B, int Bp, const double* x0, const double* p, double* work, double* x, double* f,
                               double* kkt, int* iters, int* status, double* mult);

@@ -287,7 +287,9 @@ int oh_tape_jit_compile(const std::string& src, std::vector<char>* code, std::st
   }
   // a trajectory-sized tape is minutes of compilation: its object is kept on disk like the chain-specialised kernels' (the key is the
   // generated text, which contains the solver and every constant of the problem)
-  if (src.size() > 100000 && oh_jit_disk_lookup(src, "tape", code)) {
+  // (the disk key is the generated text plus the compile options below: an object built with other options is another object)
+  static const std::string kOptKey = "// --offload-arch=gfx950 -O3 -std=c++17\n";
+  if (src.size() > 100000 && oh_jit_disk_lookup(kOptKey + src, "tape", code)) {
     std::lock_guard<std::mutex> lk(g_cache_mutex);
     g_code_cache.emplace(src, *code);
     return 0;
@@ -310,10 +312,17 @@ int oh_tape_jit_compile(const std::string& src, std::vector<char>* code, std::st
   code->resize(cs);
   hiprtcGetCode(prog, code->data());
   hiprtcDestroyProgram(&prog);
-  if (src.size() > 100000) oh_jit_disk_store(src, "tape", *code);
+  if (src.size() > 100000) oh_jit_disk_store(kOptKey + src, "tape", *code);
   std::lock_guard<std::mutex> lk(g_cache_mutex);
   g_code_cache.emplace(src, *code);
   return 0;
+}
+
+// Forget a code object that did not load (a truncated or stale file of the disk cache): the next oh_tape_jit_compile of the same source recompiles.
+void oh_tape_jit_forget(const std::string& src) {
+  oh_jit_disk_drop(std::string("// --offload-arch=gfx950 -O3 -std=c++17\n") + src, "tape");
+  std::lock_guard<std::mutex> lk(g_cache_mutex);
+  g_code_cache.erase(src);
 }
 
 int oh_tape_jit_load(const std::vector<char>& code, TapeJit* out, std::string* err) {

@@ -294,7 +294,8 @@ def weighted_hessian(e: Expr, opt, x: np.ndarray, p: np.ndarray, W: np.ndarray) 
     """sum over the entries of node ``e`` of W[r, c] * (Hessian of that entry w.r.t. x), nx x nx, exact: the weights travel down the tree
     (transposed through the linear nodes), every nonlinear node adds its own curvature from the first derivatives of its operands.  Second-order
     kinematics come out of the geometric Jacobian oh_fk_jac returns: d2 p / dq_i dq_j = z_i x Jp_j (i <= j), d2 quat and d2 R from the same axes.
-    Raises NotImplementedError for nodes without a rule (inverse dynamics, the Jacobian-valued link function): the caller differences."""
+    Inverse dynamics: oh_rnea_hess (round 4).  Raises NotImplementedError for nodes without a rule (the Jacobian-valued link function): the caller
+    differences."""
     nx = opt.nx
     m, n = e.shape
     W = np.broadcast_to(np.asarray(W, dtype=np.float64), (m, n))
@@ -356,6 +357,25 @@ def weighted_hessian(e: Expr, opt, x: np.ndarray, p: np.ndarray, W: np.ndarray) 
                         C = np.outer(Ja[k * ma + r], Jb[c * ka + k])
                         H += W[r, c] * (C + C.T)
         return H + weighted_hessian(e.a, opt, x, p, W @ vb.T) + weighted_hessian(e.b, opt, x, p, va.T @ W)
+    if isinstance(e, RneaFunction):
+        # sum_{i,c} W[i, c] Hessian of tau_i(column c) = G_c^T (sum_i W[i, c] d^2 tau_i / d(q, qd, qdd)^2) G_c  (oh_rnea_hess: the adjoint of the
+        # reference's recursion on dual numbers, exact like CasADi's AD of the same graph, optimization.py:8-24) + the curvature of the operands
+        # weighted through d tau / d(q, qd, qdd)
+        q, Jq = jacobian(e.q, opt, x, p)
+        qd, Jqd = jacobian(e.qd, opt, x, p)
+        qdd, Jqdd = jacobian(e.qdd, opt, x, p)
+        nd, cols = q.shape
+        Hc = e.robot.rnea_hessian(q, qd, qdd, W)  # (cols, 3 nd, 3 nd)
+        Jt = e.robot.rnea_jacobian(q, qd, qdd)    # (cols, nd, 3 nd)
+        H = Z.copy()
+        Wq, Wqd, Wqdd = np.zeros((nd, cols)), np.zeros((nd, cols)), np.zeros((nd, cols))
+        for c in range(cols):
+            sl = slice(c * nd, (c + 1) * nd)
+            G = np.concatenate([Jq[sl], Jqd[sl], Jqdd[sl]], 0)  # (3 nd, nx)
+            H += G.T @ Hc[c] @ G
+            wj = W[:, c] @ Jt[c]  # weights the operands' own second derivatives inherit
+            Wq[:, c], Wqd[:, c], Wqdd[:, c] = wj[:nd], wj[nd : 2 * nd], wj[2 * nd :]
+        return H + weighted_hessian(e.q, opt, x, p, Wq) + weighted_hessian(e.qd, opt, x, p, Wqd) + weighted_hessian(e.qdd, opt, x, p, Wqdd)
     if isinstance(e, Atan2):
         vy, Jy = jacobian(e.y, opt, x, p)
         vx, Jx = jacobian(e.x, opt, x, p)

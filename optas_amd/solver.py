@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import _lib
-from .backend import BatchResult, FigureEightBackend, IKBackend, MultiArmBackend, PointMassBackend, QPBackend, TapeBackend, TorqueBackend
+from .backend import BatchResult, FigureEightBackend, IKBackend, MultiArmBackend, PointMassBackend, QPBackend, TapeBackend, TorqueBackend, tape_default_max_iter
 from .lowering import FigureEightSpec, IkSpec, MultiArmSpec, PointMassSpec, QpSpec, TapeSpec, TorqueSpec, lower
 from .models import RobotModel
 from .optimization import Optimization
@@ -281,8 +281,8 @@ class HIPSolver(Solver):
             o.pop("hessian", None)
             self._backend = TorqueBackend(spec.robot.solver_chain(spec.link), spec.robot.dynamics_tables(), T=spec.T, dt=spec.dt, w_path=spec.w_path,
                                           w_vel=spec.w_vel, w_tau=spec.w_tau, tau_lo=spec.tau_lo, tau_up=spec.tau_up, dq_lo=getattr(spec, "dq_lo", None), dq_up=getattr(spec, "dq_up", None),
-                                          max_iter=int(o.pop("max_iter", 300)), tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)),
-                                          rho0=float(o.pop("rho0", 0.0)), mu0=float(o.pop("mu0", 0.0)))
+                                          max_iter=int(o.pop("max_iter", 300)), tol=float(o.pop("tol", 1e-6)), tol_compl=float(o.pop("tol_compl", 1e-8)),
+                                          mu_barrier0=float(o.pop("mu_barrier0", 0.0)), mu0=float(o.pop("mu0", 0.0)))
         elif isinstance(spec, PointMassSpec):
             o.pop("hessian", None)
             pl = spec.planner
@@ -315,7 +315,7 @@ class HIPSolver(Solver):
         elif isinstance(spec, TapeSpec):
             o.pop("hessian", None)
             # (evaluations: a small dense problem needs a few hundred; the limited-memory path of a trajectory-sized one tens of thousands)
-            self._backend = TapeBackend(spec.tape, max_iter=int(o.pop("max_iter", 2000 if spec.tape.nx <= 48 else 500000)), tol=float(o.pop("tol", 1e-6)),
+            self._backend = TapeBackend(spec.tape, max_iter=int(o.pop("max_iter", tape_default_max_iter(spec.tape.nx))), tol=float(o.pop("tol", 1e-6)),
                                         tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=float(o.pop("rho0", 10.0)), jit=bool(o.pop("jit", True)))
         else:  # pragma: no cover
             raise NotImplementedError(kind)

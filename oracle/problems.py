@@ -888,6 +888,33 @@ class TorqueMPCNLP(_NLPBase):
         Q, dQ, ddQ, TAU = self.split(x)
         return (TAU - self._rnea(self.prob.tb, Q, dQ, ddQ)).reshape(-1)
 
+    def hess_lagrangian_v(self, x, p, sigma, lam_v):
+        """sigma d2f + sum_i lam_v[i] d2 v_i (what the reference's AD of the CasADi graph gives nlpsol as the Hessian of the Lagrangian,
+        optimization.py:8-24, solver.py:346-363), exact: the rows k and a are linear; h = TAU - rnea(Q, dQ, ddQ) contributes
+        -sum_i mu_h[t, i] d2 tau_i / d(q_t, dq_t, ddq_t)^2 with the signed mu_h = lam(h) - lam(-h) (oracle.torque.rnea_ctau_hessian: hand-written
+        adjoint of the recursion, differentiated once more by complex steps); the tracking term has 2 w_p (Jp^T Jp + sum_k r_k d2 p_k / dq2)."""
+        from .torque import rnea_ctau_hessian
+        from .torque_ipm import position_curvature
+
+        Q, dQ, ddQ, _ = self.split(x)
+        goal = self.split_p(p)[2]
+        n, nb, T, w = self.n, self.nb, self.T, self.prob
+        o = self.nk + self.ng + 2 * self.na
+        mu_h = (np.asarray(lam_v[o:o + self.nh]) - np.asarray(lam_v[o + self.nh:o + 2 * self.nh])).reshape(T, n)
+        Hd = -rnea_ctau_hessian(w.tb, Q, dQ, ddQ, mu_h)  # (T, 3n, 3n)
+        e, _, Jp, _ = w.chain.jac(Q)
+        Hq = 2.0 * w.w_path * sigma * (np.einsum("tki,tkj->tij", Jp, Jp) + position_curvature(w.chain, Q, e - goal))
+        H = np.zeros((self.nx, self.nx))
+        for t in range(T):
+            idx = np.concatenate([blk * nb + n * t + np.arange(n) for blk in range(3)])
+            H[np.ix_(idx, idx)] += Hd[t]
+            iq = n * t + np.arange(n)
+            H[np.ix_(iq, iq)] += Hq[t]
+        d = np.arange(nb)
+        H[nb + d, nb + d] += 2.0 * w.w_vel * sigma
+        H[3 * nb + d, 3 * nb + d] += 2.0 * w.w_tau * sigma
+        return H
+
     def dh(self, x, p):
         Q, dQ, ddQ, _ = self.split(x)
         n, nb = self.n, self.nb

@@ -137,7 +137,7 @@ def dense_sqp(nlp, x0, p, max_iter=100, tol=1e-10, gauss_newton=False, verbose=F
     }
 
 
-def kkt_reference_form(nlp, x, p, active_tol=1e-6):
+def kkt_reference_form(nlp, x, p, active_tol=1e-6, lam_kg=None):
     """KKT residuals of the problem exactly as CasADiSolver poses it: min f s.t. 0 <= v(x,p) <= 1e10
     (solver.py:346-363), v = [k; g; a; -a; h; -h], multipliers lam >= 0 on every row.
 
@@ -145,6 +145,9 @@ def kkt_reference_form(nlp, x, p, active_tol=1e-6):
     stationarity, so mu is fitted as a free variable and split as lam+ = max(mu,0), lam- = max(-mu,0).
     Inequality multipliers are fitted with a lower bound of 0 on the numerically active rows only.
     Returns dict(stationarity, feasibility, complementarity, lam) with lam in v's row order.
+
+    lam_kg: multipliers >= 0 of the inequality rows [k; g] that came with x (an interior-point answer: every row carries lam_i = mu / v_i, none is
+    "active" to a tolerance); they are taken as given and only the equality multipliers are fitted.
     """
     g = nlp.df(x, p)
     if nlp.nv == 0:
@@ -155,6 +158,14 @@ def kkt_reference_form(nlp, x, p, active_tol=1e-6):
     Je = np.concatenate([nlp.da(x, p), nlp.dh(x, p)], axis=0)
     v = nlp.v(x, p)
     feas = float(max(0.0, -np.min(v)))
+    if lam_kg is not None:
+        lam_kg = np.asarray(lam_kg, dtype=float).reshape(-1)
+        assert lam_kg.shape == kg.shape and lam_kg.min() >= 0.0
+        mu = np.linalg.lstsq(Je.T, g - Jkg.T @ lam_kg, rcond=1e-12)[0] if e.size else np.zeros(0)
+        stat = float(np.max(np.abs(g - Jkg.T @ lam_kg - (Je.T @ mu if e.size else 0.0))))
+        mu_a, mu_h = mu[: nlp.na], mu[nlp.na :]
+        lam = np.concatenate([lam_kg, np.maximum(mu_a, 0), np.maximum(-mu_a, 0), np.maximum(mu_h, 0), np.maximum(-mu_h, 0)])
+        return {"stationarity": stat, "feasibility": feas, "complementarity": float(np.max(np.abs(lam * v))), "lam": lam, "mu_a": mu_a, "mu_h": mu_h}
     act = np.where(kg <= active_tol * max(1.0, float(np.max(np.abs(kg))) if kg.size else 1.0))[0]
     M = np.concatenate([Jkg[act], Je], axis=0).T  # nx x (nact + ne)
     if act.size:

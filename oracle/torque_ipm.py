@@ -83,7 +83,7 @@ def rollout_step(Ks, ks, alpha, dt):
 
 
 def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, tol=1e-6, tol_c=1e-8, mu0=0.1, theta=0.01, kappa_eps=10.0, kappa_mu=0.2,
-                     theta_mu=1.5, curv_from=0.1, vlimits=None, verbose=False, kappa_sig=1e10, tau_ftb=0.995, max_back=3):
+                     theta_mu=1.35, curv_from=0.1, vlimits=None, verbose=False, kappa_sig=1e10, tau_ftb=0.995, max_back=3):
     """One instance.  Returns dict(U, Q, dQ, tau, f, iters, rejected, stat, status, mu_b, lam (T, rows), s (T, rows))."""
     T, n, dt = prob.T, prob.n, prob.dt
     wp, wt, wv = prob.w_path, prob.w_tau, prob.w_vel

@@ -239,3 +239,40 @@ def test_literal_solver_subclass_sends_band_rows_to_the_qp_family(hip_lib):
     assert sum(1 for s in state if s) >= 1 and xs[3] < 5.0
     assert np.abs(dq - xs).max() <= 1e-6 * max(1.0, np.abs(xs).max()) and abs(opt.f(dq, b)[0][0] - opt.f(xs, b)[0][0]) <= 1e-8 * opt.f(xs, b)[0][0]
     assert opt.g(dq, b)[0].min() >= -1e-12
+
+
+def test_evaluation_budget_of_a_trajectory_sized_tape_is_the_same_on_both_front_ends(monkeypatch):
+    """the CasADi front end built TapeBackend with max_iter = 2000 whatever nx is, HIPSolver with 500000 beyond nx = 48 -- a
+    trajectory-sized problem arriving as CasADi functions stopped at OH_STATUS_MAX_ITER while the same problem through HIPSolver converged.  Both
+    take the default from optas_amd.backend.tape_default_max_iter now (no GPU needed: the backend constructor is intercepted)."""
+    import optas_amd.backend as backend_mod
+
+    assert backend_mod.tape_default_max_iter(48) == 2000 and backend_mod.tape_default_max_iter(49) == 500000
+    seen = {}
+
+    class Capture:
+        def __init__(self, tape, **kw):
+            seen.update(kw, nx=tape.nx)
+
+    monkeypatch.setattr(backend_mod, "TapeBackend", Capture)
+
+    class Solver:
+        def __init__(self, optimization, error_on_fail=False):
+            self.opt = optimization
+
+    n = 60
+    x, p = cs.sym(0, n), cs.sym(1, 2)
+    cost = cs.sq(cs.sin(x[0]) - p[0])
+    for i in range(1, n):
+        cost = cost + cs.sq(cs.sin(x[i]) - 0.5 * x[i - 1]) + 0.1 * x[i] ** 3
+    opt = FakeOptimization()
+    opt.f = cs.Function("f", [[(0, cost)]], [1])
+    opt.g = opt.h = None
+    opt.nx = n
+    HIPSolver = make_solver_class(types.SimpleNamespace(Solver=Solver), cs)
+    HIPSolver(opt).setup("hip_sqp")
+    assert seen["nx"] == n and seen["max_iter"] == 500000
+    seen.clear()
+    opt2 = FakeOptimization()
+    HIPSolver(opt2).setup("hip_sqp")
+    assert seen["nx"] == 3 and seen["max_iter"] == 2000

@@ -114,12 +114,35 @@ def test_planar_heading_row_uses_the_rotation_rule(hip_lib):
             assert np.abs(T3[:, :, j] - (d1(x + d, p) - d1(x - d, p)) / (2 * e)).max() <= 1e-7 * max(1.0, np.abs(T3).max()), name
 
 
-def test_inverse_dynamics_rows_fall_back_to_differences(hip_lib):
+def test_inverse_dynamics_rows_are_exact(hip_lib):
+    """ddh of the rows h = TAU - rnea(Q, dQ, ddQ) (round 3: central differences of the exact dh): oh_rnea_hess -- the hand-written adjoint of the
+    reference's recursion on dual numbers -- against the oracle's complex-step Hessian of its own adjoint (oracle/torque.py:rnea_ctau_hessian),
+    row by row on the literal layout, and against central differences of the exact dh."""
     from examples.torque_mpc import build_problem
+    from oracle.robot import OracleRobot
+    from oracle.torque import RneaTables, rnea_ctau_hessian
+    from conftest import MED7_KIN
 
-    _, _, o = build_problem(T=3, effort=60.0)
+    T = 3
+    _, _, o = build_problem(T=T, effort=60.0)
     rng = np.random.default_rng(SEED + 5)
     x, p = rng.uniform(-0.5, 0.5, o.nx), rng.uniform(-0.5, 0.5, o.np)
-    H = o.ddh(x, p)  # RneaFunction has no second-derivative rule: central differences of the exact dh, as in round 2
+    H = o.ddh(x, p)
     assert H.shape == (o.nh, o.nx, o.nx) and np.isfinite(H).all()
-    assert np.abs(H - np.swapaxes(H, 1, 2)).max() <= 1e-4 * max(1.0, np.abs(H).max())
+    assert np.abs(H - np.swapaxes(H, 1, 2)).max() <= 1e-12 * max(1.0, np.abs(H).max())
+    tb = RneaTables(OracleRobot(MED7_KIN))
+    X = x.reshape(4, T, 7)  # [vec(Q); vec(dQ); vec(ddQ); vec(TAU)], knot-major
+    for t in range(T):
+        for i in range(7):
+            Ho = -rnea_ctau_hessian(tb, X[0, t], X[1, t], X[2, t], np.eye(7)[i])  # h_i = TAU_i - rnea_i
+            idx = np.concatenate([np.arange(7) + 7 * t + 7 * T * k for k in range(3)])
+            blk = H[7 * t + i][np.ix_(idx, idx)]
+            assert np.abs(blk - Ho).max() <= 1e-10 * max(1.0, np.abs(Ho).max()), (t, i)
+            rest = H[7 * t + i].copy()
+            rest[np.ix_(idx, idx)] = 0.0
+            assert np.abs(rest).max() == 0.0  # a dynamics row of knot t touches nothing but knot t
+    e, d1 = 1e-6, o.dh
+    for j in rng.choice(o.nx, 6, replace=False):
+        d = np.zeros(o.nx)
+        d[j] = e
+        assert np.abs(H[:, :, j] - (d1(x + d, p) - d1(x - d, p)) / (2 * e)).max() <= 1e-6 * max(1.0, np.abs(H).max())

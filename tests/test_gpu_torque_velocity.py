@@ -1,7 +1,8 @@
 """Joint-velocity limits on the torque-MPC family (round-2 verdict, Missing 3): ``builder.enforce_model_limits(name, time_deriv=1)``
 (builder.py:471-509) on the problem of examples/torque_mpc.py.  The velocities are states of this family, so the rows dq_t - vlo >= 0,
-vup - dq_t >= 0 are stage-local: they join the effort rows in the augmented Lagrangian of k_tq_eval (oh_torque_desc.dq_lo / dq_up).
-Checked against the numpy port (oracle/torque.py:solve_torque_lm(vlimits=...)), the reference-form KKT conditions on the literal layout
+vup - dq_t >= 0 are stage-local: they join the effort rows under the barrier of k_tq_eval3 (oh_torque_desc.vel_limits / dq_lo / dq_up).
+Checked against the numpy port (oracle/torque_ipm.py:solve_torque_ipm(vlimits=...)), the augmented-Lagrangian machine of rounds 1-3
+(oracle/torque.py:solve_torque_lm(vlimits=...), an independent second algorithm), the reference-form KKT conditions on the literal layout
 (oracle/problems.py:TorqueMPCNLP(vlimits=...): 840 variables, 1680 + 420 rows at T = 30), through HIPSolver and on a batch."""
 import os
 import sys
@@ -16,6 +17,7 @@ from oracle.problems import TorqueMPCNLP
 from oracle.robot import OracleRobot
 from oracle.solvers import kkt_reference_form
 from oracle.torque import TorqueProblem, solve_torque_lm
+from oracle.torque_ipm import solve_torque_ipm
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from examples.torque_mpc import build_problem, figure_eight_goal  # noqa: E402
@@ -43,7 +45,7 @@ def test_velocity_limited_torque_mpc_through_hipsolver_port_and_literal_kkt(hip_
     st = solver.stats()
     assert solver.did_solve(), st
     dQ = np.asarray(sol["med7/dq"])
-    assert np.abs(dQ).max() <= VMAX + 1e-8 and np.abs(dQ).max() >= VMAX - 1e-6 and np.abs(sol["tau/y"]).max() <= eff + 1e-8
+    assert np.abs(dQ).max() < VMAX and np.abs(dQ).max() >= VMAX - 1e-5 and np.abs(sol["tau/y"]).max() < eff  # interior
     med7 = OracleRobot(MED7_KIN)
     prob = TorqueProblem(med7, LINK, T=T, dt=dt, tau_lim=eff, **W)
     nlp = TorqueMPCNLP(prob, vlimits=(-vl, vl))
@@ -55,17 +57,19 @@ def test_velocity_limited_torque_mpc_through_hipsolver_port_and_literal_kkt(hip_
     xr = x + rng.normal(0, 0.05, x.shape)
     assert np.abs(opt.k(xr, p) - nlp.k(xr, po)).max() <= 1e-12 and np.array_equal(opt.dk(xr, p), nlp.dk(xr, po))  # same rows, same order
     assert abs(nlp.f(x, po) - st["f"][0]) <= 1e-9 * st["f"][0] and np.abs(nlp.a(x, po)).max() <= 1e-12 and np.abs(nlp.h(x, po)).max() <= 1e-10
-    assert nlp.k(x, po).min() >= -1e-8
-    k = kkt_reference_form(nlp, x, po, active_tol=1e-6)
-    assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-8 and k["complementarity"] <= 1e-6, k
-    s = solve_torque_lm(prob, QC, np.zeros(7), goal.T, vlimits=(-vl, vl), max_iter=600)
-    free = solve_torque_lm(prob, QC, np.zeros(7), goal.T)
-    assert s["status"] == 0 and abs(s["f"] - st["f"][0]) <= 1e-8 * s["f"] and s["f"] > 1.5 * free["f"] and np.abs(free["dQ"]).max() > 2 * VMAX
-    assert abs(int(st["iterations"][0]) - s["iters"]) <= max(3, s["iters"] // 4), (st["iterations"][0], s["iters"])
+    assert nlp.k(x, po).min() > 0.0
     lam = solver.backend.multipliers(1)[0]
-    assert lam.shape == (T, 28) and lam.min() >= 0.0
-    assert np.abs(lam[:, 14:] - s["lam_v"]).max() <= 1e-3 * max(1.0, s["lam_v"].max()) and ((lam[:, 14:] > 1e-9) == (s["lam_v"] > 1e-9)).mean() >= 0.99
-    assert np.abs(lam[:, :14] - s["lam"]).max() <= 1e-3 * max(1.0, s["lam"].max())
+    assert lam.shape == (T, 28) and lam.min() > 0.0
+    k = kkt_reference_form(nlp, x, po, lam_kg=np.concatenate([lam[:, 7 * i:7 * i + 7].reshape(-1) for i in range(4)]))  # the multipliers that came with x
+    assert k["stationarity"] <= 1e-6 and k["feasibility"] <= 1e-10 and k["complementarity"] <= 1e-8, k
+    s = solve_torque_ipm(prob, QC, np.zeros(7), goal.T, vlimits=(-vl, vl), max_iter=600)  # the port: same state machine
+    assert s["status"] == 0 and abs(s["f"] - st["f"][0]) <= 1e-9 * s["f"] and abs(int(st["iterations"][0]) - s["iters"]) <= 2, (st["iterations"][0], s["iters"])
+    assert np.abs(lam - s["lam"]).max() <= 1e-5 * max(1.0, s["lam"].max())
+    al = solve_torque_lm(prob, QC, np.zeros(7), goal.T, vlimits=(-vl, vl), max_iter=600)  # the independent second machine
+    free = solve_torque_lm(prob, QC, np.zeros(7), goal.T)
+    assert al["status"] == 0 and abs(al["f"] - st["f"][0]) <= 1e-7 * al["f"] and al["f"] > 1.5 * free["f"] and np.abs(free["dQ"]).max() > 2 * VMAX
+    act = al["lam_v"] > 1e-6  # rows the augmented Lagrangian holds active carry the same multipliers
+    assert act.sum() >= 5 and np.abs(lam[:, 14:][act] - al["lam_v"][act]).max() <= 1e-3 * max(1.0, al["lam_v"].max())
 
 
 def test_batch_with_velocity_limits_properties_and_scalar_equivalence(hip_lib):
@@ -80,15 +84,14 @@ def test_batch_with_velocity_limits_properties_and_scalar_equivalence(hip_lib):
     x0[:, : 7 * T] = np.tile(qc, (1, T))
     r = be.solve(x0, p)
     ok = r.status == 0
-    # (velocity and effort rows binding together make the outer loop slow: p50 134 steps, and an instance in 500 is not through after 1000 --
-    #  reported as MAX_ITER, never as converged; at +-0.4 rad/s it is 1 %)
+    # (round 3, augmented Lagrangian: p50 134 steps and an instance in 500 not through after 1000; the interior point brings every one home)
     assert ok.mean() >= 0.99, ok.mean()
     dQ = r.x[:, 7 * T : 14 * T]
     tau = r.x[:, 21 * T :]
-    assert np.abs(dQ[ok]).max() <= 0.5 + 1e-8 and np.abs(tau[ok]).max() <= 58.0 + 1e-8 and (np.abs(dQ[ok]).max(1) >= 0.5 - 1e-6).mean() > 0.8
-    assert (r.kkt[ok, 0] <= 1e-6).all() and (r.kkt[ok, 1] <= 1e-9).all()
+    assert np.abs(dQ[ok]).max() < 0.5 and np.abs(tau[ok]).max() < 58.0 and (np.abs(dQ[ok]).max(1) >= 0.5 - 1e-5).mean() > 0.8
+    assert (r.kkt[ok, 0] <= 1e-6).all() and (r.kkt[ok, 1] == 0.0).all() and (r.kkt[ok, 2] <= 1e-8).all()
     lam = be.multipliers(B)
-    assert lam.shape == (B, T, 28) and lam.min() >= 0.0 and (lam[ok][:, :, 14:].max((1, 2)) > 0).mean() > 0.8
+    assert lam.shape == (B, T, 28) and lam.min() > 0.0 and (lam[ok][:, :, 14:].max((1, 2)) > 1e-3).mean() > 0.8
     for b in (0, 17, 300):  # an instance alone = the same instance in the batch, bit for bit
         a = be.solve(x0[b : b + 1], p[b : b + 1])
         assert np.array_equal(a.x[0], r.x[b]) and a.iters[0] == r.iters[b] and a.f[0] == r.f[b]
@@ -96,6 +99,6 @@ def test_batch_with_velocity_limits_properties_and_scalar_equivalence(hip_lib):
     med7 = OracleRobot(MED7_KIN)
     nlp = TorqueMPCNLP(TorqueProblem(med7, LINK, T=T, dt=0.1, tau_lim=58.0, **W), vlimits=(-0.5, 0.5))
     for b in np.flatnonzero(ok)[:3]:
-        assert np.abs(nlp.a(r.x[b], p[b])).max() <= 1e-12 and np.abs(nlp.h(r.x[b], p[b])).max() <= 1e-10 and nlp.k(r.x[b], p[b]).min() >= -1e-8
+        assert np.abs(nlp.a(r.x[b], p[b])).max() <= 1e-12 and np.abs(nlp.h(r.x[b], p[b])).max() <= 1e-10 and nlp.k(r.x[b], p[b]).min() > 0.0
         assert abs(nlp.f(r.x[b], p[b]) - r.f[b]) <= 1e-9 * r.f[b]
     be.close()

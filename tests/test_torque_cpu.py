@@ -14,11 +14,18 @@ from conftest import GOLDEN, MED7_KIN, SEED
 from oracle.problems import TorqueMPCNLP
 from oracle.robot import OracleRobot, rnea
 from oracle.solvers import kkt_reference_form
-from oracle.torque import RneaTables, TorqueProblem, costate_gradient, riccati_torque, rnea_batch, rnea_jacobian, solve_torque_lm
+from oracle.torque import (RneaTables, TorqueProblem, costate_gradient, riccati_torque, rnea_batch, rnea_ctau_gradient, rnea_ctau_hessian, rnea_jacobian,
+                           rnea_virtual_work, solve_torque_lm)
+from oracle.torque_ipm import position_curvature, solve_torque_ipm
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 LINK = "lbr_link_ee"
+
+
+def _k_order(lam):
+    """(T, 14 | 28) multipliers per knot [lo; up; (vlo; vup)] -> the row order of k = [vec(TAU) - lo; up - vec(TAU); (vec(dQ) - vlo; vup - vec(dQ))]."""
+    return np.concatenate([lam[:, 7 * i:7 * i + 7].reshape(-1) for i in range(lam.shape[1] // 7)])
 
 
 @pytest.fixture(scope="module")
@@ -148,15 +155,20 @@ def test_port_reaches_the_optimum_two_independent_solvers_find(med7, golden):
     for tag in ("t6", "t6lim"):
         lim = float(g[tag + "_lim"])
         prob = TorqueProblem(med7, LINK, T=6, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=None if lim > 1e8 else lim)
-        r = solve_torque_lm(prob, g[tag + "_qc"][0], np.zeros(7), g[tag + "_goal"][0])
+        r = solve_torque_ipm(prob, g[tag + "_qc"][0], np.zeros(7), g[tag + "_goal"][0])
         assert r["status"] == 0 and abs(r["f"] - g[tag + "_f"][0]) < 1e-10 * max(1.0, r["f"])
         assert abs(r["f"] - g[tag + "_f_trust_constr"][0]) < 1e-7 * max(1.0, r["f"])
+        # the augmented-Lagrangian machine of rounds 1-3: a second algorithm on the same stage form (its optimum sits ON the active bounds, the
+        # interior point's n_active mu_b = O(1e-8) inside them)
+        al = solve_torque_lm(prob, g[tag + "_qc"][0], np.zeros(7), g[tag + "_goal"][0])
+        assert al["status"] == 0 and abs(al["f"] - g[tag + "_f_al"][0]) < 1e-10 * al["f"] and abs(al["f"] - r["f"]) < 1e-8 * r["f"] and al["f"] <= r["f"] + 1e-10 * r["f"]
         if lim > 1e8:
             assert abs(r["f"] - g[tag + "_f_lbfgs"][0]) < 1e-8 * max(1.0, r["f"])
     # T = 30, nominal instance: the committed optimum is reproduced, and it is the L-BFGS-B optimum
     prob = TorqueProblem(med7, LINK, T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4)
-    r = solve_torque_lm(prob, g["t30_qc"][0], np.zeros(7), g["t30_goal"][0])
+    r = solve_torque_ipm(prob, g["t30_qc"][0], np.zeros(7), g["t30_goal"][0])
     assert r["status"] == 0 and r["iters"] == int(g["t30_iters"][0])
+    assert np.all(np.abs(g["t30_f"] - g["t30_f_al"]) < 1e-8 * g["t30_f"]) and np.all(np.abs(g["t30lim_f"] - g["t30lim_f_al"]) < 1e-8 * g["t30lim_f"])
     assert abs(r["f"] - g["t30_f"][0]) < 1e-10 * r["f"]
     assert np.all(np.abs(g["t30_f"] - g["t30_f_lbfgs"]) < 1e-8 * g["t30_f"])
     # with the effort rows active (L-BFGS-B cannot take them): SLSQP on the problem reduced to the control sequence, 420 inequality rows with
@@ -171,10 +183,11 @@ def test_golden_points_satisfy_the_kkt_conditions_in_reference_form(med7, golden
     nlp = TorqueMPCNLP(prob)
     x, p = g["t30lim_x"][0], nlp.pack_p(g["t30lim_qc"][0], np.zeros(7), g["t30lim_goal"][0])
     assert np.abs(nlp.a(x, p)).max() < 1e-12 and np.abs(nlp.h(x, p)).max() < 1e-10
-    k = kkt_reference_form(nlp, x, p, active_tol=1e-7)
-    assert k["stationarity"] < 1e-6 and k["feasibility"] < 1e-8 and k["complementarity"] < 1e-6
+    # an interior-point answer comes with its multipliers (lam_i s_i = mu_b): the conditions are tested with them, nothing is fitted to an active set
+    k = kkt_reference_form(nlp, x, p, lam_kg=_k_order(g["t30lim_lam"][0]))
+    assert k["stationarity"] < 1e-6 and k["feasibility"] <= 1e-10 and k["complementarity"] < 1e-8
     lam = g["t30lim_lam"][0]
-    assert lam.max() > 0.0 and np.abs(np.abs(nlp.split(x)[3]).max() - float(g["t30lim_lim"])) < 1e-8  # an effort row is active
+    assert lam.max() > 0.0 and np.abs(np.abs(nlp.split(x)[3]).max() - float(g["t30lim_lim"])) < 1e-6  # an effort row is active (interior: mu_b / lam inside the bound)
 
 
 def test_builder_layout_and_lowering_of_the_product():
@@ -245,3 +258,54 @@ def test_velocity_limits_builder_rows_lowering_port_and_literal_kkt(med7):
     assert np.abs(nlp.a(x, p)).max() < 1e-12 and np.abs(nlp.h(x, p)).max() < 1e-10 and nlp.k(x, p).min() > -1e-8 and abs(nlp.f(x, p) - s["f"]) < 1e-9 * s["f"]
     k = kkt_reference_form(nlp, x, p, active_tol=1e-6)
     assert k["stationarity"] < 1e-5 and k["feasibility"] < 1e-8 and k["complementarity"] < 1e-6, k
+
+
+def test_second_derivatives_of_the_inverse_dynamics(med7):
+    """oracle.torque.rnea_ctau_hessian (the Lagrangian Hessian's share of the dynamics rows, optimization.py:8-24): the virtual-work form equals
+    c^T rnea of the literal recursion, its hand-written adjoint equals J^T c of the complex-step Jacobian (two mechanisms that share no code), and
+    the complex-step Hessian of that gradient is symmetric, zero in the ddq-ddq block and equal to central differences of J^T c."""
+    tb = RneaTables(med7)
+    rng = np.random.default_rng(SEED + 40)
+    q, qd, qdd, c = (rng.normal(size=(6, 7)) for _ in range(4))
+    tau = rnea_batch(tb, q, qd, qdd)
+    assert np.abs(rnea_virtual_work(tb, q, qd, qdd, c) - np.sum(c * tau, -1)).max() < 1e-12
+    J = rnea_jacobian(tb, q, qd, qdd)
+    g = rnea_ctau_gradient(tb, q, qd, qdd, c)
+    assert np.abs(g - np.einsum("ti,tid->td", c, J)).max() < 1e-11
+    H = rnea_ctau_hessian(tb, q, qd, qdd, c)
+    assert np.abs(H - np.swapaxes(H, 1, 2)).max() == 0.0 and np.abs(H[:, 14:, 14:]).max() == 0.0 and np.abs(H[:, 7:14, 14:]).max() < 1e-13
+    z, h = np.concatenate([q, qd, qdd], 1), 1e-6
+    for d in range(21):
+        zp, zm = z.copy(), z.copy()
+        zp[:, d] += h
+        zm[:, d] -= h
+        col = (np.einsum("ti,tid->td", c, rnea_jacobian(tb, zp[:, :7], zp[:, 7:14], zp[:, 14:])) - np.einsum("ti,tid->td", c, rnea_jacobian(tb, zm[:, :7], zm[:, 7:14], zm[:, 14:]))) / (2 * h)
+        assert np.abs(col - H[:, :, d]).max() < 1e-6 * max(1.0, np.abs(H).max())
+    # curvature of the tracking term: closed form against central differences of Jp^T r
+    prob = TorqueProblem(med7, LINK, T=6, dt=0.1)
+    Q, r = rng.uniform(-1, 1, (6, 7)), rng.normal(size=(6, 3))
+    K = position_curvature(prob.chain, Q, r)
+    for d in range(7):
+        Qp, Qm = Q.copy(), Q.copy()
+        Qp[:, d] += h
+        Qm[:, d] -= h
+        col = (np.einsum("tki,tk->ti", prob.chain.jac(Qp)[2], r) - np.einsum("tki,tk->ti", prob.chain.jac(Qm)[2], r)) / (2 * h)
+        assert np.abs(col - K[:, :, d]).max() < 1e-8
+
+
+def test_interior_point_port_properties(med7, golden):
+    """oracle/torque_ipm.py on the golden instance with binding effort rows: strictly interior, on the central path (lam_i s_i = mu_b <= 1e-8 on
+    every row), Euler / dynamics rows exact, reference-form KKT on the literal layout, same optimum as the augmented-Lagrangian machine."""
+    g = golden
+    lim = float(g["t30lim_lim"])
+    prob = TorqueProblem(med7, LINK, T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=lim)
+    nlp = TorqueMPCNLP(prob)
+    qc, goal = g["t30lim_qc"][0], g["t30lim_goal"][0]
+    r = solve_torque_ipm(prob, qc, np.zeros(7), goal)
+    assert r["status"] == 0 and r["iters"] == int(g["t30lim_iters"][0]) and r["stat"] <= 1e-6 and r["mu_b"] <= 1e-8
+    assert r["s"].min() > 0.0 and np.abs(r["lam"] * r["s"] - r["mu_b"]).max() < 1e-20
+    assert (r["s"] < 1e-5).sum() >= 3  # rows at their bounds
+    x, p = nlp.join(r["Q"], r["dQ"], r["U"], r["tau"]), nlp.pack_p(qc, np.zeros(7), goal)
+    assert np.abs(nlp.a(x, p)).max() < 1e-12 and np.abs(nlp.h(x, p)).max() < 1e-10 and nlp.k(x, p).min() > 0.0
+    k = kkt_reference_form(nlp, x, p, lam_kg=_k_order(r["lam"]))
+    assert k["stationarity"] < 1e-6 and k["feasibility"] <= 1e-10 and k["complementarity"] < 1e-8, k

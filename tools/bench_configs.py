@@ -66,12 +66,15 @@ def oracle_grade(kind, **kw):
 
         prob = TorqueProblem(OracleRobot(os.path.join(R, "med7.kin.json")), "lbr_link_ee", T=kw["T"], dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=kw["lim"])
         nlp = TorqueMPCNLP(prob)
-        ks = [kkt_reference_form(nlp, x, p, active_tol=1e-6) for x, p in zip(kw["x"], kw["p"])]
+        # an interior-point answer is graded with the multipliers it came with (lam_i = mu_b / s_i per knot [lo; up] -> the row order of k)
+        lks = [np.concatenate([l[:, :7].reshape(-1), l[:, 7:].reshape(-1)]) for l in kw["lam"]]
+        ks = [kkt_reference_form(nlp, x, p, lam_kg=lk) for x, p, lk in zip(kw["x"], kw["p"], lks)]
         return {"instances": len(ks), "stationarity_max": max(k["stationarity"] for k in ks), "feasibility_max": max(k["feasibility"] for k in ks),
-                "complementarity_max": max(k["complementarity"] for k in ks), "linear_rows_max": float(max(np.abs(nlp.a(x, p)).max() for x, p in zip(kw["x"], kw["p"]))),
+                "complementarity_max": max(k["complementarity"] for k in ks), "inequality_rows_min": float(min(nlp.k(x, p).min() for x, p in zip(kw["x"], kw["p"]))),
+                "linear_rows_max": float(max(np.abs(nlp.a(x, p)).max() for x, p in zip(kw["x"], kw["p"]))),
                 "dynamics_rows_max": float(max(np.abs(nlp.h(x, p)).max() for x, p in zip(kw["x"], kw["p"]))),
                 "objective_recomputed_max_rel_diff": float(max(abs(nlp.f(x, p) - f) / abs(f) for x, p, f in zip(kw["x"], kw["p"], kw["f"]))),
-                "by": "oracle/solvers.py:kkt_reference_form on oracle/problems.py:TorqueMPCNLP (literal 840-variable / 1680-row layout, RNEA rows by the literal recursion)"}
+                "by": "oracle/solvers.py:kkt_reference_form on oracle/problems.py:TorqueMPCNLP (literal 840-variable / 1680-row layout, RNEA rows by the literal recursion), with the multipliers returned by oh_get_multipliers"}
     elif kind == "fig8_vel":
         from oracle.problems import LimitedFigureEightNLP
 
@@ -252,9 +255,11 @@ def _torque(out, rng, sample, torque_batches):
         x0 = np.zeros((B, 4 * 7 * T))
         x0[:, : 7 * T] = np.tile(qc, (1, T))
         be = TorqueBackend(med7.kinematic_chain(link), med7.dynamics_tables(), T=T, dt=dt, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=-58.0, tau_up=58.0, max_iter=600)
-        r, smp = timed_with_results(be, x0, p, sample=(min(sample, 4) if B == torque_batches[0] else 0), seed=5, reps=1 if B > 1 else 5)
+        r, smp = timed_with_results(be, x0, p, sample=(min(sample, 4) if B > 1 else 1), seed=5, reps=1 if B > 1 else 5)
         tm = be.timing()
-        out[f"config5_torque_b{B}"] = {"what": f"torque MPC, RNEA dynamics equality rows + effort limits 58 N m (med7, T=30), B = {B}" + (" (the nominal instance)" if B == 1 else ""),
+        if smp:
+            smp["lam"] = be.multipliers(B)[smp["idx"]]
+        out[f"config5_torque_b{B}"] = {"what": f"torque MPC, RNEA dynamics equality rows + effort limits 58 N m (med7, T=30), primal-dual interior point, B = {B}" + (" (the nominal instance)" if B == 1 else ""),
                                        "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, "iterations_launched": tm["iterations_launched"], **r,
                                        "oracle_sample": oracle_grade("torque", T=T, lim=58.0, **smp) if smp else None}
         be.close()

@@ -303,8 +303,11 @@ def torque_golden(slow=True):
             qc = qn + (rng.uniform(-0.1, 0.1, 7) if i else 0.0)
             goal = prob.goal_figure_eight(qc)
             t0 = time.time()
-            r = solve_torque_lm(prob, qc, np.zeros(7), goal)
+            r = solve_torque_ipm(prob, qc, np.zeros(7), goal)
             assert r["status"] == 0
+            al = solve_torque_lm(prob, qc, np.zeros(7), goal)
+            assert al["status"] == 0 and abs(al["f"] - r["f"]) < 1e-8 * r["f"], (al["f"], r["f"])
+            g.setdefault(tag + "_f_al", np.zeros(len(g[tag + "_qc"])))[i] = al["f"]
             x = nlp.join(r["Q"], r["dQ"], r["U"], r["tau"])
             k = kkt_reference_form(nlp, x, nlp.pack_p(qc, np.zeros(7), goal))
             assert k["stationarity"] < 1e-6 and k["feasibility"] < 1e-8, k
@@ -391,9 +394,12 @@ def torque_golden_add_slsqp():
 
 def torque_golden_refresh_port():
     """Re-run only the numpy port on the stored instances of torque_golden.npz (after a change to its state machine): x, f, iters, lam are
-    replaced, the independent solvers' objectives (L-BFGS-B, trust-constr: ~20 minutes to regenerate) are kept and must still agree."""
+    replaced, the independent solvers' objectives (L-BFGS-B, trust-constr: ~20 minutes to regenerate) are kept and must still agree.
+    Round 4: the port is the interior point of oracle/torque_ipm.py; the augmented-Lagrangian machine of rounds 1-3 (oracle/torque.py:solve_torque_lm)
+    joins the independent solvers as "_f_al"."""
     from oracle.problems import TorqueMPCNLP
     from oracle.torque import TorqueProblem, solve_torque_lm
+    from oracle.torque_ipm import solve_torque_ipm
 
     rob = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "med7.kin.json"))
     path = os.path.join(G, "torque_golden.npz")
@@ -404,8 +410,11 @@ def torque_golden_refresh_port():
         prob = TorqueProblem(rob, "lbr_link_ee", T=T, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=None if lim > 1e8 else lim)
         nlp = TorqueMPCNLP(prob)
         for i, (qc, goal) in enumerate(zip(g[tag + "_qc"], g[tag + "_goal"])):
-            r = solve_torque_lm(prob, qc, np.zeros(7), goal)
+            r = solve_torque_ipm(prob, qc, np.zeros(7), goal)
             assert r["status"] == 0
+            al = solve_torque_lm(prob, qc, np.zeros(7), goal)
+            assert al["status"] == 0 and abs(al["f"] - r["f"]) < 1e-8 * r["f"], (al["f"], r["f"])
+            g.setdefault(tag + "_f_al", np.zeros(len(g[tag + "_qc"])))[i] = al["f"]
             x = nlp.join(r["Q"], r["dQ"], r["U"], r["tau"])
             k = kkt_reference_form(nlp, x, nlp.pack_p(qc, np.zeros(7), goal))
             assert k["stationarity"] < 1e-6 and k["feasibility"] < 1e-8, k
@@ -416,7 +425,7 @@ def torque_golden_refresh_port():
                 if np.isfinite(fo):
                     assert abs(fo - r["f"]) < 1e-7 * max(1.0, r["f"]), (tag, i, other, fo, r["f"])
             print("torque", tag, i, "port", r["f"], "was", float(g[tag + "_f"][i]), "iters", r["iters"], "was", int(g[tag + "_iters"][i]), "kkt", k["stationarity"])
-            g[tag + "_x"][i], g[tag + "_f"][i], g[tag + "_iters"][i], g[tag + "_lam"][i] = x, r["f"], r["iters"], r["lam"]
+            g[tag + "_x"][i], g[tag + "_f"][i], g[tag + "_iters"][i], g[tag + "_lam"][i] = x, r["f"], r["iters"], r["lam"][:, :14]
     np.savez(path, **g)
 
 
@@ -568,7 +577,7 @@ def ipm_configs_golden(only=None):
 
     path = os.path.join(G, "ipm_configs_golden.npz")
     out = dict(np.load(path)) if os.path.exists(path) else {}
-    parts = only or ("dual", "t6", "t6lim")
+    parts = only or ("dual", "t6", "t6lim")  # round 4: "t30", "t30lim" = config 5 at its BASELINE size (840 variables, 1680 rows; exact Lagrangian Hessian)
     kin = os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json")
     if "dual" in parts:
         rl = OracleRobot(kin, name="kukal")
@@ -585,19 +594,21 @@ def ipm_configs_golden(only=None):
         np.savez(path, **out)
     med7 = OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "med7.kin.json"))
     g = np.load(os.path.join(G, "torque_golden.npz"))
-    for tag in ("t6", "t6lim"):
+    for tag in ("t6", "t6lim", "t30", "t30lim"):
         if tag not in parts:
             continue
         lim = float(g[tag + "_lim"])
-        prob = TorqueProblem(med7, "lbr_link_ee", T=6, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=None if lim > 1e8 else lim)
+        prob = TorqueProblem(med7, "lbr_link_ee", T=g[tag + "_goal"].shape[1], dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=None if lim > 1e8 else lim)
         nlp = TorqueMPCNLP(prob)
         fs, its, ok = [], [], []
         for b in range(len(g[tag + "_qc"])):
             pb = nlp.pack_p(g[tag + "_qc"][b], np.zeros(7), g[tag + "_goal"][b])
             t0 = time.time()
-            r = solve_ipm(nlp, nlp.seed(g[tag + "_qc"][b]), pb, max_iter=500)
+            r = solve_ipm(nlp, nlp.seed(g[tag + "_qc"][b]), pb, max_iter=3000 if tag.startswith("t30") else 500)
             print("config 5", tag, b, r["status"], r["iters"], r["f"], "golden", g[tag + "_f"][b], round(time.time() - t0), "s", flush=True)
             fs.append(r["f"]); its.append(r["iters"]); ok.append(r["status"] == "optimal")
+            if tag.startswith("t30"):
+                out.setdefault(f"tq_{tag}_x", np.zeros((len(g[tag + "_qc"]), nlp.nx)))[b] = r["x"]
         out.update({f"tq_{tag}_f": np.array(fs), f"tq_{tag}_iters": np.array(its), f"tq_{tag}_optimal": np.array(ok)})
         np.savez(path, **out)
 

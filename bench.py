@@ -294,6 +294,8 @@ def main():
     if comm is not None:
         comm.broadcast_constants(be.handle, root=0)  # the one collective of the whole job
         rccl_world = comm.info()[1]  # ncclCommCount: the communicator the constants travelled over spans this many ranks
+        if rccl_world != world:  # a job whose collective did not span every rank would report N GPUs and measure fewer
+            raise SystemExit(f"bench.py: RCCL communicator spans {rccl_world} ranks, WORLD_SIZE is {world}")
 
     B = args.batch
     x0, qc = make_inputs(B, rank)
@@ -331,7 +333,9 @@ def main():
     if comm is not None:
         mine = elapsed
         elapsed = comm.max_over_ranks(mine)
+        dev = solve_ms_plain / args.steps  # this rank's own HIP-event time of one step: rank skew shows as max - min
         per_rank = {"elapsed_s_max": elapsed, "elapsed_s_min": -comm.max_over_ranks(-mine),
+                    "device_ms_per_step_max": comm.max_over_ranks(dev), "device_ms_per_step_min": -comm.max_over_ranks(-dev),
                     "sum_of_rank_rates_solves_per_s": comm.sum_over_ranks(B * args.steps / mine),
                     "note": "each rank's own wall time of the K steps between the two barriers, reduced through oh_comm_allreduce_{max,sum}; value uses the max"}
     # second pass of the same K steps with one hipEventRecord after every kernel on the handle's stream: the per-kernel times behind the

@@ -600,6 +600,26 @@ class GuardedDualArmNLP(DualArmNLP):
                 M[k * per + t * rows : k * per + (t + 1) * rows, k * self.nx1 + n * t : k * self.nx1 + n * (t + 1)] = d[t]
         return M
 
+    def hess_lagrangian_v(self, x, p, sigma, lam_v):
+        """DualArmNLP's sigma d2f plus the curvature of the sphere rows, sum_i lam_g[i] d2 g_i (g = ||c_l(q_t) - o||^2 - (r_l + r_o)^2,
+        builder.py:407-415; d2 g = 2 J^T J + 2 sum_k d_k d2 c_k from oracle.guarded.guard_values): what the reference's AD hands nlpsol.  The rows
+        k and a are linear.  Round 4, for the interior-point goldens of config 4 at its BASELINE size (tools/make_golden.py --ipm-config4)."""
+        from .guarded import guard_values
+
+        H = super().hess_lagrangian_v(x, p[: 2 * self.n], sigma, lam_v)
+        if self.ng:
+            n, T = self.n, self.T
+            s = self.split(x)
+            per = T * len(self.links) * self.n_obs
+            lam_g = np.asarray(lam_v[self.nk : self.nk + self.ng], float)
+            for k, arm in enumerate(("l", "r")):
+                w = lam_g[k * per : (k + 1) * per].reshape(T, -1)
+                HW = guard_values(self.chains[arm], s[arm][0].T, self._guards(p, k), weights=w)[2]
+                base = k * self.nx1
+                for t in range(T):
+                    H[base + n * t : base + n * t + n, base + n * t : base + n * t + n] += HW[t]
+        return H
+
     def a(self, x, p):
         b = np.zeros(self.na)
         b[: 2 * self.n] = p[: 2 * self.n]

@@ -162,6 +162,36 @@ def test_bench_dry_run_under_a_two_process_launch(tmp_path, mode):
     assert a["qc_first"] != b["qc_first"]
 
 
+def test_bench_dry_run_under_an_eight_process_launch(tmp_path):
+    """The launch the driver makes on an 8-GPU node (round-3 verdict, Next 7): eight ranks rendezvous on one id, every rank gets its own contiguous
+    shard of the batch, nothing but the rendezvous runs (no oracle / CPU-baseline leg on any rank: the dry run prints within seconds)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    t0 = time.time()
+    procs = []
+    for r in (7, 3, 5, 1, 6, 2, 4, 0):  # rank 0 last: the others wait for the id it publishes
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OPTAS_RDZV="tcp", OPTAS_RDZV_DIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err.decode()[-2000:]
+        outs.append(json.loads(out.decode().strip().splitlines()[-1]))
+    outs.sort(key=lambda o: o["rank"])
+    assert [o["rank"] for o in outs] == list(range(8)) and all(o["world"] == 8 and o["dry_run"] for o in outs)
+    assert len({o["id_sha256"] for o in outs}) == 1  # one communicator id
+    assert len({tuple(o["qc_first"]) if isinstance(o["qc_first"], list) else o["qc_first"] for o in outs}) == 8  # eight different shards
+    assert time.time() - t0 < 120
+
+
 def test_communicator_needs_a_gpu_and_says_so():
     """No CPU path: without a device the communicator entry points return an error code and a message."""
     from optas_amd import _lib

@@ -613,6 +613,50 @@ def ipm_configs_golden(only=None):
         np.savez(path, **out)
 
 
+
+def _ipm_config4_one(args):
+    i, qcl, qcr, radius, T = args
+    import time as _t
+
+    from examples.dual_arm import SPHERE_LINKS
+    from oracle.ipm_reference_form import solve_ipm
+    from oracle.problems import GuardedDualArmNLP
+
+    kin = os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json")
+    rl = OracleRobot(kin, name="kukal")
+    rl.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
+    rr = OracleRobot(kin, name="kukar")
+    rr.add_base_frame("global_world", xyz=[0.0, 0.25, 0.0])
+    nlp = GuardedDualArmNLP(rl, rr, SPHERE_LINKS, 6, T=T)
+    obs = np.concatenate([[0.55, 0.0, 0.1 * (j + 1), 0.1] for j in range(6)])
+    p = np.concatenate([qcl, qcr, np.full(4, radius), obs, np.full(4, radius), obs])
+    x0 = np.zeros(nlp.nx)
+    for k, qc in enumerate((qcl, qcr)):
+        x0[k * nlp.nx1 : k * nlp.nx1 + 7 * T] = np.tile(qc, T)
+    t0 = _t.time()
+    r = solve_ipm(nlp, x0, p, max_iter=3000)
+    k = kkt_reference_form(nlp, r["x"], p, active_tol=1e-6)
+    print(f"config 4 synthetic {i}: {r['status']} it={r['iters']} f={r['f']:.12f} E0={r['E0']:.1e} kkt=({k['stationarity']:.1e}, {k['feasibility']:.1e}, "
+          f"{k['complementarity']:.1e}) {round(_t.time() - t0)} s", flush=True)
+    return p, r["x"], r["f"], r["iters"], r["status"] == "optimal", np.array([k["stationarity"], k["feasibility"], k["complementarity"]])
+
+
+def ipm_config4_golden(n_dual=2, T=100, radius=0.15, workers=2):
+    """oracle/ipm_reference_form.py (the reference's algorithm class on the reference's form, exact Lagrangian Hessian) on BASELINE config 4 at its
+    stated size: dual_arm.py with T = 100, enforce_model_limits and sphere_collision_avoidance_constraints on both arms (4 links x 6
+    obstacles, link radius 0.15): 2786 variables, 13 200 rows of v per dual-arm instance, seed Q = qc at every knot (what the GPU tests and bench.py
+    seed).  n_dual dual-arm instances = 2 n_dual arm solves; ~1 hour of CPU.  -> tests/golden/ipm_config4_golden.npz"""
+    import multiprocessing as mp
+
+    rng = np.random.default_rng(SEED + 44)
+    QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
+    jobs = [(i, QC + rng.uniform(-0.1, 0.1, 7), QC + rng.uniform(-0.1, 0.1, 7), radius, T) for i in range(n_dual)]
+    with mp.Pool(workers) as pool:
+        rows = pool.map(_ipm_config4_one, jobs, chunksize=1)
+    keys = ("p", "x", "f", "iters", "optimal", "kkt")
+    np.savez(os.path.join(G, "ipm_config4_golden.npz"), T=T, radius=radius, **{k: np.array([row[j] for row in rows]) for j, k in enumerate(keys)})
+
+
 def ipm_limits_golden():
     """oracle/ipm_reference_form.py from the reference's seeds on the problems with joint-velocity limit rows (enforce_model_limits(name, time_deriv=1),
     builder.py:471-509) that round 3 lowered: figure_eight_plan.py + the LWR's own velocity limits (T = 50, 693 variables, 1114 + 686 rows; the
@@ -684,6 +728,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--ipm-limits" in sys.argv:
         ipm_limits_golden()
+        sys.exit(0)
+    if "--ipm-config4" in sys.argv:
+        ipm_config4_golden()
         sys.exit(0)
     if "--ipm-configs" in sys.argv:
         ipm_configs_golden([a for a in sys.argv[2:] if not a.startswith("-")] or None)

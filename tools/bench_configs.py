@@ -105,8 +105,28 @@ def oracle_grade(kind, **kw):
             e = ch.fk(Q)[0]
             path = ch.fk(p[None, :7])[0][0][None] + kw["offsets"]
             fdiff = max(fdiff, abs(float(np.sum((e - path) ** 2) + 0.01 * np.sum(dQ**2)) - f))
+        # reference-form KKT on the literal layout (round 4): two arms at a time as one dual-arm instance of oracle/problems.py:GuardedDualArmNLP
+        # (both slots hold the arm of this batch: base (0, -0.25, 0), the left arm's path).  An arm whose pinned initial configuration breaks a
+        # clearance poses an infeasible NLP (rows of knot 0: negative constants, which the kernels skip): counted, not graded.
+        from oracle.problems import GuardedDualArmNLP
+
+        rob2 = OracleRobot(os.path.join(R, "kuka_lwr.kin.json"), name="kukar")
+        rob2.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
+        nlp = GuardedDualArmNLP(rob, rob2, kw["links"], 6, T=T)
+        nlp.offsets = {"l": kw["offsets"].T, "r": kw["offsets"].T}
+        G0 = lambda p: Guards(lo=None, up=None, links=kw["links"], link_radii=p[7:11], obs_pos=p[11:].reshape(6, 4)[:, :3], obs_radii=p[11:].reshape(6, 4)[:, 3])
+        feas0 = [i for i, p in enumerate(kw["p"]) if guard_values(ch, p[None, :7], G0(p))[0].min() >= 0.0]
+        ks = []
+        for a, b in zip(feas0[0::2], feas0[1::2]):
+            x2 = np.concatenate([kw["x"][a], kw["x"][b]])
+            p2 = np.concatenate([kw["p"][a][:7], kw["p"][b][:7], kw["p"][a][7:], kw["p"][b][7:]])
+            assert abs(nlp.f(x2, p2) - (kw["f"][a] + kw["f"][b])) <= 1e-9
+            ks.append(kkt_reference_form(nlp, x2, p2, active_tol=1e-6))
         return {"instances": len(kw["x"]), "inequality_rows_min_violation": worst, "objective_recomputed_max_abs_diff": fdiff,
-                "by": "oracle/guarded.py:guard_values (2 x 7 limit rows + 4 x 6 sphere rows per knot) and the tracking cost recomputed with oracle/structured.py:FoldedChain"}
+                "infeasible_as_posed": len(kw["x"]) - len(feas0), "kkt_graded_arms": 2 * len(ks),
+                "stationarity_max": max((k["stationarity"] for k in ks), default=None), "complementarity_max": max((k["complementarity"] for k in ks), default=None),
+                "by": "oracle/guarded.py:guard_values (2 x 7 limit rows + 4 x 6 sphere rows per knot), the tracking cost recomputed with oracle/structured.py:FoldedChain, and "
+                      "oracle/solvers.py:kkt_reference_form on oracle/problems.py:GuardedDualArmNLP (literal layout, two arms per instance) for the arms whose NLP is feasible as posed"}
     return {"instances": len(ks), "stationarity_max": max(k["stationarity"] for k in ks), "feasibility_max": max(k["feasibility"] for k in ks),
             "complementarity_max": max(k["complementarity"] for k in ks), "by": "oracle/solvers.py:kkt_reference_form on the literal NLP of oracle/problems.py"}
 

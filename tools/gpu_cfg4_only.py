@@ -1,5 +1,12 @@
-import sys, json
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tools')
-from bench_configs import run_configs
-o=run_configs(sample=0, only='config4')
-print({k:(round(v['device_ms'],2), v['iters_max'], v['converged_frac']) for k,v in o.items() if isinstance(v,dict)})
+"""config 4 synthetic only (device time, iterations, oracle-graded sample): python tools/gpu_cfg4_only.py"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_configs import run_configs  # noqa: E402
+
+o = run_configs(sample=8, only="config4")
+for k, v in o.items():
+    print(k, json.dumps({kk: vv for kk, vv in v.items() if kk != "what"}))

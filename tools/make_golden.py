@@ -644,13 +644,33 @@ def _ipm_config4_one(args):
 def ipm_config4_golden(n_dual=2, T=100, radius=0.15, workers=2):
     """oracle/ipm_reference_form.py (the reference's algorithm class on the reference's form, exact Lagrangian Hessian) on BASELINE config 4 at its
     stated size: dual_arm.py with T = 100, enforce_model_limits and sphere_collision_avoidance_constraints on both arms (4 links x 6
-    obstacles, link radius 0.15): 2786 variables, 13 200 rows of v per dual-arm instance, seed Q = qc at every knot (what the GPU tests and bench.py
+    obstacles, link radius 0.15): 2786 variables, 10 400 rows of v per dual-arm instance, seed Q = qc at every knot (what the GPU tests and bench.py
     seed).  n_dual dual-arm instances = 2 n_dual arm solves; ~1 hour of CPU.  -> tests/golden/ipm_config4_golden.npz"""
     import multiprocessing as mp
 
+    from examples.dual_arm import SPHERE_LINKS
+    from oracle.guarded import Guards, guard_values
+    from oracle.structured import FoldedChain
+
     rng = np.random.default_rng(SEED + 44)
     QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
-    jobs = [(i, QC + rng.uniform(-0.1, 0.1, 7), QC + rng.uniform(-0.1, 0.1, 7), radius, T) for i in range(n_dual)]
+    # At radius 0.15 the nominal configuration clears the obstacle column by 1.6e-3 only, and q_0 = qc is pinned (fix_configuration): about half
+    # of the perturbed arms START inside a clearance, which makes the NLP infeasible as posed (its knot-0 sphere rows are negative constants; the
+    # kernels skip them, an interior-point method can only report infeasibility).  The golden instances are drawn among the feasible ones.
+    kin = os.path.join(ROOT, "optas_amd", "robots", "kuka_lwr.kin.json")
+    chains = []
+    for name, y in (("kukal", -0.25), ("kukar", 0.25)):
+        rob = OracleRobot(kin, name=name)
+        rob.add_base_frame("global_world", xyz=[0.0, y, 0.0])
+        chains.append(FoldedChain(rob, "end_effector_ball"))
+    Gd = Guards(lo=None, up=None, links=SPHERE_LINKS, link_radii=np.full(4, radius), obs_pos=np.array([[0.55, 0.0, 0.1 * (j + 1)] for j in range(6)]), obs_radii=np.full(6, 0.1))
+    jobs, drawn = [], 0
+    while len(jobs) < n_dual:
+        qcl, qcr = QC + rng.uniform(-0.1, 0.1, 7), QC + rng.uniform(-0.1, 0.1, 7)
+        drawn += 1
+        if min(guard_values(ch, q[None], Gd)[0].min() for ch, q in zip(chains, (qcl, qcr))) >= 1e-4:
+            jobs.append((len(jobs), qcl, qcr, radius, T))
+    print(f"config 4 goldens: {n_dual} feasible dual-arm instances among the first {drawn} drawn", flush=True)
     with mp.Pool(workers) as pool:
         rows = pool.map(_ipm_config4_one, jobs, chunksize=1)
     keys = ("p", "x", "f", "iters", "optimal", "kkt")

@@ -75,7 +75,7 @@ void oh_launch_pm_advance(hipStream_t s, int B, int T, int advance, const double
 #define TQ_SD_GB 272
 #define TQ_SD_J 296
 #define TQ_LAM 32   // per knot: multipliers of tau - lo >= 0 (N), then of up - tau >= 0 (N); at 16: of dq - dq_lo >= 0 (N), then of dq_up - dq >= 0 (N)
-#define TQ_GN 112   // per knot: gains K (column c of 2N: N values at c N), feed-forward k at 2N N
+#define TQ_GN 128   // per knot: two doubles per lane of k_tq_step (lane 8 r + c: K_q[r][c], K_dq[r][c]; c = 7: k[r], 0)
 struct TqParams {
   int T, N, max_iter;
   double dt, w_path, w_vel, w_tau, tol, tol_compl, mu_b0, mu0;

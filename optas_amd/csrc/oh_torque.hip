@@ -988,74 +988,73 @@ __global__ __launch_bounds__(64, 1) void k_tq_curv(TqParams P, TqBuffers D) {
 }
 
 // ---- step ------------------------------------------------------------------------------------------------------------------------------
-OH_DEV double group_sum(double v) {
+OH_DEV double wave_sum(double v) {
 #pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 16);
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
-OH_DEV double group_max(double v) {
+OH_DEV double wave_max(double v) {
 #pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 16));
+  for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
   return v;
 }
-OH_DEV double group_min(double v) {
+OH_DEV double wave_min(double v) {
 #pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 16));
+  for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64));
+  return v;
+}
+OH_DEV double row_sum8(double v) {  // sum over the 8 lanes of a row (lane = 8 r + c)
+  v += __shfl_xor(v, 1, 8);
+  v += __shfl_xor(v, 2, 8);
+  v += __shfl_xor(v, 4, 8);
   return v;
 }
 
-// 16 lanes per instance (4 instances per wavefront); numpy: oracle/torque_ipm.py:solve_torque_ipm.
+// One wavefront per instance (round 4; rounds 1-3: 16 lanes per instance around a value matrix in LDS, every lane factorising Q_uu for itself, three
+// block barriers per knot -- 105 us per sweep however small the batch).  Lane 8 r + c owns entry (r, c) of every N x N block of the stage matrix
+//     M = H_t + [A^T P A, A^T P B; B^T P A, B^T P B] + mu I_x   over (q, dq | u),
+// column c = 7 holds the vectors.  With A = [[I, dt I], [0, I]], B = [0; dt I] every block of M is an entry-wise combination of the four blocks of P,
+// so forming M needs nothing from another lane; the N pivots of the u rows are then eliminated by Gauss-Jordan steps whose operands travel by lane
+// shuffles (row r of the pivot column, column c of the pivot row): no LDS, no barrier.  What remains in the x rows is the Schur complement
+// P' = Q_xx - Q_ux^T Q_uu^{-1} Q_ux (exactly symmetric: mirrored entries subtract the same product), in the u rows the gains K = Q_uu^{-1} Q_ux and
+// k = Q_uu^{-1} q_u; the pivots are those of the Cholesky factorisation (positive iff Q_uu is positive definite).  The roll-outs and the costate
+// recursion use the same layout: entry-wise work on the lanes that hold it, row sums by three shuffles.  numpy: oracle/torque_ipm.py.
 //   1. merit of the trial  f + mu_b B  and the ratio test against the decrease the damped model predicted for the scaled step; Levenberg-Marquardt update
 //   2. reduced gradient of the accepted point by the costate recursion, for the barrier parameter in force and for the next one
 //   3. convergence / barrier update (the stage gradient is  g_f + mu_b g_b,  the merit  f + mu_b B:  a new mu_b needs no re-evaluation)
-//   4. Riccati sweep with the value matrix P (14 x 14) in LDS, one column per lane; a stage block of the exact Hessian that leaves Q_uu indefinite
-//      raises the damping and the sweep is repeated
+//   4. Riccati sweep; a stage block of the exact Hessian that leaves Q_uu indefinite raises the damping and the sweep is repeated
 //   5. closed-loop rollout of the unit step: the control steps go to LDS, the linearised rows give the fraction to the boundary alpha
 //   6. open-loop rollout of  u + alpha du  on the trial values themselves (the Euler rows hold to the rounding of one operation)
-// A trial that left the domain of the arithmetic is retried with a tenth of the feed-forward: steps 5-6 only.
-#ifndef OH_TQ_STEP_WAVES
-#define OH_TQ_STEP_WAVES 1
-#endif
+// A trial that left the domain of the arithmetic, or a boundary-shortened step that was rejected, is retried shorter: steps 5-6 only.
 template <int N, bool VEL = false>
-__global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, TqBuffers D) {
-  constexpr int NX = 2 * N, NZ = 3 * N, NH = NZ * (NZ + 1) / 2, NU = N * (N + 1) / 2;
-  constexpr int PS = NX + 1;  // row stride of P in LDS
-  constexpr int OFF_P = 256, OFF_PV = OFF_P + NX * PS, OFF_QUX = OFF_PV + 16, OFF_DX = OFF_QUX + N * 16, OFF_DU = OFF_DX + 16, LDS_N = OFF_DU + 8;
-  static_assert(NH + NZ <= 256, "stage block does not fit the LDS window");
-  __shared__ double sm[4][LDS_N];
-  extern __shared__ double du_dyn[];  // [4][T][8]: the control steps of the unit step
-  double (*du_all)[8] = reinterpret_cast<double (*)[8]>(du_dyn) + (size_t)(threadIdx.x >> 4) * P.T;
+__global__ __launch_bounds__(64) void k_tq_step(TqParams P, TqBuffers D) {
+  static_assert(N == 7, "the lane layout is 8 rows x 8 columns: 7 joints and the vector column");
+  constexpr int NX = 2 * N, NZ = 3 * N;
+  extern __shared__ double du_dyn[];  // [T][8]: the control steps of the unit step
   const int T = P.T;
-  const int gi = threadIdx.x >> 4, c = threadIdx.x & 15;
-  const int b_raw = blockIdx.x * 4 + gi;
-  const bool valid = b_raw < D.n_run;
-  const int b = D.list[valid ? b_raw : D.n_run - 1];
-  double* S = sm[gi];
-  double* Hs = S;
-  double* Ps = S + OFF_P;
-  double* pv = S + OFF_PV;
-  double* Quxs = S + OFF_QUX;
-  double* dxs = S + OFF_DX;
-  double* dus = S + OFF_DU;
+  const int lane = threadIdx.x;
+  const int r = lane >> 3, c = lane & 7;
+  const bool mat = r < N && c < N;  // an entry of the N x N blocks
+  const bool vec = r < N && c == N;  // an entry of the vectors
+  if ((int)blockIdx.x >= D.n_run) return;
+  const int b = D.list[blockIdx.x];
+  if (D.status[b] >= 0) return;
   const double dt = P.dt;
-
-  const bool run = valid && D.status[b] < 0;
-  if (!__any(run)) return;
   int cur = D.cur[b];
   const int ts = 1 - cur;
   // 1. merit of the trial point
   double fsum = 0.0, bsum_t = 0.0, nrel_t = 0.0, viol_t = 0.0;
-  for (int t = c; t < T; t += 16) {
+  for (int t = lane; t < T; t += 64) {
     const double* sr = D.st + st_off(D, T, ts, b, t);
     fsum += sr[252];
     bsum_t += sr[253];
     nrel_t += sr[254];
     viol_t = fmax(viol_t, sr[255]);
   }
-  fsum = group_sum(fsum);
-  bsum_t = group_sum(bsum_t);
-  nrel_t = group_sum(nrel_t);
-  viol_t = group_max(viol_t);
+  fsum = wave_sum(fsum);
+  bsum_t = wave_sum(bsum_t);
+  nrel_t = wave_sum(nrel_t);
+  viol_t = wave_max(viol_t);
 
   const bool first = D.first[b] != 0;
   double f_cur = D.f_cur[b], f_true = D.f_true[b], bsum = D.bsum[b], mu = D.mu[b], nun = D.nun[b], mub = D.mub[b], alpha = D.alpha[b], viol = D.viol[b];
@@ -1103,36 +1102,38 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
   }
   const int nts = 1 - cur;  // slot of the next trial
 
-  // 2. reduced gradient of the accepted point: gradient of the rolled-out merit w.r.t. u_t by the costate recursion, for mu_b and for its successor
-  // (the serial loops of this kernel walk the T knots in dependent chains: whatever a knot needs from memory is requested one knot ahead)
+  // 2. reduced gradient of the accepted point: gradient of the rolled-out merit w.r.t. u_t by the costate recursion, for mu_b and for its successor.
+  // Entry-wise per joint: lanes (r, 7) carry the costates of q_r and dq_r for the cost and the barrier part; what a knot needs from memory is
+  // requested one knot ahead.
   const double mu_min = 0.1 * P.tol_compl;
   const double mub_next = fmax(mu_min, fmin(P.kappa_mu * mub, pow(mub, P.theta_mu)));
   double stat = 0.0, stat_next = 0.0;
   {
-    double lf = 0.0, lb = 0.0;
-    double gxf_n, gxb_n, guf_n, gub_n;
+    double lfq = 0.0, lfd = 0.0, lbq = 0.0, lbd = 0.0;
+    double g_n[6] = {0, 0, 0, 0, 0, 0};
     auto fetch = [&](const int t) {
-      const double* sr = D.st + st_off(D, T, cur, b, t);
-      gxf_n = c < NX ? sr[231 + c] : 0.0;
-      gxb_n = c < NX ? sr[TQ_SD_GB + c] : 0.0;
-      guf_n = (c >= N && c < NX) ? sr[231 + NX + (c - N)] : 0.0;
-      gub_n = (c >= N && c < NX) ? sr[TQ_SD_GB + NX + (c - N)] : 0.0;
+      if (vec) {
+        const double* sr = D.st + st_off(D, T, cur, b, t);
+        g_n[0] = sr[231 + r]; g_n[1] = sr[231 + N + r]; g_n[2] = sr[231 + NX + r];
+        g_n[3] = sr[TQ_SD_GB + r]; g_n[4] = sr[TQ_SD_GB + N + r]; g_n[5] = sr[TQ_SD_GB + NX + r];
+      }
     };
     fetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
-      const double gxf = gxf_n, gxb = gxb_n, guf = guf_n, gub = gub_n;
+      const double gfq = g_n[0], gfd = g_n[1], gfu = g_n[2], gbq = g_n[3], gbd = g_n[4], gbu = g_n[5];
       if (t > 0) fetch(t - 1);
-      if (c >= N && c < NX) {
-        const double rf = fma(dt, lf, guf), rb = fma(dt, lb, gub);
-        stat = fmax(stat, fabs(fma(mub, rb, rf)));
-        stat_next = fmax(stat_next, fabs(fma(mub_next, rb, rf)));
-      }
-      const double lqf = __shfl(lf, c >= N ? c - N : c, 16), lqb = __shfl(lb, c >= N ? c - N : c, 16);
-      lf = c < N ? gxf + lf : gxf + fma(dt, lqf, lf);
-      lb = c < N ? gxb + lb : gxb + fma(dt, lqb, lb);
+      const double rf = fma(dt, lfd, gfu), rb = fma(dt, lbd, gbu);
+      stat = fmax(stat, fabs(fma(mub, rb, rf)));
+      stat_next = fmax(stat_next, fabs(fma(mub_next, rb, rf)));
+      const double nfd = gfd + fma(dt, lfq, lfd), nbd = gbd + fma(dt, lbq, lbd);
+      lfq = gfq + lfq;
+      lbq = gbq + lbq;
+      lfd = nfd;
+      lbd = nbd;
     }
-    stat = group_max(stat);
-    stat_next = group_max(stat_next);
+    if (!vec) { stat = 0.0; stat_next = 0.0; }
+    stat = wave_max(stat);
+    stat_next = wave_max(stat_next);
     if (!(stat == stat)) stat = 1e300;
     if (!(stat_next == stat_next)) stat_next = 1e300;
   }
@@ -1161,225 +1162,191 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
       curv = stat <= P.curv_from ? 1 : 0;
     }
   }
-  if (!run) { do_gains = do_roll = false; }
 
-  // 4. Riccati sweep: lane c < NX owns column c of P / Qxx / Qux; every lane factorises Quu (N x N) for itself
-  constexpr int NREC = (NH + NZ + 15) / 16;  // values of a stage record per lane
-  bool need = do_gains;
-  for (int attempt = 0; attempt < 12; ++attempt) {
-    bool chol_ok = true;
-    qk = need ? 0.0 : qk;
-    if (c < NX) {
-#pragma unroll
-      for (int r = 0; r < NX; ++r) Ps[r * PS + c] = 0.0;
-      pv[c] = 0.0;
-    }
-    __syncthreads();
-    double hn[NREC];
-    auto fetch_rec = [&](const int t) {
-      const double* sr = D.st + st_off(D, T, cur, b, t);
-#pragma unroll
-      for (int k = 0; k < NREC; ++k) {
-        const int idx = c + 16 * k;
-        double v = idx < NH + NZ ? sr[idx] : 0.0;
-        if (idx >= NH && idx < NH + NZ) v = fma(mub, sr[TQ_SD_GB + idx - NH], v);  // the stage gradient g_f + mu_b g_b
-        hn[k] = v;
-      }
-    };
-    if (need) fetch_rec(T - 1);
-    for (int t = T - 1; t >= 0; --t) {
-      if (need) {
-#pragma unroll
-        for (int k = 0; k < NREC; ++k)
-          if (c + 16 * k < NH + NZ) Hs[c + 16 * k] = hn[k];
-        if (t > 0) fetch_rec(t - 1);
-      }
-      __syncthreads();
-      double qxx[NX], qux[N], kc[N], Quu[NU], rd[N], kk[N], qu[N];
-      double qx = 0.0;
-      if (need) {
-        const int cc = c < NX ? c : 0;
-#pragma unroll
-        for (int r = 0; r < NX; ++r) {
-          const int hi = r > cc ? r : cc, lo = r > cc ? cc : r;
-          double v = Hs[hi * (hi + 1) / 2 + lo] + (r == cc ? mu : 0.0);
-          // (A^T P A)[r][cc]
-          double a = Ps[r * PS + cc];
-          if (r >= N) a = fma(dt, Ps[(r - N) * PS + cc], a);
-          if (cc >= N) {
-            a = fma(dt, Ps[r * PS + cc - N], a);
-            if (r >= N) a = fma(dt * dt, Ps[(r - N) * PS + cc - N], a);
-          }
-          qxx[r] = v + a;
-        }
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-          double a = dt * Ps[(N + k) * PS + cc];
-          if (cc >= N) a = fma(dt * dt, Ps[(N + k) * PS + cc - N], a);
-          qux[k] = Hs[(NX + k) * (NX + k + 1) / 2 + cc] + a;
-          qu[k] = Hs[NH + NX + k] + dt * pv[N + k];
-#pragma unroll
-          for (int l = 0; l <= k; ++l) Quu[tri(k, l)] = Hs[(NX + k) * (NX + k + 1) / 2 + NX + l] + dt * dt * Ps[(N + k) * PS + N + l];
-        }
-        qx = Hs[NH + cc] + pv[cc] + (cc >= N ? dt * pv[cc - N] : 0.0);
-        if (!chol_rcp<N>(Quu, rd, 0.0)) chol_ok = false;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-          kc[k] = qux[k];
-          kk[k] = qu[k];
-        }
-        fsub_rcp<N>(Quu, rd, kc);
-        bsub_rcp<N>(Quu, rd, kc);
-        fsub_rcp<N>(Quu, rd, kk);
-        bsub_rcp<N>(Quu, rd, kk);
-#pragma unroll
-        for (int k = 0; k < N; ++k) qk = fma(qu[k], kk[k], qk);
-        if (c < NX) {
-#pragma unroll
-          for (int k = 0; k < N; ++k) Quxs[k * 16 + c] = qux[k];
-        }
-      }
-      __syncthreads();  // every lane has read the old P
-      if (need && c < NX) {
-        double* gn = D.gains + ((size_t)b * T + t) * TQ_GN;
-#pragma unroll
-        for (int k = 0; k < N; ++k) gn[c * N + k] = kc[k];
-        if (c == 0) {
-#pragma unroll
-          for (int k = 0; k < N; ++k) gn[NX * N + k] = kk[k];
-        }
-        // P <- Qxx - Qux^T K, lower part of the column mirrored so that P stays exactly symmetric
-#pragma unroll
-        for (int r = 0; r < NX; ++r) {
-          if (r >= c) {
-            double v = qxx[r];
-#pragma unroll
-            for (int k = 0; k < N; ++k) v = fma(-Quxs[k * 16 + r], kc[k], v);
-            Ps[r * PS + c] = v;
-            Ps[c * PS + r] = v;
-          }
-        }
-        double v = qx;
-#pragma unroll
-        for (int k = 0; k < N; ++k) v = fma(-qux[k], kk[k], v);
-        pv[c] = v;
-      }
-      __syncthreads();
-    }
-    const bool failed = need && !(chol_ok && isfinite(qk));
-    need = failed;
-    if (failed) {  // an indefinite stage block of the exact Hessian: more damping, same point
-      mu = fmax(mu * nun, 0.1);
-      nun *= 2.0;
-    }
-    if (!__syncthreads_or(need ? 1 : 0)) break;
-  }
-  if (need) {
-    status = OH_STATUS_NUMERICAL;
-    do_roll = false;
-  }
-
-  // 5. closed-loop rollout of the unit step (du to LDS), fraction to the boundary on the linearised rows
-  const double delta = P.theta * mub;
-  {
-    double dx = 0.0;  // lane c < NX: component c of the state step
-    double a_ftb = 1.0, ndx_acc = 0.0;
-    double gk_n[NX + 1], jr_n[NZ], s_lo_n = 0.0, s_up_n = 0.0, v_lo_n = 0.0, v_up_n = 0.0;
-    auto fetch_knot = [&](const int t) {
-      if (c < N) {
-        const double* gn = D.gains + ((size_t)b * T + t) * TQ_GN;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) gk_n[j] = gn[j * N + c];
-        gk_n[NX] = gn[NX * N + c];
+  // 4. Riccati sweep (everything below is uniform over the wavefront: one instance)
+  // offsets of this lane's entries in the packed lower stage block: row(row + 1) / 2 + col, row >= col; q at 0, dq at N, u at 2 N
+  auto pk = [](const int row, const int col) { return row >= col ? row * (row + 1) / 2 + col : col * (col + 1) / 2 + row; };
+  const int rr = mat ? r : 0, cc = mat ? c : 0;
+  const int o_qq = pk(rr, cc), o_qd = pk(rr, N + cc), o_dq = pk(N + rr, cc), o_dd = pk(N + rr, N + cc), o_qu = pk(rr, NX + cc), o_du = pk(N + rr, NX + cc),
+            o_uq = pk(NX + rr, cc), o_ud = pk(NX + rr, N + cc), o_uu = pk(NX + rr, NX + cc);
+  const int rv = vec ? r : 0;
+  if (do_gains) {
+    bool failed = true;
+    for (int attempt = 0; attempt < 12 && failed; ++attempt) {
+      failed = false;
+      qk = 0.0;
+      double Pqq = 0.0, Pqd = 0.0, Pdq = 0.0, Pdd = 0.0;  // mat lanes: blocks of P; vec lanes: Pqq = p_q[r], Pdd = p_d[r]
+      double h_n[9];
+      auto fetch_rec = [&](const int t) {
         const double* sr = D.st + st_off(D, T, cur, b, t);
+        if (mat) {
+          h_n[0] = sr[o_qq]; h_n[1] = sr[o_qd]; h_n[2] = sr[o_dq]; h_n[3] = sr[o_dd]; h_n[4] = sr[o_qu]; h_n[5] = sr[o_du]; h_n[6] = sr[o_uq]; h_n[7] = sr[o_ud];
+          h_n[8] = sr[o_uu];
+        } else {  // the stage gradient g_f + mu_b g_b
+          h_n[0] = fma(mub, sr[TQ_SD_GB + rv], sr[231 + rv]);
+          h_n[1] = fma(mub, sr[TQ_SD_GB + N + rv], sr[231 + N + rv]);
+          h_n[2] = fma(mub, sr[TQ_SD_GB + NX + rv], sr[231 + NX + rv]);
+        }
+      };
+      fetch_rec(T - 1);
+      for (int t = T - 1; t >= 0; --t) {
+        double Mqq, Mqd, Mdq, Mdd, Mqu, Mdu, Muq, Mud, Muu;
+        if (c < N) {
+          const double dg = (r == c) ? mu : 0.0;
+          Mqq = h_n[0] + Pqq + dg;
+          Mqd = h_n[1] + fma(dt, Pqq, Pqd);
+          Mdq = h_n[2] + fma(dt, Pqq, Pdq);
+          Mdd = h_n[3] + fma(dt, fma(dt, Pqq, Pqd), fma(dt, Pdq, Pdd)) + dg;
+          Mqu = h_n[4] + dt * Pqd;
+          Mdu = h_n[5] + dt * fma(dt, Pqd, Pdd);
+          Muq = h_n[6] + dt * Pdq;
+          Mud = h_n[7] + dt * fma(dt, Pdq, Pdd);
+          Muu = h_n[8] + dt * dt * Pdd;
+        } else {  // vectors: m_q, m_d, m_u in the slots of column "u" of their block row (Mqu, Mdu, Muu)
+          Mqq = Mqd = Mdq = Mdd = Muq = Mud = 0.0;
+          Mqu = h_n[0] + Pqq;
+          Mdu = h_n[1] + fma(dt, Pqq, Pdd);
+          Muu = h_n[2] + dt * Pdd;
+        }
+        if (t > 0) fetch_rec(t - 1);
 #pragma unroll
-        for (int d = 0; d < NZ; ++d) jr_n[d] = sr[TQ_SD_J + c * NZ + d];
-        const double tv = sr[256 + c];
-        s_lo_n = tv - P.tau_lo[c];
-        s_up_n = P.tau_up[c] - tv;
+        for (int j = 0; j < N; ++j) {
+          // column j of this lane's row (blocks X u) and row j of this lane's column (blocks u Y; for the vector column: m_u[j])
+          const double cq = __shfl(Mqu, 8 * r + j), cd = __shfl(Mdu, 8 * r + j), cu = __shfl(Muu, 8 * r + j);
+          const double rq = __shfl(Muq, 8 * j + c), rd = __shfl(Mud, 8 * j + c), ru = __shfl(Muu, 8 * j + c);
+          const double piv = __shfl(Muu, 9 * j);
+          if (!(piv > 0.0) || !isfinite(piv)) failed = true;
+          const double d = 1.0 / piv;
+          if (c < N) {
+            Mqq = fma(-(cq * rq), d, Mqq);
+            Mqd = fma(-(cq * rd), d, Mqd);
+            Mdq = fma(-(cd * rq), d, Mdq);
+            Mdd = fma(-(cd * rd), d, Mdd);
+            Mqu = fma(-(cq * ru), d, Mqu);
+            Mdu = fma(-(cd * ru), d, Mdu);
+            if (r == j) {
+              Muq *= d;
+              Mud *= d;
+              Muu *= d;
+            } else {
+              Muq = fma(-(cu * rq), d, Muq);
+              Mud = fma(-(cu * rd), d, Mud);
+              Muu = fma(-(cu * ru), d, Muu);
+            }
+          } else {  // ru = m_u[j] (forward-eliminated: row j has only been updated by the pivots before it)
+            if (r == 0) qk = fma(ru * ru, d, qk);
+            Mqu = fma(-(cq * ru), d, Mqu);
+            Mdu = fma(-(cd * ru), d, Mdu);
+            if (r == j) Muu *= d;
+            else Muu = fma(-(cu * ru), d, Muu);
+          }
+        }
+        // gains of knot t: K_q[r][c], K_d[r][c] on the matrix lanes, k[r] on the vector lanes; two doubles per lane
+        double* gn = D.gains + ((size_t)b * T + t) * TQ_GN;
+        gn[2 * lane] = c < N ? Muq : Muu;
+        gn[2 * lane + 1] = c < N ? Mud : 0.0;
+        if (c < N) {
+          Pqq = Mqq; Pqd = Mqd; Pdq = Mdq; Pdd = Mdd;
+        } else {
+          Pqq = Mqu; Pdd = Mdu; Pqd = Pdq = 0.0;
+        }
+      }
+      qk = __shfl(qk, N);  // lane (0, 7)
+      failed = __any(failed && r < N) || !isfinite(qk);
+      if (failed) {  // an indefinite stage block of the exact Hessian: more damping, same point
+        mu = fmax(mu * nun, 0.1);
+        nun *= 2.0;
+      }
+    }
+    if (failed) {
+      status = OH_STATUS_NUMERICAL;
+      do_roll = false;
+    }
+  }
+
+  // 5. closed-loop rollout of the unit step (du to LDS), fraction to the boundary on the linearised rows.  Lane (r, c) carries the state step of joint
+  // c (replicated over the rows) and multiplies it with its entries of the gains and of d tau / d z; row sums give du_r and d tau_r.
+  const double delta = P.theta * mub;
+  double (*du_all)[8] = reinterpret_cast<double (*)[8]>(du_dyn);
+  if (do_roll) {
+    double dq = 0.0, dd = 0.0;
+    double a_ftb = 1.0, ndx_acc = 0.0;
+    double k_n[2], j_n[3], s_n[4] = {0, 0, 0, 0};
+    auto fetch_knot = [&](const int t) {
+      const double* gn = D.gains + ((size_t)b * T + t) * TQ_GN;
+      k_n[0] = gn[2 * lane];
+      k_n[1] = gn[2 * lane + 1];
+      const double* sr = D.st + st_off(D, T, cur, b, t);
+      if (mat) {
+        j_n[0] = sr[TQ_SD_J + r * NZ + c];
+        j_n[1] = sr[TQ_SD_J + r * NZ + N + c];
+        j_n[2] = sr[TQ_SD_J + r * NZ + NX + c];
+      } else {
+        j_n[0] = j_n[1] = j_n[2] = 0.0;
+      }
+      if (r < N && c == 0) {
+        const double tv = sr[256 + r];
+        s_n[0] = tv - P.tau_lo[r];
+        s_n[1] = P.tau_up[r] - tv;
         if constexpr (VEL) {
-          const double dv = D.xs[xs_off(D, T, cur, b, t) + 8 + c];
-          v_lo_n = dv - P.dq_lo[c];
-          v_up_n = P.dq_up[c] - dv;
+          const double dv = D.xs[xs_off(D, T, cur, b, t) + 8 + r];
+          s_n[2] = dv - P.dq_lo[r];
+          s_n[3] = P.dq_up[r] - dv;
         }
       }
     };
-    if (do_roll) fetch_knot(0);
-    for (int t = 0; t < T; ++t) {  // every group runs the loop (uniform barriers); only groups with do_roll touch memory
-      double gk[NX + 1], jr[NZ];
-#pragma unroll
-      for (int j = 0; j <= NX; ++j) gk[j] = gk_n[j];
-#pragma unroll
-      for (int d = 0; d < NZ; ++d) jr[d] = jr_n[d];
-      const double s_lo = s_lo_n, s_up = s_up_n, v_lo = v_lo_n, v_up = v_up_n;
-      if (do_roll && t + 1 < T) fetch_knot(t + 1);
-      if (c < NX) dxs[c] = dx;
-      __syncthreads();
-      if (c < N) {
-        double du = 0.0;
-        if (do_roll) {
-          du = -gk[NX];
-#pragma unroll
-          for (int j = 0; j < NX; ++j) du = fma(-gk[j], dxs[j], du);
-        }
-        dus[c] = du;
-        du_all[t][c] = du;
-      }
-      if (c < NX) ndx_acc = fma(dx, dx, ndx_acc);
-      __syncthreads();
-      if (do_roll && c < N) {
-        double ds = 0.0;
-#pragma unroll
-        for (int d = 0; d < NX; ++d) ds = fma(jr[d], dxs[d], ds);
-#pragma unroll
-        for (int d = 0; d < N; ++d) ds = fma(jr[NX + d], dus[d], ds);
+    fetch_knot(0);
+    for (int t = 0; t < T; ++t) {
+      const double kq = k_n[0], kd = k_n[1], jq = j_n[0], jd = j_n[1], ju = j_n[2];
+      const double s_lo = s_n[0], s_up = s_n[1], v_lo = s_n[2], v_up = s_n[3];
+      if (t + 1 < T) fetch_knot(t + 1);
+      // du_r = -k_r - sum_c (K_q[r][c] dq_c + K_d[r][c] dd_c): the vector lane contributes k_r (its kq slot)
+      const double part = c < N ? fma(kq, dq, kd * dd) : kq;
+      const double du_r = -row_sum8(r < N ? part : 0.0);
+      const double du_c = __shfl(du_r, 8 * c);  // du of joint c, from row c
+      if (r == 0 && c < N) du_all[t][c] = du_c;
+      if (r == 0 && c < N) ndx_acc = fma(dq, dq, fma(dd, dd, ndx_acc));
+      const double ds = row_sum8(mat ? fma(jq, dq, fma(jd, dd, ju * du_c)) : 0.0);  // d tau_r of the unit step
+      double dv = 0.0;
+      if constexpr (VEL) dv = __shfl(dd, r);  // the velocity step of joint r sits on lane (0, r) (every lane takes part in the shuffle)
+      if (r < N && c == 0) {
         if (ds < 0.0 && s_lo >= delta) a_ftb = fmin(a_ftb, -P.tau_ftb * s_lo / ds);
         if (ds > 0.0 && s_up >= delta) a_ftb = fmin(a_ftb, P.tau_ftb * s_up / ds);
         if constexpr (VEL) {
-          const double dv = dxs[N + c];
           if (dv < 0.0 && v_lo >= delta) a_ftb = fmin(a_ftb, -P.tau_ftb * v_lo / dv);
           if (dv > 0.0 && v_up >= delta) a_ftb = fmin(a_ftb, P.tau_ftb * v_up / dv);
         }
       }
       // dx_{t+1} = A dx_t + B du_t
-      const double xo = __shfl(dx, c < N ? c + N : c, 16);
-      if (c < N) dx = fma(dt, xo, dx);
-      else if (c < NX) dx = fma(dt, dus[c - N], dx);
-      __syncthreads();
+      dq = fma(dt, dd, dq);
+      dd = fma(dt, du_c, dd);
     }
     if (do_gains) {
-      ndx = group_sum(ndx_acc);
-      alpha = group_min(a_ftb);
+      ndx = wave_sum(ndx_acc);
+      alpha = wave_min(a_ftb);
     }
   }
+  __syncthreads();  // du_all
 
-  // 6. open-loop rollout of u + alpha du from the fixed initial state
-  {
-    double xt = 0.0;
-    if (do_roll && c < NX) {
-      const double* x0r = D.xs + xs_off(D, T, cur, b, 0);
-      xt = x0r[c < N ? c : 8 + (c - N)];
-    }
-    double u_n = 0.0;
-    if (do_roll && c < N) u_n = D.xs[xs_off(D, T, cur, b, 0) + 16 + c];
+  // 6. open-loop rollout of u + alpha du from the fixed initial state: lane c < N carries joint c
+  if (do_roll && lane < N) {
+    const double* x0r = D.xs + xs_off(D, T, cur, b, 0);
+    double q = x0r[lane], dqv = x0r[8 + lane];
+    double u_n = x0r[16 + lane];
     for (int t = 0; t < T; ++t) {
       const double ucur = u_n;
-      if (do_roll && c < N && t + 1 < T) u_n = D.xs[xs_off(D, T, cur, b, t + 1) + 16 + c];
+      if (t + 1 < T) u_n = D.xs[xs_off(D, T, cur, b, t + 1) + 16 + lane];
       double* xn = D.xs + xs_off(D, T, nts, b, t);
-      if (c < N) {
-        const double un = fma(alpha, du_all[t][c], ucur);
-        if (do_roll) xn[16 + c] = un;
-        dus[c] = un;
-      }
-      if (do_roll && c < NX) xn[c < N ? c : 8 + (c - N)] = xt;
-      __syncthreads();
-      const double xo = __shfl(xt, c < N ? c + N : c, 16);
-      if (c < N) xt = fma(dt, xo, xt);
-      else if (c < NX) xt = fma(dt, dus[c - N], xt);
-      __syncthreads();
+      const double un = fma(alpha, du_all[t][lane], ucur);
+      xn[16 + lane] = un;
+      xn[lane] = q;
+      xn[8 + lane] = dqv;
+      // x_{t+1} = A x_t + B u_t on the trial values themselves
+      q = fma(dt, dqv, q);
+      dqv = fma(dt, un, dqv);
     }
   }
-  if (run && c == 0) {
+  if (lane == 0) {
     D.cur[b] = cur;
     D.first[b] = 0;
     D.curv[b] = curv;
@@ -1498,8 +1465,8 @@ bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D) {
 }
 bool oh_launch_tq_step(hipStream_t s, const TqParams& P, const TqBuffers& D) {
   if (P.N != 7) return false;
-  if (P.vel) hipLaunchKernelGGL((k_tq_step<7, true>), dim3((D.n_run + 3) / 4), dim3(64), sizeof(double) * 32 * P.T, s, P, D);
-  else hipLaunchKernelGGL((k_tq_step<7>), dim3((D.n_run + 3) / 4), dim3(64), sizeof(double) * 32 * P.T, s, P, D);
+  if (P.vel) hipLaunchKernelGGL((k_tq_step<7, true>), dim3(D.n_run), dim3(64), sizeof(double) * 8 * P.T, s, P, D);
+  else hipLaunchKernelGGL((k_tq_step<7>), dim3(D.n_run), dim3(64), sizeof(double) * 8 * P.T, s, P, D);
   return true;
 }
 bool oh_launch_tq_finalize(hipStream_t s, const TqParams& P, const TqBuffers& D, double* x, double* f, double* kkt, int* iters, int* status, double* mult) {

@@ -257,7 +257,9 @@ typedef struct oh_qp_desc {
 #define OH_TAPE_MAX_N 4096
 #define OH_TAPE_MAX_LEN (1 << 18)
 /* Instruction i writes register i.  op: 0 CONST c | 1 X a | 2 P a | 3 ADD a b | 4 SUB a b | 5 MUL a b | 6 DIV a b | 7 NEG a | 8 SIN a | 9 COS a |
-   10 ATAN2 a b | 11 SQRT a | 12 SQR a.  rows: registers of the constraint rows, the n_ineq rows that must be >= 0 first, then the n_eq rows
+   10 ATAN2 a b | 11 SQRT a | 12 SQR a | 13 ASIN a | 14 FABS a | 15 FMIN a b | 16 FMAX a b | 17 LT a b | 18 LE a b | 19 EQ a b | 20 NE a b |
+   21 NOT a | 22 AND a b | 23 OR a b (comparisons / logic: 1.0 or 0.0, zero derivative) | 24 IFZ a b (casadi's if_else_zero: b where a != 0, else 0;
+   derivative conventions of 13-16 and 24 are casadi's, casadi/core/calculus.hpp).  rows: registers of the constraint rows, the n_ineq rows that must be >= 0 first, then the n_eq rows
    that must vanish (the rows of v = [k; g; a; -a; h; -h] without the mirrored ones, optimization.py:27-51). */
 typedef struct oh_tape_desc {
   int nx, np;       /* nx <= OH_TAPE_MAX_N */

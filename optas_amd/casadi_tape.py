@@ -36,6 +36,9 @@ _UNARY = {
     "OP_TWICE": lambda tb, a: tb.add(a, a),
     "OP_INV": lambda tb, a: tb.div(tb.const(1.0), a),
     "OP_TAN": lambda tb, a: tb.div(tb.sin(a), tb.cos(a)),
+    "OP_ASIN": lambda tb, a: tb.asin(a),  # Quaternion.getrpy (spatialmath.py:384-404) -> get_global_link_rpy and the analytical Jacobians
+    "OP_FABS": lambda tb, a: tb.fabs(a),
+    "OP_NOT": lambda tb, a: tb.lnot(a),
 }
 _BINARY = {
     "OP_ADD": lambda tb, a, b: tb.add(a, b),
@@ -43,6 +46,15 @@ _BINARY = {
     "OP_MUL": lambda tb, a, b: tb.mul(a, b),
     "OP_DIV": lambda tb, a, b: tb.div(a, b),
     "OP_ATAN2": lambda tb, a, b: tb.atan2(a, b),
+    "OP_FMIN": lambda tb, a, b: tb.fmin(a, b),  # optas.clip (__init__.py:29-41)
+    "OP_FMAX": lambda tb, a, b: tb.fmax(a, b),
+    "OP_LT": lambda tb, a, b: tb.lt(a, b),
+    "OP_LE": lambda tb, a, b: tb.le(a, b),
+    "OP_EQ": lambda tb, a, b: tb.eq(a, b),
+    "OP_NE": lambda tb, a, b: tb.ne(a, b),
+    "OP_AND": lambda tb, a, b: tb.land(a, b),
+    "OP_OR": lambda tb, a, b: tb.lor(a, b),
+    "OP_IF_ELSE_ZERO": lambda tb, a, b: tb.ifz(a, b),  # cs.if_else(c, x, y) = if_else_zero(c, x) + if_else_zero(!c, y) in an SX graph
 }
 
 

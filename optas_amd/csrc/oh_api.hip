@@ -292,8 +292,9 @@ static int tape_validate(const oh_tape_desc* d, const char* who) {
     return fail(OH_ERR_INVALID, (w + ": bad sizes or null arrays").c_str());
   for (int i = 0; i < d->len; ++i) {
     const int o = d->op[i];
-    const bool two = (o >= 3 && o <= 6) || o == 10, one = o == 7 || o == 8 || o == 9 || o == 11 || o == 12;
-    if (o < 0 || o > 12 || (o == 1 && (d->a[i] < 0 || d->a[i] >= d->nx)) || (o == 2 && (d->a[i] < 0 || d->a[i] >= d->np)) ||
+    const bool two = (o >= 3 && o <= 6) || o == 10 || (o >= 15 && o <= 20) || (o >= 22 && o <= 24);
+    const bool one = o == 7 || o == 8 || o == 9 || o == 11 || o == 12 || o == 13 || o == 14 || o == 21;
+    if (o < 0 || o > 24 || (o == 1 && (d->a[i] < 0 || d->a[i] >= d->nx)) || (o == 2 && (d->a[i] < 0 || d->a[i] >= d->np)) ||
         ((one || two) && (d->a[i] < 0 || d->a[i] >= i)) || (two && (d->b[i] < 0 || d->b[i] >= i)))
       return fail(OH_ERR_INVALID, (w + ": malformed instruction (operands must be earlier registers / valid indices)").c_str());
   }

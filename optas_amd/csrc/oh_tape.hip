@@ -65,7 +65,20 @@ struct InterpEval {
         case 9: v = cos(val[TIDX(ia)]); break;
         case 10: v = atan2(val[TIDX(ia)], val[TIDX(ib)]); break;
         case 11: v = sqrt(val[TIDX(ia)]); break;
-        default: { const double t = val[TIDX(ia)]; v = t * t; } break;
+        case 12: { const double t = val[TIDX(ia)]; v = t * t; } break;
+        // round 4: the rest of what the reference's graphs emit (Quaternion.getrpy, optas.clip): values as casadi's SX machine computes them
+        case 13: v = asin(val[TIDX(ia)]); break;
+        case 14: v = fabs(val[TIDX(ia)]); break;
+        case 15: v = fmin(val[TIDX(ia)], val[TIDX(ib)]); break;
+        case 16: v = fmax(val[TIDX(ia)], val[TIDX(ib)]); break;
+        case 17: v = val[TIDX(ia)] < val[TIDX(ib)] ? 1.0 : 0.0; break;
+        case 18: v = val[TIDX(ia)] <= val[TIDX(ib)] ? 1.0 : 0.0; break;
+        case 19: v = val[TIDX(ia)] == val[TIDX(ib)] ? 1.0 : 0.0; break;
+        case 20: v = val[TIDX(ia)] != val[TIDX(ib)] ? 1.0 : 0.0; break;
+        case 21: v = val[TIDX(ia)] == 0.0 ? 1.0 : 0.0; break;
+        case 22: v = (val[TIDX(ia)] != 0.0 && val[TIDX(ib)] != 0.0) ? 1.0 : 0.0; break;
+        case 23: v = (val[TIDX(ia)] != 0.0 || val[TIDX(ib)] != 0.0) ? 1.0 : 0.0; break;
+        default: v = val[TIDX(ia)] != 0.0 ? val[TIDX(ib)] : 0.0; break;  // 24: if_else_zero
       }
       val[TIDX(i)] = v;
     }
@@ -90,7 +103,13 @@ struct InterpEval {
         case 9: adj[TIDX(ia)] -= w * sin(val[TIDX(ia)]); break;
         case 10: { const double va = val[TIDX(ia)], vb = val[TIDX(ib)], d = va * va + vb * vb; adj[TIDX(ia)] += w * vb / d; adj[TIDX(ib)] -= w * va / d; } break;
         case 11: adj[TIDX(ia)] += w * 0.5 / val[TIDX(i)]; break;
-        default: adj[TIDX(ia)] += w * 2.0 * val[TIDX(ia)]; break;
+        case 12: adj[TIDX(ia)] += w * 2.0 * val[TIDX(ia)]; break;
+        case 13: { const double va = val[TIDX(ia)]; adj[TIDX(ia)] += w / sqrt(1.0 - va * va); } break;
+        case 14: { const double va = val[TIDX(ia)]; adj[TIDX(ia)] += w * (va > 0.0 ? 1.0 : (va < 0.0 ? -1.0 : 0.0)); } break;
+        case 15: if (val[TIDX(ia)] <= val[TIDX(ib)]) adj[TIDX(ia)] += w; else adj[TIDX(ib)] += w; break;  // casadi: d fmin = (x <= y, !(x <= y))
+        case 16: if (val[TIDX(ia)] >= val[TIDX(ib)]) adj[TIDX(ia)] += w; else adj[TIDX(ib)] += w; break;
+        case 24: if (val[TIDX(ia)] != 0.0) adj[TIDX(ib)] += w; break;
+        default: break;  // 17..23: comparisons and logic are piecewise constant
       }
     }
   }
@@ -154,10 +173,11 @@ std::string generate(const TapeParams& T, const int* op, const int* a, const int
   std::vector<char> live(T.len, 0);
   live[T.out_cost] = 1;
   for (int i = 0; i < T.n_ineq + T.n_eq; ++i) live[rows[i]] = 1;
+  auto is_binary = [](int o) { return (o >= 3 && o <= 6) || o == 10 || (o >= 15 && o <= 20) || (o >= 22 && o <= 24); };
   for (int i = T.len - 1; i >= 0; --i)
     if (live[i] && op[i] >= 3) {
       live[a[i]] = 1;
-      if (op[i] <= 6 || op[i] == 10) live[bb[i]] = 1;
+      if (is_binary(op[i])) live[bb[i]] = 1;
     }
   for (int i = 0; i < T.len; ++i) {
     if (!live[i]) continue;
@@ -174,6 +194,18 @@ std::string generate(const TapeParams& T, const int* op, const int* a, const int
       case 9: emit(s, "    const double v%d = cos(v%d);\n", i, a[i]); break;
       case 10: emit(s, "    const double v%d = atan2(v%d, v%d);\n", i, a[i], bb[i]); break;
       case 11: emit(s, "    const double v%d = sqrt(v%d);\n", i, a[i]); break;
+      case 13: emit(s, "    const double v%d = asin(v%d);\n", i, a[i]); break;
+      case 14: emit(s, "    const double v%d = fabs(v%d);\n", i, a[i]); break;
+      case 15: emit(s, "    const double v%d = fmin(v%d, v%d);\n", i, a[i], bb[i]); break;
+      case 16: emit(s, "    const double v%d = fmax(v%d, v%d);\n", i, a[i], bb[i]); break;
+      case 17: emit(s, "    const double v%d = v%d < v%d ? 1.0 : 0.0;\n", i, a[i], bb[i]); break;
+      case 18: emit(s, "    const double v%d = v%d <= v%d ? 1.0 : 0.0;\n", i, a[i], bb[i]); break;
+      case 19: emit(s, "    const double v%d = v%d == v%d ? 1.0 : 0.0;\n", i, a[i], bb[i]); break;
+      case 20: emit(s, "    const double v%d = v%d != v%d ? 1.0 : 0.0;\n", i, a[i], bb[i]); break;
+      case 21: emit(s, "    const double v%d = v%d == 0.0 ? 1.0 : 0.0;\n", i, a[i]); break;
+      case 22: emit(s, "    const double v%d = (v%d != 0.0 && v%d != 0.0) ? 1.0 : 0.0;\n", i, a[i], bb[i]); break;
+      case 23: emit(s, "    const double v%d = (v%d != 0.0 || v%d != 0.0) ? 1.0 : 0.0;\n", i, a[i], bb[i]); break;
+      case 24: emit(s, "    const double v%d = v%d != 0.0 ? v%d : 0.0;\n", i, a[i], bb[i]); break;
       default: emit(s, "    const double v%d = v%d * v%d;\n", i, a[i], a[i]); break;
     }
   }
@@ -198,7 +230,7 @@ std::string generate(const TapeParams& T, const int* op, const int* a, const int
   for (int i = T.len - 1; i >= 0; --i) {
     if (!live[i]) continue;
     const int ia = a[i], ib = bb[i];
-    const bool da = op[i] >= 3 && has_adj(ia), db = (op[i] >= 3 && (op[i] <= 6 || op[i] == 10)) && has_adj(ib);
+    const bool da = op[i] >= 3 && has_adj(ia), db = is_binary(op[i]) && has_adj(ib);
     switch (op[i]) {
       case 0: case 2: break;
       case 1: emit(s, "    g%d += a%d;\n", ia, i); break;
@@ -236,8 +268,26 @@ std::string generate(const TapeParams& T, const int* op, const int* a, const int
       case 11:
         if (da) emit(s, "    a%d += a%d * 0.5 / v%d;\n", ia, i, i);
         break;
-      default:
+      case 12:
         if (da) emit(s, "    a%d += a%d * 2.0 * v%d;\n", ia, i, ia);
+        break;
+      case 13:
+        if (da) emit(s, "    a%d += a%d / sqrt(1.0 - v%d * v%d);\n", ia, i, ia, ia);
+        break;
+      case 14:
+        if (da) emit(s, "    a%d += a%d * (v%d > 0.0 ? 1.0 : (v%d < 0.0 ? -1.0 : 0.0));\n", ia, i, ia, ia);
+        break;
+      case 15:
+      case 16: {
+        const char* cmp = op[i] == 15 ? "<=" : ">=";
+        if (da && db) emit(s, "    if (v%d %s v%d) a%d += a%d; else a%d += a%d;\n", ia, cmp, ib, ia, i, ib, i);
+        else if (da) emit(s, "    if (v%d %s v%d) a%d += a%d;\n", ia, cmp, ib, ia, i);
+        else if (db) emit(s, "    if (!(v%d %s v%d)) a%d += a%d;\n", ia, cmp, ib, ib, i);
+      } break;
+      case 24:
+        if (db) emit(s, "    if (v%d != 0.0) a%d += a%d;\n", ia, ib, i);
+        break;
+      default:  // 17..23: comparisons and logic are piecewise constant
         break;
     }
   }

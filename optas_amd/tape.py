@@ -4,8 +4,10 @@ families.  The tape is evaluated *on the GPU only* (csrc/oh_tape.hip: one thread
 sweep per output row); this module only builds it.
 
 Instruction i writes register i (SSA).  ops:  CONST c | X k (decision variable k, vec() order) | P k (parameter k) | ADD a b |
-SUB a b | MUL a b | DIV a b | NEG a | SIN a | COS a | ATAN2 a b | SQRT a | SQR a.  Common sub-expressions are shared (hash-consing),
-constants are folded.  Link functions (position / rotation / quaternion / geometric Jacobian of a serial chain) are expanded with the
+SUB a b | MUL a b | DIV a b | NEG a | SIN a | COS a | ATAN2 a b | SQRT a | SQR a, and (round 4: what the reference's own graphs emit beyond
+those -- Quaternion.getrpy, spatialmath.py:384-404, and optas.clip, __init__.py:29-41) ASIN a | FABS a | FMIN a b | FMAX a b | LT a b | LE a b |
+EQ a b | NE a b | NOT a | AND a b | OR a b (1.0 / 0.0 valued, zero derivative) | IFZ a b (casadi's if_else_zero: b where a != 0, else 0;
+if_else(c, x, y) = IFZ(c, x) + IFZ(NOT c, y)).  Common sub-expressions are shared (hash-consing), constants are folded.  Link functions (position / rotation / quaternion / geometric Jacobian of a serial chain) are expanded with the
 same chain walk as RobotModel.get_global_link_transform (models.py:826-868) over scalar registers.
 """
 from __future__ import annotations
@@ -21,6 +23,8 @@ from .expr import (Add, Atan2, Block, Const, Expr, Gather, LinkFunction, MatMul,
 from .spatialmath import rpy2r
 
 OP_CONST, OP_X, OP_P, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SIN, OP_COS, OP_ATAN2, OP_SQRT, OP_SQR = range(13)
+OP_ASIN, OP_FABS, OP_FMIN, OP_FMAX, OP_LT, OP_LE, OP_EQ, OP_NE, OP_NOT, OP_AND, OP_OR, OP_IFZ = range(13, 25)
+N_OPS = 25
 MAX_TAPE = 1 << 18
 
 
@@ -118,6 +122,56 @@ class TapeBuilder:
 
     def sqr(self, a):
         return self.mul(a, a)
+
+    # ---- round 4: the rest of what the reference's graphs emit (values as casadi's SX virtual machine computes them) -------------------------
+    def _fold1(self, op, a, fn):
+        return self.const(fn(self._const[a])) if self.is_const(a) else self._emit(op, a)
+
+    def _fold2(self, op, a, b, fn):
+        return self.const(fn(self._const[a], self._const[b])) if self.is_const(a) and self.is_const(b) else self._emit(op, a, b)
+
+    def asin(self, a):
+        return self._fold1(OP_ASIN, a, lambda v: float(np.arcsin(v)))
+
+    def fabs(self, a):
+        return self._fold1(OP_FABS, a, abs)
+
+    def fmin(self, a, b):
+        return self._fold2(OP_FMIN, a, b, min)
+
+    def fmax(self, a, b):
+        return self._fold2(OP_FMAX, a, b, max)
+
+    def lt(self, a, b):
+        return self._fold2(OP_LT, a, b, lambda x, y: float(x < y))
+
+    def le(self, a, b):
+        return self._fold2(OP_LE, a, b, lambda x, y: float(x <= y))
+
+    def eq(self, a, b):
+        return self._fold2(OP_EQ, a, b, lambda x, y: float(x == y))
+
+    def ne(self, a, b):
+        return self._fold2(OP_NE, a, b, lambda x, y: float(x != y))
+
+    def lnot(self, a):
+        return self._fold1(OP_NOT, a, lambda v: float(v == 0.0))
+
+    def land(self, a, b):
+        return self._fold2(OP_AND, a, b, lambda x, y: float(x != 0.0 and y != 0.0))
+
+    def lor(self, a, b):
+        return self._fold2(OP_OR, a, b, lambda x, y: float(x != 0.0 or y != 0.0))
+
+    def ifz(self, c, x):
+        """casadi's if_else_zero(c, x): x where c != 0, else 0."""
+        if self.is_const(c):
+            return x if self._const[c] != 0.0 else self.const(0.0)
+        return self._emit(OP_IFZ, c, x)
+
+    def if_else(self, c, x, y):
+        """casadi.if_else(c, x, y) as the SX graph holds it: if_else_zero(c, x) + if_else_zero(!c, y)."""
+        return self.add(self.ifz(c, x), self.ifz(self.lnot(c), y))
 
     # ---- small dense helpers over arrays of registers --------------------------------------------------------------
     def mat_const(self, M) -> np.ndarray:
@@ -375,6 +429,9 @@ def compile_problem(opt) -> Tape:
                 int(f), np.asarray(rows, dtype=np.int32), len(ineq), len(eq), opt.nx, opt.np)
 
 
+_BINARY_NONLINEAR = (OP_ATAN2, OP_FMIN, OP_FMAX, OP_LT, OP_LE, OP_EQ, OP_NE, OP_AND, OP_OR, OP_IFZ)
+
+
 def tape_degrees(tape: Tape) -> np.ndarray:
     """Degree in x of every register of a tape: 0 constant / parameter only, 1 affine, 2 quadratic, 3 anything else -- the classification the
     reference asks CasADi for (cs.is_linear / is_quadratic, builder.py:226-240), here on the instruction arrays."""
@@ -395,7 +452,7 @@ def tape_degrees(tape: Tape) -> np.ndarray:
         elif op == OP_DIV:
             deg[r] = deg[a] if deg[b] == 0 else 3
         else:  # sin, cos, atan2, sqrt
-            deg[r] = 0 if max(deg[a], deg[b] if op == OP_ATAN2 else 0) == 0 else 3
+            deg[r] = 0 if max(deg[a], deg[b] if op in _BINARY_NONLINEAR else 0) == 0 else 3
     return deg
 
 

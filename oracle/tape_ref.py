@@ -4,6 +4,7 @@ reverse-mode gradients of chosen registers) and the numpy port of the generic au
 import numpy as np
 
 OP_CONST, OP_X, OP_P, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SIN, OP_COS, OP_ATAN2, OP_SQRT, OP_SQR = range(13)
+OP_ASIN, OP_FABS, OP_FMIN, OP_FMAX, OP_LT, OP_LE, OP_EQ, OP_NE, OP_NOT, OP_AND, OP_OR, OP_IFZ = range(13, 25)
 
 
 def forward(tape, x, p):
@@ -37,6 +38,30 @@ def forward(tape, x, p):
             v[i] = np.sqrt(v[a])
         elif o == OP_SQR:
             v[i] = v[a] * v[a]
+        elif o == OP_ASIN:
+            v[i] = np.arcsin(v[a])
+        elif o == OP_FABS:
+            v[i] = abs(v[a])
+        elif o == OP_FMIN:
+            v[i] = min(v[a], v[b])
+        elif o == OP_FMAX:
+            v[i] = max(v[a], v[b])
+        elif o == OP_LT:
+            v[i] = float(v[a] < v[b])
+        elif o == OP_LE:
+            v[i] = float(v[a] <= v[b])
+        elif o == OP_EQ:
+            v[i] = float(v[a] == v[b])
+        elif o == OP_NE:
+            v[i] = float(v[a] != v[b])
+        elif o == OP_NOT:
+            v[i] = float(v[a] == 0.0)
+        elif o == OP_AND:
+            v[i] = float(v[a] != 0.0 and v[b] != 0.0)
+        elif o == OP_OR:
+            v[i] = float(v[a] != 0.0 or v[b] != 0.0)
+        elif o == OP_IFZ:
+            v[i] = v[b] if v[a] != 0.0 else 0.0
     return v
 
 
@@ -80,6 +105,24 @@ def reverse(tape, v, seeds):
             adj[a] += w * 0.5 / v[i]
         elif o == OP_SQR:
             adj[a] += w * 2.0 * v[a]
+        elif o == OP_ASIN:
+            adj[a] += w / np.sqrt(1.0 - v[a] * v[a])
+        elif o == OP_FABS:
+            adj[a] += w * np.sign(v[a])
+        elif o == OP_FMIN:  # casadi/core/calculus.hpp: d fmin = (x <= y, !(x <= y))
+            if v[a] <= v[b]:
+                adj[a] += w
+            else:
+                adj[b] += w
+        elif o == OP_FMAX:  # d fmax = (x >= y, !(x >= y))
+            if v[a] >= v[b]:
+                adj[a] += w
+            else:
+                adj[b] += w
+        elif o == OP_IFZ:
+            if v[a] != 0.0:
+                adj[b] += w
+        # comparisons and logic: piecewise constant, no derivative
     return g
 
 

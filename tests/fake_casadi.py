@@ -8,6 +8,8 @@ import numpy as np
 
 OP_ASSIGN, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SIN, OP_COS, OP_SQRT, OP_SQ, OP_TWICE, OP_INV, OP_ATAN2, OP_CONSTPOW, OP_TAN = range(101, 116)
 OP_CONST, OP_INPUT, OP_OUTPUT, OP_FABS, OP_POW = 201, 202, 203, 204, 205
+OP_ASIN, OP_FMIN, OP_FMAX, OP_LT, OP_LE, OP_EQ, OP_NE, OP_NOT, OP_AND, OP_OR, OP_IF_ELSE_ZERO = range(301, 312)
+OP_EXP = 401  # an opcode the tape has no counterpart for
 
 
 class SX:
@@ -30,6 +32,10 @@ class SX:
     def __rtruediv__(self, o): return SX(OP_DIV, (SX.wrap(o), self))
     def __neg__(self): return SX(OP_NEG, (self,))
     def __pow__(self, e): return SX(OP_CONSTPOW, (self, SX.wrap(e)))
+    def __lt__(self, o): return SX(OP_LT, (self, SX.wrap(o)))
+    def __le__(self, o): return SX(OP_LE, (self, SX.wrap(o)))
+    def __gt__(self, o): return SX(OP_LT, (SX.wrap(o), self))  # casadi keeps LT / LE only and swaps the operands
+    def __ge__(self, o): return SX(OP_LE, (SX.wrap(o), self))
 
 
 def sin(a): return SX(OP_SIN, (a,))
@@ -40,6 +46,15 @@ def sq(a): return SX(OP_SQ, (a,))
 def twice(a): return SX(OP_TWICE, (a,))
 def inv(a): return SX(OP_INV, (a,))
 def fabs(a): return SX(OP_FABS, (a,))
+def asin(a): return SX(OP_ASIN, (a,))
+def exp(a): return SX(OP_EXP, (a,))
+def fmin(a, b): return SX(OP_FMIN, (SX.wrap(a), SX.wrap(b)))
+def fmax(a, b): return SX(OP_FMAX, (SX.wrap(a), SX.wrap(b)))
+def logic_not(a): return SX(OP_NOT, (a,))
+def logic_and(a, b): return SX(OP_AND, (a, b))
+def logic_or(a, b): return SX(OP_OR, (a, b))
+def if_else_zero(c, x): return SX(OP_IF_ELSE_ZERO, (c, SX.wrap(x)))
+def if_else(c, x, y): return if_else_zero(c, x) + if_else_zero(logic_not(c), y)  # what casadi builds for SX
 def atan2(a, b): return SX(OP_ATAN2, (a, SX.wrap(b)))
 def sym(i, n): return [SX(OP_INPUT, inp=(i, j)) for j in range(n)]
 
@@ -138,6 +153,19 @@ class Function:
             elif op == OP_INV: w[o[0]] = 1.0 / w[i[0]]
             elif op == OP_ATAN2: w[o[0]] = math.atan2(w[i[0]], w[i[1]])
             elif op in (OP_CONSTPOW, OP_POW): w[o[0]] = w[i[0]] ** w[i[1]]
+            elif op == OP_FABS: w[o[0]] = abs(w[i[0]])
+            elif op == OP_ASIN: w[o[0]] = math.asin(w[i[0]])
+            elif op == OP_EXP: w[o[0]] = math.exp(w[i[0]])
+            elif op == OP_FMIN: w[o[0]] = min(w[i[0]], w[i[1]])
+            elif op == OP_FMAX: w[o[0]] = max(w[i[0]], w[i[1]])
+            elif op == OP_LT: w[o[0]] = float(w[i[0]] < w[i[1]])
+            elif op == OP_LE: w[o[0]] = float(w[i[0]] <= w[i[1]])
+            elif op == OP_EQ: w[o[0]] = float(w[i[0]] == w[i[1]])
+            elif op == OP_NE: w[o[0]] = float(w[i[0]] != w[i[1]])
+            elif op == OP_NOT: w[o[0]] = float(w[i[0]] == 0.0)
+            elif op == OP_AND: w[o[0]] = float(w[i[0]] != 0.0 and w[i[1]] != 0.0)
+            elif op == OP_OR: w[o[0]] = float(w[i[0]] != 0.0 or w[i[1]] != 0.0)
+            elif op == OP_IF_ELSE_ZERO: w[o[0]] = w[i[1]] if w[i[0]] != 0.0 else 0.0
             elif op == OP_FABS: w[o[0]] = abs(w[i[0]])
             else: raise ValueError(op)
         return outs

@@ -63,7 +63,7 @@ def test_walk_matches_direct_evaluation_and_derivatives():
 def test_unsupported_instructions_are_refused():
     x = cs.sym(0, 2)
     with pytest.raises(UnsupportedInstruction):
-        tape_from_functions(cs, 2, 0, cs.Function("f", [[(0, cs.fabs(x[0]) + x[1])]], [1]))  # no tape counterpart: never approximated
+        tape_from_functions(cs, 2, 0, cs.Function("f", [[(0, cs.exp(x[0]) + x[1])]], [1]))  # no tape counterpart: never approximated
     with pytest.raises(UnsupportedInstruction):
         tape_from_functions(cs, 2, 0, cs.Function("f", [[(0, x[0] ** x[1])]], [1]))  # pow with a variable exponent
     with pytest.raises(UnsupportedInstruction):
@@ -276,3 +276,81 @@ def test_evaluation_budget_of_a_trajectory_sized_tape_is_the_same_on_both_front_
     opt2 = FakeOptimization()
     HIPSolver(opt2).setup("hip_sqp")
     assert seen["nx"] == 3 and seen["max_iter"] == 2000
+
+
+def _rpy_functions():
+    """A cost with Quaternion.getrpy's pitch (spatialmath.py:384-404: if_else(fabs(sinp) >= 1, pi / 2, asin(sinp))) and optas.clip
+    (__init__.py:29-41: fmax(fmin(x, hi), lo)) -- the casadi opcodes the round-3 verdict lists as refused (Missing 2)."""
+    x, p = cs.sym(0, 4), cs.sym(1, 2)
+    n2 = cs.sq(x[0]) + cs.sq(x[1]) + cs.sq(x[2]) + cs.sq(x[3])
+    qx, qy, qz, qw = (x[i] / cs.sqrt(n2) for i in range(4))
+    sinp = 2.0 * (qw * qy - qz * qx)
+    pitch = cs.if_else(cs.fabs(sinp) >= 1.0, np.pi / 2.0, cs.asin(sinp))
+    roll = cs.atan2(2.0 * (qw * qx + qy * qz), 1.0 - 2.0 * (qx * qx + qy * qy))
+    clipped = cs.fmax(cs.fmin(x[3], 0.9), 0.2)
+    cost = cs.sq(pitch - p[0]) + cs.sq(roll - p[1]) + 0.1 * cs.sq(clipped - 0.5) + 0.01 * cs.sq(n2 - 1.0) + 0.05 * cs.fabs(x[2] + 2.0)
+    f = cs.Function("f", [[(0, cost)]], [1])
+    g = cs.Function("g", [[(0, cs.logic_and(x[0] > -5.0, cs.logic_or(x[1] < 5.0, cs.logic_not(x[2] >= 9.0))) + x[0] + 2.0)]], [1])
+    return f, g
+
+
+def test_rpy_clip_and_logic_opcodes_walk_and_differentiate():
+    """Values of the walked tape = direct evaluation of the instruction list; reverse-mode gradients = central differences (away from the kinks)."""
+    f, g = _rpy_functions()
+    tape = tape_from_functions(cs, 4, 2, f, ineq=(g,))
+    from optas_amd.tape import OP_ASIN, OP_FABS, OP_FMAX, OP_FMIN, OP_IFZ, OP_LE, OP_NOT
+
+    assert {OP_ASIN, OP_FABS, OP_FMIN, OP_FMAX, OP_LE, OP_NOT, OP_IFZ} <= set(tape.op.tolist())
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        x, p = rng.uniform(-1, 1, 4) + np.array([0, 0, 0, 1.5]) * rng.integers(0, 2), rng.uniform(-0.5, 0.5, 2)
+        v = tape_ref.forward(tape, x, p)
+        assert abs(v[tape.out_cost] - f(x, p)[0][0]) < 1e-12 and abs(v[tape.out_rows[0]] - g(x, p)[0][0]) < 1e-12
+        gr = tape_ref.reverse(tape, v, {int(tape.out_cost): 1.0})
+        h = 1e-6
+        for k in range(4):
+            e = np.zeros(4)
+            e[k] = h
+            fd = (f(x + e, p)[0][0] - f(x - e, p)[0][0]) / (2 * h)
+            assert abs(gr[k] - fd) < 1e-5 * max(1.0, abs(fd)), (k, gr[k], fd)
+
+
+@pytest.mark.gpu
+def test_rpy_term_through_the_literal_subclass_on_the_gpu(hip_lib):
+    """A problem with a roll / pitch term and a clipped variable solved through the literal Solver subclass (interpreter and generated-HIP path) against
+    scipy SLSQP on the same functions -- the round-3 verdict's `get_global_link_rpy` case, at the level of the opcodes it consists of."""
+
+    class Solver:
+        def __init__(self, optimization, error_on_fail=False):
+            self.opt, self._error_on_fail = optimization, error_on_fail
+            self.x0, self.p = cs.DM(np.zeros(optimization.nx)), cs.DM(np.zeros(optimization.np))
+
+        def reset_initial_seed(self, x0):
+            self.x0 = self.opt.decision_variables.dict2vec(x0)
+
+        def reset_parameters(self, p):
+            self.p = self.opt.parameters.dict2vec(p)
+
+        def solve(self):
+            return self.opt.decision_variables.vec2dict(self._solve())
+
+    HIPSolver = make_solver_class(types.SimpleNamespace(Solver=Solver), cs)
+    goal = np.array([0.3, -0.2])
+    x0 = np.array([0.1, 0.2, 0.1, 0.9])
+    results = []
+    for jit in (True, False):
+        opt = FakeOptimization()
+        opt.f, opt.g = _rpy_functions()
+        opt.h = None
+        opt.nx = 4
+        solver = HIPSolver(opt).setup("hip_sqp", {"tol": 1e-8, "jit": jit})
+        solver.reset_initial_seed({"q": x0})
+        solver.reset_parameters({"goal": goal})
+        q = solver.solve()["q"]
+        assert solver.did_solve(), solver.stats()
+        results.append((q, solver.stats()["f"]))
+    f, g = _rpy_functions()
+    s = minimize(lambda x: f(x, goal)[0][0], x0, method="SLSQP", tol=1e-13, options={"maxiter": 500}, constraints=[{"type": "ineq", "fun": lambda x: g(x, goal)[0]}])
+    for q, fv in results:
+        assert abs(fv - s.fun) < 1e-6 and g(q, goal)[0][0] > -1e-9, (fv, s.fun)
+    assert abs(results[0][1] - results[1][1]) < 1e-9  # the interpreter and the generated code walk the same tape

@@ -106,3 +106,65 @@ def test_velocity_limited_problems_against_the_interior_point_runs(hip_lib):
         be.close()
         assert r.status[0] == 0 and bool(g["tqv_ok"])
         assert r.f[0] >= float(g["tqv_f"]) - 1e-9 and r.f[0] - float(g["tqv_f"]) <= 5e-6 * r.f[0], (r.f[0], float(g["tqv_f"]))
+
+
+def test_config3_point_mass_ticks_against_the_interior_point_on_the_reference_form(hip_lib):
+    """BASELINE config 3 (point_mass_mpc.py tick): the kernel's answers against tests/golden/ipm_pm_golden.npz -- oracle/ipm_reference_form.py on the
+    literal 264-row form from the script's zero seed (tools/make_golden.py --ipm-pm; round-3 verdict, Missing 3).  All nine ticks: same basin.  The
+    interior point's optimum sits up to sum|lam| 1e-8 ~ 4e-6 below the kernel's (IPOPT's bound relaxation of the 2 x 42 dynamics rows)."""
+    from optas_amd.backend import PointMassBackend
+    from oracle.problems import PointMassMPCNLP
+
+    gi = np.load(os.path.join(GOLDEN, "ipm_pm_golden.npz"))
+    nlp = PointMassMPCNLP()
+    assert gi["optimal"].all()
+    be = PointMassBackend(tol=1e-9)
+    r = be.solve(np.zeros((len(gi["p"]), nlp.nx)), gi["p"])
+    be.close()
+    assert (r.status == 0).all()
+    for i in range(len(gi["p"])):
+        assert abs(r.f[i] - gi["f"][i]) <= 2e-5 * max(1.0, abs(gi["f"][i])) and r.f[i] >= gi["f"][i] - 1e-12, (i, r.f[i], gi["f"][i])
+        assert np.abs(r.x[i] - gi["x"][i]).max() <= 2e-4, (i, np.abs(r.x[i] - gi["x"][i]).max())
+
+
+def test_config5_torque_mpc_at_T30_against_the_interior_point_on_the_reference_form(hip_lib):
+    """BASELINE config 5 at its stated size (T = 30: 840 variables, 1680 rows of v) against tests/golden/ipm_configs_golden.npz (tq_t30*, tools/
+    make_golden.py --ipm-configs t30 t30lim: oracle/ipm_reference_form.py with the exact Lagrangian Hessian, from the reference's seed; round-3
+    verdict, Missing 3).  What the instrument shows, and what is asserted: the interior point on the literal form ends in the kernel's basin on ONE
+    of the five instances (objective equal to the relaxation, 5e-6); on the other four it converges -- E_0 <= 1e-8 or IPOPT's "acceptable" test --
+    to KKT points with objectives 52 .. 73 against the kernel's 9.2 .. 10.0 (the arm swings the long way round: tracking 20 .. 32, velocity 19 ..
+    28).  They are genuine stationary points (tests/test_ipm_reference_form.py grades them; the kernel's own state machine seeded there stays there),
+    so the problem has several local minima and which one a run reaches is a property of the method: both answers are KKT points of the reference's
+    NLP, the kernel's is the better one.  Whether IPOPT itself would land where this restatement of its algorithm lands cannot be checked here."""
+    from optas_amd.backend import TorqueBackend
+    from oracle.problems import TorqueMPCNLP
+    from oracle.torque import TorqueProblem
+
+    g, gi = np.load(os.path.join(GOLDEN, "torque_golden.npz")), np.load(os.path.join(GOLDEN, "ipm_configs_golden.npz"))
+    med7 = RobotModel.builtin("med7")
+    orc = OracleRobot(os.path.join(os.path.dirname(KUKA_KIN), "med7.kin.json"))
+    counts = {"same basin": 0, "other basin, kernel lower": 0}
+    for tag in ("t30", "t30lim"):
+        lim = float(g[tag + "_lim"])
+        nlp = TorqueMPCNLP(TorqueProblem(orc, "lbr_link_ee", T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=None if lim > 1e8 else lim))
+        lim = 100.0 if lim > 1e8 else lim
+        be = TorqueBackend(med7.kinematic_chain("lbr_link_ee"), med7.dynamics_tables(), T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=-lim, tau_up=lim)
+        qc, goal = g[tag + "_qc"], g[tag + "_goal"]
+        B = len(qc)
+        p = np.stack([nlp.pack_p(qc[b], np.zeros(7), goal[b]) for b in range(B)])
+        r = be.solve(np.stack([nlp.seed(q) for q in qc]), p)
+        lam = be.multipliers(B)
+        be.close()
+        assert (r.status == 0).all()
+        for b in range(B):
+            f_ipm = float(gi[f"tq_{tag}_f"][b])
+            k = kkt_reference_form(nlp, r.x[b], p[b], lam_kg=np.concatenate([lam[b][:, :7].reshape(-1), lam[b][:, 7:].reshape(-1)]))
+            assert k["stationarity"] <= 1e-6 and k["feasibility"] <= 1e-10 and k["complementarity"] <= 1e-8
+            if abs(r.f[b] - f_ipm) <= 1e-5 * r.f[b]:
+                counts["same basin"] += 1
+                assert np.abs(r.x[b][: 7 * 30] - gi[f"tq_{tag}_x"][b][: 7 * 30]).max() <= 1e-3  # the joint trajectories coincide
+            else:
+                counts["other basin, kernel lower"] += 1
+                assert r.f[b] < f_ipm
+    print("config 5, T = 30, five instances vs the interior point on the reference form:", counts)
+    assert counts["same basin"] >= 1 and sum(counts.values()) == 5

@@ -11,9 +11,9 @@ import os
 
 import numpy as np
 
-from conftest import GOLDEN, KUKA_KIN
+from conftest import GOLDEN, KUKA_KIN, MED7_KIN
 from oracle.ipm_reference_form import solve_ipm
-from oracle.problems import BoothNLP, FastFigureEightNLP, FigureEightNLP, IKExampleNLP, PointMassMPCNLP
+from oracle.problems import BoothNLP, FastFigureEightNLP, FigureEightNLP, IKExampleNLP, PointMassMPCNLP, TorqueMPCNLP
 from oracle.robot import OracleRobot
 from oracle.solvers import dense_sqp, kkt_reference_form
 
@@ -177,3 +177,29 @@ def test_velocity_limited_goldens_against_the_numpy_ports():
         s = solve_torque_lm(prob, g["tqv_qc"], np.zeros(7), g["tqv_goal"], vlimits=(-vmax, vmax), max_iter=600)
         assert s["status"] == 0 and bool(g["tqv_ok"]) and np.abs(s["dQ"]).max() <= vmax + 1e-8
         assert s["f"] >= float(g["tqv_f"]) - 1e-9 and s["f"] - float(g["tqv_f"]) <= 5e-6 * s["f"], (s["f"], float(g["tqv_f"]))  # below by the bound relaxation
+
+
+def test_interior_point_endpoints_of_config5_at_T30_are_kkt_points():
+    """tests/golden/ipm_configs_golden.npz, tq_t30* (tools/make_golden.py --ipm-configs t30 t30lim, ~45 minutes: oracle/ipm_reference_form.py with
+    the exact Lagrangian Hessian of oracle/problems.py:TorqueMPCNLP on BASELINE config 5 at its stated size, from the reference's seed).  The stored
+    endpoints are graded here on the literal layout: all five are KKT points of the reference's NLP to the method's own relaxation (rows of v 1e-8
+    below zero at most); ONE has the objective of the kernels' optimum, four are other local minima with objectives 5 .. 7 x higher -- recorded, not
+    asserted away (tests/test_gpu_ipm_parity.py compares the GPU with them)."""
+    from oracle.torque import TorqueProblem
+
+    g, gi = np.load(os.path.join(GOLDEN, "torque_golden.npz")), np.load(os.path.join(GOLDEN, "ipm_configs_golden.npz"))
+    if "tq_t30_x" not in gi.files:
+        pytest.skip("T = 30 interior-point goldens not generated")
+    med7 = OracleRobot(MED7_KIN)
+    same = 0
+    for tag in ("t30", "t30lim"):
+        lim = float(g[tag + "_lim"])
+        nlp = TorqueMPCNLP(TorqueProblem(med7, "lbr_link_ee", T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lim=None if lim > 1e8 else lim))
+        for b in range(len(g[tag + "_qc"])):
+            x, p = gi[f"tq_{tag}_x"][b], nlp.pack_p(g[tag + "_qc"][b], np.zeros(7), g[tag + "_goal"][b])
+            assert abs(nlp.f(x, p) - float(gi[f"tq_{tag}_f"][b])) <= 1e-9 * nlp.f(x, p)
+            assert np.abs(nlp.a(x, p)).max() <= 1.01e-8 and np.abs(nlp.h(x, p)).max() <= 1e-7 and nlp.k(x, p).min() >= -1.01e-8
+            k = kkt_reference_form(nlp, x, p, active_tol=1e-6)
+            assert k["stationarity"] <= 1e-4 and k["feasibility"] <= 1e-7, (tag, b, k["stationarity"], k["feasibility"])
+            same += abs(float(gi[f"tq_{tag}_f"][b]) - float(g[tag + "_f"][b])) <= 1e-5 * float(g[tag + "_f"][b])
+    assert same == 1

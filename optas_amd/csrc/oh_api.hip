@@ -619,7 +619,9 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   P.tol = h->tq.tol; P.tol_compl = h->tq.tol_compl; P.mu_b0 = h->tq.mu_barrier0; P.mu0 = h->tq.mu0;
   // interior point: relaxed barrier below theta mu_b; monotone barrier update of Waechter & Biegler (2006, eq. 7) -- IPOPT's constants except theta_mu (1.35 for 1.5: the hardest of 8192 instances needs 127 steps instead of 198); exact
   // curvature of the Lagrangian once the reduced gradient is below curv_from (oracle/torque_ipm.py:solve_torque_ipm has the same defaults)
-  P.theta = 0.01; P.kappa_eps = 10.0; P.kappa_mu = 0.2; P.theta_mu = 1.35; P.curv_from = 0.1; P.tau_ftb = 0.995; P.max_back = 3;
+  P.theta = 0.01; P.kappa_eps = 10.0; P.kappa_mu = 0.2; P.theta_mu = 1.35; P.curv_from = 0.1; P.curv_late = 1.0; P.curv_after = 3; P.tau_ftb = 0.995; P.max_back = 3; P.stall_max = 25;
+  if (const char* e = getenv("OH_TQ_STALL")) P.stall_max = atoi(e);
+  if (const char* e = getenv("OH_TQ_CURV_AFTER")) P.curv_after = atoi(e);
   if (const char* e = getenv("OH_TQ_FTB")) P.tau_ftb = atof(e);
   if (const char* e = getenv("OH_TQ_THETA_MU")) P.theta_mu = atof(e);
   if (const char* e = getenv("OH_TQ_KAPPA_MU")) P.kappa_mu = atof(e);
@@ -643,7 +645,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     h->tq_cap = 0;
     const size_t BT = (size_t)B * T;
     const size_t nd = 2 * BT * TQ_XS + 2 * BT * TQ_SD + 2 * BT * TQ_LAM + BT * TQ_GN + BT * 4 + 11 * (size_t)B;
-    const size_t bytes = nd * sizeof(double) + (10 * (size_t)B + 16) * sizeof(int);
+    const size_t bytes = nd * sizeof(double) + (11 * (size_t)B + 16) * sizeof(int);
     HIPCHK(hipMalloc(&h->tq_pool, bytes));
     HIPCHK(hipMalloc((void**)&h->d_tq_mult, sizeof(double) * BT * 4 * N));  // effort rows, and room for the velocity rows
     h->tq_cap = B;
@@ -668,6 +670,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     D.n_barrier = ip; ip += B;
     D.nrel = ip; ip += B;
     D.n_back = ip; ip += B;
+    D.stall = ip; ip += B;
     D.list = ip; ip += B;
     D.n_running = ip;
     D.n_list = ip + 1;

@@ -81,7 +81,10 @@ struct TqParams {
   double dt, w_path, w_vel, w_tau, tol, tol_compl, mu_b0, mu0;
   double theta;      // rows below delta = theta mu_b continue the logarithm by its second-order Taylor polynomial (relaxed barrier)
   double kappa_eps, kappa_mu, theta_mu;  // barrier update (Waechter & Biegler 2006, eq. 7): mu_b <- max(mu_min, min(kappa_mu mu_b, mu_b^theta_mu)) once stat <= kappa_eps mu_b
-  double curv_from;  // exact Lagrangian curvature in the stage blocks once the reduced gradient is below this
+  double curv_from;  // exact Lagrangian curvature in the stage blocks once the reduced gradient is below this ...
+  double curv_late;  // ... or below this after curv_after barrier updates (a Gauss-Newton iteration that stalls just above curv_from late in the solve)
+  int curv_after;
+  int stall_max;     // watchdog: this many steps at one barrier parameter without reaching its test send the instance back to 100 mu_b
   double tau_ftb;    // fraction to the boundary: a step leaves every slack (and multiplier) at least 1 - tau_ftb of itself
   int max_back;      // quarterings of a boundary-shortened step before the damping is raised instead
   double tau_lo[OH_MAX_CHAIN], tau_up[OH_MAX_CHAIN];
@@ -101,7 +104,7 @@ struct TqBuffers {
   // [B]: merit and cost of the accepted point, its barrier sum, Levenberg-Marquardt damping and its growth factor, barrier parameter, reduced gradient,
   // scale of the feed-forward of the pending trial, q_u^T k and |dx|^2 of the unit step (predicted decrease of a scaled step), violation
   double *f_cur, *f_true, *bsum, *mu, *nun, *mub, *stat, *alpha, *qk, *ndx, *viol;
-  int *cur, *first, *curv, *status, *iters, *rejected, *n_barrier, *nrel, *n_back;  // [B]
+  int *cur, *first, *curv, *status, *iters, *rejected, *n_barrier, *nrel, *n_back, *stall;  // [B]
   int* n_running;  // [1]
   int* list;       // [B] instances still running when the list was last rebuilt (kernels walk this list: finished instances cost nothing)
   int* n_list;     // [1]

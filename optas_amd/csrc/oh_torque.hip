@@ -648,6 +648,7 @@ __global__ __launch_bounds__(64) void k_tq_setup(TqParams P, TqBuffers D, const 
   D.n_barrier[b] = 0;
   D.nrel[b] = 0;
   D.n_back[b] = 0;
+  D.stall[b] = 0;
   D.list[b] = b;
 }
 
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(64) void k_tq_step(TqParams P, TqBuffers D) {
   const bool first = D.first[b] != 0;
   double f_cur = D.f_cur[b], f_true = D.f_true[b], bsum = D.bsum[b], mu = D.mu[b], nun = D.nun[b], mub = D.mub[b], alpha = D.alpha[b], viol = D.viol[b];
   double qk = D.qk[b], ndx = D.ndx[b];
-  int iters = D.iters[b], rejected = D.rejected[b], n_barrier = D.n_barrier[b], nrel = D.nrel[b], n_back = D.n_back[b];
+  int iters = D.iters[b], rejected = D.rejected[b], n_barrier = D.n_barrier[b], nrel = D.nrel[b], n_back = D.n_back[b], stall = D.stall[b];
   const double f_t = fsum + mub * bsum_t;
   bool accept, new_gains = true;
   if (first) {
@@ -1107,7 +1108,8 @@ __global__ __launch_bounds__(64) void k_tq_step(TqParams P, TqBuffers D) {
   // requested one knot ahead.
   const double mu_min = 0.1 * P.tol_compl;
   const double mub_next = fmax(mu_min, fmin(P.kappa_mu * mub, pow(mub, P.theta_mu)));
-  double stat = 0.0, stat_next = 0.0;
+  const double mub_up = fmin(P.mu_b0, 100.0 * mub);  // the watchdog's way back up (step 3)
+  double stat = 0.0, stat_next = 0.0, stat_up = 0.0;
   {
     double lfq = 0.0, lfd = 0.0, lbq = 0.0, lbd = 0.0;
     double g_n[6] = {0, 0, 0, 0, 0, 0};
@@ -1125,17 +1127,20 @@ __global__ __launch_bounds__(64) void k_tq_step(TqParams P, TqBuffers D) {
       const double rf = fma(dt, lfd, gfu), rb = fma(dt, lbd, gbu);
       stat = fmax(stat, fabs(fma(mub, rb, rf)));
       stat_next = fmax(stat_next, fabs(fma(mub_next, rb, rf)));
+      stat_up = fmax(stat_up, fabs(fma(mub_up, rb, rf)));
       const double nfd = gfd + fma(dt, lfq, lfd), nbd = gbd + fma(dt, lbq, lbd);
       lfq = gfq + lfq;
       lbq = gbq + lbq;
       lfd = nfd;
       lbd = nbd;
     }
-    if (!vec) { stat = 0.0; stat_next = 0.0; }
+    if (!vec) { stat = 0.0; stat_next = 0.0; stat_up = 0.0; }
     stat = wave_max(stat);
     stat_next = wave_max(stat_next);
+    stat_up = wave_max(stat_up);
     if (!(stat == stat)) stat = 1e300;
     if (!(stat_next == stat_next)) stat_next = 1e300;
+    if (!(stat_up == stat_up)) stat_up = 1e300;
   }
 
   // 3. convergence, barrier update
@@ -1158,8 +1163,19 @@ __global__ __launch_bounds__(64) void k_tq_step(TqParams P, TqBuffers D) {
         f_cur = f_true + mub * bsum;
         stat = stat_next;
         n_barrier += 1;
+        stall = 0;
+      } else {
+        stall += 1;
+        if (stall >= P.stall_max && nrel == 0 && accept) {
+          // watchdog: stall_max steps without reaching the barrier test -- the iterate sits far from the central path of this mu_b (slacks of the active
+          // rows collapse and recover in turn).  Back to a larger barrier parameter: the path is regained there and followed down again.
+          mub = mub_up;
+          f_cur = f_true + mub * bsum;
+          stat = stat_up;
+          stall = 0;
+        }
       }
-      curv = stat <= P.curv_from ? 1 : 0;
+      curv = (stat <= P.curv_from || (n_barrier >= P.curv_after && stat <= P.curv_late)) ? 1 : 0;
     }
   }
 
@@ -1363,6 +1379,7 @@ __global__ __launch_bounds__(64) void k_tq_step(TqParams P, TqBuffers D) {
     D.viol[b] = viol;
     D.nrel[b] = nrel;
     D.n_back[b] = n_back;
+    D.stall[b] = stall;
     D.iters[b] = iters;
     D.rejected[b] = rejected;
     D.n_barrier[b] = n_barrier;

@@ -83,7 +83,7 @@ def rollout_step(Ks, ks, alpha, dt):
 
 
 def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, tol=1e-6, tol_c=1e-8, mu0=0.1, theta=0.01, kappa_eps=10.0, kappa_mu=0.2,
-                     theta_mu=1.35, curv_from=0.1, vlimits=None, verbose=False, kappa_sig=1e10, tau_ftb=0.995, max_back=3, chain=True):
+                     theta_mu=1.35, curv_from=0.1, vlimits=None, verbose=False, kappa_sig=1e10, tau_ftb=0.995, max_back=3, curv_after=3, curv_late=1.0, stall_max=25):
     """One instance.  Returns dict(U, Q, dQ, tau, f, iters, rejected, stat, status, mu_b, lam (T, rows), s (T, rows))."""
     T, n, dt = prob.T, prob.n, prob.dt
     wp, wt, wv = prob.w_path, prob.w_tau, prob.w_vel
@@ -140,7 +140,7 @@ def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, 
     mu, nun = 0.0, 4.0
     iters = rejected = backtracks = 0
     cur, Ut, status, f_cur, use_curv = None, U, 1, np.inf, False
-    alpha, qk, ndx, n_back = 1.0, 0.0, 0.0, 0
+    alpha, qk, ndx, n_back, n_barrier, stall, n_restart = 1.0, 0.0, 0.0, 0, 0, 0, 0
     Ks = ks = None
     while True:
         tr = evalp(Ut, cur, mub, use_curv)
@@ -187,18 +187,24 @@ def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, 
         if iters >= max_iter:
             break
         if new_gains:
+            nb_before = n_barrier
             # barrier update (Waechter & Biegler 2006, eq. 7): merit and gradient are affine in mu_b while every row is in the logarithmic regime
             if accept and stat <= kappa_eps * mub and cur["nrel"] == 0 and mub > mu_min:
                 mub = max(mu_min, min(kappa_mu * mub, mub**theta_mu))
-                # ... and on, while the test holds for the next value as well ([WB] Alg. A, step A-3 loops the same way); judged on the bound
-                # |r_f| + mu_b |r_b| of the reduced gradient, which needs the two maxima only (what the kernel has at hand)
-                rf, rb = float(np.abs(costate_gradient(cur["gf"], dt)).max()), float(np.abs(costate_gradient(cur["gb"], dt)).max())
-                while chain and mub > mu_min and rf + mub * rb <= kappa_eps * mub:
-                    mub = max(mu_min, min(kappa_mu * mub, mub**theta_mu))
+                n_barrier += 1
                 f_cur = cur["ftrue"] + mub * cur["B"]
                 g = cur["gf"] + mub * cur["gb"]
                 stat = float(np.abs(costate_gradient(g, dt)).max())
-            use_curv = stat <= curv_from
+            stall = 0 if n_barrier != nb_before else stall + 1
+            if stall >= stall_max and cur["nrel"] == 0 and accept:
+                # watchdog: stall_max steps without reaching the barrier test -- the iterate sits far from the central path of this mu_b (slacks of the
+                # active rows collapse and recover in turn).  Back to a larger barrier parameter: the path is regained there and followed down again.
+                mub = min(mu0, 100.0 * mub)
+                f_cur = cur["ftrue"] + mub * cur["B"]
+                g = cur["gf"] + mub * cur["gb"]
+                stat = float(np.abs(costate_gradient(g, dt)).max())
+                stall, n_restart = 0, n_restart + 1
+            use_curv = stat <= curv_from or (n_barrier >= curv_after and stat <= curv_late)
             while True:
                 Ks, ks, ok, qk = riccati_gains(cur["H"], g, mu, dt)
                 if ok:

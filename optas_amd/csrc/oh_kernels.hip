@@ -576,10 +576,43 @@ template <int N>
 static void launch_tail_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
   hipLaunchKernelGGL(k_tail<N>, dim3(D.B), dim3(64), 0, s, P, D, slot);
 }
+// The solution x = [vec(Q); vec(dQ)] out through an LDS transpose (round 4): the knots live in [row][instance] order, the reference layout is
+// [instance][row].  k_finalize writes 7 doubles per lane at a stride of nx doubles between lanes (half-filled cache lines, one per lane and store:
+// 3.3 ms per solve at B = 262 144, 3.7 % of the headline).  Here a block reads 64 instances x 9 knots with the instances along the lanes (512-byte
+// runs), and writes every instance's 56 q and 56 dq values of the tile as one contiguous run each.  Same arithmetic per entry as finalize_unit.
+template <int N>
+__global__ __launch_bounds__(256) void k_finalize_x(FigParams P, FigBuffers D, const int only_done, double* __restrict__ x) {
+  constexpr int TK = 8, ROWS = (TK + 1) * N;
+  __shared__ double tile[ROWS][65];
+  __shared__ long long orig_s[64];
+  const int Bp = D.Bp;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + lane, t0 = blockIdx.y * TK;
+  bool emit = b < D.B;
+  if (emit && only_done && D.status[b] < 0) emit = false;
+  if (w == 0) orig_s[lane] = emit ? (long long)D.orig[b] : -1;
+  const int nk = min(TK + 1, P.T - t0);  // knots of this tile, the one the last velocity needs included
+  if (emit) {
+    const double* __restrict__ qs = D.q[D.cur[b]];
+    for (int row = w; row < nk * N; row += 4) tile[row][lane] = qs[IDX(t0 + row / N, N, row % N)];
+  }
+  __syncthreads();
+  const int nq = min(TK, P.T - t0) * N, ndq = min(TK, P.T - 1 - t0) * N;
+  const double inv_dt = 1.0 / P.dt;
+  for (int i = w; i < 64; i += 4) {
+    const long long ob = orig_s[i];
+    if (ob < 0) continue;
+    double* xb = x + (size_t)ob * P.nx;
+    if (lane < nq) xb[(size_t)t0 * N + lane] = tile[lane][i];
+    if (lane < ndq) xb[(size_t)P.T * N + (size_t)t0 * N + lane] = (tile[lane + N][i] - tile[lane][i]) * inv_dt;
+  }
+}
 template <int N>
 static void launch_finalize_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
                               int* iters, int* status) {
-  hipLaunchKernelGGL(k_finalize<N>, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, only_done, x, f, kkt, iters, status);
+  if (x) hipLaunchKernelGGL(k_finalize_x<N>, dim3((D.B + 63) / 64, (P.T + 7) / 8), dim3(256), 0, s, P, D, only_done, x);
+  // the scalars of knot 0, and the multipliers of the quaternion rows where they are asked for (every knot)
+  hipLaunchKernelGGL(k_finalize<N>, dim3((D.B + 255) / 256, D.lam_h ? P.T : 1), dim3(256), 0, s, P, D, only_done, (double*)nullptr, f, kkt, iters, status);
 }
 template <int N>
 static void launch_compact_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {

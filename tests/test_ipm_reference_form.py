@@ -203,3 +203,20 @@ def test_interior_point_endpoints_of_config5_at_T30_are_kkt_points():
             assert k["stationarity"] <= 1e-4 and k["feasibility"] <= 1e-7, (tag, b, k["stationarity"], k["feasibility"])
             same += abs(float(gi[f"tq_{tag}_f"][b]) - float(g[tag + "_f"][b])) <= 1e-5 * float(g[tag + "_f"][b])
     assert same == 1
+
+
+def test_what_an_interior_point_run_capped_at_ipopts_default_3000_iterations_returns():
+    """Round-3 verdict, Next 2(ii): `setup("ipopt")` with default options stops at max_iter = 3000.  tools/make_golden.py --ipm-cap3000 re-ran the
+    instances of nlp_ipm_golden.npz that needed more: 5 of the 17 distinct T = 50 instances stop at the cap with status "max_iter" -- what IPOPT
+    reports as "Maximum Number of Iterations Exceeded", i.e. did_solve() == False in the reference (solver.py:407-412) -- at objectives 0.001 ..
+    0.15 above the optimum the kernels return (1e-4 .. 2e-2 relative) and optimality errors E_0 between 0.15 and 1e4.  Recorded, not an assertion
+    about IPOPT itself (this is a restatement of its published algorithm; the real code cannot run here)."""
+    g = np.load(os.path.join(GOLDEN, "nlp_ipm_golden.npz"))
+    if "f_cap3000" not in g.files:
+        pytest.skip("capped runs not generated")
+    capped = ~np.isnan(g["f_cap3000"])
+    distinct = {tuple(np.round(q, 12)) for q in g["qc"][capped]}
+    assert len(distinct) == 5 and (g["iters"][capped] > 3000).all() and (g["status_cap3000"][capped] == "max_iter").all()
+    assert (g["E0_cap3000"][capped] > 0.1).all()  # nowhere near tol = 1e-8, nor acceptable_tol = 1e-6
+    gap = g["f_cap3000"][capped] - g["f_struct"][capped]
+    assert (gap > 1e-4).all() and (gap < 0.2).all()  # feasible-ish points above the optimum of the kernels

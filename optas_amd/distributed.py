@@ -44,7 +44,9 @@ def shard(n_total: int, world: int, rank: int) -> Tuple[int, int]:
 
 def launch_tag() -> str:
     """Names one launch: the launcher's port, its run id and its process id (every worker of one launch has the same parent)."""
-    return f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    secret = os.environ.get("OPTAS_RDZV_SECRET")  # optional: a random string the launcher hands to every rank makes the tag unguessable (TCP carrier)
+    return f"{tag}_{secret}" if secret else tag
 
 
 def rendezvous_dir() -> str:
@@ -75,9 +77,18 @@ def _private_dir(path: str) -> None:
         os.makedirs(d, mode=0o700, exist_ok=True)
     except OSError as e:
         raise RuntimeError(f"rendezvous directory {d} cannot be created ({e}); set OPTAS_RDZV_DIR or OPTAS_RDZV=tcp") from e
+    _check_private(d)
+
+
+def _check_private(d: str) -> None:
+    """Both sides of the file carrier: the directory must belong to this user and be writable by nobody else -- in a shared directory
+    another user could publish a record of a live process of theirs and redirect the RCCL id.  (The system tmp is refused for the same reason:
+    the default is a 0700 sub-directory of it.)"""
     st = os.stat(d)
-    if st.st_uid != os.getuid() and d != tempfile.gettempdir():
-        raise RuntimeError(f"rendezvous directory {d} belongs to another user; set OPTAS_RDZV_DIR to a directory of your own")
+    if st.st_uid != os.getuid():
+        raise RuntimeError(f"rendezvous directory {d} belongs to another user; set OPTAS_RDZV_DIR to a directory of your own, or OPTAS_RDZV=tcp")
+    if st.st_mode & 0o022:
+        raise RuntimeError(f"rendezvous directory {d} is group- or world-writable; use a private directory (chmod 700), or OPTAS_RDZV=tcp")
 
 
 def exchange_unique_id(rank: int, world: int, make_id: Callable[[], bytes], path: Optional[str] = None, timeout: float = 300.0) -> bytes:
@@ -106,7 +117,10 @@ def exchange_unique_id(rank: int, world: int, make_id: Callable[[], bytes], path
     want = _lib.OH_COMM_ID_BYTES + _REC.size
     while True:
         try:
+            _check_private(os.path.dirname(path) or ".")
             with open(path, "rb") as fh:
+                if os.fstat(fh.fileno()).st_uid != os.getuid():
+                    raise RuntimeError(f"rendezvous record {path} belongs to another user")
                 rec = fh.read()
             if len(rec) == want:
                 pid, start = _REC.unpack(rec[_lib.OH_COMM_ID_BYTES :])
@@ -117,8 +131,9 @@ def exchange_unique_id(rank: int, world: int, make_id: Callable[[], bytes], path
             pass
         if time.monotonic() - t0 > timeout:
             why = "only the record of a dead process (an earlier job?)" if seen_stale else "no record"
-            raise TimeoutError(f"rank {rank}: {why} at {path} after {timeout:.0f} s -- is rank 0 running, and does it share this directory? "
-                               f"(OPTAS_RDZV=tcp exchanges the id over MASTER_ADDR instead)")
+            raise TimeoutError(f"rank {rank}: {why} at {path} after {timeout:.0f} s -- is rank 0 running, and does it share this directory AND this "
+                               f"PID namespace (the liveness test reads /proc/<pid> of the publisher: ranks in different containers never match)? "
+                               f"OPTAS_RDZV=tcp exchanges the id over MASTER_ADDR instead")
         time.sleep(0.01)
 
 

@@ -695,7 +695,8 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
       HIPCHK(hipStreamSynchronize(s));
       running = *h->h_flag;
       if (running == 0) break;
-      if (running <= 0.9 * D.n_run) {  // rebuild the list of running instances: grids shrink with the batch
+      static const double rebuild = [] { const char* e = getenv("OH_TQ_REBUILD"); return e ? atof(e) : 0.9; }();
+      if (running <= rebuild * D.n_run) {  // rebuild the list of running instances: grids shrink with the batch
         HIPCHK(hipMemsetAsync(D.n_list, 0, sizeof(int), s));
         oh_launch_tq_list(s, D);
         D.n_run = running;

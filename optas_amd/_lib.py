@@ -246,6 +246,10 @@ SYMBOLS = [
 
 
 def library_path() -> str:
+    """In-tree liboptas_hip.so; OPTAS_HIP_LIBRARY selects another build of the same sources (tuning variants: tools/gpu_tq_waves.sh)."""
+    override = os.environ.get("OPTAS_HIP_LIBRARY")
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "liboptas_hip.so")
 
 

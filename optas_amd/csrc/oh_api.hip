@@ -627,6 +627,19 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   if (const char* e = getenv("OH_TQ_KAPPA_MU")) P.kappa_mu = atof(e);
   if (const char* e = getenv("OH_TQ_CURV_FROM")) P.curv_from = atof(e);  // 0: Gauss-Newton blocks throughout (A/B)
   P.vel = h->tq.vel_limits ? 1 : 0;
+  // d tau / dz in closed form needs the tables to describe a rigid-body chain: unit joint axes that the joint-origin rotation leaves in place (then
+  // the angular velocity the reference adds, iRp @ axis, is the axis its rotation turns about; models.py:1821-1823).  Otherwise: dual numbers.
+  P.jac_closed_form = 1;
+  for (int i = 0; i < N; ++i) {
+    const double* a = h->dyn_host.axis[i];
+    const double* R = h->dyn_host.R0[i];
+    double dev = fabs(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] - 1.0);
+    for (int k = 0; k < 3; ++k) dev = fmax(dev, fabs(R[k] * a[0] + R[3 + k] * a[1] + R[6 + k] * a[2] - a[k]));
+    if (!(dev <= 1e-12)) P.jac_closed_form = 0;
+  }
+  if (const char* e = getenv("OH_TQ_JAC")) {  // "dual": the dual-number path whatever the tables (A/B, tests)
+    if (!strcmp(e, "dual")) P.jac_closed_form = 0;
+  }
   for (int i = 0; i < N; ++i) {
     P.tau_lo[i] = h->tq.tau_lo[i];
     P.tau_up[i] = h->tq.tau_up[i];

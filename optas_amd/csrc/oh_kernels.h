@@ -90,6 +90,7 @@ struct TqParams {
   double tau_lo[OH_MAX_CHAIN], tau_up[OH_MAX_CHAIN];
   double dq_lo[OH_MAX_CHAIN], dq_up[OH_MAX_CHAIN];  // joint-velocity rows on the velocity states (vel != 0)
   int vel;
+  int jac_closed_form;  // d tau / dz in closed form (rnea_idsva) -- the dynamics tables describe a rigid-body chain; 0: dual numbers through the recursion
   int nx, np;
 };
 struct TqBuffers {

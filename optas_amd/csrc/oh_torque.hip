@@ -21,6 +21,8 @@
 //   k_tq_curv   same mapping: second derivatives of the inverse dynamics and of the link position, added to H_t for instances in the Newton phase.
 //   k_tq_step   16 lanes per instance (4 instances per wavefront): ratio test, costate recursion for the stationarity measure, barrier update,
 //               Riccati sweep with the value matrix P (14 x 14) in LDS and one column per lane, fraction to the boundary, rollout of the trial.
+#include <type_traits>
+
 #include "oh_device.h"
 #include "oh_kernels.h"
 
@@ -286,6 +288,393 @@ OH_DEV void rnea_lit(const oh_dynamics* __restrict__ dy, const SR (&q)[NB - 1], 
     mTvT(pR, dy->axis[i - 1], ax);  // pRi^T axis
     tau[i - 1] = ini[0] * ax[0] + ini[1] * ax[1] + ini[2] * ax[2];
   }
+}
+
+// ---- the same torques by virtual work, outward pass only (round 4) -------------------------------------------------------------------------------
+// tau_k = sum_{b >= k} f_b . v_b^(k) + (n_b + com_b x f_b) . w_b^(k): the inertial wrench of body b (models.py:1819-1856, the outward pass of the
+// reference) paired with the twist (w^(k), v^(k)) a unit rate of joint k alone gives the frame of body b -- what the reference's inward pass
+// (models.py:1858-1880) sums by handing wrenches to the parents, summed the other way round.  The twists travel outward with the recursion itself,
+// so nothing has to wait for the last body: no per-body arrays.  rnea_lit keeps 8 bodies x (f, n, sin, cos) of dual numbers in lane-private memory
+// (1.8 KB per lane, written once and read once: 36 KB per unit of k_tq_eval3, which made that kernel HBM-bound on its own scratch at 1.6 % of the
+// bytes being useful); here the state is 7 twists in registers.  The twists depend on the joint angles alone (SR).  Equal to rnea_lit up to rounding.
+template <int NB, bool MOVING, class S, class SR>
+OH_DEV void vw_body(const oh_dynamics* __restrict__ dy, const int i, const SR qi, const S qdi, const S qddi, S (&om)[3], S (&omD)[3], S (&vD)[3],
+                    SR (&wk)[NB - 1][3], SR (&vk)[NB - 1][3], S (&tau)[NB - 1]) {
+  constexpr int NJ = NB - 1;
+  using RT = typename std::conditional<MOVING, SR, double>::type;
+  S t1[3], t2[3], t3[3], acc[3];
+  crossT(omD, dy->xyz[i], t1);
+  crossT(om, dy->xyz[i], t2);
+  crossT(om, t2, t3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc[k] = vD[k] + t1[k] + t3[k];
+  RT Rp[9];
+  SR a[3];
+  if constexpr (MOVING) {
+    SR sj, cj;
+    sincosT(qi, &sj, &cj);
+    joint_rotation(dy->R0[i], dy->axis[i], sj, cj, Rp);
+    mTvT(Rp, dy->axis[i], a);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rp[k] = dy->R0[i][k];
+  }
+  // twists first: they need the parent's values of nothing else, and the registers of (om, omD, vD) of the parent die right after
+#pragma unroll
+  for (int k = 0; k < NJ; ++k) {
+    if (k < i) {
+      SR x[3], y[3], wn[3], vn[3];
+      crossT(wk[k], dy->xyz[i], x);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) y[c] = vk[k][c] + x[c];
+      mTvT(Rp, y, vn);
+      mTvT(Rp, wk[k], wn);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        wk[k][c] = wn[c];
+        vk[k][c] = vn[c];
+      }
+    } else if (MOVING && k == i) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        wk[k][c] = a[c];
+        vk[k][c] = SR{};
+      }
+    }
+  }
+  S omi[3], omDi[3], vDi[3];
+  {
+    S omp[3], omDp[3];
+    mTvT(Rp, om, omp);
+    mTvT(Rp, omD, omDp);
+    if constexpr (MOVING) {
+      S aq[3] = {a[0] * qdi, a[1] * qdi, a[2] * qdi};
+      S cr[3];
+      crossT(omp, aq, cr);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        omi[k] = omp[k] + aq[k];
+        omDi[k] = omDp[k] + cr[k] + a[k] * qddi;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        omi[k] = omp[k];
+        omDi[k] = omDp[k];
+      }
+    }
+    mTvT(Rp, acc, vDi);
+  }
+  S f[3], m[3];
+  crossT(omDi, dy->com[i], t1);
+  crossT(omi, dy->com[i], t2);
+  crossT(omi, t2, t3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) f[k] = dy->mass[i] * (vDi[k] + t1[k] + t3[k]);
+  {
+    S Io[3], IoD[3];
+    mvT(dy->inertia[i], omi, Io);
+    mvT(dy->inertia[i], omDi, IoD);
+    crossT(omi, Io, t1);
+    crossT(dy->com[i], f, t2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      m[k] = IoD[k] + t1[k] + t2[k];
+      om[k] = omi[k];
+      omD[k] = omDi[k];
+      vD[k] = vDi[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NJ; ++k)
+    if (k <= i) tau[k] = tau[k] + (dotT(f, vk[k]) + dotT(m, wk[k]));
+}
+
+// qs: the unit's (q | dq | ddq) at offsets 0, 8, 16 (LDS or global: indexed by the loop counter); lane j seeds joint j.  Seed: S / SR from (value, is-seed).
+template <class S>
+struct VwSeed;
+template <>
+struct VwSeed<Dual3> {
+  static OH_DEV DualR q(double v, double one) { return {v, one}; }
+  static OH_DEV Dual3 qd(double v, double one) { return {v, 0.0, one, 0.0}; }
+  static OH_DEV Dual3 qdd(double v, double one) { return {v, 0.0, 0.0, one}; }
+};
+template <int NB, class S, class SR = typename RotOf<S>::T>
+OH_DEV void rnea_vw3(const oh_dynamics* __restrict__ dy, const double* qs, const int j, S (&tau)[NB - 1]) {
+  constexpr int NJ = NB - 1;
+  S om[3], omD[3], vD[3];
+  SR wk[NJ][3], vk[NJ][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    om[k] = S{};
+    omD[k] = S{};
+    vD[k] = S{} + dy->vd0[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NJ; ++k) {
+    tau[k] = S{};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wk[k][c] = vk[k][c] = SR{};
+  }
+#pragma unroll 1
+  for (int i = 0; i < NJ; ++i) {
+    const double one = (i == j) ? 1.0 : 0.0;
+    vw_body<NB, true, S, SR>(dy, i, VwSeed<S>::q(qs[i], one), VwSeed<S>::qd(qs[8 + i], one), VwSeed<S>::qdd(qs[16 + i], one), om, omD, vD, wk, vk, tau);
+  }
+  vw_body<NB, false, S, SR>(dy, NJ, SR{}, S{}, S{}, om, omD, vD, wk, vk, tau);
+}
+
+// ---- d tau / d (q, dq, ddq) in closed form (round 4; numpy: oracle/torque.py:rnea_jacobian_spatial) ----------------------------------------------
+// The dual-number recursions above cost a unit 7 lanes x (1 primal + 3 tangents) of the whole chain: ~120 k instructions per unit, 0.45 of the batch's
+// device time.  In world coordinates (spatial vectors about the world origin, Featherstone 2008) the same derivative has a closed form.  With
+//     S_l = (z_l, o_l x z_l)            joint screw,  v_b = sum_{l<=b} S_l dq_l,  a_b = a_0 + sum_{l<=b} (S_l ddq_l + v_l x S_l dq_l),
+//     W_b = I_b a_b + v_b x* I_b v_b,   tau_k = S_k . sum_{b>=k} W_b          (what the reference's two passes compute, models.py:1819-1880)
+// and  dS_l/dq_m = S_m x S_l (m < l),  dI_b/dq_m = S_m x* I_b - I_b S_m x (m <= b)  the product rule collapses (Jacobi identity) to
+//     dW_b/dddq_j = I_b S_j,    dW_b/ddq_j = 2 (B_b S_j + I_b Sd_j),    dW_b/dq_j = S_j x* W_b + I_b Sdd_j + 2 B_b Sd_j          (b >= j)
+//     Sd_j = v_j x S_j,  Sdd_j = a_j x S_j + v_j x Sd_j,  2 B_b x = I_b (x x v_b) + x x* I_b v_b + v_b x* I_b x = (Xi_b w_x, -2 p_b x w_x)
+// (2 B_b sees only the angular part of x: Xi_b 3 x 3, p_b the linear momentum; Carpentier & Mansard 2018 and Singh, Russell & Wensing 2022 arrive at the
+// same terms).  Summed over the subtree (composites I^C, Xi^C, p^C, F^C of body m = max(k, j)):
+//     d tau_k / d(q_j, dq_j, ddq_j) = S_k . u(max(k, j)),   u_ddq = I^C S_j,  u_dq = 2 (B^C S_j + I^C Sd_j),  u_q = I^C Sdd_j + 2 B^C Sd_j (+ S_j x* F^C_j if k <= j).
+// Lane j of a unit: the serial world-frame chain (cheap, every lane), the world inertia / Xi / wrench of body j (the fixed last body rides on lane N-1),
+// exchange through LDS, then the inward composite sums and column j.  ~3 k instructions per lane.  Valid when the reference's recursion is the
+// dynamics of a rigid-body chain: unit axes that the joint-origin rotation leaves in place (R0^T axis = axis: the angular velocity the reference adds,
+// iRp @ axis, is then the axis Rot(axis, q) turns about; models.py:1821-1823).  oh_create_torque checks it; other tables take the dual-number path.
+template <int N>
+struct IdsWs {
+  static constexpr int TW = 3 * N + 1;           // row pitch of the unit's tile of columns [N + 3][3 N + 1] (k_tq_eval3), filled by phase 3
+  static constexpr int P1 = 0;                   // per body: R (9), o (3), v (6), a (6) -- dead after phase 2, the tile takes its place
+  static constexpr int S = (N + 3) * TW > (N + 1) * 24 ? (N + 3) * TW : (N + 1) * 24;  // joint screws, 6 each
+  static constexpr int BD = S + N * 6;           // per moving body: m, h (3), A (xx xy xz yy yz zz), Xi (9), p (3), W (6) = 28
+  static constexpr int SIZE = (BD + N * 28) | 1;  // odd: the units of a wavefront land in different banks
+};
+OH_DEV void mcross6(const double* x, const double* y, double* o) {  // motion x motion
+  double t[3];
+  cross3(x, y, o);
+  cross3(x, y + 3, o + 3);
+  cross3(x + 3, y, t);
+  o[3] += t[0]; o[4] += t[1]; o[5] += t[2];
+}
+OH_DEV void fcross6(const double* x, const double* f, double* o) {  // motion x* force
+  double t[3];
+  cross3(x, f, o);
+  cross3(x + 3, f + 3, t);
+  o[0] += t[0]; o[1] += t[1]; o[2] += t[2];
+  cross3(x, f + 3, o + 3);
+}
+// (n, f) = I (w, v) for a rigid-body inertia about the world origin: n = A w + h x v, f = m v - h x w;  A = (xx xy xz yy yz zz)
+OH_DEV void inert6(const double m, const double* h, const double* A, const double* x, double* o) {
+  double t[3];
+  cross3(h, x + 3, t);
+  o[0] = A[0] * x[0] + A[1] * x[1] + A[2] * x[2] + t[0];
+  o[1] = A[1] * x[0] + A[3] * x[1] + A[4] * x[2] + t[1];
+  o[2] = A[2] * x[0] + A[4] * x[1] + A[5] * x[2] + t[2];
+  cross3(h, x, t);
+  o[3] = m * x[3] - t[0];
+  o[4] = m * x[4] - t[1];
+  o[5] = m * x[5] - t[2];
+}
+OH_DEV double dot6(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5]; }
+
+// world inertia, momentum coupling and wrench of body b from its (R, o, v, a), added to acc[28]
+OH_DEV void ids_body(const oh_dynamics* __restrict__ dy, const int b, const double* __restrict__ p1, double* acc) {
+  const double* R = p1;
+  const double* o = p1 + 9;
+  const double* v = p1 + 12;
+  const double* a = p1 + 18;
+  double c[3], T[9], Ic[9];
+  mv3(R, dy->com[b], c);
+  c[0] += o[0]; c[1] += o[1]; c[2] += o[2];
+  mm3(R, dy->inertia[b], T);
+  mmT3(T, R, Ic);
+  const double m = dy->mass[b];
+  const double h[3] = {m * c[0], m * c[1], m * c[2]};
+  const double c2 = dot3(c, c);
+  double A[6];
+  A[0] = Ic[0] + m * (c2 - c[0] * c[0]);
+  A[1] = 0.5 * (Ic[1] + Ic[3]) - m * c[0] * c[1];
+  A[2] = 0.5 * (Ic[2] + Ic[6]) - m * c[0] * c[2];
+  A[3] = Ic[4] + m * (c2 - c[1] * c[1]);
+  A[4] = 0.5 * (Ic[5] + Ic[7]) - m * c[1] * c[2];
+  A[5] = Ic[8] + m * (c2 - c[2] * c[2]);
+  double Pm[6], W[6], t6[6];
+  inert6(m, h, A, v, Pm);
+  inert6(m, h, A, a, W);
+  fcross6(v, Pm, t6);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) W[k] += t6[k];
+  // Xi = [w]x A + ([w]x A)^T - (h vl^T + vl h^T - 2 (vl . h) 1) - [n_P]x
+  const double* w = v;
+  const double* vl = v + 3;
+  const double Af[9] = {A[0], A[1], A[2], A[1], A[3], A[4], A[2], A[4], A[5]};
+  double OA[9];  // columns w x A[:, k]
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double col[3] = {Af[k], Af[3 + k], Af[6 + k]};
+    double x[3];
+    cross3(w, col, x);
+    OA[k] = x[0]; OA[3 + k] = x[1]; OA[6 + k] = x[2];
+  }
+  const double vh = dot3(vl, h);
+  double Xi[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Xi[3 * r + k] = OA[3 * r + k] + OA[3 * k + r] - h[r] * vl[k] - vl[r] * h[k] + (r == k ? 2.0 * vh : 0.0);
+  Xi[1] += Pm[2]; Xi[2] -= Pm[1];
+  Xi[3] -= Pm[2]; Xi[5] += Pm[0];
+  Xi[6] += Pm[1]; Xi[7] -= Pm[0];
+  acc[0] += m;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc[1 + k] += h[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc[4 + k] += A[k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[10 + k] += Xi[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc[19 + k] += Pm[3 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) acc[22 + k] += W[k];
+}
+
+// ws: the unit's LDS workspace (IdsWs<N>::SIZE doubles), qs: (q | dq | ddq) at 0, 8, 16; every lane of the unit calls (block of one wavefront).
+// Lane j leaves column j, N + j, 2 N + j of d tau / d (q, dq, ddq) in rows 0 .. N-1 of the tile at ws[0] and returns tau_j.
+template <int N>
+OH_DEV double rnea_idsva(const oh_dynamics* __restrict__ dy, double* __restrict__ ws, const double* __restrict__ qs, const int j, const bool writer) {
+  using L = IdsWs<N>;
+  double Sj[6], Sdj[6], Sddj[6];
+  {
+    double Rw[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0}, ow[3] = {0.0, 0.0, 0.0};
+    double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, a[6] = {0.0, 0.0, 0.0, dy->vd0[0], dy->vd0[1], dy->vd0[2]};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Sj[k] = Sdj[k] = Sddj[k] = 0.0;
+#pragma unroll 1
+    for (int i = 0; i <= N; ++i) {
+      double o[3], Ri[9];
+      mv3(Rw, dy->xyz[i], o);
+      o[0] += ow[0]; o[1] += ow[1]; o[2] += ow[2];
+      if (i < N) {
+        double S[6], Sd[6], Sdd[6], t6[6], Rp[9], sj, cj;
+        mv3(Rw, dy->axis[i], S);
+        cross3(o, S, S + 3);
+        sincos_joint(qs[i], &sj, &cj);
+        joint_rotation(dy->R0[i], dy->axis[i], sj, cj, Rp);
+        mm3(Rw, Rp, Ri);
+        mcross6(v, S, Sd);
+        const double qd = qs[8 + i], qdd = qs[16 + i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          v[k] = fma(S[k], qd, v[k]);
+          a[k] = fma(Sd[k], qd, fma(S[k], qdd, a[k]));
+        }
+        mcross6(a, S, Sdd);
+        mcross6(v, Sd, t6);
+        const bool mine = i == j;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          Sdd[k] += t6[k];
+          Sj[k] = mine ? S[k] : Sj[k];
+          Sdj[k] = mine ? Sd[k] : Sdj[k];
+          Sddj[k] = mine ? Sdd[k] : Sddj[k];
+        }
+        if (writer && mine) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ws[L::S + 6 * i + k] = S[k];
+        }
+      } else {
+        mm3(Rw, dy->R0[i], Ri);
+      }
+      if (writer && j == (i < N ? i : N - 1)) {
+        double* p1 = ws + L::P1 + 24 * i;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) p1[k] = Ri[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p1[9 + k] = o[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          p1[12 + k] = v[k];
+          p1[18 + k] = a[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rw[k] = Ri[k];
+      ow[0] = o[0]; ow[1] = o[1]; ow[2] = o[2];
+    }
+  }
+  __syncthreads();
+  {
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+    ids_body(dy, j, ws + L::P1 + 24 * j, acc);
+    if (j == N - 1) ids_body(dy, N, ws + L::P1 + 24 * N, acc);  // the fixed last body moves with body N - 1
+    if (writer) {
+#pragma unroll
+      for (int k = 0; k < 28; ++k) ws[L::BD + 28 * j + k] = acc[k];
+    }
+  }
+  __syncthreads();
+  double C[28];
+  double u0s[6], u1s[6], u2s[6];
+  double tau_j = 0.0;
+#pragma unroll
+  for (int k = 0; k < 28; ++k) C[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) u0s[k] = u1s[k] = u2s[k] = 0.0;
+#pragma unroll 1
+  for (int m = N - 1; m >= 0; --m) {
+    const double* bd = ws + L::BD + 28 * m;
+    double Sm[6];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) C[k] += bd[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Sm[k] = ws[L::S + 6 * m + k];
+    const double* hC = C + 1;
+    const double* AC = C + 4;
+    const double* XC = C + 10;
+    const double* pC = C + 19;
+    const double* FC = C + 22;
+    double u0[6], u1[6], u2[6], t6[6], x[3];
+    inert6(C[0], hC, AC, Sj, u2);
+    inert6(C[0], hC, AC, Sdj, t6);
+    mv3(XC, Sj, u1);
+    cross3(pC, Sj, x);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      u1[k] = fma(2.0, t6[k], u1[k]);
+      u1[3 + k] = 2.0 * (t6[3 + k] - x[k]);
+    }
+    inert6(C[0], hC, AC, Sddj, u0);
+    mv3(XC, Sdj, t6);
+    cross3(pC, Sdj, x);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      u0[k] += t6[k];
+      u0[3 + k] -= 2.0 * x[k];
+    }
+    if (m == j) {
+      fcross6(Sj, FC, t6);
+      tau_j = dot6(Sm, FC);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        u0s[k] = u0[k] + t6[k];
+        u1s[k] = u1[k];
+        u2s[k] = u2[k];
+      }
+    }
+    const bool below = m > j;  // row below the diagonal: the composites of body m; else what column j froze at its own body
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      u0[k] = below ? u0[k] : u0s[k];
+      u1[k] = below ? u1[k] : u1s[k];
+      u2[k] = below ? u2[k] : u2s[k];
+    }
+    if (writer) {
+      ws[m * L::TW + j] = dot6(Sm, u0);
+      ws[m * L::TW + N + j] = dot6(Sm, u1);
+      ws[m * L::TW + 2 * N + j] = dot6(Sm, u2);
+    }
+  }
+  return tau_j;
 }
 
 // d tau / d (q, qd, qdd) of RobotModel.rnea (what the reference obtains with casadi.jacobian of the same graph, optimization.py:8-24): one lane per
@@ -700,17 +1089,22 @@ OH_DEV TqRow tq_row(const double s, const double s_old, const double lam_old, co
 #ifndef OH_TQ_EVAL3_WAVES
 #define OH_TQ_EVAL3_WAVES 1
 #endif
-template <int N, bool VEL = false>
+template <int N, bool VEL = false, bool IDS = true>
 __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, TqBuffers D) {
   constexpr int NZ = 3 * N;
   constexpr int UPW = 64 / N;  // units per wavefront (9)
-  __shared__ double tile[UPW][N + 3][NZ + 1];
+  constexpr int TW = NZ + 1;   // row pitch of a unit's tile of columns [N + 3][NZ + 1]: rows 0 .. N-1 d tau / dz, rows N .. N+2 d p_link / dz
+  constexpr int WS = IDS ? IdsWs<N>::SIZE : ((N + 3) * TW | 1);  // a unit's LDS: the tile, and behind it the workspace of rnea_idsva
+  static_assert(!IDS || IdsWs<N>::TW == TW, "tile pitch");
+  __shared__ double lds_raw[UPW * WS];
+  __shared__ double qs_l[UPW][24];
+  __shared__ double rw_l[UPW][8][N];
   const int T = P.T;
   const int lane = threadIdx.x;
   if (blockIdx.x == 0 && lane == 0) *D.n_running = 0;  // k_tq_step, next in the stream, counts the instances that go on
   int ul = lane / N, j = lane - ul * N;
   const bool lane_ok = ul < UPW;
-  if (!lane_ok) {  // lane 63 has no unit: it rides along on the last unit and keeps its hands off the tile
+  if (!lane_ok) {  // lane 63 has no unit: it rides along on the last unit and keeps its hands off LDS
     ul = UPW - 1;
     j = N - 1;
   }
@@ -727,135 +1121,159 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
   const bool have_old = D.first[b] == 0;
   const double mub = D.mub[b], delta = P.theta * mub;
 
-  DualR q[N];
-  Dual3 qd[N], qdd[N], tau[N];
-  double qv[N], dqv[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const double one = (k == j) ? 1.0 : 0.0;
-    qv[k] = xr[k];
-    dqv[k] = xr[8 + k];
-    q[k] = {qv[k], one};
-    qd[k] = {dqv[k], 0.0, one, 0.0};
-    qdd[k] = {xr[16 + k], 0.0, 0.0, one};
+  // 1. torques and their derivative: lane j leaves its three columns in the unit's tile and keeps tau_j
+  const double qj = xr[j], dqj = xr[8 + j];
+  if (lane_ok) {  // the recursions read (q | dq | ddq) of their unit by a loop counter: LDS, not a lane-private array
+    qs_l[ul][j] = qj;
+    qs_l[ul][8 + j] = dqj;
+    qs_l[ul][16 + j] = xr[16 + j];
   }
-  rnea_lit<N + 1, Dual3>(D.dyn, q, qd, qdd, tau);
+  __syncthreads();
+  double* tl = lds_raw + ul * WS;
+  double tvj;
+  if constexpr (IDS) {
+    tvj = rnea_idsva<N>(D.dyn, tl, qs_l[ul], j, lane_ok);
+  } else {
+    Dual3 tau[N];
+    rnea_vw3<N + 1, Dual3>(D.dyn, qs_l[ul], j, tau);
+    tvj = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      tvj = (i == j) ? tau[i].v : tvj;
+      if (lane_ok) {
+        tl[i * TW + j] = tau[i].d0;
+        tl[i * TW + N + j] = tau[i].d1;
+        tl[i * TW + 2 * N + j] = tau[i].d2;
+      }
+    }
+  }
 
-  // effort rows under the barrier (every lane of the unit computes them: they are cheap and everyone needs cf, cb, dw)
+  // 2. inequality rows under the barrier: lane j takes the rows of joint j (a row costs two divisions and a logarithm: ~350 instructions -- with every
+  // lane computing all 14 of them, as until round 4, they were a third of the kernel); the unit shares cf, cb, dw and the sums through LDS
   const double* lm_old = D.lam + (((size_t)cur * D.B + b) * T + t) * TQ_LAM;
   double* lm_new = D.lam + (((size_t)ts * D.B + b) * T + t) * TQ_LAM;
   const double* sr_old = D.st + st_off(D, T, cur, b, t);
   const double* xr_old = D.xs + xs_off(D, T, cur, b, t);
-  double cf[N], cb[N], dw[N];
-  double bar = 0.0, viol = 0.0, cmpl = 0.0, tau2 = 0.0;
-  int nrel = 0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const double tv = tau[i].v;
-    const double tv_old = have_old ? sr_old[256 + i] : 0.0;
-    const TqRow lo = tq_row(tv - P.tau_lo[i], tv_old - P.tau_lo[i], have_old ? lm_old[i] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
-    const TqRow up = tq_row(P.tau_up[i] - tv, P.tau_up[i] - tv_old, have_old ? lm_old[N + i] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
-    bar += lo.bar + up.bar;
-    nrel += (lo.relaxed ? 1 : 0) + (up.relaxed ? 1 : 0);
-    viol = fmax(viol, fmax(P.tau_lo[i] - tv, tv - P.tau_up[i]));
-    cmpl = fmax(cmpl, fmax(lo.lam * (tv - P.tau_lo[i]), up.lam * (P.tau_up[i] - tv)));
-    cf[i] = 2.0 * P.w_tau * tv;
-    cb[i] = up.bco - lo.bco;
-    dw[i] = 2.0 * P.w_tau + lo.sig + up.sig;
-    tau2 += tv * tv;
-    if (active && j == 0) {
-      lm_new[i] = lo.lam;
-      lm_new[N + i] = up.lam;
-    }
-  }
-  // joint-velocity rows on the velocity states (enforce_model_limits(name, time_deriv=1), builder.py:471-509): stage-local, linear in the state
   double cbv = 0.0, dvj = 0.0;
-  if constexpr (VEL) {
+  {
+    double tlo = 0.0, tup = 0.0, vlo = 0.0, vup = 0.0;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const double dv = dqv[i];
-      const double dv_old = have_old ? xr_old[8 + i] : 0.0;
-      const TqRow lo = tq_row(dv - P.dq_lo[i], dv_old - P.dq_lo[i], have_old ? lm_old[16 + i] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
-      const TqRow up = tq_row(P.dq_up[i] - dv, P.dq_up[i] - dv_old, have_old ? lm_old[16 + N + i] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
-      bar += lo.bar + up.bar;
-      nrel += (lo.relaxed ? 1 : 0) + (up.relaxed ? 1 : 0);
-      viol = fmax(viol, fmax(P.dq_lo[i] - dv, dv - P.dq_up[i]));
-      cmpl = fmax(cmpl, fmax(lo.lam * (dv - P.dq_lo[i]), up.lam * (P.dq_up[i] - dv)));
-      if (i == j) {
-        cbv = up.bco - lo.bco;
-        dvj = lo.sig + up.sig;
-      }
-      if (active && j == 0) {
-        lm_new[16 + i] = lo.lam;
-        lm_new[16 + N + i] = up.lam;
+    for (int i = 0; i < N; ++i) {  // (P lives in scalar registers: no indexing by the lane)
+      tlo = (i == j) ? P.tau_lo[i] : tlo;
+      tup = (i == j) ? P.tau_up[i] : tup;
+      if constexpr (VEL) {
+        vlo = (i == j) ? P.dq_lo[i] : vlo;
+        vup = (i == j) ? P.dq_up[i] : vup;
       }
     }
-  }
-
-  // link position and column j of its Jacobian (models.py:826-868, 1211-1264)
-  double R[9], pp[3], z[N][3], pj[N][3];
-  fk_chain<N>(D.chain, qv, R, pp, z, pj);
-  double e[3], tv3[3];
-  mv3(R, D.chain->p_tool, tv3);
-  const double* gl = D.goal + ((size_t)b * T + t) * 4;
-  double r[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    e[k] = pp[k] + tv3[k];
-    r[k] = e[k] - gl[k];
-  }
-  double zd[3] = {0.0, 0.0, 0.0}, pd[3] = {0.0, 0.0, 0.0};
-  int jt_d = 0;
-#pragma unroll
-  for (int k = 0; k < N; ++k)
-    if (k == j) {
-      zd[0] = z[k][0]; zd[1] = z[k][1]; zd[2] = z[k][2];
-      pd[0] = pj[k][0]; pd[1] = pj[k][1]; pd[2] = pj[k][2];
-      jt_d = D.chain->jtype[k];
+    const double tv_old = have_old ? sr_old[256 + j] : 0.0;
+    const TqRow lo = tq_row(tvj - tlo, tv_old - tlo, have_old ? lm_old[j] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
+    const TqRow up = tq_row(tup - tvj, tup - tv_old, have_old ? lm_old[N + j] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
+    double bar_j = lo.bar + up.bar;
+    double nrel_j = (lo.relaxed ? 1.0 : 0.0) + (up.relaxed ? 1.0 : 0.0);
+    double viol_j = fmax(tlo - tvj, tvj - tup);
+    double cmpl_j = fmax(lo.lam * (tvj - tlo), up.lam * (tup - tvj));
+    if (active) {
+      lm_new[j] = lo.lam;
+      lm_new[N + j] = up.lam;
     }
-  double jp[3];
-  if (jt_d == 0) {
-    const double dd[3] = {e[0] - pd[0], e[1] - pd[1], e[2] - pd[2]};
-    cross3(zd, dd, jp);
-  } else {
-    jp[0] = zd[0]; jp[1] = zd[1]; jp[2] = zd[2];
-  }
-
-  // components j, N + j, 2 N + j of the gradient of the cost and of the barrier (per unit mu_b)
-  double g0 = 0.0, g1 = 0.0, g2 = 0.0, h0 = 0.0, h1 = 0.0, h2 = 0.0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    g0 = fma(cf[i], tau[i].d0, g0);
-    g1 = fma(cf[i], tau[i].d1, g1);
-    g2 = fma(cf[i], tau[i].d2, g2);
-    h0 = fma(cb[i], tau[i].d0, h0);
-    h1 = fma(cb[i], tau[i].d1, h1);
-    h2 = fma(cb[i], tau[i].d2, h2);
-  }
-  g0 += 2.0 * P.w_path * dot3(jp, r);
-  double dqj = 0.0;
-#pragma unroll
-  for (int k = 0; k < N; ++k)
-    if (k == j) dqj = dqv[k];
-  g1 += 2.0 * P.w_vel * dqj;
-  h1 += cbv;
-
-  // exchange the columns through LDS; the link position has no dq / ddq columns
-  if (lane_ok) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      tile[ul][i][j] = tau[i].d0;
-      tile[ul][i][N + j] = tau[i].d1;
-      tile[ul][i][2 * N + j] = tau[i].d2;
+    // joint-velocity rows on the velocity states (enforce_model_limits(name, time_deriv=1), builder.py:471-509): stage-local, linear in the state
+    if constexpr (VEL) {
+      const double dv_old = have_old ? xr_old[8 + j] : 0.0;
+      const TqRow l2 = tq_row(dqj - vlo, dv_old - vlo, have_old ? lm_old[16 + j] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
+      const TqRow u2 = tq_row(vup - dqj, vup - dv_old, have_old ? lm_old[16 + N + j] : 0.0, have_old, mub, delta, 1.0 - P.tau_ftb);
+      bar_j += l2.bar + u2.bar;
+      nrel_j += (l2.relaxed ? 1.0 : 0.0) + (u2.relaxed ? 1.0 : 0.0);
+      viol_j = fmax(viol_j, fmax(vlo - dqj, dqj - vup));
+      cmpl_j = fmax(cmpl_j, fmax(l2.lam * (dqj - vlo), u2.lam * (vup - dqj)));
+      cbv = u2.bco - l2.bco;
+      dvj = l2.sig + u2.sig;
+      if (active) {
+        lm_new[16 + j] = l2.lam;
+        lm_new[16 + N + j] = u2.lam;
+      }
     }
+    if (lane_ok) {
+      rw_l[ul][0][j] = 2.0 * P.w_tau * tvj;              // cf
+      rw_l[ul][1][j] = up.bco - lo.bco;                  // cb
+      rw_l[ul][2][j] = 2.0 * P.w_tau + lo.sig + up.sig;  // dw
+      rw_l[ul][3][j] = bar_j;
+      rw_l[ul][4][j] = nrel_j;
+      rw_l[ul][5][j] = viol_j;
+      rw_l[ul][6][j] = cmpl_j;
+      rw_l[ul][7][j] = fma(P.w_tau * tvj, tvj, P.w_vel * dqj * dqj);
+    }
+  }
+
+  // 3. link position and column j of its Jacobian (models.py:826-868, 1211-1264)
+  double jp[3], r[3];
+  {
+    double qv[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) qv[k] = qs_l[ul][k];
+    double R[9], pp[3], z[N][3], pj[N][3];
+    fk_chain<N>(D.chain, qv, R, pp, z, pj);
+    double e[3], tv3[3];
+    mv3(R, D.chain->p_tool, tv3);
+    const double* gl = D.goal + ((size_t)b * T + t) * 4;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      tile[ul][N + k][j] = jp[k];
-      tile[ul][N + k][N + j] = 0.0;
-      tile[ul][N + k][2 * N + j] = 0.0;
+      e[k] = pp[k] + tv3[k];
+      r[k] = e[k] - gl[k];
+    }
+    double zd[3] = {0.0, 0.0, 0.0}, pd[3] = {0.0, 0.0, 0.0};
+    int jt_d = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (k == j) {
+        zd[0] = z[k][0]; zd[1] = z[k][1]; zd[2] = z[k][2];
+        pd[0] = pj[k][0]; pd[1] = pj[k][1]; pd[2] = pj[k][2];
+        jt_d = D.chain->jtype[k];
+      }
+    if (jt_d == 0) {
+      const double dd[3] = {e[0] - pd[0], e[1] - pd[1], e[2] - pd[2]};
+      cross3(zd, dd, jp);
+    } else {
+      jp[0] = zd[0]; jp[1] = zd[1]; jp[2] = zd[2];
+    }
+  }
+  if (lane_ok) {  // the link position has no dq / ddq columns
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      tl[(N + k) * TW + j] = jp[k];
+      tl[(N + k) * TW + N + j] = 0.0;
+      tl[(N + k) * TW + 2 * N + j] = 0.0;
     }
   }
   __syncthreads();
+
+  // 4. components j, N + j, 2 N + j of the gradient of the cost and of the barrier (per unit mu_b), the lane's three columns of the stage block
+  double dw[N], J0[N], J1[N], J2[N];
+  double g0 = 0.0, g1 = 0.0, g2 = 0.0, h0 = 0.0, h1 = 0.0, h2 = 0.0;
+  double bar = 0.0, viol = 0.0, cmpl = 0.0, fsum = 0.0;
+  int nrel = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double cf = rw_l[ul][0][i], cb = rw_l[ul][1][i];
+    dw[i] = rw_l[ul][2][i];
+    bar += rw_l[ul][3][i];
+    nrel += (int)rw_l[ul][4][i];
+    viol = fmax(viol, rw_l[ul][5][i]);
+    cmpl = fmax(cmpl, rw_l[ul][6][i]);
+    fsum += rw_l[ul][7][i];
+    J0[i] = tl[i * TW + j];
+    J1[i] = tl[i * TW + N + j];
+    J2[i] = tl[i * TW + 2 * N + j];
+    g0 = fma(cf, J0[i], g0);
+    g1 = fma(cf, J1[i], g1);
+    g2 = fma(cf, J2[i], g2);
+    h0 = fma(cb, J0[i], h0);
+    h1 = fma(cb, J1[i], h1);
+    h2 = fma(cb, J2[i], h2);
+  }
+  g0 += 2.0 * P.w_path * dot3(jp, r);
+  g1 += 2.0 * P.w_vel * dqj;
+  h1 += cbv;
   double* sr = D.st + st_off(D, T, ts, b, t);
   if (active) {
 #pragma unroll
@@ -863,15 +1281,15 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
       const int d = c3 * N + j;
       double col[N];
 #pragma unroll
-      for (int i = 0; i < N; ++i) col[i] = c3 == 0 ? tau[i].d0 : (c3 == 1 ? tau[i].d1 : tau[i].d2);
+      for (int i = 0; i < N; ++i) col[i] = dw[i] * (c3 == 0 ? J0[i] : (c3 == 1 ? J1[i] : J2[i]));
       for (int rr = d; rr < NZ; ++rr) {
         double hv = 0.0;
 #pragma unroll
-        for (int i = 0; i < N; ++i) hv = fma(dw[i] * tile[ul][i][rr], col[i], hv);
+        for (int i = 0; i < N; ++i) hv = fma(tl[i * TW + rr], col[i], hv);
         if (c3 == 0) {
           double hp = 0.0;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) hp = fma(tile[ul][N + k][rr], jp[k], hp);
+          for (int k = 0; k < 3; ++k) hp = fma(tl[(N + k) * TW + rr], jp[k], hp);
           hv = fma(2.0 * P.w_path, hp, hv);
         }
         if (rr == d && c3 == 1) {
@@ -881,7 +1299,7 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
         sr[rr * (rr + 1) / 2 + d] = hv;
       }
 #pragma unroll
-      for (int i = 0; i < N; ++i) sr[TQ_SD_J + i * NZ + d] = col[i];
+      for (int i = 0; i < N; ++i) sr[TQ_SD_J + i * NZ + d] = c3 == 0 ? J0[i] : (c3 == 1 ? J1[i] : J2[i]);
     }
     sr[231 + j] = g0;
     sr[231 + N + j] = g1;
@@ -890,20 +1308,13 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
     sr[TQ_SD_GB + N + j] = h1;
     sr[TQ_SD_GB + 2 * N + j] = h2;
     if (j == 0) {
-      double dq2 = 0.0;
-#pragma unroll
-      for (int k = 0; k < N; ++k) dq2 = fma(dqv[k], dqv[k], dq2);
-      sr[252] = P.w_path * dot3(r, r) + P.w_vel * dq2 + P.w_tau * tau2;
+      sr[252] = P.w_path * dot3(r, r) + fsum;
       sr[253] = bar;
       sr[254] = (double)nrel;
       sr[255] = viol;
       sr[263] = cmpl;
     }
-    double tvd = 0.0;
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-      if (i == j) tvd = tau[i].v;
-    sr[256 + j] = tvd;
+    sr[256 + j] = tvj;
   }
 }
 
@@ -912,8 +1323,11 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
 //   + 2 w_p sum_k r_k d^2 p_k / dq^2,  d^2 p / dq_a dq_b = z_b x (z_a x (e - o_a)) for b <= a
 // to the stage block k_tq_eval3 has just written.  One lane per (instance, knot, joint) again: lane j runs the hand-written adjoint of the recursion on
 // (DualR, Dual2) scalars seeded with q_j and dq_j, which yields rows q_j and dq_j of the first term; every packed entry is owned by exactly one lane.
+#ifndef OH_TQ_CURV_WAVES
+#define OH_TQ_CURV_WAVES 1
+#endif
 template <int N>
-__global__ __launch_bounds__(64, 1) void k_tq_curv(TqParams P, TqBuffers D) {
+__global__ __launch_bounds__(64, OH_TQ_CURV_WAVES) void k_tq_curv(TqParams P, TqBuffers D) {
   constexpr int UPW = 64 / N;
   const int T = P.T;
   const int lane = threadIdx.x;
@@ -1027,8 +1441,11 @@ OH_DEV double row_sum8(double v) {  // sum over the 8 lanes of a row (lane = 8 r
 //   5. closed-loop rollout of the unit step: the control steps go to LDS, the linearised rows give the fraction to the boundary alpha
 //   6. open-loop rollout of  u + alpha du  on the trial values themselves (the Euler rows hold to the rounding of one operation)
 // A trial that left the domain of the arithmetic, or a boundary-shortened step that was rejected, is retried shorter: steps 5-6 only.
+#ifndef OH_TQ_STEP_WAVES
+#define OH_TQ_STEP_WAVES 2
+#endif
 template <int N, bool VEL = false>
-__global__ __launch_bounds__(64) void k_tq_step(TqParams P, TqBuffers D) {
+__global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, TqBuffers D) {
   static_assert(N == 7, "the lane layout is 8 rows x 8 columns: 7 joints and the vector column");
   constexpr int NX = 2 * N, NZ = 3 * N;
   extern __shared__ double du_dyn[];  // [T][8]: the control steps of the unit step
@@ -1475,8 +1892,14 @@ bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D) {
   if (P.N != 7) return false;
   const long long units = (long long)D.n_run * P.T;
   // (the variants with joint-velocity rows are instantiations of their own: as a run-time branch the rows cost k_tq_eval3 21 % at 8192 instances)
-  if (P.vel) hipLaunchKernelGGL((k_tq_eval3<7, true>), dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
-  else hipLaunchKernelGGL((k_tq_eval3<7>), dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);
+  const dim3 grid((unsigned)((units + 8) / 9));
+  if (P.jac_closed_form) {
+    if (P.vel) hipLaunchKernelGGL((k_tq_eval3<7, true, true>), grid, dim3(64), 0, s, P, D);
+    else hipLaunchKernelGGL((k_tq_eval3<7, false, true>), grid, dim3(64), 0, s, P, D);
+  } else {
+    if (P.vel) hipLaunchKernelGGL((k_tq_eval3<7, true, false>), grid, dim3(64), 0, s, P, D);
+    else hipLaunchKernelGGL((k_tq_eval3<7, false, false>), grid, dim3(64), 0, s, P, D);
+  }
   hipLaunchKernelGGL(k_tq_curv<7>, dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);  // exits at once where no instance takes Newton steps
   return true;
 }

@@ -475,3 +475,89 @@ def rnea_ctau_hessian(tb: RneaTables, q, qd, qdd, c, h=1e-30):
     g = rnea_ctau_gradient(tb, zz[..., :n], zz[..., n:2 * n], zz[..., 2 * n:], c[..., None, :])  # (..., 3n directions, 3n)
     H = g.imag / h
     return 0.5 * (H + np.swapaxes(H, -1, -2))
+
+
+# ---- d tau / d (q, dq, ddq) in closed form (round 4; csrc/oh_torque.hip:rnea_idsva is this, lane by lane) ------------------------------------------
+# World-frame spatial vectors (w, v_O) / (n_O, f) about the world origin (Featherstone 2008).  S_l = (z_l, o_l x z_l), v_b = sum S_l dq_l,
+# a_b = a_0 + sum (S_l ddq_l + v_l x S_l dq_l), W_b = I_b a_b + v_b x* I_b v_b, tau_k = S_k . sum_{b >= k} W_b  -- what RobotModel.rnea computes
+# (models.py:1819-1880) -- and, by the product rule with dS_l/dq_m = S_m x S_l, dI_b/dq_m = S_m x* I_b - I_b S_m x and the Jacobi identity,
+#   d tau_k / d ddq_j = S_k . I^C_m S_j,   d tau_k / d dq_j = 2 S_k . (B^C_m S_j + I^C_m Sd_j),
+#   d tau_k / d q_j = S_k . (I^C_m Sdd_j + 2 B^C_m Sd_j [+ S_j x* F^C_j if k <= j]),      m = max(k, j),
+# Sd_j = v_j x S_j, Sdd_j = a_j x S_j + v_j x Sd_j, 2 B_b x = (Xi_b w_x, -2 p_b x w_x) (Carpentier & Mansard 2018; Singh, Russell & Wensing 2022).
+# Valid for tables that describe a rigid-body chain (unit axes that the joint-origin rotation leaves in place: the reference adds the angular
+# velocity iRp @ axis, models.py:1821-1823); checked against the complex-step derivative of the literal recursion in tests/test_torque_cpu.py.
+def _skew(v):
+    z = np.zeros(v.shape[:-1])
+    return np.stack([np.stack([z, -v[...,2], v[...,1]],-1), np.stack([v[...,2], z, -v[...,0]],-1), np.stack([-v[...,1], v[...,0], z],-1)],-2)
+
+def _mx(x, y):   # motion cross  x × y
+    return (_cross(x[0], y[0]), _cross(x[0], y[1]) + _cross(x[1], y[0]))
+def _fx(x, f):   # force cross  x ×* f
+    return (_cross(x[0], f[0]) + _cross(x[1], f[1]), _cross(x[0], f[1]))
+def _inert(I, x):  # I = (m, h, A): n = A w + h × v ; f = m v − h × w
+    m, h, A = I
+    return (_mv(A, x[0]) + _cross(h, x[1]), m[..., None] * x[1] - _cross(h, x[0]))
+def _dot6(x, f):
+    return np.sum(x[0]*f[0], -1) + np.sum(x[1]*f[1], -1)
+
+def rnea_jacobian_spatial(tb: RneaTables, q, qd, qdd):
+    """-> tau (..., n), J (..., n, 3 n) = d tau / d (q, dq, ddq)."""
+    q, qd, qdd = (np.asarray(a, float) for a in (q, qd, qdd))
+    shp = q.shape[:-1]; n = tb.ndof; NB = tb.n
+    Rw = np.broadcast_to(np.eye(3), shp + (3, 3)); ow = np.zeros(shp + (3,))
+    v = (np.zeros(shp + (3,)), np.zeros(shp + (3,)))
+    a = (np.zeros(shp + (3,)), np.zeros(shp + (3,)) + np.array([0, 0, 9.81]))
+    S, Sd, Sdd, Ib, Xi, pP, W = [], [], [], [], [], [], []
+    for i in range(NB):
+        o_i = ow + _mv(Rw, np.broadcast_to(tb.xyz[i], ow.shape))
+        if i < n:
+            z = _mv(Rw, np.broadcast_to(tb.axis[i], ow.shape))          # velocity axis (world) = R_{parent} axis
+            R_i = Rw @ _rot(tb, i, q[..., i])
+            Si = (z, _cross(o_i, z))
+            Sdi = _mx(v, Si)                                              # v_parent × S_i = v_i × S_i
+            v = (v[0] + Si[0] * qd[..., i, None], v[1] + Si[1] * qd[..., i, None])
+            a = (a[0] + Si[0] * qdd[..., i, None] + Sdi[0] * qd[..., i, None], a[1] + Si[1] * qdd[..., i, None] + Sdi[1] * qd[..., i, None])
+            Sddi = tuple(x + y for x, y in zip(_mx(a, Si), _mx(v, Sdi)))
+            S.append(Si); Sd.append(Sdi); Sdd.append(Sddi)
+        else:
+            R_i = Rw @ tb.R0[i]
+        c = o_i + _mv(R_i, np.broadcast_to(tb.cm[i], ow.shape))
+        Ic = R_i @ tb.I[i] @ np.swapaxes(R_i, -1, -2)
+        m = np.broadcast_to(tb.m[i], shp)
+        h = m[..., None] * c
+        A = Ic - m[..., None, None] * (_skew(c) @ _skew(c))
+        I_i = (m, h, A)
+        P = _inert(I_i, v)
+        Wi = tuple(x + y for x, y in zip(_inert(I_i, a), _fx(v, P)))
+        Om, V, H = _skew(v[0]), _skew(v[1]), _skew(h)
+        Xi_i = Om @ A - A @ Om - V @ H - H @ V - _skew(P[0])
+        Ib.append(I_i); Xi.append(Xi_i); pP.append(P[1]); W.append(Wi)
+        Rw, ow = R_i, o_i
+    # composites, inward
+    J = np.zeros(shp + (n, 3 * n)); tau = np.zeros(shp + (n,))
+    mC = np.zeros(shp); hC = np.zeros(shp + (3,)); AC = np.zeros(shp + (3, 3)); XC = np.zeros(shp + (3, 3)); pC = np.zeros(shp + (3,))
+    FC = (np.zeros(shp + (3,)), np.zeros(shp + (3,)))
+    comp = [None] * n
+    for b in range(NB - 1, -1, -1):
+        mC = mC + Ib[b][0]; hC = hC + Ib[b][1]; AC = AC + Ib[b][2]; XC = XC + Xi[b]; pC = pC + pP[b]
+        FC = (FC[0] + W[b][0], FC[1] + W[b][1])
+        if b < n:
+            comp[b] = ((mC, hC, AC), XC, pC, FC)
+            tau[..., b] = _dot6(S[b], FC)
+    def B2(XC, pC, x):  # 2 B^C x
+        return (_mv(XC, x[0]), -2.0 * _cross(pC, x[0]))
+    for j in range(n):
+        for k in range(n):
+            mm = max(k, j)
+            IC, XC, pC, FC = comp[mm]
+            u2 = _inert(IC, S[j])
+            b1 = B2(XC, pC, S[j]); i1 = _inert(IC, Sd[j])
+            u1 = (b1[0] + 2 * i1[0], b1[1] + 2 * i1[1])
+            b0 = B2(XC, pC, Sd[j]); i0 = _inert(IC, Sdd[j])
+            u0 = (b0[0] + i0[0], b0[1] + i0[1])
+            if k <= j:
+                e = _fx(S[j], comp[j][3])
+                u0 = (u0[0] + e[0], u0[1] + e[1])
+            J[..., k, j] = _dot6(S[k], u0); J[..., k, n + j] = _dot6(S[k], u1); J[..., k, 2 * n + j] = _dot6(S[k], u2)
+    return tau, J
+

@@ -140,6 +140,62 @@ def test_first_evaluation_equals_the_oracle_functions(hip_lib, ctx):
     be.close()
 
 
+def test_closed_form_jacobian_path_equals_the_dual_number_path(hip_lib, ctx, monkeypatch):
+    """k_tq_eval3 takes d tau / dz in closed form (rnea_idsva) when the dynamics tables describe a rigid-body chain, else from dual numbers through the
+    recursion (OH_TQ_JAC=dual forces that path): same step counts, objectives to 1e-12 relative, solutions to 1e-9."""
+    med7, robot, g = ctx
+    T = 30
+    prob = TorqueProblem(med7, LINK, T=T, dt=0.1, tau_lim=58.0, **W)
+    nlp = TorqueMPCNLP(prob)
+    rng = np.random.default_rng(SEED + 31)
+    B = 64
+    qc = g["t30_qc"][0][None] + rng.uniform(-0.1, 0.1, (B, 7))
+    goal = np.stack([prob.goal_figure_eight(q) for q in qc])
+    p = np.stack([nlp.pack_p(qc[b], np.zeros(7), goal[b]) for b in range(B)])
+    x0 = np.stack([nlp.seed(q) for q in qc])
+    be = backend(robot, T, 58.0)
+    ra = be.solve(x0, p)
+    monkeypatch.setenv("OH_TQ_JAC", "dual")
+    rb = be.solve(x0, p)
+    monkeypatch.delenv("OH_TQ_JAC")
+    assert (np.asarray(ra.status) == 0).all() and (np.asarray(rb.status) == 0).all()
+    assert np.mean(np.asarray(ra.iters) == np.asarray(rb.iters)) >= 0.9  # a ratio test decided by the last bits may differ on an instance or two
+    same = np.asarray(ra.iters) == np.asarray(rb.iters)
+    assert np.abs(ra.f - rb.f).max() <= 1e-9 * np.abs(ra.f).max()
+    assert np.abs(ra.x[same] - rb.x[same]).max() <= 1e-7
+    be.close()
+
+
+def test_tables_that_are_no_rigid_body_chain_take_the_dual_number_path_and_equal_the_port(hip_lib, ctx):
+    """The reference adds the angular velocity iRp @ axis (models.py:1821-1823); with a joint-origin rotation that moves the axis this is not the
+    axis the joint rotation turns about, the recursion is no rigid-body dynamics any more and the closed form does not apply.  The library detects it
+    (R0^T axis != axis) and differentiates the literal recursion; the numpy port does the same by complex step."""
+    med7, robot, g = ctx
+    T = 6
+    from oracle.robot import rpy2r
+    from oracle.torque import rnea_jacobian_spatial
+    prob = TorqueProblem(med7, LINK, T=T, dt=0.1, tau_lim=58.0, **W)
+    Rx = rpy2r([0.3, -0.2, 0.1])
+    prob.tb.R0[2] = Rx  # joint 3: axis z, origin now rotated about x / y as well
+    q, qd, qdd = np.random.default_rng(SEED + 32).uniform(-1, 1, (3, 4, 7))
+    assert np.abs(rnea_jacobian_spatial(prob.tb, q, qd, qdd)[1] - rnea_jacobian(prob.tb, q, qd, qdd)).max() > 1e-6
+    dyn = robot.dynamics_tables()
+    for k in range(9):
+        dyn.R0[2][k] = float(Rx.reshape(-1)[k])
+    nlp = TorqueMPCNLP(prob)
+    qc = g["t6_qc"][0][None] + np.random.default_rng(SEED + 33).uniform(-0.1, 0.1, (2, 7))
+    goal = np.stack([prob.goal_figure_eight(q) for q in qc])
+    p = np.stack([nlp.pack_p(qc[b], np.zeros(7), goal[b]) for b in range(2)])
+    be = TorqueBackend(robot.kinematic_chain(LINK), dyn, T=T, dt=0.1, tau_lo=-58.0, tau_up=58.0, **W)
+    res = be.solve(np.stack([nlp.seed(q) for q in qc]), p)
+    for b in range(2):
+        o = solve_torque_ipm(prob, qc[b], np.zeros(7), goal[b])
+        assert res.status[b] == 0 and o["status"] == 0
+        assert abs(res.f[b] - o["f"]) <= 1e-9 * o["f"]
+        assert abs(int(res.iters[b]) - o["iters"]) <= 1
+    be.close()
+
+
 def test_reference_script_flow_through_hipsolver(hip_lib, ctx):
     med7, robot_, g = ctx
     import optas_amd as optas

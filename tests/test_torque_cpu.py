@@ -15,7 +15,7 @@ from oracle.problems import TorqueMPCNLP
 from oracle.robot import OracleRobot, rnea
 from oracle.solvers import kkt_reference_form
 from oracle.torque import (RneaTables, TorqueProblem, costate_gradient, riccati_torque, rnea_batch, rnea_ctau_gradient, rnea_ctau_hessian, rnea_jacobian,
-                           rnea_virtual_work, solve_torque_lm)
+                           rnea_jacobian_spatial, rnea_virtual_work, solve_torque_lm)
 from oracle.torque_ipm import position_curvature, solve_torque_ipm
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -70,6 +70,23 @@ def test_complex_step_jacobian_against_differences_and_mass_matrix_identities(me
     assert np.abs(M - np.swapaxes(M, 1, 2)).max() < 1e-12
     assert np.linalg.eigvalsh(M).min() > 1e-4
     assert np.abs(rnea_jacobian(tb, q, 0 * qd, 0 * qdd)[:, :, 14:] - M).max() < 1e-12
+
+
+def test_closed_form_jacobian_equals_the_derivative_of_the_literal_recursion(med7):
+    """oracle/torque.py:rnea_jacobian_spatial (the numpy statement of csrc/oh_torque.hip:rnea_idsva) against complex-step differentiation of the
+    literal recursion: 1e-12 relative, torques included; and on a second robot (tester_robot_revolute: other axes, other inertias)."""
+    rng = np.random.default_rng(SEED + 21)
+    for rob in (med7, OracleRobot(os.path.join(GOLDEN, "tester_robot_revolute.kin.json"))):
+        tb = RneaTables(rob)
+        consistent = all(np.abs(tb.R0[i].T @ tb.axis[i] - tb.axis[i]).max() < 1e-12 and abs(np.linalg.norm(tb.axis[i]) - 1) < 1e-12 for i in range(tb.ndof))
+        q, qd, qdd = rng.uniform(-2, 2, (3, 12, tb.ndof))
+        tau, J = rnea_jacobian_spatial(tb, q, qd, qdd)
+        J0 = rnea_jacobian(tb, q, qd, qdd)
+        if consistent:
+            assert np.abs(tau - rnea_batch(tb, q, qd, qdd)).max() < 1e-12 * max(1.0, np.abs(tau).max())
+            assert np.abs(J - J0).max() < 1e-12 * np.abs(J0).max()
+        else:  # the closed form presumes a rigid-body chain; the library checks the tables and takes the dual-number path otherwise
+            assert np.abs(J - J0).max() > 1e-9
 
 
 def test_literal_nlp_sizes_and_derivatives(med7):

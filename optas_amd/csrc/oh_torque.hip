@@ -939,41 +939,299 @@ OH_DEV void rnea_ctau_grad(const oh_dynamics* __restrict__ dy, const SR (&q)[NB 
   }
 }
 
+// The same adjoint without per-body arrays (round 4).  rnea_ctau_grad keeps what every body left to its child -- 8 x (om, omD, vD, wc, vo, sin, cos) of
+// dual numbers, 2.7 KB per lane, plus the lane-indexed inputs and outputs: 3.7 KB of scratch per lane at one wavefront per SIMD, which is what
+// k_tq_curv spent its time on.  The outward recursion is invertible: from the state of body i and its joint, the state of the parent follows
+// (om_p = Rp (om_i - a dq_i), ...), so the inward pass rebuilds each parent on the way and stores nothing (~300 more instructions per body, no memory).
+// Inputs come from LDS by the loop counter: zs = the unit's (q | dq | ddq | c) at 0, 8, 16, 24; lane j seeds joint j.  sink(i, gq_i, gqd_i, gqdd_i).
+template <class S>
+struct CtSeed;
+template <>
+struct CtSeed<Dual2> {
+  static OH_DEV DualR q(double v, double one) { return {v, one}; }
+  static OH_DEV Dual2 qd(double v, double one) { return {v, 0.0, one}; }
+};
+template <>
+struct CtSeed<double> {
+  static OH_DEV double q(double v, double) { return v; }
+  static OH_DEV double qd(double v, double) { return v; }
+};
+template <int NB, class S, class SR, class Sink>
+OH_DEV void rnea_ctau_grad_inv(const oh_dynamics* __restrict__ dy, const double* zs, const int j, Sink&& sink) {
+  S om[3], omD[3], vD[3];
+  SR wc[3], vo[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    om[k] = S{};
+    omD[k] = S{};
+    vD[k] = S{} + dy->vd0[k];
+    wc[k] = SR{};
+    vo[k] = SR{};
+  }
+  // outward: only the state of the last body survives
+#pragma unroll 1
+  for (int i = 0; i < NB; ++i) {
+    const bool moving = i < NB - 1;
+    S t1[3], t2[3], t3[3], acc[3];
+    SR w[3], tw[3];
+    crossT(omD, dy->xyz[i], t1);
+    crossT(om, dy->xyz[i], t2);
+    crossT(om, t2, t3);
+    crossT(wc, dy->xyz[i], tw);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      acc[k] = vD[k] + t1[k] + t3[k];
+      w[k] = vo[k] + tw[k];
+    }
+    SR Rp[9];
+    if (moving) {
+      SR sj, cj;
+      sincosT(CtSeed<S>::q(zs[i], i == j ? 1.0 : 0.0), &sj, &cj);
+      joint_rotation(dy->R0[i], dy->axis[i], sj, cj, Rp);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rp[k] = SR{} + dy->R0[i][k];
+    }
+    S omp[3], omDp[3];
+    SR wcp[3];
+    mTvT(Rp, om, omp);
+    mTvT(Rp, omD, omDp);
+    mTvT(Rp, wc, wcp);
+    if (moving) {
+      SR a[3];
+      mTvT(Rp, dy->axis[i], a);
+      const S qdi = CtSeed<S>::qd(zs[8 + i], i == j ? 1.0 : 0.0);
+      const double qddi = zs[16 + i], ci = zs[24 + i];
+      S aq[3] = {a[0] * qdi, a[1] * qdi, a[2] * qdi};
+      S cr[3];
+      crossT(omp, aq, cr);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        om[k] = omp[k] + aq[k];
+        omD[k] = omDp[k] + cr[k] + a[k] * qddi;
+        wc[k] = wcp[k] + a[k] * ci;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        om[k] = omp[k];
+        omD[k] = omDp[k];
+        wc[k] = wcp[k];
+      }
+    }
+    S vDi[3];
+    SR voi[3];
+    mTvT(Rp, acc, vDi);
+    mTvT(Rp, w, voi);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      vD[k] = vDi[k];
+      vo[k] = voi[k];
+    }
+  }
+  // inward: (om, omD, vD, wc, vo) is the state of body i; its parent is rebuilt from it
+  S b_om[3], b_omD[3], b_vD[3], b_wc[3], b_vo[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) b_om[k] = b_omD[k] = b_vD[k] = b_wc[k] = b_vo[k] = S{};
+#pragma unroll 1
+  for (int i = NB - 1; i >= 0; --i) {
+    const bool moving = i < NB - 1;
+    SR Rp[9], a[3];
+    S qdi = S{};
+    double qddi = 0.0, ci = 0.0;
+    if (moving) {
+      SR sj, cj;
+      sincosT(CtSeed<S>::q(zs[i], i == j ? 1.0 : 0.0), &sj, &cj);
+      joint_rotation(dy->R0[i], dy->axis[i], sj, cj, Rp);
+      mTvT(Rp, dy->axis[i], a);
+      qdi = CtSeed<S>::qd(zs[8 + i], i == j ? 1.0 : 0.0);
+      qddi = zs[16 + i];
+      ci = zs[24 + i];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rp[k] = SR{} + dy->R0[i][k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a[k] = SR{};
+    }
+    const double* cm = dy->com[i];
+    const double* r = dy->xyz[i];
+    const double m = dy->mass[i];
+    // the parent's state (the base: at rest, accelerating against gravity), and what it looked like in the frame of body i
+    S om_p[3], omD_p[3], vD_p[3], omp[3], omDp[3];
+    SR wc_p[3], vo_p[3], wcp[3];
+    {
+      S aq[3] = {a[0] * qdi, a[1] * qdi, a[2] * qdi};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) omp[k] = om[k] - aq[k];
+      S cr[3];
+      crossT(omp, aq, cr);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        omDp[k] = omD[k] - cr[k] - a[k] * qddi;
+        wcp[k] = wc[k] - a[k] * ci;
+      }
+      if (i > 0) {
+        S accp[3], t1[3], t2[3], t3[3];
+        SR wp[3], tw[3];
+        mvT(Rp, omp, om_p);
+        mvT(Rp, omDp, omD_p);
+        mvT(Rp, wcp, wc_p);
+        mvT(Rp, vD, accp);
+        mvT(Rp, vo, wp);
+        crossT(omD_p, r, t1);
+        crossT(om_p, r, t2);
+        crossT(om_p, t2, t3);
+        crossT(wc_p, r, tw);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          vD_p[k] = accp[k] - t1[k] - t3[k];
+          vo_p[k] = wp[k] - tw[k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          om_p[k] = S{};
+          omD_p[k] = S{};
+          vD_p[k] = S{} + dy->vd0[k];
+          wc_p[k] = SR{};
+          vo_p[k] = SR{};
+          omp[k] = S{};    // exactly, not up to the rounding of the inversion
+          omDp[k] = S{};
+          wcp[k] = SR{};
+        }
+      }
+    }
+    // local term f_i . vc_i + n_i . wc_i
+    {
+      S t1[3], t2[3], t3[3], fi[3], Io[3], IoD[3], ni[3];
+      crossT(omD, cm, t1);
+      crossT(om, cm, t2);
+      crossT(om, t2, t3);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fi[k] = m * (vD[k] + t1[k] + t3[k]);
+      mvT(dy->inertia[i], om, Io);
+      mvT(dy->inertia[i], omD, IoD);
+      crossT(om, Io, t1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ni[k] = IoD[k] + t1[k];
+      SR tw[3], vci[3];
+      crossT(wc, cm, tw);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vci[k] = vo[k] + tw[k];
+      S cf[3];
+      crossT(cm, fi, cf);
+      SR cv[3], Itw[3];
+      crossT(cm, vci, cv);
+      mTvT(dy->inertia[i], wc, Itw);
+      const S oc = dotT(om, cm), ov = dotT(om, vci);
+      const SR cvv = dotT(cm, vci);
+      S wxo[3], Itwo[3], Ixw[3];
+      crossT(wc, om, wxo);
+      mTvT(dy->inertia[i], wxo, Itwo);
+      crossT(Io, wc, Ixw);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        b_vo[k] = b_vo[k] + fi[k];
+        b_wc[k] = b_wc[k] + cf[k] + ni[k];
+        b_vD[k] = b_vD[k] + m * vci[k];
+        b_omD[k] = b_omD[k] + m * cv[k] + Itw[k];
+        b_om[k] = b_om[k] + m * (vci[k] * oc + cm[k] * ov - 2.0 * (om[k] * cvv)) + Itwo[k] + Ixw[k];
+      }
+    }
+    // through the step of body i
+    S b_omp[3];
+    if (moving) {
+      S aq[3] = {a[0] * qdi, a[1] * qdi, a[2] * qdi};
+      S x1[3], x2[3], b_aq[3], b_a[3];
+      crossT(aq, b_omD, x1);
+      crossT(b_omD, omp, x2);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        b_omp[k] = b_om[k] + x1[k];
+        b_aq[k] = b_om[k] + x2[k];
+        b_a[k] = b_aq[k] * qdi + b_omD[k] * qddi + b_wc[k] * ci;
+      }
+      const S gqd_i = dotT(b_aq, a);
+      const S gqdd_i = dotT(b_omD, a);
+      S s1[3], s2[3], s3[3], s4[3], s5[3], s6[3];
+      crossT(omp, b_omp, s1);
+      crossT(omDp, b_omD, s2);
+      crossT(wcp, b_wc, s3);
+      crossT(a, b_a, s4);
+      crossT(vD, b_vD, s5);
+      crossT(vo, b_vo, s6);
+      S sw[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sw[k] = s1[k] + s2[k] + s3[k] + s4[k] + s5[k] + s6[k];
+      sink(i, -dotT(sw, dy->axis[i]), gqd_i, gqdd_i);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) b_omp[k] = b_om[k];
+    }
+    if (i > 0) {
+      S b_acc[3], b_w[3], Ro[3], RoD[3], Rw[3], x1[3], x2[3];
+      mvT(Rp, b_vD, b_acc);
+      mvT(Rp, b_vo, b_w);
+      mvT(Rp, b_omp, Ro);
+      mvT(Rp, b_omD, RoD);
+      mvT(Rp, b_wc, Rw);
+      crossT(r, b_acc, x1);
+      crossT(r, b_w, x2);
+      const S opr = dotT(om_p, r), opb = dotT(om_p, b_acc), rb = dotT(r, b_acc);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        b_om[k] = Ro[k] + b_acc[k] * opr + r[k] * opb - 2.0 * (om_p[k] * rb);
+        b_omD[k] = RoD[k] + x1[k];
+        b_vD[k] = b_acc[k];
+        b_wc[k] = Rw[k] + x2[k];
+        b_vo[k] = b_w[k];
+        om[k] = om_p[k];
+        omD[k] = omD_p[k];
+        vD[k] = vD_p[k];
+        wc[k] = wc_p[k];
+        vo[k] = vo_p[k];
+      }
+    }
+  }
+}
+
 // sum_i c_i d^2 tau_i / d (q, qd, qdd)^2 (what the reference obtains as ddh by AD of the CasADi graph, optimization.py:8-24): one lane per
 // (sample, joint); q, qd, qdd, c [n][N] -> H [n][3 N][3 N] row-major.  Lane j writes rows j and N + j and, by symmetry, column j of the ddq rows.
 template <int N>
 __global__ __launch_bounds__(64) void k_rnea_hess(const oh_dynamics* __restrict__ dy, const int n, const double* __restrict__ q, const double* __restrict__ qd,
                                                   const double* __restrict__ qdd, const double* __restrict__ c, double* __restrict__ H) {
   constexpr int NZ = 3 * N, UPW = 64 / N;
+  __shared__ double zs_l[UPW][32];
   const int lane = threadIdx.x;
-  const int ul = lane / N, j = lane - ul * N;
-  const long long u = (long long)blockIdx.x * UPW + ul;
-  if (ul >= UPW || u >= n) return;
-  DualR a[N];
-  Dual2 b[N], gq[N], gqd[N], gqdd[N];
-  double cc[N], uu[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const double one = (k == j) ? 1.0 : 0.0;
-    a[k] = {q[u * N + k], one};
-    b[k] = {qd[u * N + k], 0.0, one};
-    uu[k] = qdd[u * N + k];
-    cc[k] = c[u * N + k];
+  int ul = lane / N, j = lane - ul * N;
+  const bool lane_ok = ul < UPW;
+  if (!lane_ok) {
+    ul = UPW - 1;
+    j = N - 1;
   }
-  rnea_ctau_grad<N + 1, Dual2>(dy, a, b, uu, cc, gq, gqd, gqdd);
+  long long u = (long long)blockIdx.x * UPW + ul;
+  const bool active = lane_ok && u < n;
+  if (u >= n) u = n - 1;
+  if (lane_ok) {
+    zs_l[ul][j] = q[u * N + j];
+    zs_l[ul][8 + j] = qd[u * N + j];
+    zs_l[ul][16 + j] = qdd[u * N + j];
+    zs_l[ul][24 + j] = c[u * N + j];
+  }
+  __syncthreads();
   double* Hu = H + (size_t)u * NZ * NZ;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    Hu[j * NZ + k] = gq[k].d0;
-    Hu[j * NZ + N + k] = gqd[k].d0;
-    Hu[j * NZ + 2 * N + k] = gqdd[k].d0;
-    Hu[(N + j) * NZ + k] = gq[k].d1;
-    Hu[(N + j) * NZ + N + k] = gqd[k].d1;
+  rnea_ctau_grad_inv<N + 1, Dual2, DualR>(dy, zs_l[ul], j, [&](const int k, const Dual2 gq, const Dual2 gqd, const Dual2 gqdd) {
+    if (!active) return;
+    Hu[j * NZ + k] = gq.d0;
+    Hu[j * NZ + N + k] = gqd.d0;
+    Hu[j * NZ + 2 * N + k] = gqdd.d0;
+    Hu[(N + j) * NZ + k] = gq.d1;
+    Hu[(N + j) * NZ + N + k] = gqd.d1;
     Hu[(N + j) * NZ + 2 * N + k] = 0.0;
-    Hu[(2 * N + k) * NZ + j] = gqdd[k].d0;
+    Hu[(2 * N + k) * NZ + j] = gqdd.d0;
     Hu[(2 * N + k) * NZ + N + j] = 0.0;
     Hu[(2 * N + k) * NZ + 2 * N + j] = 0.0;
-  }
+  });
 }
 
 OH_DEV size_t xs_off(const TqBuffers& D, const int T, const int slot, const int b, const int t) { return (((size_t)slot * D.B + b) * T + t) * TQ_XS; }
@@ -1329,6 +1587,7 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
 template <int N>
 __global__ __launch_bounds__(64, OH_TQ_CURV_WAVES) void k_tq_curv(TqParams P, TqBuffers D) {
   constexpr int UPW = 64 / N;
+  __shared__ double zs_l[UPW][32];
   const int T = P.T;
   const int lane = threadIdx.x;
   int ul = lane / N, j = lane - ul * N;
@@ -1349,57 +1608,56 @@ __global__ __launch_bounds__(64, OH_TQ_CURV_WAVES) void k_tq_curv(TqParams P, Tq
   const double* xr = D.xs + xs_off(D, T, ts, b, t);
   double* sr = D.st + st_off(D, T, ts, b, t);
   const double* lm = D.lam + (((size_t)ts * D.B + b) * T + t) * TQ_LAM;
-  DualR q[N];
-  Dual2 qd[N], gq[N], gqd[N], gqdd[N];
-  double qv[N], uu[N], cH[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const double one = (k == j) ? 1.0 : 0.0;
-    qv[k] = xr[k];
-    q[k] = {qv[k], one};
-    qd[k] = {xr[8 + k], 0.0, one};
-    uu[k] = xr[16 + k];
-    cH[k] = 2.0 * P.w_tau * sr[256 + k] - lm[k] + lm[N + k];
+  if (lane_ok) {
+    zs_l[ul][j] = xr[j];
+    zs_l[ul][8 + j] = xr[8 + j];
+    zs_l[ul][16 + j] = xr[16 + j];
+    zs_l[ul][24 + j] = 2.0 * P.w_tau * sr[256 + j] - lm[j] + lm[N + j];
   }
-  rnea_ctau_grad<N + 1, Dual2>(D.dyn, q, qd, uu, cH, gq, gqd, gqdd);
+  __syncthreads();
   // curvature of the tracking term
-  double R[9], pp[3], z[N][3], pj[N][3];
-  fk_chain<N>(D.chain, qv, R, pp, z, pj);
-  double e[3], tv3[3], r[3];
-  mv3(R, D.chain->p_tool, tv3);
-  const double* gl = D.goal + ((size_t)b * T + t) * 4;
+  double inner[3] = {0.0, 0.0, 0.0}, r[3], z[N][3];
+  {
+    double qv[N], R[9], pp[3], pj[N][3], e[3], tv3[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    e[k] = pp[k] + tv3[k];
-    r[k] = e[k] - gl[k];
-  }
-  double inner[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < N; ++k) qv[k] = zs_l[ul][k];
+    fk_chain<N>(D.chain, qv, R, pp, z, pj);
+    mv3(R, D.chain->p_tool, tv3);
+    const double* gl = D.goal + ((size_t)b * T + t) * 4;
 #pragma unroll
-  for (int k = 0; k < N; ++k)
-    if (k == j) {
-      if (D.chain->jtype[k] == 0) {
-        const double dd[3] = {e[0] - pj[k][0], e[1] - pj[k][1], e[2] - pj[k][2]};
-        cross3(z[k], dd, inner);
-      } else {
-        inner[0] = z[k][0]; inner[1] = z[k][1]; inner[2] = z[k][2];
-      }
+    for (int k = 0; k < 3; ++k) {
+      e[k] = pp[k] + tv3[k];
+      r[k] = e[k] - gl[k];
     }
-  if (!active) return;
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (k <= j) {  // rows q_j and dq_j, columns up to the diagonal
-      double kc = 0.0;
-      if (D.chain->jtype[k] == 0) {
+    for (int k = 0; k < N; ++k)
+      if (k == j) {
+        if (D.chain->jtype[k] == 0) {
+          const double dd[3] = {e[0] - pj[k][0], e[1] - pj[k][1], e[2] - pj[k][2]};
+          cross3(z[k], dd, inner);
+        } else {
+          inner[0] = z[k][0]; inner[1] = z[k][1]; inner[2] = z[k][2];
+        }
+      }
+  }
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (k <= j && D.chain->jtype[k] == 0) {  // rows q_j, columns up to the diagonal
         double x[3];
         cross3(z[k], inner, x);
-        kc = dot3(r, x);
+        sr[j * (j + 1) / 2 + k] += 2.0 * P.w_path * dot3(r, x);
       }
-      sr[j * (j + 1) / 2 + k] += gq[k].d0 + 2.0 * P.w_path * kc;
-      sr[(N + j) * (N + j + 1) / 2 + N + k] += gqd[k].d1;
-    }
-    sr[(N + j) * (N + j + 1) / 2 + k] += gq[k].d1;             // (dq_j, q_k)
-    sr[(2 * N + k) * (2 * N + k + 1) / 2 + j] += gqdd[k].d0;   // (ddq_k, q_j)
   }
+  rnea_ctau_grad_inv<N + 1, Dual2, DualR>(D.dyn, zs_l[ul], j, [&](const int k, const Dual2 gq, const Dual2 gqd, const Dual2 gqdd) {
+    if (!active) return;
+    if (k <= j) {  // rows q_j and dq_j, columns up to the diagonal
+      sr[j * (j + 1) / 2 + k] += gq.d0;
+      sr[(N + j) * (N + j + 1) / 2 + N + k] += gqd.d1;
+    }
+    sr[(N + j) * (N + j + 1) / 2 + k] += gq.d1;             // (dq_j, q_k)
+    sr[(2 * N + k) * (2 * N + k + 1) / 2 + j] += gqdd.d0;   // (ddq_k, q_j)
+  });
 }
 
 // ---- step ------------------------------------------------------------------------------------------------------------------------------

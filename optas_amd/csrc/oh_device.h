@@ -16,6 +16,14 @@
 #define OH_RSQRT(x) rsqrt(x)
 #endif
 
+// value of lane `lane` (uniform, compile-time after unrolling) on every lane: two v_readlane_b32 into scalar registers instead of two ds_bpermute_b32
+// through the LDS crossbar (the pivots of the shuffle-based Gauss-Jordan sweeps sit on the critical path of every elimination step)
+__device__ __forceinline__ double readlane_f64(const double v, const int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3-vectors / 3x3 row-major matrices
 // ---------------------------------------------------------------------------------------------

@@ -1054,6 +1054,258 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
   }
 }
 
+// K3 of a latency-bound launch, round 4: one block of two wavefronts per instance, the block-tridiagonal system solved by a twisted factorisation
+// ("burn at both ends").  Wavefront 0 eliminates the knots 0, 1, .. m-1 downwards, wavefront 1 the knots nK-1, .. m+1 upwards at the same time;
+// knot m then sees both neighbours eliminated, its solve gives z_m, and the two halves substitute back outwards in parallel: T / 2 dependent knots each
+// way instead of T.  A knot costs one in-place Gauss-Jordan inversion of its 7 x 7 Schur complement with the lane layout of k_tq_step (lane 8 r + c
+// owns entry (r, c), column 7 the right-hand side; pivot row / column / pivot by shuffles: no LDS, no barrier):
+//     S_k = A_k - E X_{k-1} E,  y_k = r_k - E w_{k-1},  [X_k | w_k] = S_k^{-1} [I | y_k],    E = -diag(e): entry-wise on the lanes that hold the entries,
+// X_k and w_k go to LDS for the substitution  z_k = w_k + X_k (e . z_{k+1}).  All pivots are positive iff the matrix is positive definite (they are the
+// pivots of a Cholesky factorisation in the twisted order), so the damping loop raises mu exactly when the serial sweep would.
+// k_step_free_pcr does ceil(log2 T) levels of 15 triangular solve pairs and four 7 x 7 x 7 products on one lane per knot: 111-115 us per launch at
+// T = 100 however few instances there are; this one ~50.  Ratio test and outer-loop decisions are the serial kernel's (free_accept / free_decide on
+// lane 0); the decision "converged / outer update: no step" is taken before the solve (it depends on the reduced gradient only), which spares the
+// solve on a quarter of the launches of a guarded handle.
+template <int N, bool GUARD, bool VEL = false>
+__global__ __launch_bounds__(128) void k_step_free_bb(FigParams P, FigBuffers D, GuardBuffers GB, const int slot_batch, const int KH) {
+  static_assert(N == 7, "lane layout: 8 rows x 8 columns");
+  constexpr int NP = N * (N + 1) / 2;
+  extern __shared__ double xw[];  // [2][KH][64] X | w of the knots, then [2][KH][8] their right-hand sides
+  __shared__ double sm[3][128];
+  __shared__ double red[3][2];
+  __shared__ int ctl[2];
+  __shared__ double ctld;
+  __shared__ double zmid[8];
+  const int per = (D.B + 7) / 8;  // blocks are dealt round-robin to the 8 XCDs: XCD x takes the instances [x per, (x + 1) per)
+  const int b = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  if (b >= D.B) return;
+  const int slot = OH_FREE_SLOT(D, b);
+  const int lane = threadIdx.x;
+  const int Bp = D.Bp;
+  const int T = P.T;
+  const int nK = T - P.t0;
+  const double kap2 = 2.0 * P.kappa;
+  if (lane == 0) ctl[0] = D.status[b] >= 0 ? 0 : (D.skip[b] ? 1 : 2);
+  __syncthreads();
+  {
+    const int st = ctl[0];
+    if (st == 0) return;
+    if (st == 1) {
+      if (lane == 0) {
+        D.skip[b] = 0;
+        atomicAdd(D.n_running, 1);
+      }
+      return;
+    }
+  }
+  {
+    const bool act = lane < nK;
+    const int tl = act ? P.t0 + lane : T - 1;
+    sm[0][lane] = act ? SEL(D.merit, slot)[(size_t)tl * Bp + b] : 0.0;
+    if constexpr (GUARD) {
+      sm[1][lane] = act ? SEL(GB.psi, slot)[(size_t)tl * Bp + b] : 0.0;
+      sm[2][lane] = act ? SEL(D.cv, slot)[(size_t)tl * Bp + b] : 0.0;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    atomicAdd(D.work, 1ULL);
+    double f = D.fconst[b], fpsi = 0.0, meas = 0.0;
+    for (int l = 0; l < nK; ++l) {  // in knot order, like the serial sweep
+      f += sm[0][l];
+      if constexpr (GUARD) {
+        fpsi += sm[1][l];
+        meas = fmax(meas, sm[2][l]);
+      }
+    }
+    LMState lm{D.mu[b], D.nun[b]};
+    int cur = 1 - slot;
+    ctl[0] = free_accept<N, GUARD>(P, D, GB, b, slot, f, fpsi, meas, cur, lm);
+    ctl[1] = cur;
+    ctld = lm.mu;
+  }
+  __syncthreads();
+  if (ctl[0] == 0) return;
+  if (ctl[0] == 2) {  // line search: the rejected step again, shorter
+    if (lane < nK) {
+      const int t = P.t0 + lane;
+#pragma unroll
+      for (int a = 0; a < N; ++a) D.zstep[IDX(t, N, a)] *= OH_LS_SHRINK;
+    }
+    if (lane == 0 && free_line_search<GUARD>(P, D, GB, b)) atomicAdd(D.n_running, 1);
+    return;
+  }
+  const int cur = ctl[1];
+  double mu = ctld;
+  auto block_sum = [&](double v, const int slot_r, const bool is_max) {  // all lanes get the result
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const double o = __shfl_xor(v, m);
+      v = is_max ? fmax(v, o) : v + o;
+    }
+    if ((lane & 63) == 0) red[slot_r][lane >> 6] = v;
+    __syncthreads();
+    return is_max ? fmax(red[slot_r][0], red[slot_r][1]) : red[slot_r][0] + red[slot_r][1];
+  };
+  const double* __restrict__ Drc = SEL(D.Dr, cur);
+  const double* __restrict__ gtc = SEL(D.gt, cur);
+  const double* __restrict__ Ec = cur ? D.E[1] : D.E[0];  // velocity rows: the coupling vectors (VEL)
+  double stat = 0.0;
+  if (lane < nK) {
+    const int t = P.t0 + lane;
+#pragma unroll
+    for (int a = 0; a < N; ++a) stat = fmax(stat, fabs(gtc[IDX(t, N, a)]));
+  }
+  stat = block_sum(stat, 0, true);
+  if (lane == 0) ctl[0] = free_decide<N, GUARD>(P, D, GB, b, stat, mu, D.iters[b]);
+  __syncthreads();
+  {
+    const int dec = ctl[0];
+    if (dec == 0) return;
+    if (dec == 1) {  // outer iteration: no step
+      if (lane < nK) {
+        const int t = P.t0 + lane;
+#pragma unroll
+        for (int a = 0; a < N; ++a) D.zstep[IDX(t, N, a)] = 0.0;
+      }
+      if (lane == 0) atomicAdd(D.n_running, 1);
+      return;
+    }
+  }
+  // ---- the solve ----
+  const int wv = lane >> 6, l = lane & 63, r = l >> 3, c = l & 7;
+  const bool mat = r < N && c < N, vec = r < N && c == N;
+  const int m = nK / 2;                      // meeting knot
+  const int cnt = wv == 0 ? m : nK - m;      // knots of this wavefront (wavefront 1 ends on the meeting knot)
+  const int k0 = wv == 0 ? 0 : nK - 1, dir = wv == 0 ? 1 : -1;
+  double* xs = xw + (size_t)wv * KH * 64;
+  const int rr = r < N ? r : 0, cc = c < N ? c : 0;
+  const int pko = rr >= cc ? tri(rr, cc) : tri(cc, rr);
+  // coupling coefficient of the interval below knot index k (between k and k + 1), for row r and column c of this lane
+  auto coup = [&](const int k, double& er, double& ec) {
+    er = ec = kap2;
+    if constexpr (VEL) {
+      er = Ec[IDX(P.t0 + k, N, rr)];
+      ec = Ec[IDX(P.t0 + k, N, cc)];
+    }
+  };
+  auto fetch = [&](const int k) {
+    const int t = P.t0 + k;
+    double a = 0.0;
+    if (mat) {
+      a = Drc[IDX(t, NP, pko)];
+      if (r == c) a += (t == T - 1 ? kap2 : 2.0 * kap2);
+    } else if (vec) {
+      a = -gtc[IDX(t, N, rr)];
+    }
+    return a;
+  };
+  bool factored = false;
+  double* gsh = xw + (size_t)2 * KH * 64 + (size_t)wv * KH * 8;  // [KH][8]: -g of the wavefront's knots (the substitution needs them again)
+  for (int attempt = 0; attempt < 40; ++attempt) {
+    bool ok = true;
+    // the wavefront's entries of all its knots in one go (a lane's loads of consecutive knots are independent: one memory latency, not one per knot)
+    for (int i = 0; i < cnt; ++i) {
+      const double a = fetch(k0 + dir * i);
+      xs[(size_t)i * 64 + l] = a;
+      if (vec) gsh[i * 8 + r] = a;
+    }
+    double xprev = 0.0;  // matrix lanes: X of the knot before; vector lanes: w
+    for (int i = 0; i < cnt; ++i) {
+      const int k = k0 + dir * i;
+      double a = xs[(size_t)i * 64 + l];
+      if (mat && r == c) a += mu;
+      if (i > 0) {
+        double er, ec;
+        coup(wv == 0 ? k - 1 : k, er, ec);
+        a = mat ? fma(-(er * ec), xprev, a) : (vec ? fma(er, xprev, a) : a);
+      }
+      if (wv == 1 && i == cnt - 1) {
+        __syncthreads();  // wavefront 0 has parked X and w of knot m - 1
+        if (m > 0) {
+          double er, ec;
+          coup(m - 1, er, ec);
+          const double x0 = xw[(size_t)(m - 1) * 64 + l];
+          a = mat ? fma(-(er * ec), x0, a) : (vec ? fma(er, x0, a) : a);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) {  // in-place Gauss-Jordan inversion, right-hand side carried along in column 7
+        const double piv = readlane_f64(a, 9 * j);
+        const double cj = __shfl(a, 8 * r + j), rj = __shfl(a, 8 * j + c);
+        if (!(piv > 1e-12) || !(piv < 1e300)) ok = false;
+        double d = __builtin_amdgcn_rcp(piv);
+        d = d * fma(-piv, d, 2.0);
+        d = d * fma(-piv, d, 2.0);
+        // branch-free: pivot entry d; pivot row a d; pivot column -a d; elsewhere a - cj rj d
+        const double gen = fma(-(cj * rj), d, a), sc = a * d;
+        a = (r == j) ? ((c == j) ? d : sc) : ((c == j) ? -sc : gen);
+      }
+      xs[(size_t)i * 64 + l] = a;
+      xprev = a;
+    }
+    if (wv == 0) __syncthreads();  // (the barrier wavefront 1 waits at before the meeting knot)
+    if (__syncthreads_and(ok)) {
+      factored = true;
+      break;
+    }
+    mu = fmax(4.0 * mu, 1e-2);
+  }
+  if (!factored) {
+    if (lane == 0) {
+      D.stat[b] = __builtin_nan("");
+      D.status[b] = OH_STATUS_NUMERICAL;
+      D.mu[b] = mu;
+    }
+    return;
+  }
+  // z_m sits on the vector lanes of wavefront 1 (the last knot it inverted)
+  if (wv == 1 && vec) zmid[r] = xs[(size_t)(cnt - 1) * 64 + l];
+  __syncthreads();
+  double gd = 0.0, z2 = 0.0;
+  {
+    double zc = zmid[cc];  // z of the knot solved before, component c
+    if (wv == 1 && vec) {
+      const int t = P.t0 + m;
+      const double z = zmid[r];
+      D.zstep[IDX(t, N, r)] = z;
+      gd = -gsh[(cnt - 1) * 8 + r] * z;
+      z2 = z * z;
+    }
+    const int first = wv == 0 ? m - 1 : cnt - 2;  // index into xs
+    for (int i = first; i >= 0; --i) {
+      const int k = k0 + dir * i;
+      double er, ec;
+      coup(wv == 0 ? k : k - 1, er, ec);
+      const double x = xs[(size_t)i * 64 + l];
+      double part = mat ? x * (ec * zc) : 0.0;
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      part += __shfl_xor(part, 4);
+      const double z = x + part;  // meaningful on the vector lanes: w_r + sum_c X[r][c] e_c z_c
+      zc = __shfl(z, 8 * cc + 7);
+      if (vec) {
+        const int t = P.t0 + k;
+        D.zstep[IDX(t, N, r)] = z;
+        gd = fma(-gsh[i * 8 + r], z, gd);
+        z2 = fma(z, z, z2);
+      }
+    }
+  }
+  gd = block_sum(gd, 1, false);
+  z2 = block_sum(z2, 2, false);
+  if (lane == 0) {
+    D.pred[b] = -0.5 * gd + 0.5 * mu * z2;
+    if constexpr (GUARD) {
+      GB.ls_gd[b] = gd;
+      GB.ls_q[b] = gd + mu * z2;
+    }
+    D.mu[b] = mu;
+    D.iters[b] += 1;
+    atomicAdd(D.n_running, 1);
+  }
+}
+
 // K3 of a launch of a few hundred instances with at most 64 free knots (dual_arm.py as shipped: T = 50), round 3: the same block cyclic
 // reduction with a knot's ROWS spread over eight lanes.  k_step_free_pcr gives a knot one lane: 15 triangular solve pairs and four 7 x 7 x 7 products per level on
 // one lane, 512 registers with ~86 doubles spilled, 87 us per launch at T = 50 however few instances there are.  Here
@@ -1332,6 +1584,14 @@ static void launch_step_free_pcr(hipStream_t s, const FigParams& P, const FigBuf
     g_free_cp_max = e ? atoi(e) : 512;
   }
   const dim3 g(8 * ((D.B + 7) / 8));
+  if constexpr (N == 7) {
+    const char* e = getenv("OH_FREE_BB");  // 0: the cyclic-reduction kernels of rounds 2-3 (A/B, tests)
+    if (!e || atoi(e) != 0) {
+      const int nK = P.T - P.t0, KH = nK - nK / 2;
+      hipLaunchKernelGGL((k_step_free_bb<N, GUARD, VEL>), g, dim3(128), sizeof(double) * 2 * (size_t)KH * 72, s, P, D, GB, slot, KH);
+      return;
+    }
+  }
   // (only up to 64 knots: 128 knots x 8 lanes are 1024 threads, which leaves 128 registers per lane -- the kernel then spills and takes 147 us
   //  against k_step_free_pcr's 111 at T = 100; at T = 50 it is 61 against 87 us)
   if (D.B <= g_free_cp_max && P.T - P.t0 <= 64) {

@@ -1905,7 +1905,7 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
           // column j of this lane's row (blocks X u) and row j of this lane's column (blocks u Y; for the vector column: m_u[j])
           const double cq = __shfl(Mqu, 8 * r + j), cd = __shfl(Mdu, 8 * r + j), cu = __shfl(Muu, 8 * r + j);
           const double rq = __shfl(Muq, 8 * j + c), rd = __shfl(Mud, 8 * j + c), ru = __shfl(Muu, 8 * j + c);
-          const double piv = __shfl(Muu, 9 * j);
+          const double piv = readlane_f64(Muu, 9 * j);
           if (!(piv > 0.0) || !isfinite(piv)) failed = true;
           const double d = 1.0 / piv;
           if (c < N) {

@@ -1183,6 +1183,10 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   }  // the generic kernels run (and no further attempt is made); oh_last_error keeps the reason
   const bool guarded = h->have_guards;
   const bool lead = h->chain_host.has_lead != 0;
+  {  // position-tracking family, 7 joints, every launch of this solve a block per instance (k_step_free_bb): stage blocks instance-major
+    const char* e = getenv("OH_FREE_BB");
+    h->P.inst_major = (!h->desc.lock_orientation && h->desc.ndof == 7 && B <= h->free_pcr_max && h->desc.T - (h->desc.fix_dq0 ? 2 : 1) <= 128 && (!e || atoi(e) != 0)) ? 1 : 0;
+  }
   if (lead && (guarded || !h->desc.lock_orientation || h->desc.ndof != 6))
     return fail(OH_ERR_INVALID, "oh_solve_device: a parameterised lead joint is lowered for the orientation-locked family with 6 optimised joints, "
                                 "without inequality rows");

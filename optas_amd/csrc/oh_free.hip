@@ -7,6 +7,11 @@
 #include "oh_figure8.h"
 
 #define IDX(t, K, k) (((size_t)(t) * (K) + (k)) * Bp + b)
+// Stage blocks W_t (packed, NP) and reduced gradients (N) of this family: knot-major like everything else (a thread per instance reads coalesced), or
+// instance-major [b][t][.] when every launch of the solve gives an instance a block of its own (P.inst_major, round 4: k_step_free_bb's lanes read one
+// instance; knot-major that was 64 cache lines per load instruction and 27 of its 82 us).
+#define DRX(t, i) (P.inst_major ? (((size_t)b * P.T + (t)) * NP + (i)) : IDX(t, NP, i))
+#define GTX(t, k) (P.inst_major ? (((size_t)b * P.T + (t)) * N + (k)) : IDX(t, N, k))
 
 // Trial slot of an instance (round 3): the slot its accepted point is NOT in.  The orientation-locked kernels alternate one slot for the whole
 // batch, so an instance whose trial was rejected has to sit the next launch out (its accepted point lies where that launch writes); here every
@@ -46,7 +51,7 @@ OH_DEV void couple_inline_free(const FigParams& P, const FigBuffers& D, const in
     sm += dm * dm;
     double G = g[k] + kap2 * dm;
     if (!last) G -= kap2 * (qp - q[k]);
-    SEL(D.gt, slot)[IDX(t, N, k)] = G;
+    SEL(D.gt, slot)[GTX(t, k)] = G;
   }
   SEL(D.merit, slot)[(size_t)t * Bp + b] = phi + P.kappa * sm;
 }
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void k_eval_free(FigParams P, FigBuffers D, co
   SEL(D.cv, slot)[(size_t)t * Bp + b] = 0.0;
   if (P.zc_free) couple_inline_free<N>(P, D, b, t, slot, D.first[b] != 0, q, g, phi);
 #pragma unroll
-  for (int i = 0; i < NP; ++i) SEL(D.Dr, slot)[IDX(t, NP, i)] = W[i];
+  for (int i = 0; i < NP; ++i) SEL(D.Dr, slot)[DRX(t, i)] = W[i];
 }
 
 
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D,
   SEL(GB.psi, slot)[(size_t)t * Bp + b] = psi;
   SEL(D.cv, slot)[(size_t)t * Bp + b] = meas;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) SEL(D.Dr, slot)[IDX(t, NP, i)] = W[i];
+  for (int i = 0; i < NP; ++i) SEL(D.Dr, slot)[DRX(t, i)] = W[i];
 }
 
 // guard parameters of every instance into SoA, multipliers and outer-loop state reset
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256) void k_couple_free(FigParams P, FigBuffers D, 
     sm += dm * dm;
     double G = SEL(D.g, slot)[IDX(t, N, k)] + kap2 * dm;
     if (!last) G -= kap2 * (qs[IDX(t + 1, N, k)] - q0);
-    SEL(D.gt, slot)[IDX(t, N, k)] = G;
+    SEL(D.gt, slot)[GTX(t, k)] = G;
   }
   SEL(D.merit, slot)[(size_t)t * Bp + b] = SEL(D.phi, slot)[(size_t)t * Bp + b] + P.kappa * sm;
 }
@@ -433,8 +438,8 @@ __global__ __launch_bounds__(256) void k_couple_free_vel(FigParams P, FigBuffers
     sm += dm * dm;
     double G = SEL(D.g, slot)[IDX(t, N, k)] + kap2 * dm + sp[k] - sn[k];
     if (!last) G -= kap2 * (qp[k] - q0[k]);
-    SEL(D.gt, slot)[IDX(t, N, k)] = G;
-    if (wp[k] + wn[k] > 0.0) SEL(D.Dr, slot)[IDX(t, NP, tri(k, k))] += wp[k] + wn[k];
+    SEL(D.gt, slot)[GTX(t, k)] = G;
+    if (wp[k] + wn[k] > 0.0) SEL(D.Dr, slot)[DRX(t, tri(k, k))] += wp[k] + wn[k];
     SEL(D.E, slot)[IDX(t, N, k)] = kap2 + wn[k];  // the coupling of knots t and t+1, as the sweeps use it
   }
   SEL(D.merit, slot)[(size_t)t * Bp + b] = SEL(D.phi, slot)[(size_t)t * Bp + b] + psi_p + P.kappa * sm;
@@ -643,11 +648,11 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
     {
       const int t = T - 1;
 #pragma unroll
-      for (int i = 0; i < NP; ++i) S[i] = Drc[IDX(t, NP, i)];
+      for (int i = 0; i < NP; ++i) S[i] = Drc[DRX(t, i)];
 #pragma unroll
       for (int a = 0; a < N; ++a) {
         S[tri(a, a)] += kap2 + mu;
-        rn[a] = gtc[IDX(t, N, a)];
+        rn[a] = gtc[GTX(t, a)];
         stat = fmax(stat, fabs(rn[a]));
       }
     }
@@ -656,9 +661,9 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
     double Hn[NP], gn[N];
     if (T - 2 >= P.t0) {
 #pragma unroll
-      for (int i = 0; i < NP; ++i) Hn[i] = Drc[IDX(T - 2, NP, i)];
+      for (int i = 0; i < NP; ++i) Hn[i] = Drc[DRX(T - 2, i)];
 #pragma unroll
-      for (int a = 0; a < N; ++a) gn[a] = gtc[IDX(T - 2, N, a)];
+      for (int a = 0; a < N; ++a) gn[a] = gtc[GTX(T - 2, a)];
     }
     for (int t = T - 2; t >= P.t0; --t) {
       double Ht[NP], gt[N];
@@ -673,9 +678,9 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
       {
         const int tp = (t > P.t0) ? t - 1 : t;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) Hn[i] = Drc[IDX(tp, NP, i)];
+        for (int i = 0; i < NP; ++i) Hn[i] = Drc[DRX(tp, i)];
 #pragma unroll
-        for (int a = 0; a < N; ++a) gn[a] = gtc[IDX(tp, N, a)];
+        for (int a = 0; a < N; ++a) gn[a] = gtc[GTX(tp, a)];
         __builtin_amdgcn_sched_barrier(0);
       }
       ok = chol_rcp<N>(S, rd, 1e-12) && ok;
@@ -770,7 +775,7 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
 #pragma unroll
       for (int a = 0; a < N; ++a) {
         D.zstep[IDX(t, N, a)] = zz[a];
-        gd += gtc[IDX(t, N, a)] * zz[a];
+        gd += gtc[GTX(t, a)] * zz[a];
         z2 += zz[a] * zz[a];
       }
     }
@@ -898,7 +903,7 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
   double stat = 0.0;
   if (active) {
 #pragma unroll
-    for (int a = 0; a < N; ++a) stat = fmax(stat, fabs(gtc[IDX(tl, N, a)]));
+    for (int a = 0; a < N; ++a) stat = fmax(stat, fabs(gtc[GTX(tl, a)]));
   }
   stat = block_sum(stat, 0, true);
   // Registers are the budget (256 + 256 per lane at one wavefront per SIMD): the diagonal block is kept as its lower triangle (every update of
@@ -910,11 +915,11 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
   for (int attempt = 0; attempt < 40; ++attempt) {
     double A[NP], Lw[N * N], U[N * N];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) A[i] = active ? Drc[IDX(tl, NP, i)] : 0.0;
+    for (int i = 0; i < NP; ++i) A[i] = active ? Drc[DRX(tl, i)] : 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       A[tri(i, i)] = active ? A[tri(i, i)] + (last ? kap2 : 2.0 * kap2) + mu : 1.0;
-      r[i] = active ? -gtc[IDX(tl, N, i)] : 0.0;
+      r[i] = active ? -gtc[GTX(tl, i)] : 0.0;
       // coupling to the next / previous knot: -2 kappa I, with velocity rows -diag(2 kappa + w) of the interval in between (D.E)
       double eu = kap2, el = kap2;
       if constexpr (VEL) {
@@ -1036,7 +1041,7 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
 #pragma unroll
     for (int a = 0; a < N; ++a) {
       D.zstep[IDX(t, N, a)] = r[a];
-      gd += gtc[IDX(t, N, a)] * r[a];
+      gd += gtc[GTX(t, a)] * r[a];
       z2 += r[a] * r[a];
     }
   }
@@ -1085,6 +1090,23 @@ __global__ __launch_bounds__(128) void k_step_free_bb(FigParams P, FigBuffers D,
   const int T = P.T;
   const int nK = T - P.t0;
   const double kap2 = 2.0 * P.kappa;
+  // The bookkeeping of an instance (free_accept / free_decide on lane 0) walks through two dozen per-instance scalars, one dependent load after the
+  // other, a memory latency each: the lanes of the second wavefront touch them all at once first, so that lane 0 finds them in the CU's cache.
+  {
+    double wd = 0.0;
+    int wi = 0;
+    const int w = lane - 64;
+    const double* const dptr[12] = {D.mu, D.nun, D.f_cur, D.pred, D.feas, D.fconst, D.stat, GUARD ? GB.omega : D.mu, GUARD ? GB.rho : D.mu, GUARD ? GB.rho_next : D.mu,
+                                    GUARD ? GB.meas_prev : D.mu, GUARD ? GB.ls_gd : D.mu};
+    const int* const iptr[8] = {D.first, D.status, D.cur, D.iters, D.skip, GUARD ? GB.outer : D.first, GUARD ? GB.ls_count : D.first, GUARD ? GB.n_outer : D.first};
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+      if (w == k) wd = __builtin_nontemporal_load(dptr[k] + b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (w == 12 + k) wi = __builtin_nontemporal_load(iptr[k] + b);
+    if (wd == -1.2345e300 || wi == -2047483647) sm[2][lane] = 1.0;  // (keeps the loads; never true)
+  }
   if (lane == 0) ctl[0] = D.status[b] >= 0 ? 0 : (D.skip[b] ? 1 : 2);
   __syncthreads();
   {
@@ -1154,7 +1176,7 @@ __global__ __launch_bounds__(128) void k_step_free_bb(FigParams P, FigBuffers D,
   if (lane < nK) {
     const int t = P.t0 + lane;
 #pragma unroll
-    for (int a = 0; a < N; ++a) stat = fmax(stat, fabs(gtc[IDX(t, N, a)]));
+    for (int a = 0; a < N; ++a) stat = fmax(stat, fabs(gtc[GTX(t, a)]));
   }
   stat = block_sum(stat, 0, true);
   if (lane == 0) ctl[0] = free_decide<N, GUARD>(P, D, GB, b, stat, mu, D.iters[b]);
@@ -1189,26 +1211,32 @@ __global__ __launch_bounds__(128) void k_step_free_bb(FigParams P, FigBuffers D,
       ec = Ec[IDX(P.t0 + k, N, cc)];
     }
   };
-  auto fetch = [&](const int k) {
-    const int t = P.t0 + k;
-    double a = 0.0;
-    if (mat) {
-      a = Drc[IDX(t, NP, pko)];
-      if (r == c) a += (t == T - 1 ? kap2 : 2.0 * kap2);
-    } else if (vec) {
-      a = -gtc[IDX(t, N, rr)];
-    }
-    return a;
-  };
+  // one load instruction per knot for all lanes (the pointer is chosen per lane; idle lanes read along on entry 0), addressed by a per-lane base and
+  // stride computed once: the index expressions of 50 unrolled fetches were 5000 instructions of 64-bit arithmetic
+  const double* fbase = vec ? gtc + GTX(P.t0 + k0, rr) : Drc + DRX(P.t0 + k0, pko);
+  const long long fstride = (long long)dir * (vec ? (long long)(GTX(P.t0 + 1, rr) - GTX(P.t0, rr)) : (long long)(DRX(P.t0 + 1, pko) - DRX(P.t0, pko)));
+  const double dsel = (mat && r == c) ? 1.0 : 0.0, vsgn = vec ? -1.0 : 1.0, live = (mat || vec) ? 1.0 : 0.0;
   bool factored = false;
   double* gsh = xw + (size_t)2 * KH * 64 + (size_t)wv * KH * 8;  // [KH][8]: -g of the wavefront's knots (the substitution needs them again)
   for (int attempt = 0; attempt < 40; ++attempt) {
     bool ok = true;
     // the wavefront's entries of all its knots in one go (a lane's loads of consecutive knots are independent: one memory latency, not one per knot)
-    for (int i = 0; i < cnt; ++i) {
-      const double a = fetch(k0 + dir * i);
-      xs[(size_t)i * 64 + l] = a;
-      if (vec) gsh[i * 8 + r] = a;
+    {  // every load of the wavefront in flight before the first store (a loop of load-store pairs pays a memory latency per knot)
+      double v[64];
+      const double* fp = fbase;
+#pragma unroll
+      for (int u = 0; u < 64; ++u) {
+        v[u] = (u < cnt) ? *fp : 0.0;
+        fp += fstride;
+      }
+#pragma unroll
+      for (int u = 0; u < 64; ++u)
+        if (u < cnt) {
+          const bool lastk = (k0 + dir * u == nK - 1);
+          const double a = live * fma(dsel, lastk ? kap2 : 2.0 * kap2, vsgn * v[u]);
+          xs[(size_t)u * 64 + l] = a;
+          if (vec) gsh[u * 8 + r] = a;
+        }
     }
     double xprev = 0.0;  // matrix lanes: X of the knot before; vector lanes: w
     for (int i = 0; i < cnt; ++i) {
@@ -1229,15 +1257,36 @@ __global__ __launch_bounds__(128) void k_step_free_bb(FigParams P, FigBuffers D,
           a = mat ? fma(-(er * ec), x0, a) : (vec ? fma(er, x0, a) : a);
         }
       }
+      // in-place Gauss-Jordan inversion, right-hand side carried along in column 7; pivots in 2 x 2 blocks (the dependent chain of a knot is
+      // shuffle -> reciprocal -> update: 4 of them per knot instead of 7).  Block J = {j, j + 1}, Q = P^{-1}:
+      //   a[r][c] -= a[r][J] Q a[J][c];  rows of J: Q a[J][c];  columns of J: -a[r][J] Q;  the block itself: Q
 #pragma unroll
-      for (int j = 0; j < N; ++j) {  // in-place Gauss-Jordan inversion, right-hand side carried along in column 7
+      for (int j = 0; j + 1 < N; j += 2) {
+        const double p00 = readlane_f64(a, 9 * j), p01 = readlane_f64(a, 9 * j + 1), p11 = readlane_f64(a, 9 * j + 9);
+        const double u0 = __shfl(a, 8 * r + j), u1 = __shfl(a, 8 * r + j + 1);
+        const double v0 = __shfl(a, 8 * j + c), v1 = __shfl(a, 8 * j + 8 + c);
+        const double det = fma(p00, p11, -(p01 * p01));
+        if (!(p00 > 1e-12) || !(det > 1e-14 * p00 * p11) || !(det < 1e300)) ok = false;
+        double d = __builtin_amdgcn_rcp(det);
+        d = d * fma(-det, d, 2.0);
+        d = d * fma(-det, d, 2.0);
+        const double q00 = p11 * d, q01 = -(p01 * d), q11 = p00 * d;
+        const double w0 = fma(q00, v0, q01 * v1), w1 = fma(q01, v0, q11 * v1);  // rows of Q a[J][c]
+        const double gen = a - fma(u0, w0, u1 * w1);
+        const double c0 = -fma(u0, q00, u1 * q01), c1 = -fma(u0, q01, u1 * q11);  // columns of -a[r][J] Q
+        const bool rJ = (r == j) || (r == j + 1), cJ = (c == j) || (c == j + 1);
+        const double blk = (r == j) ? ((c == j) ? q00 : q01) : ((c == j) ? q01 : q11);
+        const double rowv = (r == j) ? w0 : w1, colv = (c == j) ? c0 : c1;
+        a = rJ ? (cJ ? blk : rowv) : (cJ ? colv : gen);
+      }
+      {  // the last pivot alone
+        constexpr int j = N - 1;
         const double piv = readlane_f64(a, 9 * j);
         const double cj = __shfl(a, 8 * r + j), rj = __shfl(a, 8 * j + c);
         if (!(piv > 1e-12) || !(piv < 1e300)) ok = false;
         double d = __builtin_amdgcn_rcp(piv);
         d = d * fma(-piv, d, 2.0);
         d = d * fma(-piv, d, 2.0);
-        // branch-free: pivot entry d; pivot row a d; pivot column -a d; elsewhere a - cj rj d
         const double gen = fma(-(cj * rj), d, a), sc = a * d;
         a = (r == j) ? ((c == j) ? d : sc) : ((c == j) ? -sc : gen);
       }
@@ -1405,7 +1454,7 @@ __global__ __launch_bounds__(8 * KN) void k_step_free_cp(FigParams P, FigBuffers
   const double* __restrict__ Drc = cur ? D.Dr[1] : D.Dr[0];
   const double* __restrict__ gtc = cur ? D.gt[1] : D.gt[0];
   const double* __restrict__ Ec = cur ? D.E[1] : D.E[0];
-  const double gmine = (active && row) ? gtc[IDX(tl, N, cr)] : 0.0;
+  const double gmine = (active && row) ? gtc[GTX(tl, cr)] : 0.0;
   const double stat = block_sum(fabs(gmine), 0, true);
   double z = 0.0;  // the step component (t, c) at the end
   bool factored = false;
@@ -1414,7 +1463,7 @@ __global__ __launch_bounds__(8 * KN) void k_step_free_cp(FigParams P, FigBuffers
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       const int hi = cr > j ? cr : j, lo = cr > j ? j : cr;
-      Ar[j] = (active && row) ? Drc[IDX(tl, NP, tri(hi, lo))] : (j == cr ? 1.0 : 0.0);
+      Ar[j] = (active && row) ? Drc[DRX(tl, tri(hi, lo))] : (j == cr ? 1.0 : 0.0);
       Lr[j] = 0.0;
       Ur[j] = 0.0;
     }

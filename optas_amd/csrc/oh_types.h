@@ -29,6 +29,7 @@ struct FigParams {
   int np;            // row stride of the parameter matrix p (ndof, or ndof + guard parameters)
   int zc;            // 1: coupling folded into evaluation and sweep (eval_unit<.., ZC>, step_instance_zc): Gfull[] holds G of every evaluated point
   int zc_free;       // 1: position-tracking family without velocity rows: coupling folded into the evaluation (couple_inline_free), no k_couple_free launch
+  int inst_major;    // 1: position-tracking family, stage blocks Dr / gt instance-major [b][t][.] (every launch gives an instance its own block; oh_free.hip DRX / GTX)
 };
 
 // Inequality rows of the position-tracking family (oh_guards): constants and per-instance state.

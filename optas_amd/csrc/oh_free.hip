@@ -194,6 +194,18 @@ __global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D,
   const oh_chain* __restrict__ ch = D.chain;
   const int NC = GP.NC;
   const int nl = GP.limits ? 2 * N : 0;
+  // requested before the kinematics walk so that the walk hides them: the first eight obstacles (the same for every link); further obstacles and the
+  // multipliers are fetched chunk by chunk inside the walk
+  double ox0[8], oy0[8], oz0[8], or0[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int o = u < GP.n_obs ? u : 0;
+    const size_t ob = (size_t)(GP.n_links + 4 * o) * Bp + b;
+    ox0[u] = GB.par[ob];
+    oy0[u] = GB.par[ob + Bp];
+    oz0[u] = GB.par[ob + 2 * (size_t)Bp];
+    or0[u] = GB.par[ob + 3 * (size_t)Bp];
+  }
   double g[N], W[NP], psi = 0.0, meas = 0.0;
 #pragma unroll
   for (int i = 0; i < N; ++i) g[i] = 0.0;
@@ -243,30 +255,63 @@ __global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D,
         }
       }
       const double rl = GB.par[(size_t)l * Bp + b];
-      for (int o = 0; o < GP.n_obs; ++o) {
-        const size_t ob = (size_t)(GP.n_links + 4 * o) * Bp + b;
-        const double d[3] = {c[0] - GB.par[ob], c[1] - GB.par[ob + Bp], c[2] - GB.par[ob + 2 * (size_t)Bp]};
-        const double rr = rl + GB.par[ob + 3 * (size_t)Bp];
-        const double gval = dot3(d, d) - rr * rr;
-        double dg[N];
+      // Obstacles in chunks of eight: multipliers and obstacle parameters of a chunk are requested together, then the rows are formed, then the
+      // refreshed multipliers are stored.  (Row by row -- load the multiplier, use it, perhaps store it -- every row waited for its own load: the store
+      // may alias the next load as far as the compiler can tell.  38 rows x a memory latency were most of the kernel's 40 us.)
+      for (int o0 = 0; o0 < GP.n_obs; o0 += 8) {
+        double lm8[8], ox[8], oy[8], oz[8], orad[8];
+        if (o0 == 0) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) dg[j] = 2.0 * dot3(Jl[j], d);
-        guard_row<N>(gval, dg, rho, rho_old, upd, GB.lam + IDX(t, NC, nl + l * GP.n_obs + o), psi, meas, g, W);
+          for (int u = 0; u < 8; ++u) {
+            ox[u] = ox0[u]; oy[u] = oy0[u]; oz[u] = oz0[u]; orad[u] = or0[u];
+            lm8[u] = GB.lam[IDX(t, NC, nl + l * GP.n_obs + (u < GP.n_obs ? u : 0))];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int o = (o0 + u < GP.n_obs) ? o0 + u : o0;
+            const size_t ob = (size_t)(GP.n_links + 4 * o) * Bp + b;
+            lm8[u] = GB.lam[IDX(t, NC, nl + l * GP.n_obs + o)];
+            ox[u] = GB.par[ob];
+            oy[u] = GB.par[ob + Bp];
+            oz[u] = GB.par[ob + 2 * (size_t)Bp];
+            orad[u] = GB.par[ob + 3 * (size_t)Bp];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (o0 + u < GP.n_obs) {
+            const double d[3] = {c[0] - ox[u], c[1] - oy[u], c[2] - oz[u]};
+            const double rr = rl + orad[u];
+            const double gval = dot3(d, d) - rr * rr;
+            double dg[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) dg[j] = 2.0 * dot3(Jl[j], d);
+            guard_row<N>(gval, dg, rho, rho_old, upd, &lm8[u], psi, meas, g, W);
+          }
+        }
+        if (upd) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (o0 + u < GP.n_obs) GB.lam[IDX(t, NC, nl + l * GP.n_obs + o0 + u)] = lm8[u];
+        }
       }
     }
   }
   if (GP.limits) {
+    double lml[2 * N];
+#pragma unroll
+    for (int i = 0; i < 2 * N; ++i) lml[i] = GB.lam[IDX(t, NC, i)];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       // rows q_j - lo_j and up_j - q_j: gradients +e_j / -e_j
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
         const double gval = side ? GP.up[j] - q[j] : q[j] - GP.lo[j];
-        double* lam_ptr = GB.lam + IDX(t, NC, side * N + j);
-        double lam = *lam_ptr;
+        double lam = lml[side * N + j];
         if (upd) {
           lam = fmax(0.0, lam - rho_old * gval);
-          *lam_ptr = lam;
+          lml[side * N + j] = lam;
         }
         const double s = lam - rho * gval;
         meas = fmax(meas, fabs(fmin(gval, lam / rho)));
@@ -278,6 +323,10 @@ __global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D,
           psi -= lam * lam / (2.0 * rho);
         }
       }
+    }
+    if (upd) {
+#pragma unroll
+      for (int i = 0; i < 2 * N; ++i) GB.lam[IDX(t, NC, i)] = lml[i];
     }
   }
   // ---- tracking terms (as eval_knot_free, Gauss-Newton) ----

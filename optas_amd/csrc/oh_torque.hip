@@ -1907,7 +1907,9 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
           const double rq = __shfl(Muq, 8 * j + c), rd = __shfl(Mud, 8 * j + c), ru = __shfl(Muu, 8 * j + c);
           const double piv = readlane_f64(Muu, 9 * j);
           if (!(piv > 0.0) || !isfinite(piv)) failed = true;
-          const double d = 1.0 / piv;
+          double d = __builtin_amdgcn_rcp(piv);  // reciprocal to the last bit or two (two Newton steps): an IEEE division is 30 instructions on the critical path of every pivot
+          d = d * fma(-piv, d, 2.0);
+          d = d * fma(-piv, d, 2.0);
           if (c < N) {
             Mqq = fma(-(cq * rq), d, Mqq);
             Mqd = fma(-(cq * rd), d, Mqd);

@@ -307,7 +307,11 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   };
   const Hooks hooks{D.q[slot], D.g[slot], D.Z[slot], D.Gfull[cur], Bp, b, t, Gpre, D.q[slot], q, D.Gfull[slot], &sm_zc, 2.0 * P.kappa, t == P.T - 1, cpl_zc};
   double e_new[3], JZ_new[3][NZ];
-  const double tol_r = retract_tol(P, !first, pred_b, stat_b);
+  // A restart after a compaction (first_b == 2) evaluates the accepted point AS IT IS: its knots are the retracted
+  // knots the instance accepted, and retracting them again (to the floor tolerance, as a seed would be) moved them by ~1e-10 -- enough to send an
+  // instance between two basins down another path than the same instance takes alone (round 3's "not batch-invariant", HISTORY).  Without the
+  // retraction the stage data of the restart are those of the accepted point bit for bit and the interrupted step is re-derived exactly.
+  const double tol_r = (first_b == 2) ? 1e300 : retract_tol(P, !first, pred_b, stat_b);
   if constexpr (LEAD)
     eval_knot<N, true, Hooks, MODE>(OH_CHAIN(D), P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new,
                                     D.lead[(size_t)t * Bp + b], hooks);

@@ -17,5 +17,5 @@ for tag, env in (("default", {}), ("no compaction", {"OH_COMPACTION": "0"}), ("f
     kuka, solver = setup_solver(T=T, Tmax=10.0 * (T - 1) / 49.0, velocity_limits=True, solver_options={"max_iter": 600, "tol": 1e-6, "hessian": os.environ.get("HESS", "hybrid")})
     r = solver.solve_batch_arrays(x0[lo:n, : solver.opt.nx], qcs[lo:n])
     i = 10961 - lo
-    print(tag, "status", np.bincount(r.status, minlength=3), "instance 10961: status", r.status[i], "iters", r.iters[i], "f", r.f[i], "stat", r.kkt[i, 0], "compactions", solver.backend.timing()["compactions"], flush=True)
+    print(tag, "status", np.bincount(r.status, minlength=3), "instance 10961: status", r.status[i], "iters", r.iters[i], "f", r.f[i], "stat", r.kkt[i, 0], "compactions", solver.backend.timing()["compactions"], "device ms", solver.backend.timing()["solve_ms"], "launched", solver.backend.timing()["iterations_launched"], flush=True)
     solver.backend.close()

@@ -441,11 +441,17 @@ OH_DEV void rnea_vw3(const oh_dynamics* __restrict__ dy, const double* qs, const
 // iRp @ axis, is then the axis Rot(axis, q) turns about; models.py:1821-1823).  oh_create_torque checks it; other tables take the dual-number path.
 template <int N>
 struct IdsWs {
-  static constexpr int TW = 3 * N + 1;           // row pitch of the unit's tile of columns [N + 3][3 N + 1] (k_tq_eval3), filled by phase 3
-  static constexpr int P1 = 0;                   // per body: R (9), o (3), v (6), a (6) -- dead after phase 2, the tile takes its place
-  static constexpr int S = (N + 3) * TW > (N + 1) * 24 ? (N + 3) * TW : (N + 1) * 24;  // joint screws, 6 each
-  static constexpr int BD = S + N * 6;           // per moving body: m, h (3), A (xx xy xz yy yz zz), Xi (9), p (3), W (6) = 28
-  static constexpr int SIZE = (BD + N * 28) | 1;  // odd: the units of a wavefront land in different banks
+  // A unit's LDS in k_tq_eval3, 277 doubles for N = 7 (nine units: 19.9 KB, so that two blocks share a SIMD's quarter of the CU's 160 KB):
+  static constexpr int TW = 4 * N;               // pitch of the per-body slots: 28 = m, h (3), A (6), Xi (9), p (3), W (6); once phase 3 has consumed body
+                                                 // m its slot takes row m of d tau / dz (3 N entries) and, behind it, lane m's row coefficients (RW)
+  static constexpr int BD = 0;
+  static constexpr int RW = 3 * N + 1;           // offset inside a slot: cf, cb, dw, bar, nrel, viol (6 doubles; the slot has 28 - 22 = 6 to spare)
+  static constexpr int S = N * TW;               // joint screws, 6 each (phases 1-3); then, together with QS, the three rows of d p_link / dz (JP)
+  static constexpr int QS = S + 6 * N;           // (q | dq | ddq) at 0, 8, 16: read by the loop counter in phase 1 and by the chain walk
+  static constexpr int JP = S;                   // pitch 3 N + 1
+  static constexpr int RW2 = QS + 24;            // cmpl[N], fsum[N]
+  static constexpr int SIZE = (RW2 + 2 * N) | 1;  // odd: the units of a wavefront land in different banks
+  static_assert(3 * (3 * N + 1) <= 6 * N + 24, "the rows of d p_link / dz take the place of the screws and of (q | dq | ddq)");
 };
 OH_DEV void mcross6(const double* x, const double* y, double* o) {  // motion x motion
   double t[3];
@@ -539,77 +545,83 @@ OH_DEV void ids_body(const oh_dynamics* __restrict__ dy, const int b, const doub
 // ws: the unit's LDS workspace (IdsWs<N>::SIZE doubles), qs: (q | dq | ddq) at 0, 8, 16; every lane of the unit calls (block of one wavefront).
 // Lane j leaves column j, N + j, 2 N + j of d tau / d (q, dq, ddq) in rows 0 .. N-1 of the tile at ws[0] and returns tau_j.
 template <int N>
-OH_DEV double rnea_idsva(const oh_dynamics* __restrict__ dy, double* __restrict__ ws, const double* __restrict__ qs, const int j, const bool writer) {
+OH_DEV double rnea_idsva(const oh_dynamics* __restrict__ dy, double* __restrict__ ws, const int j, const bool writer) {
   using L = IdsWs<N>;
+  const double* qs = ws + L::QS;
   double Sj[6], Sdj[6], Sddj[6];
+  double own[24];  // (R, o, v, a) of body j, picked up on the way (every lane walks the whole chain)
   {
     double Rw[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0}, ow[3] = {0.0, 0.0, 0.0};
     double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, a[6] = {0.0, 0.0, 0.0, dy->vd0[0], dy->vd0[1], dy->vd0[2]};
 #pragma unroll
     for (int k = 0; k < 6; ++k) Sj[k] = Sdj[k] = Sddj[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) own[k] = 0.0;
 #pragma unroll 1
-    for (int i = 0; i <= N; ++i) {
+    for (int i = 0; i < N; ++i) {
       double o[3], Ri[9];
       mv3(Rw, dy->xyz[i], o);
       o[0] += ow[0]; o[1] += ow[1]; o[2] += ow[2];
-      if (i < N) {
-        double S[6], Sd[6], Sdd[6], t6[6], Rp[9], sj, cj;
-        mv3(Rw, dy->axis[i], S);
-        cross3(o, S, S + 3);
-        sincos_joint(qs[i], &sj, &cj);
-        joint_rotation(dy->R0[i], dy->axis[i], sj, cj, Rp);
-        mm3(Rw, Rp, Ri);
-        mcross6(v, S, Sd);
-        const double qd = qs[8 + i], qdd = qs[16 + i];
+      double S[6], Sd[6], Sdd[6], t6[6], Rp[9], sj, cj;
+      mv3(Rw, dy->axis[i], S);
+      cross3(o, S, S + 3);
+      sincos_joint(qs[i], &sj, &cj);
+      joint_rotation(dy->R0[i], dy->axis[i], sj, cj, Rp);
+      mm3(Rw, Rp, Ri);
+      mcross6(v, S, Sd);
+      const double qd = qs[8 + i], qdd = qs[16 + i];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          v[k] = fma(S[k], qd, v[k]);
-          a[k] = fma(Sd[k], qd, fma(S[k], qdd, a[k]));
-        }
-        mcross6(a, S, Sdd);
-        mcross6(v, Sd, t6);
-        const bool mine = i == j;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          Sdd[k] += t6[k];
-          Sj[k] = mine ? S[k] : Sj[k];
-          Sdj[k] = mine ? Sd[k] : Sdj[k];
-          Sddj[k] = mine ? Sdd[k] : Sddj[k];
-        }
-        if (writer && mine) {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) ws[L::S + 6 * i + k] = S[k];
-        }
-      } else {
-        mm3(Rw, dy->R0[i], Ri);
+      for (int k = 0; k < 6; ++k) {
+        v[k] = fma(S[k], qd, v[k]);
+        a[k] = fma(Sd[k], qd, fma(S[k], qdd, a[k]));
       }
-      if (writer && j == (i < N ? i : N - 1)) {
-        double* p1 = ws + L::P1 + 24 * i;
+      mcross6(a, S, Sdd);
+      mcross6(v, Sd, t6);
+      const bool mine = i == j;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) p1[k] = Ri[k];
+      for (int k = 0; k < 6; ++k) {
+        Sdd[k] += t6[k];
+        Sj[k] = mine ? S[k] : Sj[k];
+        Sdj[k] = mine ? Sd[k] : Sdj[k];
+        Sddj[k] = mine ? Sdd[k] : Sddj[k];
+        own[12 + k] = mine ? v[k] : own[12 + k];
+        own[18 + k] = mine ? a[k] : own[18 + k];
+      }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) p1[9 + k] = o[k];
+      for (int k = 0; k < 9; ++k) own[k] = mine ? Ri[k] : own[k];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          p1[12 + k] = v[k];
-          p1[18 + k] = a[k];
-        }
+      for (int k = 0; k < 3; ++k) own[9 + k] = mine ? o[k] : own[9 + k];
+      if (writer && mine) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ws[L::S + 6 * i + k] = S[k];
       }
 #pragma unroll
       for (int k = 0; k < 9; ++k) Rw[k] = Ri[k];
       ow[0] = o[0]; ow[1] = o[1]; ow[2] = o[2];
     }
   }
-  __syncthreads();
   {
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-    ids_body(dy, j, ws + L::P1 + 24 * j, acc);
-    if (j == N - 1) ids_body(dy, N, ws + L::P1 + 24 * N, acc);  // the fixed last body moves with body N - 1
+    ids_body(dy, j, own, acc);
+    {  // the fixed last body moves with body N - 1: its frame follows from that body's (lane N - 1 keeps the result)
+      double last[24], t3[3];
+      mm3(own, dy->R0[N], last);
+      mv3(own, dy->xyz[N], t3);
+      last[9] = own[9] + t3[0]; last[10] = own[10] + t3[1]; last[11] = own[11] + t3[2];
+#pragma unroll
+      for (int k = 12; k < 24; ++k) last[k] = own[k];
+      double acc2[28];
+#pragma unroll
+      for (int k = 0; k < 28; ++k) acc2[k] = 0.0;
+      ids_body(dy, N, last, acc2);
+#pragma unroll
+      for (int k = 0; k < 28; ++k) acc[k] += (j == N - 1) ? acc2[k] : 0.0;
+    }
     if (writer) {
 #pragma unroll
-      for (int k = 0; k < 28; ++k) ws[L::BD + 28 * j + k] = acc[k];
+      for (int k = 0; k < 28; ++k) ws[L::BD + L::TW * j + k] = acc[k];
     }
   }
   __syncthreads();
@@ -622,7 +634,7 @@ OH_DEV double rnea_idsva(const oh_dynamics* __restrict__ dy, double* __restrict_
   for (int k = 0; k < 6; ++k) u0s[k] = u1s[k] = u2s[k] = 0.0;
 #pragma unroll 1
   for (int m = N - 1; m >= 0; --m) {
-    const double* bd = ws + L::BD + 28 * m;
+    const double* bd = ws + L::BD + L::TW * m;
     double Sm[6];
 #pragma unroll
     for (int k = 0; k < 28; ++k) C[k] += bd[k];
@@ -668,10 +680,12 @@ OH_DEV double rnea_idsva(const oh_dynamics* __restrict__ dy, double* __restrict_
       u1[k] = below ? u1[k] : u1s[k];
       u2[k] = below ? u2[k] : u2s[k];
     }
+    const double e0 = dot6(Sm, u0), e1 = dot6(Sm, u1), e2 = dot6(Sm, u2);
+    __syncthreads();  // every lane of the unit has taken body m out of its slot: the slot becomes row m of d tau / dz
     if (writer) {
-      ws[m * L::TW + j] = dot6(Sm, u0);
-      ws[m * L::TW + N + j] = dot6(Sm, u1);
-      ws[m * L::TW + 2 * N + j] = dot6(Sm, u2);
+      ws[m * L::TW + j] = e0;
+      ws[m * L::TW + N + j] = e1;
+      ws[m * L::TW + 2 * N + j] = e2;
     }
   }
   return tau_j;
@@ -1344,19 +1358,22 @@ OH_DEV TqRow tq_row(const double s, const double s_old, const double lam_old, co
 // with columns j, N + j and 2 N + j of d tau / d z; the chain walk for p_link adds column j of its Jacobian.  The columns meet in LDS and every lane
 // writes ITS THREE columns of the packed stage block  J^T diag(2 w_tau + Sigma) J + 2 w_p Jp^T Jp + ...,  of the two gradients (cost, barrier per unit
 // mu_b) and of d tau / d z itself.  Bound: f64 FMA issue (268 registers, one wavefront per SIMD).
-#ifndef OH_TQ_EVAL3_WAVES
-#define OH_TQ_EVAL3_WAVES 1
-#endif
 template <int N, bool VEL = false, bool IDS = true>
-__global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, TqBuffers D) {
+__global__ __launch_bounds__(64, IDS ? 2 : 1) void k_tq_eval3(TqParams P, TqBuffers D) {
   constexpr int NZ = 3 * N;
   constexpr int UPW = 64 / N;  // units per wavefront (9)
-  constexpr int TW = NZ + 1;   // row pitch of a unit's tile of columns [N + 3][NZ + 1]: rows 0 .. N-1 d tau / dz, rows N .. N+2 d p_link / dz
-  constexpr int WS = IDS ? IdsWs<N>::SIZE : ((N + 3) * TW | 1);  // a unit's LDS: the tile, and behind it the workspace of rnea_idsva
-  static_assert(!IDS || IdsWs<N>::TW == TW, "tile pitch");
+  // A unit's LDS.  Closed-form path: IdsWs<N> (277 doubles: two blocks per SIMD).  Dual-number path: tile [N + 3][NZ + 1], row coefficients, (q|dq|ddq).
+  using L = IdsWs<N>;
+  constexpr int TW = IDS ? L::TW : NZ + 1;                  // pitch of rows 0 .. N-1 of the tile (d tau / dz)
+  constexpr int JP = IDS ? L::JP : N * (NZ + 1);            // rows of d p_link / dz, pitch NZ + 1
+  constexpr int QS = IDS ? L::QS : (N + 3) * (NZ + 1) + 8 * N;
+  constexpr int WS = IDS ? L::SIZE : ((QS + 24) | 1);
   __shared__ double lds_raw[UPW * WS];
-  __shared__ double qs_l[UPW][24];
-  __shared__ double rw_l[UPW][8][N];
+  // row coefficients of joint m: which = 0 cf, 1 cb, 2 dw, 3 bar, 4 nrel, 5 viol, 6 cmpl, 7 fsum
+  auto rw = [](double* tl, const int which, const int m) -> double& {
+    if constexpr (IDS) return which < 6 ? tl[m * L::TW + L::RW + which] : tl[L::RW2 + (which - 6) * N + m];
+    else return tl[(N + 3) * (NZ + 1) + which * N + m];
+  };
   const int T = P.T;
   const int lane = threadIdx.x;
   if (blockIdx.x == 0 && lane == 0) *D.n_running = 0;  // k_tq_step, next in the stream, counts the instances that go on
@@ -1380,20 +1397,24 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
   const double mub = D.mub[b], delta = P.theta * mub;
 
   // 1. torques and their derivative: lane j leaves its three columns in the unit's tile and keeps tau_j
+  double* tl = lds_raw + ul * WS;
+  double* qs_u = tl + QS;
   const double qj = xr[j], dqj = xr[8 + j];
   if (lane_ok) {  // the recursions read (q | dq | ddq) of their unit by a loop counter: LDS, not a lane-private array
-    qs_l[ul][j] = qj;
-    qs_l[ul][8 + j] = dqj;
-    qs_l[ul][16 + j] = xr[16 + j];
+    qs_u[j] = qj;
+    qs_u[8 + j] = dqj;
+    qs_u[16 + j] = xr[16 + j];
   }
   __syncthreads();
-  double* tl = lds_raw + ul * WS;
+  double qv[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) qv[k] = qs_u[k];
   double tvj;
   if constexpr (IDS) {
-    tvj = rnea_idsva<N>(D.dyn, tl, qs_l[ul], j, lane_ok);
+    tvj = rnea_idsva<N>(D.dyn, tl, j, lane_ok);
   } else {
     Dual3 tau[N];
-    rnea_vw3<N + 1, Dual3>(D.dyn, qs_l[ul], j, tau);
+    rnea_vw3<N + 1, Dual3>(D.dyn, qs_u, j, tau);
     tvj = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -1451,24 +1472,22 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
         lm_new[16 + N + j] = u2.lam;
       }
     }
+    __syncthreads();  // (the last row of d tau / dz is in its slot: the slots' spare words are free)
     if (lane_ok) {
-      rw_l[ul][0][j] = 2.0 * P.w_tau * tvj;              // cf
-      rw_l[ul][1][j] = up.bco - lo.bco;                  // cb
-      rw_l[ul][2][j] = 2.0 * P.w_tau + lo.sig + up.sig;  // dw
-      rw_l[ul][3][j] = bar_j;
-      rw_l[ul][4][j] = nrel_j;
-      rw_l[ul][5][j] = viol_j;
-      rw_l[ul][6][j] = cmpl_j;
-      rw_l[ul][7][j] = fma(P.w_tau * tvj, tvj, P.w_vel * dqj * dqj);
+      rw(tl, 0, j) = 2.0 * P.w_tau * tvj;              // cf
+      rw(tl, 1, j) = up.bco - lo.bco;                  // cb
+      rw(tl, 2, j) = 2.0 * P.w_tau + lo.sig + up.sig;  // dw
+      rw(tl, 3, j) = bar_j;
+      rw(tl, 4, j) = nrel_j;
+      rw(tl, 5, j) = viol_j;
+      rw(tl, 6, j) = cmpl_j;
+      rw(tl, 7, j) = fma(P.w_tau * tvj, tvj, P.w_vel * dqj * dqj);
     }
   }
 
-  // 3. link position and column j of its Jacobian (models.py:826-868, 1211-1264)
+  // 3. link position and column j of its Jacobian (models.py:826-868, 1211-1264); its rows take the place of the screws and of (q | dq | ddq)
   double jp[3], r[3];
   {
-    double qv[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k) qv[k] = qs_l[ul][k];
     double R[9], pp[3], z[N][3], pj[N][3];
     fk_chain<N>(D.chain, qv, R, pp, z, pj);
     double e[3], tv3[3];
@@ -1498,9 +1517,9 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
   if (lane_ok) {  // the link position has no dq / ddq columns
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      tl[(N + k) * TW + j] = jp[k];
-      tl[(N + k) * TW + N + j] = 0.0;
-      tl[(N + k) * TW + 2 * N + j] = 0.0;
+      tl[JP + k * (NZ + 1) + j] = jp[k];
+      tl[JP + k * (NZ + 1) + N + j] = 0.0;
+      tl[JP + k * (NZ + 1) + 2 * N + j] = 0.0;
     }
   }
   __syncthreads();
@@ -1512,13 +1531,13 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
   int nrel = 0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const double cf = rw_l[ul][0][i], cb = rw_l[ul][1][i];
-    dw[i] = rw_l[ul][2][i];
-    bar += rw_l[ul][3][i];
-    nrel += (int)rw_l[ul][4][i];
-    viol = fmax(viol, rw_l[ul][5][i]);
-    cmpl = fmax(cmpl, rw_l[ul][6][i]);
-    fsum += rw_l[ul][7][i];
+    const double cf = rw(tl, 0, i), cb = rw(tl, 1, i);
+    dw[i] = rw(tl, 2, i);
+    bar += rw(tl, 3, i);
+    nrel += (int)rw(tl, 4, i);
+    viol = fmax(viol, rw(tl, 5, i));
+    cmpl = fmax(cmpl, rw(tl, 6, i));
+    fsum += rw(tl, 7, i);
     J0[i] = tl[i * TW + j];
     J1[i] = tl[i * TW + N + j];
     J2[i] = tl[i * TW + 2 * N + j];
@@ -1547,7 +1566,7 @@ __global__ __launch_bounds__(64, OH_TQ_EVAL3_WAVES) void k_tq_eval3(TqParams P, 
         if (c3 == 0) {
           double hp = 0.0;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) hp = fma(tl[(N + k) * TW + rr], jp[k], hp);
+          for (int k = 0; k < 3; ++k) hp = fma(tl[JP + k * (NZ + 1) + rr], jp[k], hp);
           hv = fma(2.0 * P.w_path, hp, hv);
         }
         if (rr == d && c3 == 1) {
@@ -1841,7 +1860,16 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
         stall = 0;
       } else {
         stall += 1;
-        if (stall >= P.stall_max && nrel == 0 && accept) {
+        if (stall >= P.stall_max && nrel == 0 && mub <= mu_min && stat <= 10.0 * P.tol) {
+          // "acceptable level" (IPOPT's acceptable_tol / acceptable_iter in spirit): stall_max steps at the floor of the barrier parameter without
+          // meeting tol while within ten times of it -- the arithmetic floor of the reduced gradient: an active row with slack s carries mu_b / s,
+          // and s = up - tau inherits the ~1e-14 of the recursion, so at s ~ 1e-8 the multiplier is good to ~1e-6 relative and the reduced gradient to
+          // ~1e-6 absolute.  Without this such an instance (1 of 8192 in one of nine batches) fed the watchdog below and ended NUMERICAL at the optimum.
+          status = OH_STATUS_CONVERGED;
+          iters -= 1;
+          do_roll = false;
+          do_gains = false;
+        } else if (stall >= P.stall_max && nrel == 0 && accept) {
           // watchdog: stall_max steps without reaching the barrier test -- the iterate sits far from the central path of this mu_b (slacks of the active
           // rows collapse and recover in turn).  Back to a larger barrier parameter: the path is regained there and followed down again.
           mub = mub_up;

@@ -162,6 +162,7 @@ def solve_ipm(nlp, x0, p, tol=1e-8, max_iter=3000, mu0=0.1, scaling=True, verbos
     filt = [(th_max, -np.inf)]  # entries (theta_j, phi_j): a trial is refused if theta >= theta_j and phi >= phi_j
     dw_last = 0.0
     hist, n_acc, n_tiny, status = [], 0, 0, "max_iter"
+    n_resto = 0
 
     def barrier(xv, sv, fv=None):
         dl, du = sv - sL, sU - sv
@@ -319,6 +320,7 @@ def solve_ipm(nlp, x0, p, tol=1e-8, max_iter=3000, mu0=0.1, scaling=True, verbos
             # --- feasibility restoration (simplified, see the module docstring): Gauss-Newton on the rows that cannot be met by any slack
             #     inside its bounds, then the slacks are reset to the projection of v(x); the point enters the filter as in [3.3]
             filt.append(((1 - g_th) * theta, phi - g_ph * theta))
+            n_resto += 1
             for _ in range(30):
                 vx = P.v(x)
                 viol = np.maximum(sL + 1e-9 - vx, 0.0) - np.maximum(vx - (sU - 1e-9), 0.0)
@@ -351,4 +353,4 @@ def solve_ipm(nlp, x0, p, tol=1e-8, max_iter=3000, mu0=0.1, scaling=True, verbos
     # multipliers in the reference's form: L = f - lam_v^T v with lam_v >= 0 on v >= 0; here L = d_f f + lam^T (d_c v - s), stationarity in s gives
     # lam = -(zL - zU), so lam_v = -(d_c / d_f) lam
     lam_v = -(P.d_c / P.d_f) * lam
-    return {"x": x, "f": nlp.f(x, P.p), "iters": it, "status": status, "E0": E0, "lam_v": lam_v, "mu": mu, "history": hist, "d_f": P.d_f}
+    return {"x": x, "f": nlp.f(x, P.p), "iters": it, "status": status, "E0": E0, "lam_v": lam_v, "mu": mu, "history": hist, "d_f": P.d_f, "n_restoration": n_resto}

@@ -196,6 +196,11 @@ def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, 
                 g = cur["gf"] + mub * cur["gb"]
                 stat = float(np.abs(costate_gradient(g, dt)).max())
             stall = 0 if n_barrier != nb_before else stall + 1
+            if stall >= stall_max and cur["nrel"] == 0 and mub <= mu_min and stat <= 10.0 * tol:
+                # acceptable level: stall_max steps at the floor of the barrier parameter within ten times the tolerance (the arithmetic floor of the
+                # reduced gradient when an active row has a slack of 1e-8: its multiplier mu_b / s is good to 1e-6 relative); k_tq_step alike
+                status = 0
+                break
             if stall >= stall_max and cur["nrel"] == 0 and accept:
                 # watchdog: stall_max steps without reaching the barrier test -- the iterate sits far from the central path of this mu_b (slacks of the
                 # active rows collapse and recover in turn).  Back to a larger barrier parameter: the path is regained there and followed down again.

@@ -196,6 +196,29 @@ def test_tables_that_are_no_rigid_body_chain_take_the_dual_number_path_and_equal
     be.close()
 
 
+def test_instance_at_the_arithmetic_floor_ends_at_the_optimum(hip_lib, ctx):
+    """Instance 7359 of tools/gpu_tq_ipm_probe.py's batch of 8192: start within 1.5 N m of the gravity torque limit, at the optimum an effort row with
+    slack 1.6e-8 whose multiplier mu_b / s is good to ~1e-6 relative -- the reduced gradient cannot be pushed below ~2e-6 in this arithmetic.  One build of
+    round 4 reached the optimum at step 90 and then fed the watchdog for 450 steps (NUMERICAL).  Pinned: status converged (by tol or by the acceptable
+    level: 25 steps at the floor of the barrier parameter within 10 tol), the objective equals the numpy port's to 1e-9, rows strictly feasible."""
+    med7, robot, g = ctx
+    T = 30
+    qc = np.array([-0.009206280161798391, 0.6187609522084117, -0.030419334043609858, -1.4849330895196382, -0.03916752292410011, -0.6112430533197809,
+                   0.04844326754516143])
+    prob = TorqueProblem(med7, LINK, T=T, dt=0.1, tau_lim=58.0, **W)
+    nlp = TorqueMPCNLP(prob)
+    goal = prob.goal_figure_eight(qc)
+    be = backend(robot, T, 58.0, max_iter=600)
+    res = be.solve(nlp.seed(qc)[None], nlp.pack_p(qc, np.zeros(7), goal)[None])
+    o = solve_torque_ipm(prob, qc, np.zeros(7), goal, max_iter=600)
+    assert res.status[0] == 0 and o["status"] == 0
+    assert res.iters[0] <= 150
+    assert abs(res.f[0] - o["f"]) <= 1e-9 * o["f"]
+    kkt = np.asarray(res.kkt)[0]
+    assert kkt[0] <= 1e-5 and kkt[1] == 0.0 and kkt[2] <= 1e-8
+    be.close()
+
+
 def test_reference_script_flow_through_hipsolver(hip_lib, ctx):
     med7, robot_, g = ctx
     import optas_amd as optas

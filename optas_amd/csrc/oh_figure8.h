@@ -138,14 +138,15 @@ OH_DEV void velocity_rows(const GuardParams& GP, const double dt, const double r
                           double (&sigma)[N], double (&w)[N], double& psi, double& meas) {
   psi = 0.0;
   meas = 0.0;
+  const double irho = 1.0 / rho, i2rho = 1.0 / (2.0 * rho);  // (one division each instead of four per joint: an f64 division is ~30 instructions)
   const double idt = 1.0 / dt;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const double v = (qb[k] - qa[k]) * idt;
     const double g_lo = v - GP.vlo[k], g_up = GP.vup[k] - v;
     const double s_lo = fmax(0.0, lam[k] - rho * g_lo), s_up = fmax(0.0, lam[N + k] - rho * g_up);
-    psi += (s_lo * s_lo - lam[k] * lam[k]) / (2.0 * rho) + (s_up * s_up - lam[N + k] * lam[N + k]) / (2.0 * rho);
-    meas = fmax(meas, fmax(fabs(fmin(g_lo, lam[k] / rho)), fabs(fmin(g_up, lam[N + k] / rho))));
+    psi += (s_lo * s_lo - lam[k] * lam[k]) * i2rho + (s_up * s_up - lam[N + k] * lam[N + k]) * i2rho;
+    meas = fmax(meas, fmax(fabs(fmin(g_lo, lam[k] * irho)), fabs(fmin(g_up, lam[N + k] * irho))));
     sigma[k] = (s_up - s_lo) * idt;
     w[k] = rho * ((s_lo > 0.0 ? 1.0 : 0.0) + (s_up > 0.0 ? 1.0 : 0.0)) * idt * idt;
   }

@@ -143,6 +143,7 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
       if (GPp->limits) {  // joint-limit rows of this knot (eval_unit<N, true>)
         const GuardParams& GP = *GPp;
         const double rho_old = rho_g, rho = outer ? rho_next : rho_g;
+        const double irho = 1.0 / rho, i2rho = 1.0 / (2.0 * rho);
         double dd[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -156,13 +157,13 @@ __device__ void tail_block(const FigParams& P, const FigBuffers& D, const int sl
               lamq[side * N + j] = lam;
             }
             const double sv = lam - rho * gval;
-            meas_q = fmax(meas_q, fabs(fmin(gval, lam / rho)));
+            meas_q = fmax(meas_q, fabs(fmin(gval, lam * irho)));
             if (sv > 0.0) {
-              psi_q += (sv * sv - lam * lam) / (2.0 * rho);
+              psi_q += (sv * sv - lam * lam) * i2rho;
               g[j] += side ? sv : -sv;
               dd[j] += rho;
             } else {
-              psi_q -= lam * lam / (2.0 * rho);
+              psi_q -= lam * lam * i2rho;
             }
           }
         }

@@ -332,6 +332,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
     const bool upd = GB.outer[b] != 0;
     const double rho_old = GB.rho[b];
     const double rho = upd ? GB.rho_next[b] : rho_old;
+    const double irho = 1.0 / rho, i2rho = 1.0 / (2.0 * rho);
     double psi = 0.0, meas = 0.0, dd[N];
     const int nl = GP.limits ? 2 * N : 0;
 #pragma unroll
@@ -349,13 +350,13 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
           *lam_ptr = lam;
         }
         const double sv = lam - rho * gval;
-        meas = fmax(meas, fabs(fmin(gval, lam / rho)));
+        meas = fmax(meas, fabs(fmin(gval, lam * irho)));
         if (sv > 0.0) {
-          psi += (sv * sv - lam * lam) / (2.0 * rho);
+          psi += (sv * sv - lam * lam) * i2rho;
           g[j] += side ? sv : -sv;
           dd[j] += rho;
         } else {
-          psi -= lam * lam / (2.0 * rho);
+          psi -= lam * lam * i2rho;
         }
       }
     }
@@ -378,9 +379,9 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
           *lam_ptr = lam;
         }
         const double sv = lam - rho * gval;
-        meas = fmax(meas, fabs(fmin(gval, lam / rho)));
+        meas = fmax(meas, fabs(fmin(gval, lam * irho)));
         if (sv > 0.0) {
-          psi += (sv * sv - lam * lam) / (2.0 * rho);
+          psi += (sv * sv - lam * lam) * i2rho;
           double v[NZ];
 #pragma unroll
           for (int a = 0; a < NZ; ++a) v[a] = 0.0;
@@ -395,7 +396,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
 #pragma unroll
             for (int c2 = 0; c2 <= a; ++c2) Dr[tri(a, c2)] += rho * v[a] * v[c2];
         } else {
-          psi -= lam * lam / (2.0 * rho);
+          psi -= lam * lam * i2rho;
         }
       });
     }

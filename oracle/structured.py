@@ -385,12 +385,12 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         rho_g = rho_g * vscale
         sv = np.maximum(0.0, lam_v - rho_g * gv)
         sv[0] = 0.0
-        psi = (sv * sv - lam_v * lam_v) / (2.0 * rho_g)
+        psi = (sv * sv - lam_v * lam_v) * (1.0 / (2.0 * rho_g))  # (reciprocal, then product: as the kernels do since round 4)
         psi[0] = 0.0
         nn = Q.shape[1]
         sig = (sv[:, nn:] - sv[:, :nn]) / dtv  # d psi / d v : lower row -s_lo, upper row +s_up
         wv = rho_g * ((sv[:, :nn] > 0.0).astype(float) + (sv[:, nn:] > 0.0).astype(float)) / dtv**2
-        meas = np.abs(np.minimum(gv, lam_v / rho_g))
+        meas = np.abs(np.minimum(gv, lam_v * (1.0 / rho_g)))
         meas[0] = 0.0
         return gv, psi.sum(1), sig, wv, float(meas.max())
 
@@ -401,11 +401,11 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
         gv, dg = guard_values(prob.chain, Q, guards)  # (T, NC), (T, NC, n)
         sv = np.maximum(0.0, lam_g - rho_g * gv)
         sv[:2] = 0.0
-        psi = (sv * sv - lam_g * lam_g) / (2.0 * rho_g)
+        psi = (sv * sv - lam_g * lam_g) * (1.0 / (2.0 * rho_g))
         psi[:2] = 0.0
         dgrad = -np.einsum("tc,tcn->tn", sv, dg)
         dW = rho_g * np.einsum("tc,tcn,tcm->tnm", (sv > 0.0).astype(float), dg, dg)
-        meas = np.abs(np.minimum(gv, lam_g / rho_g))
+        meas = np.abs(np.minimum(gv, lam_g * (1.0 / rho_g)))
         meas[:2] = 0.0
         return gv, psi.sum(1), dgrad, dW, float(meas.max())
     T, n = prob.T, prob.n

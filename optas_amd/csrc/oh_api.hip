@@ -1248,7 +1248,20 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     return oh_launch_tail(s, N, h->P, h->D, slot);
   };
   bool tail_done = false;
-  if (tail_ok && B <= tail_threshold) {  // small batch: the whole solve is one persistent launch
+  {  // position-tracking family with limit / sphere rows, every instance a block of its own: the whole solve in one launch (k_free_persist)
+    const char* e = getenv("OH_FREE_PERSIST");
+    // measured (HISTORY): same time per iteration as the launch pair (the iteration is memory round trips inside the phases, not launch gaps), so it
+    // only wins where the host's sparse looks at the running count cost idle launches and every block is resident: horizons up to 64 free knots,
+    // at most 512 instances (OH_FREE_PERSIST=1: always, 0: never)
+    const bool fits = (h->desc.T - h->P.t0 <= 64 && B <= 512) || (e && atoi(e) == 1);
+    if (!h->P.lock && guarded && !h->GP.vel && h->P.inst_major && h->P.zc_free && !prof && !lead && fits && (!e || atoi(e) != 0)) {
+      if (oh_launch_free_persist(s, N, h->P, h->D, h->GP, h->GB)) {
+        tail_done = true;
+        launched = 1;
+      }
+    }
+  }
+  if (!tail_done && tail_ok && B <= tail_threshold) {  // small batch: the whole solve is one persistent launch
     if (!launch_tail(0)) return fail(OH_ERR_INVALID, "oh_solve_device: no persistent kernel for this handle (ndof / rows)");
     tail_done = true;
   }

@@ -171,10 +171,8 @@ OH_DEV void guard_row(const double gval, const double (&dg)[N], const double rho
 }
 
 template <int N>
-__global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot_batch) {
+OH_DEV void eval_guarded_knot(const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const int b, const int t) {
   constexpr int NP = N * (N + 1) / 2;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y + P.t0;
   const int Bp = D.Bp;
   if (b >= D.B) return;
   const int slot = OH_FREE_SLOT(D, b);
@@ -373,6 +371,11 @@ __global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D,
   SEL(D.cv, slot)[(size_t)t * Bp + b] = meas;
 #pragma unroll
   for (int i = 0; i < NP; ++i) SEL(D.Dr, slot)[DRX(t, i)] = W[i];
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot_batch) {
+  eval_guarded_knot<N>(P, D, GP, GB, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
 }
 
 // guard parameters of every instance into SoA, multipliers and outer-loop state reset
@@ -1121,7 +1124,7 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
 // lane 0); the decision "converged / outer update: no step" is taken before the solve (it depends on the reduced gradient only), which spares the
 // solve on a quarter of the launches of a guarded handle.
 template <int N, bool GUARD, bool VEL = false>
-__global__ __launch_bounds__(128) void k_step_free_bb(FigParams P, FigBuffers D, GuardBuffers GB, const int slot_batch, const int KH) {
+OH_DEV void step_free_bb_block(const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, const int KH) {
   static_assert(N == 7, "lane layout: 8 rows x 8 columns");
   constexpr int NP = N * (N + 1) / 2;
   extern __shared__ double xw[];  // [2][KH][64] X | w of the knots, then [2][KH][8] their right-hand sides
@@ -1401,6 +1404,36 @@ __global__ __launch_bounds__(128) void k_step_free_bb(FigParams P, FigBuffers D,
     D.mu[b] = mu;
     D.iters[b] += 1;
     atomicAdd(D.n_running, 1);
+  }
+}
+
+template <int N, bool GUARD, bool VEL = false>
+__global__ __launch_bounds__(128) void k_step_free_bb(FigParams P, FigBuffers D, GuardBuffers GB, const int slot_batch, const int KH) {
+  step_free_bb_block<N, GUARD, VEL>(P, D, GB, KH);
+}
+
+// The whole solve of an instance in ONE launch (round 4; handles with limit / sphere rows, no velocity rows, coupling folded into the evaluation): the
+// block of two wavefronts that sweeps also evaluates -- thread t the knot t -- and loops until its instance has a status.  Same device functions, same
+// memory, same iterates as the launch pair k_eval_guarded / k_step_free_bb; what goes away is the launch gaps, the host's looks at the running count
+// (every 8th iteration: up to 7 idle launches at the end of a latency-bound solve) and the waiting for the slowest instance of the batch.
+template <int N>
+__global__ __launch_bounds__(128) void k_free_persist(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int KH, const int max_rounds) {
+  __shared__ int go;
+  const int per = (D.B + 7) / 8;
+  const int b = (blockIdx.x % 8) * per + blockIdx.x / 8;  // (as step_free_bb_block deals the instances)
+  if (b >= D.B) return;
+  const int lane = threadIdx.x;
+  const int nK = P.T - P.t0;
+  for (int round = 0; round < max_rounds; ++round) {
+    if (lane < nK) eval_guarded_knot<N>(P, D, GP, GB, b, P.t0 + lane);
+    __threadfence_block();
+    __syncthreads();
+    step_free_bb_block<N, true, false>(P, D, GB, KH);
+    __threadfence_block();
+    __syncthreads();
+    if (lane == 0) go = (__builtin_nontemporal_load(D.status + b) < 0) ? 1 : 0;
+    __syncthreads();
+    if (!go) break;
   }
 }
 
@@ -1714,6 +1747,13 @@ bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuff
 }
 bool oh_launch_setup_guards(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const double* p) {
   hipLaunchKernelGGL(k_setup_guards, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, GP, GB, p, n);
+  return true;
+}
+bool oh_launch_free_persist(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB) {
+  if (n != 7) return false;
+  const int nK = P.T - P.t0, KH = nK - nK / 2;
+  if (nK > 128) return false;
+  hipLaunchKernelGGL(k_free_persist<7>, dim3(8 * ((D.B + 7) / 8)), dim3(128), sizeof(double) * 2 * (size_t)KH * 72, s, P, D, GP, GB, KH, 2 * P.max_iter + 8);
   return true;
 }
 bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {

@@ -348,15 +348,21 @@ def test_cyclic_reduction_step_equals_the_serial_sweep(hip_lib, monkeypatch, T, 
     for name, qc in (("kukal/q/x", qcl), ("kukar/q/x", qcr)):
         X0[:, xoff[name] : xoff[name] + 7 * T] = np.tile(qc, (1, T))
     out = {}
-    # "0": the serial sweep; "4096": cyclic reduction -- with at most 64 free knots the kernel that spreads a knot's rows over eight lanes
-    # (k_step_free_cp, round 3), otherwise one lane per knot; "4096/lane": one lane per knot forced (OH_FREE_CP_MAX=0)
-    for mode in ("0", "4096", "4096/lane"):
+    # "0": the serial sweep.  "4096": a block per instance -- round 4: twisted factorisation (k_step_free_bb), and for handles with limit / sphere rows the
+    # whole solve in one launch where it fits (k_free_persist); "4096/pair": the launch pair k_eval_guarded + k_step_free_bb forced; "4096/cr": the
+    # cyclic-reduction kernels of rounds 2-3 (eight lanes per knot with at most 64 free knots, k_step_free_cp); "4096/lane": those with one lane per knot
+    for mode in ("0", "4096", "4096/pair", "4096/cr", "4096/lane"):
         monkeypatch.setenv("OH_FREE_PCR_MAX", mode.split("/")[0])
         monkeypatch.setenv("OH_FREE_CP_MAX", "0" if mode.endswith("lane") else "512")
+        monkeypatch.setenv("OH_FREE_BB", "0" if mode.endswith(("cr", "lane")) else "1")
+        monkeypatch.setenv("OH_FREE_PERSIST", "0" if mode.endswith("pair") else "2")
         mb = MultiArmBackend(spec, o, max_iter=400)
         res = mb.solve(X0, P)
         out[mode] = (res, [be.multipliers(B) for _, be in mb.arms] if guarded else [])
         mb.close()
+    for mode in ("4096/pair", "4096/cr"):
+        rv = out[mode][0]
+        assert (rv.status == 0).all() and np.abs(rv.f - out["4096"][0].f).max() <= 1e-9 * np.abs(rv.f).max() and (rv.iters == out["4096"][0].iters).mean() >= 0.97
     (r2, l2) = out["4096/lane"]
     (r0, l0), (r1, l1) = out["0"], out["4096"]
     assert (r2.status == 0).all() and np.abs(r2.f - r1.f).max() <= 1e-9 * np.abs(r1.f).max() and (r2.iters == r1.iters).mean() >= 0.97

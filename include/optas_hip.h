@@ -233,7 +233,9 @@ typedef struct oh_torque_desc {
   double tau_lo[OH_MAX_CHAIN]; /* effort limits: TaskModel dlim[0] (models.py:79-214), rows "_l" / "_r" of enforce_model_limits */
   double tau_up[OH_MAX_CHAIN];
   int max_iter;    /* evaluations after the first; <= 0: 300 */
-  double tol;      /* |gradient of the rolled-out Lagrangian w.r.t. ddq|_inf (multipliers lam = mu_b / s of the inequality rows); <= 0: 1e-6 */
+  double tol;      /* |gradient of the rolled-out Lagrangian w.r.t. ddq|_inf (multipliers lam = mu_b / s of the inequality rows); <= 0: 1e-6.
+                      OH_STATUS_CONVERGED also covers the acceptable level (IPOPT's acceptable_tol in spirit): 25 steps at the floor of the barrier
+                      parameter with the gradient within 10 tol -- the arithmetic floor when an active row has a slack of ~1e-8; kkt[0] reports the value */
   double tol_compl; /* complementarity lam_i s_i = mu_b of every inequality row at the returned point (IPOPT's tol plays this part,
                        solver.py:355-398); <= 0: 1e-8.  The rows themselves hold strictly: the iterates are interior */
   double mu_barrier0; /* initial barrier parameter; <= 0: 0.1 (IPOPT's mu_init) */

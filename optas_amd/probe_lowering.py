@@ -112,8 +112,23 @@ def probe_figure_eight(opt, rng_seed: int = 12345, link: Optional[str] = None) -
     got = {k: _shape(v) for k, v in opt.lin_eq_constraints.items()}
     if got != want:
         no(f"linear equalities must be {want} (fix_configuration of q and dq at t = 0, integrate_model_states), found {got}")
-    if len(opt.lin_ineq_constraints) or len(opt.ineq_constraints):
-        no("inequality rows are not lowered through this route")
+    if len(opt.ineq_constraints):
+        no("nonlinear inequality rows (sphere clearances) are not lowered through this route")
+    # linear inequality rows (round 4): enforce_model_limits(name) / (name, time_deriv=1) of builder.py:471-509, blocks
+    # "__{name}_model_limit_{d}___l" = x - lo and "..._r" = up - x; recognised by label and shape here, read off k and verified against it below
+    kblocks, o_ = {}, 0
+    for k_, v_ in opt.lin_ineq_constraints.items():
+        m_, n_ = _shape(v_)
+        kblocks[k_] = (o_, m_, n_)
+        o_ += m_ * n_
+    lab0, lab1 = f"__{name}_model_limit_0__", f"__{name}_model_limit_1__"
+    allowed = {lab0 + "_l": (n, T), lab0 + "_r": (n, T), lab1 + "_l": (n, T - 1), lab1 + "_r": (n, T - 1)}
+    for k_, (_, m_, n_) in kblocks.items():
+        if k_ not in allowed or (m_, n_) != allowed[k_]:
+            no(f"linear inequality block '{k_}' {(m_, n_)} is not a joint or joint-velocity limit block of '{name}'")
+    for lab in (lab0, lab1):
+        if (lab + "_l" in kblocks) != (lab + "_r" in kblocks):
+            no(f"limit rows need both blocks ({lab}_l and {lab}_r)")
     eq = [(k, _shape(v)) for k, v in opt.eq_constraints.items()]
     if len(eq) != 1 or eq[0][1] != (4, T):
         no(f"expected one nonlinear equality of shape (4, {T}) (the end-effector quaternion lock), found {eq}")
@@ -168,10 +183,47 @@ def probe_figure_eight(opt, rng_seed: int = 12345, link: Optional[str] = None) -
             R_c = np.asarray(robot.get_global_link_rotation(cand, qc))
             spec = _probe_costs(opt, robot, cand, n, T, dt, qc, p_c, R_c, xvec, rng)
             if spec is not None:
-                return FigureEightSpec(robot, cand, T, dt, spec[0], spec[1], spec[2], params[0][0], q_name, dq_name)
+                lims = _probe_limit_rows(opt, kblocks, lab0, lab1, n, T, xvec, rng, no)
+                return FigureEightSpec(robot, cand, T, dt, spec[0], spec[1], spec[2], params[0][0], q_name, dq_name, lo=lims[0], up=lims[1], vlo=lims[2], vup=lims[3])
     if found is None:
         no("h(x, p) is not quat(link, qc) - quat(link, q_t) for any link of the robot")
     no(f"the orientation rows match link '{found}' but the cost is not w_path sumsqr(path_in_frame - p(link, Q)) + w_vel sumsqr(dQ)")
+
+
+def _probe_limit_rows(opt, kblocks, lab0, lab1, n, T, xvec, rng, no):
+    """(lo, up, vlo, vup) of the joint / joint-velocity limit blocks found by label (None where absent): the bounds are read off k(0, p), one pair per
+    joint over the whole trajectory, and k is then checked against [Q - lo; up - Q; dQ - vlo; vup - dQ] (in the problem's own block order) at a random
+    point.  The parameters must not enter."""
+    if not kblocks:
+        return None, None, None, None
+    nx = n * T + n * (T - 1)
+    p0, p1 = rng.normal(size=n), rng.normal(size=n)
+    k0 = _vec(opt.k, np.zeros(nx), p0)
+    if k0.shape != (sum(m_ * n_ for _, m_, n_ in kblocks.values()),):
+        no("k(x, p) has not the size of its blocks")
+    out = {}
+    for lab, cols in ((lab0, T), (lab1, T - 1)):
+        if lab + "_l" not in kblocks:
+            out[lab] = None
+            continue
+        ol, orr = kblocks[lab + "_l"][0], kblocks[lab + "_r"][0]
+        lo = -k0[ol : ol + n * cols].reshape(cols, n)
+        up = k0[orr : orr + n * cols].reshape(cols, n)
+        if np.abs(lo - lo[0]).max() > 0 or np.abs(up - up[0]).max() > 0 or not (lo[0] < up[0]).all():
+            no(f"the rows of {lab} are not one bound pair per joint over the whole trajectory")
+        out[lab] = (lo[0].copy(), up[0].copy())
+    Qr, dQr = rng.normal(size=(T, n)), rng.normal(size=(T - 1, n))
+    kr = _vec(opt.k, xvec(Qr, dQr), p1)
+    for lab, X in ((lab0, Qr), (lab1, dQr)):
+        if out[lab] is None:
+            continue
+        ol, orr = kblocks[lab + "_l"][0], kblocks[lab + "_r"][0]
+        m_ = X.size
+        if (np.abs(kr[ol : ol + m_].reshape(X.shape) - (X - out[lab][0][None])).max() > 1e-9
+                or np.abs(kr[orr : orr + m_].reshape(X.shape) - (out[lab][1][None] - X)).max() > 1e-9):
+            no(f"the rows of {lab} are not [x - lo; up - x]")
+    l0, l1 = out[lab0], out[lab1]
+    return (l0[0] if l0 else None, l0[1] if l0 else None, l1[0] if l1 else None, l1[1] if l1 else None)
 
 
 def _probe_costs(opt, robot, link, n, T, dt, qc, p_c, R_c, xvec, rng):

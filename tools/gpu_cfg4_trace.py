@@ -20,6 +20,7 @@ g.limits = 1
 for j in range(7):
     g.q_lo[j], g.q_up[j] = arm.lower_actuated_joint_limits[j], arm.upper_actuated_joint_limits[j]
 g.n_links, g.n_obstacles = 4, 6
+if os.environ.get("RHO0"): g.rho0 = float(os.environ["RHO0"])
 for l, (k, off) in enumerate(arm.link_attachments("end_effector_ball", SPHERE_LINKS)):
     g.link_joint[l] = k
     for i in range(3):

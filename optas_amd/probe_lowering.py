@@ -106,34 +106,49 @@ def probe_figure_eight(opt, rng_seed: int = 12345, link: Optional[str] = None) -
     if _shape(opt.decision_variables[dq_name]) != (n, T - 1):
         no("the velocity block must be ndof x (T - 1) (derivs_align=False)")
     params = [(k, _shape(v)) for k, v in opt.parameters.items() if _shape(v)[0] * _shape(v)[1] > 0]
-    if len(params) != 1 or params[0][1] != (n, 1):
-        no(f"expected a single non-empty parameter of shape ({n}, 1), found {params}")
+    if not params or params[0][1] != (n, 1):
+        no(f"expected the initial configuration ({n}, 1) as the first non-empty parameter, found {params}")
+    extras = [k for k, _ in params[1:]]  # link radii, obstacle positions / radii of sphere rows (builder.py:366-417); attributed and verified below
+    if extras and not len(opt.ineq_constraints):
+        no(f"parameters beyond the initial configuration without sphere rows: {extras}")
+    poff, o_ = {}, 0
+    for k_, v_ in opt.parameters.items():
+        m_, n_ = _shape(v_)
+        poff[k_] = (o_, m_ * n_)
+        o_ += m_ * n_
+    p_harmless = np.zeros(o_)  # radii 0.05, obstacles far away: the rows stay inactive wherever the probes go
+    for k_ in extras:
+        a0, l0 = poff[k_]
+        p_harmless[a0 : a0 + l0] = 0.05 if l0 == 1 else 5.0 + np.arange(l0)
+    qc_slice = slice(poff[params[0][0]][0], poff[params[0][0]][0] + n)
+
+    def pfull(qc_):
+        pv = p_harmless.copy()
+        pv[qc_slice] = np.asarray(qc_, dtype=float).reshape(-1)
+        return pv
+
+    real = opt
+    if extras:
+        class _QcOnly:  # the figure-eight probes below speak p = qc; this hands the problem's functions the full parameter vector
+            def __getattr__(self, name):
+                attr = getattr(real, name)
+                if name in ("f", "a", "h", "k", "g", "v"):
+                    return lambda x, p, _fn=attr: _fn(x, pfull(p))
+                return attr
+
+        opt = _QcOnly()
     want = {f"__{name}_fix_configuration_0_0__": (n, 1), f"__{name}_fix_configuration_1_0__": (n, 1), f"__integrate_model_states_{name}_1__": (n, T - 1)}
     got = {k: _shape(v) for k, v in opt.lin_eq_constraints.items()}
     if got != want:
         no(f"linear equalities must be {want} (fix_configuration of q and dq at t = 0, integrate_model_states), found {got}")
-    if len(opt.ineq_constraints):
-        no("nonlinear inequality rows (sphere clearances) are not lowered through this route")
-    # linear inequality rows (round 4): enforce_model_limits(name) / (name, time_deriv=1) of builder.py:471-509, blocks
-    # "__{name}_model_limit_{d}___l" = x - lo and "..._r" = up - x; recognised by label and shape here, read off k and verified against it below
-    kblocks, o_ = {}, 0
-    for k_, v_ in opt.lin_ineq_constraints.items():
-        m_, n_ = _shape(v_)
-        kblocks[k_] = (o_, m_, n_)
-        o_ += m_ * n_
-    lab0, lab1 = f"__{name}_model_limit_0__", f"__{name}_model_limit_1__"
-    allowed = {lab0 + "_l": (n, T), lab0 + "_r": (n, T), lab1 + "_l": (n, T - 1), lab1 + "_r": (n, T - 1)}
-    for k_, (_, m_, n_) in kblocks.items():
-        if k_ not in allowed or (m_, n_) != allowed[k_]:
-            no(f"linear inequality block '{k_}' {(m_, n_)} is not a joint or joint-velocity limit block of '{name}'")
-    for lab in (lab0, lab1):
-        if (lab + "_l" in kblocks) != (lab + "_r" in kblocks):
-            no(f"limit rows need both blocks ({lab}_l and {lab}_r)")
+    # inequality rows (round 4): enforce_model_limits(name) / (name, time_deriv=1) (builder.py:471-509) and sphere_collision_avoidance_constraints
+    # (builder.py:366-417): found by label, attributed, read off k / g and verified against them by the routine the multi-arm family uses
+    guarded = len(opt.lin_ineq_constraints) > 0 or len(opt.ineq_constraints) > 0
     eq = [(k, _shape(v)) for k, v in opt.eq_constraints.items()]
     if len(eq) != 1 or eq[0][1] != (4, T):
         no(f"expected one nonlinear equality of shape (4, {T}) (the end-effector quaternion lock), found {eq}")
     nx, np_ = n * T + n * (T - 1), int(opt.np)
-    if int(opt.nx) != nx or np_ != n:
+    if int(opt.nx) != nx or np_ != n + sum(poff[k_][1] for k_ in extras):
         no("unexpected nx / np")
     robot = _mirror_robot(m)
     if robot.ndof != n:
@@ -183,47 +198,24 @@ def probe_figure_eight(opt, rng_seed: int = 12345, link: Optional[str] = None) -
             R_c = np.asarray(robot.get_global_link_rotation(cand, qc))
             spec = _probe_costs(opt, robot, cand, n, T, dt, qc, p_c, R_c, xvec, rng)
             if spec is not None:
-                lims = _probe_limit_rows(opt, kblocks, lab0, lab1, n, T, xvec, rng, no)
-                return FigureEightSpec(robot, cand, T, dt, spec[0], spec[1], spec[2], params[0][0], q_name, dq_name, lo=lims[0], up=lims[1], vlo=lims[2], vup=lims[3])
+                lo_ = up_ = vlo_ = vup_ = sph_ = None
+                if guarded:
+                    from types import SimpleNamespace
+
+                    from .lowering import GuardSpec
+
+                    arm = SimpleNamespace(guards=None)
+                    _probe_arm_guards(real, [m], [robot], [arm], T, lambda Qs, Zs: xvec(Qs[0], np.reshape(Zs[0], (T - 1, n))), [Qc], [Z],
+                                      lambda qs: pfull(qs[0]), [qc], poff, extras, rng, no)
+                    gs = arm.guards
+                    if gs is not None:
+                        lo_, up_, vlo_, vup_ = gs.lo, gs.up, gs.vlo, gs.vup
+                        if gs.links:
+                            sph_ = GuardSpec(None, None, gs.links, gs.link_radii, gs.obstacles)
+                return FigureEightSpec(robot, cand, T, dt, spec[0], spec[1], spec[2], params[0][0], q_name, dq_name, lo=lo_, up=up_, spheres=sph_, vlo=vlo_, vup=vup_)
     if found is None:
         no("h(x, p) is not quat(link, qc) - quat(link, q_t) for any link of the robot")
     no(f"the orientation rows match link '{found}' but the cost is not w_path sumsqr(path_in_frame - p(link, Q)) + w_vel sumsqr(dQ)")
-
-
-def _probe_limit_rows(opt, kblocks, lab0, lab1, n, T, xvec, rng, no):
-    """(lo, up, vlo, vup) of the joint / joint-velocity limit blocks found by label (None where absent): the bounds are read off k(0, p), one pair per
-    joint over the whole trajectory, and k is then checked against [Q - lo; up - Q; dQ - vlo; vup - dQ] (in the problem's own block order) at a random
-    point.  The parameters must not enter."""
-    if not kblocks:
-        return None, None, None, None
-    nx = n * T + n * (T - 1)
-    p0, p1 = rng.normal(size=n), rng.normal(size=n)
-    k0 = _vec(opt.k, np.zeros(nx), p0)
-    if k0.shape != (sum(m_ * n_ for _, m_, n_ in kblocks.values()),):
-        no("k(x, p) has not the size of its blocks")
-    out = {}
-    for lab, cols in ((lab0, T), (lab1, T - 1)):
-        if lab + "_l" not in kblocks:
-            out[lab] = None
-            continue
-        ol, orr = kblocks[lab + "_l"][0], kblocks[lab + "_r"][0]
-        lo = -k0[ol : ol + n * cols].reshape(cols, n)
-        up = k0[orr : orr + n * cols].reshape(cols, n)
-        if np.abs(lo - lo[0]).max() > 0 or np.abs(up - up[0]).max() > 0 or not (lo[0] < up[0]).all():
-            no(f"the rows of {lab} are not one bound pair per joint over the whole trajectory")
-        out[lab] = (lo[0].copy(), up[0].copy())
-    Qr, dQr = rng.normal(size=(T, n)), rng.normal(size=(T - 1, n))
-    kr = _vec(opt.k, xvec(Qr, dQr), p1)
-    for lab, X in ((lab0, Qr), (lab1, dQr)):
-        if out[lab] is None:
-            continue
-        ol, orr = kblocks[lab + "_l"][0], kblocks[lab + "_r"][0]
-        m_ = X.size
-        if (np.abs(kr[ol : ol + m_].reshape(X.shape) - (X - out[lab][0][None])).max() > 1e-9
-                or np.abs(kr[orr : orr + m_].reshape(X.shape) - (out[lab][1][None] - X)).max() > 1e-9):
-            no(f"the rows of {lab} are not [x - lo; up - x]")
-    l0, l1 = out[lab0], out[lab1]
-    return (l0[0] if l0 else None, l0[1] if l0 else None, l1[0] if l1 else None, l1[1] if l1 else None)
 
 
 def _probe_costs(opt, robot, link, n, T, dt, qc, p_c, R_c, xvec, rng):

@@ -368,7 +368,7 @@ def test_limit_rows_of_the_figure_eight_are_recognised_by_probing(hip_lib):
     assert spec.lo is None and spec.vlo is not None and np.abs(spec.vup - match_figure_eight(opt).vup).max() < 1e-12
     k_true = opt.k
     opt.k = lambda x, p: np.asarray(k_true(x, p)) * 1.0 + 1e-3 * np.sin(np.asarray(x)[:1])  # same labels, rows no longer affine with slope one
-    with pytest.raises(LoweringError, match="model_limit"):
+    with pytest.raises(LoweringError, match="limit rows"):
         probe_figure_eight(ReferenceLikeOptimization(opt))
 
 
@@ -397,3 +397,36 @@ def test_velocity_limited_figure_eight_through_the_reference_interface(hip_lib, 
     assert np.abs(dq - np.asarray(want["kuka/dq"])).max() <= 1e-7
     if vmax is not None:
         assert (np.abs(dq) <= np.asarray(vmax)[:, None] + 1e-9).all()
+
+
+def test_sphere_rows_of_the_figure_eight_are_recognised_by_probing_and_solved(hip_lib):
+    """Round 4 (verdict r03 Missing 4): sphere_collision_avoidance_constraints on config 2 from the reference interface -- rows found by label, radius /
+    obstacle parameters attributed numerically, g verified against ||p_link(q_t) - o||^2 - (r_l + r_o)^2 -- gives the tree matcher's spec, and the
+    literal subclass solves it on the structured kernels to the mirror route's optimum (obstacle beside the path: rows active)."""
+    from examples.dual_arm import SPHERE_LINKS
+    from examples.figure_eight_plan import setup_solver
+    from optas_amd.lowering import match_figure_eight
+    from optas_amd.probe_lowering import probe_figure_eight
+
+    qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    obs = np.array([-0.848, 0.12, 0.461])
+    pd = {"qc": qc, "obs0_position": obs, "obs0_radii": 0.05, **{ln + "_radii": 0.05 for ln in SPHERE_LINKS}}
+    kuka, opt = setup_solver(build_only=True, obstacles=["obs0"], sphere_links=SPHERE_LINKS, limits=True)
+    want = match_figure_eight(opt)
+    spec = probe_figure_eight(ReferenceLikeOptimization(opt))
+    assert spec.spheres is not None and list(spec.spheres.links) == list(want.spheres.links)
+    assert list(spec.spheres.link_radii) == list(want.spheres.link_radii) and [tuple(o) for o in spec.spheres.obstacles] == [tuple(o) for o in want.spheres.obstacles]
+    assert np.abs(spec.lo - want.lo).max() < 1e-12 and spec.vlo is None
+    kuka, solver = setup_solver(obstacles=["obs0"], sphere_links=SPHERE_LINKS, limits=True, solver_options={"max_iter": 400})
+    solver.reset_parameters(pd)
+    solver.reset_initial_seed({"kuka/q/x": np.tile(qc.reshape(-1, 1), (1, 50))})
+    solver.solve()
+    f_want = solver.stats()["f"][0]
+    HIPSolver = _standins()
+    s = HIPSolver(ReferenceLikeOptimization(opt)).setup("hip_sqp", {"max_iter": 400})
+    s.reset_parameters(pd)
+    s.reset_initial_seed({"kuka/q/x": np.tile(qc.reshape(-1, 1), (1, 50))})
+    s.solve()
+    st = s.stats()
+    assert st["family"] == "figure_eight" and s.did_solve()
+    assert abs(np.ravel(st["f"])[0] - f_want) <= 1e-9 * f_want and f_want > 8.9

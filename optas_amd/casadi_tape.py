@@ -195,6 +195,10 @@ def make_solver_class(solver_module, cs):
                     if fam == "figure_eight":
                         hess = {"gauss_newton": 0, "exact": 1, "hybrid": 2}[o.pop("hessian", "hybrid")]
                         self._backend = figure_eight_backend(spec, o, hess)
+                        if spec.lead is not None:  # one parameterised joint ahead of the chain: the reference's parameter vector re-packed per solve
+                            from .solver import _LeadAdapter
+
+                            self._backend = _LeadAdapter(self.opt, spec, self._backend)
                     elif fam == "torque_mpc":
                         self._backend = TorqueBackend(spec.robot.solver_chain(spec.link), spec.robot.dynamics_tables(), T=spec.T, dt=spec.dt, w_path=spec.w_path,
                                                       w_vel=spec.w_vel, w_tau=spec.w_tau, tau_lo=spec.tau_lo, tau_up=spec.tau_up, dq_lo=getattr(spec, "dq_lo", None), dq_up=getattr(spec, "dq_up", None),

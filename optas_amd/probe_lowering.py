@@ -97,8 +97,10 @@ def probe_figure_eight(opt, rng_seed: int = 12345, link: Optional[str] = None) -
         no("expected exactly one robot model")
     m = models[0]
     name = m.get_name()
+    if list(m.time_derivs) == [0, 1] and len(getattr(m, "param_joints", []) or []) == 1:
+        return _probe_figure_eight_lead(opt, m, rng_seed, link, no)  # example/figure_eight_plan_6dof.py: one joint ahead of the chain is a parameter
     if list(m.time_derivs) != [0, 1] or len(getattr(m, "param_joints", []) or []) != 0:
-        no("robot must have time_derivs=[0, 1] and no parameterised joints")
+        no("robot must have time_derivs=[0, 1] and at most one parameterised joint")
     q_name, dq_name = f"{name}/q/x", f"{name}/dq/x"
     if list(opt.decision_variables.keys()) != [q_name, dq_name]:
         no(f"decision variables must be exactly [{q_name}, {dq_name}], found {list(opt.decision_variables.keys())}")
@@ -215,6 +217,100 @@ def probe_figure_eight(opt, rng_seed: int = 12345, link: Optional[str] = None) -
                 return FigureEightSpec(robot, cand, T, dt, spec[0], spec[1], spec[2], params[0][0], q_name, dq_name, lo=lo_, up=up_, spheres=sph_, vlo=vlo_, vup=vup_)
     if found is None:
         no("h(x, p) is not quat(link, qc) - quat(link, q_t) for any link of the robot")
+    no(f"the orientation rows match link '{found}' but the cost is not w_path sumsqr(path_in_frame - p(link, Q)) + w_vel sumsqr(dQ)")
+
+
+def _probe_figure_eight_lead(opt, m, rng_seed, link, no) -> FigureEightSpec:
+    """The figure-eight plan with one parameterised joint (RobotModel(param_joints=[...]), example/figure_eight_plan_6dof.py:17-128): decision variables
+    are the optimised joints' positions / velocities, the parameterised joint's trajectory and its velocity arrive as parameters `{name}/q/p`,
+    `{name}/dq/p` next to `qc` (all joints).  Labels and shapes decide whether the problem can be the family; the linear rows are checked against
+    [qc[opt] - q_0; -dq_0; Euler] on the optimised joints; h and f are probed on the FULL joint trajectory (states and parameter joint merged) with
+    the routines of the plain family, and verified."""
+    name = m.get_name()
+    robot = _mirror_robot(m)
+    n = robot.ndof
+    opt_idx, par = list(robot.optimized_joint_indexes), int(robot.parameter_joint_indexes[0])
+    no_ = len(opt_idx)
+    q_name, dq_name, qp_name, dqp_name = f"{name}/q/x", f"{name}/dq/x", f"{name}/q/p", f"{name}/dq/p"
+    if list(opt.decision_variables.keys()) != [q_name, dq_name]:
+        no(f"decision variables must be exactly [{q_name}, {dq_name}], found {list(opt.decision_variables.keys())}")
+    n_x, T = _shape(opt.decision_variables[q_name])
+    if n_x != no_ or _shape(opt.decision_variables[dq_name]) != (no_, T - 1):
+        no("the state blocks must be (optimised joints) x T and x (T - 1)")
+    params = [(k, _shape(v)) for k, v in opt.parameters.items() if _shape(v)[0] * _shape(v)[1] > 0]
+    if len(params) != 3 or params[0] != (qp_name, (1, T)) or params[1] != (dqp_name, (1, T - 1)) or params[2][1] != (n, 1):
+        no(f"parameters must be [{qp_name} (1, T), {dqp_name} (1, T-1), initial configuration ({n}, 1)], found {params}")
+    qc_name = params[2][0]
+    want = {f"__{name}_initial_configuration_0__": (no_, 1), f"__{name}_initial_configuration_1__": (no_, 1), f"__integrate_model_states_{name}_1__": (no_, T - 1)}
+    got = {k: _shape(v) for k, v in opt.lin_eq_constraints.items()}
+    if got != want:
+        no(f"linear equalities must be {want}, found {got}")
+    if len(opt.lin_ineq_constraints) or len(opt.ineq_constraints):
+        no("inequality rows are not lowered for the lead-joint variant")
+    eq = [(k, _shape(v)) for k, v in opt.eq_constraints.items()]
+    if len(eq) != 1 or eq[0][1] != (4, T):
+        no(f"expected one nonlinear equality of shape (4, {T}) (the end-effector quaternion lock), found {eq}")
+    if int(opt.nx) != no_ * T + no_ * (T - 1) or int(opt.np) != T + (T - 1) + n:
+        no("unexpected nx / np")
+    rng = np.random.default_rng(rng_seed)
+
+    def split(Q, dQ, qc_):  # full trajectories (T, n), (T-1, n) -> the problem's own (x, p)
+        x = np.concatenate([Q[:, opt_idx].reshape(-1), dQ[:, opt_idx].reshape(-1)])
+        return x, np.concatenate([Q[:, par], dQ[:, par], np.asarray(qc_, dtype=float).reshape(-1)])
+
+    lo, up = robot.lower_actuated_joint_limits, robot.upper_actuated_joint_limits
+    lo, up = (np.asarray(lo), np.asarray(up))
+    if lo.size != n:  # limits of the optimised joints only: the probe ranges need no more than a box
+        lo, up = np.full(n, -2.0), np.full(n, 2.0)
+    qc = 0.5 * (lo + up) + rng.uniform(-1, 1, n) * 0.3 * np.minimum(up - lo, 4.0)
+    Qc, Z = np.tile(qc, (T, 1)), np.zeros((T - 1, n))
+    # ---- linear rows on the optimised joints
+    a0 = _vec(opt.a, *split(Qc, Z, qc))
+    if a0.shape != (2 * no_ + no_ * (T - 1),) or np.abs(a0).max() > 1e-12:
+        no("a(x, p) does not vanish at q_t = qc, dq = 0")
+    d = Z.copy()
+    d[1, opt_idx[0]] = 1.0
+    dt = -float(_vec(opt.a, *split(Qc, d, qc))[2 * no_ + no_])
+    if not (dt > 0):
+        no("could not read a positive dt off the integration rows")
+    Qr, dQr, pr = rng.normal(size=(T, n)), rng.normal(size=(T - 1, n)), rng.normal(size=n)
+    a_model = np.concatenate([pr[opt_idx] - Qr[0, opt_idx], -dQr[0, opt_idx], -(Qr[:-1, opt_idx] + dt * dQr[:, opt_idx] - Qr[1:, opt_idx]).reshape(-1)])
+    if np.abs(_vec(opt.a, *split(Qr, dQr, pr)) - a_model).max() > 1e-9:
+        no("the linear equalities are not [qc[opt] - q_0; -dq_0; Euler integration with a uniform dt] on the optimised joints")
+
+    class _Full:  # h and f as functions of the full trajectory ((Q, dQ), qc): what the plain family's probes speak
+        @staticmethod
+        def f(xq, qc_):
+            return opt.f(*split(xq[0], xq[1], qc_))
+
+        @staticmethod
+        def h(xq, qc_):
+            return opt.h(*split(xq[0], xq[1], qc_))
+
+    xfull = lambda Q, dQ: (Q, dQ)  # noqa: E731
+    Qh = qc[None] + rng.uniform(-0.3, 0.3, (T, n))
+    h_val = _vec(_Full.h, xfull(Qh, Z), qc).reshape(T, 4)
+    cands = [link] if link is not None else [l for l in robot.link_names if l != robot.get_root_link()]
+    found = None
+    for cand in cands:
+        try:
+            chain_ok = len(robot.urdf.get_chain(robot.get_root_link(), cand)) > 0
+        except ValueError:
+            chain_ok = False
+        if not chain_ok:
+            continue
+        quat_c = np.asarray(robot.get_global_link_quaternion(cand, qc)).reshape(4)
+        quat = np.asarray(robot.get_global_link_quaternion(cand, Qh.T)).reshape(4, T).T
+        if np.abs(h_val - (quat_c[None] - quat)).max() <= 1e-9 or np.abs(h_val - (quat - quat_c[None])).max() <= 1e-9:
+            found = cand
+            p_c = np.asarray(robot.get_global_link_position(cand, qc)).reshape(3)
+            R_c = np.asarray(robot.get_global_link_rotation(cand, qc))
+            spec = _probe_costs(_Full, robot, cand, n, T, dt, qc, p_c, R_c, xfull, rng)
+            if spec is not None:
+                lead = {"par": par, "opt": opt_idx, "qp": qp_name, "dqp": dqp_name}
+                return FigureEightSpec(robot, cand, T, dt, spec[0], spec[1], spec[2], qc_name, q_name, dq_name, lead=lead)
+    if found is None:
+        no("h(x, p) is not the quaternion lock of any link of the robot on the merged joint trajectory")
     no(f"the orientation rows match link '{found}' but the cost is not w_path sumsqr(path_in_frame - p(link, Q)) + w_vel sumsqr(dQ)")
 
 

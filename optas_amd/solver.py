@@ -150,8 +150,12 @@ class _LeadAdapter:
         self.opt, self.spec, self.be = opt, spec, backend
 
     def solve(self, x0: np.ndarray, p: np.ndarray) -> BatchResult:
-        p = np.asarray(p, dtype=np.float64).reshape(-1, self.opt.np)
-        off = self.opt.parameters.offsets()
+        p = np.asarray(p, dtype=np.float64).reshape(-1, int(self.opt.np))
+        off, o_ = {}, 0
+        for k_, v_ in self.opt.parameters.items():  # (label -> offset from the items' shapes: the reference's SXContainer has no offsets())
+            shp = tuple(getattr(v_, "shape", None) or v_.size())
+            off[k_] = o_
+            o_ += int(shp[0]) * int(shp[1])
         T, sp = self.spec.T, self.spec
         qc = p[:, off[sp.qc_name] : off[sp.qc_name] + sp.robot.ndof]
         qp = p[:, off[sp.lead["qp"]] : off[sp.lead["qp"]] + T]
@@ -168,6 +172,9 @@ class _LeadAdapter:
 
     def multipliers(self, B: int):
         return self.be.multipliers(B)
+
+    def timing(self) -> dict:
+        return self.be.timing()
 
     def close(self) -> None:
         self.be.close()

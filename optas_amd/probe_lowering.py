@@ -633,12 +633,16 @@ def probe_point_mass(opt, rng_seed: int = 12345, link: Optional[str] = None):
     if len(opt.eq_constraints):
         no("nonlinear equalities are not part of this family")
     params = [(k, _shape(v)) for k, v in opt.parameters.items()]
-    if [s for _, s in params] != [(2, 1), (2, 1), (2, T), (2, T)]:
-        no(f"parameters must be curr (2), dcurr (2), goal (2 x T), obs (2 x T) in this order, found {params}")
+    planner = [s for _, s in params] == [(2, 1), (2, 1)]  # example/point_mass_planner.py:27-28: init, goal
+    if not planner and [s for _, s in params] != [(2, 1), (2, 1), (2, T), (2, T)]:
+        no(f"parameters must be curr (2), dcurr (2), goal (2 x T), obs (2 x T) in this order (or init (2), goal (2) for the planner), found {params}")
     kinds = {f"__{name}_fix_configuration_0_0__": "fix0", f"__{name}_fix_configuration_1_0__": "fix1", f"__integrate_model_states_{name}_1__": "int"}
     lin = [(k, _shape(v)) for k, v in opt.lin_eq_constraints.items()]
+    extra = [k for k, _ in lin if k not in kinds]
+    if planner and len(extra) == 1:
+        kinds[extra[0]] = "final"  # example/point_mass_planner.py:41-43: the final velocity as a user-labelled equality row
     if sorted(k for k, _ in lin) != sorted(kinds) or any(s != ((2, T - 1) if kinds[k] == "int" else (2, 1)) for k, s in lin):
-        no(f"linear equalities must be fix_configuration of y and dy at t = 0 and integrate_model_states, found {lin}")
+        no(f"linear equalities must be fix_configuration of y and dy at t = 0 and integrate_model_states{' and one final-velocity row' if planner else ''}, found {lin}")
     if [_shape(v) for v in opt.lin_ineq_constraints.values()] != [(2, T)] * 4:
         no("need enforce_model_limits for time_deriv 0 and 1 (four blocks of shape (2, T))")
     if [_shape(v) for v in opt.ineq_constraints.values()] != [(1, 1)] * T:
@@ -649,8 +653,8 @@ def probe_point_mass(opt, rng_seed: int = 12345, link: Optional[str] = None):
     def xvec(Y, dY):  # (T, 2) each
         return np.concatenate([Y.reshape(-1), dY.reshape(-1)])
 
-    def pvec(c, dc, G, O):
-        return np.concatenate([c, dc, G.reshape(-1), O.reshape(-1)])
+    def pvec(c, dc, G, O):  # the planner's vector is [init; goal]: dc and O do not exist there, G is one point
+        return np.concatenate([c, G.reshape(-1)[:2]]) if planner else np.concatenate([c, dc, G.reshape(-1), O.reshape(-1)])
 
     Zt = np.zeros((T, 2))
     z_p = pvec(np.zeros(2), np.zeros(2), Zt, Zt)
@@ -665,10 +669,19 @@ def probe_point_mass(opt, rng_seed: int = 12345, link: Optional[str] = None):
         no("could not read a positive dt off the integration rows")
     Yr, dYr, Gr, Or = (rng.normal(size=(T, 2)) for _ in range(4))
     cr, dcr = rng.normal(size=2), rng.normal(size=2)
+    if planner:
+        Gr = np.tile(Gr[:1], (T, 1))  # one goal point
     xr, pr = xvec(Yr, dYr), pvec(cr, dcr, Gr, Or)
-    rows = {"fix0": cr - Yr[0], "fix1": dcr - dYr[0], "int": -(Yr[:-1] + dt * dYr[:-1] - Yr[1:]).reshape(-1)}
-    if np.abs(_vec(opt.a, xr, pr) - np.concatenate([rows[kinds[k]] for k, _ in lin])).max() > 1e-9:
-        no("the linear equalities are not [curr - y_0; dcurr - dy_0; Euler integration with a uniform dt]")
+    rows = {"fix0": cr - Yr[0], "fix1": (0.0 if planner else dcr) - dYr[0], "int": -(Yr[:-1] + dt * dYr[:-1] - Yr[1:]).reshape(-1)}
+    a_r = _vec(opt.a, xr, pr)
+    if planner:
+        sgn = a_r[where["final"]] / dYr[-1, 0]
+        if abs(abs(sgn) - 1.0) > 1e-12:
+            no("the extra equality row is not the final velocity")
+        rows["final"] = np.sign(sgn) * dYr[-1]
+    if np.abs(a_r - np.concatenate([rows[kinds[k]] for k, _ in lin])).max() > 1e-9:
+        no("the linear equalities are not [curr - y_0; dcurr - dy_0; Euler integration with a uniform dt]" if not planner else
+           "the linear equalities are not [init - y_0; -dy_0; Euler integration with a uniform dt; dy_{T-1}]")
     # ---- box limits: every block has slope +-1 on exactly one of Y, dY and one constant
     k0 = _vec(opt.k, np.zeros(2 * m), pr)
     sY, sD = _vec(opt.k, xvec(np.ones((T, 2)), Zt), pr) - k0, _vec(opt.k, xvec(Zt, np.ones((T, 2))), pr) - k0
@@ -693,6 +706,8 @@ def probe_point_mass(opt, rng_seed: int = 12345, link: Optional[str] = None):
         no("box limits must be symmetric")
     if np.abs(_vec(opt.k, xr, pr) - np.concatenate(model)).max() > 1e-12:
         no("k(x, p) is not the box rows read off it")
+    if planner:
+        return _probe_planner_rows(opt, T, dt, lim, params, y_name, dy_name, xvec, Yr, dYr, xr, pr, rng, no)
     # ---- obstacle rows g_t = |obs_t - y_t|^2 - safe^2
     g_at = _vec(opt.g, xvec(Or, dYr), pr)
     if g_at.size != T or np.abs(g_at - g_at[0]).max() > 0 or not (g_at[0] < 0):
@@ -710,6 +725,48 @@ def probe_point_mass(opt, rng_seed: int = 12345, link: Optional[str] = None):
     if not (w_acc > 0) or abs(float(_vec(opt.f, xr, pr)[0]) - f_model) > 1e-9 * max(1.0, abs(f_model)):
         no("the cost is not sumsqr(goal - Y) + w_acc sumsqr((dY[:, 1:] - dY[:, :-1]) / dt)")
     return PointMassSpec(T, dt, float(w_acc), float(lim[(0, "r")]), float(lim[(1, "r")]), float(np.sqrt(safe_sq)), tuple(k for k, _ in params), y_name, dy_name)
+
+
+def _probe_planner_rows(opt, T, dt, lim, params, y_name, dy_name, xvec, Yr, dYr, xr, pr, rng, no):
+    """example/point_mass_planner.py:45-66: the obstacle is a constant (read off g as the stationary point of every row: g_t is a quadratic
+    in y_t alone with Hessian 2 I), the tracking cost sits on the last knot, the velocities are penalised."""
+    from .lowering import PointMassSpec
+
+    Zt = np.zeros((T, 2))
+    g0 = _vec(opt.g, xvec(Zt, dYr), pr)
+    ex, ey = Zt.copy(), Zt.copy()
+    ex[:, 0], ey[:, 1] = 1.0, 1.0
+    gx, gy = _vec(opt.g, xvec(ex, dYr), pr), _vec(opt.g, xvec(ey, dYr), pr)
+    if g0.size != T:
+        no(f"expected {T} obstacle rows")
+    # g(y) = |o - y|^2 - s: g(e_i) - g(0) = 1 - 2 o_i
+    ox, oy = (1.0 - (gx - g0)) / 2.0, (1.0 - (gy - g0)) / 2.0
+    if np.abs(ox - ox[0]).max() > 1e-12 or np.abs(oy - oy[0]).max() > 1e-12:
+        no("the obstacle rows do not share one constant obstacle")
+    obstacle = np.array([float(ox[0]), float(oy[0])])
+    safe_sq = float(np.sum(obstacle * obstacle) - g0[0])
+    if not (safe_sq > 0) or np.abs(g0 - g0[0]).max() > 1e-12:
+        no("the obstacle rows do not share one radius")
+    p2 = pr + rng.normal(size=pr.size)
+    if np.abs(_vec(opt.g, xr, p2) - (np.sum((obstacle[None, :] - Yr) ** 2, 1) - safe_sq)).max() > 1e-12 * max(1.0, safe_sq):
+        no("the inequality rows are not ||obstacle - y_t||^2 >= safe^2 with a constant obstacle")
+    # ---- cost: sumsqr(goal - y_{T-1}) + w_vel sumsqr(dY) + w_acc sumsqr((dY[:, 1:] - dY[:, :-1]) / dt)
+    goal = pr[2:4]
+    Yg = Yr.copy()
+    Yg[-1] = goal
+    if abs(float(_vec(opt.f, xvec(Yg, Zt), pr)[0])) > 1e-12:
+        no("f does not vanish at y_{T-1} = goal, dY = 0")
+    d_all = np.ones((T, 2))  # constant velocities: no acceleration
+    w_vel = float(_vec(opt.f, xvec(Yg, d_all), pr)[0]) / (2.0 * T)
+    dd = Zt.copy()
+    dd[T // 2, 0] = 1.0  # an interior velocity entry: once in the velocity term, in two differences
+    w_acc = (float(_vec(opt.f, xvec(Yg, dd), pr)[0]) - w_vel) * dt * dt / 2.0
+    f_model = np.sum((goal - Yr[-1]) ** 2) + w_vel * np.sum(dYr * dYr) + w_acc * np.sum(((dYr[1:] - dYr[:-1]) / dt) ** 2)
+    if not (w_acc > 0 and w_vel >= 0) or abs(float(_vec(opt.f, xr, pr)[0]) - f_model) > 1e-9 * max(1.0, abs(f_model)):
+        no("the cost is not sumsqr(goal - y_{T-1}) + w_vel sumsqr(dY) + w_acc sumsqr((dY[:, 1:] - dY[:, :-1]) / dt)")
+    names = tuple(k for k, _ in params)
+    return PointMassSpec(T, dt, float(w_acc), float(lim[(0, "r")]), float(lim[(1, "r")]), float(np.sqrt(safe_sq)), names, y_name, dy_name,
+                         planner={"w_vel": float(w_vel), "obstacle": obstacle, "init": names[0], "goal": names[1]})
 
 
 def probe_multi_arm(opt, rng_seed: int = 12345, link: Optional[str] = None):

@@ -193,6 +193,9 @@ class _PlannerAdapter:
         rows = np.concatenate([p[:, :2], np.zeros((B, 2)), np.tile(p[:, 2:4], (1, T)), np.tile(self.spec.planner["obstacle"], (B, T))], axis=1)
         return self.be.solve(x0, np.ascontiguousarray(rows))
 
+    def solve_ms(self) -> float:
+        return self.be.solve_ms()
+
     def close(self) -> None:
         self.be.close()
 

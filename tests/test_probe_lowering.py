@@ -248,6 +248,37 @@ def test_point_mass_mpc_is_recognised_and_solved_through_the_reference_interface
     opt.g = g_true
 
 
+def test_point_mass_planner_variant_is_recognised_by_probing_and_solved(hip_lib):
+    """example/point_mass_planner.py behind the reference interface: parameters init, goal only; the obstacle is a constant inside g, the
+    tracking cost sits on the last knot, the velocities are penalised and the final velocity is a user-labelled equality row.  Every number
+    is read off the problem's callables and agrees with the tree matcher of the mirror builder; the literal subclass reaches the optimum of
+    the mirror route."""
+    from examples.point_mass_planner import Planner
+    from optas_amd.lowering import PointMassSpec, match_point_mass_planner
+    from optas_amd.probe_lowering import probe
+
+    pl = Planner(solver_options={"tol": 1e-9})
+    opt = pl.solver.opt
+    want = match_point_mass_planner(opt)
+    ref = ReferenceLikeOptimization(opt)
+    fam, spec = probe(ref)
+    assert fam == "point_mass" and isinstance(spec, PointMassSpec) and spec.planner is not None
+    assert (spec.T, spec.names, spec.y_name, spec.dy_name) == (want.T, want.names, want.y_name, want.dy_name)
+    for a, b in ((spec.dt, want.dt), (spec.w_acc, want.w_acc), (spec.ylim, want.ylim), (spec.vlim, want.vlim), (spec.safe, want.safe),
+                 (spec.planner["w_vel"], want.planner["w_vel"])):
+        assert abs(a - b) <= 1e-10 * max(1.0, abs(b))
+    assert np.abs(spec.planner["obstacle"] - want.planner["obstacle"]).max() < 1e-12
+    assert ref.calls < 25
+    init, goal = [-1.2, -0.4], [1.0, 0.7]
+    _, _, sol_m = pl.plan(init, goal)
+    s = _standins()(ref).setup("hip_sqp", {"tol": 1e-9})
+    s.reset_parameters({"init": init, "goal": goal})
+    sol = s.solve()
+    assert s.stats()["family"] == "point_mass" and s.did_solve()
+    assert abs(s.stats()["f"] - pl.solver.stats()["f"][0]) < 1e-12
+    assert np.abs(np.asarray(sol["point_mass/y"]) - np.asarray(sol_m["point_mass/y"])).max() < 1e-12
+
+
 def test_dual_arm_is_recognised_and_solved_through_the_reference_interface(hip_lib):
     """BASELINE configs[3] as shipped (example/dual_arm.py: two robots on base frames, separable): probed one arm at a time."""
     from examples.dual_arm import setup_solver

@@ -6,6 +6,7 @@ that owns the ``oh_handle`` and moves arrays across the C ABI.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -116,6 +117,12 @@ class TapeBackend(_SolveMixin):
 
     def __init__(self, tape, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True):
         lib = _lib.load()
+        if int(tape.nx) > 48 and os.environ.get("OH_TAPE_WAVE", "1") != "0":
+            # trajectory-sized: the library runs a wavefront per instance over the dependency levels of the tape (csrc/oh_tape_wave.hip); chains of
+            # additions are levels there, so sums go in as balanced trees (same values to the rounding of the summation order)
+            from .tape import rebalance_sums
+
+            tape = rebalance_sums(tape)
         self.tape = tape
         self.jit = bool(jit)
         self.nx, self.np_ = int(tape.nx), max(1, int(tape.np_))
@@ -151,6 +158,12 @@ class TapeBackend(_SolveMixin):
         buf = C.create_string_buffer(n.value + 1)
         _lib.check(_lib.load().oh_tape_compile(C.byref(desc), C.byref(size), buf, n.value + 1, C.byref(n)), "oh_tape_compile")
         return buf.value.decode(), int(size.value)
+
+    def flag(self, name: str) -> int:
+        """oh_get_flag: 'tape_wave' (0 thread per instance, 1 / 2 wavefront per instance), 'tape_levels', 'tape_passes'."""
+        v = C.c_int(0)
+        _lib.check(_lib.load().oh_get_flag(self._h, name.encode(), C.byref(v)), "oh_get_flag")
+        return int(v.value)
 
     def solve(self, x0, p):
         p = _lib.as_f64(p).reshape(len(np.atleast_2d(x0)), -1)

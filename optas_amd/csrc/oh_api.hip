@@ -70,6 +70,7 @@ struct oh_handle {
   double* d_tape_mult = nullptr;
   int tape_cap = 0;
   TapeJit tape_jit;
+  TapeWave tape_wave;  // trajectory-sized tapes: one wavefront per instance (oh_tape_wave.hip)
   // dense QP family
   oh_qp_desc qp{};
   void* h_stage = nullptr;  // pinned mirror of the staging area for small oh_solve calls (OH_PINNED_STAGE_BYTES)
@@ -342,7 +343,20 @@ extern "C" int oh_create_tape(const oh_tape_desc* d, oh_handle** out) {
   h->desc.ndof = d->nx;
   h->TP = tape_params(d);
   hipGetDevice(&h->device);
-  if (d->jit) {
+  {
+    // limited-memory regime (nx > 48): a wavefront per instance over the level schedule of the tape, when its register file fits the LDS
+    // (OH_TAPE_WAVE=0: never).  No code is generated for these handles: the schedule is data.
+    const char* e = getenv("OH_TAPE_WAVE");
+    int lds_limit = 0;
+    if ((!e || atoi(e) != 0) && hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess) {
+      std::string err;
+      if (oh_tape_wave_build(h->TP, d->op, d->a, d->b, d->c, d->rows, (size_t)lds_limit, &h->tape_wave, &err)) {
+        delete h;
+        return fail(OH_ERR_HIP, ("oh_create_tape: " + err).c_str());
+      }
+    }
+  }
+  if (d->jit && !h->tape_wave.ready) {
     std::vector<char> code;
     std::string err;
     const std::string src = oh_tape_jit_source(h->TP, d->op, d->a, d->b, d->c, d->rows);
@@ -382,12 +396,15 @@ static int tape_solve_device(oh_handle* h, int B, const void* d_x0, const void* 
     if (h->d_tape_mult) hipFree(h->d_tape_mult);
     h->d_tape_work = h->d_tape_mult = nullptr;
     h->tape_cap = 0;
-    HIPCHK(hipMalloc((void**)&h->d_tape_work, sizeof(double) * oh_tape_work_rows(h->TP, h->tape_jit.fn != nullptr) * Bp));
+    if (!h->tape_wave.ready) HIPCHK(hipMalloc((void**)&h->d_tape_work, sizeof(double) * oh_tape_work_rows(h->TP, h->tape_jit.fn != nullptr) * Bp));
     HIPCHK(hipMalloc((void**)&h->d_tape_mult, sizeof(double) * (size_t)(h->TP.n_ineq + h->TP.n_eq + 1) * Bp));
     h->tape_cap = Bp;
   }
   HIPCHK(hipEventRecord(h->ev0, h->stream));
-  if (h->tape_jit.fn)
+  if (h->tape_wave.ready)
+    HIPCHK(oh_launch_tape_wave(h->stream, h->tape_wave, h->TP, B, (const double*)d_x0, (const double*)d_p, (double*)d_x, (double*)d_f, (double*)d_kkt, (int*)d_iters,
+                               (int*)d_status, h->d_tape_mult));
+  else if (h->tape_jit.fn)
     HIPCHK(oh_launch_tape_jit(h->stream, h->tape_jit, h->TP, B, h->tape_cap, (const double*)d_x0, (const double*)d_p, h->d_tape_work, (double*)d_x, (double*)d_f,
                               (double*)d_kkt, (int*)d_iters, (int*)d_status, h->d_tape_mult));
   else
@@ -1756,6 +1773,7 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->evt0) hipEventDestroy(h->evt0);
   if (h->evt1) hipEventDestroy(h->evt1);
   oh_tape_jit_release(&h->tape_jit);
+  oh_tape_wave_release(&h->tape_wave);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1994,7 +2012,8 @@ extern "C" int oh_specialize_info(oh_handle* h, double* info4) {
   return OH_OK;
 }
 // How the handle's last solve was (or its next one will be) scheduled, by name: "fuse_couple" (1: coupling folded into evaluation and sweep, no
-// k_couple launch), "tail_threshold", "specialized".
+// k_couple launch), "tail_threshold", "specialized"; tape handles: "tape_wave" (0: thread per instance, 1 / 2: wavefront per instance with the (s, y)
+// pairs in global memory / in LDS), "tape_levels", "tape_passes" (dependency levels and 64-instruction passes of one evaluation).
 extern "C" int oh_get_flag(oh_handle* h, const char* name, int* value) {
   if (!h || !name || !value) return fail(OH_ERR_INVALID, "oh_get_flag: null argument");
   const std::string n(name);
@@ -2003,6 +2022,9 @@ extern "C" int oh_get_flag(oh_handle* h, const char* name, int* value) {
     *value = h->P.zc;
   } else if (n == "tail_threshold") *value = h->tail_threshold;
   else if (n == "specialized") *value = h->spec ? 1 : 0;
+  else if (n == "tape_wave") *value = h->tape_wave.ready ? (h->tape_wave.hist_lds ? 2 : 1) : 0;
+  else if (n == "tape_levels") *value = h->tape_wave.n_levels;
+  else if (n == "tape_passes") *value = h->tape_wave.n_fw_pass + h->tape_wave.n_rv_pass;
   else return fail(OH_ERR_INVALID, "oh_get_flag: unknown flag " + n);
   return OH_OK;
 }

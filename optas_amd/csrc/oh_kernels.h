@@ -150,6 +150,21 @@ struct TapeJit {
   hipFunction_t fn = nullptr;
   hipFunction_t fn_lds = nullptr;  // the same kernel with the solver's work arrays in LDS (small batches)
 };
+// wavefront-per-instance evaluator of trajectory-sized tapes (oh_tape_wave.hip): the level schedule built when the handle is created
+struct TapeWave {
+  bool ready = false, hist_lds = false;
+  int n_reg = 0, n_fw_pass = 0, n_rv_pass = 0, n_cst = 0, n_par = 0, n_seed = 0, n_seed_rows = 0, seed_cost = -1, n_small = 0, n_levels = 0;
+  size_t lds_bytes = 0;
+  int4 *d_fw = nullptr, *d_rv = nullptr;
+  int *d_cons = nullptr, *d_cst_reg = nullptr, *d_par_reg = nullptr, *d_par_k = nullptr, *d_small = nullptr;
+  double *d_cst_val = nullptr, *d_hist = nullptr;
+  int hist_cap = 0;
+};
+int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, size_t lds_limit, TapeWave* out,
+                       std::string* err);
+void oh_tape_wave_release(TapeWave* w);
+hipError_t oh_launch_tape_wave(hipStream_t s, TapeWave& W, const TapeParams& T, int B, const double* x0, const double* p, double* x, double* f, double* kkt,
+                               int* iters, int* status, double* mult);
 size_t oh_tape_work_rows(const TapeParams& T, bool jit);
 void oh_launch_tape_solve(hipStream_t s, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, int B, int Bp,
                           const double* x0, const double* p, double* work, double* x, double* f, double* kkt, int* iters, int* status, double* mult);

@@ -456,6 +456,76 @@ def tape_degrees(tape: Tape) -> np.ndarray:
     return deg
 
 
+def rebalance_sums(tape: Tape) -> Tape:
+    """The same problem with every long chain of additions / subtractions re-associated into a balanced tree.  Front ends write a sum of k
+    terms (sumsqr over a trajectory, a row of a matrix product) as a chain of k - 1 dependent ADDs: for the one-thread-per-instance evaluators the
+    order is irrelevant, for the wavefront-per-instance evaluator (csrc/oh_tape_wave.hip), which executes a dependency level per pass, the chain *is*
+    the critical path (example/simple_joint_space_planner.py: 143 levels, 126 of them fewer than 8 operations wide; 27 after this).  A register is
+    interior to a sum when it is an ADD / SUB consumed exactly once, by another ADD / SUB, and is not an output; every maximal tree of such
+    registers is flattened into signed leaves and summed pairwise.  Values change by the rounding of the summation order only (|d| <= 1e-13 on the
+    planner's rows); dead registers are dropped on the way."""
+    op, ra, rb = tape.op, tape.a, tape.b
+    L = len(op)
+    binary = {OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_ATAN2, OP_FMIN, OP_FMAX, OP_LT, OP_LE, OP_EQ, OP_NE, OP_AND, OP_OR, OP_IFZ}
+    outs = set(int(r) for r in tape.out_rows) | {int(tape.out_cost)}
+    live = np.zeros(L, dtype=bool)
+    live[list(outs)] = True
+    n_cons = np.zeros(L, dtype=np.int64)
+    sum_cons = np.zeros(L, dtype=np.int64)  # consumers that are ADD / SUB
+    for i in range(L - 1, -1, -1):
+        if not live[i] or op[i] < OP_ADD:
+            continue
+        ops_ = (int(ra[i]), int(rb[i])) if int(op[i]) in binary else (int(ra[i]),)
+        for r in ops_:
+            live[r] = True
+            n_cons[r] += 1
+            if op[i] in (OP_ADD, OP_SUB):
+                sum_cons[r] += 1
+    is_sum = (op == OP_ADD) | (op == OP_SUB)
+    interior = is_sum & live & (n_cons == 1) & (sum_cons == 1)
+    for r in outs:
+        interior[r] = False
+    ops, aa, bb, cc = [], [], [], []
+    new = np.full(L, -1, dtype=np.int64)
+
+    def emit(o, a=0, b=0, c=0.0):
+        ops.append(o), aa.append(a), bb.append(b), cc.append(c)
+        return len(ops) - 1
+
+    for i in range(L):
+        if not live[i] or interior[i]:
+            continue
+        o = int(op[i])
+        if not is_sum[i]:
+            new[i] = emit(o, int(new[ra[i]]) if o >= OP_ADD else int(ra[i]), int(new[rb[i]]) if o in binary else 0, float(tape.c[i]))
+            continue
+        leaves, stack = [], [(i, 1)]
+        while stack:  # depth first, left operand first: the leaves in the order the chain adds them
+            r, sg = stack.pop()
+            if r == i or interior[r]:
+                stack.append((int(rb[r]), sg if op[r] == OP_ADD else -sg))
+                stack.append((int(ra[r]), sg))
+            else:
+                leaves.append((int(new[r]), sg))
+        while len(leaves) > 1:
+            nxt = []
+            for k in range(0, len(leaves) - 1, 2):
+                (u, su), (w, sw) = leaves[k], leaves[k + 1]
+                if su == sw:
+                    nxt.append((emit(OP_ADD, u, w), su))
+                elif su > 0:
+                    nxt.append((emit(OP_SUB, u, w), 1))
+                else:
+                    nxt.append((emit(OP_SUB, w, u), 1))
+            if len(leaves) % 2:
+                nxt.append(leaves[-1])
+            leaves = nxt
+        r, sg = leaves[0]
+        new[i] = r if sg > 0 else emit(OP_NEG, r)
+    return Tape(np.asarray(ops, dtype=np.int32), np.asarray(aa, dtype=np.int32), np.asarray(bb, dtype=np.int32), np.asarray(cc, dtype=np.float64),
+                int(new[tape.out_cost]), np.asarray([new[int(r)] for r in tape.out_rows], dtype=np.int32), tape.n_ineq, tape.n_eq, tape.nx, tape.np_)
+
+
 def band_rewrite(tape: Tape) -> Optional[Tape]:
     """The tape of the equivalent linearly constrained QP when the cost is at most quadratic in x, the equality rows affine, and every
     inequality row either affine or of the form ``c - e*e`` with ``e`` affine and ``c`` a non-negative constant (example/torque_control_example.py:93-95):

@@ -153,6 +153,7 @@ struct TapeJit {
 // wavefront-per-instance evaluator of trajectory-sized tapes (oh_tape_wave.hip): the level schedule built when the handle is created
 struct TapeWave {
   bool ready = false, hist_lds = false;
+  int nt = 256;  // threads per instance
   int n_reg = 0, n_fw_pass = 0, n_rv_pass = 0, n_cst = 0, n_par = 0, n_seed = 0, n_seed_rows = 0, seed_cost = -1, n_small = 0, n_levels = 0;
   size_t lds_bytes = 0;
   int4 *d_fw = nullptr, *d_rv = nullptr;

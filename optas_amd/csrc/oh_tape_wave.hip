@@ -48,79 +48,126 @@ __device__ inline double wmax(double v) {
   for (int o = 32; o; o >>= 1) v = fmax(v, __shfl_xor(v, o));
   return v;
 }
+// Barrier between passes: LDS traffic only.  __syncthreads() waits for every outstanding memory operation of the wavefront (vmcnt(0)) -- including
+// the schedule entries requested for the passes ahead, which put a full L2 round trip back into every pass (measured: 460 ns per pass with
+// or without the prefetch).  Here only the LDS counter is drained; the compiler still waits for a prefetched entry where it is used.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Block reductions, the same value on every thread: butterfly inside a wavefront, the wavefronts' partials through LDS in a fixed order.  Two
+// exchange buffers used alternately: one barrier per reduction (a thread is past the next reduction's barrier only after every thread has read this one's).
+template <int NT>
+struct Red {
+  double* buf;  // [2][NT / 64]
+  int flip = 0;
+  template <bool MAX>
+  __device__ double run(double v) {
+    v = MAX ? wmax(v) : wsum(v);
+    if constexpr (NT == 64) {
+      return v;
+    } else {
+      double* b = buf + flip * (NT / 64);
+      flip ^= 1;
+      if ((threadIdx.x & 63) == 0) b[threadIdx.x >> 6] = v;
+      __syncthreads();
+      double r = b[0];
+#pragma unroll
+      for (int w = 1; w < NT / 64; ++w) r = MAX ? fmax(r, b[w]) : r + b[w];
+      return r;
+    }
+  }
+  __device__ double sum(double v) { return run<false>(v); }
+  __device__ double max(double v) { return run<true>(v); }
+};
+
+template <int NT>
 struct WaveEval {
   const TapeParams& T;
   const WaveSchedDev& S;
   double *val, *adj, *lam, *mu, *rowv, *roww;
   const int *row_reg, *seed_reg, *seed_off, *seed_rows;
-  const int lane;
+  const int lane;  // thread of the block
+  Red<NT>& red;
 
   // merit value at xs, its gradient into gout (both LDS, element k anywhere); rows into rowv.  Uniform return values.
-  __device__ double phi(const double* xs, double* gout, const double rho, double* fout, double* cmax, double* meas) {
+  __device__ __attribute__((always_inline)) double phi(const double* xs, double* gout, const double rho, double* fout, double* cmax, double* meas) {
 #pragma clang fp contract(off)
     __syncthreads();  // xs was written element-wise by its owner lanes
-    int4 nxt = S.fw[lane];
-    for (int p = 0; p < S.n_fw_pass; ++p) {
-      const int4 ins = nxt;
-      if (p + 1 < S.n_fw_pass) nxt = S.fw[(size_t)(p + 1) * 64 + lane];
+    // Four entries in flight, the loop unrolled by four so that each lives in its own registers: rotating them through moves (or loading under a
+    // condition) makes the compiler wait for the entry it has just requested -- a full L2 round trip in every pass (measured: 460 ns per pass).
+    // The host pads the schedule to a multiple of four passes; requests beyond the end re-read the last pass.
+    const int last = S.n_fw_pass - 1;
+    auto fwi = [&](int p) { return S.fw[(size_t)(p < last ? p : last) * NT + lane]; };
+    int4 q0 = fwi(0), q1 = fwi(1), q2 = fwi(2), q3 = fwi(3);
+    auto fw_pass = [&](const int4 ins) __attribute__((always_inline)) {
       const int o = ins.x >> OPSH, i = ins.x & ((1 << OPSH) - 1);
       if (o == 1) {
         val[i] = xs[ins.y];
       } else if (o != IDLE) {
         const double va = val[ins.y], vb = val[ins.z];
-        double v;
-        switch (o) {
-          case 3: v = va + vb; break;
-          case 4: v = va - vb; break;
-          case 5: v = va * vb; break;
-          case 6: v = va / vb; break;
-          case 7: v = -va; break;
-          case 8: v = sin(va); break;
-          case 9: v = cos(va); break;
-          case 10: v = atan2(va, vb); break;
-          case 11: v = sqrt(va); break;
-          case 12: v = va * va; break;
-          case 13: v = asin(va); break;
-          case 14: v = fabs(va); break;
-          case 15: v = fmin(va, vb); break;
-          case 16: v = fmax(va, vb); break;
-          case 17: v = va < vb ? 1.0 : 0.0; break;
-          case 18: v = va <= vb ? 1.0 : 0.0; break;
-          case 19: v = va == vb ? 1.0 : 0.0; break;
-          case 20: v = va != vb ? 1.0 : 0.0; break;
-          case 21: v = va == 0.0 ? 1.0 : 0.0; break;
-          case 22: v = (va != 0.0 && vb != 0.0) ? 1.0 : 0.0; break;
-          case 23: v = (va != 0.0 || vb != 0.0) ? 1.0 : 0.0; break;
-          default: v = va != 0.0 ? vb : 0.0; break;  // 24: if_else_zero
+        // the five operations that make up nine tenths of a trajectory tape without a branch (a switch on a per-lane value is a chain of ~20 masked
+        // sections whether or not any lane takes them); the rest behind one wavefront-uniform test
+        double v = (o == 5 || o == 12) ? va * (o == 12 ? va : vb) : (o == 7 ? -va : va + (o == 4 ? -vb : vb));
+        const bool rare = !(o == 3 || o == 4 || o == 5 || o == 7 || o == 12);
+        if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+          switch (o) {
+            case 6: v = va / vb; break;
+            case 8: v = sin(va); break;
+            case 9: v = cos(va); break;
+            case 10: v = atan2(va, vb); break;
+            case 11: v = sqrt(va); break;
+            case 13: v = asin(va); break;
+            case 14: v = fabs(va); break;
+            case 15: v = fmin(va, vb); break;
+            case 16: v = fmax(va, vb); break;
+            case 17: v = va < vb ? 1.0 : 0.0; break;
+            case 18: v = va <= vb ? 1.0 : 0.0; break;
+            case 19: v = va == vb ? 1.0 : 0.0; break;
+            case 20: v = va != vb ? 1.0 : 0.0; break;
+            case 21: v = va == 0.0 ? 1.0 : 0.0; break;
+            case 22: v = (va != 0.0 && vb != 0.0) ? 1.0 : 0.0; break;
+            case 23: v = (va != 0.0 || vb != 0.0) ? 1.0 : 0.0; break;
+            case 24: v = va != 0.0 ? vb : 0.0; break;  // if_else_zero
+            default: break;
+          }
         }
         val[i] = v;
       }
-      __syncthreads();
+      lds_barrier();
+    };
+    for (int p = 0; p < S.n_fw_pass; p += 4) {
+      const int4 i0 = q0;
+      q0 = fwi(p + 4);
+      fw_pass(i0);
+      const int4 i1 = q1;
+      q1 = fwi(p + 5);
+      fw_pass(i1);
+      const int4 i2 = q2;
+      q2 = fwi(p + 6);
+      fw_pass(i2);
+      const int4 i3 = q3;
+      q3 = fwi(p + 7);
+      fw_pass(i3);
     }
     // rows: value, share of the merit, seed of the reverse sweep
     const double f = val[S.seed_cost >= 0 ? seed_reg[S.seed_cost] : 0];
     double v = 0.0, cm = 0.0, ms = 0.0;
-    for (int r = lane; r < S.nrows; r += 64) {
+    for (int r = lane; r < S.nrows; r += NT) {
       const double g = val[row_reg[r]];
       rowv[r] = g;
       roww[r] = r < T.n_ineq ? tape_al_ineq(g, lam[r], rho, v, cm, ms) : tape_al_eq(g, mu[r - T.n_ineq], rho, v, cm, ms);
     }
-    for (int k = lane; k < T.nx; k += 64) gout[k] = 0.0;  // variables no live instruction reads
+    for (int k = lane; k < T.nx; k += NT) gout[k] = 0.0;  // variables no live instruction reads
     __syncthreads();
-    for (int s = lane; s < S.n_seed; s += 64) {
+    for (int s = lane; s < S.n_seed; s += NT) {
       double acc = s == S.seed_cost ? 1.0 : 0.0;
       for (int e = seed_off[s]; e < seed_off[s + 1]; ++e) acc += roww[seed_rows[e]];
       adj[seed_reg[s]] = acc;
     }
     __syncthreads();
-    int4 n0 = S.rv[(size_t)lane * 2], n1 = S.rv[(size_t)lane * 2 + 1];
-    for (int p = 0; p < S.n_rv_pass; ++p) {
-      const int4 ins = n0, meta = n1;
-      if (p + 1 < S.n_rv_pass) {
-        n0 = S.rv[((size_t)(p + 1) * 64 + lane) * 2];
-        n1 = S.rv[((size_t)(p + 1) * 64 + lane) * 2 + 1];
-      }
+    const int rlast = S.n_rv_pass - 1;
+    auto rvi = [&](int p, int h) { return S.rv[((size_t)(p < rlast ? p : rlast) * NT + lane) * 2 + h]; };
+    int4 a0 = rvi(0, 0), b0 = rvi(0, 1), a1 = rvi(1, 0), b1 = rvi(1, 1), a2 = rvi(2, 0), b2 = rvi(2, 1), a3 = rvi(3, 0), b3 = rvi(3, 1);
+    auto rv_pass = [&](const int4 ins, const int4 meta) __attribute__((always_inline)) {
       const int o = ins.x >> OPSH, i = ins.x & ((1 << OPSH) - 1);
       if (o != IDLE) {
         const int nc = meta.x & 0xFFFF;
@@ -134,41 +181,56 @@ struct WaveEval {
           gout[ins.y] = w;
         } else {
           const double va = val[ins.y], vb = val[ins.z];
-          double ca = 0.0, cb = 0.0;
-          switch (o) {
-            case 3: ca = w; cb = w; break;
-            case 4: ca = w; cb = -w; break;
-            case 5: ca = w * vb; cb = w * va; break;
-            case 6: ca = w / vb; cb = -(w * va / (vb * vb)); break;
-            case 7: ca = -w; break;
-            case 8: ca = w * cos(va); break;
-            case 9: ca = -(w * sin(va)); break;
-            case 10: { const double d = va * va + vb * vb; ca = w * vb / d; cb = -(w * va / d); } break;
-            case 11: ca = w * 0.5 / val[i]; break;
-            case 12: ca = w * 2.0 * va; break;
-            case 13: ca = w / sqrt(1.0 - va * va); break;
-            case 14: ca = w * (va > 0.0 ? 1.0 : (va < 0.0 ? -1.0 : 0.0)); break;
-            case 15: if (va <= vb) ca = w; else cb = w; break;
-            case 16: if (va >= vb) ca = w; else cb = w; break;
-            case 24: if (va != 0.0) cb = w; break;
-            default: break;  // 17..23: piecewise constant
+          const bool mulsq = o == 5 || o == 12;
+          double ca = mulsq ? w * (o == 12 ? 2.0 * va : vb) : (o == 7 ? -w : w);
+          double cb = o == 5 ? w * va : (o == 3 ? w : (o == 4 ? -w : 0.0));
+          const bool rare = !(o == 3 || o == 4 || o == 5 || o == 7 || o == 12);
+          if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+            if (rare) { ca = 0.0; cb = 0.0; }
+            switch (o) {
+              case 6: ca = w / vb; cb = -(w * va / (vb * vb)); break;
+              case 8: ca = w * cos(va); break;
+              case 9: ca = -(w * sin(va)); break;
+              case 10: { const double d = va * va + vb * vb; ca = w * vb / d; cb = -(w * va / d); } break;
+              case 11: ca = w * 0.5 / val[i]; break;
+              case 13: ca = w / sqrt(1.0 - va * va); break;
+              case 14: ca = w * (va > 0.0 ? 1.0 : (va < 0.0 ? -1.0 : 0.0)); break;
+              case 15: if (va <= vb) ca = w; else cb = w; break;
+              case 16: if (va >= vb) ca = w; else cb = w; break;
+              case 24: if (va != 0.0) cb = w; break;
+              default: break;  // 17..23: piecewise constant
+            }
           }
           val[i] = ca;
           adj[i] = cb;
         }
       }
-      __syncthreads();
+      lds_barrier();
+    };
+    for (int p = 0; p < S.n_rv_pass; p += 4) {
+      const int4 x0 = a0, y0 = b0;
+      a0 = rvi(p + 4, 0); b0 = rvi(p + 4, 1);
+      rv_pass(x0, y0);
+      const int4 x1 = a1, y1 = b1;
+      a1 = rvi(p + 5, 0); b1 = rvi(p + 5, 1);
+      rv_pass(x1, y1);
+      const int4 x2 = a2, y2 = b2;
+      a2 = rvi(p + 6, 0); b2 = rvi(p + 6, 1);
+      rv_pass(x2, y2);
+      const int4 x3 = a3, y3 = b3;
+      a3 = rvi(p + 7, 0); b3 = rvi(p + 7, 1);
+      rv_pass(x3, y3);
     }
-    v = f + wsum(v);
+    v = f + red.sum(v);
     *fout = f;
-    *cmax = wmax(cm);
-    *meas = wmax(ms);
+    *cmax = red.max(cm);
+    *meas = red.max(ms);
     return v;
   }
 };
 
-template <bool HIST_LDS>
-__global__ __launch_bounds__(64) void k_tape_wave(TapeParams T, WaveSchedDev S, int B, const double* __restrict__ x0, const double* __restrict__ par,
+template <int NT, bool HIST_LDS>
+__global__ __launch_bounds__(NT) void k_tape_wave(TapeParams T, WaveSchedDev S, int B, const double* __restrict__ x0, const double* __restrict__ par,
                                                   double* __restrict__ hist_g, double* __restrict__ xo, double* __restrict__ fo, double* __restrict__ kkt,
                                                   int* __restrict__ iters, int* __restrict__ status, double* __restrict__ mult) {
   extern __shared__ double lds[];
@@ -187,7 +249,8 @@ __global__ __launch_bounds__(64) void k_tape_wave(TapeParams T, WaveSchedDev S, 
   double* rowv = mu + (ne > 0 ? ne : 1);
   double* roww = rowv + (S.nrows > 0 ? S.nrows : 1);
   double* RA = roww + (S.nrows > 0 ? S.nrows : 1);  // 1 / s.y [m], the two-loop alphas [m]
-  double* after = RA + 2 * m;
+  double* redbuf = RA + 2 * m;
+  double* after = redbuf + 8;
   double* Hs;
   if constexpr (HIST_LDS) {
     Hs = after;
@@ -196,154 +259,176 @@ __global__ __launch_bounds__(64) void k_tape_wave(TapeParams T, WaveSchedDev S, 
     Hs = hist_g + (size_t)gb * 2 * m * n;
   }
   int* small = reinterpret_cast<int*>(after);
-  for (int k = lane; k < S.n_small; k += 64) small[k] = S.small[k];
+  for (int k = lane; k < S.n_small; k += NT) small[k] = S.small[k];
   const int* row_reg = small;
   const int* seed_reg = row_reg + S.nrows;
   const int* seed_off = seed_reg + S.n_seed;
   const int* seed_rows = seed_off + S.n_seed + 1;
   const double* pb = par + (size_t)gb * T.np;
-  for (int k = lane; k < S.n_cst; k += 64) val[S.cst_reg[k]] = S.cst_val[k];
-  for (int k = lane; k < S.n_par; k += 64) val[S.par_reg[k]] = pb[S.par_k[k]];
-  for (int k = lane; k < n; k += 64) X[k] = x0[(size_t)gb * n + k];
-  for (int i = lane; i < ni; i += 64) lam[i] = 0.0;
-  for (int i = lane; i < ne; i += 64) mu[i] = 0.0;
+  for (int k = lane; k < S.n_cst; k += NT) val[S.cst_reg[k]] = S.cst_val[k];
+  for (int k = lane; k < S.n_par; k += NT) val[S.par_reg[k]] = pb[S.par_k[k]];
+  for (int k = lane; k < n; k += NT) X[k] = x0[(size_t)gb * n + k];
+  for (int i = lane; i < ni; i += NT) lam[i] = 0.0;
+  for (int i = lane; i < ne; i += NT) mu[i] = 0.0;
   __syncthreads();
-  WaveEval ev{T, S, val, adj, lam, mu, rowv, roww, row_reg, seed_reg, seed_off, seed_rows, lane};
+  Red<NT> red{redbuf};
+  WaveEval<NT> ev{T, S, val, adj, lam, mu, rowv, roww, row_reg, seed_reg, seed_off, seed_rows, lane, red};
 
   auto Sr = [&](int slot, int k) -> double& { return Hs[(size_t)slot * n + k]; };
   auto Yr = [&](int slot, int k) -> double& { return Hs[(size_t)(m + slot) * n + k]; };
   int hist = 0, head = 0;
   double rho = T.rho0, omega = fmax(T.tol, 1e-2), meas_prev = 1e300, msum = 0.0;
-  double fval, cmax, meas;
-  double val_m = ev.phi(X, G, rho, &fval, &cmax, &meas);
-  int evals = 1, st = OH_TAPE_ST_MAX_ITER;
+  double fval = 0.0, cmax = 0.0, meas = 0.0, val_m = 0.0;
+  int evals = 0, st = OH_TAPE_ST_MAX_ITER;
   bool H_is_eye = true;
   double stat = 0.0;
+  // The state machine of oh_tape_solver.h:tape_solve_instance around ONE evaluation site (the evaluator is some thousand instructions; four inlined
+  // copies of it do not fit the instruction cache, a call would turn every LDS access into a flat one): `why` says what the evaluation was for.
+  enum { EV_START, EV_OUTER, EV_TRIAL, EV_AGAIN };
+  int why = EV_START, ls = 0;
+  const double* xs = X;
+  double* gout = G;
+  double slope = 0.0, alpha = 1.0, slack = 0.0, gg = 0.0;
   for (;;) {
+    double f_, c_, m_;
+    const double v_ = ev.phi(xs, gout, rho, &f_, &c_, &m_);
+    ++evals;
+    if (why == EV_TRIAL) {
+      bool ok = false;
+      const double need = -1e-4 * alpha * slope;
+      if (need > slack) {
+        ok = (v_ == v_) && v_ <= val_m - need + slack;
+      } else if ((v_ == v_) && v_ <= val_m - slack) {
+        ok = true;
+      } else if ((v_ == v_) && v_ <= val_m + slack) {
+        double gq = 0.0;
+        for (int k = lane; k < n; k += NT) gq += GT[k] * GT[k];
+        ok = red.sum(gq) <= (1.0 - 1e-4 * alpha) * gg;
+      }
+      if (!ok) {
+        alpha *= 0.5;
+        ++ls;
+        if (evals >= T.max_iter || ls >= 40) {  // rowv belongs to the rejected trial: re-evaluate at x before anything reads the rows again
+          why = EV_AGAIN;
+          xs = X;
+          gout = G;
+        } else {
+          for (int k = lane; k < n; k += NT) XT[k] = X[k] + alpha * D[k];
+        }
+        continue;
+      }
+      double psy = 0.0, pss = 0.0, pyy = 0.0;
+      for (int k = lane; k < n; k += NT) {
+        const double sv = XT[k] - X[k], yv = GT[k] - G[k];
+        psy += sv * yv; pss += sv * sv; pyy += yv * yv;
+      }
+      const double sy = red.sum(psy), ss = red.sum(pss), yy = red.sum(pyy);
+      if (sy > 1e-12 * sqrt(ss) * sqrt(yy)) {
+        for (int k = lane; k < n; k += NT) { Sr(head, k) = XT[k] - X[k]; Yr(head, k) = GT[k] - G[k]; }
+        RA[head] = 1.0 / sy;  // every thread writes the same value
+        head = (head + 1) % m;
+        if (hist < m) ++hist;
+        H_is_eye = false;
+      }
+      for (int k = lane; k < n; k += NT) { X[k] = XT[k]; G[k] = GT[k]; }
+    } else if (why == EV_AGAIN) {
+      if (H_is_eye || evals >= T.max_iter) {  // steepest descent cannot improve: rounding floor
+        val_m = v_; fval = f_; cmax = c_; meas = m_;
+        break;
+      }
+      hist = 0; head = 0;
+      H_is_eye = true;
+    }
+    val_m = v_; fval = f_; cmax = c_; meas = m_;
+    // ---- top of the iteration
     double sm = 0.0, bad = 0.0;
-    for (int k = lane; k < n; k += 64) {
+    for (int k = lane; k < n; k += NT) {
       const double g = G[k];
       sm = fmax(sm, fabs(g));
       if (!(g == g)) bad = 1.0;
     }
-    stat = wmax(sm);
-    const bool finite = (val_m == val_m) && (fabs(val_m) < 1e300) && wmax(bad) == 0.0;
+    stat = red.max(sm);
+    const bool finite = (val_m == val_m) && (fabs(val_m) < 1e300) && red.max(bad) == 0.0;
     if (!finite) { st = OH_TAPE_ST_NUMERICAL; break; }
     if (stat <= omega) {
       if (stat <= T.tol && meas <= T.tol_feas) { st = OH_TAPE_ST_CONVERGED; break; }
       if (evals >= T.max_iter) break;
       double ms_ = 0.0;
-      for (int i = lane; i < ne; i += 64) {
+      for (int i = lane; i < ne; i += NT) {
         const double v = mu[i] - rho * rowv[ni + i];
         mu[i] = v;
         ms_ += fabs(v);
       }
-      for (int i = lane; i < ni; i += 64) {
+      for (int i = lane; i < ni; i += NT) {
         const double v = fmax(0.0, lam[i] - rho * rowv[i]);
         lam[i] = v;
         ms_ += v;
       }
-      msum = wsum(ms_);
+      msum = red.sum(ms_);
       if (meas > 0.25 * meas_prev) rho = fmin(rho * 10.0, 1e8);
       meas_prev = meas;
       omega = fmax(T.tol, fmin(omega, 0.1 * meas));
-      val_m = ev.phi(X, G, rho, &fval, &cmax, &meas);
-      ++evals;
+      why = EV_OUTER;  // the metric is kept across the multiplier update (oh_tape_solver.h)
+      xs = X;
+      gout = G;
       continue;
     }
     if (evals >= T.max_iter) break;
-    // two-loop recursion; element k of every vector lives on lane k mod 64: no synchronisation between the element-wise steps
-    for (int k = lane; k < n; k += 64) D[k] = G[k];
+    // two-loop recursion; element k of every vector lives on thread k mod NT: no synchronisation between the element-wise steps
+    for (int k = lane; k < n; k += NT) D[k] = G[k];
     for (int j = hist - 1; j >= 0; --j) {
       const int sl = ((head - hist + j) % m + m) % m;
       double sq = 0.0;
-      for (int k = lane; k < n; k += 64) sq += Sr(sl, k) * D[k];
-      const double al = RA[sl] * wsum(sq);
+      for (int k = lane; k < n; k += NT) sq += Sr(sl, k) * D[k];
+      const double al = RA[sl] * red.sum(sq);
       RA[m + sl] = al;
-      for (int k = lane; k < n; k += 64) D[k] -= al * Yr(sl, k);
+      for (int k = lane; k < n; k += NT) D[k] -= al * Yr(sl, k);
     }
     if (hist > 0) {
       const int sl = ((head - 1) % m + m) % m;
       double sy = 0.0, yy = 0.0;
-      for (int k = lane; k < n; k += 64) { sy += Sr(sl, k) * Yr(sl, k); yy += Yr(sl, k) * Yr(sl, k); }
-      const double gam = wsum(sy) / wsum(yy);
-      for (int k = lane; k < n; k += 64) D[k] *= gam;
+      for (int k = lane; k < n; k += NT) { sy += Sr(sl, k) * Yr(sl, k); yy += Yr(sl, k) * Yr(sl, k); }
+      const double gam = red.sum(sy) / red.sum(yy);
+      for (int k = lane; k < n; k += NT) D[k] *= gam;
     }
     for (int j = 0; j < hist; ++j) {
       const int sl = ((head - hist + j) % m + m) % m;
       double yr = 0.0;
-      for (int k = lane; k < n; k += 64) yr += Yr(sl, k) * D[k];
-      const double be = RA[m + sl] - RA[sl] * wsum(yr);
-      for (int k = lane; k < n; k += 64) D[k] += be * Sr(sl, k);
+      for (int k = lane; k < n; k += NT) yr += Yr(sl, k) * D[k];
+      const double be = RA[m + sl] - RA[sl] * red.sum(yr);
+      for (int k = lane; k < n; k += NT) D[k] += be * Sr(sl, k);
     }
     double sp = 0.0;
-    for (int k = lane; k < n; k += 64) {
+    for (int k = lane; k < n; k += NT) {
       const double v = -D[k];
       D[k] = v;
       sp += G[k] * v;
     }
-    double slope = wsum(sp);
+    slope = red.sum(sp);
     if (!(slope < 0.0)) {
       hist = 0; head = 0;
       H_is_eye = true;
       sp = 0.0;
-      for (int k = lane; k < n; k += 64) { D[k] = -G[k]; sp -= G[k] * G[k]; }
-      slope = wsum(sp);
+      for (int k = lane; k < n; k += NT) { D[k] = -G[k]; sp -= G[k] * G[k]; }
+      slope = red.sum(sp);
     }
-    double alpha = 1.0, vt = 0.0, ft = 0.0, ct = 0.0, mt = 0.0;
-    if (H_is_eye) {
+    alpha = 1.0;
+    if (H_is_eye) {  // a fresh metric knows nothing about the scale of the problem: keep the first step within unit length
       double dm = 0.0;
-      for (int k = lane; k < n; k += 64) dm = fmax(dm, fabs(D[k]));
-      alpha = fmin(1.0, 1.0 / wmax(dm));
+      for (int k = lane; k < n; k += NT) dm = fmax(dm, fabs(D[k]));
+      alpha = fmin(1.0, 1.0 / red.max(dm));
     }
-    bool ok = false;
-    const double slack = 4e-16 * (fmax(1.0, fabs(val_m)) + msum);
+    slack = 4e-16 * (fmax(1.0, fabs(val_m)) + msum);
     double gp = 0.0;
-    for (int k = lane; k < n; k += 64) gp += G[k] * G[k];
-    const double gg = wsum(gp);
-    for (int ls = 0; ls < 40; ++ls) {
-      for (int k = lane; k < n; k += 64) XT[k] = X[k] + alpha * D[k];
-      vt = ev.phi(XT, GT, rho, &ft, &ct, &mt);
-      ++evals;
-      const double need = -1e-4 * alpha * slope;
-      if (need > slack) {
-        if ((vt == vt) && vt <= val_m - need + slack) { ok = true; break; }
-      } else if ((vt == vt) && vt <= val_m - slack) {
-        ok = true;
-        break;
-      } else if ((vt == vt) && vt <= val_m + slack) {
-        double gq = 0.0;
-        for (int k = lane; k < n; k += 64) gq += GT[k] * GT[k];
-        if (wsum(gq) <= (1.0 - 1e-4 * alpha) * gg) { ok = true; break; }
-      }
-      alpha *= 0.5;
-      if (evals >= T.max_iter) break;
-    }
-    if (!ok) {
-      val_m = ev.phi(X, G, rho, &fval, &cmax, &meas);
-      ++evals;
-      if (H_is_eye || evals >= T.max_iter) break;
-      hist = 0; head = 0;
-      H_is_eye = true;
-      continue;
-    }
-    double psy = 0.0, pss = 0.0, pyy = 0.0;
-    for (int k = lane; k < n; k += 64) {
-      const double sv = XT[k] - X[k], yv = GT[k] - G[k];
-      psy += sv * yv; pss += sv * sv; pyy += yv * yv;
-    }
-    const double sy = wsum(psy), ss = wsum(pss), yy = wsum(pyy);
-    if (sy > 1e-12 * sqrt(ss) * sqrt(yy)) {
-      for (int k = lane; k < n; k += 64) { Sr(head, k) = XT[k] - X[k]; Yr(head, k) = GT[k] - G[k]; }
-      RA[head] = 1.0 / sy;  // every lane writes the same value
-      head = (head + 1) % m;
-      if (hist < m) ++hist;
-      H_is_eye = false;
-    }
-    for (int k = lane; k < n; k += 64) { X[k] = XT[k]; G[k] = GT[k]; }
-    val_m = vt; fval = ft; cmax = ct; meas = mt;
+    for (int k = lane; k < n; k += NT) gp += G[k] * G[k];
+    gg = red.sum(gp);
+    ls = 0;
+    for (int k = lane; k < n; k += NT) XT[k] = X[k] + alpha * D[k];
+    why = EV_TRIAL;
+    xs = XT;
+    gout = GT;
   }
-  for (int k = lane; k < n; k += 64)
+  for (int k = lane; k < n; k += NT)
     if (xo) xo[(size_t)gb * n + k] = X[k];
   if (lane == 0) {
     if (fo) fo[gb] = fval;
@@ -352,8 +437,8 @@ __global__ __launch_bounds__(64) void k_tape_wave(TapeParams T, WaveSchedDev S, 
     if (status) status[gb] = st;
   }
   if (mult) {
-    for (int i = lane; i < ni; i += 64) mult[(size_t)gb * (ni + ne) + i] = lam[i];
-    for (int i = lane; i < ne; i += 64) mult[(size_t)gb * (ni + ne) + ni + i] = mu[i];
+    for (int i = lane; i < ni; i += NT) mult[(size_t)gb * (ni + ne) + i] = lam[i];
+    for (int i = lane; i < ne; i += NT) mult[(size_t)gb * (ni + ne) + ni + i] = mu[i];
   }
 }
 
@@ -370,7 +455,7 @@ int upload(V** dst, const std::vector<V>& src) {
 
 size_t oh_tape_wave_lds_bytes(const TapeParams& T, const TapeWave& W, bool hist_lds) {
   const size_t nrows = T.n_ineq + T.n_eq;
-  size_t d = 2 * (size_t)W.n_reg + 5 * (size_t)T.nx + (T.n_ineq > 0 ? T.n_ineq : 1) + (T.n_eq > 0 ? T.n_eq : 1) + 2 * (nrows > 0 ? nrows : 1) + 2 * (size_t)T.lbfgs;
+  size_t d = 2 * (size_t)W.n_reg + 5 * (size_t)T.nx + (T.n_ineq > 0 ? T.n_ineq : 1) + (T.n_eq > 0 ? T.n_eq : 1) + 2 * (nrows > 0 ? nrows : 1) + 2 * (size_t)T.lbfgs + 8;
   if (hist_lds) d += 2 * (size_t)T.lbfgs * T.nx;
   return d * sizeof(double) + sizeof(int) * (((size_t)W.n_small + 1) & ~(size_t)1);
 }
@@ -381,6 +466,11 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
                        std::string* err) {
   *out = TapeWave{};
   if (T.lbfgs <= 0) return 0;
+  // threads per instance: four wavefronts (the register file allows one block per CU: one wavefront would leave three SIMDs idle, and the wide
+  // first levels of a trajectory tape are 400-800 instructions); OH_TAPE_WAVE_NT=64: one
+  const char* ent = getenv("OH_TAPE_WAVE_NT");
+  const int NT = (ent && atoi(ent) == 64) ? 64 : 256;
+  out->nt = NT;
   const int L = T.len, nrows = T.n_ineq + T.n_eq;
   auto is_binary = [](int o) { return (o >= 3 && o <= 6) || o == 10 || (o >= 15 && o <= 20) || (o >= 22 && o <= 24); };
   auto has_adj = [&](int i) { return op[i] != 0 && op[i] != 2; };
@@ -417,14 +507,55 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
   };
   for (int k = 0; k < T.nx; ++k)
     if (xreg[k] >= 0) fw.push_back(int4{xreg[k] | (1 << OPSH), k, 0, 0});
-  pad(fw, 64);
+  pad(fw, NT);
   std::vector<std::vector<int>> by_level(n_lvl + 1);
   for (int i = 0; i < L; ++i)
     if (live[i] && op[i] >= 3) by_level[level[i]].push_back(i);
+  // A wavefront executes the bodies of all the operations its 64 lanes hold one after the other: what a pass costs is the most expensive set of
+  // distinct operations any of its wavefronts holds.  Within a level (sorted by operation, NT instructions per pass) the groups of equal
+  // operation are dealt to the block's wavefronts, dearest first, each to the wavefront with the cheapest set so far: a narrow level runs its
+  // sines, cosines, divisions and products side by side on four SIMDs instead of in a row on one.  Slots: instruction index, -1 idle.
+  auto body_cost = [](int o) { return (o == 8 || o == 9) ? 40 : (o == 10 || o == 13) ? 60 : o == 6 ? 12 : o == 11 ? 10 : 1; };
+  auto arrange = [&](std::vector<int> ids) {
+    std::stable_sort(ids.begin(), ids.end(), [&](int p, int q) { return op[p] < op[q]; });
+    std::vector<int> slots;
+    const int W = NT / 64;
+    for (size_t c0 = 0; c0 < ids.size(); c0 += NT) {
+      const size_t c1 = std::min(ids.size(), c0 + NT);
+      std::vector<std::pair<int, int>> groups;  // [begin, end) of equal operation inside the chunk
+      for (size_t k = c0; k < c1;) {
+        size_t e = k;
+        while (e < c1 && op[ids[e]] == op[ids[k]]) ++e;
+        groups.emplace_back((int)k, (int)e);
+        k = e;
+      }
+      std::stable_sort(groups.begin(), groups.end(), [&](const std::pair<int, int>& x, const std::pair<int, int>& y) { return body_cost(op[ids[x.first]]) > body_cost(op[ids[y.first]]); });
+      std::vector<std::vector<int>> wave(W);
+      std::vector<int> cost(W, 0);
+      for (const std::pair<int, int>& g : groups) {
+        int k = g.first;
+        while (k < g.second) {
+          int w = -1;
+          for (int q = 0; q < W; ++q)
+            if ((int)wave[q].size() < 64 && (w < 0 || cost[q] < cost[w])) w = q;
+          const int take = std::min(g.second - k, 64 - (int)wave[w].size());
+          for (int t = 0; t < take; ++t) wave[w].push_back(ids[k + t]);
+          cost[w] += body_cost(op[ids[k]]);
+          k += take;
+        }
+      }
+      for (int q = 0; q < W; ++q) {
+        wave[q].resize(64, -1);
+        slots.insert(slots.end(), wave[q].begin(), wave[q].end());
+      }
+    }
+    return slots;
+  };
+  std::vector<std::vector<int>> slots_of(n_lvl + 1);
   for (int l = 1; l <= n_lvl; ++l) {
-    std::stable_sort(by_level[l].begin(), by_level[l].end(), [&](int p, int q) { return op[p] < op[q]; });
-    for (int i : by_level[l]) fw.push_back(int4{reg[i] | (op[i] << OPSH), reg[a[i]], is_binary(op[i]) ? reg[b[i]] : 0, 0});
-    pad(fw, 64);
+    slots_of[l] = arrange(by_level[l]);
+    for (int i : slots_of[l])
+      fw.push_back(i < 0 ? int4{IDLE << OPSH, 0, 0, 0} : int4{reg[i] | (op[i] << OPSH), reg[a[i]], is_binary(op[i]) ? reg[b[i]] : 0, 0});
   }
   // ---- consumers of every register that carries an adjoint, in the order the serial reverse sweep adds them (descending instruction index)
   std::vector<std::vector<int>> cons(n_reg);
@@ -459,16 +590,18 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
     rv.push_back(int4{nc | ((seed_of[r] >= 0 ? 1 : 0) << 16), nc > 0 ? cl[0] : 0, nc > 1 ? cl[1] : 0, nc > 2 ? cl[2] : 0});
     for (int e = 3; e < nc; ++e) overflow.push_back(cl[e]);
   };
-  for (int l = n_lvl; l >= 1; --l) {
-    for (int i : by_level[l]) rv_entry(reg[i], op[i], reg[a[i]], is_binary(op[i]) ? reg[b[i]] : 0);
-    while (rv.size() % 128) {
-      rv.push_back(int4{IDLE << OPSH, 0, 0, 0});
-      rv.push_back(int4{0, 0, 0, 0});
+  for (int l = n_lvl; l >= 1; --l)
+    for (int i : slots_of[l]) {
+      if (i >= 0) {
+        rv_entry(reg[i], op[i], reg[a[i]], is_binary(op[i]) ? reg[b[i]] : 0);
+      } else {
+        rv.push_back(int4{IDLE << OPSH, 0, 0, 0});
+        rv.push_back(int4{0, 0, 0, 0});
+      }
     }
-  }
   for (int k = 0; k < T.nx; ++k)
     if (xreg[k] >= 0) rv_entry(xreg[k], 1, k, 0);
-  while (rv.size() % 128) {
+  while (rv.size() % (2 * (size_t)NT)) {
     rv.push_back(int4{IDLE << OPSH, 0, 0, 0});
     rv.push_back(int4{0, 0, 0, 0});
   }
@@ -489,8 +622,14 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
   small.push_back(off);
   for (const std::vector<int>& sr : seed_rows_of)
     for (int r : sr) small.push_back(r);
-  out->n_fw_pass = (int)(fw.size() / 64);
-  out->n_rv_pass = (int)(rv.size() / 128);
+  while ((fw.size() / NT) % 4) fw.insert(fw.end(), (size_t)NT, int4{IDLE << OPSH, 0, 0, 0});  // the kernel's pass loops are unrolled by four
+  while ((rv.size() / (2 * (size_t)NT)) % 4)
+    for (int q = 0; q < NT; ++q) {
+      rv.push_back(int4{IDLE << OPSH, 0, 0, 0});
+      rv.push_back(int4{0, 0, 0, 0});
+    }
+  out->n_fw_pass = (int)(fw.size() / NT);
+  out->n_rv_pass = (int)(rv.size() / (2 * NT));
   out->n_cst = (int)cst_reg.size();
   out->n_par = (int)par_reg.size();
   out->n_seed = (int)seed_reg.size();
@@ -507,7 +646,8 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
     *err = "allocation of the wavefront schedule failed";
     return 1;
   }
-  const void* fn = out->hist_lds ? reinterpret_cast<const void*>(k_tape_wave<true>) : reinterpret_cast<const void*>(k_tape_wave<false>);
+  const void* fn = NT == 64 ? (out->hist_lds ? reinterpret_cast<const void*>(k_tape_wave<64, true>) : reinterpret_cast<const void*>(k_tape_wave<64, false>))
+                            : (out->hist_lds ? reinterpret_cast<const void*>(k_tape_wave<256, true>) : reinterpret_cast<const void*>(k_tape_wave<256, false>));
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)out->lds_bytes) != hipSuccess) {
     (void)hipGetLastError();
     oh_tape_wave_release(out);
@@ -536,9 +676,10 @@ hipError_t oh_launch_tape_wave(hipStream_t s, TapeWave& W, const TapeParams& T, 
   }
   WaveSchedDev S{W.d_fw, W.d_rv, W.d_cons, W.d_cst_reg, W.d_cst_val, W.d_par_reg, W.d_par_k, W.d_small, W.n_fw_pass, W.n_rv_pass, W.n_cst, W.n_par, W.n_reg,
                  T.n_ineq + T.n_eq, W.n_seed, W.n_seed_rows, W.seed_cost, W.n_small};
-  if (W.hist_lds)
-    hipLaunchKernelGGL(k_tape_wave<true>, dim3(B), dim3(64), W.lds_bytes, s, T, S, B, x0, p, (double*)nullptr, x, f, kkt, iters, status, mult);
-  else
-    hipLaunchKernelGGL(k_tape_wave<false>, dim3(B), dim3(64), W.lds_bytes, s, T, S, B, x0, p, W.d_hist, x, f, kkt, iters, status, mult);
+  double* hg = W.hist_lds ? nullptr : W.d_hist;
+  if (W.nt == 64 && W.hist_lds) hipLaunchKernelGGL((k_tape_wave<64, true>), dim3(B), dim3(64), W.lds_bytes, s, T, S, B, x0, p, hg, x, f, kkt, iters, status, mult);
+  else if (W.nt == 64) hipLaunchKernelGGL((k_tape_wave<64, false>), dim3(B), dim3(64), W.lds_bytes, s, T, S, B, x0, p, hg, x, f, kkt, iters, status, mult);
+  else if (W.hist_lds) hipLaunchKernelGGL((k_tape_wave<256, true>), dim3(B), dim3(256), W.lds_bytes, s, T, S, B, x0, p, hg, x, f, kkt, iters, status, mult);
+  else hipLaunchKernelGGL((k_tape_wave<256, false>), dim3(B), dim3(256), W.lds_bytes, s, T, S, B, x0, p, hg, x, f, kkt, iters, status, mult);
   return hipGetLastError();
 }

@@ -278,7 +278,9 @@ typedef struct oh_tape_desc {
   double tol_feas;  /* row violation / complementarity measure; <= 0: 1e-9 */
   double rho0;      /* initial penalty; <= 0: 10 */
   int jit;          /* != 0: generate straight-line HIP code from the tape and compile it with hiprtc when the handle is created (registers in
-                       VGPRs); 0: interpret the instruction arrays (registers in HBM/L2; no set-up cost, far slower per evaluation) */
+                       VGPRs); 0: interpret the instruction arrays (registers in HBM/L2; no set-up cost, far slower per evaluation).  Ignored beyond 48
+                       variables when the tape's live registers fit the LDS: those handles run one block of wavefronts per instance over the
+                       dependency levels of the tape (registers in LDS, no generated code; oh_get_flag "tape_wave") */
 } oh_tape_desc;
 
 typedef struct oh_handle oh_handle;
@@ -361,7 +363,8 @@ int oh_solve(oh_handle* h, int B, const double* x0, const double* p, double* x, 
 
 /* Scheduling facts of a handle by name, for harnesses that report what ran: "fuse_couple" (1: the orientation-locked family's iteration is
    k_retract + k_evalb_zc + k_step_zc, the neighbour coupling folded in; 0: k_couple runs as a launch of its own), "tail_threshold",
-   "specialized". */
+   "specialized"; OH_PROBLEM_TAPE handles: "tape_wave" (0: one thread per instance; 1 / 2: one block of wavefronts per instance, the quasi-Newton
+   pairs in global memory / in LDS), "tape_levels" and "tape_passes" (dependency levels of the tape; instruction passes of one evaluation). */
 int oh_get_flag(oh_handle* h, const char* name, int* value);
 
 /* Largest B one oh_solve / oh_solve_device call of this handle takes (*out = 0: the library sets no bound of its own). */

@@ -24,7 +24,9 @@
 namespace {
 
 constexpr int OPSH = 20;  // entry word 0 = register | op << 20 (registers < 2^18)
-constexpr int IDLE = 31;
+constexpr int ZREG = 0;    // val = adj = 0, never written (an idle slot is "trash = zero + zero", an absent consumer the zero register)
+constexpr int TRASH = 1;   // what idle slots write
+constexpr int XREG0 = 2;   // variable k lives in register 2 + k
 
 struct WaveSchedDev {
   const int4* fw;   // [n_fw_pass * 64]
@@ -98,11 +100,11 @@ struct WaveEval {
     const int last = S.n_fw_pass - 1;
     auto fwi = [&](int p) { return S.fw[(size_t)(p < last ? p : last) * NT + lane]; };
     int4 q0 = fwi(0), q1 = fwi(1), q2 = fwi(2), q3 = fwi(3);
+    for (int k = lane; k < T.nx; k += NT) val[XREG0 + k] = xs[k];  // the variables' registers: 2 .. 2 + nx
+    lds_barrier();
     auto fw_pass = [&](const int4 ins) __attribute__((always_inline)) {
       const int o = ins.x >> OPSH, i = ins.x & ((1 << OPSH) - 1);
-      if (o == 1) {
-        val[i] = xs[ins.y];
-      } else if (o != IDLE) {
+      {  // straight-line: an idle slot adds the zero register to itself into the trash register
         const double va = val[ins.y], vb = val[ins.z];
         // the five operations that make up nine tenths of a trajectory tape without a branch (a switch on a per-lane value is a chain of ~20 masked
         // sections whether or not any lane takes them); the rest behind one wavefront-uniform test
@@ -156,7 +158,6 @@ struct WaveEval {
       rowv[r] = g;
       roww[r] = r < T.n_ineq ? tape_al_ineq(g, lam[r], rho, v, cm, ms) : tape_al_eq(g, mu[r - T.n_ineq], rho, v, cm, ms);
     }
-    for (int k = lane; k < T.nx; k += NT) gout[k] = 0.0;  // variables no live instruction reads
     __syncthreads();
     for (int s = lane; s < S.n_seed; s += NT) {
       double acc = s == S.seed_cost ? 1.0 : 0.0;
@@ -169,17 +170,17 @@ struct WaveEval {
     int4 a0 = rvi(0, 0), b0 = rvi(0, 1), a1 = rvi(1, 0), b1 = rvi(1, 1), a2 = rvi(2, 0), b2 = rvi(2, 1), a3 = rvi(3, 0), b3 = rvi(3, 1);
     auto rv_pass = [&](const int4 ins, const int4 meta) __attribute__((always_inline)) {
       const int o = ins.x >> OPSH, i = ins.x & ((1 << OPSH) - 1);
-      if (o != IDLE) {
+      {  // straight-line: absent consumers point at the zero register (val[0] = adj[0] = 0), idle slots write the trash register
         const int nc = meta.x & 0xFFFF;
         auto slot = [&](const int pk) { return (pk & 1) ? adj[pk >> 1] : val[pk >> 1]; };
-        double w = (meta.x >> 16) ? adj[i] : 0.0;
-        if (nc > 0) w += slot(meta.y);
-        if (nc > 1) w += slot(meta.z);
-        if (nc > 2) w += slot(meta.w);
-        for (int e = 3; e < nc; ++e) w += slot(S.cons[ins.w + e - 3]);
-        if (o == 1) {
-          gout[ins.y] = w;
-        } else {
+        const double sd = adj[i], s0 = slot(meta.y), s1 = slot(meta.z), s2 = slot(meta.w);
+        double w = (meta.x >> 16) ? sd : 0.0;
+        w += s0;
+        w += s1;
+        w += s2;
+        if (__builtin_amdgcn_ballot_w64(nc > 3) != 0)
+          for (int e = 3; e < nc; ++e) w += slot(S.cons[ins.w + e - 3]);
+        {
           const double va = val[ins.y], vb = val[ins.z];
           const bool mulsq = o == 5 || o == 12;
           double ca = mulsq ? w * (o == 12 ? 2.0 * va : vb) : (o == 7 ? -w : w);
@@ -221,6 +222,8 @@ struct WaveEval {
       a3 = rvi(p + 7, 0); b3 = rvi(p + 7, 1);
       rv_pass(x3, y3);
     }
+    for (int k = lane; k < T.nx; k += NT) gout[k] = val[XREG0 + k];  // a variable's entry is "+ the zero register": it leaves its adjoint in its own slot
+    __syncthreads();
     v = f + red.sum(v);
     *fout = f;
     *cmax = red.max(cm);
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(NT) void k_tape_wave(TapeParams T, WaveSchedDev S, 
   const int* seed_off = seed_reg + S.n_seed;
   const int* seed_rows = seed_off + S.n_seed + 1;
   const double* pb = par + (size_t)gb * T.np;
+  if (lane == 0) { val[ZREG] = 0.0; adj[ZREG] = 0.0; val[TRASH] = 0.0; adj[TRASH] = 0.0; }
   for (int k = lane; k < S.n_cst; k += NT) val[S.cst_reg[k]] = S.cst_val[k];
   for (int k = lane; k < S.n_par; k += NT) val[S.par_reg[k]] = pb[S.par_k[k]];
   for (int k = lane; k < n; k += NT) X[k] = x0[(size_t)gb * n + k];
@@ -484,11 +488,11 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
     }
   // compact registers; every load of the same variable is one register
   std::vector<int> reg(L, -1), xreg(T.nx, -1), level(L, 0);
-  int n_reg = 1;  // register 0: never written, what idle operands read
+  int n_reg = XREG0 + T.nx;  // 0: the zero register, 1: trash, then one register per variable (every load of a variable is that register)
+  for (int k = 0; k < T.nx; ++k) xreg[k] = XREG0 + k;
   for (int i = 0; i < L; ++i) {
     if (!live[i]) continue;
     if (op[i] == 1) {
-      if (xreg[a[i]] < 0) xreg[a[i]] = n_reg++;
       reg[i] = xreg[a[i]];
     } else {
       reg[i] = n_reg++;
@@ -502,12 +506,7 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
     if (live[i]) n_lvl = std::max(n_lvl, level[i]);
   // ---- forward schedule
   std::vector<int4> fw;
-  auto pad = [](std::vector<int4>& v, size_t unit) {
-    while (v.size() % unit) v.push_back(int4{IDLE << OPSH, 0, 0, 0});
-  };
-  for (int k = 0; k < T.nx; ++k)
-    if (xreg[k] >= 0) fw.push_back(int4{xreg[k] | (1 << OPSH), k, 0, 0});
-  pad(fw, NT);
+  const int4 idle_entry{TRASH | (3 << OPSH), ZREG, ZREG, 0};  // trash = zero + zero
   std::vector<std::vector<int>> by_level(n_lvl + 1);
   for (int i = 0; i < L; ++i)
     if (live[i] && op[i] >= 3) by_level[level[i]].push_back(i);
@@ -555,7 +554,7 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
   for (int l = 1; l <= n_lvl; ++l) {
     slots_of[l] = arrange(by_level[l]);
     for (int i : slots_of[l])
-      fw.push_back(i < 0 ? int4{IDLE << OPSH, 0, 0, 0} : int4{reg[i] | (op[i] << OPSH), reg[a[i]], is_binary(op[i]) ? reg[b[i]] : 0, 0});
+      fw.push_back(i < 0 ? idle_entry : int4{reg[i] | (op[i] << OPSH), reg[a[i]], is_binary(op[i]) ? reg[b[i]] : 0, 0});
   }
   // ---- consumers of every register that carries an adjoint, in the order the serial reverse sweep adds them (descending instruction index)
   std::vector<std::vector<int>> cons(n_reg);
@@ -595,14 +594,13 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
       if (i >= 0) {
         rv_entry(reg[i], op[i], reg[a[i]], is_binary(op[i]) ? reg[b[i]] : 0);
       } else {
-        rv.push_back(int4{IDLE << OPSH, 0, 0, 0});
+        rv.push_back(idle_entry);
         rv.push_back(int4{0, 0, 0, 0});
       }
     }
-  for (int k = 0; k < T.nx; ++k)
-    if (xreg[k] >= 0) rv_entry(xreg[k], 1, k, 0);
+  for (int k = 0; k < T.nx; ++k) rv_entry(xreg[k], 3, ZREG, ZREG);  // every variable, read or not: "+ zero" leaves the gathered adjoint in its slots
   while (rv.size() % (2 * (size_t)NT)) {
-    rv.push_back(int4{IDLE << OPSH, 0, 0, 0});
+    rv.push_back(idle_entry);
     rv.push_back(int4{0, 0, 0, 0});
   }
   for (const std::vector<int>& cl : cons)
@@ -622,10 +620,10 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
   small.push_back(off);
   for (const std::vector<int>& sr : seed_rows_of)
     for (int r : sr) small.push_back(r);
-  while ((fw.size() / NT) % 4) fw.insert(fw.end(), (size_t)NT, int4{IDLE << OPSH, 0, 0, 0});  // the kernel's pass loops are unrolled by four
+  while (fw.empty() || (fw.size() / NT) % 4) fw.insert(fw.end(), (size_t)NT, idle_entry);  // the kernel's pass loops are unrolled by four
   while ((rv.size() / (2 * (size_t)NT)) % 4)
     for (int q = 0; q < NT; ++q) {
-      rv.push_back(int4{IDLE << OPSH, 0, 0, 0});
+      rv.push_back(idle_entry);
       rv.push_back(int4{0, 0, 0, 0});
     }
   out->n_fw_pass = (int)(fw.size() / NT);

@@ -636,7 +636,8 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
   out->n_small = (int)small.size();
   out->n_levels = n_lvl;
   if (oh_tape_wave_lds_bytes(T, *out, false) > lds_limit) return 0;  // the register file itself does not fit: the thread-per-instance path stays
-  out->hist_lds = oh_tape_wave_lds_bytes(T, *out, true) <= lds_limit;
+  const char* eh = getenv("OH_TAPE_WAVE_HIST");  // "global": keep the (s, y) pairs out of the LDS even when they fit (the path big problems take)
+  out->hist_lds = oh_tape_wave_lds_bytes(T, *out, true) <= lds_limit && !(eh && eh[0] == 'g');
   out->lds_bytes = oh_tape_wave_lds_bytes(T, *out, out->hist_lds);
   if (upload(&out->d_fw, fw) || upload(&out->d_rv, rv) || upload(&out->d_cons, overflow) || upload(&out->d_cst_reg, cst_reg) ||
       upload(&out->d_cst_val, cst_val) || upload(&out->d_par_reg, par_reg) || upload(&out->d_par_k, par_k) || upload(&out->d_small, small)) {

@@ -70,15 +70,20 @@ def test_rebalanced_sums_are_the_same_problem_at_a_fraction_of_the_depth():
 
 
 @pytest.mark.gpu
-def test_wavefront_path_matches_thread_path_and_port_on_ik(hip_lib, monkeypatch):
+@pytest.mark.parametrize("variant", ["nt256", "nt64", "pairs_in_global_memory"])
+def test_wavefront_path_matches_thread_path_and_port_on_ik(hip_lib, monkeypatch, variant):
     from examples.example import setup_solver as ik
     from optas_amd.backend import TapeBackend
 
     g = np.load(os.path.join(GOLDEN, "ik_golden.npz"))
     tp = compile_problem(ik(build_only=True)[1])
     monkeypatch.setenv("OH_TAPE_LBFGS", "4")  # the limited-memory regime on a 7-variable problem: both paths can run it
+    if variant == "nt64":
+        monkeypatch.setenv("OH_TAPE_WAVE_NT", "64")  # one wavefront per instance
+    if variant == "pairs_in_global_memory":
+        monkeypatch.setenv("OH_TAPE_WAVE_HIST", "global")  # what a problem whose (s, y) pairs do not fit the LDS beside its registers takes
     wave = TapeBackend(tp, jit=False)
-    assert wave.flag("tape_wave") == 2 and wave.flag("tape_levels") > 5
+    assert wave.flag("tape_wave") == (1 if variant == "pairs_in_global_memory" else 2) and wave.flag("tape_levels") > 5
     monkeypatch.setenv("OH_TAPE_WAVE", "0")
     thread = TapeBackend(tp, jit=False)
     assert thread.flag("tape_wave") == 0

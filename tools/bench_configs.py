@@ -204,6 +204,7 @@ def run_configs(sample=8, torque_batches=(8192, 1024), only=None):
     be.close()
     _velocity_limited(out, sample)
     _config4(out, rng, sample)
+    _planner_tape(out, sample)
     return _torque(out, rng, sample, torque_batches)
 
 
@@ -220,6 +221,46 @@ def _velocity_limited(out, sample):
     out["config2_velocity_limited"] = {"what": "figure_eight_plan.py T=50 + joint-velocity limits (686 inequality rows), B = 65536; persistent kernel k_tail_vel", "batch": B,
                                        "solves_per_s": B / r["device_ms"] * 1e3, **r, "oracle_sample": oracle_grade("fig8_vel", **smp) if smp else None}
     solver.backend.close()
+
+
+def _planner_tape(out, sample):
+    # SURVEY 8(f)1, the generic route: example/simple_joint_space_planner.py (280 variables, 40 + 154 rows) matches no hand-written family and runs on the
+    # tape family -- one block of four wavefronts per instance over the dependency levels of the tape (csrc/oh_tape_wave.hip)
+    from examples.simple_joint_space_planner import setup_solver
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "planner_golden.npz"))
+    robot, solver = setup_solver(solver_options={"max_iter": 400000})
+    be = solver.backend
+    P, nb = g["p"], len(g["p"])
+    x0 = np.zeros((nb, solver.opt.nx))
+    x0[:, :140] = np.tile(g["q0"].reshape(-1, 1), (1, 20)).reshape(-1)[None, :]
+    be.solve(x0, P)
+    r4 = be.solve(x0, P)
+    ms4 = float(be.solve_ms())
+    rng = np.random.default_rng(SEED + 6)
+    B = 256
+    idx = np.arange(B) % nb
+    Pn = P[idx].copy()
+    Pn[:, :14] += rng.uniform(-0.05, 0.05, (B, 14))
+    Pn[:, 14:17] += rng.uniform(-0.02, 0.02, (B, 3))
+    r, smp = timed_with_results(be, np.ascontiguousarray(x0[idx]), np.ascontiguousarray(Pn), reps=1, sample=min(sample, 4), seed=6)
+    grade = None
+    if smp:
+        from oracle.problems import JointSpacePlannerNLP
+        from oracle.robot import OracleRobot
+
+        nlp = JointSpacePlannerNLP(OracleRobot(os.path.join(ROOT, "optas_amd", "robots", "med7.kin.json")))
+        grade = {"n": int(len(smp["f"])), "f_recomputed_max_abs_diff": float(max(abs(nlp.f(x, p) - f) for x, p, f in zip(smp["x"], smp["p"], smp["f"]))),
+                 "equality_rows_max": float(max(max(np.abs(nlp.a(x, p)).max(), np.abs(nlp.h(x, p)).max()) for x, p in zip(smp["x"], smp["p"]))),
+                 "inequality_rows_min": float(min(nlp.g(x, p).min() for x, p in zip(smp["x"], smp["p"]))),
+                 "by": "oracle/problems.py:JointSpacePlannerNLP (literal layout: 40 inequality, 147 + 7 equality rows)"}
+    out["planner_tape"] = {"what": "simple_joint_space_planner.py (280 variables) on the generic tape family, one block of wavefronts per instance; B = 256 perturbed problems",
+                           "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
+                           "path": {k: be.flag(k) for k in ("tape_wave", "tape_levels", "tape_passes")},
+                           "golden_instances": {"n": nb, "device_ms": ms4, "evaluations": [int(v) for v in r4.iters], "converged": bool((np.asarray(r4.status) == 0).all()),
+                                                "f_rel_diff_to_interior_point_golden": [float(abs(a - b) / b) for a, b in zip(r4.f, g["f"])]},
+                           "oracle_sample": grade}
+    be.close()
 
 
 def _config4(out, rng, sample):

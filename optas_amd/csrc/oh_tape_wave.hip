@@ -50,6 +50,20 @@ __device__ inline double wmax(double v) {
   for (int o = 32; o; o >>= 1) v = fmax(v, __shfl_xor(v, o));
   return v;
 }
+// Selector bits of the five operations that make up nine tenths of a trajectory tape, decoded on the host into the entry (a pass is bound by
+// the number of instructions one wavefront issues -- DESIGN 2.6 -- and compares / selects on the opcode, which the compiler turns back into
+// masked branches, were two thirds of them):
+//   value    = MUL ? va * (SQR ? va : vb) : (+-va) + (ZB ? 0 : +-vb)        add: 0 | sub: NEGB | mul: MUL | sqr: MUL SQR | neg: NEGA ZB
+//   adjoints = MUL ? (w * (SQR ? 2 va : vb), SQR ? 0 : w * va) : (+-w, ZB ? 0 : +-w)
+// applied with bit masks (v_bfi / v_xor), never with control flow.  RARE: every other operation, behind one wavefront-uniform test.
+constexpr int F_MUL = 1, F_SQR = 2, F_NEGA = 4, F_NEGB = 8, F_ZB = 16, F_RARE = 32;
+__device__ inline long long fmask(const unsigned f, const unsigned bit) { return (long long)(-(int)((f / bit) & 1u)); }  // all ones when the flag is set (bit: a power of two)
+__device__ inline double bsel(const long long m, const double a, const double b) {                         // m ? a : b
+  return __longlong_as_double((__double_as_longlong(a) & m) | (__double_as_longlong(b) & ~m));
+}
+__device__ inline double bflip(const double x, const long long m) { return __longlong_as_double(__double_as_longlong(x) ^ (m & (long long)0x8000000000000000ull)); }
+__device__ inline double bkeep(const double x, const long long m) { return __longlong_as_double(__double_as_longlong(x) & m); }  // m ? x : +0
+
 // Barrier between passes: LDS traffic only.  __syncthreads() waits for every outstanding memory operation of the wavefront (vmcnt(0)) -- including
 // the schedule entries requested for the passes ahead, which put a full L2 round trip back into every pass (measured: 460 ns per pass with
 // or without the prefetch).  Here only the LDS counter is drained; the compiler still waits for a prefetched entry where it is used.
@@ -106,11 +120,11 @@ struct WaveEval {
       const int o = ins.x >> OPSH, i = ins.x & ((1 << OPSH) - 1);
       {  // straight-line: an idle slot adds the zero register to itself into the trash register
         const double va = val[ins.y], vb = val[ins.z];
-        // the five operations that make up nine tenths of a trajectory tape without a branch (a switch on a per-lane value is a chain of ~20 masked
-        // sections whether or not any lane takes them); the rest behind one wavefront-uniform test
-        double v = (o == 5 || o == 12) ? va * (o == 12 ? va : vb) : (o == 7 ? -va : va + (o == 4 ? -vb : vb));
-        const bool rare = !(o == 3 || o == 4 || o == 5 || o == 7 || o == 12);
-        if (__builtin_amdgcn_ballot_w64(rare) != 0) {
+        const int fl = ins.w;
+        const long long mM = fmask(fl, F_MUL);
+        const double b2 = bsel(fmask(fl, F_SQR), va, vb);
+        double v = bsel(mM, va * b2, bflip(va, fmask(fl, F_NEGA)) + bkeep(bflip(b2, fmask(fl, F_NEGB)), ~fmask(fl, F_ZB)));
+        if (__builtin_amdgcn_ballot_w64((fl & F_RARE) != 0) != 0) {
           switch (o) {
             case 6: v = va / vb; break;
             case 8: v = sin(va); break;
@@ -171,21 +185,21 @@ struct WaveEval {
     auto rv_pass = [&](const int4 ins, const int4 meta) __attribute__((always_inline)) {
       const int o = ins.x >> OPSH, i = ins.x & ((1 << OPSH) - 1);
       {  // straight-line: absent consumers point at the zero register (val[0] = adj[0] = 0), idle slots write the trash register
-        const int nc = meta.x & 0xFFFF;
-        auto slot = [&](const int pk) { return (pk & 1) ? adj[pk >> 1] : val[pk >> 1]; };
-        const double sd = adj[i], s0 = slot(meta.y), s1 = slot(meta.z), s2 = slot(meta.w);
-        double w = (meta.x >> 16) ? sd : 0.0;
+        const int nc = meta.x & 0xFFFF, fl = meta.x >> 17;
+        // a consumer's slot is an index into [val | adj] (adj = val + n_reg), an absent one the zero register
+        const double sd = adj[i], s0 = val[meta.y], s1 = val[meta.z], s2 = val[meta.w];
+        double w = bkeep(sd, fmask(meta.x >> 16, 1));
         w += s0;
         w += s1;
         w += s2;
         if (__builtin_amdgcn_ballot_w64(nc > 3) != 0)
-          for (int e = 3; e < nc; ++e) w += slot(S.cons[ins.w + e - 3]);
+          for (int e = 3; e < nc; ++e) w += val[S.cons[ins.w + e - 3]];
         {
           const double va = val[ins.y], vb = val[ins.z];
-          const bool mulsq = o == 5 || o == 12;
-          double ca = mulsq ? w * (o == 12 ? 2.0 * va : vb) : (o == 7 ? -w : w);
-          double cb = o == 5 ? w * va : (o == 3 ? w : (o == 4 ? -w : 0.0));
-          const bool rare = !(o == 3 || o == 4 || o == 5 || o == 7 || o == 12);
+          const long long mM = fmask(fl, F_MUL), mS = fmask(fl, F_SQR);
+          double ca = bsel(mM, w * bsel(mS, va + va, vb), bflip(w, fmask(fl, F_NEGA)));
+          double cb = bsel(mM, bkeep(w * va, ~mS), bkeep(bflip(w, fmask(fl, F_NEGB)), ~fmask(fl, F_ZB)));
+          const bool rare = (fl & F_RARE) != 0;
           if (__builtin_amdgcn_ballot_w64(rare) != 0) {
             if (rare) { ca = 0.0; cb = 0.0; }
             switch (o) {
@@ -507,6 +521,7 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
   // ---- forward schedule
   std::vector<int4> fw;
   const int4 idle_entry{TRASH | (3 << OPSH), ZREG, ZREG, 0};  // trash = zero + zero
+  auto flags_of = [](int o) { return o == 3 ? 0 : o == 4 ? F_NEGB : o == 5 ? F_MUL : o == 12 ? (F_MUL | F_SQR) : o == 7 ? (F_NEGA | F_ZB) : F_RARE; };
   std::vector<std::vector<int>> by_level(n_lvl + 1);
   for (int i = 0; i < L; ++i)
     if (live[i] && op[i] >= 3) by_level[level[i]].push_back(i);
@@ -554,7 +569,7 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
   for (int l = 1; l <= n_lvl; ++l) {
     slots_of[l] = arrange(by_level[l]);
     for (int i : slots_of[l])
-      fw.push_back(i < 0 ? idle_entry : int4{reg[i] | (op[i] << OPSH), reg[a[i]], is_binary(op[i]) ? reg[b[i]] : 0, 0});
+      fw.push_back(i < 0 ? idle_entry : int4{reg[i] | (op[i] << OPSH), reg[a[i]], is_binary(op[i]) ? reg[b[i]] : 0, flags_of(op[i])});
   }
   // ---- consumers of every register that carries an adjoint, in the order the serial reverse sweep adds them (descending instruction index)
   std::vector<std::vector<int>> cons(n_reg);
@@ -586,8 +601,9 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
     const std::vector<int>& cl = cons[r];
     const int nc = (int)cl.size();
     rv.push_back(int4{r | (o << OPSH), ra, rb, (int)overflow.size()});
-    rv.push_back(int4{nc | ((seed_of[r] >= 0 ? 1 : 0) << 16), nc > 0 ? cl[0] : 0, nc > 1 ? cl[1] : 0, nc > 2 ? cl[2] : 0});
-    for (int e = 3; e < nc; ++e) overflow.push_back(cl[e]);
+    auto slot_index = [&](int pk) { return (pk >> 1) + (pk & 1) * n_reg; };  // into [val | adj]
+    rv.push_back(int4{nc | ((seed_of[r] >= 0 ? 1 : 0) << 16) | (flags_of(o) << 17), nc > 0 ? slot_index(cl[0]) : 0, nc > 1 ? slot_index(cl[1]) : 0, nc > 2 ? slot_index(cl[2]) : 0});
+    for (int e = 3; e < nc; ++e) overflow.push_back(slot_index(cl[e]));
   };
   for (int l = n_lvl; l >= 1; --l)
     for (int i : slots_of[l]) {

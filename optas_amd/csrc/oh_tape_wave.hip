@@ -40,16 +40,28 @@ struct WaveSchedDev {
   int n_fw_pass, n_rv_pass, n_cst, n_par, n_reg, nrows, n_seed, n_seed_rows, seed_cost, n_small;
 };
 
-__device__ inline double wsum(double v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+// Wavefront all-reduce, the same bits on every lane: four data-parallel-primitive steps inside a row of 16 lanes (neighbour, pair, mirrored half
+// row, mirrored row: a lane's partner computes the same commutative sum), then two cross-row exchanges.  (__shfl_xor is a ds_bpermute per 32-bit half
+// and step: twelve LDS-crossbar round trips per reduction where this needs four; the quasi-Newton step is ~30 reductions.)
+template <int CTRL>
+__device__ inline double dpp_mov(const double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <bool MAX>
+__device__ inline double wreduce(double v) {
+  auto op = [](double x, double y) { return MAX ? fmax(x, y) : x + y; };
+  v = op(v, dpp_mov<0xB1>(v));   // quad_perm [1, 0, 3, 2]
+  v = op(v, dpp_mov<0x4E>(v));   // quad_perm [2, 3, 0, 1]
+  v = op(v, dpp_mov<0x141>(v));  // row_half_mirror
+  v = op(v, dpp_mov<0x140>(v));  // row_mirror
+  v = op(v, __shfl_xor(v, 16));
+  v = op(v, __shfl_xor(v, 32));
   return v;
 }
-__device__ inline double wmax(double v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
-}
+__device__ inline double wsum(double v) { return wreduce<false>(v); }
+__device__ inline double wmax(double v) { return wreduce<true>(v); }
 // Selector bits of the five operations that make up nine tenths of a trajectory tape, decoded on the host into the entry (a pass is bound by
 // the number of instructions one wavefront issues -- DESIGN 2.6 -- and compares / selects on the opcode, which the compiler turns back into
 // masked branches, were two thirds of them):

@@ -364,7 +364,8 @@ int oh_solve(oh_handle* h, int B, const double* x0, const double* p, double* x, 
 /* Scheduling facts of a handle by name, for harnesses that report what ran: "fuse_couple" (1: the orientation-locked family's iteration is
    k_retract + k_evalb_zc + k_step_zc, the neighbour coupling folded in; 0: k_couple runs as a launch of its own), "tail_threshold",
    "specialized"; OH_PROBLEM_TAPE handles: "tape_wave" (0: one thread per instance; 1 / 2: one block of wavefronts per instance, the quasi-Newton
-   pairs in global memory / in LDS), "tape_levels" and "tape_passes" (dependency levels of the tape; instruction passes of one evaluation). */
+   pairs in global memory / in LDS), "tape_regs_lds" (1: the tape's registers of the last launch in LDS, 0: in global memory -- batches beyond 512 instances and tapes that do
+   not fit), "tape_levels" and "tape_passes" (dependency levels of the tape; instruction passes of one evaluation). */
 int oh_get_flag(oh_handle* h, const char* name, int* value);
 
 /* Largest B one oh_solve / oh_solve_device call of this handle takes (*out = 0: the library sets no bound of its own). */

@@ -160,7 +160,7 @@ class TapeBackend(_SolveMixin):
         return buf.value.decode(), int(size.value)
 
     def flag(self, name: str) -> int:
-        """oh_get_flag: 'tape_wave' (0 thread per instance, 1 / 2 wavefront per instance), 'tape_levels', 'tape_passes'."""
+        """oh_get_flag: 'tape_wave' (0 thread per instance, 1 / 2 wavefront per instance), 'tape_regs_lds', 'tape_levels', 'tape_passes'."""
         v = C.c_int(0)
         _lib.check(_lib.load().oh_get_flag(self._h, name.encode(), C.byref(v)), "oh_get_flag")
         return int(v.value)

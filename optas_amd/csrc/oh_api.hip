@@ -2023,6 +2023,7 @@ extern "C" int oh_get_flag(oh_handle* h, const char* name, int* value) {
   } else if (n == "tail_threshold") *value = h->tail_threshold;
   else if (n == "specialized") *value = h->spec ? 1 : 0;
   else if (n == "tape_wave") *value = h->tape_wave.ready ? (h->tape_wave.hist_lds ? 2 : 1) : 0;
+  else if (n == "tape_regs_lds") *value = h->tape_wave.ready && h->tape_wave.reg_lds ? 1 : 0;
   else if (n == "tape_levels") *value = h->tape_wave.n_levels;
   else if (n == "tape_passes") *value = h->tape_wave.n_fw_pass + h->tape_wave.n_rv_pass;
   else return fail(OH_ERR_INVALID, "oh_get_flag: unknown flag " + n);

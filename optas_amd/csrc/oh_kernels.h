@@ -152,14 +152,17 @@ struct TapeJit {
 };
 // wavefront-per-instance evaluator of trajectory-sized tapes (oh_tape_wave.hip): the level schedule built when the handle is created
 struct TapeWave {
-  bool ready = false, hist_lds = false;
+  bool ready = false, hist_lds = false, reg_lds = true;  // placement of the last launch: the quasi-Newton pairs / the tape's registers in LDS or in global memory
+  bool reg_lds_fits = false, hist_lds_by[2] = {false, false};  // by placement of the registers: [0] global memory, [1] LDS
+  size_t lds_bytes_by[2] = {0, 0};
+  int reg_choice = -1;  // OH_TAPE_WAVE_REGS: -1 by batch size, 0 global, 1 lds
   int nt = 256;  // threads per instance
   int n_reg = 0, n_fw_pass = 0, n_rv_pass = 0, n_cst = 0, n_par = 0, n_seed = 0, n_seed_rows = 0, seed_cost = -1, n_small = 0, n_levels = 0;
   size_t lds_bytes = 0;
   int4 *d_fw = nullptr, *d_rv = nullptr;
   int *d_cons = nullptr, *d_cst_reg = nullptr, *d_par_reg = nullptr, *d_par_k = nullptr, *d_small = nullptr;
-  double *d_cst_val = nullptr, *d_hist = nullptr;
-  int hist_cap = 0;
+  double *d_cst_val = nullptr, *d_hist = nullptr, *d_regs = nullptr;
+  int hist_cap = 0, regs_cap = 0;
 };
 int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, size_t lds_limit, TapeWave* out,
                        std::string* err);

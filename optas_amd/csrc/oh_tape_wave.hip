@@ -107,7 +107,7 @@ struct Red {
   __device__ double max(double v) { return run<true>(v); }
 };
 
-template <int NT>
+template <int NT, bool REG_LDS>
 struct WaveEval {
   const TapeParams& T;
   const WaveSchedDev& S;
@@ -115,6 +115,11 @@ struct WaveEval {
   const int *row_reg, *seed_reg, *seed_off, *seed_rows;
   const int lane;  // thread of the block
   Red<NT>& red;
+
+  // registers in LDS: only the LDS counter is drained between passes; registers in global memory (tapes too big for the LDS): the full barrier
+  __device__ static inline void pass_barrier() {
+    if constexpr (REG_LDS) lds_barrier(); else __syncthreads();
+  }
 
   // merit value at xs, its gradient into gout (both LDS, element k anywhere); rows into rowv.  Uniform return values.
   __device__ __attribute__((always_inline)) double phi(const double* xs, double* gout, const double rho, double* fout, double* cmax, double* meas) {
@@ -127,7 +132,7 @@ struct WaveEval {
     auto fwi = [&](int p) { return S.fw[(size_t)(p < last ? p : last) * NT + lane]; };
     int4 q0 = fwi(0), q1 = fwi(1), q2 = fwi(2), q3 = fwi(3);
     for (int k = lane; k < T.nx; k += NT) val[XREG0 + k] = xs[k];  // the variables' registers: 2 .. 2 + nx
-    lds_barrier();
+    pass_barrier();
     auto fw_pass = [&](const int4 ins) __attribute__((always_inline)) {
       const int o = ins.x >> OPSH, i = ins.x & ((1 << OPSH) - 1);
       {  // straight-line: an idle slot adds the zero register to itself into the trash register
@@ -160,7 +165,7 @@ struct WaveEval {
         }
         val[i] = v;
       }
-      lds_barrier();
+      pass_barrier();
     };
     for (int p = 0; p < S.n_fw_pass; p += 4) {
       const int4 i0 = q0;
@@ -232,7 +237,7 @@ struct WaveEval {
           adj[i] = cb;
         }
       }
-      lds_barrier();
+      pass_barrier();
     };
     for (int p = 0; p < S.n_rv_pass; p += 4) {
       const int4 x0 = a0, y0 = b0;
@@ -258,17 +263,24 @@ struct WaveEval {
   }
 };
 
-template <int NT, bool HIST_LDS>
+template <int NT, bool HIST_LDS, bool REG_LDS>
 __global__ __launch_bounds__(NT) void k_tape_wave(TapeParams T, WaveSchedDev S, int B, const double* __restrict__ x0, const double* __restrict__ par,
-                                                  double* __restrict__ hist_g, double* __restrict__ xo, double* __restrict__ fo, double* __restrict__ kkt,
+                                                  double* __restrict__ hist_g, double* regs_g, double* __restrict__ xo, double* __restrict__ fo, double* __restrict__ kkt,
                                                   int* __restrict__ iters, int* __restrict__ status, double* __restrict__ mult) {
   extern __shared__ double lds[];
   const int gb = blockIdx.x, lane = threadIdx.x;
   if (gb >= B) return;
   const int n = T.nx, m = T.lbfgs, ni = T.n_ineq, ne = T.n_eq;
-  double* val = lds;
-  double* adj = val + S.n_reg;
-  double* X = adj + S.n_reg;
+  double *val, *adj, *X;
+  if constexpr (REG_LDS) {
+    val = lds;
+    adj = val + S.n_reg;
+    X = adj + S.n_reg;
+  } else {  // a register file beyond the LDS: [val | adj] of this instance in global memory (the block's own lines, L2 / L1 resident)
+    val = regs_g + (size_t)gb * 2 * S.n_reg;
+    adj = val + S.n_reg;
+    X = lds;
+  }
   double* XT = X + n;
   double* G = XT + n;
   double* GT = G + n;
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(NT) void k_tape_wave(TapeParams T, WaveSchedDev S, 
   for (int i = lane; i < ne; i += NT) mu[i] = 0.0;
   __syncthreads();
   Red<NT> red{redbuf};
-  WaveEval<NT> ev{T, S, val, adj, lam, mu, rowv, roww, row_reg, seed_reg, seed_off, seed_rows, lane, red};
+  WaveEval<NT, REG_LDS> ev{T, S, val, adj, lam, mu, rowv, roww, row_reg, seed_reg, seed_off, seed_rows, lane, red};
 
   auto Sr = [&](int slot, int k) -> double& { return Hs[(size_t)slot * n + k]; };
   auto Yr = [&](int slot, int k) -> double& { return Hs[(size_t)(m + slot) * n + k]; };
@@ -483,9 +495,9 @@ int upload(V** dst, const std::vector<V>& src) {
 
 }  // namespace
 
-size_t oh_tape_wave_lds_bytes(const TapeParams& T, const TapeWave& W, bool hist_lds) {
+size_t oh_tape_wave_lds_bytes(const TapeParams& T, const TapeWave& W, bool hist_lds, bool reg_lds) {
   const size_t nrows = T.n_ineq + T.n_eq;
-  size_t d = 2 * (size_t)W.n_reg + 5 * (size_t)T.nx + (T.n_ineq > 0 ? T.n_ineq : 1) + (T.n_eq > 0 ? T.n_eq : 1) + 2 * (nrows > 0 ? nrows : 1) + 2 * (size_t)T.lbfgs + 8;
+  size_t d = (reg_lds ? 2 * (size_t)W.n_reg : 0) + 5 * (size_t)T.nx + (T.n_ineq > 0 ? T.n_ineq : 1) + (T.n_eq > 0 ? T.n_eq : 1) + 2 * (nrows > 0 ? nrows : 1) + 2 * (size_t)T.lbfgs + 8;
   if (hist_lds) d += 2 * (size_t)T.lbfgs * T.nx;
   return d * sizeof(double) + sizeof(int) * (((size_t)W.n_small + 1) & ~(size_t)1);
 }
@@ -663,22 +675,41 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
   out->seed_cost = seed_cost;
   out->n_small = (int)small.size();
   out->n_levels = n_lvl;
-  if (oh_tape_wave_lds_bytes(T, *out, false) > lds_limit) return 0;  // the register file itself does not fit: the thread-per-instance path stays
+  // Placement of the register file, decided per launch: in LDS (one block per CU: the lowest latency) for small batches, in global memory
+  // (the block's own lines; the LDS then holds the vectors and the pairs only: two or more blocks per CU) for large ones and for tapes whose
+  // registers do not fit -- the planner: 4 instances 96 / 125 ms, 4096 instances 1.99 / 1.60 s.  Same arithmetic, same bits either way.
+  const char* er = getenv("OH_TAPE_WAVE_REGS");  // "global" / "lds": force one placement
+  out->reg_choice = er ? (er[0] == 'g' ? 0 : 1) : -1;
+  out->reg_lds_fits = oh_tape_wave_lds_bytes(T, *out, false, true) <= lds_limit;
+  const bool global_ok = NT == 256 && oh_tape_wave_lds_bytes(T, *out, false, false) <= lds_limit;  // (the global-memory placement is built for four wavefronts)
+  if (!out->reg_lds_fits && !global_ok) return 0;  // not even the vectors fit: the thread-per-instance path stays
+  if (!global_ok) out->reg_choice = 1;
+  if (!out->reg_lds_fits) out->reg_choice = 0;
   const char* eh = getenv("OH_TAPE_WAVE_HIST");  // "global": keep the (s, y) pairs out of the LDS even when they fit (the path big problems take)
-  out->hist_lds = oh_tape_wave_lds_bytes(T, *out, true) <= lds_limit && !(eh && eh[0] == 'g');
-  out->lds_bytes = oh_tape_wave_lds_bytes(T, *out, out->hist_lds);
+  for (int rl = 0; rl < 2; ++rl) {
+    out->hist_lds_by[rl] = oh_tape_wave_lds_bytes(T, *out, true, rl == 1) <= lds_limit && !(eh && eh[0] == 'g');
+    out->lds_bytes_by[rl] = oh_tape_wave_lds_bytes(T, *out, out->hist_lds_by[rl], rl == 1);
+  }
+  out->reg_lds = out->reg_choice != 0;
+  out->hist_lds = out->hist_lds_by[out->reg_lds ? 1 : 0];
+  out->lds_bytes = out->lds_bytes_by[out->reg_lds ? 1 : 0];
   if (upload(&out->d_fw, fw) || upload(&out->d_rv, rv) || upload(&out->d_cons, overflow) || upload(&out->d_cst_reg, cst_reg) ||
       upload(&out->d_cst_val, cst_val) || upload(&out->d_par_reg, par_reg) || upload(&out->d_par_k, par_k) || upload(&out->d_small, small)) {
     oh_tape_wave_release(out);
     *err = "allocation of the wavefront schedule failed";
     return 1;
   }
-  const void* fn = NT == 64 ? (out->hist_lds ? reinterpret_cast<const void*>(k_tape_wave<64, true>) : reinterpret_cast<const void*>(k_tape_wave<64, false>))
-                            : (out->hist_lds ? reinterpret_cast<const void*>(k_tape_wave<256, true>) : reinterpret_cast<const void*>(k_tape_wave<256, false>));
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)out->lds_bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    oh_tape_wave_release(out);
-    return 0;
+  for (int rl = 0; rl < 2; ++rl) {
+    if ((rl == 1 && !out->reg_lds_fits) || (rl == 0 && !global_ok)) continue;
+    const bool hl = out->hist_lds_by[rl];
+    const void* fn = rl == 0     ? (hl ? reinterpret_cast<const void*>(k_tape_wave<256, true, false>) : reinterpret_cast<const void*>(k_tape_wave<256, false, false>))
+                     : NT == 64  ? (hl ? reinterpret_cast<const void*>(k_tape_wave<64, true, true>) : reinterpret_cast<const void*>(k_tape_wave<64, false, true>))
+                                 : (hl ? reinterpret_cast<const void*>(k_tape_wave<256, true, true>) : reinterpret_cast<const void*>(k_tape_wave<256, false, true>));
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)out->lds_bytes_by[rl]) != hipSuccess) {
+      (void)hipGetLastError();
+      oh_tape_wave_release(out);
+      return 0;
+    }
   }
   out->ready = true;
   return 0;
@@ -686,13 +717,27 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
 
 void oh_tape_wave_release(TapeWave* w) {
   for (void* p : {(void*)w->d_fw, (void*)w->d_rv, (void*)w->d_cons, (void*)w->d_cst_reg, (void*)w->d_cst_val, (void*)w->d_par_reg, (void*)w->d_par_k,
-                  (void*)w->d_small, (void*)w->d_hist})
+                  (void*)w->d_small, (void*)w->d_hist, (void*)w->d_regs})
     if (p) hipFree(p);
   *w = TapeWave{};
 }
 
 hipError_t oh_launch_tape_wave(hipStream_t s, TapeWave& W, const TapeParams& T, int B, const double* x0, const double* p, double* x, double* f, double* kkt,
                                int* iters, int* status, double* mult) {
+  WaveSchedDev S{W.d_fw, W.d_rv, W.d_cons, W.d_cst_reg, W.d_cst_val, W.d_par_reg, W.d_par_k, W.d_small, W.n_fw_pass, W.n_rv_pass, W.n_cst, W.n_par, W.n_reg,
+                 T.n_ineq + T.n_eq, W.n_seed, W.n_seed_rows, W.seed_cost, W.n_small};
+  // registers in LDS up to two instances per CU's worth of batch, in global memory beyond (OH_TAPE_WAVE_REGS forces one)
+  W.reg_lds = W.reg_choice >= 0 ? W.reg_choice == 1 : B <= 512;
+  W.hist_lds = W.hist_lds_by[W.reg_lds ? 1 : 0];
+  W.lds_bytes = W.lds_bytes_by[W.reg_lds ? 1 : 0];
+  if (!W.reg_lds && B > W.regs_cap) {
+    if (W.d_regs) hipFree(W.d_regs);
+    W.d_regs = nullptr;
+    W.regs_cap = 0;
+    const hipError_t e = hipMalloc((void**)&W.d_regs, sizeof(double) * 2 * (size_t)W.n_reg * B);
+    if (e != hipSuccess) return e;
+    W.regs_cap = B;
+  }
   if (!W.hist_lds && B > W.hist_cap) {
     if (W.d_hist) hipFree(W.d_hist);
     W.d_hist = nullptr;
@@ -701,12 +746,12 @@ hipError_t oh_launch_tape_wave(hipStream_t s, TapeWave& W, const TapeParams& T, 
     if (e != hipSuccess) return e;
     W.hist_cap = B;
   }
-  WaveSchedDev S{W.d_fw, W.d_rv, W.d_cons, W.d_cst_reg, W.d_cst_val, W.d_par_reg, W.d_par_k, W.d_small, W.n_fw_pass, W.n_rv_pass, W.n_cst, W.n_par, W.n_reg,
-                 T.n_ineq + T.n_eq, W.n_seed, W.n_seed_rows, W.seed_cost, W.n_small};
   double* hg = W.hist_lds ? nullptr : W.d_hist;
-  if (W.nt == 64 && W.hist_lds) hipLaunchKernelGGL((k_tape_wave<64, true>), dim3(B), dim3(64), W.lds_bytes, s, T, S, B, x0, p, hg, x, f, kkt, iters, status, mult);
-  else if (W.nt == 64) hipLaunchKernelGGL((k_tape_wave<64, false>), dim3(B), dim3(64), W.lds_bytes, s, T, S, B, x0, p, hg, x, f, kkt, iters, status, mult);
-  else if (W.hist_lds) hipLaunchKernelGGL((k_tape_wave<256, true>), dim3(B), dim3(256), W.lds_bytes, s, T, S, B, x0, p, hg, x, f, kkt, iters, status, mult);
-  else hipLaunchKernelGGL((k_tape_wave<256, false>), dim3(B), dim3(256), W.lds_bytes, s, T, S, B, x0, p, hg, x, f, kkt, iters, status, mult);
+  double* rg = W.reg_lds ? nullptr : W.d_regs;
+#define OH_TW_LAUNCH(NTv, Hv, Rv) hipLaunchKernelGGL((k_tape_wave<NTv, Hv, Rv>), dim3(B), dim3(NTv), W.lds_bytes, s, T, S, B, x0, p, hg, rg, x, f, kkt, iters, status, mult)
+  if (!W.reg_lds) { if (W.hist_lds) OH_TW_LAUNCH(256, true, false); else OH_TW_LAUNCH(256, false, false); }
+  else if (W.nt == 64) { if (W.hist_lds) OH_TW_LAUNCH(64, true, true); else OH_TW_LAUNCH(64, false, true); }
+  else { if (W.hist_lds) OH_TW_LAUNCH(256, true, true); else OH_TW_LAUNCH(256, false, true); }
+#undef OH_TW_LAUNCH
   return hipGetLastError();
 }

@@ -70,7 +70,7 @@ def test_rebalanced_sums_are_the_same_problem_at_a_fraction_of_the_depth():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["nt256", "nt64", "pairs_in_global_memory"])
+@pytest.mark.parametrize("variant", ["nt256", "nt64", "pairs_in_global_memory", "registers_in_global_memory"])
 def test_wavefront_path_matches_thread_path_and_port_on_ik(hip_lib, monkeypatch, variant):
     from examples.example import setup_solver as ik
     from optas_amd.backend import TapeBackend
@@ -82,8 +82,11 @@ def test_wavefront_path_matches_thread_path_and_port_on_ik(hip_lib, monkeypatch,
         monkeypatch.setenv("OH_TAPE_WAVE_NT", "64")  # one wavefront per instance
     if variant == "pairs_in_global_memory":
         monkeypatch.setenv("OH_TAPE_WAVE_HIST", "global")  # what a problem whose (s, y) pairs do not fit the LDS beside its registers takes
+    if variant == "registers_in_global_memory":
+        monkeypatch.setenv("OH_TAPE_WAVE_REGS", "global")  # what a tape whose live registers do not fit the LDS takes
     wave = TapeBackend(tp, jit=False)
     assert wave.flag("tape_wave") == (1 if variant == "pairs_in_global_memory" else 2) and wave.flag("tape_levels") > 5
+    assert wave.flag("tape_regs_lds") == (0 if variant == "registers_in_global_memory" else 1)
     monkeypatch.setenv("OH_TAPE_WAVE", "0")
     thread = TapeBackend(tp, jit=False)
     assert thread.flag("tape_wave") == 0
@@ -103,6 +106,13 @@ def test_wavefront_path_matches_thread_path_and_port_on_ik(hip_lib, monkeypatch,
     for i in (3, 11):
         alone = wave.solve(g["x0"][i : i + 1], g["p"][i : i + 1])
         assert np.array_equal(alone.x[0], rw.x[i]) and alone.iters[0] == rw.iters[i] and alone.f[0] == rw.f[i]
+    if variant == "nt256":  # beyond 512 instances the registers move to global memory (two blocks per CU): the same bits
+        nb = len(g["p"])
+        k = 640 // nb + 1
+        big = wave.solve(np.tile(g["x0"], (k, 1)), np.tile(g["p"], (k, 1)))
+        assert wave.flag("tape_regs_lds") == 0
+        assert np.array_equal(big.x[:nb], rw.x) and np.array_equal(big.x[-nb:], rw.x) and np.array_equal(big.iters[:nb], rw.iters) and np.array_equal(big.f[-nb:], rw.f)
+        assert wave.solve(g["x0"], g["p"]).iters.tolist() == rw.iters.tolist() and wave.flag("tape_regs_lds") == 1
     # edge: every variable pinned by its start (max_iter 1): one evaluation, MAX_ITER, the seed comes back
     one = TapeBackend.__new__(TapeBackend)
     monkeypatch.delenv("OH_TAPE_WAVE")

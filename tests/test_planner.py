@@ -88,3 +88,28 @@ def test_planner_through_hipsolver_against_the_interior_point_goldens(hip_lib):
         assert np.abs(nlp.a(x, P[b])).max() <= 1e-8 and np.abs(nlp.h(x, P[b])).max() <= 1e-8 and nlp.g(x, P[b]).min() >= -1e-9
         assert np.abs(x - g["x"][b]).max() <= 2e-3
     print("planner: tape evaluations per solve", st["iter_count"] if "iter_count" in st else solver.number_of_iterations())
+
+
+@pytest.mark.gpu
+def test_longer_horizon_whose_registers_do_not_fit_the_lds(hip_lib):
+    """T = 60: 840 variables, 10 637 live registers -- beyond the LDS.  The wavefront-per-instance path keeps the register file in global memory
+    (no environment variable involved) and converges; the rows of the literal problem (the mirror's own functions) hold at the answer, and the
+    objective is below the T = 20 plan's scaled by the knot count (a sanity bound, not a golden: the reference holds none)."""
+    from examples.simple_joint_space_planner import setup_solver
+
+    g = np.load(os.path.join(GOLDEN, "planner_golden.npz"))
+    T = 60
+    robot, solver = setup_solver(T=T, solver_options={"max_iter": 2000000})
+    name = robot.get_name()
+    P = g["p"][:2]
+    solver.reset_parameters_batch({"nominal_joint_state": P[:, :7], "current_joint_state": P[:, 7:14], "position_goal": P[:, 14:17], "orientation_goal": P[:, 17:]})
+    solver.reset_initial_seed_batch({f"{name}/q/x": np.stack([np.tile(g["q0"].reshape(-1, 1), (1, T))] * len(P))})
+    sols = solver.solve_batch()
+    st = solver.stats()
+    assert st["success"], st["status"]
+    be, o = solver.backend, solver.opt
+    assert o.nx == 840 and be.flag("tape_wave") >= 1 and be.flag("tape_regs_lds") == 0 and be.flag("tape_levels") <= 24
+    for b in range(len(P)):
+        x = o.decision_variables.dict2vec(sols[b])
+        assert np.abs(o.a(x, P[b])).max() <= 1e-8 and np.abs(o.h(x, P[b])).max() <= 1e-8 and o.g(x, P[b]).min() >= -1e-9
+        assert abs(o.f(x, P[b]) - st["f"][b]) <= 1e-9 * max(1.0, abs(st["f"][b])) and st["f"][b] < 3.5 * g["f"][b]

@@ -274,10 +274,20 @@ def main():
                           "id_sha256": hashlib.sha256(uid).hexdigest(), "id_bytes": len(uid), "qc_first": qc[0].tolist(), "nx": int(x0.shape[1])}), flush=True)
         return
     comm = None
-    if world > 1 or ("RANK" in os.environ and os.environ.get("OH_BENCH_DIST_AT_1", "1") == "1"):  # launcher-started: one rank per GPU
+    rccl_error = None
+    if world > 1 or "RANK" in os.environ:  # launcher-started: one rank per GPU
         from optas_amd import distributed as oad
 
         comm = oad.init_from_env()  # oh_set_device(local_rank) + RCCL communicator inside liboptas_hip
+    elif os.environ.get("OH_BENCH_DIST_AT_1", "1") == "1":
+        # plain `python bench.py`: the same path at the size there is -- a communicator of one rank, the broadcast of the constants through it
+        # (round-4 verdict, Next 8).  A box without a usable librccl still measures the solves: the reason is reported, the line says rccl_world null.
+        from optas_amd import distributed as oad
+
+        try:
+            comm = oad.Communicator(0, 1, local_rank)
+        except Exception as e:  # noqa: BLE001
+            comm, rccl_error = None, f"{type(e).__name__}: {e}"
     lib = _lib.load()
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: liboptas_hip has no CPU path")
@@ -487,6 +497,7 @@ def main():
             "T": T,
             "parallelism": f"dp{world} (instances sharded, one RCCL broadcast of constants)",
             "rccl_world": rccl_world,
+            **({"rccl_error": rccl_error} if rccl_error else {}),
             "per_rank": per_rank,
             "hessian": args.hessian,
         },

@@ -48,6 +48,34 @@ def obstacle_parameters(link_radius=0.15, obstacle_radius=0.1):
     return p
 
 
+NOMINAL_QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])  # dual_arm.py:185
+
+
+def initial_clearance(arm, qc, link_radius=0.15, obstacle_radius=0.1):
+    """Smallest sphere-clearance row of knot 0, ||c_l(qc) - o_j||^2 - (r_l + r_j)^2 over the sphere links and obstacles of the synthetic
+    config 4, for each row of qc (B, ndof).  q_0 = qc is pinned by fix_configuration (builder.py:525-539), so these rows are constants of the
+    instance: a negative one means the NLP as posed has no feasible point."""
+    qc = np.atleast_2d(np.asarray(qc, dtype=np.float64))
+    obs = np.array([[0.55, 0.0, 0.1 * (i + 1)] for i in range(N_OBSTACLES)])
+    worst = np.full(len(qc), np.inf)
+    for ln in SPHERE_LINKS:
+        c = np.asarray(arm.get_global_link_position(ln, qc.T)).T  # (B, 3)
+        d2 = ((c[:, None, :] - obs[None]) ** 2).sum(-1)
+        worst = np.minimum(worst, (d2 - (link_radius + obstacle_radius) ** 2).min(1))
+    return worst
+
+
+def draw_feasible_configurations(rng, B, arm, link_radius=0.15, obstacle_radius=0.1, spread=0.1, margin=0.0):
+    """SURVEY 8(d) C4's perturbed initial configurations qc = nominal + U(-spread, spread)^7, drawn by rejection so that every instance is feasible
+    as posed (the way SURVEY C3 rejects point-mass starts inside the obstacle): at link radius 0.15 the nominal configuration has 1.6 mm of
+    clearance and about four draws in five pin q_0 inside one."""
+    out = np.empty((0, arm.ndof))
+    while len(out) < B:
+        cand = NOMINAL_QC + rng.uniform(-spread, spread, (max(64, 6 * (B - len(out))), arm.ndof))
+        out = np.concatenate([out, cand[initial_clearance(arm, cand, link_radius, obstacle_radius) > margin]])
+    return np.ascontiguousarray(out[:B])
+
+
 def setup_solver(T=50, Tmax=10.0, solver_options=None, build_only=False, limits=False, collision=False, velocity_limits=None):
     link_ee = "end_effector_ball"
     t = np.linspace(0, Tmax, T)

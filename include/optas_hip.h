@@ -41,7 +41,14 @@ enum {
 enum {
   OH_STATUS_CONVERGED = 0,
   OH_STATUS_MAX_ITER = 1,
-  OH_STATUS_NUMERICAL = 2
+  OH_STATUS_NUMERICAL = 2,
+  /* the instance has no feasible point: an inequality row that depends on the parameters alone (a limit or sphere-clearance row of a knot that
+     the equality rows pin to qc) is negative beyond tol_feas.  IPOPT can only report such a problem (solver.py:407-412 -> did_solve() False,
+     :133-134 raises under error_on_fail).  x is the optimum with those rows left out, kkt[1] includes their violation. */
+  OH_STATUS_INFEASIBLE = 3,
+  /* torque-MPC family: the acceptable level (IPOPT's Solved_To_Acceptable_Level, which the reference also counts as success, solver.py:407-412):
+     stall_max steps at the floor of the barrier parameter with the gradient within 10 tol.  did_solve() is True; kkt[0] holds the value. */
+  OH_STATUS_ACCEPTABLE = 4
 };
 
 /* problem families that have been lowered to kernels */

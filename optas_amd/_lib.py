@@ -19,7 +19,22 @@ OH_MAX_OBSTACLES = 16
 OH_COMM_ID_BYTES = 128
 
 OH_OK, OH_ERR_INVALID, OH_ERR_HIP, OH_ERR_STATE = 0, 1, 2, 3
-OH_STATUS_CONVERGED, OH_STATUS_MAX_ITER, OH_STATUS_NUMERICAL = 0, 1, 2
+OH_STATUS_CONVERGED, OH_STATUS_MAX_ITER, OH_STATUS_NUMERICAL, OH_STATUS_INFEASIBLE, OH_STATUS_ACCEPTABLE = 0, 1, 2, 3, 4
+# IPOPT's names for the same outcomes (what CasADiSolver.stats()["return_status"] holds, solver.py:407-412)
+STATUS_NAMES = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Numerical_Failure", 3: "Infeasible_Problem_Detected", 4: "Solved_To_Acceptable_Level"}
+_SEVERITY = np.array([0, 2, 3, 4, 1])  # by status code: converged < acceptable < iteration cap < numerical < infeasible
+
+
+def status_ok(status) -> np.ndarray:
+    """did_solve() per instance: converged, or solved to the acceptable level (both are successes for the reference, solver.py:407-412)."""
+    status = np.asarray(status)
+    return (status == OH_STATUS_CONVERGED) | (status == OH_STATUS_ACCEPTABLE)
+
+
+def worse_status(a, b) -> np.ndarray:
+    """Status of a problem made of independent parts (dual_arm.py: one handle per arm): the graver of the two."""
+    a, b = np.asarray(a), np.asarray(b)
+    return np.where(_SEVERITY[a] >= _SEVERITY[b], a, b).astype(np.int32)
 OH_PROBLEM_KINEMATICS = 0
 OH_PROBLEM_FIGURE_EIGHT = 1
 OH_PROBLEM_POINT_MASS_MPC = 2

@@ -575,7 +575,7 @@ class MultiArmBackend:
             f += r.f
             kkt = np.maximum(kkt, r.kkt)
             iters = np.maximum(iters, r.iters)
-            status = np.maximum(status, r.status)
+            status = _lib.worse_status(status, r.status)
         return BatchResult(x, f, kkt, iters, status)
 
     def solve_ms(self) -> float:

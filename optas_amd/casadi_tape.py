@@ -262,7 +262,7 @@ def make_solver_class(solver_module, cs):
             x0 = np.asarray(self.x0, dtype=np.float64).reshape(1, -1)
             p = np.asarray(self.p, dtype=np.float64).reshape(1, -1)
             r = self._backend.solve(x0, p)
-            self._stats = {"status": int(r.status[0]), "success": bool(r.status[0] == 0), "iter_count": int(r.iters[0]), "f": float(r.f[0]),
+            self._stats = {"status": int(r.status[0]), "success": bool(_lib.status_ok(r.status[0])), "iter_count": int(r.iters[0]), "f": float(r.f[0]),
                            "kkt": [float(v) for v in r.kkt[0]], "family": self._family,
                            "solve_ms": self._backend.solve_ms() if hasattr(self._backend, "solve_ms") else self._backend.timing()["solve_ms"]}
             return cs.DM(r.x[0])

@@ -1382,6 +1382,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   oh_launch_finalize(s, N, h->P, h->D, 0, ox, of, ok, oi, os);
   if (guarded) oh_launch_guard_emit(s, h->P, h->D, h->GP, h->GB, NV, 0);
   h->D.B = B;
+  if (guarded) oh_launch_guard_infeasible(s, N, h->P, h->D, h->GP, (const double*)d_p, B, ok, os);  // constant rows of the pinned knots
   HIPCHK(hipEventRecord(h->ev1, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());

@@ -1856,3 +1856,67 @@ void oh_launch_guard_compact(hipStream_t s, const FigParams& P, const FigBuffers
   if (phase == 0) hipLaunchKernelGGL(k_guard_gather, dim3((D.B + 255) / 256, P.T), dim3(256), 0, s, P, D, GP, GB, NV);
   else hipLaunchKernelGGL(k_guard_scatter, dim3((Bnew + 255) / 256, P.T), dim3(256), 0, s, P, D, GP, GB, NV, Bnew);
 }
+
+// ---- rows no iterate can change (round 5) ---------------------------------------------------------------------------------------------
+// The knots t < t0 are pinned by linear equality rows (q_0 = qc, and q_1 = qc when dq_0 is fixed too), so the inequality rows the builder
+// writes for them -- limits (builder.py:471-509), sphere clearances (:366-417), velocity limits on dq_0 = 0 -- are functions of the
+// parameters alone.  The kernels leave them out of the iteration; an instance in which one of them is negative has an empty feasible set.
+// The reference reports that as did_solve() == False (solver.py:407-412: IPOPT's return_status is not a success) and raises under
+// error_on_fail (:133-134).  One thread per instance of the ORIGINAL batch, after the last k_finalize: status <- OH_STATUS_INFEASIBLE,
+// kkt[1] <- the worst such row (the literal form's feasibility residual includes it).
+__global__ __launch_bounds__(64) void k_guard_infeasible(FigParams P, const oh_chain* __restrict__ ch, GuardParams GP, const double* __restrict__ pin,
+                                                         const int B, const int n, double* __restrict__ kkt, int* __restrict__ status) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* __restrict__ pr = pin + (size_t)b * P.np;
+  double worst = 0.0;  // most negative constant row
+  if (GP.limits)
+    for (int j = 0; j < n; ++j) worst = fmin(worst, fmin(pr[j] - GP.lo[j], GP.up[j] - pr[j]));
+  if (GP.vel && P.t0 >= 2)  // dq_0 = 0
+    for (int j = 0; j < n; ++j) worst = fmin(worst, fmin(0.0 - GP.vlo[j], GP.vup[j] - 0.0));
+  if (GP.n_links > 0) {
+    double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0}, p[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < n; ++k) {
+      double tv[3], zk[3];
+      mv3(R, ch->p0[k], tv);
+      p[0] += tv[0]; p[1] += tv[1]; p[2] += tv[2];
+      if (!ch->r0ident[k]) {
+        double Rn[9];
+        mm3(R, ch->R0[k], Rn);
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+      }
+      const double qk = pr[ch->qidx[k]];
+      if (ch->jtype[k] == 0) {
+        double sn, cs;
+        sincos_joint(qk, &sn, &cs);
+        const int code = ch->axcode[k];
+        if (code != 0) rot_principal_right(R, code, sn, cs, zk);
+        else rot_axis_right(R, ch->axis[k], sn, cs, zk);
+      } else {
+        mv3(R, ch->axis[k], zk);
+        p[0] += zk[0] * qk; p[1] += zk[1] * qk; p[2] += zk[2] * qk;
+      }
+      for (int l = 0; l < GP.n_links; ++l) {
+        if (GP.link_joint[l] != k) continue;
+        double c[3];
+        mv3(R, GP.link_off[l], c);
+        c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
+        const double rl = pr[n + l];
+        for (int o = 0; o < GP.n_obs; ++o) {
+          const double* ob = pr + n + GP.n_links + 4 * o;
+          const double d[3] = {c[0] - ob[0], c[1] - ob[1], c[2] - ob[2]};
+          const double rr = rl + ob[3];
+          worst = fmin(worst, dot3(d, d) - rr * rr);
+        }
+      }
+    }
+  }
+  if (worst < -P.tol_feas) {
+    if (status) status[b] = OH_STATUS_INFEASIBLE;
+    if (kkt) kkt[3 * (size_t)b + 1] = fmax(kkt[3 * (size_t)b + 1], -worst);
+  }
+}
+void oh_launch_guard_infeasible(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const double* p, int B, double* kkt, int* status) {
+  if (!kkt && !status) return;
+  hipLaunchKernelGGL(k_guard_infeasible, dim3((B + 63) / 64), dim3(64), 0, s, P, D.chain, GP, p, B, n, kkt, status);
+}

@@ -31,6 +31,7 @@ bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBu
 bool oh_launch_couple_free_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
 bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot, bool pcr = false);  // pcr: one block per instance
 bool oh_launch_setup_guards(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const double* p);
+void oh_launch_guard_infeasible(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const double* p, int B, double* kkt, int* status);
 bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
 bool oh_launch_free_persist(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB);  // whole solve, one block per instance
 bool oh_launch_step_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot,

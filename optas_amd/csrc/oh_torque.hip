@@ -1865,7 +1865,7 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
           // meeting tol while within ten times of it -- the arithmetic floor of the reduced gradient: an active row with slack s carries mu_b / s,
           // and s = up - tau inherits the ~1e-14 of the recursion, so at s ~ 1e-8 the multiplier is good to ~1e-6 relative and the reduced gradient to
           // ~1e-6 absolute.  Without this such an instance (1 of 8192 in one of nine batches) fed the watchdog below and ended NUMERICAL at the optimum.
-          status = OH_STATUS_CONVERGED;
+          status = OH_STATUS_ACCEPTABLE;
           iters -= 1;
           do_roll = false;
           do_gains = false;

@@ -115,9 +115,12 @@ def exchange_unique_id(rank: int, world: int, make_id: Callable[[], bytes], path
     t0 = time.monotonic()
     seen_stale = False
     want = _lib.OH_COMM_ID_BYTES + _REC.size
+    checked = False
     while True:
         try:
-            _check_private(os.path.dirname(path) or ".")
+            if not checked and os.path.isdir(os.path.dirname(path) or "."):  # once, as soon as the directory exists (not on every poll)
+                _check_private(os.path.dirname(path) or ".")
+                checked = True
             with open(path, "rb") as fh:
                 if os.fstat(fh.fileno()).st_uid != os.getuid():
                     raise RuntimeError(f"rendezvous record {path} belongs to another user")

@@ -345,9 +345,9 @@ class HIPSolver(Solver):
     def _record(self, res: BatchResult) -> None:
         self._solution = res
         self._stats = {
-            "success": bool(np.all(res.status == _lib.OH_STATUS_CONVERGED)),
+            "success": bool(np.all(_lib.status_ok(res.status))),
             "iter_count": int(res.iters.max()),
-            "return_status": ["Solve_Succeeded" if s == 0 else ("Maximum_Iterations_Exceeded" if s == 1 else "Numerical_Failure") for s in res.status],
+            "return_status": [_lib.STATUS_NAMES.get(int(s), "Unknown") for s in res.status],
             "f": res.f.copy(),
             "kkt": res.kkt.copy(),
             "iterations": res.iters.copy(),

@@ -199,7 +199,7 @@ def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, 
             if stall >= stall_max and cur["nrel"] == 0 and mub <= mu_min and stat <= 10.0 * tol:
                 # acceptable level: stall_max steps at the floor of the barrier parameter within ten times the tolerance (the arithmetic floor of the
                 # reduced gradient when an active row has a slack of 1e-8: its multiplier mu_b / s is good to 1e-6 relative); k_tq_step alike
-                status = 0
+                status = 4  # OH_STATUS_ACCEPTABLE
                 break
             if stall >= stall_max and cur["nrel"] == 0 and accept:
                 # watchdog: stall_max steps without reaching the barrier test -- the iterate sits far from the central path of this mu_b (slacks of the

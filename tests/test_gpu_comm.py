@@ -1,0 +1,45 @@
+"""The one collective of the design on the hardware there is: an RCCL communicator of ONE rank inside liboptas_hip (oh_comm_*), the broadcast of the
+kinematic constants through it, the reductions a timing harness uses (round-4 verdict, Next 8).  World sizes > 1 are covered by the
+multi-process CPU tests of the rendezvous (tests/test_distributed_cpu.py) and stay unmeasured on hardware."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from optas_amd import _lib
+from optas_amd.backend import FigureEightBackend
+from optas_amd.models import RobotModel
+
+pytestmark = pytest.mark.gpu
+
+
+def test_communicator_of_one_rank_broadcasts_the_constants(hip_lib, tmp_path, monkeypatch):
+    from optas_amd import distributed as oad
+
+    lib = _lib.load()
+    monkeypatch.setenv("OPTAS_RDZV_DIR", str(tmp_path))
+    comm = oad.Communicator(0, 1, 0)
+    try:
+        assert comm.info() == (0, 1)  # ncclCommUserRank / ncclCommCount
+        robot = RobotModel.builtin("kuka_lwr")
+        chain = robot.kinematic_chain("end_effector_ball")
+        T = 12
+        lp = np.zeros((T, 3))
+        be = FigureEightBackend(chain, T, 0.1, lp)
+        comm.broadcast_constants(be.handle, root=0)  # ncclBroadcast in place in the handle
+        got = _lib.oh_chain()
+        _lib.check(lib.oh_get_constants(be.handle, C.byref(got)), "oh_get_constants")
+        assert bytes(got) == bytes(chain)  # every one of the 2952 bytes
+        # the handle still solves after the collective rewrote its constants
+        qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0])[None]
+        r = be.solve(np.concatenate([np.tile(qc, (1, T)), np.zeros((1, 7 * (T - 1)))], 1), qc)
+        assert r.status[0] == 0 and r.f[0] <= 1e-12
+        assert comm.max_over_ranks(3.25) == 3.25 and comm.max_over_ranks(-1.5) == -1.5 and comm.sum_over_ranks(2.5) == 2.5
+        comm.barrier()
+        be.close()
+    finally:
+        comm.destroy()
+    # a second communicator in the same process after the first was destroyed
+    comm2 = oad.Communicator(0, 1, 0)
+    assert comm2.info() == (0, 1)
+    comm2.destroy()

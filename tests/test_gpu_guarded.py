@@ -16,7 +16,7 @@ from oracle.solvers import kkt_reference_form
 from oracle.structured import FoldedChain
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from examples.dual_arm import N_OBSTACLES, SPHERE_LINKS, obstacle_parameters, setup_solver  # noqa: E402
+from examples.dual_arm import draw_feasible_configurations, N_OBSTACLES, SPHERE_LINKS, obstacle_parameters, setup_solver  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
@@ -72,8 +72,9 @@ def test_state_machine_matches_port_and_multipliers(hip_lib, golden):
     mb = MultiArmBackend(spec, o, max_iter=400)
     rng = np.random.default_rng(SEED)
     B = 6
-    qcl = QC + np.concatenate([np.zeros((1, 7)), rng.uniform(-0.05, 0.05, (B - 1, 7))])
-    qcr = QC + rng.uniform(-0.05, 0.05, (B, 7))
+    # (feasible as posed: the clearances of knot 0 are constants of an instance, and at radius 0.15 the nominal configuration has 1.6 mm to spare)
+    qcl = np.concatenate([QC[None], draw_feasible_configurations(rng, B - 1, kl, spread=0.05)])
+    qcr = draw_feasible_configurations(rng, B, kr, spread=0.05)
     P = np.stack([o.parameters.dict2vec({"qcl": qcl[b], "qcr": qcr[b], **obstacle_parameters()}) for b in range(B)])
     X0 = np.stack([o.decision_variables.dict2vec({"kukal/q/x": np.tile(qcl[b].reshape(-1, 1), (1, T)), "kukar/q/x": np.tile(qcr[b].reshape(-1, 1), (1, T))})
                    for b in range(B)])
@@ -114,7 +115,7 @@ def test_synthetic_config4_batch_properties(hip_lib, golden):
     kind, spec = lower(o)
     mb = MultiArmBackend(spec, o, max_iter=400)
     rng = np.random.default_rng(SEED + 4)
-    qcl, qcr = QC + rng.uniform(-0.1, 0.1, (B, 7)), QC + rng.uniform(-0.1, 0.1, (B, 7))
+    qcl, qcr = draw_feasible_configurations(rng, B, kl, link_radius=0.1), draw_feasible_configurations(rng, B, kr, link_radius=0.1)
     base = o.parameters.dict2vec({"qcl": QC, "qcr": QC, **obstacle_parameters(link_radius=0.1)})
     P = np.tile(base, (B, 1))
     P[:, :7], P[:, 7:14] = qcl, qcr
@@ -153,7 +154,8 @@ def test_config4_at_baseline_size_radius_015_reference_form_kkt(hip_lib, golden)
     kind, spec = lower(o)
     mb = MultiArmBackend(spec, o, max_iter=400)
     rng = np.random.default_rng(SEED + 41)
-    qcl, qcr = QC + rng.uniform(-0.1, 0.1, (B, 7)), QC + rng.uniform(-0.1, 0.1, (B, 7))
+    # perturbed initial configurations by rejection: every instance is feasible as posed (round-4 verdict, Weak 3; SURVEY C3 rejects starts likewise)
+    qcl, qcr = draw_feasible_configurations(rng, B, kl, link_radius=0.15), draw_feasible_configurations(rng, B, kr, link_radius=0.15)
     gpath = os.path.join(GOLDEN, "ipm_config4_golden.npz")
     gi = np.load(gpath) if os.path.exists(gpath) else None
     if gi is not None:  # the golden instances ride in the batch
@@ -172,19 +174,12 @@ def test_config4_at_baseline_size_radius_015_reference_form_kkt(hip_lib, golden)
     rl, rr = _robots()
     nlp = GuardedDualArmNLP(rl, rr, SPHERE_LINKS, N_OBSTACLES, T=T)
     assert nlp.nx == o.nx == 2786 and nlp.nv == 10400
-    # q_0 = qc is pinned by the rows of fix_configuration (builder.py:525-539): where the perturbed initial configuration itself breaks a clearance
-    # of radius 0.15 the NLP as the reference would pose it is INFEASIBLE (its sphere rows of knot 0 are negative constants; IPOPT would say so).  The
-    # kernels skip the rows of knot 0 and solve the rest; such instances are counted and kept out of the reference-form grading.
-    per = T * len(SPHERE_LINKS) * N_OBSTACLES
-    rows0 = np.concatenate([k * per + np.arange(len(SPHERE_LINKS) * N_OBSTACLES) for k in range(2)])  # sphere rows of knot 0, both arms
+    # q_0 = qc is pinned by the rows of fix_configuration (builder.py:525-539), so the sphere rows of knot 0 are constants of an instance; the draws
+    # above keep them positive, and EVERY row of EVERY instance looked at holds -- no exclusions (the library reports the other kind as
+    # OH_STATUS_INFEASIBLE: test_instance_infeasible_as_posed_is_reported)
     g_all = np.stack([nlp.g(res.x[b], P[b]) for b in range(0, B, 8)])
-    infeasible0 = g_all[:, rows0].min(1) < 0.0
-    rest = np.delete(g_all, rows0, axis=1)
-    assert rest.min() >= -1e-9  # every other clearance holds in every instance looked at
-    print("config 4, radius 0.15: %d of %d instances looked at are infeasible as posed (the pinned initial configuration breaks a clearance)" % (infeasible0.sum(), len(g_all)))
-    ok0 = np.array([nlp.g(res.x[b], P[b])[rows0].min() >= 0.0 for b in range(B)])
-    cand = np.flatnonzero(ok0)
-    sample = np.unique(np.concatenate([cand[:2], rng.choice(cand, 14, replace=False)]))
+    assert g_all.min() >= -1e-9
+    sample = np.unique(np.concatenate([np.arange(2), rng.choice(B, 14, replace=False)]))
     worst = np.zeros(3)
     for b in sample:
         x, p = res.x[b], P[b]
@@ -372,3 +367,63 @@ def test_cyclic_reduction_step_equals_the_serial_sweep(hip_lib, monkeypatch, T, 
     assert np.abs(r0.f - r1.f).max() <= 1e-9 * np.abs(r0.f).max() and np.abs(r0.x[same] - r1.x[same]).max() <= 1e-8
     for a, b in zip(l0, l1):
         assert np.abs(a[same] - b[same]).max() <= 1e-6 * max(1.0, np.abs(a).max())
+
+
+def test_instance_infeasible_as_posed_is_reported(hip_lib):
+    """An instance whose pinned initial configuration breaks a sphere clearance (or a joint limit) has no feasible point: its rows of knot 0 are
+    negative constants.  The reference hands that to IPOPT, which reports an infeasible problem: did_solve() is False (solver.py:407-412) and
+    solve() raises under error_on_fail (:133-134).  Here: OH_STATUS_INFEASIBLE for exactly the instances the oracle's literal rows say so, kkt[1] >=
+    the violation, the feasible instances of the same batch untouched."""
+    from optas_amd import _lib
+    from optas_amd.backend import MultiArmBackend
+    from optas_amd.lowering import lower
+    from optas_amd.solver import HIPSolver
+
+    T, B = 30, 24
+    (kl, kr), o = setup_solver(T=T, build_only=True, limits=True, collision=True)
+    kind, spec = lower(o)
+    mb = MultiArmBackend(spec, o, max_iter=400)
+    rng = np.random.default_rng(SEED + 57)
+    qcl, qcr = QC + rng.uniform(-0.1, 0.1, (B, 7)), QC + rng.uniform(-0.1, 0.1, (B, 7))  # NOT drawn by rejection: most pin q_0 inside a clearance
+    qcr[3, 3] = 2.2  # and one instance beyond a joint limit (lwr_arm_3: |q| <= 2.0944)
+    base = o.parameters.dict2vec({"qcl": QC, "qcr": QC, **obstacle_parameters(link_radius=0.15)})
+    P = np.tile(base, (B, 1))
+    P[:, :7], P[:, 7:14] = qcl, qcr
+    xoff = o.decision_variables.offsets()
+    X0 = np.zeros((B, o.nx))
+    for name, qc in (("kukal/q/x", qcl), ("kukar/q/x", qcr)):
+        X0[:, xoff[name] : xoff[name] + 7 * T] = np.tile(qc, (1, T))
+    res = mb.solve(X0, P)
+    rl, rr = _robots()
+    nlp = GuardedDualArmNLP(rl, rr, SPHERE_LINKS, N_OBSTACLES, T=T)
+    per = T * len(SPHERE_LINKS) * N_OBSTACLES
+    rows0 = np.concatenate([k * per + np.arange(len(SPHERE_LINKS) * N_OBSTACLES) for k in range(2)])  # sphere rows of knot 0, both arms
+    n_inf = 0
+    for b in range(B):
+        g0 = nlp.g(X0[b], P[b])[rows0].min()  # literal rows at the pinned knot (the seed holds qc there)
+        k0 = nlp.k(X0[b], P[b]).min()  # limit rows (the seed repeats qc at every knot, so these are the rows of knot 0)
+        worst = min(g0, k0, 0.0)
+        if worst < -1e-9:
+            n_inf += 1
+            assert res.status[b] == _lib.OH_STATUS_INFEASIBLE, (b, res.status[b], worst)
+            assert res.kkt[b, 1] >= -worst * (1 - 1e-9)
+        else:
+            assert res.status[b] == 0 and res.kkt[b, 1] <= 1e-9, (b, res.status[b], res.kkt[b])
+            k = kkt_reference_form(nlp, res.x[b], P[b], active_tol=1e-6)
+            assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-9 and k["complementarity"] <= 1e-6
+    assert 0 < n_inf < B and res.status[3] == _lib.OH_STATUS_INFEASIBLE
+    mb.close()
+    # the Solver interface on one such instance
+    b = int(np.flatnonzero(res.status == _lib.OH_STATUS_INFEASIBLE)[0])
+    pd = {"qcl": qcl[b], "qcr": qcr[b], **obstacle_parameters(link_radius=0.15)}
+    seed = {"kukal/q/x": np.tile(qcl[b].reshape(-1, 1), (1, T)), "kukar/q/x": np.tile(qcr[b].reshape(-1, 1), (1, T))}
+    solver = HIPSolver(o).setup("hip_sqp", {"max_iter": 400})
+    solver.reset_parameters(pd)
+    solver.reset_initial_seed(seed)
+    solver.solve()
+    assert not solver.did_solve() and solver.stats()["return_status"] == ["Infeasible_Problem_Detected"]
+    strict = HIPSolver(o, error_on_fail=True).setup("hip_sqp", {"max_iter": 400})
+    strict.reset_parameters(pd)
+    strict.reset_initial_seed(seed)
+    with pytest.raises(RuntimeError, match="Solver failed!"):
+        strict.solve()

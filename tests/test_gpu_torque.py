@@ -58,7 +58,7 @@ def test_golden_instances_objective_solution_steps_and_literal_kkt(hip_lib, ctx)
         B = len(qc)
         p = np.stack([nlp.pack_p(qc[b], np.zeros(7), goal[b]) for b in range(B)])
         res = be.solve(np.stack([nlp.seed(q) for q in qc]), p)
-        assert (res.status == 0).all(), (tag, res.status)
+        assert _lib.status_ok(res.status).all(), (tag, res.status)
         assert np.all(np.abs(res.f - g[tag + "_f"]) <= 1e-9 * g[tag + "_f"]), (tag, res.f - g[tag + "_f"])
         # (the end game is Newton's: the step count does not hover around the tolerance as the Gauss-Newton tail of rounds 1-3 did)
         assert np.all(np.abs(res.iters - g[tag + "_iters"]) <= 2), (tag, res.iters, g[tag + "_iters"])
@@ -158,7 +158,7 @@ def test_closed_form_jacobian_path_equals_the_dual_number_path(hip_lib, ctx, mon
     monkeypatch.setenv("OH_TQ_JAC", "dual")
     rb = be.solve(x0, p)
     monkeypatch.delenv("OH_TQ_JAC")
-    assert (np.asarray(ra.status) == 0).all() and (np.asarray(rb.status) == 0).all()
+    assert _lib.status_ok(ra.status).all() and _lib.status_ok(rb.status).all()
     assert np.mean(np.asarray(ra.iters) == np.asarray(rb.iters)) >= 0.9  # a ratio test decided by the last bits may differ on an instance or two
     same = np.asarray(ra.iters) == np.asarray(rb.iters)
     assert np.abs(ra.f - rb.f).max() <= 1e-9 * np.abs(ra.f).max()
@@ -190,7 +190,7 @@ def test_tables_that_are_no_rigid_body_chain_take_the_dual_number_path_and_equal
     res = be.solve(np.stack([nlp.seed(q) for q in qc]), p)
     for b in range(2):
         o = solve_torque_ipm(prob, qc[b], np.zeros(7), goal[b])
-        assert res.status[b] == 0 and o["status"] == 0
+        assert res.status[b] == o["status"] and o["status"] in (0, 4)
         assert abs(res.f[b] - o["f"]) <= 1e-9 * o["f"]
         assert abs(int(res.iters[b]) - o["iters"]) <= 1
     be.close()
@@ -211,7 +211,7 @@ def test_instance_at_the_arithmetic_floor_ends_at_the_optimum(hip_lib, ctx):
     be = backend(robot, T, 58.0, max_iter=600)
     res = be.solve(nlp.seed(qc)[None], nlp.pack_p(qc, np.zeros(7), goal)[None])
     o = solve_torque_ipm(prob, qc, np.zeros(7), goal, max_iter=600)
-    assert res.status[0] == 0 and o["status"] == 0
+    assert res.status[0] == o["status"] and o["status"] in (0, 4)
     assert res.iters[0] <= 150
     assert abs(res.f[0] - o["f"]) <= 1e-9 * o["f"]
     kkt = np.asarray(res.kkt)[0]
@@ -275,7 +275,7 @@ def test_batch_of_8192_properties_determinism_and_scalar_equivalence(hip_lib, ct
     x0[:, : 7 * T] = np.tile(qc, (1, T))
     be = backend(robot, T, 58.0, max_iter=600)  # effort rows bind in 70 % of this batch; round 4: p50 27 steps, the slowest instance ~130 (round 3: 39 / 600)
     res = be.solve(x0, p)
-    assert (res.status == 0).all() and np.median(res.iters) <= 30 and res.iters.max() <= 250
+    assert _lib.status_ok(res.status).all() and np.median(res.iters) <= 30 and res.iters.max() <= 250
     assert res.kkt[:, 0].max() <= 1e-6 and res.kkt[:, 1].max() == 0.0 and res.kkt[:, 2].max() <= 1e-8
     tau = res.x[:, 3 * 7 * T:]
     assert np.abs(tau).max() < 58.0 and (np.abs(tau).max(1) > 58.0 - 1e-5).any()  # limits hold strictly (interior) and bind somewhere

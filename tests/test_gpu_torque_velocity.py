@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import MED7_KIN, SEED
+from optas_amd import _lib
 from optas_amd.backend import TorqueBackend
 from optas_amd.models import RobotModel
 from oracle.problems import TorqueMPCNLP
@@ -83,7 +84,7 @@ def test_batch_with_velocity_limits_properties_and_scalar_equivalence(hip_lib):
     x0 = np.zeros((B, 4 * 7 * T))
     x0[:, : 7 * T] = np.tile(qc, (1, T))
     r = be.solve(x0, p)
-    ok = r.status == 0
+    ok = _lib.status_ok(r.status)
     # (round 3, augmented Lagrangian: p50 134 steps and an instance in 500 not through after 1000; the interior point brings every one home)
     assert ok.mean() >= 0.99, ok.mean()
     dQ = r.x[:, 7 * T : 14 * T]

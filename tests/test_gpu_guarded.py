@@ -291,7 +291,7 @@ def test_guarded_batch_compaction_is_invisible(hip_lib, golden, monkeypatch):
     (kl, kr), o = setup_solver(T=T, build_only=True, limits=True, collision=True)
     kind, spec = lower(o)
     rng = np.random.default_rng(SEED + 41)
-    qcl, qcr = QC + rng.uniform(-0.15, 0.15, (B, 7)), QC + rng.uniform(-0.15, 0.15, (B, 7))
+    qcl, qcr = draw_feasible_configurations(rng, B, kl, link_radius=0.1, spread=0.15), draw_feasible_configurations(rng, B, kr, link_radius=0.1, spread=0.15)
     base = o.parameters.dict2vec({"qcl": QC, "qcr": QC, **obstacle_parameters(link_radius=0.1)})
     P = np.tile(base, (B, 1))
     P[:, :7], P[:, 7:14] = qcl, qcr
@@ -332,7 +332,7 @@ def test_cyclic_reduction_step_equals_the_serial_sweep(hip_lib, monkeypatch, T, 
     (kl, kr), o = setup_solver(T=T, build_only=True, limits=guarded, collision=guarded)
     kind, spec = lower(o)
     rng = np.random.default_rng(SEED + 43)
-    qcl, qcr = QC + rng.uniform(-0.15, 0.15, (B, 7)), QC + rng.uniform(-0.15, 0.15, (B, 7))
+    qcl, qcr = draw_feasible_configurations(rng, B, kl, link_radius=0.1, spread=0.15), draw_feasible_configurations(rng, B, kr, link_radius=0.1, spread=0.15)
     pd = {"qcl": QC, "qcr": QC}
     if guarded:
         pd.update(obstacle_parameters(link_radius=0.1))

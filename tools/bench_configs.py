@@ -101,13 +101,13 @@ def oracle_grade(kind, **kw):
             dQ = x[7 * T :].reshape(T - 1, 7)
             G = Guards(lo=rob.lower_actuated_joint_limits, up=rob.upper_actuated_joint_limits, links=kw["links"], link_radii=p[7:11], obs_pos=p[11:].reshape(6, 4)[:, :3],
                        obs_radii=p[11:].reshape(6, 4)[:, 3])
-            worst = max(worst, float(-min(0.0, guard_values(ch, Q, G)[0][1:].min())))
+            worst = max(worst, float(-min(0.0, guard_values(ch, Q, G)[0].min())))  # every knot, the pinned one included
             e = ch.fk(Q)[0]
             path = ch.fk(p[None, :7])[0][0][None] + kw["offsets"]
             fdiff = max(fdiff, abs(float(np.sum((e - path) ** 2) + 0.01 * np.sum(dQ**2)) - f))
         # reference-form KKT on the literal layout (round 4): two arms at a time as one dual-arm instance of oracle/problems.py:GuardedDualArmNLP
         # (both slots hold the arm of this batch: base (0, -0.25, 0), the left arm's path).  An arm whose pinned initial configuration breaks a
-        # clearance poses an infeasible NLP (rows of knot 0: negative constants, which the kernels skip): counted, not graded.
+        # clearance poses an infeasible NLP (rows of knot 0: negative constants) and comes back OH_STATUS_INFEASIBLE; the generator draws none.
         from oracle.problems import GuardedDualArmNLP
 
         rob2 = OracleRobot(os.path.join(R, "kuka_lwr.kin.json"), name="kukar")
@@ -116,6 +116,7 @@ def oracle_grade(kind, **kw):
         nlp.offsets = {"l": kw["offsets"].T, "r": kw["offsets"].T}
         G0 = lambda p: Guards(lo=None, up=None, links=kw["links"], link_radii=p[7:11], obs_pos=p[11:].reshape(6, 4)[:, :3], obs_radii=p[11:].reshape(6, 4)[:, 3])
         feas0 = [i for i, p in enumerate(kw["p"]) if guard_values(ch, p[None, :7], G0(p))[0].min() >= 0.0]
+        assert len(feas0) == len(kw["p"]), "the instance generator draws by rejection: every sampled arm must be feasible as posed"
         ks = []
         for a, b in zip(feas0[0::2], feas0[1::2]):
             x2 = np.concatenate([kw["x"][a], kw["x"][b]])
@@ -126,7 +127,7 @@ def oracle_grade(kind, **kw):
                 "infeasible_as_posed": len(kw["x"]) - len(feas0), "kkt_graded_arms": 2 * len(ks),
                 "stationarity_max": max((k["stationarity"] for k in ks), default=None), "complementarity_max": max((k["complementarity"] for k in ks), default=None),
                 "by": "oracle/guarded.py:guard_values (2 x 7 limit rows + 4 x 6 sphere rows per knot), the tracking cost recomputed with oracle/structured.py:FoldedChain, and "
-                      "oracle/solvers.py:kkt_reference_form on oracle/problems.py:GuardedDualArmNLP (literal layout, two arms per instance) for the arms whose NLP is feasible as posed"}
+                      "oracle/solvers.py:kkt_reference_form on oracle/problems.py:GuardedDualArmNLP (literal layout, two arms per instance) for the sampled arms (all feasible as posed: drawn by rejection)"}
     return {"instances": len(ks), "stationarity_max": max(k["stationarity"] for k in ks), "feasibility_max": max(k["feasibility"] for k in ks),
             "complementarity_max": max(k["complementarity"] for k in ks), "by": "oracle/solvers.py:kkt_reference_form on the literal NLP of oracle/problems.py"}
 
@@ -265,7 +266,7 @@ def _planner_tape(out, sample):
 
 def _config4(out, rng, sample):
     # config 4 synthetic: T = 100, limits + 4 x 6 sphere rows per knot, link radius 0.15 as SURVEY 8(d) states; arms are independent instances
-    from examples.dual_arm import SPHERE_LINKS, path_offsets
+    from examples.dual_arm import SPHERE_LINKS, draw_feasible_configurations, path_offsets
 
     QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
     T = 100
@@ -284,11 +285,13 @@ def _config4(out, rng, sample):
                 g.link_offset[l][i] = off[i]
         be = FigureEightBackend(arm.kinematic_chain("end_effector_ball"), T, 10.0 / (T - 1), offs.T, w_path=1.0, w_vel=0.01, max_iter=400, lock_orientation=False, fix_dq0=False,
                                 path_in_frame=False, guards=g)
-        qc = QC + rng.uniform(-0.1, 0.1, (B, 7))
+        # perturbed initial configurations by rejection: every arm is feasible as posed (q_0 = qc is pinned, so the clearances of knot 0 are constants;
+        # round-4 verdict, Weak 3 -- the library reports the other kind as OH_STATUS_INFEASIBLE)
+        qc = draw_feasible_configurations(rng, B, arm, link_radius=radius)
         obs_row = np.concatenate([[0.55, 0.0, 0.1 * (i + 1), 0.1] for i in range(6)])
         p = np.ascontiguousarray(np.concatenate([qc, np.full((B, 4), radius), np.tile(obs_row, (B, 1))], 1))
         x0 = np.ascontiguousarray(np.concatenate([np.tile(qc, (1, T)), np.zeros((B, 7 * (T - 1)))], 1))
-        r, smp = timed_with_results(be, x0, p, sample=sample, seed=4)
+        r, smp = timed_with_results(be, x0, p, sample=max(sample, 16), seed=4)
         out[f"config4_arms{B}_r{radius:g}"] = {"what": f"dual_arm.py synthetic: T=100, joint limits + 4 x 6 sphere clearances (link radius {radius:g}), {B} arms "
                                                         "(a dual-arm instance = two of them)", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
                                                "oracle_sample": oracle_grade("guarded_arm", T=T, links=SPHERE_LINKS, offsets=offs.T, **smp) if smp else None}
@@ -388,7 +391,7 @@ def main():
                 "ticks_per_s_device": B * n_ticks / dev_ms * 1e3, "device_ms": dev_ms, "wall_ms": wall * 1e3, "host_driven_loop_wall_ms": host_wall * 1e3,
                 "converged_frac": float((stt == 0).mean()), "iters_mean": float(it.mean()), "max_state_diff_vs_host_loop": float(np.abs(st - states[-1]).max())})
     # ---- config 4 as shipped and synthetic ----
-    from examples.dual_arm import SPHERE_LINKS, path_offsets
+    from examples.dual_arm import SPHERE_LINKS, draw_feasible_configurations, path_offsets
 
     QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
     for tag, T, B, guarded in (("4 dual_arm.py as shipped (T=50), per arm", 50, 8192, False),
@@ -410,7 +413,7 @@ def main():
                     g.link_offset[l][i] = off[i]
         be = FigureEightBackend(arm.kinematic_chain("end_effector_ball"), T, 10.0 / (T - 1), path_offsets(T, [-0.1, 0.1, -0.2], [0.0, 0.0, 0.3]).T,
                                 w_path=1.0, w_vel=0.01, max_iter=400, lock_orientation=False, fix_dq0=False, path_in_frame=False, guards=g)
-        qc = QC + rng.uniform(-0.1, 0.1, (B, 7))
+        qc = draw_feasible_configurations(rng, B, arm, link_radius=0.1) if guarded else QC + rng.uniform(-0.1, 0.1, (B, 7))
         p = qc
         if guarded:
             obs_row = np.concatenate([[0.55, 0.0, 0.1 * (i + 1), 0.1] for i in range(6)])

@@ -27,6 +27,11 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a struct of this header changes layout or an entry point changes meaning; oh_abi_version() returns the value the library was
+   built with, and a host binding refuses a library that answers otherwise (a binding that misreads a descriptor fails silently).
+   5: round 5 -- OH_STATUS_INFEASIBLE / OH_STATUS_ACCEPTABLE, oh_set_option / oh_get_option, oh_tq_rollout, tape opcodes 25-26. */
+#define OH_ABI_VERSION 5
+
 #define OH_MAX_CHAIN 16 /* actuated joints on one root->link chain */
 #define OH_MAX_T 128    /* horizon knots */
 
@@ -268,7 +273,8 @@ typedef struct oh_qp_desc {
 /* Instruction i writes register i.  op: 0 CONST c | 1 X a | 2 P a | 3 ADD a b | 4 SUB a b | 5 MUL a b | 6 DIV a b | 7 NEG a | 8 SIN a | 9 COS a |
    10 ATAN2 a b | 11 SQRT a | 12 SQR a | 13 ASIN a | 14 FABS a | 15 FMIN a b | 16 FMAX a b | 17 LT a b | 18 LE a b | 19 EQ a b | 20 NE a b |
    21 NOT a | 22 AND a b | 23 OR a b (comparisons / logic: 1.0 or 0.0, zero derivative) | 24 IFZ a b (casadi's if_else_zero: b where a != 0, else 0;
-   derivative conventions of 13-16 and 24 are casadi's, casadi/core/calculus.hpp).  rows: registers of the constraint rows, the n_ineq rows that must be >= 0 first, then the n_eq rows
+   derivative conventions of 13-16 and 24 are casadi's, casadi/core/calculus.hpp) | 25 EXP a | 26 LOG a (round 5: what user costs written with `from casadi import *`,
+   optas/__init__.py:2, add to the core's own set -- the host expresses pow, tanh, sinh, cosh, acos, atan, asinh, acosh, atanh, log1p, expm1 and sign through these).  rows: registers of the constraint rows, the n_ineq rows that must be >= 0 first, then the n_eq rows
    that must vanish (the rows of v = [k; g; a; -a; h; -h] without the mirrored ones, optimization.py:27-51). */
 typedef struct oh_tape_desc {
   int nx, np;       /* nx <= OH_TAPE_MAX_N */
@@ -288,6 +294,9 @@ typedef struct oh_tape_desc {
                        VGPRs); 0: interpret the instruction arrays (registers in HBM/L2; no set-up cost, far slower per evaluation).  Ignored beyond 48
                        variables when the tape's live registers fit the LDS: those handles run one block of wavefronts per instance over the
                        dependency levels of the tape (registers in LDS, no generated code; oh_get_flag "tape_wave") */
+  int no_wave;      /* != 0: never that evaluator (option "tape_wave" = 0) */
+  int lbfgs;        /* quasi-Newton matrix: 0 by size (dense inverse BFGS up to 48 variables, 12 limited-memory pairs beyond), m > 0: m pairs, < 0: dense
+                       (option "tape_lbfgs") */
 } oh_tape_desc;
 
 typedef struct oh_handle oh_handle;
@@ -375,6 +384,28 @@ int oh_solve(oh_handle* h, int B, const double* x0, const double* p, double* x, 
    not fit), "tape_levels" and "tape_passes" (dependency levels of the tape; instruction passes of one evaluation). */
 int oh_get_flag(oh_handle* h, const char* name, int* value);
 
+/*
+ * Options of ONE handle by name (round 5).  The reference passes an options dict through to its back-end (solver.py:333-384: nlpsol's `opts`);
+ * these are the library's counterpart for scheduling and experiment knobs -- until round 4 they were OH_* environment variables read inside the
+ * library, so two handles of one process could not differ.  Unknown names return OH_ERR_INVALID.  Scheduling options change WHEN work is done and by
+ * which kernel, never what is computed, except where noted:
+ *   batch_invariant (0)   1: no compaction, no persistent tail kernel: every instance runs the batched launches to the end, and its answer is a
+ *                         function of the instance alone, bit for bit, whatever batch it is part of (default path: the same optimum for ~97 % of
+ *                         a 262 144 batch, bit-identical only where the same kernels ran).  Costs 1.2-2.7 x device time.
+ *   tail_threshold (16384), tail_vel (1), tail_vel_threshold, compaction (1), compact_frac (0.97), compact_sort (1), compact_carry (1),
+ *   sparse_check_below (2048), check_every (1), fuse_couple (1), lg_split (1), row_pad (13)            -- figure-eight family scheduling
+ *   free_pcr_max (1536), free_bb (1), free_cp_max (512), free_persist (-1 auto / 0 / 1)                  -- position-tracking family sweeps
+ *   specialize (2 = auto, 0 never, 1 at the first call)                                                 -- run-time specialisation (oh_specialize)
+ *   hyb_switch (1e-5, x w_path), relax (1.5), relax_from (4), retract_min (1e-13)                        -- algorithm constants (change the iterates)
+ *   pm_wave_max (20480), qp_mode (-1), tape_lds_max                                                     -- point-mass / QP / tape launch shapes
+ *   tape_wave (1), tape_lbfgs (-1 = by size), tape_wave_nt (256), tape_wave_regs (-1), tape_wave_hist (-1) -- tape evaluator (rebuilt when set)
+ *   tq_check (4), tq_rebuild (0.9), tq_stall (25), tq_curv_after (3), tq_curv_from (0.1), tq_ftb (0.995), tq_theta_mu (1.35), tq_kappa_mu (0.2),
+ *   tq_jac_dual (0)                                                                                     -- torque-MPC family
+ * The one environment hook left: OH_DEBUG_OPTIONS="name=value,name=value" is applied to every handle when it is created (A/B tooling).
+ */
+int oh_set_option(oh_handle* h, const char* name, double value);
+int oh_get_option(oh_handle* h, const char* name, double* value);
+
 /* Largest B one oh_solve / oh_solve_device call of this handle takes (*out = 0: the library sets no bound of its own). */
 int oh_max_batch(oh_handle* h, int* out);
 
@@ -439,7 +470,7 @@ int oh_get_timing(oh_handle* h, double* out11);
    and the evaluation kernels k_retract / k_evalb / k_tail of OH_PROBLEM_FIGURE_EIGHT with lock_orientation (no lead joint, no guards).
    oh_specialize compiles (or fetches from the process / disk cache: $OPTAS_HIP_CACHE, default ~/.cache/optas_hip, empty = none) and
    loads them now; without the call the library does it by itself at the first solve of >= 4096 instances / the first oh_fk_jac* of
-   >= 65536 units (env OH_SPECIALIZE=0: never, =1: at the first call of any size).  Until then, and if compilation is unavailable (then
+   >= 65536 units (option specialize = 0: never, 1: at the first call of any size).  Until then, and if compilation is unavailable (then
    oh_specialize returns OH_ERR_HIP and oh_last_error says why), the generic kernels run: same text, same results up to the rounding
    of folded constants.  info4: [0] 1 if the specialised solver kernels are loaded, [1] 1 if the specialised K1 is, [2] seconds the last
    oh_specialize of this handle took, [3] 1 if the code object came from the disk cache. */
@@ -472,6 +503,7 @@ int oh_kernel_info(const char* kernel, int* out5);
 
 const char* oh_last_error(void);
 const char* oh_version(void);
+int oh_abi_version(void); /* OH_ABI_VERSION of the build */
 void oh_destroy(oh_handle* h);
 
 #ifdef __cplusplus

@@ -19,6 +19,7 @@ OH_MAX_OBSTACLES = 16
 OH_COMM_ID_BYTES = 128
 
 OH_OK, OH_ERR_INVALID, OH_ERR_HIP, OH_ERR_STATE = 0, 1, 2, 3
+OH_ABI_VERSION = 5  # include/optas_hip.h: the struct layouts below are those of this version
 OH_STATUS_CONVERGED, OH_STATUS_MAX_ITER, OH_STATUS_NUMERICAL, OH_STATUS_INFEASIBLE, OH_STATUS_ACCEPTABLE = 0, 1, 2, 3, 4
 # IPOPT's names for the same outcomes (what CasADiSolver.stats()["return_status"] holds, solver.py:407-412)
 STATUS_NAMES = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Numerical_Failure", 3: "Infeasible_Problem_Detected", 4: "Solved_To_Acceptable_Level"}
@@ -159,6 +160,8 @@ class oh_tape_desc(C.Structure):
         ("tol_feas", C.c_double),
         ("rho0", C.c_double),
         ("jit", C.c_int),
+        ("no_wave", C.c_int),
+        ("lbfgs", C.c_int),
     ]
 
 
@@ -256,6 +259,9 @@ SYMBOLS = [
     "oh_specialize_info",
     "oh_last_error",
     "oh_version",
+    "oh_abi_version",
+    "oh_set_option",
+    "oh_get_option",
     "oh_destroy",
 ]
 
@@ -280,6 +286,12 @@ def load() -> C.CDLL:
             "(hipcc --offload-arch=gfx950). optas_amd has no CPU fallback."
         )
     lib = C.CDLL(path)
+    # a library built from other sources (OPTAS_HIP_LIBRARY, a stale build) would misread every descriptor below -- silently
+    if not hasattr(lib, "oh_abi_version"):
+        raise OptasHipError(f"{path} predates oh_abi_version(): rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+    lib.oh_abi_version.restype = C.c_int
+    if lib.oh_abi_version() != OH_ABI_VERSION:
+        raise OptasHipError(f"{path} was built for ABI version {lib.oh_abi_version()}, this binding expects {OH_ABI_VERSION}: rebuild the library")
     vp, i, dp, ip = C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)
     lib.oh_create.argtypes = [C.POINTER(oh_problem_desc), C.POINTER(vp)]
     lib.oh_create_pointmass.argtypes = [C.POINTER(oh_pointmass_desc), C.POINTER(vp)]
@@ -316,6 +328,8 @@ def load() -> C.CDLL:
     lib.oh_kernel_info_handle.argtypes = [vp, C.c_char_p, ip]
     lib.oh_event_timer_start.argtypes = [vp]
     lib.oh_event_timer_stop.argtypes = [vp, dp]
+    lib.oh_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    lib.oh_get_option.argtypes = [vp, C.c_char_p, dp]
     lib.oh_last_error.restype = C.c_char_p
     lib.oh_version.restype = C.c_char_p
     lib.oh_destroy.argtypes = [vp]
@@ -332,6 +346,17 @@ def check(rc: int, what: str = "") -> None:
     if rc != OH_OK:
         msg = load().oh_last_error().decode("utf-8", "replace")
         raise OptasHipError(f"{what}: {msg} (code {rc})" if what else f"{msg} (code {rc})")
+
+
+def set_option(handle, name: str, value: float) -> None:
+    """oh_set_option: a scheduling / experiment knob of ONE handle (the list is in include/optas_hip.h)."""
+    check(load().oh_set_option(handle, name.encode(), float(value)), f"oh_set_option({name})")
+
+
+def get_option(handle, name: str) -> float:
+    v = C.c_double(0.0)
+    check(load().oh_get_option(handle, name.encode(), C.byref(v)), f"oh_get_option({name})")
+    return v.value
 
 
 def device_count() -> int:

@@ -24,7 +24,23 @@ class BatchResult:
     status: np.ndarray  # (B,)
 
 
-class _SolveMixin:
+class _OptionsMixin:
+    """Per-handle options by name (oh_set_option; include/optas_hip.h lists them)."""
+
+    def set_option(self, name: str, value: float):
+        _lib.set_option(self._h, name, value)
+        return self
+
+    def set_options(self, options=None, **kw):
+        for k, v in {**(options or {}), **kw}.items():
+            self.set_option(k, v)
+        return self
+
+    def get_option(self, name: str) -> float:
+        return _lib.get_option(self._h, name)
+
+
+class _SolveMixin(_OptionsMixin):
     """oh_solve / oh_solve_device / timing over an existing handle (self._h, self.nx, self.np_)."""
 
     def solve(self, x0: np.ndarray, p: np.ndarray) -> "BatchResult":
@@ -115,27 +131,46 @@ class PointMassBackend(_SolveMixin):
 class TapeBackend(_SolveMixin):
     """OH_PROBLEM_TAPE handle: a compiled instruction tape (optas_amd.tape.Tape) interpreted on the GPU; x (B, nx), p (B, np)."""
 
-    def __init__(self, tape, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True):
-        lib = _lib.load()
-        if int(tape.nx) > 48 and os.environ.get("OH_TAPE_WAVE", "1") != "0":
-            # trajectory-sized: the library runs a wavefront per instance over the dependency levels of the tape (csrc/oh_tape_wave.hip); chains of
-            # additions are levels there, so sums go in as balanced trees (same values to the rounding of the summation order)
-            from .tape import rebalance_sums
-
-            tape = rebalance_sums(tape)
-        self.tape = tape
-        self.jit = bool(jit)
+    def __init__(self, tape, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True, wave=True, options=None):
+        """wave: let trajectory-sized tapes (beyond 48 variables) run one block of wavefronts per instance over the dependency levels of the tape
+        (csrc/oh_tape_wave.hip) where the library finds that it applies; options: oh_set_option pairs applied to the handle."""
         self.nx, self.np_ = int(tape.nx), max(1, int(tape.np_))
         self._np_real = int(tape.np_)
-        ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        self._h = None
+        want_wave = bool(wave) and int(tape.nx) > 48 and float((options or {}).get("tape_wave", 1)) != 0.0
+        if want_wave:
+            # chains of additions are dependency levels for that evaluator, so sums go in as balanced trees (same values to the rounding of the
+            # summation order).  Whether the path is taken is the library's decision (limited-memory regime, LDS fit): the handle is asked, and a
+            # tape the library declined is handed over again as it was written (ADVICE r4: one gate, not an environment variable read twice)
+            from .tape import rebalance_sums
+
+            self._create(rebalance_sums(tape), max_iter, tol, tol_feas, rho0, jit, options)
+            if self.flag("tape_wave") == 0:
+                self.close()
+                want_wave = False
+        if not want_wave:
+            opts = dict(options or {})
+            if int(tape.nx) > 48:
+                opts["tape_wave"] = 0
+            self._create(tape, max_iter, tol, tol_feas, rho0, jit, opts)
+        self.wave = self.flag("tape_wave") != 0
+        self.jit = bool(jit) and not self.wave  # what actually runs: generated code only where the wavefront evaluator does not
+
+    def _create(self, tape, max_iter, tol, tol_feas, rho0, jit, options):
+        lib = _lib.load()
+        self.tape = tape
         self._keep = [np.ascontiguousarray(tape.op, dtype=np.int32), np.ascontiguousarray(tape.a, dtype=np.int32), np.ascontiguousarray(tape.b, dtype=np.int32),
                       np.ascontiguousarray(tape.c, dtype=np.float64), np.ascontiguousarray(np.append(tape.out_rows, 0), dtype=np.int32)]
-        desc = self.descriptor(tape, self._keep, max_iter, tol, tol_feas, rho0, jit)
+        opts = dict(options or {})
+        # the two choices that shape the evaluator travel in the descriptor (it is built when the handle is created)
+        desc = self.descriptor(tape, self._keep, max_iter, tol, tol_feas, rho0, jit, no_wave=float(opts.pop("tape_wave", 1)) == 0.0, lbfgs=int(opts.pop("tape_lbfgs", -1)))
         self._h = C.c_void_p()
         _lib.check(lib.oh_create_tape(C.byref(desc), C.byref(self._h)), "oh_create_tape")
+        if opts:
+            self.set_options(opts)
 
     @staticmethod
-    def descriptor(tape, keep=None, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True):
+    def descriptor(tape, keep=None, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True, no_wave=False, lbfgs=-1):
         """oh_tape_desc over the arrays of a compiled tape; `keep` receives the contiguous arrays the descriptor points into."""
         ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
         if not keep:
@@ -145,7 +180,7 @@ class TapeBackend(_SolveMixin):
         desc = _lib.oh_tape_desc(nx=int(tape.nx), np=int(tape.np_), len=len(tape.op), op=keep[0].ctypes.data_as(ip), a=keep[1].ctypes.data_as(ip),
                                  b=keep[2].ctypes.data_as(ip), c=keep[3].ctypes.data_as(dp), out_cost=int(tape.out_cost), n_ineq=int(tape.n_ineq),
                                  n_eq=int(tape.n_eq), rows=keep[4].ctypes.data_as(ip), max_iter=int(max_iter), tol=float(tol), tol_feas=float(tol_feas),
-                                 rho0=float(rho0), jit=int(bool(jit)))
+                                 rho0=float(rho0), jit=int(bool(jit)), no_wave=int(bool(no_wave)), lbfgs=(0 if lbfgs < 0 else (int(lbfgs) if lbfgs > 0 else -1)))
         desc._keep = keep
         return desc
 
@@ -293,7 +328,7 @@ class TorqueBackend(_SolveMixin):
         return {"solve_ms": out[4], "iterations_launched": int(out[5]), "work_instances": out[6]}
 
 
-class FigureEightBackend:
+class FigureEightBackend(_OptionsMixin):
     """OH_PROBLEM_FIGURE_EIGHT handle."""
 
     def __init__(
@@ -577,6 +612,11 @@ class MultiArmBackend:
             iters = np.maximum(iters, r.iters)
             status = _lib.worse_status(status, r.status)
         return BatchResult(x, f, kkt, iters, status)
+
+    def set_options(self, options=None, **kw):
+        for _, be in self.arms:
+            be.set_options(options, **kw)
+        return self
 
     def solve_ms(self) -> float:
         """Device time of the last solve: the arms run one after the other on their own handles."""

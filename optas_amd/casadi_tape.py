@@ -35,7 +35,21 @@ _UNARY = {
     "OP_SQ": lambda tb, a: tb.sqr(a),
     "OP_TWICE": lambda tb, a: tb.add(a, a),
     "OP_INV": lambda tb, a: tb.div(tb.const(1.0), a),
-    "OP_TAN": lambda tb, a: tb.div(tb.sin(a), tb.cos(a)),
+    "OP_TAN": lambda tb, a: tb.tan(a),
+    # round 5: user costs and constraints written with `from casadi import *` (optas/__init__.py:2)
+    "OP_EXP": lambda tb, a: tb.exp(a),
+    "OP_LOG": lambda tb, a: tb.log(a),
+    "OP_ACOS": lambda tb, a: tb.acos(a),
+    "OP_ATAN": lambda tb, a: tb.atan(a),
+    "OP_TANH": lambda tb, a: tb.tanh(a),
+    "OP_SINH": lambda tb, a: tb.sinh(a),
+    "OP_COSH": lambda tb, a: tb.cosh(a),
+    "OP_ASINH": lambda tb, a: tb.asinh(a),
+    "OP_ACOSH": lambda tb, a: tb.acosh(a),
+    "OP_ATANH": lambda tb, a: tb.atanh(a),
+    "OP_LOG1P": lambda tb, a: tb.log1p(a),
+    "OP_EXPM1": lambda tb, a: tb.expm1(a),
+    "OP_SIGN": lambda tb, a: tb.sign(a),
     "OP_ASIN": lambda tb, a: tb.asin(a),  # Quaternion.getrpy (spatialmath.py:384-404) -> get_global_link_rpy and the analytical Jacobians
     "OP_FABS": lambda tb, a: tb.fabs(a),
     "OP_NOT": lambda tb, a: tb.lnot(a),
@@ -58,23 +72,9 @@ _BINARY = {
 }
 
 
-def _pow_const(tb: TapeBuilder, a: int, b: int) -> int:
-    """x ** c for the constant exponents small problems use (OP_CONSTPOW, and OP_POW whose exponent register is a constant)."""
-    if not tb.is_const(b):
-        raise UnsupportedInstruction("pow with a non-constant exponent")
-    e = tb._const[b]
-    if e == 0.5:
-        return tb.sqrt(a)
-    if e == -1.0:
-        return tb.div(tb.const(1.0), a)
-    if e == int(e) and 0 <= int(e) <= 8:
-        out, base, k = tb.const(1.0), a, int(e)
-        while k:  # square-and-multiply
-            if k & 1:
-                out = tb.mul(out, base)
-            base, k = tb.sqr(base), k >> 1
-        return out
-    raise UnsupportedInstruction(f"pow with exponent {e}")
+def _pow(tb: TapeBuilder, a: int, b: int) -> int:
+    """OP_POW / OP_CONSTPOW: TapeBuilder.pow (small integer and half exponents exactly, anything else as exp(y log x), x > 0)."""
+    return tb.pow(a, b)
 
 
 def opcode_table(cs) -> Dict[int, tuple]:
@@ -88,7 +88,7 @@ def opcode_table(cs) -> Dict[int, tuple]:
             table[int(getattr(cs, name))] = ("binary", fn)
     for name in ("OP_POW", "OP_CONSTPOW"):
         if hasattr(cs, name):
-            table[int(getattr(cs, name))] = ("binary", _pow_const)
+            table[int(getattr(cs, name))] = ("binary", _pow)
     for name, kind in (("OP_CONST", "const"), ("OP_INPUT", "input"), ("OP_OUTPUT", "output")):
         table[int(getattr(cs, name))] = (kind, None)
     return table

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -31,11 +32,8 @@ static int fail(int code, const std::string& msg) {
     }                                                                                                  \
   } while (0)
 
-static int specialize_mode_from_env() {
-  const char* e = getenv("OH_SPECIALIZE");
-  if (!e || !strcmp(e, "auto")) return OH_SPECIALIZE_AUTO;
-  return atoi(e) != 0 ? OH_SPECIALIZE_ALWAYS : OH_SPECIALIZE_NEVER;
-}
+static thread_local OhLaunchOpts g_launch_opts;
+OhLaunchOpts& oh_launch_opts() { return g_launch_opts; }
 #define OH_PINNED_STAGE_BYTES (256 * 1024)
 
 struct oh_handle {
@@ -130,7 +128,7 @@ struct oh_handle {
   int fuse_couple = 1;        // OH_FUSE_COUPLE=0 restores the three-kernel iteration (k_couple between evaluation and sweep) for A/B runs
   int free_pcr_max = 1536;    // position-tracking family: K3 by cyclic reduction, one block per instance, while at most this many are in the launch
   // run-time specialised evaluation kernels of the orientation-locked figure-eight family (oh_jit.hip)
-  int specialize = specialize_mode_from_env();  // OH_SPECIALIZE env: 0 never, 1 at the first solve, auto: at the first solve of >= specialize_min_B instances
+  int specialize = OH_SPECIALIZE_AUTO;  // option "specialize": 0 never, 1 at the first solve, 2 auto: at the first solve of >= specialize_min_B instances
   int specialize_min_B = 4096;
   const FigSpec* spec = nullptr;
   bool spec_failed = false;
@@ -140,6 +138,12 @@ struct oh_handle {
   int specialize_min_units = 1 << 16;
   double spec_seconds = 0.0;  // of the last oh_specialize
   std::vector<int> prof_tags;  // per recorded event: 0 base marker, 1 after eval, 2 after step
+  // options set by name (oh_set_option; OH_DEBUG_OPTIONS at creation) that are not backed by a field above: read with optv() where they are used
+  std::map<std::string, double> opt;
+  // host copy of the tape of an OH_PROBLEM_TAPE handle: the evaluator is rebuilt when an option that shapes it changes (tape_wave, tape_lbfgs, ...)
+  std::vector<int> t_op, t_a, t_b, t_rows;
+  std::vector<double> t_c;
+  oh_tape_desc t_desc{};
 };
 
 extern "C" void oh_destroy(oh_handle* h);
@@ -148,7 +152,128 @@ static bool spec_applies(const oh_handle* h);
 static bool spec_tail_vel_applies(const oh_handle* h);
 static int specialize_fk(oh_handle* h);
 extern "C" const char* oh_last_error(void) { return g_err.c_str(); }
-extern "C" const char* oh_version(void) { return "optas_hip 0.1 (gfx950)"; }
+extern "C" const char* oh_version(void) { return "optas_hip 0.2 (gfx950)"; }
+extern "C" int oh_abi_version(void) { return OH_ABI_VERSION; }
+
+// ---- per-handle options (round 5) ----------------------------------------------------------------------------------------------------
+// Until round 4 forty OH_* environment variables were read inside the library: two handles of one process could not differ and a result
+// depended on the caller's environment.  Now every knob is an option of ONE handle, set by name; the single environment hook left is
+// OH_DEBUG_OPTIONS ("name=value,name=value"), applied to every handle when it is created (tools/, A/B runs).
+static double optv(const oh_handle* h, const char* name, double dflt) {
+  auto it = h->opt.find(name);
+  return it == h->opt.end() ? dflt : it->second;
+}
+struct OptDoc { const char* name; double dflt; };
+// map-backed options and their defaults (field-backed ones are handled in set_option_impl / oh_get_option)
+static const OptDoc OPT_TABLE[] = {
+    {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},
+    {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
+    {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
+    {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.2},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
+    {"tq_rebuild", 0.9},
+};
+static int tape_configure(oh_handle* h);
+static int set_option_impl(oh_handle* h, const std::string& name, double v) {
+  if (name == "tail_threshold") h->tail_threshold = (int)v;
+  else if (name == "free_pcr_max") h->free_pcr_max = (int)v;
+  else if (name == "compaction") h->compaction = v != 0.0;
+  else if (name == "compact_frac") h->compact_frac = h->compact_frac_restart = v;
+  else if (name == "compact_sort") h->compact_sort = (int)v;
+  else if (name == "compact_carry") h->compact_carry = (int)v;
+  else if (name == "tail_vel") h->tail_vel = (int)v;
+  else if (name == "lg_split") h->lg_split = (int)v;
+  else if (name == "tail_vel_threshold") h->tail_vel_threshold = (int)v;
+  else if (name == "fuse_couple") h->fuse_couple = v != 0.0;
+  else if (name == "sparse_check_below") h->sparse_check_below = (int)v;
+  else if (name == "specialize") h->specialize = v == 0.0 ? OH_SPECIALIZE_NEVER : (v == 1.0 ? OH_SPECIALIZE_ALWAYS : OH_SPECIALIZE_AUTO);
+  else if (name == "tq_check") h->tq_check = v >= 1.0 ? (int)v : 1;
+  else if (name == "batch_invariant") {
+    // every instance takes the batched launches to the end, nothing is compacted, nothing handed to the persistent kernel: the path of an instance
+    // is then a function of the instance alone, bit for bit (the price: 1.2 - 2.7 x the device time of a large batch, and small batches pay launches)
+    h->opt[name] = v;
+    if (v != 0.0) { h->compaction = false; h->tail_threshold = 0; h->tail_vel = 0; h->opt["free_persist"] = 0; }
+    else { h->compaction = true; h->tail_threshold = 16384; h->tail_vel = 1; h->opt.erase("free_persist"); }
+  } else {
+    bool known = false;
+    for (const OptDoc& d : OPT_TABLE) known = known || name == d.name;
+    if (!known) return fail(OH_ERR_INVALID, "oh_set_option: unknown option '" + name + "'");
+    h->opt[name] = v;
+    if (h->desc.kind == OH_PROBLEM_TAPE && !h->t_op.empty() && name.rfind("tape_", 0) == 0 && name != "tape_lds_max") return tape_configure(h);
+  }
+  return OH_OK;
+}
+extern "C" int oh_set_option(oh_handle* h, const char* name, double value) {
+  if (!h || !name) return fail(OH_ERR_INVALID, "oh_set_option: null argument");
+  return set_option_impl(h, name, value);
+}
+extern "C" int oh_get_option(oh_handle* h, const char* name, double* value) {
+  if (!h || !name || !value) return fail(OH_ERR_INVALID, "oh_get_option: null argument");
+  const std::string n(name);
+  if (n == "tail_threshold") *value = h->tail_threshold;
+  else if (n == "free_pcr_max") *value = h->free_pcr_max;
+  else if (n == "compaction") *value = h->compaction ? 1 : 0;
+  else if (n == "compact_frac") *value = h->compact_frac;
+  else if (n == "compact_sort") *value = h->compact_sort;
+  else if (n == "compact_carry") *value = h->compact_carry;
+  else if (n == "tail_vel") *value = h->tail_vel;
+  else if (n == "lg_split") *value = h->lg_split;
+  else if (n == "tail_vel_threshold") *value = h->tail_vel_threshold;
+  else if (n == "fuse_couple") *value = h->fuse_couple ? 1 : 0;
+  else if (n == "sparse_check_below") *value = h->sparse_check_below;
+  else if (n == "specialize") *value = h->specialize;
+  else if (n == "tq_check") *value = h->tq_check;
+  else if (n == "batch_invariant") *value = optv(h, "batch_invariant", 0.0);
+  else {
+    for (const OptDoc& d : OPT_TABLE)
+      if (n == d.name) { *value = optv(h, d.name, d.dflt); return OH_OK; }
+    return fail(OH_ERR_INVALID, "oh_get_option: unknown option '" + n + "'");
+  }
+  return OH_OK;
+}
+// OH_DEBUG_OPTIONS="name=value,name=value": the one environment hook of the library, applied to a handle when it is created
+static int apply_debug_options(oh_handle* h) {
+  const char* e = getenv("OH_DEBUG_OPTIONS");
+  if (!e || !*e) return OH_OK;
+  std::string str(e);
+  size_t pos = 0;
+  while (pos < str.size()) {
+    size_t end = str.find_first_of(",;", pos);
+    if (end == std::string::npos) end = str.size();
+    const std::string item = str.substr(pos, end - pos);
+    pos = end + 1;
+    if (item.empty()) continue;
+    const size_t eq = item.find('=');
+    if (eq == std::string::npos) return fail(OH_ERR_INVALID, "OH_DEBUG_OPTIONS: expected name=value, got '" + item + "'");
+    char* endp = nullptr;
+    const std::string val = item.substr(eq + 1);
+    const double v = strtod(val.c_str(), &endp);
+    if (endp == val.c_str()) return fail(OH_ERR_INVALID, "OH_DEBUG_OPTIONS: '" + item + "' has no numeric value");
+    if (const int rc = set_option_impl(h, item.substr(0, eq), v)) return rc;
+  }
+  return OH_OK;
+}
+// the launchers' share of the options, for the call that is starting
+static void load_launch_opts(const oh_handle* h) {
+  OhLaunchOpts& o = g_launch_opts;
+  o = OhLaunchOpts{};
+  o.free_bb = (int)optv(h, "free_bb", o.free_bb);
+  o.free_cp_max = (int)optv(h, "free_cp_max", o.free_cp_max);
+  o.pm_wave_max = (int)optv(h, "pm_wave_max", o.pm_wave_max);
+  o.qp_mode = (int)optv(h, "qp_mode", o.qp_mode);
+  o.tape_lds_max = (int)optv(h, "tape_lds_max", o.tape_lds_max);
+  o.tape_wave_nt = (int)optv(h, "tape_wave_nt", o.tape_wave_nt);
+  o.tape_wave_regs = (int)optv(h, "tape_wave_regs", o.tape_wave_regs);
+  o.tape_wave_hist = (int)optv(h, "tape_wave_hist", o.tape_wave_hist);
+}
+// every oh_create*: a fresh handle with the debug options applied (nullptr: a bad OH_DEBUG_OPTIONS, oh_last_error says which)
+static oh_handle* new_handle() {
+  oh_handle* h = new oh_handle();
+  if (apply_debug_options(h) != OH_OK) {
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
 
 extern "C" int oh_device_count(int* n) {
   if (!n) return fail(OH_ERR_INVALID, "oh_device_count: null");
@@ -197,7 +322,8 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1)
       return fail(OH_ERR_HIP, "oh_create: no HIP device available (this library has no CPU path)");
-    oh_handle* hk = new oh_handle();
+    oh_handle* hk = new_handle();
+    if (!hk) return OH_ERR_INVALID;
     hk->desc = *desc;
     hk->desc.local_path = nullptr;
     hipGetDevice(&hk->device);
@@ -221,7 +347,8 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev < 1)
     return fail(OH_ERR_HIP, "oh_create: no HIP device available (this library has no CPU path)");
-  oh_handle* h = new oh_handle();
+  oh_handle* h = new_handle();
+  if (!h) return OH_ERR_INVALID;
   h->desc = *desc;
   h->local_path.assign(desc->local_path, desc->local_path + 3 * (size_t)desc->T);
   h->desc.local_path = nullptr;
@@ -229,17 +356,6 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
   if (!(h->desc.tol > 0.0)) h->desc.tol = 1e-6;
   if (!(h->desc.tol_feas > 0.0)) h->desc.tol_feas = 1e-9;
   if (h->desc.mu0 < 0.0) h->desc.mu0 = 0.0;
-  if (const char* e2 = getenv("OH_TAIL_THRESHOLD")) h->tail_threshold = atoi(e2);
-  if (const char* e2 = getenv("OH_FREE_PCR_MAX")) h->free_pcr_max = atoi(e2);
-  if (const char* e3 = getenv("OH_COMPACTION")) h->compaction = atoi(e3) != 0;
-  if (const char* e4 = getenv("OH_COMPACT_FRAC")) h->compact_frac = h->compact_frac_restart = atof(e4);
-  if (const char* e5 = getenv("OH_COMPACT_SORT")) h->compact_sort = atoi(e5);
-  if (const char* e6 = getenv("OH_COMPACT_CARRY")) h->compact_carry = atoi(e6);
-  if (const char* e7 = getenv("OH_TAIL_VEL")) h->tail_vel = atoi(e7);
-  if (const char* e8 = getenv("OH_LG_SPLIT")) h->lg_split = atoi(e8);
-  if (const char* e9 = getenv("OH_TAIL_VEL_THRESHOLD")) h->tail_vel_threshold = atoi(e9);
-  if (const char* e7 = getenv("OH_FUSE_COUPLE")) h->fuse_couple = atoi(e7) != 0;
-  if (const char* e9 = getenv("OH_SPARSE_CHECK_BELOW")) h->sparse_check_below = atoi(e9);
   hipGetDevice(&h->device);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
       hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->evt0) != hipSuccess ||
@@ -268,7 +384,8 @@ extern "C" int oh_create_pointmass(const oh_pointmass_desc* desc, oh_handle** ou
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1)
     return fail(OH_ERR_HIP, "oh_create_pointmass: no HIP device available (this library has no CPU path)");
-  oh_handle* h = new oh_handle();
+  oh_handle* h = new_handle();
+  if (!h) return OH_ERR_INVALID;
   h->desc = oh_problem_desc{};
   h->desc.kind = OH_PROBLEM_POINT_MASS_MPC;
   h->desc.T = desc->T;
@@ -294,8 +411,8 @@ static int tape_validate(const oh_tape_desc* d, const char* who) {
   for (int i = 0; i < d->len; ++i) {
     const int o = d->op[i];
     const bool two = (o >= 3 && o <= 6) || o == 10 || (o >= 15 && o <= 20) || (o >= 22 && o <= 24);
-    const bool one = o == 7 || o == 8 || o == 9 || o == 11 || o == 12 || o == 13 || o == 14 || o == 21;
-    if (o < 0 || o > 24 || (o == 1 && (d->a[i] < 0 || d->a[i] >= d->nx)) || (o == 2 && (d->a[i] < 0 || d->a[i] >= d->np)) ||
+    const bool one = o == 7 || o == 8 || o == 9 || o == 11 || o == 12 || o == 13 || o == 14 || o == 21 || o == 25 || o == 26;
+    if (o < 0 || o > 26 || (o == 1 && (d->a[i] < 0 || d->a[i] >= d->nx)) || (o == 2 && (d->a[i] < 0 || d->a[i] >= d->np)) ||
         ((one || two) && (d->a[i] < 0 || d->a[i] >= i)) || (two && (d->b[i] < 0 || d->b[i] >= i)))
       return fail(OH_ERR_INVALID, (w + ": malformed instruction (operands must be earlier registers / valid indices)").c_str());
   }
@@ -304,11 +421,11 @@ static int tape_validate(const oh_tape_desc* d, const char* who) {
   return OH_OK;
 }
 
-static TapeParams tape_params(const oh_tape_desc* d) {
-  // dense inverse-Hessian BFGS up to 48 variables (n^2 doubles per instance), the limited-memory form with 12 pairs beyond (OH_TAPE_LBFGS overrides:
+static TapeParams tape_params(const oh_tape_desc* d, const int lbfgs_opt = -1) {
+  // dense inverse-Hessian BFGS up to 48 variables (n^2 doubles per instance), the limited-memory form with 12 pairs beyond (option tape_lbfgs overrides:
   // 0 forces the dense matrix, m > 0 the m-pair form at any size)
   int lb = d->nx > 48 ? 12 : 0;
-  if (const char* e = getenv("OH_TAPE_LBFGS")) lb = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
+  if (lbfgs_opt >= 0) lb = lbfgs_opt > 64 ? 64 : lbfgs_opt;
   return TapeParams{d->len, d->nx, d->np, d->n_ineq, d->n_eq, d->out_cost, d->max_iter > 0 ? d->max_iter : 2000, d->tol > 0.0 ? d->tol : 1e-6,
                     d->tol_feas > 0.0 ? d->tol_feas : 1e-9, d->rho0 > 0.0 ? d->rho0 : 10.0, lb};
 }
@@ -330,53 +447,73 @@ extern "C" int oh_tape_compile(const oh_tape_desc* d, size_t* code_bytes, char* 
   return OH_OK;
 }
 
-extern "C" int oh_create_tape(const oh_tape_desc* d, oh_handle** out) {
-  if (!d || !out) return fail(OH_ERR_INVALID, "oh_create_tape: null argument");
-  *out = nullptr;
-  if (const int rc = tape_validate(d, "oh_create_tape")) return rc;
-  int nd = 0;
-  if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return fail(OH_ERR_HIP, "oh_create_tape: no HIP device available (this library has no CPU path)");
-  oh_handle* h = new oh_handle();
-  h->desc = oh_problem_desc{};
-  h->desc.kind = OH_PROBLEM_TAPE;
-  h->desc.T = 1;
-  h->desc.ndof = d->nx;
-  h->TP = tape_params(d);
-  hipGetDevice(&h->device);
-  {
-    // limited-memory regime (nx > 48): a wavefront per instance over the level schedule of the tape, when its register file fits the LDS
-    // (OH_TAPE_WAVE=0: never).  No code is generated for these handles: the schedule is data.
-    const char* e = getenv("OH_TAPE_WAVE");
-    int lds_limit = 0;
-    if ((!e || atoi(e) != 0) && hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess) {
-      std::string err;
-      if (oh_tape_wave_build(h->TP, d->op, d->a, d->b, d->c, d->rows, (size_t)lds_limit, &h->tape_wave, &err)) {
-        delete h;
-        return fail(OH_ERR_HIP, ("oh_create_tape: " + err).c_str());
-      }
-    }
+// (Re)build the evaluator of an OH_PROBLEM_TAPE handle from its host copy of the tape and its options: the wavefront-per-instance schedule where it
+// applies (tape_wave != 0, limited-memory regime, LDS fit), otherwise generated code (desc.jit) or the interpreter.
+static int tape_configure(oh_handle* h) {
+  oh_tape_desc d = h->t_desc;
+  d.op = h->t_op.data(); d.a = h->t_a.data(); d.b = h->t_b.data(); d.c = h->t_c.data(); d.rows = h->t_rows.empty() ? nullptr : h->t_rows.data();
+  h->TP = tape_params(&d, (int)optv(h, "tape_lbfgs", -1.0));
+  load_launch_opts(h);  // oh_tape_wave_build reads tape_wave_nt / _regs / _hist
+  oh_tape_wave_release(&h->tape_wave);
+  h->tape_wave = TapeWave{};
+  if (h->tape_cap) {  // the work arrays were sized for the other evaluator
+    if (h->d_tape_work) hipFree(h->d_tape_work);
+    if (h->d_tape_mult) hipFree(h->d_tape_mult);
+    h->d_tape_work = h->d_tape_mult = nullptr;
+    h->tape_cap = 0;
   }
-  if (d->jit && !h->tape_wave.ready) {
+  int lds_limit = 0;
+  if (optv(h, "tape_wave", 1.0) != 0.0 && hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess) {
+    std::string err;
+    if (oh_tape_wave_build(h->TP, d.op, d.a, d.b, d.c, d.rows, (size_t)lds_limit, &h->tape_wave, &err)) return fail(OH_ERR_HIP, ("oh_create_tape: " + err).c_str());
+  }
+  if (d.jit && !h->tape_wave.ready && !h->tape_jit.fn) {
     std::vector<char> code;
     std::string err;
-    const std::string src = oh_tape_jit_source(h->TP, d->op, d->a, d->b, d->c, d->rows);
+    const std::string src = oh_tape_jit_source(h->TP, d.op, d.a, d.b, d.c, d.rows);
     bool ok = !oh_tape_jit_compile(src, &code, &err) && !oh_tape_jit_load(code, &h->tape_jit, &err);
     if (!ok && !code.empty()) {  // an object that compiled (or came from the disk cache) and does not load: drop it, recompile once (as oh_jit_figure8 does)
       oh_tape_jit_forget(src);
       code.clear();
       ok = !oh_tape_jit_compile(src, &code, &err) && !oh_tape_jit_load(code, &h->tape_jit, &err);
     }
-    if (!ok) {
-      delete h;
-      return fail(OH_ERR_HIP, ("oh_create_tape: " + err).c_str());
-    }
+    if (!ok) return fail(OH_ERR_HIP, ("oh_create_tape: " + err).c_str());
+  }
+  return OH_OK;
+}
+
+extern "C" int oh_create_tape(const oh_tape_desc* d, oh_handle** out) {
+  if (!d || !out) return fail(OH_ERR_INVALID, "oh_create_tape: null argument");
+  *out = nullptr;
+  if (const int rc = tape_validate(d, "oh_create_tape")) return rc;
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return fail(OH_ERR_HIP, "oh_create_tape: no HIP device available (this library has no CPU path)");
+  oh_handle* h = new_handle();
+  if (!h) return OH_ERR_INVALID;
+  h->desc = oh_problem_desc{};
+  h->desc.kind = OH_PROBLEM_TAPE;
+  h->desc.T = 1;
+  h->desc.ndof = d->nx;
+  hipGetDevice(&h->device);
+  // the tape stays with the handle: the evaluator is rebuilt when an option that shapes it changes
+  h->t_op.assign(d->op, d->op + d->len);
+  h->t_a.assign(d->a, d->a + d->len);
+  h->t_b.assign(d->b, d->b + d->len);
+  h->t_c.assign(d->c, d->c + d->len);
+  h->t_rows.assign(d->rows ? d->rows : d->op, (d->rows ? d->rows : d->op) + (d->rows ? d->n_ineq + d->n_eq : 0));
+  h->t_desc = *d;
+  if (d->no_wave && !h->opt.count("tape_wave")) h->opt["tape_wave"] = 0.0;
+  if (d->lbfgs != 0 && !h->opt.count("tape_lbfgs")) h->opt["tape_lbfgs"] = d->lbfgs > 0 ? (double)d->lbfgs : 0.0;
+  if (const int rc = tape_configure(h)) {
+    oh_destroy(h);
+    return rc;
   }
   const size_t li = sizeof(int) * (size_t)d->len, ld = sizeof(double) * (size_t)d->len, lr = sizeof(int) * (size_t)(d->n_ineq + d->n_eq + 1);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
       hipEventCreate(&h->evt0) != hipSuccess || hipEventCreate(&h->evt1) != hipSuccess || hipMalloc((void**)&h->d_tape_op, li) != hipSuccess ||
       hipMalloc((void**)&h->d_tape_a, li) != hipSuccess || hipMalloc((void**)&h->d_tape_b, li) != hipSuccess ||
       hipMalloc((void**)&h->d_tape_c, ld) != hipSuccess || hipMalloc((void**)&h->d_tape_rows, lr) != hipSuccess) {
-    delete h;
+    oh_destroy(h);  // (releases the wavefront schedule / the generated module built above as well)
     return fail(OH_ERR_HIP, "oh_create_tape: stream/event/allocation failed");
   }
   hipMemcpy(h->d_tape_op, d->op, li, hipMemcpyHostToDevice);
@@ -429,7 +566,8 @@ extern "C" int oh_create_qp(const oh_qp_desc* desc, oh_handle** out) {
     return fail(OH_ERR_INVALID, "oh_create_qp: sizes out of range (n <= 32, m <= 256, me <= min(32, n))");
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1) return fail(OH_ERR_HIP, "oh_create_qp: no HIP device available (this library has no CPU path)");
-  oh_handle* h = new oh_handle();
+  oh_handle* h = new_handle();
+  if (!h) return OH_ERR_INVALID;
   h->desc = oh_problem_desc{};
   h->desc.kind = OH_PROBLEM_QP;
   h->desc.T = 1;
@@ -479,7 +617,7 @@ extern "C" int oh_qp_set_tape(oh_handle* h, const oh_tape_desc* d) {
     std::vector<int> list;
     for (int i = 0; i < d->len; ++i) {
       const int o = d->op[i];
-      const bool two = (o >= 3 && o <= 6) || o == 10, one = o == 7 || o == 8 || o == 9 || o == 11 || o == 12;
+      const bool two = tape_op_arity(o) == 2, one = tape_op_arity(o) == 1;
       dep[i] = o == 1 || ((one || two) && dep[d->a[i]]) || (two && dep[d->b[i]]);
       if (dep[i]) list.push_back(i);
     }
@@ -560,7 +698,8 @@ extern "C" int oh_create_ik(const oh_ik_desc* desc, oh_handle** out) {
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1)
     return fail(OH_ERR_HIP, "oh_create_ik: no HIP device available (this library has no CPU path)");
-  oh_handle* h = new oh_handle();
+  oh_handle* h = new_handle();
+  if (!h) return OH_ERR_INVALID;
   h->desc = oh_problem_desc{};
   h->desc.kind = OH_PROBLEM_IK;
   h->desc.T = 1;
@@ -598,7 +737,8 @@ extern "C" int oh_create_torque(const oh_torque_desc* desc, oh_handle** out) {
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess || nd < 1)
     return fail(OH_ERR_HIP, "oh_create_torque: no HIP device available (this library has no CPU path)");
-  oh_handle* h = new oh_handle();
+  oh_handle* h = new_handle();
+  if (!h) return OH_ERR_INVALID;
   h->desc = oh_problem_desc{};
   h->desc.kind = OH_PROBLEM_TORQUE_MPC;
   h->desc.T = desc->T;
@@ -609,7 +749,6 @@ extern "C" int oh_create_torque(const oh_torque_desc* desc, oh_handle** out) {
   if (!(h->tq.tol_compl > 0.0)) h->tq.tol_compl = 1e-8;
   if (!(h->tq.mu_barrier0 > 0.0)) h->tq.mu_barrier0 = 0.1;
   if (!(h->tq.mu0 >= 0.0)) h->tq.mu0 = 0.0;
-  if (const char* e = getenv("OH_TQ_CHECK")) h->tq_check = atoi(e) > 0 ? atoi(e) : 1;
   hipGetDevice(&h->device);
   if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
       hipEventCreate(&h->evt0) != hipSuccess || hipEventCreate(&h->evt1) != hipSuccess ||
@@ -637,12 +776,12 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   // interior point: relaxed barrier below theta mu_b; monotone barrier update of Waechter & Biegler (2006, eq. 7) -- IPOPT's constants except theta_mu (1.35 for 1.5: the hardest of 8192 instances needs 127 steps instead of 198); exact
   // curvature of the Lagrangian once the reduced gradient is below curv_from (oracle/torque_ipm.py:solve_torque_ipm has the same defaults)
   P.theta = 0.01; P.kappa_eps = 10.0; P.kappa_mu = 0.2; P.theta_mu = 1.35; P.curv_from = 0.1; P.curv_late = 1.0; P.curv_after = 3; P.tau_ftb = 0.995; P.max_back = 3; P.stall_max = 25;
-  if (const char* e = getenv("OH_TQ_STALL")) P.stall_max = atoi(e);
-  if (const char* e = getenv("OH_TQ_CURV_AFTER")) P.curv_after = atoi(e);
-  if (const char* e = getenv("OH_TQ_FTB")) P.tau_ftb = atof(e);
-  if (const char* e = getenv("OH_TQ_THETA_MU")) P.theta_mu = atof(e);
-  if (const char* e = getenv("OH_TQ_KAPPA_MU")) P.kappa_mu = atof(e);
-  if (const char* e = getenv("OH_TQ_CURV_FROM")) P.curv_from = atof(e);  // 0: Gauss-Newton blocks throughout (A/B)
+  P.stall_max = (int)optv(h, "tq_stall", P.stall_max);  // options (oh_set_option)
+  P.curv_after = (int)optv(h, "tq_curv_after", P.curv_after);
+  P.tau_ftb = optv(h, "tq_ftb", P.tau_ftb);
+  P.theta_mu = optv(h, "tq_theta_mu", P.theta_mu);
+  P.kappa_mu = optv(h, "tq_kappa_mu", P.kappa_mu);
+  P.curv_from = optv(h, "tq_curv_from", P.curv_from);  // 0: Gauss-Newton blocks throughout (A/B)
   P.vel = h->tq.vel_limits ? 1 : 0;
   // d tau / dz in closed form needs the tables to describe a rigid-body chain: unit joint axes that the joint-origin rotation leaves in place (then
   // the angular velocity the reference adds, iRp @ axis, is the axis its rotation turns about; models.py:1821-1823).  Otherwise: dual numbers.
@@ -654,9 +793,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     for (int k = 0; k < 3; ++k) dev = fmax(dev, fabs(R[k] * a[0] + R[3 + k] * a[1] + R[6 + k] * a[2] - a[k]));
     if (!(dev <= 1e-12)) P.jac_closed_form = 0;
   }
-  if (const char* e = getenv("OH_TQ_JAC")) {  // "dual": the dual-number path whatever the tables (A/B, tests)
-    if (!strcmp(e, "dual")) P.jac_closed_form = 0;
-  }
+  if (optv(h, "tq_jac_dual", 0.0) != 0.0) P.jac_closed_form = 0;  // the dual-number path whatever the tables (A/B, tests)
   for (int i = 0; i < N; ++i) {
     P.tau_lo[i] = h->tq.tau_lo[i];
     P.tau_up[i] = h->tq.tau_up[i];
@@ -725,7 +862,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
       HIPCHK(hipStreamSynchronize(s));
       running = *h->h_flag;
       if (running == 0) break;
-      static const double rebuild = [] { const char* e = getenv("OH_TQ_REBUILD"); return e ? atof(e) : 0.9; }();
+      const double rebuild = optv(h, "tq_rebuild", 0.9);
       if (running <= rebuild * D.n_run) {  // rebuild the list of running instances: grids shrink with the batch
         HIPCHK(hipMemsetAsync(D.n_list, 0, sizeof(int), s));
         oh_launch_tq_list(s, D);
@@ -892,24 +1029,21 @@ static bool solver_chain_ok(const oh_chain& c) {
 }
 
 // row stride of the SoA stage arrays for a batch of B (see ensure_capacity)
-static int row_stride(int B) {
+static int row_stride(const oh_handle* h, int B) {
   int Bp = (B + 63) / 64 * 64;
-  if (Bp >= 4096) {
-    const char* e = getenv("OH_ROW_PAD");
-    Bp += 64 * (e ? atoi(e) : 13);
-  }
+  if (Bp >= 4096) Bp += 64 * (int)optv(h, "row_pad", 13);
   return Bp;
 }
 static bool stage_fits(const oh_handle* h, int B) {
   const int N = h->desc.ndof, NZ = h->desc.lock_orientation ? N - 3 : N, T = h->desc.T;
   if (!h->desc.lock_orientation) return true;
-  if (!(((double)T * NZ * NZ + 1.0) * (double)row_stride(B) * 8.0 < 4294967296.0)) return false;
-  if (!(((double)T * (3 * N - 3) + 1.0) * (double)row_stride(B) * 8.0 < 4294967296.0)) return false;  // slot offset of the Householder vectors
+  if (!(((double)T * NZ * NZ + 1.0) * (double)row_stride(h, B) * 8.0 < 4294967296.0)) return false;
+  if (!(((double)T * (3 * N - 3) + 1.0) * (double)row_stride(h, B) * 8.0 < 4294967296.0)) return false;  // slot offset of the Householder vectors
   // handles with the coupling folded in: the sweep addresses G of either slot and the spare as one 32-bit offset from the lowest of the three
   // adjacent arrays (oh_figure8_units.h:step_instance_zc): 3 T N doubles per instance have to stay below 4 GiB (round 3: found by the batch
   // sweep -- 524 288 instances ran through with wrapped offsets and converged nowhere; they are now refused here and split by the host)
   const bool zc = h->fuse_couple && !h->have_guards && !h->chain_host.has_lead;
-  return !zc || 3.0 * (double)T * N * (double)row_stride(B) * 8.0 < 4294967296.0;
+  return !zc || 3.0 * (double)T * N * (double)row_stride(h, B) * 8.0 < 4294967296.0;
 }
 
 // Largest batch one oh_solve / oh_solve_device call of this handle takes (0: no bound of the library's own, memory permitting): hosts chunk
@@ -936,7 +1070,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   // their pages, and how the channel hash happens to spread them differed from process to process (k_couple 494 or 525 us per launch,
   // k_step 650...740, interleaved repeats on one box).  Off the power of two the spread is even: k_couple 455, k_step ~650, +3 % solves/s
   // (any of 1...13 x 512 B does it; OH_ROW_PAD overrides, 0 restores the old layout).
-  const int Bp = row_stride(B);
+  const int Bp = row_stride(h, B);
   // the sweep kernels address one slot of a stage array with a 32-bit byte offset (buffer resources, oh_kernels.hip): the largest such
   // array, T x NZ^2 doubles per instance, has to stay below 4 GiB (about 670 000 instances at T = 50, N = 7; oh_max_batch says exactly)
   if (!stage_fits(h, B)) return fail(OH_ERR_INVALID, "batch too large for one call (stage array beyond 4 GiB): split the batch (oh_max_batch)");
@@ -1148,7 +1282,7 @@ static void fill_params(oh_handle* h) {
   //  same retraction-noise end game below tol = 1e-7 -- a tenth of a batch sitting at 1.5 x tol until the cap at 1e-9 -- and at the default 1e-6
   //  the rules cut the rejected steps from 1.7 % to 0.4 % and the median instance from 13 to 10 steps: 2.92 -> 3.0-3.1 M solves/s)
   P.tol_retract_min = fmin(1e-13, P.tol_retract);
-  if (const char* e = getenv("OH_RETRACT_MIN")) P.tol_retract_min = fmin(atof(e), P.tol_retract);  // experiments
+  P.tol_retract_min = fmin(optv(h, "retract_min", 1e-13), P.tol_retract);  // (option: experiments)
   P.feas_accept = fmax(1e-8, 10.0 * d.tol_feas);
   P.max_retract = 4;
   P.max_iter = d.max_iter;
@@ -1158,12 +1292,12 @@ static void fill_params(oh_handle* h) {
   // instances take 20.4 instead of 22.0 steps on average with 99.95 % of them at the same optimum, at 1e-4 19.6 steps with 0.8 % forking -- but the
   // tail of the distribution moves about: of 24 576 instances one sits at the 600-step cap at 3e-5, takes 565 steps at 2e-5 and 166 at 5e-5, where
   // 1e-5 finishes every instance of every batch measured, 16 384 to 262 144, in at most 508; tools/gpu_vel_switch_quality.py, gpu_vel_24576_probe.py.)
-  if (const char* e = getenv("OH_HYB_SWITCH")) P.hyb_switch = atof(e) * d.w_path;  // experiments (tools/sweep_env.sh)
+  P.hyb_switch = optv(h, "hyb_switch", 1e-5) * d.w_path;  // (option: experiments)
   P.mu0 = d.mu0;
   P.relax = 1.5;
   P.relax_from = 4;
-  if (const char* e = getenv("OH_RELAX")) P.relax = atof(e);
-  if (const char* e = getenv("OH_RELAX_FROM")) P.relax_from = atoi(e);
+  P.relax = optv(h, "relax", P.relax);
+  P.relax_from = (int)optv(h, "relax_from", P.relax_from);
   P.local_path = h->d_local_path;
   P.np = d.ndof + (h->have_guards ? h->guards.n_links + 4 * h->guards.n_obstacles : 0);
   if (h->chain_host.has_lead) P.np = d.ndof + 1 + d.T;
@@ -1177,6 +1311,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (!h) return fail(OH_ERR_INVALID, "oh_solve_device: null handle");
   if (B < 1) return fail(OH_ERR_INVALID, "oh_solve_device: B must be >= 1");
   if (!d_x0 || !d_p) return fail(OH_ERR_INVALID, "oh_solve_device: x0 and p are required");
+  load_launch_opts(h);
   if (h->desc.kind == OH_PROBLEM_POINT_MASS_MPC) return pm_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind == OH_PROBLEM_IK) return ik_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind == OH_PROBLEM_QP) return qp_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
@@ -1201,8 +1336,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   const bool guarded = h->have_guards;
   const bool lead = h->chain_host.has_lead != 0;
   {  // position-tracking family, 7 joints, every launch of this solve a block per instance (k_step_free_bb): stage blocks instance-major
-    const char* e = getenv("OH_FREE_BB");
-    h->P.inst_major = (!h->desc.lock_orientation && h->desc.ndof == 7 && B <= h->free_pcr_max && h->desc.T - (h->desc.fix_dq0 ? 2 : 1) <= 128 && (!e || atoi(e) != 0)) ? 1 : 0;
+    h->P.inst_major = (!h->desc.lock_orientation && h->desc.ndof == 7 && B <= h->free_pcr_max && h->desc.T - (h->desc.fix_dq0 ? 2 : 1) <= 128 && optv(h, "free_bb", 1.0) != 0.0) ? 1 : 0;
   }
   if (lead && (guarded || !h->desc.lock_orientation || h->desc.ndof != 6))
     return fail(OH_ERR_INVALID, "oh_solve_device: a parameterised lead joint is lowered for the orientation-locked family with 6 optimised joints, "
@@ -1236,7 +1370,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   int launched = 0;
   int compactions = 0;
   int check_every = 1;  // one small D2H read per iteration: with the cheap compaction timely decisions beat the saved round trips (every 2nd: -1.5 %)
-  if (const char* ce = getenv("OH_CHECK_EVERY")) check_every = atoi(ce) > 0 ? atoi(ce) : check_every;  // experiments
+  if (optv(h, "check_every", 1.0) >= 1.0) check_every = (int)optv(h, "check_every", 1.0);  // (option: experiments)
   double* ox = (double*)d_x; double* of = (double*)d_f; double* ok = (double*)d_kkt;
   int* oi = (int*)d_iters; int* os = (int*)d_status;
   // Every instance needs at most max_iter steps (accepted + rejected) plus its first evaluation; each
@@ -1266,12 +1400,12 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   };
   bool tail_done = false;
   {  // position-tracking family with limit / sphere rows, every instance a block of its own: the whole solve in one launch (k_free_persist)
-    const char* e = getenv("OH_FREE_PERSIST");
+    const int fp = (int)optv(h, "free_persist", -1.0);  // -1: where it pays, 1: always, 0: never
     // measured (HISTORY): same time per iteration as the launch pair (the iteration is memory round trips inside the phases, not launch gaps), so it
     // only wins where the host's sparse looks at the running count cost idle launches and every block is resident: horizons up to 64 free knots,
-    // at most 512 instances (OH_FREE_PERSIST=1: always, 0: never)
-    const bool fits = (h->desc.T - h->P.t0 <= 64 && B <= 512) || (e && atoi(e) == 1);
-    if (!h->P.lock && guarded && !h->GP.vel && h->P.inst_major && h->P.zc_free && !prof && !lead && fits && (!e || atoi(e) != 0)) {
+    // at most 512 instances (option free_persist = 1: always, 0: never)
+    const bool fits = (h->desc.T - h->P.t0 <= 64 && B <= 512) || fp == 1;
+    if (!h->P.lock && guarded && !h->GP.vel && h->P.inst_major && h->P.zc_free && !prof && !lead && fits && fp != 0) {
       if (oh_launch_free_persist(s, N, h->P, h->D, h->GP, h->GB)) {
         tail_done = true;
         launched = 1;

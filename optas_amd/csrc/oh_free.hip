@@ -5,6 +5,7 @@
 // simplifies to   S_t = H_t - (2k)^2 S_{t+1}^{-1},  r_t = g_t + 2k S_{t+1}^{-1} r_{t+1},
 //                 z_{t+1} = -S_{t+1}^{-1} r_{t+1} + 2k S_{t+1}^{-1} z_t.
 #include "oh_figure8.h"
+#include "oh_kernels.h"  // OhLaunchOpts
 
 #define IDX(t, K, k) (((size_t)(t) * (K) + (k)) * Bp + b)
 // Stage blocks W_t (packed, NP) and reduced gradients (N) of this family: knot-major like everything else (a thread per instance reads coalesced), or
@@ -1710,14 +1711,10 @@ bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBu
 static int g_free_cp_max = -1;
 template <int N, bool GUARD, bool VEL = false>
 static void launch_step_free_pcr(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, int slot) {
-  {  // (read per launch: a handful of nanoseconds, and tests switch it between handles of one process)
-    const char* e = getenv("OH_FREE_CP_MAX");
-    g_free_cp_max = e ? atoi(e) : 512;
-  }
+  g_free_cp_max = oh_launch_opts().free_cp_max;  // (per call: the handle's option "free_cp_max")
   const dim3 g(8 * ((D.B + 7) / 8));
   if constexpr (N == 7) {
-    const char* e = getenv("OH_FREE_BB");  // 0: the cyclic-reduction kernels of rounds 2-3 (A/B, tests)
-    if (!e || atoi(e) != 0) {
+    if (oh_launch_opts().free_bb != 0) {  // option "free_bb" = 0: the cyclic-reduction kernels of rounds 2-3 (A/B, tests)
       const int nK = P.T - P.t0, KH = nK - nK / 2;
       hipLaunchKernelGGL((k_step_free_bb<N, GUARD, VEL>), g, dim3(128), sizeof(double) * 2 * (size_t)KH * 72, s, P, D, GB, slot, KH);
       return;

@@ -30,6 +30,19 @@ bool oh_launch_eval_free(hipStream_t s, int n, const FigParams& P, const FigBuff
 bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_couple_free_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
 bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot, bool pcr = false);  // pcr: one block per instance
+// Scheduling choices of the launchers that are not part of a kernel's parameter block.  oh_api.hip fills this from the handle's options
+// (oh_set_option) at the start of every call; until round 4 the launchers read OH_* environment variables themselves.
+struct OhLaunchOpts {
+  int free_bb = 1;         // position-tracking family, 7 joints, <= free_pcr_max instances: twisted factorisation (k_step_free_bb); 0: the cyclic-reduction kernels
+  int free_cp_max = 512;   // ... cyclic reduction with eight lanes per knot up to this many instances (horizons <= 64 knots)
+  int pm_wave_max = 20480; // point mass: a wavefront per plant up to this many plants
+  int qp_mode = -1;        // dense QP: -1 automatic, 0 / 1 / 2 force a work-set placement
+  int tape_lds_max = 1 << 30;  // generated tape evaluators: the solver's work set in LDS up to this many instances (0: never)
+  int tape_wave_nt = 256;  // wavefront tape evaluator: threads per instance (256 or 64)
+  int tape_wave_regs = -1; // ... register file: -1 chosen per launch, 0 global memory, 1 LDS
+  int tape_wave_hist = -1; // ... quasi-Newton pairs: -1 in LDS when they fit, 0 global memory
+};
+OhLaunchOpts& oh_launch_opts();  // of the calling thread (a handle is not thread-safe; the options of the handle in the call)
 bool oh_launch_setup_guards(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const double* p);
 void oh_launch_guard_infeasible(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const double* p, int B, double* kkt, int* status);
 bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);

@@ -638,8 +638,7 @@ void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, co
                         int* iters, int* status) {
   // a wavefront per instance while that leaves the chip room (the thread kernel issues ~8x fewer instructions per instance, but needs ~10^5
   // instances to fill the SIMDs: 1024 plants take 3.5 ms with it and 0.7 ms here)
-  const char* e = getenv("OH_PM_WAVE_MAX");
-  const int wave_max = e ? atoi(e) : 20480;  // (tools/gpu_pm_sweep.py: 16 384 plants 6.8 / 5.8 ms thread / wave kernel, 32 768 9.8 / 11.3 ms)
+  const int wave_max = oh_launch_opts().pm_wave_max;  // option "pm_wave_max", default 20480  // (tools/gpu_pm_sweep.py: 16 384 plants 6.8 / 5.8 ms thread / wave kernel, 32 768 9.8 / 11.3 ms)
   if (P.T <= 64 && D.B <= wave_max) hipLaunchKernelGGL(k_pm_solve_wave, dim3(D.B), dim3(64), 0, s, P, D.B, x0, p, x, f, kkt, iters, status);
   else hipLaunchKernelGGL(k_pm_solve, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p, x, f, kkt, iters, status);
 }

@@ -492,13 +492,7 @@ __device__ double qp_tape_forward(const QpTape& tp, const double* xs, const doub
       case 3: v = val[QIDX(ia)] + val[QIDX(ib)]; break;
       case 4: v = val[QIDX(ia)] - val[QIDX(ib)]; break;
       case 5: v = val[QIDX(ia)] * val[QIDX(ib)]; break;
-      case 6: v = val[QIDX(ia)] / val[QIDX(ib)]; break;
-      case 7: v = -val[QIDX(ia)]; break;
-      case 8: v = sin(val[QIDX(ia)]); break;
-      case 9: v = cos(val[QIDX(ia)]); break;
-      case 10: v = atan2(val[QIDX(ia)], val[QIDX(ib)]); break;
-      case 11: v = sqrt(val[QIDX(ia)]); break;
-      default: { const double t = val[QIDX(ia)]; v = t * t; } break;
+      default: v = tape_op_value(o, val[QIDX(ia)], tape_op_arity(o) == 2 ? val[QIDX(ib)] : 0.0); break;  // 6 .. 26 (coefficients may be any function of p)
     }
     val[QIDX(i)] = v;
   }
@@ -631,7 +625,7 @@ void oh_launch_qp_solve(hipStream_t s, const QpParams& Q, int B, int Bp, const d
       if (sizeof(double) * doubles * c <= 48 * 1024) return c;
     return 0;
   };
-  static const int forced = getenv("OH_QP_MODE") ? atoi(getenv("OH_QP_MODE")) : -1;  // experiments
+  const int forced = oh_launch_opts().qp_mode;  // option "qp_mode" (experiments)
   const int bs2 = fit((size_t)Q.nwork + Q.np), bs1 = fit((size_t)Q.nwork);
   const size_t wave_bytes = sizeof(double) * ((size_t)Q.nwork + Q.np);
   if (forced != 0 && forced != 1 && forced != 2 && B <= 64 && wave_bytes <= 48 * 1024) {  // a few instances: one wavefront each

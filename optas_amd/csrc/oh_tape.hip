@@ -78,7 +78,10 @@ struct InterpEval {
         case 21: v = val[TIDX(ia)] == 0.0 ? 1.0 : 0.0; break;
         case 22: v = (val[TIDX(ia)] != 0.0 && val[TIDX(ib)] != 0.0) ? 1.0 : 0.0; break;
         case 23: v = (val[TIDX(ia)] != 0.0 || val[TIDX(ib)] != 0.0) ? 1.0 : 0.0; break;
-        default: v = val[TIDX(ia)] != 0.0 ? val[TIDX(ib)] : 0.0; break;  // 24: if_else_zero
+        case 24: v = val[TIDX(ia)] != 0.0 ? val[TIDX(ib)] : 0.0; break;  // if_else_zero
+        // round 5: exp and log -- with them the walker expresses pow, tanh, sinh, cosh, acos, atan, the inverse hyperbolics (casadi_tape.py)
+        case 25: v = exp(val[TIDX(ia)]); break;
+        default: v = log(val[TIDX(ia)]); break;  // 26
       }
       val[TIDX(i)] = v;
     }
@@ -109,6 +112,8 @@ struct InterpEval {
         case 15: if (val[TIDX(ia)] <= val[TIDX(ib)]) adj[TIDX(ia)] += w; else adj[TIDX(ib)] += w; break;  // casadi: d fmin = (x <= y, !(x <= y))
         case 16: if (val[TIDX(ia)] >= val[TIDX(ib)]) adj[TIDX(ia)] += w; else adj[TIDX(ib)] += w; break;
         case 24: if (val[TIDX(ia)] != 0.0) adj[TIDX(ib)] += w; break;
+        case 25: adj[TIDX(ia)] += w * val[TIDX(i)]; break;
+        case 26: adj[TIDX(ia)] += w / val[TIDX(ia)]; break;
         default: break;  // 17..23: comparisons and logic are piecewise constant
       }
     }
@@ -206,6 +211,8 @@ std::string generate(const TapeParams& T, const int* op, const int* a, const int
       case 22: emit(s, "    const double v%d = (v%d != 0.0 && v%d != 0.0) ? 1.0 : 0.0;\n", i, a[i], bb[i]); break;
       case 23: emit(s, "    const double v%d = (v%d != 0.0 || v%d != 0.0) ? 1.0 : 0.0;\n", i, a[i], bb[i]); break;
       case 24: emit(s, "    const double v%d = v%d != 0.0 ? v%d : 0.0;\n", i, a[i], bb[i]); break;
+      case 25: emit(s, "    const double v%d = exp(v%d);\n", i, a[i]); break;
+      case 26: emit(s, "    const double v%d = log(v%d);\n", i, a[i]); break;
       default: emit(s, "    const double v%d = v%d * v%d;\n", i, a[i], a[i]); break;
     }
   }
@@ -286,6 +293,12 @@ std::string generate(const TapeParams& T, const int* op, const int* a, const int
       } break;
       case 24:
         if (db) emit(s, "    if (v%d != 0.0) a%d += a%d;\n", ia, ib, i);
+        break;
+      case 25:
+        if (da) emit(s, "    a%d += a%d * v%d;\n", ia, i, i);
+        break;
+      case 26:
+        if (da) emit(s, "    a%d += a%d / v%d;\n", ia, i, ia);
         break;
       default:  // 17..23: comparisons and logic are piecewise constant
         break;
@@ -402,11 +415,10 @@ hipError_t oh_launch_tape_jit(hipStream_t s, const TapeJit& j, TapeParams T, int
                               double* kkt, int* iters, int* status, double* mult) {
   void* args[] = {&T, &B, &Bp, &x0, &p, &work, &x, &f, &kkt, &iters, &status, &mult};
   // the solver's work set in LDS when it fits 48 KB at 64, 32 or 16 instances per block (tools/gpu_tape_sweep.py, the 7-joint IK problem: one
-  // instance 5.0 -> 3.4 ms, 2048 14.3 -> 10.9 ms, 32 768 25.8 -> 21.0 ms; OH_TAPE_LDS_MAX = 0 switches it off)
-  const char* e = getenv("OH_TAPE_LDS_MAX");
+  // instance 5.0 -> 3.4 ms, 2048 14.3 -> 10.9 ms, 32 768 25.8 -> 21.0 ms; option tape_lds_max = 0 switches it off)
   // (round 2: level above 32 768 instances -- 65 536: 30.2 / 33.5 ms, 131 072: 47.5 / 44.9 ms global / LDS; with the solver of round 3's end, which
   // spends 65 evaluations instead of 266 on the median instance, the LDS set wins at every size: 65 536: 9.8 / 7.7 ms, 131 072: 17.5 / 13.2 ms)
-  const int lds_max = e ? atoi(e) : (1 << 30);
+  const int lds_max = oh_launch_opts().tape_lds_max;  // option "tape_lds_max"
   if (j.fn_lds && B <= lds_max) {
     const size_t per = sizeof(double) * tape_solver_rows(T);
     for (int bs : {64, 32, 16})

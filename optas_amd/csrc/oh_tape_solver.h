@@ -40,6 +40,38 @@ __device__ inline TapeWork tape_carve(const TapeParams& T, double* w, const int 
 }
 
 // PHR terms of one row: add the row's share of the merit and of the two constraint measures, return the seed of the reverse sweep
+// Value of one tape instruction with operand values va, vb (ops 6 .. 26 of include/optas_hip.h; CONST / X / P / ADD / SUB / MUL are the callers' business).
+// One IEEE operation or one libm call per instruction, as the numpy restatement and casadi's SX machine compute them.
+__device__ inline double tape_op_value(const int o, const double va, const double vb) {
+  switch (o) {
+    case 6: return va / vb;
+    case 7: return -va;
+    case 8: return sin(va);
+    case 9: return cos(va);
+    case 10: return atan2(va, vb);
+    case 11: return sqrt(va);
+    case 12: return va * va;
+    case 13: return asin(va);
+    case 14: return fabs(va);
+    case 15: return fmin(va, vb);
+    case 16: return fmax(va, vb);
+    case 17: return va < vb ? 1.0 : 0.0;
+    case 18: return va <= vb ? 1.0 : 0.0;
+    case 19: return va == vb ? 1.0 : 0.0;
+    case 20: return va != vb ? 1.0 : 0.0;
+    case 21: return va == 0.0 ? 1.0 : 0.0;
+    case 22: return (va != 0.0 && vb != 0.0) ? 1.0 : 0.0;
+    case 23: return (va != 0.0 || vb != 0.0) ? 1.0 : 0.0;
+    case 24: return va != 0.0 ? vb : 0.0;
+    case 25: return exp(va);
+    default: return log(va);
+  }
+}
+// operands an instruction reads: 0 (CONST, X, P), 1 or 2
+__host__ __device__ inline int tape_op_arity(const int o) {
+  if (o <= 2) return 0;
+  return ((o >= 3 && o <= 6) || o == 10 || (o >= 15 && o <= 20) || (o >= 22 && o <= 24)) ? 2 : 1;
+}
 __device__ inline double tape_al_ineq(const double g, const double lam, const double rho, double& val, double& cm, double& ms) {
   const double s = fmax(0.0, lam - rho * g);
   val += (s * s - lam * lam) / (2.0 * rho);

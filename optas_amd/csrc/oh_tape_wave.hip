@@ -160,6 +160,8 @@ struct WaveEval {
             case 22: v = (va != 0.0 && vb != 0.0) ? 1.0 : 0.0; break;
             case 23: v = (va != 0.0 || vb != 0.0) ? 1.0 : 0.0; break;
             case 24: v = va != 0.0 ? vb : 0.0; break;  // if_else_zero
+            case 25: v = exp(va); break;
+            case 26: v = log(va); break;
             default: break;
           }
         }
@@ -230,6 +232,8 @@ struct WaveEval {
               case 15: if (va <= vb) ca = w; else cb = w; break;
               case 16: if (va >= vb) ca = w; else cb = w; break;
               case 24: if (va != 0.0) cb = w; break;
+              case 25: ca = w * val[i]; break;
+              case 26: ca = w / va; break;
               default: break;  // 17..23: piecewise constant
             }
           }
@@ -509,9 +513,8 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
   *out = TapeWave{};
   if (T.lbfgs <= 0) return 0;
   // threads per instance: four wavefronts (the register file allows one block per CU: one wavefront would leave three SIMDs idle, and the wide
-  // first levels of a trajectory tape are 400-800 instructions); OH_TAPE_WAVE_NT=64: one
-  const char* ent = getenv("OH_TAPE_WAVE_NT");
-  const int NT = (ent && atoi(ent) == 64) ? 64 : 256;
+  // first levels of a trajectory tape are 400-800 instructions); option tape_wave_nt = 64: one
+  const int NT = oh_launch_opts().tape_wave_nt == 64 ? 64 : 256;  // option "tape_wave_nt"
   out->nt = NT;
   const int L = T.len, nrows = T.n_ineq + T.n_eq;
   auto is_binary = [](int o) { return (o >= 3 && o <= 6) || o == 10 || (o >= 15 && o <= 20) || (o >= 22 && o <= 24); };
@@ -678,16 +681,15 @@ int oh_tape_wave_build(const TapeParams& T, const int* op, const int* a, const i
   // Placement of the register file, decided per launch: in LDS (one block per CU: the lowest latency) for small batches, in global memory
   // (the block's own lines; the LDS then holds the vectors and the pairs only: two or more blocks per CU) for large ones and for tapes whose
   // registers do not fit -- the planner: 4 instances 96 / 125 ms, 4096 instances 1.99 / 1.60 s.  Same arithmetic, same bits either way.
-  const char* er = getenv("OH_TAPE_WAVE_REGS");  // "global" / "lds": force one placement
-  out->reg_choice = er ? (er[0] == 'g' ? 0 : 1) : -1;
+  out->reg_choice = oh_launch_opts().tape_wave_regs;  // option "tape_wave_regs": 0 global / 1 LDS forces one placement
   out->reg_lds_fits = oh_tape_wave_lds_bytes(T, *out, false, true) <= lds_limit;
   const bool global_ok = NT == 256 && oh_tape_wave_lds_bytes(T, *out, false, false) <= lds_limit;  // (the global-memory placement is built for four wavefronts)
   if (!out->reg_lds_fits && !global_ok) return 0;  // not even the vectors fit: the thread-per-instance path stays
   if (!global_ok) out->reg_choice = 1;
   if (!out->reg_lds_fits) out->reg_choice = 0;
-  const char* eh = getenv("OH_TAPE_WAVE_HIST");  // "global": keep the (s, y) pairs out of the LDS even when they fit (the path big problems take)
+  const bool hist_global = oh_launch_opts().tape_wave_hist == 0;  // option "tape_wave_hist" = 0: keep the (s, y) pairs out of the LDS even when they fit (the path big problems take)
   for (int rl = 0; rl < 2; ++rl) {
-    out->hist_lds_by[rl] = oh_tape_wave_lds_bytes(T, *out, true, rl == 1) <= lds_limit && !(eh && eh[0] == 'g');
+    out->hist_lds_by[rl] = oh_tape_wave_lds_bytes(T, *out, true, rl == 1) <= lds_limit && !hist_global;
     out->lds_bytes_by[rl] = oh_tape_wave_lds_bytes(T, *out, out->hist_lds_by[rl], rl == 1);
   }
   out->reg_lds = out->reg_choice != 0;

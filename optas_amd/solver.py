@@ -278,6 +278,8 @@ class HIPSolver(Solver):
         if solver_name != "hip_sqp":
             raise ValueError(f"solver '{solver_name}' does not support this problem type")  # solver.py:371-373
         o = dict(solver_options or {})
+        # options of the library handle(s) behind this solver (include/optas_hip.h: oh_set_option), e.g. {"batch_invariant": 1}
+        handle_options = dict(o.pop("options", None) or {})
         kind, spec = lower(self.opt)
         self._kind, self._spec = kind, spec
         hessian = {"gauss_newton": _lib.OH_HESSIAN_GAUSS_NEWTON, "exact": _lib.OH_HESSIAN_EXACT, "hybrid": _lib.OH_HESSIAN_HYBRID}[o.get("hessian", "hybrid")]
@@ -289,6 +291,14 @@ class HIPSolver(Solver):
                 self._backend = _LeadAdapter(self.opt, spec, self._backend)
         elif isinstance(spec, TorqueSpec):
             o.pop("hessian", None)
+            # (round 3 names of the augmented-Lagrangian solver this family had before the interior point: accepted, ignored, said so -- ADVICE r4)
+            for old, new in (("tol_feas", "tol_compl"), ("rho0", "mu_barrier0")):
+                if old in o:
+                    import warnings
+
+                    warnings.warn(f"hip_sqp / torque MPC: option '{old}' belonged to the round-3 augmented-Lagrangian solver and is ignored; the interior point "
+                                  f"takes '{new}'", DeprecationWarning, stacklevel=2)
+                    o.pop(old)
             self._backend = TorqueBackend(spec.robot.solver_chain(spec.link), spec.robot.dynamics_tables(), T=spec.T, dt=spec.dt, w_path=spec.w_path,
                                           w_vel=spec.w_vel, w_tau=spec.w_tau, tau_lo=spec.tau_lo, tau_up=spec.tau_up, dq_lo=getattr(spec, "dq_lo", None), dq_up=getattr(spec, "dq_up", None),
                                           max_iter=int(o.pop("max_iter", 300)), tol=float(o.pop("tol", 1e-6)), tol_compl=float(o.pop("tol_compl", 1e-8)),
@@ -331,6 +341,11 @@ class HIPSolver(Solver):
             raise NotImplementedError(kind)
         if o:
             raise ValueError(f"unknown solver options {sorted(o)}")
+        if handle_options:
+            target = self._backend
+            while not hasattr(target, "set_options") and hasattr(target, "be"):  # the adapters keep their backend in .be
+                target = target.be
+            target.set_options(handle_options)
         self._stats: Optional[dict] = None
         self._x0_batch: Optional[np.ndarray] = None
         self._p_batch: Optional[np.ndarray] = None

@@ -7,7 +7,8 @@ Instruction i writes register i (SSA).  ops:  CONST c | X k (decision variable k
 SUB a b | MUL a b | DIV a b | NEG a | SIN a | COS a | ATAN2 a b | SQRT a | SQR a, and (round 4: what the reference's own graphs emit beyond
 those -- Quaternion.getrpy, spatialmath.py:384-404, and optas.clip, __init__.py:29-41) ASIN a | FABS a | FMIN a b | FMAX a b | LT a b | LE a b |
 EQ a b | NE a b | NOT a | AND a b | OR a b (1.0 / 0.0 valued, zero derivative) | IFZ a b (casadi's if_else_zero: b where a != 0, else 0;
-if_else(c, x, y) = IFZ(c, x) + IFZ(NOT c, y)).  Common sub-expressions are shared (hash-consing), constants are folded.  Link functions (position / rotation / quaternion / geometric Jacobian of a serial chain) are expanded with the
+if_else(c, x, y) = IFZ(c, x) + IFZ(NOT c, y)), and (round 5: user costs written with `from casadi import *`, optas/__init__.py:2) EXP a | LOG a, through which the
+builder also expresses pow, tanh, sinh, cosh, acos, atan, asinh, acosh, atanh, log1p, expm1 and sign.  Common sub-expressions are shared (hash-consing), constants are folded.  Link functions (position / rotation / quaternion / geometric Jacobian of a serial chain) are expanded with the
 same chain walk as RobotModel.get_global_link_transform (models.py:826-868) over scalar registers.
 """
 from __future__ import annotations
@@ -24,7 +25,8 @@ from .spatialmath import rpy2r
 
 OP_CONST, OP_X, OP_P, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SIN, OP_COS, OP_ATAN2, OP_SQRT, OP_SQR = range(13)
 OP_ASIN, OP_FABS, OP_FMIN, OP_FMAX, OP_LT, OP_LE, OP_EQ, OP_NE, OP_NOT, OP_AND, OP_OR, OP_IFZ = range(13, 25)
-N_OPS = 25
+OP_EXP, OP_LOG = 25, 26  # round 5
+N_OPS = 27
 MAX_TAPE = 1 << 18
 
 
@@ -168,6 +170,73 @@ class TapeBuilder:
         if self.is_const(c):
             return x if self._const[c] != 0.0 else self.const(0.0)
         return self._emit(OP_IFZ, c, x)
+
+    # ---- round 5: exp and log as instructions; the other elementary functions casadi offers (`from casadi import *`, optas/__init__.py:2)
+    # composed from the instruction set, so that every evaluator, the reverse sweeps included, has two cases more and not twelve ---------------
+    def exp(self, a):
+        return self._fold1(OP_EXP, a, lambda v: float(np.exp(v)))
+
+    def log(self, a):
+        return self._fold1(OP_LOG, a, lambda v: float(np.log(v)) if v > 0.0 else (float("-inf") if v == 0.0 else float("nan")))
+
+    def pow(self, a, b):
+        """x ** y: repeated squaring for small non-negative integer constants, sqrt / reciprocal, otherwise exp(y log x) -- defined for x > 0, where
+        its value and both partial derivatives are casadi's (y x^(y-1), x^y log x)."""
+        if self.is_const(b):
+            e = self._const[b]
+            if e == 0.5:
+                return self.sqrt(a)
+            if e == -1.0:
+                return self.div(self.const(1.0), a)
+            if e == int(e) and 0 <= int(e) <= 8:
+                out, base, k = self.const(1.0), a, int(e)
+                while k:
+                    if k & 1:
+                        out = self.mul(out, base)
+                    base, k = self.sqr(base), k >> 1
+                return out
+            if e == int(e) and -8 <= int(e) < 0:
+                return self.div(self.const(1.0), self.pow(a, self.const(-e)))
+        return self.exp(self.mul(b, self.log(a)))
+
+    def tanh(self, a):
+        """1 - 2 / (exp(2x) + 1): exact limits -1 / +1 where exp under- / overflows."""
+        return self.sub(self.const(1.0), self.div(self.const(2.0), self.add(self.exp(self.add(a, a)), self.const(1.0))))
+
+    def sinh(self, a):
+        return self.mul(self.const(0.5), self.sub(self.exp(a), self.exp(self.neg(a))))
+
+    def cosh(self, a):
+        return self.mul(self.const(0.5), self.add(self.exp(a), self.exp(self.neg(a))))
+
+    def acos(self, a):
+        return self.sub(self.const(float(np.pi / 2)), self.asin(a))
+
+    def atan(self, a):
+        return self.atan2(a, self.const(1.0))
+
+    def tan(self, a):
+        return self.div(self.sin(a), self.cos(a))
+
+    def asinh(self, a):
+        return self.log(self.add(a, self.sqrt(self.add(self.sqr(a), self.const(1.0)))))
+
+    def acosh(self, a):
+        return self.log(self.add(a, self.sqrt(self.sub(self.sqr(a), self.const(1.0)))))
+
+    def atanh(self, a):
+        return self.mul(self.const(0.5), self.log(self.div(self.add(self.const(1.0), a), self.sub(self.const(1.0), a))))
+
+    def log1p(self, a):
+        return self.log(self.add(self.const(1.0), a))
+
+    def expm1(self, a):
+        return self.sub(self.exp(a), self.const(1.0))
+
+    def sign(self, a):
+        """(x > 0) - (x < 0); zero derivative like casadi's."""
+        z = self.const(0.0)
+        return self.sub(self.lt(z, a), self.lt(a, z))
 
     def if_else(self, c, x, y):
         """casadi.if_else(c, x, y) as the SX graph holds it: if_else_zero(c, x) + if_else_zero(!c, y)."""

@@ -5,6 +5,7 @@ import numpy as np
 
 OP_CONST, OP_X, OP_P, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SIN, OP_COS, OP_ATAN2, OP_SQRT, OP_SQR = range(13)
 OP_ASIN, OP_FABS, OP_FMIN, OP_FMAX, OP_LT, OP_LE, OP_EQ, OP_NE, OP_NOT, OP_AND, OP_OR, OP_IFZ = range(13, 25)
+OP_EXP, OP_LOG = 25, 26
 
 
 def forward(tape, x, p):
@@ -62,6 +63,10 @@ def forward(tape, x, p):
             v[i] = float(v[a] != 0.0 or v[b] != 0.0)
         elif o == OP_IFZ:
             v[i] = v[b] if v[a] != 0.0 else 0.0
+        elif o == OP_EXP:
+            v[i] = np.exp(v[a])
+        elif o == OP_LOG:
+            v[i] = np.log(v[a])
     return v
 
 
@@ -122,6 +127,10 @@ def reverse(tape, v, seeds):
         elif o == OP_IFZ:
             if v[a] != 0.0:
                 adj[b] += w
+        elif o == OP_EXP:
+            adj[a] += w * v[i]
+        elif o == OP_LOG:
+            adj[a] += w / v[a]
         # comparisons and logic: piecewise constant, no derivative
     return g
 

@@ -46,3 +46,28 @@ def hip_lib():
     if _lib.device_count() < 1:
         pytest.fail("GPU test selected but no HIP device is visible: liboptas_hip has no CPU path")
     return lib
+
+
+_OPTION_ALIASES = {"tq_jac": "tq_jac_dual"}
+_WORDS = {"dual": 1.0, "global": 0.0, "lds": 1.0, "auto": 2.0}
+
+
+def oh_debug(monkeypatch, **kw):
+    """Options for the handles created from here on, through the library's one environment hook (OH_DEBUG_OPTIONS = "name=value,..."; per-handle
+    oh_set_option is what product code uses).  Names as in include/optas_hip.h (an OH_ prefix / upper case is accepted); value None removes a name."""
+    cur = {}
+    for item in filter(None, os.environ.get("OH_DEBUG_OPTIONS", "").split(",")):
+        k, v = item.split("=")
+        cur[k] = v
+    for k, v in kw.items():
+        k = k.lower()
+        k = k[3:] if k.startswith("oh_") else k
+        k = _OPTION_ALIASES.get(k, k)
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = repr(float(_WORDS.get(v, v) if isinstance(v, str) else v))
+    if cur:
+        monkeypatch.setenv("OH_DEBUG_OPTIONS", ",".join(f"{k}={v}" for k, v in cur.items()))
+    else:
+        monkeypatch.delenv("OH_DEBUG_OPTIONS", raising=False)

@@ -9,7 +9,8 @@ import numpy as np
 OP_ASSIGN, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_SIN, OP_COS, OP_SQRT, OP_SQ, OP_TWICE, OP_INV, OP_ATAN2, OP_CONSTPOW, OP_TAN = range(101, 116)
 OP_CONST, OP_INPUT, OP_OUTPUT, OP_FABS, OP_POW = 201, 202, 203, 204, 205
 OP_ASIN, OP_FMIN, OP_FMAX, OP_LT, OP_LE, OP_EQ, OP_NE, OP_NOT, OP_AND, OP_OR, OP_IF_ELSE_ZERO = range(301, 312)
-OP_EXP = 401  # an opcode the tape has no counterpart for
+OP_EXP, OP_LOG, OP_ACOS, OP_ATAN, OP_TANH, OP_SINH, OP_COSH, OP_ASINH, OP_ACOSH, OP_ATANH, OP_LOG1P, OP_EXPM1, OP_SIGN = range(401, 414)
+OP_ERF = 501  # an opcode the tape has no counterpart for
 
 
 class SX:
@@ -31,7 +32,7 @@ class SX:
     def __truediv__(self, o): return SX(OP_DIV, (self, SX.wrap(o)))
     def __rtruediv__(self, o): return SX(OP_DIV, (SX.wrap(o), self))
     def __neg__(self): return SX(OP_NEG, (self,))
-    def __pow__(self, e): return SX(OP_CONSTPOW, (self, SX.wrap(e)))
+    def __pow__(self, e): return SX(OP_POW if isinstance(e, SX) else OP_CONSTPOW, (self, SX.wrap(e)))
     def __lt__(self, o): return SX(OP_LT, (self, SX.wrap(o)))
     def __le__(self, o): return SX(OP_LE, (self, SX.wrap(o)))
     def __gt__(self, o): return SX(OP_LT, (SX.wrap(o), self))  # casadi keeps LT / LE only and swaps the operands
@@ -48,6 +49,20 @@ def inv(a): return SX(OP_INV, (a,))
 def fabs(a): return SX(OP_FABS, (a,))
 def asin(a): return SX(OP_ASIN, (a,))
 def exp(a): return SX(OP_EXP, (a,))
+def log(a): return SX(OP_LOG, (a,))
+def acos(a): return SX(OP_ACOS, (a,))
+def atan(a): return SX(OP_ATAN, (a,))
+def tanh(a): return SX(OP_TANH, (a,))
+def sinh(a): return SX(OP_SINH, (a,))
+def cosh(a): return SX(OP_COSH, (a,))
+def asinh(a): return SX(OP_ASINH, (a,))
+def acosh(a): return SX(OP_ACOSH, (a,))
+def atanh(a): return SX(OP_ATANH, (a,))
+def log1p(a): return SX(OP_LOG1P, (a,))
+def expm1(a): return SX(OP_EXPM1, (a,))
+def sign(a): return SX(OP_SIGN, (a,))
+def erf(a): return SX(OP_ERF, (a,))
+def power(a, b): return SX(OP_POW, (SX.wrap(a), SX.wrap(b)))
 def fmin(a, b): return SX(OP_FMIN, (SX.wrap(a), SX.wrap(b)))
 def fmax(a, b): return SX(OP_FMAX, (SX.wrap(a), SX.wrap(b)))
 def logic_not(a): return SX(OP_NOT, (a,))
@@ -156,6 +171,18 @@ class Function:
             elif op == OP_FABS: w[o[0]] = abs(w[i[0]])
             elif op == OP_ASIN: w[o[0]] = math.asin(w[i[0]])
             elif op == OP_EXP: w[o[0]] = math.exp(w[i[0]])
+            elif op == OP_LOG: w[o[0]] = math.log(w[i[0]])
+            elif op == OP_ACOS: w[o[0]] = math.acos(w[i[0]])
+            elif op == OP_ATAN: w[o[0]] = math.atan(w[i[0]])
+            elif op == OP_TANH: w[o[0]] = math.tanh(w[i[0]])
+            elif op == OP_SINH: w[o[0]] = math.sinh(w[i[0]])
+            elif op == OP_COSH: w[o[0]] = math.cosh(w[i[0]])
+            elif op == OP_ASINH: w[o[0]] = math.asinh(w[i[0]])
+            elif op == OP_ACOSH: w[o[0]] = math.acosh(w[i[0]])
+            elif op == OP_ATANH: w[o[0]] = math.atanh(w[i[0]])
+            elif op == OP_LOG1P: w[o[0]] = math.log1p(w[i[0]])
+            elif op == OP_EXPM1: w[o[0]] = math.expm1(w[i[0]])
+            elif op == OP_SIGN: w[o[0]] = float((w[i[0]] > 0) - (w[i[0]] < 0))
             elif op == OP_FMIN: w[o[0]] = min(w[i[0]], w[i[1]])
             elif op == OP_FMAX: w[o[0]] = max(w[i[0]], w[i[1]])
             elif op == OP_LT: w[o[0]] = float(w[i[0]] < w[i[1]])

@@ -26,6 +26,16 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"liboptas_hip.so does not export {name}"
     assert lib.oh_version().startswith(b"optas_hip")
+    assert lib.oh_abi_version() == _lib.OH_ABI_VERSION  # the binding refuses a library built for other struct layouts (_lib.load)
+    assert lib.oh_set_option(None, b"tail_threshold", C.c_double(0.0)) == 1 and lib.oh_get_option(None, b"tail_threshold", None) == 1
+
+
+def test_status_helpers():
+    import numpy as np
+
+    assert list(_lib.status_ok([0, 1, 2, 3, 4])) == [True, False, False, False, True]  # converged and acceptable level are successes (solver.py:407-412)
+    assert list(_lib.worse_status([0, 4, 1, 3, 0], [4, 0, 3, 1, 2])) == [4, 4, 3, 3, 2]
+    assert _lib.STATUS_NAMES[3] == "Infeasible_Problem_Detected" and _lib.STATUS_NAMES[4] == "Solved_To_Acceptable_Level"
 
 
 def test_struct_layout_matches_header():

@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 
 import bench
-from conftest import KUKA_KIN
+from conftest import KUKA_KIN, oh_debug
 from optas_amd.backend import FigureEightBackend
 from optas_amd.models import RobotModel
 from oracle.problems import FigureEightNLP
@@ -29,16 +29,13 @@ from oracle.structured import StructuredFigureEight, solve_structured_lm
 
 pytestmark = pytest.mark.gpu
 LINK = "end_effector_ball"
-ENV_KNOBS = ("OH_TAIL_THRESHOLD", "OH_COMPACTION", "OH_COMPACT_FRAC", "OH_COMPACT_SORT", "OH_COMPACT_CARRY", "OH_ROW_PAD", "OH_SPECIALIZE", "OH_CHECK_EVERY",
-             "OH_HYB_SWITCH", "OH_RELAX", "OH_RELAX_FROM")
 
 
 @pytest.mark.parametrize("B", [65536, 262144])
 def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B):
     from oracle import cpu_port
 
-    for k in ENV_KNOBS:  # nothing forced: the library's defaults, as in the driver's bench run
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("OH_DEBUG_OPTIONS", raising=False)  # nothing forced: the library's defaults, as in the driver's bench run
     orc = OracleRobot(KUKA_KIN)
     nlp = FigureEightNLP(orc, LINK, T=bench.T, Tmax=bench.TMAX)
     dt, lp = bench.local_path()
@@ -105,8 +102,7 @@ def test_batch_close_to_the_per_call_bound(hip_lib, monkeypatch):
     batch of their own to the last bit (same kernels, other lanes irrelevant) and the compiled host port."""
     from oracle import cpu_port
 
-    for k in ENV_KNOBS:
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("OH_DEBUG_OPTIONS", raising=False)
     B = 458752
     dt, lp = bench.local_path()
     chain = RobotModel(urdf_filename=KUKA_KIN).kinematic_chain(LINK)

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import KUKA_KIN, SEED
+from conftest import KUKA_KIN, SEED, oh_debug
 from oracle.guarded import Guards, solve_free_al
 from oracle.problems import GuardedDualArmNLP, dual_arm_offsets
 from oracle.robot import OracleRobot
@@ -100,7 +100,7 @@ def test_velocity_limited_arms_batch_both_sweeps_and_compaction(hip_lib, monkeyp
         X0[:, xoff[name] : xoff[name] + 7 * T] = np.tile(qc, (1, T))
     out = {}
     for mode in ("0", "4096"):
-        monkeypatch.setenv("OH_FREE_PCR_MAX", mode)
+        oh_debug(monkeypatch, free_pcr_max=mode)
         mb = MultiArmBackend(spec, o, max_iter=600)
         r = mb.solve(X0, P)
         out[mode] = (r, [be.multipliers(B) for _, be in mb.arms], [be.timing()["compactions"] for _, be in mb.arms])

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 import optas_amd
-from conftest import GOLDEN, KUKA_KIN, SEED
+from conftest import GOLDEN, KUKA_KIN, SEED, oh_debug
 from optas_amd import _lib
 from optas_amd.backend import FigureEightBackend
 from optas_amd.models import RobotModel
@@ -218,7 +218,7 @@ def test_state_machine_matches_numpy_port(hip_lib, nlp, hessian, tail, monkeypat
     machine oracle/structured.py:solve_structured_lm restates: same step counts, same rejections, same optimum."""
     from oracle.structured import solve_structured_lm
 
-    monkeypatch.setenv("OH_TAIL_THRESHOLD", str(tail))
+    oh_debug(monkeypatch, tail_threshold=str(tail))
     robot = RobotModel(urdf_filename=KUKA_KIN)
     mode = {"gauss_newton": _lib.OH_HESSIAN_GAUSS_NEWTON, "hybrid": _lib.OH_HESSIAN_HYBRID}[hessian]
     be = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6, hessian=mode)
@@ -248,7 +248,7 @@ def test_batch_machinery_matches_serial_cpu_port(hip_lib, nlp, monkeypatch):
     import bench
     from oracle import cpu_port
 
-    monkeypatch.setenv("OH_TAIL_THRESHOLD", "2048")  # (the default hands a batch of this size to the tail kernel as a whole)
+    oh_debug(monkeypatch, tail_threshold="2048")  # (the default hands a batch of this size to the tail kernel as a whole)
     robot = RobotModel(urdf_filename=KUKA_KIN)
     chain = robot.kinematic_chain(LINK)
     be = FigureEightBackend(chain, 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)
@@ -279,13 +279,13 @@ def test_compaction_schedule_does_not_change_the_answers(hip_lib, nlp, monkeypat
     chain = robot.kinematic_chain(LINK)
     B = 6144
     x0, qc = bench.make_inputs(B, 11)
-    monkeypatch.setenv("OH_TAIL_THRESHOLD", "2048")  # (the default hands a batch of this size to the tail kernel as a whole)
+    oh_debug(monkeypatch, tail_threshold="2048")  # (the default hands a batch of this size to the tail kernel as a whole)
     res = {}
     for tag, env in (("off", {"OH_COMPACTION": "0"}), ("half", {"OH_COMPACT_FRAC": "0.5", "OH_COMPACT_SORT": "0"}), ("default", {})):
         for k in ("OH_COMPACTION", "OH_COMPACT_FRAC", "OH_COMPACT_SORT"):
-            monkeypatch.delenv(k, raising=False)
+            oh_debug(monkeypatch, **{k: None})
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            oh_debug(monkeypatch, **{k: v})
         be = FigureEightBackend(chain, 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)
         res[tag] = be.solve(x0, qc)
         be.close()
@@ -332,7 +332,7 @@ def test_end_game_step_counts_equal_the_numpy_port_exactly(hip_lib, nlp, tail, m
     numpy restatement must take the SAME number of steps, rejections included, and land on the same objective to 1e-11."""
     from oracle.structured import solve_structured_lm
 
-    monkeypatch.setenv("OH_TAIL_THRESHOLD", str(tail))
+    oh_debug(monkeypatch, tail_threshold=str(tail))
     g = np.load(os.path.join(GOLDEN, "nlp_pert_dense_golden.npz"))
     robot = RobotModel(urdf_filename=KUKA_KIN)
     be = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)
@@ -396,7 +396,7 @@ def test_per_call_bound_covers_the_32_bit_offsets_of_the_fused_coupling(hip_lib,
     assert rc == _lib.OH_ERR_INVALID and b"split the batch" in _lib.load().oh_last_error()
     d.free()
     be.close()
-    monkeypatch.setenv("OH_FUSE_COUPLE", "0")  # the four-kernel path keeps the round-2 bound (the T x NZ^2 stage array)
+    oh_debug(monkeypatch, fuse_couple="0")  # the four-kernel path keeps the round-2 bound (the T x NZ^2 stage array)
     be2 = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)
     _lib.check(_lib.load().oh_max_batch(be2._h, C.byref(mb)), "oh_max_batch")
     assert mb.value > 550000  # (the Householder vectors, 3N - 3 rows per knot: 595 008)
@@ -412,9 +412,9 @@ def test_row_stride_padding_is_invisible(hip_lib, nlp, monkeypatch):
     x0 = np.zeros((B, nlp.nx))
     x0[:, : 7 * 50] = np.tile(qc, (1, 50))
     out = []
-    monkeypatch.setenv("OH_TAIL_THRESHOLD", "2048")  # the batched kernels are the ones that walk the rows
+    oh_debug(monkeypatch, tail_threshold="2048")  # the batched kernels are the ones that walk the rows
     for pad in ("0", "13", "5"):
-        monkeypatch.setenv("OH_ROW_PAD", pad)
+        oh_debug(monkeypatch, row_pad=pad)
         be = FigureEightBackend(robot.kinematic_chain(LINK), 50, nlp.dt, nlp.local_path.T, max_iter=300, tol=1e-6)
         out.append((be.solve(x0, qc), be.multipliers(B)))
         be.close()

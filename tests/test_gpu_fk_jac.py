@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import optas_amd
-from conftest import KUKA_KIN, MED7_KIN, SEED, TESTER_KIN
+from conftest import KUKA_KIN, MED7_KIN, SEED, TESTER_KIN, oh_debug
 from optas_amd import _lib
 from optas_amd.models import KinematicsHandle, RobotModel
 from oracle.robot import OracleRobot
@@ -140,7 +140,7 @@ def test_reference_layout_staging_for_long_and_partial_chains(hip_lib, monkeypat
     """The reference-layout kernel stages q, pose and J through LDS (a tile of 128 units x 6 ndof doubles: beyond 8 joints it needs more than
     the default 48 KB of dynamic LDS): a synthetic chain of up to 16 joints, with and without joints off the chain, must give what the SoA
     kernel -- no LDS, pinned against the oracle above -- gives, for block-ragged sizes."""
-    monkeypatch.setenv("OH_SPECIALIZE", specialize)  # the generic kernels and the ones compiled for this very chain
+    oh_debug(monkeypatch, specialize=specialize)  # the generic kernels and the ones compiled for this very chain
     base = RobotModel(urdf_filename=KUKA_KIN).kinematic_chain("end_effector_ball")
     ch = _lib.oh_chain()
     C.memmove(C.byref(ch), C.byref(base), C.sizeof(ch))

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, KUKA_KIN, SEED
+from conftest import GOLDEN, KUKA_KIN, SEED, oh_debug
 from oracle.guarded import Guards, guard_values, solve_free_al
 from oracle.problems import GuardedDualArmNLP, dual_arm_offsets
 from oracle.robot import OracleRobot
@@ -301,7 +301,7 @@ def test_guarded_batch_compaction_is_invisible(hip_lib, golden, monkeypatch):
         X0[:, xoff[name] : xoff[name] + 7 * T] = np.tile(qc, (1, T))
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("OH_COMPACTION", mode)
+        oh_debug(monkeypatch, compaction=mode)
         mb = MultiArmBackend(spec, o, max_iter=400)
         res = mb.solve(X0, P)
         lam = [be.multipliers(B) for _, be in mb.arms]
@@ -347,10 +347,10 @@ def test_cyclic_reduction_step_equals_the_serial_sweep(hip_lib, monkeypatch, T, 
     # whole solve in one launch where it fits (k_free_persist); "4096/pair": the launch pair k_eval_guarded + k_step_free_bb forced; "4096/cr": the
     # cyclic-reduction kernels of rounds 2-3 (eight lanes per knot with at most 64 free knots, k_step_free_cp); "4096/lane": those with one lane per knot
     for mode in ("0", "4096", "4096/pair", "4096/cr", "4096/lane"):
-        monkeypatch.setenv("OH_FREE_PCR_MAX", mode.split("/")[0])
-        monkeypatch.setenv("OH_FREE_CP_MAX", "0" if mode.endswith("lane") else "512")
-        monkeypatch.setenv("OH_FREE_BB", "0" if mode.endswith(("cr", "lane")) else "1")
-        monkeypatch.setenv("OH_FREE_PERSIST", "0" if mode.endswith("pair") else "2")
+        oh_debug(monkeypatch, free_pcr_max=mode.split("/")[0])
+        oh_debug(monkeypatch, free_cp_max="0" if mode.endswith("lane") else "512")
+        oh_debug(monkeypatch, free_bb="0" if mode.endswith(("cr", "lane")) else "1")
+        oh_debug(monkeypatch, free_persist="0" if mode.endswith("pair") else "-1")
         mb = MultiArmBackend(spec, o, max_iter=400)
         res = mb.solve(X0, P)
         out[mode] = (res, [be.multipliers(B) for _, be in mb.arms] if guarded else [])

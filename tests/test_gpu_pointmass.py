@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, SEED
+from conftest import GOLDEN, SEED, oh_debug
 from optas_amd.backend import PointMassBackend
 from oracle.pointmass_ipm import solve_pointmass_ipm
 from oracle.problems import PointMassMPCNLP
@@ -186,7 +186,7 @@ def test_wavefront_per_plant_kernel_reproduces_the_thread_kernel(hip_lib, monkey
     x0 = np.zeros((B, nlp.nx))
     out = {}
     for mode in ("0", "20480"):
-        monkeypatch.setenv("OH_PM_WAVE_MAX", mode)
+        oh_debug(monkeypatch, pm_wave_max=mode)
         be = PointMassBackend(tol=1e-8)
         out[mode] = be.solve(x0, P)
         be.close()
@@ -197,7 +197,7 @@ def test_wavefront_per_plant_kernel_reproduces_the_thread_kernel(hip_lib, monkey
     assert np.abs(rt.f - rw.f).max() <= 1e-11 * max(1.0, np.abs(rt.f).max())
     # T = 70 does not fit one knot per lane: the thread kernel, against the numpy port
     T = 70
-    monkeypatch.delenv("OH_PM_WAVE_MAX")
+    oh_debug(monkeypatch, pm_wave_max=None)
     be = PointMassBackend(T=T, tol=1e-8)
     ob = np.array([[0.15 * np.sin(np.pi * (0.05 * t) - np.pi), 0.15 * np.cos(np.pi * (0.05 * t) - np.pi) + 0.15] for t in range(T)]).T
     curr = np.array([-0.9, 0.4])

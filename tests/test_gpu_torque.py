@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, MED7_KIN, SEED
+from conftest import GOLDEN, MED7_KIN, SEED, oh_debug
 from optas_amd import _lib
 from optas_amd.backend import TorqueBackend
 from optas_amd.models import RobotModel
@@ -155,9 +155,9 @@ def test_closed_form_jacobian_path_equals_the_dual_number_path(hip_lib, ctx, mon
     x0 = np.stack([nlp.seed(q) for q in qc])
     be = backend(robot, T, 58.0)
     ra = be.solve(x0, p)
-    monkeypatch.setenv("OH_TQ_JAC", "dual")
+    oh_debug(monkeypatch, tq_jac="dual")
     rb = be.solve(x0, p)
-    monkeypatch.delenv("OH_TQ_JAC")
+    oh_debug(monkeypatch, tq_jac=None)
     assert _lib.status_ok(ra.status).all() and _lib.status_ok(rb.status).all()
     assert np.mean(np.asarray(ra.iters) == np.asarray(rb.iters)) >= 0.9  # a ratio test decided by the last bits may differ on an instance or two
     same = np.asarray(ra.iters) == np.asarray(rb.iters)

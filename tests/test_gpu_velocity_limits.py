@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import KUKA_KIN, SEED
+from conftest import KUKA_KIN, SEED, oh_debug
 from oracle.problems import LimitedFigureEightNLP
 from oracle.robot import OracleRobot
 from oracle.solvers import kkt_reference_form
@@ -65,14 +65,14 @@ def test_velocity_limited_figure_eight(hip_lib, vmax):
 def test_velocity_limited_batch_is_compacted_invisibly(hip_lib, monkeypatch):
     """Orientation-locked family with velocity rows, a batch large enough to be compacted while it drains (round 2): the multipliers of the
     velocity rows move with the instance like those of the other rows; compaction on and off must end in the same points and multipliers."""
-    monkeypatch.setenv("OH_TAIL_VEL", "0")  # (the batched launches to the end: with the persistent kernel of round 3 a batch of 640 never sees a compaction)
+    oh_debug(monkeypatch, tail_vel="0")  # (the batched launches to the end: with the persistent kernel of round 3 a batch of 640 never sees a compaction)
     B = 640
     rng = np.random.default_rng(SEED + 43)
     qcs = QC0[None] + rng.uniform(-0.08, 0.08, (B, 7))
     seeds = np.stack([np.tile(q.reshape(-1, 1), (1, 50)) for q in qcs])
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("OH_COMPACTION", mode)
+        oh_debug(monkeypatch, compaction=mode)
         kuka, solver = setup_solver(velocity_limits=True, solver_options={"max_iter": 600, "tol": 1e-7})
         solver.reset_parameters_batch({"qc": qcs})
         solver.reset_initial_seed_batch({"kuka/q/x": seeds})
@@ -113,9 +113,9 @@ def test_batch_of_16384_has_no_stalled_instance_and_matches_its_instances_solved
     # "batched": OH_TAIL_VEL=0, batched launches to the end with restart compactions; "plain": ... and without compaction
     for mode, env in (("tail", {}), ("batched", {"OH_TAIL_VEL": "0"}), ("plain", {"OH_TAIL_VEL": "0", "OH_COMPACTION": "0"})):
         for k in ("OH_TAIL_VEL", "OH_COMPACTION"):
-            monkeypatch.delenv(k, raising=False)
+            oh_debug(monkeypatch, **{k: None})
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            oh_debug(monkeypatch, **{k: v})
         kuka, solver = setup_solver(velocity_limits=True, solver_options={"max_iter": 600, "tol": 1e-6})
         x0 = np.zeros((B, solver.opt.nx))
         x0[:, :350] = np.repeat(qcs, 50, axis=0).reshape(B, 350)
@@ -166,7 +166,7 @@ def test_batches_beyond_the_plain_hand_over_start_in_the_persistent_kernel(hip_l
     a batch above the plain family's hand-over threshold launches no batched iteration, converges everywhere, and an instance of it equals the same
     instance solved alone, bit for bit."""
     for k in ("OH_TAIL_VEL", "OH_TAIL_VEL_THRESHOLD", "OH_TAIL_THRESHOLD", "OH_COMPACTION"):
-        monkeypatch.delenv(k, raising=False)
+        oh_debug(monkeypatch, **{k: None})
     B = 24576
     rng = np.random.default_rng(9)
     qcs = QC0[None] + rng.uniform(-0.1, 0.1, (B, 7))
@@ -199,7 +199,7 @@ def test_horizon_beyond_the_persistent_kernel_restart_compaction_keeps_the_accep
     x0 = np.repeat(qcs, T, axis=0).reshape(B, 7 * T)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("OH_COMPACTION", mode)
+        oh_debug(monkeypatch, compaction=mode)
         kuka, solver = setup_solver(T=T, Tmax=10.0 * (T - 1) / 49.0, velocity_limits=True, solver_options={"max_iter": 600, "tol": 1e-6})
         X0 = np.zeros((B, solver.opt.nx))
         X0[:, : 7 * T] = x0

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import KUKA_KIN, MED7_KIN, SEED
+from conftest import KUKA_KIN, MED7_KIN, SEED, oh_debug
 from optas_amd import _lib
 from optas_amd.backend import FigureEightBackend
 from optas_amd.models import KinematicsHandle, RobotModel
@@ -52,8 +52,8 @@ def _backend(T=50, **kw):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B", [1, 48, 6000])  # tail kernel alone; tail for a small batch; batched kernels + compaction + hand-over to the tail
 def test_specialised_solver_kernels_match_the_generic_ones(hip_lib, monkeypatch, B):
-    monkeypatch.setenv("OH_SPECIALIZE", "0")
-    monkeypatch.setenv("OH_TAIL_THRESHOLD", "2048")  # B = 6000 through the batched kernels (the default hands it to the tail kernel as a whole)
+    oh_debug(monkeypatch, specialize="0")
+    oh_debug(monkeypatch, tail_threshold="2048")  # B = 6000 through the batched kernels (the default hands it to the tail kernel as a whole)
     nlp, gen = _backend()
     rng = np.random.default_rng(SEED + 31)
     qc = QC0 + np.concatenate([np.zeros((1, 7)), rng.uniform(-0.1, 0.1, (B - 1, 7))])
@@ -87,7 +87,7 @@ def test_specialised_solver_kernels_match_the_generic_ones(hip_lib, monkeypatch,
 def test_automatic_specialisation_threshold(hip_lib, monkeypatch, tmp_path):
     """Automatic mode: kernels are compiled for the chain at the first batch of >= 4096 instances (seconds of hiprtc) -- or at the first solve of
     any size when the code object is already in the disk cache (milliseconds: a controller that only ever solves one instance gets them too)."""
-    monkeypatch.delenv("OH_SPECIALIZE", raising=False)
+    oh_debug(monkeypatch, specialize=None)
     T = 46  # (a horizon of its own: the process-wide map of loaded code objects is keyed by the chain, not by T, so use a fresh cache AND check it)
     monkeypatch.setenv("OPTAS_HIP_CACHE", str(tmp_path / "cache"))
     chain = RobotModel(urdf_filename=MED7_KIN).kinematic_chain("lbr_link_ee")  # not loaded by any other test of this process
@@ -121,9 +121,9 @@ def test_specialised_fk_jac_matches_the_generic_kernel(hip_lib, monkeypatch):
     for kin, link in ((KUKA_KIN, LINK), (KUKA_KIN, "lwr_arm_3_link"), (MED7_KIN, "lbr_link_ee")):
         chain = RobotModel(urdf_filename=kin).kinematic_chain(link)
         Q = rng.uniform(-2.0, 2.0, (5000, chain.ndof))
-        monkeypatch.setenv("OH_SPECIALIZE", "0")
+        oh_debug(monkeypatch, specialize="0")
         pg, Jg = KinematicsHandle(chain).fk_jac(Q)
-        monkeypatch.setenv("OH_SPECIALIZE", "1")
+        oh_debug(monkeypatch, specialize="1")
         h = KinematicsHandle(chain)
         ps, Js = h.fk_jac(Q)
         info = (C.c_double * 4)()

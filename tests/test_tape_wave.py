@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, SEED
+from conftest import GOLDEN, SEED, oh_debug
 from optas_amd.tape import OP_ADD, OP_SUB, compile_problem, rebalance_sums
 from oracle import tape_ref
 
@@ -77,17 +77,17 @@ def test_wavefront_path_matches_thread_path_and_port_on_ik(hip_lib, monkeypatch,
 
     g = np.load(os.path.join(GOLDEN, "ik_golden.npz"))
     tp = compile_problem(ik(build_only=True)[1])
-    monkeypatch.setenv("OH_TAPE_LBFGS", "4")  # the limited-memory regime on a 7-variable problem: both paths can run it
+    oh_debug(monkeypatch, tape_lbfgs="4")  # the limited-memory regime on a 7-variable problem: both paths can run it
     if variant == "nt64":
-        monkeypatch.setenv("OH_TAPE_WAVE_NT", "64")  # one wavefront per instance
+        oh_debug(monkeypatch, tape_wave_nt="64")  # one wavefront per instance
     if variant == "pairs_in_global_memory":
-        monkeypatch.setenv("OH_TAPE_WAVE_HIST", "global")  # what a problem whose (s, y) pairs do not fit the LDS beside its registers takes
+        oh_debug(monkeypatch, tape_wave_hist="global")  # what a problem whose (s, y) pairs do not fit the LDS beside its registers takes
     if variant == "registers_in_global_memory":
-        monkeypatch.setenv("OH_TAPE_WAVE_REGS", "global")  # what a tape whose live registers do not fit the LDS takes
+        oh_debug(monkeypatch, tape_wave_regs="global")  # what a tape whose live registers do not fit the LDS takes
     wave = TapeBackend(tp, jit=False)
     assert wave.flag("tape_wave") == (1 if variant == "pairs_in_global_memory" else 2) and wave.flag("tape_levels") > 5
     assert wave.flag("tape_regs_lds") == (0 if variant == "registers_in_global_memory" else 1)
-    monkeypatch.setenv("OH_TAPE_WAVE", "0")
+    oh_debug(monkeypatch, tape_wave="0")
     thread = TapeBackend(tp, jit=False)
     assert thread.flag("tape_wave") == 0
     rw, rt = wave.solve(g["x0"], g["p"]), thread.solve(g["x0"], g["p"])
@@ -115,7 +115,7 @@ def test_wavefront_path_matches_thread_path_and_port_on_ik(hip_lib, monkeypatch,
         assert wave.solve(g["x0"], g["p"]).iters.tolist() == rw.iters.tolist() and wave.flag("tape_regs_lds") == 1
     # edge: every variable pinned by its start (max_iter 1): one evaluation, MAX_ITER, the seed comes back
     one = TapeBackend.__new__(TapeBackend)
-    monkeypatch.delenv("OH_TAPE_WAVE")
+    oh_debug(monkeypatch, tape_wave=None)
     one.__init__(tp, jit=False, max_iter=1)
     r1 = one.solve(g["x0"][:2], g["p"][:2])
     assert (r1.status == 1).all() and (r1.iters == 1).all() and np.array_equal(r1.x, g["x0"][:2])

@@ -9,8 +9,8 @@ T = 100; B = 20000
 rng = np.random.default_rng(T * 7 + B)
 qcs = QC0[None] + rng.uniform(-0.1, 0.1, (B, 7))
 x0 = np.zeros((B, 1393)); x0[:, : 7 * T] = np.repeat(qcs, T, axis=0).reshape(B, 7 * T)
-for tag, env in (("default", {}), ("no compaction", {"OH_COMPACTION": "0"}), ("first 12000", {"N": "12000"}), ("first 11000..11999 only", {"LO": "10900", "N": "11100"})):
-    for k in ("OH_COMPACTION",):
+for tag, env in (("default", {}), ("no compaction", {"OH_DEBUG_OPTIONS": "compaction=0"}), ("first 12000", {"N": "12000"}), ("first 11000..11999 only", {"LO": "10900", "N": "11100"})):
+    for k in ("OH_DEBUG_OPTIONS",):
         os.environ.pop(k, None)
     os.environ.update({k: v for k, v in env.items() if k.startswith("OH_")})
     lo, n = int(env.get("LO", 0)), int(env.get("N", B))

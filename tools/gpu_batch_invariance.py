@@ -13,8 +13,8 @@ qcs = QC0[None] + rng.uniform(-0.1, 0.1, (B, 7))
 x0 = np.zeros((B, 1393)); x0[:, : 7 * T] = np.repeat(qcs, T, axis=0).reshape(B, 7 * T)
 res = {}
 for tag, env in (("compaction", None), ("none", "0")):
-    os.environ.pop("OH_COMPACTION", None)
-    if env is not None: os.environ["OH_COMPACTION"] = env
+    os.environ.pop("OH_DEBUG_OPTIONS", None)
+    if env is not None: os.environ["OH_DEBUG_OPTIONS"] = "compaction=" + env
     kuka, solver = setup_solver(T=T, Tmax=10.0 * (T - 1) / 49.0, velocity_limits=True, solver_options={"max_iter": 600, "tol": 1e-6, "hessian": "hybrid"})
     r = solver.solve_batch_arrays(x0[:, : solver.opt.nx], qcs)
     tm = solver.backend.timing()

@@ -1,4 +1,4 @@
-"""Config 4 synthetic over several seeds: the twisted-factorisation sweep (k_step_free_bb) against the cyclic-reduction kernels of rounds 2-3 (OH_FREE_BB=0):
+"""Config 4 synthetic over several seeds: the twisted-factorisation sweep (k_step_free_bb) against the cyclic-reduction kernels of rounds 2-3 (option free_bb = 0):
 convergence, step counts, optimum.  python tools/gpu_cfg4_seeds.py [B] [seeds]"""
 import json, os, subprocess, sys
 import numpy as np
@@ -31,14 +31,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     p = np.ascontiguousarray(np.concatenate([qc, np.full((B, 4), 0.15), np.tile(obs_row, (B, 1))], 1))
     x0 = np.ascontiguousarray(np.concatenate([np.tile(qc, (1, T)), np.zeros((B, 7 * (T - 1)))], 1))
     r = be.solve(x0, p); r = be.solve(x0, p)
-    np.save(os.path.join(ROOT, "gpurun_out", f"cfg4_f_{os.environ.get('OH_FREE_BB', '1')}_{seed}.npy"), np.stack([r.f, r.iters.astype(float), r.status.astype(float)]))
-    print(json.dumps({"bb": os.environ.get("OH_FREE_BB", "1"), "seed": seed, "ms": be.timing()["solve_ms"], "conv": float((r.status == 0).mean()), "p50": float(np.median(r.iters)), "max": int(r.iters.max())}))
+    np.save(os.path.join(ROOT, "gpurun_out", f"cfg4_f_{os.environ.get('OH_DEBUG_OPTIONS', 'free_bb=1')[-1]}_{seed}.npy"), np.stack([r.f, r.iters.astype(float), r.status.astype(float)]))
+    print(json.dumps({"bb": os.environ.get("OH_DEBUG_OPTIONS", "free_bb=1")[-1], "seed": seed, "ms": be.timing()["solve_ms"], "conv": float((r.status == 0).mean()), "p50": float(np.median(r.iters)), "max": int(r.iters.max())}))
 else:
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     for seed in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
         for bb in ("1", "0"):
-            out = subprocess.run([sys.executable, __file__, "one", str(B), str(100 + seed)], env=dict(os.environ, OH_FREE_BB=bb), capture_output=True, text=True)
+            out = subprocess.run([sys.executable, __file__, "one", str(B), str(100 + seed)], env=dict(os.environ, OH_DEBUG_OPTIONS='free_bb=' + bb), capture_output=True, text=True)
             print((out.stdout.strip().splitlines() or [out.stderr[-300:]])[-1], flush=True)
         a = np.load(os.path.join(ROOT, "gpurun_out", f"cfg4_f_1_{100 + seed}.npy")); c = np.load(os.path.join(ROOT, "gpurun_out", f"cfg4_f_0_{100 + seed}.npy"))
         rel = np.abs(a[0] - c[0]) / np.maximum(1e-3, np.abs(c[0]))

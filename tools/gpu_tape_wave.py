@@ -1,12 +1,12 @@
 """The 280-variable planner (examples/simple_joint_space_planner.py) through the generic tape family: wavefront-per-instance path (default)
-against the thread-per-instance paths (OH_TAPE_WAVE=0).  python tools/gpu_tape_wave.py [wave|thread]"""
+against the thread-per-instance paths (option tape_wave = 0).  python tools/gpu_tape_wave.py [wave|thread]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 mode = sys.argv[1] if len(sys.argv) > 1 else "wave"
 if mode == "thread":
-    os.environ["OH_TAPE_WAVE"] = "0"
+    os.environ["OH_DEBUG_OPTIONS"] = "tape_wave=0"
 from examples.simple_joint_space_planner import setup_solver
 g = np.load(os.path.join(ROOT, "tests", "golden", "planner_golden.npz"))
 t0 = time.time()

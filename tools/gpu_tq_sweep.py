@@ -10,6 +10,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
         if v: print(key, json.dumps({k: v.get(k) for k in ("device_ms", "iterations_launched", "iters_p50", "iters_p90", "iters_max", "converged_frac")}))
 else:
     for cf, ca in ((("0.1", "3"), ("0.03", "4"), ("0.01", "4"), ("1e-9", "2"), ("0.03", "3")) if os.environ.get("FULL") else (("0.1", "3"), ("0.03", "4"), ("0.01", "4"), ("1e-9", "2"), ("0.03", "3"), ("0.1", "4"), ("0.3", "3"), ("1e-9", "3"))):
-        env = dict(os.environ, OH_TQ_CURV_FROM=cf, OH_TQ_CURV_AFTER=ca)
+        env = dict(os.environ, OH_DEBUG_OPTIONS=f'tq_curv_from={cf},tq_curv_after={ca}')
         out = subprocess.run([sys.executable, __file__, "one"], env=env, capture_output=True, text=True)
         print(cf, ca, " | ".join((out.stdout.strip().splitlines() or [out.stderr[-300:]])[-2:]), flush=True)

@@ -70,14 +70,17 @@ def test_unsupported_instructions_are_refused():
 
 def _elementary_functions():
     """The elementary functions `from casadi import *` (optas/__init__.py:2) puts into a user's hands beyond what optas's own graphs emit
-    (round-4 verdict, Missing 5): one cost and one row vector that use every one of them on arguments inside their domains."""
+    (round-4 verdict, Missing 5): one cost and one row vector that use every one of them on arguments inside their domains (a box row per
+    variable keeps the iterates there; the quadratic term makes the minimiser unique enough to compare evaluators on it)."""
     x, p = cs.sym(0, 3), cs.sym(1, 2)
-    u = 0.4 * x[0] + 0.2  # in (-0.6, 1.0) for x in (-1, 1)... kept inside (-1, 1) below
-    f = (cs.exp(0.5 * x[0]) + cs.log(2.0 + x[1]) + cs.tanh(x[2]) + cs.sinh(0.3 * x[0]) * cs.cosh(0.2 * x[1]) + cs.acos(0.5 * u) + cs.atan(x[2] * p[0])
-         + cs.power(2.0 + x[0], 1.0 + 0.3 * x[1]) + (3.0 + x[2]) ** 2.5 + (2.0 + x[1]) ** -2 + cs.asinh(x[0]) + cs.acosh(2.0 + x[1] * x[1]) + cs.atanh(0.4 * x[2])
-         + cs.log1p(0.5 + 0.2 * x[0]) + cs.expm1(0.1 * x[1]) + cs.sign(x[2] - 5.0) * x[0] + p[1] * cs.exp(-(x[0] * x[0])))
-    g = [(0, cs.exp(x[0]) - 0.1), (1, 2.0 - cs.log(3.0 + x[1])), (2, cs.tanh(x[2]) + 2.0)]
-    return cs.Function("f", [[(0, f)]], [1]), cs.Function("g", [g], [3])
+    u = 0.4 * x[0] + 0.2
+    mix = (cs.exp(0.5 * x[0]) + cs.log(2.0 + x[1]) + cs.tanh(x[2]) + cs.sinh(0.3 * x[0]) * cs.cosh(0.2 * x[1]) + cs.acos(0.5 * u) + cs.atan(x[2] * p[0])
+           + cs.power(2.0 + x[0], 1.0 + 0.3 * x[1]) + (3.0 + x[2]) ** 2.5 + (2.0 + x[1]) ** -2 + cs.asinh(x[0]) + cs.acosh(2.0 + x[1] * x[1]) + cs.atanh(0.4 * x[2])
+           + cs.log1p(0.5 + 0.2 * x[0]) + cs.expm1(0.1 * x[1]) + cs.sign(x[2] - 5.0) * x[0] + p[1] * cs.exp(-(x[0] * x[0])))
+    f = 0.2 * mix + 2.0 * ((x[0] - 0.1) * (x[0] - 0.1) + (x[1] + 0.2) * (x[1] + 0.2) + x[2] * x[2])
+    g = [(0, cs.exp(x[0]) - 0.9), (1, 1.2 - cs.log(3.0 + x[1])), (2, cs.tanh(x[2]) + 0.2)]
+    g += [(3 + i, 0.9 - x[i]) for i in range(3)] + [(6 + i, x[i] + 0.9) for i in range(3)]
+    return cs.Function("f", [[(0, f)]], [1]), cs.Function("g", [g], [9])
 
 
 def test_elementary_functions_walk_to_exp_log_and_compositions():
@@ -106,11 +109,12 @@ def test_elementary_functions_solve_on_the_gpu(hip_lib):
     rng = np.random.default_rng(12)
     B = 64
     X0, P = rng.uniform(-0.3, 0.3, (B, 3)), rng.uniform(-1, 1, (B, 2))
+    ref = tape_ref.solve_tape_al(tp, X0[0], P[0], tol=1e-7)
     results = []
     for jit in (False, True):
         be = TapeBackend(tp, max_iter=3000, tol=1e-7, jit=jit)
         r = be.solve(X0, P)
-        lam = be.multipliers(B)
+        lam, _ = be.multipliers(B)
         be.close()
         assert (r.status == 0).all()
         results.append(r)
@@ -120,7 +124,7 @@ def test_elementary_functions_solve_on_the_gpu(hip_lib):
             assert abs(v[tp.out_cost] - r.f[b]) <= 1e-12 * max(1.0, abs(r.f[b])) and rows.min() >= -1e-9
             gl = tape_ref.reverse(tp, v, {int(tp.out_cost): 1.0, **{int(rr): -float(l) for rr, l in zip(tp.out_rows, lam[b])}})
             assert np.abs(gl).max() <= 1e-6 and (lam[b] >= 0).all() and np.abs(lam[b] * rows).max() <= 1e-7
-    assert np.abs(results[0].x - results[1].x).max() <= 1e-6
+    assert np.abs(results[0].x - results[1].x).max() <= 1e-6 and np.abs(results[0].x[0] - ref["x"]).max() <= 1e-5
 
 
 @pytest.mark.gpu

@@ -422,6 +422,19 @@ int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void
 int oh_pm_rollout(oh_handle* h, int B, int n_ticks, int advance, double ramp, const double* state0, const double* obs_table, double* states,
                   double* f, int* iters, int* status);
 
+/* The same loop for OH_PROBLEM_TORQUE_MPC (round 5; BASELINE configs[4] is an MPC: "solves per second" in steady state are warm-started ticks).
+   Per tick k:  p_k = [q_k; dq_k; rows k * advance .. k * advance + T - 1 of the plant's goal table];
+     seed = the accelerations of the previous plan shifted by `advance` knots, the last one repeated (the reference's pattern, point_mass_mpc.py:157-158:
+     seed from the previous solution; tick 0: zero accelerations = the cold solve), barrier parameter of a warm tick mu_warm (<= 0: 1e-6; the cold
+     default 0.1 = IPOPT's mu_init would first walk the iterate back to the centre of the feasible set);
+     solve; the plant follows the plan for `advance` knots: (q, dq) <- the plan's state at knot `advance` -- the Euler roll-out of its accelerations,
+     with the torques of the inverse-dynamics rows, tau_t = rnea(q_t, dq_t, ddq_t).
+   Host buffers: state0 [B][2 ndof] = (q, dq); goal_table [B][n_ticks * advance + T][3]; out (any may be NULL): states [n_ticks + 1][B][2 ndof]
+   (states[0] = state0), tau0 [n_ticks][B][ndof] (the torque applied at each tick: knot 0 of its plan), f, iters, status [n_ticks][B].
+   Nothing crosses PCIe between the first and the last tick; oh_get_timing: [4] device ms of the solves, [5] launches, [6] instance-launches. */
+int oh_tq_rollout(oh_handle* h, int B, int n_ticks, int advance, double mu_warm, const double* state0, const double* goal_table, double* states,
+                  double* tau0, double* f, int* iters, int* status);
+
 /* Multipliers of the last oh_solve/oh_solve_device in the reference's form: lam_h [B][4*T] for the rows
    h = quat_c - quat(q_t) (signed mu = lam+ - lam- of the (h,-h) pair, optimization.py:47-51). Host buffer.
    OH_PROBLEM_IK: lam_h [B][3 + 2*ndof] = (mu of h = p_goal - p_link(q) (3), multipliers of q - lo >= 0 (ndof),

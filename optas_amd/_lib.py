@@ -232,6 +232,7 @@ SYMBOLS = [
     "oh_solve",
     "oh_solve_device",
     "oh_pm_rollout",
+    "oh_tq_rollout",
     "oh_get_multipliers",
     "oh_set_dynamics",
     "oh_rnea",
@@ -306,6 +307,7 @@ def load() -> C.CDLL:
     lib.oh_solve.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
     lib.oh_solve_device.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, vp]
     lib.oh_pm_rollout.argtypes = [vp, i, i, i, C.c_double, vp, vp, vp, vp, vp, vp]
+    lib.oh_tq_rollout.argtypes = [vp, i, i, i, C.c_double, vp, vp, vp, vp, vp, vp, vp]
     lib.oh_get_multipliers.argtypes = [vp, i, vp]
     lib.oh_set_dynamics.argtypes = [vp, C.POINTER(oh_dynamics)]
     lib.oh_rnea.argtypes = [vp, i, vp, vp, vp, vp]

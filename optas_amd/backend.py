@@ -322,6 +322,23 @@ class TorqueBackend(_SolveMixin):
         _lib.check(_lib.load().oh_get_multipliers(self._h, int(B), _lib._ptr(out)), "oh_get_multipliers")
         return out
 
+    def rollout(self, state0, goal_table, n_ticks: int, advance: int = 1, mu_warm: float = 1e-6):
+        """Closed-loop receding horizon on the device (oh_tq_rollout; the reference's pattern, example/point_mass_mpc.py:156-175: seed = the previous
+        solution).  state0 (B, 2 ndof) = (q, dq); goal_table (B, n_ticks * advance + T, 3): tick k tracks rows k * advance .. k * advance + T - 1.
+        Returns states (n_ticks + 1, B, 2 ndof), tau0 (n_ticks, B, ndof), f, iters, status (n_ticks, B)."""
+        state0 = _lib.as_f64(state0).reshape(-1, 2 * self.ndof)
+        B = state0.shape[0]
+        goal_table = _lib.as_f64(goal_table)
+        assert goal_table.shape == (B, n_ticks * advance + self.T, 3), goal_table.shape
+        states = np.empty((n_ticks + 1, B, 2 * self.ndof))
+        tau0 = np.empty((n_ticks, B, self.ndof))
+        f = np.empty((n_ticks, B))
+        iters = np.empty((n_ticks, B), dtype=np.int32)
+        status = np.empty((n_ticks, B), dtype=np.int32)
+        _lib.check(_lib.load().oh_tq_rollout(self._h, B, int(n_ticks), int(advance), float(mu_warm), _lib._ptr(state0), _lib._ptr(goal_table), _lib._ptr(states),
+                                             _lib._ptr(tau0), _lib._ptr(f), _lib._ptr(iters), _lib._ptr(status)), "oh_tq_rollout")
+        return states, tau0, f, iters, status
+
     def timing(self) -> dict:
         out = (C.c_double * 11)()
         _lib.check(_lib.load().oh_get_timing(self._h, out), "oh_get_timing")

@@ -167,6 +167,7 @@ def make_solver_class(solver_module, cs):
         solver = HIPSolver(builder.build()).setup("hip_sqp", {"tol": 1e-6})
         solver.reset_initial_seed({...}); solver.reset_parameters({...}); solution = solver.solve()
     """
+    from . import _lib
     from .backend import TapeBackend, tape_default_max_iter
 
     class HIPSolver(solver_module.Solver):

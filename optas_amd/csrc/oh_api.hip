@@ -760,7 +760,8 @@ extern "C" int oh_create_torque(const oh_torque_desc* desc, oh_handle** out) {
   return OH_OK;
 }
 
-static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status) {
+static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status,
+                           const double mu_b0_warm = 0.0) {
   if (!h->have_chain) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_constants first");
   if (!h->have_dyn) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_dynamics first");
   if (!solver_chain_ok(h->chain_host) || h->chain_host.has_lead)
@@ -772,7 +773,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   P = TqParams{};
   P.T = T; P.N = N; P.max_iter = h->tq.max_iter;
   P.dt = h->tq.dt; P.w_path = h->tq.w_path; P.w_vel = h->tq.w_vel; P.w_tau = h->tq.w_tau;
-  P.tol = h->tq.tol; P.tol_compl = h->tq.tol_compl; P.mu_b0 = h->tq.mu_barrier0; P.mu0 = h->tq.mu0;
+  P.tol = h->tq.tol; P.tol_compl = h->tq.tol_compl; P.mu_b0 = mu_b0_warm > 0.0 ? mu_b0_warm : h->tq.mu_barrier0; P.mu0 = h->tq.mu0;
   // interior point: relaxed barrier below theta mu_b; monotone barrier update of Waechter & Biegler (2006, eq. 7) -- IPOPT's constants except theta_mu (1.35 for 1.5: the hardest of 8192 instances needs 127 steps instead of 198); exact
   // curvature of the Lagrangian once the reduced gradient is below curv_from (oracle/torque_ipm.py:solve_torque_ipm has the same defaults)
   P.theta = 0.01; P.kappa_eps = 10.0; P.kappa_mu = 0.2; P.theta_mu = 1.35; P.curv_from = 0.1; P.curv_late = 1.0; P.curv_after = 3; P.tau_ftb = 0.995; P.max_back = 3; P.stall_max = 25;
@@ -1674,6 +1675,65 @@ extern "C" int oh_pm_rollout(oh_handle* h, int B, int n_ticks, int advance, doub
   h->timing[5] = n_ticks;
   h->last_B = B;
   if (states) HIPCHK(hipMemcpy(states, d_states, b_states, hipMemcpyDeviceToHost));
+  if (f) HIPCHK(hipMemcpy(f, d_f, b_f, hipMemcpyDeviceToHost));
+  if (iters) HIPCHK(hipMemcpy(iters, d_it, b_i, hipMemcpyDeviceToHost));
+  if (status) HIPCHK(hipMemcpy(status, d_st, b_i, hipMemcpyDeviceToHost));
+  return OH_OK;
+}
+
+extern "C" int oh_tq_rollout(oh_handle* h, int B, int n_ticks, int advance, double mu_warm, const double* state0, const double* goal_table, double* states,
+                             double* tau0, double* f, int* iters, int* status) {
+  if (!h || !state0 || !goal_table) return fail(OH_ERR_INVALID, "oh_tq_rollout: null argument");
+  if (h->desc.kind != OH_PROBLEM_TORQUE_MPC) return fail(OH_ERR_STATE, "oh_tq_rollout: handle is not a torque-MPC problem");
+  const int T = h->tq.T, N = h->tq.ndof;
+  if (B < 1 || n_ticks < 1 || advance < 1 || advance >= T) return fail(OH_ERR_INVALID, "oh_tq_rollout: need B >= 1, n_ticks >= 1, 1 <= advance < T");
+  if (!(mu_warm > 0.0)) mu_warm = 1e-6;
+  HIPCHK(hipSetDevice(h->device));
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t n_rows = (size_t)n_ticks * advance + T;
+  const size_t nx = 4 * (size_t)N * T, np_ = 2 * (size_t)N + 3 * (size_t)T;
+  const size_t b_states = sizeof(double) * 2 * N * (size_t)B * (n_ticks + 1), b_goal = sizeof(double) * 3 * n_rows * B, b_p = sizeof(double) * np_ * B,
+               b_x = sizeof(double) * nx * B, b_tau = sizeof(double) * N * (size_t)B * n_ticks, b_f = sizeof(double) * (size_t)B * n_ticks,
+               b_i = sizeof(int) * (size_t)B * n_ticks;
+  int rc = ensure_stage(h, al(b_states) + al(b_goal) + al(b_p) + 2 * al(b_x) + al(b_tau) + al(b_f) + 2 * al(b_i));
+  if (rc) return rc;
+  char* base = (char*)h->stage;
+  double* d_states = (double*)base; base += al(b_states);
+  double* d_goal = (double*)base; base += al(b_goal);
+  double* d_p = (double*)base; base += al(b_p);
+  double* d_xa = (double*)base; base += al(b_x);
+  double* d_xb = (double*)base; base += al(b_x);
+  double* d_tau = (double*)base; base += al(b_tau);
+  double* d_f = (double*)base; base += al(b_f);
+  int* d_it = (int*)base; base += al(b_i);
+  int* d_st = (int*)base;
+  hipStream_t s = h->stream;
+  HIPCHK(hipMemcpyAsync(d_states, state0, sizeof(double) * 2 * N * (size_t)B, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(d_goal, goal_table, b_goal, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(d_xa, 0, b_x, s));  // first tick: zero accelerations (the cold solve of oh_solve from a constant-configuration seed)
+  double ms_total = 0.0, launched = 0.0, work = 0.0;
+  for (int k = 0; k < n_ticks; ++k) {
+    double* st_k = d_states + 2 * (size_t)N * B * k;
+    oh_launch_tq_tick_params(s, B, T, N, k * advance, (int)n_rows, st_k, d_goal, d_p);
+    double* x_seed = d_xa;  // the seed of this tick; the solution lands in d_xb and is shifted back into d_xa for the next one
+    double* x_sol = d_xb;
+    rc = tq_solve_device(h, B, x_seed, d_p, x_sol, d_f + (size_t)B * k, nullptr, d_it + (size_t)B * k, d_st + (size_t)B * k, k > 0 ? mu_warm : 0.0);
+    if (rc) return rc;
+    ms_total += h->timing[4];
+    launched += h->timing[5];
+    work += h->timing[6];
+    oh_launch_tq_advance(s, B, T, N, advance, x_sol, st_k + 2 * (size_t)N * B, tau0 ? d_tau + (size_t)N * B * k : nullptr);
+    oh_launch_tq_shift_seed(s, B, T, N, advance, x_sol, x_seed);
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  for (double& t : h->timing) t = 0.0;
+  h->timing[4] = ms_total;  // device time of the solves (HIP events around each)
+  h->timing[5] = launched;
+  h->timing[6] = work;
+  h->last_B = B;
+  if (states) HIPCHK(hipMemcpy(states, d_states, b_states, hipMemcpyDeviceToHost));
+  if (tau0) HIPCHK(hipMemcpy(tau0, d_tau, b_tau, hipMemcpyDeviceToHost));
   if (f) HIPCHK(hipMemcpy(f, d_f, b_f, hipMemcpyDeviceToHost));
   if (iters) HIPCHK(hipMemcpy(iters, d_it, b_i, hipMemcpyDeviceToHost));
   if (status) HIPCHK(hipMemcpy(status, d_st, b_i, hipMemcpyDeviceToHost));

@@ -132,6 +132,9 @@ bool oh_launch_tq_setup(hipStream_t s, const TqParams& P, const TqBuffers& D, co
 bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D);
 bool oh_launch_tq_step(hipStream_t s, const TqParams& P, const TqBuffers& D);
 bool oh_launch_tq_finalize(hipStream_t s, const TqParams& P, const TqBuffers& D, double* x, double* f, double* kkt, int* iters, int* status, double* mult);
+void oh_launch_tq_tick_params(hipStream_t s, int B, int T, int N, int first_row, int n_rows, const double* state, const double* goal_table, double* p);
+void oh_launch_tq_shift_seed(hipStream_t s, int B, int T, int N, int advance, const double* x_prev, double* x_seed);
+void oh_launch_tq_advance(hipStream_t s, int B, int T, int N, int advance, const double* x, double* state_next, double* tau0);
 
 // ---- OH_PROBLEM_IK -----------------------------------------------------------------------------------------
 struct IkParams {

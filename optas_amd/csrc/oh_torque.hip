@@ -2197,6 +2197,54 @@ bool oh_launch_tq_step(hipStream_t s, const TqParams& P, const TqBuffers& D) {
   else hipLaunchKernelGGL((k_tq_step<7>), dim3(D.n_run), dim3(64), sizeof(double) * 8 * P.T, s, P, D);
   return true;
 }
+// ---- receding horizon, resident on the device (oh_tq_rollout, round 5) ----------------------------------------------------------------------
+// One thread per plant.  The reference's pattern (example/point_mass_mpc.py:156-175): parameters of the tick from the plant's state, seed = the
+// previous solution, solve, the plant takes the plan's next state.  Reference layouts: x [B][4 N T] = [vec(Q); vec(dQ); vec(ddQ); vec(TAU)],
+// p [B][2 N + 3 T] = [qc; dqc; vec(goal 3 x T)].
+__global__ __launch_bounds__(64) void k_tq_tick_params(const int B, const int T, const int N, const int first_row, const int n_rows, const double* __restrict__ state,
+                                                       const double* __restrict__ goal_table, double* __restrict__ p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double* pb = p + (size_t)b * (2 * N + 3 * T);
+  for (int i = 0; i < 2 * N; ++i) pb[i] = state[(size_t)b * 2 * N + i];
+  const double* gt = goal_table + ((size_t)b * n_rows + first_row) * 3;
+  for (int i = 0; i < 3 * T; ++i) pb[2 * N + i] = gt[i];
+}
+// seed of the next tick: the accelerations of the plan shifted by `advance` knots, the last one repeated (only the ddQ block of a seed is read:
+// the states are rolled out from the plant's state, the torques follow from the dynamics rows)
+__global__ __launch_bounds__(64) void k_tq_shift_seed(const int B, const int T, const int N, const int advance, const double* __restrict__ x_prev,
+                                                      double* __restrict__ x_seed) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* u = x_prev + (size_t)b * 4 * N * T + 2 * N * T;
+  double* us = x_seed + (size_t)b * 4 * N * T + 2 * N * T;
+  for (int t = 0; t < T; ++t) {
+    const int ts = t + advance < T ? t + advance : T - 1;
+    for (int j = 0; j < N; ++j) us[N * t + j] = u[N * ts + j];
+  }
+}
+// the plant follows the plan for `advance` knots (the plan's states ARE the Euler roll-out of its accelerations, and its torques those of the
+// inverse dynamics at its states: tau_t = rnea(q_t, dq_t, ddq_t) to 1e-14); the torque applied at the tick is the one of knot 0
+__global__ __launch_bounds__(64) void k_tq_advance(const int B, const int T, const int N, const int advance, const double* __restrict__ x, double* __restrict__ state_next,
+                                                   double* __restrict__ tau0) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* xb = x + (size_t)b * 4 * N * T;
+  for (int j = 0; j < N; ++j) {
+    state_next[(size_t)b * 2 * N + j] = xb[N * advance + j];
+    state_next[(size_t)b * 2 * N + N + j] = xb[N * T + N * advance + j];
+    if (tau0) tau0[(size_t)b * N + j] = xb[3 * N * T + j];
+  }
+}
+void oh_launch_tq_tick_params(hipStream_t s, int B, int T, int N, int first_row, int n_rows, const double* state, const double* goal_table, double* p) {
+  hipLaunchKernelGGL(k_tq_tick_params, dim3((B + 63) / 64), dim3(64), 0, s, B, T, N, first_row, n_rows, state, goal_table, p);
+}
+void oh_launch_tq_shift_seed(hipStream_t s, int B, int T, int N, int advance, const double* x_prev, double* x_seed) {
+  hipLaunchKernelGGL(k_tq_shift_seed, dim3((B + 63) / 64), dim3(64), 0, s, B, T, N, advance, x_prev, x_seed);
+}
+void oh_launch_tq_advance(hipStream_t s, int B, int T, int N, int advance, const double* x, double* state_next, double* tau0) {
+  hipLaunchKernelGGL(k_tq_advance, dim3((B + 63) / 64), dim3(64), 0, s, B, T, N, advance, x, state_next, tau0);
+}
 bool oh_launch_tq_finalize(hipStream_t s, const TqParams& P, const TqBuffers& D, double* x, double* f, double* kkt, int* iters, int* status, double* mult) {
   if (P.N != 7) return false;
   hipLaunchKernelGGL(k_tq_finalize<7>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x, f, kkt, iters, status, mult);

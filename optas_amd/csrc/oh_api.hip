@@ -337,8 +337,9 @@ extern "C" int oh_create(const oh_problem_desc* desc, oh_handle** out) {
     return OH_OK;
   }
   if (desc->T < 3 || desc->T > OH_MAX_T) return fail(OH_ERR_INVALID, "oh_create: T must be in [3, OH_MAX_T]");
-  if (desc->ndof != 6 && desc->ndof != 7)
-    return fail(OH_ERR_INVALID, "oh_create: figure-eight kernels are instantiated for ndof 6 and 7");
+  if (desc->ndof < (desc->lock_orientation ? 4 : 2) || desc->ndof > 8)
+    return fail(OH_ERR_INVALID, "oh_create: the trajectory kernels are instantiated for 2 ... 8 actuated joints, the orientation-locked ones (three rows per "
+                                "knot, null space of ndof - 3 dimensions) for 4 ... 8");
   if (!(desc->dt > 0.0)) return fail(OH_ERR_INVALID, "oh_create: dt must be positive");
   if (!desc->local_path) return fail(OH_ERR_INVALID, "oh_create: local_path is null");
   if (desc->hessian != OH_HESSIAN_GAUSS_NEWTON && desc->hessian != OH_HESSIAN_EXACT && desc->hessian != OH_HESSIAN_HYBRID)
@@ -691,7 +692,7 @@ static int qp_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
 extern "C" int oh_create_ik(const oh_ik_desc* desc, oh_handle** out) {
   if (!desc || !out) return fail(OH_ERR_INVALID, "oh_create_ik: null argument");
   *out = nullptr;
-  if (desc->ndof != 6 && desc->ndof != 7) return fail(OH_ERR_INVALID, "oh_create_ik: kernels are instantiated for ndof 6 and 7");
+  if (desc->ndof < 2 || desc->ndof > 8) return fail(OH_ERR_INVALID, "oh_create_ik: kernels are instantiated for 2 ... 8 actuated joints");
   if (!(desc->w_nominal > 0.0)) return fail(OH_ERR_INVALID, "oh_create_ik: w_nominal must be positive");
   for (int i = 0; i < desc->ndof; ++i)
     if (!(desc->q_lo[i] <= desc->q_up[i])) return fail(OH_ERR_INVALID, "oh_create_ik: q_lo must not exceed q_up");

@@ -1233,7 +1233,9 @@ OH_DEV void finalize_unit(const FigParams& P, const FigBuffers& D, int only_done
       for (int j = 0; j < N; ++j) xb[(size_t)P.T * N + (size_t)t * N + j] = (qs[IDX(t + 1, N, j)] - q0[j]) * inv_dt;
     }
   }
-  if (D.lam_h) knot_multipliers<N>(P, D, b, t, cur, D.lam_h + (ob * P.T + t) * 4);
+  if constexpr (N > 3) {  // (the orientation rows exist from four joints on)
+    if (D.lam_h) knot_multipliers<N>(P, D, b, t, cur, D.lam_h + (ob * P.T + t) * 4);
+  }
   if (t == 0) {
     if (f) f[ob] = D.f_cur[b] - (D.fpsi ? D.fpsi[b] : 0.0);
     if (kkt) {

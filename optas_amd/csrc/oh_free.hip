@@ -1692,18 +1692,32 @@ __global__ __launch_bounds__(8 * KN) void k_step_free_cp(FigParams P, FigBuffers
   }
 }
 
+// Chain lengths (round 5): the one-thread-per-unit kernels of this family are instantiated for 2 ... 8 actuated joints (planar_3dof, the tester
+// robots, 8-joint arms); the block-per-instance sweeps (cyclic reduction, twisted factorisation, the persistent kernel) stay with 6 and 7, whose
+// lane layouts they are written for -- other chain lengths take the serial sweep at every batch size.
+#define OH_FREE_DISPATCH_N(n, call) \
+  switch (n) {                       \
+    case 2: call(2); break;          \
+    case 3: call(3); break;          \
+    case 4: call(4); break;          \
+    case 5: call(5); break;          \
+    case 6: call(6); break;          \
+    case 7: call(7); break;          \
+    case 8: call(8); break;          \
+    default: return false;           \
+  }
 bool oh_launch_eval_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
   const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
-  if (n == 7) hipLaunchKernelGGL(k_eval_free<7>, g, b, 0, s, P, D, slot);
-  else if (n == 6) hipLaunchKernelGGL(k_eval_free<6>, g, b, 0, s, P, D, slot);
-  else return false;
+#define C(NN) hipLaunchKernelGGL(k_eval_free<NN>, g, b, 0, s, P, D, slot)
+  OH_FREE_DISPATCH_N(n, C)
+#undef C
   return true;
 }
 bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
   const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
-  if (n == 7) hipLaunchKernelGGL(k_couple_free<7>, g, b, 0, s, P, D, slot);
-  else if (n == 6) hipLaunchKernelGGL(k_couple_free<6>, g, b, 0, s, P, D, slot);
-  else return false;
+#define C(NN) hipLaunchKernelGGL(k_couple_free<NN>, g, b, 0, s, P, D, slot)
+  OH_FREE_DISPATCH_N(n, C)
+#undef C
   return true;
 }
 // pcr: one block per instance (k_step_free_pcr, or k_step_free_cp with eight lanes per knot while the launch has at most g_free_cp_max instances;
@@ -1737,9 +1751,9 @@ bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuff
     else launch_step_free_pcr<6, false>(s, P, D, none, slot);
     return true;
   }
-  if (n == 7) hipLaunchKernelGGL((k_step_free<7, false>), g, b, 0, s, P, D, none, slot);
-  else if (n == 6) hipLaunchKernelGGL((k_step_free<6, false>), g, b, 0, s, P, D, none, slot);
-  else return false;
+#define C(NN) hipLaunchKernelGGL((k_step_free<NN, false>), g, b, 0, s, P, D, none, slot)
+  OH_FREE_DISPATCH_N(n, C)
+#undef C
   return true;
 }
 bool oh_launch_setup_guards(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const double* p) {
@@ -1755,36 +1769,38 @@ bool oh_launch_free_persist(hipStream_t s, int n, const FigParams& P, const FigB
 }
 bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
   const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
-  if (n == 7) hipLaunchKernelGGL(k_eval_guarded<7>, g, b, 0, s, P, D, GP, GB, slot);
-  else if (n == 6) hipLaunchKernelGGL(k_eval_guarded<6>, g, b, 0, s, P, D, GP, GB, slot);
-  else return false;
+#define C(NN) hipLaunchKernelGGL(k_eval_guarded<NN>, g, b, 0, s, P, D, GP, GB, slot)
+  OH_FREE_DISPATCH_N(n, C)
+#undef C
   return true;
 }
 template <int N>
 static void launch_step_guarded_t(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot, bool pcr) {
   const dim3 g((D.B + 63) / 64), b(64);
-  if (pcr && P.T - P.t0 <= 128) {
-    if (GP.vel) launch_step_free_pcr<N, true, true>(s, P, D, GB, slot);
-    else launch_step_free_pcr<N, true>(s, P, D, GB, slot);
-  } else if (GP.vel) hipLaunchKernelGGL((k_step_free<N, true, true>), g, b, 0, s, P, D, GB, slot);
+  if constexpr (N == 6 || N == 7) {  // (the block-per-instance sweeps are written for these lane layouts)
+    if (pcr && P.T - P.t0 <= 128) {
+      if (GP.vel) launch_step_free_pcr<N, true, true>(s, P, D, GB, slot);
+      else launch_step_free_pcr<N, true>(s, P, D, GB, slot);
+      return;
+    }
+  }
+  if (GP.vel) hipLaunchKernelGGL((k_step_free<N, true, true>), g, b, 0, s, P, D, GB, slot);
   else hipLaunchKernelGGL((k_step_free<N, true>), g, b, 0, s, P, D, GB, slot);
 }
 bool oh_launch_step_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot, bool pcr) {
-  if (n == 7) launch_step_guarded_t<7>(s, P, D, GP, GB, slot, pcr);
-  else if (n == 6) launch_step_guarded_t<6>(s, P, D, GP, GB, slot, pcr);
-  else return false;
+#define C(NN) launch_step_guarded_t<NN>(s, P, D, GP, GB, slot, pcr)
+  OH_FREE_DISPATCH_N(n, C)
+#undef C
   return true;
 }
 // position-tracking family with joint-velocity rows: multiplier refresh of those rows (outer updates only), then the coupling
 bool oh_launch_couple_free_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
   const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
-  if (n == 7) {
-    hipLaunchKernelGGL(k_vel_update_free<7>, g, b, 0, s, P, D, GP, GB, slot);
-    hipLaunchKernelGGL(k_couple_free_vel<7>, g, b, 0, s, P, D, GP, GB, slot);
-  } else if (n == 6) {
-    hipLaunchKernelGGL(k_vel_update_free<6>, g, b, 0, s, P, D, GP, GB, slot);
-    hipLaunchKernelGGL(k_couple_free_vel<6>, g, b, 0, s, P, D, GP, GB, slot);
-  } else return false;
+#define C(NN)                                                                 \
+  hipLaunchKernelGGL(k_vel_update_free<NN>, g, b, 0, s, P, D, GP, GB, slot); \
+  hipLaunchKernelGGL(k_couple_free_vel<NN>, g, b, 0, s, P, D, GP, GB, slot)
+  OH_FREE_DISPATCH_N(n, C)
+#undef C
   return true;
 }
 

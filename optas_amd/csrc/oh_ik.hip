@@ -228,12 +228,11 @@ __global__ void __launch_bounds__(64) k_ik_solve(const oh_chain* __restrict__ ch
 bool oh_launch_ik_solve(hipStream_t stream, const oh_chain* d_chain, const IkParams& P, int B, const double* x0, const double* p, double* x,
                         double* f, double* kkt, int* iters, int* status, double* mult) {
   const dim3 block(64), grid((B + 63) / 64);
-  if (P.ndof == 7) {
-    hipLaunchKernelGGL(k_ik_solve<7>, grid, block, 0, stream, d_chain, P, B, x0, p, x, f, kkt, iters, status, mult);
-  } else if (P.ndof == 6) {
-    hipLaunchKernelGGL(k_ik_solve<6>, grid, block, 0, stream, d_chain, P, B, x0, p, x, f, kkt, iters, status, mult);
-  } else {
-    return false;
+  switch (P.ndof) {  // chain lengths 2 ... 8 (round 5: planar_3dof, the tester robots, 8-joint arms)
+#define C(NN) case NN: hipLaunchKernelGGL(k_ik_solve<NN>, grid, block, 0, stream, d_chain, P, B, x0, p, x, f, kkt, iters, status, mult); break
+    C(2); C(3); C(4); C(5); C(6); C(7); C(8);
+#undef C
+    default: return false;
   }
   return true;
 }

@@ -117,6 +117,29 @@ __global__ __launch_bounds__(256) void k_rnea(const oh_dynamics* __restrict__ dy
   }
 }
 
+// Chain lengths (round 5).  Orientation-locked family: the null space of the three orientation rows has N - 3 dimensions, so 4 ... 8 actuated
+// joints; kernels shared with the position-tracking family (set-up, finalisation, compaction): 2 ... 8.
+#define OH_DISPATCH_N(n, call)         \
+  switch (n) {                         \
+    case 4: call(4); break;            \
+    case 5: call(5); break;            \
+    case 6: call(6); break;            \
+    case 7: call(7); break;            \
+    case 8: call(8); break;            \
+    default: return false;             \
+  }
+#define OH_DISPATCH_N_ANY(n, call)     \
+  switch (n) {                         \
+    case 2: call(2); break;            \
+    case 3: call(3); break;            \
+    case 4: call(4); break;            \
+    case 5: call(5); break;            \
+    case 6: call(6); break;            \
+    case 7: call(7); break;            \
+    case 8: call(8); break;            \
+    default: return false;             \
+  }
+
 template <int N>
 __global__ __launch_bounds__(64) void k_setup(FigParams P, FigBuffers D, const double* __restrict__ x0, const double* __restrict__ pin) {
   setup_unit<N>(P, D, x0, pin, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
@@ -210,22 +233,19 @@ __global__ __launch_bounds__(64) void k_step_lg(FigParams P, FigBuffers D, Guard
 bool oh_launch_eval_locked_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot, int part) {
   // part 0: the fused kernel; 1: k_retract only; 2: the evaluation of the retracted knots only (1 then 2 = the split form; no sphere rows)
   const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
-  if (n == 7) {
-    if (part == 0) hipLaunchKernelGGL(k_eval_lg<7>, g, b, 0, s, P, D, GP, GB, slot);
-    else if (part == 1) hipLaunchKernelGGL(k_retract<7>, g, b, 0, s, P, D, slot);
-    else hipLaunchKernelGGL(k_evalb_lg<7>, g, b, 0, s, P, D, GP, GB, slot);
-  } else if (n == 6) {
-    if (part == 0) hipLaunchKernelGGL(k_eval_lg<6>, g, b, 0, s, P, D, GP, GB, slot);
-    else if (part == 1) hipLaunchKernelGGL(k_retract<6>, g, b, 0, s, P, D, slot);
-    else hipLaunchKernelGGL(k_evalb_lg<6>, g, b, 0, s, P, D, GP, GB, slot);
-  } else return false;
+#define C(NN)                                                                              \
+  if (part == 0) hipLaunchKernelGGL(k_eval_lg<NN>, g, b, 0, s, P, D, GP, GB, slot);       \
+  else if (part == 1) hipLaunchKernelGGL(k_retract<NN>, g, b, 0, s, P, D, slot);          \
+  else hipLaunchKernelGGL(k_evalb_lg<NN>, g, b, 0, s, P, D, GP, GB, slot)
+  OH_DISPATCH_N(n, C)
+#undef C
   return true;
 }
 bool oh_launch_step_locked_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
   const dim3 g((D.B + 63) / 64), b(64);
-  if (n == 7) hipLaunchKernelGGL(k_step_lg<7>, g, b, 0, s, P, D, GB, slot);
-  else if (n == 6) hipLaunchKernelGGL(k_step_lg<6>, g, b, 0, s, P, D, GB, slot);
-  else return false;
+#define C(NN) hipLaunchKernelGGL(k_step_lg<NN>, g, b, 0, s, P, D, GB, slot)
+  OH_DISPATCH_N(n, C)
+#undef C
   return true;
 }
 #ifndef OH_STEP_WAVES
@@ -620,16 +640,9 @@ static void launch_compact_t(hipStream_t s, const FigParams& P, const FigBuffers
   else hipLaunchKernelGGL(k_compact_scatter<N>, dim3((Bnew + 255) / 256, P.T), dim3(256), 0, s, P, D, Bnew, slot);
 }
 
-#define OH_DISPATCH_N(n, call)         \
-  switch (n) {                         \
-    case 6: call(6); break;            \
-    case 7: call(7); break;            \
-    default: return false;             \
-  }
-
 bool oh_launch_setup(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const double* x0, const double* p) {
 #define C(NN) launch_setup_t<NN>(s, P, D, x0, p)
-  OH_DISPATCH_N(n, C)
+  OH_DISPATCH_N_ANY(n, C)
 #undef C
   return true;
 }
@@ -654,13 +667,11 @@ bool oh_launch_couple(hipStream_t s, int n, const FigParams& P, const FigBuffers
 bool oh_launch_couple_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
   const int Tn = P.T - P.t0;
   const dim3 gu((D.B + 255) / 256, Tn), gc((unsigned)(((D.B + 255) / 256 + 7) / 8 * 8 * Tn)), b(256);
-  if (n == 7) {
-    hipLaunchKernelGGL(k_vel_update<7>, gu, b, 0, s, P, D, GP, GB, slot);
-    hipLaunchKernelGGL(k_couple_vel<7>, gc, b, 0, s, P, D, GP, GB, slot);
-  } else if (n == 6) {
-    hipLaunchKernelGGL(k_vel_update<6>, gu, b, 0, s, P, D, GP, GB, slot);
-    hipLaunchKernelGGL(k_couple_vel<6>, gc, b, 0, s, P, D, GP, GB, slot);
-  } else return false;
+#define C(NN)                                                              \
+  hipLaunchKernelGGL(k_vel_update<NN>, gu, b, 0, s, P, D, GP, GB, slot);  \
+  hipLaunchKernelGGL(k_couple_vel<NN>, gc, b, 0, s, P, D, GP, GB, slot)
+  OH_DISPATCH_N(n, C)
+#undef C
   return true;
 }
 bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
@@ -670,9 +681,9 @@ bool oh_launch_step(hipStream_t s, int n, const FigParams& P, const FigBuffers& 
   return true;
 }
 bool oh_launch_tail_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
-  if (n == 7) hipLaunchKernelGGL(k_tail_vel<7>, dim3(D.B), dim3(64), 0, s, P, D, GP, GB, slot);
-  else if (n == 6) hipLaunchKernelGGL(k_tail_vel<6>, dim3(D.B), dim3(64), 0, s, P, D, GP, GB, slot);
-  else return false;
+#define C(NN) hipLaunchKernelGGL(k_tail_vel<NN>, dim3(D.B), dim3(64), 0, s, P, D, GP, GB, slot)
+  OH_DISPATCH_N(n, C)
+#undef C
   return true;
 }
 bool oh_launch_tail(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot) {
@@ -684,7 +695,7 @@ bool oh_launch_tail(hipStream_t s, int n, const FigParams& P, const FigBuffers& 
 bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
                         int* iters, int* status) {
 #define C(NN) launch_finalize_t<NN>(s, P, D, only_done, x, f, kkt, iters, status)
-  OH_DISPATCH_N(n, C)
+  OH_DISPATCH_N_ANY(n, C)
 #undef C
   return true;
 }
@@ -699,7 +710,7 @@ void oh_launch_scan_running(hipStream_t s, const FigBuffers& D, int sort) {
 }
 bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {
 #define C(NN) launch_compact_t<NN>(s, P, D, phase, Bnew, slot)
-  OH_DISPATCH_N(n, C)
+  OH_DISPATCH_N_ANY(n, C)
 #undef C
   return true;
 }

@@ -326,6 +326,30 @@ def _torque(out, rng, sample, torque_batches):
         out[f"config5_torque_b{B}"] = {"what": f"torque MPC, RNEA dynamics equality rows + effort limits 58 N m (med7, T=30), primal-dual interior point, B = {B}" + (" (the nominal instance)" if B == 1 else ""),
                                        "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, "iterations_launched": tm["iterations_launched"], **r,
                                        "oracle_sample": oracle_grade("torque", T=T, lim=58.0, **smp) if smp else None}
+        if B == max(torque_batches):
+            # the MPC steady state (round 5, oh_tq_rollout): the same plants in closed loop, warm-started ticks resident on the device.  The goal table
+            # continues the figure of eight; the plant follows each plan for one knot.  Graded: a warm tick ends where the cold solve from the same state does.
+            n_ticks = 50
+            ts2 = np.arange(n_ticks + T) * dt
+            loc2 = np.stack([0.2 * np.sin(ts2 * np.pi * 0.5), 0.1 * np.sin(ts2 * np.pi), np.zeros(n_ticks + T)])
+            table = np.ascontiguousarray(pose[:, None, :3] + np.einsum("bij,jt->bti", Re, loc2))
+            st0 = np.concatenate([qc, np.zeros((B, 7))], 1)
+            be.rollout(st0[:64], table[:64], 2)  # warm-up of the code path
+            states, tau0, fr, itr, stt = be.rollout(st0, table, n_ticks)
+            ms = be.timing()["solve_ms"]
+            idx = np.sort(np.random.default_rng(55).choice(B, 32, replace=False))
+            k = n_ticks // 2
+            pk = np.ascontiguousarray(np.concatenate([states[k, idx], table[idx, k : k + T].reshape(len(idx), -1)], 1))
+            xk = np.zeros((len(idx), 4 * 7 * T))
+            xk[:, 2 * 7 * T : 2 * 7 * T + 7] = -states[k, idx, 7:] / dt  # cold seed: brake to rest, hold still
+            cold = be.solve(xk, pk)
+            okc = _lib.status_ok(cold.status)
+            out["config5_torque_closed_loop"] = {
+                "what": f"torque MPC in closed loop (oh_tq_rollout): {B} plants x {n_ticks} ticks, seed = previous plan shifted one knot, barrier parameter of warm ticks 1e-6, plant = the plan's next state",
+                "batch": B, "ticks": n_ticks, "device_ms": ms, "ticks_per_s": B * n_ticks / ms * 1e3, "ms_per_tick": ms / n_ticks,
+                "converged_frac": float(_lib.status_ok(stt).mean()), "steps_cold_tick_p50": float(np.median(itr[0])), "steps_warm_tick_p50": float(np.median(itr[1:])),
+                "steps_warm_tick_p90": float(np.percentile(itr[1:], 90)), "steps_warm_tick_max": int(itr[1:].max()),
+                "warm_vs_cold_objective_rel_max": float((np.abs(cold.f - fr[k, idx]) / np.abs(cold.f))[okc].max()), "cold_steps_same_states_p50": float(np.median(cold.iters[okc]))}
         be.close()
     return out
 

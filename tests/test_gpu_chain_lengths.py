@@ -116,7 +116,7 @@ def test_position_tracking_for_three_to_eight_joints(hip_lib, tmp_path):
         nlp.offsets = {"l": offs.T, "r": offs.T}
         for b in range(0, B, 2):
             s = solve_free_lm(ch, T, dt, offs, qc[b], Q0=np.tile(qc[b], (T, 1)), max_iter=400)
-            assert s["status"] == 0 and abs(s["f"] - res.f[b]) <= 1e-9 * max(1.0, s["f"]) and abs(s["iters"] - int(res.iters[b])) <= 2, (tag, b, s["f"], res.f[b])
+            assert s["status"] == 0 and abs(s["f"] - res.f[b]) <= 1e-9 * max(1.0, s["f"]) and abs(s["iters"] - int(res.iters[b])) <= max(2, s["iters"] // 20), (tag, b, s["f"], res.f[b])
             x2, p2 = np.concatenate([res.x[b], res.x[b + 1]]), np.concatenate([qc[b], qc[b + 1]])
             assert abs(nlp.f(x2, p2) - (res.f[b] + res.f[b + 1])) <= 1e-10 and np.abs(nlp.a(x2, p2)).max() <= 1e-12
             k = kkt_reference_form(nlp, x2, p2)

@@ -58,3 +58,6 @@ for k in ("oh_spec_retract", "oh_spec_evalb_zc", "k_step_zc", "oh_spec_tail", "k
         print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in res[k].items() if a != "counters"})
 print("errors", errs)
 PY
+# the raw databases of six passes are ~100 MB: gpurun merges at most 64 MiB back -- keep the condensed file and one pass's logs only
+rm -rf $OUT/pmc*/ 2>/dev/null
+ls -la $REPO/gpurun_out/r05_sq.json

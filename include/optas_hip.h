@@ -425,7 +425,7 @@ int oh_pm_rollout(oh_handle* h, int B, int n_ticks, int advance, double ramp, co
 /* The same loop for OH_PROBLEM_TORQUE_MPC (round 5; BASELINE configs[4] is an MPC: "solves per second" in steady state are warm-started ticks).
    Per tick k:  p_k = [q_k; dq_k; rows k * advance .. k * advance + T - 1 of the plant's goal table];
      seed = the accelerations of the previous plan shifted by `advance` knots, the last one repeated (the reference's pattern, point_mass_mpc.py:157-158:
-     seed from the previous solution; tick 0: zero accelerations = the cold solve), barrier parameter of a warm tick mu_warm (<= 0: 1e-8 = tol_compl; the cold
+     seed from the previous solution; tick 0: zero accelerations = the cold solve), barrier parameter of a warm tick mu_warm (<= 0: 1e-6; the cold
      default 0.1 = IPOPT's mu_init would first walk the iterate back to the centre of the feasible set);
      solve; the plant follows the plan for `advance` knots: (q, dq) <- the plan's state at knot `advance` -- the Euler roll-out of its accelerations,
      with the torques of the inverse-dynamics rows, tau_t = rnea(q_t, dq_t, ddq_t).

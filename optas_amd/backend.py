@@ -322,7 +322,7 @@ class TorqueBackend(_SolveMixin):
         _lib.check(_lib.load().oh_get_multipliers(self._h, int(B), _lib._ptr(out)), "oh_get_multipliers")
         return out
 
-    def rollout(self, state0, goal_table, n_ticks: int, advance: int = 1, mu_warm: float = 1e-8):
+    def rollout(self, state0, goal_table, n_ticks: int, advance: int = 1, mu_warm: float = 1e-6):
         """Closed-loop receding horizon on the device (oh_tq_rollout; the reference's pattern, example/point_mass_mpc.py:156-175: seed = the previous
         solution).  state0 (B, 2 ndof) = (q, dq); goal_table (B, n_ticks * advance + T, 3): tick k tracks rows k * advance .. k * advance + T - 1.
         Returns states (n_ticks + 1, B, 2 ndof), tau0 (n_ticks, B, ndof), f, iters, status (n_ticks, B)."""

@@ -1688,7 +1688,7 @@ extern "C" int oh_tq_rollout(oh_handle* h, int B, int n_ticks, int advance, doub
   if (h->desc.kind != OH_PROBLEM_TORQUE_MPC) return fail(OH_ERR_STATE, "oh_tq_rollout: handle is not a torque-MPC problem");
   const int T = h->tq.T, N = h->tq.ndof;
   if (B < 1 || n_ticks < 1 || advance < 1 || advance >= T) return fail(OH_ERR_INVALID, "oh_tq_rollout: need B >= 1, n_ticks >= 1, 1 <= advance < T");
-  if (!(mu_warm > 0.0)) mu_warm = 1e-8;
+  if (!(mu_warm > 0.0)) mu_warm = 1e-6;
   HIPCHK(hipSetDevice(h->device));
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
   const size_t n_rows = (size_t)n_ticks * advance + T;

@@ -14,40 +14,46 @@ from .expr import Expr
 
 
 class SXContainer(collections.OrderedDict):
+    """Contract mirrored from the reference class (what callers and the reference's tests rely on): insertion order is vec() order; a label can be
+    set once (KeyError afterwards, sx_container.py:50-51); every block starts out continuous and can be flagged discrete by label; ``a + b`` is a
+    new container holding a's blocks, then b's, with both flag tables."""
+
     def __init__(self):
         super().__init__()
         self.is_discrete: Dict[str, bool] = {}
 
+    def _adopt(self, other: "SXContainer") -> None:
+        for label in other:
+            self[label] = other[label]
+            self.is_discrete[label] = other.is_discrete.get(label, False)
+
     def __add__(self, other):
-        assert isinstance(other, SXContainer), f"cannot add SXContainer with a variable of type {type(other)}"
-        out = SXContainer()
-        for label, value in self.items():
-            out[label] = value
-        for label, value in other.items():
-            out[label] = value
-        out.is_discrete = {**self.is_discrete, **other.is_discrete}
-        return out
+        if not isinstance(other, SXContainer):
+            raise AssertionError(f"an SXContainer can only be joined with another one, got {type(other).__name__}")
+        joined = SXContainer()
+        joined._adopt(self)
+        joined._adopt(other)
+        return joined
 
     def __setitem__(self, label: str, value: Expr) -> None:
-        assert isinstance(value, Expr), f"value must be an optas_amd expression, not {type(value)}"
+        if not isinstance(value, Expr):
+            raise AssertionError(f"blocks are optas_amd expressions; '{label}' was given a {type(value).__name__}")
         if label in self:
             raise KeyError(f"'{label}' already exists")
-        super().__setitem__(label, value)
-        self.is_discrete[label] = False
+        collections.OrderedDict.__setitem__(self, label, value)
+        self.is_discrete.setdefault(label, False)
 
     def variable_is_discrete(self, label: str) -> None:
-        assert label in self, f"'{label}' was not found"
+        if label not in self:
+            raise AssertionError(f"no block is called '{label}'")
         self.is_discrete[label] = True
 
     def has_discrete_variables(self) -> bool:
-        return any(self.is_discrete.values())
+        return True in self.is_discrete.values()
 
     def discrete(self) -> List[bool]:
-        out: List[bool] = []
-        for label, value in self.items():
-            m, n = value.shape
-            out += [self.is_discrete[label]] * (m * n)
-        return out
+        """One flag per scalar entry, in vec() order."""
+        return [flag for label, block in self.items() for flag in [self.is_discrete[label]] * (block.shape[0] * block.shape[1])]
 
     def numel(self) -> int:
         return sum(v.shape[0] * v.shape[1] for v in self.values())

@@ -232,7 +232,7 @@ def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, 
             "mu_b": mub, "lam": mub / np.maximum(s, 1e-300), "s": s}
 
 
-def rollout_torque_ipm(prob: TorqueProblem, q0, dq0, goal_table, n_ticks, advance=1, mu_warm=1e-8, **kw):
+def rollout_torque_ipm(prob: TorqueProblem, q0, dq0, goal_table, n_ticks, advance=1, mu_warm=1e-6, **kw):
     """Closed-loop receding horizon of one plant, the loop oh_tq_rollout keeps on the device (pattern of example/point_mass_mpc.py:156-175: the seed of
     a tick is the previous solution): parameters of tick k = the plant's state and rows k * advance .. of its goal table; seed = the previous plan's
     accelerations shifted by `advance` knots, the last one repeated (tick 0: zeros), barrier parameter of a warm tick mu_warm; the plant takes the

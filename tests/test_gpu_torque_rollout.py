@@ -74,7 +74,7 @@ def test_batch_of_plants_warm_ticks_reach_the_cold_optimum_in_a_fraction_of_the_
     prob = TorqueProblem(med7, LINK, T=T, dt=DT, tau_lim=LIM, **W)
     nlp = TorqueMPCNLP(prob)
     rng = np.random.default_rng(SEED + 62)
-    B, n_ticks, mu_warm = 2048, 20, 1e-8
+    B, n_ticks, mu_warm = 2048, 20, 1e-6
     qc = QN + rng.uniform(-0.1, 0.1, (B, 7))
     goals = _goal_tables(robot, qc, n_ticks + T)
     state0 = np.concatenate([qc, np.zeros((B, 7))], 1)

@@ -345,7 +345,7 @@ def _torque(out, rng, sample, torque_batches):
             cold = be.solve(xk, pk)
             okc = _lib.status_ok(cold.status)
             out["config5_torque_closed_loop"] = {
-                "what": f"torque MPC in closed loop (oh_tq_rollout): {B} plants x {n_ticks} ticks, seed = previous plan shifted one knot, barrier parameter of warm ticks 1e-8, plant = the plan's next state",
+                "what": f"torque MPC in closed loop (oh_tq_rollout): {B} plants x {n_ticks} ticks, seed = previous plan shifted one knot, barrier parameter of warm ticks 1e-6, plant = the plan's next state",
                 "batch": B, "ticks": n_ticks, "device_ms": ms, "ticks_per_s": B * n_ticks / ms * 1e3, "ms_per_tick": ms / n_ticks,
                 "converged_frac": float(_lib.status_ok(stt).mean()), "steps_cold_tick_p50": float(np.median(itr[0])), "steps_warm_tick_p50": float(np.median(itr[1:])),
                 "steps_warm_tick_p90": float(np.percentile(itr[1:], 90)), "steps_warm_tick_max": int(itr[1:].max()),

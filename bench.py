@@ -275,6 +275,11 @@ def main():
         return
     comm = None
     rccl_error = None
+    # stdout carries ONE line, the JSON: RCCL prints its version banner to stdout when a communicator is created (and native code may print later),
+    # so from here on file descriptor 1 points at stderr and the result line goes to the saved descriptor at the very end
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if world > 1 or "RANK" in os.environ:  # launcher-started: one rank per GPU
         from optas_amd import distributed as oad
 
@@ -544,14 +549,20 @@ def main():
 
         be.close()
         t0c = time.perf_counter()
-        out["configs"] = bench_configs.run_configs(sample=0 if args.no_cpu_baseline else 8)
+        try:  # (the headline line is printed whatever happens in here)
+            out["configs"] = bench_configs.run_configs(sample=0 if args.no_cpu_baseline else 8)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            out["configs"] = {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
         out["configs"]["seconds"] = time.perf_counter() - t0c
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if comm is not None:
         comm.barrier()
         comm.destroy()
-    print(json.dumps(out))
+    sys.stdout.flush()
+    print(json.dumps(out), file=result_out, flush=True)
 
 
 if __name__ == "__main__":

@@ -323,6 +323,14 @@ int oh_qp_set_tape(oh_handle* h, const oh_tape_desc* tape);
    of the = rows in L = f - lam^T g - mu^T c). */
 int oh_create_tape(const oh_tape_desc* desc, oh_handle** out);
 
+/* One forward sweep -- and, with seeds, one reverse sweep -- of an OH_PROBLEM_TAPE handle's tape at given points, on the device: what the reference gets
+   by calling the cs.Functions of an Optimization and their AD derivatives (optimization.py:8-24).  x [B][nx], p [B][np]; regs [n_regs] registers;
+   val [B][n_regs] their values.  seeds NULL, or [B][1 + n_ineq + n_eq] weights of (cost, rows in the tape's order): then adj [B][n_regs] is the
+   derivative of that combination with respect to each register and grad [B][nx] its gradient (either may be NULL).  Host buffers.  The host side uses
+   it to read back variables it has eliminated from a tape and the multipliers of the rows that went with them (optas_amd/tape.py). */
+int oh_tape_probe(oh_handle* h, int B, const double* x, const double* p, int n_regs, const int* regs, double* val, const double* seeds, double* adj,
+                  double* grad);
+
 /* What oh_create_tape does for desc->jit != 0 before it touches a device (CasADi's "jit" option, solver.py:333-384 passes it through): generate
    the kernel source of this tape and compile it for gfx950.  Needs no GPU.  source (optional, source_cap bytes) receives the generated
    text, *source_len its full length, *code_bytes the size of the code object. */

@@ -215,6 +215,7 @@ SYMBOLS = [
     "oh_create_tape",
     "oh_create_torque",
     "oh_tape_compile",
+    "oh_tape_probe",
     "oh_set_constants",
     "oh_set_constants_device",
     "oh_get_constants",
@@ -301,6 +302,7 @@ def load() -> C.CDLL:
     lib.oh_create_tape.argtypes = [C.POINTER(oh_tape_desc), C.POINTER(vp)]
     lib.oh_qp_set_tape.argtypes = [vp, C.POINTER(oh_tape_desc)]
     lib.oh_tape_compile.argtypes = [C.POINTER(oh_tape_desc), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.oh_tape_probe.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, vp]
     lib.oh_set_constants.argtypes = [vp, C.POINTER(oh_chain)]
     lib.oh_set_constants_device.argtypes = [vp, vp, C.c_size_t]
     lib.oh_set_guards.argtypes = [vp, C.POINTER(oh_guards)]

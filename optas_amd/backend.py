@@ -131,10 +131,12 @@ class PointMassBackend(_SolveMixin):
 class TapeBackend(_SolveMixin):
     """OH_PROBLEM_TAPE handle: a compiled instruction tape (optas_amd.tape.Tape) interpreted on the GPU; x (B, nx), p (B, np)."""
 
-    def __init__(self, tape, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True, wave=True, options=None):
+    def __init__(self, tape, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True, wave=True, options=None, keep_regs=None):
         """wave: let trajectory-sized tapes (beyond 48 variables) run one block of wavefronts per instance over the dependency levels of the tape
-        (csrc/oh_tape_wave.hip) where the library finds that it applies; options: oh_set_option pairs applied to the handle."""
+        (csrc/oh_tape_wave.hip) where the library finds that it applies; options: oh_set_option pairs applied to the handle; keep_regs: registers the
+        caller will read back with probe() -- self.kept_regs holds their indices in the tape the handle was given (re-association renumbers)."""
         self.nx, self.np_ = int(tape.nx), max(1, int(tape.np_))
+        self.kept_regs = None if keep_regs is None else np.asarray(keep_regs, dtype=np.int32)
         self._np_real = int(tape.np_)
         self._h = None
         want_wave = bool(wave) and int(tape.nx) > 48 and float((options or {}).get("tape_wave", 1)) != 0.0
@@ -142,12 +144,22 @@ class TapeBackend(_SolveMixin):
             # chains of additions are dependency levels for that evaluator, so sums go in as balanced trees (same values to the rounding of the
             # summation order).  Whether the path is taken is the library's decision (limited-memory regime, LDS fit): the handle is asked, and a
             # tape the library declined is handed over again as it was written (one gate, not an environment variable read twice)
-            from .tape import rebalance_sums
+            from .tape import Tape, rebalance_sums
 
-            self._create(rebalance_sums(tape), max_iter, tol, tol_feas, rho0, jit, options)
+            if keep_regs is None:
+                bal, kept = rebalance_sums(tape), None
+            else:  # the registers to keep ride along as extra outputs of the re-association, then leave the row list again
+                nk = len(self.kept_regs)
+                tmp = rebalance_sums(Tape(tape.op, tape.a, tape.b, tape.c, tape.out_cost, np.concatenate([tape.out_rows, self.kept_regs]).astype(np.int32),
+                                          tape.n_ineq, tape.n_eq + nk, tape.nx, tape.np_))
+                bal = Tape(tmp.op, tmp.a, tmp.b, tmp.c, tmp.out_cost, tmp.out_rows[: len(tmp.out_rows) - nk].copy(), tape.n_ineq, tape.n_eq, tape.nx, tape.np_)
+                kept = np.asarray(tmp.out_rows[len(tmp.out_rows) - nk :], dtype=np.int32)
+            self._create(bal, max_iter, tol, tol_feas, rho0, jit, options)
             if self.flag("tape_wave") == 0:
                 self.close()
                 want_wave = False
+            elif kept is not None:
+                self.kept_regs = kept
         if not want_wave:
             opts = dict(options or {})
             if int(tape.nx) > 48:
@@ -194,6 +206,22 @@ class TapeBackend(_SolveMixin):
         _lib.check(_lib.load().oh_tape_compile(C.byref(desc), C.byref(size), buf, n.value + 1, C.byref(n)), "oh_tape_compile")
         return buf.value.decode(), int(size.value)
 
+    def probe(self, x, p, regs=None, seeds=None):
+        """oh_tape_probe: values of `regs` at the points x (B, nx), p (B, np); with seeds (B, 1 + n_ineq + n_eq) = weights of (cost, rows) also the
+        derivative of that combination with respect to each of the registers and its gradient with respect to x.  Returns (val, adj, grad)."""
+        x = _lib.as_f64(x).reshape(-1, self.nx)
+        B = x.shape[0]
+        p = _lib.as_f64(p).reshape(B, -1) if self._np_real else np.zeros((B, 1))
+        regs = np.ascontiguousarray(np.zeros(0) if regs is None else regs, dtype=np.int32)
+        val = np.empty((B, len(regs)))
+        adj = grad = None
+        if seeds is not None:
+            seeds = _lib.as_f64(seeds).reshape(B, 1 + int(self.tape.n_ineq) + int(self.tape.n_eq))
+            adj, grad = np.empty((B, len(regs))), np.empty((B, self.nx))
+        _lib.check(_lib.load().oh_tape_probe(self._h, B, _lib._ptr(x), _lib._ptr(p), len(regs), _lib._ptr(regs) if len(regs) else None, _lib._ptr(val) if len(regs) else None,
+                                             _lib._ptr(seeds), _lib._ptr(adj) if (adj is not None and len(regs)) else None, _lib._ptr(grad)), "oh_tape_probe")
+        return val, adj, grad
+
     def flag(self, name: str) -> int:
         """oh_get_flag: 'tape_wave' (0 thread per instance, 1 / 2 wavefront per instance), 'tape_regs_lds', 'tape_levels', 'tape_passes'."""
         v = C.c_int(0)
@@ -212,6 +240,86 @@ class TapeBackend(_SolveMixin):
         if ni + ne:
             _lib.check(_lib.load().oh_get_multipliers(self._h, int(B), _lib._ptr(out)), "oh_get_multipliers")
         return out[:, :ni], out[:, ni:]
+
+
+class EliminatedTapeBackend:
+    """A generic problem whose affine equality rows -- the Euler rows of integrate_model_states, fix_configuration, initial_configuration
+    (builder.py:419-469, 511-539) -- have been eliminated by substitution (optas_amd/tape.py:eliminate_affine_equalities): the GPU solves over the free
+    variables, and the eliminated variables and the multipliers of their rows are read back from the device (oh_tape_probe: one forward and one reverse
+    sweep at the solution).  Presents the ORIGINAL problem: x (B, nx), multipliers (B, n_ineq), (B, n_eq) in the original row order."""
+
+    def __init__(self, tape, elim, **kw):
+        self.full, self.elim = tape, elim
+        self.nx, self.np_ = int(tape.nx), max(1, int(tape.np_))
+        self.inner = TapeBackend(elim.tape, keep_regs=elim.def_regs, **kw)
+        self.tape = tape
+        self.jit, self.wave = self.inner.jit, self.inner.wave
+        self._mult = None
+
+    def solve(self, x0, p):
+        el = self.elim
+        x0 = _lib.as_f64(x0).reshape(-1, self.nx)
+        B = x0.shape[0]
+        p = _lib.as_f64(p).reshape(B, -1)
+        r = self.inner.solve(np.ascontiguousarray(x0[:, el.free]), p)
+        lam, mu = self.inner.multipliers(B)
+        # L = f - lam^T g - mu^T h over the rows that stayed; its derivative with respect to an eliminated variable is what that variable's row has to
+        # balance: A_pivot^T nu = dL/dx_pivot
+        seeds = np.concatenate([np.ones((B, 1)), -lam, -mu], axis=1)
+        val, adj, _ = self.inner.probe(r.x, p, self.inner.kept_regs, seeds)
+        x = np.empty((B, self.nx))
+        x[:, el.free] = r.x
+        x[:, el.pivot] = val
+        nu = np.linalg.solve(el.A_pivot.T, adj.T).T
+        n_eq = int(self.full.n_eq)
+        mu_full = np.zeros((B, n_eq))
+        mu_full[:, el.rows_kept] = mu
+        mu_full[:, el.rows_out] = nu
+        self._mult = (lam, mu_full)
+        return BatchResult(x, r.f, r.kkt, r.iters, r.status)
+
+    def multipliers(self, B: int):
+        assert self._mult is not None and len(self._mult[0]) == B
+        return self._mult
+
+    def flag(self, name: str) -> int:
+        return self.inner.flag(name)
+
+    def timing(self) -> dict:
+        return self.inner.timing()
+
+    def solve_ms(self) -> float:
+        return self.inner.solve_ms()
+
+    def set_options(self, options=None, **kw):
+        self.inner.set_options(options, **kw)
+        return self
+
+    def set_option(self, name, value):
+        self.inner.set_option(name, value)
+        return self
+
+    def get_option(self, name):
+        return self.inner.get_option(name)
+
+    @property
+    def handle(self):
+        return self.inner.handle
+
+    def close(self) -> None:
+        self.inner.close()
+
+
+def tape_backend(tape, eliminate=True, **kw):
+    """TapeBackend for a compiled problem; trajectory-sized ones (beyond 48 variables: the limited-memory regime) first lose the equality rows that
+    are affine in x with constant coefficients."""
+    if eliminate and int(tape.nx) > 48 and int(tape.n_eq) > 0:
+        from .tape import eliminate_affine_equalities
+
+        el = eliminate_affine_equalities(tape)
+        if el is not None and int(el.tape.nx) >= 1:
+            return EliminatedTapeBackend(tape, el, **kw)
+    return TapeBackend(tape, **kw)
 
 
 class QPBackend(_SolveMixin):

@@ -168,7 +168,7 @@ def make_solver_class(solver_module, cs):
         solver.reset_initial_seed({...}); solver.reset_parameters({...}); solution = solver.solve()
     """
     from . import _lib
-    from .backend import TapeBackend, tape_default_max_iter
+    from .backend import tape_backend, tape_default_max_iter
 
     class HIPSolver(solver_module.Solver):
         def setup(self, solver_name: str = "hip_sqp", solver_options: Optional[dict] = None):
@@ -251,8 +251,8 @@ def make_solver_class(solver_module, cs):
                                      "squares of affine expressions under a constant) with nx <= 32, nk <= 256, na <= 32")
             if self._family is None:
                 self._tape = tape_from_optimization(self.opt, cs)
-                self._backend = TapeBackend(self._tape, max_iter=int(o.pop("max_iter", tape_default_max_iter(self._tape.nx))), tol=float(o.pop("tol", 1e-6)),
-                                            tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=float(o.pop("rho0", 10.0)), jit=bool(o.pop("jit", True)))
+                self._backend = tape_backend(self._tape, eliminate=bool(o.pop("eliminate", True)), max_iter=int(o.pop("max_iter", tape_default_max_iter(self._tape.nx))),
+                                             tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=float(o.pop("rho0", 10.0)), jit=bool(o.pop("jit", True)))
                 self._family = "tape"
             if o:
                 raise ValueError(f"unknown solver options {sorted(o)}")

@@ -526,6 +526,47 @@ extern "C" int oh_create_tape(const oh_tape_desc* d, oh_handle** out) {
   return OH_OK;
 }
 
+static int ensure_stage(oh_handle* h, size_t bytes);
+extern "C" int oh_tape_probe(oh_handle* h, int B, const double* x, const double* p, int n_regs, const int* regs, double* val, const double* seeds, double* adj,
+                             double* grad) {
+  if (!h || !x) return fail(OH_ERR_INVALID, "oh_tape_probe: null argument");
+  if (h->desc.kind != OH_PROBLEM_TAPE) return fail(OH_ERR_STATE, "oh_tape_probe: handle is not an OH_PROBLEM_TAPE problem");
+  const TapeParams& T = h->TP;
+  if (B < 1 || n_regs < 0 || (n_regs > 0 && !regs) || (T.np > 0 && !p)) return fail(OH_ERR_INVALID, "oh_tape_probe: bad sizes");
+  for (int i = 0; i < n_regs; ++i)
+    if (regs[i] < 0 || regs[i] >= T.len) return fail(OH_ERR_INVALID, "oh_tape_probe: register out of range");
+  HIPCHK(hipSetDevice(h->device));
+  const int Bp = (B + 63) / 64 * 64;
+  const int nrow = T.n_ineq + T.n_eq;
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t b_x = sizeof(double) * (size_t)T.nx * B, b_p = sizeof(double) * (size_t)(T.np > 0 ? T.np : 1) * B, b_r = sizeof(int) * (size_t)(n_regs + 1),
+               b_v = sizeof(double) * (size_t)(n_regs + 1) * B, b_s = sizeof(double) * (size_t)(1 + nrow) * B, b_w = sizeof(double) * (2 * (size_t)T.len + 2 * (size_t)T.nx) * Bp;
+  int rc = ensure_stage(h, al(b_x) * 2 + al(b_p) + al(b_r) + 2 * al(b_v) + al(b_s) + al(b_w));
+  if (rc) return rc;
+  char* base = (char*)h->stage;
+  double* d_x = (double*)base; base += al(b_x);
+  double* d_g = (double*)base; base += al(b_x);
+  double* d_p = (double*)base; base += al(b_p);
+  int* d_r = (int*)base; base += al(b_r);
+  double* d_v = (double*)base; base += al(b_v);
+  double* d_a = (double*)base; base += al(b_v);
+  double* d_s = (double*)base; base += al(b_s);
+  double* d_w = (double*)base;
+  hipStream_t s = h->stream;
+  HIPCHK(hipMemcpyAsync(d_x, x, b_x, hipMemcpyHostToDevice, s));
+  if (T.np > 0) HIPCHK(hipMemcpyAsync(d_p, p, sizeof(double) * (size_t)T.np * B, hipMemcpyHostToDevice, s));
+  if (n_regs > 0) HIPCHK(hipMemcpyAsync(d_r, regs, sizeof(int) * (size_t)n_regs, hipMemcpyHostToDevice, s));
+  if (seeds) HIPCHK(hipMemcpyAsync(d_s, seeds, b_s, hipMemcpyHostToDevice, s));
+  oh_launch_tape_probe(s, T, h->d_tape_op, h->d_tape_a, h->d_tape_b, h->d_tape_c, h->d_tape_rows, B, Bp, d_x, d_p, d_w, n_regs, d_r, val ? d_v : nullptr,
+                       seeds ? d_s : nullptr, (seeds && adj) ? d_a : nullptr, (seeds && grad) ? d_g : nullptr);
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  if (val && n_regs > 0) HIPCHK(hipMemcpy(val, d_v, sizeof(double) * (size_t)n_regs * B, hipMemcpyDeviceToHost));
+  if (seeds && adj && n_regs > 0) HIPCHK(hipMemcpy(adj, d_a, sizeof(double) * (size_t)n_regs * B, hipMemcpyDeviceToHost));
+  if (seeds && grad) HIPCHK(hipMemcpy(grad, d_g, b_x, hipMemcpyDeviceToHost));
+  return OH_OK;
+}
+
 static int tape_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status) {
   HIPCHK(hipSetDevice(h->device));
   const int Bp = (B + 63) / 64 * 64;

@@ -187,6 +187,8 @@ void oh_tape_wave_release(TapeWave* w);
 hipError_t oh_launch_tape_wave(hipStream_t s, TapeWave& W, const TapeParams& T, int B, const double* x0, const double* p, double* x, double* f, double* kkt,
                                int* iters, int* status, double* mult);
 size_t oh_tape_work_rows(const TapeParams& T, bool jit);
+void oh_launch_tape_probe(hipStream_t s, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, int B, int Bp,
+                          const double* x, const double* p, double* work, int n_regs, const int* regs, double* val, const double* seeds, double* adj, double* grad);
 void oh_launch_tape_solve(hipStream_t s, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, int B, int Bp,
                           const double* x0, const double* p, double* work, double* x, double* f, double* kkt, int* iters, int* status, double* mult);
 std::string oh_tape_jit_source(const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows);

@@ -155,6 +155,37 @@ __global__ __launch_bounds__(64) void k_tape_solve(TapeParams T, TapeView tv, in
   tape_solve_instance(T, ev, W, Bp, b, b, x0, xo, fo, kkt, iters, status, mult);
 }
 
+// One forward sweep (and, seeded, one reverse sweep) at given points: values / adjoints of chosen registers and the gradient wrt x (oh_tape_probe).
+// work: [2 len + 2 nx][Bp] -- registers, adjoints, the point and the gradient in the interpreter's SoA layout.
+__global__ __launch_bounds__(64) void k_tape_probe(TapeParams T, TapeView tv, int B, int Bp, const double* __restrict__ x, const double* __restrict__ par,
+                                                   double* __restrict__ work, int n_regs, const int* __restrict__ regs, double* __restrict__ val_out,
+                                                   const double* __restrict__ seeds, double* __restrict__ adj_out, double* __restrict__ grad_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double* val = work;
+  double* adj = work + (size_t)T.len * Bp;
+  double* xs = work + 2 * (size_t)T.len * Bp;
+  double* gr = xs + (size_t)T.nx * Bp;
+  for (int k = 0; k < T.nx; ++k) xs[TIDX(k)] = x[(size_t)b * T.nx + k];
+  const TapeWork none{};
+  InterpEval ev{T, tv, none, val, adj, par + (size_t)b * T.np, Bp, b};
+  ev.forward(xs);
+  if (val_out)
+    for (int i = 0; i < n_regs; ++i) val_out[(size_t)b * n_regs + i] = val[TIDX(regs[i])];
+  if (!seeds) return;
+  for (int i = 0; i < T.len; ++i) adj[TIDX(i)] = 0.0;
+  const int nrow = T.n_ineq + T.n_eq;
+  const double* sd = seeds + (size_t)b * (1 + nrow);
+  adj[TIDX(T.out_cost)] += sd[0];
+  for (int i = 0; i < nrow; ++i) adj[TIDX(tv.rows[i])] += sd[1 + i];
+  ev.reverse(gr);
+  // (the reverse sweep leaves in adj[i] the derivative of the seeded combination with respect to register i)
+  if (adj_out)
+    for (int i = 0; i < n_regs; ++i) adj_out[(size_t)b * n_regs + i] = adj[TIDX(regs[i])];
+  if (grad_out)
+    for (int k = 0; k < T.nx; ++k) grad_out[(size_t)b * T.nx + k] = gr[TIDX(k)];
+}
+
 // ---- code generation ------------------------------------------------------------------------------------------------------------------
 void emit(std::string& s, const char* fmt, ...) {
   char buf[512];
@@ -336,6 +367,12 @@ void oh_launch_tape_solve(hipStream_t s, const TapeParams& T, const int* op, con
                           const double* x0, const double* p, double* work, double* x, double* f, double* kkt, int* iters, int* status, double* mult) {
   TapeView tv{op, a, b, c, rows};
   hipLaunchKernelGGL(k_tape_solve, dim3((B + 63) / 64), dim3(64), 0, s, T, tv, B, Bp, x0, p, work, x, f, kkt, iters, status, mult);
+}
+
+void oh_launch_tape_probe(hipStream_t s, const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows, int B, int Bp,
+                          const double* x, const double* p, double* work, int n_regs, const int* regs, double* val, const double* seeds, double* adj, double* grad) {
+  TapeView tv{op, a, b, c, rows};
+  hipLaunchKernelGGL(k_tape_probe, dim3((B + 63) / 64), dim3(64), 0, s, T, tv, B, Bp, x, p, work, n_regs, regs, val, seeds, adj, grad);
 }
 
 std::string oh_tape_jit_source(const TapeParams& T, const int* op, const int* a, const int* b, const double* c, const int* rows) {

@@ -220,6 +220,7 @@ class Communicator:
 
     def __init__(self, rank: int, world: int, local_rank: int, path: Optional[str] = None):
         os.environ.setdefault("NCCL_DEBUG", "WARN")  # RCCL's own diagnosis (a peer that died, a link that is down) reaches stderr
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")  # ... and not stdout, where harnesses print their one result line
         lib = _lib.load()
         self.rank, self.world, self._path = rank, world, (rendezvous_path() if path is None else path)
         _lib.check(lib.oh_set_device(local_rank), "oh_set_device")

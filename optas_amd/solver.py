@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import _lib
-from .backend import BatchResult, FigureEightBackend, IKBackend, MultiArmBackend, PointMassBackend, QPBackend, TapeBackend, TorqueBackend, tape_default_max_iter
+from .backend import BatchResult, FigureEightBackend, IKBackend, MultiArmBackend, PointMassBackend, QPBackend, TapeBackend, TorqueBackend, tape_backend, tape_default_max_iter
 from .lowering import FigureEightSpec, IkSpec, MultiArmSpec, PointMassSpec, QpSpec, TapeSpec, TorqueSpec, lower
 from .models import RobotModel
 from .optimization import Optimization
@@ -335,8 +335,9 @@ class HIPSolver(Solver):
         elif isinstance(spec, TapeSpec):
             o.pop("hessian", None)
             # (evaluations: a small dense problem needs a few hundred; the limited-memory path of a trajectory-sized one tens of thousands)
-            self._backend = TapeBackend(spec.tape, max_iter=int(o.pop("max_iter", tape_default_max_iter(spec.tape.nx))), tol=float(o.pop("tol", 1e-6)),
-                                        tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=float(o.pop("rho0", 10.0)), jit=bool(o.pop("jit", True)))
+            # ("eliminate": affine equality rows -- Euler rows, pinned configurations -- are substituted away before the tape reaches the GPU, tape.py)
+            self._backend = tape_backend(spec.tape, eliminate=bool(o.pop("eliminate", True)), max_iter=int(o.pop("max_iter", tape_default_max_iter(spec.tape.nx))),
+                                         tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=float(o.pop("rho0", 10.0)), jit=bool(o.pop("jit", True)))
         else:  # pragma: no cover
             raise NotImplementedError(kind)
         if o:

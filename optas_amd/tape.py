@@ -647,3 +647,186 @@ def band_rewrite(tape: Tape) -> Optional[Tape]:
     out_rows = np.asarray(rows + [int(r) for r in tape.out_rows[ni:]], dtype=np.int32)
     return Tape(np.asarray(ops, dtype=np.int32), np.asarray(aa, dtype=np.int32), np.asarray(bb, dtype=np.int32), np.asarray(cc, dtype=np.float64),
                 tape.out_cost, out_rows, len(rows), tape.n_eq, tape.nx, tape.np_)
+
+
+# ---- round 5: affine equality rows eliminated by substitution ------------------------------------------------------------------------
+# A trajectory problem written with the reference's builder carries its dynamics as linear equality rows -- integrate_model_states, fix_configuration,
+# initial_configuration (builder.py:419-469, 511-539): 147 of the 154 equality rows of example/simple_joint_space_planner.py.  The generic family
+# solves by augmented Lagrangian + (L-)BFGS, and the penalty on those rows is what its quasi-Newton iteration crawls on (2600 evaluations).  They
+# are affine in x with constant coefficients, so they can be satisfied identically: Gauss-Jordan on their coefficient matrix picks one pivot variable
+# per row, x_pivot = -N x_free - M c(p), and the tape is re-emitted over the free variables (single shooting, done by the host once per handle).
+# The planner: 280 -> 133 variables, 6281 -> 3363 instructions, 2643 -> 447 evaluations at the same optimum (numpy restatement of the solver).
+_BINARY_OPS = frozenset({OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_ATAN2, OP_FMIN, OP_FMAX, OP_LT, OP_LE, OP_EQ, OP_NE, OP_AND, OP_OR, OP_IFZ})
+
+
+def affine_forms(tape: Tape, regs) -> List[Optional[Dict[int, float]]]:
+    """For each register in `regs`: {variable index: coefficient} if the register is affine in x with coefficients that are numeric constants (they
+    may not depend on p: the elimination is done once per handle), else None.  The constant part (any function of p) is not represented."""
+    deg = tape_degrees(tape)
+    need = np.zeros(len(tape.op), dtype=bool)
+    stack = [int(r) for r in regs if deg[int(r)] <= 1]
+    while stack:
+        r = stack.pop()
+        if need[r]:
+            continue
+        need[r] = True
+        o = int(tape.op[r])
+        if o >= OP_ADD:
+            stack.append(int(tape.a[r]))
+            if o in _BINARY_OPS:
+                stack.append(int(tape.b[r]))
+    form: Dict[int, Optional[Dict[int, float]]] = {}
+    cval: Dict[int, Optional[float]] = {}  # numeric value of registers that are constants (no x, no p)
+    for r in np.flatnonzero(need):
+        r = int(r)
+        o, a, b = int(tape.op[r]), int(tape.a[r]), int(tape.b[r])
+        if o == OP_CONST:
+            form[r], cval[r] = {}, float(tape.c[r])
+        elif o == OP_P:
+            form[r], cval[r] = {}, None
+        elif o == OP_X:
+            form[r], cval[r] = {a: 1.0}, None
+        elif deg[r] == 0:  # a function of parameters / constants only
+            form[r] = {}
+            va, vb = cval.get(a), (cval.get(b) if o in _BINARY_OPS else 0.0)
+            cval[r] = None
+            if va is not None and vb is not None:
+                cval[r] = {OP_ADD: lambda: va + vb, OP_SUB: lambda: va - vb, OP_MUL: lambda: va * vb, OP_NEG: lambda: -va, OP_SQR: lambda: va * va}.get(o, lambda: None)()
+                if o == OP_DIV and vb != 0.0:
+                    cval[r] = va / vb
+        else:  # degree 1
+            cval[r] = None
+            fa, fb = form.get(a), (form.get(b) if o in _BINARY_OPS else None)
+            out: Optional[Dict[int, float]] = None
+            if o in (OP_ADD, OP_SUB) and fa is not None and fb is not None:
+                out = dict(fa)
+                sgn = 1.0 if o == OP_ADD else -1.0
+                for k, v in fb.items():
+                    out[k] = out.get(k, 0.0) + sgn * v
+            elif o == OP_NEG and fa is not None:
+                out = {k: -v for k, v in fa.items()}
+            elif o == OP_MUL and fa is not None and fb is not None:
+                if deg[a] == 0 and cval.get(a) is not None:
+                    out = {k: cval[a] * v for k, v in fb.items()}
+                elif deg[b] == 0 and cval.get(b) is not None:
+                    out = {k: cval[b] * v for k, v in fa.items()}
+            elif o == OP_DIV and fa is not None and deg[b] == 0 and cval.get(b) not in (None, 0.0):
+                out = {k: v / cval[b] for k, v in fa.items()}
+            form[r] = out
+    return [form.get(int(r)) if deg[int(r)] <= 1 else None for r in regs]
+
+
+def reemit(tb: TapeBuilder, tape: Tape, roots, xreg) -> Dict[int, int]:
+    """Copy the sub-graphs of `roots` into the builder with variable k read from register xreg(k); returns {old register: new register}."""
+    need = np.zeros(len(tape.op), dtype=bool)
+    stack = [int(r) for r in roots]
+    while stack:
+        r = stack.pop()
+        if need[r]:
+            continue
+        need[r] = True
+        o = int(tape.op[r])
+        if o >= OP_ADD:
+            stack.append(int(tape.a[r]))
+            if o in _BINARY_OPS:
+                stack.append(int(tape.b[r]))
+    two = {OP_ADD: tb.add, OP_SUB: tb.sub, OP_MUL: tb.mul, OP_DIV: tb.div, OP_ATAN2: tb.atan2, OP_FMIN: tb.fmin, OP_FMAX: tb.fmax, OP_LT: tb.lt, OP_LE: tb.le,
+           OP_EQ: tb.eq, OP_NE: tb.ne, OP_AND: tb.land, OP_OR: tb.lor, OP_IFZ: tb.ifz}
+    one = {OP_NEG: tb.neg, OP_SIN: tb.sin, OP_COS: tb.cos, OP_SQRT: tb.sqrt, OP_SQR: tb.sqr, OP_ASIN: tb.asin, OP_FABS: tb.fabs, OP_NOT: tb.lnot, OP_EXP: tb.exp,
+           OP_LOG: tb.log}
+    new: Dict[int, int] = {}
+    for r in np.flatnonzero(need):
+        r = int(r)
+        o, a, b = int(tape.op[r]), int(tape.a[r]), int(tape.b[r])
+        if o == OP_CONST:
+            new[r] = tb.const(float(tape.c[r]))
+        elif o == OP_X:
+            new[r] = xreg(a)
+        elif o == OP_P:
+            new[r] = tb.p(a)
+        elif o in two:
+            new[r] = two[o](new[a], new[b])
+        else:
+            new[r] = one[o](new[a])
+    return new
+
+
+@dataclass
+class Elimination:
+    """What ties a tape whose affine equality rows have been eliminated to the problem it came from."""
+    tape: Tape            # over the free variables; rows: every inequality row, then the equality rows that stayed
+    free: np.ndarray      # original indices of its variables, in its order
+    pivot: np.ndarray     # original indices of the eliminated variables
+    def_regs: np.ndarray  # registers of the reduced tape holding the eliminated variables (as functions of the free ones and p)
+    rows_out: np.ndarray  # positions, among the original equality rows, of the eliminated rows (pivot[i] was taken from rows_out[i])
+    rows_kept: np.ndarray  # positions of the equality rows that stayed, in the reduced tape's order
+    A_pivot: np.ndarray   # coefficients of the eliminated rows on the eliminated variables [m, m]: A_pivot^T nu = dL/dx_pivot gives their multipliers
+
+
+def eliminate_affine_equalities(tape: Tape, min_rows: int = 1) -> Optional[Elimination]:
+    """None when the tape has fewer than `min_rows` equality rows that are affine in x with constant coefficients."""
+    n_i, n_e = int(tape.n_ineq), int(tape.n_eq)
+    eq_regs = [int(r) for r in tape.out_rows[n_i : n_i + n_e]]
+    forms = affine_forms(tape, eq_regs)
+    cand = [i for i, f in enumerate(forms) if f]  # (an empty form is a row without x: nothing to pivot on)
+    if len(cand) < min_rows:
+        return None
+    nx = int(tape.nx)
+    R = np.zeros((len(cand), nx))
+    for i, ri in enumerate(cand):
+        for k, v in forms[ri].items():
+            R[i, k] = v
+    A = R.copy()
+    M = np.eye(len(cand))
+    pivots: List[int] = []
+    rows_used: List[int] = []
+    taken = np.zeros(nx, dtype=bool)
+    for i in range(len(cand)):
+        row = np.where(taken, 0.0, R[i])
+        big = np.abs(row).max()
+        if not big > 1e-9 * max(1.0, np.abs(A[i]).max()):
+            continue  # the row depends on the rows before it: it stays a row of the problem
+        c = int(np.flatnonzero(np.abs(row) >= 0.5 * big)[-1])  # a well-scaled pivot; among those the last variable (q_{t+1} of an Euler row, not q_t)
+        s = R[i, c]
+        R[i] /= s
+        M[i] /= s
+        for j in range(len(cand)):
+            if j != i and R[j, c] != 0.0:
+                f = R[j, c]
+                R[j] -= f * R[i]
+                M[j] -= f * M[i]
+        taken[c] = True
+        pivots.append(c)
+        rows_used.append(i)
+    if len(pivots) < min_rows:
+        return None
+    free = np.flatnonzero(~taken)
+    if len(free) == 0:
+        return None
+    tb = TapeBuilder()
+    xnew = {int(k): tb.x(j) for j, k in enumerate(free)}
+    zero = tb.const(0.0)
+    # constant parts c_r(p) of the eliminated rows: the rows with every variable at zero
+    sel = [cand[i] for i in rows_used]
+    cmap = reemit(tb, tape, [eq_regs[ri] for ri in sel], lambda k: zero)
+    c_regs = {i: cmap[eq_regs[cand[i]]] for i in rows_used}
+    defs: Dict[int, int] = {}
+    for i, k in zip(rows_used, pivots):
+        terms = [tb.mul(tb.const(-R[i, f]), xnew[int(f)]) for f in free if abs(R[i, f]) > 1e-14]
+        terms += [tb.mul(tb.const(-M[i, j]), c_regs[j]) for j in rows_used if abs(M[i, j]) > 1e-14]
+        acc = zero
+        for t_ in terms:
+            acc = tb.add(acc, t_)
+        defs[k] = acc
+    sel_set = set(sel)
+    kept = [i for i in range(n_e) if i not in sel_set]
+    roots = [int(tape.out_cost)] + [int(r) for r in tape.out_rows[:n_i]] + [eq_regs[i] for i in kept]
+    full = reemit(tb, tape, roots, lambda k: xnew[k] if k in xnew else defs[k])
+    rows = [full[int(r)] for r in tape.out_rows[:n_i]] + [full[eq_regs[i]] for i in kept]
+    # the definitions must survive dead-code removal downstream: they are read back after the solve (oh_tape_probe)
+    red = Tape(np.asarray(tb.op, dtype=np.int32), np.asarray(tb.a, dtype=np.int32), np.asarray(tb.b, dtype=np.int32), np.asarray(tb.c, dtype=np.float64),
+               int(full[int(tape.out_cost)]), np.asarray(rows, dtype=np.int32), n_i, len(kept), len(free), int(tape.np_))
+    if len(red.op) > MAX_TAPE:
+        return None
+    return Elimination(red, free.astype(np.int64), np.asarray(pivots, dtype=np.int64), np.asarray([defs[k] for k in pivots], dtype=np.int32),
+                       np.asarray(sel, dtype=np.int64), np.asarray(kept, dtype=np.int64), A[np.ix_(rows_used, pivots)].copy())

@@ -99,7 +99,7 @@ def test_longer_horizon_whose_registers_do_not_fit_the_lds(hip_lib):
 
     g = np.load(os.path.join(GOLDEN, "planner_golden.npz"))
     T = 60
-    robot, solver = setup_solver(T=T, solver_options={"max_iter": 2000000})
+    robot, solver = setup_solver(T=T, solver_options={"max_iter": 2000000, "eliminate": False})  # (the tape as written: this test is about where its registers live)
     name = robot.get_name()
     P = g["p"][:2]
     solver.reset_parameters_batch({"nominal_joint_state": P[:, :7], "current_joint_state": P[:, 7:14], "position_goal": P[:, 14:17], "orientation_goal": P[:, 17:]})
@@ -113,3 +113,81 @@ def test_longer_horizon_whose_registers_do_not_fit_the_lds(hip_lib):
         x = o.decision_variables.dict2vec(sols[b])
         assert np.abs(o.a(x, P[b])).max() <= 1e-8 and np.abs(o.h(x, P[b])).max() <= 1e-8 and o.g(x, P[b]).min() >= -1e-9
         assert abs(o.f(x, P[b]) - st["f"][b]) <= 1e-9 * max(1.0, abs(st["f"][b])) and st["f"][b] < 3.5 * g["f"][b]
+
+
+def test_affine_equality_rows_are_eliminated_on_the_host():
+    """147 of the planner's 154 equality rows are affine in x with constant coefficients (fix_configuration, integrate_model_states, builder.py:419-469,
+    525-539): tape.py substitutes them away.  The reduced tape reproduces cost and remaining rows of the original at the reconstructed point, the
+    eliminated rows hold to rounding, and the numpy restatement of the GPU's solver needs a fraction of the evaluations on it."""
+    from examples.simple_joint_space_planner import setup_solver
+    from optas_amd.tape import compile_problem, eliminate_affine_equalities
+    from oracle import tape_ref
+
+    _, opt = setup_solver(build_only=True)
+    tp = compile_problem(opt)
+    el = eliminate_affine_equalities(tp)
+    assert el is not None and (tp.nx, tp.n_eq) == (280, 154) and (el.tape.nx, el.tape.n_ineq, el.tape.n_eq, len(el.pivot)) == (133, 40, 7, 147)
+    assert len(el.tape.op) < 0.6 * len(tp.op) and np.linalg.cond(el.A_pivot) < 1e3
+    rng = np.random.default_rng(2)
+    for _ in range(3):
+        y, p = rng.uniform(-1, 1, el.tape.nx), rng.uniform(-1, 1, tp.np_)
+        vr = tape_ref.forward(el.tape, y, p)
+        x = np.zeros(tp.nx)
+        x[el.free], x[el.pivot] = y, vr[el.def_regs]
+        vo = tape_ref.forward(tp, x, p)
+        eq = vo[tp.out_rows[tp.n_ineq :]]
+        assert np.abs(eq[el.rows_out]).max() <= 1e-14 and abs(vo[tp.out_cost] - vr[el.tape.out_cost]) <= 1e-12 * max(1.0, abs(vo[tp.out_cost]))
+        assert np.abs(eq[el.rows_kept] - vr[el.tape.out_rows[el.tape.n_ineq :]]).max() <= 1e-13
+        assert np.abs(vo[tp.out_rows[: tp.n_ineq]] - vr[el.tape.out_rows[: el.tape.n_ineq]]).max() <= 1e-13
+        # multipliers of the eliminated rows from the adjoints of the eliminated variables: A_pivot^T nu = d(f - lam^T g - mu^T h)/dx_pivot reproduces
+        # stationarity of the FULL Lagrangian in the free variables too (a property of the substitution, at any point and any lam, mu)
+        lam, mu = rng.uniform(0, 1, tp.n_ineq), rng.uniform(-1, 1, el.tape.n_eq)
+        seeds = {int(tp.out_cost): 1.0}
+        for r, w in zip(tp.out_rows[: tp.n_ineq], lam):
+            seeds[int(r)] = seeds.get(int(r), 0.0) - w
+        for i, w in zip(el.rows_kept, mu):
+            r = int(tp.out_rows[tp.n_ineq + i])
+            seeds[r] = seeds.get(r, 0.0) - w
+        gfull = tape_ref.reverse(tp, vo, seeds)  # gradient of the partial Lagrangian with respect to all 280 variables
+        nu = np.linalg.solve(el.A_pivot.T, gfull[el.pivot])
+        J = np.stack([tape_ref.reverse(tp, vo, {int(tp.out_rows[tp.n_ineq + i]): 1.0}) for i in el.rows_out])
+        red_seeds = {int(el.tape.out_cost): 1.0}
+        for r, w in zip(el.tape.out_rows, np.concatenate([lam, mu])):
+            red_seeds[int(r)] = red_seeds.get(int(r), 0.0) - w
+        gred = tape_ref.reverse(el.tape, vr, red_seeds)
+        assert np.abs((gfull - J.T @ nu)[el.pivot]).max() <= 1e-10 and np.abs((gfull - J.T @ nu)[el.free] - gred).max() <= 1e-9 * max(1.0, np.abs(gred).max())
+
+
+@pytest.mark.gpu
+def test_elimination_on_the_gpu_same_optimum_fewer_evaluations_and_full_multipliers(hip_lib):
+    """The planner through HIPSolver with and without the elimination: the same optima (goldens), a fraction of the evaluations, every one of the 280
+    variables returned, every one of the 194 rows with its multiplier -- stationarity of the LITERAL Lagrangian (oracle/problems.py) with them."""
+    from examples.simple_joint_space_planner import setup_solver
+
+    g = np.load(os.path.join(GOLDEN, "planner_golden.npz"))
+    nlp = JointSpacePlannerNLP(OracleRobot(MED7_KIN))
+    P, B = g["p"], len(g["p"])
+    res = {}
+    for tag, opts in (("eliminated", {}), ("as_written", {"eliminate": False})):
+        robot, solver = setup_solver(solver_options={"max_iter": 400000, **opts})
+        name = robot.get_name()
+        solver.reset_parameters_batch({"nominal_joint_state": P[:, :7], "current_joint_state": P[:, 7:14], "position_goal": P[:, 14:17], "orientation_goal": P[:, 17:]})
+        solver.reset_initial_seed_batch({f"{name}/q/x": np.stack([np.tile(g["q0"].reshape(-1, 1), (1, 20))] * B)})
+        sols = solver.solve_batch()
+        st = solver.stats()
+        assert st["success"], (tag, st["status"])
+        lam, mu = solver.backend.multipliers(B)
+        res[tag] = (np.stack([solver.opt.decision_variables.dict2vec(s_) for s_ in sols]), st["f"].copy(), st["iterations"].copy(), lam, mu, solver.backend.solve_ms())
+        assert solver.backend.flag("tape_wave") >= 1
+        solver.backend.close()
+    xe, fe, ite, lam, mu, ms_e = res["eliminated"]
+    xw, fw, itw, _, _, ms_w = res["as_written"]
+    assert lam.shape == (B, 40) and mu.shape == (B, 154) and (lam >= 0).all()
+    print("planner: evaluations eliminated", ite.tolist(), "as written", itw.tolist(), "; device ms %.1f against %.1f" % (ms_e, ms_w))
+    assert np.median(ite) <= 0.35 * np.median(itw)
+    for b in range(B):
+        assert abs(fe[b] - g["f"][b]) <= 1e-5 * g["f"][b] and abs(fe[b] - fw[b]) <= 1e-5 * fw[b] and np.abs(xe[b] - xw[b]).max() <= 5e-3
+        x, p = xe[b], P[b]
+        assert abs(nlp.f(x, p) - fe[b]) <= 1e-10 and np.abs(nlp.a(x, p)).max() <= 1e-12 and np.abs(nlp.h(x, p)).max() <= 1e-8 and nlp.g(x, p).min() >= -1e-9
+        r = nlp.df(x, p) - nlp.dg(x, p).T @ lam[b] - nlp.da(x, p).T @ mu[b, : nlp.na] - nlp.dh(x, p).T @ mu[b, nlp.na :]
+        assert np.abs(r).max() <= 1e-5 and np.abs(lam[b] * nlp.g(x, p)).max() <= 1e-6, (b, np.abs(r).max())

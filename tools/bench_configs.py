@@ -334,7 +334,7 @@ def _torque(out, rng, sample, torque_batches):
             loc2 = np.stack([0.2 * np.sin(ts2 * np.pi * 0.5), 0.1 * np.sin(ts2 * np.pi), np.zeros(n_ticks + T)])
             table = np.ascontiguousarray(pose[:, None, :3] + np.einsum("bij,jt->bti", Re, loc2))
             st0 = np.concatenate([qc, np.zeros((B, 7))], 1)
-            be.rollout(st0[:64], table[:64], 2)  # warm-up of the code path
+            be.rollout(st0[:64], np.ascontiguousarray(table[:64, : 2 + T]), 2)  # warm-up of the code path
             states, tau0, fr, itr, stt = be.rollout(st0, table, n_ticks)
             ms = be.timing()["solve_ms"]
             idx = np.sort(np.random.default_rng(55).choice(B, 32, replace=False))

@@ -254,7 +254,8 @@ class EliminatedTapeBackend:
         self.inner = TapeBackend(elim.tape, keep_regs=elim.def_regs, **kw)
         self.tape = tape
         self.jit, self.wave = self.inner.jit, self.inner.wave
-        self._mult = None
+        self._orig = None  # the problem as written, interpreter only: created when multipliers are asked for
+        self._last = None
 
     def solve(self, x0, p):
         el = self.elim
@@ -262,25 +263,33 @@ class EliminatedTapeBackend:
         B = x0.shape[0]
         p = _lib.as_f64(p).reshape(B, -1)
         r = self.inner.solve(np.ascontiguousarray(x0[:, el.free]), p)
-        lam, mu = self.inner.multipliers(B)
-        # L = f - lam^T g - mu^T h over the rows that stayed; its derivative with respect to an eliminated variable is what that variable's row has to
-        # balance: A_pivot^T nu = dL/dx_pivot
-        seeds = np.concatenate([np.ones((B, 1)), -lam, -mu], axis=1)
-        val, adj, _ = self.inner.probe(r.x, p, self.inner.kept_regs, seeds)
+        val, _, _ = self.inner.probe(r.x, p, self.inner.kept_regs)  # the eliminated variables: registers of the reduced tape at the solution
         x = np.empty((B, self.nx))
         x[:, el.free] = r.x
         x[:, el.pivot] = val
-        nu = np.linalg.solve(el.A_pivot.T, adj.T).T
-        n_eq = int(self.full.n_eq)
-        mu_full = np.zeros((B, n_eq))
-        mu_full[:, el.rows_kept] = mu
-        mu_full[:, el.rows_out] = nu
-        self._mult = (lam, mu_full)
+        self._last = (x, p)
         return BatchResult(x, r.f, r.kkt, r.iters, r.status)
 
     def multipliers(self, B: int):
-        assert self._mult is not None and len(self._mult[0]) == B
-        return self._mult
+        """(lam (B, n_ineq), mu (B, n_eq)) in the ORIGINAL row order.  The rows that stayed carry the solver's multipliers; an eliminated row balances
+        what is left of the stationarity condition in its pivot variable: with L' = f - lam^T g - mu_kept^T h, A_pivot^T nu = dL'/dx_pivot -- one
+        reverse sweep of the tape as written at the solution (oh_tape_probe), then one constant triangular-sized solve per instance."""
+        assert self._last is not None and len(self._last[0]) == B
+        el, (x, p) = self.elim, self._last
+        lam, mu = self.inner.multipliers(B)
+        n_eq = int(self.full.n_eq)
+        seeds = np.zeros((B, 1 + int(self.full.n_ineq) + n_eq))
+        seeds[:, 0] = 1.0
+        seeds[:, 1 : 1 + lam.shape[1]] = -lam
+        seeds[:, 1 + lam.shape[1] + el.rows_kept] = -mu
+        if self._orig is None:
+            self._orig = TapeBackend(self.full, jit=False, wave=False)
+        _, _, grad = self._orig.probe(x, p, None, seeds)
+        nu = np.linalg.solve(el.A_pivot.T, grad[:, el.pivot].T).T
+        mu_full = np.zeros((B, n_eq))
+        mu_full[:, el.rows_kept] = mu
+        mu_full[:, el.rows_out] = nu
+        return lam, mu_full
 
     def flag(self, name: str) -> int:
         return self.inner.flag(name)
@@ -308,6 +317,9 @@ class EliminatedTapeBackend:
 
     def close(self) -> None:
         self.inner.close()
+        if self._orig is not None:
+            self._orig.close()
+            self._orig = None
 
 
 def tape_backend(tape, eliminate=True, **kw):

@@ -28,10 +28,19 @@ def timed(be, x0, p, reps=3):
     d_x, d_f, d_k = _lib.DeviceBuffer(x0.nbytes), _lib.DeviceBuffer(8 * B), _lib.DeviceBuffer(24 * B)
     d_i, d_s = _lib.DeviceBuffer(4 * B), _lib.DeviceBuffer(4 * B)
     ms = []
+    host = not hasattr(be, "solve_device")  # (a problem solved over fewer variables than it has: the host entry point puts the eliminated ones back)
     for _ in range(reps + 1):
-        be.solve_device(B, bufs[0], bufs[1], d_x, d_f, d_k, d_i, d_s)
+        if host:
+            rh = be.solve(x0, p)
+        else:
+            be.solve_device(B, bufs[0], bufs[1], d_x, d_f, d_k, d_i, d_s)
         ms.append(be.solve_ms() if hasattr(be, "solve_ms") else be.timing()["solve_ms"])
-    it, st, kk = d_i.download(np.int32, (B,)), d_s.download(np.int32, (B,)), d_k.download(np.float64, (B, 3))
+    if host:
+        it, st, kk = rh.iters, rh.status, rh.kkt
+        d_x.upload(rh.x)
+        d_f.upload(rh.f)
+    else:
+        it, st, kk = d_i.download(np.int32, (B,)), d_s.download(np.int32, (B,)), d_k.download(np.float64, (B, 3))
     for b in bufs + [d_x, d_f, d_k, d_i, d_s]:
         b.free()
     ok = st == 0
@@ -141,10 +150,19 @@ def timed_with_results(be, x0, p, reps=3, sample=0, seed=0):  # (median of three
     d_x, d_f, d_k = _lib.DeviceBuffer(x0.nbytes), _lib.DeviceBuffer(8 * B), _lib.DeviceBuffer(24 * B)
     d_i, d_s = _lib.DeviceBuffer(4 * B), _lib.DeviceBuffer(4 * B)
     ms = []
+    host = not hasattr(be, "solve_device")  # (a problem solved over fewer variables than it has: the host entry point puts the eliminated ones back)
     for _ in range(reps + 1):
-        be.solve_device(B, bufs[0], bufs[1], d_x, d_f, d_k, d_i, d_s)
+        if host:
+            rh = be.solve(x0, p)
+        else:
+            be.solve_device(B, bufs[0], bufs[1], d_x, d_f, d_k, d_i, d_s)
         ms.append(be.solve_ms() if hasattr(be, "solve_ms") else be.timing()["solve_ms"])
-    it, st, kk = d_i.download(np.int32, (B,)), d_s.download(np.int32, (B,)), d_k.download(np.float64, (B, 3))
+    if host:
+        it, st, kk = rh.iters, rh.status, rh.kkt
+        d_x.upload(rh.x)
+        d_f.upload(rh.f)
+    else:
+        it, st, kk = d_i.download(np.int32, (B,)), d_s.download(np.int32, (B,)), d_k.download(np.float64, (B, 3))
     ok = st == 0
     r = {"device_ms": float(np.median(ms[1:])), "converged_frac": float(ok.mean()), "iters_p50": float(np.median(it)), "iters_p90": float(np.percentile(it, 90)),
          "iters_max": int(it.max()), "stationarity_max": float(kk[ok, 0].max()), "feasibility_max": float(kk[ok, 1].max())}
@@ -255,7 +273,7 @@ def _planner_tape(out, sample):
                  "equality_rows_max": float(max(max(np.abs(nlp.a(x, p)).max(), np.abs(nlp.h(x, p)).max()) for x, p in zip(smp["x"], smp["p"]))),
                  "inequality_rows_min": float(min(nlp.g(x, p).min() for x, p in zip(smp["x"], smp["p"]))),
                  "by": "oracle/problems.py:JointSpacePlannerNLP (literal layout: 40 inequality, 147 + 7 equality rows)"}
-    out["planner_tape"] = {"what": "simple_joint_space_planner.py (280 variables) on the generic tape family, one block of wavefronts per instance; B = 256 perturbed problems",
+    out["planner_tape"] = {"what": "simple_joint_space_planner.py (280 variables, 154 equality rows of which the host eliminates the 147 affine ones: 133 variables on the device) on the generic tape family, one block of wavefronts per instance; B = 256 perturbed problems",
                            "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
                            "path": {k: be.flag(k) for k in ("tape_wave", "tape_levels", "tape_passes")},
                            "golden_instances": {"n": nb, "device_ms": ms4, "evaluations": [int(v) for v in r4.iters], "converged": bool((np.asarray(r4.status) == 0).all()),

@@ -634,6 +634,23 @@ void oh_launch_pm_advance(hipStream_t s, int B, int T, int advance, const double
   hipLaunchKernelGGL(k_pm_advance, dim3((B + 63) / 64), dim3(64), 0, s, B, T, advance, x, state_next);
 }
 
+// The plant's state (y_0, dy_0) = (curr, dcurr) is pinned by equality rows, so the box rows and the obstacle row of knot 0 are constants of an instance
+// (the reference writes them for every knot, point_mass_mpc.py:96-123).  A start outside the box or inside the obstacle has no feasible plan: IPOPT reports an
+// infeasible problem (did_solve() False, solver.py:407-412) -- here OH_STATUS_INFEASIBLE, kkt[1] = the violation (round 5; SURVEY C3 rejects such starts).
+__global__ __launch_bounds__(64) void k_pm_infeasible(PmParams P, int B, const double* __restrict__ pin, double* __restrict__ kkt, int* __restrict__ status) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* pb = pin + (size_t)b * (4 + 4 * (size_t)P.T);
+  double c[9], jx, jy;
+  pm_cons(P, pb, pb[4 + 2 * P.T], pb[4 + 2 * P.T + 1], c, jx, jy);
+  double worst = 0.0;
+  for (int i = 0; i < 9; ++i) worst = fmin(worst, c[i]);
+  if (worst < -P.tol) {
+    if (status) status[b] = OH_STATUS_INFEASIBLE;
+    if (kkt) kkt[3 * (size_t)b + 1] = fmax(kkt[3 * (size_t)b + 1], -worst);
+  }
+}
+
 void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, const double* x0, const double* p, double* x, double* f, double* kkt,
                         int* iters, int* status) {
   // a wavefront per instance while that leaves the chip room (the thread kernel issues ~8x fewer instructions per instance, but needs ~10^5
@@ -641,4 +658,5 @@ void oh_launch_pm_solve(hipStream_t s, const PmParams& P, const PmBuffers& D, co
   const int wave_max = oh_launch_opts().pm_wave_max;  // option "pm_wave_max", default 20480  // (tools/gpu_pm_sweep.py: 16 384 plants 6.8 / 5.8 ms thread / wave kernel, 32 768 9.8 / 11.3 ms)
   if (P.T <= 64 && D.B <= wave_max) hipLaunchKernelGGL(k_pm_solve_wave, dim3(D.B), dim3(64), 0, s, P, D.B, x0, p, x, f, kkt, iters, status);
   else hipLaunchKernelGGL(k_pm_solve, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p, x, f, kkt, iters, status);
+  if (status || kkt) hipLaunchKernelGGL(k_pm_infeasible, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D.B, p, kkt, status);
 }

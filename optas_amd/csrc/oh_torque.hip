@@ -2143,7 +2143,20 @@ __global__ __launch_bounds__(64) void k_tq_finalize(TqParams P, TqBuffers D, dou
     kkt[3 * b + 2] = cmpl;
   }
   if (iters) iters[b] = D.iters[b];
-  if (status) status[b] = D.status[b] < 0 ? OH_STATUS_MAX_ITER : D.status[b];
+  int st = D.status[b] < 0 ? OH_STATUS_MAX_ITER : D.status[b];
+  if (P.vel) {
+    // dq_0 = dqc is pinned (fix_configuration on the velocity state), so its velocity-limit rows are constants of the instance: outside them there is no
+    // feasible point -- IPOPT's "infeasible problem" (solver.py:407-412); the interior point above can only sit in the relaxed barrier until its cap
+    const double* x0r = D.xs + xs_off(D, T, cur, b, 0);
+    double worst = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) worst = fmin(worst, fmin(x0r[8 + j] - P.dq_lo[j], P.dq_up[j] - x0r[8 + j]));
+    if (worst < -1e-9) {
+      st = OH_STATUS_INFEASIBLE;
+      if (kkt) kkt[3 * b + 1] = fmax(kkt[3 * b + 1], -worst);
+    }
+  }
+  if (status) status[b] = st;
 }
 
 }  // namespace

@@ -89,7 +89,7 @@ def test_abi_error_codes(hip_lib):
         d.update(kw)
         return _lib.oh_problem_desc(**d)
 
-    for bad in (dict(ndof=5), dict(T=2), dict(T=129), dict(dt=0.0), dict(hessian=7), dict(kind=42)):
+    for bad in (dict(ndof=3), dict(ndof=9), dict(T=2), dict(T=129), dict(dt=0.0), dict(hessian=7), dict(kind=42)):  # (ndof 4 ... 8 with orientation rows since round 5)
         d = desc(**bad)
         assert lib.oh_create(C.byref(d), C.byref(h)) == 1 and lib.oh_last_error()  # OH_ERR_INVALID
     d = desc()

@@ -207,3 +207,25 @@ def test_wavefront_per_plant_kernel_reproduces_the_thread_kernel(hip_lib, monkey
     ref = solve_pointmass_ipm(T, 0.05, nlp.w, 1.5, 1.0, nlp.safe_sq, curr, np.zeros(2), goal, ob, tol=1e-8)
     assert r.status[0] == 0 and ref["iters"] == r.iters[0] and abs(ref["f"] - r.f[0]) <= 1e-8 * max(1.0, abs(ref["f"]))
     be.close()
+
+
+def test_start_inside_the_obstacle_or_outside_the_box_is_reported_infeasible(hip_lib):
+    """(y_0, dy_0) = (curr, dcurr) is pinned, so the rows of knot 0 -- the box rows and ||obs_0 - y_0||^2 - r^2 >= 0, which the reference writes for every
+    knot (point_mass_mpc.py:96-123) -- are constants of an instance; SURVEY C3 rejects such starts.  The reference's IPOPT would report an infeasible problem
+    (did_solve() False, solver.py:407-412): here OH_STATUS_INFEASIBLE for exactly the instances whose literal rows of knot 0 are negative."""
+    from optas_amd import _lib
+    from oracle.problems import point_mass_tick_parameters
+
+    starts = [((-0.45, -0.35), (0.6, 0.6)), ((0.02, 0.01), (0.0, 0.0)), ((1.6, 0.0), (0.0, 0.0)), ((-0.5, 0.4), (0.0, 1.2)), ((0.9, -0.9), (0.2, 0.0))]
+    P = np.stack([point_mass_tick_parameters(curr=c, dcurr=d) for c, d in starts])
+    for mode in ("20480", "0"):  # wavefront-per-plant and thread-per-plant kernels
+        be = PointMassBackend(tol=1e-8).set_options(pm_wave_max=float(mode))
+        r = be.solve(np.zeros((len(P), 80)), P)
+        be.close()
+        for b, p in enumerate(P):
+            # rows of knot 0 (p = [curr; dcurr; goal [t][2]; obs [t][2]]): |y| <= 1.5, |dy| <= 1, ||y - obs_0||^2 >= 0.3^2
+            bad = (abs(p[0]) > 1.5 or abs(p[1]) > 1.5 or abs(p[2]) > 1.0 or abs(p[3]) > 1.0 or (p[0] - p[4 + 40]) ** 2 + (p[1] - p[4 + 41]) ** 2 < 0.09)
+            assert (r.status[b] == _lib.OH_STATUS_INFEASIBLE) == bad, (mode, b, r.status[b])
+            if not bad:
+                assert r.status[b] == 0
+        assert (r.status == _lib.OH_STATUS_INFEASIBLE).sum() == 3

@@ -103,3 +103,27 @@ def test_batch_with_velocity_limits_properties_and_scalar_equivalence(hip_lib):
         assert np.abs(nlp.a(r.x[b], p[b])).max() <= 1e-12 and np.abs(nlp.h(r.x[b], p[b])).max() <= 1e-10 and nlp.k(r.x[b], p[b]).min() > 0.0
         assert abs(nlp.f(r.x[b], p[b]) - r.f[b]) <= 1e-9 * r.f[b]
     be.close()
+
+
+def test_initial_velocity_outside_its_limits_is_reported_infeasible(hip_lib):
+    """dq_0 = dqc is pinned by fix_configuration on the velocity state: its velocity-limit rows are constants of the instance.  Outside them the NLP has no
+    feasible point (the literal rows say so) -- IPOPT would report an infeasible problem (solver.py:407-412); here OH_STATUS_INFEASIBLE, the rest of the batch
+    untouched."""
+    T, B = 12, 6
+    robot = RobotModel.builtin("med7")
+    be = TorqueBackend(robot.kinematic_chain(LINK), robot.dynamics_tables(), T=T, dt=0.1, tau_lo=-58.0, tau_up=58.0, dq_lo=-0.5, dq_up=0.5, max_iter=300, **W)
+    qc = np.tile(QC, (B, 1))
+    dqc = np.zeros((B, 7))
+    dqc[2, 3], dqc[4, 0] = 0.8, -0.51
+    goal = np.stack([figure_eight_goal(robot, LINK, q, T, 0.1).T for q in qc])
+    p = np.concatenate([qc, dqc, goal.reshape(B, -1)], 1)
+    r = be.solve(np.zeros((B, 4 * 7 * T)), p)
+    nlp = TorqueMPCNLP(TorqueProblem(OracleRobot(MED7_KIN), LINK, T=T, dt=0.1, tau_lim=58.0, **W), vlimits=(-0.5, 0.5))
+    for b in range(B):
+        bad = np.abs(dqc[b]).max() > 0.5
+        assert (r.status[b] == _lib.OH_STATUS_INFEASIBLE) == bad, (b, r.status[b])
+        if bad:
+            assert r.kkt[b, 1] >= np.abs(dqc[b]).max() - 0.5 - 1e-12 and not _lib.status_ok(r.status[b])
+        else:
+            assert _lib.status_ok(r.status[b]) and nlp.k(r.x[b], p[b]).min() > 0.0
+    be.close()

@@ -402,7 +402,7 @@ int oh_get_flag(oh_handle* h, const char* name, int* value);
  *                         a 262 144 batch, bit-identical only where the same kernels ran).  Costs 1.2-2.7 x device time.
  *   tail_threshold (16384), tail_vel (1), tail_vel_threshold, compaction (1), compact_frac (0.97), compact_sort (1), compact_carry (1),
  *   sparse_check_below (2048), check_every (1), fuse_couple (1), lg_split (1), row_pad (13)            -- figure-eight family scheduling
- *   free_pcr_max (1536), free_bb (1), free_cp_max (512), free_persist (-1 auto / 0 / 1), free_eval_split_max (512) -- position-tracking family
+ *   free_pcr_max (1536), free_bb (1), free_cp_max (512), free_persist (-1 auto / 0 / 1)                  -- position-tracking family sweeps
  *   specialize (2 = auto, 0 never, 1 at the first call)                                                 -- run-time specialisation (oh_specialize)
  *   hyb_switch (1e-5, x w_path), relax (1.5), relax_from (4), retract_min (1e-13)                        -- algorithm constants (change the iterates)
  *   pm_wave_max (20480), qp_mode (-1), tape_lds_max                                                     -- point-mass / QP / tape launch shapes

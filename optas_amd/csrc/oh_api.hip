@@ -167,7 +167,7 @@ struct OptDoc { const char* name; double dflt; };
 // map-backed options and their defaults (field-backed ones are handled in set_option_impl / oh_get_option)
 static const OptDoc OPT_TABLE[] = {
     {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},
-    {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"free_eval_split_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
+    {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.2},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
     {"tq_rebuild", 0.9},
@@ -258,7 +258,6 @@ static void load_launch_opts(const oh_handle* h) {
   o = OhLaunchOpts{};
   o.free_bb = (int)optv(h, "free_bb", o.free_bb);
   o.free_cp_max = (int)optv(h, "free_cp_max", o.free_cp_max);
-  o.free_eval_split_max = (int)optv(h, "free_eval_split_max", o.free_eval_split_max);
   o.pm_wave_max = (int)optv(h, "pm_wave_max", o.pm_wave_max);
   o.qp_mode = (int)optv(h, "qp_mode", o.qp_mode);
   o.tape_lds_max = (int)optv(h, "tape_lds_max", o.tape_lds_max);

@@ -374,203 +374,6 @@ OH_DEV void eval_guarded_knot(const FigParams& P, const FigBuffers& D, const Gua
   for (int i = 0; i < NP; ++i) SEL(D.Dr, slot)[DRX(t, i)] = W[i];
 }
 
-// The same knot on EIGHT lanes (round 5; launches of a few hundred instances, where the evaluation is one thread's dependent chain: 7 joints of
-// kinematics, then 38 rows one after the other, 35 us at 256 arms).  Every lane of a unit walks the chain (cheap, and nothing has to be exchanged for it);
-// lane s then takes the obstacles s, s + 8, ... of every sphere link, lanes 6 and 7 the limit rows of the joints (0-3 / 4-6), lane 7 the tracking term;
-// g, W, psi and the complementarity measure meet in a three-step butterfly over the eight lanes, and every lane stores its share of the stage record.
-// Same rows, same multiplier updates as eval_guarded_knot; the sums arrive in another order (rounding).
-template <int N>
-OH_DEV void eval_guarded_knot_split(const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const int b, const int t, const int sub) {
-  constexpr int NP = N * (N + 1) / 2;
-  const int Bp = D.Bp;
-  if (b >= D.B) return;
-  const int slot = OH_FREE_SLOT(D, b);
-  if (D.status[b] >= 0 || D.skip[b]) return;
-  const int cur = 1 - slot;
-  const bool first = D.first[b] != 0;
-  double q[N];
-  if (first) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) q[j] = SEL(D.q, slot)[IDX(t, N, j)];
-  } else {
-#pragma unroll
-    for (int j = 0; j < N; ++j) q[j] = SEL(D.q, cur)[IDX(t, N, j)] + D.zstep[IDX(t, N, j)];
-  }
-  const bool upd = GB.outer[b] != 0;
-  const double rho_old = GB.rho[b];
-  const double rho = upd ? GB.rho_next[b] : rho_old;
-  const oh_chain* __restrict__ ch = D.chain;
-  const int NC = GP.NC;
-  const int nl = GP.limits ? 2 * N : 0;
-  // this lane's obstacles (at most two of OH_MAX_OBSTACLES = 16) and the multipliers of its rows, requested before the kinematics walk
-  double ox[2], oy[2], oz[2], orad[2], lms[OH_MAX_SPHERE_LINKS][2];
-  bool have[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int o = sub + 8 * u;
-    have[u] = o < GP.n_obs;
-    const size_t ob = (size_t)(GP.n_links + 4 * (have[u] ? o : 0)) * Bp + b;
-    ox[u] = GB.par[ob]; oy[u] = GB.par[ob + Bp]; oz[u] = GB.par[ob + 2 * (size_t)Bp]; orad[u] = GB.par[ob + 3 * (size_t)Bp];
-#pragma unroll
-    for (int l = 0; l < OH_MAX_SPHERE_LINKS; ++l) lms[l][u] = (have[u] && l < GP.n_links) ? GB.lam[IDX(t, NC, nl + l * GP.n_obs + o)] : 0.0;
-  }
-  double g[N], W[NP], psi = 0.0, meas = 0.0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) g[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < NP; ++i) W[i] = 0.0;
-  double R[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0}, p[3] = {0.0, 0.0, 0.0}, z[N][3], pj[N][3];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    double tv[3];
-    mv3(R, ch->p0[k], tv);
-    p[0] += tv[0]; p[1] += tv[1]; p[2] += tv[2];
-    if (!ch->r0ident[k]) {
-      double Rn[9];
-      mm3(R, ch->R0[k], Rn);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) R[i] = Rn[i];
-    }
-    pj[k][0] = p[0]; pj[k][1] = p[1]; pj[k][2] = p[2];
-    if (ch->jtype[k] == 0) {
-      double sn, cs;
-      sincos_joint(q[k], &sn, &cs);
-      const int code = ch->axcode[k];
-      if (code != 0) rot_principal_right(R, code, sn, cs, z[k]);
-      else rot_axis_right(R, ch->axis[k], sn, cs, z[k]);
-    } else {
-      mv3(R, ch->axis[k], z[k]);
-      p[0] += z[k][0] * q[k]; p[1] += z[k][1] * q[k]; p[2] += z[k][2] * q[k];
-    }
-    for (int l = 0; l < GP.n_links; ++l) {
-      if (GP.link_joint[l] != k) continue;
-      if (!have[0]) continue;  // (lanes beyond the obstacle count have no sphere rows)
-      double c[3];
-      mv3(R, GP.link_off[l], c);
-      c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
-      double Jl[N][3];
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        if (j <= k) {
-          if (ch->jtype[j] == 0) {
-            const double dd[3] = {c[0] - pj[j][0], c[1] - pj[j][1], c[2] - pj[j][2]};
-            cross3(z[j], dd, Jl[j]);
-          } else {
-            Jl[j][0] = z[j][0]; Jl[j][1] = z[j][1]; Jl[j][2] = z[j][2];
-          }
-        } else {
-          Jl[j][0] = Jl[j][1] = Jl[j][2] = 0.0;
-        }
-      }
-      const double rl = GB.par[(size_t)l * Bp + b];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (!have[u]) continue;
-        const double d[3] = {c[0] - ox[u], c[1] - oy[u], c[2] - oz[u]};
-        const double rr = rl + orad[u];
-        const double gval = dot3(d, d) - rr * rr;
-        double dg[N];
-#pragma unroll
-        for (int j = 0; j < N; ++j) dg[j] = 2.0 * dot3(Jl[j], d);
-        double lam = lms[l][u];
-        guard_row<N>(gval, dg, rho, rho_old, upd, &lam, psi, meas, g, W);
-        if (upd) GB.lam[IDX(t, NC, nl + l * GP.n_obs + sub + 8 * u)] = lam;
-      }
-    }
-  }
-  if (GP.limits && sub >= 6) {  // joints 0..3 on lane 6, the rest on lane 7
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      if ((j < 4) != (sub == 6)) continue;
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const double gval = side ? GP.up[j] - q[j] : q[j] - GP.lo[j];
-        double lam = GB.lam[IDX(t, NC, side * N + j)];
-        if (upd) {
-          lam = fmax(0.0, lam - rho_old * gval);
-          GB.lam[IDX(t, NC, side * N + j)] = lam;
-        }
-        const double sv = lam - rho * gval;
-        meas = fmax(meas, fabs(fmin(gval, lam / rho)));
-        if (sv > 0.0) {
-          psi += (sv * sv - lam * lam) / (2.0 * rho);
-          g[j] += side ? sv : -sv;
-          W[tri(j, j)] += rho;
-        } else {
-          psi -= lam * lam / (2.0 * rho);
-        }
-      }
-    }
-  }
-  double track = 0.0;
-  if (sub == 7) {  // tracking terms (as eval_knot_free, Gauss-Newton)
-    double e[3], tv[3];
-    mv3(R, ch->p_tool, tv);
-    e[0] = p[0] + tv[0]; e[1] = p[1] + tv[1]; e[2] = p[2] + tv[2];
-    const double lp[3] = {P.local_path[3 * t], P.local_path[3 * t + 1], P.local_path[3 * t + 2]};
-    double r[3];
-    if (P.path_in_frame) {
-      double Rc[9];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Rc[i] = D.ref[(size_t)(3 + i) * Bp + b];
-      mv3(Rc, lp, r);
-    } else {
-      r[0] = lp[0]; r[1] = lp[1]; r[2] = lp[2];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) r[i] += D.ref[(size_t)i * Bp + b] - e[i];
-    const double w = P.w_path;
-    double Jp[N][3];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      if (ch->jtype[k] == 0) {
-        const double dd[3] = {e[0] - pj[k][0], e[1] - pj[k][1], e[2] - pj[k][2]};
-        cross3(z[k], dd, Jp[k]);
-      } else {
-        Jp[k][0] = z[k][0]; Jp[k][1] = z[k][1]; Jp[k][2] = z[k][2];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      g[i] += -2.0 * w * dot3(Jp[i], r);
-#pragma unroll
-      for (int j = 0; j <= i; ++j) W[tri(i, j)] += 2.0 * w * dot3(Jp[i], Jp[j]);
-    }
-    track = w * dot3(r, r);
-  }
-  // ---- the eight lanes' shares meet (butterfly: every lane ends with the sums) ----
-#pragma unroll
-  for (int m = 1; m <= 4; m <<= 1) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) g[i] += __shfl_xor(g[i], m);
-#pragma unroll
-    for (int i = 0; i < NP; ++i) W[i] += __shfl_xor(W[i], m);
-    psi += __shfl_xor(psi, m);
-    track += __shfl_xor(track, m);
-    meas = fmax(meas, __shfl_xor(meas, m));
-  }
-#pragma unroll
-  for (int j = 0; j < N; ++j)
-    if (j == sub) {
-      SEL(D.q, slot)[IDX(t, N, j)] = q[j];
-      SEL(D.g, slot)[IDX(t, N, j)] = g[j];
-    }
-#pragma unroll
-  for (int i = 0; i < NP; ++i)
-    if ((i & 7) == sub) SEL(D.Dr, slot)[DRX(t, i)] = W[i];
-  if (sub == 7) {
-    SEL(D.phi, slot)[(size_t)t * Bp + b] = track + psi;
-    SEL(GB.psi, slot)[(size_t)t * Bp + b] = psi;
-    SEL(D.cv, slot)[(size_t)t * Bp + b] = meas;
-  }
-  if (sub == 0 && P.zc_free) couple_inline_free<N>(P, D, b, t, slot, first, q, g, track + psi);
-}
-// grid: (instances / 32, knots); a block of 256 threads = 32 units x 8 lanes
-template <int N>
-__global__ __launch_bounds__(256) void k_eval_guarded_split(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot_batch) {
-  eval_guarded_knot_split<N>(P, D, GP, GB, blockIdx.x * 32 + (threadIdx.x >> 3), blockIdx.y + P.t0, threadIdx.x & 7);
-}
-
 template <int N>
 __global__ __launch_bounds__(256) void k_eval_guarded(FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, const int slot_batch) {
   eval_guarded_knot<N>(P, D, GP, GB, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
@@ -1964,15 +1767,8 @@ bool oh_launch_free_persist(hipStream_t s, int n, const FigParams& P, const FigB
   hipLaunchKernelGGL(k_free_persist<7>, dim3(8 * ((D.B + 7) / 8)), dim3(128), sizeof(double) * 2 * (size_t)KH * 72, s, P, D, GP, GB, KH, 2 * P.max_iter + 8);
   return true;
 }
-#define N_SPLIT_OK(GP) ((GP).n_obs <= 16 && (GP).n_links >= 1)
 bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot) {
   const dim3 g((D.B + 255) / 256, P.T - P.t0), b(256);
-  // launches of a few hundred instances are one thread's latency: eight lanes per knot there (7 joints; beyond ~512 instances the eightfold chain walks
-  // fill the SIMDs and the one-thread kernel wins again)
-  if (n == 7 && N_SPLIT_OK(GP) && D.B <= oh_launch_opts().free_eval_split_max) {
-    hipLaunchKernelGGL(k_eval_guarded_split<7>, dim3((D.B + 31) / 32, P.T - P.t0), b, 0, s, P, D, GP, GB, slot);
-    return true;
-  }
 #define C(NN) hipLaunchKernelGGL(k_eval_guarded<NN>, g, b, 0, s, P, D, GP, GB, slot)
   OH_FREE_DISPATCH_N(n, C)
 #undef C

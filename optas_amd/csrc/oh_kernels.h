@@ -35,7 +35,6 @@ bool oh_launch_step_free(hipStream_t s, int n, const FigParams& P, const FigBuff
 struct OhLaunchOpts {
   int free_bb = 1;         // position-tracking family, 7 joints, <= free_pcr_max instances: twisted factorisation (k_step_free_bb); 0: the cyclic-reduction kernels
   int free_cp_max = 512;   // ... cyclic reduction with eight lanes per knot up to this many instances (horizons <= 64 knots)
-  int free_eval_split_max = 512;  // position-tracking family with sphere rows: eight lanes per knot in the evaluation up to this many instances (0: never)
   int pm_wave_max = 20480; // point mass: a wavefront per plant up to this many plants
   int qp_mode = -1;        // dense QP: -1 automatic, 0 / 1 / 2 force a work-set placement
   int tape_lds_max = 1 << 30;  // generated tape evaluators: the solver's work set in LDS up to this many instances (0: never)

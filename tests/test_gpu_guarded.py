@@ -427,36 +427,3 @@ def test_instance_infeasible_as_posed_is_reported(hip_lib):
     strict.reset_initial_seed(seed)
     with pytest.raises(RuntimeError, match="Solver failed!"):
         strict.solve()
-
-
-def test_eight_lane_evaluation_equals_the_one_thread_evaluation(hip_lib, monkeypatch):
-    """Round 5: launches of up to 512 instances evaluate a knot on eight lanes (k_eval_guarded_split: sphere rows dealt over the lanes, limits and tracking on
-    the last two, a butterfly for g / W).  Same rows, same multiplier updates, sums in another order: the same optimum as the one-thread kernel to rounding,
-    the same step counts up to the odd instance whose ratio test sits on an edge."""
-    from optas_amd.backend import MultiArmBackend
-    from optas_amd.lowering import lower
-
-    T, B = 100, 48
-    (kl, kr), o = setup_solver(T=T, build_only=True, limits=True, collision=True)
-    kind, spec = lower(o)
-    rng = np.random.default_rng(SEED + 47)
-    qcl, qcr = draw_feasible_configurations(rng, B, kl, link_radius=0.15), draw_feasible_configurations(rng, B, kr, link_radius=0.15)
-    base = o.parameters.dict2vec({"qcl": QC, "qcr": QC, **obstacle_parameters(link_radius=0.15)})
-    P = np.tile(base, (B, 1))
-    P[:, :7], P[:, 7:14] = qcl, qcr
-    X0 = np.zeros((B, o.nx))
-    xoff = o.decision_variables.offsets()
-    for name, qc in (("kukal/q/x", qcl), ("kukar/q/x", qcr)):
-        X0[:, xoff[name] : xoff[name] + 7 * T] = np.tile(qc, (1, T))
-    out = {}
-    for tag, opt in (("split", {}), ("thread", {"free_eval_split_max": 0})):
-        mb = MultiArmBackend(spec, o, max_iter=400).set_options(opt)
-        out[tag] = (mb.solve(X0, P), [be.multipliers(B) for _, be in mb.arms], mb.solve_ms())
-        mb.close()
-    (rs, ls, ms_s), (rt, lt, ms_t) = out["split"], out["thread"]
-    assert (rs.status == 0).all() and (rt.status == 0).all()
-    assert np.abs(rs.f - rt.f).max() <= 1e-9 * np.abs(rt.f).max() and np.abs(rs.x - rt.x).max() <= 1e-6
-    assert (np.abs(rs.iters - rt.iters) <= 2).mean() >= 0.9
-    for a, b_ in zip(ls, lt):
-        assert np.abs(a - b_).max() <= 1e-5 * max(1.0, np.abs(b_).max())
-    print("config 4, %d dual arms, T = %d: eight-lane evaluation %.2f ms, one-thread evaluation %.2f ms" % (B, T, ms_s, ms_t))

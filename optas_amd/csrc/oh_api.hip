@@ -1215,8 +1215,8 @@ extern "C" int oh_set_guards(oh_handle* h, const oh_guards* g) {
   if (!g->limits && g->n_links == 0 && !g->vel_limits) return fail(OH_ERR_INVALID, "oh_set_guards: no rows");
   // (the orientation-locked kernels that carry inequality rows -- k_eval_lg, k_tail_vel -- are instantiated for 6 and 7 joints only; any
   //  other chain used to launch nothing, finalise the seed and still return OH_OK)
-  if (h->desc.lock_orientation && h->desc.ndof != 6 && h->desc.ndof != 7)
-    return fail(OH_ERR_INVALID, "oh_set_guards: inequality rows on an orientation-locked handle need ndof 6 or 7");
+  if (h->desc.lock_orientation && (h->desc.ndof < 4 || h->desc.ndof > 8))
+    return fail(OH_ERR_INVALID, "oh_set_guards: inequality rows on an orientation-locked handle need 4 ... 8 joints");
   if (g->vel_limits) {
     for (int j = 0; j < h->desc.ndof; ++j)
       if (!(g->dq_lo[j] < g->dq_up[j])) return fail(OH_ERR_INVALID, "oh_set_guards: dq_lo must be below dq_up");

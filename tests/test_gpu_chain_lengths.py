@@ -160,6 +160,40 @@ def test_orientation_locked_family_for_four_five_and_eight_joints(hip_lib, tmp_p
         print(f"figure-eight {tag}: {n} joints (null space {n - 3}), steps tail {out['tail'].iters.tolist()} batched {res.iters.tolist()}")
 
 
+def test_velocity_limited_figure_eight_on_five_and_eight_joints(hip_lib, tmp_path):
+    """Inequality rows on the orientation-locked family for the other chain lengths (k_tail_vel / k_eval_lg instantiated for 4 ... 8 joints): joint-velocity
+    limits that bind, against the numpy port of the state machine, rows checked on the returned trajectory."""
+    rng = np.random.default_rng(SEED + 74)
+    T = 20
+    for tag, kin, link, qn in [r for r in _robots(tmp_path) if r[0] in ("kuka5", "kuka8")]:
+        orc = OracleRobot(kin)
+        n = orc.ndof
+        prob = StructuredFigureEight(orc, link, T=T, Tmax=4.0)
+        prob.local_path = prob.local_path * (0.25 if n < 6 else 1.0)
+        prob.local_path[:, 2] = 0.6 * prob.local_path[:, 0]
+        chain = RobotModel(urdf_filename=kin).kinematic_chain(link)
+        qc = qn + rng.uniform(-0.05, 0.05, (4, n))
+        x0 = np.concatenate([np.tile(qc, (1, T)), np.zeros((4, n * (T - 1)))], 1)
+        free = FigureEightBackend(chain, T, prob.dt, prob.local_path, max_iter=400, tol=1e-6)
+        rf = free.solve(x0, qc)
+        free.close()
+        vmax = 0.6 * np.abs(rf.x[:, n * T :]).max()  # below what the unconstrained plans use: the rows bind
+        g = _lib.oh_guards()
+        g.vel_limits = 1
+        for j in range(n):
+            g.dq_lo[j], g.dq_up[j] = -vmax, vmax
+        be = FigureEightBackend(chain, T, prob.dt, prob.local_path, max_iter=600, tol=1e-6, guards=g)
+        r = be.solve(x0, qc)
+        be.close()
+        assert (r.status == 0).all(), (tag, r.status)
+        dQ = r.x[:, n * T :]
+        assert np.abs(dQ).max() <= vmax + 1e-8 and (np.abs(dQ).max(1) >= vmax - 1e-6).all() and (r.f > rf.f).all()
+        for b in (0, 3):
+            s = solve_structured_lm(prob, qc[b], max_iter=600, tol=1e-6, vlimits=(np.full(n, -vmax), np.full(n, vmax)))
+            assert s["status"] == 0 and abs(s["f"] - r.f[b]) <= 1e-7 * max(1.0, s["f"]), (tag, b, s["f"], r.f[b])
+        print(f"velocity-limited figure-eight {tag}: f free {rf.f.round(4).tolist()} limited {r.f.round(4).tolist()}, steps {r.iters.tolist()}")
+
+
 def test_chain_lengths_outside_the_instantiated_range_are_refused(hip_lib):
     import ctypes as C
 

@@ -322,16 +322,21 @@ class EliminatedTapeBackend:
             self._orig = None
 
 
-def tape_backend(tape, eliminate=True, **kw):
+def tape_backend(tape, eliminate=True, rho0=None, **kw):
     """TapeBackend for a compiled problem; trajectory-sized ones (beyond 48 variables: the limited-memory regime) first lose the equality rows that
-    are affine in x with constant coefficients."""
+    are affine in x with constant coefficients.  rho0 None: the initial penalty of the augmented Lagrangian is 10 for a problem as written and 1000 once
+    its affine rows are gone (what is left are the few nonlinear rows; with 32 limited-memory pairs instead of 12 the planner takes 234-272 evaluations
+    instead of 389-498, 256 instances 18.6 instead of 35.9 ms: tools/gpu_planner_sweep.py)."""
     if eliminate and int(tape.nx) > 48 and int(tape.n_eq) > 0:
         from .tape import eliminate_affine_equalities
 
         el = eliminate_affine_equalities(tape)
         if el is not None and int(el.tape.nx) >= 1:
-            return EliminatedTapeBackend(tape, el, **kw)
-    return TapeBackend(tape, **kw)
+            opts = dict(kw.pop("options", None) or {})
+            if int(el.tape.nx) > 48:
+                opts.setdefault("tape_lbfgs", 32)
+            return EliminatedTapeBackend(tape, el, rho0=1000.0 if rho0 is None else float(rho0), options=opts, **kw)
+    return TapeBackend(tape, rho0=10.0 if rho0 is None else float(rho0), **kw)
 
 
 class QPBackend(_SolveMixin):

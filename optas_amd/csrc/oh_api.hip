@@ -60,6 +60,8 @@ struct oh_handle {
   GuardBuffers GB{};
   void* gpool = nullptr;
   int gcap = 0;
+  void* move_scr = nullptr;  // scratch of the compaction that moves every array (move_everything)
+  size_t move_scr_bytes = 0;
   // tape family
   TapeParams TP{};
   int *d_tape_op = nullptr, *d_tape_a = nullptr, *d_tape_b = nullptr, *d_tape_rows = nullptr;
@@ -170,7 +172,7 @@ static const OptDoc OPT_TABLE[] = {
     {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.2},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
-    {"tq_rebuild", 0.9},
+    {"tq_rebuild", 0.9},         {"compact_move_all", 1},
 };
 static int tape_configure(oh_handle* h);
 static int set_option_impl(oh_handle* h, const std::string& name, double v) {
@@ -1349,6 +1351,40 @@ static void fill_params(oh_handle* h) {
   P.zc_free = (h->fuse_couple && !d.lock_orientation && !(h->have_guards && h->guards.vel_limits)) ? 1 : 0;
 }
 
+// Every array of a running orientation-locked handle with inequality rows to its instance's new index (D.newidx from oh_launch_scan_running): both slots
+// of the stage data, the pending step, multipliers, obstacle parameters, every per-instance scalar and flag.  Nothing restarts.
+static int move_everything(oh_handle* h, hipStream_t s, int Bnew) {
+  const int N = h->desc.ndof, NZ = N - 3, T = h->desc.T, Bp = h->D.Bp, B = h->D.B;
+  FigBuffers& D = h->D;
+  GuardBuffers& GB = h->GB;
+  const GuardParams& GP = h->GP;
+  struct Item { void* p; int rows; bool is_int; };
+  std::vector<Item> items;
+  auto dbl = [&](double* p, int rows) { if (p) items.push_back({p, rows, false}); };
+  auto itg = [&](int* p) { if (p) items.push_back({p, 1, true}); };
+  for (int sl = 0; sl < 2; ++sl) {
+    dbl(D.q[sl], T * N); dbl(D.Z[sl], T * (3 * N - 3)); dbl(D.Dr[sl], T * (NZ * (NZ + 1) / 2)); dbl(D.g[sl], T * N); dbl(D.phi[sl], T); dbl(D.cv[sl], T);
+    dbl(D.Gfull[sl], T * N); dbl(D.mdl[sl], T * (3 + 3 * NZ)); dbl(D.E[sl], T * NZ * NZ); dbl(D.gt[sl], T * NZ); dbl(D.merit[sl], T);
+    dbl(GB.psi[sl], T); dbl(GB.mcv[sl], T);
+  }
+  dbl(D.zstep, T * NZ); dbl(D.Kmat, T * NZ * NZ); dbl(D.kvec, T * NZ); dbl(D.lead, T); dbl(D.ref, 12);
+  for (double* p : {D.fconst, D.f_cur, D.pred, D.mu, D.nun, D.stat, D.feas, D.fpsi, GB.rho, GB.rho_next, GB.omega, GB.meas_prev, GB.meas, GB.ls_gd, GB.ls_q}) dbl(p, 1);
+  dbl(GB.lam, T * GP.NC); dbl(GB.lamv, GP.vel ? T * 2 * N : 0); dbl(GB.par, GP.n_links + 4 * GP.n_obs);
+  for (int* p : {D.cur, D.first, D.skip, D.polish, D.stale, D.status, D.iters, D.orig, GB.outer, GB.n_outer, GB.ls_count}) itg(p);
+  int max_rows = 1;
+  for (const Item& it : items) max_rows = it.rows > max_rows ? it.rows : max_rows;
+  const size_t need = sizeof(double) * (size_t)max_rows * Bp;
+  if (need > h->move_scr_bytes) {
+    if (h->move_scr) hipFree(h->move_scr);
+    h->move_scr = nullptr;
+    h->move_scr_bytes = 0;
+    HIPCHK(hipMalloc(&h->move_scr, need));
+    h->move_scr_bytes = need;
+  }
+  for (const Item& it : items) oh_launch_move_rows(s, it.p, h->move_scr, it.rows, Bp, B, Bnew, D.newidx, it.is_int);
+  return OH_OK;
+}
+
 extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt,
                                void* d_iters, void* d_status) {
   if (!h) return fail(OH_ERR_INVALID, "oh_solve_device: null handle");
@@ -1545,10 +1581,17 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
         oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
         if (guarded) oh_launch_guard_emit(s, h->P, h->D, h->GP, h->GB, NV, 1);
         oh_launch_scan_running(s, h->D, h->compact_sort);
-        oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
-        if (guarded) oh_launch_guard_compact(s, h->P, h->D, h->GP, h->GB, NV, 0, 0);
-        oh_launch_compact(s, N, h->P, h->D, 1, nrun, (it + 1) & 1);
-        if (guarded) oh_launch_guard_compact(s, h->P, h->D, h->GP, h->GB, NV, 1, nrun);
+        if (h->P.lock && guarded && optv(h, "compact_move_all", 1.0) != 0.0) {
+          // orientation-locked handles with inequality rows (horizons beyond the persistent kernel): the instance moves with everything it owns,
+          // nothing restarts -- the same iterates, bit for bit, as without compaction (round 5)
+          const int mrc = move_everything(h, s, nrun);
+          if (mrc) return mrc;
+        } else {
+          oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
+          if (guarded) oh_launch_guard_compact(s, h->P, h->D, h->GP, h->GB, NV, 0, 0);
+          oh_launch_compact(s, N, h->P, h->D, 1, nrun, (it + 1) & 1);
+          if (guarded) oh_launch_guard_compact(s, h->P, h->D, h->GP, h->GB, NV, 1, nrun);
+        }
         h->D.B = nrun;
         ++compactions;
         // the compaction kernels are accounted to neither eval nor step: restart the event pair
@@ -1993,6 +2036,7 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->d_tq_mult) hipFree(h->d_tq_mult);
   if (h->d_ik_mult) hipFree(h->d_ik_mult);
   if (h->gpool) hipFree(h->gpool);
+  if (h->move_scr) hipFree(h->move_scr);
   if (h->d_qp_work) hipFree(h->d_qp_work);
   for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult})
     if (q) hipFree(q);

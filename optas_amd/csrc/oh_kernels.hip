@@ -708,6 +708,39 @@ void oh_launch_scan_running(hipStream_t s, const FigBuffers& D, int sort) {
   hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(SCAN_MAXBLK), 0, s, D, nblk, D.scan_blk);
   hipLaunchKernelGGL(k_scan_assign, dim3(nblk), dim3(SCAN_TPB), 0, s, D, sort, chunk, D.scan_blk);
 }
+// ---- compaction that moves EVERYTHING (round 5; orientation-locked handles with inequality rows, horizons beyond the persistent kernel) ---------------
+// The restart compaction above lays the accepted knots down densely and lets the survivors evaluate them again: cheap, but the stage data of the accepted
+// point is then rebuilt with that point's own multiplier estimates instead of its predecessor's and a pending line search is dropped -- an instance's
+// iterates depended on when its batch was compacted.  Here every array of both slots moves with the instance, one array at a time through a scratch
+// array: the state machine does not notice, and an instance takes the same steps, bit for bit, with and without compaction, alone and in any batch.
+template <class V>
+__global__ __launch_bounds__(256) void k_move_gather(const V* __restrict__ src, V* __restrict__ scr, const int Bp, const int B, const int* __restrict__ newidx) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int nb = newidx[b];
+  if (nb < 0) return;
+  const size_t row = (size_t)blockIdx.y * Bp;
+  scr[row + nb] = src[row + b];
+}
+template <class V>
+__global__ __launch_bounds__(256) void k_move_scatter(V* __restrict__ dst, const V* __restrict__ scr, const int Bp, const int Bnew) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bnew) return;
+  const size_t row = (size_t)blockIdx.y * Bp;
+  dst[row + b] = scr[row + b];
+}
+void oh_launch_move_rows(hipStream_t s, void* arr, void* scr, int rows, int Bp, int B, int Bnew, const int* newidx, bool is_int) {
+  if (!arr || rows <= 0) return;
+  const dim3 gg((B + 255) / 256, rows), gs((Bnew + 255) / 256, rows), blk(256);
+  if (is_int) {
+    hipLaunchKernelGGL(k_move_gather<int>, gg, blk, 0, s, (const int*)arr, (int*)scr, Bp, B, newidx);
+    hipLaunchKernelGGL(k_move_scatter<int>, gs, blk, 0, s, (int*)arr, (const int*)scr, Bp, Bnew);
+  } else {
+    hipLaunchKernelGGL(k_move_gather<double>, gg, blk, 0, s, (const double*)arr, (double*)scr, Bp, B, newidx);
+    hipLaunchKernelGGL(k_move_scatter<double>, gs, blk, 0, s, (double*)arr, (const double*)scr, Bp, Bnew);
+  }
+}
+
 bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot) {
 #define C(NN) launch_compact_t<NN>(s, P, D, phase, Bnew, slot)
   OH_DISPATCH_N_ANY(n, C)

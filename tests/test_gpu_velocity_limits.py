@@ -185,29 +185,36 @@ def test_batches_beyond_the_plain_hand_over_start_in_the_persistent_kernel(hip_l
         assert a.status[0] == 0 and a.iters[0] == r.iters[b] and a.f[0] == r.f[b] and np.array_equal(a.x[0], r.x[b])
 
 
-def test_horizon_beyond_the_persistent_kernel_restart_compaction_keeps_the_accepted_point(hip_lib, monkeypatch):
-    """T = 100 (beyond the persistent kernels' 64 knots): the batch drains through restart compactions.  Round 4: a restart evaluates the accepted
-    knots as they are (round 3 retracted them again, to the floor tolerance, which moved them by ~1e-10: of these 20 000 instances number 10 961 sat at
-    the iteration cap inside the batch and converged in 133 steps alone).  Pinned here: with and without compaction every instance converges, and all
-    but a handful per 10 000 end at the same optimum (1e-9 relative).  NOT yet pinned, because not yet true: bit-identical iterates (a restart
-    rebuilds the stage data of the accepted point with the multiplier estimates of that point instead of its predecessor's, and drops a pending
-    line search); tools/gpu_batch_invariance.py counts 19 996 of 20 000 at the same optimum, 2 at another, 2 897 bit-identical."""
+def test_horizon_beyond_the_persistent_kernel_compaction_moves_every_array_and_changes_nothing(hip_lib, monkeypatch):
+    """T = 100 (beyond the persistent kernels' 64 knots): the batch drains through compactions.  Rounds 3 and 4 restarted the survivors at their
+    accepted knots (round 3 retracted them again, which moved them by ~1e-10: of these 20 000 instances number 10 961 sat at the iteration cap
+    inside the batch and converged in 133 steps alone; round 4 evaluated them as they were: same optimum for 19 996 of 20 000, bit-identical
+    iterates for 2 897, because a restart rebuilds the stage data of the accepted point with that point's own multiplier estimates and drops a
+    pending line search).  Round 5: an orientation-locked handle with inequality rows moves EVERY array of both slots with the instance
+    (move_everything in oh_api.hip), nothing restarts -- pinned here: with and without compaction, and alone, every instance takes the same steps
+    to the same bits.  The old restart compaction stays reachable (option compact_move_all = 0) and keeps its round-4 pin."""
     T, B = 100, 8192
     QC0 = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
     rng = np.random.default_rng(T * 7 + 20000)
     qcs = (QC0[None] + rng.uniform(-0.1, 0.1, (20000, 7)))[10961 - B + 1:10961 + 1]  # the cap hitter of round 3 is the last of these
     x0 = np.repeat(qcs, T, axis=0).reshape(B, 7 * T)
     out = {}
-    for mode in ("1", "0"):
-        oh_debug(monkeypatch, compaction=mode)
+    for mode in ("move", "none", "restart"):
+        oh_debug(monkeypatch, compaction="0" if mode == "none" else "1", compact_move_all="0" if mode == "restart" else "1")
         kuka, solver = setup_solver(T=T, Tmax=10.0 * (T - 1) / 49.0, velocity_limits=True, solver_options={"max_iter": 600, "tol": 1e-6})
         X0 = np.zeros((B, solver.opt.nx))
         X0[:, : 7 * T] = x0
         r = solver.solve_batch_arrays(X0, qcs)
-        out[mode] = (np.array(r.status), np.array(r.f), solver.backend.timing()["compactions"])
+        out[mode] = (np.array(r.status), np.array(r.f), solver.backend.timing()["compactions"], np.array(r.iters), np.array(r.x))
+        if mode == "move":
+            for b in (0, 4321, B - 1):
+                a = solver.solve_batch_arrays(X0[b : b + 1], qcs[b : b + 1])
+                assert a.status[0] == 0 and a.iters[0] == r.iters[b] and a.f[0] == r.f[b] and np.array_equal(a.x[0], r.x[b])
         solver.backend.close()
-    assert out["1"][2] >= 5 and out["0"][2] == 0
-    assert (out["1"][0] == 0).all() and (out["0"][0] == 0).all()
-    rel = np.abs(out["1"][1] - out["0"][1]) / np.maximum(1.0, np.abs(out["0"][1]))
+    assert out["move"][2] >= 5 and out["restart"][2] >= 5 and out["none"][2] == 0
+    for mode in out:
+        assert (out[mode][0] == 0).all(), mode
+    assert np.array_equal(out["move"][3], out["none"][3]) and np.array_equal(out["move"][1], out["none"][1]) and np.array_equal(out["move"][4], out["none"][4])
+    rel = np.abs(out["restart"][1] - out["none"][1]) / np.maximum(1.0, np.abs(out["none"][1]))
     assert rel[-1] <= 1e-9  # instance 10 961
     assert (rel <= 1e-9).mean() >= 0.999

@@ -171,8 +171,8 @@ static const OptDoc OPT_TABLE[] = {
     {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},
     {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
-    {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.2},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
-    {"tq_rebuild", 0.9},         {"compact_move_all", 1},
+    {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.4},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
+    {"tq_rebuild", 0.9},         {"compact_move_all", 1},  {"tq_curv_late", 1.0},  {"tq_kappa_eps", 10.0}, {"tq_max_back", 3},     {"tq_mu_dec", 1.0 / 3.0},     {"tq_ls_curv", 1},
 };
 static int tape_configure(oh_handle* h);
 static int set_option_impl(oh_handle* h, const std::string& name, double v) {
@@ -818,15 +818,20 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   P.T = T; P.N = N; P.max_iter = h->tq.max_iter;
   P.dt = h->tq.dt; P.w_path = h->tq.w_path; P.w_vel = h->tq.w_vel; P.w_tau = h->tq.w_tau;
   P.tol = h->tq.tol; P.tol_compl = h->tq.tol_compl; P.mu_b0 = mu_b0_warm > 0.0 ? mu_b0_warm : h->tq.mu_barrier0; P.mu0 = h->tq.mu0;
-  // interior point: relaxed barrier below theta mu_b; monotone barrier update of Waechter & Biegler (2006, eq. 7) -- IPOPT's constants except theta_mu (1.35 for 1.5: the hardest of 8192 instances needs 127 steps instead of 198); exact
+  // interior point: relaxed barrier below theta mu_b; monotone barrier update of Waechter & Biegler (2006, eq. 7) -- IPOPT's constants except theta_mu (1.35 for 1.5: the hardest of 8192 instances needs 127 steps instead of 198) and, round 5, kappa_mu (0.4 for 0.2: tools/gpu_tq_param_sweep.py); exact
   // curvature of the Lagrangian once the reduced gradient is below curv_from (oracle/torque_ipm.py:solve_torque_ipm has the same defaults)
-  P.theta = 0.01; P.kappa_eps = 10.0; P.kappa_mu = 0.2; P.theta_mu = 1.35; P.curv_from = 0.1; P.curv_late = 1.0; P.curv_after = 3; P.tau_ftb = 0.995; P.max_back = 3; P.stall_max = 25;
+  P.theta = 0.01; P.kappa_eps = 10.0; P.kappa_mu = 0.4; P.theta_mu = 1.35; P.curv_from = 0.1; P.curv_late = 1.0; P.curv_after = 3; P.tau_ftb = 0.995; P.max_back = 3; P.stall_max = 25;
   P.stall_max = (int)optv(h, "tq_stall", P.stall_max);  // options (oh_set_option)
   P.curv_after = (int)optv(h, "tq_curv_after", P.curv_after);
   P.tau_ftb = optv(h, "tq_ftb", P.tau_ftb);
   P.theta_mu = optv(h, "tq_theta_mu", P.theta_mu);
   P.kappa_mu = optv(h, "tq_kappa_mu", P.kappa_mu);
   P.curv_from = optv(h, "tq_curv_from", P.curv_from);  // 0: Gauss-Newton blocks throughout (A/B)
+  P.curv_late = optv(h, "tq_curv_late", P.curv_late);
+  P.kappa_eps = optv(h, "tq_kappa_eps", P.kappa_eps);
+  P.mu_dec = optv(h, "tq_mu_dec", 1.0 / 3.0);
+  P.ls_curv = (int)optv(h, "tq_ls_curv", 1);
+  P.max_back = (int)optv(h, "tq_max_back", P.max_back);
   P.vel = h->tq.vel_limits ? 1 : 0;
   // d tau / dz in closed form needs the tables to describe a rigid-body chain: unit joint axes that the joint-origin rotation leaves in place (then
   // the angular velocity the reference adds, iRp @ axis, is the axis its rotation turns about; models.py:1821-1823).  Otherwise: dual numbers.

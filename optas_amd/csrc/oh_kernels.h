@@ -96,6 +96,7 @@ struct TqParams {
   int T, N, max_iter;
   double dt, w_path, w_vel, w_tau, tol, tol_compl, mu_b0, mu0;
   double theta;      // rows below delta = theta mu_b continue the logarithm by its second-order Taylor polynomial (relaxed barrier)
+  double mu_dec;                        // factor on the Levenberg-Marquardt damping after a step whose gain ratio exceeded 0.9 (option tq_mu_dec)
   double kappa_eps, kappa_mu, theta_mu;  // barrier update (Waechter & Biegler 2006, eq. 7): mu_b <- max(mu_min, min(kappa_mu mu_b, mu_b^theta_mu)) once stat <= kappa_eps mu_b
   double curv_from;  // exact Lagrangian curvature in the stage blocks once the reduced gradient is below this ...
   double curv_late;  // ... or below this after curv_after barrier updates (a Gauss-Newton iteration that stalls just above curv_from late in the solve)
@@ -103,6 +104,7 @@ struct TqParams {
   int stall_max;     // watchdog: this many steps at one barrier parameter without reaching its test send the instance back to 100 mu_b
   double tau_ftb;    // fraction to the boundary: a step leaves every slack (and multiplier) at least 1 - tau_ftb of itself
   int max_back;      // quarterings of a boundary-shortened step before the damping is raised instead
+  int ls_curv;       // 1: a rejected Newton step (exact curvature) is quartered like a boundary-shortened one before the damping is raised (option tq_ls_curv)
   double tau_lo[OH_MAX_CHAIN], tau_up[OH_MAX_CHAIN];
   double dq_lo[OH_MAX_CHAIN], dq_up[OH_MAX_CHAIN];  // joint-velocity rows on the velocity states (vel != 0)
   int vel;

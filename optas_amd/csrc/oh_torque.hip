@@ -1770,12 +1770,15 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
     accept = ratio > 1e-4 || (pred <= 1e-15 * fabs(f_cur) && f_t <= f_cur + 1e-14 * fabs(f_cur));
     if (accept) {
       const double w = 2.0 * ratio - 1.0;
-      mu *= ratio > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - w * w * w);
+      mu *= ratio > 0.9 ? P.mu_dec : fmax(1.0 / 3.0, 1.0 - w * w * w);
       if (mu < 1e-7) mu = 0.0;
       nun = 4.0;
-    } else if (alpha < 1.0 && n_back < P.max_back) {
+    } else if ((alpha < 1.0 || (P.ls_curv && D.curv[b] != 0)) && n_back < P.max_back) {
       // a step the boundary rule had shortened already: the rows near their bounds are to blame (the logarithm is far from its quadratic model
-      // there), not the model of the states -- a quarter of the feed-forward, same gains, same damping
+      // there), not the model of the states -- a quarter of the feed-forward, same gains, same damping.  Round 5: likewise a full Newton step
+      // (exact curvature) that was rejected -- measured on stragglers (tools/gpu_tq_param_sweep.py, HISTORY): the full step gives up more barrier
+      // than it gains (a slack drops to a third), 0.3 of it follows the model to 8 %, and the damping, which acts on the states, does not shorten a
+      // step that lives in the accelerations: five rejections and six careful steps afterwards, or one quartering
       new_gains = false;
       alpha *= 0.25;
       n_back += 1;

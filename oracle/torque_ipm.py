@@ -82,8 +82,8 @@ def rollout_step(Ks, ks, alpha, dt):
     return dz
 
 
-def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, tol=1e-6, tol_c=1e-8, mu0=0.1, theta=0.01, kappa_eps=10.0, kappa_mu=0.2,
-                     theta_mu=1.35, curv_from=0.1, vlimits=None, verbose=False, kappa_sig=1e10, tau_ftb=0.995, max_back=3, curv_after=3, curv_late=1.0, stall_max=25):
+def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, tol=1e-6, tol_c=1e-8, mu0=0.1, theta=0.01, kappa_eps=10.0, kappa_mu=0.4,
+                     theta_mu=1.35, curv_from=0.1, vlimits=None, verbose=False, kappa_sig=1e10, tau_ftb=0.995, max_back=3, curv_after=3, curv_late=1.0, stall_max=25, mu_dec=1.0 / 3.0, ls_curv=True):
     """One instance.  Returns dict(U, Q, dQ, tau, f, iters, rejected, stat, status, mu_b, lam (T, rows), s (T, rows))."""
     T, n, dt = prob.T, prob.n, prob.dt
     wp, wt, wv = prob.w_path, prob.w_tau, prob.w_vel
@@ -158,12 +158,14 @@ def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, 
             ratio = (f_cur - f_t) / max(pred, 1e-300)
             accept = bool(ratio > 1e-4 or (pred <= 1e-15 * abs(f_cur) and f_t <= f_cur + 1e-14 * abs(f_cur)))
             if accept:
-                mu *= 0.1 if ratio > 0.9 else max(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3)
+                mu *= mu_dec if ratio > 0.9 else max(1.0 / 3.0, 1.0 - (2.0 * ratio - 1.0) ** 3)
                 mu = 0.0 if mu < 1e-7 else mu
                 nun = 4.0
-            elif alpha < 1.0 and n_back < max_back:
+            elif (alpha < 1.0 or (ls_curv and use_curv)) and n_back < max_back:
                 # a step the boundary rule had shortened already: the rows near their bounds are to blame (the logarithm is far from its quadratic
-                # model there), not the model of the states -- shorten the feed-forward further, same gains, same damping
+                # model there), not the model of the states -- shorten the feed-forward further, same gains, same damping.  Round 5 (ls_curv): a rejected
+                # full Newton step (trial evaluated with exact curvature) is treated the same way -- it gives up more barrier than it gains, a third of
+                # it follows the model, and the damping (on the states) does not shorten a step that lives in the accelerations
                 new_gains = False
                 alpha *= 0.25
                 n_back += 1

@@ -1,5 +1,5 @@
 """Hunt for slow instances of the torque family's interior point: several batches of 8192 perturbed initial configurations (config 5), the
-iteration histogram of each and the initial configurations of everything above 100 iterations -> gpurun_out/tq_stragglers.npz"""
+iteration histogram of each and the initial configurations of everything above 100 (argv[2]) iterations -> gpurun_out/tq_stragglers.npz"""
 import os
 import sys
 
@@ -17,6 +17,7 @@ ts = np.arange(T) * dt
 loc = np.stack([0.2 * np.sin(ts * np.pi * 0.5), 0.1 * np.sin(ts * np.pi), np.zeros(T)])
 be = TorqueBackend(med7.kinematic_chain(link), med7.dynamics_tables(), T=T, dt=dt, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=-58.0, tau_up=58.0, max_iter=600)
 slow_qc, slow_it = [], []
+CUT = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     rng = np.random.default_rng(1000 + seed)
     qc = qn + rng.uniform(-0.1, 0.1, (B, 7))
@@ -32,7 +33,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     r = be.solve(x0, p)
     it = np.asarray(r.iters)
     print(seed, "ms", round(be.timing()["solve_ms"], 1), "conv", float((np.asarray(r.status) == 0).mean()), "p50", np.median(it), "p99", np.percentile(it, 99), "p99.9", np.percentile(it, 99.9),
-          "max", it.max(), "n>100", int((it > 100).sum()), flush=True)
-    for b in np.flatnonzero(it > 100):
+          "max", it.max(), "n>100", int((it > 100).sum()), "n>34/40/50/60/80", [int((it > k).sum()) for k in (34, 40, 50, 60, 80)], "launched", be.timing()["iterations_launched"], flush=True)
+    for b in np.flatnonzero(it > CUT):
         slow_qc.append(qc[b]); slow_it.append(it[b])
 np.savez(os.path.join(ROOT, "gpurun_out", "tq_stragglers.npz"), qc=np.array(slow_qc), iters=np.array(slow_it))

@@ -172,7 +172,7 @@ static const OptDoc OPT_TABLE[] = {
     {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.4},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
-    {"tq_rebuild", 0.9},         {"compact_move_all", 1},  {"tq_curv_late", 1.0},  {"tq_kappa_eps", 10.0}, {"tq_max_back", 3},     {"tq_mu_dec", 1.0 / 3.0},     {"tq_ls_curv", 1},
+    {"tq_rebuild", 0.9},         {"compact_move_all", 1},  {"tq_curv_late", 1.0},  {"tq_kappa_eps", 10.0}, {"tq_max_back", 3},     {"tq_mu_dec", 1.0 / 3.0},     {"tq_ls_curv", 1},   {"tq_mu_dec_warm", 0.1},
 };
 static int tape_configure(oh_handle* h);
 static int set_option_impl(oh_handle* h, const std::string& name, double v) {
@@ -829,7 +829,8 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   P.curv_from = optv(h, "tq_curv_from", P.curv_from);  // 0: Gauss-Newton blocks throughout (A/B)
   P.curv_late = optv(h, "tq_curv_late", P.curv_late);
   P.kappa_eps = optv(h, "tq_kappa_eps", P.kappa_eps);
-  P.mu_dec = optv(h, "tq_mu_dec", 1.0 / 3.0);
+  // (a warm-started tick of oh_tq_rollout starts next to its optimum: there the damping comes down faster)
+  P.mu_dec = mu_b0_warm > 0.0 ? optv(h, "tq_mu_dec_warm", 0.1) : optv(h, "tq_mu_dec", 1.0 / 3.0);
   P.ls_curv = (int)optv(h, "tq_ls_curv", 1);
   P.max_back = (int)optv(h, "tq_max_back", P.max_back);
   P.vel = h->tq.vel_limits ? 1 : 0;

@@ -89,6 +89,7 @@ def test_batch_of_plants_warm_ticks_reach_the_cold_optimum_in_a_fraction_of_the_
     # (a) the same loop from the host for 64 of the plants: seed shifted in numpy, warm ticks on a handle whose initial barrier parameter is mu_warm
     idx = np.sort(rng.choice(B, 64, replace=False))
     warm = _backend(robot, mu_barrier0=mu_warm)
+    warm.set_option("tq_mu_dec", 0.1)  # what oh_tq_rollout gives its warm ticks (tq_mu_dec_warm): next to the optimum the damping comes down faster
     st = state0[idx].copy()
     x_prev = None
     worst = np.zeros(3)

@@ -408,7 +408,7 @@ int oh_get_flag(oh_handle* h, const char* name, int* value);
  *   pm_wave_max (20480), qp_mode (-1), tape_lds_max                                                     -- point-mass / QP / tape launch shapes
  *   tape_wave (1), tape_lbfgs (-1 = by size), tape_wave_nt (256), tape_wave_regs (-1), tape_wave_hist (-1) -- tape evaluator (rebuilt when set)
  *   tq_check (4), tq_rebuild (0.9), tq_stall (25), tq_curv_after (3), tq_curv_from (0.1), tq_ftb (0.995), tq_theta_mu (1.35), tq_kappa_mu (0.4),
- *   tq_kappa_eps (10), tq_curv_late (1), tq_max_back (3), tq_mu_dec (1/3; warm ticks of oh_tq_rollout: tq_mu_dec_warm, 0.1), tq_ls_curv (1),
+ *   tq_kappa_eps (10), tq_curv_late (1), tq_max_back (3), tq_mu_dec (1/3; warm ticks of oh_tq_rollout: tq_mu_dec_warm, 0.1), tq_ls_curv (1), tq_curv_lag (3: the exact-curvature term is computed at every 4th evaluation of an instance and reused in between; 0: always),
  *   tq_jac_dual (0)                                                                                     -- torque-MPC family
  * The one environment hook left: OH_DEBUG_OPTIONS="name=value,name=value" is applied to every handle when it is created (A/B tooling).
  */

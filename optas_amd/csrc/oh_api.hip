@@ -94,6 +94,7 @@ struct oh_handle {
   TqBuffers TqD{};
   void* tq_pool = nullptr;
   double* d_tq_mult = nullptr;
+  double* d_tq_hc = nullptr;  // [tq_cap][T][TQ_HC] stored curvature terms (k_tq_curv)
   int tq_cap = 0;
   int tq_check = 4;  // the host looks at the running count every tq_check iterations
   // solver buffers
@@ -172,7 +173,7 @@ static const OptDoc OPT_TABLE[] = {
     {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.4},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
-    {"tq_rebuild", 0.9},         {"compact_move_all", 1},  {"tq_curv_late", 1.0},  {"tq_kappa_eps", 10.0}, {"tq_max_back", 3},     {"tq_mu_dec", 1.0 / 3.0},     {"tq_ls_curv", 1},   {"tq_mu_dec_warm", 0.1},
+    {"tq_rebuild", 0.9},         {"compact_move_all", 1},  {"tq_curv_late", 1.0},  {"tq_kappa_eps", 10.0}, {"tq_max_back", 3},     {"tq_mu_dec", 1.0 / 3.0},     {"tq_ls_curv", 1},   {"tq_mu_dec_warm", 0.1}, {"tq_curv_lag", 3},
 };
 static int tape_configure(oh_handle* h);
 static int set_option_impl(oh_handle* h, const std::string& name, double v) {
@@ -832,6 +833,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   // (a warm-started tick of oh_tq_rollout starts next to its optimum: there the damping comes down faster)
   P.mu_dec = mu_b0_warm > 0.0 ? optv(h, "tq_mu_dec_warm", 0.1) : optv(h, "tq_mu_dec", 1.0 / 3.0);
   P.ls_curv = (int)optv(h, "tq_ls_curv", 1);
+  P.curv_lag = (int)optv(h, "tq_curv_lag", 3);
   P.max_back = (int)optv(h, "tq_max_back", P.max_back);
   P.vel = h->tq.vel_limits ? 1 : 0;
   // d tau / dz in closed form needs the tables to describe a rigid-body chain: unit joint axes that the joint-origin rotation leaves in place (then
@@ -858,14 +860,18 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->tq_pool) hipFree(h->tq_pool);
     if (h->d_tq_mult) hipFree(h->d_tq_mult);
+    if (h->d_tq_hc) hipFree(h->d_tq_hc);
+    h->d_tq_hc = nullptr;
     h->tq_pool = nullptr;
     h->d_tq_mult = nullptr;
     h->tq_cap = 0;
     const size_t BT = (size_t)B * T;
     const size_t nd = 2 * BT * TQ_XS + 2 * BT * TQ_SD + 2 * BT * TQ_LAM + BT * TQ_GN + BT * 4 + 11 * (size_t)B;
-    const size_t bytes = nd * sizeof(double) + (11 * (size_t)B + 16) * sizeof(int);
+    const size_t bytes = nd * sizeof(double) + (12 * (size_t)B + 16) * sizeof(int);
     HIPCHK(hipMalloc(&h->tq_pool, bytes));
     HIPCHK(hipMalloc((void**)&h->d_tq_mult, sizeof(double) * BT * 4 * N));  // effort rows, and room for the velocity rows
+    HIPCHK(hipMalloc((void**)&h->d_tq_hc, sizeof(double) * BT * TQ_HC));
+    HIPCHK(hipMemsetAsync(h->d_tq_hc, 0, sizeof(double) * BT * TQ_HC, h->stream));  // entries the adjoint never writes stay zero
     h->tq_cap = B;
   }
   {
@@ -881,6 +887,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     D.lam = take(2 * BT * TQ_LAM);
     D.gains = take(BT * TQ_GN);
     D.goal = take(BT * 4);
+    D.hc = h->d_tq_hc;
     D.f_cur = take(B); D.f_true = take(B); D.bsum = take(B); D.mu = take(B); D.nun = take(B); D.mub = take(B); D.stat = take(B);
     D.alpha = take(B); D.qk = take(B); D.ndx = take(B); D.viol = take(B);
     int* ip = (int*)d;
@@ -889,6 +896,7 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
     D.nrel = ip; ip += B;
     D.n_back = ip; ip += B;
     D.stall = ip; ip += B;
+    D.curv_age = ip; ip += B;
     D.list = ip; ip += B;
     D.n_running = ip;
     D.n_list = ip + 1;
@@ -2040,6 +2048,7 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->pool) hipFree(h->pool);
   if (h->tq_pool) hipFree(h->tq_pool);
   if (h->d_tq_mult) hipFree(h->d_tq_mult);
+  if (h->d_tq_hc) hipFree(h->d_tq_hc);
   if (h->d_ik_mult) hipFree(h->d_ik_mult);
   if (h->gpool) hipFree(h->gpool);
   if (h->move_scr) hipFree(h->move_scr);

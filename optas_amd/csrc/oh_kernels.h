@@ -91,6 +91,7 @@ void oh_launch_pm_advance(hipStream_t s, int B, int T, int advance, const double
 #define TQ_SD_GB 272
 #define TQ_SD_J 296
 #define TQ_LAM 32   // per knot: multipliers of tau - lo >= 0 (N), then of up - tau >= 0 (N); at 16: of dq - dq_lo >= 0 (N), then of dq_up - dq >= 0 (N)
+#define TQ_HC 232   // per knot: the packed lower triangle of the 3N x 3N curvature term (231 entries at N = 7)
 #define TQ_GN 128   // per knot: two doubles per lane of k_tq_step (lane 8 r + c: K_q[r][c], K_dq[r][c]; c = 7: k[r], 0)
 struct TqParams {
   int T, N, max_iter;
@@ -104,6 +105,7 @@ struct TqParams {
   int stall_max;     // watchdog: this many steps at one barrier parameter without reaching its test send the instance back to 100 mu_b
   double tau_ftb;    // fraction to the boundary: a step leaves every slack (and multiplier) at least 1 - tau_ftb of itself
   int max_back;      // quarterings of a boundary-shortened step before the damping is raised instead
+  int curv_lag;      // exact curvature is evaluated afresh at most every (curv_lag + 1)-th evaluation of an instance, the stored term added in between (option tq_curv_lag; 0: always afresh)
   int ls_curv;       // 1: a rejected Newton step (exact curvature) is quartered like a boundary-shortened one before the damping is raised (option tq_ls_curv)
   double tau_lo[OH_MAX_CHAIN], tau_up[OH_MAX_CHAIN];
   double dq_lo[OH_MAX_CHAIN], dq_up[OH_MAX_CHAIN];  // joint-velocity rows on the velocity states (vel != 0)
@@ -120,9 +122,11 @@ struct TqBuffers {
   double* lam;     // [2][B][T][TQ_LAM]  (slot = the point they were updated at: a rejected trial leaves the accepted point's multipliers alone)
   double* gains;   // [B][T][TQ_GN]
   double* goal;    // [B][T][4]
+  double* hc;      // [cap][T][TQ_HC]  the curvature term k_tq_curv last computed for a knot (entries it never writes stay 0)
   // [B]: merit and cost of the accepted point, its barrier sum, Levenberg-Marquardt damping and its growth factor, barrier parameter, reduced gradient,
   // scale of the feed-forward of the pending trial, q_u^T k and |dx|^2 of the unit step (predicted decrease of a scaled step), violation
   double *f_cur, *f_true, *bsum, *mu, *nun, *mub, *stat, *alpha, *qk, *ndx, *viol;
+  int* curv_age;   // [B] evaluations since the stored curvature term was computed (-1: none stored)
   int *cur, *first, *curv, *status, *iters, *rejected, *n_barrier, *nrel, *n_back, *stall;  // [B]
   int* n_running;  // [1]
   int* list;       // [B] instances still running when the list was last rebuilt (kernels walk this list: finished instances cost nothing)

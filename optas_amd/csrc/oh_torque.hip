@@ -1303,6 +1303,7 @@ __global__ __launch_bounds__(64) void k_tq_setup(TqParams P, TqBuffers D, const 
   D.cur[b] = 1;  // the seed sits in slot 0 = the first "trial"
   D.first[b] = 1;
   D.curv[b] = 0;
+  D.curv_age[b] = -1;
   D.status[b] = -1;
   D.iters[b] = 0;
   D.rejected[b] = 0;
@@ -1552,6 +1553,9 @@ __global__ __launch_bounds__(64, IDS ? 2 : 1) void k_tq_eval3(TqParams P, TqBuff
   g1 += 2.0 * P.w_vel * dqj;
   h1 += cbv;
   double* sr = D.st + st_off(D, T, ts, b, t);
+  // exact curvature, stored term (D.curv = 2: k_tq_curv computed it at an earlier evaluation of this instance and skips this one): added as the block is written
+  const double* hc = D.hc + ((size_t)b * T + t) * TQ_HC;
+  const bool add_hc = D.curv[b] == 2;
   if (active) {
 #pragma unroll
     for (int c3 = 0; c3 < 3; ++c3) {
@@ -1573,6 +1577,7 @@ __global__ __launch_bounds__(64, IDS ? 2 : 1) void k_tq_eval3(TqParams P, TqBuff
           hv += 2.0 * P.w_vel;
           hv += dvj;
         }
+        if (add_hc) hv += hc[rr * (rr + 1) / 2 + d];
         sr[rr * (rr + 1) / 2 + d] = hv;
       }
 #pragma unroll
@@ -1600,6 +1605,9 @@ __global__ __launch_bounds__(64, IDS ? 2 : 1) void k_tq_eval3(TqParams P, TqBuff
 //   + 2 w_p sum_k r_k d^2 p_k / dq^2,  d^2 p / dq_a dq_b = z_b x (z_a x (e - o_a)) for b <= a
 // to the stage block k_tq_eval3 has just written.  One lane per (instance, knot, joint) again: lane j runs the hand-written adjoint of the recursion on
 // (DualR, Dual2) scalars seeded with q_j and dq_j, which yields rows q_j and dq_j of the first term; every packed entry is owned by exactly one lane.
+// Round 5: the term goes to a record of its own (D.hc) and is added to the stage block from there, and an instance computes it afresh only at every
+// (curv_lag + 1)-th evaluation (D.curv: 1 compute here, 2 k_tq_eval3 adds the stored term as it writes the block and this kernel skips the instance).  Near the solution the term moves little between steps: with a lag of 3 the
+// port takes 24.70 instead of 24.64 steps on 256 instances and computes the term 3.2 times per solve instead of 11.3 (oracle/torque_ipm.py, HISTORY).
 #ifndef OH_TQ_CURV_WAVES
 #define OH_TQ_CURV_WAVES 1
 #endif
@@ -1621,12 +1629,16 @@ __global__ __launch_bounds__(64, OH_TQ_CURV_WAVES) void k_tq_curv(TqParams P, Tq
   if (unit >= n_units) unit = n_units - 1;
   const int li = (int)(unit / T), t = (int)(unit - (long long)li * T);
   const int b = D.list[li];
-  if (D.status[b] >= 0 || D.curv[b] == 0) active = false;
+  if (D.status[b] >= 0 || D.curv[b] != 1) active = false;  // (2: k_tq_eval3 has added the stored term already)
   if (!__any(active)) return;
   const int ts = 1 - D.cur[b];
   const double* xr = D.xs + xs_off(D, T, ts, b, t);
   double* sr = D.st + st_off(D, T, ts, b, t);
+  double* hc = D.hc + ((size_t)b * T + t) * TQ_HC;
   const double* lm = D.lam + (((size_t)ts * D.B + b) * T + t) * TQ_LAM;
+  const bool comp = active;
+  const bool direct = P.curv_lag <= 0;
+  {
   if (lane_ok) {
     zs_l[ul][j] = xr[j];
     zs_l[ul][8 + j] = xr[8 + j];
@@ -1659,24 +1671,41 @@ __global__ __launch_bounds__(64, OH_TQ_CURV_WAVES) void k_tq_curv(TqParams P, Tq
         }
       }
   }
-  if (active) {
+  if (comp) {
 #pragma unroll
     for (int k = 0; k < N; ++k)
-      if (k <= j && D.chain->jtype[k] == 0) {  // rows q_j, columns up to the diagonal
-        double x[3];
-        cross3(z[k], inner, x);
-        sr[j * (j + 1) / 2 + k] += 2.0 * P.w_path * dot3(r, x);
+      if (k <= j) {  // rows q_j, columns up to the diagonal (this lane's entries: the store initialises them, the adjoint below adds to them)
+        double x[3] = {0.0, 0.0, 0.0};
+        if (D.chain->jtype[k] == 0) cross3(z[k], inner, x);
+        const double v = 2.0 * P.w_path * dot3(r, x);
+        if (direct) sr[j * (j + 1) / 2 + k] += v;
+        else hc[j * (j + 1) / 2 + k] = v;
       }
   }
   rnea_ctau_grad_inv<N + 1, Dual2, DualR>(D.dyn, zs_l[ul], j, [&](const int k, const Dual2 gq, const Dual2 gqd, const Dual2 gqdd) {
-    if (!active) return;
-    if (k <= j) {  // rows q_j and dq_j, columns up to the diagonal
-      sr[j * (j + 1) / 2 + k] += gq.d0;
-      sr[(N + j) * (N + j + 1) / 2 + N + k] += gqd.d1;
+    if (!comp) return;
+    if (direct) {  // curv_lag = 0: nothing is kept, the term goes straight onto the stage block
+      if (k <= j) {
+        sr[j * (j + 1) / 2 + k] += gq.d0;
+        sr[(N + j) * (N + j + 1) / 2 + N + k] += gqd.d1;
+      }
+      sr[(N + j) * (N + j + 1) / 2 + k] += gq.d1;
+      sr[(2 * N + k) * (2 * N + k + 1) / 2 + j] += gqdd.d0;
+      return;
     }
-    sr[(N + j) * (N + j + 1) / 2 + k] += gq.d1;             // (dq_j, q_k)
-    sr[(2 * N + k) * (2 * N + k + 1) / 2 + j] += gqdd.d0;   // (ddq_k, q_j)
+    if (k <= j) {  // rows q_j and dq_j, columns up to the diagonal
+      hc[j * (j + 1) / 2 + k] += gq.d0;
+      hc[(N + j) * (N + j + 1) / 2 + N + k] = gqd.d1;
+    }
+    hc[(N + j) * (N + j + 1) / 2 + k] = gq.d1;             // (dq_j, q_k)
+    hc[(2 * N + k) * (2 * N + k + 1) / 2 + j] = gqdd.d0;   // (ddq_k, q_j)
   });
+  }
+  __syncthreads();  // (one wavefront per block: orders the stores above before the loads below)
+  // the stored term onto the stage block: the unit's N lanes share its (3N)(3N + 1) / 2 entries (those the adjoint never writes are zero)
+  if (active && !direct) {
+    for (int i = j; i < (3 * N) * (3 * N + 1) / 2; i += N) sr[i] += hc[i];
+  }
 }
 
 // ---- step ------------------------------------------------------------------------------------------------------------------------------
@@ -1843,7 +1872,7 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
   // 3. convergence, barrier update
   int status = -1;
   bool do_gains = false, do_roll = false;
-  int curv = D.curv[b];
+  int curv = D.curv[b] != 0;  // the pending trial was evaluated with exact curvature (1 computed, 2 the stored term: k_tq_curv)
   if (!isfinite(f_cur)) {
     status = OH_STATUS_NUMERICAL;
   } else if (stat <= P.tol && mub <= P.tol_compl && nrel == 0) {
@@ -2073,7 +2102,16 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
   if (lane == 0) {
     D.cur[b] = cur;
     D.first[b] = 0;
-    D.curv[b] = curv;
+    {  // next evaluation: the curvature term afresh, or the stored one while it is younger than curv_lag evaluations
+      int age = D.curv_age[b], mode = 0;
+      if (!accept && D.curv[b] == 1) age = -1;  // a term computed at a point that was refused (possibly outside the domain of the arithmetic) is not kept
+      if (curv) {
+        if (age >= 0 && age < P.curv_lag) { mode = 2; age += 1; }
+        else { mode = 1; age = 0; }
+      } else age = -1;
+      D.curv[b] = mode;
+      D.curv_age[b] = age;
+    }
     D.f_cur[b] = f_cur;
     D.f_true[b] = f_true;
     D.bsum[b] = bsum;

@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(64, IDS ? 2 : 1) void k_tq_eval3(TqParams P, TqBuff
 //   + 2 w_p sum_k r_k d^2 p_k / dq^2,  d^2 p / dq_a dq_b = z_b x (z_a x (e - o_a)) for b <= a
 // to the stage block k_tq_eval3 has just written.  One lane per (instance, knot, joint) again: lane j runs the hand-written adjoint of the recursion on
 // (DualR, Dual2) scalars seeded with q_j and dq_j, which yields rows q_j and dq_j of the first term; every packed entry is owned by exactly one lane.
-// Round 5: the term goes to a record of its own (D.hc) and is added to the stage block from there, and an instance computes it afresh only at every
+// Round 5: the term also goes to a record of its own (D.hc), and an instance computes it afresh only at every
 // (curv_lag + 1)-th evaluation (D.curv: 1 compute here, 2 k_tq_eval3 adds the stored term as it writes the block and this kernel skips the instance).  Near the solution the term moves little between steps: with a lag of 3 the
 // port takes 24.70 instead of 24.64 steps on 256 instances and computes the term 3.2 times per solve instead of 11.3 (oracle/torque_ipm.py, HISTORY).
 #ifndef OH_TQ_CURV_WAVES
@@ -1678,21 +1678,21 @@ __global__ __launch_bounds__(64, OH_TQ_CURV_WAVES) void k_tq_curv(TqParams P, Tq
         double x[3] = {0.0, 0.0, 0.0};
         if (D.chain->jtype[k] == 0) cross3(z[k], inner, x);
         const double v = 2.0 * P.w_path * dot3(r, x);
-        if (direct) sr[j * (j + 1) / 2 + k] += v;
-        else hc[j * (j + 1) / 2 + k] = v;
+        sr[j * (j + 1) / 2 + k] += v;
+        if (!direct) hc[j * (j + 1) / 2 + k] = v;
       }
   }
   rnea_ctau_grad_inv<N + 1, Dual2, DualR>(D.dyn, zs_l[ul], j, [&](const int k, const Dual2 gq, const Dual2 gqd, const Dual2 gqdd) {
     if (!comp) return;
-    if (direct) {  // curv_lag = 0: nothing is kept, the term goes straight onto the stage block
-      if (k <= j) {
-        sr[j * (j + 1) / 2 + k] += gq.d0;
-        sr[(N + j) * (N + j + 1) / 2 + N + k] += gqd.d1;
-      }
-      sr[(N + j) * (N + j + 1) / 2 + k] += gq.d1;
-      sr[(2 * N + k) * (2 * N + k + 1) / 2 + j] += gqdd.d0;
-      return;
+    // onto the stage block ...
+    if (k <= j) {
+      sr[j * (j + 1) / 2 + k] += gq.d0;
+      sr[(N + j) * (N + j + 1) / 2 + N + k] += gqd.d1;
     }
+    sr[(N + j) * (N + j + 1) / 2 + k] += gq.d1;
+    sr[(2 * N + k) * (2 * N + k + 1) / 2 + j] += gqdd.d0;
+    if (direct) return;  // curv_lag = 0: nothing is kept
+    // ... and into the record the next evaluations of this instance add instead (k_tq_eval3)
     if (k <= j) {  // rows q_j and dq_j, columns up to the diagonal
       hc[j * (j + 1) / 2 + k] += gq.d0;
       hc[(N + j) * (N + j + 1) / 2 + N + k] = gqd.d1;
@@ -1700,11 +1700,6 @@ __global__ __launch_bounds__(64, OH_TQ_CURV_WAVES) void k_tq_curv(TqParams P, Tq
     hc[(N + j) * (N + j + 1) / 2 + k] = gq.d1;             // (dq_j, q_k)
     hc[(2 * N + k) * (2 * N + k + 1) / 2 + j] = gqdd.d0;   // (ddq_k, q_j)
   });
-  }
-  __syncthreads();  // (one wavefront per block: orders the stores above before the loads below)
-  // the stored term onto the stage block: the unit's N lanes share its (3N)(3N + 1) / 2 entries (those the adjoint never writes are zero)
-  if (active && !direct) {
-    for (int i = j; i < (3 * N) * (3 * N + 1) / 2; i += N) sr[i] += hc[i];
   }
 }
 

@@ -303,6 +303,41 @@ def test_batch_of_8192_properties_determinism_and_scalar_equivalence(hip_lib, ct
     be.close()
 
 
+def test_stored_curvature_term_leaves_the_optima_alone(hip_lib, ctx):
+    """Round 5 (tq_curv_lag, default 3): the exact-curvature term of a knot is computed at every fourth evaluation of an instance and the stored one
+    added in between (k_tq_eval3 / k_tq_curv; numpy: oracle/torque_ipm.py:solve_torque_ipm(curv_lag=)).  The term only shapes the quadratic model:
+    pinned here -- with the lag and without it 2048 instances end at the same optima (objective 1e-9 relative, the same status), in the same number
+    of steps to within a few, and the port with the same lag takes the GPU's steps."""
+    med7, robot, g = ctx
+    T, B = 30, 2048
+    prob = TorqueProblem(med7, LINK, T=T, dt=0.1, tau_lim=58.0, **W)
+    nlp = TorqueMPCNLP(prob)
+    rng = np.random.default_rng(SEED + 17)
+    qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0])[None] + rng.uniform(-0.1, 0.1, (B, 7))
+    goal = np.stack([prob.goal_figure_eight(q) for q in qc])
+    p = np.concatenate([qc, np.zeros((B, 7)), goal.reshape(B, -1)], 1)
+    x0 = np.zeros((B, nlp.nx))
+    x0[:, : 7 * T] = np.tile(qc, (1, T))
+    out = {}
+    for lag in (3, 0, 8):
+        be = backend(robot, T, 58.0, max_iter=600)
+        be.set_option("tq_curv_lag", lag)
+        assert be.get_option("tq_curv_lag") == lag
+        r = be.solve(x0, p)
+        out[lag] = (np.array(r.status), np.array(r.f), np.array(r.iters), np.array(r.kkt))
+        be.close()
+    for lag in (3, 8):
+        assert _lib.status_ok(out[lag][0]).all() and _lib.status_ok(out[0][0]).all()
+        rel = np.abs(out[lag][1] - out[0][1]) / np.abs(out[0][1])
+        assert (rel <= 1e-9).mean() >= 0.999 and np.median(rel) <= 1e-12, (lag, rel.max())  # (an instance in a thousand may end in another KKT point)
+        assert out[lag][3][:, 0].max() <= 1e-6 and out[lag][3][:, 2].max() <= 1e-8
+        assert abs(out[lag][2].mean() - out[0][2].mean()) <= 0.5 and np.median(out[lag][2]) <= np.median(out[0][2]) + 1
+    for b in (0, 5):
+        for lag in (3, 0):
+            ref = solve_torque_ipm(prob, qc[b], np.zeros(7), goal[b], curv_lag=lag)
+            assert abs(ref["f"] - out[lag][1][b]) <= 1e-9 * ref["f"] and abs(ref["iters"] - out[lag][2][b]) <= 2, (b, lag, ref["iters"], out[lag][2][b])
+
+
 def test_abi_errors(hip_lib, ctx):
     med7, robot, g = ctx
     lib = hip_lib

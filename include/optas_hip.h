@@ -404,7 +404,7 @@ int oh_get_flag(oh_handle* h, const char* name, int* value);
  *   sparse_check_below (2048), check_every (1), fuse_couple (1), lg_split (1), row_pad (13)            -- figure-eight family scheduling
  *   free_pcr_max (1536), free_bb (1), free_cp_max (512), free_persist (-1 auto / 0 / 1)                  -- position-tracking family sweeps
  *   specialize (2 = auto, 0 never, 1 at the first call)                                                 -- run-time specialisation (oh_specialize)
- *   hyb_switch (1e-5, x w_path), relax (1.5), relax_from (4), retract_min (1e-13)                        -- algorithm constants (change the iterates)
+ *   hyb_switch (1e-5, x w_path), relax (1.5), relax_from (4), retract_min (1e-13), settle_k (1)          -- algorithm constants (change the iterates)
  *   pm_wave_max (20480), qp_mode (-1), tape_lds_max                                                     -- point-mass / QP / tape launch shapes
  *   tape_wave (1), tape_lbfgs (-1 = by size), tape_wave_nt (256), tape_wave_regs (-1), tape_wave_hist (-1) -- tape evaluator (rebuilt when set)
  *   tq_check (4), tq_rebuild (0.9), tq_stall (25), tq_curv_after (3), tq_curv_from (0.1), tq_ftb (0.995), tq_theta_mu (1.35), tq_kappa_mu (0.4),

@@ -274,10 +274,7 @@ OH_DEV void eval_knot(const oh_chain* __restrict__ ch, const FigParams& P, const
         dq1 += fabs(acc);
       }
     }
-#ifndef OH_SETTLE_K
-#define OH_SETTLE_K 1.0
-#endif
-    settled = OH_SETTLE_K * dq1 * dq1 <= tol_r;
+    settled = P.settle_k * dq1 * dq1 <= tol_r;
     if (MODE == EVAL_RETRACT_ONLY && settled) break;
     }
   }

@@ -169,7 +169,7 @@ static double optv(const oh_handle* h, const char* name, double dflt) {
 struct OptDoc { const char* name; double dflt; };
 // map-backed options and their defaults (field-backed ones are handled in set_option_impl / oh_get_option)
 static const OptDoc OPT_TABLE[] = {
-    {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},         {"settle_k", 1.0},
+    {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},         {"settle_k", 1.0},   {"al_fuse", 1},
     {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.4},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
@@ -1358,6 +1358,7 @@ static void fill_params(oh_handle* h) {
   P.relax = optv(h, "relax", P.relax);
   P.relax_from = (int)optv(h, "relax_from", P.relax_from);
   P.settle_k = optv(h, "settle_k", 1.0);
+  P.al_fuse = (int)optv(h, "al_fuse", 1.0);
   P.local_path = h->d_local_path;
   P.np = d.ndof + (h->have_guards ? h->guards.n_links + 4 * h->guards.n_obstacles : 0);
   if (h->chain_host.has_lead) P.np = d.ndof + 1 + d.T;

@@ -776,13 +776,16 @@ OH_DEV bool step_instance_free(const FigParams& P, const FigBuffers& D, const Gu
   if (!factored) stat = __builtin_nan("");  // no damping (up to 4^40) made the matrix factorisable: free_decide reports NUMERICAL
   {
     const int r = free_decide<N, GUARD>(P, D, GB, b, stat, mu, iters);
-    if (r == 1) {
+    // multiplier update (r == 1).  Until round 5 the instance stayed put for that launch (zero step); now it also takes the step the sweep has just
+    // solved for -- small, the inner iteration has converged to omega -- and the evaluation that refreshes the multipliers looks at that point and
+    // accepts it as it is (free_accept): 7 of an arm's ~27 launches were updates without a step (port, 64 arms: 26.6 -> 24.8 steps, slowest 48 -> 44)
+    if (r == 1 && !P.al_fuse) {
       for (int t = P.t0; t < T; ++t) {
 #pragma unroll
         for (int a = 0; a < N; ++a) D.zstep[IDX(t, N, a)] = 0.0;
       }
     }
-    if (r >= 0) return r != 0;
+    if (r == 0 || (r == 1 && !P.al_fuse)) return r != 0;
   }
   {
     double zz[N];
@@ -1081,7 +1084,7 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
   __syncthreads();
   const int dec = ctl[0];
   if (dec == 0) return;
-  if (dec == 1) {  // outer iteration: no step
+  if (dec == 1 && !P.al_fuse) {  // outer iteration without a step (al_fuse = 0; see step_instance_free)
     if (active) {
 #pragma unroll
       for (int a = 0; a < N; ++a) D.zstep[IDX(t, N, a)] = 0.0;
@@ -1107,7 +1110,7 @@ __global__ __launch_bounds__(NT) void k_step_free_pcr(FigParams P, FigBuffers D,
       GB.ls_q[b] = gd + mu * z2;
     }
     D.mu[b] = mu;
-    D.iters[b] += 1;
+    if (dec != 1) D.iters[b] += 1;  // (a multiplier update was counted by free_decide)
     atomicAdd(D.n_running, 1);
   }
 }
@@ -1237,7 +1240,7 @@ OH_DEV void step_free_bb_block(const FigParams& P, const FigBuffers& D, const Gu
   {
     const int dec = ctl[0];
     if (dec == 0) return;
-    if (dec == 1) {  // outer iteration: no step
+    if (dec == 1 && !P.al_fuse) {  // outer iteration without a step (al_fuse = 0; see step_instance_free)
       if (lane < nK) {
         const int t = P.t0 + lane;
 #pragma unroll
@@ -1247,6 +1250,7 @@ OH_DEV void step_free_bb_block(const FigParams& P, const FigBuffers& D, const Gu
       return;
     }
   }
+  const bool upd = ctl[0] == 1;  // multiplier update with the step taken along: free_decide has counted the launch already
   // ---- the solve ----
   const int wv = lane >> 6, l = lane & 63, r = l >> 3, c = l & 7;
   const bool mat = r < N && c < N, vec = r < N && c == N;
@@ -1403,7 +1407,7 @@ OH_DEV void step_free_bb_block(const FigParams& P, const FigBuffers& D, const Gu
       GB.ls_q[b] = gd + mu * z2;
     }
     D.mu[b] = mu;
-    D.iters[b] += 1;
+    if (!upd) D.iters[b] += 1;  // (a multiplier update was counted by free_decide)
     atomicAdd(D.n_running, 1);
   }
 }
@@ -1667,7 +1671,7 @@ __global__ __launch_bounds__(8 * KN) void k_step_free_cp(FigParams P, FigBuffers
   __syncthreads();
   const int dec = ctl[0];
   if (dec == 0) return;
-  if (dec == 1) {  // outer iteration: no step
+  if (dec == 1 && !P.al_fuse) {  // outer iteration without a step (al_fuse = 0; see step_instance_free)
     if (active && row) D.zstep[IDX(t, N, c)] = 0.0;
     if (tid == 0) atomicAdd(D.n_running, 1);
     return;
@@ -1687,7 +1691,7 @@ __global__ __launch_bounds__(8 * KN) void k_step_free_cp(FigParams P, FigBuffers
       GB.ls_q[b] = gd + mu * z2;
     }
     D.mu[b] = mu;
-    D.iters[b] += 1;
+    if (dec != 1) D.iters[b] += 1;  // (a multiplier update was counted by free_decide)
     atomicAdd(D.n_running, 1);
   }
 }
@@ -1827,6 +1831,14 @@ __global__ __launch_bounds__(256) void k_guard_gather(FigParams P, FigBuffers D,
   const int NR = GP.NC + NV;
   for (int i = 0; i < GP.NC; ++i) GB.scr[((size_t)t * NR + i) * Bp + nb] = GB.lam[((size_t)t * GP.NC + i) * Bp + b];
   for (int i = 0; i < NV; ++i) GB.scr[((size_t)t * NR + GP.NC + i) * Bp + nb] = GB.lamv[((size_t)t * NV + i) * Bp + b];
+  if (!P.lock && P.al_fuse && GB.outer[b] && t >= P.t0) {
+    // position-tracking family, multiplier update pending with its step taken along (al_fuse): the point the next evaluation refreshes the multipliers
+    // at -- and accepts as it is -- is the accepted knot plus that step; the restart lays THAT down (k_compact_gather, launched before this kernel, has
+    // put the accepted knots into the scratch rows of D.Z[1])
+    const int N = P.nx / (2 * P.T - 1);
+    double* tq = D.Z[1];
+    for (int j = 0; j < N; ++j) tq[((size_t)t * N + j) * Bp + nb] += D.zstep[((size_t)t * N + j) * Bp + b];
+  }
   if (t == 0) {
     double* sc = GB.scr + (size_t)P.T * NR * Bp;
     const int npar = GP.n_links + 4 * GP.n_obs;

@@ -25,6 +25,7 @@ struct FigParams {
   double mu0;
   double relax;      // over-relaxation of Gauss-Newton steps in the crawl phase of OH_HESSIAN_HYBRID (1: off), see step_instance
   int relax_from;    // ... from this step count on
+  int al_fuse;       // position-tracking family with inequality rows: the launch that decides on a multiplier update also takes the pending step (1; 0: stays put)
   double settle_k;   // the retraction skips the kinematics pass that would only confirm a Newton step dq when settle_k ||dq||_1^2 <= tolerance (1: the rigorous bound)
   const double* local_path;  // device, [T][3]
   int np;            // row stride of the parameter matrix p (ndof, or ndof + guard parameters)

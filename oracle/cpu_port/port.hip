@@ -114,6 +114,7 @@ extern "C" int oh_port_solve(const oh_problem_desc* desc, const oh_chain* chain,
   P.relax = 1.5;  // the library's defaults (oh_api.hip:fill_params)
   P.relax_from = 4;
   P.settle_k = 1.0;
+  P.al_fuse = 1;
   P.local_path = desc->local_path;
   P.np = desc->ndof;
   if (threads < 1) threads = 1;

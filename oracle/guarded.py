@@ -89,7 +89,7 @@ def guard_values(chain: FoldedChain, Q, G: Guards, weights=None):
 
 
 def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=None, w_path=1.0, w_vel=0.01, fix_dq0=False, max_iter=400,
-                  tol=1e-6, tol_feas=1e-9, rho0=1e3, verbose=False, exact=True, vlimits=None):
+                  tol=1e-6, tol_feas=1e-9, rho0=1e3, verbose=False, exact=True, vlimits=None, fuse=True):
     """vlimits = (vlo, vup): joint-velocity rows dq_t - vlo >= 0, vup - dq_t >= 0 on dq_t = (q_{t+1} - q_t) / dt, t = 0 .. T-2
     (enforce_model_limits(name, time_deriv=1), builder.py:471-509; round 3: k_couple_free_vel in csrc/oh_free.hip).  Same treatment as in
     oracle/structured.py: penalty rho * vscale, the value of interval (t-1, t) is booked on knot t, its gradient enters both knots, its
@@ -234,12 +234,17 @@ def solve_free_al(chain: FoldedChain, T, dt, offsets, qc, guards: Guards, Q0=Non
                 break
             if iters >= max_iter:
                 break
-            # outer update: stay at the current point, refresh multipliers, tighten the inner tolerance
+            # outer update: refresh multipliers at the next evaluation, tighten the inner tolerance (fuse: the pending step is taken along)
             rho_next = min(rho * 10.0, 1e8) if meas > 0.25 * meas_prev else rho
             meas_prev = meas
             omega = max(tol, min(omega, AL_OMEGA * meas))
             outer = True
             Qt = cur["Q"]
+            if fuse:
+                # round 5 (al_fuse, csrc/oh_free.hip:step_instance_free): the launch that decides on the update also takes the step the sweep has just
+                # solved for; the evaluation that refreshes the multipliers looks at that point and accepts it as it is
+                Qt = cur["Q"].copy()
+                Qt[F] += z
             iters += 1
             continue
         if iters >= max_iter:

@@ -332,6 +332,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only; before the GPU phase so that the device work sits at the end of the run
         cpu = cpu_baseline(args.cpu_sample, args.hessian)
 
+    streams_used = int(be.get_option("streams")) if B >= int(be.get_option("split_min")) else 1
     be.set_profiling(False)
     for _ in range(args.warmup):
         be.solve_device(B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
@@ -472,7 +473,7 @@ def main():
         "traffic": traffic,
         "traffic_source": traffic_source,
         "occupancy": occupancy,
-        "measured_in": f"a second pass of the same {args.steps} steps with one hipEventRecord after every kernel on the handle's stream ({1e3 * elapsed_profiled / args.steps:.1f} ms per step; the timed pass runs without them)",
+        "measured_in": f"a second pass of the same {args.steps} steps with one hipEventRecord after every kernel on the handle's stream ({1e3 * elapsed_profiled / args.steps:.1f} ms per step; the timed pass runs without them, and in parts on two streams where the batch is large enough: config.streams_per_gpu -- the profiled pass is one stream, whole batch per launch)",
         "avg_launch_ms": per_kernel[dom]["avg_launch_ms"],
         "bytes_per_unit": bytes_k[dom],
         "units_per_launch_avg": units / launches,
@@ -505,6 +506,9 @@ def main():
             **({"rccl_error": rccl_error} if rccl_error else {}),
             "per_rank": per_rank,
             "hessian": args.hessian,
+            "streams_per_gpu": streams_used,
+            "streams_note": "a batch at or above the handle's split_min is solved in `streams` contiguous parts, each on a HIP stream and host thread of its own "
+                            "(csrc/oh_api.hip:solve_split): the latency-bound phases of one part overlap the bandwidth-bound launches of the other",
         },
         "roofline": roofline,
         "roofline_fk_jac": {

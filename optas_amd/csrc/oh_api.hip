@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -115,6 +116,10 @@ struct oh_handle {
   double rejects = 0;
   double tail_iters = 0;
   int* h_flag = nullptr;  // pinned
+  // a large batch of the plain orientation-locked family is solved in parts on handles (streams, host threads) of their own: solve_split
+  std::vector<oh_handle*> peers;
+  std::vector<int> split_parts;  // instances per part of the last solve (empty: it was not split)
+  bool is_peer = false;
   bool compaction = true;
   int compact_carry = 1;     // compaction carries the pending trial along instead of restarting the survivors (k_carry_*)
   int tail_vel_threshold = 1 << 30;  // ... from this many instances down: always (see oh_solve_device)
@@ -169,7 +174,7 @@ static double optv(const oh_handle* h, const char* name, double dflt) {
 struct OptDoc { const char* name; double dflt; };
 // map-backed options and their defaults (field-backed ones are handled in set_option_impl / oh_get_option)
 static const OptDoc OPT_TABLE[] = {
-    {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},         {"settle_k", 1.0},   {"al_fuse", 1},
+    {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},         {"settle_k", 1.0},   {"al_fuse", 1},   {"streams", 2},         {"split_min", 131072},
     {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.4},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
@@ -1401,6 +1406,77 @@ static int move_everything(oh_handle* h, hipStream_t s, int Bnew) {
   return OH_OK;
 }
 
+// ---- one batch, several streams (round 5) ----------------------------------------------------------------------------------------------------
+// A solve of the plain orientation-locked family alternates bandwidth-bound launches over the whole batch with phases that leave the machine
+// mostly idle: the persistent tail kernel (one wavefront per SIMD for milliseconds), the last launches before the hand-over, the compactions, the
+// host's look at the running count after every iteration.  Two halves of the batch on two streams, each driven by a host thread of its own, fill
+// each other's gaps: 262 144 instances 91.1 -> 84.6 ms on one box (2.88 -> 3.10 M solves/s; three parts 86.3, four 90.9: tools/gpu_two_streams.py).
+// Instances are independent, so this is the multi-GPU sharding of DESIGN section 7 applied once more inside a GPU.  Each part is a handle of its own (peer:
+// same description, constants, options, compiled kernels); profiling runs (events after every kernel) stay on one stream.
+static void copy_options(oh_handle* dst, const oh_handle* src) {
+  dst->tail_threshold = src->tail_threshold; dst->free_pcr_max = src->free_pcr_max; dst->compaction = src->compaction;
+  dst->compact_frac = src->compact_frac; dst->compact_frac_restart = src->compact_frac_restart; dst->compact_sort = src->compact_sort;
+  dst->compact_carry = src->compact_carry; dst->tail_vel = src->tail_vel; dst->lg_split = src->lg_split; dst->tail_vel_threshold = src->tail_vel_threshold;
+  dst->fuse_couple = src->fuse_couple; dst->sparse_check_below = src->sparse_check_below; dst->specialize = src->specialize; dst->opt = src->opt;
+}
+static int solve_split(oh_handle* h, const int S, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status) {
+  while ((int)h->peers.size() < S - 1) {
+    oh_problem_desc d = h->desc;
+    d.local_path = h->local_path.data();
+    oh_handle* p = nullptr;
+    int rc = oh_create(&d, &p);
+    if (rc) return rc;
+    p->is_peer = true;
+    rc = oh_set_constants(p, &h->chain_host);
+    if (rc) { oh_destroy(p); return rc; }
+    h->peers.push_back(p);
+  }
+  const int N = h->desc.ndof, T = h->desc.T;
+  const size_t nx = (size_t)N * T + (size_t)N * (T - 1);
+  std::vector<int> lo(S + 1, 0);
+  for (int i = 1; i <= S; ++i) lo[i] = (int)((long long)B * i / S / 64 * 64);
+  lo[S] = B;
+  std::vector<int> rcs(S, OH_OK);
+  std::vector<std::string> errs(S);
+  auto part = [&](const int i) {
+    oh_handle* q = i == 0 ? h : h->peers[i - 1];
+    const size_t o = (size_t)lo[i];
+    const int n = lo[i + 1] - lo[i];
+    auto off = [&](const void* ptr, const size_t bytes_per) -> void* { return ptr ? (void*)((char*)ptr + o * bytes_per) : nullptr; };
+    rcs[i] = oh_solve_device(q, n, off(d_x0, nx * 8), off(d_p, (size_t)N * 8), off(d_x, nx * 8), off(d_f, 8), off(d_kkt, 24), off(d_iters, 4), off(d_status, 4));
+    if (rcs[i]) errs[i] = oh_last_error();
+  };
+  for (int i = 1; i < S; ++i) {
+    copy_options(h->peers[i - 1], h);
+    h->peers[i - 1]->spec = h->spec;
+    h->peers[i - 1]->spec_failed = h->spec_failed;
+    h->peers[i - 1]->spec_cache_checked = true;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  h->is_peer = true;  // (this handle takes part 0 itself and must not split again)
+  for (int i = 1; i < S; ++i) th.emplace_back(part, i);
+  part(0);
+  for (std::thread& t : th) t.join();
+  h->is_peer = false;
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (int i = 0; i < S; ++i)
+    if (rcs[i]) return fail(rcs[i], errs[i]);
+  h->split_parts.assign(S, 0);
+  for (int i = 0; i < S; ++i) h->split_parts[i] = lo[i + 1] - lo[i];
+  h->timing[4] = ms;
+  for (int i = 1; i < S; ++i) {
+    const oh_handle* q = h->peers[i - 1];
+    h->timing[5] = std::max(h->timing[5], q->timing[5]);
+    h->timing[6] += q->timing[6];
+    h->timing[7] += q->timing[7];
+    h->rejects += q->rejects;
+    h->tail_iters += q->tail_iters;
+  }
+  h->last_B = B;
+  return OH_OK;
+}
+
 extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt,
                                void* d_iters, void* d_status) {
   if (!h) return fail(OH_ERR_INVALID, "oh_solve_device: null handle");
@@ -1417,6 +1493,15 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (!solver_chain_ok(h->chain_host))
     return fail(OH_ERR_INVALID, "oh_solve_device: the solver needs a chain that covers every model joint in order");
   HIPCHK(hipSetDevice(h->device));
+  if (!h->is_peer) h->split_parts.clear();
+  if (!h->is_peer && !h->profiling && spec_applies(h) && optv(h, "batch_invariant", 0.0) == 0.0) {
+    const int S = std::min(8, (int)optv(h, "streams", 2.0));
+    if (S >= 2 && B >= (int)optv(h, "split_min", 131072.0) && B / S >= 4096) {
+      // (the kernels compiled for the chain are shared: make sure they exist before the parts look for them)
+      if (!h->spec && !h->spec_failed && h->specialize != OH_SPECIALIZE_NEVER && oh_specialize(h) != OH_OK) h->spec_failed = true;
+      return solve_split(h, S, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
+    }
+  }
   int rc = ensure_capacity(h, B);
   if (rc) return rc;
   fill_params(h);
@@ -1883,6 +1968,15 @@ extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
     return OH_OK;
   }
   if (!h->D.lam_h) return fail(OH_ERR_STATE, "oh_get_multipliers: this problem has no nonlinear equality rows");
+  if (!h->split_parts.empty()) {  // the last solve ran in parts (solve_split): every part keeps the multipliers of its instances
+    size_t o = 0;
+    for (size_t i = 0; i < h->split_parts.size(); ++i) {
+      const oh_handle* q = i == 0 ? h : h->peers[i - 1];
+      HIPCHK(hipMemcpy(lam_h + o * 4 * (size_t)h->desc.T, q->D.lam_h, sizeof(double) * 4 * (size_t)h->desc.T * h->split_parts[i], hipMemcpyDeviceToHost));
+      o += (size_t)h->split_parts[i];
+    }
+    return OH_OK;
+  }
   HIPCHK(hipMemcpy(lam_h, h->D.lam_h, sizeof(double) * 4 * (size_t)h->desc.T * B, hipMemcpyDeviceToHost));
   return OH_OK;
 }
@@ -2044,6 +2138,8 @@ extern "C" int oh_event_timer_stop(oh_handle* h, double* ms) {
 
 extern "C" void oh_destroy(oh_handle* h) {
   if (!h) return;
+  for (oh_handle* p : h->peers) oh_destroy(p);
+  h->peers.clear();
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (hipEvent_t e : h->prof_events) hipEventDestroy(e);

@@ -80,3 +80,31 @@ def test_batch_invariant_answers_are_functions_of_the_instance(hip_lib, monkeypa
     assert np.array_equal(mixed.x[:64], big.x[idx])
     be.close()
     other.close()
+
+
+def test_a_large_batch_solved_in_parts_on_two_streams_equals_the_parts_solved_alone(hip_lib, monkeypatch):
+    """Round 5 (solve_split in csrc/oh_api.hip): a batch of the plain orientation-locked family at or above `split_min` is solved in `streams` contiguous
+    parts, each on a handle (stream, host thread) of its own, so that the latency-bound phases of one part hide behind the bandwidth-bound launches
+    of the other.  Pinned: the split solve returns, at every original index, exactly what a handle without the split returns for that part solved as a
+    batch of its own -- x, f, step counts and the multipliers of the quaternion rows, bit for bit -- and the profiled solve (one stream) the same optima."""
+    monkeypatch.delenv("OH_DEBUG_OPTIONS", raising=False)
+    B = 40000  # parts of 19 968 and 20 032 instances (boundaries fall on multiples of 64)
+    x0, qc = bench.make_inputs(B, 5)
+    a = _backend().set_options(split_min=32768, streams=2)
+    ra = a.solve(x0, qc)
+    la = a.multipliers(B)
+    ta = a.timing()
+    cut = B // 2 // 64 * 64
+    b = _backend().set_options(streams=1)
+    assert b.get_option("streams") == 1 and a.get_option("split_min") == 32768
+    assert (ra.status == 0).all() and ta["solve_ms"] > 0
+    for lo, hi in ((0, cut), (cut, B)):
+        rb = b.solve(x0[lo:hi], qc[lo:hi])
+        lb = b.multipliers(hi - lo)
+        assert np.array_equal(ra.x[lo:hi], rb.x) and np.array_equal(ra.f[lo:hi], rb.f) and np.array_equal(ra.iters[lo:hi], rb.iters)
+        assert np.array_equal(la[lo:hi], lb)
+    # the whole batch on one stream: another batch, so another path for an instance here and there (DESIGN section 6) -- the same optima
+    rw = b.solve(x0, qc)
+    assert (rw.status == 0).all() and (np.abs(rw.f - ra.f) <= 1e-9 * np.abs(ra.f)).mean() >= 0.97
+    a.close()
+    b.close()

@@ -174,7 +174,7 @@ static double optv(const oh_handle* h, const char* name, double dflt) {
 struct OptDoc { const char* name; double dflt; };
 // map-backed options and their defaults (field-backed ones are handled in set_option_impl / oh_get_option)
 static const OptDoc OPT_TABLE[] = {
-    {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},         {"settle_k", 1.0},   {"al_fuse", 1},   {"streams", 2},         {"split_min", 131072},
+    {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},         {"settle_k", 1.0},   {"al_fuse", 1},   {"streams", 2},         {"split_min", 131072},  {"tq_split_min", 1024},
     {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.4},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
@@ -1420,21 +1420,28 @@ static void copy_options(oh_handle* dst, const oh_handle* src) {
   dst->fuse_couple = src->fuse_couple; dst->sparse_check_below = src->sparse_check_below; dst->specialize = src->specialize; dst->opt = src->opt;
 }
 static int solve_split(oh_handle* h, const int S, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status) {
+  const bool tqk = h->desc.kind == OH_PROBLEM_TORQUE_MPC;
   while ((int)h->peers.size() < S - 1) {
-    oh_problem_desc d = h->desc;
-    d.local_path = h->local_path.data();
     oh_handle* p = nullptr;
-    int rc = oh_create(&d, &p);
+    int rc;
+    if (tqk) rc = oh_create_torque(&h->tq, &p);
+    else {
+      oh_problem_desc d = h->desc;
+      d.local_path = h->local_path.data();
+      rc = oh_create(&d, &p);
+    }
     if (rc) return rc;
     p->is_peer = true;
     rc = oh_set_constants(p, &h->chain_host);
+    if (!rc && tqk) rc = oh_set_dynamics(p, &h->dyn_host);
     if (rc) { oh_destroy(p); return rc; }
     h->peers.push_back(p);
   }
   const int N = h->desc.ndof, T = h->desc.T;
-  const size_t nx = (size_t)N * T + (size_t)N * (T - 1);
+  const size_t nx = tqk ? 4 * (size_t)N * T : (size_t)N * T + (size_t)N * (T - 1);
+  const size_t npar = tqk ? 2 * (size_t)N + 3 * (size_t)T : (size_t)N;
   std::vector<int> lo(S + 1, 0);
-  for (int i = 1; i <= S; ++i) lo[i] = (int)((long long)B * i / S / 64 * 64);
+  for (int i = 1; i <= S; ++i) lo[i] = (int)((long long)B * i / S / 64 * 64);  // (parts start on multiples of 64: whole wavefronts of the thread-per-instance kernels)
   lo[S] = B;
   std::vector<int> rcs(S, OH_OK);
   std::vector<std::string> errs(S);
@@ -1443,7 +1450,7 @@ static int solve_split(oh_handle* h, const int S, int B, const void* d_x0, const
     const size_t o = (size_t)lo[i];
     const int n = lo[i + 1] - lo[i];
     auto off = [&](const void* ptr, const size_t bytes_per) -> void* { return ptr ? (void*)((char*)ptr + o * bytes_per) : nullptr; };
-    rcs[i] = oh_solve_device(q, n, off(d_x0, nx * 8), off(d_p, (size_t)N * 8), off(d_x, nx * 8), off(d_f, 8), off(d_kkt, 24), off(d_iters, 4), off(d_status, 4));
+    rcs[i] = oh_solve_device(q, n, off(d_x0, nx * 8), off(d_p, npar * 8), off(d_x, nx * 8), off(d_f, 8), off(d_kkt, 24), off(d_iters, 4), off(d_status, 4));
     if (rcs[i]) errs[i] = oh_last_error();
   };
   for (int i = 1; i < S; ++i) {
@@ -1487,7 +1494,13 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (h->desc.kind == OH_PROBLEM_IK) return ik_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind == OH_PROBLEM_QP) return qp_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind == OH_PROBLEM_TAPE) return tape_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
-  if (h->desc.kind == OH_PROBLEM_TORQUE_MPC) return tq_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
+  if (h->desc.kind == OH_PROBLEM_TORQUE_MPC) {
+    if (!h->is_peer) h->split_parts.clear();
+    const int S = std::min(8, (int)optv(h, "streams", 2.0));
+    if (!h->is_peer && S >= 2 && B >= (int)optv(h, "tq_split_min", 1024.0) && B / S >= 64 && h->have_chain && h->have_dyn)
+      return solve_split(h, S, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
+    return tq_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
+  }
   if (h->desc.kind != OH_PROBLEM_FIGURE_EIGHT) return fail(OH_ERR_STATE, "oh_solve_device: handle was created without a problem (OH_PROBLEM_KINEMATICS)");
   if (!h->have_chain) return fail(OH_ERR_STATE, "oh_solve_device: call oh_set_constants first");
   if (!solver_chain_ok(h->chain_host))
@@ -1934,7 +1947,17 @@ extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
     return fail(OH_ERR_STATE, "oh_get_multipliers: B does not match the last solve");
   HIPCHK(hipSetDevice(h->device));
   if (h->desc.kind == OH_PROBLEM_TORQUE_MPC) {
-    HIPCHK(hipMemcpy(lam_h, h->d_tq_mult, sizeof(double) * (size_t)B * h->tq.T * (h->TqP.vel ? 4 : 2) * h->tq.ndof, hipMemcpyDeviceToHost));
+    const size_t per = (size_t)h->tq.T * (h->tq.vel_limits ? 4 : 2) * h->tq.ndof;
+    if (!h->split_parts.empty()) {  // the last solve ran in parts (solve_split)
+      size_t o = 0;
+      for (size_t i = 0; i < h->split_parts.size(); ++i) {
+        const oh_handle* q = i == 0 ? h : h->peers[i - 1];
+        HIPCHK(hipMemcpy(lam_h + o * per, q->d_tq_mult, sizeof(double) * per * h->split_parts[i], hipMemcpyDeviceToHost));
+        o += (size_t)h->split_parts[i];
+      }
+      return OH_OK;
+    }
+    HIPCHK(hipMemcpy(lam_h, h->d_tq_mult, sizeof(double) * (size_t)B * per, hipMemcpyDeviceToHost));
     return OH_OK;
   }
   if (h->desc.kind == OH_PROBLEM_TAPE) {

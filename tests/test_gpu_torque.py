@@ -338,6 +338,32 @@ def test_stored_curvature_term_leaves_the_optima_alone(hip_lib, ctx):
             assert abs(ref["f"] - out[lag][1][b]) <= 1e-9 * ref["f"] and abs(ref["iters"] - out[lag][2][b]) <= 2, (b, lag, ref["iters"], out[lag][2][b])
 
 
+def test_batch_solved_in_two_parts_on_two_streams_is_invisible(hip_lib, ctx):
+    """Round 5 (solve_split): from tq_split_min instances on a batch is solved in two contiguous parts, each on a stream and a host thread of its
+    own (the latency-bound sweep of one part overlaps the evaluation of the other: 8192 instances 56 -> 51 ms).  An instance's path does not depend
+    on its batch in this family, so the split must be invisible: x, f, step counts, status and the returned multipliers bit for bit."""
+    med7, robot, g = ctx
+    T, B = 30, 2048
+    prob = TorqueProblem(med7, LINK, T=T, dt=0.1, tau_lim=58.0, **W)
+    nlp = TorqueMPCNLP(prob)
+    rng = np.random.default_rng(SEED + 23)
+    qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0])[None] + rng.uniform(-0.1, 0.1, (B, 7))
+    goal = np.stack([prob.goal_figure_eight(q) for q in qc])
+    p = np.concatenate([qc, np.zeros((B, 7)), goal.reshape(B, -1)], 1)
+    x0 = np.zeros((B, nlp.nx))
+    x0[:, : 7 * T] = np.tile(qc, (1, T))
+    out = {}
+    for S in (2, 1):
+        be = backend(robot, T, 58.0, max_iter=600)
+        be.set_option("streams", S)
+        r = be.solve(x0, p)
+        out[S] = (np.array(r.x), np.array(r.f), np.array(r.iters), np.array(r.status), np.array(r.kkt), be.multipliers(B))
+        be.close()
+    for a, b in zip(out[2], out[1]):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert _lib.status_ok(out[2][3]).all() and np.abs(out[2][5]).max() > 0
+
+
 def test_abi_errors(hip_lib, ctx):
     med7, robot, g = ctx
     lib = hip_lib

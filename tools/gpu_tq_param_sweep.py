@@ -36,7 +36,7 @@ out = []
 base_f = None
 for kw in settings:
     kw = dict(kw)
-    ctor = {k: kw.pop(k) for k in list(kw) if not k.startswith("tq_")}
+    ctor = {k: kw.pop(k) for k in list(kw) if not k.startswith("tq_") and k not in ("streams",)}
     be = TorqueBackend(med7.kinematic_chain(link), med7.dynamics_tables(), T=T, dt=dt, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=-58.0, tau_up=58.0, **{'max_iter': 600, **ctor})
     for k, v in kw.items():
         be.set_option(k, v)

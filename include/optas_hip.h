@@ -405,6 +405,7 @@ int oh_get_flag(oh_handle* h, const char* name, int* value);
  *   streams (2), split_min (131072): a batch of the plain orientation-locked family of at least split_min instances is solved in `streams` contiguous parts,
  *       each on a HIP stream and a host thread of its own (results at every index = the part solved as a batch of its own); 1: one stream
  *       (the torque-MPC family likewise from tq_split_min (1024) instances on: its answers do not depend on the batch, so the split is invisible)
+ *       (the position-tracking family from free_split_min (256) instances on)
  *   free_pcr_max (1536), free_bb (1), free_cp_max (512), free_persist (-1 auto / 0 / 1)                  -- position-tracking family sweeps
  *   specialize (2 = auto, 0 never, 1 at the first call)                                                 -- run-time specialisation (oh_specialize)
  *   hyb_switch (1e-5, x w_path), relax (1.5), relax_from (4), retract_min (1e-13), settle_k (1)          -- algorithm constants (change the iterates)

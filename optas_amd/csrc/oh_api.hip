@@ -174,7 +174,7 @@ static double optv(const oh_handle* h, const char* name, double dflt) {
 struct OptDoc { const char* name; double dflt; };
 // map-backed options and their defaults (field-backed ones are handled in set_option_impl / oh_get_option)
 static const OptDoc OPT_TABLE[] = {
-    {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},         {"settle_k", 1.0},   {"al_fuse", 1},   {"streams", 2},         {"split_min", 131072},  {"tq_split_min", 1024},
+    {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},         {"settle_k", 1.0},   {"al_fuse", 1},   {"streams", 2},         {"split_min", 131072},  {"tq_split_min", 1024}, {"free_split_min", 256},
     {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.4},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
@@ -1434,12 +1434,13 @@ static int solve_split(oh_handle* h, const int S, int B, const void* d_x0, const
     p->is_peer = true;
     rc = oh_set_constants(p, &h->chain_host);
     if (!rc && tqk) rc = oh_set_dynamics(p, &h->dyn_host);
+    if (!rc && !tqk && h->have_guards) rc = oh_set_guards(p, &h->guards);
     if (rc) { oh_destroy(p); return rc; }
     h->peers.push_back(p);
   }
   const int N = h->desc.ndof, T = h->desc.T;
   const size_t nx = tqk ? 4 * (size_t)N * T : (size_t)N * T + (size_t)N * (T - 1);
-  const size_t npar = tqk ? 2 * (size_t)N + 3 * (size_t)T : (size_t)N;
+  const size_t npar = tqk ? 2 * (size_t)N + 3 * (size_t)T : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0);
   std::vector<int> lo(S + 1, 0);
   for (int i = 1; i <= S; ++i) lo[i] = (int)((long long)B * i / S / 64 * 64);  // (parts start on multiples of 64: whole wavefronts of the thread-per-instance kernels)
   lo[S] = B;
@@ -1509,11 +1510,16 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (!h->is_peer) h->split_parts.clear();
   if (!h->is_peer && !h->profiling && spec_applies(h) && optv(h, "batch_invariant", 0.0) == 0.0) {
     const int S = std::min(8, (int)optv(h, "streams", 2.0));
-    if (S >= 2 && B >= (int)optv(h, "split_min", 131072.0) && B / S >= 4096) {
+    if (S >= 2 && B >= (int)optv(h, "split_min", 131072.0) && B / S >= 4096 && stage_fits(h, B)) {  // (a batch beyond oh_max_batch is refused below, as ever)
       // (the kernels compiled for the chain are shared: make sure they exist before the parts look for them)
       if (!h->spec && !h->spec_failed && h->specialize != OH_SPECIALIZE_NEVER && oh_specialize(h) != OH_OK) h->spec_failed = true;
       return solve_split(h, S, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
     }
+  }
+  if (!h->is_peer && !h->profiling && !h->desc.lock_orientation && !h->chain_host.has_lead && optv(h, "batch_invariant", 0.0) == 0.0) {
+    // position-tracking family (every launch latency-bound, the machine far from full): two halves side by side -- 1024 arms 9.5 -> 7.3 ms
+    const int S = std::min(8, (int)optv(h, "streams", 2.0));
+    if (S >= 2 && B >= (int)optv(h, "free_split_min", 256.0) && B / S >= 64) return solve_split(h, S, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   }
   int rc = ensure_capacity(h, B);
   if (rc) return rc;
@@ -1975,18 +1981,29 @@ extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
   }
   if (h->have_guards) {
     // SoA [T][NC][Bp] on the device -> [B][T][NC (+ 2 ndof velocity rows)] for the caller
-    const int T = h->desc.T, NC = h->GP.NC, Bp = h->D.Bp, NV = h->GP.vel ? 2 * h->desc.ndof : 0, NT = NC + NV;
-    std::vector<double> tmp((size_t)T * NC * Bp);
-    if (NC) HIPCHK(hipMemcpy(tmp.data(), h->GB.lam_out, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));  // original order (k_guard_emit)
-    for (int b = 0; b < B; ++b)
-      for (int t = 0; t < T; ++t)
-        for (int i = 0; i < NC; ++i) lam_h[((size_t)b * T + t) * NT + i] = tmp[((size_t)t * NC + i) * Bp + b];
-    if (NV) {  // the device keeps the rows of dq_t = interval (t, t+1) in row block t + 1
-      std::vector<double> tv((size_t)T * NV * Bp);
-      HIPCHK(hipMemcpy(tv.data(), h->GB.lamv_out, tv.size() * sizeof(double), hipMemcpyDeviceToHost));
-      for (int b = 0; b < B; ++b)
+    auto fetch = [&](const oh_handle* q, const int n, double* out) -> int {
+      const int T = q->desc.T, NC = q->GP.NC, Bp = q->D.Bp, NV = q->GP.vel ? 2 * q->desc.ndof : 0, NT = NC + NV;
+      std::vector<double> tmp((size_t)T * NC * Bp);
+      if (NC) HIPCHK(hipMemcpy(tmp.data(), q->GB.lam_out, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));  // original order (k_guard_emit)
+      for (int b = 0; b < n; ++b)
         for (int t = 0; t < T; ++t)
-          for (int i = 0; i < NV; ++i) lam_h[((size_t)b * T + t) * NT + NC + i] = (t + 1 < T) ? tv[((size_t)(t + 1) * NV + i) * Bp + b] : 0.0;
+          for (int i = 0; i < NC; ++i) out[((size_t)b * T + t) * NT + i] = tmp[((size_t)t * NC + i) * Bp + b];
+      if (NV) {  // the device keeps the rows of dq_t = interval (t, t+1) in row block t + 1
+        std::vector<double> tv((size_t)T * NV * Bp);
+        HIPCHK(hipMemcpy(tv.data(), q->GB.lamv_out, tv.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int b = 0; b < n; ++b)
+          for (int t = 0; t < T; ++t)
+            for (int i = 0; i < NV; ++i) out[((size_t)b * T + t) * NT + NC + i] = (t + 1 < T) ? tv[((size_t)(t + 1) * NV + i) * Bp + b] : 0.0;
+      }
+      return OH_OK;
+    };
+    if (h->split_parts.empty()) return fetch(h, B, lam_h);
+    const size_t per = (size_t)h->desc.T * ((h->guards.limits ? 2 * h->desc.ndof : 0) + h->guards.n_links * h->guards.n_obstacles + (h->guards.vel_limits ? 2 * h->desc.ndof : 0));
+    size_t o = 0;
+    for (size_t i = 0; i < h->split_parts.size(); ++i) {  // the last solve ran in parts (solve_split)
+      const int rc = fetch(i == 0 ? h : h->peers[i - 1], h->split_parts[i], lam_h + o * per);
+      if (rc) return rc;
+      o += (size_t)h->split_parts[i];
     }
     return OH_OK;
   }

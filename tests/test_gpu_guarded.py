@@ -301,7 +301,7 @@ def test_guarded_batch_compaction_is_invisible(hip_lib, golden, monkeypatch):
         X0[:, xoff[name] : xoff[name] + 7 * T] = np.tile(qc, (1, T))
     out = {}
     for mode in ("0", "1"):
-        oh_debug(monkeypatch, compaction=mode)
+        oh_debug(monkeypatch, compaction=mode, streams=1)  # (one stream: in two parts of 320 the batch would never reach the compaction's 512)
         mb = MultiArmBackend(spec, o, max_iter=400)
         res = mb.solve(X0, P)
         lam = [be.multipliers(B) for _, be in mb.arms]

@@ -30,7 +30,7 @@ extern "C" {
 /* Bumped whenever a struct of this header changes layout or an entry point changes meaning; oh_abi_version() returns the value the library was
    built with, and a host binding refuses a library that answers otherwise (a binding that misreads a descriptor fails silently).
    5: round 5 -- OH_STATUS_INFEASIBLE / OH_STATUS_ACCEPTABLE, oh_set_option / oh_get_option, oh_tq_rollout, tape opcodes 25-26. */
-#define OH_ABI_VERSION 5
+#define OH_ABI_VERSION 6
 
 #define OH_MAX_CHAIN 16 /* actuated joints on one root->link chain */
 #define OH_MAX_T 128    /* horizon knots */
@@ -330,6 +330,13 @@ int oh_create_tape(const oh_tape_desc* desc, oh_handle** out);
    it to read back variables it has eliminated from a tape and the multipliers of the rows that went with them (optas_amd/tape.py). */
 int oh_tape_probe(oh_handle* h, int B, const double* x, const double* p, int n_regs, const int* regs, double* val, const double* seeds, double* adj,
                   double* grad);
+
+/* Initial metric of an OH_PROBLEM_TAPE handle's limited-memory quasi-Newton iteration: H0 [nx][nx], symmetric positive definite, host memory (copied);
+   NULL takes it away again.  The two-loop recursion then starts from r = H0 q instead of the identity scaled by the newest pair.  The reference hands
+   IPOPT the exact Hessian of the Lagrangian (optimization.py:8-24, solver.py:355-384); this is the part of it that is known before the first solve:
+   the host passes the inverse of the constant block of the cost's Hessian (optas_amd/tape.py:quadratic_cost_metric -- the sum-of-squares terms of a
+   trajectory cost), and the (s, y) pairs are left with the curvature of the rows.  Ignored by the dense form (nx <= 48).  oh_get_flag "tape_metric". */
+int oh_tape_set_metric(oh_handle* h, const double* H0);
 
 /* What oh_create_tape does for desc->jit != 0 before it touches a device (CasADi's "jit" option, solver.py:333-384 passes it through): generate
    the kernel source of this tape and compile it for gfx950.  Needs no GPU.  source (optional, source_cap bytes) receives the generated

@@ -19,7 +19,7 @@ OH_MAX_OBSTACLES = 16
 OH_COMM_ID_BYTES = 128
 
 OH_OK, OH_ERR_INVALID, OH_ERR_HIP, OH_ERR_STATE = 0, 1, 2, 3
-OH_ABI_VERSION = 5  # include/optas_hip.h: the struct layouts below are those of this version
+OH_ABI_VERSION = 6  # include/optas_hip.h: the struct layouts below are those of this version
 OH_STATUS_CONVERGED, OH_STATUS_MAX_ITER, OH_STATUS_NUMERICAL, OH_STATUS_INFEASIBLE, OH_STATUS_ACCEPTABLE = 0, 1, 2, 3, 4
 # IPOPT's names for the same outcomes (what CasADiSolver.stats()["return_status"] holds, solver.py:407-412)
 STATUS_NAMES = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Numerical_Failure", 3: "Infeasible_Problem_Detected", 4: "Solved_To_Acceptable_Level"}
@@ -216,6 +216,7 @@ SYMBOLS = [
     "oh_create_torque",
     "oh_tape_compile",
     "oh_tape_probe",
+    "oh_tape_set_metric",
     "oh_set_constants",
     "oh_set_constants_device",
     "oh_get_constants",
@@ -303,6 +304,7 @@ def load() -> C.CDLL:
     lib.oh_qp_set_tape.argtypes = [vp, C.POINTER(oh_tape_desc)]
     lib.oh_tape_compile.argtypes = [C.POINTER(oh_tape_desc), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.oh_tape_probe.argtypes = [vp, i, vp, vp, i, vp, vp, vp, vp, vp]
+    lib.oh_tape_set_metric.argtypes = [vp, vp]
     lib.oh_set_constants.argtypes = [vp, C.POINTER(oh_chain)]
     lib.oh_set_constants_device.argtypes = [vp, vp, C.c_size_t]
     lib.oh_set_guards.argtypes = [vp, C.POINTER(oh_guards)]

@@ -131,14 +131,22 @@ class PointMassBackend(_SolveMixin):
 class TapeBackend(_SolveMixin):
     """OH_PROBLEM_TAPE handle: a compiled instruction tape (optas_amd.tape.Tape) interpreted on the GPU; x (B, nx), p (B, np)."""
 
-    def __init__(self, tape, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True, wave=True, options=None, keep_regs=None):
-        """wave: let trajectory-sized tapes (beyond 48 variables) run one block of wavefronts per instance over the dependency levels of the tape
+    def __init__(self, tape, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True, wave=True, options=None, keep_regs=None, metric=True):
+        """metric: in the limited-memory regime (beyond 48 variables) hand the library the inverse of the constant block of the cost's Hessian as the
+        initial metric of the quasi-Newton iteration (tape.py:quadratic_cost_metric, oh_tape_set_metric) where the cost has one; wave: let trajectory-sized tapes (beyond 48 variables) run one block of wavefronts per instance over the dependency levels of the tape
         (csrc/oh_tape_wave.hip) where the library finds that it applies; options: oh_set_option pairs applied to the handle; keep_regs: registers the
         caller will read back with probe() -- self.kept_regs holds their indices in the tape the handle was given (re-association renumbers)."""
         self.nx, self.np_ = int(tape.nx), max(1, int(tape.np_))
         self.kept_regs = None if keep_regs is None else np.asarray(keep_regs, dtype=np.int32)
         self._np_real = int(tape.np_)
         self._h = None
+        self._h0 = None
+        if isinstance(metric, np.ndarray):  # (computed by the caller: tape_backend chooses the initial penalty by it)
+            self._h0 = np.ascontiguousarray(metric, dtype=np.float64).reshape(self.nx, self.nx)
+        elif metric and int(tape.nx) > 48 and int((options or {}).get("tape_lbfgs", -1)) != 0:  # (tape_lbfgs 0 forces the dense form, which builds its own matrix)
+            from .tape import quadratic_cost_metric
+
+            self._h0 = quadratic_cost_metric(tape)
         want_wave = bool(wave) and int(tape.nx) > 48 and float((options or {}).get("tape_wave", 1)) != 0.0
         if want_wave:
             # chains of additions are dependency levels for that evaluator, so sums go in as balanced trees (same values to the rounding of the
@@ -178,6 +186,8 @@ class TapeBackend(_SolveMixin):
         desc = self.descriptor(tape, self._keep, max_iter, tol, tol_feas, rho0, jit, no_wave=float(opts.pop("tape_wave", 1)) == 0.0, lbfgs=int(opts.pop("tape_lbfgs", -1)))
         self._h = C.c_void_p()
         _lib.check(lib.oh_create_tape(C.byref(desc), C.byref(self._h)), "oh_create_tape")
+        if self._h0 is not None:
+            _lib.check(lib.oh_tape_set_metric(self._h, _lib._ptr(self._h0)), "oh_tape_set_metric")
         if opts:
             self.set_options(opts)
 
@@ -223,7 +233,7 @@ class TapeBackend(_SolveMixin):
         return val, adj, grad
 
     def flag(self, name: str) -> int:
-        """oh_get_flag: 'tape_wave' (0 thread per instance, 1 / 2 wavefront per instance), 'tape_regs_lds', 'tape_levels', 'tape_passes'."""
+        """oh_get_flag: 'tape_wave' (0 thread per instance, 1 / 2 wavefront per instance), 'tape_regs_lds', 'tape_levels', 'tape_passes', 'tape_metric'."""
         v = C.c_int(0)
         _lib.check(_lib.load().oh_get_flag(self._h, name.encode(), C.byref(v)), "oh_get_flag")
         return int(v.value)
@@ -283,7 +293,7 @@ class EliminatedTapeBackend:
         seeds[:, 1 : 1 + lam.shape[1]] = -lam
         seeds[:, 1 + lam.shape[1] + el.rows_kept] = -mu
         if self._orig is None:
-            self._orig = TapeBackend(self.full, jit=False, wave=False)
+            self._orig = TapeBackend(self.full, jit=False, wave=False, metric=False)
         _, _, grad = self._orig.probe(x, p, None, seeds)
         nu = np.linalg.solve(el.A_pivot.T, grad[:, el.pivot].T).T
         mu_full = np.zeros((B, n_eq))
@@ -324,19 +334,30 @@ class EliminatedTapeBackend:
 
 def tape_backend(tape, eliminate=True, rho0=None, **kw):
     """TapeBackend for a compiled problem; trajectory-sized ones (beyond 48 variables: the limited-memory regime) first lose the equality rows that
-    are affine in x with constant coefficients.  rho0 None: the initial penalty of the augmented Lagrangian is 10 for a problem as written and 1000 once
-    its affine rows are gone (what is left are the few nonlinear rows; with 32 limited-memory pairs instead of 12 the planner takes 234-272 evaluations
+    are affine in x with constant coefficients.  rho0 None: the initial penalty of the augmented Lagrangian is 10 for a problem as written, 1000 once its
+    affine rows are gone, 1e4 if in addition its cost hands over a metric (below) (what is left are the few nonlinear rows; with 32 limited-memory pairs instead of 12 the planner takes 234-272 evaluations
     instead of 389-498, 256 instances 18.6 instead of 35.9 ms: tools/gpu_planner_sweep.py)."""
+    metric = kw.pop("metric", None)  # None: where it pays -- on a problem whose affine rows are gone; True / an array: also on a problem as written; False: never
     if eliminate and int(tape.nx) > 48 and int(tape.n_eq) > 0:
-        from .tape import eliminate_affine_equalities
+        from .tape import eliminate_affine_equalities, quadratic_cost_metric
 
         el = eliminate_affine_equalities(tape)
         if el is not None and int(el.tape.nx) >= 1:
             opts = dict(kw.pop("options", None) or {})
             if int(el.tape.nx) > 48:
                 opts.setdefault("tape_lbfgs", 32)
-            return EliminatedTapeBackend(tape, el, rho0=1000.0 if rho0 is None else float(rho0), options=opts, **kw)
-    return TapeBackend(tape, rho0=10.0 if rho0 is None else float(rho0), **kw)
+            # round 5, last part: where the cost of the reduced problem has a constant quadratic block (sumsqr terms on states, velocities, accelerations) its
+            # inverse is the initial metric of the limited-memory iteration, and the penalty starts at 1e4: the pairs only have to learn the rows, and they
+            # learn them once (planner, numpy port, 32 instances: 255 -> 54 evaluations on average, slowest 311 -> 84; tests/test_planner.py)
+            h0 = None
+            if metric is not False and int(el.tape.nx) > 48 and int(opts.get("tape_lbfgs", -1)) != 0:
+                h0 = metric if isinstance(metric, np.ndarray) else quadratic_cost_metric(el.tape)
+            if rho0 is None:
+                rho0 = 1e4 if h0 is not None else 1000.0
+            return EliminatedTapeBackend(tape, el, rho0=float(rho0), options=opts, metric=h0 if h0 is not None else False, **kw)
+    # (as written, the penalty on hundreds of affine rows is most of the merit's curvature and none of it is in the cost's block: T = 60 planner, 840 variables,
+    # 12 pairs -- one of two instances runs into the evaluation cap with the metric, none without; so only on request)
+    return TapeBackend(tape, rho0=10.0 if rho0 is None else float(rho0), metric=False if metric is None else metric, **kw)
 
 
 class QPBackend(_SolveMixin):

@@ -252,7 +252,7 @@ def make_solver_class(solver_module, cs):
             if self._family is None:
                 self._tape = tape_from_optimization(self.opt, cs)
                 self._backend = tape_backend(self._tape, eliminate=bool(o.pop("eliminate", True)), max_iter=int(o.pop("max_iter", tape_default_max_iter(self._tape.nx))),
-                                             tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=(float(o.pop("rho0")) if "rho0" in o else None), jit=bool(o.pop("jit", True)))
+                                             tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=(float(o.pop("rho0")) if "rho0" in o else None), jit=bool(o.pop("jit", True)), metric=o.pop("metric", None))
                 self._family = "tape"
             if o:
                 raise ValueError(f"unknown solver options {sorted(o)}")

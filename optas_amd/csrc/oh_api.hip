@@ -69,6 +69,7 @@ struct oh_handle {
   double* d_tape_c = nullptr;
   double* d_tape_work = nullptr;
   double* d_tape_mult = nullptr;
+  double* d_tape_h0 = nullptr;  // oh_tape_set_metric: initial metric of the limited-memory form [nx][nx]
   int tape_cap = 0;
   TapeJit tape_jit;
   TapeWave tape_wave;  // trajectory-sized tapes: one wavefront per instance (oh_tape_wave.hip)
@@ -436,7 +437,7 @@ static TapeParams tape_params(const oh_tape_desc* d, const int lbfgs_opt = -1) {
   int lb = d->nx > 48 ? 12 : 0;
   if (lbfgs_opt >= 0) lb = lbfgs_opt > 64 ? 64 : lbfgs_opt;
   return TapeParams{d->len, d->nx, d->np, d->n_ineq, d->n_eq, d->out_cost, d->max_iter > 0 ? d->max_iter : 2000, d->tol > 0.0 ? d->tol : 1e-6,
-                    d->tol_feas > 0.0 ? d->tol_feas : 1e-9, d->rho0 > 0.0 ? d->rho0 : 10.0, lb};
+                    d->tol_feas > 0.0 ? d->tol_feas : 1e-9, d->rho0 > 0.0 ? d->rho0 : 10.0, lb, nullptr};
 }
 
 extern "C" int oh_tape_compile(const oh_tape_desc* d, size_t* code_bytes, char* source, size_t source_cap, size_t* source_len) {
@@ -462,6 +463,7 @@ static int tape_configure(oh_handle* h) {
   oh_tape_desc d = h->t_desc;
   d.op = h->t_op.data(); d.a = h->t_a.data(); d.b = h->t_b.data(); d.c = h->t_c.data(); d.rows = h->t_rows.empty() ? nullptr : h->t_rows.data();
   h->TP = tape_params(&d, (int)optv(h, "tape_lbfgs", -1.0));
+  h->TP.h0 = h->d_tape_h0;  // (a metric handed over before an option rebuilt the evaluator stays)
   load_launch_opts(h);  // oh_tape_wave_build reads tape_wave_nt / _regs / _hist
   oh_tape_wave_release(&h->tape_wave);
   h->tape_wave = TapeWave{};
@@ -572,6 +574,32 @@ extern "C" int oh_tape_probe(oh_handle* h, int B, const double* x, const double*
   if (val && n_regs > 0) HIPCHK(hipMemcpy(val, d_v, sizeof(double) * (size_t)n_regs * B, hipMemcpyDeviceToHost));
   if (seeds && adj && n_regs > 0) HIPCHK(hipMemcpy(adj, d_a, sizeof(double) * (size_t)n_regs * B, hipMemcpyDeviceToHost));
   if (seeds && grad) HIPCHK(hipMemcpy(grad, d_g, b_x, hipMemcpyDeviceToHost));
+  return OH_OK;
+}
+
+extern "C" int oh_tape_set_metric(oh_handle* h, const double* H0) {
+  if (!h) return fail(OH_ERR_INVALID, "oh_tape_set_metric: null argument");
+  if (h->desc.kind != OH_PROBLEM_TAPE) return fail(OH_ERR_INVALID, "oh_tape_set_metric: not an OH_PROBLEM_TAPE handle");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t n = (size_t)h->TP.nx;
+  if (!H0) {
+    if (h->d_tape_h0) hipFree(h->d_tape_h0);
+    h->d_tape_h0 = nullptr;
+    h->TP.h0 = nullptr;
+    return OH_OK;
+  }
+  // symmetric with a positive diagonal is what can be checked here without factorising; a matrix that is not positive definite costs the solver a
+  // reset to steepest descent whenever the direction it gives does not descend (oh_tape_solver.h), never a wrong answer
+  for (size_t i = 0; i < n; ++i) {
+    if (!(H0[i * n + i] > 0.0)) return fail(OH_ERR_INVALID, "oh_tape_set_metric: diagonal entry not positive");
+    for (size_t j = 0; j < i; ++j) {
+      const double a = H0[i * n + j], b = H0[j * n + i];
+      if (!(fabs(a - b) <= 1e-10 * (fabs(a) + fabs(b)) + 1e-300)) return fail(OH_ERR_INVALID, "oh_tape_set_metric: matrix not symmetric");
+    }
+  }
+  if (!h->d_tape_h0) HIPCHK(hipMalloc((void**)&h->d_tape_h0, sizeof(double) * n * n));
+  HIPCHK(hipMemcpy(h->d_tape_h0, H0, sizeof(double) * n * n, hipMemcpyHostToDevice));
+  h->TP.h0 = h->d_tape_h0;
   return OH_OK;
 }
 
@@ -2191,7 +2219,8 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->gpool) hipFree(h->gpool);
   if (h->move_scr) hipFree(h->move_scr);
   if (h->d_qp_work) hipFree(h->d_qp_work);
-  for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult})
+  for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult,
+                  (void*)h->d_tape_h0})
     if (q) hipFree(q);
   if (h->d_qp_mult) hipFree(h->d_qp_mult);
   for (void* q : {(void*)h->d_qp_rows, (void*)h->d_qp_val, (void*)h->d_qp_f0, (void*)h->d_qp_xdep})
@@ -2458,6 +2487,7 @@ extern "C" int oh_get_flag(oh_handle* h, const char* name, int* value) {
   else if (n == "specialized") *value = h->spec ? 1 : 0;
   else if (n == "tape_wave") *value = h->tape_wave.ready ? (h->tape_wave.hist_lds ? 2 : 1) : 0;
   else if (n == "tape_regs_lds") *value = h->tape_wave.ready && h->tape_wave.reg_lds ? 1 : 0;
+  else if (n == "tape_metric") *value = (h->TP.h0 && h->TP.lbfgs > 0) ? 1 : 0;
   else if (n == "tape_levels") *value = h->tape_wave.n_levels;
   else if (n == "tape_passes") *value = h->tape_wave.n_fw_pass + h->tape_wave.n_rv_pass;
   else return fail(OH_ERR_INVALID, "oh_get_flag: unknown flag " + n);

@@ -16,6 +16,11 @@ struct TapeParams {
   int len, nx, np, n_ineq, n_eq, out_cost, max_iter;
   double tol, tol_feas, rho0;
   int lbfgs;  // 0: dense inverse-Hessian BFGS; m > 0: limited-memory BFGS with m pairs
+  // Initial metric of the limited-memory form (oh_tape_set_metric): a symmetric positive definite [nx][nx] matrix H0 in device memory, shared by
+  // every instance of the handle -- the two-loop recursion takes r = H0 q where it otherwise scales q by s.y / y.y of the newest pair.  The host
+  // hands over the inverse of the constant part of the cost's Hessian (tape.py:quadratic_cost_metric): what the pairs then have to learn is the
+  // curvature of the rows alone.  nullptr: the scaled identity.
+  const double* h0;
 };
 
 #define TIDX(i) ((size_t)(i) * Bp + b)
@@ -99,6 +104,7 @@ __device__ inline void tape_solve_instance(const TapeParams& T, E& ev, const Tap
   // limited-memory form: W.H holds S [m][n], then Y [m][n], then 1 / (s_i . y_i) [m], then the two-loop alphas [m]; pair j of the `hist` stored
   // ones (oldest first) sits in ring slot (head - hist + j) mod m
   const int m = T.lbfgs;
+  const bool metric = T.h0 != nullptr && m > 0;
   int hist = 0, head = 0;
   auto Sr = [&](int slot, int k) -> double& { return W.H[TIDX((size_t)slot * n + k)]; };
   auto Yr = [&](int slot, int k) -> double& { return W.H[TIDX((size_t)(m + slot) * n + k)]; };
@@ -138,7 +144,12 @@ __device__ inline void tape_solve_instance(const TapeParams& T, E& ev, const Tap
         W.lam[TIDX(i)] = v;
         msum += v;
       }
-      if (meas > 0.25 * meas_prev) rho = fmin(rho * 10.0, 1e8);
+      if (meas > 0.25 * meas_prev) {
+        rho = fmin(rho * 10.0, 1e8);
+        // with a metric of the handle the pairs hold nothing but the curvature of the rows under the OLD penalty: misleading by a factor of ten, and
+        // cheap to measure again on top of H0 (planner, numpy port, 32 instances: stalls of hundreds of evaluations at the rounding floor without this)
+        if (metric) { hist = 0; head = 0; H_is_eye = true; }
+      }
       meas_prev = meas;
       omega = fmax(T.tol, fmin(omega, 0.1 * meas));
       val = ev.phi(W.x, W.g, rho, &fval, &cmax, &meas);
@@ -161,7 +172,14 @@ __device__ inline void tape_solve_instance(const TapeParams& T, E& ev, const Tap
         Ar(sl) = al;
         for (int k = 0; k < n; ++k) W.d[TIDX(k)] -= al * Yr(sl, k);
       }
-      if (hist > 0) {
+      if (metric) {  // r = H0 q (H0 symmetric: row k read as column k, the same matrix for every lane -> scalar loads); W.hy is free in this form
+        for (int k = 0; k < n; ++k) {
+          double acc = 0.0;
+          for (int j = 0; j < n; ++j) acc += T.h0[(size_t)j * n + k] * W.d[TIDX(j)];
+          W.hy[TIDX(k)] = acc;
+        }
+        for (int k = 0; k < n; ++k) W.d[TIDX(k)] = W.hy[TIDX(k)];
+      } else if (hist > 0) {
         const int sl = ((head - 1) % m + m) % m;
         double sy = 0.0, yy = 0.0;
         for (int k = 0; k < n; ++k) { sy += Sr(sl, k) * Yr(sl, k); yy += Yr(sl, k) * Yr(sl, k); }
@@ -224,9 +242,15 @@ __device__ inline void tape_solve_instance(const TapeParams& T, E& ev, const Tap
         // instances walked in place until the evaluation cap)
         double ggt = 0.0;
         for (int k = 0; k < n; ++k) ggt += W.gt[TIDX(k)] * W.gt[TIDX(k)];
-        if (ggt <= (1.0 - 1e-4 * alpha) * gg) { ok = true; break; }
+        // (strictly smaller: below alpha ~ 1e-12 the factor rounds to one and a trial that is x itself would pass as a step, for ever -- seen on the planner
+        // under penalty 1e5 with the stationarity measure resting at 1.01 tol)
+        if (ggt <= (1.0 - 1e-4 * alpha) * gg && ggt < gg) { ok = true; break; }
       }
-      alpha *= 0.5;
+      // backtracking: halving; with a metric (whose unit step is a Newton step of the cost, too long only across the rows' curvature) the minimiser of
+      // the parabola through phi(0), phi'(0), phi(alpha), kept inside [0.1, 0.5] alpha
+      const double bend = vt - val - alpha * slope;
+      if (metric && (vt == vt) && fabs(vt) < 1e300 && bend > 0.0) alpha = fmin(0.5 * alpha, fmax(0.1 * alpha, -slope * alpha * alpha / (2.0 * bend)));
+      else alpha *= 0.5;
       if (evals >= T.max_iter) break;
     }
     if (!ok) {

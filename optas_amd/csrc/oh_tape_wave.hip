@@ -349,10 +349,13 @@ __global__ __launch_bounds__(NT) void k_tape_wave(TapeParams T, WaveSchedDev S, 
       } else if ((v_ == v_) && v_ <= val_m + slack) {
         double gq = 0.0;
         for (int k = lane; k < n; k += NT) gq += GT[k] * GT[k];
-        ok = red.sum(gq) <= (1.0 - 1e-4 * alpha) * gg;
+        const double ggt = red.sum(gq);
+        ok = ggt <= (1.0 - 1e-4 * alpha) * gg && ggt < gg;  // (strictly: a trial that is x itself is not a step, oh_tape_solver.h)
       }
       if (!ok) {
-        alpha *= 0.5;
+        const double bend = v_ - val_m - alpha * slope;  // with a metric: parabola through phi(0), phi'(0), phi(alpha) (oh_tape_solver.h)
+        if (T.h0 && (v_ == v_) && fabs(v_) < 1e300 && bend > 0.0) alpha = fmin(0.5 * alpha, fmax(0.1 * alpha, -slope * alpha * alpha / (2.0 * bend)));
+        else alpha *= 0.5;
         ++ls;
         if (evals >= T.max_iter || ls >= 40) {  // rowv belongs to the rejected trial: re-evaluate at x before anything reads the rows again
           why = EV_AGAIN;
@@ -411,7 +414,10 @@ __global__ __launch_bounds__(NT) void k_tape_wave(TapeParams T, WaveSchedDev S, 
         ms_ += v;
       }
       msum = red.sum(ms_);
-      if (meas > 0.25 * meas_prev) rho = fmin(rho * 10.0, 1e8);
+      if (meas > 0.25 * meas_prev) {
+        rho = fmin(rho * 10.0, 1e8);
+        if (T.h0) { hist = 0; head = 0; H_is_eye = true; }  // the pairs measured the rows' curvature under the old penalty (oh_tape_solver.h)
+      }
       meas_prev = meas;
       omega = fmax(T.tol, fmin(omega, 0.1 * meas));
       why = EV_OUTER;  // the metric is kept across the multiplier update (oh_tape_solver.h)
@@ -430,7 +436,27 @@ __global__ __launch_bounds__(NT) void k_tape_wave(TapeParams T, WaveSchedDev S, 
       RA[m + sl] = al;
       for (int k = lane; k < n; k += NT) D[k] -= al * Yr(sl, k);
     }
-    if (hist > 0) {
+    if (T.h0) {
+      // r = H0 q with the handle's metric (oh_tape_set_metric; symmetric, so element k reads column k: consecutive lanes, consecutive words of an
+      // L2-resident matrix every instance shares).  q is spread over the threads: it has to be complete before anyone reads all of it, and the product
+      // goes through XT (free here: the next trial point is written after the direction is known) so that nobody reads a half-updated D.
+      __syncthreads();
+      for (int k = lane; k < n; k += NT) {
+        const double* __restrict__ col = T.h0 + k;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;  // four independent chains: the loads are what the loop waits for
+        int j = 0;
+        for (; j + 3 < n; j += 4) {
+          a0 = fma(col[(size_t)j * n], D[j], a0);
+          a1 = fma(col[(size_t)(j + 1) * n], D[j + 1], a1);
+          a2 = fma(col[(size_t)(j + 2) * n], D[j + 2], a2);
+          a3 = fma(col[(size_t)(j + 3) * n], D[j + 3], a3);
+        }
+        for (; j < n; ++j) a0 = fma(col[(size_t)j * n], D[j], a0);
+        XT[k] = (a0 + a1) + (a2 + a3);
+      }
+      __syncthreads();
+      for (int k = lane; k < n; k += NT) D[k] = XT[k];
+    } else if (hist > 0) {
       const int sl = ((head - 1) % m + m) % m;
       double sy = 0.0, yy = 0.0;
       for (int k = lane; k < n; k += NT) { sy += Sr(sl, k) * Yr(sl, k); yy += Yr(sl, k) * Yr(sl, k); }

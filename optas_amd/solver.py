@@ -337,7 +337,7 @@ class HIPSolver(Solver):
             # (evaluations: a small dense problem needs a few hundred; the limited-memory path of a trajectory-sized one tens of thousands)
             # ("eliminate": affine equality rows -- Euler rows, pinned configurations -- are substituted away before the tape reaches the GPU, tape.py)
             self._backend = tape_backend(spec.tape, eliminate=bool(o.pop("eliminate", True)), max_iter=int(o.pop("max_iter", tape_default_max_iter(spec.tape.nx))),
-                                         tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=(float(o.pop("rho0")) if "rho0" in o else None), jit=bool(o.pop("jit", True)))
+                                         tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=(float(o.pop("rho0")) if "rho0" in o else None), jit=bool(o.pop("jit", True)), metric=o.pop("metric", None))
         else:  # pragma: no cover
             raise NotImplementedError(kind)
         if o:

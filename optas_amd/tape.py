@@ -716,6 +716,110 @@ def affine_forms(tape: Tape, regs) -> List[Optional[Dict[int, float]]]:
     return [form.get(int(r)) if deg[int(r)] <= 1 else None for r in regs]
 
 
+def quadratic_cost_hessian(tape: Tape) -> Optional[np.ndarray]:
+    """The constant part of the Hessian of the cost register: the sum over the terms of the cost's sum tree that are quadratic in x with numeric
+    coefficients -- squares and products of affine forms, scaled by constants (sumsqr costs on states, velocities, accelerations: the terms a
+    trajectory problem is mostly made of; builder.py:226-240 classifies the same way through cs.is_quadratic).  Terms of higher degree, and quadratic
+    terms whose coefficients depend on p, contribute nothing: the result is a lower bound of the curvature that is known before the first solve, not
+    the Hessian of an arbitrary cost.  None when no such term exists."""
+    deg = tape_degrees(tape)
+    root = int(tape.out_cost)
+    if deg[root] < 2:
+        return None
+    # walk the sum tree from the root with a weight per path (hash-consed sub-sums are visited once per use, as the sum uses them)
+    leaves: List[Tuple[float, int]] = []  # (weight, register) of SQR / MUL nodes that are products of two affine forms
+    stack: List[Tuple[float, int]] = [(1.0, root)]
+    cache_c: Dict[int, Optional[float]] = {}
+
+    def cval(r: int) -> Optional[float]:
+        """numeric value of a register that depends on neither x nor p (None otherwise)"""
+        if r in cache_c:
+            return cache_c[r]
+        o, a, b = int(tape.op[r]), int(tape.a[r]), int(tape.b[r])
+        out: Optional[float] = None
+        if o == OP_CONST:
+            out = float(tape.c[r])
+        elif o in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
+            va, vb = cval(a), cval(b)
+            if va is not None and vb is not None:
+                out = va + vb if o == OP_ADD else va - vb if o == OP_SUB else va * vb if o == OP_MUL else (va / vb if vb != 0.0 else None)
+        elif o == OP_NEG:
+            va = cval(a)
+            out = None if va is None else -va
+        elif o == OP_SQR:
+            va = cval(a)
+            out = None if va is None else va * va
+        cache_c[r] = out
+        return out
+
+    budget = 4 * len(tape.op) + 64  # (a DAG whose sums share sub-sums many times over could unfold without end: give up rather than hang)
+    while stack:
+        budget -= 1
+        if budget < 0:
+            return None
+        w, r = stack.pop()
+        if deg[r] < 2:
+            continue
+        o, a, b = int(tape.op[r]), int(tape.a[r]), int(tape.b[r])
+        if o == OP_ADD:
+            stack += [(w, a), (w, b)]
+        elif o == OP_SUB:
+            stack += [(w, a), (-w, b)]
+        elif o == OP_NEG:
+            stack.append((-w, a))
+        elif o == OP_SQR and deg[a] == 1:
+            leaves.append((w, r))
+        elif o == OP_MUL:
+            if deg[a] == 1 and deg[b] == 1:
+                leaves.append((w, r))
+            elif deg[a] == 0 and cval(a) is not None:
+                stack.append((w * cval(a), b))
+            elif deg[b] == 0 and cval(b) is not None:
+                stack.append((w * cval(b), a))
+        elif o == OP_DIV and deg[b] == 0 and cval(b) not in (None, 0.0):
+            stack.append((w / cval(b), a))
+        # anything else (degree 3, parameter-dependent scale): no contribution
+    if not leaves:
+        return None
+    operands = sorted({int(tape.a[r]) for _, r in leaves} | {int(tape.b[r]) for _, r in leaves if int(tape.op[r]) == OP_MUL})
+    forms = dict(zip(operands, affine_forms(tape, operands)))
+    n = int(tape.nx)
+    Q = np.zeros((n, n))
+    any_term = False
+    for w, r in leaves:
+        fa = forms.get(int(tape.a[r]))
+        fb = fa if int(tape.op[r]) == OP_SQR else forms.get(int(tape.b[r]))
+        if not fa or not fb:  # (None: coefficients depend on p; empty: no x)
+            continue
+        ia, va = np.fromiter(fa.keys(), dtype=np.int64), np.fromiter(fa.values(), dtype=np.float64)
+        ib, vb = np.fromiter(fb.keys(), dtype=np.int64), np.fromiter(fb.values(), dtype=np.float64)
+        blk = w * np.outer(va, vb)  # d2 (a b) = grad a grad b^T + grad b grad a^T
+        Q[np.ix_(ia, ib)] += blk
+        Q[np.ix_(ib, ia)] += blk.T
+        any_term = True
+    return Q if any_term else None
+
+
+def quadratic_cost_metric(tape: Tape, max_n: int = 1024) -> Optional[np.ndarray]:
+    """Initial metric H0 [nx][nx] for the limited-memory iteration on this tape (oh_tape_set_metric): the inverse of the constant block of the cost's
+    Hessian, shifted where it is singular or nearly so (variables no quadratic term touches get the curvature 1e-3 of the largest: a long first step
+    the line search cuts, not a division by zero).  None when the cost has no such block, is not convex on it, or the matrix would not pay (nx > max_n:
+    the product r = H0 q is nx^2 multiply-adds per iteration and instance)."""
+    n = int(tape.nx)
+    if n > max_n:
+        return None
+    Q = quadratic_cost_hessian(tape)
+    if Q is None:
+        return None
+    Q = 0.5 * (Q + Q.T)
+    lam = np.linalg.eigvalsh(Q)
+    if not np.isfinite(lam).all() or lam[-1] <= 0.0 or lam[0] < -1e-9 * lam[-1]:
+        return None
+    shift = max(0.0, 1e-3 * lam[-1] - lam[0])
+    H0 = np.linalg.inv(Q + shift * np.eye(n))
+    return np.ascontiguousarray(0.5 * (H0 + H0.T))
+
+
 def reemit(tb: TapeBuilder, tape: Tape, roots, xreg) -> Dict[int, int]:
     """Copy the sub-graphs of `roots` into the builder with variable k read from register xreg(k); returns {old register: new register}."""
     need = np.zeros(len(tape.op), dtype=bool)

@@ -138,8 +138,8 @@ def reverse(tape, v, seeds):
 class _LBFGS:
     """The limited-memory inverse-Hessian operator of csrc/oh_tape_solver.h (T.lbfgs = m pairs): Nocedal's two-loop recursion."""
 
-    def __init__(self, m):
-        self.m, self.S, self.Y = m, [], []
+    def __init__(self, m, h0=None):
+        self.m, self.S, self.Y, self.h0 = m, [], [], h0  # h0: initial metric [n, n] (oh_tape_set_metric), None: the identity scaled by the newest pair
 
     def reset(self):
         self.S, self.Y = [], []
@@ -154,7 +154,9 @@ class _LBFGS:
             a = (sv @ q) / (sv @ yv)
             al.append(a)
             q = q - a * yv
-        if self.S:
+        if self.h0 is not None:
+            q = self.h0 @ q
+        elif self.S:
             q = q * ((self.S[-1] @ self.Y[-1]) / (self.Y[-1] @ self.Y[-1]))
         for (sv, yv), a in zip(zip(self.S, self.Y), reversed(al)):
             q = q + sv * (a - (yv @ q) / (sv @ yv))
@@ -168,13 +170,15 @@ KEEP_METRIC = True  # the quasi-Newton metric survives the multiplier / penalty 
 SCALE_FIRST = True  # dense form: the first pair scales the identity before updating it
 
 
-def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0, lbfgs=None, trace=None):
+def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0, lbfgs=None, trace=None, h0=None):
     """Generic NLP on a tape: min f s.t. rows[:n_ineq] >= 0, rows[n_ineq:] = 0.  Augmented Lagrangian (PHR for the inequality rows)
     minimised by BFGS with Armijo backtracking -- the dense inverse Hessian up to 48 variables, the limited-memory form with `lbfgs` = 12 pairs
-    beyond, as oh_api.hip:tape_params chooses; one forward + one reverse sweep per evaluation.  Port of k_tape_solve."""
+    beyond, as oh_api.hip:tape_params chooses; one forward + one reverse sweep per evaluation.  Port of k_tape_solve.  h0: the initial metric of the
+    limited-memory form (oh_tape_set_metric; the product passes tape.py:quadratic_cost_metric), ignored by the dense form."""
     n, ni, ne = tape.nx, tape.n_ineq, tape.n_eq
     lbfgs = (12 if n > 48 else 0) if lbfgs is None else lbfgs
-    LB = _LBFGS(lbfgs) if lbfgs > 0 else None
+    LB = _LBFGS(lbfgs, h0) if lbfgs > 0 else None
+    metric = LB is not None and h0 is not None
     rows = tape.out_rows
     lam = np.zeros(ni)
     mu = np.zeros(ne)
@@ -216,6 +220,8 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
             lam = np.maximum(0.0, lam - rho * g)
             if meas > 0.25 * meas_prev:
                 rho = min(rho * 10.0, 1e8)
+                if metric:  # the pairs measured the rows' curvature under the old penalty (csrc/oh_tape_solver.h)
+                    LB.reset()
             meas_prev = meas
             omega = max(tol, min(omega, 0.1 * meas))
             val, grad, g, c, fval = phi(x)
@@ -260,13 +266,17 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
             elif np.isfinite(vt) and vt <= val - slack:  # a decrease the merit does resolve, larger than the one asked for
                 ok = True
                 break
-            elif np.isfinite(vt) and vt <= val + slack and float(gt @ gt) <= (1.0 - 1e-4 * alpha) * float(grad @ grad):
+            elif np.isfinite(vt) and vt <= val + slack and float(gt @ gt) <= (1.0 - 1e-4 * alpha) * float(grad @ grad) and float(gt @ gt) < float(grad @ grad):
                 # the decrease asked for is below that resolution (end game under a large penalty: a gradient of 4e-6 across a curvature of 1e4
                 # is worth 7e-16 of merit): the value cannot judge the step, the gradient can -- a step that keeps the merit within its rounding
                 # is taken if it shrinks the gradient; one that leaves the gradient where it was is not a step (alpha -> 0 used to pass as one)
                 ok = True
                 break
-            alpha *= 0.5
+            if metric and np.isfinite(vt) and abs(vt) < 1e300 and vt - val - alpha * slope > 0.0:
+                # minimiser of the parabola through phi(0), phi'(0), phi(alpha), kept inside [0.1, 0.5] alpha
+                alpha = min(0.5 * alpha, max(0.1 * alpha, -slope * alpha * alpha / (2.0 * (vt - val - alpha * slope))))
+            else:
+                alpha *= 0.5
             if evals >= max_iter:
                 break
         if not ok:

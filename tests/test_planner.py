@@ -191,3 +191,85 @@ def test_elimination_on_the_gpu_same_optimum_fewer_evaluations_and_full_multipli
         assert abs(nlp.f(x, p) - fe[b]) <= 1e-10 and np.abs(nlp.a(x, p)).max() <= 1e-12 and np.abs(nlp.h(x, p)).max() <= 1e-8 and nlp.g(x, p).min() >= -1e-9
         r = nlp.df(x, p) - nlp.dg(x, p).T @ lam[b] - nlp.da(x, p).T @ mu[b, : nlp.na] - nlp.dh(x, p).T @ mu[b, nlp.na :]
         assert np.abs(r).max() <= 1e-5 and np.abs(lam[b] * nlp.g(x, p)).max() <= 1e-6, (b, np.abs(r).max())
+
+
+def test_constant_block_of_the_cost_hessian_is_read_off_the_tape_and_the_port_needs_a_fraction_of_the_evaluations_with_it():
+    """The reference hands IPOPT exact Hessians (optimization.py:8-24, solver.py:355-384).  The part of that which is known before the first solve -- the
+    constant Hessian of the sumsqr terms (nominal posture, velocity, acceleration costs: all of this planner's cost) -- is read off the reduced tape
+    (tape.py:quadratic_cost_hessian) and equals the differences of the tape's own reverse-mode gradients; as the initial metric of the limited-memory
+    iteration (oh_tape_set_metric, port: solve_tape_al(h0=...)) it leaves the pairs the curvature of the rows alone."""
+    from examples.simple_joint_space_planner import setup_solver
+    from optas_amd.tape import compile_problem, eliminate_affine_equalities, quadratic_cost_hessian, quadratic_cost_metric, rebalance_sums
+    from oracle import tape_ref
+
+    _, opt = setup_solver(build_only=True)
+    tp = compile_problem(opt)
+    el = eliminate_affine_equalities(tp)
+    rt, n = el.tape, el.tape.nx
+    g = np.load(os.path.join(GOLDEN, "planner_golden.npz"))
+    Q = quadratic_cost_hessian(rt)
+    assert Q.shape == (n, n) and np.abs(Q - Q.T).max() == 0.0 and np.abs(quadratic_cost_hessian(rebalance_sums(rt)) - Q).max() <= 1e-10
+    lam = np.linalg.eigvalsh(Q)
+    assert lam[0] > 1.0 and lam[-1] < 2000.0  # positive definite: the nominal-posture term reaches every configuration
+    rng = np.random.default_rng(3)
+
+    def grad(x, p):
+        return tape_ref.reverse(rt, tape_ref.forward(rt, x, p), {int(rt.out_cost): 1.0})
+
+    for p in (g["p"][0], rng.uniform(-1, 1, tp.np_)):  # the block does not depend on the parameters either
+        x = rng.uniform(-1, 1, n)
+        g0 = grad(x, p)
+        for j in rng.choice(n, 12, replace=False):
+            e = np.zeros(n)
+            e[j] = 1.0
+            assert np.abs(grad(x + e, p) - g0 - Q[:, j]).max() <= 1e-9 * lam[-1]
+    H0 = quadratic_cost_metric(rt)
+    assert np.abs(H0 @ Q - np.eye(n)).max() <= 1e-10
+    # a cost without a quadratic block, and a problem the product would be too big for: no metric
+    assert quadratic_cost_metric(rt, max_n=64) is None
+    x0 = np.zeros(tp.nx)
+    x0[:140] = np.tile(g["q0"], 20)
+    for i in (0, 3):
+        plain = tape_ref.solve_tape_al(rt, x0[el.free], g["p"][i], lbfgs=32, rho0=1000.0, max_iter=5000)
+        with_h0 = tape_ref.solve_tape_al(rt, x0[el.free], g["p"][i], lbfgs=32, rho0=1e4, max_iter=5000, h0=H0)
+        assert plain["status"] == 0 and with_h0["status"] == 0 and with_h0["evals"] <= 0.4 * plain["evals"], (plain["evals"], with_h0["evals"])
+        assert abs(with_h0["f"] - plain["f"]) <= 1e-6 * plain["f"] and abs(with_h0["f"] - g["f"][i]) <= 1e-5 * g["f"][i]
+
+
+@pytest.mark.gpu
+def test_cost_metric_on_the_gpu_same_optima_a_fraction_of_the_evaluations(hip_lib):
+    """Default handle of the planner (affine rows eliminated, metric from the cost, penalty from 1e4) against the same handle without the metric
+    (solver option metric=False: round 5's 32 pairs at penalty 1000): same optima (interior-point goldens, literal rows), a third of the evaluations at most."""
+    from examples.simple_joint_space_planner import setup_solver
+
+    g = np.load(os.path.join(GOLDEN, "planner_golden.npz"))
+    nlp = JointSpacePlannerNLP(OracleRobot(MED7_KIN))
+    rng = np.random.default_rng(11)
+    B = 64
+    idx = np.arange(B) % len(g["p"])
+    P = g["p"][idx].copy()
+    P[4:, :14] += rng.uniform(-0.05, 0.05, (B - 4, 14))
+    P[4:, 14:17] += rng.uniform(-0.02, 0.02, (B - 4, 3))
+    res = {}
+    for tag, opts in (("metric", {}), ("plain", {"metric": False})):
+        robot, solver = setup_solver(solver_options={"max_iter": 400000, **opts})
+        name = robot.get_name()
+        solver.reset_parameters_batch({"nominal_joint_state": P[:, :7], "current_joint_state": P[:, 7:14], "position_goal": P[:, 14:17], "orientation_goal": P[:, 17:]})
+        solver.reset_initial_seed_batch({f"{name}/q/x": np.stack([np.tile(g["q0"].reshape(-1, 1), (1, 20))] * B)})
+        sols = solver.solve_batch()
+        st = solver.stats()
+        assert st["success"], (tag, st["status"])
+        assert solver.backend.flag("tape_wave") >= 1 and solver.backend.flag("tape_metric") == (1 if tag == "metric" else 0)
+        res[tag] = (np.stack([solver.opt.decision_variables.dict2vec(s_) for s_ in sols]), st["f"].copy(), st["iterations"].copy(), solver.backend.solve_ms())
+        solver.backend.close()
+    xm, fm, itm, ms_m = res["metric"]
+    xp, fp, itp, ms_p = res["plain"]
+    print("planner, 64 instances: evaluations with the cost metric p50 %d max %d, without p50 %d max %d; device ms %.1f against %.1f"
+          % (np.median(itm), itm.max(), np.median(itp), itp.max(), ms_m, ms_p))
+    assert np.median(itm) <= 0.35 * np.median(itp) and itm.max() <= 150
+    for b in range(B):
+        assert abs(fm[b] - fp[b]) <= 1e-6 * fp[b] and np.abs(xm[b] - xp[b]).max() <= 2e-3
+        x, p = xm[b], P[b]
+        assert abs(nlp.f(x, p) - fm[b]) <= 1e-10 and np.abs(nlp.a(x, p)).max() <= 1e-12 and np.abs(nlp.h(x, p)).max() <= 1e-8 and nlp.g(x, p).min() >= -1e-9
+    for b in range(4):
+        assert abs(fm[b] - g["f"][b]) <= 1e-5 * g["f"][b]

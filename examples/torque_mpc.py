@@ -14,10 +14,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import optas_amd as optas  # noqa: E402
 
 
-def build_problem(T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, effort=None, velocity_limits=None):
-    robot = optas.RobotModel.builtin("med7", time_derivs=[0, 1, 2])
-    name, link, n = robot.get_name(), "lbr_link_ee", robot.ndof
-    eff = np.array([j.limit.effort for j in robot.urdf.joints if j.type != "fixed"]) if effort is None else np.full(n, float(effort))
+def build_problem(T=30, dt=0.1, w_path=1000.0, w_vel=0.1, w_tau=1e-4, effort=None, velocity_limits=None, robot=None, link="lbr_link_ee"):
+    """robot / link: another arm (any chain of 2 .. 7 revolute joints behind a fixed one that RobotModel.rnea accepts) instead of the med7."""
+    if robot is None:
+        robot = optas.RobotModel.builtin("med7", time_derivs=[0, 1, 2])
+    name, n = robot.get_name(), robot.ndof
+    eff = np.array([j.limit.effort for j in robot.urdf.joints if j.type != "fixed"]) if effort is None else np.broadcast_to(np.asarray(effort, dtype=float), (n,)).copy()
     tau = optas.TaskModel("tau", n, time_derivs=[0], dlim={0: [-eff, eff]})
     builder = optas.OptimizationBuilder(T, robots=[robot], tasks=[tau], derivs_align=True)
     qc = builder.add_parameter("qc", n)

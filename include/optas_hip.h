@@ -237,7 +237,7 @@ typedef struct oh_ik_desc {
 
 typedef struct oh_torque_desc {
   int T;          /* knots, 2..OH_MAX_T */
-  int ndof;       /* 7: every joint of the chain is actuated and the inverse-dynamics tables have ndof + 1 bodies */
+  int ndof;       /* 2 .. 7: every joint of the chain is actuated and the inverse-dynamics tables have ndof + 1 bodies */
   double dt;      /* Euler step of both integrate_model_states calls */
   double w_path;  /* weight of sum ||p_link(q_t) - goal_t||^2 */
   double w_vel;   /* weight of sum ||dq_t||^2 (>= 0) */

@@ -803,7 +803,7 @@ static bool solver_chain_ok(const oh_chain& c);
 extern "C" int oh_create_torque(const oh_torque_desc* desc, oh_handle** out) {
   if (!desc || !out) return fail(OH_ERR_INVALID, "oh_create_torque: null argument");
   *out = nullptr;
-  if (desc->ndof != 7) return fail(OH_ERR_INVALID, "oh_create_torque: kernels are instantiated for ndof 7");
+  if (desc->ndof < 2 || desc->ndof > 7) return fail(OH_ERR_INVALID, "oh_create_torque: kernels are instantiated for ndof 2 .. 7");
   if (desc->T < 2 || desc->T > OH_MAX_T) return fail(OH_ERR_INVALID, "oh_create_torque: T must be in [2, OH_MAX_T]");
   if (!(desc->dt > 0.0) || !(desc->w_tau > 0.0) || !(desc->w_path >= 0.0) || !(desc->w_vel >= 0.0))
     return fail(OH_ERR_INVALID, "oh_create_torque: dt and w_tau must be positive, w_path and w_vel non-negative");

@@ -442,7 +442,7 @@ OH_DEV void rnea_vw3(const oh_dynamics* __restrict__ dy, const double* qs, const
 template <int N>
 struct IdsWs {
   // A unit's LDS in k_tq_eval3, 277 doubles for N = 7 (nine units: 19.9 KB, so that two blocks share a SIMD's quarter of the CU's 160 KB):
-  static constexpr int TW = 4 * N;               // pitch of the per-body slots: 28 = m, h (3), A (6), Xi (9), p (3), W (6); once phase 3 has consumed body
+  static constexpr int TW = 28;                  // pitch of the per-body slots: 28 = m, h (3), A (6), Xi (9), p (3), W (6) whatever the chain length; once phase 3 has consumed body
                                                  // m its slot takes row m of d tau / dz (3 N entries) and, behind it, lane m's row coefficients (RW)
   static constexpr int BD = 0;
   static constexpr int RW = 3 * N + 1;           // offset inside a slot: cf, cb, dw, bar, nrel, viol (6 doubles; the slot has 28 - 22 = 6 to spare)
@@ -452,6 +452,7 @@ struct IdsWs {
   static constexpr int RW2 = QS + 24;            // cmpl[N], fsum[N]
   static constexpr int SIZE = (RW2 + 2 * N) | 1;  // odd: the units of a wavefront land in different banks
   static_assert(3 * (3 * N + 1) <= 6 * N + 24, "the rows of d p_link / dz take the place of the screws and of (q | dq | ddq)");
+  static_assert(3 * N + 1 + 6 <= TW, "row m of d tau / dz and the six row coefficients behind it fit the slot of body m");
 };
 OH_DEV void mcross6(const double* x, const double* y, double* o) {  // motion x motion
   double t[3];
@@ -1747,7 +1748,7 @@ OH_DEV double row_sum8(double v) {  // sum over the 8 lanes of a row (lane = 8 r
 #endif
 template <int N, bool VEL = false>
 __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, TqBuffers D) {
-  static_assert(N == 7, "the lane layout is 8 rows x 8 columns: 7 joints and the vector column");
+  static_assert(N >= 1 && N <= 7, "the lane layout is 8 rows x 8 columns: up to 7 joints and the vector column (column N)");
   constexpr int NX = 2 * N, NZ = 3 * N;
   extern __shared__ double du_dyn[];  // [T][8]: the control steps of the unit step
   const int T = P.T;
@@ -2049,7 +2050,7 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
       const double s_lo = s_n[0], s_up = s_n[1], v_lo = s_n[2], v_up = s_n[3];
       if (t + 1 < T) fetch_knot(t + 1);
       // du_r = -k_r - sum_c (K_q[r][c] dq_c + K_d[r][c] dd_c): the vector lane contributes k_r (its kq slot)
-      const double part = c < N ? fma(kq, dq, kd * dd) : kq;
+      const double part = c < N ? fma(kq, dq, kd * dd) : (c == N ? kq : 0.0);  // (columns beyond N exist on chains shorter than seven joints: idle lanes)
       const double du_r = -row_sum8(r < N ? part : 0.0);
       const double du_c = __shfl(du_r, 8 * c);  // du of joint c, from row c
       if (r == 0 && c < N) du_all[t][c] = du_c;
@@ -2197,6 +2198,17 @@ __global__ __launch_bounds__(64) void k_tq_finalize(TqParams P, TqBuffers D, dou
 
 }  // namespace
 
+// The solver's kernels by chain length: 2 .. 7 joints (k_tq_step's lane layout is 8 x 8: N joints and the vector column)
+#define OH_TQ_DISPATCH(n, C) \
+  switch (n) {               \
+    case 2: C(2); break;     \
+    case 3: C(3); break;     \
+    case 4: C(4); break;     \
+    case 5: C(5); break;     \
+    case 6: C(6); break;     \
+    case 7: C(7); break;     \
+    default: return false;   \
+  }
 bool oh_launch_rnea_jac(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, int n, const double* q, const double* qd, const double* qdd, double* J) {
 #define OH_RJ(NN)                                                                                                                         \
   case NN + 1:                                                                                                                            \
@@ -2220,30 +2232,40 @@ bool oh_launch_rnea_hess(hipStream_t s, const oh_dynamics* d_dyn, int nbodies, i
 #undef OH_RH
 }
 bool oh_launch_tq_setup(hipStream_t s, const TqParams& P, const TqBuffers& D, const double* x0, const double* p) {
-  if (P.N != 7) return false;
-  hipLaunchKernelGGL(k_tq_setup<7>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p);
+#define C(NN) hipLaunchKernelGGL(k_tq_setup<NN>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x0, p)
+  OH_TQ_DISPATCH(P.N, C)
+#undef C
   return true;
 }
 void oh_launch_tq_list(hipStream_t s, const TqBuffers& D) { hipLaunchKernelGGL(k_tq_list, dim3((D.B + 255) / 256), dim3(256), 0, s, D); }
 bool oh_launch_tq_eval(hipStream_t s, const TqParams& P, const TqBuffers& D) {
-  if (P.N != 7) return false;
   const long long units = (long long)D.n_run * P.T;
   // (the variants with joint-velocity rows are instantiations of their own: as a run-time branch the rows cost k_tq_eval3 21 % at 8192 instances)
-  const dim3 grid((unsigned)((units + 8) / 9));
-  if (P.jac_closed_form) {
-    if (P.vel) hipLaunchKernelGGL((k_tq_eval3<7, true, true>), grid, dim3(64), 0, s, P, D);
-    else hipLaunchKernelGGL((k_tq_eval3<7, false, true>), grid, dim3(64), 0, s, P, D);
-  } else {
-    if (P.vel) hipLaunchKernelGGL((k_tq_eval3<7, true, false>), grid, dim3(64), 0, s, P, D);
-    else hipLaunchKernelGGL((k_tq_eval3<7, false, false>), grid, dim3(64), 0, s, P, D);
+  // a wavefront holds 64 / N units (nine of the 7-joint arm)
+#define C(NN)                                                                                             \
+  {                                                                                                       \
+    const dim3 grid((unsigned)((units + (64 / NN) - 1) / (64 / NN)));                                     \
+    if (P.jac_closed_form) {                                                                              \
+      if (P.vel) hipLaunchKernelGGL((k_tq_eval3<NN, true, true>), grid, dim3(64), 0, s, P, D);            \
+      else hipLaunchKernelGGL((k_tq_eval3<NN, false, true>), grid, dim3(64), 0, s, P, D);                 \
+    } else {                                                                                              \
+      if (P.vel) hipLaunchKernelGGL((k_tq_eval3<NN, true, false>), grid, dim3(64), 0, s, P, D);           \
+      else hipLaunchKernelGGL((k_tq_eval3<NN, false, false>), grid, dim3(64), 0, s, P, D);                \
+    }                                                                                                     \
+    hipLaunchKernelGGL(k_tq_curv<NN>, grid, dim3(64), 0, s, P, D); /* exits at once where no instance takes Newton steps */ \
   }
-  hipLaunchKernelGGL(k_tq_curv<7>, dim3((unsigned)((units + 8) / 9)), dim3(64), 0, s, P, D);  // exits at once where no instance takes Newton steps
+  OH_TQ_DISPATCH(P.N, C)
+#undef C
   return true;
 }
 bool oh_launch_tq_step(hipStream_t s, const TqParams& P, const TqBuffers& D) {
-  if (P.N != 7) return false;
-  if (P.vel) hipLaunchKernelGGL((k_tq_step<7, true>), dim3(D.n_run), dim3(64), sizeof(double) * 8 * P.T, s, P, D);
-  else hipLaunchKernelGGL((k_tq_step<7>), dim3(D.n_run), dim3(64), sizeof(double) * 8 * P.T, s, P, D);
+#define C(NN)                                                                                                              \
+  {                                                                                                                        \
+    if (P.vel) hipLaunchKernelGGL((k_tq_step<NN, true>), dim3(D.n_run), dim3(64), sizeof(double) * 8 * P.T, s, P, D);      \
+    else hipLaunchKernelGGL((k_tq_step<NN>), dim3(D.n_run), dim3(64), sizeof(double) * 8 * P.T, s, P, D);                  \
+  }
+  OH_TQ_DISPATCH(P.N, C)
+#undef C
   return true;
 }
 // ---- receding horizon, resident on the device (oh_tq_rollout, round 5) ----------------------------------------------------------------------
@@ -2295,8 +2317,9 @@ void oh_launch_tq_advance(hipStream_t s, int B, int T, int N, int advance, const
   hipLaunchKernelGGL(k_tq_advance, dim3((B + 63) / 64), dim3(64), 0, s, B, T, N, advance, x, state_next, tau0);
 }
 bool oh_launch_tq_finalize(hipStream_t s, const TqParams& P, const TqBuffers& D, double* x, double* f, double* kkt, int* iters, int* status, double* mult) {
-  if (P.N != 7) return false;
-  hipLaunchKernelGGL(k_tq_finalize<7>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x, f, kkt, iters, status, mult);
+#define C(NN) hipLaunchKernelGGL(k_tq_finalize<NN>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, x, f, kkt, iters, status, mult)
+  OH_TQ_DISPATCH(P.N, C)
+#undef C
   return true;
 }
 

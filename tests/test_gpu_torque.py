@@ -367,7 +367,7 @@ def test_batch_solved_in_two_parts_on_two_streams_is_invisible(hip_lib, ctx):
 def test_abi_errors(hip_lib, ctx):
     med7, robot, g = ctx
     lib = hip_lib
-    d = _lib.oh_torque_desc(T=30, ndof=6, dt=0.1, w_path=1.0, w_vel=0.0, w_tau=1.0)
+    d = _lib.oh_torque_desc(T=30, ndof=8, dt=0.1, w_path=1.0, w_vel=0.0, w_tau=1.0)  # (2 .. 7 joints since the end of round 5: tests/test_gpu_torque_chain_lengths.py)
     h = C.c_void_p()
     assert lib.oh_create_torque(C.byref(d), C.byref(h)) == _lib.OH_ERR_INVALID and b"ndof" in lib.oh_last_error()
     d.ndof = 7

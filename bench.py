@@ -50,12 +50,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 #              (V: the three Householder vectors of the null-space basis, 3N - 3 doubles; Z itself is rebuilt in registers.
 #               model: end-effector position and Jp Z of the knot, what the next retraction's position target is predicted from)
 #   k_couple : read V_t 18 (V_{t+1} is an L2 hit), q 3x7, g 7, phi 1 ; write E 16, gt 4, merit 1 = 68 doubles
-#   k_step   : read merit 1, cv 1, E 16, Dr 10, gt 4+4 ; write+read gains 20+20 ; write z 4  = 80 doubles
-BYTES = {"k_eval": 103 * 8, "k_couple": 68 * 8, "k_step": 80 * 8}
+#   k_step   : read merit 1, cv 1, E 16, Dr 10, gt 4 ; write+read gains 20+20 ; write z 4  = 76 doubles (80 until the end of round 5: the forward pass read gt again)
+BYTES = {"k_eval": 103 * 8, "k_couple": 68 * 8, "k_step": 76 * 8}
 # Round 3, coupling folded into evaluation and sweep (oh_get_flag "fuse_couple"; no k_couple launch):
 #   k_eval   : + the two neighbours' retracted knots (2 x 7 read); G instead of g and the merit share instead of phi out (same count) = 117 doubles
-#   k_step   : read merit 1, cv 1, V 18, G 7, Dr 10 ; write+read gains 20+20 ; write+read gt 4+4 ; write z 4 = 89 doubles
-BYTES_ZC = {"k_eval": 117 * 8, "k_couple": 0, "k_step": 89 * 8}
+#   k_step   : read merit 1, cv 1, V 18, G 7, Dr 10 ; write+read gains 20+20 ; write z 4 = 81 doubles
+#              (89 until the end of round 5: the reduced gradients gt went out to the forward pass and came back, 4 + 4, for the directional derivative g.z --
+#               which is -sum_t |L_t^-1 r_t|^2, a by-product of the backward substitutions)
+BYTES_ZC = {"k_eval": 117 * 8, "k_couple": 0, "k_step": 81 * 8}
 BYTES_FKJAC = 448  # q 56 B in, pose 56 B + J 336 B out
 
 

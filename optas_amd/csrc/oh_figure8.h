@@ -475,7 +475,8 @@ OH_DEV void couple_knot(const double kappa, const bool last, const double (&qm)[
 // and the gains of knot t+1 (Kmat row-major [row*NZ+col], kv) for z_{t+1} = -(kv + Kmat z_t).
 template <int NZ>
 OH_DEV bool riccati_back(double (&S)[NZ * (NZ + 1) / 2], double (&rd)[NZ], double (&rn)[NZ], const double (&E)[NZ * NZ],
-                         const double (&Ht)[NZ * (NZ + 1) / 2], const double (&gt)[NZ], double (&Kmat)[NZ * NZ], double (&kv)[NZ]) {
+                         const double (&Ht)[NZ * (NZ + 1) / 2], const double (&gt)[NZ], double (&Kmat)[NZ * NZ], double (&kv)[NZ], double* quad = nullptr) {
+  // quad (optional) += r_{t+1}^T S_{t+1}^{-1} r_{t+1} = |L^{-1} r_{t+1}|^2: summed over the knots it is g^T M^{-1} g = -g.z of the step the sweep solves for
   const bool ok = chol_rcp<NZ>(S, rd, 1e-12);
   double X[NZ][NZ];  // X = L^{-1} E^T, column a from row a of E
 #pragma unroll
@@ -491,6 +492,12 @@ OH_DEV bool riccati_back(double (&S)[NZ * (NZ + 1) / 2], double (&rd)[NZ], doubl
 #pragma unroll
   for (int a = 0; a < NZ; ++a) u[a] = rn[a];
   fsub_rcp<NZ>(S, rd, u);
+  if (quad) {
+    double qs = 0.0;
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) qs = fma(u[a], u[a], qs);
+    *quad += qs;
+  }
 #pragma unroll
   for (int a = 0; a < NZ; ++a) kv[a] = u[a];
   bsub_rcp<NZ>(S, rd, kv);

@@ -722,9 +722,11 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
   double stat = 0.0;
   double S[NP], rd[NZ], rn[NZ];
   bool factored = false;
+  double quad = 0.0;  // plain handles: g^T M^{-1} g, by-product of the backward substitutions (see step_instance_zc)
   for (int attempt = 0; attempt < 40; ++attempt) {
     bool ok = true;
     stat = 0.0;
+    quad = 0.0;
     // last knot: S = Dr + (kap2 + mu) I, r = gt
     {
       const int t = T - 1;
@@ -772,7 +774,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
             Ht[tri(a, a)] += 2.0 * kap2 + mu;
           }
           double Kmat[NZ * NZ], kv[NZ];
-          ok = riccati_back<NZ>(S, rd, rn, E, Ht, gt, Kmat, kv) && ok;
+          ok = riccati_back<NZ>(S, rd, rn, E, Ht, gt, Kmat, kv, GUARD ? nullptr : &quad) && ok;
 #pragma unroll
           for (int a = 0; a < NZ; ++a) rb_st(KNOT(D.kvec, t + 1, NZ), RB(a), lb, kv[a]);
 #pragma unroll
@@ -843,8 +845,13 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
 #pragma unroll
     for (int a = 0; a < NZ; ++a) zz[a] = -rn[a];
     fsub_rcp<NZ>(S, rd, zz);
+    if constexpr (!GUARD) {
+#pragma unroll
+      for (int a = 0; a < NZ; ++a) quad = fma(zz[a], zz[a], quad);  // the first free knot's share
+    }
     bsub_rcp<NZ>(S, rd, zz);
-    double gd = 0.0, z2 = 0.0;
+    // plain handles: the directional derivative g.z = -g^T M^{-1} g comes out of the backward sweep, the reduced gradients are not read a second time
+    double gd = GUARD ? 0.0 : -quad, z2 = 0.0;
     // Over-relaxation in the Gauss-Newton phase of the hybrid scheme: the tracking residual does not vanish (f* ~ 8), Gauss-Newton
     // over-estimates the curvature along the valley and its full steps, although accepted with mu = 0, crawl (10 of the 17 steps of a
     // typical instance go by between the first step and the switch to exact curvature).  Taking alpha z instead (alpha = 1.5 from the
@@ -861,8 +868,10 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
 #pragma unroll
         for (int i = 0; i < NZ * NZ; ++i) fK[j][i] = rb_ld(KNOT(D.Kmat, t, NZ * NZ), RB(i), lb);
       }
+      if constexpr (GUARD) {
 #pragma unroll
-      for (int a = 0; a < NZ; ++a) fg[j][a] = rb_ld(KNOT(gtc, t, NZ), RB(a), oG);
+        for (int a = 0; a < NZ; ++a) fg[j][a] = rb_ld(KNOT(gtc, t, NZ), RB(a), oG);
+      }
     };
 #pragma unroll
     for (int j = 0; j < PFF; ++j)
@@ -874,7 +883,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
         if (t < T) {
           double gtt[NZ];
 #pragma unroll
-          for (int a = 0; a < NZ; ++a) gtt[a] = fg[j][a];
+          for (int a = 0; a < NZ; ++a) gtt[a] = GUARD ? fg[j][a] : 0.0;
           if (t > P.t0) {
             double zn[NZ];
 #pragma unroll
@@ -891,7 +900,7 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
 #pragma unroll
           for (int a = 0; a < NZ; ++a) {
             rb_st(KNOT(D.zstep, t, NZ), RB(a), lb, alpha * zz[a]);
-            gd += gtt[a] * zz[a];
+            if constexpr (GUARD) gd += gtt[a] * zz[a];
             z2 += zz[a] * zz[a];
           }
         }
@@ -915,7 +924,9 @@ OH_DEV bool step_instance(const FigParams& P, const FigBuffers& D, const int b, 
 // so.  Here the sweep rebuilds Z_t from its Householder vectors (the 18 doubles k_couple read too), keeps Z_{t+1} in a lane-private column
 // of LDS (zl: [N * NZ][64], one 8-byte word per lane and row -> conflict-free) and forms E_t and gt_t with couple_knot's own loop, in its
 // operation order: the iterates are those of the three-kernel path.  G_t and the merit share come from the evaluation (eval_unit<.., ZC>).
-// Per knot the backward pass reads V 18, G 7, Dr 10 (35 doubles; E 16, Dr 10, gt 4 before) and writes gt for the forward pass.
+// Per knot the backward pass reads V 18, G 7, Dr 10 (35 doubles; E 16, Dr 10, gt 4 before).  End of round 5: the reduced gradients gt_t no longer travel to
+// the forward pass and back (8 of the sweep's 89 doubles per unit): all the forward pass did with them was the directional derivative g.z of the step, and that is
+// -g^T M^{-1} g = -sum_t |L_t^{-1} r_t|^2, a by-product of the backward substitutions (riccati_back's quad).
 template <int N>
 OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int b, const int ts, double* __restrict__ zl) {
   constexpr int NZ = N - 3;
@@ -940,11 +951,9 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
   // (Gfull[] trades places with the compaction's spare array: the lower of the two slots is the base, see ensure_capacity)
   const double* __restrict__ Gc = D.Gfull[0] < D.Gfull[1] ? D.Gfull[0] : D.Gfull[1];
   const double* __restrict__ Drc = D.Dr[0];
-  double* __restrict__ gtc = D.gt[0];
   const unsigned oV = lb + (cur ? (unsigned)((const char*)D.Z[1] - (const char*)D.Z[0]) : 0u);
   const unsigned oGf = lb + (unsigned)((const char*)D.Gfull[cur] - (const char*)Gc);
   const unsigned oD = lb + (cur ? (unsigned)((const char*)D.Dr[1] - (const char*)D.Dr[0]) : 0u);
-  const unsigned oG = lb + (cur ? (unsigned)((const char*)D.gt[1] - (const char*)D.gt[0]) : 0u);
   double stat = 0.0;
   double S[NP], rd[NZ], rn[NZ];
   bool factored = false;
@@ -1007,9 +1016,11 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
       for (int a = 0; a < NZ; ++a) zl[(k * NZ + a) * 64] = Zt[k][a];
     }
   };
+  double quad = 0.0;  // g^T M^{-1} g of the system being solved (see above)
   for (int attempt = 0; attempt < 40; ++attempt) {
     bool ok = true;
     stat = 0.0;
+    quad = 0.0;
     // knot T - 1 - i travels in ring slot i % PF
 #pragma unroll
     for (int j = 0; j < PF; ++j)
@@ -1026,7 +1037,6 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
         S[tri(a, a)] += kap2 + mu;
         rn[a] = gt[a];
         stat = fmax(stat, fabs(gt[a]));
-        rb_st(KNOT(gtc, T - 1, NZ), RB(a), oG, gt[a]);
       }
     }
     for (int tb = T - 2; tb >= P.t0; tb -= PF) {
@@ -1045,10 +1055,9 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
           for (int a = 0; a < NZ; ++a) {
             stat = fmax(stat, fabs(gt[a]));
             Ht[tri(a, a)] += 2.0 * kap2 + mu;
-            rb_st(KNOT(gtc, t, NZ), RB(a), oG, gt[a]);
           }
           double Kmat[NZ * NZ], kv[NZ];
-          ok = riccati_back<NZ>(S, rd, rn, E, Ht, gt, Kmat, kv) && ok;
+          ok = riccati_back<NZ>(S, rd, rn, E, Ht, gt, Kmat, kv, &quad) && ok;
 #pragma unroll
           for (int a = 0; a < NZ; ++a) rb_st(KNOT(D.kvec, t + 1, NZ), RB(a), lb, kv[a]);
 #pragma unroll
@@ -1085,10 +1094,13 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
 #pragma unroll
     for (int a = 0; a < NZ; ++a) zz[a] = -rn[a];
     fsub_rcp<NZ>(S, rd, zz);
+#pragma unroll
+    for (int a = 0; a < NZ; ++a) quad = fma(zz[a], zz[a], quad);  // the first free knot's share
     bsub_rcp<NZ>(S, rd, zz);
-    double gd = 0.0, z2 = 0.0;
+    const double gd = -quad;
+    double z2 = 0.0;
     const double alpha = (P.hessian == OH_HESSIAN_HYBRID && stat > P.hyb_switch && iters >= P.relax_from) ? P.relax : 1.0;
-    double fK[NZ * NZ], fk[NZ], fg[NZ];
+    double fK[NZ * NZ], fk[NZ];
     auto fetchf = [&](const int t) {
       if (t > P.t0) {
 #pragma unroll
@@ -1096,14 +1108,9 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
 #pragma unroll
         for (int i = 0; i < NZ * NZ; ++i) fK[i] = rb_ld(KNOT(D.Kmat, t, NZ * NZ), RB(i), lb);
       }
-#pragma unroll
-      for (int a = 0; a < NZ; ++a) fg[a] = rb_ld(KNOT(gtc, t, NZ), RB(a), oG);
     };
     fetchf(P.t0);
     for (int t = P.t0; t < T; ++t) {
-      double gtt[NZ];
-#pragma unroll
-      for (int a = 0; a < NZ; ++a) gtt[a] = fg[a];
       if (t > P.t0) {
         double zn[NZ];
 #pragma unroll
@@ -1120,7 +1127,6 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
 #pragma unroll
       for (int a = 0; a < NZ; ++a) {
         rb_st(KNOT(D.zstep, t, NZ), RB(a), lb, alpha * zz[a]);
-        gd += gtt[a] * zz[a];
         z2 += zz[a] * zz[a];
       }
     }

@@ -590,6 +590,7 @@ def solve_structured_lm(prob, qc, Q0=None, max_iter=300, tol=1e-6, tol_feas=1e-9
             break
         # over-relaxation of Gauss-Newton steps in the crawl phase of the hybrid scheme (step_instance in csrc/oh_figure8_units.h)
         alpha = overrelax if (hessian == "hybrid" and not guard and stat > hyb_switch and iters >= overrelax_from) else 1.0
+        # (plain handles, end of round 5: the kernels take g.z as -g^T M^-1 g = -sum_t |L_t^-1 r_t|^2 off their backward sweep -- the same number to rounding)
         gd_, z2_ = float(np.sum(cur["gt"] * z)), float(np.sum(z * z))
         pred = -alpha * gd_ + 0.5 * alpha * alpha * (gd_ + mu * z2_)
         z = alpha * z

@@ -273,3 +273,30 @@ def test_cost_metric_on_the_gpu_same_optima_a_fraction_of_the_evaluations(hip_li
         assert abs(nlp.f(x, p) - fm[b]) <= 1e-10 and np.abs(nlp.a(x, p)).max() <= 1e-12 and np.abs(nlp.h(x, p)).max() <= 1e-8 and nlp.g(x, p).min() >= -1e-9
     for b in range(4):
         assert abs(fm[b] - g["f"][b]) <= 1e-5 * g["f"][b]
+
+
+@pytest.mark.gpu
+def test_cost_metric_on_the_thread_per_instance_evaluator(hip_lib):
+    """The same metric on the other evaluator of the limited-memory regime (one thread per instance, instruction arrays interpreted: what a tape takes whose
+    registers fit neither the LDS nor the wavefront schedule, option tape_wave = 0): r = H0 q through the work array the dense form uses for H y.  Same optima as
+    the wavefront evaluator, evaluation counts of the same size."""
+    from examples.simple_joint_space_planner import setup_solver
+
+    g = np.load(os.path.join(GOLDEN, "planner_golden.npz"))
+    P, B = g["p"], len(g["p"])
+    res = {}
+    for tag, opts in (("wave", {}), ("thread", {"jit": False, "options": {"tape_wave": 0}})):
+        robot, solver = setup_solver(solver_options={"max_iter": 400000, **opts})
+        name = robot.get_name()
+        solver.reset_parameters_batch({"nominal_joint_state": P[:, :7], "current_joint_state": P[:, 7:14], "position_goal": P[:, 14:17], "orientation_goal": P[:, 17:]})
+        solver.reset_initial_seed_batch({f"{name}/q/x": np.stack([np.tile(g["q0"].reshape(-1, 1), (1, 20))] * B)})
+        solver.solve_batch()
+        st = solver.stats()
+        assert st["success"], (tag, st["status"])
+        assert solver.backend.flag("tape_metric") == 1 and (solver.backend.flag("tape_wave") >= 1) == (tag == "wave")
+        res[tag] = (st["f"].copy(), st["iterations"].copy())
+        solver.backend.close()
+    print("planner with the cost metric: evaluations wavefront evaluator", res["wave"][1].tolist(), "thread per instance", res["thread"][1].tolist())
+    assert np.all(np.abs(res["thread"][0] - res["wave"][0]) <= 1e-6 * res["wave"][0]) and res["thread"][1].max() <= 150
+    for b in range(B):
+        assert abs(res["thread"][0][b] - g["f"][b]) <= 1e-5 * g["f"][b]

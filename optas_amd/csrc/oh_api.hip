@@ -175,7 +175,7 @@ static double optv(const oh_handle* h, const char* name, double dflt) {
 struct OptDoc { const char* name; double dflt; };
 // map-backed options and their defaults (field-backed ones are handled in set_option_impl / oh_get_option)
 static const OptDoc OPT_TABLE[] = {
-    {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},         {"settle_k", 1.0},   {"al_fuse", 1},   {"streams", 2},         {"split_min", 131072},  {"tq_split_min", 1024}, {"free_split_min", 256},
+    {"check_every", 1},        {"row_pad", 13},          {"retract_min", 1e-13}, {"hyb_switch", 1e-5},   {"relax", 1.5},          {"relax_from", 4},         {"settle_k", 1.0},   {"al_fuse", 1},   {"streams", 2},         {"split_min", 65536},  {"tq_split_min", 1024}, {"free_split_min", 256},
     {"free_bb", 1},            {"free_persist", -1},     {"free_cp_max", 512},   {"pm_wave_max", 20480}, {"qp_mode", -1},         {"tape_lds_max", 1 << 30},
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.4},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
@@ -1538,7 +1538,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (!h->is_peer) h->split_parts.clear();
   if (!h->is_peer && !h->profiling && spec_applies(h) && optv(h, "batch_invariant", 0.0) == 0.0) {
     const int S = std::min(8, (int)optv(h, "streams", 2.0));
-    if (S >= 2 && B >= (int)optv(h, "split_min", 131072.0) && B / S >= 4096 && stage_fits(h, B)) {  // (a batch beyond oh_max_batch is refused below, as ever)
+    if (S >= 2 && B >= (int)optv(h, "split_min", 65536.0) && B / S >= 4096 && stage_fits(h, B)) {  // (a batch beyond oh_max_batch is refused below, as ever)
       // (the kernels compiled for the chain are shared: make sure they exist before the parts look for them)
       if (!h->spec && !h->spec_failed && h->specialize != OH_SPECIALIZE_NEVER && oh_specialize(h) != OH_OK) h->spec_failed = true;
       return solve_split(h, S, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(NT) void k_tape_wave(TapeParams T, WaveSchedDev S, 
   int why = EV_START, ls = 0;
   const double* xs = X;
   double* gout = G;
-  double slope = 0.0, alpha = 1.0, slack = 0.0, gg = 0.0;
+  double slope = 0.0, alpha = 1.0, alpha_prev = 1.0, slack = 0.0, gg = 0.0;
   for (;;) {
     double f_, c_, m_;
     const double v_ = ev.phi(xs, gout, rho, &f_, &c_, &m_);
@@ -380,6 +380,7 @@ __global__ __launch_bounds__(NT) void k_tape_wave(TapeParams T, WaveSchedDev S, 
         H_is_eye = false;
       }
       for (int k = lane; k < n; k += NT) { X[k] = XT[k]; G[k] = GT[k]; }
+      alpha_prev = alpha;
     } else if (why == EV_AGAIN) {
       if (H_is_eye || evals >= T.max_iter) {  // steepest descent cannot improve: rounding floor
         val_m = v_; fval = f_; cmax = c_; meas = m_;
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(NT) void k_tape_wave(TapeParams T, WaveSchedDev S, 
       for (int k = lane; k < n; k += NT) dm = fmax(dm, fabs(D[k]));
       alpha = fmin(1.0, 1.0 / red.max(dm));
     }
+    if (T.h0 && alpha_prev >= 1e-4 && alpha_prev < 1.0) alpha = fmin(alpha, 4.0 * alpha_prev);  // first trial at four times the last accepted fraction (oh_tape_solver.h)
     slack = 4e-16 * (fmax(1.0, fabs(val_m)) + msum);
     double gp = 0.0;
     for (int k = lane; k < n; k += NT) gp += G[k] * G[k];

@@ -203,6 +203,7 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
     H = np.eye(n) if LB is None else None
     fresh = True  # dense form: H is the identity (nothing measured yet)
     omega, meas_prev = max(tol, 1e-2), np.inf
+    alpha_prev = 1.0
     status = 1
     while True:
         stat = np.abs(grad).max() if n else 0.0
@@ -250,6 +251,8 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
         if LB is not None:
             fresh = LB.is_identity()
         alpha = min(1.0, 1.0 / np.abs(d).max()) if fresh else 1.0
+        if metric and 1e-4 <= alpha_prev < 1.0:  # the last accepted step was a fraction of the metric's unit step: this one is tried at four times that first
+            alpha = min(alpha, 4.0 * alpha_prev)  # (csrc/oh_tape_solver.h; 32 planner instances: 54 -> 40 evaluations)
         ok = False
         for _ in range(40):
             xt = x + alpha * d
@@ -291,6 +294,7 @@ def solve_tape_al(tape, x0, p, tol=1e-6, tol_feas=1e-9, max_iter=2000, rho0=10.0
                 LB.reset()
             fresh = True
             continue
+        alpha_prev = alpha
         sv, yv = xt - x, gt - grad
         sy = float(sv @ yv)
         if trace is not None:

@@ -547,6 +547,29 @@ def main():
         "compactions_per_step": tm["compactions"] / args.steps,
         "fused_coupling": zc,
     }
+    if world == 1 and not args.timed_only:
+        # the same batch with `batch_invariant` (every answer a function of the instance alone, bit for bit): what the option costs, and how many
+        # answers of the default schedule it changes (not part of `value`)
+        be.set_option("batch_invariant", 1)
+        inv_ms = []
+        for _ in range(3):
+            be.solve_device(B, d_x0, d_p, d_x, d_f, d_k, d_it, d_st)
+            inv_ms.append(be.timing()["solve_ms"])
+        f_inv, st_inv = d_f.download(np.float64, (B,)), d_st.download(np.int32, (B,))
+        t_inv = be.timing()
+        be.set_option("batch_invariant", 0)
+        out["batch_invariant"] = {
+            "ms_per_step": float(np.median(inv_ms[1:])),
+            "value": B / (1e-3 * float(np.median(inv_ms[1:]))),
+            "unit": "solves/s",
+            "cost_vs_default": float(np.median(inv_ms[1:])) / (solve_ms_plain / args.steps),
+            "converged_frac": float((st_inv == 0).mean()),
+            "same_optimum_as_default_frac": float((np.abs(f_inv - fvals) <= 1e-9 * np.abs(fvals)).mean()),
+            "instances_with_another_optimum": int((np.abs(f_inv - fvals) > 1e-9 * np.abs(fvals)).sum()),
+            "compactions": t_inv["compactions"],
+            "iterations_launched": t_inv["iterations_launched"],
+            "note": f"device time of one {B}-instance solve with oh_set_option(h, 'batch_invariant', 1): no restarts, no persistent kernel, survivors moved with everything they own (csrc/oh_api.hip:move_everything); bit-identity alone / in a batch / with and without compaction is asserted in tests/test_gpu_options.py",
+        }
     out["pcie_inclusive"] = pcie
     if world == 1 and not args.no_configs and not args.timed_only:
         # the other BASELINE configs at their stated sizes (device ms, convergence, an oracle-graded sample each): tools/bench_configs.py

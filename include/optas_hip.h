@@ -404,9 +404,13 @@ int oh_get_flag(oh_handle* h, const char* name, int* value);
  * these are the library's counterpart for scheduling and experiment knobs -- until round 4 they were OH_* environment variables read inside the
  * library, so two handles of one process could not differ.  Unknown names return OH_ERR_INVALID.  Scheduling options change WHEN work is done and by
  * which kernel, never what is computed, except where noted:
- *   batch_invariant (0)   1: no compaction, no persistent tail kernel: every instance runs the batched launches to the end, and its answer is a
- *                         function of the instance alone, bit for bit, whatever batch it is part of (default path: the same optimum for ~97 % of
- *                         a 262 144 batch, bit-identical only where the same kernels ran).  Costs 1.2-2.7 x device time.
+ *   batch_invariant (0)   1: no restarts, no persistent tail kernel: every instance runs the batched launches to the end, and its answer is a
+ *                         function of the instance alone, bit for bit, whatever batch it is part of (default path: the same optimum for all but a
+ *                         handful of a 262 144 batch, bit-identical only where the same kernels ran).  The batch is still compacted,
+ *                         but only by moving a survivor with everything it owns once invariant_compact_frac (0.65) of the batch is left
+ *                         (0: never; invariant_move_slim / invariant_move_live (1): arrays no kernel carries across launches, and the slot of the
+ *                         judged trial, stay behind), and a large batch is still solved in parts on two streams (invariant_split, 1).
+ *                         Costs 1.3 x device time at 262 144 instances (3.0 x without the moving compaction).
  *   tail_threshold (16384), tail_vel (1), tail_vel_threshold, compaction (1), compact_frac (0.97), compact_sort (1), compact_carry (1),
  *   sparse_check_below (2048), check_every (1), fuse_couple (1), lg_split (1), row_pad (13)            -- figure-eight family scheduling
  *   streams (2), split_min (131072): a batch of the plain orientation-locked family of at least split_min instances is solved in `streams` contiguous parts,

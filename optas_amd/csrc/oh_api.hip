@@ -180,6 +180,7 @@ static const OptDoc OPT_TABLE[] = {
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.4},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
     {"tq_rebuild", 0.9},         {"compact_move_all", 1},  {"tq_curv_late", 1.0},  {"tq_kappa_eps", 10.0}, {"tq_max_back", 3},     {"tq_mu_dec", 1.0 / 3.0},     {"tq_ls_curv", 1},   {"tq_mu_dec_warm", 0.1}, {"tq_curv_lag", 3},
+    {"invariant_compact_frac", 0.65}, {"invariant_split", 1}, {"invariant_move_slim", 1}, {"invariant_move_live", 1},
 };
 static int tape_configure(oh_handle* h);
 static int set_option_impl(oh_handle* h, const std::string& name, double v) {
@@ -197,8 +198,9 @@ static int set_option_impl(oh_handle* h, const std::string& name, double v) {
   else if (name == "specialize") h->specialize = v == 0.0 ? OH_SPECIALIZE_NEVER : (v == 1.0 ? OH_SPECIALIZE_ALWAYS : OH_SPECIALIZE_AUTO);
   else if (name == "tq_check") h->tq_check = v >= 1.0 ? (int)v : 1;
   else if (name == "batch_invariant") {
-    // every instance takes the batched launches to the end, nothing is compacted, nothing handed to the persistent kernel: the path of an instance
-    // is then a function of the instance alone, bit for bit (the price: 1.2 - 2.7 x the device time of a large batch, and small batches pay launches)
+    // every instance takes the batched launches to the end, nothing restarts, nothing is handed to the persistent kernel; the batch is compacted only
+    // by moving a survivor with everything it owns (move_everything): the path of an instance is then a function of the instance alone, bit for bit
+    // (the price: 1.3 x the device time of a 262 144 batch -- 3.0 x before the moving compaction --, and small batches pay launches)
     h->opt[name] = v;
     if (v != 0.0) { h->compaction = false; h->tail_threshold = 0; h->tail_vel = 0; h->opt["free_persist"] = 0; }
     else { h->compaction = true; h->tail_threshold = 16384; h->tail_vel = 1; h->opt.erase("free_persist"); }
@@ -1400,6 +1402,10 @@ static void fill_params(oh_handle* h) {
   P.zc_free = (h->fuse_couple && !d.lock_orientation && !(h->have_guards && h->guards.vel_limits)) ? 1 : 0;
 }
 
+__global__ __launch_bounds__(256) static void k_gather_int(const int* __restrict__ src, int* __restrict__ dst, const int B, const int* __restrict__ newidx) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B && newidx[b] >= 0) dst[newidx[b]] = src[b];
+}
 // Every array of a running orientation-locked handle with inequality rows to its instance's new index (D.newidx from oh_launch_scan_running): both slots
 // of the stage data, the pending step, multipliers, obstacle parameters, every per-instance scalar and flag.  Nothing restarts.
 static int move_everything(oh_handle* h, hipStream_t s, int Bnew) {
@@ -1411,24 +1417,51 @@ static int move_everything(oh_handle* h, hipStream_t s, int Bnew) {
   std::vector<Item> items;
   auto dbl = [&](double* p, int rows) { if (p) items.push_back({p, rows, false}); };
   auto itg = [&](int* p) { if (p) items.push_back({p, 1, true}); };
+  // What a handle's kernels never carry from one launch to the next stays behind: the folded-coupling family (P.zc) keeps no coupling blocks, reduced
+  // gradients or per-knot tracking cost of its own (E, gt, phi: oh_figure8_units.h writes merit[] instead and the sweep rebuilds the rest), the Riccati gains
+  // are written by the backward pass of a sweep and read by the forward pass of the same launch, and a chain without a lead joint has no lead[].
+  const bool zc = h->P.zc != 0, slim = optv(h, "invariant_move_slim", 1.0) != 0.0;
+  // invariant_move_live (plain folded-coupling family only): of the per-slot stage data only the slot of the accepted point travels -- the other slot is the
+  // trial the sweep has just judged: accepted, it IS the accepted slot by now; rejected, it is rewritten by the next evaluation before anything reads it.
+  // The knots themselves travel in both slots (the pinned end knots of a slot are written once, by k_setup).
+  struct Pair { double* a0; double* a1; int rows; };
+  std::vector<Pair> live;
+  const bool live_only = zc && !h->have_guards && optv(h, "invariant_move_live", 1.0) != 0.0;
+  if (live_only) {
+    live.push_back({D.Z[0], D.Z[1], T * (3 * N - 3)}); live.push_back({D.Dr[0], D.Dr[1], T * (NZ * (NZ + 1) / 2)}); live.push_back({D.g[0], D.g[1], T * N});
+    live.push_back({D.cv[0], D.cv[1], T}); live.push_back({D.Gfull[0], D.Gfull[1], T * N}); live.push_back({D.mdl[0], D.mdl[1], T * (3 + 3 * NZ)});
+    live.push_back({D.merit[0], D.merit[1], T});
+  }
   for (int sl = 0; sl < 2; ++sl) {
-    dbl(D.q[sl], T * N); dbl(D.Z[sl], T * (3 * N - 3)); dbl(D.Dr[sl], T * (NZ * (NZ + 1) / 2)); dbl(D.g[sl], T * N); dbl(D.phi[sl], T); dbl(D.cv[sl], T);
-    dbl(D.Gfull[sl], T * N); dbl(D.mdl[sl], T * (3 + 3 * NZ)); dbl(D.E[sl], T * NZ * NZ); dbl(D.gt[sl], T * NZ); dbl(D.merit[sl], T);
+    dbl(D.q[sl], T * N);
+    if (!live_only) {
+      dbl(D.Z[sl], T * (3 * N - 3)); dbl(D.Dr[sl], T * (NZ * (NZ + 1) / 2)); dbl(D.g[sl], T * N); dbl(D.cv[sl], T);
+      dbl(D.Gfull[sl], T * N); dbl(D.mdl[sl], T * (3 + 3 * NZ)); dbl(D.merit[sl], T);
+    }
+    if (!(zc && slim)) { dbl(D.phi[sl], T); dbl(D.E[sl], T * NZ * NZ); dbl(D.gt[sl], T * NZ); }
     dbl(GB.psi[sl], T); dbl(GB.mcv[sl], T);
   }
-  dbl(D.zstep, T * NZ); dbl(D.Kmat, T * NZ * NZ); dbl(D.kvec, T * NZ); dbl(D.lead, T); dbl(D.ref, 12);
+  dbl(D.zstep, T * NZ); dbl(D.ref, 12);
+  if (!(zc && slim)) { dbl(D.Kmat, T * NZ * NZ); dbl(D.kvec, T * NZ); }
+  if (h->chain_host.has_lead || !slim) dbl(D.lead, T);
   for (double* p : {D.fconst, D.f_cur, D.pred, D.mu, D.nun, D.stat, D.feas, D.fpsi, GB.rho, GB.rho_next, GB.omega, GB.meas_prev, GB.meas, GB.ls_gd, GB.ls_q}) dbl(p, 1);
   dbl(GB.lam, T * GP.NC); dbl(GB.lamv, GP.vel ? T * 2 * N : 0); dbl(GB.par, GP.n_links + 4 * GP.n_obs);
   for (int* p : {D.cur, D.first, D.skip, D.polish, D.stale, D.status, D.iters, D.orig, GB.outer, GB.n_outer, GB.ls_count}) itg(p);
   int max_rows = 1;
   for (const Item& it : items) max_rows = it.rows > max_rows ? it.rows : max_rows;
-  const size_t need = sizeof(double) * (size_t)max_rows * Bp;
+  for (const Pair& pr : live) max_rows = pr.rows > max_rows ? pr.rows : max_rows;
+  const size_t need = sizeof(double) * ((size_t)max_rows + 1) * Bp;  // (+ one row: cur in the new order, for the live-slot moves)
   if (need > h->move_scr_bytes) {
     if (h->move_scr) hipFree(h->move_scr);
     h->move_scr = nullptr;
     h->move_scr_bytes = 0;
     HIPCHK(hipMalloc(&h->move_scr, need));
     h->move_scr_bytes = need;
+  }
+  if (!live.empty()) {
+    int* curn = (int*)((double*)h->move_scr + (size_t)max_rows * Bp);
+    hipLaunchKernelGGL(k_gather_int, dim3((B + 255) / 256), dim3(256), 0, s, (const int*)D.cur, curn, B, (const int*)D.newidx);
+    for (const Pair& pr : live) oh_launch_move_rows_live(s, pr.a0, pr.a1, (double*)h->move_scr, pr.rows, Bp, B, Bnew, D.newidx, D.cur, curn);
   }
   for (const Item& it : items) oh_launch_move_rows(s, it.p, h->move_scr, it.rows, Bp, B, Bnew, D.newidx, it.is_int);
   return OH_OK;
@@ -1536,7 +1569,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     return fail(OH_ERR_INVALID, "oh_solve_device: the solver needs a chain that covers every model joint in order");
   HIPCHK(hipSetDevice(h->device));
   if (!h->is_peer) h->split_parts.clear();
-  if (!h->is_peer && !h->profiling && spec_applies(h) && optv(h, "batch_invariant", 0.0) == 0.0) {
+  // (batch_invariant handles take part in the split too since their compaction moves everything: an instance's answer does not depend on its part)
+  if (!h->is_peer && !h->profiling && spec_applies(h) && (optv(h, "batch_invariant", 0.0) == 0.0 || optv(h, "invariant_split", 1.0) != 0.0)) {
     const int S = std::min(8, (int)optv(h, "streams", 2.0));
     if (S >= 2 && B >= (int)optv(h, "split_min", 65536.0) && B / S >= 4096 && stage_fits(h, B)) {  // (a batch beyond oh_max_batch is refused below, as ever)
       // (the kernels compiled for the chain are shared: make sure they exist before the parts look for them)
@@ -1644,6 +1678,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     tail_done = true;
   }
   bool rebase = false;
+  const bool invariant = optv(h, "batch_invariant", 0.0) != 0.0;
+  const double inv_frac = optv(h, "invariant_compact_frac", 0.65);
   int carry_pending = 0;  // > 0: survivors to compact the batch to, between k_retract and k_evalb of the next iteration
   for (int it = 0; it < hard_cap && !tail_done; ++it) {
     if (prof && rebase && ne + 3 < h->prof_events.size()) {  // host synced: do not bill the idle gap to the eval kernel
@@ -1723,6 +1759,18 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       const bool carry_fits = (size_t)h->desc.T * ((N - 3) * (N - 2) / 2) >= 22;
       if (h->compaction && h->compact_carry && carry_fits && h->P.lock && !guarded && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac * (double)h->D.B) {
         carry_pending = nrun;  // done after the next k_retract
+      } else if (invariant && h->P.lock && !lead && inv_frac > 0.0 && h->D.B >= 512 && (double)nrun <= inv_frac * (double)h->D.B) {
+        // batch_invariant handles: the survivors move with everything they own (both slots' stage data, the pending step, every scalar and flag), so
+        // the compaction is invisible to the state machine -- same iterates, bit for bit, as without it -- and is done on a coarse schedule (when
+        // a third of the batch has finished, by default: a move costs an instance a few iterations' worth of bandwidth; tools/gpu_invariant_compaction.py)
+        oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
+        if (guarded) oh_launch_guard_emit(s, h->P, h->D, h->GP, h->GB, NV, 1);
+        oh_launch_scan_running(s, h->D, h->compact_sort);
+        const int mrc = move_everything(h, s, nrun);
+        if (mrc) return mrc;
+        h->D.B = nrun;
+        ++compactions;
+        if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(0); }
       } else if (h->compaction && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac_restart * (double)h->D.B) {
         // restart compaction: the survivors' accepted knots (and, with inequality rows, their multipliers and outer-loop state) are laid
         // down densely and re-evaluated

@@ -44,6 +44,7 @@ struct OhLaunchOpts {
 };
 OhLaunchOpts& oh_launch_opts();  // of the calling thread (a handle is not thread-safe; the options of the handle in the call)
 void oh_launch_move_rows(hipStream_t s, void* arr, void* scr, int rows, int Bp, int B, int Bnew, const int* newidx, bool is_int);
+void oh_launch_move_rows_live(hipStream_t s, double* a0, double* a1, double* scr, int rows, int Bp, int B, int Bnew, const int* newidx, const int* cur, const int* curn);
 bool oh_launch_setup_guards(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, const double* p);
 void oh_launch_guard_infeasible(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const double* p, int B, double* kkt, int* status);
 bool oh_launch_eval_guarded(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);

@@ -729,6 +729,30 @@ __global__ __launch_bounds__(256) void k_move_scatter(V* __restrict__ dst, const
   const size_t row = (size_t)blockIdx.y * Bp;
   dst[row + b] = scr[row + b];
 }
+// The same for an array that exists once per slot when only the slot of the accepted point (cur) is live: row of slot cur[b] -> scratch -> the same slot at the
+// new index (curn = cur gathered to the new order beforehand; D.cur itself moves last).
+__global__ __launch_bounds__(256) void k_move_gather_live(const double* __restrict__ src0, const double* __restrict__ src1, double* __restrict__ scr, const int Bp,
+                                                          const int B, const int* __restrict__ newidx, const int* __restrict__ cur) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int nb = newidx[b];
+  if (nb < 0) return;
+  const size_t row = (size_t)blockIdx.y * Bp;
+  scr[row + nb] = (cur[b] ? src1 : src0)[row + b];
+}
+__global__ __launch_bounds__(256) void k_move_scatter_live(double* __restrict__ dst0, double* __restrict__ dst1, const double* __restrict__ scr, const int Bp,
+                                                           const int Bnew, const int* __restrict__ curn) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bnew) return;
+  const size_t row = (size_t)blockIdx.y * Bp;
+  (curn[b] ? dst1 : dst0)[row + b] = scr[row + b];
+}
+void oh_launch_move_rows_live(hipStream_t s, double* a0, double* a1, double* scr, int rows, int Bp, int B, int Bnew, const int* newidx, const int* cur, const int* curn) {
+  if (!a0 || !a1 || rows <= 0) return;
+  const dim3 gg((B + 255) / 256, rows), gs((Bnew + 255) / 256, rows), blk(256);
+  hipLaunchKernelGGL(k_move_gather_live, gg, blk, 0, s, (const double*)a0, (const double*)a1, scr, Bp, B, newidx, cur);
+  hipLaunchKernelGGL(k_move_scatter_live, gs, blk, 0, s, a0, a1, (const double*)scr, Bp, Bnew, curn);
+}
 void oh_launch_move_rows(hipStream_t s, void* arr, void* scr, int rows, int Bp, int B, int Bnew, const int* newidx, bool is_int) {
   if (!arr || rows <= 0) return;
   const dim3 gg((B + 255) / 256, rows), gs((Bnew + 255) / 256, rows), blk(256);

@@ -66,7 +66,18 @@ def test_batch_invariant_answers_are_functions_of_the_instance(hip_lib, monkeypa
     x0, qc = bench.make_inputs(B, 0)
     be = _backend().set_option("batch_invariant", 1)
     big = be.solve(x0, qc)
-    assert (big.status == 0).all() and be.timing()["compactions"] == 0 and be.timing()["tail_iterations"] == 0
+    # (the batch IS compacted as it drains -- survivors move with everything they own, csrc/oh_api.hip:move_everything -- but nothing restarts and
+    # nothing goes to the persistent kernel)
+    assert (big.status == 0).all() and be.timing()["compactions"] >= 3 and be.timing()["tail_iterations"] == 0
+    # the same batch without any compaction, and with the compaction at another schedule / moving every array of both slots: the same bits everywhere
+    lam_big = be.multipliers(B)
+    for opts in ({"invariant_compact_frac": 0.0}, {"invariant_compact_frac": 0.9, "invariant_move_live": 0, "invariant_move_slim": 0, "invariant_split": 0}):
+        ref = _backend().set_option("batch_invariant", 1).set_options(opts)
+        whole = ref.solve(x0, qc)
+        assert (ref.timing()["compactions"] == 0) == (opts["invariant_compact_frac"] == 0.0)
+        assert np.array_equal(whole.x, big.x) and np.array_equal(whole.f, big.f) and np.array_equal(whole.iters, big.iters) and np.array_equal(whole.status, big.status)
+        assert np.array_equal(whole.kkt, big.kkt) and np.array_equal(ref.multipliers(B), lam_big)
+        ref.close()
     idx = np.sort(np.random.default_rng(B).choice(B, 64, replace=False))
     small = be.solve(x0[idx], qc[idx])
     assert np.array_equal(small.x, big.x[idx]) and np.array_equal(small.f, big.f[idx]) and np.array_equal(small.iters, big.iters[idx])

@@ -71,11 +71,16 @@ def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B):
     for b in idx:
         k = kkt_reference_form(nlp, r.x[b], qc[b])
         assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-9 and k["complementarity"] <= 1e-8, (b, k["stationarity"], k["feasibility"], k["complementarity"])
-    _, f_port, _, it_port, st_port = cpu_port.solve(chain, T, dt, lp, x0[idx], qc[idx], threads=bench.usable_cores())
+    # ... and EVERY instance against the compiled host port (other arithmetic, no batch at all): the same optimum to 1e-9 for all but a handful of the
+    # 262 144 (measured: 4, tools/gpu_fork_rate.py / profiles/r05_fork_rate.json -- instances whose path met a restart of the default schedule and
+    # stopped a few steps earlier in a flat valley, reduced gradient below the tolerance all the same), and none of the 64 sampled ones
+    _, f_port, _, it_port, st_port = cpu_port.solve(chain, T, dt, lp, x0, qc, threads=bench.usable_cores())
     assert (st_port == 0).all()
-    same = np.abs(r.f[idx] - f_port) <= 1e-9 * np.abs(f_port)
-    assert same.sum() >= 62, (same.sum(), r.f[idx][~same], f_port[~same])
-    assert (r.f[idx][~same] < 1225.0).all()  # a fork instance still ended in a KKT point (asserted above) below its seed's objective
+    same_all = np.abs(r.f - f_port) <= 1e-9 * np.abs(f_port)
+    assert (~same_all).sum() <= 8, ((~same_all).sum(), np.nonzero(~same_all)[0][:16])
+    assert np.abs(r.f[~same_all] - f_port[~same_all]).max(initial=0.0) <= 2e-3 * 8.2 and (r.kkt[~same_all, 0] <= 1e-6).all()  # the same valley, within the tolerance
+    same = same_all[idx]
+    assert same.sum() == 64, (same.sum(), r.f[idx][~same], f_port[idx][~same])
     prob = StructuredFigureEight(orc, LINK, T=T, Tmax=bench.TMAX)
     n_same_np = 0
     for b in idx[:12]:
@@ -89,7 +94,7 @@ def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B):
     xa = np.stack([a.x[0] for a in alone])
     assert all(a.status[0] == 0 for a in alone)
     same_a = np.abs(fa - r.f[idx]) <= 1e-9 * np.abs(fa)
-    assert same_a.sum() >= 62, (same_a.sum(), fa[~same_a], r.f[idx][~same_a])
+    assert same_a.sum() == 64, (same_a.sum(), fa[~same_a], r.f[idx][~same_a])
     assert np.abs(xa[same_a] - r.x[idx][same_a]).max() <= 1e-3
     r64 = be.solve(x0[idx], qc[idx])
     assert np.array_equal(r64.x, xa) and np.array_equal(r64.f, fa) and np.array_equal(r64.iters, np.array([a.iters[0] for a in alone]))
@@ -116,5 +121,5 @@ def test_batch_close_to_the_per_call_bound(hip_lib, monkeypatch):
     idx = np.sort(np.random.default_rng(B).choice(B, 64, replace=False))
     _, f_port, _, _, st_port = cpu_port.solve(chain, bench.T, dt, lp, x0[idx], qc[idx], threads=bench.usable_cores())
     same = np.abs(r.f[idx] - f_port) <= 1e-9 * np.abs(f_port)
-    assert (st_port == 0).all() and same.sum() >= 62, (same.sum(), r.f[idx][~same], f_port[~same])
+    assert (st_port == 0).all() and same.sum() == 64, (same.sum(), r.f[idx][~same], f_port[~same])
     be.close()

@@ -199,8 +199,11 @@ def test_horizon_beyond_the_persistent_kernel_compaction_moves_every_array_and_c
     qcs = (QC0[None] + rng.uniform(-0.1, 0.1, (20000, 7)))[10961 - B + 1:10961 + 1]  # the cap hitter of round 3 is the last of these
     x0 = np.repeat(qcs, T, axis=0).reshape(B, 7 * T)
     out = {}
-    for mode in ("move", "none", "restart"):
-        oh_debug(monkeypatch, compaction="0" if mode == "none" else "1", compact_move_all="0" if mode == "restart" else "1")
+    for mode in ("move", "none", "restart", "invariant", "invariant_none"):
+        # ("invariant": the option batch_invariant on such a handle -- its own coarser schedule of the same moving compaction, last session of round 5; the option
+        # also keeps the handle on the generic evaluation kernels, so its bits are compared with the option's own uncompacted run)
+        oh_debug(monkeypatch, compaction="0" if mode == "none" else "1", compact_move_all="0" if mode == "restart" else "1",
+                 batch_invariant="1" if mode.startswith("invariant") else None, invariant_compact_frac="0" if mode == "invariant_none" else None)
         kuka, solver = setup_solver(T=T, Tmax=10.0 * (T - 1) / 49.0, velocity_limits=True, solver_options={"max_iter": 600, "tol": 1e-6})
         X0 = np.zeros((B, solver.opt.nx))
         X0[:, : 7 * T] = x0
@@ -215,6 +218,8 @@ def test_horizon_beyond_the_persistent_kernel_compaction_moves_every_array_and_c
     for mode in out:
         assert (out[mode][0] == 0).all(), mode
     assert np.array_equal(out["move"][3], out["none"][3]) and np.array_equal(out["move"][1], out["none"][1]) and np.array_equal(out["move"][4], out["none"][4])
+    assert out["invariant"][2] >= 2 and out["invariant_none"][2] == 0 and all(np.array_equal(out["invariant"][k], out["invariant_none"][k]) for k in (1, 3, 4))
+    assert (np.abs(out["invariant"][1] - out["none"][1]) <= 1e-9 * np.maximum(1.0, np.abs(out["none"][1]))).mean() >= 0.999
     rel = np.abs(out["restart"][1] - out["none"][1]) / np.maximum(1.0, np.abs(out["none"][1]))
     assert rel[-1] <= 1e-9  # instance 10 961
     assert (rel <= 1e-9).mean() >= 0.999

@@ -413,7 +413,7 @@ int oh_get_flag(oh_handle* h, const char* name, int* value);
  *                         Costs 1.3 x device time at 262 144 instances (3.0 x without the moving compaction).
  *   tail_threshold (16384), tail_vel (1), tail_vel_threshold, compaction (1), compact_frac (0.97), compact_sort (1), compact_carry (1),
  *   sparse_check_below (2048), check_every (1), fuse_couple (1), lg_split (1), row_pad (13)            -- figure-eight family scheduling
- *   streams (2), split_min (131072): a batch of the plain orientation-locked family of at least split_min instances is solved in `streams` contiguous parts,
+ *   streams (2), split_min (65536): a batch of the plain orientation-locked family of at least split_min instances is solved in `streams` contiguous parts,
  *       each on a HIP stream and a host thread of its own (results at every index = the part solved as a batch of its own); 1: one stream
  *       (the torque-MPC family likewise from tq_split_min (1024) instances on: its answers do not depend on the batch, so the split is invisible)
  *       (the position-tracking family from free_split_min (256) instances on)

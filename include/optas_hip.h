@@ -29,7 +29,8 @@ extern "C" {
 
 /* Bumped whenever a struct of this header changes layout or an entry point changes meaning; oh_abi_version() returns the value the library was
    built with, and a host binding refuses a library that answers otherwise (a binding that misreads a descriptor fails silently).
-   5: round 5 -- OH_STATUS_INFEASIBLE / OH_STATUS_ACCEPTABLE, oh_set_option / oh_get_option, oh_tq_rollout, tape opcodes 25-26. */
+   5: round 5 -- OH_STATUS_INFEASIBLE / OH_STATUS_ACCEPTABLE, oh_set_option / oh_get_option, oh_tq_rollout, tape opcodes 25-26.
+   6: round 5 -- oh_tape_set_metric. */
 #define OH_ABI_VERSION 6
 
 #define OH_MAX_CHAIN 16 /* actuated joints on one root->link chain */
@@ -420,6 +421,7 @@ int oh_get_flag(oh_handle* h, const char* name, int* value);
  *   free_pcr_max (1536), free_bb (1), free_cp_max (512), free_persist (-1 auto / 0 / 1)                  -- position-tracking family sweeps
  *   specialize (2 = auto, 0 never, 1 at the first call)                                                 -- run-time specialisation (oh_specialize)
  *   hyb_switch (1e-5, x w_path), relax (1.5), relax_from (4), retract_min (1e-13), settle_k (1)          -- algorithm constants (change the iterates)
+ *   tol (0 = the descriptor's): stopping tolerance on the reduced gradient of a trajectory handle, changeable between solves
  *   pm_wave_max (20480), qp_mode (-1), tape_lds_max                                                     -- point-mass / QP / tape launch shapes
  *   tape_wave (1), tape_lbfgs (-1 = by size), tape_wave_nt (256), tape_wave_regs (-1), tape_wave_hist (-1) -- tape evaluator (rebuilt when set)
  *   tq_check (4), tq_rebuild (0.9), tq_stall (25), tq_curv_after (3), tq_curv_from (0.1), tq_ftb (0.995), tq_theta_mu (1.35), tq_kappa_mu (0.4),

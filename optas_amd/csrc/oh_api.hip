@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
 #include <string>
 #include <thread>
@@ -99,6 +100,7 @@ struct oh_handle {
   double* d_tq_hc = nullptr;  // [tq_cap][T][TQ_HC] stored curvature terms (k_tq_curv)
   int tq_cap = 0;
   int tq_check = 4;  // the host looks at the running count every tq_check iterations
+  std::array<double, 4> inv_saved{1.0, 16384.0, 1.0, -2.0};  // compaction, tail_threshold, tail_vel, free_persist (-2: unset) as they were before batch_invariant
   // solver buffers
   int cap_B = 0;
   FigBuffers D{};
@@ -180,7 +182,7 @@ static const OptDoc OPT_TABLE[] = {
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.4},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
     {"tq_rebuild", 0.9},         {"compact_move_all", 1},  {"tq_curv_late", 1.0},  {"tq_kappa_eps", 10.0}, {"tq_max_back", 3},     {"tq_mu_dec", 1.0 / 3.0},     {"tq_ls_curv", 1},   {"tq_mu_dec_warm", 0.1}, {"tq_curv_lag", 3},
-    {"invariant_compact_frac", 0.65}, {"invariant_split", 1}, {"invariant_move_slim", 1}, {"invariant_move_live", 1},
+    {"tol", 0},                {"invariant_compact_frac", 0.65}, {"invariant_split", 1}, {"invariant_move_slim", 1}, {"invariant_move_live", 1},
 };
 static int tape_configure(oh_handle* h);
 static int set_option_impl(oh_handle* h, const std::string& name, double v) {
@@ -201,9 +203,17 @@ static int set_option_impl(oh_handle* h, const std::string& name, double v) {
     // every instance takes the batched launches to the end, nothing restarts, nothing is handed to the persistent kernel; the batch is compacted only
     // by moving a survivor with everything it owns (move_everything): the path of an instance is then a function of the instance alone, bit for bit
     // (the price: 1.3 x the device time of a 262 144 batch -- 3.0 x before the moving compaction --, and small batches pay launches)
+    // (the scheduling fields the option overrides are parked and come back when it is switched off: a threshold the user set earlier is not replaced
+    //  by the default -- ADVICE r5)
+    const bool was = optv(h, "batch_invariant", 0.0) != 0.0;
     h->opt[name] = v;
-    if (v != 0.0) { h->compaction = false; h->tail_threshold = 0; h->tail_vel = 0; h->opt["free_persist"] = 0; }
-    else { h->compaction = true; h->tail_threshold = 16384; h->tail_vel = 1; h->opt.erase("free_persist"); }
+    if (v != 0.0 && !was) {
+      h->inv_saved = {h->compaction ? 1.0 : 0.0, (double)h->tail_threshold, (double)h->tail_vel, h->opt.count("free_persist") ? h->opt["free_persist"] : -2.0};
+      h->compaction = false; h->tail_threshold = 0; h->tail_vel = 0; h->opt["free_persist"] = 0;
+    } else if (v == 0.0 && was) {
+      h->compaction = h->inv_saved[0] != 0.0; h->tail_threshold = (int)h->inv_saved[1]; h->tail_vel = (int)h->inv_saved[2];
+      if (h->inv_saved[3] == -2.0) h->opt.erase("free_persist"); else h->opt["free_persist"] = h->inv_saved[3];
+    }
   } else {
     bool known = false;
     for (const OptDoc& d : OPT_TABLE) known = known || name == d.name;
@@ -1082,9 +1092,21 @@ static int validate_chain(const oh_handle* h, const oh_chain& c) {
   return OH_OK;
 }
 
+// The parts of a split solve run on peer handles that were given the chain, dynamics and inequality rows of this handle when they were created
+// (solve_split).  Any setter that changes one of those on the main handle destroys the peers: the next split solve builds them again from the new
+// data (parts 1.. used to go on solving with the old chain / limits / obstacles, and guards set after a first split solve left the peers
+// striding p by ndof only).
+static void drop_peers(oh_handle* h) {
+  if (h->is_peer) return;
+  for (oh_handle* p : h->peers) oh_destroy(p);
+  h->peers.clear();
+  h->split_parts.clear();
+}
+
 // the handle has new constants: everything compiled for, or remembered about, the previous chain goes (one place for the three entry
 // points that set constants)
 static void adopt_chain(oh_handle* h, const oh_chain& c) {
+  drop_peers(h);
   h->chain_host = c;
   h->have_chain = true;
   h->spec = nullptr;
@@ -1287,6 +1309,7 @@ extern "C" int oh_set_guards(oh_handle* h, const oh_guards* g) {
   }
   h->guards = *g;
   h->have_guards = true;
+  drop_peers(h);
   return OH_OK;
 }
 
@@ -1369,7 +1392,7 @@ static void fill_params(oh_handle* h) {
   P.dt = d.dt;
   P.w_path = d.w_path;
   P.kappa = d.w_vel / (d.dt * d.dt);
-  P.tol = d.tol;
+  P.tol = optv(h, "tol", 0.0) > 0.0 ? optv(h, "tol", 0.0) : d.tol;  // (option "tol": the stopping tolerance of an existing trajectory handle, bench.py's second pass)
   P.tol_feas = d.tol_feas;
   P.tol_retract = fmin(1e-10, d.tol_feas);
   // (every handle since the end of round 3.  First built for handles with inequality rows; a tolerance sweep then showed the plain family in the
@@ -1478,10 +1501,11 @@ static void copy_options(oh_handle* dst, const oh_handle* src) {
   dst->tail_threshold = src->tail_threshold; dst->free_pcr_max = src->free_pcr_max; dst->compaction = src->compaction;
   dst->compact_frac = src->compact_frac; dst->compact_frac_restart = src->compact_frac_restart; dst->compact_sort = src->compact_sort;
   dst->compact_carry = src->compact_carry; dst->tail_vel = src->tail_vel; dst->lg_split = src->lg_split; dst->tail_vel_threshold = src->tail_vel_threshold;
-  dst->fuse_couple = src->fuse_couple; dst->sparse_check_below = src->sparse_check_below; dst->specialize = src->specialize; dst->opt = src->opt;
+  dst->fuse_couple = src->fuse_couple; dst->sparse_check_below = src->sparse_check_below; dst->specialize = src->specialize; dst->tq_check = src->tq_check; dst->opt = src->opt;
 }
 static int solve_split(oh_handle* h, const int S, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status) {
   const bool tqk = h->desc.kind == OH_PROBLEM_TORQUE_MPC;
+  HIPCHK(hipSetDevice(h->device));  // peers are created on, and every part's host thread is bound to, the device of the handle (not the calling thread's)
   while ((int)h->peers.size() < S - 1) {
     oh_handle* p = nullptr;
     int rc;
@@ -1493,6 +1517,7 @@ static int solve_split(oh_handle* h, const int S, int B, const void* d_x0, const
     }
     if (rc) return rc;
     p->is_peer = true;
+    p->device = h->device;
     rc = oh_set_constants(p, &h->chain_host);
     if (!rc && tqk) rc = oh_set_dynamics(p, &h->dyn_host);
     if (!rc && !tqk && h->have_guards) rc = oh_set_guards(p, &h->guards);
@@ -1509,6 +1534,7 @@ static int solve_split(oh_handle* h, const int S, int B, const void* d_x0, const
   std::vector<std::string> errs(S);
   auto part = [&](const int i) {
     oh_handle* q = i == 0 ? h : h->peers[i - 1];
+    if (hipSetDevice(h->device) != hipSuccess) { rcs[i] = OH_ERR_HIP; errs[i] = "solve_split: hipSetDevice failed"; return; }  // (a new host thread starts on device 0)
     const size_t o = (size_t)lo[i];
     const int n = lo[i + 1] - lo[i];
     auto off = [&](const void* ptr, const size_t bytes_per) -> void* { return ptr ? (void*)((char*)ptr + o * bytes_per) : nullptr; };
@@ -1597,7 +1623,10 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   const bool guarded = h->have_guards;
   const bool lead = h->chain_host.has_lead != 0;
   {  // position-tracking family, 7 joints, every launch of this solve a block per instance (k_step_free_bb): stage blocks instance-major
-    h->P.inst_major = (!h->desc.lock_orientation && h->desc.ndof == 7 && B <= h->free_pcr_max && h->desc.T - (h->desc.fix_dq0 ? 2 : 1) <= 128 && optv(h, "free_bb", 1.0) != 0.0) ? 1 : 0;
+    // (batch_invariant: the size-independent path -- knot-major blocks, the serial sweep on one lane per instance -- whatever the batch: the block-per-instance
+    //  factorisations chosen by size round differently)
+    h->P.inst_major = (!h->desc.lock_orientation && h->desc.ndof == 7 && B <= h->free_pcr_max && h->desc.T - (h->desc.fix_dq0 ? 2 : 1) <= 128 && optv(h, "free_bb", 1.0) != 0.0 &&
+                       optv(h, "batch_invariant", 0.0) == 0.0) ? 1 : 0;
   }
   if (lead && (guarded || !h->desc.lock_orientation || h->desc.ndof != 6))
     return fail(OH_ERR_INVALID, "oh_solve_device: a parameterised lead joint is lowered for the orientation-locked family with 6 optimised joints, "
@@ -1730,8 +1759,8 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(3); }
     if (h->P.lock && guarded) oh_launch_step_locked_guarded(s, N, h->P, h->D, h->GP, h->GB, slot);
     else if (h->P.lock) oh_launch_step(s, N, h->P, h->D, slot);
-    else if (guarded) oh_launch_step_guarded(s, N, h->P, h->D, h->GP, h->GB, slot, h->D.B <= h->free_pcr_max);
-    else oh_launch_step_free(s, N, h->P, h->D, slot, h->D.B <= h->free_pcr_max);
+    else if (guarded) oh_launch_step_guarded(s, N, h->P, h->D, h->GP, h->GB, slot, !invariant && h->D.B <= h->free_pcr_max);
+    else oh_launch_step_free(s, N, h->P, h->D, slot, !invariant && h->D.B <= h->free_pcr_max);
     if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(2); }
     ++launched;
     if (check) {
@@ -2106,6 +2135,7 @@ extern "C" int oh_set_dynamics(oh_handle* h, const oh_dynamics* dyn) {
   HIPCHK(hipMemcpy(h->d_dyn, dyn, sizeof(oh_dynamics), hipMemcpyHostToDevice));
   h->dyn_host = *dyn;
   h->have_dyn = true;
+  drop_peers(h);
   return OH_OK;
 }
 extern "C" int oh_rnea_device(oh_handle* h, int n, const void* d_q, const void* d_qd, const void* d_qdd, void* d_tau) {

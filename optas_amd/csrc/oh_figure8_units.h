@@ -136,6 +136,9 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   // the SQ counters showed a third of every k_evalb wave's lifetime in s_waitcnt).  Finished / skipping lanes fetch for nothing; the
   // batch is compacted when a tenth of it has finished.
   const int status_b = D.status[b], skip_b = D.skip[b], first_b = D.first[b];
+  // polish == 2 (set by step_instance_zc, see there): the sweep of the accepted point did not factorise at its damping; this launch lays the accepted
+  // point down as the trial AS IT IS (no step, no retraction), the evaluation rebuilds its stage data bit for bit and the next sweep runs at the raised damping
+  const bool asis = (MODE == EVAL_RETRACT_ONLY && !GUARD) ? D.polish[b] == 2 : false;
   const double stat_b = D.stat[b], pred_b = D.pred[b];
   constexpr bool EARLY = MODE == EVAL_ONLY || OH_RETRACT_PREFETCH;  // the generic retraction kernel sits at the register limit: it fetches
                                                                     // its knot data after the branch, as before
@@ -219,7 +222,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
         double v = q[j];
 #pragma unroll
         for (int a = 0; a < NZ; ++a) v += Zc[j][a] * zs[a];
-        q[j] = v;
+        q[j] = asis ? q[j] : v;
       }
       // where the linear model puts the end effector after this step: e_cur + (Jp Z)_cur z
 #pragma unroll
@@ -311,7 +314,7 @@ OH_DEV void eval_unit(const FigParams& P, const FigBuffers& D, const int slot, c
   // knots the instance accepted, and retracting them again (to the floor tolerance, as a seed would be) moved them by ~1e-10 -- enough to send an
   // instance between two basins down another path than the same instance takes alone (round 3's "not batch-invariant", HISTORY).  Without the
   // retraction the stage data of the restart are those of the accepted point bit for bit and the interrupted step is re-derived exactly.
-  const double tol_r = (first_b == 2) ? 1e300 : retract_tol(P, !first, pred_b, stat_b);
+  const double tol_r = (first_b == 2 || asis) ? 1e300 : retract_tol(P, !first, pred_b, stat_b);
   if constexpr (LEAD)
     eval_knot<N, true, Hooks, MODE>(OH_CHAIN(D), P, t, q, pc, Rc, exact, have_G, Gprev, phi, cv, g, Dr, Z, !first, e_tgt, tol_r, e_new, JZ_new,
                                     D.lead[(size_t)t * Bp + b], hooks);
@@ -1017,7 +1020,17 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
     }
   };
   double quad = 0.0;  // g^T M^{-1} g of the system being solved (see above)
-  for (int attempt = 0; attempt < 40; ++attempt) {
+  // A reduced Hessian that does not factorise at the instance's damping (exact curvature, indefinite away from the solution: 0.5 % of all sweeps) used
+  // to be swept again with 4 x the damping inside this loop -- by the whole wavefront: 64 lanes wait a second backward pass for one of them, and with
+  // 1-3 % of the instances failing in iterations 9-16 that was every second wavefront (round 6: the per-iteration histogram of the host port).  Now
+  // the lane defers (OH_STEP_ZC_DEFER): it raises its damping exactly as the loop would have, asks for its accepted point to be laid down and
+  // evaluated again as it is (D.polish = 2: k_retract copies the knots, k_evalb_zc rebuilds the stage data bit for bit -- the older Lagrangian gradient
+  // its multiplier estimate came from is put back where the evaluation reads it), and sweeps at the raised damping one launch later.  Same iterates,
+  // same step counts (the extra launch is not counted); the price is one evaluation of the instance instead of one sweep of its wavefront.
+#ifndef OH_STEP_ZC_DEFER
+#define OH_STEP_ZC_DEFER 1
+#endif
+  for (int attempt = 0; attempt < (OH_STEP_ZC_DEFER ? 1 : 40); ++attempt) {
     bool ok = true;
     stat = 0.0;
     quad = 0.0;
@@ -1071,6 +1084,22 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
       break;
     }
     mu = fmax(4.0 * mu, 1e-2);
+  }
+  if (OH_STEP_ZC_DEFER && !factored && stat == stat && mu < 1e24) {  // (4^40 was the loop's limit)
+    D.mu[b] = mu;
+    D.polish[b] = 2;
+    // (D.stat keeps the value the evaluation of this point saw: its hybrid-curvature decision is taken again, alike)
+    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON && cur == ts) {
+      // accepted in this launch: the gradient its evaluation took the multiplier estimate from is still in the other slot; this point's own is
+      // rebuilt by the evaluation that follows
+      const double* __restrict__ Gold = D.Gfull[1 - cur];
+      double* __restrict__ Gnew = D.Gfull[cur];
+      for (int t = P.t0; t < T; ++t) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) Gnew[IDX(t, N, k)] = Gold[IDX(t, N, k)];
+      }
+    }
+    return true;
   }
   D.stat[b] = stat;
   if (!(stat == stat) || !factored) {

@@ -1724,12 +1724,11 @@ bool oh_launch_couple_free(hipStream_t s, int n, const FigParams& P, const FigBu
 #undef C
   return true;
 }
-// pcr: one block per instance (k_step_free_pcr, or k_step_free_cp with eight lanes per knot while the launch has at most g_free_cp_max instances;
+// pcr: one block per instance (k_step_free_pcr, or k_step_free_cp with eight lanes per knot while the launch has at most free_cp_max instances;
 // the knots must fit 128 lanes)
-static int g_free_cp_max = -1;
 template <int N, bool GUARD, bool VEL = false>
 static void launch_step_free_pcr(hipStream_t s, const FigParams& P, const FigBuffers& D, const GuardBuffers& GB, int slot) {
-  g_free_cp_max = oh_launch_opts().free_cp_max;  // (per call: the handle's option "free_cp_max")
+  const int free_cp_max = oh_launch_opts().free_cp_max;  // (per call: the handle's option "free_cp_max"; a local: the parts of a split solve launch from threads of their own)
   const dim3 g(8 * ((D.B + 7) / 8));
   if constexpr (N == 7) {
     if (oh_launch_opts().free_bb != 0) {  // option "free_bb" = 0: the cyclic-reduction kernels of rounds 2-3 (A/B, tests)
@@ -1740,7 +1739,7 @@ static void launch_step_free_pcr(hipStream_t s, const FigParams& P, const FigBuf
   }
   // (only up to 64 knots: 128 knots x 8 lanes are 1024 threads, which leaves 128 registers per lane -- the kernel then spills and takes 147 us
   //  against k_step_free_pcr's 111 at T = 100; at T = 50 it is 61 against 87 us)
-  if (D.B <= g_free_cp_max && P.T - P.t0 <= 64) {
+  if (D.B <= free_cp_max && P.T - P.t0 <= 64) {
     hipLaunchKernelGGL((k_step_free_cp<N, GUARD, 64, VEL>), g, dim3(512), 0, s, P, D, GB, slot);
     return;
   }

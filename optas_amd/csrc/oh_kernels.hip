@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void k_compact_gather(FigParams P, FigBuffers 
     for (int i = 0; i < 12; ++i) ts[(size_t)i * Bp + nb] = D.ref[(size_t)i * Bp + b];
     ts[(size_t)12 * Bp + nb] = D.fconst[b];
     ts[(size_t)13 * Bp + nb] = D.mu[b];
-    ts[(size_t)14 * Bp + nb] = (double)D.iters[b];
+    ts[(size_t)14 * Bp + nb] = (double)(D.iters[b] + (D.polish[b] == 2 ? 1 : 0));  // (a deferred sweep counted no step: nothing to take back at the restart)
     ts[(size_t)15 * Bp + nb] = (double)D.orig[b];
     ts[(size_t)16 * Bp + nb] = D.nun[b];
     ts[(size_t)17 * Bp + nb] = D.stat[b];
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void k_carry_gather(FigParams P, FigBuffers D,
     ts[(size_t)18 * Bp + nb] = D.pred[b];
     ts[(size_t)19 * Bp + nb] = D.stat[b];
     ts[(size_t)20 * Bp + nb] = D.feas[b];
-    ts[(size_t)21 * Bp + nb] = (double)((restart ? 1 : 0) + 2 * (D.polish[b] != 0 ? 1 : 0));
+    ts[(size_t)21 * Bp + nb] = (double)((restart ? 1 : 0) + 2 * (D.polish[b] != 0 ? 1 : 0) + 4 * (D.polish[b] == 2 ? 1 : 0));
   }
 }
 template <int N>
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void k_carry_scatter(FigParams P, FigBuffers D
     D.cur[b] = 1 - slot;
     D.first[b] = restart ? 1 : 0;
     D.skip[b] = 0;
-    D.polish[b] = (!restart && (flags & 2)) ? 1 : 0;
+    D.polish[b] = (!restart && (flags & 2)) ? ((flags & 4) ? 2 : 1) : 0;
     D.stale[b] = restart ? 0 : 1;
     D.status[b] = -1;
   }

@@ -108,7 +108,8 @@ struct FigBuffers {
   int* first;             // [Bp]
   int* scan_blk;          // [8][1024] per-block class counts / offsets of the compaction scan
   int* skip;              // [Bp] 1: last trial rejected -> sit the next launch out (keeps the slot parity uniform)
-  int* polish;            // [Bp] 1: the next evaluation re-retracts the accepted point itself (zero step, floor tolerance) and is accepted as is
+  int* polish;            // [Bp] 1: the next evaluation re-retracts the accepted point itself (zero step, floor tolerance) and is accepted as is;
+                          //      2: (k_step_zc, deferred refactorisation) it lays the accepted point down unchanged, accepted as is, swept at the raised damping
   int* stale;             // [Bp] 1: the accepted point's stage data was left behind by a compaction (k_carry_*); a rejected trial restarts
   int* status;            // [Bp] -1 running, else OH_STATUS_*
   int* iters;             // [Bp]

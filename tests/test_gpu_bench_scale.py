@@ -31,8 +31,11 @@ pytestmark = pytest.mark.gpu
 LINK = "end_effector_ball"
 
 
-@pytest.mark.parametrize("B", [65536, 262144])
-def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B):
+@pytest.mark.parametrize("B,tol", [(65536, 1e-8), (262144, 1e-8), (262144, 1e-6)])
+def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B, tol):
+    """tol = 1e-8: bench.py's default since round 6 (IPOPT's own default, what the reference's configs run with) -- there EVERY instance of the batch reaches
+    the optimum of the compiled host port (1e-9 relative: no misses allowed); tol = 1e-6: what rounds 1-5 quoted, where a handful of instances whose path met a
+    restart stop a few steps early in a flat valley (reduced gradient below the tolerance all the same)."""
     from oracle import cpu_port
 
     monkeypatch.delenv("OH_DEBUG_OPTIONS", raising=False)  # nothing forced: the library's defaults, as in the driver's bench run
@@ -40,7 +43,7 @@ def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B):
     nlp = FigureEightNLP(orc, LINK, T=bench.T, Tmax=bench.TMAX)
     dt, lp = bench.local_path()
     chain = RobotModel(urdf_filename=KUKA_KIN).kinematic_chain(LINK)
-    be = FigureEightBackend(chain, bench.T, dt, lp, max_iter=300, tol=1e-6, hessian=2)  # bench.py's handle
+    be = FigureEightBackend(chain, bench.T, dt, lp, max_iter=300, tol=tol, hessian=2)  # bench.py's handle
     x0, qc = bench.make_inputs(B, 0)
     r = be.solve(x0, qc)
     tm = be.timing()
@@ -48,7 +51,7 @@ def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B):
     n, T = 7, bench.T
     conv = r.status == 0
     assert conv.mean() >= 0.9999, conv.mean()
-    assert (r.kkt[conv, 0] <= 1e-6).all() and (r.kkt[:, 1] <= 1e-9).all()
+    assert (r.kkt[conv, 0] <= tol).all() and (r.kkt[:, 1] <= 1e-9).all()
 
     # (i) all instances
     Q = r.x[:, : n * T].reshape(B, T, n)
@@ -74,9 +77,11 @@ def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B):
     # ... and EVERY instance against the compiled host port (other arithmetic, no batch at all): the same optimum to 1e-9 for all but a handful of the
     # 262 144 (measured: 4, tools/gpu_fork_rate.py / profiles/r05_fork_rate.json -- instances whose path met a restart of the default schedule and
     # stopped a few steps earlier in a flat valley, reduced gradient below the tolerance all the same), and none of the 64 sampled ones
-    _, f_port, _, it_port, st_port = cpu_port.solve(chain, T, dt, lp, x0, qc, threads=bench.usable_cores())
+    _, f_port, _, it_port, st_port = cpu_port.solve(chain, T, dt, lp, x0, qc, tol=tol, threads=bench.usable_cores())
     assert (st_port == 0).all()
     same_all = np.abs(r.f - f_port) <= 1e-9 * np.abs(f_port)
+    if tol <= 1e-8:  # round 6 (tools/gpu_fork_rate.py at 1e-8, profiles/r06_fork_rate.json): default schedule = batch_invariant = persistent kernel = host port on all 262 144
+        assert (~same_all).sum() == 0, ((~same_all).sum(), np.nonzero(~same_all)[0][:16], r.f[~same_all][:8], f_port[~same_all][:8])
     assert (~same_all).sum() <= 8, ((~same_all).sum(), np.nonzero(~same_all)[0][:16])
     assert np.abs(r.f[~same_all] - f_port[~same_all]).max(initial=0.0) <= 2e-3 * 8.2 and (r.kkt[~same_all, 0] <= 1e-6).all()  # the same valley, within the tolerance
     same = same_all[idx]
@@ -84,9 +89,9 @@ def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B):
     prob = StructuredFigureEight(orc, LINK, T=T, Tmax=bench.TMAX)
     n_same_np = 0
     for b in idx[:12]:
-        s = solve_structured_lm(prob, qc[b], max_iter=300, tol=1e-6)
+        s = solve_structured_lm(prob, qc[b], max_iter=300, tol=tol)
         n_same_np += abs(s["f"] - r.f[b]) <= 1e-9 * abs(s["f"])
-    assert n_same_np >= 11
+    assert n_same_np >= (12 if tol <= 1e-8 else 11)
 
     # (iii) the same 64 alone
     alone = [be.solve(x0[b], qc[b]) for b in idx]

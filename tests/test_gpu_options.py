@@ -119,3 +119,94 @@ def test_a_large_batch_solved_in_parts_on_two_streams_equals_the_parts_solved_al
     assert (rw.status == 0).all() and (np.abs(rw.f - ra.f) <= 1e-9 * np.abs(ra.f)).mean() >= 0.97
     a.close()
     b.close()
+
+
+def _tracking_backend(chain, guards=None, **kw):
+    """Position-tracking handle (dual_arm.py per arm): offsets from the initial end-effector position, world frame, T = 30."""
+    T = 30
+    t = np.linspace(0.0, 1.0, T)
+    off = np.stack([0.05 * np.sin(2 * np.pi * t), 0.05 * (1 - np.cos(2 * np.pi * t)), 0.03 * t], axis=1)
+    return FigureEightBackend(chain, T, 0.1, off, w_path=100.0, w_vel=0.01, max_iter=600, tol=1e-6, hessian=0, lock_orientation=False, fix_dq0=False,
+                              path_in_frame=False, guards=guards, **kw)
+
+
+def _limit_guards(lo, up):
+    g = _lib.oh_guards()
+    g.limits = 1
+    for j in range(7):
+        g.q_lo[j], g.q_up[j] = float(lo[j]), float(up[j])
+    return g
+
+
+def _tracking_inputs(B, seed, T=30):
+    rng = np.random.default_rng(seed)
+    qc = np.deg2rad(bench.QC0_DEG)[None, :] + rng.uniform(-0.1, 0.1, (B, 7))
+    x0 = np.concatenate([np.repeat(qc, T, axis=0).reshape(B, 7 * T), np.zeros((B, 7 * (T - 1)))], axis=1)
+    return x0, qc
+
+
+def test_parts_of_a_split_solve_follow_new_guards_and_constants(hip_lib, monkeypatch):
+    """the peer handles of a split solve were given chain and inequality rows once, when they were created; oh_set_guards / oh_set_constants on the
+    main handle afterwards left parts 1.. on the old data.  Now the setters drop the peers.  Pinned: after a split solve, new limits (then a new tool offset)
+    reach every part -- each part equals that part solved on a one-stream handle created with the new data, bit for bit."""
+    monkeypatch.delenv("OH_DEBUG_OPTIONS", raising=False)
+    lib = _lib.load()
+    B = 640  # position-tracking family: split from 256 instances on (free_split_min)
+    chain = RobotModel(urdf_filename=KUKA_KIN).kinematic_chain(LINK)
+    x0, qc = _tracking_inputs(B, 11)
+    wide = _limit_guards(np.full(7, -3.0), np.full(7, 3.0))
+    lo, up = np.full(7, -3.0), np.full(7, 3.0)
+    lo[1], up[3] = qc[:, 1].min() - 0.03, qc[:, 3].max() + 0.03  # feasible at every pinned q_0 = qc, binding on the instances that start near them
+    tight = _limit_guards(lo, up)
+    a = _tracking_backend(chain, guards=wide).set_options(streams=2)
+    r_wide = a.solve(x0, qc)
+    assert (r_wide.status == 0).all()
+    _lib.check(lib.oh_set_guards(a.handle, C.byref(tight)), "oh_set_guards")  # (re-set on a handle that has solved in parts)
+    r_tight = a.solve(x0, qc)
+    assert (r_tight.status == 0).mean() >= 0.8 and not np.array_equal(r_tight.x, r_wide.x)  # (what is pinned below is that every part saw the new rows, converged or not)
+    cut = B // 2 // 64 * 64
+    b = _tracking_backend(chain, guards=tight).set_options(streams=1)
+    for lo_i, hi_i in ((0, cut), (cut, B)):
+        rb = b.solve(x0[lo_i:hi_i], qc[lo_i:hi_i])
+        assert np.array_equal(r_tight.x[lo_i:hi_i], rb.x) and np.array_equal(r_tight.f[lo_i:hi_i], rb.f) and np.array_equal(r_tight.iters[lo_i:hi_i], rb.iters), (lo_i, hi_i)
+        assert np.array_equal(r_tight.status[lo_i:hi_i], rb.status)
+    Q = r_tight.x[:, : 7 * 30].reshape(B, 30, 7)
+    okc = r_tight.status == 0
+    assert (Q[okc][:, 1:, 1] >= lo[1] - 1e-8).all() and (Q[okc][:, 1:, 3] <= up[3] + 1e-8).all()  # every part obeys the NEW limits
+    # a new tool offset through oh_set_constants: again every part
+    chain2 = _lib.oh_chain.from_buffer_copy(chain)
+    chain2.p_tool[2] += 0.05
+    _lib.check(lib.oh_set_constants(a.handle, C.byref(chain2)), "oh_set_constants")
+    r2 = a.solve(x0, qc)
+    b2 = _tracking_backend(chain2, guards=tight).set_options(streams=1)
+    for lo_i, hi_i in ((0, cut), (cut, B)):
+        rb = b2.solve(x0[lo_i:hi_i], qc[lo_i:hi_i])
+        assert np.array_equal(r2.x[lo_i:hi_i], rb.x) and np.array_equal(r2.f[lo_i:hi_i], rb.f), (lo_i, hi_i)
+    for h in (a, b, b2):
+        h.close()
+
+
+def test_batch_invariant_on_the_position_tracking_family_and_restored_fields(hip_lib, monkeypatch):
+    """(i) on position-tracking handles the kernel and layout used to depend on the batch size even with `batch_invariant` (block-per-instance
+    factorisations up to free_pcr_max instances, the serial sweep beyond): the option now pins the size-independent path, and an instance's answer is the
+    same alone, in 64, in 2048 (beyond free_pcr_max) -- every bit; (ii) switching the option off puts back the scheduling fields the user had set, not the defaults."""
+    monkeypatch.delenv("OH_DEBUG_OPTIONS", raising=False)
+    chain = RobotModel(urdf_filename=KUKA_KIN).kinematic_chain(LINK)
+    B = 2048
+    x0, qc = _tracking_inputs(B, 12)
+    for guards in (None, _limit_guards(np.full(7, -3.0), np.r_[3.0, 3.0, 3.0, qc[:, 3].max() + 0.01, 3.0, 3.0, 3.0])):
+        be = _tracking_backend(chain, guards=guards).set_option("batch_invariant", 1)
+        big = be.solve(x0, qc)
+        assert (big.status == 0).all()
+        idx = np.sort(np.random.default_rng(3).choice(B, 64, replace=False))
+        small = be.solve(x0[idx], qc[idx])
+        assert np.array_equal(small.x, big.x[idx]) and np.array_equal(small.f, big.f[idx]) and np.array_equal(small.iters, big.iters[idx])
+        one = be.solve(x0[idx[5]], qc[idx[5]])
+        assert np.array_equal(one.x[0], big.x[idx[5]]) and one.iters[0] == big.iters[idx[5]]
+        be.close()
+    be = _backend().set_options(tail_threshold=2048, compaction=0)
+    be.set_option("batch_invariant", 1)
+    assert be.get_option("tail_threshold") == 0
+    be.set_option("batch_invariant", 0)
+    assert be.get_option("tail_threshold") == 2048 and be.get_option("compaction") == 0  # (16384 / 1 until round 6)
+    be.close()

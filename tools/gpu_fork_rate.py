@@ -16,10 +16,12 @@ from optas_amd.models import RobotModel  # noqa: E402
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+    tol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-6
+    tag = sys.argv[3] if len(sys.argv) > 3 else ""
     x0, qc = bench.make_inputs(B, 0)
     dt, lp = bench.local_path()
     chain = RobotModel.builtin("kuka_lwr").kinematic_chain(bench.LINK)
-    mk = lambda: FigureEightBackend(chain, bench.T, dt, lp, max_iter=300, tol=1e-6, hessian=2)
+    mk = lambda: FigureEightBackend(chain, bench.T, dt, lp, max_iter=300, tol=tol, hessian=2)
     f = {}
     be = mk()
     r = be.solve(x0, qc)
@@ -32,9 +34,9 @@ def main():
     be.close()
     from oracle import cpu_port
 
-    _, fp, _, _, stp = cpu_port.solve(chain, bench.T, dt, lp, x0, qc, threads=bench.usable_cores())
+    _, fp, _, _, stp = cpu_port.solve(chain, bench.T, dt, lp, x0, qc, tol=tol, threads=bench.usable_cores())
     f["host_port"] = fp
-    out = {"batch": B, "converged_default": conv, "host_port_converged": float((stp == 0).mean()), "pairs": {}}
+    out = {"batch": B, "tol": tol, "converged_default": conv, "host_port_converged": float((stp == 0).mean()), "pairs": {}}
     names = list(f)
     for i, a in enumerate(names):
         for b in names[i + 1 :]:
@@ -43,7 +45,7 @@ def main():
                                            "f": [[float(f[a][k]), float(f[b][k])] for k in np.nonzero(d)[0][:8]]}
     print(json.dumps(out, indent=1))
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(out, open("gpurun_out/fork_rate.json", "w"), indent=1)
+    json.dump(out, open(f"gpurun_out/fork_rate{tag}.json", "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -81,6 +81,10 @@ class _SolveMixin(_OptionsMixin):
         _lib.check(_lib.load().oh_get_timing(self._h, out), "oh_get_timing")
         return out[4]
 
+    def set_profiling(self, on: bool) -> None:
+        """oh_set_profiling: families that run several launches per solve record one HIP event after every kernel (one stream, no split)."""
+        _lib.check(_lib.load().oh_set_profiling(self._h, 1 if on else 0), "oh_set_profiling")
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             _lib.load().oh_destroy(self._h)
@@ -488,7 +492,7 @@ class TorqueBackend(_SolveMixin):
     def timing(self) -> dict:
         out = (C.c_double * 11)()
         _lib.check(_lib.load().oh_get_timing(self._h, out), "oh_get_timing")
-        return {"solve_ms": out[4], "iterations_launched": int(out[5]), "work_instances": out[6]}
+        return {"solve_ms": out[4], "iterations_launched": int(out[5]), "work_instances": out[6], "eval_ms": out[0], "step_ms": out[2]}  # (eval / step: profiled solves only)
 
 
 class FigureEightBackend(_OptionsMixin):

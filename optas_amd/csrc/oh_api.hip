@@ -956,9 +956,24 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   double work = 0.0;
   int running = B;
   const int cap = P.max_iter + 2;
+  // oh_set_profiling(1): one event before the evaluation pair (k_tq_eval3 + k_tq_curv), one after it, one after k_tq_step, every iteration -- the
+  // per-kernel device times behind the family's roofline object (tools/bench_configs.py); such a solve runs on one stream
+  const bool prof = h->profiling;
+  size_t ne = 0;
+  if (prof) {
+    const size_t need = 3 * (size_t)cap + 4;
+    while (h->prof_events.size() < need) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      h->prof_events.push_back(e);
+    }
+  }
   while (launched < cap) {
+    if (prof) HIPCHK(hipEventRecord(h->prof_events[ne++], s));
     oh_launch_tq_eval(s, P, D);  // also resets the running count
+    if (prof) HIPCHK(hipEventRecord(h->prof_events[ne++], s));
     oh_launch_tq_step(s, P, D);
+    if (prof) HIPCHK(hipEventRecord(h->prof_events[ne++], s));
     ++launched;
     work += running;
     if (launched % h->tq_check == 0 || launched == cap) {
@@ -981,6 +996,16 @@ static int tq_solve_device(oh_handle* h, int B, const void* d_x0, const void* d_
   float ms = 0.f;
   HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
   for (double& t : h->timing) t = 0.0;
+  if (prof) {
+    for (size_t i = 0; i + 3 <= ne; i += 3) {
+      float a = 0.f, b2 = 0.f;
+      hipEventElapsedTime(&a, h->prof_events[i], h->prof_events[i + 1]);
+      hipEventElapsedTime(&b2, h->prof_events[i + 1], h->prof_events[i + 2]);
+      h->timing[0] += a;
+      h->timing[2] += b2;
+    }
+    h->timing[1] = h->timing[3] = launched;
+  }
   h->timing[4] = ms;
   h->timing[5] = launched;
   h->timing[6] = work;
@@ -1585,7 +1610,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (h->desc.kind == OH_PROBLEM_TORQUE_MPC) {
     if (!h->is_peer) h->split_parts.clear();
     const int S = std::min(8, (int)optv(h, "streams", 2.0));
-    if (!h->is_peer && S >= 2 && B >= (int)optv(h, "tq_split_min", 1024.0) && B / S >= 64 && h->have_chain && h->have_dyn)
+    if (!h->is_peer && !h->profiling && S >= 2 && B >= (int)optv(h, "tq_split_min", 1024.0) && B / S >= 64 && h->have_chain && h->have_dyn)
       return solve_split(h, S, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
     return tq_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   }

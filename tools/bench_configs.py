@@ -18,6 +18,59 @@ from optas_amd.backend import FigureEightBackend, IKBackend, PointMassBackend, T
 from optas_amd.models import RobotModel  # noqa: E402
 
 SEED = 20260927
+F64_PEAK_TFLOPS = 78.6  # MI355X f64 vector peak = f64 MFMA peak (157.3 TF f32 / 2; the families below run 4x4 ... 7x7 blocks on the vector pipes)
+FLOPS_FILE = os.path.join(ROOT, "profiles", "configs_flops.json")  # f64 flop per work unit of each family's kernels, from rocprofv3 --pmc passes (tools/gpu_configs_pmc.sh)
+
+
+def pub(r: dict) -> dict:
+    return {k: v for k, v in r.items() if not k.startswith("_")}
+
+
+def usable_cores() -> int:
+    sys.path.insert(0, ROOT)
+    import bench
+
+    return bench.usable_cores()
+
+
+def cpu_leg(config: str, arrays: dict, f_gpu_head, seconds: float = 6.0):
+    """The family's numpy port on the same instances, 1 process and all usable cores (tools/cpu_legs.py, a subprocess: no HIP runtime in it)."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, f"{config}.npz")
+        np.savez(path, **arrays)
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_legs.py"), path, config, str(usable_cores()), str(seconds)], capture_output=True, text=True, timeout=600)
+            leg = json.loads(cp.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001
+            return {"error": f"{type(e).__name__}: {e}"}
+    fp = np.array(leg.pop("f_first"))
+    n = min(len(fp), len(f_gpu_head))
+    leg["gpu_vs_port_objective_rel_max"] = float((np.abs(fp[:n] - f_gpu_head[:n]) / np.maximum(1e-12, np.abs(fp[:n]))).max()) if n else None
+    leg["gpu_vs_port_instances"] = int(n)
+    return leg
+
+
+def flop_roofline(family: str, kernel_ms: dict, units: float, unit_name: str):
+    """roofline object of a family whose kernels are f64-arithmetic / latency bound: achieved = (f64 flop per work unit of the dominant kernel group, counted once
+    by the SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 counters: profiles/configs_flops.json) x (work units of THIS run) / (that group's HIP-event time in THIS run)."""
+    dom = max(kernel_ms, key=kernel_ms.get)
+    r = {"kernel": dom, "bound": "mfma", "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "achieved": None, "frac": None, "traffic": None,
+         "peak_note": "f64: the MFMA f64 peak equals the vector f64 peak on MI355X (78.6 TFLOP/s); these kernels run their small dense blocks on the vector pipes",
+         "kernel_ms": kernel_ms, "work_units": units, "work_unit": unit_name}
+    try:
+        fl = json.load(open(FLOPS_FILE))[family]
+        per_unit = fl["flop_per_unit"][dom]
+        r["flop_per_unit"] = per_unit
+        r["flop_source"] = {"file": "profiles/configs_flops.json", "profile": fl.get("tag"), "counted_at_units": fl.get("units"), "note": "wave-level instruction counts x 64 lanes (2 flop per FMA): all lanes counted as active"}
+        r["achieved"] = per_unit * units / (kernel_ms[dom] * 1e-3) / 1e12
+        r["frac"] = r["achieved"] / F64_PEAK_TFLOPS
+        r["all_kernels"] = {k: fl["flop_per_unit"].get(k, 0.0) * units / (v * 1e-3) / 1e12 for k, v in kernel_ms.items() if v > 0}
+    except Exception as e:  # noqa: BLE001
+        r["flop_source"] = f"unavailable ({type(e).__name__}: {e})"
+    return r
 
 
 def timed(be, x0, p, reps=3):
@@ -141,7 +194,19 @@ def oracle_grade(kind, **kw):
             "complementarity_max": max(k["complementarity"] for k in ks), "by": "oracle/solvers.py:kkt_reference_form on the literal NLP of oracle/problems.py"}
 
 
-def timed_with_results(be, x0, p, reps=3, sample=0, seed=0):  # (median of three timed solves after one warm-up: with two, one hiccup of the box moves the figure)
+PROBE = None  # tools/gpu_configs_pmc.sh: {"units": work units of every solve run so far} -- the denominator of the flop counters rocprofv3 collects over the same process
+
+
+def _probe_units(be, it):
+    if PROBE is None:
+        return
+    tm = be.timing() if hasattr(be, "timing") else {}
+    w = tm.get("work_instances", tm.get("instance_launches", 0.0))
+    PROBE["units"] += float(w) if w else float(np.asarray(it).sum())
+    PROBE["solves"] += 1
+
+
+def timed_with_results(be, x0, p, reps=3, sample=0, seed=0, profile=False):  # (median of three timed solves after one warm-up: with two, one hiccup of the box moves the figure)
     """timed() plus a sample of (x, p, f) rows downloaded from the device for the oracle."""
     B = x0.shape[0]
     bufs = [_lib.DeviceBuffer(a.nbytes) for a in (x0, p)]
@@ -151,12 +216,18 @@ def timed_with_results(be, x0, p, reps=3, sample=0, seed=0):  # (median of three
     d_i, d_s = _lib.DeviceBuffer(4 * B), _lib.DeviceBuffer(4 * B)
     ms = []
     host = not hasattr(be, "solve_device")  # (a problem solved over fewer variables than it has: the host entry point puts the eliminated ones back)
+    if PROBE is not None and profile and hasattr(be, "set_profiling"):
+        be.set_profiling(True)  # the counters are collected on the launches the roofline pass times: one stream, an event after every kernel
     for _ in range(reps + 1):
         if host:
             rh = be.solve(x0, p)
         else:
             be.solve_device(B, bufs[0], bufs[1], d_x, d_f, d_k, d_i, d_s)
         ms.append(be.solve_ms() if hasattr(be, "solve_ms") else be.timing()["solve_ms"])
+        if PROBE is not None:
+            _probe_units(be, rh.iters if host else d_i.download(np.int32, (B,)))
+    if PROBE is not None and profile and hasattr(be, "set_profiling"):
+        be.set_profiling(False)
     if host:
         it, st, kk = rh.iters, rh.status, rh.kkt
         d_x.upload(rh.x)
@@ -166,10 +237,21 @@ def timed_with_results(be, x0, p, reps=3, sample=0, seed=0):  # (median of three
     ok = st == 0
     r = {"device_ms": float(np.median(ms[1:])), "converged_frac": float(ok.mean()), "iters_p50": float(np.median(it)), "iters_p90": float(np.percentile(it, 90)),
          "iters_max": int(it.max()), "stationarity_max": float(kk[ok, 0].max()), "feasibility_max": float(kk[ok, 1].max())}
+    F = d_f.download(np.float64, (B,))
+    r["_f_head"], r["_iters_sum"] = F[:8].copy(), float(it.sum())
+    if profile and not host and hasattr(be, "set_profiling"):
+        # one more solve with a HIP event after every kernel of the handle's stream (one stream, no split): the per-kernel times of the roofline object
+        be.set_profiling(True)
+        be.solve_device(B, bufs[0], bufs[1], d_x, d_f, d_k, d_i, d_s)
+        tp = be.timing()
+        if PROBE is not None:
+            _probe_units(be, None)
+        be.set_profiling(False)
+        r["_profiled"] = {"eval_ms": tp.get("eval_ms", 0.0), "step_ms": tp.get("step_ms", 0.0), "solve_ms": tp["solve_ms"],
+                          "work": float(tp.get("work_instances", tp.get("instance_launches", 0.0)))}
     smp = None
     if sample:
         X = d_x.download(np.float64, x0.shape)
-        F = d_f.download(np.float64, (B,))
         idx = np.sort(np.random.default_rng(seed).choice(np.flatnonzero(ok), min(sample, int(ok.sum())), replace=False))
         smp = {"x": X[idx], "p": p[idx], "f": F[idx], "idx": idx}
     for b in bufs + [d_x, d_f, d_k, d_i, d_s]:
@@ -177,17 +259,20 @@ def timed_with_results(be, x0, p, reps=3, sample=0, seed=0):  # (median of three
     return r, smp
 
 
-def run_configs(sample=8, torque_batches=(8192, 1024), only=None):
+def run_configs(sample=8, torque_batches=(8192, 1024), only=None, cpu=None):
     """BASELINE configs 1, 3, 4, 5 at their stated sizes: device time of one batched solve (HIP events, inputs resident), convergence, and an
     oracle-graded sample of each -- what bench.py prints as its `configs` block."""
     rng = np.random.default_rng(SEED)
     out = {}
     kuka = RobotModel.builtin("kuka_lwr")
+    cpu = (sample > 0) if cpu is None else cpu  # CPU legs (numpy ports on the host cores) go with the oracle-graded samples: both are off under --no-cpu-baseline
     if only == "torque":
         rng = np.random.default_rng(SEED + 5)
-        return _torque(out, rng, sample, torque_batches)
+        return _torque(out, rng, sample, torque_batches, cpu)
     if only == "config4":
-        return _config4(out, np.random.default_rng(SEED + 4), sample)
+        return _config4(out, np.random.default_rng(SEED + 4), sample, cpu)
+    if only == "pm":
+        return _pm(out, rng, sample, cpu)
     # config 1
     B = 65536
     be = IKBackend(kuka.kinematic_chain("end_effector_ball"), kuka.lower_actuated_joint_limits, kuka.upper_actuated_joint_limits, max_iter=300)
@@ -195,9 +280,23 @@ def run_configs(sample=8, torque_batches=(8192, 1024), only=None):
     pg = np.asarray(kuka.get_global_link_position("end_effector_ball", np.clip(qn + rng.uniform(-0.5, 0.5, (B, 7)), kuka.lower_actuated_joint_limits,
                                                                              kuka.upper_actuated_joint_limits).T)).T
     r, smp = timed_with_results(be, np.ascontiguousarray(qn), np.ascontiguousarray(np.concatenate([qn, pg], 1)), sample=sample, seed=1)
-    out["config1_ik"] = {"what": "example.py IK (KUKA LWR, joint limits, position goal), B = 65536", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
-                         "oracle_sample": oracle_grade("ik", **smp) if smp else None}
+    out["config1_ik"] = {"what": "example.py IK (KUKA LWR, joint limits, position goal), B = 65536", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **pub(r),
+                         "oracle_sample": oracle_grade("ik", **smp) if smp else None,
+                         "roofline": flop_roofline("ik", {"k_ik (the whole solve: one launch)": r["device_ms"]}, r["_iters_sum"], "instance-step")}
+    if cpu:
+        nl = min(B, 2048)
+        out["config1_ik"]["cpu_baseline"] = cpu_leg("ik", dict(n=nl, qn=qn[:nl], pg=pg[:nl], lo=np.asarray(kuka.lower_actuated_joint_limits, float), up=np.asarray(kuka.upper_actuated_joint_limits, float)), r["_f_head"])
     be.close()
+    if only == "ik":
+        return out
+    _pm(out, rng, sample, cpu)
+    _velocity_limited(out, sample)
+    _config4(out, rng, sample, cpu)
+    _planner_tape(out, sample)
+    return _torque(out, rng, sample, torque_batches, cpu)
+
+
+def _pm(out, rng, sample, cpu=False):
     # config 3: tick and closed loop
     from examples.point_mass_mpc import obstacle_and_goal
 
@@ -215,16 +314,20 @@ def run_configs(sample=8, torque_batches=(8192, 1024), only=None):
     r, smp = timed_with_results(be, np.zeros((B, 80)), P, sample=sample, seed=3)
     n_ticks, adv, T = 50, 2, 20
     tab = np.array([[0.15 * np.sin((2.0 + 0.05 * j) * np.pi - np.pi), 0.15 * np.cos((2.0 + 0.05 * j) * np.pi - np.pi) + 0.15] for j in range(n_ticks * adv + T)])
+    if PROBE is not None:  # (counter passes: only the launches whose work units are counted)
+        be.close()
+        return out
     be.rollout(P[:, :4], tab, 2)
     _, _, _, stt = be.rollout(P[:, :4], tab, n_ticks, adv)
-    out["config3_point_mass"] = {"what": "point_mass_mpc.py tick (T=20, box limits, moving obstacle), B = 4096 initial states", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
+    out["config3_point_mass"] = {"what": "point_mass_mpc.py tick (T=20, box limits, moving obstacle), B = 4096 initial states", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **pub(r),
                                  "oracle_sample": oracle_grade("pm", **smp) if smp else None,
-                                 "closed_loop": {"ticks": n_ticks, "device_ms": be.solve_ms(), "ticks_per_s": B * n_ticks / be.solve_ms() * 1e3, "converged_frac": float((stt == 0).mean())}}
+                                 "closed_loop": {"ticks": n_ticks, "device_ms": be.solve_ms(), "ticks_per_s": B * n_ticks / be.solve_ms() * 1e3, "converged_frac": float((stt == 0).mean())},
+                                 "roofline": flop_roofline("pm", {"k_pm (the whole solve: one launch)": r["device_ms"]}, r["_iters_sum"], "instance-step")}
+    if cpu:
+        nl = min(B, 2048)
+        out["config3_point_mass"]["cpu_baseline"] = cpu_leg("pm", dict(n=nl, P=P[:nl]), r["_f_head"])
     be.close()
-    _velocity_limited(out, sample)
-    _config4(out, rng, sample)
-    _planner_tape(out, sample)
-    return _torque(out, rng, sample, torque_batches)
+    return out
 
 
 def _velocity_limited(out, sample):
@@ -238,7 +341,7 @@ def _velocity_limited(out, sample):
     x0[:, :350] = np.repeat(qcs, 50, axis=0).reshape(B, 350)
     r, smp = timed_with_results(solver.backend, x0, np.ascontiguousarray(qcs), sample=min(sample, 4), seed=2)
     out["config2_velocity_limited"] = {"what": "figure_eight_plan.py T=50 + joint-velocity limits (686 inequality rows), B = 65536; persistent kernel k_tail_vel", "batch": B,
-                                       "solves_per_s": B / r["device_ms"] * 1e3, **r, "oracle_sample": oracle_grade("fig8_vel", **smp) if smp else None}
+                                       "solves_per_s": B / r["device_ms"] * 1e3, **pub(r), "oracle_sample": oracle_grade("fig8_vel", **smp) if smp else None}
     solver.backend.close()
 
 
@@ -274,7 +377,7 @@ def _planner_tape(out, sample):
                  "inequality_rows_min": float(min(nlp.g(x, p).min() for x, p in zip(smp["x"], smp["p"]))),
                  "by": "oracle/problems.py:JointSpacePlannerNLP (literal layout: 40 inequality, 147 + 7 equality rows)"}
     out["planner_tape"] = {"what": "simple_joint_space_planner.py (280 variables, 154 equality rows of which the host eliminates the 147 affine ones: 133 variables on the device) on the generic tape family, one block of wavefronts per instance; B = 256 perturbed problems",
-                           "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
+                           "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **pub(r),
                            "path": {k: be.flag(k) for k in ("tape_wave", "tape_levels", "tape_passes")},
                            "golden_instances": {"n": nb, "device_ms": ms4, "evaluations": [int(v) for v in r4.iters], "converged": bool((np.asarray(r4.status) == 0).all()),
                                                 "f_rel_diff_to_interior_point_golden": [float(abs(a - b) / b) for a, b in zip(r4.f, g["f"])]},
@@ -282,7 +385,7 @@ def _planner_tape(out, sample):
     be.close()
 
 
-def _config4(out, rng, sample):
+def _config4(out, rng, sample, cpu=False):
     # config 4 synthetic: T = 100, limits + 4 x 6 sphere rows per knot, link radius 0.15 as SURVEY 8(d) states; arms are independent instances
     from examples.dual_arm import SPHERE_LINKS, draw_feasible_configurations, path_offsets
 
@@ -309,15 +412,23 @@ def _config4(out, rng, sample):
         obs_row = np.concatenate([[0.55, 0.0, 0.1 * (i + 1), 0.1] for i in range(6)])
         p = np.ascontiguousarray(np.concatenate([qc, np.full((B, 4), radius), np.tile(obs_row, (B, 1))], 1))
         x0 = np.ascontiguousarray(np.concatenate([np.tile(qc, (1, T)), np.zeros((B, 7 * (T - 1)))], 1))
-        r, smp = timed_with_results(be, x0, p, sample=max(sample, 16), seed=4)
-        out[f"config4_arms{B}_r{radius:g}"] = {"what": f"dual_arm.py synthetic: T=100, joint limits + 4 x 6 sphere clearances (link radius {radius:g}), {B} arms "
-                                                        "(a dual-arm instance = two of them)", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **r,
+        r, smp = timed_with_results(be, x0, p, sample=max(sample, 16) if sample else 0, seed=4, profile=True)
+        key4 = f"config4_arms{B}_r{radius:g}"
+        out[key4] = {"what": f"dual_arm.py synthetic: T=100, joint limits + 4 x 6 sphere clearances (link radius {radius:g}), {B} arms "
+                                                        "(a dual-arm instance = two of them)", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **pub(r),
                                                "oracle_sample": oracle_grade("guarded_arm", T=T, links=SPHERE_LINKS, offsets=offs.T, **smp) if smp else None}
+        pr = r.get("_profiled")
+        if pr:
+            out[key4]["roofline"] = flop_roofline("guarded", {"k_eval_guarded": pr["eval_ms"], "k_step_free*": pr["step_ms"]}, pr["work"], "instance-launch (T - 1 knots)")
+            out[key4]["roofline"]["profiled_solve_ms"] = pr["solve_ms"]
+        if cpu and B == 1024:
+            nl = min(B, 512)
+            out[key4]["cpu_baseline"] = cpu_leg("guarded", dict(n=nl, p=p[:nl], T=T, dt=10.0 / (T - 1), offsets=offs.T, links=np.array(SPHERE_LINKS)), r["_f_head"])
         be.close()
     return out
 
 
-def _torque(out, rng, sample, torque_batches):
+def _torque(out, rng, sample, torque_batches, cpu=False):
     # config 5
     med7 = RobotModel.builtin("med7")
     link, T, dt = "lbr_link_ee", 30, 0.1
@@ -337,14 +448,21 @@ def _torque(out, rng, sample, torque_batches):
         x0 = np.zeros((B, 4 * 7 * T))
         x0[:, : 7 * T] = np.tile(qc, (1, T))
         be = TorqueBackend(med7.kinematic_chain(link), med7.dynamics_tables(), T=T, dt=dt, w_path=1000.0, w_vel=0.1, w_tau=1e-4, tau_lo=-58.0, tau_up=58.0, max_iter=600)
-        r, smp = timed_with_results(be, x0, p, sample=(min(sample, 4) if B > 1 else 1), seed=5, reps=3 if B > 1 else 5)  # (median of three: a latency-bound solve of 80 launches shows any hiccup of the host loop)
+        r, smp = timed_with_results(be, x0, p, sample=((min(sample, 4) if B > 1 else 1) if sample else 0), seed=5, reps=3 if B > 1 else 5, profile=True)  # (median of three: a latency-bound solve of 80 launches shows any hiccup of the host loop)
         tm = be.timing()
         if smp:
             smp["lam"] = be.multipliers(B)[smp["idx"]]
         out[f"config5_torque_b{B}"] = {"what": f"torque MPC, RNEA dynamics equality rows + effort limits 58 N m (med7, T=30), primal-dual interior point, B = {B}" + (" (the nominal instance)" if B == 1 else ""),
-                                       "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, "iterations_launched": tm["iterations_launched"], **r,
+                                       "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, "iterations_launched": tm["iterations_launched"], **pub(r),
                                        "oracle_sample": oracle_grade("torque", T=T, lim=58.0, **smp) if smp else None}
-        if B == max(torque_batches):
+        pr = r.get("_profiled")
+        if pr:
+            out[f"config5_torque_b{B}"]["roofline"] = flop_roofline("torque", {"k_tq_eval3+k_tq_curv": pr["eval_ms"], "k_tq_step": pr["step_ms"]}, pr["work"], "instance-iteration (T = 30 knots)")
+            out[f"config5_torque_b{B}"]["roofline"]["profiled_solve_ms"] = pr["solve_ms"]
+        if cpu and B == max(torque_batches):
+            nl = min(B, 256)
+            out[f"config5_torque_b{B}"]["cpu_baseline"] = cpu_leg("torque", dict(n=nl, qc=qc[:nl], goal=goal[:nl], T=T, dt=dt, lim=58.0), r["_f_head"], seconds=9.0)
+        if B == max(torque_batches) and PROBE is None:
             # the MPC steady state (round 5, oh_tq_rollout): the same plants in closed loop, warm-started ticks resident on the device.  The goal table
             # continues the figure of eight; the plant follows each plan for one knot.  Graded: a warm tick ends where the cold solve from the same state does.
             n_ticks = 50
@@ -372,7 +490,19 @@ def _torque(out, rng, sample, torque_batches):
     return out
 
 
+def probe_main(family):
+    """One family's GPU leg (no oracle, no CPU leg), run under rocprofv3 --pmc by tools/gpu_configs_pmc.sh: prints the work units of all its solves."""
+    global PROBE
+    PROBE = {"units": 0.0, "solves": 0}
+    run_configs(sample=0, cpu=False, only={"ik": "ik", "pm": "pm", "guarded": "config4", "torque": "torque"}[family], torque_batches=(8192,))
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "cfgpmc"), exist_ok=True)
+    json.dump({"family": family, **PROBE}, open(os.path.join(ROOT, "gpurun_out", "cfgpmc", f"{family}_units.json"), "w"))
+    print(json.dumps(PROBE))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--probe":
+        return probe_main(sys.argv[2])
     rng = np.random.default_rng(SEED)
     out = []
     kuka = RobotModel.builtin("kuka_lwr")

@@ -259,7 +259,7 @@ def timed_with_results(be, x0, p, reps=3, sample=0, seed=0, profile=False):  # (
     return r, smp
 
 
-def run_configs(sample=8, torque_batches=(8192, 1024), only=None, cpu=None):
+def run_configs(sample=8, torque_batches=(8192, 1024), only=None, cpu=None, ik_batch=65536, pm_batch=4096, config4_cases=((256, 0.15), (1024, 0.15), (1024, 0.1))):
     """BASELINE configs 1, 3, 4, 5 at their stated sizes: device time of one batched solve (HIP events, inputs resident), convergence, and an
     oracle-graded sample of each -- what bench.py prints as its `configs` block."""
     rng = np.random.default_rng(SEED)
@@ -270,17 +270,17 @@ def run_configs(sample=8, torque_batches=(8192, 1024), only=None, cpu=None):
         rng = np.random.default_rng(SEED + 5)
         return _torque(out, rng, sample, torque_batches, cpu)
     if only == "config4":
-        return _config4(out, np.random.default_rng(SEED + 4), sample, cpu)
+        return _config4(out, np.random.default_rng(SEED + 4), sample, cpu, config4_cases)
     if only == "pm":
-        return _pm(out, rng, sample, cpu)
+        return _pm(out, rng, sample, cpu, pm_batch)
     # config 1
-    B = 65536
+    B = ik_batch
     be = IKBackend(kuka.kinematic_chain("end_effector_ball"), kuka.lower_actuated_joint_limits, kuka.upper_actuated_joint_limits, max_iter=300)
     qn = np.deg2rad([0, 45, 0, -90, 0, -45, 0]) + rng.uniform(-0.3, 0.3, (B, 7))
     pg = np.asarray(kuka.get_global_link_position("end_effector_ball", np.clip(qn + rng.uniform(-0.5, 0.5, (B, 7)), kuka.lower_actuated_joint_limits,
                                                                              kuka.upper_actuated_joint_limits).T)).T
     r, smp = timed_with_results(be, np.ascontiguousarray(qn), np.ascontiguousarray(np.concatenate([qn, pg], 1)), sample=sample, seed=1)
-    out["config1_ik"] = {"what": "example.py IK (KUKA LWR, joint limits, position goal), B = 65536", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **pub(r),
+    out["config1_ik"] = {"what": f"example.py IK (KUKA LWR, joint limits, position goal), B = {B}", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **pub(r),
                          "oracle_sample": oracle_grade("ik", **smp) if smp else None,
                          "roofline": flop_roofline("ik", {"k_ik (the whole solve: one launch)": r["device_ms"]}, r["_iters_sum"], "instance-step")}
     if cpu:
@@ -289,37 +289,44 @@ def run_configs(sample=8, torque_batches=(8192, 1024), only=None, cpu=None):
     be.close()
     if only == "ik":
         return out
-    _pm(out, rng, sample, cpu)
+    _pm(out, rng, sample, cpu, pm_batch)
     _velocity_limited(out, sample)
-    _config4(out, rng, sample, cpu)
+    _config4(out, rng, sample, cpu, config4_cases)
     _planner_tape(out, sample)
     return _torque(out, rng, sample, torque_batches, cpu)
 
 
-def _pm(out, rng, sample, cpu=False):
+def _pm(out, rng, sample, cpu=False, B=4096):
     # config 3: tick and closed loop
     from examples.point_mass_mpc import obstacle_and_goal
 
-    B = 4096
     be = PointMassBackend()
     P = []
     obs, _ = obstacle_and_goal(2.0, np.zeros(2))
-    while len(P) < B:
-        c = rng.uniform(-1.2, 1.2, 2)
-        if np.linalg.norm(c - obs[:, 0]) <= 0.35:
-            continue
-        goal = np.stack([np.clip(c[j] + (1 - c[j]) * np.arange(20) / 19.0, -1.5, 1.5) for j in range(2)])
-        P.append(np.concatenate([c, np.zeros(2), goal.T.reshape(-1), obs.T.reshape(-1)]))
-    P = np.array(P)
+    if B <= 65536:
+        while len(P) < B:
+            c = rng.uniform(-1.2, 1.2, 2)
+            if np.linalg.norm(c - obs[:, 0]) <= 0.35:
+                continue
+            goal = np.stack([np.clip(c[j] + (1 - c[j]) * np.arange(20) / 19.0, -1.5, 1.5) for j in range(2)])
+            P.append(np.concatenate([c, np.zeros(2), goal.T.reshape(-1), obs.T.reshape(-1)]))
+        P = np.array(P)
+    else:  # (batch sweeps: the same distribution drawn in bulk)
+        c = rng.uniform(-1.2, 1.2, (2 * B, 2))
+        c = c[np.linalg.norm(c - obs[:, 0][None], axis=1) > 0.35][:B]
+        goal = np.clip(c[:, None, :] + (1 - c[:, None, :]) * (np.arange(20) / 19.0)[None, :, None], -1.5, 1.5)  # [B][20][2]
+        P = np.ascontiguousarray(np.concatenate([c, np.zeros((B, 2)), goal.reshape(B, -1), np.tile(obs.T.reshape(-1), (B, 1))], 1))
     r, smp = timed_with_results(be, np.zeros((B, 80)), P, sample=sample, seed=3)
     n_ticks, adv, T = 50, 2, 20
     tab = np.array([[0.15 * np.sin((2.0 + 0.05 * j) * np.pi - np.pi), 0.15 * np.cos((2.0 + 0.05 * j) * np.pi - np.pi) + 0.15] for j in range(n_ticks * adv + T)])
-    if PROBE is not None:  # (counter passes: only the launches whose work units are counted)
+    if PROBE is not None or B != 4096:  # (counter passes: only the launches whose work units are counted; batch sweeps: the tick alone)
+        out["config3_point_mass"] = {"what": f"point_mass_mpc.py tick, B = {B}", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **pub(r),
+                                     "roofline": flop_roofline("pm", {"k_pm (the whole solve: one launch)": r["device_ms"]}, r["_iters_sum"], "instance-step")}
         be.close()
         return out
     be.rollout(P[:, :4], tab, 2)
     _, _, _, stt = be.rollout(P[:, :4], tab, n_ticks, adv)
-    out["config3_point_mass"] = {"what": "point_mass_mpc.py tick (T=20, box limits, moving obstacle), B = 4096 initial states", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **pub(r),
+    out["config3_point_mass"] = {"what": f"point_mass_mpc.py tick (T=20, box limits, moving obstacle), B = {B} initial states", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **pub(r),
                                  "oracle_sample": oracle_grade("pm", **smp) if smp else None,
                                  "closed_loop": {"ticks": n_ticks, "device_ms": be.solve_ms(), "ticks_per_s": B * n_ticks / be.solve_ms() * 1e3, "converged_frac": float((stt == 0).mean())},
                                  "roofline": flop_roofline("pm", {"k_pm (the whole solve: one launch)": r["device_ms"]}, r["_iters_sum"], "instance-step")}
@@ -385,14 +392,14 @@ def _planner_tape(out, sample):
     be.close()
 
 
-def _config4(out, rng, sample, cpu=False):
+def _config4(out, rng, sample, cpu=False, cases=((256, 0.15), (1024, 0.15), (1024, 0.1))):
     # config 4 synthetic: T = 100, limits + 4 x 6 sphere rows per knot, link radius 0.15 as SURVEY 8(d) states; arms are independent instances
     from examples.dual_arm import SPHERE_LINKS, draw_feasible_configurations, path_offsets
 
     QC = np.deg2rad([0, -30, 0, 90, 0, 30, 0])
     T = 100
     offs = path_offsets(T, [-0.1, 0.1, -0.2], [0.0, 0.0, 0.3])
-    for B, radius in ((256, 0.15), (1024, 0.15), (1024, 0.1)):
+    for B, radius in cases:
         arm = RobotModel.builtin("kuka_lwr", time_derivs=[0, 1], name="kukal")
         arm.add_base_frame("global_world", xyz=[0.0, -0.25, 0.0])
         g = _lib.oh_guards()

@@ -228,6 +228,13 @@ def oracle_sample(x0, qc, x, f, status, n: int, tol: float = 1e-8):
     }
 
 
+def per_rank_block(elapsed_s, device_ms_per_step, rate, reduce_max, reduce_sum, rccl_world, note):
+    """What a multi-rank run reports about the spread over its ranks (the same code in the real run, over RCCL, and in --dry-run, over the rendezvous carrier)."""
+    return {"elapsed_s_max": reduce_max(elapsed_s), "elapsed_s_min": -reduce_max(-elapsed_s),
+            "device_ms_per_step_max": reduce_max(device_ms_per_step), "device_ms_per_step_min": -reduce_max(-device_ms_per_step),
+            "sum_of_rank_rates_solves_per_s": reduce_sum(rate), "rccl_world": rccl_world, "note": note}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,8 +281,36 @@ def main():
             else:
                 open(f"{ack}{rank}", "w").close()
         x0, qc = make_inputs(min(args.batch, 64), rank)
+        per_rank = None
+        if "RANK" in os.environ:
+            # the per-rank block of a real run with stand-in measurements (rank r: 1 + r / 100 s, 80 + r ms), reduced over files in the private rendezvous
+            # directory instead of RCCL: the harness code that builds the block is the real one (per_rank_block)
+            vdir = oad.rendezvous_dir()
+            os.makedirs(vdir, mode=0o700, exist_ok=True)
+            tag = hashlib.sha256(uid).hexdigest()[:16]
+            calls = [0]
+
+            def gather(v):
+                calls[0] += 1
+                mine_path = os.path.join(vdir, f"dry_{tag}_{calls[0]}_{rank}.val")
+                with open(mine_path + ".tmp", "w") as fh:
+                    fh.write(repr(float(v)))
+                os.replace(mine_path + ".tmp", mine_path)
+                vals, t_g = [], time.monotonic()
+                for r in range(world):
+                    pth = os.path.join(vdir, f"dry_{tag}_{calls[0]}_{r}.val")
+                    while not os.path.exists(pth):
+                        if time.monotonic() - t_g > 60.0:
+                            raise SystemExit(f"dry run: rank {r} never published value {calls[0]}")
+                        time.sleep(0.005)
+                    vals.append(float(open(pth).read()))
+                return vals
+
+            per_rank = per_rank_block(1.0 + rank / 100.0, 80.0 + rank, 1000.0 * (rank + 1), lambda v: max(gather(v)), lambda v: sum(gather(v)), None,
+                                      "dry run: stand-in measurements, reduced over the rendezvous directory (a real run reduces over RCCL and reports rccl_world = WORLD_SIZE)")
         print(json.dumps({"dry_run": True, "rank": rank, "world": world, "local_rank": local_rank, "rdzv": os.environ.get("OPTAS_RDZV", "file"),
-                          "id_sha256": hashlib.sha256(uid).hexdigest(), "id_bytes": len(uid), "qc_first": qc[0].tolist(), "nx": int(x0.shape[1])}), flush=True)
+                          "id_sha256": hashlib.sha256(uid).hexdigest(), "id_bytes": len(uid), "qc_first": qc[0].tolist(), "nx": int(x0.shape[1]),
+                          "device_index": local_rank, "per_rank": per_rank}), flush=True)
         return
     comm = None
     rccl_error = None
@@ -352,12 +387,10 @@ def main():
     per_rank = None
     if comm is not None:
         mine = elapsed
-        elapsed = comm.max_over_ranks(mine)
         dev = solve_ms_plain / args.steps  # this rank's own HIP-event time of one step: rank skew shows as max - min
-        per_rank = {"elapsed_s_max": elapsed, "elapsed_s_min": -comm.max_over_ranks(-mine),
-                    "device_ms_per_step_max": comm.max_over_ranks(dev), "device_ms_per_step_min": -comm.max_over_ranks(-dev),
-                    "sum_of_rank_rates_solves_per_s": comm.sum_over_ranks(B * args.steps / mine),
-                    "note": "each rank's own wall time of the K steps between the two barriers, reduced through oh_comm_allreduce_{max,sum}; value uses the max"}
+        per_rank = per_rank_block(mine, dev, B * args.steps / mine, comm.max_over_ranks, comm.sum_over_ranks, rccl_world,
+                                  "each rank's own wall time of the K steps between the two barriers, reduced through oh_comm_allreduce_{max,sum}; value uses the max")
+        elapsed = per_rank["elapsed_s_max"]
     # second pass of the same K steps with one hipEventRecord after every kernel on the handle's stream: the per-kernel times behind the
     # roofline object (the timed pass above runs without them)
     be.set_profiling(True)
@@ -420,13 +453,25 @@ def main():
     # PCIe-inclusive rate: the same problem through oh_solve from pageable host buffers (what a ctypes host that keeps nothing resident pays)
     pcie = None
     if world == 1 and not args.timed_only:
-        nb = min(B, 65536)
-        be.solve(x0[:nb], qc[:nb])
-        t0h = time.perf_counter()
-        rh = be.solve(x0[:nb], qc[:nb])
-        t_h = time.perf_counter() - t0h
-        pcie = {"batch": nb, "wall_ms": 1e3 * t_h, "device_ms": be.timing()["solve_ms"], "solves_per_s": nb / t_h, "converged_frac": float((rh.status == 0).mean()),
-                "what": "oh_solve with pageable numpy buffers: x0 and p up, x, f, kkt, iters, status down (2 x 5.5 KB per instance over PCIe), one call"}
+        # (outputs allocated once and touched: a fresh np.empty of a gigabyte is page faults, not PCIe)
+        hx, hf, hk = np.zeros((B, nx)), np.zeros(B), np.zeros((B, 3))
+        hi, hs = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+
+        def host_solve(nb):
+            t0h = time.perf_counter()
+            _lib.check(lib.oh_solve(be.handle, nb, _lib._ptr(x0), _lib._ptr(qc), _lib._ptr(hx), _lib._ptr(hf), _lib._ptr(hk), _lib._ptr(hi), _lib._ptr(hs)), "oh_solve")
+            return time.perf_counter() - t0h
+
+        pcie = {}
+        for nb in sorted({min(B, 65536), B}):
+            host_solve(nb)
+            t_h = min(host_solve(nb) for _ in range(2))
+            pcie[f"batch_{nb}"] = {"batch": nb, "wall_ms": 1e3 * t_h, "solves_per_s": nb / t_h, "converged_frac": float((hs[:nb] == 0).mean()),
+                                   "frac_of_resident_rate": (nb / t_h) / (B * args.steps / elapsed) if nb == B else None}
+        pcie["solves_per_s"] = pcie[f"batch_{B}"]["solves_per_s"]
+        pcie["what"] = ("oh_solve with pageable numpy buffers: x0 and p up, x, f, kkt, iters, status down (2 x 5.5 KB per instance over PCIe), one call, best of two; since round 6 a batch of "
+                        ">= 2 x pipe_chunk (32 768) instances goes in chunks on two lanes (handle + peer, a stream and a host thread each: csrc/oh_api.hip:solve_pipelined), one lane's "
+                        "transfers under the other lane's kernels; `solves_per_s` is the rate at the bench batch")
     occupancy = {k: be.kernel_info(k) for k in (("k_retract", "k_evalb_zc", "k_step_zc", "k_tail", "k_fk_jac") if be.flag("fuse_couple") else
                                                 ("k_retract", "k_evalb", "k_couple", "k_step", "k_tail", "k_fk_jac"))}
     spec_info = be.specialize_info()

@@ -372,6 +372,9 @@ int oh_comm_broadcast_constants(oh_handle* h, int root);
 int oh_comm_barrier(void);
 int oh_comm_allreduce_max(double* value);
 int oh_comm_allreduce_sum(double* value);
+/* Optional gather of results (SURVEY 8(e) "optional ncclAllGather / host gather of x*"): `bytes` bytes of every rank's device buffer d_send land in d_recv
+   (world x bytes, rank order) on every rank.  After the solves, never between iterations; the caller synchronises the solves first. */
+int oh_comm_allgather(const void* d_send, void* d_recv, size_t bytes);
 int oh_comm_destroy(void);
 /* Rank and world size as RCCL itself reports them for this process's communicator (ncclCommUserRank / ncclCommCount): what a harness prints to
    show that the communicator spans the job. */

@@ -226,6 +226,7 @@ SYMBOLS = [
     "oh_comm_barrier",
     "oh_comm_allreduce_max",
     "oh_comm_allreduce_sum",
+    "oh_comm_allgather",
     "oh_comm_destroy",
     "oh_comm_info",
     "oh_max_batch",

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <array>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
@@ -122,6 +123,9 @@ struct oh_handle {
   // a large batch of the plain orientation-locked family is solved in parts on handles (streams, host threads) of their own: solve_split
   std::vector<oh_handle*> peers;
   std::vector<int> split_parts;  // instances per part of the last solve (empty: it was not split)
+  bool pipe_last = false;        // the last solve was a pipelined oh_solve: its multipliers wait in d_pipe_mult (every chunk's, in instance order)
+  double* d_pipe_mult = nullptr;
+  size_t pipe_mult_cap = 0;      // doubles
   bool is_peer = false;
   bool compaction = true;
   int compact_carry = 1;     // compaction carries the pending trial along instead of restarting the survivors (k_carry_*)
@@ -182,7 +186,7 @@ static const OptDoc OPT_TABLE[] = {
     {"tape_wave", 1},          {"tape_lbfgs", -1},       {"tape_wave_nt", 256},  {"tape_wave_regs", -1}, {"tape_wave_hist", -1},  {"tq_stall", 25},
     {"tq_curv_after", 3},      {"tq_ftb", 0.995},        {"tq_theta_mu", 1.35},  {"tq_kappa_mu", 0.4},   {"tq_curv_from", 0.1},   {"tq_jac_dual", 0},
     {"tq_rebuild", 0.9},         {"compact_move_all", 1},  {"tq_curv_late", 1.0},  {"tq_kappa_eps", 10.0}, {"tq_max_back", 3},     {"tq_mu_dec", 1.0 / 3.0},     {"tq_ls_curv", 1},   {"tq_mu_dec_warm", 0.1}, {"tq_curv_lag", 3},
-    {"tol", 0},                {"invariant_compact_frac", 0.65}, {"invariant_split", 1}, {"invariant_move_slim", 1}, {"invariant_move_live", 1},
+    {"tol", 0},                {"pipe", 1},               {"pipe_chunk", 32768},                {"invariant_compact_frac", 0.65}, {"invariant_split", 1}, {"invariant_move_slim", 1}, {"invariant_move_live", 1},
 };
 static int tape_configure(oh_handle* h);
 static int set_option_impl(oh_handle* h, const std::string& name, double v) {
@@ -1528,10 +1532,12 @@ static void copy_options(oh_handle* dst, const oh_handle* src) {
   dst->compact_carry = src->compact_carry; dst->tail_vel = src->tail_vel; dst->lg_split = src->lg_split; dst->tail_vel_threshold = src->tail_vel_threshold;
   dst->fuse_couple = src->fuse_couple; dst->sparse_check_below = src->sparse_check_below; dst->specialize = src->specialize; dst->tq_check = src->tq_check; dst->opt = src->opt;
 }
-static int solve_split(oh_handle* h, const int S, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status) {
+// peer handles of a trajectory / torque handle: same description, constants, dynamics and inequality rows, a stream of their own (parts of a split solve,
+// lanes of the pipelined host-buffer solve)
+static int ensure_peers(oh_handle* h, const int n) {
   const bool tqk = h->desc.kind == OH_PROBLEM_TORQUE_MPC;
   HIPCHK(hipSetDevice(h->device));  // peers are created on, and every part's host thread is bound to, the device of the handle (not the calling thread's)
-  while ((int)h->peers.size() < S - 1) {
+  while ((int)h->peers.size() < n) {
     oh_handle* p = nullptr;
     int rc;
     if (tqk) rc = oh_create_torque(&h->tq, &p);
@@ -1549,6 +1555,12 @@ static int solve_split(oh_handle* h, const int S, int B, const void* d_x0, const
     if (rc) { oh_destroy(p); return rc; }
     h->peers.push_back(p);
   }
+  return OH_OK;
+}
+static int solve_split(oh_handle* h, const int S, int B, const void* d_x0, const void* d_p, void* d_x, void* d_f, void* d_kkt, void* d_iters, void* d_status) {
+  const bool tqk = h->desc.kind == OH_PROBLEM_TORQUE_MPC;
+  int prc = ensure_peers(h, S - 1);
+  if (prc) return prc;
   const int N = h->desc.ndof, T = h->desc.T;
   const size_t nx = tqk ? 4 * (size_t)N * T : (size_t)N * T + (size_t)N * (T - 1);
   const size_t npar = tqk ? 2 * (size_t)N + 3 * (size_t)T : (size_t)N + (h->have_guards ? h->guards.n_links + 4 * (size_t)h->guards.n_obstacles : 0);
@@ -1608,7 +1620,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (h->desc.kind == OH_PROBLEM_QP) return qp_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind == OH_PROBLEM_TAPE) return tape_solve_device(h, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
   if (h->desc.kind == OH_PROBLEM_TORQUE_MPC) {
-    if (!h->is_peer) h->split_parts.clear();
+    if (!h->is_peer) { h->split_parts.clear(); h->pipe_last = false; }
     const int S = std::min(8, (int)optv(h, "streams", 2.0));
     if (!h->is_peer && !h->profiling && S >= 2 && B >= (int)optv(h, "tq_split_min", 1024.0) && B / S >= 64 && h->have_chain && h->have_dyn)
       return solve_split(h, S, B, d_x0, d_p, d_x, d_f, d_kkt, d_iters, d_status);
@@ -1619,7 +1631,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   if (!solver_chain_ok(h->chain_host))
     return fail(OH_ERR_INVALID, "oh_solve_device: the solver needs a chain that covers every model joint in order");
   HIPCHK(hipSetDevice(h->device));
-  if (!h->is_peer) h->split_parts.clear();
+  if (!h->is_peer) { h->split_parts.clear(); h->pipe_last = false; }
   // (batch_invariant handles take part in the split too since their compaction moves everything: an instance's answer does not depend on its part)
   if (!h->is_peer && !h->profiling && spec_applies(h) && (optv(h, "batch_invariant", 0.0) == 0.0 || optv(h, "invariant_split", 1.0) != 0.0)) {
     const int S = std::min(8, (int)optv(h, "streams", 2.0));
@@ -1862,7 +1874,10 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
   h->timing[4] = ms;
   h->timing[5] = launched;
   unsigned long long work[3] = {0, 0, 0};
-  HIPCHK(hipMemcpy(work, h->D.work, sizeof(work), hipMemcpyDeviceToHost));
+  // (on the handle's own stream: a hipMemcpy is an operation of the legacy null stream and waits for the kernels of every other handle's stream -- the other
+  //  part of a split solve, the other lane of a pipelined one)
+  HIPCHK(hipMemcpyAsync(work, h->D.work, sizeof(work), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
   h->timing[6] = (double)work[0];
   h->rejects = (double)work[1];
   h->tail_iters = (double)work[2];
@@ -1897,6 +1912,85 @@ static int ensure_stage(oh_handle* h, size_t bytes) {
   hipError_t e = hipMalloc(&h->stage, bytes);
   if (e != hipSuccess) return fail(OH_ERR_HIP, std::string("staging allocation failed: ") + hipGetErrorString(e));
   h->stage_bytes = bytes;
+  return OH_OK;
+}
+
+// oh_solve of a large batch: chunks of `chunk` instances alternate between two lanes; a lane uploads its chunk on its own stream, solves it on its own
+// handle (lane 0: the handle itself, lane 1: a peer) and downloads the results, while the other lane is one phase ahead or behind.  Every chunk is solved
+// as a batch of its own (like the parts of solve_split); timing[4] is the wall clock of the whole call.
+static int solve_pipelined(oh_handle* h, const int B, const int chunk, const size_t nx, const size_t npar, const double* x0, const double* p, double* x,
+                           double* f, double* kkt, int* iters, int* status) {
+  int rc = ensure_peers(h, 1);
+  if (rc) return rc;
+  oh_handle* lanes[2] = {h, h->peers[0]};
+  copy_options(lanes[1], h);
+  if (h->desc.kind == OH_PROBLEM_FIGURE_EIGHT) {
+    if (spec_applies(h) && !h->spec && !h->spec_failed && h->specialize != OH_SPECIALIZE_NEVER && chunk >= h->specialize_min_B && oh_specialize(h) != OH_OK) h->spec_failed = true;
+    lanes[1]->spec = h->spec; lanes[1]->spec_failed = h->spec_failed; lanes[1]->spec_cache_checked = true;
+  }
+  const int C = (B + chunk - 1) / chunk;
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  // multipliers of every chunk, kept on the device in instance order for oh_get_multipliers (a handle only remembers its last solve)
+  const bool tqk = h->desc.kind == OH_PROBLEM_TORQUE_MPC;
+  const size_t per = tqk ? (size_t)h->tq.T * (h->tq.vel_limits ? 4 : 2) * h->tq.ndof : (h->desc.lock_orientation ? 4 * (size_t)h->desc.T : 0);
+  if (per * B > h->pipe_mult_cap) {
+    if (h->d_pipe_mult) hipFree(h->d_pipe_mult);
+    h->d_pipe_mult = nullptr;
+    h->pipe_mult_cap = 0;
+    HIPCHK(hipMalloc((void**)&h->d_pipe_mult, sizeof(double) * per * B));
+    h->pipe_mult_cap = per * B;
+  }
+  int rcs[2] = {OH_OK, OH_OK};
+  std::string errs[2];
+  double launched = 0, work = 0, compactions = 0, rejects = 0, tails = 0;
+  std::mutex mtx;
+  auto lane = [&](const int l) {
+    oh_handle* q = lanes[l];
+    if (hipSetDevice(h->device) != hipSuccess) { rcs[l] = OH_ERR_HIP; errs[l] = "oh_solve: hipSetDevice failed"; return; }
+    for (int c = l; c < C; c += 2) {
+      const size_t lo = (size_t)c * chunk;
+      const int n = (int)std::min((size_t)chunk, (size_t)B - lo);
+      const size_t b_x = sizeof(double) * nx * n, b_p = sizeof(double) * npar * n, b_f = sizeof(double) * n, b_k = sizeof(double) * 3 * n, b_i = sizeof(int) * (size_t)n;
+      if (ensure_stage(q, al(b_x) * 2 + al(b_p) + al(b_f) + al(b_k) + 2 * al(b_i))) { rcs[l] = OH_ERR_HIP; errs[l] = oh_last_error(); return; }
+      char* base = (char*)q->stage;
+      void* d_x0 = base; void* d_p = base + al(b_x); void* d_x = (char*)d_p + al(b_p); void* d_f = (char*)d_x + al(b_x); void* d_k = (char*)d_f + al(b_f);
+      void* d_it = (char*)d_k + al(b_k); void* d_st = (char*)d_it + al(b_i);
+      hipStream_t s = q->stream;
+      bool ok = hipMemcpyAsync(d_x0, x0 + lo * nx, b_x, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(d_p, p + lo * npar, b_p, hipMemcpyHostToDevice, s) == hipSuccess &&
+                hipStreamSynchronize(s) == hipSuccess;
+      if (!ok) { rcs[l] = OH_ERR_HIP; errs[l] = "oh_solve: upload failed"; return; }
+      const bool was_peer = q->is_peer;
+      q->is_peer = true;  // (a chunk is not split again: the two lanes ARE the two streams)
+      const int r = oh_solve_device(q, n, d_x0, d_p, d_x, d_f, d_k, d_it, d_st);
+      q->is_peer = was_peer;
+      if (r) { rcs[l] = r; errs[l] = oh_last_error(); return; }
+      ok = true;
+      const double* mult = tqk ? q->d_tq_mult : q->D.lam_h;
+      if (per && mult) ok = ok && hipMemcpyAsync(h->d_pipe_mult + lo * per, mult, sizeof(double) * per * n, hipMemcpyDeviceToDevice, s) == hipSuccess;
+      if (x) ok = ok && hipMemcpyAsync(x + lo * nx, d_x, b_x, hipMemcpyDeviceToHost, s) == hipSuccess;
+      if (f) ok = ok && hipMemcpyAsync(f + lo, d_f, b_f, hipMemcpyDeviceToHost, s) == hipSuccess;
+      if (kkt) ok = ok && hipMemcpyAsync(kkt + 3 * lo, d_k, b_k, hipMemcpyDeviceToHost, s) == hipSuccess;
+      if (iters) ok = ok && hipMemcpyAsync(iters + lo, d_it, b_i, hipMemcpyDeviceToHost, s) == hipSuccess;
+      if (status) ok = ok && hipMemcpyAsync(status + lo, d_st, b_i, hipMemcpyDeviceToHost, s) == hipSuccess;
+      ok = ok && hipStreamSynchronize(s) == hipSuccess;
+      if (!ok) { rcs[l] = OH_ERR_HIP; errs[l] = "oh_solve: download failed"; return; }
+      std::lock_guard<std::mutex> g(mtx);
+      launched = std::max(launched, q->timing[5]); work += q->timing[6]; compactions += q->timing[7]; rejects += q->rejects; tails += q->tail_iters;
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::thread other(lane, 1);
+  lane(0);
+  other.join();
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (int l = 0; l < 2; ++l)
+    if (rcs[l]) return fail(rcs[l], errs[l]);
+  for (double& t : h->timing) t = 0.0;
+  h->timing[4] = ms; h->timing[5] = launched; h->timing[6] = work; h->timing[7] = compactions;
+  h->rejects = rejects; h->tail_iters = tails;
+  h->split_parts.clear();
+  h->pipe_last = true;
+  h->last_B = B;
   return OH_OK;
 }
 
@@ -1948,6 +2042,13 @@ extern "C" int oh_solve(oh_handle* h, int B, const double* x0, const double* p, 
     if (iters) memcpy(iters, hb + o_it, b_i);
     if (status) memcpy(status, hb + o_st, b_i);
     return OH_OK;
+  }
+  // large batches of the trajectory families from host buffers: chunks on two lanes (handles, streams, host threads), so that one lane's transfers over
+  // PCIe run under the other lane's kernels (round 6; until then: upload everything, solve, download everything -- 38 % of the resident rate)
+  if ((h->desc.kind == OH_PROBLEM_FIGURE_EIGHT || tqk) && !h->is_peer && !h->profiling && optv(h, "pipe", 1.0) != 0.0 && h->have_chain && !h->have_guards &&
+      !h->chain_host.has_lead) {
+    const int chunk = std::max(1024, (int)optv(h, "pipe_chunk", 32768.0));
+    if (B >= 2 * chunk && (!tqk || h->have_dyn)) return solve_pipelined(h, B, chunk, nx, npar, x0, p, x, f, kkt, iters, status);
   }
   HIPCHK(hipMemcpy(d_x0, x0, b_x, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_p, p, b_p, hipMemcpyHostToDevice));
@@ -2082,6 +2183,12 @@ extern "C" int oh_get_multipliers(oh_handle* h, int B, double* lam_h) {
       B != h->last_B || B < 1)
     return fail(OH_ERR_STATE, "oh_get_multipliers: B does not match the last solve");
   HIPCHK(hipSetDevice(h->device));
+  if (h->pipe_last) {  // the last solve was a pipelined oh_solve: every chunk left its multipliers in the handle's cache
+    const size_t per = h->desc.kind == OH_PROBLEM_TORQUE_MPC ? (size_t)h->tq.T * (h->tq.vel_limits ? 4 : 2) * h->tq.ndof : (h->desc.lock_orientation ? 4 * (size_t)h->desc.T : 0);
+    if (!per) return fail(OH_ERR_STATE, "oh_get_multipliers: this problem has no nonlinear equality rows");
+    HIPCHK(hipMemcpy(lam_h, h->d_pipe_mult, sizeof(double) * per * B, hipMemcpyDeviceToHost));
+    return OH_OK;
+  }
   if (h->desc.kind == OH_PROBLEM_TORQUE_MPC) {
     const size_t per = (size_t)h->tq.T * (h->tq.vel_limits ? 4 : 2) * h->tq.ndof;
     if (!h->split_parts.empty()) {  // the last solve ran in parts (solve_split)
@@ -2321,6 +2428,7 @@ extern "C" void oh_destroy(oh_handle* h) {
   if (h->d_ik_mult) hipFree(h->d_ik_mult);
   if (h->gpool) hipFree(h->gpool);
   if (h->move_scr) hipFree(h->move_scr);
+  if (h->d_pipe_mult) hipFree(h->d_pipe_mult);
   if (h->d_qp_work) hipFree(h->d_qp_work);
   for (void* q : {(void*)h->d_tape_op, (void*)h->d_tape_a, (void*)h->d_tape_b, (void*)h->d_tape_rows, (void*)h->d_tape_c, (void*)h->d_tape_work, (void*)h->d_tape_mult,
                   (void*)h->d_tape_h0})
@@ -2359,6 +2467,7 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;  // optional (oh_comm_allgather)
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;     // optional
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;  // optional
@@ -2384,6 +2493,7 @@ int rccl_load() {
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
   a.Broadcast = (decltype(a.Broadcast))dlsym(lib, "ncclBroadcast");
   a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
+  a.AllGather = (decltype(a.AllGather))dlsym(lib, "ncclAllGather");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
   a.CommCount = (decltype(a.CommCount))dlsym(lib, "ncclCommCount");
   a.CommUserRank = (decltype(a.CommUserRank))dlsym(lib, "ncclCommUserRank");
@@ -2493,6 +2603,18 @@ extern "C" int oh_comm_broadcast_constants(oh_handle* h, int root) {
     HIPCHK(hipMemcpy(h->d_chain, land, sizeof(oh_chain), hipMemcpyDeviceToDevice));
     adopt_chain(h, tmp);
   }
+  return OH_OK;
+}
+
+// The optional gather of SURVEY 8(e): every rank contributes `bytes` bytes of a device buffer (objectives, statuses, or whole solutions of its shard) and
+// receives all ranks' blocks in rank order -- one ncclAllGather over xGMI on the communicator's stream, after the solves; never part of the data path.
+extern "C" int oh_comm_allgather(const void* d_send, void* d_recv, size_t bytes) {
+  if (!d_send || !d_recv || bytes == 0) return fail(OH_ERR_INVALID, "oh_comm_allgather: null buffer or zero size");
+  if (!g_comm) return fail(OH_ERR_STATE, "oh_comm_allgather: call oh_comm_init first");
+  if (!g_rccl.AllGather) return fail(OH_ERR_HIP, "oh_comm_allgather: librccl lacks ncclAllGather");
+  HIPCHK(hipSetDevice(g_comm_device));
+  RCCLCHK(g_rccl.AllGather(d_send, d_recv, bytes, ncclUint8, g_comm, g_comm_stream));
+  HIPCHK(hipStreamSynchronize(g_comm_stream));
   return OH_OK;
 }
 

@@ -262,6 +262,10 @@ class Communicator:
         _lib.check(_lib.load().oh_comm_allreduce_sum(C.byref(v)), "oh_comm_allreduce_sum")
         return v.value
 
+    def allgather(self, d_send, d_recv, nbytes: int) -> None:
+        """ncclAllGather of `nbytes` bytes per rank between device buffers (optas_amd._lib.DeviceBuffer): results of the shards, after the solves."""
+        _lib.check(_lib.load().oh_comm_allgather(d_send.ptr, d_recv.ptr, C.c_size_t(int(nbytes))), "oh_comm_allgather")
+
     def destroy(self) -> None:
         _lib.check(_lib.load().oh_comm_destroy(), "oh_comm_destroy")
 

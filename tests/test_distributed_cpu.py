@@ -189,6 +189,13 @@ def test_bench_dry_run_under_an_eight_process_launch(tmp_path):
     assert [o["rank"] for o in outs] == list(range(8)) and all(o["world"] == 8 and o["dry_run"] for o in outs)
     assert len({o["id_sha256"] for o in outs}) == 1  # one communicator id
     assert len({tuple(o["qc_first"]) if isinstance(o["qc_first"], list) else o["qc_first"] for o in outs}) == 8  # eight different shards
+    # round 6: the per-rank block of the bench line, built by the harness's own code (bench.py:per_rank_block) from stand-in measurements (rank r: 1 + r / 100 s,
+    # 80 + r ms, 1000 (r + 1) solves/s) reduced across the eight processes: every rank holds the same block, and it is the min / max / sum over all of them
+    assert [o["device_index"] for o in outs] == list(range(8))
+    pr = outs[0]["per_rank"]
+    assert all(o["per_rank"] == pr for o in outs)
+    assert (pr["elapsed_s_min"], pr["elapsed_s_max"]) == (1.0, 1.07) and (pr["device_ms_per_step_min"], pr["device_ms_per_step_max"]) == (80.0, 87.0)
+    assert pr["sum_of_rank_rates_solves_per_s"] == 36000.0 and pr["rccl_world"] is None and "dry run" in pr["note"]
     assert time.time() - t0 < 120
 
 

@@ -44,6 +44,9 @@ def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B, tol):
     dt, lp = bench.local_path()
     chain = RobotModel(urdf_filename=KUKA_KIN).kinematic_chain(LINK)
     be = FigureEightBackend(chain, bench.T, dt, lp, max_iter=300, tol=tol, hessian=2)  # bench.py's handle
+    # bench.py times oh_solve_device on the whole batch: from host buffers that is oh_solve without the chunked PCIe pipeline of round 6 (the pipelined composition is
+    # looked at further down)
+    be.set_option("pipe", 0)
     x0, qc = bench.make_inputs(B, 0)
     r = be.solve(x0, qc)
     tm = be.timing()
@@ -86,6 +89,20 @@ def test_bench_workload_at_default_settings(hip_lib, monkeypatch, B, tol):
     assert np.abs(r.f[~same_all] - f_port[~same_all]).max(initial=0.0) <= 2e-3 * 8.2 and (r.kkt[~same_all, 0] <= 1e-6).all()  # the same valley, within the tolerance
     same = same_all[idx]
     assert same.sum() == 64, (same.sum(), r.f[idx][~same], f_port[idx][~same])
+    if tol <= 1e-8 and B >= 131072:
+        # The same batch through the default host-buffer path: chunks of 32 768 on two lanes (solve_pipelined), i.e. another batch composition and schedule for every
+        # instance.  The problem is non-convex: an instance that starts near a watershed between two local minima can be sent to the other one by the last bits of
+        # another schedule's arithmetic (measured on this batch: instance 165 077 ends at f = 8.2070, the host port and the whole-batch solve at 8.3837 -- both KKT points
+        # of the literal NLP, the pipelined one the lower).  Allowed: at most 2 such instances of the 262 144, each converged to the tolerance.
+        be.set_option("pipe", 1)
+        rp = be.solve(x0, qc)
+        assert (rp.status == 0).all() and (rp.kkt[:, 0] <= tol).all() and (rp.kkt[:, 1] <= 1e-9).all()
+        other = np.abs(rp.f - f_port) > 1e-9 * np.abs(f_port)
+        assert other.sum() <= 2, (other.sum(), np.nonzero(other)[0][:8], rp.f[other][:8], f_port[other][:8])
+        for b in np.nonzero(other)[0]:
+            k = kkt_reference_form(nlp, rp.x[b], qc[b])
+            assert k["stationarity"] <= 1e-5 and k["feasibility"] <= 1e-9 and k["complementarity"] <= 1e-8, (b, k)
+        be.set_option("pipe", 0)
     prob = StructuredFigureEight(orc, LINK, T=T, Tmax=bench.TMAX)
     n_same_np = 0
     for b in idx[:12]:
@@ -117,6 +134,7 @@ def test_batch_close_to_the_per_call_bound(hip_lib, monkeypatch):
     dt, lp = bench.local_path()
     chain = RobotModel(urdf_filename=KUKA_KIN).kinematic_chain(LINK)
     be = FigureEightBackend(chain, bench.T, dt, lp, max_iter=300, tol=1e-6, hessian=2)
+    be.set_option("pipe", 0)  # (round 6: oh_solve would take a host batch of this size in chunks of 32 768 on two lanes -- this test is about ONE call at the bound)
     assert be.max_batch >= B
     x0, qc = bench.make_inputs(B, 0)
     r = be.solve(x0, qc)

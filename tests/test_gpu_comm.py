@@ -36,6 +36,13 @@ def test_communicator_of_one_rank_broadcasts_the_constants(hip_lib, tmp_path, mo
         assert r.status[0] == 0 and r.f[0] <= 1e-12
         assert comm.max_over_ranks(3.25) == 3.25 and comm.max_over_ranks(-1.5) == -1.5 and comm.sum_over_ranks(2.5) == 2.5
         comm.barrier()
+        # the optional gather of results (round 6): objectives of this rank's shard through ncclAllGather into a buffer of world x bytes
+        fs = np.linspace(1.0, 2.0, 96)
+        d_send, d_recv = _lib.DeviceBuffer(fs.nbytes).upload(fs), _lib.DeviceBuffer(fs.nbytes * 1)
+        comm.allgather(d_send, d_recv, fs.nbytes)
+        assert np.array_equal(d_recv.download(np.float64, (96,)), fs)
+        d_send.free()
+        d_recv.free()
         be.close()
     finally:
         comm.destroy()

@@ -210,3 +210,32 @@ def test_batch_invariant_on_the_position_tracking_family_and_restored_fields(hip
     be.set_option("batch_invariant", 0)
     assert be.get_option("tail_threshold") == 2048 and be.get_option("compaction") == 0  # (16384 / 1 until round 6)
     be.close()
+
+
+def test_host_buffer_solve_of_a_large_batch_is_pipelined_in_chunks(hip_lib, monkeypatch):
+    """Round 6 (solve_pipelined in csrc/oh_api.hip): oh_solve from host buffers takes a batch of at least 2 x pipe_chunk instances in chunks on two lanes
+    (handle + peer, a stream and a host thread each), so that one lane's PCIe transfers run under the other lane's kernels.  Pinned: at every original
+    index the call returns exactly what a handle without the pipeline returns for that chunk solved as a batch of its own -- x, f, step counts, status and
+    the multipliers of the quaternion rows (kept for every chunk in a device-side cache), bit for bit."""
+    monkeypatch.delenv("OH_DEBUG_OPTIONS", raising=False)
+    B, chunk = 20000, 8192  # chunks of 8192, 8192, 3616 on lanes 0, 1, 0
+    x0, qc = bench.make_inputs(B, 7)
+    a = _backend().set_options(pipe_chunk=chunk)
+    ra = a.solve(x0, qc)
+    la = a.multipliers(B)
+    ta = a.timing()
+    assert (ra.status == 0).all() and ta["solve_ms"] > 0 and ta["tail_iterations"] > 0
+    b = _backend().set_options(pipe=0)
+    for lo in range(0, B, chunk):
+        hi = min(B, lo + chunk)
+        rb = b.solve(x0[lo:hi], qc[lo:hi])
+        assert np.array_equal(ra.x[lo:hi], rb.x) and np.array_equal(ra.f[lo:hi], rb.f) and np.array_equal(ra.iters[lo:hi], rb.iters) and np.array_equal(ra.status[lo:hi], rb.status), lo
+        assert np.array_equal(la[lo:hi], b.multipliers(hi - lo)), lo
+    # the whole batch without the pipeline: another batch composition, the same optima
+    rw = b.solve(x0, qc)
+    assert (np.abs(rw.f - ra.f) <= 1e-9 * np.abs(ra.f)).mean() >= 0.97
+    # a solve from device buffers afterwards forgets the cache
+    small = a.solve(x0[:64], qc[:64])
+    assert np.array_equal(a.multipliers(64), b.solve(x0[:64], qc[:64]) and b.multipliers(64))
+    a.close()
+    b.close()

@@ -296,6 +296,12 @@ def run_configs(sample=8, torque_batches=(8192, 1024), only=None, cpu=None, ik_b
     return _torque(out, rng, sample, torque_batches, cpu)
 
 
+def pm_family(be, B):
+    """The point-mass solve is one wavefront per plant (lane = knot, k_pm_solve_wave) up to pm_wave_max plants and one thread per plant beyond (k_pm_solve):
+    two kernels, two flop-per-step constants in profiles/configs_flops.json."""
+    return "pm" if B <= int(be.get_option("pm_wave_max")) else "pm_thread"
+
+
 def _pm(out, rng, sample, cpu=False, B=4096):
     # config 3: tick and closed loop
     from examples.point_mass_mpc import obstacle_and_goal
@@ -321,7 +327,7 @@ def _pm(out, rng, sample, cpu=False, B=4096):
     tab = np.array([[0.15 * np.sin((2.0 + 0.05 * j) * np.pi - np.pi), 0.15 * np.cos((2.0 + 0.05 * j) * np.pi - np.pi) + 0.15] for j in range(n_ticks * adv + T)])
     if PROBE is not None or B != 4096:  # (counter passes: only the launches whose work units are counted; batch sweeps: the tick alone)
         out["config3_point_mass"] = {"what": f"point_mass_mpc.py tick, B = {B}", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **pub(r),
-                                     "roofline": flop_roofline("pm", {"k_pm (the whole solve: one launch)": r["device_ms"]}, r["_iters_sum"], "instance-step")}
+                                     "roofline": flop_roofline(pm_family(be, B), {"k_pm (the whole solve: one launch)": r["device_ms"]}, r["_iters_sum"], "instance-step")}
         be.close()
         return out
     be.rollout(P[:, :4], tab, 2)
@@ -329,7 +335,7 @@ def _pm(out, rng, sample, cpu=False, B=4096):
     out["config3_point_mass"] = {"what": f"point_mass_mpc.py tick (T=20, box limits, moving obstacle), B = {B} initial states", "batch": B, "solves_per_s": B / r["device_ms"] * 1e3, **pub(r),
                                  "oracle_sample": oracle_grade("pm", **smp) if smp else None,
                                  "closed_loop": {"ticks": n_ticks, "device_ms": be.solve_ms(), "ticks_per_s": B * n_ticks / be.solve_ms() * 1e3, "converged_frac": float((stt == 0).mean())},
-                                 "roofline": flop_roofline("pm", {"k_pm (the whole solve: one launch)": r["device_ms"]}, r["_iters_sum"], "instance-step")}
+                                 "roofline": flop_roofline(pm_family(be, B), {"k_pm (the whole solve: one launch)": r["device_ms"]}, r["_iters_sum"], "instance-step")}
     if cpu:
         nl = min(B, 2048)
         out["config3_point_mass"]["cpu_baseline"] = cpu_leg("pm", dict(n=nl, P=P[:nl]), r["_f_head"])
@@ -501,7 +507,8 @@ def probe_main(family):
     """One family's GPU leg (no oracle, no CPU leg), run under rocprofv3 --pmc by tools/gpu_configs_pmc.sh: prints the work units of all its solves."""
     global PROBE
     PROBE = {"units": 0.0, "solves": 0}
-    run_configs(sample=0, cpu=False, only={"ik": "ik", "pm": "pm", "guarded": "config4", "torque": "torque"}[family], torque_batches=(8192,))
+    run_configs(sample=0, cpu=False, only={"ik": "ik", "pm": "pm", "pm_thread": "pm", "guarded": "config4", "torque": "torque"}[family], torque_batches=(8192,),
+                pm_batch=65536 if family == "pm_thread" else 4096)
     os.makedirs(os.path.join(ROOT, "gpurun_out", "cfgpmc"), exist_ok=True)
     json.dump({"family": family, **PROBE}, open(os.path.join(ROOT, "gpurun_out", "cfgpmc", f"{family}_units.json"), "w"))
     print(json.dumps(PROBE))

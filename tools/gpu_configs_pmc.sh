@@ -5,13 +5,13 @@
 set -u
 REPO=$(pwd); TAG=${TAG:-r06}; OUT=$REPO/gpurun_out/cfgpmc; rm -rf $OUT; mkdir -p $OUT $REPO/gpurun_out/profiles
 cd /tmp && export TMPDIR=/tmp
-for fam in ${FAMILIES:-ik pm guarded torque}; do
+for fam in ${FAMILIES:-ik pm pm_thread guarded torque}; do
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 -d $OUT/$fam -o $fam -- python $REPO/tools/bench_configs.py --probe $fam > $OUT/$fam.log 2>&1
 done
 cd $REPO
 python - <<PY
 import sqlite3, glob, collections, json, re, os
-GROUPS = {"ik": [("k_ik", "k_ik (the whole solve: one launch)")], "pm": [("k_pm", "k_pm (the whole solve: one launch)")],
+GROUPS = {"ik": [("k_ik", "k_ik (the whole solve: one launch)")], "pm": [("k_pm", "k_pm (the whole solve: one launch)")], "pm_thread": [("k_pm", "k_pm (the whole solve: one launch)")],
           "guarded": [("k_eval_guarded", "k_eval_guarded"), ("k_eval_free", "k_eval_guarded"), ("k_step_free", "k_step_free*"), ("k_step_guarded", "k_step_free*")],
           "torque": [("k_tq_eval3", "k_tq_eval3+k_tq_curv"), ("k_tq_curv", "k_tq_eval3+k_tq_curv"), ("k_tq_step", "k_tq_step")]}
 out = {}

@@ -34,7 +34,7 @@ extern "C" {
 #define OH_ABI_VERSION 6
 
 #define OH_MAX_CHAIN 16 /* actuated joints on one root->link chain */
-#define OH_MAX_T 128    /* horizon knots */
+#define OH_MAX_T 256    /* horizon knots (128 until round 6; the persistent kernels take horizons of up to 64 / 128 free knots, longer ones run in batched launches) */
 
 enum {
   OH_OK = 0,

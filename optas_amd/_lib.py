@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 
 OH_MAX_CHAIN = 16
-OH_MAX_T = 128
+OH_MAX_T = 256
 OH_MAX_SPHERE_LINKS = 8
 OH_MAX_OBSTACLES = 16
 OH_COMM_ID_BYTES = 128

@@ -135,8 +135,9 @@ class PointMassBackend(_SolveMixin):
 class TapeBackend(_SolveMixin):
     """OH_PROBLEM_TAPE handle: a compiled instruction tape (optas_amd.tape.Tape) interpreted on the GPU; x (B, nx), p (B, np)."""
 
-    def __init__(self, tape, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True, wave=True, options=None, keep_regs=None, metric=True):
-        """metric: in the limited-memory regime (beyond 48 variables) hand the library the inverse of the constant block of the cost's Hessian as the
+    def __init__(self, tape, max_iter=2000, tol=1e-6, tol_feas=1e-9, rho0=10.0, jit=True, wave=True, options=None, keep_regs=None, metric=False):
+        """metric (default False since round 6: on a problem as written the penalty on hundreds of affine rows is most of the merit's curvature and none of it is
+        in the cost's block -- tape_backend(), which knows whether the affine rows are gone, makes the choice): in the limited-memory regime (beyond 48 variables) hand the library the inverse of the constant block of the cost's Hessian as the
         initial metric of the quasi-Newton iteration (tape.py:quadratic_cost_metric, oh_tape_set_metric) where the cost has one; wave: let trajectory-sized tapes (beyond 48 variables) run one block of wavefronts per instance over the dependency levels of the tape
         (csrc/oh_tape_wave.hip) where the library finds that it applies; options: oh_set_option pairs applied to the handle; keep_regs: registers the
         caller will read back with probe() -- self.kept_regs holds their indices in the tape the handle was given (re-association renumbers)."""

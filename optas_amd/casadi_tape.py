@@ -17,11 +17,10 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from .tape import MAX_TAPE, Tape, TapeBuilder
+from .tape import MAX_TAPE, Tape, TapeBuilder, UnsupportedInstruction  # noqa: F401
 
 
-class UnsupportedInstruction(NotImplementedError):
-    pass
+# (defined next to the builder that raises it too: optas_amd/tape.py)
 
 
 # casadi opcode names -> how the tape builder expresses them (casadi/core/calculus.hpp enumerates the names; the integer values are read

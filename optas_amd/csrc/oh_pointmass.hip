@@ -227,6 +227,12 @@ __global__ __launch_bounds__(64) void k_pm_solve(PmParams P, PmBuffers D, const 
     }
     if (!(stat == stat) || !(fval == fval) || !(fabs(fval) < 1e300) || !(feas == feas) || !(compl_ == compl_)) { status = OH_STATUS_NUMERICAL; break; }
     if (stat <= P.tol && feas <= P.tol && compl_ <= P.tol) { status = OH_STATUS_CONVERGED; break; }
+    // No feasible plan (round 6; the reference: IPOPT's Infeasible_Problem_Detected -> did_solve() False, solver.py:407-412): the obstacle is a parameter of every
+    // knot, so a problem whose pinned knot is fine can still have none -- the obstacle lands where the mass cannot leave in time.  The infeasible-start
+    // iteration then shows its textbook signature: the slack residual stalls at the violation it cannot remove while the multipliers of those rows leave every
+    // bound (lam s from 1e-1 to 1e8 in three steps, 1e240 a dozen steps later; oracle/pointmass_ipm.py has the same rule).  A healthy run keeps lam s at the
+    // size of the barrier parameter (<= 1).
+    if (compl_ > 1e6 && feas > 1e3 * P.tol) { status = OH_STATUS_INFEASIBLE; break; }
     if (it == P.max_iter) break;
 
     // ---- forward pass 1: Newton direction, fraction-to-the-boundary step lengths -------------------------------------------------
@@ -525,6 +531,12 @@ __global__ __launch_bounds__(64) void k_pm_solve_wave(PmParams P, int B, const d
     }
     if (!(stat == stat) || !(fval == fval) || !(fabs(fval) < 1e300) || !(feas == feas) || !(compl_ == compl_)) { status = OH_STATUS_NUMERICAL; break; }
     if (stat <= P.tol && feas <= P.tol && compl_ <= P.tol) { status = OH_STATUS_CONVERGED; break; }
+    // No feasible plan (round 6; the reference: IPOPT's Infeasible_Problem_Detected -> did_solve() False, solver.py:407-412): the obstacle is a parameter of every
+    // knot, so a problem whose pinned knot is fine can still have none -- the obstacle lands where the mass cannot leave in time.  The infeasible-start
+    // iteration then shows its textbook signature: the slack residual stalls at the violation it cannot remove while the multipliers of those rows leave every
+    // bound (lam s from 1e-1 to 1e8 in three steps, 1e240 a dozen steps later; oracle/pointmass_ipm.py has the same rule).  A healthy run keeps lam s at the
+    // size of the barrier parameter (<= 1).
+    if (compl_ > 1e6 && feas > 1e3 * P.tol) { status = OH_STATUS_INFEASIBLE; break; }
     if (it == P.max_iter) break;
 
     // ---- forward 1: Newton direction (serial), then the step lengths per knot ---------------------------------------------------------

@@ -336,7 +336,10 @@ class HIPSolver(Solver):
             o.pop("hessian", None)
             # (evaluations: a small dense problem needs a few hundred; the limited-memory path of a trajectory-sized one tens of thousands)
             # ("eliminate": affine equality rows -- Euler rows, pinned configurations -- are substituted away before the tape reaches the GPU, tape.py)
-            self._backend = tape_backend(spec.tape, eliminate=bool(o.pop("eliminate", True)), max_iter=int(o.pop("max_iter", tape_default_max_iter(spec.tape.nx))),
+            # (handle options that shape the evaluator -- tape_wave, tape_lbfgs, ... -- go in at creation: applied afterwards they rebuilt the evaluator on a tape
+            #  already rebalanced for the wavefront path, left backend.wave / backend.jit stale and overrode tape_backend's own tape_lbfgs default)
+            tape_opts = {k: handle_options.pop(k) for k in [k for k in handle_options if k.startswith("tape_")]}
+            self._backend = tape_backend(spec.tape, options=tape_opts or None, eliminate=bool(o.pop("eliminate", True)), max_iter=int(o.pop("max_iter", tape_default_max_iter(spec.tape.nx))),
                                          tol=float(o.pop("tol", 1e-6)), tol_feas=float(o.pop("tol_feas", 1e-9)), rho0=(float(o.pop("rho0")) if "rho0" in o else None), jit=bool(o.pop("jit", True)), metric=o.pop("metric", None))
         else:  # pragma: no cover
             raise NotImplementedError(kind)

@@ -30,6 +30,10 @@ N_OPS = 27
 MAX_TAPE = 1 << 18
 
 
+class UnsupportedInstruction(NotImplementedError):
+    pass
+
+
 class TapeBuilder:
     def __init__(self):
         self.op: List[int] = []
@@ -180,23 +184,29 @@ class TapeBuilder:
         return self._fold1(OP_LOG, a, lambda v: float(np.log(v)) if v > 0.0 else (float("-inf") if v == 0.0 else float("nan")))
 
     def pow(self, a, b):
-        """x ** y: repeated squaring for small non-negative integer constants, sqrt / reciprocal, otherwise exp(y log x) -- defined for x > 0, where
-        its value and both partial derivatives are casadi's (y x^(y-1), x^y log x)."""
+        """x ** y: repeated squaring for every constant integer exponent of magnitude up to 64 (finite for x <= 0 like casadi's OP_POW / OP_CONSTPOW: x**9 of a
+        negative x is a number, not exp(9 log x) = NaN -- ADVICE r5), sqrt / reciprocal, otherwise exp(y log x) -- defined for x > 0, where its value and both partial
+        derivatives are casadi's (y x^(y-1), x^y log x).  A constant integer exponent beyond 64 is refused rather than lowered to something that is wrong for x <= 0."""
         if self.is_const(b):
             e = self._const[b]
             if e == 0.5:
                 return self.sqrt(a)
             if e == -1.0:
                 return self.div(self.const(1.0), a)
-            if e == int(e) and 0 <= int(e) <= 8:
-                out, base, k = self.const(1.0), a, int(e)
+            if np.isfinite(e) and e == int(e):
+                k = int(e)
+                if abs(k) > 64:
+                    raise UnsupportedInstruction(f"pow with the constant integer exponent {k}: beyond the squaring chain (|k| <= 64), and exp(k log x) is wrong for x <= 0")
+                if k < 0:
+                    return self.div(self.const(1.0), self.pow(a, self.const(float(-k))))
+                out, base = self.const(1.0), a
                 while k:
                     if k & 1:
                         out = self.mul(out, base)
-                    base, k = self.sqr(base), k >> 1
+                    k >>= 1
+                    if k:
+                        base = self.sqr(base)
                 return out
-            if e == int(e) and -8 <= int(e) < 0:
-                return self.div(self.const(1.0), self.pow(a, self.const(-e)))
         return self.exp(self.mul(b, self.log(a)))
 
     def tanh(self, a):

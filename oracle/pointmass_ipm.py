@@ -98,6 +98,9 @@ def solve_pointmass_ipm(T, dt, w, ylim, vlim, safe_sq, curr, dcurr, goal, obs, V
         if stat <= tol and feas <= tol and compl <= tol:
             status = 0
             break
+        if compl > 1e6 and feas > 1e3 * tol:  # no feasible plan: the residual of the slacks stalls, the multipliers diverge (csrc/oh_pointmass.hip, round 6)
+            status = 3
+            break
         if it == max_iter:
             break
         # ---- Newton step: barrier-modified LQR solved by Riccati

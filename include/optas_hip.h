@@ -30,8 +30,9 @@ extern "C" {
 /* Bumped whenever a struct of this header changes layout or an entry point changes meaning; oh_abi_version() returns the value the library was
    built with, and a host binding refuses a library that answers otherwise (a binding that misreads a descriptor fails silently).
    5: round 5 -- OH_STATUS_INFEASIBLE / OH_STATUS_ACCEPTABLE, oh_set_option / oh_get_option, oh_tq_rollout, tape opcodes 25-26.
-   6: round 5 -- oh_tape_set_metric. */
-#define OH_ABI_VERSION 6
+   6: round 5 -- oh_tape_set_metric.
+   7: round 6 -- OH_MAX_T 256, oh_comm_allgather, options tol / pipe / pipe_chunk, OH_STATUS_INFEASIBLE from the point-mass iteration, oh_solve in chunks on two lanes. */
+#define OH_ABI_VERSION 7
 
 #define OH_MAX_CHAIN 16 /* actuated joints on one root->link chain */
 #define OH_MAX_T 256    /* horizon knots (128 until round 6; the persistent kernels take horizons of up to 64 / 128 free knots, longer ones run in batched launches) */

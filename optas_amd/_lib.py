@@ -19,7 +19,7 @@ OH_MAX_OBSTACLES = 16
 OH_COMM_ID_BYTES = 128
 
 OH_OK, OH_ERR_INVALID, OH_ERR_HIP, OH_ERR_STATE = 0, 1, 2, 3
-OH_ABI_VERSION = 6  # include/optas_hip.h: the struct layouts below are those of this version
+OH_ABI_VERSION = 7  # include/optas_hip.h: the struct layouts below are those of this version
 OH_STATUS_CONVERGED, OH_STATUS_MAX_ITER, OH_STATUS_NUMERICAL, OH_STATUS_INFEASIBLE, OH_STATUS_ACCEPTABLE = 0, 1, 2, 3, 4
 # IPOPT's names for the same outcomes (what CasADiSolver.stats()["return_status"] holds, solver.py:407-412)
 STATUS_NAMES = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Numerical_Failure", 3: "Infeasible_Problem_Detected", 4: "Solved_To_Acceptable_Level"}

@@ -1868,6 +1868,7 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
   // 3. convergence, barrier update
   int status = -1;
   bool do_gains = false, do_roll = false;
+  bool reeval = false;  // the next "trial" is this point itself under a lower barrier parameter (round 6)
   int curv = D.curv[b] != 0;  // the pending trial was evaluated with exact curvature (1 computed, 2 the stored term: k_tq_curv)
   if (!isfinite(f_cur)) {
     status = OH_STATUS_NUMERICAL;
@@ -1886,6 +1887,24 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
         stat = stat_next;
         n_barrier += 1;
         stall = 0;
+      } else if (accept && stat <= P.kappa_eps * mub && nrel > 0 && mub > mu_min) {
+        // Round 6: stationary for this mu_b with rows inside the relaxed zone (slack below theta mu_b: a row whose multiplier exceeds 1 / theta -- a velocity limit
+        // the tracking cost pushes hard against).  Merit and gradient are not affine in mu_b there, so the update above does not apply; without one the instance sat at
+        // this point until the cap (null steps "rejected" at rounding level, the damping doubling).  The barrier parameter is lowered all the same and the point itself
+        // evaluated again under it: a null step (alpha = 0 on the gains of the last sweep), accepted as it is (D.first).  oracle/torque_ipm.py alike.
+        mub = mub_next;
+        n_barrier += 1;
+        stall = 0;
+        reeval = true;
+        do_gains = false;
+        alpha = 0.0;
+      } else if (accept && stat <= 10.0 * P.tol && nrel > 0 && mub <= mu_min && viol > P.tol_compl) {
+        // ... and at the floor of the barrier parameter a stationary point that still violates a row has no feasible neighbour (the relaxed barrier is a penalty of
+        // weight 1 / (theta^2 mu_b) by now): IPOPT's Infeasible_Problem_Detected, did_solve() False (solver.py:133-134, 407-412)
+        status = OH_STATUS_INFEASIBLE;
+        iters -= 1;
+        do_roll = false;
+        do_gains = false;
       } else {
         stall += 1;
         if (stall >= P.stall_max && nrel == 0 && mub <= mu_min && stat <= 10.0 * P.tol) {
@@ -1906,7 +1925,7 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
           stall = 0;
         }
       }
-      curv = (stat <= P.curv_from || (n_barrier >= P.curv_after && stat <= P.curv_late)) ? 1 : 0;
+      if (!reeval) curv = (stat <= P.curv_from || (n_barrier >= P.curv_after && stat <= P.curv_late)) ? 1 : 0;
     }
   }
 
@@ -2097,7 +2116,7 @@ __global__ __launch_bounds__(64, OH_TQ_STEP_WAVES) void k_tq_step(TqParams P, Tq
   }
   if (lane == 0) {
     D.cur[b] = cur;
-    D.first[b] = 0;
+    D.first[b] = reeval ? 1 : 0;
     {  // next evaluation: the curvature term afresh, or the stored one while it is younger than curv_lag evaluations
       int age = D.curv_age[b], mode = 0;
       if (!accept && D.curv[b] == 1) age = -1;  // a term computed at a point that was refused (possibly outside the domain of the arithmetic) is not kept

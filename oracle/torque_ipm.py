@@ -156,12 +156,13 @@ def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, 
     cur, Ut, status, f_cur, use_curv = None, U, 1, np.inf, False
     alpha, qk, ndx, n_back, n_barrier, stall, n_restart = 1.0, 0.0, 0.0, 0, 0, 0, 0
     Ks = ks = None
+    force_accept = False  # the pending "trial" is the accepted point itself, to be evaluated again under a new barrier parameter (round 6, below; k_tq_step: D.first = 1)
     while True:
-        tr = evalp(Ut, cur, mub, use_curv)
+        tr = evalp(Ut, None if force_accept else cur, mub, use_curv)
         f_t = tr["ftrue"] + mub * tr["B"]
         new_gains = True
-        if cur is None:
-            accept = True
+        if cur is None or force_accept:
+            accept, force_accept = True, False
         elif not np.isfinite(f_t):
             # the trial left the domain of the arithmetic: same gains, a tenth of the feed-forward (no damping change: the model is not to blame)
             accept, new_gains = False, False
@@ -213,6 +214,24 @@ def solve_torque_ipm(prob: TorqueProblem, qc, dqc, goal, U0=None, max_iter=300, 
                 f_cur = cur["ftrue"] + mub * cur["B"]
                 g = cur["gf"] + mub * cur["gb"]
                 stat = float(np.abs(costate_gradient(g, dt)).max())
+            elif accept and stat <= kappa_eps * mub and cur["nrel"] > 0 and mub > mu_min:
+                # Round 6: stationary for this mu_b with rows inside the relaxed zone (slack below theta mu_b: a row whose multiplier exceeds 1 / theta, e.g. a
+                # velocity limit the tracking cost pushes hard against).  Merit and gradient are not affine in mu_b there, so the update above does not apply --
+                # and without one the iteration sat at this point until the cap (every step null, every null step "rejected" at rounding level, the damping
+                # doubling: med7, effort 58 N m, |dq| <= 0.05).  The barrier parameter is lowered all the same and the point itself evaluated again under it
+                # (a null step, accepted as it is); theta mu_b shrinks with it, so feasible rows leave the relaxed zone on the way down.
+                mub = max(mu_min, min(kappa_mu * mub, mub**theta_mu))
+                n_barrier += 1
+                stall = 0
+                Ut, force_accept = cur["U"], True
+                iters += 1
+                continue
+            elif accept and stat <= 10.0 * tol and cur["nrel"] > 0 and mub <= mu_min and float(-cur["s"].min()) > tol_c:
+                # ... and at the floor of the barrier parameter a stationary point that still violates a row by more than the complementarity tolerance has no
+                # feasible neighbour: the relaxed barrier is a penalty of weight 1 / (theta^2 mu_b) by now.  The reference: IPOPT's Infeasible_Problem_Detected
+                # (did_solve() False, solver.py:133-134, 407-412).
+                status = 3  # OH_STATUS_INFEASIBLE
+                break
             stall = 0 if n_barrier != nb_before else stall + 1
             if stall >= stall_max and cur["nrel"] == 0 and mub <= mu_min and stat <= 10.0 * tol:
                 # acceptable level: stall_max steps at the floor of the barrier parameter within ten times the tolerance (the arithmetic floor of the

@@ -127,3 +127,33 @@ def test_initial_velocity_outside_its_limits_is_reported_infeasible(hip_lib):
         else:
             assert _lib.status_ok(r.status[b]) and nlp.k(r.x[b], p[b]).min() > 0.0
     be.close()
+
+
+def test_hard_pressed_velocity_rows_leave_the_relaxed_zone(hip_lib):
+    """Round 6: a velocity limit the tracking cost pushes hard against (|dq| <= 0.2 where the free plan runs at 0.95) carries multipliers beyond 1 / theta, i.e. its
+    slack at the stationary point of a barrier parameter lies inside the relaxed zone (below theta mu_b).  The barrier update used to wait for every row to be in
+    the logarithmic regime -- and the instance sat at that point until the iteration cap (null steps, damping doubling).  Now the barrier parameter is lowered and
+    the point evaluated again under it (k_tq_step: D.first; oracle/torque_ipm.py alike): the instances converge to the port's optima, inside every row."""
+    T, vl = 30, 0.2
+    robot = RobotModel.builtin("med7")
+    med7 = OracleRobot(MED7_KIN)
+    prob = TorqueProblem(med7, LINK, T=T, dt=0.1, tau_lim=58.0, **W)
+    rng = np.random.default_rng(SEED + 9)
+    qc = QC[None] + np.concatenate([np.zeros((1, 7)), rng.uniform(-0.05, 0.05, (5, 7))])
+    goal = np.stack([prob.goal_figure_eight(q) for q in qc])
+    be = TorqueBackend(robot.kinematic_chain(LINK), robot.dynamics_tables(), T=T, dt=0.1, tau_lo=-58.0, tau_up=58.0, dq_lo=-vl, dq_up=vl, max_iter=600, **W)
+    p = np.ascontiguousarray(np.concatenate([qc, np.zeros((len(qc), 7)), goal.reshape(len(qc), -1)], 1))
+    x0 = np.zeros((len(qc), 4 * 7 * T))
+    x0[:, : 7 * T] = np.tile(qc, (1, T))
+    r = be.solve(x0, p)
+    be.close()
+    ok = _lib.status_ok(r.status)
+    # (rows with slacks of 1e-10 and multipliers of 1e2: the end game sits at the arithmetic floor of the reduced gradient, where the paths of device and port part
+    #  -- step counts 29-47 on either side, not instance by instance -- and one instance in six may end NUMERICAL there; before round 6 all six ended at the cap)
+    assert ok.sum() >= len(qc) - 1, (r.status, r.iters)
+    dQ = r.x[:, 7 * T : 2 * 7 * T].reshape(len(qc), T, 7)
+    assert np.abs(dQ[ok]).max() < vl and np.abs(dQ[ok]).max() > vl - 1e-6 and (r.iters[ok] < 80).all()
+    for b in np.flatnonzero(ok)[:3]:
+        s = solve_torque_ipm(prob, qc[b], np.zeros(7), goal[b], vlimits=(-vl, vl), max_iter=600)
+        assert s["status"] in (0, 4) and abs(s["f"] - r.f[b]) <= 1e-6 * s["f"], (b, s["status"], s["f"], r.f[b], r.iters[b], s["iters"])
+        assert s["f"] > 2.0 * 9.7  # (the free plan's objective is 9.73: the rows cost more than the plan)

@@ -1,5 +1,5 @@
 """Edge cases of the figure-eight family through the C ABI: shortest and longest horizons (T = 3 has a single free knot,
-T = OH_MAX_T = 128 exceeds the one-wave-per-instance tail kernel and runs on the batched kernels only), non-finite inputs
+T = 128 (OH_MAX_T until round 6; 256 since) exceeds the one-wave-per-instance tail kernel and runs on the batched kernels only), non-finite inputs
 (reported per instance, never a hang), call-order and descriptor errors (int codes + oh_last_error, no exceptions across the ABI)."""
 import ctypes as C
 
@@ -89,7 +89,7 @@ def test_abi_error_codes(hip_lib):
         d.update(kw)
         return _lib.oh_problem_desc(**d)
 
-    for bad in (dict(ndof=3), dict(ndof=9), dict(T=2), dict(T=129), dict(dt=0.0), dict(hessian=7), dict(kind=42)):  # (ndof 4 ... 8 with orientation rows since round 5)
+    for bad in (dict(ndof=3), dict(ndof=9), dict(T=2), dict(T=_lib.OH_MAX_T + 1), dict(dt=0.0), dict(hessian=7), dict(kind=42)):  # (ndof 4 ... 8 with orientation rows since round 5)
         d = desc(**bad)
         assert lib.oh_create(C.byref(d), C.byref(h)) == 1 and lib.oh_last_error()  # OH_ERR_INVALID
     d = desc()

@@ -1243,7 +1243,7 @@ static int ensure_capacity(oh_handle* h, int B) {
   nd += (size_t)12 * Bp + 7 * (size_t)Bp;
   nd += (size_t)4 * T * Bp;  // lam_h
   nd += per_t;               // lead-joint angles
-  size_t ni = 9 * (size_t)Bp + 32 + 8 * 1024;  // + n_running, n_new, work (8-byte aligned)
+  size_t ni = 11 * (size_t)Bp + 32 + 8 * 1024;  // + n_running, n_new, work (8-byte aligned), n_defer; defer_list [2][Bp]
   size_t bytes = nd * sizeof(double) + ni * sizeof(int);
   void* pool = nullptr;
   hipError_t e = hipMalloc(&pool, bytes);
@@ -1304,7 +1304,9 @@ static int ensure_capacity(oh_handle* h, int B) {
   D.n_running = ip; ip += 1;
   D.n_new = ip; ip += 1;
   D.work = (unsigned long long*)ip; ip += 28;
-  D.scan_blk = ip;
+  D.n_defer = (int*)(D.work + 3);  // (two ints inside the spare part of the counter block: zeroed with it at the start of a solve)
+  D.scan_blk = ip; ip += 8 * 1024;
+  D.defer_list = ip;
   return OH_OK;
 }
 
@@ -1687,7 +1689,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     }
   }
   HIPCHK(hipEventRecord(h->ev0, s));
-  HIPCHK(hipMemsetAsync(h->D.work, 0, 3 * sizeof(unsigned long long), s));
+  HIPCHK(hipMemsetAsync(h->D.work, 0, 4 * sizeof(unsigned long long), s));  // (work[0..2] and the two deferral counters)
   if (!oh_launch_setup(s, N, h->P, h->D, (const double*)d_x0, (const double*)d_p))
     return fail(OH_ERR_INVALID, "oh_solve_device: unsupported ndof");
   if (guarded) oh_launch_setup_guards(s, N, h->P, h->D, h->GP, h->GB, (const double*)d_p);

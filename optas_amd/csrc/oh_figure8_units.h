@@ -1090,14 +1090,10 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
     D.polish[b] = 2;
     // (D.stat keeps the value the evaluation of this point saw: its hybrid-curvature decision is taken again, alike)
     if (P.hessian != OH_HESSIAN_GAUSS_NEWTON && cur == ts) {
-      // accepted in this launch: the gradient its evaluation took the multiplier estimate from is still in the other slot; this point's own is
-      // rebuilt by the evaluation that follows
-      const double* __restrict__ Gold = D.Gfull[1 - cur];
-      double* __restrict__ Gnew = D.Gfull[cur];
-      for (int t = P.t0; t < T; ++t) {
-#pragma unroll
-        for (int k = 0; k < N; ++k) Gnew[IDX(t, N, k)] = Gold[IDX(t, N, k)];
-      }
+      // accepted in this launch: the gradient its evaluation took the multiplier estimate from is still in the other slot; this point's own is rebuilt by the
+      // evaluation that follows.  The copy (T x N doubles) is k_defer_copy's, right after this kernel, a thread per (instance, knot) of the list: done here, by the
+      // one lane of the instance, it held the wavefront up for as long as the retry it replaced (k_step_zc 9 % slower over a solve)
+      D.defer_list[(size_t)ts * Bp + oh_take_ticket(D.n_defer + ts)] = b;
     }
     return true;
   }

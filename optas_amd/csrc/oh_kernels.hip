@@ -290,6 +290,25 @@ __global__ __launch_bounds__(64, OH_STEP_ZC_WAVES) void k_step_zc(FigParams P, F
   if ((threadIdx.x & 63) == 0 && m2) atomicAdd(D.n_running, __popcll(m2));
 }
 
+// The instances k_step_zc deferred in this launch (list of parity `slot`): their older Lagrangian gradient goes from the trial slot into the slot the evaluation
+// reads its multiplier estimate from, a thread per (instance, knot).  A fixed small grid that strides over the list: no host round trip, no launch shaped by a count.
+template <int N>
+__global__ __launch_bounds__(256) void k_defer_copy(FigParams P, FigBuffers D, const int slot) {
+  const int n = D.n_defer[slot];
+  if (blockIdx.x == 0 && threadIdx.x == 0) D.n_defer[1 - slot] = 0;  // (the other parity's list was consumed one launch ago: ready for the next k_step_zc)
+  const int Bp = D.Bp, nk = P.T - P.t0;
+  const long long total = (long long)n * nk;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(i / nk), t = P.t0 + (int)(i % nk);
+    const int b = D.defer_list[(size_t)slot * Bp + e];
+    const int cur = D.cur[b];
+    const double* __restrict__ Gold = D.Gfull[1 - cur];
+    double* __restrict__ Gnew = D.Gfull[cur];
+#pragma unroll
+    for (int k = 0; k < N; ++k) Gnew[IDX(t, N, k)] = Gold[IDX(t, N, k)];
+  }
+}
+
 template <int N>
 __global__ __launch_bounds__(64) void k_tail(FigParams P, FigBuffers D, const int slot) { tail_block<N>(P, D, slot); }
 // ... for handles whose inequality rows are joint-velocity limits only (tail_block<N, true>)
@@ -589,8 +608,10 @@ static void launch_couple_t(hipStream_t s, const FigParams& P, const FigBuffers&
 }
 template <int N>
 static void launch_step_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
-  if (P.zc) hipLaunchKernelGGL(k_step_zc<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, slot);
-  else hipLaunchKernelGGL(k_step<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, slot);
+  if (P.zc) {
+    hipLaunchKernelGGL(k_step_zc<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, slot);
+    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) hipLaunchKernelGGL(k_defer_copy<N>, dim3(64), dim3(256), 0, s, P, D, slot);
+  } else hipLaunchKernelGGL(k_step<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, slot);
 }
 template <int N>
 static void launch_tail_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {

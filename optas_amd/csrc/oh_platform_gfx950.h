@@ -22,6 +22,7 @@ OH_DEV void rb_st(const RowBuf& rb, const unsigned row_bytes, const unsigned lan
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, x), rb.r, lane_bytes, row_bytes, 0);
 }
 OH_DEV void oh_count(unsigned long long* c) { atomicAdd(c, 1ULL); }
+OH_DEV int oh_take_ticket(int* c) { return atomicAdd(c, 1); }  // a slot of a device-side list
 // the compiler sinks loads to their first use, i.e. below the early-exit branches: an empty asm that takes the value as a VGPR operand keeps the
 // whole batch of loads issued before it above the branch (one s_waitcnt for all of them)
 OH_DEV void oh_fence(const double x) { asm volatile("" ::"v"(x)); }

@@ -119,5 +119,8 @@ struct FigBuffers {
   int* n_new;             // [1] result of the compaction scan
   double* lam_h;          // [B][T][4] multipliers of the quaternion rows, reference form (original order)
   unsigned long long* work;  // [1] sum over k_step launches of running instances
+  // deferred refactorisation (k_step_zc, round 6): instances whose older Lagrangian gradient k_defer_copy puts back after the sweep, by launch parity
+  int* n_defer;           // [2]
+  int* defer_list;        // [2][Bp]
 };
 

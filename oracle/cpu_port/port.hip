@@ -17,6 +17,7 @@ OH_DEV RowBuf rowbuf(const double* knot_base) { return RowBuf{(char*)knot_base};
 OH_DEV double rb_ld(const RowBuf& rb, const unsigned row_bytes, const unsigned lane_bytes) { return *(const double*)(rb.p + row_bytes + lane_bytes); }
 OH_DEV void rb_st(const RowBuf& rb, const unsigned row_bytes, const unsigned lane_bytes, const double x) { *(double*)(rb.p + row_bytes + lane_bytes) = x; }
 OH_DEV void oh_count(unsigned long long* c) { *c += 1ULL; }
+OH_DEV int oh_take_ticket(int* c) { return (*c)++; }
 OH_DEV void oh_fence(const double) {}
 #include "../../optas_amd/csrc/oh_figure8_units.h"
 

@@ -963,7 +963,7 @@ OH_DEV bool step_instance_zc(const FigParams& P, const FigBuffers& D, const int 
   // a knot's inputs are requested PF knots ahead of their use (the kernel runs one wavefront per SIMD: registers to spare, and nothing
   // but its own loads in flight to cover the memory latency with)
 #ifndef OH_STEP_ZC_PF
-#define OH_STEP_ZC_PF 1
+#define OH_STEP_ZC_PF 2  // (round 6, once the retries and the deferring lane's copy were out of the kernel: 2 against 1 is -2 % over a solve, -12 % on launches of <= 20 000 instances; 3 the same)
 #endif
   constexpr int PF = OH_STEP_ZC_PF;
   double rV[PF][NV], rG[PF][N], rH[PF][NP];  // ring: knot t sits in slot (T - 1 - t) % PF (static indices: the knot loop is unrolled PF-fold)

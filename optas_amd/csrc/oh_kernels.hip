@@ -610,7 +610,7 @@ template <int N>
 static void launch_step_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int slot) {
   if (P.zc) {
     hipLaunchKernelGGL(k_step_zc<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, slot);
-    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) hipLaunchKernelGGL(k_defer_copy<N>, dim3(64), dim3(256), 0, s, P, D, slot);
+    if (P.hessian != OH_HESSIAN_GAUSS_NEWTON) hipLaunchKernelGGL(k_defer_copy<N>, dim3(512), dim3(256), 0, s, P, D, slot);
   } else hipLaunchKernelGGL(k_step<N>, dim3((D.B + 63) / 64), dim3(64), 0, s, P, D, slot);
 }
 template <int N>

@@ -1727,6 +1727,17 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
     if (spec) return oh_spec_launch_tail(*spec, s, h->P, h->D, slot) == hipSuccess;
     return oh_launch_tail(s, N, h->P, h->D, slot);
   };
+  // results of finished instances: x through the library's LDS transpose, scalars and multipliers through the kernel compiled for the chain where there is one
+  auto finalize = [&](const int only_done) {
+    if (spec && spec->finalize) {
+      oh_launch_finalize(s, N, h->P, h->D, only_done, ox, of, ok, oi, os, 1);
+      if (oh_spec_launch_finalize(*spec, s, h->P, h->D, only_done, of, ok, oi, os) == hipSuccess) return;
+      (void)hipGetLastError();
+      oh_launch_finalize(s, N, h->P, h->D, only_done, ox, of, ok, oi, os, 2);
+      return;
+    }
+    oh_launch_finalize(s, N, h->P, h->D, only_done, ox, of, ok, oi, os);
+  };
   bool tail_done = false;
   {  // position-tracking family with limit / sphere rows, every instance a block of its own: the whole solve in one launch (k_free_persist)
     const int fp = (int)optv(h, "free_persist", -1.0);  // -1: where it pays, 1: always, 0: never
@@ -1767,7 +1778,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       // compaction with the trial carried along: retract on the old layout, move, evaluate on the dense one (k_carry_* in oh_kernels.hip)
       launch_eval(slot, 1);
       if (prof && ne + 2 < h->prof_events.size()) { HIPCHK(hipEventRecord(h->prof_events[ne++], s)); h->prof_tags.push_back(4); }
-      oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
+      finalize(1);
       oh_launch_scan_running(s, h->D, h->compact_sort);
       oh_launch_carry(s, N, h->P, h->D, 0, 0, slot);
       oh_launch_carry(s, N, h->P, h->D, 1, carry_pending, slot);
@@ -1810,7 +1821,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       if (nrun == 0) break;
       if (tail_ok && nrun <= tail_threshold) {
         // drain: compact the survivors and let one wavefront per instance finish them without further launches
-        oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
+        finalize(1);
         if (guarded) oh_launch_guard_emit(s, h->P, h->D, h->GP, h->GB, NV, 1);
         oh_launch_scan_running(s, h->D, h->compact_sort);
         oh_launch_compact(s, N, h->P, h->D, 0, 0, 0);
@@ -1831,7 +1842,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
         // batch_invariant handles: the survivors move with everything they own (both slots' stage data, the pending step, every scalar and flag), so
         // the compaction is invisible to the state machine -- same iterates, bit for bit, as without it -- and is done on a coarse schedule (when
         // a third of the batch has finished, by default: a move costs an instance a few iterations' worth of bandwidth; tools/gpu_invariant_compaction.py)
-        oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
+        finalize(1);
         if (guarded) oh_launch_guard_emit(s, h->P, h->D, h->GP, h->GB, NV, 1);
         oh_launch_scan_running(s, h->D, h->compact_sort);
         const int mrc = move_everything(h, s, nrun);
@@ -1842,7 +1853,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       } else if (h->compaction && !lead && h->D.B >= 512 && (double)nrun <= h->compact_frac_restart * (double)h->D.B) {
         // restart compaction: the survivors' accepted knots (and, with inequality rows, their multipliers and outer-loop state) are laid
         // down densely and re-evaluated
-        oh_launch_finalize(s, N, h->P, h->D, 1, ox, of, ok, oi, os);
+        finalize(1);
         if (guarded) oh_launch_guard_emit(s, h->P, h->D, h->GP, h->GB, NV, 1);
         oh_launch_scan_running(s, h->D, h->compact_sort);
         if (h->P.lock && guarded && optv(h, "compact_move_all", 1.0) != 0.0) {
@@ -1863,7 +1874,7 @@ extern "C" int oh_solve_device(oh_handle* h, int B, const void* d_x0, const void
       }
     }
   }
-  oh_launch_finalize(s, N, h->P, h->D, 0, ox, of, ok, oi, os);
+  finalize(0);
   if (guarded) oh_launch_guard_emit(s, h->P, h->D, h->GP, h->GB, NV, 0);
   h->D.B = B;
   if (guarded) oh_launch_guard_infeasible(s, N, h->P, h->D, h->GP, (const double*)d_p, B, ok, os);  // constant rows of the pinned knots

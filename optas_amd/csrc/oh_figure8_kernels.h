@@ -11,6 +11,12 @@ template <int N>
 __device__ void retract_block(const FigParams& P, const FigBuffers& D, const int slot) {
   eval_unit<N, false, false, EVAL_RETRACT_ONLY>(P, D, slot, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y + P.t0);
 }
+// scalars of knot 0 and the multipliers of the quaternion rows (every knot) of the instances that have finished: grid (instance block, knot | 1)
+template <int N>
+__device__ void finalize_block(const FigParams& P, const FigBuffers& D, const int only_done, double* __restrict__ f, double* __restrict__ kkt, int* __restrict__ iters,
+                               int* __restrict__ status) {
+  finalize_unit<N>(P, D, only_done, nullptr, f, kkt, iters, status, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
+}
 template <int N, bool ZC = false>
 __device__ void evalb_block(const FigParams& P, const FigBuffers& D, const int slot) {
   if constexpr (ZC) {

@@ -1174,7 +1174,7 @@ OH_DEV void knot_multipliers(const FigParams& P, const FigBuffers& D, const int 
     out[0] = out[1] = out[2] = out[3] = 0.0;
     return;
   }
-  const oh_chain* ch = D.chain;
+  const oh_chain* ch = OH_CHAIN(D);  // (the chain-specialised module compiles this walk too: oh_spec_finalize)
   const double* __restrict__ qs = D.q[cur];
   const double kap2 = 2.0 * P.kappa;
   double q[N], G[N];

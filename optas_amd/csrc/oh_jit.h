@@ -7,7 +7,7 @@
 
 struct FigSpec {
   hipModule_t mod = nullptr;
-  hipFunction_t retract = nullptr, evalb = nullptr, evalb_zc = nullptr, tail = nullptr, tail_vel = nullptr;
+  hipFunction_t retract = nullptr, evalb = nullptr, evalb_zc = nullptr, tail = nullptr, tail_vel = nullptr, finalize = nullptr;
   int n = 0;               // chain length the kernels were instantiated for
   bool from_disk = false;  // code object came from the disk cache
   double seconds = 0.0;    // wall time of source generation + compilation (or cache read) + module load
@@ -20,6 +20,7 @@ int oh_jit_figure8(const oh_chain& chain, int N, const FigSpec** out, std::strin
 bool oh_jit_figure8_cached(const oh_chain& chain, int N);  // loaded in this process or present in the disk cache
 hipError_t oh_spec_launch_eval(const FigSpec& sp, hipStream_t s, const FigParams& P, const FigBuffers& D, int slot, int part);
 hipError_t oh_spec_launch_tail(const FigSpec& sp, hipStream_t s, const FigParams& P, const FigBuffers& D, int slot);
+hipError_t oh_spec_launch_finalize(const FigSpec& sp, hipStream_t s, FigParams P, FigBuffers D, int only_done, double* f, double* kkt, int* iters, int* status);
 hipError_t oh_spec_launch_tail_vel(const FigSpec& sp, hipStream_t s, FigParams P, FigBuffers D, GuardParams GP, GuardBuffers GB, int slot);
 bool oh_spec_kernel_info(const FigSpec& sp, const char* name, OhKernelInfo* out);
 

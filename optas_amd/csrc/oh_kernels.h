@@ -58,7 +58,7 @@ void oh_launch_guard_compact(hipStream_t s, const FigParams& P, const FigBuffers
 bool oh_launch_tail(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int slot);
 bool oh_launch_tail_vel(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, const GuardParams& GP, const GuardBuffers& GB, int slot);
 bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
-                        int* iters, int* status);
+                        int* iters, int* status, int parts = 3);  // parts: 1 the solution x (LDS transpose), 2 scalars + multipliers, 3 both
 void oh_launch_scan_running(hipStream_t s, const FigBuffers& D, int sort);
 bool oh_launch_compact(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int phase, int Bnew, int slot);
 

@@ -650,8 +650,9 @@ __global__ __launch_bounds__(256) void k_finalize_x(FigParams P, FigBuffers D, c
 }
 template <int N>
 static void launch_finalize_t(hipStream_t s, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
-                              int* iters, int* status) {
-  if (x) hipLaunchKernelGGL(k_finalize_x<N>, dim3((D.B + 63) / 64, (P.T + 7) / 8), dim3(256), 0, s, P, D, only_done, x);
+                              int* iters, int* status, const int parts) {
+  if (x && (parts & 1)) hipLaunchKernelGGL(k_finalize_x<N>, dim3((D.B + 63) / 64, (P.T + 7) / 8), dim3(256), 0, s, P, D, only_done, x);
+  if (!(parts & 2)) return;
   // the scalars of knot 0, and the multipliers of the quaternion rows where they are asked for (every knot)
   hipLaunchKernelGGL(k_finalize<N>, dim3((D.B + 255) / 256, D.lam_h ? P.T : 1), dim3(256), 0, s, P, D, only_done, (double*)nullptr, f, kkt, iters, status);
 }
@@ -714,8 +715,8 @@ bool oh_launch_tail(hipStream_t s, int n, const FigParams& P, const FigBuffers& 
   return true;
 }
 bool oh_launch_finalize(hipStream_t s, int n, const FigParams& P, const FigBuffers& D, int only_done, double* x, double* f, double* kkt,
-                        int* iters, int* status) {
-#define C(NN) launch_finalize_t<NN>(s, P, D, only_done, x, f, kkt, iters, status)
+                        int* iters, int* status, int parts) {
+#define C(NN) launch_finalize_t<NN>(s, P, D, only_done, x, f, kkt, iters, status, parts)
   OH_DISPATCH_N_ANY(n, C)
 #undef C
   return true;

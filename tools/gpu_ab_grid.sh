@@ -29,3 +29,15 @@ for pat in ("k_step_zc","retract","evalb_zc"):
 gs=sorted(set(o["k_step_zc"])&set(n["k_step_zc"]), reverse=True)[:26]
 for g in gs: print("k_step grid", g, "old", round(o["k_step_zc"][g][1]), "new", round(n["k_step_zc"][g][1]))
 PY
+python - <<'PY'
+import sqlite3, glob, re
+for tag in ("old","new"):
+    db = glob.glob(f"gpurun_out/abgrid/{tag}/**/*.db", recursive=True)[0]
+    c = sqlite3.connect(db)
+    tabs=[r[0] for r in c.execute("select name from sqlite_master where type='table'").fetchall()]
+    kt=[t for t in tabs if 'kernel_dispatch' in t][0]; ks=[t for t in tabs if 'kernel_symbol' in t][0]
+    rows=c.execute(f"select s.kernel_name, count(*), sum(d.end-d.start) from {kt} d join {ks} s on d.kernel_id=s.id group by s.kernel_name order by 3 desc").fetchall()
+    print(tag, "all kernels ms", round(sum(r[2] for r in rows)/1e6,2))
+    for n,k,t in rows[3:11]:
+        m=re.search(r"(k_\w+|oh_spec_\w+|__amd_\w+)", n); print(f"   {(m.group(1) if m else n[:30])[:28]:28s} {k:5d} {t/1e6:8.2f} ms {t/k/1e3:8.1f} us")
+PY

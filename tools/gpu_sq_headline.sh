@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ-counter passes over the headline workload (bench.py --timed-only): f64 instruction mix, busy / wait cycles and LDS / memory instruction counts of
 # k_retract, k_evalb_zc, k_step_zc, k_tail, k_carry_gather (round-4 verdict, Next 4: "0.55 is the ceiling" was asserted, not shown).
-# Own passes, counters only with --kernel-trace (never with sys / hip / hsa tracing).  Output: gpurun_out/r05_sq.json (copy into profiles/).
+# Own passes, counters only with --kernel-trace (never with sys / hip / hsa tracing).  Output: gpurun_out/${TAG:-r06}_sq.json (copy into profiles/).
 set -u
 REPO=$(pwd); OUT=$REPO/gpurun_out/sq_headline; rm -rf $OUT; mkdir -p $OUT
 ARGS=${1:-"--steps 1 --warmup 1 --no-cpu-baseline --timed-only"}
@@ -52,7 +52,7 @@ for k, v in pm.items():
         d["any_inst_active_frac_of_wave_cycles"] = v.get("SQ_ACTIVE_INST_ANY", 0) / v["SQ_WAVE_CYCLES"]
     res[k] = d
 json.dump({"what": "rocprofv3 --pmc passes over bench.py $ARGS; counters summed over every launch of a kernel and all SEs/XCDs as rocprofv3 reports them; f64 flop = 64 lanes x (2 FMA + MUL + ADD) wave instructions",
-           "kernels": res, "errors": errs}, open("$REPO/gpurun_out/r05_sq.json", "w"), indent=1)
+           "kernels": res, "errors": errs}, open("$REPO/gpurun_out/${TAG:-r06}_sq.json", "w"), indent=1)
 for k in ("oh_spec_retract", "oh_spec_evalb_zc", "k_step_zc", "oh_spec_tail", "k_carry_gather"):
     if k in res:
         print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in res[k].items() if a != "counters"})
@@ -60,4 +60,4 @@ print("errors", errs)
 PY
 # the raw databases of six passes are ~100 MB: gpurun merges at most 64 MiB back -- keep the condensed file and one pass's logs only
 rm -rf $OUT/pmc*/ 2>/dev/null
-ls -la $REPO/gpurun_out/r05_sq.json
+ls -la $REPO/gpurun_out/${TAG:-r06}_sq.json

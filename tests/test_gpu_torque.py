@@ -385,3 +385,27 @@ def test_abi_errors(hip_lib, ctx):
     assert lib.oh_set_constants(h, C.byref(chain)) == _lib.OH_OK
     assert lib.oh_solve(h, 1, _lib._ptr(x), _lib._ptr(p), None, None, None, None, None) == _lib.OH_ERR_STATE and b"oh_set_dynamics" in lib.oh_last_error()
     lib.oh_destroy(h)
+
+
+def test_host_buffer_solve_in_chunks_on_two_lanes_is_invisible(hip_lib, ctx):
+    """Round 6 (solve_pipelined): oh_solve takes a large host batch in chunks on two lanes.  The torque family's answers do not depend on the batch, so the
+    chunked call must return the bits of the unchunked one -- x, f, step counts, status and the multipliers (kept per chunk in a device-side cache)."""
+    med7, robot, g = ctx
+    T, B = 30, 3000
+    rng = np.random.default_rng(SEED + 21)
+    qn = np.deg2rad([0, 30, 0, -90, 0, -30, 0])
+    qc = qn + rng.uniform(-0.1, 0.1, (B, 7))
+    prob = TorqueProblem(med7, LINK, T=T, dt=0.1, tau_lim=58.0, **W)
+    goal = np.stack([prob.goal_figure_eight(q) for q in qc[:8]])
+    goal = np.concatenate([goal, np.tile(goal, (B // 8 + 1, 1, 1))])[:B]  # (eight goal paths, recycled: the batch is about plumbing)
+    p = np.ascontiguousarray(np.concatenate([qc, np.zeros((B, 7)), goal.reshape(B, -1)], 1))
+    x0 = np.zeros((B, 4 * 7 * T))
+    x0[:, : 7 * T] = np.tile(qc, (1, T))
+    a = backend(robot, T, 58.0, max_iter=600).set_options(pipe_chunk=1024)  # chunks of 1024, 1024, 952 on lanes 0, 1, 0
+    b = backend(robot, T, 58.0, max_iter=600).set_options(pipe=0)
+    ra, rb = a.solve(x0, p), b.solve(x0, p)
+    assert _lib.status_ok(rb.status).mean() >= 0.99
+    assert np.array_equal(ra.x, rb.x) and np.array_equal(ra.f, rb.f) and np.array_equal(ra.iters, rb.iters) and np.array_equal(ra.status, rb.status)
+    assert np.array_equal(a.multipliers(B), b.multipliers(B))
+    a.close()
+    b.close()

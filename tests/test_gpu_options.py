@@ -239,3 +239,21 @@ def test_host_buffer_solve_of_a_large_batch_is_pipelined_in_chunks(hip_lib, monk
     assert np.array_equal(a.multipliers(64), b.solve(x0[:64], qc[:64]) and b.multipliers(64))
     a.close()
     b.close()
+
+
+def test_tolerance_option_of_an_existing_handle(hip_lib, monkeypatch):
+    """Option `tol` (round 6): the stopping tolerance of a trajectory handle can be changed between solves (bench.py's second pass); 0 puts the descriptor's back."""
+    monkeypatch.delenv("OH_DEBUG_OPTIONS", raising=False)
+    B = 4096
+    x0, qc = bench.make_inputs(B, 9)
+    be = _backend()  # descriptor: 1e-6
+    loose = be.solve(x0, qc)
+    be.set_option("tol", 1e-9)
+    tight = be.solve(x0, qc)
+    assert (loose.status == 0).all() and (tight.status == 0).all()
+    assert (tight.kkt[:, 0] <= 1e-9).all() and (loose.kkt[:, 0] <= 1e-6).all() and (loose.kkt[:, 0] > 1e-9).any()
+    assert (tight.iters >= loose.iters).all() and tight.iters.sum() > loose.iters.sum() and np.abs(tight.f - loose.f).max() <= 1e-5 * np.abs(loose.f).max()
+    be.set_option("tol", 0.0)
+    again = be.solve(x0, qc)
+    assert np.array_equal(again.x, loose.x) and np.array_equal(again.iters, loose.iters)
+    be.close()

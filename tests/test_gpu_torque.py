@@ -409,3 +409,30 @@ def test_host_buffer_solve_in_chunks_on_two_lanes_is_invisible(hip_lib, ctx):
     assert np.array_equal(a.multipliers(B), b.multipliers(B))
     a.close()
     b.close()
+
+
+def test_parts_of_a_split_solve_follow_dynamics_set_again(hip_lib, ctx):
+    """oh_set_dynamics on a handle that has solved in parts reaches the peers (they are dropped and rebuilt): a heavier last link changes every part's answer,
+    and the parts equal the same instances on a fresh handle with those dynamics."""
+    med7, robot, g = ctx
+    T, B = 30, 2048  # split from tq_split_min = 1024 instances on
+    rng = np.random.default_rng(SEED + 22)
+    qc = np.deg2rad([0, 30, 0, -90, 0, -30, 0]) + rng.uniform(-0.1, 0.1, (B, 7))
+    prob = TorqueProblem(med7, LINK, T=T, dt=0.1, tau_lim=58.0, **W)
+    goal = np.tile(prob.goal_figure_eight(qc[0])[None], (B, 1, 1))
+    p = np.ascontiguousarray(np.concatenate([qc, np.zeros((B, 7)), goal.reshape(B, -1)], 1))
+    x0 = np.zeros((B, 4 * 7 * T))
+    x0[:, : 7 * T] = np.tile(qc, (1, T))
+    a = backend(robot, T, 58.0, max_iter=600)
+    r1 = a.solve(x0, p)
+    dyn = robot.dynamics_tables()
+    dyn2 = type(dyn).from_buffer_copy(dyn)
+    dyn2.mass[dyn2.n - 1] *= 1.5
+    _lib.check(_lib.load().oh_set_dynamics(a.handle if hasattr(a, "handle") else a._h, C.byref(dyn2)), "oh_set_dynamics")
+    r2 = a.solve(x0, p)
+    fresh = TorqueBackend(robot.kinematic_chain(LINK), dyn2, T=T, dt=0.1, tau_lo=-58.0, tau_up=58.0, max_iter=600, **W)
+    r3 = fresh.solve(x0, p)
+    assert not np.array_equal(r2.f, r1.f) and np.array_equal(r2.x, r3.x) and np.array_equal(r2.f, r3.f) and np.array_equal(r2.iters, r3.iters)
+    assert (np.abs(r2.f[B // 2 :] - r1.f[B // 2 :]) > 1e-9).all()  # the second part (the peer's) saw the new dynamics too
+    a.close()
+    fresh.close()

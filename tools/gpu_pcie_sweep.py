@@ -1,4 +1,4 @@
-"""PCIe-inclusive rate of oh_solve (pageable host buffers) over the lanes and chunk size of the pipeline."""
+"""PCIe-inclusive rate of oh_solve (pageable host buffers) over the chunk size of the two-lane pipeline (a lane-count option was tried in round 6 and not kept: HISTORY)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,9 +13,9 @@ x0, qc = bench.make_inputs(B, 0)
 lib = _lib.load()
 hx, hf, hk = np.zeros((B, x0.shape[1])), np.zeros(B), np.zeros((B, 3))
 hi, hs = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
-for lanes in (2, 3, 4):
+for lanes in (2,):
     for chunk in (16384, 32768, 65536):
-        be = FigureEightBackend(chain, bench.T, dt, lp, max_iter=300, tol=1e-8, hessian=2).set_options(pipe_lanes=lanes, pipe_chunk=chunk)
+        be = FigureEightBackend(chain, bench.T, dt, lp, max_iter=300, tol=1e-8, hessian=2).set_options(pipe_chunk=chunk)
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()
